@@ -1,0 +1,238 @@
+/*
+ * svo_hip.h -- C ABI of the MI355X-native SVO direct front end (libsvo_hip.so).
+ *
+ * This is the drop-in boundary for the per-frame direct front end of
+ * Jianxff/svo_pro_universal.  Host C++ (the adapter that subclasses the
+ * reference's SparseImgAlignBase etc.) calls these entry
+ * points; everything behind them is hand-written HIP for gfx950.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, POD structs only.
+ *   - every function returns an int status: SVOH_OK (0) or a negative
+ *     svoh_status; no exception or abort crosses the ABI.  The text of the last
+ *     error of a context is available from svoh_last_error_string().
+ *   - the caller owns all host buffers; the context owns device buffers.
+ *   - frames (image pyramids) live on the device and are referenced by 64-bit
+ *     handles returned from svoh_upload_pyramid()/svoh_build_pyramid().
+ *   - matrices are column-major (Eigen default in the reference): a "2xN"
+ *     array stores column i at [2*i, 2*i+1].
+ *   - a context is single-threaded (one hipStream_t); use one context per
+ *     calling thread, as the reference uses one Matcher per thread.
+ *   - pointers in problem structs are host pointers unless the struct's
+ *     mem_space field says SVOH_MEM_DEVICE.
+ *
+ * Each entry point cites (file:line, relative to the reference tree) the
+ * reference interface it replaces.
+ */
+#ifndef SVO_HIP_H_
+#define SVO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVOH_ABI_VERSION 1
+#define SVOH_MAX_LEVELS 8
+#define SVOH_MAX_CAMS 4
+
+typedef enum svoh_status {
+  SVOH_OK = 0,
+  SVOH_ERR_INVALID_ARGUMENT = -1,
+  SVOH_ERR_HIP = -2,           /* a HIP runtime call failed (see error string) */
+  SVOH_ERR_OUT_OF_MEMORY = -3,
+  SVOH_ERR_BAD_HANDLE = -4,
+  SVOH_ERR_UNSUPPORTED = -5,   /* e.g. patch size / camera model not built */
+  SVOH_ERR_NO_DEVICE = -6
+} svoh_status;
+
+typedef enum svoh_mem_space { SVOH_MEM_HOST = 0, SVOH_MEM_DEVICE = 1 } svoh_mem_space;
+
+typedef struct svoh_ctx svoh_ctx; /* opaque */
+typedef uint64_t svoh_frame_t;    /* 0 is never a valid handle */
+
+/* ---- context ---------------------------------------------------------- */
+
+int svoh_abi_version(void);
+/* device: HIP device ordinal.  Fails with SVOH_ERR_NO_DEVICE when no GPU. */
+int svoh_create(int device, svoh_ctx** out_ctx);
+int svoh_destroy(svoh_ctx* ctx);
+/* never NULL; valid until the next call on ctx (ctx may be NULL: global msg) */
+const char* svoh_last_error_string(const svoh_ctx* ctx);
+/* blocks until all work queued on the context's stream is complete */
+int svoh_synchronize(svoh_ctx* ctx);
+/* the context's hipStream_t as an opaque pointer (for event timing) */
+void* svoh_stream(svoh_ctx* ctx);
+
+/* ---- geometry PODs ---------------------------------------------------- */
+
+/* Rigid transform as minkindr's QuatTransformation: unit quaternion (w,x,y,z)
+ * + translation.  (3rd/minkindr/include/kindr/minimal/quat-transformation.h) */
+typedef struct svoh_se3 {
+  double q[4]; /* w, x, y, z */
+  double t[3];
+} svoh_se3;
+
+typedef enum svoh_distortion {
+  SVOH_DISTORTION_NONE = 0,   /* vk::cameras::NoDistortion */
+  SVOH_DISTORTION_RADTAN = 1  /* vk::cameras::RadialTangentialDistortion k1 k2 p1 p2 */
+} svoh_distortion;
+
+/* vk::cameras::PinholeProjection<Distortion>
+ * (src/vikit/vikit_cameras/include/vikit/cameras/implementation/pinhole_projection.hpp:10-64) */
+typedef struct svoh_camera {
+  double fx, fy, cx, cy;
+  double d[4];          /* k1 k2 p1 p2 for RADTAN, ignored for NONE */
+  int32_t distortion;   /* svoh_distortion */
+  int32_t width, height;
+  int32_t reserved;
+} svoh_camera;
+
+/* ---- frames / image pyramid  (a-0) ------------------------------------ */
+
+typedef enum svoh_halfsample_rounding {
+  /* what the reference does on x86: the SSE2 double-rounding rule when
+   * cols%16==0, else the scalar truncating rule, chosen per level
+   * (src/vikit/vikit_common/src/vision.cpp:73-111) */
+  SVOH_HALFSAMPLE_REFERENCE = 0,
+  SVOH_HALFSAMPLE_SCALAR = 1,   /* always (a+b+c+d)/4           (vision.cpp:108) */
+  SVOH_HALFSAMPLE_SSE2 = 2      /* always avg(avg(a,c),avg(b,d)) (vision.cpp:19-44) */
+} svoh_halfsample_rounding;
+
+/* Upload an existing host pyramid (n_levels row-major u8 images).
+ * Replaces nothing in the reference: it is how Frame::img_pyr_
+ * (src/svo_common/include/svo/common/frame.h:46) gets to the device. */
+int svoh_upload_pyramid(svoh_ctx* ctx, int n_levels,
+                        const uint8_t* const* level_data, const int* width,
+                        const int* height, const int* pitch,
+                        svoh_frame_t* out_frame);
+
+/* Build the pyramid on the device from a level-0 image.
+ * Replaces frame_utils::createImgPyramid (src/svo_common/src/frame.cpp:372-386)
+ * -> vk::halfSample (src/vikit/vikit_common/src/vision.cpp:73-111).
+ * img may be host or device memory (mem_space).  If host_levels_out is not
+ * NULL it must hold n_levels pointers to tightly packed (pitch == width)
+ * host buffers; levels 1..n-1 (and 0) are copied back so that the reference's
+ * host-side Frame::img_pyr_ stays bit-identical to the device copy. */
+int svoh_build_pyramid(svoh_ctx* ctx, const uint8_t* img, int width, int height,
+                       int pitch, int mem_space, int n_levels, int rounding,
+                       uint8_t* const* host_levels_out, svoh_frame_t* out_frame);
+
+/* Batched variant: n_images level-0 images of identical size, image i at
+ * img + i*image_stride bytes.  out_frames receives n_images handles. */
+int svoh_build_pyramid_batch(svoh_ctx* ctx, const uint8_t* img, size_t image_stride,
+                             int n_images, int width, int height, int pitch,
+                             int mem_space, int n_levels, int rounding,
+                             svoh_frame_t* out_frames);
+
+/* Copy one level of a device frame back to the host (tightly packed). */
+int svoh_download_level(svoh_ctx* ctx, svoh_frame_t frame, int level,
+                        uint8_t* out, int* out_width, int* out_height);
+int svoh_frame_info(svoh_ctx* ctx, svoh_frame_t frame, int* n_levels,
+                    int* width0, int* height0);
+int svoh_release_frame(svoh_ctx* ctx, svoh_frame_t frame);
+
+/* ---- sparse image alignment  (a-1 ... a-8) ---------------------------- */
+
+/* SparseImgAlignOptions + the solver options the reference hard-wires
+ * (src/svo_img_align/include/svo/img_align/sparse_img_align_base.h:37-46,
+ *  src/svo_img_align/src/sparse_img_align_base.cpp:35-42). */
+typedef struct svoh_align_options {
+  int32_t max_level;   /* 4 */
+  int32_t min_level;   /* 1 (FrameHandlerBase sets 2: svo_factory.cpp:137-138) */
+  int32_t patch_size;  /* 4 (sparse_img_align.cpp:31); 8 also built */
+  int32_t max_iter;    /* 10 */
+  double eps;          /* 5e-4 */
+  int32_t estimate_illumination_gain;
+  int32_t estimate_illumination_offset;
+  int32_t use_distortion_jacobian;
+  int32_t robustification; /* Tukey weights, b = 4.6851 */
+  double weight_scale;     /* 10 */
+} svoh_align_options;
+
+/* SparseImgAlignBase::setWeightedPrior
+ * (src/svo_img_align/src/sparse_img_align_base.cpp:44-62). */
+typedef struct svoh_align_prior {
+  int32_t have_prior;
+  int32_t reserved;
+  svoh_se3 T_prior;          /* T_cur_ref_prior (imu frames) */
+  double alpha_prior, beta_prior;
+  double lambda_rot, lambda_trans, lambda_alpha, lambda_beta;
+} svoh_align_prior;
+
+/* One camera of the (ref, cur) frame bundles, in the reference's own SoA
+ * feature layout (src/svo_common/include/svo/common/frame.h:62-73). */
+typedef struct svoh_align_camera {
+  svoh_frame_t ref_frame;    /* pyramids, >= max_level+1 levels */
+  svoh_frame_t cur_frame;
+  svoh_camera cam;           /* Frame::cam() of this camera index */
+  svoh_se3 ref_T_imu_cam;    /* ref_frame.T_imu_cam() */
+  svoh_se3 ref_T_cam_imu;    /* ref_frame.T_cam_imu() */
+  svoh_se3 cur_T_cam_imu;    /* cur_frame.T_cam_imu() */
+  double ref_pos[3];         /* ref_frame.pos() = T_world_cam().getPosition() */
+  int32_t n_features;        /* ref_frame.num_features_ */
+  int32_t mem_space;         /* where px/f/pos_world/flags live */
+  const double* px;          /* 2 x n  px_vec_ */
+  const double* f;           /* 3 x n  f_vec_ (bearing vectors) */
+  /* 3 x n: landmark_vec_[i]->pos_, or for seeds
+   * seed_ref.keyframe->T_world_cam()*getSeedPosInFrame(seed_id)
+   * (sparse_img_align.cpp:281-292); ignored where flags[i]==0 */
+  const double* pos_world;
+  /* n: 1 iff (landmark_vec_[i] || seed_ref_vec_[i].keyframe) && !isMapPoint(type_vec_[i])
+   * (sparse_img_align.cpp:239-245) */
+  const uint8_t* flags;
+} svoh_align_camera;
+
+typedef struct svoh_align_problem {
+  int32_t n_cams;
+  int32_t reserved;
+  svoh_align_camera cams[SVOH_MAX_CAMS];
+  svoh_se3 T_icur_iref;      /* initial value: cur.T_imu_world * ref.T_imu_world^-1 */
+  double alpha_init, beta_init;
+  svoh_align_prior prior;
+} svoh_align_problem;
+
+typedef struct svoh_align_result {
+  int32_t status;            /* 0 ok; 1 = no features to track (run() returns 0);
+                                2 = solver stopped on NaN (state rolled back) */
+  int32_t n_fts_to_track;    /* return value of SparseImgAlign::run */
+  svoh_se3 T_icur_iref;      /* optimised state */
+  double alpha, beta;
+  int32_t iters[SVOH_MAX_LEVELS];     /* evaluateError calls per level */
+  int32_t n_meas[SVOH_MAX_LEVELS];    /* residuals in the last evaluation  */
+  double chi2[SVOH_MAX_LEVELS];       /* chi2/n_meas of the last evaluation */
+} svoh_align_result;
+
+/* Replaces SparseImgAlign::run (src/svo_img_align/src/sparse_img_align.cpp:34-113)
+ * for n_problems independent (ref bundle, cur bundle) pairs in one launch:
+ * feature selection (a-3), base caches (a-4), per-level Jacobians/ref patches
+ * (a-5), residuals (a-6), normal equations (a-7), GN driver incl. prior,
+ * LDLT and SE3 update (a-1, a-2) all run on the device with no host round trip.
+ * The caller composes f->T_f_w_ = T_cam_imu * T_icur_iref * T_iref_world. */
+int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options,
+                            int n_problems, const svoh_align_problem* problems,
+                            svoh_align_result* results);
+
+/* Split form of the above for callers that want to overlap: enqueue returns
+ * as soon as the launch is queued on the context stream; fetch blocks and
+ * copies the results of the last enqueue. */
+int svoh_sparse_align_enqueue(svoh_ctx* ctx, const svoh_align_options* options,
+                              int n_problems, const svoh_align_problem* problems);
+int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* results);
+
+/* Diagnostic/parity entry: evaluate H (8x8 col-major), g (8), chi2, n_meas for
+ * ONE problem at a given level and state, i.e. SparseImgAlign::evaluateError
+ * (sparse_img_align.cpp:115-156) on a fresh level.  visibility (may be NULL)
+ * receives one byte per selected feature, in selection order. */
+int svoh_sparse_align_evaluate(svoh_ctx* ctx, const svoh_align_options* options,
+                               const svoh_align_problem* problem, int level,
+                               double* H64, double* g8, double* chi2,
+                               int32_t* n_meas, uint8_t* visibility,
+                               int32_t* n_selected);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVO_HIP_H_ */

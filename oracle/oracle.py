@@ -1,0 +1,219 @@
+"""ctypes wrapper of liboracle.so -- TEST INFRASTRUCTURE ONLY (see svo_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  PARITY UNPINNED: see svo_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from svo_pro_universal_amd import _capi as capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+class orc_image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+                ("pitch", C.c_int32), ("reserved", C.c_int32)]
+
+
+class orc_pyramid(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("reserved", C.c_int32),
+                ("level", orc_image * capi.SVOH_MAX_LEVELS)]
+
+
+class orc_align_camera(C.Structure):
+    _fields_ = [("ref_pyr", orc_pyramid), ("cur_pyr", orc_pyramid), ("cam", capi.svoh_camera),
+                ("ref_T_imu_cam", capi.svoh_se3), ("ref_T_cam_imu", capi.svoh_se3),
+                ("cur_T_cam_imu", capi.svoh_se3), ("ref_pos", C.c_double * 3),
+                ("n_features", C.c_int32), ("reserved", C.c_int32),
+                ("px", C.c_void_p), ("f", C.c_void_p), ("pos_world", C.c_void_p), ("flags", C.c_void_p)]
+
+
+class orc_align_problem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("reserved", C.c_int32),
+                ("cams", orc_align_camera * capi.SVOH_MAX_CAMS), ("T_icur_iref", capi.svoh_se3),
+                ("alpha_init", C.c_double), ("beta_init", C.c_double), ("prior", capi.svoh_align_prior)]
+
+
+class orc_align_trace(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("count", C.c_int32), ("level", C.c_void_p),
+                ("H", C.c_void_p), ("g", C.c_void_p), ("chi2", C.c_void_p),
+                ("n_meas", C.c_void_p), ("state", C.c_void_p)]
+
+
+def build(fast=False):
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_fast.so" if fast else "liboracle.so"])
+
+
+def load(fast=False):
+    key = "fast" if fast else "strict"
+    if key in _LIBS:
+        return _LIBS[key]
+    path = os.path.join(_HERE, "liboracle_fast.so" if fast else "liboracle.so")
+    if not os.path.exists(path):
+        build(fast)
+    lib = C.CDLL(path)
+    P = C.POINTER
+    lib.orc_half_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    lib.orc_half_sample.restype = None
+    lib.orc_create_img_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           P(C.c_void_p)]
+    lib.orc_create_img_pyramid.restype = None
+    lib.orc_sparse_align_run.argtypes = [P(capi.svoh_align_options), P(orc_align_problem),
+                                         P(capi.svoh_align_result), P(orc_align_trace)]
+    lib.orc_sparse_align_evaluate.argtypes = [P(capi.svoh_align_options), P(orc_align_problem), C.c_int,
+                                              C.c_void_p, C.c_void_p, P(C.c_double), P(C.c_int32),
+                                              C.c_void_p, P(C.c_int32)]
+    lib.orc_extract_features_subset.argtypes = [P(orc_align_camera), C.c_int, C.c_int, C.c_void_p]
+    lib.orc_ldlt_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    for nm in ("orc_quat_mul", "orc_quat_rotate", "orc_quat_exp", "orc_quat_log", "orc_quat_to_matrix"):
+        getattr(lib, nm).restype = None
+    lib.orc_se3_mul.argtypes = [P(capi.svoh_se3)] * 3
+    lib.orc_se3_mul.restype = None
+    lib.orc_se3_inverse.argtypes = [P(capi.svoh_se3)] * 2
+    lib.orc_se3_inverse.restype = None
+    lib.orc_se3_exp.argtypes = [C.c_void_p, P(capi.svoh_se3)]
+    lib.orc_se3_exp.restype = None
+    lib.orc_se3_log.argtypes = [P(capi.svoh_se3), C.c_void_p]
+    lib.orc_se3_log.restype = None
+    lib.orc_project3.argtypes = [P(capi.svoh_camera), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_project3.restype = None
+    lib.orc_back_project3.argtypes = [P(capi.svoh_camera), C.c_void_p, C.c_void_p]
+    lib.orc_back_project3.restype = None
+    _LIBS[key] = lib
+    return lib
+
+
+# ---------------------------------------------------------------------------
+# conversions
+# ---------------------------------------------------------------------------
+
+def to_se3(T):
+    """synth.SE3 (or 7-vector q,t) -> svoh_se3"""
+    s = capi.svoh_se3()
+    v = T.as7() if hasattr(T, "as7") else np.asarray(T, dtype=np.float64)
+    for i in range(4):
+        s.q[i] = float(v[i])
+    for i in range(3):
+        s.t[i] = float(v[4 + i])
+    return s
+
+
+def from_se3(s):
+    from svo_pro_universal_amd.synth import SE3
+    return SE3([s.q[i] for i in range(4)], [s.t[i] for i in range(3)])
+
+
+def to_camera(cam):
+    c = capi.svoh_camera()
+    c.fx, c.fy, c.cx, c.cy = cam.fx, cam.fy, cam.cx, cam.cy
+    c.width, c.height = cam.width, cam.height
+    if cam.dist is None:
+        c.distortion = capi.SVOH_DISTORTION_NONE
+    else:
+        c.distortion = capi.SVOH_DISTORTION_RADTAN
+        for i in range(4):
+            c.d[i] = cam.dist[i]
+    return c
+
+
+def create_img_pyramid(img0, n_levels, rounding=capi.SVOH_HALFSAMPLE_REFERENCE, fast=False):
+    """frame_utils::createImgPyramid on the CPU; returns list of HxW u8 arrays."""
+    lib = load(fast)
+    img0 = np.ascontiguousarray(img0, dtype=np.uint8)
+    h, w = img0.shape
+    levels = [img0]
+    for i in range(1, n_levels):
+        levels.append(np.zeros((levels[-1].shape[0] // 2, levels[-1].shape[1] // 2), dtype=np.uint8))
+    ptrs = (C.c_void_p * n_levels)(*[lv.ctypes.data for lv in levels])
+    lib.orc_create_img_pyramid(img0.ctypes.data, w, h, w, n_levels, rounding, ptrs)
+    return levels
+
+
+def make_pyramid_struct(levels):
+    p = orc_pyramid()
+    p.n_levels = len(levels)
+    for i, lv in enumerate(levels):
+        assert lv.dtype == np.uint8 and lv.flags["C_CONTIGUOUS"]
+        p.level[i].data = lv.ctypes.data
+        p.level[i].width = lv.shape[1]
+        p.level[i].height = lv.shape[0]
+        p.level[i].pitch = lv.strides[0]
+    return p
+
+
+class AlignProblem(object):
+    """Keeps numpy buffers alive next to the ctypes struct."""
+
+    def __init__(self):
+        self.c = orc_align_problem()
+        self._keep = []
+
+
+def problem_from_scenes(scenes_pyr, T_init=None, prior=None, alpha_init=0.0, beta_init=0.0):
+    """scenes_pyr: list (one per camera) of (AlignScene, ref_levels, cur_levels)."""
+    pb = AlignProblem()
+    pb.c.n_cams = len(scenes_pyr)
+    for i, (sc, ref_lv, cur_lv) in enumerate(scenes_pyr):
+        cam = pb.c.cams[i]
+        cam.ref_pyr = make_pyramid_struct(ref_lv)
+        cam.cur_pyr = make_pyramid_struct(cur_lv)
+        cam.cam = to_camera(sc.cam)
+        cam.ref_T_imu_cam = to_se3(sc.T_imu_cam)
+        cam.ref_T_cam_imu = to_se3(sc.T_cam_imu)
+        cam.cur_T_cam_imu = to_se3(sc.T_cam_imu)
+        for k in range(3):
+            cam.ref_pos[k] = float(sc.ref_pos[k])
+        cam.n_features = sc.n_features
+        arrs = [np.ascontiguousarray(sc.px, dtype=np.float64), np.ascontiguousarray(sc.f, dtype=np.float64),
+                np.ascontiguousarray(sc.pos_world, dtype=np.float64),
+                np.ascontiguousarray(sc.flags, dtype=np.uint8)]
+        cam.px, cam.f, cam.pos_world, cam.flags = [a.ctypes.data for a in arrs]
+        pb._keep += arrs + list(ref_lv) + list(cur_lv)
+    sc0 = scenes_pyr[0][0]
+    pb.c.T_icur_iref = to_se3(T_init if T_init is not None else sc0.T_icur_iref_init)
+    pb.c.alpha_init, pb.c.beta_init = alpha_init, beta_init
+    if prior is not None:
+        pb.c.prior = prior
+    return pb
+
+
+def sparse_align_run(opt, pb, trace_capacity=0, fast=False):
+    lib = load(fast)
+    res = capi.svoh_align_result()
+    tr = None
+    trp = None
+    if trace_capacity > 0:
+        tr = {
+            "level": np.zeros(trace_capacity, np.int32), "H": np.zeros((trace_capacity, 64)),
+            "g": np.zeros((trace_capacity, 8)), "chi2": np.zeros(trace_capacity),
+            "n_meas": np.zeros(trace_capacity, np.int32), "state": np.zeros((trace_capacity, 9)),
+        }
+        t = orc_align_trace()
+        t.capacity = trace_capacity
+        for k in ("level", "H", "g", "chi2", "n_meas", "state"):
+            setattr(t, k, tr[k].ctypes.data)
+        trp = C.byref(t)
+    n = lib.orc_sparse_align_run(C.byref(opt), C.byref(pb.c), C.byref(res), trp)
+    if tr is not None:
+        cnt = t.count
+        tr = {k: v[:cnt] for k, v in tr.items()}
+    return n, res, tr
+
+
+def sparse_align_evaluate(opt, pb, level, fast=False):
+    lib = load(fast)
+    H = np.zeros(64)
+    g = np.zeros(8)
+    chi2 = C.c_double()
+    nm = C.c_int32()
+    nsel = C.c_int32()
+    ntot = sum(pb.c.cams[i].n_features for i in range(pb.c.n_cams))
+    vis = np.zeros(max(ntot, 1), np.uint8)
+    lib.orc_sparse_align_evaluate(C.byref(opt), C.byref(pb.c), level, H.ctypes.data, g.ctypes.data,
+                                  C.byref(chi2), C.byref(nm), vis.ctypes.data, C.byref(nsel))
+    return H.reshape(8, 8).T.copy(), g, chi2.value, nm.value, vis[:nsel.value].copy()

@@ -1,0 +1,142 @@
+"""ctypes mirror of include/svo_hip.h and loader of libsvo_hip.so.
+
+The library is the product; there is no CPU fallback.  Importing this module
+never touches the GPU; `load()` raises if the HIP extension has not been built
+(run `python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes as C
+import os
+
+SVOH_MAX_LEVELS = 8
+SVOH_MAX_CAMS = 4
+
+SVOH_OK = 0
+SVOH_MEM_HOST = 0
+SVOH_MEM_DEVICE = 1
+
+SVOH_DISTORTION_NONE = 0
+SVOH_DISTORTION_RADTAN = 1
+
+SVOH_HALFSAMPLE_REFERENCE = 0
+SVOH_HALFSAMPLE_SCALAR = 1
+SVOH_HALFSAMPLE_SSE2 = 2
+
+svoh_frame_t = C.c_uint64
+
+
+class svoh_se3(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3)]
+
+
+class svoh_camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("d", C.c_double * 4), ("distortion", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("reserved", C.c_int32)]
+
+
+class svoh_align_options(C.Structure):
+    _fields_ = [("max_level", C.c_int32), ("min_level", C.c_int32), ("patch_size", C.c_int32),
+                ("max_iter", C.c_int32), ("eps", C.c_double),
+                ("estimate_illumination_gain", C.c_int32), ("estimate_illumination_offset", C.c_int32),
+                ("use_distortion_jacobian", C.c_int32), ("robustification", C.c_int32),
+                ("weight_scale", C.c_double)]
+
+
+class svoh_align_prior(C.Structure):
+    _fields_ = [("have_prior", C.c_int32), ("reserved", C.c_int32), ("T_prior", svoh_se3),
+                ("alpha_prior", C.c_double), ("beta_prior", C.c_double),
+                ("lambda_rot", C.c_double), ("lambda_trans", C.c_double),
+                ("lambda_alpha", C.c_double), ("lambda_beta", C.c_double)]
+
+
+class svoh_align_camera(C.Structure):
+    _fields_ = [("ref_frame", svoh_frame_t), ("cur_frame", svoh_frame_t), ("cam", svoh_camera),
+                ("ref_T_imu_cam", svoh_se3), ("ref_T_cam_imu", svoh_se3), ("cur_T_cam_imu", svoh_se3),
+                ("ref_pos", C.c_double * 3), ("n_features", C.c_int32), ("mem_space", C.c_int32),
+                ("px", C.c_void_p), ("f", C.c_void_p), ("pos_world", C.c_void_p), ("flags", C.c_void_p)]
+
+
+class svoh_align_problem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("reserved", C.c_int32),
+                ("cams", svoh_align_camera * SVOH_MAX_CAMS), ("T_icur_iref", svoh_se3),
+                ("alpha_init", C.c_double), ("beta_init", C.c_double), ("prior", svoh_align_prior)]
+
+
+class svoh_align_result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_fts_to_track", C.c_int32), ("T_icur_iref", svoh_se3),
+                ("alpha", C.c_double), ("beta", C.c_double),
+                ("iters", C.c_int32 * SVOH_MAX_LEVELS), ("n_meas", C.c_int32 * SVOH_MAX_LEVELS),
+                ("chi2", C.c_double * SVOH_MAX_LEVELS)]
+
+
+def default_align_options(**kw):
+    """SparseImgAlignOptions defaults (sparse_img_align_base.h:37-46) + solver
+    defaults (sparse_img_align_base.cpp:35-42)."""
+    o = svoh_align_options(max_level=4, min_level=1, patch_size=4, max_iter=10, eps=0.0005,
+                           estimate_illumination_gain=0, estimate_illumination_offset=0,
+                           use_distortion_jacobian=0, robustification=0, weight_scale=10.0)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsvo_hip.so")
+
+# every symbol include/svo_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "svoh_abi_version", "svoh_create", "svoh_destroy", "svoh_last_error_string",
+    "svoh_synchronize", "svoh_stream",
+    "svoh_upload_pyramid", "svoh_build_pyramid", "svoh_build_pyramid_batch",
+    "svoh_download_level", "svoh_frame_info", "svoh_release_frame",
+    "svoh_sparse_align_batch", "svoh_sparse_align_enqueue", "svoh_sparse_align_fetch",
+    "svoh_sparse_align_evaluate",
+]
+
+
+def load():
+    """dlopen libsvo_hip.so (in-tree).  Raises RuntimeError if it is missing:
+    the product has no CPU path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libsvo_hip.so not built (%s). Build it with __graft_entry__.build(); "
+            "there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.svoh_abi_version.restype = C.c_int
+    lib.svoh_create.argtypes = [C.c_int, P(C.c_void_p)]
+    lib.svoh_destroy.argtypes = [C.c_void_p]
+    lib.svoh_last_error_string.argtypes = [C.c_void_p]
+    lib.svoh_last_error_string.restype = C.c_char_p
+    lib.svoh_synchronize.argtypes = [C.c_void_p]
+    lib.svoh_stream.argtypes = [C.c_void_p]
+    lib.svoh_stream.restype = C.c_void_p
+    lib.svoh_upload_pyramid.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_int), P(C.c_int),
+                                        P(C.c_int), P(svoh_frame_t)]
+    lib.svoh_build_pyramid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, P(C.c_void_p), P(svoh_frame_t)]
+    lib.svoh_build_pyramid_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             P(svoh_frame_t)]
+    lib.svoh_download_level.argtypes = [C.c_void_p, svoh_frame_t, C.c_int, C.c_void_p, P(C.c_int), P(C.c_int)]
+    lib.svoh_frame_info.argtypes = [C.c_void_p, svoh_frame_t, P(C.c_int), P(C.c_int), P(C.c_int)]
+    lib.svoh_release_frame.argtypes = [C.c_void_p, svoh_frame_t]
+    lib.svoh_sparse_align_batch.argtypes = [C.c_void_p, P(svoh_align_options), C.c_int,
+                                            P(svoh_align_problem), P(svoh_align_result)]
+    lib.svoh_sparse_align_enqueue.argtypes = [C.c_void_p, P(svoh_align_options), C.c_int,
+                                              P(svoh_align_problem)]
+    lib.svoh_sparse_align_fetch.argtypes = [C.c_void_p, C.c_int, P(svoh_align_result)]
+    lib.svoh_sparse_align_evaluate.argtypes = [C.c_void_p, P(svoh_align_options), P(svoh_align_problem),
+                                               C.c_int, C.c_void_p, C.c_void_p, P(C.c_double),
+                                               P(C.c_int32), C.c_void_p, P(C.c_int32)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name != "svoh_abi_version":
+            pass
+    _LIB = lib
+    return lib

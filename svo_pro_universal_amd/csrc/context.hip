@@ -1,0 +1,328 @@
+// context.hip -- context lifetime, error strings, device frames and the image
+// pyramid kernel (a-0).
+//
+// Pyramid: replaces frame_utils::createImgPyramid
+// (src/svo_common/src/frame.cpp:372-386) -> vk::halfSample
+// (src/vikit/vikit_common/src/vision.cpp:19-44 SSE2 rule, :73-111 dispatch and
+// scalar rule).  Integer work: results are bit-identical to the reference's.
+#include <cstdarg>
+#include <cstring>
+
+#include "svoh_internal.h"
+
+namespace svoh {
+
+static thread_local std::string g_global_err = "no error";
+
+int set_error(svoh_ctx* ctx, int code, const char* fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf; else g_global_err = buf;
+  return code;
+}
+
+void set_global_error(const char* msg) { g_global_err = msg; }
+
+const Frame* find_frame(const svoh_ctx* ctx, svoh_frame_t id)
+{
+  auto it = ctx->frames.find(id);
+  return it == ctx->frames.end() ? nullptr : &it->second;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// layout of one frame inside a slab: levels tightly packed (pitch == width),
+// each level starting on a 256-byte boundary
+static size_t frame_layout(int w, int h, int n_levels, size_t* offs, int* ws, int* hs)
+{
+  size_t off = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    offs[i] = off; ws[i] = w; hs[i] = h;
+    off = align_up(off + (size_t)w * h, 256);
+    w /= 2; h /= 2;
+  }
+  return off;
+}
+
+// ---------------------------------------------------------------------------
+// halfSample kernel: one thread makes 4 horizontally adjacent output pixels
+// from 2 rows x 8 input bytes.  Memory-bound: reads 4 B, writes 1 B per output
+// pixel, all accesses coalesced (8-byte loads, 4-byte stores when aligned).
+// grid.z indexes the image of a batch.
+// ---------------------------------------------------------------------------
+template <bool SSE2_RULE>
+__device__ __forceinline__ unsigned half4(unsigned a, unsigned b, unsigned c, unsigned d)
+{
+  if (SSE2_RULE) {
+    // _mm_avg_epu8(top,bottom) then _mm_avg_epu16(even,odd): round half up twice
+    const unsigned v0 = (a + c + 1u) >> 1;
+    const unsigned v1 = (b + d + 1u) >> 1;
+    return (v0 + v1 + 1u) >> 1;
+  }
+  return (a + b + c + d) >> 2;  // (a+b+c+d)/4, truncating
+}
+
+template <bool SSE2_RULE>
+__global__ __launch_bounds__(256) void half_sample_kernel(
+    const uint8_t* __restrict__ in, size_t in_image_stride, int in_pitch,
+    uint8_t* __restrict__ out, size_t out_image_stride, int out_pitch,
+    int out_w_written, int out_h_written)
+{
+  const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;  // first output column
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x4 >= out_w_written || y >= out_h_written) return;
+  const uint8_t* top = in + (size_t)blockIdx.z * in_image_stride + (size_t)(2 * y) * in_pitch + 2 * x4;
+  const uint8_t* bot = top + in_pitch;
+  uint8_t* o = out + (size_t)blockIdx.z * out_image_stride + (size_t)y * out_pitch + x4;
+  const int n = min(4, out_w_written - x4);
+  if (n == 4 && ((reinterpret_cast<uintptr_t>(top) | reinterpret_cast<uintptr_t>(bot)) & 7) == 0 &&
+      (reinterpret_cast<uintptr_t>(o) & 3) == 0) {
+    const uint2 t = *reinterpret_cast<const uint2*>(top);
+    const uint2 b = *reinterpret_cast<const uint2*>(bot);
+    unsigned r = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned tw = (k < 2) ? t.x : t.y;
+      const unsigned bw = (k < 2) ? b.x : b.y;
+      const int sh = (k & 1) * 16;
+      const unsigned a = (tw >> sh) & 0xff, bb = (tw >> (sh + 8)) & 0xff;
+      const unsigned c = (bw >> sh) & 0xff, d = (bw >> (sh + 8)) & 0xff;
+      r |= half4<SSE2_RULE>(a, bb, c, d) << (8 * k);
+    }
+    *reinterpret_cast<unsigned*>(o) = r;
+  } else {
+    for (int k = 0; k < n; ++k)
+      o[k] = (uint8_t)half4<SSE2_RULE>(top[2 * k], top[2 * k + 1], bot[2 * k], bot[2 * k + 1]);
+  }
+}
+
+// One pyramid step for a batch of images living at a fixed stride.
+static hipError_t launch_half_sample(hipStream_t s, const uint8_t* in, size_t in_stride, int in_w, int in_h,
+                                     int in_pitch, uint8_t* out, size_t out_stride, int out_pitch,
+                                     int n_images, int rounding)
+{
+  const int out_w = in_w / 2, out_h = in_h / 2;
+  bool sse = false;
+  if (rounding == SVOH_HALFSAMPLE_SSE2) sse = true;
+  else if (rounding == SVOH_HALFSAMPLE_REFERENCE) sse = (in_w % 16 == 0) && (in_pitch == in_w);
+  // the SSE2 routine writes (w>>4)*8 columns and h>>1 rows; the scalar one out_w x out_h
+  const int ww = sse ? (in_w >> 4) * 8 : out_w;
+  const int hw = sse ? (in_h >> 1) : out_h;
+  if (ww <= 0 || hw <= 0 || n_images <= 0) return hipSuccess;
+  dim3 block(64, 4, 1);
+  dim3 grid((unsigned)((ww + 4 * 64 - 1) / (4 * 64)), (unsigned)((hw + 3) / 4), (unsigned)n_images);
+  if (sse)
+    hipLaunchKernelGGL(half_sample_kernel<true>, grid, block, 0, s, in, in_stride, in_pitch, out, out_stride,
+                       out_pitch, ww, hw);
+  else
+    hipLaunchKernelGGL(half_sample_kernel<false>, grid, block, 0, s, in, in_stride, in_pitch, out, out_stride,
+                       out_pitch, ww, hw);
+  return hipGetLastError();
+}
+
+static uint64_t register_frame(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab, uint8_t* base, int w, int h,
+                               int n_levels)
+{
+  size_t offs[SVOH_MAX_LEVELS];
+  int ws[SVOH_MAX_LEVELS], hs[SVOH_MAX_LEVELS];
+  frame_layout(w, h, n_levels, offs, ws, hs);
+  Frame f;
+  f.slab = slab;
+  f.n_levels = n_levels;
+  for (int i = 0; i < n_levels; ++i) {
+    f.lv[i].data = base + offs[i];
+    f.lv[i].w = ws[i]; f.lv[i].h = hs[i]; f.lv[i].pitch = ws[i]; f.lv[i].pad = 0;
+  }
+  const uint64_t id = ctx->next_frame_id++;
+  ctx->frames.emplace(id, std::move(f));
+  return id;
+}
+
+}  // namespace svoh
+
+using namespace svoh;
+
+extern "C" {
+
+int svoh_abi_version(void) { return SVOH_ABI_VERSION; }
+
+int svoh_create(int device, svoh_ctx** out_ctx)
+{
+  if (!out_ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_error(nullptr, SVOH_ERR_NO_DEVICE, "no HIP device available (%s); libsvo_hip has no CPU path",
+                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n)
+    return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, n);
+  svoh_ctx* ctx = new (std::nothrow) svoh_ctx();
+  if (!ctx) return set_error(nullptr, SVOH_ERR_OUT_OF_MEMORY, "out of host memory");
+  ctx->device = device;
+  ctx->err = "no error";
+  e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  hipDeviceProp_t prop;
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    set_error(nullptr, SVOH_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
+    delete ctx;
+    return SVOH_ERR_HIP;
+  }
+  ctx->num_cus = prop.multiProcessorCount;
+  ctx->lds_per_block = prop.sharedMemPerBlock;
+  *out_ctx = ctx;
+  return SVOH_OK;
+}
+
+int svoh_destroy(svoh_ctx* ctx)
+{
+  if (!ctx) return SVOH_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+  ctx->frames.clear();
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return SVOH_OK;
+}
+
+const char* svoh_last_error_string(const svoh_ctx* ctx)
+{
+  return ctx ? ctx->err.c_str() : g_global_err.c_str();
+}
+
+int svoh_synchronize(svoh_ctx* ctx)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SVOH_OK;
+}
+
+void* svoh_stream(svoh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int svoh_upload_pyramid(svoh_ctx* ctx, int n_levels, const uint8_t* const* level_data, const int* width,
+                        const int* height, const int* pitch, svoh_frame_t* out_frame)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, out_frame && level_data && width && height && pitch, "NULL argument");
+  SVOH_REQUIRE(ctx, n_levels >= 1 && n_levels <= SVOH_MAX_LEVELS, "n_levels out of range");
+  for (int i = 0; i < n_levels; ++i) {
+    SVOH_REQUIRE(ctx, level_data[i] && width[i] > 0 && height[i] > 0 && pitch[i] >= width[i], "bad level");
+    // the frame layout assumes the reference's rows/2 x cols/2 rule
+    if (i > 0) SVOH_REQUIRE(ctx, width[i] == width[i - 1] / 2 && height[i] == height[i - 1] / 2,
+                            "level sizes must halve (createImgPyramid, frame.cpp:381-384)");
+  }
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t offs[SVOH_MAX_LEVELS]; int ws[SVOH_MAX_LEVELS], hs[SVOH_MAX_LEVELS];
+  const size_t bytes = frame_layout(width[0], height[0], n_levels, offs, ws, hs);
+  auto slab = std::make_shared<Slab>();
+  SVOH_HIP_TRY(ctx, hipMalloc(&slab->ptr, bytes));
+  slab->bytes = bytes;
+  uint8_t* base = static_cast<uint8_t*>(slab->ptr);
+  for (int i = 0; i < n_levels; ++i)
+    SVOH_HIP_TRY(ctx, hipMemcpy2DAsync(base + offs[i], (size_t)ws[i], level_data[i], (size_t)pitch[i],
+                                       (size_t)ws[i], (size_t)hs[i], hipMemcpyHostToDevice, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *out_frame = register_frame(ctx, slab, base, width[0], height[0], n_levels);
+  return SVOH_OK;
+}
+
+int svoh_build_pyramid_batch(svoh_ctx* ctx, const uint8_t* img, size_t image_stride, int n_images, int width,
+                             int height, int pitch, int mem_space, int n_levels, int rounding,
+                             svoh_frame_t* out_frames)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, img && out_frames, "NULL argument");
+  SVOH_REQUIRE(ctx, n_images >= 1 && width > 0 && height > 0 && pitch >= width, "bad image geometry");
+  SVOH_REQUIRE(ctx, n_levels >= 1 && n_levels <= SVOH_MAX_LEVELS, "n_levels out of range");
+  SVOH_REQUIRE(ctx, rounding >= 0 && rounding <= 2, "bad rounding mode");
+  SVOH_REQUIRE(ctx, (width >> (n_levels - 1)) > 0 && (height >> (n_levels - 1)) > 0, "too many levels");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t offs[SVOH_MAX_LEVELS]; int ws[SVOH_MAX_LEVELS], hs[SVOH_MAX_LEVELS];
+  const size_t fbytes = frame_layout(width, height, n_levels, offs, ws, hs);
+  auto slab = std::make_shared<Slab>();
+  SVOH_HIP_TRY(ctx, hipMalloc(&slab->ptr, fbytes * (size_t)n_images));
+  slab->bytes = fbytes * (size_t)n_images;
+  uint8_t* base = static_cast<uint8_t*>(slab->ptr);
+  // level 0: copy into the tightly packed layout
+  const hipMemcpyKind kind = mem_space == SVOH_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (pitch == width && image_stride == (size_t)width * height && fbytes == image_stride) {
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(base, img, image_stride * n_images, kind, ctx->stream));
+  } else {
+    for (int i = 0; i < n_images; ++i)
+      SVOH_HIP_TRY(ctx, hipMemcpy2DAsync(base + fbytes * i, (size_t)width, img + image_stride * i, (size_t)pitch,
+                                         (size_t)width, (size_t)height, kind, ctx->stream));
+  }
+  for (int l = 1; l < n_levels; ++l) {
+    // zero-fill is not needed: every byte of a level the reference would write is written
+    SVOH_HIP_TRY(ctx, launch_half_sample(ctx->stream, base + offs[l - 1], fbytes, ws[l - 1], hs[l - 1], ws[l - 1],
+                                         base + offs[l], fbytes, ws[l], n_images, rounding));
+  }
+  for (int i = 0; i < n_images; ++i)
+    out_frames[i] = register_frame(ctx, slab, base + fbytes * i, width, height, n_levels);
+  return SVOH_OK;
+}
+
+int svoh_build_pyramid(svoh_ctx* ctx, const uint8_t* img, int width, int height, int pitch, int mem_space,
+                       int n_levels, int rounding, uint8_t* const* host_levels_out, svoh_frame_t* out_frame)
+{
+  int rc = svoh_build_pyramid_batch(ctx, img, (size_t)pitch * height, 1, width, height, pitch, mem_space, n_levels,
+                                    rounding, out_frame);
+  if (rc != SVOH_OK) return rc;
+  if (host_levels_out) {
+    const Frame* f = find_frame(ctx, *out_frame);
+    for (int l = 0; l < n_levels; ++l) {
+      if (!host_levels_out[l]) continue;
+      SVOH_HIP_TRY(ctx, hipMemcpyAsync(host_levels_out[l], f->lv[l].data, (size_t)f->lv[l].w * f->lv[l].h,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return SVOH_OK;
+}
+
+int svoh_download_level(svoh_ctx* ctx, svoh_frame_t frame, int level, uint8_t* out, int* out_width, int* out_height)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  const Frame* f = find_frame(ctx, frame);
+  if (!f) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frame);
+  SVOH_REQUIRE(ctx, level >= 0 && level < f->n_levels, "level out of range");
+  if (out_width) *out_width = f->lv[level].w;
+  if (out_height) *out_height = f->lv[level].h;
+  if (out) {
+    SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(out, f->lv[level].data, (size_t)f->lv[level].w * f->lv[level].h,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+    SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return SVOH_OK;
+}
+
+int svoh_frame_info(svoh_ctx* ctx, svoh_frame_t frame, int* n_levels, int* width0, int* height0)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  const Frame* f = find_frame(ctx, frame);
+  if (!f) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frame);
+  if (n_levels) *n_levels = f->n_levels;
+  if (width0) *width0 = f->lv[0].w;
+  if (height0) *height0 = f->lv[0].h;
+  return SVOH_OK;
+}
+
+int svoh_release_frame(svoh_ctx* ctx, svoh_frame_t frame)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  auto it = ctx->frames.find(frame);
+  if (it == ctx->frames.end())
+    return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frame);
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // no kernel may still read it
+  ctx->frames.erase(it);
+  return SVOH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,804 @@
+// sparse_align.hip -- device-resident sparse image alignment for gfx950.
+//
+// Replaces, for a batch of independent (reference bundle, current bundle)
+// pairs, the reference's
+//   SparseImgAlign::run / evaluateError      src/svo_img_align/src/sparse_img_align.cpp:34-156
+//   sparse_img_align_utils::*                src/svo_img_align/src/sparse_img_align.cpp:209-541
+//   SparseImgAlignBase::update / applyPrior  src/svo_img_align/src/sparse_img_align_base.cpp:64-107
+//   MiniLeastSquaresSolver::optimizeGaussNewton / solveDefaultImpl
+//        src/vikit/vikit_solver/include/vikit/solver/implementation/mini_least_squares_solver.hpp:42-107,253-262
+//   TukeyWeightFunction::weight              src/vikit/vikit_solver/src/robust_cost.cpp:48-60
+//
+// Design (MI355X-first, not a translation of the reference's loops):
+//   * ONE workgroup owns ONE alignment problem for its whole life: all pyramid
+//     levels and all Gauss-Newton iterations run inside one launch with no
+//     host round trip; the 8x8 solve and the SE3 update happen in LDS.
+//   * one thread owns one patch per pass (wave64: 64 patches in flight per
+//     wave); per-patch state is two coalesced SoA loads (xyz_ref, uv).
+//   * nothing per-pixel is ever written to memory: the reference's
+//     jacobian_cache_ / ref_patch_cache_ / residual_cache_ (the 485 B per
+//     patch-iteration of SURVEY 8(d)) are recomputed in registers from the
+//     u8 pyramid level, which is staged ONCE per level into LDS (both the
+//     reference and the current level) when it fits, with 16-byte coalesced
+//     loads.  All arithmetic is fp64 like the reference (FloatType = double);
+//     MI355X runs vector fp64 at half the fp32 rate, so this is cheap.
+//   * the per-thread partial normal equations (upper triangle of J J^T, J r,
+//     chi2) are reduced with wave shuffles, then across waves through LDS.
+//     The summation order differs from the reference's sequential order; all
+//     other arithmetic follows the reference expression by expression.
+#include <cstdlib>
+#include <cstring>
+
+#include "svoh_internal.h"
+#include "svoh_math.h"
+
+namespace svoh {
+
+struct DevCamDesc {
+  DevImage ref[SVOH_MAX_LEVELS];
+  DevImage cur[SVOH_MAX_LEVELS];
+  svoh_camera cam;
+  svoh_se3 ref_T_imu_cam, ref_T_cam_imu, cur_T_cam_imu;
+  double ref_pos[3];
+  const double* px;
+  const double* f;
+  const double* pos_world;
+  const uint8_t* flags;
+  int32_t n_features;
+  int32_t feat_off;  // first slot of this camera in the feature workspace
+};
+
+struct DevProblemDesc {
+  int32_t n_cams, cam_begin;
+  svoh_se3 T_init;
+  double alpha_init, beta_init;
+  svoh_align_prior prior;
+};
+
+struct AlignKernelArgs {
+  const DevProblemDesc* problems;
+  const DevCamDesc* cams;
+  svoh_align_result* results;
+  // feature workspace (SoA over all features of all problems)
+  double* wx; double* wy; double* wz;   // xyz_ref (a-4)
+  double* wu; double* wv;               // uv in the reference image, level 0
+  uint8_t* wsel;                        // selected by extractFeaturesSubset (a-3)
+  uint8_t* wvis;                        // visibility of the last evaluation
+  svoh_align_options opt;
+  int32_t lds_img_bytes;                // dynamic LDS available for image staging
+  int32_t eval_level;                   // <0: full run; >=0: evaluate once at that level
+  double* eval_out;                     // [64 H][8 g][chi2][n_meas] for eval mode
+};
+
+struct ShState {
+  Rigid T, Told;
+  double alpha, beta, alpha_old, beta_old;
+  Rigid Tcr[SVOH_MAX_CAMS];
+  double I_prior[8];
+  float alpha_f, beta_f;
+  int stop, level_done, nsel, status;
+};
+
+// ---- image accessors --------------------------------------------------------
+struct ImgView {
+  const uint8_t* p;
+  int pitch;
+  __device__ __forceinline__ double at(int off) const { return (double)p[off]; }
+};
+
+template <int D>
+struct AccLayout {
+  static constexpr int NH = D * (D + 1) / 2;
+  static constexpr int NACC = NH + D + 1;
+};
+
+__device__ __forceinline__ float tukey_weight(float e)
+{
+  const float b = 4.6851f;
+  const float b2 = b * b;
+  const float x2 = e * e;
+  if (x2 <= b2) {
+    const float t = 1.0f - x2 / b2;
+    return t * t;
+  }
+  return 0.0f;
+}
+
+// Frame::jacobian_xyz2uv_imu (frame.h:342-357) times focal length, or
+// Frame::jacobian_xyz2image_imu (frame.cpp:274-290) times -1
+// (sparse_img_align.cpp:298-309).  jp0 = row 0 (du), jp1 = row 1 (dv).
+__device__ __forceinline__ void projection_jacobian(const Vec3& xyz_ref, const Rigid& T_imu_cam,
+                                                    const Rigid& T_cam_imu, const double* R /*row-major*/,
+                                                    const CamModel& cm, bool use_distortion_jac,
+                                                    double jp0[6], double jp1[6])
+{
+  const Vec3 p = transform(T_imu_cam, xyz_ref);  // xyz_in_imu
+  const Vec3 pc = transform(T_cam_imu, p);       // p_in_cam
+  double A[6];
+  if (!use_distortion_jac) {
+    const double s = -1.0 / pc.z;
+    const double jx = -pc.x / pc.z, jy = -pc.y / pc.z;
+    A[0] = s * 1.0; A[1] = s * 0.0; A[2] = s * jx;
+    A[3] = s * 0.0; A[4] = s * 1.0; A[5] = s * jy;
+  } else {
+    project3_jacobian(cm, pc, A);
+  }
+  double B[6];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      B[r * 3 + c] = A[r * 3 + 0] * R[c] + A[r * 3 + 1] * R[3 + c] + A[r * 3 + 2] * R[6 + c];
+  const double m = use_distortion_jac ? -1.0 : fabs(cm.fx);
+  // G_x = [I, -skew(p)]
+  jp0[0] = B[0] * m; jp0[1] = B[1] * m; jp0[2] = B[2] * m;
+  jp0[3] = (B[1] * (-p.z) + B[2] * p.y) * m;
+  jp0[4] = (B[0] * p.z + B[2] * (-p.x)) * m;
+  jp0[5] = (B[0] * (-p.y) + B[1] * p.x) * m;
+  jp1[0] = B[3] * m; jp1[1] = B[4] * m; jp1[2] = B[5] * m;
+  jp1[3] = (B[4] * (-p.z) + B[5] * p.y) * m;
+  jp1[4] = (B[3] * p.z + B[5] * (-p.x)) * m;
+  jp1[5] = (B[3] * (-p.y) + B[4] * p.x) * m;
+}
+
+// One patch: residuals (a-6), Jacobians / reference patch (a-5) and the normal
+// equation contribution (a-7), all in registers.
+template <int P, int D>
+__device__ __forceinline__ void patch_contribution(
+    const ImgView& ref, const ImgView& cur, int ru, int rv, double rsu, double rsv, int cu, int cv,
+    double csu, double csv, const double jp0[6], const double jp1[6], double scale, double one_plus_alpha,
+    double beta, bool est_alpha, bool est_beta, bool robust, float weight_scale,
+    double (&acc)[AccLayout<D>::NACC])
+{
+  constexpr int NH = AccLayout<D>::NH;
+  constexpr int WB = P + 2;
+  // bilinear weights (sparse_img_align.cpp:355-360 and :456-461)
+  const double rwtl = (1.0 - rsu) * (1.0 - rsv), rwtr = rsu * (1.0 - rsv);
+  const double rwbl = (1.0 - rsu) * rsv, rwbr = rsu * rsv;
+  const double cwtl = (1.0 - csu) * (1.0 - csv), cwtr = csu * (1.0 - csv);
+  const double cwbl = (1.0 - csu) * csv, cwbr = csu * csv;
+
+  double rawA[WB + 1], rawB[WB + 1];
+  double it0[WB], it1[WB], it2[WB];
+  double curA[P + 1], curB[P + 1];
+  const int roff = rv * ref.pitch + ru;
+  const int coff = cv * cur.pitch + cu;
+#pragma unroll
+  for (int i = 0; i < WB + 1; ++i) rawA[i] = ref.at(roff + i);
+#pragma unroll
+  for (int i = 0; i < WB; ++i) { it0[i] = 0.0; it1[i] = 0.0; it2[i] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < P + 1; ++i) { curA[i] = 0.0; curB[i] = 0.0; }
+
+#pragma unroll
+  for (int j = 0; j < WB; ++j) {
+    // interpolated reference row j of the (P+2)^2 patch-with-border
+#pragma unroll
+    for (int i = 0; i < WB + 1; ++i) rawB[i] = ref.at(roff + (j + 1) * ref.pitch + i);
+#pragma unroll
+    for (int i = 0; i < WB; ++i) {
+      it0[i] = it1[i];
+      it1[i] = it2[i];
+      it2[i] = rwtl * rawA[i] + rwtr * rawA[i + 1] + rwbl * rawB[i] + rwbr * rawB[i + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < WB + 1; ++i) rawA[i] = rawB[i];
+    if (j == 1) {
+#pragma unroll
+      for (int i = 0; i < P + 1; ++i) curB[i] = cur.at(coff + i);
+    }
+    if (j >= 2) {
+      const int y = j - 2;  // output row: it0 = row y (up), it1 = y+1 (centre), it2 = y+2 (down)
+#pragma unroll
+      for (int i = 0; i < P + 1; ++i) { curA[i] = curB[i]; curB[i] = cur.at(coff + (y + 1) * cur.pitch + i); }
+#pragma unroll
+      for (int x = 0; x < P; ++x) {
+        const double ref_val = it1[x + 1];
+        const double dx = 0.5 * (it1[x + 2] - it1[x]);
+        const double dy = 0.5 * (it2[x + 1] - it0[x + 1]);
+        double J[D];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J[k] = (dx * jp0[k] + dy * jp1[k]) * scale;
+        if constexpr (D == 8) {
+          J[6] = est_alpha ? -ref_val : 0.0;
+          J[7] = est_beta ? -1.0 : 0.0;
+        }
+        const double intensity_cur = cwtl * curA[x] + cwtr * curA[x + 1] + cwbl * curB[x] + cwbr * curB[x + 1];
+        const double res = (intensity_cur * one_plus_alpha + beta) - ref_val;
+        double w = 1.0;
+        if (robust) w = (double)tukey_weight((float)(res / (double)weight_scale));
+        acc[NH + D] += res * res * w;  // chi2 (fp64 here; the reference accumulates it in float)
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const double Jw = robust ? J[a] * w : J[a];
+#pragma unroll
+          for (int b = a; b < D; ++b) { acc[idx] += Jw * J[b]; ++idx; }
+          acc[NH + a] -= Jw * res;
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void stage_image(unsigned char* dst, const DevImage& im, int tid)
+{
+  const int total = im.w * im.h;
+  if (im.pitch == im.w && (reinterpret_cast<uintptr_t>(im.data) & 15) == 0) {
+    const int n16 = total >> 4;
+    const uint4* s = reinterpret_cast<const uint4*>(im.data);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    for (int i = tid; i < n16; i += NT) d[i] = s[i];
+    for (int i = (n16 << 4) + tid; i < total; i += NT) dst[i] = im.data[i];
+  } else {
+    for (int i = tid; i < total; i += NT) {
+      const int y = i / im.w, x = i - y * im.w;
+      dst[i] = im.data[(size_t)y * im.pitch + x];
+    }
+  }
+}
+
+template <int P, int NT, bool ILLUM>
+__global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs a)
+{
+  constexpr int D = ILLUM ? 8 : 6;
+  constexpr int NH = AccLayout<D>::NH;
+  constexpr int NACC = AccLayout<D>::NACC;
+  constexpr int NW = NT / 64;
+
+  extern __shared__ __align__(16) unsigned char lds_img[];
+  __shared__ double s_red[NW][NACC];
+  __shared__ double s_sum[NACC];
+  __shared__ double s_H[64];
+  __shared__ double s_x[8];
+  __shared__ double s_tmp[8];
+  __shared__ int s_tr[8];
+  __shared__ int s_nvis;
+  __shared__ ShState s;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const DevProblemDesc& pb = a.problems[blockIdx.x];
+  const DevCamDesc* cams = a.cams + pb.cam_begin;
+  const int n_cams = pb.n_cams;
+  const svoh_align_options& opt = a.opt;
+  const bool eval_mode = a.eval_level >= 0;
+
+  if (tid == 0) {
+    s.T = load_rigid(pb.T_init);
+    s.Told = s.T;
+    s.alpha = pb.alpha_init; s.beta = pb.beta_init;
+    s.alpha_old = s.alpha; s.beta_old = s.beta;
+    s.stop = 0; s.level_done = 0; s.nsel = 0; s.status = 0;
+    for (int k = 0; k < 8; ++k) s.I_prior[k] = 0.0;
+    s_nvis = 0;
+  }
+  __syncthreads();
+
+  // ---- a-3 extractFeaturesSubset + a-4 precomputeBaseCaches (depth, xyz_ref) ----
+  {
+    int my_sel = 0;
+    const int patch_size_wb = P + 2;
+    const double scale = 1.0f / (1 << opt.max_level);
+    const double patch_center_wb = (patch_size_wb - 1) / 2.0f;
+    for (int c = 0; c < n_cams; ++c) {
+      const DevCamDesc& cd = cams[c];
+      const int rows_minus_two = cd.ref[opt.max_level].h - 2;
+      const int cols_minus_two = cd.ref[opt.max_level].w - 2;
+      for (int i = tid; i < cd.n_features; i += NT) {
+        const int gi = cd.feat_off + i;
+        bool sel = cd.flags[i] != 0;
+        const double pu = cd.px[2 * i], pv = cd.px[2 * i + 1];
+        if (sel) {
+          const double u_tl = pu * scale - patch_center_wb;
+          const double v_tl = pv * scale - patch_center_wb;
+          const int u_tl_i = (int)floor(u_tl);
+          const int v_tl_i = (int)floor(v_tl);
+          sel = !(u_tl_i < 0 || v_tl_i < 0 || u_tl_i + patch_size_wb >= cols_minus_two ||
+                  v_tl_i + patch_size_wb >= rows_minus_two);
+        }
+        a.wsel[gi] = sel ? 1 : 0;
+        a.wvis[gi] = 0;
+        if (sel) {
+          const double dx = cd.pos_world[3 * i + 0] - cd.ref_pos[0];
+          const double dy = cd.pos_world[3 * i + 1] - cd.ref_pos[1];
+          const double dz = cd.pos_world[3 * i + 2] - cd.ref_pos[2];
+          const double depth = sqrt(dx * dx + dy * dy + dz * dz);
+          a.wx[gi] = cd.f[3 * i + 0] * depth;
+          a.wy[gi] = cd.f[3 * i + 1] * depth;
+          a.wz[gi] = cd.f[3 * i + 2] * depth;
+          a.wu[gi] = pu;
+          a.wv[gi] = pv;
+          ++my_sel;
+        }
+      }
+    }
+    if (my_sel) atomicAdd(&s.nsel, my_sel);
+  }
+  __syncthreads();
+  const int n_sel = s.nsel;
+  if (n_sel == 0) {
+    if (tid == 0) {
+      svoh_align_result& r = a.results[blockIdx.x];
+      r.status = 1; r.n_fts_to_track = 0;
+      store_rigid(s.T, r.T_icur_iref);
+      r.alpha = s.alpha; r.beta = s.beta;
+      for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = 0; r.n_meas[l] = 0; r.chi2[l] = 0.0; }
+      if (eval_mode) for (int k = 0; k < 74; ++k) a.eval_out[k] = 0.0;
+    }
+    return;
+  }
+  if (tid == 0) {
+    svoh_align_result& r = a.results[blockIdx.x];
+    for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = 0; r.n_meas[l] = 0; r.chi2[l] = 0.0; }
+  }
+
+  const bool est_alpha = opt.estimate_illumination_gain != 0;
+  const bool est_beta = opt.estimate_illumination_offset != 0;
+  const bool robust = opt.robustification != 0;
+  const bool dist_jac = opt.use_distortion_jacobian != 0;
+  const float weight_scale = (float)opt.weight_scale;
+
+  const int level_hi = eval_mode ? a.eval_level : opt.max_level;
+  const int level_lo = eval_mode ? a.eval_level : opt.min_level;
+
+  for (int level = level_hi; level >= level_lo; --level) {
+    const double scale = 1.0f / (1 << level);
+    // ---- stage the level's images in LDS if they all fit ----
+    int need = 0;
+    for (int c = 0; c < n_cams; ++c) {
+      need += ((cams[c].ref[level].w * cams[c].ref[level].h + 15) & ~15);
+      need += ((cams[c].cur[level].w * cams[c].cur[level].h + 15) & ~15);
+    }
+    const bool in_lds = need <= a.lds_img_bytes;
+    __syncthreads();  // previous level's readers are done with lds_img
+    if (in_lds) {
+      int off = 0;
+      for (int c = 0; c < n_cams; ++c) {
+        stage_image<NT>(lds_img + off, cams[c].ref[level], tid);
+        off += ((cams[c].ref[level].w * cams[c].ref[level].h + 15) & ~15);
+        stage_image<NT>(lds_img + off, cams[c].cur[level], tid);
+        off += ((cams[c].cur[level].w * cams[c].cur[level].h + 15) & ~15);
+      }
+    }
+    if (tid == 0) {
+      s.level_done = 0;
+      for (int c = 0; c < n_cams; ++c)
+        s.Tcr[c] = mul(mul(load_rigid(cams[c].cur_T_cam_imu), s.T), load_rigid(cams[c].ref_T_imu_cam));
+      s.alpha_f = (float)s.alpha; s.beta_f = (float)s.beta;
+      s.Told = s.T; s.alpha_old = s.alpha; s.beta_old = s.beta;  // old_state = state (hpp:45)
+    }
+    __syncthreads();
+
+    for (int iter = 0; iter < opt.max_iter; ++iter) {
+      double acc[NACC];
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+      int nvis = 0;
+      const double one_plus_alpha = 1.0 + (double)s.alpha_f;
+      const double beta_d = (double)s.beta_f;
+
+      int off = 0;
+      for (int c = 0; c < n_cams; ++c) {
+        const DevCamDesc& cd = cams[c];
+        const DevImage& rim = cd.ref[level];
+        const DevImage& cim = cd.cur[level];
+        ImgView ref, cur;
+        if (in_lds) {
+          ref.p = lds_img + off; ref.pitch = rim.w;
+          off += ((rim.w * rim.h + 15) & ~15);
+          cur.p = lds_img + off; cur.pitch = cim.w;
+          off += ((cim.w * cim.h + 15) & ~15);
+        } else {
+          ref.p = rim.data; ref.pitch = rim.pitch;
+          cur.p = cim.data; cur.pitch = cim.pitch;
+        }
+        const Rigid Tcr = s.Tcr[c];
+        const CamModel cm = load_camera(cd.cam);
+        const Rigid T_imu_cam = load_rigid(cd.ref_T_imu_cam);
+        const Rigid T_cam_imu = load_rigid(cd.ref_T_cam_imu);
+        double R[9];
+        to_matrix(T_cam_imu.q, R);
+        const double patch_center = (P - 1) / 2.0f;
+        const double patch_center_wb = (P + 2 - 1) / 2.0f;
+        const int cw = cim.w, ch = cim.h;
+
+        for (int i = tid; i < cd.n_features; i += NT) {
+          const int gi = cd.feat_off + i;
+          if (!a.wsel[gi]) continue;
+          const Vec3 X = { a.wx[gi], a.wy[gi], a.wz[gi] };
+          // ---- a-6 projection into the current level + visibility ----
+          const Vec3 Y = transform(Tcr, X);
+          bool vis = !(Y.z < 0.0);
+          int cu = 0, cv = 0;
+          double csu = 0.0, csv = 0.0;
+          if (vis) {
+            double u, v;
+            project3(cm, Y, u, v);
+            const double u_tl = u * scale - patch_center;
+            const double v_tl = v * scale - patch_center;
+            vis = !(u_tl < 0.0 || v_tl < 0.0 || u_tl + P + 2.0 >= cw || v_tl + P + 2.0 >= ch);
+            if (vis) {
+              const double fu = floor(u_tl), fv = floor(v_tl);
+              cu = (int)fu; cv = (int)fv;
+              csu = u_tl - cu; csv = v_tl - cv;
+            }
+          }
+          if (eval_mode) a.wvis[gi] = vis ? 1 : 0;
+          if (!vis) continue;
+          ++nvis;
+          // ---- a-5 reference side (recomputed, never stored) ----
+          const double ru_tl = a.wu[gi] * scale - patch_center_wb;
+          const double rv_tl = a.wv[gi] * scale - patch_center_wb;
+          const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
+          const double rsu = ru_tl - ru, rsv = rv_tl - rv;
+          double jp0[6], jp1[6];
+          projection_jacobian(X, T_imu_cam, T_cam_imu, R, cm, dist_jac, jp0, jp1);
+          patch_contribution<P, D>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, jp0, jp1, scale,
+                                   one_plus_alpha, beta_d, est_alpha, est_beta, robust, weight_scale, acc);
+        }
+      }
+
+      // ---- reduce: wave shuffles, then across waves through LDS ----
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[k] = v;
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) nvis += __shfl_xor(nvis, o, 64);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) s_red[wave][k] = acc[k];
+        atomicAdd(&s_nvis, nvis);
+      }
+      __syncthreads();
+      if (tid < NACC) {
+        double v = 0.0;
+        for (int w = 0; w < NW; ++w) v += s_red[w][tid];
+        s_sum[tid] = v;
+      }
+      __syncthreads();
+
+      // ---- serial part: prior, 8x8 LDL^T, SE3 update, convergence ----
+      if (tid == 0) {
+        const int n_meas = s_nvis * P * P;
+        s_nvis = 0;
+        const double chi2 = s_sum[NH + D] / (double)n_meas;
+        for (int k = 0; k < 64; ++k) s_H[k] = 0.0;
+        for (int k = 0; k < 8; ++k) s_x[k] = 0.0;
+        int idx = 0;
+        for (int r = 0; r < D; ++r)
+          for (int c2 = r; c2 < D; ++c2) {
+            const double v = s_sum[idx++];
+            s_H[c2 * 8 + r] = v;
+            s_H[r * 8 + c2] = v;
+          }
+        for (int r = 0; r < D; ++r) s_x[r] = s_sum[NH + r];
+        svoh_align_result& res = a.results[blockIdx.x];
+        if (level < SVOH_MAX_LEVELS) {
+          res.iters[level] = iter + 1;
+          res.n_meas[level] = n_meas;
+          res.chi2[level] = chi2;
+        }
+        if (eval_mode) {
+          for (int k = 0; k < 64; ++k) a.eval_out[k] = s_H[k];
+          for (int k = 0; k < 8; ++k) a.eval_out[64 + k] = s_x[k];
+          a.eval_out[72] = chi2;
+          a.eval_out[73] = (double)n_meas;
+          s.level_done = 1;
+        } else {
+          if (pb.prior.have_prior) {
+            // SparseImgAlignBase::applyPrior (sparse_img_align_base.cpp:77-107)
+            if (iter == 0) {
+              double mt = 0, mr = 0;
+              for (int j = 0; j < 3; ++j) mt = fmax(mt, fabs(s_H[j * 8 + j]));
+              for (int j = 3; j < 6; ++j) mr = fmax(mr, fabs(s_H[j * 8 + j]));
+              for (int j = 0; j < 3; ++j) s.I_prior[j] = 1.0 * pb.prior.lambda_trans * mt;
+              for (int j = 3; j < 6; ++j) s.I_prior[j] = 1.0 * pb.prior.lambda_rot * mr;
+              s.I_prior[6] = pb.prior.lambda_alpha * s_H[6 * 8 + 6];
+              s.I_prior[7] = pb.prior.lambda_beta * s_H[7 * 8 + 7];
+            }
+            for (int j = 0; j < 8; ++j) s_H[j * 8 + j] += s.I_prior[j];
+            double lg[6];
+            rigid_log(mul(inverse(load_rigid(pb.prior.T_prior)), s.T), lg);
+            for (int j = 0; j < 6; ++j) s_x[j] += s.I_prior[j] * lg[j];
+            s_x[6] += s.I_prior[6] * (pb.prior.alpha_prior - s.alpha);
+            s_x[7] += s.I_prior[7] * (pb.prior.beta_prior - s.beta);
+          }
+          if (!ldlt_solve_inplace<8>(s_H, s_x, s_tr, s_tmp)) s.stop = 1;
+          if (s.stop) {
+            // rollback (mini_least_squares_solver.hpp:73-82); stop_ is only cleared by reset()
+            s.T = s.Told; s.alpha = s.alpha_old; s.beta = s.beta_old;
+            s.status = 2;
+            s.level_done = 1;
+          } else {
+            // SparseImgAlignBase::update (sparse_img_align_base.cpp:64-75)
+            double mdx[6];
+            for (int j = 0; j < 6; ++j) mdx[j] = -s_x[j];
+            Rigid Tn = mul(s.T, rigid_exp(mdx));
+            const double an = (s.alpha - s_x[6]) / (1.0 + s_x[6]);
+            const double bn = (s.beta - s_x[7]) / (1.0 + s_x[6]);
+            Tn.q = normalized(Tn.q);
+            s.Told = s.T; s.alpha_old = s.alpha; s.beta_old = s.beta;
+            s.T = Tn; s.alpha = an; s.beta = bn;
+            double x_norm = -1.0;
+            for (int j = 0; j < 8; ++j) { const double v = fabs(s_x[j]); if (v > x_norm) x_norm = v; }
+            if (x_norm < opt.eps) s.level_done = 1;
+          }
+          for (int c = 0; c < n_cams; ++c)
+            s.Tcr[c] = mul(mul(load_rigid(cams[c].cur_T_cam_imu), s.T), load_rigid(cams[c].ref_T_imu_cam));
+          s.alpha_f = (float)s.alpha; s.beta_f = (float)s.beta;
+        }
+      }
+      __syncthreads();
+      if (s.level_done) break;
+    }
+  }
+
+  if (tid == 0) {
+    svoh_align_result& r = a.results[blockIdx.x];
+    r.status = s.status;
+    r.n_fts_to_track = n_sel;
+    store_rigid(s.T, r.T_icur_iref);
+    r.alpha = s.alpha; r.beta = s.beta;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+struct LaunchCfg { int nt; size_t lds; };
+
+template <int P, int NT, bool ILLUM>
+static hipError_t launch_one(hipStream_t st, int grid, size_t lds, const AlignKernelArgs& args)
+{
+  auto kern = sparse_align_kernel<P, NT, ILLUM>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, args);
+  return hipGetLastError();
+}
+
+template <int P, bool ILLUM>
+static hipError_t launch_nt(hipStream_t st, int nt, int grid, size_t lds, const AlignKernelArgs& args)
+{
+  switch (nt) {
+    case 256: return launch_one<P, 256, ILLUM>(st, grid, lds, args);
+    case 512: return launch_one<P, 512, ILLUM>(st, grid, lds, args);
+    default: return launch_one<P, 1024, ILLUM>(st, grid, lds, args);
+  }
+}
+
+static int getenv_int(const char* name, int dflt)
+{
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+static int validate_options(svoh_ctx* ctx, const svoh_align_options* o)
+{
+  SVOH_REQUIRE(ctx, o != nullptr, "options is NULL");
+  if (o->patch_size != 4 && o->patch_size != 8)
+    return set_error(ctx, SVOH_ERR_UNSUPPORTED, "patch_size %d not built (4 and 8 are)", o->patch_size);
+  SVOH_REQUIRE(ctx, o->max_level >= o->min_level && o->min_level >= 0 && o->max_level < SVOH_MAX_LEVELS,
+               "bad level range");
+  SVOH_REQUIRE(ctx, o->max_iter >= 1, "max_iter must be >= 1");
+  return SVOH_OK;
+}
+
+// Build descriptors, upload host feature arrays if needed, launch.
+static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_problems,
+                         const svoh_align_problem* problems, int eval_level)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  int rc = validate_options(ctx, opt);
+  if (rc != SVOH_OK) return rc;
+  SVOH_REQUIRE(ctx, n_problems >= 1 && problems, "no problems");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  // pass 1: sizes
+  size_t n_cams_total = 0, n_feat_total = 0, host_bytes = 0;
+  int max_feat_per_problem = 0;
+  for (int p = 0; p < n_problems; ++p) {
+    const svoh_align_problem& pb = problems[p];
+    SVOH_REQUIRE(ctx, pb.n_cams >= 1 && pb.n_cams <= SVOH_MAX_CAMS, "n_cams out of range");
+    int nf = 0;
+    for (int c = 0; c < pb.n_cams; ++c) {
+      const svoh_align_camera& cam = pb.cams[c];
+      SVOH_REQUIRE(ctx, cam.n_features >= 0, "negative n_features");
+      SVOH_REQUIRE(ctx, cam.n_features == 0 || (cam.px && cam.f && cam.pos_world && cam.flags),
+                   "NULL feature array");
+      SVOH_REQUIRE(ctx, cam.cam.distortion == SVOH_DISTORTION_NONE || cam.cam.distortion == SVOH_DISTORTION_RADTAN,
+                   "unsupported distortion model");
+      nf += cam.n_features;
+      if (cam.mem_space == SVOH_MEM_HOST) host_bytes += ((size_t)cam.n_features * (8 * 8 + 1) + 63) & ~(size_t)63;
+    }
+    n_cams_total += pb.n_cams;
+    n_feat_total += nf;
+    if (nf > max_feat_per_problem) max_feat_per_problem = nf;
+  }
+  const size_t feat_slots = n_feat_total ? n_feat_total : 1;
+
+  const size_t desc_bytes = sizeof(DevProblemDesc) * n_problems + sizeof(DevCamDesc) * n_cams_total;
+  SVOH_HIP_TRY(ctx, ctx->h_desc.reserve(desc_bytes));
+  SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
+  SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * n_problems));
+  SVOH_HIP_TRY(ctx, ctx->h_results.reserve(sizeof(svoh_align_result) * n_problems));
+  SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (5 * 8 + 2) + 256));
+  if (host_bytes) {
+    SVOH_HIP_TRY(ctx, ctx->h_upload.reserve(host_bytes));
+    SVOH_HIP_TRY(ctx, ctx->d_upload.reserve(host_bytes));
+  }
+  SVOH_HIP_TRY(ctx, ctx->d_eval.reserve(74 * sizeof(double)));
+
+  DevProblemDesc* hp = static_cast<DevProblemDesc*>(ctx->h_desc.ptr);
+  DevCamDesc* hc = reinterpret_cast<DevCamDesc*>(hp + n_problems);
+  uint8_t* hup = static_cast<uint8_t*>(ctx->h_upload.ptr);
+  uint8_t* dup = static_cast<uint8_t*>(ctx->d_upload.ptr);
+  size_t up_off = 0;
+  int cam_idx = 0, feat_off = 0;
+  const int need_levels = opt->max_level + 1;
+  for (int p = 0; p < n_problems; ++p) {
+    const svoh_align_problem& pb = problems[p];
+    DevProblemDesc& d = hp[p];
+    d.n_cams = pb.n_cams;
+    d.cam_begin = cam_idx;
+    d.T_init = pb.T_icur_iref;
+    d.alpha_init = pb.alpha_init; d.beta_init = pb.beta_init;
+    d.prior = pb.prior;
+    for (int c = 0; c < pb.n_cams; ++c, ++cam_idx) {
+      const svoh_align_camera& cam = pb.cams[c];
+      DevCamDesc& dc = hc[cam_idx];
+      const Frame* fr = find_frame(ctx, cam.ref_frame);
+      const Frame* fc = find_frame(ctx, cam.cur_frame);
+      if (!fr || !fc) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "problem %d camera %d: unknown frame handle", p, c);
+      if (fr->n_levels < need_levels || fc->n_levels < need_levels)
+        return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "problem %d camera %d: pyramid has fewer than %d levels", p,
+                         c, need_levels);
+      for (int l = 0; l < SVOH_MAX_LEVELS; ++l) {
+        dc.ref[l] = l < fr->n_levels ? fr->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
+        dc.cur[l] = l < fc->n_levels ? fc->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
+      }
+      dc.cam = cam.cam;
+      dc.ref_T_imu_cam = cam.ref_T_imu_cam;
+      dc.ref_T_cam_imu = cam.ref_T_cam_imu;
+      dc.cur_T_cam_imu = cam.cur_T_cam_imu;
+      for (int k = 0; k < 3; ++k) dc.ref_pos[k] = cam.ref_pos[k];
+      dc.n_features = cam.n_features;
+      dc.feat_off = feat_off;
+      feat_off += cam.n_features;
+      if (cam.mem_space == SVOH_MEM_DEVICE || cam.n_features == 0) {
+        dc.px = cam.px; dc.f = cam.f; dc.pos_world = cam.pos_world; dc.flags = cam.flags;
+      } else {
+        const size_t n = (size_t)cam.n_features;
+        uint8_t* h = hup + up_off;
+        uint8_t* dv = dup + up_off;
+        memcpy(h, cam.px, n * 16);
+        memcpy(h + n * 16, cam.f, n * 24);
+        memcpy(h + n * 40, cam.pos_world, n * 24);
+        memcpy(h + n * 64, cam.flags, n);
+        dc.px = reinterpret_cast<const double*>(dv);
+        dc.f = reinterpret_cast<const double*>(dv + n * 16);
+        dc.pos_world = reinterpret_cast<const double*>(dv + n * 40);
+        dc.flags = dv + n * 64;
+        up_off += (n * 65 + 63) & ~(size_t)63;
+      }
+    }
+  }
+  if (up_off)
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_upload.ptr, ctx->h_upload.ptr, up_off, hipMemcpyHostToDevice, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc.ptr, ctx->h_desc.ptr, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+
+  AlignKernelArgs args;
+  args.problems = static_cast<const DevProblemDesc*>(ctx->d_desc.ptr);
+  args.cams = reinterpret_cast<const DevCamDesc*>(args.problems + n_problems);
+  args.results = static_cast<svoh_align_result*>(ctx->d_results.ptr);
+  double* w = static_cast<double*>(ctx->d_feat.ptr);
+  args.wx = w; args.wy = w + feat_slots; args.wz = w + 2 * feat_slots;
+  args.wu = w + 3 * feat_slots; args.wv = w + 4 * feat_slots;
+  args.wsel = reinterpret_cast<uint8_t*>(w + 5 * feat_slots);
+  args.wvis = args.wsel + feat_slots;
+  args.opt = *opt;
+  args.eval_level = eval_level;
+  args.eval_out = static_cast<double*>(ctx->d_eval.ptr);
+
+  // Geometry.  Many problems: 256-thread workgroups, several per CU, so that one
+  // problem's serial solve overlaps the others' patch work; LDS holds levels >= 2
+  // of a 640x480 pyramid.  Few problems (latency mode): one 1024-thread
+  // workgroup per CU with almost all of the 160 KiB LDS, which holds level 1 too.
+  int nt = (n_problems >= 2 * ctx->num_cus) ? 256 : 1024;
+  if (max_feat_per_problem <= 512 && nt > 512) nt = 512;
+  if (max_feat_per_problem <= 256) nt = 256;
+  nt = getenv_int("SVOH_ALIGN_THREADS", nt);
+  if (nt != 256 && nt != 512 && nt != 1024) nt = 256;
+  size_t lds = (nt == 256) ? 38400 : (nt == 512 ? 78 * 1024 : 153856);
+  lds = (size_t)getenv_int("SVOH_ALIGN_LDS", (int)lds);
+  if (lds > 153856) lds = 153856;
+  args.lds_img_bytes = (int32_t)lds;
+
+  const bool illum = opt->estimate_illumination_gain || opt->estimate_illumination_offset;
+  hipError_t e;
+  if (opt->patch_size == 4)
+    e = illum ? launch_nt<4, true>(ctx->stream, nt, n_problems, lds, args)
+              : launch_nt<4, false>(ctx->stream, nt, n_problems, lds, args);
+  else
+    e = illum ? launch_nt<8, true>(ctx->stream, nt, n_problems, lds, args)
+              : launch_nt<8, false>(ctx->stream, nt, n_problems, lds, args);
+  if (e != hipSuccess)
+    return set_error(ctx, SVOH_ERR_HIP, "sparse_align launch failed: %s", hipGetErrorString(e));
+  ctx->last_align_n = n_problems;
+  return SVOH_OK;
+}
+
+}  // namespace svoh
+
+using namespace svoh;
+
+extern "C" {
+
+int svoh_sparse_align_enqueue(svoh_ctx* ctx, const svoh_align_options* options, int n_problems,
+                              const svoh_align_problem* problems)
+{
+  return enqueue_align(ctx, options, n_problems, problems, -1);
+}
+
+int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* results)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, results && n_problems >= 1 && n_problems <= ctx->last_align_n, "nothing to fetch");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results.ptr, ctx->d_results.ptr, sizeof(svoh_align_result) * n_problems,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(results, ctx->h_results.ptr, sizeof(svoh_align_result) * n_problems);
+  return SVOH_OK;
+}
+
+int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options, int n_problems,
+                            const svoh_align_problem* problems, svoh_align_result* results)
+{
+  int rc = enqueue_align(ctx, options, n_problems, problems, -1);
+  if (rc != SVOH_OK) return rc;
+  return svoh_sparse_align_fetch(ctx, n_problems, results);
+}
+
+int svoh_sparse_align_evaluate(svoh_ctx* ctx, const svoh_align_options* options, const svoh_align_problem* problem,
+                               int level, double* H64, double* g8, double* chi2, int32_t* n_meas,
+                               uint8_t* visibility, int32_t* n_selected)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, problem && H64 && g8, "NULL argument");
+  SVOH_REQUIRE(ctx, level >= 0 && options && level <= options->max_level, "level out of range");
+  int rc = enqueue_align(ctx, options, 1, problem, level);
+  if (rc != SVOH_OK) return rc;
+  double out[74];
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_eval.ptr, sizeof out, hipMemcpyDeviceToHost, ctx->stream));
+  int nf = 0;
+  for (int c = 0; c < problem->n_cams; ++c) nf += problem->cams[c].n_features;
+  std::vector<uint8_t> sel((size_t)nf + 1), vis((size_t)nf + 1);
+  // workspace layout: see enqueue_align
+  const size_t slots = nf ? (size_t)nf : 1;
+  const uint8_t* dsel = reinterpret_cast<const uint8_t*>(static_cast<double*>(ctx->d_feat.ptr) + 5 * slots);
+  if (nf) {
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(sel.data(), dsel, (size_t)nf, hipMemcpyDeviceToHost, ctx->stream));
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(vis.data(), dsel + slots, (size_t)nf, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(H64, out, 64 * sizeof(double));
+  memcpy(g8, out + 64, 8 * sizeof(double));
+  if (chi2) *chi2 = out[72];
+  if (n_meas) *n_meas = (int32_t)out[73];
+  int k = 0;
+  for (int i = 0; i < nf; ++i)
+    if (sel[i]) { if (visibility) visibility[k] = vis[i]; ++k; }
+  if (n_selected) *n_selected = k;
+  return SVOH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// svoh_internal.h -- context, device frames and shared helpers of libsvo_hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/svo_hip.h"
+
+namespace svoh {
+
+// one pyramid level in device memory (row-major u8)
+struct DevImage {
+  const uint8_t* data;
+  int32_t w, h, pitch, pad;
+};
+
+// device allocation shared by the frames carved out of it
+struct Slab {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  ~Slab() { if (ptr) (void)hipFree(ptr); }
+};
+
+struct Frame {
+  std::shared_ptr<Slab> slab;
+  int n_levels = 0;
+  DevImage lv[SVOH_MAX_LEVELS];
+};
+
+// grow-only device / pinned-host scratch buffers (never reallocated inside a
+// timed loop once warmed up)
+struct DevBuffer {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes)
+  {
+    if (bytes <= cap) return hipSuccess;
+    if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  ~DevBuffer() { if (ptr) (void)hipFree(ptr); }
+};
+
+struct PinnedBuffer {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes)
+  {
+    if (bytes <= cap) return hipSuccess;
+    if (ptr) { (void)hipHostFree(ptr); ptr = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  ~PinnedBuffer() { if (ptr) (void)hipHostFree(ptr); }
+};
+
+}  // namespace svoh
+
+struct svoh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cus = 0;
+  size_t lds_per_block = 0;
+  std::string err;
+  std::unordered_map<uint64_t, svoh::Frame> frames;
+  uint64_t next_frame_id = 1;
+
+  // sparse-align workspaces
+  svoh::DevBuffer d_desc;      // problem + camera descriptors
+  svoh::DevBuffer d_results;   // svoh_align_result[n]
+  svoh::DevBuffer d_feat;      // per-feature workspace
+  svoh::DevBuffer d_upload;    // staged host feature arrays
+  svoh::DevBuffer d_eval;      // evaluate() outputs
+  svoh::PinnedBuffer h_desc;
+  svoh::PinnedBuffer h_upload;
+  svoh::PinnedBuffer h_results;
+  int last_align_n = 0;
+
+  // generic scratch for the other paths
+  svoh::DevBuffer d_scratch0, d_scratch1, d_scratch2;
+  svoh::PinnedBuffer h_scratch0, h_scratch1;
+};
+
+namespace svoh {
+
+int set_error(svoh_ctx* ctx, int code, const char* fmt, ...);
+void set_global_error(const char* msg);
+const Frame* find_frame(const svoh_ctx* ctx, svoh_frame_t id);
+
+#define SVOH_HIP_TRY(ctx, expr)                                                          \
+  do {                                                                                   \
+    hipError_t svoh_e_ = (expr);                                                         \
+    if (svoh_e_ != hipSuccess)                                                           \
+      return svoh::set_error((ctx), SVOH_ERR_HIP, "%s failed: %s (%s:%d)", #expr,        \
+                             hipGetErrorString(svoh_e_), __FILE__, __LINE__);            \
+  } while (0)
+
+#define SVOH_REQUIRE(ctx, cond, msg)                                                     \
+  do {                                                                                   \
+    if (!(cond)) return svoh::set_error((ctx), SVOH_ERR_INVALID_ARGUMENT, "%s", (msg));  \
+  } while (0)
+
+}  // namespace svoh

@@ -1,0 +1,204 @@
+"""Thin Python plumbing over the C ABI (include/svo_hip.h) for tests and bench.
+
+This is not the product's host layer (that is C++, svo_pro_universal_amd/host/,
+mirroring the reference's SparseImgAlignBase etc.); it only marshals numpy /
+device pointers into the POD structs and raises on non-zero status codes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+
+
+class SvohError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "svoh error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _se3(T):
+    s = capi.svoh_se3()
+    v = T.as7() if hasattr(T, "as7") else np.asarray(T, dtype=np.float64)
+    for i in range(4):
+        s.q[i] = float(v[i])
+    for i in range(3):
+        s.t[i] = float(v[4 + i])
+    return s
+
+
+def _camera(cam):
+    c = capi.svoh_camera()
+    c.fx, c.fy, c.cx, c.cy = cam.fx, cam.fy, cam.cx, cam.cy
+    c.width, c.height = cam.width, cam.height
+    if cam.dist is None:
+        c.distortion = capi.SVOH_DISTORTION_NONE
+    else:
+        c.distortion = capi.SVOH_DISTORTION_RADTAN
+        for i in range(4):
+            c.d[i] = cam.dist[i]
+    return c
+
+
+def se3_to_numpy(s):
+    return np.array([s.q[0], s.q[1], s.q[2], s.q[3], s.t[0], s.t[1], s.t[2]])
+
+
+class Context(object):
+    """One svoh_ctx (one HIP stream).  Not thread-safe, like the ABI."""
+
+    def __init__(self, device=0):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        rc = self.lib.svoh_create(int(device), C.byref(h))
+        if rc != 0:
+            raise SvohError(rc, self.lib.svoh_last_error_string(None).decode())
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.lib.svoh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SvohError(rc, self.lib.svoh_last_error_string(self.h).decode())
+
+    def synchronize(self):
+        self._check(self.lib.svoh_synchronize(self.h))
+
+    def stream(self):
+        return self.lib.svoh_stream(self.h)
+
+    # ---- frames -----------------------------------------------------------
+    def upload_pyramid(self, levels):
+        n = len(levels)
+        levels = [np.ascontiguousarray(lv, dtype=np.uint8) for lv in levels]
+        ptrs = (C.c_void_p * n)(*[lv.ctypes.data for lv in levels])
+        w = (C.c_int * n)(*[lv.shape[1] for lv in levels])
+        h = (C.c_int * n)(*[lv.shape[0] for lv in levels])
+        p = (C.c_int * n)(*[lv.strides[0] for lv in levels])
+        out = capi.svoh_frame_t()
+        self._check(self.lib.svoh_upload_pyramid(self.h, n, ptrs, w, h, p, C.byref(out)))
+        return out.value
+
+    def build_pyramid(self, img, n_levels, rounding=capi.SVOH_HALFSAMPLE_REFERENCE, return_levels=False):
+        """img: HxW uint8 numpy array (host).  Returns handle [, list of level arrays]."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        out = capi.svoh_frame_t()
+        host = None
+        if return_levels:
+            lv = [np.zeros((h >> i, w >> i), dtype=np.uint8) for i in range(n_levels)]
+            host = (C.c_void_p * n_levels)(*[a.ctypes.data for a in lv])
+        self._check(self.lib.svoh_build_pyramid(self.h, img.ctypes.data, w, h, img.strides[0], capi.SVOH_MEM_HOST,
+                                                n_levels, rounding, host, C.byref(out)))
+        return (out.value, lv) if return_levels else out.value
+
+    def build_pyramid_batch_device(self, dev_ptr, image_stride, n_images, width, height, pitch, n_levels,
+                                   rounding=capi.SVOH_HALFSAMPLE_REFERENCE):
+        out = (capi.svoh_frame_t * n_images)()
+        self._check(self.lib.svoh_build_pyramid_batch(self.h, C.c_void_p(dev_ptr), image_stride, n_images, width,
+                                                      height, pitch, capi.SVOH_MEM_DEVICE, n_levels, rounding, out))
+        return [int(x) for x in out]
+
+    def build_pyramid_batch_host(self, imgs, n_levels, rounding=capi.SVOH_HALFSAMPLE_REFERENCE):
+        """imgs: NxHxW uint8"""
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        n, h, w = imgs.shape
+        out = (capi.svoh_frame_t * n)()
+        self._check(self.lib.svoh_build_pyramid_batch(self.h, imgs.ctypes.data, h * w, n, w, h, w,
+                                                      capi.SVOH_MEM_HOST, n_levels, rounding, out))
+        return [int(x) for x in out]
+
+    def download_level(self, frame, level):
+        w, h = C.c_int(), C.c_int()
+        self._check(self.lib.svoh_download_level(self.h, frame, level, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), dtype=np.uint8)
+        self._check(self.lib.svoh_download_level(self.h, frame, level, out.ctypes.data, C.byref(w), C.byref(h)))
+        return out
+
+    def release_frame(self, frame):
+        self._check(self.lib.svoh_release_frame(self.h, frame))
+
+    # ---- sparse image alignment --------------------------------------------
+    def sparse_align(self, opt, problems):
+        """problems: ctypes array of svoh_align_problem (see make_align_problems)."""
+        n = len(problems)
+        res = (capi.svoh_align_result * n)()
+        self._check(self.lib.svoh_sparse_align_batch(self.h, C.byref(opt), n, problems, res))
+        return res
+
+    def sparse_align_enqueue(self, opt, problems):
+        self._check(self.lib.svoh_sparse_align_enqueue(self.h, C.byref(opt), len(problems), problems))
+
+    def sparse_align_fetch(self, n):
+        res = (capi.svoh_align_result * n)()
+        self._check(self.lib.svoh_sparse_align_fetch(self.h, n, res))
+        return res
+
+    def sparse_align_evaluate(self, opt, problem, level):
+        H = np.zeros(64)
+        g = np.zeros(8)
+        chi2, nm, nsel = C.c_double(), C.c_int32(), C.c_int32()
+        ntot = sum(problem.cams[i].n_features for i in range(problem.n_cams))
+        vis = np.zeros(max(1, ntot), np.uint8)
+        self._check(self.lib.svoh_sparse_align_evaluate(self.h, C.byref(opt), C.byref(problem), level,
+                                                        H.ctypes.data, g.ctypes.data, C.byref(chi2), C.byref(nm),
+                                                        vis.ctypes.data, C.byref(nsel)))
+        return H.reshape(8, 8).T.copy(), g, chi2.value, nm.value, vis[:nsel.value].copy()
+
+
+def fill_align_camera(cam_struct, scene, ref_frame, cur_frame, keep, device_ptrs=None):
+    """Fill one svoh_align_camera from a synth.AlignScene.  device_ptrs: optional
+    dict(px=, f=, pos_world=, flags=) of device addresses (SVOH_MEM_DEVICE)."""
+    cam_struct.ref_frame = ref_frame
+    cam_struct.cur_frame = cur_frame
+    cam_struct.cam = _camera(scene.cam)
+    cam_struct.ref_T_imu_cam = _se3(scene.T_imu_cam)
+    cam_struct.ref_T_cam_imu = _se3(scene.T_cam_imu)
+    cam_struct.cur_T_cam_imu = _se3(scene.T_cam_imu)
+    for k in range(3):
+        cam_struct.ref_pos[k] = float(scene.ref_pos[k])
+    cam_struct.n_features = int(scene.n_features)
+    if device_ptrs is not None:
+        cam_struct.mem_space = capi.SVOH_MEM_DEVICE
+        cam_struct.px, cam_struct.f = device_ptrs["px"], device_ptrs["f"]
+        cam_struct.pos_world, cam_struct.flags = device_ptrs["pos_world"], device_ptrs["flags"]
+    else:
+        arrs = [np.ascontiguousarray(scene.px, dtype=np.float64), np.ascontiguousarray(scene.f, dtype=np.float64),
+                np.ascontiguousarray(scene.pos_world, dtype=np.float64),
+                np.ascontiguousarray(scene.flags, dtype=np.uint8)]
+        keep.extend(arrs)
+        cam_struct.mem_space = capi.SVOH_MEM_HOST
+        cam_struct.px, cam_struct.f, cam_struct.pos_world, cam_struct.flags = [a.ctypes.data for a in arrs]
+
+
+def make_align_problems(items, T_init=None, prior=None, alpha_init=0.0, beta_init=0.0):
+    """items: list of problems; each problem is a list (one per camera) of
+    (scene, ref_frame_handle, cur_frame_handle[, device_ptrs]).
+    Returns (ctypes array, keepalive list)."""
+    n = len(items)
+    arr = (capi.svoh_align_problem * n)()
+    keep = []
+    for i, cams in enumerate(items):
+        pb = arr[i]
+        pb.n_cams = len(cams)
+        for c, it in enumerate(cams):
+            sc, rf, cf = it[0], it[1], it[2]
+            dp = it[3] if len(it) > 3 else None
+            fill_align_camera(pb.cams[c], sc, rf, cf, keep, dp)
+        sc0 = cams[0][0]
+        Ti = T_init[i] if isinstance(T_init, (list, tuple)) else T_init
+        pb.T_icur_iref = _se3(Ti if Ti is not None else sc0.T_icur_iref_init)
+        pb.alpha_init, pb.beta_init = alpha_init, beta_init
+        if prior is not None:
+            pb.prior = prior[i] if isinstance(prior, (list, tuple)) else prior
+    return arr, keep
