@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned patches/s of the MI355X-native SVO sparse image alignment.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8(d) "C2"): SparseImgAlign only,
+synthetic 640x480 frames, 2000 patches x 4x4, 5 pyramid levels (4..0), SE3 6-DoF,
+<= 10 Gauss-Newton iterations per level, eps 5e-4.  One "step" = one call of
+svoh_sparse_align_batch() over B independent (reference, current) frame pairs
+whose pyramids and feature arrays are already resident in HBM (B defaults to
+1024: ~0.9 GB of pyramids, far beyond the 256 MiB Infinity Cache).
+
+Multi-GPU: the path shards by independent frame pairs; every rank aligns its own
+B pairs, no data-path collective; scaling is "weak".
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # first: libsvo_hip must share torch's HIP runtime (same SONAME)
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from svo_pro_universal_amd import _capi as capi  # noqa: E402
+from svo_pro_universal_amd import frontend as fe  # noqa: E402
+from svo_pro_universal_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(P, D, patch_iters, n_sel_levels):
+    """B_iter(P,D) per patch-iteration + per-level precompute per patch."""
+    b_iter = (P + 1) ** 2 + 12 + 4 * P * P + 4 * D * P * P
+    b_pre = ((P + 3) ** 2 + 8 + 48) + 4 * P * P * (1 + D)
+    return b_iter * patch_iters + b_pre * n_sel_levels
+
+
+def build_problems(ctx, dev, rank, B, N, P, max_level):
+    """B synthetic frame pairs rendered on the GPU; returns problems + keepalives."""
+    cam = synth.Camera.test_camera()
+    scenes = []
+    imgs = torch.empty((2 * B, cam.height, cam.width), dtype=torch.uint8, device=dev)
+    for i in range(B):
+        sc = synth.make_align_scene(1000003 * rank + i, n_features=N, patch_size=P, cam=cam,
+                                    max_level=max_level, render_images=False)
+        imgs[2 * i] = synth.render(cam, sc.T_w_ref, sc.plane, sc.tex, xp=torch, device=dev)
+        imgs[2 * i + 1] = synth.render(cam, sc.T_w_cur, sc.plane, sc.tex, xp=torch, device=dev)
+        scenes.append(sc)
+    torch.cuda.synchronize()
+    frames = ctx.build_pyramid_batch_device(imgs.data_ptr(), cam.width * cam.height, 2 * B, cam.width, cam.height,
+                                            cam.width, max_level + 1)
+    ctx.synchronize()
+    # feature arrays resident in HBM (one buffer per kind)
+    px = torch.from_numpy(np.concatenate([s.px for s in scenes])).to(dev)
+    f = torch.from_numpy(np.concatenate([s.f for s in scenes])).to(dev)
+    pw = torch.from_numpy(np.concatenate([s.pos_world for s in scenes])).to(dev)
+    fl = torch.from_numpy(np.concatenate([s.flags for s in scenes])).to(dev)
+    items = []
+    off = 0
+    for i, sc in enumerate(scenes):
+        n = sc.n_features
+        dp = dict(px=px.data_ptr() + 16 * off, f=f.data_ptr() + 24 * off, pos_world=pw.data_ptr() + 24 * off,
+                  flags=fl.data_ptr() + off)
+        items.append([(sc, frames[2 * i], frames[2 * i + 1], dp)])
+        off += n
+    problems, keep = fe.make_align_problems(items)
+    return problems, scenes, imgs, (px, f, pw, fl, keep, frames)
+
+
+def cpu_baseline(scenes, imgs, opt, max_level, budget_s=15.0):
+    """Time the CPU restatement (oracle, -O3 -march=native build, 1 thread) on a
+    bounded sample of the same problems: kind "port"."""
+    from oracle import oracle as orc  # test infrastructure: used only as the timed CPU baseline
+    orc.build(fast=True)
+    done_patches, n_done, t_total = 0, 0, 0.0
+    for i, sc in enumerate(scenes):
+        ref = orc.create_img_pyramid(imgs[2 * i].cpu().numpy(), max_level + 1, fast=True)
+        cur = orc.create_img_pyramid(imgs[2 * i + 1].cpu().numpy(), max_level + 1, fast=True)
+        pb = orc.problem_from_scenes([(sc, ref, cur)])
+        t0 = time.perf_counter()
+        n, res, _ = orc.sparse_align_run(opt, pb, fast=True)
+        t_total += time.perf_counter() - t0
+        done_patches += n
+        n_done += 1
+        if t_total > budget_s:
+            break
+    return {"value": done_patches / t_total, "unit": "aligned patches/s", "cores": 1, "kind": "port",
+            "sample": "%d of the benchmark's frame pairs (%d patches), SparseImgAlign::run restatement "
+                      "(oracle/svo_oracle.c, gcc -O3 -march=native, fp64, single thread), %.1f s of CPU time"
+                      % (n_done, done_patches, t_total),
+            "ms_per_frame": 1e3 * t_total / n_done}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--problems", type=int, default=1024, help="frame pairs per GPU per step")
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--patch", type=int, default=4)
+    ap.add_argument("--min-level", type=int, default=0)
+    ap.add_argument("--max-level", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ctx = fe.Context(local_rank)
+    P, N, B = args.patch, args.features, args.problems
+    opt = capi.default_align_options(max_level=args.max_level, min_level=args.min_level, patch_size=P)
+    problems, scenes, imgs, keep = build_problems(ctx, dev, rank, B, N, P, args.max_level)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    kern_ms = ctypes.c_float()
+    for _ in range(args.warmup):
+        res = ctx.sparse_align(opt, problems)
+    barrier()
+    kernel_ms_sum = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = ctx.sparse_align(opt, problems)
+        ctx.lib.svoh_sparse_align_last_kernel_ms(ctx.h, ctypes.byref(kern_ms))
+        kernel_ms_sum += kern_ms.value
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_sel = sum(r.n_fts_to_track for r in res)
+    patch_iters = sum(r.n_patch_iters for r in res)
+    n_levels = args.max_level - args.min_level + 1
+    n_bad = sum(1 for r in res if r.status != 0)
+    # accuracy against the synthetic ground truth (informational)
+    errs = [synth.se3_error(synth.SE3.from7(fe.se3_to_numpy(r.T_icur_iref)), sc.T_icur_iref_gt)
+            for r, sc in zip(res, scenes)]
+    patches_total = n_sel * world  # every rank runs the same-sized job (weak scaling)
+    value = patches_total * args.steps / elapsed
+
+    if rank == 0:
+        kernel_ms = kernel_ms_sum / args.steps
+        D = 6
+        alg = algorithmic_bytes(P, D, patch_iters, n_sel * n_levels)
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "aligned patches/sec + ms/frame, EuRoC 640x480 mono, 1/2/4/8 MI355X",
+            "value": value,
+            "unit": "aligned patches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_frame": 1e3 * elapsed / args.steps / B,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "SparseImgAlign only: synthetic 640x480, %d patches x %dx%d, levels %d..%d, SE3 6-DoF, "
+                            "GN <=10 it/level, eps 5e-4; %d independent frame pairs per GPU per step, inputs "
+                            "resident in HBM" % (N, P, P, args.max_level, args.min_level, B),
+                "frame_pairs_per_gpu": B, "patches_per_frame": N, "patch_size": P,
+                "levels": [args.max_level, args.min_level], "parallelism": "frame-pairs sharded x%d, no collective" % world,
+            },
+            "patch_iterations_per_step": patch_iters,
+            "patch_iterations_per_s": patch_iters * world * args.steps / elapsed,
+            "kernel_ms": kernel_ms,
+            "pose_err_vs_gt": {"rot_rad_median": float(np.median([e[0] for e in errs])),
+                               "trans_m_median": float(np.median([e[1] for e in errs])),
+                               "rot_rad_max": float(np.max([e[0] for e in errs])),
+                               "trans_m_max": float(np.max([e[1] for e in errs]))},
+            "solver_failures": n_bad,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sparse_align_kernel<%d,*,false>" % P,
+                         "algorithmic_bytes_per_launch": alg},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scenes, imgs, opt, args.max_level)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

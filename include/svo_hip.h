@@ -203,6 +203,9 @@ typedef struct svoh_align_result {
   int32_t iters[SVOH_MAX_LEVELS];     /* evaluateError calls per level */
   int32_t n_meas[SVOH_MAX_LEVELS];    /* residuals in the last evaluation  */
   double chi2[SVOH_MAX_LEVELS];       /* chi2/n_meas of the last evaluation */
+  /* sum over every evaluateError call of the number of visible patches: the
+   * "patch-iterations" the run executed (the unit of SURVEY.md 8(d)) */
+  int64_t n_patch_iters;
 } svoh_align_result;
 
 /* Replaces SparseImgAlign::run (src/svo_img_align/src/sparse_img_align.cpp:34-113)
@@ -221,6 +224,10 @@ int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options,
 int svoh_sparse_align_enqueue(svoh_ctx* ctx, const svoh_align_options* options,
                               int n_problems, const svoh_align_problem* problems);
 int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* results);
+
+/* Device time (ms, HIP events on the context stream) of the alignment kernel
+ * of the last enqueue/batch call; valid after fetch/batch returned. */
+int svoh_sparse_align_last_kernel_ms(svoh_ctx* ctx, float* ms);
 
 /* Diagnostic/parity entry: evaluate H (8x8 col-major), g (8), chi2, n_meas for
  * ONE problem at a given level and state, i.e. SparseImgAlign::evaluateError

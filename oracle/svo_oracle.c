@@ -856,6 +856,7 @@ int orc_sparse_align_run(const svoh_align_options* opt, const orc_align_problem*
       int n_meas = 0;
       const double new_chi2 = evaluate_error(&a, &state, H, g, &n_meas);
       ++n_eval;
+      res->n_patch_iters += n_meas / (opt->patch_size * opt->patch_size);
       if (a.level < SVOH_MAX_LEVELS) {
         res->iters[a.level] = n_eval;
         res->n_meas[a.level] = n_meas;

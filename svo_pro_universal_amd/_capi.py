@@ -66,7 +66,7 @@ class svoh_align_result(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_fts_to_track", C.c_int32), ("T_icur_iref", svoh_se3),
                 ("alpha", C.c_double), ("beta", C.c_double),
                 ("iters", C.c_int32 * SVOH_MAX_LEVELS), ("n_meas", C.c_int32 * SVOH_MAX_LEVELS),
-                ("chi2", C.c_double * SVOH_MAX_LEVELS)]
+                ("chi2", C.c_double * SVOH_MAX_LEVELS), ("n_patch_iters", C.c_int64)]
 
 
 def default_align_options(**kw):
@@ -92,7 +92,7 @@ EXPORTS = [
     "svoh_upload_pyramid", "svoh_build_pyramid", "svoh_build_pyramid_batch",
     "svoh_download_level", "svoh_frame_info", "svoh_release_frame",
     "svoh_sparse_align_batch", "svoh_sparse_align_enqueue", "svoh_sparse_align_fetch",
-    "svoh_sparse_align_evaluate",
+    "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms",
 ]
 
 
@@ -134,9 +134,6 @@ def load():
     lib.svoh_sparse_align_evaluate.argtypes = [C.c_void_p, P(svoh_align_options), P(svoh_align_problem),
                                                C.c_int, C.c_void_p, C.c_void_p, P(C.c_double),
                                                P(C.c_int32), C.c_void_p, P(C.c_int32)]
-    for name in EXPORTS:
-        fn = getattr(lib, name)
-        if fn.restype is C.c_int and name != "svoh_abi_version":
-            pass
+    lib.svoh_sparse_align_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float)]
     _LIB = lib
     return lib

@@ -167,6 +167,8 @@ int svoh_create(int device, svoh_ctx** out_ctx)
   ctx->err = "no error";
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev_align_start);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev_align_stop);
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
   if (e != hipSuccess) {
@@ -186,6 +188,8 @@ int svoh_destroy(svoh_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
   ctx->frames.clear();
+  if (ctx->ev_align_start) (void)hipEventDestroy(ctx->ev_align_start);
+  if (ctx->ev_align_stop) (void)hipEventDestroy(ctx->ev_align_stop);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SVOH_OK;

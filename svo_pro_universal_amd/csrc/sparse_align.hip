@@ -77,6 +77,7 @@ struct ShState {
   double I_prior[8];
   float alpha_f, beta_f;
   int stop, level_done, nsel, status;
+  long long patch_iters;
 };
 
 // ---- image accessors --------------------------------------------------------
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
     s.Told = s.T;
     s.alpha = pb.alpha_init; s.beta = pb.beta_init;
     s.alpha_old = s.alpha; s.beta_old = s.beta;
-    s.stop = 0; s.level_done = 0; s.nsel = 0; s.status = 0;
+    s.stop = 0; s.level_done = 0; s.nsel = 0; s.status = 0; s.patch_iters = 0;
     for (int k = 0; k < 8; ++k) s.I_prior[k] = 0.0;
     s_nvis = 0;
   }
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
       r.status = 1; r.n_fts_to_track = 0;
       store_rigid(s.T, r.T_icur_iref);
       r.alpha = s.alpha; r.beta = s.beta;
+      r.n_patch_iters = 0;
       for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = 0; r.n_meas[l] = 0; r.chi2[l] = 0.0; }
       if (eval_mode) for (int k = 0; k < 74; ++k) a.eval_out[k] = 0.0;
     }
@@ -466,6 +468,7 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
       // ---- serial part: prior, 8x8 LDL^T, SE3 update, convergence ----
       if (tid == 0) {
         const int n_meas = s_nvis * P * P;
+        s.patch_iters += s_nvis;
         s_nvis = 0;
         const double chi2 = s_sum[NH + D] / (double)n_meas;
         for (int k = 0; k < 64; ++k) s_H[k] = 0.0;
@@ -545,6 +548,7 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
     r.n_fts_to_track = n_sel;
     store_rigid(s.T, r.T_icur_iref);
     r.alpha = s.alpha; r.beta = s.beta;
+    r.n_patch_iters = s.patch_iters;
   }
 }
 
@@ -724,6 +728,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
 
   const bool illum = opt->estimate_illumination_gain || opt->estimate_illumination_offset;
   hipError_t e;
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_start, ctx->stream));
   if (opt->patch_size == 4)
     e = illum ? launch_nt<4, true>(ctx->stream, nt, n_problems, lds, args)
               : launch_nt<4, false>(ctx->stream, nt, n_problems, lds, args);
@@ -732,6 +737,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
               : launch_nt<8, false>(ctx->stream, nt, n_problems, lds, args);
   if (e != hipSuccess)
     return set_error(ctx, SVOH_ERR_HIP, "sparse_align launch failed: %s", hipGetErrorString(e));
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_stop, ctx->stream));
   ctx->last_align_n = n_problems;
   return SVOH_OK;
 }
@@ -766,6 +772,15 @@ int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options, in
   int rc = enqueue_align(ctx, options, n_problems, problems, -1);
   if (rc != SVOH_OK) return rc;
   return svoh_sparse_align_fetch(ctx, n_problems, results);
+}
+
+int svoh_sparse_align_last_kernel_ms(svoh_ctx* ctx, float* ms)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, ms != nullptr && ctx->last_align_n > 0, "no alignment launch to time");
+  SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_stop));
+  SVOH_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_align_start, ctx->ev_align_stop));
+  return SVOH_OK;
 }
 
 int svoh_sparse_align_evaluate(svoh_ctx* ctx, const svoh_align_options* options, const svoh_align_problem* problem,

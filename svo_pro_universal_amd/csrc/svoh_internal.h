@@ -86,6 +86,7 @@ struct svoh_ctx {
   svoh::PinnedBuffer h_upload;
   svoh::PinnedBuffer h_results;
   int last_align_n = 0;
+  hipEvent_t ev_align_start = nullptr, ev_align_stop = nullptr;
 
   // generic scratch for the other paths
   svoh::DevBuffer d_scratch0, d_scratch1, d_scratch2;
