@@ -96,6 +96,30 @@ EXPORTS = [
 ]
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).
+    Two HIP runtimes in one process cannot both own the GPU, so if torch is
+    installed (it is only plumbing here: device buffers and torch.distributed in
+    bench.py/tests) make libsvo_hip bind to torch's copy, whichever is imported
+    first.  Set SVOH_SYSTEM_HIP=1 to bind to /opt/rocm's runtime instead."""
+    import importlib.util
+    import sys
+    if os.environ.get("SVOH_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen libsvo_hip.so (in-tree).  Raises RuntimeError if it is missing:
     the product has no CPU path."""
@@ -106,6 +130,7 @@ def load():
         raise RuntimeError(
             "libsvo_hip.so not built (%s). Build it with __graft_entry__.build(); "
             "there is no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     P = C.POINTER
     lib.svoh_abi_version.restype = C.c_int

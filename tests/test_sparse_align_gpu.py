@@ -1,0 +1,263 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs, against the committed golden fixtures, and --
+at BASELINE's full size -- through size-independent properties.
+
+Tolerances (fp64 on both sides; only the summation order of the normal
+equations and FMA contraction differ):
+  H, g            relative 1e-10 of the largest entry
+  visibility, n_meas, iteration counts, selection   exact
+  final pose / alpha / beta    1e-8 absolute (observed ~1e-15)
+  chi2            relative 1e-4 (the reference accumulates it in float; we use fp64)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from svo_pro_universal_amd import _capi as capi, frontend as fe, synth
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+TOL_HG = 1e-10
+TOL_POSE = 1e-8
+
+
+def both(gpu_ctx, orc, scenes, n_levels=5, **mk):
+    """Build the oracle problem and the device problem for a list of cameras."""
+    cams_o, cams_g = [], []
+    for sc in scenes:
+        ref, cur = helpers.scene_pyramids(orc, sc, n_levels)
+        fr, lv = gpu_ctx.build_pyramid(sc.img_ref, n_levels, return_levels=True)
+        fc = gpu_ctx.build_pyramid(sc.img_cur, n_levels)
+        for a, b in zip(lv, ref):
+            assert np.array_equal(a, b)
+        cams_o.append((sc, ref, cur))
+        cams_g.append((sc, fr, fc))
+    opb = orc.problem_from_scenes(cams_o, **mk)
+    gpb, keep = fe.make_align_problems([cams_g], **mk)
+    return opb, gpb, keep
+
+
+def check_evaluate(gpu_ctx, orc, opt, opb, gpb, levels):
+    for level in levels:
+        Ho, go, c2o, nmo, viso = orc.sparse_align_evaluate(opt, opb, level)
+        Hg, gg, c2g, nmg, visg = gpu_ctx.sparse_align_evaluate(opt, gpb[0], level)
+        assert nmo == nmg and np.array_equal(viso, visg)
+        assert np.abs(Hg - Ho).max() <= TOL_HG * np.abs(Ho).max()
+        assert np.abs(gg - go).max() <= TOL_HG * np.abs(go).max()
+        assert np.array_equal(Hg, Hg.T)
+        if nmo:
+            assert abs(c2g - c2o) <= 1e-4 * abs(c2o)
+
+
+def check_run(gpu_ctx, orc, opt, opb, gpb):
+    n, ro, _ = orc.sparse_align_run(opt, opb)
+    rg = gpu_ctx.sparse_align(opt, gpb)[0]
+    assert rg.n_fts_to_track == n and rg.status == ro.status
+    assert list(rg.iters) == list(ro.iters) and list(rg.n_meas) == list(ro.n_meas)
+    assert rg.n_patch_iters == ro.n_patch_iters
+    assert helpers.se3_max_abs_diff(rg.T_icur_iref, ro.T_icur_iref) < TOL_POSE
+    assert abs(rg.alpha - ro.alpha) < TOL_POSE and abs(rg.beta - ro.beta) < 1e-6
+    return rg, ro
+
+
+@pytest.mark.parametrize("P", [4, 8])
+@pytest.mark.parametrize("cam_kind", ["pinhole", "radtan"])
+def test_evaluate_and_run_option_matrix(gpu_ctx, oracle_lib, P, cam_kind):
+    orc = oracle_lib
+    cam = synth.Camera.test_camera() if cam_kind == "pinhole" else synth.Camera.euroc_like()
+    sc = helpers.small_scene(31, n=400, P=P, cam=cam, border_features=60, invalid_fraction=0.1)
+    opb, gpb, keep = both(gpu_ctx, orc, [sc])
+    for illum in (0, 1):
+        for robust in (0, 1):
+            for dj in (0, 1):
+                opt = capi.default_align_options(patch_size=P, min_level=0, estimate_illumination_gain=illum,
+                                                 estimate_illumination_offset=illum, robustification=robust,
+                                                 use_distortion_jacobian=dj)
+                check_evaluate(gpu_ctx, orc, opt, opb, gpb, (4, 1, 0))
+                check_run(gpu_ctx, orc, opt, opb, gpb)
+
+
+def test_only_gain_or_only_offset(gpu_ctx, oracle_lib):
+    orc = oracle_lib
+    sc = helpers.small_scene(32, n=300, gain=1.05, offset=3.0)
+    opb, gpb, keep = both(gpu_ctx, orc, [sc])
+    for ga, of in ((1, 0), (0, 1)):
+        opt = capi.default_align_options(min_level=1, estimate_illumination_gain=ga, estimate_illumination_offset=of)
+        check_evaluate(gpu_ctx, orc, opt, opb, gpb, (3,))
+        check_run(gpu_ctx, orc, opt, opb, gpb)
+
+
+def test_handler_levels_and_iteration_caps(gpu_ctx, oracle_lib):
+    """FrameHandlerBase uses levels 4..2 (svo_factory.cpp:137-138); also max_iter 1 and a huge eps."""
+    orc = oracle_lib
+    sc = helpers.small_scene(33, n=180)
+    opb, gpb, keep = both(gpu_ctx, orc, [sc])
+    for kw in (dict(min_level=2), dict(min_level=0, max_iter=1), dict(min_level=3, eps=10.0),
+               dict(max_level=2, min_level=2, max_iter=30, eps=1e-9)):
+        opt = capi.default_align_options(**kw)
+        rg, ro = check_run(gpu_ctx, orc, opt, opb, gpb)
+        assert max(rg.iters) <= opt.max_iter
+
+
+def test_stereo_bundle(gpu_ctx, oracle_lib):
+    """Two cameras with different extrinsics and features: one H/g summed over cameras
+    (sparse_img_align.cpp:138-154)."""
+    orc = oracle_lib
+    a = helpers.small_scene(34, n=250, border_features=30)
+    b = synth.make_align_scene(34, n_features=220, cam=synth.Camera.euroc_like(), border_features=10)
+    # second camera: same motion of the rig, different camera-imu extrinsics
+    opb, gpb, keep = both(gpu_ctx, orc, [a, b])
+    opt = capi.default_align_options(min_level=1)
+    check_evaluate(gpu_ctx, orc, opt, opb, gpb, (4, 2))
+    check_run(gpu_ctx, orc, opt, opb, gpb)
+
+
+def test_prior(gpu_ctx, oracle_lib):
+    orc = oracle_lib
+    sc = helpers.small_scene(35, n=300, gain=1.02, offset=1.0)
+    Tp = synth.SE3(synth.quat_from_axis_angle([0.3, -1, 0.2], 0.004), [0.003, -0.002, 0.001])
+    for lam_r, lam_t, la, lb in ((0.5, 0.0, 0.0, 0.0), (2.0, 3.0, 0.0, 0.0), (0.1, 0.1, 0.5, 0.5)):
+        prior = helpers.make_prior(Tp, lam_r, lam_t, alpha=0.01, beta=-0.5, lambda_alpha=la, lambda_beta=lb)
+        opb, gpb, keep = both(gpu_ctx, orc, [sc], prior=prior)
+        opt = capi.default_align_options(min_level=1, estimate_illumination_gain=int(la > 0),
+                                         estimate_illumination_offset=int(la > 0))
+        check_run(gpu_ctx, orc, opt, opb, gpb)
+
+
+def test_no_features_and_all_invisible(gpu_ctx, oracle_lib):
+    orc = oracle_lib
+    sc = helpers.small_scene(36, n=120)
+    sc.flags[:] = 0
+    opb, gpb, keep = both(gpu_ctx, orc, [sc])
+    opt = capi.default_align_options()
+    rg, ro = check_run(gpu_ctx, orc, opt, opb, gpb)
+    assert rg.status == 1 and rg.n_fts_to_track == 0
+    assert helpers.se3_max_abs_diff(rg.T_icur_iref, gpb[0].T_icur_iref) == 0.0
+    # selected but invisible: start from a pose that looks away -> H = 0, zero step, converged
+    sc = helpers.small_scene(36, n=120)
+    away = synth.SE3(synth.quat_from_axis_angle([0, 1, 0], 2.5), [0, 0, 0])
+    opb, gpb, keep = both(gpu_ctx, orc, [sc], T_init=away)
+    check_evaluate(gpu_ctx, orc, opt, opb, gpb, (4,))
+    rg, ro = check_run(gpu_ctx, orc, opt, opb, gpb)
+    assert list(rg.n_meas)[:5] == [0, 0, 0, 0, 0]
+
+
+def test_ragged_batch_equals_singles(gpu_ctx, oracle_lib):
+    """A batch of problems of very different sizes (12 ... 2000 features, mixed cameras)
+    gives exactly the per-problem results."""
+    orc = oracle_lib
+    sizes = [12, 33, 64, 65, 300, 2000, 513]  # (a single patch gives a rank-2 H: ill-posed, no parity to check)
+    items, singles = [], []
+    opt = capi.default_align_options(min_level=1)
+    for k, n in enumerate(sizes):
+        cam = synth.Camera.euroc_like() if k % 2 else synth.Camera.test_camera()
+        sc = helpers.small_scene(40 + k, n=n, cam=cam)
+        opb, gpb, keep = both(gpu_ctx, orc, [sc])
+        items.append([(sc, gpb[0].cams[0].ref_frame, gpb[0].cams[0].cur_frame)])
+        singles.append(orc.sparse_align_run(opt, opb)[1])
+    pbs, keep = fe.make_align_problems(items)
+    res = gpu_ctx.sparse_align(opt, pbs)
+    for rg, ro in zip(res, singles):
+        assert rg.n_fts_to_track == ro.n_fts_to_track and list(rg.iters) == list(ro.iters)
+        assert helpers.se3_max_abs_diff(rg.T_icur_iref, ro.T_icur_iref) < TOL_POSE
+
+
+@pytest.mark.parametrize("nt", ["256", "512", "1024"])
+def test_all_workgroup_geometries(gpu_ctx, oracle_lib, nt, monkeypatch):
+    orc = oracle_lib
+    monkeypatch.setenv("SVOH_ALIGN_THREADS", nt)
+    sc = helpers.small_scene(37, n=700, border_features=50)
+    opb, gpb, keep = both(gpu_ctx, orc, [sc])
+    for lds in ("0", "38400", "153856"):  # global gathers only / levels>=2 in LDS / levels>=1 in LDS
+        monkeypatch.setenv("SVOH_ALIGN_LDS", lds)
+        opt = capi.default_align_options(min_level=0)
+        check_evaluate(gpu_ctx, orc, opt, opb, gpb, (4, 1, 0))
+        check_run(gpu_ctx, orc, opt, opb, gpb)
+
+
+def test_device_resident_inputs(gpu_ctx, oracle_lib):
+    import torch
+    orc = oracle_lib
+    sc = helpers.small_scene(38, n=256)
+    opb, gpb, keep = both(gpu_ctx, orc, [sc])
+    t = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (sc.px, sc.f, sc.pos_world, sc.flags)]
+    torch.cuda.synchronize()
+    dp = dict(px=t[0].data_ptr(), f=t[1].data_ptr(), pos_world=t[2].data_ptr(), flags=t[3].data_ptr())
+    pbs, keep2 = fe.make_align_problems([[(sc, gpb[0].cams[0].ref_frame, gpb[0].cams[0].cur_frame, dp)]])
+    opt = capi.default_align_options()
+    check_run(gpu_ctx, orc, opt, opb, pbs)
+
+
+@pytest.mark.parametrize("tag", ["pinhole", "radtan"])
+def test_golden_fixtures(gpu_ctx, tag):
+    """HIP path vs the committed fixtures (no oracle call)."""
+    z = np.load(helpers.GOLDEN)
+    sc = helpers.scene_from_golden(z, tag)
+    fr, lv = gpu_ctx.build_pyramid(sc.img_ref, 4, return_levels=True)
+    fc, lvc = gpu_ctx.build_pyramid(sc.img_cur, 4, return_levels=True)
+    assert np.array_equal(lv[3], z[tag + "/ref_level3"]) and np.array_equal(lvc[3], z[tag + "/cur_level3"])
+    gpb, keep = fe.make_align_problems([[(sc, fr, fc)]])
+    for name, kw in helpers.GOLDEN_OPTION_SETS.items():
+        opt = capi.default_align_options(**kw)
+        q = "%s/%s/" % (tag, name)
+        for level in range(opt.min_level, opt.max_level + 1):
+            H, g, chi2, nm, vis = gpu_ctx.sparse_align_evaluate(opt, gpb[0], level)
+            assert np.array_equal(vis, z[q + "vis%d" % level]) and nm == int(z[q + "chi2_nmeas%d" % level][1])
+            assert np.abs(H - z[q + "H%d" % level]).max() <= TOL_HG * np.abs(H).max()
+            assert np.abs(g - z[q + "g%d" % level]).max() <= TOL_HG * np.abs(g).max()
+        res = gpu_ctx.sparse_align(opt, gpb)[0]
+        assert [res.n_fts_to_track, res.status, res.n_patch_iters] == list(z[q + "run_misc"])
+        assert list(res.iters) == list(z[q + "run_iters"]) and list(res.n_meas) == list(z[q + "run_nmeas"])
+        assert helpers.se3_vec_diff(z[q + "run_T"], res.T_icur_iref) < TOL_POSE
+
+
+def test_full_size_properties(gpu_ctx):
+    """BASELINE configs[1] size (2000 patches, 640x480, levels 4..0), 8 frame pairs:
+    size-independent properties only -- ground-truth pose recovery, determinism,
+    invariance to a permutation of the features, batch == single."""
+    cam = synth.Camera.test_camera()
+    scenes = [synth.make_align_scene(100 + i, n_features=2000, cam=cam) for i in range(8)]
+    items = []
+    for sc in scenes:
+        items.append([(sc, gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5))])
+    opt = capi.default_align_options(min_level=0)
+    pbs, keep = fe.make_align_problems(items)
+    r1 = gpu_ctx.sparse_align(opt, pbs)
+    r2 = gpu_ctx.sparse_align(opt, pbs)
+    for a, b, sc in zip(r1, r2, scenes):
+        assert a.status == 0 and a.n_fts_to_track == 2000
+        assert helpers.se3_max_abs_diff(a.T_icur_iref, b.T_icur_iref) == 0.0  # bitwise repeatable
+        e0 = synth.se3_error(sc.T_icur_iref_init, sc.T_icur_iref_gt)
+        e1 = synth.se3_error(synth.SE3.from7(fe.se3_to_numpy(a.T_icur_iref)), sc.T_icur_iref_gt)
+        assert e1[0] < 0.05 * e0[0] + 1e-4 and e1[1] < 0.05 * e0[1] + 3e-4, (e0, e1)
+    # permuting the features changes only the summation order
+    sc = scenes[0]
+    perm = np.random.RandomState(0).permutation(sc.n_features)
+    sp = synth.make_align_scene(100, n_features=2000, cam=cam, render_images=False)
+    sp.px = sc.px.reshape(-1, 2)[perm].ravel(); sp.f = sc.f.reshape(-1, 3)[perm].ravel()
+    sp.pos_world = sc.pos_world.reshape(-1, 3)[perm].ravel(); sp.flags = sc.flags[perm]
+    pp, keep2 = fe.make_align_problems([[(sp, items[0][0][1], items[0][0][2])]])
+    rp = gpu_ctx.sparse_align(opt, pp)[0]
+    assert list(rp.iters) == list(r1[0].iters)
+    assert helpers.se3_max_abs_diff(rp.T_icur_iref, r1[0].T_icur_iref) < 1e-9
+
+
+def test_error_codes(gpu_ctx):
+    sc = helpers.small_scene(39, n=50)
+    fr = gpu_ctx.build_pyramid(sc.img_ref, 3)
+    gpb, keep = fe.make_align_problems([[(sc, fr, fr)]])
+    with pytest.raises(fe.SvohError) as e:  # pyramid too shallow for max_level 4
+        gpu_ctx.sparse_align(capi.default_align_options(), gpb)
+    assert e.value.code == -1 and "levels" in str(e.value)
+    with pytest.raises(fe.SvohError) as e:
+        gpu_ctx.sparse_align(capi.default_align_options(patch_size=5, max_level=2, min_level=1), gpb)
+    assert e.value.code == -5
+    gpb[0].cams[0].ref_frame = 987654321
+    with pytest.raises(fe.SvohError) as e:
+        gpu_ctx.sparse_align(capi.default_align_options(max_level=2, min_level=1), gpb)
+    assert e.value.code == -4
+    with pytest.raises(fe.SvohError):
+        gpu_ctx.release_frame(987654321)
