@@ -1,0 +1,13 @@
+import sys, os, ctypes
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from svo_pro_universal_amd import _capi as capi, frontend as fe
+import bench
+B = int(os.environ.get("B", "512")); P = int(os.environ.get("P", "4"))
+ctx = fe.Context(0)
+problems, scenes, imgs, keep = bench.build_problems(ctx, torch.device("cuda", 0), 0, B, 2000, P, 4)
+for kw in (dict(min_level=0), dict(min_level=2), dict(max_level=0, min_level=0)):
+    opt = capi.default_align_options(patch_size=P, **kw)
+    print(kw, flush=True)
+    for i in range(2):
+        ctx.sparse_align(opt, problems)

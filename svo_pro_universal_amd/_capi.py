@@ -83,7 +83,9 @@ def default_align_options(**kw):
 
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsvo_hip.so")
+# SVOH_LIB: diagnostic builds only (e.g. the phase-stamp build used while profiling)
+LIB_PATH = os.environ.get("SVOH_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                     "libsvo_hip.so")
 
 # every symbol include/svo_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [

@@ -62,13 +62,34 @@ struct AlignKernelArgs {
   // feature workspace (SoA over all features of all problems)
   double* wx; double* wy; double* wz;   // xyz_ref (a-4)
   double* wu; double* wv;               // uv in the reference image, level 0
+  double* wjp;                          // 12 x slots: projection Jacobian rows (jacobian_proj_cache_, a-4)
+  int64_t slots;                        // stride of the SoA arrays
   uint8_t* wsel;                        // selected by extractFeaturesSubset (a-3)
   uint8_t* wvis;                        // visibility of the last evaluation
   svoh_align_options opt;
   int32_t lds_img_bytes;                // dynamic LDS available for image staging
   int32_t eval_level;                   // <0: full run; >=0: evaluate once at that level
   double* eval_out;                     // [64 H][8 g][chi2][n_meas] for eval mode
+  long long* stamps;                    // diagnostic builds only (SVOH_PHASE_STAMPS): 8 per block
 };
+
+#ifndef SVOH_ROW_UNROLL
+#define SVOH_ROW_UNROLL 1
+#endif
+
+#ifdef SVOH_PHASE_STAMPS
+// Diagnostic build only: wave 0 / lane 0 accumulates shader-clock cycles per
+// phase.  Never enabled in the shipped library (rule: read shares, not length).
+#define SVOH_STAMP_DECL long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long st_begin = (long long)__builtin_amdgcn_s_memtime();
+#define SVOH_STAMP_START() do { st_t0 = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define SVOH_STAMP_ADD(k) do { long long st_n = (long long)__builtin_amdgcn_s_memtime(); st_acc[k] += st_n - st_t0; st_t0 = st_n; } while (0)
+#define SVOH_STAMP_FLUSH() do { if (threadIdx.x == 0) { st_acc[7] = (long long)__builtin_amdgcn_s_memtime() - st_begin; for (int k_ = 0; k_ < 8; ++k_) a.stamps[blockIdx.x * 8 + k_] = st_acc[k_]; } } while (0)
+#else
+#define SVOH_STAMP_DECL
+#define SVOH_STAMP_START() do {} while (0)
+#define SVOH_STAMP_ADD(k) do {} while (0)
+#define SVOH_STAMP_FLUSH() do {} while (0)
+#endif
 
 struct ShState {
   Rigid T, Told;
@@ -81,16 +102,29 @@ struct ShState {
 };
 
 // ---- image accessors --------------------------------------------------------
-struct ImgView {
+// LDS=true: the level lives in the workgroup's LDS (address space 3 -> ds_read);
+// LDS=false: gathers go to global memory (L1/L2).
+template <bool LDS>
+struct ImgView;
+template <>
+struct ImgView<false> {
   const uint8_t* p;
   int pitch;
-  __device__ __forceinline__ double at(int off) const { return (double)p[off]; }
+  __device__ __forceinline__ unsigned at(int off) const { return p[off]; }
+};
+template <>
+struct ImgView<true> {
+  const __attribute__((address_space(3))) uint8_t* p;
+  int pitch;
+  __device__ __forceinline__ unsigned at(int off) const { return p[off]; }
 };
 
 template <int D>
 struct AccLayout {
   static constexpr int NH = D * (D + 1) / 2;
   static constexpr int NACC = NH + D + 1;
+  // weighted per-patch moments: Sxx Sxy Syy Sxr Syr Srr [SxI SyI SII SI Sx Sy S1 SIr Sr]
+  static constexpr int NMOM = (D == 8) ? 15 : 6;
 };
 
 __device__ __forceinline__ float tukey_weight(float e)
@@ -142,16 +176,21 @@ __device__ __forceinline__ void projection_jacobian(const Vec3& xyz_ref, const R
   jp1[5] = (B[3] * (-p.y) + B[4] * p.x) * m;
 }
 
-// One patch: residuals (a-6), Jacobians / reference patch (a-5) and the normal
-// equation contribution (a-7), all in registers.
-template <int P, int D>
-__device__ __forceinline__ void patch_contribution(
-    const ImgView& ref, const ImgView& cur, int ru, int rv, double rsu, double rsv, int cu, int cv,
-    double csu, double csv, const double jp0[6], const double jp1[6], double scale, double one_plus_alpha,
-    double beta, bool est_alpha, bool est_beta, bool robust, float weight_scale,
-    double (&acc)[AccLayout<D>::NACC])
+// One patch, pixel part: interpolated reference patch with border and its
+// central differences (a-5), interpolated current patch and residual (a-6),
+// robust weight (a-7), reduced to the weighted moments of (dx, dy, I_ref, 1)
+// against themselves and against the residual.  Every pixel's Jacobian is
+//   J = [ (dx*jp0 + dy*jp1)*scale , -I_ref , -1 ]        (sparse_img_align.cpp:389-398)
+// i.e. a fixed linear map of (dx, dy, I_ref, 1), so the patch's contribution to
+// H = sum w J J^T and g = -sum w J r is that map applied to these moments.
+// This regroups the reference's per-pixel sum algebraically (same real-number
+// result; rounding differs at the 1e-16 level, like the reduction order does).
+template <int P, int D, bool RLDS, bool CLDS>
+__device__ __forceinline__ void patch_moments(
+    const ImgView<RLDS>& ref, const ImgView<CLDS>& cur, int ru, int rv, double rsu, double rsv, int cu, int cv,
+    double csu, double csv, double one_plus_alpha, double beta, bool robust, float weight_scale,
+    double (&mom)[AccLayout<D>::NMOM])
 {
-  constexpr int NH = AccLayout<D>::NH;
   constexpr int WB = P + 2;
   // bilinear weights (sparse_img_align.cpp:355-360 and :456-461)
   const double rwtl = (1.0 - rsu) * (1.0 - rsv), rwtr = rsu * (1.0 - rsv);
@@ -159,67 +198,131 @@ __device__ __forceinline__ void patch_contribution(
   const double cwtl = (1.0 - csu) * (1.0 - csv), cwtr = csu * (1.0 - csv);
   const double cwbl = (1.0 - csu) * csv, cwbr = csu * csv;
 
-  double rawA[WB + 1], rawB[WB + 1];
-  double it0[WB], it1[WB], it2[WB];
-  double curA[P + 1], curB[P + 1];
   const int roff = rv * ref.pitch + ru;
   const int coff = cv * cur.pitch + cu;
 #pragma unroll
-  for (int i = 0; i < WB + 1; ++i) rawA[i] = ref.at(roff + i);
-#pragma unroll
-  for (int i = 0; i < WB; ++i) { it0[i] = 0.0; it1[i] = 0.0; it2[i] = 0.0; }
-#pragma unroll
-  for (int i = 0; i < P + 1; ++i) { curA[i] = 0.0; curB[i] = 0.0; }
+  for (int k = 0; k < AccLayout<D>::NMOM; ++k) mom[k] = 0.0;
 
+  // rolling window: three interpolated reference rows (up / centre / down) and
+  // two raw current rows; one new row of each per output row
+  unsigned rawA[WB + 1], rawB[WB + 1];
+  double it0[WB], it1[WB], it2[WB];
+  unsigned curA[P + 1], curB[P + 1];
 #pragma unroll
-  for (int j = 0; j < WB; ++j) {
-    // interpolated reference row j of the (P+2)^2 patch-with-border
+  for (int i = 0; i < WB + 1; ++i) { rawA[i] = ref.at(roff + i); rawB[i] = ref.at(roff + ref.pitch + i); }
 #pragma unroll
-    for (int i = 0; i < WB + 1; ++i) rawB[i] = ref.at(roff + (j + 1) * ref.pitch + i);
+  for (int i = 0; i < WB; ++i)
+    it1[i] = rwtl * (double)rawA[i] + rwtr * (double)rawA[i + 1] + rwbl * (double)rawB[i] + rwbr * (double)rawB[i + 1];
+#pragma unroll
+  for (int i = 0; i < WB + 1; ++i) rawA[i] = ref.at(roff + 2 * ref.pitch + i);
+#pragma unroll
+  for (int i = 0; i < WB; ++i)
+    it2[i] = rwtl * (double)rawB[i] + rwtr * (double)rawB[i + 1] + rwbl * (double)rawA[i] + rwbr * (double)rawA[i + 1];
+#pragma unroll
+  for (int i = 0; i < P + 1; ++i) curB[i] = cur.at(coff + i);
+  // here: rawA = raw row 2, it1 = interp row 0, it2 = interp row 1, curB = cur row 0
+
+#pragma unroll SVOH_ROW_UNROLL
+  for (int y = 0; y < P; ++y) {
+    const int rrow = roff + (y + 3) * ref.pitch;
+    const int crow = coff + (y + 1) * cur.pitch;
+#pragma unroll
+    for (int i = 0; i < WB + 1; ++i) rawB[i] = ref.at(rrow + i);
 #pragma unroll
     for (int i = 0; i < WB; ++i) {
       it0[i] = it1[i];
       it1[i] = it2[i];
-      it2[i] = rwtl * rawA[i] + rwtr * rawA[i + 1] + rwbl * rawB[i] + rwbr * rawB[i + 1];
+      it2[i] = rwtl * (double)rawA[i] + rwtr * (double)rawA[i + 1] + rwbl * (double)rawB[i] +
+               rwbr * (double)rawB[i + 1];
     }
 #pragma unroll
     for (int i = 0; i < WB + 1; ++i) rawA[i] = rawB[i];
-    if (j == 1) {
 #pragma unroll
-      for (int i = 0; i < P + 1; ++i) curB[i] = cur.at(coff + i);
-    }
-    if (j >= 2) {
-      const int y = j - 2;  // output row: it0 = row y (up), it1 = y+1 (centre), it2 = y+2 (down)
+    for (int i = 0; i < P + 1; ++i) { curA[i] = curB[i]; curB[i] = cur.at(crow + i); }
+    // output row y: it0 = interp row y (up), it1 = y+1 (centre), it2 = y+2 (down)
 #pragma unroll
-      for (int i = 0; i < P + 1; ++i) { curA[i] = curB[i]; curB[i] = cur.at(coff + (y + 1) * cur.pitch + i); }
-#pragma unroll
-      for (int x = 0; x < P; ++x) {
-        const double ref_val = it1[x + 1];
-        const double dx = 0.5 * (it1[x + 2] - it1[x]);
-        const double dy = 0.5 * (it2[x + 1] - it0[x + 1]);
-        double J[D];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) J[k] = (dx * jp0[k] + dy * jp1[k]) * scale;
+    for (int x = 0; x < P; ++x) {
+      const double ref_val = it1[x + 1];
+      const double dx = 0.5 * (it1[x + 2] - it1[x]);
+      const double dy = 0.5 * (it2[x + 1] - it0[x + 1]);
+      const double intensity_cur = cwtl * (double)curA[x] + cwtr * (double)curA[x + 1] +
+                                   cwbl * (double)curB[x] + cwbr * (double)curB[x + 1];
+      const double res = (intensity_cur * one_plus_alpha + beta) - ref_val;
+      double wdx = dx, wdy = dy, wr = res;
+      if (robust) {
+        const double w = (double)tukey_weight((float)(res / (double)weight_scale));
+        wdx = dx * w; wdy = dy * w; wr = res * w;
         if constexpr (D == 8) {
-          J[6] = est_alpha ? -ref_val : 0.0;
-          J[7] = est_beta ? -1.0 : 0.0;
+          mom[8] += (ref_val * w) * ref_val;  // SII
+          mom[9] += ref_val * w;              // SI
+          mom[12] += w;                       // S1
         }
-        const double intensity_cur = cwtl * curA[x] + cwtr * curA[x + 1] + cwbl * curB[x] + cwbr * curB[x + 1];
-        const double res = (intensity_cur * one_plus_alpha + beta) - ref_val;
-        double w = 1.0;
-        if (robust) w = (double)tukey_weight((float)(res / (double)weight_scale));
-        acc[NH + D] += res * res * w;  // chi2 (fp64 here; the reference accumulates it in float)
-        int idx = 0;
-#pragma unroll
-        for (int a = 0; a < D; ++a) {
-          const double Jw = robust ? J[a] * w : J[a];
-#pragma unroll
-          for (int b = a; b < D; ++b) { acc[idx] += Jw * J[b]; ++idx; }
-          acc[NH + a] -= Jw * res;
-        }
+      } else if constexpr (D == 8) {
+        mom[8] += ref_val * ref_val;
+        mom[9] += ref_val;
+        mom[12] += 1.0;
+      }
+      mom[0] += wdx * dx;   // Sxx
+      mom[1] += wdx * dy;   // Sxy
+      mom[2] += wdy * dy;   // Syy
+      mom[3] += wdx * res;  // Sxr
+      mom[4] += wdy * res;  // Syr
+      mom[5] += wr * res;   // Srr (chi2)
+      if constexpr (D == 8) {
+        mom[6] += wdx * ref_val;   // SxI
+        mom[7] += wdy * ref_val;   // SyI
+        mom[10] += wdx;            // Sx
+        mom[11] += wdy;            // Sy
+        mom[13] += wr * ref_val;   // SIr
+        mom[14] += wr;             // Sr
       }
     }
   }
+}
+
+// Apply the patch's linear map to its moments: acc += (H upper triangle, g, chi2).
+template <int D>
+__device__ __forceinline__ void accumulate_patch(const double (&mom)[AccLayout<D>::NMOM], const double jp0[6],
+                                                 const double jp1[6], double scale, bool est_alpha, bool est_beta,
+                                                 double (&acc)[AccLayout<D>::NACC])
+{
+  constexpr int NH = AccLayout<D>::NH;
+  double a[6], b[6], u[6], v[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    a[k] = jp0[k] * scale;  // scale is a power of two: (dx*jp0+dy*jp1)*scale == dx*a+dy*b exactly
+    b[k] = jp1[k] * scale;
+    u[k] = mom[0] * a[k] + mom[1] * b[k];
+    v[k] = mom[1] * a[k] + mom[2] * b[k];
+  }
+  int idx = 0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      if (j < 6) {
+        acc[idx] += u[i] * a[j] + v[i] * b[j];
+      } else if constexpr (D == 8) {
+        if (i < 6) {
+          if (j == 6) { if (est_alpha) acc[idx] -= a[i] * mom[6] + b[i] * mom[7]; }
+          else { if (est_beta) acc[idx] -= a[i] * mom[10] + b[i] * mom[11]; }
+        } else if (i == 6) {
+          if (j == 6) { if (est_alpha) acc[idx] += mom[8]; }
+          else { if (est_alpha && est_beta) acc[idx] += mom[9]; }
+        } else {
+          if (est_beta) acc[idx] += mom[12];
+        }
+      }
+      ++idx;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[NH + i] -= a[i] * mom[3] + b[i] * mom[4];
+  if constexpr (D == 8) {
+    if (est_alpha) acc[NH + 6] += mom[13];  // g6 -= sum w (-I) r
+    if (est_beta) acc[NH + 7] += mom[14];   // g7 -= sum w (-1) r
+  }
+  acc[NH + D] += mom[5];
 }
 
 template <int NT>
@@ -240,8 +343,185 @@ __device__ __forceinline__ void stage_image(unsigned char* dst, const DevImage& 
   }
 }
 
+// Values read from LDS are wave-uniform here but the compiler cannot know it;
+// moving them to SGPRs frees a VGPR pair per double in the patch loop.
+__device__ __forceinline__ double uniform_f64(double v)
+{
+  const unsigned long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ Rigid uniform_rigid(const Rigid& T)
+{
+  Rigid r;
+  r.q.w = uniform_f64(T.q.w); r.q.x = uniform_f64(T.q.x); r.q.y = uniform_f64(T.q.y); r.q.z = uniform_f64(T.q.z);
+  r.t.x = uniform_f64(T.t.x); r.t.y = uniform_f64(T.t.y); r.t.z = uniform_f64(T.t.z);
+  return r;
+}
+
+// All patches of one camera at one Gauss-Newton iteration: one thread per patch.
+template <int P, int D, int NT, bool LDS>
+__device__ __forceinline__ void accumulate_camera(
+    const AlignKernelArgs& a, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
+    const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
+    bool robust, bool dist_jac, float weight_scale, bool write_vis, int tid,
+    double (&acc)[AccLayout<D>::NACC], int& nvis)
+{
+  const CamModel cm = load_camera(cd.cam);
+  const double patch_center = (P - 1) / 2.0f;
+  const double patch_center_wb = (P + 2 - 1) / 2.0f;
+
+  for (int i = tid; i < cd.n_features; i += NT) {
+    const int gi = cd.feat_off + i;
+    if (!a.wsel[gi]) continue;
+    const Vec3 X = { a.wx[gi], a.wy[gi], a.wz[gi] };
+    // ---- a-6 projection into the current level + visibility ----
+    const Vec3 Y = transform(Tcr, X);
+    bool vis = !(Y.z < 0.0);
+    int cu = 0, cv = 0;
+    double csu = 0.0, csv = 0.0;
+    if (vis) {
+      double u, v;
+      project3(cm, Y, u, v);
+      const double u_tl = u * scale - patch_center;
+      const double v_tl = v * scale - patch_center;
+      vis = !(u_tl < 0.0 || v_tl < 0.0 || u_tl + P + 2.0 >= cw || v_tl + P + 2.0 >= ch);
+      if (vis) {
+        const double fu = floor(u_tl), fv = floor(v_tl);
+        cu = (int)fu; cv = (int)fv;
+        csu = u_tl - cu; csv = v_tl - cv;
+      }
+    }
+    if (write_vis) a.wvis[gi] = vis ? 1 : 0;
+    if (!vis) continue;
+    ++nvis;
+    // ---- a-5 reference side (recomputed, never stored) ----
+    const double ru_tl = a.wu[gi] * scale - patch_center_wb;
+    const double rv_tl = a.wv[gi] * scale - patch_center_wb;
+    const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
+    const double rsu = ru_tl - ru, rsv = rv_tl - rv;
+    double mom[AccLayout<D>::NMOM];
+    patch_moments<P, D, LDS, LDS>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d, robust,
+                                  weight_scale, mom);
+    double jp0[6], jp1[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      jp0[k] = a.wjp[(int64_t)k * a.slots + gi];
+      jp1[k] = a.wjp[(int64_t)(6 + k) * a.slots + gi];
+    }
+    accumulate_patch<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
+  }
+}
+
+// 8x8 LDL^T with diagonal pivoting, Eigen-3.4 semantics (see svoh_math.h), with
+// the matrix held in registers: every index is a compile-time constant after
+// unrolling, the run-time pivot position only steers predicated swaps.  Used by
+// the one lane that runs the Gauss-Newton bookkeeping, where the LDS-resident
+// variant paid an LDS round trip per matrix access.
+__device__ __forceinline__ void swap_d(double& a, double& b) { const double t = a; a = b; b = t; }
+
+// packed lower triangle: element (r, c), r >= c, at r*(r+1)/2 + c
+#define SVOH_L(r, c) m[(r) * ((r) + 1) / 2 + (c)]
+template <int N>
+__device__ __forceinline__ bool ldlt_solve_regs(double (&m)[N * (N + 1) / 2], double (&x)[N])
+{
+  int tr[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    int big = k;
+    double bigv = fabs(SVOH_L(k, k));
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const double v = fabs(SVOH_L(i, i));
+      const bool gt = v > bigv;
+      bigv = gt ? v : bigv;
+      big = gt ? i : big;
+    }
+    tr[k] = big;
+#pragma unroll
+    for (int bb = k + 1; bb < N; ++bb) {
+      if (big == bb) {
+#pragma unroll
+        for (int c = 0; c < k; ++c) swap_d(SVOH_L(k, c), SVOH_L(bb, c));
+#pragma unroll
+        for (int r = bb + 1; r < N; ++r) swap_d(SVOH_L(r, k), SVOH_L(r, bb));
+        swap_d(SVOH_L(k, k), SVOH_L(bb, bb));
+#pragma unroll
+        for (int i = k + 1; i < bb; ++i) swap_d(SVOH_L(i, k), SVOH_L(bb, i));
+      }
+    }
+    if (k > 0) {
+      double tmp[N];
+#pragma unroll
+      for (int c = 0; c < k; ++c) tmp[c] = SVOH_L(c, c) * SVOH_L(k, c);
+      double accd = 0.0;
+#pragma unroll
+      for (int c = 0; c < k; ++c) accd += SVOH_L(k, c) * tmp[c];
+      SVOH_L(k, k) -= accd;
+#pragma unroll
+      for (int r = k + 1; r < N; ++r) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int c = 0; c < k; ++c) sacc += SVOH_L(r, c) * tmp[c];
+        SVOH_L(r, k) -= sacc;
+      }
+    }
+    const double akk = SVOH_L(k, k);
+    const bool pivot_ok = fabs(akk) > 0.0;
+    if (k == 0 && !pivot_ok) {
+      // the whole diagonal is zero: Eigen stops with identity transpositions and
+      // the D^-1 step zeroes every component of the solution
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] = 0.0;
+      return true;
+    }
+    if (pivot_ok) {
+#pragma unroll
+      for (int r = k + 1; r < N; ++r) SVOH_L(r, k) /= akk;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int bb = k + 1; bb < N; ++bb)
+      if (tr[k] == bb) swap_d(x[k], x[bb]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double sacc = x[i];
+#pragma unroll
+    for (int c = 0; c < i; ++c) sacc -= SVOH_L(i, c) * x[c];
+    x[i] = sacc;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double d = SVOH_L(i, i);
+    x[i] = (fabs(d) > DBL_MIN) ? x[i] / d : 0.0;
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double sacc = x[i];
+#pragma unroll
+    for (int c = i + 1; c < N; ++c) sacc -= SVOH_L(c, i) * x[c];
+    x[i] = sacc;
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+    for (int bb = k + 1; bb < N; ++bb)
+      if (tr[k] == bb) swap_d(x[k], x[bb]);
+  }
+  return !(x[0] != x[0]);
+}
+
+#ifndef SVOH_ALIGN_MIN_WAVES_256
+#define SVOH_ALIGN_MIN_WAVES_256 2
+#endif
+
 template <int P, int NT, bool ILLUM>
-__global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs a)
+__global__ __launch_bounds__(NT, (NT == 256 ? SVOH_ALIGN_MIN_WAVES_256 : (NT == 512 ? 2 : 4)))
+void sparse_align_kernel(const AlignKernelArgs a)
 {
   constexpr int D = ILLUM ? 8 : 6;
   constexpr int NH = AccLayout<D>::NH;
@@ -251,10 +531,6 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
   extern __shared__ __align__(16) unsigned char lds_img[];
   __shared__ double s_red[NW][NACC];
   __shared__ double s_sum[NACC];
-  __shared__ double s_H[64];
-  __shared__ double s_x[8];
-  __shared__ double s_tmp[8];
-  __shared__ int s_tr[8];
   __shared__ int s_nvis;
   __shared__ ShState s;
 
@@ -266,6 +542,8 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
   const svoh_align_options& opt = a.opt;
   const bool eval_mode = a.eval_level >= 0;
 
+  SVOH_STAMP_DECL
+  SVOH_STAMP_START();
   if (tid == 0) {
     s.T = load_rigid(pb.T_init);
     s.Told = s.T;
@@ -287,6 +565,12 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
       const DevCamDesc& cd = cams[c];
       const int rows_minus_two = cd.ref[opt.max_level].h - 2;
       const int cols_minus_two = cd.ref[opt.max_level].w - 2;
+      const CamModel cm0 = load_camera(cd.cam);
+      const Rigid T_imu_cam0 = load_rigid(cd.ref_T_imu_cam);
+      const Rigid T_cam_imu0 = load_rigid(cd.ref_T_cam_imu);
+      double R0[9];
+      to_matrix(T_cam_imu0.q, R0);
+      const bool dist_jac0 = opt.use_distortion_jacobian != 0;
       for (int i = tid; i < cd.n_features; i += NT) {
         const int gi = cd.feat_off + i;
         bool sel = cd.flags[i] != 0;
@@ -311,6 +595,14 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
           a.wz[gi] = cd.f[3 * i + 2] * depth;
           a.wu[gi] = pu;
           a.wv[gi] = pv;
+          const Vec3 X = { a.wx[gi], a.wy[gi], a.wz[gi] };
+          double jp0[6], jp1[6];
+          projection_jacobian(X, T_imu_cam0, T_cam_imu0, R0, cm0, dist_jac0, jp0, jp1);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            a.wjp[(int64_t)k * a.slots + gi] = jp0[k];
+            a.wjp[(int64_t)(6 + k) * a.slots + gi] = jp1[k];
+          }
           ++my_sel;
         }
       }
@@ -318,6 +610,7 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
     if (my_sel) atomicAdd(&s.nsel, my_sel);
   }
   __syncthreads();
+  SVOH_STAMP_ADD(0);
   const int n_sel = s.nsel;
   if (n_sel == 0) {
     if (tid == 0) {
@@ -329,6 +622,7 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
       for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = 0; r.n_meas[l] = 0; r.chi2[l] = 0.0; }
       if (eval_mode) for (int k = 0; k < 74; ++k) a.eval_out[k] = 0.0;
     }
+    SVOH_STAMP_FLUSH();
     return;
   }
   if (tid == 0) {
@@ -372,76 +666,42 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
       s.Told = s.T; s.alpha_old = s.alpha; s.beta_old = s.beta;  // old_state = state (hpp:45)
     }
     __syncthreads();
+    SVOH_STAMP_ADD(1);
 
     for (int iter = 0; iter < opt.max_iter; ++iter) {
       double acc[NACC];
 #pragma unroll
       for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
       int nvis = 0;
-      const double one_plus_alpha = 1.0 + (double)s.alpha_f;
-      const double beta_d = (double)s.beta_f;
+      const double one_plus_alpha = uniform_f64(1.0 + (double)s.alpha_f);
+      const double beta_d = uniform_f64((double)s.beta_f);
 
       int off = 0;
       for (int c = 0; c < n_cams; ++c) {
         const DevCamDesc& cd = cams[c];
         const DevImage& rim = cd.ref[level];
         const DevImage& cim = cd.cur[level];
-        ImgView ref, cur;
+        const Rigid Tcr = uniform_rigid(s.Tcr[c]);
         if (in_lds) {
-          ref.p = lds_img + off; ref.pitch = rim.w;
+          ImgView<true> ref, cur;
+          ref.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); ref.pitch = rim.w;
           off += ((rim.w * rim.h + 15) & ~15);
-          cur.p = lds_img + off; cur.pitch = cim.w;
+          cur.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); cur.pitch = cim.w;
           off += ((cim.w * cim.h + 15) & ~15);
+          accumulate_camera<P, D, NT, true>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                            est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
+                                            acc, nvis);
         } else {
+          ImgView<false> ref, cur;
           ref.p = rim.data; ref.pitch = rim.pitch;
           cur.p = cim.data; cur.pitch = cim.pitch;
-        }
-        const Rigid Tcr = s.Tcr[c];
-        const CamModel cm = load_camera(cd.cam);
-        const Rigid T_imu_cam = load_rigid(cd.ref_T_imu_cam);
-        const Rigid T_cam_imu = load_rigid(cd.ref_T_cam_imu);
-        double R[9];
-        to_matrix(T_cam_imu.q, R);
-        const double patch_center = (P - 1) / 2.0f;
-        const double patch_center_wb = (P + 2 - 1) / 2.0f;
-        const int cw = cim.w, ch = cim.h;
-
-        for (int i = tid; i < cd.n_features; i += NT) {
-          const int gi = cd.feat_off + i;
-          if (!a.wsel[gi]) continue;
-          const Vec3 X = { a.wx[gi], a.wy[gi], a.wz[gi] };
-          // ---- a-6 projection into the current level + visibility ----
-          const Vec3 Y = transform(Tcr, X);
-          bool vis = !(Y.z < 0.0);
-          int cu = 0, cv = 0;
-          double csu = 0.0, csv = 0.0;
-          if (vis) {
-            double u, v;
-            project3(cm, Y, u, v);
-            const double u_tl = u * scale - patch_center;
-            const double v_tl = v * scale - patch_center;
-            vis = !(u_tl < 0.0 || v_tl < 0.0 || u_tl + P + 2.0 >= cw || v_tl + P + 2.0 >= ch);
-            if (vis) {
-              const double fu = floor(u_tl), fv = floor(v_tl);
-              cu = (int)fu; cv = (int)fv;
-              csu = u_tl - cu; csv = v_tl - cv;
-            }
-          }
-          if (eval_mode) a.wvis[gi] = vis ? 1 : 0;
-          if (!vis) continue;
-          ++nvis;
-          // ---- a-5 reference side (recomputed, never stored) ----
-          const double ru_tl = a.wu[gi] * scale - patch_center_wb;
-          const double rv_tl = a.wv[gi] * scale - patch_center_wb;
-          const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
-          const double rsu = ru_tl - ru, rsv = rv_tl - rv;
-          double jp0[6], jp1[6];
-          projection_jacobian(X, T_imu_cam, T_cam_imu, R, cm, dist_jac, jp0, jp1);
-          patch_contribution<P, D>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, jp0, jp1, scale,
-                                   one_plus_alpha, beta_d, est_alpha, est_beta, robust, weight_scale, acc);
+          accumulate_camera<P, D, NT, false>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                             est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
+                                             acc, nvis);
         }
       }
 
+      SVOH_STAMP_ADD(2);
       // ---- reduce: wave shuffles, then across waves through LDS ----
 #pragma unroll
       for (int k = 0; k < NACC; ++k) {
@@ -465,22 +725,27 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
       }
       __syncthreads();
 
+      SVOH_STAMP_ADD(3);
       // ---- serial part: prior, 8x8 LDL^T, SE3 update, convergence ----
       if (tid == 0) {
         const int n_meas = s_nvis * P * P;
         s.patch_iters += s_nvis;
         s_nvis = 0;
         const double chi2 = s_sum[NH + D] / (double)n_meas;
-        for (int k = 0; k < 64; ++k) s_H[k] = 0.0;
-        for (int k = 0; k < 8; ++k) s_x[k] = 0.0;
-        int idx = 0;
-        for (int r = 0; r < D; ++r)
-          for (int c2 = r; c2 < D; ++c2) {
-            const double v = s_sum[idx++];
-            s_H[c2 * 8 + r] = v;
-            s_H[r * 8 + c2] = v;
-          }
-        for (int r = 0; r < D; ++r) s_x[r] = s_sum[NH + r];
+        double m[36], xg[8];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) m[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xg[k] = 0.0;
+        {
+          int idx = 0;
+#pragma unroll
+          for (int r = 0; r < D; ++r)
+#pragma unroll
+            for (int c2 = r; c2 < D; ++c2) SVOH_L(c2, r) = s_sum[idx++];  // H(r,c2) = H(c2,r)
+#pragma unroll
+          for (int r = 0; r < D; ++r) xg[r] = s_sum[NH + r];
+        }
         svoh_align_result& res = a.results[blockIdx.x];
         if (level < SVOH_MAX_LEVELS) {
           res.iters[level] = iter + 1;
@@ -488,8 +753,15 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
           res.chi2[level] = chi2;
         }
         if (eval_mode) {
-          for (int k = 0; k < 64; ++k) a.eval_out[k] = s_H[k];
-          for (int k = 0; k < 8; ++k) a.eval_out[64 + k] = s_x[k];
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c2 = 0; c2 <= r; ++c2) {
+              a.eval_out[c2 * 8 + r] = SVOH_L(r, c2);
+              a.eval_out[r * 8 + c2] = SVOH_L(r, c2);
+            }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a.eval_out[64 + k] = xg[k];
           a.eval_out[72] = chi2;
           a.eval_out[73] = (double)n_meas;
           s.level_done = 1;
@@ -498,21 +770,25 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
             // SparseImgAlignBase::applyPrior (sparse_img_align_base.cpp:77-107)
             if (iter == 0) {
               double mt = 0, mr = 0;
-              for (int j = 0; j < 3; ++j) mt = fmax(mt, fabs(s_H[j * 8 + j]));
-              for (int j = 3; j < 6; ++j) mr = fmax(mr, fabs(s_H[j * 8 + j]));
+#pragma unroll
+              for (int j = 0; j < 3; ++j) mt = fmax(mt, fabs(SVOH_L(j, j)));
+#pragma unroll
+              for (int j = 3; j < 6; ++j) mr = fmax(mr, fabs(SVOH_L(j, j)));
               for (int j = 0; j < 3; ++j) s.I_prior[j] = 1.0 * pb.prior.lambda_trans * mt;
               for (int j = 3; j < 6; ++j) s.I_prior[j] = 1.0 * pb.prior.lambda_rot * mr;
-              s.I_prior[6] = pb.prior.lambda_alpha * s_H[6 * 8 + 6];
-              s.I_prior[7] = pb.prior.lambda_beta * s_H[7 * 8 + 7];
+              s.I_prior[6] = pb.prior.lambda_alpha * SVOH_L(6, 6);
+              s.I_prior[7] = pb.prior.lambda_beta * SVOH_L(7, 7);
             }
-            for (int j = 0; j < 8; ++j) s_H[j * 8 + j] += s.I_prior[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) SVOH_L(j, j) += s.I_prior[j];
             double lg[6];
             rigid_log(mul(inverse(load_rigid(pb.prior.T_prior)), s.T), lg);
-            for (int j = 0; j < 6; ++j) s_x[j] += s.I_prior[j] * lg[j];
-            s_x[6] += s.I_prior[6] * (pb.prior.alpha_prior - s.alpha);
-            s_x[7] += s.I_prior[7] * (pb.prior.beta_prior - s.beta);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) xg[j] += s.I_prior[j] * lg[j];
+            xg[6] += s.I_prior[6] * (pb.prior.alpha_prior - s.alpha);
+            xg[7] += s.I_prior[7] * (pb.prior.beta_prior - s.beta);
           }
-          if (!ldlt_solve_inplace<8>(s_H, s_x, s_tr, s_tmp)) s.stop = 1;
+          if (!ldlt_solve_regs<8>(m, xg)) s.stop = 1;
           if (s.stop) {
             // rollback (mini_least_squares_solver.hpp:73-82); stop_ is only cleared by reset()
             s.T = s.Told; s.alpha = s.alpha_old; s.beta = s.beta_old;
@@ -521,15 +797,17 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
           } else {
             // SparseImgAlignBase::update (sparse_img_align_base.cpp:64-75)
             double mdx[6];
-            for (int j = 0; j < 6; ++j) mdx[j] = -s_x[j];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) mdx[j] = -xg[j];
             Rigid Tn = mul(s.T, rigid_exp(mdx));
-            const double an = (s.alpha - s_x[6]) / (1.0 + s_x[6]);
-            const double bn = (s.beta - s_x[7]) / (1.0 + s_x[6]);
+            const double an = (s.alpha - xg[6]) / (1.0 + xg[6]);
+            const double bn = (s.beta - xg[7]) / (1.0 + xg[6]);
             Tn.q = normalized(Tn.q);
             s.Told = s.T; s.alpha_old = s.alpha; s.beta_old = s.beta;
             s.T = Tn; s.alpha = an; s.beta = bn;
             double x_norm = -1.0;
-            for (int j = 0; j < 8; ++j) { const double v = fabs(s_x[j]); if (v > x_norm) x_norm = v; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const double v = fabs(xg[j]); if (v > x_norm) x_norm = v; }
             if (x_norm < opt.eps) s.level_done = 1;
           }
           for (int c = 0; c < n_cams; ++c)
@@ -538,6 +816,7 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
         }
       }
       __syncthreads();
+      SVOH_STAMP_ADD(4);
       if (s.level_done) break;
     }
   }
@@ -550,6 +829,7 @@ __global__ __launch_bounds__(NT) void sparse_align_kernel(const AlignKernelArgs 
     r.alpha = s.alpha; r.beta = s.beta;
     r.n_patch_iters = s.patch_iters;
   }
+  SVOH_STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------
@@ -634,7 +914,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
   SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * n_problems));
   SVOH_HIP_TRY(ctx, ctx->h_results.reserve(sizeof(svoh_align_result) * n_problems));
-  SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (5 * 8 + 2) + 256));
+  SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (17 * 8 + 2) + 256));
   if (host_bytes) {
     SVOH_HIP_TRY(ctx, ctx->h_upload.reserve(host_bytes));
     SVOH_HIP_TRY(ctx, ctx->d_upload.reserve(host_bytes));
@@ -706,11 +986,18 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   double* w = static_cast<double*>(ctx->d_feat.ptr);
   args.wx = w; args.wy = w + feat_slots; args.wz = w + 2 * feat_slots;
   args.wu = w + 3 * feat_slots; args.wv = w + 4 * feat_slots;
-  args.wsel = reinterpret_cast<uint8_t*>(w + 5 * feat_slots);
+  args.wjp = w + 5 * feat_slots;
+  args.slots = (int64_t)feat_slots;
+  args.wsel = reinterpret_cast<uint8_t*>(w + 17 * feat_slots);
   args.wvis = args.wsel + feat_slots;
   args.opt = *opt;
   args.eval_level = eval_level;
   args.eval_out = static_cast<double*>(ctx->d_eval.ptr);
+  args.stamps = nullptr;
+#ifdef SVOH_PHASE_STAMPS
+  SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(sizeof(long long) * 8 * (size_t)n_problems));
+  args.stamps = static_cast<long long*>(ctx->d_scratch0.ptr);
+#endif
 
   // Geometry.  Many problems: 256-thread workgroups, several per CU, so that one
   // problem's serial solve overlaps the others' patch work; LDS holds levels >= 2
@@ -738,6 +1025,18 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   if (e != hipSuccess)
     return set_error(ctx, SVOH_ERR_HIP, "sparse_align launch failed: %s", hipGetErrorString(e));
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_stop, ctx->stream));
+#ifdef SVOH_PHASE_STAMPS
+  {
+    std::vector<long long> h((size_t)n_problems * 8);
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(h.data(), args.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double sum[8] = {0};
+    for (int p = 0; p < n_problems; ++p) for (int k = 0; k < 8; ++k) sum[k] += (double)h[(size_t)p * 8 + k];
+    fprintf(stderr, "[stamps] n=%d nt=%d avg cycles/block: base %.0f stage %.0f patch %.0f reduce %.0f serial %.0f total %.0f\n",
+            n_problems, nt, sum[0] / n_problems, sum[1] / n_problems, sum[2] / n_problems, sum[3] / n_problems,
+            sum[4] / n_problems, sum[7] / n_problems);
+  }
+#endif
   ctx->last_align_n = n_problems;
   return SVOH_OK;
 }
@@ -799,7 +1098,7 @@ int svoh_sparse_align_evaluate(svoh_ctx* ctx, const svoh_align_options* options,
   std::vector<uint8_t> sel((size_t)nf + 1), vis((size_t)nf + 1);
   // workspace layout: see enqueue_align
   const size_t slots = nf ? (size_t)nf : 1;
-  const uint8_t* dsel = reinterpret_cast<const uint8_t*>(static_cast<double*>(ctx->d_feat.ptr) + 5 * slots);
+  const uint8_t* dsel = reinterpret_cast<const uint8_t*>(static_cast<double*>(ctx->d_feat.ptr) + 17 * slots);
   if (nf) {
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(sel.data(), dsel, (size_t)nf, hipMemcpyDeviceToHost, ctx->stream));
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(vis.data(), dsel + slots, (size_t)nf, hipMemcpyDeviceToHost, ctx->stream));
