@@ -43,14 +43,14 @@ def algorithmic_bytes(P, D, patch_iters, n_sel_levels):
 def build_problems(ctx, dev, rank, B, N, P, max_level):
     """B synthetic frame pairs rendered on the GPU; returns problems + keepalives."""
     cam = synth.Camera.test_camera()
-    scenes = []
-    imgs = torch.empty((2 * B, cam.height, cam.width), dtype=torch.uint8, device=dev)
-    for i in range(B):
-        sc = synth.make_align_scene(1000003 * rank + i, n_features=N, patch_size=P, cam=cam,
-                                    max_level=max_level, render_images=False)
-        imgs[2 * i] = synth.render(cam, sc.T_w_ref, sc.plane, sc.tex, xp=torch, device=dev)
-        imgs[2 * i + 1] = synth.render(cam, sc.T_w_cur, sc.plane, sc.tex, xp=torch, device=dev)
-        scenes.append(sc)
+    scenes = [synth.make_align_scene(1000003 * rank + i, n_features=N, patch_size=P, cam=cam,
+                                     max_level=max_level, render_images=False) for i in range(B)]
+    poses, planes, texs = [], [], []
+    for sc in scenes:  # image 2i = reference frame, 2i+1 = current frame of pair i
+        poses += [sc.T_w_ref, sc.T_w_cur]
+        planes += [sc.plane, sc.plane]
+        texs += [sc.tex, sc.tex]
+    imgs = synth.render_batch_torch(cam, poses, planes, texs, dev)
     torch.cuda.synchronize()
     frames = ctx.build_pyramid_batch_device(imgs.data_ptr(), cam.width * cam.height, 2 * B, cam.width, cam.height,
                                             cam.width, max_level + 1)

@@ -204,6 +204,50 @@ def render(cam, T_w_c, plane, tex, xp=np, device=None, dtype=None, gain=1.0, off
     return xp.clip(xp.floor(img + 0.5), 0, 255).to(xp.uint8)
 
 
+def render_batch_torch(cam, poses, planes, texs, device, chunk=32):
+    """torch only: render len(poses) u8 images (N x H x W) in chunks, vectorised
+    over the scene parameters (same arithmetic as render(), fp64)."""
+    import torch
+    n = len(poses)
+    out = torch.empty((n, cam.height, cam.width), dtype=torch.uint8, device=device)
+    u = torch.arange(cam.width, dtype=torch.float64, device=device)[None, :].expand(cam.height, cam.width)
+    v = torch.arange(cam.height, dtype=torch.float64, device=device)[:, None].expand(cam.height, cam.width)
+    x, y = cam.undistorted_xy(u, v)
+    x, y = x[None], y[None]
+
+    def col(vals):
+        return torch.tensor(np.asarray(vals, dtype=np.float64), device=device)
+
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        R = col([poses[i].R() for i in range(c0, c1)])            # b x 3 x 3
+        o = col([poses[i].t for i in range(c0, c1)])              # b x 3
+        nn = col([planes[i].n for i in range(c0, c1)])
+        hh = col([planes[i].h for i in range(c0, c1)])
+        e1 = col([planes[i].e1 for i in range(c0, c1)])
+        e2 = col([planes[i].e2 for i in range(c0, c1)])
+        B3 = lambda t, k: t[:, k][:, None, None]
+        dx = R[:, 0, 0][:, None, None] * x + R[:, 0, 1][:, None, None] * y + R[:, 0, 2][:, None, None]
+        dy = R[:, 1, 0][:, None, None] * x + R[:, 1, 1][:, None, None] * y + R[:, 1, 2][:, None, None]
+        dz = R[:, 2, 0][:, None, None] * x + R[:, 2, 1][:, None, None] * y + R[:, 2, 2][:, None, None]
+        denom = B3(nn, 0) * dx + B3(nn, 1) * dy + B3(nn, 2) * dz
+        lam = ((hh - (nn * o).sum(1))[:, None, None]) / denom
+        X = B3(o, 0) + lam * dx
+        Y = B3(o, 1) + lam * dy
+        Z = B3(o, 2) + lam * dz
+        s = B3(e1, 0) * X + B3(e1, 1) * Y + B3(e1, 2) * Z
+        t = B3(e2, 0) * X + B3(e2, 1) * Y + B3(e2, 2) * Z
+        amp = col([texs[i].amp for i in range(c0, c1)])
+        fs = col([texs[i].fs for i in range(c0, c1)])
+        ft = col([texs[i].ft for i in range(c0, c1)])
+        phi = col([texs[i].phi for i in range(c0, c1)])
+        acc = torch.full_like(s, 128.0)
+        for k in range(amp.shape[1]):
+            acc += B3(amp, k) * torch.sin((2 * math.pi) * (B3(fs, k) * s + B3(ft, k) * t) + B3(phi, k))
+        out[c0:c1] = torch.clip(torch.floor(acc + 0.5), 0, 255).to(torch.uint8)
+    return out
+
+
 class AlignScene(object):
     """One (reference frame, current frame) pair with features and ground truth."""
     pass
