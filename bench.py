@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from svo_pro_universal_amd import _capi as capi  # noqa: E402
+from svo_pro_universal_amd import dist_utils as du  # noqa: E402
 from svo_pro_universal_amd import frontend as fe  # noqa: E402
 from svo_pro_universal_amd import synth  # noqa: E402
 
@@ -43,7 +44,7 @@ def algorithmic_bytes(P, D, patch_iters, n_sel_levels):
 def build_problems(ctx, dev, rank, B, N, P, max_level):
     """B synthetic frame pairs rendered on the GPU; returns problems + keepalives."""
     cam = synth.Camera.test_camera()
-    scenes = [synth.make_align_scene(1000003 * rank + i, n_features=N, patch_size=P, cam=cam,
+    scenes = [synth.make_align_scene(du.problem_seed(rank, i), n_features=N, patch_size=P, cam=cam,
                                      max_level=max_level, render_images=False) for i in range(B)]
     poses, planes, texs = [], [], []
     for sc in scenes:  # image 2i = reference frame, 2i+1 = current frame of pair i
@@ -109,14 +110,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local_rank, world = du.env_world()
+    dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist = du.init("nccl", rank, world, torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -146,19 +143,16 @@ def main():
         kernel_ms_sum += kern_ms.value
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     n_sel = sum(r.n_fts_to_track for r in res)
+    # whole-job numbers: MAX of the elapsed time, SUM of the patches all ranks aligned
+    elapsed, patches_total = du.combine(dist, world, elapsed, n_sel, dev)
     patch_iters = sum(r.n_patch_iters for r in res)
     n_levels = args.max_level - args.min_level + 1
     n_bad = sum(1 for r in res if r.status != 0)
     # accuracy against the synthetic ground truth (informational)
     errs = [synth.se3_error(synth.SE3.from7(fe.se3_to_numpy(r.T_icur_iref)), sc.T_icur_iref_gt)
             for r, sc in zip(res, scenes)]
-    patches_total = n_sel * world  # every rank runs the same-sized job (weak scaling)
     value = patches_total * args.steps / elapsed
 
     if rank == 0:

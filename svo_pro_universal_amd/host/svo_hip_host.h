@@ -1,0 +1,116 @@
+// svo_hip_host.h -- C++ host layer above the C ABI (include/svo_hip.h) that
+// mirrors the reference's interface for the sparse-image-alignment seam:
+//
+//   svo::SparseImgAlignBase / svo::SparseImgAlign
+//       src/svo_img_align/include/svo/img_align/sparse_img_align_base.h:59-163
+//       src/svo_img_align/include/svo/img_align/sparse_img_align.h:30-89
+//   the calls FrameHandlerBase makes on it
+//       src/svo/src/frame_handler_base.cpp:621-634 (reset, setWeightedPrior,
+//       setMaxNumFeaturesToAlign, run) and :1247 (setCompensation)
+//
+// Same names, argument meaning and return values.  The reference's Frame /
+// FrameBundle / Transformation depend on Eigen + OpenCV, which this image does
+// not have, so light POD mirrors of exactly the members run() reads are
+// defined here; the adapter that subclasses the real svo::SparseImgAlignBase is
+// in INTEGRATION.md.  No CPU fallback: every call goes to libsvo_hip.so.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/svo_hip.h"
+#include "../csrc/svoh_math.h"
+
+namespace svo_hip {
+
+using Transformation = svoh::Rigid;  // minkindr QuatTransformation semantics (svoh_math.h)
+
+// The members of svo::Frame that SparseImgAlign::run reads (frame.h:46-73, 252-306).
+struct Frame {
+  svoh_frame_t pyramid = 0;      // device copy of img_pyr_
+  svoh_camera cam{};             // cam()
+  Transformation T_f_w_{ {1, 0, 0, 0}, {0, 0, 0} };
+  Transformation T_cam_imu_{ {1, 0, 0, 0}, {0, 0, 0} };
+  Transformation T_imu_cam_{ {1, 0, 0, 0}, {0, 0, 0} };
+  size_t num_features_ = 0;
+  std::vector<double> px_vec_;       // 2 x n
+  std::vector<double> f_vec_;        // 3 x n
+  // landmark_vec_[i]->pos_ or the seed position in the world (sparse_img_align.cpp:281-292)
+  std::vector<double> pos_world_;    // 3 x n
+  // landmark or seed reference present and not a map point (sparse_img_align.cpp:239-245)
+  std::vector<uint8_t> alignable_;   // n
+
+  void set_T_cam_imu(const Transformation& T) { T_cam_imu_ = T; T_imu_cam_ = svoh::inverse(T); }  // frame.h:270-274
+  const Transformation& T_cam_imu() const { return T_cam_imu_; }
+  const Transformation& T_imu_cam() const { return T_imu_cam_; }
+  Transformation T_imu_world() const { return svoh::mul(T_imu_cam_, T_f_w_); }  // frame.h:267
+  svoh::Vec3 pos() const { return svoh::inverse(T_f_w_).t; }                    // frame.h:306
+};
+using FramePtr = std::shared_ptr<Frame>;
+
+struct FrameBundle {
+  std::vector<FramePtr> frames_;
+  bool empty() const { return frames_.empty(); }
+  size_t size() const { return frames_.size(); }
+  const FramePtr& at(size_t i) const { return frames_.at(i); }
+  using Ptr = std::shared_ptr<FrameBundle>;
+};
+
+// sparse_img_align_base.h:37-46
+struct SparseImgAlignOptions {
+  int max_level = 4;
+  int min_level = 1;
+  bool estimate_illumination_gain = false;
+  bool estimate_illumination_offset = false;
+  bool use_distortion_jacobian = false;
+  bool robustification = false;
+  double weight_scale = 10;
+};
+
+// the two solver options the reference sets (sparse_img_align_base.cpp:35-42)
+struct SolverOptions {
+  size_t max_iter = 10;
+  double eps = 0.0005;
+};
+
+class SparseImgAlignHip {
+ public:
+  using Ptr = std::shared_ptr<SparseImgAlignHip>;
+
+  SparseImgAlignHip(svoh_ctx* ctx, SolverOptions solver_options, SparseImgAlignOptions options);
+
+  static SolverOptions getDefaultSolverOptions() { return SolverOptions(); }
+
+  // MiniLeastSquaresSolver::reset (mini_least_squares_solver.hpp:240-250): drops the prior
+  void reset();
+  void setWeightedPrior(const Transformation& T_cur_ref_prior, double alpha_prior, double beta_prior,
+                        double lambda_rot, double lambda_trans, double lambda_alpha, double lambda_beta);
+  void setMaxNumFeaturesToAlign(int num) { max_num_features_ = num; }  // ignored by the reference too (SURVEY gotcha 12)
+  void setAlphaInitialValue(double a) { alpha_init_ = a; }
+  void setBetaInitialValue(double b) { beta_init_ = b; }
+  void setCompensation(bool do_compensation);
+  void setPatchSize(int patch_size) { patch_size_ = patch_size; }
+
+  // SparseImgAlign::run: optimises the pose of cur_frames (writes T_f_w_ of every
+  // frame of the bundle) and returns the number of features tracked; 0 = none.
+  // Throws std::runtime_error on an ABI error (the reference CHECK-aborts).
+  size_t run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames);
+
+  // last run's statistics
+  const svoh_align_result& lastResult() const { return last_; }
+
+ private:
+  svoh_ctx* ctx_;
+  SolverOptions solver_options_;
+  SparseImgAlignOptions options_;
+  int patch_size_ = 4;
+  int max_num_features_ = -1;
+  double alpha_init_ = 0.0, beta_init_ = 0.0;
+  svoh_align_prior prior_{};
+  svoh_align_result last_{};
+};
+
+}  // namespace svo_hip
