@@ -239,6 +239,126 @@ int svoh_sparse_align_evaluate(svoh_ctx* ctx, const svoh_align_options* options,
                                int32_t* n_meas, uint8_t* visibility,
                                int32_t* n_selected);
 
+/* ---- KLT feature alignment (a-9) -------------------------------------- */
+
+/* FeatureTrackerOptions klt_* (src/svo_tracker/include/svo/tracker/feature_tracking_types.h:15-29) */
+typedef struct svoh_klt_options {
+  int32_t max_level;                      /* 4 */
+  int32_t min_level;                      /* 0 */
+  int32_t patch_sizes[SVOH_MAX_LEVELS];   /* {16,16,16,8,8}, indexed by level, multiples of 8, <= 32 */
+  int32_t max_iter;                       /* 30 */
+  float min_update_squared;               /* 0.001 */
+  int32_t reserved;
+} svoh_klt_options;
+
+/* Replaces the per-track loop of FeatureTracker::trackFrameBundle
+ * (src/svo_tracker/src/feature_tracker.cpp:64-99), i.e. n_tracks calls of
+ * feature_alignment::alignPyr2D (src/svo_direct/src/feature_alignment.cpp:761-973;
+ * batch form alignPyr2DVec :732-758).  ref_frames[i]: pyramid holding track i's
+ * template; px_ref: 2 x n int (ref_observation.getPx().cast<int>());
+ * px_cur: 2 x n double, in = track.back().getPx(), out = aligned position;
+ * status[i] = 1 iff alignPyr2D returned true.  Host pointers. */
+int svoh_klt_track_batch(svoh_ctx* ctx, const svoh_klt_options* options, int n_tracks,
+                         const svoh_frame_t* ref_frames, svoh_frame_t cur_frame,
+                         const int32_t* px_ref, double* px_cur, uint8_t* status);
+
+/* ---- matcher and depth filter (a-10 ... a-14) -------------------------- */
+
+/* svo::FeatureType (src/svo_common/include/svo/common/types.h:60-73) */
+typedef enum svoh_feature_type {
+  SVOH_FT_EDGELET_SEED = 0, SVOH_FT_CORNER_SEED = 1, SVOH_FT_MAPPOINT_SEED = 2,
+  SVOH_FT_EDGELET_SEED_CONVERGED = 3, SVOH_FT_CORNER_SEED_CONVERGED = 4,
+  SVOH_FT_MAPPOINT_SEED_CONVERGED = 5, SVOH_FT_EDGELET = 6, SVOH_FT_CORNER = 7,
+  SVOH_FT_MAPPOINT = 8, SVOH_FT_FIXED_LANDMARK = 9, SVOH_FT_OUTLIER = 10
+} svoh_feature_type;
+
+/* Matcher::MatchResult (src/svo_direct/include/svo/direct/matcher.h:56-68) */
+typedef enum svoh_match_result {
+  SVOH_MATCH_SUCCESS = 0, SVOH_MATCH_FAIL_SCORE = 1, SVOH_MATCH_FAIL_TRIANGULATION = 2,
+  SVOH_MATCH_FAIL_VISIBILITY = 3, SVOH_MATCH_FAIL_WARP = 4, SVOH_MATCH_FAIL_ALIGNMENT = 5,
+  SVOH_MATCH_FAIL_RANGE = 6, SVOH_MATCH_FAIL_ANGLE = 7, SVOH_MATCH_FAIL_CLOSE_VIEW = 8,
+  SVOH_MATCH_FAIL_LOCK = 9, SVOH_MATCH_FAIL_TOO_FAR = 10,
+  SVOH_MATCH_NOT_RUN = 100  /* updateSeed returned before calling the matcher */
+} svoh_match_result;
+
+/* Matcher::Options (matcher.h:39-54); align_1d is chosen per feature by the callers */
+typedef struct svoh_matcher_options {
+  int32_t align_max_iter;                 /* 10 */
+  int32_t max_epi_search_steps;           /* 100 (500 in StereoTriangulation) */
+  int32_t subpix_refinement;              /* 1 */
+  int32_t epi_search_edgelet_filtering;   /* 1 */
+  int32_t scan_on_unit_sphere;            /* Matcher default 1; DepthFilterOptions default 0 */
+  int32_t affine_est_offset;              /* 1 */
+  int32_t affine_est_gain;                /* 0 */
+  int32_t reserved;
+  double epi_search_edgelet_max_angle;    /* 0.7 */
+  double max_patch_diff_ratio;            /* 2.0 */
+} svoh_matcher_options;
+
+/* What the matcher reads of a Frame: pyramid, camera, pose */
+typedef struct svoh_frame_view {
+  svoh_frame_t frame;
+  svoh_camera cam;
+  svoh_se3 T_f_w;                         /* Frame::T_f_w_ (camera <- world) */
+  double seed_mu_range;                   /* Frame::seed_mu_range_ (depth filter only) */
+  int32_t id;                             /* Frame::id() */
+  int32_t reserved;
+} svoh_frame_view;
+
+/* n features referencing one of n_ref_frames reference frames, SoA like Frame's
+ * feature storage (frame.h:62-73) */
+typedef struct svoh_feature_batch {
+  int32_t n;
+  int32_t reserved;
+  const int32_t* ref_frame_idx;           /* n: index into the ref_frames array */
+  const double* px;                       /* 2 x n  px_vec_ */
+  const double* f;                        /* 3 x n  f_vec_ */
+  const double* grad;                     /* 2 x n  grad_vec_ */
+  const int32_t* level;                   /* n      level_vec_ */
+  uint8_t* type;                          /* n      type_vec_ (svoh_feature_type), updated by update_seeds */
+} svoh_feature_batch;
+
+/* Replaces n calls of Matcher::findMatchDirect (src/svo_direct/src/matcher.cpp:31-141),
+ * as made by reprojector_utils::matchCandidate (src/svo/src/reprojector.cpp:384-460).
+ * depth: n reference depths; px_cur: 2 x n, in = projection estimate, out = match;
+ * outputs per feature: result (svoh_match_result), f_cur (3 x n, normalised bearing),
+ * search_level, h_inv (align1D only), A_cur_ref (4 x n, col-major 2x2).  Optional
+ * outputs may be NULL.  The caller replays the sequential grid-occupancy logic. */
+int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options,
+                            int n_ref_frames, const svoh_frame_view* ref_frames,
+                            const svoh_frame_view* cur_frame, const svoh_feature_batch* features,
+                            const double* depth, double* px_cur, int32_t* result,
+                            double* f_cur, int32_t* search_level, double* h_inv, double* A_cur_ref);
+
+/* DepthFilterOptions used by updateSeed (src/svo_direct/include/svo/direct/depth_filter.h:40-100) */
+typedef struct svoh_depth_filter_options {
+  double seed_convergence_sigma2_thresh;      /* 200 */
+  double mappoint_convergence_sigma2_thresh;  /* 500 */
+  /* the function-local static of updateSeed: cur_frame.getAngleError(1.0) of the FIRST
+   * frame ever passed (depth_filter.cpp:383-384): atan(1/(2fx)) + atan(1/(2fy)) */
+  double px_error_angle;
+  int32_t check_visibility;                   /* 1 */
+  int32_t check_convergence;                  /* 0 */
+  int32_t use_vogiatzis_update;               /* 1 */
+  int32_t reserved;
+} svoh_depth_filter_options;
+
+/* Replaces the synchronous branch of DepthFilter::updateSeeds
+ * (src/svo_direct/src/depth_filter.cpp:200-233): for every feature whose type isSeed(),
+ * depth_filter_utils::updateSeed (:367-499) = visibility test, epipolar search
+ * (Matcher::findEpipolarMatchDirect, matcher.cpp:157-241), computeTau (:580-596),
+ * updateFilterVogiatzis/Gaussian (:501-578), convergence test (seed.h:143-151).
+ * state: 4 x n [mu = 1/depth, sigma2, a, b] (invmu_sigma2_a_b_vec_), updated in place;
+ * features->type updated in place (converged / outlier); success[i] = return value of
+ * updateSeed; match_result (may be NULL) = svoh_match_result of the epipolar search.
+ * Returns the number of successes in *n_success. */
+int svoh_update_seeds_batch(svoh_ctx* ctx, const svoh_matcher_options* matcher_options,
+                            const svoh_depth_filter_options* options,
+                            int n_ref_frames, const svoh_frame_view* ref_frames,
+                            const svoh_frame_view* cur_frame, const svoh_feature_batch* features,
+                            double* state, uint8_t* success, int32_t* match_result,
+                            int32_t* n_success);
+
 #ifdef __cplusplus
 }
 #endif

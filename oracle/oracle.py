@@ -217,3 +217,107 @@ def sparse_align_evaluate(opt, pb, level, fast=False):
     lib.orc_sparse_align_evaluate(C.byref(opt), C.byref(pb.c), level, H.ctypes.data, g.ctypes.data,
                                   C.byref(chi2), C.byref(nm), vis.ctypes.data, C.byref(nsel))
     return H.reshape(8, 8).T.copy(), g, chi2.value, nm.value, vis[:nsel.value].copy()
+
+
+# ---------------------------------------------------------------------------
+# KLT / matcher / depth filter (svo_oracle_klt.c, svo_oracle_matcher.c)
+# ---------------------------------------------------------------------------
+
+class orc_frame_view(C.Structure):
+    _fields_ = [("pyr", orc_pyramid), ("cam", capi.svoh_camera), ("T_f_w", capi.svoh_se3),
+                ("seed_mu_range", C.c_double), ("id", C.c_int32), ("reserved", C.c_int32)]
+
+
+def _bind_part2(lib):
+    if getattr(lib, "_part2", False):
+        return
+    P = C.POINTER
+    lib.orc_klt_track_batch.argtypes = [P(P(orc_pyramid)), P(orc_pyramid), C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_klt_track_batch.restype = None
+    lib.orc_match_direct_batch.argtypes = [P(capi.svoh_matcher_options), C.c_int, P(orc_frame_view), P(orc_frame_view),
+                                           P(capi.svoh_feature_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_match_direct_batch.restype = None
+    lib.orc_update_seeds_batch.argtypes = [P(capi.svoh_matcher_options), P(capi.svoh_depth_filter_options), C.c_int,
+                                           P(orc_frame_view), P(orc_frame_view), P(capi.svoh_feature_batch),
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_zmssd_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_warp_affine.argtypes = [C.c_void_p, P(orc_image), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.orc_get_warp_matrix_affine.argtypes = [P(capi.svoh_camera), P(capi.svoh_camera), C.c_void_p, C.c_void_p,
+                                               C.c_double, P(capi.svoh_se3), C.c_int, C.c_void_p]
+    lib.orc_get_warp_matrix_affine.restype = None
+    lib.orc_get_best_search_level.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_align_2d.argtypes = [P(orc_image), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.orc_align_1d.argtypes = [P(orc_image), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p]
+    lib._part2 = True
+
+
+def klt_track_batch(opt, ref_levels_list, cur_levels, px_ref, px_cur, fast=False):
+    """ref_levels_list: one pyramid (list of arrays) per track, or a single pyramid for all."""
+    lib = load(fast)
+    _bind_part2(lib)
+    n = len(px_ref) // 2
+    if not isinstance(ref_levels_list[0], (list, tuple)):
+        ref_levels_list = [ref_levels_list] * n
+    uniq = {}
+    for lv in ref_levels_list:
+        uniq.setdefault(id(lv), make_pyramid_struct(lv))
+    ptrs = (C.POINTER(orc_pyramid) * n)(*[C.pointer(uniq[id(lv)]) for lv in ref_levels_list])
+    cur = make_pyramid_struct(cur_levels)
+    px_ref = np.ascontiguousarray(px_ref, np.int32)
+    out = np.ascontiguousarray(px_cur, np.float64).copy()
+    status = np.zeros(n, np.uint8)
+    ps = (C.c_int32 * capi.SVOH_MAX_LEVELS)(*list(opt.patch_sizes))
+    lib.orc_klt_track_batch(ptrs, C.byref(cur), opt.max_level, opt.min_level, ps, opt.max_iter,
+                            opt.min_update_squared, n, px_ref.ctypes.data, out.ctypes.data, status.ctypes.data)
+    return out, status
+
+
+def make_frame_view(levels, cam, T_f_w, seed_mu_range=0.0, frame_id=0):
+    v = orc_frame_view()
+    v.pyr = make_pyramid_struct(levels)
+    v.cam = to_camera(cam)
+    v.T_f_w = to_se3(T_f_w)
+    v.seed_mu_range = seed_mu_range
+    v.id = frame_id
+    return v
+
+
+def make_feature_batch(ref_frame_idx, px, f, grad, level, ftype):
+    arrs = dict(ref_frame_idx=np.ascontiguousarray(ref_frame_idx, np.int32), px=np.ascontiguousarray(px, np.float64),
+                f=np.ascontiguousarray(f, np.float64), grad=np.ascontiguousarray(grad, np.float64),
+                level=np.ascontiguousarray(level, np.int32), type=np.ascontiguousarray(ftype, np.uint8).copy())
+    fb = capi.svoh_feature_batch()
+    fb.n = int(arrs["level"].size)
+    for k, a in arrs.items():
+        setattr(fb, k, a.ctypes.data)
+    return fb, arrs
+
+
+def match_direct_batch(mopt, ref_views, cur_view, fb, depth, px_cur, fast=False):
+    lib = load(fast)
+    _bind_part2(lib)
+    n = fb.n
+    rv = (orc_frame_view * len(ref_views))(*ref_views)
+    depth = np.ascontiguousarray(depth, np.float64)
+    out = dict(px_cur=np.ascontiguousarray(px_cur, np.float64).copy(), result=np.zeros(n, np.int32),
+               f_cur=np.zeros(3 * n), search_level=np.zeros(n, np.int32), h_inv=np.zeros(n), A=np.zeros(4 * n))
+    lib.orc_match_direct_batch(C.byref(mopt), len(ref_views), rv, C.byref(cur_view), C.byref(fb), depth.ctypes.data,
+                               out["px_cur"].ctypes.data, out["result"].ctypes.data, out["f_cur"].ctypes.data,
+                               out["search_level"].ctypes.data, out["h_inv"].ctypes.data, out["A"].ctypes.data)
+    return out
+
+
+def update_seeds_batch(mopt, dopt, ref_views, cur_view, fb, state, fast=False):
+    lib = load(fast)
+    _bind_part2(lib)
+    n = fb.n
+    rv = (orc_frame_view * len(ref_views))(*ref_views)
+    st = np.ascontiguousarray(state, np.float64).copy()
+    success = np.zeros(n, np.uint8)
+    mr = np.zeros(n, np.int32)
+    ns = lib.orc_update_seeds_batch(C.byref(mopt), C.byref(dopt), len(ref_views), rv, C.byref(cur_view), C.byref(fb),
+                                    st.ctypes.data, success.ctypes.data, mr.ctypes.data)
+    return ns, st, success, mr

@@ -69,6 +69,83 @@ class svoh_align_result(C.Structure):
                 ("chi2", C.c_double * SVOH_MAX_LEVELS), ("n_patch_iters", C.c_int64)]
 
 
+class svoh_klt_options(C.Structure):
+    _fields_ = [("max_level", C.c_int32), ("min_level", C.c_int32), ("patch_sizes", C.c_int32 * SVOH_MAX_LEVELS),
+                ("max_iter", C.c_int32), ("min_update_squared", C.c_float), ("reserved", C.c_int32)]
+
+
+class svoh_matcher_options(C.Structure):
+    _fields_ = [("align_max_iter", C.c_int32), ("max_epi_search_steps", C.c_int32), ("subpix_refinement", C.c_int32),
+                ("epi_search_edgelet_filtering", C.c_int32), ("scan_on_unit_sphere", C.c_int32),
+                ("affine_est_offset", C.c_int32), ("affine_est_gain", C.c_int32), ("reserved", C.c_int32),
+                ("epi_search_edgelet_max_angle", C.c_double), ("max_patch_diff_ratio", C.c_double)]
+
+
+class svoh_frame_view(C.Structure):
+    _fields_ = [("frame", svoh_frame_t), ("cam", svoh_camera), ("T_f_w", svoh_se3), ("seed_mu_range", C.c_double),
+                ("id", C.c_int32), ("reserved", C.c_int32)]
+
+
+class svoh_feature_batch(C.Structure):
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("ref_frame_idx", C.c_void_p), ("px", C.c_void_p),
+                ("f", C.c_void_p), ("grad", C.c_void_p), ("level", C.c_void_p), ("type", C.c_void_p)]
+
+
+class svoh_depth_filter_options(C.Structure):
+    _fields_ = [("seed_convergence_sigma2_thresh", C.c_double), ("mappoint_convergence_sigma2_thresh", C.c_double),
+                ("px_error_angle", C.c_double), ("check_visibility", C.c_int32), ("check_convergence", C.c_int32),
+                ("use_vogiatzis_update", C.c_int32), ("reserved", C.c_int32)]
+
+
+# svo::FeatureType (types.h:60-73)
+FT_EDGELET_SEED, FT_CORNER_SEED, FT_MAPPOINT_SEED = 0, 1, 2
+FT_EDGELET_SEED_CONVERGED, FT_CORNER_SEED_CONVERGED, FT_MAPPOINT_SEED_CONVERGED = 3, 4, 5
+FT_EDGELET, FT_CORNER, FT_MAPPOINT, FT_FIXED_LANDMARK, FT_OUTLIER = 6, 7, 8, 9, 10
+MATCH_NOT_RUN = 100
+
+
+def default_klt_options(**kw):
+    """FeatureTrackerOptions klt_* defaults (feature_tracking_types.h:15-29)."""
+    o = svoh_klt_options(max_level=4, min_level=0, max_iter=30, min_update_squared=0.001)
+    for i, v in enumerate([16, 16, 16, 8, 8, 8, 8, 8]):
+        o.patch_sizes[i] = v
+    for k, v in kw.items():
+        if k == "patch_sizes":
+            for i, x in enumerate(v):
+                o.patch_sizes[i] = x
+        else:
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+    return o
+
+
+def default_matcher_options(**kw):
+    """Matcher::Options defaults (matcher.h:39-54) with the depth filter's unit-plane scan
+    (svo_factory.cpp:261)."""
+    o = svoh_matcher_options(align_max_iter=10, max_epi_search_steps=100, subpix_refinement=1,
+                             epi_search_edgelet_filtering=1, scan_on_unit_sphere=0, affine_est_offset=1,
+                             affine_est_gain=0, epi_search_edgelet_max_angle=0.7, max_patch_diff_ratio=2.0)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def default_depth_filter_options(cam=None, **kw):
+    import math
+    o = svoh_depth_filter_options(seed_convergence_sigma2_thresh=200.0, mappoint_convergence_sigma2_thresh=500.0,
+                                  px_error_angle=0.0, check_visibility=1, check_convergence=0, use_vogiatzis_update=1)
+    if cam is not None:  # PinholeProjection::getAngleError(1.0) (pinhole_projection.hpp:72-76)
+        o.px_error_angle = math.atan(1.0 / (2.0 * cam.fx)) + math.atan(1.0 / (2.0 * cam.fy))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
 def default_align_options(**kw):
     """SparseImgAlignOptions defaults (sparse_img_align_base.h:37-46) + solver
     defaults (sparse_img_align_base.cpp:35-42)."""
@@ -95,6 +172,7 @@ EXPORTS = [
     "svoh_download_level", "svoh_frame_info", "svoh_release_frame",
     "svoh_sparse_align_batch", "svoh_sparse_align_enqueue", "svoh_sparse_align_fetch",
     "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms",
+    "svoh_klt_track_batch", "svoh_match_direct_batch", "svoh_update_seeds_batch",
 ]
 
 
@@ -162,5 +240,13 @@ def load():
                                                C.c_int, C.c_void_p, C.c_void_p, P(C.c_double),
                                                P(C.c_int32), C.c_void_p, P(C.c_int32)]
     lib.svoh_sparse_align_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float)]
+    lib.svoh_klt_track_batch.argtypes = [C.c_void_p, P(svoh_klt_options), C.c_int, C.c_void_p, svoh_frame_t,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svoh_match_direct_batch.argtypes = [C.c_void_p, P(svoh_matcher_options), C.c_int, P(svoh_frame_view),
+                                            P(svoh_frame_view), P(svoh_feature_batch), C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svoh_update_seeds_batch.argtypes = [C.c_void_p, P(svoh_matcher_options), P(svoh_depth_filter_options),
+                                            C.c_int, P(svoh_frame_view), P(svoh_frame_view), P(svoh_feature_batch),
+                                            C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int32)]
     _LIB = lib
     return lib

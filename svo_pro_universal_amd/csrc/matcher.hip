@@ -1,0 +1,965 @@
+// matcher.hip -- batched Matcher (direct + epipolar) and depth-filter seed update
+// for gfx950 (a-10 ... a-14).
+//
+// Replaces, for a batch of independent features / seeds:
+//   warp::getWarpMatrixAffine / getBestSearchLevel / warpAffine   src/svo_direct/src/patch_warp.cpp:20-60, 97-156
+//   patch_utils::createPatchFromPatchWithBorder                   src/svo_direct/include/svo/direct/patch_utils.h:18-30
+//   patch_score::ZMSSD<4>                                         src/svo_direct/include/svo/direct/patch_score.h:44-285
+//   feature_alignment::align1D / align2D                          src/svo_direct/src/feature_alignment.cpp:31-391
+//   Matcher::findMatchDirect / findEpipolarMatchDirect / scanEpipolar* / findLocalMatch
+//                                                                 src/svo_direct/src/matcher.cpp:31-505
+//   depth_filter_utils::updateSeed / updateFilterVogiatzis / updateFilterGaussian / computeTau
+//                                                                 src/svo_direct/src/depth_filter.cpp:367-596
+//   DepthFilter::updateSeeds (synchronous branch)                 src/svo_direct/src/depth_filter.cpp:200-233
+//
+// One thread owns one feature / seed from warp to filter update: units are
+// independent (that is the data parallelism of this path), every unit is a short,
+// branchy, mostly-integer program, and the reference's float accumulators (Jres in
+// align1D/2D) are order dependent, so a sequential per-unit evaluation in the
+// reference's own order is what keeps results identical.  The 10x10 warped patch
+// of every thread lives in LDS (100 B per thread, stride 25 dwords: conflict-free);
+// gradients are recomputed from it instead of being stored.  Integer results
+// (warped patch bytes, ZMSSD scores, visited pixels, result codes) are exact; this
+// file is compiled with -ffp-contract=off so the float/double expressions round
+// like the reference's (non fast-math) evaluation order.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "svoh_internal.h"
+#include "svoh_math.h"
+
+namespace svoh {
+
+struct DevFrameView {
+  DevImage lv[SVOH_MAX_LEVELS];
+  CamModel cam;
+  Rigid T_f_w;
+  double seed_mu_range;
+  int32_t n_levels;
+  int32_t id;
+};
+
+struct MatcherArgs {
+  const DevFrameView* ref_frames;
+  const DevFrameView* cur_frame;
+  svoh_matcher_options mopt;
+  svoh_depth_filter_options dopt;
+  int n;
+  const int32_t* ref_frame_idx;
+  const double* px;
+  const double* f;
+  const double* grad;
+  const int32_t* level;
+  uint8_t* type;
+  // direct
+  const double* depth;
+  double* px_cur;
+  int32_t* result;
+  double* f_cur;
+  int32_t* search_level;
+  double* h_inv;
+  double* A_cur_ref;
+  // seeds
+  double* state;
+  uint8_t* success;
+};
+
+constexpr int kPwbStride = 100;
+
+struct MatcherState {
+  unsigned char* pwb;  // this thread's 10x10 patch with border, in LDS
+  double A[4];         // A_cur_ref, col-major
+  double epi_image[2];
+  double epi_length_pyramid;
+  double h_inv;
+  int search_level;
+  bool reject;
+  bool align_1d;
+  double px_cur[2];
+  Vec3 f_cur;
+};
+
+__device__ __forceinline__ int patch_at(const unsigned char* pwb, int r) { return pwb[((r >> 3) + 1) * 10 + (r & 7) + 1]; }
+
+__device__ __forceinline__ void normalize2(double& x, double& y)
+{
+  const double z = x * x + y * y;
+  if (z > 0.0) { const double n = sqrt(z); x /= n; y /= n; }
+}
+__device__ __forceinline__ void normalize3(Vec3& v)
+{
+  const double z = v.x * v.x + v.y * v.y + v.z * v.z;
+  if (z > 0.0) { const double n = sqrt(z); v.x /= n; v.y /= n; v.z /= n; }
+}
+__device__ __forceinline__ void mat2d_inverse(const double m[4], double r[4])
+{
+  const double det = m[0] * m[3] - m[1] * m[2];
+  const double invdet = 1.0 / det;
+  r[0] = m[3] * invdet; r[1] = -m[1] * invdet; r[2] = -m[2] * invdet; r[3] = m[0] * invdet;
+}
+__device__ __forceinline__ bool is_edgelet(int t)
+{
+  return t == SVOH_FT_EDGELET || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_EDGELET_SEED_CONVERGED;
+}
+
+// patch_warp.cpp:20-60 (pinhole cameras)
+__device__ void get_warp_matrix_affine(const CamModel& cam_ref, const CamModel& cam_cur, double pxr, double pyr,
+                                       const Vec3& f_ref, double depth_ref, const Rigid& T_cur_ref, int level_ref,
+                                       double A[4])
+{
+  const int kHalfPatchSize = 5;
+  const Vec3 xyz_ref = { f_ref.x * depth_ref, f_ref.y * depth_ref, f_ref.z * depth_ref };
+  Vec3 du = back_project3(cam_ref, pxr + (double)kHalfPatchSize * (1 << level_ref), pyr + 0.0 * (1 << level_ref));
+  Vec3 dv = back_project3(cam_ref, pxr + 0.0 * (1 << level_ref), pyr + (double)kHalfPatchSize * (1 << level_ref));
+  du.x *= xyz_ref.z; du.y *= xyz_ref.z; du.z *= xyz_ref.z;
+  dv.x *= xyz_ref.z; dv.y *= xyz_ref.z; dv.z *= xyz_ref.z;
+  double cu, cv, duu, duv, dvu, dvv;
+  project3(cam_cur, transform(T_cur_ref, xyz_ref), cu, cv);
+  project3(cam_cur, transform(T_cur_ref, du), duu, duv);
+  project3(cam_cur, transform(T_cur_ref, dv), dvu, dvv);
+  A[0] = (duu - cu) / kHalfPatchSize;
+  A[1] = (duv - cv) / kHalfPatchSize;
+  A[2] = (dvu - cu) / kHalfPatchSize;
+  A[3] = (dvv - cv) / kHalfPatchSize;
+}
+
+// patch_warp.cpp:97-110
+__device__ __forceinline__ int get_best_search_level(const double A[4], int max_level)
+{
+  int search_level = 0;
+  double D = A[0] * A[3] - A[1] * A[2];
+  while (D > 3.0 && search_level < max_level) {
+    search_level += 1;
+    D *= 0.25;
+  }
+  return search_level;
+}
+
+// patch_warp.cpp:112-156, halfpatch_size = 5 (10x10 patch with border)
+__device__ bool warp_affine(const double A_cur_ref[4], const DevImage& img_ref, double pxr, double pyr, int level_ref,
+                            int search_level, unsigned char* patch)
+{
+  const int halfpatch_size = 5;
+  double Ai[4];
+  mat2d_inverse(A_cur_ref, Ai);
+  const float s = (float)(1 << search_level);
+  const float a00 = (float)Ai[0] * s, a10 = (float)Ai[1] * s, a01 = (float)Ai[2] * s, a11 = (float)Ai[3] * s;
+  if (a00 != a00) return false;
+  const float prx = (float)pxr / (float)(1 << level_ref);
+  const float pry = (float)pyr / (float)(1 << level_ref);
+  const int stride = img_ref.pitch;
+  int k = 0;
+  for (int y = -halfpatch_size; y < halfpatch_size; ++y) {
+    for (int x = -halfpatch_size; x < halfpatch_size; ++x, ++k) {
+      const float fx = (float)x, fy = (float)y;
+      const float pxx = (a00 * fx + a01 * fy) + prx;
+      const float pxy = (a10 * fx + a11 * fy) + pry;
+      const int xi = (int)floorf(pxx);
+      const int yi = (int)floorf(pxy);
+      if (xi < 0 || yi < 0 || xi + 1 >= img_ref.w || yi + 1 >= img_ref.h) return false;
+      const float subpix_x = pxx - xi;
+      const float subpix_y = pxy - yi;
+      const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+      const float w01 = (1.0f - subpix_x) * subpix_y;
+      const float w10 = subpix_x * (1.0f - subpix_y);
+      const float w11 = 1.0f - w00 - w01 - w10;
+      const uint8_t* ptr = img_ref.data + (ptrdiff_t)yi * stride + xi;
+      patch[k] = (unsigned char)(w00 * ptr[0] + w01 * ptr[stride] + w10 * ptr[1] + w11 * ptr[stride + 1]);
+    }
+  }
+  return true;
+}
+
+// patch_score.h:264-283 with the constructor's sums (patch_score.h:80-92)
+__device__ int zmssd_score(const unsigned char* pwb, int sumA, int sumAA, const uint8_t* cur_patch, int stride)
+{
+  unsigned sumB = 0, sumBB = 0, sumAB = 0;
+  for (int y = 0, r = 0; y < 8; ++y) {
+    const uint8_t* p = cur_patch + (ptrdiff_t)y * stride;
+    for (int x = 0; x < 8; ++x, ++r) {
+      const unsigned c = p[x];
+      sumB += c; sumBB += c * c; sumAB += c * (unsigned)patch_at(pwb, r);
+    }
+  }
+  const int iB = (int)sumB, iBB = (int)sumBB, iAB = (int)sumAB;
+  return sumAA - 2 * iAB + iBB - (sumA * sumA - 2 * sumA * iB + iB * iB) / 64;
+}
+
+__device__ void mat3f_inverse(const float* m, float* r)
+{
+#define M3(i, j) m[(i) * 3 + (j)]
+#define COF3(i, j) (M3(((i) + 1) % 3, ((j) + 1) % 3) * M3(((i) + 2) % 3, ((j) + 2) % 3) - M3(((i) + 1) % 3, ((j) + 2) % 3) * M3(((i) + 2) % 3, ((j) + 1) % 3))
+  const float c00 = COF3(0, 0), c10 = COF3(1, 0), c20 = COF3(2, 0);
+  const float det = (c00 * M3(0, 0) + c10 * M3(1, 0)) + c20 * M3(2, 0);
+  const float invdet = 1.0f / det;
+  r[0] = c00 * invdet; r[1] = c10 * invdet; r[2] = c20 * invdet;
+  r[3] = COF3(0, 1) * invdet; r[4] = COF3(1, 1) * invdet; r[5] = COF3(2, 1) * invdet;
+  r[6] = COF3(0, 2) * invdet; r[7] = COF3(1, 2) * invdet; r[8] = COF3(2, 2) * invdet;
+#undef COF3
+#undef M3
+}
+
+#define M4(i, j) m[(i) * 4 + (j)]
+__device__ __forceinline__ float det3_helper(const float* m, int i1, int i2, int i3, int j1, int j2, int j3)
+{
+  return M4(i1, j1) * (M4(i2, j2) * M4(i3, j3) - M4(i2, j3) * M4(i3, j2));
+}
+__device__ __forceinline__ float cofactor4(const float* m, int i, int j)
+{
+  const int i1 = (i + 1) % 4, i2 = (i + 2) % 4, i3 = (i + 3) % 4;
+  const int j1 = (j + 1) % 4, j2 = (j + 2) % 4, j3 = (j + 3) % 4;
+  return det3_helper(m, i1, i2, i3, j1, j2, j3) + det3_helper(m, i2, i3, i1, j1, j2, j3) + det3_helper(m, i3, i1, i2, j1, j2, j3);
+}
+__device__ void mat4f_inverse(const float* m, float* r)
+{
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float c = cofactor4(m, i, j);
+      r[j * 4 + i] = ((i + j) & 1) ? -c : c;
+    }
+  const float d = ((M4(0, 0) * r[0] + M4(1, 0) * r[1]) + M4(2, 0) * r[2]) + M4(3, 0) * r[3];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) r[k] /= d;
+}
+#undef M4
+
+// feature_alignment.cpp:31-209
+__device__ bool align_1d(const DevImage& cur_img, double dir0, double dir1, const unsigned char* pwb, int n_iter,
+                         bool affine_est_offset, bool affine_est_gain, double& px, double& py, double* h_inv)
+{
+  constexpr int kHalfPatchSize = 4, kPatchSize = 8, ref_step = 10;
+  bool converged = false;
+  float H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  for (int y = 0; y < kPatchSize; ++y) {
+    const unsigned char* it = pwb + (y + 1) * ref_step + 1;
+    for (int x = 0; x < kPatchSize; ++x, ++it) {
+      float J[3];
+      const float dx = (float)it[1] - (float)it[-1];
+      const float dy = (float)it[ref_step] - (float)it[-ref_step];
+      J[0] = (float)(0.5f * (dir0 * dx + dir1 * dy));
+      J[1] = affine_est_offset ? 1.0f : 0.0f;
+      J[2] = affine_est_gain ? -1.0f * it[0] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) H[r * 3 + c] += J[r] * J[c];
+    }
+  }
+  if (!affine_est_offset) H[4] = 1.0f;
+  if (!affine_est_gain) H[8] = 1.0f;
+  if (h_inv) *h_inv = 1.0 / H[0] * kPatchSize * kPatchSize;
+  float Hinv[9];
+  mat3f_inverse(H, Hinv);
+  float mean_diff = 0;
+  float alpha = 1.0;
+  float u = (float)px;
+  float v = (float)py;
+  const float min_update_squared = (float)(0.03 * 0.03);
+  const int cur_step = cur_img.pitch;
+  for (int iter = 0; iter < n_iter; ++iter) {
+    const int u_r = (int)floorf(u);
+    const int v_r = (int)floorf(v);
+    if (u_r < kHalfPatchSize || v_r < kHalfPatchSize || u_r >= cur_img.w - kHalfPatchSize || v_r >= cur_img.h - kHalfPatchSize)
+      break;
+    if (u != u || v != v) return false;
+    const float subpix_x = u - u_r;
+    const float subpix_y = v - v_r;
+    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
+    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
+    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
+    const float wBR = subpix_x * subpix_y;
+    float Jres[3] = { 0, 0, 0 };
+    for (int y = 0; y < kPatchSize; ++y) {
+      const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + y - kHalfPatchSize) * cur_step + u_r - kHalfPatchSize;
+      const unsigned char* rp = pwb + (y + 1) * ref_step + 1;
+      for (int x = 0; x < kPatchSize; ++x, ++it, ++rp) {
+        const float gdx = (float)rp[1] - (float)rp[-1];
+        const float gdy = (float)rp[ref_step] - (float)rp[-ref_step];
+        const float ref_dv = (float)(0.5f * (dir0 * gdx + dir1 * gdy));
+        const float cur_intensity = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
+        const float res = cur_intensity - alpha * rp[0] + mean_diff;
+        Jres[0] -= res * ref_dv;
+        if (affine_est_offset) Jres[1] -= res;
+        if (affine_est_gain) Jres[2] -= (-1) * res * rp[0];
+      }
+    }
+    if (!affine_est_offset) Jres[1] = 0.0f;
+    if (!affine_est_gain) Jres[2] = 0.0f;
+    float update[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) update[r] = (Hinv[r * 3 + 0] * Jres[0] + Hinv[r * 3 + 1] * Jres[1]) + Hinv[r * 3 + 2] * Jres[2];
+    u = (float)(u + update[0] * dir0);
+    v = (float)(v + update[0] * dir1);
+    mean_diff += update[1];
+    alpha += update[2];
+    if (update[0] * update[0] < min_update_squared) { converged = true; break; }
+  }
+  px = u;
+  py = v;
+  return converged;
+}
+
+// feature_alignment.cpp:212-391
+__device__ bool align_2d(const DevImage& cur_img, const unsigned char* pwb, int n_iter, bool affine_est_offset,
+                         bool affine_est_gain, double& px, double& py)
+{
+  constexpr int halfpatch_size_ = 4, patch_size_ = 8, ref_step = 10;
+  bool converged = false;
+  float H[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  for (int y = 0; y < patch_size_; ++y) {
+    const unsigned char* it = pwb + (y + 1) * ref_step + 1;
+    for (int x = 0; x < patch_size_; ++x, ++it) {
+      float J[4];
+      J[0] = (float)(0.5 * ((int)it[1] - (int)it[-1]));
+      J[1] = (float)(0.5 * ((int)it[ref_step] - (int)it[-ref_step]));
+      J[2] = affine_est_offset ? 1.0f : 0.0f;
+      J[3] = affine_est_gain ? (float)(-1.0 * it[0]) : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) H[r * 4 + c] += J[r] * J[c];
+    }
+  }
+  if (!affine_est_offset) H[10] = 1.0f;
+  if (!affine_est_gain) H[15] = 1.0f;
+  float Hinv[16];
+  mat4f_inverse(H, Hinv);
+  float mean_diff = 0;
+  float alpha = 1.0;
+  float u = (float)px;
+  float v = (float)py;
+  const float min_update_squared = (float)(0.03 * 0.03);
+  const int cur_step = cur_img.pitch;
+  for (int iter = 0; iter < n_iter; ++iter) {
+    const int u_r = (int)floorf(u);
+    const int v_r = (int)floorf(v);
+    if (u_r < halfpatch_size_ || v_r < halfpatch_size_ || u_r >= cur_img.w - halfpatch_size_ || v_r >= cur_img.h - halfpatch_size_)
+      break;
+    if (u != u || v != v) return false;
+    const float subpix_x = u - u_r;
+    const float subpix_y = v - v_r;
+    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
+    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
+    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
+    const float wBR = subpix_x * subpix_y;
+    float Jres[4] = { 0, 0, 0, 0 };
+    for (int y = 0; y < patch_size_; ++y) {
+      const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + y - halfpatch_size_) * cur_step + u_r - halfpatch_size_;
+      const unsigned char* rp = pwb + (y + 1) * ref_step + 1;
+      for (int x = 0; x < patch_size_; ++x, ++it, ++rp) {
+        const float ref_dx = (float)(0.5 * ((int)rp[1] - (int)rp[-1]));
+        const float ref_dy = (float)(0.5 * ((int)rp[ref_step] - (int)rp[-ref_step]));
+        const float search_pixel = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
+        const float res = search_pixel - alpha * rp[0] + mean_diff;
+        Jres[0] -= res * ref_dx;
+        Jres[1] -= res * ref_dy;
+        if (affine_est_offset) Jres[2] -= res;
+        if (affine_est_gain) Jres[3] -= (-1) * res * rp[0];
+      }
+    }
+    if (!affine_est_offset) Jres[2] = 0.0f;
+    if (!affine_est_gain) Jres[3] = 0.0f;
+    float update[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      update[r] = ((Hinv[r * 4 + 0] * Jres[0] + Hinv[r * 4 + 1] * Jres[1]) + Hinv[r * 4 + 2] * Jres[2]) + Hinv[r * 4 + 3] * Jres[3];
+    u += update[0];
+    v += update[1];
+    mean_diff += update[2];
+    alpha += update[3];
+    if (update[0] * update[0] + update[1] * update[1] < min_update_squared) { converged = true; break; }
+  }
+  px = u;
+  py = v;
+  return converged;
+}
+
+__device__ __forceinline__ Rigid T_cur_ref_of(const DevFrameView& ref, const DevFrameView& cur)
+{
+  return mul(cur.T_f_w, inverse(ref.T_f_w));
+}
+
+// matcher.cpp:31-141
+__device__ int find_match_direct(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
+                                 const DevFrameView& cur_frame, double pxr, double pyr, const Vec3& f_ref, double gx,
+                                 double gy, int level, int type, double ref_depth, double& pcx, double& pcy)
+{
+  constexpr int kHalfPatchSize = 4, kPatchSize = 8;
+  const int pxi0 = (int)pxr / (1 << level), pxi1 = (int)pyr / (1 << level);
+  const int boundary = kHalfPatchSize + 2;
+  if (pxi0 < boundary || pxi1 < boundary || pxi0 >= (int)(ref_frame.cam.width / (1 << level)) - boundary ||
+      pxi1 >= (int)(ref_frame.cam.height / (1 << level)) - boundary)
+    return SVOH_MATCH_FAIL_VISIBILITY;
+  const Rigid T_cur_ref = T_cur_ref_of(ref_frame, cur_frame);
+  get_warp_matrix_affine(ref_frame.cam, cur_frame.cam, pxr, pyr, f_ref, ref_depth, T_cur_ref, level, m.A);
+  m.search_level = get_best_search_level(m.A, ref_frame.n_levels - 1);
+  if (!warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb)) return SVOH_MATCH_FAIL_WARP;
+  double sx = pcx / (1 << m.search_level), sy = pcy / (1 << m.search_level);
+  const double sx0 = sx, sy0 = sy;
+  bool ok;
+  if (is_edgelet(type)) {
+    double d0 = m.A[0] * gx + m.A[2] * gy, d1 = m.A[1] * gx + m.A[3] * gy;
+    normalize2(d0, d1);
+    ok = align_1d(cur_frame.lv[m.search_level], d0, d1, m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
+                  opt.affine_est_gain != 0, sx, sy, &m.h_inv);
+  } else {
+    ok = align_2d(cur_frame.lv[m.search_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
+                  opt.affine_est_gain != 0, sx, sy);
+  }
+  if (!ok) return SVOH_MATCH_FAIL_ALIGNMENT;
+  const double dx = sx - sx0, dy = sy - sy0;
+  if (sqrt(dx * dx + dy * dy) > opt.max_patch_diff_ratio * kPatchSize) return SVOH_MATCH_FAIL_TOO_FAR;
+  pcx = sx * (1 << m.search_level);
+  pcy = sy * (1 << m.search_level);
+  m.px_cur[0] = pcx; m.px_cur[1] = pcy;
+  m.f_cur = back_project3(cur_frame.cam, pcx, pcy);
+  normalize3(m.f_cur);
+  return SVOH_MATCH_SUCCESS;
+}
+
+// matcher.cpp:262-289
+__device__ int find_local_match(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& frame, double dir0,
+                                double dir1, int patch_level, double& pcx, double& pcy)
+{
+  double sx = pcx / (1 << patch_level), sy = pcy / (1 << patch_level);
+  bool res;
+  if (m.align_1d)
+    res = align_1d(frame.lv[patch_level], dir0, dir1, m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
+                   opt.affine_est_gain != 0, sx, sy, &m.h_inv);
+  else
+    res = align_2d(frame.lv[patch_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0, opt.affine_est_gain != 0,
+                   sx, sy);
+  if (!res) return SVOH_MATCH_FAIL_ALIGNMENT;
+  pcx = sx * (1 << patch_level);
+  pcy = sy * (1 << patch_level);
+  return SVOH_MATCH_SUCCESS;
+}
+
+__device__ __forceinline__ bool is_patch_within_image(const DevFrameView& frame, int px, int py, int patch_level)
+{
+  constexpr int kPatchSize = 8;
+  return !(px < kPatchSize || py < kPatchSize || px >= ((int)(frame.cam.width / (1 << patch_level)) - kPatchSize) ||
+           py >= ((int)(frame.cam.height / (1 << patch_level)) - kPatchSize));
+}
+
+__device__ __forceinline__ bool update_zmssd(const DevFrameView& frame, int px, int py, int patch_level,
+                                             const unsigned char* pwb, int sumA, int sumAA, int& zmssd_best)
+{
+  const DevImage& im = frame.lv[patch_level];
+  const uint8_t* cur_patch_ptr = im.data + (ptrdiff_t)(py - 4) * im.pitch + (px - 4);
+  const int z = zmssd_score(pwb, sumA, sumAA, cur_patch_ptr, im.pitch);
+  if (z < zmssd_best) { zmssd_best = z; return true; }
+  return false;
+}
+
+// matcher.cpp:340-413
+__device__ void scan_epipolar_unit_plane(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& frame,
+                                         const Vec3& A, const Vec3& B, const Vec3& C, int patch_level, int sumA, int sumAA,
+                                         double& bx, double& by, int& zmssd_best)
+{
+  size_t n_steps = (size_t)(m.epi_length_pyramid / 0.7);
+  double step0 = (A.x / A.z - B.x / B.z) / n_steps, step1 = (A.y / A.z - B.y / B.z) / n_steps;
+  if (n_steps > (size_t)opt.max_epi_search_steps) n_steps = (size_t)opt.max_epi_search_steps;
+  const double uvC0 = C.x / C.z, uvC1 = C.y / C.z;
+  double uv0 = uvC0, uv1 = uvC1;
+  double best0 = uv0, best1 = uv1;
+  bool forward = true;
+  int last0 = 0, last1 = 0;
+  for (size_t i = 0; i < n_steps; ++i, uv0 += step0, uv1 += step1) {
+    double px, py;
+    const Vec3 p3 = { uv0, uv1, 1.0 };
+    project3(frame.cam, p3, px, py);
+    const int pxi0 = (int)(px / (1 << patch_level) + 0.5), pxi1 = (int)(py / (1 << patch_level) + 0.5);
+    if (pxi0 == last0 && pxi1 == last1) continue;
+    last0 = pxi0; last1 = pxi1;
+    if (!is_patch_within_image(frame, pxi0, pxi1, patch_level)) {
+      if (forward) {
+        i = (size_t)(n_steps * 0.5);
+        step0 = -step0; step1 = -step1;
+        uv0 = uvC0; uv1 = uvC1;
+        forward = false;
+        continue;
+      } else
+        break;
+    }
+    if (update_zmssd(frame, pxi0, pxi1, patch_level, m.pwb, sumA, sumAA, zmssd_best)) { best0 = uv0; best1 = uv1; }
+    if (forward && i > n_steps * 0.5) {
+      step0 = -step0; step1 = -step1;
+      uv0 = uvC0; uv1 = uvC1;
+      forward = false;
+    }
+  }
+  const Vec3 p3 = { best0, best1, 1.0 };
+  project3(frame.cam, p3, bx, by);
+}
+
+// Eigen AngleAxis::toRotationMatrix() * v
+__device__ Vec3 angle_axis_rotate(const Vec3& axis, double angle, const Vec3& v)
+{
+  const double s = sin(angle), c = cos(angle);
+  const double sa0 = s * axis.x, sa1 = s * axis.y, sa2 = s * axis.z;
+  const double c0 = (1.0 - c) * axis.x, c1 = (1.0 - c) * axis.y, c2 = (1.0 - c) * axis.z;
+  double R[9];
+  double tmp;
+  tmp = c0 * axis.y; R[1] = tmp - sa2; R[3] = tmp + sa2;
+  tmp = c0 * axis.z; R[2] = tmp + sa1; R[6] = tmp - sa1;
+  tmp = c1 * axis.z; R[5] = tmp - sa0; R[7] = tmp + sa0;
+  R[0] = c0 * axis.x + c; R[4] = c1 * axis.y + c; R[8] = c2 * axis.z + c;
+  Vec3 o;
+  o.x = (R[0] * v.x + R[1] * v.y) + R[2] * v.z;
+  o.y = (R[3] * v.x + R[4] * v.y) + R[5] * v.z;
+  o.z = (R[6] * v.x + R[7] * v.y) + R[8] * v.z;
+  return o;
+}
+
+// matcher.cpp:415-488
+__device__ void scan_epipolar_unit_sphere(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& frame,
+                                          const Vec3& A, const Vec3& B, const Vec3& C, int patch_level, int sumA, int sumAA,
+                                          double& bx, double& by, int& zmssd_best)
+{
+  size_t n_steps = (size_t)(m.epi_length_pyramid / 0.7);
+  n_steps = n_steps > (size_t)opt.max_epi_search_steps ? (size_t)opt.max_epi_search_steps : n_steps;
+  const size_t half_steps = n_steps / 2;
+  Vec3 f_A = A, f_B = B, f_C = C;
+  normalize3(f_A); normalize3(f_B); normalize3(f_C);
+  const double step = acos((f_A.x * f_B.x + f_A.y * f_B.y) + f_A.z * f_B.z) / n_steps;
+  Vec3 axis = { f_B.y * f_A.z - f_B.z * f_A.y, f_B.z * f_A.x - f_B.x * f_A.z, f_B.x * f_A.y - f_B.y * f_A.x };
+  normalize3(axis);
+  Vec3 f = f_C, f_best = f_C;
+  int last0 = 0, last1 = 0;
+  for (size_t i = 0; i < n_steps; i++) {
+    double angle;
+    if (i < half_steps) angle = i * step;
+    else angle = (i - half_steps) * (-step);
+    f = angle_axis_rotate(axis, angle, f_C);
+    double px, py;
+    project3(frame.cam, f, px, py);
+    const int pxi0 = (int)(px / (1 << patch_level) + 0.5), pxi1 = (int)(py / (1 << patch_level) + 0.5);
+    if (pxi0 == last0 && pxi1 == last1) continue;
+    last0 = pxi0; last1 = pxi1;
+    if (!is_patch_within_image(frame, pxi0, pxi1, patch_level)) {
+      if (i < half_steps) { i = half_steps; continue; }
+      else break;
+    }
+    if (update_zmssd(frame, pxi0, pxi1, patch_level, m.pwb, sumA, sumAA, zmssd_best)) f_best = f;
+  }
+  project3(frame.cam, f_best, bx, by);
+}
+
+// matcher.cpp:492-505
+__device__ int depth_from_triangulation(const Rigid& T_search_ref, const Vec3& f_ref, const Vec3& f_cur, double& depth)
+{
+  const Vec3 a = rotate(T_search_ref.q, f_ref);
+  const Vec3& b = f_cur;
+  const double AtA[4] = { (a.x * a.x + a.y * a.y) + a.z * a.z, (b.x * a.x + b.y * a.y) + b.z * a.z,
+                          (a.x * b.x + a.y * b.y) + a.z * b.z, (b.x * b.x + b.y * b.y) + b.z * b.z };
+  if (AtA[0] * AtA[3] - AtA[1] * AtA[2] < 0.000001) return SVOH_MATCH_FAIL_TRIANGULATION;
+  double inv[4];
+  mat2d_inverse(AtA, inv);
+  const double m0 = (-inv[0]) * a.x + (-inv[2]) * b.x;
+  const double m1 = (-inv[0]) * a.y + (-inv[2]) * b.y;
+  const double m2 = (-inv[0]) * a.z + (-inv[2]) * b.z;
+  const double d0 = (m0 * T_search_ref.t.x + m1 * T_search_ref.t.y) + m2 * T_search_ref.t.z;
+  depth = fabs(d0);
+  return SVOH_MATCH_SUCCESS;
+}
+
+// matcher.cpp:157-241
+__device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
+                                          const DevFrameView& cur_frame, const Rigid& T_cur_ref, double pxr, double pyr,
+                                          const Vec3& f_ref, double gx, double gy, int level, int type,
+                                          double d_estimate_inv, double d_min_inv, double d_max_inv, double& depth)
+{
+  constexpr int ZMSSD_THRESHOLD = 2000 * 64;
+  int zmssd_best = ZMSSD_THRESHOLD;
+  const Vec3 Rf = rotate(T_cur_ref.q, f_ref);
+  const Vec3 A = { Rf.x + T_cur_ref.t.x * d_min_inv, Rf.y + T_cur_ref.t.y * d_min_inv, Rf.z + T_cur_ref.t.z * d_min_inv };
+  const Vec3 B = { Rf.x + T_cur_ref.t.x * d_max_inv, Rf.y + T_cur_ref.t.y * d_max_inv, Rf.z + T_cur_ref.t.z * d_max_inv };
+  double pAx, pAy, pBx, pBy;
+  project3(cur_frame.cam, A, pAx, pAy);
+  project3(cur_frame.cam, B, pBx, pBy);
+  m.epi_image[0] = pAx - pBx;
+  m.epi_image[1] = pAy - pBy;
+  get_warp_matrix_affine(ref_frame.cam, cur_frame.cam, pxr, pyr, f_ref, 1.0 / fmax(0.000001, d_estimate_inv), T_cur_ref,
+                         level, m.A);
+  m.reject = false;
+  if (is_edgelet(type) && opt.epi_search_edgelet_filtering) {
+    double g0 = m.A[0] * gx + m.A[2] * gy, g1 = m.A[1] * gx + m.A[3] * gy;
+    normalize2(g0, g1);
+    double e0 = m.epi_image[0], e1 = m.epi_image[1];
+    normalize2(e0, e1);
+    const double cosangle = fabs(g0 * e0 + g1 * e1);
+    if (cosangle < opt.epi_search_edgelet_max_angle) {
+      m.reject = true;
+      return SVOH_MATCH_FAIL_ANGLE;
+    }
+  }
+  m.search_level = get_best_search_level(m.A, ref_frame.n_levels - 1);
+  m.epi_length_pyramid = sqrt(m.epi_image[0] * m.epi_image[0] + m.epi_image[1] * m.epi_image[1]) / (1 << m.search_level);
+  double ed0 = m.epi_image[0], ed1 = m.epi_image[1];
+  normalize2(ed0, ed1);
+  if (!warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb)) return SVOH_MATCH_FAIL_WARP;
+
+  if (m.epi_length_pyramid < 2.0) {
+    m.px_cur[0] = (pAx + pBx) / 2.0;
+    m.px_cur[1] = (pAy + pBy) / 2.0;
+    const int res = find_local_match(m, opt, cur_frame, ed0, ed1, m.search_level, m.px_cur[0], m.px_cur[1]);
+    if (res != SVOH_MATCH_SUCCESS) return res;
+    m.f_cur = back_project3(cur_frame.cam, m.px_cur[0], m.px_cur[1]);
+    normalize3(m.f_cur);
+    return depth_from_triangulation(T_cur_ref, f_ref, m.f_cur, depth);
+  }
+
+  // PatchScore constructor (patch_score.h:80-92)
+  int sumA = 0, sumAA = 0;
+  for (int r = 0; r < 64; ++r) { const int n = patch_at(m.pwb, r); sumA += n; sumAA += n * n; }
+  const Vec3 C = { Rf.x + T_cur_ref.t.x * d_estimate_inv, Rf.y + T_cur_ref.t.y * d_estimate_inv,
+                   Rf.z + T_cur_ref.t.z * d_estimate_inv };
+  if (opt.scan_on_unit_sphere)
+    scan_epipolar_unit_sphere(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
+  else
+    scan_epipolar_unit_plane(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
+
+  if (zmssd_best < ZMSSD_THRESHOLD) {
+    if (opt.subpix_refinement) {
+      const int res = find_local_match(m, opt, cur_frame, ed0, ed1, m.search_level, m.px_cur[0], m.px_cur[1]);
+      if (res != SVOH_MATCH_SUCCESS) return res;
+    }
+    m.f_cur = back_project3(cur_frame.cam, m.px_cur[0], m.px_cur[1]);
+    normalize3(m.f_cur);
+    return depth_from_triangulation(T_cur_ref, f_ref, m.f_cur, depth);
+  }
+  return SVOH_MATCH_FAIL_SCORE;
+}
+
+// math_utils.h:186-194
+__device__ __forceinline__ double norm_pdf(double x, double mean, double sigma)
+{
+  double exponent = x - mean;
+  exponent *= -exponent;
+  exponent /= 2 * sigma * sigma;
+  double result = exp(exponent);
+  result /= sigma * sqrt(2 * 3.14159265358979323846);
+  return result;
+}
+
+// depth_filter.cpp:501-552
+__device__ bool update_filter_vogiatzis(double z, double tau2, double mu_range, double* st)
+{
+  double mu = st[0], sigma2 = st[1], a = st[2], b = st[3];
+  const double norm_scale = sqrt(sigma2 + tau2);
+  if (norm_scale != norm_scale) return false;
+  const double oldsigma2 = sigma2;
+  const double s2 = 1.0 / (1.0 / sigma2 + 1.0 / tau2);
+  const double mm = s2 * (mu / sigma2 + z / tau2);
+  const double uniform_x = 1.0 / mu_range;
+  double C1 = a / (a + b) * norm_pdf(z, mu, norm_scale);
+  double C2 = b / (a + b) * uniform_x;
+  const double normalization_constant = C1 + C2;
+  C1 /= normalization_constant;
+  C2 /= normalization_constant;
+  const double f = C1 * (a + 1.0) / (a + b + 1.0) + C2 * a / (a + b + 1.0);
+  const double e = C1 * (a + 1.0) * (a + 2.0) / ((a + b + 1.0) * (a + b + 2.0)) +
+                   C2 * a * (a + 1.0) / ((a + b + 1.0) * (a + b + 2.0));
+  const double mu_new = C1 * mm + C2 * mu;
+  sigma2 = C1 * (s2 + mm * mm) + C2 * (sigma2 + mu * mu) - mu_new * mu_new;
+  mu = mu_new;
+  a = (e - f) / (f - e / f);
+  b = a * (1.0 - f) / f;
+  bool ok = true;
+  if (sigma2 < 0.0) sigma2 = oldsigma2;
+  if (mu < 0.0) { mu = 1.0; ok = false; }
+  st[0] = mu; st[1] = sigma2; st[2] = a; st[3] = b;
+  return ok;
+}
+
+// depth_filter.cpp:554-578
+__device__ bool update_filter_gaussian(double z, double tau2, double* st)
+{
+  const double norm_scale = sqrt(st[1] + tau2);
+  if (norm_scale != norm_scale) return false;
+  const double denom = (st[1] + tau2);
+  st[0] = (st[1] * z + tau2 * st[0]) / denom;
+  st[1] = st[1] * tau2 / denom;
+  return true;
+}
+
+// depth_filter.cpp:580-596
+__device__ double compute_tau(const Rigid& T_ref_cur, const Vec3& f, double z, double px_error_angle)
+{
+  const Vec3& t = T_ref_cur.t;
+  const Vec3 a = { f.x * z - t.x, f.y * z - t.y, f.z * z - t.z };
+  const double t_norm = sqrt((t.x * t.x + t.y * t.y) + t.z * t.z);
+  const double a_norm = sqrt((a.x * a.x + a.y * a.y) + a.z * a.z);
+  const double alpha = acos(((f.x * t.x + f.y * t.y) + f.z * t.z) / t_norm);
+  const double beta = acos(((a.x * -t.x + a.y * -t.y) + a.z * -t.z) / (t_norm * a_norm));
+  const double beta_plus = beta + px_error_angle;
+  const double gamma_plus = 3.14159265358979323846 - alpha - beta_plus;
+  const double z_plus = t_norm * sin(beta_plus) / sin(gamma_plus);
+  return (z_plus - z);
+}
+
+__global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
+{
+  __shared__ unsigned char s_pwb[64 * kPwbStride];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  MatcherState m;
+  m.pwb = s_pwb + threadIdx.x * kPwbStride;
+  m.h_inv = 0.0; m.search_level = 0; m.reject = false; m.align_1d = false;
+  m.A[0] = m.A[1] = m.A[2] = m.A[3] = 0.0;
+  m.f_cur = { 0.0, 0.0, 0.0 };
+  const DevFrameView& ref = a.ref_frames[a.ref_frame_idx[i]];
+  const Vec3 f = { a.f[3 * i], a.f[3 * i + 1], a.f[3 * i + 2] };
+  double pcx = a.px_cur[2 * i], pcy = a.px_cur[2 * i + 1];
+  const int r = find_match_direct(m, a.mopt, ref, *a.cur_frame, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
+                                  a.grad[2 * i + 1], a.level[i], a.type[i], a.depth[i], pcx, pcy);
+  a.result[i] = r;
+  a.px_cur[2 * i] = pcx; a.px_cur[2 * i + 1] = pcy;
+  if (a.f_cur) { a.f_cur[3 * i] = m.f_cur.x; a.f_cur[3 * i + 1] = m.f_cur.y; a.f_cur[3 * i + 2] = m.f_cur.z; }
+  if (a.search_level) a.search_level[i] = m.search_level;
+  if (a.h_inv) a.h_inv[i] = m.h_inv;
+  if (a.A_cur_ref) for (int k = 0; k < 4; ++k) a.A_cur_ref[4 * i + k] = m.A[k];
+}
+
+// DepthFilter::updateSeeds (depth_filter.cpp:200-233) + depth_filter_utils::updateSeed (:367-499)
+__global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
+{
+  __shared__ unsigned char s_pwb[64 * kPwbStride];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  a.success[i] = 0;
+  if (a.result) a.result[i] = SVOH_MATCH_NOT_RUN;
+  const int type = a.type[i];
+  if (!(type < 6)) return;  // isSeed
+  double cur_thresh = a.dopt.seed_convergence_sigma2_thresh;
+  if (type == SVOH_FT_MAPPOINT_SEED || type == SVOH_FT_MAPPOINT_SEED_CONVERGED)
+    cur_thresh = a.dopt.mappoint_convergence_sigma2_thresh;
+  const DevFrameView& ref = a.ref_frames[a.ref_frame_idx[i]];
+  const DevFrameView& cur = *a.cur_frame;
+  if (cur.id == ref.id) return;
+  if (type == SVOH_FT_OUTLIER) return;
+  if ((type == SVOH_FT_CORNER_SEED_CONVERGED || type == SVOH_FT_EDGELET_SEED_CONVERGED ||
+       type == SVOH_FT_MAPPOINT_SEED_CONVERGED) && a.dopt.check_convergence)
+    return;
+  double st[4] = { a.state[4 * i], a.state[4 * i + 1], a.state[4 * i + 2], a.state[4 * i + 3] };
+  const Vec3 f = { a.f[3 * i], a.f[3 * i + 1], a.f[3 * i + 2] };
+  const Rigid T_cur_ref = T_cur_ref_of(ref, cur);
+  if (a.dopt.check_visibility) {
+    const double depth = 1.0 / st[0];
+    const Vec3 p = { depth * f.x, depth * f.y, depth * f.z };
+    double px, py;
+    project3(cur.cam, transform(T_cur_ref, p), px, py);
+    if (!(px >= 0.0 && py >= 0.0 && px < (double)cur.cam.width && py < (double)cur.cam.height)) return;
+    const int pxi0 = (int)px, pxi1 = (int)py;
+    const int boundary = 9;
+    if (!(pxi0 >= boundary && pxi1 >= boundary && pxi0 < cur.cam.width - boundary && pxi1 < cur.cam.height - boundary)) return;
+  }
+  MatcherState m;
+  m.pwb = s_pwb + threadIdx.x * kPwbStride;
+  m.h_inv = 0.0; m.search_level = 0; m.reject = false;
+  m.align_1d = (type == SVOH_FT_EDGELET_SEED || type == SVOH_FT_EDGELET_SEED_CONVERGED);
+  double depth = 0.0;
+  const double inv_min = st[0] + sqrt(st[1]);
+  const double inv_max = fmax(st[0] - sqrt(st[1]), 0.00000001);
+  const int res = find_epipolar_match_direct(m, a.mopt, ref, cur, T_cur_ref, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
+                                             a.grad[2 * i + 1], a.level[i], type, st[0], inv_min, inv_max, depth);
+  if (a.result) a.result[i] = res;
+  if (res != SVOH_MATCH_SUCCESS) {
+    if (!m.reject) a.state[4 * i + 3] = st[3] + 1;  // seed::increaseOutlierProbability
+    return;
+  }
+  const double depth_sigma = compute_tau(inverse(T_cur_ref), f, depth, a.dopt.px_error_angle);
+  const double z = 1.0 / depth;
+  const double sg = 0.5 * (1.0 / fmax(0.000000000001, depth - depth_sigma) - 1.0 / (depth + depth_sigma));
+  const double tau2 = sg * sg;
+  bool ok;
+  if (a.dopt.use_vogiatzis_update) ok = update_filter_vogiatzis(z, tau2, ref.seed_mu_range, st);
+  else ok = update_filter_gaussian(z, tau2, st);
+  a.state[4 * i] = st[0]; a.state[4 * i + 1] = st[1]; a.state[4 * i + 2] = st[2]; a.state[4 * i + 3] = st[3];
+  if (!ok) { a.type[i] = SVOH_FT_OUTLIER; return; }
+  const double thresh = ref.seed_mu_range / cur_thresh;
+  if (st[1] < thresh * thresh) {
+    if (type == SVOH_FT_CORNER_SEED) a.type[i] = SVOH_FT_CORNER_SEED_CONVERGED;
+    else if (type == SVOH_FT_EDGELET_SEED) a.type[i] = SVOH_FT_EDGELET_SEED_CONVERGED;
+    else if (type == SVOH_FT_MAPPOINT_SEED) a.type[i] = SVOH_FT_MAPPOINT_SEED_CONVERGED;
+  }
+  a.success[i] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+static int fill_view(svoh_ctx* ctx, const svoh_frame_view& v, DevFrameView* out, const char* what)
+{
+  const Frame* f = find_frame(ctx, v.frame);
+  if (!f) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "%s: unknown frame handle %llu", what, (unsigned long long)v.frame);
+  if (v.cam.distortion != SVOH_DISTORTION_NONE && v.cam.distortion != SVOH_DISTORTION_RADTAN)
+    return set_error(ctx, SVOH_ERR_UNSUPPORTED, "%s: unsupported distortion model", what);
+  for (int l = 0; l < SVOH_MAX_LEVELS; ++l) out->lv[l] = l < f->n_levels ? f->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
+  out->cam = load_camera(v.cam);
+  out->T_f_w = load_rigid(v.T_f_w);
+  out->seed_mu_range = v.seed_mu_range;
+  out->n_levels = f->n_levels;
+  out->id = v.id;
+  return SVOH_OK;
+}
+
+struct Staging {
+  std::vector<std::pair<const void*, size_t>> in;   // host source, bytes
+  std::vector<size_t> off;
+  size_t total = 0;
+  size_t add(const void* p, size_t bytes)
+  {
+    const size_t o = total;
+    in.emplace_back(p, bytes);
+    off.push_back(o);
+    total = (total + bytes + 63) & ~(size_t)63;
+    return o;
+  }
+};
+
+static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mopt, const svoh_depth_filter_options* dopt,
+                       int n_ref_frames, const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
+                       const svoh_feature_batch* fb, const double* depth, double* px_cur, int32_t* result, double* f_cur,
+                       int32_t* search_level, double* h_inv, double* A_cur_ref, double* state, uint8_t* success,
+                       int32_t* n_success)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, mopt && ref_frames && cur_frame && fb && n_ref_frames >= 1, "NULL argument");
+  const int n = fb->n;
+  if (n_success) *n_success = 0;
+  if (n <= 0) return SVOH_OK;
+  SVOH_REQUIRE(ctx, fb->ref_frame_idx && fb->px && fb->f && fb->grad && fb->level && fb->type, "NULL feature array");
+  if (seeds) SVOH_REQUIRE(ctx, dopt && state && success, "NULL seed argument");
+  else SVOH_REQUIRE(ctx, depth && px_cur && result, "NULL match argument");
+  for (int i = 0; i < n; ++i) {
+    SVOH_REQUIRE(ctx, fb->ref_frame_idx[i] >= 0 && fb->ref_frame_idx[i] < n_ref_frames, "ref_frame_idx out of range");
+    SVOH_REQUIRE(ctx, fb->level[i] >= 0 && fb->level[i] < SVOH_MAX_LEVELS, "feature level out of range");
+  }
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  std::vector<DevFrameView> views((size_t)n_ref_frames + 1);
+  for (int k = 0; k < n_ref_frames; ++k) {
+    int rc = fill_view(ctx, ref_frames[k], &views[k], "reference frame");
+    if (rc != SVOH_OK) return rc;
+  }
+  {
+    int rc = fill_view(ctx, *cur_frame, &views[n_ref_frames], "current frame");
+    if (rc != SVOH_OK) return rc;
+  }
+  for (int i = 0; i < n; ++i)
+    SVOH_REQUIRE(ctx, fb->level[i] < views[fb->ref_frame_idx[i]].n_levels, "feature level beyond the reference pyramid");
+
+  Staging s;
+  const size_t o_views = s.add(views.data(), sizeof(DevFrameView) * views.size());
+  const size_t o_idx = s.add(fb->ref_frame_idx, sizeof(int32_t) * n);
+  const size_t o_px = s.add(fb->px, sizeof(double) * 2 * n);
+  const size_t o_f = s.add(fb->f, sizeof(double) * 3 * n);
+  const size_t o_grad = s.add(fb->grad, sizeof(double) * 2 * n);
+  const size_t o_level = s.add(fb->level, sizeof(int32_t) * n);
+  const size_t o_type = s.add(fb->type, (size_t)n);
+  size_t o_depth = 0, o_pxcur = 0, o_state = 0;
+  if (seeds) o_state = s.add(state, sizeof(double) * 4 * n);
+  else { o_depth = s.add(depth, sizeof(double) * n); o_pxcur = s.add(px_cur, sizeof(double) * 2 * n); }
+  const size_t in_total = s.total;
+  // outputs (device only, appended)
+  auto out_add = [&](size_t bytes) { const size_t o = s.total; s.total = (s.total + bytes + 63) & ~(size_t)63; return o; };
+  const size_t o_result = out_add(sizeof(int32_t) * n);
+  const size_t o_fcur = out_add(sizeof(double) * 3 * n);
+  const size_t o_slevel = out_add(sizeof(int32_t) * n);
+  const size_t o_hinv = out_add(sizeof(double) * n);
+  const size_t o_A = out_add(sizeof(double) * 4 * n);
+  const size_t o_success = out_add((size_t)n);
+
+  SVOH_HIP_TRY(ctx, ctx->h_scratch1.reserve(s.total));
+  SVOH_HIP_TRY(ctx, ctx->d_scratch1.reserve(s.total));
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch1.ptr);
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch1.ptr);
+  for (size_t k = 0; k < s.in.size(); ++k) memcpy(h + s.off[k], s.in[k].first, s.in[k].second);
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
+
+  MatcherArgs a;
+  memset(&a, 0, sizeof a);
+  a.ref_frames = reinterpret_cast<const DevFrameView*>(d + o_views);
+  a.cur_frame = a.ref_frames + n_ref_frames;
+  a.mopt = *mopt;
+  if (dopt) a.dopt = *dopt;
+  a.n = n;
+  a.ref_frame_idx = reinterpret_cast<const int32_t*>(d + o_idx);
+  a.px = reinterpret_cast<const double*>(d + o_px);
+  a.f = reinterpret_cast<const double*>(d + o_f);
+  a.grad = reinterpret_cast<const double*>(d + o_grad);
+  a.level = reinterpret_cast<const int32_t*>(d + o_level);
+  a.type = d + o_type;
+  a.result = reinterpret_cast<int32_t*>(d + o_result);
+  a.f_cur = reinterpret_cast<double*>(d + o_fcur);
+  a.search_level = reinterpret_cast<int32_t*>(d + o_slevel);
+  a.h_inv = reinterpret_cast<double*>(d + o_hinv);
+  a.A_cur_ref = reinterpret_cast<double*>(d + o_A);
+  a.success = d + o_success;
+  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  if (seeds) {
+    a.state = reinterpret_cast<double*>(d + o_state);
+    hipLaunchKernelGGL(update_seeds_kernel, grid, block, 0, ctx->stream, a);
+  } else {
+    a.depth = reinterpret_cast<const double*>(d + o_depth);
+    a.px_cur = reinterpret_cast<double*>(d + o_pxcur);
+    hipLaunchKernelGGL(match_direct_kernel, grid, block, 0, ctx->stream, a);
+  }
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  // everything after the inputs that may have changed comes back in one copy
+  const size_t back_from = o_type;
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + back_from, d + back_from, s.total - back_from, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (seeds) {
+    memcpy(fb->type, h + o_type, (size_t)n);
+    memcpy(state, h + o_state, sizeof(double) * 4 * n);
+    memcpy(success, h + o_success, (size_t)n);
+    if (result) memcpy(result, h + o_result, sizeof(int32_t) * n);
+    if (n_success) {
+      int c = 0;
+      for (int i = 0; i < n; ++i) c += success[i];
+      *n_success = c;
+    }
+  } else {
+    memcpy(px_cur, h + o_pxcur, sizeof(double) * 2 * n);
+    memcpy(result, h + o_result, sizeof(int32_t) * n);
+    if (f_cur) memcpy(f_cur, h + o_fcur, sizeof(double) * 3 * n);
+    if (search_level) memcpy(search_level, h + o_slevel, sizeof(int32_t) * n);
+    if (h_inv) memcpy(h_inv, h + o_hinv, sizeof(double) * n);
+    if (A_cur_ref) memcpy(A_cur_ref, h + o_A, sizeof(double) * 4 * n);
+  }
+  return SVOH_OK;
+}
+
+}  // namespace svoh
+
+using namespace svoh;
+
+extern "C" {
+
+int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options, int n_ref_frames,
+                            const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
+                            const svoh_feature_batch* features, const double* depth, double* px_cur, int32_t* result,
+                            double* f_cur, int32_t* search_level, double* h_inv, double* A_cur_ref)
+{
+  return run_matcher(ctx, false, options, nullptr, n_ref_frames, ref_frames, cur_frame, features, depth, px_cur, result,
+                     f_cur, search_level, h_inv, A_cur_ref, nullptr, nullptr, nullptr);
+}
+
+int svoh_update_seeds_batch(svoh_ctx* ctx, const svoh_matcher_options* matcher_options,
+                            const svoh_depth_filter_options* options, int n_ref_frames,
+                            const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
+                            const svoh_feature_batch* features, double* state, uint8_t* success, int32_t* match_result,
+                            int32_t* n_success)
+{
+  return run_matcher(ctx, true, matcher_options, options, n_ref_frames, ref_frames, cur_frame, features, nullptr, nullptr,
+                     match_result, nullptr, nullptr, nullptr, nullptr, state, success, n_success);
+}
+
+}  // extern "C"

@@ -202,3 +202,71 @@ def make_align_problems(items, T_init=None, prior=None, alpha_init=0.0, beta_ini
         if prior is not None:
             pb.prior = prior[i] if isinstance(prior, (list, tuple)) else prior
     return arr, keep
+
+
+# ---- KLT / matcher / depth filter ------------------------------------------------
+
+def make_frame_view(frame_handle, cam, T_f_w, seed_mu_range=0.0, frame_id=0):
+    v = capi.svoh_frame_view()
+    v.frame = frame_handle
+    v.cam = _camera(cam)
+    v.T_f_w = _se3(T_f_w)
+    v.seed_mu_range = float(seed_mu_range)
+    v.id = int(frame_id)
+    return v
+
+
+def make_feature_batch(ref_frame_idx, px, f, grad, level, ftype):
+    arrs = dict(ref_frame_idx=np.ascontiguousarray(ref_frame_idx, np.int32), px=np.ascontiguousarray(px, np.float64),
+                f=np.ascontiguousarray(f, np.float64), grad=np.ascontiguousarray(grad, np.float64),
+                level=np.ascontiguousarray(level, np.int32), type=np.ascontiguousarray(ftype, np.uint8).copy())
+    fb = capi.svoh_feature_batch()
+    fb.n = int(arrs["level"].size)
+    for k, a in arrs.items():
+        setattr(fb, k, a.ctypes.data)
+    return fb, arrs
+
+
+def _klt_track_batch(self, opt, ref_frames, cur_frame, px_ref, px_cur):
+    n = len(px_ref) // 2
+    if isinstance(ref_frames, int):
+        ref_frames = [ref_frames] * n
+    rf = (capi.svoh_frame_t * max(n, 1))(*ref_frames)
+    px_ref = np.ascontiguousarray(px_ref, np.int32)
+    out = np.ascontiguousarray(px_cur, np.float64).copy()
+    status = np.zeros(max(n, 1), np.uint8)
+    self._check(self.lib.svoh_klt_track_batch(self.h, C.byref(opt), n, rf, cur_frame, px_ref.ctypes.data,
+                                              out.ctypes.data, status.ctypes.data))
+    return out, status[:n]
+
+
+def _match_direct_batch(self, mopt, ref_views, cur_view, fb, depth, px_cur):
+    n = fb.n
+    rv = (capi.svoh_frame_view * len(ref_views))(*ref_views)
+    depth = np.ascontiguousarray(depth, np.float64)
+    out = dict(px_cur=np.ascontiguousarray(px_cur, np.float64).copy(), result=np.zeros(n, np.int32),
+               f_cur=np.zeros(3 * n), search_level=np.zeros(n, np.int32), h_inv=np.zeros(n), A=np.zeros(4 * n))
+    self._check(self.lib.svoh_match_direct_batch(self.h, C.byref(mopt), len(ref_views), rv, C.byref(cur_view),
+                                                 C.byref(fb), depth.ctypes.data, out["px_cur"].ctypes.data,
+                                                 out["result"].ctypes.data, out["f_cur"].ctypes.data,
+                                                 out["search_level"].ctypes.data, out["h_inv"].ctypes.data,
+                                                 out["A"].ctypes.data))
+    return out
+
+
+def _update_seeds_batch(self, mopt, dopt, ref_views, cur_view, fb, state):
+    n = fb.n
+    rv = (capi.svoh_frame_view * len(ref_views))(*ref_views)
+    st = np.ascontiguousarray(state, np.float64).copy()
+    success = np.zeros(max(n, 1), np.uint8)
+    mr = np.zeros(max(n, 1), np.int32)
+    ns = C.c_int32()
+    self._check(self.lib.svoh_update_seeds_batch(self.h, C.byref(mopt), C.byref(dopt), len(ref_views), rv,
+                                                 C.byref(cur_view), C.byref(fb), st.ctypes.data, success.ctypes.data,
+                                                 mr.ctypes.data, C.byref(ns)))
+    return ns.value, st, success[:n], mr[:n]
+
+
+Context.klt_track_batch = _klt_track_batch
+Context.match_direct_batch = _match_direct_batch
+Context.update_seeds_batch = _update_seeds_batch

@@ -352,3 +352,65 @@ def make_align_scene(seed, n_features=2000, patch_size=4, cam=None, max_level=4,
     sc.T_icur_iref_init = SE3()
     sc.ref_pos = T_w_ref.t.copy()
     return sc
+
+
+# ----------------------------------------------------------------------------
+# KLT tracks and depth-filter seeds on top of an AlignScene
+# ----------------------------------------------------------------------------
+
+
+def make_track_set(sc, n_tracks=400, seed=0, margin=40):
+    """KLT-synth: integer reference pixels on a jittered grid, the
+    tracker's start value (= last position = reference pixel) and the true
+    position in the current frame."""
+    rng = np.random.RandomState(seed + 7919)
+    cam = sc.cam
+    nx = int(math.ceil(math.sqrt(n_tracks * cam.width / float(cam.height))))
+    ny = int(math.ceil(n_tracks / float(nx)))
+    gx, gy = np.meshgrid(np.arange(nx), np.arange(ny))
+    gx, gy = gx.ravel()[:n_tracks], gy.ravel()[:n_tracks]
+    w_in, h_in = cam.width - 2 * margin, cam.height - 2 * margin
+    px = np.stack([margin + (gx + rng.uniform(0.1, 0.9, gx.size)) * (w_in / float(nx)),
+                   margin + (gy + rng.uniform(0.1, 0.9, gy.size)) * (h_in / float(ny))])
+    px_ref = np.floor(px).astype(np.int32)                      # detector returns integer positions
+    x, y = cam.undistorted_xy(px_ref[0].astype(np.float64), px_ref[1].astype(np.float64))
+    ray = np.stack([x, y, np.ones_like(x)])
+    n_cam = sc.T_w_ref.R().T @ sc.plane.n
+    h_cam = sc.plane.h - float(sc.plane.n @ sc.T_w_ref.t)
+    lam = h_cam / (n_cam @ ray)
+    Xw = sc.T_w_ref.transform(ray * lam)
+    Xc = sc.T_w_cur.inverse().transform(Xw)
+    px_true = cam.project(Xc)
+    return dict(px_ref=np.ascontiguousarray(px_ref.T).ravel().copy(),
+                px_cur_init=np.ascontiguousarray(px_ref.T.astype(np.float64)).ravel().copy(),
+                px_true=np.ascontiguousarray(px_true.T).ravel().copy())
+
+
+def make_seed_set(sc, n_seeds=3000, seed=0, margin=30, edgelet_fraction=0.3, depth_noise=(0.7, 1.3),
+                  levels=(0, 1, 2)):
+    """C4-synth: seeds of a reference keyframe with inverse-depth state
+    [mu, sigma2, a, b] initialised like depth_filter_utils::initializeSeeds
+    (depth_filter.cpp:349-361): mu = 1/d_guess, sigma2 = mu_range^2/36, a = b = 10."""
+    rng = np.random.RandomState(seed + 104729)
+    cam = sc.cam
+    px = np.stack([rng.uniform(margin, cam.width - margin, n_seeds), rng.uniform(margin, cam.height - margin, n_seeds)])
+    px = np.floor(px)  # detector positions
+    x, y = cam.undistorted_xy(px[0], px[1])
+    ray = np.stack([x, y, np.ones_like(x)])
+    f = ray / np.linalg.norm(ray, axis=0, keepdims=True)
+    n_cam = sc.T_w_ref.R().T @ sc.plane.n
+    h_cam = sc.plane.h - float(sc.plane.n @ sc.T_w_ref.t)
+    dist = h_cam / (n_cam @ f)                                   # true depth along the bearing vector
+    d_min = float(dist.min()) * 0.5
+    mu_range = 1.0 / d_min                                       # seed::getMeanRangeFromDepthMinMax
+    mu0 = 1.0 / (dist * rng.uniform(depth_noise[0], depth_noise[1], n_seeds))
+    state = np.stack([mu0, np.full(n_seeds, mu_range * mu_range / 36.0), np.full(n_seeds, 10.0), np.full(n_seeds, 10.0)])
+    is_edge = rng.uniform(size=n_seeds) < edgelet_fraction
+    ftype = np.where(is_edge, 0, 1).astype(np.uint8)             # kEdgeletSeed / kCornerSeed
+    ang = rng.uniform(0, 2 * math.pi, n_seeds)
+    grad = np.stack([np.cos(ang), np.sin(ang)])
+    level = rng.choice(np.asarray(levels, dtype=np.int32), n_seeds).astype(np.int32)
+    return dict(px=np.ascontiguousarray(px.T).ravel().copy(), f=np.ascontiguousarray(f.T).ravel().copy(),
+                grad=np.ascontiguousarray(grad.T).ravel().copy(), level=level, type=ftype,
+                state=np.ascontiguousarray(state.T).ravel().copy(), mu_range=mu_range, true_depth=dist,
+                ref_frame_idx=np.zeros(n_seeds, np.int32))

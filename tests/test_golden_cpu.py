@@ -30,3 +30,35 @@ def test_oracle_reproduces_golden(oracle_lib, tag):
         assert list(res.iters) == list(z[q + "run_iters"]) and list(res.n_meas) == list(z[q + "run_nmeas"])
         assert helpers.se3_vec_diff(z[q + "run_T"], res.T_icur_iref) < 1e-12
         assert np.abs(np.array([res.alpha, res.beta]) - z[q + "run_ab"]).max() < 1e-10
+
+
+def _golden2_inputs(z):
+    from svo_pro_universal_amd import synth
+    c = z["cam"]
+    cam = synth.Camera(int(c[0]), int(c[1]), c[2], c[3], c[4], c[5], dist=list(c[6:10]))
+    return cam, synth.SE3.from7(z["T_ref_f_w"]), synth.SE3.from7(z["T_cur_f_w"])
+
+
+def test_oracle_reproduces_golden_klt_seeds(oracle_lib):
+    import os
+    orc = oracle_lib
+    z = np.load(os.path.join(os.path.dirname(helpers.GOLDEN), "klt_seeds_small.npz"))
+    cam, T_ref, T_cur = _golden2_inputs(z)
+    ref = orc.create_img_pyramid(z["img_ref"], 4); cur = orc.create_img_pyramid(z["img_cur"], 4)
+    kopt = capi.default_klt_options(max_level=3, patch_sizes=[16, 16, 8, 8])
+    p, s = orc.klt_track_batch(kopt, ref, cur, z["klt_px_ref"], z["klt_px_init"])
+    assert np.array_equal(s, z["klt_status"]) and np.array_equal(p, z["klt_px_out"])
+    mopt = capi.default_matcher_options()
+    dopt = capi.default_depth_filter_options(px_error_angle=float(z["seed_px_error_angle"][0]))
+    rv = orc.make_frame_view(ref, cam, T_ref, float(z["seed_mu_range"][0]), 1)
+    cv = orc.make_frame_view(cur, cam, T_cur, 0.0, 2)
+    n = z["seed_level"].size
+    fb, keep = orc.make_feature_batch(np.zeros(n, np.int32), z["seed_px"], z["seed_f"], z["seed_grad"], z["seed_level"], z["seed_type_in"])
+    ns, st, succ, mr = orc.update_seeds_batch(mopt, dopt, [rv], cv, fb, z["seed_state_in"])
+    assert np.array_equal(succ, z["seed_success"]) and np.array_equal(mr, z["seed_match_result"])
+    assert np.array_equal(keep["type"], z["seed_type_out"]) and np.allclose(st, z["seed_state_out"], rtol=1e-12, atol=0)
+    fb2, keep2 = orc.make_feature_batch(np.zeros(80, np.int32), z["seed_px"][:160], z["seed_f"][:240], z["seed_grad"][:160],
+                                        z["seed_level"][:80], z["direct_type"])
+    o = orc.match_direct_batch(mopt, [rv], cv, fb2, z["direct_depth"], z["direct_px_init"])
+    assert np.array_equal(o["result"], z["direct_result"]) and np.array_equal(o["search_level"], z["direct_search_level"])
+    assert np.abs(o["px_cur"] - z["direct_px_out"]).max() < 1e-9

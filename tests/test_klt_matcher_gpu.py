@@ -1,0 +1,194 @@
+"""GPU parity for a-9 (KLT) and a-10..a-14 (warp / ZMSSD / align / matcher / depth
+filter): HIP kernels through the C ABI vs the CPU oracle on the same seeded inputs.
+
+Bars: integer outputs (status, match result codes, search levels, feature types,
+success flags) exact; KLT positions bit-identical (its float part is evaluated in
+the same order on both sides and the per-pixel part is integer); matcher sub-pixel
+positions <= 1e-4 px; depth-filter state relative 1e-9 (libm vs device libm)."""
+import numpy as np
+import pytest
+
+from svo_pro_universal_amd import _capi as capi, frontend as fe, synth
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def scene_and_frames(gpu_ctx, orc, seed, cam=None, **kw):
+    sc = synth.make_align_scene(seed, n_features=10, cam=cam, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15), **kw)
+    ref = orc.create_img_pyramid(sc.img_ref, 5)
+    cur = orc.create_img_pyramid(sc.img_cur, 5)
+    fr = gpu_ctx.build_pyramid(sc.img_ref, 5)
+    fc = gpu_ctx.build_pyramid(sc.img_cur, 5)
+    return sc, ref, cur, fr, fc
+
+
+@pytest.mark.parametrize("cam_kind", ["pinhole", "radtan"])
+def test_klt_bit_identical(gpu_ctx, oracle_lib, cam_kind):
+    orc = oracle_lib
+    cam = synth.Camera.test_camera() if cam_kind == "pinhole" else synth.Camera.euroc_like()
+    sc, ref, cur, fr, fc = scene_and_frames(gpu_ctx, orc, 51, cam)
+    tr = synth.make_track_set(sc, 400, margin=6)   # some tracks start next to the border
+    for kw in (dict(), dict(min_level=2), dict(max_iter=3), dict(patch_sizes=[8, 8, 16, 16, 8]),
+               dict(min_update_squared=1e-6)):
+        opt = capi.default_klt_options(**kw)
+        po, so = orc.klt_track_batch(opt, ref, cur, tr["px_ref"], tr["px_cur_init"])
+        pg, sg = gpu_ctx.klt_track_batch(opt, fr, fc, tr["px_ref"], tr["px_cur_init"])
+        assert np.array_equal(so, sg)
+        assert np.array_equal(po, pg), np.abs(po - pg).max()
+        if not kw:
+            ok = so == 1
+            err = np.linalg.norm((pg - tr["px_true"]).reshape(-1, 2), axis=1)
+            assert ok.mean() > 0.9 and np.median(err[ok]) < 0.1
+
+
+def test_klt_per_track_reference_frames_and_edge_cases(gpu_ctx, oracle_lib):
+    orc = oracle_lib
+    sc, ref, cur, fr, fc = scene_and_frames(gpu_ctx, orc, 52)
+    sc2, ref2, cur2, fr2, fc2 = scene_and_frames(gpu_ctx, orc, 53)
+    tr = synth.make_track_set(sc, 64)
+    # half of the tracks take their template from another frame (klt_template_is_first_observation)
+    refs_o = [ref if i % 2 else ref2 for i in range(64)]
+    refs_g = [fr if i % 2 else fr2 for i in range(64)]
+    opt = capi.default_klt_options()
+    # start far away / outside the image / at the border
+    px0 = tr["px_cur_init"].copy().reshape(-1, 2)
+    px0[0] = [-50.0, 10.0]; px0[1] = [5000.0, 5000.0]; px0[2] = [0.0, 0.0]; px0[3] += 80.0
+    po, so = orc.klt_track_batch(opt, refs_o, cur, tr["px_ref"], px0.ravel())
+    pg, sg = gpu_ctx.klt_track_batch(opt, refs_g, fc, tr["px_ref"], px0.ravel())
+    assert np.array_equal(so, sg) and np.array_equal(po, pg)
+    assert so[1] == 0
+    # empty batch
+    pg, sg = gpu_ctx.klt_track_batch(opt, [], fc, np.zeros(0, np.int32), np.zeros(0))
+    assert pg.size == 0 and sg.size == 0
+    with pytest.raises(fe.SvohError) as e:
+        gpu_ctx.klt_track_batch(capi.default_klt_options(patch_sizes=[12, 16, 16, 8, 8]), fr, fc, tr["px_ref"], tr["px_cur_init"])
+    assert e.value.code == -5
+
+
+def views(gpu_ctx, orc, sc, ref, cur, fr, fc, mu_range):
+    ov_r = orc.make_frame_view(ref, sc.cam, sc.T_ref_f_w, mu_range, 1)
+    ov_c = orc.make_frame_view(cur, sc.cam, sc.T_cur_f_w_gt, 0.0, 2)
+    gv_r = fe.make_frame_view(fr, sc.cam, sc.T_ref_f_w, mu_range, 1)
+    gv_c = fe.make_frame_view(fc, sc.cam, sc.T_cur_f_w_gt, 0.0, 2)
+    return ov_r, ov_c, gv_r, gv_c
+
+
+@pytest.mark.parametrize("cam_kind", ["pinhole", "radtan"])
+@pytest.mark.parametrize("sphere", [0, 1])
+def test_update_seeds_parity(gpu_ctx, oracle_lib, cam_kind, sphere):
+    orc = oracle_lib
+    cam = synth.Camera.test_camera() if cam_kind == "pinhole" else synth.Camera.euroc_like()
+    sc, ref, cur, fr, fc = scene_and_frames(gpu_ctx, orc, 61, cam)
+    sd = synth.make_seed_set(sc, 3000, margin=12)
+    sd["type"][::17] = capi.FT_MAPPOINT_SEED
+    sd["type"][5::41] = capi.FT_CORNER        # not a seed: skipped
+    sd["type"][7::53] = capi.FT_OUTLIER
+    sd["type"][9::59] = capi.FT_EDGELET_SEED_CONVERGED
+    ov_r, ov_c, gv_r, gv_c = views(gpu_ctx, orc, sc, ref, cur, fr, fc, sd["mu_range"])
+    for mkw, dkw in ((dict(), dict()), (dict(affine_est_gain=1, max_epi_search_steps=500), dict(check_convergence=1)),
+                     (dict(subpix_refinement=0, affine_est_offset=0), dict(use_vogiatzis_update=0, check_visibility=0))):
+        mopt = capi.default_matcher_options(scan_on_unit_sphere=sphere, **mkw)
+        dopt = capi.default_depth_filter_options(sc.cam, **dkw)
+        fbo, ko = orc.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+        fbg, kg = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+        state_o, state_g = sd["state"], sd["state"]
+        for rnd in range(3):  # several updates, feeding the state back like successive frames do
+            nso, state_o, so, mro = orc.update_seeds_batch(mopt, dopt, [ov_r], ov_c, fbo, state_o)
+            nsg, state_g, sg, mrg = gpu_ctx.update_seeds_batch(mopt, dopt, [gv_r], gv_c, fbg, state_g)
+            assert nso == nsg and np.array_equal(so, sg)
+            assert np.array_equal(mro, mrg), np.nonzero(mro != mrg)
+            assert np.array_equal(ko["type"], kg["type"])
+            assert np.allclose(state_g, state_o, rtol=1e-9, atol=0)
+        assert nso > 1500
+        ok = so == 1
+        e = np.abs(1 / state_g.reshape(-1, 4)[ok, 0] - sd["true_depth"][ok]) / sd["true_depth"][ok]
+        assert np.median(e) < 0.03
+
+
+def test_seed_edge_cases(gpu_ctx, oracle_lib):
+    orc = oracle_lib
+    sc, ref, cur, fr, fc = scene_and_frames(gpu_ctx, orc, 62)
+    sd = synth.make_seed_set(sc, 200, margin=2)  # seeds right at the image border
+    ov_r, ov_c, gv_r, gv_c = views(gpu_ctx, orc, sc, ref, cur, fr, fc, sd["mu_range"])
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(sc.cam)
+    # same frame id -> every update is refused, state untouched
+    gv_same = fe.make_frame_view(fc, sc.cam, sc.T_cur_f_w_gt, 0.0, 1)
+    fbg, kg = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+    ns, st, succ, mr = gpu_ctx.update_seeds_batch(mopt, dopt, [gv_r], gv_same, fbg, sd["state"])
+    assert ns == 0 and np.array_equal(st, sd["state"]) and np.all(mr == capi.MATCH_NOT_RUN)
+    # border seeds + huge uncertainty + zero-translation (warp NaN path) against the oracle
+    state = sd["state"].copy().reshape(-1, 4)
+    state[::3, 1] *= 100.0
+    for T_cur in (sc.T_cur_f_w_gt, sc.T_ref_f_w):
+        ov_c2 = orc.make_frame_view(cur, sc.cam, T_cur, 0.0, 2)
+        gv_c2 = fe.make_frame_view(fc, sc.cam, T_cur, 0.0, 2)
+        fbo, ko = orc.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+        fbg, kg = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+        nso, sto, so, mro = orc.update_seeds_batch(mopt, dopt, [ov_r], ov_c2, fbo, state.ravel())
+        nsg, stg, sg, mrg = gpu_ctx.update_seeds_batch(mopt, dopt, [gv_r], gv_c2, fbg, state.ravel())
+        assert nso == nsg and np.array_equal(mro, mrg) and np.array_equal(ko["type"], kg["type"])
+        assert np.allclose(stg, sto, rtol=1e-9, atol=0, equal_nan=True)
+    # empty batch
+    fbe, ke = fe.make_feature_batch(np.zeros(0, np.int32), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0, np.int32),
+                                    np.zeros(0, np.uint8))
+    ns, st, succ, mr = gpu_ctx.update_seeds_batch(mopt, dopt, [gv_r], gv_c, fbe, np.zeros(0))
+    assert ns == 0
+
+
+@pytest.mark.parametrize("cam_kind", ["pinhole", "radtan"])
+def test_match_direct_parity(gpu_ctx, oracle_lib, cam_kind):
+    orc = oracle_lib
+    cam = synth.Camera.test_camera() if cam_kind == "pinhole" else synth.Camera.euroc_like()
+    sc, ref, cur, fr, fc = scene_and_frames(gpu_ctx, orc, 63, cam)
+    sd = synth.make_seed_set(sc, 2000, margin=3, levels=(0, 1, 2, 3))
+    ov_r, ov_c, gv_r, gv_c = views(gpu_ctx, orc, sc, ref, cur, fr, fc, sd["mu_range"])
+    x = sd["f"].reshape(-1, 3).T * sd["true_depth"]
+    px_true = sc.cam.project(sc.T_w_cur.inverse().transform(sc.T_w_ref.transform(x)))
+    px_init = np.ascontiguousarray((px_true + np.random.RandomState(1).uniform(-2.0, 2.0, px_true.shape)).T).ravel()
+    px_init[:20] += 40.0  # some hopeless starts -> alignment failures / too far
+    ftype = np.where(sd["type"] == 0, capi.FT_EDGELET, capi.FT_CORNER)
+    for mkw in (dict(), dict(affine_est_gain=1), dict(affine_est_offset=0, align_max_iter=3)):
+        mopt = capi.default_matcher_options(**mkw)
+        fbo, ko = orc.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+        fbg, kg = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+        oo = orc.match_direct_batch(mopt, [ov_r], ov_c, fbo, sd["true_depth"], px_init)
+        og = gpu_ctx.match_direct_batch(mopt, [gv_r], gv_c, fbg, sd["true_depth"], px_init)
+        assert np.array_equal(oo["result"], og["result"])
+        assert np.array_equal(oo["search_level"], og["search_level"])
+        assert np.abs(oo["px_cur"] - og["px_cur"]).max() <= 1e-4
+        ok = oo["result"] == 0
+        assert ok.sum() > 1000 and len(set(oo["result"])) >= 3  # successes and several failure kinds
+        assert np.allclose(oo["A"], og["A"], rtol=1e-12, atol=1e-14)
+        assert np.abs(oo["f_cur"] - og["f_cur"])[np.repeat(ok, 3)].max() < 1e-6
+        assert np.allclose(oo["h_inv"], og["h_inv"], rtol=1e-6)
+        e = np.linalg.norm(og["px_cur"].reshape(-1, 2)[ok] - px_true.T[ok], axis=1)
+        assert np.median(e) < 0.3
+
+
+def test_golden_klt_seeds_fixture(gpu_ctx):
+    """HIP path vs the committed fixture (no oracle call)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(helpers.GOLDEN), "klt_seeds_small.npz"))
+    c = z["cam"]
+    cam = synth.Camera(int(c[0]), int(c[1]), c[2], c[3], c[4], c[5], dist=list(c[6:10]))
+    T_ref, T_cur = synth.SE3.from7(z["T_ref_f_w"]), synth.SE3.from7(z["T_cur_f_w"])
+    fr = gpu_ctx.build_pyramid(z["img_ref"], 4); fc = gpu_ctx.build_pyramid(z["img_cur"], 4)
+    kopt = capi.default_klt_options(max_level=3, patch_sizes=[16, 16, 8, 8])
+    p, s = gpu_ctx.klt_track_batch(kopt, fr, fc, z["klt_px_ref"], z["klt_px_init"])
+    assert np.array_equal(s, z["klt_status"]) and np.array_equal(p, z["klt_px_out"])
+    mopt = capi.default_matcher_options()
+    dopt = capi.default_depth_filter_options(px_error_angle=float(z["seed_px_error_angle"][0]))
+    rv = fe.make_frame_view(fr, cam, T_ref, float(z["seed_mu_range"][0]), 1)
+    cv = fe.make_frame_view(fc, cam, T_cur, 0.0, 2)
+    n = z["seed_level"].size
+    fb, keep = fe.make_feature_batch(np.zeros(n, np.int32), z["seed_px"], z["seed_f"], z["seed_grad"], z["seed_level"], z["seed_type_in"])
+    ns, st, succ, mr = gpu_ctx.update_seeds_batch(mopt, dopt, [rv], cv, fb, z["seed_state_in"])
+    assert np.array_equal(succ, z["seed_success"]) and np.array_equal(mr, z["seed_match_result"])
+    assert np.array_equal(keep["type"], z["seed_type_out"]) and np.allclose(st, z["seed_state_out"], rtol=1e-9, atol=0)
+    fb2, keep2 = fe.make_feature_batch(np.zeros(80, np.int32), z["seed_px"][:160], z["seed_f"][:240], z["seed_grad"][:160],
+                                       z["seed_level"][:80], z["direct_type"])
+    o = gpu_ctx.match_direct_batch(mopt, [rv], cv, fb2, z["direct_depth"], z["direct_px_init"])
+    assert np.array_equal(o["result"], z["direct_result"]) and np.array_equal(o["search_level"], z["direct_search_level"])
+    assert np.abs(o["px_cur"] - z["direct_px_out"]).max() < 1e-4
