@@ -97,12 +97,192 @@ def cpu_baseline(scenes, imgs, opt, max_level, budget_s=15.0):
             "ms_per_frame": 1e3 * t_total / n_done}
 
 
+def timed_steps(ctx, dist, world, dev, step_fn, steps, warmup):
+    """W untimed + K timed steps between barriers; returns (elapsed_s, mean kernel ms, last result)."""
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    out = None
+    for _ in range(warmup):
+        out, _ = step_fn()
+    barrier()
+    ksum = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out, kms = step_fn()
+        ksum += kms
+    barrier()
+    return time.perf_counter() - t0, ksum / steps, out
+
+
+def misc_kernel_ms(ctx):
+    ms = ctypes.c_float()
+    ctx.lib.svoh_last_kernel_ms(ctx.h, ctypes.byref(ms))
+    return ms.value
+
+
+def misc_counters(ctx):
+    c = (ctypes.c_uint64 * 8)()
+    ctx.lib.svoh_last_kernel_counters(ctx.h, c)
+    return [int(x) for x in c]
+
+
+def render_pairs(ctx, dev, rank, B, max_level, **scene_kw):
+    cam = synth.Camera.test_camera()
+    scenes = [synth.make_align_scene(du.problem_seed(rank, i), n_features=8, cam=cam, max_level=max_level,
+                                     render_images=False, **scene_kw) for i in range(B)]
+    poses, planes, texs = [], [], []
+    for sc in scenes:
+        poses += [sc.T_w_ref, sc.T_w_cur]
+        planes += [sc.plane, sc.plane]
+        texs += [sc.tex, sc.tex]
+    imgs = synth.render_batch_torch(cam, poses, planes, texs, dev)
+    torch.cuda.synchronize()
+    frames = ctx.build_pyramid_batch_device(imgs.data_ptr(), cam.width * cam.height, 2 * B, cam.width, cam.height,
+                                            cam.width, max_level + 1)
+    ctx.synchronize()
+    return cam, scenes, imgs, frames
+
+
+def bench_klt(args, ctx, dist, rank, world, dev):
+    """KLT-synth: 400 tracks per frame pair, patches {16,16,16,8,8}, <=30 it, B pairs per step."""
+    B = args.problems or 256
+    NT = 400
+    cam, scenes, imgs, frames = render_pairs(ctx, dev, rank, B, 4, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))
+    opt = capi.default_klt_options()
+    tracks = [synth.make_track_set(sc, NT, seed=i) for i, sc in enumerate(scenes)]
+    px_ref = np.concatenate([t["px_ref"] for t in tracks]); px0 = np.concatenate([t["px_cur_init"] for t in tracks])
+    n = B * NT
+    rf = (capi.svoh_frame_t * n)(*[frames[2 * (i // NT)] for i in range(n)])
+    cf = (capi.svoh_frame_t * n)(*[frames[2 * (i // NT) + 1] for i in range(n)])
+    status = np.zeros(n, np.uint8)
+
+    def step():
+        out = px0.copy()
+        ctx._check(ctx.lib.svoh_klt_track_multi(ctx.h, ctypes.byref(opt), n, rf, cf, px_ref.ctypes.data, out.ctypes.data,
+                                                status.ctypes.data))
+        return (out, status.copy()), misc_kernel_ms(ctx)
+
+    elapsed, kms, (out, st) = timed_steps(ctx, dist, world, dev, step, args.steps, args.warmup)
+    cnt = misc_counters(ctx)
+    # SURVEY 8(d): per track-iteration (P+1)^2 + P^2 + 4 P^2 bytes; template build (P+2)^2 read per level
+    alg = cnt[0] * (17 * 17 + 5 * 256) + cnt[1] * (9 * 9 + 5 * 64) + cnt[2] * 18 * 18 + cnt[3] * 10 * 10
+    elapsed, total = du.combine(dist, world, elapsed, n, dev)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        orc.build(fast=True)
+        t_cpu, n_cpu = 0.0, 0
+        for i, sc in enumerate(scenes):
+            ref = orc.create_img_pyramid(imgs[2 * i].cpu().numpy(), 5, fast=True)
+            cur = orc.create_img_pyramid(imgs[2 * i + 1].cpu().numpy(), 5, fast=True)
+            t0 = time.perf_counter()
+            po, so = orc.klt_track_batch(opt, ref, cur, tracks[i]["px_ref"], tracks[i]["px_cur_init"], fast=True)
+            t_cpu += time.perf_counter() - t0
+            n_cpu += NT
+            assert np.array_equal(so, st[i * NT:(i + 1) * NT]) and np.array_equal(po, out[2 * i * NT:2 * (i + 1) * NT])
+            if t_cpu > 10.0:
+                break
+        cpu = {"value": n_cpu / t_cpu, "unit": "tracks/s", "cores": 1, "kind": "port",
+               "sample": "%d tracks of the benchmark (oracle alignPyr2D, gcc -O3 -march=native, 1 thread, %.1f s); "
+                         "GPU results bit-identical on the sample" % (n_cpu, t_cpu)}
+    if rank != 0:
+        return None
+    ok = st == 1
+    return {"metric": "KLT tracks/s (alignPyr2D, 400 tracks/frame, patches {16,16,16,8,8}, <=30 it)",
+            "value": total * args.steps / elapsed, "unit": "tracks/s", "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_frame": 1e3 * elapsed / args.steps / B, "dtype": "i32+f32",
+            "config": {"workload": "KLT-synth: %d frame pairs x %d tracks per GPU per step, 640x480, levels 4..0" % (B, NT),
+                       "frame_pairs_per_gpu": B, "tracks_per_frame": NT},
+            "kernel_ms": kms, "converged_fraction": float(ok.mean()),
+            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "klt_track_kernel",
+                         "algorithmic_bytes_per_launch": alg, "counters": cnt[:4]},
+            "cpu_baseline": cpu}
+
+
+def bench_seeds(args, ctx, dist, rank, world, dev):
+    """C4-synth: 3000 seeds per keyframe, 8x8 patches, epipolar ZMSSD scan (<=100 steps) +
+    align1D/2D + Vogiatzis update; B (keyframe, frame) pairs per step."""
+    B = args.problems or 64
+    NS = 3000
+    cam, scenes, imgs, frames = render_pairs(ctx, dev, rank, B, 4, rot_deg=(0.3, 1.0), trans_m=(0.05, 0.15))
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(cam)
+    seeds = [synth.make_seed_set(sc, NS, seed=i) for i, sc in enumerate(scenes)]
+    ref_views = [fe.make_frame_view(frames[2 * i], cam, sc.T_ref_f_w, seeds[i]["mu_range"], 2 * i) for i, sc in enumerate(scenes)]
+    cur_views = (capi.svoh_frame_view * B)(*[fe.make_frame_view(frames[2 * i + 1], cam, sc.T_cur_f_w_gt, 0.0, 2 * i + 1)
+                                             for i, sc in enumerate(scenes)])
+    idx = np.repeat(np.arange(B, dtype=np.int32), NS)
+    cat = lambda k: np.concatenate([s[k] for s in seeds])
+    fb, keep = fe.make_feature_batch(idx, cat("px"), cat("f"), cat("grad"), cat("level"), cat("type"))
+    fb.cur_frame_idx = idx.ctypes.data
+    fb.n_cur_frames = B
+    state0 = cat("state")
+    type0 = keep["type"].copy()
+    n = B * NS
+    rv = (capi.svoh_frame_view * B)(*ref_views)
+    success = np.zeros(n, np.uint8); mr = np.zeros(n, np.int32); ns = ctypes.c_int32()
+
+    def step():
+        st = state0.copy()
+        keep["type"][:] = type0
+        ctx._check(ctx.lib.svoh_update_seeds_batch(ctx.h, ctypes.byref(mopt), ctypes.byref(dopt), B, rv, cur_views,
+                                                   ctypes.byref(fb), st.ctypes.data, success.ctypes.data, mr.ctypes.data,
+                                                   ctypes.byref(ns)))
+        return (st, success.copy(), mr.copy()), misc_kernel_ms(ctx)
+
+    elapsed, kms, (st, succ, mres) = timed_steps(ctx, dist, world, dev, step, args.steps, args.warmup)
+    cnt = misc_counters(ctx)
+    # SURVEY 8(d): warp <= 11x11 B, scan 64+64 B per ZMSSD, align 81 B per iteration, state 32 B in + out
+    alg = cnt[0] * 121 + cnt[1] * 128 + cnt[2] * 81 + n * 32 + cnt[3] * 32
+    elapsed, total = du.combine(dist, world, elapsed, n, dev)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        orc.build(fast=True)
+        t_cpu, n_cpu = 0.0, 0
+        for i, sc in enumerate(scenes):
+            ref = orc.create_img_pyramid(imgs[2 * i].cpu().numpy(), 5, fast=True)
+            cur = orc.create_img_pyramid(imgs[2 * i + 1].cpu().numpy(), 5, fast=True)
+            ov_r = orc.make_frame_view(ref, cam, sc.T_ref_f_w, seeds[i]["mu_range"], 2 * i)
+            ov_c = orc.make_frame_view(cur, cam, sc.T_cur_f_w_gt, 0.0, 2 * i + 1)
+            sd = seeds[i]
+            fbo, ko = orc.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+            t0 = time.perf_counter()
+            nso, sto, so, mro = orc.update_seeds_batch(mopt, dopt, [ov_r], ov_c, fbo, sd["state"], fast=True)
+            t_cpu += time.perf_counter() - t0
+            n_cpu += NS
+            sl = slice(i * NS, (i + 1) * NS)
+            assert (mro != mres[sl]).mean() < 1e-3  # -O3 -march=native may contract FMAs: rare knife-edge flips allowed
+            if t_cpu > 10.0:
+                break
+        cpu = {"value": n_cpu / t_cpu, "unit": "seed updates/s", "cores": 1, "kind": "port",
+               "sample": "%d seeds of the benchmark (oracle updateSeed, gcc -O3 -march=native, 1 thread, %.1f s)" % (n_cpu, t_cpu)}
+    if rank != 0:
+        return None
+    return {"metric": "depth-filter seed updates/s (updateSeed: epipolar ZMSSD scan + align + Vogiatzis)",
+            "value": total * args.steps / elapsed, "unit": "seed updates/s", "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_frame": 1e3 * elapsed / args.steps / B, "dtype": "i32+f32+f64",
+            "config": {"workload": "C4-synth: %d (keyframe, frame) pairs x %d seeds per GPU per step, 640x480, 8x8 patches, "
+                                   "<=100 epipolar steps" % (B, NS), "frame_pairs_per_gpu": B, "seeds_per_keyframe": NS},
+            "kernel_ms": kms, "success_fraction": float(succ.mean()),
+            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "update_seeds_kernel",
+                         "algorithmic_bytes_per_launch": alg, "counters": cnt[:4]},
+            "cpu_baseline": cpu}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--problems", type=int, default=1024, help="frame pairs per GPU per step")
+    ap.add_argument("--problems", type=int, default=0, help="frame pairs per GPU per step (default: per workload)")
+    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds"],
+                    help="align = the headline SparseImgAlign config (default); klt / seeds = the other hot-path rows")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--patch", type=int, default=4)
     ap.add_argument("--min-level", type=int, default=0)
@@ -120,7 +300,17 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     ctx = fe.Context(local_rank)
-    P, N, B = args.patch, args.features, args.problems
+    if args.workload != "align":
+        out = (bench_klt if args.workload == "klt" else bench_seeds)(args, ctx, dist, rank, world, dev)
+        if rank == 0:
+            out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                        "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    P, N, B = args.patch, args.features, (args.problems or 1024)
     opt = capi.default_align_options(max_level=args.max_level, min_level=args.min_level, patch_size=P)
     problems, scenes, imgs, keep = build_problems(ctx, dev, rank, B, N, P, args.max_level)
 

@@ -262,6 +262,20 @@ int svoh_klt_track_batch(svoh_ctx* ctx, const svoh_klt_options* options, int n_t
                          const svoh_frame_t* ref_frames, svoh_frame_t cur_frame,
                          const int32_t* px_ref, double* px_cur, uint8_t* status);
 
+/* Same, with one current frame per track (cur_frames[i]): batches the tracks of
+ * many frame bundles / camera streams into one launch. */
+int svoh_klt_track_multi(svoh_ctx* ctx, const svoh_klt_options* options, int n_tracks,
+                         const svoh_frame_t* ref_frames, const svoh_frame_t* cur_frames,
+                         const int32_t* px_ref, double* px_cur, uint8_t* status);
+
+/* Device time (ms) of the last KLT / matcher / seed-update kernel of this context. */
+int svoh_last_kernel_ms(svoh_ctx* ctx, float* ms);
+/* Work counters of that kernel (for the roofline accounting of SURVEY.md 8(d)):
+ *   KLT:     [0] track-iterations at 16x16, [1] at 8x8, [2] templates built 16x16, [3] 8x8
+ *   matcher: [0] affine warps done, [1] ZMSSD evaluations, [2] align1D/2D iterations,
+ *            [3] seeds whose filter state was updated */
+int svoh_last_kernel_counters(svoh_ctx* ctx, uint64_t out[8]);
+
 /* ---- matcher and depth filter (a-10 ... a-14) -------------------------- */
 
 /* svo::FeatureType (src/svo_common/include/svo/common/types.h:60-73) */
@@ -316,6 +330,11 @@ typedef struct svoh_feature_batch {
   const double* grad;                     /* 2 x n  grad_vec_ */
   const int32_t* level;                   /* n      level_vec_ */
   uint8_t* type;                          /* n      type_vec_ (svoh_feature_type), updated by update_seeds */
+  /* optional multi-stream batching: feature i is matched into cur_frames[cur_frame_idx[i]];
+   * NULL / 0 = every feature uses cur_frames[0] (the reference's one-frame call) */
+  const int32_t* cur_frame_idx;           /* n or NULL */
+  int32_t n_cur_frames;                   /* length of the cur_frame array passed to the call (0 = 1) */
+  int32_t reserved2;
 } svoh_feature_batch;
 
 /* Replaces n calls of Matcher::findMatchDirect (src/svo_direct/src/matcher.cpp:31-141),

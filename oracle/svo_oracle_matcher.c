@@ -783,7 +783,8 @@ void orc_match_direct_batch(const svoh_matcher_options* options, int n_ref_frame
     memset(&m, 0, sizeof m);
     m.opt = *options;
     double p[2] = { px_cur[2 * i], px_cur[2 * i + 1] };
-    const int r = orc_find_match_direct(&m, &ref_frames[fb->ref_frame_idx[i]], cur_frame, &fb->px[2 * i], &fb->f[3 * i],
+    const orc_frame_view* cf = fb->cur_frame_idx ? &cur_frame[fb->cur_frame_idx[i]] : cur_frame;
+    const int r = orc_find_match_direct(&m, &ref_frames[fb->ref_frame_idx[i]], cf, &fb->px[2 * i], &fb->f[3 * i],
                                         &fb->grad[2 * i], fb->level[i], fb->type[i], depth[i], p);
     result[i] = r;
     px_cur[2 * i] = p[0]; px_cur[2 * i + 1] = p[1];
@@ -813,7 +814,8 @@ int orc_update_seeds_batch(const svoh_matcher_options* mopt, const svoh_depth_fi
     memset(&m, 0, sizeof m);
     m.opt = *mopt;
     int mr;
-    const int ok = orc_update_seed(&m, opt, cur_frame, &ref_frames[fb->ref_frame_idx[i]], &fb->px[2 * i], &fb->f[3 * i],
+    const orc_frame_view* cf = fb->cur_frame_idx ? &cur_frame[fb->cur_frame_idx[i]] : cur_frame;
+    const int ok = orc_update_seed(&m, opt, cf, &ref_frames[fb->ref_frame_idx[i]], &fb->px[2 * i], &fb->f[3 * i],
                                    &fb->grad[2 * i], fb->level[i], &fb->type[i], &state[4 * i], cur_thresh, &mr);
     if (match_result) match_result[i] = mr;
     success[i] = (uint8_t)ok;

@@ -33,6 +33,50 @@ const Frame* find_frame(const svoh_ctx* ctx, svoh_frame_t id)
   return it == ctx->frames.end() ? nullptr : &it->second;
 }
 
+int reset_counters(svoh_ctx* ctx, unsigned long long** out)
+{
+  SVOH_HIP_TRY(ctx, ctx->d_counters.reserve(8 * sizeof(unsigned long long)));
+  SVOH_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  *out = static_cast<unsigned long long*>(ctx->d_counters.ptr);
+  return SVOH_OK;
+}
+
+__global__ __launch_bounds__(256) void reduce_unit_counts_kernel(const unsigned int* __restrict__ counts, size_t n,
+                                                                  unsigned long long* __restrict__ out)
+{
+  unsigned long long acc[4] = { 0, 0, 0, 0 };
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint4 c = reinterpret_cast<const uint4*>(counts)[i];
+    acc[0] += c.x; acc[1] += c.y; acc[2] += c.z; acc[3] += c.w;
+  }
+  __shared__ unsigned long long s[4][4];
+  for (int k = 0; k < 4; ++k) {
+    unsigned long long v = acc[k];
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(&out[threadIdx.x], s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+
+int reserve_unit_counts(svoh_ctx* ctx, size_t n_units, unsigned int** out)
+{
+  SVOH_HIP_TRY(ctx, ctx->d_unit_counts.reserve(n_units * 4 * sizeof(unsigned int)));
+  SVOH_HIP_TRY(ctx, hipMemsetAsync(ctx->d_unit_counts.ptr, 0, n_units * 4 * sizeof(unsigned int), ctx->stream));
+  *out = static_cast<unsigned int*>(ctx->d_unit_counts.ptr);
+  return SVOH_OK;
+}
+
+int reduce_unit_counts(svoh_ctx* ctx, size_t n_units)
+{
+  const int blocks = (int)((n_units + 255) / 256 > 64 ? 64 : (n_units + 255) / 256);
+  hipLaunchKernelGGL(reduce_unit_counts_kernel, dim3(blocks), dim3(256), 0, ctx->stream,
+                     static_cast<const unsigned int*>(ctx->d_unit_counts.ptr), n_units,
+                     static_cast<unsigned long long*>(ctx->d_counters.ptr));
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  return SVOH_OK;
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // layout of one frame inside a slab: levels tightly packed (pitch == width),
@@ -169,6 +213,8 @@ int svoh_create(int device, svoh_ctx** out_ctx)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev_align_start);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev_align_stop);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev_misc_start);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev_misc_stop);
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
   if (e != hipSuccess) {
@@ -190,6 +236,8 @@ int svoh_destroy(svoh_ctx* ctx)
   ctx->frames.clear();
   if (ctx->ev_align_start) (void)hipEventDestroy(ctx->ev_align_start);
   if (ctx->ev_align_stop) (void)hipEventDestroy(ctx->ev_align_stop);
+  if (ctx->ev_misc_start) (void)hipEventDestroy(ctx->ev_misc_start);
+  if (ctx->ev_misc_stop) (void)hipEventDestroy(ctx->ev_misc_stop);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SVOH_OK;
@@ -208,6 +256,24 @@ int svoh_synchronize(svoh_ctx* ctx)
 }
 
 void* svoh_stream(svoh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int svoh_last_kernel_counters(svoh_ctx* ctx, uint64_t out[8])
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, out != nullptr && ctx->misc_timed && ctx->d_counters.ptr, "no counters yet");
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_counters.ptr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SVOH_OK;
+}
+
+int svoh_last_kernel_ms(svoh_ctx* ctx, float* ms)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, ms != nullptr && ctx->misc_timed, "no KLT / matcher / seed kernel has been launched yet");
+  SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_misc_stop));
+  SVOH_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_misc_start, ctx->ev_misc_stop));
+  return SVOH_OK;
+}
 
 int svoh_upload_pyramid(svoh_ctx* ctx, int n_levels, const uint8_t* const* level_data, const int* width,
                         const int* height, const int* pitch, svoh_frame_t* out_frame)

@@ -18,6 +18,7 @@
 // Memory per track-iteration: (P+1)^2 bytes of the current level (L2-resident).
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "svoh_internal.h"
@@ -25,13 +26,15 @@
 namespace svoh {
 
 struct KltArgs {
-  const DevImage* ref_levels;   // n_tracks x SVOH_MAX_LEVELS
-  DevImage cur_levels[SVOH_MAX_LEVELS];
+  const DevImage* frame_levels; // n_frames x SVOH_MAX_LEVELS (table of the distinct frames of this call)
+  const int32_t* ref_idx;       // n_tracks: row of frame_levels holding the template
+  const int32_t* cur_idx;       // n_tracks: row of frame_levels of the current frame
   svoh_klt_options opt;
   int n_tracks;
   const int32_t* px_ref;        // 2 x n
   double* px_cur;               // 2 x n, in/out
   uint8_t* status;              // n
+  unsigned int* unit_counts;    // 4 per track: iterations 16x16, 8x8, templates 16x16, 8x8
 };
 
 __device__ __forceinline__ int wave_sum_i32(int v)
@@ -46,7 +49,7 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 template <int P>
 __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage& img_cur, int level, int px_ref0_x,
                                          int px_ref0_y, int n_iter, float min_update_squared, double& pcx, double& pcy,
-                                         bool& converged, int lane)
+                                         bool& converged, int lane, int& n_iters, int& n_tmpl)
 {
   constexpr int PPL = P * P / 64;  // pixels per lane: 4 (16x16) or 1 (8x8)
   const int halfpatch_size = P / 2;
@@ -76,6 +79,7 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
       h11 += gdy[k] * gdy[k];
     }
   }
+  ++n_tmpl;
   const float H00 = (float)wave_sum_i32(h00), H01 = (float)wave_sum_i32(h01), H11 = (float)wave_sum_i32(h11);
   const float H10 = H01;
   // Eigen Matrix2f::inverse()
@@ -97,6 +101,7 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
       go_to_next_level = true;
       break;
     }
+    ++n_iters;
     const float subpix_x = u - u_r;
     const float subpix_y = v - v_r;
     const int wTL = (int)(unsigned short)((1.0f - subpix_x) * (1.0f - subpix_y) * 128);
@@ -132,25 +137,28 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
   return 0;
 }
 
-__global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs a)
+// blockDim.x / 64 tracks per workgroup (one wave each); waves never synchronise
+__global__ __launch_bounds__(256) void klt_track_kernel(const KltArgs a)
 {
-  const int t = blockIdx.x;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= a.n_tracks) return;
-  const int lane = threadIdx.x;
-  const DevImage* ref = a.ref_levels + (size_t)t * SVOH_MAX_LEVELS;
+  const int lane = threadIdx.x & 63;
+  const DevImage* ref = a.frame_levels + (size_t)a.ref_idx[t] * SVOH_MAX_LEVELS;
+  const DevImage* curl = a.frame_levels + (size_t)a.cur_idx[t] * SVOH_MAX_LEVELS;
   double pcx = a.px_cur[2 * t], pcy = a.px_cur[2 * t + 1];
   const int rx = a.px_ref[2 * t], ry = a.px_ref[2 * t + 1];
   bool converged = false;
   bool failed = false;
+  int it16 = 0, it8 = 0, t16 = 0, t8 = 0;
   for (int level = a.opt.max_level; level >= a.opt.min_level; --level) {
     const int P = a.opt.patch_sizes[level];
     int rc;
     if (P == 16)
-      rc = klt_level<16>(ref[level], a.cur_levels[level], level, rx, ry, a.opt.max_iter, a.opt.min_update_squared, pcx,
-                         pcy, converged, lane);
+      rc = klt_level<16>(ref[level], curl[level], level, rx, ry, a.opt.max_iter, a.opt.min_update_squared, pcx,
+                         pcy, converged, lane, it16, t16);
     else if (P == 8)
-      rc = klt_level<8>(ref[level], a.cur_levels[level], level, rx, ry, a.opt.max_iter, a.opt.min_update_squared, pcx,
-                        pcy, converged, lane);
+      rc = klt_level<8>(ref[level], curl[level], level, rx, ry, a.opt.max_iter, a.opt.min_update_squared, pcx,
+                        pcy, converged, lane, it8, t8);
     else if (P == 32)
       rc = 1;  // rejected on the host
     else
@@ -161,6 +169,7 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs a)
     a.px_cur[2 * t] = pcx;
     a.px_cur[2 * t + 1] = pcy;
     a.status[t] = (!failed && converged) ? 1 : 0;
+    reinterpret_cast<uint4*>(a.unit_counts)[t] = make_uint4((unsigned)it16, (unsigned)it8, (unsigned)t16, (unsigned)t8);
   }
 }
 
@@ -168,14 +177,14 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs a)
 
 using namespace svoh;
 
-extern "C" int svoh_klt_track_batch(svoh_ctx* ctx, const svoh_klt_options* options, int n_tracks,
-                                    const svoh_frame_t* ref_frames, svoh_frame_t cur_frame, const int32_t* px_ref,
-                                    double* px_cur, uint8_t* status)
+extern "C" int svoh_klt_track_multi(svoh_ctx* ctx, const svoh_klt_options* options, int n_tracks,
+                                    const svoh_frame_t* ref_frames, const svoh_frame_t* cur_frames,
+                                    const int32_t* px_ref, double* px_cur, uint8_t* status)
 {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, options && n_tracks >= 0, "bad arguments");
   if (n_tracks == 0) return SVOH_OK;
-  SVOH_REQUIRE(ctx, ref_frames && px_ref && px_cur && status, "NULL argument");
+  SVOH_REQUIRE(ctx, ref_frames && cur_frames && px_ref && px_cur && status, "NULL argument");
   SVOH_REQUIRE(ctx, options->max_level >= options->min_level && options->min_level >= 0 &&
                         options->max_level < SVOH_MAX_LEVELS && options->max_iter >= 1,
                "bad KLT level range / max_iter");
@@ -183,47 +192,97 @@ extern "C" int svoh_klt_track_batch(svoh_ctx* ctx, const svoh_klt_options* optio
     if (options->patch_sizes[l] != 8 && options->patch_sizes[l] != 16)
       return set_error(ctx, SVOH_ERR_UNSUPPORTED, "KLT patch size %d at level %d not built (8 and 16 are)",
                        options->patch_sizes[l], l);
-  const Frame* fc = find_frame(ctx, cur_frame);
-  if (!fc) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown current frame handle");
-  SVOH_REQUIRE(ctx, fc->n_levels > options->max_level, "current pyramid has too few levels");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-  const size_t lv_bytes = sizeof(DevImage) * SVOH_MAX_LEVELS * (size_t)n_tracks;
-  const size_t in_bytes = lv_bytes + sizeof(int32_t) * 2 * (size_t)n_tracks;
+  // table of the distinct frames + two indices per track
+  std::unordered_map<svoh_frame_t, int32_t> table;
+  std::vector<const Frame*> frames;
+  std::vector<int32_t> idx(2 * (size_t)n_tracks);
+  auto lookup = [&](svoh_frame_t hnd) -> int32_t {
+    auto it = table.find(hnd);
+    if (it != table.end()) return it->second;
+    const Frame* f = find_frame(ctx, hnd);
+    if (!f) return -1;
+    const int32_t k = (int32_t)frames.size();
+    frames.push_back(f);
+    table.emplace(hnd, k);
+    return k;
+  };
+  svoh_frame_t last_r = 0, last_c = 0;
+  int32_t ir = -1, ic = -1;
+  for (int i = 0; i < n_tracks; ++i) {
+    if (ir < 0 || ref_frames[i] != last_r) { ir = lookup(ref_frames[i]); last_r = ref_frames[i]; }
+    if (ic < 0 || cur_frames[i] != last_c) { ic = lookup(cur_frames[i]); last_c = cur_frames[i]; }
+    if (ir < 0 || ic < 0) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "track %d: unknown frame handle", i);
+    const Frame* fr = frames[ir];
+    const Frame* fc = frames[ic];
+    if (fr->n_levels <= options->max_level || fc->n_levels <= options->max_level)
+      return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "track %d: pyramid has too few levels", i);
+    for (int l = options->min_level; l <= options->max_level; ++l)
+      if (fr->lv[l].w != fc->lv[l].w || fr->lv[l].h != fc->lv[l].h)
+        return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "track %d: reference and current level %d differ in size", i, l);
+    idx[i] = ir;
+    idx[(size_t)n_tracks + i] = ic;
+  }
+  const size_t lv_bytes = (sizeof(DevImage) * SVOH_MAX_LEVELS * frames.size() + 63) & ~(size_t)63;
+  const size_t idx_bytes = (sizeof(int32_t) * 2 * (size_t)n_tracks + 63) & ~(size_t)63;
+  const size_t in_bytes = lv_bytes + idx_bytes + ((sizeof(int32_t) * 2 * (size_t)n_tracks + 63) & ~(size_t)63);
   const size_t io_bytes = sizeof(double) * 2 * (size_t)n_tracks + (size_t)n_tracks;
   SVOH_HIP_TRY(ctx, ctx->h_scratch0.reserve(in_bytes + io_bytes));
   SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(in_bytes + io_bytes));
   uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch0.ptr);
   uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch0.ptr);
   DevImage* hl = reinterpret_cast<DevImage*>(h);
-  for (int i = 0; i < n_tracks; ++i) {
-    const Frame* fr = find_frame(ctx, ref_frames[i]);
-    if (!fr) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "track %d: unknown reference frame handle", i);
-    if (fr->n_levels <= options->max_level)
-      return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "track %d: reference pyramid has too few levels", i);
+  for (size_t k = 0; k < frames.size(); ++k)
     for (int l = 0; l < SVOH_MAX_LEVELS; ++l)
-      hl[(size_t)i * SVOH_MAX_LEVELS + l] = l < fr->n_levels ? fr->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
-    for (int l = options->min_level; l <= options->max_level; ++l)
-      if (fr->lv[l].w != fc->lv[l].w || fr->lv[l].h != fc->lv[l].h)
-        return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "track %d: reference and current level %d differ in size", i, l);
-  }
-  memcpy(h + lv_bytes, px_ref, sizeof(int32_t) * 2 * (size_t)n_tracks);
+      hl[k * SVOH_MAX_LEVELS + l] = l < frames[k]->n_levels ? frames[k]->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
+  memcpy(h + lv_bytes, idx.data(), sizeof(int32_t) * 2 * (size_t)n_tracks);
+  memcpy(h + lv_bytes + idx_bytes, px_ref, sizeof(int32_t) * 2 * (size_t)n_tracks);
   memcpy(h + in_bytes, px_cur, sizeof(double) * 2 * (size_t)n_tracks);
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes + sizeof(double) * 2 * (size_t)n_tracks, hipMemcpyHostToDevice,
                                    ctx->stream));
   KltArgs args;
-  args.ref_levels = reinterpret_cast<const DevImage*>(d);
-  for (int l = 0; l < SVOH_MAX_LEVELS; ++l) args.cur_levels[l] = l < fc->n_levels ? fc->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
+  args.frame_levels = reinterpret_cast<const DevImage*>(d);
+  args.ref_idx = reinterpret_cast<const int32_t*>(d + lv_bytes);
+  args.cur_idx = args.ref_idx + n_tracks;
   args.opt = *options;
   args.n_tracks = n_tracks;
-  args.px_ref = reinterpret_cast<const int32_t*>(d + lv_bytes);
+  args.px_ref = reinterpret_cast<const int32_t*>(d + lv_bytes + idx_bytes);
   args.px_cur = reinterpret_cast<double*>(d + in_bytes);
   args.status = d + in_bytes + sizeof(double) * 2 * (size_t)n_tracks;
-  hipLaunchKernelGGL(klt_track_kernel, dim3(n_tracks), dim3(64), 0, ctx->stream, args);
+  {
+    unsigned long long* dummy;
+    int rc = reset_counters(ctx, &dummy);
+    if (rc == SVOH_OK) rc = reserve_unit_counts(ctx, (size_t)n_tracks, &args.unit_counts);
+    if (rc != SVOH_OK) return rc;
+  }
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  {
+    const char* e = getenv("SVOH_KLT_BLOCK");
+    int block = e ? atoi(e) : 256;
+    if (block != 64 && block != 128 && block != 256) block = 256;
+    const int tpb = block / 64;
+    hipLaunchKernelGGL(klt_track_kernel, dim3((n_tracks + tpb - 1) / tpb), dim3(block), 0, ctx->stream, args);
+  }
   SVOH_HIP_TRY(ctx, hipGetLastError());
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = true;
+  {
+    int rc = reduce_unit_counts(ctx, (size_t)n_tracks);
+    if (rc != SVOH_OK) return rc;
+  }
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + in_bytes, d + in_bytes, io_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(px_cur, h + in_bytes, sizeof(double) * 2 * (size_t)n_tracks);
   memcpy(status, h + in_bytes + sizeof(double) * 2 * (size_t)n_tracks, (size_t)n_tracks);
   return SVOH_OK;
+}
+
+extern "C" int svoh_klt_track_batch(svoh_ctx* ctx, const svoh_klt_options* options, int n_tracks,
+                                    const svoh_frame_t* ref_frames, svoh_frame_t cur_frame, const int32_t* px_ref,
+                                    double* px_cur, uint8_t* status)
+{
+  if (n_tracks <= 0) return n_tracks == 0 ? SVOH_OK : set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "negative n_tracks");
+  std::vector<svoh_frame_t> cur((size_t)n_tracks, cur_frame);
+  return svoh_klt_track_multi(ctx, options, n_tracks, ref_frames, cur.data(), px_ref, px_cur, status);
 }

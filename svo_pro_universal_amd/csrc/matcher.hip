@@ -47,6 +47,7 @@ struct MatcherArgs {
   svoh_depth_filter_options dopt;
   int n;
   const int32_t* ref_frame_idx;
+  const int32_t* cur_frame_idx;  // may be NULL
   const double* px;
   const double* f;
   const double* grad;
@@ -63,6 +64,7 @@ struct MatcherArgs {
   // seeds
   double* state;
   uint8_t* success;
+  unsigned int* unit_counts;  // 4 per feature: warps, ZMSSD evaluations, align iterations, filter updates
 };
 
 constexpr int kPwbStride = 100;
@@ -78,6 +80,7 @@ struct MatcherState {
   bool align_1d;
   double px_cur[2];
   Vec3 f_cur;
+  int n_warp, n_zmssd, n_align_it;  // work counters
 };
 
 __device__ __forceinline__ int patch_at(const unsigned char* pwb, int r) { return pwb[((r >> 3) + 1) * 10 + (r & 7) + 1]; }
@@ -228,7 +231,8 @@ __device__ void mat4f_inverse(const float* m, float* r)
 
 // feature_alignment.cpp:31-209
 __device__ bool align_1d(const DevImage& cur_img, double dir0, double dir1, const unsigned char* pwb, int n_iter,
-                         bool affine_est_offset, bool affine_est_gain, double& px, double& py, double* h_inv)
+                         bool affine_est_offset, bool affine_est_gain, double& px, double& py, double* h_inv,
+                         int& n_it)
 {
   constexpr int kHalfPatchSize = 4, kPatchSize = 8, ref_step = 10;
   bool converged = false;
@@ -265,6 +269,7 @@ __device__ bool align_1d(const DevImage& cur_img, double dir0, double dir1, cons
     if (u_r < kHalfPatchSize || v_r < kHalfPatchSize || u_r >= cur_img.w - kHalfPatchSize || v_r >= cur_img.h - kHalfPatchSize)
       break;
     if (u != u || v != v) return false;
+    ++n_it;
     const float subpix_x = u - u_r;
     const float subpix_y = v - v_r;
     const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
@@ -304,7 +309,7 @@ __device__ bool align_1d(const DevImage& cur_img, double dir0, double dir1, cons
 
 // feature_alignment.cpp:212-391
 __device__ bool align_2d(const DevImage& cur_img, const unsigned char* pwb, int n_iter, bool affine_est_offset,
-                         bool affine_est_gain, double& px, double& py)
+                         bool affine_est_gain, double& px, double& py, int& n_it)
 {
   constexpr int halfpatch_size_ = 4, patch_size_ = 8, ref_step = 10;
   bool converged = false;
@@ -339,6 +344,7 @@ __device__ bool align_2d(const DevImage& cur_img, const unsigned char* pwb, int 
     if (u_r < halfpatch_size_ || v_r < halfpatch_size_ || u_r >= cur_img.w - halfpatch_size_ || v_r >= cur_img.h - halfpatch_size_)
       break;
     if (u != u || v != v) return false;
+    ++n_it;
     const float subpix_x = u - u_r;
     const float subpix_y = v - v_r;
     const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
@@ -396,6 +402,7 @@ __device__ int find_match_direct(MatcherState& m, const svoh_matcher_options& op
   const Rigid T_cur_ref = T_cur_ref_of(ref_frame, cur_frame);
   get_warp_matrix_affine(ref_frame.cam, cur_frame.cam, pxr, pyr, f_ref, ref_depth, T_cur_ref, level, m.A);
   m.search_level = get_best_search_level(m.A, ref_frame.n_levels - 1);
+  ++m.n_warp;
   if (!warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb)) return SVOH_MATCH_FAIL_WARP;
   double sx = pcx / (1 << m.search_level), sy = pcy / (1 << m.search_level);
   const double sx0 = sx, sy0 = sy;
@@ -404,10 +411,10 @@ __device__ int find_match_direct(MatcherState& m, const svoh_matcher_options& op
     double d0 = m.A[0] * gx + m.A[2] * gy, d1 = m.A[1] * gx + m.A[3] * gy;
     normalize2(d0, d1);
     ok = align_1d(cur_frame.lv[m.search_level], d0, d1, m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
-                  opt.affine_est_gain != 0, sx, sy, &m.h_inv);
+                  opt.affine_est_gain != 0, sx, sy, &m.h_inv, m.n_align_it);
   } else {
     ok = align_2d(cur_frame.lv[m.search_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
-                  opt.affine_est_gain != 0, sx, sy);
+                  opt.affine_est_gain != 0, sx, sy, m.n_align_it);
   }
   if (!ok) return SVOH_MATCH_FAIL_ALIGNMENT;
   const double dx = sx - sx0, dy = sy - sy0;
@@ -428,10 +435,10 @@ __device__ int find_local_match(MatcherState& m, const svoh_matcher_options& opt
   bool res;
   if (m.align_1d)
     res = align_1d(frame.lv[patch_level], dir0, dir1, m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
-                   opt.affine_est_gain != 0, sx, sy, &m.h_inv);
+                   opt.affine_est_gain != 0, sx, sy, &m.h_inv, m.n_align_it);
   else
     res = align_2d(frame.lv[patch_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0, opt.affine_est_gain != 0,
-                   sx, sy);
+                   sx, sy, m.n_align_it);
   if (!res) return SVOH_MATCH_FAIL_ALIGNMENT;
   pcx = sx * (1 << patch_level);
   pcy = sy * (1 << patch_level);
@@ -485,6 +492,7 @@ __device__ void scan_epipolar_unit_plane(MatcherState& m, const svoh_matcher_opt
       } else
         break;
     }
+    ++m.n_zmssd;
     if (update_zmssd(frame, pxi0, pxi1, patch_level, m.pwb, sumA, sumAA, zmssd_best)) { best0 = uv0; best1 = uv1; }
     if (forward && i > n_steps * 0.5) {
       step0 = -step0; step1 = -step1;
@@ -544,6 +552,7 @@ __device__ void scan_epipolar_unit_sphere(MatcherState& m, const svoh_matcher_op
       if (i < half_steps) { i = half_steps; continue; }
       else break;
     }
+    ++m.n_zmssd;
     if (update_zmssd(frame, pxi0, pxi1, patch_level, m.pwb, sumA, sumAA, zmssd_best)) f_best = f;
   }
   project3(frame.cam, f_best, bx, by);
@@ -601,6 +610,7 @@ __device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_op
   m.epi_length_pyramid = sqrt(m.epi_image[0] * m.epi_image[0] + m.epi_image[1] * m.epi_image[1]) / (1 << m.search_level);
   double ed0 = m.epi_image[0], ed1 = m.epi_image[1];
   normalize2(ed0, ed1);
+  ++m.n_warp;
   if (!warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb)) return SVOH_MATCH_FAIL_WARP;
 
   if (m.epi_length_pyramid < 2.0) {
@@ -702,6 +712,11 @@ __device__ double compute_tau(const Rigid& T_ref_cur, const Vec3& f, double z, d
   return (z_plus - z);
 }
 
+__device__ __forceinline__ void flush_counters(unsigned int* c, int i, const MatcherState& m, int updated)
+{
+  reinterpret_cast<uint4*>(c)[i] = make_uint4((unsigned)m.n_warp, (unsigned)m.n_zmssd, (unsigned)m.n_align_it, (unsigned)updated);
+}
+
 __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
 {
   __shared__ unsigned char s_pwb[64 * kPwbStride];
@@ -710,12 +725,14 @@ __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
   MatcherState m;
   m.pwb = s_pwb + threadIdx.x * kPwbStride;
   m.h_inv = 0.0; m.search_level = 0; m.reject = false; m.align_1d = false;
+  m.n_warp = 0; m.n_zmssd = 0; m.n_align_it = 0;
   m.A[0] = m.A[1] = m.A[2] = m.A[3] = 0.0;
   m.f_cur = { 0.0, 0.0, 0.0 };
   const DevFrameView& ref = a.ref_frames[a.ref_frame_idx[i]];
   const Vec3 f = { a.f[3 * i], a.f[3 * i + 1], a.f[3 * i + 2] };
   double pcx = a.px_cur[2 * i], pcy = a.px_cur[2 * i + 1];
-  const int r = find_match_direct(m, a.mopt, ref, *a.cur_frame, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
+  const DevFrameView& curf = a.cur_frame[a.cur_frame_idx ? a.cur_frame_idx[i] : 0];
+  const int r = find_match_direct(m, a.mopt, ref, curf, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
                                   a.grad[2 * i + 1], a.level[i], a.type[i], a.depth[i], pcx, pcy);
   a.result[i] = r;
   a.px_cur[2 * i] = pcx; a.px_cur[2 * i + 1] = pcy;
@@ -723,6 +740,7 @@ __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
   if (a.search_level) a.search_level[i] = m.search_level;
   if (a.h_inv) a.h_inv[i] = m.h_inv;
   if (a.A_cur_ref) for (int k = 0; k < 4; ++k) a.A_cur_ref[4 * i + k] = m.A[k];
+  flush_counters(a.unit_counts, i, m, 0);
 }
 
 // DepthFilter::updateSeeds (depth_filter.cpp:200-233) + depth_filter_utils::updateSeed (:367-499)
@@ -739,7 +757,7 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
   if (type == SVOH_FT_MAPPOINT_SEED || type == SVOH_FT_MAPPOINT_SEED_CONVERGED)
     cur_thresh = a.dopt.mappoint_convergence_sigma2_thresh;
   const DevFrameView& ref = a.ref_frames[a.ref_frame_idx[i]];
-  const DevFrameView& cur = *a.cur_frame;
+  const DevFrameView& cur = a.cur_frame[a.cur_frame_idx ? a.cur_frame_idx[i] : 0];
   if (cur.id == ref.id) return;
   if (type == SVOH_FT_OUTLIER) return;
   if ((type == SVOH_FT_CORNER_SEED_CONVERGED || type == SVOH_FT_EDGELET_SEED_CONVERGED ||
@@ -761,6 +779,7 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
   MatcherState m;
   m.pwb = s_pwb + threadIdx.x * kPwbStride;
   m.h_inv = 0.0; m.search_level = 0; m.reject = false;
+  m.n_warp = 0; m.n_zmssd = 0; m.n_align_it = 0;
   m.align_1d = (type == SVOH_FT_EDGELET_SEED || type == SVOH_FT_EDGELET_SEED_CONVERGED);
   double depth = 0.0;
   const double inv_min = st[0] + sqrt(st[1]);
@@ -768,6 +787,7 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
   const int res = find_epipolar_match_direct(m, a.mopt, ref, cur, T_cur_ref, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
                                              a.grad[2 * i + 1], a.level[i], type, st[0], inv_min, inv_max, depth);
   if (a.result) a.result[i] = res;
+  flush_counters(a.unit_counts, i, m, res == SVOH_MATCH_SUCCESS ? 1 : 0);
   if (res != SVOH_MATCH_SUCCESS) {
     if (!m.reject) a.state[4 * i + 3] = st[3] + 1;  // seed::increaseOutlierProbability
     return;
@@ -843,13 +863,17 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   }
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-  std::vector<DevFrameView> views((size_t)n_ref_frames + 1);
+  const int n_cur = (fb->cur_frame_idx && fb->n_cur_frames > 0) ? fb->n_cur_frames : 1;
+  if (fb->cur_frame_idx)
+    for (int i = 0; i < n; ++i)
+      SVOH_REQUIRE(ctx, fb->cur_frame_idx[i] >= 0 && fb->cur_frame_idx[i] < n_cur, "cur_frame_idx out of range");
+  std::vector<DevFrameView> views((size_t)n_ref_frames + n_cur);
   for (int k = 0; k < n_ref_frames; ++k) {
     int rc = fill_view(ctx, ref_frames[k], &views[k], "reference frame");
     if (rc != SVOH_OK) return rc;
   }
-  {
-    int rc = fill_view(ctx, *cur_frame, &views[n_ref_frames], "current frame");
+  for (int k = 0; k < n_cur; ++k) {
+    int rc = fill_view(ctx, cur_frame[k], &views[n_ref_frames + k], "current frame");
     if (rc != SVOH_OK) return rc;
   }
   for (int i = 0; i < n; ++i)
@@ -858,6 +882,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   Staging s;
   const size_t o_views = s.add(views.data(), sizeof(DevFrameView) * views.size());
   const size_t o_idx = s.add(fb->ref_frame_idx, sizeof(int32_t) * n);
+  const size_t o_cidx = fb->cur_frame_idx ? s.add(fb->cur_frame_idx, sizeof(int32_t) * n) : 0;
   const size_t o_px = s.add(fb->px, sizeof(double) * 2 * n);
   const size_t o_f = s.add(fb->f, sizeof(double) * 3 * n);
   const size_t o_grad = s.add(fb->grad, sizeof(double) * 2 * n);
@@ -891,6 +916,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   if (dopt) a.dopt = *dopt;
   a.n = n;
   a.ref_frame_idx = reinterpret_cast<const int32_t*>(d + o_idx);
+  a.cur_frame_idx = fb->cur_frame_idx ? reinterpret_cast<const int32_t*>(d + o_cidx) : nullptr;
   a.px = reinterpret_cast<const double*>(d + o_px);
   a.f = reinterpret_cast<const double*>(d + o_f);
   a.grad = reinterpret_cast<const double*>(d + o_grad);
@@ -903,6 +929,13 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   a.A_cur_ref = reinterpret_cast<double*>(d + o_A);
   a.success = d + o_success;
   const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  {
+    unsigned long long* dummy;
+    int rc = reset_counters(ctx, &dummy);
+    if (rc == SVOH_OK) rc = reserve_unit_counts(ctx, (size_t)n, &a.unit_counts);
+    if (rc != SVOH_OK) return rc;
+  }
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   if (seeds) {
     a.state = reinterpret_cast<double*>(d + o_state);
     hipLaunchKernelGGL(update_seeds_kernel, grid, block, 0, ctx->stream, a);
@@ -912,6 +945,12 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     hipLaunchKernelGGL(match_direct_kernel, grid, block, 0, ctx->stream, a);
   }
   SVOH_HIP_TRY(ctx, hipGetLastError());
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = true;
+  {
+    int rc = reduce_unit_counts(ctx, (size_t)n);
+    if (rc != SVOH_OK) return rc;
+  }
   // everything after the inputs that may have changed comes back in one copy
   const size_t back_from = o_type;
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + back_from, d + back_from, s.total - back_from, hipMemcpyDeviceToHost, ctx->stream));

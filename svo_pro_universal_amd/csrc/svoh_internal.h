@@ -87,6 +87,10 @@ struct svoh_ctx {
   svoh::PinnedBuffer h_results;
   int last_align_n = 0;
   hipEvent_t ev_align_start = nullptr, ev_align_stop = nullptr;
+  hipEvent_t ev_misc_start = nullptr, ev_misc_stop = nullptr;  // KLT / matcher / seeds
+  bool misc_timed = false;
+  svoh::DevBuffer d_counters;  // 8 x uint64 work counters of the last KLT / matcher kernel
+  svoh::DevBuffer d_unit_counts;  // 4 x uint32 per unit
 
   // generic scratch for the other paths
   svoh::DevBuffer d_scratch0, d_scratch1, d_scratch2;
@@ -96,6 +100,13 @@ struct svoh_ctx {
 namespace svoh {
 
 int set_error(svoh_ctx* ctx, int code, const char* fmt, ...);
+// zeroes the context's 8 work counters on its stream and returns the device pointer
+int reset_counters(svoh_ctx* ctx, unsigned long long** out);
+// per-unit work counts (4 x uint32 per unit) written by a kernel with plain stores; reduce_unit_counts
+// sums them into the context's 8 counters AFTER the timed region (atomics on a few shared words
+// inside the kernel would serialise it)
+int reserve_unit_counts(svoh_ctx* ctx, size_t n_units, unsigned int** out);
+int reduce_unit_counts(svoh_ctx* ctx, size_t n_units);
 void set_global_error(const char* msg);
 const Frame* find_frame(const svoh_ctx* ctx, svoh_frame_t id);
 
