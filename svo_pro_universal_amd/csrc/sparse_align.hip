@@ -70,7 +70,9 @@ struct AlignKernelArgs {
   int32_t lds_img_bytes;                // dynamic LDS available for image staging
   int32_t eval_level;                   // <0: full run; >=0: evaluate once at that level
   double* eval_out;                     // [64 H][8 g][chi2][n_meas] for eval mode
-  long long* stamps;                    // diagnostic builds only (SVOH_PHASE_STAMPS): 8 per block
+  long long* stamps;                    // diagnostic builds only (SVOH_PHASE_STAMPS): 8 per problem
+  int32_t n_problems;
+  int32_t* queue;                       // work queue head: workgroups pull problem indices from it
 };
 
 #ifndef SVOH_ROW_UNROLL
@@ -83,7 +85,7 @@ struct AlignKernelArgs {
 #define SVOH_STAMP_DECL long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long st_begin = (long long)__builtin_amdgcn_s_memtime();
 #define SVOH_STAMP_START() do { st_t0 = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define SVOH_STAMP_ADD(k) do { long long st_n = (long long)__builtin_amdgcn_s_memtime(); st_acc[k] += st_n - st_t0; st_t0 = st_n; } while (0)
-#define SVOH_STAMP_FLUSH() do { if (threadIdx.x == 0) { st_acc[7] = (long long)__builtin_amdgcn_s_memtime() - st_begin; for (int k_ = 0; k_ < 8; ++k_) a.stamps[blockIdx.x * 8 + k_] = st_acc[k_]; } } while (0)
+#define SVOH_STAMP_FLUSH() do { if (threadIdx.x == 0) { st_acc[7] = (long long)__builtin_amdgcn_s_memtime() - st_begin; for (int k_ = 0; k_ < 8; ++k_) a.stamps[pbi * 8 + k_] = st_acc[k_]; } } while (0)
 #else
 #define SVOH_STAMP_DECL
 #define SVOH_STAMP_START() do {} while (0)
@@ -536,7 +538,17 @@ void sparse_align_kernel(const AlignKernelArgs a)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const DevProblemDesc& pb = a.problems[blockIdx.x];
+  __shared__ int s_pbi;
+  // Persistent workgroups: the grid is sized to what is resident at once and every
+  // workgroup pulls the next problem index from a queue head, so problems that need
+  // more Gauss-Newton iterations do not leave CUs idle at the end of the launch.
+  for (;;) {
+  __syncthreads();  // everyone is done with the previous problem's shared state
+  if (tid == 0) s_pbi = atomicAdd(a.queue, 1);
+  __syncthreads();
+  const int pbi = s_pbi;
+  if (pbi >= a.n_problems) break;
+  const DevProblemDesc& pb = a.problems[pbi];
   const DevCamDesc* cams = a.cams + pb.cam_begin;
   const int n_cams = pb.n_cams;
   const svoh_align_options& opt = a.opt;
@@ -614,7 +626,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
   const int n_sel = s.nsel;
   if (n_sel == 0) {
     if (tid == 0) {
-      svoh_align_result& r = a.results[blockIdx.x];
+      svoh_align_result& r = a.results[pbi];
       r.status = 1; r.n_fts_to_track = 0;
       store_rigid(s.T, r.T_icur_iref);
       r.alpha = s.alpha; r.beta = s.beta;
@@ -623,10 +635,10 @@ void sparse_align_kernel(const AlignKernelArgs a)
       if (eval_mode) for (int k = 0; k < 74; ++k) a.eval_out[k] = 0.0;
     }
     SVOH_STAMP_FLUSH();
-    return;
+    continue;
   }
   if (tid == 0) {
-    svoh_align_result& r = a.results[blockIdx.x];
+    svoh_align_result& r = a.results[pbi];
     for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = 0; r.n_meas[l] = 0; r.chi2[l] = 0.0; }
   }
 
@@ -746,7 +758,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
 #pragma unroll
           for (int r = 0; r < D; ++r) xg[r] = s_sum[NH + r];
         }
-        svoh_align_result& res = a.results[blockIdx.x];
+        svoh_align_result& res = a.results[pbi];
         if (level < SVOH_MAX_LEVELS) {
           res.iters[level] = iter + 1;
           res.n_meas[level] = n_meas;
@@ -822,7 +834,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
   }
 
   if (tid == 0) {
-    svoh_align_result& r = a.results[blockIdx.x];
+    svoh_align_result& r = a.results[pbi];
     r.status = s.status;
     r.n_fts_to_track = n_sel;
     store_rigid(s.T, r.T_icur_iref);
@@ -830,6 +842,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
     r.n_patch_iters = s.patch_iters;
   }
   SVOH_STAMP_FLUSH();
+  }  // next problem
 }
 
 // ---------------------------------------------------------------------------
@@ -994,6 +1007,10 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.eval_level = eval_level;
   args.eval_out = static_cast<double*>(ctx->d_eval.ptr);
   args.stamps = nullptr;
+  args.n_problems = n_problems;
+  SVOH_HIP_TRY(ctx, ctx->d_scratch2.reserve(64));
+  SVOH_HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch2.ptr, 0, sizeof(int32_t), ctx->stream));
+  args.queue = static_cast<int32_t*>(ctx->d_scratch2.ptr);
 #ifdef SVOH_PHASE_STAMPS
   SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(sizeof(long long) * 8 * (size_t)n_problems));
   args.stamps = static_cast<long long*>(ctx->d_scratch0.ptr);
@@ -1014,14 +1031,17 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.lds_img_bytes = (int32_t)lds;
 
   const bool illum = opt->estimate_illumination_gain || opt->estimate_illumination_offset;
+  // resident workgroups per CU: 256-thread groups at 256 VGPRs -> 2; larger groups -> 1
+  int grid = ctx->num_cus * getenv_int("SVOH_ALIGN_WG_PER_CU", nt == 256 ? 2 : 1);
+  if (grid > n_problems || grid <= 0) grid = n_problems;
   hipError_t e;
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_start, ctx->stream));
   if (opt->patch_size == 4)
-    e = illum ? launch_nt<4, true>(ctx->stream, nt, n_problems, lds, args)
-              : launch_nt<4, false>(ctx->stream, nt, n_problems, lds, args);
+    e = illum ? launch_nt<4, true>(ctx->stream, nt, grid, lds, args)
+              : launch_nt<4, false>(ctx->stream, nt, grid, lds, args);
   else
-    e = illum ? launch_nt<8, true>(ctx->stream, nt, n_problems, lds, args)
-              : launch_nt<8, false>(ctx->stream, nt, n_problems, lds, args);
+    e = illum ? launch_nt<8, true>(ctx->stream, nt, grid, lds, args)
+              : launch_nt<8, false>(ctx->stream, nt, grid, lds, args);
   if (e != hipSuccess)
     return set_error(ctx, SVOH_ERR_HIP, "sparse_align launch failed: %s", hipGetErrorString(e));
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_stop, ctx->stream));
