@@ -1016,12 +1016,12 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.stamps = static_cast<long long*>(ctx->d_scratch0.ptr);
 #endif
 
-  // Geometry.  Many problems: 256-thread workgroups, several per CU, so that one
-  // problem's serial solve overlaps the others' patch work; LDS holds levels >= 2
-  // of a 640x480 pyramid.  Few problems (latency mode): one 1024-thread
-  // workgroup per CU with almost all of the 160 KiB LDS, which holds level 1 too.
-  int nt = (n_problems >= 2 * ctx->num_cus) ? 256 : 1024;
-  if (max_feat_per_problem <= 512 && nt > 512) nt = 512;
+  // Geometry.  Many problems: 256-thread workgroups, two per CU (256 VGPRs each), so
+  // that one problem's serial solve overlaps the other's patch work; LDS holds levels
+  // >= 2 of a 640x480 pyramid.  Few problems (latency mode): 512-thread workgroups.
+  // measured on MI355X (2000 patches): one problem takes 0.42 ms with 512 threads, 0.50 ms
+  // with 256 and 0.91 ms with 1024 (128-VGPR budget spills), so 512 is the latency geometry
+  int nt = (n_problems >= 2 * ctx->num_cus) ? 256 : 512;
   if (max_feat_per_problem <= 256) nt = 256;
   nt = getenv_int("SVOH_ALIGN_THREADS", nt);
   if (nt != 256 && nt != 512 && nt != 1024) nt = 256;
