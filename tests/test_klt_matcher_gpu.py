@@ -192,3 +192,85 @@ def test_golden_klt_seeds_fixture(gpu_ctx):
     o = gpu_ctx.match_direct_batch(mopt, [rv], cv, fb2, z["direct_depth"], z["direct_px_init"])
     assert np.array_equal(o["result"], z["direct_result"]) and np.array_equal(o["search_level"], z["direct_search_level"])
     assert np.abs(o["px_cur"] - z["direct_px_out"]).max() < 1e-4
+
+
+def test_euroc_752x480_geometry_all_paths(gpu_ctx, oracle_lib):
+    """EuRoC's real geometry (752x480, radtan): the pyramid mixes the SSE2 and the scalar
+    halfSample rule (376 % 16 != 0) and level widths become odd (47); every path must agree with the oracle."""
+    orc = oracle_lib
+    cam = synth.Camera(752, 480, 458.654, 457.296, 367.215, 248.375, dist=[-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05])
+    sc = synth.make_align_scene(71, n_features=600, cam=cam, border_features=80, rot_deg=(0.3, 1.0), trans_m=(0.04, 0.1))
+    ref = orc.create_img_pyramid(sc.img_ref, 5); cur = orc.create_img_pyramid(sc.img_cur, 5)
+    assert [l.shape[1] for l in ref] == [752, 376, 188, 94, 47]
+    fr, lv = gpu_ctx.build_pyramid(sc.img_ref, 5, return_levels=True)
+    fc, lvc = gpu_ctx.build_pyramid(sc.img_cur, 5, return_levels=True)
+    for a, b in zip(lv + lvc, ref + cur):
+        assert np.array_equal(a, b)
+    # sparse image alignment with the frame handler's levels (4..2) and with all levels
+    for kw in (dict(min_level=2), dict(min_level=0, robustification=1)):
+        opt = capi.default_align_options(**kw)
+        n, ro, _ = orc.sparse_align_run(opt, orc.problem_from_scenes([(sc, ref, cur)]))
+        pbs, keep = fe.make_align_problems([[(sc, fr, fc)]])
+        rg = gpu_ctx.sparse_align(opt, pbs)[0]
+        assert rg.n_fts_to_track == n and list(rg.iters) == list(ro.iters) and list(rg.n_meas) == list(ro.n_meas)
+        assert helpers.se3_max_abs_diff(rg.T_icur_iref, ro.T_icur_iref) < 1e-8
+    # KLT
+    tr = synth.make_track_set(sc, 300, margin=10)
+    kopt = capi.default_klt_options()
+    po, so = orc.klt_track_batch(kopt, ref, cur, tr["px_ref"], tr["px_cur_init"])
+    pg, sg = gpu_ctx.klt_track_batch(kopt, fr, fc, tr["px_ref"], tr["px_cur_init"])
+    assert np.array_equal(so, sg) and np.array_equal(po, pg) and so.mean() > 0.8
+    # seeds
+    sd = synth.make_seed_set(sc, 1500, margin=10)
+    ov_r, ov_c, gv_r, gv_c = views(gpu_ctx, orc, sc, ref, cur, fr, fc, sd["mu_range"])
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(cam)
+    fbo, ko = orc.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+    fbg, kg = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+    nso, sto, so2, mro = orc.update_seeds_batch(mopt, dopt, [ov_r], ov_c, fbo, sd["state"])
+    nsg, stg, sg2, mrg = gpu_ctx.update_seeds_batch(mopt, dopt, [gv_r], gv_c, fbg, sd["state"])
+    assert nso == nsg and np.array_equal(mro, mrg) and np.array_equal(ko["type"], kg["type"])
+    assert np.allclose(stg, sto, rtol=1e-9, atol=0) and nso > 700
+
+
+def test_multi_stream_batch_equals_per_frame_calls(gpu_ctx, oracle_lib):
+    """cur_frame_idx batching (several camera streams in one launch) gives exactly the per-frame results."""
+    orc = oracle_lib
+    packs = [scene_and_frames(gpu_ctx, orc, 80 + k) for k in range(3)]
+    mopt = capi.default_matcher_options()
+    seeds = [synth.make_seed_set(p[0], 400, seed=k) for k, p in enumerate(packs)]
+    dopt = capi.default_depth_filter_options(packs[0][0].cam)
+    singles = []
+    for k, (sc, ref, cur, fr, fc) in enumerate(packs):
+        sd = seeds[k]
+        rv = fe.make_frame_view(fr, sc.cam, sc.T_ref_f_w, sd["mu_range"], 2 * k)
+        cv = fe.make_frame_view(fc, sc.cam, sc.T_cur_f_w_gt, 0.0, 2 * k + 1)
+        fb, kk = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+        singles.append(gpu_ctx.update_seeds_batch(mopt, dopt, [rv], cv, fb, sd["state"]) + (kk["type"].copy(),))
+    import ctypes as C
+    rvs = [fe.make_frame_view(p[3], p[0].cam, p[0].T_ref_f_w, seeds[k]["mu_range"], 2 * k) for k, p in enumerate(packs)]
+    cvs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(p[4], p[0].cam, p[0].T_cur_f_w_gt, 0.0, 2 * k + 1) for k, p in enumerate(packs)])
+    idx = np.repeat(np.arange(3, dtype=np.int32), 400)
+    cat = lambda key: np.concatenate([s[key] for s in seeds])
+    fb, kk = fe.make_feature_batch(idx, cat("px"), cat("f"), cat("grad"), cat("level"), cat("type"))
+    fb.cur_frame_idx = idx.ctypes.data
+    fb.n_cur_frames = 3
+    st = cat("state").copy(); succ = np.zeros(1200, np.uint8); mr = np.zeros(1200, np.int32); ns = C.c_int32()
+    rv_arr = (capi.svoh_frame_view * 3)(*rvs)
+    gpu_ctx._check(gpu_ctx.lib.svoh_update_seeds_batch(gpu_ctx.h, C.byref(mopt), C.byref(dopt), 3, rv_arr, cvs, C.byref(fb),
+                                                       st.ctypes.data, succ.ctypes.data, mr.ctypes.data, C.byref(ns)))
+    assert ns.value == sum(s[0] for s in singles)
+    for k, s in enumerate(singles):
+        sl = slice(400 * k, 400 * (k + 1))
+        assert np.array_equal(st[4 * 400 * k:4 * 400 * (k + 1)], s[1]) and np.array_equal(succ[sl], s[2])
+        assert np.array_equal(mr[sl], s[3]) and np.array_equal(kk["type"][sl], s[4])
+    # KLT: per-track current frames
+    trs = [synth.make_track_set(p[0], 50, seed=k) for k, p in enumerate(packs)]
+    kopt = capi.default_klt_options()
+    rf = (capi.svoh_frame_t * 150)(*[packs[i // 50][3] for i in range(150)])
+    cf = (capi.svoh_frame_t * 150)(*[packs[i // 50][4] for i in range(150)])
+    pr = np.concatenate([t["px_ref"] for t in trs]); p0 = np.concatenate([t["px_cur_init"] for t in trs])
+    out = p0.copy(); stt = np.zeros(150, np.uint8)
+    gpu_ctx._check(gpu_ctx.lib.svoh_klt_track_multi(gpu_ctx.h, C.byref(kopt), 150, rf, cf, pr.ctypes.data, out.ctypes.data, stt.ctypes.data))
+    for k, p in enumerate(packs):
+        pg, sg = gpu_ctx.klt_track_batch(kopt, p[3], p[4], trs[k]["px_ref"], trs[k]["px_cur_init"])
+        assert np.array_equal(pg, out[100 * k:100 * (k + 1)]) and np.array_equal(sg, stt[50 * k:50 * (k + 1)])
