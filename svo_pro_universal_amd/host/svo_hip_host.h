@@ -42,6 +42,14 @@ struct Frame {
   std::vector<double> pos_world_;    // 3 x n
   // landmark or seed reference present and not a map point (sparse_img_align.cpp:239-245)
   std::vector<uint8_t> alignable_;   // n
+  // members read / written by the matcher and the depth filter (frame.h:62-73, 160-170)
+  std::vector<double> grad_vec_;                 // 2 x n
+  std::vector<int32_t> level_vec_;               // n
+  std::vector<uint8_t> type_vec_;                // n  svo::FeatureType
+  std::vector<double> invmu_sigma2_a_b_vec_;     // 4 x n  seed states
+  double seed_mu_range_ = 0.0;
+  int id_ = 0;
+  int id() const { return id_; }
 
   void set_T_cam_imu(const Transformation& T) { T_cam_imu_ = T; T_imu_cam_ = svoh::inverse(T); }  // frame.h:270-274
   const Transformation& T_cam_imu() const { return T_cam_imu_; }
@@ -112,5 +120,50 @@ class SparseImgAlignHip {
   svoh_align_prior prior_{};
   svoh_align_result last_{};
 };
+
+// ---------------------------------------------------------------------------
+// Seam 2: depth filter.  Mirrors svo::DepthFilter::updateSeeds
+// (src/svo_direct/include/svo/direct/depth_filter.h:158-160,
+//  src/svo_direct/src/depth_filter.cpp:200-233) and the options it reads
+// (depth_filter.h:40-100, matcher.h:39-54).
+// ---------------------------------------------------------------------------
+struct DepthFilterOptions {
+  double seed_convergence_sigma2_thresh = 200.0;
+  double mappoint_convergence_sigma2_thresh = 500.0;
+  bool scan_epi_unit_sphere = false;   // svo_factory.cpp:261
+  bool affine_est_offset = true;
+  bool affine_est_gain = false;
+  bool use_threaded_depthfilter = false;  // must stay false: the threaded variant races
+};
+
+class DepthFilterHip {
+ public:
+  DepthFilterHip(svoh_ctx* ctx, const DepthFilterOptions& options);
+  // returns the number of successfully updated seeds; updates invmu_sigma2_a_b_vec_ and
+  // type_vec_ of the reference frames in place, exactly like the reference
+  size_t updateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame);
+  svoh_matcher_options& getMatcherOptions() { return matcher_options_; }
+  // Matcher::MatchResult of every seed of the last call, in (frame, feature) order
+  const std::vector<int32_t>& lastMatchResults() const { return last_results_; }
+
+ private:
+  svoh_ctx* ctx_;
+  DepthFilterOptions options_;
+  svoh_matcher_options matcher_options_{};
+  bool have_px_error_angle_ = false;   // the function-local static of updateSeed (depth_filter.cpp:383-384)
+  double px_error_angle_ = 0.0;
+  std::vector<int32_t> last_results_;
+};
+
+// ---------------------------------------------------------------------------
+// Seam 3: KLT.  Mirrors feature_alignment::alignPyr2DVec
+// (src/svo_direct/include/svo/direct/feature_alignment.h:59-69): cv::Point2f becomes Point2f.
+// ---------------------------------------------------------------------------
+struct Point2f { float x, y; };
+namespace feature_alignment {
+void alignPyr2DVec(svoh_ctx* ctx, svoh_frame_t img_pyr_ref, svoh_frame_t img_pyr_cur, int max_level, int min_level,
+                   const std::vector<int>& patch_sizes, int n_iter, float min_update_squared,
+                   const std::vector<Point2f>& px_ref, std::vector<Point2f>& px_cur, std::vector<uint8_t>& status);
+}
 
 }  // namespace svo_hip
