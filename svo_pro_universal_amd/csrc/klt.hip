@@ -37,12 +37,7 @@ struct KltArgs {
   unsigned int* unit_counts;    // 4 per track: iterations 16x16, 8x8, templates 16x16, 8x8
 };
 
-__device__ __forceinline__ int wave_sum_i32(int v)
-{
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ int wave_sum_i32(int v) { return svoh::wave_sum_i32_dpp(v); }
 
 // One level of alignPyr2D for patch size P (16 or 8).  Returns: 0 = continue to the
 // next level, 1 = return false (not converged / NaN).  `converged` and px_cur are updated.

@@ -139,11 +139,16 @@ __device__ __forceinline__ int get_best_search_level(const double A[4], int max_
   return search_level;
 }
 
-// patch_warp.cpp:112-156, halfpatch_size = 5 (10x10 patch with border)
+// patch_warp.cpp:112-156, halfpatch_size = 5 (10x10 patch with border).
+// Two passes so that the gathers have memory-level parallelism: pass 1 evaluates the
+// reference's in-image test for all 100 sample positions without touching memory
+// (the reference returns false at the first failing pixel and the caller discards the
+// patch, so "any pixel fails" is the same outcome); pass 2 recomputes the same float
+// coordinates and issues a whole row of taps before using them.
 __device__ bool warp_affine(const double A_cur_ref[4], const DevImage& img_ref, double pxr, double pyr, int level_ref,
                             int search_level, unsigned char* patch)
 {
-  const int halfpatch_size = 5;
+  constexpr int halfpatch_size = 5;
   double Ai[4];
   mat2d_inverse(A_cur_ref, Ai);
   const float s = (float)(1 << search_level);
@@ -152,23 +157,43 @@ __device__ bool warp_affine(const double A_cur_ref[4], const DevImage& img_ref, 
   const float prx = (float)pxr / (float)(1 << level_ref);
   const float pry = (float)pyr / (float)(1 << level_ref);
   const int stride = img_ref.pitch;
-  int k = 0;
+  bool inside = true;
   for (int y = -halfpatch_size; y < halfpatch_size; ++y) {
-    for (int x = -halfpatch_size; x < halfpatch_size; ++x, ++k) {
+#pragma unroll
+    for (int x = -halfpatch_size; x < halfpatch_size; ++x) {
       const float fx = (float)x, fy = (float)y;
       const float pxx = (a00 * fx + a01 * fy) + prx;
       const float pxy = (a10 * fx + a11 * fy) + pry;
       const int xi = (int)floorf(pxx);
       const int yi = (int)floorf(pxy);
-      if (xi < 0 || yi < 0 || xi + 1 >= img_ref.w || yi + 1 >= img_ref.h) return false;
-      const float subpix_x = pxx - xi;
-      const float subpix_y = pxy - yi;
+      inside = inside && !(xi < 0 || yi < 0 || xi + 1 >= img_ref.w || yi + 1 >= img_ref.h);
+    }
+  }
+  if (!inside) return false;
+  for (int y = -halfpatch_size; y < halfpatch_size; ++y) {
+    unsigned t00[10], t01[10], t10[10], t11[10];
+    float sx[10], sy[10];
+#pragma unroll
+    for (int x = -halfpatch_size; x < halfpatch_size; ++x) {
+      const int k = x + halfpatch_size;
+      const float fx = (float)x, fy = (float)y;
+      const float pxx = (a00 * fx + a01 * fy) + prx;
+      const float pxy = (a10 * fx + a11 * fy) + pry;
+      const int xi = (int)floorf(pxx);
+      const int yi = (int)floorf(pxy);
+      sx[k] = pxx - xi;
+      sy[k] = pxy - yi;
+      const uint8_t* ptr = img_ref.data + (ptrdiff_t)yi * stride + xi;
+      t00[k] = ptr[0]; t10[k] = ptr[1]; t01[k] = ptr[stride]; t11[k] = ptr[stride + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const float subpix_x = sx[k], subpix_y = sy[k];
       const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
       const float w01 = (1.0f - subpix_x) * subpix_y;
       const float w10 = subpix_x * (1.0f - subpix_y);
       const float w11 = 1.0f - w00 - w01 - w10;
-      const uint8_t* ptr = img_ref.data + (ptrdiff_t)yi * stride + xi;
-      patch[k] = (unsigned char)(w00 * ptr[0] + w01 * ptr[stride] + w10 * ptr[1] + w11 * ptr[stride + 1]);
+      patch[(y + halfpatch_size) * 10 + k] = (unsigned char)(w00 * t00[k] + w01 * t01[k] + w10 * t10[k] + w11 * t11[k]);
     }
   }
   return true;
@@ -178,12 +203,17 @@ __device__ bool warp_affine(const double A_cur_ref[4], const DevImage& img_ref, 
 __device__ int zmssd_score(const unsigned char* pwb, int sumA, int sumAA, const uint8_t* cur_patch, int stride)
 {
   unsigned sumB = 0, sumBB = 0, sumAB = 0;
-  for (int y = 0, r = 0; y < 8; ++y) {
+  unsigned cpx[64];
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
     const uint8_t* p = cur_patch + (ptrdiff_t)y * stride;
-    for (int x = 0; x < 8; ++x, ++r) {
-      const unsigned c = p[x];
-      sumB += c; sumBB += c * c; sumAB += c * (unsigned)patch_at(pwb, r);
-    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) cpx[y * 8 + x] = p[x];  // all 64 loads are independent: issue them together
+  }
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const unsigned c = cpx[r];
+    sumB += c; sumBB += c * c; sumAB += c * (unsigned)patch_at(pwb, r);
   }
   const int iB = (int)sumB, iBB = (int)sumBB, iAB = (int)sumAB;
   return sumAA - 2 * iAB + iBB - (sumA * sumA - 2 * sumA * iB + iB * iB) / 64;
@@ -277,6 +307,7 @@ __device__ bool align_1d(const DevImage& cur_img, double dir0, double dir1, cons
     const float wBL = (float)((1.0 - subpix_x) * subpix_y);
     const float wBR = subpix_x * subpix_y;
     float Jres[3] = { 0, 0, 0 };
+#pragma unroll 2
     for (int y = 0; y < kPatchSize; ++y) {
       const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + y - kHalfPatchSize) * cur_step + u_r - kHalfPatchSize;
       const unsigned char* rp = pwb + (y + 1) * ref_step + 1;
@@ -352,6 +383,7 @@ __device__ bool align_2d(const DevImage& cur_img, const unsigned char* pwb, int 
     const float wBL = (float)((1.0 - subpix_x) * subpix_y);
     const float wBR = subpix_x * subpix_y;
     float Jres[4] = { 0, 0, 0, 0 };
+#pragma unroll 2
     for (int y = 0; y < patch_size_; ++y) {
       const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + y - halfpatch_size_) * cur_step + u_r - halfpatch_size_;
       const unsigned char* rp = pwb + (y + 1) * ref_step + 1;

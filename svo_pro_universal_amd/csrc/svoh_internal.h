@@ -110,6 +110,23 @@ int reduce_unit_counts(svoh_ctx* ctx, size_t n_units);
 void set_global_error(const char* msg);
 const Frame* find_frame(const svoh_ctx* ctx, svoh_frame_t id);
 
+#if defined(__HIPCC__)
+// Wave64 all-lanes integer sum on the VALU's DPP network (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror, row_bcast:15, row_bcast:31, then v_readlane of lane
+// 63): 6 dependent v_add_u32 instead of 6 ds_bpermute round trips through the LDS
+// crossbar that __shfl_xor lowers to on gfx950.  Integer adds: exact in any order.
+__device__ __forceinline__ int wave_sum_i32_dpp(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+#endif
+
 #define SVOH_HIP_TRY(ctx, expr)                                                          \
   do {                                                                                   \
     hipError_t svoh_e_ = (expr);                                                         \
