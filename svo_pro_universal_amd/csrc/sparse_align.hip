@@ -800,7 +800,22 @@ void sparse_align_kernel(const AlignKernelArgs a)
             xg[6] += s.I_prior[6] * (pb.prior.alpha_prior - s.alpha);
             xg[7] += s.I_prior[7] * (pb.prior.beta_prior - s.beta);
           }
-          if (!ldlt_solve_regs<8>(m, xg)) s.stop = 1;
+          // without illumination terms rows/columns 6 and 7 are exactly zero: the
+          // pivoted factorisation never selects them before the six pose pivots and
+          // they contribute exact zeros, so the 6x6 leading block gives the same bits
+          if constexpr (ILLUM) {
+            if (!ldlt_solve_regs<8>(m, xg)) s.stop = 1;
+          } else {
+            double m6[21], x6[6];
+#pragma unroll
+            for (int k = 0; k < 21; ++k) m6[k] = m[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) x6[k] = xg[k];
+            if (!ldlt_solve_regs<6>(m6, x6)) s.stop = 1;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) xg[k] = x6[k];
+            xg[6] = 0.0; xg[7] = 0.0;
+          }
           if (s.stop) {
             // rollback (mini_least_squares_solver.hpp:73-82); stop_ is only cleared by reset()
             s.T = s.Told; s.alpha = s.alpha_old; s.beta = s.beta_old;
