@@ -41,6 +41,27 @@ def algorithmic_bytes(P, D, patch_iters, n_sel_levels):
     return b_iter * patch_iters + b_pre * n_sel_levels
 
 
+def pmc_traffic(workload_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this very
+    workload (profiles/rNN_summary.json, written by scripts/profile_bench.sh: separate --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE runs).  Counters are reported in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B
+    (MI355X_MICROARCH.md, HBM section) and is doubled, WRITE_SIZE is taken as is.  None when no summary for the
+    same workload is committed -- the counters cannot be read from inside the timed process."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload_key", "align:B1024:N2000:P4:L4-0") != workload_key:
+            continue
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            best = (2.0 * d["FETCH_SIZE"]["mean_per_dispatch_KB_as_reported"]
+                    + d["WRITE_SIZE"]["mean_per_dispatch_KB_as_reported"]) * 1024.0
+    return best
+
+
 def build_problems(ctx, dev, rank, B, N, P, max_level):
     """B synthetic frame pairs rendered on the GPU; returns problems + keepalives."""
     cam = synth.Camera.test_camera()
@@ -147,7 +168,7 @@ def render_pairs(ctx, dev, rank, B, max_level, **scene_kw):
     return cam, scenes, imgs, frames
 
 
-def bench_klt(args, ctx, dist, rank, world, dev):
+def bench_klt(args, ctx, dist, rank, world, dev, comm_dev=None):
     """KLT-synth: 400 tracks per frame pair, patches {16,16,16,8,8}, <=30 it, B pairs per step."""
     B = args.problems or 256
     NT = 400
@@ -170,7 +191,7 @@ def bench_klt(args, ctx, dist, rank, world, dev):
     cnt = misc_counters(ctx)
     # per track-iteration (P+1)^2 + P^2 + 4 P^2 bytes; template build (P+2)^2 read per level
     alg = cnt[0] * (17 * 17 + 5 * 256) + cnt[1] * (9 * 9 + 5 * 64) + cnt[2] * 18 * 18 + cnt[3] * 10 * 10
-    elapsed, total = du.combine(dist, world, elapsed, n, dev)
+    elapsed, total = du.combine(dist, world, elapsed, n, comm_dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
@@ -204,7 +225,7 @@ def bench_klt(args, ctx, dist, rank, world, dev):
             "cpu_baseline": cpu}
 
 
-def bench_seeds(args, ctx, dist, rank, world, dev):
+def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
     """C4-synth: 3000 seeds per keyframe, 8x8 patches, epipolar ZMSSD scan (<=100 steps) +
     align1D/2D + Vogiatzis update; B (keyframe, frame) pairs per step."""
     B = args.problems or 64
@@ -238,7 +259,7 @@ def bench_seeds(args, ctx, dist, rank, world, dev):
     cnt = misc_counters(ctx)
     # warp <= 11x11 B, scan 64+64 B per ZMSSD, align 81 B per iteration, state 32 B in + out
     alg = cnt[0] * 121 + cnt[1] * 128 + cnt[2] * 81 + n * 32 + cnt[3] * 32
-    elapsed, total = du.combine(dist, world, elapsed, n, dev)
+    elapsed, total = du.combine(dist, world, elapsed, n, comm_dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
@@ -291,17 +312,23 @@ def main():
     args = ap.parse_args()
 
     rank, local_rank, world = du.env_world()
+    # Rehearsal knobs for a one-GPU box (never set by the driver): all ranks on cuda:0 and gloo for the
+    # barrier / MAX / SUM, because RCCL refuses two ranks on one device.
+    backend = os.environ.get("SVOH_BENCH_BACKEND", "nccl")
+    if os.environ.get("SVOH_BENCH_ONE_DEVICE", "0") == "1":
+        local_rank = 0
     dist = None
     if world > 1:
-        dist = du.init("nccl", rank, world, torch.device("cuda", local_rank))
+        dist = du.init(backend, rank, world, torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if backend == "nccl" else None
 
     ctx = fe.Context(local_rank)
     if args.workload != "align":
-        out = (bench_klt if args.workload == "klt" else bench_seeds)(args, ctx, dist, rank, world, dev)
+        out = (bench_klt if args.workload == "klt" else bench_seeds)(args, ctx, dist, rank, world, dev, comm_dev)
         if rank == 0:
             out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
                         "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
@@ -336,7 +363,7 @@ def main():
 
     n_sel = sum(r.n_fts_to_track for r in res)
     # whole-job numbers: MAX of the elapsed time, SUM of the patches all ranks aligned
-    elapsed, patches_total = du.combine(dist, world, elapsed, n_sel, dev)
+    elapsed, patches_total = du.combine(dist, world, elapsed, n_sel, comm_dev)
     patch_iters = sum(r.n_patch_iters for r in res)
     n_levels = args.max_level - args.min_level + 1
     n_bad = sum(1 for r in res if r.status != 0)
@@ -380,7 +407,8 @@ def main():
                                "trans_m_max": float(np.max([e[1] for e in errs]))},
             "solver_failures": n_bad,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("align:B%d:N%d:P%d:L%d-%d" % (B, N, P, args.max_level, args.min_level)),
                          "kernel": "sparse_align_kernel<%d,*,false>" % P,
                          "algorithmic_bytes_per_launch": alg},
         }

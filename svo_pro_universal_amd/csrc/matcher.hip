@@ -81,7 +81,16 @@ struct MatcherState {
   double px_cur[2];
   Vec3 f_cur;
   int n_warp, n_zmssd, n_align_it;  // work counters
+#ifdef SVOH_SEED_STAMPS
+  long long t[4], tlast;  // diagnostic builds: cycles in geometry / warp / scan / align+rest
+#endif
 };
+
+#ifdef SVOH_SEED_STAMPS
+#define SVOH_MSTAMP(m, k) do { const long long now_ = clock64(); (m).t[k] += now_ - (m).tlast; (m).tlast = now_; } while (0)
+#else
+#define SVOH_MSTAMP(m, k) do { } while (0)
+#endif
 
 __device__ __forceinline__ int patch_at(const unsigned char* pwb, int r) { return pwb[((r >> 3) + 1) * 10 + (r & 7) + 1]; }
 
@@ -643,12 +652,16 @@ __device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_op
   double ed0 = m.epi_image[0], ed1 = m.epi_image[1];
   normalize2(ed0, ed1);
   ++m.n_warp;
-  if (!warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb)) return SVOH_MATCH_FAIL_WARP;
+  SVOH_MSTAMP(m, 0);
+  const bool warp_ok = warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
+  SVOH_MSTAMP(m, 1);
+  if (!warp_ok) return SVOH_MATCH_FAIL_WARP;
 
   if (m.epi_length_pyramid < 2.0) {
     m.px_cur[0] = (pAx + pBx) / 2.0;
     m.px_cur[1] = (pAy + pBy) / 2.0;
     const int res = find_local_match(m, opt, cur_frame, ed0, ed1, m.search_level, m.px_cur[0], m.px_cur[1]);
+    SVOH_MSTAMP(m, 3);
     if (res != SVOH_MATCH_SUCCESS) return res;
     m.f_cur = back_project3(cur_frame.cam, m.px_cur[0], m.px_cur[1]);
     normalize3(m.f_cur);
@@ -664,10 +677,12 @@ __device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_op
     scan_epipolar_unit_sphere(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
   else
     scan_epipolar_unit_plane(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
+  SVOH_MSTAMP(m, 2);
 
   if (zmssd_best < ZMSSD_THRESHOLD) {
     if (opt.subpix_refinement) {
       const int res = find_local_match(m, opt, cur_frame, ed0, ed1, m.search_level, m.px_cur[0], m.px_cur[1]);
+      SVOH_MSTAMP(m, 3);
       if (res != SVOH_MATCH_SUCCESS) return res;
     }
     m.f_cur = back_project3(cur_frame.cam, m.px_cur[0], m.px_cur[1]);
@@ -746,7 +761,11 @@ __device__ double compute_tau(const Rigid& T_ref_cur, const Vec3& f, double z, d
 
 __device__ __forceinline__ void flush_counters(unsigned int* c, int i, const MatcherState& m, int updated)
 {
+#ifdef SVOH_SEED_STAMPS
+  reinterpret_cast<uint4*>(c)[i] = make_uint4((unsigned)(m.t[0] >> 4), (unsigned)(m.t[1] >> 4), (unsigned)(m.t[2] >> 4), (unsigned)(m.t[3] >> 4));
+#else
   reinterpret_cast<uint4*>(c)[i] = make_uint4((unsigned)m.n_warp, (unsigned)m.n_zmssd, (unsigned)m.n_align_it, (unsigned)updated);
+#endif
 }
 
 __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
@@ -813,6 +832,9 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
   m.h_inv = 0.0; m.search_level = 0; m.reject = false;
   m.n_warp = 0; m.n_zmssd = 0; m.n_align_it = 0;
   m.align_1d = (type == SVOH_FT_EDGELET_SEED || type == SVOH_FT_EDGELET_SEED_CONVERGED);
+#ifdef SVOH_SEED_STAMPS
+  m.t[0] = m.t[1] = m.t[2] = m.t[3] = 0; m.tlast = clock64();
+#endif
   double depth = 0.0;
   const double inv_min = st[0] + sqrt(st[1]);
   const double inv_max = fmax(st[0] - sqrt(st[1]), 0.00000001);
@@ -840,6 +862,10 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
     else if (type == SVOH_FT_MAPPOINT_SEED) a.type[i] = SVOH_FT_MAPPOINT_SEED_CONVERGED;
   }
   a.success[i] = 1;
+#ifdef SVOH_SEED_STAMPS
+  SVOH_MSTAMP(m, 0);
+  flush_counters(a.unit_counts, i, m, 1);
+#endif
 }
 
 // ---------------------------------------------------------------------------
