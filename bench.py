@@ -132,11 +132,17 @@ def timed_steps(ctx, dist, world, dev, step_fn, steps, warmup):
     barrier()
     ksum = 0.0
     t0 = time.perf_counter()
+    have_kms = True
     for _ in range(steps):
         out, kms = step_fn()
-        ksum += kms
+        if kms is None:
+            have_kms = False
+        else:
+            ksum += kms
     barrier()
-    return time.perf_counter() - t0, ksum / steps, out
+    elapsed = time.perf_counter() - t0
+    # stream-ordered (device-resident) steps do not wait for their kernel: read the last launch's events afterwards
+    return elapsed, (ksum / steps if have_kms else misc_kernel_ms(ctx)), out
 
 
 def misc_kernel_ms(ctx):
@@ -181,13 +187,33 @@ def bench_klt(args, ctx, dist, rank, world, dev, comm_dev=None):
     cf = (capi.svoh_frame_t * n)(*[frames[2 * (i // NT) + 1] for i in range(n)])
     status = np.zeros(n, np.uint8)
 
-    def step():
+    def step_host():
         out = px0.copy()
         ctx._check(ctx.lib.svoh_klt_track_multi(ctx.h, ctypes.byref(opt), n, rf, cf, px_ref.ctypes.data, out.ctypes.data,
                                                 status.ctypes.data))
         return (out, status.copy()), misc_kernel_ms(ctx)
 
-    elapsed, kms, (out, st) = timed_steps(ctx, dist, world, dev, step, args.steps, args.warmup)
+    # value: per-track arrays resident in HBM, used in place through the frame-table entry
+    ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+    t_ridx = torch.from_numpy(np.repeat(2 * np.arange(B, dtype=np.int32), NT)).to(dev)
+    t_cidx = t_ridx + 1
+    t_pxr = torch.from_numpy(px_ref.astype(np.int32)).to(dev)
+    t_px0 = torch.from_numpy(px0).to(dev)
+    t_px = t_px0.clone()
+    t_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        with torch.cuda.stream(ext):
+            t_px.copy_(t_px0)
+        ctx.klt_track_indexed(opt, list(frames), n, t_ridx.data_ptr(), t_cidx.data_ptr(), t_pxr.data_ptr(),
+                              t_px.data_ptr(), t_st.data_ptr())
+        return None, None
+
+    h_elapsed, _hk, (out, st) = timed_steps(ctx, dist, world, dev, step_host, max(2, args.steps // 4), 1)
+    host_rate = n * max(2, args.steps // 4) / h_elapsed
+    elapsed, kms, _ = timed_steps(ctx, dist, world, dev, step, args.steps, args.warmup)
+    assert np.array_equal(t_px.cpu().numpy(), out) and np.array_equal(t_st.cpu().numpy(), st)
     cnt = misc_counters(ctx)
     # per track-iteration (P+1)^2 + P^2 + 4 P^2 bytes; template build (P+2)^2 read per level
     alg = cnt[0] * (17 * 17 + 5 * 256) + cnt[1] * (9 * 9 + 5 * 64) + cnt[2] * 18 * 18 + cnt[3] * 10 * 10
@@ -216,9 +242,10 @@ def bench_klt(args, ctx, dist, rank, world, dev, comm_dev=None):
     return {"metric": "KLT tracks/s (alignPyr2D, 400 tracks/frame, patches {16,16,16,8,8}, <=30 it)",
             "value": total * args.steps / elapsed, "unit": "tracks/s", "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_frame": 1e3 * elapsed / args.steps / B, "dtype": "i32+f32",
-            "config": {"workload": "KLT-synth: %d frame pairs x %d tracks per GPU per step, 640x480, levels 4..0" % (B, NT),
+            "config": {"workload": "KLT-synth: %d frame pairs x %d tracks per GPU per step, 640x480, levels 4..0, track arrays resident in HBM" % (B, NT),
                        "frame_pairs_per_gpu": B, "tracks_per_frame": NT},
             "kernel_ms": kms, "converged_fraction": float(ok.mean()),
+            "host_staged_tracks_per_s": host_rate,  # same work through svoh_klt_track_multi with host arrays (PCIe-inclusive)
             "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "klt_track_kernel",
                          "algorithmic_bytes_per_launch": alg, "counters": cnt[:4]},
@@ -247,7 +274,7 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
     rv = (capi.svoh_frame_view * B)(*ref_views)
     success = np.zeros(n, np.uint8); mr = np.zeros(n, np.int32); ns = ctypes.c_int32()
 
-    def step():
+    def step_host():
         st = state0.copy()
         keep["type"][:] = type0
         ctx._check(ctx.lib.svoh_update_seeds_batch(ctx.h, ctypes.byref(mopt), ctypes.byref(dopt), B, rv, cur_views,
@@ -255,7 +282,31 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
                                                    ctypes.byref(ns)))
         return (st, success.copy(), mr.copy()), misc_kernel_ms(ctx)
 
-    elapsed, kms, (st, succ, mres) = timed_steps(ctx, dist, world, dev, step, args.steps, args.warmup)
+    # value: seed arrays resident in HBM, updated in place (mem_space = SVOH_MEM_DEVICE)
+    ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in
+         dict(idx=idx, px=cat("px"), f=cat("f"), grad=cat("grad"), level=cat("level").astype(np.int32),
+              type0=type0, state0=state0).items()}
+    t["type"] = t["type0"].clone(); t["state"] = t["state0"].clone()
+    t["succ"] = torch.zeros(n, dtype=torch.uint8, device=dev); t["mr"] = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    fbd = fe.make_feature_batch_device(n, t["idx"].data_ptr(), t["px"].data_ptr(), t["f"].data_ptr(), t["grad"].data_ptr(),
+                                       t["level"].data_ptr(), t["type"].data_ptr(), cur_frame_idx=t["idx"].data_ptr(),
+                                       n_cur_frames=B)
+    cur_list = [cur_views[i] for i in range(B)]
+
+    def step():
+        with torch.cuda.stream(ext):
+            t["state"].copy_(t["state0"]); t["type"].copy_(t["type0"])
+        ctx.update_seeds_device(mopt, dopt, ref_views, cur_list, fbd, t["state"].data_ptr(), t["succ"].data_ptr(),
+                                t["mr"].data_ptr())
+        return None, None
+
+    h_steps = max(2, args.steps // 4)
+    h_elapsed, _hk, (st, succ, mres) = timed_steps(ctx, dist, world, dev, step_host, h_steps, 1)
+    host_rate = n * h_steps / h_elapsed
+    elapsed, kms, _ = timed_steps(ctx, dist, world, dev, step, args.steps, args.warmup)
+    assert np.array_equal(t["state"].cpu().numpy(), st) and np.array_equal(t["mr"].cpu().numpy(), mres)
     cnt = misc_counters(ctx)
     # warp <= 11x11 B, scan 64+64 B per ZMSSD, align 81 B per iteration, state 32 B in + out
     alg = cnt[0] * 121 + cnt[1] * 128 + cnt[2] * 81 + n * 32 + cnt[3] * 32
@@ -288,8 +339,9 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
             "value": total * args.steps / elapsed, "unit": "seed updates/s", "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_frame": 1e3 * elapsed / args.steps / B, "dtype": "i32+f32+f64",
             "config": {"workload": "C4-synth: %d (keyframe, frame) pairs x %d seeds per GPU per step, 640x480, 8x8 patches, "
-                                   "<=100 epipolar steps" % (B, NS), "frame_pairs_per_gpu": B, "seeds_per_keyframe": NS},
+                                   "<=100 epipolar steps, seed arrays resident in HBM" % (B, NS), "frame_pairs_per_gpu": B, "seeds_per_keyframe": NS},
             "kernel_ms": kms, "success_fraction": float(succ.mean()),
+            "host_staged_seed_updates_per_s": host_rate,  # same work with host arrays staged per call (PCIe-inclusive)
             "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "update_seeds_kernel",
                          "algorithmic_bytes_per_launch": alg, "counters": cnt[:4]},

@@ -268,6 +268,19 @@ int svoh_klt_track_multi(svoh_ctx* ctx, const svoh_klt_options* options, int n_t
                          const svoh_frame_t* ref_frames, const svoh_frame_t* cur_frames,
                          const int32_t* px_ref, double* px_cur, uint8_t* status);
 
+/* Same tracks addressed through a frame table, the layout of choice when the per-track
+ * arrays already live on the device: frames[n_frames] (host array of handles; all with
+ * more than max_level levels and one common size per level), ref_frame_idx / cur_frame_idx
+ * (n_tracks each) index into it.  mem_space = SVOH_MEM_HOST: the five per-track arrays are
+ * host pointers, indices are validated, results are copied back (identical to
+ * svoh_klt_track_multi).  SVOH_MEM_DEVICE: device pointers used in place on the context's
+ * stream, a track with an out-of-range index gets status 0, and the call returns without
+ * synchronising. */
+int svoh_klt_track_indexed(svoh_ctx* ctx, const svoh_klt_options* options, int n_frames,
+                           const svoh_frame_t* frames, int n_tracks,
+                           const int32_t* ref_frame_idx, const int32_t* cur_frame_idx,
+                           const int32_t* px_ref, double* px_cur, uint8_t* status, int mem_space);
+
 /* Device time (ms) of the last KLT / matcher / seed-update kernel of this context. */
 int svoh_last_kernel_ms(svoh_ctx* ctx, float* ms);
 /* Work counters of that kernel (for the roofline accounting of SURVEY.md 8(d)):
@@ -334,7 +347,13 @@ typedef struct svoh_feature_batch {
    * NULL / 0 = every feature uses cur_frames[0] (the reference's one-frame call) */
   const int32_t* cur_frame_idx;           /* n or NULL */
   int32_t n_cur_frames;                   /* length of the cur_frame array passed to the call (0 = 1) */
-  int32_t reserved2;
+  /* SVOH_MEM_HOST (0): every array above and every per-feature argument of the call is a
+   * host pointer; the call stages them, synchronises and copies the results back.
+   * SVOH_MEM_DEVICE: they are device pointers of the context's device, used in place on
+   * the context's stream; out-of-range indices mark the feature SVOH_MATCH_NOT_RUN instead
+   * of failing the call, and the call returns without synchronising (unless n_success is
+   * requested): order later work on svoh_stream() or call svoh_synchronize(). */
+  int32_t mem_space;
 } svoh_feature_batch;
 
 /* Replaces n calls of Matcher::findMatchDirect (src/svo_direct/src/matcher.cpp:31-141),

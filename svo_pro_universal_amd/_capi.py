@@ -89,7 +89,7 @@ class svoh_frame_view(C.Structure):
 class svoh_feature_batch(C.Structure):
     _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("ref_frame_idx", C.c_void_p), ("px", C.c_void_p),
                 ("f", C.c_void_p), ("grad", C.c_void_p), ("level", C.c_void_p), ("type", C.c_void_p),
-                ("cur_frame_idx", C.c_void_p), ("n_cur_frames", C.c_int32), ("reserved2", C.c_int32)]
+                ("cur_frame_idx", C.c_void_p), ("n_cur_frames", C.c_int32), ("mem_space", C.c_int32)]
 
 
 class svoh_depth_filter_options(C.Structure):
@@ -173,7 +173,7 @@ EXPORTS = [
     "svoh_download_level", "svoh_frame_info", "svoh_release_frame",
     "svoh_sparse_align_batch", "svoh_sparse_align_enqueue", "svoh_sparse_align_fetch",
     "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms",
-    "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
+    "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
     "svoh_match_direct_batch",
     "svoh_update_seeds_batch",
 ]
@@ -247,6 +247,8 @@ def load():
                                          C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svoh_klt_track_multi.argtypes = [C.c_void_p, P(svoh_klt_options), C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svoh_klt_track_indexed.argtypes = [C.c_void_p, P(svoh_klt_options), C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.svoh_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float)]
     lib.svoh_last_kernel_counters.argtypes = [C.c_void_p, C.c_void_p]
     lib.svoh_match_direct_batch.argtypes = [C.c_void_p, P(svoh_matcher_options), C.c_int, P(svoh_frame_view),

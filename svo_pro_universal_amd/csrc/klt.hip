@@ -31,6 +31,7 @@ struct KltArgs {
   const int32_t* cur_idx;       // n_tracks: row of frame_levels of the current frame
   svoh_klt_options opt;
   int n_tracks;
+  int n_frames;                 // rows of frame_levels (device-resident indices are range-checked in the kernel)
   const int32_t* px_ref;        // 2 x n
   double* px_cur;               // 2 x n, in/out
   uint8_t* status;              // n
@@ -138,8 +139,16 @@ __global__ __launch_bounds__(256) void klt_track_kernel(const KltArgs a)
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= a.n_tracks) return;
   const int lane = threadIdx.x & 63;
-  const DevImage* ref = a.frame_levels + (size_t)a.ref_idx[t] * SVOH_MAX_LEVELS;
-  const DevImage* curl = a.frame_levels + (size_t)a.cur_idx[t] * SVOH_MAX_LEVELS;
+  const int ri = a.ref_idx[t], ci = a.cur_idx[t];
+  if ((unsigned)ri >= (unsigned)a.n_frames || (unsigned)ci >= (unsigned)a.n_frames) {
+    if (lane == 0) {
+      a.status[t] = 0;
+      reinterpret_cast<uint4*>(a.unit_counts)[t] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return;
+  }
+  const DevImage* ref = a.frame_levels + (size_t)ri * SVOH_MAX_LEVELS;
+  const DevImage* curl = a.frame_levels + (size_t)ci * SVOH_MAX_LEVELS;
   double pcx = a.px_cur[2 * t], pcy = a.px_cur[2 * t + 1];
   const int rx = a.px_ref[2 * t], ry = a.px_ref[2 * t + 1];
   bool converged = false;
@@ -172,6 +181,91 @@ __global__ __launch_bounds__(256) void klt_track_kernel(const KltArgs a)
 
 using namespace svoh;
 
+static int check_klt_options(svoh_ctx* ctx, const svoh_klt_options* options)
+{
+  SVOH_REQUIRE(ctx, options->max_level >= options->min_level && options->min_level >= 0 &&
+                        options->max_level < SVOH_MAX_LEVELS && options->max_iter >= 1,
+               "bad KLT level range / max_iter");
+  for (int l = options->min_level; l <= options->max_level; ++l)
+    if (options->patch_sizes[l] != 8 && options->patch_sizes[l] != 16)
+      return set_error(ctx, SVOH_ERR_UNSUPPORTED, "KLT patch size %d at level %d not built (8 and 16 are)",
+                       options->patch_sizes[l], l);
+  return SVOH_OK;
+}
+
+// Stage what is host-resident, launch, fetch what the caller wants on the host.
+// idx = [ref_idx (n) | cur_idx (n)] when host-resident; with SVOH_MEM_DEVICE the five
+// per-track arrays are used where they are and nothing is copied back.
+static int launch_klt(svoh_ctx* ctx, const svoh_klt_options* options, const std::vector<const Frame*>& frames,
+                      int n_tracks, int mem_space, const int32_t* ref_idx, const int32_t* cur_idx,
+                      const int32_t* px_ref, double* px_cur, uint8_t* status)
+{
+  const bool on_device = mem_space == SVOH_MEM_DEVICE;
+  const size_t n = (size_t)n_tracks;
+  const size_t lv_bytes = (sizeof(DevImage) * SVOH_MAX_LEVELS * frames.size() + 63) & ~(size_t)63;
+  const size_t idx_bytes = on_device ? 0 : ((sizeof(int32_t) * 2 * n + 63) & ~(size_t)63);
+  const size_t pxr_bytes = on_device ? 0 : ((sizeof(int32_t) * 2 * n + 63) & ~(size_t)63);
+  const size_t in_bytes = lv_bytes + idx_bytes + pxr_bytes;
+  const size_t io_bytes = on_device ? 0 : (sizeof(double) * 2 * n + n);
+  SVOH_HIP_TRY(ctx, ctx->h_scratch0.reserve(in_bytes + io_bytes));
+  SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(in_bytes + io_bytes));
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch0.ptr);
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch0.ptr);
+  DevImage* hl = reinterpret_cast<DevImage*>(h);
+  for (size_t k = 0; k < frames.size(); ++k)
+    for (int l = 0; l < SVOH_MAX_LEVELS; ++l)
+      hl[k * SVOH_MAX_LEVELS + l] = l < frames[k]->n_levels ? frames[k]->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
+  if (!on_device) {
+    memcpy(h + lv_bytes, ref_idx, sizeof(int32_t) * n);
+    memcpy(h + lv_bytes + sizeof(int32_t) * n, cur_idx, sizeof(int32_t) * n);
+    memcpy(h + lv_bytes + idx_bytes, px_ref, sizeof(int32_t) * 2 * n);
+    memcpy(h + in_bytes, px_cur, sizeof(double) * 2 * n);
+  }
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes + (on_device ? 0 : sizeof(double) * 2 * n), hipMemcpyHostToDevice,
+                                   ctx->stream));
+  KltArgs args;
+  args.frame_levels = reinterpret_cast<const DevImage*>(d);
+  args.opt = *options;
+  args.n_tracks = n_tracks;
+  args.n_frames = (int)frames.size();
+  if (on_device) {
+    args.ref_idx = ref_idx; args.cur_idx = cur_idx; args.px_ref = px_ref; args.px_cur = px_cur; args.status = status;
+  } else {
+    args.ref_idx = reinterpret_cast<const int32_t*>(d + lv_bytes);
+    args.cur_idx = args.ref_idx + n_tracks;
+    args.px_ref = reinterpret_cast<const int32_t*>(d + lv_bytes + idx_bytes);
+    args.px_cur = reinterpret_cast<double*>(d + in_bytes);
+    args.status = d + in_bytes + sizeof(double) * 2 * n;
+  }
+  {
+    unsigned long long* dummy;
+    int rc = reset_counters(ctx, &dummy);
+    if (rc == SVOH_OK) rc = reserve_unit_counts(ctx, n, &args.unit_counts);
+    if (rc != SVOH_OK) return rc;
+  }
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  {
+    const char* e = getenv("SVOH_KLT_BLOCK");
+    int block = e ? atoi(e) : 256;
+    if (block != 64 && block != 128 && block != 256) block = 256;
+    const int tpb = block / 64;
+    hipLaunchKernelGGL(klt_track_kernel, dim3((n_tracks + tpb - 1) / tpb), dim3(block), 0, ctx->stream, args);
+  }
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = true;
+  {
+    int rc = reduce_unit_counts(ctx, n);
+    if (rc != SVOH_OK) return rc;
+  }
+  if (on_device) return SVOH_OK;  // stream-ordered; the caller synchronises when it needs the results
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + in_bytes, d + in_bytes, io_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(px_cur, h + in_bytes, sizeof(double) * 2 * n);
+  memcpy(status, h + in_bytes + sizeof(double) * 2 * n, n);
+  return SVOH_OK;
+}
+
 extern "C" int svoh_klt_track_multi(svoh_ctx* ctx, const svoh_klt_options* options, int n_tracks,
                                     const svoh_frame_t* ref_frames, const svoh_frame_t* cur_frames,
                                     const int32_t* px_ref, double* px_cur, uint8_t* status)
@@ -180,13 +274,10 @@ extern "C" int svoh_klt_track_multi(svoh_ctx* ctx, const svoh_klt_options* optio
   SVOH_REQUIRE(ctx, options && n_tracks >= 0, "bad arguments");
   if (n_tracks == 0) return SVOH_OK;
   SVOH_REQUIRE(ctx, ref_frames && cur_frames && px_ref && px_cur && status, "NULL argument");
-  SVOH_REQUIRE(ctx, options->max_level >= options->min_level && options->min_level >= 0 &&
-                        options->max_level < SVOH_MAX_LEVELS && options->max_iter >= 1,
-               "bad KLT level range / max_iter");
-  for (int l = options->min_level; l <= options->max_level; ++l)
-    if (options->patch_sizes[l] != 8 && options->patch_sizes[l] != 16)
-      return set_error(ctx, SVOH_ERR_UNSUPPORTED, "KLT patch size %d at level %d not built (8 and 16 are)",
-                       options->patch_sizes[l], l);
+  {
+    const int rc = check_klt_options(ctx, options);
+    if (rc != SVOH_OK) return rc;
+  }
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
 
   // table of the distinct frames + two indices per track
@@ -219,58 +310,8 @@ extern "C" int svoh_klt_track_multi(svoh_ctx* ctx, const svoh_klt_options* optio
     idx[i] = ir;
     idx[(size_t)n_tracks + i] = ic;
   }
-  const size_t lv_bytes = (sizeof(DevImage) * SVOH_MAX_LEVELS * frames.size() + 63) & ~(size_t)63;
-  const size_t idx_bytes = (sizeof(int32_t) * 2 * (size_t)n_tracks + 63) & ~(size_t)63;
-  const size_t in_bytes = lv_bytes + idx_bytes + ((sizeof(int32_t) * 2 * (size_t)n_tracks + 63) & ~(size_t)63);
-  const size_t io_bytes = sizeof(double) * 2 * (size_t)n_tracks + (size_t)n_tracks;
-  SVOH_HIP_TRY(ctx, ctx->h_scratch0.reserve(in_bytes + io_bytes));
-  SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(in_bytes + io_bytes));
-  uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch0.ptr);
-  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch0.ptr);
-  DevImage* hl = reinterpret_cast<DevImage*>(h);
-  for (size_t k = 0; k < frames.size(); ++k)
-    for (int l = 0; l < SVOH_MAX_LEVELS; ++l)
-      hl[k * SVOH_MAX_LEVELS + l] = l < frames[k]->n_levels ? frames[k]->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
-  memcpy(h + lv_bytes, idx.data(), sizeof(int32_t) * 2 * (size_t)n_tracks);
-  memcpy(h + lv_bytes + idx_bytes, px_ref, sizeof(int32_t) * 2 * (size_t)n_tracks);
-  memcpy(h + in_bytes, px_cur, sizeof(double) * 2 * (size_t)n_tracks);
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes + sizeof(double) * 2 * (size_t)n_tracks, hipMemcpyHostToDevice,
-                                   ctx->stream));
-  KltArgs args;
-  args.frame_levels = reinterpret_cast<const DevImage*>(d);
-  args.ref_idx = reinterpret_cast<const int32_t*>(d + lv_bytes);
-  args.cur_idx = args.ref_idx + n_tracks;
-  args.opt = *options;
-  args.n_tracks = n_tracks;
-  args.px_ref = reinterpret_cast<const int32_t*>(d + lv_bytes + idx_bytes);
-  args.px_cur = reinterpret_cast<double*>(d + in_bytes);
-  args.status = d + in_bytes + sizeof(double) * 2 * (size_t)n_tracks;
-  {
-    unsigned long long* dummy;
-    int rc = reset_counters(ctx, &dummy);
-    if (rc == SVOH_OK) rc = reserve_unit_counts(ctx, (size_t)n_tracks, &args.unit_counts);
-    if (rc != SVOH_OK) return rc;
-  }
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
-  {
-    const char* e = getenv("SVOH_KLT_BLOCK");
-    int block = e ? atoi(e) : 256;
-    if (block != 64 && block != 128 && block != 256) block = 256;
-    const int tpb = block / 64;
-    hipLaunchKernelGGL(klt_track_kernel, dim3((n_tracks + tpb - 1) / tpb), dim3(block), 0, ctx->stream, args);
-  }
-  SVOH_HIP_TRY(ctx, hipGetLastError());
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
-  ctx->misc_timed = true;
-  {
-    int rc = reduce_unit_counts(ctx, (size_t)n_tracks);
-    if (rc != SVOH_OK) return rc;
-  }
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + in_bytes, d + in_bytes, io_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  memcpy(px_cur, h + in_bytes, sizeof(double) * 2 * (size_t)n_tracks);
-  memcpy(status, h + in_bytes + sizeof(double) * 2 * (size_t)n_tracks, (size_t)n_tracks);
-  return SVOH_OK;
+  return launch_klt(ctx, options, frames, n_tracks, SVOH_MEM_HOST, idx.data(), idx.data() + n_tracks, px_ref, px_cur,
+                    status);
 }
 
 extern "C" int svoh_klt_track_batch(svoh_ctx* ctx, const svoh_klt_options* options, int n_tracks,
@@ -280,4 +321,38 @@ extern "C" int svoh_klt_track_batch(svoh_ctx* ctx, const svoh_klt_options* optio
   if (n_tracks <= 0) return n_tracks == 0 ? SVOH_OK : set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "negative n_tracks");
   std::vector<svoh_frame_t> cur((size_t)n_tracks, cur_frame);
   return svoh_klt_track_multi(ctx, options, n_tracks, ref_frames, cur.data(), px_ref, px_cur, status);
+}
+
+extern "C" int svoh_klt_track_indexed(svoh_ctx* ctx, const svoh_klt_options* options, int n_frames,
+                                      const svoh_frame_t* frames, int n_tracks, const int32_t* ref_frame_idx,
+                                      const int32_t* cur_frame_idx, const int32_t* px_ref, double* px_cur,
+                                      uint8_t* status, int mem_space)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, options && n_tracks >= 0 && n_frames >= 1 && frames, "bad arguments");
+  SVOH_REQUIRE(ctx, mem_space == SVOH_MEM_HOST || mem_space == SVOH_MEM_DEVICE, "bad mem_space");
+  if (n_tracks == 0) return SVOH_OK;
+  SVOH_REQUIRE(ctx, ref_frame_idx && cur_frame_idx && px_ref && px_cur && status, "NULL argument");
+  {
+    const int rc = check_klt_options(ctx, options);
+    if (rc != SVOH_OK) return rc;
+  }
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // every frame of the table must be usable as reference and as current frame of any
+  // track: enough levels, and one common size per level (alignPyr2D assumes it)
+  std::vector<const Frame*> tab((size_t)n_frames);
+  for (int k = 0; k < n_frames; ++k) {
+    tab[k] = find_frame(ctx, frames[k]);
+    if (!tab[k]) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "frames[%d]: unknown frame handle", k);
+    if (tab[k]->n_levels <= options->max_level)
+      return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "frames[%d]: pyramid has too few levels", k);
+    for (int l = options->min_level; l <= options->max_level; ++l)
+      if (tab[k]->lv[l].w != tab[0]->lv[l].w || tab[k]->lv[l].h != tab[0]->lv[l].h)
+        return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "frames[%d]: level %d differs in size from frames[0]", k, l);
+  }
+  if (mem_space == SVOH_MEM_HOST)
+    for (int i = 0; i < n_tracks; ++i)
+      if (ref_frame_idx[i] < 0 || ref_frame_idx[i] >= n_frames || cur_frame_idx[i] < 0 || cur_frame_idx[i] >= n_frames)
+        return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "track %d: frame index out of range", i);
+  return launch_klt(ctx, options, tab, n_tracks, mem_space, ref_frame_idx, cur_frame_idx, px_ref, px_cur, status);
 }

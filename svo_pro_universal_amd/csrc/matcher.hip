@@ -46,6 +46,7 @@ struct MatcherArgs {
   svoh_matcher_options mopt;
   svoh_depth_filter_options dopt;
   int n;
+  int n_ref_frames, n_cur_frames;  // device-resident indices are range-checked in the kernels
   const int32_t* ref_frame_idx;
   const int32_t* cur_frame_idx;  // may be NULL
   const double* px;
@@ -68,6 +69,16 @@ struct MatcherArgs {
 };
 
 constexpr int kPwbStride = 100;
+
+// indices of feature i are usable (always true for host-resident batches, which the host validates)
+__device__ __forceinline__ bool feature_indices_ok(const MatcherArgs& a, int i)
+{
+  const int ri = a.ref_frame_idx[i];
+  if ((unsigned)ri >= (unsigned)a.n_ref_frames) return false;
+  if (a.cur_frame_idx && (unsigned)a.cur_frame_idx[i] >= (unsigned)a.n_cur_frames) return false;
+  const int lv = a.level[i];
+  return lv >= 0 && lv < a.ref_frames[ri].n_levels;
+}
 
 struct MatcherState {
   unsigned char* pwb;  // this thread's 10x10 patch with border, in LDS
@@ -773,6 +784,11 @@ __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
   __shared__ unsigned char s_pwb[64 * kPwbStride];
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= a.n) return;
+  if (!feature_indices_ok(a, i)) {
+    a.result[i] = SVOH_MATCH_NOT_RUN;
+    reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
   MatcherState m;
   m.pwb = s_pwb + threadIdx.x * kPwbStride;
   m.h_inv = 0.0; m.search_level = 0; m.reject = false; m.align_1d = false;
@@ -802,6 +818,7 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
   if (i >= a.n) return;
   a.success[i] = 0;
   if (a.result) a.result[i] = SVOH_MATCH_NOT_RUN;
+  if (!feature_indices_ok(a, i)) return;
   const int type = a.type[i];
   if (!(type < 6)) return;  // isSeed
   double cur_thresh = a.dopt.seed_convergence_sigma2_thresh;
@@ -901,6 +918,14 @@ struct Staging {
   }
 };
 
+__global__ void count_success_kernel(const uint8_t* success, int n, int* out)
+{
+  int c = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += success[i];
+  c = wave_sum_i32_dpp(c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mopt, const svoh_depth_filter_options* dopt,
                        int n_ref_frames, const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
                        const svoh_feature_batch* fb, const double* depth, double* px_cur, int32_t* result, double* f_cur,
@@ -912,19 +937,23 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   const int n = fb->n;
   if (n_success) *n_success = 0;
   if (n <= 0) return SVOH_OK;
+  SVOH_REQUIRE(ctx, fb->mem_space == SVOH_MEM_HOST || fb->mem_space == SVOH_MEM_DEVICE, "bad mem_space");
+  const bool on_device = fb->mem_space == SVOH_MEM_DEVICE;
   SVOH_REQUIRE(ctx, fb->ref_frame_idx && fb->px && fb->f && fb->grad && fb->level && fb->type, "NULL feature array");
   if (seeds) SVOH_REQUIRE(ctx, dopt && state && success, "NULL seed argument");
   else SVOH_REQUIRE(ctx, depth && px_cur && result, "NULL match argument");
-  for (int i = 0; i < n; ++i) {
-    SVOH_REQUIRE(ctx, fb->ref_frame_idx[i] >= 0 && fb->ref_frame_idx[i] < n_ref_frames, "ref_frame_idx out of range");
-    SVOH_REQUIRE(ctx, fb->level[i] >= 0 && fb->level[i] < SVOH_MAX_LEVELS, "feature level out of range");
+  const int n_cur = (fb->cur_frame_idx && fb->n_cur_frames > 0) ? fb->n_cur_frames : 1;
+  if (!on_device) {
+    for (int i = 0; i < n; ++i) {
+      SVOH_REQUIRE(ctx, fb->ref_frame_idx[i] >= 0 && fb->ref_frame_idx[i] < n_ref_frames, "ref_frame_idx out of range");
+      SVOH_REQUIRE(ctx, fb->level[i] >= 0 && fb->level[i] < SVOH_MAX_LEVELS, "feature level out of range");
+    }
+    if (fb->cur_frame_idx)
+      for (int i = 0; i < n; ++i)
+        SVOH_REQUIRE(ctx, fb->cur_frame_idx[i] >= 0 && fb->cur_frame_idx[i] < n_cur, "cur_frame_idx out of range");
   }
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-  const int n_cur = (fb->cur_frame_idx && fb->n_cur_frames > 0) ? fb->n_cur_frames : 1;
-  if (fb->cur_frame_idx)
-    for (int i = 0; i < n; ++i)
-      SVOH_REQUIRE(ctx, fb->cur_frame_idx[i] >= 0 && fb->cur_frame_idx[i] < n_cur, "cur_frame_idx out of range");
   std::vector<DevFrameView> views((size_t)n_ref_frames + n_cur);
   for (int k = 0; k < n_ref_frames; ++k) {
     int rc = fill_view(ctx, ref_frames[k], &views[k], "reference frame");
@@ -934,30 +963,40 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     int rc = fill_view(ctx, cur_frame[k], &views[n_ref_frames + k], "current frame");
     if (rc != SVOH_OK) return rc;
   }
-  for (int i = 0; i < n; ++i)
-    SVOH_REQUIRE(ctx, fb->level[i] < views[fb->ref_frame_idx[i]].n_levels, "feature level beyond the reference pyramid");
+  if (!on_device)
+    for (int i = 0; i < n; ++i)
+      SVOH_REQUIRE(ctx, fb->level[i] < views[fb->ref_frame_idx[i]].n_levels, "feature level beyond the reference pyramid");
 
+  // Host-resident batches travel through one pinned staging block and one device block:
+  // [views | inputs | in/out | outputs]; device-resident batches stage the views only
+  // and the kernel reads and writes the caller's arrays in place.
   Staging s;
   const size_t o_views = s.add(views.data(), sizeof(DevFrameView) * views.size());
-  const size_t o_idx = s.add(fb->ref_frame_idx, sizeof(int32_t) * n);
-  const size_t o_cidx = fb->cur_frame_idx ? s.add(fb->cur_frame_idx, sizeof(int32_t) * n) : 0;
-  const size_t o_px = s.add(fb->px, sizeof(double) * 2 * n);
-  const size_t o_f = s.add(fb->f, sizeof(double) * 3 * n);
-  const size_t o_grad = s.add(fb->grad, sizeof(double) * 2 * n);
-  const size_t o_level = s.add(fb->level, sizeof(int32_t) * n);
-  const size_t o_type = s.add(fb->type, (size_t)n);
-  size_t o_depth = 0, o_pxcur = 0, o_state = 0;
-  if (seeds) o_state = s.add(state, sizeof(double) * 4 * n);
-  else { o_depth = s.add(depth, sizeof(double) * n); o_pxcur = s.add(px_cur, sizeof(double) * 2 * n); }
+  size_t o_idx = 0, o_cidx = 0, o_px = 0, o_f = 0, o_grad = 0, o_level = 0, o_type = 0, o_depth = 0, o_pxcur = 0,
+         o_state = 0, o_result = 0, o_fcur = 0, o_slevel = 0, o_hinv = 0, o_A = 0, o_success = 0;
+  if (!on_device) {
+    o_idx = s.add(fb->ref_frame_idx, sizeof(int32_t) * n);
+    o_cidx = fb->cur_frame_idx ? s.add(fb->cur_frame_idx, sizeof(int32_t) * n) : 0;
+    o_px = s.add(fb->px, sizeof(double) * 2 * n);
+    o_f = s.add(fb->f, sizeof(double) * 3 * n);
+    o_grad = s.add(fb->grad, sizeof(double) * 2 * n);
+    o_level = s.add(fb->level, sizeof(int32_t) * n);
+    o_type = s.add(fb->type, (size_t)n);
+    if (seeds) o_state = s.add(state, sizeof(double) * 4 * n);
+    else { o_depth = s.add(depth, sizeof(double) * n); o_pxcur = s.add(px_cur, sizeof(double) * 2 * n); }
+  }
   const size_t in_total = s.total;
   // outputs (device only, appended)
   auto out_add = [&](size_t bytes) { const size_t o = s.total; s.total = (s.total + bytes + 63) & ~(size_t)63; return o; };
-  const size_t o_result = out_add(sizeof(int32_t) * n);
-  const size_t o_fcur = out_add(sizeof(double) * 3 * n);
-  const size_t o_slevel = out_add(sizeof(int32_t) * n);
-  const size_t o_hinv = out_add(sizeof(double) * n);
-  const size_t o_A = out_add(sizeof(double) * 4 * n);
-  const size_t o_success = out_add((size_t)n);
+  if (!on_device) {
+    o_result = out_add(sizeof(int32_t) * n);
+    o_fcur = out_add(sizeof(double) * 3 * n);
+    o_slevel = out_add(sizeof(int32_t) * n);
+    o_hinv = out_add(sizeof(double) * n);
+    o_A = out_add(sizeof(double) * 4 * n);
+    o_success = out_add((size_t)n);
+  }
+  const size_t o_nsucc = out_add(sizeof(int32_t));
 
   SVOH_HIP_TRY(ctx, ctx->h_scratch1.reserve(s.total));
   SVOH_HIP_TRY(ctx, ctx->d_scratch1.reserve(s.total));
@@ -973,19 +1012,30 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   a.mopt = *mopt;
   if (dopt) a.dopt = *dopt;
   a.n = n;
-  a.ref_frame_idx = reinterpret_cast<const int32_t*>(d + o_idx);
-  a.cur_frame_idx = fb->cur_frame_idx ? reinterpret_cast<const int32_t*>(d + o_cidx) : nullptr;
-  a.px = reinterpret_cast<const double*>(d + o_px);
-  a.f = reinterpret_cast<const double*>(d + o_f);
-  a.grad = reinterpret_cast<const double*>(d + o_grad);
-  a.level = reinterpret_cast<const int32_t*>(d + o_level);
-  a.type = d + o_type;
-  a.result = reinterpret_cast<int32_t*>(d + o_result);
-  a.f_cur = reinterpret_cast<double*>(d + o_fcur);
-  a.search_level = reinterpret_cast<int32_t*>(d + o_slevel);
-  a.h_inv = reinterpret_cast<double*>(d + o_hinv);
-  a.A_cur_ref = reinterpret_cast<double*>(d + o_A);
-  a.success = d + o_success;
+  a.n_ref_frames = n_ref_frames;
+  a.n_cur_frames = n_cur;
+  if (on_device) {
+    a.ref_frame_idx = fb->ref_frame_idx; a.cur_frame_idx = fb->cur_frame_idx;
+    a.px = fb->px; a.f = fb->f; a.grad = fb->grad; a.level = fb->level; a.type = fb->type;
+    a.result = result; a.f_cur = f_cur; a.search_level = search_level; a.h_inv = h_inv; a.A_cur_ref = A_cur_ref;
+    a.success = success; a.state = state; a.depth = depth; a.px_cur = px_cur;
+  } else {
+    a.ref_frame_idx = reinterpret_cast<const int32_t*>(d + o_idx);
+    a.cur_frame_idx = fb->cur_frame_idx ? reinterpret_cast<const int32_t*>(d + o_cidx) : nullptr;
+    a.px = reinterpret_cast<const double*>(d + o_px);
+    a.f = reinterpret_cast<const double*>(d + o_f);
+    a.grad = reinterpret_cast<const double*>(d + o_grad);
+    a.level = reinterpret_cast<const int32_t*>(d + o_level);
+    a.type = d + o_type;
+    a.result = reinterpret_cast<int32_t*>(d + o_result);
+    a.f_cur = reinterpret_cast<double*>(d + o_fcur);
+    a.search_level = reinterpret_cast<int32_t*>(d + o_slevel);
+    a.h_inv = reinterpret_cast<double*>(d + o_hinv);
+    a.A_cur_ref = reinterpret_cast<double*>(d + o_A);
+    a.success = d + o_success;
+    if (seeds) a.state = reinterpret_cast<double*>(d + o_state);
+    else { a.depth = reinterpret_cast<const double*>(d + o_depth); a.px_cur = reinterpret_cast<double*>(d + o_pxcur); }
+  }
   const dim3 grid((unsigned)((n + 63) / 64)), block(64);
   {
     unsigned long long* dummy;
@@ -994,14 +1044,8 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     if (rc != SVOH_OK) return rc;
   }
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
-  if (seeds) {
-    a.state = reinterpret_cast<double*>(d + o_state);
-    hipLaunchKernelGGL(update_seeds_kernel, grid, block, 0, ctx->stream, a);
-  } else {
-    a.depth = reinterpret_cast<const double*>(d + o_depth);
-    a.px_cur = reinterpret_cast<double*>(d + o_pxcur);
-    hipLaunchKernelGGL(match_direct_kernel, grid, block, 0, ctx->stream, a);
-  }
+  if (seeds) hipLaunchKernelGGL(update_seeds_kernel, grid, block, 0, ctx->stream, a);
+  else hipLaunchKernelGGL(match_direct_kernel, grid, block, 0, ctx->stream, a);
   SVOH_HIP_TRY(ctx, hipGetLastError());
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
   ctx->misc_timed = true;
@@ -1009,9 +1053,23 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     int rc = reduce_unit_counts(ctx, (size_t)n);
     if (rc != SVOH_OK) return rc;
   }
+  if (on_device) {
+    // results stay where the caller put them; only the success count (if asked for) comes back
+    if (seeds && n_success) {
+      int* d_ns = reinterpret_cast<int*>(d + o_nsucc);
+      SVOH_HIP_TRY(ctx, hipMemsetAsync(d_ns, 0, sizeof(int), ctx->stream));
+      const int blocks = (n + 255) / 256 > 256 ? 256 : (n + 255) / 256;
+      hipLaunchKernelGGL(count_success_kernel, dim3(blocks), dim3(256), 0, ctx->stream, success, n, d_ns);
+      SVOH_HIP_TRY(ctx, hipGetLastError());
+      SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_nsucc, d_ns, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      *n_success = *reinterpret_cast<const int*>(h + o_nsucc);
+    }
+    return SVOH_OK;
+  }
   // everything after the inputs that may have changed comes back in one copy
   const size_t back_from = o_type;
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + back_from, d + back_from, s.total - back_from, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + back_from, d + back_from, o_nsucc - back_from, hipMemcpyDeviceToHost, ctx->stream));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (seeds) {
     memcpy(fb->type, h + o_type, (size_t)n);

@@ -267,6 +267,55 @@ def _update_seeds_batch(self, mopt, dopt, ref_views, cur_view, fb, state):
     return ns.value, st, success[:n], mr[:n]
 
 
+def make_feature_batch_device(n, ref_frame_idx, px, f, grad, level, ftype, cur_frame_idx=0, n_cur_frames=0):
+    """Feature batch whose arrays are DEVICE pointers (ints, e.g. torch.Tensor.data_ptr()); the caller keeps
+    the owning tensors alive until the stream has run the call."""
+    fb = capi.svoh_feature_batch()
+    fb.n = int(n)
+    fb.ref_frame_idx, fb.px, fb.f, fb.grad, fb.level, fb.type = ref_frame_idx, px, f, grad, level, ftype
+    fb.cur_frame_idx = cur_frame_idx or None
+    fb.n_cur_frames = int(n_cur_frames)
+    fb.mem_space = capi.SVOH_MEM_DEVICE
+    return fb
+
+
+def _views(views):
+    if isinstance(views, (list, tuple)):
+        return (capi.svoh_frame_view * len(views))(*views), len(views)
+    return C.byref(views), 1
+
+
+def _klt_track_indexed(self, opt, frames, n_tracks, ref_idx, cur_idx, px_ref, px_cur, status,
+                       mem_space=capi.SVOH_MEM_DEVICE):
+    """svoh_klt_track_indexed with raw pointers (ints); device-resident by default, stream-ordered."""
+    tab = (capi.svoh_frame_t * len(frames))(*frames)
+    self._check(self.lib.svoh_klt_track_indexed(self.h, C.byref(opt), len(frames), tab, int(n_tracks), ref_idx, cur_idx,
+                                                px_ref, px_cur, status, int(mem_space)))
+
+
+def _update_seeds_device(self, mopt, dopt, ref_views, cur_views, fb, state, success, match_result=None,
+                         want_count=False):
+    """Device-resident svoh_update_seeds_batch: state / success / match_result are device pointers (ints)
+    updated in place; returns the success count only if want_count (that synchronises)."""
+    rv, n_ref = _views(ref_views)
+    cv, _ = _views(cur_views)
+    ns = C.c_int32()
+    self._check(self.lib.svoh_update_seeds_batch(self.h, C.byref(mopt), C.byref(dopt), n_ref, rv, cv, C.byref(fb),
+                                                 state, success, match_result, C.byref(ns) if want_count else None))
+    return ns.value if want_count else None
+
+
+def _match_direct_device(self, mopt, ref_views, cur_views, fb, depth, px_cur, result, f_cur=None, search_level=None,
+                         h_inv=None, A_cur_ref=None):
+    rv, n_ref = _views(ref_views)
+    cv, _ = _views(cur_views)
+    self._check(self.lib.svoh_match_direct_batch(self.h, C.byref(mopt), n_ref, rv, cv, C.byref(fb), depth, px_cur,
+                                                 result, f_cur, search_level, h_inv, A_cur_ref))
+
+
 Context.klt_track_batch = _klt_track_batch
+Context.klt_track_indexed = _klt_track_indexed
+Context.update_seeds_device = _update_seeds_device
+Context.match_direct_device = _match_direct_device
 Context.match_direct_batch = _match_direct_batch
 Context.update_seeds_batch = _update_seeds_batch

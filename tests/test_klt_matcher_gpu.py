@@ -274,3 +274,113 @@ def test_multi_stream_batch_equals_per_frame_calls(gpu_ctx, oracle_lib):
     for k, p in enumerate(packs):
         pg, sg = gpu_ctx.klt_track_batch(kopt, p[3], p[4], trs[k]["px_ref"], trs[k]["px_cur_init"])
         assert np.array_equal(pg, out[100 * k:100 * (k + 1)]) and np.array_equal(sg, stt[50 * k:50 * (k + 1)])
+
+
+def test_device_resident_batches_equal_host_batches(gpu_ctx, oracle_lib):
+    """mem_space = SVOH_MEM_DEVICE (arrays used in place, stream-ordered) gives bit-identical results to the
+    staged host-pointer calls, for the seed update, the direct matcher and the indexed KLT entry; out-of-range
+    indices in a device batch mark the unit instead of faulting."""
+    import torch
+    dev = torch.device("cuda", 0)
+    orc = oracle_lib
+    packs = [scene_and_frames(gpu_ctx, orc, 90 + k) for k in range(2)]
+    mopt = capi.default_matcher_options()
+    dopt = capi.default_depth_filter_options(packs[0][0].cam)
+    seeds = [synth.make_seed_set(p[0], 500, seed=10 + k) for k, p in enumerate(packs)]
+    rvs = [fe.make_frame_view(p[3], p[0].cam, p[0].T_ref_f_w, seeds[k]["mu_range"], 2 * k) for k, p in enumerate(packs)]
+    cvs = [fe.make_frame_view(p[4], p[0].cam, p[0].T_cur_f_w_gt, 0.0, 2 * k + 1) for k, p in enumerate(packs)]
+    n = 1000
+    idx = np.repeat(np.arange(2, dtype=np.int32), 500)
+    cat = lambda key: np.concatenate([s[key] for s in seeds])
+    # host reference (multi-stream host batch)
+    fb, kk = fe.make_feature_batch(idx, cat("px"), cat("f"), cat("grad"), cat("level"), cat("type"))
+    fb.cur_frame_idx = idx.ctypes.data
+    fb.n_cur_frames = 2
+    import ctypes as C
+    st = cat("state").copy(); succ = np.zeros(n, np.uint8); mr = np.zeros(n, np.int32); ns = C.c_int32()
+    gpu_ctx._check(gpu_ctx.lib.svoh_update_seeds_batch(
+        gpu_ctx.h, C.byref(mopt), C.byref(dopt), 2, (capi.svoh_frame_view * 2)(*rvs), (capi.svoh_frame_view * 2)(*cvs),
+        C.byref(fb), st.ctypes.data, succ.ctypes.data, mr.ctypes.data, C.byref(ns)))
+    # device batch; two extra features with bad indices at the end
+    bad_idx = np.concatenate([idx, np.array([7, 0], np.int32)])
+    bad_lvl = np.concatenate([cat("level").astype(np.int32), np.array([0, 99], np.int32)])
+    pad = lambda a, k: np.concatenate([a, a[:k * 2]])
+    t = dict(idx=torch.from_numpy(bad_idx).to(dev), px=torch.from_numpy(pad(cat("px"), 2)).to(dev),
+             f=torch.from_numpy(pad(cat("f"), 3)).to(dev), grad=torch.from_numpy(pad(cat("grad"), 2)).to(dev),
+             level=torch.from_numpy(bad_lvl).to(dev), type=torch.from_numpy(pad(cat("type").astype(np.uint8), 1)).to(dev),
+             state=torch.from_numpy(pad(cat("state"), 4)).to(dev), succ=torch.full((n + 2,), 9, dtype=torch.uint8, device=dev),
+             mr=torch.zeros(n + 2, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    fbd = fe.make_feature_batch_device(n + 2, t["idx"].data_ptr(), t["px"].data_ptr(), t["f"].data_ptr(),
+                                       t["grad"].data_ptr(), t["level"].data_ptr(), t["type"].data_ptr(),
+                                       cur_frame_idx=t["idx"].data_ptr(), n_cur_frames=2)
+    cnt = gpu_ctx.update_seeds_device(mopt, dopt, rvs, cvs, fbd, t["state"].data_ptr(), t["succ"].data_ptr(),
+                                      t["mr"].data_ptr(), want_count=True)
+    gpu_ctx.synchronize()
+    assert cnt == ns.value
+    assert np.array_equal(t["state"].cpu().numpy()[:4 * n], st)
+    assert np.array_equal(t["succ"].cpu().numpy()[:n], succ) and np.array_equal(t["mr"].cpu().numpy()[:n], mr)
+    assert np.array_equal(t["type"].cpu().numpy()[:n], kk["type"])
+    assert t["succ"].cpu().numpy()[n:].tolist() == [0, 0]
+    assert t["mr"].cpu().numpy()[n:].tolist() == [capi.MATCH_NOT_RUN] * 2
+    # without the count the call does not synchronise; results are stream-ordered
+    t["state"].copy_(torch.from_numpy(pad(cat("state"), 4)).to(dev)); t["type"].copy_(torch.from_numpy(pad(cat("type").astype(np.uint8), 1)).to(dev))
+    torch.cuda.synchronize()
+    assert gpu_ctx.update_seeds_device(mopt, dopt, rvs, cvs, fbd, t["state"].data_ptr(), t["succ"].data_ptr()) is None
+    gpu_ctx.synchronize()
+    assert np.array_equal(t["state"].cpu().numpy()[:4 * n], st)
+
+    # direct matcher
+    sc, ref, cur, fr, fc = packs[0]
+    ms = synth.make_seed_set(sc, 300, seed=3)
+    depth = np.ascontiguousarray(ms["true_depth"], np.float64)
+    types = np.where(ms["type"] == capi.FT_EDGELET_SEED, capi.FT_EDGELET, capi.FT_CORNER).astype(np.uint8)
+    x = ms["f"].reshape(-1, 3).T * ms["true_depth"]
+    px_true = sc.cam.project(sc.T_w_cur.inverse().transform(sc.T_w_ref.transform(x)))
+    px0 = np.ascontiguousarray((px_true + np.random.RandomState(2).uniform(-2.0, 2.0, px_true.shape)).T).ravel()
+    fbh, _k = fe.make_feature_batch(ms["ref_frame_idx"], ms["px"], ms["f"], ms["grad"], ms["level"], types)
+    host = gpu_ctx.match_direct_batch(mopt, [rvs[0]], cvs[0], fbh, depth, px0)
+    d = dict(idx=torch.from_numpy(ms["ref_frame_idx"].astype(np.int32)).to(dev), px=torch.from_numpy(ms["px"]).to(dev),
+             f=torch.from_numpy(ms["f"]).to(dev), grad=torch.from_numpy(ms["grad"]).to(dev),
+             level=torch.from_numpy(ms["level"].astype(np.int32)).to(dev), type=torch.from_numpy(types).to(dev),
+             depth=torch.from_numpy(depth).to(dev), pxc=torch.from_numpy(px0).to(dev),
+             res=torch.zeros(300, dtype=torch.int32, device=dev), fcur=torch.zeros(900, dtype=torch.float64, device=dev),
+             A=torch.zeros(1200, dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    fbm = fe.make_feature_batch_device(300, d["idx"].data_ptr(), d["px"].data_ptr(), d["f"].data_ptr(), d["grad"].data_ptr(),
+                                       d["level"].data_ptr(), d["type"].data_ptr())
+    gpu_ctx.match_direct_device(mopt, [rvs[0]], cvs[0], fbm, d["depth"].data_ptr(), d["pxc"].data_ptr(), d["res"].data_ptr(),
+                                f_cur=d["fcur"].data_ptr(), A_cur_ref=d["A"].data_ptr())
+    gpu_ctx.synchronize()
+    assert np.array_equal(d["res"].cpu().numpy(), host["result"]) and np.array_equal(d["pxc"].cpu().numpy(), host["px_cur"])
+    assert np.array_equal(d["fcur"].cpu().numpy(), host["f_cur"]) and np.array_equal(d["A"].cpu().numpy(), host["A"])
+
+    # indexed KLT: host mode == multi, device mode == host mode, bad index -> status 0
+    trs = [synth.make_track_set(p[0], 60, seed=20 + k) for k, p in enumerate(packs)]
+    kopt = capi.default_klt_options()
+    frames = [packs[0][3], packs[0][4], packs[1][3], packs[1][4]]
+    ridx = np.repeat(np.array([0, 2], np.int32), 60); cidx = ridx + 1
+    pr = np.concatenate([tr["px_ref"] for tr in trs]).astype(np.int32); p0 = np.concatenate([tr["px_cur_init"] for tr in trs])
+    outs, sts = [], []
+    for k, p in enumerate(packs):
+        pg, sg = gpu_ctx.klt_track_batch(kopt, p[3], p[4], trs[k]["px_ref"], trs[k]["px_cur_init"])
+        outs.append(pg); sts.append(sg)
+    want_px, want_st = np.concatenate(outs), np.concatenate(sts)
+    hp = p0.copy(); hs = np.zeros(120, np.uint8)
+    gpu_ctx.klt_track_indexed(kopt, frames, 120, ridx.ctypes.data, cidx.ctypes.data, pr.ctypes.data, hp.ctypes.data,
+                              hs.ctypes.data, mem_space=capi.SVOH_MEM_HOST)
+    assert np.array_equal(hp, want_px) and np.array_equal(hs, want_st)
+    ridx_bad = np.concatenate([ridx, np.array([4], np.int32)]); cidx_bad = np.concatenate([cidx, np.array([1], np.int32)])
+    k_t = dict(r=torch.from_numpy(ridx_bad).to(dev), c=torch.from_numpy(cidx_bad).to(dev),
+               pr=torch.from_numpy(np.concatenate([pr, pr[:2]])).to(dev), pc=torch.from_numpy(np.concatenate([p0, p0[:2]])).to(dev),
+               st=torch.full((121,), 7, dtype=torch.uint8, device=dev))
+    torch.cuda.synchronize()
+    gpu_ctx.klt_track_indexed(kopt, frames, 121, k_t["r"].data_ptr(), k_t["c"].data_ptr(), k_t["pr"].data_ptr(),
+                              k_t["pc"].data_ptr(), k_t["st"].data_ptr())
+    gpu_ctx.synchronize()
+    assert np.array_equal(k_t["pc"].cpu().numpy()[:240], want_px) and np.array_equal(k_t["st"].cpu().numpy()[:120], want_st)
+    assert int(k_t["st"][120]) == 0
+    # host-mode validation still fails the call
+    with pytest.raises(fe.SvohError):
+        gpu_ctx.klt_track_indexed(kopt, frames, 121, ridx_bad.ctypes.data, cidx_bad.ctypes.data, pr.ctypes.data,
+                                  hp.ctypes.data, hs.ctypes.data, mem_space=capi.SVOH_MEM_HOST)
