@@ -348,14 +348,115 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
             "cpu_baseline": cpu}
 
 
+def bench_frame(args, ctx, dist, rank, world, dev, comm_dev=None):
+    """C3-synth: the per-frame hot path at the EuRoC mono sizes of SURVEY.md Appendix A, one frame at a time
+    (latency, not throughput): 752x480 radtan camera; 5-level pyramid of the new image (host image in);
+    SparseImgAlign 180 features, 4x4, levels 4..2 (host arrays in, pose out); KLT 180 tracks {16,16,16,8,8};
+    depth-filter update of 3 keyframes x 540 seeds against the new frame (host arrays in/out).  Every stage is
+    one blocking C-ABI call, as the frame handler would make it."""
+    cam = synth.Camera.euroc_like(752, 480)
+    NF, NS, NKF = 180, 540, 3
+    sc = synth.make_align_scene(du.problem_seed(rank, 7), n_features=NF, patch_size=4, cam=cam, max_level=4,
+                                rot_deg=(0.3, 1.0), trans_m=(0.03, 0.10))
+    opt = capi.default_align_options(max_level=4, min_level=2, patch_size=4)
+    kopt = capi.default_klt_options()
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(cam)
+    f_ref = ctx.build_pyramid(sc.img_ref, 5)
+    tracks = synth.make_track_set(sc, NF, seed=1)
+    seeds = synth.make_seed_set(sc, NS * NKF, seed=2)
+    kf_idx = np.repeat(np.arange(NKF, dtype=np.int32), NS)
+    stages = {k: [] for k in ("pyramid", "align", "klt", "seeds", "total")}
+    last = {}
+
+    def one_frame():
+        t0 = time.perf_counter()
+        f_cur = ctx.build_pyramid(sc.img_cur, 5)
+        t1 = time.perf_counter()
+        problems, keep = fe.make_align_problems([[(sc, f_ref, f_cur, None)]])
+        res = ctx.sparse_align(opt, problems)
+        t2 = time.perf_counter()
+        pk, sk = ctx.klt_track_batch(kopt, f_ref, f_cur, tracks["px_ref"], tracks["px_cur_init"])
+        t3 = time.perf_counter()
+        ref_views = [fe.make_frame_view(f_ref, cam, sc.T_ref_f_w, seeds["mu_range"], k) for k in range(NKF)]
+        cur_view = fe.make_frame_view(f_cur, cam, sc.T_cur_f_w_gt, 0.0, 100)
+        fb, kk = fe.make_feature_batch(kf_idx, seeds["px"], seeds["f"], seeds["grad"], seeds["level"], seeds["type"])
+        ns, st, succ, mr = ctx.update_seeds_batch(mopt, dopt, ref_views, cur_view, fb, seeds["state"])
+        t4 = time.perf_counter()
+        ctx.release_frame(f_cur)
+        last.update(res=res[0], klt=(pk, sk), seeds=(ns, st, succ, mr))
+        return t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0
+
+    for _ in range(args.warmup):
+        one_frame()
+    if world > 1:
+        dist.barrier()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        ts = one_frame()
+        for k, v in zip(("pyramid", "align", "klt", "seeds", "total"), ts):
+            stages[k].append(1e3 * v)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t_begin
+    elapsed, total_frames = du.combine(dist, world, elapsed, args.steps, comm_dev)
+    med = {k: float(np.median(v)) for k, v in stages.items()}
+    err = synth.se3_error(synth.SE3.from7(fe.se3_to_numpy(last["res"].T_icur_iref)), sc.T_icur_iref_gt)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc  # test infrastructure: the timed CPU baseline only
+        orc.build(fast=True)
+        ref = orc.create_img_pyramid(sc.img_ref, 5, fast=True)
+        c = {k: [] for k in stages}
+        t_cpu0 = time.perf_counter()
+        while time.perf_counter() - t_cpu0 < 10.0 and len(c["total"]) < 200:
+            t0 = time.perf_counter()
+            cur = orc.create_img_pyramid(sc.img_cur, 5, fast=True)
+            t1 = time.perf_counter()
+            pb = orc.problem_from_scenes([(sc, ref, cur)])
+            n_o, res_o, _ = orc.sparse_align_run(opt, pb, fast=True)
+            t2 = time.perf_counter()
+            po, so = orc.klt_track_batch(kopt, ref, cur, tracks["px_ref"], tracks["px_cur_init"], fast=True)
+            t3 = time.perf_counter()
+            ov_r = [orc.make_frame_view(ref, cam, sc.T_ref_f_w, seeds["mu_range"], k) for k in range(NKF)]
+            ov_c = orc.make_frame_view(cur, cam, sc.T_cur_f_w_gt, 0.0, 100)
+            fbo, ko = orc.make_feature_batch(kf_idx, seeds["px"], seeds["f"], seeds["grad"], seeds["level"], seeds["type"])
+            nso, sto, so2, mro = orc.update_seeds_batch(mopt, dopt, ov_r, ov_c, fbo, seeds["state"], fast=True)
+            t4 = time.perf_counter()
+            for k, v in zip(("pyramid", "align", "klt", "seeds", "total"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)):
+                c[k].append(1e3 * v)
+        cmed = {k: float(np.median(v)) for k, v in c.items()}
+        assert np.array_equal(so, last["klt"][1]) and np.array_equal(po, last["klt"][0])
+        cpu = {"value": 1e3 / cmed["total"], "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "%d repetitions of the same frame through the oracle (gcc -O3 -march=native, 1 thread)" % len(c["total"]),
+               "stage_ms_median": cmed}
+    if rank != 0:
+        return None
+    kms = ctypes.c_float()
+    ctx.lib.svoh_sparse_align_last_kernel_ms(ctx.h, ctypes.byref(kms))
+    alg = algorithmic_bytes(4, 6, last["res"].n_patch_iters, last["res"].n_fts_to_track * 3)
+    return {"metric": "frames/s, one frame at a time (pyramid + SparseImgAlign + KLT + depth-filter update, EuRoC mono sizes)",
+            "value": total_frames / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_frame": med["total"], "dtype": "u8+i32+f32+f64",
+            "config": {"workload": "C3-synth: 752x480 radtan, 5-level pyramid, align 180 feat 4x4 levels 4..2, KLT 180 tracks, "
+                                   "3 keyframes x 540 seeds; blocking C-ABI calls with host arrays, one frame at a time",
+                       "features": NF, "seeds": NS * NKF},
+            "stage_ms_median": med, "align_pose_err_vs_gt": {"rot_rad": err[0], "trans_m": err[1]},
+            "seed_successes": int(last["seeds"][0]), "klt_converged": int(last["klt"][1].sum()),
+            "roofline": {"bound": "hbm", "achieved": alg / (kms.value * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (kms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sparse_align_kernel<4,*,false> (single problem: latency-bound by design)",
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kms.value},
+            "cpu_baseline": cpu}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--problems", type=int, default=0, help="frame pairs per GPU per step (default: per workload)")
-    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds"],
-                    help="align = the headline SparseImgAlign config (default); klt / seeds = the other hot-path rows")
+    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds", "frame"],
+                    help="align = the headline SparseImgAlign config (default); klt / seeds = the other hot-path rows; "
+                         "frame = the whole per-frame chain at EuRoC mono sizes, one frame at a time (latency)")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--patch", type=int, default=4)
     ap.add_argument("--min-level", type=int, default=0)
@@ -380,7 +481,8 @@ def main():
 
     ctx = fe.Context(local_rank)
     if args.workload != "align":
-        out = (bench_klt if args.workload == "klt" else bench_seeds)(args, ctx, dist, rank, world, dev, comm_dev)
+        out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame}[args.workload](
+            args, ctx, dist, rank, world, dev, comm_dev)
         if rank == 0:
             out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
                         "scaling": "weak", "vs_baseline": None, "data": "synthetic"})

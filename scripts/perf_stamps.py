@@ -3,9 +3,9 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from svo_pro_universal_amd import _capi as capi, frontend as fe
 import bench
-B = int(os.environ.get("B", "512")); P = int(os.environ.get("P", "4"))
+B = int(os.environ.get("B", "512")); P = int(os.environ.get("P", "4")); N = int(os.environ.get("N", "2000"))
 ctx = fe.Context(0)
-problems, scenes, imgs, keep = bench.build_problems(ctx, torch.device("cuda", 0), 0, B, 2000, P, 4)
+problems, scenes, imgs, keep = bench.build_problems(ctx, torch.device("cuda", 0), 0, B, N, P, 4)
 for kw in (dict(min_level=0), dict(min_level=2), dict(max_level=0, min_level=0)):
     opt = capi.default_align_options(patch_size=P, **kw)
     print(kw, flush=True)
