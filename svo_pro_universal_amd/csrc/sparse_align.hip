@@ -327,6 +327,58 @@ __device__ __forceinline__ void accumulate_patch(const double (&mom)[AccLayout<D
   acc[NH + D] += mom[5];
 }
 
+// ---- wave-level reduce-scatter of the normal-equation accumulators ----
+// A butterfly in which every stage halves the number of live values: the lane pair
+// (l, l ^ off) splits the index range, each side keeps one half and adds the partner's
+// copy of it.  NACC -> ceil/2 -> ... -> 1 takes 31 exchanges for the 29 accumulators of
+// the SE3 case (47 for 45) instead of 6 x NACC with an all-reduce per value, and the
+// two widest stages (off 1 and 2) run on the DPP network instead of ds_bpermute.
+// Afterwards lane l holds the wave total of accumulator `idx` (if `valid`).
+template <int OFF>
+__device__ __forceinline__ double xor_exchange(double v)
+{
+  if constexpr (OFF == 1 || OFF == 2) {
+    constexpr int ctrl = OFF == 1 ? 0xB1 : 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
+    const unsigned long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, ctrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), ctrl, 0xF, 0xF, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+  } else {
+    return __shfl_xor(v, OFF, 64);
+  }
+}
+
+template <int N, int OFF>
+__device__ __forceinline__ void reduce_scatter_stage(double* v, int lane, int& base, int& cnt)
+{
+  constexpr int HALF = (N + 1) / 2;
+  const bool up = (lane & OFF) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const double a = v[i];
+    const double b = (i + HALF < N) ? v[i + HALF] : 0.0;
+    const double recv = xor_exchange<OFF>(up ? a : b);
+    v[i] = (up ? b : a) + recv;
+  }
+  if (up) { base += HALF; cnt -= HALF; }
+  else cnt = cnt < HALF ? cnt : HALF;
+}
+
+template <int NACC>
+__device__ __forceinline__ void wave_reduce_scatter(double (&v)[NACC], int lane, int& idx, bool& valid)
+{
+  constexpr int N1 = (NACC + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
+  int base = 0, cnt = NACC;
+  reduce_scatter_stage<NACC, 1>(v, lane, base, cnt);
+  reduce_scatter_stage<N1, 2>(v, lane, base, cnt);
+  reduce_scatter_stage<N2, 4>(v, lane, base, cnt);
+  reduce_scatter_stage<N3, 8>(v, lane, base, cnt);
+  reduce_scatter_stage<N4, 16>(v, lane, base, cnt);
+  reduce_scatter_stage<N5, 32>(v, lane, base, cnt);
+  idx = base;
+  valid = cnt >= 1;
+}
+
 template <int NT>
 __device__ __forceinline__ void stage_image(unsigned char* dst, const DevImage& im, int tid)
 {
@@ -516,6 +568,124 @@ __device__ __forceinline__ bool ldlt_solve_regs(double (&m)[N * (N + 1) / 2], do
   }
   return !(x[0] != x[0]);
 }
+
+// One Gauss-Newton bookkeeping step, run by a single lane: prior, pivoted LDL^T, SE3
+// update, convergence (MiniLeastSquaresSolver::optimizeGaussNewton,
+// mini_least_squares_solver.hpp:42-107).  Kept out of line on purpose: inlined into the
+// kernel its ~3000 instructions and ~100 live registers share one register allocation
+// with the patch loop, and both ends pay for it with spills.
+template <int P, int D, bool ILLUM>
+__device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& a, const DevProblemDesc& pb,
+                                                         const DevCamDesc* cams, int n_cams, int pbi, int level,
+                                                         int iter, bool eval_mode, ShState& s, const double* s_sum,
+                                                         int* s_nvis_p)
+{
+  constexpr int NH = AccLayout<D>::NH;
+  const svoh_align_options& opt = a.opt;
+  int& s_nvis = *s_nvis_p;
+
+    const int n_meas = s_nvis * P * P;
+    s.patch_iters += s_nvis;
+    s_nvis = 0;
+    const double chi2 = s_sum[NH + D] / (double)n_meas;
+    double m[36], xg[8];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) m[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xg[k] = 0.0;
+    {
+      int idx = 0;
+#pragma unroll
+      for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c2 = r; c2 < D; ++c2) SVOH_L(c2, r) = s_sum[idx++];  // H(r,c2) = H(c2,r)
+#pragma unroll
+      for (int r = 0; r < D; ++r) xg[r] = s_sum[NH + r];
+    }
+    svoh_align_result& res = a.results[pbi];
+    if (level < SVOH_MAX_LEVELS) {
+      res.iters[level] = iter + 1;
+      res.n_meas[level] = n_meas;
+      res.chi2[level] = chi2;
+    }
+    if (eval_mode) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c2 = 0; c2 <= r; ++c2) {
+          a.eval_out[c2 * 8 + r] = SVOH_L(r, c2);
+          a.eval_out[r * 8 + c2] = SVOH_L(r, c2);
+        }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a.eval_out[64 + k] = xg[k];
+      a.eval_out[72] = chi2;
+      a.eval_out[73] = (double)n_meas;
+      s.level_done = 1;
+    } else {
+      if (pb.prior.have_prior) {
+        // SparseImgAlignBase::applyPrior (sparse_img_align_base.cpp:77-107)
+        if (iter == 0) {
+          double mt = 0, mr = 0;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) mt = fmax(mt, fabs(SVOH_L(j, j)));
+#pragma unroll
+          for (int j = 3; j < 6; ++j) mr = fmax(mr, fabs(SVOH_L(j, j)));
+          for (int j = 0; j < 3; ++j) s.I_prior[j] = 1.0 * pb.prior.lambda_trans * mt;
+          for (int j = 3; j < 6; ++j) s.I_prior[j] = 1.0 * pb.prior.lambda_rot * mr;
+          s.I_prior[6] = pb.prior.lambda_alpha * SVOH_L(6, 6);
+          s.I_prior[7] = pb.prior.lambda_beta * SVOH_L(7, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) SVOH_L(j, j) += s.I_prior[j];
+        double lg[6];
+        rigid_log(mul(inverse(load_rigid(pb.prior.T_prior)), s.T), lg);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xg[j] += s.I_prior[j] * lg[j];
+        xg[6] += s.I_prior[6] * (pb.prior.alpha_prior - s.alpha);
+        xg[7] += s.I_prior[7] * (pb.prior.beta_prior - s.beta);
+      }
+      // without illumination terms rows/columns 6 and 7 are exactly zero: the
+      // pivoted factorisation never selects them before the six pose pivots and
+      // they contribute exact zeros, so the 6x6 leading block gives the same bits
+      if constexpr (ILLUM) {
+        if (!ldlt_solve_regs<8>(m, xg)) s.stop = 1;
+      } else {
+        double m6[21], x6[6];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) m6[k] = m[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x6[k] = xg[k];
+        if (!ldlt_solve_regs<6>(m6, x6)) s.stop = 1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xg[k] = x6[k];
+        xg[6] = 0.0; xg[7] = 0.0;
+      }
+      if (s.stop) {
+        // rollback (mini_least_squares_solver.hpp:73-82); stop_ is only cleared by reset()
+        s.T = s.Told; s.alpha = s.alpha_old; s.beta = s.beta_old;
+        s.status = 2;
+        s.level_done = 1;
+      } else {
+        // SparseImgAlignBase::update (sparse_img_align_base.cpp:64-75)
+        double mdx[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) mdx[j] = -xg[j];
+        Rigid Tn = mul(s.T, rigid_exp(mdx));
+        const double an = (s.alpha - xg[6]) / (1.0 + xg[6]);
+        const double bn = (s.beta - xg[7]) / (1.0 + xg[6]);
+        Tn.q = normalized(Tn.q);
+        s.Told = s.T; s.alpha_old = s.alpha; s.beta_old = s.beta;
+        s.T = Tn; s.alpha = an; s.beta = bn;
+        double x_norm = -1.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double v = fabs(xg[j]); if (v > x_norm) x_norm = v; }
+        if (x_norm < opt.eps) s.level_done = 1;
+      }
+      for (int c = 0; c < n_cams; ++c)
+        s.Tcr[c] = mul(mul(load_rigid(cams[c].cur_T_cam_imu), s.T), load_rigid(cams[c].ref_T_imu_cam));
+      s.alpha_f = (float)s.alpha; s.beta_f = (float)s.beta;
+    }
+  }
 
 #ifndef SVOH_ALIGN_MIN_WAVES_256
 #define SVOH_ALIGN_MIN_WAVES_256 2
@@ -714,21 +884,15 @@ void sparse_align_kernel(const AlignKernelArgs a)
       }
 
       SVOH_STAMP_ADD(2);
-      // ---- reduce: wave shuffles, then across waves through LDS ----
-#pragma unroll
-      for (int k = 0; k < NACC; ++k) {
-        double v = acc[k];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-        acc[k] = v;
+      // ---- reduce: butterfly reduce-scatter per wave, then across waves through LDS ----
+      {
+        int ridx;
+        bool rvalid;
+        wave_reduce_scatter<NACC>(acc, lane, ridx, rvalid);
+        if (rvalid) s_red[wave][ridx] = acc[0];
       }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) nvis += __shfl_xor(nvis, o, 64);
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) s_red[wave][k] = acc[k];
-        atomicAdd(&s_nvis, nvis);
-      }
+      nvis = wave_sum_i32_dpp(nvis);
+      if (lane == 0) atomicAdd(&s_nvis, nvis);
       __syncthreads();
       if (tid < NACC) {
         double v = 0.0;
@@ -738,110 +902,8 @@ void sparse_align_kernel(const AlignKernelArgs a)
       __syncthreads();
 
       SVOH_STAMP_ADD(3);
-      // ---- serial part: prior, 8x8 LDL^T, SE3 update, convergence ----
-      if (tid == 0) {
-        const int n_meas = s_nvis * P * P;
-        s.patch_iters += s_nvis;
-        s_nvis = 0;
-        const double chi2 = s_sum[NH + D] / (double)n_meas;
-        double m[36], xg[8];
-#pragma unroll
-        for (int k = 0; k < 36; ++k) m[k] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) xg[k] = 0.0;
-        {
-          int idx = 0;
-#pragma unroll
-          for (int r = 0; r < D; ++r)
-#pragma unroll
-            for (int c2 = r; c2 < D; ++c2) SVOH_L(c2, r) = s_sum[idx++];  // H(r,c2) = H(c2,r)
-#pragma unroll
-          for (int r = 0; r < D; ++r) xg[r] = s_sum[NH + r];
-        }
-        svoh_align_result& res = a.results[pbi];
-        if (level < SVOH_MAX_LEVELS) {
-          res.iters[level] = iter + 1;
-          res.n_meas[level] = n_meas;
-          res.chi2[level] = chi2;
-        }
-        if (eval_mode) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int c2 = 0; c2 <= r; ++c2) {
-              a.eval_out[c2 * 8 + r] = SVOH_L(r, c2);
-              a.eval_out[r * 8 + c2] = SVOH_L(r, c2);
-            }
-#pragma unroll
-          for (int k = 0; k < 8; ++k) a.eval_out[64 + k] = xg[k];
-          a.eval_out[72] = chi2;
-          a.eval_out[73] = (double)n_meas;
-          s.level_done = 1;
-        } else {
-          if (pb.prior.have_prior) {
-            // SparseImgAlignBase::applyPrior (sparse_img_align_base.cpp:77-107)
-            if (iter == 0) {
-              double mt = 0, mr = 0;
-#pragma unroll
-              for (int j = 0; j < 3; ++j) mt = fmax(mt, fabs(SVOH_L(j, j)));
-#pragma unroll
-              for (int j = 3; j < 6; ++j) mr = fmax(mr, fabs(SVOH_L(j, j)));
-              for (int j = 0; j < 3; ++j) s.I_prior[j] = 1.0 * pb.prior.lambda_trans * mt;
-              for (int j = 3; j < 6; ++j) s.I_prior[j] = 1.0 * pb.prior.lambda_rot * mr;
-              s.I_prior[6] = pb.prior.lambda_alpha * SVOH_L(6, 6);
-              s.I_prior[7] = pb.prior.lambda_beta * SVOH_L(7, 7);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) SVOH_L(j, j) += s.I_prior[j];
-            double lg[6];
-            rigid_log(mul(inverse(load_rigid(pb.prior.T_prior)), s.T), lg);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) xg[j] += s.I_prior[j] * lg[j];
-            xg[6] += s.I_prior[6] * (pb.prior.alpha_prior - s.alpha);
-            xg[7] += s.I_prior[7] * (pb.prior.beta_prior - s.beta);
-          }
-          // without illumination terms rows/columns 6 and 7 are exactly zero: the
-          // pivoted factorisation never selects them before the six pose pivots and
-          // they contribute exact zeros, so the 6x6 leading block gives the same bits
-          if constexpr (ILLUM) {
-            if (!ldlt_solve_regs<8>(m, xg)) s.stop = 1;
-          } else {
-            double m6[21], x6[6];
-#pragma unroll
-            for (int k = 0; k < 21; ++k) m6[k] = m[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) x6[k] = xg[k];
-            if (!ldlt_solve_regs<6>(m6, x6)) s.stop = 1;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) xg[k] = x6[k];
-            xg[6] = 0.0; xg[7] = 0.0;
-          }
-          if (s.stop) {
-            // rollback (mini_least_squares_solver.hpp:73-82); stop_ is only cleared by reset()
-            s.T = s.Told; s.alpha = s.alpha_old; s.beta = s.beta_old;
-            s.status = 2;
-            s.level_done = 1;
-          } else {
-            // SparseImgAlignBase::update (sparse_img_align_base.cpp:64-75)
-            double mdx[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) mdx[j] = -xg[j];
-            Rigid Tn = mul(s.T, rigid_exp(mdx));
-            const double an = (s.alpha - xg[6]) / (1.0 + xg[6]);
-            const double bn = (s.beta - xg[7]) / (1.0 + xg[6]);
-            Tn.q = normalized(Tn.q);
-            s.Told = s.T; s.alpha_old = s.alpha; s.beta_old = s.beta;
-            s.T = Tn; s.alpha = an; s.beta = bn;
-            double x_norm = -1.0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const double v = fabs(xg[j]); if (v > x_norm) x_norm = v; }
-            if (x_norm < opt.eps) s.level_done = 1;
-          }
-          for (int c = 0; c < n_cams; ++c)
-            s.Tcr[c] = mul(mul(load_rigid(cams[c].cur_T_cam_imu), s.T), load_rigid(cams[c].ref_T_imu_cam));
-          s.alpha_f = (float)s.alpha; s.beta_f = (float)s.beta;
-        }
-      }
+      // ---- serial part: prior, pivoted LDL^T, SE3 update, convergence ----
+      if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, pbi, level, iter, eval_mode, s, s_sum, &s_nvis);
       __syncthreads();
       SVOH_STAMP_ADD(4);
       if (s.level_done) break;
