@@ -10,4 +10,5 @@ for kw in (dict(min_level=0), dict(min_level=2), dict(max_level=0, min_level=0))
     opt = capi.default_align_options(patch_size=P, **kw)
     print(kw, flush=True)
     for i in range(2):
-        ctx.sparse_align(opt, problems)
+        res = ctx.sparse_align(opt, problems)
+    print("iters of problem 0:", list(res[0].iters), "sum", sum(res[0].iters), flush=True)
