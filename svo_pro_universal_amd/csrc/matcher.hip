@@ -186,7 +186,7 @@ __device__ bool warp_affine(const double A_cur_ref[4], const DevImage& img_ref, 
       const float pxy = (a10 * fx + a11 * fy) + pry;
       const int xi = (int)floorf(pxx);
       const int yi = (int)floorf(pxy);
-      inside = inside && !(xi < 0 || yi < 0 || xi + 1 >= img_ref.w || yi + 1 >= img_ref.h);
+      inside = inside && pxx == pxx && pxy == pxy && !(xi < 0 || yi < 0 || xi >= img_ref.w - 1 || yi >= img_ref.h - 1);  // no `xi + 1`: xi may be INT_MAX
     }
   }
   if (!inside) return false;
@@ -895,6 +895,10 @@ static int fill_view(svoh_ctx* ctx, const svoh_frame_view& v, DevFrameView* out,
   if (!f) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "%s: unknown frame handle %llu", what, (unsigned long long)v.frame);
   if (v.cam.distortion != SVOH_DISTORTION_NONE && v.cam.distortion != SVOH_DISTORTION_RADTAN)
     return set_error(ctx, SVOH_ERR_UNSUPPORTED, "%s: unsupported distortion model", what);
+  // the matcher's bounds tests use the camera's size (matcher.cpp:67-70, 340-413): it must be the frame's
+  if (v.cam.width != f->lv[0].w || v.cam.height != f->lv[0].h)
+    return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "%s: camera is %dx%d but the frame's level 0 is %dx%d", what,
+                     v.cam.width, v.cam.height, f->lv[0].w, f->lv[0].h);
   for (int l = 0; l < SVOH_MAX_LEVELS; ++l) out->lv[l] = l < f->n_levels ? f->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
   out->cam = load_camera(v.cam);
   out->T_f_w = load_rigid(v.T_f_w);
@@ -962,6 +966,14 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   for (int k = 0; k < n_cur; ++k) {
     int rc = fill_view(ctx, cur_frame[k], &views[n_ref_frames + k], "current frame");
     if (rc != SVOH_OK) return rc;
+  }
+  {
+    // the search level is chosen up to the reference pyramid's top (patch_warp.cpp:97-110) and then read
+    // from the current frame: every current frame needs at least as many levels
+    int ref_levels = 0;
+    for (int k = 0; k < n_ref_frames; ++k) ref_levels = views[k].n_levels > ref_levels ? views[k].n_levels : ref_levels;
+    for (int k = 0; k < n_cur; ++k)
+      SVOH_REQUIRE(ctx, views[n_ref_frames + k].n_levels >= ref_levels, "current frame has fewer pyramid levels than a reference frame");
   }
   if (!on_device)
     for (int i = 0; i < n; ++i)

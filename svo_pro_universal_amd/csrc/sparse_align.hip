@@ -441,6 +441,7 @@ __device__ __forceinline__ void accumulate_camera(
       const double u_tl = u * scale - patch_center;
       const double v_tl = v * scale - patch_center;
       vis = !(u_tl < 0.0 || v_tl < 0.0 || u_tl + P + 2.0 >= cw || v_tl + P + 2.0 >= ch);
+      vis = vis && u_tl == u_tl && v_tl == v_tl;  // a NaN passes the reference's test; never index with it
       if (vis) {
         const double fu = floor(u_tl), fv = floor(v_tl);
         cu = (int)fu; cv = (int)fv;
@@ -696,7 +697,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? SVOH_ALIGN_MIN_WAVES_256 : (NT == 
 void sparse_align_kernel(const AlignKernelArgs a)
 {
   constexpr int D = ILLUM ? 8 : 6;
-  constexpr int NH = AccLayout<D>::NH;
   constexpr int NACC = AccLayout<D>::NACC;
   constexpr int NW = NT / 64;
 
@@ -762,8 +762,10 @@ void sparse_align_kernel(const AlignKernelArgs a)
           const double v_tl = pv * scale - patch_center_wb;
           const int u_tl_i = (int)floor(u_tl);
           const int v_tl_i = (int)floor(v_tl);
-          sel = !(u_tl_i < 0 || v_tl_i < 0 || u_tl_i + patch_size_wb >= cols_minus_two ||
-                  v_tl_i + patch_size_wb >= rows_minus_two);
+          // same test as sparse_img_align.cpp:221-225 with the constant moved to the right-hand side:
+          // a wild pixel saturates the int conversion and `+ patch_size_wb` must not wrap around
+          sel = !(u_tl_i < 0 || v_tl_i < 0 || u_tl_i >= cols_minus_two - patch_size_wb ||
+                  v_tl_i >= rows_minus_two - patch_size_wb);
         }
         a.wsel[gi] = sel ? 1 : 0;
         a.wvis[gi] = 0;
