@@ -245,6 +245,32 @@ def test_full_size_properties(gpu_ctx):
     assert helpers.se3_max_abs_diff(rp.T_icur_iref, r1[0].T_icur_iref) < 1e-9
 
 
+def test_normal_equations_are_additive_over_patch_shards(gpu_ctx):
+    """The sharding rule of SURVEY.md 8(e): H, g, chi2*n and n_meas of a frame are the sums of the same
+    quantities over any partition of its patches (what a patch-split all-reduce would add up), at full size."""
+    cam = synth.Camera.test_camera()
+    sc = synth.make_align_scene(120, n_features=2000, cam=cam)
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+    opt = capi.default_align_options(estimate_illumination_gain=1, estimate_illumination_offset=1)
+    flags0 = sc.flags.copy()
+    rng = np.random.RandomState(5)
+    owner = rng.randint(0, 4, sc.n_features)          # 4 "ranks"
+    for level in (4, 2, 0):
+        pb, keep = fe.make_align_problems([[(sc, fr, fc)]])
+        H, g, chi2, nm, vis = gpu_ctx.sparse_align_evaluate(opt, pb[0], level)
+        Hs, gs, cs, ns = np.zeros((8, 8)), np.zeros(8), 0.0, 0
+        for r in range(4):
+            sc.flags = (flags0 * (owner == r)).astype(np.uint8)
+            pbr, keepr = fe.make_align_problems([[(sc, fr, fc)]])
+            Hr, gr, cr, nr, vr = gpu_ctx.sparse_align_evaluate(opt, pbr[0], level)
+            Hs += Hr; gs += gr; cs += cr * nr; ns += nr
+        sc.flags = flags0
+        assert ns == nm and nm > 0
+        assert np.abs(Hs - H).max() <= 1e-11 * np.abs(H).max()
+        assert np.abs(gs - g).max() <= 1e-11 * np.abs(g).max()
+        assert abs(cs - chi2 * nm) <= 1e-11 * chi2 * nm
+
+
 def test_error_codes(gpu_ctx):
     sc = helpers.small_scene(39, n=50)
     fr = gpu_ctx.build_pyramid(sc.img_ref, 3)
