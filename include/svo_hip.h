@@ -397,6 +397,29 @@ int svoh_update_seeds_batch(svoh_ctx* ctx, const svoh_matcher_options* matcher_o
                             double* state, uint8_t* success, int32_t* match_result,
                             int32_t* n_success);
 
+/* What Matcher holds after the epipolar search of updateSeed and what
+ * reprojector_utils::matchCandidate (src/svo/src/reprojector.cpp:403-413, 473-476) reads
+ * from it when an unconverged seed is matched during reprojection: px_cur_, f_cur_,
+ * search_level_, A_cur_ref_.  Every pointer may be NULL; arrays are n-long batches like
+ * the outputs of svoh_match_direct_batch and live where features->mem_space says. */
+typedef struct svoh_seed_match_outputs {
+  double* px_cur;          /* 2 x n */
+  double* f_cur;           /* 3 x n */
+  int32_t* search_level;   /* n */
+  double* A_cur_ref;       /* 4 x n, col-major 2x2 */
+} svoh_seed_match_outputs;
+
+/* svoh_update_seeds_batch that also returns the matcher state of every seed (outputs may
+ * be NULL = svoh_update_seeds_batch).  Entries of seeds whose update returned before the
+ * epipolar search (match_result SVOH_MATCH_NOT_RUN) read back as zeros from a host-resident
+ * batch and are left untouched in a device-resident one. */
+int svoh_update_seeds_batch_ex(svoh_ctx* ctx, const svoh_matcher_options* matcher_options,
+                               const svoh_depth_filter_options* options,
+                               int n_ref_frames, const svoh_frame_view* ref_frames,
+                               const svoh_frame_view* cur_frame, const svoh_feature_batch* features,
+                               double* state, uint8_t* success, int32_t* match_result,
+                               int32_t* n_success, const svoh_seed_match_outputs* outputs);
+
 #ifdef __cplusplus
 }
 #endif

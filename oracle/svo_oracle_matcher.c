@@ -823,3 +823,69 @@ int orc_update_seeds_batch(const svoh_matcher_options* mopt, const svoh_depth_fi
   }
   return n_success;
 }
+
+/* ---- reprojector_utils::matchCandidates (reprojector.cpp:342-382) + matchCandidate (:384-486) ---- */
+int orc_match_candidates(const svoh_matcher_options* mopt, const svoh_depth_filter_options* dopt, int n_ref_frames,
+                         const orc_frame_view* ref_frames, const orc_frame_view* cur_frame, int n_candidates,
+                         orc_candidate* cands, int max_n_features_per_frame, int* num_features_io, int cell_size,
+                         int n_cols, int n_rows, uint8_t* occupancy, uint8_t* visited, int32_t* result,
+                         orc_new_feature* out, int* n_out, int* n_trials, int* n_matches,
+                         int* n_failed_reproj, int* n_succeeded_reproj)
+{
+  (void)n_ref_frames; (void)n_rows;
+  int i = 0;
+  *n_out = 0;
+  for (int k = 0; k < n_candidates; ++k) { visited[k] = 0; result[k] = -1; }
+  for (int k = 0; k < n_candidates; ++k) {
+    orc_candidate* c = &cands[k];
+    ++i;
+    /* grid.getCellIndex(candidate.cur_px.x(), candidate.cur_px.y(), 1): the doubles narrow to the int
+     * parameters (occupancy_grid_2d.h:91-94), then floor(y / cell_size) * n_cols + floor(x / cell_size) */
+    const int xi = (int)c->cur_px[0], yi = (int)c->cur_px[1];
+    const size_t grid_index = (size_t)(floor((double)yi / cell_size) * n_cols + floor((double)xi / cell_size));
+    if (max_n_features_per_frame > 0 && occupancy[grid_index]) continue;
+    ++*n_trials;
+    visited[k] = 1;
+    orc_matcher m;
+    memset(&m, 0, sizeof m);
+    m.opt = *mopt;
+    const orc_frame_view* rf = &ref_frames[c->ref_frame_idx];
+    int ok = 0;
+    if (c->kind == 0 || c->kind == 2) {
+      const int r = orc_find_match_direct(&m, rf, cur_frame, c->px, c->f, c->grad, c->level, c->ref_type, c->depth, c->cur_px);
+      result[k] = r;
+      ok = r == SVOH_MATCH_SUCCESS;
+      if (c->kind == 2) { if (ok) ++*n_succeeded_reproj; else ++*n_failed_reproj; }
+    } else if (c->kind == 1) {
+      int mr;
+      /* updateSeed(*frame, *c.ref_frame, c.ref_index, matcher, seed_sigma2_thresh, false, false) */
+      ok = orc_update_seed(&m, dopt, cur_frame, rf, c->px, c->f, c->grad, c->level, &c->ref_type, c->state,
+                           dopt->seed_convergence_sigma2_thresh, &mr);
+      result[k] = mr;
+    } else {
+      result[k] = 1000;  /* getCloseViewObs returned false */
+    }
+    if (!ok) continue;
+    orc_new_feature* o = &out[(*n_out)++];
+    memset(o, 0, sizeof *o);
+    o->candidate = k;
+    if (is_edgelet(c->type)) {  /* (matcher.A_cur_ref_ * grad_ref).normalized() */
+      double g0 = m.A_cur_ref[0] * c->grad[0] + m.A_cur_ref[2] * c->grad[1];
+      double g1 = m.A_cur_ref[1] * c->grad[0] + m.A_cur_ref[3] * c->grad[1];
+      const double z = g0 * g0 + g1 * g1;
+      if (z > 0.0) { const double nn = sqrt(z); g0 /= nn; g1 /= nn; }
+      o->grad[0] = g0; o->grad[1] = g1;
+    }
+    o->type = c->type;
+    o->px[0] = m.px_cur[0]; o->px[1] = m.px_cur[1];
+    for (int j = 0; j < 3; ++j) o->f[j] = m.f_cur[j];
+    o->level = m.search_level;
+    o->score = c->score;
+    for (int j = 0; j < 4; ++j) o->state[j] = c->state[j];
+    ++*n_matches;
+    ++*num_features_io;
+    occupancy[grid_index] = 1;
+    if (max_n_features_per_frame > 0 && *num_features_io >= max_n_features_per_frame) break;
+  }
+  return i;
+}

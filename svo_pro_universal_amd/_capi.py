@@ -99,6 +99,10 @@ class svoh_depth_filter_options(C.Structure):
 
 
 # svo::FeatureType (types.h:60-73)
+class svoh_seed_match_outputs(C.Structure):
+    _fields_ = [("px_cur", C.c_void_p), ("f_cur", C.c_void_p), ("search_level", C.c_void_p), ("A_cur_ref", C.c_void_p)]
+
+
 FT_EDGELET_SEED, FT_CORNER_SEED, FT_MAPPOINT_SEED = 0, 1, 2
 FT_EDGELET_SEED_CONVERGED, FT_CORNER_SEED_CONVERGED, FT_MAPPOINT_SEED_CONVERGED = 3, 4, 5
 FT_EDGELET, FT_CORNER, FT_MAPPOINT, FT_FIXED_LANDMARK, FT_OUTLIER = 6, 7, 8, 9, 10
@@ -175,7 +179,7 @@ EXPORTS = [
     "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms",
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
     "svoh_match_direct_batch",
-    "svoh_update_seeds_batch",
+    "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex",
 ]
 
 
@@ -257,5 +261,6 @@ def load():
     lib.svoh_update_seeds_batch.argtypes = [C.c_void_p, P(svoh_matcher_options), P(svoh_depth_filter_options),
                                             C.c_int, P(svoh_frame_view), P(svoh_frame_view), P(svoh_feature_batch),
                                             C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int32)]
+    lib.svoh_update_seeds_batch_ex.argtypes = lib.svoh_update_seeds_batch.argtypes + [P(svoh_seed_match_outputs)]
     _LIB = lib
     return lib

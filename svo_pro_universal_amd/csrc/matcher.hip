@@ -849,6 +849,9 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
   m.h_inv = 0.0; m.search_level = 0; m.reject = false;
   m.n_warp = 0; m.n_zmssd = 0; m.n_align_it = 0;
   m.align_1d = (type == SVOH_FT_EDGELET_SEED || type == SVOH_FT_EDGELET_SEED_CONVERGED);
+  m.A[0] = m.A[1] = m.A[2] = m.A[3] = 0.0;
+  m.px_cur[0] = m.px_cur[1] = 0.0;
+  m.f_cur = { 0.0, 0.0, 0.0 };
 #ifdef SVOH_SEED_STAMPS
   m.t[0] = m.t[1] = m.t[2] = m.t[3] = 0; m.tlast = clock64();
 #endif
@@ -858,6 +861,11 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
   const int res = find_epipolar_match_direct(m, a.mopt, ref, cur, T_cur_ref, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
                                              a.grad[2 * i + 1], a.level[i], type, st[0], inv_min, inv_max, depth);
   if (a.result) a.result[i] = res;
+  // matcher state as reprojector_utils::matchCandidate reads it after updateSeed (reprojector.cpp:403-413, 473-476)
+  if (a.px_cur) { a.px_cur[2 * i] = m.px_cur[0]; a.px_cur[2 * i + 1] = m.px_cur[1]; }
+  if (a.f_cur) { a.f_cur[3 * i] = m.f_cur.x; a.f_cur[3 * i + 1] = m.f_cur.y; a.f_cur[3 * i + 2] = m.f_cur.z; }
+  if (a.search_level) a.search_level[i] = m.search_level;
+  if (a.A_cur_ref) for (int k = 0; k < 4; ++k) a.A_cur_ref[4 * i + k] = m.A[k];
   flush_counters(a.unit_counts, i, m, res == SVOH_MATCH_SUCCESS ? 1 : 0);
   if (res != SVOH_MATCH_SUCCESS) {
     if (!m.reject) a.state[4 * i + 3] = st[3] + 1;  // seed::increaseOutlierProbability
@@ -1007,6 +1015,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     o_hinv = out_add(sizeof(double) * n);
     o_A = out_add(sizeof(double) * 4 * n);
     o_success = out_add((size_t)n);
+    if (seeds && px_cur) o_pxcur = out_add(sizeof(double) * 2 * n);  // matcher px_cur_ of the seed update (output only)
   }
   const size_t o_nsucc = out_add(sizeof(int32_t));
 
@@ -1016,6 +1025,8 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch1.ptr);
   for (size_t k = 0; k < s.in.size(); ++k) memcpy(h + s.off[k], s.in[k].first, s.in[k].second);
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
+  // optional outputs of units that return before the matcher runs read back as zeros
+  if (!on_device) SVOH_HIP_TRY(ctx, hipMemsetAsync(d + in_total, 0, s.total - in_total, ctx->stream));
 
   MatcherArgs a;
   memset(&a, 0, sizeof a);
@@ -1045,8 +1056,13 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     a.h_inv = reinterpret_cast<double*>(d + o_hinv);
     a.A_cur_ref = reinterpret_cast<double*>(d + o_A);
     a.success = d + o_success;
-    if (seeds) a.state = reinterpret_cast<double*>(d + o_state);
-    else { a.depth = reinterpret_cast<const double*>(d + o_depth); a.px_cur = reinterpret_cast<double*>(d + o_pxcur); }
+    if (seeds) {
+      a.state = reinterpret_cast<double*>(d + o_state);
+      a.px_cur = px_cur ? reinterpret_cast<double*>(d + o_pxcur) : nullptr;
+    } else {
+      a.depth = reinterpret_cast<const double*>(d + o_depth);
+      a.px_cur = reinterpret_cast<double*>(d + o_pxcur);
+    }
   }
   const dim3 grid((unsigned)((n + 63) / 64)), block(64);
   {
@@ -1088,6 +1104,10 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     memcpy(state, h + o_state, sizeof(double) * 4 * n);
     memcpy(success, h + o_success, (size_t)n);
     if (result) memcpy(result, h + o_result, sizeof(int32_t) * n);
+    if (px_cur) memcpy(px_cur, h + o_pxcur, sizeof(double) * 2 * n);
+    if (f_cur) memcpy(f_cur, h + o_fcur, sizeof(double) * 3 * n);
+    if (search_level) memcpy(search_level, h + o_slevel, sizeof(int32_t) * n);
+    if (A_cur_ref) memcpy(A_cur_ref, h + o_A, sizeof(double) * 4 * n);
     if (n_success) {
       int c = 0;
       for (int i = 0; i < n; ++i) c += success[i];
@@ -1127,6 +1147,18 @@ int svoh_update_seeds_batch(svoh_ctx* ctx, const svoh_matcher_options* matcher_o
 {
   return run_matcher(ctx, true, matcher_options, options, n_ref_frames, ref_frames, cur_frame, features, nullptr, nullptr,
                      match_result, nullptr, nullptr, nullptr, nullptr, state, success, n_success);
+}
+
+int svoh_update_seeds_batch_ex(svoh_ctx* ctx, const svoh_matcher_options* matcher_options,
+                               const svoh_depth_filter_options* options, int n_ref_frames,
+                               const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
+                               const svoh_feature_batch* features, double* state, uint8_t* success,
+                               int32_t* match_result, int32_t* n_success, const svoh_seed_match_outputs* outputs)
+{
+  const svoh_seed_match_outputs none = { nullptr, nullptr, nullptr, nullptr };
+  const svoh_seed_match_outputs& o = outputs ? *outputs : none;
+  return run_matcher(ctx, true, matcher_options, options, n_ref_frames, ref_frames, cur_frame, features, nullptr, o.px_cur,
+                     match_result, o.f_cur, o.search_level, nullptr, o.A_cur_ref, state, success, n_success);
 }
 
 }  // extern "C"

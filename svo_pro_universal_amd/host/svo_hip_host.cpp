@@ -126,10 +126,8 @@ static svoh_frame_view view_of(const Frame& f)
 size_t DepthFilterHip::updateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame)
 {
   if (!cur_frame) throw std::runtime_error("DepthFilterHip::updateSeeds: NULL current frame");
-  if (!have_px_error_angle_) {  // static double px_error_angle = cur_frame.getAngleError(1.0)
-    px_error_angle_ = atan(1.0 / (2.0 * cur_frame->cam.fx)) + atan(1.0 / (2.0 * cur_frame->cam.fy));
-    have_px_error_angle_ = true;
-  }
+  px_error_angle_ = updateSeedPxErrorAngle(*cur_frame);
+  have_px_error_angle_ = true;
   std::vector<svoh_frame_view> refs;
   std::vector<int32_t> ref_idx, level;
   std::vector<double> px, f, grad, state;
@@ -175,6 +173,254 @@ size_t DepthFilterHip::updateSeeds(const std::vector<FramePtr>& ref_frames_with_
   }
   return static_cast<size_t>(n_success);
 }
+
+double updateSeedPxErrorAngle(const Frame& cur_frame)
+{
+  // static double px_error_angle = cur_frame.getAngleError(1.0);  (depth_filter.cpp:383-384,
+  // camera_geometry_base.hpp: atan(1/(2 fx)) + atan(1/(2 fy)))
+  static const double px_error_angle = atan(1.0 / (2.0 * cur_frame.cam.fx)) + atan(1.0 / (2.0 * cur_frame.cam.fy));
+  return px_error_angle;
+}
+
+// ---- reprojector ------------------------------------------------------------------
+bool Point::getCloseViewObs(const svoh::Vec3& framepos, FramePtr& ref_frame, size_t& ref_feature_index) const
+{
+  double min_cos_angle = 0.0;
+  svoh::Vec3 obs_dir{ framepos.x - pos_.x, framepos.y - pos_.y, framepos.z - pos_.z };
+  {
+    const double n = sqrt(obs_dir.x * obs_dir.x + obs_dir.y * obs_dir.y + obs_dir.z * obs_dir.z);
+    if (n > 0.0) { obs_dir.x /= n; obs_dir.y /= n; obs_dir.z /= n; }
+  }
+  for (const Obs& obs : obs_) {
+    FramePtr frame = obs.frame.lock();
+    if (!frame) return false;
+    const svoh::Vec3 fp = frame->pos();
+    svoh::Vec3 dir{ fp.x - pos_.x, fp.y - pos_.y, fp.z - pos_.z };
+    const double n = sqrt(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+    if (n > 0.0) { dir.x /= n; dir.y /= n; dir.z /= n; }
+    const double cos_angle = obs_dir.x * dir.x + obs_dir.y * dir.y + obs_dir.z * dir.z;
+    if (cos_angle > min_cos_angle) {
+      min_cos_angle = cos_angle;
+      ref_frame = frame;
+      ref_feature_index = obs.keypoint_index_;
+    }
+  }
+  return !(min_cos_angle < 0.4);  // observations more than 60 degrees away are useless
+}
+
+int OccupandyGrid2D::getNCell(int n_pixels, int size)
+{
+  return static_cast<int>(std::ceil(static_cast<double>(n_pixels) / static_cast<double>(size)));
+}
+int OccupandyGrid2D::numOccupied() const { return static_cast<int>(std::count(occupancy_.begin(), occupancy_.end(), true)); }
+size_t OccupandyGrid2D::getCellIndex(int x, int y, int scale) const
+{
+  // getCellIndex(Eigen::Vector2d(scale * x, scale * y)) (occupancy_grid_2d.h:82-94)
+  const double px = scale * x, py = scale * y;
+  return static_cast<size_t>(std::floor(py / cell_size) * n_cols + std::floor(px / cell_size));
+}
+
+namespace reprojector_utils {
+namespace {
+thread_local std::vector<int32_t> g_last_results;
+bool is_edgelet(uint8_t t) { return t == SVOH_FT_EDGELET || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_EDGELET_SEED_CONVERGED; }
+bool is_converged_seed(uint8_t t)
+{
+  return t == SVOH_FT_CORNER_SEED_CONVERGED || t == SVOH_FT_EDGELET_SEED_CONVERGED || t == SVOH_FT_MAPPOINT_SEED_CONVERGED;
+}
+bool is_unconverged_seed(uint8_t t)
+{
+  return t == SVOH_FT_CORNER_SEED || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_MAPPOINT_SEED;
+}
+template <class T>
+void grow(std::vector<T>& v, size_t n, const T& fill = T()) { if (v.size() < n) v.resize(n, fill); }
+}  // namespace
+
+const std::vector<int32_t>& lastMatchResults() { return g_last_results; }
+
+void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features_per_frame, bool affine_est_offset,
+                     bool affine_est_gain, std::vector<reprojector::Candidate>& candidates, OccupandyGrid2D& grid,
+                     reprojector::Statistics& stats, double seed_sigma2_thresh)
+{
+  if (!ctx) throw std::runtime_error("matchCandidates: NULL svoh_ctx (no CPU fallback exists)");
+  if (!frame) throw std::runtime_error("matchCandidates: NULL frame");
+  const size_t n = candidates.size();
+  g_last_results.assign(n, -1);
+  if (n == 0) return;
+
+  // Matcher matcher; (defaults of matcher.h:39-54) + the two affine flags (reprojector.cpp:352-354)
+  svoh_matcher_options mopt{};
+  mopt.align_max_iter = 10; mopt.max_epi_search_steps = 100; mopt.subpix_refinement = 1;
+  mopt.epi_search_edgelet_filtering = 1; mopt.scan_on_unit_sphere = 1;
+  mopt.epi_search_edgelet_max_angle = 0.7; mopt.max_patch_diff_ratio = 2.0;
+  mopt.affine_est_offset = affine_est_offset; mopt.affine_est_gain = affine_est_gain;
+
+  // ---- what each candidate matches against (no dependence on any match result) ----
+  enum Kind { kConvergedSeed = 0, kUnconvergedSeed = 1, kLandmark = 2, kNoCloseView = 3 };
+  struct Resolved { Kind kind; FramePtr ref; size_t idx; PointPtr point; int frame_slot; int batch_pos; };
+  std::vector<Resolved> rs(n);
+  std::vector<FramePtr> frames;  // distinct reference frames
+  auto slot_of = [&](const FramePtr& f) {
+    for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == f) return static_cast<int>(k);
+    frames.push_back(f);
+    return static_cast<int>(frames.size() - 1);
+  };
+  for (size_t i = 0; i < n; ++i) {
+    const reprojector::Candidate& c = candidates[i];
+    if (!c.ref_frame || c.ref_index >= c.ref_frame->num_features_) throw std::runtime_error("matchCandidates: bad candidate");
+    Resolved& r = rs[i];
+    r.batch_pos = -1; r.frame_slot = -1;
+    PointPtr lm = c.ref_index < c.ref_frame->landmark_vec_.size() ? c.ref_frame->landmark_vec_[c.ref_index] : nullptr;
+    if (!lm) {
+      r.ref = c.ref_frame; r.idx = c.ref_index;
+      if (is_converged_seed(c.type)) r.kind = kConvergedSeed;
+      else if (is_unconverged_seed(c.type)) r.kind = kUnconvergedSeed;
+      else throw std::runtime_error("matchCandidates: seed type unknown");  // CHECK(false) in the reference
+    } else {
+      r.point = lm;
+      FramePtr rf; size_t ri = 0;
+      if (lm->getCloseViewObs(frame->pos(), rf, ri)) { r.kind = kLandmark; r.ref = rf; r.idx = ri; }
+      else r.kind = kNoCloseView;
+    }
+    if (r.kind != kNoCloseView) r.frame_slot = slot_of(r.ref);
+  }
+  std::vector<svoh_frame_view> views;
+  for (const FramePtr& f : frames) {
+    svoh_frame_view v{};
+    v.frame = f->pyramid; v.cam = f->cam; svoh::store_rigid(f->T_f_w_, v.T_f_w);
+    v.seed_mu_range = f->seed_mu_range_; v.id = f->id();
+    views.push_back(v);
+  }
+  svoh_frame_view cur{};
+  cur.frame = frame->pyramid; cur.cam = frame->cam; svoh::store_rigid(frame->T_f_w_, cur.T_f_w);
+  cur.seed_mu_range = frame->seed_mu_range_; cur.id = frame->id();
+
+  // ---- two speculative batches ----
+  struct Batch {
+    std::vector<int32_t> ref_idx, level, result, search_level;
+    std::vector<double> px, f, grad, depth, state, px_cur, f_cur, A;
+    std::vector<uint8_t> type, success;
+    void push(const Frame& r, size_t i, int slot)
+    {
+      ref_idx.push_back(slot); level.push_back(r.level_vec_[i]); type.push_back(r.type_vec_[i]);
+      px.insert(px.end(), r.px_vec_.begin() + 2 * i, r.px_vec_.begin() + 2 * i + 2);
+      f.insert(f.end(), r.f_vec_.begin() + 3 * i, r.f_vec_.begin() + 3 * i + 3);
+      grad.insert(grad.end(), r.grad_vec_.begin() + 2 * i, r.grad_vec_.begin() + 2 * i + 2);
+    }
+    size_t size() const { return level.size(); }
+  } direct, seeds;
+  for (size_t i = 0; i < n; ++i) {
+    Resolved& r = rs[i];
+    const reprojector::Candidate& c = candidates[i];
+    if (r.kind == kConvergedSeed || r.kind == kLandmark) {
+      r.batch_pos = static_cast<int>(direct.size());
+      direct.push(*r.ref, r.idx, r.frame_slot);
+      if (r.kind == kConvergedSeed) direct.depth.push_back(r.ref->getSeedDepth(r.idx));
+      else {
+        const svoh::Vec3 p = r.ref->pos(), q = r.point->pos();  // (ref_frame->pos() - landmark->pos()).norm()
+        direct.depth.push_back(sqrt((p.x - q.x) * (p.x - q.x) + (p.y - q.y) * (p.y - q.y) + (p.z - q.z) * (p.z - q.z)));
+      }
+      direct.px_cur.push_back(c.cur_px[0]); direct.px_cur.push_back(c.cur_px[1]);
+    } else if (r.kind == kUnconvergedSeed) {
+      r.batch_pos = static_cast<int>(seeds.size());
+      seeds.push(*r.ref, r.idx, r.frame_slot);
+      seeds.state.insert(seeds.state.end(), r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx,
+                         r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx + 4);
+    }
+  }
+  auto batch_of = [](Batch& b) {
+    svoh_feature_batch fb{};
+    fb.n = static_cast<int32_t>(b.size());
+    fb.ref_frame_idx = b.ref_idx.data(); fb.px = b.px.data(); fb.f = b.f.data(); fb.grad = b.grad.data();
+    fb.level = b.level.data(); fb.type = b.type.data();
+    return fb;
+  };
+  if (direct.size()) {
+    const size_t m = direct.size();
+    direct.result.assign(m, 0); direct.search_level.assign(m, 0); direct.f_cur.assign(3 * m, 0.0); direct.A.assign(4 * m, 0.0);
+    const svoh_feature_batch fb = batch_of(direct);
+    const int rc = svoh_match_direct_batch(ctx, &mopt, static_cast<int>(views.size()), views.data(), &cur, &fb,
+                                           direct.depth.data(), direct.px_cur.data(), direct.result.data(),
+                                           direct.f_cur.data(), direct.search_level.data(), nullptr, direct.A.data());
+    if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_match_direct_batch: ") + svoh_last_error_string(ctx));
+  }
+  if (seeds.size()) {
+    const size_t m = seeds.size();
+    seeds.result.assign(m, 0); seeds.search_level.assign(m, 0); seeds.success.assign(m, 0);
+    seeds.px_cur.assign(2 * m, 0.0); seeds.f_cur.assign(3 * m, 0.0); seeds.A.assign(4 * m, 0.0);
+    const svoh_feature_batch fb = batch_of(seeds);
+    svoh_depth_filter_options o{};
+    o.seed_convergence_sigma2_thresh = seed_sigma2_thresh;      // updateSeed(..., seed_sigma2_thresh, false, false):
+    o.mappoint_convergence_sigma2_thresh = seed_sigma2_thresh;  // one threshold for every seed type here
+    o.px_error_angle = updateSeedPxErrorAngle(*frame);
+    o.check_visibility = 0; o.check_convergence = 0; o.use_vogiatzis_update = 1;
+    const svoh_seed_match_outputs outs{ seeds.px_cur.data(), seeds.f_cur.data(), seeds.search_level.data(), seeds.A.data() };
+    const int rc = svoh_update_seeds_batch_ex(ctx, &mopt, &o, static_cast<int>(views.size()), views.data(), &cur, &fb,
+                                              seeds.state.data(), seeds.success.data(), seeds.result.data(), nullptr, &outs);
+    if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_update_seeds_batch_ex: ") + svoh_last_error_string(ctx));
+  }
+
+  // ---- the reference's loop, replayed in candidate order (reprojector.cpp:356-381) ----
+  size_t i = 0;
+  for (size_t k = 0; k < n; ++k) {
+    reprojector::Candidate& c = candidates[k];
+    const Resolved& r = rs[k];
+    ++i;
+    const size_t grid_index = grid.getCellIndex(static_cast<int>(c.cur_px[0]), static_cast<int>(c.cur_px[1]), 1);
+    if (max_n_features_per_frame > 0 && grid.isOccupied(grid_index)) continue;
+    ++stats.n_trials;
+    bool ok = false;
+    const Batch* b = nullptr;
+    if (r.kind == kConvergedSeed || r.kind == kLandmark) {
+      b = &direct;
+      const int res = direct.result[r.batch_pos];
+      g_last_results[k] = res;
+      ok = res == SVOH_MATCH_SUCCESS;
+      c.cur_px[0] = direct.px_cur[2 * r.batch_pos]; c.cur_px[1] = direct.px_cur[2 * r.batch_pos + 1];  // Keypoint& px_cur
+      if (r.kind == kLandmark) { if (ok) r.point->n_succeeded_reproj_ += 1; else r.point->n_failed_reproj_++; }
+    } else if (r.kind == kUnconvergedSeed) {
+      b = &seeds;
+      g_last_results[k] = seeds.result[r.batch_pos];
+      ok = seeds.success[r.batch_pos] != 0;
+      // updateSeed changed the seed of the reference frame whether it succeeded or not
+      std::copy(seeds.state.begin() + 4 * r.batch_pos, seeds.state.begin() + 4 * r.batch_pos + 4,
+                r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx);
+      r.ref->type_vec_[r.idx] = seeds.type[r.batch_pos];
+    } else {
+      g_last_results[k] = 1000;
+    }
+    if (!ok) continue;
+    // matchCandidate's tail (:455-486): fill the first free slot of the frame
+    const size_t s = frame->num_features_;
+    grow(frame->px_vec_, 2 * (s + 1)); grow(frame->f_vec_, 3 * (s + 1)); grow(frame->grad_vec_, 2 * (s + 1));
+    grow(frame->level_vec_, s + 1); grow(frame->type_vec_, s + 1); grow(frame->score_vec_, s + 1);
+    grow(frame->invmu_sigma2_a_b_vec_, 4 * (s + 1)); grow(frame->landmark_vec_, s + 1); grow(frame->seed_ref_vec_, s + 1);
+    const int p = r.batch_pos;
+    if (is_edgelet(c.type)) {
+      const double* A = &b->A[4 * p];
+      const double* g = &r.ref->grad_vec_[2 * r.idx];
+      double g0 = A[0] * g[0] + A[2] * g[1], g1 = A[1] * g[0] + A[3] * g[1];
+      const double z = g0 * g0 + g1 * g1;
+      if (z > 0.0) { const double nn = sqrt(z); g0 /= nn; g1 /= nn; }
+      frame->grad_vec_[2 * s] = g0; frame->grad_vec_[2 * s + 1] = g1;
+    }
+    frame->type_vec_[s] = c.type;
+    frame->px_vec_[2 * s] = b->px_cur[2 * p]; frame->px_vec_[2 * s + 1] = b->px_cur[2 * p + 1];
+    for (int j = 0; j < 3; ++j) frame->f_vec_[3 * s + j] = b->f_cur[3 * p + j];
+    frame->level_vec_[s] = b->search_level[p];
+    frame->score_vec_[s] = c.score;
+    if (r.kind == kLandmark) frame->landmark_vec_[s] = r.point;
+    else { frame->seed_ref_vec_[s].keyframe = c.ref_frame; frame->seed_ref_vec_[s].seed_id = static_cast<int>(c.ref_index); }
+    std::copy(c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index,
+              c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index + 4, frame->invmu_sigma2_a_b_vec_.begin() + 4 * s);
+    ++stats.n_matches;
+    ++frame->num_features_;
+    grid.setOccupied(grid_index);
+    if (max_n_features_per_frame > 0 && frame->num_features_ >= max_n_features_per_frame) break;
+  }
+  candidates.erase(candidates.begin(), candidates.begin() + static_cast<std::ptrdiff_t>(i));
+}
+}  // namespace reprojector_utils
 
 // ---- alignPyr2DVec ----------------------------------------------------------------
 namespace feature_alignment {

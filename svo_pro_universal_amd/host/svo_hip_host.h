@@ -15,6 +15,7 @@
 // in INTEGRATION.md.  No CPU fallback: every call goes to libsvo_hip.so.
 #pragma once
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <memory>
@@ -50,6 +51,12 @@ struct Frame {
   double seed_mu_range_ = 0.0;
   int id_ = 0;
   int id() const { return id_; }
+  // members the reprojector writes for a newly matched feature (frame.h:62-86); optional otherwise
+  std::vector<double> score_vec_;                       // n
+  std::vector<std::shared_ptr<struct Point>> landmark_vec_;   // n, nullptr = no landmark
+  struct SeedRef { std::shared_ptr<Frame> keyframe; int seed_id = -1; };
+  std::vector<SeedRef> seed_ref_vec_;                   // n
+  double getSeedDepth(size_t idx) const { return 1.0 / invmu_sigma2_a_b_vec_[4 * idx]; }   // seed.h:110-113 (inverse depth)
 
   void set_T_cam_imu(const Transformation& T) { T_cam_imu_ = T; T_imu_cam_ = svoh::inverse(T); }  // frame.h:270-274
   const Transformation& T_cam_imu() const { return T_cam_imu_; }
@@ -165,5 +172,71 @@ void alignPyr2DVec(svoh_ctx* ctx, svoh_frame_t img_pyr_ref, svoh_frame_t img_pyr
                    const std::vector<int>& patch_sizes, int n_iter, float min_update_squared,
                    const std::vector<Point2f>& px_ref, std::vector<Point2f>& px_cur, std::vector<uint8_t>& status);
 }
+
+// ---------------------------------------------------------------------------
+// Seam 2b: reprojector.  Mirrors reprojector_utils::matchCandidates
+// (src/svo/include/svo/reprojector.h, src/svo/src/reprojector.cpp:342-382) and what it
+// touches: OccupandyGrid2D (svo_common/include/svo/common/occupancy_grid_2d.h:10-113),
+// Reprojector::Candidate / Statistics, Point::getCloseViewObs (point.cpp:83-129).
+// The per-candidate matcher work of matchCandidate (:384-486) runs speculatively for all
+// candidates in two batched launches; the reference's loop -- grid occupancy, n_trials /
+// n_matches, num_features_, the early break, n_failed_reproj_ / n_succeeded_reproj_, the
+// in-place seed updates -- is then replayed on the host in candidate order, and only the
+// candidates that loop visits leave side effects.
+// ---------------------------------------------------------------------------
+struct Point {
+  svoh::Vec3 pos_{ 0, 0, 0 };
+  int id_ = 0;
+  int n_failed_reproj_ = 0, n_succeeded_reproj_ = 0;
+  struct Obs { std::weak_ptr<Frame> frame; size_t keypoint_index_ = 0; };
+  std::vector<Obs> obs_;
+  const svoh::Vec3& pos() const { return pos_; }
+  int id() const { return id_; }
+  bool getCloseViewObs(const svoh::Vec3& framepos, FramePtr& ref_frame, size_t& ref_feature_index) const;
+};
+using PointPtr = std::shared_ptr<Point>;
+
+struct OccupandyGrid2D {
+  OccupandyGrid2D(int cell_size, int n_cols, int n_rows)
+      : cell_size(cell_size), n_cols(n_cols), n_rows(n_rows), occupancy_(static_cast<size_t>(n_cols) * n_rows, false) {}
+  static int getNCell(int n_pixels, int size);
+  const int cell_size, n_cols, n_rows;
+  std::vector<bool> occupancy_;
+  void reset() { std::fill(occupancy_.begin(), occupancy_.end(), false); }
+  size_t size() const { return occupancy_.size(); }
+  bool isOccupied(size_t cell_index) const { return occupancy_.at(cell_index); }
+  void setOccupied(size_t cell_index) { occupancy_.at(cell_index) = true; }
+  int numOccupied() const;
+  size_t getCellIndex(int x, int y, int scale = 1) const;
+};
+
+namespace reprojector {
+struct Candidate {   // Reprojector::Candidate (reprojector.h)
+  FramePtr ref_frame;
+  size_t ref_index = 0;
+  double cur_px[2] = { 0, 0 };
+  uint8_t type = 0;      // svo::FeatureType of the reference feature when the candidate was made
+  double score = 0.0;
+};
+struct Statistics { size_t n_matches = 0, n_trials = 0; };
+}  // namespace reprojector
+
+namespace reprojector_utils {
+// Appends every matched feature to `frame` (px_vec_, f_vec_, grad_vec_, level_vec_, type_vec_, score_vec_,
+// invmu_sigma2_a_b_vec_, landmark_vec_, seed_ref_vec_ at index num_features_, then ++num_features_), updates
+// the seeds of the reference frames and the landmarks' reprojection counters exactly as the sequential
+// reference loop does, and erases the consumed candidates from the front of the list.
+void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features_per_frame, bool affine_est_offset,
+                     bool affine_est_gain, std::vector<reprojector::Candidate>& candidates, OccupandyGrid2D& grid,
+                     reprojector::Statistics& stats, double seed_sigma2_thresh);
+// Matcher::MatchResult per candidate of the last call on this thread (-1 = never reached / cell taken,
+// 1000 = landmark without a close view), for tests and statistics.
+const std::vector<int32_t>& lastMatchResults();
+}  // namespace reprojector_utils
+
+// The function-local `static double px_error_angle` of depth_filter_utils::updateSeed
+// (depth_filter.cpp:383-384): the first camera ever passed sets it for the whole process,
+// for the depth filter and the reprojector alike.
+double updateSeedPxErrorAngle(const Frame& cur_frame);
 
 }  // namespace svo_hip

@@ -1,0 +1,217 @@
+// test_host_reprojector.cpp -- the C++ host mirror reprojector_utils::matchCandidates (two speculative GPU
+// batches + ordered host replay) against the oracle's sequential restatement of the reference loop
+// (src/svo/src/reprojector.cpp:342-486), in the call shape of Reprojector::reprojectFrames (:104-131).
+// Input: a dump written by tests/test_host_cpp_gpu.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../oracle/svo_oracle.h"
+#include "../../svo_pro_universal_amd/host/svo_hip_host.h"
+
+using namespace svo_hip;
+
+#define CHECK(cond)                                                            \
+  do { if (!(cond)) { fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); return 1; } } while (0)
+
+template <class T>
+static std::vector<T> rd(FILE* f, size_t n)
+{
+  std::vector<T> v(n);
+  if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
+  return v;
+}
+static Transformation to_T(const double* v) { Transformation T{ { v[0], v[1], v[2], v[3] }, { v[4], v[5], v[6] } }; return T; }
+
+struct OrcPyr {
+  std::vector<std::vector<uint8_t>> lv;
+  orc_frame_view view;
+  void build(const std::vector<uint8_t>& img, int w, int h, int n_levels, const svoh_camera& cam, const Transformation& T,
+             double mu_range, int id)
+  {
+    lv.resize(n_levels);
+    uint8_t* p[SVOH_MAX_LEVELS];
+    for (int l = 0; l < n_levels; ++l) { lv[l].resize((size_t)(w >> l) * (h >> l)); p[l] = lv[l].data(); }
+    orc_create_img_pyramid(img.data(), w, h, w, n_levels, SVOH_HALFSAMPLE_REFERENCE, p);
+    memset(&view, 0, sizeof view);
+    view.pyr.n_levels = n_levels;
+    for (int l = 0; l < n_levels; ++l) view.pyr.level[l] = orc_image{ lv[l].data(), w >> l, h >> l, w >> l, 0 };
+    view.cam = cam;
+    svoh::store_rigid(T, view.T_f_w);
+    view.seed_mu_range = mu_range;
+    view.id = id;
+  }
+};
+
+int main(int argc, char** argv)
+{
+  if (argc < 2) return 2;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) { perror("open"); return 2; }
+  std::vector<int32_t> hdr = rd<int32_t>(f, 4);  // w, h, n_features, max_n_features_per_frame
+  const int w = hdr[0], h = hdr[1], n = hdr[2], max_n = hdr[3];
+  std::vector<double> camv = rd<double>(f, 9), T_kf = rd<double>(f, 7), T_cur = rd<double>(f, 7), T_far = rd<double>(f, 7),
+                      mu_range = rd<double>(f, 1);
+  std::vector<double> px = rd<double>(f, 2 * (size_t)n), fv = rd<double>(f, 3 * (size_t)n), grad = rd<double>(f, 2 * (size_t)n),
+                      state = rd<double>(f, 4 * (size_t)n), lm_pos = rd<double>(f, 3 * (size_t)n);
+  std::vector<int32_t> level = rd<int32_t>(f, n);
+  std::vector<uint8_t> type = rd<uint8_t>(f, n), lm_kind = rd<uint8_t>(f, n);  // 0 none, 1 landmark, 2 landmark seen only from afar
+  std::vector<int32_t> order = rd<int32_t>(f, n);
+  std::vector<double> cur_px = rd<double>(f, 2 * (size_t)n), score = rd<double>(f, n);
+  std::vector<uint8_t> img_kf = rd<uint8_t>(f, (size_t)w * h), img_cur = rd<uint8_t>(f, (size_t)w * h);
+  fclose(f);
+
+  svoh_ctx* ctx = nullptr;
+  if (svoh_create(0, &ctx) != SVOH_OK) { fprintf(stderr, "svoh_create: %s\n", svoh_last_error_string(nullptr)); return 3; }
+  svoh_camera cam{};
+  cam.fx = camv[0]; cam.fy = camv[1]; cam.cx = camv[2]; cam.cy = camv[3];
+  for (int i = 0; i < 4; ++i) cam.d[i] = camv[4 + i];
+  cam.distortion = camv[8] != 0.0 ? SVOH_DISTORTION_RADTAN : SVOH_DISTORTION_NONE;
+  cam.width = w; cam.height = h;
+  const int n_levels = 5;
+
+  auto make_frame = [&](const std::vector<uint8_t>& img, const double* T, int id) {
+    FramePtr fr(new Frame);
+    if (svoh_build_pyramid(ctx, img.data(), w, h, w, SVOH_MEM_HOST, n_levels, SVOH_HALFSAMPLE_REFERENCE, nullptr, &fr->pyramid) != SVOH_OK)
+      { fprintf(stderr, "build_pyramid: %s\n", svoh_last_error_string(ctx)); exit(3); }
+    fr->cam = cam; fr->T_f_w_ = to_T(T); fr->id_ = id;
+    return fr;
+  };
+  FramePtr kf = make_frame(img_kf, T_kf.data(), 7), cur = make_frame(img_cur, T_cur.data(), 8), far = make_frame(img_kf, T_far.data(), 9);
+  kf->num_features_ = (size_t)n;
+  kf->px_vec_ = px; kf->f_vec_ = fv; kf->grad_vec_ = grad; kf->level_vec_ = level; kf->type_vec_ = type;
+  kf->invmu_sigma2_a_b_vec_ = state; kf->seed_mu_range_ = mu_range[0];
+  kf->landmark_vec_.resize(n);
+  far->num_features_ = 1; far->px_vec_ = { 100, 100 }; far->f_vec_ = { 0, 0, 1 }; far->grad_vec_ = { 1, 0 };
+  far->level_vec_ = { 0 }; far->type_vec_ = { SVOH_FT_CORNER }; far->invmu_sigma2_a_b_vec_ = { 1, 1, 10, 10 };
+  std::vector<PointPtr> points(n);
+  for (int i = 0; i < n; ++i) {
+    if (!lm_kind[i]) continue;
+    PointPtr p(new Point);
+    p->pos_ = { lm_pos[3 * i], lm_pos[3 * i + 1], lm_pos[3 * i + 2] };
+    p->id_ = 1000 + i;
+    p->obs_.push_back(Point::Obs{ far, 0 });
+    if (lm_kind[i] == 1) p->obs_.push_back(Point::Obs{ kf, (size_t)i });
+    kf->landmark_vec_[i] = p;
+    points[i] = p;
+  }
+  std::vector<reprojector::Candidate> candidates;
+  for (int k = 0; k < n; ++k) {
+    const int i = order[k];
+    reprojector::Candidate c;
+    c.ref_frame = kf; c.ref_index = (size_t)i; c.cur_px[0] = cur_px[2 * i]; c.cur_px[1] = cur_px[2 * i + 1];
+    c.type = type[i]; c.score = score[i];
+    candidates.push_back(c);
+  }
+  const int cell = 30;
+  OccupandyGrid2D grid(cell, OccupandyGrid2D::getNCell(w, cell), OccupandyGrid2D::getNCell(h, cell));
+  // a few cells are already taken (features matched from a previous keyframe)
+  for (size_t k = 0; k < grid.size(); k += 17) grid.setOccupied(k);
+  std::vector<uint8_t> occ0(grid.size());
+  for (size_t k = 0; k < grid.size(); ++k) occ0[k] = grid.isOccupied(k);
+  cur->num_features_ = 0;
+  reprojector::Statistics stats;
+  const double seed_sigma2_thresh = 200.0;
+
+  // ---- oracle first (the mirror mutates kf's seeds) ----
+  OrcPyr o_kf, o_cur;
+  o_kf.build(img_kf, w, h, n_levels, cam, kf->T_f_w_, mu_range[0], 7);
+  o_cur.build(img_cur, w, h, n_levels, cam, cur->T_f_w_, 0.0, 8);
+  std::vector<orc_candidate> oc(n);
+  for (int k = 0; k < n; ++k) {
+    const int i = order[k];
+    orc_candidate& c = oc[k];
+    memset(&c, 0, sizeof c);
+    c.ref_frame_idx = 0;
+    const uint8_t t = type[i];
+    if (lm_kind[i] == 2) c.kind = 3;
+    else if (lm_kind[i] == 1) c.kind = 2;
+    else c.kind = (t == SVOH_FT_CORNER_SEED_CONVERGED || t == SVOH_FT_EDGELET_SEED_CONVERGED || t == SVOH_FT_MAPPOINT_SEED_CONVERGED) ? 0 : 1;
+    c.cur_px[0] = cur_px[2 * i]; c.cur_px[1] = cur_px[2 * i + 1];
+    for (int j = 0; j < 2; ++j) { c.px[j] = px[2 * i + j]; c.grad[j] = grad[2 * i + j]; }
+    for (int j = 0; j < 3; ++j) c.f[j] = fv[3 * i + j];
+    for (int j = 0; j < 4; ++j) c.state[j] = state[4 * i + j];
+    c.level = level[i]; c.type = t; c.ref_type = t; c.score = score[i];
+    if (c.kind == 0) c.depth = 1.0 / state[4 * i];
+    if (c.kind == 2) {
+      const svoh::Vec3 p = kf->pos();
+      c.depth = sqrt((p.x - lm_pos[3 * i]) * (p.x - lm_pos[3 * i]) + (p.y - lm_pos[3 * i + 1]) * (p.y - lm_pos[3 * i + 1]) +
+                     (p.z - lm_pos[3 * i + 2]) * (p.z - lm_pos[3 * i + 2]));
+    }
+  }
+  svoh_matcher_options mo{};
+  mo.align_max_iter = 10; mo.max_epi_search_steps = 100; mo.subpix_refinement = 1; mo.epi_search_edgelet_filtering = 1;
+  mo.scan_on_unit_sphere = 1; mo.affine_est_offset = 1; mo.affine_est_gain = 0;
+  mo.epi_search_edgelet_max_angle = 0.7; mo.max_patch_diff_ratio = 2.0;
+  svoh_depth_filter_options dopt{};
+  dopt.seed_convergence_sigma2_thresh = seed_sigma2_thresh; dopt.mappoint_convergence_sigma2_thresh = seed_sigma2_thresh;
+  dopt.px_error_angle = atan(1.0 / (2.0 * cam.fx)) + atan(1.0 / (2.0 * cam.fy));
+  dopt.check_visibility = 0; dopt.check_convergence = 0; dopt.use_vogiatzis_update = 1;
+  std::vector<uint8_t> oocc = occ0, ovis(n);
+  std::vector<int32_t> ores(n);
+  std::vector<orc_new_feature> onew(n);
+  int o_nout = 0, o_trials = 0, o_matches = 0, o_failed = 0, o_succ = 0, o_numf = 0;
+  const int o_consumed = orc_match_candidates(&mo, &dopt, 1, &o_kf.view, &o_cur.view, n, oc.data(), max_n, &o_numf, cell,
+                                              grid.n_cols, grid.n_rows, oocc.data(), ovis.data(), ores.data(), onew.data(),
+                                              &o_nout, &o_trials, &o_matches, &o_failed, &o_succ);
+
+  // ---- the reference's call: reprojector_utils::matchCandidates(frame, max_n, aff_off, aff_gain, candidates, grid, stats, thresh) ----
+  reprojector_utils::matchCandidates(ctx, cur, (size_t)max_n, true, false, candidates, grid, stats, seed_sigma2_thresh);
+  const std::vector<int32_t>& res = reprojector_utils::lastMatchResults();
+
+  CHECK((int)candidates.size() == n - o_consumed);
+  CHECK((int)stats.n_trials == o_trials && (int)stats.n_matches == o_matches);
+  CHECK((int)cur->num_features_ == o_numf && o_numf == o_nout);
+  for (size_t k = 0; k < grid.size(); ++k) CHECK(grid.isOccupied(k) == (oocc[k] != 0));
+  int n_kinds[4] = { 0, 0, 0, 0 }, n_visited = 0;
+  for (int k = 0; k < n; ++k) {
+    if (res[k] != ores[k])
+      fprintf(stderr, "candidate %d (feature %d, kind %d, type %d, level %d): mirror result %d, oracle %d\n", k, order[k], oc[k].kind,
+              (int)type[order[k]], level[order[k]], res[k], ores[k]);
+    CHECK(res[k] == ores[k]);
+    if (ovis[k]) { ++n_visited; ++n_kinds[oc[k].kind]; }
+  }
+  // side effects on the keyframe: seeds of visited unconverged candidates changed, all others untouched
+  double worst_state = 0;
+  for (int k = 0; k < n; ++k) {
+    const int i = order[k];
+    CHECK(kf->type_vec_[i] == oc[k].ref_type);
+    for (int j = 0; j < 4; ++j) {
+      const double a = kf->invmu_sigma2_a_b_vec_[4 * i + j], b = oc[k].state[j];
+      const double d = fabs(a - b) / fmax(1e-300, fabs(b));
+      if (d > worst_state) worst_state = d;
+      if (!(ovis[k] && oc[k].kind == 1)) CHECK(a == state[4 * i + j]);
+    }
+  }
+  CHECK(worst_state < 1e-9);
+  int failed = 0, succ = 0;
+  for (int i = 0; i < n; ++i) if (points[i]) { failed += points[i]->n_failed_reproj_; succ += points[i]->n_succeeded_reproj_; }
+  CHECK(failed == o_failed && succ == o_succ);
+  // the new features of the current frame, slot by slot
+  double worst_px = 0, worst_f = 0, worst_g = 0;
+  for (int s = 0; s < o_nout; ++s) {
+    const orc_new_feature& o = onew[s];
+    const int i = order[o.candidate];
+    CHECK(cur->type_vec_[s] == o.type && cur->level_vec_[s] == o.level && cur->score_vec_[s] == o.score);
+    for (int j = 0; j < 2; ++j) {
+      worst_px = fmax(worst_px, fabs(cur->px_vec_[2 * s + j] - o.px[j]));
+      worst_g = fmax(worst_g, fabs(cur->grad_vec_[2 * s + j] - o.grad[j]));
+    }
+    for (int j = 0; j < 3; ++j) worst_f = fmax(worst_f, fabs(cur->f_vec_[3 * s + j] - o.f[j]));
+    for (int j = 0; j < 4; ++j)
+      CHECK(fabs(cur->invmu_sigma2_a_b_vec_[4 * s + j] - o.state[j]) <= 1e-9 * fabs(o.state[j]));
+    if (lm_kind[i] == 1) CHECK(cur->landmark_vec_[s] == points[i]);
+    else CHECK(cur->seed_ref_vec_[s].keyframe == kf && cur->seed_ref_vec_[s].seed_id == i);
+  }
+  printf("reprojector: %d candidates, %d visited (converged seeds %d, seed updates %d, landmarks %d, no close view %d), "
+         "%d matched, %d consumed; worst |dpx| %.2e |df| %.2e |dgrad| %.2e, seed state rel %.2e\n",
+         n, n_visited, n_kinds[0], n_kinds[1], n_kinds[2], n_kinds[3], o_nout, o_consumed, worst_px, worst_f, worst_g, worst_state);
+  CHECK(worst_px <= 1e-4 && worst_f <= 1e-6 && worst_g <= 1e-9);
+  CHECK(n_kinds[0] > 0 && n_kinds[1] > 0 && n_kinds[2] > 0 && n_kinds[3] > 0 && o_nout > 10);
+  if (max_n > 0) CHECK(o_consumed < n);   // the early break was exercised
+  svoh_destroy(ctx);
+  printf("PASS\n");
+  return 0;
+}

@@ -71,3 +71,59 @@ def test_cpp_depth_filter_and_klt_mirrors_match_oracle(tmp_path, oracle_lib):
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASS" in out.stdout
+
+
+@pytest.mark.parametrize("max_n", [60, 0])
+def test_cpp_reprojector_match_candidates_mirror_matches_oracle(tmp_path, oracle_lib, max_n):
+    """reprojector_utils::matchCandidates (reprojector.cpp:342-486): speculative GPU batches + ordered host
+    replay vs the oracle's sequential loop -- converged seeds, seed updates, landmarks with and without a close
+    view, pre-occupied grid cells, the early break at max_n_features_per_frame."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    cam = synth.Camera.euroc_like()
+    sc = synth.make_align_scene(91, n_features=10, cam=cam, rot_deg=(0.4, 1.0), trans_m=(0.06, 0.12))
+    n = 400
+    sd = synth.make_seed_set(sc, n, margin=14, levels=(0, 1, 2))
+    rng = np.random.RandomState(4)
+    typ = sd["type"].copy()                       # 0 edgelet seed / 1 corner seed
+    state = sd["state"].copy().reshape(-1, 4)
+    kind = rng.randint(0, 10, n)
+    conv = kind < 3                               # converged seeds: matched directly at the seed depth
+    state[conv, 0] = 1.0 / sd["true_depth"][conv]
+    typ[conv] = typ[conv] + 3
+    mp = kind == 3                                # map-point seeds (unconverged)
+    typ[mp] = 2
+    lm = (kind == 4) | (kind == 5)                # landmarks: types kEdgelet / kCorner
+    typ[lm] = np.where(sd["type"][lm] == 0, 6, 7)
+    lm_far = kind == 6                            # landmarks observed only from far away
+    typ[lm_far] = 7
+    lm_kind = np.zeros(n, np.uint8); lm_kind[lm] = 1; lm_kind[lm_far] = 2
+    x_ref = sd["f"].reshape(-1, 3).T * sd["true_depth"]
+    x_w = sc.T_w_ref.transform(x_ref)
+    px_true = sc.cam.project(sc.T_w_cur.inverse().transform(x_w))
+    cur_px = np.ascontiguousarray((px_true + rng.uniform(-1.5, 1.5, px_true.shape)).T).ravel()
+    order = rng.permutation(n).astype(np.int32)
+    # a frame on the far side of the scene plane: its observation is never a close view (cos < 0.4)
+    T_far_w = (sc.T_w_ref * synth.SE3(synth.quat_from_axis_angle([0, 1, 0], 2.5), [0.0, 0.0, 25.0])).inverse()
+    path = str(tmp_path / "reproj.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("4i", cam.width, cam.height, n, max_n))
+        np.array([cam.fx, cam.fy, cam.cx, cam.cy] + list(cam.dist) + [1.0]).tofile(f)
+        sc.T_ref_f_w.as7().tofile(f); sc.T_cur_f_w_gt.as7().tofile(f); T_far_w.as7().tofile(f)
+        np.array([sd["mu_range"]]).tofile(f)
+        np.ascontiguousarray(sd["px"], np.float64).tofile(f)
+        np.ascontiguousarray(sd["f"], np.float64).tofile(f)
+        np.ascontiguousarray(sd["grad"], np.float64).tofile(f)
+        np.ascontiguousarray(state.ravel(), np.float64).tofile(f)
+        np.ascontiguousarray(x_w.T.ravel(), np.float64).tofile(f)
+        np.ascontiguousarray(sd["level"], np.int32).tofile(f)
+        np.ascontiguousarray(typ, np.uint8).tofile(f)
+        lm_kind.tofile(f)
+        order.tofile(f)
+        cur_px.tofile(f)
+        rng.uniform(10, 100, n).tofile(f)
+        sc.img_ref.tofile(f); sc.img_cur.tofile(f)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_host_reprojector"), path], capture_output=True, text=True)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASS" in out.stdout
