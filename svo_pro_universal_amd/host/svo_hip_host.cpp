@@ -174,6 +174,113 @@ size_t DepthFilterHip::updateSeeds(const std::vector<FramePtr>& ref_frames_with_
   return static_cast<size_t>(n_success);
 }
 
+// ---- FeatureTracker ---------------------------------------------------------------
+FeatureTrackerHip::FeatureTrackerHip(svoh_ctx* ctx, const FeatureTrackerOptions& options, size_t bundle_size)
+    : ctx_(ctx), options_(options), bundle_size_(bundle_size), active_tracks_(bundle_size), terminated_tracks_(bundle_size)
+{
+  if (!ctx_) throw std::runtime_error("FeatureTrackerHip: NULL svoh_ctx (no CPU fallback exists)");
+}
+
+size_t FeatureTrackerHip::getTotalActiveTracks() const
+{
+  size_t n = 0;
+  for (const FeatureTracks& t : active_tracks_) n += t.size();
+  return n;
+}
+
+size_t FeatureTrackerHip::initializeNewTracks(const FrameBundle::Ptr& nframe, const std::vector<size_t>& n_old_per_frame)
+{
+  if (!nframe || nframe->size() != bundle_size_ || n_old_per_frame.size() != bundle_size_)
+    throw std::runtime_error("FeatureTrackerHip::initializeNewTracks: bundle size mismatch");
+  for (size_t frame_index = 0; frame_index < bundle_size_; ++frame_index) {
+    const FramePtr& frame = nframe->at(frame_index);
+    FeatureTracks& tracks = active_tracks_[frame_index];
+    if (frame->track_id_vec_.size() < frame->num_features_) frame->track_id_vec_.resize(frame->num_features_, -1);
+    for (size_t feature_index = n_old_per_frame[frame_index]; feature_index < frame->num_features_; ++feature_index) {
+      const int new_track_id = next_track_id_++;
+      tracks.emplace_back(new_track_id);
+      tracks.back().pushBack(nframe, frame_index, feature_index);
+      frame->track_id_vec_[feature_index] = new_track_id;
+    }
+  }
+  return getTotalActiveTracks();
+}
+
+size_t FeatureTrackerHip::trackFrameBundle(const FrameBundle::Ptr& nframe_kp1)
+{
+  if (!nframe_kp1 || nframe_kp1->size() != bundle_size_) throw std::runtime_error("FeatureTrackerHip: bundle size mismatch");
+  resetTerminatedTracks();
+
+  // gather every track of every frame of the bundle (feature_tracker.cpp:64-80)
+  std::vector<svoh_frame_t> ref_frames, cur_frames;
+  std::vector<int32_t> px_ref;
+  std::vector<double> px_cur;
+  for (size_t frame_index = 0; frame_index < bundle_size_; ++frame_index) {
+    const FramePtr& cur_frame = nframe_kp1->at(frame_index);
+    for (const FeatureTrack& track : active_tracks_[frame_index]) {
+      const FeatureRef& ref_observation = options_.klt_template_is_first_observation ? track.front() : track.back();
+      ref_frames.push_back(ref_observation.getFrame()->pyramid);
+      cur_frames.push_back(cur_frame->pyramid);
+      px_ref.push_back(static_cast<int32_t>(ref_observation.getPx()[0]));  // getPx().cast<int>(): truncation
+      px_ref.push_back(static_cast<int32_t>(ref_observation.getPx()[1]));
+      px_cur.push_back(track.back().getPx()[0]);
+      px_cur.push_back(track.back().getPx()[1]);
+    }
+  }
+  const size_t n = ref_frames.size();
+  std::vector<uint8_t> status(n, 0);
+  if (n) {
+    svoh_klt_options o{};
+    o.max_level = options_.klt_max_level; o.min_level = options_.klt_min_level; o.max_iter = options_.klt_max_iter;
+    o.min_update_squared = static_cast<float>(options_.klt_min_update_squared);
+    for (size_t l = 0; l < options_.klt_patch_sizes.size() && l < SVOH_MAX_LEVELS; ++l) o.patch_sizes[l] = options_.klt_patch_sizes[l];
+    const int rc = svoh_klt_track_multi(ctx_, &o, static_cast<int>(n), ref_frames.data(), cur_frames.data(), px_ref.data(),
+                                        px_cur.data(), status.data());
+    if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_klt_track_multi: ") + svoh_last_error_string(ctx_));
+  }
+
+  // the reference's bookkeeping, frame by frame and track by track (feature_tracker.cpp:86-118)
+  size_t t = 0;
+  for (size_t frame_index = 0; frame_index < bundle_size_; ++frame_index) {
+    FeatureTracks& tracks = active_tracks_[frame_index];
+    const FramePtr& cur_frame = nframe_kp1->at(frame_index);
+    std::vector<double> new_keypoints, new_scores;
+    std::vector<int> new_track_ids;
+    FeatureTracks kept;
+    size_t new_keypoints_counter = 0;
+    for (size_t track_index = 0; track_index < tracks.size(); ++track_index, ++t) {
+      FeatureTrack& track = tracks[track_index];
+      const FeatureRef& ref_observation = options_.klt_template_is_first_observation ? track.front() : track.back();
+      if (status[t]) {
+        new_keypoints.push_back(px_cur[2 * t]); new_keypoints.push_back(px_cur[2 * t + 1]);
+        const Frame& rf = *ref_observation.getFrame();
+        new_scores.push_back(ref_observation.getFeatureIndex() < rf.score_vec_.size() ? rf.score_vec_[ref_observation.getFeatureIndex()] : 0.0);
+        new_track_ids.push_back(track.getTrackId());
+        track.pushBack(nframe_kp1, frame_index, new_keypoints_counter);
+        ++new_keypoints_counter;
+        kept.push_back(track);
+      } else {
+        terminated_tracks_[frame_index].push_back(track);
+      }
+    }
+    tracks.swap(kept);
+    // insert the new keypoints in the frame (resizeFeatureStorage + assignments)
+    cur_frame->px_vec_ = new_keypoints;
+    cur_frame->score_vec_ = new_scores;
+    cur_frame->track_id_vec_ = new_track_ids;
+    cur_frame->num_features_ = new_keypoints_counter;
+    // frame_utils::computeNormalizedBearingVectors (frame.cpp:427-439)
+    cur_frame->f_vec_.resize(3 * new_keypoints_counter);
+    const svoh::CamModel cm = svoh::load_camera(cur_frame->cam);
+    for (size_t i = 0; i < new_keypoints_counter; ++i) {
+      svoh::Vec3 f = svoh::back_project3(cm, new_keypoints[2 * i], new_keypoints[2 * i + 1]);
+      const double nn = sqrt(f.x * f.x + f.y * f.y + f.z * f.z);
+      cur_frame->f_vec_[3 * i] = f.x / nn; cur_frame->f_vec_[3 * i + 1] = f.y / nn; cur_frame->f_vec_[3 * i + 2] = f.z / nn;
+    }
+  }
+  return getTotalActiveTracks();
+}
+
 double updateSeedPxErrorAngle(const Frame& cur_frame)
 {
   // static double px_error_angle = cur_frame.getAngleError(1.0);  (depth_filter.cpp:383-384,

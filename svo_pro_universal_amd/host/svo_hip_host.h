@@ -53,6 +53,7 @@ struct Frame {
   int id() const { return id_; }
   // members the reprojector writes for a newly matched feature (frame.h:62-86); optional otherwise
   std::vector<double> score_vec_;                       // n
+  std::vector<int> track_id_vec_;                       // n (FeatureTracker)
   std::vector<std::shared_ptr<struct Point>> landmark_vec_;   // n, nullptr = no landmark
   struct SeedRef { std::shared_ptr<Frame> keyframe; int seed_id = -1; };
   std::vector<SeedRef> seed_ref_vec_;                   // n
@@ -172,6 +173,76 @@ void alignPyr2DVec(svoh_ctx* ctx, svoh_frame_t img_pyr_ref, svoh_frame_t img_pyr
                    const std::vector<int>& patch_sizes, int n_iter, float min_update_squared,
                    const std::vector<Point2f>& px_ref, std::vector<Point2f>& px_cur, std::vector<uint8_t>& status);
 }
+
+// FeatureTracker (src/svo_tracker/include/svo/tracker/feature_tracker.h,
+// feature_tracking_types.h:15-139): trackFrameBundle with the tracks of the whole bundle in
+// ONE batched launch; the bookkeeping (pushBack, terminated tracks, px / score / track id /
+// bearing vectors of the new frame) is the reference's, run on the host afterwards.
+struct FeatureTrackerOptions {   // feature_tracking_types.h:15-49
+  int klt_max_level = 4;
+  int klt_min_level = 0;
+  std::vector<int> klt_patch_sizes = { 16, 16, 16, 8, 8 };
+  int klt_max_iter = 30;
+  double klt_min_update_squared = 0.001;
+  bool klt_template_is_first_observation = true;
+  size_t min_tracks_to_detect_new_features = 50;
+  bool reset_before_detection = true;
+};
+
+class FeatureRef {
+ public:
+  FeatureRef(const FrameBundle::Ptr& frame_bundle, size_t frame_index, size_t feature_index)
+      : frame_bundle_(frame_bundle), frame_index_(frame_index), feature_index_(feature_index) {}
+  const FrameBundle::Ptr& getFrameBundle() const { return frame_bundle_; }
+  size_t getFrameIndex() const { return frame_index_; }
+  size_t getFeatureIndex() const { return feature_index_; }
+  const double* getPx() const { return &getFrame()->px_vec_[2 * feature_index_]; }
+  const FramePtr& getFrame() const { return frame_bundle_->at(frame_index_); }
+ private:
+  FrameBundle::Ptr frame_bundle_;
+  size_t frame_index_, feature_index_;
+};
+
+class FeatureTrack {
+ public:
+  explicit FeatureTrack(int track_id) : track_id_(track_id) {}
+  int getTrackId() const { return track_id_; }
+  size_t size() const { return feature_track_.size(); }
+  bool empty() const { return feature_track_.empty(); }
+  const FeatureRef& front() const { return feature_track_.front(); }   // first observation
+  const FeatureRef& back() const { return feature_track_.back(); }     // last observation
+  const FeatureRef& at(size_t i) const { return feature_track_.at(i); }
+  void pushBack(const FrameBundle::Ptr& frame_bundle, size_t frame_index, size_t feature_index)
+  {
+    feature_track_.emplace_back(frame_bundle, frame_index, feature_index);
+  }
+ private:
+  int track_id_;
+  std::vector<FeatureRef> feature_track_;
+};
+using FeatureTracks = std::vector<FeatureTrack>;
+
+class FeatureTrackerHip {
+ public:
+  FeatureTrackerHip(svoh_ctx* ctx, const FeatureTrackerOptions& options, size_t bundle_size);
+  // feature_tracker.cpp:52-122; returns getTotalActiveTracks()
+  size_t trackFrameBundle(const FrameBundle::Ptr& nframe_kp1);
+  // The track-creating tail of initializeNewTracks (feature_tracker.cpp:168-178) for the features
+  // [n_old, num_features_) of every frame of the bundle; detection itself is SURVEY.md 8(f-2).
+  size_t initializeNewTracks(const FrameBundle::Ptr& nframe, const std::vector<size_t>& n_old_per_frame);
+  const FeatureTracks& getActiveTracks(size_t frame_index) const { return active_tracks_.at(frame_index); }
+  const FeatureTracks& getTerminatedTracks(size_t frame_index) const { return terminated_tracks_.at(frame_index); }
+  size_t getTotalActiveTracks() const;
+  void resetActiveTracks() { for (auto& t : active_tracks_) t.clear(); }
+  void resetTerminatedTracks() { for (auto& t : terminated_tracks_) t.clear(); }
+  void reset() { resetActiveTracks(); resetTerminatedTracks(); }
+ private:
+  svoh_ctx* ctx_;
+  FeatureTrackerOptions options_;
+  size_t bundle_size_;
+  std::vector<FeatureTracks> active_tracks_, terminated_tracks_;
+  int next_track_id_ = 0;   // PointIdProvider::getNewPointId()
+};
 
 // ---------------------------------------------------------------------------
 // Seam 2b: reprojector.  Mirrors reprojector_utils::matchCandidates

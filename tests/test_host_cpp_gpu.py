@@ -127,3 +127,35 @@ def test_cpp_reprojector_match_candidates_mirror_matches_oracle(tmp_path, oracle
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASS" in out.stdout
+
+
+@pytest.mark.parametrize("first_obs", [1, 0])
+def test_cpp_feature_tracker_mirror_matches_oracle(tmp_path, oracle_lib, first_obs):
+    """FeatureTracker::trackFrameBundle (feature_tracker.cpp:52-122) over a 2-camera bundle and three time
+    steps: template from the first / the last observation, start from the last position, truncated reference
+    pixel, terminated tracks, new frame's px / track ids / bearing vectors."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    cam = synth.Camera.euroc_like()
+    n = 150
+    imgs, px0 = [[], [], []], []
+    for c, seed in enumerate((95, 96)):
+        sc = synth.make_align_scene(seed, n_features=10, cam=cam, rot_deg=(0.4, 1.0), trans_m=(0.03, 0.08))
+        T_ref_cur = sc.T_w_ref.inverse() * sc.T_w_cur
+        T_w_2 = sc.T_w_cur * T_ref_cur                       # the same motion once more
+        imgs[0].append(sc.img_ref); imgs[1].append(sc.img_cur)
+        imgs[2].append(synth.render(cam, T_w_2, sc.plane, sc.tex))
+        tr = synth.make_track_set(sc, n, seed=c, margin=10)   # some start close to the border and get lost
+        px0.append(np.asarray(tr["px_ref"], np.int32))
+    path = str(tmp_path / "tracker.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("4i", cam.width, cam.height, n, first_obs))
+        np.array([cam.fx, cam.fy, cam.cx, cam.cy] + list(cam.dist) + [1.0]).tofile(f)
+        np.concatenate(px0).astype(np.int32).tofile(f)
+        for t in range(3):
+            for c in range(2):
+                np.ascontiguousarray(imgs[t][c], np.uint8).tofile(f)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_host_tracker"), path], capture_output=True, text=True)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASS" in out.stdout
