@@ -448,13 +448,70 @@ def bench_frame(args, ctx, dist, rank, world, dev, comm_dev=None):
             "cpu_baseline": cpu}
 
 
+def bench_detect(args, ctx, dist, rank, world, dev, comm_dev=None):
+    """Keyframe feature detection (SURVEY.md 8(f-2)): FastGradDetector::detect on a 752x480 5-level pyramid
+    (FAST-10 on levels 0..2, best corner per 30-px cell, edgelets on level 1 in the free cells), one keyframe
+    per call with the pyramid resident in HBM, results on the host."""
+    cam = synth.Camera.euroc_like(752, 480)
+    B = args.problems or 16
+    scenes = [synth.make_align_scene(du.problem_seed(rank, 300 + i), n_features=8, cam=cam) for i in range(B)]
+    frames = [ctx.build_pyramid(sc.img_ref, 5) for sc in scenes]
+    opt = capi.default_detector_options()
+    last = {}
+
+    def step():
+        n = 0
+        for fr in frames:
+            last["d"] = ctx.detect_features(opt, fr, cam.width, cam.height)
+            n += len(last["d"]["score"])
+        last["n"] = n
+        return None, misc_kernel_ms(ctx)
+
+    elapsed, kms, _ = timed_steps(ctx, dist, world, dev, step, args.steps, args.warmup)
+    elapsed, total = du.combine(dist, world, elapsed, B, comm_dev)
+    # per keyframe: every level's image read once, its u8 score map written and read once; level 1 read once more,
+    # its float magnitude map written and read once
+    px = [(cam.width >> l) * (cam.height >> l) for l in range(5)]
+    alg = sum(3 * px[l] for l in range(opt.min_level, opt.max_level + 1)) + 9 * px[1]
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc  # test infrastructure: the timed CPU baseline only
+        orc.build(fast=True)
+        t_cpu, n_cpu = 0.0, 0
+        for sc in scenes:
+            levels = orc.create_img_pyramid(sc.img_ref, 5, fast=True)
+            t0 = time.perf_counter()
+            d = orc.detect_features(opt, levels, fast=True)
+            t_cpu += time.perf_counter() - t0
+            n_cpu += 1
+            if t_cpu > 10.0:
+                break
+        assert np.array_equal(d["px"], last["d"]["px"]) if n_cpu == B else True
+        cpu = {"value": n_cpu / t_cpu, "unit": "keyframes/s", "cores": 1, "kind": "port",
+               "sample": "%d keyframes of the benchmark (oracle detector: definitional FAST-10, gcc -O3 -march=native, "
+                         "1 thread, %.1f s; the reference uses the SSE2 decision-tree detector, faster than this port)" % (n_cpu, t_cpu)}
+    if rank != 0:
+        return None
+    return {"metric": "keyframes/s (FastGradDetector::detect, 752x480, FAST-10 levels 0..2 + edgelets, 30-px grid)",
+            "value": total * args.steps / elapsed, "unit": "keyframes/s", "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_frame": 1e3 * elapsed / args.steps / B, "dtype": "u8+i32+f32",
+            "config": {"workload": "detector: %d keyframes per step, 752x480, pyramid resident in HBM, one blocking call each" % B,
+                       "keyframes_per_step": B},
+            "kernel_ms": kms, "features_per_keyframe": last["n"] / float(B),
+            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fast_score/select + edge_score/select/angle kernels of one keyframe (latency-bound: 9 launches)",
+                         "algorithmic_bytes_per_launch": alg},
+            "cpu_baseline": cpu}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--problems", type=int, default=0, help="frame pairs per GPU per step (default: per workload)")
-    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds", "frame"],
+    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds", "frame", "detect"],
                     help="align = the headline SparseImgAlign config (default); klt / seeds = the other hot-path rows; "
                          "frame = the whole per-frame chain at EuRoC mono sizes, one frame at a time (latency)")
     ap.add_argument("--features", type=int, default=2000)
@@ -481,7 +538,7 @@ def main():
 
     ctx = fe.Context(local_rank)
     if args.workload != "align":
-        out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame}[args.workload](
+        out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame, "detect": bench_detect}[args.workload](
             args, ctx, dist, rank, world, dev, comm_dev)
         if rank == 0:
             out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,

@@ -420,6 +420,34 @@ int svoh_update_seeds_batch_ex(svoh_ctx* ctx, const svoh_matcher_options* matche
                                double* state, uint8_t* success, int32_t* match_result,
                                int32_t* n_success, const svoh_seed_match_outputs* outputs);
 
+/* ---- keyframe feature detector ----------------------- */
+
+/* DetectorOptions (src/svo_direct/include/svo/direct/feature_detection_types.h:49-84) */
+typedef struct svoh_detector_options {
+  int32_t cell_size;            /* 30: at most one feature per cell_size x cell_size bucket */
+  int32_t max_level;            /* 2 */
+  int32_t min_level;            /* 0 */
+  int32_t border;               /* 8 */
+  int32_t detect_edgelets;      /* 0 = DetectorType::kFast, 1 = kFastGrad (corners, then edgelets in free cells) */
+  int32_t reserved;
+  double threshold_primary;     /* 10: FAST barrier and minimum corner score */
+  double threshold_secondary;   /* 100: gradient magnitude threshold of the edgelet detector */
+} svoh_detector_options;
+
+/* Replaces FastDetector::detect / FastGradDetector::detect (src/svo_direct/src/feature_detection.cpp:113-194):
+ * FAST-10 corners on levels min_level..max_level (fast_corner_detect_10 + fast_corner_score_10 + 3x3 non-maximum
+ * suppression, src/fast_neon), best corner per free grid cell; optionally Scharr-gradient edgelets on level 1 in
+ * the cells that are still free; fillFeatures' threshold / mask / sort by score.
+ * occupancy: ceil(width/cell_size) * ceil(height/cell_size) bytes, non-zero = cell already holds a feature
+ * (OccupandyGrid2D::fillWithKeypoints), may be NULL; not modified (the reference resets its grid after detect).
+ * mask: level-0 sized u8 image (0 = no feature here) or NULL.  Outputs hold one entry per grid cell at most:
+ * px (2 x n, level-0 pixels), score, level, grad (2 x n, unit vector), type (svoh_feature_type).  Host pointers.
+ * Equal scores keep cell order (the reference's std::sort leaves their order to the library). */
+int svoh_detect_features(svoh_ctx* ctx, svoh_frame_t frame, const svoh_detector_options* options,
+                         const uint8_t* occupancy, const uint8_t* mask, int mask_pitch, int max_n_features,
+                         double* px, double* score, int32_t* level, double* grad, uint8_t* type,
+                         int32_t* n_features);
+
 #ifdef __cplusplus
 }
 #endif

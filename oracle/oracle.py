@@ -321,3 +321,87 @@ def update_seeds_batch(mopt, dopt, ref_views, cur_view, fb, state, fast=False):
     ns = lib.orc_update_seeds_batch(C.byref(mopt), C.byref(dopt), len(ref_views), rv, C.byref(cur_view), C.byref(fb),
                                     st.ctypes.data, success.ctypes.data, mr.ctypes.data)
     return ns, st, success, mr
+
+
+# ---- keyframe feature detector ----------------------------------
+
+def _bind_detector(lib):
+    if getattr(lib, "_det", False):
+        return
+    P = C.POINTER
+    lib.orc_fast_corner_detect_10.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.orc_fast_corner_score_10.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.orc_fast_corner_score_10.restype = None
+    lib.orc_fast_nonmax_3x3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_gaussian_blur_3x3.argtypes = [P(orc_image), C.c_void_p]
+    lib.orc_gaussian_blur_3x3.restype = None
+    lib.orc_scharr_16s.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.orc_scharr_16s.restype = None
+    lib.orc_angle_at_pixel_using_histogram.argtypes = [P(orc_image), C.c_int, C.c_int, C.c_int]
+    lib.orc_angle_at_pixel_using_histogram.restype = C.c_double
+    lib.orc_detect_features.argtypes = [P(orc_pyramid), P(capi.svoh_detector_options), C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib._det = True
+
+
+def _image_struct(img):
+    assert img.dtype == np.uint8 and img.flags["C_CONTIGUOUS"]
+    s = orc_image()
+    s.data, s.width, s.height, s.pitch = img.ctypes.data, img.shape[1], img.shape[0], img.strides[0]
+    return s
+
+
+def fast_corners(img, barrier, fast=False):
+    """(xy [n,2] in raster order, score [n], indices surviving the 3x3 non-maximum suppression)."""
+    lib = load(fast); _bind_detector(lib)
+    cap = img.size
+    xy = np.zeros(2 * cap, np.int32)
+    n = lib.orc_fast_corner_detect_10(img.ctypes.data, img.shape[1], img.shape[0], img.strides[0], int(barrier), xy.ctypes.data, cap)
+    xy = xy[:2 * n].copy()
+    sc = np.zeros(max(n, 1), np.int32)
+    lib.orc_fast_corner_score_10(img.ctypes.data, img.strides[0], xy.ctypes.data, n, int(barrier), sc.ctypes.data)
+    nm = np.zeros(max(n, 1), np.int32)
+    k = lib.orc_fast_nonmax_3x3(xy.ctypes.data, sc.ctypes.data, n, nm.ctypes.data)
+    return xy.reshape(-1, 2), sc[:n], nm[:k]
+
+
+def gaussian_blur_3x3(img, fast=False):
+    lib = load(fast); _bind_detector(lib)
+    out = np.zeros(img.shape, np.uint8)
+    s = _image_struct(img)
+    lib.orc_gaussian_blur_3x3(C.byref(s), out.ctypes.data)
+    return out
+
+
+def scharr_16s(img, x_derivative, fast=False):
+    lib = load(fast); _bind_detector(lib)
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(img.shape, np.int16)
+    lib.orc_scharr_16s(img.ctypes.data, img.shape[1], img.shape[0], int(bool(x_derivative)), out.ctypes.data)
+    return out
+
+
+def angle_at_pixel(img, x, y, halfpatch=4, fast=False):
+    lib = load(fast); _bind_detector(lib)
+    s = _image_struct(img)
+    return lib.orc_angle_at_pixel_using_histogram(C.byref(s), int(x), int(y), int(halfpatch))
+
+
+def detect_features(opt, levels, occupancy=None, mask=None, max_n_features=None, fast=False):
+    """FastDetector / FastGradDetector::detect restatement: dict(px [n,2], score, level, grad [n,2], type)."""
+    lib = load(fast); _bind_detector(lib)
+    pyr = make_pyramid_struct(levels)
+    h, w = levels[0].shape
+    n_cells = int(np.ceil(w / opt.cell_size)) * int(np.ceil(h / opt.cell_size))
+    if max_n_features is None:
+        max_n_features = n_cells
+    px = np.zeros(2 * n_cells); score = np.zeros(n_cells); level = np.zeros(n_cells, np.int32)
+    grad = np.zeros(2 * n_cells); typ = np.zeros(n_cells, np.uint8)
+    occ = None if occupancy is None else np.ascontiguousarray(occupancy, np.uint8)
+    msk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    n = lib.orc_detect_features(C.byref(pyr), C.byref(opt), None if occ is None else occ.ctypes.data,
+                                None if msk is None else msk.ctypes.data, 0 if msk is None else msk.strides[0],
+                                int(max_n_features), px.ctypes.data, score.ctypes.data, level.ctypes.data,
+                                grad.ctypes.data, typ.ctypes.data)
+    return dict(px=px[:2 * n].reshape(-1, 2).copy(), score=score[:n].copy(), level=level[:n].copy(),
+                grad=grad[:2 * n].reshape(-1, 2).copy(), type=typ[:n].copy())

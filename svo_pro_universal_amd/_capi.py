@@ -103,6 +103,23 @@ class svoh_seed_match_outputs(C.Structure):
     _fields_ = [("px_cur", C.c_void_p), ("f_cur", C.c_void_p), ("search_level", C.c_void_p), ("A_cur_ref", C.c_void_p)]
 
 
+class svoh_detector_options(C.Structure):
+    _fields_ = [("cell_size", C.c_int32), ("max_level", C.c_int32), ("min_level", C.c_int32), ("border", C.c_int32),
+                ("detect_edgelets", C.c_int32), ("reserved", C.c_int32),
+                ("threshold_primary", C.c_double), ("threshold_secondary", C.c_double)]
+
+
+def default_detector_options(**kw):
+    """DetectorOptions defaults (feature_detection_types.h:49-84) with the FAST_GRAD detector of pinhole.yaml."""
+    o = svoh_detector_options(cell_size=30, max_level=2, min_level=0, border=8, detect_edgelets=1,
+                              threshold_primary=10.0, threshold_secondary=100.0)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
 FT_EDGELET_SEED, FT_CORNER_SEED, FT_MAPPOINT_SEED = 0, 1, 2
 FT_EDGELET_SEED_CONVERGED, FT_CORNER_SEED_CONVERGED, FT_MAPPOINT_SEED_CONVERGED = 3, 4, 5
 FT_EDGELET, FT_CORNER, FT_MAPPOINT, FT_FIXED_LANDMARK, FT_OUTLIER = 6, 7, 8, 9, 10
@@ -180,6 +197,7 @@ EXPORTS = [
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
     "svoh_match_direct_batch",
     "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex",
+    "svoh_detect_features",
 ]
 
 
@@ -261,6 +279,9 @@ def load():
     lib.svoh_update_seeds_batch.argtypes = [C.c_void_p, P(svoh_matcher_options), P(svoh_depth_filter_options),
                                             C.c_int, P(svoh_frame_view), P(svoh_frame_view), P(svoh_feature_batch),
                                             C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int32)]
+    lib.svoh_detect_features.argtypes = [C.c_void_p, svoh_frame_t, P(svoh_detector_options), C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         P(C.c_int32)]
     lib.svoh_update_seeds_batch_ex.argtypes = lib.svoh_update_seeds_batch.argtypes + [P(svoh_seed_match_outputs)]
     _LIB = lib
     return lib

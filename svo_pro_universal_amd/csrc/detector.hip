@@ -1,0 +1,370 @@
+// detector.hip -- keyframe feature detector for gfx950.
+//
+// Replaces FastDetector::detect / FastGradDetector::detect
+//   src/svo_direct/src/feature_detection.cpp:113-194
+// i.e. fd_utils::fastDetector (feature_detection_utils.cpp:145-195: fast_corner_detect_10 +
+// fast_corner_score_10 + fast_nonmax_3x3 of src/fast_neon, best corner per free grid cell),
+// fd_utils::edgeletDetector_V2 (:313-385: GaussianBlur 3x3 + Scharr on level 1, 8-neighbour
+// non-maximum suppression, histogram angle :831-839, 947-1009) and fd_utils::fillFeatures (:72-143).
+//
+// The reference makes corner LISTS (detect -> score -> nonmax -> per-cell best); here every
+// stage is dense and per pixel, which is what the list algorithms compute:
+//   * FAST-10 score map: the largest barrier for which the pixel still is a corner (the value
+//     fast_corner_score_10's iteration converges to), 0 where it is not one at the threshold;
+//   * a corner survives fast_nonmax_3x3 iff no 8-neighbour that is a corner has a score >= its own;
+//   * the per-cell "first strictly better in visiting order" (levels ascending, raster order
+//     inside a level) is an atomicMax on (score, ~visit order) packed in 64 bits.
+// Everything is integer except the edgelet magnitude (float of a correctly rounded double sqrt of
+// an int) and the histogram angle (double; atan2 of the device libm).
+// HBM-bound in principle (17 bytes read per pixel and level from a 0.36 MB image that sits in L2);
+// at keyframe rate it is launch-latency bound.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+#include "svoh_internal.h"
+
+namespace svoh {
+
+__device__ __constant__ int kCircleDx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+__device__ __constant__ int kCircleDy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+
+// ---- FAST-10 score map (fast_10_score.cpp:21-3148 by its fixed point) ----
+// score(x, y) = max over the 16 arcs of 10 contiguous circle pixels of min(p_i - c) resp. min(c - p_i), minus 1;
+// stored as u8 when >= barrier (>= 1), else 0.
+__global__ __launch_bounds__(256) void fast_score_kernel(DevImage im, int barrier, uint8_t* __restrict__ S)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= im.w || y >= im.h) return;
+  int out = 0;
+  if (x >= 3 && y >= 3 && x < im.w - 3 && y < im.h - 3) {
+    const uint8_t* p = im.data + (size_t)y * im.pitch + x;
+    const int c = *p;
+    int d[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = (int)p[kCircleDx[i] + (ptrdiff_t)im.pitch * kCircleDy[i]] - c;
+    // sliding minima of window 10 = 8 + 2 over the circular sequence, for d (brighter) and -d (darker)
+    int best = -1000;
+#pragma unroll
+    for (int sign = 0; sign < 2; ++sign) {
+      int v[16], m2[16], m4[16], m8[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = sign ? -d[i] : d[i];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m2[i] = min(v[i], v[(i + 1) & 15]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m4[i] = min(m2[i], m2[(i + 2) & 15]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m8[i] = min(m4[i], m4[(i + 4) & 15]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) best = max(best, min(m8[i], m2[(i + 8) & 15]));
+    }
+    const int score = best - 1;
+    out = score >= barrier ? score : 0;
+  }
+  S[(size_t)y * im.w + x] = (uint8_t)out;
+}
+
+struct GridDesc {
+  int cell_size, n_cols, n_rows;
+  const uint8_t* occupancy;          // n_cols * n_rows
+  unsigned long long* keys;          // n_cols * n_rows, atomicMax targets
+};
+
+__device__ __forceinline__ int cell_index(const GridDesc& g, int x, int y, int scale)
+{
+  // getCellIndex(Eigen::Vector2d(scale*x, scale*y)): floor(py / cell_size) * n_cols + floor(px / cell_size)
+  const double px = (double)(scale * x), py = (double)(scale * y);
+  return (int)(floor(py / g.cell_size) * g.n_cols + floor(px / g.cell_size));
+}
+
+// ---- fast_nonmax_3x3 + border + per-cell best (feature_detection_utils.cpp:176-192) ----
+__global__ __launch_bounds__(256) void fast_select_kernel(const uint8_t* __restrict__ S, int w, int h, int level, int border,
+                                                          float init_score, GridDesc g)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const int s = S[(size_t)y * w + x];
+  if (s == 0) return;   // not a corner (corners lie in [3, w-3) x [3, h-3): the 8 neighbours exist)
+  const uint8_t* p = S + (size_t)y * w + x;
+  if (p[-1] >= s || p[1] >= s || p[-w - 1] >= s || p[-w] >= s || p[-w + 1] >= s || p[w - 1] >= s || p[w] >= s || p[w + 1] >= s)
+    return;
+  if (x < border || y < border || x >= w - border || y >= h - border) return;
+  const int k = cell_index(g, x, y, 1 << level);
+  if ((unsigned)k >= (unsigned)(g.n_cols * g.n_rows) || g.occupancy[k]) return;
+  if (!((float)s > init_score)) return;   // score > corners.at(k).score, which starts at threshold_primary
+  const unsigned order = ((unsigned)level << 28) | ((unsigned)y << 14) | (unsigned)x;   // the reference's visiting order
+  const unsigned long long key = ((unsigned long long)(unsigned)s << 32) | (unsigned long long)(0xFFFFFFFFu - order);
+  atomicMax(g.keys + k, key);
+}
+
+// ---- edgelets: GaussianBlur 3x3 + Scharr + magnitude (feature_detection_utils.cpp:326-346) ----
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void edge_score_kernel(DevImage im, int border, int threshold, float* __restrict__ E)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= im.w || y >= im.h) return;
+  float out = 0.0f;
+  if (x >= border && y >= border && x < im.w - border && y < im.h - border) {
+    // 5x5 raw footprint -> 3x3 blurred ([1 2 1] x [1 2 1], (s + 8) >> 4) -> Scharr
+    int raw[5][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const uint8_t* row = im.data + (size_t)reflect101(y + j - 2, im.h) * im.pitch;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) raw[j][i] = row[reflect101(x + i - 2, im.w)];
+    }
+    int b[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int s = (raw[j][i] + 2 * raw[j][i + 1] + raw[j][i + 2]) + 2 * (raw[j + 1][i] + 2 * raw[j + 1][i + 1] + raw[j + 1][i + 2]) +
+                      (raw[j + 2][i] + 2 * raw[j + 2][i + 1] + raw[j + 2][i + 2]);
+        b[j][i] = (s + 8) >> 4;
+      }
+    // The blurred image's own border reflection only matters within 1 pixel of the image edge; border >= 1
+    // keeps the 3x3 blurred neighbourhood inside the image, where reflecting the raw footprint is the same thing
+    // as long as border >= 2.  (Smaller borders are refused on the host.)
+    const int gx = 3 * (b[0][2] - b[0][0]) + 10 * (b[1][2] - b[1][0]) + 3 * (b[2][2] - b[2][0]);
+    const int gy = 3 * (b[2][0] - b[0][0]) + 10 * (b[2][1] - b[0][1]) + 3 * (b[2][2] - b[0][2]);
+    const float mag = (float)sqrt((double)(gx * gx + gy * gy));
+    out = (mag > (float)threshold) ? mag : 0.0f;
+  }
+  E[(size_t)y * im.w + x] = out;
+}
+
+// 8-neighbour non-maximum suppression with the reference's asymmetric comparisons + per-cell best (:349-383)
+__global__ __launch_bounds__(256) void edge_select_kernel(const float* __restrict__ E, int w, int h, int border, int threshold,
+                                                          float init_score, GridDesc g)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x < border || y < border || x >= w - border || y >= h - border) return;
+  const int k = cell_index(g, x, y, 2);
+  if ((unsigned)k >= (unsigned)(g.n_cols * g.n_rows) || g.occupancy[k]) return;
+  const float* p = E + (size_t)y * w + x;
+  const float c = *p;
+  if (c < (float)threshold) return;
+  if (p[1] >= c || p[-1] > c || p[w] >= c || p[-w] > c || p[w + 1] >= c || p[w - 1] > c || p[-w + 1] >= c || p[-w - 1] > c) return;
+  if (!(c > init_score)) return;
+  const unsigned order = ((unsigned)y << 14) | (unsigned)x;
+  const unsigned long long key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned long long)(0xFFFFFFFFu - order);
+  atomicMax(g.keys + k, key);   // positive floats order like their bit patterns
+}
+
+// getAngleAtPixelUsingHistogram(img_pyr[1], (x, y), 4) for the winner of every cell (:831-839, 947-1009)
+__global__ __launch_bounds__(64) void edge_angle_kernel(DevImage im, const unsigned long long* __restrict__ keys, int n_cells,
+                                                        float* __restrict__ angle)
+{
+  constexpr int n_bins = 36;
+  __shared__ double s_hist[64][n_bins + 1];
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= n_cells) return;
+  const unsigned long long key = keys[k];
+  if (key == 0ull) { angle[k] = 0.0f; return; }
+  const unsigned order = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+  const int px = (int)(order & 0x3FFFu), py = (int)((order >> 14) & 0x3FFFu);
+  double* hist = s_hist[threadIdx.x];
+  for (int i = 0; i < n_bins; ++i) hist[i] = 0.0;
+  const double pi = 3.14159265358979323846, pi2 = 2.0 * 3.14159265358979323846;
+  for (int dy = -4; dy <= 4; ++dy)
+    for (int dx = -4; dx <= 4; ++dx) {
+      const int x = px + dx, y = py + dy;
+      if (y > 0 && y < im.h - 1 && x > 0 && x < im.w - 1) {
+        const uint8_t* q = im.data + (size_t)y * im.pitch + x;
+        const double gx = (double)((int)q[1] - (int)q[-1]);
+        const double gy = (double)((int)q[im.pitch] - (int)q[-(ptrdiff_t)im.pitch]);
+        const double mag = sqrt(gx * gx + gy * gy);
+        const double ang = atan2(gy, gx);
+        size_t bin = (size_t)round(n_bins * (ang + pi) / pi2);
+        bin = (bin < (size_t)n_bins) ? bin : 0u;
+        hist[bin] += mag;
+      }
+    }
+  double prev = hist[n_bins - 1];
+  const double h0 = hist[0];
+  for (int i = 0; i < n_bins; ++i) {
+    const double tmp = hist[i];
+    hist[i] = 0.25 * prev + 0.5 * hist[i] + 0.25 * ((i + 1 == n_bins) ? h0 : hist[i + 1]);
+    prev = tmp;
+  }
+  double max_v = hist[0];
+  int max_bin = 0;
+  for (int i = 1; i < n_bins; ++i)
+    if (hist[i] > max_v) { max_v = hist[i]; max_bin = i; }
+  angle[k] = (float)(max_bin * 2.0 * pi / n_bins);
+}
+
+// ---- host side: fd_utils::fillFeatures (feature_detection_utils.cpp:72-143) ----
+struct HostCorner { int x, y, level; float score, angle; };
+
+static int fill_features(const std::vector<HostCorner>& corners, int type, const uint8_t* mask, int mask_pitch, double threshold,
+                         int max_n_features, int n_old, const svoh_detector_options& opt, int n_cols, std::vector<uint8_t>& occupancy,
+                         double* px, double* score, int32_t* level, double* grad, uint8_t* types)
+{
+  std::vector<int> idx;
+  for (size_t k = 0; k < corners.size(); ++k) {
+    const HostCorner& c = corners[k];
+    if (!((double)c.score > threshold)) continue;
+    if (mask && mask[(size_t)c.y * mask_pitch + c.x] == 0) continue;
+    idx.push_back((int)k);
+    const size_t cell = (size_t)(std::floor((double)c.y / opt.cell_size) * n_cols + std::floor((double)c.x / opt.cell_size));
+    occupancy[cell] = 1;
+  }
+  // bigger score first; equal scores keep cell order (the reference's std::sort leaves them in library order)
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return corners[a].score > corners[b].score; });
+  const int n_new = std::min<int>(max_n_features, (int)idx.size());
+  for (int i = 0; i < n_new; ++i) {
+    const HostCorner& c = corners[idx[i]];
+    const int o = n_old + i;
+    px[2 * o] = c.x; px[2 * o + 1] = c.y;
+    score[o] = c.score; level[o] = c.level;
+    grad[2 * o] = (double)std::cos(c.angle); grad[2 * o + 1] = (double)std::sin(c.angle);   // std::cos(float)
+    types[o] = (uint8_t)type;
+  }
+  return n_old + n_new;
+}
+
+}  // namespace svoh
+
+using namespace svoh;
+
+extern "C" int svoh_detect_features(svoh_ctx* ctx, svoh_frame_t frame, const svoh_detector_options* options,
+                                    const uint8_t* occupancy, const uint8_t* mask, int mask_pitch, int max_n_features,
+                                    double* px, double* score, int32_t* level, double* grad, uint8_t* type,
+                                    int32_t* n_features)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, options && px && score && level && grad && type && n_features, "NULL argument");
+  *n_features = 0;
+  const svoh_detector_options& opt = *options;
+  SVOH_REQUIRE(ctx, opt.cell_size >= 1 && opt.min_level >= 0 && opt.max_level >= opt.min_level && opt.max_level < SVOH_MAX_LEVELS,
+               "bad detector cell size / level range");
+  SVOH_REQUIRE(ctx, opt.border >= 3, "detector border must be >= 3 (FAST circle radius; the reference's default is 8)");
+  SVOH_REQUIRE(ctx, opt.threshold_primary >= 1.0 && opt.threshold_primary <= 254.0, "threshold_primary out of [1, 254]");
+  const Frame* f = find_frame(ctx, frame);
+  if (!f) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frame);
+  SVOH_REQUIRE(ctx, f->n_levels > opt.max_level, "pyramid has too few levels for the detector");
+  SVOH_REQUIRE(ctx, !opt.detect_edgelets || f->n_levels > 1, "the edgelet detector works on level 1");
+  const int w = f->lv[0].w, h = f->lv[0].h;
+  SVOH_REQUIRE(ctx, w < (1 << 14) && h < (1 << 14), "image larger than 16383 pixels a side");
+  SVOH_REQUIRE(ctx, !mask || mask_pitch >= w, "mask pitch smaller than the image width");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int n_cols = (int)std::ceil((double)w / opt.cell_size), n_rows = (int)std::ceil((double)h / opt.cell_size);
+  const int n_cells = n_cols * n_rows;
+  if (max_n_features <= 0) return SVOH_OK;
+
+  // device scratch: [occupancy n_cells | keys 8*n_cells | angles 4*n_cells | maps]
+  size_t map_bytes = 0;
+  for (int l = opt.min_level; l <= opt.max_level; ++l) map_bytes = std::max(map_bytes, (size_t)f->lv[l].w * f->lv[l].h);
+  if (opt.detect_edgelets) map_bytes = std::max(map_bytes, sizeof(float) * (size_t)f->lv[1].w * f->lv[1].h);
+  const size_t o_keys = ((size_t)n_cells + 63) & ~(size_t)63;
+  const size_t o_angle = o_keys + sizeof(unsigned long long) * (size_t)n_cells;
+  const size_t o_map = (o_angle + sizeof(float) * (size_t)n_cells + 255) & ~(size_t)255;
+  SVOH_HIP_TRY(ctx, ctx->d_scratch2.reserve(o_map + map_bytes));
+  SVOH_HIP_TRY(ctx, ctx->h_scratch1.reserve(o_map));
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch2.ptr);
+  uint8_t* hs = static_cast<uint8_t*>(ctx->h_scratch1.ptr);
+  std::vector<uint8_t> occ((size_t)n_cells, 0);
+  if (occupancy) for (int k = 0; k < n_cells; ++k) occ[k] = occupancy[k] ? 1 : 0;
+
+  GridDesc g;
+  g.cell_size = opt.cell_size; g.n_cols = n_cols; g.n_rows = n_rows;
+  g.occupancy = d;
+  g.keys = reinterpret_cast<unsigned long long*>(d + o_keys);
+  auto upload_grid = [&]() -> int {
+    memcpy(hs, occ.data(), (size_t)n_cells);
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, hs, (size_t)n_cells, hipMemcpyHostToDevice, ctx->stream));
+    SVOH_HIP_TRY(ctx, hipMemsetAsync(g.keys, 0, sizeof(unsigned long long) * (size_t)n_cells, ctx->stream));
+    return SVOH_OK;
+  };
+  auto fetch_keys = [&](bool with_angles) -> int {
+    const size_t bytes = with_angles ? o_map - o_keys : o_angle - o_keys;
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(hs + o_keys, d + o_keys, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SVOH_OK;
+  };
+  auto grid2d = [](int iw, int ih) { return dim3((unsigned)((iw + 63) / 64), (unsigned)((ih + 3) / 4)); };
+
+  // ---- corners: fd_utils::fastDetector ----
+  {
+    const int rc = upload_grid();
+    if (rc != SVOH_OK) return rc;
+  }
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  for (int l = opt.min_level; l <= opt.max_level; ++l) {
+    const DevImage& im = f->lv[l];
+    if (im.h < 7 || im.w < 7) continue;
+    uint8_t* S = d + o_map;
+    hipLaunchKernelGGL(fast_score_kernel, grid2d(im.w, im.h), dim3(256), 0, ctx->stream, im, (int)opt.threshold_primary, S);
+    hipLaunchKernelGGL(fast_select_kernel, grid2d(im.w, im.h), dim3(256), 0, ctx->stream, S, im.w, im.h, l, opt.border,
+                       (float)opt.threshold_primary, g);
+  }
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  {
+    const int rc = fetch_keys(false);
+    if (rc != SVOH_OK) return rc;
+  }
+  const unsigned long long* hk = reinterpret_cast<const unsigned long long*>(hs + o_keys);
+  std::vector<HostCorner> corners((size_t)n_cells);
+  for (int k = 0; k < n_cells; ++k) {
+    HostCorner c{ 0, 0, 0, (float)opt.threshold_primary, 0.0f };
+    if (hk[k]) {
+      const unsigned order = 0xFFFFFFFFu - (unsigned)(hk[k] & 0xFFFFFFFFull);
+      const int lv = (int)(order >> 28), y = (int)((order >> 14) & 0x3FFFu), x = (int)(order & 0x3FFFu);
+      c = HostCorner{ x << lv, y << lv, lv, (float)(unsigned)(hk[k] >> 32), 0.0f };
+    }
+    corners[k] = c;
+  }
+  int n = fill_features(corners, SVOH_FT_CORNER, mask, mask_pitch, opt.threshold_primary, max_n_features, 0, opt, n_cols, occ, px, score,
+                        level, grad, type);
+
+  // ---- edgelets in the cells that are still free: fd_utils::edgeletDetector_V2 ----
+  const int max_features = max_n_features - n;
+  if (opt.detect_edgelets && max_features > 0) {
+    const int rc = upload_grid();
+    if (rc != SVOH_OK) return rc;
+    const DevImage& im = f->lv[1];
+    float* E = reinterpret_cast<float*>(d + o_map);
+    float* d_angle = reinterpret_cast<float*>(d + o_angle);
+    hipLaunchKernelGGL(edge_score_kernel, grid2d(im.w, im.h), dim3(256), 0, ctx->stream, im, opt.border, (int)opt.threshold_secondary, E);
+    hipLaunchKernelGGL(edge_select_kernel, grid2d(im.w, im.h), dim3(256), 0, ctx->stream, E, im.w, im.h, opt.border,
+                       (int)opt.threshold_secondary, (float)opt.threshold_secondary, g);
+    hipLaunchKernelGGL(edge_angle_kernel, dim3((unsigned)((n_cells + 63) / 64)), dim3(64), 0, ctx->stream, im, g.keys, n_cells, d_angle);
+    SVOH_HIP_TRY(ctx, hipGetLastError());
+    const int rc2 = fetch_keys(true);
+    if (rc2 != SVOH_OK) return rc2;
+    const float* ha = reinterpret_cast<const float*>(hs + o_angle);
+    for (int k = 0; k < n_cells; ++k) {
+      HostCorner c{ 0, 0, 0, (float)opt.threshold_secondary, 0.0f };
+      if (hk[k]) {
+        const unsigned order = 0xFFFFFFFFu - (unsigned)(hk[k] & 0xFFFFFFFFull);
+        const int y = (int)((order >> 14) & 0x3FFFu), x = (int)(order & 0x3FFFu);
+        const unsigned bits = (unsigned)(hk[k] >> 32);
+        float sc;
+        memcpy(&sc, &bits, sizeof sc);
+        c = HostCorner{ x * 2, y * 2, 0, sc, ha[k] };   // level = 1 - 1, coordinates scaled to level 0
+      }
+      corners[k] = c;
+    }
+    n = fill_features(corners, SVOH_FT_EDGELET, mask, mask_pitch, opt.threshold_secondary, max_features, n, opt, n_cols, occ, px, score,
+                      level, grad, type);
+  }
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->misc_timed = true;
+  *n_features = n;
+  return SVOH_OK;
+}

@@ -313,6 +313,27 @@ def _match_direct_device(self, mopt, ref_views, cur_views, fb, depth, px_cur, re
                                                  result, f_cur, search_level, h_inv, A_cur_ref))
 
 
+def _detect_features(self, opt, frame, width, height, occupancy=None, mask=None, max_n_features=None):
+    """svoh_detect_features: dict(px [n,2], score, level, grad [n,2], type) like FastGradDetector::detect."""
+    n_cells = int(np.ceil(width / opt.cell_size)) * int(np.ceil(height / opt.cell_size))
+    if max_n_features is None:
+        max_n_features = n_cells
+    px = np.zeros(2 * n_cells); score = np.zeros(n_cells); level = np.zeros(n_cells, np.int32)
+    grad = np.zeros(2 * n_cells); typ = np.zeros(n_cells, np.uint8)
+    occ = None if occupancy is None else np.ascontiguousarray(occupancy, np.uint8)
+    msk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    n = C.c_int32()
+    self._check(self.lib.svoh_detect_features(self.h, frame, C.byref(opt), None if occ is None else occ.ctypes.data,
+                                              None if msk is None else msk.ctypes.data,
+                                              0 if msk is None else msk.strides[0], int(max_n_features), px.ctypes.data,
+                                              score.ctypes.data, level.ctypes.data, grad.ctypes.data, typ.ctypes.data,
+                                              C.byref(n)))
+    n = n.value
+    return dict(px=px[:2 * n].reshape(-1, 2).copy(), score=score[:n].copy(), level=level[:n].copy(),
+                grad=grad[:2 * n].reshape(-1, 2).copy(), type=typ[:n].copy())
+
+
+Context.detect_features = _detect_features
 Context.klt_track_batch = _klt_track_batch
 Context.klt_track_indexed = _klt_track_indexed
 Context.update_seeds_device = _update_seeds_device

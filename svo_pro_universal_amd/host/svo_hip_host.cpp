@@ -281,6 +281,67 @@ size_t FeatureTrackerHip::trackFrameBundle(const FrameBundle::Ptr& nframe_kp1)
   return getTotalActiveTracks();
 }
 
+// ---- feature detector ---------------------------------------------------------------
+DetectorHip::DetectorHip(svoh_ctx* ctx, const DetectorOptions& options, int image_width, int image_height)
+    : grid_(static_cast<int>(options.cell_size), OccupandyGrid2D::getNCell(image_width, static_cast<int>(options.cell_size)),
+            OccupandyGrid2D::getNCell(image_height, static_cast<int>(options.cell_size))),
+      ctx_(ctx), options_(options)
+{
+  if (!ctx_) throw std::runtime_error("DetectorHip: NULL svoh_ctx (no CPU fallback exists)");
+}
+
+void DetectorHip::detect(svoh_frame_t img_pyr, const uint8_t* mask, int mask_pitch, size_t max_n_features,
+                         std::vector<double>& px_vec, std::vector<double>& score_vec, std::vector<int32_t>& level_vec,
+                         std::vector<double>& grad_vec, std::vector<uint8_t>& types_vec)
+{
+  svoh_detector_options o{};
+  o.cell_size = static_cast<int32_t>(options_.cell_size);
+  o.max_level = options_.max_level; o.min_level = options_.min_level; o.border = options_.border;
+  o.detect_edgelets = options_.detector_type == DetectorType::kFastGrad;
+  o.threshold_primary = options_.threshold_primary; o.threshold_secondary = options_.threshold_secondary;
+  const size_t n_cells = grid_.size();
+  std::vector<uint8_t> occ(n_cells);
+  for (size_t k = 0; k < n_cells; ++k) occ[k] = grid_.isOccupied(k);
+  std::vector<double> px(2 * n_cells), score(n_cells), grad(2 * n_cells);
+  std::vector<int32_t> level(n_cells);
+  std::vector<uint8_t> type(n_cells);
+  int32_t n = 0;
+  const int rc = svoh_detect_features(ctx_, img_pyr, &o, occ.data(), mask, mask_pitch,
+                                      static_cast<int>(std::min<size_t>(max_n_features, n_cells)), px.data(), score.data(),
+                                      level.data(), grad.data(), type.data(), &n);
+  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_detect_features: ") + svoh_last_error_string(ctx_));
+  px_vec.insert(px_vec.end(), px.begin(), px.begin() + 2 * n);
+  score_vec.insert(score_vec.end(), score.begin(), score.begin() + n);
+  level_vec.insert(level_vec.end(), level.begin(), level.begin() + n);
+  grad_vec.insert(grad_vec.end(), grad.begin(), grad.begin() + 2 * n);
+  types_vec.insert(types_vec.end(), type.begin(), type.begin() + n);
+  resetGrid();   // FastDetector / FastGradDetector::detect end with resetGrid()
+}
+
+void DetectorHip::detect(const FramePtr& frame)
+{
+  if (!frame) throw std::runtime_error("DetectorHip::detect: NULL frame");
+  // the reference passes the frame's own (empty or resized) members: the new features replace the old ones
+  std::vector<double> px = std::move(frame->px_vec_), score = std::move(frame->score_vec_), grad = std::move(frame->grad_vec_);
+  std::vector<int32_t> level = std::move(frame->level_vec_);
+  std::vector<uint8_t> type = std::move(frame->type_vec_);
+  px.resize(2 * frame->num_features_); score.resize(frame->num_features_); grad.resize(2 * frame->num_features_);
+  level.resize(frame->num_features_); type.resize(frame->num_features_);
+  detect(frame->pyramid, nullptr, 0, grid_.size(), px, score, level, grad, type);
+  frame->px_vec_ = px; frame->score_vec_ = score; frame->grad_vec_ = grad; frame->level_vec_ = level; frame->type_vec_ = type;
+  frame->num_features_ = level.size();
+  frame->landmark_vec_.assign(frame->num_features_, nullptr);
+  frame->seed_ref_vec_.assign(frame->num_features_, Frame::SeedRef());
+  frame->invmu_sigma2_a_b_vec_.resize(4 * frame->num_features_);
+  frame->f_vec_.resize(3 * frame->num_features_);
+  const svoh::CamModel cm = svoh::load_camera(frame->cam);
+  for (size_t i = 0; i < frame->num_features_; ++i) {   // frame_utils::computeNormalizedBearingVectors
+    const svoh::Vec3 f = svoh::back_project3(cm, px[2 * i], px[2 * i + 1]);
+    const double nn = sqrt(f.x * f.x + f.y * f.y + f.z * f.z);
+    frame->f_vec_[3 * i] = f.x / nn; frame->f_vec_[3 * i + 1] = f.y / nn; frame->f_vec_[3 * i + 2] = f.z / nn;
+  }
+}
+
 double updateSeedPxErrorAngle(const Frame& cur_frame)
 {
   // static double px_error_angle = cur_frame.getAngleError(1.0);  (depth_filter.cpp:383-384,

@@ -305,6 +305,40 @@ void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features
 const std::vector<int32_t>& lastMatchResults();
 }  // namespace reprojector_utils
 
+// ---------------------------------------------------------------------------
+// Keyframe feature detection.  Mirrors AbstractDetector / FastDetector /
+// FastGradDetector (src/svo_direct/include/svo/direct/feature_detection.h,
+// src/svo_direct/src/feature_detection.cpp:27-50, 113-194) and DetectorOptions
+// (feature_detection_types.h:49-84).
+// ---------------------------------------------------------------------------
+enum class DetectorType { kFast, kFastGrad };
+struct DetectorOptions {
+  size_t cell_size = 30;
+  int max_level = 2;
+  int min_level = 0;
+  int border = 8;
+  DetectorType detector_type = DetectorType::kFast;
+  double threshold_primary = 10.0;
+  double threshold_secondary = 100.0;
+};
+
+class DetectorHip {
+ public:
+  DetectorHip(svoh_ctx* ctx, const DetectorOptions& options, int image_width, int image_height);
+  // AbstractDetector::detect(const FramePtr&) (feature_detection.cpp:40-50): replaces the frame's features
+  // by the detected ones (px, score, level, grad, type, normalised bearing vectors, empty seed / landmark slots)
+  void detect(const FramePtr& frame);
+  // the virtual detect(img_pyr, mask, max_n_features, px_vec, score_vec, level_vec, grad_vec, types_vec): appends
+  void detect(svoh_frame_t img_pyr, const uint8_t* mask, int mask_pitch, size_t max_n_features, std::vector<double>& px_vec,
+              std::vector<double>& score_vec, std::vector<int32_t>& level_vec, std::vector<double>& grad_vec,
+              std::vector<uint8_t>& types_vec);
+  void resetGrid() { grid_.reset(); }
+  OccupandyGrid2D grid_;   // callers mark cells of existing features: grid_.fillWithKeypoints / setOccupied
+ private:
+  svoh_ctx* ctx_;
+  DetectorOptions options_;
+};
+
 // The function-local `static double px_error_angle` of depth_filter_utils::updateSeed
 // (depth_filter.cpp:383-384): the first camera ever passed sets it for the whole process,
 // for the depth filter and the reprojector alike.

@@ -148,6 +148,42 @@ int main(int argc, char** argv)
     printf("tracker: step %d: %zu active tracks (bit-identical positions), %zu terminated so far\n", t, n_active, total_terminated);
   }
   CHECK(total_terminated > 0 && tracker.getTotalActiveTracks() > (size_t)n);
+
+  // ---- AbstractDetector::detect(frame) on the last frame, cells of the tracked features marked occupied
+  //      (FeatureTracker::initializeNewTracks, feature_tracker.cpp:135-166) ----
+  {
+    DetectorOptions dopt;
+    dopt.detector_type = DetectorType::kFastGrad;
+    DetectorHip detector(ctx, dopt, w, h);
+    FramePtr fr = bundles[2]->frames_[0];
+    const size_t n_old = fr->num_features_;
+    std::vector<uint8_t> occ(detector.grid_.size(), 0);
+    for (size_t i = 0; i < n_old; ++i) {   // grid_.fillWithKeypoints(frame->px_vec_)
+      const size_t k = detector.grid_.getCellIndex((int)fr->px_vec_[2 * i], (int)fr->px_vec_[2 * i + 1], 1);
+      detector.grid_.setOccupied(k);
+      occ[k] = 1;
+    }
+    fr->grad_vec_.assign(2 * n_old, 0.0); fr->level_vec_.assign(n_old, 0); fr->type_vec_.assign(n_old, SVOH_FT_CORNER);
+    detector.detect(fr);
+    svoh_detector_options o{};
+    o.cell_size = 30; o.max_level = 2; o.min_level = 0; o.border = 8; o.detect_edgelets = 1;
+    o.threshold_primary = 10.0; o.threshold_secondary = 100.0;
+    const size_t n_cells = detector.grid_.size();
+    std::vector<double> opx(2 * n_cells), osc(n_cells), ogr(2 * n_cells);
+    std::vector<int32_t> olv(n_cells);
+    std::vector<uint8_t> oty(n_cells);
+    const int on = orc_detect_features(&opyr[2][0].pyr, &o, occ.data(), nullptr, 0, (int)n_cells, opx.data(), osc.data(), olv.data(),
+                                       ogr.data(), oty.data());
+    CHECK(fr->num_features_ == n_old + (size_t)on && on > 20);
+    for (int i = 0; i < on; ++i) {
+      const size_t s = n_old + (size_t)i;
+      CHECK(fr->px_vec_[2 * s] == opx[2 * i] && fr->px_vec_[2 * s + 1] == opx[2 * i + 1]);
+      CHECK(fr->score_vec_[s] == osc[i] && fr->level_vec_[s] == olv[i] && fr->type_vec_[s] == oty[i]);
+      CHECK(fabs(fr->f_vec_[3 * s] * fr->f_vec_[3 * s] + fr->f_vec_[3 * s + 1] * fr->f_vec_[3 * s + 1] + fr->f_vec_[3 * s + 2] * fr->f_vec_[3 * s + 2] - 1.0) < 1e-12);
+    }
+    CHECK(detector.grid_.numOccupied() == 0);   // resetGrid() at the end of detect
+    printf("detector: %d new features next to %zu tracked ones, identical to the oracle\n", on, n_old);
+  }
   svoh_destroy(ctx);
   printf("PASS\n");
   return 0;

@@ -1,0 +1,65 @@
+"""GPU parity for the keyframe feature detector: svoh_detect_features through the C ABI vs the
+CPU oracle.  Bars: positions, levels, types, scores of the FAST corners exact (integer work); edgelet positions
+and scores exact (float of a correctly rounded sqrt of an int); gradient directions exact unless the device's
+atan2 puts a pixel of the 9x9 histogram window into the other of two adjacent 10-degree bins (tolerated for
+<= 2 % of the edgelets, which then differ by one bin)."""
+import numpy as np
+import pytest
+
+from svo_pro_universal_amd import _capi as capi, frontend as fe, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(dg, do):
+    assert np.array_equal(dg["type"], do["type"]) and np.array_equal(dg["px"], do["px"])
+    assert np.array_equal(dg["level"], do["level"]) and np.array_equal(dg["score"], do["score"])
+    same = np.all(dg["grad"] == do["grad"], axis=1)
+    if not same.all():
+        ang = np.arccos(np.clip(np.sum(dg["grad"] * do["grad"], axis=1), -1, 1))
+        assert (~same).mean() <= 0.02 and ang.max() < np.deg2rad(10.5), ((~same).sum(), ang.max())
+
+
+@pytest.mark.parametrize("shape", [(640, 480), (752, 480), (327, 243)])
+@pytest.mark.parametrize("edgelets", [1, 0])
+def test_detector_parity(gpu_ctx, oracle_lib, shape, edgelets):
+    w, h = shape
+    cam = synth.Camera.euroc_like(w, h)
+    sc = synth.make_align_scene(140 + w, n_features=8, cam=cam)
+    levels = oracle_lib.create_img_pyramid(sc.img_ref, 5)
+    fr = gpu_ctx.build_pyramid(sc.img_ref, 5)
+    n_cells = int(np.ceil(w / 30)) * int(np.ceil(h / 30))
+    rng = np.random.RandomState(w)
+    for kw, occ, mask, max_n in (
+            (dict(), None, None, None),
+            (dict(), (rng.uniform(size=n_cells) < 0.3).astype(np.uint8), None, None),
+            (dict(threshold_primary=20.0, threshold_secondary=60.0, border=5, max_level=3, min_level=1), None, None, None),
+            (dict(cell_size=17), None, (rng.uniform(size=(h, w)) < 0.7).astype(np.uint8) * 255, 50)):
+        opt = capi.default_detector_options(detect_edgelets=edgelets, **kw)
+        if occ is not None and "cell_size" in kw:
+            occ = None
+        do = oracle_lib.detect_features(opt, levels, occ, mask, max_n)
+        dg = gpu_ctx.detect_features(opt, fr, w, h, occ, mask, max_n)
+        assert len(do["score"]) > 10
+        compare(dg, do)
+
+
+def test_detector_edge_cases(gpu_ctx, oracle_lib):
+    # flat image: nothing; saturated checkerboard: scores at the u8 limits; tiny pyramid top level
+    opt = capi.default_detector_options()
+    flat = np.full((120, 160), 77, np.uint8)
+    fr = gpu_ctx.build_pyramid(flat, 3)
+    assert len(gpu_ctx.detect_features(opt, fr, 160, 120)["score"]) == 0
+    chk = (np.kron(np.indices((16, 20)).sum(0) % 2, np.ones((8, 8))) * 255).astype(np.uint8)   # 160 x 128
+    levels = oracle_lib.create_img_pyramid(chk, 4)
+    fr = gpu_ctx.build_pyramid(chk, 4)
+    for kw in (dict(), dict(max_level=3), dict(threshold_primary=254.0), dict(border=3)):
+        o = capi.default_detector_options(**kw)
+        compare(gpu_ctx.detect_features(o, fr, 160, 128), oracle_lib.detect_features(o, levels))
+    # every cell occupied -> nothing; max_n_features = 0 -> nothing
+    assert len(gpu_ctx.detect_features(opt, fr, 160, 128, occupancy=np.ones(6 * 5, np.uint8))["score"]) == 0
+    assert len(gpu_ctx.detect_features(opt, fr, 160, 128, max_n_features=0)["score"]) == 0
+    with pytest.raises(fe.SvohError):
+        gpu_ctx.detect_features(capi.default_detector_options(max_level=6), fr, 160, 128)
+    with pytest.raises(fe.SvohError):
+        gpu_ctx.detect_features(capi.default_detector_options(border=1), fr, 160, 128)
