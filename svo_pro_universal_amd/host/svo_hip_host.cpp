@@ -206,6 +206,48 @@ size_t FeatureTrackerHip::initializeNewTracks(const FrameBundle::Ptr& nframe, co
   return getTotalActiveTracks();
 }
 
+void FeatureTrackerHip::trackAndDetect(const FrameBundle::Ptr& nframe_kp1)
+{
+  const size_t n_tracked = trackFrameBundle(nframe_kp1);
+  if (n_tracked < options_.min_tracks_to_detect_new_features) {
+    if (options_.reset_before_detection) {
+      resetActiveTracks();
+      for (const FramePtr& frame : nframe_kp1->frames_) {   // frame->clearFeatureStorage()
+        frame->num_features_ = 0;
+        frame->px_vec_.clear(); frame->f_vec_.clear(); frame->grad_vec_.clear(); frame->level_vec_.clear();
+        frame->type_vec_.clear(); frame->score_vec_.clear(); frame->track_id_vec_.clear();
+        frame->landmark_vec_.clear(); frame->seed_ref_vec_.clear(); frame->invmu_sigma2_a_b_vec_.clear();
+      }
+    }
+    initializeNewTracks(nframe_kp1);
+  }
+}
+
+size_t FeatureTrackerHip::initializeNewTracks(const FrameBundle::Ptr& nframe)
+{
+  if (!nframe || nframe->size() != bundle_size_ || detectors_.size() != bundle_size_)
+    throw std::runtime_error("FeatureTrackerHip::initializeNewTracks: bundle / detector count mismatch");
+  std::vector<size_t> n_old(bundle_size_);
+  for (size_t frame_index = 0; frame_index < bundle_size_; ++frame_index) {
+    const FramePtr& frame = nframe->at(frame_index);
+    DetectorHip& det = *detectors_[frame_index];
+    det.resetGrid();
+    det.fillGridWithKeypoints(frame->px_vec_, frame->num_features_);
+    n_old[frame_index] = frame->num_features_;
+    // detect(frame->img_pyr_, frame->getMask(), grid_.size(), new_px, ...) and append; the frame-level overload
+    // also computes the normalised bearing vectors (feature_tracker.cpp:143-166)
+    frame->grad_vec_.resize(2 * frame->num_features_, 0.0);
+    frame->level_vec_.resize(frame->num_features_, 0);
+    frame->type_vec_.resize(frame->num_features_, SVOH_FT_CORNER);
+    frame->score_vec_.resize(frame->num_features_, 0.0);
+    std::vector<int> ids = frame->track_id_vec_;
+    det.detect(frame);
+    ids.resize(frame->num_features_, -1);
+    frame->track_id_vec_ = ids;
+  }
+  return initializeNewTracks(nframe, n_old);
+}
+
 size_t FeatureTrackerHip::trackFrameBundle(const FrameBundle::Ptr& nframe_kp1)
 {
   if (!nframe_kp1 || nframe_kp1->size() != bundle_size_) throw std::runtime_error("FeatureTrackerHip: bundle size mismatch");
@@ -316,6 +358,12 @@ void DetectorHip::detect(svoh_frame_t img_pyr, const uint8_t* mask, int mask_pit
   grad_vec.insert(grad_vec.end(), grad.begin(), grad.begin() + 2 * n);
   types_vec.insert(types_vec.end(), type.begin(), type.begin() + n);
   resetGrid();   // FastDetector / FastGradDetector::detect end with resetGrid()
+}
+
+void DetectorHip::fillGridWithKeypoints(const std::vector<double>& px_vec, size_t n)
+{
+  for (size_t i = 0; i < n; ++i)
+    grid_.setOccupied(grid_.getCellIndex(static_cast<int>(px_vec[2 * i]), static_cast<int>(px_vec[2 * i + 1]), 1));
 }
 
 void DetectorHip::detect(const FramePtr& frame)

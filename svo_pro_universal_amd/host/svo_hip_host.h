@@ -222,9 +222,18 @@ class FeatureTrack {
 };
 using FeatureTracks = std::vector<FeatureTrack>;
 
+class DetectorHip;
+
 class FeatureTrackerHip {
  public:
   FeatureTrackerHip(svoh_ctx* ctx, const FeatureTrackerOptions& options, size_t bundle_size);
+  // one detector per camera of the bundle (the reference builds them from DetectorOptions in its constructor)
+  void setDetectors(const std::vector<std::shared_ptr<DetectorHip>>& detectors) { detectors_ = detectors; }
+  // feature_tracker.cpp:24-50: track, and when fewer than min_tracks_to_detect_new_features survive,
+  // (optionally reset and) detect new features and start a track for each
+  void trackAndDetect(const FrameBundle::Ptr& nframe_kp1);
+  // feature_tracker.cpp:124-182 with the detectors set above
+  size_t initializeNewTracks(const FrameBundle::Ptr& nframe);
   // feature_tracker.cpp:52-122; returns getTotalActiveTracks()
   size_t trackFrameBundle(const FrameBundle::Ptr& nframe_kp1);
   // The track-creating tail of initializeNewTracks (feature_tracker.cpp:168-178) for the features
@@ -241,6 +250,7 @@ class FeatureTrackerHip {
   FeatureTrackerOptions options_;
   size_t bundle_size_;
   std::vector<FeatureTracks> active_tracks_, terminated_tracks_;
+  std::vector<std::shared_ptr<DetectorHip>> detectors_;
   int next_track_id_ = 0;   // PointIdProvider::getNewPointId()
 };
 
@@ -333,6 +343,8 @@ class DetectorHip {
               std::vector<double>& score_vec, std::vector<int32_t>& level_vec, std::vector<double>& grad_vec,
               std::vector<uint8_t>& types_vec);
   void resetGrid() { grid_.reset(); }
+  // OccupandyGrid2D::fillWithKeypoints (occupancy_grid_2d.h:96-107): 2 x n pixel coordinates
+  void fillGridWithKeypoints(const std::vector<double>& px_vec, size_t n);
   OccupandyGrid2D grid_;   // callers mark cells of existing features: grid_.fillWithKeypoints / setOccupied
  private:
   svoh_ctx* ctx_;
