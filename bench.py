@@ -505,13 +505,69 @@ def bench_detect(args, ctx, dist, rank, world, dev, comm_dev=None):
             "cpu_baseline": cpu}
 
 
+def bench_pose(args, ctx, dist, rank, world, dev, comm_dev=None):
+    """PoseOptimizer::run (SURVEY.md 8(f-3)) for B frame bundles of 180 features per call (multi-stream batch),
+    unit-plane error, 10 % gross outliers; host arrays in, poses + outlier flags out."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import pose_helpers as ph
+    B = args.problems or 2048
+    n_unique = 64
+    scenes = [ph.make_pose_scene(du.problem_seed(rank, 500 + i), n=180) for i in range(n_unique)]
+    opt = capi.default_pose_options(scenes[0]["cam"])
+    built = [fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"]) for sc in scenes]
+    problems = [built[i % n_unique][0] for i in range(B)]
+    arr = (capi.svoh_pose_problem * B)(*problems)
+    res = (capi.svoh_pose_result * B)()
+    n_meas = [0]
+
+    def step():
+        ctx._check(ctx.lib.svoh_optimize_pose_batch(ctx.h, ctypes.byref(opt), B, arr, res))
+        return None, misc_kernel_ms(ctx)
+
+    elapsed, kms, _ = timed_steps(ctx, dist, world, dev, step, args.steps, args.warmup)
+    elapsed, total = du.combine(dist, world, elapsed, B, comm_dev)
+    iters = sum(r.iters for r in res)
+    meas = sum(r.n_meas for r in res)
+    # per measurement and iteration: px 16 + f 24 + grad 16 + xyz 24 + level 4 + type 1 + usable 1 bytes
+    alg = 86 * sum(r.n_meas * (r.iters + 2) for r in res)
+    t1 = time.perf_counter()
+    for _ in range(50):
+        ctx.optimize_pose(opt, [problems[0]])
+    single_ms = (time.perf_counter() - t1) / 50 * 1e3
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc  # test infrastructure: the timed CPU baseline only
+        orc.build(fast=True)
+        t_cpu, n_cpu = 0.0, 0
+        while t_cpu < 5.0 and n_cpu < B:
+            t0 = time.perf_counter()
+            ro = orc.optimize_pose(opt, problems[n_cpu], fast=True)
+            t_cpu += time.perf_counter() - t0
+            assert ro.iters == res[n_cpu].iters
+            n_cpu += 1
+        cpu = {"value": n_cpu / t_cpu, "unit": "bundles/s", "cores": 1, "kind": "port",
+               "sample": "%d bundles of the benchmark (oracle PoseOptimizer::run, gcc -O3 -march=native, 1 thread, %.1f s)" % (n_cpu, t_cpu)}
+    if rank != 0:
+        return None
+    return {"metric": "frame bundles/s (PoseOptimizer::run, 180 features, unit-plane error, Tukey + MAD)",
+            "value": total * args.steps / elapsed, "unit": "bundles/s", "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_frame": 1e3 * elapsed / args.steps / B, "dtype": "f64",
+            "config": {"workload": "pose: %d bundles x 180 features per call, host arrays staged per call" % B, "bundles_per_step": B},
+            "kernel_ms": kms, "mean_iterations": iters / float(B), "measurements_per_bundle": meas / float(B),
+            "single_bundle_call_ms": single_ms,
+            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "pose_optimize_kernel",
+                         "algorithmic_bytes_per_launch": alg},
+            "cpu_baseline": cpu}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--problems", type=int, default=0, help="frame pairs per GPU per step (default: per workload)")
-    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds", "frame", "detect"],
+    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds", "frame", "detect", "pose"],
                     help="align = the headline SparseImgAlign config (default); klt / seeds = the other hot-path rows; "
                          "frame = the whole per-frame chain at EuRoC mono sizes, one frame at a time (latency)")
     ap.add_argument("--features", type=int, default=2000)
@@ -538,7 +594,7 @@ def main():
 
     ctx = fe.Context(local_rank)
     if args.workload != "align":
-        out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame, "detect": bench_detect}[args.workload](
+        out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame, "detect": bench_detect, "pose": bench_pose}[args.workload](
             args, ctx, dist, rank, world, dev, comm_dev)
         if rank == 0:
             out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,

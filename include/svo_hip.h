@@ -448,6 +448,70 @@ int svoh_detect_features(svoh_ctx* ctx, svoh_frame_t frame, const svoh_detector_
                          double* px, double* score, int32_t* level, double* grad, uint8_t* type,
                          int32_t* n_features);
 
+/* ---- pose optimiser ----------------------------------- */
+
+/* PoseOptimizer::ErrorType (src/svo/include/svo/pose_optimizer.h:33) */
+typedef enum svoh_pose_error_type {
+  SVOH_POSE_ERR_UNIT_PLANE = 0, SVOH_POSE_ERR_BEARING_DIFF = 1, SVOH_POSE_ERR_IMAGE_PLANE = 2
+} svoh_pose_error_type;
+
+typedef struct svoh_pose_options {
+  int32_t max_iter;               /* 10  (PoseOptimizer::getDefaultSolverOptions, pose_optimizer.cpp:22-29) */
+  int32_t error_type;             /* svoh_pose_error_type; kUnitPlane unless poseoptim_using_unit_sphere */
+  double eps;                     /* 1e-6 */
+  /* removeOutliers' threshold in the unit of the error type (pose_optimizer.cpp:211-218: reproj_thresh / focal
+   * length on the unit plane, |2 sin(angle_error / 2)| for bearing differences, pixels on the image plane);
+   * the reference computes it once per process in function-local statics -- the caller owns that quirk */
+  double outlier_threshold;
+  int32_t have_rotation_prior;    /* setRotationPrior (pose_optimizer.cpp:30-37) */
+  int32_t reserved;
+  double prior_lambda;
+  double R_prior[4];              /* R_frame_world, quaternion w x y z */
+} svoh_pose_options;
+
+/* one frame of the bundle: the SoA columns PoseOptimizer reads (frame.h:62-73) + the 3-D point of every
+ * feature as evaluateErrorImpl resolves it (landmark position or seed position, pose_optimizer.cpp:128-139) */
+typedef struct svoh_pose_camera {
+  svoh_camera cam;
+  svoh_se3 T_cam_imu;
+  int32_t n_features;
+  int32_t reserved;
+  const double* px;               /* 2 x n */
+  const double* f;                /* 3 x n */
+  const double* grad;             /* 2 x n */
+  const int32_t* level;           /* n */
+  const uint8_t* type;            /* n  svoh_feature_type (edgelets get the 1-D residual and 2x sigma) */
+  const double* xyz_world;        /* 3 x n */
+  const uint8_t* usable;          /* n: 1 = has a landmark or is a corner/edgelet seed; 0 = skipped */
+  uint8_t* outlier;               /* n out (may be NULL): 1 = removeOutliers marks it kOutlier */
+  double* final_error;            /* n out (may be NULL): unwhitened error / 2^level after the optimisation */
+} svoh_pose_camera;
+
+typedef struct svoh_pose_problem {
+  int32_t n_cams;
+  int32_t reserved;
+  svoh_pose_camera cams[SVOH_MAX_CAMS];
+  svoh_se3 T_imu_world;           /* frame_bundle->at(0)->T_imu_world() */
+} svoh_pose_problem;
+
+typedef struct svoh_pose_result {
+  svoh_se3 T_imu_world;           /* optimised; the caller sets T_f_w_ = T_cam_imu * T_imu_world per frame */
+  double measurement_sigma;       /* 1.48 * median of the start errors (MADScaleEstimator) */
+  double reproj_error_before;     /* median start error, median final error (stats_, in the error type's unit) */
+  double reproj_error_after;
+  int32_t n_meas;
+  int32_t n_deleted_edges, n_deleted_corners;
+  int32_t iters;
+  int32_t status;                 /* 0 ok, 1 no measurement, 2 solver stopped (singular system) */
+  int32_t reserved;
+} svoh_pose_result;
+
+/* Replaces PoseOptimizer::run (src/svo/src/pose_optimizer.cpp:39-113) for n_problems frame bundles at once:
+ * start errors -> MAD scale, Gauss-Newton on T_imu_world with Tukey weights (and the optional rotation prior),
+ * removeOutliers.  run()'s return value is n_meas - n_deleted_edges - n_deleted_corners.  Host pointers. */
+int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
+                             const svoh_pose_problem* problems, svoh_pose_result* results);
+
 #ifdef __cplusplus
 }
 #endif

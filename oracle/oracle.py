@@ -405,3 +405,48 @@ def detect_features(opt, levels, occupancy=None, mask=None, max_n_features=None,
                                 grad.ctypes.data, typ.ctypes.data)
     return dict(px=px[:2 * n].reshape(-1, 2).copy(), score=score[:n].copy(), level=level[:n].copy(),
                 grad=grad[:2 * n].reshape(-1, 2).copy(), type=typ[:n].copy())
+
+
+# ---- pose optimiser ----------------------------------------------
+
+def _bind_pose(lib):
+    if getattr(lib, "_pose", False):
+        return
+    P = C.POINTER
+    lib.orc_jacobian_xyz2uv_imu.argtypes = [P(capi.svoh_se3), C.c_void_p, C.c_void_p]
+    lib.orc_jacobian_xyz2uv_imu.restype = None
+    lib.orc_jacobian_xyz2img_imu.argtypes = [P(capi.svoh_se3), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_jacobian_xyz2img_imu.restype = None
+    lib.orc_jacobian_xyz2f_imu.argtypes = [P(capi.svoh_se3), C.c_void_p, C.c_void_p]
+    lib.orc_jacobian_xyz2f_imu.restype = None
+    lib.orc_optimize_pose.argtypes = [P(capi.svoh_pose_options), P(capi.svoh_pose_problem), P(capi.svoh_pose_result)]
+    lib.orc_optimize_pose.restype = None
+    lib.orc_project3.argtypes = [P(capi.svoh_camera), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_project3.restype = None
+    lib._pose = True
+
+
+def pose_jacobians(T_cam_imu, p_in_imu, cam=None, fast=False):
+    """(J_uv 2x6, J_f 3x6, J_img 2x6 or None) of frame.h:342-397 at p_in_imu."""
+    lib = load(fast); _bind_pose(lib)
+    T = to_se3(T_cam_imu)
+    p = np.ascontiguousarray(p_in_imu, np.float64)
+    Juv, Jf = np.zeros(12), np.zeros(18)
+    lib.orc_jacobian_xyz2uv_imu(C.byref(T), p.ctypes.data, Juv.ctypes.data)
+    lib.orc_jacobian_xyz2f_imu(C.byref(T), p.ctypes.data, Jf.ctypes.data)
+    Jimg = None
+    if cam is not None:
+        pc = np.ascontiguousarray(T_cam_imu.transform(p), np.float64)
+        uv, Jc, Jimg = np.zeros(2), np.zeros(6), np.zeros(12)
+        c = to_camera(cam)
+        lib.orc_project3(C.byref(c), pc.ctypes.data, uv.ctypes.data, Jc.ctypes.data)
+        lib.orc_jacobian_xyz2img_imu(C.byref(T), p.ctypes.data, Jc.ctypes.data, Jimg.ctypes.data)
+        Jimg = Jimg.reshape(2, 6)
+    return Juv.reshape(2, 6), Jf.reshape(3, 6), Jimg
+
+
+def optimize_pose(opt, problem, fast=False):
+    lib = load(fast); _bind_pose(lib)
+    res = capi.svoh_pose_result()
+    lib.orc_optimize_pose(C.byref(opt), C.byref(problem), C.byref(res))
+    return res

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 dst=gpurun_out/profiles
 mkdir -p $dst
-for wl in klt seeds detect; do
+for wl in klt seeds detect pose; do
   out=/tmp/prof_${ROUND}_$wl
   rm -rf $out
   rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $out.log 2>&1 || { tail -20 $out.log; exit 1; }

@@ -103,6 +103,58 @@ class svoh_seed_match_outputs(C.Structure):
     _fields_ = [("px_cur", C.c_void_p), ("f_cur", C.c_void_p), ("search_level", C.c_void_p), ("A_cur_ref", C.c_void_p)]
 
 
+POSE_ERR_UNIT_PLANE, POSE_ERR_BEARING_DIFF, POSE_ERR_IMAGE_PLANE = 0, 1, 2
+
+
+class svoh_pose_options(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("error_type", C.c_int32), ("eps", C.c_double),
+                ("outlier_threshold", C.c_double), ("have_rotation_prior", C.c_int32), ("reserved", C.c_int32),
+                ("prior_lambda", C.c_double), ("R_prior", C.c_double * 4)]
+
+
+class svoh_pose_camera(C.Structure):
+    _fields_ = [("cam", svoh_camera), ("T_cam_imu", svoh_se3), ("n_features", C.c_int32), ("reserved", C.c_int32),
+                ("px", C.c_void_p), ("f", C.c_void_p), ("grad", C.c_void_p), ("level", C.c_void_p), ("type", C.c_void_p),
+                ("xyz_world", C.c_void_p), ("usable", C.c_void_p), ("outlier", C.c_void_p), ("final_error", C.c_void_p)]
+
+
+class svoh_pose_problem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("reserved", C.c_int32), ("cams", svoh_pose_camera * SVOH_MAX_CAMS),
+                ("T_imu_world", svoh_se3)]
+
+
+class svoh_pose_result(C.Structure):
+    _fields_ = [("T_imu_world", svoh_se3), ("measurement_sigma", C.c_double), ("reproj_error_before", C.c_double),
+                ("reproj_error_after", C.c_double), ("n_meas", C.c_int32), ("n_deleted_edges", C.c_int32),
+                ("n_deleted_corners", C.c_int32), ("iters", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+def default_pose_options(cam=None, reproj_thresh_px=2.0, **kw):
+    """PoseOptimizer::getDefaultSolverOptions + the outlier threshold of removeOutliers for `cam`
+    (pose_optimizer.cpp:22-29, 211-218; poseoptim_thresh = 2.0, svo_factory.cpp:147)."""
+    import math
+    o = svoh_pose_options(max_iter=10, error_type=POSE_ERR_UNIT_PLANE, eps=1e-6, outlier_threshold=0.0,
+                          have_rotation_prior=0, prior_lambda=0.0)
+    o.R_prior[0] = 1.0
+    for k, v in kw.items():
+        if k == "R_prior":
+            for i in range(4):
+                o.R_prior[i] = float(v[i])
+        elif not hasattr(o, k):
+            raise AttributeError(k)
+        else:
+            setattr(o, k, v)
+    if cam is not None and "outlier_threshold" not in kw:
+        if o.error_type == POSE_ERR_UNIT_PLANE:
+            o.outlier_threshold = reproj_thresh_px / abs(cam.fx)
+        elif o.error_type == POSE_ERR_BEARING_DIFF:
+            ang = math.atan(reproj_thresh_px / (2.0 * cam.fx)) + math.atan(reproj_thresh_px / (2.0 * cam.fy))
+            o.outlier_threshold = abs(2 * math.sin(0.5 * ang))
+        else:
+            o.outlier_threshold = reproj_thresh_px
+    return o
+
+
 class svoh_detector_options(C.Structure):
     _fields_ = [("cell_size", C.c_int32), ("max_level", C.c_int32), ("min_level", C.c_int32), ("border", C.c_int32),
                 ("detect_edgelets", C.c_int32), ("reserved", C.c_int32),
@@ -197,7 +249,7 @@ EXPORTS = [
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
     "svoh_match_direct_batch",
     "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex",
-    "svoh_detect_features",
+    "svoh_detect_features", "svoh_optimize_pose_batch",
 ]
 
 
@@ -282,6 +334,8 @@ def load():
     lib.svoh_detect_features.argtypes = [C.c_void_p, svoh_frame_t, P(svoh_detector_options), C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          P(C.c_int32)]
+    lib.svoh_optimize_pose_batch.argtypes = [C.c_void_p, P(svoh_pose_options), C.c_int, P(svoh_pose_problem),
+                                             P(svoh_pose_result)]
     lib.svoh_update_seeds_batch_ex.argtypes = lib.svoh_update_seeds_batch.argtypes + [P(svoh_seed_match_outputs)]
     _LIB = lib
     return lib

@@ -1,0 +1,482 @@
+// pose.hip -- batched pose optimiser for gfx950.
+//
+// Replaces PoseOptimizer::run (src/svo/src/pose_optimizer.cpp:39-113): start errors -> MAD scale
+// (robust_cost.cpp:21-27), Gauss-Newton on T_imu_world (mini_least_squares_solver.hpp:42-107) over the
+// six residual kinds of pose_optimizer_utils (:338-627) with Tukey weights, optional rotation prior
+// (:320-334), update T <- exp(dx) T (:309-318), removeOutliers (:198-307).
+//
+// Same skeleton as the alignment kernel: one workgroup owns one frame bundle for the whole
+// optimisation, one thread per feature, fp64 like the reference, the 27 normal-equation accumulators go
+// through the wave reduce-scatter, one lane runs the 6x6 pivoted LDL^T and the update.  The problem is
+// tiny (<= a few hundred 2-D residuals): the point of running it here is batching many bundles per
+// launch (multi-stream) and keeping the per-frame chain on the device; one bundle alone is latency-bound.
+// Medians (MAD scale, statistics) are rank selections in LDS -- order-independent, so identical to
+// nth_element; sums differ from the sequential reference in rounding only.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "svoh_internal.h"
+#include "svoh_math.h"
+#include "svoh_device_utils.h"
+
+namespace svoh {
+
+constexpr int kPoseThreads = 256;
+constexpr int kPoseMaxMeas = 4096;   // measurements per bundle (LDS-resident error list)
+
+struct DevPoseCam {
+  svoh_camera cam;
+  svoh_se3 T_cam_imu;
+  int n_features;
+  int feat_off;                // offset of this camera's features in the problem's concatenated arrays
+};
+
+struct DevPoseProblem {
+  int n_cams, n_total;
+  int cam_begin;               // into cams[]
+  long long arr_off;           // offset (in features) of the problem's arrays
+  svoh_se3 T_imu_world;
+};
+
+struct PoseArgs {
+  svoh_pose_options opt;
+  const DevPoseProblem* problems;
+  const DevPoseCam* cams;
+  // concatenated over all problems and cameras
+  const double* px; const double* f; const double* grad; const int32_t* level; const uint8_t* type;
+  const double* xyz; const uint8_t* usable;
+  uint8_t* outlier; double* final_error;
+  svoh_pose_result* results;
+  int n_problems;
+};
+
+__device__ __forceinline__ float tukey_weight_f(float e)
+{
+  const float b2 = 4.6851f * 4.6851f;
+  const float x2 = e * e;
+  if (x2 <= b2) { const float t = 1.0f - x2 / b2; return t * t; }
+  return 0.0f;
+}
+
+__device__ __forceinline__ bool is_edgelet_type(int t) { return t == SVOH_FT_EDGELET || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_EDGELET_SEED_CONVERGED; }
+
+// J (rows x 6) = A (rows x 3) * R_cam_imu * [I | -skew(p_in_imu)]   (frame.h:342-397)
+template <int ROWS>
+__device__ __forceinline__ void chain_G(const double* A, const double* R, const Vec3& p, double* J)
+{
+  const double S[9] = { 0, p.z, -p.y, -p.z, 0, p.x, p.y, -p.x, 0 };
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    double AR[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) AR[c] = A[r * 3 + 0] * R[0 + c] + A[r * 3 + 1] * R[3 + c] + A[r * 3 + 2] * R[6 + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) J[r * 6 + c] = AR[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) J[r * 6 + 3 + c] = AR[0] * S[0 + c] + AR[1] * S[3 + c] + AR[2] * S[6 + c];
+  }
+}
+
+// one measurement (pose_optimizer.cpp:338-627); acc = upper triangle of H (21) + g (6), row-major packing
+__device__ void pose_residual(const svoh_pose_options& opt, const CamModel& cm, const Rigid& T_cam_imu, const double* Rci,
+                              const Rigid& T_imu_world, const double* f, const double* px, const double* grad,
+                              const Vec3& xyz_world, bool edgelet, double measurement_sigma, double& unwhitened_error,
+                              double* acc /* may be NULL */)
+{
+  const Vec3 p_imu = transform(T_imu_world, xyz_world);
+  const Vec3 p_cam = transform(T_cam_imu, p_imu);
+  const double Rw = 1.0 / measurement_sigma;
+  double e[3] = { 0, 0, 0 };
+  double J[18];
+  int rows;
+  const bool want_J = acc != nullptr;
+  if (opt.error_type == SVOH_POSE_ERR_UNIT_PLANE) {
+    const double d0 = f[0] / f[2] - p_cam.x / p_cam.z, d1 = f[1] / f[2] - p_cam.y / p_cam.z;
+    double Juv[12];
+    if (want_J) {
+      const double s = -1.0 / p_cam.z;
+      const double A[6] = { s * 1.0, 0.0, s * (-p_cam.x / p_cam.z), 0.0, s * 1.0, s * (-p_cam.y / p_cam.z) };
+      chain_G<2>(A, Rci, p_imu, Juv);
+    }
+    if (!edgelet) {
+      rows = 2; e[0] = d0; e[1] = d1;
+      if (want_J) for (int c = 0; c < 12; ++c) J[c] = Juv[c];
+    } else {
+      rows = 1; e[0] = grad[0] * d0 + grad[1] * d1;
+      if (want_J) for (int c = 0; c < 6; ++c) J[c] = grad[0] * Juv[c] + grad[1] * Juv[6 + c];
+    }
+  } else if (opt.error_type == SVOH_POSE_ERR_IMAGE_PLANE) {
+    double u, v, Jc[6], Jimg[12];
+    project3(cm, p_cam, u, v);
+    project3_jacobian(cm, p_cam, Jc);
+    const double d0 = px[0] - u, d1 = px[1] - v;
+    if (want_J) { chain_G<2>(Jc, Rci, p_imu, Jimg); for (int c = 0; c < 12; ++c) Jimg[c] = (-1.0) * Jimg[c]; }
+    if (!edgelet) {
+      rows = 2; e[0] = d0; e[1] = d1;
+      if (want_J) for (int c = 0; c < 12; ++c) J[c] = Jimg[c];
+    } else {
+      rows = 1; e[0] = grad[0] * d0 + grad[1] * d1;
+      if (want_J) for (int c = 0; c < 6; ++c) J[c] = grad[0] * Jimg[c] + grad[1] * Jimg[6 + c];
+    }
+  } else {
+    const double x2 = p_cam.x * p_cam.x, y2 = p_cam.y * p_cam.y, z2 = p_cam.z * p_cam.z;
+    const double nrm = sqrt(x2 + y2 + z2);
+    const double fd[3] = { f[0] - p_cam.x / nrm, f[1] - p_cam.y / nrm, f[2] - p_cam.z / nrm };
+    double Jb[18];
+    if (want_J) {
+      const double xy = p_cam.x * p_cam.y, yz = p_cam.y * p_cam.z, zx = p_cam.z * p_cam.x;
+      const double k = 1 / pow(x2 + y2 + z2, 1.5);
+      const double A[9] = { k * (y2 + z2), k * -xy, k * -zx, k * -xy, k * (x2 + z2), k * -yz, k * -zx, k * -yz, k * (x2 + y2) };
+      chain_G<3>(A, Rci, p_imu, Jb);
+    }
+    if (!edgelet) {
+      rows = 3; e[0] = fd[0]; e[1] = fd[1]; e[2] = fd[2];
+      if (want_J) for (int c = 0; c < 18; ++c) J[c] = (-1.0) * Jb[c];
+    } else {
+      double u, v, Jc[6];
+      project3(cm, p_cam, u, v);
+      project3_jacobian(cm, p_cam, Jc);
+      const double pd[2] = { px[0] - u, px[1] - v };
+      const double pd2 = pd[0] * pd[0] + pd[1] * pd[1];
+      const double fd2 = fd[0] * fd[0] + fd[1] * fd[1] + fd[2] * fd[2];
+      const double e_img = grad[0] * pd[0] + grad[1] * pd[1];
+      const double scale_ratio = sqrt(fd2) / sqrt(pd2);
+      rows = 1; e[0] = e_img * scale_ratio;
+      if (want_J) {
+        double Jp[12];
+        chain_G<2>(Jc, Rci, p_imu, Jp);
+        for (int c = 0; c < 6; ++c) {
+          const double J_img = (grad[0] * (-1.0)) * Jp[c] + (grad[1] * (-1.0)) * Jp[6 + c];
+          const double J_ftf = (2 * fd[0] * (-1.0)) * Jb[c] + (2 * fd[1] * (-1.0)) * Jb[6 + c] + (2 * fd[2] * (-1.0)) * Jb[12 + c];
+          const double J_ptp = (2 * pd[0] * (-1.0)) * Jp[c] + (2 * pd[1] * (-1.0)) * Jp[6 + c];
+          const double J_ratio = (0.5) * (1.0 / (scale_ratio)) * (1 / (pd2 * pd2)) * (J_ftf * pd2 - J_ptp * fd2);
+          J[c] = e_img * J_ratio + scale_ratio * J_img;
+        }
+      }
+    }
+  }
+  double en2 = 0.0;
+  for (int r = 0; r < rows; ++r) en2 += e[r] * e[r];
+  unwhitened_error = rows == 1 ? fabs(e[0]) : sqrt(en2);
+  if (!want_J) return;
+  for (int r = 0; r < rows; ++r) e[r] *= Rw;
+  const double en = rows == 1 ? e[0] : sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  const double weight = (double)tukey_weight_f((float)en);
+  for (int c = 0; c < rows * 6; ++c) J[c] *= Rw;
+  int idx = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+#pragma unroll
+    for (int b = a; b < 6; ++b) {
+      double s = 0.0;
+      for (int r = 0; r < rows; ++r) s += J[r * 6 + a] * J[r * 6 + b];
+      acc[idx++] += s * weight;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += J[r * 6 + a] * e[r];
+    acc[21 + a] -= s * weight;
+  }
+}
+
+// value of rank k (0-based, ties by index) among vals[0..n): what nth_element leaves at position k
+template <typename T>
+__device__ T rank_select(const T* vals, int n, int k, int tid, T* s_out)
+{
+  for (int i = tid; i < n; i += kPoseThreads) {
+    const T v = vals[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const T u = vals[j];
+      rank += (u < v) || (u == v && j < i);
+    }
+    if (rank == k) *s_out = v;
+  }
+  __syncthreads();
+  return *s_out;
+}
+
+__global__ __launch_bounds__(kPoseThreads) void pose_optimize_kernel(const PoseArgs a)
+{
+  constexpr int NACC = 27, NW = kPoseThreads / 64;
+  __shared__ double s_err[kPoseMaxMeas];       // start errors as float values, later final errors (double)
+  __shared__ double s_red[NW][NACC];
+  __shared__ double s_sum[NACC];
+  __shared__ Rigid s_T, s_Told;
+  __shared__ double s_sigma, s_Iprior, s_median;
+  __shared__ float s_medf;
+  __shared__ int s_n, s_done, s_stop, s_del_e, s_del_c;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pbi = blockIdx.x;
+  if (pbi >= a.n_problems) return;
+  const DevPoseProblem& pb = a.problems[pbi];
+  const DevPoseCam* cams = a.cams + pb.cam_begin;
+  const svoh_pose_options& opt = a.opt;
+  float* s_errf = reinterpret_cast<float*>(s_err);
+  if (tid == 0) {
+    s_T = load_rigid(pb.T_imu_world); s_Told = s_T;
+    s_n = 0; s_done = 0; s_stop = 0; s_del_e = 0; s_del_c = 0; s_Iprior = 0.0;
+  }
+  __syncthreads();
+
+  // helper: iterate this thread's features
+  auto for_each_feature = [&](auto&& fn) {
+    for (int c = 0; c < pb.n_cams; ++c) {
+      const DevPoseCam& dc = cams[c];
+      const CamModel cm = load_camera(dc.cam);
+      const Rigid T_cam_imu = load_rigid(dc.T_cam_imu);
+      double Rci[9];
+      to_matrix(T_cam_imu.q, Rci);
+      for (int i = tid; i < dc.n_features; i += kPoseThreads) {
+        const long long gi = pb.arr_off + dc.feat_off + i;
+        if (!a.usable[gi]) continue;
+        fn(cm, T_cam_imu, Rci, gi);
+      }
+    }
+  };
+
+  // ---- start errors and the MAD scale (pose_optimizer.cpp:48-52) ----
+  {
+    const Rigid T = s_T;
+    for_each_feature([&](const CamModel& cm, const Rigid& T_cam_imu, const double* Rci, long long gi) {
+      const int scale = 1 << a.level[gi];
+      double ue;
+      const Vec3 X = { a.xyz[3 * gi], a.xyz[3 * gi + 1], a.xyz[3 * gi + 2] };
+      pose_residual(opt, cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, is_edgelet_type(a.type[gi]),
+                    1.0, ue, nullptr);
+      const int slot = atomicAdd(&s_n, 1);
+      if (slot < kPoseMaxMeas) s_errf[slot] = (float)(ue / scale);
+    });
+  }
+  __syncthreads();
+  const int n_meas = s_n < kPoseMaxMeas ? s_n : kPoseMaxMeas;
+  svoh_pose_result& res = a.results[pbi];
+  if (n_meas == 0) {
+    if (tid == 0) {
+      memset(&res, 0, sizeof res);
+      store_rigid(s_T, res.T_imu_world);
+      res.status = 1;
+    }
+    for (int c = 0; c < pb.n_cams; ++c)
+      for (int i = tid; i < cams[c].n_features; i += kPoseThreads) {
+        a.outlier[pb.arr_off + cams[c].feat_off + i] = 0;
+        a.final_error[pb.arr_off + cams[c].feat_off + i] = 0.0;
+      }
+    return;
+  }
+  const float med = rank_select<float>(s_errf, n_meas, n_meas / 2, tid, &s_medf);
+  if (tid == 0) s_sigma = (double)(1.48f * med);
+  __syncthreads();
+  const double measurement_sigma = s_sigma;
+
+  // ---- optimizeGaussNewton ----
+  int iters = 0;
+  for (int iter = 0; iter < opt.max_iter; ++iter) {
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+    const Rigid T = s_T;
+    for_each_feature([&](const CamModel& cm, const Rigid& T_cam_imu, const double* Rci, long long gi) {
+      const int scale = 1 << a.level[gi];
+      const bool edgelet = is_edgelet_type(a.type[gi]);
+      double sigma = measurement_sigma * scale;
+      if (edgelet) sigma *= 2.0;   // kEdgeletSigmaExtraFactor
+      double ue;
+      const Vec3 X = { a.xyz[3 * gi], a.xyz[3 * gi + 1], a.xyz[3 * gi + 2] };
+      pose_residual(opt, cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, edgelet, sigma, ue, acc);
+    });
+    {
+      int ridx;
+      bool rvalid;
+      wave_reduce_scatter<NACC>(acc, lane, ridx, rvalid);
+      if (rvalid) s_red[wave][ridx] = acc[0];
+    }
+    __syncthreads();
+    if (tid < NACC) {
+      double v = 0.0;
+      for (int w = 0; w < NW; ++w) v += s_red[w][tid];
+      s_sum[tid] = v;
+    }
+    __syncthreads();
+    ++iters;
+    if (tid == 0) {
+      double m[21], xg[6];
+      {
+        int idx = 0;
+        for (int r = 0; r < 6; ++r)
+          for (int c = r; c < 6; ++c) SVOH_L(c, r) = s_sum[idx++];
+        for (int r = 0; r < 6; ++r) xg[r] = s_sum[21 + r];
+      }
+      if (opt.have_rotation_prior) {   // applyPrior (pose_optimizer.cpp:320-334)
+        if (iter == 0) {
+          double hmax = 0;
+          for (int j = 3; j < 6; ++j) hmax = fmax(hmax, fabs(SVOH_L(j, j)));
+          s_Iprior = hmax * opt.prior_lambda;
+        }
+        for (int j = 3; j < 6; ++j) SVOH_L(j, j) += s_Iprior;
+        Rigid prior;
+        prior.q = { opt.R_prior[0], opt.R_prior[1], opt.R_prior[2], opt.R_prior[3] };
+        prior.t = { 0.0, 0.0, 0.0 };
+        double lg[6];
+        rigid_log(mul(s_T, inverse(prior)), lg);
+        for (int j = 3; j < 6; ++j) xg[j] -= s_Iprior * lg[j];
+      }
+      if (!ldlt_solve_regs<6>(m, xg)) s_stop = 1;
+      if (s_stop) {
+        s_T = s_Told;
+        s_done = 1;
+      } else {
+        Rigid Tn = mul(rigid_exp(xg), s_T);   // T_new = exp(dx) * T_old (pose_optimizer.cpp:309-318)
+        Tn.q = normalized(Tn.q);
+        s_Told = s_T;
+        s_T = Tn;
+        double x_norm = -1.0;
+        for (int j = 0; j < 6; ++j) { const double v = fabs(xg[j]); if (v > x_norm) x_norm = v; }
+        if (x_norm < opt.eps) s_done = 1;
+      }
+    }
+    __syncthreads();
+    if (s_done) break;
+  }
+
+  // ---- removeOutliers (pose_optimizer.cpp:198-307) + statistics ----
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  {
+    const Rigid T = s_T;
+    for (int c = 0; c < pb.n_cams; ++c)
+      for (int i = tid; i < cams[c].n_features; i += kPoseThreads) {
+        const long long gi = pb.arr_off + cams[c].feat_off + i;
+        if (!a.usable[gi]) { a.outlier[gi] = 0; a.final_error[gi] = 0.0; }
+      }
+    for_each_feature([&](const CamModel& cm, const Rigid& T_cam_imu, const double* Rci, long long gi) {
+      const bool edgelet = is_edgelet_type(a.type[gi]);
+      double ue;
+      const Vec3 X = { a.xyz[3 * gi], a.xyz[3 * gi + 1], a.xyz[3 * gi + 2] };
+      pose_residual(opt, cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, edgelet, 1.0, ue, nullptr);
+      ue *= 1.0 / (1 << a.level[gi]);
+      a.final_error[gi] = ue;
+      const bool out = fabs(ue) > opt.outlier_threshold;
+      a.outlier[gi] = out ? 1 : 0;
+      if (out) atomicAdd(edgelet ? &s_del_e : &s_del_c, 1);
+      const int slot = atomicAdd(&s_n, 1);
+      if (slot < kPoseMaxMeas) s_err[slot] = ue;
+    });
+  }
+  __syncthreads();
+  const int n_final = s_n < kPoseMaxMeas ? s_n : kPoseMaxMeas;
+  const double med_after = rank_select<double>(s_err, n_final, n_final / 2, tid, &s_median);
+  if (tid == 0) {
+    store_rigid(s_T, res.T_imu_world);
+    res.measurement_sigma = measurement_sigma;
+    res.reproj_error_before = (double)med;
+    res.reproj_error_after = med_after;
+    res.n_meas = n_meas;
+    res.n_deleted_edges = s_del_e;
+    res.n_deleted_corners = s_del_c;
+    res.iters = iters;
+    res.status = s_stop ? 2 : 0;
+    res.reserved = 0;
+  }
+}
+
+}  // namespace svoh
+
+using namespace svoh;
+
+extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
+                                        const svoh_pose_problem* problems, svoh_pose_result* results)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, options && n_problems >= 0, "bad arguments");
+  if (n_problems == 0) return SVOH_OK;
+  SVOH_REQUIRE(ctx, problems && results, "NULL argument");
+  SVOH_REQUIRE(ctx, options->max_iter >= 1 && options->error_type >= 0 && options->error_type <= 2, "bad max_iter / error_type");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  size_t n_cams_total = 0, n_feat_total = 0;
+  for (int p = 0; p < n_problems; ++p) {
+    const svoh_pose_problem& pb = problems[p];
+    SVOH_REQUIRE(ctx, pb.n_cams >= 1 && pb.n_cams <= SVOH_MAX_CAMS, "n_cams out of range");
+    size_t n = 0;
+    for (int c = 0; c < pb.n_cams; ++c) {
+      const svoh_pose_camera& cam = pb.cams[c];
+      SVOH_REQUIRE(ctx, cam.n_features >= 0, "negative n_features");
+      SVOH_REQUIRE(ctx, cam.n_features == 0 || (cam.px && cam.f && cam.grad && cam.level && cam.type && cam.xyz_world && cam.usable),
+                   "NULL feature array");
+      SVOH_REQUIRE(ctx, cam.cam.distortion == SVOH_DISTORTION_NONE || cam.cam.distortion == SVOH_DISTORTION_RADTAN,
+                   "unsupported distortion model");
+      for (int i = 0; i < cam.n_features; ++i) SVOH_REQUIRE(ctx, cam.level[i] >= 0 && cam.level[i] < 30, "feature level out of range");
+      n += (size_t)cam.n_features;
+    }
+    SVOH_REQUIRE(ctx, n <= (size_t)kPoseMaxMeas, "more than 4096 features in one bundle");
+    n_cams_total += (size_t)pb.n_cams;
+    n_feat_total += n;
+  }
+  const size_t nf = n_feat_total ? n_feat_total : 1;
+  // one staging block: [problems | cams | px | f | grad | xyz | level | type | usable]  -> device; outputs appended
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  const size_t o_pb = 0, o_cam = al(sizeof(DevPoseProblem) * (size_t)n_problems), o_px = o_cam + al(sizeof(DevPoseCam) * n_cams_total);
+  const size_t o_f = o_px + al(16 * nf), o_grad = o_f + al(24 * nf), o_xyz = o_grad + al(16 * nf), o_level = o_xyz + al(24 * nf);
+  const size_t o_type = o_level + al(4 * nf), o_usable = o_type + al(nf), in_total = o_usable + al(nf);
+  const size_t o_outlier = in_total, o_ferr = o_outlier + al(nf), o_res = o_ferr + al(8 * nf);
+  const size_t total = o_res + al(sizeof(svoh_pose_result) * (size_t)n_problems);
+  SVOH_HIP_TRY(ctx, ctx->h_scratch0.reserve(total));
+  SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(total));
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch0.ptr);
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch0.ptr);
+  DevPoseProblem* hp = reinterpret_cast<DevPoseProblem*>(h + o_pb);
+  DevPoseCam* hc = reinterpret_cast<DevPoseCam*>(h + o_cam);
+  size_t cam_i = 0, off = 0;
+  for (int p = 0; p < n_problems; ++p) {
+    const svoh_pose_problem& pb = problems[p];
+    hp[p].n_cams = pb.n_cams; hp[p].cam_begin = (int)cam_i; hp[p].arr_off = (long long)off; hp[p].T_imu_world = pb.T_imu_world;
+    int local = 0;
+    for (int c = 0; c < pb.n_cams; ++c) {
+      const svoh_pose_camera& cam = pb.cams[c];
+      hc[cam_i].cam = cam.cam; hc[cam_i].T_cam_imu = cam.T_cam_imu; hc[cam_i].n_features = cam.n_features; hc[cam_i].feat_off = local;
+      const size_t n = (size_t)cam.n_features, g = off + (size_t)local;
+      if (n) {
+        memcpy(h + o_px + 16 * g, cam.px, 16 * n); memcpy(h + o_f + 24 * g, cam.f, 24 * n);
+        memcpy(h + o_grad + 16 * g, cam.grad, 16 * n); memcpy(h + o_xyz + 24 * g, cam.xyz_world, 24 * n);
+        memcpy(h + o_level + 4 * g, cam.level, 4 * n); memcpy(h + o_type + g, cam.type, n); memcpy(h + o_usable + g, cam.usable, n);
+      }
+      local += cam.n_features;
+      ++cam_i;
+    }
+    hp[p].n_total = local;
+    off += (size_t)local;
+  }
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
+  PoseArgs a;
+  a.opt = *options;
+  a.problems = reinterpret_cast<const DevPoseProblem*>(d + o_pb);
+  a.cams = reinterpret_cast<const DevPoseCam*>(d + o_cam);
+  a.px = reinterpret_cast<const double*>(d + o_px); a.f = reinterpret_cast<const double*>(d + o_f);
+  a.grad = reinterpret_cast<const double*>(d + o_grad); a.xyz = reinterpret_cast<const double*>(d + o_xyz);
+  a.level = reinterpret_cast<const int32_t*>(d + o_level); a.type = d + o_type; a.usable = d + o_usable;
+  a.outlier = d + o_outlier; a.final_error = reinterpret_cast<double*>(d + o_ferr);
+  a.results = reinterpret_cast<svoh_pose_result*>(d + o_res);
+  a.n_problems = n_problems;
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  hipLaunchKernelGGL(pose_optimize_kernel, dim3((unsigned)n_problems), dim3(kPoseThreads), 0, ctx->stream, a);
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = true;
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_outlier, d + o_outlier, total - o_outlier, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(results, h + o_res, sizeof(svoh_pose_result) * (size_t)n_problems);
+  off = 0;
+  for (int p = 0; p < n_problems; ++p)
+    for (int c = 0; c < problems[p].n_cams; ++c) {
+      const svoh_pose_camera& cam = problems[p].cams[c];
+      const size_t n = (size_t)cam.n_features;
+      if (cam.outlier && n) memcpy(cam.outlier, h + o_outlier + off, n);
+      if (cam.final_error && n) memcpy(cam.final_error, h + o_ferr + 8 * off, 8 * n);
+      off += n;
+    }
+  return SVOH_OK;
+}

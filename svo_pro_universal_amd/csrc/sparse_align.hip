@@ -30,6 +30,7 @@
 #include <cstring>
 
 #include "svoh_internal.h"
+#include "svoh_device_utils.h"
 #include "svoh_math.h"
 
 namespace svoh {
@@ -327,58 +328,6 @@ __device__ __forceinline__ void accumulate_patch(const double (&mom)[AccLayout<D
   acc[NH + D] += mom[5];
 }
 
-// ---- wave-level reduce-scatter of the normal-equation accumulators ----
-// A butterfly in which every stage halves the number of live values: the lane pair
-// (l, l ^ off) splits the index range, each side keeps one half and adds the partner's
-// copy of it.  NACC -> ceil/2 -> ... -> 1 takes 31 exchanges for the 29 accumulators of
-// the SE3 case (47 for 45) instead of 6 x NACC with an all-reduce per value, and the
-// two widest stages (off 1 and 2) run on the DPP network instead of ds_bpermute.
-// Afterwards lane l holds the wave total of accumulator `idx` (if `valid`).
-template <int OFF>
-__device__ __forceinline__ double xor_exchange(double v)
-{
-  if constexpr (OFF == 1 || OFF == 2) {
-    constexpr int ctrl = OFF == 1 ? 0xB1 : 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
-    const unsigned long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, ctrl, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), ctrl, 0xF, 0xF, false);
-    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-  } else {
-    return __shfl_xor(v, OFF, 64);
-  }
-}
-
-template <int N, int OFF>
-__device__ __forceinline__ void reduce_scatter_stage(double* v, int lane, int& base, int& cnt)
-{
-  constexpr int HALF = (N + 1) / 2;
-  const bool up = (lane & OFF) != 0;
-#pragma unroll
-  for (int i = 0; i < HALF; ++i) {
-    const double a = v[i];
-    const double b = (i + HALF < N) ? v[i + HALF] : 0.0;
-    const double recv = xor_exchange<OFF>(up ? a : b);
-    v[i] = (up ? b : a) + recv;
-  }
-  if (up) { base += HALF; cnt -= HALF; }
-  else cnt = cnt < HALF ? cnt : HALF;
-}
-
-template <int NACC>
-__device__ __forceinline__ void wave_reduce_scatter(double (&v)[NACC], int lane, int& idx, bool& valid)
-{
-  constexpr int N1 = (NACC + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
-  int base = 0, cnt = NACC;
-  reduce_scatter_stage<NACC, 1>(v, lane, base, cnt);
-  reduce_scatter_stage<N1, 2>(v, lane, base, cnt);
-  reduce_scatter_stage<N2, 4>(v, lane, base, cnt);
-  reduce_scatter_stage<N3, 8>(v, lane, base, cnt);
-  reduce_scatter_stage<N4, 16>(v, lane, base, cnt);
-  reduce_scatter_stage<N5, 32>(v, lane, base, cnt);
-  idx = base;
-  valid = cnt >= 1;
-}
-
 template <int NT>
 __device__ __forceinline__ void stage_image(unsigned char* dst, const DevImage& im, int tid)
 {
@@ -467,107 +416,6 @@ __device__ __forceinline__ void accumulate_camera(
     }
     accumulate_patch<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
   }
-}
-
-// 8x8 LDL^T with diagonal pivoting, Eigen-3.4 semantics (see svoh_math.h), with
-// the matrix held in registers: every index is a compile-time constant after
-// unrolling, the run-time pivot position only steers predicated swaps.  Used by
-// the one lane that runs the Gauss-Newton bookkeeping, where the LDS-resident
-// variant paid an LDS round trip per matrix access.
-__device__ __forceinline__ void swap_d(double& a, double& b) { const double t = a; a = b; b = t; }
-
-// packed lower triangle: element (r, c), r >= c, at r*(r+1)/2 + c
-#define SVOH_L(r, c) m[(r) * ((r) + 1) / 2 + (c)]
-template <int N>
-__device__ __forceinline__ bool ldlt_solve_regs(double (&m)[N * (N + 1) / 2], double (&x)[N])
-{
-  int tr[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    int big = k;
-    double bigv = fabs(SVOH_L(k, k));
-#pragma unroll
-    for (int i = k + 1; i < N; ++i) {
-      const double v = fabs(SVOH_L(i, i));
-      const bool gt = v > bigv;
-      bigv = gt ? v : bigv;
-      big = gt ? i : big;
-    }
-    tr[k] = big;
-#pragma unroll
-    for (int bb = k + 1; bb < N; ++bb) {
-      if (big == bb) {
-#pragma unroll
-        for (int c = 0; c < k; ++c) swap_d(SVOH_L(k, c), SVOH_L(bb, c));
-#pragma unroll
-        for (int r = bb + 1; r < N; ++r) swap_d(SVOH_L(r, k), SVOH_L(r, bb));
-        swap_d(SVOH_L(k, k), SVOH_L(bb, bb));
-#pragma unroll
-        for (int i = k + 1; i < bb; ++i) swap_d(SVOH_L(i, k), SVOH_L(bb, i));
-      }
-    }
-    if (k > 0) {
-      double tmp[N];
-#pragma unroll
-      for (int c = 0; c < k; ++c) tmp[c] = SVOH_L(c, c) * SVOH_L(k, c);
-      double accd = 0.0;
-#pragma unroll
-      for (int c = 0; c < k; ++c) accd += SVOH_L(k, c) * tmp[c];
-      SVOH_L(k, k) -= accd;
-#pragma unroll
-      for (int r = k + 1; r < N; ++r) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int c = 0; c < k; ++c) sacc += SVOH_L(r, c) * tmp[c];
-        SVOH_L(r, k) -= sacc;
-      }
-    }
-    const double akk = SVOH_L(k, k);
-    const bool pivot_ok = fabs(akk) > 0.0;
-    if (k == 0 && !pivot_ok) {
-      // the whole diagonal is zero: Eigen stops with identity transpositions and
-      // the D^-1 step zeroes every component of the solution
-#pragma unroll
-      for (int j = 0; j < N; ++j) x[j] = 0.0;
-      return true;
-    }
-    if (pivot_ok) {
-#pragma unroll
-      for (int r = k + 1; r < N; ++r) SVOH_L(r, k) /= akk;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-#pragma unroll
-    for (int bb = k + 1; bb < N; ++bb)
-      if (tr[k] == bb) swap_d(x[k], x[bb]);
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    double sacc = x[i];
-#pragma unroll
-    for (int c = 0; c < i; ++c) sacc -= SVOH_L(i, c) * x[c];
-    x[i] = sacc;
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const double d = SVOH_L(i, i);
-    x[i] = (fabs(d) > DBL_MIN) ? x[i] / d : 0.0;
-  }
-#pragma unroll
-  for (int i = N - 1; i >= 0; --i) {
-    double sacc = x[i];
-#pragma unroll
-    for (int c = i + 1; c < N; ++c) sacc -= SVOH_L(c, i) * x[c];
-    x[i] = sacc;
-  }
-#pragma unroll
-  for (int k = N - 1; k >= 0; --k) {
-#pragma unroll
-    for (int bb = k + 1; bb < N; ++bb)
-      if (tr[k] == bb) swap_d(x[k], x[bb]);
-  }
-  return !(x[0] != x[0]);
 }
 
 // One Gauss-Newton bookkeeping step, run by a single lane: prior, pivoted LDL^T, SE3

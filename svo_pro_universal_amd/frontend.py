@@ -313,6 +313,39 @@ def _match_direct_device(self, mopt, ref_views, cur_views, fb, depth, px_cur, re
                                                  result, f_cur, search_level, h_inv, A_cur_ref))
 
 
+def make_pose_problem(cams, T_imu_world):
+    """cams: list of dict(cam=synth.Camera, T_cam_imu=SE3, px, f, grad, level, type, xyz_world, usable); returns
+    (svoh_pose_problem, keepalive) with per-feature outputs `outlier` / `final_error` in keepalive[i]."""
+    pb = capi.svoh_pose_problem()
+    pb.n_cams = len(cams)
+    pb.T_imu_world = _se3(T_imu_world)
+    keep = []
+    for c, d in enumerate(cams):
+        n = int(np.asarray(d["level"]).size)
+        a = dict(px=np.ascontiguousarray(d["px"], np.float64), f=np.ascontiguousarray(d["f"], np.float64),
+                 grad=np.ascontiguousarray(d["grad"], np.float64), level=np.ascontiguousarray(d["level"], np.int32),
+                 type=np.ascontiguousarray(d["type"], np.uint8), xyz_world=np.ascontiguousarray(d["xyz_world"], np.float64),
+                 usable=np.ascontiguousarray(d["usable"], np.uint8), outlier=np.zeros(max(n, 1), np.uint8),
+                 final_error=np.zeros(max(n, 1), np.float64))
+        pc = pb.cams[c]
+        pc.cam = _camera(d["cam"])
+        pc.T_cam_imu = _se3(d["T_cam_imu"])
+        pc.n_features = n
+        for k, v in a.items():
+            setattr(pc, k, v.ctypes.data)
+        keep.append(a)
+    return pb, keep
+
+
+def _optimize_pose(self, opt, problems):
+    """svoh_optimize_pose_batch over a list of svoh_pose_problem; returns the list of svoh_pose_result."""
+    n = len(problems)
+    arr = (capi.svoh_pose_problem * n)(*problems)
+    res = (capi.svoh_pose_result * n)()
+    self._check(self.lib.svoh_optimize_pose_batch(self.h, C.byref(opt), n, arr, res))
+    return list(res)
+
+
 def _detect_features(self, opt, frame, width, height, occupancy=None, mask=None, max_n_features=None):
     """svoh_detect_features: dict(px [n,2], score, level, grad [n,2], type) like FastGradDetector::detect."""
     n_cells = int(np.ceil(width / opt.cell_size)) * int(np.ceil(height / opt.cell_size))
@@ -334,6 +367,7 @@ def _detect_features(self, opt, frame, width, height, occupancy=None, mask=None,
 
 
 Context.detect_features = _detect_features
+Context.optimize_pose = _optimize_pose
 Context.klt_track_batch = _klt_track_batch
 Context.klt_track_indexed = _klt_track_indexed
 Context.update_seeds_device = _update_seeds_device

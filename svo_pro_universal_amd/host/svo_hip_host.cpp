@@ -390,6 +390,97 @@ void DetectorHip::detect(const FramePtr& frame)
   }
 }
 
+// ---- pose optimiser -------------------------------------------------------------------
+PoseOptimizerHip::PoseOptimizerHip(svoh_ctx* ctx, SolverOptions solver_options) : ctx_(ctx), solver_options_(solver_options)
+{
+  if (!ctx_) throw std::runtime_error("PoseOptimizerHip: NULL svoh_ctx (no CPU fallback exists)");
+}
+
+void PoseOptimizerHip::setRotationPrior(const svoh::Quat& R_frame_world, double lambda)
+{
+  R_prior_ = R_frame_world;
+  prior_lambda_ = lambda;
+  have_prior_ = true;
+}
+
+size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px)
+{
+  if (!frame_bundle || frame_bundle->empty()) throw std::runtime_error("PoseOptimizer: FrameBundle is empty");   // CHECK
+  const size_t nc = frame_bundle->size();
+  if (nc > SVOH_MAX_CAMS) throw std::runtime_error("PoseOptimizerHip: too many cameras in the bundle");
+  const Frame& f0 = *frame_bundle->at(0);
+  // removeOutliers' thresholds are function-local statics: the first bundle ever optimised fixes them
+  // (pose_optimizer.cpp:211-212)
+  static const double threshold_uplane = reproj_thresh_px / std::fabs(f0.cam.fx);
+  static const double threshold_bearing_diff =
+      std::fabs(2 * std::sin(0.5 * (std::atan(reproj_thresh_px / (2.0 * f0.cam.fx)) + std::atan(reproj_thresh_px / (2.0 * f0.cam.fy)))));
+  svoh_pose_options o{};
+  o.max_iter = static_cast<int32_t>(solver_options_.max_iter);
+  o.eps = solver_options_.eps;
+  o.error_type = err_type_ == ErrorType::kUnitPlane ? SVOH_POSE_ERR_UNIT_PLANE
+                 : err_type_ == ErrorType::kBearingVectorDiff ? SVOH_POSE_ERR_BEARING_DIFF : SVOH_POSE_ERR_IMAGE_PLANE;
+  o.outlier_threshold = err_type_ == ErrorType::kUnitPlane ? threshold_uplane
+                        : err_type_ == ErrorType::kBearingVectorDiff ? threshold_bearing_diff : reproj_thresh_px;
+  o.have_rotation_prior = have_prior_;
+  o.prior_lambda = prior_lambda_;
+  o.R_prior[0] = R_prior_.w; o.R_prior[1] = R_prior_.x; o.R_prior[2] = R_prior_.y; o.R_prior[3] = R_prior_.z;
+
+  svoh_pose_problem pb{};
+  pb.n_cams = static_cast<int32_t>(nc);
+  svoh::store_rigid(f0.T_imu_world(), pb.T_imu_world);
+  std::vector<std::vector<double>> xyz(nc);
+  std::vector<std::vector<uint8_t>> usable(nc), outlier(nc);
+  size_t n_features = 0;
+  for (size_t c = 0; c < nc; ++c) {
+    Frame& fr = *frame_bundle->at(c);
+    const size_t n = fr.num_features_;
+    n_features += n;
+    xyz[c].assign(3 * n, 0.0); usable[c].assign(n, 0); outlier[c].assign(n, 0);
+    fr.landmark_vec_.resize(n); fr.seed_ref_vec_.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      // evaluateErrorImpl (pose_optimizer.cpp:128-139): landmark position, or the seed's position in the world
+      svoh::Vec3 p{ 0, 0, 0 };
+      const uint8_t t = fr.type_vec_[i];
+      if (fr.landmark_vec_[i]) p = fr.landmark_vec_[i]->pos_;
+      else if ((t == SVOH_FT_CORNER_SEED || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_CORNER_SEED_CONVERGED ||
+                t == SVOH_FT_EDGELET_SEED_CONVERGED) && fr.seed_ref_vec_[i].keyframe) {
+        const Frame& kf = *fr.seed_ref_vec_[i].keyframe;
+        const size_t k = static_cast<size_t>(fr.seed_ref_vec_[i].seed_id);
+        const double depth = kf.getSeedDepth(k);
+        const svoh::Vec3 in_kf{ kf.f_vec_[3 * k] * depth, kf.f_vec_[3 * k + 1] * depth, kf.f_vec_[3 * k + 2] * depth };
+        p = svoh::transform(svoh::inverse(kf.T_f_w_), in_kf);   // T_world_cam() * getSeedPosInFrame
+      } else continue;
+      usable[c][i] = 1;
+      xyz[c][3 * i] = p.x; xyz[c][3 * i + 1] = p.y; xyz[c][3 * i + 2] = p.z;
+    }
+    svoh_pose_camera& pc = pb.cams[c];
+    pc.cam = fr.cam;
+    svoh::store_rigid(fr.T_cam_imu(), pc.T_cam_imu);
+    pc.n_features = static_cast<int32_t>(n);
+    pc.px = fr.px_vec_.data(); pc.f = fr.f_vec_.data(); pc.grad = fr.grad_vec_.data(); pc.level = fr.level_vec_.data();
+    pc.type = fr.type_vec_.data(); pc.xyz_world = xyz[c].data(); pc.usable = usable[c].data(); pc.outlier = outlier[c].data();
+  }
+  if (n_features == 0) throw std::runtime_error("PoseOptimizer: No features in frames");   // CHECK_GT
+  const int rc = svoh_optimize_pose_batch(ctx_, &o, 1, &pb, &last_);
+  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_optimize_pose_batch: ") + svoh_last_error_string(ctx_));
+  measurement_sigma_ = last_.measurement_sigma;
+  const Transformation T_imu_world = svoh::load_rigid(last_.T_imu_world);
+  for (size_t c = 0; c < nc; ++c) {
+    Frame& fr = *frame_bundle->at(c);
+    fr.T_f_w_ = svoh::mul(fr.T_cam_imu(), T_imu_world);
+    for (size_t i = 0; i < fr.num_features_; ++i)
+      if (outlier[c][i]) {
+        fr.type_vec_[i] = SVOH_FT_OUTLIER;
+        fr.seed_ref_vec_[i].keyframe.reset();
+        fr.landmark_vec_[i] = nullptr;
+      }
+  }
+  const double error_scale = err_type_ == ErrorType::kUnitPlane ? std::fabs(f0.cam.fx) : 1.0;   // focal_length_
+  stats_.reproj_error_before = last_.reproj_error_before * error_scale;
+  stats_.reproj_error_after = last_.reproj_error_after * error_scale;
+  return static_cast<size_t>(last_.n_meas - last_.n_deleted_edges - last_.n_deleted_corners);
+}
+
 double updateSeedPxErrorAngle(const Frame& cur_frame)
 {
   // static double px_error_angle = cur_frame.getAngleError(1.0);  (depth_filter.cpp:383-384,

@@ -351,6 +351,36 @@ class DetectorHip {
   DetectorOptions options_;
 };
 
+// ---------------------------------------------------------------------------
+// Pose optimiser.  Mirrors svo::PoseOptimizer (src/svo/include/svo/pose_optimizer.h:20-80,
+// src/svo/src/pose_optimizer.cpp:17-113, 198-307) as FrameHandlerBase::optimizePose drives it
+// (frame_handler_base.cpp:746-790): setRotationPrior, run(frame_bundle, reproj_thresh_px).
+// ---------------------------------------------------------------------------
+class PoseOptimizerHip {
+ public:
+  enum class ErrorType { kUnitPlane, kBearingVectorDiff, kImagePlane };
+  struct Statistics { double reproj_error_after = 0.0, reproj_error_before = 0.0; } stats_;
+  explicit PoseOptimizerHip(svoh_ctx* ctx, SolverOptions solver_options = getDefaultSolverOptions());
+  static SolverOptions getDefaultSolverOptions() { SolverOptions o; o.max_iter = 10; o.eps = 0.000001; return o; }
+  void setErrorType(ErrorType type) { err_type_ = type; }
+  void setRotationPrior(const svoh::Quat& R_frame_world, double lambda);
+  void reset() { have_prior_ = false; }   // MiniLeastSquaresSolver::reset drops the prior
+  // optimises frame_bundle->at(0)->T_imu_world(), writes T_f_w_ of every frame, marks outliers
+  // (type_vec_[i] = kOutlier, landmark / seed reference dropped) and returns the number of remaining measurements
+  size_t run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px);
+  size_t iterCount() const { return static_cast<size_t>(last_.iters); }
+  const svoh_pose_result& lastResult() const { return last_; }
+  double measurement_sigma_ = 1.0;
+ private:
+  svoh_ctx* ctx_;
+  SolverOptions solver_options_;
+  ErrorType err_type_ = ErrorType::kUnitPlane;
+  bool have_prior_ = false;
+  double prior_lambda_ = 0.0;
+  svoh::Quat R_prior_{ 1, 0, 0, 0 };
+  svoh_pose_result last_{};
+};
+
 // The function-local `static double px_error_angle` of depth_filter_utils::updateSeed
 // (depth_filter.cpp:383-384): the first camera ever passed sets it for the whole process,
 // for the depth filter and the reprojector alike.

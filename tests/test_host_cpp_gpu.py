@@ -159,3 +159,30 @@ def test_cpp_feature_tracker_mirror_matches_oracle(tmp_path, oracle_lib, first_o
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASS" in out.stdout
+
+
+@pytest.mark.parametrize("error_type", [0, 1, 2])
+def test_cpp_pose_optimizer_mirror_matches_oracle(tmp_path, oracle_lib, error_type):
+    """PoseOptimizer::run as FrameHandlerBase::optimizePose calls it: points from landmarks and seed references,
+    pose written back into the frame, outliers marked."""
+    import pose_helpers as ph
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host"), "libsvo_hip_host.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    sc = ph.make_pose_scene(70 + error_type, n=220)
+    c = sc["cams"][0]
+    cam = sc["cam"]
+    T_kf_w = synth.SE3(synth.quat_from_axis_angle([0.3, -0.2, 0.9], 0.4), [0.5, -0.3, 0.2])
+    path = str(tmp_path / "pose.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("4i", cam.width, cam.height, len(c["level"]), error_type))
+        np.array([cam.fx, cam.fy, cam.cx, cam.cy] + list(cam.dist) + [1.0]).tofile(f)
+        c["T_cam_imu"].as7().tofile(f); sc["T_imu_world_init"].as7().tofile(f); T_kf_w.as7().tofile(f)
+        for k in ("px", "f", "grad", "xyz_world"):
+            np.ascontiguousarray(c[k], np.float64).tofile(f)
+        np.ascontiguousarray(c["level"], np.int32).tofile(f)
+        np.ascontiguousarray(c["type"], np.uint8).tofile(f)
+        np.ascontiguousarray(c["usable"], np.uint8).tofile(f)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_host_pose"), path], capture_output=True, text=True)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASS" in out.stdout

@@ -1,0 +1,86 @@
+"""GPU parity for the pose optimiser: svoh_optimize_pose_batch through the C ABI vs the
+CPU oracle.  Bars: measurement sigma (a float median) exact, iteration counts / outlier flags / counters exact,
+pose <= 1e-9 (fp64 sums in a different order), per-feature final errors rel 1e-9."""
+import numpy as np
+import pytest
+
+from svo_pro_universal_amd import _capi as capi, frontend as fe, synth
+
+import pose_helpers as ph
+
+pytestmark = pytest.mark.gpu
+
+
+def check(rg, ro, keep_g, keep_o, cams):
+    assert rg.status == ro.status and rg.iters == ro.iters and rg.n_meas == ro.n_meas
+    assert rg.measurement_sigma == ro.measurement_sigma and rg.reproj_error_before == ro.reproj_error_before
+    assert np.abs(fe.se3_to_numpy(rg.T_imu_world) - fe.se3_to_numpy(ro.T_imu_world)).max() < 1e-9
+    assert rg.n_deleted_edges == ro.n_deleted_edges and rg.n_deleted_corners == ro.n_deleted_corners
+    assert rg.reproj_error_after == pytest.approx(ro.reproj_error_after, rel=1e-9)
+    for kg, ko, c in zip(keep_g, keep_o, cams):
+        n = len(c["level"])
+        assert np.array_equal(kg["outlier"][:n], ko["outlier"][:n])
+        assert np.allclose(kg["final_error"][:n], ko["final_error"][:n], rtol=1e-9, atol=1e-15)
+
+
+@pytest.mark.parametrize("error_type", [capi.POSE_ERR_UNIT_PLANE, capi.POSE_ERR_BEARING_DIFF, capi.POSE_ERR_IMAGE_PLANE])
+@pytest.mark.parametrize("n_cams", [1, 2])
+def test_pose_parity(gpu_ctx, oracle_lib, error_type, n_cams):
+    for seed, cam in ((31, synth.Camera.euroc_like(752, 480)), (32, synth.Camera.test_camera())):
+        sc = ph.make_pose_scene(seed + n_cams, n=300, cam=cam, n_cams=n_cams)
+        opt = capi.default_pose_options(sc["cam"], error_type=error_type)
+        pbg, kg = fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"])
+        pbo, ko = fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"])
+        rg = gpu_ctx.optimize_pose(opt, [pbg])[0]
+        ro = oracle_lib.optimize_pose(opt, pbo)
+        check(rg, ro, kg, ko, sc["cams"])
+        e1 = synth.se3_error(synth.SE3.from7(fe.se3_to_numpy(rg.T_imu_world)), sc["T_imu_world_gt"])
+        e0 = synth.se3_error(sc["T_imu_world_init"], sc["T_imu_world_gt"])
+        assert e1[0] < 0.1 * e0[0] and e1[1] < 0.1 * e0[1]
+
+
+def test_pose_prior_iteration_cap_and_degenerate(gpu_ctx, oracle_lib):
+    sc = ph.make_pose_scene(41, n=120)
+    q_init = sc["T_imu_world_init"].as7()[:4]
+    for kw in (dict(have_rotation_prior=1, prior_lambda=50.0, R_prior=q_init), dict(max_iter=2), dict(eps=1e-3),
+               dict(outlier_threshold=1e-9), dict(outlier_threshold=1e9)):
+        opt = capi.default_pose_options(sc["cam"], **kw)
+        pbg, kg = fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"])
+        pbo, ko = fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"])
+        check(gpu_ctx.optimize_pose(opt, [pbg])[0], oracle_lib.optimize_pose(opt, pbo), kg, ko, sc["cams"])
+    # nothing usable / no feature at all / a single measurement (rank-deficient system: the solver stops)
+    opt = capi.default_pose_options(sc["cam"])
+    for mode in ("none_usable", "empty", "single"):
+        cams = [dict(c) for c in sc["cams"]]
+        for c in cams:
+            c["usable"] = c["usable"].copy()
+            if mode == "none_usable":
+                c["usable"][:] = 0
+            elif mode == "single":
+                c["usable"][:] = 0; c["usable"][5] = 1
+            else:
+                for k in ("px", "f", "grad", "xyz_world"):
+                    c[k] = c[k][:0]
+                c["level"] = c["level"][:0]; c["type"] = c["type"][:0]; c["usable"] = c["usable"][:0]
+        pbg, kg = fe.make_pose_problem(cams, sc["T_imu_world_init"])
+        pbo, ko = fe.make_pose_problem(cams, sc["T_imu_world_init"])
+        rg, ro = gpu_ctx.optimize_pose(opt, [pbg])[0], oracle_lib.optimize_pose(opt, pbo)
+        assert rg.status == ro.status and rg.n_meas == ro.n_meas
+        if mode != "single":
+            assert rg.status == 1 and np.array_equal(fe.se3_to_numpy(rg.T_imu_world), sc["T_imu_world_init"].as7())
+
+
+def test_pose_batch_equals_singles(gpu_ctx):
+    scenes = [ph.make_pose_scene(50 + i, n=40 + 37 * i, n_cams=1 + (i % 2)) for i in range(9)]
+    opt = capi.default_pose_options(scenes[0]["cam"])
+    built = [fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"]) for sc in scenes]
+    batch = gpu_ctx.optimize_pose(opt, [b[0] for b in built])
+    flags = [[k["outlier"].copy() for k in b[1]] for b in built]
+    for i, sc in enumerate(scenes):
+        pb, keep = fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"])
+        r = gpu_ctx.optimize_pose(opt, [pb])[0]
+        assert np.array_equal(fe.se3_to_numpy(r.T_imu_world), fe.se3_to_numpy(batch[i].T_imu_world))
+        assert r.iters == batch[i].iters and r.n_deleted_corners == batch[i].n_deleted_corners
+        assert all(np.array_equal(a, k["outlier"]) for a, k in zip(flags[i], keep))
+    with pytest.raises(fe.SvohError):
+        gpu_ctx.optimize_pose(capi.default_pose_options(scenes[0]["cam"], error_type=7), [built[0][0]])
