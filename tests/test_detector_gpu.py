@@ -63,3 +63,16 @@ def test_detector_edge_cases(gpu_ctx, oracle_lib):
         gpu_ctx.detect_features(capi.default_detector_options(max_level=6), fr, 160, 128)
     with pytest.raises(fe.SvohError):
         gpu_ctx.detect_features(capi.default_detector_options(border=1), fr, 160, 128)
+
+
+def test_golden_detect_pose_fixture(gpu_ctx):
+    """HIP path vs the committed fixture (no oracle call): detector + pose optimiser."""
+    import os
+    import helpers
+    from test_golden_cpu import _golden3, check_golden3
+    z = np.load(os.path.join(os.path.dirname(helpers.GOLDEN), "detect_pose_small.npz"))
+    cam, cams, popt = _golden3(z)
+    fr = gpu_ctx.build_pyramid(z["img"], 4)
+    d = gpu_ctx.detect_features(capi.default_detector_options(cell_size=20), fr, 320, 240, z["det_occupancy"])
+    pb, keep = fe.make_pose_problem(cams, synth.SE3.from7(z["pose_T_init"]))
+    check_golden3(z, d, gpu_ctx.optimize_pose(popt, [pb])[0], keep)

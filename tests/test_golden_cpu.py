@@ -3,7 +3,7 @@ against drift; the GPU box re-checks the HIP path against the same file)."""
 import numpy as np
 import pytest
 
-from svo_pro_universal_amd import _capi as capi
+from svo_pro_universal_amd import _capi as capi, frontend as fe, synth
 
 import helpers
 
@@ -62,3 +62,39 @@ def test_oracle_reproduces_golden_klt_seeds(oracle_lib):
     o = orc.match_direct_batch(mopt, [rv], cv, fb2, z["direct_depth"], z["direct_px_init"])
     assert np.array_equal(o["result"], z["direct_result"]) and np.array_equal(o["search_level"], z["direct_search_level"])
     assert np.abs(o["px_cur"] - z["direct_px_out"]).max() < 1e-9
+
+
+def _golden3(z):
+    c = z["cam"]
+    cam = synth.Camera(int(c[0]), int(c[1]), c[2], c[3], c[4], c[5], dist=list(c[6:10]))
+    cams = []
+    for k in range(2):
+        cams.append(dict(cam=cam, T_cam_imu=synth.SE3.from7(z["pose%d_T_cam_imu" % k]), px=z["pose%d_px" % k], f=z["pose%d_f" % k],
+                         grad=z["pose%d_grad" % k], level=z["pose%d_level" % k], type=z["pose%d_type" % k],
+                         xyz_world=z["pose%d_xyz_world" % k], usable=z["pose%d_usable" % k]))
+    popt = capi.default_pose_options(outlier_threshold=float(z["pose_outlier_threshold"][0]))
+    return cam, cams, popt
+
+
+def check_golden3(z, d, r, keep):
+    """shared by the CPU (oracle) and GPU (HIP) golden tests"""
+    assert np.array_equal(d["px"], z["det_px"]) and np.array_equal(d["score"], z["det_score"])
+    assert np.array_equal(d["level"], z["det_level"]) and np.array_equal(d["type"], z["det_type"])
+    assert np.abs(d["grad"] - z["det_grad"]).max() < 1e-12
+    assert list(z["pose_counts"]) == [r.n_meas, r.n_deleted_edges, r.n_deleted_corners, r.iters, r.status]
+    assert r.measurement_sigma == float(z["pose_sigma"][0])
+    assert np.abs(fe.se3_to_numpy(r.T_imu_world) - z["pose_T_out"]).max() < 1e-9
+    for k in range(2):
+        n = len(z["pose%d_level" % k])
+        assert np.array_equal(keep[k]["outlier"][:n], z["pose%d_outlier" % k])
+        assert np.allclose(keep[k]["final_error"][:n], z["pose%d_final_error" % k], rtol=1e-9, atol=1e-15)
+
+
+def test_oracle_reproduces_golden_detect_pose(oracle_lib):
+    import os
+    z = np.load(os.path.join(os.path.dirname(helpers.GOLDEN), "detect_pose_small.npz"))
+    cam, cams, popt = _golden3(z)
+    levels = oracle_lib.create_img_pyramid(z["img"], 4)
+    d = oracle_lib.detect_features(capi.default_detector_options(cell_size=20), levels, z["det_occupancy"])
+    pb, keep = fe.make_pose_problem(cams, synth.SE3.from7(z["pose_T_init"]))
+    check_golden3(z, d, oracle_lib.optimize_pose(popt, pb), keep)
