@@ -61,9 +61,11 @@ struct AlignKernelArgs {
   const DevCamDesc* cams;
   svoh_align_result* results;
   // feature workspace (SoA over all features of all problems)
-  double* wx; double* wy; double* wz;   // xyz_ref (a-4)
-  double* wu; double* wv;               // uv in the reference image, level 0
-  double* wjp;                          // 12 x slots: projection Jacobian rows (jacobian_proj_cache_, a-4)
+  // per-feature workspace, 9 pairs of doubles per slot, pair-major: wpk[(pair * slots + gi) * 2 + {0,1}]
+  //   pair 0 (x, y)  1 (z, u)  2 (v, selected)   xyz_ref (a-4), uv in the reference image (level 0), a-3 flag
+  //   pairs 3..5 jp0[0..5], 6..8 jp1[0..5]       projection Jacobian rows (jacobian_proj_cache_, a-4)
+  // 16 bytes per lane and pair = one global_load_lds_dwordx4 per pair in the staged patch loop
+  double* wpk;
   int64_t slots;                        // stride of the SoA arrays
   uint8_t* wsel;                        // selected by extractFeaturesSubset (a-3)
   uint8_t* wvis;                        // visibility of the last evaluation
@@ -363,6 +365,9 @@ __device__ __forceinline__ Rigid uniform_rigid(const Rigid& T)
   return r;
 }
 
+constexpr int kWsPairs = 9;
+__device__ __forceinline__ double* ws_pair(const AlignKernelArgs& a, int pair, int64_t gi) { return a.wpk + ((int64_t)pair * a.slots + gi) * 2; }
+
 // All patches of one camera at one Gauss-Newton iteration: one thread per patch.
 template <int P, int D, int NT, bool LDS>
 __device__ __forceinline__ void accumulate_camera(
@@ -378,7 +383,9 @@ __device__ __forceinline__ void accumulate_camera(
   for (int i = tid; i < cd.n_features; i += NT) {
     const int gi = cd.feat_off + i;
     if (!a.wsel[gi]) continue;
-    const Vec3 X = { a.wx[gi], a.wy[gi], a.wz[gi] };
+    const double2 xy = *reinterpret_cast<const double2*>(ws_pair(a, 0, gi));
+    const double2 zu = *reinterpret_cast<const double2*>(ws_pair(a, 1, gi));
+    const Vec3 X = { xy.x, xy.y, zu.x };
     // ---- a-6 projection into the current level + visibility ----
     const Vec3 Y = transform(Tcr, X);
     bool vis = !(Y.z < 0.0);
@@ -401,8 +408,8 @@ __device__ __forceinline__ void accumulate_camera(
     if (!vis) continue;
     ++nvis;
     // ---- a-5 reference side (recomputed, never stored) ----
-    const double ru_tl = a.wu[gi] * scale - patch_center_wb;
-    const double rv_tl = a.wv[gi] * scale - patch_center_wb;
+    const double ru_tl = zu.y * scale - patch_center_wb;
+    const double rv_tl = ws_pair(a, 2, gi)[0] * scale - patch_center_wb;
     const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
     const double rsu = ru_tl - ru, rsv = rv_tl - rv;
     double mom[AccLayout<D>::NMOM];
@@ -410,11 +417,100 @@ __device__ __forceinline__ void accumulate_camera(
                                   weight_scale, mom);
     double jp0[6], jp1[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      jp0[k] = a.wjp[(int64_t)k * a.slots + gi];
-      jp1[k] = a.wjp[(int64_t)(6 + k) * a.slots + gi];
+    for (int k = 0; k < 3; ++k) {
+      const double2 q0 = *reinterpret_cast<const double2*>(ws_pair(a, 3 + k, gi));
+      const double2 q1 = *reinterpret_cast<const double2*>(ws_pair(a, 6 + k, gi));
+      jp0[2 * k] = q0.x; jp0[2 * k + 1] = q0.y;
+      jp1[2 * k] = q1.x; jp1[2 * k + 1] = q1.y;
     }
     accumulate_patch<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
+  }
+}
+
+// The same loop with the workspace row of every patch brought in by LDS-DMA (global_load_lds_dwordx4:
+// 16 bytes per lane straight into LDS, no VGPR and no wait at issue).  Without it the loads of a patch sit on
+// its critical path twice: xyz / uv before the projection can start, the twelve Jacobian entries before the
+// accumulation -- a round trip to L2 / Infinity Cache each, with only two waves per SIMD to hide it.  Here
+// the head (pairs 0..2) of the NEXT patch and the Jacobian rows (pairs 3..8) of THIS patch are requested right
+// after this patch's head has been read, and both arrive while the pixel loop runs.
+// stage: this wave's 9 x 64 x 16 B staging area.  Control flow is wave-uniform (every lane runs every pass).
+template <int P, int D, int NT, bool LDS>
+__device__ __forceinline__ void accumulate_camera_staged(
+    const AlignKernelArgs& a, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
+    const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
+    bool robust, bool dist_jac, float weight_scale, bool write_vis, int tid, double* stage,
+    double (&acc)[AccLayout<D>::NACC], int& nvis)
+{
+  typedef const __attribute__((address_space(1))) void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  const CamModel cm = load_camera(cd.cam);
+  const double patch_center = (P - 1) / 2.0f;
+  const double patch_center_wb = (P + 2 - 1) / 2.0f;
+  const int lane = tid & 63;
+  const int n = cd.n_features;
+  const int n_round = (n + NT - 1) / NT * NT;
+  auto request = [&](int pair_lo, int pair_hi, int64_t gi) {
+#pragma unroll
+    for (int pr = pair_lo; pr < pair_hi; ++pr)
+      __builtin_amdgcn_global_load_lds((gptr)ws_pair(a, pr, gi), (lptr)(stage + pr * 128), 16, 0, 0);
+  };
+  if (tid < n) request(0, 3, cd.feat_off + tid);
+  for (int i = tid; i < n_round; i += NT) {
+    const int64_t gi = cd.feat_off + i;
+    const bool in_range = i < n;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this pass's head has landed in LDS
+    const double2 xy = *reinterpret_cast<const double2*>(stage + 0 * 128 + lane * 2);
+    const double2 zu = *reinterpret_cast<const double2*>(stage + 1 * 128 + lane * 2);
+    const double2 vs = *reinterpret_cast<const double2*>(stage + 2 * 128 + lane * 2);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the head is in registers before its buffer is requested again
+    if (i + NT < n) request(0, 3, gi + NT);
+    const bool sel = in_range && vs.y != 0.0;
+    if (sel) request(3, kWsPairs, gi);
+    bool vis = false;
+    double mom[AccLayout<D>::NMOM];
+    if (sel) {
+      const Vec3 X = { xy.x, xy.y, zu.x };
+      const Vec3 Y = transform(Tcr, X);
+      vis = !(Y.z < 0.0);
+      int cu = 0, cv = 0;
+      double csu = 0.0, csv = 0.0;
+      if (vis) {
+        double u, v;
+        project3(cm, Y, u, v);
+        const double u_tl = u * scale - patch_center;
+        const double v_tl = v * scale - patch_center;
+        vis = !(u_tl < 0.0 || v_tl < 0.0 || u_tl + P + 2.0 >= cw || v_tl + P + 2.0 >= ch);
+        vis = vis && u_tl == u_tl && v_tl == v_tl;
+        if (vis) {
+          const double fu = floor(u_tl), fv = floor(v_tl);
+          cu = (int)fu; cv = (int)fv;
+          csu = u_tl - cu; csv = v_tl - cv;
+        }
+      }
+      if (write_vis) a.wvis[gi] = vis ? 1 : 0;
+      if (vis) {
+        ++nvis;
+        const double ru_tl = zu.y * scale - patch_center_wb;
+        const double rv_tl = vs.x * scale - patch_center_wb;
+        const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
+        const double rsu = ru_tl - ru, rsv = rv_tl - rv;
+        patch_moments<P, D, LDS, LDS>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d, robust,
+                                      weight_scale, mom);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the Jacobian rows (requested before the pixel loop) are in LDS
+    if (vis) {
+      double jp0[6], jp1[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double2 q0 = *reinterpret_cast<const double2*>(stage + (3 + k) * 128 + lane * 2);
+        const double2 q1 = *reinterpret_cast<const double2*>(stage + (6 + k) * 128 + lane * 2);
+        jp0[2 * k] = q0.x; jp0[2 * k + 1] = q0.y;
+        jp1[2 * k] = q1.x; jp1[2 * k + 1] = q1.y;
+      }
+      accumulate_patch<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) before the next pass may request the Jacobian buffer again
   }
 }
 
@@ -536,6 +632,9 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
     }
   }
 
+#ifndef SVOH_ALIGN_STAGED
+#define SVOH_ALIGN_STAGED 1
+#endif
 #ifndef SVOH_ALIGN_MIN_WAVES_256
 #define SVOH_ALIGN_MIN_WAVES_256 2
 #endif
@@ -548,7 +647,11 @@ void sparse_align_kernel(const AlignKernelArgs a)
   constexpr int NACC = AccLayout<D>::NACC;
   constexpr int NW = NT / 64;
 
+  // LDS-DMA staging of the workspace rows (accumulate_camera_staged) in the batch geometry; the wide
+  // geometries keep their LDS for finer image levels and read the workspace with ordinary loads
+  constexpr bool STAGED = SVOH_ALIGN_STAGED && NT == 256;
   extern __shared__ __align__(16) unsigned char lds_img[];
+  __shared__ __align__(16) double s_stage[STAGED ? NW * kWsPairs * 128 : 2];
   __shared__ double s_red[NW][NACC];
   __shared__ double s_sum[NACC];
   __shared__ int s_nvis;
@@ -617,23 +720,22 @@ void sparse_align_kernel(const AlignKernelArgs a)
         }
         a.wsel[gi] = sel ? 1 : 0;
         a.wvis[gi] = 0;
+        if (!sel) *reinterpret_cast<double2*>(ws_pair(a, 2, gi)) = make_double2(0.0, 0.0);
         if (sel) {
           const double dx = cd.pos_world[3 * i + 0] - cd.ref_pos[0];
           const double dy = cd.pos_world[3 * i + 1] - cd.ref_pos[1];
           const double dz = cd.pos_world[3 * i + 2] - cd.ref_pos[2];
           const double depth = sqrt(dx * dx + dy * dy + dz * dz);
-          a.wx[gi] = cd.f[3 * i + 0] * depth;
-          a.wy[gi] = cd.f[3 * i + 1] * depth;
-          a.wz[gi] = cd.f[3 * i + 2] * depth;
-          a.wu[gi] = pu;
-          a.wv[gi] = pv;
-          const Vec3 X = { a.wx[gi], a.wy[gi], a.wz[gi] };
+          const Vec3 X = { cd.f[3 * i + 0] * depth, cd.f[3 * i + 1] * depth, cd.f[3 * i + 2] * depth };
+          *reinterpret_cast<double2*>(ws_pair(a, 0, gi)) = make_double2(X.x, X.y);
+          *reinterpret_cast<double2*>(ws_pair(a, 1, gi)) = make_double2(X.z, pu);
+          *reinterpret_cast<double2*>(ws_pair(a, 2, gi)) = make_double2(pv, 1.0);
           double jp0[6], jp1[6];
           projection_jacobian(X, T_imu_cam0, T_cam_imu0, R0, cm0, dist_jac0, jp0, jp1);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            a.wjp[(int64_t)k * a.slots + gi] = jp0[k];
-            a.wjp[(int64_t)(6 + k) * a.slots + gi] = jp1[k];
+          for (int k = 0; k < 3; ++k) {
+            *reinterpret_cast<double2*>(ws_pair(a, 3 + k, gi)) = make_double2(jp0[2 * k], jp0[2 * k + 1]);
+            *reinterpret_cast<double2*>(ws_pair(a, 6 + k, gi)) = make_double2(jp1[2 * k], jp1[2 * k + 1]);
           }
           ++my_sel;
         }
@@ -720,16 +822,26 @@ void sparse_align_kernel(const AlignKernelArgs a)
           off += ((rim.w * rim.h + 15) & ~15);
           cur.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); cur.pitch = cim.w;
           off += ((cim.w * cim.h + 15) & ~15);
-          accumulate_camera<P, D, NT, true>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                            est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
-                                            acc, nvis);
+          if constexpr (STAGED)
+            accumulate_camera_staged<P, D, NT, true>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                     est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
+                                                     s_stage + wave * kWsPairs * 128, acc, nvis);
+          else
+            accumulate_camera<P, D, NT, true>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                              est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
+                                              acc, nvis);
         } else {
           ImgView<false> ref, cur;
           ref.p = rim.data; ref.pitch = rim.pitch;
           cur.p = cim.data; cur.pitch = cim.pitch;
-          accumulate_camera<P, D, NT, false>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                             est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
-                                             acc, nvis);
+          if constexpr (STAGED)
+            accumulate_camera_staged<P, D, NT, false>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                      est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
+                                                      s_stage + wave * kWsPairs * 128, acc, nvis);
+          else
+            accumulate_camera<P, D, NT, false>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                               est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
+                                               acc, nvis);
         }
       }
 
@@ -854,7 +966,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
   SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * n_problems));
   SVOH_HIP_TRY(ctx, ctx->h_results.reserve(sizeof(svoh_align_result) * n_problems));
-  SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (17 * 8 + 2) + 256));
+  SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (kWsPairs * 16 + 2) + 256));
   if (host_bytes) {
     SVOH_HIP_TRY(ctx, ctx->h_upload.reserve(host_bytes));
     SVOH_HIP_TRY(ctx, ctx->d_upload.reserve(host_bytes));
@@ -924,11 +1036,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.cams = reinterpret_cast<const DevCamDesc*>(args.problems + n_problems);
   args.results = static_cast<svoh_align_result*>(ctx->d_results.ptr);
   double* w = static_cast<double*>(ctx->d_feat.ptr);
-  args.wx = w; args.wy = w + feat_slots; args.wz = w + 2 * feat_slots;
-  args.wu = w + 3 * feat_slots; args.wv = w + 4 * feat_slots;
-  args.wjp = w + 5 * feat_slots;
+  args.wpk = w;
   args.slots = (int64_t)feat_slots;
-  args.wsel = reinterpret_cast<uint8_t*>(w + 17 * feat_slots);
+  args.wsel = reinterpret_cast<uint8_t*>(w + 2 * kWsPairs * feat_slots);
   args.wvis = args.wsel + feat_slots;
   args.opt = *opt;
   args.eval_level = eval_level;
@@ -954,7 +1064,10 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   if (nt != 256 && nt != 512 && nt != 1024) nt = 256;
   size_t lds = (nt == 256) ? 38400 : (nt == 512 ? 78 * 1024 : 153856);
   lds = (size_t)getenv_int("SVOH_ALIGN_LDS", (int)lds);
-  if (lds > 153856) lds = 153856;
+  // 160 KB per workgroup minus the kernel's static LDS (reduction scratch; in the 256-thread geometry also the
+  // 36 KB LDS-DMA staging area of the workspace rows)
+  const size_t lds_cap = (nt == 256 && SVOH_ALIGN_STAGED) ? 163840 - 40960 : 153856;
+  if (lds > lds_cap) lds = lds_cap;
   args.lds_img_bytes = (int32_t)lds;
 
   const bool illum = opt->estimate_illumination_gain || opt->estimate_illumination_offset;
@@ -1045,7 +1158,7 @@ int svoh_sparse_align_evaluate(svoh_ctx* ctx, const svoh_align_options* options,
   std::vector<uint8_t> sel((size_t)nf + 1), vis((size_t)nf + 1);
   // workspace layout: see enqueue_align
   const size_t slots = nf ? (size_t)nf : 1;
-  const uint8_t* dsel = reinterpret_cast<const uint8_t*>(static_cast<double*>(ctx->d_feat.ptr) + 17 * slots);
+  const uint8_t* dsel = reinterpret_cast<const uint8_t*>(static_cast<double*>(ctx->d_feat.ptr) + 2 * kWsPairs * slots);
   if (nf) {
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(sel.data(), dsel, (size_t)nf, hipMemcpyDeviceToHost, ctx->stream));
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(vis.data(), dsel + slots, (size_t)nf, hipMemcpyDeviceToHost, ctx->stream));
