@@ -291,7 +291,7 @@ int svoh_upload_pyramid(svoh_ctx* ctx, int n_levels, const uint8_t* const* level
   size_t offs[SVOH_MAX_LEVELS]; int ws[SVOH_MAX_LEVELS], hs[SVOH_MAX_LEVELS];
   const size_t bytes = frame_layout(width[0], height[0], n_levels, offs, ws, hs);
   auto slab = std::make_shared<Slab>();
-  SVOH_HIP_TRY(ctx, hipMalloc(&slab->ptr, bytes));
+  SVOH_HIP_TRY(ctx, hipMalloc(&slab->ptr, bytes + kSlabTailPad));
   slab->bytes = bytes;
   uint8_t* base = static_cast<uint8_t*>(slab->ptr);
   for (int i = 0; i < n_levels; ++i)
@@ -316,7 +316,7 @@ int svoh_build_pyramid_batch(svoh_ctx* ctx, const uint8_t* img, size_t image_str
   size_t offs[SVOH_MAX_LEVELS]; int ws[SVOH_MAX_LEVELS], hs[SVOH_MAX_LEVELS];
   const size_t fbytes = frame_layout(width, height, n_levels, offs, ws, hs);
   auto slab = std::make_shared<Slab>();
-  SVOH_HIP_TRY(ctx, hipMalloc(&slab->ptr, fbytes * (size_t)n_images));
+  SVOH_HIP_TRY(ctx, hipMalloc(&slab->ptr, fbytes * (size_t)n_images + kSlabTailPad));
   slab->bytes = fbytes * (size_t)n_images;
   uint8_t* base = static_cast<uint8_t*>(slab->ptr);
   // level 0: copy into the tightly packed layout

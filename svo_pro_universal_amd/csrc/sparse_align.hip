@@ -109,19 +109,48 @@ struct ShState {
 // ---- image accessors --------------------------------------------------------
 // LDS=true: the level lives in the workgroup's LDS (address space 3 -> ds_read);
 // LDS=false: gathers go to global memory (L1/L2).
+template <int N>
+struct PackedRow { static constexpr int NQ = (N + 7) / 8; unsigned long long v[NQ]; };
+
 template <bool LDS>
 struct ImgView;
+// row<N>(off, out): N consecutive pixels.  From global memory they come as one unaligned 8- or 16-byte load
+// (a row of the (P+3)- or (P+1)-pixel footprint) instead of N byte gathers: the L1 / texture path of a CU
+// serves every wave-wide load instruction separately, and 74 byte loads per 4x4 patch were what the levels
+// that do not fit in LDS spent their time on.  (Reads up to 15 bytes past the row: kSlabTailPad.)
 template <>
 struct ImgView<false> {
   const uint8_t* p;
   int pitch;
   __device__ __forceinline__ unsigned at(int off) const { return p[off]; }
+  template <int N>
+  __device__ __forceinline__ void row(int off, unsigned (&out)[N]) const
+  {
+    PackedRow<N> r;
+    fetch<N>(off, r);
+    unpack<N>(r, out);
+  }
+  // the load and the use of a row, separately: patch_moments requests the next row before it works on this one
+  template <int N>
+  __device__ __forceinline__ void fetch(int off, PackedRow<N>& r) const { __builtin_memcpy(r.v, p + off, 8 * PackedRow<N>::NQ); }
+  template <int N>
+  static __device__ __forceinline__ void unpack(const PackedRow<N>& r, unsigned (&out)[N])
+  {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = (unsigned)(r.v[i / 8] >> (8 * (i % 8))) & 0xFFu;
+  }
 };
 template <>
 struct ImgView<true> {
   const __attribute__((address_space(3))) uint8_t* p;
   int pitch;
   __device__ __forceinline__ unsigned at(int off) const { return p[off]; }
+  template <int N>
+  __device__ __forceinline__ void row(int off, unsigned (&out)[N]) const
+  {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = p[off + i];
+  }
 };
 
 template <int D>
@@ -213,18 +242,40 @@ __device__ __forceinline__ void patch_moments(
   unsigned rawA[WB + 1], rawB[WB + 1];
   double it0[WB], it1[WB], it2[WB];
   unsigned curA[P + 1], curB[P + 1];
+  // Rows from global memory are requested one row ahead (packed, 2-4 VGPRs each): the round trip to L2 then
+  // overlaps the interpolation of the row before instead of preceding every row's arithmetic.
+  PackedRow<WB + 1> pref_r;
+  PackedRow<P + 1> pref_c;
+  if constexpr (!RLDS) {
+    PackedRow<WB + 1> r0, r1, r2;
+    ref.template fetch<WB + 1>(roff, r0);
+    ref.template fetch<WB + 1>(roff + ref.pitch, r1);
+    ref.template fetch<WB + 1>(roff + 2 * ref.pitch, r2);
+    ref.template fetch<WB + 1>(roff + 3 * ref.pitch, pref_r);
+    if constexpr (!CLDS) {
+      PackedRow<P + 1> c0;
+      cur.template fetch<P + 1>(coff, c0);
+      cur.template fetch<P + 1>(coff + cur.pitch, pref_c);
+      ImgView<false>::unpack<P + 1>(c0, curB);
+    }
+    ImgView<false>::unpack<WB + 1>(r0, rawA);
+    ImgView<false>::unpack<WB + 1>(r1, rawB);
 #pragma unroll
-  for (int i = 0; i < WB + 1; ++i) { rawA[i] = ref.at(roff + i); rawB[i] = ref.at(roff + ref.pitch + i); }
+    for (int i = 0; i < WB; ++i)
+      it1[i] = rwtl * (double)rawA[i] + rwtr * (double)rawA[i + 1] + rwbl * (double)rawB[i] + rwbr * (double)rawB[i + 1];
+    ImgView<false>::unpack<WB + 1>(r2, rawA);
+  } else {
+    ref.template row<WB + 1>(roff, rawA);
+    ref.template row<WB + 1>(roff + ref.pitch, rawB);
 #pragma unroll
-  for (int i = 0; i < WB; ++i)
-    it1[i] = rwtl * (double)rawA[i] + rwtr * (double)rawA[i + 1] + rwbl * (double)rawB[i] + rwbr * (double)rawB[i + 1];
-#pragma unroll
-  for (int i = 0; i < WB + 1; ++i) rawA[i] = ref.at(roff + 2 * ref.pitch + i);
+    for (int i = 0; i < WB; ++i)
+      it1[i] = rwtl * (double)rawA[i] + rwtr * (double)rawA[i + 1] + rwbl * (double)rawB[i] + rwbr * (double)rawB[i + 1];
+    ref.template row<WB + 1>(roff + 2 * ref.pitch, rawA);
+  }
 #pragma unroll
   for (int i = 0; i < WB; ++i)
     it2[i] = rwtl * (double)rawB[i] + rwtr * (double)rawB[i + 1] + rwbl * (double)rawA[i] + rwbr * (double)rawA[i + 1];
-#pragma unroll
-  for (int i = 0; i < P + 1; ++i) curB[i] = cur.at(coff + i);
+  if constexpr (RLDS || CLDS) cur.template row<P + 1>(coff, curB);
   // here: rawA = raw row 2, it1 = interp row 0, it2 = interp row 1, curB = cur row 0
 
 #pragma unroll SVOH_ROW_UNROLL
@@ -232,7 +283,19 @@ __device__ __forceinline__ void patch_moments(
     const int rrow = roff + (y + 3) * ref.pitch;
     const int crow = coff + (y + 1) * cur.pitch;
 #pragma unroll
-    for (int i = 0; i < WB + 1; ++i) rawB[i] = ref.at(rrow + i);
+    for (int i = 0; i < P + 1; ++i) curA[i] = curB[i];
+    if constexpr (!RLDS && !CLDS) {
+      ImgView<false>::unpack<WB + 1>(pref_r, rawB);
+      ImgView<false>::unpack<P + 1>(pref_c, curB);
+      if (y + 1 < P) {   // request the rows of the next output row now (they are inside the footprint)
+        ref.template fetch<WB + 1>(rrow + ref.pitch, pref_r);
+        cur.template fetch<P + 1>(crow + cur.pitch, pref_c);
+      }
+      asm volatile("" ::: "memory");   // keep the requests ahead of this row's arithmetic
+    } else {
+      ref.template row<WB + 1>(rrow, rawB);
+      cur.template row<P + 1>(crow, curB);
+    }
 #pragma unroll
     for (int i = 0; i < WB; ++i) {
       it0[i] = it1[i];
@@ -242,8 +305,6 @@ __device__ __forceinline__ void patch_moments(
     }
 #pragma unroll
     for (int i = 0; i < WB + 1; ++i) rawA[i] = rawB[i];
-#pragma unroll
-    for (int i = 0; i < P + 1; ++i) { curA[i] = curB[i]; curB[i] = cur.at(crow + i); }
     // output row y: it0 = interp row y (up), it1 = y+1 (centre), it2 = y+2 (down)
 #pragma unroll
     for (int x = 0; x < P; ++x) {
@@ -335,11 +396,18 @@ __device__ __forceinline__ void stage_image(unsigned char* dst, const DevImage& 
 {
   const int total = im.w * im.h;
   if (im.pitch == im.w && (reinterpret_cast<uintptr_t>(im.data) & 15) == 0) {
+    // LDS-DMA: every wave copies 1 KB per instruction (16 bytes per lane, lane-contiguous on both sides) without a
+    // round trip through VGPRs, and all of a thread's requests are in flight at once.  The caller's barrier
+    // follows the vmcnt wait below.
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
     const int n16 = total >> 4;
-    const uint4* s = reinterpret_cast<const uint4*>(im.data);
-    uint4* d = reinterpret_cast<uint4*>(dst);
-    for (int i = tid; i < n16; i += NT) d[i] = s[i];
+    const int lane = tid & 63, wave_base = tid - lane;
+    for (int i0 = wave_base; i0 < n16; i0 += NT)
+      if (i0 + lane < n16)
+        __builtin_amdgcn_global_load_lds((gptr)(im.data + (size_t)(i0 + lane) * 16), (lptr)(dst + (size_t)i0 * 16), 16, 0, 0);
     for (int i = (n16 << 4) + tid; i < total; i += NT) dst[i] = im.data[i];
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   } else {
     for (int i = tid; i < total; i += NT) {
       const int y = i / im.w, x = i - y * im.w;
@@ -706,8 +774,13 @@ void sparse_align_kernel(const AlignKernelArgs a)
       const bool dist_jac0 = opt.use_distortion_jacobian != 0;
       for (int i = tid; i < cd.n_features; i += NT) {
         const int gi = cd.feat_off + i;
+        // all of the feature's inputs are requested together (they are independent); behind the selection test
+        // each would be its own round trip to memory
         bool sel = cd.flags[i] != 0;
         const double pu = cd.px[2 * i], pv = cd.px[2 * i + 1];
+        const double pwx = cd.pos_world[3 * i + 0], pwy = cd.pos_world[3 * i + 1], pwz = cd.pos_world[3 * i + 2];
+        const double fx_ = cd.f[3 * i + 0], fy_ = cd.f[3 * i + 1], fz_ = cd.f[3 * i + 2];
+        asm volatile("" ::: "memory");
         if (sel) {
           const double u_tl = pu * scale - patch_center_wb;
           const double v_tl = pv * scale - patch_center_wb;
@@ -722,11 +795,11 @@ void sparse_align_kernel(const AlignKernelArgs a)
         a.wvis[gi] = 0;
         if (!sel) *reinterpret_cast<double2*>(ws_pair(a, 2, gi)) = make_double2(0.0, 0.0);
         if (sel) {
-          const double dx = cd.pos_world[3 * i + 0] - cd.ref_pos[0];
-          const double dy = cd.pos_world[3 * i + 1] - cd.ref_pos[1];
-          const double dz = cd.pos_world[3 * i + 2] - cd.ref_pos[2];
+          const double dx = pwx - cd.ref_pos[0];
+          const double dy = pwy - cd.ref_pos[1];
+          const double dz = pwz - cd.ref_pos[2];
           const double depth = sqrt(dx * dx + dy * dy + dz * dz);
-          const Vec3 X = { cd.f[3 * i + 0] * depth, cd.f[3 * i + 1] * depth, cd.f[3 * i + 2] * depth };
+          const Vec3 X = { fx_ * depth, fy_ * depth, fz_ * depth };
           *reinterpret_cast<double2*>(ws_pair(a, 0, gi)) = make_double2(X.x, X.y);
           *reinterpret_cast<double2*>(ws_pair(a, 1, gi)) = make_double2(X.z, pu);
           *reinterpret_cast<double2*>(ws_pair(a, 2, gi)) = make_double2(pv, 1.0);

@@ -20,6 +20,10 @@ struct DevImage {
   int32_t w, h, pitch, pad;
 };
 
+// Kernels read pixel rows in 8/16-byte pieces (sparse_align.hip, ImgView<false>::row): the last piece of the
+// last row of the last level may reach up to 15 bytes past the image, so every slab ends with readable padding.
+constexpr size_t kSlabTailPad = 64;
+
 // device allocation shared by the frames carved out of it
 struct Slab {
   void* ptr = nullptr;
