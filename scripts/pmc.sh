@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 out=/tmp/pmc_$tag
 rm -rf $out
 cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc $ctrs --kernel-include-regex "sparse_align" --output-format csv -d $out -- python scripts/prof_align.py > $out.log 2>&1 || { tail -20 $out.log; exit 1; }
+rocprofv3 --pmc $ctrs --kernel-include-regex "${KREGEX:-sparse_align}" --output-format csv -d $out -- python ${PROG:-scripts/prof_align.py} > $out.log 2>&1 || { tail -20 $out.log; exit 1; }
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python - "$f" "$tag" <<'PY'
 import sys, csv, collections
