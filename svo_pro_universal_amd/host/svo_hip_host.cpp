@@ -527,7 +527,186 @@ size_t OccupandyGrid2D::getCellIndex(int x, int y, int scale) const
   return static_cast<size_t>(std::floor(py / cell_size) * n_cols + std::floor(px / cell_size));
 }
 
+// ---- Frame helpers the reprojector needs ----
+static bool is_corner_edgelet_seed(uint8_t t)
+{
+  return t == SVOH_FT_CORNER_SEED || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_CORNER_SEED_CONVERGED || t == SVOH_FT_EDGELET_SEED_CONVERGED;
+}
+static bool is_map_point(uint8_t t) { return t == SVOH_FT_MAPPOINT || t == SVOH_FT_MAPPOINT_SEED || t == SVOH_FT_MAPPOINT_SEED_CONVERGED; }
+
+size_t Frame::numTrackedFeatures() const
+{
+  size_t count = 0;
+  for (size_t i = 0; i < num_features_; ++i) {
+    const uint8_t t = type_vec_[i];
+    const bool valid_landmark = i < landmark_vec_.size() && landmark_vec_[i] != nullptr;
+    if ((valid_landmark && t != SVOH_FT_FIXED_LANDMARK && !is_map_point(t)) || is_corner_edgelet_seed(t)) ++count;
+  }
+  return count;
+}
+
+bool Frame::isVisible(const svoh::Vec3& xyz_w, double* px) const
+{
+  const svoh::Vec3 xyz_f = svoh::transform(T_f_w_, xyz_w);
+  const svoh::CamModel cm = svoh::load_camera(cam);
+  {   // pinhole: not farther off the optical axis than the image's top-left corner (frame.cpp:233-246)
+    svoh::Vec3 f_tl = svoh::back_project3(cm, 0.0, 0.0);
+    const double n = sqrt(f_tl.x * f_tl.x + f_tl.y * f_tl.y + f_tl.z * f_tl.z);
+    const double min_cos = f_tl.z / n;
+    const double nf = sqrt(xyz_f.x * xyz_f.x + xyz_f.y * xyz_f.y + xyz_f.z * xyz_f.z);
+    const double cur_cos = xyz_f.z / nf;
+    if (cur_cos < min_cos) return false;
+  }
+  // cam_->project3(xyz_f, &px).isKeypointVisible(): inside the image box (camera_geometry.hpp:29-38)
+  double u, v;
+  svoh::project3(cm, xyz_f, u, v);
+  if (px) { px[0] = u; px[1] = v; }
+  return u >= 0.0 && v >= 0.0 && u < static_cast<double>(cam.width) && v < static_cast<double>(cam.height);
+}
+
+// ---- Reprojector::reprojectFrames (reprojector.cpp:27-306) ----
+ReprojectorHip::ReprojectorHip(svoh_ctx* ctx, const ReprojectorOptions& options, size_t camera_index)
+    : options_(options), ctx_(ctx), camera_index_(camera_index)
+{
+  if (!ctx_) throw std::runtime_error("ReprojectorHip: NULL svoh_ctx (no CPU fallback exists)");
+  if (camera_index_ >= SVOH_MAX_CAMS) throw std::runtime_error("ReprojectorHip: camera index out of range");
+}
+
+void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs,
+                                     std::vector<PointPtr>& trash_points)
+{
+  const size_t max_total_n_features = options_.max_n_features_per_frame;   // + max_n_fixed_lm, 0 without the global map
+  if (options_.max_n_features_per_frame == 0) throw std::runtime_error("Reprojector: max_n_features_per_frame must be > 0");   // CHECK_GT
+  if (!grid_)
+    grid_.reset(new OccupandyGrid2D(static_cast<int>(options_.cell_size),
+                                    OccupandyGrid2D::getNCell(cur_frame->cam.width, static_cast<int>(options_.cell_size)),
+                                    OccupandyGrid2D::getNCell(cur_frame->cam.height, static_cast<int>(options_.cell_size))));
+  grid_->reset();
+  stats_ = reprojector::Statistics();
+  auto add = [&](const reprojector::Statistics& st) { stats_.n_matches += st.n_matches; stats_.n_trials += st.n_trials; };
+
+  // landmarks of the closest keyframes with overlap (:131-176)
+  candidates_.clear();
+  for (const FramePtr& ref_frame : visible_kfs) {
+    for (size_t i = 0; i < ref_frame->num_features_; ++i) {
+      const uint8_t type = ref_frame->type_vec_[i];
+      const PointPtr point = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i] : nullptr;
+      if (!point || type == SVOH_FT_OUTLIER || is_map_point(type) || type == SVOH_FT_FIXED_LANDMARK) continue;
+      if (point->n_failed_reproj_ > 10) { trash_points.push_back(point); continue; }
+      if (point->last_projected_kf_id_.at(camera_index_) == cur_frame->id_) continue;   // project a point only once
+      point->last_projected_kf_id_[camera_index_] = cur_frame->id_;
+      if (point->obs_.size() < 2 && options_.remove_unconstrained_points) { trash_points.push_back(point); continue; }
+      reprojector::Candidate candidate;
+      if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) candidates_.push_back(candidate);
+    }
+  }
+  reprojector::Statistics lm_stats;
+  reprojector_utils::sortCandidatesByReprojStats(candidates_);
+  reprojector_utils::matchCandidates(ctx_, cur_frame, max_total_n_features, options_.affine_est_offset, options_.affine_est_gain,
+                                     candidates_, *grid_, lm_stats, options_.seed_sigma2_thresh);
+  add(lm_stats);
+  if (doesFrameHaveEnoughFeatures(cur_frame)) reprojector_utils::setGridCellsOccupied(candidates_, *grid_);
+
+  // converged seeds (:201-241)
+  candidates_.clear();
+  for (const FramePtr& ref_frame : visible_kfs)
+    for (size_t i = 0; i < ref_frame->num_features_; ++i) {
+      const uint8_t t = ref_frame->type_vec_[i];
+      if (t == SVOH_FT_CORNER_SEED_CONVERGED || t == SVOH_FT_EDGELET_SEED_CONVERGED) {
+        reprojector::Candidate candidate;
+        if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) candidates_.push_back(candidate);
+      }
+    }
+  if (doesFrameHaveEnoughFeatures(cur_frame)) {
+    reprojector_utils::setGridCellsOccupied(candidates_, *grid_);
+    candidates_.clear();
+    return;
+  }
+  reprojector::Statistics sd_stats;
+  reprojector_utils::sortCandidatesByReprojStats(candidates_);
+  reprojector_utils::matchCandidates(ctx_, cur_frame, max_total_n_features, options_.affine_est_offset, options_.affine_est_gain,
+                                     candidates_, *grid_, sd_stats, options_.seed_sigma2_thresh);
+  add(sd_stats);
+  if (doesFrameHaveEnoughFeatures(cur_frame) || !options_.reproject_unconverged_seeds) {
+    reprojector_utils::setGridCellsOccupied(candidates_, *grid_);
+    candidates_.clear();
+    return;
+  }
+
+  // unconverged seeds (:243-306)
+  candidates_.clear();
+  for (const FramePtr& ref_frame : visible_kfs)
+    for (size_t i = 0; i < ref_frame->num_features_; ++i) {
+      const uint8_t t = ref_frame->type_vec_[i];
+      if (t == SVOH_FT_CORNER_SEED || t == SVOH_FT_EDGELET_SEED) {
+        reprojector::Candidate candidate;
+        if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) candidates_.push_back(candidate);
+      }
+    }
+  reprojector::Statistics un_sd_stats;
+  size_t max_allowed_total = max_total_n_features;
+  if (options_.max_unconverged_seeds_ratio > 0) {
+    const double min_lm_seeds_ratio = 1 - options_.max_unconverged_seeds_ratio;
+    const size_t max_allowed_alternative = static_cast<size_t>(cur_frame->numTrackedFeatures() / min_lm_seeds_ratio);
+    if (max_allowed_total > max_allowed_alternative) max_allowed_total = max_allowed_alternative;
+  }
+  if (max_allowed_total < options_.min_required_features) max_allowed_total = options_.min_required_features;
+  reprojector_utils::sortCandidatesByReprojStats(candidates_);
+  reprojector_utils::matchCandidates(ctx_, cur_frame, max_allowed_total, options_.affine_est_offset, options_.affine_est_gain,
+                                     candidates_, *grid_, un_sd_stats, options_.seed_sigma2_thresh);
+  add(un_sd_stats);
+  if (doesFrameHaveEnoughFeatures(cur_frame)) reprojector_utils::setGridCellsOccupied(candidates_, *grid_);
+}
+
 namespace reprojector_utils {
+void sortCandidatesByReprojStats(std::vector<reprojector::Candidate>& candidates)
+{
+  std::sort(candidates.begin(), candidates.end(), [](const reprojector::Candidate& lhs, const reprojector::Candidate& rhs) {
+    return lhs.type > rhs.type || (lhs.type == rhs.type && lhs.n_reproj > rhs.n_reproj) ||
+           (lhs.type == rhs.type && lhs.n_reproj == rhs.n_reproj && lhs.score > rhs.score);
+  });
+}
+
+bool projectPointAndCheckVisibility(const FramePtr& frame, const svoh::Vec3& xyz, double* px)
+{
+  if (!frame->isVisible(xyz, px)) return false;
+  const int pxi0 = static_cast<int>(px[0]), pxi1 = static_cast<int>(px[1]);   // px->cast<int>()
+  constexpr int kPatchSize = 8;                                               // isKeypointVisibleWithMargin
+  return pxi0 >= kPatchSize && pxi1 >= kPatchSize && pxi0 < frame->cam.width - kPatchSize && pxi1 < frame->cam.height - kPatchSize;
+}
+
+bool getCandidate(const FramePtr& cur_frame, const FramePtr& ref_frame, size_t ref_index, reprojector::Candidate& candidate)
+{
+  svoh::Vec3 xyz_world{ 0, 0, 0 };
+  int n_reproj = 0;
+  const PointPtr lm = ref_index < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[ref_index] : nullptr;
+  if (lm) {
+    xyz_world = lm->pos();
+    n_reproj = lm->n_succeeded_reproj_ - lm->n_failed_reproj_;
+  } else {
+    const double depth = ref_frame->getSeedDepth(ref_index);   // T_world_cam() * getSeedPosInFrame(ref_index)
+    const svoh::Vec3 in_f{ ref_frame->f_vec_[3 * ref_index] * depth, ref_frame->f_vec_[3 * ref_index + 1] * depth,
+                           ref_frame->f_vec_[3 * ref_index + 2] * depth };
+    xyz_world = svoh::transform(svoh::inverse(ref_frame->T_f_w_), in_f);
+  }
+  double px[2];
+  if (!projectPointAndCheckVisibility(cur_frame, xyz_world, px)) return false;
+  candidate = reprojector::Candidate();
+  candidate.ref_frame = ref_frame; candidate.ref_index = ref_index;
+  candidate.cur_px[0] = px[0]; candidate.cur_px[1] = px[1];
+  candidate.n_reproj = n_reproj;
+  candidate.score = ref_index < ref_frame->score_vec_.size() ? ref_frame->score_vec_[ref_index] : 0.0;
+  candidate.type = ref_frame->type_vec_[ref_index];
+  candidate.n_obs = lm ? lm->obs_.size() : 0u;
+  return true;
+}
+
+void setGridCellsOccupied(const std::vector<reprojector::Candidate>& candidates, OccupandyGrid2D& grid)
+{
+  for (const reprojector::Candidate& c : candidates)
+    grid.setOccupied(grid.getCellIndex(static_cast<int>(c.cur_px[0]), static_cast<int>(c.cur_px[1]), 1));
+}
+
 namespace {
 thread_local std::vector<int32_t> g_last_results;
 bool is_edgelet(uint8_t t) { return t == SVOH_FT_EDGELET || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_EDGELET_SEED_CONVERGED; }

@@ -58,6 +58,8 @@ struct Frame {
   struct SeedRef { std::shared_ptr<Frame> keyframe; int seed_id = -1; };
   std::vector<SeedRef> seed_ref_vec_;                   // n
   double getSeedDepth(size_t idx) const { return 1.0 / invmu_sigma2_a_b_vec_[4 * idx]; }   // seed.h:110-113 (inverse depth)
+  size_t numTrackedFeatures() const;                                      // frame.h:153-163
+  bool isVisible(const svoh::Vec3& xyz_w, double* px /* 2, may be NULL */) const;   // frame.cpp:229-260
 
   void set_T_cam_imu(const Transformation& T) { T_cam_imu_ = T; T_imu_cam_ = svoh::inverse(T); }  // frame.h:270-274
   const Transformation& T_cam_imu() const { return T_cam_imu_; }
@@ -271,6 +273,7 @@ struct Point {
   int n_failed_reproj_ = 0, n_succeeded_reproj_ = 0;
   struct Obs { std::weak_ptr<Frame> frame; size_t keypoint_index_ = 0; };
   std::vector<Obs> obs_;
+  std::vector<int> last_projected_kf_id_ = std::vector<int>(SVOH_MAX_CAMS, -1);   // per camera (point.h)
   const svoh::Vec3& pos() const { return pos_; }
   int id() const { return id_; }
   bool getCloseViewObs(const svoh::Vec3& framepos, FramePtr& ref_frame, size_t& ref_feature_index) const;
@@ -296,13 +299,54 @@ struct Candidate {   // Reprojector::Candidate (reprojector.h)
   FramePtr ref_frame;
   size_t ref_index = 0;
   double cur_px[2] = { 0, 0 };
+  int n_reproj = 0;      // n_succeeded_reproj_ - n_failed_reproj_ of the landmark
   uint8_t type = 0;      // svo::FeatureType of the reference feature when the candidate was made
   double score = 0.0;
+  size_t n_obs = 0;
 };
 struct Statistics { size_t n_matches = 0, n_trials = 0; };
 }  // namespace reprojector
 
+// ReprojectorOptions / Reprojector::reprojectFrames (src/svo/include/svo/reprojector.h:26-165,
+// src/svo/src/reprojector.cpp:27-306): candidate generation from the landmarks and seeds of
+// the visible keyframes, three matchCandidates passes (landmarks, converged seeds, unconverged seeds).  The
+// SVO_GLOBAL_MAP block (fixed landmarks, :51-129) is not compiled in the reference's default build and not mirrored.
+struct ReprojectorOptions {
+  size_t max_n_features_per_frame = 120;
+  size_t cell_size = 30;
+  size_t max_n_kfs = 5;
+  bool reproject_unconverged_seeds = true;
+  double max_unconverged_seeds_ratio = -1.0;
+  size_t min_required_features = 0;
+  double seed_sigma2_thresh = 200;
+  bool remove_unconstrained_points = true;
+  bool affine_est_offset = true;
+  bool affine_est_gain = false;
+};
+
+class ReprojectorHip {
+ public:
+  ReprojectorHip(svoh_ctx* ctx, const ReprojectorOptions& options, size_t camera_index);
+  void reprojectFrames(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points);
+  bool doesFrameHaveEnoughFeatures(const FramePtr& frame) const
+  {
+    return options_.max_n_features_per_frame > 0 && frame->numTrackedFeatures() >= options_.max_n_features_per_frame;
+  }
+  std::unique_ptr<OccupandyGrid2D> grid_;
+  std::vector<reprojector::Candidate> candidates_;
+  reprojector::Statistics stats_;
+  ReprojectorOptions options_;
+ private:
+  svoh_ctx* ctx_;
+  size_t camera_index_;
+};
+
 namespace reprojector_utils {
+// reprojector.cpp:309-339, 489-543
+void sortCandidatesByReprojStats(std::vector<reprojector::Candidate>& candidates);
+bool getCandidate(const FramePtr& cur_frame, const FramePtr& ref_frame, size_t ref_index, reprojector::Candidate& candidate);
+bool projectPointAndCheckVisibility(const FramePtr& frame, const svoh::Vec3& xyz, double* px);
+void setGridCellsOccupied(const std::vector<reprojector::Candidate>& candidates, OccupandyGrid2D& grid);
 // Appends every matched feature to `frame` (px_vec_, f_vec_, grad_vec_, level_vec_, type_vec_, score_vec_,
 // invmu_sigma2_a_b_vec_, landmark_vec_, seed_ref_vec_ at index num_features_, then ++num_features_), updates
 // the seeds of the reference frames and the landmarks' reprojection counters exactly as the sequential

@@ -2,6 +2,7 @@
 // batches + ordered host replay) against the oracle's sequential restatement of the reference loop
 // (src/svo/src/reprojector.cpp:342-486), in the call shape of Reprojector::reprojectFrames (:104-131).
 // Input: a dump written by tests/test_host_cpp_gpu.py.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -211,6 +212,165 @@ int main(int argc, char** argv)
   CHECK(worst_px <= 1e-4 && worst_f <= 1e-6 && worst_g <= 1e-9);
   CHECK(n_kinds[0] > 0 && n_kinds[1] > 0 && n_kinds[2] > 0 && n_kinds[3] > 0 && o_nout > 10);
   if (max_n > 0) CHECK(o_consumed < n);   // the early break was exercised
+  // ================= Reprojector::reprojectFrames (reprojector.cpp:27-306), fresh frames =================
+  {
+    FramePtr kf2 = make_frame(img_kf, T_kf.data(), 17), cur2 = make_frame(img_cur, T_cur.data(), 18), far2 = make_frame(img_kf, T_far.data(), 19);
+    kf2->num_features_ = (size_t)n;
+    kf2->px_vec_ = px; kf2->f_vec_ = fv; kf2->grad_vec_ = grad; kf2->level_vec_ = level; kf2->type_vec_ = type;
+    kf2->invmu_sigma2_a_b_vec_ = state; kf2->seed_mu_range_ = mu_range[0]; kf2->score_vec_ = score;
+    kf2->landmark_vec_.assign(n, nullptr);
+    far2->num_features_ = 1; far2->px_vec_ = { 100, 100 }; far2->f_vec_ = { 0, 0, 1 }; far2->grad_vec_ = { 1, 0 };
+    far2->level_vec_ = { 0 }; far2->type_vec_ = { SVOH_FT_CORNER }; far2->invmu_sigma2_a_b_vec_ = { 1, 1, 10, 10 };
+    std::vector<PointPtr> pts(n);
+    for (int i = 0; i < n; ++i) {
+      if (!lm_kind[i]) continue;
+      PointPtr p(new Point);
+      p->pos_ = { lm_pos[3 * i], lm_pos[3 * i + 1], lm_pos[3 * i + 2] };
+      p->obs_.push_back(Point::Obs{ far2, 0 });
+      if (lm_kind[i] == 1) p->obs_.push_back(Point::Obs{ kf2, (size_t)i });
+      p->n_succeeded_reproj_ = i % 5; p->n_failed_reproj_ = i % 3;
+      kf2->landmark_vec_[i] = p;
+      pts[i] = p;
+    }
+    ReprojectorOptions ro;
+    ro.max_n_features_per_frame = (size_t)(max_n > 0 ? max_n : 220);
+    ro.max_unconverged_seeds_ratio = 0.6;
+    ReprojectorHip reprojector(ctx, ro, 0);
+    std::vector<PointPtr> trash;
+
+    // ---- expected: the same three passes, sequential, with the oracle's matcher ----
+    const int n_cols = OccupandyGrid2D::getNCell(w, 30), n_rows = OccupandyGrid2D::getNCell(h, 30);
+    std::vector<uint8_t> eocc((size_t)n_cols * n_rows, 0);
+    struct Cand { int i; int n_reproj; double score; uint8_t type; double cur_px[2]; };
+    auto project = [&](const double* xyz_w, double* pxo) {
+      double xf[3], tl[3], z0[2] = { 0, 0 };
+      orc_se3_transform(&o_cur.view.T_f_w, xyz_w, xf);
+      orc_back_project3(&cam, z0, tl);
+      const double min_cos = tl[2] / sqrt(tl[0] * tl[0] + tl[1] * tl[1] + tl[2] * tl[2]);
+      if (xf[2] / sqrt(xf[0] * xf[0] + xf[1] * xf[1] + xf[2] * xf[2]) < min_cos) return false;
+      orc_project3(&cam, xf, pxo, nullptr);
+      if (!(pxo[0] >= 0 && pxo[1] >= 0 && pxo[0] < w && pxo[1] < h)) return false;
+      const int a = (int)pxo[0], b = (int)pxo[1];
+      return a >= 8 && b >= 8 && a < w - 8 && b < h - 8;
+    };
+    auto sort_c = [](std::vector<Cand>& v) {
+      std::sort(v.begin(), v.end(), [](const Cand& l, const Cand& r) {
+        return l.type > r.type || (l.type == r.type && l.n_reproj > r.n_reproj) || (l.type == r.type && l.n_reproj == r.n_reproj && l.score > r.score);
+      });
+    };
+    std::vector<double> estate = state;
+    std::vector<uint8_t> etype = type;
+    std::vector<int> e_failed(n, 0), e_succ(n, 0);
+    for (int i = 0; i < n; ++i) if (pts[i]) { e_failed[i] = pts[i]->n_failed_reproj_; e_succ[i] = pts[i]->n_succeeded_reproj_; }
+    int e_numf = 0, e_trials = 0, e_matches = 0, e_trash = 0;
+    std::vector<orc_new_feature> e_new;
+    auto run_pass = [&](std::vector<Cand>& cs, int kind_of, int max_allowed) {
+      sort_c(cs);
+      std::vector<orc_candidate> ocs(cs.size());
+      for (size_t k = 0; k < cs.size(); ++k) {
+        orc_candidate& c = ocs[k];
+        const int i = cs[k].i;
+        memset(&c, 0, sizeof c);
+        c.kind = kind_of; c.cur_px[0] = cs[k].cur_px[0]; c.cur_px[1] = cs[k].cur_px[1];
+        for (int j = 0; j < 2; ++j) { c.px[j] = px[2 * i + j]; c.grad[j] = grad[2 * i + j]; }
+        for (int j = 0; j < 3; ++j) c.f[j] = fv[3 * i + j];
+        for (int j = 0; j < 4; ++j) c.state[j] = estate[4 * i + j];
+        c.level = level[i]; c.type = cs[k].type; c.ref_type = etype[i]; c.score = cs[k].score;
+        if (kind_of == 0) c.depth = 1.0 / estate[4 * i];
+        if (kind_of == 2) {
+          const svoh::Vec3 p = kf2->pos();
+          c.depth = sqrt((p.x - lm_pos[3 * i]) * (p.x - lm_pos[3 * i]) + (p.y - lm_pos[3 * i + 1]) * (p.y - lm_pos[3 * i + 1]) +
+                         (p.z - lm_pos[3 * i + 2]) * (p.z - lm_pos[3 * i + 2]));
+        }
+      }
+      std::vector<uint8_t> vis(cs.size() + 1);
+      std::vector<int32_t> res(cs.size() + 1);
+      std::vector<orc_new_feature> nf(cs.size() + 1);
+      int nout = 0, trials = 0, matches = 0, failed = 0, succ = 0;
+      const int consumed = orc_match_candidates(&mo, &dopt, 1, &o_kf.view, &o_cur.view, (int)cs.size(), ocs.data(), max_allowed, &e_numf, 30, n_cols,
+                                                n_rows, eocc.data(), vis.data(), res.data(), nf.data(), &nout, &trials, &matches, &failed, &succ);
+      e_trials += trials; e_matches += matches;
+      for (size_t k = 0; k < cs.size(); ++k) {
+        const int i = cs[k].i;
+        if (vis[k] && kind_of == 1) { for (int j = 0; j < 4; ++j) estate[4 * i + j] = ocs[k].state[j]; etype[i] = ocs[k].ref_type; }
+        if (vis[k] && kind_of == 2) { if (res[k] == 0) ++e_succ[i]; else ++e_failed[i]; }
+      }
+      for (int k = 0; k < nout; ++k) { nf[k].candidate = cs[nf[k].candidate].i; e_new.push_back(nf[k]); }
+      cs.erase(cs.begin(), cs.begin() + consumed);
+    };
+    auto enough = [&]() { return e_numf >= (int)ro.max_n_features_per_frame; };
+    auto occupy = [&](const std::vector<Cand>& cs) {
+      for (const Cand& c : cs) eocc[(size_t)(floor((double)(int)c.cur_px[1] / 30) * n_cols + floor((double)(int)c.cur_px[0] / 30))] = 1;
+    };
+    bool e_done = false;
+    {
+      std::vector<Cand> cs;
+      for (int i = 0; i < n; ++i) {
+        if (!lm_kind[i]) continue;
+        if (lm_kind[i] == 2) { ++e_trash; continue; }   // one observation only: unconstrained
+        Cand c{ i, e_succ[i] - e_failed[i], score[i], type[i], { 0, 0 } };
+        if (project(&lm_pos[3 * i], c.cur_px)) cs.push_back(c);
+      }
+      run_pass(cs, 2, (int)ro.max_n_features_per_frame);
+      if (enough()) occupy(cs);
+    }
+    auto seed_pass = [&](bool converged) {
+      std::vector<Cand> cs;
+      for (int i = 0; i < n; ++i) {
+        if (lm_kind[i]) continue;
+        const uint8_t t = etype[i];
+        const bool conv = t == SVOH_FT_CORNER_SEED_CONVERGED || t == SVOH_FT_EDGELET_SEED_CONVERGED;
+        const bool unconv = t == SVOH_FT_CORNER_SEED || t == SVOH_FT_EDGELET_SEED;
+        if (!(converged ? conv : unconv)) continue;
+        const double depth = 1.0 / estate[4 * i];
+        const double in_f[3] = { fv[3 * i] * depth, fv[3 * i + 1] * depth, fv[3 * i + 2] * depth };
+        svoh_se3 T_w_f;
+        double xw[3];
+        orc_se3_inverse(&o_kf.view.T_f_w, &T_w_f);
+        orc_se3_transform(&T_w_f, in_f, xw);
+        Cand c{ i, 0, score[i], t, { 0, 0 } };
+        if (project(xw, c.cur_px)) cs.push_back(c);
+      }
+      return cs;
+    };
+    {
+      std::vector<Cand> cs = seed_pass(true);
+      if (enough()) { occupy(cs); e_done = true; }
+      else { run_pass(cs, 0, (int)ro.max_n_features_per_frame); if (enough()) { occupy(cs); e_done = true; } }
+    }
+    if (!e_done) {
+      std::vector<Cand> cs = seed_pass(false);
+      size_t max_allowed_total = ro.max_n_features_per_frame;
+      const size_t alt = (size_t)(e_numf / (1 - ro.max_unconverged_seeds_ratio));
+      if (max_allowed_total > alt) max_allowed_total = alt;
+      run_pass(cs, 1, (int)max_allowed_total);
+      if (enough()) occupy(cs);
+    }
+
+    // ---- the mirror ----
+    reprojector.reprojectFrames(cur2, { kf2 }, trash);
+    CHECK((int)trash.size() == e_trash && e_trash > 0);
+    CHECK((int)reprojector.stats_.n_trials == e_trials && (int)reprojector.stats_.n_matches == e_matches);
+    CHECK((int)cur2->num_features_ == e_numf && e_numf == (int)e_new.size() && e_numf > 20);
+    for (size_t k = 0; k < eocc.size(); ++k) CHECK(reprojector.grid_->isOccupied(k) == (eocc[k] != 0));
+    int kinds[3] = { 0, 0, 0 };
+    for (int s2 = 0; s2 < e_numf; ++s2) {
+      const orc_new_feature& o = e_new[s2];
+      const int i = o.candidate;
+      CHECK(cur2->type_vec_[s2] == o.type && cur2->level_vec_[s2] == o.level);
+      CHECK(fabs(cur2->px_vec_[2 * s2] - o.px[0]) <= 1e-4 && fabs(cur2->px_vec_[2 * s2 + 1] - o.px[1]) <= 1e-4);
+      if (lm_kind[i]) { CHECK(cur2->landmark_vec_[s2] == pts[i]); ++kinds[0]; }
+      else { CHECK(cur2->seed_ref_vec_[s2].keyframe == kf2 && cur2->seed_ref_vec_[s2].seed_id == i); ++kinds[(type[i] == 3 || type[i] == 4) ? 1 : 2]; }
+    }
+    for (int i = 0; i < n; ++i) {
+      CHECK(kf2->type_vec_[i] == etype[i]);
+      for (int j = 0; j < 4; ++j) CHECK(fabs(kf2->invmu_sigma2_a_b_vec_[4 * i + j] - estate[4 * i + j]) <= 1e-9 * fabs(estate[4 * i + j]));
+      if (pts[i]) CHECK(pts[i]->n_failed_reproj_ == e_failed[i] && pts[i]->n_succeeded_reproj_ == e_succ[i]);
+    }
+    printf("reprojectFrames: %d features (%d landmarks, %d converged seeds, %d seed updates), %d trials, %d unconstrained points trashed\n",
+           e_numf, kinds[0], kinds[1], kinds[2], e_trials, e_trash);
+    CHECK(kinds[0] > 0 && (max_n > 0 || (kinds[1] > 0 && kinds[2] > 0)));   // the 220-feature run reaches all three passes
+  }
   svoh_destroy(ctx);
   printf("PASS\n");
   return 0;
