@@ -481,6 +481,71 @@ size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj
   return static_cast<size_t>(last_.n_meas - last_.n_deleted_edges - last_.n_deleted_corners);
 }
 
+void resolveAlignmentPoints(Frame& frame)
+{
+  const size_t n = frame.num_features_;
+  frame.pos_world_.assign(3 * n, 0.0);
+  frame.alignable_.assign(n, 0);
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t t = frame.type_vec_[i];
+    if (t == SVOH_FT_MAPPOINT || t == SVOH_FT_MAPPOINT_SEED || t == SVOH_FT_MAPPOINT_SEED_CONVERGED) continue;
+    svoh::Vec3 p;
+    if (i < frame.landmark_vec_.size() && frame.landmark_vec_[i]) p = frame.landmark_vec_[i]->pos_;
+    else if (i < frame.seed_ref_vec_.size() && frame.seed_ref_vec_[i].keyframe) {
+      const Frame& kf = *frame.seed_ref_vec_[i].keyframe;
+      const size_t k = static_cast<size_t>(frame.seed_ref_vec_[i].seed_id);
+      const double depth = kf.getSeedDepth(k);
+      p = svoh::transform(svoh::inverse(kf.T_f_w_),
+                          svoh::Vec3{ kf.f_vec_[3 * k] * depth, kf.f_vec_[3 * k + 1] * depth, kf.f_vec_[3 * k + 2] * depth });
+    } else continue;
+    frame.alignable_[i] = 1;
+    frame.pos_world_[3 * i] = p.x; frame.pos_world_[3 * i + 1] = p.y; frame.pos_world_[3 * i + 2] = p.z;
+  }
+}
+
+namespace depth_filter_utils {
+void initializeSeeds(const FramePtr& frame, DetectorHip& feature_detector, size_t max_n_seeds, float depth_min, float /*depth_max*/,
+                     float depth_mean)
+{
+  const int max_n_features = static_cast<int>(max_n_seeds) - static_cast<int>(frame->num_features_);
+  if (max_n_features <= 0) return;   // "Skip seed initialization. Have already enough features."
+  const size_t n_old = frame->num_features_;
+  std::vector<double> px, score, grad;
+  std::vector<int32_t> level;
+  std::vector<uint8_t> type;
+  feature_detector.detect(frame->pyramid, nullptr, 0, static_cast<size_t>(max_n_features), px, score, level, grad, type);
+  const size_t n_new = level.size();
+  const size_t n = n_old + n_new;
+  frame->px_vec_.resize(2 * n_old); frame->px_vec_.insert(frame->px_vec_.end(), px.begin(), px.end());
+  frame->grad_vec_.resize(2 * n_old); frame->grad_vec_.insert(frame->grad_vec_.end(), grad.begin(), grad.end());
+  frame->score_vec_.resize(n_old); frame->score_vec_.insert(frame->score_vec_.end(), score.begin(), score.end());
+  frame->level_vec_.resize(n_old); frame->level_vec_.insert(frame->level_vec_.end(), level.begin(), level.end());
+  frame->type_vec_.resize(n_old);
+  for (size_t i = 0; i < n_new; ++i) {
+    if (type[i] == SVOH_FT_CORNER) frame->type_vec_.push_back(SVOH_FT_CORNER_SEED);
+    else if (type[i] == SVOH_FT_EDGELET) frame->type_vec_.push_back(SVOH_FT_EDGELET_SEED);
+    else throw std::runtime_error("initializeSeeds: unknown feature type");   // LOG(FATAL)
+  }
+  frame->f_vec_.resize(3 * n);
+  const svoh::CamModel cm = svoh::load_camera(frame->cam);
+  for (size_t i = n_old; i < n; ++i) {
+    const svoh::Vec3 f = svoh::back_project3(cm, frame->px_vec_[2 * i], frame->px_vec_[2 * i + 1]);
+    const double nn = sqrt(f.x * f.x + f.y * f.y + f.z * f.z);
+    frame->f_vec_[3 * i] = f.x / nn; frame->f_vec_[3 * i + 1] = f.y / nn; frame->f_vec_[3 * i + 2] = f.z / nn;
+  }
+  frame->landmark_vec_.resize(n); frame->seed_ref_vec_.resize(n); frame->track_id_vec_.resize(n, -1);
+  frame->num_features_ = n;
+  frame->seed_mu_range_ = 1.0 / depth_min;                               // getMeanRangeFromDepthMinMax
+  frame->invmu_sigma2_a_b_vec_.resize(4 * n);
+  for (size_t i = n_old; i < n; ++i) {
+    frame->invmu_sigma2_a_b_vec_[4 * i] = 1.0 / depth_mean;              // getMeanFromDepth
+    frame->invmu_sigma2_a_b_vec_[4 * i + 1] = frame->seed_mu_range_ * frame->seed_mu_range_ / 36.0;   // getInitSigma2FromMuRange
+    frame->invmu_sigma2_a_b_vec_[4 * i + 2] = 10.0;
+    frame->invmu_sigma2_a_b_vec_[4 * i + 3] = 10.0;
+  }
+}
+}  // namespace depth_filter_utils
+
 double updateSeedPxErrorAngle(const Frame& cur_frame)
 {
   // static double px_error_angle = cur_frame.getAngleError(1.0);  (depth_filter.cpp:383-384,

@@ -94,6 +94,10 @@ struct SolverOptions {
   double eps = 0.0005;
 };
 
+// Fills Frame::pos_world_ / alignable_ the way sparse_img_align.cpp:239-245 and :281-292 resolve them: the
+// landmark's position, or the seed's position via seed_ref_vec_; neither, or a map point -> not alignable.
+void resolveAlignmentPoints(Frame& frame);
+
 class SparseImgAlignHip {
  public:
   using Ptr = std::shared_ptr<SparseImgAlignHip>;
@@ -145,6 +149,15 @@ struct DepthFilterOptions {
   bool affine_est_gain = false;
   bool use_threaded_depthfilter = false;  // must stay false: the threaded variant races
 };
+
+class DetectorHip;
+namespace depth_filter_utils {
+// depth_filter_utils::initializeSeeds (depth_filter.cpp:255-365): detect features in the free cells of the
+// detector's grid (the caller has marked the occupied ones) and append them to the frame as seeds with
+// mu = 1 / depth_mean, sigma2 = mu_range^2 / 36, a = b = 10, mu_range = 1 / depth_min (seed.h:130-145)
+void initializeSeeds(const FramePtr& frame, DetectorHip& feature_detector, size_t max_n_seeds, float depth_min, float depth_max,
+                     float depth_mean);
+}  // namespace depth_filter_utils
 
 class DepthFilterHip {
  public:

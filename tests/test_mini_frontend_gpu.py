@@ -1,0 +1,75 @@
+"""Integration: the per-frame chain of FrameHandlerMono::processFrame assembled from this library's mirrors
+(tools/svoh_mini_frontend.cpp: sparse alignment -> reprojection -> pose optimisation -> depth filter, detector and
+seed initialisation at keyframes) on a synthetic EuRoC-layout sequence, against the scene's ground-truth trajectory.
+No reference output exists to compare with; the bar is the trajectory error."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from svo_pro_universal_amd import synth
+from test_io_cpu import write_png
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+def test_mini_frontend_tracks_a_synthetic_sequence(tmp_path):
+    import ate
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host")])
+    cam = synth.Camera.euroc_like(752, 480)
+    sc = synth.make_align_scene(160, n_features=8, cam=cam, rot_deg=(0.3, 0.5), trans_m=(0.015, 0.025))
+    step = sc.T_w_ref.inverse() * sc.T_w_cur
+    n_frames = 40
+    poses = [sc.T_w_ref]
+    for k in range(1, n_frames):
+        poses.append(poses[-1] * step)
+    data = tmp_path / "ds" / "mav0" / "cam0" / "data"
+    data.mkdir(parents=True)
+    stamps = [1403636579763555584 + 50000000 * k for k in range(n_frames)]
+    for k, T in enumerate(poses):
+        write_png(str(data / ("%d.png" % stamps[k])), synth.render(cam, T, sc.plane, sc.tex), chunk=65536)
+    (tmp_path / "ds" / "mav0" / "cam0" / "data.csv").write_text("#timestamp [ns],filename\n" + "".join("%d,%d.png\n" % (t, t) for t in stamps))
+    (tmp_path / "calib.yaml").write_text("""cameras:
+- camera:
+    label: cam0
+    image_height: %d
+    image_width: %d
+    type: pinhole
+    intrinsics:
+      data: [%.17g, %.17g, %.17g, %.17g]
+    distortion:
+      type: radial-tangential
+      parameters:
+        data: [%.17g, %.17g, %.17g, %.17g]
+  T_B_C:
+    data: [1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+""" % ((cam.height, cam.width, cam.fx, cam.fy, cam.cx, cam.cy) + tuple(cam.dist)))
+    (tmp_path / "params.yaml").write_text("max_fts: 180\ngrid_size: 30\nn_pyr_levels: 3\ndetector_threshold_secondary: 100\n"
+                                          "use_threaded_depthfilter: False\nimg_align_max_level: 4\nimg_align_min_level: 2\n")
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    d = float(np.mean(sc.depth))
+    T0 = poses[0].inverse().as7()
+    tool = os.path.join(ROOT, "svo_pro_universal_amd", "host", "svoh_mini_frontend")
+    r = subprocess.run([tool, str(tmp_path / "ds"), str(tmp_path / "calib.yaml"), str(tmp_path / "params.yaml"), str(out_dir)]
+                       + ["%.17g" % v for v in T0] + ["%.6f" % (0.5 * d), "%.6f" % d, "%.6f" % (2.0 * d)],
+                       capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    est = ate.load_tum(str(out_dir / "trajectory.txt"))
+    gt = np.array([[stamps[k] * 1e-9] + list(T.t) + [T.q[1], T.q[2], T.q[3], T.q[0]] for k, T in enumerate(poses)])
+    res = ate.ate(est, gt, with_scale=True, max_dt=1e-3)
+    path_len = float(np.linalg.norm(np.diff(gt[:, 1:4], axis=0), axis=1).sum())
+    fc = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)
+    print("ATE rmse %.4f m over a %.3f m path (scale %.3f); reprojected features per frame: median %d; converged seeds at the end: %d"
+          % (res["rmse"], path_len, res["scale"], int(np.median(fc[1:, 3])), int(fc[-1, 6])))
+    assert res["n"] == n_frames
+    assert res["rmse"] < 0.03 * path_len + 0.003          # a few per cent of the distance travelled
+    assert 0.8 < res["scale"] < 1.25                      # the depth prior fixes the scale
+    assert np.median(fc[1:, 3]) > 80                      # the reprojector keeps enough features alive
+    assert fc[-1, 6] > 100                                # seeds converge
+    assert fc[:, 1].sum() >= 4                            # several keyframes were made

@@ -1,0 +1,155 @@
+// svoh_mini_frontend -- the per-frame chain of FrameHandlerMono::processFrame (src/svo/src/frame_handler_mono.cpp,
+// frame_handler_base.cpp:610-825) assembled from this library's mirrors, on an EuRoC-layout image sequence:
+//
+//   sparse image alignment (last frame -> new frame)            SparseImgAlignHip::run
+//   reprojection of the keyframes' landmarks / seeds            ReprojectorHip::reprojectFrames
+//   pose optimisation on the matched features                   PoseOptimizerHip::run
+//   depth-filter update of the keyframes' seeds                 DepthFilterHip::updateSeeds
+//   at keyframes: feature detection + seed initialisation       DetectorHip + depth_filter_utils::initializeSeeds
+//
+// It is an integration harness, NOT the reference's frame handler: there is no map, no initialiser (the first
+// pose and a depth prior are given), no structure optimisation, no relocalisation, and keyframes are chosen by a
+// fixed rule (every <kf_every> frames or when fewer than <min_tracked> features survive).
+//
+//   svoh_mini_frontend <dataset_root> <calib.yaml> <params.yaml|-> <out_dir> <T_f_w of frame 0: qw qx qy qz tx ty tz>
+//                      <depth_min> <depth_mean> <depth_max> [max_frames] [kf_every]
+// Writes <out>/trajectory.txt (TUM format, T_world_cam) and <out>/frontend.csv (per-frame counters and timings).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <stdexcept>
+#include <string>
+
+#include "../svo_pro_universal_amd/host/svo_hip_io.h"
+
+using namespace svo_hip;
+
+static double now_ms()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char** argv)
+{
+  if (argc < 15) {
+    fprintf(stderr, "usage: %s <dataset_root> <calib.yaml> <params.yaml|-> <out_dir> qw qx qy qz tx ty tz depth_min depth_mean depth_max [max_frames] [kf_every]\n", argv[0]);
+    return 2;
+  }
+  try {
+    const io::EurocSequence seq = io::openEuroc(argv[1]);
+    const std::vector<io::RigCamera> rig = io::loadCameraRig(argv[2]);
+    io::FrontendParams params = std::string(argv[3]) == "-" ? io::frontendParamsFromYaml(io::YamlNode()) : io::loadFrontendParams(argv[3]);
+    const std::string out_dir = argv[4];
+    Transformation T0{ { atof(argv[5]), atof(argv[6]), atof(argv[7]), atof(argv[8]) }, { atof(argv[9]), atof(argv[10]), atof(argv[11]) } };
+    const float depth_min = (float)atof(argv[12]), depth_mean = (float)atof(argv[13]), depth_max = (float)atof(argv[14]);
+    const size_t max_frames = argc > 15 ? (size_t)atol(argv[15]) : seq.size();
+    const size_t kf_every = argc > 16 ? (size_t)atol(argv[16]) : 8;
+    const size_t min_tracked = 60;
+    svoh_ctx* ctx = nullptr;
+    if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
+    const svoh_camera& cam = rig.at(0).cam;
+
+    params.depth_filter.use_threaded_depthfilter = false;   // the synchronous path
+    SparseImgAlignHip img_align(ctx, SparseImgAlignHip::getDefaultSolverOptions(), params.img_align);
+    ReprojectorOptions ropt;
+    ropt.max_n_features_per_frame = (size_t)params.max_fts;
+    ropt.cell_size = (size_t)params.grid_size;
+    ropt.seed_sigma2_thresh = params.seed_sigma2_thresh;
+    ropt.affine_est_offset = params.reprojector_affine_est_offset;
+    ropt.affine_est_gain = params.reprojector_affine_est_gain;
+    ReprojectorHip reprojector(ctx, ropt, 0);
+    PoseOptimizerHip pose_optimizer(ctx);
+    DepthFilterHip depth_filter(ctx, params.depth_filter);
+    DetectorHip detector(ctx, params.detector, cam.width, cam.height);
+
+    io::TrajectoryWriter traj(out_dir + "/trajectory.txt");
+    FILE* fc = fopen((out_dir + "/frontend.csv").c_str(), "w");
+    if (!fc) throw std::runtime_error("cannot write into " + out_dir);
+    fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_converged_seeds,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf\n");
+
+    std::deque<FramePtr> kfs;   // the last reprojector.max_n_kfs keyframes
+    FramePtr last;
+    auto make_keyframe = [&](const FramePtr& f) {
+      detector.resetGrid();
+      detector.fillGridWithKeypoints(f->px_vec_, f->num_features_);
+      const size_t n_old = f->num_features_;
+      depth_filter_utils::initializeSeeds(f, detector, (size_t)params.max_n_seeds_per_frame, depth_min, depth_max, depth_mean);
+      // bootstrap stand-in for the initialiser's landmarks: a keyframe's own new seeds are usable for the
+      // alignment of the next frame at their current depth estimate (self reference)
+      for (size_t i = n_old; i < f->num_features_; ++i) { f->seed_ref_vec_[i].keyframe = f; f->seed_ref_vec_[i].seed_id = (int)i; }
+      kfs.push_back(f);
+      while (kfs.size() > ropt.max_n_kfs) {
+        for (auto& sr : kfs.front()->seed_ref_vec_) sr.keyframe.reset();   // break the self references
+        kfs.pop_front();
+      }
+    };
+    double sum_ms = 0;
+    size_t n_done = 0;
+    for (size_t k = 0; k < seq.size() && k < max_frames; ++k) {
+      const io::GrayImage img = io::readPngGray(seq.cam0_files[k]);
+      const double t0 = now_ms();
+      FramePtr frame(new Frame, [ctx](Frame* f) { if (f->pyramid) svoh_release_frame(ctx, f->pyramid); delete f; });
+      if (svoh_build_pyramid(ctx, img.data.data(), img.width, img.height, img.width, SVOH_MEM_HOST, params.n_pyr_levels_to_build,
+                             SVOH_HALFSAMPLE_REFERENCE, nullptr, &frame->pyramid) != SVOH_OK)
+        throw std::runtime_error(std::string("svoh_build_pyramid: ") + svoh_last_error_string(ctx));
+      frame->cam = cam;
+      frame->set_T_cam_imu(svoh::inverse(rig[0].T_B_C));
+      frame->id_ = (int)k;
+      const double t1 = now_ms();
+      size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0;
+      double t2 = t1, t3 = t1, t4 = t1, t5 = t1;
+      bool is_kf = false;
+      if (k == 0) {
+        frame->T_f_w_ = T0;
+        make_keyframe(frame);
+        is_kf = true;
+        t2 = t3 = t4 = t5 = now_ms();
+      } else {
+        // 1. sparse image alignment against the last frame (frame_handler_base.cpp:610-643)
+        frame->T_f_w_ = last->T_f_w_;
+        resolveAlignmentPoints(*last);
+        FrameBundle::Ptr b_last(new FrameBundle), b_cur(new FrameBundle);
+        b_last->frames_.push_back(last); b_cur->frames_.push_back(frame);
+        img_align.reset();
+        n_aligned = img_align.run(b_last, b_cur);
+        t2 = now_ms();
+        // 2. reprojection (frame_handler_base.cpp:645-744)
+        std::vector<FramePtr> visible(kfs.begin(), kfs.end());
+        std::vector<PointPtr> trash;
+        reprojector.reprojectFrames(frame, visible, trash);
+        n_reproj = frame->num_features_;
+        t3 = now_ms();
+        // 3. pose optimisation (frame_handler_base.cpp:746-790)
+        if (frame->num_features_ >= 10) n_pose = pose_optimizer.run(b_cur, 2.0);
+        t4 = now_ms();
+        // 4. depth filter (frame_handler_mono.cpp:125)
+        n_seed_upd = depth_filter.updateSeeds(visible, frame);
+        t5 = now_ms();
+        // 5. keyframe rule
+        if (k % kf_every == 0 || frame->numTrackedFeatures() < min_tracked) { make_keyframe(frame); is_kf = true; }
+      }
+      const double t6 = now_ms();
+      size_t n_conv = 0;
+      for (const FramePtr& f : kfs)
+        for (size_t i = 0; i < f->num_features_; ++i)
+          n_conv += f->type_vec_[i] == SVOH_FT_CORNER_SEED_CONVERGED || f->type_vec_[i] == SVOH_FT_EDGELET_SEED_CONVERGED;
+      traj.write(seq.cam_ts[k], svoh::inverse(frame->T_f_w_));
+      fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", k, (int)is_kf, n_aligned, n_reproj, n_pose, n_seed_upd, n_conv,
+              t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5);
+      if (k > 0) { sum_ms += t6 - t0; ++n_done; }
+      last = frame;
+    }
+    fclose(fc);
+    printf("svoh_mini_frontend: %zu frames, %.3f ms/frame on the GPU path, %zu keyframes alive\n", n_done + 1, n_done ? sum_ms / n_done : 0.0,
+           kfs.size());
+    for (const FramePtr& f : kfs) for (auto& sr : f->seed_ref_vec_) sr.keyframe.reset();
+    if (last) for (auto& sr : last->seed_ref_vec_) sr.keyframe.reset();
+    kfs.clear(); last.reset();
+    svoh_destroy(ctx);
+    return 0;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "svoh_mini_frontend: %s\n", e.what());
+    return 1;
+  }
+}
