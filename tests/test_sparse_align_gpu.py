@@ -176,6 +176,16 @@ def test_all_workgroup_geometries(gpu_ctx, oracle_lib, nt, monkeypatch):
         opt = capi.default_align_options(min_level=0)
         check_evaluate(gpu_ctx, orc, opt, opb, gpb, (4, 1, 0))
         check_run(gpu_ctx, orc, opt, opb, gpb)
+    # 8x8 patches, illumination terms, stereo and a radtan camera through the same geometry (the 256-thread one
+    # brings the workspace rows in by LDS-DMA and reads 11- / 9-pixel footprint rows as 16-byte loads)
+    monkeypatch.setenv("SVOH_ALIGN_LDS", "38400")
+    a = helpers.small_scene(41, n=400, P=8, border_features=30)
+    b = synth.make_align_scene(42, n_features=333, patch_size=8, cam=synth.Camera.euroc_like(), border_features=10, gain=1.05, offset=4.0)
+    opb2, gpb2, keep2 = both(gpu_ctx, orc, [a, b])
+    for kw in (dict(), dict(estimate_illumination_gain=1, estimate_illumination_offset=1), dict(robustification=1)):
+        opt = capi.default_align_options(min_level=0, patch_size=8, **kw)
+        check_evaluate(gpu_ctx, orc, opt, opb2, gpb2, (3, 0))
+        check_run(gpu_ctx, orc, opt, opb2, gpb2)
 
 
 def test_device_resident_inputs(gpu_ctx, oracle_lib):
