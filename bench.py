@@ -582,13 +582,152 @@ def bench_pose(args, ctx, dist, rank, world, dev, comm_dev=None):
             "cpu_baseline": cpu}
 
 
+def bench_align_split(args, ctx, dist, rank, world, dev, comm_dev=None):
+    """SURVEY.md 8(e) second row / BASELINE config 5's collective: ONE frame pair, its N patches split over the
+    ranks, every Gauss-Newton iteration = partial normal equations per rank -> all-reduce of 74 doubles (RCCL) ->
+    identical update on every rank.  Strong scaling (the problem is fixed); latency-bound by construction, the
+    per-iteration breakdown says where the crossover against the resident single-GPU kernel lies."""
+    import torch.distributed as tdist
+    from svo_pro_universal_amd import split_align
+    P, N = args.patch, args.features
+    opt = capi.default_align_options(max_level=args.max_level, min_level=args.min_level, patch_size=P)
+    cam = synth.Camera.test_camera()
+    sc = synth.make_align_scene(du.problem_seed(0, 900), n_features=N, patch_size=P, cam=cam, max_level=args.max_level,
+                                render_images=False)   # the same scene on every rank
+    imgs = synth.render_batch_torch(cam, [sc.T_w_ref, sc.T_w_cur], [sc.plane] * 2, [sc.tex] * 2, dev)
+    torch.cuda.synchronize()
+    frames = ctx.build_pyramid_batch_device(imgs.data_ptr(), cam.width * cam.height, 2, cam.width, cam.height,
+                                            cam.width, args.max_level + 1)
+    ctx.synchronize()
+    px, f = torch.from_numpy(sc.px).to(dev), torch.from_numpy(sc.f).to(dev)
+    pw, fl = torch.from_numpy(sc.pos_world).to(dev), torch.from_numpy(sc.flags).to(dev)
+
+    def problem_of(lo, hi):
+        import copy
+        share = copy.copy(sc)
+        share.n_features = hi - lo
+        dp = dict(px=px.data_ptr() + 16 * lo, f=f.data_ptr() + 24 * lo, pos_world=pw.data_ptr() + 24 * lo,
+                  flags=fl.data_ptr() + lo)
+        return fe.make_align_problems([[(share, frames[0], frames[1], dp)]])
+
+    lo, hi = du.shard_range(sc.n_features, rank, world)
+    mine, keep_m = problem_of(lo, hi)
+    whole, keep_w = problem_of(0, sc.n_features)
+    d_state = torch.zeros(ctypes.sizeof(capi.svoh_align_gn_state) // 8, dtype=torch.float64, device=dev)
+    d_sums = torch.zeros(capi.SVOH_ALIGN_SUMS_DOUBLES, dtype=torch.float64, device=dev)
+    own_group = False
+    if world == 1 and not tdist.is_initialized():
+        # a one-rank RCCL group, so that the all-reduce's launch floor is part of the single-GPU number too
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29731")
+        tdist.init_process_group(os.environ.get("SVOH_BENCH_BACKEND", "nccl"), rank=0, world_size=1)
+        own_group = True
+    t_part, t_red, t_upd = [0.0], [0.0], [0.0]
+
+    def all_reduce():
+        t0 = time.perf_counter()
+        if tdist.get_backend() == "gloo":   # one-GPU rehearsal only: gloo sums on the host
+            h = d_sums.cpu()
+            tdist.all_reduce(h)
+            d_sums.copy_(h)
+        else:
+            tdist.all_reduce(d_sums)
+        torch.cuda.synchronize()
+        t_red[0] += time.perf_counter() - t0
+
+    def one_run():
+        ctx.split_init(mine[0], d_state.data_ptr())
+
+        def partial(level):
+            t0 = time.perf_counter()
+            ctx.partial_sums(opt, mine[0], level, d_state.data_ptr(), d_sums.data_ptr())
+            ctx.synchronize()
+            t_part[0] += time.perf_counter() - t0
+
+        def update(level, it):
+            t0 = time.perf_counter()
+            st = ctx.gn_update(opt, mine[0], level, it, d_sums.data_ptr(), d_state.data_ptr())
+            t_upd[0] += time.perf_counter() - t0
+            return st
+
+        return split_align.gauss_newton_split(opt.max_level, opt.min_level, opt.max_iter, partial, all_reduce, update), 0.0
+
+    for _ in range(max(1, args.warmup)):   # also creates the communicator: not part of the per-iteration figures
+        one_run()
+    t_part[0] = t_red[0] = t_upd[0] = 0.0
+    elapsed, _, res = timed_steps(ctx, dist, world, dev, one_run, args.steps, 0)
+    n_runs = args.steps
+    iters = res.n_evaluations
+    n_meas_last = res.n_meas[opt.min_level]
+    elapsed, _ = du.combine(dist, world, elapsed, 0, comm_dev)
+    # the same problem, unsplit, in the resident kernel on this GPU (what the split has to beat)
+    kms = ctypes.c_float()
+    wres = None
+    for _ in range(3):
+        wres = ctx.sparse_align(opt, whole)[0]
+    t0 = time.perf_counter()
+    for _ in range(10):
+        wres = ctx.sparse_align(opt, whole)[0]
+    resident_call_ms = (time.perf_counter() - t0) / 10 * 1e3
+    ctx.lib.svoh_sparse_align_last_kernel_ms(ctx.h, ctypes.byref(kms))
+    Ts = synth.SE3.from7(fe.se3_to_numpy(res.state.T_icur_iref))
+    err = synth.se3_error(Ts, sc.T_icur_iref_gt)
+    dvs = synth.se3_error(Ts, synth.SE3.from7(fe.se3_to_numpy(wres.T_icur_iref)))
+    if own_group:
+        tdist.destroy_process_group()
+    if rank != 0:
+        return None
+    per_it = lambda t: 1e6 * t[0] / (n_runs * iters)
+    ms_run = 1e3 * elapsed / args.steps
+    D = 6
+    patch_iters = sum(res.iters[l] * res.n_meas[l] // (P * P) for l in range(capi.SVOH_MAX_LEVELS))
+    alg = algorithmic_bytes(P, D, patch_iters, 0)
+    return {"metric": "aligned patches/s, one frame pair split over the GPUs (all-reduce of the normal equations per iteration)",
+            "value": wres.n_fts_to_track / (ms_run * 1e-3), "unit": "aligned patches/s", "ms_per_step": ms_run,
+            "ms_per_frame": ms_run, "dtype": "f64", "scaling": "strong",
+            "config": {"workload": "SparseImgAlign, ONE synthetic 640x480 frame pair, %d patches x %dx%d, levels %d..%d, "
+                                   "patches split over %d rank(s), 74-double all-reduce per iteration" %
+                                   (sc.n_features, P, P, args.max_level, args.min_level, world),
+                       "patches": sc.n_features, "patch_size": P, "levels": [args.max_level, args.min_level],
+                       "parallelism": "patch-split x%d, RCCL all-reduce 592 B per iteration" % world},
+            "iterations": iters, "iterations_per_level": res.iters[:args.max_level + 1],
+            "per_iteration_us": {"partial_sums": per_it(t_part), "all_reduce": per_it(t_red), "gn_update": per_it(t_upd)},
+            "resident_single_gpu": {"kernel_ms": kms.value, "blocking_call_ms": resident_call_ms,
+                                    "iterations": sum(wres.iters)},
+            "pose_err_vs_gt": {"rot_rad": err[0], "trans_m": err[1]},
+            "pose_diff_vs_resident": {"rot_rad": dvs[0], "trans_m": dvs[1]},
+            "roofline": {"bound": "hbm", "achieved": alg / (ms_run * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (ms_run * 1e-3) / 1e9 / HBM_PEAK_GBS / world, "traffic": None,
+                         "kernel": "sparse_align_kernel (evaluate mode) + all-reduce + align_gn_update_kernel, whole run",
+                         "algorithmic_bytes_per_launch": alg},
+            "cpu_baseline": None}
+
+
+_JSON_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when a communicator is
+    created, and libraries may add their own chatter: send everything to stderr and keep the real stdout for
+    the result line."""
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(obj):
+    sys.stdout.flush()
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(obj) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--problems", type=int, default=0, help="frame pairs per GPU per step (default: per workload)")
-    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds", "frame", "detect", "pose"],
+    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds", "frame", "detect", "pose", "align-split"],
                     help="align = the headline SparseImgAlign config (default); klt / seeds = the other hot-path rows; "
                          "frame = the whole per-frame chain at EuRoC mono sizes, one frame at a time (latency)")
     ap.add_argument("--features", type=int, default=2000)
@@ -597,6 +736,7 @@ def main():
     ap.add_argument("--max-level", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    claim_stdout()
 
     rank, local_rank, world = du.env_world()
     # Rehearsal knobs for a one-GPU box (never set by the driver): all ranks on cuda:0 and gloo for the
@@ -615,12 +755,14 @@ def main():
 
     ctx = fe.Context(local_rank)
     if args.workload != "align":
-        out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame, "detect": bench_detect, "pose": bench_pose}[args.workload](
+        out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame, "detect": bench_detect, "pose": bench_pose,
+               "align-split": bench_align_split}[args.workload](
             args, ctx, dist, rank, world, dev, comm_dev)
         if rank == 0:
+            out.setdefault("scaling", "weak")
             out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
-                        "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
-            print(json.dumps(out))
+                        "vs_baseline": None, "data": "synthetic"})
+            emit(out)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -702,7 +844,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scenes, imgs, opt, args.max_level)
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

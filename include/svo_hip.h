@@ -239,6 +239,61 @@ int svoh_sparse_align_evaluate(svoh_ctx* ctx, const svoh_align_options* options,
                                int32_t* n_meas, uint8_t* visibility,
                                int32_t* n_selected);
 
+/* ---- patch-split Gauss-Newton (second row) -------------- */
+
+/* One alignment problem whose patches are split over several GPUs (or several
+ * contexts): every participant holds the same frames and a share of the
+ * features, computes the normal equations of its share at the common state,
+ * the 74 doubles are summed over the participants (RCCL all-reduce of the
+ * caller's device buffer), and every participant then applies the identical
+ * update.  The reference already sums per-camera contributions into one H
+ * (sparse_img_align.cpp:138-154); this extends the same sum across devices.
+ * The state lives in DEVICE memory owned by the caller. */
+typedef struct svoh_align_gn_state {
+  svoh_se3 T_icur_iref;      /* current estimate (model of the GN solver) */
+  double alpha, beta;
+  svoh_se3 T_old;            /* state before the last update: restored when the solve fails */
+  double alpha_old, beta_old;
+  double I_prior[8];         /* prior information, fixed at iteration 0 of a level (applyPrior) */
+  double chi2;               /* chi2 / n_meas of the sums the last update consumed */
+  int32_t n_meas;            /* residuals in those sums */
+  int32_t stop;              /* sticky: the solver met a NaN (mini_least_squares_solver.hpp:73-82) */
+  int32_t level_done;        /* the last update converged (or stopped): leave the level */
+  int32_t status;            /* as svoh_align_result.status */
+} svoh_align_gn_state;
+
+#define SVOH_ALIGN_SUMS_DOUBLES 74   /* H 8x8 column-major, g[8], sum of w*res^2, number of residuals */
+
+/* Context-owned device buffers for one split run (a state and SVOH_ALIGN_SUMS_DOUBLES
+ * doubles), for hosts that have no device allocator of their own; valid until
+ * svoh_destroy.  Callers with their own device memory may pass that instead. */
+int svoh_sparse_align_split_buffers(svoh_ctx* ctx, svoh_align_gn_state** d_state, double** d_sums);
+
+/* Write the problem's initial state (T_icur_iref, alpha_init, beta_init) to d_state. */
+int svoh_sparse_align_split_init(svoh_ctx* ctx, const svoh_align_problem* problem,
+                                 svoh_align_gn_state* d_state);
+
+/* SparseImgAlign::evaluateError (sparse_img_align.cpp:115-156) over THIS participant's
+ * features at the state in d_state, on a fresh level (caches rebuilt):
+ * d_sums[0..63] = H, [64..71] = g, [72] = sum of weighted squared residuals
+ * (not yet divided), [73] = number of residuals.  The features are spread over
+ * n_workgroups workgroups of this GPU (0 = about 256 patches each), whose blocks
+ * are added in a fixed order.  Both pointers are device memory; the work is queued on the context stream and the call does not
+ * block (svoh_synchronize before handing d_sums to another stream). */
+int svoh_sparse_align_partial_sums(svoh_ctx* ctx, const svoh_align_options* options,
+                                   const svoh_align_problem* problem, int level, int n_workgroups,
+                                   const svoh_align_gn_state* d_state, double* d_sums);
+
+/* One iteration of MiniLeastSquaresSolver::optimizeGaussNewton
+ * (mini_least_squares_solver.hpp:42-107) on the summed normal equations:
+ * applyPrior, pivoted LDLT, update, convergence test -- the same device code
+ * the resident kernel runs.  iter = 0 starts a level.  Blocks; *h_state (may be
+ * NULL) receives a copy of the updated state. */
+int svoh_sparse_align_gn_update(svoh_ctx* ctx, const svoh_align_options* options,
+                                const svoh_align_problem* problem, int level, int iter,
+                                const double* d_sums, svoh_align_gn_state* d_state,
+                                svoh_align_gn_state* h_state);
+
 /* ---- KLT feature alignment (a-9) -------------------------------------- */
 
 /* FeatureTrackerOptions klt_* (src/svo_tracker/include/svo/tracker/feature_tracking_types.h:15-29) */

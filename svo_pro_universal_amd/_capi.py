@@ -69,6 +69,16 @@ class svoh_align_result(C.Structure):
                 ("chi2", C.c_double * SVOH_MAX_LEVELS), ("n_patch_iters", C.c_int64)]
 
 
+class svoh_align_gn_state(C.Structure):
+    _fields_ = [("T_icur_iref", svoh_se3), ("alpha", C.c_double), ("beta", C.c_double),
+                ("T_old", svoh_se3), ("alpha_old", C.c_double), ("beta_old", C.c_double),
+                ("I_prior", C.c_double * 8), ("chi2", C.c_double), ("n_meas", C.c_int32), ("stop", C.c_int32),
+                ("level_done", C.c_int32), ("status", C.c_int32)]
+
+
+SVOH_ALIGN_SUMS_DOUBLES = 74
+
+
 class svoh_klt_options(C.Structure):
     _fields_ = [("max_level", C.c_int32), ("min_level", C.c_int32), ("patch_sizes", C.c_int32 * SVOH_MAX_LEVELS),
                 ("max_iter", C.c_int32), ("min_update_squared", C.c_float), ("reserved", C.c_int32)]
@@ -246,6 +256,7 @@ EXPORTS = [
     "svoh_download_level", "svoh_frame_info", "svoh_release_frame",
     "svoh_sparse_align_batch", "svoh_sparse_align_enqueue", "svoh_sparse_align_fetch",
     "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms",
+    "svoh_sparse_align_split_buffers", "svoh_sparse_align_split_init", "svoh_sparse_align_partial_sums", "svoh_sparse_align_gn_update",
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
     "svoh_match_direct_batch",
     "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex",
@@ -317,6 +328,12 @@ def load():
                                                C.c_int, C.c_void_p, C.c_void_p, P(C.c_double),
                                                P(C.c_int32), C.c_void_p, P(C.c_int32)]
     lib.svoh_sparse_align_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float)]
+    lib.svoh_sparse_align_split_buffers.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_void_p)]
+    lib.svoh_sparse_align_split_init.argtypes = [C.c_void_p, P(svoh_align_problem), C.c_void_p]
+    lib.svoh_sparse_align_partial_sums.argtypes = [C.c_void_p, P(svoh_align_options), P(svoh_align_problem), C.c_int,
+                                                   C.c_int, C.c_void_p, C.c_void_p]
+    lib.svoh_sparse_align_gn_update.argtypes = [C.c_void_p, P(svoh_align_options), P(svoh_align_problem), C.c_int,
+                                                C.c_int, C.c_void_p, C.c_void_p, P(svoh_align_gn_state)]
     lib.svoh_klt_track_batch.argtypes = [C.c_void_p, P(svoh_klt_options), C.c_int, C.c_void_p, svoh_frame_t,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svoh_klt_track_multi.argtypes = [C.c_void_p, P(svoh_klt_options), C.c_int, C.c_void_p, C.c_void_p,

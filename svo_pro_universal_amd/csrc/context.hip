@@ -213,6 +213,7 @@ int svoh_create(int device, svoh_ctx** out_ctx)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev_align_start);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev_align_stop);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_align_staged, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev_misc_start);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev_misc_stop);
   hipDeviceProp_t prop;
@@ -236,6 +237,7 @@ int svoh_destroy(svoh_ctx* ctx)
   ctx->frames.clear();
   if (ctx->ev_align_start) (void)hipEventDestroy(ctx->ev_align_start);
   if (ctx->ev_align_stop) (void)hipEventDestroy(ctx->ev_align_stop);
+  if (ctx->ev_align_staged) (void)hipEventDestroy(ctx->ev_align_staged);
   if (ctx->ev_misc_start) (void)hipEventDestroy(ctx->ev_misc_start);
   if (ctx->ev_misc_stop) (void)hipEventDestroy(ctx->ev_misc_stop);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -76,6 +76,9 @@ struct AlignKernelArgs {
   long long* stamps;                    // diagnostic builds only (SVOH_PHASE_STAMPS): 8 per problem
   int32_t n_problems;
   int32_t* queue;                       // work queue head: workgroups pull problem indices from it
+  // patch-split mode: evaluate at a caller-owned device state, hand out the undivided sums
+  const svoh_align_gn_state* ext_state;
+  int32_t raw_sums;
 };
 
 #ifndef SVOH_ROW_UNROLL
@@ -622,17 +625,18 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
       res.chi2[level] = chi2;
     }
     if (eval_mode) {
+      double* eo = a.eval_out + 74 * pbi;   // one block per problem (the shares of a patch-split evaluation)
 #pragma unroll
       for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int c2 = 0; c2 <= r; ++c2) {
-          a.eval_out[c2 * 8 + r] = SVOH_L(r, c2);
-          a.eval_out[r * 8 + c2] = SVOH_L(r, c2);
+          eo[c2 * 8 + r] = SVOH_L(r, c2);
+          eo[r * 8 + c2] = SVOH_L(r, c2);
         }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) a.eval_out[64 + k] = xg[k];
-      a.eval_out[72] = chi2;
-      a.eval_out[73] = (double)n_meas;
+      for (int k = 0; k < 8; ++k) eo[64 + k] = xg[k];
+      eo[72] = a.raw_sums ? s_sum[NH + D] : chi2;
+      eo[73] = (double)n_meas;
       s.level_done = 1;
     } else {
       if (pb.prior.have_prior) {
@@ -749,6 +753,11 @@ void sparse_align_kernel(const AlignKernelArgs a)
     s.T = load_rigid(pb.T_init);
     s.Told = s.T;
     s.alpha = pb.alpha_init; s.beta = pb.beta_init;
+    if (a.ext_state) {
+      s.T = load_rigid(a.ext_state->T_icur_iref);
+      s.Told = s.T;
+      s.alpha = a.ext_state->alpha; s.beta = a.ext_state->beta;
+    }
     s.alpha_old = s.alpha; s.beta_old = s.beta;
     s.stop = 0; s.level_done = 0; s.nsel = 0; s.status = 0; s.patch_iters = 0;
     for (int k = 0; k < 8; ++k) s.I_prior[k] = 0.0;
@@ -827,7 +836,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
       r.alpha = s.alpha; r.beta = s.beta;
       r.n_patch_iters = 0;
       for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = 0; r.n_meas[l] = 0; r.chi2[l] = 0.0; }
-      if (eval_mode) for (int k = 0; k < 74; ++k) a.eval_out[k] = 0.0;
+      if (eval_mode) for (int k = 0; k < 74; ++k) a.eval_out[74 * pbi + k] = 0.0;
     }
     SVOH_STAMP_FLUSH();
     continue;
@@ -961,6 +970,60 @@ void sparse_align_kernel(const AlignKernelArgs a)
 // host side
 // ---------------------------------------------------------------------------
 
+// Shares of one problem evaluated by several workgroups: add their 74-double blocks in share order.
+__global__ __launch_bounds__(128)
+void sum_shares_kernel(const double* parts, int n_shares, double* out)
+{
+  const int k = threadIdx.x;
+  if (k >= 74) return;
+  double v = 0.0;
+  for (int s = 0; s < n_shares; ++s) v += parts[74 * s + k];
+  out[k] = v;
+}
+
+// One Gauss-Newton iteration on normal equations that were summed outside the resident kernel (patch-split
+// mode): unpack the 74 doubles into the packed layout, run the very same serial step, write the state back.
+template <int P, bool ILLUM>
+__global__ __launch_bounds__(64)
+void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_align_gn_state* st, int level, int iter)
+{
+  constexpr int D = ILLUM ? 8 : 6;
+  constexpr int NH = AccLayout<D>::NH;
+  __shared__ ShState s;
+  __shared__ double s_sum[AccLayout<D>::NACC];
+  if (threadIdx.x != 0) return;
+  const DevProblemDesc& pb = a.problems[0];
+  const DevCamDesc* cams = a.cams + pb.cam_begin;
+  s.T = load_rigid(st->T_icur_iref);
+  s.alpha = st->alpha; s.beta = st->beta;
+  if (iter == 0) {   // old_state = state at the start of a level (hpp:45)
+    s.Told = s.T; s.alpha_old = s.alpha; s.beta_old = s.beta;
+    for (int k = 0; k < 8; ++k) s.I_prior[k] = 0.0;
+  } else {
+    s.Told = load_rigid(st->T_old); s.alpha_old = st->alpha_old; s.beta_old = st->beta_old;
+    for (int k = 0; k < 8; ++k) s.I_prior[k] = st->I_prior[k];
+  }
+  s.stop = st->stop; s.status = st->status; s.level_done = 0; s.nsel = 0; s.patch_iters = 0;
+  {
+    int idx = 0;
+    for (int r = 0; r < D; ++r)
+      for (int c2 = r; c2 < D; ++c2) s_sum[idx++] = sums[c2 * 8 + r];
+    for (int r = 0; r < D; ++r) s_sum[NH + r] = sums[64 + r];
+    s_sum[NH + D] = sums[72];
+  }
+  const int n_meas = (int)sums[73];
+  int nvis = n_meas / (P * P);
+  gn_serial_step<P, D, ILLUM>(a, pb, cams, pb.n_cams, 0, level, iter, false, s, s_sum, &nvis);
+  store_rigid(s.T, st->T_icur_iref);
+  st->alpha = s.alpha; st->beta = s.beta;
+  store_rigid(s.Told, st->T_old);
+  st->alpha_old = s.alpha_old; st->beta_old = s.beta_old;
+  for (int k = 0; k < 8; ++k) st->I_prior[k] = s.I_prior[k];
+  st->chi2 = s_sum[NH + D] / (double)n_meas;
+  st->n_meas = n_meas;
+  st->stop = s.stop; st->level_done = s.level_done; st->status = s.status;
+}
+
 struct LaunchCfg { int nt; size_t lds; };
 
 template <int P, int NT, bool ILLUM>
@@ -1002,14 +1065,32 @@ static int validate_options(svoh_ctx* ctx, const svoh_align_options* o)
 }
 
 // Build descriptors, upload host feature arrays if needed, launch.
+// patch-split mode: either evaluate at a device-resident state into the caller's buffer, or run one
+// Gauss-Newton update on summed normal equations
+struct SplitArgs {
+  const svoh_align_gn_state* ext_state = nullptr;   // evaluate: state to evaluate at
+  double* sums_out = nullptr;                       // evaluate: 74 doubles, device
+  const double* sums_in = nullptr;                  // update: summed normal equations, device
+  svoh_align_gn_state* state = nullptr;             // update: state to advance, device
+  int iter = 0;
+  bool update = false;
+  int n_shares = 1;                                 // evaluate: workgroups the problem's features are spread over
+};
+
 static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_problems,
-                         const svoh_align_problem* problems, int eval_level)
+                         const svoh_align_problem* problems, int eval_level, const SplitArgs* split = nullptr)
 {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   int rc = validate_options(ctx, opt);
   if (rc != SVOH_OK) return rc;
   SVOH_REQUIRE(ctx, n_problems >= 1 && problems, "no problems");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  // patch-split evaluation: the one problem becomes S descriptors, share s holding features
+  // [n*s/S, n*(s+1)/S) of every camera, one workgroup each
+  const int S = (split && !split->update && split->n_shares > 1) ? split->n_shares : 1;
+  SVOH_REQUIRE(ctx, S == 1 || n_problems == 1, "shares apply to a single problem");
+  const int n_desc = n_problems * S;
 
   // pass 1: sizes
   size_t n_cams_total = 0, n_feat_total = 0, host_bytes = 0;
@@ -1026,36 +1107,46 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
       SVOH_REQUIRE(ctx, cam.cam.distortion == SVOH_DISTORTION_NONE || cam.cam.distortion == SVOH_DISTORTION_RADTAN,
                    "unsupported distortion model");
       nf += cam.n_features;
-      if (cam.mem_space == SVOH_MEM_HOST) host_bytes += ((size_t)cam.n_features * (8 * 8 + 1) + 63) & ~(size_t)63;
+      if (cam.mem_space == SVOH_MEM_HOST && !(split && split->update))
+        host_bytes += ((size_t)cam.n_features * (8 * 8 + 1) + 63) & ~(size_t)63;
     }
-    n_cams_total += pb.n_cams;
+    n_cams_total += (size_t)pb.n_cams * S;
     n_feat_total += nf;
-    if (nf > max_feat_per_problem) max_feat_per_problem = nf;
+    const int per_share = S > 1 ? nf / S + pb.n_cams : nf;
+    if (per_share > max_feat_per_problem) max_feat_per_problem = per_share;
   }
   const size_t feat_slots = n_feat_total ? n_feat_total : 1;
 
-  const size_t desc_bytes = sizeof(DevProblemDesc) * n_problems + sizeof(DevCamDesc) * n_cams_total;
+  const size_t desc_bytes = sizeof(DevProblemDesc) * n_desc + sizeof(DevCamDesc) * n_cams_total;
   SVOH_HIP_TRY(ctx, ctx->h_desc.reserve(desc_bytes));
   SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
-  SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * n_problems));
-  SVOH_HIP_TRY(ctx, ctx->h_results.reserve(sizeof(svoh_align_result) * n_problems));
+  SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * n_desc));
+  SVOH_HIP_TRY(ctx, ctx->h_results.reserve(sizeof(svoh_align_result) * n_desc));
   SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (kWsPairs * 16 + 2) + 256));
   if (host_bytes) {
     SVOH_HIP_TRY(ctx, ctx->h_upload.reserve(host_bytes));
     SVOH_HIP_TRY(ctx, ctx->d_upload.reserve(host_bytes));
   }
-  SVOH_HIP_TRY(ctx, ctx->d_eval.reserve(74 * sizeof(double)));
+  SVOH_HIP_TRY(ctx, ctx->d_eval.reserve(74 * sizeof(double) * S));
 
+  // the pinned staging buffers are reused by every call: a call queued right behind another (enqueue without
+  // fetch, the patch-split entries) must not overwrite them before the earlier copies have read them
+  if (ctx->align_staging_in_flight) {
+    SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_staged));
+    ctx->align_staging_in_flight = false;
+  }
   DevProblemDesc* hp = static_cast<DevProblemDesc*>(ctx->h_desc.ptr);
-  DevCamDesc* hc = reinterpret_cast<DevCamDesc*>(hp + n_problems);
+  DevCamDesc* hc = reinterpret_cast<DevCamDesc*>(hp + n_desc);
   uint8_t* hup = static_cast<uint8_t*>(ctx->h_upload.ptr);
   uint8_t* dup = static_cast<uint8_t*>(ctx->d_upload.ptr);
   size_t up_off = 0;
   int cam_idx = 0, feat_off = 0;
   const int need_levels = opt->max_level + 1;
-  for (int p = 0; p < n_problems; ++p) {
+  const uint8_t* share_base[SVOH_MAX_CAMS] = {};   // uploaded block of camera c (host arrays, S > 1)
+  for (int pd = 0; pd < n_desc; ++pd) {
+    const int p = pd / S, sh = pd % S;
     const svoh_align_problem& pb = problems[p];
-    DevProblemDesc& d = hp[p];
+    DevProblemDesc& d = hp[pd];
     d.n_cams = pb.n_cams;
     d.cam_begin = cam_idx;
     d.T_init = pb.T_icur_iref;
@@ -1079,34 +1170,40 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
       dc.ref_T_cam_imu = cam.ref_T_cam_imu;
       dc.cur_T_cam_imu = cam.cur_T_cam_imu;
       for (int k = 0; k < 3; ++k) dc.ref_pos[k] = cam.ref_pos[k];
-      dc.n_features = cam.n_features;
+      const size_t lo = (size_t)((int64_t)cam.n_features * sh / S), hi = (size_t)((int64_t)cam.n_features * (sh + 1) / S);
+      dc.n_features = (int32_t)(hi - lo);
       dc.feat_off = feat_off;
-      feat_off += cam.n_features;
-      if (cam.mem_space == SVOH_MEM_DEVICE || cam.n_features == 0) {
-        dc.px = cam.px; dc.f = cam.f; dc.pos_world = cam.pos_world; dc.flags = cam.flags;
+      feat_off += dc.n_features;
+      if (cam.mem_space == SVOH_MEM_DEVICE || cam.n_features == 0 || (split && split->update)) {
+        dc.px = cam.px + 2 * lo; dc.f = cam.f + 3 * lo; dc.pos_world = cam.pos_world + 3 * lo; dc.flags = cam.flags + lo;
       } else {
         const size_t n = (size_t)cam.n_features;
-        uint8_t* h = hup + up_off;
-        uint8_t* dv = dup + up_off;
-        memcpy(h, cam.px, n * 16);
-        memcpy(h + n * 16, cam.f, n * 24);
-        memcpy(h + n * 40, cam.pos_world, n * 24);
-        memcpy(h + n * 64, cam.flags, n);
-        dc.px = reinterpret_cast<const double*>(dv);
-        dc.f = reinterpret_cast<const double*>(dv + n * 16);
-        dc.pos_world = reinterpret_cast<const double*>(dv + n * 40);
-        dc.flags = dv + n * 64;
-        up_off += (n * 65 + 63) & ~(size_t)63;
+        if (sh == 0) {   // the camera's arrays go up once; every share points into the same block
+          uint8_t* h = hup + up_off;
+          memcpy(h, cam.px, n * 16);
+          memcpy(h + n * 16, cam.f, n * 24);
+          memcpy(h + n * 40, cam.pos_world, n * 24);
+          memcpy(h + n * 64, cam.flags, n);
+          share_base[c] = dup + up_off;
+          up_off += (n * 65 + 63) & ~(size_t)63;
+        }
+        const uint8_t* dv = share_base[c];
+        dc.px = reinterpret_cast<const double*>(dv) + 2 * lo;
+        dc.f = reinterpret_cast<const double*>(dv + n * 16) + 3 * lo;
+        dc.pos_world = reinterpret_cast<const double*>(dv + n * 40) + 3 * lo;
+        dc.flags = dv + n * 64 + lo;
       }
     }
   }
   if (up_off)
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_upload.ptr, ctx->h_upload.ptr, up_off, hipMemcpyHostToDevice, ctx->stream));
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc.ptr, ctx->h_desc.ptr, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_staged, ctx->stream));
+  ctx->align_staging_in_flight = true;
 
   AlignKernelArgs args;
   args.problems = static_cast<const DevProblemDesc*>(ctx->d_desc.ptr);
-  args.cams = reinterpret_cast<const DevCamDesc*>(args.problems + n_problems);
+  args.cams = reinterpret_cast<const DevCamDesc*>(args.problems + n_desc);
   args.results = static_cast<svoh_align_result*>(ctx->d_results.ptr);
   double* w = static_cast<double*>(ctx->d_feat.ptr);
   args.wpk = w;
@@ -1117,7 +1214,28 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.eval_level = eval_level;
   args.eval_out = static_cast<double*>(ctx->d_eval.ptr);
   args.stamps = nullptr;
-  args.n_problems = n_problems;
+  args.n_problems = n_desc;
+  args.ext_state = nullptr;
+  args.raw_sums = 0;
+  if (split && !split->update) {
+    args.ext_state = split->ext_state;
+    if (S == 1) args.eval_out = split->sums_out;
+    args.raw_sums = 1;
+  }
+  if (split && split->update) {
+    // the serial step only: one lane, no feature work
+    const bool illum_u = opt->estimate_illumination_gain || opt->estimate_illumination_offset;
+    if (opt->patch_size == 4) {
+      if (illum_u) hipLaunchKernelGGL((align_gn_update_kernel<4, true>), dim3(1), dim3(64), 0, ctx->stream, args, split->sums_in, split->state, eval_level, split->iter);
+      else hipLaunchKernelGGL((align_gn_update_kernel<4, false>), dim3(1), dim3(64), 0, ctx->stream, args, split->sums_in, split->state, eval_level, split->iter);
+    } else {
+      if (illum_u) hipLaunchKernelGGL((align_gn_update_kernel<8, true>), dim3(1), dim3(64), 0, ctx->stream, args, split->sums_in, split->state, eval_level, split->iter);
+      else hipLaunchKernelGGL((align_gn_update_kernel<8, false>), dim3(1), dim3(64), 0, ctx->stream, args, split->sums_in, split->state, eval_level, split->iter);
+    }
+    const hipError_t eu = hipGetLastError();
+    if (eu != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "gn_update launch failed: %s", hipGetErrorString(eu));
+    return SVOH_OK;
+  }
   SVOH_HIP_TRY(ctx, ctx->d_scratch2.reserve(64));
   SVOH_HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch2.ptr, 0, sizeof(int32_t), ctx->stream));
   args.queue = static_cast<int32_t*>(ctx->d_scratch2.ptr);
@@ -1131,7 +1249,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // >= 2 of a 640x480 pyramid.  Few problems (latency mode): 512-thread workgroups.
   // measured on MI355X (2000 patches): one problem takes 0.42 ms with 512 threads, 0.50 ms
   // with 256 and 0.91 ms with 1024 (128-VGPR budget spills), so 512 is the latency geometry
-  int nt = (n_problems >= 2 * ctx->num_cus) ? 256 : 512;
+  int nt = (n_desc >= 2 * ctx->num_cus) ? 256 : 512;
   if (max_feat_per_problem <= 256) nt = 256;
   nt = getenv_int("SVOH_ALIGN_THREADS", nt);
   if (nt != 256 && nt != 512 && nt != 1024) nt = 256;
@@ -1146,7 +1264,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   const bool illum = opt->estimate_illumination_gain || opt->estimate_illumination_offset;
   // resident workgroups per CU: 256-thread groups at 256 VGPRs -> 2; larger groups -> 1
   int grid = ctx->num_cus * getenv_int("SVOH_ALIGN_WG_PER_CU", nt == 256 ? 2 : 1);
-  if (grid > n_problems || grid <= 0) grid = n_problems;
+  if (grid > n_desc || grid <= 0) grid = n_desc;
   hipError_t e;
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_start, ctx->stream));
   if (opt->patch_size == 4)
@@ -1157,6 +1275,12 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
               : launch_nt<8, false>(ctx->stream, nt, grid, lds, args);
   if (e != hipSuccess)
     return set_error(ctx, SVOH_ERR_HIP, "sparse_align launch failed: %s", hipGetErrorString(e));
+  if (S > 1) {
+    hipLaunchKernelGGL(sum_shares_kernel, dim3(1), dim3(128), 0, ctx->stream, static_cast<const double*>(ctx->d_eval.ptr), S,
+                       split->sums_out);
+    const hipError_t es = hipGetLastError();
+    if (es != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "sum_shares launch failed: %s", hipGetErrorString(es));
+  }
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_stop, ctx->stream));
 #ifdef SVOH_PHASE_STAMPS
   {
@@ -1170,7 +1294,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
             sum[4] / n_problems, sum[7] / n_problems);
   }
 #endif
-  ctx->last_align_n = n_problems;
+  ctx->last_align_n = S > 1 ? 0 : n_problems;   // the shares' result slots are not a caller's problems
   return SVOH_OK;
 }
 
@@ -1245,6 +1369,77 @@ int svoh_sparse_align_evaluate(svoh_ctx* ctx, const svoh_align_options* options,
   for (int i = 0; i < nf; ++i)
     if (sel[i]) { if (visibility) visibility[k] = vis[i]; ++k; }
   if (n_selected) *n_selected = k;
+  return SVOH_OK;
+}
+
+int svoh_sparse_align_split_buffers(svoh_ctx* ctx, svoh_align_gn_state** d_state, double** d_sums)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, d_state && d_sums, "NULL argument");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t state_bytes = (sizeof(svoh_align_gn_state) + 255) & ~(size_t)255;
+  SVOH_HIP_TRY(ctx, ctx->d_split.reserve(state_bytes + SVOH_ALIGN_SUMS_DOUBLES * sizeof(double)));
+  *d_state = static_cast<svoh_align_gn_state*>(ctx->d_split.ptr);
+  *d_sums = reinterpret_cast<double*>(static_cast<uint8_t*>(ctx->d_split.ptr) + state_bytes);
+  return SVOH_OK;
+}
+
+int svoh_sparse_align_split_init(svoh_ctx* ctx, const svoh_align_problem* problem, svoh_align_gn_state* d_state)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, problem && d_state, "NULL argument");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  svoh_align_gn_state h;
+  memset(&h, 0, sizeof h);
+  h.T_icur_iref = problem->T_icur_iref;
+  h.T_old = problem->T_icur_iref;
+  h.alpha = h.alpha_old = problem->alpha_init;
+  h.beta = h.beta_old = problem->beta_init;
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d_state, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // h is a stack object
+  return SVOH_OK;
+}
+
+int svoh_sparse_align_partial_sums(svoh_ctx* ctx, const svoh_align_options* options, const svoh_align_problem* problem,
+                                   int level, int n_workgroups, const svoh_align_gn_state* d_state, double* d_sums)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, problem && d_state && d_sums, "NULL argument");
+  SVOH_REQUIRE(ctx, options && level >= 0 && level <= options->max_level, "level out of range");
+  SVOH_REQUIRE(ctx, n_workgroups >= 0 && n_workgroups <= 4096, "n_workgroups out of range");
+  SVOH_REQUIRE(ctx, problem->n_cams >= 1 && problem->n_cams <= SVOH_MAX_CAMS, "n_cams out of range");
+  if (n_workgroups == 0) {
+    // about 256 patches per workgroup (one per lane of the 256-thread geometry), at most two workgroups per CU
+    int64_t nf = 0;
+    for (int c = 0; c < problem->n_cams; ++c) nf += problem->cams[c].n_features > 0 ? problem->cams[c].n_features : 0;
+    int64_t w = (nf + 255) / 256;
+    if (w > 2 * ctx->num_cus) w = 2 * ctx->num_cus;
+    n_workgroups = w < 1 ? 1 : (int)w;
+  }
+  SplitArgs sp;
+  sp.ext_state = d_state;
+  sp.sums_out = d_sums;
+  sp.n_shares = n_workgroups;
+  return enqueue_align(ctx, options, 1, problem, level, &sp);
+}
+
+int svoh_sparse_align_gn_update(svoh_ctx* ctx, const svoh_align_options* options, const svoh_align_problem* problem,
+                                int level, int iter, const double* d_sums, svoh_align_gn_state* d_state,
+                                svoh_align_gn_state* h_state)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, problem && d_state && d_sums, "NULL argument");
+  SVOH_REQUIRE(ctx, options && level >= 0 && level <= options->max_level && iter >= 0, "level / iteration out of range");
+  SplitArgs sp;
+  sp.sums_in = d_sums;
+  sp.state = d_state;
+  sp.iter = iter;
+  sp.update = true;
+  int rc = enqueue_align(ctx, options, 1, problem, level, &sp);
+  if (rc != SVOH_OK) return rc;
+  if (h_state)
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(h_state, d_state, sizeof *h_state, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return SVOH_OK;
 }
 

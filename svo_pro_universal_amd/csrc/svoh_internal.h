@@ -86,11 +86,14 @@ struct svoh_ctx {
   svoh::DevBuffer d_feat;      // per-feature workspace
   svoh::DevBuffer d_upload;    // staged host feature arrays
   svoh::DevBuffer d_eval;      // evaluate() outputs
+  svoh::DevBuffer d_split;     // svoh_sparse_align_split_buffers: a Gauss-Newton state + 74 sums
   svoh::PinnedBuffer h_desc;
   svoh::PinnedBuffer h_upload;
   svoh::PinnedBuffer h_results;
   int last_align_n = 0;
   hipEvent_t ev_align_start = nullptr, ev_align_stop = nullptr;
+  hipEvent_t ev_align_staged = nullptr;   // the alignment's pinned staging buffers have been consumed
+  bool align_staging_in_flight = false;
   hipEvent_t ev_misc_start = nullptr, ev_misc_stop = nullptr;  // KLT / matcher / seeds
   bool misc_timed = false;
   svoh::DevBuffer d_counters;  // 8 x uint64 work counters of the last KLT / matcher kernel

@@ -155,6 +155,20 @@ class Context(object):
                                                         vis.ctypes.data, C.byref(nsel)))
         return H.reshape(8, 8).T.copy(), g, chi2.value, nm.value, vis[:nsel.value].copy()
 
+    # ---- patch-split Gauss-Newton; the loop itself is split_align.gauss_newton_split ----
+    def split_init(self, problem, d_state):
+        self._check(self.lib.svoh_sparse_align_split_init(self.h, C.byref(problem), C.c_void_p(d_state)))
+
+    def partial_sums(self, opt, problem, level, d_state, d_sums, n_workgroups=0):
+        self._check(self.lib.svoh_sparse_align_partial_sums(self.h, C.byref(opt), C.byref(problem), level,
+                                                            n_workgroups, C.c_void_p(d_state), C.c_void_p(d_sums)))
+
+    def gn_update(self, opt, problem, level, it, d_sums, d_state):
+        st = capi.svoh_align_gn_state()
+        self._check(self.lib.svoh_sparse_align_gn_update(self.h, C.byref(opt), C.byref(problem), level, it,
+                                                         C.c_void_p(d_sums), C.c_void_p(d_state), C.byref(st)))
+        return st
+
 
 def fill_align_camera(cam_struct, scene, ref_frame, cur_frame, keep, device_ptrs=None):
     """Fill one svoh_align_camera from a synth.AlignScene.  device_ptrs: optional

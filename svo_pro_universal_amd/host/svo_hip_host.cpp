@@ -35,13 +35,15 @@ void SparseImgAlignHip::setCompensation(bool do_compensation)
   options_.estimate_illumination_offset = do_compensation;
 }
 
-size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames)
+Transformation SparseImgAlignHip::buildProblem(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames,
+                                               int rank, int world, svoh_align_options& opt, svoh_align_problem& pb) const
 {
   if (!ref_frames || !cur_frames || ref_frames->empty() || ref_frames->size() != cur_frames->size())
     throw std::runtime_error("SparseImgAlignHip::run: bundles must be non-empty and of equal size");
   if (ref_frames->size() > SVOH_MAX_CAMS) throw std::runtime_error("SparseImgAlignHip::run: too many cameras");
+  if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("SparseImgAlignHip: rank / world out of range");
 
-  svoh_align_options opt{};
+  opt = svoh_align_options{};
   opt.max_level = options_.max_level;
   opt.min_level = options_.min_level;
   opt.patch_size = patch_size_;
@@ -53,7 +55,7 @@ size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBun
   opt.robustification = options_.robustification;
   opt.weight_scale = options_.weight_scale;
 
-  svoh_align_problem pb{};
+  pb = svoh_align_problem{};
   pb.n_cams = static_cast<int32_t>(ref_frames->size());
   for (size_t i = 0; i < ref_frames->size(); ++i) {
     const Frame& r = *ref_frames->at(i);
@@ -67,12 +69,15 @@ size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBun
     svoh::store_rigid(c.T_cam_imu(), cam.cur_T_cam_imu);
     const svoh::Vec3 p = r.pos();
     cam.ref_pos[0] = p.x; cam.ref_pos[1] = p.y; cam.ref_pos[2] = p.z;
-    cam.n_features = static_cast<int32_t>(r.num_features_);
+    // this participant's share of the camera's features (the whole list when world == 1)
+    const size_t lo = r.num_features_ * static_cast<size_t>(rank) / world;
+    const size_t hi = r.num_features_ * static_cast<size_t>(rank + 1) / world;
+    cam.n_features = static_cast<int32_t>(hi - lo);
     cam.mem_space = SVOH_MEM_HOST;
-    cam.px = r.px_vec_.data();
-    cam.f = r.f_vec_.data();
-    cam.pos_world = r.pos_world_.data();
-    cam.flags = r.alignable_.data();
+    cam.px = r.px_vec_.data() + 2 * lo;
+    cam.f = r.f_vec_.data() + 3 * lo;
+    cam.pos_world = r.pos_world_.data() + 3 * lo;
+    cam.flags = r.alignable_.data() + lo;
   }
   // T_iref_world_ and the optimisation variable (sparse_img_align.cpp:62, 74-75)
   const Transformation T_iref_world = ref_frames->at(0)->T_imu_world();
@@ -81,7 +86,14 @@ size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBun
   pb.alpha_init = alpha_init_;
   pb.beta_init = beta_init_;
   pb.prior = prior_;
+  return T_iref_world;
+}
 
+size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames)
+{
+  svoh_align_options opt;
+  svoh_align_problem pb;
+  const Transformation T_iref_world = buildProblem(ref_frames, cur_frames, 0, 1, opt, pb);
   const int rc = svoh_sparse_align_batch(ctx_, &opt, 1, &pb, &last_);
   if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_sparse_align_batch: ") + svoh_last_error_string(ctx_));
   if (last_.n_fts_to_track == 0) return 0;  // "no features to track" (sparse_img_align.cpp:53-57)
@@ -90,6 +102,53 @@ size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBun
   const Transformation T_opt = svoh::load_rigid(last_.T_icur_iref);
   for (const FramePtr& f : cur_frames->frames_) f->T_f_w_ = svoh::mul(svoh::mul(f->T_cam_imu(), T_opt), T_iref_world);
   alpha_init_ = 0.0;  // sparse_img_align.cpp:109-110
+  beta_init_ = 0.0;
+  return static_cast<size_t>(last_.n_fts_to_track);
+}
+
+size_t SparseImgAlignHip::runSplit(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames, int rank, int world,
+                                   const SumOverParticipants& sum_over_participants)
+{
+  svoh_align_options opt;
+  svoh_align_problem pb;
+  const Transformation T_iref_world = buildProblem(ref_frames, cur_frames, rank, world, opt, pb);
+  auto check = [this](int rc, const char* what) {
+    if (rc != SVOH_OK) throw std::runtime_error(std::string(what) + ": " + svoh_last_error_string(ctx_));
+  };
+  svoh_align_gn_state* d_state = nullptr;
+  double* d_sums = nullptr;
+  check(svoh_sparse_align_split_buffers(ctx_, &d_state, &d_sums), "svoh_sparse_align_split_buffers");
+  check(svoh_sparse_align_split_init(ctx_, &pb, d_state), "svoh_sparse_align_split_init");
+  last_ = svoh_align_result{};
+  svoh_align_gn_state st{};
+  long long first_visible = -1;
+  // SparseImgAlign::run's level loop (sparse_img_align.cpp:80-96) around optimizeGaussNewton
+  // (mini_least_squares_solver.hpp:42-107), with the sum over the participants between evaluateError and the solve
+  for (int level = opt.max_level; level >= opt.min_level; --level) {
+    for (int iter = 0; iter < opt.max_iter; ++iter) {
+      check(svoh_sparse_align_partial_sums(ctx_, &opt, &pb, level, 0, d_state, d_sums), "svoh_sparse_align_partial_sums");
+      check(svoh_synchronize(ctx_), "svoh_synchronize");
+      if (sum_over_participants) sum_over_participants(d_sums, SVOH_ALIGN_SUMS_DOUBLES);
+      check(svoh_sparse_align_gn_update(ctx_, &opt, &pb, level, iter, d_sums, d_state, &st), "svoh_sparse_align_gn_update");
+      last_.iters[level] = iter + 1;
+      last_.n_meas[level] = st.n_meas;
+      last_.chi2[level] = st.chi2;
+      last_.n_patch_iters += st.n_meas / (patch_size_ * patch_size_);
+      if (first_visible < 0) first_visible = st.n_meas / (patch_size_ * patch_size_);
+      if (st.level_done) break;
+    }
+  }
+  last_.status = st.status;
+  last_.T_icur_iref = st.T_icur_iref;
+  last_.alpha = st.alpha;
+  last_.beta = st.beta;
+  // run() returns the number of selected features; the shares only know the patches that were visible in the
+  // first evaluation, summed over the participants -- zero in the same cases
+  last_.n_fts_to_track = static_cast<int32_t>(first_visible < 0 ? 0 : first_visible);
+  if (last_.n_fts_to_track == 0) { last_.status = 1; return 0; }
+  const Transformation T_opt = svoh::load_rigid(last_.T_icur_iref);
+  for (const FramePtr& f : cur_frames->frames_) f->T_f_w_ = svoh::mul(svoh::mul(f->T_cam_imu(), T_opt), T_iref_world);
+  alpha_init_ = 0.0;
   beta_init_ = 0.0;
   return static_cast<size_t>(last_.n_fts_to_track);
 }

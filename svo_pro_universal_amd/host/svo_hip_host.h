@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -121,10 +122,22 @@ class SparseImgAlignHip {
   // Throws std::runtime_error on an ABI error (the reference CHECK-aborts).
   size_t run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames);
 
+  // The same optimisation with the patches split over `world` participants (GPUs): this one takes share `rank`
+  // of every camera's features, and between evaluateError and the solve the 74 doubles at d_sums (DEVICE memory)
+  // are summed over the participants by the callback -- ncclAllReduce(d_sums, d_sums, n, ncclDouble, ncclSum, ...)
+  // followed by a stream synchronisation in a multi-GPU host, nothing for world == 1.  Every participant computes
+  // the same update and ends in the same state (second row).  Returns the number of patches
+  // visible in the first evaluation, summed over the participants (0 = nothing to track).
+  using SumOverParticipants = std::function<void(double* d_sums, size_t n)>;
+  size_t runSplit(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames, int rank, int world,
+                  const SumOverParticipants& sum_over_participants);
+
   // last run's statistics
   const svoh_align_result& lastResult() const { return last_; }
 
  private:
+  Transformation buildProblem(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames, int rank, int world,
+                              svoh_align_options& opt, svoh_align_problem& pb) const;
   svoh_ctx* ctx_;
   SolverOptions solver_options_;
   SparseImgAlignOptions options_;

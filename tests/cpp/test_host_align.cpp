@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <vector>
 
 #include "../../oracle/svo_oracle.h"
@@ -133,6 +134,36 @@ int main(int argc, char** argv)
          sparse_img_align->lastResult().iters[3], ores.iters[3], sparse_img_align->lastResult().iters[2], ores.iters[2]);
   CHECK(m < 1e-8);  // fp64 both sides; only summation order differs
   for (int l = 0; l < SVOH_MAX_LEVELS; ++l) CHECK(sparse_img_align->lastResult().iters[l] == ores.iters[l]);
+
+  // ---- the patch-split form: one participant, the sum over participants is the identity ----
+  {
+    const Transformation T_run = cur->T_f_w_;
+    const svoh_align_result whole = sparse_img_align->lastResult();
+    cur->T_f_w_ = to_T(T_cur_init_f_w.data());
+    if (hdr[3]) sparse_img_align->setWeightedPrior(T_prior, 0.0, 0.0, 0.5, 0.0, 0.0, 0.0);
+    int n_sums = 0;
+    bool args_ok = true;
+    const size_t n_split = sparse_img_align->runSplit(last_frames, new_frames, 0, 1, [&](double* d_sums, size_t n) {
+      args_ok = args_ok && d_sums != nullptr && n == SVOH_ALIGN_SUMS_DOUBLES;
+      ++n_sums;
+    });
+    CHECK(args_ok);
+    const svoh_align_result& sp = sparse_img_align->lastResult();
+    int total_iters = 0;
+    for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { CHECK(sp.iters[l] == whole.iters[l]); CHECK(sp.n_meas[l] == whole.n_meas[l]); total_iters += sp.iters[l]; }
+    CHECK(n_sums == total_iters);
+    CHECK(n_split > 0 && n_split <= img_align_n_tracked);
+    const double ds[7] = { cur->T_f_w_.q.w - T_run.q.w, cur->T_f_w_.q.x - T_run.q.x, cur->T_f_w_.q.y - T_run.q.y,
+                           cur->T_f_w_.q.z - T_run.q.z, cur->T_f_w_.t.x - T_run.t.x, cur->T_f_w_.t.y - T_run.t.y,
+                           cur->T_f_w_.t.z - T_run.t.z };
+    double ms = 0;
+    for (double v : ds) ms = fmax(ms, fabs(v));
+    printf("runSplit: %zu visible patches, %d evaluations, |T_f_w(split) - T_f_w(run)| = %.3e\n", n_split, n_sums, ms);
+    CHECK(ms < 1e-9);
+    bool threw = false;
+    try { sparse_img_align->runSplit(last_frames, new_frames, 2, 2, nullptr); } catch (const std::runtime_error&) { threw = true; }
+    CHECK(threw);
+  }
   svoh_destroy(ctx);
   printf("PASS\n");
   return 0;
