@@ -567,6 +567,19 @@ typedef struct svoh_pose_result {
 int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
                              const svoh_pose_problem* problems, svoh_pose_result* results);
 
+/* Replaces Point::optimize (src/svo_common/src/point.cpp:248-325) for a batch of landmarks, as
+ * FrameHandlerBase::optimizeStructure (src/svo/src/frame_handler_base.cpp:779-825) calls it for every
+ * landmark of a new keyframe: 3-DoF Gauss-Newton on the landmark position over its observations
+ * (bearing vector f of the observing feature and T_f_w of its frame), unit-plane residuals or, with
+ * using_bearing_vector (omnidirectional cameras), unit-sphere residuals; at most n_iter iterations,
+ * stop on growing error (step rolled back) or max|dp| <= 1e-10.  Landmark i owns observations
+ * [obs_begin[i], obs_begin[i+1]); obs_view indexes T_f_w.  A landmark with fewer than two
+ * observations is left unchanged.  pos is updated in place; iters (may be NULL) receives the
+ * iterations started per landmark.  Host pointers. */
+int svoh_optimize_points_batch(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,
+                               const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
+                               const int32_t* obs_view, const double* obs_f, double* pos, int32_t* iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -450,3 +450,25 @@ def optimize_pose(opt, problem, fast=False):
     res = capi.svoh_pose_result()
     lib.orc_optimize_pose(C.byref(opt), C.byref(problem), C.byref(res))
     return res
+
+
+def optimize_points(views, obs_begin, obs_view, obs_f, pos, n_iter=5, using_bearing_vector=False, fast=False):
+    """Point::optimize (orc_optimize_point) for every landmark of a batch; same arguments as
+    frontend.Context.optimize_points.  Returns (pos, iters)."""
+    lib = load(fast)
+    P = C.POINTER
+    lib.orc_optimize_point.argtypes = [C.c_int, C.c_int, C.c_int, P(P(capi.svoh_se3)), C.c_void_p, C.c_void_p]
+    lib.orc_optimize_point.restype = C.c_int
+    T = [to_se3(v) for v in views]
+    obs_f = np.ascontiguousarray(obs_f, dtype=np.float64).reshape(-1, 3)
+    out = np.array(pos, dtype=np.float64, order="C", copy=True)
+    iters = np.zeros(out.shape[0], np.int32)
+    for i in range(out.shape[0]):
+        o0, o1 = int(obs_begin[i]), int(obs_begin[i + 1])
+        ptrs = (P(capi.svoh_se3) * max(1, o1 - o0))(*[C.pointer(T[int(obs_view[o])]) for o in range(o0, o1)])
+        f = np.ascontiguousarray(obs_f[o0:o1])
+        p = out[i].copy()
+        iters[i] = lib.orc_optimize_point(int(n_iter), int(bool(using_bearing_vector)), o1 - o0, ptrs, f.ctypes.data,
+                                          p.ctypes.data)
+        out[i] = p
+    return out, iters

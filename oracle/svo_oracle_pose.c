@@ -301,3 +301,77 @@ void orc_optimize_pose(const svoh_pose_options* opt, const svoh_pose_problem* pb
   if (nf) { qsort(final_errors, (size_t)nf, sizeof(double), cmp_double); res->reproj_error_after = final_errors[nf / 2]; }
   free(final_errors); free(start_errors);
 }
+
+/* ======================================================================== */
+/* f-3 (second half)  Point::optimize                                        */
+/* ======================================================================== */
+/* src/svo_common/src/point.cpp:216-325 with Point::jacobian_xyz2uv / xyz2f
+ * (src/svo_common/include/svo/common/point.h:170-204).  3-DoF Gauss-Newton on one landmark over its
+ * observations; A.ldlt().solve(b) is the same Eigen LDLT as everywhere else (orc_ldlt_solve, n = 3);
+ * stops when the error grows (rolling the last step back), on NaN, or when max|dp| <= 1e-10.
+ * Returns the number of iterations started; a point with fewer than two observations is left alone (:255-259). */
+int orc_optimize_point(int n_iter, int using_bearing_vector, int n_obs, const svoh_se3* const* T_f_w,
+                       const double* f /* 3 per observation */, double pos[3])
+{
+  double old_point[3] = { pos[0], pos[1], pos[2] };
+  double chi2 = 0.0;
+  const double eps = 0.0000000001;
+  if (n_obs < 2) return 0;
+  int i;
+  for (i = 0; i < n_iter; ++i) {
+    double A[9] = { 0 }, b[3] = { 0 };
+    double new_chi2 = 0.0;
+    for (int o = 0; o < n_obs; ++o) {
+      double R[9], p[3];
+      mat3_of_se3(T_f_w[o], R);
+      orc_se3_transform(T_f_w[o], pos, p);
+      const double* fo = f + 3 * o;
+      if (using_bearing_vector) {
+        /* updateHessianGradientUnitSphere, point.cpp:232-246 */
+        const double x2 = p[0] * p[0], y2 = p[1] * p[1], z2 = p[2] * p[2];
+        const double xy = p[0] * p[1], yz = p[1] * p[2], zx = p[2] * p[0];
+        double Jn[9] = { y2 + z2, -xy, -zx, -xy, x2 + z2, -yz, -zx, -yz, x2 + y2 };
+        const double s = 1.0 / pow(x2 + y2 + z2, 1.5);
+        for (int k = 0; k < 9; ++k) Jn[k] *= s;
+        double J[9];
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c)
+            J[r * 3 + c] = (-1.0 * Jn[r * 3 + 0]) * R[0 + c] + (-1.0 * Jn[r * 3 + 1]) * R[3 + c] + (-1.0 * Jn[r * 3 + 2]) * R[6 + c];
+        const double nrm = sqrt(x2 + y2 + z2);
+        const double e[3] = { fo[0] - p[0] / nrm, fo[1] - p[1] / nrm, fo[2] - p[2] / nrm };
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c) A[c * 3 + r] += J[0 + r] * J[0 + c] + J[3 + r] * J[3 + c] + J[6 + r] * J[6 + c];
+          b[r] -= J[0 + r] * e[0] + J[3 + r] * e[1] + J[6 + r] * e[2];
+        }
+        new_chi2 += e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+      } else {
+        /* updateHessianGradientUnitPlane, point.cpp:216-230 */
+        const double z_inv = 1.0 / p[2];
+        const double z_inv_sq = z_inv * z_inv;
+        const double Jp[6] = { z_inv, 0.0, -p[0] * z_inv_sq, 0.0, z_inv, -p[1] * z_inv_sq };
+        double J[6];
+        for (int r = 0; r < 2; ++r)
+          for (int c = 0; c < 3; ++c)
+            J[r * 3 + c] = (-Jp[r * 3 + 0]) * R[0 + c] + (-Jp[r * 3 + 1]) * R[3 + c] + (-Jp[r * 3 + 2]) * R[6 + c];
+        const double e[2] = { fo[0] / fo[2] - p[0] / p[2], fo[1] / fo[2] - p[1] / p[2] };   /* vk::project2 */
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c) A[c * 3 + r] += J[0 + r] * J[0 + c] + J[3 + r] * J[3 + c];
+          b[r] -= J[0 + r] * e[0] + J[3 + r] * e[1];
+        }
+        new_chi2 += e[0] * e[0] + e[1] * e[1];
+      }
+    }
+    double dp[3];
+    orc_ldlt_solve(3, A, b, dp);
+    if ((i > 0 && new_chi2 > chi2) || dp[0] != dp[0]) {
+      pos[0] = old_point[0]; pos[1] = old_point[1]; pos[2] = old_point[2];   /* roll-back */
+      return i + 1;
+    }
+    for (int k = 0; k < 3; ++k) { old_point[k] = pos[k]; pos[k] = pos[k] + dp[k]; }
+    chi2 = new_chi2;
+    double nm = -1.0;
+    for (int k = 0; k < 3; ++k) { const double v = fabs(dp[k]); if (v > nm) nm = v; }
+    if (nm <= eps) return i + 1;
+  }
+  return i;
+}

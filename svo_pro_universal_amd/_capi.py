@@ -260,7 +260,7 @@ EXPORTS = [
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
     "svoh_match_direct_batch",
     "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex",
-    "svoh_detect_features", "svoh_optimize_pose_batch",
+    "svoh_detect_features", "svoh_optimize_pose_batch", "svoh_optimize_points_batch",
 ]
 
 
@@ -351,6 +351,8 @@ def load():
     lib.svoh_detect_features.argtypes = [C.c_void_p, svoh_frame_t, P(svoh_detector_options), C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          P(C.c_int32)]
+    lib.svoh_optimize_points_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(svoh_se3), C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svoh_optimize_pose_batch.argtypes = [C.c_void_p, P(svoh_pose_options), C.c_int, P(svoh_pose_problem),
                                              P(svoh_pose_result)]
     lib.svoh_update_seeds_batch_ex.argtypes = lib.svoh_update_seeds_batch.argtypes + [P(svoh_seed_match_outputs)]

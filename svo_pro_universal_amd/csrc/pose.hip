@@ -383,6 +383,105 @@ __global__ __launch_bounds__(kPoseThreads) void pose_optimize_kernel(const PoseA
   }
 }
 
+
+// ---- Point::optimize (second half) ---------------------------------------------------------
+// src/svo_common/src/point.cpp:216-325: 3-DoF Gauss-Newton on one landmark over its observations (unit plane, or
+// unit sphere for omnidirectional cameras), pivoted LDL^T of the 3x3 system, stop when the error grows (the step
+// is rolled back), on NaN, or when max|dp| <= 1e-10.  One thread per landmark: a landmark has a handful of
+// observations and the batch is a keyframe's few hundred landmarks (FrameHandlerBase::optimizeStructure,
+// frame_handler_base.cpp:779-825), so there is nothing to reduce across lanes.
+struct PointArgs {
+  const svoh_se3* T_f_w;      // per view
+  const int32_t* obs_begin;   // n_points + 1
+  const int32_t* obs_view;    // per observation
+  const double* obs_f;        // 3 per observation
+  double* pos;                // 3 per point, in/out
+  int32_t* iters;             // per point
+  int n_points, n_iter, on_sphere;
+};
+
+__global__ __launch_bounds__(256)
+void point_optimize_kernel(const PointArgs a)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_points) return;
+  const int o0 = a.obs_begin[i], o1 = a.obs_begin[i + 1];
+  Vec3 pos = { a.pos[3 * i], a.pos[3 * i + 1], a.pos[3 * i + 2] };
+  Vec3 old_point = pos;
+  double chi2 = 0.0;
+  int it = 0;
+  if (o1 - o0 >= 2) {   // "optimizing point with less than two observations": left alone (:255-259)
+    for (it = 0; it < a.n_iter; ++it) {
+      double A[6] = { 0, 0, 0, 0, 0, 0 };   // packed lower triangle, (r,c) at r(r+1)/2 + c
+      double b[3] = { 0, 0, 0 };
+      double new_chi2 = 0.0;
+      for (int o = o0; o < o1; ++o) {
+        const Rigid T = load_rigid(a.T_f_w[a.obs_view[o]]);
+        double R[9];
+        to_matrix(T.q, R);
+        const Vec3 p = transform(T, pos);
+        const double fx = a.obs_f[3 * o], fy = a.obs_f[3 * o + 1], fz = a.obs_f[3 * o + 2];
+        if (a.on_sphere) {
+          // updateHessianGradientUnitSphere (:232-246), jacobian_xyz2f (point.h:187-204)
+          const double x2 = p.x * p.x, y2 = p.y * p.y, z2 = p.z * p.z;
+          const double xy = p.x * p.y, yz = p.y * p.z, zx = p.z * p.x;
+          double Jn[9] = { y2 + z2, -xy, -zx, -xy, x2 + z2, -yz, -zx, -yz, x2 + y2 };
+          const double s = 1.0 / pow(x2 + y2 + z2, 1.5);
+          double J[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Jn[k] *= s;
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              J[r * 3 + c] = (-1.0 * Jn[r * 3 + 0]) * R[0 + c] + (-1.0 * Jn[r * 3 + 1]) * R[3 + c] + (-1.0 * Jn[r * 3 + 2]) * R[6 + c];
+          const double nrm = sqrt(x2 + y2 + z2);
+          const double e[3] = { fx - p.x / nrm, fy - p.y / nrm, fz - p.z / nrm };
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) A[r * (r + 1) / 2 + c] += J[0 + r] * J[0 + c] + J[3 + r] * J[3 + c] + J[6 + r] * J[6 + c];
+            b[r] -= J[0 + r] * e[0] + J[3 + r] * e[1] + J[6 + r] * e[2];
+          }
+          new_chi2 += e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        } else {
+          // updateHessianGradientUnitPlane (:216-230), jacobian_xyz2uv (point.h:170-184)
+          const double z_inv = 1.0 / p.z;
+          const double z_inv_sq = z_inv * z_inv;
+          const double Jp[6] = { z_inv, 0.0, -p.x * z_inv_sq, 0.0, z_inv, -p.y * z_inv_sq };
+          double J[6];
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              J[r * 3 + c] = (-Jp[r * 3 + 0]) * R[0 + c] + (-Jp[r * 3 + 1]) * R[3 + c] + (-Jp[r * 3 + 2]) * R[6 + c];
+          const double e[2] = { fx / fz - p.x / p.z, fy / fz - p.y / p.z };   // vk::project2
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) A[r * (r + 1) / 2 + c] += J[0 + r] * J[0 + c] + J[3 + r] * J[3 + c];
+            b[r] -= J[0 + r] * e[0] + J[3 + r] * e[1];
+          }
+          new_chi2 += e[0] * e[0] + e[1] * e[1];
+        }
+      }
+      (void)ldlt_solve_regs<3>(A, b);   // b <- dp
+      if ((it > 0 && new_chi2 > chi2) || b[0] != b[0]) {
+        pos = old_point;   // roll-back
+        ++it;
+        break;
+      }
+      old_point = pos;
+      pos.x += b[0]; pos.y += b[1]; pos.z += b[2];
+      chi2 = new_chi2;
+      const double nm = fmax(fabs(b[0]), fmax(fabs(b[1]), fabs(b[2])));
+      if (nm <= 0.0000000001) { ++it; break; }
+    }
+  }
+  a.pos[3 * i] = pos.x; a.pos[3 * i + 1] = pos.y; a.pos[3 * i + 2] = pos.z;
+  if (a.iters) a.iters[i] = it;
+}
+
 }  // namespace svoh
 
 using namespace svoh;
@@ -478,5 +577,53 @@ extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* 
       if (cam.final_error && n) memcpy(cam.final_error, h + o_ferr + 8 * off, 8 * n);
       off += n;
     }
+  return SVOH_OK;
+}
+
+extern "C" int svoh_optimize_points_batch(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,
+                                          const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
+                                          const int32_t* obs_view, const double* obs_f, double* pos, int32_t* iters)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, n_points >= 0 && n_views >= 0 && n_iter >= 0, "negative count");
+  if (n_points == 0) return SVOH_OK;
+  SVOH_REQUIRE(ctx, obs_begin && pos, "NULL argument");
+  SVOH_REQUIRE(ctx, obs_begin[0] == 0, "obs_begin must start at 0");
+  for (int i = 0; i < n_points; ++i) SVOH_REQUIRE(ctx, obs_begin[i + 1] >= obs_begin[i], "obs_begin must not decrease");
+  const size_t n_obs = (size_t)obs_begin[n_points];
+  SVOH_REQUIRE(ctx, n_obs == 0 || (obs_view && obs_f && T_f_w), "NULL observation array");
+  for (size_t o = 0; o < n_obs; ++o) SVOH_REQUIRE(ctx, obs_view[o] >= 0 && obs_view[o] < n_views, "observation refers to an unknown view");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  const size_t o_T = 0, o_begin = al(sizeof(svoh_se3) * (size_t)(n_views ? n_views : 1));
+  const size_t o_view = o_begin + al(4 * ((size_t)n_points + 1)), o_f = o_view + al(4 * (n_obs ? n_obs : 1));
+  const size_t o_pos = o_f + al(24 * (n_obs ? n_obs : 1)), o_it = o_pos + al(24 * (size_t)n_points);
+  const size_t total = o_it + al(4 * (size_t)n_points);
+  SVOH_HIP_TRY(ctx, ctx->h_scratch0.reserve(total));
+  SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(total));
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch0.ptr);
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch0.ptr);
+  if (n_views) memcpy(h + o_T, T_f_w, sizeof(svoh_se3) * (size_t)n_views);
+  memcpy(h + o_begin, obs_begin, 4 * ((size_t)n_points + 1));
+  if (n_obs) { memcpy(h + o_view, obs_view, 4 * n_obs); memcpy(h + o_f, obs_f, 24 * n_obs); }
+  memcpy(h + o_pos, pos, 24 * (size_t)n_points);
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, o_it, hipMemcpyHostToDevice, ctx->stream));
+  PointArgs a;
+  a.T_f_w = reinterpret_cast<const svoh_se3*>(d + o_T);
+  a.obs_begin = reinterpret_cast<const int32_t*>(d + o_begin);
+  a.obs_view = reinterpret_cast<const int32_t*>(d + o_view);
+  a.obs_f = reinterpret_cast<const double*>(d + o_f);
+  a.pos = reinterpret_cast<double*>(d + o_pos);
+  a.iters = reinterpret_cast<int32_t*>(d + o_it);
+  a.n_points = n_points; a.n_iter = n_iter; a.on_sphere = using_bearing_vector != 0;
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  hipLaunchKernelGGL(point_optimize_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, ctx->stream, a);
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = true;
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_pos, d + o_pos, total - o_pos, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(pos, h + o_pos, 24 * (size_t)n_points);
+  if (iters) memcpy(iters, h + o_it, 4 * (size_t)n_points);
   return SVOH_OK;
 }

@@ -360,6 +360,22 @@ def _optimize_pose(self, opt, problems):
     return list(res)
 
 
+def _optimize_points(self, views, obs_begin, obs_view, obs_f, pos, n_iter=5, using_bearing_vector=False):
+    """svoh_optimize_points_batch (Point::optimize for a batch of landmarks).  views: list of 7-vectors
+    (q wxyz, t) T_f_w; obs_begin [n+1], obs_view [n_obs], obs_f [n_obs,3], pos [n,3].  Returns (pos, iters)."""
+    T = (capi.svoh_se3 * max(1, len(views)))(*[_se3(v) for v in views])
+    obs_begin = np.ascontiguousarray(obs_begin, dtype=np.int32)
+    obs_view = np.ascontiguousarray(obs_view, dtype=np.int32)
+    obs_f = np.ascontiguousarray(obs_f, dtype=np.float64)
+    out = np.array(pos, dtype=np.float64, order="C", copy=True)
+    n = out.shape[0]
+    iters = np.zeros(max(1, n), np.int32)
+    self._check(self.lib.svoh_optimize_points_batch(self.h, int(n_iter), int(bool(using_bearing_vector)), len(views), T, n,
+                                                    obs_begin.ctypes.data, obs_view.ctypes.data, obs_f.ctypes.data,
+                                                    out.ctypes.data, iters.ctypes.data))
+    return out, iters[:n]
+
+
 def _detect_features(self, opt, frame, width, height, occupancy=None, mask=None, max_n_features=None):
     """svoh_detect_features: dict(px [n,2], score, level, grad [n,2], type) like FastGradDetector::detect."""
     n_cells = int(np.ceil(width / opt.cell_size)) * int(np.ceil(height / opt.cell_size))
@@ -382,6 +398,7 @@ def _detect_features(self, opt, frame, width, height, occupancy=None, mask=None,
 
 Context.detect_features = _detect_features
 Context.optimize_pose = _optimize_pose
+Context.optimize_points = _optimize_points
 Context.klt_track_batch = _klt_track_batch
 Context.klt_track_indexed = _klt_track_indexed
 Context.update_seeds_device = _update_seeds_device

@@ -1032,6 +1032,193 @@ void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features
 }
 }  // namespace reprojector_utils
 
+// ---- structure optimisation -------------------------------------------------------
+size_t optimizeStructure(svoh_ctx* ctx, const FrameBundle::Ptr& frames, int max_n_pts, int max_iter)
+{
+  if (!ctx) throw std::runtime_error("optimizeStructure: NULL svoh_ctx (no CPU fallback exists)");
+  if (!frames) throw std::runtime_error("optimizeStructure: NULL frame bundle");
+  if (max_n_pts == 0) return 0;   // -1 = optimise all points (frame_handler_base.cpp:785-786)
+  size_t n_total = 0;
+  for (const FramePtr& frame : frames->frames_) {
+    const bool optimize_on_sphere = false;   // Camera::Type::kOmni only (:794-796); svoh_camera has no such model
+    std::vector<PointPtr> pts;
+    for (size_t i = 0; i < frame->num_features_; ++i) {
+      if (i >= frame->landmark_vec_.size() || frame->landmark_vec_[i] == nullptr) continue;
+      const uint8_t t = frame->type_vec_[i];   // isEdgelet (types.h:113-118)
+      if (t == SVOH_FT_EDGELET || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_EDGELET_SEED_CONVERGED) continue;
+      pts.push_back(frame->landmark_vec_[i]);
+    }
+    if (max_n_pts > 0) {
+      // the reference partitions the candidates here and then still loops over all of them (:804-819)
+      const size_t n = std::min(static_cast<size_t>(max_n_pts), pts.size());
+      max_n_pts = static_cast<int>(n);
+      std::nth_element(pts.begin(), pts.begin() + n, pts.end(),
+                       [](const PointPtr& lhs, const PointPtr& rhs) { return lhs->last_structure_optim_ < rhs->last_structure_optim_; });
+    }
+    if (pts.empty()) continue;
+    // one device call for the frame's landmarks: views = the frames the observations live in
+    std::vector<const Frame*> view_frames;
+    std::vector<svoh_se3> views;
+    std::vector<int32_t> obs_begin(1, 0), obs_view;
+    std::vector<double> obs_f, pos(3 * pts.size());
+    for (size_t k = 0; k < pts.size(); ++k) {
+      const Point& pt = *pts[k];
+      pos[3 * k] = pt.pos_.x; pos[3 * k + 1] = pt.pos_.y; pos[3 * k + 2] = pt.pos_.z;
+      for (const Point::Obs& obs : pt.obs_) {
+        const FramePtr f = obs.frame.lock();
+        if (!f) continue;   // "could not unlock weak_ptr<Frame> in Point::optimize": the observation is skipped
+        size_t v = 0;
+        while (v < view_frames.size() && view_frames[v] != f.get()) ++v;
+        if (v == view_frames.size()) {
+          view_frames.push_back(f.get());
+          svoh_se3 T;
+          svoh::store_rigid(f->T_f_w_, T);
+          views.push_back(T);
+        }
+        obs_view.push_back(static_cast<int32_t>(v));
+        for (int c = 0; c < 3; ++c) obs_f.push_back(f->f_vec_[3 * obs.keypoint_index_ + c]);
+      }
+      obs_begin.push_back(static_cast<int32_t>(obs_view.size()));
+    }
+    // Point::optimize returns before touching anything when obs_.size() < 2 (point.cpp:255-259); the device applies
+    // the same rule to the observations it is given.  (The two differ only for a landmark whose stored observations
+    // are >= 2 while fewer than two of their frames are still alive, which the reference reports as an error.)
+    const int rc = svoh_optimize_points_batch(ctx, max_iter, optimize_on_sphere ? 1 : 0, static_cast<int>(views.size()), views.data(),
+                                              static_cast<int>(pts.size()), obs_begin.data(), obs_view.data(), obs_f.data(),
+                                              pos.data(), nullptr);
+    if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_optimize_points_batch: ") + svoh_last_error_string(ctx));
+    for (size_t k = 0; k < pts.size(); ++k) {
+      pts[k]->pos_ = svoh::Vec3{ pos[3 * k], pos[3 * k + 1], pos[3 * k + 2] };
+      pts[k]->last_structure_optim_ = frame->id_;
+    }
+    n_total += pts.size();
+  }
+  return n_total;
+}
+
+// ---- key points and the keyframe map ----------------------------------------------
+void Frame::setKeyPoints()
+{
+  // frame.cpp:171-227, including its use of cv on the u axis for the two left-hand quadrants
+  const double cu = static_cast<double>(cam.width / 2);
+  const double cv = static_cast<double>(cam.height / 2);
+  auto px = [this](int i, int c) { return px_vec_[2 * static_cast<size_t>(i) + c]; };
+  for (size_t i = 0; i < num_features_; ++i) {
+    if (i >= landmark_vec_.size() || landmark_vec_[i] == nullptr || type_vec_[i] == SVOH_FT_OUTLIER) continue;
+    const double u = px_vec_[2 * i], v = px_vec_[2 * i + 1];
+    const KeyPoint here{ static_cast<int>(i), landmark_vec_[i]->pos_ };
+    // center
+    if (key_pts_[0].first == -1)
+      key_pts_[0] = here;
+    else if (std::max(std::fabs(u - cu), std::fabs(v - cv)) <
+             std::max(std::fabs(px(key_pts_[0].first, 0) - cu), std::fabs(px(key_pts_[0].first, 1) - cv)))
+      key_pts_[0] = here;
+    // corners
+    auto corner = [&](int k) {
+      if (key_pts_[k].first == -1)
+        key_pts_[k] = here;
+      else if ((u - cu) * (v - cv) > (px(key_pts_[k].first, 0) - cu) * (px(key_pts_[k].first, 1) - cv))
+        key_pts_[k] = here;
+    };
+    if (u >= cu && v >= cv) corner(1);
+    if (u >= cu && v < cv) corner(2);
+    if (u < cv && v < cv) corner(3);
+    if (u < cv && v >= cv) corner(4);
+  }
+}
+
+void Map::addKeyframe(const FramePtr& new_keyframe, bool temporal_map)
+{
+  keyframes_.insert(std::make_pair(new_keyframe->id(), new_keyframe));
+  last_added_kf_id_ = new_keyframe->id();
+  if (temporal_map) sorted_keyframe_ids_.push_back(new_keyframe->id());
+}
+
+void Map::removeKeyframe(int frame_id)
+{
+  auto it_kf = keyframes_.find(frame_id);
+  if (it_kf == keyframes_.end()) return;   // "Cannot find the keyframe ..., will not do anything"
+  const FramePtr frame = it_kf->second;
+  for (size_t i = 0; i < frame->num_features_ && i < frame->landmark_vec_.size(); ++i) {
+    if (!frame->landmark_vec_[i]) continue;
+    // Point::removeObservation(frame_id) (point.cpp:60-66)
+    std::vector<Point::Obs>& obs = frame->landmark_vec_[i]->obs_;
+    obs.erase(std::remove_if(obs.begin(), obs.end(),
+                             [&](const Point::Obs& o) { const FramePtr f = o.frame.lock(); return f && f->id_ == frame_id; }),
+              obs.end());
+  }
+  keyframes_.erase(it_kf);
+}
+
+void Map::getOverlapKeyframes(const FramePtr& frame, std::vector<std::pair<FramePtr, double>>* close_kfs) const
+{
+  if (!close_kfs || !frame) throw std::runtime_error("Map::getOverlapKeyframes: NULL argument");
+  const svoh::Vec3 tp = frame->T_f_w_.t;   // T_f_w_.getPosition(): the translation of T_f_w, not the camera centre
+  for (const auto& kf : keyframes_) {
+    for (const Frame::KeyPoint& keypoint : kf.second->key_pts_) {
+      if (keypoint.first == -1) continue;
+      if (frame->isVisible(keypoint.second, nullptr)) {
+        const svoh::Vec3 tk = kf.second->T_f_w_.t;
+        const double dx = tp.x - tk.x, dy = tp.y - tk.y, dz = tp.z - tk.z;
+        close_kfs->push_back(std::make_pair(kf.second, std::sqrt(dx * dx + dy * dy + dz * dz)));
+        break;   // this keyframe has an overlapping field of view
+      }
+    }
+  }
+}
+
+void Map::getClosestNKeyframesWithOverlap(const FramePtr& cur_frame, size_t num_frames, std::vector<FramePtr>* close_kfs) const
+{
+  if (!close_kfs) throw std::runtime_error("Map::getClosestNKeyframesWithOverlap: NULL argument");
+  std::vector<std::pair<FramePtr, double>> overlap_kfs;
+  getOverlapKeyframes(cur_frame, &overlap_kfs);
+  if (overlap_kfs.empty()) return;
+  const size_t N = std::min(num_frames, overlap_kfs.size());
+  std::nth_element(overlap_kfs.begin(), overlap_kfs.begin() + N, overlap_kfs.end(),
+                   [](const std::pair<FramePtr, double>& lhs, const std::pair<FramePtr, double>& rhs) { return lhs.second < rhs.second; });
+  overlap_kfs.resize(N);
+  close_kfs->reserve(num_frames);
+  for (const auto& p : overlap_kfs) close_kfs->push_back(p.first);
+}
+
+FramePtr Map::getClosestKeyframe(const FramePtr& frame) const
+{
+  std::vector<std::pair<FramePtr, double>> close_kfs;
+  getOverlapKeyframes(frame, &close_kfs);
+  if (close_kfs.empty()) return nullptr;
+  std::sort(close_kfs.begin(), close_kfs.end(),
+            [](const std::pair<FramePtr, double>& lhs, const std::pair<FramePtr, double>& rhs) { return lhs.second < rhs.second; });
+  if (close_kfs.at(0).first != frame) return close_kfs.at(0).first;
+  if (close_kfs.size() == 1) return nullptr;
+  return close_kfs.at(1).first;
+}
+
+FramePtr Map::getFurthestKeyframe(const svoh::Vec3& pos) const
+{
+  FramePtr furthest_kf;
+  double maxdist = 0.0;
+  for (const auto& kf : keyframes_) {
+    const svoh::Vec3 p = kf.second->pos();
+    const double dx = p.x - pos.x, dy = p.y - pos.y, dz = p.z - pos.z;
+    const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
+    if (dist > maxdist) { maxdist = dist; furthest_kf = kf.second; }
+  }
+  return furthest_kf;
+}
+
+FramePtr Map::getKeyframeById(int id) const
+{
+  auto it_kf = keyframes_.find(id);
+  return it_kf == keyframes_.end() ? nullptr : it_kf->second;
+}
+
+void Map::getSortedKeyframes(std::vector<FramePtr>& kfs_sorted) const
+{
+  kfs_sorted.reserve(keyframes_.size());
+  for (const auto& kv : keyframes_) kfs_sorted.push_back(kv.second);
+  std::sort(kfs_sorted.begin(), kfs_sorted.end(), [](const FramePtr& left, const FramePtr& right) { return left->id_ < right->id_; });
+}
+
 // ---- alignPyr2DVec ----------------------------------------------------------------
 namespace feature_alignment {
 void alignPyr2DVec(svoh_ctx* ctx, svoh_frame_t img_pyr_ref, svoh_frame_t img_pyr_cur, int max_level, int min_level,

@@ -21,6 +21,8 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/svo_hip.h"
@@ -58,6 +60,12 @@ struct Frame {
   std::vector<std::shared_ptr<struct Point>> landmark_vec_;   // n, nullptr = no landmark
   struct SeedRef { std::shared_ptr<Frame> keyframe; int seed_id = -1; };
   std::vector<SeedRef> seed_ref_vec_;                   // n
+  // five landmarks (closest to the centre and to the four corners) that decide whether two frames have
+  // overlapping fields of view (frame.h:49-50, frame.cpp:171-227); first = feature index or -1
+  struct KeyPoint { int first = -1; svoh::Vec3 second{ 0, 0, 0 }; };
+  KeyPoint key_pts_[5];
+  void resetKeyPoints() { for (KeyPoint& k : key_pts_) k = KeyPoint(); }   // frame.cpp:218-221
+  void setKeyPoints();
   double getSeedDepth(size_t idx) const { return 1.0 / invmu_sigma2_a_b_vec_[4 * idx]; }   // seed.h:110-113 (inverse depth)
   size_t numTrackedFeatures() const;                                      // frame.h:153-163
   bool isVisible(const svoh::Vec3& xyz_w, double* px /* 2, may be NULL */) const;   // frame.cpp:229-260
@@ -300,6 +308,7 @@ struct Point {
   struct Obs { std::weak_ptr<Frame> frame; size_t keypoint_index_ = 0; };
   std::vector<Obs> obs_;
   std::vector<int> last_projected_kf_id_ = std::vector<int>(SVOH_MAX_CAMS, -1);   // per camera (point.h)
+  int last_structure_optim_ = 0;   // frame id of the last optimizeStructure that touched the point (point.h)
   const svoh::Vec3& pos() const { return pos_; }
   int id() const { return id_; }
   bool getCloseViewObs(const svoh::Vec3& framepos, FramePtr& ref_frame, size_t& ref_feature_index) const;
@@ -449,6 +458,43 @@ class PoseOptimizerHip {
   double prior_lambda_ = 0.0;
   svoh::Quat R_prior_{ 1, 0, 0, 0 };
   svoh_pose_result last_{};
+};
+
+// ---------------------------------------------------------------------------
+// Structure optimisation (second half).  FrameHandlerBase::optimizeStructure
+// (frame_handler_base.cpp:779-825): every landmark of the new keyframe's frames that is not an edgelet gets
+// Point::optimize(max_iter) (point.cpp:248-325) over all its observations, one batched device call per frame.
+// Like the reference, max_n_pts > 0 only reorders the candidates (std::nth_element on last_structure_optim_) --
+// its range-for runs over the whole container, not up to the partition point -- so every candidate is optimised
+// and stamped; max_n_pts == 0 returns at once.  Returns the number of landmarks handed to the optimiser.
+// ---------------------------------------------------------------------------
+size_t optimizeStructure(svoh_ctx* ctx, const FrameBundle::Ptr& frames, int max_n_pts, int max_iter);
+
+// ---------------------------------------------------------------------------
+// The part of svo::Map the reprojector's caller uses (second half): keyframe container and
+// the overlap query of FrameHandlerBase::projectMapInFrame (frame_handler_base.cpp:653-661).  keyframes_ is the
+// reference's own container type (map.h:23), so that iteration order -- which decides the order of equally
+// distant keyframes and of the reprojection passes -- is the standard library's, as in the reference.
+// ---------------------------------------------------------------------------
+class Map {
+ public:
+  using Ptr = std::shared_ptr<Map>;
+  using Keyframes = std::unordered_map<int, FramePtr>;   // frame id -> frame
+  Keyframes keyframes_;
+  int last_added_kf_id_ = -1;
+  std::vector<int> sorted_keyframe_ids_;
+
+  void reset() { keyframes_.clear(); sorted_keyframe_ids_.clear(); last_added_kf_id_ = -1; }   // map.cpp:21-27
+  void addKeyframe(const FramePtr& new_keyframe, bool temporal_map);                            // map.cpp:99-109
+  void removeKeyframe(int frame_id);                                                             // map.cpp:29-57 (container part)
+  // keyframes with one of their key points visible in `frame`, with the distance between the camera centres
+  void getOverlapKeyframes(const FramePtr& frame, std::vector<std::pair<FramePtr, double>>* close_kfs) const;   // map.cpp:111-133
+  void getClosestNKeyframesWithOverlap(const FramePtr& cur_frame, size_t num_frames, std::vector<FramePtr>* close_kfs) const;   // :135-158
+  FramePtr getClosestKeyframe(const FramePtr& frame) const;                                     // map.cpp:160-177
+  FramePtr getFurthestKeyframe(const svoh::Vec3& pos) const;                                    // map.cpp:184-197
+  FramePtr getKeyframeById(int id) const;                                                       // map.cpp:199-205
+  void getSortedKeyframes(std::vector<FramePtr>& kfs_sorted) const;                             // map.cpp:207-218
+  size_t size() const { return keyframes_.size(); }
 };
 
 // The function-local `static double px_error_angle` of depth_filter_utils::updateSeed

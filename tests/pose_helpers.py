@@ -44,3 +44,36 @@ def make_pose_scene(seed, n=180, cam=None, n_cams=1, noise_px=0.3, outlier_fract
         inliers.append(inl)
     d = synth.SE3(synth.quat_from_axis_angle(rng.normal(size=3), pose_err[0]), rng.normal(size=3) / np.sqrt(3) * pose_err[1])
     return dict(cams=cams, T_imu_world_gt=T_imu_world_gt, T_imu_world_init=d * T_imu_world_gt, inlier=inliers, cam=cam)
+
+
+def make_structure_scene(seed, n_points=300, n_views=5, noise=2e-3, start_err=0.08, degenerate=True):
+    """Landmarks seen from a few keyframes (FrameHandlerBase::optimizeStructure's input): random views looking
+    at a cloud of points, each point observed in 2..n_views of them with noisy bearing vectors, a starting
+    position off by start_err (relative to the depth).  With `degenerate`: some points with 0/1 observations
+    (left alone), one with two identical observations (singular system), one behind a camera.
+    Returns dict(views=[7-vectors T_f_w], obs_begin, obs_view, obs_f, pos0, pos_gt)."""
+    rng = np.random.RandomState(seed)
+    views = []
+    for v in range(n_views):
+        T_w_f = synth.SE3(synth.quat_from_axis_angle(rng.normal(size=3), rng.uniform(0, 0.25)), rng.uniform(-0.6, 0.6, 3))
+        views.append(T_w_f.inverse())
+    pos_gt = np.stack([rng.uniform(-2, 2, n_points), rng.uniform(-1.5, 1.5, n_points), rng.uniform(3, 9, n_points)], 1)
+    obs_begin, obs_view, obs_f = [0], [], []
+    for i in range(n_points):
+        k = rng.randint(2, n_views + 1)
+        if degenerate and i % 37 == 5:
+            k = i % 2          # 0 or 1 observation
+        sel = rng.choice(n_views, k, replace=False)
+        if degenerate and i == 11:
+            sel = np.array([sel[0], sel[0]])     # the same view twice: rank-deficient normal equations
+        for v in sel:
+            p = views[v].transform(pos_gt[i])
+            f = p / np.linalg.norm(p) + rng.normal(0, noise, 3)
+            obs_view.append(int(v))
+            obs_f.append(f / np.linalg.norm(f))
+        obs_begin.append(len(obs_view))
+    pos0 = pos_gt * (1.0 + rng.normal(0, start_err, (n_points, 1))) + rng.normal(0, 0.02, (n_points, 3))
+    if degenerate and n_points > 23:
+        pos0[23] = views[obs_view[obs_begin[23]]].inverse().transform(np.array([0.1, 0.1, -2.0]))   # behind its first view
+    return dict(views=[v.as7() for v in views], obs_begin=np.array(obs_begin, np.int32), obs_view=np.array(obs_view, np.int32),
+                obs_f=np.array(obs_f).reshape(-1, 3), pos0=pos0, pos_gt=pos_gt)

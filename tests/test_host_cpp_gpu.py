@@ -186,3 +186,14 @@ def test_cpp_pose_optimizer_mirror_matches_oracle(tmp_path, oracle_lib, error_ty
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASS" in out.stdout
+
+
+def test_cpp_structure_optimisation_and_map_mirrors():
+    """optimizeStructure (FrameHandlerBase::optimizeStructure -> Point::optimize on the device) against the oracle
+    per landmark, and the Map / key-point mirrors against brute force (tests/cpp/test_host_map_structure.cpp)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host"), "libsvo_hip_host.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_host_map_structure")], capture_output=True, text=True)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASS" in out.stdout

@@ -224,3 +224,12 @@ def test_ate_script(tmp_path):
     np.savetxt(e, est, fmt="%.9f"); np.savetxt(g, gt, fmt="%.9f")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ate.py"), e, g, "--scale"], capture_output=True, text=True)
     assert out.returncode == 0 and "ATE rmse 0.0000" in out.stdout
+
+
+def test_map_and_key_point_mirrors_host_logic():
+    """Frame::setKeyPoints and Map::getClosestNKeyframesWithOverlap & co. are host logic: the C++ test's map part
+    runs without a GPU (the structure-optimisation part of the same binary is a GPU test)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host"), "libsvo_hip_host.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "test_host_map_structure"])
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_host_map_structure"), "--map-only"], capture_output=True, text=True)
+    assert out.returncode == 0 and "PASS" in out.stdout, out.stdout + out.stderr

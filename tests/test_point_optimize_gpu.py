@@ -1,0 +1,73 @@
+"""svoh_optimize_points_batch (Point::optimize, SURVEY.md 8(f-3) second half) through the C ABI against the
+oracle on the same seeded landmarks.  Tolerance: positions 1e-6 absolute, median 1e-12 (fp64 both sides; FMA
+contraction, device pow / division differ in the last bits and ill-conditioned depths amplify that), iteration
+counts exact until convergence (see the comment in the test)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from svo_pro_universal_amd import frontend as fe
+
+import pose_helpers as ph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("sphere", [False, True])
+@pytest.mark.parametrize("seed,n_points,n_views,n_iter", [(6, 300, 5, 5), (7, 1000, 8, 10), (8, 5, 2, 3)])
+def test_matches_the_oracle(gpu_ctx, sphere, seed, n_points, n_views, n_iter):
+    sc = ph.make_structure_scene(seed, n_points=n_points, n_views=n_views)
+    args = (sc["views"], sc["obs_begin"], sc["obs_view"], sc["obs_f"], sc["pos0"])
+    po, io = orc.optimize_points(*args, n_iter=n_iter, using_bearing_vector=sphere)
+    pg, ig = gpu_ctx.optimize_points(*args, n_iter=n_iter, using_bearing_vector=sphere)
+    fin = np.isfinite(po).all(1)
+    assert np.array_equal(fin, np.isfinite(pg).all(1))
+    # once a landmark has converged its chi2 only moves in the last bits, so the "error grew -> roll back and stop"
+    # rule (point.cpp:296-304) can fire one iteration apart on the two sides; the positions then differ by that
+    # last, negligible step.  Everything before convergence is in lockstep.
+    wild = np.zeros(n_points, bool)
+    if n_points > 23:
+        wild[[11, 23]] = True     # constructed degenerate landmarks, compared separately below
+    assert np.abs(ig - io)[~wild].max() <= 1 and np.mean((ig != io)[~wild]) < 0.05
+    if n_iter <= 5:
+        assert np.array_equal(ig[~wild], io[~wild])
+    d = np.abs(pg - po).max(1)
+    if n_points > 23:
+        # landmark 11 sees the same view twice: the 3x3 system is singular along the viewing ray and its solution
+        # there is rounding noise over a tiny pivot -- the two sides agree in the direction seen from that view.
+        # landmark 23 starts behind a camera and the iteration runs away chaotically (up to 1e16 m): same order of
+        # magnitude on both sides is all that can be asked.
+        wild[[11, 23]] = True
+        from svo_pro_universal_amd import synth
+        T = synth.SE3.from7(sc["views"][sc["obs_view"][sc["obs_begin"][11]]])
+        bo, bg = T.transform(po[11]), T.transform(pg[11])
+        assert np.linalg.norm(np.cross(bo / np.linalg.norm(bo), bg / np.linalg.norm(bg))) < 1e-9
+        if fin[23]:
+            assert d[23] <= 1e-2 * (1.0 + np.abs(po[23]).max())
+    ok = fin & ~wild
+    # depth along nearly parallel rays is conditioned ~1e8: last-bit differences of the two sides (FMA contraction,
+    # pow, division) and a stop one iteration apart show up at 1e-7 for a few landmarks and at 1e-15 for the rest
+    assert d[ok].max() < 1e-6, (np.argmax(np.where(ok, d, 0)), d[ok].max())
+    assert np.median(d[ok]) < 1e-12
+    lone = np.diff(sc["obs_begin"]) < 2
+    assert np.array_equal(pg[lone], sc["pos0"][lone])
+
+
+def test_recovers_noise_free_landmarks_at_scale(gpu_ctx):
+    sc = ph.make_structure_scene(9, n_points=20000, n_views=6, noise=0.0, degenerate=False)
+    pg, ig = gpu_ctx.optimize_points(sc["views"], sc["obs_begin"], sc["obs_view"], sc["obs_f"], sc["pos0"], n_iter=15)
+    assert np.abs(pg - sc["pos_gt"]).max() < 1e-6 and ig.max() <= 15
+
+
+def test_empty_and_bad_arguments(gpu_ctx):
+    sc = ph.make_structure_scene(10, n_points=4, degenerate=False)
+    pg, ig = gpu_ctx.optimize_points(sc["views"], np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros((0, 3)), np.zeros((0, 3)))
+    assert pg.shape == (0, 3)
+    bad_view = sc["obs_view"].copy()
+    bad_view[0] = 99
+    with pytest.raises(fe.SvohError):
+        gpu_ctx.optimize_points(sc["views"], sc["obs_begin"], bad_view, sc["obs_f"], sc["pos0"])
+    bad_begin = sc["obs_begin"].copy()
+    bad_begin[2] = bad_begin[1] - 1
+    with pytest.raises(fe.SvohError):
+        gpu_ctx.optimize_points(sc["views"], bad_begin, sc["obs_view"], sc["obs_f"], sc["pos0"])
