@@ -98,3 +98,14 @@ def test_oracle_reproduces_golden_detect_pose(oracle_lib):
     d = oracle_lib.detect_features(capi.default_detector_options(cell_size=20), levels, z["det_occupancy"])
     pb, keep = fe.make_pose_problem(cams, synth.SE3.from7(z["pose_T_init"]))
     check_golden3(z, d, oracle_lib.optimize_pose(popt, pb), keep)
+
+
+def test_oracle_reproduces_golden_structure(oracle_lib):
+    """Point::optimize fixture (tests/golden/structure_small.npz, made by make_golden_structure.py)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(helpers.GOLDEN), "structure_small.npz"))
+    for sphere in (0, 1):
+        p, it = oracle_lib.optimize_points(list(z["views"]), z["obs_begin"], z["obs_view"], z["obs_f"], z["pos0"], n_iter=5,
+                                           using_bearing_vector=bool(sphere))
+        assert np.array_equal(it, z["iters_%d" % sphere])
+        assert np.array_equal(p, z["pos_out_%d" % sphere])     # same code, same machine arithmetic: bit for bit

@@ -71,3 +71,17 @@ def test_empty_and_bad_arguments(gpu_ctx):
     bad_begin[2] = bad_begin[1] - 1
     with pytest.raises(fe.SvohError):
         gpu_ctx.optimize_points(sc["views"], bad_begin, sc["obs_view"], sc["obs_f"], sc["pos0"])
+
+
+def test_against_the_committed_fixture(gpu_ctx):
+    """tests/golden/structure_small.npz (oracle output, generator committed next to it)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "structure_small.npz"))
+    wild = np.zeros(60, bool)
+    wild[[11, 23]] = True
+    for sphere in (0, 1):
+        p, it = gpu_ctx.optimize_points(list(z["views"]), z["obs_begin"], z["obs_view"], z["obs_f"], z["pos0"], n_iter=5,
+                                        using_bearing_vector=bool(sphere))
+        assert np.array_equal(it[~wild], z["iters_%d" % sphere][~wild])
+        d = np.abs(p - z["pos_out_%d" % sphere]).max(1)
+        assert d[~wild].max() < 1e-6 and np.median(d[~wild]) < 1e-12

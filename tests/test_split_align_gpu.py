@@ -178,3 +178,31 @@ def test_argument_errors(gpu_ctx):
     gpu_ctx.synchronize()
     a, b = out1.cpu().numpy(), out2.cpu().numpy()
     assert a[73] == b[73] > 0 and np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+
+
+@pytest.mark.parametrize("tag", ["pinhole", "radtan"])
+def test_partial_sums_against_the_committed_fixture(gpu_ctx, tag):
+    """tests/golden/align_small.npz holds H, g, n per level of the golden scenes: the 74-double block of
+    svoh_sparse_align_partial_sums must carry the same numbers, with one workgroup and with several."""
+    z = np.load(helpers.GOLDEN)
+    sc = helpers.scene_from_golden(z, tag)
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 4), gpu_ctx.build_pyramid(sc.img_cur, 4)
+    opt = capi.default_align_options(**helpers.GOLDEN_OPTION_SETS["plain"])
+    gpb, keep = fe.make_align_problems([[(sc, fr, fc)]])
+    dev = torch.device("cuda", 0)
+    d_state = torch.zeros(C.sizeof(capi.svoh_align_gn_state) // 8, dtype=torch.float64, device=dev)
+    d_sums = torch.zeros(capi.SVOH_ALIGN_SUMS_DOUBLES, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.split_init(gpb[0], d_state.data_ptr())
+    q = "%s/plain/" % tag
+    for level in range(opt.min_level, opt.max_level + 1):
+        for wg in (1, 5):
+            gpu_ctx.partial_sums(opt, gpb[0], level, d_state.data_ptr(), d_sums.data_ptr(), wg)
+            gpu_ctx.synchronize()
+            s = d_sums.cpu().numpy()
+            H, g = s[:64].reshape(8, 8).T, s[64:72]
+            Hz, gz = z[q + "H%d" % level], z[q + "g%d" % level]
+            assert int(s[73]) == int(z[q + "chi2_nmeas%d" % level][1])
+            assert np.abs(H - Hz).max() <= 1e-10 * np.abs(Hz).max() and np.abs(g - gz).max() <= 1e-10 * np.abs(gz).max()
+            chi2 = z[q + "chi2_nmeas%d" % level][0]
+            assert abs(s[72] / s[73] - chi2) <= 1e-4 * abs(chi2)     # the reference (and the oracle) sum chi2 in float
