@@ -141,6 +141,7 @@ int main(int argc, char** argv)
     const svoh_align_result whole = sparse_img_align->lastResult();
     cur->T_f_w_ = to_T(T_cur_init_f_w.data());
     if (hdr[3]) sparse_img_align->setWeightedPrior(T_prior, 0.0, 0.0, 0.5, 0.0, 0.0, 0.0);
+    sparse_img_align->setMaxNumFeaturesToAlign(5);   // has no effect, as in the reference
     int n_sums = 0;
     bool args_ok = true;
     const size_t n_split = sparse_img_align->runSplit(last_frames, new_frames, 0, 1, [&](double* d_sums, size_t n) {
