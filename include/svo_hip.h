@@ -219,8 +219,10 @@ int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options,
                             svoh_align_result* results);
 
 /* Split form of the above for callers that want to overlap: enqueue returns
- * as soon as the launch is queued on the context stream; fetch blocks and
- * copies the results of the last enqueue. */
+ * as soon as the launch is queued on the context stream (kernel and the copy of
+ * its results to pinned host memory); fetch blocks and hands out the results of
+ * the last enqueue.  Several enqueue calls may be queued before one fetch: the
+ * host-side preparation of a launch then overlaps the previous kernel. */
 int svoh_sparse_align_enqueue(svoh_ctx* ctx, const svoh_align_options* options,
                               int n_problems, const svoh_align_problem* problems);
 int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* results);
@@ -228,6 +230,10 @@ int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* re
 /* Device time (ms, HIP events on the context stream) of the alignment kernel
  * of the last enqueue/batch call; valid after fetch/batch returned. */
 int svoh_sparse_align_last_kernel_ms(svoh_ctx* ctx, float* ms);
+
+/* Device times (ms) of the last n alignment launches, oldest first (the library keeps the event pairs of the
+ * last 32): for callers that queue several enqueue calls before one fetch.  *n_out = entries written. */
+int svoh_sparse_align_kernel_ms_history(svoh_ctx* ctx, int n, float* ms, int* n_out);
 
 /* Diagnostic/parity entry: evaluate H (8x8 col-major), g (8), chi2, n_meas for
  * ONE problem at a given level and state, i.e. SparseImgAlign::evaluateError

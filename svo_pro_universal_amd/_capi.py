@@ -255,7 +255,7 @@ EXPORTS = [
     "svoh_upload_pyramid", "svoh_build_pyramid", "svoh_build_pyramid_batch",
     "svoh_download_level", "svoh_frame_info", "svoh_release_frame",
     "svoh_sparse_align_batch", "svoh_sparse_align_enqueue", "svoh_sparse_align_fetch",
-    "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms",
+    "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms", "svoh_sparse_align_kernel_ms_history",
     "svoh_sparse_align_split_buffers", "svoh_sparse_align_split_init", "svoh_sparse_align_partial_sums", "svoh_sparse_align_gn_update",
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
     "svoh_match_direct_batch",
@@ -328,6 +328,7 @@ def load():
                                                C.c_int, C.c_void_p, C.c_void_p, P(C.c_double),
                                                P(C.c_int32), C.c_void_p, P(C.c_int32)]
     lib.svoh_sparse_align_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float)]
+    lib.svoh_sparse_align_kernel_ms_history.argtypes = [C.c_void_p, C.c_int, P(C.c_float), P(C.c_int)]
     lib.svoh_sparse_align_split_buffers.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_void_p)]
     lib.svoh_sparse_align_split_init.argtypes = [C.c_void_p, P(svoh_align_problem), C.c_void_p]
     lib.svoh_sparse_align_partial_sums.argtypes = [C.c_void_p, P(svoh_align_options), P(svoh_align_problem), C.c_int,

@@ -211,8 +211,10 @@ int svoh_create(int device, svoh_ctx** out_ctx)
   ctx->err = "no error";
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreate(&ctx->ev_align_start);
-  if (e == hipSuccess) e = hipEventCreate(&ctx->ev_align_stop);
+  for (int k = 0; k < svoh_ctx::kAlignEventRing; ++k) {
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_align_start[k]);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_align_stop[k]);
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_align_staged, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev_misc_start);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev_misc_stop);
@@ -235,8 +237,10 @@ int svoh_destroy(svoh_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
   ctx->frames.clear();
-  if (ctx->ev_align_start) (void)hipEventDestroy(ctx->ev_align_start);
-  if (ctx->ev_align_stop) (void)hipEventDestroy(ctx->ev_align_stop);
+  for (int k = 0; k < svoh_ctx::kAlignEventRing; ++k) {
+    if (ctx->ev_align_start[k]) (void)hipEventDestroy(ctx->ev_align_start[k]);
+    if (ctx->ev_align_stop[k]) (void)hipEventDestroy(ctx->ev_align_stop[k]);
+  }
   if (ctx->ev_align_staged) (void)hipEventDestroy(ctx->ev_align_staged);
   if (ctx->ev_misc_start) (void)hipEventDestroy(ctx->ev_misc_start);
   if (ctx->ev_misc_stop) (void)hipEventDestroy(ctx->ev_misc_stop);

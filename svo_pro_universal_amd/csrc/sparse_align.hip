@@ -1266,7 +1266,8 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   int grid = ctx->num_cus * getenv_int("SVOH_ALIGN_WG_PER_CU", nt == 256 ? 2 : 1);
   if (grid > n_desc || grid <= 0) grid = n_desc;
   hipError_t e;
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_start, ctx->stream));
+  const int ev_slot = (int)(ctx->align_launches % svoh_ctx::kAlignEventRing);
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_start[ev_slot], ctx->stream));
   if (opt->patch_size == 4)
     e = illum ? launch_nt<4, true>(ctx->stream, nt, grid, lds, args)
               : launch_nt<4, false>(ctx->stream, nt, grid, lds, args);
@@ -1281,7 +1282,13 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
     const hipError_t es = hipGetLastError();
     if (es != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "sum_shares launch failed: %s", hipGetErrorString(es));
   }
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_stop, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_stop[ev_slot], ctx->stream));
+  ++ctx->align_launches;
+  // the results follow the kernel to pinned host memory right away, so that a caller which queues several
+  // launches and fetches once still has every launch's output delivered
+  if (S == 1 && eval_level < 0)
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results.ptr, ctx->d_results.ptr, sizeof(svoh_align_result) * n_problems,
+                                     hipMemcpyDeviceToHost, ctx->stream));
 #ifdef SVOH_PHASE_STAMPS
   {
     std::vector<long long> h((size_t)n_problems * 8);
@@ -1315,9 +1322,7 @@ int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* re
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, results && n_problems >= 1 && n_problems <= ctx->last_align_n, "nothing to fetch");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results.ptr, ctx->d_results.ptr, sizeof(svoh_align_result) * n_problems,
-                                   hipMemcpyDeviceToHost, ctx->stream));
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the copy to h_results was queued behind the kernel
   memcpy(results, ctx->h_results.ptr, sizeof(svoh_align_result) * n_problems);
   return SVOH_OK;
 }
@@ -1333,9 +1338,26 @@ int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options, in
 int svoh_sparse_align_last_kernel_ms(svoh_ctx* ctx, float* ms)
 {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
-  SVOH_REQUIRE(ctx, ms != nullptr && ctx->last_align_n > 0, "no alignment launch to time");
-  SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_stop));
-  SVOH_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_align_start, ctx->ev_align_stop));
+  SVOH_REQUIRE(ctx, ms != nullptr && ctx->align_launches > 0, "no alignment launch to time");
+  const int slot = (int)((ctx->align_launches - 1) % svoh_ctx::kAlignEventRing);
+  SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_stop[slot]));
+  SVOH_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_align_start[slot], ctx->ev_align_stop[slot]));
+  return SVOH_OK;
+}
+
+int svoh_sparse_align_kernel_ms_history(svoh_ctx* ctx, int n, float* ms, int* n_out)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, ms != nullptr && n_out != nullptr && n >= 0, "bad arguments");
+  int have = (int)(ctx->align_launches < (unsigned long long)svoh_ctx::kAlignEventRing ? ctx->align_launches
+                                                                                       : (unsigned long long)svoh_ctx::kAlignEventRing);
+  if (n < have) have = n;
+  for (int k = 0; k < have; ++k) {   // oldest of the requested launches first
+    const int slot = (int)((ctx->align_launches - (unsigned long long)have + (unsigned long long)k) % svoh_ctx::kAlignEventRing);
+    SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_stop[slot]));
+    SVOH_HIP_TRY(ctx, hipEventElapsedTime(&ms[k], ctx->ev_align_start[slot], ctx->ev_align_stop[slot]));
+  }
+  *n_out = have;
   return SVOH_OK;
 }
 

@@ -91,7 +91,11 @@ struct svoh_ctx {
   svoh::PinnedBuffer h_upload;
   svoh::PinnedBuffer h_results;
   int last_align_n = 0;
-  hipEvent_t ev_align_start = nullptr, ev_align_stop = nullptr;
+  // a ring of event pairs, one per alignment launch: callers that queue launches back to back (enqueue without
+  // fetch) can still read every launch's device time afterwards
+  static constexpr int kAlignEventRing = 32;
+  hipEvent_t ev_align_start[kAlignEventRing] = {}, ev_align_stop[kAlignEventRing] = {};
+  unsigned long long align_launches = 0;
   hipEvent_t ev_align_staged = nullptr;   // the alignment's pinned staging buffers have been consumed
   bool align_staging_in_flight = false;
   hipEvent_t ev_misc_start = nullptr, ev_misc_stop = nullptr;  // KLT / matcher / seeds
