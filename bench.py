@@ -582,6 +582,85 @@ def bench_pose(args, ctx, dist, rank, world, dev, comm_dev=None):
             "cpu_baseline": cpu}
 
 
+def bench_align_c4(args, ctx, dist, rank, world, dev, comm_dev=None):
+    """BASELINE config 4's alignment (SURVEY.md Appendix A, C4 column): a stereo bundle per problem -- two cameras
+    with different intrinsics (pinhole and EuRoC radtan) behind one rig motion, `--features` patches per camera --
+    illumination gain and offset estimated (8-DoF), rotation prior with lambda_rot 0.5, levels 4..2, 4x4 patches."""
+    P, N, B = args.patch, args.features, (args.problems or 512)
+    opt = capi.default_align_options(max_level=4, min_level=2, patch_size=P, estimate_illumination_gain=1,
+                                     estimate_illumination_offset=1)
+    cams = [synth.Camera.test_camera(), synth.Camera.euroc_like()]
+    scenes = [[synth.make_align_scene(du.problem_seed(rank, i), n_features=N, patch_size=P, cam=cam, max_level=4,
+                                      render_images=False, gain=1.03, offset=2.0) for cam in cams] for i in range(B)]
+    frames, imgs_keep = [], []
+    for c, cam in enumerate(cams):   # one rendering + pyramid batch per camera model
+        poses, planes, texs = [], [], []
+        for pair in scenes:
+            sc = pair[c]
+            poses += [sc.T_w_ref, sc.T_w_cur]; planes += [sc.plane] * 2; texs += [sc.tex] * 2
+        imgs = synth.render_batch_torch(cam, poses, planes, texs, dev, gains=[1.0, 1.03] * B, offsets=[0.0, 2.0] * B)
+        torch.cuda.synchronize()
+        frames.append(ctx.build_pyramid_batch_device(imgs.data_ptr(), cam.width * cam.height, 2 * B, cam.width, cam.height,
+                                                     cam.width, 5))
+        imgs_keep.append(imgs)
+    ctx.synchronize()
+    flat = [sc for pair in scenes for sc in pair]
+    px = torch.from_numpy(np.concatenate([s.px for s in flat])).to(dev)
+    f = torch.from_numpy(np.concatenate([s.f for s in flat])).to(dev)
+    pw = torch.from_numpy(np.concatenate([s.pos_world for s in flat])).to(dev)
+    fl = torch.from_numpy(np.concatenate([s.flags for s in flat])).to(dev)
+    items, priors, off = [], [], 0
+    for i, pair in enumerate(scenes):
+        cams_i = []
+        for c, sc in enumerate(pair):
+            dp = dict(px=px.data_ptr() + 16 * off, f=f.data_ptr() + 24 * off, pos_world=pw.data_ptr() + 24 * off,
+                      flags=fl.data_ptr() + off)
+            cams_i.append((sc, frames[c][2 * i], frames[c][2 * i + 1], dp))
+            off += sc.n_features
+        items.append(cams_i)
+        pr = capi.svoh_align_prior()
+        pr.have_prior = 1
+        pr.T_prior = fe._se3(pair[0].T_icur_iref_gt)    # an IMU-integrated rotation prior: the true relative pose
+        pr.lambda_rot = 0.5
+        priors.append(pr)
+    problems, keep = fe.make_align_problems(items, prior=priors)
+
+    def step():
+        ctx.sparse_align_enqueue(opt, problems)
+        return None, 0.0
+
+    for _ in range(max(1, args.warmup)):
+        res = ctx.sparse_align(opt, problems)
+    elapsed, _, _ = timed_steps(ctx, dist, world, dev, step, args.steps, 0)
+    res = ctx.sparse_align_fetch(len(problems))
+    n_hist = ctypes.c_int()
+    hist = (ctypes.c_float * 32)()
+    ctx._check(ctx.lib.svoh_sparse_align_kernel_ms_history(ctx.h, min(32, args.steps), hist, ctypes.byref(n_hist)))
+    kms = sum(hist[i] for i in range(n_hist.value)) / max(1, n_hist.value)
+    n_sel = sum(r.n_fts_to_track for r in res)
+    elapsed, total = du.combine(dist, world, elapsed, n_sel, comm_dev)
+    patch_iters = sum(r.n_patch_iters for r in res)
+    errs = [synth.se3_error(synth.SE3.from7(fe.se3_to_numpy(r.T_icur_iref)), pair[0].T_icur_iref_gt) for r, pair in zip(res, scenes)]
+    if rank != 0:
+        return None
+    alg = algorithmic_bytes(P, 8, patch_iters, n_sel * 3)
+    return {"metric": "aligned patches/s, stereo bundles with illumination terms and rotation prior (BASELINE config 4's alignment)",
+            "value": total * args.steps / elapsed, "unit": "aligned patches/s", "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_frame": 1e3 * elapsed / args.steps / B, "dtype": "f64",
+            "config": {"workload": "C4-synth alignment: %d stereo bundles per GPU per step, 2 cameras x %d patches x %dx%d, "
+                                   "levels 4..2, SE3 + gain + offset (8-DoF), rotation prior 0.5, inputs resident in HBM" % (B, N, P, P),
+                       "bundles_per_gpu": B, "patches_per_camera": N, "patch_size": P, "levels": [4, 2],
+                       "parallelism": "bundles sharded x%d, no collective" % world},
+            "patch_iterations_per_step": patch_iters, "patch_iterations_per_s": patch_iters * world * args.steps / elapsed,
+            "kernel_ms": kms, "solver_failures": sum(1 for r in res if r.status != 0),
+            "illumination_median": {"alpha": float(np.median([r.alpha for r in res])), "beta": float(np.median([r.beta for r in res]))},
+            "pose_err_vs_gt": {"rot_rad_median": float(np.median([e[0] for e in errs])), "trans_m_median": float(np.median([e[1] for e in errs]))},
+            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "sparse_align_kernel<%d,*,true>" % P,
+                         "algorithmic_bytes_per_launch": alg},
+            "cpu_baseline": None}
+
+
 def bench_align_split(args, ctx, dist, rank, world, dev, comm_dev=None):
     """SURVEY.md 8(e) second row / BASELINE config 5's collective: ONE frame pair, its N patches split over the
     ranks, every Gauss-Newton iteration = partial normal equations per rank -> all-reduce of 74 doubles (RCCL) ->
@@ -727,7 +806,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--problems", type=int, default=0, help="frame pairs per GPU per step (default: per workload)")
-    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds", "frame", "detect", "pose", "align-split"],
+    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds", "frame", "detect", "pose", "align-split", "align-c4"],
                     help="align = the headline SparseImgAlign config (default); klt / seeds = the other hot-path rows; "
                          "frame = the whole per-frame chain at EuRoC mono sizes, one frame at a time (latency)")
     ap.add_argument("--features", type=int, default=2000)
@@ -756,7 +835,7 @@ def main():
     ctx = fe.Context(local_rank)
     if args.workload != "align":
         out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame, "detect": bench_detect, "pose": bench_pose,
-               "align-split": bench_align_split}[args.workload](
+               "align-split": bench_align_split, "align-c4": bench_align_c4}[args.workload](
             args, ctx, dist, rank, world, dev, comm_dev)
         if rank == 0:
             out.setdefault("scaling", "weak")

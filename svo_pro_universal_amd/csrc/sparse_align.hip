@@ -29,6 +29,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <type_traits>
+
 #include "svoh_internal.h"
 #include "svoh_device_utils.h"
 #include "svoh_math.h"
@@ -107,6 +109,10 @@ struct ShState {
   float alpha_f, beta_f;
   int stop, level_done, nsel, status;
   long long patch_iters;
+  // LDL^T factor of the level's (H + prior information), kept while the Hessian is (gn_serial_step)
+  double fact[36];
+  int fact_tr[8];
+  int fact_nonzero;
 };
 
 // ---- image accessors --------------------------------------------------------
@@ -222,7 +228,10 @@ __device__ __forceinline__ void projection_jacobian(const Vec3& xyz_ref, const R
 // H = sum w J J^T and g = -sum w J r is that map applied to these moments.
 // This regroups the reference's per-pixel sum algebraically (same real-number
 // result; rounding differs at the 1e-16 level, like the reduction order does).
-template <int P, int D, bool RLDS, bool CLDS>
+// GONLY: the unweighted Hessian of a level does not change while the set of visible patches does not (inverse
+// compositional: the Jacobians are those of the reference patch), so later iterations only need the moments
+// against the residual -- Sxr Syr Srr [SIr Sr] -- i.e. the gradient and chi2.
+template <int P, int D, bool RLDS, bool CLDS, bool GONLY = false>
 __device__ __forceinline__ void patch_moments(
     const ImgView<RLDS>& ref, const ImgView<CLDS>& cur, int ru, int rv, double rsu, double rsv, int cu, int cv,
     double csu, double csv, double one_plus_alpha, double beta, bool robust, float weight_scale,
@@ -317,6 +326,16 @@ __device__ __forceinline__ void patch_moments(
       const double intensity_cur = cwtl * (double)curA[x] + cwtr * (double)curA[x + 1] +
                                    cwbl * (double)curB[x] + cwbr * (double)curB[x + 1];
       const double res = (intensity_cur * one_plus_alpha + beta) - ref_val;
+      if constexpr (GONLY) {
+        mom[3] += dx * res;   // Sxr
+        mom[4] += dy * res;   // Syr
+        mom[5] += res * res;  // Srr (chi2)
+        if constexpr (D == 8) {
+          mom[13] += res * ref_val;   // SIr
+          mom[14] += res;             // Sr
+        }
+        continue;
+      }
       double wdx = dx, wdy = dy, wr = res;
       if (robust) {
         const double w = (double)tukey_weight((float)(res / (double)weight_scale));
@@ -394,6 +413,21 @@ __device__ __forceinline__ void accumulate_patch(const double (&mom)[AccLayout<D
   acc[NH + D] += mom[5];
 }
 
+// Gradient-only form of the above for the iterations that reuse the level's Hessian: accg = (g[0..D), chi2).
+template <int D>
+__device__ __forceinline__ void accumulate_patch_gradient(const double (&mom)[AccLayout<D>::NMOM], const double jp0[6],
+                                                          const double jp1[6], double scale, bool est_alpha, bool est_beta,
+                                                          double (&accg)[D + 1])
+{
+#pragma unroll
+  for (int i = 0; i < 6; ++i) accg[i] -= (jp0[i] * scale) * mom[3] + (jp1[i] * scale) * mom[4];
+  if constexpr (D == 8) {
+    if (est_alpha) accg[6] += mom[13];
+    if (est_beta) accg[7] += mom[14];
+  }
+  accg[D] += mom[5];
+}
+
 template <int NT>
 __device__ __forceinline__ void stage_image(unsigned char* dst, const DevImage& im, int tid)
 {
@@ -440,12 +474,15 @@ constexpr int kWsPairs = 9;
 __device__ __forceinline__ double* ws_pair(const AlignKernelArgs& a, int pair, int64_t gi) { return a.wpk + ((int64_t)pair * a.slots + gi) * 2; }
 
 // All patches of one camera at one Gauss-Newton iteration: one thread per patch.
-template <int P, int D, int NT, bool LDS>
+// GONLY (see patch_moments): accumulate the gradient and chi2 only and report in `changed` whether any patch's
+// visibility differs from the one recorded by the last full pass (a.wvis) -- the caller then repeats the
+// iteration with a full pass.  A full pass records the visibility.
+template <int P, int D, int NT, bool LDS, bool GONLY = false>
 __device__ __forceinline__ void accumulate_camera(
     const AlignKernelArgs& a, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
-    bool robust, bool dist_jac, float weight_scale, bool write_vis, int tid,
-    double (&acc)[AccLayout<D>::NACC], int& nvis)
+    bool robust, bool dist_jac, float weight_scale, int tid,
+    double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed)
 {
   const CamModel cm = load_camera(cd.cam);
   const double patch_center = (P - 1) / 2.0f;
@@ -475,7 +512,8 @@ __device__ __forceinline__ void accumulate_camera(
         csu = u_tl - cu; csv = v_tl - cv;
       }
     }
-    if (write_vis) a.wvis[gi] = vis ? 1 : 0;
+    if constexpr (GONLY) changed |= (int)(a.wvis[gi] != (vis ? 1 : 0));
+    else a.wvis[gi] = vis ? 1 : 0;
     if (!vis) continue;
     ++nvis;
     // ---- a-5 reference side (recomputed, never stored) ----
@@ -484,8 +522,8 @@ __device__ __forceinline__ void accumulate_camera(
     const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
     const double rsu = ru_tl - ru, rsv = rv_tl - rv;
     double mom[AccLayout<D>::NMOM];
-    patch_moments<P, D, LDS, LDS>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d, robust,
-                                  weight_scale, mom);
+    patch_moments<P, D, LDS, LDS, GONLY>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d, robust,
+                                         weight_scale, mom);
     double jp0[6], jp1[6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -494,7 +532,8 @@ __device__ __forceinline__ void accumulate_camera(
       jp0[2 * k] = q0.x; jp0[2 * k + 1] = q0.y;
       jp1[2 * k] = q1.x; jp1[2 * k + 1] = q1.y;
     }
-    accumulate_patch<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
+    if constexpr (GONLY) accumulate_patch_gradient<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
+    else accumulate_patch<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
   }
 }
 
@@ -505,12 +544,12 @@ __device__ __forceinline__ void accumulate_camera(
 // the head (pairs 0..2) of the NEXT patch and the Jacobian rows (pairs 3..8) of THIS patch are requested right
 // after this patch's head has been read, and both arrive while the pixel loop runs.
 // stage: this wave's 9 x 64 x 16 B staging area.  Control flow is wave-uniform (every lane runs every pass).
-template <int P, int D, int NT, bool LDS>
+template <int P, int D, int NT, bool LDS, bool GONLY = false>
 __device__ __forceinline__ void accumulate_camera_staged(
     const AlignKernelArgs& a, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
-    bool robust, bool dist_jac, float weight_scale, bool write_vis, int tid, double* stage,
-    double (&acc)[AccLayout<D>::NACC], int& nvis)
+    bool robust, bool dist_jac, float weight_scale, int tid, double* stage,
+    double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed)
 {
   typedef const __attribute__((address_space(1))) void* gptr;
   typedef __attribute__((address_space(3))) void* lptr;
@@ -537,6 +576,10 @@ __device__ __forceinline__ void accumulate_camera_staged(
     if (i + NT < n) request(0, 3, gi + NT);
     const bool sel = in_range && vs.y != 0.0;
     if (sel) request(3, kWsPairs, gi);
+    // visibility recorded by the last full pass: requested here, compared after the pixel loop (a use any earlier
+    // would wait for the Jacobian rows as well -- the vector memory counter is shared)
+    unsigned vis_recorded = 0;
+    if constexpr (GONLY) { if (sel) vis_recorded = a.wvis[gi]; }
     bool vis = false;
     double mom[AccLayout<D>::NMOM];
     if (sel) {
@@ -558,18 +601,19 @@ __device__ __forceinline__ void accumulate_camera_staged(
           csu = u_tl - cu; csv = v_tl - cv;
         }
       }
-      if (write_vis) a.wvis[gi] = vis ? 1 : 0;
+      if constexpr (!GONLY) a.wvis[gi] = vis ? 1 : 0;
       if (vis) {
         ++nvis;
         const double ru_tl = zu.y * scale - patch_center_wb;
         const double rv_tl = vs.x * scale - patch_center_wb;
         const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
         const double rsu = ru_tl - ru, rsv = rv_tl - rv;
-        patch_moments<P, D, LDS, LDS>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d, robust,
-                                      weight_scale, mom);
+        patch_moments<P, D, LDS, LDS, GONLY>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d,
+                                             robust, weight_scale, mom);
       }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the Jacobian rows (requested before the pixel loop) are in LDS
+    if constexpr (GONLY) { if (sel) changed |= (int)(vis_recorded != (vis ? 1u : 0u)); }
     if (vis) {
       double jp0[6], jp1[6];
 #pragma unroll
@@ -579,7 +623,8 @@ __device__ __forceinline__ void accumulate_camera_staged(
         jp0[2 * k] = q0.x; jp0[2 * k + 1] = q0.y;
         jp1[2 * k] = q1.x; jp1[2 * k + 1] = q1.y;
       }
-      accumulate_patch<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
+      if constexpr (GONLY) accumulate_patch_gradient<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
+      else accumulate_patch<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) before the next pass may request the Jacobian buffer again
   }
@@ -593,8 +638,8 @@ __device__ __forceinline__ void accumulate_camera_staged(
 template <int P, int D, bool ILLUM>
 __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& a, const DevProblemDesc& pb,
                                                          const DevCamDesc* cams, int n_cams, int pbi, int level,
-                                                         int iter, bool eval_mode, ShState& s, const double* s_sum,
-                                                         int* s_nvis_p)
+                                                         int iter, bool eval_mode, bool reuse_factor, ShState& s,
+                                                         const double* s_sum, int* s_nvis_p)
 {
   constexpr int NH = AccLayout<D>::NH;
   const svoh_align_options& opt = a.opt;
@@ -652,8 +697,10 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
           s.I_prior[6] = pb.prior.lambda_alpha * SVOH_L(6, 6);
           s.I_prior[7] = pb.prior.lambda_beta * SVOH_L(7, 7);
         }
+        if (!reuse_factor) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) SVOH_L(j, j) += s.I_prior[j];
+          for (int j = 0; j < 8; ++j) SVOH_L(j, j) += s.I_prior[j];
+        }
         double lg[6];
         rigid_log(mul(inverse(load_rigid(pb.prior.T_prior)), s.T), lg);
 #pragma unroll
@@ -664,15 +711,49 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
       // without illumination terms rows/columns 6 and 7 are exactly zero: the
       // pivoted factorisation never selects them before the six pose pivots and
       // they contribute exact zeros, so the 6x6 leading block gives the same bits
+      // The factor is computed when the normal matrix is new (a full pass) and kept in s.fact for the iterations
+      // that only refresh the gradient: same matrix, same factor, same bits as factorising again.
       if constexpr (ILLUM) {
-        if (!ldlt_solve_regs<8>(m, xg)) s.stop = 1;
+        int tr[8];
+        bool nonzero;
+        if (!reuse_factor) {
+          nonzero = ldlt_factor_regs<8>(m, tr);
+#pragma unroll
+          for (int k = 0; k < 36; ++k) s.fact[k] = m[k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s.fact_tr[k] = tr[k];
+          s.fact_nonzero = nonzero ? 1 : 0;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 36; ++k) m[k] = s.fact[k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) tr[k] = s.fact_tr[k];
+          nonzero = s.fact_nonzero != 0;
+        }
+        if (!ldlt_apply_regs<8>(m, tr, nonzero, xg)) s.stop = 1;
       } else {
         double m6[21], x6[6];
+        int tr[6];
+        bool nonzero;
+        if (!reuse_factor) {
 #pragma unroll
-        for (int k = 0; k < 21; ++k) m6[k] = m[k];
+          for (int k = 0; k < 21; ++k) m6[k] = m[k];
+          nonzero = ldlt_factor_regs<6>(m6, tr);
+#pragma unroll
+          for (int k = 0; k < 21; ++k) s.fact[k] = m6[k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) s.fact_tr[k] = tr[k];
+          s.fact_nonzero = nonzero ? 1 : 0;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 21; ++k) m6[k] = s.fact[k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) tr[k] = s.fact_tr[k];
+          nonzero = s.fact_nonzero != 0;
+        }
 #pragma unroll
         for (int k = 0; k < 6; ++k) x6[k] = xg[k];
-        if (!ldlt_solve_regs<6>(m6, x6)) s.stop = 1;
+        if (!ldlt_apply_regs<6>(m6, tr, nonzero, x6)) s.stop = 1;
 #pragma unroll
         for (int k = 0; k < 6; ++k) xg[k] = x6[k];
         xg[6] = 0.0; xg[7] = 0.0;
@@ -706,6 +787,9 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
 
 #ifndef SVOH_ALIGN_STAGED
 #define SVOH_ALIGN_STAGED 1
+#endif
+#ifndef SVOH_ALIGN_REUSE_HESSIAN
+#define SVOH_ALIGN_REUSE_HESSIAN 1
 #endif
 #ifndef SVOH_ALIGN_MIN_WAVES_256
 #define SVOH_ALIGN_MIN_WAVES_256 2
@@ -885,69 +969,104 @@ void sparse_align_kernel(const AlignKernelArgs a)
     SVOH_STAMP_ADD(1);
 
     for (int iter = 0; iter < opt.max_iter; ++iter) {
-      double acc[NACC];
-#pragma unroll
-      for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-      int nvis = 0;
       const double one_plus_alpha = uniform_f64(1.0 + (double)s.alpha_f);
       const double beta_d = uniform_f64((double)s.beta_f);
-
-      int off = 0;
-      for (int c = 0; c < n_cams; ++c) {
-        const DevCamDesc& cd = cams[c];
-        const DevImage& rim = cd.ref[level];
-        const DevImage& cim = cd.cur[level];
-        const Rigid Tcr = uniform_rigid(s.Tcr[c]);
-        if (in_lds) {
-          ImgView<true> ref, cur;
-          ref.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); ref.pitch = rim.w;
-          off += ((rim.w * rim.h + 15) & ~15);
-          cur.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); cur.pitch = cim.w;
-          off += ((cim.w * cim.h + 15) & ~15);
-          if constexpr (STAGED)
-            accumulate_camera_staged<P, D, NT, true>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                                     est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
-                                                     s_stage + wave * kWsPairs * 128, acc, nvis);
-          else
-            accumulate_camera<P, D, NT, true>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                              est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
-                                              acc, nvis);
+      // Without robust weights the Hessian of a level only depends on which patches are visible (the Jacobians
+      // are the reference patch's: inverse compositional), so after the level's first iteration a pass computes
+      // the gradient and chi2 only and the solver reuses the level's factorisation.  A pass that finds a patch
+      // whose visibility differs from the last full pass is thrown away and repeated in full: the numbers are
+      // those of recomputing the Hessian every iteration, as the reference does.
+      bool light = SVOH_ALIGN_REUSE_HESSIAN && !eval_mode && !robust && iter > 0;
+      for (;;) {
+        int nvis = 0, changed = 0;
+        auto run_cameras = [&](auto gonly_tag, auto& acc_ref) {
+          constexpr bool G = decltype(gonly_tag)::value;
+          int off = 0;
+          for (int c = 0; c < n_cams; ++c) {
+            const DevCamDesc& cd = cams[c];
+            const DevImage& rim = cd.ref[level];
+            const DevImage& cim = cd.cur[level];
+            const Rigid Tcr = uniform_rigid(s.Tcr[c]);
+            if (in_lds) {
+              ImgView<true> ref, cur;
+              ref.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); ref.pitch = rim.w;
+              off += ((rim.w * rim.h + 15) & ~15);
+              cur.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); cur.pitch = cim.w;
+              off += ((cim.w * cim.h + 15) & ~15);
+              if constexpr (STAGED)
+                accumulate_camera_staged<P, D, NT, true, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                            est_alpha, est_beta, robust, dist_jac, weight_scale, tid,
+                                                            s_stage + wave * kWsPairs * 128, acc_ref, nvis, changed);
+              else
+                accumulate_camera<P, D, NT, true, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                     est_alpha, est_beta, robust, dist_jac, weight_scale, tid, acc_ref, nvis,
+                                                     changed);
+            } else {
+              ImgView<false> ref, cur;
+              ref.p = rim.data; ref.pitch = rim.pitch;
+              cur.p = cim.data; cur.pitch = cim.pitch;
+              if constexpr (STAGED)
+                accumulate_camera_staged<P, D, NT, false, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                             est_alpha, est_beta, robust, dist_jac, weight_scale, tid,
+                                                             s_stage + wave * kWsPairs * 128, acc_ref, nvis, changed);
+              else
+                accumulate_camera<P, D, NT, false, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                      est_alpha, est_beta, robust, dist_jac, weight_scale, tid, acc_ref, nvis,
+                                                      changed);
+            }
+          }
+        };
+        if (light) {
+          double accg[D + 1];
+#pragma unroll
+          for (int k = 0; k < D + 1; ++k) accg[k] = 0.0;
+          run_cameras(std::true_type(), accg);
+          if (__syncthreads_or(changed)) { light = false; continue; }   // visibility moved: this iteration in full
+          SVOH_STAMP_ADD(2);
+          {
+            int ridx;
+            bool rvalid;
+            wave_reduce_scatter<D + 1>(accg, lane, ridx, rvalid);
+            if (rvalid) s_red[wave][ridx] = accg[0];
+          }
+          nvis = wave_sum_i32_dpp(nvis);
+          if (lane == 0) atomicAdd(&s_nvis, nvis);
+          __syncthreads();
+          if (tid < D + 1) {   // gradient and chi2 only: s_sum[0 .. NH) still holds the level's Hessian
+            double v = 0.0;
+            for (int w = 0; w < NW; ++w) v += s_red[w][tid];
+            s_sum[AccLayout<D>::NH + tid] = v;
+          }
+          __syncthreads();
         } else {
-          ImgView<false> ref, cur;
-          ref.p = rim.data; ref.pitch = rim.pitch;
-          cur.p = cim.data; cur.pitch = cim.pitch;
-          if constexpr (STAGED)
-            accumulate_camera_staged<P, D, NT, false>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                                      est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
-                                                      s_stage + wave * kWsPairs * 128, acc, nvis);
-          else
-            accumulate_camera<P, D, NT, false>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                               est_alpha, est_beta, robust, dist_jac, weight_scale, eval_mode, tid,
-                                               acc, nvis);
+          double acc[NACC];
+#pragma unroll
+          for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+          run_cameras(std::false_type(), acc);
+          SVOH_STAMP_ADD(2);
+          // ---- reduce: butterfly reduce-scatter per wave, then across waves through LDS ----
+          {
+            int ridx;
+            bool rvalid;
+            wave_reduce_scatter<NACC>(acc, lane, ridx, rvalid);
+            if (rvalid) s_red[wave][ridx] = acc[0];
+          }
+          nvis = wave_sum_i32_dpp(nvis);
+          if (lane == 0) atomicAdd(&s_nvis, nvis);
+          __syncthreads();
+          if (tid < NACC) {
+            double v = 0.0;
+            for (int w = 0; w < NW; ++w) v += s_red[w][tid];
+            s_sum[tid] = v;
+          }
+          __syncthreads();
         }
+        break;
       }
-
-      SVOH_STAMP_ADD(2);
-      // ---- reduce: butterfly reduce-scatter per wave, then across waves through LDS ----
-      {
-        int ridx;
-        bool rvalid;
-        wave_reduce_scatter<NACC>(acc, lane, ridx, rvalid);
-        if (rvalid) s_red[wave][ridx] = acc[0];
-      }
-      nvis = wave_sum_i32_dpp(nvis);
-      if (lane == 0) atomicAdd(&s_nvis, nvis);
-      __syncthreads();
-      if (tid < NACC) {
-        double v = 0.0;
-        for (int w = 0; w < NW; ++w) v += s_red[w][tid];
-        s_sum[tid] = v;
-      }
-      __syncthreads();
 
       SVOH_STAMP_ADD(3);
-      // ---- serial part: prior, pivoted LDL^T, SE3 update, convergence ----
-      if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, pbi, level, iter, eval_mode, s, s_sum, &s_nvis);
+      // ---- serial part: prior, pivoted LDL^T (or the level's factor again), SE3 update, convergence ----
+      if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, pbi, level, iter, eval_mode, light, s, s_sum, &s_nvis);
       __syncthreads();
       SVOH_STAMP_ADD(4);
       if (s.level_done) break;
@@ -1013,7 +1132,7 @@ void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_al
   }
   const int n_meas = (int)sums[73];
   int nvis = n_meas / (P * P);
-  gn_serial_step<P, D, ILLUM>(a, pb, cams, pb.n_cams, 0, level, iter, false, s, s_sum, &nvis);
+  gn_serial_step<P, D, ILLUM>(a, pb, cams, pb.n_cams, 0, level, iter, false, false, s, s_sum, &nvis);
   store_rigid(s.T, st->T_icur_iref);
   st->alpha = s.alpha; st->beta = s.beta;
   store_rigid(s.Told, st->T_old);

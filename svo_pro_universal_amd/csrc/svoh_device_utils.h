@@ -72,10 +72,16 @@ __device__ __forceinline__ void swap_d(double& a, double& b) { const double t = 
 #ifndef SVOH_L
 #define SVOH_L(r, c) m[(r) * ((r) + 1) / 2 + (c)]
 #endif
+// Eigen 3.4 LDLT<Lower> (unblocked, diagonal pivoting) in registers, split into the factorisation and the solve
+// so that a caller whose matrix does not change between solves (inverse-compositional Gauss-Newton: the Hessian
+// of a level is constant while the visible set is) can keep the factor.  m: packed lower triangle, overwritten
+// with L (unit diagonal implied) and D; tr: transpositions.  Returns false when the whole diagonal is zero:
+// Eigen then stops with identity transpositions and the D^-1 step zeroes every component of the solution.
 template <int N>
-__device__ __forceinline__ bool ldlt_solve_regs(double (&m)[N * (N + 1) / 2], double (&x)[N])
+__device__ __forceinline__ bool ldlt_factor_regs(double (&m)[N * (N + 1) / 2], int (&tr)[N])
 {
-  int tr[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) tr[k] = k;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     int big = k;
@@ -118,17 +124,23 @@ __device__ __forceinline__ bool ldlt_solve_regs(double (&m)[N * (N + 1) / 2], do
     }
     const double akk = SVOH_L(k, k);
     const bool pivot_ok = fabs(akk) > 0.0;
-    if (k == 0 && !pivot_ok) {
-      // the whole diagonal is zero: Eigen stops with identity transpositions and
-      // the D^-1 step zeroes every component of the solution
-#pragma unroll
-      for (int j = 0; j < N; ++j) x[j] = 0.0;
-      return true;
-    }
+    if (k == 0 && !pivot_ok) return false;
     if (pivot_ok) {
 #pragma unroll
       for (int r = k + 1; r < N; ++r) SVOH_L(r, k) /= akk;
     }
+  }
+  return true;
+}
+
+// x <- A^-1 x with the factor of ldlt_factor_regs (nonzero = its return value); false when the solution is NaN.
+template <int N>
+__device__ __forceinline__ bool ldlt_apply_regs(const double (&m)[N * (N + 1) / 2], const int (&tr)[N], bool nonzero, double (&x)[N])
+{
+  if (!nonzero) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] = 0.0;
+    return true;
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -162,6 +174,14 @@ __device__ __forceinline__ bool ldlt_solve_regs(double (&m)[N * (N + 1) / 2], do
       if (tr[k] == bb) swap_d(x[k], x[bb]);
   }
   return !(x[0] != x[0]);
+}
+
+template <int N>
+__device__ __forceinline__ bool ldlt_solve_regs(double (&m)[N * (N + 1) / 2], double (&x)[N])
+{
+  int tr[N];
+  const bool nonzero = ldlt_factor_regs<N>(m, tr);
+  return ldlt_apply_regs<N>(m, tr, nonzero, x);
 }
 
 

@@ -204,9 +204,10 @@ def render(cam, T_w_c, plane, tex, xp=np, device=None, dtype=None, gain=1.0, off
     return xp.clip(xp.floor(img + 0.5), 0, 255).to(xp.uint8)
 
 
-def render_batch_torch(cam, poses, planes, texs, device, chunk=32):
+def render_batch_torch(cam, poses, planes, texs, device, chunk=32, gains=None, offsets=None):
     """torch only: render len(poses) u8 images (N x H x W) in chunks, vectorised
-    over the scene parameters (same arithmetic as render(), fp64)."""
+    over the scene parameters (same arithmetic as render(), fp64).  gains / offsets: optional per-image
+    illumination change I -> gain * I + offset before quantisation."""
     import torch
     n = len(poses)
     out = torch.empty((n, cam.height, cam.width), dtype=torch.uint8, device=device)
@@ -244,6 +245,10 @@ def render_batch_torch(cam, poses, planes, texs, device, chunk=32):
         acc = torch.full_like(s, 128.0)
         for k in range(amp.shape[1]):
             acc += B3(amp, k) * torch.sin((2 * math.pi) * (B3(fs, k) * s + B3(ft, k) * t) + B3(phi, k))
+        if gains is not None:
+            acc = acc * col(gains[c0:c1])[:, None, None]
+        if offsets is not None:
+            acc = acc + col(offsets[c0:c1])[:, None, None]
         out[c0:c1] = torch.clip(torch.floor(acc + 0.5), 0, 255).to(torch.uint8)
     return out
 
