@@ -668,39 +668,39 @@ __device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_op
   SVOH_MSTAMP(m, 1);
   if (!warp_ok) return SVOH_MATCH_FAIL_WARP;
 
+  // The reference refines the match at two places (matcher.cpp:205-215 for an epipolar segment shorter than two
+  // pixels, :229-235 after the scan).  Here both kinds of lanes meet at ONE call of find_local_match: inlined
+  // twice, the alignment loops of the two places run one after the other in every wave that holds both kinds.
+  bool refine;
   if (m.epi_length_pyramid < 2.0) {
     m.px_cur[0] = (pAx + pBx) / 2.0;
     m.px_cur[1] = (pAy + pBy) / 2.0;
+    refine = true;
+  } else {
+    // PatchScore constructor (patch_score.h:80-92)
+    int sumA = 0, sumAA = 0;
+    for (int r = 0; r < 64; ++r) { const int n = patch_at(m.pwb, r); sumA += n; sumAA += n * n; }
+    const Vec3 C = { Rf.x + T_cur_ref.t.x * d_estimate_inv, Rf.y + T_cur_ref.t.y * d_estimate_inv,
+                     Rf.z + T_cur_ref.t.z * d_estimate_inv };
+    if (opt.scan_on_unit_sphere)
+      scan_epipolar_unit_sphere(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
+    else
+      scan_epipolar_unit_plane(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
+    if (!(zmssd_best < ZMSSD_THRESHOLD)) {
+      SVOH_MSTAMP(m, 2);
+      return SVOH_MATCH_FAIL_SCORE;
+    }
+    refine = opt.subpix_refinement != 0;
+  }
+  SVOH_MSTAMP(m, 2);
+  if (refine) {
     const int res = find_local_match(m, opt, cur_frame, ed0, ed1, m.search_level, m.px_cur[0], m.px_cur[1]);
     SVOH_MSTAMP(m, 3);
     if (res != SVOH_MATCH_SUCCESS) return res;
-    m.f_cur = back_project3(cur_frame.cam, m.px_cur[0], m.px_cur[1]);
-    normalize3(m.f_cur);
-    return depth_from_triangulation(T_cur_ref, f_ref, m.f_cur, depth);
   }
-
-  // PatchScore constructor (patch_score.h:80-92)
-  int sumA = 0, sumAA = 0;
-  for (int r = 0; r < 64; ++r) { const int n = patch_at(m.pwb, r); sumA += n; sumAA += n * n; }
-  const Vec3 C = { Rf.x + T_cur_ref.t.x * d_estimate_inv, Rf.y + T_cur_ref.t.y * d_estimate_inv,
-                   Rf.z + T_cur_ref.t.z * d_estimate_inv };
-  if (opt.scan_on_unit_sphere)
-    scan_epipolar_unit_sphere(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
-  else
-    scan_epipolar_unit_plane(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
-  SVOH_MSTAMP(m, 2);
-
-  if (zmssd_best < ZMSSD_THRESHOLD) {
-    if (opt.subpix_refinement) {
-      const int res = find_local_match(m, opt, cur_frame, ed0, ed1, m.search_level, m.px_cur[0], m.px_cur[1]);
-      SVOH_MSTAMP(m, 3);
-      if (res != SVOH_MATCH_SUCCESS) return res;
-    }
-    m.f_cur = back_project3(cur_frame.cam, m.px_cur[0], m.px_cur[1]);
-    normalize3(m.f_cur);
-    return depth_from_triangulation(T_cur_ref, f_ref, m.f_cur, depth);
-  }
-  return SVOH_MATCH_FAIL_SCORE;
+  m.f_cur = back_project3(cur_frame.cam, m.px_cur[0], m.px_cur[1]);
+  normalize3(m.f_cur);
+  return depth_from_triangulation(T_cur_ref, f_ref, m.f_cur, depth);
 }
 
 // math_utils.h:186-194
