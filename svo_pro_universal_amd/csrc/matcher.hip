@@ -280,22 +280,31 @@ __device__ void mat4f_inverse(const float* m, float* r)
 #undef M4
 
 // feature_alignment.cpp:31-209
-__device__ bool align_1d(const DevImage& cur_img, double dir0, double dir1, const unsigned char* pwb, int n_iter,
-                         bool affine_est_offset, bool affine_est_gain, double& px, double& py, double* h_inv,
-                         int& n_it)
+// The two sub-pixel refinements are written as (set-up, one iteration): the seed kernel runs the iterations of
+// many seeds through a shared job queue (update_seeds_kernel), the direct matcher runs them in place.
+struct AlignIter {
+  float Hinv[16];      // 4x4 (2-D) or 3x3 in the first nine entries (1-D)
+  float u, v, mean_diff, alpha;
+  double dir0, dir1;   // 1-D only
+  int n_it;
+};
+enum { ALIGN_CONTINUE = 0, ALIGN_CONVERGED = 1, ALIGN_STOPPED = 2, ALIGN_NAN = 3 };
+
+// feature_alignment.cpp:31-209, the part before the iterations (H, its inverse, h_inv)
+__device__ void align_1d_init(double dir0, double dir1, const unsigned char* pwb, bool affine_est_offset, bool affine_est_gain,
+                              double px, double py, double* h_inv, AlignIter& it)
 {
-  constexpr int kHalfPatchSize = 4, kPatchSize = 8, ref_step = 10;
-  bool converged = false;
+  constexpr int kPatchSize = 8, ref_step = 10;
   float H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   for (int y = 0; y < kPatchSize; ++y) {
-    const unsigned char* it = pwb + (y + 1) * ref_step + 1;
-    for (int x = 0; x < kPatchSize; ++x, ++it) {
+    const unsigned char* p = pwb + (y + 1) * ref_step + 1;
+    for (int x = 0; x < kPatchSize; ++x, ++p) {
       float J[3];
-      const float dx = (float)it[1] - (float)it[-1];
-      const float dy = (float)it[ref_step] - (float)it[-ref_step];
+      const float dx = (float)p[1] - (float)p[-1];
+      const float dy = (float)p[ref_step] - (float)p[-ref_step];
       J[0] = (float)(0.5f * (dir0 * dx + dir1 * dy));
       J[1] = affine_est_offset ? 1.0f : 0.0f;
-      J[2] = affine_est_gain ? -1.0f * it[0] : 0.0f;
+      J[2] = affine_est_gain ? -1.0f * p[0] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -305,74 +314,98 @@ __device__ bool align_1d(const DevImage& cur_img, double dir0, double dir1, cons
   if (!affine_est_offset) H[4] = 1.0f;
   if (!affine_est_gain) H[8] = 1.0f;
   if (h_inv) *h_inv = 1.0 / H[0] * kPatchSize * kPatchSize;
-  float Hinv[9];
-  mat3f_inverse(H, Hinv);
-  float mean_diff = 0;
-  float alpha = 1.0;
-  float u = (float)px;
-  float v = (float)py;
+  mat3f_inverse(H, it.Hinv);
+  it.mean_diff = 0;
+  it.alpha = 1.0;
+  it.u = (float)px;
+  it.v = (float)py;
+  it.dir0 = dir0; it.dir1 = dir1;
+  it.n_it = 0;
+}
+
+// one pass of the loop body of feature_alignment.cpp:103-204
+__device__ int align_1d_step(const DevImage& cur_img, const unsigned char* pwb, bool affine_est_offset, bool affine_est_gain,
+                             AlignIter& it)
+{
+  constexpr int kHalfPatchSize = 4, kPatchSize = 8, ref_step = 10;
   const float min_update_squared = (float)(0.03 * 0.03);
   const int cur_step = cur_img.pitch;
-  for (int iter = 0; iter < n_iter; ++iter) {
-    const int u_r = (int)floorf(u);
-    const int v_r = (int)floorf(v);
-    if (u_r < kHalfPatchSize || v_r < kHalfPatchSize || u_r >= cur_img.w - kHalfPatchSize || v_r >= cur_img.h - kHalfPatchSize)
-      break;
-    if (u != u || v != v) return false;
-    ++n_it;
-    const float subpix_x = u - u_r;
-    const float subpix_y = v - v_r;
-    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
-    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
-    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
-    const float wBR = subpix_x * subpix_y;
-    float Jres[3] = { 0, 0, 0 };
+  const double dir0 = it.dir0, dir1 = it.dir1;
+  float u = it.u, v = it.v;
+  const int u_r = (int)floorf(u);
+  const int v_r = (int)floorf(v);
+  if (u_r < kHalfPatchSize || v_r < kHalfPatchSize || u_r >= cur_img.w - kHalfPatchSize || v_r >= cur_img.h - kHalfPatchSize)
+    return ALIGN_STOPPED;
+  if (u != u || v != v) return ALIGN_NAN;
+  ++it.n_it;
+  const float subpix_x = u - u_r;
+  const float subpix_y = v - v_r;
+  const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
+  const float wTR = (float)(subpix_x * (1.0 - subpix_y));
+  const float wBL = (float)((1.0 - subpix_x) * subpix_y);
+  const float wBR = subpix_x * subpix_y;
+  float Jres[3] = { 0, 0, 0 };
 #pragma unroll 2
-    for (int y = 0; y < kPatchSize; ++y) {
-      const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + y - kHalfPatchSize) * cur_step + u_r - kHalfPatchSize;
-      const unsigned char* rp = pwb + (y + 1) * ref_step + 1;
-      for (int x = 0; x < kPatchSize; ++x, ++it, ++rp) {
-        const float gdx = (float)rp[1] - (float)rp[-1];
-        const float gdy = (float)rp[ref_step] - (float)rp[-ref_step];
-        const float ref_dv = (float)(0.5f * (dir0 * gdx + dir1 * gdy));
-        const float cur_intensity = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
-        const float res = cur_intensity - alpha * rp[0] + mean_diff;
-        Jres[0] -= res * ref_dv;
-        if (affine_est_offset) Jres[1] -= res;
-        if (affine_est_gain) Jres[2] -= (-1) * res * rp[0];
-      }
+  for (int y = 0; y < kPatchSize; ++y) {
+    const uint8_t* p = cur_img.data + (ptrdiff_t)(v_r + y - kHalfPatchSize) * cur_step + u_r - kHalfPatchSize;
+    const unsigned char* rp = pwb + (y + 1) * ref_step + 1;
+    for (int x = 0; x < kPatchSize; ++x, ++p, ++rp) {
+      const float gdx = (float)rp[1] - (float)rp[-1];
+      const float gdy = (float)rp[ref_step] - (float)rp[-ref_step];
+      const float ref_dv = (float)(0.5f * (dir0 * gdx + dir1 * gdy));
+      const float cur_intensity = wTL * p[0] + wTR * p[1] + wBL * p[cur_step] + wBR * p[cur_step + 1];
+      const float res = cur_intensity - it.alpha * rp[0] + it.mean_diff;
+      Jres[0] -= res * ref_dv;
+      if (affine_est_offset) Jres[1] -= res;
+      if (affine_est_gain) Jres[2] -= (-1) * res * rp[0];
     }
-    if (!affine_est_offset) Jres[1] = 0.0f;
-    if (!affine_est_gain) Jres[2] = 0.0f;
-    float update[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) update[r] = (Hinv[r * 3 + 0] * Jres[0] + Hinv[r * 3 + 1] * Jres[1]) + Hinv[r * 3 + 2] * Jres[2];
-    u = (float)(u + update[0] * dir0);
-    v = (float)(v + update[0] * dir1);
-    mean_diff += update[1];
-    alpha += update[2];
-    if (update[0] * update[0] < min_update_squared) { converged = true; break; }
   }
-  px = u;
-  py = v;
+  if (!affine_est_offset) Jres[1] = 0.0f;
+  if (!affine_est_gain) Jres[2] = 0.0f;
+  float update[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) update[r] = (it.Hinv[r * 3 + 0] * Jres[0] + it.Hinv[r * 3 + 1] * Jres[1]) + it.Hinv[r * 3 + 2] * Jres[2];
+  it.u = (float)(u + update[0] * dir0);
+  it.v = (float)(v + update[0] * dir1);
+  it.mean_diff += update[1];
+  it.alpha += update[2];
+  return (update[0] * update[0] < min_update_squared) ? ALIGN_CONVERGED : ALIGN_CONTINUE;
+}
+
+// feature_alignment.cpp:31-209
+__device__ bool align_1d(const DevImage& cur_img, double dir0, double dir1, const unsigned char* pwb, int n_iter,
+                         bool affine_est_offset, bool affine_est_gain, double& px, double& py, double* h_inv,
+                         int& n_it)
+{
+  AlignIter it;
+  align_1d_init(dir0, dir1, pwb, affine_est_offset, affine_est_gain, px, py, h_inv, it);
+  bool converged = false;
+  for (int iter = 0; iter < n_iter; ++iter) {
+    const int st = align_1d_step(cur_img, pwb, affine_est_offset, affine_est_gain, it);
+    if (st == ALIGN_NAN) { n_it += it.n_it; return false; }
+    if (st == ALIGN_STOPPED) break;
+    if (st == ALIGN_CONVERGED) { converged = true; break; }
+  }
+  n_it += it.n_it;
+  px = it.u;
+  py = it.v;
   return converged;
 }
 
-// feature_alignment.cpp:212-391
-__device__ bool align_2d(const DevImage& cur_img, const unsigned char* pwb, int n_iter, bool affine_est_offset,
-                         bool affine_est_gain, double& px, double& py, int& n_it)
+// feature_alignment.cpp:212-391, the part before the iterations
+__device__ void align_2d_init(const unsigned char* pwb, bool affine_est_offset, bool affine_est_gain, double px, double py,
+                              AlignIter& it)
 {
-  constexpr int halfpatch_size_ = 4, patch_size_ = 8, ref_step = 10;
-  bool converged = false;
+  constexpr int patch_size_ = 8, ref_step = 10;
   float H[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   for (int y = 0; y < patch_size_; ++y) {
-    const unsigned char* it = pwb + (y + 1) * ref_step + 1;
-    for (int x = 0; x < patch_size_; ++x, ++it) {
+    const unsigned char* p = pwb + (y + 1) * ref_step + 1;
+    for (int x = 0; x < patch_size_; ++x, ++p) {
       float J[4];
-      J[0] = (float)(0.5 * ((int)it[1] - (int)it[-1]));
-      J[1] = (float)(0.5 * ((int)it[ref_step] - (int)it[-ref_step]));
+      J[0] = (float)(0.5 * ((int)p[1] - (int)p[-1]));
+      J[1] = (float)(0.5 * ((int)p[ref_step] - (int)p[-ref_step]));
       J[2] = affine_est_offset ? 1.0f : 0.0f;
-      J[3] = affine_est_gain ? (float)(-1.0 * it[0]) : 0.0f;
+      J[3] = affine_est_gain ? (float)(-1.0 * p[0]) : 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -381,57 +414,80 @@ __device__ bool align_2d(const DevImage& cur_img, const unsigned char* pwb, int 
   }
   if (!affine_est_offset) H[10] = 1.0f;
   if (!affine_est_gain) H[15] = 1.0f;
-  float Hinv[16];
-  mat4f_inverse(H, Hinv);
-  float mean_diff = 0;
-  float alpha = 1.0;
-  float u = (float)px;
-  float v = (float)py;
+  mat4f_inverse(H, it.Hinv);
+  it.mean_diff = 0;
+  it.alpha = 1.0;
+  it.u = (float)px;
+  it.v = (float)py;
+  it.dir0 = it.dir1 = 0.0;
+  it.n_it = 0;
+}
+
+// one pass of the loop body of feature_alignment.cpp:300-384
+__device__ int align_2d_step(const DevImage& cur_img, const unsigned char* pwb, bool affine_est_offset, bool affine_est_gain,
+                             AlignIter& it)
+{
+  constexpr int halfpatch_size_ = 4, patch_size_ = 8, ref_step = 10;
   const float min_update_squared = (float)(0.03 * 0.03);
   const int cur_step = cur_img.pitch;
-  for (int iter = 0; iter < n_iter; ++iter) {
-    const int u_r = (int)floorf(u);
-    const int v_r = (int)floorf(v);
-    if (u_r < halfpatch_size_ || v_r < halfpatch_size_ || u_r >= cur_img.w - halfpatch_size_ || v_r >= cur_img.h - halfpatch_size_)
-      break;
-    if (u != u || v != v) return false;
-    ++n_it;
-    const float subpix_x = u - u_r;
-    const float subpix_y = v - v_r;
-    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
-    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
-    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
-    const float wBR = subpix_x * subpix_y;
-    float Jres[4] = { 0, 0, 0, 0 };
+  const float u = it.u, v = it.v;
+  const int u_r = (int)floorf(u);
+  const int v_r = (int)floorf(v);
+  if (u_r < halfpatch_size_ || v_r < halfpatch_size_ || u_r >= cur_img.w - halfpatch_size_ || v_r >= cur_img.h - halfpatch_size_)
+    return ALIGN_STOPPED;
+  if (u != u || v != v) return ALIGN_NAN;
+  ++it.n_it;
+  const float subpix_x = u - u_r;
+  const float subpix_y = v - v_r;
+  const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
+  const float wTR = (float)(subpix_x * (1.0 - subpix_y));
+  const float wBL = (float)((1.0 - subpix_x) * subpix_y);
+  const float wBR = subpix_x * subpix_y;
+  float Jres[4] = { 0, 0, 0, 0 };
 #pragma unroll 2
-    for (int y = 0; y < patch_size_; ++y) {
-      const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + y - halfpatch_size_) * cur_step + u_r - halfpatch_size_;
-      const unsigned char* rp = pwb + (y + 1) * ref_step + 1;
-      for (int x = 0; x < patch_size_; ++x, ++it, ++rp) {
-        const float ref_dx = (float)(0.5 * ((int)rp[1] - (int)rp[-1]));
-        const float ref_dy = (float)(0.5 * ((int)rp[ref_step] - (int)rp[-ref_step]));
-        const float search_pixel = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
-        const float res = search_pixel - alpha * rp[0] + mean_diff;
-        Jres[0] -= res * ref_dx;
-        Jres[1] -= res * ref_dy;
-        if (affine_est_offset) Jres[2] -= res;
-        if (affine_est_gain) Jres[3] -= (-1) * res * rp[0];
-      }
+  for (int y = 0; y < patch_size_; ++y) {
+    const uint8_t* p = cur_img.data + (ptrdiff_t)(v_r + y - halfpatch_size_) * cur_step + u_r - halfpatch_size_;
+    const unsigned char* rp = pwb + (y + 1) * ref_step + 1;
+    for (int x = 0; x < patch_size_; ++x, ++p, ++rp) {
+      const float ref_dx = (float)(0.5 * ((int)rp[1] - (int)rp[-1]));
+      const float ref_dy = (float)(0.5 * ((int)rp[ref_step] - (int)rp[-ref_step]));
+      const float search_pixel = wTL * p[0] + wTR * p[1] + wBL * p[cur_step] + wBR * p[cur_step + 1];
+      const float res = search_pixel - it.alpha * rp[0] + it.mean_diff;
+      Jres[0] -= res * ref_dx;
+      Jres[1] -= res * ref_dy;
+      if (affine_est_offset) Jres[2] -= res;
+      if (affine_est_gain) Jres[3] -= (-1) * res * rp[0];
     }
-    if (!affine_est_offset) Jres[2] = 0.0f;
-    if (!affine_est_gain) Jres[3] = 0.0f;
-    float update[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      update[r] = ((Hinv[r * 4 + 0] * Jres[0] + Hinv[r * 4 + 1] * Jres[1]) + Hinv[r * 4 + 2] * Jres[2]) + Hinv[r * 4 + 3] * Jres[3];
-    u += update[0];
-    v += update[1];
-    mean_diff += update[2];
-    alpha += update[3];
-    if (update[0] * update[0] + update[1] * update[1] < min_update_squared) { converged = true; break; }
   }
-  px = u;
-  py = v;
+  if (!affine_est_offset) Jres[2] = 0.0f;
+  if (!affine_est_gain) Jres[3] = 0.0f;
+  float update[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    update[r] = ((it.Hinv[r * 4 + 0] * Jres[0] + it.Hinv[r * 4 + 1] * Jres[1]) + it.Hinv[r * 4 + 2] * Jres[2]) + it.Hinv[r * 4 + 3] * Jres[3];
+  it.u = u + update[0];
+  it.v = v + update[1];
+  it.mean_diff += update[2];
+  it.alpha += update[3];
+  return (update[0] * update[0] + update[1] * update[1] < min_update_squared) ? ALIGN_CONVERGED : ALIGN_CONTINUE;
+}
+
+// feature_alignment.cpp:212-391
+__device__ bool align_2d(const DevImage& cur_img, const unsigned char* pwb, int n_iter, bool affine_est_offset,
+                         bool affine_est_gain, double& px, double& py, int& n_it)
+{
+  AlignIter it;
+  align_2d_init(pwb, affine_est_offset, affine_est_gain, px, py, it);
+  bool converged = false;
+  for (int iter = 0; iter < n_iter; ++iter) {
+    const int st = align_2d_step(cur_img, pwb, affine_est_offset, affine_est_gain, it);
+    if (st == ALIGN_NAN) { n_it += it.n_it; return false; }
+    if (st == ALIGN_STOPPED) break;
+    if (st == ALIGN_CONVERGED) { converged = true; break; }
+  }
+  n_it += it.n_it;
+  px = it.u;
+  py = it.v;
   return converged;
 }
 
