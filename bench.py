@@ -365,7 +365,9 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
             "host_staged_seed_updates_per_s": host_rate,  # same work with host arrays staged per call (PCIe-inclusive)
             "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "update_seeds_kernel",
-                         "algorithmic_bytes_per_launch": alg, "counters": cnt[:4]},
+                         "algorithmic_bytes_per_launch": alg, "counters": cnt[:4],
+                         "unit_tails": {"align_iters_ge5": cnt[4], "align_iters_ge10": cnt[5], "zmssd_ge20": cnt[6],
+                                        "zmssd_ge50": cnt[7]}},
             "cpu_baseline": cpu}
 
 

@@ -347,7 +347,9 @@ int svoh_last_kernel_ms(svoh_ctx* ctx, float* ms);
 /* Work counters of that kernel (for the roofline accounting of SURVEY.md 8(d)):
  *   KLT:     [0] track-iterations at 16x16, [1] at 8x8, [2] templates built 16x16, [3] 8x8
  *   matcher: [0] affine warps done, [1] ZMSSD evaluations, [2] align1D/2D iterations,
- *            [3] seeds whose filter state was updated */
+ *            [3] seeds whose filter state was updated,
+ *            [4] / [5] units with >= 5 / >= 10 alignment iterations, [6] / [7] units with >= 20 / >= 50
+ *            ZMSSD evaluations (how uneven the units are) */
 int svoh_last_kernel_counters(svoh_ctx* ctx, uint64_t out[8]);
 
 /* ---- matcher and depth filter (a-10 ... a-14) -------------------------- */

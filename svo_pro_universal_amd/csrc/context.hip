@@ -44,19 +44,22 @@ int reset_counters(svoh_ctx* ctx, unsigned long long** out)
 __global__ __launch_bounds__(256) void reduce_unit_counts_kernel(const unsigned int* __restrict__ counts, size_t n,
                                                                   unsigned long long* __restrict__ out)
 {
-  unsigned long long acc[4] = { 0, 0, 0, 0 };
+  // [0..3] sums of the four per-unit counters; [4..7] tails of the two loop counters (units with >= 5 / >= 10 of
+  // the third counter, >= 20 / >= 50 of the second): how uneven the units of a wave are
+  unsigned long long acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const uint4 c = reinterpret_cast<const uint4*>(counts)[i];
     acc[0] += c.x; acc[1] += c.y; acc[2] += c.z; acc[3] += c.w;
+    acc[4] += c.z >= 5u; acc[5] += c.z >= 10u; acc[6] += c.y >= 20u; acc[7] += c.y >= 50u;
   }
-  __shared__ unsigned long long s[4][4];
-  for (int k = 0; k < 4; ++k) {
+  __shared__ unsigned long long s[4][8];
+  for (int k = 0; k < 8; ++k) {
     unsigned long long v = acc[k];
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 4) atomicAdd(&out[threadIdx.x], s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]);
+  if (threadIdx.x < 8) atomicAdd(&out[threadIdx.x], s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]);
 }
 
 int reserve_unit_counts(svoh_ctx* ctx, size_t n_units, unsigned int** out)

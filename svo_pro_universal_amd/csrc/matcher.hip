@@ -84,6 +84,7 @@ struct MatcherState {
   unsigned char* pwb;  // this thread's 10x10 patch with border, in LDS
   double A[4];         // A_cur_ref, col-major
   double epi_image[2];
+  double epi_dir[2];   // normalised epipolar direction (the 1-D refinement's direction)
   double epi_length_pyramid;
   double h_inv;
   int search_level;
@@ -280,8 +281,10 @@ __device__ void mat4f_inverse(const float* m, float* r)
 #undef M4
 
 // feature_alignment.cpp:31-209
-// The two sub-pixel refinements are written as (set-up, one iteration): the seed kernel runs the iterations of
-// many seeds through a shared job queue (update_seeds_kernel), the direct matcher runs them in place.
+// The two sub-pixel refinements are written as (set-up, one iteration).  A block-wide job queue that hands the
+// iterations of finished lanes' successors to idle lanes was built on this split and measured: no gain with one
+// job per lane (the slowest job still sets the pace: 0.3 % of the seeds need all 10 iterations, 4 % five or more,
+// so most waves run 5-7 trips for a mean of 2.8) -- it needs several seeds per lane, i.e. a global queue.
 struct AlignIter {
   float Hinv[16];      // 4x4 (2-D) or 3x3 in the first nine entries (1-D)
   float u, v, mean_diff, alpha;
@@ -535,24 +538,6 @@ __device__ int find_match_direct(MatcherState& m, const svoh_matcher_options& op
   return SVOH_MATCH_SUCCESS;
 }
 
-// matcher.cpp:262-289
-__device__ int find_local_match(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& frame, double dir0,
-                                double dir1, int patch_level, double& pcx, double& pcy)
-{
-  double sx = pcx / (1 << patch_level), sy = pcy / (1 << patch_level);
-  bool res;
-  if (m.align_1d)
-    res = align_1d(frame.lv[patch_level], dir0, dir1, m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
-                   opt.affine_est_gain != 0, sx, sy, &m.h_inv, m.n_align_it);
-  else
-    res = align_2d(frame.lv[patch_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0, opt.affine_est_gain != 0,
-                   sx, sy, m.n_align_it);
-  if (!res) return SVOH_MATCH_FAIL_ALIGNMENT;
-  pcx = sx * (1 << patch_level);
-  pcy = sy * (1 << patch_level);
-  return SVOH_MATCH_SUCCESS;
-}
-
 __device__ __forceinline__ bool is_patch_within_image(const DevFrameView& frame, int px, int py, int patch_level)
 {
   constexpr int kPatchSize = 8;
@@ -685,10 +670,14 @@ __device__ int depth_from_triangulation(const Rigid& T_search_ref, const Vec3& f
 }
 
 // matcher.cpp:157-241
-__device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
-                                          const DevFrameView& cur_frame, const Rigid& T_cur_ref, double pxr, double pyr,
-                                          const Vec3& f_ref, double gx, double gy, int level, int type,
-                                          double d_estimate_inv, double d_min_inv, double d_max_inv, double& depth)
+// Matcher::findEpipolarMatchDirect (matcher.cpp:157-241) up to the sub-pixel refinement: epipolar segment, warp,
+// ZMSSD scan.  Returns a final result code, or kMatchRefinePending (m.px_cur = start of the refinement at level 0,
+// m.epi_dir = its 1-D direction) / kMatchTriangulatePending (no refinement wanted).
+constexpr int kMatchRefinePending = -1000, kMatchTriangulatePending = -1001;
+__device__ int epipolar_match_search(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
+                                     const DevFrameView& cur_frame, const Rigid& T_cur_ref, double pxr, double pyr,
+                                     const Vec3& f_ref, double gx, double gy, int level, int type,
+                                     double d_estimate_inv, double d_min_inv, double d_max_inv)
 {
   constexpr int ZMSSD_THRESHOLD = 2000 * 64;
   int zmssd_best = ZMSSD_THRESHOLD;
@@ -725,7 +714,7 @@ __device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_op
   if (!warp_ok) return SVOH_MATCH_FAIL_WARP;
 
   // The reference refines the match at two places (matcher.cpp:205-215 for an epipolar segment shorter than two
-  // pixels, :229-235 after the scan).  Here both kinds of lanes meet at ONE call of find_local_match: inlined
+  // pixels, :229-235 after the scan).  Here both kinds of lanes meet at ONE refinement (find_epipolar_match_direct): inlined
   // twice, the alignment loops of the two places run one after the other in every wave that holds both kinds.
   bool refine;
   if (m.epi_length_pyramid < 2.0) {
@@ -749,14 +738,47 @@ __device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_op
     refine = opt.subpix_refinement != 0;
   }
   SVOH_MSTAMP(m, 2);
-  if (refine) {
-    const int res = find_local_match(m, opt, cur_frame, ed0, ed1, m.search_level, m.px_cur[0], m.px_cur[1]);
-    SVOH_MSTAMP(m, 3);
-    if (res != SVOH_MATCH_SUCCESS) return res;
+  m.epi_dir[0] = ed0; m.epi_dir[1] = ed1;
+  return refine ? kMatchRefinePending : kMatchTriangulatePending;
+}
+
+// The rest of Matcher::findEpipolarMatchDirect once the refinement (if any) has run: matcher.cpp:262-289 tail,
+// :216-219 / :236-239.  aligned = return value of align1D / align2D, (sx, sy) = its result at the search level.
+__device__ int epipolar_match_finish(MatcherState& m, const DevFrameView& cur_frame, const Rigid& T_cur_ref, const Vec3& f_ref,
+                                     bool refined, bool aligned, double sx, double sy, double& depth)
+{
+  if (refined) {
+    if (!aligned) return SVOH_MATCH_FAIL_ALIGNMENT;
+    m.px_cur[0] = sx * (1 << m.search_level);
+    m.px_cur[1] = sy * (1 << m.search_level);
   }
   m.f_cur = back_project3(cur_frame.cam, m.px_cur[0], m.px_cur[1]);
   normalize3(m.f_cur);
   return depth_from_triangulation(T_cur_ref, f_ref, m.f_cur, depth);
+}
+
+// Matcher::findEpipolarMatchDirect in one piece
+__device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
+                                          const DevFrameView& cur_frame, const Rigid& T_cur_ref, double pxr, double pyr,
+                                          const Vec3& f_ref, double gx, double gy, int level, int type,
+                                          double d_estimate_inv, double d_min_inv, double d_max_inv, double& depth)
+{
+  const int st = epipolar_match_search(m, opt, ref_frame, cur_frame, T_cur_ref, pxr, pyr, f_ref, gx, gy, level, type,
+                                       d_estimate_inv, d_min_inv, d_max_inv);
+  if (st != kMatchRefinePending && st != kMatchTriangulatePending) return st;
+  bool aligned = false;
+  double sx = 0.0, sy = 0.0;
+  if (st == kMatchRefinePending) {
+    sx = m.px_cur[0] / (1 << m.search_level); sy = m.px_cur[1] / (1 << m.search_level);
+    if (m.align_1d)
+      aligned = align_1d(cur_frame.lv[m.search_level], m.epi_dir[0], m.epi_dir[1], m.pwb, opt.align_max_iter,
+                         opt.affine_est_offset != 0, opt.affine_est_gain != 0, sx, sy, &m.h_inv, m.n_align_it);
+    else
+      aligned = align_2d(cur_frame.lv[m.search_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
+                         opt.affine_est_gain != 0, sx, sy, m.n_align_it);
+    SVOH_MSTAMP(m, 3);
+  }
+  return epipolar_match_finish(m, cur_frame, T_cur_ref, f_ref, st == kMatchRefinePending, aligned, sx, sy, depth);
 }
 
 // math_utils.h:186-194
