@@ -873,15 +873,27 @@ void sparse_align_kernel(const AlignKernelArgs a)
       double R0[9];
       to_matrix(T_cam_imu0.q, R0);
       const bool dist_jac0 = opt.use_distortion_jacobian != 0;
+      // all of a feature's inputs are requested together (they are independent; behind the selection test each
+      // would be its own round trip to memory), and one feature ahead: the next feature's nine values travel while
+      // this one's Jacobians are computed
+      struct FeatIn { double pu, pv, pwx, pwy, pwz, fx, fy, fz; unsigned flag; };
+      auto request = [&](int k, FeatIn& o) {
+        o.flag = cd.flags[k];
+        o.pu = cd.px[2 * k]; o.pv = cd.px[2 * k + 1];
+        o.pwx = cd.pos_world[3 * k + 0]; o.pwy = cd.pos_world[3 * k + 1]; o.pwz = cd.pos_world[3 * k + 2];
+        o.fx = cd.f[3 * k + 0]; o.fy = cd.f[3 * k + 1]; o.fz = cd.f[3 * k + 2];
+      };
+      FeatIn ahead = { 0, 0, 0, 0, 0, 0, 0, 0, 0u };
+      if (tid < cd.n_features) request(tid, ahead);
       for (int i = tid; i < cd.n_features; i += NT) {
         const int gi = cd.feat_off + i;
-        // all of the feature's inputs are requested together (they are independent); behind the selection test
-        // each would be its own round trip to memory
-        bool sel = cd.flags[i] != 0;
-        const double pu = cd.px[2 * i], pv = cd.px[2 * i + 1];
-        const double pwx = cd.pos_world[3 * i + 0], pwy = cd.pos_world[3 * i + 1], pwz = cd.pos_world[3 * i + 2];
-        const double fx_ = cd.f[3 * i + 0], fy_ = cd.f[3 * i + 1], fz_ = cd.f[3 * i + 2];
+        const FeatIn in = ahead;
+        if (i + NT < cd.n_features) request(i + NT, ahead);
         asm volatile("" ::: "memory");
+        bool sel = in.flag != 0;
+        const double pu = in.pu, pv = in.pv;
+        const double pwx = in.pwx, pwy = in.pwy, pwz = in.pwz;
+        const double fx_ = in.fx, fy_ = in.fy, fz_ = in.fz;
         if (sel) {
           const double u_tl = pu * scale - patch_center_wb;
           const double v_tl = pv * scale - patch_center_wb;
