@@ -115,3 +115,73 @@ def test_matcher_and_seeds_wild_units(gpu_ctx):
         fb, kk = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
         gpu_ctx.update_seeds_batch(mopt, capi.default_depth_filter_options(sc.cam), [rv],
                                    fe.make_frame_view(f_small, sc.cam, sc.T_cur_f_w_gt, 0.0, 2), fb, sd["state"])
+
+
+def test_point_optimizer_wild_landmarks(gpu_ctx):
+    """NaN / huge positions, bearing vectors and poses in svoh_optimize_points_batch: the call returns, wild
+    landmarks end wherever their arithmetic leads, the well-formed ones next to them are untouched by it."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pose_helpers as ph
+    sc = ph.make_structure_scene(310, n_points=128, n_views=4, degenerate=False)
+    good, it_good = gpu_ctx.optimize_points(sc["views"], sc["obs_begin"], sc["obs_view"], sc["obs_f"], sc["pos0"], n_iter=5)
+    pos = sc["pos0"].copy()
+    obs_f = sc["obs_f"].copy()
+    views = [np.array(v, dtype=np.float64) for v in sc["views"]]
+    for k, w in enumerate(WILD):
+        pos[k] = [w, WILD[(k + 1) % len(WILD)], WILD[(k + 2) % len(WILD)]]
+    wild_pts = list(range(len(WILD)))
+    for k in (20, 21, 22):                       # wild bearing vectors on three landmarks
+        obs_f[sc["obs_begin"][k]] = [np.nan, 1e300, 0.0]
+        wild_pts.append(k)
+    out, iters = gpu_ctx.optimize_points(views, sc["obs_begin"], sc["obs_view"], obs_f, pos, n_iter=5)
+    clean = np.ones(128, bool)
+    clean[wild_pts] = False
+    assert np.array_equal(out[clean], good[clean]) and np.array_equal(iters[clean], it_good[clean])
+    assert (iters >= 0).all() and (iters <= 5).all()
+    # a NaN pose poisons exactly the landmarks that are observed from it
+    views_bad = [v.copy() for v in views]
+    views_bad[2][0] = np.nan
+    out2, it2 = gpu_ctx.optimize_points(views_bad, sc["obs_begin"], sc["obs_view"], sc["obs_f"], sc["pos0"], n_iter=5)
+    sees_bad = np.array([2 in sc["obs_view"][sc["obs_begin"][i]:sc["obs_begin"][i + 1]] for i in range(128)])
+    assert np.array_equal(out2[~sees_bad], good[~sees_bad])
+    # the context still works
+    again, _ = gpu_ctx.optimize_points(sc["views"], sc["obs_begin"], sc["obs_view"], sc["obs_f"], sc["pos0"], n_iter=5)
+    assert np.array_equal(again, good)
+
+
+def test_split_alignment_wild_state_and_sums(gpu_ctx):
+    """The patch-split entries with NaN / huge states and sums: no fault, the solver reports the failure
+    (status 2, state rolled back) like the resident kernel does, and the context keeps working."""
+    import ctypes as C
+    import torch
+    sc = synth.make_align_scene(311, n_features=200)
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+    opt = capi.default_align_options()
+    problems, keep = fe.make_align_problems([[(sc, fr, fc)]])
+    dev = torch.device("cuda", 0)
+    d_state = torch.zeros(C.sizeof(capi.svoh_align_gn_state) // 8, dtype=torch.float64, device=dev)
+    d_sums = torch.zeros(capi.SVOH_ALIGN_SUMS_DOUBLES, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.split_init(problems[0], d_state.data_ptr())
+    gpu_ctx.partial_sums(opt, problems[0], 4, d_state.data_ptr(), d_sums.data_ptr())
+    gpu_ctx.synchronize()
+    ref_sums = d_sums.clone()
+    # NaN in the summed gradient: the update reports a stopped solver and keeps the state (a NaN on the diagonal
+    # of H alone would not: like Eigen's LDLT the solver treats an unusable pivot as zero)
+    d_sums[64:70] = float("nan")
+    torch.cuda.synchronize()
+    st = gpu_ctx.gn_update(opt, problems[0], 4, 0, d_sums.data_ptr(), d_state.data_ptr())
+    assert st.status == 2 and st.stop == 1 and st.level_done == 1
+    assert [st.T_icur_iref.q[k] for k in range(4)] == [problems[0].T_icur_iref.q[k] for k in range(4)]
+    # a wild state: the evaluation sees nothing (every comparison with NaN fails) and returns
+    d_state.fill_(float("nan"))
+    torch.cuda.synchronize()
+    gpu_ctx.partial_sums(opt, problems[0], 4, d_state.data_ptr(), d_sums.data_ptr(), 3)
+    gpu_ctx.synchronize()
+    assert int(d_sums[73].item()) == 0
+    # healthy again
+    gpu_ctx.split_init(problems[0], d_state.data_ptr())
+    gpu_ctx.partial_sums(opt, problems[0], 4, d_state.data_ptr(), d_sums.data_ptr())
+    gpu_ctx.synchronize()
+    assert torch.equal(d_sums, ref_sums)
