@@ -196,7 +196,10 @@ typedef struct svoh_align_problem {
 
 typedef struct svoh_align_result {
   int32_t status;            /* 0 ok; 1 = no features to track (run() returns 0);
-                                2 = solver stopped on NaN (state rolled back) */
+                                2 = solver stopped on NaN (state rolled back);
+                                3 = a single large problem was spread over several workgroups and one of them
+                                    never reached the device-side barrier (the kernel gives up instead of
+                                    hanging; not expected to happen) */
   int32_t n_fts_to_track;    /* return value of SparseImgAlign::run */
   svoh_se3 T_icur_iref;      /* optimised state */
   double alpha, beta;

@@ -81,7 +81,14 @@ struct AlignKernelArgs {
   // patch-split mode: evaluate at a caller-owned device state, hand out the undivided sums
   const svoh_align_gn_state* ext_state;
   int32_t raw_sums;
+  // cluster mode: ONE problem whose feature shares (one descriptor each, as in the patch-split evaluation) are
+  // owned by `cluster` co-resident workgroups that add their normal equations through xchg every iteration
+  int32_t cluster;                      // 0 / 1: off
+  double* xchg;                         // 2 x cluster x kXchgStride doubles
+  unsigned int* bar;                    // arrival counter, zeroed before the launch
 };
+
+constexpr int kXchgStride = 64;         // doubles per share and parity (>= 45 + 8 + 1 accumulators + 2)
 
 #ifndef SVOH_ROW_UNROLL_GONLY
 #define SVOH_ROW_UNROLL_GONLY 4
@@ -638,6 +645,42 @@ __device__ __forceinline__ void accumulate_camera_staged(
   }
 }
 
+// Cluster mode: replace vals[0 .. n) (LDS) by their sums over the workgroups of the cluster, added in share order
+// so that every workgroup gets the same bits.  Slots alternate between two buffers by epoch: a workgroup can be
+// one barrier ahead of the slowest, never two.  The wait is bounded; false = a partner never arrived (the
+// caller gives up with status 3 instead of hanging the device).
+template <int NT>
+__device__ __forceinline__ bool cluster_sum(const AlignKernelArgs& a, int share, unsigned& epoch, double* vals, int n, int tid,
+                                            int* s_flag)
+{
+  const int G = a.cluster;
+  double* buf = a.xchg + (size_t)(epoch & 1u) * G * kXchgStride;
+  if (tid < n) buf[(size_t)share * kXchgStride + tid] = vals[tid];
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();   // this workgroup's slot is visible device-wide before it counts as arrived
+    atomicAdd(a.bar, 1u);
+    const unsigned target = (unsigned)G * (epoch + 1u);
+    int ok = 0;
+    for (long long spin = 0; spin < (1ll << 24); ++spin) {
+      if (__hip_atomic_load(a.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  const bool ok = *s_flag != 0;
+  if (ok && tid < n) {
+    __threadfence();   // acquire on the reading lane as well
+    double v = 0.0;
+    for (int g = 0; g < G; ++g) v += buf[(size_t)g * kXchgStride + tid];
+    vals[tid] = v;
+  }
+  __syncthreads();
+  ++epoch;
+  return ok;
+}
+
 // One Gauss-Newton bookkeeping step, run by a single lane: prior, pivoted LDL^T, SE3
 // update, convergence (MiniLeastSquaresSolver::optimizeGaussNewton,
 // mini_least_squares_solver.hpp:42-107).  Kept out of line on purpose: inlined into the
@@ -803,7 +846,9 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
 #define SVOH_ALIGN_MIN_WAVES_256 2
 #endif
 
-template <int P, int NT, bool ILLUM>
+// CLUSTER: the cluster mode's exchanges are compiled in (256-thread geometry only); the batch instantiation stays
+// free of them -- as run-time branches they cost the batch kernel 5 %.
+template <int P, int NT, bool ILLUM, bool CLUSTER = false>
 __global__ __launch_bounds__(NT, (NT == 256 ? SVOH_ALIGN_MIN_WAVES_256 : (NT == 512 ? 2 : 4)))
 void sparse_align_kernel(const AlignKernelArgs a)
 {
@@ -819,6 +864,8 @@ void sparse_align_kernel(const AlignKernelArgs a)
   __shared__ double s_red[NW][NACC];
   __shared__ double s_sum[NACC];
   __shared__ int s_nvis;
+  __shared__ double s_x[kXchgStride];   // cluster mode: the block handed to cluster_sum
+  __shared__ int s_cluster_ok;
   __shared__ ShState s;
 
   const int tid = threadIdx.x;
@@ -931,11 +978,21 @@ void sparse_align_kernel(const AlignKernelArgs a)
   }
   __syncthreads();
   SVOH_STAMP_ADD(0);
-  const int n_sel = s.nsel;
+  constexpr bool cluster = CLUSTER;
+  unsigned cluster_epoch = 0;
+  bool cluster_failed = false;
+  int n_sel = s.nsel;
+  if (cluster) {   // the number of selected features of the whole problem, not of this share
+    if (tid == 0) s_x[0] = (double)n_sel;
+    __syncthreads();
+    cluster_failed = !cluster_sum<NT>(a, pbi, cluster_epoch, s_x, 1, tid, &s_cluster_ok);
+    n_sel = cluster_failed ? 0 : (int)s_x[0];
+    __syncthreads();
+  }
   if (n_sel == 0) {
     if (tid == 0) {
       svoh_align_result& r = a.results[pbi];
-      r.status = 1; r.n_fts_to_track = 0;
+      r.status = cluster_failed ? 3 : 1; r.n_fts_to_track = 0;
       store_rigid(s.T, r.T_icur_iref);
       r.alpha = s.alpha; r.beta = s.beta;
       r.n_patch_iters = 0;
@@ -1041,7 +1098,8 @@ void sparse_align_kernel(const AlignKernelArgs a)
 #pragma unroll
           for (int k = 0; k < D + 1; ++k) accg[k] = 0.0;
           run_cameras(std::true_type(), accg);
-          if (__syncthreads_or(changed)) {   // visibility moved: this iteration in full
+          const int changed_here = __syncthreads_or(changed);
+          if (changed_here && !cluster) {   // visibility moved: this iteration in full
             SVOH_STAMP_COUNT(5);
             light = false;
             continue;
@@ -1063,6 +1121,23 @@ void sparse_align_kernel(const AlignKernelArgs a)
             s_sum[AccLayout<D>::NH + tid] = v;
           }
           __syncthreads();
+          if (cluster) {   // gradient, chi2, visible count and the visibility vote of all shares
+            if (tid < D + 1) s_x[tid] = s_sum[AccLayout<D>::NH + tid];
+            if (tid == 0) { s_x[D + 1] = (double)s_nvis; s_x[D + 2] = changed_here ? 1.0 : 0.0; }
+            __syncthreads();
+            if (!cluster_sum<NT>(a, pbi, cluster_epoch, s_x, D + 3, tid, &s_cluster_ok)) { cluster_failed = true; break; }
+            const bool changed_anywhere = s_x[D + 2] != 0.0;
+            __syncthreads();
+            if (changed_anywhere) {
+              if (tid == 0) s_nvis = 0;
+              __syncthreads();
+              light = false;
+              continue;
+            }
+            if (tid < D + 1) s_sum[AccLayout<D>::NH + tid] = s_x[tid];
+            if (tid == 0) s_nvis = (int)s_x[D + 1];
+            __syncthreads();
+          }
         } else {
           double acc[NACC];
 #pragma unroll
@@ -1085,9 +1160,19 @@ void sparse_align_kernel(const AlignKernelArgs a)
             s_sum[tid] = v;
           }
           __syncthreads();
+          if (cluster) {
+            if (tid < NACC) s_x[tid] = s_sum[tid];
+            if (tid == 0) s_x[NACC] = (double)s_nvis;
+            __syncthreads();
+            if (!cluster_sum<NT>(a, pbi, cluster_epoch, s_x, NACC + 1, tid, &s_cluster_ok)) { cluster_failed = true; break; }
+            if (tid < NACC) s_sum[tid] = s_x[tid];
+            if (tid == 0) s_nvis = (int)s_x[NACC];
+            __syncthreads();
+          }
         }
         break;
       }
+      if (cluster_failed) break;
 
       SVOH_STAMP_ADD(3);
       // ---- serial part: prior, pivoted LDL^T (or the level's factor again), SE3 update, convergence ----
@@ -1096,11 +1181,12 @@ void sparse_align_kernel(const AlignKernelArgs a)
       SVOH_STAMP_ADD(4);
       if (s.level_done) break;
     }
+    if (cluster_failed) break;
   }
 
   if (tid == 0) {
     svoh_align_result& r = a.results[pbi];
-    r.status = s.status;
+    r.status = cluster_failed ? 3 : s.status;   // 3: a workgroup of the cluster never arrived (see cluster_sum)
     r.n_fts_to_track = n_sel;
     store_rigid(s.T, r.T_icur_iref);
     r.alpha = s.alpha; r.beta = s.beta;
@@ -1170,10 +1256,10 @@ void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_al
 
 struct LaunchCfg { int nt; size_t lds; };
 
-template <int P, int NT, bool ILLUM>
+template <int P, int NT, bool ILLUM, bool CLUSTER = false>
 static hipError_t launch_one(hipStream_t st, int grid, size_t lds, const AlignKernelArgs& args)
 {
-  auto kern = sparse_align_kernel<P, NT, ILLUM>;
+  auto kern = sparse_align_kernel<P, NT, ILLUM, CLUSTER>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1184,12 +1270,19 @@ static hipError_t launch_one(hipStream_t st, int grid, size_t lds, const AlignKe
 template <int P, bool ILLUM>
 static hipError_t launch_nt(hipStream_t st, int nt, int grid, size_t lds, const AlignKernelArgs& args)
 {
+  if (args.cluster > 1) return launch_one<P, 256, ILLUM, true>(st, grid, lds, args);
   switch (nt) {
     case 256: return launch_one<P, 256, ILLUM>(st, grid, lds, args);
     case 512: return launch_one<P, 512, ILLUM>(st, grid, lds, args);
     default: return launch_one<P, 1024, ILLUM>(st, grid, lds, args);
   }
 }
+
+// cluster mode thresholds (measured): an exchange costs ~2 us, so below ~500 patches the barriers
+// cost more than the idle CUs; ~200 patches per workgroup is where the per-iteration time stops falling
+constexpr int kClusterMinFeatures = 512;
+constexpr int kClusterFeaturesPerWorkgroup = 192;
+constexpr int kClusterMaxWorkgroups = 32;
 
 static int getenv_int(const char* name, int dflt)
 {
@@ -1232,7 +1325,20 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
 
   // patch-split evaluation: the one problem becomes S descriptors, share s holding features
   // [n*s/S, n*(s+1)/S) of every camera, one workgroup each
-  const int S = (split && !split->update && split->n_shares > 1) ? split->n_shares : 1;
+  int S = (split && !split->update && split->n_shares > 1) ? split->n_shares : 1;
+  // cluster mode: a single problem with many features gets several co-resident workgroups of the resident kernel
+  // (one share each) that add their normal equations through a device-side barrier every iteration, instead of
+  // one workgroup on one CU.  SVOH_ALIGN_CLUSTER=0 turns it off, =G forces G workgroups.
+  bool cluster = false;
+  if (!split && eval_level < 0 && n_problems == 1 && problems[0].n_cams >= 1 && problems[0].n_cams <= SVOH_MAX_CAMS) {
+    int64_t nf = 0;
+    for (int c = 0; c < problems[0].n_cams; ++c) nf += problems[0].cams[c].n_features > 0 ? problems[0].cams[c].n_features : 0;
+    int g = getenv_int("SVOH_ALIGN_CLUSTER", -1);
+    if (g < 0) g = nf >= kClusterMinFeatures ? (int)((nf + kClusterFeaturesPerWorkgroup - 1) / kClusterFeaturesPerWorkgroup) : 0;
+    if (g > kClusterMaxWorkgroups) g = kClusterMaxWorkgroups;
+    if (g > ctx->num_cus) g = ctx->num_cus;
+    if (g >= 2) { S = g; cluster = true; }
+  }
   SVOH_REQUIRE(ctx, S == 1 || n_problems == 1, "shares apply to a single problem");
   const int n_desc = n_problems * S;
 
@@ -1361,6 +1467,17 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.n_problems = n_desc;
   args.ext_state = nullptr;
   args.raw_sums = 0;
+  args.cluster = 0;
+  args.xchg = nullptr;
+  args.bar = nullptr;
+  if (cluster) {
+    const size_t xchg_bytes = 2 * (size_t)S * kXchgStride * sizeof(double);
+    SVOH_HIP_TRY(ctx, ctx->d_xchg.reserve(xchg_bytes + 256));
+    args.cluster = S;
+    args.xchg = static_cast<double*>(ctx->d_xchg.ptr);
+    args.bar = reinterpret_cast<unsigned int*>(static_cast<uint8_t*>(ctx->d_xchg.ptr) + xchg_bytes);
+    SVOH_HIP_TRY(ctx, hipMemsetAsync(args.bar, 0, 256, ctx->stream));
+  }
   if (split && !split->update) {
     args.ext_state = split->ext_state;
     if (S == 1) args.eval_out = split->sums_out;
@@ -1396,6 +1513,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   int nt = (n_desc >= 2 * ctx->num_cus) ? 256 : 512;
   if (max_feat_per_problem <= 256) nt = 256;
   nt = getenv_int("SVOH_ALIGN_THREADS", nt);
+  if (cluster) nt = 256;   // one workgroup per CU at most: all of them are resident together
   if (nt != 256 && nt != 512 && nt != 1024) nt = 256;
   size_t lds = (nt == 256) ? 38400 : (nt == 512 ? 78 * 1024 : 153856);
   lds = (size_t)getenv_int("SVOH_ALIGN_LDS", (int)lds);
@@ -1409,6 +1527,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // resident workgroups per CU: 256-thread groups at 256 VGPRs -> 2; larger groups -> 1
   int grid = ctx->num_cus * getenv_int("SVOH_ALIGN_WG_PER_CU", nt == 256 ? 2 : 1);
   if (grid > n_desc || grid <= 0) grid = n_desc;
+  if (cluster) grid = n_desc;
   hipError_t e;
   const int ev_slot = (int)(ctx->align_launches % svoh_ctx::kAlignEventRing);
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_start[ev_slot], ctx->stream));
@@ -1420,7 +1539,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
               : launch_nt<8, false>(ctx->stream, nt, grid, lds, args);
   if (e != hipSuccess)
     return set_error(ctx, SVOH_ERR_HIP, "sparse_align launch failed: %s", hipGetErrorString(e));
-  if (S > 1) {
+  if (S > 1 && !cluster) {
     hipLaunchKernelGGL(sum_shares_kernel, dim3(1), dim3(128), 0, ctx->stream, static_cast<const double*>(ctx->d_eval.ptr), S,
                        split->sums_out);
     const hipError_t es = hipGetLastError();
@@ -1430,7 +1549,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   ++ctx->align_launches;
   // the results follow the kernel to pinned host memory right away, so that a caller which queues several
   // launches and fetches once still has every launch's output delivered
-  if (S == 1 && eval_level < 0)
+  if ((S == 1 || cluster) && eval_level < 0)   // cluster: entry 0 is share 0's copy of the common result
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results.ptr, ctx->d_results.ptr, sizeof(svoh_align_result) * n_problems,
                                      hipMemcpyDeviceToHost, ctx->stream));
 #ifdef SVOH_PHASE_STAMPS
@@ -1446,7 +1565,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
             sum[4] / n_problems, sum[7] / n_problems, sum[6] / n_problems, sum[5] / n_problems);
   }
 #endif
-  ctx->last_align_n = S > 1 ? 0 : n_problems;   // the shares' result slots are not a caller's problems
+  ctx->last_align_n = (S > 1 && !cluster) ? 0 : n_problems;   // the shares' result slots are not a caller's problems
   return SVOH_OK;
 }
 

@@ -86,6 +86,7 @@ struct svoh_ctx {
   svoh::DevBuffer d_feat;      // per-feature workspace
   svoh::DevBuffer d_upload;    // staged host feature arrays
   svoh::DevBuffer d_eval;      // evaluate() outputs
+  svoh::DevBuffer d_xchg;      // cluster mode of the alignment: exchange slots + arrival counter
   svoh::DevBuffer d_split;     // svoh_sparse_align_split_buffers: a Gauss-Newton state + 74 sums
   svoh::PinnedBuffer h_desc;
   svoh::PinnedBuffer h_upload;

@@ -297,3 +297,39 @@ def test_error_codes(gpu_ctx):
     assert e.value.code == -4
     with pytest.raises(fe.SvohError):
         gpu_ctx.release_frame(987654321)
+
+
+@pytest.mark.parametrize("n,cluster", [(2000, None), (1500, 3), (700, 2), (4000, 16)])
+def test_cluster_mode_single_problem(gpu_ctx, oracle_lib, n, cluster):
+    """One problem spread over several co-resident workgroups (device-side barrier per iteration; automatic from
+    512 features, SVOH_ALIGN_CLUSTER forces a size): same iteration counts and pose as the oracle and as the
+    one-workgroup kernel (summation order differs: 1e-9)."""
+    import os
+    orc = oracle_lib
+    sc = helpers.small_scene(81, n=n, border_features=100, invalid_fraction=0.05)
+    opb, gpb, keep = both(gpu_ctx, orc, [sc])
+    opt = capi.default_align_options(min_level=0)
+    old = os.environ.get("SVOH_ALIGN_CLUSTER")
+    try:
+        os.environ["SVOH_ALIGN_CLUSTER"] = "0"
+        single = gpu_ctx.sparse_align(opt, gpb)[0]
+        if cluster is None:
+            del os.environ["SVOH_ALIGN_CLUSTER"]
+        else:
+            os.environ["SVOH_ALIGN_CLUSTER"] = str(cluster)
+        rg, ro = check_run(gpu_ctx, orc, opt, opb, gpb)
+        assert rg.status == 0 and list(rg.iters) == list(single.iters) and rg.n_fts_to_track == single.n_fts_to_track
+        assert rg.n_patch_iters == single.n_patch_iters
+        assert helpers.se3_max_abs_diff(rg.T_icur_iref, single.T_icur_iref) < 1e-9
+        # illumination terms + prior + stereo through the cluster path
+        b = synth.make_align_scene(81, n_features=n // 2, cam=synth.Camera.euroc_like(), border_features=10)
+        Tp = synth.SE3(synth.quat_from_axis_angle([0.3, -1, 0.2], 0.004), [0.003, -0.002, 0.001])
+        prior = helpers.make_prior(Tp, 0.5, 0.3)
+        opb2, gpb2, keep2 = both(gpu_ctx, orc, [sc, b], prior=prior)
+        opt2 = capi.default_align_options(min_level=1, estimate_illumination_gain=1, estimate_illumination_offset=1)
+        check_run(gpu_ctx, orc, opt2, opb2, gpb2)
+    finally:
+        if old is None:
+            os.environ.pop("SVOH_ALIGN_CLUSTER", None)
+        else:
+            os.environ["SVOH_ALIGN_CLUSTER"] = old
