@@ -877,6 +877,18 @@ def main():
     ctx._check(ctx.lib.svoh_sparse_align_kernel_ms_history(ctx.h, min(32, args.steps), hist, ctypes.byref(n_hist)))
     kernel_ms_sum = sum(hist[i] for i in range(n_hist.value)) * (args.steps / float(max(1, n_hist.value)))
 
+    # latency of ONE frame pair of the same workload (outside the timed region): what a single camera stream sees
+    one_arr = (capi.svoh_align_problem * 1)(problems[0])
+    lat_call, lat_kern = [], []
+    for k in range(12):
+        t1 = time.perf_counter()
+        ctx.sparse_align(opt, one_arr)
+        t2 = time.perf_counter()
+        ctx.lib.svoh_sparse_align_last_kernel_ms(ctx.h, ctypes.byref(kern_ms))
+        if k >= 2:
+            lat_call.append((t2 - t1) * 1e3)
+            lat_kern.append(kern_ms.value)
+
     n_sel = sum(r.n_fts_to_track for r in res)
     # whole-job numbers: MAX of the elapsed time, SUM of the patches all ranks aligned
     elapsed, patches_total = du.combine(dist, world, elapsed, n_sel, comm_dev)
@@ -922,6 +934,8 @@ def main():
                                "rot_rad_max": float(np.max([e[0] for e in errs])),
                                "trans_m_max": float(np.max([e[1] for e in errs]))},
             "solver_failures": n_bad,
+            "one_frame_pair_latency_ms": {"blocking_call": float(np.median(lat_call)), "kernel": float(np.median(lat_kern)),
+                                          "note": "one problem of the same workload, several workgroups per problem"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic("align:B%d:N%d:P%d:L%d-%d" % (B, N, P, args.max_level, args.min_level)),
