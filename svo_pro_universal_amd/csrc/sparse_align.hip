@@ -650,20 +650,21 @@ __device__ __forceinline__ void accumulate_camera_staged(
 // one barrier ahead of the slowest, never two.  The wait is bounded; false = a partner never arrived (the
 // caller gives up with status 3 instead of hanging the device).
 template <int NT>
-__device__ __forceinline__ bool cluster_sum(const AlignKernelArgs& a, int share, unsigned& epoch, double* vals, int n, int tid,
-                                            int* s_flag)
+__device__ __forceinline__ bool cluster_sum(const AlignKernelArgs& a, int prob, int share, unsigned& epoch, double* vals, int n,
+                                            int tid, int* s_flag)
 {
   const int G = a.cluster;
-  double* buf = a.xchg + (size_t)(epoch & 1u) * G * kXchgStride;
+  double* buf = a.xchg + ((size_t)prob * 2 + (epoch & 1u)) * G * kXchgStride;   // this problem's slots
+  unsigned int* bar = a.bar + prob;
   if (tid < n) buf[(size_t)share * kXchgStride + tid] = vals[tid];
   __syncthreads();
   if (tid == 0) {
     __threadfence();   // this workgroup's slot is visible device-wide before it counts as arrived
-    atomicAdd(a.bar, 1u);
+    atomicAdd(bar, 1u);
     const unsigned target = (unsigned)G * (epoch + 1u);
     int ok = 0;
     for (long long spin = 0; spin < (1ll << 24); ++spin) {
-      if (__hip_atomic_load(a.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+      if (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
       __builtin_amdgcn_s_sleep(2);
     }
     *s_flag = ok;
@@ -979,19 +980,24 @@ void sparse_align_kernel(const AlignKernelArgs a)
   __syncthreads();
   SVOH_STAMP_ADD(0);
   constexpr bool cluster = CLUSTER;
+  // cluster mode: descriptor pbi is share (pbi % G) of problem (pbi / G); share 0 reports the common result in
+  // the problem's slot, the other shares write theirs behind the problems' slots
+  const int c_prob = cluster ? pbi / a.cluster : pbi;
+  const int c_share = cluster ? pbi % a.cluster : 0;
+  const int res_idx = cluster ? (c_share == 0 ? c_prob : a.n_problems / a.cluster + pbi) : pbi;
   unsigned cluster_epoch = 0;
   bool cluster_failed = false;
   int n_sel = s.nsel;
   if (cluster) {   // the number of selected features of the whole problem, not of this share
     if (tid == 0) s_x[0] = (double)n_sel;
     __syncthreads();
-    cluster_failed = !cluster_sum<NT>(a, pbi, cluster_epoch, s_x, 1, tid, &s_cluster_ok);
+    cluster_failed = !cluster_sum<NT>(a, c_prob, c_share, cluster_epoch, s_x, 1, tid, &s_cluster_ok);
     n_sel = cluster_failed ? 0 : (int)s_x[0];
     __syncthreads();
   }
   if (n_sel == 0) {
     if (tid == 0) {
-      svoh_align_result& r = a.results[pbi];
+      svoh_align_result& r = a.results[res_idx];
       r.status = cluster_failed ? 3 : 1; r.n_fts_to_track = 0;
       store_rigid(s.T, r.T_icur_iref);
       r.alpha = s.alpha; r.beta = s.beta;
@@ -1003,7 +1009,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
     continue;
   }
   if (tid == 0) {
-    svoh_align_result& r = a.results[pbi];
+    svoh_align_result& r = a.results[res_idx];
     for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = 0; r.n_meas[l] = 0; r.chi2[l] = 0.0; }
   }
 
@@ -1125,7 +1131,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
             if (tid < D + 1) s_x[tid] = s_sum[AccLayout<D>::NH + tid];
             if (tid == 0) { s_x[D + 1] = (double)s_nvis; s_x[D + 2] = changed_here ? 1.0 : 0.0; }
             __syncthreads();
-            if (!cluster_sum<NT>(a, pbi, cluster_epoch, s_x, D + 3, tid, &s_cluster_ok)) { cluster_failed = true; break; }
+            if (!cluster_sum<NT>(a, c_prob, c_share, cluster_epoch, s_x, D + 3, tid, &s_cluster_ok)) { cluster_failed = true; break; }
             const bool changed_anywhere = s_x[D + 2] != 0.0;
             __syncthreads();
             if (changed_anywhere) {
@@ -1164,7 +1170,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
             if (tid < NACC) s_x[tid] = s_sum[tid];
             if (tid == 0) s_x[NACC] = (double)s_nvis;
             __syncthreads();
-            if (!cluster_sum<NT>(a, pbi, cluster_epoch, s_x, NACC + 1, tid, &s_cluster_ok)) { cluster_failed = true; break; }
+            if (!cluster_sum<NT>(a, c_prob, c_share, cluster_epoch, s_x, NACC + 1, tid, &s_cluster_ok)) { cluster_failed = true; break; }
             if (tid < NACC) s_sum[tid] = s_x[tid];
             if (tid == 0) s_nvis = (int)s_x[NACC];
             __syncthreads();
@@ -1176,7 +1182,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
 
       SVOH_STAMP_ADD(3);
       // ---- serial part: prior, pivoted LDL^T (or the level's factor again), SE3 update, convergence ----
-      if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, pbi, level, iter, eval_mode, light, s, s_sum, &s_nvis);
+      if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, res_idx, level, iter, eval_mode, light, s, s_sum, &s_nvis);
       __syncthreads();
       SVOH_STAMP_ADD(4);
       if (s.level_done) break;
@@ -1185,7 +1191,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
   }
 
   if (tid == 0) {
-    svoh_align_result& r = a.results[pbi];
+    svoh_align_result& r = a.results[res_idx];
     r.status = cluster_failed ? 3 : s.status;   // 3: a workgroup of the cluster never arrived (see cluster_sum)
     r.n_fts_to_track = n_sel;
     store_rigid(s.T, r.T_icur_iref);
@@ -1283,6 +1289,7 @@ static hipError_t launch_nt(hipStream_t st, int nt, int grid, size_t lds, const 
 constexpr int kClusterMinFeatures = 512;
 constexpr int kClusterFeaturesPerWorkgroup = 192;
 constexpr int kClusterMaxWorkgroups = 32;
+constexpr int kClusterMaxProblems = 16;   // arrival counters: one 32-bit word per problem in a 256-byte block
 
 static int getenv_int(const char* name, int dflt)
 {
@@ -1329,17 +1336,25 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // cluster mode: a single problem with many features gets several co-resident workgroups of the resident kernel
   // (one share each) that add their normal equations through a device-side barrier every iteration, instead of
   // one workgroup on one CU.  SVOH_ALIGN_CLUSTER=0 turns it off, =G forces G workgroups.
+  // A handful of such problems (a stereo pair of streams, a few cameras) are clustered alike, each with its own
+  // exchange slots, as long as every one of them is large and they all fit on the device at once.
   bool cluster = false;
-  if (!split && eval_level < 0 && n_problems == 1 && problems[0].n_cams >= 1 && problems[0].n_cams <= SVOH_MAX_CAMS) {
-    int64_t nf = 0;
-    for (int c = 0; c < problems[0].n_cams; ++c) nf += problems[0].cams[c].n_features > 0 ? problems[0].cams[c].n_features : 0;
+  if (!split && eval_level < 0 && n_problems <= kClusterMaxProblems) {
+    int64_t nf_min = INT64_MAX, nf_max = 0;
+    for (int p = 0; p < n_problems; ++p) {
+      int64_t nf = 0;
+      if (problems[p].n_cams >= 1 && problems[p].n_cams <= SVOH_MAX_CAMS)
+        for (int c = 0; c < problems[p].n_cams; ++c) nf += problems[p].cams[c].n_features > 0 ? problems[p].cams[c].n_features : 0;
+      nf_min = nf < nf_min ? nf : nf_min;
+      nf_max = nf > nf_max ? nf : nf_max;
+    }
     int g = getenv_int("SVOH_ALIGN_CLUSTER", -1);
-    if (g < 0) g = nf >= kClusterMinFeatures ? (int)((nf + kClusterFeaturesPerWorkgroup - 1) / kClusterFeaturesPerWorkgroup) : 0;
+    if (g < 0) g = nf_min >= kClusterMinFeatures ? (int)((nf_max + kClusterFeaturesPerWorkgroup - 1) / kClusterFeaturesPerWorkgroup) : 0;
     if (g > kClusterMaxWorkgroups) g = kClusterMaxWorkgroups;
-    if (g > ctx->num_cus) g = ctx->num_cus;
+    if ((int64_t)g * n_problems > ctx->num_cus) g = ctx->num_cus / n_problems;   // every workgroup on its own CU
     if (g >= 2) { S = g; cluster = true; }
   }
-  SVOH_REQUIRE(ctx, S == 1 || n_problems == 1, "shares apply to a single problem");
+  SVOH_REQUIRE(ctx, S == 1 || n_problems == 1 || cluster, "shares apply to a single problem");
   const int n_desc = n_problems * S;
 
   // pass 1: sizes
@@ -1370,8 +1385,8 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   const size_t desc_bytes = sizeof(DevProblemDesc) * n_desc + sizeof(DevCamDesc) * n_cams_total;
   SVOH_HIP_TRY(ctx, ctx->h_desc.reserve(desc_bytes));
   SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
-  SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * n_desc));
-  SVOH_HIP_TRY(ctx, ctx->h_results.reserve(sizeof(svoh_align_result) * n_desc));
+  SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
+  SVOH_HIP_TRY(ctx, ctx->h_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
   SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (kWsPairs * 16 + 2) + 256));
   if (host_bytes) {
     SVOH_HIP_TRY(ctx, ctx->h_upload.reserve(host_bytes));
@@ -1471,7 +1486,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.xchg = nullptr;
   args.bar = nullptr;
   if (cluster) {
-    const size_t xchg_bytes = 2 * (size_t)S * kXchgStride * sizeof(double);
+    const size_t xchg_bytes = 2 * (size_t)S * kXchgStride * sizeof(double) * n_problems;
     SVOH_HIP_TRY(ctx, ctx->d_xchg.reserve(xchg_bytes + 256));
     args.cluster = S;
     args.xchg = static_cast<double*>(ctx->d_xchg.ptr);

@@ -333,3 +333,37 @@ def test_cluster_mode_single_problem(gpu_ctx, oracle_lib, n, cluster):
             os.environ.pop("SVOH_ALIGN_CLUSTER", None)
         else:
             os.environ["SVOH_ALIGN_CLUSTER"] = old
+
+
+def test_cluster_mode_small_batch_of_large_problems(gpu_ctx, oracle_lib):
+    """A few large problems in one call: each gets its own cluster of workgroups (own exchange slots and
+    arrival counter); the results are those of the one-workgroup kernel problem by problem."""
+    import os
+    orc = oracle_lib
+    scenes = [helpers.small_scene(90 + k, n=n, border_features=40) for k, n in enumerate((900, 1500, 700))]
+    items, oracle_pbs = [], []
+    for sc in scenes:
+        fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+        items.append([(sc, fr, fc)])
+        ref, cur = helpers.scene_pyramids(orc, sc, 5)
+        oracle_pbs.append(orc.problem_from_scenes([(sc, ref, cur)]))
+    gpb, keep = fe.make_align_problems(items)
+    opt = capi.default_align_options(min_level=1)
+    old = os.environ.get("SVOH_ALIGN_CLUSTER")
+    try:
+        os.environ["SVOH_ALIGN_CLUSTER"] = "0"
+        single = gpu_ctx.sparse_align(opt, gpb)
+        single = [(list(r.iters), r.n_fts_to_track, fe.se3_to_numpy(r.T_icur_iref)) for r in single]
+        os.environ.pop("SVOH_ALIGN_CLUSTER")
+        clustered = gpu_ctx.sparse_align(opt, gpb)
+        for r, (it, nf, T), opb in zip(clustered, single, oracle_pbs):
+            assert r.status == 0 and list(r.iters) == it and r.n_fts_to_track == nf
+            assert np.abs(fe.se3_to_numpy(r.T_icur_iref) - T).max() < 1e-9
+            n, ro, _ = orc.sparse_align_run(opt, opb)
+            assert n == r.n_fts_to_track and list(ro.iters) == list(r.iters) and list(ro.n_meas) == list(r.n_meas)
+            assert helpers.se3_max_abs_diff(r.T_icur_iref, ro.T_icur_iref) < TOL_POSE
+    finally:
+        if old is None:
+            os.environ.pop("SVOH_ALIGN_CLUSTER", None)
+        else:
+            os.environ["SVOH_ALIGN_CLUSTER"] = old
