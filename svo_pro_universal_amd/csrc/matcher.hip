@@ -69,6 +69,7 @@ struct MatcherArgs {
 };
 
 constexpr int kPwbStride = 100;
+constexpr int kG8MaxUnits = 49152;   // up to here a launch uses eight lanes per unit (measured crossover)
 
 // indices of feature i are usable (always true for host-resident batches, which the host validates)
 __device__ __forceinline__ bool feature_indices_ok(const MatcherArgs& a, int i)
@@ -81,7 +82,8 @@ __device__ __forceinline__ bool feature_indices_ok(const MatcherArgs& a, int i)
 }
 
 struct MatcherState {
-  unsigned char* pwb;  // this thread's 10x10 patch with border, in LDS
+  unsigned char* pwb;  // this unit's 10x10 patch with border, in LDS
+  int sub;             // eight lanes per unit (template G8): this lane's row of the patch; unused otherwise
   double A[4];         // A_cur_ref, col-major
   double epi_image[2];
   double epi_dir[2];   // normalised epipolar direction (the 1-D refinement's direction)
@@ -281,6 +283,102 @@ __device__ void mat4f_inverse(const float* m, float* r)
 #undef M4
 
 // feature_alignment.cpp:31-209
+// ---- eight lanes per unit (small batches) -----------------------------------------------------------------------
+// A launch of a few hundred or thousand units is as slow as its slowest lane, and a lone lane needs ~0.1 ms for
+// warp + scan + refinement (every instruction waits for the one before).  For small batches eight neighbouring
+// lanes share a unit: lane `sub` owns row `sub` of the 8x8 patch (and every eighth pixel of the 10x10 warp).
+// Integer sums (ZMSSD) are combined with three exchanges; the order-dependent float sums of the refinements
+// are handed from row to row, so every unit goes through exactly the additions of the one-lane code and the
+// results are bit-identical.  The scalar geometry is computed by all eight lanes alike.
+__device__ __forceinline__ int g8_sum(int v)
+{
+  v += __shfl_xor(v, 1, 8); v += __shfl_xor(v, 2, 8); v += __shfl_xor(v, 4, 8);
+  return v;
+}
+__device__ __forceinline__ float g8_sum_exact(float v)   // only for sums whose every partial is exactly representable
+{
+  v += __shfl_xor(v, 1, 8); v += __shfl_xor(v, 2, 8); v += __shfl_xor(v, 4, 8);
+  return v;
+}
+__device__ __forceinline__ bool g8_all(bool p)
+{
+  int v = p ? 1 : 0;
+  v &= __shfl_xor(v, 1, 8); v &= __shfl_xor(v, 2, 8); v &= __shfl_xor(v, 4, 8);
+  return v != 0;
+}
+// the LDS patch is written and read by different lanes of the same wave
+__device__ __forceinline__ void g8_lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// warp_affine with the 100 pixels dealt out to the eight lanes (pixel k = y*10 + x to lane k % 8)
+__device__ bool warp_affine_g8(const double A_cur_ref[4], const DevImage& img_ref, double pxr, double pyr, int level_ref,
+                               int search_level, unsigned char* patch, int sub)
+{
+  constexpr int halfpatch_size = 5;
+  double Ai[4];
+  mat2d_inverse(A_cur_ref, Ai);
+  const float s = (float)(1 << search_level);
+  const float a00 = (float)Ai[0] * s, a10 = (float)Ai[1] * s, a01 = (float)Ai[2] * s, a11 = (float)Ai[3] * s;
+  if (a00 != a00) return false;
+  const float prx = (float)pxr / (float)(1 << level_ref);
+  const float pry = (float)pyr / (float)(1 << level_ref);
+  const int stride = img_ref.pitch;
+  bool inside = true;
+  for (int k = sub; k < 100; k += 8) {
+    const float fx = (float)(k % 10 - halfpatch_size), fy = (float)(k / 10 - halfpatch_size);
+    const float pxx = (a00 * fx + a01 * fy) + prx;
+    const float pxy = (a10 * fx + a11 * fy) + pry;
+    const int xi = (int)floorf(pxx);
+    const int yi = (int)floorf(pxy);
+    inside = inside && pxx == pxx && pxy == pxy && !(xi < 0 || yi < 0 || xi >= img_ref.w - 1 || yi >= img_ref.h - 1);
+  }
+  if (!g8_all(inside)) return false;
+  for (int k = sub; k < 100; k += 8) {
+    const float fx = (float)(k % 10 - halfpatch_size), fy = (float)(k / 10 - halfpatch_size);
+    const float pxx = (a00 * fx + a01 * fy) + prx;
+    const float pxy = (a10 * fx + a11 * fy) + pry;
+    const int xi = (int)floorf(pxx);
+    const int yi = (int)floorf(pxy);
+    const float subpix_x = pxx - xi, subpix_y = pxy - yi;
+    const uint8_t* ptr = img_ref.data + (ptrdiff_t)yi * stride + xi;
+    const unsigned t00 = ptr[0], t10 = ptr[1], t01 = ptr[stride], t11 = ptr[stride + 1];
+    const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+    const float w01 = (1.0f - subpix_x) * subpix_y;
+    const float w10 = subpix_x * (1.0f - subpix_y);
+    const float w11 = 1.0f - w00 - w01 - w10;
+    patch[k] = (unsigned char)(w00 * t00 + w01 * t01 + w10 * t10 + w11 * t11);
+  }
+  g8_lds_fence();
+  return true;
+}
+
+// PatchScore constructor sums (patch_score.h:80-92), one row per lane
+__device__ __forceinline__ void patch_sums_g8(const unsigned char* pwb, int sub, int& sumA, int& sumAA)
+{
+  int a = 0, aa = 0;
+#pragma unroll
+  for (int x = 0; x < 8; ++x) { const int n = patch_at(pwb, sub * 8 + x); a += n; aa += n * n; }
+  sumA = g8_sum(a); sumAA = g8_sum(aa);
+}
+
+// zmssd_score, one row per lane (integer sums: any order)
+__device__ int zmssd_score_g8(const unsigned char* pwb, int sumA, int sumAA, const uint8_t* cur_patch, int stride, int sub)
+{
+  unsigned sumB = 0, sumBB = 0, sumAB = 0;
+  const uint8_t* p = cur_patch + (ptrdiff_t)sub * stride;
+  unsigned c[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) c[x] = p[x];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) { sumB += c[x]; sumBB += c[x] * c[x]; sumAB += c[x] * (unsigned)patch_at(pwb, sub * 8 + x); }
+  const int iB = g8_sum((int)sumB), iBB = g8_sum((int)sumBB), iAB = g8_sum((int)sumAB);
+  return sumAA - 2 * iAB + iBB - (sumA * sumA - 2 * sumA * iB + iB * iB) / 64;
+}
+
 // The two sub-pixel refinements are written as (set-up, one iteration).  A block-wide job queue that hands the
 // iterations of finished lanes' successors to idle lanes was built on this split and measured: no gain with one
 // job per lane (the slowest job still sets the pace: 0.3 % of the seeds need all 10 iterations, 4 % five or more,
@@ -494,12 +592,206 @@ __device__ bool align_2d(const DevImage& cur_img, const unsigned char* pwb, int 
   return converged;
 }
 
+// ---- the refinements with eight lanes per unit ----
+// acc[a] <- acc[a] - t[a][0] - ... - t[a][7] over the rows 0..7 in row order: lane `sub` continues where lane sub-1
+// stopped, so the additions are those of the one-lane loops (a sum is the same chain with negated terms).
+template <int NA>
+__device__ __forceinline__ void g8_chain_sub(float (&acc)[NA], const float (&t)[NA][8], int sub)
+{
+  float c[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) c[a] = acc[a];
+  for (int s = 0; s < 8; ++s) {
+    float in[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) in[a] = __shfl_up(c[a], 1, 8);
+    if (sub == s) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        float v = (s == 0) ? acc[a] : in[a];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) v -= t[a][x];
+        c[a] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acc[a] = __shfl(c[a], 7, 8);
+}
+
+// align_2d (feature_alignment.cpp:212-391).  The entries of H are sums of products of half-integers and
+// integers below 2^16: every partial sum is exact in float, so the rows may be added in any order.
+__device__ bool align_2d_g8(const DevImage& cur_img, const unsigned char* pwb, int n_iter, bool affine_est_offset,
+                            bool affine_est_gain, double& px, double& py, int& n_it, int sub)
+{
+  constexpr int halfpatch_size_ = 4, patch_size_ = 8, ref_step = 10;
+  bool converged = false;
+  float H[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  {
+    const unsigned char* it = pwb + (sub + 1) * ref_step + 1;
+    for (int x = 0; x < patch_size_; ++x, ++it) {
+      float J[4];
+      J[0] = (float)(0.5 * ((int)it[1] - (int)it[-1]));
+      J[1] = (float)(0.5 * ((int)it[ref_step] - (int)it[-ref_step]));
+      J[2] = affine_est_offset ? 1.0f : 0.0f;
+      J[3] = affine_est_gain ? (float)(-1.0 * it[0]) : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) H[r * 4 + c] += J[r] * J[c];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) H[k] = g8_sum_exact(H[k]);
+  }
+  if (!affine_est_offset) H[10] = 1.0f;
+  if (!affine_est_gain) H[15] = 1.0f;
+  float Hinv[16];
+  mat4f_inverse(H, Hinv);
+  float mean_diff = 0;
+  float alpha = 1.0;
+  float u = (float)px;
+  float v = (float)py;
+  const float min_update_squared = (float)(0.03 * 0.03);
+  const int cur_step = cur_img.pitch;
+  for (int iter = 0; iter < n_iter; ++iter) {
+    const int u_r = (int)floorf(u);
+    const int v_r = (int)floorf(v);
+    if (u_r < halfpatch_size_ || v_r < halfpatch_size_ || u_r >= cur_img.w - halfpatch_size_ || v_r >= cur_img.h - halfpatch_size_)
+      break;
+    if (u != u || v != v) return false;
+    ++n_it;
+    const float subpix_x = u - u_r;
+    const float subpix_y = v - v_r;
+    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
+    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
+    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
+    const float wBR = subpix_x * subpix_y;
+    float t[4][8];
+    {
+      const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + sub - halfpatch_size_) * cur_step + u_r - halfpatch_size_;
+      const unsigned char* rp = pwb + (sub + 1) * ref_step + 1;
+#pragma unroll
+      for (int x = 0; x < patch_size_; ++x, ++it, ++rp) {
+        const float ref_dx = (float)(0.5 * ((int)rp[1] - (int)rp[-1]));
+        const float ref_dy = (float)(0.5 * ((int)rp[ref_step] - (int)rp[-ref_step]));
+        const float search_pixel = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
+        const float res = search_pixel - alpha * rp[0] + mean_diff;
+        t[0][x] = res * ref_dx;
+        t[1][x] = res * ref_dy;
+        t[2][x] = affine_est_offset ? res : 0.0f;
+        t[3][x] = affine_est_gain ? (-1) * res * rp[0] : 0.0f;
+      }
+    }
+    float Jres[4] = { 0, 0, 0, 0 };
+    g8_chain_sub<4>(Jres, t, sub);
+    if (!affine_est_offset) Jres[2] = 0.0f;
+    if (!affine_est_gain) Jres[3] = 0.0f;
+    float update[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      update[r] = ((Hinv[r * 4 + 0] * Jres[0] + Hinv[r * 4 + 1] * Jres[1]) + Hinv[r * 4 + 2] * Jres[2]) + Hinv[r * 4 + 3] * Jres[3];
+    u += update[0];
+    v += update[1];
+    mean_diff += update[2];
+    alpha += update[3];
+    if (update[0] * update[0] + update[1] * update[1] < min_update_squared) { converged = true; break; }
+  }
+  px = u;
+  py = v;
+  return converged;
+}
+
+// align_1d (feature_alignment.cpp:31-209): the Jacobian entries are arbitrary floats here, H goes through the chain too
+__device__ bool align_1d_g8(const DevImage& cur_img, double dir0, double dir1, const unsigned char* pwb, int n_iter,
+                            bool affine_est_offset, bool affine_est_gain, double& px, double& py, double* h_inv,
+                            int& n_it, int sub)
+{
+  constexpr int kHalfPatchSize = 4, kPatchSize = 8, ref_step = 10;
+  bool converged = false;
+  float H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  {
+    float t[9][8];
+    const unsigned char* it = pwb + (sub + 1) * ref_step + 1;
+#pragma unroll
+    for (int x = 0; x < kPatchSize; ++x, ++it) {
+      float J[3];
+      const float dx = (float)it[1] - (float)it[-1];
+      const float dy = (float)it[ref_step] - (float)it[-ref_step];
+      J[0] = (float)(0.5f * (dir0 * dx + dir1 * dy));
+      J[1] = affine_est_offset ? 1.0f : 0.0f;
+      J[2] = affine_est_gain ? -1.0f * it[0] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[r * 3 + c][x] = -(J[r] * J[c]);   // H += J J^T as H -= (-J J^T)
+    }
+    g8_chain_sub<9>(H, t, sub);
+  }
+  if (!affine_est_offset) H[4] = 1.0f;
+  if (!affine_est_gain) H[8] = 1.0f;
+  if (h_inv) *h_inv = 1.0 / H[0] * kPatchSize * kPatchSize;
+  float Hinv[9];
+  mat3f_inverse(H, Hinv);
+  float mean_diff = 0;
+  float alpha = 1.0;
+  float u = (float)px;
+  float v = (float)py;
+  const float min_update_squared = (float)(0.03 * 0.03);
+  const int cur_step = cur_img.pitch;
+  for (int iter = 0; iter < n_iter; ++iter) {
+    const int u_r = (int)floorf(u);
+    const int v_r = (int)floorf(v);
+    if (u_r < kHalfPatchSize || v_r < kHalfPatchSize || u_r >= cur_img.w - kHalfPatchSize || v_r >= cur_img.h - kHalfPatchSize)
+      break;
+    if (u != u || v != v) return false;
+    ++n_it;
+    const float subpix_x = u - u_r;
+    const float subpix_y = v - v_r;
+    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
+    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
+    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
+    const float wBR = subpix_x * subpix_y;
+    float t[3][8];
+    {
+      const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + sub - kHalfPatchSize) * cur_step + u_r - kHalfPatchSize;
+      const unsigned char* rp = pwb + (sub + 1) * ref_step + 1;
+#pragma unroll
+      for (int x = 0; x < kPatchSize; ++x, ++it, ++rp) {
+        const float gdx = (float)rp[1] - (float)rp[-1];
+        const float gdy = (float)rp[ref_step] - (float)rp[-ref_step];
+        const float ref_dv = (float)(0.5f * (dir0 * gdx + dir1 * gdy));
+        const float cur_intensity = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
+        const float res = cur_intensity - alpha * rp[0] + mean_diff;
+        t[0][x] = res * ref_dv;
+        t[1][x] = affine_est_offset ? res : 0.0f;
+        t[2][x] = affine_est_gain ? (-1) * res * rp[0] : 0.0f;
+      }
+    }
+    float Jres[3] = { 0, 0, 0 };
+    g8_chain_sub<3>(Jres, t, sub);
+    if (!affine_est_offset) Jres[1] = 0.0f;
+    if (!affine_est_gain) Jres[2] = 0.0f;
+    float update[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) update[r] = (Hinv[r * 3 + 0] * Jres[0] + Hinv[r * 3 + 1] * Jres[1]) + Hinv[r * 3 + 2] * Jres[2];
+    u = (float)(u + update[0] * dir0);
+    v = (float)(v + update[0] * dir1);
+    mean_diff += update[1];
+    alpha += update[2];
+    if (update[0] * update[0] < min_update_squared) { converged = true; break; }
+  }
+  px = u;
+  py = v;
+  return converged;
+}
+
 __device__ __forceinline__ Rigid T_cur_ref_of(const DevFrameView& ref, const DevFrameView& cur)
 {
   return mul(cur.T_f_w, inverse(ref.T_f_w));
 }
 
 // matcher.cpp:31-141
+template <bool G8 = false>
 __device__ int find_match_direct(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
                                  const DevFrameView& cur_frame, double pxr, double pyr, const Vec3& f_ref, double gx,
                                  double gy, int level, int type, double ref_depth, double& pcx, double& pcy)
@@ -514,18 +806,24 @@ __device__ int find_match_direct(MatcherState& m, const svoh_matcher_options& op
   get_warp_matrix_affine(ref_frame.cam, cur_frame.cam, pxr, pyr, f_ref, ref_depth, T_cur_ref, level, m.A);
   m.search_level = get_best_search_level(m.A, ref_frame.n_levels - 1);
   ++m.n_warp;
-  if (!warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb)) return SVOH_MATCH_FAIL_WARP;
+  const bool warped = G8 ? warp_affine_g8(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb, m.sub)
+                         : warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
+  if (!warped) return SVOH_MATCH_FAIL_WARP;
   double sx = pcx / (1 << m.search_level), sy = pcy / (1 << m.search_level);
   const double sx0 = sx, sy0 = sy;
   bool ok;
   if (is_edgelet(type)) {
     double d0 = m.A[0] * gx + m.A[2] * gy, d1 = m.A[1] * gx + m.A[3] * gy;
     normalize2(d0, d1);
-    ok = align_1d(cur_frame.lv[m.search_level], d0, d1, m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
-                  opt.affine_est_gain != 0, sx, sy, &m.h_inv, m.n_align_it);
+    ok = G8 ? align_1d_g8(cur_frame.lv[m.search_level], d0, d1, m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
+                          opt.affine_est_gain != 0, sx, sy, &m.h_inv, m.n_align_it, m.sub)
+            : align_1d(cur_frame.lv[m.search_level], d0, d1, m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
+                       opt.affine_est_gain != 0, sx, sy, &m.h_inv, m.n_align_it);
   } else {
-    ok = align_2d(cur_frame.lv[m.search_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
-                  opt.affine_est_gain != 0, sx, sy, m.n_align_it);
+    ok = G8 ? align_2d_g8(cur_frame.lv[m.search_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
+                          opt.affine_est_gain != 0, sx, sy, m.n_align_it, m.sub)
+            : align_2d(cur_frame.lv[m.search_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
+                       opt.affine_est_gain != 0, sx, sy, m.n_align_it);
   }
   if (!ok) return SVOH_MATCH_FAIL_ALIGNMENT;
   const double dx = sx - sx0, dy = sy - sy0;
@@ -545,17 +843,19 @@ __device__ __forceinline__ bool is_patch_within_image(const DevFrameView& frame,
            py >= ((int)(frame.cam.height / (1 << patch_level)) - kPatchSize));
 }
 
+template <bool G8>
 __device__ __forceinline__ bool update_zmssd(const DevFrameView& frame, int px, int py, int patch_level,
-                                             const unsigned char* pwb, int sumA, int sumAA, int& zmssd_best)
+                                             const unsigned char* pwb, int sub, int sumA, int sumAA, int& zmssd_best)
 {
   const DevImage& im = frame.lv[patch_level];
   const uint8_t* cur_patch_ptr = im.data + (ptrdiff_t)(py - 4) * im.pitch + (px - 4);
-  const int z = zmssd_score(pwb, sumA, sumAA, cur_patch_ptr, im.pitch);
+  const int z = G8 ? zmssd_score_g8(pwb, sumA, sumAA, cur_patch_ptr, im.pitch, sub) : zmssd_score(pwb, sumA, sumAA, cur_patch_ptr, im.pitch);
   if (z < zmssd_best) { zmssd_best = z; return true; }
   return false;
 }
 
 // matcher.cpp:340-413
+template <bool G8>
 __device__ void scan_epipolar_unit_plane(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& frame,
                                          const Vec3& A, const Vec3& B, const Vec3& C, int patch_level, int sumA, int sumAA,
                                          double& bx, double& by, int& zmssd_best)
@@ -586,7 +886,7 @@ __device__ void scan_epipolar_unit_plane(MatcherState& m, const svoh_matcher_opt
         break;
     }
     ++m.n_zmssd;
-    if (update_zmssd(frame, pxi0, pxi1, patch_level, m.pwb, sumA, sumAA, zmssd_best)) { best0 = uv0; best1 = uv1; }
+    if (update_zmssd<G8>(frame, pxi0, pxi1, patch_level, m.pwb, m.sub, sumA, sumAA, zmssd_best)) { best0 = uv0; best1 = uv1; }
     if (forward && i > n_steps * 0.5) {
       step0 = -step0; step1 = -step1;
       uv0 = uvC0; uv1 = uvC1;
@@ -617,6 +917,7 @@ __device__ Vec3 angle_axis_rotate(const Vec3& axis, double angle, const Vec3& v)
 }
 
 // matcher.cpp:415-488
+template <bool G8>
 __device__ void scan_epipolar_unit_sphere(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& frame,
                                           const Vec3& A, const Vec3& B, const Vec3& C, int patch_level, int sumA, int sumAA,
                                           double& bx, double& by, int& zmssd_best)
@@ -646,7 +947,7 @@ __device__ void scan_epipolar_unit_sphere(MatcherState& m, const svoh_matcher_op
       else break;
     }
     ++m.n_zmssd;
-    if (update_zmssd(frame, pxi0, pxi1, patch_level, m.pwb, sumA, sumAA, zmssd_best)) f_best = f;
+    if (update_zmssd<G8>(frame, pxi0, pxi1, patch_level, m.pwb, m.sub, sumA, sumAA, zmssd_best)) f_best = f;
   }
   project3(frame.cam, f_best, bx, by);
 }
@@ -674,6 +975,7 @@ __device__ int depth_from_triangulation(const Rigid& T_search_ref, const Vec3& f
 // ZMSSD scan.  Returns a final result code, or kMatchRefinePending (m.px_cur = start of the refinement at level 0,
 // m.epi_dir = its 1-D direction) / kMatchTriangulatePending (no refinement wanted).
 constexpr int kMatchRefinePending = -1000, kMatchTriangulatePending = -1001;
+template <bool G8 = false>
 __device__ int epipolar_match_search(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
                                      const DevFrameView& cur_frame, const Rigid& T_cur_ref, double pxr, double pyr,
                                      const Vec3& f_ref, double gx, double gy, int level, int type,
@@ -709,7 +1011,8 @@ __device__ int epipolar_match_search(MatcherState& m, const svoh_matcher_options
   normalize2(ed0, ed1);
   ++m.n_warp;
   SVOH_MSTAMP(m, 0);
-  const bool warp_ok = warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
+  const bool warp_ok = G8 ? warp_affine_g8(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb, m.sub)
+                          : warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
   SVOH_MSTAMP(m, 1);
   if (!warp_ok) return SVOH_MATCH_FAIL_WARP;
 
@@ -724,13 +1027,14 @@ __device__ int epipolar_match_search(MatcherState& m, const svoh_matcher_options
   } else {
     // PatchScore constructor (patch_score.h:80-92)
     int sumA = 0, sumAA = 0;
-    for (int r = 0; r < 64; ++r) { const int n = patch_at(m.pwb, r); sumA += n; sumAA += n * n; }
+    if (G8) patch_sums_g8(m.pwb, m.sub, sumA, sumAA);
+    else for (int r = 0; r < 64; ++r) { const int n = patch_at(m.pwb, r); sumA += n; sumAA += n * n; }
     const Vec3 C = { Rf.x + T_cur_ref.t.x * d_estimate_inv, Rf.y + T_cur_ref.t.y * d_estimate_inv,
                      Rf.z + T_cur_ref.t.z * d_estimate_inv };
     if (opt.scan_on_unit_sphere)
-      scan_epipolar_unit_sphere(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
+      scan_epipolar_unit_sphere<G8>(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
     else
-      scan_epipolar_unit_plane(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
+      scan_epipolar_unit_plane<G8>(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
     if (!(zmssd_best < ZMSSD_THRESHOLD)) {
       SVOH_MSTAMP(m, 2);
       return SVOH_MATCH_FAIL_SCORE;
@@ -758,24 +1062,29 @@ __device__ int epipolar_match_finish(MatcherState& m, const DevFrameView& cur_fr
 }
 
 // Matcher::findEpipolarMatchDirect in one piece
+template <bool G8 = false>
 __device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
                                           const DevFrameView& cur_frame, const Rigid& T_cur_ref, double pxr, double pyr,
                                           const Vec3& f_ref, double gx, double gy, int level, int type,
                                           double d_estimate_inv, double d_min_inv, double d_max_inv, double& depth)
 {
-  const int st = epipolar_match_search(m, opt, ref_frame, cur_frame, T_cur_ref, pxr, pyr, f_ref, gx, gy, level, type,
-                                       d_estimate_inv, d_min_inv, d_max_inv);
+  const int st = epipolar_match_search<G8>(m, opt, ref_frame, cur_frame, T_cur_ref, pxr, pyr, f_ref, gx, gy, level, type,
+                                           d_estimate_inv, d_min_inv, d_max_inv);
   if (st != kMatchRefinePending && st != kMatchTriangulatePending) return st;
   bool aligned = false;
   double sx = 0.0, sy = 0.0;
   if (st == kMatchRefinePending) {
     sx = m.px_cur[0] / (1 << m.search_level); sy = m.px_cur[1] / (1 << m.search_level);
     if (m.align_1d)
-      aligned = align_1d(cur_frame.lv[m.search_level], m.epi_dir[0], m.epi_dir[1], m.pwb, opt.align_max_iter,
-                         opt.affine_est_offset != 0, opt.affine_est_gain != 0, sx, sy, &m.h_inv, m.n_align_it);
+      aligned = G8 ? align_1d_g8(cur_frame.lv[m.search_level], m.epi_dir[0], m.epi_dir[1], m.pwb, opt.align_max_iter,
+                                 opt.affine_est_offset != 0, opt.affine_est_gain != 0, sx, sy, &m.h_inv, m.n_align_it, m.sub)
+                   : align_1d(cur_frame.lv[m.search_level], m.epi_dir[0], m.epi_dir[1], m.pwb, opt.align_max_iter,
+                              opt.affine_est_offset != 0, opt.affine_est_gain != 0, sx, sy, &m.h_inv, m.n_align_it);
     else
-      aligned = align_2d(cur_frame.lv[m.search_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
-                         opt.affine_est_gain != 0, sx, sy, m.n_align_it);
+      aligned = G8 ? align_2d_g8(cur_frame.lv[m.search_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
+                                 opt.affine_est_gain != 0, sx, sy, m.n_align_it, m.sub)
+                   : align_2d(cur_frame.lv[m.search_level], m.pwb, opt.align_max_iter, opt.affine_est_offset != 0,
+                              opt.affine_est_gain != 0, sx, sy, m.n_align_it);
     SVOH_MSTAMP(m, 3);
   }
   return epipolar_match_finish(m, cur_frame, T_cur_ref, f_ref, st == kMatchRefinePending, aligned, sx, sy, depth);
@@ -857,10 +1166,13 @@ __device__ __forceinline__ void flush_counters(unsigned int* c, int i, const Mat
 #endif
 }
 
+// G8: eight lanes per unit (small batches, see g8_sum): unit = threadIdx.x / 8, the lane's patch row = threadIdx.x % 8
+template <bool G8>
 __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
 {
   __shared__ unsigned char s_pwb[64 * kPwbStride];
-  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int unit = G8 ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;
+  const int i = blockIdx.x * (G8 ? 8 : 64) + unit;
   if (i >= a.n) return;
   if (!feature_indices_ok(a, i)) {
     a.result[i] = SVOH_MATCH_NOT_RUN;
@@ -868,7 +1180,8 @@ __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
     return;
   }
   MatcherState m;
-  m.pwb = s_pwb + threadIdx.x * kPwbStride;
+  m.pwb = s_pwb + unit * kPwbStride;
+  m.sub = G8 ? (int)(threadIdx.x & 7) : 0;
   m.h_inv = 0.0; m.search_level = 0; m.reject = false; m.align_1d = false;
   m.n_warp = 0; m.n_zmssd = 0; m.n_align_it = 0;
   m.A[0] = m.A[1] = m.A[2] = m.A[3] = 0.0;
@@ -877,8 +1190,9 @@ __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
   const Vec3 f = { a.f[3 * i], a.f[3 * i + 1], a.f[3 * i + 2] };
   double pcx = a.px_cur[2 * i], pcy = a.px_cur[2 * i + 1];
   const DevFrameView& curf = a.cur_frame[a.cur_frame_idx ? a.cur_frame_idx[i] : 0];
-  const int r = find_match_direct(m, a.mopt, ref, curf, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
-                                  a.grad[2 * i + 1], a.level[i], a.type[i], a.depth[i], pcx, pcy);
+  const int r = find_match_direct<G8>(m, a.mopt, ref, curf, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
+                                      a.grad[2 * i + 1], a.level[i], a.type[i], a.depth[i], pcx, pcy);
+  if (G8 && m.sub != 0) return;   // the eight lanes hold the same results: one of them reports
   a.result[i] = r;
   a.px_cur[2 * i] = pcx; a.px_cur[2 * i + 1] = pcy;
   if (a.f_cur) { a.f_cur[3 * i] = m.f_cur.x; a.f_cur[3 * i + 1] = m.f_cur.y; a.f_cur[3 * i + 2] = m.f_cur.z; }
@@ -889,10 +1203,12 @@ __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
 }
 
 // DepthFilter::updateSeeds (depth_filter.cpp:200-233) + depth_filter_utils::updateSeed (:367-499)
+template <bool G8>
 __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
 {
   __shared__ unsigned char s_pwb[64 * kPwbStride];
-  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int unit = G8 ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;
+  const int i = blockIdx.x * (G8 ? 8 : 64) + unit;
   if (i >= a.n) return;
   a.success[i] = 0;
   if (a.result) a.result[i] = SVOH_MATCH_NOT_RUN;
@@ -923,7 +1239,8 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
     if (!(pxi0 >= boundary && pxi1 >= boundary && pxi0 < cur.cam.width - boundary && pxi1 < cur.cam.height - boundary)) return;
   }
   MatcherState m;
-  m.pwb = s_pwb + threadIdx.x * kPwbStride;
+  m.pwb = s_pwb + unit * kPwbStride;
+  m.sub = G8 ? (int)(threadIdx.x & 7) : 0;
   m.h_inv = 0.0; m.search_level = 0; m.reject = false;
   m.n_warp = 0; m.n_zmssd = 0; m.n_align_it = 0;
   m.align_1d = (type == SVOH_FT_EDGELET_SEED || type == SVOH_FT_EDGELET_SEED_CONVERGED);
@@ -936,8 +1253,9 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
   double depth = 0.0;
   const double inv_min = st[0] + sqrt(st[1]);
   const double inv_max = fmax(st[0] - sqrt(st[1]), 0.00000001);
-  const int res = find_epipolar_match_direct(m, a.mopt, ref, cur, T_cur_ref, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
-                                             a.grad[2 * i + 1], a.level[i], type, st[0], inv_min, inv_max, depth);
+  const int res = find_epipolar_match_direct<G8>(m, a.mopt, ref, cur, T_cur_ref, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
+                                                 a.grad[2 * i + 1], a.level[i], type, st[0], inv_min, inv_max, depth);
+  if (G8 && m.sub != 0) return;   // the eight lanes hold the same results: one of them reports and updates the seed
   if (a.result) a.result[i] = res;
   // matcher state as reprojector_utils::matchCandidate reads it after updateSeed (reprojector.cpp:403-413, 473-476)
   if (a.px_cur) { a.px_cur[2 * i] = m.px_cur[0]; a.px_cur[2 * i + 1] = m.px_cur[1]; }
@@ -1142,7 +1460,12 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
       a.px_cur = reinterpret_cast<double*>(d + o_pxcur);
     }
   }
-  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  // small batches: eight lanes per unit (a launch is as slow as its slowest lane, and eight lanes get a unit done
+  // ~3x sooner); large batches: one lane per unit (fewer instructions per unit).  SVOH_MATCHER_G8=0/1 forces it.
+  int g8 = n <= kG8MaxUnits ? 1 : 0;
+  if (const char* e = getenv("SVOH_MATCHER_G8")) g8 = atoi(e) != 0;
+  const int units_per_block = g8 ? 8 : 64;
+  const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
   {
     unsigned long long* dummy;
     int rc = reset_counters(ctx, &dummy);
@@ -1150,8 +1473,13 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     if (rc != SVOH_OK) return rc;
   }
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
-  if (seeds) hipLaunchKernelGGL(update_seeds_kernel, grid, block, 0, ctx->stream, a);
-  else hipLaunchKernelGGL(match_direct_kernel, grid, block, 0, ctx->stream, a);
+  if (seeds) {
+    if (g8) hipLaunchKernelGGL(update_seeds_kernel<true>, grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL(update_seeds_kernel<false>, grid, block, 0, ctx->stream, a);
+  } else {
+    if (g8) hipLaunchKernelGGL(match_direct_kernel<true>, grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL(match_direct_kernel<false>, grid, block, 0, ctx->stream, a);
+  }
   SVOH_HIP_TRY(ctx, hipGetLastError());
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
   ctx->misc_timed = true;

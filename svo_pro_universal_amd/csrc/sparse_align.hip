@@ -663,7 +663,7 @@ __device__ __forceinline__ bool cluster_sum(const AlignKernelArgs& a, int prob, 
     atomicAdd(bar, 1u);
     const unsigned target = (unsigned)G * (epoch + 1u);
     int ok = 0;
-    for (long long spin = 0; spin < (1ll << 24); ++spin) {
+    for (long long spin = 0; spin < (1ll << 19); ++spin) {   // ~1 s; an exchange normally completes in ~2 us
       if (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
       __builtin_amdgcn_s_sleep(2);
     }
@@ -1339,7 +1339,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // A handful of such problems (a stereo pair of streams, a few cameras) are clustered alike, each with its own
   // exchange slots, as long as every one of them is large and they all fit on the device at once.
   bool cluster = false;
-  if (!split && eval_level < 0 && n_problems <= kClusterMaxProblems) {
+  if (!split && eval_level < 0 && n_problems <= kClusterMaxProblems && !ctx->align_no_cluster) {
     int64_t nf_min = INT64_MAX, nf_max = 0;
     for (int p = 0; p < n_problems; ++p) {
       int64_t nf = 0;
@@ -1611,7 +1611,21 @@ int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options, in
 {
   int rc = enqueue_align(ctx, options, n_problems, problems, -1);
   if (rc != SVOH_OK) return rc;
-  return svoh_sparse_align_fetch(ctx, n_problems, results);
+  rc = svoh_sparse_align_fetch(ctx, n_problems, results);
+  if (rc != SVOH_OK) return rc;
+  // Cluster mode gives up (status 3) when the workgroups of a problem do not all become resident within its
+  // bounded wait -- possible when something else holds the device.  The call does not fail for that: it runs
+  // the problems again, one workgroup each.
+  bool gave_up = false;
+  for (int p = 0; p < n_problems; ++p) gave_up = gave_up || results[p].status == 3;
+  if (gave_up) {
+    ctx->align_no_cluster = true;
+    rc = enqueue_align(ctx, options, n_problems, problems, -1);
+    ctx->align_no_cluster = false;
+    if (rc != SVOH_OK) return rc;
+    rc = svoh_sparse_align_fetch(ctx, n_problems, results);
+  }
+  return rc;
 }
 
 int svoh_sparse_align_last_kernel_ms(svoh_ctx* ctx, float* ms)

@@ -99,6 +99,7 @@ struct svoh_ctx {
   unsigned long long align_launches = 0;
   hipEvent_t ev_align_staged = nullptr;   // the alignment's pinned staging buffers have been consumed
   bool align_staging_in_flight = false;
+  bool align_no_cluster = false;   // svoh_sparse_align_batch repeating a launch whose cluster gave up
   hipEvent_t ev_misc_start = nullptr, ev_misc_stop = nullptr;  // KLT / matcher / seeds
   bool misc_timed = false;
   svoh::DevBuffer d_counters;  // 8 x uint64 work counters of the last KLT / matcher kernel

@@ -15,6 +15,20 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["eight_lanes_per_unit", "one_lane_per_unit"], autouse=True)
+def matcher_geometry(request):
+    """The matcher kernels exist in two geometries with bit-identical results: eight lanes per unit (what a small
+    batch gets) and one lane per unit (large batches).  Every test of this file runs through both."""
+    import os
+    old = os.environ.get("SVOH_MATCHER_G8")
+    os.environ["SVOH_MATCHER_G8"] = "1" if request.param == "eight_lanes_per_unit" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("SVOH_MATCHER_G8", None)
+    else:
+        os.environ["SVOH_MATCHER_G8"] = old
+
+
 def scene_and_frames(gpu_ctx, orc, seed, cam=None, **kw):
     sc = synth.make_align_scene(seed, n_features=10, cam=cam, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15), **kw)
     ref = orc.create_img_pyramid(sc.img_ref, 5)

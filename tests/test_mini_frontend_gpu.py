@@ -67,6 +67,9 @@ def test_mini_frontend_tracks_a_synthetic_sequence(tmp_path):
     fc = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)
     print("ATE rmse %.4f m over a %.3f m path (scale %.3f); reprojected features per frame: median %d; converged seeds at the end: %d"
           % (res["rmse"], path_len, res["scale"], int(np.median(fc[1:, 3])), int(fc[-1, 6])))
+    stage = fc[1:, 7:13].mean(0)
+    print("mean ms per frame: pyramid %.3f align %.3f reproject %.3f pose %.3f seeds %.3f keyframe %.3f  total %.3f"
+          % (tuple(stage) + (stage.sum(),)))
     assert res["n"] == n_frames
     assert res["rmse"] < 0.03 * path_len + 0.003          # a few per cent of the distance travelled
     assert 0.8 < res["scale"] < 1.25                      # the depth prior fixes the scale
