@@ -36,8 +36,7 @@ const Frame* find_frame(const svoh_ctx* ctx, svoh_frame_t id)
 int reset_counters(svoh_ctx* ctx, unsigned long long** out)
 {
   SVOH_HIP_TRY(ctx, ctx->d_counters.reserve(8 * sizeof(unsigned long long)));
-  SVOH_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
-  *out = static_cast<unsigned long long*>(ctx->d_counters.ptr);
+  *out = static_cast<unsigned long long*>(ctx->d_counters.ptr);   // zeroed when the totals are asked for
   return SVOH_OK;
 }
 
@@ -70,8 +69,17 @@ int reserve_unit_counts(svoh_ctx* ctx, size_t n_units, unsigned int** out)
   return SVOH_OK;
 }
 
+// The totals are a diagnostic: the per-unit counts of a launch are only added up when svoh_last_kernel_counters
+// asks for them (a memset and a kernel less on every tracking / matching call).
 int reduce_unit_counts(svoh_ctx* ctx, size_t n_units)
 {
+  ctx->unit_counts_pending = n_units;
+  return SVOH_OK;
+}
+
+static int reduce_unit_counts_now(svoh_ctx* ctx, size_t n_units)
+{
+  SVOH_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
   const int blocks = (int)((n_units + 255) / 256 > 64 ? 64 : (n_units + 255) / 256);
   hipLaunchKernelGGL(reduce_unit_counts_kernel, dim3(blocks), dim3(256), 0, ctx->stream,
                      static_cast<const unsigned int*>(ctx->d_unit_counts.ptr), n_units,
@@ -270,6 +278,11 @@ int svoh_last_kernel_counters(svoh_ctx* ctx, uint64_t out[8])
 {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, out != nullptr && ctx->misc_timed && ctx->d_counters.ptr, "no counters yet");
+  if (ctx->unit_counts_pending) {
+    const int rc = reduce_unit_counts_now(ctx, ctx->unit_counts_pending);
+    if (rc != SVOH_OK) return rc;
+    ctx->unit_counts_pending = 0;
+  }
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_counters.ptr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return SVOH_OK;

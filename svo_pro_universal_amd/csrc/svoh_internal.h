@@ -104,6 +104,7 @@ struct svoh_ctx {
   bool misc_timed = false;
   svoh::DevBuffer d_counters;  // 8 x uint64 work counters of the last KLT / matcher kernel
   svoh::DevBuffer d_unit_counts;  // 4 x uint32 per unit
+  size_t unit_counts_pending = 0; // units of the last launch whose counts have not been added up yet
 
   // generic scratch for the other paths
   svoh::DevBuffer d_scratch0, d_scratch1, d_scratch2;
