@@ -1382,9 +1382,13 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   }
   const size_t feat_slots = n_feat_total ? n_feat_total : 1;
 
-  const size_t desc_bytes = sizeof(DevProblemDesc) * n_desc + sizeof(DevCamDesc) * n_cams_total;
+  // descriptors, then (256-byte aligned) the zeroed work-queue head and the cluster arrival counters: one upload
+  const size_t desc_only = sizeof(DevProblemDesc) * n_desc + sizeof(DevCamDesc) * n_cams_total;
+  const size_t ctl_off = (desc_only + 255) & ~(size_t)255;
+  const size_t desc_bytes = ctl_off + 512;
   SVOH_HIP_TRY(ctx, ctx->h_desc.reserve(desc_bytes));
   SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
+  memset(static_cast<uint8_t*>(ctx->h_desc.ptr) + ctl_off, 0, 512);
   SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
   SVOH_HIP_TRY(ctx, ctx->h_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
   SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (kWsPairs * 16 + 2) + 256));
@@ -1487,11 +1491,10 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.bar = nullptr;
   if (cluster) {
     const size_t xchg_bytes = 2 * (size_t)S * kXchgStride * sizeof(double) * n_problems;
-    SVOH_HIP_TRY(ctx, ctx->d_xchg.reserve(xchg_bytes + 256));
+    SVOH_HIP_TRY(ctx, ctx->d_xchg.reserve(xchg_bytes));
     args.cluster = S;
     args.xchg = static_cast<double*>(ctx->d_xchg.ptr);
-    args.bar = reinterpret_cast<unsigned int*>(static_cast<uint8_t*>(ctx->d_xchg.ptr) + xchg_bytes);
-    SVOH_HIP_TRY(ctx, hipMemsetAsync(args.bar, 0, 256, ctx->stream));
+    args.bar = reinterpret_cast<unsigned int*>(static_cast<uint8_t*>(ctx->d_desc.ptr) + ctl_off + 256);   // zero, as above
   }
   if (split && !split->update) {
     args.ext_state = split->ext_state;
@@ -1512,9 +1515,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
     if (eu != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "gn_update launch failed: %s", hipGetErrorString(eu));
     return SVOH_OK;
   }
-  SVOH_HIP_TRY(ctx, ctx->d_scratch2.reserve(64));
-  SVOH_HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch2.ptr, 0, sizeof(int32_t), ctx->stream));
-  args.queue = static_cast<int32_t*>(ctx->d_scratch2.ptr);
+  args.queue = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(ctx->d_desc.ptr) + ctl_off);   // zero: uploaded with the descriptors
 #ifdef SVOH_PHASE_STAMPS
   SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(sizeof(long long) * 8 * (size_t)n_problems));
   args.stamps = static_cast<long long*>(ctx->d_scratch0.ptr);
