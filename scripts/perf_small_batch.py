@@ -7,7 +7,7 @@ import bench
 ctx = fe.Context(0)
 ms = ctypes.c_float()
 opt = capi.default_align_options(min_level=0)
-for B, N in ((2, 2000), (4, 2000), (8, 2000), (16, 2000), (8, 700), (16, 4000)):
+for B, N in ((2, 2000), (8, 2000), (16, 2000), (32, 2000), (64, 2000), (128, 2000), (32, 700), (64, 4000)):
     problems, scenes, imgs, keep = bench.build_problems(ctx, torch.device("cuda", 0), 0, B, N, 4, 4)
     row = []
     for g in ("0", None):

@@ -1289,7 +1289,7 @@ static hipError_t launch_nt(hipStream_t st, int nt, int grid, size_t lds, const 
 constexpr int kClusterMinFeatures = 512;
 constexpr int kClusterFeaturesPerWorkgroup = 192;
 constexpr int kClusterMaxWorkgroups = 32;
-constexpr int kClusterMaxProblems = 16;   // arrival counters: one 32-bit word per problem in a 256-byte block
+constexpr int kClusterMaxProblems = 64;   // arrival counters: one 32-bit word per problem in a 256-byte block
 
 static int getenv_int(const char* name, int dflt)
 {
@@ -1349,7 +1349,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
       nf_max = nf > nf_max ? nf : nf_max;
     }
     int g = getenv_int("SVOH_ALIGN_CLUSTER", -1);
-    if (g < 0) g = nf_min >= kClusterMinFeatures ? (int)((nf_max + kClusterFeaturesPerWorkgroup - 1) / kClusterFeaturesPerWorkgroup) : 0;
+    // measured (scripts/perf_small_batch.py): up to 16 problems always gain; 32..64 only when each is large
+    const bool worth = nf_min >= kClusterMinFeatures && (n_problems <= 16 || nf_min >= 3000);
+    if (g < 0) g = worth ? (int)((nf_max + kClusterFeaturesPerWorkgroup - 1) / kClusterFeaturesPerWorkgroup) : 0;
     if (g > kClusterMaxWorkgroups) g = kClusterMaxWorkgroups;
     if ((int64_t)g * n_problems > ctx->num_cus) g = ctx->num_cus / n_problems;   // every workgroup on its own CU
     if (g >= 2) { S = g; cluster = true; }
