@@ -136,6 +136,11 @@ def cpu_baseline(scenes, imgs, opt, max_level, budget_s=15.0):
                              "sample": "%d frame pairs, one per thread, %.1f s wall" % (n_par, t_par)}
     except Exception as e:  # the baseline leg must not take the benchmark down
         base["all_cores"] = {"error": str(e)}
+    try:   # the host the baseline ran on (core count and CPU model stated)
+        model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown")
+        base["host"] = {"cpu_model": model, "logical_cpus": os.cpu_count(), "cpus_available_to_this_process": len(os.sched_getaffinity(0))}
+    except Exception:
+        pass
     return base
 
 
