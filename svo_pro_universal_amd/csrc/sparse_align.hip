@@ -1528,7 +1528,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // >= 2 of a 640x480 pyramid.  Few problems (latency mode): 512-thread workgroups.
   // measured on MI355X (2000 patches): one problem takes 0.42 ms with 512 threads, 0.50 ms
   // with 256 and 0.91 ms with 1024 (128-VGPR budget spills), so 512 is the latency geometry
-  int nt = (n_desc >= 2 * ctx->num_cus) ? 256 : 512;
+  // (measured, scripts/perf_mid_batch.py: from one problem per CU on, two 256-thread workgroups per CU with the
+  // LDS-DMA workspace path beat one 512-thread workgroup: 384 problems 1.06 -> 0.82 ms)
+  int nt = (n_desc >= ctx->num_cus) ? 256 : 512;
   if (max_feat_per_problem <= 256) nt = 256;
   nt = getenv_int("SVOH_ALIGN_THREADS", nt);
   if (cluster) nt = 256;   // one workgroup per CU at most: all of them are resident together
