@@ -138,3 +138,71 @@ def evaluate(scene, ref_levels, cur_levels, level, P, T_icur_iref_q, T_icur_iref
     g = -(Jm * (rm * wm)[:, None]).sum(0)
     chi2 = float((rm * rm * wm).sum() / max(1, rm.size))
     return H, g, chi2, int(rm.size), vis.astype(np.uint8)
+
+
+def align_pyr_2d(pyr_ref, pyr_cur, max_level, min_level, patch_sizes, n_iter, min_update_squared, px_ref_level_0,
+                 px_cur_level_0):
+    """feature_alignment::alignPyr2D (src/svo_direct/src/feature_alignment.cpp:761-973, scalar branch), written
+    independently of oracle/svo_oracle_klt.c with numpy float32 scalars and whole-patch integer arithmetic.
+    Every sum in it is a sum of integers below 2^24, so the order of the additions does not matter.
+    Returns (converged, (x, y))."""
+    f32 = np.float32
+    px_cur = [float(px_cur_level_0[0]), float(px_cur_level_0[1])]
+    converged = False
+    for level in range(max_level, min_level - 1, -1):
+        P = int(patch_sizes[level])
+        half = P // 2
+        scale = 1 << level
+        ref, cur = pyr_ref[level].astype(np.int64), pyr_cur[level].astype(np.int64)
+        height, width = ref.shape
+        px_ref_flt = [f32(f32(px_ref_level_0[k]) / f32(scale)) - f32(half) for k in range(2)]
+        px_ref = [int(px_ref_flt[k]) for k in range(2)]                       # cast<int>: truncation
+        off = [f32(px_ref_flt[k] - f32(px_ref[k])) for k in range(2)]
+        if px_ref[0] < 1 or px_ref[1] < 1 or px_ref[0] >= width - P - 1 or px_ref[1] >= height - P - 1:
+            continue
+        x0, y0 = px_ref
+        tmpl = ref[y0:y0 + P, x0:x0 + P]
+        dx = ref[y0:y0 + P, x0 + 1:x0 + P + 1] - ref[y0:y0 + P, x0 - 1:x0 + P - 1]
+        dy = ref[y0 + 1:y0 + P + 1, x0:x0 + P] - ref[y0 - 1:y0 + P - 1, x0:x0 + P]
+        H00, H01, H11 = f32((dx * dx).sum()), f32((dx * dy).sum()), f32((dy * dy).sum())
+        assert (dx * dx).sum() < 2 ** 24 and (dy * dy).sum() < 2 ** 24
+        det = f32(f32(H00 * H11) - f32(H01 * H01))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            invdet = f32(f32(1.0) / det)
+            Hi00, Hi01, Hi10, Hi11 = f32(H11 * invdet), f32(f32(-H01) * invdet), f32(f32(-H01) * invdet), f32(H00 * invdet)
+        u = f32(px_cur[0] / scale - half - float(off[0]))
+        v = f32(px_cur[1] / scale - half - float(off[1]))
+        go_to_next_level = False
+        converged = False
+        for _ in range(n_iter):
+            if np.isnan(u) or np.isnan(v):
+                return False, tuple(px_cur)
+            go_to_next_level = False
+            u_r, v_r = int(np.floor(u)), int(np.floor(v))
+            if u_r < 0 or v_r < 0 or u_r >= width - P or v_r >= height - P:
+                go_to_next_level = True
+                break
+            sx, sy = f32(u - f32(u_r)), f32(v - f32(v_r))
+            one = f32(1.0)
+            wTL = int(f32(f32(f32(one - sx) * f32(one - sy)) * f32(128)))
+            wTR = int(f32(f32(sx * f32(one - sy)) * f32(128)))
+            wBL = int(f32(f32(f32(one - sx) * sy) * f32(128)))
+            wBR = 128 - wTL - wTR - wBL
+            a = cur[v_r:v_r + P, u_r:u_r + P]
+            b = cur[v_r:v_r + P, u_r + 1:u_r + P + 1]
+            c = cur[v_r + 1:v_r + P + 1, u_r:u_r + P]
+            d = cur[v_r + 1:v_r + P + 1, u_r + 1:u_r + P + 1]
+            interp = (wTL * a + wTR * b + wBL * c + wBR * d + 64) >> 7
+            res = interp - tmpl
+            Jres0, Jres1 = f32(-(res * dx).sum()), f32(-(res * dy).sum())
+            assert abs((res * dx).sum()) < 2 ** 24 and abs((res * dy).sum()) < 2 ** 24
+            up0 = f32(f32(f32(Hi00 * Jres0) + f32(Hi01 * Jres1)) * f32(2.0))
+            up1 = f32(f32(f32(Hi10 * Jres0) + f32(Hi11 * Jres1)) * f32(2.0))
+            u, v = f32(u + up0), f32(v + up1)
+            if f32(f32(up0 * up0) + f32(up1 * up1)) < f32(min_update_squared):
+                converged = True
+                break
+        px_cur = [float(f32(f32(f32(u + f32(half)) + off[0]) * f32(scale))), float(f32(f32(f32(v + f32(half)) + off[1]) * f32(scale)))]
+        if not converged and not go_to_next_level:
+            return False, tuple(px_cur)
+    return converged, tuple(px_cur)

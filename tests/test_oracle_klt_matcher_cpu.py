@@ -169,3 +169,29 @@ def test_vogiatzis_update_formula_against_numpy(oracle_lib):
         assert 0 < f < 1 and 0 < e < f
         # the posterior mean lies between prior mean and the measurement-fused mean; variance decreased
         assert s21 <= s2 * (1 + 1e-9)
+
+
+def test_klt_oracle_against_an_independent_numpy_restatement(oracle_lib):
+    """Two restatements of feature_alignment.cpp:761-973 written separately (C in oracle/, numpy float32 in
+    tests/np_restatement.py) must agree bit for bit: tracks inside the image, at the border, starting far off."""
+    import np_restatement as npr
+    orc = oracle_lib
+    sc = synth.make_align_scene(77, n_features=10, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))
+    ref = orc.create_img_pyramid(sc.img_ref, 5)
+    cur = orc.create_img_pyramid(sc.img_cur, 5)
+    tr = synth.make_track_set(sc, 40, seed=5)
+    px_ref = tr["px_ref"].copy().reshape(-1, 2)
+    px0 = tr["px_cur_init"].copy().reshape(-1, 2)
+    px_ref[0] = [9, 200]; px_ref[1] = [640 - 10, 240]; px_ref[2] = [300, 9]      # template bounds of the coarse levels
+    px0[3] += 60.0; px0[4] = [2.0, 3.0]; px0[5] = [636.0, 476.0]                  # far off / at the borders
+    opt = capi.default_klt_options()
+    po, so = orc.klt_track_batch(opt, [ref] * 40, cur, px_ref.ravel(), px0.ravel())
+    sizes = [opt.patch_sizes[k] for k in range(5)]
+    n_conv = 0
+    for i in range(40):
+        ok, p = npr.align_pyr_2d(ref, cur, opt.max_level, opt.min_level, sizes, opt.max_iter, opt.min_update_squared,
+                                 [int(px_ref[i, 0]), int(px_ref[i, 1])], px0[i])
+        assert int(ok) == int(so[i]), i
+        assert p[0] == po[2 * i] and p[1] == po[2 * i + 1], (i, p, po[2 * i:2 * i + 2])
+        n_conv += int(ok)
+    assert 25 <= n_conv < 40
