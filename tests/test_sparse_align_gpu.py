@@ -367,3 +367,28 @@ def test_cluster_mode_small_batch_of_large_problems(gpu_ctx, oracle_lib):
             os.environ.pop("SVOH_ALIGN_CLUSTER", None)
         else:
             os.environ["SVOH_ALIGN_CLUSTER"] = old
+
+
+@pytest.mark.parametrize("seed", [48, 52, 53, 56])
+def test_visibility_changes_inside_a_level(gpu_ctx, oracle_lib, seed):
+    """Scenes whose set of visible patches changes between iterations of the same level (the oracle's trace says
+    so): the kernel's gradient-only passes must notice, repeat the iteration with a fresh Hessian and end exactly
+    where the every-iteration recomputation ends -- with one workgroup and with a cluster of three."""
+    import os
+    orc = oracle_lib
+    sc = helpers.small_scene(seed, n=300, border_features=300, rot_deg=(1.5, 3.0), trans_m=(0.05, 0.12))
+    opb, gpb, keep = both(gpu_ctx, orc, [sc])
+    opt = capi.default_align_options(min_level=0)
+    n, ro, tr = orc.sparse_align_run(opt, opb, trace_capacity=80)
+    lv, nm = tr["level"], tr["n_meas"]
+    assert any(lv[k] == lv[k - 1] and nm[k] != nm[k - 1] for k in range(1, len(lv)))   # the premise of the test
+    old = os.environ.get("SVOH_ALIGN_CLUSTER")
+    try:
+        for g in ("0", "3"):
+            os.environ["SVOH_ALIGN_CLUSTER"] = g
+            check_run(gpu_ctx, orc, opt, opb, gpb)
+    finally:
+        if old is None:
+            os.environ.pop("SVOH_ALIGN_CLUSTER", None)
+        else:
+            os.environ["SVOH_ALIGN_CLUSTER"] = old
