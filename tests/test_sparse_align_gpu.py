@@ -392,3 +392,31 @@ def test_visibility_changes_inside_a_level(gpu_ctx, oracle_lib, seed):
             os.environ.pop("SVOH_ALIGN_CLUSTER", None)
         else:
             os.environ["SVOH_ALIGN_CLUSTER"] = old
+
+
+def test_queued_launches_and_kernel_time_history(gpu_ctx):
+    """Several enqueue calls before one fetch: the last launch's results are handed out, every launch's device
+    time can be read afterwards (the library keeps the last 32 event pairs)."""
+    import ctypes as C
+    scs = [helpers.small_scene(95 + k, n=200) for k in range(3)]
+    items = []
+    for sc in scs:
+        items.append([(sc, gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5))])
+    gpb, keep = fe.make_align_problems(items)
+    opt = capi.default_align_options(min_level=1)
+    want = gpu_ctx.sparse_align(opt, gpb)
+    want = [fe.se3_to_numpy(r.T_icur_iref) for r in want]
+    for _ in range(5):
+        gpu_ctx.sparse_align_enqueue(opt, gpb)
+    got = gpu_ctx.sparse_align_fetch(3)
+    for r, T in zip(got, want):
+        assert r.status == 0 and np.array_equal(fe.se3_to_numpy(r.T_icur_iref), T)
+    ms = (C.c_float * 40)()
+    n = C.c_int()
+    gpu_ctx._check(gpu_ctx.lib.svoh_sparse_align_kernel_ms_history(gpu_ctx.h, 5, ms, C.byref(n)))
+    assert n.value == 5 and all(0.0 < ms[k] < 50.0 for k in range(5))
+    gpu_ctx._check(gpu_ctx.lib.svoh_sparse_align_kernel_ms_history(gpu_ctx.h, 40, ms, C.byref(n)))
+    assert 6 <= n.value <= 32
+    last = C.c_float()
+    gpu_ctx._check(gpu_ctx.lib.svoh_sparse_align_last_kernel_ms(gpu_ctx.h, C.byref(last)))
+    assert last.value == ms[n.value - 1]
