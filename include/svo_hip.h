@@ -198,7 +198,7 @@ typedef struct svoh_align_result {
   int32_t status;            /* 0 ok; 1 = no features to track (run() returns 0);
                                 2 = solver stopped on NaN (state rolled back);
                                 3 = a large problem was spread over several workgroups and one of them did not
-                                    reach the device-side barrier within ~1 s (the kernel gives up instead of
+                                    reach the device-side barrier within its bounded wait of ~0.1 s (the kernel gives up instead of
                                     hanging).  svoh_sparse_align_batch then repeats the launch with one
                                     workgroup per problem, so only enqueue / fetch callers can see this value */
   int32_t n_fts_to_track;    /* return value of SparseImgAlign::run */

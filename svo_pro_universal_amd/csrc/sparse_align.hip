@@ -86,6 +86,7 @@ struct AlignKernelArgs {
   int32_t cluster;                      // 0 / 1: off
   double* xchg;                         // 2 x cluster x kXchgStride doubles
   unsigned int* bar;                    // arrival counter, zeroed before the launch
+  int32_t cluster_test_absent;          // test hook (SVOH_ALIGN_CLUSTER_TEST_ABSENT): share 1 never arrives
 };
 
 constexpr int kXchgStride = 64;         // doubles per share and parity (>= 45 + 8 + 1 accumulators + 2)
@@ -663,7 +664,7 @@ __device__ __forceinline__ bool cluster_sum(const AlignKernelArgs& a, int prob, 
     atomicAdd(bar, 1u);
     const unsigned target = (unsigned)G * (epoch + 1u);
     int ok = 0;
-    for (long long spin = 0; spin < (1ll << 19); ++spin) {   // ~1 s; an exchange normally completes in ~2 us
+    for (long long spin = 0; spin < (1ll << 19); ++spin) {   // ~0.1 s; an exchange normally completes in ~2 us
       if (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
       __builtin_amdgcn_s_sleep(2);
     }
@@ -881,6 +882,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
   __syncthreads();
   const int pbi = s_pbi;
   if (pbi >= a.n_problems) break;
+  if (CLUSTER && a.cluster_test_absent && pbi % a.cluster == 1) continue;   // test hook: a partner that never arrives
   const DevProblemDesc& pb = a.problems[pbi];
   const DevCamDesc* cams = a.cams + pb.cam_begin;
   const int n_cams = pb.n_cams;
@@ -1491,6 +1493,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.cluster = 0;
   args.xchg = nullptr;
   args.bar = nullptr;
+  args.cluster_test_absent = getenv_int("SVOH_ALIGN_CLUSTER_TEST_ABSENT", 0);
   if (cluster) {
     const size_t xchg_bytes = 2 * (size_t)S * kXchgStride * sizeof(double) * n_problems;
     SVOH_HIP_TRY(ctx, ctx->d_xchg.reserve(xchg_bytes));

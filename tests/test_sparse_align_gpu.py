@@ -420,3 +420,33 @@ def test_queued_launches_and_kernel_time_history(gpu_ctx):
     last = C.c_float()
     gpu_ctx._check(gpu_ctx.lib.svoh_sparse_align_last_kernel_ms(gpu_ctx.h, C.byref(last)))
     assert last.value == ms[n.value - 1]
+
+
+def test_cluster_that_never_completes_falls_back(gpu_ctx):
+    """A workgroup of a cluster that never reaches the device-side barrier (test hook) must not hang the device:
+    its partners give up after their bounded wait (status 3 for enqueue / fetch callers) and
+    svoh_sparse_align_batch runs the problem again with one workgroup."""
+    import os, time
+    sc = helpers.small_scene(97, n=1200)
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+    gpb, keep = fe.make_align_problems([[(sc, fr, fc)]])
+    opt = capi.default_align_options(min_level=2)
+    old = {k: os.environ.get(k) for k in ("SVOH_ALIGN_CLUSTER", "SVOH_ALIGN_CLUSTER_TEST_ABSENT")}
+    try:
+        os.environ["SVOH_ALIGN_CLUSTER"] = "0"
+        want = gpu_ctx.sparse_align(opt, gpb)[0]
+        os.environ["SVOH_ALIGN_CLUSTER"] = "4"
+        os.environ["SVOH_ALIGN_CLUSTER_TEST_ABSENT"] = "1"
+        gpu_ctx.sparse_align_enqueue(opt, gpb)
+        t0 = time.perf_counter()
+        gave_up = gpu_ctx.sparse_align_fetch(1)[0]
+        assert gave_up.status == 3 and time.perf_counter() - t0 < 30.0
+        got = gpu_ctx.sparse_align(opt, gpb)[0]          # the batch entry repeats the launch without the cluster
+        assert got.status == 0 and list(got.iters) == list(want.iters)
+        assert np.array_equal(fe.se3_to_numpy(got.T_icur_iref), fe.se3_to_numpy(want.T_icur_iref))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
