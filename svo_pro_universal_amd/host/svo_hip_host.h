@@ -316,8 +316,8 @@ struct Point {
 using PointPtr = std::shared_ptr<Point>;
 
 struct OccupandyGrid2D {
-  OccupandyGrid2D(int cell_size, int n_cols, int n_rows)
-      : cell_size(cell_size), n_cols(n_cols), n_rows(n_rows), occupancy_(static_cast<size_t>(n_cols) * n_rows, false) {}
+  OccupandyGrid2D(int cell, int cols, int rows)
+      : cell_size(cell), n_cols(cols), n_rows(rows), occupancy_(static_cast<size_t>(cols) * rows, false) {}
   static int getNCell(int n_pixels, int size);
   const int cell_size, n_cols, n_rows;
   std::vector<bool> occupancy_;
