@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <stdexcept>
 
 namespace svo_hip {
@@ -674,9 +675,14 @@ bool Frame::isVisible(const svoh::Vec3& xyz_w, double* px) const
   const svoh::Vec3 xyz_f = svoh::transform(T_f_w_, xyz_w);
   const svoh::CamModel cm = svoh::load_camera(cam);
   {   // pinhole: not farther off the optical axis than the image's top-left corner (frame.cpp:233-246)
-    svoh::Vec3 f_tl = svoh::back_project3(cm, 0.0, 0.0);
-    const double n = sqrt(f_tl.x * f_tl.x + f_tl.y * f_tl.y + f_tl.z * f_tl.z);
-    const double min_cos = f_tl.z / n;
+    if (!min_cos_valid_ || memcmp(&min_cos_cam_, &cam, sizeof cam) != 0) {
+      const svoh::Vec3 f_tl = svoh::back_project3(cm, 0.0, 0.0);
+      const double n = sqrt(f_tl.x * f_tl.x + f_tl.y * f_tl.y + f_tl.z * f_tl.z);
+      min_cos_ = f_tl.z / n;
+      min_cos_cam_ = cam;
+      min_cos_valid_ = true;
+    }
+    const double min_cos = min_cos_;
     const double nf = sqrt(xyz_f.x * xyz_f.x + xyz_f.y * xyz_f.y + xyz_f.z * xyz_f.z);
     const double cur_cos = xyz_f.z / nf;
     if (cur_cos < min_cos) return false;

@@ -69,6 +69,11 @@ struct Frame {
   double getSeedDepth(size_t idx) const { return 1.0 / invmu_sigma2_a_b_vec_[4 * idx]; }   // seed.h:110-113 (inverse depth)
   size_t numTrackedFeatures() const;                                      // frame.h:153-163
   bool isVisible(const svoh::Vec3& xyz_w, double* px /* 2, may be NULL */) const;   // frame.cpp:229-260
+  // isVisible's cosine of the image corner's off-axis angle: a function of the intrinsics alone, which the
+  // reference recomputes (an undistortion included) on every call; kept here until `cam` changes
+  mutable svoh_camera min_cos_cam_{};
+  mutable double min_cos_ = 0.0;
+  mutable bool min_cos_valid_ = false;
 
   void set_T_cam_imu(const Transformation& T) { T_cam_imu_ = T; T_imu_cam_ = svoh::inverse(T); }  // frame.h:270-274
   const Transformation& T_cam_imu() const { return T_cam_imu_; }

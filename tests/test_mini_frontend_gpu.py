@@ -70,6 +70,8 @@ def test_mini_frontend_tracks_a_synthetic_sequence(tmp_path):
     stage = fc[1:, 7:13].mean(0)
     print("mean ms per frame: pyramid %.3f align %.3f reproject %.3f pose %.3f seeds %.3f keyframe %.3f  total %.3f"
           % (tuple(stage) + (stage.sum(),)))
+    slow = np.argsort(-fc[1:, 8])[:3] + 1
+    print("slowest alignment frames:", [(int(k), int(fc[k, 1]), round(float(fc[k, 8]), 3)) for k in slow], "(frame, is_kf, ms)")
     assert res["n"] == n_frames
     assert res["rmse"] < 0.03 * path_len + 0.003          # a few per cent of the distance travelled
     assert 0.8 < res["scale"] < 1.25                      # the depth prior fixes the scale
