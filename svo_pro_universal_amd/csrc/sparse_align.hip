@@ -1386,20 +1386,18 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   }
   const size_t feat_slots = n_feat_total ? n_feat_total : 1;
 
-  // descriptors, then (256-byte aligned) the zeroed work-queue head and the cluster arrival counters: one upload
+  // descriptors, then (256-byte aligned) the zeroed work-queue head and the cluster arrival counters, then the
+  // feature arrays of host-resident cameras: one staging block, one upload
   const size_t desc_only = sizeof(DevProblemDesc) * n_desc + sizeof(DevCamDesc) * n_cams_total;
   const size_t ctl_off = (desc_only + 255) & ~(size_t)255;
-  const size_t desc_bytes = ctl_off + 512;
+  const size_t up_base = ctl_off + 512;
+  const size_t desc_bytes = up_base + host_bytes;
   SVOH_HIP_TRY(ctx, ctx->h_desc.reserve(desc_bytes));
   SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
   memset(static_cast<uint8_t*>(ctx->h_desc.ptr) + ctl_off, 0, 512);
   SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
   SVOH_HIP_TRY(ctx, ctx->h_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
   SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (kWsPairs * 16 + 2) + 256));
-  if (host_bytes) {
-    SVOH_HIP_TRY(ctx, ctx->h_upload.reserve(host_bytes));
-    SVOH_HIP_TRY(ctx, ctx->d_upload.reserve(host_bytes));
-  }
   SVOH_HIP_TRY(ctx, ctx->d_eval.reserve(74 * sizeof(double) * S));
 
   // the pinned staging buffers are reused by every call: a call queued right behind another (enqueue without
@@ -1410,8 +1408,8 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   }
   DevProblemDesc* hp = static_cast<DevProblemDesc*>(ctx->h_desc.ptr);
   DevCamDesc* hc = reinterpret_cast<DevCamDesc*>(hp + n_desc);
-  uint8_t* hup = static_cast<uint8_t*>(ctx->h_upload.ptr);
-  uint8_t* dup = static_cast<uint8_t*>(ctx->d_upload.ptr);
+  uint8_t* hup = static_cast<uint8_t*>(ctx->h_desc.ptr) + up_base;
+  uint8_t* dup = static_cast<uint8_t*>(ctx->d_desc.ptr) + up_base;
   size_t up_off = 0;
   int cam_idx = 0, feat_off = 0;
   const int need_levels = opt->max_level + 1;
@@ -1468,9 +1466,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
       }
     }
   }
-  if (up_off)
-    SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_upload.ptr, ctx->h_upload.ptr, up_off, hipMemcpyHostToDevice, ctx->stream));
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc.ptr, ctx->h_desc.ptr, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc.ptr, ctx->h_desc.ptr, up_base + up_off, hipMemcpyHostToDevice, ctx->stream));
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_staged, ctx->stream));
   ctx->align_staging_in_flight = true;
 

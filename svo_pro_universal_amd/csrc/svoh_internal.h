@@ -84,12 +84,10 @@ struct svoh_ctx {
   svoh::DevBuffer d_desc;      // problem + camera descriptors
   svoh::DevBuffer d_results;   // svoh_align_result[n]
   svoh::DevBuffer d_feat;      // per-feature workspace
-  svoh::DevBuffer d_upload;    // staged host feature arrays
   svoh::DevBuffer d_eval;      // evaluate() outputs
   svoh::DevBuffer d_xchg;      // cluster mode of the alignment: exchange slots + arrival counter
   svoh::DevBuffer d_split;     // svoh_sparse_align_split_buffers: a Gauss-Newton state + 74 sums
   svoh::PinnedBuffer h_desc;
-  svoh::PinnedBuffer h_upload;
   svoh::PinnedBuffer h_results;
   int last_align_n = 0;
   // a ring of event pairs, one per alignment launch: callers that queue launches back to back (enqueue without
