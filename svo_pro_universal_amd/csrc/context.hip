@@ -63,8 +63,7 @@ __global__ __launch_bounds__(256) void reduce_unit_counts_kernel(const unsigned 
 
 int reserve_unit_counts(svoh_ctx* ctx, size_t n_units, unsigned int** out)
 {
-  SVOH_HIP_TRY(ctx, ctx->d_unit_counts.reserve(n_units * 4 * sizeof(unsigned int)));
-  SVOH_HIP_TRY(ctx, hipMemsetAsync(ctx->d_unit_counts.ptr, 0, n_units * 4 * sizeof(unsigned int), ctx->stream));
+  SVOH_HIP_TRY(ctx, ctx->d_unit_counts.reserve(n_units * 4 * sizeof(unsigned int)));   // every unit writes its own entry
   *out = static_cast<unsigned int*>(ctx->d_unit_counts.ptr);
   return SVOH_OK;
 }

@@ -1212,6 +1212,7 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
   if (i >= a.n) return;
   a.success[i] = 0;
   if (a.result) a.result[i] = SVOH_MATCH_NOT_RUN;
+  if (!G8 || (threadIdx.x & 7) == 0) reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(0u, 0u, 0u, 0u);   // units that are not run
   if (!feature_indices_ok(a, i)) return;
   const int type = a.type[i];
   if (!(type < 6)) return;  // isSeed
