@@ -156,37 +156,47 @@ __device__ void pose_residual(const svoh_pose_options& opt, const CamModel& cm, 
       }
     }
   }
+  // rows is 1, 2 or 3: the loops below are unrolled to three with a row test, so that J and e stay in registers
   double en2 = 0.0;
-  for (int r = 0; r < rows; ++r) en2 += e[r] * e[r];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) if (r < rows) en2 += e[r] * e[r];
   unwhitened_error = rows == 1 ? fabs(e[0]) : sqrt(en2);
   if (!want_J) return;
-  for (int r = 0; r < rows; ++r) e[r] *= Rw;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) if (r < rows) e[r] *= Rw;
   const double en = rows == 1 ? e[0] : sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
   const double weight = (double)tukey_weight_f((float)en);
-  for (int c = 0; c < rows * 6; ++c) J[c] *= Rw;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    if (r < rows) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) J[r * 6 + c] *= Rw;
+    }
   int idx = 0;
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
 #pragma unroll
     for (int b = a; b < 6; ++b) {
       double s = 0.0;
-      for (int r = 0; r < rows; ++r) s += J[r * 6 + a] * J[r * 6 + b];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) if (r < rows) s += J[r * 6 + a] * J[r * 6 + b];
       acc[idx++] += s * weight;
     }
   }
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
     double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += J[r * 6 + a] * e[r];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) if (r < rows) s += J[r * 6 + a] * e[r];
     acc[21 + a] -= s * weight;
   }
 }
 
 // value of rank k (0-based, ties by index) among vals[0..n): what nth_element leaves at position k
-template <typename T>
+template <int NT, typename T>
 __device__ T rank_select(const T* vals, int n, int k, int tid, T* s_out)
 {
-  for (int i = tid; i < n; i += kPoseThreads) {
+  for (int i = tid; i < n; i += NT) {
     const T v = vals[i];
     int rank = 0;
     for (int j = 0; j < n; ++j) {
@@ -199,9 +209,14 @@ __device__ T rank_select(const T* vals, int n, int k, int tid, T* s_out)
   return *s_out;
 }
 
-__global__ __launch_bounds__(kPoseThreads) void pose_optimize_kernel(const PoseArgs a)
+// NT = 256: one bundle spread over four waves (lowest latency of a single bundle).  NT = 64: one wave per bundle,
+// about three features per lane; four bundles share a compute unit (the kernel needs >256 registers, so a SIMD
+// holds one wave), and the one-lane solve of one bundle overlaps the residuals of the other three: the geometry for
+// batches that outnumber the compute units.
+template <int NT>
+__global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
 {
-  constexpr int NACC = 27, NW = kPoseThreads / 64;
+  constexpr int NACC = 27, NW = NT / 64;
   __shared__ double s_err[kPoseMaxMeas];       // start errors as float values, later final errors (double)
   __shared__ double s_red[NW][NACC];
   __shared__ double s_sum[NACC];
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_optimize_kernel(const PoseA
       const Rigid T_cam_imu = load_rigid(dc.T_cam_imu);
       double Rci[9];
       to_matrix(T_cam_imu.q, Rci);
-      for (int i = tid; i < dc.n_features; i += kPoseThreads) {
+      for (int i = tid; i < dc.n_features; i += NT) {
         const long long gi = pb.arr_off + dc.feat_off + i;
         if (!a.usable[gi]) continue;
         fn(cm, T_cam_imu, Rci, gi);
@@ -261,13 +276,13 @@ __global__ __launch_bounds__(kPoseThreads) void pose_optimize_kernel(const PoseA
       res.status = 1;
     }
     for (int c = 0; c < pb.n_cams; ++c)
-      for (int i = tid; i < cams[c].n_features; i += kPoseThreads) {
+      for (int i = tid; i < cams[c].n_features; i += NT) {
         a.outlier[pb.arr_off + cams[c].feat_off + i] = 0;
         a.final_error[pb.arr_off + cams[c].feat_off + i] = 0.0;
       }
     return;
   }
-  const float med = rank_select<float>(s_errf, n_meas, n_meas / 2, tid, &s_medf);
+  const float med = rank_select<NT, float>(s_errf, n_meas, n_meas / 2, tid, &s_medf);
   if (tid == 0) s_sigma = (double)(1.48f * med);
   __syncthreads();
   const double measurement_sigma = s_sigma;
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_optimize_kernel(const PoseA
   {
     const Rigid T = s_T;
     for (int c = 0; c < pb.n_cams; ++c)
-      for (int i = tid; i < cams[c].n_features; i += kPoseThreads) {
+      for (int i = tid; i < cams[c].n_features; i += NT) {
         const long long gi = pb.arr_off + cams[c].feat_off + i;
         if (!a.usable[gi]) { a.outlier[gi] = 0; a.final_error[gi] = 0.0; }
       }
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_optimize_kernel(const PoseA
   }
   __syncthreads();
   const int n_final = s_n < kPoseMaxMeas ? s_n : kPoseMaxMeas;
-  const double med_after = rank_select<double>(s_err, n_final, n_final / 2, tid, &s_median);
+  const double med_after = rank_select<NT, double>(s_err, n_final, n_final / 2, tid, &s_median);
   if (tid == 0) {
     store_rigid(s_T, res.T_imu_world);
     res.measurement_sigma = measurement_sigma;
@@ -561,7 +576,11 @@ extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* 
   a.results = reinterpret_cast<svoh_pose_result*>(d + o_res);
   a.n_problems = n_problems;
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
-  hipLaunchKernelGGL(pose_optimize_kernel, dim3((unsigned)n_problems), dim3(kPoseThreads), 0, ctx->stream, a);
+  // geometry: see pose_optimize_kernel.  SVOH_POSE_THREADS=64/256 forces one (tests run both).
+  int nt = n_problems > ctx->num_cus ? 64 : kPoseThreads;
+  if (const char* e = getenv("SVOH_POSE_THREADS")) { const int v = atoi(e); if (v == 64 || v == kPoseThreads) nt = v; }
+  if (nt == 64) hipLaunchKernelGGL(pose_optimize_kernel<64>, dim3((unsigned)n_problems), dim3(64), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(pose_optimize_kernel<kPoseThreads>, dim3((unsigned)n_problems), dim3(kPoseThreads), 0, ctx->stream, a);
   SVOH_HIP_TRY(ctx, hipGetLastError());
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
   ctx->misc_timed = true;

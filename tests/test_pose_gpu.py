@@ -11,6 +11,20 @@ import pose_helpers as ph
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["four_waves_per_bundle", "one_wave_per_bundle"], autouse=True)
+def pose_geometry(request):
+    """The pose kernel has two geometries (pose.hip, pose_optimize_kernel<256> for batches up to one bundle per compute
+    unit, <64> beyond): every test of this file runs through both, against the same bars."""
+    import os
+    old = os.environ.get("SVOH_POSE_THREADS")
+    os.environ["SVOH_POSE_THREADS"] = "256" if request.param == "four_waves_per_bundle" else "64"
+    yield request.param
+    if old is None:
+        os.environ.pop("SVOH_POSE_THREADS", None)
+    else:
+        os.environ["SVOH_POSE_THREADS"] = old
+
+
 def check(rg, ro, keep_g, keep_o, cams):
     assert rg.status == ro.status and rg.iters == ro.iters and rg.n_meas == ro.n_meas
     assert rg.measurement_sigma == ro.measurement_sigma and rg.reproj_error_before == ro.reproj_error_before
