@@ -13,7 +13,9 @@
 // Medians (MAD scale, statistics) are rank selections in LDS -- order-independent, so identical to
 // nth_element; sums differ from the sequential reference in rounding only.
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "svoh_internal.h"
@@ -24,6 +26,7 @@ namespace svoh {
 
 constexpr int kPoseThreads = 256;
 constexpr int kPoseMaxMeas = 4096;   // measurements per bundle (LDS-resident error list)
+constexpr size_t kPoseParallelStagingFeatures = 65536;   // host staging of a batch this large is split over threads
 
 struct DevPoseCam {
   svoh_camera cam;
@@ -545,24 +548,43 @@ extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* 
   DevPoseProblem* hp = reinterpret_cast<DevPoseProblem*>(h + o_pb);
   DevPoseCam* hc = reinterpret_cast<DevPoseCam*>(h + o_cam);
   size_t cam_i = 0, off = 0;
-  for (int p = 0; p < n_problems; ++p) {
+  for (int p = 0; p < n_problems; ++p) {   // descriptors and offsets (serial: each depends on the one before)
     const svoh_pose_problem& pb = problems[p];
     hp[p].n_cams = pb.n_cams; hp[p].cam_begin = (int)cam_i; hp[p].arr_off = (long long)off; hp[p].T_imu_world = pb.T_imu_world;
     int local = 0;
     for (int c = 0; c < pb.n_cams; ++c) {
       const svoh_pose_camera& cam = pb.cams[c];
       hc[cam_i].cam = cam.cam; hc[cam_i].T_cam_imu = cam.T_cam_imu; hc[cam_i].n_features = cam.n_features; hc[cam_i].feat_off = local;
-      const size_t n = (size_t)cam.n_features, g = off + (size_t)local;
-      if (n) {
-        memcpy(h + o_px + 16 * g, cam.px, 16 * n); memcpy(h + o_f + 24 * g, cam.f, 24 * n);
-        memcpy(h + o_grad + 16 * g, cam.grad, 16 * n); memcpy(h + o_xyz + 24 * g, cam.xyz_world, 24 * n);
-        memcpy(h + o_level + 4 * g, cam.level, 4 * n); memcpy(h + o_type + g, cam.type, n); memcpy(h + o_usable + g, cam.usable, n);
-      }
       local += cam.n_features;
       ++cam_i;
     }
     hp[p].n_total = local;
     off += (size_t)local;
+  }
+  // the feature arrays (86 bytes per feature) into the pinned block; a large batch is copied by a few threads
+  auto stage_range = [&](int p0, int p1) {
+    for (int p = p0; p < p1; ++p) {
+      const svoh_pose_problem& pb = problems[p];
+      for (int c = 0; c < pb.n_cams; ++c) {
+        const svoh_pose_camera& cam = pb.cams[c];
+        const size_t n = (size_t)cam.n_features, g = (size_t)hp[p].arr_off + (size_t)hc[hp[p].cam_begin + c].feat_off;
+        if (!n) continue;
+        memcpy(h + o_px + 16 * g, cam.px, 16 * n); memcpy(h + o_f + 24 * g, cam.f, 24 * n);
+        memcpy(h + o_grad + 16 * g, cam.grad, 16 * n); memcpy(h + o_xyz + 24 * g, cam.xyz_world, 24 * n);
+        memcpy(h + o_level + 4 * g, cam.level, 4 * n); memcpy(h + o_type + g, cam.type, n); memcpy(h + o_usable + g, cam.usable, n);
+      }
+    }
+  };
+  const int n_stage_threads = n_feat_total >= kPoseParallelStagingFeatures
+      ? (int)std::min<size_t>({ (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)n_problems }) : 1;
+  if (n_stage_threads <= 1) {
+    stage_range(0, n_problems);
+  } else {
+    std::vector<std::thread> workers;
+    for (int t = 1; t < n_stage_threads; ++t)
+      workers.emplace_back(stage_range, (int)((long long)n_problems * t / n_stage_threads), (int)((long long)n_problems * (t + 1) / n_stage_threads));
+    stage_range(0, n_problems / n_stage_threads);
+    for (auto& w : workers) w.join();
   }
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
   PoseArgs a;

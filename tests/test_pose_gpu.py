@@ -98,3 +98,30 @@ def test_pose_batch_equals_singles(gpu_ctx):
         assert all(np.array_equal(a, k["outlier"]) for a, k in zip(flags[i], keep))
     with pytest.raises(fe.SvohError):
         gpu_ctx.optimize_pose(capi.default_pose_options(scenes[0]["cam"], error_type=7), [built[0][0]])
+
+
+def test_pose_large_batch_staged_by_threads(gpu_ctx):
+    """A batch above 65 536 features is staged into the pinned block by several host threads (pose.hip,
+    kPoseParallelStagingFeatures): every bundle, including its per-feature outputs, must come out as when it is
+    submitted alone.  Ragged sizes and one- / two-camera bundles, so that a wrong offset cannot cancel."""
+    scenes = [ph.make_pose_scene(700 + i, n=120 + 41 * i, n_cams=1 + (i % 2)) for i in range(6)]
+    opt = capi.default_pose_options(scenes[0]["cam"])
+    singles = []
+    for sc in scenes:
+        pb, keep = fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"])
+        r = gpu_ctx.optimize_pose(opt, [pb])[0]
+        singles.append((fe.se3_to_numpy(r.T_imu_world).copy(), r.iters, r.n_meas,
+                        [k["outlier"].copy() for k in keep], [k["final_error"].copy() for k in keep]))
+    n_feat = [sum(len(c["level"]) for c in sc["cams"]) for sc in scenes]
+    B = 66000 // min(n_feat) + 6
+    built = [fe.make_pose_problem(scenes[i % 6]["cams"], scenes[i % 6]["T_imu_world_init"]) for i in range(B)]
+    assert sum(n_feat[i % 6] for i in range(B)) >= 65536
+    batch = gpu_ctx.optimize_pose(opt, [b[0] for b in built])
+    for i in range(B):
+        T, iters, n_meas, out, ferr = singles[i % 6]
+        assert batch[i].iters == iters and batch[i].n_meas == n_meas
+        # a batch this large runs one wave per bundle unless the fixture forces four: summation order may differ
+        assert np.abs(fe.se3_to_numpy(batch[i].T_imu_world) - T).max() < 1e-9
+        for k, o, e in zip(built[i][1], out, ferr):
+            assert np.array_equal(k["outlier"], o)
+            assert np.allclose(k["final_error"], e, rtol=1e-9, atol=1e-15)
