@@ -43,8 +43,8 @@ def algorithmic_bytes(P, D, patch_iters, n_sel_levels):
 
 def pmc_traffic(workload_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this very
-    workload (profiles/rNN_summary.json, written by scripts/profile_bench.sh: separate --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE runs).  Counters are reported in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B
+    workload (profiles/rNN_summary.json, written by scripts/profile_bench.sh, and rNN_<workload>_pmc_summary.json
+    by scripts/profile_workloads_pmc.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs).  Counters are reported in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B
     (MI355X_MICROARCH.md, HBM section) and is doubled, WRITE_SIZE is taken as is.  None when no summary for the
     same workload is committed -- the counters cannot be read from inside the timed process."""
     import glob
@@ -273,7 +273,7 @@ def bench_klt(args, ctx, dist, rank, world, dev, comm_dev=None):
             "kernel_ms": kms, "converged_fraction": float(ok.mean()),
             "host_staged_tracks_per_s": host_rate,  # same work through svoh_klt_track_multi with host arrays (PCIe-inclusive)
             "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "klt_track_kernel",
+                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (None if args.problems else pmc_traffic("klt:default")), "kernel": "klt_track_kernel",
                          "algorithmic_bytes_per_launch": alg, "counters": cnt[:4]},
             "cpu_baseline": cpu}
 
@@ -369,7 +369,7 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
             "kernel_ms": kms, "success_fraction": float(succ.mean()),
             "host_staged_seed_updates_per_s": host_rate,  # same work with host arrays staged per call (PCIe-inclusive)
             "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "update_seeds_kernel",
+                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (None if args.problems else pmc_traffic("seeds:default")), "kernel": "update_seeds_kernel",
                          "algorithmic_bytes_per_launch": alg, "counters": cnt[:4],
                          "unit_tails": {"align_iters_ge5": cnt[4], "align_iters_ge10": cnt[5], "zmssd_ge20": cnt[6],
                                         "zmssd_ge50": cnt[7]}},
@@ -584,7 +584,7 @@ def bench_pose(args, ctx, dist, rank, world, dev, comm_dev=None):
             "kernel_ms": kms, "mean_iterations": iters / float(B), "measurements_per_bundle": meas / float(B),
             "single_bundle_call_ms": single_ms,
             "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "pose_optimize_kernel",
+                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (None if args.problems else pmc_traffic("pose:default")), "kernel": "pose_optimize_kernel",
                          "algorithmic_bytes_per_launch": alg},
             "cpu_baseline": cpu}
 
