@@ -807,30 +807,107 @@ def emit(obj):
     os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(obj) + "\n").encode())
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--problems", type=int, default=0, help="frame pairs per GPU per step (default: per workload)")
-    ap.add_argument("--workload", default="align", choices=["align", "klt", "seeds", "frame", "detect", "pose", "align-split", "align-c4"],
-                    help="align = the headline SparseImgAlign config (default); klt / seeds = the other hot-path rows; "
-                         "frame = the whole per-frame chain at EuRoC mono sizes, one frame at a time (latency)")
+    ap.add_argument("--workload", default="align",
+                    choices=["align", "klt", "seeds", "frame", "detect", "pose", "align-split", "align-c4", "stereo",
+                             "launch-check"],
+                    help="align = the headline SparseImgAlign config (default); klt / seeds / stereo = the other "
+                         "hot-path rows; frame = the whole per-frame chain at EuRoC mono sizes, one frame at a time "
+                         "(latency); launch-check = the N-rank launch, barrier and MAX/SUM plumbing with an empty step")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--patch", type=int, default=4)
     ap.add_argument("--min-level", type=int, default=0)
     ap.add_argument("--max-level", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the 8x8-patch leg that the default line carries as `secondary`")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_workers(n, argv):
+    """`bench.py --gpus N` started directly (no WORLD_SIZE in the environment): start N fresh worker processes
+    through torch.distributed.run, one per GPU, and hand their exit code back.  This process has made no GPU call
+    and makes none; it is never replaced by exec (that is fatal on the GPU boxes once a process has touched the GPU,
+    and a child is just as good).  Rank 0's JSON line goes straight to the inherited stdout."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def bench_launch_check(args, dist, rank, world, comm_dev):
+    """The N-rank plumbing alone: W+K empty steps between the same barriers, MAX of the elapsed time and SUM of the
+    units over the ranks.  Needs no GPU with SVOH_BENCH_BACKEND=gloo (the CPU test of the launcher)."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        pass
+    barrier()
+    t0 = time.perf_counter()
+    units = 0
+    for _ in range(args.steps):
+        units += 1000 + rank
+    barrier()
+    elapsed, total = du.combine(dist, world, time.perf_counter() - t0, units, comm_dev)
+    ranks_seen = 1
+    if world > 1:
+        t = torch.ones(1, dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())
+    return {"metric": "launch check (empty steps)", "value": total / max(elapsed, 1e-9), "unit": "units/s",
+            "ms_per_step": 1e3 * elapsed / max(1, args.steps), "dtype": "none", "units_total": total,
+            "ranks_in_collective": ranks_seen, "backend": dist.get_backend() if world > 1 else None,
+            "config": {"workload": "launch-check"}}
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    rank, local_rank, world = du.env_world()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torchrun: be the launcher (before anything touches the GPU), relay the workers' exit code
+        raise SystemExit(launch_workers(args.gpus, sys.argv[1:] if argv is None else argv))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a different n_gpus than asked for"
+                         % (args.gpus, world))
     claim_stdout()
 
-    rank, local_rank, world = du.env_world()
     # Rehearsal knobs for a one-GPU box (never set by the driver): all ranks on cuda:0 and gloo for the
     # barrier / MAX / SUM, because RCCL refuses two ranks on one device.
     backend = os.environ.get("SVOH_BENCH_BACKEND", "nccl")
     if os.environ.get("SVOH_BENCH_ONE_DEVICE", "0") == "1":
         local_rank = 0
     dist = None
+    if args.workload == "launch-check" and backend == "gloo":     # CPU rehearsal of the launcher: no GPU call at all
+        if world > 1:
+            dist = du.init(backend, rank, world)
+        out = bench_launch_check(args, dist, rank, world, None)
+        if rank == 0:
+            out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                        "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
+            emit(out)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if world > 1:
         dist = du.init(backend, rank, world, torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -842,7 +919,8 @@ def main():
     ctx = fe.Context(local_rank)
     if args.workload != "align":
         out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame, "detect": bench_detect, "pose": bench_pose,
-               "align-split": bench_align_split, "align-c4": bench_align_c4}[args.workload](
+               "align-split": bench_align_split, "align-c4": bench_align_c4,
+               "launch-check": lambda a, c, d, r, w, dv, cd: bench_launch_check(a, d, r, w, cd)}[args.workload](
             args, ctx, dist, rank, world, dev, comm_dev)
         if rank == 0:
             out.setdefault("scaling", "weak")

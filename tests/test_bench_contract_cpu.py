@@ -41,3 +41,36 @@ def test_bench_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""     # no JSON line, no CPU fallback
+
+
+def _run_bench(argv, env_extra, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                          timeout=timeout, env=env)
+
+
+def test_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two fresh workers itself: rehearsed
+    over gloo with the empty-step workload, which makes no GPU call."""
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "launch-check"],
+                   {"SVOH_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                          # ONE JSON line, from rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_in_collective"] == 2 and d["backend"] == "gloo"
+    assert d["units_total"] == 3 * 1000 + 3 * 1001            # SUM over both ranks' units
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+
+
+def test_gpus_flag_must_agree_with_world_size():
+    """Under a launcher (WORLD_SIZE set) a different --gpus is an error, not a silently different n_gpus."""
+    r = _run_bench(["--gpus", "4", "--workload", "launch-check"],
+                   {"SVOH_BENCH_BACKEND": "gloo", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "refusing" in r.stderr and r.stdout.strip() == ""
+    r = _run_bench(["--gpus", "1", "--steps", "2", "--workload", "launch-check"], {"SVOH_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
