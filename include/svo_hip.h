@@ -230,6 +230,10 @@ int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options,
 int svoh_sparse_align_enqueue(svoh_ctx* ctx, const svoh_align_options* options,
                               int n_problems, const svoh_align_problem* problems);
 int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* results);
+/* The results of EVERY launch queued since the last fetch / fetch_all, in launch
+ * order; n_results must be their total number.  At most 2^18 results may be
+ * queued (enqueue fails beyond that: fetch first). */
+int svoh_sparse_align_fetch_all(svoh_ctx* ctx, int n_results, svoh_align_result* results);
 
 /* Device time (ms, HIP events on the context stream) of the alignment kernel
  * of the last enqueue/batch call; valid after fetch/batch returned. */

@@ -254,7 +254,7 @@ EXPORTS = [
     "svoh_synchronize", "svoh_stream",
     "svoh_upload_pyramid", "svoh_build_pyramid", "svoh_build_pyramid_batch",
     "svoh_download_level", "svoh_frame_info", "svoh_release_frame",
-    "svoh_sparse_align_batch", "svoh_sparse_align_enqueue", "svoh_sparse_align_fetch",
+    "svoh_sparse_align_batch", "svoh_sparse_align_enqueue", "svoh_sparse_align_fetch", "svoh_sparse_align_fetch_all",
     "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms", "svoh_sparse_align_kernel_ms_history",
     "svoh_sparse_align_split_buffers", "svoh_sparse_align_split_init", "svoh_sparse_align_partial_sums", "svoh_sparse_align_gn_update",
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
@@ -324,6 +324,7 @@ def load():
     lib.svoh_sparse_align_enqueue.argtypes = [C.c_void_p, P(svoh_align_options), C.c_int,
                                               P(svoh_align_problem)]
     lib.svoh_sparse_align_fetch.argtypes = [C.c_void_p, C.c_int, P(svoh_align_result)]
+    lib.svoh_sparse_align_fetch_all.argtypes = [C.c_void_p, C.c_int, P(svoh_align_result)]
     lib.svoh_sparse_align_evaluate.argtypes = [C.c_void_p, P(svoh_align_options), P(svoh_align_problem),
                                                C.c_int, C.c_void_p, C.c_void_p, P(C.c_double),
                                                P(C.c_int32), C.c_void_p, P(C.c_int32)]

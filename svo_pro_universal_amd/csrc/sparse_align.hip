@@ -1392,20 +1392,40 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   const size_t ctl_off = (desc_only + 255) & ~(size_t)255;
   const size_t up_base = ctl_off + 512;
   const size_t desc_bytes = up_base + host_bytes;
-  SVOH_HIP_TRY(ctx, ctx->h_desc.reserve(desc_bytes));
-  SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
-  memset(static_cast<uint8_t*>(ctx->h_desc.ptr) + ctl_off, 0, 512);
-  SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
-  SVOH_HIP_TRY(ctx, ctx->h_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
-  SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (kWsPairs * 16 + 2) + 256));
-  SVOH_HIP_TRY(ctx, ctx->d_eval.reserve(74 * sizeof(double) * S));
-
-  // the pinned staging buffers are reused by every call: a call queued right behind another (enqueue without
-  // fetch, the patch-split entries) must not overwrite them before the earlier copies have read them
+  // The pinned staging buffer is reused by every call.  A call queued right behind another (enqueue without fetch,
+  // the patch-split entries) must not write a byte of it -- not even the zeroed control block, whose offset moves
+  // with the descriptor count and would land inside the earlier call's descriptors -- nor let reserve() replace
+  // it, before the earlier call's upload has read it.
   if (ctx->align_staging_in_flight) {
     SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_staged));
     ctx->align_staging_in_flight = false;
   }
+  SVOH_HIP_TRY(ctx, ctx->h_desc.reserve(desc_bytes));
+  SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
+  memset(static_cast<uint8_t*>(ctx->h_desc.ptr) + ctl_off, 0, 512);
+  SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
+  // results of launches queued since the last fetch are kept one after the other in pinned host memory
+  const bool delivers = (S == 1 || cluster) && eval_level < 0;
+  if (delivers) {
+    SVOH_REQUIRE(ctx, ctx->align_pending_results + (size_t)n_problems <= svoh_ctx::kMaxQueuedResults,
+                 "too many alignment results queued without a fetch");
+    const size_t need = sizeof(svoh_align_result) * (ctx->align_pending_results + (size_t)n_problems);
+    if (need > ctx->h_results.cap) {
+      if (ctx->align_pending_results) {   // earlier launches still deliver into the old block: let them finish, keep theirs
+        SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        PinnedBuffer bigger;
+        SVOH_HIP_TRY(ctx, bigger.reserve(need * 2));
+        memcpy(bigger.ptr, ctx->h_results.ptr, sizeof(svoh_align_result) * ctx->align_pending_results);
+        std::swap(bigger.ptr, ctx->h_results.ptr);
+        std::swap(bigger.cap, ctx->h_results.cap);
+      } else {
+        SVOH_HIP_TRY(ctx, ctx->h_results.reserve(need));
+      }
+    }
+  }
+  SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (kWsPairs * 16 + 2) + 256));
+  SVOH_HIP_TRY(ctx, ctx->d_eval.reserve(74 * sizeof(double) * S));
+
   DevProblemDesc* hp = static_cast<DevProblemDesc*>(ctx->h_desc.ptr);
   DevCamDesc* hc = reinterpret_cast<DevCamDesc*>(hp + n_desc);
   uint8_t* hup = static_cast<uint8_t*>(ctx->h_desc.ptr) + up_base;
@@ -1568,9 +1588,13 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   ++ctx->align_launches;
   // the results follow the kernel to pinned host memory right away, so that a caller which queues several
   // launches and fetches once still has every launch's output delivered
-  if ((S == 1 || cluster) && eval_level < 0)   // cluster: entry 0 is share 0's copy of the common result
-    SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results.ptr, ctx->d_results.ptr, sizeof(svoh_align_result) * n_problems,
+  if (delivers) {   // cluster: entry 0 is share 0's copy of the common result
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(static_cast<svoh_align_result*>(ctx->h_results.ptr) + ctx->align_pending_results,
+                                     ctx->d_results.ptr, sizeof(svoh_align_result) * n_problems,
                                      hipMemcpyDeviceToHost, ctx->stream));
+    ctx->align_last_results_off = ctx->align_pending_results;
+    ctx->align_pending_results += (size_t)n_problems;
+  }
 #ifdef SVOH_PHASE_STAMPS
   {
     std::vector<long long> h((size_t)n_problems * 8);
@@ -1606,7 +1630,21 @@ int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* re
   SVOH_REQUIRE(ctx, results && n_problems >= 1 && n_problems <= ctx->last_align_n, "nothing to fetch");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the copy to h_results was queued behind the kernel
-  memcpy(results, ctx->h_results.ptr, sizeof(svoh_align_result) * n_problems);
+  memcpy(results, static_cast<const svoh_align_result*>(ctx->h_results.ptr) + ctx->align_last_results_off,
+         sizeof(svoh_align_result) * n_problems);
+  ctx->align_pending_results = 0;
+  return SVOH_OK;
+}
+
+int svoh_sparse_align_fetch_all(svoh_ctx* ctx, int n_results, svoh_align_result* results)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, results && n_results >= 1 && (size_t)n_results == ctx->align_pending_results,
+               "n_results is not the number of results queued since the last fetch");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(results, ctx->h_results.ptr, sizeof(svoh_align_result) * (size_t)n_results);
+  ctx->align_pending_results = 0;
   return SVOH_OK;
 }
 

@@ -90,6 +90,9 @@ struct svoh_ctx {
   svoh::PinnedBuffer h_desc;
   svoh::PinnedBuffer h_results;
   int last_align_n = 0;
+  // results of the launches queued since the last fetch, launch after launch in h_results
+  static constexpr size_t kMaxQueuedResults = (size_t)1 << 18;
+  size_t align_pending_results = 0, align_last_results_off = 0;
   // a ring of event pairs, one per alignment launch: callers that queue launches back to back (enqueue without
   // fetch) can still read every launch's device time afterwards
   static constexpr int kAlignEventRing = 32;

@@ -144,6 +144,12 @@ class Context(object):
         self._check(self.lib.svoh_sparse_align_fetch(self.h, n, res))
         return res
 
+    def sparse_align_fetch_all(self, n_total):
+        """Results of every launch queued since the last fetch, in launch order."""
+        res = (capi.svoh_align_result * n_total)()
+        self._check(self.lib.svoh_sparse_align_fetch_all(self.h, n_total, res))
+        return res
+
     def sparse_align_evaluate(self, opt, problem, level):
         H = np.zeros(64)
         g = np.zeros(8)

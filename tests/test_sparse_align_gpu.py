@@ -422,6 +422,33 @@ def test_queued_launches_and_kernel_time_history(gpu_ctx):
     assert last.value == ms[n.value - 1]
 
 
+def test_queued_launches_of_different_sizes_each_deliver(gpu_ctx):
+    """A large launch queued right behind... a smaller one: the second call's staging (descriptor block,
+    zeroed control words, host feature arrays -- all in one reused pinned buffer whose layout moves with the problem
+    count) must not touch what the first launch's upload has not read yet.  fetch_all hands out every queued
+    launch's results; each must equal the blocking call's, bit for bit."""
+    sizes = [700, 40, 333, 512, 90, 260, 1500, 64]
+    scs = [helpers.small_scene(140 + k, n=n) for k, n in enumerate(sizes)]
+    items = [[(sc, gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5))] for sc in scs]
+    big, keep1 = fe.make_align_problems(items)            # host-resident feature arrays: staged per call
+    small, keep2 = fe.make_align_problems(items[1:2])
+    mid, keep3 = fe.make_align_problems(items[3:6])
+    opt = capi.default_align_options(min_level=1)
+    want = [fe.se3_to_numpy(r.T_icur_iref) for r in gpu_ctx.sparse_align(opt, big)]
+    for rounds in range(3):
+        gpu_ctx.sparse_align_enqueue(opt, big)
+        gpu_ctx.sparse_align_enqueue(opt, small)
+        gpu_ctx.sparse_align_enqueue(opt, mid)
+        gpu_ctx.sparse_align_enqueue(opt, big)
+        got = gpu_ctx.sparse_align_fetch_all(8 + 1 + 3 + 8)
+        order = list(range(8)) + [1] + [3, 4, 5] + list(range(8))
+        for r, k in zip(got, order):
+            assert r.status == 0 and r.n_fts_to_track > 0
+            assert np.array_equal(fe.se3_to_numpy(r.T_icur_iref), want[k]), k
+    with pytest.raises(Exception):                        # nothing is queued any more
+        gpu_ctx.sparse_align_fetch_all(1)
+
+
 def test_cluster_that_never_completes_falls_back(gpu_ctx):
     """A workgroup of a cluster that never reaches the device-side barrier (test hook) must not hang the device:
     its partners give up after their bounded wait (status 3 for enqueue / fetch callers) and
