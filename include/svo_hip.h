@@ -491,6 +491,38 @@ int svoh_update_seeds_batch_ex(svoh_ctx* ctx, const svoh_matcher_options* matche
                                double* state, uint8_t* success, int32_t* match_result,
                                int32_t* n_success, const svoh_seed_match_outputs* outputs);
 
+/* ---- stereo seam: plain epipolar matches with their triangulated depth ---- */
+
+/* Per-feature outputs of svoh_epipolar_match_batch: what Matcher::findEpipolarMatchDirect
+ * returns and leaves in the Matcher (matcher.h:70-90).  result and depth are required,
+ * the others may be NULL; arrays live where features->mem_space says. */
+typedef struct svoh_epipolar_match_outputs {
+  int32_t* result;         /* n      svoh_match_result */
+  double* depth;           /* n      `depth` out-parameter (valid when result == SVOH_MATCH_SUCCESS) */
+  double* px_cur;          /* 2 x n  Matcher::px_cur_ */
+  double* f_cur;           /* 3 x n  Matcher::f_cur_ */
+  int32_t* search_level;   /* n      Matcher::search_level_ */
+  double* h_inv;           /* n      Matcher::h_inv_ (align1D) */
+  double* A_cur_ref;       /* 4 x n  Matcher::A_cur_ref_, col-major 2x2 */
+} svoh_epipolar_match_outputs;
+
+/* Replaces n calls of
+ *   Matcher::findEpipolarMatchDirect(ref_frame, cur_frame, T_cur_ref, ref_ftr, d_estimate_inv, d_min_inv, d_max_inv, depth)
+ * (src/svo_direct/src/matcher.cpp:157-241), each on a fresh Matcher with options_.align_1d = isEdgelet(type),
+ * which is how StereoTriangulation::compute (src/svo/src/stereo_triangulation.cpp:92-104) matches the new
+ * features of the left frame into the right frame (max_epi_search_steps = 500 there).
+ * T_cur_ref: n_ref_frames x n_cur_frames transforms (host array), entry [ref_idx * n_cur_frames + cur_idx], as the
+ * stereo caller passes T_f1f0 = T_cam1_body * T_body_cam0; NULL = cur.T_f_w * ref.T_f_w^-1 (the 7-argument
+ * overload, matcher.cpp:143-155).
+ * d_inv_common = {d_estimate_inv, d_min_inv, d_max_inv} for every feature; d_inv (3 x n, may be NULL, lives
+ * where features->mem_space says) overrides it per feature.
+ * The caller replays its own sequential bookkeeping (the stereo loop stops at n_desired successes). */
+int svoh_epipolar_match_batch(svoh_ctx* ctx, const svoh_matcher_options* options,
+                              int n_ref_frames, const svoh_frame_view* ref_frames,
+                              const svoh_frame_view* cur_frame, const svoh_se3* T_cur_ref,
+                              const svoh_feature_batch* features, const double d_inv_common[3],
+                              const double* d_inv, const svoh_epipolar_match_outputs* outputs);
+
 /* ---- keyframe feature detector ----------------------- */
 
 /* DetectorOptions (src/svo_direct/include/svo/direct/feature_detection_types.h:49-84) */

@@ -251,6 +251,11 @@ def _bind_part2(lib):
     lib.orc_align_2d.argtypes = [P(orc_image), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.orc_align_1d.argtypes = [P(orc_image), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p]
+    lib.orc_epipolar_match_batch.argtypes = [P(capi.svoh_matcher_options), C.c_int, P(orc_frame_view), P(orc_frame_view),
+                                             P(capi.svoh_se3), P(capi.svoh_feature_batch), P(C.c_double), C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]
+    lib.orc_epipolar_match_batch.restype = None
     lib._part2 = True
 
 
@@ -307,6 +312,31 @@ def match_direct_batch(mopt, ref_views, cur_view, fb, depth, px_cur, fast=False)
     lib.orc_match_direct_batch(C.byref(mopt), len(ref_views), rv, C.byref(cur_view), C.byref(fb), depth.ctypes.data,
                                out["px_cur"].ctypes.data, out["result"].ctypes.data, out["f_cur"].ctypes.data,
                                out["search_level"].ctypes.data, out["h_inv"].ctypes.data, out["A"].ctypes.data)
+    return out
+
+
+def epipolar_match_batch(mopt, ref_views, cur_views, fb, d_inv_common=None, d_inv=None, T_cur_ref=None, fast=False):
+    """n x Matcher::findEpipolarMatchDirect with align_1d = isEdgelet(type) (stereo_triangulation.cpp:92-104)."""
+    lib = load(fast)
+    _bind_part2(lib)
+    n = fb.n
+    rv = (orc_frame_view * len(ref_views))(*ref_views)
+    if not isinstance(cur_views, (list, tuple)):
+        cur_views = [cur_views]
+    cv = (orc_frame_view * len(cur_views))(*cur_views)
+    out = dict(result=np.zeros(n, np.int32), depth=np.zeros(n), px_cur=np.zeros(2 * n), f_cur=np.zeros(3 * n),
+               search_level=np.zeros(n, np.int32), h_inv=np.zeros(n), A=np.zeros(4 * n))
+    dc = (C.c_double * 3)(*d_inv_common) if d_inv_common is not None else None
+    di = None if d_inv is None else np.ascontiguousarray(d_inv, np.float64)
+    T = None
+    if T_cur_ref is not None:
+        T = (capi.svoh_se3 * len(T_cur_ref))()
+        for k, t in enumerate(T_cur_ref):
+            T[k] = to_se3(t)
+    lib.orc_epipolar_match_batch(C.byref(mopt), len(ref_views), rv, cv, T, C.byref(fb), dc,
+                                 None if di is None else di.ctypes.data, out["result"].ctypes.data, out["depth"].ctypes.data,
+                                 out["px_cur"].ctypes.data, out["f_cur"].ctypes.data, out["search_level"].ctypes.data,
+                                 out["h_inv"].ctypes.data, out["A"].ctypes.data)
     return out
 
 

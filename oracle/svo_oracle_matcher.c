@@ -889,3 +889,83 @@ int orc_match_candidates(const svoh_matcher_options* mopt, const svoh_depth_filt
   }
   return i;
 }
+
+/* ---- stereo seam: n x Matcher::findEpipolarMatchDirect with an explicit T_cur_ref, as
+ * StereoTriangulation::compute calls it (src/svo/src/stereo_triangulation.cpp:92-104: a fresh Matcher,
+ * max_epi_search_steps = 500, subpix_refinement on, align_1d = isEdgelet(type)); the 7-argument overload
+ * (matcher.cpp:143-155) when T_cur_ref is NULL.  d_inv = [estimate, min, max] inverse depths, common to all
+ * features (d_inv_common) or 3 per feature (d_inv, may be NULL). ---- */
+void orc_epipolar_match_batch(const svoh_matcher_options* options, int n_ref_frames, const orc_frame_view* ref_frames,
+                              const orc_frame_view* cur_frame, const svoh_se3* T_cur_ref, const orc_feature_batch* fb,
+                              const double d_inv_common[3], const double* d_inv, int32_t* result, double* depth,
+                              double* px_cur, double* f_cur, int32_t* search_level, double* h_inv, double* A_cur_ref)
+{
+  (void)n_ref_frames;
+  const int n_cur = (fb->cur_frame_idx && fb->n_cur_frames > 0) ? fb->n_cur_frames : 1;
+  for (int i = 0; i < fb->n; ++i) {
+    orc_matcher m;
+    memset(&m, 0, sizeof m);
+    m.opt = *options;
+    m.align_1d = is_edgelet(fb->type[i]);
+    const int ci = fb->cur_frame_idx ? fb->cur_frame_idx[i] : 0;
+    const orc_frame_view* rf = &ref_frames[fb->ref_frame_idx[i]];
+    const orc_frame_view* cf = &cur_frame[ci];
+    svoh_se3 T;
+    if (T_cur_ref) T = T_cur_ref[(size_t)fb->ref_frame_idx[i] * n_cur + ci];
+    else T_cur_ref_from_frames(rf, cf, &T);
+    const double* d = d_inv ? &d_inv[3 * i] : d_inv_common;
+    double z = 0.0;
+    result[i] = orc_find_epipolar_match_direct(&m, rf, cf, &T, &fb->px[2 * i], &fb->f[3 * i], &fb->grad[2 * i], fb->level[i],
+                                               fb->type[i], d[0], d[1], d[2], &z);
+    depth[i] = z;
+    if (px_cur) { px_cur[2 * i] = m.px_cur[0]; px_cur[2 * i + 1] = m.px_cur[1]; }
+    if (f_cur) { f_cur[3 * i] = m.f_cur[0]; f_cur[3 * i + 1] = m.f_cur[1]; f_cur[3 * i + 2] = m.f_cur[2]; }
+    if (search_level) search_level[i] = m.search_level;
+    if (h_inv) h_inv[i] = m.h_inv;
+    if (A_cur_ref) for (int k = 0; k < 4; ++k) A_cur_ref[4 * i + k] = m.A_cur_ref[k];
+  }
+}
+
+/* StereoTriangulation::compute, the loop over the shuffled new features (stereo_triangulation.cpp:86-139):
+ * indices[n_indices] = features of frame0 in visiting order; stops once n_desired have been triangulated.
+ * out[k] for the k-th success: i_ref, xyz in frame0's camera frame (f * depth; the caller applies T_world_cam),
+ * and what frame1 receives (px, f, normalised A_cur_ref * grad).  Returns the number of successes. */
+int orc_stereo_triangulate(const orc_frame_view* frame0, const orc_frame_view* frame1, const svoh_se3* T_f1f0,
+                           const orc_feature_batch* fb, int n_indices, const int32_t* indices, int n_desired,
+                           const double d_inv[3], orc_stereo_match* out, int32_t* result, int* n_failed)
+{
+  int n_succeeded = 0;
+  *n_failed = 0;
+  for (int i = 0; i < fb->n; ++i) result[i] = -1;   /* not visited */
+  for (int k = 0; k < n_indices; ++k) {
+    const int i = indices[k];
+    orc_matcher m;
+    memset(&m, 0, sizeof m);
+    m.opt.align_max_iter = 10; m.opt.max_epi_search_steps = 500; m.opt.subpix_refinement = 1;   /* matcher.h:39-54 + :93-94 */
+    m.opt.epi_search_edgelet_filtering = 1; m.opt.scan_on_unit_sphere = 1; m.opt.affine_est_offset = 1;
+    m.opt.affine_est_gain = 0; m.opt.epi_search_edgelet_max_angle = 0.7; m.opt.max_patch_diff_ratio = 2.0;
+    m.align_1d = is_edgelet(fb->type[i]);
+    double depth = 0.0;
+    const int res = orc_find_epipolar_match_direct(&m, frame0, frame1, T_f1f0, &fb->px[2 * i], &fb->f[3 * i], &fb->grad[2 * i],
+                                                   fb->level[i], fb->type[i], d_inv[0], d_inv[1], d_inv[2], &depth);
+    result[i] = res;
+    if (res == SVOH_MATCH_SUCCESS) {
+      orc_stereo_match* o = &out[n_succeeded];
+      memset(o, 0, sizeof *o);
+      o->i_ref = i;
+      for (int j = 0; j < 3; ++j) o->xyz_cam0[j] = fb->f[3 * i + j] * depth;
+      o->px[0] = m.px_cur[0]; o->px[1] = m.px_cur[1];
+      for (int j = 0; j < 3; ++j) o->f[j] = m.f_cur[j];
+      double g[2] = { m.A_cur_ref[0] * fb->grad[2 * i] + m.A_cur_ref[2] * fb->grad[2 * i + 1],
+                      m.A_cur_ref[1] * fb->grad[2 * i] + m.A_cur_ref[3] * fb->grad[2 * i + 1] };
+      normalize2(g);
+      o->grad[0] = g[0]; o->grad[1] = g[1];
+      o->depth = depth;
+      ++n_succeeded;
+    } else {
+      ++*n_failed;
+    }
+    if (n_succeeded >= n_desired) break;
+  }
+  return n_succeeded;
+}

@@ -109,6 +109,11 @@ class svoh_depth_filter_options(C.Structure):
 
 
 # svo::FeatureType (types.h:60-73)
+class svoh_epipolar_match_outputs(C.Structure):
+    _fields_ = [("result", C.c_void_p), ("depth", C.c_void_p), ("px_cur", C.c_void_p), ("f_cur", C.c_void_p),
+                ("search_level", C.c_void_p), ("h_inv", C.c_void_p), ("A_cur_ref", C.c_void_p)]
+
+
 class svoh_seed_match_outputs(C.Structure):
     _fields_ = [("px_cur", C.c_void_p), ("f_cur", C.c_void_p), ("search_level", C.c_void_p), ("A_cur_ref", C.c_void_p)]
 
@@ -185,6 +190,7 @@ def default_detector_options(**kw):
 FT_EDGELET_SEED, FT_CORNER_SEED, FT_MAPPOINT_SEED = 0, 1, 2
 FT_EDGELET_SEED_CONVERGED, FT_CORNER_SEED_CONVERGED, FT_MAPPOINT_SEED_CONVERGED = 3, 4, 5
 FT_EDGELET, FT_CORNER, FT_MAPPOINT, FT_FIXED_LANDMARK, FT_OUTLIER = 6, 7, 8, 9, 10
+MATCH_SUCCESS = 0
 MATCH_NOT_RUN = 100
 
 
@@ -259,7 +265,7 @@ EXPORTS = [
     "svoh_sparse_align_split_buffers", "svoh_sparse_align_split_init", "svoh_sparse_align_partial_sums", "svoh_sparse_align_gn_update",
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
     "svoh_match_direct_batch",
-    "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex",
+    "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex", "svoh_epipolar_match_batch",
     "svoh_detect_features", "svoh_optimize_pose_batch", "svoh_optimize_points_batch",
 ]
 
@@ -358,5 +364,8 @@ def load():
     lib.svoh_optimize_pose_batch.argtypes = [C.c_void_p, P(svoh_pose_options), C.c_int, P(svoh_pose_problem),
                                              P(svoh_pose_result)]
     lib.svoh_update_seeds_batch_ex.argtypes = lib.svoh_update_seeds_batch.argtypes + [P(svoh_seed_match_outputs)]
+    lib.svoh_epipolar_match_batch.argtypes = [C.c_void_p, P(svoh_matcher_options), C.c_int, P(svoh_frame_view),
+                                              P(svoh_frame_view), P(svoh_se3), P(svoh_feature_batch), P(C.c_double),
+                                              C.c_void_p, P(svoh_epipolar_match_outputs)]
     _LIB = lib
     return lib

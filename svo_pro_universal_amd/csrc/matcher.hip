@@ -66,6 +66,11 @@ struct MatcherArgs {
   double* state;
   uint8_t* success;
   unsigned int* unit_counts;  // 4 per feature: warps, ZMSSD evaluations, align iterations, filter updates
+  // plain epipolar matches (stereo seam)
+  const Rigid* T_cur_ref;     // n_ref_frames x n_cur_frames, or NULL = from the poses
+  const double* d_inv;        // 3 per feature, or NULL = d_inv_common
+  double d_inv_common[3];
+  double* depth_out;
 };
 
 constexpr int kPwbStride = 100;
@@ -1290,6 +1295,58 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
 #endif
 }
 
+// n x Matcher::findEpipolarMatchDirect with an explicit T_cur_ref (matcher.cpp:157-241), align_1d = isEdgelet(type):
+// the call StereoTriangulation::compute makes per new feature (stereo_triangulation.cpp:92-104)
+template <bool G8>
+__global__ __launch_bounds__(64) void epipolar_match_kernel(const MatcherArgs a)
+{
+  __shared__ unsigned char s_pwb[64 * kPwbStride];
+  const int unit = G8 ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;
+  const int i = blockIdx.x * (G8 ? 8 : 64) + unit;
+  if (i >= a.n) return;
+  const bool reporter = !G8 || (threadIdx.x & 7) == 0;
+  if (!feature_indices_ok(a, i)) {
+    if (reporter) {
+      a.result[i] = SVOH_MATCH_NOT_RUN;
+      reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return;
+  }
+  const int ri = a.ref_frame_idx[i], ci = a.cur_frame_idx ? a.cur_frame_idx[i] : 0;
+  const DevFrameView& ref = a.ref_frames[ri];
+  const DevFrameView& cur = a.cur_frame[ci];
+  const Rigid T_cur_ref = a.T_cur_ref ? a.T_cur_ref[(size_t)ri * a.n_cur_frames + ci] : T_cur_ref_of(ref, cur);
+  const int type = a.type[i];
+  MatcherState m;
+  m.pwb = s_pwb + unit * kPwbStride;
+  m.sub = G8 ? (int)(threadIdx.x & 7) : 0;
+  m.h_inv = 0.0; m.search_level = 0; m.reject = false;
+  m.n_warp = 0; m.n_zmssd = 0; m.n_align_it = 0;
+  m.align_1d = is_edgelet(type);
+  m.A[0] = m.A[1] = m.A[2] = m.A[3] = 0.0;
+  m.px_cur[0] = m.px_cur[1] = 0.0;
+  m.f_cur = { 0.0, 0.0, 0.0 };
+#ifdef SVOH_SEED_STAMPS
+  m.t[0] = m.t[1] = m.t[2] = m.t[3] = 0; m.tlast = clock64();
+#endif
+  const Vec3 f = { a.f[3 * i], a.f[3 * i + 1], a.f[3 * i + 2] };
+  const double d_est = a.d_inv ? a.d_inv[3 * i] : a.d_inv_common[0];
+  const double d_min = a.d_inv ? a.d_inv[3 * i + 1] : a.d_inv_common[1];
+  const double d_max = a.d_inv ? a.d_inv[3 * i + 2] : a.d_inv_common[2];
+  double depth = 0.0;
+  const int res = find_epipolar_match_direct<G8>(m, a.mopt, ref, cur, T_cur_ref, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
+                                                 a.grad[2 * i + 1], a.level[i], type, d_est, d_min, d_max, depth);
+  if (!reporter) return;
+  a.result[i] = res;
+  a.depth_out[i] = depth;
+  if (a.px_cur) { a.px_cur[2 * i] = m.px_cur[0]; a.px_cur[2 * i + 1] = m.px_cur[1]; }
+  if (a.f_cur) { a.f_cur[3 * i] = m.f_cur.x; a.f_cur[3 * i + 1] = m.f_cur.y; a.f_cur[3 * i + 2] = m.f_cur.z; }
+  if (a.search_level) a.search_level[i] = m.search_level;
+  if (a.h_inv) a.h_inv[i] = m.h_inv;
+  if (a.A_cur_ref) for (int k = 0; k < 4; ++k) a.A_cur_ref[4 * i + k] = m.A[k];
+  flush_counters(a.unit_counts, i, m, res == SVOH_MATCH_SUCCESS ? 1 : 0);
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1531,11 +1588,166 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   return SVOH_OK;
 }
 
+// svoh_epipolar_match_batch: same staging scheme as run_matcher ([views | transforms | inputs | outputs])
+static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_ref_frames, const svoh_frame_view* ref_frames,
+                        const svoh_frame_view* cur_frame, const svoh_se3* T_cur_ref, const svoh_feature_batch* fb,
+                        const double d_inv_common[3], const double* d_inv, const svoh_epipolar_match_outputs* out)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, mopt && ref_frames && cur_frame && fb && out && n_ref_frames >= 1, "NULL argument");
+  SVOH_REQUIRE(ctx, d_inv_common || d_inv, "no depth range given");
+  const int n = fb->n;
+  if (n <= 0) return SVOH_OK;
+  SVOH_REQUIRE(ctx, fb->mem_space == SVOH_MEM_HOST || fb->mem_space == SVOH_MEM_DEVICE, "bad mem_space");
+  const bool on_device = fb->mem_space == SVOH_MEM_DEVICE;
+  SVOH_REQUIRE(ctx, fb->ref_frame_idx && fb->px && fb->f && fb->grad && fb->level && fb->type, "NULL feature array");
+  SVOH_REQUIRE(ctx, out->result && out->depth, "result and depth outputs are required");
+  const int n_cur = (fb->cur_frame_idx && fb->n_cur_frames > 0) ? fb->n_cur_frames : 1;
+  if (!on_device) {
+    for (int i = 0; i < n; ++i) {
+      SVOH_REQUIRE(ctx, fb->ref_frame_idx[i] >= 0 && fb->ref_frame_idx[i] < n_ref_frames, "ref_frame_idx out of range");
+      SVOH_REQUIRE(ctx, fb->level[i] >= 0 && fb->level[i] < SVOH_MAX_LEVELS, "feature level out of range");
+      if (fb->cur_frame_idx)
+        SVOH_REQUIRE(ctx, fb->cur_frame_idx[i] >= 0 && fb->cur_frame_idx[i] < n_cur, "cur_frame_idx out of range");
+    }
+  }
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<DevFrameView> views((size_t)n_ref_frames + n_cur);
+  int ref_levels = 0;
+  for (int k = 0; k < n_ref_frames; ++k) {
+    const int rc = fill_view(ctx, ref_frames[k], &views[k], "reference frame");
+    if (rc != SVOH_OK) return rc;
+    ref_levels = views[k].n_levels > ref_levels ? views[k].n_levels : ref_levels;
+  }
+  for (int k = 0; k < n_cur; ++k) {
+    const int rc = fill_view(ctx, cur_frame[k], &views[n_ref_frames + k], "current frame");
+    if (rc != SVOH_OK) return rc;
+    SVOH_REQUIRE(ctx, views[n_ref_frames + k].n_levels >= ref_levels, "current frame has fewer pyramid levels than a reference frame");
+  }
+  if (!on_device)
+    for (int i = 0; i < n; ++i)
+      SVOH_REQUIRE(ctx, fb->level[i] < views[fb->ref_frame_idx[i]].n_levels, "feature level beyond the reference pyramid");
+  std::vector<Rigid> T;
+  if (T_cur_ref) {
+    T.resize((size_t)n_ref_frames * n_cur);
+    for (size_t k = 0; k < T.size(); ++k) T[k] = load_rigid(T_cur_ref[k]);
+  }
+
+  Staging s;
+  const size_t o_views = s.add(views.data(), sizeof(DevFrameView) * views.size());
+  const size_t o_T = T_cur_ref ? s.add(T.data(), sizeof(Rigid) * T.size()) : 0;
+  size_t o_idx = 0, o_cidx = 0, o_px = 0, o_f = 0, o_grad = 0, o_level = 0, o_type = 0, o_dinv = 0;
+  if (!on_device) {
+    o_idx = s.add(fb->ref_frame_idx, sizeof(int32_t) * n);
+    o_cidx = fb->cur_frame_idx ? s.add(fb->cur_frame_idx, sizeof(int32_t) * n) : 0;
+    o_px = s.add(fb->px, sizeof(double) * 2 * n);
+    o_f = s.add(fb->f, sizeof(double) * 3 * n);
+    o_grad = s.add(fb->grad, sizeof(double) * 2 * n);
+    o_level = s.add(fb->level, sizeof(int32_t) * n);
+    o_type = s.add(fb->type, (size_t)n);
+    o_dinv = d_inv ? s.add(d_inv, sizeof(double) * 3 * n) : 0;
+  }
+  const size_t in_total = s.total;
+  auto out_add = [&](size_t bytes) { const size_t o = s.total; s.total = (s.total + bytes + 63) & ~(size_t)63; return o; };
+  size_t o_result = 0, o_depth = 0, o_pxcur = 0, o_fcur = 0, o_slevel = 0, o_hinv = 0, o_A = 0;
+  if (!on_device) {
+    o_result = out_add(sizeof(int32_t) * n);
+    o_depth = out_add(sizeof(double) * n);
+    o_pxcur = out_add(sizeof(double) * 2 * n);
+    o_fcur = out_add(sizeof(double) * 3 * n);
+    o_slevel = out_add(sizeof(int32_t) * n);
+    o_hinv = out_add(sizeof(double) * n);
+    o_A = out_add(sizeof(double) * 4 * n);
+  }
+  const size_t o_end = s.total;
+  SVOH_HIP_TRY(ctx, ctx->h_scratch1.reserve(s.total));
+  SVOH_HIP_TRY(ctx, ctx->d_scratch1.reserve(s.total));
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch1.ptr);
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch1.ptr);
+  for (size_t k = 0; k < s.in.size(); ++k) memcpy(h + s.off[k], s.in[k].first, s.in[k].second);
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
+  if (!on_device && o_end > in_total) SVOH_HIP_TRY(ctx, hipMemsetAsync(d + in_total, 0, o_end - in_total, ctx->stream));
+
+  MatcherArgs a;
+  memset(&a, 0, sizeof a);
+  a.ref_frames = reinterpret_cast<const DevFrameView*>(d + o_views);
+  a.cur_frame = a.ref_frames + n_ref_frames;
+  a.T_cur_ref = T_cur_ref ? reinterpret_cast<const Rigid*>(d + o_T) : nullptr;
+  a.mopt = *mopt;
+  a.n = n;
+  a.n_ref_frames = n_ref_frames;
+  a.n_cur_frames = n_cur;
+  if (d_inv_common) for (int k = 0; k < 3; ++k) a.d_inv_common[k] = d_inv_common[k];
+  if (on_device) {
+    a.ref_frame_idx = fb->ref_frame_idx; a.cur_frame_idx = fb->cur_frame_idx;
+    a.px = fb->px; a.f = fb->f; a.grad = fb->grad; a.level = fb->level; a.type = fb->type;
+    a.d_inv = d_inv;
+    a.result = out->result; a.depth_out = out->depth; a.px_cur = out->px_cur; a.f_cur = out->f_cur;
+    a.search_level = out->search_level; a.h_inv = out->h_inv; a.A_cur_ref = out->A_cur_ref;
+  } else {
+    a.ref_frame_idx = reinterpret_cast<const int32_t*>(d + o_idx);
+    a.cur_frame_idx = fb->cur_frame_idx ? reinterpret_cast<const int32_t*>(d + o_cidx) : nullptr;
+    a.px = reinterpret_cast<const double*>(d + o_px);
+    a.f = reinterpret_cast<const double*>(d + o_f);
+    a.grad = reinterpret_cast<const double*>(d + o_grad);
+    a.level = reinterpret_cast<const int32_t*>(d + o_level);
+    a.type = d + o_type;
+    a.d_inv = d_inv ? reinterpret_cast<const double*>(d + o_dinv) : nullptr;
+    a.result = reinterpret_cast<int32_t*>(d + o_result);
+    a.depth_out = reinterpret_cast<double*>(d + o_depth);
+    a.px_cur = reinterpret_cast<double*>(d + o_pxcur);
+    a.f_cur = reinterpret_cast<double*>(d + o_fcur);
+    a.search_level = reinterpret_cast<int32_t*>(d + o_slevel);
+    a.h_inv = reinterpret_cast<double*>(d + o_hinv);
+    a.A_cur_ref = reinterpret_cast<double*>(d + o_A);
+  }
+  int g8 = n <= kG8MaxUnits ? 1 : 0;
+  if (const char* e = getenv("SVOH_MATCHER_G8")) g8 = atoi(e) != 0;
+  const int units_per_block = g8 ? 8 : 64;
+  const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
+  {
+    unsigned long long* dummy;
+    int rc = reset_counters(ctx, &dummy);
+    if (rc == SVOH_OK) rc = reserve_unit_counts(ctx, (size_t)n, &a.unit_counts);
+    if (rc != SVOH_OK) return rc;
+  }
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  if (g8) hipLaunchKernelGGL(epipolar_match_kernel<true>, grid, block, 0, ctx->stream, a);
+  else hipLaunchKernelGGL(epipolar_match_kernel<false>, grid, block, 0, ctx->stream, a);
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = true;
+  {
+    const int rc = reduce_unit_counts(ctx, (size_t)n);
+    if (rc != SVOH_OK) return rc;
+  }
+  if (on_device) return SVOH_OK;
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_result, d + o_result, o_end - o_result, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out->result, h + o_result, sizeof(int32_t) * n);
+  memcpy(out->depth, h + o_depth, sizeof(double) * n);
+  if (out->px_cur) memcpy(out->px_cur, h + o_pxcur, sizeof(double) * 2 * n);
+  if (out->f_cur) memcpy(out->f_cur, h + o_fcur, sizeof(double) * 3 * n);
+  if (out->search_level) memcpy(out->search_level, h + o_slevel, sizeof(int32_t) * n);
+  if (out->h_inv) memcpy(out->h_inv, h + o_hinv, sizeof(double) * n);
+  if (out->A_cur_ref) memcpy(out->A_cur_ref, h + o_A, sizeof(double) * 4 * n);
+  return SVOH_OK;
+}
+
 }  // namespace svoh
 
 using namespace svoh;
 
 extern "C" {
+
+int svoh_epipolar_match_batch(svoh_ctx* ctx, const svoh_matcher_options* options, int n_ref_frames,
+                              const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
+                              const svoh_se3* T_cur_ref, const svoh_feature_batch* features,
+                              const double d_inv_common[3], const double* d_inv,
+                              const svoh_epipolar_match_outputs* outputs)
+{
+  return run_epipolar(ctx, options, n_ref_frames, ref_frames, cur_frame, T_cur_ref, features, d_inv_common, d_inv, outputs);
+}
 
 int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options, int n_ref_frames,
                             const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,

@@ -333,6 +333,26 @@ def _match_direct_device(self, mopt, ref_views, cur_views, fb, depth, px_cur, re
                                                  result, f_cur, search_level, h_inv, A_cur_ref))
 
 
+def _epipolar_match_batch(self, mopt, ref_views, cur_views, fb, d_inv_common=None, d_inv=None, T_cur_ref=None):
+    """svoh_epipolar_match_batch on host arrays: n x Matcher::findEpipolarMatchDirect (the stereo triangulation's call).
+    T_cur_ref: list of 7-vectors (n_ref x n_cur, row-major) or None.  Returns a dict of per-feature arrays."""
+    rv, n_ref = _views(ref_views)
+    cv, _ = _views(cur_views)
+    n = fb.n
+    out = dict(result=np.zeros(max(n, 1), np.int32), depth=np.zeros(max(n, 1)), px_cur=np.zeros(2 * max(n, 1)),
+               f_cur=np.zeros(3 * max(n, 1)), search_level=np.zeros(max(n, 1), np.int32), h_inv=np.zeros(max(n, 1)),
+               A=np.zeros(4 * max(n, 1)))
+    o = capi.svoh_epipolar_match_outputs()
+    o.result, o.depth, o.px_cur, o.f_cur = (out[k].ctypes.data for k in ("result", "depth", "px_cur", "f_cur"))
+    o.search_level, o.h_inv, o.A_cur_ref = (out[k].ctypes.data for k in ("search_level", "h_inv", "A"))
+    dc = (C.c_double * 3)(*d_inv_common) if d_inv_common is not None else None
+    di = None if d_inv is None else np.ascontiguousarray(d_inv, np.float64)
+    T = None if T_cur_ref is None else (capi.svoh_se3 * len(T_cur_ref))(*[_se3(t) for t in T_cur_ref])
+    self._check(self.lib.svoh_epipolar_match_batch(self.h, C.byref(mopt), n_ref, rv, cv, T, C.byref(fb), dc,
+                                                   None if di is None else di.ctypes.data, C.byref(o)))
+    return {k: v[:n * (v.size // max(n, 1))] for k, v in out.items()}
+
+
 def make_pose_problem(cams, T_imu_world):
     """cams: list of dict(cam=synth.Camera, T_cam_imu=SE3, px, f, grad, level, type, xyz_world, usable); returns
     (svoh_pose_problem, keepalive) with per-feature outputs `outlier` / `final_error` in keepalive[i]."""
@@ -402,6 +422,7 @@ def _detect_features(self, opt, frame, width, height, occupancy=None, mask=None,
                 grad=grad[:2 * n].reshape(-1, 2).copy(), type=typ[:n].copy())
 
 
+Context.epipolar_match_batch = _epipolar_match_batch
 Context.detect_features = _detect_features
 Context.optimize_pose = _optimize_pose
 Context.optimize_points = _optimize_points

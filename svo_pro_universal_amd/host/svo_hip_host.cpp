@@ -450,6 +450,148 @@ void DetectorHip::detect(const FramePtr& frame)
   }
 }
 
+// ---- StereoTriangulationHip (stereo_triangulation.cpp:16-140) -----------------------------------
+StereoTriangulationHip::StereoTriangulationHip(svoh_ctx* ctx, const StereoTriangulationOptions& options,
+                                               const std::shared_ptr<DetectorHip>& feature_detector)
+  : options_(options), feature_detector_(feature_detector), ctx_(ctx)
+{
+  if (!ctx_) throw std::runtime_error("StereoTriangulationHip: NULL svoh_ctx (no CPU fallback exists)");
+  shuffle_ = [](std::vector<size_t>& indices, size_t n_corners) {
+    // std::random_shuffle(first, last) as libstdc++ implements it on rand() (stereo_triangulation.cpp:77-78)
+    auto rs = [](std::vector<size_t>::iterator first, std::vector<size_t>::iterator last) {
+      if (first == last) return;
+      for (auto i = first + 1; i != last; ++i) {
+        auto j = first + std::rand() % ((i - first) + 1);
+        if (i != j) std::iter_swap(i, j);
+      }
+    };
+    rs(indices.begin(), indices.begin() + static_cast<long>(n_corners));
+    rs(indices.begin() + static_cast<long>(n_corners), indices.end());
+  };
+}
+
+void StereoTriangulationHip::compute(const FramePtr& frame0, const FramePtr& frame1)
+{
+  last_indices_.clear(); last_results_.clear(); last_n_succeeded_ = last_n_failed_ = 0;
+  if (!frame0 || !frame1) throw std::runtime_error("StereoTriangulationHip::compute: NULL frame");
+  auto num_landmarks = [](const Frame& f) {   // Frame::numLandmarks (frame.cpp:144-151)
+    size_t n = 0;
+    for (size_t i = 0; i < f.num_features_ && i < f.landmark_vec_.size(); ++i) n += f.landmark_vec_[i] != nullptr;
+    return n;
+  };
+  const size_t n_landmarks0 = num_landmarks(*frame0);
+  if (n_landmarks0 >= options_.triangulate_n_features) return;   // "sufficient number of features": no effect
+
+  // detect new features (the detector's grid holds what the caller marked; every cell may deliver one)
+  std::vector<double> new_px, new_scores, new_grads;
+  std::vector<int32_t> new_levels;
+  std::vector<uint8_t> new_types;
+  const size_t max_n_features = feature_detector_->grid_.size();
+  feature_detector_->detect(frame0->pyramid, nullptr, 0, max_n_features, new_px, new_scores, new_levels, new_grads, new_types);
+  const size_t n_new = new_levels.size();
+  if (n_new == 0) return;   // "Stereo Triangulation: No features detected."
+
+  // add them to the first frame (:56-69)
+  Frame& f0 = *frame0;
+  const size_t n_old = f0.num_features_;
+  const size_t n0 = n_old + n_new;
+  f0.px_vec_.resize(2 * n_old); f0.px_vec_.insert(f0.px_vec_.end(), new_px.begin(), new_px.end());
+  f0.grad_vec_.resize(2 * n_old); f0.grad_vec_.insert(f0.grad_vec_.end(), new_grads.begin(), new_grads.end());
+  f0.score_vec_.resize(n_old); f0.score_vec_.insert(f0.score_vec_.end(), new_scores.begin(), new_scores.end());
+  f0.level_vec_.resize(n_old); f0.level_vec_.insert(f0.level_vec_.end(), new_levels.begin(), new_levels.end());
+  f0.type_vec_.resize(n_old); f0.type_vec_.insert(f0.type_vec_.end(), new_types.begin(), new_types.end());
+  f0.f_vec_.resize(3 * n0);
+  const svoh::CamModel cm0 = svoh::load_camera(f0.cam);
+  for (size_t i = n_old; i < n0; ++i) {   // frame_utils::computeNormalizedBearingVectors
+    const svoh::Vec3 f = svoh::back_project3(cm0, f0.px_vec_[2 * i], f0.px_vec_[2 * i + 1]);
+    const double nn = sqrt(f.x * f.x + f.y * f.y + f.z * f.z);
+    f0.f_vec_[3 * i] = f.x / nn; f0.f_vec_[3 * i + 1] = f.y / nn; f0.f_vec_[3 * i + 2] = f.z / nn;
+  }
+  f0.landmark_vec_.resize(n0); f0.seed_ref_vec_.resize(n0); f0.track_id_vec_.resize(n0, -1);
+  f0.invmu_sigma2_a_b_vec_.resize(4 * n0);
+  f0.num_features_ = n0;
+
+  // visiting order: corners first, each part shuffled (:71-78)
+  std::vector<size_t> indices(n_new);
+  for (size_t k = 0; k < n_new; ++k) indices[k] = n_old + k;
+  const size_t n_corners = static_cast<size_t>(std::count(new_types.begin(), new_types.end(), static_cast<uint8_t>(SVOH_FT_CORNER)));
+  shuffle_(indices, n_corners);
+  const size_t n_desired = options_.triangulate_n_features - n_landmarks0;
+
+  Frame& f1 = *frame1;
+  {  // reserve space for features in the second frame (:86-90)
+    const size_t need = f1.num_features_ + n_desired;
+    if (need > f1.landmark_vec_.size() || 2 * need > f1.px_vec_.size()) {
+      f1.px_vec_.resize(2 * need); f1.f_vec_.resize(3 * need); f1.grad_vec_.resize(2 * need); f1.score_vec_.resize(need);
+      f1.level_vec_.resize(need); f1.type_vec_.resize(need, SVOH_FT_OUTLIER); f1.landmark_vec_.resize(need);
+      f1.seed_ref_vec_.resize(need); f1.track_id_vec_.resize(need, -1); f1.invmu_sigma2_a_b_vec_.resize(4 * need);
+    }
+  }
+
+  // every candidate through Matcher::findEpipolarMatchDirect in one launch (the loop below only reads the results)
+  svoh_matcher_options mo{};   // Matcher::Options defaults (matcher.h:39-54) + :93-94
+  mo.align_max_iter = 10; mo.max_epi_search_steps = 500; mo.subpix_refinement = 1; mo.epi_search_edgelet_filtering = 1;
+  mo.scan_on_unit_sphere = 1; mo.affine_est_offset = 1; mo.affine_est_gain = 0;
+  mo.epi_search_edgelet_max_angle = 0.7; mo.max_patch_diff_ratio = 2.0;
+  const Transformation T_f1f0 = svoh::mul(f1.T_cam_imu_, f0.T_imu_cam_);   // frame1->T_cam_body_ * frame0->T_body_cam_
+  svoh_se3 T_abi;
+  svoh::store_rigid(T_f1f0, T_abi);
+  std::vector<int32_t> ref_idx(n_new, 0);
+  svoh_feature_batch fb{};
+  fb.n = static_cast<int32_t>(n_new);
+  fb.ref_frame_idx = ref_idx.data();
+  fb.px = f0.px_vec_.data() + 2 * n_old; fb.f = f0.f_vec_.data() + 3 * n_old; fb.grad = f0.grad_vec_.data() + 2 * n_old;
+  fb.level = f0.level_vec_.data() + n_old; fb.type = f0.type_vec_.data() + n_old;
+  const svoh_frame_view v0 = view_of(f0), v1 = view_of(f1);
+  const double d_inv[3] = { options_.mean_depth_inv, options_.min_depth_inv, options_.max_depth_inv };
+  std::vector<int32_t> result(n_new);
+  std::vector<double> depth(n_new), px_cur(2 * n_new), f_cur(3 * n_new), A(4 * n_new);
+  svoh_epipolar_match_outputs out{};
+  out.result = result.data(); out.depth = depth.data(); out.px_cur = px_cur.data(); out.f_cur = f_cur.data();
+  out.A_cur_ref = A.data();
+  const int rc = svoh_epipolar_match_batch(ctx_, &mo, 1, &v0, &v1, &T_abi, &fb, d_inv, nullptr, &out);
+  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_epipolar_match_batch: ") + svoh_last_error_string(ctx_));
+
+  // the reference's loop (:95-137)
+  last_indices_ = indices;
+  last_results_.assign(n_new, -1);
+  const Transformation T_world_cam0 = svoh::inverse(f0.T_f_w_);
+  size_t n_succeeded = 0, n_failed = 0;
+  for (const size_t i_ref : indices) {
+    const size_t k = i_ref - n_old;
+    last_results_[k] = result[k];
+    if (result[k] == SVOH_MATCH_SUCCESS) {
+      const svoh::Vec3 p_cam = { f0.f_vec_[3 * i_ref] * depth[k], f0.f_vec_[3 * i_ref + 1] * depth[k], f0.f_vec_[3 * i_ref + 2] * depth[k] };
+      PointPtr new_point = std::make_shared<Point>();
+      new_point->pos_ = svoh::transform(T_world_cam0, p_cam);
+      new_point->id_ = next_point_id_++;
+      f0.landmark_vec_[i_ref] = new_point;
+      f0.track_id_vec_[i_ref] = new_point->id();
+      new_point->obs_.push_back(Point::Obs{ frame0, i_ref });
+      const size_t i_cur = f1.num_features_;
+      f1.type_vec_[i_cur] = f0.type_vec_[i_ref];
+      f1.level_vec_[i_cur] = f0.level_vec_[i_ref];
+      f1.px_vec_[2 * i_cur] = px_cur[2 * k]; f1.px_vec_[2 * i_cur + 1] = px_cur[2 * k + 1];
+      for (int j = 0; j < 3; ++j) f1.f_vec_[3 * i_cur + j] = f_cur[3 * k + j];
+      f1.score_vec_[i_cur] = f0.score_vec_[i_ref];
+      double g0 = A[4 * k] * f0.grad_vec_[2 * i_ref] + A[4 * k + 2] * f0.grad_vec_[2 * i_ref + 1];
+      double g1 = A[4 * k + 1] * f0.grad_vec_[2 * i_ref] + A[4 * k + 3] * f0.grad_vec_[2 * i_ref + 1];
+      const double z = g0 * g0 + g1 * g1;
+      if (z > 0.0) { const double nn = sqrt(z); g0 /= nn; g1 /= nn; }   // .normalized()
+      f1.grad_vec_[2 * i_cur] = g0; f1.grad_vec_[2 * i_cur + 1] = g1;
+      f1.landmark_vec_[i_cur] = new_point;
+      f1.track_id_vec_[i_cur] = new_point->id();
+      new_point->obs_.push_back(Point::Obs{ frame1, i_cur });
+      f1.num_features_++;
+      ++n_succeeded;
+    } else {
+      ++n_failed;
+    }
+    if (n_succeeded >= n_desired) break;
+  }
+  last_n_succeeded_ = n_succeeded; last_n_failed_ = n_failed;
+}
+
 // ---- pose optimiser -------------------------------------------------------------------
 PoseOptimizerHip::PoseOptimizerHip(svoh_ctx* ctx, SolverOptions solver_options) : ctx_(ctx), solver_options_(solver_options)
 {

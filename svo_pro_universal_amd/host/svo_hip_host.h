@@ -436,6 +436,39 @@ class DetectorHip {
 };
 
 // ---------------------------------------------------------------------------
+// Stereo seam.  Mirrors svo::StereoTriangulation (src/svo/include/svo/stereo_triangulation.h:14-40,
+// src/svo/src/stereo_triangulation.cpp:23-140) as FrameHandlerStereo::makeKeyframe drives it
+// (frame_handler_stereo.cpp:170-205): detect new features in the left frame, match each into the right frame along
+// its epipolar line (Matcher::findEpipolarMatchDirect, 500 steps) and make landmarks of the successes.
+// All candidates are matched in ONE svoh_epipolar_match_batch launch; the reference's loop (shuffled order,
+// stop after n_desired successes, feature / landmark bookkeeping of both frames) is replayed on the host.
+// ---------------------------------------------------------------------------
+struct StereoTriangulationOptions {   // stereo_triangulation.h:14-20
+  size_t triangulate_n_features = 120;
+  double mean_depth_inv = 1.0 / 3.0;
+  double min_depth_inv = 1.0 / 1.0;
+  double max_depth_inv = 1.0 / 50.0;
+};
+
+class StereoTriangulationHip {
+ public:
+  StereoTriangulationOptions options_;
+  std::shared_ptr<DetectorHip> feature_detector_;
+  StereoTriangulationHip(svoh_ctx* ctx, const StereoTriangulationOptions& options, const std::shared_ptr<DetectorHip>& feature_detector);
+  void compute(const FramePtr& frame0, const FramePtr& frame1);
+  // The reference shuffles the corner and the edgelet part of the new indices with std::random_shuffle (rand()):
+  // the default does the same; a caller that needs a reproducible order (tests) sets its own.
+  std::function<void(std::vector<size_t>& indices, size_t n_corners)> shuffle_;
+  // of the last compute(): the visiting order, Matcher::MatchResult per visited index (-1 = not reached), counts
+  std::vector<size_t> last_indices_;
+  std::vector<int32_t> last_results_;
+  size_t last_n_succeeded_ = 0, last_n_failed_ = 0;
+  int next_point_id_ = 0;   // PointIdProvider::getNewPointId() of the landmarks made here
+ private:
+  svoh_ctx* ctx_;
+};
+
+// ---------------------------------------------------------------------------
 // Pose optimiser.  Mirrors svo::PoseOptimizer (src/svo/include/svo/pose_optimizer.h:20-80,
 // src/svo/src/pose_optimizer.cpp:17-113, 198-307) as FrameHandlerBase::optimizePose drives it
 // (frame_handler_base.cpp:746-790): setRotationPrior, run(frame_bundle, reproj_thresh_px).

@@ -197,3 +197,28 @@ def test_cpp_structure_optimisation_and_map_mirrors():
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASS" in out.stdout
+
+
+@pytest.mark.parametrize("n_want,n_have", [(60, 5), (4000, 0)])
+def test_cpp_stereo_triangulation_mirror_matches_oracle(tmp_path, oracle_lib, n_want, n_have):
+    """StereoTriangulationHip::compute (stereo_triangulation.cpp:23-140) vs the oracle's sequential loop: the early
+    stop at n_desired (60 wanted, 5 landmarks already there) and the run through every new feature (4000 wanted)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    cam = synth.Camera.euroc_like()
+    # left = the scene's reference view, right = its current view: a 9-12 cm baseline with a slight vergence
+    sc = synth.make_align_scene(81, n_features=10, cam=cam, rot_deg=(0.2, 0.6), trans_m=(0.09, 0.12))
+    T_c0_b = sc.T_cam_imu
+    T_b_w = T_c0_b.inverse() * sc.T_ref_f_w
+    T_c1_b = sc.T_cur_f_w_gt * T_b_w.inverse()
+    path = str(tmp_path / "stereo.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("4i", cam.width, cam.height, n_want, n_have))
+        np.array([cam.fx, cam.fy, cam.cx, cam.cy] + list(cam.dist) + [1.0]).tofile(f)
+        T_c0_b.as7().tofile(f); T_c1_b.as7().tofile(f); T_b_w.as7().tofile(f)
+        np.array([1.0 / 3.0, 1.0 / 1.0, 1.0 / 50.0]).tofile(f)      # StereoTriangulationOptions defaults
+        sc.img_ref.tofile(f); sc.img_cur.tofile(f)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_host_stereo"), path], capture_output=True, text=True)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASS" in out.stdout

@@ -181,6 +181,41 @@ def test_match_direct_parity(gpu_ctx, oracle_lib, cam_kind):
         assert np.median(e) < 0.3
 
 
+@pytest.mark.parametrize("n_features,cam_kind,sphere", [(120, "pinhole", 1), (3000, "radtan", 1), (3000, "pinhole", 0)])
+def test_epipolar_match_batch_parity_stereo_seam(gpu_ctx, oracle_lib, n_features, cam_kind, sphere):
+    """Row *J (VERDICT r01): n x Matcher::findEpipolarMatchDirect(frame0, frame1, T_f1f0, ftr, mean / min / max inverse
+    depth, depth) with max_epi_search_steps = 500 and align_1d = isEdgelet(type), the call of
+    StereoTriangulation::compute (stereo_triangulation.cpp:92-104), against the oracle: result codes, search levels
+    exact, depth relative 1e-9, matched pixel <= 1e-4."""
+    orc = oracle_lib
+    cam = synth.Camera.test_camera() if cam_kind == "pinhole" else synth.Camera.euroc_like()
+    sc, ref, cur, fr, fc = scene_and_frames(gpu_ctx, orc, 66, cam)     # "left" = ref, "right" = cur (5-15 cm baseline)
+    sd = synth.make_seed_set(sc, n_features, margin=6, levels=(0, 1, 2))
+    ftype = np.where(sd["type"] == 0, capi.FT_EDGELET, capi.FT_CORNER).astype(np.uint8)   # detector output, not seeds
+    ov_r, ov_c, gv_r, gv_c = views(gpu_ctx, orc, sc, ref, cur, fr, fc, 0.0)
+    T_f1f0 = (sc.T_cur_f_w_gt * sc.T_ref_f_w.inverse()).as7()
+    d_mean = float(np.median(sd["true_depth"]))
+    d_inv = [1.0 / d_mean, 1.0 / (0.3 * d_mean), 1.0 / (15.0 * d_mean)]   # StereoTriangulationOptions: mean / min / max
+    mopt = capi.default_matcher_options(max_epi_search_steps=500, subpix_refinement=1, scan_on_unit_sphere=sphere)
+    fbo, ko = orc.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+    fbg, kg = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+    oo = orc.epipolar_match_batch(mopt, [ov_r], ov_c, fbo, d_inv_common=d_inv, T_cur_ref=[T_f1f0])
+    og = gpu_ctx.epipolar_match_batch(mopt, [gv_r], gv_c, fbg, d_inv_common=d_inv, T_cur_ref=[T_f1f0])
+    assert np.array_equal(oo["result"], og["result"]), np.nonzero(oo["result"] != og["result"])
+    assert np.array_equal(oo["search_level"], og["search_level"])
+    ok = oo["result"] == capi.MATCH_SUCCESS
+    assert ok.mean() > 0.5 and len(set(oo["result"])) >= 3
+    assert np.allclose(og["depth"][ok], oo["depth"][ok], rtol=1e-9, atol=0)
+    assert np.abs(oo["px_cur"] - og["px_cur"])[np.repeat(ok, 2)].max() <= 1e-4
+    assert np.abs(oo["f_cur"] - og["f_cur"])[np.repeat(ok, 3)].max() < 1e-6
+    assert np.allclose(oo["A"], og["A"], rtol=1e-12, atol=1e-14)
+    e = np.abs(og["depth"][ok] - sd["true_depth"][ok]) / sd["true_depth"][ok]
+    assert np.median(e) < 0.03                              # the triangulated depth is the scene's
+    # per-feature depth ranges (3 x n) and the pose-derived transform (NULL) give the same answers here
+    og2 = gpu_ctx.epipolar_match_batch(mopt, [gv_r], gv_c, fbg, d_inv=np.tile(d_inv, n_features))
+    assert np.array_equal(og2["result"], og["result"]) and np.allclose(og2["depth"], og["depth"], rtol=1e-9, atol=0)
+
+
 def test_golden_klt_seeds_fixture(gpu_ctx):
     """HIP path vs the committed fixture (no oracle call)."""
     import os
