@@ -100,6 +100,7 @@ struct MatcherState {
   double px_cur[2];
   Vec3 f_cur;
   int n_warp, n_zmssd, n_align_it;  // work counters
+  unsigned tpl[16];    // packed geometry (G == 2): the 8x8 template as 16 dwords; unused (and optimised away) otherwise
 #ifdef SVOH_SEED_STAMPS
   long long t[4], tlast;  // diagnostic builds: cycles in geometry / warp / scan / align+rest
 #endif
@@ -790,6 +791,116 @@ __device__ bool align_1d_g8(const DevImage& cur_img, double dir0, double dir1, c
   return converged;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Packed geometry (large batches).  The one-lane-per-seed kernel above spends its vector instructions on waiting
+// lanes: a wave runs the epipolar scan for its longest seed, and the 1-D and the 2-D refinement loops one after
+// the other, each for its slowest seed (SQ counters, profiles/r02: 568 VALU instructions per seed, of which ~300
+// are the seed's own).  Here a 256-thread workgroup takes 256 seeds through three phases:
+//   A  one lane per seed: geometry, affine warp (10x10 patch into LDS), epipolar scan with a packed ZMSSD
+//      (template rows held as 16 dwords, current rows as unaligned 8-byte loads, v_dot4_u32_u8 sums); a seed that
+//      needs the sub-pixel refinement leaves a JOB (its slot) in one of two LDS queues (2-D / 1-D);
+//   E  the refinements, eight lanes per job (the row-split code of the eight-lane geometry: lane `sub` owns patch row
+//      `sub`, order-dependent sums handed from row to row): every wave takes eight jobs of ONE kind per round, so no
+//      wave runs both loops, a round lasts as long as the slowest of 8 (not 64) jobs, and all four SIMDs share the work;
+//   F  one lane per seed again: triangulation, tau, filter update, outputs.
+// Every seed goes through exactly the arithmetic of the one-lane code (same expressions, same order): results are
+// bit-identical to the other two geometries (tests/test_klt_matcher_gpu.py runs all three).
+constexpr int kPkThreads = 256;
+
+__device__ __forceinline__ unsigned udot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+
+// the 8x8 inner patch of a 10x10 LDS patch (4-byte aligned slot) as 16 dwords, row-major, 2 per row
+__device__ __forceinline__ void pack_template(const unsigned char* pwb, unsigned (&t)[16])
+{
+  const unsigned* w = reinterpret_cast<const unsigned*>(pwb);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int o = (r + 1) * 10 + 1;          // byte offset of the row's first pixel: 11, 21, ...: o & 3 = 3 or 1
+    const int d = o >> 2, sh = o & 3;
+    const unsigned w0 = w[d], w1 = w[d + 1], w2 = w[d + 2];
+    t[2 * r] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    t[2 * r + 1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+  }
+}
+
+// zmssd_score on packed rows: the same integer sums (patch_score.h:264-283)
+__device__ __forceinline__ int zmssd_score_packed(const unsigned (&t)[16], int sumA, int sumAA, const uint8_t* cur_patch, int stride)
+{
+  uint2 c[8];
+#pragma unroll
+  for (int y = 0; y < 8; ++y) __builtin_memcpy(&c[y], cur_patch + (ptrdiff_t)y * stride, 8);   // unaligned 8-byte loads, all in flight
+  unsigned sumB = 0, sumBB = 0, sumAB = 0;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    sumB = udot4(c[y].x, 0x01010101u, sumB);  sumB = udot4(c[y].y, 0x01010101u, sumB);
+    sumBB = udot4(c[y].x, c[y].x, sumBB);     sumBB = udot4(c[y].y, c[y].y, sumBB);
+    sumAB = udot4(c[y].x, t[2 * y], sumAB);   sumAB = udot4(c[y].y, t[2 * y + 1], sumAB);
+  }
+  const int iB = (int)sumB, iBB = (int)sumBB, iAB = (int)sumAB;
+  return sumAA - 2 * iAB + iBB - (sumA * sumA - 2 * sumA * iB + iB * iB) / 64;
+}
+
+// warp_affine (patch_warp.cpp:112-156) with the in-image test made on the four corner samples: the sample
+// coordinates are (a00*fx + a01*fy) + prx evaluated in float, monotone in fx and in fy (every float operation is),
+// so floor() takes its extremes over the 10x10 grid at the corners; a non-finite coefficient makes all four
+// corner values non-finite (fx, fy != 0 there), which the test rejects like the per-sample test does.
+__device__ bool warp_affine_packed(const double A_cur_ref[4], const DevImage& img_ref, double pxr, double pyr, int level_ref,
+                                   int search_level, unsigned char* patch)
+{
+  constexpr int halfpatch_size = 5;
+  double Ai[4];
+  mat2d_inverse(A_cur_ref, Ai);
+  const float s = (float)(1 << search_level);
+  const float a00 = (float)Ai[0] * s, a10 = (float)Ai[1] * s, a01 = (float)Ai[2] * s, a11 = (float)Ai[3] * s;
+  if (a00 != a00) return false;
+  const float prx = (float)pxr / (float)(1 << level_ref);
+  const float pry = (float)pyr / (float)(1 << level_ref);
+  const int stride = img_ref.pitch;
+  bool inside = true;
+#pragma unroll
+  for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+    for (int cx = 0; cx < 2; ++cx) {
+      const float fx = cx ? (float)(halfpatch_size - 1) : (float)(-halfpatch_size);
+      const float fy = cy ? (float)(halfpatch_size - 1) : (float)(-halfpatch_size);
+      const float pxx = (a00 * fx + a01 * fy) + prx;
+      const float pxy = (a10 * fx + a11 * fy) + pry;
+      const int xi = (int)floorf(pxx);
+      const int yi = (int)floorf(pxy);
+      inside = inside && pxx == pxx && pxy == pxy && !(xi < 0 || yi < 0 || xi >= img_ref.w - 1 || yi >= img_ref.h - 1);
+    }
+  if (!inside) return false;
+  for (int y = -halfpatch_size; y < halfpatch_size; ++y) {
+    unsigned short t0[10], t1[10];
+    float sx[10], sy[10];
+#pragma unroll
+    for (int x = -halfpatch_size; x < halfpatch_size; ++x) {
+      const int k = x + halfpatch_size;
+      const float fx = (float)x, fy = (float)y;
+      const float pxx = (a00 * fx + a01 * fy) + prx;
+      const float pxy = (a10 * fx + a11 * fy) + pry;
+      const int xi = (int)floorf(pxx);
+      const int yi = (int)floorf(pxy);
+      sx[k] = pxx - xi;
+      sy[k] = pxy - yi;
+      const uint8_t* ptr = img_ref.data + (ptrdiff_t)yi * stride + xi;
+      __builtin_memcpy(&t0[k], ptr, 2);            // the two taps of a row in one (unaligned) 2-byte load
+      __builtin_memcpy(&t1[k], ptr + stride, 2);
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const float subpix_x = sx[k], subpix_y = sy[k];
+      const unsigned t00 = t0[k] & 255u, t10 = t0[k] >> 8, t01 = t1[k] & 255u, t11 = t1[k] >> 8;
+      const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+      const float w01 = (1.0f - subpix_x) * subpix_y;
+      const float w10 = subpix_x * (1.0f - subpix_y);
+      const float w11 = 1.0f - w00 - w01 - w10;
+      patch[(y + halfpatch_size) * 10 + k] = (unsigned char)(w00 * t00 + w01 * t01 + w10 * t10 + w11 * t11);
+    }
+  }
+  return true;
+}
+
 __device__ __forceinline__ Rigid T_cur_ref_of(const DevFrameView& ref, const DevFrameView& cur)
 {
   return mul(cur.T_f_w, inverse(ref.T_f_w));
@@ -848,19 +959,23 @@ __device__ __forceinline__ bool is_patch_within_image(const DevFrameView& frame,
            py >= ((int)(frame.cam.height / (1 << patch_level)) - kPatchSize));
 }
 
-template <bool G8>
+// G: 0 = one lane per unit, 1 = eight lanes per unit, 2 = packed (one lane per unit in this phase, packed template)
+template <int G8>
 __device__ __forceinline__ bool update_zmssd(const DevFrameView& frame, int px, int py, int patch_level,
-                                             const unsigned char* pwb, int sub, int sumA, int sumAA, int& zmssd_best)
+                                             const MatcherState& m, int sumA, int sumAA, int& zmssd_best)
 {
   const DevImage& im = frame.lv[patch_level];
   const uint8_t* cur_patch_ptr = im.data + (ptrdiff_t)(py - 4) * im.pitch + (px - 4);
-  const int z = G8 ? zmssd_score_g8(pwb, sumA, sumAA, cur_patch_ptr, im.pitch, sub) : zmssd_score(pwb, sumA, sumAA, cur_patch_ptr, im.pitch);
+  int z;
+  if constexpr (G8 == 1) z = zmssd_score_g8(m.pwb, sumA, sumAA, cur_patch_ptr, im.pitch, m.sub);
+  else if constexpr (G8 == 2) z = zmssd_score_packed(m.tpl, sumA, sumAA, cur_patch_ptr, im.pitch);
+  else z = zmssd_score(m.pwb, sumA, sumAA, cur_patch_ptr, im.pitch);
   if (z < zmssd_best) { zmssd_best = z; return true; }
   return false;
 }
 
 // matcher.cpp:340-413
-template <bool G8>
+template <int G8>
 __device__ void scan_epipolar_unit_plane(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& frame,
                                          const Vec3& A, const Vec3& B, const Vec3& C, int patch_level, int sumA, int sumAA,
                                          double& bx, double& by, int& zmssd_best)
@@ -891,7 +1006,7 @@ __device__ void scan_epipolar_unit_plane(MatcherState& m, const svoh_matcher_opt
         break;
     }
     ++m.n_zmssd;
-    if (update_zmssd<G8>(frame, pxi0, pxi1, patch_level, m.pwb, m.sub, sumA, sumAA, zmssd_best)) { best0 = uv0; best1 = uv1; }
+    if (update_zmssd<G8>(frame, pxi0, pxi1, patch_level, m, sumA, sumAA, zmssd_best)) { best0 = uv0; best1 = uv1; }
     if (forward && i > n_steps * 0.5) {
       step0 = -step0; step1 = -step1;
       uv0 = uvC0; uv1 = uvC1;
@@ -922,7 +1037,7 @@ __device__ Vec3 angle_axis_rotate(const Vec3& axis, double angle, const Vec3& v)
 }
 
 // matcher.cpp:415-488
-template <bool G8>
+template <int G8>
 __device__ void scan_epipolar_unit_sphere(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& frame,
                                           const Vec3& A, const Vec3& B, const Vec3& C, int patch_level, int sumA, int sumAA,
                                           double& bx, double& by, int& zmssd_best)
@@ -952,7 +1067,7 @@ __device__ void scan_epipolar_unit_sphere(MatcherState& m, const svoh_matcher_op
       else break;
     }
     ++m.n_zmssd;
-    if (update_zmssd<G8>(frame, pxi0, pxi1, patch_level, m.pwb, m.sub, sumA, sumAA, zmssd_best)) f_best = f;
+    if (update_zmssd<G8>(frame, pxi0, pxi1, patch_level, m, sumA, sumAA, zmssd_best)) f_best = f;
   }
   project3(frame.cam, f_best, bx, by);
 }
@@ -980,7 +1095,7 @@ __device__ int depth_from_triangulation(const Rigid& T_search_ref, const Vec3& f
 // ZMSSD scan.  Returns a final result code, or kMatchRefinePending (m.px_cur = start of the refinement at level 0,
 // m.epi_dir = its 1-D direction) / kMatchTriangulatePending (no refinement wanted).
 constexpr int kMatchRefinePending = -1000, kMatchTriangulatePending = -1001;
-template <bool G8 = false>
+template <int G8 = 0>
 __device__ int epipolar_match_search(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
                                      const DevFrameView& cur_frame, const Rigid& T_cur_ref, double pxr, double pyr,
                                      const Vec3& f_ref, double gx, double gy, int level, int type,
@@ -1016,8 +1131,10 @@ __device__ int epipolar_match_search(MatcherState& m, const svoh_matcher_options
   normalize2(ed0, ed1);
   ++m.n_warp;
   SVOH_MSTAMP(m, 0);
-  const bool warp_ok = G8 ? warp_affine_g8(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb, m.sub)
-                          : warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
+  bool warp_ok;
+  if constexpr (G8 == 1) warp_ok = warp_affine_g8(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb, m.sub);
+  else if constexpr (G8 == 2) warp_ok = warp_affine_packed(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
+  else warp_ok = warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
   SVOH_MSTAMP(m, 1);
   if (!warp_ok) return SVOH_MATCH_FAIL_WARP;
 
@@ -1032,8 +1149,14 @@ __device__ int epipolar_match_search(MatcherState& m, const svoh_matcher_options
   } else {
     // PatchScore constructor (patch_score.h:80-92)
     int sumA = 0, sumAA = 0;
-    if (G8) patch_sums_g8(m.pwb, m.sub, sumA, sumAA);
-    else for (int r = 0; r < 64; ++r) { const int n = patch_at(m.pwb, r); sumA += n; sumAA += n * n; }
+    if constexpr (G8 == 1) patch_sums_g8(m.pwb, m.sub, sumA, sumAA);
+    else if constexpr (G8 == 2) {
+      pack_template(m.pwb, m.tpl);
+      unsigned a1 = 0, a2 = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { a1 = udot4(m.tpl[k], 0x01010101u, a1); a2 = udot4(m.tpl[k], m.tpl[k], a2); }
+      sumA = (int)a1; sumAA = (int)a2;
+    } else for (int r = 0; r < 64; ++r) { const int n = patch_at(m.pwb, r); sumA += n; sumAA += n * n; }
     const Vec3 C = { Rf.x + T_cur_ref.t.x * d_estimate_inv, Rf.y + T_cur_ref.t.y * d_estimate_inv,
                      Rf.z + T_cur_ref.t.z * d_estimate_inv };
     if (opt.scan_on_unit_sphere)
@@ -1073,8 +1196,8 @@ __device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_op
                                           const Vec3& f_ref, double gx, double gy, int level, int type,
                                           double d_estimate_inv, double d_min_inv, double d_max_inv, double& depth)
 {
-  const int st = epipolar_match_search<G8>(m, opt, ref_frame, cur_frame, T_cur_ref, pxr, pyr, f_ref, gx, gy, level, type,
-                                           d_estimate_inv, d_min_inv, d_max_inv);
+  const int st = epipolar_match_search<G8 ? 1 : 0>(m, opt, ref_frame, cur_frame, T_cur_ref, pxr, pyr, f_ref, gx, gy, level, type,
+                                                   d_estimate_inv, d_min_inv, d_max_inv);
   if (st != kMatchRefinePending && st != kMatchTriangulatePending) return st;
   bool aligned = false;
   double sx = 0.0, sy = 0.0;
@@ -1295,6 +1418,356 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
 #endif
 }
 
+// ---- spatial binning of a large seed batch -------------------------------------------------------------------------
+// Seeds arrive in the detector's order (by score): neighbours in the batch lie anywhere in the image, so every seed
+// pulls its own ~20 cache lines (10-12 rows of the reference patch, as many of the current image) through L2 and
+// nothing is shared.  A counting sort by (reference frame, 128x32-pixel tile of the reference pixel) makes the
+// seeds of a workgroup neighbours in both images (the frames of an update are close): their rows share lines.
+// Results do not depend on the processing order; every seed still writes its own entries.
+constexpr int kBinShiftX = 7, kBinShiftY = 5;
+constexpr size_t kBinMaxKeys = (size_t)1 << 20;
+
+__device__ __forceinline__ unsigned seed_bin_key(const MatcherArgs& a, int i, int tiles_x, int tiles_y)
+{
+  int ri = a.ref_frame_idx[i];
+  if ((unsigned)ri >= (unsigned)a.n_ref_frames) ri = 0;   // such a seed is not run; it only needs some place in the order
+  const double x = a.px[2 * i], y = a.px[2 * i + 1];
+  int tx = (x >= 0.0 && x < 1e9) ? ((int)x >> kBinShiftX) : 0, ty = (y >= 0.0 && y < 1e9) ? ((int)y >> kBinShiftY) : 0;
+  tx = tx < tiles_x ? tx : tiles_x - 1; ty = ty < tiles_y ? ty : tiles_y - 1;
+  return ((unsigned)ri * (unsigned)tiles_y + (unsigned)ty) * (unsigned)tiles_x + (unsigned)tx;
+}
+
+__global__ __launch_bounds__(256) void seed_bin_count_kernel(const MatcherArgs a, int tiles_x, int tiles_y, unsigned* hist, unsigned* rank)
+{
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i < a.n) rank[i] = atomicAdd(&hist[seed_bin_key(a, i, tiles_x, tiles_y)], 1u);
+}
+
+// exclusive scan of hist[0 .. n_keys) in place (one workgroup)
+__global__ __launch_bounds__(1024) void seed_bin_scan_kernel(unsigned* hist, unsigned n_keys)
+{
+  __shared__ unsigned s_part[1024];
+  const unsigned t = threadIdx.x;
+  const unsigned per = (n_keys + 1023u) / 1024u;
+  const unsigned lo = t * per, hi = lo + per < n_keys ? lo + per : n_keys;
+  unsigned sum = 0;
+  for (unsigned k = lo; k < hi; ++k) sum += hist[k];
+  s_part[t] = sum;
+  __syncthreads();
+  for (unsigned o = 1; o < 1024u; o <<= 1) {
+    const unsigned v = t >= o ? s_part[t - o] : 0u;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  unsigned run = s_part[t] - sum;
+  for (unsigned k = lo; k < hi; ++k) { const unsigned c = hist[k]; hist[k] = run; run += c; }
+}
+
+
+// Sorted seed records (binned batches): the binning pass gathers every seed's inputs into ONE 128-byte line at its
+// place in the processing order, the packed kernel leaves its results in a 64-byte record next to it, and a last
+// pass copies the results back to the caller's arrays in the caller's order (coalesced on that side).  Without it
+// every seed of a binned batch would touch ~10 separate lines of the caller's arrays (8 input arrays + outputs).
+struct SeedRecIn {    // 128 bytes
+  double px[2], f[3], grad[2], state[4];
+  int32_t ri, ci, level, type;
+  int32_t index;      // the seed's place in the caller's arrays
+  int32_t pad[5];
+};
+struct SeedRecOut {   // 64 bytes
+  double state[4];
+  unsigned counts[4];
+  int32_t result, type, success, pad;
+};
+static_assert(sizeof(SeedRecIn) == 128 && sizeof(SeedRecOut) == 64, "record sizes");
+
+__global__ __launch_bounds__(256) void seed_bin_scatter_kernel(const MatcherArgs a, int tiles_x, int tiles_y, const unsigned* offs,
+                                                               const unsigned* rank, unsigned* pos_of, SeedRecIn* rec)
+{
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= a.n) return;
+  const unsigned pos = offs[seed_bin_key(a, i, tiles_x, tiles_y)] + rank[i];
+  pos_of[i] = pos;
+  SeedRecIn r;
+  r.px[0] = a.px[2 * i]; r.px[1] = a.px[2 * i + 1];
+  r.f[0] = a.f[3 * i]; r.f[1] = a.f[3 * i + 1]; r.f[2] = a.f[3 * i + 2];
+  r.grad[0] = a.grad[2 * i]; r.grad[1] = a.grad[2 * i + 1];
+  for (int k = 0; k < 4; ++k) r.state[k] = a.state[4 * i + k];
+  r.ri = a.ref_frame_idx[i]; r.ci = a.cur_frame_idx ? a.cur_frame_idx[i] : 0; r.level = a.level[i]; r.type = a.type[i];
+  r.index = i;
+  for (int k = 0; k < 5; ++k) r.pad[k] = 0;
+  rec[pos] = r;
+}
+
+// results back into the caller's arrays, one thread per seed in the caller's order
+__global__ __launch_bounds__(256) void seed_unsort_kernel(const MatcherArgs a, const unsigned* pos_of, const SeedRecOut* out)
+{
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= a.n) return;
+  const SeedRecOut r = out[pos_of[i]];
+  for (int k = 0; k < 4; ++k) a.state[4 * i + k] = r.state[k];
+  a.type[i] = (uint8_t)r.type;
+  a.success[i] = (uint8_t)r.success;
+  if (a.result) a.result[i] = r.result;
+  reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(r.counts[0], r.counts[1], r.counts[2], r.counts[3]);
+}
+
+// DepthFilter::updateSeeds + depth_filter_utils::updateSeed, packed geometry (see "Packed geometry" above)
+__global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3))) void update_seeds_packed_kernel(
+    const MatcherArgs a, const SeedRecIn* __restrict__ rec_in, SeedRecOut* __restrict__ rec_out)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char s_pwb[kPkThreads * kPwbStride + 16];
+  __shared__ int s_res[kPkThreads];              // out of the refinement: (iterations << 8) | converged
+  __shared__ double s_dir[2 * kPkThreads];       // 1-D refinements: the direction
+  __shared__ float s_u[kPkThreads], s_v[kPkThreads];   // in: start of the refinement; out: its result
+  __shared__ int s_stat[kPkThreads];             // (cur frame << 8) | search level of the slot
+  __shared__ unsigned short s_q[2][kPkThreads];  // job queues: slots with a pending 2-D / 1-D refinement
+  __shared__ int s_qn[2], s_qh[2];
+  const int tid = (int)threadIdx.x;
+  if (tid < 2) { s_qn[tid] = 0; s_qh[tid] = 0; }
+  __syncthreads();
+  const int slot_i = (int)blockIdx.x * kPkThreads + tid;
+  const bool live = slot_i < a.n;
+  const bool est_offset = a.mopt.affine_est_offset != 0, est_gain = a.mopt.affine_est_gain != 0;
+
+#ifdef SVOH_PK_STAMPS
+  const long long ts0 = clock64(); long long tsA1 = ts0, tsA2 = ts0, tsE0 = ts0, tsE1 = ts0;
+  long long tsg[3] = { 0, 0, 0 };
+#endif
+  // the seed's inputs: from its sorted record, or straight from the caller's arrays
+  int i = slot_i, ri = 0, ci = 0, level = 0, type = 0;
+  double pxr = 0.0, pyr = 0.0, gx = 0.0, gy = 0.0;
+  if (live) {
+    if (rec_in) {
+      const SeedRecIn& r = rec_in[slot_i];
+      pxr = r.px[0]; pyr = r.px[1]; gx = r.grad[0]; gy = r.grad[1];
+      ri = r.ri; ci = r.ci; level = r.level; type = r.type; i = r.index;
+    } else {
+      pxr = a.px[2 * i]; pyr = a.px[2 * i + 1]; gx = a.grad[2 * i]; gy = a.grad[2 * i + 1];
+      ri = a.ref_frame_idx[i]; ci = a.cur_frame_idx ? a.cur_frame_idx[i] : 0; level = a.level[i]; type = a.type[i];
+    }
+  }
+  auto load_f = [&]() -> Vec3 {
+    if (rec_in) { const SeedRecIn& r = rec_in[slot_i]; return Vec3{ r.f[0], r.f[1], r.f[2] }; }
+    return Vec3{ a.f[3 * i], a.f[3 * i + 1], a.f[3 * i + 2] };
+  };
+  auto load_state = [&](double (&st)[4]) {
+    if (rec_in) { const SeedRecIn& r = rec_in[slot_i]; for (int k = 0; k < 4; ++k) st[k] = r.state[k]; }
+    else for (int k = 0; k < 4; ++k) st[k] = a.state[4 * i + k];
+  };
+
+  // ---- phase A: one lane per seed, up to the refinement ----
+  // code: kMatchRefinePending / kMatchTriangulatePending / a final svoh_match_result / kNotRun
+  constexpr int kNotRun = -2000;
+  int code = kNotRun;
+  int search_level = 0;
+  bool reject = false;
+  int n_warp = 0, n_zmssd = 0;
+  double px_cur0 = 0.0, px_cur1 = 0.0;
+  const bool indices_ok = live && (unsigned)ri < (unsigned)a.n_ref_frames && (unsigned)ci < (unsigned)a.n_cur_frames &&
+                          level >= 0 && level < a.ref_frames[(unsigned)ri < (unsigned)a.n_ref_frames ? ri : 0].n_levels;
+  if (indices_ok) {
+    const DevFrameView& ref = a.ref_frames[ri];
+    const DevFrameView& cur = a.cur_frame[ci];
+    bool run = type < 6 && cur.id != ref.id && type != SVOH_FT_OUTLIER;
+    if ((type == SVOH_FT_CORNER_SEED_CONVERGED || type == SVOH_FT_EDGELET_SEED_CONVERGED ||
+         type == SVOH_FT_MAPPOINT_SEED_CONVERGED) && a.dopt.check_convergence)
+      run = false;
+    if (run) {
+      double st[4];
+      load_state(st);
+      const double st0 = st[0], st1 = st[1];
+      const Vec3 f = load_f();
+      const Rigid T_cur_ref = T_cur_ref_of(ref, cur);
+      if (a.dopt.check_visibility) {
+        const double depth = 1.0 / st0;
+        const Vec3 p = { depth * f.x, depth * f.y, depth * f.z };
+        double px, py;
+        project3(cur.cam, transform(T_cur_ref, p), px, py);
+        if (!(px >= 0.0 && py >= 0.0 && px < (double)cur.cam.width && py < (double)cur.cam.height)) run = false;
+        else {
+          const int pxi0 = (int)px, pxi1 = (int)py;
+          const int boundary = 9;
+          if (!(pxi0 >= boundary && pxi1 >= boundary && pxi0 < cur.cam.width - boundary && pxi1 < cur.cam.height - boundary)) run = false;
+        }
+      }
+      if (run) {
+        MatcherState m;
+        m.pwb = s_pwb + tid * kPwbStride;
+        m.sub = 0;
+        m.h_inv = 0.0; m.search_level = 0; m.reject = false;
+        m.n_warp = 0; m.n_zmssd = 0; m.n_align_it = 0;
+        m.align_1d = (type == SVOH_FT_EDGELET_SEED || type == SVOH_FT_EDGELET_SEED_CONVERGED);
+        m.A[0] = m.A[1] = m.A[2] = m.A[3] = 0.0;
+        m.px_cur[0] = m.px_cur[1] = 0.0;
+        m.f_cur = { 0.0, 0.0, 0.0 };
+#ifdef SVOH_SEED_STAMPS
+        m.t[0] = m.t[1] = m.t[2] = m.t[3] = 0; m.tlast = clock64();
+#endif
+        const double inv_min = st0 + sqrt(st1);
+        const double inv_max = fmax(st0 - sqrt(st1), 0.00000001);
+        code = epipolar_match_search<2>(m, a.mopt, ref, cur, T_cur_ref, pxr, pyr, f, gx, gy, level, type, st0, inv_min, inv_max);
+        search_level = m.search_level; reject = m.reject;
+        n_warp = m.n_warp; n_zmssd = m.n_zmssd;
+#if defined(SVOH_PK_STAMPS) && defined(SVOH_SEED_STAMPS)
+        tsg[0] = m.t[0]; tsg[1] = m.t[1]; tsg[2] = m.t[2];
+#endif
+        px_cur0 = m.px_cur[0]; px_cur1 = m.px_cur[1];
+        if (a.search_level) a.search_level[i] = m.search_level;
+        if (a.A_cur_ref) for (int k = 0; k < 4; ++k) a.A_cur_ref[4 * i + k] = m.A[k];
+#ifdef SVOH_PK_STAMPS
+        tsA1 = clock64();
+#endif
+        if (code == kMatchRefinePending) {
+          // the refinement (feature_alignment.cpp:31-209 / 212-391) is phase E's job
+          s_u[tid] = (float)(m.px_cur[0] / (1 << m.search_level));
+          s_v[tid] = (float)(m.px_cur[1] / (1 << m.search_level));
+          if (m.align_1d) { s_dir[2 * tid] = m.epi_dir[0]; s_dir[2 * tid + 1] = m.epi_dir[1]; }
+          const int kind = m.align_1d ? 1 : 0;
+          const int j = atomicAdd(&s_qn[kind], 1);
+          s_q[kind][j] = (unsigned short)tid;
+        }
+      }
+    }
+  }
+  // every lane leaves (cur frame, search level) of its slot where the job's lane finds them
+  s_stat[tid] = (ci << 8) | search_level;
+#ifdef SVOH_PK_STAMPS
+  tsA2 = clock64();
+#endif
+  __syncthreads();
+#ifdef SVOH_PK_STAMPS
+  tsE0 = tsE1 = clock64();
+#endif
+
+  // ---- phase E: the refinements, eight lanes per job, eight jobs of one kind per wave and round ----
+  {
+    const int lane = tid & 63, sub = lane & 7;
+    int kind = (tid >> 6) & 1;          // waves start on different queues and move to the other one when theirs is empty
+    int tried = 0;
+    while (tried < 2) {
+      int slot = -1;
+      if (sub == 0) {
+        const int j = atomicAdd(&s_qh[kind], 1);
+        if (j < s_qn[kind]) slot = s_q[kind][j];
+      }
+      slot = __shfl(slot, 0, 8);
+      if (__ballot(slot >= 0) == 0) { kind ^= 1; ++tried; continue; }
+      if (slot >= 0) {
+        const int meta = s_stat[slot];
+        const DevImage img = a.cur_frame[meta >> 8].lv[meta & 255];
+        const unsigned char* pwb = s_pwb + slot * kPwbStride;
+        double sx = s_u[slot], sy = s_v[slot];
+        int n_it = 0;
+        bool aligned;
+        if (kind == 1) {
+          double h_inv_unused;
+          aligned = align_1d_g8(img, s_dir[2 * slot], s_dir[2 * slot + 1], pwb, a.mopt.align_max_iter, est_offset, est_gain, sx, sy,
+                                &h_inv_unused, n_it, sub);
+        } else {
+          aligned = align_2d_g8(img, pwb, a.mopt.align_max_iter, est_offset, est_gain, sx, sy, n_it, sub);
+        }
+        if (sub == 0) {
+          s_u[slot] = (float)sx; s_v[slot] = (float)sy;      // align1D / 2D hand back px = u, py = v (floats)
+          s_res[slot] = (n_it << 8) | (aligned ? 1 : 0);
+        }
+      }
+    }
+#ifdef SVOH_PK_STAMPS
+    tsE1 = clock64();
+#endif
+  }
+  __syncthreads();
+
+  // ---- phase F: one lane per seed: triangulation, tau, filter update, outputs ----
+  if (!live) return;
+  double st[4] = { 0.0, 0.0, 0.0, 0.0 };
+  int out_type = type, out_success = 0, out_result = SVOH_MATCH_NOT_RUN;
+  unsigned counts[4] = { 0u, 0u, 0u, 0u };
+  bool state_changed = false;
+  if (rec_out || code != kNotRun) load_state(st);
+  if (code != kNotRun) {
+    int res = code;
+    int n_align_it = 0;
+    Vec3 f_cur = { 0.0, 0.0, 0.0 };
+    const DevFrameView& ref = a.ref_frames[ri];
+    const DevFrameView& cur = a.cur_frame[ci];
+    const Vec3 f = load_f();
+    const Rigid T_cur_ref = T_cur_ref_of(ref, cur);
+    double depth = 0.0;
+    if (code == kMatchRefinePending || code == kMatchTriangulatePending) {
+      MatcherState m;
+      m.search_level = search_level;
+      m.px_cur[0] = px_cur0; m.px_cur[1] = px_cur1;
+      bool aligned = false;
+      double sx = 0.0, sy = 0.0;
+      if (code == kMatchRefinePending) {
+        const int r = s_res[tid];
+        n_align_it = r >> 8;
+        aligned = (r & 1) != 0;
+        sx = s_u[tid]; sy = s_v[tid];
+      }
+      res = epipolar_match_finish(m, cur, T_cur_ref, f, code == kMatchRefinePending, aligned, sx, sy, depth);
+      px_cur0 = m.px_cur[0]; px_cur1 = m.px_cur[1];
+      f_cur = m.f_cur;
+    }
+    out_result = res;
+    if (a.px_cur) { a.px_cur[2 * i] = px_cur0; a.px_cur[2 * i + 1] = px_cur1; }
+    if (a.f_cur) { a.f_cur[3 * i] = f_cur.x; a.f_cur[3 * i + 1] = f_cur.y; a.f_cur[3 * i + 2] = f_cur.z; }
+    counts[0] = (unsigned)n_warp; counts[1] = (unsigned)n_zmssd; counts[2] = (unsigned)n_align_it;
+    counts[3] = res == SVOH_MATCH_SUCCESS ? 1u : 0u;
+    if (res != SVOH_MATCH_SUCCESS) {
+      if (!reject) { st[3] = st[3] + 1; state_changed = true; }  // seed::increaseOutlierProbability
+    } else {
+      double cur_thresh = a.dopt.seed_convergence_sigma2_thresh;
+      if (type == SVOH_FT_MAPPOINT_SEED || type == SVOH_FT_MAPPOINT_SEED_CONVERGED)
+        cur_thresh = a.dopt.mappoint_convergence_sigma2_thresh;
+      const double depth_sigma = compute_tau(inverse(T_cur_ref), f, depth, a.dopt.px_error_angle);
+      const double z = 1.0 / depth;
+      const double sg = 0.5 * (1.0 / fmax(0.000000000001, depth - depth_sigma) - 1.0 / (depth + depth_sigma));
+      const double tau2 = sg * sg;
+      bool ok;
+      if (a.dopt.use_vogiatzis_update) ok = update_filter_vogiatzis(z, tau2, ref.seed_mu_range, st);
+      else ok = update_filter_gaussian(z, tau2, st);
+      state_changed = true;
+      if (!ok) out_type = SVOH_FT_OUTLIER;
+      else {
+        const double thresh = ref.seed_mu_range / cur_thresh;
+        if (st[1] < thresh * thresh) {
+          if (type == SVOH_FT_CORNER_SEED) out_type = SVOH_FT_CORNER_SEED_CONVERGED;
+          else if (type == SVOH_FT_EDGELET_SEED) out_type = SVOH_FT_EDGELET_SEED_CONVERGED;
+          else if (type == SVOH_FT_MAPPOINT_SEED) out_type = SVOH_FT_MAPPOINT_SEED_CONVERGED;
+        }
+        out_success = 1;
+      }
+    }
+  }
+#ifdef SVOH_PK_STAMPS
+  {  // diagnostic build: cycles / 16 in search (geometry, warp, scan), refinement set-up, job loop (participating waves), whole kernel
+    const long long tsF = clock64();
+    counts[0] = (unsigned)((tsA1 - ts0) >> 4); counts[1] = (unsigned)((tsA2 - tsA1) >> 4);
+    counts[2] = (unsigned)((tsE1 - tsE0) >> 4); counts[3] = (unsigned)((tsF - ts0) >> 4);
+#ifdef SVOH_SEED_STAMPS   // second diagnostic variant: geometry / warp / scan / set-up
+    counts[0] = (unsigned)(tsg[0] >> 4); counts[1] = (unsigned)(tsg[1] >> 4); counts[2] = (unsigned)(tsg[2] >> 4);
+    counts[3] = (unsigned)((tsA2 - tsA1) >> 4);
+#endif
+  }
+#endif
+  if (rec_out) {
+    SeedRecOut o;
+    for (int k = 0; k < 4; ++k) { o.state[k] = st[k]; o.counts[k] = counts[k]; }
+    o.result = out_result; o.type = out_type; o.success = out_success; o.pad = 0;
+    rec_out[slot_i] = o;
+  } else {
+    a.success[i] = (uint8_t)out_success;
+    if (a.result) a.result[i] = out_result;
+    reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(counts[0], counts[1], counts[2], counts[3]);
+    if (state_changed) for (int k = 0; k < 4; ++k) a.state[4 * i + k] = st[k];
+    if (out_type != type) a.type[i] = (uint8_t)out_type;
+  }
+}
+
 // n x Matcher::findEpipolarMatchDirect with an explicit T_cur_ref (matcher.cpp:157-241), align_1d = isEdgelet(type):
 // the call StereoTriangulation::compute makes per new feature (stereo_triangulation.cpp:92-104)
 template <bool G8>
@@ -1350,6 +1823,12 @@ __global__ __launch_bounds__(64) void epipolar_match_kernel(const MatcherArgs a)
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+
+static int getenv_int_m(const char* name, int dflt)
+{
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 
 static int fill_view(svoh_ctx* ctx, const svoh_frame_view& v, DevFrameView* out, const char* what)
 {
@@ -1520,9 +1999,11 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   }
   // small batches: eight lanes per unit (a launch is as slow as its slowest lane, and eight lanes get a unit done
   // ~3x sooner); large batches: one lane per unit (fewer instructions per unit).  SVOH_MATCHER_G8=0/1 forces it.
-  int g8 = n <= kG8MaxUnits ? 1 : 0;
-  if (const char* e = getenv("SVOH_MATCHER_G8")) g8 = atoi(e) != 0;
-  const int units_per_block = g8 ? 8 : 64;
+  // geometry: 1 = eight lanes per unit, 0 = one lane per unit, 2 = packed (seed update only; large batches)
+  int g8 = n <= kG8MaxUnits ? 1 : (seeds ? 2 : 0);
+  if (const char* e = getenv("SVOH_MATCHER_G8")) g8 = atoi(e);
+  if (g8 < 0 || g8 > 2 || (g8 == 2 && !seeds)) g8 = 0;
+  const int units_per_block = g8 == 1 ? 8 : 64;
   const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
   {
     unsigned long long* dummy;
@@ -1532,7 +2013,40 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   }
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   if (seeds) {
-    if (g8) hipLaunchKernelGGL(update_seeds_kernel<true>, grid, block, 0, ctx->stream, a);
+    if (g8 == 2) {
+      int max_w = 1, max_h = 1;
+      for (int k = 0; k < n_ref_frames; ++k) { max_w = views[k].lv[0].w > max_w ? views[k].lv[0].w : max_w; max_h = views[k].lv[0].h > max_h ? views[k].lv[0].h : max_h; }
+      const int tiles_x = (max_w + (1 << kBinShiftX) - 1) >> kBinShiftX, tiles_y = (max_h + (1 << kBinShiftY) - 1) >> kBinShiftY;
+      const size_t n_keys = (size_t)n_ref_frames * tiles_x * tiles_y;
+      const SeedRecIn* rec_in = nullptr;
+      SeedRecOut* rec_out = nullptr;
+      const unsigned* pos_of = nullptr;
+      const dim3 gb((unsigned)((n + 255) / 256));
+      if (n_keys <= kBinMaxKeys && getenv_int_m("SVOH_SEED_BINNING", 1) != 0) {
+        // [hist | rank | pos_of | records in (128 B each) | records out (64 B each)]
+        const size_t o_rank = (n_keys * sizeof(unsigned) + 255) & ~(size_t)255;
+        const size_t o_pos = o_rank + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255);
+        const size_t o_in = o_pos + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255);
+        const size_t o_out = o_in + (size_t)n * sizeof(SeedRecIn);
+        SVOH_HIP_TRY(ctx, ctx->d_scratch2.reserve(o_out + (size_t)n * sizeof(SeedRecOut)));
+        uint8_t* base = static_cast<uint8_t*>(ctx->d_scratch2.ptr);
+        unsigned* hist = reinterpret_cast<unsigned*>(base);
+        unsigned* rank = reinterpret_cast<unsigned*>(base + o_rank);
+        unsigned* pos = reinterpret_cast<unsigned*>(base + o_pos);
+        SVOH_HIP_TRY(ctx, hipMemsetAsync(hist, 0, n_keys * sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(seed_bin_count_kernel, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank);
+        hipLaunchKernelGGL(seed_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, (unsigned)n_keys);
+        hipLaunchKernelGGL(seed_bin_scatter_kernel, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank, pos,
+                           reinterpret_cast<SeedRecIn*>(base + o_in));
+        rec_in = reinterpret_cast<const SeedRecIn*>(base + o_in);
+        rec_out = reinterpret_cast<SeedRecOut*>(base + o_out);
+        pos_of = pos;
+      }
+      hipLaunchKernelGGL(update_seeds_packed_kernel, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0,
+                         ctx->stream, a, rec_in, rec_out);
+      if (rec_out) hipLaunchKernelGGL(seed_unsort_kernel, gb, dim3(256), 0, ctx->stream, a, pos_of, static_cast<const SeedRecOut*>(rec_out));
+    }
+    else if (g8) hipLaunchKernelGGL(update_seeds_kernel<true>, grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL(update_seeds_kernel<false>, grid, block, 0, ctx->stream, a);
   } else {
     if (g8) hipLaunchKernelGGL(match_direct_kernel<true>, grid, block, 0, ctx->stream, a);
@@ -1702,7 +2216,7 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
     a.A_cur_ref = reinterpret_cast<double*>(d + o_A);
   }
   int g8 = n <= kG8MaxUnits ? 1 : 0;
-  if (const char* e = getenv("SVOH_MATCHER_G8")) g8 = atoi(e) != 0;
+  if (const char* e = getenv("SVOH_MATCHER_G8")) g8 = atoi(e) == 1;
   const int units_per_block = g8 ? 8 : 64;
   const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
   {

@@ -15,13 +15,16 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["eight_lanes_per_unit", "one_lane_per_unit"], autouse=True)
+@pytest.fixture(params=["eight_lanes_per_unit", "one_lane_per_unit", "packed"], autouse=True)
 def matcher_geometry(request):
-    """The matcher kernels exist in two geometries with bit-identical results: eight lanes per unit (what a small
-    batch gets) and one lane per unit (large batches).  Every test of this file runs through both."""
+    """The matcher kernels exist in three geometries with bit-identical results: eight lanes per unit (what a small
+    batch gets), one lane per unit, and -- for the seed update of large batches -- the packed geometry (one lane per
+    seed for geometry / warp / scan, the refinements as jobs of a workgroup-wide queue; the direct matcher and the
+    plain epipolar match have no packed kernel and run one lane per unit there).  Every test of this file runs
+    through all of them."""
     import os
     old = os.environ.get("SVOH_MATCHER_G8")
-    os.environ["SVOH_MATCHER_G8"] = "1" if request.param == "eight_lanes_per_unit" else "0"
+    os.environ["SVOH_MATCHER_G8"] = {"eight_lanes_per_unit": "1", "one_lane_per_unit": "0", "packed": "2"}[request.param]
     yield request.param
     if old is None:
         os.environ.pop("SVOH_MATCHER_G8", None)
