@@ -41,42 +41,76 @@ def algorithmic_bytes(P, D, patch_iters, n_sel_levels):
     return b_iter * patch_iters + b_pre * n_sel_levels
 
 
-def pmc_traffic(workload_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this very
-    workload (profiles/rNN_summary.json, written by scripts/profile_bench.sh, and rNN_<workload>_pmc_summary.json
-    by scripts/profile_workloads_pmc.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs).  Counters are reported in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B
-    (MI355X_MICROARCH.md, HBM section) and is doubled, WRITE_SIZE is taken as is.  None when no summary for the
-    same workload is committed -- the counters cannot be read from inside the timed process."""
+FP64_PEAK_TFLOPS = 63.8   # measured: tools/svoh_microbench, independent v_fma_f64 on every SIMD (profiles/r02_fetch_calibration.json)
+
+
+def pmc_summary(workload_key):
+    """The committed rocprofv3 counter summary of this very workload (profiles/rNN_<tag>_pmc_summary.json, written by
+    scripts/profile_round.sh + scripts/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE / SQ passes), newest
+    round first; None when there is none -- the counters cannot be read from inside the timed process."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_summary.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload_key", "align:B1024:N2000:P4:L4-0") != workload_key:
-            continue
-        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-            best = (2.0 * d["FETCH_SIZE"]["mean_per_dispatch_KB_as_reported"]
-                    + d["WRITE_SIZE"]["mean_per_dispatch_KB_as_reported"]) * 1024.0
+        if d.get("workload_key") == workload_key and d.get("traffic_bytes_per_step"):
+            d["_file"] = os.path.basename(f)
+            best = d
     return best
 
 
-def build_problems(ctx, dev, rank, B, N, P, max_level):
-    """B synthetic frame pairs rendered on the GPU; returns problems + keepalives."""
+def roofline(kernel, kernel_ms, alg_bytes, workload_key, **extra):
+    """roofline object of the bench line.  `achieved` / `frac` are PHYSICAL: HBM-side bytes per step from the PMC
+    passes of this workload (2 x FETCH_SIZE + WRITE_SIZE, see scripts/pmc_summary.py) over the kernel time measured
+    live, against the 8 TB/s peak.  The SURVEY 8(d) algorithmic figure (bytes the cache-everything formulation would
+    move) is kept beside it as algorithmic_*: it exceeds 1 for kernels that recompute instead of re-reading."""
+    t = kernel_ms * 1e-3
+    alg = alg_bytes / t / 1e9
+    summ = pmc_summary(workload_key)
+    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": kernel,
+         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_achieved": alg, "algorithmic_frac": alg / HBM_PEAK_GBS}
+    if summ:
+        traffic = float(summ["traffic_bytes_per_step"])
+        r.update({"achieved": traffic / t / 1e9, "frac": traffic / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                  "frac_basis": "measured HBM-side traffic (PMC) / live kernel time", "traffic_source": "profiles/" + summ["_file"]})
+        prof_ms = summ.get("kernel_ms_per_step_rocprof") or (summ.get("bench_under_rocprof") or {}).get("kernel_ms")
+        if prof_ms:
+            r["kernel_ms_when_profiled"] = prof_ms
+            r["traffic_stale"] = bool(abs(prof_ms - kernel_ms) > 0.25 * kernel_ms)   # kernel changed since the PMC passes?
+        cs = summ.get("compute_side")
+        if cs:
+            r["compute_side"] = {k: cs[k] for k in cs if k != "counters_mean_per_dispatch"}
+            c = cs.get("counters_mean_per_dispatch", {})
+            if "SQ_INSTS_VALU" in c:
+                r["compute_side"]["valu_wave_instructions_per_launch"] = c["SQ_INSTS_VALU"]
+    else:
+        r.update({"achieved": alg, "frac": alg / HBM_PEAK_GBS, "traffic": None,
+                  "frac_basis": "algorithmic bytes (no PMC summary committed for this workload key)"})
+    r.update(extra)
+    return r
+
+
+def build_problems(ctx, dev, rank, B, N, P, max_level, reuse=None):
+    """B synthetic frame pairs rendered on the GPU; returns problems + keepalives.  reuse = (imgs, frames) of an
+    earlier call with the same B / seeds: the scenes' images do not depend on the patch size, only the features do."""
     cam = synth.Camera.test_camera()
     scenes = [synth.make_align_scene(du.problem_seed(rank, i), n_features=N, patch_size=P, cam=cam,
                                      max_level=max_level, render_images=False) for i in range(B)]
-    poses, planes, texs = [], [], []
-    for sc in scenes:  # image 2i = reference frame, 2i+1 = current frame of pair i
-        poses += [sc.T_w_ref, sc.T_w_cur]
-        planes += [sc.plane, sc.plane]
-        texs += [sc.tex, sc.tex]
-    imgs = synth.render_batch_torch(cam, poses, planes, texs, dev)
-    torch.cuda.synchronize()
-    frames = ctx.build_pyramid_batch_device(imgs.data_ptr(), cam.width * cam.height, 2 * B, cam.width, cam.height,
-                                            cam.width, max_level + 1)
-    ctx.synchronize()
+    if reuse is not None:
+        imgs, frames = reuse
+    else:
+        poses, planes, texs = [], [], []
+        for sc in scenes:  # image 2i = reference frame, 2i+1 = current frame of pair i
+            poses += [sc.T_w_ref, sc.T_w_cur]
+            planes += [sc.plane, sc.plane]
+            texs += [sc.tex, sc.tex]
+        imgs = synth.render_batch_torch(cam, poses, planes, texs, dev)
+        torch.cuda.synchronize()
+        frames = ctx.build_pyramid_batch_device(imgs.data_ptr(), cam.width * cam.height, 2 * B, cam.width, cam.height,
+                                                cam.width, max_level + 1)
+        ctx.synchronize()
     # feature arrays resident in HBM (one buffer per kind)
     px = torch.from_numpy(np.concatenate([s.px for s in scenes])).to(dev)
     f = torch.from_numpy(np.concatenate([s.f for s in scenes])).to(dev)
@@ -272,9 +306,7 @@ def bench_klt(args, ctx, dist, rank, world, dev, comm_dev=None):
                        "frame_pairs_per_gpu": B, "tracks_per_frame": NT},
             "kernel_ms": kms, "converged_fraction": float(ok.mean()),
             "host_staged_tracks_per_s": host_rate,  # same work through svoh_klt_track_multi with host arrays (PCIe-inclusive)
-            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (None if args.problems else pmc_traffic("klt:default")), "kernel": "klt_track_kernel",
-                         "algorithmic_bytes_per_launch": alg, "counters": cnt[:4]},
+            "roofline": roofline("klt_track_kernel", kms, alg, "klt:default" if not args.problems else "klt:B%d" % B, counters=cnt[:4]),
             "cpu_baseline": cpu}
 
 
@@ -368,11 +400,10 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
                                    "<=100 epipolar steps, seed arrays resident in HBM" % (B, NS), "frame_pairs_per_gpu": B, "seeds_per_keyframe": NS},
             "kernel_ms": kms, "success_fraction": float(succ.mean()),
             "host_staged_seed_updates_per_s": host_rate,  # same work with host arrays staged per call (PCIe-inclusive)
-            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (None if args.problems else pmc_traffic("seeds:default")), "kernel": "update_seeds_kernel",
-                         "algorithmic_bytes_per_launch": alg, "counters": cnt[:4],
-                         "unit_tails": {"align_iters_ge5": cnt[4], "align_iters_ge10": cnt[5], "zmssd_ge20": cnt[6],
-                                        "zmssd_ge50": cnt[7]}},
+            "roofline": roofline("update_seeds_packed_kernel (+ seed_bin_count / scan / scatter, seed_unsort: the whole step)", kms,
+                                 alg, "seeds:default" if not args.problems else "seeds:B%d" % B, counters=cnt[:4],
+                                 unit_tails={"align_iters_ge5": cnt[4], "align_iters_ge10": cnt[5], "zmssd_ge20": cnt[6],
+                                             "zmssd_ge50": cnt[7]}),
             "cpu_baseline": cpu}
 
 
@@ -469,10 +500,8 @@ def bench_frame(args, ctx, dist, rank, world, dev, comm_dev=None):
                        "features": NF, "seeds": NS * NKF},
             "stage_ms_median": med, "align_pose_err_vs_gt": {"rot_rad": err[0], "trans_m": err[1]},
             "seed_successes": int(last["seeds"][0]), "klt_converged": int(last["klt"][1].sum()),
-            "roofline": {"bound": "hbm", "achieved": alg / (kms.value * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sparse_align_kernel<4,*,false> (single problem: latency-bound by design)",
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kms.value},
+            "roofline": roofline("sparse_align_kernel<4,*,false> (single problem: latency-bound by design)", kms.value, alg,
+                                 "frame:default", kernel_ms=kms.value),
             "cpu_baseline": cpu}
 
 
@@ -526,10 +555,8 @@ def bench_detect(args, ctx, dist, rank, world, dev, comm_dev=None):
             "config": {"workload": "detector: %d keyframes per step, 752x480, pyramid resident in HBM, one blocking call each" % B,
                        "keyframes_per_step": B},
             "kernel_ms": kms, "features_per_keyframe": last["n"] / float(B),
-            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "fast_score/select + edge_score/select/angle kernels of one keyframe (latency-bound: 9 launches)",
-                         "algorithmic_bytes_per_launch": alg},
+            "roofline": roofline("fast_score/select + edge_score/select/angle kernels of one keyframe (latency-bound: 9 launches)",
+                                 kms, alg, "detect:default"),
             "cpu_baseline": cpu}
 
 
@@ -583,9 +610,7 @@ def bench_pose(args, ctx, dist, rank, world, dev, comm_dev=None):
             "config": {"workload": "pose: %d bundles x 180 features per call, host arrays staged per call" % B, "bundles_per_step": B},
             "kernel_ms": kms, "mean_iterations": iters / float(B), "measurements_per_bundle": meas / float(B),
             "single_bundle_call_ms": single_ms,
-            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (None if args.problems else pmc_traffic("pose:default")), "kernel": "pose_optimize_kernel",
-                         "algorithmic_bytes_per_launch": alg},
+            "roofline": roofline("pose_optimize_kernel", kms, alg, "pose:default" if not args.problems else "pose:B%d" % B),
             "cpu_baseline": cpu}
 
 
@@ -662,9 +687,8 @@ def bench_align_c4(args, ctx, dist, rank, world, dev, comm_dev=None):
             "kernel_ms": kms, "solver_failures": sum(1 for r in res if r.status != 0),
             "illumination_median": {"alpha": float(np.median([r.alpha for r in res])), "beta": float(np.median([r.beta for r in res]))},
             "pose_err_vs_gt": {"rot_rad_median": float(np.median([e[0] for e in errs])), "trans_m_median": float(np.median([e[1] for e in errs]))},
-            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "sparse_align_kernel<%d,*,true>" % P,
-                         "algorithmic_bytes_per_launch": alg},
+            "roofline": roofline("sparse_align_kernel<%d,256,true,false>" % P, kms, alg,
+                                 "align-c4:default" if (not args.problems and N == 1500 and P == 4) else "align-c4:B%d:N%d:P%d" % (B, N, P)),
             "cpu_baseline": None}
 
 
@@ -782,10 +806,8 @@ def bench_align_split(args, ctx, dist, rank, world, dev, comm_dev=None):
                                     "iterations": sum(wres.iters)},
             "pose_err_vs_gt": {"rot_rad": err[0], "trans_m": err[1]},
             "pose_diff_vs_resident": {"rot_rad": dvs[0], "trans_m": dvs[1]},
-            "roofline": {"bound": "hbm", "achieved": alg / (ms_run * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (ms_run * 1e-3) / 1e9 / HBM_PEAK_GBS / world, "traffic": None,
-                         "kernel": "sparse_align_kernel (evaluate mode) + all-reduce + align_gn_update_kernel, whole run",
-                         "algorithmic_bytes_per_launch": alg},
+            "roofline": roofline("sparse_align_kernel (evaluate mode) + all-reduce + align_gn_update_kernel, whole run (per rank)",
+                                 ms_run, alg / world, "align-split:N%d:W%d" % (args.features, world)),
             "cpu_baseline": None}
 
 
@@ -932,8 +954,28 @@ def main(argv=None):
             dist.destroy_process_group()
         return
     P, N, B = args.patch, args.features, (args.problems or 1024)
+    out, shared = run_align(args, ctx, dist, rank, world, dev, comm_dev, P, N, B, None, not args.no_cpu_baseline and world == 1)
+    # the 8x8-patch configuration north_star quotes its roofline target on, carried in the same line (same frame
+    # pairs, same launch shape; its own features because the border margin depends on the patch size)
+    if P == 4 and not args.no_secondary and not args.problems and N == 2000 and args.min_level == 0 and args.max_level == 4:
+        sec, _ = run_align(args, ctx, dist, rank, world, dev, comm_dev, 8, N, B, shared, False, steps=max(3, args.steps // 2))
+        if rank == 0:
+            out["secondary"] = {k: sec[k] for k in ("value", "unit", "kernel_ms", "ms_per_step", "patch_iterations_per_step",
+                                                    "patch_iterations_per_s", "solver_failures", "roofline")}
+            out["secondary"]["config"] = sec["config"]
+            out["secondary"]["steps"] = max(3, args.steps // 2)
+    if rank == 0:
+        emit(out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_align(args, ctx, dist, rank, world, dev, comm_dev, P, N, B, shared, with_cpu, steps=None):
+    """The headline workload at patch size P: W warm-up + K timed steps of one launch over B frame pairs."""
+    steps = steps or args.steps
     opt = capi.default_align_options(max_level=args.max_level, min_level=args.min_level, patch_size=P)
-    problems, scenes, imgs, keep = build_problems(ctx, dev, rank, B, N, P, args.max_level)
+    problems, scenes, imgs, keep = build_problems(ctx, dev, rank, B, N, P, args.max_level, reuse=shared)
 
     def barrier():
         ctx.synchronize()
@@ -948,17 +990,26 @@ def main(argv=None):
     barrier()
     # K steps queued back to back on the context stream: each enqueue builds and uploads its launch descriptors
     # while the previous step's kernel runs, and every step's results are copied to pinned host memory behind its
-    # kernel; one fetch hands out the last step's.  Kernel times come from the library's per-launch HIP events.
+    # kernel; a fetch hands out the last step's (one every 32 steps: the library keeps 32 event pairs and a bounded
+    # number of queued results).  Kernel times come from the library's per-launch HIP events.
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.sparse_align_enqueue(opt, problems)
-    res = ctx.sparse_align_fetch(len(problems))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    n_hist = ctypes.c_int()
+    kernel_ms_sum, n_timed = 0.0, 0
     hist = (ctypes.c_float * 32)()
-    ctx._check(ctx.lib.svoh_sparse_align_kernel_ms_history(ctx.h, min(32, args.steps), hist, ctypes.byref(n_hist)))
-    kernel_ms_sum = sum(hist[i] for i in range(n_hist.value)) * (args.steps / float(max(1, n_hist.value)))
+    n_hist = ctypes.c_int()
+    done = 0
+    while done < steps:
+        chunk = min(32, steps - done)
+        for _ in range(chunk):
+            ctx.sparse_align_enqueue(opt, problems)
+        res = ctx.sparse_align_fetch(len(problems))
+        done += chunk
+        if done >= steps:
+            barrier()
+            elapsed = time.perf_counter() - t0
+        ctx._check(ctx.lib.svoh_sparse_align_kernel_ms_history(ctx.h, chunk, hist, ctypes.byref(n_hist)))
+        kernel_ms_sum += sum(hist[i] for i in range(n_hist.value))
+        n_timed += n_hist.value
+    kernel_ms_sum *= steps / float(max(1, n_timed))
 
     # latency of ONE frame pair of the same workload (outside the timed region): what a single camera stream sees
     one_arr = (capi.svoh_align_problem * 1)(problems[0])
@@ -981,23 +1032,24 @@ def main(argv=None):
     # accuracy against the synthetic ground truth (informational)
     errs = [synth.se3_error(synth.SE3.from7(fe.se3_to_numpy(r.T_icur_iref)), sc.T_icur_iref_gt)
             for r, sc in zip(res, scenes)]
-    value = patches_total * args.steps / elapsed
-
+    value = patches_total * steps / elapsed
+    out = None
     if rank == 0:
-        kernel_ms = kernel_ms_sum / args.steps
+        kernel_ms = kernel_ms_sum / steps
         D = 6
         alg = algorithmic_bytes(P, D, patch_iters, n_sel * n_levels)
-        achieved = alg / (kernel_ms * 1e-3) / 1e9
-        traffic = pmc_traffic("align:B%d:N%d:P%d:L%d-%d" % (B, N, P, args.max_level, args.min_level))
         out = {
             "metric": "aligned patches/sec + ms/frame, EuRoC 640x480 mono, 1/2/4/8 MI355X",
             "value": value,
             "unit": "aligned patches/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "ms_per_frame": 1e3 * elapsed / args.steps / B,
+            "ms_per_step": 1e3 * elapsed / steps,
+            # batch-amortised: one step aligns B frame pairs at once; the latency ONE frame pair sees is
+            # one_frame_pair_latency_ms below (and the whole per-frame chain: bench.py --workload frame)
+            "ms_per_frame": 1e3 * elapsed / steps / B,
+            "ms_per_frame_is": "ms_per_step / frame pairs per step (throughput of a multi-stream batch, not a latency)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -1011,8 +1063,11 @@ def main(argv=None):
                 "levels": [args.max_level, args.min_level], "parallelism": "frame-pairs sharded x%d, no collective" % world,
             },
             "patch_iterations_per_step": patch_iters,
-            "patch_iterations_per_s": patch_iters * world * args.steps / elapsed,
+            "patch_iterations_per_s": patch_iters * world * steps / elapsed,
             "kernel_ms": kernel_ms,
+            # median 1e-4 m: what Gauss-Newton on bilinearly rendered 640x480 scenes resolves; the tail (max) belongs to
+            # scenes with little texture under the patches -- the algorithm's answer, not the kernel's: GPU and oracle
+            # agree to 1e-15 on every one of them (tests/test_sparse_align_gpu.py)
             "pose_err_vs_gt": {"rot_rad_median": float(np.median([e[0] for e in errs])),
                                "trans_m_median": float(np.median([e[1] for e in errs])),
                                "rot_rad_max": float(np.max([e[0] for e in errs])),
@@ -1020,21 +1075,14 @@ def main(argv=None):
             "solver_failures": n_bad,
             "one_frame_pair_latency_ms": {"blocking_call": float(np.median(lat_call)), "kernel": float(np.median(lat_kern)),
                                           "note": "one problem of the same workload, several workgroups per problem"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         # the measured bytes over the same time: what the kernel really asks of HBM (frac above counts
-                         # the algorithmic bytes of the cache-everything formulation, which this kernel does not move)
-                         "traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "kernel": "sparse_align_kernel<%d,*,false>" % P,
-                         "algorithmic_bytes_per_launch": alg},
+            "roofline": roofline("sparse_align_kernel<%d,256,false,false>" % P, kernel_ms, alg,
+                                 "align:B%d:N%d:P%d:L%d-%d" % (B, N, P, args.max_level, args.min_level),
+                                 patch_iterations=patch_iters,
+                                 fp64_note="fp64 vector peak measured %.1f TFLOP/s (tools/svoh_microbench)" % FP64_PEAK_TFLOPS),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if with_cpu:
             out["cpu_baseline"] = cpu_baseline(scenes, imgs, opt, args.max_level)
-        emit(out)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out, (imgs, keep[5])
 
 
 if __name__ == "__main__":

@@ -350,6 +350,8 @@ void orc_back_project3(const svoh_camera* cam, const double kp[2], double f[3])
 /* a-2  Eigen 3.4 LDLT (Lower, unblocked, diagonal pivoting) + solve        */
 /* ======================================================================== */
 
+extern int g_orc_ldlt_mode;   /* svo_oracle_matcher.c: orc_set_third_party_modes */
+
 int orc_ldlt_solve(int n, const double* H, const double* g, double* dx)
 {
   double m[64];
@@ -381,6 +383,24 @@ int orc_ldlt_solve(int n, const double* H, const double* g, double* dx)
     const int rs = n - k - 1;
     if (k > 0) {
       for (int c = 0; c < k; ++c) temp[c] = M(c, c) * M(k, c);
+      if (g_orc_ldlt_mode == 1) {
+        /* sensitivity mode: the same sums taken as a two-lane packet reduction (even + odd partial sums, then the
+         * tail), the order a vectorised dot product would use -- same real numbers, other rounding */
+        double pe = 0.0, po = 0.0;
+        int c = 0;
+        for (; c + 1 < k; c += 2) { pe += M(k, c) * temp[c]; po += M(k, c + 1) * temp[c + 1]; }
+        double acc = pe + po;
+        if (c < k) acc += M(k, c) * temp[c];
+        M(k, k) -= acc;
+        for (int r = 0; r < rs; ++r) {
+          double qe = 0.0, qo = 0.0;
+          int cc = 0;
+          for (; cc + 1 < k; cc += 2) { qe += M(k + 1 + r, cc) * temp[cc]; qo += M(k + 1 + r, cc + 1) * temp[cc + 1]; }
+          double a = qe + qo;
+          if (cc < k) a += M(k + 1 + r, cc) * temp[cc];
+          M(k + 1 + r, k) -= a;
+        }
+      } else {
       double acc = 0.0;
       for (int c = 0; c < k; ++c) acc += M(k, c) * temp[c];
       M(k, k) -= acc;
@@ -388,6 +408,7 @@ int orc_ldlt_solve(int n, const double* H, const double* g, double* dx)
         double a = 0.0;
         for (int c = 0; c < k; ++c) a += M(k + 1 + r, c) * temp[c];
         M(k + 1 + r, k) -= a;
+      }
       }
     }
     const double akk = M(k, k);

@@ -188,8 +188,69 @@ static float cofactor4(const float* m, int i, int j)
   const int j1 = (j + 1) % 4, j2 = (j + 2) % 4, j3 = (j + 3) % 4;
   return det3_helper(m, i1, i2, i3, j1, j2, j3) + det3_helper(m, i2, i3, i1, j1, j2, j3) + det3_helper(m, i3, i1, i2, j1, j2, j3);
 }
+/* ---- sensitivity mode: Eigen 3.4's VECTORISED 4x4 float inverse -----------------------------------------------
+ * The reference's x86 build takes Eigen/src/LU/arch/InverseSize4.h (compute_inverse_size4<Architecture::Target,
+ * float, ...>: the 2x2 block formula of Intel's AP-928 note in Eigen's generic packet operations) instead of the
+ * scalar cofactor path restated above.  Restated here from the published Eigen 3.4.0 source, packets as float[4]:
+ *   input = [[A, B], [C, D]] (2x2 blocks), AB = A# B, DC = D# C (# = adjugate), det = |A||D| + |B||C| - tr(AB DC),
+ *   iA = A|D| - B DC, iD = D|A| - C AB, iB = C|B| - D AB#, iC = B|C| - A DC#, all times (+,-,-,+)/det.
+ * Same real-number result, different rounding: orc_set_third_party_modes(1, x) switches to it so that the number
+ * of result codes / iteration counts that depend on the choice can be counted (tests/golden/eigen_sensitivity.json). */
+static int g_inv4_mode = 0;   /* 0 = generic cofactor path, 1 = vectorised block formula */
+int g_orc_ldlt_mode = 0;      /* used by svo_oracle.c: 0 = sequential sums, 1 = packet-of-two partial sums */
+void orc_set_third_party_modes(int inverse4_mode, int ldlt_mode) { g_inv4_mode = inverse4_mode; g_orc_ldlt_mode = ldlt_mode; }
+
+typedef struct { float v[4]; } pk4;
+static pk4 pk_swz(pk4 a, pk4 b, int p, int q, int r, int s) { pk4 o = { { a.v[p], a.v[q], b.v[r], b.v[s] } }; return o; }  /* vec4f_swizzle2 */
+static pk4 pk_movelh(pk4 a, pk4 b) { pk4 o = { { a.v[0], a.v[1], b.v[0], b.v[1] } }; return o; }
+static pk4 pk_movehl(pk4 a, pk4 b) { pk4 o = { { b.v[2], b.v[3], a.v[2], a.v[3] } }; return o; }
+static pk4 pk_dup(pk4 a, int p) { pk4 o = { { a.v[p], a.v[p], a.v[p], a.v[p] } }; return o; }
+static pk4 pk_mul(pk4 a, pk4 b) { pk4 o; for (int k = 0; k < 4; ++k) o.v[k] = a.v[k] * b.v[k]; return o; }
+static pk4 pk_add(pk4 a, pk4 b) { pk4 o; for (int k = 0; k < 4; ++k) o.v[k] = a.v[k] + b.v[k]; return o; }
+static pk4 pk_sub(pk4 a, pk4 b) { pk4 o; for (int k = 0; k < 4; ++k) o.v[k] = a.v[k] - b.v[k]; return o; }
+
+static void mat4f_inverse_vectorised(const float m[16] /*row-major*/, float r[16])
+{
+  /* Eigen's Matrix4f is column-major: packet L_k = column k; source and result orders match (movelh / movehl branch) */
+  pk4 L1, L2, L3, L4;
+  for (int k = 0; k < 4; ++k) { L1.v[k] = m[k * 4 + 0]; L2.v[k] = m[k * 4 + 1]; L3.v[k] = m[k * 4 + 2]; L4.v[k] = m[k * 4 + 3]; }
+  const pk4 A = pk_movelh(L1, L2), B = pk_movehl(L2, L1), C = pk_movelh(L3, L4), D = pk_movehl(L4, L3);
+  pk4 AB = pk_mul(pk_swz(A, A, 3, 3, 0, 0), B);
+  AB = pk_sub(AB, pk_mul(pk_swz(A, A, 1, 1, 2, 2), pk_swz(B, B, 2, 3, 0, 1)));
+  pk4 DC = pk_mul(pk_swz(D, D, 3, 3, 0, 0), C);
+  DC = pk_sub(DC, pk_mul(pk_swz(D, D, 1, 1, 2, 2), pk_swz(C, C, 2, 3, 0, 1)));
+  pk4 dA = pk_mul(pk_swz(A, A, 3, 3, 1, 1), A); dA = pk_sub(dA, pk_movehl(dA, dA));
+  pk4 dB = pk_mul(pk_swz(B, B, 3, 3, 1, 1), B); dB = pk_sub(dB, pk_movehl(dB, dB));
+  pk4 dC = pk_mul(pk_swz(C, C, 3, 3, 1, 1), C); dC = pk_sub(dC, pk_movehl(dC, dC));
+  pk4 dD = pk_mul(pk_swz(D, D, 3, 3, 1, 1), D); dD = pk_sub(dD, pk_movehl(dD, dD));
+  pk4 d = pk_mul(pk_swz(DC, DC, 0, 2, 1, 3), AB);
+  d = pk_add(d, pk_movehl(d, d));
+  d = pk_add(d, pk_swz(d, d, 1, 0, 0, 0));
+  const pk4 d1 = pk_mul(dA, dD), d2 = pk_mul(dB, dC);
+  const pk4 det = pk_dup(pk_sub(pk_add(d1, d2), d), 0);
+  pk4 rd;
+  for (int k = 0; k < 4; ++k) rd.v[k] = 1.0f / det.v[k];
+  pk4 iD = pk_mul(pk_swz(C, C, 0, 0, 2, 2), pk_movelh(AB, AB));
+  iD = pk_add(iD, pk_mul(pk_swz(C, C, 1, 1, 3, 3), pk_movehl(AB, AB)));
+  iD = pk_sub(pk_mul(D, pk_dup(dA, 0)), iD);
+  pk4 iA = pk_mul(pk_swz(B, B, 0, 0, 2, 2), pk_movelh(DC, DC));
+  iA = pk_add(iA, pk_mul(pk_swz(B, B, 1, 1, 3, 3), pk_movehl(DC, DC)));
+  iA = pk_sub(pk_mul(A, pk_dup(dD, 0)), iA);
+  pk4 iB = pk_mul(D, pk_swz(AB, AB, 3, 0, 3, 0));
+  iB = pk_sub(iB, pk_mul(pk_swz(D, D, 1, 0, 3, 2), pk_swz(AB, AB, 2, 1, 2, 1)));
+  iB = pk_sub(pk_mul(C, pk_dup(dB, 0)), iB);
+  pk4 iC = pk_mul(A, pk_swz(DC, DC, 3, 0, 3, 0));
+  iC = pk_sub(iC, pk_mul(pk_swz(A, A, 1, 0, 3, 2), pk_swz(DC, DC, 2, 1, 2, 1)));
+  iC = pk_sub(pk_mul(B, pk_dup(dC, 0)), iC);
+  rd.v[1] = -rd.v[1]; rd.v[2] = -rd.v[2];    /* sign mask (+, -, -, +) */
+  iA = pk_mul(iA, rd); iB = pk_mul(iB, rd); iC = pk_mul(iC, rd); iD = pk_mul(iD, rd);
+  const pk4 c0 = pk_swz(iA, iB, 3, 1, 3, 1), c1 = pk_swz(iA, iB, 2, 0, 2, 0), c2 = pk_swz(iC, iD, 3, 1, 3, 1), c3 = pk_swz(iC, iD, 2, 0, 2, 0);
+  for (int k = 0; k < 4; ++k) { r[k * 4 + 0] = c0.v[k]; r[k * 4 + 1] = c1.v[k]; r[k * 4 + 2] = c2.v[k]; r[k * 4 + 3] = c3.v[k]; }   /* column j of the result */
+}
+
 static void mat4f_inverse(const float m[16] /*row-major*/, float r[16])
 {
+  if (g_inv4_mode == 1) { mat4f_inverse_vectorised(m, r); return; }
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
       const float c = cofactor4(m, i, j);
@@ -968,4 +1029,13 @@ int orc_stereo_triangulate(const orc_frame_view* frame0, const orc_frame_view* f
     if (n_succeeded >= n_desired) break;
   }
   return n_succeeded;
+}
+
+/* test hook: Matrix4f::inverse() in the given mode (row-major in and out) */
+void orc_mat4f_inverse(const float m[16], float r[16], int mode)
+{
+  const int old = g_inv4_mode;
+  g_inv4_mode = mode;
+  mat4f_inverse(m, r);
+  g_inv4_mode = old;
 }

@@ -244,12 +244,18 @@ __device__ __forceinline__ void projection_jacobian(const Vec3& xyz_ref, const R
 // GONLY: the unweighted Hessian of a level does not change while the set of visible patches does not (inverse
 // compositional: the Jacobians are those of the reference patch), so later iterations only need the moments
 // against the residual -- Sxr Syr Srr [SIr Sr] -- i.e. the gradient and chi2.
-template <int P, int D, bool RLDS, bool CLDS, bool GONLY = false>
-__device__ __forceinline__ void patch_moments(
+// PH x PW: the rows and columns of the (sub-)patch this call covers.  An 8x8 patch is taken as two 8x4 column
+// halves (patch_moments below): the rolling window is (PW+2) wide, and the three interpolated rows, the raw rows and
+// the current rows of a 10-wide window are what pushed the 8x8 kernel 200-400 registers over the budget
+// (.vgpr_spill_count 209 / 436 in round 1).  The halves add into the same moments; the two window columns they
+// share are interpolated twice.
+template <int PH, int PW, int D, bool RLDS, bool CLDS, bool GONLY, bool ZERO>
+__device__ __forceinline__ void patch_moments_part(
     const ImgView<RLDS>& ref, const ImgView<CLDS>& cur, int ru, int rv, double rsu, double rsv, int cu, int cv,
     double csu, double csv, double one_plus_alpha, double beta, bool robust, float weight_scale,
     double (&mom)[AccLayout<D>::NMOM])
 {
+  constexpr int P = PW;      // width of this call's window
   constexpr int WB = P + 2;
   // bilinear weights (sparse_img_align.cpp:355-360 and :456-461)
   const double rwtl = (1.0 - rsu) * (1.0 - rsv), rwtr = rsu * (1.0 - rsv);
@@ -259,8 +265,10 @@ __device__ __forceinline__ void patch_moments(
 
   const int roff = rv * ref.pitch + ru;
   const int coff = cv * cur.pitch + cu;
+  if constexpr (ZERO) {
 #pragma unroll
-  for (int k = 0; k < AccLayout<D>::NMOM; ++k) mom[k] = 0.0;
+    for (int k = 0; k < AccLayout<D>::NMOM; ++k) mom[k] = 0.0;
+  }
 
   // rolling window: three interpolated reference rows (up / centre / down) and
   // two raw current rows; one new row of each per output row
@@ -307,7 +315,7 @@ __device__ __forceinline__ void patch_moments(
   // next row's LDS / L2 reads overlap this row's arithmetic (1.64 -> 1.59 ms on the headline config)
   constexpr int kRowUnroll = GONLY ? SVOH_ROW_UNROLL_GONLY : SVOH_ROW_UNROLL;
 #pragma unroll kRowUnroll
-  for (int y = 0; y < P; ++y) {
+  for (int y = 0; y < PH; ++y) {
     const int rrow = roff + (y + 3) * ref.pitch;
     const int crow = coff + (y + 1) * cur.pitch;
 #pragma unroll
@@ -315,7 +323,7 @@ __device__ __forceinline__ void patch_moments(
     if constexpr (!RLDS && !CLDS) {
       ImgView<false>::unpack<WB + 1>(pref_r, rawB);
       ImgView<false>::unpack<P + 1>(pref_c, curB);
-      if (y + 1 < P) {   // request the rows of the next output row now (they are inside the footprint)
+      if (y + 1 < PH) {   // request the rows of the next output row now (they are inside the footprint)
         ref.template fetch<WB + 1>(rrow + ref.pitch, pref_r);
         cur.template fetch<P + 1>(crow + cur.pitch, pref_c);
       }
@@ -381,6 +389,23 @@ __device__ __forceinline__ void patch_moments(
         mom[14] += wr;             // Sr
       }
     }
+  }
+}
+
+template <int P, int D, bool RLDS, bool CLDS, bool GONLY = false>
+__device__ __forceinline__ void patch_moments(
+    const ImgView<RLDS>& ref, const ImgView<CLDS>& cur, int ru, int rv, double rsu, double rsv, int cu, int cv,
+    double csu, double csv, double one_plus_alpha, double beta, bool robust, float weight_scale,
+    double (&mom)[AccLayout<D>::NMOM])
+{
+  if constexpr (P == 8) {
+    patch_moments_part<8, 4, D, RLDS, CLDS, GONLY, true>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta,
+                                                         robust, weight_scale, mom);
+    patch_moments_part<8, 4, D, RLDS, CLDS, GONLY, false>(ref, cur, ru + 4, rv, rsu, rsv, cu + 4, cv, csu, csv, one_plus_alpha,
+                                                          beta, robust, weight_scale, mom);
+  } else {
+    patch_moments_part<P, P, D, RLDS, CLDS, GONLY, true>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta,
+                                                         robust, weight_scale, mom);
   }
 }
 
