@@ -134,6 +134,16 @@ int svoh_frame_info(svoh_ctx* ctx, svoh_frame_t frame, int* n_levels,
                     int* width0, int* height0);
 int svoh_release_frame(svoh_ctx* ctx, svoh_frame_t frame);
 
+/* What the context holds on the device right now: live frame handles, bytes of the frame
+ * slabs they keep alive, bytes of the grow-only workspaces.  A host that forgets to release
+ * frames (Frame objects die, their device pyramids do not) shows up here. */
+typedef struct svoh_context_stats_t {
+  int64_t live_frames;
+  int64_t frame_bytes;
+  int64_t workspace_bytes;
+} svoh_context_stats_t;
+int svoh_context_stats(svoh_ctx* ctx, svoh_context_stats_t* out);
+
 /* ---- sparse image alignment  (a-1 ... a-8) ---------------------------- */
 
 /* SparseImgAlignOptions + the solver options the reference hard-wires

@@ -405,6 +405,25 @@ int svoh_frame_info(svoh_ctx* ctx, svoh_frame_t frame, int* n_levels, int* width
   return SVOH_OK;
 }
 
+int svoh_context_stats(svoh_ctx* ctx, svoh_context_stats_t* out)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, out != nullptr, "NULL argument");
+  out->live_frames = (int64_t)ctx->frames.size();
+  std::unordered_map<const void*, size_t> slabs;   // frames of a batch share one slab
+  for (const auto& kv : ctx->frames)
+    if (kv.second.slab) slabs[kv.second.slab.get()] = kv.second.slab->bytes;
+  size_t fb = 0;
+  for (const auto& kv : slabs) fb += kv.second;
+  out->frame_bytes = (int64_t)fb;
+  const svoh::DevBuffer* bufs[] = { &ctx->d_desc, &ctx->d_results, &ctx->d_feat, &ctx->d_eval, &ctx->d_xchg, &ctx->d_split,
+                                    &ctx->d_counters, &ctx->d_unit_counts, &ctx->d_scratch0, &ctx->d_scratch1, &ctx->d_scratch2 };
+  size_t wb = 0;
+  for (const svoh::DevBuffer* b : bufs) wb += b->cap;
+  out->workspace_bytes = (int64_t)wb;
+  return SVOH_OK;
+}
+
 int svoh_release_frame(svoh_ctx* ctx, svoh_frame_t frame)
 {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");

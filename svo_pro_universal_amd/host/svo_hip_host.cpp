@@ -154,6 +154,28 @@ size_t SparseImgAlignHip::runSplit(const FrameBundle::Ptr& ref_frames, const Fra
   return static_cast<size_t>(last_.n_fts_to_track);
 }
 
+// ---- DeviceFrameCache -------------------------------------------------------------
+void DeviceFrameCache::release(svoh_frame_t h)
+{
+  if (h && ctx_) (void)svoh_release_frame(ctx_, h);   // an unknown handle (context torn down first) is not an error here
+}
+
+size_t DeviceFrameCache::sweep()
+{
+  size_t n = 0;
+  for (auto it = entries_.begin(); it != entries_.end();) {
+    if (it->second.alive.expired()) { release(it->second.handle); it = entries_.erase(it); ++n; }
+    else ++it;
+  }
+  return n;
+}
+
+void DeviceFrameCache::clear()
+{
+  for (auto& kv : entries_) release(kv.second.handle);
+  entries_.clear();
+}
+
 // ---- DepthFilterHip -------------------------------------------------------------
 DepthFilterHip::DepthFilterHip(svoh_ctx* ctx, const DepthFilterOptions& options) : ctx_(ctx), options_(options)
 {

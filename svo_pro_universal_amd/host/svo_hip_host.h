@@ -91,6 +91,44 @@ struct FrameBundle {
   using Ptr = std::shared_ptr<FrameBundle>;
 };
 
+// ---------------------------------------------------------------------------
+// Device pyramids of host frames.  The reference's Frame owns img_pyr_ (cv::Mat) and dies with its last
+// shared_ptr; its device copy must die with it or a long sequence leaks one slab per frame.  The cache keeps
+// one handle per live frame object, keyed by the object's address with a weak_ptr as the liveness witness (no
+// change to the Frame class needed), builds the device pyramid on first use and releases the handles of expired
+// frames on every call (`sweep`).  The adapter of INTEGRATION.md uses exactly this class with svo::Frame.
+// ---------------------------------------------------------------------------
+class DeviceFrameCache {
+ public:
+  explicit DeviceFrameCache(svoh_ctx* ctx) : ctx_(ctx) {}
+  ~DeviceFrameCache() { clear(); }
+  DeviceFrameCache(const DeviceFrameCache&) = delete;
+  DeviceFrameCache& operator=(const DeviceFrameCache&) = delete;
+  // handle of `frame`'s device pyramid; `make` uploads / builds it when the frame is seen for the first time
+  template <class FrameT, class Make>
+  svoh_frame_t get(const std::shared_ptr<FrameT>& frame, Make make)
+  {
+    sweep();
+    const void* key = frame.get();
+    auto it = entries_.find(key);
+    if (it != entries_.end() && !it->second.alive.expired()) return it->second.handle;
+    if (it != entries_.end()) { release(it->second.handle); entries_.erase(it); }   // the address was reused by a new frame
+    const svoh_frame_t h = make(*frame);
+    entries_[key] = Entry{ std::weak_ptr<const void>(std::shared_ptr<const void>(frame, frame.get())), h };
+    return h;
+  }
+  // release the device pyramids of frames that no longer exist; returns how many were released
+  size_t sweep();
+  void clear();
+  size_t size() const { return entries_.size(); }
+
+ private:
+  struct Entry { std::weak_ptr<const void> alive; svoh_frame_t handle; };
+  void release(svoh_frame_t h);
+  svoh_ctx* ctx_;
+  std::unordered_map<const void*, Entry> entries_;
+};
+
 // sparse_img_align_base.h:37-46
 struct SparseImgAlignOptions {
   int max_level = 4;

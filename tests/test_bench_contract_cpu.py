@@ -14,7 +14,7 @@ def _last_json(path):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = _last_json(os.path.join(ROOT, "profiles", "r01_bench_default.json"))
+    d = _last_json(os.path.join(ROOT, "profiles", "r02_bench_default.json"))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k

@@ -222,3 +222,14 @@ def test_cpp_stereo_triangulation_mirror_matches_oracle(tmp_path, oracle_lib, n_
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASS" in out.stdout
+
+
+def test_cpp_500_frames_keep_device_memory_bounded(oracle_lib):
+    """500 frames through SparseImgAlignHip / DepthFilterHip with the adapter's per-Frame handle cache
+    (DeviceFrameCache): live device frames and device bytes stay bounded, everything is released at the end."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_host_leak"), "500"], capture_output=True, text=True, timeout=280)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASS" in out.stdout

@@ -233,3 +233,60 @@ def test_map_and_key_point_mirrors_host_logic():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "test_host_map_structure"])
     out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_host_map_structure"), "--map-only"], capture_output=True, text=True)
     assert out.returncode == 0 and "PASS" in out.stdout, out.stdout + out.stderr
+
+
+REF_PARAM = "/root/reference/examples/param"
+
+
+def _dump(what, path):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "test_io"])
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_io"), what, path], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_PARAM), reason="the reference tree exists in the build container only")
+def test_reference_configuration_files_parse_to_survey_appendix_a():
+    """The loader on the reference's OWN files (read in place, never copied): examples/param/pinhole.yaml,
+    calib/euroc_mono.yaml, calib/euroc_stereo.yaml, frontend_imu/euroc_stereo_imu.yaml -> the values of SURVEY.md
+    Appendix A (the loader had only ever been fed YAML the tests wrote)."""
+    # --- calib/euroc_mono.yaml: 752x480 pinhole + radtan (examples/param/calib/euroc_mono.yaml:8-21)
+    rig = _dump("rig", os.path.join(REF_PARAM, "calib", "euroc_mono.yaml"))
+    assert rig["label"] == "cam0" and rig["size"] == "752 480"
+    fx, fy, cx, cy = map(float, rig["intrinsics"].split())
+    assert (fx, fy, cx, cy) == (458.6548807207614, 457.2966964634893, 367.2158039615726, 248.37534060980727)
+    d = rig["distortion"].split()
+    assert int(d[0]) == 1                                             # SVOH_DISTORTION_RADTAN
+    assert [float(x) for x in d[1:]] == [-0.28340811217029355, 0.07395907389290132, 0.00019359502856909603, 1.7618711454538528e-05]
+    q = np.array(list(map(float, rig["T_B_C"].split())))
+    R = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422], [0.999557249008, 0.0149672133247, 0.025715529948],
+                  [-0.0257744366974, 0.00375618835797, 0.999660727178]])
+    w, x, y, z = q[:4]
+    Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    assert np.abs(Rq - R).max() < 1e-6 and np.allclose(q[4:], [-0.0216401454975, -0.064676986768, 0.00981073058949])
+    # --- pinhole.yaml (the README's mono example): max_fts 180, grid 30, levels 4..2, FAST 10 / edgelet 200
+    p = _dump("params", os.path.join(REF_PARAM, "pinhole.yaml"))
+    assert p["img_align"] == "4 2 0 0 0 0"                            # max / min level, no robust weight, no illumination terms
+    assert p["prior"].split() == ["0", "0"]
+    mf, grid, sigma2, ro, rg = p["reprojector"].split()
+    assert (int(mf), int(grid), float(sigma2), int(ro), int(rg)) == (180, 30, 200.0, 1, 0)
+    thr, s2, mp2, sphere, ao, ag, nseeds = p["depth_filter"].split()
+    assert int(thr) == 1                                              # use_threaded_depthfilter: the file leaves the default (true)
+    assert (float(s2), int(sphere), int(ao), int(ag)) == (200.0, 0, 1, 0) and int(nseeds) == 180 * 3
+    cell, maxlvl, t1, t2, grad = p["detector"].split()
+    assert (int(cell), int(maxlvl), float(t1), float(t2)) == (30, 2, 10.0, 200.0)
+    assert p["tracker"].split()[-1] == "5"                            # img_align_max_level + 1 pyramid levels
+    # --- frontend_imu/euroc_stereo_imu.yaml (C4): illumination gain + offset on, depth filter thread OFF, grid 35
+    s = _dump("params", os.path.join(REF_PARAM, "frontend_imu", "euroc_stereo_imu.yaml"))
+    assert s["img_align"].split()[4:] == ["1", "1"]
+    assert s["depth_filter"].split()[0] == "0" and s["depth_filter"].split()[4:6] == ["1", "1"]
+    mf, grid, _, ro, rg = s["reprojector"].split()
+    assert (int(mf), int(grid), int(ro), int(rg)) == (160, 35, 1, 1)   # max_fts absent -> the factory's default 160
+    assert int(s["depth_filter"].split()[-1]) == 120 * 3               # depth-filter default max_fts 120 x max_seeds_ratio 3
+    # --- calib/euroc_stereo.yaml: two cameras
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_io"), "rig", os.path.join(REF_PARAM, "calib", "euroc_stereo.yaml")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.count("label ") == 2 and out.stdout.count("size 752 480") == 2
