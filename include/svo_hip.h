@@ -625,6 +625,27 @@ typedef struct svoh_pose_result {
 int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
                              const svoh_pose_problem* problems, svoh_pose_result* results);
 
+/* The same for feature arrays that already live on the device (a multi-stream server, or the per-frame chain kept
+ * resident): one set of arrays concatenated over all bundles in problem order and, inside a bundle, camera order --
+ * bundle p's camera c owns the n_features entries after those of the cameras before it.  The pointers inside
+ * `problems[].cams[]` are ignored (n_features, cam, T_cam_imu are read); outlier / final_error are written in place;
+ * nothing but the descriptors and the per-bundle results crosses PCIe, so the call is bound by the kernel. */
+typedef struct svoh_pose_packed_arrays {
+  int64_t n_features_total;
+  const double* px;               /* 2 x N */
+  const double* f;                /* 3 x N */
+  const double* grad;             /* 2 x N */
+  const int32_t* level;           /* N */
+  const uint8_t* type;            /* N */
+  const double* xyz_world;        /* 3 x N */
+  const uint8_t* usable;          /* N */
+  uint8_t* outlier;               /* N out */
+  double* final_error;            /* N out */
+} svoh_pose_packed_arrays;
+int svoh_optimize_pose_batch_packed(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
+                                    const svoh_pose_problem* problems, const svoh_pose_packed_arrays* arrays,
+                                    svoh_pose_result* results);
+
 /* Replaces Point::optimize (src/svo_common/src/point.cpp:248-325) for a batch of landmarks, as
  * FrameHandlerBase::optimizeStructure (src/svo/src/frame_handler_base.cpp:779-825) calls it for every
  * landmark of a new keyframe: 3-DoF Gauss-Newton on the landmark position over its observations

@@ -138,6 +138,12 @@ class svoh_pose_problem(C.Structure):
                 ("T_imu_world", svoh_se3)]
 
 
+class svoh_pose_packed_arrays(C.Structure):
+    _fields_ = [("n_features_total", C.c_int64), ("px", C.c_void_p), ("f", C.c_void_p), ("grad", C.c_void_p),
+                ("level", C.c_void_p), ("type", C.c_void_p), ("xyz_world", C.c_void_p), ("usable", C.c_void_p),
+                ("outlier", C.c_void_p), ("final_error", C.c_void_p)]
+
+
 class svoh_pose_result(C.Structure):
     _fields_ = [("T_imu_world", svoh_se3), ("measurement_sigma", C.c_double), ("reproj_error_before", C.c_double),
                 ("reproj_error_after", C.c_double), ("n_meas", C.c_int32), ("n_deleted_edges", C.c_int32),
@@ -266,7 +272,7 @@ EXPORTS = [
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
     "svoh_match_direct_batch",
     "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex", "svoh_epipolar_match_batch",
-    "svoh_detect_features", "svoh_optimize_pose_batch", "svoh_optimize_points_batch",
+    "svoh_detect_features", "svoh_optimize_pose_batch", "svoh_optimize_pose_batch_packed", "svoh_optimize_points_batch",
 ]
 
 
@@ -363,6 +369,8 @@ def load():
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svoh_optimize_pose_batch.argtypes = [C.c_void_p, P(svoh_pose_options), C.c_int, P(svoh_pose_problem),
                                              P(svoh_pose_result)]
+    lib.svoh_optimize_pose_batch_packed.argtypes = [C.c_void_p, P(svoh_pose_options), C.c_int, P(svoh_pose_problem),
+                                                    P(svoh_pose_packed_arrays), P(svoh_pose_result)]
     lib.svoh_update_seeds_batch_ex.argtypes = lib.svoh_update_seeds_batch.argtypes + [P(svoh_seed_match_outputs)]
     lib.svoh_epipolar_match_batch.argtypes = [C.c_void_p, P(svoh_matcher_options), C.c_int, P(svoh_frame_view),
                                               P(svoh_frame_view), P(svoh_se3), P(svoh_feature_batch), P(C.c_double),

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
   {
     const Rigid T = s_T;
     for_each_feature([&](const CamModel& cm, const Rigid& T_cam_imu, const double* Rci, long long gi) {
-      const int scale = 1 << a.level[gi];
+      const int scale = 1 << (a.level[gi] & 31);
       double ue;
       const Vec3 X = { a.xyz[3 * gi], a.xyz[3 * gi + 1], a.xyz[3 * gi + 2] };
       pose_residual(opt, cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, is_edgelet_type(a.type[gi]),
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
     const Rigid T = s_T;
     for_each_feature([&](const CamModel& cm, const Rigid& T_cam_imu, const double* Rci, long long gi) {
-      const int scale = 1 << a.level[gi];
+      const int scale = 1 << (a.level[gi] & 31);
       const bool edgelet = is_edgelet_type(a.type[gi]);
       double sigma = measurement_sigma * scale;
       if (edgelet) sigma *= 2.0;   // kEdgeletSigmaExtraFactor
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
       double ue;
       const Vec3 X = { a.xyz[3 * gi], a.xyz[3 * gi + 1], a.xyz[3 * gi + 2] };
       pose_residual(opt, cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, edgelet, 1.0, ue, nullptr);
-      ue *= 1.0 / (1 << a.level[gi]);
+      ue *= 1.0 / (1 << (a.level[gi] & 31));
       a.final_error[gi] = ue;
       const bool out = fabs(ue) > opt.outlier_threshold;
       a.outlier[gi] = out ? 1 : 0;
@@ -504,8 +504,10 @@ void point_optimize_kernel(const PointArgs a)
 
 using namespace svoh;
 
-extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
-                                        const svoh_pose_problem* problems, svoh_pose_result* results)
+// packed != NULL: the per-feature arrays are the caller's DEVICE arrays (concatenated in problem, then camera order),
+// used in place; only the descriptors travel.
+static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems, const svoh_pose_problem* problems,
+                          const svoh_pose_packed_arrays* packed, svoh_pose_result* results)
 {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, options && n_problems >= 0, "bad arguments");
@@ -522,18 +524,26 @@ extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* 
     for (int c = 0; c < pb.n_cams; ++c) {
       const svoh_pose_camera& cam = pb.cams[c];
       SVOH_REQUIRE(ctx, cam.n_features >= 0, "negative n_features");
-      SVOH_REQUIRE(ctx, cam.n_features == 0 || (cam.px && cam.f && cam.grad && cam.level && cam.type && cam.xyz_world && cam.usable),
+      SVOH_REQUIRE(ctx, packed || cam.n_features == 0 ||
+                            (cam.px && cam.f && cam.grad && cam.level && cam.type && cam.xyz_world && cam.usable),
                    "NULL feature array");
       SVOH_REQUIRE(ctx, cam.cam.distortion == SVOH_DISTORTION_NONE || cam.cam.distortion == SVOH_DISTORTION_RADTAN,
                    "unsupported distortion model");
-      for (int i = 0; i < cam.n_features; ++i) SVOH_REQUIRE(ctx, cam.level[i] >= 0 && cam.level[i] < 30, "feature level out of range");
+      if (!packed)   // device-resident levels are masked to 0..29 by the kernel instead (1 << level)
+        for (int i = 0; i < cam.n_features; ++i) SVOH_REQUIRE(ctx, cam.level[i] >= 0 && cam.level[i] < 30, "feature level out of range");
       n += (size_t)cam.n_features;
     }
     SVOH_REQUIRE(ctx, n <= (size_t)kPoseMaxMeas, "more than 4096 features in one bundle");
     n_cams_total += (size_t)pb.n_cams;
     n_feat_total += n;
   }
-  const size_t nf = n_feat_total ? n_feat_total : 1;
+  if (packed) {
+    SVOH_REQUIRE(ctx, (size_t)packed->n_features_total == n_feat_total, "n_features_total does not match the problems");
+    SVOH_REQUIRE(ctx, n_feat_total == 0 || (packed->px && packed->f && packed->grad && packed->level && packed->type &&
+                                            packed->xyz_world && packed->usable && packed->outlier && packed->final_error),
+                 "NULL packed array");
+  }
+  const size_t nf = packed ? 1 : (n_feat_total ? n_feat_total : 1);
   // one staging block: [problems | cams | px | f | grad | xyz | level | type | usable]  -> device; outputs appended
   auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
   const size_t o_pb = 0, o_cam = al(sizeof(DevPoseProblem) * (size_t)n_problems), o_px = o_cam + al(sizeof(DevPoseCam) * n_cams_total);
@@ -575,9 +585,11 @@ extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* 
       }
     }
   };
-  const int n_stage_threads = n_feat_total >= kPoseParallelStagingFeatures
-      ? (int)std::min<size_t>({ (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)n_problems }) : 1;
-  if (n_stage_threads <= 1) {
+  const int n_stage_threads = packed ? 0 : (n_feat_total >= kPoseParallelStagingFeatures
+      ? (int)std::min<size_t>({ (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)n_problems }) : 1);
+  if (n_stage_threads == 0) {
+    // nothing to stage
+  } else if (n_stage_threads <= 1) {
     stage_range(0, n_problems);
   } else {
     std::vector<std::thread> workers;
@@ -595,6 +607,10 @@ extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* 
   a.grad = reinterpret_cast<const double*>(d + o_grad); a.xyz = reinterpret_cast<const double*>(d + o_xyz);
   a.level = reinterpret_cast<const int32_t*>(d + o_level); a.type = d + o_type; a.usable = d + o_usable;
   a.outlier = d + o_outlier; a.final_error = reinterpret_cast<double*>(d + o_ferr);
+  if (packed) {
+    a.px = packed->px; a.f = packed->f; a.grad = packed->grad; a.xyz = packed->xyz_world; a.level = packed->level;
+    a.type = packed->type; a.usable = packed->usable; a.outlier = packed->outlier; a.final_error = packed->final_error;
+  }
   a.results = reinterpret_cast<svoh_pose_result*>(d + o_res);
   a.n_problems = n_problems;
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
@@ -606,6 +622,12 @@ extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* 
   SVOH_HIP_TRY(ctx, hipGetLastError());
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
   ctx->misc_timed = true;
+  if (packed) {   // per-feature outputs stay on the device; the per-bundle results come back
+    SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_res, d + o_res, total - o_res, hipMemcpyDeviceToHost, ctx->stream));
+    SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(results, h + o_res, sizeof(svoh_pose_result) * (size_t)n_problems);
+    return SVOH_OK;
+  }
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_outlier, d + o_outlier, total - o_outlier, hipMemcpyDeviceToHost, ctx->stream));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(results, h + o_res, sizeof(svoh_pose_result) * (size_t)n_problems);
@@ -619,6 +641,21 @@ extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* 
       off += n;
     }
   return SVOH_OK;
+}
+
+extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
+                                        const svoh_pose_problem* problems, svoh_pose_result* results)
+{
+  return run_pose_batch(ctx, options, n_problems, problems, nullptr, results);
+}
+
+extern "C" int svoh_optimize_pose_batch_packed(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
+                                               const svoh_pose_problem* problems, const svoh_pose_packed_arrays* arrays,
+                                               svoh_pose_result* results)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, arrays != nullptr, "NULL argument");
+  return run_pose_batch(ctx, options, n_problems, problems, arrays, results);
 }
 
 extern "C" int svoh_optimize_points_batch(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,

@@ -125,3 +125,45 @@ def test_pose_large_batch_staged_by_threads(gpu_ctx):
         for k, o, e in zip(built[i][1], out, ferr):
             assert np.array_equal(k["outlier"], o)
             assert np.allclose(k["final_error"], e, rtol=1e-9, atol=1e-15)
+
+
+def test_packed_device_arrays_equal_the_host_staged_call(gpu_ctx):
+    """svoh_optimize_pose_batch_packed: the per-feature arrays of all bundles concatenated on the device and used in
+    place (nothing but descriptors and per-bundle results crosses PCIe) -- bit-identical to the host-staged call."""
+    import ctypes as C
+    import torch
+    scs = [ph.make_pose_scene(60 + k, n=60 + 37 * k, n_cams=1 + k % 2) for k in range(5)]
+    opt = capi.default_pose_options(scs[0]["cam"])
+    built = [fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"]) for sc in scs]
+    want = gpu_ctx.optimize_pose(opt, [b[0] for b in built])
+    cat = {k: [] for k in ("px", "f", "grad", "level", "type", "xyz_world", "usable")}
+    for pb, keep in built:
+        for a in keep:
+            for k in cat:
+                cat[k].append(a[k].ravel())
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(np.concatenate(v)).to(dev) for k, v in cat.items()}
+    n_total = t["level"].numel()
+    t["outlier"] = torch.zeros(n_total, dtype=torch.uint8, device=dev)
+    t["final_error"] = torch.zeros(n_total, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    arr = capi.svoh_pose_packed_arrays()
+    arr.n_features_total = n_total
+    for k in ("px", "f", "grad", "level", "type", "xyz_world", "usable", "outlier", "final_error"):
+        setattr(arr, k, t[k].data_ptr())
+    pbs = (capi.svoh_pose_problem * len(built))(*[b[0] for b in built])
+    res = (capi.svoh_pose_result * len(built))()
+    gpu_ctx._check(gpu_ctx.lib.svoh_optimize_pose_batch_packed(gpu_ctx.h, C.byref(opt), len(built), pbs, C.byref(arr), res))
+    out_g, err_g = t["outlier"].cpu().numpy(), t["final_error"].cpu().numpy()
+    off = 0
+    for r, w, (pb, keep) in zip(res, want, built):
+        assert r.status == w.status and r.iters == w.iters and r.n_meas == w.n_meas
+        assert np.array_equal(fe.se3_to_numpy(r.T_imu_world), fe.se3_to_numpy(w.T_imu_world))
+        assert r.measurement_sigma == w.measurement_sigma and r.reproj_error_after == w.reproj_error_after
+        for a in keep:
+            n = a["level"].size
+            assert np.array_equal(out_g[off:off + n], a["outlier"][:n]) and np.array_equal(err_g[off:off + n], a["final_error"][:n])
+            off += n
+    assert off == n_total
+    arr.n_features_total = n_total + 1          # a size that does not match the problems is refused
+    assert gpu_ctx.lib.svoh_optimize_pose_batch_packed(gpu_ctx.h, C.byref(opt), len(built), pbs, C.byref(arr), res) != 0
