@@ -449,6 +449,15 @@ int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options,
                             const double* depth, double* px_cur, int32_t* result,
                             double* f_cur, int32_t* search_level, double* h_inv, double* A_cur_ref);
 
+/* Deferred section: between begin and collect, ONE svoh_match_direct_batch and ONE svoh_update_seeds_batch(_ex)
+ * with host arrays are queued on the context's stream without a synchronisation; collect waits once and copies
+ * every result to the caller's arrays (which must stay valid until then).  This is how one reprojection
+ * (Reprojector::reprojectFrames: landmarks and converged seeds through findMatchDirect, unconverged seeds through
+ * updateSeed) costs one round trip instead of one per call.  Device-resident batches are stream-ordered anyway and
+ * not affected. */
+int svoh_matcher_begin_deferred(svoh_ctx* ctx);
+int svoh_matcher_collect(svoh_ctx* ctx);
+
 /* DepthFilterOptions used by updateSeed (src/svo_direct/include/svo/direct/depth_filter.h:40-100) */
 typedef struct svoh_depth_filter_options {
   double seed_convergence_sigma2_thresh;      /* 200 */

@@ -1952,10 +1952,20 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   }
   const size_t o_nsucc = out_add(sizeof(int32_t));
 
-  SVOH_HIP_TRY(ctx, ctx->h_scratch1.reserve(s.total));
-  SVOH_HIP_TRY(ctx, ctx->d_scratch1.reserve(s.total));
-  uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch1.ptr);
-  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch1.ptr);
+  // deferred section (svoh_matcher_begin_deferred): no synchronisation here; the seed batch stages through its own
+  // buffers so that a direct batch queued before it is not overwritten while in flight
+  const bool defer = ctx->matcher_deferred && !on_device;
+  if (defer) {
+    SVOH_REQUIRE(ctx, !ctx->matcher_deferred_used[seeds ? 1 : 0], "one batch of each kind per deferred section: collect first");
+    ctx->matcher_deferred_used[seeds ? 1 : 0] = true;
+  }
+  PinnedBuffer& hbuf = (defer && seeds) ? ctx->h_match_seeds : ctx->h_scratch1;
+  DevBuffer& dbuf = (defer && seeds) ? ctx->d_match_seeds : ctx->d_scratch1;
+  if (!defer && ctx->matcher_deferred_used[0] && !seeds) SVOH_REQUIRE(ctx, false, "a deferred direct batch is pending: collect first");
+  SVOH_HIP_TRY(ctx, hbuf.reserve(s.total));
+  SVOH_HIP_TRY(ctx, dbuf.reserve(s.total));
+  uint8_t* h = static_cast<uint8_t*>(hbuf.ptr);
+  uint8_t* d = static_cast<uint8_t*>(dbuf.ptr);
   for (size_t k = 0; k < s.in.size(); ++k) memcpy(h + s.off[k], s.in[k].first, s.in[k].second);
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
   // optional outputs of units that return before the matcher runs read back as zeros
@@ -2076,6 +2086,21 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   // everything after the inputs that may have changed comes back in one copy
   const size_t back_from = o_type;
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + back_from, d + back_from, o_nsucc - back_from, hipMemcpyDeviceToHost, ctx->stream));
+  if (defer) {   // the copies to the caller's arrays wait for svoh_matcher_collect
+    auto later = [&](void* dst, size_t off, size_t bytes) { if (dst && bytes) ctx->matcher_pending.push_back({ dst, h + off, bytes }); };
+    if (seeds) {
+      later(fb->type, o_type, (size_t)n); later(state, o_state, sizeof(double) * 4 * n); later(success, o_success, (size_t)n);
+      later(result, o_result, sizeof(int32_t) * n); later(px_cur, o_pxcur, sizeof(double) * 2 * n);
+      later(f_cur, o_fcur, sizeof(double) * 3 * n); later(search_level, o_slevel, sizeof(int32_t) * n);
+      later(A_cur_ref, o_A, sizeof(double) * 4 * n);
+      if (n_success) ctx->matcher_pending_counts.push_back({ n_success, h + o_success, n });
+    } else {
+      later(px_cur, o_pxcur, sizeof(double) * 2 * n); later(result, o_result, sizeof(int32_t) * n);
+      later(f_cur, o_fcur, sizeof(double) * 3 * n); later(search_level, o_slevel, sizeof(int32_t) * n);
+      later(h_inv, o_hinv, sizeof(double) * n); later(A_cur_ref, o_A, sizeof(double) * 4 * n);
+    }
+    return SVOH_OK;
+  }
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (seeds) {
     memcpy(fb->type, h + o_type, (size_t)n);
@@ -2261,6 +2286,36 @@ int svoh_epipolar_match_batch(svoh_ctx* ctx, const svoh_matcher_options* options
                               const svoh_epipolar_match_outputs* outputs)
 {
   return run_epipolar(ctx, options, n_ref_frames, ref_frames, cur_frame, T_cur_ref, features, d_inv_common, d_inv, outputs);
+}
+
+int svoh_matcher_begin_deferred(svoh_ctx* ctx)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, !ctx->matcher_deferred, "a deferred section is already open");
+  ctx->matcher_deferred = true;
+  ctx->matcher_deferred_used[0] = ctx->matcher_deferred_used[1] = false;
+  ctx->matcher_pending.clear();
+  ctx->matcher_pending_counts.clear();
+  return SVOH_OK;
+}
+
+int svoh_matcher_collect(svoh_ctx* ctx)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, ctx->matcher_deferred, "no deferred section is open");
+  ctx->matcher_deferred = false;
+  ctx->matcher_deferred_used[0] = ctx->matcher_deferred_used[1] = false;
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (const auto& c : ctx->matcher_pending) memcpy(c.dst, c.src, c.bytes);
+  for (const auto& c : ctx->matcher_pending_counts) {
+    int k = 0;
+    for (int i = 0; i < c.n; ++i) k += c.flags[i];
+    *c.dst = k;
+  }
+  ctx->matcher_pending.clear();
+  ctx->matcher_pending_counts.clear();
+  return SVOH_OK;
 }
 
 int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options, int n_ref_frames,

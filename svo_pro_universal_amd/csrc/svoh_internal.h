@@ -107,6 +107,18 @@ struct svoh_ctx {
   svoh::DevBuffer d_unit_counts;  // 4 x uint32 per unit
   size_t unit_counts_pending = 0; // units of the last launch whose counts have not been added up yet
 
+  // matcher calls between svoh_matcher_begin_deferred / svoh_matcher_collect: host-array batches are queued without
+  // a synchronisation (the direct matches and the seed updates of one reprojection share ONE round trip); what has
+  // to be copied to the caller's arrays once the stream has drained is remembered here
+  bool matcher_deferred = false;
+  bool matcher_deferred_used[2] = { false, false };   // [0] direct, [1] seeds: one batch of each kind per section
+  struct PendingCopy { void* dst; const void* src; size_t bytes; };
+  std::vector<PendingCopy> matcher_pending;
+  struct PendingCount { int32_t* dst; const uint8_t* flags; int n; };
+  std::vector<PendingCount> matcher_pending_counts;
+  svoh::DevBuffer d_match_seeds;       // staging of the deferred seed batch (the direct one keeps d_scratch1)
+  svoh::PinnedBuffer h_match_seeds;
+
   // generic scratch for the other paths
   svoh::DevBuffer d_scratch0, d_scratch1, d_scratch2;
   svoh::PinnedBuffer h_scratch0, h_scratch1;

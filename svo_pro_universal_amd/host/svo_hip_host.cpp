@@ -894,62 +894,61 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
       if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) candidates_.push_back(candidate);
     }
   }
-  reprojector::Statistics lm_stats;
   reprojector_utils::sortCandidatesByReprojStats(candidates_);
-  reprojector_utils::matchCandidates(ctx_, cur_frame, max_total_n_features, options_.affine_est_offset, options_.affine_est_gain,
-                                     candidates_, *grid_, lm_stats, options_.seed_sigma2_thresh);
-  add(lm_stats);
-  if (doesFrameHaveEnoughFeatures(cur_frame)) reprojector_utils::setGridCellsOccupied(candidates_, *grid_);
 
-  // converged seeds (:201-241)
-  candidates_.clear();
+  // converged seeds (:201-241) and unconverged seeds (:243-306): their candidate lists depend on the visible
+  // keyframes and the current pose only, so they are gathered now and matched together with the landmarks
+  std::vector<reprojector::Candidate> converged, unconverged;
   for (const FramePtr& ref_frame : visible_kfs)
     for (size_t i = 0; i < ref_frame->num_features_; ++i) {
       const uint8_t t = ref_frame->type_vec_[i];
-      if (t == SVOH_FT_CORNER_SEED_CONVERGED || t == SVOH_FT_EDGELET_SEED_CONVERGED) {
-        reprojector::Candidate candidate;
-        if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) candidates_.push_back(candidate);
-      }
+      const bool conv = t == SVOH_FT_CORNER_SEED_CONVERGED || t == SVOH_FT_EDGELET_SEED_CONVERGED;
+      const bool unconv = (t == SVOH_FT_CORNER_SEED || t == SVOH_FT_EDGELET_SEED) && options_.reproject_unconverged_seeds;
+      if (!conv && !unconv) continue;
+      reprojector::Candidate candidate;
+      if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) (conv ? converged : unconverged).push_back(candidate);
     }
-  if (doesFrameHaveEnoughFeatures(cur_frame)) {
-    reprojector_utils::setGridCellsOccupied(candidates_, *grid_);
-    candidates_.clear();
-    return;
-  }
-  reprojector::Statistics sd_stats;
-  reprojector_utils::sortCandidatesByReprojStats(candidates_);
-  reprojector_utils::matchCandidates(ctx_, cur_frame, max_total_n_features, options_.affine_est_offset, options_.affine_est_gain,
-                                     candidates_, *grid_, sd_stats, options_.seed_sigma2_thresh);
-  add(sd_stats);
-  if (doesFrameHaveEnoughFeatures(cur_frame) || !options_.reproject_unconverged_seeds) {
-    reprojector_utils::setGridCellsOccupied(candidates_, *grid_);
-    candidates_.clear();
-    return;
-  }
+  reprojector_utils::sortCandidatesByReprojStats(converged);
+  reprojector_utils::sortCandidatesByReprojStats(unconverged);
 
-  // unconverged seeds (:243-306)
-  candidates_.clear();
-  for (const FramePtr& ref_frame : visible_kfs)
-    for (size_t i = 0; i < ref_frame->num_features_; ++i) {
-      const uint8_t t = ref_frame->type_vec_[i];
-      if (t == SVOH_FT_CORNER_SEED || t == SVOH_FT_EDGELET_SEED) {
-        reprojector::Candidate candidate;
-        if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) candidates_.push_back(candidate);
-      }
+  std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged, &unconverged };
+  reprojector::Statistics st[3];
+  auto before_pass = [&](int pass, size_t& max_n) -> bool {
+    max_n = max_total_n_features;
+    if (pass == 0) return true;
+    if (pass == 1) {
+      if (doesFrameHaveEnoughFeatures(cur_frame)) { reprojector_utils::setGridCellsOccupied(converged, *grid_); return false; }   // :226-231
+      return true;
     }
-  reprojector::Statistics un_sd_stats;
-  size_t max_allowed_total = max_total_n_features;
-  if (options_.max_unconverged_seeds_ratio > 0) {
-    const double min_lm_seeds_ratio = 1 - options_.max_unconverged_seeds_ratio;
-    const size_t max_allowed_alternative = static_cast<size_t>(cur_frame->numTrackedFeatures() / min_lm_seeds_ratio);
-    if (max_allowed_total > max_allowed_alternative) max_allowed_total = max_allowed_alternative;
-  }
-  if (max_allowed_total < options_.min_required_features) max_allowed_total = options_.min_required_features;
-  reprojector_utils::sortCandidatesByReprojStats(candidates_);
-  reprojector_utils::matchCandidates(ctx_, cur_frame, max_allowed_total, options_.affine_est_offset, options_.affine_est_gain,
-                                     candidates_, *grid_, un_sd_stats, options_.seed_sigma2_thresh);
-  add(un_sd_stats);
-  if (doesFrameHaveEnoughFeatures(cur_frame)) reprojector_utils::setGridCellsOccupied(candidates_, *grid_);
+    // pass 2: the feature budget of the unconverged seeds (:269-284)
+    size_t max_allowed_total = max_total_n_features;
+    if (options_.max_unconverged_seeds_ratio > 0) {
+      const double min_lm_seeds_ratio = 1 - options_.max_unconverged_seeds_ratio;
+      const size_t max_allowed_alternative = static_cast<size_t>(cur_frame->numTrackedFeatures() / min_lm_seeds_ratio);
+      if (max_allowed_total > max_allowed_alternative) max_allowed_total = max_allowed_alternative;
+    }
+    if (max_allowed_total < options_.min_required_features) max_allowed_total = options_.min_required_features;
+    max_n = max_allowed_total;
+    return true;
+  };
+  bool stop = false;
+  auto after_pass = [&](int pass) {
+    add(st[pass]);
+    if (pass == 0) {
+      if (doesFrameHaveEnoughFeatures(cur_frame)) reprojector_utils::setGridCellsOccupied(candidates_, *grid_);   // :193-199
+    } else if (pass == 1) {
+      if (doesFrameHaveEnoughFeatures(cur_frame) || !options_.reproject_unconverged_seeds) {                        // :236-241
+        reprojector_utils::setGridCellsOccupied(converged, *grid_);
+        stop = true;
+      }
+    } else {
+      if (doesFrameHaveEnoughFeatures(cur_frame)) reprojector_utils::setGridCellsOccupied(unconverged, *grid_);    // :300-305
+    }
+  };
+  reprojector_utils::matchCandidatesFused(ctx_, cur_frame, options_.affine_est_offset, options_.affine_est_gain, options_.seed_sigma2_thresh,
+                                          lists, [&](int pass, size_t& max_n) { return !stop && before_pass(pass, max_n); }, after_pass,
+                                          *grid_, st);
+  candidates_.clear();
 }
 
 namespace reprojector_utils {
@@ -1018,187 +1017,240 @@ void grow(std::vector<T>& v, size_t n, const T& fill = T()) { if (v.size() < n) 
 
 const std::vector<int32_t>& lastMatchResults() { return g_last_results; }
 
+// The matcher work of matchCandidate (reprojector.cpp:384-486) for every candidate, speculatively: it depends on no
+// match result, only on the candidate.  plan() resolves what each candidate matches against and appends it to one of
+// two batches (findMatchDirect / updateSeed); the batches of SEVERAL candidate lists can share one pair of launches
+// (run()); replay() is the reference's loop over one list (:356-381), reading the finished batches.
+namespace {
+enum Kind { kConvergedSeed = 0, kUnconvergedSeed = 1, kLandmark = 2, kNoCloseView = 3 };
+struct Resolved { Kind kind; FramePtr ref; size_t idx; PointPtr point; int frame_slot; int batch_pos; };
+struct Batch {
+  std::vector<int32_t> ref_idx, level, result, search_level;
+  std::vector<double> px, f, grad, depth, state, px_cur, f_cur, A;
+  std::vector<uint8_t> type, success;
+  void push(const Frame& r, size_t i, int slot)
+  {
+    ref_idx.push_back(slot); level.push_back(r.level_vec_[i]); type.push_back(r.type_vec_[i]);
+    px.insert(px.end(), r.px_vec_.begin() + 2 * i, r.px_vec_.begin() + 2 * i + 2);
+    f.insert(f.end(), r.f_vec_.begin() + 3 * i, r.f_vec_.begin() + 3 * i + 3);
+    grad.insert(grad.end(), r.grad_vec_.begin() + 2 * i, r.grad_vec_.begin() + 2 * i + 2);
+  }
+  size_t size() const { return level.size(); }
+};
+struct SpeculativeMatches {
+  std::vector<FramePtr> frames;   // distinct reference frames of all lists
+  Batch direct, seeds;
+  int slot_of(const FramePtr& f)
+  {
+    for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == f) return static_cast<int>(k);
+    frames.push_back(f);
+    return static_cast<int>(frames.size() - 1);
+  }
+  // what each candidate of one list matches against
+  std::vector<Resolved> plan(const FramePtr& frame, const std::vector<reprojector::Candidate>& candidates)
+  {
+    const size_t n = candidates.size();
+    std::vector<Resolved> rs(n);
+    for (size_t i = 0; i < n; ++i) {
+      const reprojector::Candidate& c = candidates[i];
+      if (!c.ref_frame || c.ref_index >= c.ref_frame->num_features_) throw std::runtime_error("matchCandidates: bad candidate");
+      Resolved& r = rs[i];
+      r.batch_pos = -1; r.frame_slot = -1;
+      PointPtr lm = c.ref_index < c.ref_frame->landmark_vec_.size() ? c.ref_frame->landmark_vec_[c.ref_index] : nullptr;
+      if (!lm) {
+        r.ref = c.ref_frame; r.idx = c.ref_index;
+        if (is_converged_seed(c.type)) r.kind = kConvergedSeed;
+        else if (is_unconverged_seed(c.type)) r.kind = kUnconvergedSeed;
+        else throw std::runtime_error("matchCandidates: seed type unknown");  // CHECK(false) in the reference
+      } else {
+        r.point = lm;
+        FramePtr rf; size_t ri = 0;
+        if (lm->getCloseViewObs(frame->pos(), rf, ri)) { r.kind = kLandmark; r.ref = rf; r.idx = ri; }
+        else r.kind = kNoCloseView;
+      }
+      if (r.kind != kNoCloseView) r.frame_slot = slot_of(r.ref);
+      if (r.kind == kConvergedSeed || r.kind == kLandmark) {
+        r.batch_pos = static_cast<int>(direct.size());
+        direct.push(*r.ref, r.idx, r.frame_slot);
+        if (r.kind == kConvergedSeed) direct.depth.push_back(r.ref->getSeedDepth(r.idx));
+        else {
+          const svoh::Vec3 p = r.ref->pos(), q = r.point->pos();  // (ref_frame->pos() - landmark->pos()).norm()
+          direct.depth.push_back(sqrt((p.x - q.x) * (p.x - q.x) + (p.y - q.y) * (p.y - q.y) + (p.z - q.z) * (p.z - q.z)));
+        }
+        direct.px_cur.push_back(c.cur_px[0]); direct.px_cur.push_back(c.cur_px[1]);
+      } else if (r.kind == kUnconvergedSeed) {
+        r.batch_pos = static_cast<int>(seeds.size());
+        seeds.push(*r.ref, r.idx, r.frame_slot);
+        seeds.state.insert(seeds.state.end(), r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx,
+                           r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx + 4);
+      }
+    }
+    return rs;
+  }
+  // both batches, queued back to back, ONE wait (svoh_matcher_begin_deferred / collect)
+  void run(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh)
+  {
+    if (!direct.size() && !seeds.size()) return;
+    // Matcher matcher; (defaults of matcher.h:39-54) + the two affine flags (reprojector.cpp:352-354)
+    svoh_matcher_options mopt{};
+    mopt.align_max_iter = 10; mopt.max_epi_search_steps = 100; mopt.subpix_refinement = 1;
+    mopt.epi_search_edgelet_filtering = 1; mopt.scan_on_unit_sphere = 1;
+    mopt.epi_search_edgelet_max_angle = 0.7; mopt.max_patch_diff_ratio = 2.0;
+    mopt.affine_est_offset = affine_est_offset; mopt.affine_est_gain = affine_est_gain;
+    std::vector<svoh_frame_view> views;
+    for (const FramePtr& f : frames) {
+      svoh_frame_view v{};
+      v.frame = f->pyramid; v.cam = f->cam; svoh::store_rigid(f->T_f_w_, v.T_f_w);
+      v.seed_mu_range = f->seed_mu_range_; v.id = f->id();
+      views.push_back(v);
+    }
+    svoh_frame_view cur{};
+    cur.frame = frame->pyramid; cur.cam = frame->cam; svoh::store_rigid(frame->T_f_w_, cur.T_f_w);
+    cur.seed_mu_range = frame->seed_mu_range_; cur.id = frame->id();
+    auto batch_of = [](Batch& b) {
+      svoh_feature_batch fb{};
+      fb.n = static_cast<int32_t>(b.size());
+      fb.ref_frame_idx = b.ref_idx.data(); fb.px = b.px.data(); fb.f = b.f.data(); fb.grad = b.grad.data();
+      fb.level = b.level.data(); fb.type = b.type.data();
+      return fb;
+    };
+    auto fail = [&](const char* what) {
+      const std::string msg = std::string(what) + ": " + svoh_last_error_string(ctx);
+      (void)svoh_matcher_collect(ctx);   // leave no open section behind
+      throw std::runtime_error(msg);
+    };
+    const bool both = direct.size() && seeds.size();
+    if (both && svoh_matcher_begin_deferred(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_begin_deferred: ") + svoh_last_error_string(ctx));
+    svoh_feature_batch fbd{}, fbs{};
+    if (direct.size()) {
+      const size_t m = direct.size();
+      direct.result.assign(m, 0); direct.search_level.assign(m, 0); direct.f_cur.assign(3 * m, 0.0); direct.A.assign(4 * m, 0.0);
+      fbd = batch_of(direct);
+      const int rc = svoh_match_direct_batch(ctx, &mopt, static_cast<int>(views.size()), views.data(), &cur, &fbd,
+                                             direct.depth.data(), direct.px_cur.data(), direct.result.data(),
+                                             direct.f_cur.data(), direct.search_level.data(), nullptr, direct.A.data());
+      if (rc != SVOH_OK) { if (both) fail("svoh_match_direct_batch"); throw std::runtime_error(std::string("svoh_match_direct_batch: ") + svoh_last_error_string(ctx)); }
+    }
+    if (seeds.size()) {
+      const size_t m = seeds.size();
+      seeds.result.assign(m, 0); seeds.search_level.assign(m, 0); seeds.success.assign(m, 0);
+      seeds.px_cur.assign(2 * m, 0.0); seeds.f_cur.assign(3 * m, 0.0); seeds.A.assign(4 * m, 0.0);
+      fbs = batch_of(seeds);
+      svoh_depth_filter_options o{};
+      o.seed_convergence_sigma2_thresh = seed_sigma2_thresh;      // updateSeed(..., seed_sigma2_thresh, false, false):
+      o.mappoint_convergence_sigma2_thresh = seed_sigma2_thresh;  // one threshold for every seed type here
+      o.px_error_angle = updateSeedPxErrorAngle(*frame);
+      o.check_visibility = 0; o.check_convergence = 0; o.use_vogiatzis_update = 1;
+      const svoh_seed_match_outputs outs{ seeds.px_cur.data(), seeds.f_cur.data(), seeds.search_level.data(), seeds.A.data() };
+      const int rc = svoh_update_seeds_batch_ex(ctx, &mopt, &o, static_cast<int>(views.size()), views.data(), &cur, &fbs,
+                                                seeds.state.data(), seeds.success.data(), seeds.result.data(), nullptr, &outs);
+      if (rc != SVOH_OK) { if (both) fail("svoh_update_seeds_batch_ex"); throw std::runtime_error(std::string("svoh_update_seeds_batch_ex: ") + svoh_last_error_string(ctx)); }
+    }
+    if (both && svoh_matcher_collect(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_collect: ") + svoh_last_error_string(ctx));
+  }
+  // the reference's loop over one candidate list, in candidate order (reprojector.cpp:356-381)
+  void replay(const FramePtr& frame, size_t max_n_features_per_frame, std::vector<reprojector::Candidate>& candidates,
+              const std::vector<Resolved>& rs, OccupandyGrid2D& grid, reprojector::Statistics& stats)
+  {
+    const size_t n = candidates.size();
+    g_last_results.assign(n, -1);
+    size_t i = 0;
+    for (size_t k = 0; k < n; ++k) {
+      reprojector::Candidate& c = candidates[k];
+      const Resolved& r = rs[k];
+      ++i;
+      const size_t grid_index = grid.getCellIndex(static_cast<int>(c.cur_px[0]), static_cast<int>(c.cur_px[1]), 1);
+      if (max_n_features_per_frame > 0 && grid.isOccupied(grid_index)) continue;
+      ++stats.n_trials;
+      bool ok = false;
+      const Batch* b = nullptr;
+      if (r.kind == kConvergedSeed || r.kind == kLandmark) {
+        b = &direct;
+        const int res = direct.result[r.batch_pos];
+        g_last_results[k] = res;
+        ok = res == SVOH_MATCH_SUCCESS;
+        c.cur_px[0] = direct.px_cur[2 * r.batch_pos]; c.cur_px[1] = direct.px_cur[2 * r.batch_pos + 1];  // Keypoint& px_cur
+        if (r.kind == kLandmark) { if (ok) r.point->n_succeeded_reproj_ += 1; else r.point->n_failed_reproj_++; }
+      } else if (r.kind == kUnconvergedSeed) {
+        b = &seeds;
+        g_last_results[k] = seeds.result[r.batch_pos];
+        ok = seeds.success[r.batch_pos] != 0;
+        // updateSeed changed the seed of the reference frame whether it succeeded or not
+        std::copy(seeds.state.begin() + 4 * r.batch_pos, seeds.state.begin() + 4 * r.batch_pos + 4,
+                  r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx);
+        r.ref->type_vec_[r.idx] = seeds.type[r.batch_pos];
+      } else {
+        g_last_results[k] = 1000;
+      }
+      if (!ok) continue;
+      // matchCandidate's tail (:455-486): fill the first free slot of the frame
+      const size_t s = frame->num_features_;
+      grow(frame->px_vec_, 2 * (s + 1)); grow(frame->f_vec_, 3 * (s + 1)); grow(frame->grad_vec_, 2 * (s + 1));
+      grow(frame->level_vec_, s + 1); grow(frame->type_vec_, s + 1); grow(frame->score_vec_, s + 1);
+      grow(frame->invmu_sigma2_a_b_vec_, 4 * (s + 1)); grow(frame->landmark_vec_, s + 1); grow(frame->seed_ref_vec_, s + 1);
+      const int p = r.batch_pos;
+      if (is_edgelet(c.type)) {
+        const double* A = &b->A[4 * p];
+        const double* g = &r.ref->grad_vec_[2 * r.idx];
+        double g0 = A[0] * g[0] + A[2] * g[1], g1 = A[1] * g[0] + A[3] * g[1];
+        const double z = g0 * g0 + g1 * g1;
+        if (z > 0.0) { const double nn = sqrt(z); g0 /= nn; g1 /= nn; }
+        frame->grad_vec_[2 * s] = g0; frame->grad_vec_[2 * s + 1] = g1;
+      }
+      frame->type_vec_[s] = c.type;
+      frame->px_vec_[2 * s] = b->px_cur[2 * p]; frame->px_vec_[2 * s + 1] = b->px_cur[2 * p + 1];
+      for (int j = 0; j < 3; ++j) frame->f_vec_[3 * s + j] = b->f_cur[3 * p + j];
+      frame->level_vec_[s] = b->search_level[p];
+      frame->score_vec_[s] = c.score;
+      if (r.kind == kLandmark) frame->landmark_vec_[s] = r.point;
+      else { frame->seed_ref_vec_[s].keyframe = c.ref_frame; frame->seed_ref_vec_[s].seed_id = static_cast<int>(c.ref_index); }
+      std::copy(c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index,
+                c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index + 4, frame->invmu_sigma2_a_b_vec_.begin() + 4 * s);
+      ++stats.n_matches;
+      ++frame->num_features_;
+      grid.setOccupied(grid_index);
+      if (max_n_features_per_frame > 0 && frame->num_features_ >= max_n_features_per_frame) break;
+    }
+    candidates.erase(candidates.begin(), candidates.begin() + static_cast<std::ptrdiff_t>(i));
+  }
+};
+}  // namespace
+
 void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features_per_frame, bool affine_est_offset,
                      bool affine_est_gain, std::vector<reprojector::Candidate>& candidates, OccupandyGrid2D& grid,
                      reprojector::Statistics& stats, double seed_sigma2_thresh)
 {
   if (!ctx) throw std::runtime_error("matchCandidates: NULL svoh_ctx (no CPU fallback exists)");
   if (!frame) throw std::runtime_error("matchCandidates: NULL frame");
-  const size_t n = candidates.size();
-  g_last_results.assign(n, -1);
-  if (n == 0) return;
+  g_last_results.assign(candidates.size(), -1);
+  if (candidates.empty()) return;
+  SpeculativeMatches sm;
+  const std::vector<Resolved> rs = sm.plan(frame, candidates);
+  sm.run(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
+  sm.replay(frame, max_n_features_per_frame, candidates, rs, grid, stats);
+}
 
-  // Matcher matcher; (defaults of matcher.h:39-54) + the two affine flags (reprojector.cpp:352-354)
-  svoh_matcher_options mopt{};
-  mopt.align_max_iter = 10; mopt.max_epi_search_steps = 100; mopt.subpix_refinement = 1;
-  mopt.epi_search_edgelet_filtering = 1; mopt.scan_on_unit_sphere = 1;
-  mopt.epi_search_edgelet_max_angle = 0.7; mopt.max_patch_diff_ratio = 2.0;
-  mopt.affine_est_offset = affine_est_offset; mopt.affine_est_gain = affine_est_gain;
-
-  // ---- what each candidate matches against (no dependence on any match result) ----
-  enum Kind { kConvergedSeed = 0, kUnconvergedSeed = 1, kLandmark = 2, kNoCloseView = 3 };
-  struct Resolved { Kind kind; FramePtr ref; size_t idx; PointPtr point; int frame_slot; int batch_pos; };
-  std::vector<Resolved> rs(n);
-  std::vector<FramePtr> frames;  // distinct reference frames
-  auto slot_of = [&](const FramePtr& f) {
-    for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == f) return static_cast<int>(k);
-    frames.push_back(f);
-    return static_cast<int>(frames.size() - 1);
-  };
-  for (size_t i = 0; i < n; ++i) {
-    const reprojector::Candidate& c = candidates[i];
-    if (!c.ref_frame || c.ref_index >= c.ref_frame->num_features_) throw std::runtime_error("matchCandidates: bad candidate");
-    Resolved& r = rs[i];
-    r.batch_pos = -1; r.frame_slot = -1;
-    PointPtr lm = c.ref_index < c.ref_frame->landmark_vec_.size() ? c.ref_frame->landmark_vec_[c.ref_index] : nullptr;
-    if (!lm) {
-      r.ref = c.ref_frame; r.idx = c.ref_index;
-      if (is_converged_seed(c.type)) r.kind = kConvergedSeed;
-      else if (is_unconverged_seed(c.type)) r.kind = kUnconvergedSeed;
-      else throw std::runtime_error("matchCandidates: seed type unknown");  // CHECK(false) in the reference
-    } else {
-      r.point = lm;
-      FramePtr rf; size_t ri = 0;
-      if (lm->getCloseViewObs(frame->pos(), rf, ri)) { r.kind = kLandmark; r.ref = rf; r.idx = ri; }
-      else r.kind = kNoCloseView;
-    }
-    if (r.kind != kNoCloseView) r.frame_slot = slot_of(r.ref);
+// Reprojector::reprojectFrames' three matchCandidates passes (reprojector.cpp:177-306) with ONE round trip to the
+// device: none of the three candidate lists depends on a match result (only on the visible keyframes and the current
+// pose), so all three are planned first, their matcher work runs as one direct batch plus one seed batch queued back
+// to back, and then the reference's control flow -- pass, enough-features test, grid marking, early return, the
+// feature budget of the unconverged seeds -- is replayed on finished results.  Work of a pass the control flow never
+// reaches is wasted, never visible: replay() alone touches the frame, the grid, the points and the seeds.
+void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh,
+                          std::vector<reprojector::Candidate>* lists[3], const std::function<bool(int pass, size_t& max_n)>& before_pass,
+                          const std::function<void(int pass)>& after_pass, OccupandyGrid2D& grid, reprojector::Statistics stats[3])
+{
+  if (!ctx) throw std::runtime_error("matchCandidatesFused: NULL svoh_ctx (no CPU fallback exists)");
+  SpeculativeMatches sm;
+  std::vector<Resolved> rs[3];
+  for (int k = 0; k < 3; ++k) rs[k] = sm.plan(frame, *lists[k]);
+  sm.run(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
+  for (int k = 0; k < 3; ++k) {
+    size_t max_n = 0;
+    if (!before_pass(k, max_n)) return;
+    sm.replay(frame, max_n, *lists[k], rs[k], grid, stats[k]);
+    after_pass(k);
   }
-  std::vector<svoh_frame_view> views;
-  for (const FramePtr& f : frames) {
-    svoh_frame_view v{};
-    v.frame = f->pyramid; v.cam = f->cam; svoh::store_rigid(f->T_f_w_, v.T_f_w);
-    v.seed_mu_range = f->seed_mu_range_; v.id = f->id();
-    views.push_back(v);
-  }
-  svoh_frame_view cur{};
-  cur.frame = frame->pyramid; cur.cam = frame->cam; svoh::store_rigid(frame->T_f_w_, cur.T_f_w);
-  cur.seed_mu_range = frame->seed_mu_range_; cur.id = frame->id();
-
-  // ---- two speculative batches ----
-  struct Batch {
-    std::vector<int32_t> ref_idx, level, result, search_level;
-    std::vector<double> px, f, grad, depth, state, px_cur, f_cur, A;
-    std::vector<uint8_t> type, success;
-    void push(const Frame& r, size_t i, int slot)
-    {
-      ref_idx.push_back(slot); level.push_back(r.level_vec_[i]); type.push_back(r.type_vec_[i]);
-      px.insert(px.end(), r.px_vec_.begin() + 2 * i, r.px_vec_.begin() + 2 * i + 2);
-      f.insert(f.end(), r.f_vec_.begin() + 3 * i, r.f_vec_.begin() + 3 * i + 3);
-      grad.insert(grad.end(), r.grad_vec_.begin() + 2 * i, r.grad_vec_.begin() + 2 * i + 2);
-    }
-    size_t size() const { return level.size(); }
-  } direct, seeds;
-  for (size_t i = 0; i < n; ++i) {
-    Resolved& r = rs[i];
-    const reprojector::Candidate& c = candidates[i];
-    if (r.kind == kConvergedSeed || r.kind == kLandmark) {
-      r.batch_pos = static_cast<int>(direct.size());
-      direct.push(*r.ref, r.idx, r.frame_slot);
-      if (r.kind == kConvergedSeed) direct.depth.push_back(r.ref->getSeedDepth(r.idx));
-      else {
-        const svoh::Vec3 p = r.ref->pos(), q = r.point->pos();  // (ref_frame->pos() - landmark->pos()).norm()
-        direct.depth.push_back(sqrt((p.x - q.x) * (p.x - q.x) + (p.y - q.y) * (p.y - q.y) + (p.z - q.z) * (p.z - q.z)));
-      }
-      direct.px_cur.push_back(c.cur_px[0]); direct.px_cur.push_back(c.cur_px[1]);
-    } else if (r.kind == kUnconvergedSeed) {
-      r.batch_pos = static_cast<int>(seeds.size());
-      seeds.push(*r.ref, r.idx, r.frame_slot);
-      seeds.state.insert(seeds.state.end(), r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx,
-                         r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx + 4);
-    }
-  }
-  auto batch_of = [](Batch& b) {
-    svoh_feature_batch fb{};
-    fb.n = static_cast<int32_t>(b.size());
-    fb.ref_frame_idx = b.ref_idx.data(); fb.px = b.px.data(); fb.f = b.f.data(); fb.grad = b.grad.data();
-    fb.level = b.level.data(); fb.type = b.type.data();
-    return fb;
-  };
-  if (direct.size()) {
-    const size_t m = direct.size();
-    direct.result.assign(m, 0); direct.search_level.assign(m, 0); direct.f_cur.assign(3 * m, 0.0); direct.A.assign(4 * m, 0.0);
-    const svoh_feature_batch fb = batch_of(direct);
-    const int rc = svoh_match_direct_batch(ctx, &mopt, static_cast<int>(views.size()), views.data(), &cur, &fb,
-                                           direct.depth.data(), direct.px_cur.data(), direct.result.data(),
-                                           direct.f_cur.data(), direct.search_level.data(), nullptr, direct.A.data());
-    if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_match_direct_batch: ") + svoh_last_error_string(ctx));
-  }
-  if (seeds.size()) {
-    const size_t m = seeds.size();
-    seeds.result.assign(m, 0); seeds.search_level.assign(m, 0); seeds.success.assign(m, 0);
-    seeds.px_cur.assign(2 * m, 0.0); seeds.f_cur.assign(3 * m, 0.0); seeds.A.assign(4 * m, 0.0);
-    const svoh_feature_batch fb = batch_of(seeds);
-    svoh_depth_filter_options o{};
-    o.seed_convergence_sigma2_thresh = seed_sigma2_thresh;      // updateSeed(..., seed_sigma2_thresh, false, false):
-    o.mappoint_convergence_sigma2_thresh = seed_sigma2_thresh;  // one threshold for every seed type here
-    o.px_error_angle = updateSeedPxErrorAngle(*frame);
-    o.check_visibility = 0; o.check_convergence = 0; o.use_vogiatzis_update = 1;
-    const svoh_seed_match_outputs outs{ seeds.px_cur.data(), seeds.f_cur.data(), seeds.search_level.data(), seeds.A.data() };
-    const int rc = svoh_update_seeds_batch_ex(ctx, &mopt, &o, static_cast<int>(views.size()), views.data(), &cur, &fb,
-                                              seeds.state.data(), seeds.success.data(), seeds.result.data(), nullptr, &outs);
-    if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_update_seeds_batch_ex: ") + svoh_last_error_string(ctx));
-  }
-
-  // ---- the reference's loop, replayed in candidate order (reprojector.cpp:356-381) ----
-  size_t i = 0;
-  for (size_t k = 0; k < n; ++k) {
-    reprojector::Candidate& c = candidates[k];
-    const Resolved& r = rs[k];
-    ++i;
-    const size_t grid_index = grid.getCellIndex(static_cast<int>(c.cur_px[0]), static_cast<int>(c.cur_px[1]), 1);
-    if (max_n_features_per_frame > 0 && grid.isOccupied(grid_index)) continue;
-    ++stats.n_trials;
-    bool ok = false;
-    const Batch* b = nullptr;
-    if (r.kind == kConvergedSeed || r.kind == kLandmark) {
-      b = &direct;
-      const int res = direct.result[r.batch_pos];
-      g_last_results[k] = res;
-      ok = res == SVOH_MATCH_SUCCESS;
-      c.cur_px[0] = direct.px_cur[2 * r.batch_pos]; c.cur_px[1] = direct.px_cur[2 * r.batch_pos + 1];  // Keypoint& px_cur
-      if (r.kind == kLandmark) { if (ok) r.point->n_succeeded_reproj_ += 1; else r.point->n_failed_reproj_++; }
-    } else if (r.kind == kUnconvergedSeed) {
-      b = &seeds;
-      g_last_results[k] = seeds.result[r.batch_pos];
-      ok = seeds.success[r.batch_pos] != 0;
-      // updateSeed changed the seed of the reference frame whether it succeeded or not
-      std::copy(seeds.state.begin() + 4 * r.batch_pos, seeds.state.begin() + 4 * r.batch_pos + 4,
-                r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx);
-      r.ref->type_vec_[r.idx] = seeds.type[r.batch_pos];
-    } else {
-      g_last_results[k] = 1000;
-    }
-    if (!ok) continue;
-    // matchCandidate's tail (:455-486): fill the first free slot of the frame
-    const size_t s = frame->num_features_;
-    grow(frame->px_vec_, 2 * (s + 1)); grow(frame->f_vec_, 3 * (s + 1)); grow(frame->grad_vec_, 2 * (s + 1));
-    grow(frame->level_vec_, s + 1); grow(frame->type_vec_, s + 1); grow(frame->score_vec_, s + 1);
-    grow(frame->invmu_sigma2_a_b_vec_, 4 * (s + 1)); grow(frame->landmark_vec_, s + 1); grow(frame->seed_ref_vec_, s + 1);
-    const int p = r.batch_pos;
-    if (is_edgelet(c.type)) {
-      const double* A = &b->A[4 * p];
-      const double* g = &r.ref->grad_vec_[2 * r.idx];
-      double g0 = A[0] * g[0] + A[2] * g[1], g1 = A[1] * g[0] + A[3] * g[1];
-      const double z = g0 * g0 + g1 * g1;
-      if (z > 0.0) { const double nn = sqrt(z); g0 /= nn; g1 /= nn; }
-      frame->grad_vec_[2 * s] = g0; frame->grad_vec_[2 * s + 1] = g1;
-    }
-    frame->type_vec_[s] = c.type;
-    frame->px_vec_[2 * s] = b->px_cur[2 * p]; frame->px_vec_[2 * s + 1] = b->px_cur[2 * p + 1];
-    for (int j = 0; j < 3; ++j) frame->f_vec_[3 * s + j] = b->f_cur[3 * p + j];
-    frame->level_vec_[s] = b->search_level[p];
-    frame->score_vec_[s] = c.score;
-    if (r.kind == kLandmark) frame->landmark_vec_[s] = r.point;
-    else { frame->seed_ref_vec_[s].keyframe = c.ref_frame; frame->seed_ref_vec_[s].seed_id = static_cast<int>(c.ref_index); }
-    std::copy(c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index,
-              c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index + 4, frame->invmu_sigma2_a_b_vec_.begin() + 4 * s);
-    ++stats.n_matches;
-    ++frame->num_features_;
-    grid.setOccupied(grid_index);
-    if (max_n_features_per_frame > 0 && frame->num_features_ >= max_n_features_per_frame) break;
-  }
-  candidates.erase(candidates.begin(), candidates.begin() + static_cast<std::ptrdiff_t>(i));
 }
 }  // namespace reprojector_utils
 

@@ -3,6 +3,7 @@ CPU oracle.  Bars: measurement sigma (a float median) exact, iteration counts / 
 pose <= 1e-9 (fp64 sums in a different order), per-feature final errors rel 1e-9."""
 import numpy as np
 import pytest
+import torch  # before the first svoh call of the process: one HIP runtime for both (see _capi._share_hip_runtime_with_torch)
 
 from svo_pro_universal_amd import _capi as capi, frontend as fe, synth
 
@@ -131,7 +132,6 @@ def test_packed_device_arrays_equal_the_host_staged_call(gpu_ctx):
     """svoh_optimize_pose_batch_packed: the per-feature arrays of all bundles concatenated on the device and used in
     place (nothing but descriptors and per-bundle results crosses PCIe) -- bit-identical to the host-staged call."""
     import ctypes as C
-    import torch
     scs = [ph.make_pose_scene(60 + k, n=60 + 37 * k, n_cams=1 + k % 2) for k in range(5)]
     opt = capi.default_pose_options(scs[0]["cam"])
     built = [fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"]) for sc in scs]
