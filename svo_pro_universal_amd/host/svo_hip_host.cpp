@@ -1,6 +1,9 @@
 #include "svo_hip_host.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -866,9 +869,25 @@ ReprojectorHip::ReprojectorHip(svoh_ctx* ctx, const ReprojectorOptions& options,
   if (camera_index_ >= SVOH_MAX_CAMS) throw std::runtime_error("ReprojectorHip: camera index out of range");
 }
 
+namespace {
+struct ReprojTiming {   // SVOH_REPROJ_TIMING=1: mean host / device split of reprojectFrames, printed at exit
+  bool on = getenv("SVOH_REPROJ_TIMING") != nullptr;
+  double t[6] = { 0, 0, 0, 0, 0, 0 };
+  long n = 0, n_direct = 0, n_seeds = 0, n_reached3 = 0, n_spec3 = 0;
+  static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  ~ReprojTiming()
+  {
+    if (on && n)
+      fprintf(stderr, "[reproject] per call: candidates %.3f ms, sort %.3f, plan %.3f, device round trip(s) %.3f, replay %.3f, other %.3f (%ld calls; per call %.0f direct + %.0f seed units speculated; unconverged pass reached %ld x, speculated %ld x)\n",
+              t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n, n, (double)n_direct / n, (double)n_seeds / n, n_reached3, n_spec3);
+  }
+} g_reproj_timing;
+}  // namespace
+
 void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs,
                                      std::vector<PointPtr>& trash_points)
 {
+  const double ts0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   const size_t max_total_n_features = options_.max_n_features_per_frame;   // + max_n_fixed_lm, 0 without the global map
   if (options_.max_n_features_per_frame == 0) throw std::runtime_error("Reprojector: max_n_features_per_frame must be > 0");   // CHECK_GT
   if (!grid_)
@@ -894,6 +913,7 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
       if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) candidates_.push_back(candidate);
     }
   }
+  const double ts1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   reprojector_utils::sortCandidatesByReprojStats(candidates_);
 
   // converged seeds (:201-241) and unconverged seeds (:243-306): their candidate lists depend on the visible
@@ -908,8 +928,10 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
       reprojector::Candidate candidate;
       if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) (conv ? converged : unconverged).push_back(candidate);
     }
+  const double ts2 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   reprojector_utils::sortCandidatesByReprojStats(converged);
   reprojector_utils::sortCandidatesByReprojStats(unconverged);
+  const double ts3 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
 
   std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged, &unconverged };
   reprojector::Statistics st[3];
@@ -945,10 +967,23 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
       if (doesFrameHaveEnoughFeatures(cur_frame)) reprojector_utils::setGridCellsOccupied(unconverged, *grid_);    // :300-305
     }
   };
+  // The unconverged seeds are many (up to max_n_kfs x max_seeds per frame) and their pass is only reached when the
+  // landmarks and converged seeds did not fill the frame: their matcher work joins the common round trip only if the
+  // pass was reached on the previous frame (a wrong guess costs one extra round trip or some unused work, nothing else).
+  bool reached_unconverged = false;
+  auto after = [&](int pass) { if (pass == 2) reached_unconverged = true; after_pass(pass); };
   reprojector_utils::matchCandidatesFused(ctx_, cur_frame, options_.affine_est_offset, options_.affine_est_gain, options_.seed_sigma2_thresh,
-                                          lists, [&](int pass, size_t& max_n) { return !stop && before_pass(pass, max_n); }, after_pass,
-                                          *grid_, st);
+                                          lists, [&](int pass, size_t& max_n) { return !stop && before_pass(pass, max_n); }, after,
+                                          *grid_, st, speculate_unconverged_ ? 3 : 2);
+  speculate_unconverged_ = reached_unconverged;
   candidates_.clear();
+  if (g_reproj_timing.on) {
+    g_reproj_timing.n_reached3 += reached_unconverged;
+    const double ts4 = ReprojTiming::now();
+    g_reproj_timing.t[0] += (ts1 - ts0) + (ts2 - ts1 - 0.0) ; g_reproj_timing.t[1] += ts3 - ts2;
+    g_reproj_timing.t[5] += ts4 - ts3;   // plan + device + replay together (split below when the fused call reports it)
+    ++g_reproj_timing.n;
+  }
 }
 
 namespace reprojector_utils {
@@ -1238,17 +1273,23 @@ void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features
 // reaches is wasted, never visible: replay() alone touches the frame, the grid, the points and the seeds.
 void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh,
                           std::vector<reprojector::Candidate>* lists[3], const std::function<bool(int pass, size_t& max_n)>& before_pass,
-                          const std::function<void(int pass)>& after_pass, OccupandyGrid2D& grid, reprojector::Statistics stats[3])
+                          const std::function<void(int pass)>& after_pass, OccupandyGrid2D& grid, reprojector::Statistics stats[3],
+                          int n_speculated)
 {
   if (!ctx) throw std::runtime_error("matchCandidatesFused: NULL svoh_ctx (no CPU fallback exists)");
   SpeculativeMatches sm;
   std::vector<Resolved> rs[3];
-  for (int k = 0; k < 3; ++k) rs[k] = sm.plan(frame, *lists[k]);
+  const double tp0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  for (int k = 0; k < 3 && k < n_speculated; ++k) rs[k] = sm.plan(frame, *lists[k]);
+  const double tp1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   sm.run(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
+  if (g_reproj_timing.on) { g_reproj_timing.n_direct += (long)sm.direct.size(); g_reproj_timing.n_seeds += (long)sm.seeds.size(); g_reproj_timing.n_spec3 += n_speculated == 3; }
+  if (g_reproj_timing.on) { const double tp2 = ReprojTiming::now(); g_reproj_timing.t[2] += tp1 - tp0; g_reproj_timing.t[3] += tp2 - tp1; g_reproj_timing.t[5] -= tp2 - tp0; }
   for (int k = 0; k < 3; ++k) {
     size_t max_n = 0;
     if (!before_pass(k, max_n)) return;
-    sm.replay(frame, max_n, *lists[k], rs[k], grid, stats[k]);
+    if (k < n_speculated) sm.replay(frame, max_n, *lists[k], rs[k], grid, stats[k]);
+    else matchCandidates(ctx, frame, max_n, affine_est_offset, affine_est_gain, *lists[k], grid, stats[k], seed_sigma2_thresh);   // a pass nobody bet on: its own round trip
     after_pass(k);
   }
 }

@@ -417,6 +417,7 @@ class ReprojectorHip {
  private:
   svoh_ctx* ctx_;
   size_t camera_index_;
+  bool speculate_unconverged_ = false;   // was the unconverged-seed pass reached on the previous frame?
 };
 
 namespace reprojector_utils {
@@ -437,7 +438,8 @@ void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features
 // loop over list k / after_pass(k) run for k = 0, 1, 2 until before_pass says stop (Reprojector::reprojectFrames).
 void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh,
                           std::vector<reprojector::Candidate>* lists[3], const std::function<bool(int pass, size_t& max_n)>& before_pass,
-                          const std::function<void(int pass)>& after_pass, OccupandyGrid2D& grid, reprojector::Statistics stats[3]);
+                          const std::function<void(int pass)>& after_pass, OccupandyGrid2D& grid, reprojector::Statistics stats[3],
+                          int n_speculated = 3);   // lists [n_speculated, 3) are matched only when their pass is reached
 // Matcher::MatchResult per candidate of the last call on this thread (-1 = never reached / cell taken,
 // 1000 = landmark without a close view), for tests and statistics.
 const std::vector<int32_t>& lastMatchResults();
