@@ -205,7 +205,7 @@ extern "C" {
 int svoh_abi_version(void) { return SVOH_ABI_VERSION; }
 
 int svoh_create(int device, svoh_ctx** out_ctx)
-{
+try {
   if (!out_ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
   *out_ctx = nullptr;
   int n = 0;
@@ -239,10 +239,10 @@ int svoh_create(int device, svoh_ctx** out_ctx)
   ctx->lds_per_block = prop.sharedMemPerBlock;
   *out_ctx = ctx;
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(nullptr)
 
 int svoh_destroy(svoh_ctx* ctx)
-{
+try {
   if (!ctx) return SVOH_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
@@ -257,7 +257,7 @@ int svoh_destroy(svoh_ctx* ctx)
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 const char* svoh_last_error_string(const svoh_ctx* ctx)
 {
@@ -265,16 +265,16 @@ const char* svoh_last_error_string(const svoh_ctx* ctx)
 }
 
 int svoh_synchronize(svoh_ctx* ctx)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 void* svoh_stream(svoh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int svoh_last_kernel_counters(svoh_ctx* ctx, uint64_t out[8])
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, out != nullptr && ctx->misc_timed && ctx->d_counters.ptr, "no counters yet");
   if (ctx->unit_counts_pending) {
@@ -285,20 +285,20 @@ int svoh_last_kernel_counters(svoh_ctx* ctx, uint64_t out[8])
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_counters.ptr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_last_kernel_ms(svoh_ctx* ctx, float* ms)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, ms != nullptr && ctx->misc_timed, "no KLT / matcher / seed kernel has been launched yet");
   SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_misc_stop));
   SVOH_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_misc_start, ctx->ev_misc_stop));
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_upload_pyramid(svoh_ctx* ctx, int n_levels, const uint8_t* const* level_data, const int* width,
                         const int* height, const int* pitch, svoh_frame_t* out_frame)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, out_frame && level_data && width && height && pitch, "NULL argument");
   SVOH_REQUIRE(ctx, n_levels >= 1 && n_levels <= SVOH_MAX_LEVELS, "n_levels out of range");
@@ -321,12 +321,12 @@ int svoh_upload_pyramid(svoh_ctx* ctx, int n_levels, const uint8_t* const* level
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   *out_frame = register_frame(ctx, slab, base, width[0], height[0], n_levels);
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_build_pyramid_batch(svoh_ctx* ctx, const uint8_t* img, size_t image_stride, int n_images, int width,
                              int height, int pitch, int mem_space, int n_levels, int rounding,
                              svoh_frame_t* out_frames)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, img && out_frames, "NULL argument");
   SVOH_REQUIRE(ctx, n_images >= 1 && width > 0 && height > 0 && pitch >= width, "bad image geometry");
@@ -357,11 +357,11 @@ int svoh_build_pyramid_batch(svoh_ctx* ctx, const uint8_t* img, size_t image_str
   for (int i = 0; i < n_images; ++i)
     out_frames[i] = register_frame(ctx, slab, base + fbytes * i, width, height, n_levels);
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_build_pyramid(svoh_ctx* ctx, const uint8_t* img, int width, int height, int pitch, int mem_space,
                        int n_levels, int rounding, uint8_t* const* host_levels_out, svoh_frame_t* out_frame)
-{
+try {
   int rc = svoh_build_pyramid_batch(ctx, img, (size_t)pitch * height, 1, width, height, pitch, mem_space, n_levels,
                                     rounding, out_frame);
   if (rc != SVOH_OK) return rc;
@@ -375,10 +375,10 @@ int svoh_build_pyramid(svoh_ctx* ctx, const uint8_t* img, int width, int height,
     SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_download_level(svoh_ctx* ctx, svoh_frame_t frame, int level, uint8_t* out, int* out_width, int* out_height)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   const Frame* f = find_frame(ctx, frame);
   if (!f) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frame);
@@ -392,10 +392,10 @@ int svoh_download_level(svoh_ctx* ctx, svoh_frame_t frame, int level, uint8_t* o
     SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_frame_info(svoh_ctx* ctx, svoh_frame_t frame, int* n_levels, int* width0, int* height0)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   const Frame* f = find_frame(ctx, frame);
   if (!f) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frame);
@@ -403,10 +403,10 @@ int svoh_frame_info(svoh_ctx* ctx, svoh_frame_t frame, int* n_levels, int* width
   if (width0) *width0 = f->lv[0].w;
   if (height0) *height0 = f->lv[0].h;
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_context_stats(svoh_ctx* ctx, svoh_context_stats_t* out)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, out != nullptr, "NULL argument");
   out->live_frames = (int64_t)ctx->frames.size();
@@ -422,10 +422,10 @@ int svoh_context_stats(svoh_ctx* ctx, svoh_context_stats_t* out)
   for (const svoh::DevBuffer* b : bufs) wb += b->cap;
   out->workspace_bytes = (int64_t)wb;
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_release_frame(svoh_ctx* ctx, svoh_frame_t frame)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   auto it = ctx->frames.find(frame);
   if (it == ctx->frames.end())
@@ -433,6 +433,6 @@ int svoh_release_frame(svoh_ctx* ctx, svoh_frame_t frame)
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // no kernel may still read it
   ctx->frames.erase(it);
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 }  // extern "C"

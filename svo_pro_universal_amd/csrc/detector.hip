@@ -245,7 +245,7 @@ extern "C" int svoh_detect_features(svoh_ctx* ctx, svoh_frame_t frame, const svo
                                     const uint8_t* occupancy, const uint8_t* mask, int mask_pitch, int max_n_features,
                                     double* px, double* score, int32_t* level, double* grad, uint8_t* type,
                                     int32_t* n_features)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, options && px && score && level && grad && type && n_features, "NULL argument");
   *n_features = 0;
@@ -367,4 +367,4 @@ extern "C" int svoh_detect_features(svoh_ctx* ctx, svoh_frame_t frame, const svo
   ctx->misc_timed = true;
   *n_features = n;
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)

@@ -269,7 +269,7 @@ static int launch_klt(svoh_ctx* ctx, const svoh_klt_options* options, const std:
 extern "C" int svoh_klt_track_multi(svoh_ctx* ctx, const svoh_klt_options* options, int n_tracks,
                                     const svoh_frame_t* ref_frames, const svoh_frame_t* cur_frames,
                                     const int32_t* px_ref, double* px_cur, uint8_t* status)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, options && n_tracks >= 0, "bad arguments");
   if (n_tracks == 0) return SVOH_OK;
@@ -312,22 +312,22 @@ extern "C" int svoh_klt_track_multi(svoh_ctx* ctx, const svoh_klt_options* optio
   }
   return launch_klt(ctx, options, frames, n_tracks, SVOH_MEM_HOST, idx.data(), idx.data() + n_tracks, px_ref, px_cur,
                     status);
-}
+} SVOH_ABI_CATCH(ctx)
 
 extern "C" int svoh_klt_track_batch(svoh_ctx* ctx, const svoh_klt_options* options, int n_tracks,
                                     const svoh_frame_t* ref_frames, svoh_frame_t cur_frame, const int32_t* px_ref,
                                     double* px_cur, uint8_t* status)
-{
+try {
   if (n_tracks <= 0) return n_tracks == 0 ? SVOH_OK : set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "negative n_tracks");
   std::vector<svoh_frame_t> cur((size_t)n_tracks, cur_frame);
   return svoh_klt_track_multi(ctx, options, n_tracks, ref_frames, cur.data(), px_ref, px_cur, status);
-}
+} SVOH_ABI_CATCH(ctx)
 
 extern "C" int svoh_klt_track_indexed(svoh_ctx* ctx, const svoh_klt_options* options, int n_frames,
                                       const svoh_frame_t* frames, int n_tracks, const int32_t* ref_frame_idx,
                                       const int32_t* cur_frame_idx, const int32_t* px_ref, double* px_cur,
                                       uint8_t* status, int mem_space)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, options && n_tracks >= 0 && n_frames >= 1 && frames, "bad arguments");
   SVOH_REQUIRE(ctx, mem_space == SVOH_MEM_HOST || mem_space == SVOH_MEM_DEVICE, "bad mem_space");
@@ -355,4 +355,4 @@ extern "C" int svoh_klt_track_indexed(svoh_ctx* ctx, const svoh_klt_options* opt
       if (ref_frame_idx[i] < 0 || ref_frame_idx[i] >= n_frames || cur_frame_idx[i] < 0 || cur_frame_idx[i] >= n_frames)
         return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "track %d: frame index out of range", i);
   return launch_klt(ctx, options, tab, n_tracks, mem_space, ref_frame_idx, cur_frame_idx, px_ref, px_cur, status);
-}
+} SVOH_ABI_CATCH(ctx)

@@ -609,8 +609,12 @@ __device__ __forceinline__ void g8_chain_sub(float (&acc)[NA], const float (&t)[
   for (int a = 0; a < NA; ++a) c[a] = acc[a];
   for (int s = 0; s < 8; ++s) {
     float in[NA];
+    // lane i takes lane i-1's value on the VALU's DPP network (row_shr:1; one v_mov_dpp instead of a ds_bpermute round
+    // trip through the LDS crossbar per stage and accumulator).  Rows are 16 lanes: the first lane of the second
+    // group of a row receives the last lane of the first group's value, which it never uses (sub == 0 starts from acc).
 #pragma unroll
-    for (int a = 0; a < NA; ++a) in[a] = __shfl_up(c[a], 1, 8);
+    for (int a = 0; a < NA; ++a)
+      in[a] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[a]), 0x111, 0xF, 0xF, false));
     if (sub == s) {
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
@@ -2284,12 +2288,12 @@ int svoh_epipolar_match_batch(svoh_ctx* ctx, const svoh_matcher_options* options
                               const svoh_se3* T_cur_ref, const svoh_feature_batch* features,
                               const double d_inv_common[3], const double* d_inv,
                               const svoh_epipolar_match_outputs* outputs)
-{
+try {
   return run_epipolar(ctx, options, n_ref_frames, ref_frames, cur_frame, T_cur_ref, features, d_inv_common, d_inv, outputs);
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_matcher_begin_deferred(svoh_ctx* ctx)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, !ctx->matcher_deferred, "a deferred section is already open");
   ctx->matcher_deferred = true;
@@ -2297,10 +2301,10 @@ int svoh_matcher_begin_deferred(svoh_ctx* ctx)
   ctx->matcher_pending.clear();
   ctx->matcher_pending_counts.clear();
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_matcher_collect(svoh_ctx* ctx)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, ctx->matcher_deferred, "no deferred section is open");
   ctx->matcher_deferred = false;
@@ -2316,37 +2320,37 @@ int svoh_matcher_collect(svoh_ctx* ctx)
   ctx->matcher_pending.clear();
   ctx->matcher_pending_counts.clear();
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options, int n_ref_frames,
                             const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
                             const svoh_feature_batch* features, const double* depth, double* px_cur, int32_t* result,
                             double* f_cur, int32_t* search_level, double* h_inv, double* A_cur_ref)
-{
+try {
   return run_matcher(ctx, false, options, nullptr, n_ref_frames, ref_frames, cur_frame, features, depth, px_cur, result,
                      f_cur, search_level, h_inv, A_cur_ref, nullptr, nullptr, nullptr);
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_update_seeds_batch(svoh_ctx* ctx, const svoh_matcher_options* matcher_options,
                             const svoh_depth_filter_options* options, int n_ref_frames,
                             const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
                             const svoh_feature_batch* features, double* state, uint8_t* success, int32_t* match_result,
                             int32_t* n_success)
-{
+try {
   return run_matcher(ctx, true, matcher_options, options, n_ref_frames, ref_frames, cur_frame, features, nullptr, nullptr,
                      match_result, nullptr, nullptr, nullptr, nullptr, state, success, n_success);
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_update_seeds_batch_ex(svoh_ctx* ctx, const svoh_matcher_options* matcher_options,
                                const svoh_depth_filter_options* options, int n_ref_frames,
                                const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
                                const svoh_feature_batch* features, double* state, uint8_t* success,
                                int32_t* match_result, int32_t* n_success, const svoh_seed_match_outputs* outputs)
-{
+try {
   const svoh_seed_match_outputs none = { nullptr, nullptr, nullptr, nullptr };
   const svoh_seed_match_outputs& o = outputs ? *outputs : none;
   return run_matcher(ctx, true, matcher_options, options, n_ref_frames, ref_frames, cur_frame, features, nullptr, o.px_cur,
                      match_result, o.f_cur, o.search_level, nullptr, o.A_cur_ref, state, success, n_success);
-}
+} SVOH_ABI_CATCH(ctx)
 
 }  // extern "C"

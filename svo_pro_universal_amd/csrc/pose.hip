@@ -592,10 +592,19 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
   } else if (n_stage_threads <= 1) {
     stage_range(0, n_problems);
   } else {
+    // a thread that cannot be started (pid limit of a container) must not take the call down: its range, and every
+    // later one, is copied by this thread, and whatever was started is joined before anything can be thrown past it
     std::vector<std::thread> workers;
-    for (int t = 1; t < n_stage_threads; ++t)
-      workers.emplace_back(stage_range, (int)((long long)n_problems * t / n_stage_threads), (int)((long long)n_problems * (t + 1) / n_stage_threads));
+    workers.reserve((size_t)n_stage_threads);
+    int first_serial = n_stage_threads;
+    for (int t = 1; t < n_stage_threads; ++t) {
+      try {
+        workers.emplace_back(stage_range, (int)((long long)n_problems * t / n_stage_threads), (int)((long long)n_problems * (t + 1) / n_stage_threads));
+      } catch (...) { first_serial = t; break; }
+    }
     stage_range(0, n_problems / n_stage_threads);
+    for (int t = first_serial; t < n_stage_threads; ++t)
+      stage_range((int)((long long)n_problems * t / n_stage_threads), (int)((long long)n_problems * (t + 1) / n_stage_threads));
     for (auto& w : workers) w.join();
   }
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
@@ -645,23 +654,23 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
 
 extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
                                         const svoh_pose_problem* problems, svoh_pose_result* results)
-{
+try {
   return run_pose_batch(ctx, options, n_problems, problems, nullptr, results);
-}
+} SVOH_ABI_CATCH(ctx)
 
 extern "C" int svoh_optimize_pose_batch_packed(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
                                                const svoh_pose_problem* problems, const svoh_pose_packed_arrays* arrays,
                                                svoh_pose_result* results)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, arrays != nullptr, "NULL argument");
   return run_pose_batch(ctx, options, n_problems, problems, arrays, results);
-}
+} SVOH_ABI_CATCH(ctx)
 
 extern "C" int svoh_optimize_points_batch(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,
                                           const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
                                           const int32_t* obs_view, const double* obs_f, double* pos, int32_t* iters)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, n_points >= 0 && n_views >= 0 && n_iter >= 0, "negative count");
   if (n_points == 0) return SVOH_OK;
@@ -704,4 +713,4 @@ extern "C" int svoh_optimize_points_batch(svoh_ctx* ctx, int n_iter, int using_b
   memcpy(pos, h + o_pos, 24 * (size_t)n_points);
   if (iters) memcpy(iters, h + o_it, 4 * (size_t)n_points);
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)

@@ -345,8 +345,10 @@ __device__ __forceinline__ void patch_moments_part(
 #pragma unroll
     for (int x = 0; x < P; ++x) {
       const double ref_val = it1[x + 1];
-      const double dx = 0.5 * (it1[x + 2] - it1[x]);
-      const double dy = 0.5 * (it2[x + 1] - it0[x + 1]);
+      // twice the central differences: the factor 1/2 (1/4 for the products of two gradients) is applied to the
+      // finished moments in patch_moments -- a power of two commutes with every rounding, so the bits are the same
+      const double dx = it1[x + 2] - it1[x];
+      const double dy = it2[x + 1] - it0[x + 1];
       const double intensity_cur = cwtl * (double)curA[x] + cwtr * (double)curA[x + 1] +
                                    cwbl * (double)curB[x] + cwbr * (double)curB[x + 1];
       const double res = (intensity_cur * one_plus_alpha + beta) - ref_val;
@@ -406,6 +408,12 @@ __device__ __forceinline__ void patch_moments(
   } else {
     patch_moments_part<P, P, D, RLDS, CLDS, GONLY, true>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta,
                                                          robust, weight_scale, mom);
+  }
+  // dx, dy above are twice the central differences (sparse_img_align.cpp:386-387 has the 0.5)
+  mom[3] *= 0.5; mom[4] *= 0.5;
+  if constexpr (!GONLY) {
+    mom[0] *= 0.25; mom[1] *= 0.25; mom[2] *= 0.25;
+    if constexpr (D == 8) { mom[6] *= 0.5; mom[7] *= 0.5; mom[10] *= 0.5; mom[11] *= 0.5; }
   }
 }
 
@@ -1645,12 +1653,12 @@ extern "C" {
 
 int svoh_sparse_align_enqueue(svoh_ctx* ctx, const svoh_align_options* options, int n_problems,
                               const svoh_align_problem* problems)
-{
+try {
   return enqueue_align(ctx, options, n_problems, problems, -1);
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* results)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, results && n_problems >= 1 && n_problems <= ctx->last_align_n, "nothing to fetch");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1659,10 +1667,10 @@ int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* re
          sizeof(svoh_align_result) * n_problems);
   ctx->align_pending_results = 0;
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_sparse_align_fetch_all(svoh_ctx* ctx, int n_results, svoh_align_result* results)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, results && n_results >= 1 && (size_t)n_results == ctx->align_pending_results,
                "n_results is not the number of results queued since the last fetch");
@@ -1671,11 +1679,11 @@ int svoh_sparse_align_fetch_all(svoh_ctx* ctx, int n_results, svoh_align_result*
   memcpy(results, ctx->h_results.ptr, sizeof(svoh_align_result) * (size_t)n_results);
   ctx->align_pending_results = 0;
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options, int n_problems,
                             const svoh_align_problem* problems, svoh_align_result* results)
-{
+try {
   int rc = enqueue_align(ctx, options, n_problems, problems, -1);
   if (rc != SVOH_OK) return rc;
   rc = svoh_sparse_align_fetch(ctx, n_problems, results);
@@ -1693,20 +1701,20 @@ int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options, in
     rc = svoh_sparse_align_fetch(ctx, n_problems, results);
   }
   return rc;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_sparse_align_last_kernel_ms(svoh_ctx* ctx, float* ms)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, ms != nullptr && ctx->align_launches > 0, "no alignment launch to time");
   const int slot = (int)((ctx->align_launches - 1) % svoh_ctx::kAlignEventRing);
   SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_stop[slot]));
   SVOH_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_align_start[slot], ctx->ev_align_stop[slot]));
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_sparse_align_kernel_ms_history(svoh_ctx* ctx, int n, float* ms, int* n_out)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, ms != nullptr && n_out != nullptr && n >= 0, "bad arguments");
   int have = (int)(ctx->align_launches < (unsigned long long)svoh_ctx::kAlignEventRing ? ctx->align_launches
@@ -1719,12 +1727,12 @@ int svoh_sparse_align_kernel_ms_history(svoh_ctx* ctx, int n, float* ms, int* n_
   }
   *n_out = have;
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_sparse_align_evaluate(svoh_ctx* ctx, const svoh_align_options* options, const svoh_align_problem* problem,
                                int level, double* H64, double* g8, double* chi2, int32_t* n_meas,
                                uint8_t* visibility, int32_t* n_selected)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, problem && H64 && g8, "NULL argument");
   SVOH_REQUIRE(ctx, level >= 0 && options && level <= options->max_level, "level out of range");
@@ -1752,10 +1760,10 @@ int svoh_sparse_align_evaluate(svoh_ctx* ctx, const svoh_align_options* options,
     if (sel[i]) { if (visibility) visibility[k] = vis[i]; ++k; }
   if (n_selected) *n_selected = k;
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_sparse_align_split_buffers(svoh_ctx* ctx, svoh_align_gn_state** d_state, double** d_sums)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, d_state && d_sums, "NULL argument");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1764,10 +1772,10 @@ int svoh_sparse_align_split_buffers(svoh_ctx* ctx, svoh_align_gn_state** d_state
   *d_state = static_cast<svoh_align_gn_state*>(ctx->d_split.ptr);
   *d_sums = reinterpret_cast<double*>(static_cast<uint8_t*>(ctx->d_split.ptr) + state_bytes);
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_sparse_align_split_init(svoh_ctx* ctx, const svoh_align_problem* problem, svoh_align_gn_state* d_state)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, problem && d_state, "NULL argument");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1780,11 +1788,11 @@ int svoh_sparse_align_split_init(svoh_ctx* ctx, const svoh_align_problem* proble
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(d_state, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // h is a stack object
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_sparse_align_partial_sums(svoh_ctx* ctx, const svoh_align_options* options, const svoh_align_problem* problem,
                                    int level, int n_workgroups, const svoh_align_gn_state* d_state, double* d_sums)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, problem && d_state && d_sums, "NULL argument");
   SVOH_REQUIRE(ctx, options && level >= 0 && level <= options->max_level, "level out of range");
@@ -1803,12 +1811,12 @@ int svoh_sparse_align_partial_sums(svoh_ctx* ctx, const svoh_align_options* opti
   sp.sums_out = d_sums;
   sp.n_shares = n_workgroups;
   return enqueue_align(ctx, options, 1, problem, level, &sp);
-}
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_sparse_align_gn_update(svoh_ctx* ctx, const svoh_align_options* options, const svoh_align_problem* problem,
                                 int level, int iter, const double* d_sums, svoh_align_gn_state* d_state,
                                 svoh_align_gn_state* h_state)
-{
+try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, problem && d_state && d_sums, "NULL argument");
   SVOH_REQUIRE(ctx, options && level >= 0 && level <= options->max_level && iter >= 0, "level / iteration out of range");
@@ -1823,6 +1831,6 @@ int svoh_sparse_align_gn_update(svoh_ctx* ctx, const svoh_align_options* options
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(h_state, d_state, sizeof *h_state, hipMemcpyDeviceToHost, ctx->stream));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return SVOH_OK;
-}
+} SVOH_ABI_CATCH(ctx)
 
 }  // extern "C"

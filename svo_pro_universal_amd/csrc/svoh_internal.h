@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -153,6 +155,12 @@ __device__ __forceinline__ int wave_sum_i32_dpp(int v)
   return __builtin_amdgcn_readlane(v, 63);
 }
 #endif
+
+// No exception crosses the C ABI (include/svo_hip.h): every entry point is a function-try-block ending in this.
+#define SVOH_ABI_CATCH(ctxexpr)                                                                                  \
+  catch (const std::bad_alloc&) { return svoh::set_error((ctxexpr), SVOH_ERR_OUT_OF_MEMORY, "out of host memory"); } \
+  catch (const std::exception& e_) { return svoh::set_error((ctxexpr), SVOH_ERR_HIP, "exception at the ABI: %s", e_.what()); } \
+  catch (...) { return svoh::set_error((ctxexpr), SVOH_ERR_HIP, "unknown exception at the ABI"); }
 
 #define SVOH_HIP_TRY(ctx, expr)                                                          \
   do {                                                                                   \

@@ -30,6 +30,37 @@ __global__ __launch_bounds__(256) void fma64_kernel(double* out, int iters, doub
   if (s == 12345.678) out[0] = s;   // never true: keeps the loop alive
 }
 
+// issue rate of v_cvt_f64_u32 against the two-instruction exact alternative (2^52 trick: or the integer into the
+// mantissa of 2^52, subtract 2^52), 8 independent chains each
+__global__ __launch_bounds__(256) void cvt64_kernel(double* out, int iters, unsigned seed)
+{
+  unsigned x0 = seed + threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  double s = 0.0;
+  for (int i = 0; i < iters; ++i) {
+    const double d0 = (double)(x0 & 255u), d1 = (double)(x1 & 255u), d2 = (double)(x2 & 255u), d3 = (double)(x3 & 255u);
+    const double d4 = (double)(x4 & 255u), d5 = (double)(x5 & 255u), d6 = (double)(x6 & 255u), d7 = (double)(x7 & 255u);
+    s += ((d0 + d1) + (d2 + d3)) + ((d4 + d5) + (d6 + d7));
+    x0 += 3; x1 += 5; x2 += 7; x3 += 11; x4 += 13; x5 += 17; x6 += 19; x7 += 23;
+  }
+  if (s == 12345.678) out[0] = s;
+}
+__device__ __forceinline__ double u8_to_f64_magic(unsigned v)
+{
+  return __hiloint2double(0x43300000, (int)v) - 4503599627370496.0;   // exact for v < 2^32
+}
+__global__ __launch_bounds__(256) void cvt64_magic_kernel(double* out, int iters, unsigned seed)
+{
+  unsigned x0 = seed + threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  double s = 0.0;
+  for (int i = 0; i < iters; ++i) {
+    const double d0 = u8_to_f64_magic(x0 & 255u), d1 = u8_to_f64_magic(x1 & 255u), d2 = u8_to_f64_magic(x2 & 255u), d3 = u8_to_f64_magic(x3 & 255u);
+    const double d4 = u8_to_f64_magic(x4 & 255u), d5 = u8_to_f64_magic(x5 & 255u), d6 = u8_to_f64_magic(x6 & 255u), d7 = u8_to_f64_magic(x7 & 255u);
+    s += ((d0 + d1) + (d2 + d3)) + ((d4 + d5) + (d6 + d7));
+    x0 += 3; x1 += 5; x2 += 7; x3 += 11; x4 += 13; x5 += 17; x6 += 19; x7 += 23;
+  }
+  if (s == 12345.678) out[0] = s;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void stream_read_kernel(const T* __restrict__ src, size_t n, unsigned* sink)
 {
@@ -120,6 +151,8 @@ int main(int argc, char** argv)
   // (1) fp64 FMA peak: cus*8 blocks * 256 lanes * 8 accumulators * iters FMAs, 2 flop each
   const int iters = 1 << 15;
   if (time_it("fma64", 2.0 * 8.0 * iters * 256.0 * grid, "flop", [&] { hipLaunchKernelGGL(fma64_kernel, dim3(grid), dim3(256), 0, 0, dout, iters, 0.5); })) return 1;
+  if (time_it("cvt_f64_u32_x8_plus_adds", 8.0 * (1 << 13) * 256.0 * grid, "conversions", [&] { hipLaunchKernelGGL(cvt64_kernel, dim3(grid), dim3(256), 0, 0, dout, 1 << 13, 1u); })) return 1;
+  if (time_it("magic_2p52_x8_plus_adds", 8.0 * (1 << 13) * 256.0 * grid, "conversions", [&] { hipLaunchKernelGGL(cvt64_magic_kernel, dim3(grid), dim3(256), 0, 0, dout, 1 << 13, 1u); })) return 1;
   // (2) known-bytes reads
   if (time_it("stream16", (double)bytes, "bytes", [&] { hipLaunchKernelGGL(stream_read_kernel<uint4>, dim3(grid * 4), dim3(256), 0, 0, reinterpret_cast<const uint4*>(buf), bytes / 16, sink); })) return 1;
   if (time_it("stream8", (double)bytes, "bytes", [&] { hipLaunchKernelGGL(stream_read_kernel<uint2>, dim3(grid * 4), dim3(256), 0, 0, reinterpret_cast<const uint2*>(buf), bytes / 8, sink); })) return 1;
