@@ -331,6 +331,9 @@ def load():
     lib.svoh_download_level.argtypes = [C.c_void_p, svoh_frame_t, C.c_int, C.c_void_p, P(C.c_int), P(C.c_int)]
     lib.svoh_frame_info.argtypes = [C.c_void_p, svoh_frame_t, P(C.c_int), P(C.c_int), P(C.c_int)]
     lib.svoh_release_frame.argtypes = [C.c_void_p, svoh_frame_t]
+    lib.svoh_context_stats.argtypes = [C.c_void_p, C.c_void_p]
+    lib.svoh_matcher_begin_deferred.argtypes = [C.c_void_p]
+    lib.svoh_matcher_collect.argtypes = [C.c_void_p]
     lib.svoh_sparse_align_batch.argtypes = [C.c_void_p, P(svoh_align_options), C.c_int,
                                             P(svoh_align_problem), P(svoh_align_result)]
     lib.svoh_sparse_align_enqueue.argtypes = [C.c_void_p, P(svoh_align_options), C.c_int,

@@ -185,3 +185,74 @@ def test_split_alignment_wild_state_and_sums(gpu_ctx):
     gpu_ctx.partial_sums(opt, problems[0], 4, d_state.data_ptr(), d_sums.data_ptr())
     gpu_ctx.synchronize()
     assert torch.equal(d_sums, ref_sums)
+
+
+@pytest.mark.parametrize("geometry", ["0", "1", "2"])
+def test_seed_update_wild_units_in_every_geometry(gpu_ctx, geometry, monkeypatch):
+    """The same wild seeds through the one-lane, the eight-lane and the packed geometry (whose binning pass turns the
+    reference pixel into a tile index: NaN / inf / 1e30 must land in some tile, not index out of the histogram)."""
+    monkeypatch.setenv("SVOH_MATCHER_G8", geometry)
+    sc = synth.make_align_scene(306, n_features=8, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+    sd = synth.make_seed_set(sc, 700)
+    rv = fe.make_frame_view(fr, sc.cam, sc.T_ref_f_w, sd["mu_range"], 1)
+    cv = fe.make_frame_view(fc, sc.cam, sc.T_cur_f_w_gt, 0.0, 2)
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(sc.cam)
+    fb, kk = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+    ref = gpu_ctx.update_seeds_batch(mopt, dopt, [rv], cv, fb, sd["state"])
+    px, state = sd["px"].copy(), sd["state"].copy()
+    for k, w in enumerate(WILD):
+        px[2 * k] = w; px[2 * k + 1] = WILD[(k + 2) % len(WILD)]
+        state[4 * (k + 24):4 * (k + 24) + 4] = [w, 1.0, 10.0, 10.0]
+        state[4 * (k + 32):4 * (k + 32) + 4] = [0.5, w, 10.0, 10.0]
+    level = sd["level"].copy()
+    fb, kk = fe.make_feature_batch(sd["ref_frame_idx"], px, sd["f"], sd["grad"], level, sd["type"])
+    ns, st, succ, mr = gpu_ctx.update_seeds_batch(mopt, dopt, [rv], cv, fb, state)
+    assert np.array_equal(st[4 * 48:], ref[1][4 * 48:]) and np.array_equal(succ[48:], ref[2][48:]) and np.array_equal(mr[48:], ref[3][48:])
+    assert not succ[:8].any()
+
+
+def test_new_entries_refuse_bad_arguments(gpu_ctx):
+    """svoh_epipolar_match_batch, the deferred matcher section, svoh_sparse_align_fetch_all, svoh_context_stats and the
+    packed pose call return error codes (never fault, never leave the context unusable) on misuse."""
+    import ctypes as C
+    lib, h = gpu_ctx.lib, gpu_ctx.h
+    sc = synth.make_align_scene(307, n_features=8, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+    sd = synth.make_seed_set(sc, 64)
+    rv = fe.make_frame_view(fr, sc.cam, sc.T_ref_f_w, 0.0, 1)
+    cv = fe.make_frame_view(fc, sc.cam, sc.T_cur_f_w_gt, 0.0, 2)
+    mopt = capi.default_matcher_options(max_epi_search_steps=500)
+    ftype = np.where(sd["type"] == 0, capi.FT_EDGELET, capi.FT_CORNER).astype(np.uint8)
+    fb, kk = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+    dm = float(np.median(sd["true_depth"]))
+    good = gpu_ctx.epipolar_match_batch(mopt, [rv], cv, fb, d_inv_common=[1 / dm, 3 / dm, 0.05 / dm])
+    assert (good["result"] == 0).sum() > 20
+    # no depth range at all / missing required outputs
+    o = capi.svoh_epipolar_match_outputs()
+    assert lib.svoh_epipolar_match_batch(h, C.byref(mopt), 1, C.byref(rv), C.byref(cv), None, C.byref(fb), None, None, C.byref(o)) != 0
+    dc = (C.c_double * 3)(1 / dm, 3 / dm, 0.05 / dm)
+    assert lib.svoh_epipolar_match_batch(h, C.byref(mopt), 1, C.byref(rv), C.byref(cv), None, C.byref(fb), dc, None, C.byref(o)) != 0
+    # wild depth ranges per feature: the units fail or succeed, the call returns, the rest is unaffected
+    d_inv = np.tile([1 / dm, 3 / dm, 0.05 / dm], 64)
+    for k, w in enumerate(WILD):
+        d_inv[3 * k:3 * k + 3] = [w, WILD[(k + 1) % len(WILD)], WILD[(k + 3) % len(WILD)]]
+    wild = gpu_ctx.epipolar_match_batch(mopt, [rv], cv, fb, d_inv=d_inv)
+    assert np.array_equal(wild["result"][8:], good["result"][8:]) and np.allclose(wild["depth"][8:], good["depth"][8:], rtol=1e-12, atol=0)
+    # index out of range in a host batch is refused
+    bad_idx = sd["ref_frame_idx"].copy(); bad_idx[5] = 3
+    fbb, kb = fe.make_feature_batch(bad_idx, sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+    with pytest.raises(fe.SvohError):
+        gpu_ctx.epipolar_match_batch(mopt, [rv], cv, fbb, d_inv_common=[1 / dm, 3 / dm, 0.05 / dm])
+    # deferred section misuse
+    assert lib.svoh_matcher_collect(h) != 0                 # nothing open
+    assert lib.svoh_matcher_begin_deferred(h) == 0
+    assert lib.svoh_matcher_begin_deferred(h) != 0          # already open
+    assert lib.svoh_matcher_collect(h) == 0                 # an empty section is fine
+    # fetch_all with nothing queued, stats with a NULL output
+    res = (capi.svoh_align_result * 1)()
+    assert lib.svoh_sparse_align_fetch_all(h, 1, res) != 0
+    assert lib.svoh_context_stats(h, None) != 0
+    # the context still works
+    again = gpu_ctx.epipolar_match_batch(mopt, [rv], cv, fb, d_inv_common=[1 / dm, 3 / dm, 0.05 / dm])
+    assert np.array_equal(again["result"], good["result"]) and np.array_equal(again["depth"], good["depth"])
