@@ -109,3 +109,23 @@ def test_oracle_reproduces_golden_structure(oracle_lib):
                                            using_bearing_vector=bool(sphere))
         assert np.array_equal(it, z["iters_%d" % sphere])
         assert np.array_equal(p, z["pos_out_%d" % sphere])     # same code, same machine arithmetic: bit for bit
+
+
+def test_oracle_reproduces_the_stereo_seam_fixture(oracle_lib):
+    """tests/golden/stereo_small.npz (make_golden_stereo.py): 100 x Matcher::findEpipolarMatchDirect as
+    StereoTriangulation::compute calls it, on the frame pair of klt_seeds_small.npz."""
+    import os
+    orc = oracle_lib
+    z = np.load(os.path.join(os.path.dirname(helpers.GOLDEN), "klt_seeds_small.npz"))
+    s = np.load(os.path.join(os.path.dirname(helpers.GOLDEN), "stereo_small.npz"))
+    cam, T_ref, T_cur = _golden2_inputs(z)
+    ref = orc.create_img_pyramid(z["img_ref"], 4); cur = orc.create_img_pyramid(z["img_cur"], 4)
+    n = int(s["n"][0])
+    mopt = capi.default_matcher_options(max_epi_search_steps=500, subpix_refinement=1, scan_on_unit_sphere=1)
+    fb, keep = orc.make_feature_batch(np.zeros(n, np.int32), z["seed_px"][:2 * n], z["seed_f"][:3 * n], z["seed_grad"][:2 * n],
+                                      z["seed_level"][:n], s["type"])
+    o = orc.epipolar_match_batch(mopt, [orc.make_frame_view(ref, cam, T_ref, 0.0, 1)], orc.make_frame_view(cur, cam, T_cur, 0.0, 2), fb,
+                                 d_inv_common=list(s["d_inv"]), T_cur_ref=[s["T_f1f0"]])
+    assert np.array_equal(o["result"], s["result"]) and np.array_equal(o["search_level"], s["search_level"])
+    assert np.array_equal(o["depth"], s["depth"]) and np.array_equal(o["px_cur"], s["px_cur"])
+    assert (s["result"] == 0).sum() > 60 and len(set(s["result"])) >= 3

@@ -246,6 +246,27 @@ def test_golden_klt_seeds_fixture(gpu_ctx):
     assert np.abs(o["px_cur"] - z["direct_px_out"]).max() < 1e-4
 
 
+def test_golden_stereo_fixture(gpu_ctx):
+    """HIP path vs tests/golden/stereo_small.npz (no oracle call): the stereo seam's epipolar matches."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(helpers.GOLDEN), "klt_seeds_small.npz"))
+    s = np.load(os.path.join(os.path.dirname(helpers.GOLDEN), "stereo_small.npz"))
+    c = z["cam"]
+    cam = synth.Camera(int(c[0]), int(c[1]), c[2], c[3], c[4], c[5], dist=list(c[6:10]))
+    T_ref, T_cur = synth.SE3.from7(z["T_ref_f_w"]), synth.SE3.from7(z["T_cur_f_w"])
+    fr = gpu_ctx.build_pyramid(z["img_ref"], 4); fc = gpu_ctx.build_pyramid(z["img_cur"], 4)
+    n = int(s["n"][0])
+    mopt = capi.default_matcher_options(max_epi_search_steps=500, subpix_refinement=1, scan_on_unit_sphere=1)
+    fb, keep = fe.make_feature_batch(np.zeros(n, np.int32), z["seed_px"][:2 * n], z["seed_f"][:3 * n], z["seed_grad"][:2 * n],
+                                     z["seed_level"][:n], s["type"])
+    o = gpu_ctx.epipolar_match_batch(mopt, [fe.make_frame_view(fr, cam, T_ref, 0.0, 1)], fe.make_frame_view(fc, cam, T_cur, 0.0, 2), fb,
+                                     d_inv_common=list(s["d_inv"]), T_cur_ref=[s["T_f1f0"]])
+    assert np.array_equal(o["result"], s["result"]) and np.array_equal(o["search_level"], s["search_level"])
+    ok = s["result"] == 0
+    assert np.allclose(o["depth"][ok], s["depth"][ok], rtol=1e-9, atol=0)
+    assert np.abs(o["px_cur"] - s["px_cur"])[np.repeat(ok, 2)].max() <= 1e-4
+
+
 def test_euroc_752x480_geometry_all_paths(gpu_ctx, oracle_lib):
     """EuRoC's real geometry (752x480, radtan): the pyramid mixes the SSE2 and the scalar
     halfSample rule (376 % 16 != 0) and level widths become odd (47); every path must agree with the oracle."""
