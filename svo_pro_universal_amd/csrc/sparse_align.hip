@@ -1442,7 +1442,12 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   if (delivers) {
     SVOH_REQUIRE(ctx, ctx->align_pending_results + (size_t)n_problems <= svoh_ctx::kMaxQueuedResults,
                  "too many alignment results queued without a fetch");
-    const size_t need = sizeof(svoh_align_result) * (ctx->align_pending_results + (size_t)n_problems);
+    // room for a queue of launches of this size (svoh_ctx::kAlignEventRing of them), so that a caller that queues
+    // steps back to back never waits here for the stream to drain and the block to be replaced
+    size_t want_results = ctx->align_pending_results + (size_t)n_problems;
+    const size_t queue_of_these = (size_t)svoh_ctx::kAlignEventRing * (size_t)n_problems;
+    if (want_results < queue_of_these && queue_of_these <= svoh_ctx::kMaxQueuedResults) want_results = queue_of_these;
+    const size_t need = sizeof(svoh_align_result) * want_results;
     if (need > ctx->h_results.cap) {
       if (ctx->align_pending_results) {   // earlier launches still deliver into the old block: let them finish, keep theirs
         SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
