@@ -1486,12 +1486,37 @@ struct SeedRecOut {   // 64 bytes
 };
 static_assert(sizeof(SeedRecIn) == 128 && sizeof(SeedRecOut) == 64, "record sizes");
 
+// SCAN_HERE: `offs` still holds the histogram and every workgroup scans it for itself into LDS (n_keys <= kBinScanHereMaxKeys:
+// a few thousand adds per workgroup, all workgroups at once, instead of a one-workgroup kernel in between)
+constexpr unsigned kBinScanHereMaxKeys = 8192;
+template <bool SCAN_HERE>
 __global__ __launch_bounds__(256) void seed_bin_scatter_kernel(const MatcherArgs a, int tiles_x, int tiles_y, const unsigned* offs,
-                                                               const unsigned* rank, unsigned* pos_of, SeedRecIn* rec)
+                                                               const unsigned* rank, unsigned* pos_of, SeedRecIn* rec, unsigned n_keys)
 {
+  __shared__ unsigned s_off[SCAN_HERE ? kBinScanHereMaxKeys : 1];
+  __shared__ unsigned s_part[256];
+  if constexpr (SCAN_HERE) {
+    const unsigned t = threadIdx.x;
+    const unsigned per = (n_keys + 255u) / 256u;
+    const unsigned lo = t * per, hi = lo + per < n_keys ? lo + per : n_keys;
+    unsigned sum = 0;
+    for (unsigned k = lo; k < hi; ++k) { const unsigned c = offs[k]; s_off[k] = c; sum += c; }
+    s_part[t] = sum;
+    __syncthreads();
+    for (unsigned o = 1; o < 256u; o <<= 1) {
+      const unsigned v = t >= o ? s_part[t - o] : 0u;
+      __syncthreads();
+      s_part[t] += v;
+      __syncthreads();
+    }
+    unsigned run = s_part[t] - sum;
+    for (unsigned k = lo; k < hi; ++k) { const unsigned c = s_off[k]; s_off[k] = run; run += c; }
+    __syncthreads();
+  }
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
   if (i >= a.n) return;
-  const unsigned pos = offs[seed_bin_key(a, i, tiles_x, tiles_y)] + rank[i];
+  const unsigned key = seed_bin_key(a, i, tiles_x, tiles_y);
+  const unsigned pos = (SCAN_HERE ? s_off[key] : offs[key]) + rank[i];
   pos_of[i] = pos;
   SeedRecIn r;
   r.px[0] = a.px[2 * i]; r.px[1] = a.px[2 * i + 1];
@@ -1505,8 +1530,11 @@ __global__ __launch_bounds__(256) void seed_bin_scatter_kernel(const MatcherArgs
 }
 
 // results back into the caller's arrays, one thread per seed in the caller's order
-__global__ __launch_bounds__(256) void seed_unsort_kernel(const MatcherArgs a, const unsigned* pos_of, const SeedRecOut* out)
+// (also leaves the histogram zeroed for the next call: one memset launch less per step)
+__global__ __launch_bounds__(256) void seed_unsort_kernel(const MatcherArgs a, const unsigned* pos_of, const SeedRecOut* out,
+                                                          unsigned* hist, unsigned n_keys)
 {
+  for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < n_keys; k += gridDim.x * 256) hist[k] = 0u;
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
   if (i >= a.n) return;
   const SeedRecOut r = out[pos_of[i]];
@@ -2035,6 +2063,8 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
       const SeedRecIn* rec_in = nullptr;
       SeedRecOut* rec_out = nullptr;
       const unsigned* pos_of = nullptr;
+      unsigned* hist_ptr = nullptr;
+      unsigned hist_keys = 0;
       const dim3 gb((unsigned)((n + 255) / 256));
       if (n_keys <= kBinMaxKeys && getenv_int_m("SVOH_SEED_BINNING", 1) != 0) {
         // [hist | rank | pos_of | records in (128 B each) | records out (64 B each)]
@@ -2042,23 +2072,35 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
         const size_t o_pos = o_rank + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255);
         const size_t o_in = o_pos + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255);
         const size_t o_out = o_in + (size_t)n * sizeof(SeedRecIn);
-        SVOH_HIP_TRY(ctx, ctx->d_scratch2.reserve(o_out + (size_t)n * sizeof(SeedRecOut)));
-        uint8_t* base = static_cast<uint8_t*>(ctx->d_scratch2.ptr);
+        SVOH_HIP_TRY(ctx, ctx->d_seed_bin.reserve(o_out + (size_t)n * sizeof(SeedRecOut)));
+        uint8_t* base = static_cast<uint8_t*>(ctx->d_seed_bin.ptr);
         unsigned* hist = reinterpret_cast<unsigned*>(base);
         unsigned* rank = reinterpret_cast<unsigned*>(base + o_rank);
         unsigned* pos = reinterpret_cast<unsigned*>(base + o_pos);
-        SVOH_HIP_TRY(ctx, hipMemsetAsync(hist, 0, n_keys * sizeof(unsigned), ctx->stream));
+        // the histogram is left zeroed by the previous call's last pass unless the block moved or the key count grew
+        if (ctx->seed_hist_ptr != static_cast<void*>(hist) || n_keys > ctx->seed_hist_clean_keys)
+          SVOH_HIP_TRY(ctx, hipMemsetAsync(hist, 0, n_keys * sizeof(unsigned), ctx->stream));
+        ctx->seed_hist_ptr = hist;
+        ctx->seed_hist_clean_keys = n_keys;
+        hist_keys = (unsigned)n_keys;
+        hist_ptr = hist;
         hipLaunchKernelGGL(seed_bin_count_kernel, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank);
-        hipLaunchKernelGGL(seed_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, (unsigned)n_keys);
-        hipLaunchKernelGGL(seed_bin_scatter_kernel, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank, pos,
-                           reinterpret_cast<SeedRecIn*>(base + o_in));
+        if (n_keys <= kBinScanHereMaxKeys) {
+          hipLaunchKernelGGL(seed_bin_scatter_kernel<true>, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank, pos,
+                             reinterpret_cast<SeedRecIn*>(base + o_in), (unsigned)n_keys);
+        } else {
+          hipLaunchKernelGGL(seed_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, (unsigned)n_keys);
+          hipLaunchKernelGGL(seed_bin_scatter_kernel<false>, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank, pos,
+                             reinterpret_cast<SeedRecIn*>(base + o_in), (unsigned)n_keys);
+        }
         rec_in = reinterpret_cast<const SeedRecIn*>(base + o_in);
         rec_out = reinterpret_cast<SeedRecOut*>(base + o_out);
         pos_of = pos;
       }
       hipLaunchKernelGGL(update_seeds_packed_kernel, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0,
                          ctx->stream, a, rec_in, rec_out);
-      if (rec_out) hipLaunchKernelGGL(seed_unsort_kernel, gb, dim3(256), 0, ctx->stream, a, pos_of, static_cast<const SeedRecOut*>(rec_out));
+      if (rec_out) hipLaunchKernelGGL(seed_unsort_kernel, gb, dim3(256), 0, ctx->stream, a, pos_of, static_cast<const SeedRecOut*>(rec_out),
+                                      hist_ptr, hist_keys);
     }
     else if (g8) hipLaunchKernelGGL(update_seeds_kernel<true>, grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL(update_seeds_kernel<false>, grid, block, 0, ctx->stream, a);

@@ -121,6 +121,10 @@ struct svoh_ctx {
   svoh::DevBuffer d_match_seeds;       // staging of the deferred seed batch (the direct one keeps d_scratch1)
   svoh::PinnedBuffer h_match_seeds;
 
+  svoh::DevBuffer d_seed_bin;          // packed seed update: histogram, ranks, sorted records (nothing else writes here)
+  void* seed_hist_ptr = nullptr;       // the binning histogram at this address ...
+  size_t seed_hist_clean_keys = 0;     // ... is known to be zero for this many keys (its last pass clears it)
+
   // generic scratch for the other paths
   svoh::DevBuffer d_scratch0, d_scratch1, d_scratch2;
   svoh::PinnedBuffer h_scratch0, h_scratch1;
