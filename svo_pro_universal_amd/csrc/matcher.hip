@@ -629,6 +629,18 @@ __device__ __forceinline__ void g8_chain_sub(float (&acc)[NA], const float (&t)[
   for (int a = 0; a < NA; ++a) acc[a] = __shfl(c[a], 7, 8);
 }
 
+// nine consecutive pixels as one unaligned 12-byte load (the three spare bytes stay inside the row, the next row or
+// the slab's tail padding): 2 loads per lane and iteration instead of 32 single-byte gathers, which is what the
+// texture-address unit of a CU (one lane address per cycle for scattered loads) spent the refinement phase on
+__device__ __forceinline__ void load_row9_u8(const uint8_t* p, unsigned (&px)[9])
+{
+  unsigned w[3];
+  __builtin_memcpy(w, p, 12);
+  px[0] = w[0] & 255u; px[1] = (w[0] >> 8) & 255u; px[2] = (w[0] >> 16) & 255u; px[3] = w[0] >> 24;
+  px[4] = w[1] & 255u; px[5] = (w[1] >> 8) & 255u; px[6] = (w[1] >> 16) & 255u; px[7] = w[1] >> 24;
+  px[8] = w[2] & 255u;
+}
+
 // align_2d (feature_alignment.cpp:212-391).  The entries of H are sums of products of half-integers and
 // integers below 2^16: every partial sum is exact in float, so the rows may be added in any order.
 __device__ bool align_2d_g8(const DevImage& cur_img, const unsigned char* pwb, int n_iter, bool affine_est_offset,
@@ -680,11 +692,14 @@ __device__ bool align_2d_g8(const DevImage& cur_img, const unsigned char* pwb, i
     {
       const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + sub - halfpatch_size_) * cur_step + u_r - halfpatch_size_;
       const unsigned char* rp = pwb + (sub + 1) * ref_step + 1;
+      unsigned top[9], bot[9];
+      load_row9_u8(it, top);
+      load_row9_u8(it + cur_step, bot);
 #pragma unroll
-      for (int x = 0; x < patch_size_; ++x, ++it, ++rp) {
+      for (int x = 0; x < patch_size_; ++x, ++rp) {
         const float ref_dx = (float)(0.5 * ((int)rp[1] - (int)rp[-1]));
         const float ref_dy = (float)(0.5 * ((int)rp[ref_step] - (int)rp[-ref_step]));
-        const float search_pixel = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
+        const float search_pixel = wTL * top[x] + wTR * top[x + 1] + wBL * bot[x] + wBR * bot[x + 1];
         const float res = search_pixel - alpha * rp[0] + mean_diff;
         t[0][x] = res * ref_dx;
         t[1][x] = res * ref_dy;
@@ -693,7 +708,17 @@ __device__ bool align_2d_g8(const DevImage& cur_img, const unsigned char* pwb, i
       }
     }
     float Jres[4] = { 0, 0, 0, 0 };
-    g8_chain_sub<4>(Jres, t, sub);
+    if (affine_est_gain) g8_chain_sub<4>(Jres, t, sub);
+    else {   // the fourth sum is a sum of zeros then (and reset below): hand three accumulators from row to row
+      float J3[3] = { 0, 0, 0 };
+      float t3[3][8];
+#pragma unroll
+      for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) t3[a3][x] = t[a3][x];
+      g8_chain_sub<3>(J3, t3, sub);
+      Jres[0] = J3[0]; Jres[1] = J3[1]; Jres[2] = J3[2];
+    }
     if (!affine_est_offset) Jres[2] = 0.0f;
     if (!affine_est_gain) Jres[3] = 0.0f;
     float update[4];
@@ -765,12 +790,15 @@ __device__ bool align_1d_g8(const DevImage& cur_img, double dir0, double dir1, c
     {
       const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + sub - kHalfPatchSize) * cur_step + u_r - kHalfPatchSize;
       const unsigned char* rp = pwb + (sub + 1) * ref_step + 1;
+      unsigned top[9], bot[9];
+      load_row9_u8(it, top);
+      load_row9_u8(it + cur_step, bot);
 #pragma unroll
-      for (int x = 0; x < kPatchSize; ++x, ++it, ++rp) {
+      for (int x = 0; x < kPatchSize; ++x, ++rp) {
         const float gdx = (float)rp[1] - (float)rp[-1];
         const float gdy = (float)rp[ref_step] - (float)rp[-ref_step];
         const float ref_dv = (float)(0.5f * (dir0 * gdx + dir1 * gdy));
-        const float cur_intensity = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
+        const float cur_intensity = wTL * top[x] + wTR * top[x + 1] + wBL * bot[x] + wBR * bot[x + 1];
         const float res = cur_intensity - alpha * rp[0] + mean_diff;
         t[0][x] = res * ref_dv;
         t[1][x] = affine_est_offset ? res : 0.0f;
@@ -778,7 +806,17 @@ __device__ bool align_1d_g8(const DevImage& cur_img, double dir0, double dir1, c
       }
     }
     float Jres[3] = { 0, 0, 0 };
-    g8_chain_sub<3>(Jres, t, sub);
+    if (affine_est_gain) g8_chain_sub<3>(Jres, t, sub);
+    else {
+      float J2[2] = { 0, 0 };
+      float t2[2][8];
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) t2[a2][x] = t[a2][x];
+      g8_chain_sub<2>(J2, t2, sub);
+      Jres[0] = J2[0]; Jres[1] = J2[1];
+    }
     if (!affine_est_offset) Jres[1] = 0.0f;
     if (!affine_est_gain) Jres[2] = 0.0f;
     float update[3];
