@@ -88,6 +88,21 @@ def main():
             for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
                 if k in c:
                     d[k + "_share_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
+        if "SQ_INSTS_VALU_FMA_F64" in c:
+            # wave-instructions x 64 lanes (an upper bound where lanes are masked off); FMA = 2 flop
+            flop = 64.0 * (c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + 2.0 * c["SQ_INSTS_VALU_FMA_F64"])
+            d["fp64_flop_per_dispatch_upper_bound"] = flop
+            if "kernel_cycles" in d and out.get("kernel_ms_per_step_rocprof"):
+                dom_ms = None
+                for r in out.get("kernel_stats", []):
+                    if r["Name"].split("(")[0] == dom:
+                        dom_ms = float(r["AverageNs"]) * 1e-6
+                if dom_ms:
+                    d["fp64_tflops_upper_bound"] = flop / (dom_ms * 1e-3) / 1e12
+                    d["fp64_fraction_of_measured_peak_63p8"] = d["fp64_tflops_upper_bound"] / 63.8
+            if "SQ_INSTS_VALU" in c and c["SQ_INSTS_VALU"]:
+                d["fp64_arith_share_of_valu_instructions"] = (c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) +
+                                                              c["SQ_INSTS_VALU_FMA_F64"]) / c["SQ_INSTS_VALU"]
         if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
             d["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
         out["compute_side"] = d

@@ -27,9 +27,10 @@ for tag in $TAGS; do
   st=$(find $out/trace -name "*kernel_stats.csv" | head -1)
   (head -1 $st; grep -E "svoh::" $st) > $dst/${ROUND}_${tag}_kernel_stats_svoh.csv
   for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
-             "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM"; do
+             "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM" \
+             "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32"; do
     t=$(echo $ctr | cut -d' ' -f1)
-    [ "$t" = "SQ_WAVES" ] && t=SQ1; [ "$t" = "SQ_INSTS_VMEM_RD" ] && t=SQ2
+    [ "$t" = "SQ_WAVES" ] && t=SQ1; [ "$t" = "SQ_INSTS_VMEM_RD" ] && t=SQ2; [ "$t" = "SQ_INSTS_VALU_ADD_F64" ] && t=SQ3
     rocprofv3 --pmc $ctr --kernel-include-regex "svoh" --output-format csv -d $out/$t -- python bench.py $args > $out/$t.log 2>&1 || { tail -5 $out/$t.log; continue; }
     f=$(find $out/$t -name "*counter_collection.csv" | head -1)
     # keep the columns that matter, svoh kernels only (raw per-dispatch values: the summary can be re-derived)
