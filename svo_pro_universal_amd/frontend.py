@@ -281,8 +281,9 @@ def _update_seeds_batch(self, mopt, dopt, ref_views, cur_view, fb, state):
     success = np.zeros(max(n, 1), np.uint8)
     mr = np.zeros(max(n, 1), np.int32)
     ns = C.c_int32()
+    cv, _ = _views(cur_view)          # one current frame, or a list (fb.cur_frame_idx picks per feature)
     self._check(self.lib.svoh_update_seeds_batch(self.h, C.byref(mopt), C.byref(dopt), len(ref_views), rv,
-                                                 C.byref(cur_view), C.byref(fb), st.ctypes.data, success.ctypes.data,
+                                                 cv, C.byref(fb), st.ctypes.data, success.ctypes.data,
                                                  mr.ctypes.data, C.byref(ns)))
     return ns.value, st, success[:n], mr[:n]
 

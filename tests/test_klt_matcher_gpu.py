@@ -457,3 +457,61 @@ def test_device_resident_batches_equal_host_batches(gpu_ctx, oracle_lib):
     with pytest.raises(fe.SvohError):
         gpu_ctx.klt_track_indexed(kopt, frames, 121, ridx_bad.ctypes.data, cidx_bad.ctypes.data, pr.ctypes.data,
                                   hp.ctypes.data, hs.ctypes.data, mem_space=capi.SVOH_MEM_HOST)
+
+
+def test_benchmark_size_batch_is_identical_in_every_geometry(gpu_ctx):
+    """BASELINE's C4 size through size-independent properties: 24 (keyframe, frame) pairs x 3000 seeds = 72 000 seeds in
+    ONE launch (beyond the eight-lane threshold, so the library itself picks the packed geometry with spatial binning)
+    must give bit for bit what the one-lane and the eight-lane kernels give, with and without binning, and what 24
+    separate launches give (no seed depends on its neighbours, its place in the batch or the processing order)."""
+    import os
+    B, NS = 24, 3000
+    views_r, views_c, parts = [], [], []
+    for b in range(B):
+        sc = synth.make_align_scene(900 + b, n_features=8, rot_deg=(0.3, 1.0), trans_m=(0.05, 0.15))
+        fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+        sd = synth.make_seed_set(sc, NS, seed=b)
+        views_r.append(fe.make_frame_view(fr, sc.cam, sc.T_ref_f_w, sd["mu_range"], 2 * b))
+        views_c.append(fe.make_frame_view(fc, sc.cam, sc.T_cur_f_w_gt, 0.0, 2 * b + 1))
+        parts.append((sc, sd))
+    cat = lambda k: np.concatenate([p[1][k] for p in parts])
+    idx = np.repeat(np.arange(B, dtype=np.int32), NS)
+    mopt = capi.default_matcher_options()
+    dopt = capi.default_depth_filter_options(parts[0][0].cam)
+
+    def run():
+        fb, keep = fe.make_feature_batch(idx, cat("px"), cat("f"), cat("grad"), cat("level"), cat("type"))
+        fb.cur_frame_idx = idx.ctypes.data
+        fb.n_cur_frames = B
+        ns, st, succ, mr = gpu_ctx.update_seeds_batch(mopt, dopt, views_r, views_c, fb, cat("state"))
+        return ns, st, succ, mr, keep["type"].copy()
+
+    old = {k: os.environ.get(k) for k in ("SVOH_MATCHER_G8", "SVOH_SEED_BINNING")}
+    try:
+        out = {}
+        for name, g8, binning in (("auto", None, None), ("one_lane", "0", None), ("eight_lanes", "1", None), ("packed_unbinned", "2", "0")):
+            for k, v in (("SVOH_MATCHER_G8", g8), ("SVOH_SEED_BINNING", binning)):
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            out[name] = run()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    ref = out["one_lane"]
+    assert ref[0] > 0.5 * B * NS
+    for name, o in out.items():
+        assert o[0] == ref[0], name
+        for a, b in zip(o[1:], ref[1:]):
+            assert np.array_equal(a, b), name
+    # one pair alone (a small batch: eight lanes per seed) gives the batch's rows
+    b = 7
+    sd = parts[b][1]
+    fb1, keep1 = fe.make_feature_batch(np.zeros(NS, np.int32), sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+    ns1, st1, succ1, mr1 = gpu_ctx.update_seeds_batch(mopt, dopt, [views_r[b]], views_c[b], fb1, sd["state"])
+    sl = slice(b * NS, (b + 1) * NS)
+    assert np.array_equal(st1, ref[1][4 * b * NS:4 * (b + 1) * NS]) and np.array_equal(succ1, ref[2][sl]) and np.array_equal(mr1, ref[3][sl])
