@@ -38,16 +38,29 @@ struct KltArgs {
   unsigned int* unit_counts;    // 4 per track: iterations 16x16, 8x8, templates 16x16, 8x8
 };
 
-__device__ __forceinline__ int wave_sum_i32(int v) { return svoh::wave_sum_i32_dpp(v); }
+// sum over the LANES lanes that share a track: the whole wave (6 DPP adds + v_readlane), or one DPP row of 16 lanes
+// (4 DPP adds, no lane of another row is read: safe when other rows are switched off)
+template <int LANES>
+__device__ __forceinline__ int group_sum_i32(int v)
+{
+  if constexpr (LANES == 64) return svoh::wave_sum_i32_dpp(v);
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror
+  return v;
+}
 
-// One level of alignPyr2D for patch size P (16 or 8).  Returns: 0 = continue to the
-// next level, 1 = return false (not converged / NaN).  `converged` and px_cur are updated.
-template <int P>
+// One level of alignPyr2D for patch size P (16 or 8), LANES lanes per track: 64 (the wave owns one track) or 16 (four
+// tracks side by side, one per DPP row; every value below is then uniform per row, not per wave, and a row whose
+// track has left the loop idles while the others finish).  Returns per lane: 0 = continue to the next level,
+// 1 = return false (not converged / NaN).  `converged` and px_cur are updated.  `run` = this lane's track takes part.
+template <int P, int LANES>
 __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage& img_cur, int level, int px_ref0_x,
                                          int px_ref0_y, int n_iter, float min_update_squared, double& pcx, double& pcy,
-                                         bool& converged, int lane, int& n_iters, int& n_tmpl)
+                                         bool& converged, int lane, int& n_iters, int& n_tmpl, bool run)
 {
-  constexpr int PPL = P * P / 64;  // pixels per lane: 4 (16x16) or 1 (8x8)
+  constexpr int PPL = P * P / LANES;  // pixels per lane: 4 (16x16 on a wave, 8x8 on a row) or 1 (8x8 on a wave)
   const int halfpatch_size = P / 2;
   const int scale = 1 << level;
   const int width = img_ref.w, height = img_ref.h;
@@ -56,14 +69,13 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
   const float prfy = (float)px_ref0_y / (float)scale - (float)halfpatch_size;
   const int prx = (int)prfx, pry = (int)prfy;
   const float offx = prfx - (float)prx, offy = prfy - (float)pry;
-  if (prx < 1 || pry < 1 || prx >= width - P - 1 || pry >= height - P - 1) return 0;  // too close to the border
-
+  bool active = run && !(prx < 1 || pry < 1 || prx >= width - P - 1 || pry >= height - P - 1);  // else: too close to the border
   // this lane's pixels: row y, columns x0 .. x0+PPL-1
   const int y = (lane * PPL) / P;
   const int x0 = (lane * PPL) % P;
   int tmpl[PPL], gdx[PPL], gdy[PPL];
   int h00 = 0, h01 = 0, h11 = 0;
-  {
+  if (active) {
     const uint8_t* it = img_ref.data + (ptrdiff_t)(pry + y) * step + prx + x0;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
@@ -74,106 +86,172 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
       h01 += gdx[k] * gdy[k];
       h11 += gdy[k] * gdy[k];
     }
+    ++n_tmpl;
+  } else {
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) { tmpl[k] = 0; gdx[k] = 0; gdy[k] = 0; }
   }
-  ++n_tmpl;
-  const float H00 = (float)wave_sum_i32(h00), H01 = (float)wave_sum_i32(h01), H11 = (float)wave_sum_i32(h11);
-  const float H10 = H01;
-  // Eigen Matrix2f::inverse()
-  const float det = H00 * H11 - H10 * H01;
-  const float invdet = 1.0f / det;
-  const float Hi00 = H11 * invdet, Hi10 = -H10 * invdet, Hi01 = -H01 * invdet, Hi11 = H00 * invdet;
-
-  float u = (float)(pcx / scale - halfpatch_size - offx);
-  float v = (float)(pcy / scale - halfpatch_size - offy);
+  int rc = 0;
+  float u = 0.f, v = 0.f, Hi00 = 0.f, Hi01 = 0.f, Hi10 = 0.f, Hi11 = 0.f;
   bool go_to_next_level = false;
-  converged = false;
+  const bool entered = active;
+  if (active) {
+    const float H00 = (float)group_sum_i32<LANES>(h00), H01 = (float)group_sum_i32<LANES>(h01), H11 = (float)group_sum_i32<LANES>(h11);
+    const float H10 = H01;
+    // Eigen Matrix2f::inverse()
+    const float det = H00 * H11 - H10 * H01;
+    const float invdet = 1.0f / det;
+    Hi00 = H11 * invdet; Hi10 = -H10 * invdet; Hi01 = -H01 * invdet; Hi11 = H00 * invdet;
+    u = (float)(pcx / scale - halfpatch_size - offx);
+    v = (float)(pcy / scale - halfpatch_size - offy);
+    converged = false;
+  }
   const int cur_step = img_ref.pitch;  // the reference indexes the current image with the reference's step
   for (int iter = 0; iter < n_iter; ++iter) {
-    if (u != u || v != v) return 1;
-    go_to_next_level = false;
-    const int u_r = (int)floorf(u);
-    const int v_r = (int)floorf(v);
-    if (u_r < 0 || v_r < 0 || u_r >= width - P || v_r >= height - P) {
-      go_to_next_level = true;
-      break;
+    if (__ballot(active) == 0) break;
+    if (active) {
+      if (u != u || v != v) { rc = 1; active = false; }
     }
-    ++n_iters;
-    const float subpix_x = u - u_r;
-    const float subpix_y = v - v_r;
-    const int wTL = (int)(unsigned short)((1.0f - subpix_x) * (1.0f - subpix_y) * 128);
-    const int wTR = (int)(unsigned short)(subpix_x * (1.0f - subpix_y) * 128);
-    const int wBL = (int)(unsigned short)((1.0f - subpix_x) * subpix_y * 128);
-    const int wBR = (int)(unsigned short)(128 - wTL - wTR - wBL);
-    const uint8_t* it = img_cur.data + (ptrdiff_t)(v_r + y) * cur_step + u_r + x0;
-    int top[PPL + 1], bot[PPL + 1];
+    if (active) {
+      go_to_next_level = false;
+      const int u_r = (int)floorf(u);
+      const int v_r = (int)floorf(v);
+      if (u_r < 0 || v_r < 0 || u_r >= width - P || v_r >= height - P) {
+        go_to_next_level = true;
+        active = false;
+      }
+      if (active) {
+        ++n_iters;
+        const float subpix_x = u - u_r;
+        const float subpix_y = v - v_r;
+        const int wTL = (int)(unsigned short)((1.0f - subpix_x) * (1.0f - subpix_y) * 128);
+        const int wTR = (int)(unsigned short)(subpix_x * (1.0f - subpix_y) * 128);
+        const int wBL = (int)(unsigned short)((1.0f - subpix_x) * subpix_y * 128);
+        const int wBR = (int)(unsigned short)(128 - wTL - wTR - wBL);
+        const uint8_t* it = img_cur.data + (ptrdiff_t)(v_r + y) * cur_step + u_r + x0;
+        int j0 = 0, j1 = 0;
+        if constexpr (PPL == 4) {
+          // the lane's 2 x 5 pixels as two unaligned 8-byte loads (the spare bytes stay inside the row, the next row or
+          // the slab's tail padding); per pixel the four taps are gathered into one dword (v_perm_b32) and the 7-bit
+          // fixed-point bilinear sum is ONE v_dot4_u32_u8 against the packed weights (all <= 128): the same integers
+          uint2 T, B;
+          __builtin_memcpy(&T, it, 8);
+          __builtin_memcpy(&B, it + cur_step, 8);
+          const unsigned W = (unsigned)wTL | ((unsigned)wTR << 8) | ((unsigned)wBL << 16) | ((unsigned)wBR << 24);
+          const unsigned T3 = __builtin_amdgcn_alignbyte(T.y, T.x, 3), B3 = __builtin_amdgcn_alignbyte(B.y, B.x, 3);
+          const unsigned q0 = __builtin_amdgcn_perm(B.x, T.x, 0x05040100u), q1 = __builtin_amdgcn_perm(B.x, T.x, 0x06050201u);
+          const unsigned q2 = __builtin_amdgcn_perm(B.x, T.x, 0x07060302u), q3 = __builtin_amdgcn_perm(B3, T3, 0x05040100u);
+          const unsigned q[4] = { q0, q1, q2, q3 };
 #pragma unroll
-    for (int k = 0; k < PPL + 1; ++k) { top[k] = it[k]; bot[k] = it[k + cur_step]; }
-    int j0 = 0, j1 = 0;
+          for (int k = 0; k < 4; ++k) {
+            const int cur = (int)(unsigned short)(__builtin_amdgcn_udot4(q[k], W, 64u, false) >> 7);
+            const int res = cur - tmpl[k];
+            j0 += res * gdx[k];
+            j1 += res * gdy[k];
+          }
+        } else {
+          int top[PPL + 1], bot[PPL + 1];
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) {
-      const int cur = (int)(unsigned short)((wTL * top[k] + wTR * top[k + 1] + wBL * bot[k] + wBR * bot[k + 1] + 64) >> 7);
-      const int res = cur - tmpl[k];
-      j0 += res * gdx[k];
-      j1 += res * gdy[k];
-    }
-    const float Jres0 = -(float)wave_sum_i32(j0);
-    const float Jres1 = -(float)wave_sum_i32(j1);
-    const float up0 = (Hi00 * Jres0 + Hi01 * Jres1) * 2.0f;
-    const float up1 = (Hi10 * Jres0 + Hi11 * Jres1) * 2.0f;
-    u += up0;
-    v += up1;
-    if (up0 * up0 + up1 * up1 < min_update_squared) {
-      converged = true;
-      break;
+          for (int k = 0; k < PPL + 1; ++k) { top[k] = it[k]; bot[k] = it[k + cur_step]; }
+#pragma unroll
+          for (int k = 0; k < PPL; ++k) {
+            const int cur = (int)(unsigned short)((wTL * top[k] + wTR * top[k + 1] + wBL * bot[k] + wBR * bot[k + 1] + 64) >> 7);
+            const int res = cur - tmpl[k];
+            j0 += res * gdx[k];
+            j1 += res * gdy[k];
+          }
+        }
+        const float Jres0 = -(float)group_sum_i32<LANES>(j0);
+        const float Jres1 = -(float)group_sum_i32<LANES>(j1);
+        const float up0 = (Hi00 * Jres0 + Hi01 * Jres1) * 2.0f;
+        const float up1 = (Hi10 * Jres0 + Hi11 * Jres1) * 2.0f;
+        u += up0;
+        v += up1;
+        if (up0 * up0 + up1 * up1 < min_update_squared) {
+          converged = true;
+          active = false;
+        }
+      }
     }
   }
-  pcx = (double)((u + halfpatch_size + offx) * scale);
-  pcy = (double)((v + halfpatch_size + offy) * scale);
-  if (!converged && !go_to_next_level) return 1;
-  return 0;
+  if (entered && rc == 0) {
+    pcx = (double)((u + halfpatch_size + offx) * scale);
+    pcy = (double)((v + halfpatch_size + offy) * scale);
+    if (!converged && !go_to_next_level) rc = 1;
+  }
+  return rc;
 }
 
-// blockDim.x / 64 tracks per workgroup (one wave each); waves never synchronise
+__device__ __forceinline__ double readlane_f64(double x, int src_lane)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// A wave owns FOUR tracks (DPP row r = lanes 16r .. 16r+15 holds the state of track 4*wave + r).  Levels whose patch is
+// 16x16 are taken one track after the other with the whole wave (4 pixels per lane); levels whose patch is 8x8 are taken
+// by the four tracks side by side, sixteen lanes and 4 pixels per lane each -- on a wave of its own an 8x8 patch
+// gives a lane ONE pixel and the per-iteration bookkeeping (weights, reductions, the 2x2 update: ~55 of ~65
+// instructions) is spent on it alone.  Waves never synchronise.
 __global__ __launch_bounds__(256) void klt_track_kernel(const KltArgs a)
 {
-  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (t >= a.n_tracks) return;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int ri = a.ref_idx[t], ci = a.cur_idx[t];
-  if ((unsigned)ri >= (unsigned)a.n_frames || (unsigned)ci >= (unsigned)a.n_frames) {
-    if (lane == 0) {
-      a.status[t] = 0;
-      reinterpret_cast<uint4*>(a.unit_counts)[t] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    return;
-  }
-  const DevImage* ref = a.frame_levels + (size_t)ri * SVOH_MAX_LEVELS;
-  const DevImage* curl = a.frame_levels + (size_t)ci * SVOH_MAX_LEVELS;
-  double pcx = a.px_cur[2 * t], pcy = a.px_cur[2 * t + 1];
-  const int rx = a.px_ref[2 * t], ry = a.px_ref[2 * t + 1];
-  bool converged = false;
-  bool failed = false;
+  const int row = lane >> 4, lane16 = lane & 15;
+  const int t = wave * 4 + row;                      // this lane's track
+  const bool exists = t < a.n_tracks;
+  int ri = 0, ci = 0;
+  if (exists) { ri = a.ref_idx[t]; ci = a.cur_idx[t]; }
+  const bool ok_idx = exists && (unsigned)ri < (unsigned)a.n_frames && (unsigned)ci < (unsigned)a.n_frames;
+  double pcx = 0.0, pcy = 0.0;
+  int rx = 0, ry = 0;
+  if (ok_idx) { pcx = a.px_cur[2 * t]; pcy = a.px_cur[2 * t + 1]; rx = a.px_ref[2 * t]; ry = a.px_ref[2 * t + 1]; }
+  bool converged = false, failed = false;
   int it16 = 0, it8 = 0, t16 = 0, t8 = 0;
   for (int level = a.opt.max_level; level >= a.opt.min_level; --level) {
     const int P = a.opt.patch_sizes[level];
-    int rc;
-    if (P == 16)
-      rc = klt_level<16>(ref[level], curl[level], level, rx, ry, a.opt.max_iter, a.opt.min_update_squared, pcx,
-                         pcy, converged, lane, it16, t16);
-    else if (P == 8)
-      rc = klt_level<8>(ref[level], curl[level], level, rx, ry, a.opt.max_iter, a.opt.min_update_squared, pcx,
-                        pcy, converged, lane, it8, t8);
-    else if (P == 32)
-      rc = 1;  // rejected on the host
-    else
-      rc = 1;
-    if (rc) { failed = true; break; }
+    if (P == 16) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) {
+        // track j's state, taken from the first lane of its row: uniform over the wave
+        const int src = 16 * j;
+        const bool alive = __builtin_amdgcn_readlane((int)(ok_idx && !failed), src) != 0;
+        if (!alive) continue;
+        const int jri = __builtin_amdgcn_readlane(ri, src), jci = __builtin_amdgcn_readlane(ci, src);
+        const int jrx = __builtin_amdgcn_readlane(rx, src), jry = __builtin_amdgcn_readlane(ry, src);
+        double jx = readlane_f64(pcx, src), jy = readlane_f64(pcy, src);
+        bool jconv = __builtin_amdgcn_readlane((int)converged, src) != 0;
+        int jit = 0, jt = 0;
+        const DevImage& ref = a.frame_levels[(size_t)jri * SVOH_MAX_LEVELS + level];
+        const DevImage& cur = a.frame_levels[(size_t)jci * SVOH_MAX_LEVELS + level];
+        const int rc = klt_level<16, 64>(ref, cur, level, jrx, jry, a.opt.max_iter, a.opt.min_update_squared, jx, jy, jconv, lane,
+                                         jit, jt, true);
+        if (row == j) { pcx = jx; pcy = jy; converged = jconv; it16 += jit; t16 += jt; if (rc) failed = true; }
+      }
+    } else if (P == 8) {
+      const bool run = ok_idx && !failed;
+      if (__ballot(run) != 0) {
+        const DevImage ref = a.frame_levels[(size_t)(run ? ri : 0) * SVOH_MAX_LEVELS + level];
+        const DevImage cur = a.frame_levels[(size_t)(run ? ci : 0) * SVOH_MAX_LEVELS + level];
+        const int rc = klt_level<8, 16>(ref, cur, level, rx, ry, a.opt.max_iter, a.opt.min_update_squared, pcx, pcy, converged,
+                                        lane16, it8, t8, run);
+        if (run && rc) failed = true;
+      }
+    } else {
+      if (ok_idx) failed = true;   // rejected on the host
+    }
+    if (__ballot(ok_idx && !failed) == 0) break;
   }
-  if (lane == 0) {
-    a.px_cur[2 * t] = pcx;
-    a.px_cur[2 * t + 1] = pcy;
-    a.status[t] = (!failed && converged) ? 1 : 0;
-    reinterpret_cast<uint4*>(a.unit_counts)[t] = make_uint4((unsigned)it16, (unsigned)it8, (unsigned)t16, (unsigned)t8);
+  if (exists && lane16 == 0) {
+    if (ok_idx) {
+      a.px_cur[2 * t] = pcx;
+      a.px_cur[2 * t + 1] = pcy;
+      a.status[t] = (!failed && converged) ? 1 : 0;
+      reinterpret_cast<uint4*>(a.unit_counts)[t] = make_uint4((unsigned)it16, (unsigned)it8, (unsigned)t16, (unsigned)t8);
+    } else {
+      a.status[t] = 0;
+      reinterpret_cast<uint4*>(a.unit_counts)[t] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
 }
 
@@ -248,7 +326,7 @@ static int launch_klt(svoh_ctx* ctx, const svoh_klt_options* options, const std:
     const char* e = getenv("SVOH_KLT_BLOCK");
     int block = e ? atoi(e) : 256;
     if (block != 64 && block != 128 && block != 256) block = 256;
-    const int tpb = block / 64;
+    const int tpb = block / 64 * 4;   // four tracks per wave
     hipLaunchKernelGGL(klt_track_kernel, dim3((n_tracks + tpb - 1) / tpb), dim3(block), 0, ctx->stream, args);
   }
   SVOH_HIP_TRY(ctx, hipGetLastError());
