@@ -501,7 +501,7 @@ def bench_frame(args, ctx, dist, rank, world, dev, comm_dev=None):
             "stage_ms_median": med, "align_pose_err_vs_gt": {"rot_rad": err[0], "trans_m": err[1]},
             "seed_successes": int(last["seeds"][0]), "klt_converged": int(last["klt"][1].sum()),
             "roofline": roofline("sparse_align_kernel<4,*,false> (single problem: latency-bound by design)", kms.value, alg,
-                                 "frame:default", kernel_ms=kms.value),
+                                 "frame:default"),
             "cpu_baseline": cpu}
 
 

@@ -374,13 +374,20 @@ __device__ __forceinline__ void patch_sums_g8(const unsigned char* pwb, int sub,
 // zmssd_score, one row per lane (integer sums: any order)
 __device__ int zmssd_score_g8(const unsigned char* pwb, int sumA, int sumAA, const uint8_t* cur_patch, int stride, int sub)
 {
-  unsigned sumB = 0, sumBB = 0, sumAB = 0;
-  const uint8_t* p = cur_patch + (ptrdiff_t)sub * stride;
-  unsigned c[8];
-#pragma unroll
-  for (int x = 0; x < 8; ++x) c[x] = p[x];
-#pragma unroll
-  for (int x = 0; x < 8; ++x) { sumB += c[x]; sumBB += c[x] * c[x]; sumAB += c[x] * (unsigned)patch_at(pwb, sub * 8 + x); }
+  // the lane's row of the current patch as one unaligned 8-byte load, its template row from three aligned LDS dwords;
+  // the three integer sums as v_dot4_u32_u8 (same integers as the byte-by-byte loop)
+  uint2 c;
+  __builtin_memcpy(&c, cur_patch + (ptrdiff_t)sub * stride, 8);
+  const int o = (sub + 1) * 10 + 1;                        // byte offset of the row's first pixel in the 10x10 patch
+  const unsigned* w = reinterpret_cast<const unsigned*>(pwb) + (o >> 2);
+  const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+  const unsigned t0 = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)(o & 3)), t1 = __builtin_amdgcn_alignbyte(w2, w1, (unsigned)(o & 3));
+  unsigned sumB = __builtin_amdgcn_udot4(c.x, 0x01010101u, 0u, false);
+  sumB = __builtin_amdgcn_udot4(c.y, 0x01010101u, sumB, false);
+  unsigned sumBB = __builtin_amdgcn_udot4(c.x, c.x, 0u, false);
+  sumBB = __builtin_amdgcn_udot4(c.y, c.y, sumBB, false);
+  unsigned sumAB = __builtin_amdgcn_udot4(c.x, t0, 0u, false);
+  sumAB = __builtin_amdgcn_udot4(c.y, t1, sumAB, false);
   const int iB = g8_sum((int)sumB), iBB = g8_sum((int)sumBB), iAB = g8_sum((int)sumAB);
   return sumAA - 2 * iAB + iBB - (sumA * sumA - 2 * sumA * iB + iB * iB) / 64;
 }
@@ -1340,7 +1347,7 @@ __device__ __forceinline__ void flush_counters(unsigned int* c, int i, const Mat
 template <bool G8>
 __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
 {
-  __shared__ unsigned char s_pwb[64 * kPwbStride];
+  __shared__ __attribute__((aligned(16))) unsigned char s_pwb[64 * kPwbStride];
   const int unit = G8 ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;
   const int i = blockIdx.x * (G8 ? 8 : 64) + unit;
   if (i >= a.n) return;
@@ -1376,7 +1383,7 @@ __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
 template <bool G8>
 __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
 {
-  __shared__ unsigned char s_pwb[64 * kPwbStride];
+  __shared__ __attribute__((aligned(16))) unsigned char s_pwb[64 * kPwbStride];
   const int unit = G8 ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;
   const int i = blockIdx.x * (G8 ? 8 : 64) + unit;
   if (i >= a.n) return;
@@ -1843,7 +1850,7 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
 template <bool G8>
 __global__ __launch_bounds__(64) void epipolar_match_kernel(const MatcherArgs a)
 {
-  __shared__ unsigned char s_pwb[64 * kPwbStride];
+  __shared__ __attribute__((aligned(16))) unsigned char s_pwb[64 * kPwbStride];
   const int unit = G8 ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;
   const int i = blockIdx.x * (G8 ? 8 : 64) + unit;
   if (i >= a.n) return;
