@@ -715,7 +715,7 @@ def bench_align_c4(args, ctx, dist, rank, world, dev, comm_dev=None):
             "illumination_median": {"alpha": float(np.median([r.alpha for r in res])), "beta": float(np.median([r.beta for r in res]))},
             "pose_err_vs_gt": {"rot_rad_median": float(np.median([e[0] for e in errs])), "trans_m_median": float(np.median([e[1] for e in errs]))},
             "roofline": roofline("sparse_align_kernel<%d,256,true,false>" % P, kms, alg,
-                                 "align-c4:default" if (not args.problems and N == 1500 and P == 4) else "align-c4:B%d:N%d:P%d" % (B, N, P)),
+                                 "align-c4:default" if (not args.problems and N == 2000 and P == 4) else "align-c4:B%d:N%d:P%d" % (B, N, P)),
             "cpu_baseline": None}
 
 
