@@ -1345,11 +1345,10 @@ __device__ __forceinline__ void flush_counters(unsigned int* c, int i, const Mat
 
 // G8: eight lanes per unit (small batches, see g8_sum): unit = threadIdx.x / 8, the lane's patch row = threadIdx.x % 8
 template <bool G8>
-__global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
+__device__ __forceinline__ void match_direct_body(const MatcherArgs& a, int block, unsigned char* s_pwb)
 {
-  __shared__ __attribute__((aligned(16))) unsigned char s_pwb[64 * kPwbStride];
   const int unit = G8 ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;
-  const int i = blockIdx.x * (G8 ? 8 : 64) + unit;
+  const int i = block * (G8 ? 8 : 64) + unit;
   if (i >= a.n) return;
   if (!feature_indices_ok(a, i)) {
     a.result[i] = SVOH_MATCH_NOT_RUN;
@@ -1379,13 +1378,19 @@ __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
   flush_counters(a.unit_counts, i, m, 0);
 }
 
-// DepthFilter::updateSeeds (depth_filter.cpp:200-233) + depth_filter_utils::updateSeed (:367-499)
 template <bool G8>
-__global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
+__global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
 {
   __shared__ __attribute__((aligned(16))) unsigned char s_pwb[64 * kPwbStride];
+  match_direct_body<G8>(a, (int)blockIdx.x, s_pwb);
+}
+
+// DepthFilter::updateSeeds (depth_filter.cpp:200-233) + depth_filter_utils::updateSeed (:367-499)
+template <bool G8>
+__device__ __forceinline__ void update_seeds_body(const MatcherArgs& a, int block, unsigned char* s_pwb)
+{
   const int unit = G8 ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;
-  const int i = blockIdx.x * (G8 ? 8 : 64) + unit;
+  const int i = block * (G8 ? 8 : 64) + unit;
   if (i >= a.n) return;
   a.success[i] = 0;
   if (a.result) a.result[i] = SVOH_MATCH_NOT_RUN;
@@ -1465,6 +1470,24 @@ __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
   SVOH_MSTAMP(m, 0);
   flush_counters(a.unit_counts, i, m, 1);
 #endif
+}
+
+template <bool G8>
+__global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char s_pwb[64 * kPwbStride];
+  update_seeds_body<G8>(a, (int)blockIdx.x, s_pwb);
+}
+
+// The direct matches and the seed updates of one reprojection (a deferred section, svoh_matcher_begin_deferred) in ONE
+// launch: workgroups [0, n_blocks_direct) run the direct matcher's body, the rest the seed update's.  Both are small
+// (a few hundred to a few thousand units on a 256-CU device): one after the other they cost two kernel latencies.
+template <bool G8>
+__global__ __launch_bounds__(64) void match_mixed_kernel(const MatcherArgs ad, const MatcherArgs as, int n_blocks_direct)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char s_pwb[64 * kPwbStride];
+  if ((int)blockIdx.x < n_blocks_direct) match_direct_body<G8>(ad, (int)blockIdx.x, s_pwb);
+  else update_seeds_body<G8>(as, (int)blockIdx.x - n_blocks_direct, s_pwb);
 }
 
 // ---- spatial binning of a large seed batch -------------------------------------------------------------------------
@@ -2090,6 +2113,28 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   int g8 = n <= kG8MaxUnits ? 1 : (seeds ? 2 : 0);
   if (const char* e = getenv("SVOH_MATCHER_G8")) g8 = atoi(e);
   if (g8 < 0 || g8 > 2 || (g8 == 2 && !seeds)) g8 = 0;
+  if (defer && g8 != 2) {
+    // Deferred section: the launch itself waits for svoh_matcher_collect, where a direct batch and a seed batch of
+    // the same geometry go out as ONE kernel (match_mixed_kernel).  Remembered: the arguments, the copy of the
+    // results back to the pinned block, and the copies from there to the caller's arrays.
+    svoh_ctx::DeferredLaunch& dl = ctx->matcher_deferred_launch[seeds ? 1 : 0];
+    dl.args.assign(reinterpret_cast<const uint8_t*>(&a), reinterpret_cast<const uint8_t*>(&a) + sizeof a);
+    dl.n = n; dl.g8 = g8; dl.valid = true;
+    dl.d2h_dst = h + o_type; dl.d2h_src = d + o_type; dl.d2h_bytes = o_nsucc - o_type;
+    auto later = [&](void* dst, size_t off, size_t bytes) { if (dst && bytes) ctx->matcher_pending.push_back({ dst, h + off, bytes }); };
+    if (seeds) {
+      later(fb->type, o_type, (size_t)n); later(state, o_state, sizeof(double) * 4 * n); later(success, o_success, (size_t)n);
+      later(result, o_result, sizeof(int32_t) * n); later(px_cur, o_pxcur, sizeof(double) * 2 * n);
+      later(f_cur, o_fcur, sizeof(double) * 3 * n); later(search_level, o_slevel, sizeof(int32_t) * n);
+      later(A_cur_ref, o_A, sizeof(double) * 4 * n);
+      if (n_success) ctx->matcher_pending_counts.push_back({ n_success, h + o_success, n });
+    } else {
+      later(px_cur, o_pxcur, sizeof(double) * 2 * n); later(result, o_result, sizeof(int32_t) * n);
+      later(f_cur, o_fcur, sizeof(double) * 3 * n); later(search_level, o_slevel, sizeof(int32_t) * n);
+      later(h_inv, o_hinv, sizeof(double) * n); later(A_cur_ref, o_A, sizeof(double) * 4 * n);
+    }
+    return SVOH_OK;
+  }
   const int units_per_block = g8 == 1 ? 8 : 64;
   const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
   {
@@ -2387,6 +2432,7 @@ try {
   ctx->matcher_deferred_used[0] = ctx->matcher_deferred_used[1] = false;
   ctx->matcher_pending.clear();
   ctx->matcher_pending_counts.clear();
+  ctx->matcher_deferred_launch[0].valid = ctx->matcher_deferred_launch[1].valid = false;
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
@@ -2397,6 +2443,48 @@ try {
   ctx->matcher_deferred = false;
   ctx->matcher_deferred_used[0] = ctx->matcher_deferred_used[1] = false;
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    svoh_ctx::DeferredLaunch& d0 = ctx->matcher_deferred_launch[0];
+    svoh_ctx::DeferredLaunch& d1 = ctx->matcher_deferred_launch[1];
+    const bool v0 = d0.valid, v1 = d1.valid;
+    d0.valid = d1.valid = false;
+    if (v0 || v1) {
+      MatcherArgs a0, a1;
+      memset(&a0, 0, sizeof a0); memset(&a1, 0, sizeof a1);
+      if (v0) memcpy(&a0, d0.args.data(), sizeof a0);
+      if (v1) memcpy(&a1, d1.args.data(), sizeof a1);
+      const size_t n0 = v0 ? (size_t)d0.n : 0, n1 = v1 ? (size_t)d1.n : 0;
+      unsigned long long* dummy;
+      unsigned int* uc = nullptr;
+      int rc = reset_counters(ctx, &dummy);
+      if (rc == SVOH_OK) rc = reserve_unit_counts(ctx, n0 + n1, &uc);
+      if (rc != SVOH_OK) return rc;
+      a0.unit_counts = uc; a1.unit_counts = uc + 4 * n0;
+      auto blocks = [](const svoh_ctx::DeferredLaunch& d) { const int u = d.g8 ? 8 : 64; return (unsigned)((d.n + u - 1) / u); };
+      SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+      if (v0 && v1 && d0.g8 == d1.g8) {
+        const unsigned b0 = blocks(d0), b1 = blocks(d1);
+        if (d0.g8) hipLaunchKernelGGL(match_mixed_kernel<true>, dim3(b0 + b1), dim3(64), 0, ctx->stream, a0, a1, (int)b0);
+        else hipLaunchKernelGGL(match_mixed_kernel<false>, dim3(b0 + b1), dim3(64), 0, ctx->stream, a0, a1, (int)b0);
+      } else {
+        if (v0) {
+          if (d0.g8) hipLaunchKernelGGL(match_direct_kernel<true>, dim3(blocks(d0)), dim3(64), 0, ctx->stream, a0);
+          else hipLaunchKernelGGL(match_direct_kernel<false>, dim3(blocks(d0)), dim3(64), 0, ctx->stream, a0);
+        }
+        if (v1) {
+          if (d1.g8) hipLaunchKernelGGL(update_seeds_kernel<true>, dim3(blocks(d1)), dim3(64), 0, ctx->stream, a1);
+          else hipLaunchKernelGGL(update_seeds_kernel<false>, dim3(blocks(d1)), dim3(64), 0, ctx->stream, a1);
+        }
+      }
+      SVOH_HIP_TRY(ctx, hipGetLastError());
+      SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+      ctx->misc_timed = true;
+      rc = reduce_unit_counts(ctx, n0 + n1);
+      if (rc != SVOH_OK) return rc;
+      if (v0) SVOH_HIP_TRY(ctx, hipMemcpyAsync(d0.d2h_dst, d0.d2h_src, d0.d2h_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      if (v1) SVOH_HIP_TRY(ctx, hipMemcpyAsync(d1.d2h_dst, d1.d2h_src, d1.d2h_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (const auto& c : ctx->matcher_pending) memcpy(c.dst, c.src, c.bytes);
   for (const auto& c : ctx->matcher_pending_counts) {

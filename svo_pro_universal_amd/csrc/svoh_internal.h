@@ -118,6 +118,12 @@ struct svoh_ctx {
   std::vector<PendingCopy> matcher_pending;
   struct PendingCount { int32_t* dst; const uint8_t* flags; int n; };
   std::vector<PendingCount> matcher_pending_counts;
+  struct DeferredLaunch {              // a matcher launch waiting for svoh_matcher_collect (kernel arguments as bytes)
+    std::vector<uint8_t> args;
+    int n = 0, g8 = 0;
+    bool valid = false;
+    void* d2h_dst = nullptr; const void* d2h_src = nullptr; size_t d2h_bytes = 0;
+  } matcher_deferred_launch[2];
   svoh::DevBuffer d_match_seeds;       // staging of the deferred seed batch (the direct one keeps d_scratch1)
   svoh::PinnedBuffer h_match_seeds;
 
