@@ -130,7 +130,28 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
         const int wBR = (int)(unsigned short)(128 - wTL - wTR - wBL);
         const uint8_t* it = img_cur.data + (ptrdiff_t)(v_r + y) * cur_step + u_r + x0;
         int j0 = 0, j1 = 0;
-        if constexpr (PPL == 4) {
+        if constexpr (PPL == 16) {
+          // a whole 16-pixel row per lane: 2 x 17 pixels as three unaligned 8-byte loads each (the spare bytes stay
+          // inside the row, the next row or the slab's tail padding), taps packed and summed as in the 4-pixel case
+          unsigned T[6], B[6];
+          __builtin_memcpy(T, it, 24);
+          __builtin_memcpy(B, it + cur_step, 24);
+          const unsigned W = (unsigned)wTL | ((unsigned)wTR << 8) | ((unsigned)wBL << 16) | ((unsigned)wBR << 24);
+#pragma unroll
+          for (int dq = 0; dq < 4; ++dq) {
+            const unsigned T3 = __builtin_amdgcn_alignbyte(T[dq + 1], T[dq], 3), B3 = __builtin_amdgcn_alignbyte(B[dq + 1], B[dq], 3);
+            const unsigned q[4] = { __builtin_amdgcn_perm(B[dq], T[dq], 0x05040100u), __builtin_amdgcn_perm(B[dq], T[dq], 0x06050201u),
+                                    __builtin_amdgcn_perm(B[dq], T[dq], 0x07060302u), __builtin_amdgcn_perm(B3, T3, 0x05040100u) };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int k = 4 * dq + r;
+              const int cur = (int)(unsigned short)(__builtin_amdgcn_udot4(q[r], W, 64u, false) >> 7);
+              const int res = cur - tmpl[k];
+              j0 += res * gdx[k];
+              j1 += res * gdy[k];
+            }
+          }
+        } else if constexpr (PPL == 4) {
           // the lane's 2 x 5 pixels as two unaligned 8-byte loads (the spare bytes stay inside the row, the next row or
           // the slab's tail padding); per pixel the four taps are gathered into one dword (v_perm_b32) and the 7-bit
           // fixed-point bilinear sum is ONE v_dot4_u32_u8 against the packed weights (all <= 128): the same integers
@@ -188,11 +209,11 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane)
   return __hiloint2double(hi, lo);
 }
 
-// A wave owns FOUR tracks (DPP row r = lanes 16r .. 16r+15 holds the state of track 4*wave + r).  Levels whose patch is
-// 16x16 are taken one track after the other with the whole wave (4 pixels per lane); levels whose patch is 8x8 are taken
-// by the four tracks side by side, sixteen lanes and 4 pixels per lane each -- on a wave of its own an 8x8 patch
-// gives a lane ONE pixel and the per-iteration bookkeeping (weights, reductions, the 2x2 update: ~55 of ~65
-// instructions) is spent on it alone.  Waves never synchronise.
+// A wave owns FOUR tracks, one per DPP row (lanes 16r .. 16r+15 hold track 4*wave + r) through all levels and
+// iterations: a 16x16 patch gives a lane one row of 16 pixels, an 8x8 patch 4 pixels.  On a wave of its own a track
+// spent most of an iteration's instructions on bookkeeping that is the same for 1, 4 or 16 pixels per lane (weights,
+// two reductions, the 2x2 update); side by side the four tracks share it, reductions stay inside a row (4 DPP adds),
+// and a row whose track has left the loop idles while the others finish.  Waves never synchronise.
 __global__ __launch_bounds__(256) void klt_track_kernel(const KltArgs a)
 {
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -211,22 +232,13 @@ __global__ __launch_bounds__(256) void klt_track_kernel(const KltArgs a)
   for (int level = a.opt.max_level; level >= a.opt.min_level; --level) {
     const int P = a.opt.patch_sizes[level];
     if (P == 16) {
-#pragma unroll 1
-      for (int j = 0; j < 4; ++j) {
-        // track j's state, taken from the first lane of its row: uniform over the wave
-        const int src = 16 * j;
-        const bool alive = __builtin_amdgcn_readlane((int)(ok_idx && !failed), src) != 0;
-        if (!alive) continue;
-        const int jri = __builtin_amdgcn_readlane(ri, src), jci = __builtin_amdgcn_readlane(ci, src);
-        const int jrx = __builtin_amdgcn_readlane(rx, src), jry = __builtin_amdgcn_readlane(ry, src);
-        double jx = readlane_f64(pcx, src), jy = readlane_f64(pcy, src);
-        bool jconv = __builtin_amdgcn_readlane((int)converged, src) != 0;
-        int jit = 0, jt = 0;
-        const DevImage& ref = a.frame_levels[(size_t)jri * SVOH_MAX_LEVELS + level];
-        const DevImage& cur = a.frame_levels[(size_t)jci * SVOH_MAX_LEVELS + level];
-        const int rc = klt_level<16, 64>(ref, cur, level, jrx, jry, a.opt.max_iter, a.opt.min_update_squared, jx, jy, jconv, lane,
-                                         jit, jt, true);
-        if (row == j) { pcx = jx; pcy = jy; converged = jconv; it16 += jit; t16 += jt; if (rc) failed = true; }
+      const bool run = ok_idx && !failed;
+      if (__ballot(run) != 0) {
+        const DevImage ref = a.frame_levels[(size_t)(run ? ri : 0) * SVOH_MAX_LEVELS + level];
+        const DevImage cur = a.frame_levels[(size_t)(run ? ci : 0) * SVOH_MAX_LEVELS + level];
+        const int rc = klt_level<16, 16>(ref, cur, level, rx, ry, a.opt.max_iter, a.opt.min_update_squared, pcx, pcy, converged,
+                                         lane16, it16, t16, run);
+        if (run && rc) failed = true;
       }
     } else if (P == 8) {
       const bool run = ok_idx && !failed;
