@@ -898,37 +898,37 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
   stats_ = reprojector::Statistics();
   auto add = [&](const reprojector::Statistics& st) { stats_.n_matches += st.n_matches; stats_.n_trials += st.n_trials; };
 
-  // landmarks of the closest keyframes with overlap (:131-176)
+  // landmarks of the closest keyframes with overlap (:131-176), converged seeds (:201-241) and unconverged seeds
+  // (:243-306): the three candidate lists depend on the visible keyframes and the current pose only, so one walk over
+  // the keyframes' features gathers all of them (each list in the order its own loop of the reference gives), and they
+  // are matched together
   candidates_.clear();
+  thread_local std::vector<reprojector::Candidate> converged, unconverged;
+  converged.clear(); unconverged.clear();
+  struct Release { std::vector<reprojector::Candidate>&a, &b, &c; ~Release() { a.clear(); b.clear(); c.clear(); } } release{ candidates_, converged, unconverged };
   for (const FramePtr& ref_frame : visible_kfs) {
+    const svoh::Rigid T_world_ref = svoh::inverse(ref_frame->T_f_w_);
     for (size_t i = 0; i < ref_frame->num_features_; ++i) {
       const uint8_t type = ref_frame->type_vec_[i];
-      const PointPtr point = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i] : nullptr;
-      if (!point || type == SVOH_FT_OUTLIER || is_map_point(type) || type == SVOH_FT_FIXED_LANDMARK) continue;
-      if (point->n_failed_reproj_ > 10) { trash_points.push_back(point); continue; }
-      if (point->last_projected_kf_id_.at(camera_index_) == cur_frame->id_) continue;   // project a point only once
-      point->last_projected_kf_id_[camera_index_] = cur_frame->id_;
-      if (point->obs_.size() < 2 && options_.remove_unconstrained_points) { trash_points.push_back(point); continue; }
+      static const PointPtr no_point;
+      const PointPtr& point = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i] : no_point;
       reprojector::Candidate candidate;
-      if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) candidates_.push_back(candidate);
+      if (point && type != SVOH_FT_OUTLIER && !is_map_point(type) && type != SVOH_FT_FIXED_LANDMARK) {
+        if (point->n_failed_reproj_ > 10) trash_points.push_back(point);
+        else if (point->last_projected_kf_id_.at(camera_index_) != cur_frame->id_) {   // project a point only once
+          point->last_projected_kf_id_[camera_index_] = cur_frame->id_;
+          if (point->obs_.size() < 2 && options_.remove_unconstrained_points) trash_points.push_back(point);
+          else if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref)) candidates_.push_back(candidate);
+        }
+      }
+      const bool conv = type == SVOH_FT_CORNER_SEED_CONVERGED || type == SVOH_FT_EDGELET_SEED_CONVERGED;
+      const bool unconv = (type == SVOH_FT_CORNER_SEED || type == SVOH_FT_EDGELET_SEED) && options_.reproject_unconverged_seeds;
+      if ((conv || unconv) && reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref))
+        (conv ? converged : unconverged).push_back(candidate);
     }
   }
   const double ts1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   reprojector_utils::sortCandidatesByReprojStats(candidates_);
-
-  // converged seeds (:201-241) and unconverged seeds (:243-306): their candidate lists depend on the visible
-  // keyframes and the current pose only, so they are gathered now and matched together with the landmarks
-  std::vector<reprojector::Candidate> converged, unconverged;
-  for (const FramePtr& ref_frame : visible_kfs)
-    for (size_t i = 0; i < ref_frame->num_features_; ++i) {
-      const uint8_t t = ref_frame->type_vec_[i];
-      const bool conv = t == SVOH_FT_CORNER_SEED_CONVERGED || t == SVOH_FT_EDGELET_SEED_CONVERGED;
-      const bool unconv = (t == SVOH_FT_CORNER_SEED || t == SVOH_FT_EDGELET_SEED) && options_.reproject_unconverged_seeds;
-      if (!conv && !unconv) continue;
-      reprojector::Candidate candidate;
-      if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate)) (conv ? converged : unconverged).push_back(candidate);
-    }
-  const double ts2 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   reprojector_utils::sortCandidatesByReprojStats(converged);
   reprojector_utils::sortCandidatesByReprojStats(unconverged);
   const double ts3 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
@@ -976,11 +976,11 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
                                           lists, [&](int pass, size_t& max_n) { return !stop && before_pass(pass, max_n); }, after,
                                           *grid_, st, speculate_unconverged_ ? 3 : 2);
   speculate_unconverged_ = reached_unconverged;
-  candidates_.clear();
+  // (the candidate lists are emptied on return: their buffers stay, the frame references go)
   if (g_reproj_timing.on) {
     g_reproj_timing.n_reached3 += reached_unconverged;
     const double ts4 = ReprojTiming::now();
-    g_reproj_timing.t[0] += (ts1 - ts0) + (ts2 - ts1 - 0.0) ; g_reproj_timing.t[1] += ts3 - ts2;
+    g_reproj_timing.t[0] += ts1 - ts0; g_reproj_timing.t[1] += ts3 - ts1;
     g_reproj_timing.t[5] += ts4 - ts3;   // plan + device + replay together (split below when the fused call reports it)
     ++g_reproj_timing.n;
   }
@@ -989,10 +989,26 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
 namespace reprojector_utils {
 void sortCandidatesByReprojStats(std::vector<reprojector::Candidate>& candidates)
 {
-  std::sort(candidates.begin(), candidates.end(), [](const reprojector::Candidate& lhs, const reprojector::Candidate& rhs) {
+  // std::sort(candidates, type > , n_reproj > , score >) of reprojector.cpp:545-556.  The order of EQUAL candidates is
+  // whatever libstdc++'s introsort leaves, and its moves depend on the comparison results only: sorting 24-byte keys
+  // with the same comparator and applying the permutation gives the vector the reference's call gives, for less
+  // memory traffic than sorting the 64-byte candidates.
+  struct Key { double score; int n_reproj; uint8_t type; uint32_t at; };
+  thread_local std::vector<Key> keys;
+  thread_local std::vector<reprojector::Candidate> sorted;
+  const size_t n = candidates.size();
+  if (n < 2) return;
+  keys.resize(n);
+  for (size_t i = 0; i < n; ++i) keys[i] = Key{ candidates[i].score, candidates[i].n_reproj, candidates[i].type, static_cast<uint32_t>(i) };
+  std::sort(keys.begin(), keys.end(), [](const Key& lhs, const Key& rhs) {
     return lhs.type > rhs.type || (lhs.type == rhs.type && lhs.n_reproj > rhs.n_reproj) ||
            (lhs.type == rhs.type && lhs.n_reproj == rhs.n_reproj && lhs.score > rhs.score);
   });
+  sorted.clear();
+  sorted.reserve(n);
+  for (size_t i = 0; i < n; ++i) sorted.push_back(std::move(candidates[keys[i].at]));
+  candidates.swap(sorted);
+  sorted.clear();
 }
 
 bool projectPointAndCheckVisibility(const FramePtr& frame, const svoh::Vec3& xyz, double* px)
@@ -1005,6 +1021,13 @@ bool projectPointAndCheckVisibility(const FramePtr& frame, const svoh::Vec3& xyz
 
 bool getCandidate(const FramePtr& cur_frame, const FramePtr& ref_frame, size_t ref_index, reprojector::Candidate& candidate)
 {
+  return getCandidate(cur_frame, ref_frame, ref_index, candidate, nullptr);
+}
+
+// T_world_ref: ref_frame->T_world_cam() when the caller has it already (one inverse per keyframe, not per seed)
+bool getCandidate(const FramePtr& cur_frame, const FramePtr& ref_frame, size_t ref_index, reprojector::Candidate& candidate,
+                  const svoh::Rigid* T_world_ref)
+{
   svoh::Vec3 xyz_world{ 0, 0, 0 };
   int n_reproj = 0;
   const PointPtr lm = ref_index < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[ref_index] : nullptr;
@@ -1015,7 +1038,7 @@ bool getCandidate(const FramePtr& cur_frame, const FramePtr& ref_frame, size_t r
     const double depth = ref_frame->getSeedDepth(ref_index);   // T_world_cam() * getSeedPosInFrame(ref_index)
     const svoh::Vec3 in_f{ ref_frame->f_vec_[3 * ref_index] * depth, ref_frame->f_vec_[3 * ref_index + 1] * depth,
                            ref_frame->f_vec_[3 * ref_index + 2] * depth };
-    xyz_world = svoh::transform(svoh::inverse(ref_frame->T_f_w_), in_f);
+    xyz_world = T_world_ref ? svoh::transform(*T_world_ref, in_f) : svoh::transform(svoh::inverse(ref_frame->T_f_w_), in_f);
   }
   double px[2];
   if (!projectPointAndCheckVisibility(cur_frame, xyz_world, px)) return false;
@@ -1071,10 +1094,16 @@ struct Batch {
     grad.insert(grad.end(), r.grad_vec_.begin() + 2 * i, r.grad_vec_.begin() + 2 * i + 2);
   }
   size_t size() const { return level.size(); }
+  void clear()
+  {
+    ref_idx.clear(); level.clear(); result.clear(); search_level.clear(); px.clear(); f.clear(); grad.clear(); depth.clear();
+    state.clear(); px_cur.clear(); f_cur.clear(); A.clear(); type.clear(); success.clear();
+  }
 };
 struct SpeculativeMatches {
   std::vector<FramePtr> frames;   // distinct reference frames of all lists
   Batch direct, seeds;
+  void clear() { frames.clear(); direct.clear(); seeds.clear(); }
   int slot_of(const FramePtr& f)
   {
     for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == f) return static_cast<int>(k);
@@ -1277,7 +1306,9 @@ void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_
                           int n_speculated)
 {
   if (!ctx) throw std::runtime_error("matchCandidatesFused: NULL svoh_ctx (no CPU fallback exists)");
-  SpeculativeMatches sm;
+  thread_local SpeculativeMatches sm;   // keeps its buffers from frame to frame ...
+  sm.clear();
+  struct Release { SpeculativeMatches& s; ~Release() { s.clear(); } } release{ sm };   // ... but no frame reference past the call
   std::vector<Resolved> rs[3];
   const double tp0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   for (int k = 0; k < 3 && k < n_speculated; ++k) rs[k] = sm.plan(frame, *lists[k]);
@@ -1287,7 +1318,7 @@ void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_
   if (g_reproj_timing.on) { const double tp2 = ReprojTiming::now(); g_reproj_timing.t[2] += tp1 - tp0; g_reproj_timing.t[3] += tp2 - tp1; g_reproj_timing.t[5] -= tp2 - tp0; }
   for (int k = 0; k < 3; ++k) {
     size_t max_n = 0;
-    if (!before_pass(k, max_n)) return;
+    if (!before_pass(k, max_n)) break;
     if (k < n_speculated) sm.replay(frame, max_n, *lists[k], rs[k], grid, stats[k]);
     else matchCandidates(ctx, frame, max_n, affine_est_offset, affine_est_gain, *lists[k], grid, stats[k], seed_sigma2_thresh);   // a pass nobody bet on: its own round trip
     after_pass(k);

@@ -424,6 +424,8 @@ namespace reprojector_utils {
 // reprojector.cpp:309-339, 489-543
 void sortCandidatesByReprojStats(std::vector<reprojector::Candidate>& candidates);
 bool getCandidate(const FramePtr& cur_frame, const FramePtr& ref_frame, size_t ref_index, reprojector::Candidate& candidate);
+bool getCandidate(const FramePtr& cur_frame, const FramePtr& ref_frame, size_t ref_index, reprojector::Candidate& candidate,
+                  const svoh::Rigid* T_world_ref);   // with ref_frame->T_world_cam() already at hand
 bool projectPointAndCheckVisibility(const FramePtr& frame, const svoh::Vec3& xyz, double* px);
 void setGridCellsOccupied(const std::vector<reprojector::Candidate>& candidates, OccupandyGrid2D& grid);
 // Appends every matched feature to `frame` (px_vec_, f_vec_, grad_vec_, level_vec_, type_vec_, score_vec_,
