@@ -126,6 +126,13 @@ struct ShState {
   double fact[36];
   int fact_tr[8];
   int fact_nonzero;
+  // what the one-lane step needs of the problem and camera descriptors, and what it reports per level: in LDS for the
+  // problem's life, so that the step makes no round trip to global memory (a load it must wait for, or a store the
+  // barrier behind it must wait for) between two passes over the patches
+  Rigid cam_cur_T_cam_imu[SVOH_MAX_CAMS], cam_ref_T_imu_cam[SVOH_MAX_CAMS];
+  svoh_align_prior prior;
+  int lvl_iters[SVOH_MAX_LEVELS], lvl_n_meas[SVOH_MAX_LEVELS];
+  double lvl_chi2[SVOH_MAX_LEVELS];
 };
 
 // ---- image accessors --------------------------------------------------------
@@ -749,11 +756,10 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
 #pragma unroll
       for (int r = 0; r < D; ++r) xg[r] = s_sum[NH + r];
     }
-    svoh_align_result& res = a.results[pbi];
     if (level < SVOH_MAX_LEVELS) {
-      res.iters[level] = iter + 1;
-      res.n_meas[level] = n_meas;
-      res.chi2[level] = chi2;
+      s.lvl_iters[level] = iter + 1;
+      s.lvl_n_meas[level] = n_meas;
+      s.lvl_chi2[level] = chi2;
     }
     if (eval_mode) {
       double* eo = a.eval_out + 74 * pbi;   // one block per problem (the shares of a patch-split evaluation)
@@ -770,7 +776,7 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
       eo[73] = (double)n_meas;
       s.level_done = 1;
     } else {
-      if (pb.prior.have_prior) {
+      if (s.prior.have_prior) {
         // SparseImgAlignBase::applyPrior (sparse_img_align_base.cpp:77-107)
         if (iter == 0) {
           double mt = 0, mr = 0;
@@ -778,21 +784,21 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
           for (int j = 0; j < 3; ++j) mt = fmax(mt, fabs(SVOH_L(j, j)));
 #pragma unroll
           for (int j = 3; j < 6; ++j) mr = fmax(mr, fabs(SVOH_L(j, j)));
-          for (int j = 0; j < 3; ++j) s.I_prior[j] = 1.0 * pb.prior.lambda_trans * mt;
-          for (int j = 3; j < 6; ++j) s.I_prior[j] = 1.0 * pb.prior.lambda_rot * mr;
-          s.I_prior[6] = pb.prior.lambda_alpha * SVOH_L(6, 6);
-          s.I_prior[7] = pb.prior.lambda_beta * SVOH_L(7, 7);
+          for (int j = 0; j < 3; ++j) s.I_prior[j] = 1.0 * s.prior.lambda_trans * mt;
+          for (int j = 3; j < 6; ++j) s.I_prior[j] = 1.0 * s.prior.lambda_rot * mr;
+          s.I_prior[6] = s.prior.lambda_alpha * SVOH_L(6, 6);
+          s.I_prior[7] = s.prior.lambda_beta * SVOH_L(7, 7);
         }
         if (!reuse_factor) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) SVOH_L(j, j) += s.I_prior[j];
         }
         double lg[6];
-        rigid_log(mul(inverse(load_rigid(pb.prior.T_prior)), s.T), lg);
+        rigid_log(mul(inverse(load_rigid(s.prior.T_prior)), s.T), lg);
 #pragma unroll
         for (int j = 0; j < 6; ++j) xg[j] += s.I_prior[j] * lg[j];
-        xg[6] += s.I_prior[6] * (pb.prior.alpha_prior - s.alpha);
-        xg[7] += s.I_prior[7] * (pb.prior.beta_prior - s.beta);
+        xg[6] += s.I_prior[6] * (s.prior.alpha_prior - s.alpha);
+        xg[7] += s.I_prior[7] * (s.prior.beta_prior - s.beta);
       }
       // without illumination terms rows/columns 6 and 7 are exactly zero: the
       // pivoted factorisation never selects them before the six pose pivots and
@@ -866,7 +872,7 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
         if (x_norm < opt.eps) s.level_done = 1;
       }
       for (int c = 0; c < n_cams; ++c)
-        s.Tcr[c] = mul(mul(load_rigid(cams[c].cur_T_cam_imu), s.T), load_rigid(cams[c].ref_T_imu_cam));
+        s.Tcr[c] = mul(mul(s.cam_cur_T_cam_imu[c], s.T), s.cam_ref_T_imu_cam[c]);
       s.alpha_f = (float)s.alpha; s.beta_f = (float)s.beta;
     }
   }
@@ -937,6 +943,12 @@ void sparse_align_kernel(const AlignKernelArgs a)
     s.stop = 0; s.level_done = 0; s.nsel = 0; s.status = 0; s.patch_iters = 0;
     for (int k = 0; k < 8; ++k) s.I_prior[k] = 0.0;
     s_nvis = 0;
+    s.prior = pb.prior;
+    for (int c = 0; c < n_cams; ++c) {
+      s.cam_cur_T_cam_imu[c] = load_rigid(cams[c].cur_T_cam_imu);
+      s.cam_ref_T_imu_cam[c] = load_rigid(cams[c].ref_T_imu_cam);
+    }
+    for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { s.lvl_iters[l] = 0; s.lvl_n_meas[l] = 0; s.lvl_chi2[l] = 0.0; }
   }
   __syncthreads();
 
@@ -1043,11 +1055,6 @@ void sparse_align_kernel(const AlignKernelArgs a)
     SVOH_STAMP_FLUSH();
     continue;
   }
-  if (tid == 0) {
-    svoh_align_result& r = a.results[res_idx];
-    for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = 0; r.n_meas[l] = 0; r.chi2[l] = 0.0; }
-  }
-
   const bool est_alpha = opt.estimate_illumination_gain != 0;
   const bool est_beta = opt.estimate_illumination_offset != 0;
   const bool robust = opt.robustification != 0;
@@ -1079,7 +1086,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
     if (tid == 0) {
       s.level_done = 0;
       for (int c = 0; c < n_cams; ++c)
-        s.Tcr[c] = mul(mul(load_rigid(cams[c].cur_T_cam_imu), s.T), load_rigid(cams[c].ref_T_imu_cam));
+        s.Tcr[c] = mul(mul(s.cam_cur_T_cam_imu[c], s.T), s.cam_ref_T_imu_cam[c]);
       s.alpha_f = (float)s.alpha; s.beta_f = (float)s.beta;
       s.Told = s.T; s.alpha_old = s.alpha; s.beta_old = s.beta;  // old_state = state (hpp:45)
     }
@@ -1232,6 +1239,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
     store_rigid(s.T, r.T_icur_iref);
     r.alpha = s.alpha; r.beta = s.beta;
     r.n_patch_iters = s.patch_iters;
+    for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = s.lvl_iters[l]; r.n_meas[l] = s.lvl_n_meas[l]; r.chi2[l] = s.lvl_chi2[l]; }
   }
   SVOH_STAMP_FLUSH();
   }  // next problem
@@ -1284,7 +1292,16 @@ void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_al
   }
   const int n_meas = (int)sums[73];
   int nvis = n_meas / (P * P);
+  s.prior = pb.prior;
+  for (int c = 0; c < pb.n_cams; ++c) {
+    s.cam_cur_T_cam_imu[c] = load_rigid(cams[c].cur_T_cam_imu);
+    s.cam_ref_T_imu_cam[c] = load_rigid(cams[c].ref_T_imu_cam);
+  }
   gn_serial_step<P, D, ILLUM>(a, pb, cams, pb.n_cams, 0, level, iter, false, false, s, s_sum, &nvis);
+  if (level < SVOH_MAX_LEVELS) {
+    svoh_align_result& res = a.results[0];
+    res.iters[level] = s.lvl_iters[level]; res.n_meas[level] = s.lvl_n_meas[level]; res.chi2[level] = s.lvl_chi2[level];
+  }
   store_rigid(s.T, st->T_icur_iref);
   st->alpha = s.alpha; st->beta = s.beta;
   store_rigid(s.Told, st->T_old);
