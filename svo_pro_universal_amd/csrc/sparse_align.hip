@@ -105,13 +105,15 @@ constexpr int kXchgStride = 64;         // doubles per share and parity (>= 45 +
 #define SVOH_STAMP_START() do { st_t0 = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define SVOH_STAMP_ADD(k) do { long long st_n = (long long)__builtin_amdgcn_s_memtime(); st_acc[k] += st_n - st_t0; st_t0 = st_n; } while (0)
 #define SVOH_STAMP_COUNT(k) do { st_acc[k] += 1; } while (0)
-#define SVOH_STAMP_FLUSH() do { if (threadIdx.x == 0) { st_acc[7] = (long long)__builtin_amdgcn_s_memtime() - st_begin; for (int k_ = 0; k_ < 8; ++k_) a.stamps[pbi * 8 + k_] = st_acc[k_]; } } while (0)
+#define SVOH_STAMP_FLUSH() do { if (threadIdx.x == 0) { st_acc[7] = (long long)__builtin_amdgcn_s_memtime() - st_begin; for (int k_ = 0; k_ < 8; ++k_) a.stamps[pbi * 12 + k_] = st_acc[k_]; for (int k_ = 0; k_ < 4; ++k_) a.stamps[pbi * 12 + 8 + k_] = s.dbg[k_]; } } while (0)
+#define SVOH_SERIAL_STAMP(k) do { long long st_n = (long long)__builtin_amdgcn_s_memtime(); s.dbg[k] += st_n - st_s0; st_s0 = st_n; } while (0)
 #else
 #define SVOH_STAMP_DECL
 #define SVOH_STAMP_START() do {} while (0)
 #define SVOH_STAMP_ADD(k) do {} while (0)
 #define SVOH_STAMP_COUNT(k) do {} while (0)
 #define SVOH_STAMP_FLUSH() do {} while (0)
+#define SVOH_SERIAL_STAMP(k) do {} while (0)
 #endif
 
 struct ShState {
@@ -133,6 +135,9 @@ struct ShState {
   svoh_align_prior prior;
   int lvl_iters[SVOH_MAX_LEVELS], lvl_n_meas[SVOH_MAX_LEVELS];
   double lvl_chi2[SVOH_MAX_LEVELS];
+#ifdef SVOH_PHASE_STAMPS
+  long long dbg[4];   // diagnostic build: cycles of the one-lane step in set-up / solve / update / camera poses
+#endif
 };
 
 // ---- image accessors --------------------------------------------------------
@@ -738,6 +743,9 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
   const svoh_align_options& opt = a.opt;
   int& s_nvis = *s_nvis_p;
 
+#ifdef SVOH_PHASE_STAMPS
+    long long st_s0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
     const int n_meas = s_nvis * P * P;
     s.patch_iters += s_nvis;
     s_nvis = 0;
@@ -800,6 +808,7 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
         xg[6] += s.I_prior[6] * (s.prior.alpha_prior - s.alpha);
         xg[7] += s.I_prior[7] * (s.prior.beta_prior - s.beta);
       }
+      SVOH_SERIAL_STAMP(0);
       // without illumination terms rows/columns 6 and 7 are exactly zero: the
       // pivoted factorisation never selects them before the six pose pivots and
       // they contribute exact zeros, so the 6x6 leading block gives the same bits
@@ -850,6 +859,7 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
         for (int k = 0; k < 6; ++k) xg[k] = x6[k];
         xg[6] = 0.0; xg[7] = 0.0;
       }
+      SVOH_SERIAL_STAMP(1);
       if (s.stop) {
         // rollback (mini_least_squares_solver.hpp:73-82); stop_ is only cleared by reset()
         s.T = s.Told; s.alpha = s.alpha_old; s.beta = s.beta_old;
@@ -871,9 +881,11 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
         for (int j = 0; j < 8; ++j) { const double v = fabs(xg[j]); if (v > x_norm) x_norm = v; }
         if (x_norm < opt.eps) s.level_done = 1;
       }
+      SVOH_SERIAL_STAMP(2);
       for (int c = 0; c < n_cams; ++c)
         s.Tcr[c] = mul(mul(s.cam_cur_T_cam_imu[c], s.T), s.cam_ref_T_imu_cam[c]);
       s.alpha_f = (float)s.alpha; s.beta_f = (float)s.beta;
+      SVOH_SERIAL_STAMP(3);
     }
   }
 
@@ -948,6 +960,9 @@ void sparse_align_kernel(const AlignKernelArgs a)
       s.cam_cur_T_cam_imu[c] = load_rigid(cams[c].cur_T_cam_imu);
       s.cam_ref_T_imu_cam[c] = load_rigid(cams[c].ref_T_imu_cam);
     }
+#ifdef SVOH_PHASE_STAMPS
+    for (int k = 0; k < 4; ++k) s.dbg[k] = 0;
+#endif
     for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { s.lvl_iters[l] = 0; s.lvl_n_meas[l] = 0; s.lvl_chi2[l] = 0.0; }
   }
   __syncthreads();
@@ -1593,7 +1608,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   }
   args.queue = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(ctx->d_desc.ptr) + ctl_off);   // zero: uploaded with the descriptors
 #ifdef SVOH_PHASE_STAMPS
-  SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(sizeof(long long) * 8 * (size_t)n_problems));
+  SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(sizeof(long long) * 12 * (size_t)n_problems));
   args.stamps = static_cast<long long*>(ctx->d_scratch0.ptr);
 #endif
 
@@ -1652,11 +1667,13 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   }
 #ifdef SVOH_PHASE_STAMPS
   {
-    std::vector<long long> h((size_t)n_problems * 8);
+    std::vector<long long> h((size_t)n_problems * 12);
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(h.data(), args.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    double sum[8] = {0};
-    for (int p = 0; p < n_problems; ++p) for (int k = 0; k < 8; ++k) sum[k] += (double)h[(size_t)p * 8 + k];
+    double sum[12] = {0};
+    for (int p = 0; p < n_problems; ++p) for (int k = 0; k < 12; ++k) sum[k] += (double)h[(size_t)p * 12 + k];
+    fprintf(stderr, "[stamps] one-lane step: set-up %.0f solve %.0f update %.0f camera poses %.0f\n", sum[8] / n_problems, sum[9] / n_problems,
+            sum[10] / n_problems, sum[11] / n_problems);
     fprintf(stderr, "[stamps] n=%d nt=%d avg cycles/block: base %.0f stage %.0f patch %.0f reduce %.0f serial %.0f total %.0f; "
             "gradient-only passes kept %.2f / discarded %.2f per problem\n",
             n_problems, nt, sum[0] / n_problems, sum[1] / n_problems, sum[2] / n_problems, sum[3] / n_problems,
