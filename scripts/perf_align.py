@@ -18,6 +18,7 @@ def run(tag, reps=5, **kw):
     for k in ("SVOH_ALIGN_THREADS", "SVOH_ALIGN_LDS"):
         os.environ.pop(k, None)
     os.environ.update(env)
+    ctx.reload_knobs()
     opt = capi.default_align_options(patch_size=P, **kw)
     ts = []
     for i in range(reps + 1):

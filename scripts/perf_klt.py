@@ -25,6 +25,7 @@ def run(tag, **kw):
     print("%-28s kernel %.3f ms  wall %.3f ms  ok %.3f counters %s" % (tag, np.mean([t[0] for t in ts]), np.mean([t[1] for t in ts]), status.mean(), bench.misc_counters(ctx)[:4]), flush=True)
 for blk in (64, 128, 256):
     os.environ["SVOH_KLT_BLOCK"] = str(blk)
+    ctx.reload_knobs()
     run("block %d" % blk)
 run("max_iter 1", max_iter=1)
 run("levels 4..4", min_level=4)

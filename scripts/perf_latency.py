@@ -11,6 +11,7 @@ for n in (1, 2, 8, 16):
     for nt in (256, 512, 1024):
         for levels in ((4, 0), (4, 2)):
             os.environ["SVOH_ALIGN_THREADS"] = str(nt)
+            ctx.reload_knobs()
             opt = capi.default_align_options(max_level=levels[0], min_level=levels[1])
             pbs = (capi.svoh_align_problem * n)(*[problems[i] for i in range(n)])
             ks, ws = [], []

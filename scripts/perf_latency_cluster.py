@@ -14,6 +14,7 @@ for N in (180, 700, 1000, 2000, 4000, 8000, 20000):
         for g in ("0", "2", "4", "8", "16", "32", None):
             if g is None: os.environ.pop("SVOH_ALIGN_CLUSTER", None)
             else: os.environ["SVOH_ALIGN_CLUSTER"] = g
+            ctx.reload_knobs()
             ts = []; t0 = None
             for i in range(8):
                 a = time.perf_counter(); res = ctx.sparse_align(opt, problems); b = time.perf_counter()

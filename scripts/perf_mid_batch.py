@@ -8,11 +8,13 @@ ctx = fe.Context(0)
 ms = ctypes.c_float()
 opt = capi.default_align_options(min_level=0)
 os.environ["SVOH_ALIGN_CLUSTER"] = "0"
+ctx.reload_knobs()
 for B in (24, 48, 96, 128, 192, 256, 384, 512):
     problems, scenes, imgs, keep = bench.build_problems(ctx, torch.device("cuda", 0), 0, B, 2000, 4, 4)
     row = []
     for nt in ("512", "256"):
         os.environ["SVOH_ALIGN_THREADS"] = nt
+        ctx.reload_knobs()
         ts = []
         for i in range(6):
             ctx.sparse_align(opt, problems)

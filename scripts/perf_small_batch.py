@@ -13,6 +13,7 @@ for B, N in ((2, 2000), (8, 2000), (16, 2000), (32, 2000), (64, 2000), (128, 200
     for g in ("0", None):
         if g is None: os.environ.pop("SVOH_ALIGN_CLUSTER", None)
         else: os.environ["SVOH_ALIGN_CLUSTER"] = g
+        ctx.reload_knobs()
         ts = []
         for i in range(8):
             res = ctx.sparse_align(opt, problems)

@@ -200,9 +200,30 @@ static uint64_t register_frame(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab,
 
 using namespace svoh;
 
+void load_knobs_from_env(SvohKnobs& k)
+{
+  auto get = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : kKnobUnset; };
+  k.klt_block = get("SVOH_KLT_BLOCK");
+  k.matcher_g8 = get("SVOH_MATCHER_G8");
+  k.seed_binning = get("SVOH_SEED_BINNING");
+  k.pose_threads = get("SVOH_POSE_THREADS");
+  k.align_cluster = get("SVOH_ALIGN_CLUSTER");
+  k.align_cluster_test_absent = get("SVOH_ALIGN_CLUSTER_TEST_ABSENT");
+  k.align_threads = get("SVOH_ALIGN_THREADS");
+  k.align_lds = get("SVOH_ALIGN_LDS");
+  k.align_wg_per_cu = get("SVOH_ALIGN_WG_PER_CU");
+}
+
 extern "C" {
 
 int svoh_abi_version(void) { return SVOH_ABI_VERSION; }
+
+int svoh_reload_knobs(svoh_ctx* ctx)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  load_knobs_from_env(ctx->knobs);
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_create(int device, svoh_ctx** out_ctx)
 try {
@@ -219,6 +240,7 @@ try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_OUT_OF_MEMORY, "out of host memory");
   ctx->device = device;
   ctx->err = "no error";
+  load_knobs_from_env(ctx->knobs);
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   for (int k = 0; k < svoh_ctx::kAlignEventRing; ++k) {

@@ -335,8 +335,7 @@ static int launch_klt(svoh_ctx* ctx, const svoh_klt_options* options, const std:
   }
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   {
-    const char* e = getenv("SVOH_KLT_BLOCK");
-    int block = e ? atoi(e) : 256;
+    int block = SvohKnobs::or_default(ctx->knobs.klt_block, 256);
     if (block != 64 && block != 128 && block != 256) block = 256;
     const int tpb = block / 64 * 4;   // four tracks per wave
     hipLaunchKernelGGL(klt_track_kernel, dim3((n_tracks + tpb - 1) / tpb), dim3(block), 0, ctx->stream, args);

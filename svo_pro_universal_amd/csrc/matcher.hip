@@ -1924,12 +1924,6 @@ __global__ __launch_bounds__(64) void epipolar_match_kernel(const MatcherArgs a)
 // host side
 // ---------------------------------------------------------------------------
 
-static int getenv_int_m(const char* name, int dflt)
-{
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 static int fill_view(svoh_ctx* ctx, const svoh_frame_view& v, DevFrameView* out, const char* what)
 {
   const Frame* f = find_frame(ctx, v.frame);
@@ -2108,10 +2102,10 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     }
   }
   // small batches: eight lanes per unit (a launch is as slow as its slowest lane, and eight lanes get a unit done
-  // ~3x sooner); large batches: one lane per unit (fewer instructions per unit).  SVOH_MATCHER_G8=0/1 forces it.
+  // ~3x sooner); large batches: one lane per unit (fewer instructions per unit).  The knob SVOH_MATCHER_G8 (read when the context is made) forces one.
   // geometry: 1 = eight lanes per unit, 0 = one lane per unit, 2 = packed (seed update only; large batches)
   int g8 = n <= kG8MaxUnits ? 1 : (seeds ? 2 : 0);
-  if (const char* e = getenv("SVOH_MATCHER_G8")) g8 = atoi(e);
+  g8 = SvohKnobs::or_default(ctx->knobs.matcher_g8, g8);
   if (g8 < 0 || g8 > 2 || (g8 == 2 && !seeds)) g8 = 0;
   if (defer && g8 != 2) {
     // Deferred section: the launch itself waits for svoh_matcher_collect, where a direct batch and a seed batch of
@@ -2156,7 +2150,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
       unsigned* hist_ptr = nullptr;
       unsigned hist_keys = 0;
       const dim3 gb((unsigned)((n + 255) / 256));
-      if (n_keys <= kBinMaxKeys && getenv_int_m("SVOH_SEED_BINNING", 1) != 0) {
+      if (n_keys <= kBinMaxKeys && SvohKnobs::or_default(ctx->knobs.seed_binning, 1) != 0) {
         // [hist | rank | pos_of | records in (128 B each) | records out (64 B each)]
         const size_t o_rank = (n_keys * sizeof(unsigned) + 255) & ~(size_t)255;
         const size_t o_pos = o_rank + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255);
@@ -2377,7 +2371,7 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
     a.A_cur_ref = reinterpret_cast<double*>(d + o_A);
   }
   int g8 = n <= kG8MaxUnits ? 1 : 0;
-  if (const char* e = getenv("SVOH_MATCHER_G8")) g8 = atoi(e) == 1;
+  if (ctx->knobs.matcher_g8 != kKnobUnset) g8 = ctx->knobs.matcher_g8 == 1;
   const int units_per_block = g8 ? 8 : 64;
   const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
   {

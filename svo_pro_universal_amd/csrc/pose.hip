@@ -625,7 +625,7 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   // geometry: see pose_optimize_kernel.  SVOH_POSE_THREADS=64/256 forces one (tests run both).
   int nt = n_problems > ctx->num_cus ? 64 : kPoseThreads;
-  if (const char* e = getenv("SVOH_POSE_THREADS")) { const int v = atoi(e); if (v == 64 || v == kPoseThreads) nt = v; }
+  { const int v = ctx->knobs.pose_threads; if (v == 64 || v == kPoseThreads) nt = v; }
   if (nt == 64) hipLaunchKernelGGL(pose_optimize_kernel<64>, dim3((unsigned)n_problems), dim3(64), 0, ctx->stream, a);
   else hipLaunchKernelGGL(pose_optimize_kernel<kPoseThreads>, dim3((unsigned)n_problems), dim3(kPoseThreads), 0, ctx->stream, a);
   SVOH_HIP_TRY(ctx, hipGetLastError());

@@ -1358,12 +1358,6 @@ constexpr int kClusterFeaturesPerWorkgroup = 192;
 constexpr int kClusterMaxWorkgroups = 32;
 constexpr int kClusterMaxProblems = 64;   // arrival counters: one 32-bit word per problem in a 256-byte block
 
-static int getenv_int(const char* name, int dflt)
-{
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 static int validate_options(svoh_ctx* ctx, const svoh_align_options* o)
 {
   SVOH_REQUIRE(ctx, o != nullptr, "options is NULL");
@@ -1415,7 +1409,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
       nf_min = nf < nf_min ? nf : nf_min;
       nf_max = nf > nf_max ? nf : nf_max;
     }
-    int g = getenv_int("SVOH_ALIGN_CLUSTER", -1);
+    int g = SvohKnobs::or_default(ctx->knobs.align_cluster, -1);
     // measured (scripts/perf_small_batch.py): up to 16 problems always gain; 32..64 only when each is large
     const bool worth = nf_min >= kClusterMinFeatures && (n_problems <= 16 || nf_min >= 3000);
     if (g < 0) g = worth ? (int)((nf_max + kClusterFeaturesPerWorkgroup - 1) / kClusterFeaturesPerWorkgroup) : 0;
@@ -1579,7 +1573,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.cluster = 0;
   args.xchg = nullptr;
   args.bar = nullptr;
-  args.cluster_test_absent = getenv_int("SVOH_ALIGN_CLUSTER_TEST_ABSENT", 0);
+  args.cluster_test_absent = SvohKnobs::or_default(ctx->knobs.align_cluster_test_absent, 0);
   if (cluster) {
     const size_t xchg_bytes = 2 * (size_t)S * kXchgStride * sizeof(double) * n_problems;
     SVOH_HIP_TRY(ctx, ctx->d_xchg.reserve(xchg_bytes));
@@ -1621,11 +1615,11 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // LDS-DMA workspace path beat one 512-thread workgroup: 384 problems 1.06 -> 0.82 ms)
   int nt = (n_desc >= ctx->num_cus) ? 256 : 512;
   if (max_feat_per_problem <= 256) nt = 256;
-  nt = getenv_int("SVOH_ALIGN_THREADS", nt);
+  nt = SvohKnobs::or_default(ctx->knobs.align_threads, nt);
   if (cluster) nt = 256;   // one workgroup per CU at most: all of them are resident together
   if (nt != 256 && nt != 512 && nt != 1024) nt = 256;
   size_t lds = (nt == 256) ? 38400 : (nt == 512 ? 78 * 1024 : 153856);
-  lds = (size_t)getenv_int("SVOH_ALIGN_LDS", (int)lds);
+  lds = (size_t)SvohKnobs::or_default(ctx->knobs.align_lds, (int)lds);
   // 160 KB per workgroup minus the kernel's static LDS (reduction scratch; in the 256-thread geometry also the
   // 36 KB LDS-DMA staging area of the workspace rows)
   const size_t lds_cap = (nt == 256 && SVOH_ALIGN_STAGED) ? 163840 - 40960 : 153856;
@@ -1634,7 +1628,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
 
   const bool illum = opt->estimate_illumination_gain || opt->estimate_illumination_offset;
   // resident workgroups per CU: 256-thread groups at 256 VGPRs -> 2; larger groups -> 1
-  int grid = ctx->num_cus * getenv_int("SVOH_ALIGN_WG_PER_CU", nt == 256 ? 2 : 1);
+  int grid = ctx->num_cus * SvohKnobs::or_default(ctx->knobs.align_wg_per_cu, nt == 256 ? 2 : 1);
   if (grid > n_desc || grid <= 0) grid = n_desc;
   if (cluster) grid = n_desc;
   hipError_t e;

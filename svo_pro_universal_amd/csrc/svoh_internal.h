@@ -73,7 +73,25 @@ struct PinnedBuffer {
 
 }  // namespace svoh
 
+// Tuning and diagnostic knobs: read from the environment (SVOH_*) ONCE, when the context is made, and again only on
+// svoh_reload_knobs -- no launch path calls getenv.  kKnobUnset = "let the launch code decide".
+constexpr int kKnobUnset = -2147483647 - 1;
+struct SvohKnobs {
+  int klt_block = kKnobUnset;                 // SVOH_KLT_BLOCK: 64 / 128 / 256 threads per KLT workgroup
+  int matcher_g8 = kKnobUnset;                // SVOH_MATCHER_G8: 0 one lane per unit, 1 eight lanes, 2 packed (seed update)
+  int seed_binning = kKnobUnset;              // SVOH_SEED_BINNING: 0 = no spatial binning of large seed batches
+  int pose_threads = kKnobUnset;              // SVOH_POSE_THREADS: 64 / 256
+  int align_cluster = kKnobUnset;             // SVOH_ALIGN_CLUSTER: workgroups per problem (0 = never)
+  int align_cluster_test_absent = kKnobUnset; // SVOH_ALIGN_CLUSTER_TEST_ABSENT: test hook, a partner that never arrives
+  int align_threads = kKnobUnset;             // SVOH_ALIGN_THREADS: 256 / 512 / 1024
+  int align_lds = kKnobUnset;                 // SVOH_ALIGN_LDS: bytes of LDS for image levels
+  int align_wg_per_cu = kKnobUnset;           // SVOH_ALIGN_WG_PER_CU
+  static int or_default(int v, int dflt) { return v == kKnobUnset ? dflt : v; }
+};
+void load_knobs_from_env(SvohKnobs& k);
+
 struct svoh_ctx {
+  SvohKnobs knobs;
   int device = 0;
   hipStream_t stream = nullptr;
   int num_cus = 0;

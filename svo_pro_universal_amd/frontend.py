@@ -77,6 +77,10 @@ class Context(object):
     def stream(self):
         return self.lib.svoh_stream(self.h)
 
+    def reload_knobs(self):
+        """The SVOH_* tuning knobs are read from the environment when the context is made; read them again."""
+        self._check(self.lib.svoh_reload_knobs(self.h))
+
     # ---- frames -----------------------------------------------------------
     def upload_pyramid(self, levels):
         n = len(levels)

@@ -25,5 +25,21 @@ def gpu_ctx():
     the HIP extension is missing or no GPU is present."""
     from svo_pro_universal_amd import frontend as fe
     ctx = fe.Context(0)
+    _live_ctx.append(ctx)
     yield ctx
+    _live_ctx.clear()
     ctx.close()
+
+
+_live_ctx = []
+
+
+@pytest.fixture(autouse=True)
+def _knobs_follow_the_environment():
+    """The library reads its SVOH_* tuning knobs when a context is made, never in a launch path
+    (svoh_reload_knobs, include/svo_hip.h).  Tests that force a kernel geometry change the environment and call
+    ctx.reload_knobs(); after a test -- and after monkeypatch has put the environment back -- the session's context
+    reads them again, so no test inherits another's geometry."""
+    yield
+    for ctx in _live_ctx:
+        ctx.reload_knobs()

@@ -192,6 +192,7 @@ def test_seed_update_wild_units_in_every_geometry(gpu_ctx, geometry, monkeypatch
     """The same wild seeds through the one-lane, the eight-lane and the packed geometry (whose binning pass turns the
     reference pixel into a tile index: NaN / inf / 1e30 must land in some tile, not index out of the histogram)."""
     monkeypatch.setenv("SVOH_MATCHER_G8", geometry)
+    gpu_ctx.reload_knobs()
     sc = synth.make_align_scene(306, n_features=8, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))
     fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
     sd = synth.make_seed_set(sc, 700)

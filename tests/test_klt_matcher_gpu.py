@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["eight_lanes_per_unit", "one_lane_per_unit", "packed"], autouse=True)
-def matcher_geometry(request):
+def matcher_geometry(request, gpu_ctx):
     """The matcher kernels exist in three geometries with bit-identical results: eight lanes per unit (what a small
     batch gets), one lane per unit, and -- for the seed update of large batches -- the packed geometry (one lane per
     seed for geometry / warp / scan, the refinements as jobs of a workgroup-wide queue; the direct matcher and the
@@ -25,11 +25,14 @@ def matcher_geometry(request):
     import os
     old = os.environ.get("SVOH_MATCHER_G8")
     os.environ["SVOH_MATCHER_G8"] = {"eight_lanes_per_unit": "1", "one_lane_per_unit": "0", "packed": "2"}[request.param]
+    gpu_ctx.reload_knobs()
     yield request.param
     if old is None:
         os.environ.pop("SVOH_MATCHER_G8", None)
+        gpu_ctx.reload_knobs()
     else:
         os.environ["SVOH_MATCHER_G8"] = old
+        gpu_ctx.reload_knobs()
 
 
 def scene_and_frames(gpu_ctx, orc, seed, cam=None, **kw):
@@ -493,15 +496,19 @@ def test_benchmark_size_batch_is_identical_in_every_geometry(gpu_ctx):
             for k, v in (("SVOH_MATCHER_G8", g8), ("SVOH_SEED_BINNING", binning)):
                 if v is None:
                     os.environ.pop(k, None)
+                    gpu_ctx.reload_knobs()
                 else:
                     os.environ[k] = v
+                    gpu_ctx.reload_knobs()
             out[name] = run()
     finally:
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
+                gpu_ctx.reload_knobs()
             else:
                 os.environ[k] = v
+                gpu_ctx.reload_knobs()
     ref = out["one_lane"]
     assert ref[0] > 0.5 * B * NS
     for name, o in out.items():

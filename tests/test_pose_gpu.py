@@ -13,17 +13,20 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["four_waves_per_bundle", "one_wave_per_bundle"], autouse=True)
-def pose_geometry(request):
+def pose_geometry(request, gpu_ctx):
     """The pose kernel has two geometries (pose.hip, pose_optimize_kernel<256> for batches up to one bundle per compute
     unit, <64> beyond): every test of this file runs through both, against the same bars."""
     import os
     old = os.environ.get("SVOH_POSE_THREADS")
     os.environ["SVOH_POSE_THREADS"] = "256" if request.param == "four_waves_per_bundle" else "64"
+    gpu_ctx.reload_knobs()
     yield request.param
     if old is None:
         os.environ.pop("SVOH_POSE_THREADS", None)
+        gpu_ctx.reload_knobs()
     else:
         os.environ["SVOH_POSE_THREADS"] = old
+        gpu_ctx.reload_knobs()
 
 
 def check(rg, ro, keep_g, keep_o, cams):

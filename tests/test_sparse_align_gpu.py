@@ -169,16 +169,19 @@ def test_ragged_batch_equals_singles(gpu_ctx, oracle_lib):
 def test_all_workgroup_geometries(gpu_ctx, oracle_lib, nt, monkeypatch):
     orc = oracle_lib
     monkeypatch.setenv("SVOH_ALIGN_THREADS", nt)
+    gpu_ctx.reload_knobs()
     sc = helpers.small_scene(37, n=700, border_features=50)
     opb, gpb, keep = both(gpu_ctx, orc, [sc])
     for lds in ("0", "38400", "153856"):  # global gathers only / levels>=2 in LDS / levels>=1 in LDS
         monkeypatch.setenv("SVOH_ALIGN_LDS", lds)
+        gpu_ctx.reload_knobs()
         opt = capi.default_align_options(min_level=0)
         check_evaluate(gpu_ctx, orc, opt, opb, gpb, (4, 1, 0))
         check_run(gpu_ctx, orc, opt, opb, gpb)
     # 8x8 patches, illumination terms, stereo and a radtan camera through the same geometry (the 256-thread one
     # brings the workspace rows in by LDS-DMA and reads 11- / 9-pixel footprint rows as 16-byte loads)
     monkeypatch.setenv("SVOH_ALIGN_LDS", "38400")
+    gpu_ctx.reload_knobs()
     a = helpers.small_scene(41, n=400, P=8, border_features=30)
     b = synth.make_align_scene(42, n_features=333, patch_size=8, cam=synth.Camera.euroc_like(), border_features=10, gain=1.05, offset=4.0)
     opb2, gpb2, keep2 = both(gpu_ctx, orc, [a, b])
@@ -312,11 +315,14 @@ def test_cluster_mode_single_problem(gpu_ctx, oracle_lib, n, cluster):
     old = os.environ.get("SVOH_ALIGN_CLUSTER")
     try:
         os.environ["SVOH_ALIGN_CLUSTER"] = "0"
+        gpu_ctx.reload_knobs()
         single = gpu_ctx.sparse_align(opt, gpb)[0]
         if cluster is None:
             del os.environ["SVOH_ALIGN_CLUSTER"]
+            gpu_ctx.reload_knobs()
         else:
             os.environ["SVOH_ALIGN_CLUSTER"] = str(cluster)
+            gpu_ctx.reload_knobs()
         rg, ro = check_run(gpu_ctx, orc, opt, opb, gpb)
         assert rg.status == 0 and list(rg.iters) == list(single.iters) and rg.n_fts_to_track == single.n_fts_to_track
         assert rg.n_patch_iters == single.n_patch_iters
@@ -331,8 +337,10 @@ def test_cluster_mode_single_problem(gpu_ctx, oracle_lib, n, cluster):
     finally:
         if old is None:
             os.environ.pop("SVOH_ALIGN_CLUSTER", None)
+            gpu_ctx.reload_knobs()
         else:
             os.environ["SVOH_ALIGN_CLUSTER"] = old
+            gpu_ctx.reload_knobs()
 
 
 def test_cluster_mode_small_batch_of_large_problems(gpu_ctx, oracle_lib):
@@ -352,9 +360,11 @@ def test_cluster_mode_small_batch_of_large_problems(gpu_ctx, oracle_lib):
     old = os.environ.get("SVOH_ALIGN_CLUSTER")
     try:
         os.environ["SVOH_ALIGN_CLUSTER"] = "0"
+        gpu_ctx.reload_knobs()
         single = gpu_ctx.sparse_align(opt, gpb)
         single = [(list(r.iters), r.n_fts_to_track, fe.se3_to_numpy(r.T_icur_iref)) for r in single]
         os.environ.pop("SVOH_ALIGN_CLUSTER")
+        gpu_ctx.reload_knobs()
         clustered = gpu_ctx.sparse_align(opt, gpb)
         for r, (it, nf, T), opb in zip(clustered, single, oracle_pbs):
             assert r.status == 0 and list(r.iters) == it and r.n_fts_to_track == nf
@@ -365,8 +375,10 @@ def test_cluster_mode_small_batch_of_large_problems(gpu_ctx, oracle_lib):
     finally:
         if old is None:
             os.environ.pop("SVOH_ALIGN_CLUSTER", None)
+            gpu_ctx.reload_knobs()
         else:
             os.environ["SVOH_ALIGN_CLUSTER"] = old
+            gpu_ctx.reload_knobs()
 
 
 @pytest.mark.parametrize("seed", [48, 52, 53, 56])
@@ -386,12 +398,15 @@ def test_visibility_changes_inside_a_level(gpu_ctx, oracle_lib, seed):
     try:
         for g in ("0", "3"):
             os.environ["SVOH_ALIGN_CLUSTER"] = g
+            gpu_ctx.reload_knobs()
             check_run(gpu_ctx, orc, opt, opb, gpb)
     finally:
         if old is None:
             os.environ.pop("SVOH_ALIGN_CLUSTER", None)
+            gpu_ctx.reload_knobs()
         else:
             os.environ["SVOH_ALIGN_CLUSTER"] = old
+            gpu_ctx.reload_knobs()
 
 
 def test_queued_launches_and_kernel_time_history(gpu_ctx):
@@ -462,9 +477,12 @@ def test_cluster_that_never_completes_falls_back(gpu_ctx):
     old = {k: os.environ.get(k) for k in ("SVOH_ALIGN_CLUSTER", "SVOH_ALIGN_CLUSTER_TEST_ABSENT")}
     try:
         os.environ["SVOH_ALIGN_CLUSTER"] = "0"
+        gpu_ctx.reload_knobs()
         want = gpu_ctx.sparse_align(opt, gpb)[0]
         os.environ["SVOH_ALIGN_CLUSTER"] = "4"
+        gpu_ctx.reload_knobs()
         os.environ["SVOH_ALIGN_CLUSTER_TEST_ABSENT"] = "1"
+        gpu_ctx.reload_knobs()
         gpu_ctx.sparse_align_enqueue(opt, gpb)
         t0 = time.perf_counter()
         gave_up = gpu_ctx.sparse_align_fetch(1)[0]
@@ -476,5 +494,7 @@ def test_cluster_that_never_completes_falls_back(gpu_ctx):
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
+                gpu_ctx.reload_knobs()
             else:
                 os.environ[k] = v
+                gpu_ctx.reload_knobs()
