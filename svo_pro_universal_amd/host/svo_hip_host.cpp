@@ -873,13 +873,14 @@ namespace {
 struct ReprojTiming {   // SVOH_REPROJ_TIMING=1: mean host / device split of reprojectFrames, printed at exit
   bool on = getenv("SVOH_REPROJ_TIMING") != nullptr;
   double t[6] = { 0, 0, 0, 0, 0, 0 };
+  double kernel_ms = 0;
   long n = 0, n_direct = 0, n_seeds = 0, n_reached3 = 0, n_spec3 = 0;
   static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   ~ReprojTiming()
   {
     if (on && n)
-      fprintf(stderr, "[reproject] per call: candidates %.3f ms, sort %.3f, plan %.3f, device round trip(s) %.3f, replay %.3f, other %.3f (%ld calls; per call %.0f direct + %.0f seed units speculated; unconverged pass reached %ld x, speculated %ld x)\n",
-              t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n, n, (double)n_direct / n, (double)n_seeds / n, n_reached3, n_spec3);
+      fprintf(stderr, "[reproject] per call: candidates %.3f ms, sort %.3f, plan %.3f, device round trip(s) %.3f (kernel %.3f), replay %.3f, other %.3f (%ld calls; per call %.0f direct + %.0f seed units speculated; unconverged pass reached %ld x, speculated %ld x)\n",
+              t[0] / n, t[1] / n, t[2] / n, t[3] / n, kernel_ms / n, t[4] / n, t[5] / n, n, (double)n_direct / n, (double)n_seeds / n, n_reached3, n_spec3);
   }
 } g_reproj_timing;
 }  // namespace
@@ -1315,6 +1316,7 @@ void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_
   const double tp1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   sm.run(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
   if (g_reproj_timing.on) { g_reproj_timing.n_direct += (long)sm.direct.size(); g_reproj_timing.n_seeds += (long)sm.seeds.size(); g_reproj_timing.n_spec3 += n_speculated == 3; }
+  if (g_reproj_timing.on) { float kms = 0.f; if (svoh_last_kernel_ms(ctx, &kms) == SVOH_OK) g_reproj_timing.kernel_ms += kms; }
   if (g_reproj_timing.on) { const double tp2 = ReprojTiming::now(); g_reproj_timing.t[2] += tp1 - tp0; g_reproj_timing.t[3] += tp2 - tp1; g_reproj_timing.t[5] -= tp2 - tp0; }
   for (int k = 0; k < 3; ++k) {
     size_t max_n = 0;
