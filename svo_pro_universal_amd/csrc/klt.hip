@@ -60,7 +60,9 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
                                          int px_ref0_y, int n_iter, float min_update_squared, double& pcx, double& pcy,
                                          bool& converged, int lane, int& n_iters, int& n_tmpl, bool run)
 {
-  constexpr int PPL = P * P / LANES;  // pixels per lane: 4 (16x16 on a wave, 8x8 on a row) or 1 (8x8 on a wave)
+  constexpr int PPL = P * P / LANES;  // pixels per lane: 16 (16x16 patch on a row of lanes: one patch row each) or 4 (8x8)
+  static_assert(PPL == 4 || PPL == 16, "a lane holds 4 or 16 consecutive pixels of one patch row");
+  typedef short short2v __attribute__((ext_vector_type(2)));
   const int halfpatch_size = P / 2;
   const int scale = 1 << level;
   const int width = img_ref.w, height = img_ref.h;
@@ -73,24 +75,50 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
   // this lane's pixels: row y, columns x0 .. x0+PPL-1
   const int y = (lane * PPL) / P;
   const int x0 = (lane * PPL) % P;
-  int tmpl[PPL], gdx[PPL], gdy[PPL];
+  // The template and its raw differences stay in registers for the level, packed: four u8 template pixels per dword,
+  // two int16 differences per dword (|d| <= 255) -- 20 registers instead of 48 for a 16-pixel row, which is what lets
+  // five waves per SIMD share the latency of the row loads.  Every sum below is an exact integer (v_dot2_i32_i16).
+  unsigned tq[PPL / 4];
+  short2v gx2[PPL / 2], gy2[PPL / 2];
   int h00 = 0, h01 = 0, h11 = 0;
   if (active) {
-    const uint8_t* it = img_ref.data + (ptrdiff_t)(pry + y) * step + prx + x0;
+    // rows y-1, y, y+1 from column x0-1 on: PPL+2 pixels each, as unaligned 8-byte loads (the spare bytes stay inside
+    // the row, the next row or the slab's tail padding)
+    constexpr int NW = PPL == 16 ? 6 : 2;
+    unsigned U[NW], M[NW], D[NW];
+    const uint8_t* it = img_ref.data + (ptrdiff_t)(pry + y) * step + prx + x0 - 1;
+    __builtin_memcpy(U, it - step, NW * 4);
+    __builtin_memcpy(M, it, NW * 4);
+    __builtin_memcpy(D, it + step, NW * 4);
+    auto byte_of = [](const unsigned (&w)[NW], int j) { return (int)((w[j >> 2] >> (8 * (j & 3))) & 255u); };
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) {
-      tmpl[k] = it[k];
-      gdx[k] = (int)it[k + 1] - (int)it[k - 1];
-      gdy[k] = (int)it[k + step] - (int)it[k - step];
-      h00 += gdx[k] * gdx[k];
-      h01 += gdx[k] * gdy[k];
-      h11 += gdy[k] * gdy[k];
+    for (int i = 0; i < PPL / 4; ++i) tq[i] = __builtin_amdgcn_alignbyte(M[i + 1], M[i], 1);   // pixels 4i .. 4i+3 = bytes 4i+1 .. 4i+4
+#pragma unroll
+    for (int k = 0; k < PPL; k += 2) {
+      short2v gx, gy;
+      gx.x = (short)(byte_of(M, k + 2) - byte_of(M, k));      gx.y = (short)(byte_of(M, k + 3) - byte_of(M, k + 1));
+      gy.x = (short)(byte_of(D, k + 1) - byte_of(U, k + 1));  gy.y = (short)(byte_of(D, k + 2) - byte_of(U, k + 2));
+      gx2[k / 2] = gx; gy2[k / 2] = gy;
+      h00 = __builtin_amdgcn_sdot2(gx, gx, h00, false);
+      h01 = __builtin_amdgcn_sdot2(gx, gy, h01, false);
+      h11 = __builtin_amdgcn_sdot2(gy, gy, h11, false);
     }
     ++n_tmpl;
   } else {
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) { tmpl[k] = 0; gdx[k] = 0; gdy[k] = 0; }
+    for (int i = 0; i < PPL / 4; ++i) tq[i] = 0u;
+#pragma unroll
+    for (int k = 0; k < PPL / 2; ++k) { gx2[k] = short2v{ 0, 0 }; gy2[k] = short2v{ 0, 0 }; }
   }
+  // residuals of two neighbouring pixels at once: (cur0, cur1) - (tmpl0, tmpl1) as a packed int16 subtraction, then one
+  // v_dot2_i32_i16 per Jacobian row
+  auto accumulate_pair = [&](int k, int cur0, int cur1, int& j0, int& j1) {
+    const unsigned c2 = (unsigned)cur0 | ((unsigned)cur1 << 16);
+    const unsigned t2 = __builtin_amdgcn_perm(0u, tq[k >> 2], (k & 2) ? 0x0c030c02u : 0x0c010c00u);
+    const short2v r2 = __builtin_bit_cast(short2v, c2) - __builtin_bit_cast(short2v, t2);
+    j0 = __builtin_amdgcn_sdot2(r2, gx2[k >> 1], j0, false);
+    j1 = __builtin_amdgcn_sdot2(r2, gy2[k >> 1], j1, false);
+  };
   int rc = 0;
   float u = 0.f, v = 0.f, Hi00 = 0.f, Hi01 = 0.f, Hi10 = 0.f, Hi11 = 0.f;
   bool go_to_next_level = false;
@@ -142,16 +170,13 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
             const unsigned T3 = __builtin_amdgcn_alignbyte(T[dq + 1], T[dq], 3), B3 = __builtin_amdgcn_alignbyte(B[dq + 1], B[dq], 3);
             const unsigned q[4] = { __builtin_amdgcn_perm(B[dq], T[dq], 0x05040100u), __builtin_amdgcn_perm(B[dq], T[dq], 0x06050201u),
                                     __builtin_amdgcn_perm(B[dq], T[dq], 0x07060302u), __builtin_amdgcn_perm(B3, T3, 0x05040100u) };
+            int cur[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int k = 4 * dq + r;
-              const int cur = (int)(unsigned short)(__builtin_amdgcn_udot4(q[r], W, 64u, false) >> 7);
-              const int res = cur - tmpl[k];
-              j0 += res * gdx[k];
-              j1 += res * gdy[k];
-            }
+            for (int r = 0; r < 4; ++r) cur[r] = (int)(unsigned short)(__builtin_amdgcn_udot4(q[r], W, 64u, false) >> 7);
+            accumulate_pair(4 * dq, cur[0], cur[1], j0, j1);
+            accumulate_pair(4 * dq + 2, cur[2], cur[3], j0, j1);
           }
-        } else if constexpr (PPL == 4) {
+        } else {
           // the lane's 2 x 5 pixels as two unaligned 8-byte loads (the spare bytes stay inside the row, the next row or
           // the slab's tail padding); per pixel the four taps are gathered into one dword (v_perm_b32) and the 7-bit
           // fixed-point bilinear sum is ONE v_dot4_u32_u8 against the packed weights (all <= 128): the same integers
@@ -163,24 +188,11 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
           const unsigned q0 = __builtin_amdgcn_perm(B.x, T.x, 0x05040100u), q1 = __builtin_amdgcn_perm(B.x, T.x, 0x06050201u);
           const unsigned q2 = __builtin_amdgcn_perm(B.x, T.x, 0x07060302u), q3 = __builtin_amdgcn_perm(B3, T3, 0x05040100u);
           const unsigned q[4] = { q0, q1, q2, q3 };
+          int cur[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int cur = (int)(unsigned short)(__builtin_amdgcn_udot4(q[k], W, 64u, false) >> 7);
-            const int res = cur - tmpl[k];
-            j0 += res * gdx[k];
-            j1 += res * gdy[k];
-          }
-        } else {
-          int top[PPL + 1], bot[PPL + 1];
-#pragma unroll
-          for (int k = 0; k < PPL + 1; ++k) { top[k] = it[k]; bot[k] = it[k + cur_step]; }
-#pragma unroll
-          for (int k = 0; k < PPL; ++k) {
-            const int cur = (int)(unsigned short)((wTL * top[k] + wTR * top[k + 1] + wBL * bot[k] + wBR * bot[k + 1] + 64) >> 7);
-            const int res = cur - tmpl[k];
-            j0 += res * gdx[k];
-            j1 += res * gdy[k];
-          }
+          for (int k = 0; k < 4; ++k) cur[k] = (int)(unsigned short)(__builtin_amdgcn_udot4(q[k], W, 64u, false) >> 7);
+          accumulate_pair(0, cur[0], cur[1], j0, j1);
+          accumulate_pair(2, cur[2], cur[3], j0, j1);
         }
         const float Jres0 = -(float)group_sum_i32<LANES>(j0);
         const float Jres1 = -(float)group_sum_i32<LANES>(j1);
