@@ -150,6 +150,12 @@ int svoh_context_stats(svoh_ctx* ctx, svoh_context_stats_t* out);
  * changes those variables afterwards (the test-suite does, to run every kernel geometry) asks for them to be read again: */
 int svoh_reload_knobs(svoh_ctx* ctx);
 
+/* Kernel timing.  Off by default: bracketing a launch with an event pair costs ~9 us of every call on an MI355X
+ * (tools/svoh_call_overhead), a quarter of a small call.  When on (this call, or SVOH_KERNEL_TIMING=1 in the
+ * environment of svoh_create), svoh_sparse_align_last_kernel_ms / _kernel_ms_history / svoh_last_kernel_ms report the
+ * device time of the launches made since; when off they fail with SVOH_ERR_INVALID_ARGUMENT. */
+int svoh_set_kernel_timing(svoh_ctx* ctx, int enabled);
+
 /* ---- sparse image alignment  (a-1 ... a-8) ---------------------------- */
 
 /* SparseImgAlignOptions + the solver options the reference hard-wires

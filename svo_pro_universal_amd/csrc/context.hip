@@ -212,16 +212,26 @@ void load_knobs_from_env(SvohKnobs& k)
   k.align_threads = get("SVOH_ALIGN_THREADS");
   k.align_lds = get("SVOH_ALIGN_LDS");
   k.align_wg_per_cu = get("SVOH_ALIGN_WG_PER_CU");
+  k.kernel_timing = get("SVOH_KERNEL_TIMING");
 }
 
 extern "C" {
 
 int svoh_abi_version(void) { return SVOH_ABI_VERSION; }
 
+int svoh_set_kernel_timing(svoh_ctx* ctx, int enabled)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  ctx->knobs.kernel_timing = enabled ? 1 : 0;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
 int svoh_reload_knobs(svoh_ctx* ctx)
 try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  const int timing = ctx->knobs.kernel_timing;
   load_knobs_from_env(ctx->knobs);
+  if (ctx->knobs.kernel_timing == kKnobUnset) ctx->knobs.kernel_timing = timing;   // set by svoh_set_kernel_timing, not by the environment
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
@@ -298,7 +308,7 @@ void* svoh_stream(svoh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int svoh_last_kernel_counters(svoh_ctx* ctx, uint64_t out[8])
 try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
-  SVOH_REQUIRE(ctx, out != nullptr && ctx->misc_timed && ctx->d_counters.ptr, "no counters yet");
+  SVOH_REQUIRE(ctx, out != nullptr && ctx->misc_launched && ctx->d_counters.ptr, "no counters yet");
   if (ctx->unit_counts_pending) {
     const int rc = reduce_unit_counts_now(ctx, ctx->unit_counts_pending);
     if (rc != SVOH_OK) return rc;
@@ -312,7 +322,7 @@ try {
 int svoh_last_kernel_ms(svoh_ctx* ctx, float* ms)
 try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
-  SVOH_REQUIRE(ctx, ms != nullptr && ctx->misc_timed, "no KLT / matcher / seed kernel has been launched yet");
+  SVOH_REQUIRE(ctx, ms != nullptr && ctx->misc_timed, "the last KLT / matcher / seed / pose launch was not timed (svoh_set_kernel_timing), or there was none");
   SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_misc_stop));
   SVOH_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_misc_start, ctx->ev_misc_stop));
   return SVOH_OK;

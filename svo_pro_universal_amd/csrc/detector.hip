@@ -303,7 +303,7 @@ try {
     const int rc = upload_grid();
     if (rc != SVOH_OK) return rc;
   }
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   for (int l = opt.min_level; l <= opt.max_level; ++l) {
     const DevImage& im = f->lv[l];
     if (im.h < 7 || im.w < 7) continue;
@@ -362,9 +362,9 @@ try {
     n = fill_features(corners, SVOH_FT_EDGELET, mask, mask_pitch, opt.threshold_secondary, max_features, n, opt, n_cols, occ, px, score,
                       level, grad, type);
   }
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->misc_timed = true;
+  ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
   *n_features = n;
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)

@@ -345,7 +345,7 @@ static int launch_klt(svoh_ctx* ctx, const svoh_klt_options* options, const std:
     if (rc == SVOH_OK) rc = reserve_unit_counts(ctx, n, &args.unit_counts);
     if (rc != SVOH_OK) return rc;
   }
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   {
     int block = SvohKnobs::or_default(ctx->knobs.klt_block, 256);
     if (block != 64 && block != 128 && block != 256) block = 256;
@@ -353,8 +353,8 @@ static int launch_klt(svoh_ctx* ctx, const svoh_klt_options* options, const std:
     hipLaunchKernelGGL(klt_track_kernel, dim3((n_tracks + tpb - 1) / tpb), dim3(block), 0, ctx->stream, args);
   }
   SVOH_HIP_TRY(ctx, hipGetLastError());
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
-  ctx->misc_timed = true;
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
   {
     int rc = reduce_unit_counts(ctx, n);
     if (rc != SVOH_OK) return rc;

@@ -2137,7 +2137,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     if (rc == SVOH_OK) rc = reserve_unit_counts(ctx, (size_t)n, &a.unit_counts);
     if (rc != SVOH_OK) return rc;
   }
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   if (seeds) {
     if (g8 == 2) {
       int max_w = 1, max_h = 1;
@@ -2193,8 +2193,8 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     else hipLaunchKernelGGL(match_direct_kernel<false>, grid, block, 0, ctx->stream, a);
   }
   SVOH_HIP_TRY(ctx, hipGetLastError());
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
-  ctx->misc_timed = true;
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
   {
     int rc = reduce_unit_counts(ctx, (size_t)n);
     if (rc != SVOH_OK) return rc;
@@ -2380,12 +2380,12 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
     if (rc == SVOH_OK) rc = reserve_unit_counts(ctx, (size_t)n, &a.unit_counts);
     if (rc != SVOH_OK) return rc;
   }
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   if (g8) hipLaunchKernelGGL(epipolar_match_kernel<true>, grid, block, 0, ctx->stream, a);
   else hipLaunchKernelGGL(epipolar_match_kernel<false>, grid, block, 0, ctx->stream, a);
   SVOH_HIP_TRY(ctx, hipGetLastError());
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
-  ctx->misc_timed = true;
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
   {
     const int rc = reduce_unit_counts(ctx, (size_t)n);
     if (rc != SVOH_OK) return rc;
@@ -2455,7 +2455,7 @@ try {
       if (rc != SVOH_OK) return rc;
       a0.unit_counts = uc; a1.unit_counts = uc + 4 * n0;
       auto blocks = [](const svoh_ctx::DeferredLaunch& d) { const int u = d.g8 ? 8 : 64; return (unsigned)((d.n + u - 1) / u); };
-      SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+      if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
       if (v0 && v1 && d0.g8 == d1.g8) {
         const unsigned b0 = blocks(d0), b1 = blocks(d1);
         if (d0.g8) hipLaunchKernelGGL(match_mixed_kernel<true>, dim3(b0 + b1), dim3(64), 0, ctx->stream, a0, a1, (int)b0);
@@ -2471,8 +2471,8 @@ try {
         }
       }
       SVOH_HIP_TRY(ctx, hipGetLastError());
-      SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
-      ctx->misc_timed = true;
+      if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+      ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
       rc = reduce_unit_counts(ctx, n0 + n1);
       if (rc != SVOH_OK) return rc;
       if (v0) SVOH_HIP_TRY(ctx, hipMemcpyAsync(d0.d2h_dst, d0.d2h_src, d0.d2h_bytes, hipMemcpyDeviceToHost, ctx->stream));

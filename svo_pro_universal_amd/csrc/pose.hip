@@ -622,15 +622,15 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
   }
   a.results = reinterpret_cast<svoh_pose_result*>(d + o_res);
   a.n_problems = n_problems;
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   // geometry: see pose_optimize_kernel.  SVOH_POSE_THREADS=64/256 forces one (tests run both).
   int nt = n_problems > ctx->num_cus ? 64 : kPoseThreads;
   { const int v = ctx->knobs.pose_threads; if (v == 64 || v == kPoseThreads) nt = v; }
   if (nt == 64) hipLaunchKernelGGL(pose_optimize_kernel<64>, dim3((unsigned)n_problems), dim3(64), 0, ctx->stream, a);
   else hipLaunchKernelGGL(pose_optimize_kernel<kPoseThreads>, dim3((unsigned)n_problems), dim3(kPoseThreads), 0, ctx->stream, a);
   SVOH_HIP_TRY(ctx, hipGetLastError());
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
-  ctx->misc_timed = true;
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
   if (packed) {   // per-feature outputs stay on the device; the per-bundle results come back
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_res, d + o_res, total - o_res, hipMemcpyDeviceToHost, ctx->stream));
     SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -703,11 +703,11 @@ try {
   a.pos = reinterpret_cast<double*>(d + o_pos);
   a.iters = reinterpret_cast<int32_t*>(d + o_it);
   a.n_points = n_points; a.n_iter = n_iter; a.on_sphere = using_bearing_vector != 0;
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   hipLaunchKernelGGL(point_optimize_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, ctx->stream, a);
   SVOH_HIP_TRY(ctx, hipGetLastError());
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
-  ctx->misc_timed = true;
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_pos, d + o_pos, total - o_pos, hipMemcpyDeviceToHost, ctx->stream));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(pos, h + o_pos, 24 * (size_t)n_points);

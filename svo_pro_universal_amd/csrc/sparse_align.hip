@@ -1632,8 +1632,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   if (grid > n_desc || grid <= 0) grid = n_desc;
   if (cluster) grid = n_desc;
   hipError_t e;
-  const int ev_slot = (int)(ctx->align_launches % svoh_ctx::kAlignEventRing);
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_start[ev_slot], ctx->stream));
+  const bool timed = ctx->timing_on();
+  const int ev_slot = (int)(ctx->align_timed_launches % svoh_ctx::kAlignEventRing);
+  if (timed) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_start[ev_slot], ctx->stream));
   if (opt->patch_size == 4)
     e = illum ? launch_nt<4, true>(ctx->stream, nt, grid, lds, args)
               : launch_nt<4, false>(ctx->stream, nt, grid, lds, args);
@@ -1648,7 +1649,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
     const hipError_t es = hipGetLastError();
     if (es != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "sum_shares launch failed: %s", hipGetErrorString(es));
   }
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_stop[ev_slot], ctx->stream));
+  if (timed) { SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_stop[ev_slot], ctx->stream)); ++ctx->align_timed_launches; }
   ++ctx->align_launches;
   // the results follow the kernel to pinned host memory right away, so that a caller which queues several
   // launches and fetches once still has every launch's output delivered
@@ -1739,8 +1740,8 @@ try {
 int svoh_sparse_align_last_kernel_ms(svoh_ctx* ctx, float* ms)
 try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
-  SVOH_REQUIRE(ctx, ms != nullptr && ctx->align_launches > 0, "no alignment launch to time");
-  const int slot = (int)((ctx->align_launches - 1) % svoh_ctx::kAlignEventRing);
+  SVOH_REQUIRE(ctx, ms != nullptr && ctx->align_timed_launches > 0, "no timed alignment launch (svoh_set_kernel_timing)");
+  const int slot = (int)((ctx->align_timed_launches - 1) % svoh_ctx::kAlignEventRing);
   SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_stop[slot]));
   SVOH_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_align_start[slot], ctx->ev_align_stop[slot]));
   return SVOH_OK;
@@ -1750,11 +1751,11 @@ int svoh_sparse_align_kernel_ms_history(svoh_ctx* ctx, int n, float* ms, int* n_
 try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, ms != nullptr && n_out != nullptr && n >= 0, "bad arguments");
-  int have = (int)(ctx->align_launches < (unsigned long long)svoh_ctx::kAlignEventRing ? ctx->align_launches
-                                                                                       : (unsigned long long)svoh_ctx::kAlignEventRing);
+  int have = (int)(ctx->align_timed_launches < (unsigned long long)svoh_ctx::kAlignEventRing ? ctx->align_timed_launches
+                                                                                             : (unsigned long long)svoh_ctx::kAlignEventRing);
   if (n < have) have = n;
   for (int k = 0; k < have; ++k) {   // oldest of the requested launches first
-    const int slot = (int)((ctx->align_launches - (unsigned long long)have + (unsigned long long)k) % svoh_ctx::kAlignEventRing);
+    const int slot = (int)((ctx->align_timed_launches - (unsigned long long)have + (unsigned long long)k) % svoh_ctx::kAlignEventRing);
     SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_stop[slot]));
     SVOH_HIP_TRY(ctx, hipEventElapsedTime(&ms[k], ctx->ev_align_start[slot], ctx->ev_align_stop[slot]));
   }

@@ -86,6 +86,7 @@ struct SvohKnobs {
   int align_threads = kKnobUnset;             // SVOH_ALIGN_THREADS: 256 / 512 / 1024
   int align_lds = kKnobUnset;                 // SVOH_ALIGN_LDS: bytes of LDS for image levels
   int align_wg_per_cu = kKnobUnset;           // SVOH_ALIGN_WG_PER_CU
+  int kernel_timing = kKnobUnset;             // SVOH_KERNEL_TIMING: 1 = bracket every kernel with an event pair (svoh_set_kernel_timing)
   static int or_default(int v, int dflt) { return v == kKnobUnset ? dflt : v; }
 };
 void load_knobs_from_env(SvohKnobs& k);
@@ -122,7 +123,10 @@ struct svoh_ctx {
   bool align_staging_in_flight = false;
   bool align_no_cluster = false;   // svoh_sparse_align_batch repeating a launch whose cluster gave up
   hipEvent_t ev_misc_start = nullptr, ev_misc_stop = nullptr;  // KLT / matcher / seeds
-  bool misc_timed = false;
+  bool misc_timed = false;     // the last KLT / matcher / seed / pose / detector launch was bracketed by the event pair
+  bool misc_launched = false;  // ... has happened at all (its work counters exist)
+  unsigned long long align_timed_launches = 0;   // alignment launches bracketed by events (ring slots in use)
+  bool timing_on() const { return knobs.kernel_timing != kKnobUnset && knobs.kernel_timing != 0; }
   svoh::DevBuffer d_counters;  // 8 x uint64 work counters of the last KLT / matcher kernel
   svoh::DevBuffer d_unit_counts;  // 4 x uint32 per unit
   size_t unit_counts_pending = 0; // units of the last launch whose counts have not been added up yet

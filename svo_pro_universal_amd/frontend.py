@@ -47,7 +47,9 @@ def se3_to_numpy(s):
 class Context(object):
     """One svoh_ctx (one HIP stream).  Not thread-safe, like the ABI."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, kernel_timing=True):
+        """kernel_timing: bracket every launch with an event pair so that the *_kernel_ms calls work (what the
+        benchmark and the tests want; the library's own default is off: svoh_set_kernel_timing)."""
         self.lib = capi.load()
         h = C.c_void_p()
         rc = self.lib.svoh_create(int(device), C.byref(h))
@@ -55,6 +57,10 @@ class Context(object):
             raise SvohError(rc, self.lib.svoh_last_error_string(None).decode())
         self.h = h
         self._keep = []
+        self.set_kernel_timing(kernel_timing)
+
+    def set_kernel_timing(self, on):
+        self._check(self.lib.svoh_set_kernel_timing(self.h, 1 if on else 0))
 
     def close(self):
         if self.h:

@@ -1307,6 +1307,7 @@ void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_
                           int n_speculated)
 {
   if (!ctx) throw std::runtime_error("matchCandidatesFused: NULL svoh_ctx (no CPU fallback exists)");
+  if (g_reproj_timing.on) (void)svoh_set_kernel_timing(ctx, 1);
   thread_local SpeculativeMatches sm;   // keeps its buffers from frame to frame ...
   sm.clear();
   struct Release { SpeculativeMatches& s; ~Release() { s.clear(); } } release{ sm };   // ... but no frame reference past the call

@@ -409,6 +409,31 @@ def test_visibility_changes_inside_a_level(gpu_ctx, oracle_lib, seed):
             gpu_ctx.reload_knobs()
 
 
+def test_kernel_timing_is_a_switch(gpu_ctx):
+    """The library's default is no event pair around a launch (svoh_set_kernel_timing, include/svo_hip.h): the *_kernel_ms
+    calls then refuse instead of reporting a stale time, results are the same either way."""
+    import ctypes as C
+    sc = helpers.small_scene(91, n=150)
+    gpb, keep = fe.make_align_problems([[(sc, gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5))]])
+    opt = capi.default_align_options(min_level=2)
+    timed = fe.se3_to_numpy(gpu_ctx.sparse_align(opt, gpb)[0].T_icur_iref)
+    ms = C.c_float()
+    assert gpu_ctx.lib.svoh_sparse_align_last_kernel_ms(gpu_ctx.h, C.byref(ms)) == 0 and 0.0 < ms.value < 50.0
+    fresh = fe.Context(0, kernel_timing=False)
+    try:
+        gpb2, keep2 = fe.make_align_problems([[(sc, fresh.build_pyramid(sc.img_ref, 5), fresh.build_pyramid(sc.img_cur, 5))]])
+        untimed = fe.se3_to_numpy(fresh.sparse_align(opt, gpb2)[0].T_icur_iref)
+        assert np.array_equal(untimed, timed)
+        assert fresh.lib.svoh_sparse_align_last_kernel_ms(fresh.h, C.byref(ms)) != 0
+        assert b"svoh_set_kernel_timing" in fresh.lib.svoh_last_error_string(fresh.h)
+        assert fresh.lib.svoh_last_kernel_ms(fresh.h, C.byref(ms)) != 0
+        fresh.set_kernel_timing(True)
+        fresh.sparse_align(opt, gpb2)
+        assert fresh.lib.svoh_sparse_align_last_kernel_ms(fresh.h, C.byref(ms)) == 0 and ms.value > 0.0
+    finally:
+        fresh.close()
+
+
 def test_queued_launches_and_kernel_time_history(gpu_ctx):
     """Several enqueue calls before one fetch: the last launch's results are handed out, every launch's device
     time can be read afterwards (the library keeps the last 32 event pairs)."""

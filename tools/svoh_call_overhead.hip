@@ -1,0 +1,82 @@
+// What a blocking call costs around its kernel on this machine: staging copy, launch, copy back, wake-up -- and what
+// the same call costs when the kernel reads its (small) inputs from pinned host memory and writes its results there.
+// Diagnostic tool (per-frame chain); prints one JSON object.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// reads n_in doubles (every lane strides through them), spins `work` dependent FMAs, writes n_out doubles
+__global__ void work_kernel(const double* in, double* out, int n_in, int n_out, int work)
+{
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_in; i += blockDim.x) acc += in[i];
+  for (int k = 0; k < work; ++k) acc = acc * 1.0000001 + 1e-9;
+  for (int i = threadIdx.x; i < n_out; i += blockDim.x) out[i] = acc + i;
+}
+
+__global__ void zero_kernel(double* p, int n) { for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.0; }
+
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main()
+{
+  const int n_in = 2048, n_out = 512, reps = 300;   // 16 KB in, 4 KB out: one frame's features and results
+  hipStream_t s;
+  CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  double *h_in, *h_out, *h_in_nc, *h_out_nc, *d_in, *d_out;
+  CK(hipHostMalloc(&h_in, n_in * 8, hipHostMallocDefault));
+  CK(hipHostMalloc(&h_out, n_out * 8, hipHostMallocDefault));
+  CK(hipHostMalloc(&h_in_nc, n_in * 8, hipHostMallocNonCoherent));
+  CK(hipHostMalloc(&h_out_nc, n_out * 8, hipHostMallocNonCoherent));
+  CK(hipMalloc(&d_in, n_in * 8));
+  CK(hipMalloc(&d_out, n_out * 8));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < n_in; ++i) h_in[i] = h_in_nc[i] = 1.0;
+  printf("{");
+  const char* names[] = { "kernel_sync", "h2d_kernel_sync", "h2d_kernel_d2h_sync", "h2d_memset_events_kernel_d2h_sync",
+                          "zero_copy_coherent", "zero_copy_noncoherent", "zero_copy_in_noncoherent_out_device_d2h", "h2d_events_kernel_d2h_sync", "h2d_memset_kernel_d2h_sync", "h2d_fillkernel_kernel_d2h_sync" };
+  for (int work : { 0, 20000 }) {
+    for (int v = 0; v < 10; ++v) {
+      std::vector<double> t;
+      for (int r = 0; r < reps + 20; ++r) {
+        h_in[0] = h_in_nc[0] = (double)r;
+        const double t0 = now_us();
+        switch (v) {
+          case 0: work_kernel<<<1, 256, 0, s>>>(d_in, d_out, n_in, n_out, work); break;
+          case 1: CK(hipMemcpyAsync(d_in, h_in, n_in * 8, hipMemcpyHostToDevice, s)); work_kernel<<<1, 256, 0, s>>>(d_in, d_out, n_in, n_out, work); break;
+          case 2: CK(hipMemcpyAsync(d_in, h_in, n_in * 8, hipMemcpyHostToDevice, s)); work_kernel<<<1, 256, 0, s>>>(d_in, d_out, n_in, n_out, work);
+                  CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); break;
+          case 3: CK(hipMemcpyAsync(d_in, h_in, n_in * 8, hipMemcpyHostToDevice, s)); CK(hipMemsetAsync(d_out, 0, n_out * 8, s)); CK(hipEventRecord(e0, s));
+                  work_kernel<<<1, 256, 0, s>>>(d_in, d_out, n_in, n_out, work); CK(hipEventRecord(e1, s));
+                  CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); break;
+          case 4: work_kernel<<<1, 256, 0, s>>>(h_in, h_out, n_in, n_out, work); break;
+          case 5: work_kernel<<<1, 256, 0, s>>>(h_in_nc, h_out_nc, n_in, n_out, work); break;
+          case 7: CK(hipMemcpyAsync(d_in, h_in, n_in * 8, hipMemcpyHostToDevice, s)); CK(hipEventRecord(e0, s));
+                  work_kernel<<<1, 256, 0, s>>>(d_in, d_out, n_in, n_out, work); CK(hipEventRecord(e1, s));
+                  CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); break;
+          case 8: CK(hipMemcpyAsync(d_in, h_in, n_in * 8, hipMemcpyHostToDevice, s)); CK(hipMemsetAsync(d_out, 0, n_out * 8, s));
+                  work_kernel<<<1, 256, 0, s>>>(d_in, d_out, n_in, n_out, work);
+                  CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); break;
+          case 9: CK(hipMemcpyAsync(d_in, h_in, n_in * 8, hipMemcpyHostToDevice, s)); zero_kernel<<<1, 256, 0, s>>>(d_out, n_out);
+                  work_kernel<<<1, 256, 0, s>>>(d_in, d_out, n_in, n_out, work);
+                  CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); break;
+          case 6: work_kernel<<<1, 256, 0, s>>>(h_in_nc, d_out, n_in, n_out, work); CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); break;
+        }
+        CK(hipStreamSynchronize(s));
+        const double t1 = now_us();
+        if (r >= 20) t.push_back(t1 - t0);
+      }
+      std::sort(t.begin(), t.end());
+      printf("%s\"%s_work%d_us\": {\"median\": %.1f, \"p10\": %.1f}", (work == 0 && v == 0) ? "" : ", ", names[v], work, t[t.size() / 2], t[t.size() / 10]);
+    }
+  }
+  printf("}\n");
+  return 0;
+}
