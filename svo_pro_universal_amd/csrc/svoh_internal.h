@@ -40,7 +40,10 @@ struct Frame {
 };
 
 // grow-only device / pinned-host scratch buffers (never reallocated inside a
-// timed loop once warmed up)
+// timed loop once warmed up).  A regrowth frees and allocates (0.3 - 1 ms, and hipFree waits for the device): a buffer
+// starts at 1 MB -- nothing next to 288 GB, and what a per-frame call of an EuRoC-sized front end never outgrows --
+// and grows by half.
+constexpr size_t kMinScratchBytes = (size_t)1 << 20;
 struct DevBuffer {
   void* ptr = nullptr;
   size_t cap = 0;
@@ -48,7 +51,8 @@ struct DevBuffer {
   {
     if (bytes <= cap) return hipSuccess;
     if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
-    size_t want = bytes + bytes / 4 + 4096;
+    size_t want = bytes + bytes / 2 + 4096;
+    if (want < kMinScratchBytes) want = kMinScratchBytes;
     hipError_t e = hipMalloc(&ptr, want);
     if (e == hipSuccess) cap = want;
     return e;
@@ -63,7 +67,8 @@ struct PinnedBuffer {
   {
     if (bytes <= cap) return hipSuccess;
     if (ptr) { (void)hipHostFree(ptr); ptr = nullptr; cap = 0; }
-    size_t want = bytes + bytes / 4 + 4096;
+    size_t want = bytes + bytes / 2 + 4096;
+    if (want < kMinScratchBytes) want = kMinScratchBytes;
     hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
     if (e == hipSuccess) cap = want;
     return e;

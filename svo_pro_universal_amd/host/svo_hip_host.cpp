@@ -874,13 +874,14 @@ struct ReprojTiming {   // SVOH_REPROJ_TIMING=1: mean host / device split of rep
   bool on = getenv("SVOH_REPROJ_TIMING") != nullptr;
   double t[6] = { 0, 0, 0, 0, 0, 0 };
   double kernel_ms = 0;
+  double rt[4] = { 0, 0, 0, 0 };   // device round trip: direct batch call, seed batch call, collect, the rest
   long n = 0, n_direct = 0, n_seeds = 0, n_reached3 = 0, n_spec3 = 0;
   static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   ~ReprojTiming()
   {
     if (on && n)
-      fprintf(stderr, "[reproject] per call: candidates %.3f ms, sort %.3f, plan %.3f, device round trip(s) %.3f (kernel %.3f), replay %.3f, other %.3f (%ld calls; per call %.0f direct + %.0f seed units speculated; unconverged pass reached %ld x, speculated %ld x)\n",
-              t[0] / n, t[1] / n, t[2] / n, t[3] / n, kernel_ms / n, t[4] / n, t[5] / n, n, (double)n_direct / n, (double)n_seeds / n, n_reached3, n_spec3);
+      fprintf(stderr, "[reproject] per call: candidates %.3f ms, sort %.3f, plan %.3f, device round trip(s) %.3f (kernel %.3f), replay %.3f, other %.3f [round trip: stage direct %.3f, stage seeds %.3f, launch + wait %.3f] (%ld calls; per call %.0f direct + %.0f seed units speculated; unconverged pass reached %ld x, speculated %ld x)\n",
+              t[0] / n, t[1] / n, t[2] / n, t[3] / n, kernel_ms / n, t[4] / n, t[5] / n, rt[0] / n, rt[1] / n, rt[2] / n, n, (double)n_direct / n, (double)n_seeds / n, n_reached3, n_spec3);
   }
 } g_reproj_timing;
 }  // namespace
@@ -1187,6 +1188,7 @@ struct SpeculativeMatches {
     const bool both = direct.size() && seeds.size();
     if (both && svoh_matcher_begin_deferred(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_begin_deferred: ") + svoh_last_error_string(ctx));
     svoh_feature_batch fbd{}, fbs{};
+    const double tr0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
     if (direct.size()) {
       const size_t m = direct.size();
       direct.result.assign(m, 0); direct.search_level.assign(m, 0); direct.f_cur.assign(3 * m, 0.0); direct.A.assign(4 * m, 0.0);
@@ -1196,6 +1198,7 @@ struct SpeculativeMatches {
                                              direct.f_cur.data(), direct.search_level.data(), nullptr, direct.A.data());
       if (rc != SVOH_OK) { if (both) fail("svoh_match_direct_batch"); throw std::runtime_error(std::string("svoh_match_direct_batch: ") + svoh_last_error_string(ctx)); }
     }
+    const double tr1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
     if (seeds.size()) {
       const size_t m = seeds.size();
       seeds.result.assign(m, 0); seeds.search_level.assign(m, 0); seeds.success.assign(m, 0);
@@ -1211,7 +1214,9 @@ struct SpeculativeMatches {
                                                 seeds.state.data(), seeds.success.data(), seeds.result.data(), nullptr, &outs);
       if (rc != SVOH_OK) { if (both) fail("svoh_update_seeds_batch_ex"); throw std::runtime_error(std::string("svoh_update_seeds_batch_ex: ") + svoh_last_error_string(ctx)); }
     }
+    const double tr2 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
     if (both && svoh_matcher_collect(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_collect: ") + svoh_last_error_string(ctx));
+    if (g_reproj_timing.on) { const double tr3 = ReprojTiming::now(); g_reproj_timing.rt[0] += tr1 - tr0; g_reproj_timing.rt[1] += tr2 - tr1; g_reproj_timing.rt[2] += tr3 - tr2; }
   }
   // the reference's loop over one candidate list, in candidate order (reprojector.cpp:356-381)
   void replay(const FramePtr& frame, size_t max_n_features_per_frame, std::vector<reprojector::Candidate>& candidates,
