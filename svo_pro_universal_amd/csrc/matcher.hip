@@ -343,20 +343,41 @@ __device__ bool warp_affine_g8(const double A_cur_ref[4], const DevImage& img_re
     inside = inside && pxx == pxx && pxy == pxy && !(xi < 0 || yi < 0 || xi >= img_ref.w - 1 || yi >= img_ref.h - 1);
   }
   if (!g8_all(inside)) return false;
-  for (int k = sub; k < 100; k += 8) {
-    const float fx = (float)(k % 10 - halfpatch_size), fy = (float)(k / 10 - halfpatch_size);
-    const float pxx = (a00 * fx + a01 * fy) + prx;
-    const float pxy = (a10 * fx + a11 * fy) + pry;
-    const int xi = (int)floorf(pxx);
-    const int yi = (int)floorf(pxy);
-    const float subpix_x = pxx - xi, subpix_y = pxy - yi;
-    const uint8_t* ptr = img_ref.data + (ptrdiff_t)yi * stride + xi;
-    const unsigned t00 = ptr[0], t10 = ptr[1], t01 = ptr[stride], t11 = ptr[stride + 1];
-    const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
-    const float w01 = (1.0f - subpix_x) * subpix_y;
-    const float w10 = subpix_x * (1.0f - subpix_y);
-    const float w11 = 1.0f - w00 - w01 - w10;
-    patch[k] = (unsigned char)(w00 * t00 + w01 * t01 + w10 * t10 + w11 * t11);
+  // a lane's 12 or 13 samples: all tap loads first (two unaligned 2-byte loads per sample, every one of them in flight
+  // together), then the arithmetic -- one round trip to memory per lane instead of one per sample
+  unsigned short t0[13], t1[13];
+#pragma unroll
+  for (int j = 0; j < 13; ++j) {
+    const int k = sub + 8 * j;
+    t0[j] = 0; t1[j] = 0;
+    if (k < 100) {
+      const float fx = (float)(k % 10 - halfpatch_size), fy = (float)(k / 10 - halfpatch_size);
+      const float pxx = (a00 * fx + a01 * fy) + prx;
+      const float pxy = (a10 * fx + a11 * fy) + pry;
+      const int xi = (int)floorf(pxx);
+      const int yi = (int)floorf(pxy);
+      const uint8_t* ptr = img_ref.data + (ptrdiff_t)yi * stride + xi;
+      __builtin_memcpy(&t0[j], ptr, 2);
+      __builtin_memcpy(&t1[j], ptr + stride, 2);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 13; ++j) {
+    const int k = sub + 8 * j;
+    if (k < 100) {
+      const float fx = (float)(k % 10 - halfpatch_size), fy = (float)(k / 10 - halfpatch_size);
+      const float pxx = (a00 * fx + a01 * fy) + prx;
+      const float pxy = (a10 * fx + a11 * fy) + pry;
+      const int xi = (int)floorf(pxx);
+      const int yi = (int)floorf(pxy);
+      const float subpix_x = pxx - xi, subpix_y = pxy - yi;
+      const unsigned t00 = t0[j] & 255u, t10 = t0[j] >> 8, t01 = t1[j] & 255u, t11 = t1[j] >> 8;
+      const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+      const float w01 = (1.0f - subpix_x) * subpix_y;
+      const float w10 = subpix_x * (1.0f - subpix_y);
+      const float w11 = 1.0f - w00 - w01 - w10;
+      patch[k] = (unsigned char)(w00 * t00 + w01 * t01 + w10 * t10 + w11 * t11);
+    }
   }
   g8_lds_fence();
   return true;
@@ -1037,6 +1058,94 @@ __device__ void scan_epipolar_unit_plane(MatcherState& m, const svoh_matcher_opt
   double best0 = uv0, best1 = uv1;
   bool forward = true;
   int last0 = 0, last1 = 0;
+  if constexpr (G8 == 1) {
+    // Eight steps at a time, as in the unit-sphere scan below.  A step's position is the centre plus a number of
+    // SEQUENTIAL additions of the step vector (the reference's `uv += step`), restarted from the centre with the negated
+    // step when the walk turns round; where it turns depends on the positions only.  Lane `sub` repeats the additions up
+    // to its own step, projects that one position, and the group replays the loop's control flow over the eight pixels.
+    const DevImage& im = frame.lv[patch_level];
+    const int o = (m.sub + 1) * 10 + 1;   // this lane's template row (see zmssd_score_g8)
+    const unsigned* w = reinterpret_cast<const unsigned*>(m.pwb) + (o >> 2);
+    const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+    const unsigned tr0 = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)(o & 3)), tr1 = __builtin_amdgcn_alignbyte(w2, w1, (unsigned)(o & 3));
+    const double half = n_steps * 0.5;
+    size_t i0 = 0;
+    bool stop = false;
+    while (!stop && i0 < n_steps) {
+      // uv0, uv1: position of step i0; mine / after: position of step i0 + sub / i0 + 8
+      double mine0 = uv0, mine1 = uv1, after0 = uv0, after1 = uv1;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        after0 += step0; after1 += step1;
+        if (k < m.sub) { mine0 = after0; mine1 = after1; }
+      }
+      int pxi0 = 0, pxi1 = 0;
+      bool within = false;
+      if (i0 + (size_t)m.sub < n_steps) {
+        double px, py;
+        const Vec3 p3 = { mine0, mine1, 1.0 };
+        project3(frame.cam, p3, px, py);
+        pxi0 = (int)(px / (1 << patch_level) + 0.5); pxi1 = (int)(py / (1 << patch_level) + 0.5);
+        within = is_patch_within_image(frame, pxi0, pxi1, patch_level);
+      }
+      unsigned scored = 0;
+      int turn_after = -1;      // the walk turns round after step i0 + turn_after ...
+      bool turn_jump = false;   // ... by the out-of-image rule (the index jumps to the middle) rather than past the middle
+      int q0[8], q1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        q0[j] = __shfl(pxi0, j, 8); q1[j] = __shfl(pxi1, j, 8);
+        const bool in_j = __shfl((int)within, j, 8) != 0;
+        if (stop || turn_after >= 0 || i0 + j >= n_steps) continue;
+        if (q0[j] == last0 && q1[j] == last1) continue;
+        last0 = q0[j]; last1 = q1[j];
+        if (!in_j) {
+          if (forward) { turn_after = j; turn_jump = true; }
+          else stop = true;
+          continue;
+        }
+        scored |= 1u << j;
+        if (forward && (double)(i0 + j) > half) turn_after = j;
+      }
+      uint2 c[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (scored & (1u << j))
+          __builtin_memcpy(&c[j], im.data + (ptrdiff_t)(q1[j] - 4 + m.sub) * im.pitch + (q0[j] - 4), 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (scored & (1u << j)) {
+          unsigned sumB = __builtin_amdgcn_udot4(c[j].x, 0x01010101u, 0u, false);
+          sumB = __builtin_amdgcn_udot4(c[j].y, 0x01010101u, sumB, false);
+          unsigned sumBB = __builtin_amdgcn_udot4(c[j].x, c[j].x, 0u, false);
+          sumBB = __builtin_amdgcn_udot4(c[j].y, c[j].y, sumBB, false);
+          unsigned sumAB = __builtin_amdgcn_udot4(c[j].x, tr0, 0u, false);
+          sumAB = __builtin_amdgcn_udot4(c[j].y, tr1, sumAB, false);
+          const int iB = g8_sum((int)sumB), iBB = g8_sum((int)sumBB), iAB = g8_sum((int)sumAB);
+          const int z = sumAA - 2 * iAB + iBB - (sumA * sumA - 2 * sumA * iB + iB * iB) / 64;
+          ++m.n_zmssd;
+          if (z < zmssd_best) {
+            zmssd_best = z;
+            best0 = __hiloint2double(__shfl(__double2hiint(mine0), j, 8), __shfl(__double2loint(mine0), j, 8));
+            best1 = __hiloint2double(__shfl(__double2hiint(mine1), j, 8), __shfl(__double2loint(mine1), j, 8));
+          }
+        }
+      if (stop) break;
+      if (turn_after >= 0) {
+        // `i = n_steps * 0.5; continue` or the flip after a scored step: either way the loop's own increment follows
+        i0 = (turn_jump ? (size_t)half : i0 + (size_t)turn_after) + 1;
+        step0 = -step0; step1 = -step1;
+        uv0 = uvC0 + step0; uv1 = uvC1 + step1;
+        forward = false;
+      } else {
+        i0 += 8;
+        uv0 = after0; uv1 = after1;
+      }
+    }
+    const Vec3 p3 = { best0, best1, 1.0 };
+    project3(frame.cam, p3, bx, by);
+    return;
+  }
   for (size_t i = 0; i < n_steps; ++i, uv0 += step0, uv1 += step1) {
     double px, py;
     const Vec3 p3 = { uv0, uv1, 1.0 };
@@ -1101,6 +1210,79 @@ __device__ void scan_epipolar_unit_sphere(MatcherState& m, const svoh_matcher_op
   normalize3(axis);
   Vec3 f = f_C, f_best = f_C;
   int last0 = 0, last1 = 0;
+  if constexpr (G8 == 1) {
+    // Eight steps at a time: a step's pixel depends on its index only, not on any score, so lane `sub` computes the
+    // position of step i0 + sub (the rotation and the projection are the expensive part of a step, and all eight lanes
+    // used to compute the same one), the group then walks the eight positions in order with the reference's rules --
+    // skip a pixel equal to the one before, jump to the second half or stop when the patch leaves the image -- which
+    // fixes WHICH steps are scored before any score exists; the rows of all of them are requested together (one round
+    // trip to memory per eight steps instead of one per step) and scored in step order with the same `<`.
+    const DevImage& im = frame.lv[patch_level];
+    const int o = (m.sub + 1) * 10 + 1;   // this lane's template row (see zmssd_score_g8)
+    const unsigned* w = reinterpret_cast<const unsigned*>(m.pwb) + (o >> 2);
+    const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+    const unsigned tr0 = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)(o & 3)), tr1 = __builtin_amdgcn_alignbyte(w2, w1, (unsigned)(o & 3));
+    long long best_i = -1;
+    size_t i0 = 0;
+    while (i0 < n_steps) {
+      const size_t i = i0 + (size_t)m.sub;
+      int pxi0 = 0, pxi1 = 0;
+      bool within = false;
+      if (i < n_steps) {
+        const double angle = i < half_steps ? i * step : (i - half_steps) * (-step);
+        const Vec3 fi = angle_axis_rotate(axis, angle, f_C);
+        double px, py;
+        project3(frame.cam, fi, px, py);
+        pxi0 = (int)(px / (1 << patch_level) + 0.5); pxi1 = (int)(py / (1 << patch_level) + 0.5);
+        within = is_patch_within_image(frame, pxi0, pxi1, patch_level);
+      }
+      unsigned scored = 0;      // bit j: step i0 + j gets a score
+      long long jump = -1;      // >= 0: the next block starts there
+      bool stop = false;
+      int q0[8], q1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        q0[j] = __shfl(pxi0, j, 8); q1[j] = __shfl(pxi1, j, 8);
+        const bool in_j = __shfl((int)within, j, 8) != 0;
+        if (stop || jump >= 0 || i0 + j >= n_steps) continue;
+        if (q0[j] == last0 && q1[j] == last1) continue;
+        last0 = q0[j]; last1 = q1[j];
+        if (!in_j) {
+          if (i0 + j < half_steps) jump = (long long)half_steps + 1;
+          else stop = true;
+          continue;
+        }
+        scored |= 1u << j;
+      }
+      uint2 c[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (scored & (1u << j))
+          __builtin_memcpy(&c[j], im.data + (ptrdiff_t)(q1[j] - 4 + m.sub) * im.pitch + (q0[j] - 4), 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (scored & (1u << j)) {
+          unsigned sumB = __builtin_amdgcn_udot4(c[j].x, 0x01010101u, 0u, false);
+          sumB = __builtin_amdgcn_udot4(c[j].y, 0x01010101u, sumB, false);
+          unsigned sumBB = __builtin_amdgcn_udot4(c[j].x, c[j].x, 0u, false);
+          sumBB = __builtin_amdgcn_udot4(c[j].y, c[j].y, sumBB, false);
+          unsigned sumAB = __builtin_amdgcn_udot4(c[j].x, tr0, 0u, false);
+          sumAB = __builtin_amdgcn_udot4(c[j].y, tr1, sumAB, false);
+          const int iB = g8_sum((int)sumB), iBB = g8_sum((int)sumBB), iAB = g8_sum((int)sumAB);
+          const int z = sumAA - 2 * iAB + iBB - (sumA * sumA - 2 * sumA * iB + iB * iB) / 64;
+          ++m.n_zmssd;
+          if (z < zmssd_best) { zmssd_best = z; best_i = (long long)(i0 + j); }
+        }
+      if (stop) break;
+      i0 = jump >= 0 ? (size_t)jump : i0 + 8;
+    }
+    if (best_i >= 0) {
+      const size_t bi = (size_t)best_i;
+      f_best = angle_axis_rotate(axis, bi < half_steps ? bi * step : (bi - half_steps) * (-step), f_C);
+    }
+    project3(frame.cam, f_best, bx, by);
+    return;
+  }
   for (size_t i = 0; i < n_steps; i++) {
     double angle;
     if (i < half_steps) angle = i * step;
