@@ -407,6 +407,72 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
             "cpu_baseline": cpu}
 
 
+def bench_stereo(args, ctx, dist, rank, world, dev, comm_dev=None):
+    """The stereo keyframe seam (StereoTriangulation::compute, stereo_triangulation.cpp:60-140): per stereo pair 120
+    features of the left frame searched along the epipolar line in the right frame (Matcher defaults: unit sphere,
+    max_epi_search_steps = 500), depth triangulated.  B pairs per step through svoh_epipolar_match_batch (host arrays)."""
+    B = args.problems or 64
+    NF = 120
+    cam, scenes, imgs, frames = render_pairs(ctx, dev, rank, B, 4, rot_deg=(0.0, 0.2), trans_m=(0.08, 0.12))
+    mopt = capi.default_matcher_options(max_epi_search_steps=500, subpix_refinement=1, scan_on_unit_sphere=1)
+    feats = [synth.make_seed_set(sc, NF, seed=i, margin=6, levels=(0, 1, 2)) for i, sc in enumerate(scenes)]
+    ref_views = [fe.make_frame_view(frames[2 * i], cam, sc.T_ref_f_w, 0.0, 2 * i) for i, sc in enumerate(scenes)]
+    cur_views = [fe.make_frame_view(frames[2 * i + 1], cam, sc.T_cur_f_w_gt, 0.0, 2 * i + 1) for i, sc in enumerate(scenes)]
+    idx = np.repeat(np.arange(B, dtype=np.int32), NF)
+    cat = lambda k: np.concatenate([f[k] for f in feats])
+    ftype = np.where(cat("type") == 0, capi.FT_EDGELET, capi.FT_CORNER).astype(np.uint8)   # detector output, not seeds
+    fb, keep = fe.make_feature_batch(idx, cat("px"), cat("f"), cat("grad"), cat("level"), ftype)
+    fb.cur_frame_idx = idx.ctypes.data
+    fb.n_cur_frames = B
+    n = B * NF
+    d_inv = np.concatenate([np.tile([1.0 / np.median(f["true_depth"]), 1.0 / (0.3 * np.median(f["true_depth"])),
+                                     1.0 / (15.0 * np.median(f["true_depth"]))], NF) for f in feats])
+
+    def step():
+        out = ctx.epipolar_match_batch(mopt, ref_views, cur_views, fb, d_inv=d_inv)
+        return out, misc_kernel_ms(ctx)
+
+    elapsed, kms, out = timed_steps(ctx, dist, world, dev, step, args.steps, args.warmup)
+    ok = out["result"] == capi.MATCH_SUCCESS
+    td = cat("true_depth")
+    depth_err = float(np.median(np.abs(out["depth"][ok] - td[ok]) / td[ok])) if ok.any() else None
+    cnt = misc_counters(ctx)
+    alg = cnt[0] * 121 + cnt[1] * 128 + cnt[2] * 81 + n * 8
+    elapsed, total = du.combine(dist, world, elapsed, n, comm_dev)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc  # test infrastructure: the timed CPU baseline only
+        orc.build(fast=True)
+        t_cpu, n_cpu = 0.0, 0
+        for i, sc in enumerate(scenes):
+            ref = orc.create_img_pyramid(imgs[2 * i].cpu().numpy(), 5, fast=True)
+            cur = orc.create_img_pyramid(imgs[2 * i + 1].cpu().numpy(), 5, fast=True)
+            ov_r = orc.make_frame_view(ref, cam, sc.T_ref_f_w, 0.0, 2 * i)
+            ov_c = orc.make_frame_view(cur, cam, sc.T_cur_f_w_gt, 0.0, 2 * i + 1)
+            f = feats[i]
+            sl = slice(i * NF, (i + 1) * NF)
+            fbo, ko = orc.make_feature_batch(f["ref_frame_idx"], f["px"], f["f"], f["grad"], f["level"], ftype[sl])
+            for rep in range(40):   # a pair's 120 features take ~0.2 ms: repeated for a stable time
+                t0 = time.perf_counter()
+                oo = orc.epipolar_match_batch(mopt, [ov_r], ov_c, fbo, d_inv=d_inv[3 * i * NF:3 * (i + 1) * NF], fast=True)
+                t_cpu += time.perf_counter() - t0
+                n_cpu += NF
+            assert (oo["result"] != out["result"][sl]).mean() < 1e-2   # -O3 -march=native may contract FMAs: rare knife-edge flips
+            if t_cpu > 10.0:
+                break
+        cpu = {"value": n_cpu / t_cpu, "unit": "features/s", "cores": 1, "kind": "port",
+               "sample": "%d feature searches: every pair of the benchmark 40 times (oracle findEpipolarMatchDirect, gcc -O3 -march=native, 1 thread, %.1f s)" % (n_cpu, t_cpu)}
+    if rank != 0:
+        return None
+    return {"metric": "stereo-triangulated features/s (findEpipolarMatchDirect, <=500 epipolar steps, 120 features per stereo pair)",
+            "value": total / elapsed, "unit": "features/s", "ms_per_step": 1e3 * elapsed / args.steps, "dtype": "u8+i32+f32+f64",
+            "config": {"workload": "stereo seam: %d stereo pairs x %d features per GPU per step, 640x480, unit-sphere scan, host arrays in / out" % (B, NF),
+                       "pairs_per_gpu": B, "features_per_pair": NF},
+            "kernel_ms": kms, "success_fraction": float(ok.mean()), "median_depth_error": depth_err,
+            "roofline": roofline("epipolar_match_kernel", kms, alg, "stereo:default", counters=cnt[:4]),
+            "cpu_baseline": cpu}
+
+
 def bench_frame(args, ctx, dist, rank, world, dev, comm_dev=None):
     """C3-synth: the per-frame hot path at the EuRoC mono sizes of SURVEY.md Appendix A, one frame at a time
     (latency, not throughput): 752x480 radtan camera; 5-level pyramid of the new image (host image in);
@@ -972,7 +1038,7 @@ def main(argv=None):
     ctx = fe.Context(local_rank)
     if args.workload != "align":
         out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame, "detect": bench_detect, "pose": bench_pose,
-               "align-split": bench_align_split, "align-c4": bench_align_c4,
+               "align-split": bench_align_split, "align-c4": bench_align_c4, "stereo": bench_stereo,
                "launch-check": lambda a, c, d, r, w, dv, cd: bench_launch_check(a, d, r, w, cd)}[args.workload](
             args, ctx, dist, rank, world, dev, comm_dev)
         if rank == 0:

@@ -74,3 +74,14 @@ def test_gpus_flag_must_agree_with_world_size():
     assert r.returncode != 0 and "refusing" in r.stderr and r.stdout.strip() == ""
     r = _run_bench(["--gpus", "1", "--steps", "2", "--workload", "launch-check"], {"SVOH_BENCH_BACKEND": "gloo"})
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_every_workload_choice_has_a_bench_function():
+    """`--workload stereo` was once an accepted choice that nothing dispatched."""
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    choices = re.search(r'"--workload".*?choices=\[(.*?)\]', src, re.S).group(1)
+    choices = set(re.findall(r'"([a-z0-9-]+)"', choices))
+    table = re.search(r'out = \{(.*?)\}\[args.workload\]', src, re.S).group(1)
+    dispatched = set(re.findall(r'"([a-z0-9-]+)":', table)) | {"align"}
+    assert choices == dispatched, (choices ^ dispatched)
