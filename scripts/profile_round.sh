@@ -2,10 +2,10 @@
 # Runs on the GPU box.  For every benchmark workload: rocprofv3 kernel-trace/stats of the bench command, then separate
 # counter passes of the SAME command (FETCH_SIZE, WRITE_SIZE, two SQ sets; never mixed with trace flags), raw CSVs of
 # the svoh kernels kept, and one summary json per workload (scripts/pmc_summary.py) -> gpurun_out/profiles/.
-# usage: scripts/profile_round.sh <round> [tags...]     tags: align_p4 align_p8 align_c4 klt seeds pose
+# usage: scripts/profile_round.sh <round> [tags...]     tags: align_p4 align_p8 align_c4 klt seeds pose stereo
 set -e
 ROUND=${1:-r02}; shift || true
-TAGS=${@:-align_p4 align_p8 align_c4 klt seeds pose}
+TAGS=${@:-align_p4 align_p8 align_c4 klt seeds pose stereo}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 dst=gpurun_out/profiles
@@ -19,6 +19,7 @@ for tag in $TAGS; do
     klt) args="--workload klt $STEPS"; key="klt:default"; rx="klt_track_kernel";;
     seeds) args="--workload seeds $STEPS"; key="seeds:default"; rx="update_seeds|seed_bin|seed_unsort";;
     pose) args="--workload pose $STEPS"; key="pose:default"; rx="pose_optimize_kernel";;
+    stereo) args="--workload stereo $STEPS"; key="stereo:default"; rx="epipolar_match_kernel";;
   esac
   out=/tmp/prof_${ROUND}_$tag
   rm -rf $out; mkdir -p $out
