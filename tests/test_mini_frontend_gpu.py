@@ -17,8 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 
-def test_mini_frontend_tracks_a_synthetic_sequence(tmp_path):
-    import ate
+def make_dataset(tmp_path):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host")])
     cam = synth.Camera.euroc_like(752, 480)
     sc = synth.make_align_scene(160, n_features=8, cam=cam, rot_deg=(0.3, 0.5), trans_m=(0.015, 0.025))
@@ -55,9 +54,15 @@ def test_mini_frontend_tracks_a_synthetic_sequence(tmp_path):
     d = float(np.mean(sc.depth))
     T0 = poses[0].inverse().as7()
     tool = os.path.join(ROOT, "svo_pro_universal_amd", "host", "svoh_mini_frontend")
-    r = subprocess.run([tool, str(tmp_path / "ds"), str(tmp_path / "calib.yaml"), str(tmp_path / "params.yaml"), str(out_dir)]
-                       + ["%.17g" % v for v in T0] + ["%.6f" % (0.5 * d), "%.6f" % d, "%.6f" % (2.0 * d)],
-                       capture_output=True, text=True)
+    cmd = ([tool, str(tmp_path / "ds"), str(tmp_path / "calib.yaml"), str(tmp_path / "params.yaml"), str(out_dir)]
+           + ["%.17g" % v for v in T0] + ["%.6f" % (0.5 * d), "%.6f" % d, "%.6f" % (2.0 * d)])
+    return cmd, out_dir, poses, stamps, n_frames
+
+
+def test_mini_frontend_tracks_a_synthetic_sequence(tmp_path):
+    import ate
+    cmd, out_dir, poses, stamps, n_frames = make_dataset(tmp_path)
+    r = subprocess.run(cmd, capture_output=True, text=True)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     est = ate.load_tum(str(out_dir / "trajectory.txt"))
@@ -81,3 +86,24 @@ def test_mini_frontend_tracks_a_synthetic_sequence(tmp_path):
     assert np.median(fc[1:, 3]) > 80                      # the reprojector keeps enough features alive
     assert fc[-1, 6] > 100                                # seeds converge
     assert fc[:, 1].sum() >= 4                            # several keyframes were made
+
+
+def test_streams_share_one_gpu(tmp_path):
+    """SURVEY.md 8(e) row 1 on ONE device: independent camera streams, one svoh_ctx and one host thread each, no exchange.
+    Every stream must produce exactly the single stream's trajectory (contexts share nothing), and since a stream at
+    EuRoC sizes is a chain of latency-bound round trips the aggregate frame rate must grow with the number of streams."""
+    cmd, out_dir, poses, stamps, n_frames = make_dataset(tmp_path)
+    rates = {}
+    for n_streams in (1, 4, 8):
+        r = subprocess.run(cmd + [str(n_frames), "8", str(n_streams)], capture_output=True, text=True)
+        print(r.stdout, r.stderr)
+        assert r.returncode == 0, r.stdout + r.stderr
+        dirs = [out_dir] + [out_dir / ("stream%d" % k) for k in range(1, n_streams)]
+        if n_streams == 1:
+            single = open(str(out_dir / "trajectory.txt")).read()
+        for d in dirs:
+            assert open(str(d / "trajectory.txt")).read() == single
+        # steady state (frames 1-2 pay the one-time costs): the streams run side by side throughout, so their rates add
+        rates[n_streams] = sum(1e3 / np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[3:, 7:13].sum(1).mean() for d in dirs)
+    print("steady-state frames/s on one GPU: one stream %.0f, four streams %.0f, eight streams %.0f in total" % (rates[1], rates[4], rates[8]))
+    assert rates[4] > 1.5 * rates[1]

@@ -12,14 +12,24 @@
 // fixed rule (every <kf_every> frames or when fewer than <min_tracked> features survive).
 //
 //   svoh_mini_frontend <dataset_root> <calib.yaml> <params.yaml|-> <out_dir> <T_f_w of frame 0: qw qx qy qz tx ty tz>
-//                      <depth_min> <depth_mean> <depth_max> [max_frames] [kf_every]
+//                      <depth_min> <depth_mean> <depth_max> [max_frames] [kf_every] [n_streams]
 // Writes <out>/trajectory.txt (TUM format, T_world_cam) and <out>/frontend.csv (per-frame counters and timings).
+// n_streams > 1 (independent camera streams need no exchange): that many host threads, each
+// with its own svoh_ctx (own HIP stream) and its own copy of the chain's state, run the same sequence side by side on
+// ONE GPU; stream k > 0 writes into <out>/stream<k>/.  At EuRoC sizes a stream keeps the GPU busy for a small part
+// of its frame time (every stage is a latency-bound round trip), so streams share a GPU almost for free until the
+// host cores or the launch path saturate: the tool prints the aggregate frame rate.
+#include <sys/stat.h>
+
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../svo_pro_universal_amd/host/svo_hip_io.h"
 
@@ -30,21 +40,15 @@ static double now_ms()
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-int main(int argc, char** argv)
+namespace {
+struct StreamResult { size_t n_done = 0, n_kfs = 0; double sum_ms = 0, wall_ms = 0; std::string error; };
+
+// one camera stream through the whole chain; images are decoded beforehand and shared read-only
+void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& images, const std::vector<io::RigCamera>& rig,
+                io::FrontendParams params, const std::string& out_dir, const Transformation& T0, float depth_min, float depth_mean,
+                float depth_max, size_t kf_every, std::atomic<int>* start_gate, int n_streams, StreamResult* out)
 {
-  if (argc < 15) {
-    fprintf(stderr, "usage: %s <dataset_root> <calib.yaml> <params.yaml|-> <out_dir> qw qx qy qz tx ty tz depth_min depth_mean depth_max [max_frames] [kf_every]\n", argv[0]);
-    return 2;
-  }
   try {
-    const io::EurocSequence seq = io::openEuroc(argv[1]);
-    const std::vector<io::RigCamera> rig = io::loadCameraRig(argv[2]);
-    io::FrontendParams params = std::string(argv[3]) == "-" ? io::frontendParamsFromYaml(io::YamlNode()) : io::loadFrontendParams(argv[3]);
-    const std::string out_dir = argv[4];
-    Transformation T0{ { atof(argv[5]), atof(argv[6]), atof(argv[7]), atof(argv[8]) }, { atof(argv[9]), atof(argv[10]), atof(argv[11]) } };
-    const float depth_min = (float)atof(argv[12]), depth_mean = (float)atof(argv[13]), depth_max = (float)atof(argv[14]);
-    const size_t max_frames = argc > 15 ? (size_t)atol(argv[15]) : seq.size();
-    const size_t kf_every = argc > 16 ? (size_t)atol(argv[16]) : 8;
     const size_t min_tracked = 60;
     svoh_ctx* ctx = nullptr;
     if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
@@ -84,10 +88,14 @@ int main(int argc, char** argv)
         kfs.pop_front();
       }
     };
+    // all streams start their first frame together
+    start_gate->fetch_add(1);
+    while (start_gate->load() < n_streams) std::this_thread::yield();
+    const double wall0 = now_ms();
     double sum_ms = 0;
     size_t n_done = 0;
-    for (size_t k = 0; k < seq.size() && k < max_frames; ++k) {
-      const io::GrayImage img = io::readPngGray(seq.cam0_files[k]);
+    for (size_t k = 0; k < images.size(); ++k) {
+      const io::GrayImage& img = images[k];
       const double t0 = now_ms();
       FramePtr frame(new Frame, [ctx](Frame* f) { if (f->pyramid) svoh_release_frame(ctx, f->pyramid); delete f; });
       if (svoh_build_pyramid(ctx, img.data.data(), img.width, img.height, img.width, SVOH_MEM_HOST, params.n_pyr_levels_to_build,
@@ -140,13 +148,60 @@ int main(int argc, char** argv)
       if (k > 0) { sum_ms += t6 - t0; ++n_done; }
       last = frame;
     }
+    out->wall_ms = now_ms() - wall0;
     fclose(fc);
-    printf("svoh_mini_frontend: %zu frames, %.3f ms/frame on the GPU path, %zu keyframes alive\n", n_done + 1, n_done ? sum_ms / n_done : 0.0,
-           kfs.size());
+    out->n_done = n_done; out->sum_ms = sum_ms; out->n_kfs = kfs.size();
     for (const FramePtr& f : kfs) for (auto& sr : f->seed_ref_vec_) sr.keyframe.reset();
     if (last) for (auto& sr : last->seed_ref_vec_) sr.keyframe.reset();
     kfs.clear(); last.reset();
     svoh_destroy(ctx);
+  } catch (const std::exception& e) {
+    out->error = e.what();
+    start_gate->fetch_add(1);   // never leave the other streams waiting at the gate
+  }
+}
+}  // namespace
+
+int main(int argc, char** argv)
+{
+  if (argc < 15) {
+    fprintf(stderr, "usage: %s <dataset_root> <calib.yaml> <params.yaml|-> <out_dir> qw qx qy qz tx ty tz depth_min depth_mean depth_max [max_frames] [kf_every] [n_streams]\n", argv[0]);
+    return 2;
+  }
+  try {
+    const io::EurocSequence seq = io::openEuroc(argv[1]);
+    const std::vector<io::RigCamera> rig = io::loadCameraRig(argv[2]);
+    const io::FrontendParams params = std::string(argv[3]) == "-" ? io::frontendParamsFromYaml(io::YamlNode()) : io::loadFrontendParams(argv[3]);
+    const std::string out_dir = argv[4];
+    const Transformation T0{ { atof(argv[5]), atof(argv[6]), atof(argv[7]), atof(argv[8]) }, { atof(argv[9]), atof(argv[10]), atof(argv[11]) } };
+    const float depth_min = (float)atof(argv[12]), depth_mean = (float)atof(argv[13]), depth_max = (float)atof(argv[14]);
+    const size_t max_frames = argc > 15 ? (size_t)atol(argv[15]) : seq.size();
+    const size_t kf_every = argc > 16 ? (size_t)atol(argv[16]) : 8;
+    const int n_streams = argc > 17 ? atoi(argv[17]) : 1;
+    if (n_streams < 1 || n_streams > 64) throw std::runtime_error("n_streams out of range [1, 64]");
+    std::vector<io::GrayImage> images;
+    for (size_t k = 0; k < seq.size() && k < max_frames; ++k) images.push_back(io::readPngGray(seq.cam0_files[k]));
+    std::vector<StreamResult> results((size_t)n_streams);
+    std::atomic<int> gate(0);
+    std::vector<std::thread> threads;
+    for (int s = 1; s < n_streams; ++s) {
+      const std::string dir = out_dir + "/stream" + std::to_string(s);
+      (void)mkdir(dir.c_str(), 0755);
+      threads.emplace_back(run_stream, std::cref(seq), std::cref(images), std::cref(rig), params, dir, std::cref(T0), depth_min, depth_mean,
+                           depth_max, kf_every, &gate, n_streams, &results[(size_t)s]);
+    }
+    run_stream(seq, images, rig, params, out_dir, T0, depth_min, depth_mean, depth_max, kf_every, &gate, n_streams, &results[0]);
+    for (std::thread& t : threads) t.join();
+    for (const StreamResult& r : results) if (!r.error.empty()) throw std::runtime_error(r.error);
+    printf("svoh_mini_frontend: %zu frames, %.3f ms/frame on the GPU path, %zu keyframes alive\n", results[0].n_done + 1,
+           results[0].n_done ? results[0].sum_ms / results[0].n_done : 0.0, results[0].n_kfs);
+    if (n_streams > 1) {
+      double wall = 0, per_frame = 0;
+      size_t frames = 0;
+      for (const StreamResult& r : results) { wall = r.wall_ms > wall ? r.wall_ms : wall; frames += r.n_done + 1; per_frame += r.n_done ? r.sum_ms / r.n_done : 0.0; }
+      printf("svoh_mini_frontend: %d streams on one GPU: %zu frames in %.1f ms = %.0f frames/s in total, %.3f ms/frame per stream (mean)\n",
+             n_streams, frames, wall, 1e3 * frames / wall, per_frame / n_streams);
+    }
     return 0;
   } catch (const std::exception& e) {
     fprintf(stderr, "svoh_mini_frontend: %s\n", e.what());
