@@ -254,6 +254,18 @@ def test_new_entries_refuse_bad_arguments(gpu_ctx):
     res = (capi.svoh_align_result * 1)()
     assert lib.svoh_sparse_align_fetch_all(h, 1, res) != 0
     assert lib.svoh_context_stats(h, None) != 0
+    # knob / timing calls without a context
+    assert lib.svoh_reload_knobs(None) != 0 and lib.svoh_set_kernel_timing(None, 1) != 0
+    # a knob with a value the launch code does not know is ignored, not obeyed
+    import os
+    os.environ["SVOH_MATCHER_G8"] = "77"; os.environ["SVOH_KLT_BLOCK"] = "-5"
+    try:
+        gpu_ctx.reload_knobs()
+        odd = gpu_ctx.epipolar_match_batch(mopt, [rv], cv, fb, d_inv_common=[1 / dm, 3 / dm, 0.05 / dm])
+        assert np.array_equal(odd["result"], good["result"]) and np.array_equal(odd["depth"], good["depth"])
+    finally:
+        os.environ.pop("SVOH_MATCHER_G8"); os.environ.pop("SVOH_KLT_BLOCK")
+        gpu_ctx.reload_knobs()
     # the context still works
     again = gpu_ctx.epipolar_match_batch(mopt, [rv], cv, fb, d_inv_common=[1 / dm, 3 / dm, 0.05 / dm])
     assert np.array_equal(again["result"], good["result"]) and np.array_equal(again["depth"], good["depth"])
