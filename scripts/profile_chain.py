@@ -1,0 +1,20 @@
+"""rocprofv3 kernel statistics of the per-frame chain (tools/svoh_mini_frontend on the synthetic EuRoC-layout sequence of
+tests/test_mini_frontend_gpu.py): which kernels a frame launches and how long they run.  Writes
+gpurun_out/profiles/<round>_chain_kernel_stats.csv.  Run on the GPU box:  python scripts/profile_chain.py r02"""
+import glob, os, pathlib, shutil, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_mini_frontend_gpu as t
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tmp = pathlib.Path(tempfile.mkdtemp(prefix="chain_", dir="/tmp"))
+cmd, out_dir, poses, stamps, n_frames = t.make_dataset(tmp)
+prof = tmp / "prof"
+env = dict(os.environ, TMPDIR="/tmp")
+# the tool itself directly after `--` (no shell, no env wrapper: the profiler's preload initialises the GPU first)
+subprocess.check_call(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(prof), "--"] + cmd, env=env, cwd="/tmp")
+st = glob.glob(str(prof / "**" / "*kernel_stats.csv"), recursive=True)[0]
+dst = os.path.join(ROOT, "gpurun_out", "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(st, os.path.join(dst, "%s_chain_kernel_stats.csv" % rnd))
+print(open(st).read()[:3000])
