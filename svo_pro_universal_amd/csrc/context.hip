@@ -178,6 +178,106 @@ static hipError_t launch_half_sample(hipStream_t s, const uint8_t* in, size_t in
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Up to four halfSample steps in ONE launch: a workgroup takes a 64x64 tile of the input level, makes the 32x32 tile of
+// the next level from global memory (as half_sample_kernel does: four outputs per thread from 2 x 8 bytes) and the
+// 16x16, 8x8 and 4x4 tiles after it from LDS; every level is written to the slab.  64 is a multiple of 2^4, so a tile
+// needs no neighbour's pixels.  Each step uses its own rounding rule (bit k of sse_mask), as the per-level launches
+// do: same integers.  Three launches less per frame and levels 1..3 are not read back from memory.
+// ---------------------------------------------------------------------------
+struct PyramidArgs {
+  uint8_t* base;           // level 0 of image 0
+  size_t frame_stride;     // bytes between the images of a batch
+  size_t off[5];           // byte offset of level k inside a frame
+  int w[5], h[5];          // level sizes (pitch == width)
+  int n_steps;             // 2..4
+  unsigned sse_mask;       // bit k: step k -> k+1 rounds with the SSE2 rule
+};
+
+__device__ __forceinline__ unsigned half4_rule(bool sse, unsigned a, unsigned b, unsigned c, unsigned d)
+{
+  return sse ? half4<true>(a, b, c, d) : half4<false>(a, b, c, d);
+}
+
+__global__ __launch_bounds__(256) void pyramid_fused_kernel(const PyramidArgs a)
+{
+  __shared__ uint8_t s1[32 * 32], s2[16 * 16], s3[8 * 8];
+  uint8_t* img = a.base + (size_t)blockIdx.z * a.frame_stride;
+  const int t = (int)threadIdx.x;
+  const int x0 = (int)blockIdx.x * 64, y0 = (int)blockIdx.y * 64;   // tile origin at the input level
+  {
+    // step 0: 32x32 outputs, thread t -> row t / 8, columns 4 * (t % 8) .. + 3
+    const bool sse = (a.sse_mask & 1u) != 0;
+    const int r = t >> 3, c4 = (t & 7) * 4;
+    const int gx = x0 / 2 + c4, gy = y0 / 2 + r;
+    const int n = gy < a.h[1] ? min(4, a.w[1] - gx) : 0;
+    if (n > 0) {
+      const uint8_t* top = img + a.off[0] + (size_t)(2 * gy) * a.w[0] + 2 * gx;
+      const uint8_t* bot = top + a.w[0];
+      uint8_t* o = img + a.off[1] + (size_t)gy * a.w[1] + gx;
+      unsigned v[4] = { 0, 0, 0, 0 };
+      if (n == 4 && ((reinterpret_cast<uintptr_t>(top) | reinterpret_cast<uintptr_t>(bot)) & 7) == 0) {
+        const uint2 tt = *reinterpret_cast<const uint2*>(top);
+        const uint2 bb = *reinterpret_cast<const uint2*>(bot);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned tw = (k < 2) ? tt.x : tt.y, bw = (k < 2) ? bb.x : bb.y;
+          const int sh = (k & 1) * 16;
+          v[k] = half4_rule(sse, (tw >> sh) & 0xff, (tw >> (sh + 8)) & 0xff, (bw >> sh) & 0xff, (bw >> (sh + 8)) & 0xff);
+        }
+      } else {
+        for (int k = 0; k < n; ++k) v[k] = half4_rule(sse, top[2 * k], top[2 * k + 1], bot[2 * k], bot[2 * k + 1]);
+      }
+      if (n == 4 && (reinterpret_cast<uintptr_t>(o) & 3) == 0) *reinterpret_cast<unsigned*>(o) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+      else for (int k = 0; k < n; ++k) o[k] = (uint8_t)v[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s1[r * 32 + c4 + k] = (uint8_t)v[k];
+    }
+  }
+  __syncthreads();
+  // steps 1..3 from LDS: a pixel inside its level has both its source rows and columns inside the level below
+  if (a.n_steps >= 2) {
+    const int r = t >> 4, c = t & 15;
+    const int gx = x0 / 4 + c, gy = y0 / 4 + r;
+    if (gx < a.w[2] && gy < a.h[2]) {
+      const uint8_t* p = s1 + (2 * r) * 32 + 2 * c;
+      const unsigned v = half4_rule((a.sse_mask & 2u) != 0, p[0], p[1], p[32], p[33]);
+      s2[r * 16 + c] = (uint8_t)v;
+      img[a.off[2] + (size_t)gy * a.w[2] + gx] = (uint8_t)v;
+    }
+  }
+  __syncthreads();
+  if (a.n_steps >= 3 && t < 64) {
+    const int r = t >> 3, c = t & 7;
+    const int gx = x0 / 8 + c, gy = y0 / 8 + r;
+    if (gx < a.w[3] && gy < a.h[3]) {
+      const uint8_t* p = s2 + (2 * r) * 16 + 2 * c;
+      const unsigned v = half4_rule((a.sse_mask & 4u) != 0, p[0], p[1], p[16], p[17]);
+      s3[r * 8 + c] = (uint8_t)v;
+      img[a.off[3] + (size_t)gy * a.w[3] + gx] = (uint8_t)v;
+    }
+  }
+  __syncthreads();
+  if (a.n_steps >= 4 && t < 16) {
+    const int r = t >> 2, c = t & 3;
+    const int gx = x0 / 16 + c, gy = y0 / 16 + r;
+    if (gx < a.w[4] && gy < a.h[4]) {
+      const uint8_t* p = s3 + (2 * r) * 8 + 2 * c;
+      img[a.off[4] + (size_t)gy * a.w[4] + gx] = (uint8_t)half4_rule((a.sse_mask & 8u) != 0, p[0], p[1], p[8], p[9]);
+    }
+  }
+}
+
+// the rounding rule of one step, and whether it writes the whole next level (see launch_half_sample)
+static bool step_rule(int rounding, int in_w, int in_h, bool* writes_all)
+{
+  bool sse = false;
+  if (rounding == SVOH_HALFSAMPLE_SSE2) sse = true;
+  else if (rounding == SVOH_HALFSAMPLE_REFERENCE) sse = (in_w % 16 == 0);
+  *writes_all = !sse || ((in_w >> 4) * 8 == in_w / 2);
+  return sse;
+}
+
 static uint64_t register_frame(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab, uint8_t* base, int w, int h,
                                int n_levels)
 {
@@ -381,7 +481,27 @@ try {
       SVOH_HIP_TRY(ctx, hipMemcpy2DAsync(base + fbytes * i, (size_t)width, img + image_stride * i, (size_t)pitch,
                                          (size_t)width, (size_t)height, kind, ctx->stream));
   }
-  for (int l = 1; l < n_levels; ++l) {
+  int first_single = 1;   // levels from here on are made one launch each
+  {
+    // the first 2..4 steps as one launch when every one of them writes its whole level
+    const int n_steps = n_levels - 1 < 4 ? n_levels - 1 : 4;
+    PyramidArgs pa{};
+    bool ok = n_steps >= 2;
+    for (int k = 0; ok && k < n_steps; ++k) {
+      bool all = false;
+      if (step_rule(rounding, ws[k], hs[k], &all)) pa.sse_mask |= 1u << k;
+      ok = all;
+    }
+    if (ok) {
+      pa.base = base; pa.frame_stride = fbytes; pa.n_steps = n_steps;
+      for (int k = 0; k <= n_steps; ++k) { pa.off[k] = offs[k]; pa.w[k] = ws[k]; pa.h[k] = hs[k]; }
+      const dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 63) / 64), (unsigned)n_images);
+      hipLaunchKernelGGL(pyramid_fused_kernel, grid, dim3(256), 0, ctx->stream, pa);
+      SVOH_HIP_TRY(ctx, hipGetLastError());
+      first_single = n_steps + 1;
+    }
+  }
+  for (int l = first_single; l < n_levels; ++l) {
     // zero-fill is not needed: every byte of a level the reference would write is written
     SVOH_HIP_TRY(ctx, launch_half_sample(ctx->stream, base + offs[l - 1], fbytes, ws[l - 1], hs[l - 1], ws[l - 1],
                                          base + offs[l], fbytes, ws[l], n_images, rounding));
