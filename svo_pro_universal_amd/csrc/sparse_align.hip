@@ -105,7 +105,7 @@ constexpr int kXchgStride = 64;         // doubles per share and parity (>= 45 +
 #define SVOH_STAMP_START() do { st_t0 = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define SVOH_STAMP_ADD(k) do { long long st_n = (long long)__builtin_amdgcn_s_memtime(); st_acc[k] += st_n - st_t0; st_t0 = st_n; } while (0)
 #define SVOH_STAMP_COUNT(k) do { st_acc[k] += 1; } while (0)
-#define SVOH_STAMP_FLUSH() do { if (threadIdx.x == 0) { st_acc[7] = (long long)__builtin_amdgcn_s_memtime() - st_begin; for (int k_ = 0; k_ < 8; ++k_) a.stamps[pbi * 12 + k_] = st_acc[k_]; for (int k_ = 0; k_ < 4; ++k_) a.stamps[pbi * 12 + 8 + k_] = s.dbg[k_]; } } while (0)
+#define SVOH_STAMP_FLUSH() do { if (threadIdx.x == 0) { st_acc[7] = (long long)__builtin_amdgcn_s_memtime() - st_begin; for (int k_ = 0; k_ < 8; ++k_) a.stamps[pbi * 12 + k_] = st_acc[k_]; for (int k_ = 0; k_ < 4; ++k_) a.stamps[pbi * 12 + 8 + k_] = g_state.dbg[k_]; } } while (0)
 #define SVOH_SERIAL_STAMP(k) do { long long st_n = (long long)__builtin_amdgcn_s_memtime(); s.dbg[k] += st_n - st_s0; st_s0 = st_n; } while (0)
 #else
 #define SVOH_STAMP_DECL
@@ -139,6 +139,13 @@ struct ShState {
   long long dbg[4];   // diagnostic build: cycles of the one-lane step in set-up / solve / update / camera poses
 #endif
 };
+
+// The Gauss-Newton state of the workgroup's problem, the summed normal equations and the visible count live at file
+// scope: the out-of-line one-lane step (gn_serial_step) then addresses them as LDS (ds_read / ds_write) instead of
+// through generic pointers handed to it (flat loads and stores, which wait on both memory counters).
+__shared__ ShState g_state;
+__shared__ double g_sum[45];   // AccLayout<8>::NACC: upper triangle of H, g, chi2
+__shared__ int g_nvis;
 
 // ---- image accessors --------------------------------------------------------
 // LDS=true: the level lives in the workgroup's LDS (address space 3 -> ds_read);
@@ -736,12 +743,13 @@ __device__ __forceinline__ bool cluster_sum(const AlignKernelArgs& a, int prob, 
 template <int P, int D, bool ILLUM>
 __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& a, const DevProblemDesc& pb,
                                                          const DevCamDesc* cams, int n_cams, int pbi, int level,
-                                                         int iter, bool eval_mode, bool reuse_factor, ShState& s,
-                                                         const double* s_sum, int* s_nvis_p)
+                                                         int iter, bool eval_mode, bool reuse_factor)
 {
   constexpr int NH = AccLayout<D>::NH;
   const svoh_align_options& opt = a.opt;
-  int& s_nvis = *s_nvis_p;
+  ShState& s = g_state;
+  const double (&s_sum)[45] = g_sum;
+  int& s_nvis = g_nvis;
 
 #ifdef SVOH_PHASE_STAMPS
     long long st_s0 = (long long)__builtin_amdgcn_s_memtime();
@@ -915,11 +923,9 @@ void sparse_align_kernel(const AlignKernelArgs a)
   extern __shared__ __align__(16) unsigned char lds_img[];
   __shared__ __align__(16) double s_stage[STAGED ? NW * kWsPairs * 128 : 2];
   __shared__ double s_red[NW][NACC];
-  __shared__ double s_sum[NACC];
-  __shared__ int s_nvis;
+  static_assert(NACC <= 45, "g_sum is sized for the 8-parameter case");
   __shared__ double s_x[kXchgStride];   // cluster mode: the block handed to cluster_sum
   __shared__ int s_cluster_ok;
-  __shared__ ShState s;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -943,27 +949,27 @@ void sparse_align_kernel(const AlignKernelArgs a)
   SVOH_STAMP_DECL
   SVOH_STAMP_START();
   if (tid == 0) {
-    s.T = load_rigid(pb.T_init);
-    s.Told = s.T;
-    s.alpha = pb.alpha_init; s.beta = pb.beta_init;
+    g_state.T = load_rigid(pb.T_init);
+    g_state.Told = g_state.T;
+    g_state.alpha = pb.alpha_init; g_state.beta = pb.beta_init;
     if (a.ext_state) {
-      s.T = load_rigid(a.ext_state->T_icur_iref);
-      s.Told = s.T;
-      s.alpha = a.ext_state->alpha; s.beta = a.ext_state->beta;
+      g_state.T = load_rigid(a.ext_state->T_icur_iref);
+      g_state.Told = g_state.T;
+      g_state.alpha = a.ext_state->alpha; g_state.beta = a.ext_state->beta;
     }
-    s.alpha_old = s.alpha; s.beta_old = s.beta;
-    s.stop = 0; s.level_done = 0; s.nsel = 0; s.status = 0; s.patch_iters = 0;
-    for (int k = 0; k < 8; ++k) s.I_prior[k] = 0.0;
-    s_nvis = 0;
-    s.prior = pb.prior;
+    g_state.alpha_old = g_state.alpha; g_state.beta_old = g_state.beta;
+    g_state.stop = 0; g_state.level_done = 0; g_state.nsel = 0; g_state.status = 0; g_state.patch_iters = 0;
+    for (int k = 0; k < 8; ++k) g_state.I_prior[k] = 0.0;
+    g_nvis = 0;
+    g_state.prior = pb.prior;
     for (int c = 0; c < n_cams; ++c) {
-      s.cam_cur_T_cam_imu[c] = load_rigid(cams[c].cur_T_cam_imu);
-      s.cam_ref_T_imu_cam[c] = load_rigid(cams[c].ref_T_imu_cam);
+      g_state.cam_cur_T_cam_imu[c] = load_rigid(cams[c].cur_T_cam_imu);
+      g_state.cam_ref_T_imu_cam[c] = load_rigid(cams[c].ref_T_imu_cam);
     }
 #ifdef SVOH_PHASE_STAMPS
-    for (int k = 0; k < 4; ++k) s.dbg[k] = 0;
+    for (int k = 0; k < 4; ++k) g_state.dbg[k] = 0;
 #endif
-    for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { s.lvl_iters[l] = 0; s.lvl_n_meas[l] = 0; s.lvl_chi2[l] = 0.0; }
+    for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { g_state.lvl_iters[l] = 0; g_state.lvl_n_meas[l] = 0; g_state.lvl_chi2[l] = 0.0; }
   }
   __syncthreads();
 
@@ -1037,7 +1043,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
         }
       }
     }
-    if (my_sel) atomicAdd(&s.nsel, my_sel);
+    if (my_sel) atomicAdd(&g_state.nsel, my_sel);
   }
   __syncthreads();
   SVOH_STAMP_ADD(0);
@@ -1049,7 +1055,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
   const int res_idx = cluster ? (c_share == 0 ? c_prob : a.n_problems / a.cluster + pbi) : pbi;
   unsigned cluster_epoch = 0;
   bool cluster_failed = false;
-  int n_sel = s.nsel;
+  int n_sel = g_state.nsel;
   if (cluster) {   // the number of selected features of the whole problem, not of this share
     if (tid == 0) s_x[0] = (double)n_sel;
     __syncthreads();
@@ -1061,8 +1067,8 @@ void sparse_align_kernel(const AlignKernelArgs a)
     if (tid == 0) {
       svoh_align_result& r = a.results[res_idx];
       r.status = cluster_failed ? 3 : 1; r.n_fts_to_track = 0;
-      store_rigid(s.T, r.T_icur_iref);
-      r.alpha = s.alpha; r.beta = s.beta;
+      store_rigid(g_state.T, r.T_icur_iref);
+      r.alpha = g_state.alpha; r.beta = g_state.beta;
       r.n_patch_iters = 0;
       for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = 0; r.n_meas[l] = 0; r.chi2[l] = 0.0; }
       if (eval_mode) for (int k = 0; k < 74; ++k) a.eval_out[74 * pbi + k] = 0.0;
@@ -1099,18 +1105,18 @@ void sparse_align_kernel(const AlignKernelArgs a)
       }
     }
     if (tid == 0) {
-      s.level_done = 0;
+      g_state.level_done = 0;
       for (int c = 0; c < n_cams; ++c)
-        s.Tcr[c] = mul(mul(s.cam_cur_T_cam_imu[c], s.T), s.cam_ref_T_imu_cam[c]);
-      s.alpha_f = (float)s.alpha; s.beta_f = (float)s.beta;
-      s.Told = s.T; s.alpha_old = s.alpha; s.beta_old = s.beta;  // old_state = state (hpp:45)
+        g_state.Tcr[c] = mul(mul(g_state.cam_cur_T_cam_imu[c], g_state.T), g_state.cam_ref_T_imu_cam[c]);
+      g_state.alpha_f = (float)g_state.alpha; g_state.beta_f = (float)g_state.beta;
+      g_state.Told = g_state.T; g_state.alpha_old = g_state.alpha; g_state.beta_old = g_state.beta;  // old_state = state (hpp:45)
     }
     __syncthreads();
     SVOH_STAMP_ADD(1);
 
     for (int iter = 0; iter < opt.max_iter; ++iter) {
-      const double one_plus_alpha = uniform_f64(1.0 + (double)s.alpha_f);
-      const double beta_d = uniform_f64((double)s.beta_f);
+      const double one_plus_alpha = uniform_f64(1.0 + (double)g_state.alpha_f);
+      const double beta_d = uniform_f64((double)g_state.beta_f);
       // Without robust weights the Hessian of a level only depends on which patches are visible (the Jacobians
       // are the reference patch's: inverse compositional), so after the level's first iteration a pass computes
       // the gradient and chi2 only and the solver reuses the level's factorisation.  A pass that finds a patch
@@ -1126,7 +1132,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
             const DevCamDesc& cd = cams[c];
             const DevImage& rim = cd.ref[level];
             const DevImage& cim = cd.cur[level];
-            const Rigid Tcr = uniform_rigid(s.Tcr[c]);
+            const Rigid Tcr = uniform_rigid(g_state.Tcr[c]);
             if (in_lds) {
               ImgView<true> ref, cur;
               ref.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); ref.pitch = rim.w;
@@ -1176,29 +1182,29 @@ void sparse_align_kernel(const AlignKernelArgs a)
             if (rvalid) s_red[wave][ridx] = accg[0];
           }
           nvis = wave_sum_i32_dpp(nvis);
-          if (lane == 0) atomicAdd(&s_nvis, nvis);
+          if (lane == 0) atomicAdd(&g_nvis, nvis);
           __syncthreads();
-          if (tid < D + 1) {   // gradient and chi2 only: s_sum[0 .. NH) still holds the level's Hessian
+          if (tid < D + 1) {   // gradient and chi2 only: g_sum[0 .. NH) still holds the level's Hessian
             double v = 0.0;
             for (int w = 0; w < NW; ++w) v += s_red[w][tid];
-            s_sum[AccLayout<D>::NH + tid] = v;
+            g_sum[AccLayout<D>::NH + tid] = v;
           }
           __syncthreads();
           if (cluster) {   // gradient, chi2, visible count and the visibility vote of all shares
-            if (tid < D + 1) s_x[tid] = s_sum[AccLayout<D>::NH + tid];
-            if (tid == 0) { s_x[D + 1] = (double)s_nvis; s_x[D + 2] = changed_here ? 1.0 : 0.0; }
+            if (tid < D + 1) s_x[tid] = g_sum[AccLayout<D>::NH + tid];
+            if (tid == 0) { s_x[D + 1] = (double)g_nvis; s_x[D + 2] = changed_here ? 1.0 : 0.0; }
             __syncthreads();
             if (!cluster_sum<NT>(a, c_prob, c_share, cluster_epoch, s_x, D + 3, tid, &s_cluster_ok)) { cluster_failed = true; break; }
             const bool changed_anywhere = s_x[D + 2] != 0.0;
             __syncthreads();
             if (changed_anywhere) {
-              if (tid == 0) s_nvis = 0;
+              if (tid == 0) g_nvis = 0;
               __syncthreads();
               light = false;
               continue;
             }
-            if (tid < D + 1) s_sum[AccLayout<D>::NH + tid] = s_x[tid];
-            if (tid == 0) s_nvis = (int)s_x[D + 1];
+            if (tid < D + 1) g_sum[AccLayout<D>::NH + tid] = s_x[tid];
+            if (tid == 0) g_nvis = (int)s_x[D + 1];
             __syncthreads();
           }
         } else {
@@ -1215,21 +1221,21 @@ void sparse_align_kernel(const AlignKernelArgs a)
             if (rvalid) s_red[wave][ridx] = acc[0];
           }
           nvis = wave_sum_i32_dpp(nvis);
-          if (lane == 0) atomicAdd(&s_nvis, nvis);
+          if (lane == 0) atomicAdd(&g_nvis, nvis);
           __syncthreads();
           if (tid < NACC) {
             double v = 0.0;
             for (int w = 0; w < NW; ++w) v += s_red[w][tid];
-            s_sum[tid] = v;
+            g_sum[tid] = v;
           }
           __syncthreads();
           if (cluster) {
-            if (tid < NACC) s_x[tid] = s_sum[tid];
-            if (tid == 0) s_x[NACC] = (double)s_nvis;
+            if (tid < NACC) s_x[tid] = g_sum[tid];
+            if (tid == 0) s_x[NACC] = (double)g_nvis;
             __syncthreads();
             if (!cluster_sum<NT>(a, c_prob, c_share, cluster_epoch, s_x, NACC + 1, tid, &s_cluster_ok)) { cluster_failed = true; break; }
-            if (tid < NACC) s_sum[tid] = s_x[tid];
-            if (tid == 0) s_nvis = (int)s_x[NACC];
+            if (tid < NACC) g_sum[tid] = s_x[tid];
+            if (tid == 0) g_nvis = (int)s_x[NACC];
             __syncthreads();
           }
         }
@@ -1239,22 +1245,22 @@ void sparse_align_kernel(const AlignKernelArgs a)
 
       SVOH_STAMP_ADD(3);
       // ---- serial part: prior, pivoted LDL^T (or the level's factor again), SE3 update, convergence ----
-      if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, res_idx, level, iter, eval_mode, light, s, s_sum, &s_nvis);
+      if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, res_idx, level, iter, eval_mode, light);
       __syncthreads();
       SVOH_STAMP_ADD(4);
-      if (s.level_done) break;
+      if (g_state.level_done) break;
     }
     if (cluster_failed) break;
   }
 
   if (tid == 0) {
     svoh_align_result& r = a.results[res_idx];
-    r.status = cluster_failed ? 3 : s.status;   // 3: a workgroup of the cluster never arrived (see cluster_sum)
+    r.status = cluster_failed ? 3 : g_state.status;   // 3: a workgroup of the cluster never arrived (see cluster_sum)
     r.n_fts_to_track = n_sel;
-    store_rigid(s.T, r.T_icur_iref);
-    r.alpha = s.alpha; r.beta = s.beta;
-    r.n_patch_iters = s.patch_iters;
-    for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = s.lvl_iters[l]; r.n_meas[l] = s.lvl_n_meas[l]; r.chi2[l] = s.lvl_chi2[l]; }
+    store_rigid(g_state.T, r.T_icur_iref);
+    r.alpha = g_state.alpha; r.beta = g_state.beta;
+    r.n_patch_iters = g_state.patch_iters;
+    for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { r.iters[l] = g_state.lvl_iters[l]; r.n_meas[l] = g_state.lvl_n_meas[l]; r.chi2[l] = g_state.lvl_chi2[l]; }
   }
   SVOH_STAMP_FLUSH();
   }  // next problem
@@ -1283,8 +1289,8 @@ void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_al
 {
   constexpr int D = ILLUM ? 8 : 6;
   constexpr int NH = AccLayout<D>::NH;
-  __shared__ ShState s;
-  __shared__ double s_sum[AccLayout<D>::NACC];
+  ShState& s = g_state;
+  double (&s_sum)[45] = g_sum;
   if (threadIdx.x != 0) return;
   const DevProblemDesc& pb = a.problems[0];
   const DevCamDesc* cams = a.cams + pb.cam_begin;
@@ -1306,13 +1312,13 @@ void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_al
     s_sum[NH + D] = sums[72];
   }
   const int n_meas = (int)sums[73];
-  int nvis = n_meas / (P * P);
+  g_nvis = n_meas / (P * P);
   s.prior = pb.prior;
   for (int c = 0; c < pb.n_cams; ++c) {
     s.cam_cur_T_cam_imu[c] = load_rigid(cams[c].cur_T_cam_imu);
     s.cam_ref_T_imu_cam[c] = load_rigid(cams[c].ref_T_imu_cam);
   }
-  gn_serial_step<P, D, ILLUM>(a, pb, cams, pb.n_cams, 0, level, iter, false, false, s, s_sum, &nvis);
+  gn_serial_step<P, D, ILLUM>(a, pb, cams, pb.n_cams, 0, level, iter, false, false);
   if (level < SVOH_MAX_LEVELS) {
     svoh_align_result& res = a.results[0];
     res.iters[level] = s.lvl_iters[level]; res.n_meas[level] = s.lvl_n_meas[level]; res.chi2[level] = s.lvl_chi2[level];
