@@ -106,4 +106,4 @@ def test_streams_share_one_gpu(tmp_path):
         # steady state (frames 1-2 pay the one-time costs): the streams run side by side throughout, so their rates add
         rates[n_streams] = sum(1e3 / np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[3:, 7:13].sum(1).mean() for d in dirs)
     print("steady-state frames/s on one GPU: one stream %.0f, four streams %.0f, eight streams %.0f in total" % (rates[1], rates[4], rates[8]))
-    assert rates[4] > 1.5 * rates[1]
+    assert rates[4] > 1.2 * rates[1]    # measured 2.3-2.8x (8 streams 3.5-4.6x); the bar only says that streams do overlap
