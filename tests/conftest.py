@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:   # before libsvo_hip is loaded anywhere in the session: one HIP runtime for both (_capi._share_hip_runtime_with_torch),
+    import torch  # noqa: F401  -- and never a first `import torch` in the middle of a GPU test
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
