@@ -465,8 +465,10 @@ int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options,
  * with host arrays are queued on the context's stream without a synchronisation; collect waits once and copies
  * every result to the caller's arrays (which must stay valid until then).  This is how one reprojection
  * (Reprojector::reprojectFrames: landmarks and converged seeds through findMatchDirect, unconverged seeds through
- * updateSeed) costs one round trip instead of one per call.  Device-resident batches are stream-ordered anyway and
- * not affected. */
+ * updateSeed) costs one round trip instead of one per call.  The two queued batches stage through buffers of their
+ * own, so other calls on the context inside the section -- device-resident batches (stream-ordered, they run at
+ * once), svoh_epipolar_match_batch, svoh_detect_features -- are allowed and leave the queued batches intact; a second
+ * host-array batch of a kind already queued fails with "collect first". */
 int svoh_matcher_begin_deferred(svoh_ctx* ctx);
 int svoh_matcher_collect(svoh_ctx* ctx);
 

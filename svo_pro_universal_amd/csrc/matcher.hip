@@ -2228,16 +2228,15 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   }
   const size_t o_nsucc = out_add(sizeof(int32_t));
 
-  // deferred section (svoh_matcher_begin_deferred): no synchronisation here; the seed batch stages through its own
-  // buffers so that a direct batch queued before it is not overwritten while in flight
+  // deferred section (svoh_matcher_begin_deferred): no synchronisation here; each deferred batch stages through
+  // buffers of its own kind, which no other call touches (svoh_internal.h)
   const bool defer = ctx->matcher_deferred && !on_device;
   if (defer) {
     SVOH_REQUIRE(ctx, !ctx->matcher_deferred_used[seeds ? 1 : 0], "one batch of each kind per deferred section: collect first");
     ctx->matcher_deferred_used[seeds ? 1 : 0] = true;
   }
-  PinnedBuffer& hbuf = (defer && seeds) ? ctx->h_match_seeds : ctx->h_scratch1;
-  DevBuffer& dbuf = (defer && seeds) ? ctx->d_match_seeds : ctx->d_scratch1;
-  if (!defer && ctx->matcher_deferred_used[0] && !seeds) SVOH_REQUIRE(ctx, false, "a deferred direct batch is pending: collect first");
+  PinnedBuffer& hbuf = defer ? (seeds ? ctx->h_match_seeds : ctx->h_match_direct) : ctx->h_scratch1;
+  DevBuffer& dbuf = defer ? (seeds ? ctx->d_match_seeds : ctx->d_match_direct) : ctx->d_scratch1;
   SVOH_HIP_TRY(ctx, hbuf.reserve(s.total));
   SVOH_HIP_TRY(ctx, dbuf.reserve(s.total));
   uint8_t* h = static_cast<uint8_t*>(hbuf.ptr);

@@ -63,10 +63,13 @@ struct AlignKernelArgs {
   const DevCamDesc* cams;
   svoh_align_result* results;
   // feature workspace (SoA over all features of all problems)
-  // per-feature workspace, 9 pairs of doubles per slot, pair-major: wpk[(pair * slots + gi) * 2 + {0,1}]
-  //   pair 0 (x, y)  1 (z, u)  2 (v, selected)   xyz_ref (a-4), uv in the reference image (level 0), a-3 flag
-  //   pairs 3..5 jp0[0..5], 6..8 jp1[0..5]       projection Jacobian rows (jacobian_proj_cache_, a-4)
-  // 16 bytes per lane and pair = one global_load_lds_dwordx4 per pair in the staged patch loop
+  // per-feature workspace, 3 pairs of doubles per slot, pair-major: wpk[(pair * slots + gi) * 2 + {0,1}]
+  //   pair 0 (x, y)  1 (z, u)  2 (v, state)   xyz_ref (a-4), uv in the reference image (level 0);
+  //   state: 0 not selected by a-3, 1 selected, 2 selected and visible in the last full pass
+  // 16 bytes per lane and pair = one global_load_lds_dwordx4 per pair in the staged patch loop.  The rows of the
+  // projection Jacobian (jacobian_proj_cache_, a-4: 96 bytes per feature) are NOT kept: every patch-iteration
+  // rebuilds them from xyz_ref (jac_rows below) -- ~50 fp64 operations against two thirds of the kernel's HBM-side
+  // traffic in round 2 (3.85 of 5.27 GB per 1024 x 2000 launch were these rows read again every iteration)
   double* wpk;
   int64_t slots;                        // stride of the SoA arrays
   uint8_t* wsel;                        // selected by extractFeaturesSubset (a-3)
@@ -214,41 +217,54 @@ __device__ __forceinline__ float tukey_weight(float e)
   return 0.0f;
 }
 
-// Frame::jacobian_xyz2uv_imu (frame.h:342-357) times focal length, or
-// Frame::jacobian_xyz2image_imu (frame.cpp:274-290) times -1
-// (sparse_img_align.cpp:298-309).  jp0 = row 0 (du), jp1 = row 1 (dv).
-__device__ __forceinline__ void projection_jacobian(const Vec3& xyz_ref, const Rigid& T_imu_cam,
-                                                    const Rigid& T_cam_imu, const double* R /*row-major*/,
-                                                    const CamModel& cm, bool use_distortion_jac,
-                                                    double jp0[6], double jp1[6])
+// Per-camera constants of the Jacobian rows, in LDS for the problem's life (21 doubles per camera):
+//   [0..9) R_imu_cam row-major, [9..12) t_imu_cam, [12..21) R_cam_imu row-major
+constexpr int kJacConsts = 24;
+
+// Rows of the projection Jacobian of one feature, scaled to the pyramid level:
+//   a = jp0 * scale, b = jp1 * scale with (jp0; jp1) = Frame::jacobian_xyz2uv_imu (frame.h:342-357) times the focal
+//   length, or Frame::jacobian_xyz2image_imu (frame.cpp:274-290) times -1 (sparse_img_align.cpp:298-309).
+// The reference keeps them per feature (jacobian_proj_cache_); here they are rebuilt from xyz_ref in every
+// patch-iteration (see AlignKernelArgs::wpk).  p_in_cam of the reference is T_cam_imu * (T_imu_cam * xyz_ref):
+// xyz_ref itself up to rounding (the two transformations of a frame are inverses of each other), which is what is
+// used; -x/z is taken as -x * (1/z).  Both are last-bit differences, inside the stated tolerance of H and g.
+__device__ __forceinline__ void jac_rows(const double* jc, const CamModel& cm, bool use_distortion_jac, const Vec3& X,
+                                         double scale, double (&a)[6], double (&b)[6])
 {
-  const Vec3 p = transform(T_imu_cam, xyz_ref);  // xyz_in_imu
-  const Vec3 pc = transform(T_cam_imu, p);       // p_in_cam
-  double A[6];
-  if (!use_distortion_jac) {
-    const double s = -1.0 / pc.z;
-    const double jx = -pc.x / pc.z, jy = -pc.y / pc.z;
-    A[0] = s * 1.0; A[1] = s * 0.0; A[2] = s * jx;
-    A[3] = s * 0.0; A[4] = s * 1.0; A[5] = s * jy;
-  } else {
-    project3_jacobian(cm, pc, A);
-  }
+  // xyz_in_imu = T_imu_cam * xyz_ref
+  const Vec3 p = { jc[0] * X.x + jc[1] * X.y + jc[2] * X.z + jc[9], jc[3] * X.x + jc[4] * X.y + jc[5] * X.z + jc[10],
+                   jc[6] * X.x + jc[7] * X.y + jc[8] * X.z + jc[11] };
+  const double* R = jc + 12;
   double B[6];
+  if (!use_distortion_jac) {
+    // A = -(1/z) [1 0 -x/z; 0 1 -y/z] * |fx| * scale  (the two zeros are not multiplied out)
+    const double rz = 1.0 / X.z;
+    const double sm = -rz * (fabs(cm.fx) * scale);
+    const double a2 = sm * (-X.x * rz), a5 = sm * (-X.y * rz);
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+    for (int c = 0; c < 3; ++c) {
+      B[c] = sm * R[c] + a2 * R[6 + c];
+      B[3 + c] = sm * R[3 + c] + a5 * R[6 + c];
+    }
+  } else {
+    double A[6];
+    project3_jacobian(cm, X, A);
+    const double m = -scale;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-      B[r * 3 + c] = A[r * 3 + 0] * R[c] + A[r * 3 + 1] * R[3 + c] + A[r * 3 + 2] * R[6 + c];
-  const double m = use_distortion_jac ? -1.0 : fabs(cm.fx);
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        B[r * 3 + c] = (A[r * 3 + 0] * R[c] + A[r * 3 + 1] * R[3 + c] + A[r * 3 + 2] * R[6 + c]) * m;
+  }
   // G_x = [I, -skew(p)]
-  jp0[0] = B[0] * m; jp0[1] = B[1] * m; jp0[2] = B[2] * m;
-  jp0[3] = (B[1] * (-p.z) + B[2] * p.y) * m;
-  jp0[4] = (B[0] * p.z + B[2] * (-p.x)) * m;
-  jp0[5] = (B[0] * (-p.y) + B[1] * p.x) * m;
-  jp1[0] = B[3] * m; jp1[1] = B[4] * m; jp1[2] = B[5] * m;
-  jp1[3] = (B[4] * (-p.z) + B[5] * p.y) * m;
-  jp1[4] = (B[3] * p.z + B[5] * (-p.x)) * m;
-  jp1[5] = (B[3] * (-p.y) + B[4] * p.x) * m;
+  a[0] = B[0]; a[1] = B[1]; a[2] = B[2];
+  a[3] = B[1] * (-p.z) + B[2] * p.y;
+  a[4] = B[0] * p.z + B[2] * (-p.x);
+  a[5] = B[0] * (-p.y) + B[1] * p.x;
+  b[0] = B[3]; b[1] = B[4]; b[2] = B[5];
+  b[3] = B[4] * (-p.z) + B[5] * p.y;
+  b[4] = B[3] * p.z + B[5] * (-p.x);
+  b[5] = B[3] * (-p.y) + B[4] * p.x;
 }
 
 // One patch, pixel part: interpolated reference patch with border and its
@@ -437,17 +453,16 @@ __device__ __forceinline__ void patch_moments(
 }
 
 // Apply the patch's linear map to its moments: acc += (H upper triangle, g, chi2).
+// a = jp0 * scale, b = jp1 * scale (scale is a power of two: (dx*jp0+dy*jp1)*scale == dx*a+dy*b exactly)
 template <int D>
-__device__ __forceinline__ void accumulate_patch(const double (&mom)[AccLayout<D>::NMOM], const double jp0[6],
-                                                 const double jp1[6], double scale, bool est_alpha, bool est_beta,
+__device__ __forceinline__ void accumulate_patch(const double (&mom)[AccLayout<D>::NMOM], const double (&a)[6],
+                                                 const double (&b)[6], bool est_alpha, bool est_beta,
                                                  double (&acc)[AccLayout<D>::NACC])
 {
   constexpr int NH = AccLayout<D>::NH;
-  double a[6], b[6], u[6], v[6];
+  double u[6], v[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    a[k] = jp0[k] * scale;  // scale is a power of two: (dx*jp0+dy*jp1)*scale == dx*a+dy*b exactly
-    b[k] = jp1[k] * scale;
     u[k] = mom[0] * a[k] + mom[1] * b[k];
     v[k] = mom[1] * a[k] + mom[2] * b[k];
   }
@@ -483,12 +498,12 @@ __device__ __forceinline__ void accumulate_patch(const double (&mom)[AccLayout<D
 
 // Gradient-only form of the above for the iterations that reuse the level's Hessian: accg = (g[0..D), chi2).
 template <int D>
-__device__ __forceinline__ void accumulate_patch_gradient(const double (&mom)[AccLayout<D>::NMOM], const double jp0[6],
-                                                          const double jp1[6], double scale, bool est_alpha, bool est_beta,
+__device__ __forceinline__ void accumulate_patch_gradient(const double (&mom)[AccLayout<D>::NMOM], const double (&a)[6],
+                                                          const double (&b)[6], bool est_alpha, bool est_beta,
                                                           double (&accg)[D + 1])
 {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) accg[i] -= (jp0[i] * scale) * mom[3] + (jp1[i] * scale) * mom[4];
+  for (int i = 0; i < 6; ++i) accg[i] -= a[i] * mom[3] + b[i] * mom[4];
   if constexpr (D == 8) {
     if (est_alpha) accg[6] += mom[13];
     if (est_beta) accg[7] += mom[14];
@@ -538,18 +553,19 @@ __device__ __forceinline__ Rigid uniform_rigid(const Rigid& T)
   return r;
 }
 
-constexpr int kWsPairs = 9;
+constexpr int kWsPairs = 3;
 __device__ __forceinline__ double* ws_pair(const AlignKernelArgs& a, int pair, int64_t gi) { return a.wpk + ((int64_t)pair * a.slots + gi) * 2; }
 
 // All patches of one camera at one Gauss-Newton iteration: one thread per patch.
 // GONLY (see patch_moments): accumulate the gradient and chi2 only and report in `changed` whether any patch's
-// visibility differs from the one recorded by the last full pass (a.wvis) -- the caller then repeats the
-// iteration with a full pass.  A full pass records the visibility.
+// visibility differs from the one recorded by the last full pass (the state value of its workspace row) -- the
+// caller then repeats the iteration with a full pass.  A full pass records the visibility.
+// jc: the camera's kJacConsts block (LDS).
 template <int P, int D, int NT, bool LDS, bool GONLY = false>
 __device__ __forceinline__ void accumulate_camera(
     const AlignKernelArgs& a, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
-    bool robust, bool dist_jac, float weight_scale, int tid,
+    bool robust, bool dist_jac, float weight_scale, int tid, const double* jc,
     double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed)
 {
   const CamModel cm = load_camera(cd.cam);
@@ -558,7 +574,8 @@ __device__ __forceinline__ void accumulate_camera(
 
   for (int i = tid; i < cd.n_features; i += NT) {
     const int gi = cd.feat_off + i;
-    if (!a.wsel[gi]) continue;
+    const double2 vs = *reinterpret_cast<const double2*>(ws_pair(a, 2, gi));
+    if (vs.y == 0.0) continue;
     const double2 xy = *reinterpret_cast<const double2*>(ws_pair(a, 0, gi));
     const double2 zu = *reinterpret_cast<const double2*>(ws_pair(a, 1, gi));
     const Vec3 X = { xy.x, xy.y, zu.x };
@@ -580,43 +597,41 @@ __device__ __forceinline__ void accumulate_camera(
         csu = u_tl - cu; csv = v_tl - cv;
       }
     }
-    if constexpr (GONLY) changed |= (int)(a.wvis[gi] != (vis ? 1 : 0));
-    else a.wvis[gi] = vis ? 1 : 0;
+    if constexpr (GONLY) changed |= (int)((vs.y == 2.0) != vis);
+    else {
+      ws_pair(a, 2, gi)[1] = vis ? 2.0 : 1.0;
+      if (a.eval_level >= 0) a.wvis[gi] = vis ? 1 : 0;   // svoh_sparse_align_evaluate hands the mask out
+    }
     if (!vis) continue;
     ++nvis;
     // ---- a-5 reference side (recomputed, never stored) ----
     const double ru_tl = zu.y * scale - patch_center_wb;
-    const double rv_tl = ws_pair(a, 2, gi)[0] * scale - patch_center_wb;
+    const double rv_tl = vs.x * scale - patch_center_wb;
     const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
     const double rsu = ru_tl - ru, rsv = rv_tl - rv;
     double mom[AccLayout<D>::NMOM];
     patch_moments<P, D, LDS, LDS, GONLY>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d, robust,
                                          weight_scale, mom);
-    double jp0[6], jp1[6];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double2 q0 = *reinterpret_cast<const double2*>(ws_pair(a, 3 + k, gi));
-      const double2 q1 = *reinterpret_cast<const double2*>(ws_pair(a, 6 + k, gi));
-      jp0[2 * k] = q0.x; jp0[2 * k + 1] = q0.y;
-      jp1[2 * k] = q1.x; jp1[2 * k + 1] = q1.y;
-    }
-    if constexpr (GONLY) accumulate_patch_gradient<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
-    else accumulate_patch<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
+    double ja[6], jb[6];
+    jac_rows(jc, cm, dist_jac, X, scale, ja, jb);
+    if constexpr (GONLY) accumulate_patch_gradient<D>(mom, ja, jb, est_alpha, est_beta, acc);
+    else accumulate_patch<D>(mom, ja, jb, est_alpha, est_beta, acc);
   }
 }
 
-// The same loop with the workspace row of every patch brought in by LDS-DMA (global_load_lds_dwordx4:
-// 16 bytes per lane straight into LDS, no VGPR and no wait at issue).  Without it the loads of a patch sit on
-// its critical path twice: xyz / uv before the projection can start, the twelve Jacobian entries before the
-// accumulation -- a round trip to L2 / Infinity Cache each, with only two waves per SIMD to hide it.  Here
-// the head (pairs 0..2) of the NEXT patch and the Jacobian rows (pairs 3..8) of THIS patch are requested right
-// after this patch's head has been read, and both arrive while the pixel loop runs.
-// stage: this wave's 9 x 64 x 16 B staging area.  Control flow is wave-uniform (every lane runs every pass).
+// The same loop with the workspace row of every patch (48 bytes: xyz_ref, uv, state) brought in by LDS-DMA
+// (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no VGPR and no wait at issue).  Without it the
+// row's load sits on the patch's critical path: a round trip to L2 / Infinity Cache before the projection can
+// start, with only two waves per SIMD to hide it.  Here the row of the NEXT patch is requested right after this
+// patch's has been read and arrives while the pixel loop runs.  Two buffers per wave: xyz_ref is read again
+// behind the pixel loop for the Jacobian rows (three doubles that need not stay in registers through it).
+// stage: this wave's 2 x 3 x 64 x 16 B staging area.  Control flow is wave-uniform (every lane runs every pass).
+constexpr int kStageDoubles = 2 * kWsPairs * 128;
 template <int P, int D, int NT, bool LDS, bool GONLY = false>
 __device__ __forceinline__ void accumulate_camera_staged(
     const AlignKernelArgs& a, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
-    bool robust, bool dist_jac, float weight_scale, int tid, double* stage,
+    bool robust, bool dist_jac, float weight_scale, int tid, double* stage, const double* jc,
     double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed)
 {
   typedef const __attribute__((address_space(1))) void* gptr;
@@ -627,27 +642,24 @@ __device__ __forceinline__ void accumulate_camera_staged(
   const int lane = tid & 63;
   const int n = cd.n_features;
   const int n_round = (n + NT - 1) / NT * NT;
-  auto request = [&](int pair_lo, int pair_hi, int64_t gi) {
+  auto request = [&](double* buf, int64_t gi) {
 #pragma unroll
-    for (int pr = pair_lo; pr < pair_hi; ++pr)
-      __builtin_amdgcn_global_load_lds((gptr)ws_pair(a, pr, gi), (lptr)(stage + pr * 128), 16, 0, 0);
+    for (int pr = 0; pr < kWsPairs; ++pr)
+      __builtin_amdgcn_global_load_lds((gptr)ws_pair(a, pr, gi), (lptr)(buf + pr * 128), 16, 0, 0);
   };
-  if (tid < n) request(0, 3, cd.feat_off + tid);
-  for (int i = tid; i < n_round; i += NT) {
+  if (tid < n) request(stage, cd.feat_off + tid);
+  int which = 0;
+  for (int i = tid; i < n_round; i += NT, which ^= 1) {
     const int64_t gi = cd.feat_off + i;
     const bool in_range = i < n;
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this pass's head has landed in LDS
-    const double2 xy = *reinterpret_cast<const double2*>(stage + 0 * 128 + lane * 2);
-    const double2 zu = *reinterpret_cast<const double2*>(stage + 1 * 128 + lane * 2);
-    const double2 vs = *reinterpret_cast<const double2*>(stage + 2 * 128 + lane * 2);
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the head is in registers before its buffer is requested again
-    if (i + NT < n) request(0, 3, gi + NT);
+    double* buf = stage + which * (kWsPairs * 128);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this pass's row has landed in LDS
+    const double2 xy = *reinterpret_cast<const double2*>(buf + 0 * 128 + lane * 2);
+    const double2 zu = *reinterpret_cast<const double2*>(buf + 1 * 128 + lane * 2);
+    const double2 vs = *reinterpret_cast<const double2*>(buf + 2 * 128 + lane * 2);
+    // the other buffer: its last readers (the previous pass's Jacobian rows) are done -- lgkmcnt(0) at the loop's end
+    if (i + NT < n) request(stage + (which ^ 1) * (kWsPairs * 128), gi + NT);
     const bool sel = in_range && vs.y != 0.0;
-    if (sel) request(3, kWsPairs, gi);
-    // visibility recorded by the last full pass: requested here, compared after the pixel loop (a use any earlier
-    // would wait for the Jacobian rows as well -- the vector memory counter is shared)
-    unsigned vis_recorded = 0;
-    if constexpr (GONLY) { if (sel) vis_recorded = a.wvis[gi]; }
     bool vis = false;
     double mom[AccLayout<D>::NMOM];
     if (sel) {
@@ -669,7 +681,11 @@ __device__ __forceinline__ void accumulate_camera_staged(
           csu = u_tl - cu; csv = v_tl - cv;
         }
       }
-      if constexpr (!GONLY) a.wvis[gi] = vis ? 1 : 0;
+      if constexpr (GONLY) changed |= (int)((vs.y == 2.0) != vis);
+      else {
+        ws_pair(a, 2, gi)[1] = vis ? 2.0 : 1.0;
+        if (a.eval_level >= 0) a.wvis[gi] = vis ? 1 : 0;
+      }
       if (vis) {
         ++nvis;
         const double ru_tl = zu.y * scale - patch_center_wb;
@@ -680,21 +696,17 @@ __device__ __forceinline__ void accumulate_camera_staged(
                                              robust, weight_scale, mom);
       }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the Jacobian rows (requested before the pixel loop) are in LDS
-    if constexpr (GONLY) { if (sel) changed |= (int)(vis_recorded != (vis ? 1u : 0u)); }
     if (vis) {
-      double jp0[6], jp1[6];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double2 q0 = *reinterpret_cast<const double2*>(stage + (3 + k) * 128 + lane * 2);
-        const double2 q1 = *reinterpret_cast<const double2*>(stage + (6 + k) * 128 + lane * 2);
-        jp0[2 * k] = q0.x; jp0[2 * k + 1] = q0.y;
-        jp1[2 * k] = q1.x; jp1[2 * k + 1] = q1.y;
-      }
-      if constexpr (GONLY) accumulate_patch_gradient<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
-      else accumulate_patch<D>(mom, jp0, jp1, scale, est_alpha, est_beta, acc);
+      asm volatile("" ::: "memory");   // xyz_ref comes from LDS again here instead of living through the pixel loop
+      const double2 xy2 = *reinterpret_cast<const double2*>(buf + 0 * 128 + lane * 2);
+      const double z2 = buf[1 * 128 + lane * 2];
+      const Vec3 X = { xy2.x, xy2.y, z2 };
+      double ja[6], jb[6];
+      jac_rows(jc, cm, dist_jac, X, scale, ja, jb);
+      if constexpr (GONLY) accumulate_patch_gradient<D>(mom, ja, jb, est_alpha, est_beta, acc);
+      else accumulate_patch<D>(mom, ja, jb, est_alpha, est_beta, acc);
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) before the next pass may request the Jacobian buffer again
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) before the next pass may request this buffer again
   }
 }
 
@@ -921,7 +933,8 @@ void sparse_align_kernel(const AlignKernelArgs a)
   // geometries keep their LDS for finer image levels and read the workspace with ordinary loads
   constexpr bool STAGED = SVOH_ALIGN_STAGED && NT == 256;
   extern __shared__ __align__(16) unsigned char lds_img[];
-  __shared__ __align__(16) double s_stage[STAGED ? NW * kWsPairs * 128 : 2];
+  __shared__ __align__(16) double s_stage[STAGED ? NW * kStageDoubles : 2];
+  __shared__ double s_jc[SVOH_MAX_CAMS][kJacConsts];   // per-camera constants of jac_rows
   __shared__ double s_red[NW][NACC];
   static_assert(NACC <= 45, "g_sum is sized for the 8-parameter case");
   __shared__ double s_x[kXchgStride];   // cluster mode: the block handed to cluster_sum
@@ -965,6 +978,10 @@ void sparse_align_kernel(const AlignKernelArgs a)
     for (int c = 0; c < n_cams; ++c) {
       g_state.cam_cur_T_cam_imu[c] = load_rigid(cams[c].cur_T_cam_imu);
       g_state.cam_ref_T_imu_cam[c] = load_rigid(cams[c].ref_T_imu_cam);
+      to_matrix(g_state.cam_ref_T_imu_cam[c].q, &s_jc[c][0]);
+      s_jc[c][9] = g_state.cam_ref_T_imu_cam[c].t.x; s_jc[c][10] = g_state.cam_ref_T_imu_cam[c].t.y;
+      s_jc[c][11] = g_state.cam_ref_T_imu_cam[c].t.z;
+      to_matrix(load_rigid(cams[c].ref_T_cam_imu).q, &s_jc[c][12]);
     }
 #ifdef SVOH_PHASE_STAMPS
     for (int k = 0; k < 4; ++k) g_state.dbg[k] = 0;
@@ -983,15 +1000,8 @@ void sparse_align_kernel(const AlignKernelArgs a)
       const DevCamDesc& cd = cams[c];
       const int rows_minus_two = cd.ref[opt.max_level].h - 2;
       const int cols_minus_two = cd.ref[opt.max_level].w - 2;
-      const CamModel cm0 = load_camera(cd.cam);
-      const Rigid T_imu_cam0 = load_rigid(cd.ref_T_imu_cam);
-      const Rigid T_cam_imu0 = load_rigid(cd.ref_T_cam_imu);
-      double R0[9];
-      to_matrix(T_cam_imu0.q, R0);
-      const bool dist_jac0 = opt.use_distortion_jacobian != 0;
       // all of a feature's inputs are requested together (they are independent; behind the selection test each
-      // would be its own round trip to memory), and one feature ahead: the next feature's nine values travel while
-      // this one's Jacobians are computed
+      // would be its own round trip to memory), and one feature ahead
       struct FeatIn { double pu, pv, pwx, pwy, pwz, fx, fy, fz; unsigned flag; };
       auto request = [&](int k, FeatIn& o) {
         o.flag = cd.flags[k];
@@ -1032,13 +1042,6 @@ void sparse_align_kernel(const AlignKernelArgs a)
           *reinterpret_cast<double2*>(ws_pair(a, 0, gi)) = make_double2(X.x, X.y);
           *reinterpret_cast<double2*>(ws_pair(a, 1, gi)) = make_double2(X.z, pu);
           *reinterpret_cast<double2*>(ws_pair(a, 2, gi)) = make_double2(pv, 1.0);
-          double jp0[6], jp1[6];
-          projection_jacobian(X, T_imu_cam0, T_cam_imu0, R0, cm0, dist_jac0, jp0, jp1);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            *reinterpret_cast<double2*>(ws_pair(a, 3 + k, gi)) = make_double2(jp0[2 * k], jp0[2 * k + 1]);
-            *reinterpret_cast<double2*>(ws_pair(a, 6 + k, gi)) = make_double2(jp1[2 * k], jp1[2 * k + 1]);
-          }
           ++my_sel;
         }
       }
@@ -1142,11 +1145,11 @@ void sparse_align_kernel(const AlignKernelArgs a)
               if constexpr (STAGED)
                 accumulate_camera_staged<P, D, NT, true, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                             est_alpha, est_beta, robust, dist_jac, weight_scale, tid,
-                                                            s_stage + wave * kWsPairs * 128, acc_ref, nvis, changed);
+                                                            s_stage + wave * kStageDoubles, s_jc[c], acc_ref, nvis, changed);
               else
                 accumulate_camera<P, D, NT, true, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                                     est_alpha, est_beta, robust, dist_jac, weight_scale, tid, acc_ref, nvis,
-                                                     changed);
+                                                     est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c], acc_ref,
+                                                     nvis, changed);
             } else {
               ImgView<false> ref, cur;
               ref.p = rim.data; ref.pitch = rim.pitch;
@@ -1154,11 +1157,11 @@ void sparse_align_kernel(const AlignKernelArgs a)
               if constexpr (STAGED)
                 accumulate_camera_staged<P, D, NT, false, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                              est_alpha, est_beta, robust, dist_jac, weight_scale, tid,
-                                                             s_stage + wave * kWsPairs * 128, acc_ref, nvis, changed);
+                                                             s_stage + wave * kStageDoubles, s_jc[c], acc_ref, nvis, changed);
               else
                 accumulate_camera<P, D, NT, false, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                                      est_alpha, est_beta, robust, dist_jac, weight_scale, tid, acc_ref, nvis,
-                                                      changed);
+                                                      est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c], acc_ref,
+                                                      nvis, changed);
             }
           }
         };

@@ -151,8 +151,11 @@ struct svoh_ctx {
     bool valid = false;
     void* d2h_dst = nullptr; const void* d2h_src = nullptr; size_t d2h_bytes = 0;
   } matcher_deferred_launch[2];
-  svoh::DevBuffer d_match_seeds;       // staging of the deferred seed batch (the direct one keeps d_scratch1)
-  svoh::PinnedBuffer h_match_seeds;
+  // staging of the deferred batches, one pair per kind: nothing else stages through them, so any other call made
+  // inside the section (a device-resident batch, an epipolar batch, the detector -- all on d_scratch1 / h_scratch1)
+  // can neither overwrite a queued batch's inputs before its copy has read them nor make reserve() free them
+  svoh::DevBuffer d_match_seeds, d_match_direct;
+  svoh::PinnedBuffer h_match_seeds, h_match_direct;
 
   svoh::DevBuffer d_seed_bin;          // packed seed update: histogram, ranks, sorted records (nothing else writes here)
   void* seed_hist_ptr = nullptr;       // the binning histogram at this address ...

@@ -269,3 +269,72 @@ def test_new_entries_refuse_bad_arguments(gpu_ctx):
     # the context still works
     again = gpu_ctx.epipolar_match_batch(mopt, [rv], cv, fb, d_inv_common=[1 / dm, 3 / dm, 0.05 / dm])
     assert np.array_equal(again["result"], good["result"]) and np.array_equal(again["depth"], good["depth"])
+
+
+def test_deferred_section_survives_other_calls(gpu_ctx):
+    """Between svoh_matcher_begin_deferred and svoh_matcher_collect the two queued host batches stage through buffers
+    of their own: an epipolar batch (larger than anything staged before, so the shared scratch is re-allocated), a
+    detector call and a device-resident seed batch made inside the section leave them intact (round-2 advisor finding:
+    they used to share the pinned / device scratch of the queued direct batch)."""
+    import ctypes as C
+    import torch
+    lib, h = gpu_ctx.lib, gpu_ctx.h
+    sc = synth.make_align_scene(311, n_features=8, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+    sd = synth.make_seed_set(sc, 300)
+    big = synth.make_seed_set(sc, 6000, seed=5)
+    rv = fe.make_frame_view(fr, sc.cam, sc.T_ref_f_w, float(sd["mu_range"]), 1)
+    cv = fe.make_frame_view(fc, sc.cam, sc.T_cur_f_w_gt, 0.0, 2)
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(sc.cam)
+    ftype = np.where(sd["type"] == 0, capi.FT_EDGELET, capi.FT_CORNER).astype(np.uint8)
+    x = sd["f"].reshape(-1, 3).T * sd["true_depth"]
+    px_true = sc.cam.project(sc.T_w_cur.inverse().transform(sc.T_w_ref.transform(x)))
+    px_init = np.ascontiguousarray((px_true + 1.0).T).ravel()
+    fb, kk = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+    fbs, ks = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+    # the answers, call by call
+    want_d = gpu_ctx.match_direct_batch(mopt, [rv], cv, fb, sd["true_depth"], px_init)
+    want_s = gpu_ctx.update_seeds_batch(mopt, dopt, [rv], cv, fbs, sd["state"])
+    bt = np.where(big["type"] == 0, capi.FT_EDGELET, capi.FT_CORNER).astype(np.uint8)
+    fbb, kb = fe.make_feature_batch(big["ref_frame_idx"], big["px"], big["f"], big["grad"], big["level"], bt)
+    dm = float(np.median(big["true_depth"]))
+    mopt500 = capi.default_matcher_options(max_epi_search_steps=500)
+    want_e = gpu_ctx.epipolar_match_batch(mopt500, [rv], cv, fbb, d_inv_common=[1 / dm, 3 / dm, 0.05 / dm])
+    # the same inside ONE deferred section, with the other calls in between
+    n = fb.n
+    rva = (capi.svoh_frame_view * 1)(rv)
+    got_d = dict(px_cur=px_init.copy(), result=np.zeros(n, np.int32), f_cur=np.zeros(3 * n), search_level=np.zeros(n, np.int32),
+                 h_inv=np.zeros(n), A=np.zeros(4 * n))
+    depth = np.ascontiguousarray(sd["true_depth"], np.float64)
+    st = np.ascontiguousarray(sd["state"], np.float64).copy()
+    succ, mr, ns = np.zeros(n, np.uint8), np.zeros(n, np.int32), C.c_int32()
+    assert lib.svoh_matcher_begin_deferred(h) == 0
+    try:
+        assert lib.svoh_match_direct_batch(h, C.byref(mopt), 1, rva, C.byref(cv), C.byref(fb), depth.ctypes.data,
+                                           got_d["px_cur"].ctypes.data, got_d["result"].ctypes.data, got_d["f_cur"].ctypes.data,
+                                           got_d["search_level"].ctypes.data, got_d["h_inv"].ctypes.data, got_d["A"].ctypes.data) == 0
+        assert lib.svoh_update_seeds_batch(h, C.byref(mopt), C.byref(dopt), 1, rva, C.byref(cv), C.byref(fbs), st.ctypes.data,
+                                           succ.ctypes.data, mr.ctypes.data, C.byref(ns)) == 0
+        # a second host batch of a kind that is queued is refused
+        assert lib.svoh_match_direct_batch(h, C.byref(mopt), 1, rva, C.byref(cv), C.byref(fb), depth.ctypes.data,
+                                           got_d["px_cur"].ctypes.data, got_d["result"].ctypes.data, None, None, None, None) != 0
+        got_e = gpu_ctx.epipolar_match_batch(mopt500, [rv], cv, fbb, d_inv_common=[1 / dm, 3 / dm, 0.05 / dm])
+        gpu_ctx.detect_features(capi.default_detector_options(), fr, sc.cam.width, sc.cam.height)
+        # a device-resident seed batch runs at once (stream order) and stages its views through the shared scratch
+        dev = torch.device("cuda", 0)
+        t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in
+             dict(idx=sd["ref_frame_idx"].astype(np.int32), px=sd["px"], f=sd["f"], grad=sd["grad"], level=sd["level"].astype(np.int32),
+                  type=sd["type"].astype(np.uint8), state=sd["state"].astype(np.float64)).items()}
+        d_succ = torch.zeros(n, dtype=torch.uint8, device=dev)
+        fbd = fe.make_feature_batch_device(n, t["idx"].data_ptr(), t["px"].data_ptr(), t["f"].data_ptr(), t["grad"].data_ptr(),
+                                           t["level"].data_ptr(), t["type"].data_ptr())
+        gpu_ctx.update_seeds_device(mopt, dopt, [rv], [cv], fbd, t["state"].data_ptr(), d_succ.data_ptr())
+    finally:
+        assert lib.svoh_matcher_collect(h) == 0
+    gpu_ctx.synchronize()
+    for k in want_d:
+        assert np.array_equal(want_d[k], got_d[k]), k
+    assert ns.value == want_s[0] and np.array_equal(st, want_s[1]) and np.array_equal(succ, want_s[2]) and np.array_equal(mr, want_s[3])
+    for k in want_e:
+        assert np.array_equal(want_e[k], got_e[k]), k
+    assert np.array_equal(t["state"].cpu().numpy(), want_s[1]) and np.array_equal(d_succ.cpu().numpy(), want_s[2])
