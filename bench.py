@@ -74,7 +74,10 @@ def roofline(kernel, kernel_ms, alg_bytes, workload_key, **extra):
     if summ:
         traffic = float(summ["traffic_bytes_per_step"])
         r.update({"achieved": traffic / t / 1e9, "frac": traffic / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                  "frac_basis": "measured HBM-side traffic (PMC) / live kernel time", "traffic_source": "profiles/" + summ["_file"]})
+                  "frac_basis": "measured HBM-side traffic (PMC) / live kernel time", "traffic_source": "profiles/" + summ["_file"],
+                  # the counters cannot be read inside the timed process: `traffic` is the committed profile's figure for
+                  # this workload key, only the kernel time it is divided by is measured in this run
+                  "traffic_live": False, "kernel_ms_live": kernel_ms})
         prof_ms = summ.get("kernel_ms_per_step_rocprof") or (summ.get("bench_under_rocprof") or {}).get("kernel_ms")
         if prof_ms:
             r["kernel_ms_when_profiled"] = prof_ms

@@ -258,11 +258,13 @@ int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* re
 int svoh_sparse_align_fetch_all(svoh_ctx* ctx, int n_results, svoh_align_result* results);
 
 /* Device time (ms, HIP events on the context stream) of the alignment kernel
- * of the last enqueue/batch call; valid after fetch/batch returned. */
+ * of the last enqueue/batch call; valid after fetch/batch returned.  Fails when that launch was made with kernel
+ * timing off (it never hands out the time of an older launch). */
 int svoh_sparse_align_last_kernel_ms(svoh_ctx* ctx, float* ms);
 
-/* Device times (ms) of the last n alignment launches, oldest first (the library keeps the event pairs of the
- * last 32): for callers that queue several enqueue calls before one fetch.  *n_out = entries written. */
+/* Device times (ms) of the last n TIMED alignment launches, oldest first (the library keeps the event pairs of the
+ * last 32; launches made while kernel timing was off leave no entry): for callers that queue several enqueue calls
+ * before one fetch.  *n_out = entries written. */
 int svoh_sparse_align_kernel_ms_history(svoh_ctx* ctx, int n, float* ms, int* n_out);
 
 /* Diagnostic/parity entry: evaluate H (8x8 col-major), g (8), chi2, n_meas for

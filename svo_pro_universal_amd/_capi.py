@@ -300,18 +300,24 @@ def _share_hip_runtime_with_torch():
             pass
 
 
-def load():
+# the same library with the test hooks compiled in (-DSVOH_TEST_HOOKS: make testhooks); loaded by the tests that need a
+# hook, never by the product
+TESTHOOKS_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsvo_hip_testhooks.so")
+
+
+def load(path=None):
     """dlopen libsvo_hip.so (in-tree).  Raises RuntimeError if it is missing:
-    the product has no CPU path."""
+    the product has no CPU path.  path: another build of the same library (tests: TESTHOOKS_LIB_PATH)."""
     global _LIB
-    if _LIB is not None:
+    if path is None and _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH):
+    lib_path = path or LIB_PATH
+    if not os.path.exists(lib_path):
         raise RuntimeError(
             "libsvo_hip.so not built (%s). Build it with __graft_entry__.build(); "
-            "there is no CPU fallback." % LIB_PATH)
+            "there is no CPU fallback." % lib_path)
     _share_hip_runtime_with_torch()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(lib_path)
     P = C.POINTER
     lib.svoh_abi_version.restype = C.c_int
     lib.svoh_create.argtypes = [C.c_int, P(C.c_void_p)]
@@ -380,5 +386,6 @@ def load():
     lib.svoh_epipolar_match_batch.argtypes = [C.c_void_p, P(svoh_matcher_options), C.c_int, P(svoh_frame_view),
                                               P(svoh_frame_view), P(svoh_se3), P(svoh_feature_batch), P(C.c_double),
                                               C.c_void_p, P(svoh_epipolar_match_outputs)]
-    _LIB = lib
+    if path is None:
+        _LIB = lib
     return lib

@@ -308,7 +308,9 @@ void load_knobs_from_env(SvohKnobs& k)
   k.seed_binning = get("SVOH_SEED_BINNING");
   k.pose_threads = get("SVOH_POSE_THREADS");
   k.align_cluster = get("SVOH_ALIGN_CLUSTER");
+#ifdef SVOH_TEST_HOOKS
   k.align_cluster_test_absent = get("SVOH_ALIGN_CLUSTER_TEST_ABSENT");
+#endif
   k.align_threads = get("SVOH_ALIGN_THREADS");
   k.align_lds = get("SVOH_ALIGN_LDS");
   k.align_wg_per_cu = get("SVOH_ALIGN_WG_PER_CU");

@@ -216,6 +216,11 @@ __device__ T rank_select(const T* vals, int n, int k, int tid, T* s_out)
 // about three features per lane; four bundles share a compute unit (the kernel needs >256 registers, so a SIMD
 // holds one wave), and the one-lane solve of one bundle overlaps the residuals of the other three: the geometry for
 // batches that outnumber the compute units.
+// pyramid level of a feature as the shift count of its scale: host arrays are checked to be 0..29 before the launch,
+// device-resident ones are clamped here (a level outside that range is a caller's error; it must not become a
+// negative scale or an undefined shift)
+__device__ __forceinline__ int pose_level(int l) { return l < 0 ? 0 : (l > 29 ? 29 : l); }
+
 template <int NT>
 __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
 {
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
   {
     const Rigid T = s_T;
     for_each_feature([&](const CamModel& cm, const Rigid& T_cam_imu, const double* Rci, long long gi) {
-      const int scale = 1 << (a.level[gi] & 31);
+      const int scale = 1 << pose_level(a.level[gi]);
       double ue;
       const Vec3 X = { a.xyz[3 * gi], a.xyz[3 * gi + 1], a.xyz[3 * gi + 2] };
       pose_residual(opt, cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, is_edgelet_type(a.type[gi]),
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
     const Rigid T = s_T;
     for_each_feature([&](const CamModel& cm, const Rigid& T_cam_imu, const double* Rci, long long gi) {
-      const int scale = 1 << (a.level[gi] & 31);
+      const int scale = 1 << pose_level(a.level[gi]);
       const bool edgelet = is_edgelet_type(a.type[gi]);
       double sigma = measurement_sigma * scale;
       if (edgelet) sigma *= 2.0;   // kEdgeletSigmaExtraFactor
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
       double ue;
       const Vec3 X = { a.xyz[3 * gi], a.xyz[3 * gi + 1], a.xyz[3 * gi + 2] };
       pose_residual(opt, cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, edgelet, 1.0, ue, nullptr);
-      ue *= 1.0 / (1 << (a.level[gi] & 31));
+      ue *= 1.0 / (1 << pose_level(a.level[gi]));
       a.final_error[gi] = ue;
       const bool out = fabs(ue) > opt.outlier_threshold;
       a.outlier[gi] = out ? 1 : 0;
@@ -529,7 +534,7 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
                    "NULL feature array");
       SVOH_REQUIRE(ctx, cam.cam.distortion == SVOH_DISTORTION_NONE || cam.cam.distortion == SVOH_DISTORTION_RADTAN,
                    "unsupported distortion model");
-      if (!packed)   // device-resident levels are masked to 0..29 by the kernel instead (1 << level)
+      if (!packed)   // device-resident levels are clamped to 0..29 by the kernel instead (pose_level)
         for (int i = 0; i < cam.n_features; ++i) SVOH_REQUIRE(ctx, cam.level[i] >= 0 && cam.level[i] < 30, "feature level out of range");
       n += (size_t)cam.n_features;
     }

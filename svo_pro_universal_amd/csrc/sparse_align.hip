@@ -89,7 +89,9 @@ struct AlignKernelArgs {
   int32_t cluster;                      // 0 / 1: off
   double* xchg;                         // 2 x cluster x kXchgStride doubles
   unsigned int* bar;                    // arrival counter, zeroed before the launch
-  int32_t cluster_test_absent;          // test hook (SVOH_ALIGN_CLUSTER_TEST_ABSENT): share 1 never arrives
+#ifdef SVOH_TEST_HOOKS
+  int32_t cluster_test_absent;          // libsvo_hip_testhooks.so only (SVOH_ALIGN_CLUSTER_TEST_ABSENT): share 1 never arrives
+#endif
 };
 
 constexpr int kXchgStride = 64;         // doubles per share and parity (>= 45 + 8 + 1 accumulators + 2)
@@ -952,7 +954,9 @@ void sparse_align_kernel(const AlignKernelArgs a)
   __syncthreads();
   const int pbi = s_pbi;
   if (pbi >= a.n_problems) break;
-  if (CLUSTER && a.cluster_test_absent && pbi % a.cluster == 1) continue;   // test hook: a partner that never arrives
+#ifdef SVOH_TEST_HOOKS
+  if (CLUSTER && a.cluster_test_absent && pbi % a.cluster == 1) continue;   // a partner that never arrives
+#endif
   const DevProblemDesc& pb = a.problems[pbi];
   const DevCamDesc* cams = a.cams + pb.cam_begin;
   const int n_cams = pb.n_cams;
@@ -1582,7 +1586,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.cluster = 0;
   args.xchg = nullptr;
   args.bar = nullptr;
+#ifdef SVOH_TEST_HOOKS
   args.cluster_test_absent = SvohKnobs::or_default(ctx->knobs.align_cluster_test_absent, 0);
+#endif
   if (cluster) {
     const size_t xchg_bytes = 2 * (size_t)S * kXchgStride * sizeof(double) * n_problems;
     SVOH_HIP_TRY(ctx, ctx->d_xchg.reserve(xchg_bytes));
@@ -1659,6 +1665,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
     if (es != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "sum_shares launch failed: %s", hipGetErrorString(es));
   }
   if (timed) { SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_stop[ev_slot], ctx->stream)); ++ctx->align_timed_launches; }
+  ctx->align_last_timed = timed;
   ++ctx->align_launches;
   // the results follow the kernel to pinned host memory right away, so that a caller which queues several
   // launches and fetches once still has every launch's output delivered
@@ -1684,7 +1691,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
             sum[4] / n_problems, sum[7] / n_problems, sum[6] / n_problems, sum[5] / n_problems);
   }
 #endif
-  ctx->last_align_n = (S > 1 && !cluster) ? 0 : n_problems;   // the shares' result slots are not a caller's problems
+  // what svoh_sparse_align_fetch may hand out: only a launch that delivered into h_results (not an evaluation, not
+  // the shares of a patch-split evaluation, whose result slots are not a caller's problems)
+  ctx->last_align_n = delivers ? n_problems : 0;
   return SVOH_OK;
 }
 
@@ -1703,7 +1712,8 @@ try {
 int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* results)
 try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
-  SVOH_REQUIRE(ctx, results && n_problems >= 1 && n_problems <= ctx->last_align_n, "nothing to fetch");
+  SVOH_REQUIRE(ctx, results && n_problems >= 1 && n_problems <= ctx->last_align_n && ctx->h_results.ptr &&
+                        ctx->align_pending_results >= (size_t)n_problems, "nothing to fetch");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the copy to h_results was queued behind the kernel
   memcpy(results, static_cast<const svoh_align_result*>(ctx->h_results.ptr) + ctx->align_last_results_off,
@@ -1749,7 +1759,8 @@ try {
 int svoh_sparse_align_last_kernel_ms(svoh_ctx* ctx, float* ms)
 try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
-  SVOH_REQUIRE(ctx, ms != nullptr && ctx->align_timed_launches > 0, "no timed alignment launch (svoh_set_kernel_timing)");
+  SVOH_REQUIRE(ctx, ms != nullptr && ctx->align_timed_launches > 0 && ctx->align_last_timed,
+               "the last alignment launch was not timed (svoh_set_kernel_timing)");
   const int slot = (int)((ctx->align_timed_launches - 1) % svoh_ctx::kAlignEventRing);
   SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_stop[slot]));
   SVOH_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_align_start[slot], ctx->ev_align_stop[slot]));

@@ -87,7 +87,9 @@ struct SvohKnobs {
   int seed_binning = kKnobUnset;              // SVOH_SEED_BINNING: 0 = no spatial binning of large seed batches
   int pose_threads = kKnobUnset;              // SVOH_POSE_THREADS: 64 / 256
   int align_cluster = kKnobUnset;             // SVOH_ALIGN_CLUSTER: workgroups per problem (0 = never)
-  int align_cluster_test_absent = kKnobUnset; // SVOH_ALIGN_CLUSTER_TEST_ABSENT: test hook, a partner that never arrives
+#ifdef SVOH_TEST_HOOKS
+  int align_cluster_test_absent = kKnobUnset; // SVOH_ALIGN_CLUSTER_TEST_ABSENT: a partner that never arrives (libsvo_hip_testhooks.so only)
+#endif
   int align_threads = kKnobUnset;             // SVOH_ALIGN_THREADS: 256 / 512 / 1024
   int align_lds = kKnobUnset;                 // SVOH_ALIGN_LDS: bytes of LDS for image levels
   int align_wg_per_cu = kKnobUnset;           // SVOH_ALIGN_WG_PER_CU
@@ -131,6 +133,7 @@ struct svoh_ctx {
   bool misc_timed = false;     // the last KLT / matcher / seed / pose / detector launch was bracketed by the event pair
   bool misc_launched = false;  // ... has happened at all (its work counters exist)
   unsigned long long align_timed_launches = 0;   // alignment launches bracketed by events (ring slots in use)
+  bool align_last_timed = false;                 // ... and whether the most recent alignment launch was one of them
   bool timing_on() const { return knobs.kernel_timing != kKnobUnset && knobs.kernel_timing != 0; }
   svoh::DevBuffer d_counters;  // 8 x uint64 work counters of the last KLT / matcher kernel
   svoh::DevBuffer d_unit_counts;  // 4 x uint32 per unit

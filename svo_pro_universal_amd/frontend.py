@@ -47,10 +47,11 @@ def se3_to_numpy(s):
 class Context(object):
     """One svoh_ctx (one HIP stream).  Not thread-safe, like the ABI."""
 
-    def __init__(self, device=0, kernel_timing=True):
+    def __init__(self, device=0, kernel_timing=True, lib=None):
         """kernel_timing: bracket every launch with an event pair so that the *_kernel_ms calls work (what the
-        benchmark and the tests want; the library's own default is off: svoh_set_kernel_timing)."""
-        self.lib = capi.load()
+        benchmark and the tests want; the library's own default is off: svoh_set_kernel_timing).
+        lib: another build of libsvo_hip loaded with capi.load(path) (the test-hook build)."""
+        self.lib = lib or capi.load()
         h = C.c_void_p()
         rc = self.lib.svoh_create(int(device), C.byref(h))
         if rc != 0:

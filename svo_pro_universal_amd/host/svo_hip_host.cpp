@@ -870,7 +870,8 @@ ReprojectorHip::ReprojectorHip(svoh_ctx* ctx, const ReprojectorOptions& options,
 }
 
 namespace {
-struct ReprojTiming {   // SVOH_REPROJ_TIMING=1: mean host / device split of reprojectFrames, printed at exit
+// per thread (one camera stream = one host thread in tools/svoh_mini_frontend): nothing is shared between streams
+struct ReprojTiming {   // SVOH_REPROJ_TIMING=1: mean host / device split of reprojectFrames, printed when the thread ends
   bool on = getenv("SVOH_REPROJ_TIMING") != nullptr;
   double t[6] = { 0, 0, 0, 0, 0, 0 };
   double kernel_ms = 0;
@@ -883,7 +884,8 @@ struct ReprojTiming {   // SVOH_REPROJ_TIMING=1: mean host / device split of rep
       fprintf(stderr, "[reproject] per call: candidates %.3f ms, sort %.3f, plan %.3f, device round trip(s) %.3f (kernel %.3f), replay %.3f, other %.3f [round trip: stage direct %.3f, stage seeds %.3f, launch + wait %.3f] (%ld calls; per call %.0f direct + %.0f seed units speculated; unconverged pass reached %ld x, speculated %ld x)\n",
               t[0] / n, t[1] / n, t[2] / n, t[3] / n, kernel_ms / n, t[4] / n, t[5] / n, rt[0] / n, rt[1] / n, rt[2] / n, n, (double)n_direct / n, (double)n_seeds / n, n_reached3, n_spec3);
   }
-} g_reproj_timing;
+};
+thread_local ReprojTiming g_reproj_timing;
 }  // namespace
 
 void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs,

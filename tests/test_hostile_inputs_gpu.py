@@ -338,3 +338,30 @@ def test_deferred_section_survives_other_calls(gpu_ctx):
     for k in want_e:
         assert np.array_equal(want_e[k], got_e[k]), k
     assert np.array_equal(t["state"].cpu().numpy(), want_s[1]) and np.array_equal(d_succ.cpu().numpy(), want_s[2])
+
+
+def test_fetch_and_kernel_time_never_hand_out_an_older_launch(gpu_ctx):
+    """Round-2 advisor findings: svoh_sparse_align_fetch after an evaluation (which delivers nothing) must fail instead
+    of copying an older launch's results, and svoh_sparse_align_last_kernel_ms must fail for a launch made with kernel
+    timing off instead of returning the time of the last timed one."""
+    import ctypes as C
+    lib, h = gpu_ctx.lib, gpu_ctx.h
+    sc = synth.make_align_scene(313, n_features=120)
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+    pbs, keep = fe.make_align_problems([[(sc, fr, fc)]])
+    opt = capi.default_align_options(min_level=2)
+    first = gpu_ctx.sparse_align(opt, pbs)[0]
+    ms = C.c_float()
+    assert lib.svoh_sparse_align_last_kernel_ms(h, C.byref(ms)) == 0 and ms.value > 0
+    gpu_ctx.sparse_align_evaluate(opt, pbs[0], 2)
+    res = (capi.svoh_align_result * 1)()
+    assert lib.svoh_sparse_align_fetch(h, 1, res) != 0            # the evaluation queued no result
+    gpu_ctx.set_kernel_timing(False)
+    try:
+        again = gpu_ctx.sparse_align(opt, pbs)[0]
+        assert lib.svoh_sparse_align_last_kernel_ms(h, C.byref(ms)) != 0   # that launch was not timed
+    finally:
+        gpu_ctx.set_kernel_timing(True)
+    assert list(again.iters) == list(first.iters)
+    gpu_ctx.sparse_align(opt, pbs)
+    assert lib.svoh_sparse_align_last_kernel_ms(h, C.byref(ms)) == 0

@@ -495,6 +495,9 @@ def test_cluster_that_never_completes_falls_back(gpu_ctx):
     its partners give up after their bounded wait (status 3 for enqueue / fetch callers) and
     svoh_sparse_align_batch runs the problem again with one workgroup."""
     import os, time
+    # the hook (a share that never arrives) exists only in the test build of the library, on a context of its own
+    hooks_lib = capi.load(capi.TESTHOOKS_LIB_PATH)
+    product_ctx, gpu_ctx = gpu_ctx, fe.Context(0, lib=hooks_lib)
     sc = helpers.small_scene(97, n=1200)
     fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
     gpb, keep = fe.make_align_problems([[(sc, fr, fc)]])
@@ -523,3 +526,5 @@ def test_cluster_that_never_completes_falls_back(gpu_ctx):
             else:
                 os.environ[k] = v
                 gpu_ctx.reload_knobs()
+        gpu_ctx.close()
+        product_ctx.reload_knobs()
