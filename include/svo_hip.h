@@ -90,6 +90,16 @@ typedef struct svoh_camera {
   int32_t reserved;
 } svoh_camera;
 
+/* Diagnostic / parity entry (a-15): the camera maths every kernel uses (csrc/svoh_math.h), evaluated ON THE DEVICE for
+ * n points, so that the reference's own camera tests (src/vikit/vikit_cameras/test/test_cameras.cpp:83-121, 162-173)
+ * can be restated against the device code and not only against the host compilation of the same header:
+ *   px[2i..]     = PinholeProjection::project3(xyz[3i..])                        pinhole_projection.hpp:44-64
+ *   J[6i..]      = its 2x3 Jacobian, row-major (diag(fx,fy) * distortion.jacobian(uv) * d(uv)/d(xyz))
+ *   f_back[3i..] = PinholeProjection::backProject3(px[2i..]) (radtan: five fixed-point iterations)  :30-42
+ * Host pointers; J and f_back may be NULL. */
+int svoh_camera_maths(svoh_ctx* ctx, const svoh_camera* cam, int n, const double* xyz, double* px, double* J,
+                      double* f_back);
+
 /* ---- frames / image pyramid  (a-0) ------------------------------------ */
 
 typedef enum svoh_halfsample_rounding {

@@ -265,7 +265,7 @@ EXPORTS = [
     "svoh_abi_version", "svoh_create", "svoh_destroy", "svoh_last_error_string",
     "svoh_synchronize", "svoh_stream",
     "svoh_upload_pyramid", "svoh_build_pyramid", "svoh_build_pyramid_batch",
-    "svoh_download_level", "svoh_frame_info", "svoh_release_frame", "svoh_context_stats", "svoh_reload_knobs", "svoh_set_kernel_timing",
+    "svoh_download_level", "svoh_frame_info", "svoh_release_frame", "svoh_camera_maths", "svoh_context_stats", "svoh_reload_knobs", "svoh_set_kernel_timing",
     "svoh_sparse_align_batch", "svoh_sparse_align_enqueue", "svoh_sparse_align_fetch", "svoh_sparse_align_fetch_all",
     "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms", "svoh_sparse_align_kernel_ms_history",
     "svoh_sparse_align_split_buffers", "svoh_sparse_align_split_init", "svoh_sparse_align_partial_sums", "svoh_sparse_align_gn_update",
@@ -337,6 +337,7 @@ def load(path=None):
     lib.svoh_download_level.argtypes = [C.c_void_p, svoh_frame_t, C.c_int, C.c_void_p, P(C.c_int), P(C.c_int)]
     lib.svoh_frame_info.argtypes = [C.c_void_p, svoh_frame_t, P(C.c_int), P(C.c_int), P(C.c_int)]
     lib.svoh_release_frame.argtypes = [C.c_void_p, svoh_frame_t]
+    lib.svoh_camera_maths.argtypes = [C.c_void_p, P(svoh_camera), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svoh_context_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.svoh_reload_knobs.argtypes = [C.c_void_p]
     lib.svoh_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]

@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "svoh_internal.h"
+#include "svoh_math.h"
 
 namespace svoh {
 
@@ -300,6 +301,23 @@ static uint64_t register_frame(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab,
 
 using namespace svoh;
 
+// svoh_camera_maths: project3 (+ Jacobian) and backProject3 of svoh_math.h as the device compiles them
+__global__ __launch_bounds__(64) void camera_maths_kernel(const svoh_camera cam, int n, const double* xyz, double* px, double* J, double* f_back)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const CamModel cm = load_camera(cam);
+  const Vec3 p = { xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] };
+  double u, v;
+  project3(cm, p, u, v);
+  px[2 * i] = u; px[2 * i + 1] = v;
+  double Jl[6];
+  project3_jacobian(cm, p, Jl);
+  for (int k = 0; k < 6; ++k) J[6 * i + k] = Jl[k];
+  const Vec3 f = back_project3(cm, u, v);
+  f_back[3 * i] = f.x; f_back[3 * i + 1] = f.y; f_back[3 * i + 2] = f.z;
+}
+
 void load_knobs_from_env(SvohKnobs& k)
 {
   auto get = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : kKnobUnset; };
@@ -575,6 +593,28 @@ try {
   size_t wb = 0;
   for (const svoh::DevBuffer* b : bufs) wb += b->cap;
   out->workspace_bytes = (int64_t)wb;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_camera_maths(svoh_ctx* ctx, const svoh_camera* cam, int n, const double* xyz, double* px, double* J, double* f_back)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, cam && xyz && px && n >= 1 && n <= (1 << 20), "bad arguments");
+  SVOH_REQUIRE(ctx, cam->distortion == SVOH_DISTORTION_NONE || cam->distortion == SVOH_DISTORTION_RADTAN, "unsupported distortion model");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // [xyz 3n | px 2n | J 6n | f 3n] doubles on the device
+  const size_t nd = (size_t)n;
+  SVOH_HIP_TRY(ctx, ctx->d_scratch2.reserve(14 * nd * sizeof(double)));
+  double* d = static_cast<double*>(ctx->d_scratch2.ptr);
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, xyz, 3 * nd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(camera_maths_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, *cam, n, d, d + 3 * nd, d + 5 * nd,
+                     d + 11 * nd);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "camera_maths launch failed: %s", hipGetErrorString(e));
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(px, d + 3 * nd, 2 * nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (J) SVOH_HIP_TRY(ctx, hipMemcpyAsync(J, d + 5 * nd, 6 * nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (f_back) SVOH_HIP_TRY(ctx, hipMemcpyAsync(f_back, d + 11 * nd, 3 * nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 

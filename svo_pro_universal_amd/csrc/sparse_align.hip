@@ -519,8 +519,7 @@ __device__ __forceinline__ void stage_image(unsigned char* dst, const DevImage& 
   const int total = im.w * im.h;
   if (im.pitch == im.w && (reinterpret_cast<uintptr_t>(im.data) & 15) == 0) {
     // LDS-DMA: every wave copies 1 KB per instruction (16 bytes per lane, lane-contiguous on both sides) without a
-    // round trip through VGPRs, and all of a thread's requests are in flight at once.  The caller's barrier
-    // follows the vmcnt wait below.
+    // round trip through VGPRs, and all of a thread's requests are in flight at once.
     typedef const __attribute__((address_space(1))) void* gptr;
     typedef __attribute__((address_space(3))) void* lptr;
     const int n16 = total >> 4;
@@ -529,7 +528,7 @@ __device__ __forceinline__ void stage_image(unsigned char* dst, const DevImage& 
       if (i0 + lane < n16)
         __builtin_amdgcn_global_load_lds((gptr)(im.data + (size_t)(i0 + lane) * 16), (lptr)(dst + (size_t)i0 * 16), 16, 0, 0);
     for (int i = (n16 << 4) + tid; i < total; i += NT) dst[i] = im.data[i];
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    // no wait here: the requests stay in flight, the caller waits (vmcnt(0)) before the barrier in front of the first read
   } else {
     for (int i = tid; i < total; i += NT) {
       const int y = i / im.w, x = i - y * im.w;
@@ -937,6 +936,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
   extern __shared__ __align__(16) unsigned char lds_img[];
   __shared__ __align__(16) double s_stage[STAGED ? NW * kStageDoubles : 2];
   __shared__ double s_jc[SVOH_MAX_CAMS][kJacConsts];   // per-camera constants of jac_rows
+  __shared__ int s_lvl_off[SVOH_MAX_LEVELS];           // where the level's images start in lds_img; -1: not resident
   __shared__ double s_red[NW][NACC];
   static_assert(NACC <= 45, "g_sum is sized for the 8-parameter case");
   __shared__ double s_x[kXchgStride];   // cluster mode: the block handed to cluster_sum
@@ -962,9 +962,42 @@ void sparse_align_kernel(const AlignKernelArgs a)
   const int n_cams = pb.n_cams;
   const svoh_align_options& opt = a.opt;
   const bool eval_mode = a.eval_level >= 0;
+  const int level_hi = eval_mode ? a.eval_level : opt.max_level;
+  const int level_lo = eval_mode ? a.eval_level : opt.min_level;
+  // LDS bytes of a level's images (all cameras), and their copy into lds_img + off (requests only: no wait)
+  auto level_bytes = [&](int l) {
+    int need = 0;
+    for (int c = 0; c < n_cams; ++c) {
+      need += ((cams[c].ref[l].w * cams[c].ref[l].h + 15) & ~15);
+      need += ((cams[c].cur[l].w * cams[c].cur[l].h + 15) & ~15);
+    }
+    return need;
+  };
+  auto stage_level = [&](int l, int off) {
+    for (int c = 0; c < n_cams; ++c) {
+      stage_image<NT>(lds_img + off, cams[c].ref[l], tid);
+      off += ((cams[c].ref[l].w * cams[c].ref[l].h + 15) & ~15);
+      stage_image<NT>(lds_img + off, cams[c].cur[l], tid);
+      off += ((cams[c].cur[l].w * cams[c].cur[l].h + 15) & ~15);
+    }
+  };
 
   SVOH_STAMP_DECL
   SVOH_STAMP_START();
+  // The images of the coarse levels are requested NOW, for the problem's whole life, from the coarsest level down
+  // as long as they fit side by side (640x480: levels 4, 3, 2 = 50 400 bytes): their way from HBM overlaps the base
+  // phase instead of standing in front of every level's first iteration (three exposed copies per problem before:
+  // 6 % of a workgroup's life).  A finer level that fits only by itself is staged when its turn comes, over them.
+  {
+    int off = 0;
+    bool room = true;
+    for (int l = level_hi; l >= level_lo; --l) {
+      const int need = level_bytes(l);
+      room = room && off + need <= a.lds_img_bytes;
+      if (room) { stage_level(l, off); if (tid == 0) s_lvl_off[l] = off; off += need; }
+      else if (tid == 0) s_lvl_off[l] = -1;
+    }
+  }
   if (tid == 0) {
     g_state.T = load_rigid(pb.T_init);
     g_state.Told = g_state.T;
@@ -1081,6 +1114,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
       if (eval_mode) for (int k = 0; k < 74; ++k) a.eval_out[74 * pbi + k] = 0.0;
     }
     SVOH_STAMP_FLUSH();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no image request of this problem lands in the next one's
     continue;
   }
   const bool est_alpha = opt.estimate_illumination_gain != 0;
@@ -1089,28 +1123,20 @@ void sparse_align_kernel(const AlignKernelArgs a)
   const bool dist_jac = opt.use_distortion_jacobian != 0;
   const float weight_scale = (float)opt.weight_scale;
 
-  const int level_hi = eval_mode ? a.eval_level : opt.max_level;
-  const int level_lo = eval_mode ? a.eval_level : opt.min_level;
-
   for (int level = level_hi; level >= level_lo; --level) {
     const double scale = 1.0f / (1 << level);
-    // ---- stage the level's images in LDS if they all fit ----
-    int need = 0;
-    for (int c = 0; c < n_cams; ++c) {
-      need += ((cams[c].ref[level].w * cams[c].ref[level].h + 15) & ~15);
-      need += ((cams[c].cur[level].w * cams[c].cur[level].h + 15) & ~15);
+    // ---- the level's images: resident since the problem's start, staged now, or read from global memory ----
+    int lvl_off = s_lvl_off[level];
+    bool in_lds = lvl_off >= 0;
+    if (!in_lds && level_bytes(level) <= a.lds_img_bytes) {
+      // not resident (the coarser levels took the room) but it fits by itself: over the levels that are done
+      __syncthreads();  // their readers are done with lds_img
+      stage_level(level, 0);
+      lvl_off = 0;
+      in_lds = true;
     }
-    const bool in_lds = need <= a.lds_img_bytes;
-    __syncthreads();  // previous level's readers are done with lds_img
-    if (in_lds) {
-      int off = 0;
-      for (int c = 0; c < n_cams; ++c) {
-        stage_image<NT>(lds_img + off, cams[c].ref[level], tid);
-        off += ((cams[c].ref[level].w * cams[c].ref[level].h + 15) & ~15);
-        stage_image<NT>(lds_img + off, cams[c].cur[level], tid);
-        off += ((cams[c].cur[level].w * cams[c].cur[level].h + 15) & ~15);
-      }
-    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this thread's image requests (issued here or at the problem's start) have landed
+    __syncthreads();
     if (tid == 0) {
       g_state.level_done = 0;
       for (int c = 0; c < n_cams; ++c)
@@ -1134,7 +1160,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
         int nvis = 0, changed = 0;
         auto run_cameras = [&](auto gonly_tag, auto& acc_ref) {
           constexpr bool G = decltype(gonly_tag)::value;
-          int off = 0;
+          int off = lvl_off;
           for (int c = 0; c < n_cams; ++c) {
             const DevCamDesc& cd = cams[c];
             const DevImage& rim = cd.ref[level];
@@ -1633,11 +1659,12 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   nt = SvohKnobs::or_default(ctx->knobs.align_threads, nt);
   if (cluster) nt = 256;   // one workgroup per CU at most: all of them are resident together
   if (nt != 256 && nt != 512 && nt != 1024) nt = 256;
-  size_t lds = (nt == 256) ? 38400 : (nt == 512 ? 78 * 1024 : 153856);
+  // 256 threads: two workgroups per CU, each with <= 29.5 KB of static LDS (reduction scratch, the 24 KB LDS-DMA staging
+  // area of the workspace rows) -> 51 KB for images: levels 4, 3 and 2 of a 640x480 pyramid side by side (50 400 B)
+  size_t lds = (nt == 256) ? 52224 : (nt == 512 ? 78 * 1024 : 153856);
   lds = (size_t)SvohKnobs::or_default(ctx->knobs.align_lds, (int)lds);
-  // 160 KB per workgroup minus the kernel's static LDS (reduction scratch; in the 256-thread geometry also the
-  // 36 KB LDS-DMA staging area of the workspace rows)
-  const size_t lds_cap = (nt == 256 && SVOH_ALIGN_STAGED) ? 163840 - 40960 : 153856;
+  // 160 KB per workgroup minus the kernel's static LDS
+  const size_t lds_cap = (nt == 256 && SVOH_ALIGN_STAGED) ? 163840 - 32768 : 153856;
   if (lds > lds_cap) lds = lds_cap;
   args.lds_img_bytes = (int32_t)lds;
 

@@ -88,6 +88,16 @@ class Context(object):
         """The SVOH_* tuning knobs are read from the environment when the context is made; read them again."""
         self._check(self.lib.svoh_reload_knobs(self.h))
 
+    def camera_maths(self, cam, xyz):
+        """svoh_camera_maths: (px 2n, J 6n, f_back 3n) of the n points xyz (3n) as the DEVICE evaluates svoh_math.h."""
+        xyz = np.ascontiguousarray(xyz, np.float64).ravel()
+        n = xyz.size // 3
+        px, J, fb = np.zeros(2 * n), np.zeros(6 * n), np.zeros(3 * n)
+        c = _camera(cam)
+        self._check(self.lib.svoh_camera_maths(self.h, C.byref(c), n, xyz.ctypes.data, px.ctypes.data, J.ctypes.data,
+                                               fb.ctypes.data))
+        return px, J, fb
+
     # ---- frames -----------------------------------------------------------
     def upload_pyramid(self, levels):
         n = len(levels)
