@@ -484,6 +484,32 @@ int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options,
 int svoh_matcher_begin_deferred(svoh_ctx* ctx);
 int svoh_matcher_collect(svoh_ctx* ctx);
 
+/* ---- f-4: candidate projection of the reprojector ----------------------------------------------------------
+ * Replaces the arithmetic of reprojector_utils::getCandidate / projectPointAndCheckVisibility
+ * (src/svo/src/reprojector.cpp:489-543; Frame::isVisible, src/svo_common/src/frame.cpp:229-260) for n points of the
+ * local map: point i is a world position (kind 0: v = landmark_vec_[i]->pos()) or a seed of keyframe kf[i] (kind 1:
+ * v = f_vec_ column, mu = inverse depth; position T_world_kf[kf[i]] * (v / mu)).  Outputs per point: px (2 x n, the
+ * projection into the current frame) and visible (1 = getCandidate would return a candidate at px).  Which keyframes
+ * are visible, the landmark bookkeeping, std::sort and the ordered replay stay with the caller
+ * (host/svo_hip_host.cpp: ReprojectorHip).
+ *
+ * The enqueue form does not synchronise.  With align_result_index >= 0 the current frame's pose is composed ON THE
+ * DEVICE from result #align_result_index of the alignment launch queued just before (svoh_sparse_align_enqueue):
+ *   T_f_w = T_cam_imu (first pose argument) * T_icur_iref (alignment result) * T_imu_world_ref
+ * (sparse_img_align.cpp:100-107), so that one svoh_sparse_align_fetch delivers the pose AND the candidates of the
+ * frame: the candidate projection costs no round trip of its own.  With align_result_index < 0 the first pose argument
+ * is T_f_w itself.  collect copies the results out (n must be the queued call's n).  Host pointers; one queued call
+ * at a time. */
+int svoh_project_candidates_enqueue(svoh_ctx* ctx, const svoh_camera* cam, const svoh_se3* T_f_w_or_T_cam_imu,
+                                    const svoh_se3* T_imu_world_ref, int align_result_index, int n_kf,
+                                    const svoh_se3* T_world_kf, int n, const uint8_t* kind, const int32_t* kf,
+                                    const double* v, const double* mu);
+int svoh_project_candidates_collect(svoh_ctx* ctx, int n, double* px, uint8_t* visible);
+/* blocking form with an explicit T_f_w */
+int svoh_project_candidates(svoh_ctx* ctx, const svoh_camera* cam, const svoh_se3* T_f_w, int n_kf,
+                            const svoh_se3* T_world_kf, int n, const uint8_t* kind, const int32_t* kf, const double* v,
+                            const double* mu, double* px, uint8_t* visible);
+
 /* DepthFilterOptions used by updateSeed (src/svo_direct/include/svo/direct/depth_filter.h:40-100) */
 typedef struct svoh_depth_filter_options {
   double seed_convergence_sigma2_thresh;      /* 200 */

@@ -272,6 +272,7 @@ EXPORTS = [
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
     "svoh_match_direct_batch", "svoh_matcher_begin_deferred", "svoh_matcher_collect",
     "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex", "svoh_epipolar_match_batch",
+    "svoh_project_candidates_enqueue", "svoh_project_candidates_collect", "svoh_project_candidates",
     "svoh_detect_features", "svoh_optimize_pose_batch", "svoh_optimize_pose_batch_packed", "svoh_optimize_points_batch",
 ]
 
@@ -337,6 +338,11 @@ def load(path=None):
     lib.svoh_download_level.argtypes = [C.c_void_p, svoh_frame_t, C.c_int, C.c_void_p, P(C.c_int), P(C.c_int)]
     lib.svoh_frame_info.argtypes = [C.c_void_p, svoh_frame_t, P(C.c_int), P(C.c_int), P(C.c_int)]
     lib.svoh_release_frame.argtypes = [C.c_void_p, svoh_frame_t]
+    lib.svoh_project_candidates_enqueue.argtypes = [C.c_void_p, P(svoh_camera), P(svoh_se3), P(svoh_se3), C.c_int, C.c_int, C.c_void_p,
+                                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svoh_project_candidates_collect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.svoh_project_candidates.argtypes = [C.c_void_p, P(svoh_camera), P(svoh_se3), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svoh_camera_maths.argtypes = [C.c_void_p, P(svoh_camera), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svoh_context_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.svoh_reload_knobs.argtypes = [C.c_void_p]

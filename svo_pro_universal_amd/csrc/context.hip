@@ -589,7 +589,7 @@ try {
   for (const auto& kv : slabs) fb += kv.second;
   out->frame_bytes = (int64_t)fb;
   const svoh::DevBuffer* bufs[] = { &ctx->d_desc, &ctx->d_results, &ctx->d_feat, &ctx->d_eval, &ctx->d_xchg, &ctx->d_split,
-                                    &ctx->d_counters, &ctx->d_unit_counts, &ctx->d_scratch0, &ctx->d_scratch1, &ctx->d_scratch2, &ctx->d_seed_bin, &ctx->d_match_seeds, &ctx->d_match_direct };
+                                    &ctx->d_counters, &ctx->d_unit_counts, &ctx->d_scratch0, &ctx->d_scratch1, &ctx->d_scratch2, &ctx->d_seed_bin, &ctx->d_match_seeds, &ctx->d_match_direct, &ctx->d_cand };
   size_t wb = 0;
   for (const svoh::DevBuffer* b : bufs) wb += b->cap;
   out->workspace_bytes = (int64_t)wb;

@@ -2584,11 +2584,149 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
   return SVOH_OK;
 }
 
+
+// ---- f-4: candidate projection of Reprojector::reprojectFrames ---------------------------------------------------
+// reprojector_utils::getCandidate / projectPointAndCheckVisibility (src/svo/src/reprojector.cpp:489-543) with
+// Frame::isVisible (src/svo_common/src/frame.cpp:229-260) for every point of the local map: the position of a
+// landmark, or of a seed T_world_kf * (f / mu) (Frame::getSeedPosInFrame), is taken into the current frame, tested
+// against the cone of the image's top-left corner and the image box, then against the 8-pixel margin on the
+// truncated pixel.  The current frame's pose is given, or composed on the device from the alignment result that
+// the launch queued in front of this one has left in device memory (T_f_w = T_cam_imu * T_icur_iref * T_imu_world of
+// the reference frame: sparse_img_align.cpp:100-107), so that the projection needs no round trip of its own.
+// This file is compiled without FMA contraction and the maths is the host mirror's (svoh_math.h): same bits as
+// reprojector_utils::getCandidate of the host layer.
+struct CandidateArgs {
+  svoh_camera cam;
+  svoh_se3 T_a;                       // T_f_w of the current frame, or T_cam_imu of it when `align_result` is set
+  svoh_se3 T_b;                       // ... then T_imu_world of the alignment's reference frame
+  const svoh_align_result* align_result;
+  const svoh_se3* T_world_kf;         // n_kf
+  const uint8_t* kind;                // n: 0 world point, 1 seed of keyframe kf[i]
+  const int32_t* kf;                  // n
+  const double* v;                    // 3 x n: position, or bearing vector of the seed
+  const double* mu;                   // n: inverse depth of the seed
+  double* px;                         // 2 x n
+  uint8_t* visible;                   // n
+  int n, n_kf;
+};
+
+__global__ __launch_bounds__(256) void project_candidates_kernel(const CandidateArgs a)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  Rigid T_f_w = load_rigid(a.T_a);
+  if (a.align_result) T_f_w = mul(mul(T_f_w, load_rigid(a.align_result->T_icur_iref)), load_rigid(a.T_b));
+  const CamModel cm = load_camera(a.cam);
+  Vec3 xyz = { a.v[3 * i], a.v[3 * i + 1], a.v[3 * i + 2] };
+  bool ok = true;
+  if (a.kind[i]) {
+    const int k = a.kf[i];
+    ok = k >= 0 && k < a.n_kf;
+    if (ok) {
+      const double depth = 1.0 / a.mu[i];                        // seed::getDepth (seed.h:110-113)
+      const Vec3 in_f = { xyz.x * depth, xyz.y * depth, xyz.z * depth };
+      xyz = transform(load_rigid(a.T_world_kf[k]), in_f);
+    }
+  }
+  double u = 0.0, v = 0.0;
+  if (ok) {
+    const Vec3 xyz_f = transform(T_f_w, xyz);
+    // pinhole: not farther off the optical axis than the image's top-left corner (frame.cpp:233-246)
+    const Vec3 f_tl = back_project3(cm, 0.0, 0.0);
+    const double min_cos = f_tl.z / sqrt(f_tl.x * f_tl.x + f_tl.y * f_tl.y + f_tl.z * f_tl.z);
+    const double cur_cos = xyz_f.z / sqrt(xyz_f.x * xyz_f.x + xyz_f.y * xyz_f.y + xyz_f.z * xyz_f.z);
+    ok = !(cur_cos < min_cos);
+    if (ok) {
+      project3(cm, xyz_f, u, v);
+      ok = u >= 0.0 && v >= 0.0 && u < (double)a.cam.width && v < (double)a.cam.height;   // isKeypointVisible
+      if (ok) {
+        const int pxi0 = (int)u, pxi1 = (int)v;                  // px->cast<int>(), margin kPatchSize = 8 (:526-529)
+        ok = pxi0 >= 8 && pxi1 >= 8 && pxi0 < a.cam.width - 8 && pxi1 < a.cam.height - 8;
+      }
+    }
+  }
+  a.px[2 * i] = u; a.px[2 * i + 1] = v;
+  a.visible[i] = ok ? 1 : 0;
+}
+
+static int enqueue_candidates(svoh_ctx* ctx, const svoh_camera* cam, const svoh_se3* T_a, const svoh_se3* T_b, int align_result_index,
+                              int n_kf, const svoh_se3* T_world_kf, int n, const uint8_t* kind, const int32_t* kf, const double* v,
+                              const double* mu)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, cam && T_a && n >= 1 && n <= (1 << 22) && kind && kf && v && mu, "bad arguments");
+  SVOH_REQUIRE(ctx, n_kf >= 0 && n_kf <= 4096 && (n_kf == 0 || T_world_kf), "bad keyframe table");
+  SVOH_REQUIRE(ctx, cam->distortion == SVOH_DISTORTION_NONE || cam->distortion == SVOH_DISTORTION_RADTAN, "unsupported distortion model");
+  SVOH_REQUIRE(ctx, ctx->cand_pending_n == 0, "a candidate projection is queued already: collect first");
+  if (align_result_index >= 0) {
+    SVOH_REQUIRE(ctx, T_b != nullptr, "T_post is NULL");
+    SVOH_REQUIRE(ctx, align_result_index < ctx->last_align_n && ctx->d_results.ptr, "no queued alignment result with this index");
+  }
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t nd = (size_t)n;
+  auto al = [](size_t b) { return (b + 63) & ~(size_t)63; };
+  const size_t o_kf = 0, o_kind = o_kf + al(sizeof(svoh_se3) * (size_t)(n_kf > 0 ? n_kf : 1)), o_idx = o_kind + al(nd);
+  const size_t o_v = o_idx + al(4 * nd), o_mu = o_v + al(24 * nd), in_total = o_mu + al(8 * nd);
+  const size_t o_px = in_total, o_vis = o_px + al(16 * nd), total = o_vis + al(nd);
+  SVOH_HIP_TRY(ctx, ctx->h_cand.reserve(total));
+  SVOH_HIP_TRY(ctx, ctx->d_cand.reserve(total));
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_cand.ptr);
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_cand.ptr);
+  if (n_kf > 0) memcpy(h + o_kf, T_world_kf, sizeof(svoh_se3) * (size_t)n_kf);
+  memcpy(h + o_kind, kind, nd); memcpy(h + o_idx, kf, 4 * nd); memcpy(h + o_v, v, 24 * nd); memcpy(h + o_mu, mu, 8 * nd);
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
+  CandidateArgs a;
+  memset(&a, 0, sizeof a);
+  a.cam = *cam; a.T_a = *T_a;
+  if (T_b) a.T_b = *T_b;
+  a.align_result = align_result_index >= 0 ? static_cast<const svoh_align_result*>(ctx->d_results.ptr) + align_result_index : nullptr;
+  a.T_world_kf = reinterpret_cast<const svoh_se3*>(d + o_kf);
+  a.kind = d + o_kind; a.kf = reinterpret_cast<const int32_t*>(d + o_idx);
+  a.v = reinterpret_cast<const double*>(d + o_v); a.mu = reinterpret_cast<const double*>(d + o_mu);
+  a.px = reinterpret_cast<double*>(d + o_px); a.visible = d + o_vis;
+  a.n = n; a.n_kf = n_kf;
+  hipLaunchKernelGGL(project_candidates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "project_candidates launch failed: %s", hipGetErrorString(e));
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_px, d + o_px, total - o_px, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->cand_pending_n = n;
+  ctx->cand_out_off = o_px;
+  return SVOH_OK;
+}
+
 }  // namespace svoh
 
 using namespace svoh;
 
 extern "C" {
+
+int svoh_project_candidates_enqueue(svoh_ctx* ctx, const svoh_camera* cam, const svoh_se3* T_f_w_or_T_cam_imu, const svoh_se3* T_imu_world_ref,
+                                    int align_result_index, int n_kf, const svoh_se3* T_world_kf, int n, const uint8_t* kind,
+                                    const int32_t* kf, const double* v, const double* mu)
+try {
+  return enqueue_candidates(ctx, cam, T_f_w_or_T_cam_imu, T_imu_world_ref, align_result_index, n_kf, T_world_kf, n, kind, kf, v, mu);
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_project_candidates_collect(svoh_ctx* ctx, int n, double* px, uint8_t* visible)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, px && visible && n >= 1 && n == ctx->cand_pending_n, "n is not the number of points of the queued candidate projection");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // returns at once when a fetch of the alignment in front has waited already
+  const uint8_t* h = static_cast<const uint8_t*>(ctx->h_cand.ptr) + ctx->cand_out_off;
+  memcpy(px, h, sizeof(double) * 2 * (size_t)n);
+  memcpy(visible, h + ((sizeof(double) * 2 * (size_t)n + 63) & ~(size_t)63), (size_t)n);
+  ctx->cand_pending_n = 0;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_project_candidates(svoh_ctx* ctx, const svoh_camera* cam, const svoh_se3* T_f_w, int n_kf, const svoh_se3* T_world_kf, int n,
+                            const uint8_t* kind, const int32_t* kf, const double* v, const double* mu, double* px, uint8_t* visible)
+try {
+  int rc = enqueue_candidates(ctx, cam, T_f_w, nullptr, -1, n_kf, T_world_kf, n, kind, kf, v, mu);
+  if (rc != SVOH_OK) return rc;
+  return svoh_project_candidates_collect(ctx, n, px, visible);
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_epipolar_match_batch(svoh_ctx* ctx, const svoh_matcher_options* options, int n_ref_frames,
                               const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,

@@ -922,7 +922,11 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
 
 // CLUSTER: the cluster mode's exchanges are compiled in (256-thread geometry only); the batch instantiation stays
 // free of them -- as run-time branches they cost the batch kernel 5 %.
-template <int P, int NT, bool ILLUM, bool CLUSTER = false>
+// ROBUST: the Tukey weights (SparseImgAlignOptions::robustification, off in the reference's handlers) as a compile-time
+// switch: as a run-time flag the per-pixel branch, its float division and the weighted forms of the moments stayed in
+// the full pass of every launch (320 instructions per patch row against 106 in the gradient-only pass); the robust
+// instantiation in turn has no gradient-only pass (the weights change every iteration).
+template <int P, int NT, bool ILLUM, bool CLUSTER = false, bool ROBUST = false>
 __global__ __launch_bounds__(NT, (NT == 256 ? SVOH_ALIGN_MIN_WAVES_256 : (NT == 512 ? 2 : 4)))
 void sparse_align_kernel(const AlignKernelArgs a)
 {
@@ -1119,7 +1123,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
   }
   const bool est_alpha = opt.estimate_illumination_gain != 0;
   const bool est_beta = opt.estimate_illumination_offset != 0;
-  const bool robust = opt.robustification != 0;
+  constexpr bool robust = ROBUST;
   const bool dist_jac = opt.use_distortion_jacobian != 0;
   const float weight_scale = (float)opt.weight_scale;
 
@@ -1368,10 +1372,10 @@ void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_al
 
 struct LaunchCfg { int nt; size_t lds; };
 
-template <int P, int NT, bool ILLUM, bool CLUSTER = false>
+template <int P, int NT, bool ILLUM, bool CLUSTER, bool ROBUST>
 static hipError_t launch_one(hipStream_t st, int grid, size_t lds, const AlignKernelArgs& args)
 {
-  auto kern = sparse_align_kernel<P, NT, ILLUM, CLUSTER>;
+  auto kern = sparse_align_kernel<P, NT, ILLUM, CLUSTER, ROBUST>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1379,14 +1383,14 @@ static hipError_t launch_one(hipStream_t st, int grid, size_t lds, const AlignKe
   return hipGetLastError();
 }
 
-template <int P, bool ILLUM>
+template <int P, bool ILLUM, bool ROBUST>
 static hipError_t launch_nt(hipStream_t st, int nt, int grid, size_t lds, const AlignKernelArgs& args)
 {
-  if (args.cluster > 1) return launch_one<P, 256, ILLUM, true>(st, grid, lds, args);
+  if (args.cluster > 1) return launch_one<P, 256, ILLUM, true, ROBUST>(st, grid, lds, args);
   switch (nt) {
-    case 256: return launch_one<P, 256, ILLUM>(st, grid, lds, args);
-    case 512: return launch_one<P, 512, ILLUM>(st, grid, lds, args);
-    default: return launch_one<P, 1024, ILLUM>(st, grid, lds, args);
+    case 256: return launch_one<P, 256, ILLUM, false, ROBUST>(st, grid, lds, args);
+    case 512: return launch_one<P, 512, ILLUM, false, ROBUST>(st, grid, lds, args);
+    default: return launch_one<P, 1024, ILLUM, false, ROBUST>(st, grid, lds, args);
   }
 }
 
@@ -1677,12 +1681,14 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   const bool timed = ctx->timing_on();
   const int ev_slot = (int)(ctx->align_timed_launches % svoh_ctx::kAlignEventRing);
   if (timed) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_start[ev_slot], ctx->stream));
-  if (opt->patch_size == 4)
-    e = illum ? launch_nt<4, true>(ctx->stream, nt, grid, lds, args)
-              : launch_nt<4, false>(ctx->stream, nt, grid, lds, args);
-  else
-    e = illum ? launch_nt<8, true>(ctx->stream, nt, grid, lds, args)
-              : launch_nt<8, false>(ctx->stream, nt, grid, lds, args);
+  const bool robust = opt->robustification != 0;
+  if (opt->patch_size == 4) {
+    if (robust) e = illum ? launch_nt<4, true, true>(ctx->stream, nt, grid, lds, args) : launch_nt<4, false, true>(ctx->stream, nt, grid, lds, args);
+    else e = illum ? launch_nt<4, true, false>(ctx->stream, nt, grid, lds, args) : launch_nt<4, false, false>(ctx->stream, nt, grid, lds, args);
+  } else {
+    if (robust) e = illum ? launch_nt<8, true, true>(ctx->stream, nt, grid, lds, args) : launch_nt<8, false, true>(ctx->stream, nt, grid, lds, args);
+    else e = illum ? launch_nt<8, true, false>(ctx->stream, nt, grid, lds, args) : launch_nt<8, false, false>(ctx->stream, nt, grid, lds, args);
+  }
   if (e != hipSuccess)
     return set_error(ctx, SVOH_ERR_HIP, "sparse_align launch failed: %s", hipGetErrorString(e));
   if (S > 1 && !cluster) {

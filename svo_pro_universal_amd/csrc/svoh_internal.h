@@ -160,6 +160,13 @@ struct svoh_ctx {
   svoh::DevBuffer d_match_seeds, d_match_direct;
   svoh::PinnedBuffer h_match_seeds, h_match_direct;
 
+  // candidate projection of the reprojector (svoh_project_candidates_enqueue / _collect): its own staging pair -- the
+  // call is queued behind an alignment launch whose own staging is still in flight
+  svoh::DevBuffer d_cand;
+  svoh::PinnedBuffer h_cand;
+  int cand_pending_n = 0;              // points of the queued call whose results wait in h_cand (0: nothing queued)
+  size_t cand_out_off = 0;
+
   svoh::DevBuffer d_seed_bin;          // packed seed update: histogram, ranks, sorted records (nothing else writes here)
   void* seed_hist_ptr = nullptr;       // the binning histogram at this address ...
   size_t seed_hist_clean_keys = 0;     // ... is known to be zero for this many keys (its last pass clears it)
