@@ -483,6 +483,12 @@ int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options,
  * host-array batch of a kind already queued fails with "collect first". */
 int svoh_matcher_begin_deferred(svoh_ctx* ctx);
 int svoh_matcher_collect(svoh_ctx* ctx);
+/* Sends the kernels of the batches queued so far in the open section to the device WITHOUT waiting (collect does
+ * that by itself otherwise): the caller goes on with host work -- the next frame's image, its pyramid -- and collects
+ * when it needs the results.  The section stays open; a batch of a kind that has been flushed cannot be queued again
+ * before collect.  This is how the depth filter's seed update leaves the per-frame critical path
+ * (DepthFilterHip::updateSeedsAsync). */
+int svoh_matcher_flush(svoh_ctx* ctx);
 
 /* ---- f-4: candidate projection of the reprojector ----------------------------------------------------------
  * Replaces the arithmetic of reprojector_utils::getCandidate / projectPointAndCheckVisibility

@@ -2749,12 +2749,10 @@ try {
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
-int svoh_matcher_collect(svoh_ctx* ctx)
-try {
-  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
-  SVOH_REQUIRE(ctx, ctx->matcher_deferred, "no deferred section is open");
-  ctx->matcher_deferred = false;
-  ctx->matcher_deferred_used[0] = ctx->matcher_deferred_used[1] = false;
+// the kernels of the batches queued in the open deferred section go out now (one kernel when both kinds share a
+// geometry), followed by the copies of their results to the pinned blocks; nothing is waited for
+static int launch_deferred(svoh_ctx* ctx)
+{
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   {
     svoh_ctx::DeferredLaunch& d0 = ctx->matcher_deferred_launch[0];
@@ -2798,6 +2796,24 @@ try {
       if (v1) SVOH_HIP_TRY(ctx, hipMemcpyAsync(d1.d2h_dst, d1.d2h_src, d1.d2h_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
   }
+  return SVOH_OK;
+}
+
+int svoh_matcher_flush(svoh_ctx* ctx)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, ctx->matcher_deferred, "no deferred section is open");
+  return launch_deferred(ctx);
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_matcher_collect(svoh_ctx* ctx)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, ctx->matcher_deferred, "no deferred section is open");
+  ctx->matcher_deferred = false;
+  ctx->matcher_deferred_used[0] = ctx->matcher_deferred_used[1] = false;
+  const int rc_launch = launch_deferred(ctx);   // whatever svoh_matcher_flush has not sent yet
+  if (rc_launch != SVOH_OK) return rc_launch;
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (const auto& c : ctx->matcher_pending) memcpy(c.dst, c.src, c.bytes);
   for (const auto& c : ctx->matcher_pending_counts) {

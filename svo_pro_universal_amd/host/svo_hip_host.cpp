@@ -110,6 +110,30 @@ size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBun
   return static_cast<size_t>(last_.n_fts_to_track);
 }
 
+size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames, const AfterEnqueue& after_enqueue)
+{
+  svoh_align_options opt;
+  svoh_align_problem pb;
+  const Transformation T_iref_world = buildProblem(ref_frames, cur_frames, 0, 1, opt, pb);
+  last_run_repeated_ = false;
+  int rc = svoh_sparse_align_enqueue(ctx_, &opt, 1, &pb);
+  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_sparse_align_enqueue: ") + svoh_last_error_string(ctx_));
+  if (after_enqueue) after_enqueue(T_iref_world);
+  rc = svoh_sparse_align_fetch(ctx_, 1, &last_);
+  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_sparse_align_fetch: ") + svoh_last_error_string(ctx_));
+  if (last_.status == 3) {   // a cluster that never completed: the blocking entry repeats the launch with one workgroup
+    last_run_repeated_ = true;
+    rc = svoh_sparse_align_batch(ctx_, &opt, 1, &pb, &last_);
+    if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_sparse_align_batch: ") + svoh_last_error_string(ctx_));
+  }
+  if (last_.n_fts_to_track == 0) return 0;
+  const Transformation T_opt = svoh::load_rigid(last_.T_icur_iref);
+  for (const FramePtr& f : cur_frames->frames_) f->T_f_w_ = svoh::mul(svoh::mul(f->T_cam_imu(), T_opt), T_iref_world);
+  alpha_init_ = 0.0;
+  beta_init_ = 0.0;
+  return static_cast<size_t>(last_.n_fts_to_track);
+}
+
 size_t SparseImgAlignHip::runSplit(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames, int rank, int world,
                                    const SumOverParticipants& sum_over_participants)
 {
@@ -210,53 +234,82 @@ static svoh_frame_view view_of(const Frame& f)
 
 size_t DepthFilterHip::updateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame)
 {
+  updateSeedsAsync(ref_frames_with_seeds, cur_frame);
+  return finishUpdateSeeds();
+}
+
+void DepthFilterHip::updateSeedsAsync(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame)
+{
   if (!cur_frame) throw std::runtime_error("DepthFilterHip::updateSeeds: NULL current frame");
+  if (async_open_) throw std::runtime_error("DepthFilterHip::updateSeedsAsync: the previous update has not been finished");
   px_error_angle_ = updateSeedPxErrorAngle(*cur_frame);
   have_px_error_angle_ = true;
-  std::vector<svoh_frame_view> refs;
-  std::vector<int32_t> ref_idx, level;
-  std::vector<double> px, f, grad, state;
-  std::vector<uint8_t> type;
+  Pending& q = pending_;
+  q.frames = ref_frames_with_seeds;
+  q.counts.clear();
+  q.refs.clear(); q.ref_idx.clear(); q.level.clear(); q.px.clear(); q.f.clear(); q.grad.clear(); q.state.clear(); q.type.clear();
   for (size_t k = 0; k < ref_frames_with_seeds.size(); ++k) {
     const Frame& r = *ref_frames_with_seeds[k];
-    refs.push_back(view_of(r));
+    q.refs.push_back(view_of(r));
     const size_t n = r.num_features_;
-    ref_idx.insert(ref_idx.end(), n, static_cast<int32_t>(k));
-    px.insert(px.end(), r.px_vec_.begin(), r.px_vec_.begin() + 2 * n);
-    f.insert(f.end(), r.f_vec_.begin(), r.f_vec_.begin() + 3 * n);
-    grad.insert(grad.end(), r.grad_vec_.begin(), r.grad_vec_.begin() + 2 * n);
-    level.insert(level.end(), r.level_vec_.begin(), r.level_vec_.begin() + n);
-    type.insert(type.end(), r.type_vec_.begin(), r.type_vec_.begin() + n);
-    state.insert(state.end(), r.invmu_sigma2_a_b_vec_.begin(), r.invmu_sigma2_a_b_vec_.begin() + 4 * n);
+    q.counts.push_back(n);
+    q.ref_idx.insert(q.ref_idx.end(), n, static_cast<int32_t>(k));
+    q.px.insert(q.px.end(), r.px_vec_.begin(), r.px_vec_.begin() + 2 * n);
+    q.f.insert(q.f.end(), r.f_vec_.begin(), r.f_vec_.begin() + 3 * n);
+    q.grad.insert(q.grad.end(), r.grad_vec_.begin(), r.grad_vec_.begin() + 2 * n);
+    q.level.insert(q.level.end(), r.level_vec_.begin(), r.level_vec_.begin() + n);
+    q.type.insert(q.type.end(), r.type_vec_.begin(), r.type_vec_.begin() + n);
+    q.state.insert(q.state.end(), r.invmu_sigma2_a_b_vec_.begin(), r.invmu_sigma2_a_b_vec_.begin() + 4 * n);
   }
-  const size_t n_total = ref_idx.size();
+  const size_t n_total = q.ref_idx.size();
   last_results_.assign(n_total, SVOH_MATCH_NOT_RUN);
-  if (n_total == 0) return 0;
+  q.n_success = 0;
+  if (n_total == 0) { q.frames.clear(); return; }
   svoh_feature_batch fb{};
   fb.n = static_cast<int32_t>(n_total);
-  fb.ref_frame_idx = ref_idx.data(); fb.px = px.data(); fb.f = f.data(); fb.grad = grad.data();
-  fb.level = level.data(); fb.type = type.data();
+  fb.ref_frame_idx = q.ref_idx.data(); fb.px = q.px.data(); fb.f = q.f.data(); fb.grad = q.grad.data();
+  fb.level = q.level.data(); fb.type = q.type.data();
   svoh_depth_filter_options o{};
   o.seed_convergence_sigma2_thresh = options_.seed_convergence_sigma2_thresh;
   o.mappoint_convergence_sigma2_thresh = options_.mappoint_convergence_sigma2_thresh;
   o.px_error_angle = px_error_angle_;
   o.check_visibility = 1; o.check_convergence = 0; o.use_vogiatzis_update = 1;  // depth_filter.cpp:224-225
   const svoh_frame_view cur = view_of(*cur_frame);
-  std::vector<uint8_t> success(n_total);
-  int32_t n_success = 0;
-  const int rc = svoh_update_seeds_batch(ctx_, &matcher_options_, &o, static_cast<int>(refs.size()), refs.data(), &cur, &fb,
-                                         state.data(), success.data(), last_results_.data(), &n_success);
-  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_update_seeds_batch: ") + svoh_last_error_string(ctx_));
-  // scatter back in place (ref_frame.invmu_sigma2_a_b_vec_.col(i), type_vec_[i])
+  q.success.assign(n_total, 0);
+  // queued in a deferred section and sent to the device at once (svoh_matcher_flush): the kernel runs while the caller
+  // goes on; finishUpdateSeeds waits for it and puts the results where the reference's loop leaves them
+  if (svoh_matcher_begin_deferred(ctx_) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_begin_deferred: ") + svoh_last_error_string(ctx_));
+  async_open_ = true;
+  int rc = svoh_update_seeds_batch(ctx_, &matcher_options_, &o, static_cast<int>(q.refs.size()), q.refs.data(), &cur, &fb,
+                                   q.state.data(), q.success.data(), last_results_.data(), &q.n_success);
+  if (rc == SVOH_OK) rc = svoh_matcher_flush(ctx_);
+  if (rc != SVOH_OK) {
+    const std::string msg = svoh_last_error_string(ctx_);
+    (void)svoh_matcher_collect(ctx_);
+    async_open_ = false;
+    q.frames.clear();
+    throw std::runtime_error("svoh_update_seeds_batch: " + msg);
+  }
+}
+
+size_t DepthFilterHip::finishUpdateSeeds()
+{
+  Pending& q = pending_;
+  if (!async_open_) { q.frames.clear(); return 0; }
+  async_open_ = false;
+  if (svoh_matcher_collect(ctx_) != SVOH_OK) { q.frames.clear(); throw std::runtime_error(std::string("svoh_matcher_collect: ") + svoh_last_error_string(ctx_)); }
+  // scatter back in place (ref_frame.invmu_sigma2_a_b_vec_.col(i), type_vec_[i]); a frame's block is the features
+  // it had when the update was queued (features are only ever appended)
   size_t off = 0;
-  for (const FramePtr& rp : ref_frames_with_seeds) {
-    Frame& r = *rp;
-    const size_t n = r.num_features_;
-    std::copy(state.begin() + 4 * off, state.begin() + 4 * (off + n), r.invmu_sigma2_a_b_vec_.begin());
-    std::copy(type.begin() + off, type.begin() + off + n, r.type_vec_.begin());
+  for (size_t k = 0; k < q.frames.size(); ++k) {
+    Frame& r = *q.frames[k];
+    const size_t n = q.counts[k];
+    std::copy(q.state.begin() + 4 * off, q.state.begin() + 4 * (off + n), r.invmu_sigma2_a_b_vec_.begin());
+    std::copy(q.type.begin() + off, q.type.begin() + off + n, r.type_vec_.begin());
     off += n;
   }
-  return static_cast<size_t>(n_success);
+  q.frames.clear();
+  return static_cast<size_t>(q.n_success);
 }
 
 // ---- FeatureTracker ---------------------------------------------------------------
@@ -888,10 +941,75 @@ struct ReprojTiming {   // SVOH_REPROJ_TIMING=1: mean host / device split of rep
 thread_local ReprojTiming g_reproj_timing;
 }  // namespace
 
+void ReprojectorHip::enqueueCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const Transformation* T_iref_world,
+                                                int align_result_index)
+{
+  discardCandidateProjection();
+  proj_kf_off_.clear(); proj_kind_.clear(); proj_kf_.clear(); proj_v_.clear(); proj_mu_.clear(); proj_T_world_kf_.clear();
+  for (const FramePtr& kf : kfs) {
+    if (!kf || kf->num_features_ == 0) continue;
+    const int32_t k = static_cast<int32_t>(proj_T_world_kf_.size());
+    svoh_se3 T;
+    svoh::store_rigid(svoh::inverse(kf->T_f_w_), T);
+    proj_T_world_kf_.push_back(T);
+    proj_kf_off_.emplace_back(kf.get(), proj_kind_.size());
+    for (size_t i = 0; i < kf->num_features_; ++i) {
+      const PointPtr& lm = i < kf->landmark_vec_.size() ? kf->landmark_vec_[i] : PointPtr();
+      if (lm) {                                       // getCandidate: the landmark's position ...
+        const svoh::Vec3 p = lm->pos();
+        proj_kind_.push_back(0); proj_v_.insert(proj_v_.end(), { p.x, p.y, p.z }); proj_mu_.push_back(1.0);
+      } else {                                        // ... or T_world_cam() * getSeedPosInFrame(i)
+        proj_kind_.push_back(1);
+        proj_v_.insert(proj_v_.end(), { kf->f_vec_[3 * i], kf->f_vec_[3 * i + 1], kf->f_vec_[3 * i + 2] });
+        proj_mu_.push_back(4 * i < kf->invmu_sigma2_a_b_vec_.size() ? kf->invmu_sigma2_a_b_vec_[4 * i] : 1.0);
+      }
+      proj_kf_.push_back(k);
+    }
+  }
+  const int n = static_cast<int>(proj_kind_.size());
+  if (n == 0) return;
+  svoh_se3 Ta, Tb;
+  int rc;
+  if (align_result_index >= 0 && T_iref_world) {
+    svoh::store_rigid(cur_frame->T_cam_imu(), Ta);
+    svoh::store_rigid(*T_iref_world, Tb);
+    rc = svoh_project_candidates_enqueue(ctx_, &cur_frame->cam, &Ta, &Tb, align_result_index, static_cast<int>(proj_T_world_kf_.size()),
+                                         proj_T_world_kf_.data(), n, proj_kind_.data(), proj_kf_.data(), proj_v_.data(), proj_mu_.data());
+  } else {
+    svoh::store_rigid(cur_frame->T_f_w_, Ta);
+    rc = svoh_project_candidates_enqueue(ctx_, &cur_frame->cam, &Ta, nullptr, -1, static_cast<int>(proj_T_world_kf_.size()),
+                                         proj_T_world_kf_.data(), n, proj_kind_.data(), proj_kf_.data(), proj_v_.data(), proj_mu_.data());
+  }
+  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_project_candidates_enqueue: ") + svoh_last_error_string(ctx_));
+  proj_frame_ = cur_frame.get();
+  proj_collected_ = false;
+}
+
+void ReprojectorHip::discardCandidateProjection()
+{
+  if (proj_frame_ && !proj_collected_) {   // the queued call's results are dropped, the context is free for the next one
+    proj_px_.resize(2 * proj_kind_.size()); proj_visible_.resize(proj_kind_.size());
+    (void)svoh_project_candidates_collect(ctx_, static_cast<int>(proj_kind_.size()), proj_px_.data(), proj_visible_.data());
+  }
+  proj_frame_ = nullptr;
+  proj_collected_ = false;
+}
+
 void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs,
                                      std::vector<PointPtr>& trash_points)
 {
   const double ts0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  // device projection queued for this frame (enqueueCandidateProjection): take it out of the context now
+  const bool have_proj = proj_frame_ == cur_frame.get();
+  if (have_proj && !proj_collected_) {
+    proj_px_.resize(2 * proj_kind_.size()); proj_visible_.resize(proj_kind_.size());
+    if (svoh_project_candidates_collect(ctx_, static_cast<int>(proj_kind_.size()), proj_px_.data(), proj_visible_.data()) != SVOH_OK)
+      throw std::runtime_error(std::string("svoh_project_candidates_collect: ") + svoh_last_error_string(ctx_));
+    proj_collected_ = true;
+  } else if (!have_proj) {
+    discardCandidateProjection();
+  }
+  struct ProjRelease { ReprojectorHip* r; bool on; ~ProjRelease() { if (on) { r->proj_frame_ = nullptr; r->proj_collected_ = false; } } } proj_release{ this, have_proj };
   const size_t max_total_n_features = options_.max_n_features_per_frame;   // + max_n_fixed_lm, 0 without the global map
   if (options_.max_n_features_per_frame == 0) throw std::runtime_error("Reprojector: max_n_features_per_frame must be > 0");   // CHECK_GT
   if (!grid_)
@@ -912,6 +1030,24 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
   struct Release { std::vector<reprojector::Candidate>&a, &b, &c; ~Release() { a.clear(); b.clear(); c.clear(); } } release{ candidates_, converged, unconverged };
   for (const FramePtr& ref_frame : visible_kfs) {
     const svoh::Rigid T_world_ref = svoh::inverse(ref_frame->T_f_w_);
+    // this keyframe's slice of the device projection, if it was part of it
+    long proj_off = -1;
+    if (have_proj)
+      for (const auto& ko : proj_kf_off_) if (ko.first == ref_frame.get()) { proj_off = static_cast<long>(ko.second); break; }
+    auto get_candidate = [&](size_t i, reprojector::Candidate& candidate) -> bool {
+      if (proj_off < 0) return reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref);
+      const size_t at = static_cast<size_t>(proj_off) + i;
+      if (!proj_visible_[at]) return false;
+      const PointPtr lm = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i] : nullptr;
+      candidate = reprojector::Candidate();
+      candidate.ref_frame = ref_frame; candidate.ref_index = i;
+      candidate.cur_px[0] = proj_px_[2 * at]; candidate.cur_px[1] = proj_px_[2 * at + 1];
+      candidate.n_reproj = lm ? lm->n_succeeded_reproj_ - lm->n_failed_reproj_ : 0;
+      candidate.score = i < ref_frame->score_vec_.size() ? ref_frame->score_vec_[i] : 0.0;
+      candidate.type = ref_frame->type_vec_[i];
+      candidate.n_obs = lm ? lm->obs_.size() : 0u;
+      return true;
+    };
     for (size_t i = 0; i < ref_frame->num_features_; ++i) {
       const uint8_t type = ref_frame->type_vec_[i];
       static const PointPtr no_point;
@@ -922,12 +1058,12 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
         else if (point->last_projected_kf_id_.at(camera_index_) != cur_frame->id_) {   // project a point only once
           point->last_projected_kf_id_[camera_index_] = cur_frame->id_;
           if (point->obs_.size() < 2 && options_.remove_unconstrained_points) trash_points.push_back(point);
-          else if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref)) candidates_.push_back(candidate);
+          else if (get_candidate(i, candidate)) candidates_.push_back(candidate);
         }
       }
       const bool conv = type == SVOH_FT_CORNER_SEED_CONVERGED || type == SVOH_FT_EDGELET_SEED_CONVERGED;
       const bool unconv = (type == SVOH_FT_CORNER_SEED || type == SVOH_FT_EDGELET_SEED) && options_.reproject_unconverged_seeds;
-      if ((conv || unconv) && reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref))
+      if ((conv || unconv) && get_candidate(i, candidate))
         (conv ? converged : unconverged).push_back(candidate);
     }
   }

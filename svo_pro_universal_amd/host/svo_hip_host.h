@@ -172,6 +172,14 @@ class SparseImgAlignHip {
   // frame of the bundle) and returns the number of features tracked; 0 = none.
   // Throws std::runtime_error on an ABI error (the reference CHECK-aborts).
   size_t run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames);
+  // The same with a hook between the launch and the wait for it: after_enqueue(T_iref_world) runs while the
+  // alignment kernel does, and device work it queues on the context (ReprojectorHip::enqueueCandidateProjection)
+  // runs right behind the alignment and comes back with the same round trip.  lastRunRepeated(): the launch had to
+  // be repeated (a cluster of workgroups gave up, svoh_sparse_align_batch's fallback), so whatever was queued behind
+  // the first launch has used a pose that is not the result's and must be discarded by the caller.
+  using AfterEnqueue = std::function<void(const Transformation& T_iref_world)>;
+  size_t run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames, const AfterEnqueue& after_enqueue);
+  bool lastRunRepeated() const { return last_run_repeated_; }
 
   // The same optimisation with the patches split over `world` participants (GPUs): this one takes share `rank`
   // of every camera's features, and between evaluateError and the solve the 74 doubles at d_sums (DEVICE memory)
@@ -197,6 +205,7 @@ class SparseImgAlignHip {
   double alpha_init_ = 0.0, beta_init_ = 0.0;
   svoh_align_prior prior_{};
   svoh_align_result last_{};
+  bool last_run_repeated_ = false;
 };
 
 // ---------------------------------------------------------------------------
@@ -229,6 +238,15 @@ class DepthFilterHip {
   // returns the number of successfully updated seeds; updates invmu_sigma2_a_b_vec_ and
   // type_vec_ of the reference frames in place, exactly like the reference
   size_t updateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame);
+  // The same in two halves: updateSeedsAsync sends the update to the device and returns (the reference frames must
+  // not be touched by anything that reads or writes their seeds until the update is finished -- appending features to
+  // them is fine); finishUpdateSeeds waits for it, writes the states and types back and returns the success count.
+  // Nothing in a frame's chain needs the updated seeds before the NEXT frame's alignment, so a caller that finishes
+  // there takes the seed update (kernel + round trip) off the per-frame critical path.  No other deferred matcher
+  // section can be opened on the context in between (ReprojectorHip opens one: finish first).
+  void updateSeedsAsync(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame);
+  size_t finishUpdateSeeds();
+  bool updatePending() const { return async_open_; }
   svoh_matcher_options& getMatcherOptions() { return matcher_options_; }
   // Matcher::MatchResult of every seed of the last call, in (frame, feature) order
   const std::vector<int32_t>& lastMatchResults() const { return last_results_; }
@@ -240,6 +258,16 @@ class DepthFilterHip {
   bool have_px_error_angle_ = false;   // the function-local static of updateSeed (depth_filter.cpp:383-384)
   double px_error_angle_ = 0.0;
   std::vector<int32_t> last_results_;
+  struct Pending {   // the arrays of the queued update: alive until finishUpdateSeeds
+    std::vector<FramePtr> frames;
+    std::vector<size_t> counts;
+    std::vector<svoh_frame_view> refs;
+    std::vector<int32_t> ref_idx, level;
+    std::vector<double> px, f, grad, state;
+    std::vector<uint8_t> type, success;
+    int32_t n_success = 0;
+  } pending_;
+  bool async_open_ = false;
 };
 
 // ---------------------------------------------------------------------------
@@ -406,6 +434,17 @@ class ReprojectorHip {
  public:
   ReprojectorHip(svoh_ctx* ctx, const ReprojectorOptions& options, size_t camera_index);
   void reprojectFrames(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points);
+  // f-4 on the device: the arithmetic of reprojector_utils::getCandidate -- seed position, projection into
+  // cur_frame, visibility cone, image box, 8-pixel margin -- for EVERY feature of `kfs` (the local map: which of them
+  // are visible is only known once the pose is), queued on the context without a wait (svoh_project_candidates_enqueue).
+  // Called from SparseImgAlignHip::run's after_enqueue hook with align_result_index >= 0, the pose is composed on the
+  // device from the alignment's result and the projection comes back with the alignment's own round trip; the next
+  // reprojectFrames(cur_frame, ...) then takes the pixel and the verdict of every candidate of these keyframes from
+  // the device instead of computing them (same bits: tests/cpp/test_host_reprojector.cpp), and walks, sorts and
+  // replays as before.  discardCandidateProjection() drops a queued projection (lastRunRepeated()).
+  void enqueueCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const Transformation* T_iref_world,
+                                  int align_result_index);
+  void discardCandidateProjection();
   bool doesFrameHaveEnoughFeatures(const FramePtr& frame) const
   {
     return options_.max_n_features_per_frame > 0 && frame->numTrackedFeatures() >= options_.max_n_features_per_frame;
@@ -418,6 +457,14 @@ class ReprojectorHip {
   svoh_ctx* ctx_;
   size_t camera_index_;
   bool speculate_unconverged_ = false;   // was the unconverged-seed pass reached on the previous frame?
+  // queued / collected device projection: per keyframe the offset of its first feature in the flat arrays
+  const Frame* proj_frame_ = nullptr;
+  bool proj_collected_ = false;
+  std::vector<std::pair<const Frame*, size_t>> proj_kf_off_;
+  std::vector<uint8_t> proj_kind_, proj_visible_;
+  std::vector<int32_t> proj_kf_;
+  std::vector<double> proj_v_, proj_mu_, proj_px_;
+  std::vector<svoh_se3> proj_T_world_kf_;
 };
 
 namespace reprojector_utils {

@@ -107,3 +107,23 @@ def test_streams_share_one_gpu(tmp_path):
         rates[n_streams] = sum(1e3 / np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[3:, 7:13].sum(1).mean() for d in dirs)
     print("steady-state frames/s on one GPU: one stream %.0f, four streams %.0f, eight streams %.0f in total" % (rates[1], rates[4], rates[8]))
     assert rates[4] > 1.2 * rates[1]    # measured 2.3-2.8x (8 streams 3.5-4.6x); the bar only says that streams do overlap
+
+
+def test_pipelined_flow_equals_the_blocking_flow(tmp_path):
+    """Round 3: the harness queues the reprojector's candidate projection (f-4) on the device behind the alignment launch
+    and takes the depth filter's seed update off the critical path (sent off, finished at the next frame's start).
+    Both are re-orderings of the same arithmetic: the trajectory file and every counter of frontend.csv must be those of
+    the blocking flow (SVOH_MINI_SYNC=1: the reference's order, host-side candidate projection), byte for byte."""
+    cmd, out_dir, poses, stamps, n_frames = make_dataset(tmp_path)
+    runs = {}
+    for name, env in (("pipelined", {}), ("blocking", {"SVOH_MINI_SYNC": "1"})):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=e)
+        assert r.returncode == 0, r.stdout + r.stderr
+        fc = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)
+        runs[name] = (open(str(out_dir / "trajectory.txt")).read(), fc[:, :7].copy(), fc[3:, 7:13].sum(1))
+        print(name, r.stdout.strip())
+    assert runs["pipelined"][0] == runs["blocking"][0]
+    assert np.array_equal(runs["pipelined"][1], runs["blocking"][1])
+    print("steady-state ms/frame: pipelined mean %.3f median %.3f, blocking mean %.3f median %.3f" %
+          (runs["pipelined"][2].mean(), np.median(runs["pipelined"][2]), runs["blocking"][2].mean(), np.median(runs["blocking"][2])))

@@ -14,6 +14,11 @@
 //   svoh_mini_frontend <dataset_root> <calib.yaml> <params.yaml|-> <out_dir> <T_f_w of frame 0: qw qx qy qz tx ty tz>
 //                      <depth_min> <depth_mean> <depth_max> [max_frames] [kf_every] [n_streams]
 // Writes <out>/trajectory.txt (TUM format, T_world_cam) and <out>/frontend.csv (per-frame counters and timings).
+// Environment: SVOH_MINI_SYNC=1 runs every stage as a blocking call, in the reference's order (round 2's flow); by
+// default (a) the candidate projection of the reprojector (f-4) is queued on the device behind the alignment launch
+// and comes back with the alignment's round trip, and (b) the depth filter's seed update is sent off without a wait
+// and finished at the start of the next frame, before anything reads the seeds again.  Both flows give the same
+// trajectory file byte for byte (tests/test_mini_frontend_gpu.py).
 // n_streams > 1 (independent camera streams need no exchange): that many host threads, each
 // with its own svoh_ctx (own HIP stream) and its own copy of the chain's state, run the same sequence side by side on
 // ONE GPU; stream k > 0 writes into <out>/stream<k>/.  At EuRoC sizes a stream keeps the GPU busy for a small part
@@ -50,6 +55,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
 {
   try {
     const size_t min_tracked = 60;
+    const bool sync_flow = getenv("SVOH_MINI_SYNC") != nullptr && atoi(getenv("SVOH_MINI_SYNC")) != 0;
     svoh_ctx* ctx = nullptr;
     if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
     const svoh_camera& cam = rig.at(0).cam;
@@ -94,6 +100,25 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
     const double wall0 = now_ms();
     double sum_ms = 0;
     size_t n_done = 0;
+    // a frame's CSV row is written once its seed update has been finished (at the start of the next frame in the
+    // default flow): the counters of both flows are the same
+    struct Row { bool valid = false, finished = false; size_t k = 0, n_seed_upd = 0; int is_kf = 0; size_t n_aligned = 0, n_reproj = 0, n_pose = 0; double ms[6] = {0, 0, 0, 0, 0, 0}; } row;
+    auto finish_row = [&]() {
+      if (!row.valid) return;
+      if (!row.finished) {
+        const double tf0 = now_ms();
+        row.n_seed_upd = depth_filter.finishUpdateSeeds();
+        row.ms[4] += now_ms() - tf0;
+      }
+      const size_t n_seed_upd = row.n_seed_upd;
+      size_t n_conv = 0;
+      for (const FramePtr& f : kfs)
+        for (size_t i = 0; i < f->num_features_; ++i)
+          n_conv += f->type_vec_[i] == SVOH_FT_CORNER_SEED_CONVERGED || f->type_vec_[i] == SVOH_FT_EDGELET_SEED_CONVERGED;
+      fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", row.k, row.is_kf, row.n_aligned, row.n_reproj, row.n_pose,
+              n_seed_upd, n_conv, row.ms[0], row.ms[1], row.ms[2], row.ms[3], row.ms[4], row.ms[5]);
+      row.valid = false;
+    };
     for (size_t k = 0; k < images.size(); ++k) {
       const io::GrayImage& img = images[k];
       const double t0 = now_ms();
@@ -104,8 +129,11 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
       frame->cam = cam;
       frame->set_T_cam_imu(svoh::inverse(rig[0].T_B_C));
       frame->id_ = (int)k;
+      // the previous frame's seed update: its results are needed from here on (alignment points, candidates)
+      finish_row();
       const double t1 = now_ms();
       size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0;
+      bool seeds_finished = false;
       double t2 = t1, t3 = t1, t4 = t1, t5 = t1;
       bool is_kf = false;
       if (k == 0) {
@@ -120,10 +148,19 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
         FrameBundle::Ptr b_last(new FrameBundle), b_cur(new FrameBundle);
         b_last->frames_.push_back(last); b_cur->frames_.push_back(frame);
         img_align.reset();
-        n_aligned = img_align.run(b_last, b_cur);
+        std::vector<FramePtr> visible(kfs.begin(), kfs.end());
+        if (sync_flow) {
+          n_aligned = img_align.run(b_last, b_cur);
+        } else {
+          // the candidates' projection is queued behind the alignment kernel; its pose is the alignment's result,
+          // composed on the device (ReprojectorHip::enqueueCandidateProjection)
+          n_aligned = img_align.run(b_last, b_cur, [&](const Transformation& T_iref_world) {
+            reprojector.enqueueCandidateProjection(frame, visible, &T_iref_world, 0);
+          });
+          if (img_align.lastRunRepeated() || n_aligned == 0) reprojector.discardCandidateProjection();
+        }
         t2 = now_ms();
         // 2. reprojection (frame_handler_base.cpp:645-744)
-        std::vector<FramePtr> visible(kfs.begin(), kfs.end());
         std::vector<PointPtr> trash;
         reprojector.reprojectFrames(frame, visible, trash);
         n_reproj = frame->num_features_;
@@ -132,22 +169,21 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
         if (frame->num_features_ >= 10) n_pose = pose_optimizer.run(b_cur, 2.0);
         t4 = now_ms();
         // 4. depth filter (frame_handler_mono.cpp:125)
-        n_seed_upd = depth_filter.updateSeeds(visible, frame);
+        depth_filter.updateSeedsAsync(visible, frame);
+        if (sync_flow) { n_seed_upd = depth_filter.finishUpdateSeeds(); seeds_finished = true; }   // wait here, as the reference does
         t5 = now_ms();
         // 5. keyframe rule
         if (k % kf_every == 0 || frame->numTrackedFeatures() < min_tracked) { make_keyframe(frame); is_kf = true; }
       }
       const double t6 = now_ms();
-      size_t n_conv = 0;
-      for (const FramePtr& f : kfs)
-        for (size_t i = 0; i < f->num_features_; ++i)
-          n_conv += f->type_vec_[i] == SVOH_FT_CORNER_SEED_CONVERGED || f->type_vec_[i] == SVOH_FT_EDGELET_SEED_CONVERGED;
       traj.write(seq.cam_ts[k], svoh::inverse(frame->T_f_w_));
-      fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", k, (int)is_kf, n_aligned, n_reproj, n_pose, n_seed_upd, n_conv,
-              t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5);
+      row.valid = true; row.finished = seeds_finished || k == 0; row.n_seed_upd = n_seed_upd; row.k = k; row.is_kf = (int)is_kf; row.n_aligned = n_aligned; row.n_reproj = n_reproj; row.n_pose = n_pose;
+      row.ms[0] = t1 - t0; row.ms[1] = t2 - t1; row.ms[2] = t3 - t2; row.ms[3] = t4 - t3; row.ms[4] = t5 - t4; row.ms[5] = t6 - t5;
+      if (sync_flow) finish_row();
       if (k > 0) { sum_ms += t6 - t0; ++n_done; }
       last = frame;
     }
+    finish_row();
     out->wall_ms = now_ms() - wall0;
     fclose(fc);
     out->n_done = n_done; out->sum_ms = sum_ms; out->n_kfs = kfs.size();
