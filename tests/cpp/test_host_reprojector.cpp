@@ -371,6 +371,97 @@ int main(int argc, char** argv)
            e_numf, kinds[0], kinds[1], kinds[2], e_trials, e_trash);
     CHECK(kinds[0] > 0 && (max_n > 0 || (kinds[1] > 0 && kinds[2] > 0)));   // the 220-feature run reaches all three passes
   }
+  // ================= f-4 on the device: candidate projection queued on the context =================
+  // The same reprojection twice on fresh frames: once with the candidates' projection computed by the host mirror
+  // (reprojector_utils::getCandidate), once with the projection of every feature of the keyframe queued on the device
+  // first (ReprojectorHip::enqueueCandidateProjection -> svoh_project_candidates_enqueue).  The device's pixel and
+  // verdict of every feature must be the host's bit for bit, and so must everything reprojectFrames leaves behind.
+  {
+    struct Set { FramePtr kf, cur, far; std::vector<PointPtr> pts; };
+    auto build = [&](int id0) {
+      Set s;
+      s.kf = make_frame(img_kf, T_kf.data(), id0); s.cur = make_frame(img_cur, T_cur.data(), id0 + 1); s.far = make_frame(img_kf, T_far.data(), id0 + 2);
+      s.kf->num_features_ = (size_t)n;
+      s.kf->px_vec_ = px; s.kf->f_vec_ = fv; s.kf->grad_vec_ = grad; s.kf->level_vec_ = level; s.kf->type_vec_ = type;
+      s.kf->invmu_sigma2_a_b_vec_ = state; s.kf->seed_mu_range_ = mu_range[0]; s.kf->score_vec_ = score;
+      s.kf->landmark_vec_.assign(n, nullptr);
+      s.far->num_features_ = 1; s.far->px_vec_ = { 100, 100 }; s.far->f_vec_ = { 0, 0, 1 }; s.far->grad_vec_ = { 1, 0 };
+      s.far->level_vec_ = { 0 }; s.far->type_vec_ = { SVOH_FT_CORNER }; s.far->invmu_sigma2_a_b_vec_ = { 1, 1, 10, 10 };
+      s.pts.resize(n);
+      for (int i = 0; i < n; ++i) {
+        if (!lm_kind[i]) continue;
+        PointPtr p(new Point);
+        p->pos_ = { lm_pos[3 * i], lm_pos[3 * i + 1], lm_pos[3 * i + 2] };
+        p->obs_.push_back(Point::Obs{ s.far, 0 });
+        if (lm_kind[i] == 1) p->obs_.push_back(Point::Obs{ s.kf, (size_t)i });
+        p->n_succeeded_reproj_ = i % 5; p->n_failed_reproj_ = i % 3;
+        s.kf->landmark_vec_[i] = p;
+        s.pts[i] = p;
+      }
+      return s;
+    };
+    ReprojectorOptions ro;
+    ro.max_n_features_per_frame = (size_t)(max_n > 0 ? max_n : 220);
+    ro.max_unconverged_seeds_ratio = 0.6;
+    Set host = build(31), dev = build(41);
+    // (a) the device's projection of every feature against the host's getCandidate
+    {
+      std::vector<uint8_t> kind(n), vis(n);
+      std::vector<int32_t> kfi(n, 0);
+      std::vector<double> v(3 * (size_t)n), mu(n), dpx(2 * (size_t)n);
+      for (int i = 0; i < n; ++i) {
+        kind[i] = lm_kind[i] ? 0 : 1;
+        for (int j = 0; j < 3; ++j) v[3 * i + j] = lm_kind[i] ? lm_pos[3 * i + j] : fv[3 * i + j];
+        mu[i] = state[4 * i];
+      }
+      svoh_se3 T_f_w, T_w_kf;
+      svoh::store_rigid(dev.cur->T_f_w_, T_f_w);
+      svoh::store_rigid(svoh::inverse(dev.kf->T_f_w_), T_w_kf);
+      CHECK(svoh_project_candidates(ctx, &dev.cur->cam, &T_f_w, 1, &T_w_kf, n, kind.data(), kfi.data(), v.data(), mu.data(), dpx.data(), vis.data()) == SVOH_OK);
+      int n_vis = 0;
+      for (int i = 0; i < n; ++i) {
+        reprojector::Candidate c;
+        const bool ok = reprojector_utils::getCandidate(host.cur, host.kf, (size_t)i, c);
+        CHECK(ok == (vis[i] != 0));
+        if (ok) { CHECK(c.cur_px[0] == dpx[2 * i] && c.cur_px[1] == dpx[2 * i + 1]); ++n_vis; }
+      }
+      CHECK(n_vis > 20);
+      // misuse: a second queued call before the first is collected, a collect with the wrong count
+      CHECK(svoh_project_candidates_enqueue(ctx, &dev.cur->cam, &T_f_w, nullptr, -1, 1, &T_w_kf, n, kind.data(), kfi.data(), v.data(), mu.data()) == SVOH_OK);
+      CHECK(svoh_project_candidates_enqueue(ctx, &dev.cur->cam, &T_f_w, nullptr, -1, 1, &T_w_kf, n, kind.data(), kfi.data(), v.data(), mu.data()) != SVOH_OK);
+      CHECK(svoh_project_candidates_collect(ctx, n - 1, dpx.data(), vis.data()) != SVOH_OK);
+      CHECK(svoh_project_candidates_collect(ctx, n, dpx.data(), vis.data()) == SVOH_OK);
+      CHECK(svoh_project_candidates_enqueue(ctx, &dev.cur->cam, &T_f_w, nullptr, 0, 1, &T_w_kf, n, kind.data(), kfi.data(), v.data(), mu.data()) != SVOH_OK);   // pose from an alignment result without T_post
+    }
+    // (b) reprojectFrames with and without the queued projection
+    ReprojectorHip r_host(ctx, ro, 0), r_dev(ctx, ro, 0);
+    std::vector<PointPtr> trash_h, trash_d;
+    r_host.reprojectFrames(host.cur, { host.kf }, trash_h);
+    r_dev.enqueueCandidateProjection(dev.cur, { dev.kf }, nullptr, -1);
+    r_dev.reprojectFrames(dev.cur, { dev.kf }, trash_d);
+    CHECK(trash_h.size() == trash_d.size());
+    CHECK(host.cur->num_features_ == dev.cur->num_features_ && host.cur->num_features_ > 20);
+    CHECK(r_host.stats_.n_trials == r_dev.stats_.n_trials && r_host.stats_.n_matches == r_dev.stats_.n_matches);
+    for (size_t k = 0; k < (size_t)r_host.grid_->occupancy_.size(); ++k) CHECK(r_host.grid_->isOccupied(k) == r_dev.grid_->isOccupied(k));
+    for (size_t s2 = 0; s2 < host.cur->num_features_; ++s2) {
+      CHECK(host.cur->px_vec_[2 * s2] == dev.cur->px_vec_[2 * s2] && host.cur->px_vec_[2 * s2 + 1] == dev.cur->px_vec_[2 * s2 + 1]);
+      CHECK(host.cur->type_vec_[s2] == dev.cur->type_vec_[s2] && host.cur->level_vec_[s2] == dev.cur->level_vec_[s2]);
+      for (int j = 0; j < 3; ++j) CHECK(host.cur->f_vec_[3 * s2 + j] == dev.cur->f_vec_[3 * s2 + j]);
+    }
+    for (int i = 0; i < n; ++i) {
+      CHECK(host.kf->type_vec_[i] == dev.kf->type_vec_[i]);
+      for (int j = 0; j < 4; ++j) CHECK(host.kf->invmu_sigma2_a_b_vec_[4 * i + j] == dev.kf->invmu_sigma2_a_b_vec_[4 * i + j]);
+      if (host.pts[i]) CHECK(host.pts[i]->n_failed_reproj_ == dev.pts[i]->n_failed_reproj_ && host.pts[i]->n_succeeded_reproj_ == dev.pts[i]->n_succeeded_reproj_);
+    }
+    // a projection queued for another frame is not used (and does not block the context)
+    Set other = build(51);
+    r_dev.enqueueCandidateProjection(other.cur, { other.kf }, nullptr, -1);
+    Set again = build(61);
+    std::vector<PointPtr> trash_a;
+    r_dev.reprojectFrames(again.cur, { again.kf }, trash_a);
+    CHECK(again.cur->num_features_ == host.cur->num_features_);
+    printf("device candidate projection: %zu features, identical to the host mirror\n", dev.cur->num_features_);
+  }
   svoh_destroy(ctx);
   printf("PASS\n");
   return 0;

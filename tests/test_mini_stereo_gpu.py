@@ -1,0 +1,105 @@
+"""BASELINE config 3 end to end on synthetic data: the per-frame chain of FrameHandlerStereo::processFrame assembled from
+this library's mirrors (tools/svoh_mini_stereo.cpp) on an EuRoC-layout STEREO sequence -- bootstrap by stereo
+triangulation of the first pair (StereoTriangulationHip::compute), bundle alignment with 8 parameters (pose +
+illumination gain and offset, euroc_stereo_imu.yaml:30-31) under the IMU's rotation prior (setWeightedPrior,
+frame_handler_base.cpp:629-631), per-camera reprojection and depth-filter update, rig pose optimisation.  The images'
+gain and offset drift from frame to frame.  No reference output exists to compare with: the bar is the
+trajectory error against the scene's ground truth, at METRIC scale (the stereo baseline fixes it)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from svo_pro_universal_amd import synth
+from test_io_cpu import write_png
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+BASELINE_M = 0.11
+
+
+def make_stereo_dataset(tmp_path, n_frames=30):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host")])
+    cam = synth.Camera.euroc_like(752, 480)
+    sc = synth.make_align_scene(171, n_features=8, cam=cam, rot_deg=(0.3, 0.5), trans_m=(0.015, 0.025))
+    step = sc.T_w_ref.inverse() * sc.T_w_cur
+    poses = [sc.T_w_ref]                       # T_world_imu (= left camera)
+    for k in range(1, n_frames):
+        poses.append(poses[-1] * step)
+    T_B_C = [synth.SE3(), synth.SE3((1.0, 0.0, 0.0, 0.0), (BASELINE_M, 0.0, 0.0))]
+    stamps = [1403636579763555584 + 50000000 * k for k in range(n_frames)]
+    for c in range(2):
+        data = tmp_path / "ds" / "mav0" / ("cam%d" % c) / "data"
+        data.mkdir(parents=True)
+        for k, T in enumerate(poses):
+            gain, offset = 1.0 + 0.08 * np.sin(k / 4.0), 6.0 * np.cos(k / 5.0)
+            img = synth.render(cam, T * T_B_C[c], sc.plane, sc.tex, gain=gain, offset=offset)
+            write_png(str(data / ("%d.png" % stamps[k])), img, chunk=65536)
+        (tmp_path / "ds" / "mav0" / ("cam%d" % c) / "data.csv").write_text("#timestamp [ns],filename\n" + "".join("%d,%d.png\n" % (t, t) for t in stamps))
+    # what a gyroscope integration would hand to the front end: R_imu(k)_imu(k-1), slightly off
+    rng = np.random.RandomState(3)
+    lines = ["1.0,0.0,0.0,0.0"]
+    for k in range(1, n_frames):
+        d = poses[k].inverse() * poses[k - 1]
+        noise = synth.SE3(synth.quat_from_axis_angle(rng.normal(size=3), 2e-4), (0, 0, 0))
+        q = (noise * d).q
+        lines.append(",".join("%.17g" % v for v in q))
+    (tmp_path / "ds" / "mav0" / "imu_prior.csv").write_text("#qw,qx,qy,qz of R_imu(k)_imu(k-1)\n" + "\n".join(lines) + "\n")
+    cam_yaml = """- camera:
+    label: cam%d
+    image_height: %d
+    image_width: %d
+    type: pinhole
+    intrinsics:
+      data: [%.17g, %.17g, %.17g, %.17g]
+    distortion:
+      type: radial-tangential
+      parameters:
+        data: [%.17g, %.17g, %.17g, %.17g]
+  T_B_C:
+    data: [1.0, 0.0, 0.0, %.17g, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+"""
+    (tmp_path / "calib.yaml").write_text("cameras:\n" + "".join(
+        cam_yaml % ((c, cam.height, cam.width, cam.fx, cam.fy, cam.cx, cam.cy) + tuple(cam.dist) + (BASELINE_M * c,)) for c in range(2)))
+    (tmp_path / "params.yaml").write_text("max_fts: 160\ngrid_size: 35\nn_pyr_levels: 3\ndetector_threshold_secondary: 100\n"
+                                          "use_threaded_depthfilter: False\nimg_align_max_level: 4\nimg_align_min_level: 2\n")
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    T0 = poses[0].inverse().as7()
+    tool = os.path.join(ROOT, "svo_pro_universal_amd", "host", "svoh_mini_stereo")
+    cmd = ([tool, str(tmp_path / "ds"), str(tmp_path / "calib.yaml"), str(tmp_path / "params.yaml"), str(out_dir)] + ["%.17g" % v for v in T0])
+    return cmd, out_dir, poses, stamps
+
+
+def test_mini_stereo_tracks_a_synthetic_stereo_sequence(tmp_path):
+    import ate
+    n_frames = 30
+    cmd, out_dir, poses, stamps = make_stereo_dataset(tmp_path, n_frames)
+    r = subprocess.run(cmd + [str(n_frames), "8", "0.5"], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    est = ate.load_tum(str(out_dir / "trajectory.txt"))
+    gt = np.array([[stamps[k] * 1e-9] + list(T.t) + [T.q[1], T.q[2], T.q[3], T.q[0]] for k, T in enumerate(poses)])
+    res = ate.ate(est, gt, with_scale=False, max_dt=1e-3)
+    res_s = ate.ate(est, gt, with_scale=True, max_dt=1e-3)
+    path_len = float(np.linalg.norm(np.diff(gt[:, 1:4], axis=0), axis=1).sum())
+    fc = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)
+    print("stereo: ATE rmse %.4f m over a %.3f m path at metric scale (free scale would be %.3f); features per pair: median %d; "
+          "landmarks at the end %d; alpha range [%.3f, %.3f], beta range [%.2f, %.2f]"
+          % (res["rmse"], path_len, res_s["scale"], int(np.median(fc[1:, 3])), int(fc[-1, 6]), fc[1:, 7].min(), fc[1:, 7].max(),
+             fc[1:, 8].min(), fc[1:, 8].max()))
+    stage = np.median(fc[3:, 9:15], axis=0)
+    print("median ms per pair: pyramids %.3f align %.3f reproject %.3f pose %.3f seeds %.3f keyframe %.3f  total %.3f"
+          % (tuple(stage) + (stage.sum(),)))
+    assert res["n"] == n_frames
+    assert res["rmse"] < 0.03 * path_len + 0.003          # a few per cent of the distance travelled, no scale freedom
+    assert 0.9 < res_s["scale"] < 1.1                     # the stereo bootstrap has fixed the scale
+    assert np.median(fc[1:, 3]) > 100                     # both reprojectors keep features alive
+    assert fc[0, 6] >= 60                                 # the first pair was triangulated (landmarks in both frames)
+    assert np.abs(fc[1:, 7]).max() > 0.005 and np.abs(fc[1:, 8]).max() > 0.3   # the illumination terms were estimated, not zero
+    # without the rotation prior the chain still runs (lambda 0): the prior is a weight, not a requirement
+    r0 = subprocess.run(cmd + [str(10), "8", "0"], capture_output=True, text=True)
+    assert r0.returncode == 0, r0.stdout + r0.stderr

@@ -1,0 +1,220 @@
+// svoh_mini_stereo -- the per-frame chain of FrameHandlerStereo::processFrame (src/svo/src/frame_handler_stereo.cpp:90-205,
+// frame_handler_base.cpp:610-825) assembled from this library's mirrors on an EuRoC-layout STEREO sequence: BASELINE
+// config 3 (stereo + IMU rotation prior, illumination gain and offset estimated) end to end.
+//
+//   first pair: stereo triangulation of new features                StereoTriangulationHip::compute  (StereoInit)
+//   sparse image alignment of the bundle (2 cameras, 8 parameters:  SparseImgAlignHip::run, setWeightedPrior with the
+//     pose + illumination gain / offset) with the rotation prior      IMU's relative rotation (frame_handler_base.cpp:619-631)
+//   reprojection of the keyframes' landmarks / seeds, per camera    ReprojectorHip::reprojectFrames
+//   pose optimisation of the rig on both cameras' matches           PoseOptimizerHip::run
+//   depth-filter update of the keyframes' seeds, per camera         DepthFilterHip::updateSeeds
+//   at keyframes: stereo triangulation again + new seeds            StereoTriangulationHip::compute, initializeSeeds
+//
+// A harness over the built mirrors, NOT FrameHandlerStereo: no map (every live keyframe counts as overlapping), no
+// upgrade of converged seeds to landmarks, keyframes by a fixed rule, the first rig pose given.  The IMU prior is read
+// from <dataset_root>/mav0/imu_prior.csv (one line per frame: qw qx qy qz of R_imu(k)_imu(k-1), as a gyroscope
+// integration would deliver it); without the file no prior is set.
+//
+//   svoh_mini_stereo <dataset_root> <calib.yaml (two cameras)> <params.yaml|-> <out_dir> <T_imu_world of frame 0: qw qx qy qz tx ty tz>
+//                    [max_frames] [kf_every] [prior_lambda_rot]
+// Writes <out>/trajectory.txt (TUM format, T_world_imu) and <out>/frontend.csv.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../svo_pro_universal_amd/host/svo_hip_io.h"
+
+using namespace svo_hip;
+
+static double now_ms()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char** argv)
+{
+  if (argc < 12) {
+    fprintf(stderr, "usage: %s <dataset_root> <calib.yaml> <params.yaml|-> <out_dir> qw qx qy qz tx ty tz [max_frames] [kf_every] [prior_lambda_rot]\n", argv[0]);
+    return 2;
+  }
+  svoh_ctx* ctx = nullptr;
+  try {
+    const io::EurocSequence seq = io::openEuroc(argv[1]);
+    const std::vector<io::RigCamera> rig = io::loadCameraRig(argv[2]);
+    if (rig.size() != 2 || seq.cam1_files.size() != seq.cam0_files.size()) throw std::runtime_error("a stereo rig and two image folders are needed");
+    io::FrontendParams params = std::string(argv[3]) == "-" ? io::frontendParamsFromYaml(io::YamlNode()) : io::loadFrontendParams(argv[3]);
+    const std::string out_dir = argv[4];
+    const Transformation T_imu_world0{ { atof(argv[5]), atof(argv[6]), atof(argv[7]), atof(argv[8]) }, { atof(argv[9]), atof(argv[10]), atof(argv[11]) } };
+    const size_t max_frames = argc > 12 ? (size_t)atol(argv[12]) : seq.size();
+    const size_t kf_every = argc > 13 ? (size_t)atol(argv[13]) : 8;
+    const double lambda_rot = argc > 14 ? atof(argv[14]) : 0.5;
+    const size_t n_frames = std::min(seq.size(), max_frames);
+
+    // the IMU's relative rotations, if the dataset has them
+    std::vector<svoh::Quat> imu_prior;
+    {
+      std::ifstream in(std::string(argv[1]) + "/mav0/imu_prior.csv");
+      std::string line;
+      while (std::getline(in, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        for (char& c : line) if (c == ',') c = ' ';
+        std::istringstream ss(line);
+        svoh::Quat q{ 1, 0, 0, 0 };
+        ss >> q.w >> q.x >> q.y >> q.z;
+        imu_prior.push_back(q);
+      }
+    }
+
+    if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
+    params.depth_filter.use_threaded_depthfilter = false;
+    // euroc_stereo_imu.yaml:30-31: img_align_est_illumination_gain / _offset
+    params.img_align.estimate_illumination_gain = true;
+    params.img_align.estimate_illumination_offset = true;
+    SparseImgAlignHip img_align(ctx, SparseImgAlignHip::getDefaultSolverOptions(), params.img_align);
+    ReprojectorOptions ropt;
+    ropt.max_n_features_per_frame = (size_t)params.max_fts;
+    ropt.cell_size = (size_t)params.grid_size;
+    ropt.seed_sigma2_thresh = params.seed_sigma2_thresh;
+    ropt.affine_est_offset = params.reprojector_affine_est_offset;
+    ropt.affine_est_gain = true;   // the stereo-imu configuration estimates the gain in the matcher as well
+    ReprojectorHip reprojector0(ctx, ropt, 0), reprojector1(ctx, ropt, 1);
+    ReprojectorHip* reprojectors[2] = { &reprojector0, &reprojector1 };
+    PoseOptimizerHip pose_optimizer(ctx);
+    DepthFilterHip depth_filter(ctx, params.depth_filter);
+    DetectorHip seed_detector(ctx, params.detector, rig[0].cam.width, rig[0].cam.height);
+    std::shared_ptr<DetectorHip> tri_detector(new DetectorHip(ctx, params.detector, rig[0].cam.width, rig[0].cam.height));
+    StereoTriangulationOptions sto;
+    sto.triangulate_n_features = 120;   // svo_factory.cpp:240
+    StereoTriangulationHip stereo(ctx, sto, tri_detector);
+    unsigned shuffle_state = 12345u;    // reproducible order instead of rand()
+    stereo.shuffle_ = [&](std::vector<size_t>& idx, size_t n_corners) {
+      auto rnd = [&]() { shuffle_state = shuffle_state * 1664525u + 1013904223u; return shuffle_state >> 8; };
+      auto shuf = [&](size_t a, size_t b) { for (size_t i = b; i > a + 1; --i) std::swap(idx[i - 1], idx[a + rnd() % (i - a)]); };
+      shuf(0, std::min(n_corners, idx.size())); shuf(std::min(n_corners, idx.size()), idx.size());
+    };
+
+    io::TrajectoryWriter traj(out_dir + "/trajectory.txt");
+    FILE* fc = fopen((out_dir + "/frontend.csv").c_str(), "w");
+    if (!fc) throw std::runtime_error("cannot write into " + out_dir);
+    fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_landmarks,alpha,beta,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf\n");
+
+    std::deque<FramePtr> kfs;
+    FrameBundle::Ptr last;
+    auto num_landmarks = [](const Frame& f) { size_t n = 0; for (size_t i = 0; i < f.num_features_ && i < f.landmark_vec_.size(); ++i) n += f.landmark_vec_[i] != nullptr; return n; };
+    auto scene_depth = [](const Frame& f, double& d_med, double& d_min) {   // frame_utils::getSceneDepth on the landmarks
+      std::vector<double> d;
+      for (size_t i = 0; i < f.num_features_ && i < f.landmark_vec_.size(); ++i)
+        if (f.landmark_vec_[i]) { const svoh::Vec3 p = svoh::transform(f.T_f_w_, f.landmark_vec_[i]->pos()); d.push_back(sqrt(p.x * p.x + p.y * p.y + p.z * p.z)); }
+      if (d.empty()) return false;
+      std::sort(d.begin(), d.end());
+      d_med = d[d.size() / 2]; d_min = d.front();
+      return true;
+    };
+    auto add_keyframe = [&](const FramePtr& f) {
+      kfs.push_back(f);
+      while (kfs.size() > 2 * ropt.max_n_kfs) {
+        for (auto& sr : kfs.front()->seed_ref_vec_) sr.keyframe.reset();
+        kfs.pop_front();
+      }
+    };
+    auto make_keyframe = [&](const FrameBundle::Ptr& b, size_t kf_id) {
+      // stereo triangulation of new features where the left frame has no feature yet (frame_handler_stereo.cpp:146-155)
+      tri_detector->resetGrid();
+      tri_detector->fillGridWithKeypoints(b->at(0)->px_vec_, b->at(0)->num_features_);
+      stereo.compute(b->at(0), b->at(1));
+      // new seeds in the keyframe's free cells (depth_filter_->addKeyframe, :167-173)
+      double d_med = 0, d_min = 0;
+      const FramePtr& f = b->at(kf_id);
+      if (scene_depth(*b->at(0), d_med, d_min)) {
+        seed_detector.resetGrid();
+        seed_detector.fillGridWithKeypoints(f->px_vec_, f->num_features_);
+        const size_t n_old = f->num_features_;
+        depth_filter_utils::initializeSeeds(f, seed_detector, (size_t)params.max_n_seeds_per_frame, (float)(0.5 * d_min), (float)(1.5 * d_med), (float)d_med);
+        for (size_t i = n_old; i < f->num_features_; ++i) { f->seed_ref_vec_[i].keyframe = f; f->seed_ref_vec_[i].seed_id = (int)i; }
+      }
+      add_keyframe(b->at(0));
+      add_keyframe(b->at(1));
+    };
+
+    double sum_ms = 0;
+    size_t n_done = 0;
+    for (size_t k = 0; k < n_frames; ++k) {
+      const double t0 = now_ms();
+      const io::GrayImage img0 = io::readPngGray(seq.cam0_files[k]), img1 = io::readPngGray(seq.cam1_files[k]);
+      const double t0b = now_ms();
+      FrameBundle::Ptr bundle(new FrameBundle);
+      const io::GrayImage* imgs[2] = { &img0, &img1 };
+      for (int c = 0; c < 2; ++c) {
+        FramePtr frame(new Frame, [ctx](Frame* f) { if (f->pyramid) svoh_release_frame(ctx, f->pyramid); delete f; });
+        if (svoh_build_pyramid(ctx, imgs[c]->data.data(), imgs[c]->width, imgs[c]->height, imgs[c]->width, SVOH_MEM_HOST, params.n_pyr_levels_to_build,
+                               SVOH_HALFSAMPLE_REFERENCE, nullptr, &frame->pyramid) != SVOH_OK)
+          throw std::runtime_error(std::string("svoh_build_pyramid: ") + svoh_last_error_string(ctx));
+        frame->cam = rig[(size_t)c].cam;
+        frame->set_T_cam_imu(svoh::inverse(rig[(size_t)c].T_B_C));
+        frame->id_ = (int)(2 * k + (size_t)c);
+        bundle->frames_.push_back(frame);
+      }
+      const double t1 = now_ms();
+      size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0;
+      double t2 = t1, t3 = t1, t4 = t1, t5 = t1;
+      bool is_kf = false;
+      if (k == 0) {
+        for (const FramePtr& f : bundle->frames_) f->T_f_w_ = svoh::mul(f->T_cam_imu(), T_imu_world0);
+        make_keyframe(bundle, 0);
+        is_kf = true;
+        t2 = t3 = t4 = t5 = now_ms();
+      } else {
+        // 1. sparse image alignment of the bundle, with the IMU's rotation prior (frame_handler_base.cpp:610-643)
+        for (size_t c = 0; c < 2; ++c) { bundle->at(c)->T_f_w_ = last->at(c)->T_f_w_; resolveAlignmentPoints(*last->at(c)); }
+        img_align.reset();
+        if (k < imu_prior.size() && lambda_rot > 0) {
+          Transformation T_prior{ imu_prior[k], { 0, 0, 0 } };   // T_newimu_lastimu_prior: the rotation is what the weights use
+          img_align.setWeightedPrior(T_prior, 0.0, 0.0, lambda_rot, 0.0, 0.0, 0.0);
+        }
+        n_aligned = img_align.run(last, bundle);
+        t2 = now_ms();
+        // 2. reprojection, per camera (frame_handler_base.cpp:645-744)
+        std::vector<FramePtr> visible(kfs.begin(), kfs.end());
+        for (size_t c = 0; c < 2; ++c) {
+          std::vector<PointPtr> trash;
+          reprojectors[c]->reprojectFrames(bundle->at(c), visible, trash);
+          n_reproj += bundle->at(c)->num_features_;
+        }
+        t3 = now_ms();
+        // 3. pose optimisation of the rig
+        if (n_reproj >= 10) n_pose = pose_optimizer.run(bundle, 2.0);
+        t4 = now_ms();
+        // 4. depth filter, per camera (frame_handler_stereo.cpp:127-129)
+        for (size_t c = 0; c < 2; ++c) n_seed_upd += depth_filter.updateSeeds(visible, bundle->at(c));
+        t5 = now_ms();
+        // 5. keyframe rule
+        if (k % kf_every == 0 || n_pose < 60) { make_keyframe(bundle, (k / kf_every) % 2); is_kf = true; }
+      }
+      const double t6 = now_ms();
+      traj.write(seq.cam_ts[k], svoh::inverse(bundle->at(0)->T_imu_world()));
+      fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.6f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", k, (int)is_kf, n_aligned, n_reproj, n_pose, n_seed_upd,
+              num_landmarks(*bundle->at(0)) + num_landmarks(*bundle->at(1)), img_align.lastResult().alpha, img_align.lastResult().beta,
+              t1 - t0b, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5);
+      if (k > 0) { sum_ms += t6 - t0b; ++n_done; }
+      (void)t0;
+      last = bundle;
+    }
+    fclose(fc);
+    printf("svoh_mini_stereo: %zu frame pairs, %.3f ms per pair on the GPU path (image decoding excluded), %zu keyframes alive\n", n_done + 1,
+           n_done ? sum_ms / n_done : 0.0, kfs.size());
+    for (const FramePtr& f : kfs) for (auto& sr : f->seed_ref_vec_) sr.keyframe.reset();
+    if (last) for (const FramePtr& f : last->frames_) for (auto& sr : f->seed_ref_vec_) sr.keyframe.reset();
+    kfs.clear(); last.reset();
+    svoh_destroy(ctx);
+    return 0;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "svoh_mini_stereo: %s\n", e.what());
+    return 1;
+  }
+}
