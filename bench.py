@@ -578,6 +578,131 @@ def bench_frame(args, ctx, dist, rank, world, dev, comm_dev=None):
             "cpu_baseline": cpu}
 
 
+def bench_frame_stereo(args, ctx, dist, rank, world, dev, comm_dev=None):
+    """C4-synth, one stereo frame pair at a time (latency): BASELINE config 3 / 4 at the sizes of SURVEY.md Appendix A's
+    stereo column.  Per pair: two 5-level pyramids (host images in); SparseImgAlign of the BUNDLE -- two cameras x 160
+    features, 4x4, levels 4..2, pose + illumination gain and offset (8 parameters), rotation prior lambda 0.5
+    (euroc_stereo_imu.yaml) -- one call; depth-filter update of 3 keyframes x 360 seeds per camera against that camera's
+    new frame (two calls).  The keyframe-only stereo seam (120 features, 500 epipolar steps) is timed beside the frame.
+    Every stage is a blocking C-ABI call with host arrays, as FrameHandlerStereo would make it."""
+    cam = synth.Camera.euroc_like(752, 480)
+    NF, NS, NKF, NTRI = 160, 360, 3, 120
+    seed = du.problem_seed(rank, 9)
+    scs = [synth.make_align_scene(seed, n_features=NF, patch_size=4, cam=cam, max_level=4, rot_deg=(0.3, 1.0), trans_m=(0.03, 0.10),
+                                  gain=1.03, offset=2.0) for _ in range(2)]
+    opt = capi.default_align_options(max_level=4, min_level=2, patch_size=4, estimate_illumination_gain=1, estimate_illumination_offset=1)
+    mopt, dopt = capi.default_matcher_options(affine_est_gain=1), capi.default_depth_filter_options(cam)
+    mtri = capi.default_matcher_options(max_epi_search_steps=500, subpix_refinement=1, scan_on_unit_sphere=1)
+    f_ref = [ctx.build_pyramid(sc.img_ref, 5) for sc in scs]
+    seeds = [synth.make_seed_set(sc, NS * NKF, seed=2 + c) for c, sc in enumerate(scs)]
+    tri = synth.make_seed_set(scs[0], NTRI, seed=11, margin=6, levels=(0, 1, 2))
+    tri_type = np.where(tri["type"] == 0, capi.FT_EDGELET, capi.FT_CORNER).astype(np.uint8)
+    dm = float(np.median(tri["true_depth"]))
+    kf_idx = np.repeat(np.arange(NKF, dtype=np.int32), NS)
+    pr = capi.svoh_align_prior()
+    pr.have_prior = 1
+    pr.T_prior = fe._se3(scs[0].T_icur_iref_gt)
+    pr.lambda_rot = 0.5
+    names = ("pyramids", "align_bundle", "seeds", "total")
+    stages = {k: [] for k in names}
+    last = {}
+
+    def one_pair():
+        t0 = time.perf_counter()
+        f_cur = [ctx.build_pyramid(sc.img_cur, 5) for sc in scs]
+        t1 = time.perf_counter()
+        problems, keep = fe.make_align_problems([[(scs[0], f_ref[0], f_cur[0], None), (scs[1], f_ref[1], f_cur[1], None)]], prior=[pr])
+        res = ctx.sparse_align(opt, problems)
+        t2 = time.perf_counter()
+        ns = 0
+        for c, sc in enumerate(scs):
+            ref_views = [fe.make_frame_view(f_ref[c], cam, sc.T_ref_f_w, seeds[c]["mu_range"], k) for k in range(NKF)]
+            cur_view = fe.make_frame_view(f_cur[c], cam, sc.T_cur_f_w_gt, 0.0, 100 + c)
+            fb, kk = fe.make_feature_batch(kf_idx, seeds[c]["px"], seeds[c]["f"], seeds[c]["grad"], seeds[c]["level"], seeds[c]["type"])
+            n1, st, succ, mr = ctx.update_seeds_batch(mopt, dopt, ref_views, cur_view, fb, seeds[c]["state"])
+            ns += n1
+        t3 = time.perf_counter()
+        last.update(res=res[0], ns=ns, f_cur=f_cur)
+        return t1 - t0, t2 - t1, t3 - t2, t3 - t0
+
+    def seam():   # the left frame's new features into the right frame (here: the pair's other image), 500 steps
+        rv = fe.make_frame_view(f_ref[0], cam, scs[0].T_ref_f_w, 0.0, 1)
+        cv = fe.make_frame_view(last["f_cur"][0], cam, scs[0].T_cur_f_w_gt, 0.0, 2)
+        fb, kk = fe.make_feature_batch(tri["ref_frame_idx"], tri["px"], tri["f"], tri["grad"], tri["level"], tri_type)
+        t0 = time.perf_counter()
+        out = ctx.epipolar_match_batch(mtri, [rv], cv, fb, d_inv_common=[1 / dm, 3 / dm, 0.05 / dm])
+        return time.perf_counter() - t0, out
+
+    def release():
+        for f in last.get("f_cur", []):
+            ctx.release_frame(f)
+
+    for _ in range(3):
+        one_pair(); release()
+    kms = ctypes.c_float()
+    ctx.lib.svoh_sparse_align_last_kernel_ms(ctx.h, ctypes.byref(kms))
+    ctx.set_kernel_timing(False)
+    for _ in range(args.warmup):
+        one_pair(); release()
+    if world > 1:
+        dist.barrier()
+    seam_ms = []
+    t_begin = time.perf_counter()
+    t_seam = 0.0
+    for _ in range(args.steps):
+        ts = one_pair()
+        for k, v in zip(names, ts):
+            stages[k].append(1e3 * v)
+        tsm, seam_out = seam()
+        t_seam += tsm
+        seam_ms.append(1e3 * tsm)
+        release()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t_begin - t_seam
+    ctx.set_kernel_timing(True)
+    elapsed, total_pairs = du.combine(dist, world, elapsed, args.steps, comm_dev)
+    med = {k: float(np.median(v)) for k, v in stages.items()}
+    err = synth.se3_error(synth.SE3.from7(fe.se3_to_numpy(last["res"].T_icur_iref)), scs[0].T_icur_iref_gt)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc  # test infrastructure: the timed CPU baseline only
+        orc.build(fast=True)
+        refs = [orc.create_img_pyramid(sc.img_ref, 5, fast=True) for sc in scs]
+        c_tot = []
+        t_cpu0 = time.perf_counter()
+        while time.perf_counter() - t_cpu0 < 10.0 and len(c_tot) < 100:
+            t0 = time.perf_counter()
+            curs = [orc.create_img_pyramid(sc.img_cur, 5, fast=True) for sc in scs]
+            pb = orc.problem_from_scenes([(scs[0], refs[0], curs[0]), (scs[1], refs[1], curs[1])], prior=pr)
+            n_o, res_o, _ = orc.sparse_align_run(opt, pb, fast=True)
+            for c, sc in enumerate(scs):
+                ov_r = [orc.make_frame_view(refs[c], cam, sc.T_ref_f_w, seeds[c]["mu_range"], k) for k in range(NKF)]
+                ov_c = orc.make_frame_view(curs[c], cam, sc.T_cur_f_w_gt, 0.0, 100 + c)
+                fbo, ko = orc.make_feature_batch(kf_idx, seeds[c]["px"], seeds[c]["f"], seeds[c]["grad"], seeds[c]["level"], seeds[c]["type"])
+                orc.update_seeds_batch(mopt, dopt, ov_r, ov_c, fbo, seeds[c]["state"], fast=True)
+            c_tot.append(1e3 * (time.perf_counter() - t0))
+        assert list(res_o.iters) == list(last["res"].iters)
+        cpu = {"value": 1e3 / float(np.median(c_tot)), "unit": "frame pairs/s", "cores": 1, "kind": "port",
+               "sample": "%d repetitions of the same pair through the oracle (gcc -O3 -march=native, 1 thread)" % len(c_tot),
+               "ms_per_pair_median": float(np.median(c_tot))}
+    if rank != 0:
+        return None
+    alg = algorithmic_bytes(4, 8, last["res"].n_patch_iters, last["res"].n_fts_to_track * 3)
+    return {"metric": "stereo frame pairs/s, one pair at a time (2 pyramids + bundle SparseImgAlign with illumination terms and rotation prior "
+                      "+ depth-filter update per camera, EuRoC stereo sizes)",
+            "value": total_pairs / elapsed, "unit": "frame pairs/s", "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_frame": med["total"], "dtype": "u8+i32+f32+f64",
+            "config": {"workload": "C4-synth per pair: 2 x 752x480 radtan, 5-level pyramids, bundle alignment 2 x %d features 4x4 levels 4..2 with gain + offset "
+                                   "and rotation prior, 2 x 3 keyframes x %d seeds; blocking C-ABI calls with host arrays" % (NF, NS),
+                       "features_per_camera": NF, "seeds_per_camera": NS * NKF, "cameras": 2},
+            "stage_ms_median": med, "stereo_seam_ms_median": float(np.median(seam_ms)),
+            "stereo_seam_successes": int((seam_out["result"] == capi.MATCH_SUCCESS).sum()),
+            "align_pose_err_vs_gt": {"rot_rad": err[0], "trans_m": err[1]}, "align_alpha_beta": [last["res"].alpha, last["res"].beta],
+            "seed_successes": int(last["ns"]),
+            "roofline": roofline("sparse_align_kernel<4,*,true> (single stereo bundle: latency-bound by design)", kms.value, alg, "frame-stereo:default"),
+            "cpu_baseline": cpu}
+
+
 def bench_detect(args, ctx, dist, rank, world, dev, comm_dev=None):
     """Keyframe feature detection (SURVEY.md 8(f-2)): FastGradDetector::detect on a 752x480 5-level pyramid
     (FAST-10 on levels 0..2, best corner per 30-px cell, edgelets on level 1 in the free cells), one keyframe
@@ -945,6 +1070,7 @@ def parse_args(argv=None):
     ap.add_argument("--patch", type=int, default=4)
     ap.add_argument("--min-level", type=int, default=0)
     ap.add_argument("--max-level", type=int, default=4)
+    ap.add_argument("--stereo", action="store_true", help="with --workload frame: the stereo pair chain (BASELINE config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the 8x8-patch leg that the default line carries as `secondary`")
@@ -1040,7 +1166,8 @@ def main(argv=None):
 
     ctx = fe.Context(local_rank)
     if args.workload != "align":
-        out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame, "detect": bench_detect, "pose": bench_pose,
+        out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame_stereo if args.stereo else bench_frame, "detect": bench_detect,
+               "pose": bench_pose,
                "align-split": bench_align_split, "align-c4": bench_align_c4, "stereo": bench_stereo,
                "launch-check": lambda a, c, d, r, w, dv, cd: bench_launch_check(a, d, r, w, cd)}[args.workload](
             args, ctx, dist, rank, world, dev, comm_dev)

@@ -1796,6 +1796,49 @@ __global__ __launch_bounds__(256) void seed_unsort_kernel(const MatcherArgs a, c
 }
 
 // DepthFilter::updateSeeds + depth_filter_utils::updateSeed, packed geometry (see "Packed geometry" above)
+// Phase E of the packed geometry: the sub-pixel refinements (align1D / align2D) of a 256-unit workgroup as jobs.  Units
+// that need one have left their slot in one of two LDS queues (s_q[0]: 2-D, s_q[1]: 1-D); every wave takes eight jobs of
+// ONE kind per round and runs them with eight lanes per job (the row-split code of the eight-lane geometry).
+// In: s_u / s_v start position, s_dir direction (1-D), s_stat (cur frame << 8) | search level, the slot's warped patch.
+// Out: s_u / s_v result, s_res (iterations << 8) | converged, s_hinv (1-D: h_inv; may be NULL).
+__device__ __forceinline__ void packed_refine_phase(const MatcherArgs& a, int tid, const unsigned char* s_pwb, int* s_res, const double* s_dir,
+                                                    float* s_u, float* s_v, const int* s_stat, unsigned short (*s_q)[kPkThreads], int* s_qn,
+                                                    int* s_qh, double* s_hinv, bool est_offset, bool est_gain)
+{
+  const int lane = tid & 63, sub = lane & 7;
+  int kind = (tid >> 6) & 1;          // waves start on different queues and move to the other one when theirs is empty
+  int tried = 0;
+  while (tried < 2) {
+    int slot = -1;
+    if (sub == 0) {
+      const int j = atomicAdd(&s_qh[kind], 1);
+      if (j < s_qn[kind]) slot = s_q[kind][j];
+    }
+    slot = __shfl(slot, 0, 8);
+    if (__ballot(slot >= 0) == 0) { kind ^= 1; ++tried; continue; }
+    if (slot >= 0) {
+      const int meta = s_stat[slot];
+      const DevImage img = a.cur_frame[meta >> 8].lv[meta & 255];
+      const unsigned char* pwb = s_pwb + slot * kPwbStride;
+      double sx = s_u[slot], sy = s_v[slot];
+      int n_it = 0;
+      bool aligned;
+      if (kind == 1) {
+        double h_inv = 0.0;
+        aligned = align_1d_g8(img, s_dir[2 * slot], s_dir[2 * slot + 1], pwb, a.mopt.align_max_iter, est_offset, est_gain, sx, sy,
+                              &h_inv, n_it, sub);
+        if (s_hinv && sub == 0) s_hinv[slot] = h_inv;
+      } else {
+        aligned = align_2d_g8(img, pwb, a.mopt.align_max_iter, est_offset, est_gain, sx, sy, n_it, sub);
+      }
+      if (sub == 0) {
+        s_u[slot] = (float)sx; s_v[slot] = (float)sy;      // align1D / 2D hand back px = u, py = v (floats)
+        s_res[slot] = (n_it << 8) | (aligned ? 1 : 0);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3))) void update_seeds_packed_kernel(
     const MatcherArgs a, const SeedRecIn* __restrict__ rec_in, SeedRecOut* __restrict__ rec_out)
 {
@@ -1924,42 +1967,10 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
 #endif
 
   // ---- phase E: the refinements, eight lanes per job, eight jobs of one kind per wave and round ----
-  {
-    const int lane = tid & 63, sub = lane & 7;
-    int kind = (tid >> 6) & 1;          // waves start on different queues and move to the other one when theirs is empty
-    int tried = 0;
-    while (tried < 2) {
-      int slot = -1;
-      if (sub == 0) {
-        const int j = atomicAdd(&s_qh[kind], 1);
-        if (j < s_qn[kind]) slot = s_q[kind][j];
-      }
-      slot = __shfl(slot, 0, 8);
-      if (__ballot(slot >= 0) == 0) { kind ^= 1; ++tried; continue; }
-      if (slot >= 0) {
-        const int meta = s_stat[slot];
-        const DevImage img = a.cur_frame[meta >> 8].lv[meta & 255];
-        const unsigned char* pwb = s_pwb + slot * kPwbStride;
-        double sx = s_u[slot], sy = s_v[slot];
-        int n_it = 0;
-        bool aligned;
-        if (kind == 1) {
-          double h_inv_unused;
-          aligned = align_1d_g8(img, s_dir[2 * slot], s_dir[2 * slot + 1], pwb, a.mopt.align_max_iter, est_offset, est_gain, sx, sy,
-                                &h_inv_unused, n_it, sub);
-        } else {
-          aligned = align_2d_g8(img, pwb, a.mopt.align_max_iter, est_offset, est_gain, sx, sy, n_it, sub);
-        }
-        if (sub == 0) {
-          s_u[slot] = (float)sx; s_v[slot] = (float)sy;      // align1D / 2D hand back px = u, py = v (floats)
-          s_res[slot] = (n_it << 8) | (aligned ? 1 : 0);
-        }
-      }
-    }
+  packed_refine_phase(a, tid, s_pwb, s_res, s_dir, s_u, s_v, s_stat, s_q, s_qn, s_qh, nullptr, est_offset, est_gain);
 #ifdef SVOH_PK_STAMPS
-    tsE1 = clock64();
+  tsE1 = clock64();
 #endif
-  }
   __syncthreads();
 
   // ---- phase F: one lane per seed: triangulation, tau, filter update, outputs ----
@@ -2100,6 +2111,168 @@ __global__ __launch_bounds__(64) void epipolar_match_kernel(const MatcherArgs a)
   if (a.h_inv) a.h_inv[i] = m.h_inv;
   if (a.A_cur_ref) for (int k = 0; k < 4; ++k) a.A_cur_ref[4 * i + k] = m.A[k];
   flush_counters(a.unit_counts, i, m, res == SVOH_MATCH_SUCCESS ? 1 : 0);
+}
+
+
+// The packed geometry for the other two matcher entries (large batches of svoh_match_direct_batch /
+// svoh_epipolar_match_batch): phase A one lane per unit (geometry, affine warp with the corner test and two-tap loads,
+// for the epipolar match the scan with the packed ZMSSD), phase E the refinements as eight-lane jobs
+// (packed_refine_phase), phase F one lane per unit (too-far test / triangulation, outputs).  Every unit goes through the
+// arithmetic of the one-lane and eight-lane kernels: identical outputs, successes and failures alike.
+template <bool DIRECT>
+__global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3))) void match_packed_kernel(const MatcherArgs a)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char s_pwb[kPkThreads * kPwbStride + 16];
+  __shared__ int s_res[kPkThreads];
+  __shared__ double s_dir[2 * kPkThreads];
+  __shared__ double s_hinv[kPkThreads];
+  __shared__ float s_u[kPkThreads], s_v[kPkThreads];
+  __shared__ int s_stat[kPkThreads];
+  __shared__ unsigned short s_q[2][kPkThreads];
+  __shared__ int s_qn[2], s_qh[2];
+  const int tid = (int)threadIdx.x;
+  if (tid < 2) { s_qn[tid] = 0; s_qh[tid] = 0; }
+  s_hinv[tid] = 0.0;
+  __syncthreads();
+  const int i = (int)blockIdx.x * kPkThreads + tid;
+  const bool live = i < a.n;
+  const bool est_offset = a.mopt.affine_est_offset != 0, est_gain = a.mopt.affine_est_gain != 0;
+  constexpr int kNotRun = -2000;
+  int code = kNotRun, search_level = 0, ci = 0, n_warp = 0, n_zmssd = 0;
+  double A4[4] = { 0.0, 0.0, 0.0, 0.0 };
+  double px0 = 0.0, px1 = 0.0, sx0 = 0.0, sy0 = 0.0;
+  bool is_1d = false;
+  const bool ok_idx = live && feature_indices_ok(a, i);
+  if (ok_idx) {
+    const int ri = a.ref_frame_idx[i];
+    ci = a.cur_frame_idx ? a.cur_frame_idx[i] : 0;
+    const DevFrameView& ref = a.ref_frames[ri];
+    const DevFrameView& cur = a.cur_frame[ci];
+    const int type = a.type[i], level = a.level[i];
+    const Vec3 f = { a.f[3 * i], a.f[3 * i + 1], a.f[3 * i + 2] };
+    const double pxr = a.px[2 * i], pyr = a.px[2 * i + 1], gx = a.grad[2 * i], gy = a.grad[2 * i + 1];
+    MatcherState m;
+    m.pwb = s_pwb + tid * kPwbStride;
+    m.sub = 0;
+    m.h_inv = 0.0; m.search_level = 0; m.reject = false;
+    m.n_warp = 0; m.n_zmssd = 0; m.n_align_it = 0;
+    m.align_1d = is_edgelet(type);
+    m.A[0] = m.A[1] = m.A[2] = m.A[3] = 0.0;
+    m.px_cur[0] = m.px_cur[1] = 0.0;
+    m.f_cur = { 0.0, 0.0, 0.0 };
+#ifdef SVOH_SEED_STAMPS
+    m.t[0] = m.t[1] = m.t[2] = m.t[3] = 0; m.tlast = clock64();
+#endif
+    is_1d = m.align_1d;
+    if constexpr (DIRECT) {
+      // Matcher::findMatchDirect up to the refinement (matcher.cpp:31-93)
+      px0 = a.px_cur[2 * i]; px1 = a.px_cur[2 * i + 1];
+      constexpr int kHalfPatchSize = 4;
+      const int pxi0 = (int)pxr / (1 << level), pxi1 = (int)pyr / (1 << level);
+      const int boundary = kHalfPatchSize + 2;
+      if (pxi0 < boundary || pxi1 < boundary || pxi0 >= (int)(ref.cam.width / (1 << level)) - boundary ||
+          pxi1 >= (int)(ref.cam.height / (1 << level)) - boundary) {
+        code = SVOH_MATCH_FAIL_VISIBILITY;
+      } else {
+        const Rigid T_cur_ref = T_cur_ref_of(ref, cur);
+        get_warp_matrix_affine(ref.cam, cur.cam, pxr, pyr, f, a.depth[i], T_cur_ref, level, m.A);
+        m.search_level = get_best_search_level(m.A, ref.n_levels - 1);
+        ++m.n_warp;
+        if (!warp_affine_packed(m.A, ref.lv[level], pxr, pyr, level, m.search_level, m.pwb)) code = SVOH_MATCH_FAIL_WARP;
+        else {
+          code = kMatchRefinePending;
+          sx0 = px0 / (1 << m.search_level); sy0 = px1 / (1 << m.search_level);
+          if (m.align_1d) {
+            double d0 = m.A[0] * gx + m.A[2] * gy, d1 = m.A[1] * gx + m.A[3] * gy;
+            normalize2(d0, d1);
+            m.epi_dir[0] = d0; m.epi_dir[1] = d1;
+          }
+        }
+      }
+    } else {
+      const Rigid T_cur_ref = a.T_cur_ref ? a.T_cur_ref[(size_t)ri * a.n_cur_frames + ci] : T_cur_ref_of(ref, cur);
+      const double d_est = a.d_inv ? a.d_inv[3 * i] : a.d_inv_common[0];
+      const double d_min = a.d_inv ? a.d_inv[3 * i + 1] : a.d_inv_common[1];
+      const double d_max = a.d_inv ? a.d_inv[3 * i + 2] : a.d_inv_common[2];
+      code = epipolar_match_search<2>(m, a.mopt, ref, cur, T_cur_ref, pxr, pyr, f, gx, gy, level, type, d_est, d_min, d_max);
+      px0 = m.px_cur[0]; px1 = m.px_cur[1];
+      if (code == kMatchRefinePending) { sx0 = m.px_cur[0] / (1 << m.search_level); sy0 = m.px_cur[1] / (1 << m.search_level); }
+    }
+    search_level = m.search_level;
+    n_warp = m.n_warp; n_zmssd = m.n_zmssd;
+    for (int k = 0; k < 4; ++k) A4[k] = m.A[k];
+    if (code == kMatchRefinePending) {
+      s_u[tid] = (float)sx0; s_v[tid] = (float)sy0;
+      if (m.align_1d) { s_dir[2 * tid] = m.epi_dir[0]; s_dir[2 * tid + 1] = m.epi_dir[1]; }
+      const int kind = m.align_1d ? 1 : 0;
+      const int j = atomicAdd(&s_qn[kind], 1);
+      s_q[kind][j] = (unsigned short)tid;
+    }
+  }
+  s_stat[tid] = (ci << 8) | search_level;
+  __syncthreads();
+  packed_refine_phase(a, tid, s_pwb, s_res, s_dir, s_u, s_v, s_stat, s_q, s_qn, s_qh, s_hinv, est_offset, est_gain);
+  __syncthreads();
+  if (!live) return;
+  if (!ok_idx) {
+    a.result[i] = SVOH_MATCH_NOT_RUN;
+    reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  const DevFrameView& cur = a.cur_frame[ci];
+  int res = code, n_align_it = 0;
+  Vec3 f_cur = { 0.0, 0.0, 0.0 };
+  double depth = 0.0;
+  bool aligned = false;
+  double sx = 0.0, sy = 0.0;
+  if (code == kMatchRefinePending) {
+    const int r = s_res[tid];
+    n_align_it = r >> 8;
+    aligned = (r & 1) != 0;
+    sx = s_u[tid]; sy = s_v[tid];
+  }
+  if constexpr (DIRECT) {
+    if (code == kMatchRefinePending) {
+      // the tail of Matcher::findMatchDirect (matcher.cpp:94-141)
+      if (!aligned) res = SVOH_MATCH_FAIL_ALIGNMENT;
+      else {
+        const double dx = sx - sx0, dy = sy - sy0;   // against the start position before its narrowing to float
+        constexpr int kPatchSize = 8;
+        if (sqrt(dx * dx + dy * dy) > a.mopt.max_patch_diff_ratio * kPatchSize) res = SVOH_MATCH_FAIL_TOO_FAR;
+        else {
+          px0 = sx * (1 << search_level); px1 = sy * (1 << search_level);
+          f_cur = back_project3(cur.cam, px0, px1);
+          normalize3(f_cur);
+          res = SVOH_MATCH_SUCCESS;
+        }
+      }
+    }
+    a.result[i] = res;
+    a.px_cur[2 * i] = px0; a.px_cur[2 * i + 1] = px1;
+  } else {
+    if (code == kMatchRefinePending || code == kMatchTriangulatePending) {
+      const int ri = a.ref_frame_idx[i];
+      const DevFrameView& ref = a.ref_frames[ri];
+      const Rigid T_cur_ref = a.T_cur_ref ? a.T_cur_ref[(size_t)ri * a.n_cur_frames + ci] : T_cur_ref_of(ref, cur);
+      const Vec3 f = { a.f[3 * i], a.f[3 * i + 1], a.f[3 * i + 2] };
+      MatcherState m;
+      m.search_level = search_level;
+      m.px_cur[0] = px0; m.px_cur[1] = px1;
+      m.f_cur = { 0.0, 0.0, 0.0 };
+      res = epipolar_match_finish(m, cur, T_cur_ref, f, code == kMatchRefinePending, aligned, sx, sy, depth);
+      px0 = m.px_cur[0]; px1 = m.px_cur[1];
+      f_cur = m.f_cur;
+    }
+    a.result[i] = res;
+    a.depth_out[i] = depth;
+    if (a.px_cur) { a.px_cur[2 * i] = px0; a.px_cur[2 * i + 1] = px1; }
+  }
+  if (a.f_cur) { a.f_cur[3 * i] = f_cur.x; a.f_cur[3 * i + 1] = f_cur.y; a.f_cur[3 * i + 2] = f_cur.z; }
+  if (a.search_level) a.search_level[i] = search_level;
+  if (a.h_inv) a.h_inv[i] = (code == kMatchRefinePending && is_1d) ? s_hinv[tid] : 0.0;
+  if (a.A_cur_ref) for (int k = 0; k < 4; ++k) a.A_cur_ref[4 * i + k] = A4[k];
+  reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4((unsigned)n_warp, (unsigned)n_zmssd, (unsigned)n_align_it,
+                                                           (!DIRECT && res == SVOH_MATCH_SUCCESS) ? 1u : 0u);
 }
 
 // ---------------------------------------------------------------------------
@@ -2285,9 +2458,9 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   // small batches: eight lanes per unit (a launch is as slow as its slowest lane, and eight lanes get a unit done
   // ~3x sooner); large batches: one lane per unit (fewer instructions per unit).  The knob SVOH_MATCHER_G8 (read when the context is made) forces one.
   // geometry: 1 = eight lanes per unit, 0 = one lane per unit, 2 = packed (seed update only; large batches)
-  int g8 = n <= kG8MaxUnits ? 1 : (seeds ? 2 : 0);
+  int g8 = n <= kG8MaxUnits ? 1 : 2;
   g8 = SvohKnobs::or_default(ctx->knobs.matcher_g8, g8);
-  if (g8 < 0 || g8 > 2 || (g8 == 2 && !seeds)) g8 = 0;
+  if (g8 < 0 || g8 > 2) g8 = 0;
   if (defer && g8 != 2) {
     // Deferred section: the launch itself waits for svoh_matcher_collect, where a direct batch and a seed batch of
     // the same geometry go out as ONE kernel (match_mixed_kernel).  Remembered: the arguments, the copy of the
@@ -2370,7 +2543,8 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     else if (g8) hipLaunchKernelGGL(update_seeds_kernel<true>, grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL(update_seeds_kernel<false>, grid, block, 0, ctx->stream, a);
   } else {
-    if (g8) hipLaunchKernelGGL(match_direct_kernel<true>, grid, block, 0, ctx->stream, a);
+    if (g8 == 2) hipLaunchKernelGGL(match_packed_kernel<true>, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0, ctx->stream, a);
+    else if (g8) hipLaunchKernelGGL(match_direct_kernel<true>, grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL(match_direct_kernel<false>, grid, block, 0, ctx->stream, a);
   }
   SVOH_HIP_TRY(ctx, hipGetLastError());
@@ -2551,9 +2725,11 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
     a.h_inv = reinterpret_cast<double*>(d + o_hinv);
     a.A_cur_ref = reinterpret_cast<double*>(d + o_A);
   }
-  int g8 = n <= kG8MaxUnits ? 1 : 0;
-  if (ctx->knobs.matcher_g8 != kKnobUnset) g8 = ctx->knobs.matcher_g8 == 1;
-  const int units_per_block = g8 ? 8 : 64;
+  // geometry as in run_matcher: 1 = eight lanes per unit, 0 = one lane per unit, 2 = packed (large batches)
+  int g8 = n <= kG8MaxUnits ? 1 : 2;
+  g8 = SvohKnobs::or_default(ctx->knobs.matcher_g8, g8);
+  if (g8 < 0 || g8 > 2) g8 = 0;
+  const int units_per_block = g8 == 1 ? 8 : 64;
   const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
   {
     unsigned long long* dummy;
@@ -2562,7 +2738,8 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
     if (rc != SVOH_OK) return rc;
   }
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
-  if (g8) hipLaunchKernelGGL(epipolar_match_kernel<true>, grid, block, 0, ctx->stream, a);
+  if (g8 == 2) hipLaunchKernelGGL(match_packed_kernel<false>, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0, ctx->stream, a);
+  else if (g8) hipLaunchKernelGGL(epipolar_match_kernel<true>, grid, block, 0, ctx->stream, a);
   else hipLaunchKernelGGL(epipolar_match_kernel<false>, grid, block, 0, ctx->stream, a);
   SVOH_HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));

@@ -99,8 +99,10 @@ constexpr int kXchgStride = 64;         // doubles per share and parity (>= 45 +
 #ifndef SVOH_ROW_UNROLL_GONLY
 #define SVOH_ROW_UNROLL_GONLY 4
 #endif
+// rows of the full pass taken per loop trip: measured per configuration (round 3, scripts/ab.sh: 4x4 1.377 -> 1.365 ms with 2,
+// 1.44 with 4; 8x8 3.36 -> 3.25 with 4; with the illumination terms' 15 moments live, 1 for 4x4)
 #ifndef SVOH_ROW_UNROLL
-#define SVOH_ROW_UNROLL 1
+#define SVOH_ROW_UNROLL (PH == 8 ? 4 : (D == 8 ? 1 : 2))
 #endif
 
 #ifdef SVOH_PHASE_STAMPS

@@ -18,10 +18,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(params=["eight_lanes_per_unit", "one_lane_per_unit", "packed"], autouse=True)
 def matcher_geometry(request, gpu_ctx):
     """The matcher kernels exist in three geometries with bit-identical results: eight lanes per unit (what a small
-    batch gets), one lane per unit, and -- for the seed update of large batches -- the packed geometry (one lane per
-    seed for geometry / warp / scan, the refinements as jobs of a workgroup-wide queue; the direct matcher and the
-    plain epipolar match have no packed kernel and run one lane per unit there).  Every test of this file runs
-    through all of them."""
+    batch gets), one lane per unit, and the packed geometry of large batches (one lane per unit for geometry / warp /
+    scan, the refinements as jobs of a workgroup-wide queue: update_seeds_packed_kernel, and since round 3
+    match_packed_kernel for the direct matcher and the plain epipolar match).  Every test of this file runs through
+    all of them."""
     import os
     old = os.environ.get("SVOH_MATCHER_G8")
     os.environ["SVOH_MATCHER_G8"] = {"eight_lanes_per_unit": "1", "one_lane_per_unit": "0", "packed": "2"}[request.param]
@@ -522,3 +522,47 @@ def test_benchmark_size_batch_is_identical_in_every_geometry(gpu_ctx):
     ns1, st1, succ1, mr1 = gpu_ctx.update_seeds_batch(mopt, dopt, [views_r[b]], views_c[b], fb1, sd["state"])
     sl = slice(b * NS, (b + 1) * NS)
     assert np.array_equal(st1, ref[1][4 * b * NS:4 * (b + 1) * NS]) and np.array_equal(succ1, ref[2][sl]) and np.array_equal(mr1, ref[3][sl])
+
+
+def test_direct_and_epipolar_outputs_identical_in_every_geometry(gpu_ctx):
+    """Every output array of svoh_match_direct_batch and svoh_epipolar_match_batch -- result codes, pixels, bearing
+    vectors, search levels, h_inv, warp matrices, depths; successes and every kind of failure -- is the same bit for bit
+    in the three geometries (the packed kernels of round 3 included)."""
+    import os
+    cam = synth.Camera.euroc_like()
+    sc = synth.make_align_scene(71, n_features=10, cam=cam, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+    sd = synth.make_seed_set(sc, 3000, margin=3, levels=(0, 1, 2, 3))
+    rv = fe.make_frame_view(fr, sc.cam, sc.T_ref_f_w, float(sd["mu_range"]), 1)
+    cv = fe.make_frame_view(fc, sc.cam, sc.T_cur_f_w_gt, 0.0, 2)
+    x = sd["f"].reshape(-1, 3).T * sd["true_depth"]
+    px_true = sc.cam.project(sc.T_w_cur.inverse().transform(sc.T_w_ref.transform(x)))
+    px_init = np.ascontiguousarray((px_true + np.random.RandomState(1).uniform(-2.0, 2.0, px_true.shape)).T).ravel()
+    px_init[:40] += 40.0
+    ftype = np.where(sd["type"] == 0, capi.FT_EDGELET, capi.FT_CORNER).astype(np.uint8)
+    dm = float(np.median(sd["true_depth"]))
+    old = os.environ.get("SVOH_MATCHER_G8")
+    outs = {}
+    try:
+        for g in ("1", "0", "2"):
+            os.environ["SVOH_MATCHER_G8"] = g
+            gpu_ctx.reload_knobs()
+            for mkw in (dict(), dict(affine_est_gain=1, scan_on_unit_sphere=0)):
+                mopt = capi.default_matcher_options(max_epi_search_steps=500, **mkw)
+                fb, kk = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+                d = gpu_ctx.match_direct_batch(mopt, [rv], cv, fb, sd["true_depth"], px_init)
+                e = gpu_ctx.epipolar_match_batch(mopt, [rv], cv, fb, d_inv_common=[1 / dm, 3 / dm, 0.05 / dm])
+                outs[(g, tuple(sorted(mkw)))] = (d, e)
+    finally:
+        if old is None:
+            os.environ.pop("SVOH_MATCHER_G8", None)
+        else:
+            os.environ["SVOH_MATCHER_G8"] = old
+        gpu_ctx.reload_knobs()
+    for key in [k for k in outs if k[0] == "1"]:
+        for g in ("0", "2"):
+            for a, b in zip(outs[key], outs[(g, key[1])]):
+                for name in a:
+                    assert np.array_equal(a[name], b[name]), (g, key, name, int(np.sum(a[name] != b[name])))
+        d, e = outs[key]
+        assert len(set(d["result"].tolist())) >= 4 and len(set(e["result"].tolist())) >= 4   # successes and several failure kinds
