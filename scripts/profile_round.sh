@@ -4,7 +4,7 @@
 # the svoh kernels kept, and one summary json per workload (scripts/pmc_summary.py) -> gpurun_out/profiles/.
 # usage: scripts/profile_round.sh <round> [tags...]     tags: align_p4 align_p8 align_c4 klt seeds pose stereo
 set -e
-ROUND=${1:-r02}; shift || true
+ROUND=${1:-r03}; shift || true
 TAGS=${@:-align_p4 align_p8 align_c4 klt seeds pose stereo}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
@@ -13,9 +13,9 @@ mkdir -p $dst
 STEPS="--steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
 for tag in $TAGS; do
   case $tag in
-    align_p4) args="$STEPS"; key="align:B1024:N2000:P4:L4-0"; rx="sparse_align_kernel<4, 256, false, false>|sparse_align_kernel.*Li4ELi256ELb0ELb0";;
-    align_p8) args="--patch 8 $STEPS"; key="align:B1024:N2000:P8:L4-0"; rx="sparse_align_kernel<8, 256, false, false>";;
-    align_c4) args="--workload align-c4 $STEPS"; key="align-c4:default"; rx="sparse_align_kernel<4, 256, true, false>";;
+    align_p4) args="$STEPS"; key="align:B1024:N2000:P4:L4-0"; rx="sparse_align_kernel<4, 256, false, false|sparse_align_kernel.*Li4ELi256ELb0ELb0";;
+    align_p8) args="--patch 8 $STEPS"; key="align:B1024:N2000:P8:L4-0"; rx="sparse_align_kernel<8, 256, false, false";;
+    align_c4) args="--workload align-c4 $STEPS"; key="align-c4:default"; rx="sparse_align_kernel<4, 256, true, false";;
     klt) args="--workload klt $STEPS"; key="klt:default"; rx="klt_track_kernel";;
     seeds) args="--workload seeds $STEPS"; key="seeds:default"; rx="update_seeds|seed_bin|seed_unsort";;
     pose) args="--workload pose $STEPS"; key="pose:default"; rx="pose_optimize_kernel";;

@@ -383,6 +383,60 @@ __device__ bool warp_affine_g8(const double A_cur_ref[4], const DevImage& img_re
   return true;
 }
 
+// the same with the 100 pixels dealt out to the 64 lanes of a wave (geometry 3: pixel k to lane k % 64, two samples per lane)
+__device__ bool warp_affine_w64(const double A_cur_ref[4], const DevImage& img_ref, double pxr, double pyr, int level_ref,
+                                int search_level, unsigned char* patch)
+{
+  constexpr int halfpatch_size = 5;
+  const int lane = (int)(threadIdx.x & 63);
+  double Ai[4];
+  mat2d_inverse(A_cur_ref, Ai);
+  const float s = (float)(1 << search_level);
+  const float a00 = (float)Ai[0] * s, a10 = (float)Ai[1] * s, a01 = (float)Ai[2] * s, a11 = (float)Ai[3] * s;
+  if (a00 != a00) return false;
+  const float prx = (float)pxr / (float)(1 << level_ref);
+  const float pry = (float)pyr / (float)(1 << level_ref);
+  const int stride = img_ref.pitch;
+  bool inside = true;
+  float pxx[2], pxy[2];
+  int xi[2], yi[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = lane + 64 * j;
+    const float fx = (float)(k % 10 - halfpatch_size), fy = (float)(k / 10 - halfpatch_size);
+    pxx[j] = (a00 * fx + a01 * fy) + prx;
+    pxy[j] = (a10 * fx + a11 * fy) + pry;
+    xi[j] = (int)floorf(pxx[j]);
+    yi[j] = (int)floorf(pxy[j]);
+    if (k < 100)
+      inside = inside && pxx[j] == pxx[j] && pxy[j] == pxy[j] && !(xi[j] < 0 || yi[j] < 0 || xi[j] >= img_ref.w - 1 || yi[j] >= img_ref.h - 1);
+  }
+  if (!__all(inside)) return false;
+  unsigned short t0[2] = { 0, 0 }, t1[2] = { 0, 0 };
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (lane + 64 * j < 100) {
+      const uint8_t* ptr = img_ref.data + (ptrdiff_t)yi[j] * stride + xi[j];
+      __builtin_memcpy(&t0[j], ptr, 2);
+      __builtin_memcpy(&t1[j], ptr + stride, 2);
+    }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = lane + 64 * j;
+    if (k < 100) {
+      const float subpix_x = pxx[j] - xi[j], subpix_y = pxy[j] - yi[j];
+      const unsigned t00 = t0[j] & 255u, t10 = t0[j] >> 8, t01 = t1[j] & 255u, t11 = t1[j] >> 8;
+      const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+      const float w01 = (1.0f - subpix_x) * subpix_y;
+      const float w10 = subpix_x * (1.0f - subpix_y);
+      const float w11 = 1.0f - w00 - w01 - w10;
+      patch[k] = (unsigned char)(w00 * t00 + w01 * t01 + w10 * t10 + w11 * t11);
+    }
+  }
+  g8_lds_fence();
+  return true;
+}
+
 // PatchScore constructor sums (patch_score.h:80-92), one row per lane
 __device__ __forceinline__ void patch_sums_g8(const unsigned char* pwb, int sub, int& sumA, int& sumAA)
 {
@@ -1303,6 +1357,167 @@ __device__ void scan_epipolar_unit_sphere(MatcherState& m, const svoh_matcher_op
   project3(frame.cam, f_best, bx, by);
 }
 
+// ---- one wave per unit: 64 steps of the epipolar scan at a time (geometry 3) -------------------------------------------
+// The stereo seam searches up to 500 steps per feature (stereo_triangulation.cpp:93) and a launch is as slow as its
+// slowest feature: with eight lanes per feature that is 63 dependent rounds of (positions -> rows -> scores).  A step's
+// pixel depends on its index only, so a whole wave takes 64 steps per round: lane l computes the position of step
+// i0 + l, the loop's control flow over the 64 pixels is three ballots (a pixel equal to its predecessor's is skipped,
+// the first patch that leaves the image ends the round: jump to the second half, turn round, or stop), every scored
+// lane evaluates its OWN step's ZMSSD with the packed template (eight unaligned 8-byte rows, v_dot4), and the winner is
+// the smallest score, the earliest step among equals -- the sequential loop's `if (z < best)` in step order.
+// Same visit order, same scores, same first minimum, same counters: bit-identical to the other geometries.
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+  const int big = 0x7fffffff;
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x140, 0xF, 0xF, false));   // row_mirror
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// what one round of 64 steps decides: which lanes are scored, where the first leaving patch is, the last pixel seen
+struct W64Round { bool scored; int e_out; int n_proc; };
+__device__ __forceinline__ W64Round w64_round(bool valid, bool within, int pxi0, int pxi1, int& last0, int& last1, int lane)
+{
+  int p0 = __shfl_up(pxi0, 1), p1 = __shfl_up(pxi1, 1);
+  if (lane == 0) { p0 = last0; p1 = last1; }
+  const bool dup = valid && pxi0 == p0 && pxi1 == p1;
+  const unsigned long long m_valid = __ballot(valid), m_out = __ballot(valid && !dup && !within);
+  W64Round r;
+  r.e_out = m_out ? __ffsll((long long)m_out) - 1 : 64;
+  r.scored = valid && !dup && within && lane < r.e_out;
+  r.n_proc = r.e_out < 64 ? r.e_out + 1 : __popcll(m_valid);
+  return r;
+}
+
+__device__ void scan_epipolar_unit_sphere_w64(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& frame,
+                                              const Vec3& A, const Vec3& B, const Vec3& C, int patch_level, int sumA, int sumAA,
+                                              double& bx, double& by, int& zmssd_best)
+{
+  size_t n_steps = (size_t)(m.epi_length_pyramid / 0.7);
+  n_steps = n_steps > (size_t)opt.max_epi_search_steps ? (size_t)opt.max_epi_search_steps : n_steps;
+  const size_t half_steps = n_steps / 2;
+  Vec3 f_A = A, f_B = B, f_C = C;
+  normalize3(f_A); normalize3(f_B); normalize3(f_C);
+  const double step = acos((f_A.x * f_B.x + f_A.y * f_B.y) + f_A.z * f_B.z) / n_steps;
+  Vec3 axis = { f_B.y * f_A.z - f_B.z * f_A.y, f_B.z * f_A.x - f_B.x * f_A.z, f_B.x * f_A.y - f_B.y * f_A.x };
+  normalize3(axis);
+  Vec3 f_best = f_C;
+  const int lane = (int)(threadIdx.x & 63);
+  const DevImage& im = frame.lv[patch_level];
+  int last0 = 0, last1 = 0;
+  long long best_i = -1;
+  size_t i0 = 0;
+  while (i0 < n_steps) {
+    const size_t i = i0 + (size_t)lane;
+    const bool valid = i < n_steps;
+    int pxi0 = 0, pxi1 = 0;
+    bool within = false;
+    if (valid) {
+      const double angle = i < half_steps ? i * step : (i - half_steps) * (-step);
+      const Vec3 fi = angle_axis_rotate(axis, angle, f_C);
+      double px, py;
+      project3(frame.cam, fi, px, py);
+      pxi0 = (int)(px / (1 << patch_level) + 0.5); pxi1 = (int)(py / (1 << patch_level) + 0.5);
+      within = is_patch_within_image(frame, pxi0, pxi1, patch_level);
+    }
+    const W64Round r = w64_round(valid, within, pxi0, pxi1, last0, last1, lane);
+    int z = 0x7fffffff;
+    if (r.scored) z = zmssd_score_packed(m.tpl, sumA, sumAA, im.data + (ptrdiff_t)(pxi1 - 4) * im.pitch + (pxi0 - 4), im.pitch);
+    m.n_zmssd += __popcll(__ballot(r.scored));
+    const int zmin = wave_min_i32(z);
+    if (zmin < zmssd_best) {
+      zmssd_best = zmin;
+      best_i = (long long)i0 + (__ffsll((long long)__ballot(r.scored && z == zmin)) - 1);
+    }
+    last0 = __builtin_amdgcn_readlane(pxi0, r.n_proc - 1); last1 = __builtin_amdgcn_readlane(pxi1, r.n_proc - 1);
+    if (r.e_out < 64) {
+      if (i0 + (size_t)r.e_out < half_steps) i0 = half_steps + 1;   // `i = half_steps; continue` and the loop's increment
+      else break;
+    } else {
+      i0 += 64;
+    }
+  }
+  if (best_i >= 0) {
+    const size_t bi = (size_t)best_i;
+    f_best = angle_axis_rotate(axis, bi < half_steps ? bi * step : (bi - half_steps) * (-step), f_C);
+  }
+  project3(frame.cam, f_best, bx, by);
+}
+
+__device__ void scan_epipolar_unit_plane_w64(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& frame,
+                                             const Vec3& A, const Vec3& B, const Vec3& C, int patch_level, int sumA, int sumAA,
+                                             double& bx, double& by, int& zmssd_best)
+{
+  size_t n_steps = (size_t)(m.epi_length_pyramid / 0.7);
+  double step0 = (A.x / A.z - B.x / B.z) / n_steps, step1 = (A.y / A.z - B.y / B.z) / n_steps;
+  if (n_steps > (size_t)opt.max_epi_search_steps) n_steps = (size_t)opt.max_epi_search_steps;
+  const double uvC0 = C.x / C.z, uvC1 = C.y / C.z;
+  double uv0 = uvC0, uv1 = uvC1;       // position of step i0
+  double best0 = uv0, best1 = uv1;
+  bool forward = true;
+  const int lane = (int)(threadIdx.x & 63);
+  const DevImage& im = frame.lv[patch_level];
+  const double half = n_steps * 0.5;
+  int last0 = 0, last1 = 0;
+  size_t i0 = 0;
+  while (i0 < n_steps) {
+    // a step's position is the round's start plus SEQUENTIAL additions of the step vector (the reference's `uv += step`)
+    double mine0 = uv0, mine1 = uv1;
+    for (int k = 0; k < 63; ++k)
+      if (k < lane) { mine0 += step0; mine1 += step1; }
+    const bool valid = i0 + (size_t)lane < n_steps;
+    int pxi0 = 0, pxi1 = 0;
+    bool within = false;
+    if (valid) {
+      double px, py;
+      const Vec3 p3 = { mine0, mine1, 1.0 };
+      project3(frame.cam, p3, px, py);
+      pxi0 = (int)(px / (1 << patch_level) + 0.5); pxi1 = (int)(py / (1 << patch_level) + 0.5);
+      within = is_patch_within_image(frame, pxi0, pxi1, patch_level);
+    }
+    W64Round r = w64_round(valid, within, pxi0, pxi1, last0, last1, lane);
+    // walking forward, the first scored step past the middle turns the walk round behind itself
+    const unsigned long long m_turn = __ballot(r.scored && forward && (double)(i0 + (size_t)lane) > half);
+    const int e_turn = m_turn ? __ffsll((long long)m_turn) - 1 : 64;
+    if (e_turn < r.e_out) { r.scored = r.scored && lane <= e_turn; r.n_proc = e_turn + 1; }
+    int z = 0x7fffffff;
+    if (r.scored) z = zmssd_score_packed(m.tpl, sumA, sumAA, im.data + (ptrdiff_t)(pxi1 - 4) * im.pitch + (pxi0 - 4), im.pitch);
+    m.n_zmssd += __popcll(__ballot(r.scored));
+    const int zmin = wave_min_i32(z);
+    if (zmin < zmssd_best) {
+      zmssd_best = zmin;
+      const int bl = __ffsll((long long)__ballot(r.scored && z == zmin)) - 1;
+      best0 = readlane_f64(mine0, bl); best1 = readlane_f64(mine1, bl);
+    }
+    last0 = __builtin_amdgcn_readlane(pxi0, r.n_proc - 1); last1 = __builtin_amdgcn_readlane(pxi1, r.n_proc - 1);
+    if (e_turn < r.e_out) {                 // past the middle: `step = -step; uv = uv_C`, then the loop's own increment
+      i0 = i0 + (size_t)e_turn + 1;
+      step0 = -step0; step1 = -step1;
+      uv0 = uvC0 + step0; uv1 = uvC1 + step1;
+      forward = false;
+    } else if (r.e_out < 64) {
+      if (!forward) break;
+      i0 = (size_t)half + 1;                // `i = n_steps * 0.5; ...; continue` and the loop's increment
+      step0 = -step0; step1 = -step1;
+      uv0 = uvC0 + step0; uv1 = uvC1 + step1;
+      forward = false;
+    } else {
+      i0 += 64;
+      uv0 = readlane_f64(mine0, 63) + step0; uv1 = readlane_f64(mine1, 63) + step1;
+    }
+  }
+  const Vec3 p3 = { best0, best1, 1.0 };
+  project3(frame.cam, p3, bx, by);
+}
+
 // matcher.cpp:492-505
 __device__ int depth_from_triangulation(const Rigid& T_search_ref, const Vec3& f_ref, const Vec3& f_cur, double& depth)
 {
@@ -1364,6 +1579,7 @@ __device__ int epipolar_match_search(MatcherState& m, const svoh_matcher_options
   SVOH_MSTAMP(m, 0);
   bool warp_ok;
   if constexpr (G8 == 1) warp_ok = warp_affine_g8(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb, m.sub);
+  else if constexpr (G8 == 3) warp_ok = warp_affine_w64(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
   else if constexpr (G8 == 2) warp_ok = warp_affine_packed(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
   else warp_ok = warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
   SVOH_MSTAMP(m, 1);
@@ -1381,7 +1597,7 @@ __device__ int epipolar_match_search(MatcherState& m, const svoh_matcher_options
     // PatchScore constructor (patch_score.h:80-92)
     int sumA = 0, sumAA = 0;
     if constexpr (G8 == 1) patch_sums_g8(m.pwb, m.sub, sumA, sumAA);
-    else if constexpr (G8 == 2) {
+    else if constexpr (G8 == 2 || G8 == 3) {
       pack_template(m.pwb, m.tpl);
       unsigned a1 = 0, a2 = 0;
 #pragma unroll
@@ -1390,7 +1606,12 @@ __device__ int epipolar_match_search(MatcherState& m, const svoh_matcher_options
     } else for (int r = 0; r < 64; ++r) { const int n = patch_at(m.pwb, r); sumA += n; sumAA += n * n; }
     const Vec3 C = { Rf.x + T_cur_ref.t.x * d_estimate_inv, Rf.y + T_cur_ref.t.y * d_estimate_inv,
                      Rf.z + T_cur_ref.t.z * d_estimate_inv };
-    if (opt.scan_on_unit_sphere)
+    if constexpr (G8 == 3) {
+      if (opt.scan_on_unit_sphere)
+        scan_epipolar_unit_sphere_w64(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
+      else
+        scan_epipolar_unit_plane_w64(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
+    } else if (opt.scan_on_unit_sphere)
       scan_epipolar_unit_sphere<G8>(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
     else
       scan_epipolar_unit_plane<G8>(m, opt, cur_frame, A, B, C, m.search_level, sumA, sumAA, m.px_cur[0], m.px_cur[1], zmssd_best);
@@ -1420,14 +1641,15 @@ __device__ int epipolar_match_finish(MatcherState& m, const DevFrameView& cur_fr
   return depth_from_triangulation(T_cur_ref, f_ref, m.f_cur, depth);
 }
 
-// Matcher::findEpipolarMatchDirect in one piece
-template <bool G8 = false>
+// Matcher::findEpipolarMatchDirect in one piece.  G8: 0 one lane per unit, 1 eight lanes per unit, 3 one wave per unit
+// (the search of geometry 3, the refinement by its eight-lane groups, all of which compute the same)
+template <int G8 = 0>
 __device__ int find_epipolar_match_direct(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
                                           const DevFrameView& cur_frame, const Rigid& T_cur_ref, double pxr, double pyr,
                                           const Vec3& f_ref, double gx, double gy, int level, int type,
                                           double d_estimate_inv, double d_min_inv, double d_max_inv, double& depth)
 {
-  const int st = epipolar_match_search<G8 ? 1 : 0>(m, opt, ref_frame, cur_frame, T_cur_ref, pxr, pyr, f_ref, gx, gy, level, type,
+  const int st = epipolar_match_search<G8>(m, opt, ref_frame, cur_frame, T_cur_ref, pxr, pyr, f_ref, gx, gy, level, type,
                                                    d_estimate_inv, d_min_inv, d_max_inv);
   if (st != kMatchRefinePending && st != kMatchTriangulatePending) return st;
   bool aligned = false;
@@ -1568,15 +1790,19 @@ __global__ __launch_bounds__(64) void match_direct_kernel(const MatcherArgs a)
 }
 
 // DepthFilter::updateSeeds (depth_filter.cpp:200-233) + depth_filter_utils::updateSeed (:367-499)
-template <bool G8>
+// G8: 0 one lane per unit, 1 eight lanes per unit, 3 one wave per unit (scan 64 steps at a time)
+template <int G8>
 __device__ __forceinline__ void update_seeds_body(const MatcherArgs& a, int block, unsigned char* s_pwb)
 {
-  const int unit = G8 ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;
-  const int i = block * (G8 ? 8 : 64) + unit;
+  const int unit = G8 == 1 ? (int)(threadIdx.x >> 3) : (G8 == 3 ? 0 : (int)threadIdx.x);
+  const int i = block * (G8 == 1 ? 8 : (G8 == 3 ? 1 : 64)) + unit;
   if (i >= a.n) return;
-  a.success[i] = 0;
-  if (a.result) a.result[i] = SVOH_MATCH_NOT_RUN;
-  if (!G8 || (threadIdx.x & 7) == 0) reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(0u, 0u, 0u, 0u);   // units that are not run
+  const bool reporter = G8 == 0 || (G8 == 1 && (threadIdx.x & 7) == 0) || (G8 == 3 && (threadIdx.x & 63) == 0);
+  if (reporter) {
+    a.success[i] = 0;
+    if (a.result) a.result[i] = SVOH_MATCH_NOT_RUN;
+    reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(0u, 0u, 0u, 0u);   // units that are not run
+  }
   if (!feature_indices_ok(a, i)) return;
   const int type = a.type[i];
   if (!(type < 6)) return;  // isSeed
@@ -1620,7 +1846,7 @@ __device__ __forceinline__ void update_seeds_body(const MatcherArgs& a, int bloc
   const double inv_max = fmax(st[0] - sqrt(st[1]), 0.00000001);
   const int res = find_epipolar_match_direct<G8>(m, a.mopt, ref, cur, T_cur_ref, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
                                                  a.grad[2 * i + 1], a.level[i], type, st[0], inv_min, inv_max, depth);
-  if (G8 && m.sub != 0) return;   // the eight lanes hold the same results: one of them reports and updates the seed
+  if (!reporter) return;   // the lanes of a unit hold the same results: one of them reports and updates the seed
   if (a.result) a.result[i] = res;
   // matcher state as reprojector_utils::matchCandidate reads it after updateSeed (reprojector.cpp:403-413, 473-476)
   if (a.px_cur) { a.px_cur[2 * i] = m.px_cur[0]; a.px_cur[2 * i + 1] = m.px_cur[1]; }
@@ -1654,7 +1880,7 @@ __device__ __forceinline__ void update_seeds_body(const MatcherArgs& a, int bloc
 #endif
 }
 
-template <bool G8>
+template <int G8>
 __global__ __launch_bounds__(64) void update_seeds_kernel(const MatcherArgs a)
 {
   __shared__ __attribute__((aligned(16))) unsigned char s_pwb[64 * kPwbStride];
@@ -1669,7 +1895,7 @@ __global__ __launch_bounds__(64) void match_mixed_kernel(const MatcherArgs ad, c
 {
   __shared__ __attribute__((aligned(16))) unsigned char s_pwb[64 * kPwbStride];
   if ((int)blockIdx.x < n_blocks_direct) match_direct_body<G8>(ad, (int)blockIdx.x, s_pwb);
-  else update_seeds_body<G8>(as, (int)blockIdx.x - n_blocks_direct, s_pwb);
+  else update_seeds_body<G8 ? 1 : 0>(as, (int)blockIdx.x - n_blocks_direct, s_pwb);
 }
 
 // ---- spatial binning of a large seed batch -------------------------------------------------------------------------
@@ -2063,14 +2289,14 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
 
 // n x Matcher::findEpipolarMatchDirect with an explicit T_cur_ref (matcher.cpp:157-241), align_1d = isEdgelet(type):
 // the call StereoTriangulation::compute makes per new feature (stereo_triangulation.cpp:92-104)
-template <bool G8>
+template <int G8>
 __global__ __launch_bounds__(64) void epipolar_match_kernel(const MatcherArgs a)
 {
   __shared__ __attribute__((aligned(16))) unsigned char s_pwb[64 * kPwbStride];
-  const int unit = G8 ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;
-  const int i = blockIdx.x * (G8 ? 8 : 64) + unit;
+  const int unit = G8 == 1 ? (int)(threadIdx.x >> 3) : (G8 == 3 ? 0 : (int)threadIdx.x);
+  const int i = blockIdx.x * (G8 == 1 ? 8 : (G8 == 3 ? 1 : 64)) + unit;
   if (i >= a.n) return;
-  const bool reporter = !G8 || (threadIdx.x & 7) == 0;
+  const bool reporter = G8 == 0 || (G8 == 1 && (threadIdx.x & 7) == 0) || (G8 == 3 && (threadIdx.x & 63) == 0);
   if (!feature_indices_ok(a, i)) {
     if (reporter) {
       a.result[i] = SVOH_MATCH_NOT_RUN;
@@ -2458,9 +2684,11 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   // small batches: eight lanes per unit (a launch is as slow as its slowest lane, and eight lanes get a unit done
   // ~3x sooner); large batches: one lane per unit (fewer instructions per unit).  The knob SVOH_MATCHER_G8 (read when the context is made) forces one.
   // geometry: 1 = eight lanes per unit, 0 = one lane per unit, 2 = packed (seed update only; large batches)
+  // 3 = one wave per unit (the epipolar scan 64 steps at a time; seed update only, on request: its scans are short)
   int g8 = n <= kG8MaxUnits ? 1 : 2;
   g8 = SvohKnobs::or_default(ctx->knobs.matcher_g8, g8);
-  if (g8 < 0 || g8 > 2) g8 = 0;
+  if (g8 < 0 || g8 > 3) g8 = 0;
+  if (g8 == 3 && (!seeds || defer)) g8 = 1;   // the direct matcher has no scan
   if (defer && g8 != 2) {
     // Deferred section: the launch itself waits for svoh_matcher_collect, where a direct batch and a seed batch of
     // the same geometry go out as ONE kernel (match_mixed_kernel).  Remembered: the arguments, the copy of the
@@ -2483,7 +2711,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     }
     return SVOH_OK;
   }
-  const int units_per_block = g8 == 1 ? 8 : 64;
+  const int units_per_block = g8 == 1 ? 8 : (g8 == 3 ? 1 : 64);
   const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
   {
     unsigned long long* dummy;
@@ -2540,8 +2768,9 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
       if (rec_out) hipLaunchKernelGGL(seed_unsort_kernel, gb, dim3(256), 0, ctx->stream, a, pos_of, static_cast<const SeedRecOut*>(rec_out),
                                       hist_ptr, hist_keys);
     }
-    else if (g8) hipLaunchKernelGGL(update_seeds_kernel<true>, grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL(update_seeds_kernel<false>, grid, block, 0, ctx->stream, a);
+    else if (g8 == 3) hipLaunchKernelGGL(update_seeds_kernel<3>, grid, block, 0, ctx->stream, a);
+    else if (g8) hipLaunchKernelGGL(update_seeds_kernel<1>, grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL(update_seeds_kernel<0>, grid, block, 0, ctx->stream, a);
   } else {
     if (g8 == 2) hipLaunchKernelGGL(match_packed_kernel<true>, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0, ctx->stream, a);
     else if (g8) hipLaunchKernelGGL(match_direct_kernel<true>, grid, block, 0, ctx->stream, a);
@@ -2725,11 +2954,14 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
     a.h_inv = reinterpret_cast<double*>(d + o_hinv);
     a.A_cur_ref = reinterpret_cast<double*>(d + o_A);
   }
-  // geometry as in run_matcher: 1 = eight lanes per unit, 0 = one lane per unit, 2 = packed (large batches)
-  int g8 = n <= kG8MaxUnits ? 1 : 2;
+  // geometry as in run_matcher: 1 = eight lanes per unit, 0 = one lane per unit, 2 = packed (large batches),
+  // 3 = one wave per unit, the scan 64 steps at a time: what a long search (the stereo seam's 500 steps) gets while the
+  // batch leaves the device room for a wave per feature (a launch is as slow as its slowest feature: 8 rounds instead of 63)
+  constexpr int kW64MaxUnits = 16384;
+  int g8 = n <= kG8MaxUnits ? ((mopt->max_epi_search_steps > 128 && n <= kW64MaxUnits) ? 3 : 1) : 2;
   g8 = SvohKnobs::or_default(ctx->knobs.matcher_g8, g8);
-  if (g8 < 0 || g8 > 2) g8 = 0;
-  const int units_per_block = g8 == 1 ? 8 : 64;
+  if (g8 < 0 || g8 > 3) g8 = 0;
+  const int units_per_block = g8 == 1 ? 8 : (g8 == 3 ? 1 : 64);
   const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
   {
     unsigned long long* dummy;
@@ -2739,8 +2971,9 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
   }
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   if (g8 == 2) hipLaunchKernelGGL(match_packed_kernel<false>, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0, ctx->stream, a);
-  else if (g8) hipLaunchKernelGGL(epipolar_match_kernel<true>, grid, block, 0, ctx->stream, a);
-  else hipLaunchKernelGGL(epipolar_match_kernel<false>, grid, block, 0, ctx->stream, a);
+  else if (g8 == 3) hipLaunchKernelGGL(epipolar_match_kernel<3>, grid, block, 0, ctx->stream, a);
+  else if (g8) hipLaunchKernelGGL(epipolar_match_kernel<1>, grid, block, 0, ctx->stream, a);
+  else hipLaunchKernelGGL(epipolar_match_kernel<0>, grid, block, 0, ctx->stream, a);
   SVOH_HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
   ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
@@ -2960,8 +3193,8 @@ static int launch_deferred(svoh_ctx* ctx)
           else hipLaunchKernelGGL(match_direct_kernel<false>, dim3(blocks(d0)), dim3(64), 0, ctx->stream, a0);
         }
         if (v1) {
-          if (d1.g8) hipLaunchKernelGGL(update_seeds_kernel<true>, dim3(blocks(d1)), dim3(64), 0, ctx->stream, a1);
-          else hipLaunchKernelGGL(update_seeds_kernel<false>, dim3(blocks(d1)), dim3(64), 0, ctx->stream, a1);
+          if (d1.g8) hipLaunchKernelGGL(update_seeds_kernel<1>, dim3(blocks(d1)), dim3(64), 0, ctx->stream, a1);
+          else hipLaunchKernelGGL(update_seeds_kernel<0>, dim3(blocks(d1)), dim3(64), 0, ctx->stream, a1);
         }
       }
       SVOH_HIP_TRY(ctx, hipGetLastError());
