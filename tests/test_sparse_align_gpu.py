@@ -528,3 +528,70 @@ def test_cluster_that_never_completes_falls_back(gpu_ctx):
                 gpu_ctx.reload_knobs()
         gpu_ctx.close()
         product_ctx.reload_knobs()
+
+
+def test_candidate_projection_rides_the_alignment_launch(gpu_ctx):
+    """f-4 on the device: svoh_project_candidates_enqueue queued behind svoh_sparse_align_enqueue with align_result_index = 0
+    composes the current frame's pose ON THE DEVICE from the alignment result (T_f_w = T_cam_imu * T_icur_iref *
+    T_imu_world_ref, sparse_img_align.cpp:100-107); one fetch delivers both.  Pixels and verdicts against an independent
+    NumPy restatement of reprojector.cpp:489-543 / frame.cpp:229-260 (tests/np_restatement_direct.py) at the pose the
+    fetch returns: verdicts exact, pixels to rounding."""
+    import ctypes as C
+    import np_restatement_direct as nd
+    lib, h = gpu_ctx.lib, gpu_ctx.h
+    cam = synth.Camera.euroc_like()
+    sc = helpers.small_scene(131, n=400, cam=cam)
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+    pbs, keep = fe.make_align_problems([[(sc, fr, fc)]])
+    opt = capi.default_align_options(min_level=1)
+    rng = np.random.RandomState(4)
+    # the "local map": two keyframes; world points all around the current view (many outside it) and seeds of both keyframes
+    T_w_kf = [sc.T_w_ref, sc.T_w_ref * synth.SE3(synth.quat_from_axis_angle([0, 1, 0], 0.2), (0.3, 0.0, 0.1))]
+    n = 3000
+    kind = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    kf = rng.randint(0, 2, n).astype(np.int32)
+    v = np.zeros((n, 3)); mu = np.ones(n)
+    for i in range(n):
+        if kind[i]:
+            f = np.array([rng.uniform(-0.9, 0.9), rng.uniform(-0.7, 0.7), 1.0]); v[i] = f / np.linalg.norm(f)
+            mu[i] = 1.0 / rng.uniform(0.5, 8.0)
+        else:
+            v[i] = sc.T_w_cur.transform(np.array([rng.uniform(-6, 6), rng.uniform(-4, 4), rng.uniform(-1.0, 8.0)]))
+    T_imu_world_ref = sc.T_imu_cam * sc.T_ref_f_w if hasattr(sc, "T_imu_cam") else sc.T_ref_f_w
+    Ta, Tb = fe._se3(sc.T_cam_imu), fe._se3(T_imu_world_ref)
+    Tk = (capi.svoh_se3 * 2)(*[fe._se3(t) for t in T_w_kf])
+    c = fe._camera(cam)
+    v_flat = np.ascontiguousarray(v).ravel()
+    gpu_ctx.sparse_align_enqueue(opt, pbs)
+    assert lib.svoh_project_candidates_enqueue(h, C.byref(c), C.byref(Ta), C.byref(Tb), 0, 2, Tk, n, kind.ctypes.data, kf.ctypes.data,
+                                               v_flat.ctypes.data, mu.ctypes.data) == 0
+    res = gpu_ctx.sparse_align_fetch(1)[0]
+    px, vis = np.zeros(2 * n), np.zeros(n, np.uint8)
+    assert lib.svoh_project_candidates_collect(h, n, px.ctypes.data, vis.ctypes.data) == 0
+    # the same at the pose the fetch has returned, in NumPy
+    T_icur_iref = nd.Tf.from7(fe.se3_to_numpy(res.T_icur_iref))
+    T_f_w = nd.Tf.from7(sc.T_cam_imu.as7()) * T_icur_iref * nd.Tf.from7(T_imu_world_ref.as7())
+    ncam = nd.Cam.of(cam)
+    f_tl = ncam.back_project3(np.zeros(2)); min_cos = f_tl[2] / np.linalg.norm(f_tl)
+    n_vis = 0
+    for i in range(n):
+        xyz = v[i] if not kind[i] else nd.Tf.from7(T_w_kf[kf[i]].as7()).apply(v[i] * (1.0 / mu[i]))
+        xf = T_f_w.apply(xyz)
+        ok = not (xf[2] / np.linalg.norm(xf) < min_cos)
+        p = np.zeros(2)
+        if ok:
+            p = ncam.project3(xf)
+            ok = ncam.is_keypoint_visible(p) and ncam.is_keypoint_visible_with_margin((int(p[0]), int(p[1])), 8)
+        near_edge = ok != bool(vis[i])
+        if near_edge:   # a pixel within rounding of an integer boundary may fall on either side
+            assert min(abs(p[0] - round(p[0])), abs(p[1] - round(p[1]))) < 1e-9 or abs(xf[2] / np.linalg.norm(xf) - min_cos) < 1e-12, i
+        elif ok:
+            assert np.abs(px[2 * i:2 * i + 2] - p).max() < 1e-9
+            n_vis += 1
+    assert 200 < n_vis < n - 200
+    # without a queued alignment result the composed form is refused, the explicit form works
+    T_explicit = fe._se3(synth.SE3.from7(np.concatenate([T_f_w.q, T_f_w.t])))
+    px2, vis2 = np.zeros(2 * n), np.zeros(n, np.uint8)
+    assert lib.svoh_project_candidates(h, C.byref(c), C.byref(T_explicit), 2, Tk, n, kind.ctypes.data, kf.ctypes.data, v_flat.ctypes.data,
+                                       mu.ctypes.data, px2.ctypes.data, vis2.ctypes.data) == 0
+    assert np.array_equal(vis, vis2) and np.abs(px - px2)[np.repeat(vis.astype(bool), 2)].max() < 1e-9
