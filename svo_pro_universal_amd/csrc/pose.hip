@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "svoh_internal.h"
@@ -52,6 +53,7 @@ struct PoseArgs {
   uint8_t* outlier; double* final_error;
   svoh_pose_result* results;
   int n_problems;
+  int max_meas;   // capacity of the LDS error list (largest bundle of the batch, rounded up to 64)
 };
 
 __device__ __forceinline__ float tukey_weight_f(float e)
@@ -82,7 +84,10 @@ __device__ __forceinline__ void chain_G(const double* A, const double* R, const 
 }
 
 // one measurement (pose_optimizer.cpp:338-627); acc = upper triangle of H (21) + g (6), row-major packing
-__device__ void pose_residual(const svoh_pose_options& opt, const CamModel& cm, const Rigid& T_cam_imu, const double* Rci,
+// ET (the error type) and WANT_J are compile-time: each kernel instance carries one error model only, which is what
+// keeps it within 256 registers (two waves per SIMD)
+template <int ET, bool WANT_J>
+__device__ __forceinline__ void pose_residual(const CamModel& cm, const Rigid& T_cam_imu, const double* Rci,
                               const Rigid& T_imu_world, const double* f, const double* px, const double* grad,
                               const Vec3& xyz_world, bool edgelet, double measurement_sigma, double& unwhitened_error,
                               double* acc /* may be NULL */)
@@ -93,8 +98,8 @@ __device__ void pose_residual(const svoh_pose_options& opt, const CamModel& cm, 
   double e[3] = { 0, 0, 0 };
   double J[18];
   int rows;
-  const bool want_J = acc != nullptr;
-  if (opt.error_type == SVOH_POSE_ERR_UNIT_PLANE) {
+  constexpr bool want_J = WANT_J;
+  if (ET == SVOH_POSE_ERR_UNIT_PLANE) {
     const double d0 = f[0] / f[2] - p_cam.x / p_cam.z, d1 = f[1] / f[2] - p_cam.y / p_cam.z;
     double Juv[12];
     if (want_J) {
@@ -109,7 +114,7 @@ __device__ void pose_residual(const svoh_pose_options& opt, const CamModel& cm, 
       rows = 1; e[0] = grad[0] * d0 + grad[1] * d1;
       if (want_J) for (int c = 0; c < 6; ++c) J[c] = grad[0] * Juv[c] + grad[1] * Juv[6 + c];
     }
-  } else if (opt.error_type == SVOH_POSE_ERR_IMAGE_PLANE) {
+  } else if (ET == SVOH_POSE_ERR_IMAGE_PLANE) {
     double u, v, Jc[6], Jimg[12];
     project3(cm, p_cam, u, v);
     project3_jacobian(cm, p_cam, Jc);
@@ -221,11 +226,13 @@ __device__ T rank_select(const T* vals, int n, int k, int tid, T* s_out)
 // negative scale or an undefined shift)
 __device__ __forceinline__ int pose_level(int l) { return l < 0 ? 0 : (l > 29 ? 29 : l); }
 
-template <int NT>
+template <int NT, int ET>
 __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
 {
   constexpr int NACC = 27, NW = NT / 64;
-  __shared__ double s_err[kPoseMaxMeas];       // start errors as float values, later final errors (double)
+  // start errors as float values, later final errors (double); sized by the launch to the largest bundle of the
+  // batch (a.max_meas), so that bundles of a few hundred features leave room for eight workgroups per compute unit
+  extern __shared__ double s_err[];
   __shared__ double s_red[NW][NACC];
   __shared__ double s_sum[NACC];
   __shared__ Rigid s_T, s_Told;
@@ -268,14 +275,14 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
       const int scale = 1 << pose_level(a.level[gi]);
       double ue;
       const Vec3 X = { a.xyz[3 * gi], a.xyz[3 * gi + 1], a.xyz[3 * gi + 2] };
-      pose_residual(opt, cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, is_edgelet_type(a.type[gi]),
-                    1.0, ue, nullptr);
+      pose_residual<ET, false>(cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X,
+                               is_edgelet_type(a.type[gi]), 1.0, ue, nullptr);
       const int slot = atomicAdd(&s_n, 1);
-      if (slot < kPoseMaxMeas) s_errf[slot] = (float)(ue / scale);
+      if (slot < a.max_meas) s_errf[slot] = (float)(ue / scale);
     });
   }
   __syncthreads();
-  const int n_meas = s_n < kPoseMaxMeas ? s_n : kPoseMaxMeas;
+  const int n_meas = s_n < a.max_meas ? s_n : a.max_meas;
   svoh_pose_result& res = a.results[pbi];
   if (n_meas == 0) {
     if (tid == 0) {
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
       if (edgelet) sigma *= 2.0;   // kEdgeletSigmaExtraFactor
       double ue;
       const Vec3 X = { a.xyz[3 * gi], a.xyz[3 * gi + 1], a.xyz[3 * gi + 2] };
-      pose_residual(opt, cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, edgelet, sigma, ue, acc);
+      pose_residual<ET, true>(cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, edgelet, sigma, ue, acc);
     });
     {
       int ridx;
@@ -379,18 +386,18 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
       const bool edgelet = is_edgelet_type(a.type[gi]);
       double ue;
       const Vec3 X = { a.xyz[3 * gi], a.xyz[3 * gi + 1], a.xyz[3 * gi + 2] };
-      pose_residual(opt, cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, edgelet, 1.0, ue, nullptr);
+      pose_residual<ET, false>(cm, T_cam_imu, Rci, T, &a.f[3 * gi], &a.px[2 * gi], &a.grad[2 * gi], X, edgelet, 1.0, ue, nullptr);
       ue *= 1.0 / (1 << pose_level(a.level[gi]));
       a.final_error[gi] = ue;
       const bool out = fabs(ue) > opt.outlier_threshold;
       a.outlier[gi] = out ? 1 : 0;
       if (out) atomicAdd(edgelet ? &s_del_e : &s_del_c, 1);
       const int slot = atomicAdd(&s_n, 1);
-      if (slot < kPoseMaxMeas) s_err[slot] = ue;
+      if (slot < a.max_meas) s_err[slot] = ue;
     });
   }
   __syncthreads();
-  const int n_final = s_n < kPoseMaxMeas ? s_n : kPoseMaxMeas;
+  const int n_final = s_n < a.max_meas ? s_n : a.max_meas;
   const double med_after = rank_select<NT, double>(s_err, n_final, n_final / 2, tid, &s_median);
   if (tid == 0) {
     store_rigid(s_T, res.T_imu_world);
@@ -521,7 +528,7 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
   SVOH_REQUIRE(ctx, options->max_iter >= 1 && options->error_type >= 0 && options->error_type <= 2, "bad max_iter / error_type");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-  size_t n_cams_total = 0, n_feat_total = 0;
+  size_t n_cams_total = 0, n_feat_total = 0, max_meas = 0;
   for (int p = 0; p < n_problems; ++p) {
     const svoh_pose_problem& pb = problems[p];
     SVOH_REQUIRE(ctx, pb.n_cams >= 1 && pb.n_cams <= SVOH_MAX_CAMS, "n_cams out of range");
@@ -541,6 +548,7 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
     SVOH_REQUIRE(ctx, n <= (size_t)kPoseMaxMeas, "more than 4096 features in one bundle");
     n_cams_total += (size_t)pb.n_cams;
     n_feat_total += n;
+    max_meas = std::max(max_meas, n);
   }
   if (packed) {
     SVOH_REQUIRE(ctx, (size_t)packed->n_features_total == n_feat_total, "n_features_total does not match the problems");
@@ -627,12 +635,21 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
   }
   a.results = reinterpret_cast<svoh_pose_result*>(d + o_res);
   a.n_problems = n_problems;
+  a.max_meas = (int)((max_meas + 63) & ~(size_t)63);
+  if (a.max_meas == 0) a.max_meas = 64;
+  const size_t err_bytes = sizeof(double) * (size_t)a.max_meas;
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   // geometry: see pose_optimize_kernel.  SVOH_POSE_THREADS=64/256 forces one (tests run both).
   int nt = n_problems > ctx->num_cus ? 64 : kPoseThreads;
   { const int v = ctx->knobs.pose_threads; if (v == 64 || v == kPoseThreads) nt = v; }
-  if (nt == 64) hipLaunchKernelGGL(pose_optimize_kernel<64>, dim3((unsigned)n_problems), dim3(64), 0, ctx->stream, a);
-  else hipLaunchKernelGGL(pose_optimize_kernel<kPoseThreads>, dim3((unsigned)n_problems), dim3(kPoseThreads), 0, ctx->stream, a);
+  auto launch = [&](auto et) {
+    constexpr int ET = decltype(et)::value;
+    if (nt == 64) hipLaunchKernelGGL((pose_optimize_kernel<64, ET>), dim3((unsigned)n_problems), dim3(64), err_bytes, ctx->stream, a);
+    else hipLaunchKernelGGL((pose_optimize_kernel<kPoseThreads, ET>), dim3((unsigned)n_problems), dim3(kPoseThreads), err_bytes, ctx->stream, a);
+  };
+  if (options->error_type == SVOH_POSE_ERR_UNIT_PLANE) launch(std::integral_constant<int, SVOH_POSE_ERR_UNIT_PLANE>{});
+  else if (options->error_type == SVOH_POSE_ERR_IMAGE_PLANE) launch(std::integral_constant<int, SVOH_POSE_ERR_IMAGE_PLANE>{});
+  else launch(std::integral_constant<int, SVOH_POSE_ERR_BEARING_DIFF>{});
   SVOH_HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
   ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
