@@ -680,20 +680,21 @@ __device__ bool align_2d(const DevImage& cur_img, const unsigned char* pwb, int 
   return converged;
 }
 
-// ---- the refinements with eight lanes per unit ----
-// acc[a] <- acc[a] - t[a][0] - ... - t[a][7] over the rows 0..7 in row order: lane `sub` continues where lane sub-1
-// stopped, so the additions are those of the one-lane loops (a sum is the same chain with negated terms).
-template <int NA>
-__device__ __forceinline__ void g8_chain_sub(float (&acc)[NA], const float (&t)[NA][8], int sub)
+// ---- the refinements with L lanes per unit (L = 8: the eight-lane geometry; L = 4: the packed geometry's jobs) ----
+// acc[a] <- acc[a] - t[a][0] - ... over the 64 pixels in row order: lane `sub` owns 64 / L consecutive pixels (8 / L
+// patch rows) and continues where lane sub-1 stopped, so the additions are those of the one-lane loops (a sum is the
+// same chain with negated terms).
+template <int NA, int L>
+__device__ __forceinline__ void gl_chain_sub(float (&acc)[NA], const float (&t)[NA][64 / L], int sub)
 {
   float c[NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a) c[a] = acc[a];
-  for (int s = 0; s < 8; ++s) {
+  for (int s = 0; s < L; ++s) {
     float in[NA];
     // lane i takes lane i-1's value on the VALU's DPP network (row_shr:1; one v_mov_dpp instead of a ds_bpermute round
-    // trip through the LDS crossbar per stage and accumulator).  Rows are 16 lanes: the first lane of the second
-    // group of a row receives the last lane of the first group's value, which it never uses (sub == 0 starts from acc).
+    // trip through the LDS crossbar per stage and accumulator).  Rows are 16 lanes: the first lane of a later
+    // group of a row receives the last lane of the group before it, which it never uses (sub == 0 starts from acc).
 #pragma unroll
     for (int a = 0; a < NA; ++a)
       in[a] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[a]), 0x111, 0xF, 0xF, false));
@@ -702,13 +703,13 @@ __device__ __forceinline__ void g8_chain_sub(float (&acc)[NA], const float (&t)[
       for (int a = 0; a < NA; ++a) {
         float v = (s == 0) ? acc[a] : in[a];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) v -= t[a][x];
+        for (int x = 0; x < 64 / L; ++x) v -= t[a][x];
         c[a] = v;
       }
     }
   }
 #pragma unroll
-  for (int a = 0; a < NA; ++a) acc[a] = __shfl(c[a], 7, 8);
+  for (int a = 0; a < NA; ++a) acc[a] = __shfl(c[a], L - 1, L);
 }
 
 // nine consecutive pixels as one unaligned 12-byte load (the three spare bytes stay inside the row, the next row or
@@ -723,12 +724,81 @@ __device__ __forceinline__ void load_row9_u8(const uint8_t* p, unsigned (&px)[9]
   px[8] = w[2] & 255u;
 }
 
+// One pass of the loop body of align_2d (feature_alignment.cpp:300-384) by the L lanes of a unit.  ALIGN_STOPPED /
+// ALIGN_NAN leave every argument as it was.
+template <int L>
+__device__ __forceinline__ int align_2d_gl_iter(const DevImage& cur_img, const unsigned char* pwb, bool affine_est_offset,
+                                                bool affine_est_gain, const float (&Hinv)[16], float& u, float& v,
+                                                float& mean_diff, float& alpha, int& n_it, int sub)
+{
+  constexpr int halfpatch_size_ = 4, patch_size_ = 8, ref_step = 10, R = 8 / L;
+  const float min_update_squared = (float)(0.03 * 0.03);
+  const int cur_step = cur_img.pitch;
+  const int u_r = (int)floorf(u);
+  const int v_r = (int)floorf(v);
+  if (u_r < halfpatch_size_ || v_r < halfpatch_size_ || u_r >= cur_img.w - halfpatch_size_ || v_r >= cur_img.h - halfpatch_size_)
+    return ALIGN_STOPPED;
+  if (u != u || v != v) return ALIGN_NAN;
+  ++n_it;
+  const float subpix_x = u - u_r;
+  const float subpix_y = v - v_r;
+  const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
+  const float wTR = (float)(subpix_x * (1.0 - subpix_y));
+  const float wBL = (float)((1.0 - subpix_x) * subpix_y);
+  const float wBR = subpix_x * subpix_y;
+  float t[4][8 * R];
+  {
+    const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + sub * R - halfpatch_size_) * cur_step + u_r - halfpatch_size_;
+    unsigned rows[R + 1][9];
+#pragma unroll
+    for (int r = 0; r <= R; ++r) load_row9_u8(it + (ptrdiff_t)r * cur_step, rows[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const unsigned char* rp = pwb + (sub * R + r + 1) * ref_step + 1;
+#pragma unroll
+      for (int x = 0; x < patch_size_; ++x, ++rp) {
+        const float ref_dx = (float)(0.5 * ((int)rp[1] - (int)rp[-1]));
+        const float ref_dy = (float)(0.5 * ((int)rp[ref_step] - (int)rp[-ref_step]));
+        const float search_pixel = wTL * rows[r][x] + wTR * rows[r][x + 1] + wBL * rows[r + 1][x] + wBR * rows[r + 1][x + 1];
+        const float res = search_pixel - alpha * rp[0] + mean_diff;
+        t[0][r * 8 + x] = res * ref_dx;
+        t[1][r * 8 + x] = res * ref_dy;
+        t[2][r * 8 + x] = affine_est_offset ? res : 0.0f;
+        t[3][r * 8 + x] = affine_est_gain ? (-1) * res * rp[0] : 0.0f;
+      }
+    }
+  }
+  float Jres[4] = { 0, 0, 0, 0 };
+  if (affine_est_gain) gl_chain_sub<4, L>(Jres, t, sub);
+  else {   // the fourth sum is a sum of zeros then (and reset below): hand three accumulators from lane to lane
+    float J3[3] = { 0, 0, 0 };
+    float t3[3][8 * R];
+#pragma unroll
+    for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+      for (int x = 0; x < 8 * R; ++x) t3[a3][x] = t[a3][x];
+    gl_chain_sub<3, L>(J3, t3, sub);
+    Jres[0] = J3[0]; Jres[1] = J3[1]; Jres[2] = J3[2];
+  }
+  if (!affine_est_offset) Jres[2] = 0.0f;
+  if (!affine_est_gain) Jres[3] = 0.0f;
+  float update[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    update[r] = ((Hinv[r * 4 + 0] * Jres[0] + Hinv[r * 4 + 1] * Jres[1]) + Hinv[r * 4 + 2] * Jres[2]) + Hinv[r * 4 + 3] * Jres[3];
+  u += update[0];
+  v += update[1];
+  mean_diff += update[2];
+  alpha += update[3];
+  return (update[0] * update[0] + update[1] * update[1] < min_update_squared) ? ALIGN_CONVERGED : ALIGN_CONTINUE;
+}
+
 // align_2d (feature_alignment.cpp:212-391).  The entries of H are sums of products of half-integers and
 // integers below 2^16: every partial sum is exact in float, so the rows may be added in any order.
 __device__ bool align_2d_g8(const DevImage& cur_img, const unsigned char* pwb, int n_iter, bool affine_est_offset,
                             bool affine_est_gain, double& px, double& py, int& n_it, int sub)
 {
-  constexpr int halfpatch_size_ = 4, patch_size_ = 8, ref_step = 10;
+  constexpr int patch_size_ = 8, ref_step = 10;
   bool converged = false;
   float H[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   {
@@ -755,67 +825,82 @@ __device__ bool align_2d_g8(const DevImage& cur_img, const unsigned char* pwb, i
   float alpha = 1.0;
   float u = (float)px;
   float v = (float)py;
-  const float min_update_squared = (float)(0.03 * 0.03);
-  const int cur_step = cur_img.pitch;
   for (int iter = 0; iter < n_iter; ++iter) {
-    const int u_r = (int)floorf(u);
-    const int v_r = (int)floorf(v);
-    if (u_r < halfpatch_size_ || v_r < halfpatch_size_ || u_r >= cur_img.w - halfpatch_size_ || v_r >= cur_img.h - halfpatch_size_)
-      break;
-    if (u != u || v != v) return false;
-    ++n_it;
-    const float subpix_x = u - u_r;
-    const float subpix_y = v - v_r;
-    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
-    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
-    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
-    const float wBR = subpix_x * subpix_y;
-    float t[4][8];
-    {
-      const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + sub - halfpatch_size_) * cur_step + u_r - halfpatch_size_;
-      const unsigned char* rp = pwb + (sub + 1) * ref_step + 1;
-      unsigned top[9], bot[9];
-      load_row9_u8(it, top);
-      load_row9_u8(it + cur_step, bot);
-#pragma unroll
-      for (int x = 0; x < patch_size_; ++x, ++rp) {
-        const float ref_dx = (float)(0.5 * ((int)rp[1] - (int)rp[-1]));
-        const float ref_dy = (float)(0.5 * ((int)rp[ref_step] - (int)rp[-ref_step]));
-        const float search_pixel = wTL * top[x] + wTR * top[x + 1] + wBL * bot[x] + wBR * bot[x + 1];
-        const float res = search_pixel - alpha * rp[0] + mean_diff;
-        t[0][x] = res * ref_dx;
-        t[1][x] = res * ref_dy;
-        t[2][x] = affine_est_offset ? res : 0.0f;
-        t[3][x] = affine_est_gain ? (-1) * res * rp[0] : 0.0f;
-      }
-    }
-    float Jres[4] = { 0, 0, 0, 0 };
-    if (affine_est_gain) g8_chain_sub<4>(Jres, t, sub);
-    else {   // the fourth sum is a sum of zeros then (and reset below): hand three accumulators from row to row
-      float J3[3] = { 0, 0, 0 };
-      float t3[3][8];
-#pragma unroll
-      for (int a3 = 0; a3 < 3; ++a3)
-#pragma unroll
-        for (int x = 0; x < 8; ++x) t3[a3][x] = t[a3][x];
-      g8_chain_sub<3>(J3, t3, sub);
-      Jres[0] = J3[0]; Jres[1] = J3[1]; Jres[2] = J3[2];
-    }
-    if (!affine_est_offset) Jres[2] = 0.0f;
-    if (!affine_est_gain) Jres[3] = 0.0f;
-    float update[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      update[r] = ((Hinv[r * 4 + 0] * Jres[0] + Hinv[r * 4 + 1] * Jres[1]) + Hinv[r * 4 + 2] * Jres[2]) + Hinv[r * 4 + 3] * Jres[3];
-    u += update[0];
-    v += update[1];
-    mean_diff += update[2];
-    alpha += update[3];
-    if (update[0] * update[0] + update[1] * update[1] < min_update_squared) { converged = true; break; }
+    const int st = align_2d_gl_iter<8>(cur_img, pwb, affine_est_offset, affine_est_gain, Hinv, u, v, mean_diff, alpha, n_it, sub);
+    if (st == ALIGN_NAN) return false;
+    if (st == ALIGN_STOPPED) break;
+    if (st == ALIGN_CONVERGED) { converged = true; break; }
   }
   px = u;
   py = v;
   return converged;
+}
+
+// one pass of the loop body of align_1d (feature_alignment.cpp:103-204) by the L lanes of a unit
+template <int L>
+__device__ __forceinline__ int align_1d_gl_iter(const DevImage& cur_img, double dir0, double dir1, const unsigned char* pwb,
+                                                bool affine_est_offset, bool affine_est_gain, const float (&Hinv)[16], float& u,
+                                                float& v, float& mean_diff, float& alpha, int& n_it, int sub)
+{
+  constexpr int kHalfPatchSize = 4, kPatchSize = 8, ref_step = 10, R = 8 / L;
+  const float min_update_squared = (float)(0.03 * 0.03);
+  const int cur_step = cur_img.pitch;
+  const int u_r = (int)floorf(u);
+  const int v_r = (int)floorf(v);
+  if (u_r < kHalfPatchSize || v_r < kHalfPatchSize || u_r >= cur_img.w - kHalfPatchSize || v_r >= cur_img.h - kHalfPatchSize)
+    return ALIGN_STOPPED;
+  if (u != u || v != v) return ALIGN_NAN;
+  ++n_it;
+  const float subpix_x = u - u_r;
+  const float subpix_y = v - v_r;
+  const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
+  const float wTR = (float)(subpix_x * (1.0 - subpix_y));
+  const float wBL = (float)((1.0 - subpix_x) * subpix_y);
+  const float wBR = subpix_x * subpix_y;
+  float t[3][8 * R];
+  {
+    const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + sub * R - kHalfPatchSize) * cur_step + u_r - kHalfPatchSize;
+    unsigned rows[R + 1][9];
+#pragma unroll
+    for (int r = 0; r <= R; ++r) load_row9_u8(it + (ptrdiff_t)r * cur_step, rows[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const unsigned char* rp = pwb + (sub * R + r + 1) * ref_step + 1;
+#pragma unroll
+      for (int x = 0; x < kPatchSize; ++x, ++rp) {
+        const float gdx = (float)rp[1] - (float)rp[-1];
+        const float gdy = (float)rp[ref_step] - (float)rp[-ref_step];
+        const float ref_dv = (float)(0.5f * (dir0 * gdx + dir1 * gdy));
+        const float cur_intensity = wTL * rows[r][x] + wTR * rows[r][x + 1] + wBL * rows[r + 1][x] + wBR * rows[r + 1][x + 1];
+        const float res = cur_intensity - alpha * rp[0] + mean_diff;
+        t[0][r * 8 + x] = res * ref_dv;
+        t[1][r * 8 + x] = affine_est_offset ? res : 0.0f;
+        t[2][r * 8 + x] = affine_est_gain ? (-1) * res * rp[0] : 0.0f;
+      }
+    }
+  }
+  float Jres[3] = { 0, 0, 0 };
+  if (affine_est_gain) gl_chain_sub<3, L>(Jres, t, sub);
+  else {
+    float J2[2] = { 0, 0 };
+    float t2[2][8 * R];
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+      for (int x = 0; x < 8 * R; ++x) t2[a2][x] = t[a2][x];
+    gl_chain_sub<2, L>(J2, t2, sub);
+    Jres[0] = J2[0]; Jres[1] = J2[1];
+  }
+  if (!affine_est_offset) Jres[1] = 0.0f;
+  if (!affine_est_gain) Jres[2] = 0.0f;
+  float update[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) update[r] = (Hinv[r * 3 + 0] * Jres[0] + Hinv[r * 3 + 1] * Jres[1]) + Hinv[r * 3 + 2] * Jres[2];
+  u = (float)(u + update[0] * dir0);
+  v = (float)(v + update[0] * dir1);
+  mean_diff += update[1];
+  alpha += update[2];
+  return (update[0] * update[0] < min_update_squared) ? ALIGN_CONVERGED : ALIGN_CONTINUE;
 }
 
 // align_1d (feature_alignment.cpp:31-209): the Jacobian entries are arbitrary floats here, H goes through the chain too
@@ -823,7 +908,7 @@ __device__ bool align_1d_g8(const DevImage& cur_img, double dir0, double dir1, c
                             bool affine_est_offset, bool affine_est_gain, double& px, double& py, double* h_inv,
                             int& n_it, int sub)
 {
-  constexpr int kHalfPatchSize = 4, kPatchSize = 8, ref_step = 10;
+  constexpr int kPatchSize = 8, ref_step = 10;
   bool converged = false;
   float H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   {
@@ -842,77 +927,96 @@ __device__ bool align_1d_g8(const DevImage& cur_img, double dir0, double dir1, c
 #pragma unroll
         for (int c = 0; c < 3; ++c) t[r * 3 + c][x] = -(J[r] * J[c]);   // H += J J^T as H -= (-J J^T)
     }
-    g8_chain_sub<9>(H, t, sub);
+    gl_chain_sub<9, 8>(H, t, sub);
   }
   if (!affine_est_offset) H[4] = 1.0f;
   if (!affine_est_gain) H[8] = 1.0f;
   if (h_inv) *h_inv = 1.0 / H[0] * kPatchSize * kPatchSize;
-  float Hinv[9];
-  mat3f_inverse(H, Hinv);
+  float Hinv[16];
+  {
+    float Hi[9];
+    mat3f_inverse(H, Hi);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Hinv[k] = Hi[k];
+#pragma unroll
+    for (int k = 9; k < 16; ++k) Hinv[k] = 0.0f;
+  }
   float mean_diff = 0;
   float alpha = 1.0;
   float u = (float)px;
   float v = (float)py;
-  const float min_update_squared = (float)(0.03 * 0.03);
-  const int cur_step = cur_img.pitch;
   for (int iter = 0; iter < n_iter; ++iter) {
-    const int u_r = (int)floorf(u);
-    const int v_r = (int)floorf(v);
-    if (u_r < kHalfPatchSize || v_r < kHalfPatchSize || u_r >= cur_img.w - kHalfPatchSize || v_r >= cur_img.h - kHalfPatchSize)
-      break;
-    if (u != u || v != v) return false;
-    ++n_it;
-    const float subpix_x = u - u_r;
-    const float subpix_y = v - v_r;
-    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
-    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
-    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
-    const float wBR = subpix_x * subpix_y;
-    float t[3][8];
-    {
-      const uint8_t* it = cur_img.data + (ptrdiff_t)(v_r + sub - kHalfPatchSize) * cur_step + u_r - kHalfPatchSize;
-      const unsigned char* rp = pwb + (sub + 1) * ref_step + 1;
-      unsigned top[9], bot[9];
-      load_row9_u8(it, top);
-      load_row9_u8(it + cur_step, bot);
-#pragma unroll
-      for (int x = 0; x < kPatchSize; ++x, ++rp) {
-        const float gdx = (float)rp[1] - (float)rp[-1];
-        const float gdy = (float)rp[ref_step] - (float)rp[-ref_step];
-        const float ref_dv = (float)(0.5f * (dir0 * gdx + dir1 * gdy));
-        const float cur_intensity = wTL * top[x] + wTR * top[x + 1] + wBL * bot[x] + wBR * bot[x + 1];
-        const float res = cur_intensity - alpha * rp[0] + mean_diff;
-        t[0][x] = res * ref_dv;
-        t[1][x] = affine_est_offset ? res : 0.0f;
-        t[2][x] = affine_est_gain ? (-1) * res * rp[0] : 0.0f;
-      }
-    }
-    float Jres[3] = { 0, 0, 0 };
-    if (affine_est_gain) g8_chain_sub<3>(Jres, t, sub);
-    else {
-      float J2[2] = { 0, 0 };
-      float t2[2][8];
-#pragma unroll
-      for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-        for (int x = 0; x < 8; ++x) t2[a2][x] = t[a2][x];
-      g8_chain_sub<2>(J2, t2, sub);
-      Jres[0] = J2[0]; Jres[1] = J2[1];
-    }
-    if (!affine_est_offset) Jres[1] = 0.0f;
-    if (!affine_est_gain) Jres[2] = 0.0f;
-    float update[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) update[r] = (Hinv[r * 3 + 0] * Jres[0] + Hinv[r * 3 + 1] * Jres[1]) + Hinv[r * 3 + 2] * Jres[2];
-    u = (float)(u + update[0] * dir0);
-    v = (float)(v + update[0] * dir1);
-    mean_diff += update[1];
-    alpha += update[2];
-    if (update[0] * update[0] < min_update_squared) { converged = true; break; }
+    const int st = align_1d_gl_iter<8>(cur_img, dir0, dir1, pwb, affine_est_offset, affine_est_gain, Hinv, u, v, mean_diff, alpha, n_it, sub);
+    if (st == ALIGN_NAN) return false;
+    if (st == ALIGN_STOPPED) break;
+    if (st == ALIGN_CONVERGED) { converged = true; break; }
   }
   px = u;
   py = v;
   return converged;
+}
+
+// H^-1 of a refinement by ONE lane, for the jobs of the packed geometry (the part of align_2d / align_1d before the
+// iterations, feature_alignment.cpp:31-101 / 212-298).  H is symmetric and its entries are sums of commutative
+// products, so only the upper triangle is accumulated (each entry by the additions of the one-lane code, in its order)
+// and mirrored; with a constant Jacobian entry (1 for the offset, 0 for a parameter that is not estimated) the
+// products are the other factor or a zero, exactly.
+__device__ void refine_prepare_2d(const unsigned char* pwb, bool affine_est_offset, bool affine_est_gain, float (&Hinv)[16])
+{
+  constexpr int patch_size_ = 8, ref_step = 10;
+  float h00 = 0, h01 = 0, h11 = 0, h02 = 0, h12 = 0, h03 = 0, h13 = 0, h23 = 0, h33 = 0;
+  for (int y = 0; y < patch_size_; ++y) {
+    const unsigned char* p = pwb + (y + 1) * ref_step + 1;
+#pragma unroll
+    for (int x = 0; x < patch_size_; ++x, ++p) {
+      const float J0 = (float)(0.5 * ((int)p[1] - (int)p[-1]));
+      const float J1 = (float)(0.5 * ((int)p[ref_step] - (int)p[-ref_step]));
+      h00 += J0 * J0; h01 += J0 * J1; h11 += J1 * J1;
+      if (affine_est_offset) { h02 += J0; h12 += J1; }
+      if (affine_est_gain) {
+        const float J3 = (float)(-1.0 * p[0]);
+        h03 += J0 * J3; h13 += J1 * J3; h33 += J3 * J3;
+        if (affine_est_offset) h23 += J3;
+      }
+    }
+  }
+  const float h22 = affine_est_offset ? (float)(patch_size_ * patch_size_) : 1.0f;
+  if (!affine_est_gain) h33 = 1.0f;
+  const float H[16] = { h00, h01, h02, h03, h01, h11, h12, h13, h02, h12, h22, h23, h03, h13, h23, h33 };
+  mat4f_inverse(H, Hinv);
+}
+
+__device__ void refine_prepare_1d(double dir0, double dir1, const unsigned char* pwb, bool affine_est_offset, bool affine_est_gain,
+                                  float (&Hinv)[16], double& h_inv)
+{
+  constexpr int kPatchSize = 8, ref_step = 10;
+  float h00 = 0, h01 = 0, h02 = 0, h12 = 0, h22 = 0;
+  for (int y = 0; y < kPatchSize; ++y) {
+    const unsigned char* p = pwb + (y + 1) * ref_step + 1;
+#pragma unroll
+    for (int x = 0; x < kPatchSize; ++x, ++p) {
+      const float dx = (float)p[1] - (float)p[-1];
+      const float dy = (float)p[ref_step] - (float)p[-ref_step];
+      const float J0 = (float)(0.5f * (dir0 * dx + dir1 * dy));
+      h00 += J0 * J0;
+      if (affine_est_offset) h01 += J0;
+      if (affine_est_gain) {
+        const float J2 = -1.0f * p[0];
+        h02 += J0 * J2; h22 += J2 * J2;
+        if (affine_est_offset) h12 += J2;
+      }
+    }
+  }
+  const float h11 = affine_est_offset ? (float)(kPatchSize * kPatchSize) : 1.0f;
+  if (!affine_est_gain) h22 = 1.0f;
+  const float H[9] = { h00, h01, h02, h01, h11, h12, h02, h12, h22 };
+  h_inv = 1.0 / H[0] * kPatchSize * kPatchSize;
+  float Hi[9];
+  mat3f_inverse(H, Hi);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Hinv[k] = Hi[k];
+#pragma unroll
+  for (int k = 9; k < 16; ++k) Hinv[k] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -929,7 +1033,10 @@ __device__ bool align_1d_g8(const DevImage& cur_img, double dir0, double dir1, c
 //   F  one lane per seed again: triangulation, tau, filter update, outputs.
 // Every seed goes through exactly the arithmetic of the one-lane code (same expressions, same order): results are
 // bit-identical to the other two geometries (tests/test_klt_matcher_gpu.py runs all three).
-constexpr int kPkThreads = 256;
+#ifndef SVOH_PK_THREADS
+#define SVOH_PK_THREADS 256
+#endif
+constexpr int kPkThreads = SVOH_PK_THREADS;
 
 __device__ __forceinline__ unsigned udot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 
@@ -2023,46 +2130,93 @@ __global__ __launch_bounds__(256) void seed_unsort_kernel(const MatcherArgs a, c
 
 // DepthFilter::updateSeeds + depth_filter_utils::updateSeed, packed geometry (see "Packed geometry" above)
 // Phase E of the packed geometry: the sub-pixel refinements (align1D / align2D) of a 256-unit workgroup as jobs.  Units
-// that need one have left their slot in one of two LDS queues (s_q[0]: 2-D, s_q[1]: 1-D); every wave takes eight jobs of
-// ONE kind per round and runs them with eight lanes per job (the row-split code of the eight-lane geometry).
+// that need one have left their slot in one of two LDS queues (s_q[0]: 2-D, s_q[1]: 1-D) and H^-1 of their patch in
+// s_hm (refine_prepare_*, by the unit's own lane in phase A).  A wave is sixteen groups of kPkJobLanes = 4 lanes; a group
+// takes a job, runs its iterations (every lane two patch rows, order-dependent sums handed from lane to lane) and takes
+// the next one as soon as its own job ends -- no group waits for the slowest job of a round.  A wave works on ONE kind
+// at a time and moves to the other queue when its own is empty.
 // In: s_u / s_v start position, s_dir direction (1-D), s_stat (cur frame << 8) | search level, the slot's warped patch.
-// Out: s_u / s_v result, s_res (iterations << 8) | converged, s_hinv (1-D: h_inv; may be NULL).
+// Out: s_u / s_v result, s_res (iterations << 8) | converged.
+constexpr int kPkJobLanes = 4;
 __device__ __forceinline__ void packed_refine_phase(const MatcherArgs& a, int tid, const unsigned char* s_pwb, int* s_res, const double* s_dir,
                                                     float* s_u, float* s_v, const int* s_stat, unsigned short (*s_q)[kPkThreads], int* s_qn,
-                                                    int* s_qh, double* s_hinv, bool est_offset, bool est_gain)
+                                                    int* s_qh, const float (*s_hm)[16], bool est_offset, bool est_gain)
 {
-  const int lane = tid & 63, sub = lane & 7;
-  int kind = (tid >> 6) & 1;          // waves start on different queues and move to the other one when theirs is empty
-  int tried = 0;
-  while (tried < 2) {
-    int slot = -1;
-    if (sub == 0) {
-      const int j = atomicAdd(&s_qh[kind], 1);
-      if (j < s_qn[kind]) slot = s_q[kind][j];
-    }
-    slot = __shfl(slot, 0, 8);
-    if (__ballot(slot >= 0) == 0) { kind ^= 1; ++tried; continue; }
-    if (slot >= 0) {
-      const int meta = s_stat[slot];
-      const DevImage img = a.cur_frame[meta >> 8].lv[meta & 255];
-      const unsigned char* pwb = s_pwb + slot * kPwbStride;
-      double sx = s_u[slot], sy = s_v[slot];
-      int n_it = 0;
-      bool aligned;
-      if (kind == 1) {
-        double h_inv = 0.0;
-        aligned = align_1d_g8(img, s_dir[2 * slot], s_dir[2 * slot + 1], pwb, a.mopt.align_max_iter, est_offset, est_gain, sx, sy,
-                              &h_inv, n_it, sub);
-        if (s_hinv && sub == 0) s_hinv[slot] = h_inv;
-      } else {
-        aligned = align_2d_g8(img, pwb, a.mopt.align_max_iter, est_offset, est_gain, sx, sy, n_it, sub);
+  constexpr int L = kPkJobLanes;
+  const int sub = tid & (L - 1);
+  const int max_iter = a.mopt.align_max_iter;
+  int kind = (tid >> 6) & 1;          // waves start on different queues
+  for (int tried = 0; tried < 2; ++tried, kind ^= 1) {
+    const int qn = s_qn[kind];
+    int slot = -1, iter = 0, n_it = 0;
+    bool dry = false;
+    float Hm[16], u = 0.0f, v = 0.0f, mean_diff = 0.0f, alpha = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Hm[k] = 0.0f;
+    double dir0 = 0.0, dir1 = 0.0;
+    DevImage img = { nullptr, 0, 0, 0, 0 };
+    const unsigned char* pwb = s_pwb;
+    // a group runs at most qn jobs of at most max_iter passes (plus one pass per job that takes it): the bound is never
+    // reached, it is the exit every wave has whatever the queue holds
+    const long long pass_bound = (long long)qn * ((max_iter > 0 ? max_iter : 0) + 1) + 1;
+    for (long long pass = 0; pass <= pass_bound; ++pass) {
+      if (slot < 0 && !dry) {
+        int s2 = -1;
+        if (sub == 0) {
+          const int j = atomicAdd(&s_qh[kind], 1);
+          if (j < qn) s2 = s_q[kind][j];
+        }
+        s2 = __shfl(s2, 0, L);
+        if (s2 >= 0) {
+          slot = s2; iter = 0; n_it = 0;
+          const int meta = s_stat[slot];
+          img = a.cur_frame[meta >> 8].lv[meta & 255];
+          pwb = s_pwb + slot * kPwbStride;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) Hm[k] = s_hm[slot][k];
+          u = s_u[slot]; v = s_v[slot];     // align1D / 2D start from the position narrowed to float
+          mean_diff = 0.0f; alpha = 1.0f;
+          if (kind == 1) { dir0 = s_dir[2 * slot]; dir1 = s_dir[2 * slot + 1]; }
+        } else dry = true;
       }
-      if (sub == 0) {
-        s_u[slot] = (float)sx; s_v[slot] = (float)sy;      // align1D / 2D hand back px = u, py = v (floats)
-        s_res[slot] = (n_it << 8) | (aligned ? 1 : 0);
+      if (__ballot(slot >= 0) == 0) break;
+      if (slot >= 0) {
+        int st = ALIGN_STOPPED;
+        if (iter < max_iter)
+          st = kind == 1 ? align_1d_gl_iter<L>(img, dir0, dir1, pwb, est_offset, est_gain, Hm, u, v, mean_diff, alpha, n_it, sub)
+                         : align_2d_gl_iter<L>(img, pwb, est_offset, est_gain, Hm, u, v, mean_diff, alpha, n_it, sub);
+        ++iter;
+        if (st != ALIGN_CONTINUE || iter >= max_iter) {
+          if (sub == 0) {
+            if (st != ALIGN_NAN) { s_u[slot] = u; s_v[slot] = v; }   // align1D / 2D hand back px = u, py = v (floats); not on NaN
+            s_res[slot] = (n_it << 8) | (st == ALIGN_CONVERGED ? 1 : 0);
+          }
+          slot = -1;
+        }
       }
     }
   }
+}
+
+// phase A's hand-over of a unit to phase E: H^-1 (by this lane), start position, direction, queue entry
+__device__ __forceinline__ double packed_refine_enqueue(int tid, bool align_1d, double dir0, double dir1, const unsigned char* pwb,
+                                                        double sx, double sy, bool est_offset, bool est_gain, float (*s_hm)[16],
+                                                        double* s_dir, float* s_u, float* s_v, unsigned short (*s_q)[kPkThreads],
+                                                        int* s_qn)
+{
+  float Hinv[16];
+  double h_inv = 0.0;
+  if (align_1d) refine_prepare_1d(dir0, dir1, pwb, est_offset, est_gain, Hinv, h_inv);
+  else refine_prepare_2d(pwb, est_offset, est_gain, Hinv);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s_hm[tid][k] = Hinv[k];
+  s_u[tid] = (float)sx;
+  s_v[tid] = (float)sy;
+  if (align_1d) { s_dir[2 * tid] = dir0; s_dir[2 * tid + 1] = dir1; }
+  const int kind = align_1d ? 1 : 0;
+  const int j = atomicAdd(&s_qn[kind], 1);
+  s_q[kind][j] = (unsigned short)tid;
+  return h_inv;
 }
 
 __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3))) void update_seeds_packed_kernel(
@@ -2074,6 +2228,7 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
   __shared__ float s_u[kPkThreads], s_v[kPkThreads];   // in: start of the refinement; out: its result
   __shared__ int s_stat[kPkThreads];             // (cur frame << 8) | search level of the slot
   __shared__ unsigned short s_q[2][kPkThreads];  // job queues: slots with a pending 2-D / 1-D refinement
+  __shared__ __attribute__((aligned(16))) float s_hm[kPkThreads][16];   // H^-1 of the slot's refinement
   __shared__ int s_qn[2], s_qh[2];
   const int tid = (int)threadIdx.x;
   if (tid < 2) { s_qn[tid] = 0; s_qh[tid] = 0; }
@@ -2115,7 +2270,8 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
   int search_level = 0;
   bool reject = false;
   int n_warp = 0, n_zmssd = 0;
-  double px_cur0 = 0.0, px_cur1 = 0.0;
+  double px_cur0 = 0.0, px_cur1 = 0.0, edir0 = 0.0, edir1 = 0.0;
+  bool is_1d = false;
   const bool indices_ok = live && (unsigned)ri < (unsigned)a.n_ref_frames && (unsigned)ci < (unsigned)a.n_cur_frames &&
                           level >= 0 && level < a.ref_frames[(unsigned)ri < (unsigned)a.n_ref_frames ? ri : 0].n_levels;
   if (indices_ok) {
@@ -2153,6 +2309,7 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
         m.A[0] = m.A[1] = m.A[2] = m.A[3] = 0.0;
         m.px_cur[0] = m.px_cur[1] = 0.0;
         m.f_cur = { 0.0, 0.0, 0.0 };
+        m.epi_dir[0] = m.epi_dir[1] = 0.0;
 #ifdef SVOH_SEED_STAMPS
         m.t[0] = m.t[1] = m.t[2] = m.t[3] = 0; m.tlast = clock64();
 #endif
@@ -2170,20 +2327,16 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
 #ifdef SVOH_PK_STAMPS
         tsA1 = clock64();
 #endif
-        if (code == kMatchRefinePending) {
-          // the refinement (feature_alignment.cpp:31-209 / 212-391) is phase E's job
-          s_u[tid] = (float)(m.px_cur[0] / (1 << m.search_level));
-          s_v[tid] = (float)(m.px_cur[1] / (1 << m.search_level));
-          if (m.align_1d) { s_dir[2 * tid] = m.epi_dir[0]; s_dir[2 * tid + 1] = m.epi_dir[1]; }
-          const int kind = m.align_1d ? 1 : 0;
-          const int j = atomicAdd(&s_qn[kind], 1);
-          s_q[kind][j] = (unsigned short)tid;
-        }
+        is_1d = m.align_1d; edir0 = m.epi_dir[0]; edir1 = m.epi_dir[1];
       }
     }
   }
-  // every lane leaves (cur frame, search level) of its slot where the job's lane finds them
+  // every lane leaves (cur frame, search level) of its slot where the lanes of a refinement job find them
   s_stat[tid] = (ci << 8) | search_level;
+  // the refinement (feature_alignment.cpp:31-209 / 212-391) is phase E's job
+  if (code == kMatchRefinePending)
+    packed_refine_enqueue(tid, is_1d, edir0, edir1, s_pwb + tid * kPwbStride, px_cur0 / (1 << search_level),
+                          px_cur1 / (1 << search_level), est_offset, est_gain, s_hm, s_dir, s_u, s_v, s_q, s_qn);
 #ifdef SVOH_PK_STAMPS
   tsA2 = clock64();
 #endif
@@ -2192,8 +2345,8 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
   tsE0 = tsE1 = clock64();
 #endif
 
-  // ---- phase E: the refinements, eight lanes per job, eight jobs of one kind per wave and round ----
-  packed_refine_phase(a, tid, s_pwb, s_res, s_dir, s_u, s_v, s_stat, s_q, s_qn, s_qh, nullptr, est_offset, est_gain);
+  // ---- phase E: the refinements as jobs of four-lane groups (packed_refine_phase) ----
+  packed_refine_phase(a, tid, s_pwb, s_res, s_dir, s_u, s_v, s_stat, s_q, s_qn, s_qh, s_hm, est_offset, est_gain);
 #ifdef SVOH_PK_STAMPS
   tsE1 = clock64();
 #endif
@@ -2351,15 +2504,15 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
   __shared__ __attribute__((aligned(16))) unsigned char s_pwb[kPkThreads * kPwbStride + 16];
   __shared__ int s_res[kPkThreads];
   __shared__ double s_dir[2 * kPkThreads];
-  __shared__ double s_hinv[kPkThreads];
   __shared__ float s_u[kPkThreads], s_v[kPkThreads];
   __shared__ int s_stat[kPkThreads];
   __shared__ unsigned short s_q[2][kPkThreads];
+  __shared__ __attribute__((aligned(16))) float s_hm[kPkThreads][16];
   __shared__ int s_qn[2], s_qh[2];
   const int tid = (int)threadIdx.x;
   if (tid < 2) { s_qn[tid] = 0; s_qh[tid] = 0; }
-  s_hinv[tid] = 0.0;
   __syncthreads();
+  double h_inv_1d = 0.0, edir0 = 0.0, edir1 = 0.0;
   const int i = (int)blockIdx.x * kPkThreads + tid;
   const bool live = i < a.n;
   const bool est_offset = a.mopt.affine_est_offset != 0, est_gain = a.mopt.affine_est_gain != 0;
@@ -2386,6 +2539,7 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
     m.A[0] = m.A[1] = m.A[2] = m.A[3] = 0.0;
     m.px_cur[0] = m.px_cur[1] = 0.0;
     m.f_cur = { 0.0, 0.0, 0.0 };
+    m.epi_dir[0] = m.epi_dir[1] = 0.0;
 #ifdef SVOH_SEED_STAMPS
     m.t[0] = m.t[1] = m.t[2] = m.t[3] = 0; m.tlast = clock64();
 #endif
@@ -2427,17 +2581,14 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
     search_level = m.search_level;
     n_warp = m.n_warp; n_zmssd = m.n_zmssd;
     for (int k = 0; k < 4; ++k) A4[k] = m.A[k];
-    if (code == kMatchRefinePending) {
-      s_u[tid] = (float)sx0; s_v[tid] = (float)sy0;
-      if (m.align_1d) { s_dir[2 * tid] = m.epi_dir[0]; s_dir[2 * tid + 1] = m.epi_dir[1]; }
-      const int kind = m.align_1d ? 1 : 0;
-      const int j = atomicAdd(&s_qn[kind], 1);
-      s_q[kind][j] = (unsigned short)tid;
-    }
+    edir0 = m.epi_dir[0]; edir1 = m.epi_dir[1];
   }
   s_stat[tid] = (ci << 8) | search_level;
+  if (code == kMatchRefinePending)
+    h_inv_1d = packed_refine_enqueue(tid, is_1d, edir0, edir1, s_pwb + tid * kPwbStride, sx0, sy0, est_offset, est_gain, s_hm, s_dir,
+                                     s_u, s_v, s_q, s_qn);
   __syncthreads();
-  packed_refine_phase(a, tid, s_pwb, s_res, s_dir, s_u, s_v, s_stat, s_q, s_qn, s_qh, s_hinv, est_offset, est_gain);
+  packed_refine_phase(a, tid, s_pwb, s_res, s_dir, s_u, s_v, s_stat, s_q, s_qn, s_qh, s_hm, est_offset, est_gain);
   __syncthreads();
   if (!live) return;
   if (!ok_idx) {
@@ -2495,7 +2646,7 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
   }
   if (a.f_cur) { a.f_cur[3 * i] = f_cur.x; a.f_cur[3 * i + 1] = f_cur.y; a.f_cur[3 * i + 2] = f_cur.z; }
   if (a.search_level) a.search_level[i] = search_level;
-  if (a.h_inv) a.h_inv[i] = (code == kMatchRefinePending && is_1d) ? s_hinv[tid] : 0.0;
+  if (a.h_inv) a.h_inv[i] = (code == kMatchRefinePending && is_1d) ? h_inv_1d : 0.0;
   if (a.A_cur_ref) for (int k = 0; k < 4; ++k) a.A_cur_ref[4 * i + k] = A4[k];
   reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4((unsigned)n_warp, (unsigned)n_zmssd, (unsigned)n_align_it,
                                                            (!DIRECT && res == SVOH_MATCH_SUCCESS) ? 1u : 0u);
