@@ -473,6 +473,18 @@ int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options,
                             const double* depth, double* px_cur, int32_t* result,
                             double* f_cur, int32_t* search_level, double* h_inv, double* A_cur_ref);
 
+/* The same with Matcher::Options::use_affine_warp_ == false (src/svo_direct/include/svo/direct/matcher.h:50,
+ * matcher.cpp:67-81): the reference patch comes from warp::warpPixelwise (src/svo_direct/src/patch_warp.cpp:158-230),
+ * which needs the landmark's position: landmark_xyz = 3 x n, world frame (ref_ftr.landmark->pos()), in the memory
+ * space of the batch.  A_cur_ref and search_level are those of the affine warp, as in the reference.  Nothing in the
+ * reference clears the flag; the branch is built for completeness and runs one lane per feature at every batch size.
+ * Not allowed inside a deferred section. */
+int svoh_match_direct_batch_pixelwise(svoh_ctx* ctx, const svoh_matcher_options* options, int n_ref_frames,
+                                      const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
+                                      const svoh_feature_batch* features, const double* depth, const double* landmark_xyz,
+                                      double* px_cur, int32_t* result, double* f_cur, int32_t* search_level, double* h_inv,
+                                      double* A_cur_ref);
+
 /* Deferred section: between begin and collect, ONE svoh_match_direct_batch and ONE svoh_update_seeds_batch(_ex)
  * with host arrays are queued on the context's stream without a synchronisation; collect waits once and copies
  * every result to the caller's arrays (which must stay valid until then).  This is how one reprojection

@@ -239,6 +239,10 @@ def _bind_part2(lib):
                                            P(capi.svoh_feature_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_match_direct_batch.restype = None
+    lib.orc_match_direct_batch_ex.argtypes = [P(capi.svoh_matcher_options), C.c_int, P(orc_frame_view), P(orc_frame_view),
+                                              P(capi.svoh_feature_batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_match_direct_batch_ex.restype = None
     lib.orc_update_seeds_batch.argtypes = [P(capi.svoh_matcher_options), P(capi.svoh_depth_filter_options), C.c_int,
                                            P(orc_frame_view), P(orc_frame_view), P(capi.svoh_feature_batch),
                                            C.c_void_p, C.c_void_p, C.c_void_p]
@@ -301,18 +305,34 @@ def make_feature_batch(ref_frame_idx, px, f, grad, level, ftype):
     return fb, arrs
 
 
-def match_direct_batch(mopt, ref_views, cur_view, fb, depth, px_cur, fast=False):
+def match_direct_batch(mopt, ref_views, cur_view, fb, depth, px_cur, fast=False, landmark_xyz=None):
+    """landmark_xyz (n x 3, world): Matcher::Options::use_affine_warp_ == false (warpPixelwise)."""
     lib = load(fast)
     _bind_part2(lib)
     n = fb.n
     rv = (orc_frame_view * len(ref_views))(*ref_views)
     depth = np.ascontiguousarray(depth, np.float64)
+    lm = None if landmark_xyz is None else np.ascontiguousarray(landmark_xyz, np.float64)
     out = dict(px_cur=np.ascontiguousarray(px_cur, np.float64).copy(), result=np.zeros(n, np.int32),
                f_cur=np.zeros(3 * n), search_level=np.zeros(n, np.int32), h_inv=np.zeros(n), A=np.zeros(4 * n))
-    lib.orc_match_direct_batch(C.byref(mopt), len(ref_views), rv, C.byref(cur_view), C.byref(fb), depth.ctypes.data,
-                               out["px_cur"].ctypes.data, out["result"].ctypes.data, out["f_cur"].ctypes.data,
-                               out["search_level"].ctypes.data, out["h_inv"].ctypes.data, out["A"].ctypes.data)
+    lib.orc_match_direct_batch_ex(C.byref(mopt), len(ref_views), rv, C.byref(cur_view), C.byref(fb), depth.ctypes.data,
+                                  lm.ctypes.data if lm is not None else None,
+                                  out["px_cur"].ctypes.data, out["result"].ctypes.data, out["f_cur"].ctypes.data,
+                                  out["search_level"].ctypes.data, out["h_inv"].ctypes.data, out["A"].ctypes.data)
     return out
+
+
+def warp_pixelwise(cur_view, ref_view, px_ref, landmark_xyz, level_ref, level_cur, halfpatch=5, fast=False):
+    """warp::warpPixelwise (patch_warp.cpp:158-230): the (2 halfpatch)^2 patch, or None where the reference returns false."""
+    lib = load(fast)
+    lib.orc_warp_pixelwise.argtypes = [C.POINTER(orc_frame_view), C.POINTER(orc_frame_view), C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p]
+    lib.orc_warp_pixelwise.restype = C.c_int
+    px = np.ascontiguousarray(px_ref, np.float64); lm = np.ascontiguousarray(landmark_xyz, np.float64)
+    out = np.zeros((2 * halfpatch, 2 * halfpatch), np.uint8)
+    ok = lib.orc_warp_pixelwise(C.byref(cur_view), C.byref(ref_view), px.ctypes.data, lm.ctypes.data, level_ref, level_cur,
+                                halfpatch, out.ctypes.data)
+    return out if ok else None
 
 
 def epipolar_match_batch(mopt, ref_views, cur_views, fb, d_inv_common=None, d_inv=None, T_cur_ref=None, fast=False):

@@ -126,6 +126,59 @@ int orc_warp_affine(const double A_cur_ref[4], const orc_image* img_ref, const d
   return 1;
 }
 
+/* patch_warp.cpp:158-230 warpPixelwise: every pixel of the patch (at the search level of the current frame) is
+ * back-projected at the landmark's distance from the current camera, carried into the reference frame and sampled
+ * there.  landmark_xyz = ref_ftr.landmark->pos() (world). */
+int orc_warp_pixelwise(const orc_frame_view* cur_frame, const orc_frame_view* ref_frame, const double px_ref[2],
+                       const double landmark_xyz[3], int level_ref, int level_cur, int halfpatch_size, uint8_t* patch)
+{
+  svoh_se3 T_w_ref, T_w_cur, T_cur_ref, T_ref_cur;
+  orc_se3_inverse(&ref_frame->T_f_w, &T_w_ref);   /* Frame::pos() = T_world_cam().getPosition() (frame.h:261,306) */
+  orc_se3_inverse(&cur_frame->T_f_w, &T_w_cur);
+  const double dr[3] = { T_w_ref.t[0] - landmark_xyz[0], T_w_ref.t[1] - landmark_xyz[1], T_w_ref.t[2] - landmark_xyz[2] };
+  const double dc[3] = { T_w_cur.t[0] - landmark_xyz[0], T_w_cur.t[1] - landmark_xyz[1], T_w_cur.t[2] - landmark_xyz[2] };
+  const double depth_ref = sqrt(dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]);
+  const double depth_cur = sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]);
+  double xyz_ref[3];
+  orc_back_project3(&ref_frame->cam, px_ref, xyz_ref);
+  normalize3(xyz_ref);
+  xyz_ref[0] *= depth_ref; xyz_ref[1] *= depth_ref; xyz_ref[2] *= depth_ref;
+  orc_se3_mul(&cur_frame->T_f_w, &T_w_ref, &T_cur_ref);
+  double xyz_cur[3], px_cur[2];
+  orc_se3_transform(&T_cur_ref, xyz_ref, xyz_cur);
+  orc_project3(&cur_frame->cam, xyz_cur, px_cur, NULL);
+  const double pcs[2] = { px_cur[0] / (1 << level_cur), px_cur[1] / (1 << level_cur) };
+  orc_se3_mul(&ref_frame->T_f_w, &T_w_cur, &T_ref_cur);
+  const orc_image* img_ref = &ref_frame->pyr.level[level_ref];
+  const int stride = img_ref->pitch;
+  uint8_t* patch_ptr = patch;
+  for (int y = -halfpatch_size; y < halfpatch_size; ++y) {
+    for (int x = -halfpatch_size; x < halfpatch_size; ++x, ++patch_ptr) {
+      const double ele_search[2] = { (double)x + pcs[0], (double)y + pcs[1] };
+      const double ele_px[2] = { ele_search[0] * (1 << level_cur), ele_search[1] * (1 << level_cur) };
+      double e_cur[3], e_ref[3], ele_ref[2];
+      orc_back_project3(&cur_frame->cam, ele_px, e_cur);
+      normalize3(e_cur);
+      e_cur[0] *= depth_cur; e_cur[1] *= depth_cur; e_cur[2] *= depth_cur;
+      orc_se3_transform(&T_ref_cur, e_cur, e_ref);
+      orc_project3(&ref_frame->cam, e_ref, ele_ref, NULL);
+      ele_ref[0] = ele_ref[0] / (1 << level_ref); ele_ref[1] = ele_ref[1] / (1 << level_ref);
+      const int xi = (int)floor(ele_ref[0]);
+      const int yi = (int)floor(ele_ref[1]);
+      if (xi < 0 || yi < 0 || xi + 1 >= img_ref->width || yi + 1 >= img_ref->height) return 0;
+      const float subpix_x = (float)(ele_ref[0] - xi);
+      const float subpix_y = (float)(ele_ref[1] - yi);
+      const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+      const float w01 = (1.0f - subpix_x) * subpix_y;
+      const float w10 = subpix_x * (1.0f - subpix_y);
+      const float w11 = 1.0f - w00 - w01 - w10;
+      const uint8_t* ptr = img_ref->data + (ptrdiff_t)yi * stride + xi;
+      *patch_ptr = (uint8_t)(w00 * ptr[0] + w01 * ptr[stride] + w10 * ptr[1] + w11 * ptr[stride + 1]);
+    }
+  }
+  return 1;
+}
+
 /* patch_utils.h:18-30 */
 static void create_patch_from_patch_with_border(const uint8_t* pwb, int patch_size, uint8_t* patch)
 {
@@ -443,9 +496,20 @@ static void T_cur_ref_from_frames(const orc_frame_view* ref, const orc_frame_vie
 }
 
 /* matcher.cpp:31-141 */
+int orc_find_match_direct_lm(orc_matcher* m, const orc_frame_view* ref_frame, const orc_frame_view* cur_frame,
+                             const double px_ref[2], const double f_ref[3], const double grad_ref[2], int level,
+                             int type, double ref_depth, const double* landmark_xyz, double px_cur[2]);
 int orc_find_match_direct(orc_matcher* m, const orc_frame_view* ref_frame, const orc_frame_view* cur_frame,
                           const double px_ref[2], const double f_ref[3], const double grad_ref[2], int level,
                           int type, double ref_depth, double px_cur[2])
+{
+  return orc_find_match_direct_lm(m, ref_frame, cur_frame, px_ref, f_ref, grad_ref, level, type, ref_depth, NULL, px_cur);
+}
+
+/* landmark_xyz != NULL: Matcher::Options::use_affine_warp_ == false (matcher.cpp:67-81), the patch by warpPixelwise */
+int orc_find_match_direct_lm(orc_matcher* m, const orc_frame_view* ref_frame, const orc_frame_view* cur_frame,
+                             const double px_ref[2], const double f_ref[3], const double grad_ref[2], int level,
+                             int type, double ref_depth, const double* landmark_xyz, double px_cur[2])
 {
   enum { kHalfPatchSize = 4, kPatchSize = 8 };
   const int pxi0 = (int)px_ref[0] / (1 << level), pxi1 = (int)px_ref[1] / (1 << level);
@@ -457,8 +521,12 @@ int orc_find_match_direct(orc_matcher* m, const orc_frame_view* ref_frame, const
   T_cur_ref_from_frames(ref_frame, cur_frame, &T_cur_ref);
   orc_get_warp_matrix_affine(&ref_frame->cam, &cur_frame->cam, px_ref, f_ref, ref_depth, &T_cur_ref, level, m->A_cur_ref);
   m->search_level = orc_get_best_search_level(m->A_cur_ref, ref_frame->pyr.n_levels - 1);
-  if (!orc_warp_affine(m->A_cur_ref, &ref_frame->pyr.level[level], px_ref, level, m->search_level, kHalfPatchSize + 1,
-                       m->patch_with_border))
+  if (landmark_xyz) {
+    if (!orc_warp_pixelwise(cur_frame, ref_frame, px_ref, landmark_xyz, level, m->search_level, kHalfPatchSize + 1,
+                            m->patch_with_border))
+      return SVOH_MATCH_FAIL_WARP;
+  } else if (!orc_warp_affine(m->A_cur_ref, &ref_frame->pyr.level[level], px_ref, level, m->search_level, kHalfPatchSize + 1,
+                              m->patch_with_border))
     return SVOH_MATCH_FAIL_WARP;
   create_patch_from_patch_with_border(m->patch_with_border, kPatchSize, m->patch);
   double px_scaled[2] = { px_cur[0] / (1 << m->search_level), px_cur[1] / (1 << m->search_level) };
@@ -838,6 +906,16 @@ void orc_match_direct_batch(const svoh_matcher_options* options, int n_ref_frame
                             double* px_cur, int32_t* result, double* f_cur, int32_t* search_level, double* h_inv,
                             double* A_cur_ref)
 {
+  orc_match_direct_batch_ex(options, n_ref_frames, ref_frames, cur_frame, fb, depth, NULL, px_cur, result, f_cur, search_level,
+                            h_inv, A_cur_ref);
+}
+
+/* landmark_xyz (3 x n, world) != NULL: use_affine_warp_ == false */
+void orc_match_direct_batch_ex(const svoh_matcher_options* options, int n_ref_frames, const orc_frame_view* ref_frames,
+                               const orc_frame_view* cur_frame, const orc_feature_batch* fb, const double* depth,
+                               const double* landmark_xyz, double* px_cur, int32_t* result, double* f_cur,
+                               int32_t* search_level, double* h_inv, double* A_cur_ref)
+{
   (void)n_ref_frames;
   for (int i = 0; i < fb->n; ++i) {
     orc_matcher m;
@@ -845,8 +923,9 @@ void orc_match_direct_batch(const svoh_matcher_options* options, int n_ref_frame
     m.opt = *options;
     double p[2] = { px_cur[2 * i], px_cur[2 * i + 1] };
     const orc_frame_view* cf = fb->cur_frame_idx ? &cur_frame[fb->cur_frame_idx[i]] : cur_frame;
-    const int r = orc_find_match_direct(&m, &ref_frames[fb->ref_frame_idx[i]], cf, &fb->px[2 * i], &fb->f[3 * i],
-                                        &fb->grad[2 * i], fb->level[i], fb->type[i], depth[i], p);
+    const int r = orc_find_match_direct_lm(&m, &ref_frames[fb->ref_frame_idx[i]], cf, &fb->px[2 * i], &fb->f[3 * i],
+                                           &fb->grad[2 * i], fb->level[i], fb->type[i], depth[i],
+                                           landmark_xyz ? &landmark_xyz[3 * i] : NULL, p);
     result[i] = r;
     px_cur[2 * i] = p[0]; px_cur[2 * i + 1] = p[1];
     if (f_cur) { f_cur[3 * i] = m.f_cur[0]; f_cur[3 * i + 1] = m.f_cur[1]; f_cur[3 * i + 2] = m.f_cur[2]; }

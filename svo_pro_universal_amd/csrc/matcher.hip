@@ -56,6 +56,7 @@ struct MatcherArgs {
   uint8_t* type;
   // direct
   const double* depth;
+  const double* landmark_xyz;  // 3 per feature (world) = the pixelwise warp (one lane per unit), or NULL = the affine warp
   double* px_cur;
   int32_t* result;
   double* f_cur;
@@ -229,6 +230,55 @@ __device__ bool warp_affine(const double A_cur_ref[4], const DevImage& img_ref, 
 }
 
 // patch_score.h:264-283 with the constructor's sums (patch_score.h:80-92)
+// warp::warpPixelwise (patch_warp.cpp:158-230; Matcher::Options::use_affine_warp_ == false, matcher.cpp:67-81): every
+// pixel of the 10x10 patch (search level of the current frame) is back-projected to the landmark's distance from the
+// current camera, carried into the reference frame and sampled in the reference level.  One lane per unit: nothing in
+// the reference clears the flag, the branch exists for completeness (svoh_match_direct_batch_pixelwise).
+__device__ bool warp_pixelwise(const DevFrameView& cur_frame, const DevFrameView& ref_frame, double pxr, double pyr,
+                               const Vec3& landmark, int level_ref, int level_cur, unsigned char* patch)
+{
+  constexpr int halfpatch_size = 5;
+  const Rigid T_w_ref = inverse(ref_frame.T_f_w), T_w_cur = inverse(cur_frame.T_f_w);   // Frame::pos() = T_world_cam().getPosition()
+  const double dr0 = T_w_ref.t.x - landmark.x, dr1 = T_w_ref.t.y - landmark.y, dr2 = T_w_ref.t.z - landmark.z;
+  const double dc0 = T_w_cur.t.x - landmark.x, dc1 = T_w_cur.t.y - landmark.y, dc2 = T_w_cur.t.z - landmark.z;
+  const double depth_ref = sqrt(dr0 * dr0 + dr1 * dr1 + dr2 * dr2);
+  const double depth_cur = sqrt(dc0 * dc0 + dc1 * dc1 + dc2 * dc2);
+  Vec3 xyz_ref = back_project3(ref_frame.cam, pxr, pyr);
+  normalize3(xyz_ref);
+  xyz_ref.x *= depth_ref; xyz_ref.y *= depth_ref; xyz_ref.z *= depth_ref;
+  const Rigid T_cur_ref = mul(cur_frame.T_f_w, T_w_ref);
+  double pcx, pcy;
+  project3(cur_frame.cam, transform(T_cur_ref, xyz_ref), pcx, pcy);
+  const double pcs0 = pcx / (1 << level_cur), pcs1 = pcy / (1 << level_cur);
+  const Rigid T_ref_cur = mul(ref_frame.T_f_w, T_w_cur);
+  const DevImage& img_ref = ref_frame.lv[level_ref];
+  const int stride = img_ref.pitch;
+  for (int y = -halfpatch_size; y < halfpatch_size; ++y) {
+    for (int x = -halfpatch_size; x < halfpatch_size; ++x) {
+      const double es0 = (double)x + pcs0, es1 = (double)y + pcs1;
+      Vec3 e_cur = back_project3(cur_frame.cam, es0 * (1 << level_cur), es1 * (1 << level_cur));
+      normalize3(e_cur);
+      e_cur.x *= depth_cur; e_cur.y *= depth_cur; e_cur.z *= depth_cur;
+      double er0, er1;
+      project3(ref_frame.cam, transform(T_ref_cur, e_cur), er0, er1);
+      er0 = er0 / (1 << level_ref); er1 = er1 / (1 << level_ref);
+      const int xi = (int)floor(er0);
+      const int yi = (int)floor(er1);
+      if (!(er0 == er0) || !(er1 == er1) || xi < 0 || yi < 0 || xi + 1 >= img_ref.w || yi + 1 >= img_ref.h) return false;
+      const float subpix_x = (float)(er0 - xi);
+      const float subpix_y = (float)(er1 - yi);
+      const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+      const float w01 = (1.0f - subpix_x) * subpix_y;
+      const float w10 = subpix_x * (1.0f - subpix_y);
+      const float w11 = 1.0f - w00 - w01 - w10;
+      const uint8_t* ptr = img_ref.data + (ptrdiff_t)yi * stride + xi;
+      patch[(y + halfpatch_size) * 10 + (x + halfpatch_size)] =
+          (unsigned char)(w00 * ptr[0] + w01 * ptr[stride] + w10 * ptr[1] + w11 * ptr[stride + 1]);
+    }
+  }
+  return true;
+}
+
 __device__ int zmssd_score(const unsigned char* pwb, int sumA, int sumAA, const uint8_t* cur_patch, int stride)
 {
   unsigned sumB = 0, sumBB = 0, sumAB = 0;
@@ -1141,7 +1191,8 @@ __device__ __forceinline__ Rigid T_cur_ref_of(const DevFrameView& ref, const Dev
 template <bool G8 = false>
 __device__ int find_match_direct(MatcherState& m, const svoh_matcher_options& opt, const DevFrameView& ref_frame,
                                  const DevFrameView& cur_frame, double pxr, double pyr, const Vec3& f_ref, double gx,
-                                 double gy, int level, int type, double ref_depth, double& pcx, double& pcy)
+                                 double gy, int level, int type, double ref_depth, double& pcx, double& pcy,
+                                 const double* landmark = nullptr /* one lane per unit only: the pixelwise warp */)
 {
   constexpr int kHalfPatchSize = 4, kPatchSize = 8;
   const int pxi0 = (int)pxr / (1 << level), pxi1 = (int)pyr / (1 << level);
@@ -1153,8 +1204,11 @@ __device__ int find_match_direct(MatcherState& m, const svoh_matcher_options& op
   get_warp_matrix_affine(ref_frame.cam, cur_frame.cam, pxr, pyr, f_ref, ref_depth, T_cur_ref, level, m.A);
   m.search_level = get_best_search_level(m.A, ref_frame.n_levels - 1);
   ++m.n_warp;
-  const bool warped = G8 ? warp_affine_g8(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb, m.sub)
-                         : warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
+  bool warped;
+  if constexpr (G8) warped = warp_affine_g8(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb, m.sub);
+  else if (landmark) warped = warp_pixelwise(cur_frame, ref_frame, pxr, pyr, Vec3{ landmark[0], landmark[1], landmark[2] }, level,
+                                             m.search_level, m.pwb);
+  else warped = warp_affine(m.A, ref_frame.lv[level], pxr, pyr, level, m.search_level, m.pwb);
   if (!warped) return SVOH_MATCH_FAIL_WARP;
   double sx = pcx / (1 << m.search_level), sy = pcy / (1 << m.search_level);
   const double sx0 = sx, sy0 = sy;
@@ -1878,7 +1932,8 @@ __device__ __forceinline__ void match_direct_body(const MatcherArgs& a, int bloc
   double pcx = a.px_cur[2 * i], pcy = a.px_cur[2 * i + 1];
   const DevFrameView& curf = a.cur_frame[a.cur_frame_idx ? a.cur_frame_idx[i] : 0];
   const int r = find_match_direct<G8>(m, a.mopt, ref, curf, a.px[2 * i], a.px[2 * i + 1], f, a.grad[2 * i],
-                                      a.grad[2 * i + 1], a.level[i], a.type[i], a.depth[i], pcx, pcy);
+                                      a.grad[2 * i + 1], a.level[i], a.type[i], a.depth[i], pcx, pcy,
+                                      (!G8 && a.landmark_xyz) ? &a.landmark_xyz[3 * i] : nullptr);
   if (G8 && m.sub != 0) return;   // the eight lanes hold the same results: one of them reports
   a.result[i] = r;
   a.px_cur[2 * i] = pcx; a.px_cur[2 * i + 1] = pcy;
@@ -2701,10 +2756,11 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
                        int n_ref_frames, const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
                        const svoh_feature_batch* fb, const double* depth, double* px_cur, int32_t* result, double* f_cur,
                        int32_t* search_level, double* h_inv, double* A_cur_ref, double* state, uint8_t* success,
-                       int32_t* n_success)
+                       int32_t* n_success, const double* landmark_xyz = nullptr)
 {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, mopt && ref_frames && cur_frame && fb && n_ref_frames >= 1, "NULL argument");
+  SVOH_REQUIRE(ctx, !landmark_xyz || (!seeds && !ctx->matcher_deferred), "the pixelwise warp: direct matches only, outside a deferred section");
   const int n = fb->n;
   if (n_success) *n_success = 0;
   if (n <= 0) return SVOH_OK;
@@ -2751,7 +2807,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   // and the kernel reads and writes the caller's arrays in place.
   Staging s;
   const size_t o_views = s.add(views.data(), sizeof(DevFrameView) * views.size());
-  size_t o_idx = 0, o_cidx = 0, o_px = 0, o_f = 0, o_grad = 0, o_level = 0, o_type = 0, o_depth = 0, o_pxcur = 0,
+  size_t o_idx = 0, o_cidx = 0, o_px = 0, o_f = 0, o_grad = 0, o_level = 0, o_type = 0, o_depth = 0, o_pxcur = 0, o_lm = 0,
          o_state = 0, o_result = 0, o_fcur = 0, o_slevel = 0, o_hinv = 0, o_A = 0, o_success = 0;
   if (!on_device) {
     o_idx = s.add(fb->ref_frame_idx, sizeof(int32_t) * n);
@@ -2763,6 +2819,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     o_type = s.add(fb->type, (size_t)n);
     if (seeds) o_state = s.add(state, sizeof(double) * 4 * n);
     else { o_depth = s.add(depth, sizeof(double) * n); o_pxcur = s.add(px_cur, sizeof(double) * 2 * n); }
+    if (landmark_xyz) o_lm = s.add(landmark_xyz, sizeof(double) * 3 * n);
   }
   const size_t in_total = s.total;
   // outputs (device only, appended)
@@ -2809,7 +2866,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     a.ref_frame_idx = fb->ref_frame_idx; a.cur_frame_idx = fb->cur_frame_idx;
     a.px = fb->px; a.f = fb->f; a.grad = fb->grad; a.level = fb->level; a.type = fb->type;
     a.result = result; a.f_cur = f_cur; a.search_level = search_level; a.h_inv = h_inv; a.A_cur_ref = A_cur_ref;
-    a.success = success; a.state = state; a.depth = depth; a.px_cur = px_cur;
+    a.success = success; a.state = state; a.depth = depth; a.px_cur = px_cur; a.landmark_xyz = landmark_xyz;
   } else {
     a.ref_frame_idx = reinterpret_cast<const int32_t*>(d + o_idx);
     a.cur_frame_idx = fb->cur_frame_idx ? reinterpret_cast<const int32_t*>(d + o_cidx) : nullptr;
@@ -2830,6 +2887,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     } else {
       a.depth = reinterpret_cast<const double*>(d + o_depth);
       a.px_cur = reinterpret_cast<double*>(d + o_pxcur);
+      a.landmark_xyz = landmark_xyz ? reinterpret_cast<const double*>(d + o_lm) : nullptr;
     }
   }
   // small batches: eight lanes per unit (a launch is as slow as its slowest lane, and eight lanes get a unit done
@@ -2840,6 +2898,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   g8 = SvohKnobs::or_default(ctx->knobs.matcher_g8, g8);
   if (g8 < 0 || g8 > 3) g8 = 0;
   if (g8 == 3 && (!seeds || defer)) g8 = 1;   // the direct matcher has no scan
+  if (landmark_xyz) g8 = 0;                    // the pixelwise warp exists with one lane per unit only
   if (defer && g8 != 2) {
     // Deferred section: the launch itself waits for svoh_matcher_collect, where a direct batch and a seed batch of
     // the same geometry go out as ONE kernel (match_mixed_kernel).  Remembered: the arguments, the copy of the
@@ -3394,6 +3453,18 @@ int svoh_match_direct_batch(svoh_ctx* ctx, const svoh_matcher_options* options, 
 try {
   return run_matcher(ctx, false, options, nullptr, n_ref_frames, ref_frames, cur_frame, features, depth, px_cur, result,
                      f_cur, search_level, h_inv, A_cur_ref, nullptr, nullptr, nullptr);
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_match_direct_batch_pixelwise(svoh_ctx* ctx, const svoh_matcher_options* options, int n_ref_frames,
+                                      const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
+                                      const svoh_feature_batch* features, const double* depth, const double* landmark_xyz,
+                                      double* px_cur, int32_t* result, double* f_cur, int32_t* search_level, double* h_inv,
+                                      double* A_cur_ref)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, landmark_xyz, "landmark_xyz is NULL (svoh_match_direct_batch is the affine warp)");
+  return run_matcher(ctx, false, options, nullptr, n_ref_frames, ref_frames, cur_frame, features, depth, px_cur, result,
+                     f_cur, search_level, h_inv, A_cur_ref, nullptr, nullptr, nullptr, landmark_xyz);
 } SVOH_ABI_CATCH(ctx)
 
 int svoh_update_seeds_batch(svoh_ctx* ctx, const svoh_matcher_options* matcher_options,

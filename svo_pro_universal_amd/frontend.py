@@ -281,12 +281,22 @@ def _klt_track_batch(self, opt, ref_frames, cur_frame, px_ref, px_cur):
     return out, status[:n]
 
 
-def _match_direct_batch(self, mopt, ref_views, cur_view, fb, depth, px_cur):
+def _match_direct_batch(self, mopt, ref_views, cur_view, fb, depth, px_cur, landmark_xyz=None):
+    """landmark_xyz (n x 3, world): the pixelwise warp (Matcher::Options::use_affine_warp_ == false)."""
     n = fb.n
     rv = (capi.svoh_frame_view * len(ref_views))(*ref_views)
     depth = np.ascontiguousarray(depth, np.float64)
     out = dict(px_cur=np.ascontiguousarray(px_cur, np.float64).copy(), result=np.zeros(n, np.int32),
                f_cur=np.zeros(3 * n), search_level=np.zeros(n, np.int32), h_inv=np.zeros(n), A=np.zeros(4 * n))
+    if landmark_xyz is not None:
+        lm = np.ascontiguousarray(landmark_xyz, np.float64)
+        assert lm.size == 3 * n
+        self._check(self.lib.svoh_match_direct_batch_pixelwise(self.h, C.byref(mopt), len(ref_views), rv, C.byref(cur_view),
+                                                               C.byref(fb), depth.ctypes.data, lm.ctypes.data,
+                                                               out["px_cur"].ctypes.data, out["result"].ctypes.data,
+                                                               out["f_cur"].ctypes.data, out["search_level"].ctypes.data,
+                                                               out["h_inv"].ctypes.data, out["A"].ctypes.data))
+        return out
     self._check(self.lib.svoh_match_direct_batch(self.h, C.byref(mopt), len(ref_views), rv, C.byref(cur_view),
                                                  C.byref(fb), depth.ctypes.data, out["px_cur"].ctypes.data,
                                                  out["result"].ctypes.data, out["f_cur"].ctypes.data,

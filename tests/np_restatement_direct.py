@@ -7,7 +7,7 @@ a line misread by the author of the C oracle and of the kernels does not pass un
 it.  tests/test_np_second_opinion_cpu.py compares the C oracle with this file on thousands of units.
 
 Restated:
-  warp::getWarpMatrixAffine / getBestSearchLevel / warpAffine      src/svo_direct/src/patch_warp.cpp:20-60, 97-156
+  warp::getWarpMatrixAffine / getBestSearchLevel / warpAffine / warpPixelwise   src/svo_direct/src/patch_warp.cpp:20-60, 97-230
   patch_utils::createPatchFromPatchWithBorder                      src/svo_direct/include/svo/direct/patch_utils.h:18-30
   patch_score::ZMSSD<4>                                            src/svo_direct/include/svo/direct/patch_score.h:44-285
   feature_alignment::align1D / align2D                             src/svo_direct/src/feature_alignment.cpp:31-391
@@ -284,6 +284,40 @@ def warp_affine(A_cur_ref, img_ref, px_ref, level_ref, search_level, halfpatch):
     return val.astype(np.uint8)                    # C's float -> uint8_t: truncation (values are in [0, 255])
 
 
+def warp_pixelwise(cur, ref, px_ref, landmark_pos, level_ref, level_cur, halfpatch):
+    """patch_warp.cpp:158-230: (2 halfpatch)^2 u8 patch or None.  The patch's pixels (search level of the current frame)
+    are back-projected to the landmark's distance from the current camera and sampled in the reference level; double
+    coordinates, float32 weights.  Frame::pos() = T_world_cam().getPosition() (frame.h:261, 306)."""
+    lm = np.asarray(landmark_pos, np.float64)
+    T_w_ref, T_w_cur = ref.T_f_w.inverse(), cur.T_f_w.inverse()
+    depth_ref = math.sqrt(float(np.sum((T_w_ref.t - lm) ** 2)))
+    depth_cur = math.sqrt(float(np.sum((T_w_cur.t - lm) ** 2)))
+    xyz_ref = normalized(ref.cam.back_project3(px_ref)) * depth_ref
+    xyz_cur = (cur.T_f_w * T_w_ref).apply(xyz_ref)
+    px_cur_search = cur.cam.project3(xyz_cur) / (1 << level_cur)
+    T_ref_cur = ref.T_f_w * T_w_cur
+    img_ref = ref.levels[level_ref]
+    rows, cols = img_ref.shape
+    out = np.zeros((2 * halfpatch, 2 * halfpatch), np.uint8)
+    one = f32(1.0)
+    for iy, y in enumerate(range(-halfpatch, halfpatch)):
+        for ix, x in enumerate(range(-halfpatch, halfpatch)):
+            ele_search = np.array([float(x), float(y)]) + px_cur_search
+            e_cur = normalized(cur.cam.back_project3(ele_search * (1 << level_cur))) * depth_cur
+            ele_ref = ref.cam.project3(T_ref_cur.apply(e_cur)) / (1 << level_ref)
+            xi, yi = int(math.floor(ele_ref[0])), int(math.floor(ele_ref[1]))
+            if xi < 0 or yi < 0 or xi + 1 >= cols or yi + 1 >= rows:
+                return None
+            sx, sy = f32(ele_ref[0] - xi), f32(ele_ref[1] - yi)
+            w00 = (one - sx) * (one - sy)
+            w01 = (one - sx) * sy
+            w10 = sx * (one - sy)
+            w11 = ((one - w00) - w01) - w10
+            val = ((w00 * f32(img_ref[yi, xi]) + w01 * f32(img_ref[yi + 1, xi])) + w10 * f32(img_ref[yi, xi + 1])) + w11 * f32(img_ref[yi + 1, xi + 1])
+            out[iy, ix] = np.uint8(int(val))          # truncation
+    return out
+
+
 def patch_from_patch_with_border(pwb, patch_size=K_PATCH):
     """patch_utils.h:18-30."""
     return np.ascontiguousarray(pwb[1:patch_size + 1, 1:patch_size + 1])
@@ -519,7 +553,9 @@ class Matcher(object):
         self.pwb = None; self.patch = None; self.epi_image = np.zeros(2); self.epi_length_pyramid = 0.0
 
     # -- matcher.cpp:31-141
-    def find_match_direct(self, ref, cur, px, f, grad, level, ftype, ref_depth, px_cur):
+    def find_match_direct(self, ref, cur, px, f, grad, level, ftype, ref_depth, px_cur, landmark_pos=None):
+        """landmark_pos given = options_.use_affine_warp_ false (matcher.cpp:67-81): the patch by warpPixelwise, with
+        the search level of the affine warp."""
         o = self.options
         pxi = (int(px[0]) // (1 << level), int(px[1]) // (1 << level))   # cast<int>() truncates; pixels are >= 0 here
         if px[0] < 0 or px[1] < 0:
@@ -531,7 +567,10 @@ class Matcher(object):
         T_cur_ref = cur.T_f_w * ref.T_f_w.inverse()
         self.A_cur_ref = get_warp_matrix_affine(ref.cam, cur.cam, px, f, ref_depth, T_cur_ref, level)
         self.search_level = get_best_search_level(self.A_cur_ref, len(ref.levels) - 1)
-        self.pwb = warp_affine(self.A_cur_ref, ref.levels[level], px, level, self.search_level, K_HALF_PATCH + 1)
+        if landmark_pos is None:
+            self.pwb = warp_affine(self.A_cur_ref, ref.levels[level], px, level, self.search_level, K_HALF_PATCH + 1)
+        else:
+            self.pwb = warp_pixelwise(cur, ref, px, landmark_pos, level, self.search_level, K_HALF_PATCH + 1)
         if self.pwb is None:
             return FAIL_WARP, px_cur
         self.patch = patch_from_patch_with_border(self.pwb)
@@ -855,8 +894,8 @@ def update_seeds(cur, refs, ref_idx, px, f, grad, level, ftype, state, mopt, see
     return dict(state=st.ravel(), type=types, success=success, match_result=mres, px_cur=pxc.ravel(), search_level=slv)
 
 
-def match_direct_batch(cur, refs, ref_idx, px, f, grad, level, ftype, depth, px_cur, mopt):
-    """n x Matcher::findMatchDirect."""
+def match_direct_batch(cur, refs, ref_idx, px, f, grad, level, ftype, depth, px_cur, mopt, landmark_xyz=None):
+    """n x Matcher::findMatchDirect (landmark_xyz, n x 3: with the pixelwise warp)."""
     n = len(level)
     out = dict(result=np.zeros(n, np.int32), px_cur=np.asarray(px_cur, np.float64).copy(), search_level=np.zeros(n, np.int32),
                f_cur=np.zeros(3 * n), h_inv=np.zeros(n), A=np.zeros(4 * n))
@@ -864,7 +903,8 @@ def match_direct_batch(cur, refs, ref_idx, px, f, grad, level, ftype, depth, px_
     for i in range(n):
         r, pc = m.find_match_direct(refs[ref_idx[i]], cur, np.asarray(px[2 * i:2 * i + 2], np.float64), np.asarray(f[3 * i:3 * i + 3], np.float64),
                                     np.asarray(grad[2 * i:2 * i + 2], np.float64), int(level[i]), int(ftype[i]), float(depth[i]),
-                                    out["px_cur"][2 * i:2 * i + 2].copy())
+                                    out["px_cur"][2 * i:2 * i + 2].copy(),
+                                    None if landmark_xyz is None else np.asarray(landmark_xyz, np.float64).reshape(-1, 3)[i])
         out["result"][i] = r
         out["px_cur"][2 * i:2 * i + 2] = pc
         if r not in (FAIL_VISIBILITY,):

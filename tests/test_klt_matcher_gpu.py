@@ -188,6 +188,45 @@ def test_match_direct_parity(gpu_ctx, oracle_lib, cam_kind):
         assert np.median(e) < 0.3
 
 
+@pytest.mark.parametrize("cam_kind", ["pinhole", "radtan"])
+def test_match_direct_pixelwise_warp_parity(gpu_ctx, oracle_lib, cam_kind):
+    """Matcher::Options::use_affine_warp_ == false: findMatchDirect with warp::warpPixelwise (matcher.cpp:67-81,
+    patch_warp.cpp:158-230) through svoh_match_direct_batch_pixelwise against the oracle: result codes and search
+    levels exact, matched pixels <= 1e-4 (the patch itself is exact or the codes and float32 positions would move)."""
+    orc = oracle_lib
+    cam = synth.Camera.test_camera() if cam_kind == "pinhole" else synth.Camera.euroc_like()
+    sc, ref, cur, fr, fc = scene_and_frames(gpu_ctx, orc, 67, cam)
+    sd = synth.make_seed_set(sc, 1500, margin=3, levels=(0, 1, 2, 3))
+    ov_r, ov_c, gv_r, gv_c = views(gpu_ctx, orc, sc, ref, cur, fr, fc, sd["mu_range"])
+    x = sd["f"].reshape(-1, 3).T * sd["true_depth"]
+    lm = np.ascontiguousarray(sc.T_w_ref.transform(x).T)
+    lm[::97] += 50.0          # landmarks far off their pixel: patches that leave the reference image (kFailWarp) or match nothing
+    px_true = sc.cam.project(sc.T_w_cur.inverse().transform(sc.T_w_ref.transform(x)))
+    px_init = np.ascontiguousarray((px_true + np.random.RandomState(3).uniform(-2.0, 2.0, px_true.shape)).T).ravel()
+    ftype = np.where(sd["type"] == 0, capi.FT_EDGELET, capi.FT_CORNER)
+    for mkw in (dict(), dict(affine_est_gain=1)):
+        mopt = capi.default_matcher_options(**mkw)
+        fbo, ko = orc.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+        fbg, kg = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+        oo = orc.match_direct_batch(mopt, [ov_r], ov_c, fbo, sd["true_depth"], px_init, landmark_xyz=lm)
+        og = gpu_ctx.match_direct_batch(mopt, [gv_r], gv_c, fbg, sd["true_depth"], px_init, landmark_xyz=lm)
+        assert np.array_equal(oo["result"], og["result"]), np.nonzero(oo["result"] != og["result"])[0][:10]
+        assert np.array_equal(oo["search_level"], og["search_level"])
+        assert np.abs(oo["px_cur"] - og["px_cur"]).max() <= 1e-4
+        ok = oo["result"] == 0
+        assert ok.sum() > 700 and len(set(oo["result"])) >= 3
+        assert np.allclose(oo["A"], og["A"], rtol=1e-12, atol=1e-14)
+        assert np.abs(oo["f_cur"] - og["f_cur"])[np.repeat(ok, 3)].max() < 1e-6
+        e = np.linalg.norm(og["px_cur"].reshape(-1, 2)[ok] - px_true.T[ok], axis=1)
+        assert np.median(e) < 0.3
+    # the affine entry is untouched by the new argument, and the pixelwise entry refuses a NULL landmark array
+    import ctypes as C
+    rv = (capi.svoh_frame_view * 1)(gv_r)
+    rc = gpu_ctx.lib.svoh_match_direct_batch_pixelwise(gpu_ctx.h, C.byref(mopt), 1, rv, C.byref(gv_c), C.byref(fbg), None, None,
+                                                       None, None, None, None, None, None)
+    assert rc != 0
+
+
 @pytest.mark.parametrize("n_features,cam_kind,sphere", [(120, "pinhole", 1), (3000, "radtan", 1), (3000, "pinhole", 0)])
 def test_epipolar_match_batch_parity_stereo_seam(gpu_ctx, oracle_lib, n_features, cam_kind, sphere):
     """Row *J (VERDICT r01): n x Matcher::findEpipolarMatchDirect(frame0, frame1, T_f1f0, ftr, mean / min / max inverse

@@ -100,6 +100,53 @@ def test_match_direct_oracle_vs_numpy_second_opinion(oracle_lib, cam_kind):
         assert np.allclose(oo["h_inv"][edge_ok], gg["h_inv"][edge_ok], rtol=1e-5)
 
 
+@pytest.mark.parametrize("cam_kind", ["pinhole", "radtan"])
+def test_pixelwise_warp_oracle_vs_numpy_second_opinion(oracle_lib, cam_kind):
+    """Matcher::Options::use_affine_warp_ == false (matcher.cpp:67-81, patch_warp.cpp:158-230): nothing in the reference
+    clears the flag, the branch is restated all the same.  Patches byte for byte, then the matches built on them."""
+    orc = oracle_lib
+    cam = synth.Camera.test_camera() if cam_kind == "pinhole" else synth.Camera.euroc_like()
+    sc = synth.make_align_scene(66, n_features=10, cam=cam, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))
+    n = 300
+    sd = synth.make_seed_set(sc, n, margin=3, levels=(0, 1, 2, 3))
+    rv, cv, nrv, ncv = _views(orc, sc, sd, cam_kind)
+    x = sd["f"].reshape(-1, 3).T * sd["true_depth"]
+    lm = np.ascontiguousarray(sc.T_w_ref.transform(x).T)                 # landmark positions (world), n x 3
+    px_true = sc.cam.project(sc.T_w_cur.inverse().transform(sc.T_w_ref.transform(x)))
+    px_init = np.ascontiguousarray((px_true + np.random.RandomState(2).uniform(-2.0, 2.0, px_true.shape)).T).ravel()
+    ftype = np.where(sd["type"] == 0, capi.FT_EDGELET, capi.FT_CORNER)
+    n_patch = n_none = n_px_diff = 0
+    for i in range(0, n, 3):
+        lvl = int(sd["level"][i])
+        for search_level in (lvl, min(lvl + 1, 4)):
+            po = orc.warp_pixelwise(cv, rv, sd["px"][2 * i:2 * i + 2], lm[i], lvl, search_level)
+            pn = nd.warp_pixelwise(ncv, nrv, sd["px"][2 * i:2 * i + 2], lm[i], lvl, search_level, 5)
+            assert (po is None) == (pn is None)
+            if po is None:
+                n_none += 1
+                continue
+            n_patch += 1
+            d = np.abs(po.astype(int) - pn.astype(int))
+            assert d.max() <= 1          # a weight on a truncation edge may differ in the last bit of a norm
+            n_px_diff += int((d != 0).sum())
+    assert n_patch > 100 and n_px_diff <= n_patch      # at most one pixel in a hundred patches ...  (observed: none)
+    mopt = capi.default_matcher_options()
+    fb, keep = orc.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+    oo = orc.match_direct_batch(mopt, [rv], cv, fb, sd["true_depth"], px_init, landmark_xyz=lm)
+    gg = nd.match_direct_batch(ncv, [nrv], sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype,
+                               sd["true_depth"], px_init, _nd_options(mopt), landmark_xyz=lm)
+    aff = orc.match_direct_batch(mopt, [rv], cv, fb, sd["true_depth"], px_init)
+    assert np.array_equal(oo["result"], gg["result"])
+    ok = oo["result"] == 0
+    assert ok.sum() > 0.5 * n
+    assert np.abs(oo["px_cur"] - gg["px_cur"]).max() <= 1e-4
+    # the two warps agree on what matches where (same plane-induced motion), not bit for bit
+    both = ok & (aff["result"] == 0)
+    assert both.sum() > 0.45 * n
+    dpx = np.abs(oo["px_cur"] - aff["px_cur"]).reshape(-1, 2)[both]
+    assert np.median(dpx) < 0.1 and (dpx > 0).any()
+
+
 @pytest.mark.parametrize("error_type", [capi.POSE_ERR_UNIT_PLANE, capi.POSE_ERR_BEARING_DIFF, capi.POSE_ERR_IMAGE_PLANE])
 @pytest.mark.parametrize("n_cams,prior", [(1, False), (2, True)])
 def test_pose_optimizer_oracle_vs_numpy_second_opinion(oracle_lib, error_type, n_cams, prior):
