@@ -8,6 +8,7 @@ import pytest
 
 from svo_pro_universal_amd import _capi as capi, synth
 import np_restatement_direct as nd
+import np_restatement_detector as ndet
 
 
 def _views(orc, sc, sd, cam_kind):
@@ -178,3 +179,54 @@ def test_pose_optimizer_oracle_vs_numpy_second_opinion(oracle_lib, error_type, n
         assert np.abs(T - Tg).max() <= 1e-9, np.abs(T - Tg).max()
         assert r.reproj_error_before == pytest.approx(g["err_before"], rel=1e-7)
         assert r.reproj_error_after == pytest.approx(g["err_after"], rel=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(640, 480), (327, 243)])
+def test_detector_oracle_vs_numpy_second_opinion(oracle_lib, shape):
+    """f-2: FAST-10 + score + 3x3 non-maximum suppression + grid, Scharr edgelets + angle histogram, fillFeatures -- the
+    oracle against the dense-array reading of tests/np_restatement_detector.py: positions, levels, types, scores exact,
+    directions exact (same libm on both sides here)."""
+    orc = oracle_lib
+    w, h = shape
+    cam = synth.Camera.euroc_like(w, h)
+    sc = synth.make_align_scene(150 + w, n_features=8, cam=cam)
+    levels = orc.create_img_pyramid(sc.img_ref, 5)
+    n_cells = int(np.ceil(w / 30)) * int(np.ceil(h / 30))
+    rng = np.random.RandomState(w)
+    n_total = n_edgelets = 0
+    for kw, occ, mask, max_n in (
+            (dict(), None, None, None),
+            (dict(threshold_secondary=25.0, threshold_primary=30.0), None, None, None),
+            (dict(detect_edgelets=0), (rng.uniform(size=n_cells) < 0.3).astype(np.uint8), None, None),
+            (dict(threshold_primary=20.0, threshold_secondary=60.0, border=5, max_level=3, min_level=1), None, None, None),
+            (dict(cell_size=17), None, (rng.uniform(size=(h, w)) < 0.7).astype(np.uint8) * 255, None)):
+        opt = capi.default_detector_options(**kw)
+        do = orc.detect_features(opt, levels, occ, mask, max_n)
+        dn = ndet.detect(levels, cell_size=opt.cell_size, max_level=opt.max_level, min_level=opt.min_level, border=opt.border,
+                         detect_edgelets=bool(opt.detect_edgelets), threshold_primary=opt.threshold_primary,
+                         threshold_secondary=opt.threshold_secondary, occupancy=occ, mask=mask, max_n_features=max_n)
+        assert len(do["score"]) > 10
+        n_edgelets += int((do["type"] == capi.FT_EDGELET).sum())
+        assert np.array_equal(do["type"], dn["type"])
+        assert np.array_equal(do["px"], dn["px"]) and np.array_equal(do["level"], dn["level"])
+        assert np.array_equal(do["score"], dn["score"])
+        assert np.abs(do["grad"] - dn["grad"]).max() < 1e-6
+        n_total += len(do["score"])
+    assert n_total > 300 and n_edgelets > 50
+    # the FAST pieces on their own: the score image against the oracle's per-corner calls, on a level with saturated pixels
+    img = levels[1].copy()
+    img[::7, ::5] = 255; img[3::11, 2::9] = 0
+    img = np.ascontiguousarray(img)
+    s = ndet.fast_score_image(img)
+    ys, xs = np.nonzero(s >= 10)
+    assert len(xs) > 100
+    xy_o, sc_o, nm_o = orc.fast_corners(img, 10)
+    assert np.array_equal(xy_o, np.stack([xs, ys], axis=1)) and np.array_equal(sc_o, s[ys, xs])      # same set, same scores
+    kept = ndet.fast_corners(img, 10)
+    assert [(int(x), int(y)) for x, y in xy_o[nm_o]] == [(x, y) for x, y, _ in kept]                  # list walk == dense 3x3
+    # blur / Scharr / histogram angle piece by piece
+    assert np.array_equal(orc.gaussian_blur_3x3(img), ndet.gaussian_blur_3x3(img))
+    for xd in (True, False):
+        assert np.array_equal(orc.scharr_16s(img, xd), ndet.scharr(img, xd))
+    for (x, y) in ((20, 20), (1, 1), (img.shape[1] - 2, img.shape[0] - 3), (57, 33)):
+        assert orc.angle_at_pixel(img, x, y) == ndet.angle_at_pixel_using_histogram(img, x, y, 4)
