@@ -206,3 +206,26 @@ def align_pyr_2d(pyr_ref, pyr_cur, max_level, min_level, patch_sizes, n_iter, mi
         if not converged and not go_to_next_level:
             return False, tuple(px_cur)
     return converged, tuple(px_cur)
+
+
+def half_sample(img):
+    """vk::halfSample (src/vikit/vikit_common/src/vision.cpp:70-112) on an x86 build: the SSE2 routine (:19-44: _mm_avg_epu8
+    of the two rows, then _mm_avg_epu16 of the even and odd columns -- two roundings, each half up) when the width is
+    a multiple of 16 (aligned, continuous rows), else the scalar sum of four divided by 4 (truncating).  Whole-array
+    NumPy; a second reading beside oracle/svo_oracle.c."""
+    h, w = img.shape
+    oh, ow = h // 2, w // 2
+    a = img.astype(np.uint16)
+    if w % 16 == 0:
+        v = (a[0:2 * oh:2] + a[1:2 * oh:2] + 1) >> 1
+        return ((v[:, 0::2] + v[:, 1::2] + 1) >> 1).astype(np.uint8)
+    top, bot = a[0:2 * oh:2], a[1:2 * oh:2]
+    return ((top[:, 0:2 * ow:2] + top[:, 1:2 * ow:2] + bot[:, 0:2 * ow:2] + bot[:, 1:2 * ow:2]) // 4).astype(np.uint8)
+
+
+def create_img_pyramid(img, n_levels):
+    """frame_utils::createImgPyramid (src/svo_common/src/frame.cpp:372-386)."""
+    pyr = [np.ascontiguousarray(img, np.uint8)]
+    for _ in range(1, n_levels):
+        pyr.append(half_sample(pyr[-1]))
+    return pyr

@@ -230,3 +230,19 @@ def test_detector_oracle_vs_numpy_second_opinion(oracle_lib, shape):
         assert np.array_equal(orc.scharr_16s(img, xd), ndet.scharr(img, xd))
     for (x, y) in ((20, 20), (1, 1), (img.shape[1] - 2, img.shape[0] - 3), (57, 33)):
         assert orc.angle_at_pixel(img, x, y) == ndet.angle_at_pixel_using_histogram(img, x, y, 4)
+
+
+@pytest.mark.parametrize("shape", [(640, 480), (752, 480), (327, 243), (48, 33), (32, 2)])
+def test_pyramid_oracle_vs_numpy_second_opinion(oracle_lib, shape):
+    """a-0: createImgPyramid / halfSample, the SSE2 rule where the level's width is a multiple of 16 and the scalar rule
+    elsewhere (752 -> 376 -> 188 switches after the first level), odd sizes included."""
+    import np_restatement as n0
+    w, h = shape
+    rng = np.random.RandomState(w * 7 + h)
+    img = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    img[: h // 3] = np.where(rng.uniform(size=(h // 3, w)) < 0.5, 255, 254)     # sums on the rounding edges
+    n_levels = 5 if min(w, h) >= 32 else 2
+    po = oracle_lib.create_img_pyramid(img, n_levels)
+    pn = n0.create_img_pyramid(img, n_levels)
+    for a, b in zip(po, pn):
+        assert a.shape == b.shape and np.array_equal(a, b)
