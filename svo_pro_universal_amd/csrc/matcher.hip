@@ -1393,7 +1393,8 @@ __device__ void scan_epipolar_unit_plane(MatcherState& m, const svoh_matcher_opt
 // Eigen AngleAxis::toRotationMatrix() * v
 __device__ Vec3 angle_axis_rotate(const Vec3& axis, double angle, const Vec3& v)
 {
-  const double s = sin(angle), c = cos(angle);
+  double s, c;
+  sincos(angle, &s, &c);   // one argument reduction for both (the values are those of sin() and cos())
   const double sa0 = s * axis.x, sa1 = s * axis.y, sa2 = s * axis.z;
   const double c0 = (1.0 - c) * axis.x, c1 = (1.0 - c) * axis.y, c2 = (1.0 - c) * axis.z;
   double R[9];
