@@ -118,10 +118,11 @@ SVOH_HD Rigid inverse(const Rigid& a)
 SVOH_HD Quat quat_exp(const Vec3& w)
 {
   const double theta = sqrt(w.x * w.x + w.y * w.y + w.z * w.z);
-  double na;
+  double na, sh, ch;
+  sincos(theta * 0.5, &sh, &ch);   // one argument reduction for both (the one-lane Gauss-Newton step pays for every instruction)
   if (theta < SVOH_EPS_4TH_ROOT) na = 0.5 + (theta * theta) * (1.0 / 48.0);
-  else na = sin(theta * 0.5) / theta;
-  Quat q = { cos(theta * 0.5), w.x * na, w.y * na, w.z * na };
+  else na = sh / theta;
+  Quat q = { ch, w.x * na, w.y * na, w.z * na };
   return q;
 }
 
