@@ -446,6 +446,55 @@ EurocSequence openEuroc(const std::string& root)
 }
 
 // ---------------------------------------------------------------------------
+std::vector<ImuMeasurement> readEurocImu(const std::string& root)
+{
+  std::vector<ImuMeasurement> out;
+  const std::string csv = root + "/mav0/imu0/data.csv";
+  std::ifstream f(csv);
+  if (!f) return out;
+  std::string s;
+  while (std::getline(f, s)) {
+    for (char& c : s) if (c == ',') c = ' ';
+    s = strip(s);
+    if (s.empty() || s[0] == '#') continue;
+    std::istringstream ss(s);
+    unsigned long long ts = 0;
+    ImuMeasurement m;
+    if (!(ss >> ts >> m.w[0] >> m.w[1] >> m.w[2] >> m.a[0] >> m.a[1] >> m.a[2])) throw std::runtime_error(csv + ": bad line '" + s + "'");
+    m.t = (double)ts * 1e-9;
+    if (!out.empty() && m.t < out.back().t) throw std::runtime_error(csv + ": timestamps not ascending");
+    out.push_back(m);
+  }
+  return out;
+}
+
+bool relativeRotationPrior(const std::vector<ImuMeasurement>& imu, double t_old_cam, double t_new_cam, const double gyro_bias[3],
+                           double delay_imu_cam, double max_imu_delta_t, svoh::Quat* R)
+{
+  *R = svoh::Quat{ 1.0, 0.0, 0.0, 0.0 };
+  if (imu.empty() || !(t_new_cam > t_old_cam)) return false;
+  const double t1 = t_old_cam - delay_imu_cam, t2 = t_new_cam - delay_imu_cam;
+  // the reference walks its list from the newest measurement: it2 = the first with timestamp < t2, it1 = the first with
+  // timestamp <= t1 (imu_handler.cpp:180-193)
+  long i1 = -1, i2 = -1;
+  for (long i = (long)imu.size() - 1; i >= 0; --i) {
+    if (i2 < 0 && imu[(size_t)i].t < t2) i2 = i;
+    if (imu[(size_t)i].t <= t1) { i1 = i; break; }
+  }
+  if (i1 < 0 || i2 < 0 || i1 == i2) return false;
+  if (t2 - imu[(size_t)i2].t > max_imu_delta_t) return false;
+  svoh::Quat q{ 1.0, 0.0, 0.0, 0.0 };
+  for (long j = i1; j <= i2; ++j) {
+    const double tj = j == i1 ? t1 : imu[(size_t)j].t;                        // "change timestamp of oldest measurement"
+    const double dt = j == i2 ? t2 - imu[(size_t)j].t : imu[(size_t)j + 1].t - tj;   // the newest one counts up to the new frame
+    const svoh::Vec3 w{ (imu[(size_t)j].w[0] - gyro_bias[0]) * dt, (imu[(size_t)j].w[1] - gyro_bias[1]) * dt, (imu[(size_t)j].w[2] - gyro_bias[2]) * dt };
+    q = svoh::mul(q, svoh::quat_exp(w));
+  }
+  *R = q;
+  return true;
+}
+
+// ---------------------------------------------------------------------------
 struct TrajectoryWriter::Impl { FILE* f = nullptr; };
 TrajectoryWriter::TrajectoryWriter(const std::string& path) : impl_(new Impl)
 {

@@ -81,6 +81,19 @@ struct EurocSequence {
 };
 EurocSequence openEuroc(const std::string& dataset_root);
 
+// ---- EuRoC IMU (<root>/mav0/imu0/data.csv: "timestamp [ns], w_x, w_y, w_z [rad/s], a_x, a_y, a_z [m/s^2]") ----
+struct ImuMeasurement { double t = 0.0; double w[3] = { 0, 0, 0 }; double a[3] = { 0, 0, 0 }; };   // t in seconds
+std::vector<ImuMeasurement> readEurocImu(const std::string& dataset_root);   // ascending time; empty when the file is absent
+
+// ImuHandler::getRelativeRotationPrior (src/svo/src/imu_handler.cpp:270-297 over getMeasurements, :157-233): the
+// gyroscope integrated between two camera timestamps, R_oldimu_newimu = prod exp((omega_j - bias) dt_j) over the
+// measurements from the newest one at or before t_old (its time moved to t_old) to the newest one before t_new (which
+// counts up to t_new); camera times are shifted by delay_imu_cam first.  False (and identity) where the reference
+// returns false: no measurement at or before t_old, none before t_new, both the same, or the newest one older than
+// max_imu_delta_t.  `imu` in ascending time.
+bool relativeRotationPrior(const std::vector<ImuMeasurement>& imu, double t_old_cam, double t_new_cam, const double gyro_bias[3],
+                           double delay_imu_cam, double max_imu_delta_t, svoh::Quat* R_oldimu_newimu);
+
 // ---- trajectory output, TUM format: "timestamp tx ty tz qx qy qz qw" (seconds) ----
 class TrajectoryWriter {
  public:

@@ -44,6 +44,13 @@ int main(int argc, char** argv)
       const io::EurocSequence s = io::openEuroc(argv[2]);
       printf("n %zu\n", s.size());
       for (size_t i = 0; i < s.size(); ++i) printf("frame %llu %s\n", (unsigned long long)s.cam_ts[i], s.cam0_files[i].c_str());
+    } else if (what == "imu") {
+      // imu <dataset_root> <t_old> <t_new> <max_dt>: the gyroscope prior between two camera times
+      const std::vector<io::ImuMeasurement> imu = io::readEurocImu(argv[2]);
+      const double bias[3] = { argc > 6 ? atof(argv[6]) : 0.0, argc > 7 ? atof(argv[7]) : 0.0, argc > 8 ? atof(argv[8]) : 0.0 };
+      svoh::Quat q;
+      const bool ok = io::relativeRotationPrior(imu, atof(argv[3]), atof(argv[4]), bias, 0.0, atof(argv[5]), &q);
+      printf("n %zu\nok %d\nq %.17g %.17g %.17g %.17g\n", imu.size(), ok ? 1 : 0, q.w, q.x, q.y, q.z);
     } else if (what == "yaml") {
       const io::YamlNode n = io::loadYamlFile(argv[2]);
       printf("a.b.c %d\nlist %zu %.17g\nseq %zu %s %s\nstr %s\nkeyslash %d\nmissing %d\n", n["a"]["b"]["c"].asInt(-1), n["list"].size(),

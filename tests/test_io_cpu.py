@@ -290,3 +290,60 @@ def test_reference_configuration_files_parse_to_survey_appendix_a():
     out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_io"), "rig", os.path.join(REF_PARAM, "calib", "euroc_stereo.yaml")],
                          capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.count("label ") == 2 and out.stdout.count("size 752 480") == 2
+
+
+def test_gyroscope_rotation_prior_of_an_euroc_folder(tmp_path):
+    """io::readEurocImu + io::relativeRotationPrior (ImuHandler::getRelativeRotationPrior, imu_handler.cpp:157-233,
+    270-297) against an independent integration in NumPy: which measurements take part (newest at or before t_old with
+    its time moved to t_old, up to the newest before t_new, which counts up to t_new), the order of the product, and
+    the cases where the reference gives up."""
+    d = tmp_path / "mav0" / "imu0"
+    d.mkdir(parents=True)
+    rng = np.random.RandomState(3)
+    ts = 1403636579_000000000 + (np.arange(400) * 5_000_000).astype(np.int64)      # 200 Hz
+    w = rng.normal(scale=0.4, size=(400, 3)); acc = rng.normal(size=(400, 3))
+    with open(d / "data.csv", "w") as f:
+        f.write("#timestamp [ns],w_RS_S_x [rad s^-1],w_RS_S_y [rad s^-1],w_RS_S_z [rad s^-1],a_RS_S_x [m s^-2],a_RS_S_y [m s^-2],a_RS_S_z [m s^-2]\n")
+        for t, wi, ai in zip(ts, w, acc):
+            f.write("%d,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n" % (t, wi[0], wi[1], wi[2], ai[0], ai[1], ai[2]))
+    tsec = ts * 1e-9
+
+    def qmul(a, b):
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+    def qexp(v):
+        th = np.linalg.norm(v)
+        return np.array([1.0, 0, 0, 0]) if th < 1e-12 else np.concatenate([[np.cos(th / 2)], np.sin(th / 2) * v / th])
+
+    def expected(t_old, t_new, bias, max_dt):
+        older = np.nonzero(tsec <= t_old)[0]; before = np.nonzero(tsec < t_new)[0]
+        if len(older) == 0 or len(before) == 0 or older[-1] == before[-1] or t_new - tsec[before[-1]] > max_dt:
+            return None
+        i1, i2 = older[-1], before[-1]
+        q = np.array([1.0, 0, 0, 0])
+        for j in range(i1, i2 + 1):
+            tj = t_old if j == i1 else tsec[j]
+            dt = (t_new - tsec[j]) if j == i2 else (tsec[j + 1] - tj)
+            q = qmul(q, qexp((w[j] - bias) * dt))
+        return q
+
+    cases = [(tsec[10] + 0.0012, tsec[14] + 0.0031, (0, 0, 0), 0.01),          # between measurements, 5 take part
+             (tsec[20], tsec[30], (0.01, -0.02, 0.005), 0.01),                   # on measurement times: [t_old] included, [t_new] not
+             (tsec[50] + 0.001, tsec[50] + 0.004, (0, 0, 0), 0.01),              # one measurement only -> false (it1 == it2)
+             (tsec[0] - 0.01, tsec[5], (0, 0, 0), 0.01),                         # nothing at or before t_old -> false
+             (tsec[390], tsec[399] + 0.05, (0, 0, 0), 0.01),                     # newest measurement too old -> false
+             (tsec[100] + 0.002, tsec[110] + 0.002, (0, 0, 0), 0.01)]            # a 50 ms frame interval
+    for t_old, t_new, bias, max_dt in cases:
+        rc, out, raw = run("imu", str(tmp_path), "%.17g" % t_old, "%.17g" % t_new, "%.17g" % max_dt, *["%.17g" % b for b in bias])
+        assert rc == 0, raw
+        assert int(out["n"]) == 400
+        want = expected(t_old, t_new, np.array(bias), max_dt)
+        q = np.array([float(x) for x in out["q"].split()])
+        if want is None:
+            assert out["ok"] == "0" and np.array_equal(q, [1, 0, 0, 0])
+        else:
+            assert out["ok"] == "1" and np.abs(q - want).max() < 1e-14 and abs(np.linalg.norm(q) - 1) < 1e-14
+    # no imu folder: empty, and no prior
+    rc, out, raw = run("imu", str(tmp_path / "nowhere"), "0", "1", "0.01")
+    assert rc == 0 and out["n"] == "0" and out["ok"] == "0"

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 BASELINE_M = 0.11
 
 
-def make_stereo_dataset(tmp_path, n_frames=30):
+def make_stereo_dataset(tmp_path, n_frames=30, raw_gyro=False):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host")])
     cam = synth.Camera.euroc_like(752, 480)
     sc = synth.make_align_scene(171, n_features=8, cam=cam, rot_deg=(0.3, 0.5), trans_m=(0.015, 0.025))
@@ -47,7 +47,21 @@ def make_stereo_dataset(tmp_path, n_frames=30):
         noise = synth.SE3(synth.quat_from_axis_angle(rng.normal(size=3), 2e-4), (0, 0, 0))
         q = (noise * d).q
         lines.append(",".join("%.17g" % v for v in q))
-    (tmp_path / "ds" / "mav0" / "imu_prior.csv").write_text("#qw,qx,qy,qz of R_imu(k)_imu(k-1)\n" + "\n".join(lines) + "\n")
+    if not raw_gyro:
+        (tmp_path / "ds" / "mav0" / "imu_prior.csv").write_text("#qw,qx,qy,qz of R_imu(k)_imu(k-1)\n" + "\n".join(lines) + "\n")
+    else:
+        # a real EuRoC folder has no such file: the raw gyroscope instead (200 Hz, body rates of the constant motion + noise)
+        q = step.q
+        ang = 2.0 * np.arctan2(np.linalg.norm(q[1:]), q[0])
+        omega = np.asarray(q[1:]) / np.linalg.norm(q[1:]) * ang / 0.05        # R_imu(k-1)_imu(k) = exp(omega * 50 ms)
+        imu_dir = tmp_path / "ds" / "mav0" / "imu0"
+        imu_dir.mkdir(parents=True)
+        t = stamps[0] - 20_000_000 + 5_000_000 * np.arange((n_frames - 1) * 10 + 9)
+        with open(imu_dir / "data.csv", "w") as f:
+            f.write("#timestamp [ns],w_RS_S_x [rad s^-1],w_RS_S_y [rad s^-1],w_RS_S_z [rad s^-1],a_RS_S_x [m s^-2],a_RS_S_y [m s^-2],a_RS_S_z [m s^-2]\n")
+            for ti in t:
+                wn = omega + rng.normal(scale=2e-3, size=3)
+                f.write("%d,%.17g,%.17g,%.17g,0.0,0.0,9.81\n" % (ti, wn[0], wn[1], wn[2]))
     cam_yaml = """- camera:
     label: cam%d
     image_height: %d
@@ -103,3 +117,20 @@ def test_mini_stereo_tracks_a_synthetic_stereo_sequence(tmp_path):
     # without the rotation prior the chain still runs (lambda 0): the prior is a weight, not a requirement
     r0 = subprocess.run(cmd + [str(10), "8", "0"], capture_output=True, text=True)
     assert r0.returncode == 0, r0.stdout + r0.stderr
+
+
+def test_mini_stereo_takes_its_rotation_prior_from_the_raw_gyroscope(tmp_path):
+    """A real EuRoC folder carries mav0/imu0/data.csv, not a prior file: the harness integrates the gyroscope between the
+    camera timestamps (io::relativeRotationPrior = ImuHandler::getRelativeRotationPrior) and runs from there."""
+    import ate
+    n_frames = 20
+    cmd, out_dir, poses, stamps = make_stereo_dataset(tmp_path, n_frames, raw_gyro=True)
+    r = subprocess.run(cmd + [str(n_frames), "8", "0.5"], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rotation priors from" in r.stderr and "(%d of %d frame intervals covered)" % (n_frames - 1, n_frames - 1) in r.stderr
+    est = ate.load_tum(str(out_dir / "trajectory.txt"))
+    gt = np.array([[stamps[k] * 1e-9] + list(T.t) + [T.q[1], T.q[2], T.q[3], T.q[0]] for k, T in enumerate(poses)])
+    res = ate.ate(est, gt, with_scale=False, max_dt=1e-3)
+    path_len = float(np.linalg.norm(np.diff(gt[:, 1:4], axis=0), axis=1).sum())
+    assert res["n"] == n_frames and res["rmse"] < 0.03 * path_len + 0.003

@@ -12,8 +12,9 @@
 //
 // A harness over the built mirrors, NOT FrameHandlerStereo: no map (every live keyframe counts as overlapping), no
 // upgrade of converged seeds to landmarks, keyframes by a fixed rule, the first rig pose given.  The IMU prior is read
-// from <dataset_root>/mav0/imu_prior.csv (one line per frame: qw qx qy qz of R_imu(k)_imu(k-1), as a gyroscope
-// integration would deliver it); without the file no prior is set.
+// from <dataset_root>/mav0/imu_prior.csv (one line per frame: qw qx qy qz of R_imu(k)_imu(k-1)), or, without that file,
+// integrated from the raw gyroscope of an EuRoC folder (mav0/imu0/data.csv, io::relativeRotationPrior); with neither no
+// prior is set.
 //
 //   svoh_mini_stereo <dataset_root> <calib.yaml (two cameras)> <params.yaml|-> <out_dir> <T_imu_world of frame 0: qw qx qy qz tx ty tz>
 //                    [max_frames] [kf_every] [prior_lambda_rot]
@@ -68,6 +69,25 @@ int main(int argc, char** argv)
         svoh::Quat q{ 1, 0, 0, 0 };
         ss >> q.w >> q.x >> q.y >> q.z;
         imu_prior.push_back(q);
+      }
+    }
+    // ... or the raw gyroscope of a real EuRoC folder (mav0/imu0/data.csv), integrated between the camera timestamps
+    // as ImuHandler::getRelativeRotationPrior does (no bias estimate here: zero); T_newimu_lastimu_prior is the
+    // inverse of R_lastimu_newimu (frame_handler_base.cpp:563, 1129)
+    if (imu_prior.empty()) {
+      const std::vector<io::ImuMeasurement> imu = io::readEurocImu(argv[1]);
+      if (!imu.empty()) {
+        const double bias[3] = { 0.0, 0.0, 0.0 };
+        imu_prior.assign(n_frames, svoh::Quat{ 1, 0, 0, 0 });
+        size_t n_ok = 0;
+        for (size_t k = 1; k < n_frames; ++k) {
+          svoh::Quat R_old_new;
+          if (io::relativeRotationPrior(imu, (double)seq.cam_ts[k - 1] * 1e-9, (double)seq.cam_ts[k] * 1e-9, bias, 0.0, 0.01, &R_old_new)) {
+            imu_prior[k] = svoh::Quat{ R_old_new.w, -R_old_new.x, -R_old_new.y, -R_old_new.z };
+            ++n_ok;
+          }
+        }
+        fprintf(stderr, "svoh_mini_stereo: rotation priors from %zu gyroscope measurements (%zu of %zu frame intervals covered)\n", imu.size(), n_ok, n_frames - 1);
       }
     }
 
