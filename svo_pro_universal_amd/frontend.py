@@ -358,9 +358,14 @@ def _update_seeds_device(self, mopt, dopt, ref_views, cur_views, fb, state, succ
 
 
 def _match_direct_device(self, mopt, ref_views, cur_views, fb, depth, px_cur, result, f_cur=None, search_level=None,
-                         h_inv=None, A_cur_ref=None):
+                         h_inv=None, A_cur_ref=None, landmark_xyz=None):
+    """landmark_xyz (device pointer, 3 x n, world): the pixelwise warp (svoh_match_direct_batch_pixelwise)."""
     rv, n_ref = _views(ref_views)
     cv, _ = _views(cur_views)
+    if landmark_xyz is not None:
+        self._check(self.lib.svoh_match_direct_batch_pixelwise(self.h, C.byref(mopt), n_ref, rv, cv, C.byref(fb), depth, landmark_xyz,
+                                                               px_cur, result, f_cur, search_level, h_inv, A_cur_ref))
+        return
     self._check(self.lib.svoh_match_direct_batch(self.h, C.byref(mopt), n_ref, rv, cv, C.byref(fb), depth, px_cur,
                                                  result, f_cur, search_level, h_inv, A_cur_ref))
 

@@ -470,6 +470,18 @@ def test_device_resident_batches_equal_host_batches(gpu_ctx, oracle_lib):
     gpu_ctx.synchronize()
     assert np.array_equal(d["res"].cpu().numpy(), host["result"]) and np.array_equal(d["pxc"].cpu().numpy(), host["px_cur"])
     assert np.array_equal(d["fcur"].cpu().numpy(), host["f_cur"]) and np.array_equal(d["A"].cpu().numpy(), host["A"])
+    # the pixelwise warp's entry with device-resident arrays == with host arrays
+    lm = np.ascontiguousarray(sc.T_w_ref.transform(x).T)
+    host_pw = gpu_ctx.match_direct_batch(mopt, [rvs[0]], cvs[0], fbh, depth, px0, landmark_xyz=lm)
+    d["pxc"].copy_(torch.from_numpy(px0).to(dev)); d["res"].zero_(); d["fcur"].zero_(); d["A"].zero_()
+    d["lm"] = torch.from_numpy(lm).to(dev)
+    torch.cuda.synchronize()
+    gpu_ctx.match_direct_device(mopt, [rvs[0]], cvs[0], fbm, d["depth"].data_ptr(), d["pxc"].data_ptr(), d["res"].data_ptr(),
+                                f_cur=d["fcur"].data_ptr(), A_cur_ref=d["A"].data_ptr(), landmark_xyz=d["lm"].data_ptr())
+    gpu_ctx.synchronize()
+    assert np.array_equal(d["res"].cpu().numpy(), host_pw["result"]) and np.array_equal(d["pxc"].cpu().numpy(), host_pw["px_cur"])
+    assert np.array_equal(d["fcur"].cpu().numpy(), host_pw["f_cur"]) and (host_pw["result"] == 0).sum() > 100
+    assert not np.array_equal(host_pw["px_cur"], host["px_cur"])        # it is the other warp
 
     # indexed KLT: host mode == multi, device mode == host mode, bad index -> status 0
     trs = [synth.make_track_set(p[0], 60, seed=20 + k) for k, p in enumerate(packs)]
