@@ -76,6 +76,7 @@ struct AlignKernelArgs {
   uint8_t* wvis;                        // visibility of the last evaluation
   svoh_align_options opt;
   int32_t lds_img_bytes;                // dynamic LDS available for image staging
+  int32_t ws_lds_bytes;                 // > 0: the feature workspace of a (small) problem lives in LDS behind the image area (512-thread geometry)
   int32_t eval_level;                   // <0: full run; >=0: evaluate once at that level
   double* eval_out;                     // [64 H][8 g][chi2][n_meas] for eval mode
   long long* stamps;                    // diagnostic builds only (SVOH_PHASE_STAMPS): 8 per problem
@@ -99,6 +100,9 @@ constexpr int kXchgStride = 64;         // doubles per share and parity (>= 45 +
 #ifndef SVOH_ROW_UNROLL_GONLY
 #define SVOH_ROW_UNROLL_GONLY 4
 #endif
+#ifndef SVOH_PIN_MOMENTS
+#define SVOH_PIN_MOMENTS 1
+#endif
 // rows of the full pass taken per loop trip: measured per configuration (round 3, scripts/ab.sh: 4x4 1.377 -> 1.365 ms with 2,
 // 1.44 with 4; 8x8 3.36 -> 3.25 with 4; with the illumination terms' 15 moments live, 1 for 4x4)
 #ifndef SVOH_ROW_UNROLL
@@ -112,9 +116,18 @@ constexpr int kXchgStride = 64;         // doubles per share and parity (>= 45 +
 #define SVOH_STAMP_START() do { st_t0 = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define SVOH_STAMP_ADD(k) do { long long st_n = (long long)__builtin_amdgcn_s_memtime(); st_acc[k] += st_n - st_t0; st_t0 = st_n; } while (0)
 #define SVOH_STAMP_COUNT(k) do { st_acc[k] += 1; } while (0)
-#define SVOH_STAMP_FLUSH() do { if (threadIdx.x == 0) { st_acc[7] = (long long)__builtin_amdgcn_s_memtime() - st_begin; for (int k_ = 0; k_ < 8; ++k_) a.stamps[pbi * 12 + k_] = st_acc[k_]; for (int k_ = 0; k_ < 4; ++k_) a.stamps[pbi * 12 + 8 + k_] = g_state.dbg[k_]; } } while (0)
+#define SVOH_STAMP_FLUSH() do { if (threadIdx.x == 0) { st_acc[7] = (long long)__builtin_amdgcn_s_memtime() - st_begin; for (int k_ = 0; k_ < 8; ++k_) a.stamps[pbi * 20 + k_] = st_acc[k_]; for (int k_ = 0; k_ < 4; ++k_) a.stamps[pbi * 20 + 8 + k_] = g_state.dbg[k_]; for (int k_ = 0; k_ < 8; ++k_) a.stamps[pbi * 20 + 12 + k_] = g_state.dbg2[k_]; } } while (0)
 #define SVOH_SERIAL_STAMP(k) do { long long st_n = (long long)__builtin_amdgcn_s_memtime(); s.dbg[k] += st_n - st_s0; st_s0 = st_n; } while (0)
+// inside a pass over the patches (thread 0 only; waits for everything in flight first, so the pieces add up)
+#define SVOH_PASS_STAMP_BEGIN() long long ps_t0 = 0; if (threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); ps_t0 = (long long)__builtin_amdgcn_s_memtime(); }
+#define SVOH_PASS_STAMP(k) do { if (threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); long long ps_n = (long long)__builtin_amdgcn_s_memtime(); g_state.dbg2[k] += ps_n - ps_t0; ps_t0 = ps_n; } } while (0)
+#define SVOH_OUTER_STAMP_BEGIN() long long os_t0 = 0; if (threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); os_t0 = (long long)__builtin_amdgcn_s_memtime(); }
+#define SVOH_OUTER_STAMP(k) do { if (threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); long long os_n = (long long)__builtin_amdgcn_s_memtime(); g_state.dbg2[k] += os_n - os_t0; os_t0 = os_n; } } while (0)
 #else
+#define SVOH_PASS_STAMP_BEGIN()
+#define SVOH_PASS_STAMP(k) do {} while (0)
+#define SVOH_OUTER_STAMP_BEGIN()
+#define SVOH_OUTER_STAMP(k) do {} while (0)
 #define SVOH_STAMP_DECL
 #define SVOH_STAMP_START() do {} while (0)
 #define SVOH_STAMP_ADD(k) do {} while (0)
@@ -144,6 +157,7 @@ struct ShState {
   double lvl_chi2[SVOH_MAX_LEVELS];
 #ifdef SVOH_PHASE_STAMPS
   long long dbg[4];   // diagnostic build: cycles of the one-lane step in set-up / solve / update / camera poses
+  long long dbg2[8];  // ... and of thread 0 inside the passes: row arrival / projection / pixels / Jacobian rows + map / loop exit
 #endif
 };
 
@@ -456,6 +470,42 @@ __device__ __forceinline__ void patch_moments(
   }
 }
 
+// ---- rows geometry: LPP lanes per patch, lane r owns the P / LPP output rows from r * P / LPP on ----------------
+// north_star's "several lanes per patch".  A problem with few patches (one camera stream: <= 180 at C3) fills a
+// fraction of a workgroup's lanes when a lane owns a whole patch, and that lane's pass is one long chain of P rolling
+// rows.  Here the LPP consecutive lanes of a group share a patch: each runs the rolling window of patch_moments_part
+// over its own P / LPP rows (the window's first two interpolated rows are computed again by every lane: (P / LPP + 2)
+// interpolated rows per lane instead of P + 2 per patch).  Same expressions as the lane-per-patch code, so every
+// interpolated value and every residual has the same bits; a lane's moments are partial sums of the patch's.  Nothing
+// is exchanged between the lanes of a group: the map from moments to normal equations (accumulate_patch) is linear in
+// the moments, so every lane applies it to its own rows and the wave reduction adds row groups instead of patches.
+// (Exchanging would cost more than it saves: a double moved over DPP is two VALU slots, an interpolated value
+// recomputed is four; summing a group's moments first costs 18-36 slots per lane against the 66 of the map.)
+template <int P, int LPP, int D, bool RLDS, bool CLDS, bool GONLY = false>
+__device__ __forceinline__ void patch_rows_moments(
+    const ImgView<RLDS>& ref, const ImgView<CLDS>& cur, int ru, int rv, double rsu, double rsv, int cu, int cv,
+    double csu, double csv, int r, double one_plus_alpha, double beta, bool robust, float weight_scale,
+    double (&mom)[AccLayout<D>::NMOM])
+{
+  constexpr int PH = P / LPP;
+  static_assert(PH * LPP == P && PH >= 1, "lanes per patch must divide the patch height");
+  const int rv0 = rv + r * PH, cv0 = cv + r * PH;
+  if constexpr (P == 8) {
+    patch_moments_part<PH, 4, D, RLDS, CLDS, GONLY, true>(ref, cur, ru, rv0, rsu, rsv, cu, cv0, csu, csv, one_plus_alpha, beta,
+                                                          robust, weight_scale, mom);
+    patch_moments_part<PH, 4, D, RLDS, CLDS, GONLY, false>(ref, cur, ru + 4, rv0, rsu, rsv, cu + 4, cv0, csu, csv, one_plus_alpha,
+                                                           beta, robust, weight_scale, mom);
+  } else {
+    patch_moments_part<PH, P, D, RLDS, CLDS, GONLY, true>(ref, cur, ru, rv0, rsu, rsv, cu, cv0, csu, csv, one_plus_alpha, beta,
+                                                          robust, weight_scale, mom);
+  }
+  mom[3] *= 0.5; mom[4] *= 0.5;
+  if constexpr (!GONLY) {
+    mom[0] *= 0.25; mom[1] *= 0.25; mom[2] *= 0.25;
+    if constexpr (D == 8) { mom[6] *= 0.5; mom[7] *= 0.5; mom[10] *= 0.5; mom[11] *= 0.5; }
+  }
+}
+
 // Apply the patch's linear map to its moments: acc += (H upper triangle, g, chi2).
 // a = jp0 * scale, b = jp1 * scale (scale is a power of two: (dx*jp0+dy*jp1)*scale == dx*a+dy*b exactly)
 template <int D>
@@ -558,6 +608,14 @@ __device__ __forceinline__ Rigid uniform_rigid(const Rigid& T)
 
 constexpr int kWsPairs = 3;
 __device__ __forceinline__ double* ws_pair(const AlignKernelArgs& a, int pair, int64_t gi) { return a.wpk + ((int64_t)pair * a.slots + gi) * 2; }
+// The workspace as the passes of the 512-thread geometry see it: the launch's global arrays, or -- a problem of a few
+// hundred features, what one camera stream aligns -- the workgroup's own copy in LDS (a generic pointer into the
+// dynamic LDS area: the same code reads either).  A pass then starts with an LDS read instead of a round trip to L2 for
+// its 48-byte row (measured on a 180-patch problem: 1.2 K of the 5.7 K cycles of a wave's pass).
+// first: the launch-wide slot that is this view's slot 0 (every address formed stays inside the view's memory: a generic
+// pointer that leaves the LDS aperture on the way, to come back with the index, is an aperture violation on gfx950)
+struct WsView { double* base; int64_t slots; int64_t first; };
+__device__ __forceinline__ double* ws_pair(const WsView& w, int pair, int64_t gi) { return w.base + ((int64_t)pair * w.slots + (gi - w.first)) * 2; }
 
 // All patches of one camera at one Gauss-Newton iteration: one thread per patch.
 // GONLY (see patch_moments): accumulate the gradient and chi2 only and report in `changed` whether any patch's
@@ -566,21 +624,24 @@ __device__ __forceinline__ double* ws_pair(const AlignKernelArgs& a, int pair, i
 // jc: the camera's kJacConsts block (LDS).
 template <int P, int D, int NT, bool LDS, bool GONLY = false>
 __device__ __forceinline__ void accumulate_camera(
-    const AlignKernelArgs& a, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
+    const AlignKernelArgs& a, const WsView& ws, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
     bool robust, bool dist_jac, float weight_scale, int tid, const double* jc,
     double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed)
 {
+  SVOH_PASS_STAMP_BEGIN();
   const CamModel cm = load_camera(cd.cam);
   const double patch_center = (P - 1) / 2.0f;
   const double patch_center_wb = (P + 2 - 1) / 2.0f;
+  SVOH_PASS_STAMP(0);
 
   for (int i = tid; i < cd.n_features; i += NT) {
     const int gi = cd.feat_off + i;
-    const double2 vs = *reinterpret_cast<const double2*>(ws_pair(a, 2, gi));
+    const double2 vs = *reinterpret_cast<const double2*>(ws_pair(ws, 2, gi));
     if (vs.y == 0.0) continue;
-    const double2 xy = *reinterpret_cast<const double2*>(ws_pair(a, 0, gi));
-    const double2 zu = *reinterpret_cast<const double2*>(ws_pair(a, 1, gi));
+    const double2 xy = *reinterpret_cast<const double2*>(ws_pair(ws, 0, gi));
+    const double2 zu = *reinterpret_cast<const double2*>(ws_pair(ws, 1, gi));
+    SVOH_PASS_STAMP(1);
     const Vec3 X = { xy.x, xy.y, zu.x };
     // ---- a-6 projection into the current level + visibility ----
     const Vec3 Y = transform(Tcr, X);
@@ -602,11 +663,12 @@ __device__ __forceinline__ void accumulate_camera(
     }
     if constexpr (GONLY) changed |= (int)((vs.y == 2.0) != vis);
     else {
-      ws_pair(a, 2, gi)[1] = vis ? 2.0 : 1.0;
+      ws_pair(ws, 2, gi)[1] = vis ? 2.0 : 1.0;
       if (a.eval_level >= 0) a.wvis[gi] = vis ? 1 : 0;   // svoh_sparse_align_evaluate hands the mask out
     }
     if (!vis) continue;
     ++nvis;
+    SVOH_PASS_STAMP(2);
     // ---- a-5 reference side (recomputed, never stored) ----
     const double ru_tl = zu.y * scale - patch_center_wb;
     const double rv_tl = vs.x * scale - patch_center_wb;
@@ -615,10 +677,103 @@ __device__ __forceinline__ void accumulate_camera(
     double mom[AccLayout<D>::NMOM];
     patch_moments<P, D, LDS, LDS, GONLY>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d, robust,
                                          weight_scale, mom);
+#if SVOH_PIN_MOMENTS
+    // see accumulate_camera_rows: the moments are finished here, the pixel arithmetic is not sunk behind what follows.
+    // On the LDS-resident levels only: where the rows come from global memory the interleaving hides their latency
+    // (A/B on one box, 1024 x 2000 patches: levels 4..2 0.996 -> 0.904-0.954 ms with the pin, level 0 alone 0.787 -> 0.82-0.84)
+    if constexpr (LDS) {
+#pragma unroll
+      for (int k = 0; k < AccLayout<D>::NMOM; ++k)
+        if (!GONLY || k == 3 || k == 4 || k == 5 || k == 13 || k == 14) asm volatile("" : "+v"(mom[k]));
+    }
+#endif
+    SVOH_PASS_STAMP(3);
     double ja[6], jb[6];
     jac_rows(jc, cm, dist_jac, X, scale, ja, jb);
     if constexpr (GONLY) accumulate_patch_gradient<D>(mom, ja, jb, est_alpha, est_beta, acc);
     else accumulate_patch<D>(mom, ja, jb, est_alpha, est_beta, acc);
+#ifdef SVOH_PHASE_STAMPS
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+#endif
+    SVOH_PASS_STAMP(4);
+  }
+}
+
+// Rows geometry: the LPP lanes of a group (consecutive lanes, so a wave holds 64 / LPP patches) take one patch per pass,
+// lane r its rows.  What belongs to the patch as a whole -- the workspace row (the group's lanes read the same 48
+// bytes: one request), projection and visibility, the Jacobian rows -- is computed by every lane of the group alike:
+// identical values, no exchange, and no divergence inside a group.  The patch is counted and its visibility recorded
+// by the group's lane 0.
+template <int P, int LPP, int D, int NT, bool LDS, bool GONLY = false>
+__device__ __forceinline__ void accumulate_camera_rows(
+    const AlignKernelArgs& a, const WsView& ws, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
+    const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
+    bool robust, bool dist_jac, float weight_scale, int tid, const double* jc,
+    double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed)
+{
+  static_assert(LPP == 2 || LPP == 4 || LPP == 8, "a group is 2, 4 or 8 consecutive lanes");
+  SVOH_PASS_STAMP_BEGIN();
+  const CamModel cm = load_camera(cd.cam);
+  const double patch_center = (P - 1) / 2.0f;
+  const double patch_center_wb = (P + 2 - 1) / 2.0f;
+  const int r = tid & (LPP - 1);
+  SVOH_PASS_STAMP(0);
+
+  for (int i = tid / LPP; i < cd.n_features; i += NT / LPP) {
+    const int gi = cd.feat_off + i;
+    const double2 vs = *reinterpret_cast<const double2*>(ws_pair(ws, 2, gi));
+    if (vs.y == 0.0) continue;
+    const double2 xy = *reinterpret_cast<const double2*>(ws_pair(ws, 0, gi));
+    const double2 zu = *reinterpret_cast<const double2*>(ws_pair(ws, 1, gi));
+    SVOH_PASS_STAMP(1);
+    const Vec3 X = { xy.x, xy.y, zu.x };
+    const Vec3 Y = transform(Tcr, X);
+    bool vis = !(Y.z < 0.0);
+    int cu = 0, cv = 0;
+    double csu = 0.0, csv = 0.0;
+    if (vis) {
+      double u, v;
+      project3(cm, Y, u, v);
+      const double u_tl = u * scale - patch_center;
+      const double v_tl = v * scale - patch_center;
+      vis = !(u_tl < 0.0 || v_tl < 0.0 || u_tl + P + 2.0 >= cw || v_tl + P + 2.0 >= ch);
+      vis = vis && u_tl == u_tl && v_tl == v_tl;
+      if (vis) {
+        const double fu = floor(u_tl), fv = floor(v_tl);
+        cu = (int)fu; cv = (int)fv;
+        csu = u_tl - cu; csv = v_tl - cv;
+      }
+    }
+    if constexpr (GONLY) changed |= (int)((vs.y == 2.0) != vis);
+    else if (r == 0) {
+      ws_pair(ws, 2, gi)[1] = vis ? 2.0 : 1.0;
+      if (a.eval_level >= 0) a.wvis[gi] = vis ? 1 : 0;
+    }
+    if (!vis) continue;
+    nvis += (r == 0) ? 1 : 0;
+    SVOH_PASS_STAMP(2);
+    const double ru_tl = zu.y * scale - patch_center_wb;
+    const double rv_tl = vs.x * scale - patch_center_wb;
+    const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
+    const double rsu = ru_tl - ru, rsv = rv_tl - rv;
+    double mom[AccLayout<D>::NMOM];
+    patch_rows_moments<P, LPP, D, LDS, LDS, GONLY>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, r, one_plus_alpha, beta_d, robust,
+                                                   weight_scale, mom);
+    // the moments are finished HERE: left alone, the compiler sinks the pixel arithmetic (pure) behind the branches of
+    // the Jacobian rows, towards its use, while the rows' bytes wait in registers -- spilled ones (measured: the pass of
+    // two lanes per patch 20 % slower than the lane-per-patch pass without this line, 25 % faster with it)
+#pragma unroll
+    for (int k = 0; k < AccLayout<D>::NMOM; ++k)
+      if (!GONLY || k == 3 || k == 4 || k == 5 || k == 13 || k == 14) asm volatile("" : "+v"(mom[k]));
+    SVOH_PASS_STAMP(3);
+    double ja[6], jb[6];
+    jac_rows(jc, cm, dist_jac, X, scale, ja, jb);
+    if constexpr (GONLY) accumulate_patch_gradient<D>(mom, ja, jb, est_alpha, est_beta, acc);
+    else accumulate_patch<D>(mom, ja, jb, est_alpha, est_beta, acc);
+#ifdef SVOH_PHASE_STAMPS
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+#endif
+    SVOH_PASS_STAMP(4);
   }
 }
 
@@ -700,6 +855,14 @@ __device__ __forceinline__ void accumulate_camera_staged(
       }
     }
     if (vis) {
+#if SVOH_PIN_MOMENTS
+      if constexpr (LDS) {   // see accumulate_camera
+#pragma unroll
+        for (int k = 0; k < AccLayout<D>::NMOM; ++k)
+          if (!GONLY || k == 3 || k == 4 || k == 5 || k == 13 || k == 14) asm volatile("" : "+v"(mom[k]));
+      }
+#endif
+
       asm volatile("" ::: "memory");   // xyz_ref comes from LDS again here instead of living through the pixel loop
       const double2 xy2 = *reinterpret_cast<const double2*>(buf + 0 * 128 + lane * 2);
       const double z2 = buf[1 * 128 + lane * 2];
@@ -921,6 +1084,10 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
 #ifndef SVOH_ALIGN_MIN_WAVES_256
 #define SVOH_ALIGN_MIN_WAVES_256 2
 #endif
+// the lanes per patch a small problem gets by default, as a function of what fits (measured: DESIGN.md 4.2)
+#ifndef SVOH_ALIGN_ROWS_DEFAULT
+#define SVOH_ALIGN_ROWS_DEFAULT(fit) (fit)
+#endif
 
 // CLUSTER: the cluster mode's exchanges are compiled in (256-thread geometry only); the batch instantiation stays
 // free of them -- as run-time branches they cost the batch kernel 5 %.
@@ -928,17 +1095,22 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
 // switch: as a run-time flag the per-pixel branch, its float division and the weighted forms of the moments stayed in
 // the full pass of every launch (320 instructions per patch row against 106 in the gradient-only pass); the robust
 // instantiation in turn has no gradient-only pass (the weights change every iteration).
-template <int P, int NT, bool ILLUM, bool CLUSTER = false, bool ROBUST = false>
-__global__ __launch_bounds__(NT, (NT == 256 ? SVOH_ALIGN_MIN_WAVES_256 : (NT == 512 ? 2 : 4)))
+// LPP > 1: the rows geometry (accumulate_camera_rows: LPP lanes per patch), in the 512-thread workgroup of the latency
+// mode (few problems), at the same 256 registers.
+template <int P, int NT, bool ILLUM, bool CLUSTER = false, bool ROBUST = false, int LPP = 1>
+__global__ __launch_bounds__(NT, (NT == 256 ? SVOH_ALIGN_MIN_WAVES_256 : 2))
 void sparse_align_kernel(const AlignKernelArgs a)
 {
+  static_assert(LPP == 1 || (!CLUSTER && NT == 512 && LPP <= P), "rows geometry: 512 threads, no cluster mode");
+  static_assert(NT == 256 || NT == 512, "workgroups of 256 or 512 threads");
+  constexpr bool ROWS = LPP > 1;
   constexpr int D = ILLUM ? 8 : 6;
   constexpr int NACC = AccLayout<D>::NACC;
   constexpr int NW = NT / 64;
 
   // LDS-DMA staging of the workspace rows (accumulate_camera_staged) in the batch geometry; the wide
   // geometries keep their LDS for finer image levels and read the workspace with ordinary loads
-  constexpr bool STAGED = SVOH_ALIGN_STAGED && NT == 256;
+  constexpr bool STAGED = SVOH_ALIGN_STAGED && NT == 256 && !ROWS;
   extern __shared__ __align__(16) unsigned char lds_img[];
   __shared__ __align__(16) double s_stage[STAGED ? NW * kStageDoubles : 2];
   __shared__ double s_jc[SVOH_MAX_CAMS][kJacConsts];   // per-camera constants of jac_rows
@@ -1028,11 +1200,24 @@ void sparse_align_kernel(const AlignKernelArgs a)
     }
 #ifdef SVOH_PHASE_STAMPS
     for (int k = 0; k < 4; ++k) g_state.dbg[k] = 0;
+    for (int k = 0; k < 8; ++k) g_state.dbg2[k] = 0;
 #endif
     for (int l = 0; l < SVOH_MAX_LEVELS; ++l) { g_state.lvl_iters[l] = 0; g_state.lvl_n_meas[l] = 0; g_state.lvl_chi2[l] = 0.0; }
   }
   __syncthreads();
 
+  WsView ws = { a.wpk, a.slots, 0 };
+  if constexpr (NT == 512) {
+    if (a.ws_lds_bytes > 0) {   // this problem's rows (all cameras: consecutive slots from cams[0].feat_off on) in LDS
+      int n_local = 0;
+      for (int c = 0; c < n_cams; ++c) n_local += cams[c].n_features;
+      if (n_local * kWsPairs * 16 <= a.ws_lds_bytes) {   // (the host sized the area for the launch's largest problem)
+        ws.base = reinterpret_cast<double*>(lds_img + a.lds_img_bytes);
+        ws.slots = n_local;
+        ws.first = cams[0].feat_off;
+      }
+    }
+  }
   // ---- a-3 extractFeaturesSubset + a-4 precomputeBaseCaches (depth, xyz_ref) ----
   {
     int my_sel = 0;
@@ -1075,16 +1260,16 @@ void sparse_align_kernel(const AlignKernelArgs a)
         }
         a.wsel[gi] = sel ? 1 : 0;
         a.wvis[gi] = 0;
-        if (!sel) *reinterpret_cast<double2*>(ws_pair(a, 2, gi)) = make_double2(0.0, 0.0);
+        if (!sel) *reinterpret_cast<double2*>(ws_pair(ws, 2, gi)) = make_double2(0.0, 0.0);
         if (sel) {
           const double dx = pwx - cd.ref_pos[0];
           const double dy = pwy - cd.ref_pos[1];
           const double dz = pwz - cd.ref_pos[2];
           const double depth = sqrt(dx * dx + dy * dy + dz * dz);
           const Vec3 X = { fx_ * depth, fy_ * depth, fz_ * depth };
-          *reinterpret_cast<double2*>(ws_pair(a, 0, gi)) = make_double2(X.x, X.y);
-          *reinterpret_cast<double2*>(ws_pair(a, 1, gi)) = make_double2(X.z, pu);
-          *reinterpret_cast<double2*>(ws_pair(a, 2, gi)) = make_double2(pv, 1.0);
+          *reinterpret_cast<double2*>(ws_pair(ws, 0, gi)) = make_double2(X.x, X.y);
+          *reinterpret_cast<double2*>(ws_pair(ws, 1, gi)) = make_double2(X.z, pu);
+          *reinterpret_cast<double2*>(ws_pair(ws, 2, gi)) = make_double2(pv, 1.0);
           ++my_sel;
         }
       }
@@ -1178,24 +1363,32 @@ void sparse_align_kernel(const AlignKernelArgs a)
               off += ((rim.w * rim.h + 15) & ~15);
               cur.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); cur.pitch = cim.w;
               off += ((cim.w * cim.h + 15) & ~15);
-              if constexpr (STAGED)
+              if constexpr (ROWS) {
+                accumulate_camera_rows<P, (ROWS ? LPP : 2), D, NT, true, G>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                                            est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c],
+                                                                            acc_ref, nvis, changed);
+              } else if constexpr (STAGED)
                 accumulate_camera_staged<P, D, NT, true, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                             est_alpha, est_beta, robust, dist_jac, weight_scale, tid,
                                                             s_stage + wave * kStageDoubles, s_jc[c], acc_ref, nvis, changed);
               else
-                accumulate_camera<P, D, NT, true, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                accumulate_camera<P, D, NT, true, G>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                      est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c], acc_ref,
                                                      nvis, changed);
             } else {
               ImgView<false> ref, cur;
               ref.p = rim.data; ref.pitch = rim.pitch;
               cur.p = cim.data; cur.pitch = cim.pitch;
-              if constexpr (STAGED)
+              if constexpr (ROWS) {
+                accumulate_camera_rows<P, (ROWS ? LPP : 2), D, NT, false, G>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                                             est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c],
+                                                                             acc_ref, nvis, changed);
+              } else if constexpr (STAGED)
                 accumulate_camera_staged<P, D, NT, false, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                              est_alpha, est_beta, robust, dist_jac, weight_scale, tid,
                                                              s_stage + wave * kStageDoubles, s_jc[c], acc_ref, nvis, changed);
               else
-                accumulate_camera<P, D, NT, false, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                accumulate_camera<P, D, NT, false, G>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                       est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c], acc_ref,
                                                       nvis, changed);
             }
@@ -1205,8 +1398,11 @@ void sparse_align_kernel(const AlignKernelArgs a)
           double accg[D + 1];
 #pragma unroll
           for (int k = 0; k < D + 1; ++k) accg[k] = 0.0;
+          SVOH_OUTER_STAMP_BEGIN();
           run_cameras(std::true_type(), accg);
+          SVOH_OUTER_STAMP(5);   // includes the pieces 0..4 counted inside
           const int changed_here = __syncthreads_or(changed);
+          SVOH_OUTER_STAMP(6);
           if (changed_here && !cluster) {   // visibility moved: this iteration in full
             SVOH_STAMP_COUNT(5);
             light = false;
@@ -1374,10 +1570,10 @@ void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_al
 
 struct LaunchCfg { int nt; size_t lds; };
 
-template <int P, int NT, bool ILLUM, bool CLUSTER, bool ROBUST>
+template <int P, int NT, bool ILLUM, bool CLUSTER, bool ROBUST, int LPP = 1>
 static hipError_t launch_one(hipStream_t st, int grid, size_t lds, const AlignKernelArgs& args)
 {
-  auto kern = sparse_align_kernel<P, NT, ILLUM, CLUSTER, ROBUST>;
+  auto kern = sparse_align_kernel<P, NT, ILLUM, CLUSTER, ROBUST, LPP>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1385,19 +1581,23 @@ static hipError_t launch_one(hipStream_t st, int grid, size_t lds, const AlignKe
   return hipGetLastError();
 }
 
+// lpp: lanes per patch (1: a lane owns a patch; 2, 4, 8 <= P: the rows geometry, 512 threads)
 template <int P, bool ILLUM, bool ROBUST>
-static hipError_t launch_nt(hipStream_t st, int nt, int grid, size_t lds, const AlignKernelArgs& args)
+static hipError_t launch_nt(hipStream_t st, int nt, int lpp, int grid, size_t lds, const AlignKernelArgs& args)
 {
   if (args.cluster > 1) return launch_one<P, 256, ILLUM, true, ROBUST>(st, grid, lds, args);
-  switch (nt) {
-    case 256: return launch_one<P, 256, ILLUM, false, ROBUST>(st, grid, lds, args);
-    case 512: return launch_one<P, 512, ILLUM, false, ROBUST>(st, grid, lds, args);
-    default: return launch_one<P, 1024, ILLUM, false, ROBUST>(st, grid, lds, args);
+  if (nt == 256) return launch_one<P, 256, ILLUM, false, ROBUST>(st, grid, lds, args);
+  switch (lpp) {
+    case 2: return launch_one<P, 512, ILLUM, false, ROBUST, 2>(st, grid, lds, args);
+    case 4: return launch_one<P, 512, ILLUM, false, ROBUST, 4>(st, grid, lds, args);
+    case 8: if constexpr (P == 8) return launch_one<P, 512, ILLUM, false, ROBUST, 8>(st, grid, lds, args);
+    default: return launch_one<P, 512, ILLUM, false, ROBUST>(st, grid, lds, args);
   }
 }
 
 // cluster mode thresholds (measured): an exchange costs ~2 us, so below ~500 patches the barriers
 // cost more than the idle CUs; ~200 patches per workgroup is where the per-iteration time stops falling
+constexpr int kWsLdsMaxFeatures = 340;    // features of a problem whose workspace rows are kept in LDS (16 KB)
 constexpr int kClusterMinFeatures = 512;
 constexpr int kClusterFeaturesPerWorkgroup = 192;
 constexpr int kClusterMaxWorkgroups = 32;
@@ -1649,7 +1849,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   }
   args.queue = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(ctx->d_desc.ptr) + ctl_off);   // zero: uploaded with the descriptors
 #ifdef SVOH_PHASE_STAMPS
-  SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(sizeof(long long) * 12 * (size_t)n_problems));
+  SVOH_HIP_TRY(ctx, ctx->d_scratch0.reserve(sizeof(long long) * 20 * (size_t)n_problems));
   args.stamps = static_cast<long long*>(ctx->d_scratch0.ptr);
 #endif
 
@@ -1662,17 +1862,41 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // LDS-DMA workspace path beat one 512-thread workgroup: 384 problems 1.06 -> 0.82 ms)
   int nt = (n_desc >= ctx->num_cus) ? 256 : 512;
   if (max_feat_per_problem <= 256) nt = 256;
+  // Rows geometry (LPP lanes per patch, accumulate_camera_rows): a problem with so few patches that they do not give
+  // every SIMD of its compute unit a wave gets 2, 4 or 8 lanes per patch, as many as keep it at one wave per SIMD (256
+  // lanes) -- a lane's pass is then a chain of P / LPP rolling rows instead of P.  Measured (one problem, levels 4..2,
+  // kernel ms, lanes per patch 1 / 2 / 4 / 8): 60 patches of 8x8 0.151 / 0.131 / 0.119 / 0.126; 100 of 4x4 0.092 / 0.087 /
+  // 0.092; 180 of 4x4 0.092 / 0.095 / 0.098; 180 of 8x8 0.137 / 0.143 / 0.137 / 0.169; 2000 of 4x4 0.184 / 0.230 / 0.330:
+  // beyond one wave per SIMD the compute unit is bound by vector issue, and more lanes per patch are more instructions
+  // per patch (every lane repeats the projection, the Jacobian rows and two interpolated rows).
+  // SVOH_ALIGN_ROWS: lanes per patch; 0 or 1 = a lane per patch.
+  int rows = 1;
+  if (!cluster && n_desc < ctx->num_cus) {
+    while (rows * 2 <= opt->patch_size && rows * 2 <= 8 && (int64_t)max_feat_per_problem * rows * 2 <= 256) rows *= 2;
+    rows = SVOH_ALIGN_ROWS_DEFAULT(rows);
+  }
+  rows = SvohKnobs::or_default(ctx->knobs.align_rows, rows);
+  if (rows != 2 && rows != 4 && rows != 8) rows = 1;
+  if (rows > opt->patch_size || cluster) rows = 1;
+  if (rows > 1) nt = 512;
   nt = SvohKnobs::or_default(ctx->knobs.align_threads, nt);
   if (cluster) nt = 256;   // one workgroup per CU at most: all of them are resident together
-  if (nt != 256 && nt != 512 && nt != 1024) nt = 256;
+  if (nt != 256 && nt != 512) nt = 256;
+  if (nt == 256) rows = 1;
   // 256 threads: two workgroups per CU, each with <= 29.5 KB of static LDS (reduction scratch, the 24 KB LDS-DMA staging
   // area of the workspace rows) -> 51 KB for images: levels 4, 3 and 2 of a 640x480 pyramid side by side (50 400 B)
-  size_t lds = (nt == 256) ? 52224 : (nt == 512 ? 78 * 1024 : 153856);
+  size_t lds = (nt == 256) ? 52224 : 78 * 1024;
   lds = (size_t)SvohKnobs::or_default(ctx->knobs.align_lds, (int)lds);
   // 160 KB per workgroup minus the kernel's static LDS
   const size_t lds_cap = (nt == 256 && SVOH_ALIGN_STAGED) ? 163840 - 32768 : 153856;
   if (lds > lds_cap) lds = lds_cap;
-  args.lds_img_bytes = (int32_t)lds;
+  // a small problem's feature workspace in LDS, behind the image area (512-thread geometry: 78 KB hold the 50 KB of the
+  // levels 4..2 of a 640x480 pair and 16 KB of rows; the next finer level would not fit either way)
+  args.ws_lds_bytes = 0;
+  if (nt == 512 && !cluster && max_feat_per_problem <= kWsLdsMaxFeatures && lds >= (size_t)kWsLdsMaxFeatures * kWsPairs * 16 + 4096) {
+    args.ws_lds_bytes = ((max_feat_per_problem > 0 ? max_feat_per_problem : 1) * kWsPairs * 16 + 15) & ~15;
+  }
+  args.lds_img_bytes = (int32_t)(lds - (size_t)args.ws_lds_bytes);   // the launch still asks for all of `lds`
 
   const bool illum = opt->estimate_illumination_gain || opt->estimate_illumination_offset;
   // resident workgroups per CU: 256-thread groups at 256 VGPRs -> 2; larger groups -> 1
@@ -1684,13 +1908,19 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   const int ev_slot = (int)(ctx->align_timed_launches % svoh_ctx::kAlignEventRing);
   if (timed) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_start[ev_slot], ctx->stream));
   const bool robust = opt->robustification != 0;
+#ifdef SVOH_DEV_ONLY_PLAIN   // development builds only (scripts/kernel_resources.sh, quick A/B libraries): the 4x4 / 8x8 kernels without illumination terms and robust weights
+  if (robust || illum) return set_error(ctx, SVOH_ERR_UNSUPPORTED, "development build: plain kernels only");
+  e = opt->patch_size == 4 ? launch_nt<4, false, false>(ctx->stream, nt, rows, grid, lds, args)
+                           : launch_nt<8, false, false>(ctx->stream, nt, rows, grid, lds, args);
+#else
   if (opt->patch_size == 4) {
-    if (robust) e = illum ? launch_nt<4, true, true>(ctx->stream, nt, grid, lds, args) : launch_nt<4, false, true>(ctx->stream, nt, grid, lds, args);
-    else e = illum ? launch_nt<4, true, false>(ctx->stream, nt, grid, lds, args) : launch_nt<4, false, false>(ctx->stream, nt, grid, lds, args);
+    if (robust) e = illum ? launch_nt<4, true, true>(ctx->stream, nt, rows, grid, lds, args) : launch_nt<4, false, true>(ctx->stream, nt, rows, grid, lds, args);
+    else e = illum ? launch_nt<4, true, false>(ctx->stream, nt, rows, grid, lds, args) : launch_nt<4, false, false>(ctx->stream, nt, rows, grid, lds, args);
   } else {
-    if (robust) e = illum ? launch_nt<8, true, true>(ctx->stream, nt, grid, lds, args) : launch_nt<8, false, true>(ctx->stream, nt, grid, lds, args);
-    else e = illum ? launch_nt<8, true, false>(ctx->stream, nt, grid, lds, args) : launch_nt<8, false, false>(ctx->stream, nt, grid, lds, args);
+    if (robust) e = illum ? launch_nt<8, true, true>(ctx->stream, nt, rows, grid, lds, args) : launch_nt<8, false, true>(ctx->stream, nt, rows, grid, lds, args);
+    else e = illum ? launch_nt<8, true, false>(ctx->stream, nt, rows, grid, lds, args) : launch_nt<8, false, false>(ctx->stream, nt, rows, grid, lds, args);
   }
+#endif
   if (e != hipSuccess)
     return set_error(ctx, SVOH_ERR_HIP, "sparse_align launch failed: %s", hipGetErrorString(e));
   if (S > 1 && !cluster) {
@@ -1713,13 +1943,15 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   }
 #ifdef SVOH_PHASE_STAMPS
   {
-    std::vector<long long> h((size_t)n_problems * 12);
+    std::vector<long long> h((size_t)n_problems * 20);
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(h.data(), args.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    double sum[12] = {0};
-    for (int p = 0; p < n_problems; ++p) for (int k = 0; k < 12; ++k) sum[k] += (double)h[(size_t)p * 12 + k];
+    double sum[20] = {0};
+    for (int p = 0; p < n_problems; ++p) for (int k = 0; k < 20; ++k) sum[k] += (double)h[(size_t)p * 20 + k];
     fprintf(stderr, "[stamps] one-lane step: set-up %.0f solve %.0f update %.0f camera poses %.0f\n", sum[8] / n_problems, sum[9] / n_problems,
             sum[10] / n_problems, sum[11] / n_problems);
+    fprintf(stderr, "[stamps] inside the passes (thread 0): set-up %.0f row arrival %.0f projection %.0f pixels %.0f Jacobian rows + map %.0f; gradient-only passes as a whole %.0f, the vote's barrier behind them %.0f\n", sum[12] / n_problems,
+            sum[13] / n_problems, sum[14] / n_problems, sum[15] / n_problems, sum[16] / n_problems, sum[17] / n_problems, sum[18] / n_problems);
     fprintf(stderr, "[stamps] n=%d nt=%d avg cycles/block: base %.0f stage %.0f patch %.0f reduce %.0f serial %.0f total %.0f; "
             "gradient-only passes kept %.2f / discarded %.2f per problem\n",
             n_problems, nt, sum[0] / n_problems, sum[1] / n_problems, sum[2] / n_problems, sum[3] / n_problems,

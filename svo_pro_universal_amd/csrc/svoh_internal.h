@@ -91,6 +91,7 @@ struct SvohKnobs {
   int align_cluster_test_absent = kKnobUnset; // SVOH_ALIGN_CLUSTER_TEST_ABSENT: a partner that never arrives (libsvo_hip_testhooks.so only)
 #endif
   int align_threads = kKnobUnset;             // SVOH_ALIGN_THREADS: 256 / 512 / 1024
+  int align_rows = kKnobUnset;                // SVOH_ALIGN_ROWS: 0 / 1 rows geometry of the alignment (P lanes per patch; 512 / 1024 threads)
   int align_lds = kKnobUnset;                 // SVOH_ALIGN_LDS: bytes of LDS for image levels
   int align_wg_per_cu = kKnobUnset;           // SVOH_ALIGN_WG_PER_CU
   int kernel_timing = kKnobUnset;             // SVOH_KERNEL_TIMING: 1 = bracket every kernel with an event pair (svoh_set_kernel_timing)

@@ -165,10 +165,14 @@ def test_ragged_batch_equals_singles(gpu_ctx, oracle_lib):
         assert helpers.se3_max_abs_diff(rg.T_icur_iref, ro.T_icur_iref) < TOL_POSE
 
 
-@pytest.mark.parametrize("nt", ["256", "512", "1024"])
-def test_all_workgroup_geometries(gpu_ctx, oracle_lib, nt, monkeypatch):
+@pytest.mark.parametrize("nt,rows", [("256", "0"), ("512", "0"), ("512", "2"), ("512", "4"), ("512", "8")])
+def test_all_workgroup_geometries(gpu_ctx, oracle_lib, nt, rows, monkeypatch):
+    """One lane per patch (256 / 512 threads) and the rows geometry (2, 4 or -- 8x8 patches -- 8 lanes per patch, 512
+    threads) against the oracle.  (A small single problem runs in the rows geometry by default, so the other tests of this
+    file exercise it too.)"""
     orc = oracle_lib
     monkeypatch.setenv("SVOH_ALIGN_THREADS", nt)
+    monkeypatch.setenv("SVOH_ALIGN_ROWS", rows)
     gpu_ctx.reload_knobs()
     sc = helpers.small_scene(37, n=700, border_features=50)
     opb, gpb, keep = both(gpu_ctx, orc, [sc])
