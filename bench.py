@@ -42,6 +42,7 @@ def algorithmic_bytes(P, D, patch_iters, n_sel_levels):
 
 
 FP64_PEAK_TFLOPS = 63.8   # measured: tools/svoh_microbench, independent v_fma_f64 on every SIMD (profiles/r02_fetch_calibration.json)
+FP64_VENDOR_PEAK_TFLOPS = 78.6   # the vendor's vector fp64 figure for the part (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
 
 
 def pmc_summary(workload_key):
@@ -88,6 +89,29 @@ def roofline(kernel, kernel_ms, alg_bytes, workload_key, **extra):
             c = cs.get("counters_mean_per_dispatch", {})
             if "SQ_INSTS_VALU" in c:
                 r["compute_side"]["valu_wave_instructions_per_launch"] = c["SQ_INSTS_VALU"]
+            # fp64 arithmetic against BOTH peaks: the one measured on these boxes with independent v_fma_f64 on every
+            # SIMD (tools/svoh_microbench: 63.8 TFLOP/s) and the vendor figure (78.6); the flop count is the profiled
+            # launch's, the time the live one
+            flop = cs.get("fp64_flop_per_dispatch_upper_bound")
+            if flop:
+                tf = flop / t / 1e12
+                r["compute_side"]["fp64_tflops_live"] = tf
+                r["compute_side"]["fp64_fraction_of_measured_peak_63p8_live"] = tf / FP64_PEAK_TFLOPS
+                r["compute_side"]["fp64_fraction_of_vendor_peak_78p6_live"] = tf / FP64_VENDOR_PEAK_TFLOPS
+            # which resource is nearest its ceiling (what `bound` names): the three candidates with their fractions
+            cand = {"hbm": r["frac"]}
+            if flop:
+                cand["fp64 VALU issue"] = r["compute_side"]["fp64_fraction_of_measured_peak_63p8_live"]
+            busy, waiting = cs.get("valu_busy_fraction_of_simd_time"), cs.get("SQ_WAIT_ANY_share_of_wave_cycles")
+            r["ceilings"] = dict(cand, valu_busy=busy, waves_waiting_share=waiting)
+            top = max(cand, key=lambda k: cand[k])
+            if busy is not None and waiting is not None and waiting >= 0.40 and busy < 0.60:
+                # no throughput resource past 60 %: the waves spend their time waiting on their own dependent chains
+                r["bound"] = "latency (waves wait %.0f %% of their cycles; VALU busy %.0f %%, %s %.2f)" % (
+                    100 * waiting, 100 * busy, top, cand[top])
+            else:
+                r["bound"] = "%s (%.2f of its ceiling%s)" % (top, cand[top], "; VALU busy %.0f %%" % (100 * busy) if busy is not None else "")
+            r["bound_of_the_unit_in_SURVEY_8d"] = "hbm"   # the roofline the metric is priced against; `peak` / `frac` refer to it
     else:
         r.update({"achieved": alg, "frac": alg / HBM_PEAK_GBS, "traffic": None,
                   "frac_basis": "algorithmic bytes (no PMC summary committed for this workload key)"})
@@ -1116,11 +1140,7 @@ def bench_launch_check(args, dist, rank, world, comm_dev):
         units += 1000 + rank
     barrier()
     elapsed, total = du.combine(dist, world, time.perf_counter() - t0, units, comm_dev)
-    ranks_seen = 1
-    if world > 1:
-        t = torch.ones(1, dtype=torch.int64, device=comm_dev)
-        dist.all_reduce(t)
-        ranks_seen = int(t.item())
+    ranks_seen = du.ranks_in_collective(dist, world, comm_dev)
     return {"metric": "launch check (empty steps)", "value": total / max(elapsed, 1e-9), "unit": "units/s",
             "ms_per_step": 1e3 * elapsed / max(1, args.steps), "dtype": "none", "units_total": total,
             "ranks_in_collective": ranks_seen, "backend": dist.get_backend() if world > 1 else None,
@@ -1171,10 +1191,13 @@ def main(argv=None):
                "align-split": bench_align_split, "align-c4": bench_align_c4, "stereo": bench_stereo,
                "launch-check": lambda a, c, d, r, w, dv, cd: bench_launch_check(a, d, r, w, cd)}[args.workload](
             args, ctx, dist, rank, world, dev, comm_dev)
+        ranks_seen = du.ranks_in_collective(dist, world, comm_dev)   # a collective: every rank calls it
         if rank == 0:
             out.setdefault("scaling", "weak")
             out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
                         "vs_baseline": None, "data": "synthetic"})
+            out.setdefault("ranks_in_collective", ranks_seen)
+            out.setdefault("backend", dist.get_backend() if world > 1 else None)
             emit(out)
         if world > 1:
             dist.barrier()
@@ -1187,11 +1210,14 @@ def main(argv=None):
     if P == 4 and not args.no_secondary and not args.problems and N == 2000 and args.min_level == 0 and args.max_level == 4:
         sec, _ = run_align(args, ctx, dist, rank, world, dev, comm_dev, 8, N, B, shared, False, steps=max(3, args.steps // 2))
         if rank == 0:
-            out["secondary"] = {k: sec[k] for k in ("value", "unit", "kernel_ms", "ms_per_step", "patch_iterations_per_step",
+            out["secondary"] = {k: sec[k] for k in ("value", "unit", "kernel_ms", "kernel_ms_min", "kernel_ms_max", "ms_per_step", "patch_iterations_per_step",
                                                     "patch_iterations_per_s", "solver_failures", "roofline")}
             out["secondary"]["config"] = sec["config"]
             out["secondary"]["steps"] = max(3, args.steps // 2)
+    ranks_seen = du.ranks_in_collective(dist, world, comm_dev)   # a collective: every rank calls it
     if rank == 0:
+        out["ranks_in_collective"] = ranks_seen
+        out["backend"] = dist.get_backend() if world > 1 else None
         emit(out)
     if world > 1:
         dist.barrier()
@@ -1221,6 +1247,7 @@ def run_align(args, ctx, dist, rank, world, dev, comm_dev, P, N, B, shared, with
     # number of queued results).  Kernel times come from the library's per-launch HIP events.
     t0 = time.perf_counter()
     kernel_ms_sum, n_timed = 0.0, 0
+    kernel_ms_all = []
     hist = (ctypes.c_float * 32)()
     n_hist = ctypes.c_int()
     done = 0
@@ -1235,6 +1262,7 @@ def run_align(args, ctx, dist, rank, world, dev, comm_dev, P, N, B, shared, with
             elapsed = time.perf_counter() - t0
         ctx._check(ctx.lib.svoh_sparse_align_kernel_ms_history(ctx.h, chunk, hist, ctypes.byref(n_hist)))
         kernel_ms_sum += sum(hist[i] for i in range(n_hist.value))
+        kernel_ms_all += [float(hist[i]) for i in range(n_hist.value)]
         n_timed += n_hist.value
     kernel_ms_sum *= steps / float(max(1, n_timed))
 
@@ -1292,6 +1320,9 @@ def run_align(args, ctx, dist, rank, world, dev, comm_dev, P, N, B, shared, with
             "patch_iterations_per_step": patch_iters,
             "patch_iterations_per_s": patch_iters * world * steps / elapsed,
             "kernel_ms": kernel_ms,
+            "kernel_ms_min": min(kernel_ms_all) if kernel_ms_all else None,
+            "kernel_ms_max": max(kernel_ms_all) if kernel_ms_all else None,
+            "kernel_ms_launches_timed": len(kernel_ms_all),
             # median 1e-4 m: what Gauss-Newton on bilinearly rendered 640x480 scenes resolves; the tail (max) belongs to
             # scenes with little texture under the patches -- the algorithm's answer, not the kernel's: GPU and oracle
             # agree to 1e-15 on every one of them (tests/test_sparse_align_gpu.py)

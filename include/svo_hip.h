@@ -201,7 +201,10 @@ typedef struct svoh_align_camera {
   svoh_frame_t cur_frame;
   svoh_camera cam;           /* Frame::cam() of this camera index */
   svoh_se3 ref_T_imu_cam;    /* ref_frame.T_imu_cam() */
-  svoh_se3 ref_T_cam_imu;    /* ref_frame.T_cam_imu() */
+  svoh_se3 ref_T_cam_imu;    /* ref_frame.T_cam_imu(): MUST be the inverse of ref_T_imu_cam (as in a reference Frame, which
+                                derives both from one transformation; checked to 1e-9, SVOH_ERR_INVALID_ARGUMENT otherwise).
+                                Only its rotation is read: the Jacobian rows take T_cam_imu * (T_imu_cam * xyz_ref) of
+                                frame.h:342-357 to be xyz_ref itself */
   svoh_se3 cur_T_cam_imu;    /* cur_frame.T_cam_imu() */
   double ref_pos[3];         /* ref_frame.pos() = T_world_cam().getPosition() */
   int32_t n_features;        /* ref_frame.num_features_ */

@@ -76,6 +76,7 @@ struct AlignKernelArgs {
   uint8_t* wvis;                        // visibility of the last evaluation
   svoh_align_options opt;
   int32_t lds_img_bytes;                // dynamic LDS available for image staging
+  int32_t lds_two_per_cu;               // host side only: the launch counts on two workgroups per compute unit (launch_one sizes the image area for it)
   int32_t ws_lds_bytes;                 // > 0: the feature workspace of a (small) problem lives in LDS behind the image area (512-thread geometry)
   int32_t eval_level;                   // <0: full run; >=0: evaluate once at that level
   double* eval_out;                     // [64 H][8 g][chi2][n_meas] for eval mode
@@ -1570,10 +1571,30 @@ void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_al
 
 struct LaunchCfg { int nt; size_t lds; };
 
+constexpr size_t kLdsPerCu = 163840;   // gfx950: 160 KB per compute unit
 template <int P, int NT, bool ILLUM, bool CLUSTER, bool ROBUST, int LPP = 1>
-static hipError_t launch_one(hipStream_t st, int grid, size_t lds, const AlignKernelArgs& args)
+static hipError_t launch_one(hipStream_t st, int grid, size_t lds, AlignKernelArgs args)
 {
   auto kern = sparse_align_kernel<P, NT, ILLUM, CLUSTER, ROBUST, LPP>;
+  if (NT == 256 && args.lds_two_per_cu) {
+    // Two workgroups per compute unit is what the batch geometry is built on, and the budget is tight (28-29.5 KB of
+    // static LDS + 51 KB of images = 79-80.5 of the 80 KB a workgroup may have).  The static part is asked of the code
+    // object, not assumed: if it ever grows, the image area shrinks (a level fewer in LDS) instead of the second
+    // workgroup silently not fitting -- half the throughput with every test green.
+    static size_t static_lds = 0;   // per instantiation; the same for every context (one code object)
+    if (static_lds == 0) {
+      hipFuncAttributes attr;
+      hipError_t ea = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern));
+      if (ea != hipSuccess) return ea;
+      static_lds = attr.sharedSizeBytes ? attr.sharedSizeBytes : 1;
+    }
+    const size_t room = kLdsPerCu / 2 > static_lds ? (kLdsPerCu / 2 - static_lds) & ~(size_t)15 : 0;
+    if (lds > room) {
+      args.lds_img_bytes -= (int32_t)(lds - room);
+      if (args.lds_img_bytes < 0) args.lds_img_bytes = 0;
+      lds = room;
+    }
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1766,6 +1787,18 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
         dc.cur[l] = l < fc->n_levels ? fc->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
       }
       dc.cam = cam.cam;
+      {
+        // The Jacobian rows take p_in_cam = T_cam_imu * (T_imu_cam * xyz_ref) to be xyz_ref itself (jac_rows): the two
+        // extrinsic transformations of the reference frame must be inverses of each other, as they are in a
+        // reference Frame (frame.h:342-357 builds both from one T_cam_imu).  A pair that is not would silently get
+        // a different Jacobian than the reference computes: refused instead.
+        const Rigid I = mul(load_rigid(cam.ref_T_cam_imu), load_rigid(cam.ref_T_imu_cam));
+        const double dev = fmax(fmax(fabs(fabs(I.q.w) - 1.0), fmax(fabs(I.q.x), fmax(fabs(I.q.y), fabs(I.q.z)))),
+                                fmax(fabs(I.t.x), fmax(fabs(I.t.y), fabs(I.t.z))));
+        if (!(dev <= 1e-9))
+          return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT,
+                           "problem %d camera %d: ref_T_cam_imu is not the inverse of ref_T_imu_cam (deviation %.3g)", p, c, dev);
+      }
       dc.ref_T_imu_cam = cam.ref_T_imu_cam;
       dc.ref_T_cam_imu = cam.ref_T_cam_imu;
       dc.cur_T_cam_imu = cam.cur_T_cam_imu;
@@ -1883,9 +1916,11 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   if (cluster) nt = 256;   // one workgroup per CU at most: all of them are resident together
   if (nt != 256 && nt != 512) nt = 256;
   if (nt == 256) rows = 1;
-  // 256 threads: two workgroups per CU, each with <= 29.5 KB of static LDS (reduction scratch, the 24 KB LDS-DMA staging
-  // area of the workspace rows) -> 51 KB for images: levels 4, 3 and 2 of a 640x480 pyramid side by side (50 400 B)
+  // 256 threads: two workgroups per CU, each with <= 29 KB of static LDS (reduction scratch, the 24 KB LDS-DMA staging
+  // area of the workspace rows) -> 51 KB for images: levels 4, 3 and 2 of a 640x480 pyramid side by side (50 400 B);
+  // launch_one trims the image area to what the instantiation's static LDS really leaves of half a compute unit
   size_t lds = (nt == 256) ? 52224 : 78 * 1024;
+  args.lds_two_per_cu = (nt == 256 && !cluster && ctx->knobs.align_lds == kKnobUnset && ctx->knobs.align_wg_per_cu == kKnobUnset) ? 1 : 0;
   lds = (size_t)SvohKnobs::or_default(ctx->knobs.align_lds, (int)lds);
   // 160 KB per workgroup minus the kernel's static LDS
   const size_t lds_cap = (nt == 256 && SVOH_ALIGN_STAGED) ? 163840 - 32768 : 153856;

@@ -45,3 +45,14 @@ def combine(dist, world, elapsed_s, units, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), int(u.item())
+
+
+def ranks_in_collective(dist, world, device=None):
+    """How many ranks the process group's all-reduce really spans: a sum of ones (1 without a group).  Every
+    multi-rank benchmark line carries it, so that a scaling run shows that RCCL saw N ranks."""
+    if world == 1 or dist is None:
+        return 1
+    import torch
+    t = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())

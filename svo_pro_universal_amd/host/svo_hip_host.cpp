@@ -6,7 +6,9 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
+#include <unordered_map>
 
 namespace svo_hip {
 
@@ -204,6 +206,30 @@ void DeviceFrameCache::clear()
 }
 
 // ---- DepthFilterHip -------------------------------------------------------------
+// The context has ONE deferred matcher section.  A seed update sent off with updateSeedsAsync holds it until it is
+// finished; anything else of this layer that needs the section on the same context (ReprojectorHip::reprojectFrames)
+// finishes that update first instead of failing with "a deferred section is already open": the owner is looked up here.
+namespace {
+std::mutex g_async_seed_mu;
+std::unordered_map<svoh_ctx*, DepthFilterHip*> g_async_seed_owner;
+}  // namespace
+
+void finishPendingSeedUpdate(svoh_ctx* ctx)
+{
+  DepthFilterHip* owner = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_async_seed_mu);
+    auto it = g_async_seed_owner.find(ctx);
+    if (it != g_async_seed_owner.end()) owner = it->second;
+  }
+  if (owner) owner->finishUpdateSeedsEarly();
+}
+
+DepthFilterHip::~DepthFilterHip()
+{
+  if (async_open_) { try { (void)finishUpdateSeedsNow(); } catch (...) {} }
+}
+
 DepthFilterHip::DepthFilterHip(svoh_ctx* ctx, const DepthFilterOptions& options) : ctx_(ctx), options_(options)
 {
   if (!ctx_) throw std::runtime_error("DepthFilterHip: NULL svoh_ctx (no CPU fallback exists)");
@@ -241,7 +267,7 @@ size_t DepthFilterHip::updateSeeds(const std::vector<FramePtr>& ref_frames_with_
 void DepthFilterHip::updateSeedsAsync(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame)
 {
   if (!cur_frame) throw std::runtime_error("DepthFilterHip::updateSeeds: NULL current frame");
-  if (async_open_) throw std::runtime_error("DepthFilterHip::updateSeedsAsync: the previous update has not been finished");
+  if (async_open_ || finished_early_) throw std::runtime_error("DepthFilterHip::updateSeedsAsync: the previous update has not been finished");
   px_error_angle_ = updateSeedPxErrorAngle(*cur_frame);
   have_px_error_angle_ = true;
   Pending& q = pending_;
@@ -280,6 +306,7 @@ void DepthFilterHip::updateSeedsAsync(const std::vector<FramePtr>& ref_frames_wi
   // goes on; finishUpdateSeeds waits for it and puts the results where the reference's loop leaves them
   if (svoh_matcher_begin_deferred(ctx_) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_begin_deferred: ") + svoh_last_error_string(ctx_));
   async_open_ = true;
+  { std::lock_guard<std::mutex> lock(g_async_seed_mu); g_async_seed_owner[ctx_] = this; }
   int rc = svoh_update_seeds_batch(ctx_, &matcher_options_, &o, static_cast<int>(q.refs.size()), q.refs.data(), &cur, &fb,
                                    q.state.data(), q.success.data(), last_results_.data(), &q.n_success);
   if (rc == SVOH_OK) rc = svoh_matcher_flush(ctx_);
@@ -287,16 +314,34 @@ void DepthFilterHip::updateSeedsAsync(const std::vector<FramePtr>& ref_frames_wi
     const std::string msg = svoh_last_error_string(ctx_);
     (void)svoh_matcher_collect(ctx_);
     async_open_ = false;
+    { std::lock_guard<std::mutex> lock(g_async_seed_mu); g_async_seed_owner.erase(ctx_); }
     q.frames.clear();
     throw std::runtime_error("svoh_update_seeds_batch: " + msg);
   }
 }
 
+void DepthFilterHip::finishUpdateSeedsEarly()
+{
+  if (!async_open_) return;
+  early_count_ = finishUpdateSeedsNow();
+  finished_early_ = true;
+}
+
 size_t DepthFilterHip::finishUpdateSeeds()
+{
+  if (finished_early_) {   // someone needed the context's deferred section in between (finishPendingSeedUpdate)
+    finished_early_ = false;
+    return early_count_;
+  }
+  return finishUpdateSeedsNow();
+}
+
+size_t DepthFilterHip::finishUpdateSeedsNow()
 {
   Pending& q = pending_;
   if (!async_open_) { q.frames.clear(); return 0; }
   async_open_ = false;
+  { std::lock_guard<std::mutex> lock(g_async_seed_mu); g_async_seed_owner.erase(ctx_); }
   if (svoh_matcher_collect(ctx_) != SVOH_OK) { q.frames.clear(); throw std::runtime_error(std::string("svoh_matcher_collect: ") + svoh_last_error_string(ctx_)); }
   // scatter back in place (ref_frame.invmu_sigma2_a_b_vec_.col(i), type_vec_[i]); a frame's block is the features
   // it had when the update was queued (features are only ever appended)
@@ -941,6 +986,11 @@ struct ReprojTiming {   // SVOH_REPROJ_TIMING=1: mean host / device split of rep
 thread_local ReprojTiming g_reproj_timing;
 }  // namespace
 
+static bool same_pose(const Transformation& a, const Transformation& b)
+{
+  return a.q.w == b.q.w && a.q.x == b.q.x && a.q.y == b.q.y && a.q.z == b.q.z && a.t.x == b.t.x && a.t.y == b.t.y && a.t.z == b.t.z;
+}
+
 void ReprojectorHip::enqueueCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const Transformation* T_iref_world,
                                                 int align_result_index)
 {
@@ -952,7 +1002,7 @@ void ReprojectorHip::enqueueCandidateProjection(const FramePtr& cur_frame, const
     svoh_se3 T;
     svoh::store_rigid(svoh::inverse(kf->T_f_w_), T);
     proj_T_world_kf_.push_back(T);
-    proj_kf_off_.emplace_back(kf.get(), proj_kind_.size());
+    proj_kf_off_.push_back(ProjKf{ kf.get(), kf->id_, proj_kind_.size(), kf->num_features_, kf->T_f_w_ });
     for (size_t i = 0; i < kf->num_features_; ++i) {
       const PointPtr& lm = i < kf->landmark_vec_.size() ? kf->landmark_vec_[i] : PointPtr();
       if (lm) {                                       // getCandidate: the landmark's position ...
@@ -982,6 +1032,7 @@ void ReprojectorHip::enqueueCandidateProjection(const FramePtr& cur_frame, const
   }
   if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_project_candidates_enqueue: ") + svoh_last_error_string(ctx_));
   proj_frame_ = cur_frame.get();
+  proj_frame_id_ = cur_frame->id_;
   proj_collected_ = false;
 }
 
@@ -1000,7 +1051,8 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
 {
   const double ts0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   // device projection queued for this frame (enqueueCandidateProjection): take it out of the context now
-  const bool have_proj = proj_frame_ == cur_frame.get();
+  // (pointer AND id: a frame destroyed with its projection still queued may be followed by a new one at the same address)
+  const bool have_proj = proj_frame_ == cur_frame.get() && proj_frame_id_ == cur_frame->id_;
   if (have_proj && !proj_collected_) {
     proj_px_.resize(2 * proj_kind_.size()); proj_visible_.resize(proj_kind_.size());
     if (svoh_project_candidates_collect(ctx_, static_cast<int>(proj_kind_.size()), proj_px_.data(), proj_visible_.data()) != SVOH_OK)
@@ -1031,14 +1083,27 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
   for (const FramePtr& ref_frame : visible_kfs) {
     const svoh::Rigid T_world_ref = svoh::inverse(ref_frame->T_f_w_);
     // this keyframe's slice of the device projection, if it was part of it
+    // ... and only as far as it still describes the keyframe: the projection took a snapshot of the keyframe's pose, of
+    // the landmark positions and of the seeds' inverse depths when it was queued.  A keyframe whose pose has moved
+    // since, a feature appended since, a landmark or seed that has changed since is computed here instead.
     long proj_off = -1;
+    size_t proj_n = 0;
     if (have_proj)
-      for (const auto& ko : proj_kf_off_) if (ko.first == ref_frame.get()) { proj_off = static_cast<long>(ko.second); break; }
+      for (const ProjKf& ko : proj_kf_off_)
+        if (ko.frame == ref_frame.get() && ko.id == ref_frame->id_ && same_pose(ko.T_f_w, ref_frame->T_f_w_)) {
+          proj_off = static_cast<long>(ko.offset); proj_n = ko.n_features; break;
+        }
     auto get_candidate = [&](size_t i, reprojector::Candidate& candidate) -> bool {
-      if (proj_off < 0) return reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref);
+      if (proj_off < 0 || i >= proj_n) return reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref);
       const size_t at = static_cast<size_t>(proj_off) + i;
-      if (!proj_visible_[at]) return false;
       const PointPtr lm = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i] : nullptr;
+      {
+        bool fresh;
+        if (lm) { const svoh::Vec3 p = lm->pos(); fresh = proj_kind_[at] == 0 && p.x == proj_v_[3 * at] && p.y == proj_v_[3 * at + 1] && p.z == proj_v_[3 * at + 2]; }
+        else fresh = proj_kind_[at] == 1 && (4 * i < ref_frame->invmu_sigma2_a_b_vec_.size() ? ref_frame->invmu_sigma2_a_b_vec_[4 * i] : 1.0) == proj_mu_[at];
+        if (!fresh) return reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref);
+      }
+      if (!proj_visible_[at]) return false;
       candidate = reprojector::Candidate();
       candidate.ref_frame = ref_frame; candidate.ref_index = i;
       candidate.cur_px[0] = proj_px_[2 * at]; candidate.cur_px[1] = proj_px_[2 * at + 1];
@@ -1324,6 +1389,9 @@ struct SpeculativeMatches {
       throw std::runtime_error(msg);
     };
     const bool both = direct.size() && seeds.size();
+    // a seed update still in flight (DepthFilterHip::updateSeedsAsync) holds the context's one deferred section: a batch
+    // issued now would be queued INTO it instead of running -- finish the update first
+    finishPendingSeedUpdate(ctx);
     if (both && svoh_matcher_begin_deferred(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_begin_deferred: ") + svoh_last_error_string(ctx));
     svoh_feature_batch fbd{}, fbs{};
     const double tr0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;

@@ -242,11 +242,18 @@ class DepthFilterHip {
   // not be touched by anything that reads or writes their seeds until the update is finished -- appending features to
   // them is fine); finishUpdateSeeds waits for it, writes the states and types back and returns the success count.
   // Nothing in a frame's chain needs the updated seeds before the NEXT frame's alignment, so a caller that finishes
-  // there takes the seed update (kernel + round trip) off the per-frame critical path.  No other deferred matcher
-  // section can be opened on the context in between (ReprojectorHip opens one: finish first).
+  // there takes the seed update (kernel + round trip) off the per-frame critical path.  The update holds the context's
+  // ONE deferred matcher section: a ReprojectorHip::reprojectFrames on the same context in between finishes it first
+  // (finishPendingSeedUpdate; the later finishUpdateSeeds then only hands out the count).  Caveat: anything that
+  // synchronises the context's stream in between also waits for the update's kernel -- on a keyframe the detector
+  // (svoh_detect_features) and frame releases do, so the saving is a non-keyframe saving.
   void updateSeedsAsync(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame);
   size_t finishUpdateSeeds();
+  void finishUpdateSeedsEarly();   // what finishPendingSeedUpdate calls
   bool updatePending() const { return async_open_; }
+  ~DepthFilterHip();
+  DepthFilterHip(const DepthFilterHip&) = delete;
+  DepthFilterHip& operator=(const DepthFilterHip&) = delete;
   svoh_matcher_options& getMatcherOptions() { return matcher_options_; }
   // Matcher::MatchResult of every seed of the last call, in (frame, feature) order
   const std::vector<int32_t>& lastMatchResults() const { return last_results_; }
@@ -268,7 +275,13 @@ class DepthFilterHip {
     int32_t n_success = 0;
   } pending_;
   bool async_open_ = false;
+  bool finished_early_ = false;
+  size_t early_count_ = 0;
+  size_t finishUpdateSeedsNow();
 };
+
+// Finishes the seed update that a DepthFilterHip has in flight on this context, if there is one (see updateSeedsAsync).
+void finishPendingSeedUpdate(svoh_ctx* ctx);
 
 // ---------------------------------------------------------------------------
 // Seam 3: KLT.  Mirrors feature_alignment::alignPyr2DVec
@@ -459,8 +472,12 @@ class ReprojectorHip {
   bool speculate_unconverged_ = false;   // was the unconverged-seed pass reached on the previous frame?
   // queued / collected device projection: per keyframe the offset of its first feature in the flat arrays
   const Frame* proj_frame_ = nullptr;
+  int proj_frame_id_ = 0;
   bool proj_collected_ = false;
-  std::vector<std::pair<const Frame*, size_t>> proj_kf_off_;
+  // a keyframe of the queued projection as it was when queued: identity (address and id), its slice of the flat arrays,
+  // how many features the slice covers, the pose it was projected with
+  struct ProjKf { const Frame* frame; int id; size_t offset; size_t n_features; Transformation T_f_w; };
+  std::vector<ProjKf> proj_kf_off_;
   std::vector<uint8_t> proj_kind_, proj_visible_;
   std::vector<int32_t> proj_kf_;
   std::vector<double> proj_v_, proj_mu_, proj_px_;

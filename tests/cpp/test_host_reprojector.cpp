@@ -461,6 +461,59 @@ int main(int argc, char** argv)
     r_dev.reprojectFrames(again.cur, { again.kf }, trash_a);
     CHECK(again.cur->num_features_ == host.cur->num_features_);
     printf("device candidate projection: %zu features, identical to the host mirror\n", dev.cur->num_features_);
+
+    // (c) a projection goes stale: a seed changes, and the keyframe's pose moves, between the queueing and the use.  The
+    // reprojection must then be the one of a reprojector that never had a projection queued (the stale entries are
+    // computed on the host instead of being taken from the snapshot).
+    {
+      Set a = build(71), b = build(71);
+      ReprojectorHip ra(ctx, ro, 0), rb(ctx, ro, 0);
+      ra.enqueueCandidateProjection(a.cur, { a.kf }, nullptr, -1);
+      for (Set* s3 : { &a, &b }) {
+        for (size_t i = 0; i < s3->kf->num_features_; i += 7)
+          if (!s3->pts[i]) s3->kf->invmu_sigma2_a_b_vec_[4 * i] *= 1.02;   // every seventh seed has moved
+      }
+      std::vector<PointPtr> ta, tb;
+      ra.reprojectFrames(a.cur, { a.kf }, ta);
+      rb.reprojectFrames(b.cur, { b.kf }, tb);
+      CHECK(a.cur->num_features_ == b.cur->num_features_ && ra.stats_.n_trials == rb.stats_.n_trials && ra.stats_.n_matches == rb.stats_.n_matches);
+      for (size_t s2 = 0; s2 < a.cur->num_features_; ++s2)
+        CHECK(a.cur->px_vec_[2 * s2] == b.cur->px_vec_[2 * s2] && a.cur->px_vec_[2 * s2 + 1] == b.cur->px_vec_[2 * s2 + 1]);
+      Set c = build(81), d = build(81);
+      ReprojectorHip rc(ctx, ro, 0), rd(ctx, ro, 0);
+      rc.enqueueCandidateProjection(c.cur, { c.kf }, nullptr, -1);
+      c.kf->T_f_w_.t.x += 0.01; d.kf->T_f_w_.t.x += 0.01;                      // the keyframe's pose has moved
+      std::vector<PointPtr> tc, td;
+      rc.reprojectFrames(c.cur, { c.kf }, tc);
+      rd.reprojectFrames(d.cur, { d.kf }, td);
+      CHECK(c.cur->num_features_ == d.cur->num_features_ && rc.stats_.n_trials == rd.stats_.n_trials && rc.stats_.n_matches == rd.stats_.n_matches);
+      for (size_t s2 = 0; s2 < c.cur->num_features_; ++s2)
+        CHECK(c.cur->px_vec_[2 * s2] == d.cur->px_vec_[2 * s2] && c.cur->px_vec_[2 * s2 + 1] == d.cur->px_vec_[2 * s2 + 1]);
+      printf("stale projections (moved seeds, moved keyframe): recomputed on the host, same result\n");
+    }
+
+    // (d) a seed update sent off with updateSeedsAsync holds the context's one deferred section; a reprojection on the
+    // same context in between finishes it instead of failing, and the update's results are those of the blocking call
+    {
+      Set e = build(91), f = build(91), g = build(92);
+      DepthFilterOptions dfo;
+      DepthFilterHip df_async(ctx, dfo), df_block(ctx, dfo);
+      const size_t n_block = df_block.updateSeeds({ f.kf }, f.cur);
+      df_async.updateSeedsAsync({ e.kf }, e.cur);
+      CHECK(df_async.updatePending());
+      ReprojectorHip rg(ctx, ro, 0);
+      std::vector<PointPtr> tg;
+      rg.reprojectFrames(g.cur, { g.kf }, tg);                                  // needs the deferred section
+      CHECK(!df_async.updatePending());
+      const size_t n_async = df_async.finishUpdateSeeds();
+      CHECK(n_async == n_block && n_block > 0);
+      for (size_t i = 0; i < e.kf->num_features_; ++i) {
+        CHECK(e.kf->type_vec_[i] == f.kf->type_vec_[i]);
+        for (int j = 0; j < 4; ++j) CHECK(e.kf->invmu_sigma2_a_b_vec_[4 * i + j] == f.kf->invmu_sigma2_a_b_vec_[4 * i + j]);
+      }
+      CHECK(g.cur->num_features_ > 20);
+      printf("seed update in flight + reprojection on one context: finished early, %zu seeds updated as in the blocking call\n", n_async);
+    }
   }
   svoh_destroy(ctx);
   printf("PASS\n");

@@ -58,7 +58,11 @@ int main(int argc, char** argv)
     const size_t n_frames = std::min(seq.size(), max_frames);
 
     // the IMU's relative rotations, if the dataset has them
+    // have_prior[k]: a prior was really parsed / integrated for frame k.  The reference applies NO prior to a frame whose
+    // ImuHandler::getRelativeRotationPrior fails (frame_handler_base.cpp:622: have_motion_prior_ stays false) -- a frame
+    // without one must not be pulled towards zero rotation by an identity stand-in.
     std::vector<svoh::Quat> imu_prior;
+    std::vector<bool> have_prior;
     {
       std::ifstream in(std::string(argv[1]) + "/mav0/imu_prior.csv");
       std::string line;
@@ -67,8 +71,9 @@ int main(int argc, char** argv)
         for (char& c : line) if (c == ',') c = ' ';
         std::istringstream ss(line);
         svoh::Quat q{ 1, 0, 0, 0 };
-        ss >> q.w >> q.x >> q.y >> q.z;
-        imu_prior.push_back(q);
+        const bool parsed = static_cast<bool>(ss >> q.w >> q.x >> q.y >> q.z);   // a short or garbled line: no prior for that frame
+        imu_prior.push_back(parsed ? q : svoh::Quat{ 1, 0, 0, 0 });
+        have_prior.push_back(parsed);
       }
     }
     // ... or the raw gyroscope of a real EuRoC folder (mav0/imu0/data.csv), integrated between the camera timestamps
@@ -79,11 +84,13 @@ int main(int argc, char** argv)
       if (!imu.empty()) {
         const double bias[3] = { 0.0, 0.0, 0.0 };
         imu_prior.assign(n_frames, svoh::Quat{ 1, 0, 0, 0 });
+        have_prior.assign(n_frames, false);
         size_t n_ok = 0;
         for (size_t k = 1; k < n_frames; ++k) {
           svoh::Quat R_old_new;
           if (io::relativeRotationPrior(imu, (double)seq.cam_ts[k - 1] * 1e-9, (double)seq.cam_ts[k] * 1e-9, bias, 0.0, 0.01, &R_old_new)) {
             imu_prior[k] = svoh::Quat{ R_old_new.w, -R_old_new.x, -R_old_new.y, -R_old_new.z };
+            have_prior[k] = true;
             ++n_ok;
           }
         }
@@ -193,7 +200,7 @@ int main(int argc, char** argv)
         // 1. sparse image alignment of the bundle, with the IMU's rotation prior (frame_handler_base.cpp:610-643)
         for (size_t c = 0; c < 2; ++c) { bundle->at(c)->T_f_w_ = last->at(c)->T_f_w_; resolveAlignmentPoints(*last->at(c)); }
         img_align.reset();
-        if (k < imu_prior.size() && lambda_rot > 0) {
+        if (k < imu_prior.size() && have_prior[k] && lambda_rot > 0) {
           Transformation T_prior{ imu_prior[k], { 0, 0, 0 } };   // T_newimu_lastimu_prior: the rotation is what the weights use
           img_align.setWeightedPrior(T_prior, 0.0, 0.0, lambda_rot, 0.0, 0.0, 0.0);
         }
