@@ -360,6 +360,35 @@ def epipolar_match_batch(mopt, ref_views, cur_views, fb, d_inv_common=None, d_in
     return out
 
 
+
+class orc_stereo_match(C.Structure):
+    _fields_ = [("i_ref", C.c_int32), ("pad", C.c_int32), ("xyz_cam0", C.c_double * 3), ("px", C.c_double * 2),
+                ("f", C.c_double * 3), ("grad", C.c_double * 2), ("depth", C.c_double)]
+
+
+def stereo_triangulate(frame0, frame1, T_f1f0, fb, indices, n_desired, d_inv, fast=False):
+    """The loop of StereoTriangulation::compute (orc_stereo_triangulate, stereo_triangulation.cpp:92-137) over the new
+    features in the given (already shuffled) order.  Returns (matches: list of dicts, result per feature of the batch with -1 for the ones never visited, n_failed)."""
+    lib = load(fast)
+    _bind_part2(lib)
+    P = C.POINTER
+    lib.orc_stereo_triangulate.argtypes = [P(orc_frame_view), P(orc_frame_view), P(capi.svoh_se3), P(capi.svoh_feature_batch),
+                                           C.c_int, C.c_void_p, C.c_int, P(C.c_double), P(orc_stereo_match), C.c_void_p,
+                                           P(C.c_int)]
+    lib.orc_stereo_triangulate.restype = C.c_int
+    idx = np.ascontiguousarray(indices, np.int32)
+    out = (orc_stereo_match * max(1, int(n_desired)))()
+    result = np.full(int(fb.n), -1, np.int32)   # per feature of the batch; -1: not visited
+    n_failed = C.c_int(0)
+    T = to_se3(T_f1f0)
+    di = (C.c_double * 3)(*d_inv)
+    n = lib.orc_stereo_triangulate(C.byref(frame0), C.byref(frame1), C.byref(T), C.byref(fb), int(idx.size), idx.ctypes.data,
+                                   int(n_desired), di, out, result.ctypes.data, C.byref(n_failed))
+    matches = [dict(i_ref=int(m.i_ref), xyz_cam0=np.array(m.xyz_cam0[:]), px=np.array(m.px[:]), f=np.array(m.f[:]),
+                    grad=np.array(m.grad[:]), depth=float(m.depth)) for m in out[:n]]
+    return matches, result, int(n_failed.value)
+
+
 def update_seeds_batch(mopt, dopt, ref_views, cur_view, fb, state, fast=False):
     lib = load(fast)
     _bind_part2(lib)

@@ -915,3 +915,79 @@ def match_direct_batch(cur, refs, ref_idx, px, f, grad, level, ftype, depth, px_
             if is_edgelet(int(ftype[i])):
                 out["h_inv"][i] = m.h_inv
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# StereoTriangulation::compute, the loop over the new features (src/svo/src/stereo_triangulation.cpp:88-137)
+# ---------------------------------------------------------------------------------------------------------------
+def stereo_triangulate(frame0, frame1, T_f1f0, px, f, grad, level, ftype, indices, n_desired, mean_depth_inv,
+                       min_depth_inv, max_depth_inv):
+    """frame0 / frame1: FrameView of the left / right image; the new features of frame0 (arrays per feature) are visited
+    in the order `indices` (the reference shuffles corners and the rest separately with std::random_shuffle: the order
+    is an input here).  ONE Matcher for the whole loop, max_epi_search_steps 500, subpix_refinement on, align_1d set per
+    feature to isEdgelet(type) (:92-98).  A success makes a landmark at f * depth (frame0's camera frame) and a feature
+    in frame1: the matched pixel, its bearing vector, the reference feature's level / type, the gradient A_cur_ref * grad
+    normalised (:106-124).  The loop ends when n_desired features have succeeded (:131-132).
+    Returns (matches, result per visited index, n_failed)."""
+    matcher = Matcher(MatcherOptions(max_epi_search_steps=500, subpix_refinement=True))
+    matches, results = [], []
+    n_succeeded = n_failed = 0
+    for i_ref in indices:
+        i_ref = int(i_ref)
+        matcher.options.align_1d = is_edgelet(int(ftype[i_ref]))
+        res, depth = matcher.find_epipolar_match_direct(frame0, frame1, T_f1f0, px[i_ref], f[i_ref], grad[i_ref], int(level[i_ref]),
+                                                        int(ftype[i_ref]), mean_depth_inv, min_depth_inv, max_depth_inv)
+        results.append(res)
+        if res == SUCCESS:
+            g = matcher.A_cur_ref @ grad[i_ref]
+            matches.append(dict(i_ref=i_ref, xyz_cam0=f[i_ref] * depth, px=np.array(matcher.px_cur, np.float64),
+                                f=np.array(matcher.f_cur, np.float64), grad=normalized(g), depth=depth))
+            n_succeeded += 1
+        else:
+            n_failed += 1
+        if n_succeeded >= n_desired:
+            break
+    return matches, np.array(results, np.int32), n_failed
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reprojector_utils::getCandidate / projectPointAndCheckVisibility (src/svo/src/reprojector.cpp:489-543) with
+# Frame::isVisible (src/svo_common/src/frame.cpp:229-260)
+# ---------------------------------------------------------------------------------------------------------------
+K_REPROJ_PATCH = 8     # kPatchSize of projectPointAndCheckVisibility (reprojector.cpp:538)
+
+
+def frame_is_visible(cam, T_f_w, xyz_w):
+    """frame.cpp:229-260 for a pinhole-type camera: the point must lie inside the cone through the image's top-left
+    corner (cos of the angle to the optical axis against that of backProject3((0, 0))), then project inside the image.
+    Returns (visible, px)."""
+    xyz_f = T_f_w.apply(xyz_w)
+    f_top_left = normalized(cam.back_project3(np.zeros(2)))
+    min_cos = f_top_left[2]
+    cur_cos = normalized(xyz_f)[2]
+    if cur_cos < min_cos:
+        return False, np.zeros(2)
+    px = cam.project3(xyz_f)
+    return bool(cam.is_keypoint_visible(px)), px
+
+
+def project_point_and_check_visibility(cam, T_f_w, xyz_w):
+    """reprojector.cpp:525-543: visible in the frame, and the truncated pixel at least kPatchSize from every border."""
+    ok, px = frame_is_visible(cam, T_f_w, xyz_w)
+    if not ok:
+        return False, px
+    pxi = (int(px[0]), int(px[1]))                      # px->cast<int>()
+    if not cam.is_keypoint_visible_with_margin(pxi, K_REPROJ_PATCH):
+        return False, px
+    return True, px
+
+
+def get_candidate(cam_cur, T_f_w_cur, T_f_w_ref, landmark_pos, f_ref, inv_depth):
+    """reprojector.cpp:489-523: the landmark's position if the feature has one (landmark_pos not None), else the seed's
+    position T_world_cam * (f * depth) with depth = 1 / mu (seed.h:110-113, the inverse-depth parametrisation the
+    reference is built with); then projectPointAndCheckVisibility.  Returns (is a candidate, pixel in the current frame)."""
+    if landmark_pos is not None:
+        xyz_world = np.asarray(landmark_pos, np.float64)
+    else:
+        xyz_world = T_f_w_ref.inverse().apply(np.asarray(f_ref, np.float64) * (1.0 / inv_depth))
+    return project_point_and_check_visibility(cam_cur, T_f_w_cur, xyz_world)

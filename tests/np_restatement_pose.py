@@ -266,3 +266,67 @@ def optimize_pose(err_type, cams, T_imu_world, outlier_threshold, max_iter=10, e
     fs = np.sort(np.array(final))
     return dict(status=status, T=T, sigma=sigma, iters=iters, n_meas=n_meas, outlier=outlier, n_deleted_edges=n_edges,
                 n_deleted_corners=n_corners, err_before=float(srt[len(srt) // 2]), err_after=float(fs[len(fs) // 2]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Point::optimize  (src/svo_common/src/point.cpp:248-325; Jacobians src/svo_common/include/svo/common/point.h:170-204)
+# Written from those lines: a 3-DoF Gauss-Newton on the landmark's world position over its observations, residual on
+# the unit plane (project2(f) - project2(p_in_f)) or between unit bearing vectors (f - p_in_f / |p_in_f|); the step is
+# rolled back when the error grew (from the second iteration on) or the solve gave a NaN; stop when max |dp| <= 1e-10.
+# Machinery: numpy matrices and numpy.linalg.solve for A.ldlt().solve(b) (3x3, positive definite for >= 2 views).
+# ---------------------------------------------------------------------------------------------------------------
+def point_jacobian_xyz2uv(p_in_f, R_f_w):             # point.h:170-184
+    z_inv = 1.0 / p_in_f[2]
+    J = np.array([[z_inv, 0.0, -p_in_f[0] * z_inv * z_inv],
+                  [0.0, z_inv, -p_in_f[1] * z_inv * z_inv]])
+    return -J @ R_f_w
+
+
+def point_jacobian_xyz2f(p_in_f, R_f_w):              # point.h:187-204
+    x, y, z = p_in_f
+    Jn = np.array([[y * y + z * z, -x * y, -z * x],
+                   [-x * y, x * x + z * z, -y * z],
+                   [-z * x, -y * z, x * x + y * y]]) * (1.0 / (x * x + y * y + z * z) ** 1.5)
+    return -Jn @ R_f_w
+
+
+def point_optimize(obs, pos, n_iter, using_bearing_vector):
+    """obs: list of (T_f_w as Tf, bearing vector f) -- the observations whose frame is still alive; pos: start position.
+    Returns (position, iterations executed: the number of times the normal equations were built)."""
+    pos = np.array(pos, np.float64)
+    if len(obs) < 2:                                  # point.cpp:255-259: nothing is done
+        return pos, 0
+    old_point = pos.copy()
+    chi2 = 0.0
+    eps = 0.0000000001
+    iters = 0
+    for i in range(n_iter):
+        A, b, new_chi2 = np.zeros((3, 3)), np.zeros(3), 0.0
+        for T_f_w, f in obs:
+            p_in_f = T_f_w.apply(pos)
+            R_f_w = rot_matrix(T_f_w.q)
+            if using_bearing_vector:                  # updateHessianGradientUnitSphere, :232-246
+                J = point_jacobian_xyz2f(p_in_f, R_f_w)
+                e = f - p_in_f / math.sqrt(float(p_in_f @ p_in_f))
+            else:                                     # updateHessianGradientUnitPlane, :216-230; vk::project2 = (x/z, y/z)
+                J = point_jacobian_xyz2uv(p_in_f, R_f_w)
+                e = np.array([f[0] / f[2], f[1] / f[2]]) - np.array([p_in_f[0] / p_in_f[2], p_in_f[1] / p_in_f[2]])
+            A += J.T @ J
+            b -= J.T @ e
+            new_chi2 += float(e @ e)
+        iters += 1
+        with np.errstate(all="ignore"):
+            try:
+                dp = np.linalg.solve(A, b)
+            except np.linalg.LinAlgError:             # exactly singular: Eigen's LDLT returns something finite or NaN; treat as NaN
+                dp = np.full(3, np.nan)
+        if (i > 0 and new_chi2 > chi2) or np.isnan(dp[0]):
+            pos = old_point                           # roll-back
+            break
+        new_point = pos + dp
+        old_point = pos
+        pos = new_point
+        chi2 = new_chi2
+        if np.max(np.abs(dp)) <= eps:
+            break
+    return pos, iters

@@ -246,3 +246,219 @@ def test_pyramid_oracle_vs_numpy_second_opinion(oracle_lib, shape):
     pn = n0.create_img_pyramid(img, n_levels)
     for a, b in zip(po, pn):
         assert a.shape == b.shape and np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SparseImgAlign's Gauss-Newton LOOP (a-1, a-2, a-8): update, applyPrior with I_prior_ rebuilt at iteration 0 of every
+# level, the stop / roll-back rules -- tests/np_restatement_gn.py on top of np_restatement.evaluate
+# ---------------------------------------------------------------------------------------------------------------
+def _gn_compare(orc, cams, opt, T_init=None, alpha_init=0.0, beta_init=0.0, prior_c=None, prior_np=None, tol_pose=1e-9):
+    import helpers
+    import np_restatement_gn as ngn
+    pb = orc.problem_from_scenes(cams, T_init=T_init, prior=prior_c, alpha_init=alpha_init, beta_init=beta_init)
+    n, ro, _ = orc.sparse_align_run(opt, pb)
+    sc0 = cams[0][0]
+    Ti = T_init if T_init is not None else sc0.T_icur_iref_init
+    rn = ngn.run(cams, opt.max_level, opt.min_level, opt.patch_size, Ti, alpha_init, beta_init, max_iter=opt.max_iter,
+                 eps=opt.eps, est_alpha=bool(opt.estimate_illumination_gain), est_beta=bool(opt.estimate_illumination_offset),
+                 robust=bool(opt.robustification), weight_scale=opt.weight_scale, prior=prior_np)
+    for level in range(opt.max_level, opt.min_level - 1, -1):
+        assert ro.iters[level] == rn["iters"][level], (level, list(ro.iters), rn["iters"])
+        assert ro.n_meas[level] == rn["n_meas"][level]
+    assert ro.status == rn["status"]
+    qo = np.array([ro.T_icur_iref.q[i] for i in range(4)]); to = np.array([ro.T_icur_iref.t[i] for i in range(3)])
+    dq = min(np.abs(qo - rn["T"].q).max(), np.abs(qo + rn["T"].q).max())
+    assert max(dq, np.abs(to - rn["T"].t).max()) < tol_pose
+    assert abs(ro.alpha - rn["alpha"]) < 1e-9 and abs(ro.beta - rn["beta"]) < 1e-7
+    return ro, rn
+
+
+@pytest.mark.parametrize("cam_kind", ["pinhole", "radtan"])
+def test_gauss_newton_loop_oracle_vs_numpy_second_opinion(oracle_lib, cam_kind):
+    import helpers
+    orc = oracle_lib
+    cam = synth.Camera.test_camera() if cam_kind == "pinhole" else synth.Camera.euroc_like()
+    sc = helpers.small_scene(71, n=220, cam=cam, border_features=30, invalid_fraction=0.05, gain=1.03, offset=2.0)
+    ref, cur = helpers.scene_pyramids(orc, sc)
+    cams = [(sc, ref, cur)]
+    total_iters = 0
+    # the handler's levels, all levels, an iteration cap that cuts levels short, an eps nothing reaches
+    for kw in (dict(min_level=2), dict(min_level=0), dict(min_level=1, max_iter=3), dict(min_level=3, eps=1e-12, max_iter=6)):
+        ro, rn = _gn_compare(orc, cams, capi.default_align_options(**kw))
+        total_iters += sum(rn["iters"].values())
+    # illumination gain and offset estimated, with and without robust weights, from non-zero starting values
+    for robust in (0, 1):
+        opt = capi.default_align_options(min_level=1, estimate_illumination_gain=1, estimate_illumination_offset=1,
+                                         robustification=robust)
+        _gn_compare(orc, cams, opt, alpha_init=0.01, beta_init=-0.5)
+    # only one of the two illumination terms: the other's row and column stay exactly zero
+    _gn_compare(orc, cams, capi.default_align_options(min_level=2, estimate_illumination_gain=1))
+    _gn_compare(orc, cams, capi.default_align_options(min_level=2, estimate_illumination_offset=1))
+    assert total_iters > 20
+
+
+def test_gauss_newton_prior_oracle_vs_numpy_second_opinion(oracle_lib):
+    """applyPrior over three levels (I_prior_ rebuilt from each level's first Hessian), prior x illumination."""
+    import helpers
+    import np_restatement_direct as nd2
+    orc = oracle_lib
+    sc = helpers.small_scene(72, n=260, gain=1.02, offset=1.0)
+    ref, cur = helpers.scene_pyramids(orc, sc)
+    cams = [(sc, ref, cur)]
+    Tp = synth.SE3(synth.quat_from_axis_angle([0.3, -1, 0.2], 0.004), [0.003, -0.002, 0.001])
+    Tp_np = nd2.Tf.from7(Tp.as7())
+    for lam_r, lam_t, la, lb in ((0.5, 0.0, 0.0, 0.0), (2.0, 3.0, 0.0, 0.0), (0.1, 0.1, 0.5, 0.5), (0.0, 0.7, 0.0, 0.3)):
+        illum = int(la > 0 or lb > 0)
+        prior_c = helpers.make_prior(Tp, lam_r, lam_t, alpha=0.01, beta=-0.5, lambda_alpha=la, lambda_beta=lb)
+        prior_np = dict(T=Tp_np, alpha=0.01, beta=-0.5, lambda_rot=lam_r, lambda_trans=lam_t, lambda_alpha=la, lambda_beta=lb)
+        opt = capi.default_align_options(min_level=2, estimate_illumination_gain=illum, estimate_illumination_offset=illum)
+        ro, rn = _gn_compare(orc, cams, opt, prior_c=prior_c, prior_np=prior_np)
+        assert sum(rn["iters"].values()) >= 3
+        # the prior really acts: the unconstrained run ends somewhere else
+        r_free = orc.sparse_align_run(opt, orc.problem_from_scenes(cams))[1]
+        if lam_r >= 0.5:
+            assert helpers.se3_max_abs_diff(r_free.T_icur_iref, ro.T_icur_iref) > 1e-6
+
+
+def test_gauss_newton_stereo_and_failed_solve_oracle_vs_numpy_second_opinion(oracle_lib):
+    import helpers
+    orc = oracle_lib
+    a = helpers.small_scene(73, n=200, border_features=20)
+    b = synth.make_align_scene(73, n_features=180, cam=synth.Camera.euroc_like(), border_features=10)
+    ra, ca = helpers.scene_pyramids(orc, a)
+    rb, cb = helpers.scene_pyramids(orc, b)
+    # two cameras with different extrinsics and intrinsics: one H, one g (sparse_img_align.cpp:138-154)
+    _gn_compare(orc, [(a, ra, ca), (b, rb, cb)], capi.default_align_options(min_level=1))
+    # a solve that fails -- every patch invisible: H = 0, g = 0, Eigen's LDLT returns zeros, NOT a NaN: no failure, the
+    # step is zero, the level ends at once (max |dx| = 0 < eps)
+    far = synth.SE3(synth.quat_from_axis_angle([0, 1, 0], 3.0), [0.0, 0.0, 0.0])   # everything behind the camera
+    ro, rn = _gn_compare(orc, [(a, ra, ca)], capi.default_align_options(min_level=2), T_init=far)
+    assert all(rn["iters"][l] == 1 for l in (4, 3, 2)) and all(rn["n_meas"][l] == 0 for l in (4, 3, 2))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Point::optimize (f-3, second half): point.cpp:248-325 restated in tests/np_restatement_pose.py
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sphere", [False, True])
+@pytest.mark.parametrize("seed,n_points,n_views,n_iter", [(6, 300, 5, 5), (7, 400, 8, 10), (8, 5, 2, 3)])
+def test_point_optimize_oracle_vs_numpy_second_opinion(oracle_lib, sphere, seed, n_points, n_views, n_iter):
+    import np_restatement_pose as npp
+    import pose_helpers as ph
+    orc = oracle_lib
+    sc = ph.make_structure_scene(seed, n_points=n_points, n_views=n_views)
+    po, io = orc.optimize_points(sc["views"], sc["obs_begin"], sc["obs_view"], sc["obs_f"], sc["pos0"], n_iter=n_iter,
+                                 using_bearing_vector=sphere)
+    views = [nd.Tf.from7(np.asarray(v, np.float64)) for v in sc["views"]]
+    pn, it_n = np.zeros_like(po), np.zeros(n_points, np.int32)
+    for i in range(n_points):
+        o0, o1 = int(sc["obs_begin"][i]), int(sc["obs_begin"][i + 1])
+        obs = [(views[int(sc["obs_view"][o])], sc["obs_f"][o]) for o in range(o0, o1)]
+        pn[i], it_n[i] = npp.point_optimize(obs, sc["pos0"][i], n_iter, sphere)
+    # constructed degenerate landmarks (pose_helpers): 11 sees one view twice (singular along the ray: the solution
+    # there is rounding noise over a tiny pivot), 23 starts behind a camera and runs away -- compared loosely below
+    wild = np.zeros(n_points, bool)
+    if n_points > 23:
+        wild[[11, 23]] = True
+    lone = np.diff(sc["obs_begin"]) < 2
+    assert np.array_equal(pn[lone], sc["pos0"][lone]) and np.array_equal(po[lone], sc["pos0"][lone])
+    assert (it_n[lone] == 0).all() and (io[lone] == 0).all()
+    # iteration counts: in lockstep until convergence; once converged chi2 only moves in its last bits, so the "error
+    # grew" stop can fire one iteration apart between the two readings (different solvers)
+    ok = ~wild & ~lone
+    assert np.abs(it_n - io)[ok].max() <= 1 and np.mean((it_n != io)[ok]) < 0.05
+    if n_iter <= 5:
+        assert np.array_equal(it_n[ok], io[ok])
+    d = np.abs(pn - po).max(1)
+    fin = np.isfinite(po).all(1)
+    assert np.array_equal(fin, np.isfinite(pn).all(1))
+    assert d[ok & fin].max() < 1e-6 and np.median(d[ok & fin]) < 1e-12
+    # (landmark 11's singular 3x3 system has no defined solution: what comes out is the solver's -- Eigen's LDLT in the
+    # oracle and the kernel, LAPACK here -- so it is not compared; the GPU test compares it with the oracle, same solver)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The loop of StereoTriangulation::compute (row *J): one Matcher, align_1d per feature, landmark + frame1 feature per
+# success, stop at n_desired -- stereo_triangulation.cpp:88-137 restated in tests/np_restatement_direct.py
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cam_kind,n_desired", [("pinhole", 60), ("radtan", 10_000)])
+def test_stereo_triangulation_loop_oracle_vs_numpy_second_opinion(oracle_lib, cam_kind, n_desired):
+    orc = oracle_lib
+    cam = synth.Camera.test_camera() if cam_kind == "pinhole" else synth.Camera.euroc_like()
+    sc = synth.make_align_scene(66, n_features=10, cam=cam, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))   # "left" = ref, "right" = cur
+    n = 240
+    sd = synth.make_seed_set(sc, n, margin=6, levels=(0, 1, 2))
+    ftype = np.where(sd["type"] == 0, capi.FT_EDGELET, capi.FT_CORNER).astype(np.uint8)   # detector output, not seeds
+    rv, cv, nrv, ncv = _views(orc, sc, dict(mu_range=0.0), cam_kind)
+    T = sc.T_cur_f_w_gt * sc.T_ref_f_w.inverse()
+    d_mean = float(np.median(sd["true_depth"]))
+    d_inv = [1.0 / d_mean, 1.0 / (0.3 * d_mean), 1.0 / (15.0 * d_mean)]
+    # the reference's order: corners shuffled, then the rest shuffled (:76-84) -- any order is an input to both readings
+    rng = np.random.RandomState(5)
+    corners = np.nonzero(ftype == capi.FT_CORNER)[0]; rest = np.nonzero(ftype != capi.FT_CORNER)[0]
+    order = np.concatenate([rng.permutation(corners), rng.permutation(rest)]).astype(np.int32)
+    fb, keep = orc.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], ftype)
+    mo, ro, fo = orc.stereo_triangulate(rv, cv, T, fb, order, n_desired, d_inv)
+    mn, rn, fn = nd.stereo_triangulate(nrv, ncv, nd.Tf.from7(T.as7()), sd["px"].reshape(-1, 2), sd["f"].reshape(-1, 3),
+                                       sd["grad"].reshape(-1, 2), sd["level"], ftype, order, n_desired, *d_inv)
+    visited = len(rn)
+    # the same features visited, the same codes (the oracle reports per feature index, -1 = never visited)
+    assert np.array_equal(ro[order[:visited]], rn) and (ro[order[visited:]] == -1).all()
+    assert fo == fn and len(mo) == len(mn) and len(mn) == min(n_desired, int((rn == nd.SUCCESS).sum()))
+    if n_desired < 100:
+        assert len(mn) == n_desired and visited < n      # the early stop (:131-132)
+    else:
+        assert visited == n and fn > 0 and len(set(rn.tolist())) >= 3
+    for a, b in zip(mo, mn):
+        assert a["i_ref"] == b["i_ref"]
+        assert abs(a["depth"] - b["depth"]) <= 1e-9 * abs(b["depth"])
+        assert np.abs(a["xyz_cam0"] - b["xyz_cam0"]).max() <= 1e-9 * abs(b["depth"])
+        assert np.abs(a["px"] - b["px"]).max() <= 1e-4 and np.abs(a["f"] - b["f"]).max() < 1e-6
+        assert np.abs(a["grad"] - b["grad"]).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reprojector_utils::getCandidate (f-4): reprojector.cpp:489-543 + Frame::isVisible restated in
+# tests/np_restatement_direct.py, against the HOST MIRROR's getCandidate (svo_hip_host.cpp) run on the CPU through
+# tests/cpp/host_candidates_cpu (the device kernel is compared with the same restatement in test_sparse_align_gpu.py)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cam_kind", ["pinhole", "radtan"])
+def test_get_candidate_host_mirror_vs_numpy_second_opinion(tmp_path, cam_kind):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "svo_pro_universal_amd", "host"), "libsvo_hip_host.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp"), "host_candidates_cpu"])
+    cam = synth.Camera.test_camera() if cam_kind == "pinhole" else synth.Camera.euroc_like()
+    rng = np.random.RandomState(17)
+    T_w_cur = synth.SE3(synth.quat_from_axis_angle([0.2, 1, -0.1], 0.15), (0.4, -0.1, 0.2))
+    T_w_ref = T_w_cur * synth.SE3(synth.quat_from_axis_angle([0, 1, 0.3], 0.25), (0.3, 0.05, 0.1))
+    T_cur, T_ref = T_w_cur.inverse(), T_w_ref.inverse()
+    n = 4000
+    kind = (rng.uniform(size=n) < 0.5).astype(int)
+    v, mu = np.zeros((n, 3)), np.ones(n)
+    for i in range(n):
+        if kind[i]:    # a seed of the reference keyframe: bearing vector and inverse depth
+            f = np.array([rng.uniform(-0.9, 0.9), rng.uniform(-0.7, 0.7), 1.0]); v[i] = f / np.linalg.norm(f)
+            mu[i] = 1.0 / rng.uniform(0.5, 8.0)
+        else:          # a landmark somewhere around the current view, many outside it or behind it
+            v[i] = T_w_cur.transform(np.array([rng.uniform(-6, 6), rng.uniform(-4, 4), rng.uniform(-1.0, 8.0)]))
+    d = list(cam.dist) if cam.dist is not None else [0.0] * 4
+    lines = ["%d %d %.17g %.17g %.17g %.17g %d %.17g %.17g %.17g %.17g" % (cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
+                                                                          1 if cam.dist is not None else 0, *d),
+             " ".join("%.17g" % x for x in T_cur.as7()), " ".join("%.17g" % x for x in T_ref.as7()), str(n)]
+    lines += ["%d %.17g %.17g %.17g %.17g" % (0 if not kind[i] else 1, v[i, 0], v[i, 1], v[i, 2], mu[i]) for i in range(n)]
+    fin, fout = tmp_path / "in.txt", tmp_path / "out.txt"
+    fin.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([os.path.join(root, "tests", "cpp", "host_candidates_cpu"), str(fin), str(fout)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    host = np.loadtxt(str(fout))
+    ncam = nd.Cam.of(cam)
+    Tc, Tr = nd.Tf.from7(T_cur.as7()), nd.Tf.from7(T_ref.as7())
+    n_vis = 0
+    for i in range(n):
+        ok, px = nd.get_candidate(ncam, Tc, Tr, v[i] if not kind[i] else None, v[i], mu[i])
+        if ok != bool(host[i, 0]):   # a pixel within rounding of an integer boundary may fall on either side
+            assert min(abs(px[0] - round(px[0])), abs(px[1] - round(px[1]))) < 1e-9, i
+        elif ok:
+            assert np.abs(host[i, 1:3] - px).max() < 1e-9
+            n_vis += 1
+    assert 300 < n_vis < n - 300

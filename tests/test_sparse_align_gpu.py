@@ -579,15 +579,13 @@ def test_candidate_projection_rides_the_alignment_launch(gpu_ctx):
     f_tl = ncam.back_project3(np.zeros(2)); min_cos = f_tl[2] / np.linalg.norm(f_tl)
     n_vis = 0
     for i in range(n):
-        xyz = v[i] if not kind[i] else nd.Tf.from7(T_w_kf[kf[i]].as7()).apply(v[i] * (1.0 / mu[i]))
-        xf = T_f_w.apply(xyz)
-        ok = not (xf[2] / np.linalg.norm(xf) < min_cos)
-        p = np.zeros(2)
-        if ok:
-            p = ncam.project3(xf)
-            ok = ncam.is_keypoint_visible(p) and ncam.is_keypoint_visible_with_margin((int(p[0]), int(p[1])), 8)
-        near_edge = ok != bool(vis[i])
-        if near_edge:   # a pixel within rounding of an integer boundary may fall on either side
+        # tests/np_restatement_direct.get_candidate: reprojector.cpp:489-543 (the same function the host mirror is checked
+        # against on the CPU, tests/test_np_second_opinion_cpu.py)
+        T_kf = nd.Tf.from7(T_w_kf[kf[i]].as7()).inverse()
+        ok, p = nd.get_candidate(ncam, T_f_w, T_kf, v[i] if not kind[i] else None, v[i], mu[i])
+        if ok != bool(vis[i]):   # a pixel within rounding of an integer boundary, or a point on the cone, may fall on either side
+            xyz = v[i] if not kind[i] else nd.Tf.from7(T_w_kf[kf[i]].as7()).apply(v[i] * (1.0 / mu[i]))
+            xf = T_f_w.apply(xyz)
             assert min(abs(p[0] - round(p[0])), abs(p[1] - round(p[1]))) < 1e-9 or abs(xf[2] / np.linalg.norm(xf) - min_cos) < 1e-12, i
         elif ok:
             assert np.abs(px[2 * i:2 * i + 2] - p).max() < 1e-9
