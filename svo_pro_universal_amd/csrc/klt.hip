@@ -51,6 +51,51 @@ __device__ __forceinline__ int group_sum_i32(int v)
   return v;
 }
 
+// ---- a track's windows in LDS (round 4) ---------------------------------------------------------------------------
+// Round 3's counters (VALU busy 58 %, waves waiting 55 %, SQ_INSTS_LDS = 0) read as latency, but the arithmetic of the
+// vector L1 says otherwise: every lane of a track read ITS OWN patch row, so a wave-wide load instruction touched 64
+// different cache lines, and at ~1 200 line look-ups per track (96 per 16x16 iteration, 144 per template) x 400 waves per
+// compute unit the L1's one line per cycle was the kernel's time (490 K of its 525 K cycles).  Now a track's search window
+// of the current level -- the patch plus kKltMargin pixels on every side, the motion inside a level being a few pixels at
+// most -- and its template's 18 x 18 (10 x 10) reference footprint are staged ONCE per level into LDS by loads in which
+// the four lanes of a quad read the four 8-byte pieces of one row (one line look-up per row instead of one per lane and
+// instruction: 48 look-ups per track and 16x16 level instead of ~330), and every iteration reads its rows from LDS.  A
+// patch that leaves its window (more than kKltMargin pixels from where the level began) has the window staged again
+// around it.  Same integers everywhere: positions and status stay bit-identical (tests/test_klt_matcher_gpu.py).
+constexpr int kKltMargin = 4;
+constexpr int kKltLdsPitch = 40;                   // bytes per staged row: 10 dwords -- 16 consecutive rows start in 16 different banks
+constexpr int kKltLdsRows = 28;                    // 16 + 2 * margin + 1 rows, rounded up to the 4 rows of a staging step
+constexpr int kKltLdsPerTrack = kKltLdsRows * kKltLdsPitch;
+typedef __attribute__((address_space(3))) unsigned char* klt_lds_ptr;
+
+// NDW dwords from a byte address in LDS that need not be aligned (gfx950 reads misaligned LDS words in hardware)
+template <int NDW>
+__device__ __forceinline__ void klt_lds_read(klt_lds_ptr p, unsigned (&out)[NDW])
+{
+  typedef unsigned u32_unaligned __attribute__((aligned(1)));
+#pragma unroll
+  for (int i = 0; i < NDW; ++i) out[i] = *reinterpret_cast<const __attribute__((address_space(3))) u32_unaligned*>(p + 4 * i);
+}
+
+// rows wy .. wy + n_rows - 1, 32 bytes from column wx on, of `img` into the track's LDS area (lane16: lane within the
+// track's 16).  Row indices are clamped into the image (a clamped row is never read back); bytes beyond a row's end
+// are the next row's or the slab's tail padding (never used either: kSlabTailPad >= 32).
+template <int N_ROWS>
+__device__ __forceinline__ void klt_stage_window(const DevImage& img, int wx, int wy, int lane16, klt_lds_ptr lds)
+{
+  const int piece = lane16 & 3, r0 = lane16 >> 2;
+#pragma unroll
+  for (int k = 0; k < (N_ROWS + 3) / 4; ++k) {
+    const int row = r0 + 4 * k;
+    int yy = wy + row;
+    yy = yy < 0 ? 0 : (yy >= img.h ? img.h - 1 : yy);
+    unsigned long long v;
+    __builtin_memcpy(&v, img.data + (ptrdiff_t)yy * img.pitch + wx + 8 * piece, 8);
+    if (N_ROWS % 4 == 0 || row < N_ROWS)
+      *reinterpret_cast<__attribute__((address_space(3))) unsigned long long*>(lds + row * kKltLdsPitch + 8 * piece) = v;
+  }
+}
+
 // One level of alignPyr2D for patch size P (16 or 8), LANES lanes per track: 64 (the wave owns one track) or 16 (four
 // tracks side by side, one per DPP row; every value below is then uniform per row, not per wave, and a row whose
 // track has left the loop idles while the others finish).  Returns per lane: 0 = continue to the next level,
@@ -58,15 +103,15 @@ __device__ __forceinline__ int group_sum_i32(int v)
 template <int P, int LANES>
 __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage& img_cur, int level, int px_ref0_x,
                                          int px_ref0_y, int n_iter, float min_update_squared, double& pcx, double& pcy,
-                                         bool& converged, int lane, int& n_iters, int& n_tmpl, bool run)
+                                         bool& converged, int lane, int& n_iters, int& n_tmpl, bool run, klt_lds_ptr lds)
 {
+  static_assert(LANES == 16, "the LDS windows are staged by the 16 lanes of a track");
   constexpr int PPL = P * P / LANES;  // pixels per lane: 16 (16x16 patch on a row of lanes: one patch row each) or 4 (8x8)
   static_assert(PPL == 4 || PPL == 16, "a lane holds 4 or 16 consecutive pixels of one patch row");
   typedef short short2v __attribute__((ext_vector_type(2)));
   const int halfpatch_size = P / 2;
   const int scale = 1 << level;
   const int width = img_ref.w, height = img_ref.h;
-  const int step = img_ref.pitch;
   const float prfx = (float)px_ref0_x / (float)scale - (float)halfpatch_size;
   const float prfy = (float)px_ref0_y / (float)scale - (float)halfpatch_size;
   const int prx = (int)prfx, pry = (int)prfy;
@@ -86,10 +131,17 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
     // the row, the next row or the slab's tail padding)
     constexpr int NW = PPL == 16 ? 6 : 2;
     unsigned U[NW], M[NW], D[NW];
-    const uint8_t* it = img_ref.data + (ptrdiff_t)(pry + y) * step + prx + x0 - 1;
-    __builtin_memcpy(U, it - step, NW * 4);
-    __builtin_memcpy(M, it, NW * 4);
-    __builtin_memcpy(D, it + step, NW * 4);
+    // the footprint rows pry - 1 .. pry + P from column prx - 1 on, through LDS (window row r = image row pry - 1 + r)
+    klt_stage_window<P + 2>(img_ref, prx - 1, pry - 1, lane, lds);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const klt_lds_ptr it = lds + y * kKltLdsPitch + x0;   // row y of the window = image row pry + y - 1
+      klt_lds_read<NW>(it, U);
+      klt_lds_read<NW>(it + kKltLdsPitch, M);
+      klt_lds_read<NW>(it + 2 * kKltLdsPitch, D);
+    }
+    __builtin_amdgcn_wave_barrier();   // the area is written again (the current window) only after every lane has read
     auto byte_of = [](const unsigned (&w)[NW], int j) { return (int)((w[j >> 2] >> (8 * (j & 3))) & 255u); };
 #pragma unroll
     for (int i = 0; i < PPL / 4; ++i) tq[i] = __builtin_amdgcn_alignbyte(M[i + 1], M[i], 1);   // pixels 4i .. 4i+3 = bytes 4i+1 .. 4i+4
@@ -135,6 +187,10 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
     converged = false;
   }
   const int cur_step = img_ref.pitch;  // the reference indexes the current image with the reference's step
+  DevImage img_win = img_cur;          // ... so the window's rows are taken with that step too
+  img_win.pitch = cur_step;
+  int wx = 0, wy = 0;
+  bool have_window = false;
   for (int iter = 0; iter < n_iter; ++iter) {
     if (__ballot(active) == 0) break;
     if (active) {
@@ -150,20 +206,30 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
       }
       if (active) {
         ++n_iters;
+        // the patch's 17 (9) rows and columns from (u_r, v_r) on must lie inside the staged window
+        if (!have_window || u_r < wx || v_r < wy || u_r - wx > 2 * kKltMargin || v_r - wy > 2 * kKltMargin) {
+          wx = u_r > kKltMargin ? u_r - kKltMargin : 0;
+          wy = v_r > kKltMargin ? v_r - kKltMargin : 0;
+          __builtin_amdgcn_wave_barrier();
+          klt_stage_window<P + 2 * kKltMargin + 1>(img_win, wx, wy, lane, lds);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          have_window = true;
+        }
+        const klt_lds_ptr wit = lds + (v_r - wy + y) * kKltLdsPitch + (u_r - wx) + x0;
         const float subpix_x = u - u_r;
         const float subpix_y = v - v_r;
         const int wTL = (int)(unsigned short)((1.0f - subpix_x) * (1.0f - subpix_y) * 128);
         const int wTR = (int)(unsigned short)(subpix_x * (1.0f - subpix_y) * 128);
         const int wBL = (int)(unsigned short)((1.0f - subpix_x) * subpix_y * 128);
         const int wBR = (int)(unsigned short)(128 - wTL - wTR - wBL);
-        const uint8_t* it = img_cur.data + (ptrdiff_t)(v_r + y) * cur_step + u_r + x0;
         int j0 = 0, j1 = 0;
         if constexpr (PPL == 16) {
           // a whole 16-pixel row per lane: 2 x 17 pixels as three unaligned 8-byte loads each (the spare bytes stay
           // inside the row, the next row or the slab's tail padding), taps packed and summed as in the 4-pixel case
           unsigned T[6], B[6];
-          __builtin_memcpy(T, it, 24);
-          __builtin_memcpy(B, it + cur_step, 24);
+          klt_lds_read<6>(wit, T);
+          klt_lds_read<6>(wit + kKltLdsPitch, B);
           const unsigned W = (unsigned)wTL | ((unsigned)wTR << 8) | ((unsigned)wBL << 16) | ((unsigned)wBR << 24);
 #pragma unroll
           for (int dq = 0; dq < 4; ++dq) {
@@ -181,8 +247,12 @@ __device__ __forceinline__ int klt_level(const DevImage& img_ref, const DevImage
           // the slab's tail padding); per pixel the four taps are gathered into one dword (v_perm_b32) and the 7-bit
           // fixed-point bilinear sum is ONE v_dot4_u32_u8 against the packed weights (all <= 128): the same integers
           uint2 T, B;
-          __builtin_memcpy(&T, it, 8);
-          __builtin_memcpy(&B, it + cur_step, 8);
+          {
+            unsigned t2[2], b2[2];
+            klt_lds_read<2>(wit, t2);
+            klt_lds_read<2>(wit + kKltLdsPitch, b2);
+            T = make_uint2(t2[0], t2[1]); B = make_uint2(b2[0], b2[1]);
+          }
           const unsigned W = (unsigned)wTL | ((unsigned)wTR << 8) | ((unsigned)wBL << 16) | ((unsigned)wBR << 24);
           const unsigned T3 = __builtin_amdgcn_alignbyte(T.y, T.x, 3), B3 = __builtin_amdgcn_alignbyte(B.y, B.x, 3);
           const unsigned q0 = __builtin_amdgcn_perm(B.x, T.x, 0x05040100u), q1 = __builtin_amdgcn_perm(B.x, T.x, 0x06050201u);
@@ -232,6 +302,8 @@ __global__ __launch_bounds__(256) void klt_track_kernel(const KltArgs a)
   const int lane = threadIdx.x & 63;
   const int row = lane >> 4, lane16 = lane & 15;
   const int t = wave * 4 + row;                      // this lane's track
+  extern __shared__ __align__(16) unsigned char s_win[];   // one window area per track of the workgroup (4 per wave)
+  const klt_lds_ptr lds = (klt_lds_ptr)s_win + ((threadIdx.x >> 6) * 4 + row) * kKltLdsPerTrack;
   const bool exists = t < a.n_tracks;
   int ri = 0, ci = 0;
   if (exists) { ri = a.ref_idx[t]; ci = a.cur_idx[t]; }
@@ -249,7 +321,7 @@ __global__ __launch_bounds__(256) void klt_track_kernel(const KltArgs a)
         const DevImage ref = a.frame_levels[(size_t)(run ? ri : 0) * SVOH_MAX_LEVELS + level];
         const DevImage cur = a.frame_levels[(size_t)(run ? ci : 0) * SVOH_MAX_LEVELS + level];
         const int rc = klt_level<16, 16>(ref, cur, level, rx, ry, a.opt.max_iter, a.opt.min_update_squared, pcx, pcy, converged,
-                                         lane16, it16, t16, run);
+                                         lane16, it16, t16, run, lds);
         if (run && rc) failed = true;
       }
     } else if (P == 8) {
@@ -258,7 +330,7 @@ __global__ __launch_bounds__(256) void klt_track_kernel(const KltArgs a)
         const DevImage ref = a.frame_levels[(size_t)(run ? ri : 0) * SVOH_MAX_LEVELS + level];
         const DevImage cur = a.frame_levels[(size_t)(run ? ci : 0) * SVOH_MAX_LEVELS + level];
         const int rc = klt_level<8, 16>(ref, cur, level, rx, ry, a.opt.max_iter, a.opt.min_update_squared, pcx, pcy, converged,
-                                        lane16, it8, t8, run);
+                                        lane16, it8, t8, run, lds);
         if (run && rc) failed = true;
       }
     } else {
@@ -350,7 +422,7 @@ static int launch_klt(svoh_ctx* ctx, const svoh_klt_options* options, const std:
     int block = SvohKnobs::or_default(ctx->knobs.klt_block, 256);
     if (block != 64 && block != 128 && block != 256) block = 256;
     const int tpb = block / 64 * 4;   // four tracks per wave
-    hipLaunchKernelGGL(klt_track_kernel, dim3((n_tracks + tpb - 1) / tpb), dim3(block), 0, ctx->stream, args);
+    hipLaunchKernelGGL(klt_track_kernel, dim3((n_tracks + tpb - 1) / tpb), dim3(block), (size_t)tpb * kKltLdsPerTrack, ctx->stream, args);
   }
   SVOH_HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
