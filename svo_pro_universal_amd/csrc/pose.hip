@@ -239,6 +239,9 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
   __shared__ double s_sigma, s_Iprior, s_median;
   __shared__ float s_medf;
   __shared__ int s_n, s_done, s_stop, s_del_e, s_del_c;
+  // the wave-wide solve (ldlt_apply_wave, svoh_device_utils.h): factor, permutation, right-hand side, solution
+  __shared__ double s_fact[21], s_rhs[6], s_dx[6];
+  __shared__ int s_perm[6], s_nonzero;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pbi = blockIdx.x;
   if (pbi >= a.n_problems) return;
@@ -332,40 +335,73 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
     }
     __syncthreads();
     ++iters;
-    if (tid == 0) {
-      double m[21], xg[6];
-      {
-        int idx = 0;
-        for (int r = 0; r < 6; ++r)
-          for (int c = r; c < 6; ++c) SVOH_L(c, r) = s_sum[idx++];
-        for (int r = 0; r < 6; ++r) xg[r] = s_sum[21 + r];
-      }
-      if (opt.have_rotation_prior) {   // applyPrior (pose_optimizer.cpp:320-334)
-        if (iter == 0) {
-          double hmax = 0;
-          for (int j = 3; j < 6; ++j) hmax = fmax(hmax, fabs(SVOH_L(j, j)));
-          s_Iprior = hmax * opt.prior_lambda;
+    // The step between two passes, by the first wave (round 4; as the alignment kernel's gn_wave_step): lane 0 unpacks,
+    // adds the prior and factorises (the Hessian is new in every iteration here); the substitution is taken by lanes
+    // 0..5 (permutation as an index, six divisions in one, a forward step one multiply-add for all lanes behind it) and
+    // the four divisions of the quaternion's normalisation by lanes 0..3 -- the operations of the one-lane step in
+    // their order, so the same bits.  On one lane the step was three quarters of a single bundle's kernel.
+    if (tid < 64) {
+      if (tid == 0) {
+        double m[21], xg[6];
+        {
+          int idx = 0;
+          for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) SVOH_L(c, r) = s_sum[idx++];
+          for (int r = 0; r < 6; ++r) xg[r] = s_sum[21 + r];
         }
-        for (int j = 3; j < 6; ++j) SVOH_L(j, j) += s_Iprior;
-        Rigid prior;
-        prior.q = { opt.R_prior[0], opt.R_prior[1], opt.R_prior[2], opt.R_prior[3] };
-        prior.t = { 0.0, 0.0, 0.0 };
-        double lg[6];
-        rigid_log(mul(s_T, inverse(prior)), lg);
-        for (int j = 3; j < 6; ++j) xg[j] -= s_Iprior * lg[j];
+        if (opt.have_rotation_prior) {   // applyPrior (pose_optimizer.cpp:320-334)
+          if (iter == 0) {
+            double hmax = 0;
+            for (int j = 3; j < 6; ++j) hmax = fmax(hmax, fabs(SVOH_L(j, j)));
+            s_Iprior = hmax * opt.prior_lambda;
+          }
+          for (int j = 3; j < 6; ++j) SVOH_L(j, j) += s_Iprior;
+          Rigid prior;
+          prior.q = { opt.R_prior[0], opt.R_prior[1], opt.R_prior[2], opt.R_prior[3] };
+          prior.t = { 0.0, 0.0, 0.0 };
+          double lg[6];
+          rigid_log(mul(s_T, inverse(prior)), lg);
+          for (int j = 3; j < 6; ++j) xg[j] -= s_Iprior * lg[j];
+        }
+        int tr[6];
+        const bool nonzero = ldlt_factor_regs<6>(m, tr);
+#pragma unroll
+        for (int k = 0; k < 21; ++k) s_fact[k] = m[k];
+        ldlt_perm_from_transpositions<6>(tr, s_perm);
+        s_nonzero = nonzero ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_rhs[k] = xg[k];
       }
-      if (!ldlt_solve_regs<6>(m, xg)) s_stop = 1;
-      if (s_stop) {
-        s_T = s_Told;
-        s_done = 1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int pi = s_perm[tid < 6 ? tid : 0];
+        const double x = ldlt_apply_wave<6>(s_fact, s_nonzero != 0, s_rhs[pi], tid);
+        if (tid < 6) s_dx[pi] = x;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double xg[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) xg[k] = s_dx[k];
+      const bool stop = s_stop != 0 || xg[0] != xg[0];
+      const Rigid T_old = s_T, T_older = s_Told;
+      __builtin_amdgcn_wave_barrier();   // every lane has read the state lane 0 is about to replace
+      if (stop) {
+        if (tid == 0) { s_stop = 1; s_T = T_older; s_done = 1; }
       } else {
-        Rigid Tn = mul(rigid_exp(xg), s_T);   // T_new = exp(dx) * T_old (pose_optimizer.cpp:309-318)
-        Tn.q = normalized(Tn.q);
-        s_Told = s_T;
-        s_T = Tn;
+        Rigid Tn = mul(rigid_exp(xg), T_old);   // T_new = exp(dx) * T_old (pose_optimizer.cpp:309-318)
+        const double nrm = sqrt(sqnorm(Tn.q));
+        const double num = tid == 0 ? Tn.q.w : tid == 1 ? Tn.q.x : tid == 2 ? Tn.q.y : Tn.q.z;
+        const double qd = num / nrm;             // normalized(Tn.q), one component per lane
+        Tn.q.w = wave_bcast_f64(qd, 0); Tn.q.x = wave_bcast_f64(qd, 1); Tn.q.y = wave_bcast_f64(qd, 2); Tn.q.z = wave_bcast_f64(qd, 3);
         double x_norm = -1.0;
         for (int j = 0; j < 6; ++j) { const double v = fabs(xg[j]); if (v > x_norm) x_norm = v; }
-        if (x_norm < opt.eps) s_done = 1;
+        if (tid == 0) {
+          s_Told = T_old;
+          s_T = Tn;
+          if (x_norm < opt.eps) s_done = 1;
+        }
       }
     }
     __syncthreads();

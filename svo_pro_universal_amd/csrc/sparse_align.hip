@@ -104,6 +104,9 @@ constexpr int kXchgStride = 64;         // doubles per share and parity (>= 45 +
 #ifndef SVOH_PIN_MOMENTS
 #define SVOH_PIN_MOMENTS 1
 #endif
+#ifndef SVOH_ALIGN_WAVE_STEP
+#define SVOH_ALIGN_WAVE_STEP 1
+#endif
 // rows of the full pass taken per loop trip: measured per configuration (round 3, scripts/ab.sh: 4x4 1.377 -> 1.365 ms with 2,
 // 1.44 with 4; 8x8 3.36 -> 3.25 with 4; with the illumination terms' 15 moments live, 1 for 4x4)
 #ifndef SVOH_ROW_UNROLL
@@ -149,6 +152,11 @@ struct ShState {
   double fact[36];
   int fact_tr[8];
   int fact_nonzero;
+  // the wave-wide step (gn_wave_step): the factorisation's permutation as an index, the prior's share of the gradient,
+  // the solution
+  int fact_perm[8];
+  double prior_g[8];
+  double dx[8];
   // what the one-lane step needs of the problem and camera descriptors, and what it reports per level: in LDS for the
   // problem's life, so that the step makes no round trip to global memory (a load it must wait for, or a store the
   // barrier behind it must wait for) between two passes over the patches
@@ -1076,6 +1084,169 @@ __device__ __attribute__((noinline)) void gn_serial_step(const AlignKernelArgs& 
     }
   }
 
+// The same step by the 64 lanes of the workgroup's first wave (round 4).  On one lane the step is ~1 500 instructions
+// issued one after the other while every other wave of the workgroup waits at the barrier behind it: 31 % of a single
+// 180-patch problem's kernel, 14 % of a workgroup's life in the batch.  What one lane must do stays on lane 0 and runs
+// only when it is needed -- the factorisation when the level's Hessian is new, the prior's share of the gradient (a
+// logarithm) when there is a prior.  The rest is spread: the substitution by lanes 0 .. N-1 (ldlt_apply_wave: the
+// permutation is an index, the N divisions are one, a forward step is one multiply-add for all lanes behind it), the
+// four divisions of the quaternion's normalisation and the two of the illumination update in ONE division slot
+// (lanes 0 .. 5), the cameras' poses one camera per lane.  Every value is computed by the operations of the one-lane
+// step in their order: the states are the same to the last bit or two (multiply-adds the compiler contracts either way).
+template <int P, int D, bool ILLUM>
+__device__ __attribute__((noinline)) void gn_wave_step(const AlignKernelArgs& a, int n_cams, int level, int iter,
+                                                       bool reuse_factor, int lane)
+{
+  constexpr int NH = AccLayout<D>::NH;
+  constexpr int N = ILLUM ? 8 : 6;
+  const svoh_align_options& opt = a.opt;
+  ShState& s = g_state;
+  const int nvis = g_nvis;
+  const int n_meas = nvis * P * P;
+  const double chi2 = g_sum[NH + D] / (double)n_meas;
+  const bool have_prior = s.prior.have_prior != 0;
+  const int stop_before = s.stop;
+#ifdef SVOH_PHASE_STAMPS
+  long long st_s0 = (long long)__builtin_amdgcn_s_memtime();
+#define SVOH_WAVE_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) { long long st_n = (long long)__builtin_amdgcn_s_memtime(); s.dbg[k] += st_n - st_s0; st_s0 = st_n; } else { st_s0 = (long long)__builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define SVOH_WAVE_STAMP(k) do {} while (0)
+#endif
+  __builtin_amdgcn_wave_barrier();   // every lane has read what lane 0 is about to overwrite
+  if (lane == 0) {
+    s.patch_iters += nvis;
+    g_nvis = 0;
+    if (level < SVOH_MAX_LEVELS) {
+      s.lvl_iters[level] = iter + 1;
+      s.lvl_n_meas[level] = n_meas;
+      s.lvl_chi2[level] = chi2;
+    }
+    if (!reuse_factor || have_prior) {
+      double m[36];
+#pragma unroll
+      for (int k = 0; k < 36; ++k) m[k] = 0.0;
+      if (!reuse_factor || iter == 0) {
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < D; ++r)
+#pragma unroll
+          for (int c2 = r; c2 < D; ++c2) SVOH_L(c2, r) = g_sum[idx++];
+      }
+      if (have_prior) {
+        // SparseImgAlignBase::applyPrior (sparse_img_align_base.cpp:77-107), as in gn_serial_step
+        if (iter == 0) {
+          double mt = 0, mr = 0;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) mt = fmax(mt, fabs(SVOH_L(j, j)));
+#pragma unroll
+          for (int j = 3; j < 6; ++j) mr = fmax(mr, fabs(SVOH_L(j, j)));
+          for (int j = 0; j < 3; ++j) s.I_prior[j] = 1.0 * s.prior.lambda_trans * mt;
+          for (int j = 3; j < 6; ++j) s.I_prior[j] = 1.0 * s.prior.lambda_rot * mr;
+          s.I_prior[6] = s.prior.lambda_alpha * SVOH_L(6, 6);
+          s.I_prior[7] = s.prior.lambda_beta * SVOH_L(7, 7);
+        }
+        if (!reuse_factor) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) SVOH_L(j, j) += s.I_prior[j];
+        }
+        double lg[6];
+        rigid_log(mul(inverse(load_rigid(s.prior.T_prior)), s.T), lg);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s.prior_g[j] = s.I_prior[j] * lg[j];
+        s.prior_g[6] = s.I_prior[6] * (s.prior.alpha_prior - s.alpha);
+        s.prior_g[7] = s.I_prior[7] * (s.prior.beta_prior - s.beta);
+      }
+      if (!reuse_factor) {
+        if constexpr (ILLUM) {
+          int tr[8];
+          const bool nonzero = ldlt_factor_regs<8>(m, tr);
+#pragma unroll
+          for (int k = 0; k < 36; ++k) s.fact[k] = m[k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s.fact_tr[k] = tr[k];
+          ldlt_perm_from_transpositions<8>(tr, s.fact_perm);
+          s.fact_nonzero = nonzero ? 1 : 0;
+        } else {
+          double m6[21];
+          int tr[6];
+#pragma unroll
+          for (int k = 0; k < 21; ++k) m6[k] = m[k];
+          const bool nonzero = ldlt_factor_regs<6>(m6, tr);
+#pragma unroll
+          for (int k = 0; k < 21; ++k) s.fact[k] = m6[k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) s.fact_tr[k] = tr[k];
+          ldlt_perm_from_transpositions<6>(tr, s.fact_perm);
+          s.fact_nonzero = nonzero ? 1 : 0;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  SVOH_WAVE_STAMP(0);
+  // ---- the substitution, lane i < N its component ----
+  {
+    const int pi = s.fact_perm[lane < N ? lane : 0];
+    double rhs = g_sum[NH + pi];
+    if (have_prior) rhs += s.prior_g[pi];
+    const double x = ldlt_apply_wave<N>(s.fact, s.fact_nonzero != 0, rhs, lane);
+    if (lane < N) s.dx[pi] = x;
+    else if (lane < 8) s.dx[lane] = 0.0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double xg[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) xg[k] = s.dx[k];
+  SVOH_WAVE_STAMP(1);
+  const bool stop = stop_before != 0 || xg[0] != xg[0];   // solveDefaultImpl: failure iff dx[0] is NaN; stop_ is sticky
+  Rigid T = s.T;
+  double alpha = s.alpha, beta = s.beta;
+  int level_done = 0;
+  if (stop) {
+    // rollback (mini_least_squares_solver.hpp:73-82)
+    T = s.Told; alpha = s.alpha_old; beta = s.beta_old;
+    level_done = 1;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { s.stop = 1; s.T = T; s.alpha = alpha; s.beta = beta; s.status = 2; s.level_done = 1; }
+  } else {
+    // SparseImgAlignBase::update (sparse_img_align_base.cpp:64-75)
+    double mdx[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) mdx[j] = -xg[j];
+    Rigid Tn = mul(T, rigid_exp(mdx));
+    const double nrm = sqrt(sqnorm(Tn.q));
+    // one division slot: lanes 0..3 the quaternion's components over its norm, lanes 4, 5 the illumination terms
+    const double num = lane == 0 ? Tn.q.w : lane == 1 ? Tn.q.x : lane == 2 ? Tn.q.y : lane == 3 ? Tn.q.z
+                     : lane == 4 ? (alpha - xg[6]) : (beta - xg[7]);
+    const double den = lane < 4 ? nrm : (1.0 + xg[6]);
+    const double qd = num / den;
+    Tn.q.w = wave_bcast_f64(qd, 0); Tn.q.x = wave_bcast_f64(qd, 1); Tn.q.y = wave_bcast_f64(qd, 2); Tn.q.z = wave_bcast_f64(qd, 3);
+    const double an = wave_bcast_f64(qd, 4), bn = wave_bcast_f64(qd, 5);
+    double x_norm = -1.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const double v = fabs(xg[j]); if (v > x_norm) x_norm = v; }
+    if (x_norm < opt.eps) level_done = 1;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      s.Told = T; s.alpha_old = alpha; s.beta_old = beta;
+      s.T = Tn; s.alpha = an; s.beta = bn;
+      if (level_done) s.level_done = 1;
+    }
+    T = Tn; alpha = an; beta = bn;
+  }
+  SVOH_WAVE_STAMP(2);
+  // ---- the cameras' poses, one camera per lane ----
+  {
+    const int c = lane < n_cams ? lane : 0;
+    const Rigid Tcr = mul(mul(s.cam_cur_T_cam_imu[c], T), s.cam_ref_T_imu_cam[c]);
+    if (lane < n_cams) s.Tcr[c] = Tcr;
+    if (lane == 0) { s.alpha_f = (float)alpha; s.beta_f = (float)beta; }
+  }
+  SVOH_WAVE_STAMP(3);
+}
+
 #ifndef SVOH_ALIGN_STAGED
 #define SVOH_ALIGN_STAGED 1
 #endif
@@ -1481,7 +1652,12 @@ void sparse_align_kernel(const AlignKernelArgs a)
 
       SVOH_STAMP_ADD(3);
       // ---- serial part: prior, pivoted LDL^T (or the level's factor again), SE3 update, convergence ----
+#if SVOH_ALIGN_WAVE_STEP
+      if (eval_mode) { if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, res_idx, level, iter, eval_mode, light); }
+      else if (tid < 64) gn_wave_step<P, D, ILLUM>(a, n_cams, level, iter, light, tid);
+#else
       if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, res_idx, level, iter, eval_mode, light);
+#endif
       __syncthreads();
       SVOH_STAMP_ADD(4);
       if (g_state.level_done) break;

@@ -176,6 +176,71 @@ __device__ __forceinline__ bool ldlt_apply_regs(const double (&m)[N * (N + 1) / 
   return !(x[0] != x[0]);
 }
 
+
+// ---- the same solve by the lanes of ONE wave (round 4) -------------------------------------------------------------
+// ldlt_apply_regs is a chain of ~400 instructions on one lane: two permutations by predicated swaps, 2 x 15 dependent
+// multiply-adds, N divisions.  By the lanes i < N of a wave, lane i owning component i: the permutation is an index
+// (perm[], written once by the lane that factorised), the N divisions are ONE division, a step of the forward
+// substitution is one multiply-add for all lanes behind it.  Every component goes through exactly the operations of the
+// one-lane code in its order (x_i -= L(i,c) x_c for ascending c, forward and backward): the same bits.
+__device__ __forceinline__ double wave_bcast_f64(double v, int src_lane)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// perm[i]: the input component that the transpositions of the factorisation move to position i
+template <int N>
+__device__ __forceinline__ void ldlt_perm_from_transpositions(const int (&tr)[N], int* perm)
+{
+  int idx[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) idx[k] = k;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int bb = k + 1; bb < N; ++bb)
+      if (tr[k] == bb) { const int t = idx[k]; idx[k] = idx[bb]; idx[bb] = t; }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) perm[k] = idx[k];
+}
+
+// fact: packed lower triangle as ldlt_factor_regs leaves it (LDS or global); rhs_at_perm: component perm[lane] of the
+// right-hand side (lanes < N).  Returns this lane's solved component, which belongs at index perm[lane] of the solution.
+// Called by all 64 lanes of a wave (lanes >= N take part in the broadcasts only).
+template <int N>
+__device__ __forceinline__ double ldlt_apply_wave(const double* fact, bool nonzero, double rhs_at_perm, int lane)
+{
+  if (!nonzero) return 0.0;
+  const int i = lane < N ? lane : N - 1;
+  double M[N];     // M[c] = L(i, c) for c < i, L(c, i) for c > i (the lane's row and column of the factor)
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    const int r2 = c < i ? i : c, c2 = c < i ? c : i;
+    M[c] = fact[r2 * (r2 + 1) / 2 + c2];
+  }
+  const double dd = fact[i * (i + 1) / 2 + i];
+  double x = rhs_at_perm;
+#pragma unroll
+  for (int c = 0; c < N - 1; ++c) {
+    const double xc = wave_bcast_f64(x, c);
+    const double t = __builtin_fma(-M[c], xc, x);
+    x = lane > c ? t : x;
+  }
+  x = (fabs(dd) > DBL_MIN) ? x / dd : 0.0;
+#pragma unroll
+  for (int r = N - 2; r >= 0; --r) {
+#pragma unroll
+    for (int c = r + 1; c < N; ++c) {
+      const double xc = wave_bcast_f64(x, c);
+      const double t = __builtin_fma(-M[c], xc, x);
+      x = lane == r ? t : x;
+    }
+  }
+  return x;
+}
+
 template <int N>
 __device__ __forceinline__ bool ldlt_solve_regs(double (&m)[N * (N + 1) / 2], double (&x)[N])
 {
