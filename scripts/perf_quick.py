@@ -22,3 +22,6 @@ run("0 only", max_level=0, min_level=0)
 if os.environ.get("ILLUM", "1") == "1":
     run("4..2 illum", min_level=2, estimate_illumination_gain=1, estimate_illumination_offset=1)
     run("4..0 illum", min_level=0, estimate_illumination_gain=1, estimate_illumination_offset=1)
+if os.environ.get("ROBUST", "0") == "1":
+    run("4..0 robust", min_level=0, robustification=1)
+    run("4..0 robust+illum", min_level=0, robustification=1, estimate_illumination_gain=1, estimate_illumination_offset=1)

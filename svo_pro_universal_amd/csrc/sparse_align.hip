@@ -311,7 +311,7 @@ __device__ __forceinline__ void jac_rows(const double* jc, const CamModel& cm, b
 // the current rows of a 10-wide window are what pushed the 8x8 kernel 200-400 registers over the budget
 // (.vgpr_spill_count 209 / 436 in round 1).  The halves add into the same moments; the two window columns they
 // share are interpolated twice.
-template <int PH, int PW, int D, bool RLDS, bool CLDS, bool GONLY, bool ZERO>
+template <int PH, int PW, int D, bool RLDS, bool CLDS, bool GONLY, bool ZERO, bool ROB = false>
 __device__ __forceinline__ void patch_moments_part(
     const ImgView<RLDS>& ref, const ImgView<CLDS>& cur, int ru, int rv, double rsu, double rsv, int cu, int cv,
     double csu, double csv, double one_plus_alpha, double beta, bool robust, float weight_scale,
@@ -375,7 +375,9 @@ __device__ __forceinline__ void patch_moments_part(
 
   // the gradient-only pass has registers to spare (7 or 9 accumulators instead of 28 or 45): unrolled rows let the
   // next row's LDS / L2 reads overlap this row's arithmetic (1.64 -> 1.59 ms on the headline config)
-  constexpr int kRowUnroll = GONLY ? SVOH_ROW_UNROLL_GONLY : SVOH_ROW_UNROLL;
+  // (with Tukey weights a row carries a float division and the weighted forms of all moments: one row per trip -- four
+  // unrolled rows of an 8x8 patch were 240-390 spilled registers)
+  constexpr int kRowUnroll = GONLY ? SVOH_ROW_UNROLL_GONLY : (ROB ? 1 : SVOH_ROW_UNROLL);
 #pragma unroll kRowUnroll
   for (int y = 0; y < PH; ++y) {
     const int rrow = roff + (y + 3) * ref.pitch;
@@ -456,20 +458,20 @@ __device__ __forceinline__ void patch_moments_part(
   }
 }
 
-template <int P, int D, bool RLDS, bool CLDS, bool GONLY = false>
+template <int P, int D, bool RLDS, bool CLDS, bool GONLY = false, bool ROB = false>
 __device__ __forceinline__ void patch_moments(
     const ImgView<RLDS>& ref, const ImgView<CLDS>& cur, int ru, int rv, double rsu, double rsv, int cu, int cv,
     double csu, double csv, double one_plus_alpha, double beta, bool robust, float weight_scale,
     double (&mom)[AccLayout<D>::NMOM])
 {
   if constexpr (P == 8) {
-    patch_moments_part<8, 4, D, RLDS, CLDS, GONLY, true>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta,
-                                                         robust, weight_scale, mom);
-    patch_moments_part<8, 4, D, RLDS, CLDS, GONLY, false>(ref, cur, ru + 4, rv, rsu, rsv, cu + 4, cv, csu, csv, one_plus_alpha,
-                                                          beta, robust, weight_scale, mom);
+    patch_moments_part<8, 4, D, RLDS, CLDS, GONLY, true, ROB>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta,
+                                                              robust, weight_scale, mom);
+    patch_moments_part<8, 4, D, RLDS, CLDS, GONLY, false, ROB>(ref, cur, ru + 4, rv, rsu, rsv, cu + 4, cv, csu, csv, one_plus_alpha,
+                                                               beta, robust, weight_scale, mom);
   } else {
-    patch_moments_part<P, P, D, RLDS, CLDS, GONLY, true>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta,
-                                                         robust, weight_scale, mom);
+    patch_moments_part<P, P, D, RLDS, CLDS, GONLY, true, ROB>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta,
+                                                              robust, weight_scale, mom);
   }
   // dx, dy above are twice the central differences (sparse_img_align.cpp:386-387 has the 0.5)
   mom[3] *= 0.5; mom[4] *= 0.5;
@@ -490,7 +492,7 @@ __device__ __forceinline__ void patch_moments(
 // the moments, so every lane applies it to its own rows and the wave reduction adds row groups instead of patches.
 // (Exchanging would cost more than it saves: a double moved over DPP is two VALU slots, an interpolated value
 // recomputed is four; summing a group's moments first costs 18-36 slots per lane against the 66 of the map.)
-template <int P, int LPP, int D, bool RLDS, bool CLDS, bool GONLY = false>
+template <int P, int LPP, int D, bool RLDS, bool CLDS, bool GONLY = false, bool ROB = false>
 __device__ __forceinline__ void patch_rows_moments(
     const ImgView<RLDS>& ref, const ImgView<CLDS>& cur, int ru, int rv, double rsu, double rsv, int cu, int cv,
     double csu, double csv, int r, double one_plus_alpha, double beta, bool robust, float weight_scale,
@@ -500,13 +502,13 @@ __device__ __forceinline__ void patch_rows_moments(
   static_assert(PH * LPP == P && PH >= 1, "lanes per patch must divide the patch height");
   const int rv0 = rv + r * PH, cv0 = cv + r * PH;
   if constexpr (P == 8) {
-    patch_moments_part<PH, 4, D, RLDS, CLDS, GONLY, true>(ref, cur, ru, rv0, rsu, rsv, cu, cv0, csu, csv, one_plus_alpha, beta,
-                                                          robust, weight_scale, mom);
-    patch_moments_part<PH, 4, D, RLDS, CLDS, GONLY, false>(ref, cur, ru + 4, rv0, rsu, rsv, cu + 4, cv0, csu, csv, one_plus_alpha,
-                                                           beta, robust, weight_scale, mom);
+    patch_moments_part<PH, 4, D, RLDS, CLDS, GONLY, true, ROB>(ref, cur, ru, rv0, rsu, rsv, cu, cv0, csu, csv, one_plus_alpha, beta,
+                                                               robust, weight_scale, mom);
+    patch_moments_part<PH, 4, D, RLDS, CLDS, GONLY, false, ROB>(ref, cur, ru + 4, rv0, rsu, rsv, cu + 4, cv0, csu, csv, one_plus_alpha,
+                                                                beta, robust, weight_scale, mom);
   } else {
-    patch_moments_part<PH, P, D, RLDS, CLDS, GONLY, true>(ref, cur, ru, rv0, rsu, rsv, cu, cv0, csu, csv, one_plus_alpha, beta,
-                                                          robust, weight_scale, mom);
+    patch_moments_part<PH, P, D, RLDS, CLDS, GONLY, true, ROB>(ref, cur, ru, rv0, rsu, rsv, cu, cv0, csu, csv, one_plus_alpha, beta,
+                                                               robust, weight_scale, mom);
   }
   mom[3] *= 0.5; mom[4] *= 0.5;
   if constexpr (!GONLY) {
@@ -631,7 +633,7 @@ __device__ __forceinline__ double* ws_pair(const WsView& w, int pair, int64_t gi
 // visibility differs from the one recorded by the last full pass (the state value of its workspace row) -- the
 // caller then repeats the iteration with a full pass.  A full pass records the visibility.
 // jc: the camera's kJacConsts block (LDS).
-template <int P, int D, int NT, bool LDS, bool GONLY = false>
+template <int P, int D, int NT, bool LDS, bool GONLY = false, bool ROB = false>
 __device__ __forceinline__ void accumulate_camera(
     const AlignKernelArgs& a, const WsView& ws, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
@@ -684,8 +686,8 @@ __device__ __forceinline__ void accumulate_camera(
     const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
     const double rsu = ru_tl - ru, rsv = rv_tl - rv;
     double mom[AccLayout<D>::NMOM];
-    patch_moments<P, D, LDS, LDS, GONLY>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d, robust,
-                                         weight_scale, mom);
+    patch_moments<P, D, LDS, LDS, GONLY, ROB>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d, robust,
+                                              weight_scale, mom);
 #if SVOH_PIN_MOMENTS
     // see accumulate_camera_rows: the moments are finished here, the pixel arithmetic is not sunk behind what follows.
     // On the LDS-resident levels only: where the rows come from global memory the interleaving hides their latency
@@ -713,7 +715,7 @@ __device__ __forceinline__ void accumulate_camera(
 // bytes: one request), projection and visibility, the Jacobian rows -- is computed by every lane of the group alike:
 // identical values, no exchange, and no divergence inside a group.  The patch is counted and its visibility recorded
 // by the group's lane 0.
-template <int P, int LPP, int D, int NT, bool LDS, bool GONLY = false>
+template <int P, int LPP, int D, int NT, bool LDS, bool GONLY = false, bool ROB = false>
 __device__ __forceinline__ void accumulate_camera_rows(
     const AlignKernelArgs& a, const WsView& ws, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
@@ -766,7 +768,7 @@ __device__ __forceinline__ void accumulate_camera_rows(
     const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
     const double rsu = ru_tl - ru, rsv = rv_tl - rv;
     double mom[AccLayout<D>::NMOM];
-    patch_rows_moments<P, LPP, D, LDS, LDS, GONLY>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, r, one_plus_alpha, beta_d, robust,
+    patch_rows_moments<P, LPP, D, LDS, LDS, GONLY, ROB>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, r, one_plus_alpha, beta_d, robust,
                                                    weight_scale, mom);
     // the moments are finished HERE: left alone, the compiler sinks the pixel arithmetic (pure) behind the branches of
     // the Jacobian rows, towards its use, while the rows' bytes wait in registers -- spilled ones (measured: the pass of
@@ -794,7 +796,7 @@ __device__ __forceinline__ void accumulate_camera_rows(
 // behind the pixel loop for the Jacobian rows (three doubles that need not stay in registers through it).
 // stage: this wave's 2 x 3 x 64 x 16 B staging area.  Control flow is wave-uniform (every lane runs every pass).
 constexpr int kStageDoubles = 2 * kWsPairs * 128;
-template <int P, int D, int NT, bool LDS, bool GONLY = false>
+template <int P, int D, int NT, bool LDS, bool GONLY = false, bool ROB = false>
 __device__ __forceinline__ void accumulate_camera_staged(
     const AlignKernelArgs& a, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
@@ -859,8 +861,8 @@ __device__ __forceinline__ void accumulate_camera_staged(
         const double rv_tl = vs.x * scale - patch_center_wb;
         const int ru = (int)floor(ru_tl), rv = (int)floor(rv_tl);
         const double rsu = ru_tl - ru, rsv = rv_tl - rv;
-        patch_moments<P, D, LDS, LDS, GONLY>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d,
-                                             robust, weight_scale, mom);
+        patch_moments<P, D, LDS, LDS, GONLY, ROB>(ref, cur, ru, rv, rsu, rsv, cu, cv, csu, csv, one_plus_alpha, beta_d,
+                                                  robust, weight_scale, mom);
       }
     }
     if (vis) {
@@ -1536,15 +1538,15 @@ void sparse_align_kernel(const AlignKernelArgs a)
               cur.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); cur.pitch = cim.w;
               off += ((cim.w * cim.h + 15) & ~15);
               if constexpr (ROWS) {
-                accumulate_camera_rows<P, (ROWS ? LPP : 2), D, NT, true, G>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                accumulate_camera_rows<P, (ROWS ? LPP : 2), D, NT, true, G, ROBUST>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                                             est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c],
                                                                             acc_ref, nvis, changed);
               } else if constexpr (STAGED)
-                accumulate_camera_staged<P, D, NT, true, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                accumulate_camera_staged<P, D, NT, true, G, ROBUST>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                             est_alpha, est_beta, robust, dist_jac, weight_scale, tid,
                                                             s_stage + wave * kStageDoubles, s_jc[c], acc_ref, nvis, changed);
               else
-                accumulate_camera<P, D, NT, true, G>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                accumulate_camera<P, D, NT, true, G, ROBUST>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                      est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c], acc_ref,
                                                      nvis, changed);
             } else {
@@ -1552,15 +1554,15 @@ void sparse_align_kernel(const AlignKernelArgs a)
               ref.p = rim.data; ref.pitch = rim.pitch;
               cur.p = cim.data; cur.pitch = cim.pitch;
               if constexpr (ROWS) {
-                accumulate_camera_rows<P, (ROWS ? LPP : 2), D, NT, false, G>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                accumulate_camera_rows<P, (ROWS ? LPP : 2), D, NT, false, G, ROBUST>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                                              est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c],
                                                                              acc_ref, nvis, changed);
               } else if constexpr (STAGED)
-                accumulate_camera_staged<P, D, NT, false, G>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                accumulate_camera_staged<P, D, NT, false, G, ROBUST>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                              est_alpha, est_beta, robust, dist_jac, weight_scale, tid,
                                                              s_stage + wave * kStageDoubles, s_jc[c], acc_ref, nvis, changed);
               else
-                accumulate_camera<P, D, NT, false, G>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                accumulate_camera<P, D, NT, false, G, ROBUST>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
                                                       est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c], acc_ref,
                                                       nvis, changed);
             }

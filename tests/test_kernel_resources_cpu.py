@@ -1,0 +1,67 @@
+"""Register / LDS budgets of the built kernels, read from the objects build() leaves next to libsvo_hip.so (no compiler
+run, no GPU: scripts/kernel_resources_built.py takes the gfx950 code object out of the .o and reads its metadata).
+
+A regression here costs throughput without failing any parity test: a kernel that spills into its pixel loops, a
+256-thread alignment workgroup whose static LDS no longer leaves room for two workgroups per compute unit,
+a KLT kernel that drops below five waves per SIMD."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "svo_pro_universal_amd", "csrc")
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import kernel_resources_built as krb
+    if not all(os.path.exists(os.path.join(CSRC, f)) for f in ("sparse_align.o", "klt.o", "matcher.o", "pose.o")):
+        subprocess.check_call(["make", "-s", "-C", CSRC])
+    return {f: krb.kernels(os.path.join(CSRC, f)) for f in ("sparse_align.o", "klt.o", "matcher.o", "pose.o")}
+
+
+def _align(built, P, NT, illum, cluster, robust, lpp):
+    b = lambda x: "true" if x else "false"
+    return built["sparse_align.o"]["sparse_align_kernel<%d, %d, %s, %s, %s, %d>" % (P, NT, b(illum), b(cluster), b(robust), lpp)]
+
+
+def test_alignment_kernels_fit_their_geometry(built):
+    ks = {k: v for k, v in built["sparse_align.o"].items() if k.startswith("sparse_align_kernel<")}
+    assert len(ks) >= 40
+    for name, d in ks.items():
+        assert d["vgpr"] <= 256, name                    # two waves per SIMD: 256- and 512-thread workgroups alike
+        if ", 256, " in name:
+            # two 256-thread workgroups per compute unit: static LDS + the 51 KB image area within half of 160 KB
+            # (launch_one trims the image area by what the code object reports, but levels 4..2 of a 640x480 pair need
+            # 50 400 bytes of it)
+            assert d["lds"] + 50400 <= 163840 // 2, (name, d["lds"])
+
+
+def test_spill_budgets(built):
+    # the headline instantiations: what spills, spills outside the pixel loops (scripts/isa_loop_census.sh); a count
+    # well above today's means the allocation has changed character
+    assert _align(built, 4, 256, False, False, False, 1)["vgpr_spill"] <= 60      # today 33
+    assert _align(built, 8, 256, False, False, False, 1)["vgpr_spill"] <= 90      # today 56
+    assert _align(built, 4, 256, True, False, False, 1)["vgpr_spill"] <= 100      # today 61
+    # the robust 8x8 instantiations were at 238 - 388 spilled registers (four unrolled rows of
+    # Tukey-weighted moments); one row per trip: 36 - 105
+    for illum in (False, True):
+        for cluster in (False, True):
+            assert _align(built, 8, 256, illum, cluster, True, 1)["vgpr_spill"] <= 150, (illum, cluster)
+        assert _align(built, 8, 512, illum, False, True, 1)["vgpr_spill"] <= 150
+    # the rows geometry of small problems
+    assert _align(built, 4, 512, False, False, False, 2)["vgpr_spill"] <= 40      # today 14
+    assert _align(built, 8, 512, False, False, False, 4)["vgpr_spill"] <= 80      # today 39
+
+
+def test_klt_seeds_pose_occupancy(built):
+    klt = built["klt.o"]["klt_track_kernel"]
+    assert klt["vgpr"] <= 96 and klt["vgpr_spill"] == 0          # five waves per SIMD
+    seeds = built["matcher.o"]["update_seeds_packed_kernel"]
+    assert seeds["vgpr"] <= 168 and seeds["vgpr_spill"] <= 4     # three waves per SIMD
+    for name, d in built["pose.o"].items():
+        if name.startswith("pose_optimize_kernel<") and not name.endswith(", 1>"):   # unit-plane / image-plane error models
+            assert d["vgpr"] <= 256 and d["vgpr_spill"] == 0, name
