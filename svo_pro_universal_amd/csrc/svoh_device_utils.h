@@ -25,8 +25,34 @@ __device__ __forceinline__ double xor_exchange(double v)
     const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, ctrl, 0xF, 0xF, false);
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), ctrl, 0xF, 0xF, false);
     return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+  } else if constexpr (OFF == 4 || OFF == 8) {
+    // inside a row of 16 lanes: both rotations over the DPP network, each lane keeps the one that comes from lane ^ OFF
+    // (row_ror:n hands lane l the value of lane (l - n) mod 16)
+    const unsigned long long b = __double_as_longlong(v);
+    const int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
+    const int lo_dn = __builtin_amdgcn_update_dpp(0, lo, 0x120 + OFF, 0xF, 0xF, false), hi_dn = __builtin_amdgcn_update_dpp(0, hi, 0x120 + OFF, 0xF, 0xF, false);
+    const int lo_up = __builtin_amdgcn_update_dpp(0, lo, 0x120 + 16 - OFF, 0xF, 0xF, false), hi_up = __builtin_amdgcn_update_dpp(0, hi, 0x120 + 16 - OFF, 0xF, 0xF, false);
+    const bool upper = (__lane_id() & OFF) != 0;   // this lane's partner is the lower one: lane - OFF
+    const int rlo = upper ? lo_dn : lo_up, rhi = upper ? hi_dn : hi_up;
+    return __longlong_as_double(((unsigned long long)(unsigned)rhi << 32) | (unsigned)rlo);
   } else {
-    return __shfl_xor(v, OFF, 64);
+    // across rows: gfx950's v_permlane16_swap (odd rows of the first operand <-> even rows of the second) and
+    // v_permlane32_swap (upper half <-> lower half) instead of two trips through the LDS crossbar (ds_bpermute)
+    static_assert(OFF == 16 || OFF == 32, "wave64 butterfly");
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const bool upper = (__lane_id() & OFF) != 0;
+    unsigned rlo, rhi;
+    if constexpr (OFF == 16) {
+      const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+      const auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      rlo = upper ? a[0] : a[1]; rhi = upper ? c[0] : c[1];
+    } else {
+      const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+      const auto c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      rlo = upper ? a[0] : a[1]; rhi = upper ? c[0] : c[1];
+    }
+    return __longlong_as_double(((unsigned long long)rhi << 32) | rlo);
   }
 }
 
