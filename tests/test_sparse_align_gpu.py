@@ -195,6 +195,33 @@ def test_all_workgroup_geometries(gpu_ctx, oracle_lib, nt, rows, monkeypatch):
         check_run(gpu_ctx, orc, opt, opb2, gpb2)
 
 
+@pytest.mark.parametrize("rows", [None, "0", "2", "4"])
+def test_small_stereo_bundle_with_prior_in_every_lane_geometry(gpu_ctx, oracle_lib, rows, monkeypatch):
+    """Round 4's small-problem paths together: a stereo bundle of 2 x ~60 features (the workspace rows of both cameras live
+    in LDS, the default geometry gives such a problem two lanes per patch), gain + offset estimated, a rotation /
+    translation / illumination prior (the wave-wide Gauss-Newton step with lane 0's prior part, eight parameters, one
+    camera pose per lane) -- against the oracle, in the default geometry and with the lanes per patch forced."""
+    orc = oracle_lib
+    if rows is not None:
+        monkeypatch.setenv("SVOH_ALIGN_ROWS", rows)
+        gpu_ctx.reload_knobs()
+    a = helpers.small_scene(141, n=64, border_features=8, gain=1.03, offset=2.0)
+    b = synth.make_align_scene(141, n_features=58, cam=synth.Camera.euroc_like(), border_features=6, gain=1.03, offset=2.0)
+    Tp = synth.SE3(synth.quat_from_axis_angle([0.2, -1, 0.3], 0.003), [0.002, -0.001, 0.001])
+    prior = helpers.make_prior(Tp, 0.5, 0.2, alpha=0.02, beta=-0.3, lambda_alpha=0.3, lambda_beta=0.3)
+    opb, gpb, keep = both(gpu_ctx, orc, [a, b], prior=prior)
+    for kw in (dict(min_level=2), dict(min_level=0, robustification=1)):
+        opt = capi.default_align_options(estimate_illumination_gain=1, estimate_illumination_offset=1, **kw)
+        check_evaluate(gpu_ctx, orc, opt, opb, gpb, (4, 2))
+        check_run(gpu_ctx, orc, opt, opb, gpb)
+    # the same bundle with 8x8 patches (up to eight lanes per patch)
+    a8 = helpers.small_scene(142, n=30, P=8, border_features=4)
+    opb8, gpb8, keep8 = both(gpu_ctx, orc, [a8])
+    opt8 = capi.default_align_options(patch_size=8, min_level=1)
+    check_evaluate(gpu_ctx, orc, opt8, opb8, gpb8, (3, 1))
+    check_run(gpu_ctx, orc, opt8, opb8, gpb8)
+
+
 def test_device_resident_inputs(gpu_ctx, oracle_lib):
     import torch
     orc = oracle_lib
