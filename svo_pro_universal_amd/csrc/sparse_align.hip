@@ -107,6 +107,9 @@ constexpr int kXchgStride = 64;         // doubles per share and parity (>= 45 +
 #ifndef SVOH_ALIGN_WAVE_STEP
 #define SVOH_ALIGN_WAVE_STEP 1
 #endif
+#ifndef SVOH_STEP_PRIO
+#define SVOH_STEP_PRIO 1
+#endif
 // rows of the full pass taken per loop trip: measured per configuration (round 3, scripts/ab.sh: 4x4 1.377 -> 1.365 ms with 2,
 // 1.44 with 4; 8x8 3.36 -> 3.25 with 4; with the illumination terms' 15 moments live, 1 for 4x4)
 #ifndef SVOH_ROW_UNROLL
@@ -1667,7 +1670,17 @@ void sparse_align_kernel(const AlignKernelArgs a)
       // ---- serial part: prior, pivoted LDL^T (or the level's factor again), SE3 update, convergence ----
 #if SVOH_ALIGN_WAVE_STEP
       if (eval_mode) { if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, res_idx, level, iter, eval_mode, light); }
-      else if (tid < 64) gn_wave_step<P, D, ILLUM>(a, n_cams, level, iter, light, tid);
+      else if (tid < 64) {
+        // the step is its workgroup's critical path (three waves wait at the barrier behind it): it goes ahead of the
+        // other workgroup's pass waves on its SIMD
+#if SVOH_STEP_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        gn_wave_step<P, D, ILLUM>(a, n_cams, level, iter, light, tid);
+#if SVOH_STEP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+      }
 #else
       if (tid == 0) gn_serial_step<P, D, ILLUM>(a, pb, cams, n_cams, res_idx, level, iter, eval_mode, light);
 #endif
