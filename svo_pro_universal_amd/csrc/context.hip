@@ -331,6 +331,7 @@ void load_knobs_from_env(SvohKnobs& k)
 #endif
   k.align_threads = get("SVOH_ALIGN_THREADS");
   k.align_rows = get("SVOH_ALIGN_ROWS");
+  k.align_latency_build = get("SVOH_ALIGN_LATENCY_BUILD");
   k.align_lds = get("SVOH_ALIGN_LDS");
   k.align_wg_per_cu = get("SVOH_ALIGN_WG_PER_CU");
   k.kernel_timing = get("SVOH_KERNEL_TIMING");

@@ -76,6 +76,7 @@ struct AlignKernelArgs {
   uint8_t* wvis;                        // visibility of the last evaluation
   svoh_align_options opt;
   int32_t lds_img_bytes;                // dynamic LDS available for image staging
+  int32_t latency_build;                // host side only: fewer problems than compute units -> the one-wave-per-SIMD build of the 256-thread kernel
   int32_t lds_two_per_cu;               // host side only: the launch counts on two workgroups per compute unit (launch_one sizes the image area for it)
   int32_t ws_lds_bytes;                 // > 0: the feature workspace of a (small) problem lives in LDS behind the image area (512-thread geometry)
   int32_t eval_level;                   // <0: full run; >=0: evaluate once at that level
@@ -1274,10 +1275,15 @@ __device__ __attribute__((noinline)) void gn_wave_step(const AlignKernelArgs& a,
 // instantiation in turn has no gradient-only pass (the weights change every iteration).
 // LPP > 1: the rows geometry (accumulate_camera_rows: LPP lanes per patch), in the 512-thread workgroup of the latency
 // mode (few problems), at the same 256 registers.
-template <int P, int NT, bool ILLUM, bool CLUSTER = false, bool ROBUST = false, int LPP = 1>
-__global__ __launch_bounds__(NT, (NT == 256 ? SVOH_ALIGN_MIN_WAVES_256 : 2))
+// LAT: the 256-thread kernel built for ONE wave per SIMD (a launch of fewer problems than compute units: nothing shares
+// the SIMD anyway).  With the whole register file to itself the kernel spills nothing (274-302 registers instead of
+// 256 + 26-56 spilled), and in a launch that small a spilled register is a round trip to memory nobody hides: the
+// full passes of a single 180-patch problem took twice the cycles of its gradient-only passes.
+template <int P, int NT, bool ILLUM, bool CLUSTER = false, bool ROBUST = false, int LPP = 1, bool LAT = false>
+__global__ __launch_bounds__(NT, (NT == 256 ? (LAT ? 1 : SVOH_ALIGN_MIN_WAVES_256) : 2))
 void sparse_align_kernel(const AlignKernelArgs a)
 {
+  static_assert(!LAT || (NT == 256 && !CLUSTER && LPP == 1), "latency build: the 256-thread lane-per-patch geometry");
   static_assert(LPP == 1 || (!CLUSTER && NT == 512 && LPP <= P), "rows geometry: 512 threads, no cluster mode");
   static_assert(NT == 256 || NT == 512, "workgroups of 256 or 512 threads");
   constexpr bool ROWS = LPP > 1;
@@ -1774,10 +1780,10 @@ void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_al
 struct LaunchCfg { int nt; size_t lds; };
 
 constexpr size_t kLdsPerCu = 163840;   // gfx950: 160 KB per compute unit
-template <int P, int NT, bool ILLUM, bool CLUSTER, bool ROBUST, int LPP = 1>
+template <int P, int NT, bool ILLUM, bool CLUSTER, bool ROBUST, int LPP = 1, bool LAT = false>
 static hipError_t launch_one(hipStream_t st, int grid, size_t lds, AlignKernelArgs args)
 {
-  auto kern = sparse_align_kernel<P, NT, ILLUM, CLUSTER, ROBUST, LPP>;
+  auto kern = sparse_align_kernel<P, NT, ILLUM, CLUSTER, ROBUST, LPP, LAT>;
   if (NT == 256 && args.lds_two_per_cu) {
     // Two workgroups per compute unit is what the batch geometry is built on, and the budget is tight (28-29.5 KB of
     // static LDS + 51 KB of images = 79-80.5 of the 80 KB a workgroup may have).  The static part is asked of the code
@@ -1809,7 +1815,8 @@ template <int P, bool ILLUM, bool ROBUST>
 static hipError_t launch_nt(hipStream_t st, int nt, int lpp, int grid, size_t lds, const AlignKernelArgs& args)
 {
   if (args.cluster > 1) return launch_one<P, 256, ILLUM, true, ROBUST>(st, grid, lds, args);
-  if (nt == 256) return launch_one<P, 256, ILLUM, false, ROBUST>(st, grid, lds, args);
+  if (nt == 256) return args.latency_build ? launch_one<P, 256, ILLUM, false, ROBUST, 1, true>(st, grid, lds, args)
+                                           : launch_one<P, 256, ILLUM, false, ROBUST>(st, grid, lds, args);
   switch (lpp) {
     case 2: return launch_one<P, 512, ILLUM, false, ROBUST, 2>(st, grid, lds, args);
     case 4: return launch_one<P, 512, ILLUM, false, ROBUST, 4>(st, grid, lds, args);
@@ -2122,6 +2129,8 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // area of the workspace rows) -> 51 KB for images: levels 4, 3 and 2 of a 640x480 pyramid side by side (50 400 B);
   // launch_one trims the image area to what the instantiation's static LDS really leaves of half a compute unit
   size_t lds = (nt == 256) ? 52224 : 78 * 1024;
+  // SVOH_ALIGN_LATENCY_BUILD=0 keeps the batch build for small launches too (A/B)
+  args.latency_build = (nt == 256 && !cluster && n_desc < ctx->num_cus && SvohKnobs::or_default(ctx->knobs.align_latency_build, 1) != 0) ? 1 : 0;
   args.lds_two_per_cu = (nt == 256 && !cluster && ctx->knobs.align_lds == kKnobUnset && ctx->knobs.align_wg_per_cu == kKnobUnset) ? 1 : 0;
   lds = (size_t)SvohKnobs::or_default(ctx->knobs.align_lds, (int)lds);
   // 160 KB per workgroup minus the kernel's static LDS

@@ -92,6 +92,7 @@ struct SvohKnobs {
 #endif
   int align_threads = kKnobUnset;             // SVOH_ALIGN_THREADS: 256 / 512 / 1024
   int align_rows = kKnobUnset;                // SVOH_ALIGN_ROWS: 0 / 1 rows geometry of the alignment (P lanes per patch; 512 / 1024 threads)
+  int align_latency_build = kKnobUnset;       // SVOH_ALIGN_LATENCY_BUILD: 0 = small launches use the batch build of the 256-thread kernel too
   int align_lds = kKnobUnset;                 // SVOH_ALIGN_LDS: bytes of LDS for image levels
   int align_wg_per_cu = kKnobUnset;           // SVOH_ALIGN_WG_PER_CU
   int kernel_timing = kKnobUnset;             // SVOH_KERNEL_TIMING: 1 = bracket every kernel with an event pair (svoh_set_kernel_timing)
