@@ -26,6 +26,7 @@
 //     chi2) are reduced with wave shuffles, then across waves through LDS.
 //     The summation order differs from the reference's sequential order; all
 //     other arithmetic follows the reference expression by expression.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -1789,12 +1790,14 @@ static hipError_t launch_one(hipStream_t st, int grid, size_t lds, AlignKernelAr
     // static LDS + 51 KB of images = 79-80.5 of the 80 KB a workgroup may have).  The static part is asked of the code
     // object, not assumed: if it ever grows, the image area shrinks (a level fewer in LDS) instead of the second
     // workgroup silently not fitting -- half the throughput with every test green.
-    static size_t static_lds = 0;   // per instantiation; the same for every context (one code object)
+    static std::atomic<size_t> static_lds_cache{ 0 };   // per instantiation; the same for every context and host thread (one code object)
+    size_t static_lds = static_lds_cache.load(std::memory_order_relaxed);
     if (static_lds == 0) {
       hipFuncAttributes attr;
       hipError_t ea = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern));
       if (ea != hipSuccess) return ea;
       static_lds = attr.sharedSizeBytes ? attr.sharedSizeBytes : 1;
+      static_lds_cache.store(static_lds, std::memory_order_relaxed);
     }
     const size_t room = kLdsPerCu / 2 > static_lds ? (kLdsPerCu / 2 - static_lds) & ~(size_t)15 : 0;
     if (lds > room) {
