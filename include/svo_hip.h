@@ -142,6 +142,11 @@ int svoh_download_level(svoh_ctx* ctx, svoh_frame_t frame, int level,
                         uint8_t* out, int* out_width, int* out_height);
 int svoh_frame_info(svoh_ctx* ctx, svoh_frame_t frame, int* n_levels,
                     int* width0, int* height0);
+/* Gives the frame up (the reference drops a Frame's img_pyr_ with the Frame).  Returns at once: launches queued before
+ * the call may still read the frame, and they will -- its memory goes to a small per-context pool (8 allocations) and is
+ * only written again by a later svoh_build_pyramid / svoh_upload_pyramid of the same size, on the context's stream,
+ * behind them; a frame that does not fit the pool is freed (which waits for the device).  The handle is invalid from
+ * here on. */
 int svoh_release_frame(svoh_ctx* ctx, svoh_frame_t frame);
 
 /* What the context holds on the device right now: live frame handles, bytes of the frame

@@ -279,6 +279,22 @@ static bool step_rule(int rounding, int in_w, int in_h, bool* writes_all)
   return sse;
 }
 
+// a slab of `bytes` (+ tail padding): from the context's pool of released slabs when one of that size is there
+static hipError_t make_slab(svoh_ctx* ctx, size_t bytes, std::shared_ptr<Slab>* out)
+{
+  auto slab = std::make_shared<Slab>();
+  slab->alloc = bytes + kSlabTailPad;
+  slab->ptr = ctx->slab_pool->take(slab->alloc);
+  if (!slab->ptr) {
+    hipError_t e = hipMalloc(&slab->ptr, slab->alloc);
+    if (e != hipSuccess) { slab->ptr = nullptr; return e; }
+  }
+  slab->bytes = bytes;
+  slab->pool = ctx->slab_pool;
+  *out = std::move(slab);
+  return hipSuccess;
+}
+
 static uint64_t register_frame(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab, uint8_t* base, int w, int h,
                                int n_levels)
 {
@@ -465,9 +481,8 @@ try {
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   size_t offs[SVOH_MAX_LEVELS]; int ws[SVOH_MAX_LEVELS], hs[SVOH_MAX_LEVELS];
   const size_t bytes = frame_layout(width[0], height[0], n_levels, offs, ws, hs);
-  auto slab = std::make_shared<Slab>();
-  SVOH_HIP_TRY(ctx, hipMalloc(&slab->ptr, bytes + kSlabTailPad));
-  slab->bytes = bytes;
+  std::shared_ptr<Slab> slab;
+  SVOH_HIP_TRY(ctx, make_slab(ctx, bytes, &slab));
   uint8_t* base = static_cast<uint8_t*>(slab->ptr);
   for (int i = 0; i < n_levels; ++i)
     SVOH_HIP_TRY(ctx, hipMemcpy2DAsync(base + offs[i], (size_t)ws[i], level_data[i], (size_t)pitch[i],
@@ -490,9 +505,8 @@ try {
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   size_t offs[SVOH_MAX_LEVELS]; int ws[SVOH_MAX_LEVELS], hs[SVOH_MAX_LEVELS];
   const size_t fbytes = frame_layout(width, height, n_levels, offs, ws, hs);
-  auto slab = std::make_shared<Slab>();
-  SVOH_HIP_TRY(ctx, hipMalloc(&slab->ptr, fbytes * (size_t)n_images + kSlabTailPad));
-  slab->bytes = fbytes * (size_t)n_images;
+  std::shared_ptr<Slab> slab;
+  SVOH_HIP_TRY(ctx, make_slab(ctx, fbytes * (size_t)n_images, &slab));
   uint8_t* base = static_cast<uint8_t*>(slab->ptr);
   // level 0: copy into the tightly packed layout
   const hipMemcpyKind kind = mem_space == SVOH_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -626,7 +640,9 @@ try {
   auto it = ctx->frames.find(frame);
   if (it == ctx->frames.end())
     return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frame);
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // no kernel may still read it
+  // No wait here: kernels queued before this call may still read the frame.  Its slab either goes to the context's
+  // pool -- the next frame is then written on the context's stream, behind those kernels -- or is freed by hipFree,
+  // which waits for the device by itself.
   ctx->frames.erase(it);
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)

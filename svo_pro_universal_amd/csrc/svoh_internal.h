@@ -26,11 +26,44 @@ struct DevImage {
 // last row of the last level may reach up to 15 bytes past the image, so every slab ends with readable padding.
 constexpr size_t kSlabTailPad = 64;
 
+// Released frame slabs, kept for the next frame of the same size.  A per-frame front end makes one pyramid and drops
+// one per image: hipMalloc + hipFree are 2 x 10-100 us of host time and hipFree waits for the whole device -- also for
+// the depth filter's seed update that the caller deliberately left in flight.  A slab taken from here may still be read
+// by kernels queued before its frame was released: whoever fills it again does so on the context's stream, behind them.
+struct SlabPool {
+  struct Entry { void* ptr; size_t alloc; };
+  static constexpr size_t kMaxEntries = 8;
+  static constexpr size_t kMaxBytes = (size_t)256 << 20;
+  std::vector<Entry> free_list;
+  size_t held = 0;
+  void* take(size_t alloc)
+  {
+    for (size_t i = free_list.size(); i-- > 0;)
+      if (free_list[i].alloc == alloc) {
+        void* p = free_list[i].ptr;
+        free_list.erase(free_list.begin() + (long)i);
+        held -= alloc;
+        return p;
+      }
+    return nullptr;
+  }
+  bool give(void* p, size_t alloc)
+  {
+    if (free_list.size() >= kMaxEntries || held + alloc > kMaxBytes) return false;
+    free_list.push_back({ p, alloc });
+    held += alloc;
+    return true;
+  }
+  ~SlabPool() { for (const Entry& e : free_list) (void)hipFree(e.ptr); }
+};
+
 // device allocation shared by the frames carved out of it
 struct Slab {
   void* ptr = nullptr;
   size_t bytes = 0;
-  ~Slab() { if (ptr) (void)hipFree(ptr); }
+  size_t alloc = 0;                  // what was asked of hipMalloc (bytes + tail padding)
+  std::shared_ptr<SlabPool> pool;    // where the allocation goes when the last frame of the slab is released
+  ~Slab() { if (ptr && !(pool && pool->give(ptr, alloc))) (void)hipFree(ptr); }   // hipFree waits for the device
 };
 
 struct Frame {
@@ -107,6 +140,7 @@ struct svoh_ctx {
   int num_cus = 0;
   size_t lds_per_block = 0;
   std::string err;
+  std::shared_ptr<svoh::SlabPool> slab_pool = std::make_shared<svoh::SlabPool>();   // declared before `frames`: outlives them
   std::unordered_map<uint64_t, svoh::Frame> frames;
   uint64_t next_frame_id = 1;
 

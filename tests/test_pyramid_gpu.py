@@ -67,3 +67,54 @@ def test_bad_arguments(gpu_ctx):
     assert e.value.code == -1
     with pytest.raises(fe.SvohError):
         gpu_ctx.download_level(123456, 0)
+
+
+def test_released_slabs_are_reused_and_refilled(gpu_ctx, oracle_lib):
+    """svoh_release_frame keeps a frame's allocation for the next frame of the same size (a pool of at most 8: the rest
+    is freed).  Whatever the new frame gets -- a recycled slab, a fresh one -- its levels are the oracle's for ITS
+    image, and other sizes in between are served as well."""
+    rng = np.random.RandomState(11)
+    for rnd in range(3):
+        imgs = rng.randint(0, 256, (12, 120, 160)).astype(np.uint8)
+        frames = [gpu_ctx.build_pyramid(imgs[k], 4) for k in range(12)]
+        other = rng.randint(0, 256, (90, 130)).astype(np.uint8)
+        fo = gpu_ctx.build_pyramid(other, 3)
+        for k, fr in enumerate(frames):
+            exp = oracle_lib.create_img_pyramid(imgs[k], 4)
+            for l in range(4):
+                assert np.array_equal(gpu_ctx.download_level(fr, l), exp[l]), (rnd, k, l)
+        exp = oracle_lib.create_img_pyramid(other, 3)
+        assert all(np.array_equal(gpu_ctx.download_level(fo, l), exp[l]) for l in range(3))
+        for fr in frames + [fo]:
+            gpu_ctx.release_frame(fr)
+    with pytest.raises(fe.SvohError):
+        gpu_ctx.download_level(frames[0], 0)   # the handle is gone, whatever became of its memory
+
+
+def test_release_does_not_wait_and_does_not_disturb_queued_work(gpu_ctx):
+    """A frame released while an alignment that reads it is still queued: the release returns at once (no wait for the
+    device), the next frame of the same size takes the slab over -- written on the context's stream, BEHIND the queued
+    kernel -- and the queued alignment delivers what the blocking call delivered."""
+    import helpers
+    sc = helpers.small_scene(321, n=300)
+    other = helpers.small_scene(322, n=50)
+    opt = capi.default_align_options(min_level=0)
+
+    def problem():
+        fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+        pb, keep = fe.make_align_problems([[(sc, fr, fc)]])
+        return fr, fc, pb, keep
+
+    fr, fc, pb, keep = problem()
+    want = fe.se3_to_numpy(gpu_ctx.sparse_align(opt, pb)[0].T_icur_iref)
+    gpu_ctx.release_frame(fr); gpu_ctx.release_frame(fc)
+    for _ in range(4):
+        fr, fc, pb, keep = problem()
+        for _ in range(3):
+            gpu_ctx.sparse_align_enqueue(opt, pb)           # three launches in the queue, all reading fr / fc
+        gpu_ctx.release_frame(fr); gpu_ctx.release_frame(fc)
+        # same size: these take the two slabs just released and overwrite them with other images
+        f1, f2 = gpu_ctx.build_pyramid(other.img_ref, 5), gpu_ctx.build_pyramid(other.img_cur, 5)
+        got = gpu_ctx.sparse_align_fetch(1)
+        assert got[0].status == 0 and np.array_equal(fe.se3_to_numpy(got[0].T_icur_iref), want)
+        gpu_ctx.release_frame(f1); gpu_ctx.release_frame(f2)

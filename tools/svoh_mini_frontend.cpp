@@ -76,7 +76,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
     io::TrajectoryWriter traj(out_dir + "/trajectory.txt");
     FILE* fc = fopen((out_dir + "/frontend.csv").c_str(), "w");
     if (!fc) throw std::runtime_error("cannot write into " + out_dir);
-    fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_converged_seeds,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf\n");
+    fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_converged_seeds,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf,ms_frame\n");
 
     std::deque<FramePtr> kfs;   // the last reprojector.max_n_kfs keyframes
     FramePtr last;
@@ -102,7 +102,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
     size_t n_done = 0;
     // a frame's CSV row is written once its seed update has been finished (at the start of the next frame in the
     // default flow): the counters of both flows are the same
-    struct Row { bool valid = false, finished = false; size_t k = 0, n_seed_upd = 0; int is_kf = 0; size_t n_aligned = 0, n_reproj = 0, n_pose = 0; double ms[6] = {0, 0, 0, 0, 0, 0}; } row;
+    struct Row { bool valid = false, finished = false; size_t k = 0, n_seed_upd = 0; int is_kf = 0; size_t n_aligned = 0, n_reproj = 0, n_pose = 0; double ms[7] = {0, 0, 0, 0, 0, 0, 0}; } row;
     auto finish_row = [&]() {
       if (!row.valid) return;
       if (!row.finished) {
@@ -115,8 +115,8 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
       for (const FramePtr& f : kfs)
         for (size_t i = 0; i < f->num_features_; ++i)
           n_conv += f->type_vec_[i] == SVOH_FT_CORNER_SEED_CONVERGED || f->type_vec_[i] == SVOH_FT_EDGELET_SEED_CONVERGED;
-      fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", row.k, row.is_kf, row.n_aligned, row.n_reproj, row.n_pose,
-              n_seed_upd, n_conv, row.ms[0], row.ms[1], row.ms[2], row.ms[3], row.ms[4], row.ms[5]);
+      fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", row.k, row.is_kf, row.n_aligned, row.n_reproj, row.n_pose,
+              n_seed_upd, n_conv, row.ms[0], row.ms[1], row.ms[2], row.ms[3], row.ms[4], row.ms[5], row.ms[6]);
       row.valid = false;
     };
     for (size_t k = 0; k < images.size(); ++k) {
@@ -129,7 +129,9 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
       frame->cam = cam;
       frame->set_T_cam_imu(svoh::inverse(rig[0].T_B_C));
       frame->id_ = (int)k;
-      // the previous frame's seed update: its results are needed from here on (alignment points, candidates)
+      // the previous frame's seed update: its results are needed from here on (alignment points, candidates); the wait
+      // and the write-back are booked on that frame's ms_seeds (finish_row), not on this frame's ms_pyramid
+      const double t0f = now_ms();
       finish_row();
       const double t1 = now_ms();
       size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0;
@@ -175,13 +177,16 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
         // 5. keyframe rule
         if (k % kf_every == 0 || frame->numTrackedFeatures() < min_tracked) { make_keyframe(frame); is_kf = true; }
       }
+      // the frame before this one is dropped here unless it is a keyframe: its release (svoh_release_frame) is part of
+      // the frame's time
+      last = frame;
       const double t6 = now_ms();
       traj.write(seq.cam_ts[k], svoh::inverse(frame->T_f_w_));
       row.valid = true; row.finished = seeds_finished || k == 0; row.n_seed_upd = n_seed_upd; row.k = k; row.is_kf = (int)is_kf; row.n_aligned = n_aligned; row.n_reproj = n_reproj; row.n_pose = n_pose;
-      row.ms[0] = t1 - t0; row.ms[1] = t2 - t1; row.ms[2] = t3 - t2; row.ms[3] = t4 - t3; row.ms[4] = t5 - t4; row.ms[5] = t6 - t5;
+      row.ms[0] = t0f - t0; row.ms[1] = t2 - t1; row.ms[2] = t3 - t2; row.ms[3] = t4 - t3; row.ms[4] = t5 - t4; row.ms[5] = t6 - t5;
+      row.ms[6] = t6 - t0;   // the frame as the caller's clock sees it, the previous frame's seed write-back included
       if (sync_flow) finish_row();
       if (k > 0) { sum_ms += t6 - t0; ++n_done; }
-      last = frame;
     }
     finish_row();
     out->wall_ms = now_ms() - wall0;

@@ -223,6 +223,7 @@ int main(int argc, char** argv)
         // 5. keyframe rule
         if (k % kf_every == 0 || n_pose < 60) { make_keyframe(bundle, (k / kf_every) % 2); is_kf = true; }
       }
+      last = bundle;   // the pair before this one is dropped here unless it is a keyframe: its release is part of the pair's time
       const double t6 = now_ms();
       traj.write(seq.cam_ts[k], svoh::inverse(bundle->at(0)->T_imu_world()));
       fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.6f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", k, (int)is_kf, n_aligned, n_reproj, n_pose, n_seed_upd,
@@ -230,7 +231,6 @@ int main(int argc, char** argv)
               t1 - t0b, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5);
       if (k > 0) { sum_ms += t6 - t0b; ++n_done; }
       (void)t0;
-      last = bundle;
     }
     fclose(fc);
     printf("svoh_mini_stereo: %zu frame pairs, %.3f ms per pair on the GPU path (image decoding excluded), %zu keyframes alive\n", n_done + 1,
