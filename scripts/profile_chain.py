@@ -12,9 +12,18 @@ cmd, out_dir, poses, stamps, n_frames = t.make_dataset(tmp)
 prof = tmp / "prof"
 env = dict(os.environ, TMPDIR="/tmp")
 # the tool itself directly after `--` (no shell, no env wrapper: the profiler's preload initialises the GPU first)
-subprocess.check_call(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(prof), "--"] + cmd, env=env, cwd="/tmp")
-st = glob.glob(str(prof / "**" / "*kernel_stats.csv"), recursive=True)[0]
 dst = os.path.join(ROOT, "gpurun_out", "profiles")
 os.makedirs(dst, exist_ok=True)
-shutil.copy(st, os.path.join(dst, "%s_chain_kernel_stats.csv" % rnd))
-print(open(st).read()[:3000])
+if os.environ.get("MODE", "kernel") == "hip":
+    # the host side of the chain: which HIP runtime calls a frame makes and what they cost the caller's thread
+    # (no counters in this run: --hip-trace is a trace domain)
+    subprocess.check_call(["rocprofv3", "--hip-trace", "--stats", "--output-format", "csv", "-d", str(prof), "--"] + cmd, env=env, cwd="/tmp")
+    st = glob.glob(str(prof / "**" / "*hip_api_stats.csv"), recursive=True)[0]
+    shutil.copy(st, os.path.join(dst, "%s_chain_hip_api_stats.csv" % rnd))
+    shutil.copy(glob.glob(str(prof / "**" / "*hip_api_trace.csv"), recursive=True)[0], os.path.join(dst, "%s_chain_hip_api_trace.csv" % rnd))
+    print("frames:", n_frames)
+else:
+    subprocess.check_call(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(prof), "--"] + cmd, env=env, cwd="/tmp")
+    st = glob.glob(str(prof / "**" / "*kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(st, os.path.join(dst, "%s_chain_kernel_stats.csv" % rnd))
+print(open(st).read()[:4000])

@@ -969,18 +969,36 @@ ReprojectorHip::ReprojectorHip(svoh_ctx* ctx, const ReprojectorOptions& options,
 
 namespace {
 // per thread (one camera stream = one host thread in tools/svoh_mini_frontend): nothing is shared between streams
-struct ReprojTiming {   // SVOH_REPROJ_TIMING=1: mean host / device split of reprojectFrames, printed when the thread ends
+struct ReprojTiming {   // SVOH_REPROJ_TIMING=1: host / device split of reprojectFrames (MEDIANS per call, steady state), printed when the thread ends
   bool on = getenv("SVOH_REPROJ_TIMING") != nullptr;
+  long skip = 5;        // the first calls pay one-time costs (code objects, first allocations): not part of the statistics
+  // accumulators of the call in progress; closed into the sample lists by end_call()
   double t[6] = { 0, 0, 0, 0, 0, 0 };
   double kernel_ms = 0;
   double rt[4] = { 0, 0, 0, 0 };   // device round trip: direct batch call, seed batch call, collect, the rest
+  std::vector<double> samples[11];
   long n = 0, n_direct = 0, n_seeds = 0, n_reached3 = 0, n_spec3 = 0;
   static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  void end_call()
+  {
+    if (skip > 0) { --skip; n = n_direct = n_seeds = n_reached3 = n_spec3 = 0; }
+    else {
+      for (int k = 0; k < 6; ++k) samples[k].push_back(t[k]);
+      samples[6].push_back(kernel_ms);
+      for (int k = 0; k < 3; ++k) samples[7 + k].push_back(rt[k]);
+      samples[10].push_back(t[0] + t[1] + t[2] + t[3] + t[4] + t[5]);
+    }
+    for (double& v : t) v = 0;
+    for (double& v : rt) v = 0;
+    kernel_ms = 0;
+  }
+  static double med(std::vector<double> v) { if (v.empty()) return 0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
   ~ReprojTiming()
   {
     if (on && n)
-      fprintf(stderr, "[reproject] per call: candidates %.3f ms, sort %.3f, plan %.3f, device round trip(s) %.3f (kernel %.3f), replay %.3f, other %.3f [round trip: stage direct %.3f, stage seeds %.3f, launch + wait %.3f] (%ld calls; per call %.0f direct + %.0f seed units speculated; unconverged pass reached %ld x, speculated %ld x)\n",
-              t[0] / n, t[1] / n, t[2] / n, t[3] / n, kernel_ms / n, t[4] / n, t[5] / n, rt[0] / n, rt[1] / n, rt[2] / n, n, (double)n_direct / n, (double)n_seeds / n, n_reached3, n_spec3);
+      fprintf(stderr, "[reproject] median per call (ms): whole call %.3f = candidates %.3f, sort %.3f, plan %.3f, device round trip(s) %.3f (kernel %.3f), other (replay, grid) %.3f [round trip: stage direct %.3f, stage seeds %.3f, launch + wait %.3f] (%ld calls; per call %.0f direct + %.0f seed units speculated; unconverged pass reached %ld x, speculated %ld x)\n",
+              med(samples[10]), med(samples[0]), med(samples[1]), med(samples[2]), med(samples[3]), med(samples[6]), med(samples[5]), med(samples[7]), med(samples[8]), med(samples[9]),
+              n, (double)n_direct / n, (double)n_seeds / n, n_reached3, n_spec3);
   }
 };
 thread_local ReprojTiming g_reproj_timing;
@@ -1132,11 +1150,10 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
         (conv ? converged : unconverged).push_back(candidate);
     }
   }
+  // the three sortCandidatesByReprojStats calls (:188, 224, 263) happen inside matchCandidatesFused, while the matcher
+  // work of the lists is on the device
   const double ts1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
-  reprojector_utils::sortCandidatesByReprojStats(candidates_);
-  reprojector_utils::sortCandidatesByReprojStats(converged);
-  reprojector_utils::sortCandidatesByReprojStats(unconverged);
-  const double ts3 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  const double ts3 = ts1;
 
   std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged, &unconverged };
   reprojector::Statistics st[3];
@@ -1179,7 +1196,7 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
   auto after = [&](int pass) { if (pass == 2) reached_unconverged = true; after_pass(pass); };
   reprojector_utils::matchCandidatesFused(ctx_, cur_frame, options_.affine_est_offset, options_.affine_est_gain, options_.seed_sigma2_thresh,
                                           lists, [&](int pass, size_t& max_n) { return !stop && before_pass(pass, max_n); }, after,
-                                          *grid_, st, speculate_unconverged_ ? 3 : 2);
+                                          *grid_, st, speculate_unconverged_ ? 3 : 2, true);
   speculate_unconverged_ = reached_unconverged;
   // (the candidate lists are emptied on return: their buffers stay, the frame references go)
   if (g_reproj_timing.on) {
@@ -1188,11 +1205,13 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
     g_reproj_timing.t[0] += ts1 - ts0; g_reproj_timing.t[1] += ts3 - ts1;
     g_reproj_timing.t[5] += ts4 - ts3;   // plan + device + replay together (split below when the fused call reports it)
     ++g_reproj_timing.n;
+    g_reproj_timing.end_call();
   }
 }
 
 namespace reprojector_utils {
-void sortCandidatesByReprojStats(std::vector<reprojector::Candidate>& candidates)
+// order[k] = where the k-th candidate of the sorted list stood before (empty for lists of fewer than two)
+static void sortCandidatesWithOrder(std::vector<reprojector::Candidate>& candidates, std::vector<uint32_t>* order)
 {
   // std::sort(candidates, type > , n_reproj > , score >) of reprojector.cpp:545-556.  The order of EQUAL candidates is
   // whatever libstdc++'s introsort leaves, and its moves depend on the comparison results only: sorting 24-byte keys
@@ -1202,6 +1221,7 @@ void sortCandidatesByReprojStats(std::vector<reprojector::Candidate>& candidates
   thread_local std::vector<Key> keys;
   thread_local std::vector<reprojector::Candidate> sorted;
   const size_t n = candidates.size();
+  if (order) order->clear();
   if (n < 2) return;
   keys.resize(n);
   for (size_t i = 0; i < n; ++i) keys[i] = Key{ candidates[i].score, candidates[i].n_reproj, candidates[i].type, static_cast<uint32_t>(i) };
@@ -1214,7 +1234,10 @@ void sortCandidatesByReprojStats(std::vector<reprojector::Candidate>& candidates
   for (size_t i = 0; i < n; ++i) sorted.push_back(std::move(candidates[keys[i].at]));
   candidates.swap(sorted);
   sorted.clear();
+  if (order) { order->resize(n); for (size_t i = 0; i < n; ++i) (*order)[i] = keys[i].at; }
 }
+
+void sortCandidatesByReprojStats(std::vector<reprojector::Candidate>& candidates) { sortCandidatesWithOrder(candidates, nullptr); }
 
 bool projectPointAndCheckVisibility(const FramePtr& frame, const svoh::Vec3& xyz, double* px)
 {
@@ -1356,8 +1379,11 @@ struct SpeculativeMatches {
     }
     return rs;
   }
-  // both batches, queued back to back, ONE wait (svoh_matcher_begin_deferred / collect)
-  void run(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh)
+  // both batches, queued back to back and sent to the device (svoh_matcher_begin_deferred / flush): nothing is waited
+  // for.  finish() is the one wait (svoh_matcher_collect); the caller may work in between -- the reprojector sorts its
+  // candidate lists there, which the matcher work does not depend on.
+  bool in_flight = false;
+  void enqueue(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh)
   {
     if (!direct.size() && !seeds.size()) return;
     // Matcher matcher; (defaults of matcher.h:39-54) + the two affine flags (reprojector.cpp:352-354)
@@ -1366,7 +1392,8 @@ struct SpeculativeMatches {
     mopt.epi_search_edgelet_filtering = 1; mopt.scan_on_unit_sphere = 1;
     mopt.epi_search_edgelet_max_angle = 0.7; mopt.max_patch_diff_ratio = 2.0;
     mopt.affine_est_offset = affine_est_offset; mopt.affine_est_gain = affine_est_gain;
-    std::vector<svoh_frame_view> views;
+    thread_local std::vector<svoh_frame_view> views;
+    views.clear();
     for (const FramePtr& f : frames) {
       svoh_frame_view v{};
       v.frame = f->pyramid; v.cam = f->cam; svoh::store_rigid(f->T_f_w_, v.T_f_w);
@@ -1388,11 +1415,10 @@ struct SpeculativeMatches {
       (void)svoh_matcher_collect(ctx);   // leave no open section behind
       throw std::runtime_error(msg);
     };
-    const bool both = direct.size() && seeds.size();
     // a seed update still in flight (DepthFilterHip::updateSeedsAsync) holds the context's one deferred section: a batch
     // issued now would be queued INTO it instead of running -- finish the update first
     finishPendingSeedUpdate(ctx);
-    if (both && svoh_matcher_begin_deferred(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_begin_deferred: ") + svoh_last_error_string(ctx));
+    if (svoh_matcher_begin_deferred(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_begin_deferred: ") + svoh_last_error_string(ctx));
     svoh_feature_batch fbd{}, fbs{};
     const double tr0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
     if (direct.size()) {
@@ -1402,7 +1428,7 @@ struct SpeculativeMatches {
       const int rc = svoh_match_direct_batch(ctx, &mopt, static_cast<int>(views.size()), views.data(), &cur, &fbd,
                                              direct.depth.data(), direct.px_cur.data(), direct.result.data(),
                                              direct.f_cur.data(), direct.search_level.data(), nullptr, direct.A.data());
-      if (rc != SVOH_OK) { if (both) fail("svoh_match_direct_batch"); throw std::runtime_error(std::string("svoh_match_direct_batch: ") + svoh_last_error_string(ctx)); }
+      if (rc != SVOH_OK) fail("svoh_match_direct_batch");
     }
     const double tr1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
     if (seeds.size()) {
@@ -1418,11 +1444,24 @@ struct SpeculativeMatches {
       const svoh_seed_match_outputs outs{ seeds.px_cur.data(), seeds.f_cur.data(), seeds.search_level.data(), seeds.A.data() };
       const int rc = svoh_update_seeds_batch_ex(ctx, &mopt, &o, static_cast<int>(views.size()), views.data(), &cur, &fbs,
                                                 seeds.state.data(), seeds.success.data(), seeds.result.data(), nullptr, &outs);
-      if (rc != SVOH_OK) { if (both) fail("svoh_update_seeds_batch_ex"); throw std::runtime_error(std::string("svoh_update_seeds_batch_ex: ") + svoh_last_error_string(ctx)); }
+      if (rc != SVOH_OK) fail("svoh_update_seeds_batch_ex");
     }
+    if (svoh_matcher_flush(ctx) != SVOH_OK) fail("svoh_matcher_flush");
+    in_flight = true;
+    if (g_reproj_timing.on) { const double tr2 = ReprojTiming::now(); g_reproj_timing.rt[0] += tr1 - tr0; g_reproj_timing.rt[1] += tr2 - tr1; }
+  }
+  void finish(svoh_ctx* ctx)
+  {
+    if (!in_flight) return;
+    in_flight = false;
     const double tr2 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
-    if (both && svoh_matcher_collect(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_collect: ") + svoh_last_error_string(ctx));
-    if (g_reproj_timing.on) { const double tr3 = ReprojTiming::now(); g_reproj_timing.rt[0] += tr1 - tr0; g_reproj_timing.rt[1] += tr2 - tr1; g_reproj_timing.rt[2] += tr3 - tr2; }
+    if (svoh_matcher_collect(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_collect: ") + svoh_last_error_string(ctx));
+    if (g_reproj_timing.on) g_reproj_timing.rt[2] += ReprojTiming::now() - tr2;
+  }
+  void run(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh)
+  {
+    enqueue(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
+    finish(ctx);
   }
   // the reference's loop over one candidate list, in candidate order (reprojector.cpp:356-381)
   void replay(const FramePtr& frame, size_t max_n_features_per_frame, std::vector<reprojector::Candidate>& candidates,
@@ -1515,21 +1554,41 @@ void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features
 void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh,
                           std::vector<reprojector::Candidate>* lists[3], const std::function<bool(int pass, size_t& max_n)>& before_pass,
                           const std::function<void(int pass)>& after_pass, OccupandyGrid2D& grid, reprojector::Statistics stats[3],
-                          int n_speculated)
+                          int n_speculated, bool sort_in_flight)
 {
   if (!ctx) throw std::runtime_error("matchCandidatesFused: NULL svoh_ctx (no CPU fallback exists)");
   if (g_reproj_timing.on) (void)svoh_set_kernel_timing(ctx, 1);
   thread_local SpeculativeMatches sm;   // keeps its buffers from frame to frame ...
   sm.clear();
-  struct Release { SpeculativeMatches& s; ~Release() { s.clear(); } } release{ sm };   // ... but no frame reference past the call
+  // ... but no frame reference past the call, and no deferred section left open if something throws in between
+  struct Release { SpeculativeMatches& s; svoh_ctx* c; ~Release() { if (s.in_flight) { s.in_flight = false; (void)svoh_matcher_collect(c); } s.clear(); } } release{ sm, ctx };
   std::vector<Resolved> rs[3];
   const double tp0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   for (int k = 0; k < 3 && k < n_speculated; ++k) rs[k] = sm.plan(frame, *lists[k]);
   const double tp1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
-  sm.run(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
+  sm.enqueue(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
+  const double tp2 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  if (sort_in_flight) {
+    // sortCandidatesByReprojStats of the three lists (reprojector.cpp:188, 224, 263) while the device works: what a
+    // candidate is matched against does not depend on its place in the list, only the replay's visiting order does
+    thread_local std::vector<uint32_t> order;
+    for (int k = 0; k < 3; ++k) {
+      sortCandidatesWithOrder(*lists[k], &order);
+      if (k < n_speculated && !order.empty()) {
+        std::vector<Resolved> sorted(order.size());
+        for (size_t i = 0; i < order.size(); ++i) sorted[i] = std::move(rs[k][order[i]]);
+        rs[k].swap(sorted);
+      }
+    }
+  }
+  const double tp3 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  sm.finish(ctx);
   if (g_reproj_timing.on) { g_reproj_timing.n_direct += (long)sm.direct.size(); g_reproj_timing.n_seeds += (long)sm.seeds.size(); g_reproj_timing.n_spec3 += n_speculated == 3; }
   if (g_reproj_timing.on) { float kms = 0.f; if (svoh_last_kernel_ms(ctx, &kms) == SVOH_OK) g_reproj_timing.kernel_ms += kms; }
-  if (g_reproj_timing.on) { const double tp2 = ReprojTiming::now(); g_reproj_timing.t[2] += tp1 - tp0; g_reproj_timing.t[3] += tp2 - tp1; g_reproj_timing.t[5] -= tp2 - tp0; }
+  if (g_reproj_timing.on) {
+    const double tp4 = ReprojTiming::now();
+    g_reproj_timing.t[2] += tp1 - tp0; g_reproj_timing.t[3] += (tp2 - tp1) + (tp4 - tp3); g_reproj_timing.t[1] += tp3 - tp2; g_reproj_timing.t[5] -= tp4 - tp0;
+  }
   for (int k = 0; k < 3; ++k) {
     size_t max_n = 0;
     if (!before_pass(k, max_n)) break;

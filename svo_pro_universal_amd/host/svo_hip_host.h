@@ -502,10 +502,12 @@ void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features
 // Three candidate lists (landmarks, converged seeds, unconverged seeds) matched with ONE round trip to the device:
 // all matcher work is queued as one direct batch plus one seed batch, then before_pass(k, max_n) / the reference's
 // loop over list k / after_pass(k) run for k = 0, 1, 2 until before_pass says stop (Reprojector::reprojectFrames).
+// sort_in_flight: the lists come UNSORTED and are put through sortCandidatesByReprojStats here, between sending the
+// matcher work off and waiting for it (the work of a candidate does not depend on its place in its list).
 void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh,
                           std::vector<reprojector::Candidate>* lists[3], const std::function<bool(int pass, size_t& max_n)>& before_pass,
                           const std::function<void(int pass)>& after_pass, OccupandyGrid2D& grid, reprojector::Statistics stats[3],
-                          int n_speculated = 3);   // lists [n_speculated, 3) are matched only when their pass is reached
+                          int n_speculated = 3, bool sort_in_flight = false);   // lists [n_speculated, 3) are matched only when their pass is reached
 // Matcher::MatchResult per candidate of the last call on this thread (-1 = never reached / cell taken,
 // 1000 = landmark without a close view), for tests and statistics.
 const std::vector<int32_t>& lastMatchResults();
