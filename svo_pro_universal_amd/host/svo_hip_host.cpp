@@ -1111,43 +1111,46 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
         if (ko.frame == ref_frame.get() && ko.id == ref_frame->id_ && same_pose(ko.T_f_w, ref_frame->T_f_w_)) {
           proj_off = static_cast<long>(ko.offset); proj_n = ko.n_features; break;
         }
-    auto get_candidate = [&](size_t i, reprojector::Candidate& candidate) -> bool {
-      if (proj_off < 0 || i >= proj_n) return reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref);
-      const size_t at = static_cast<size_t>(proj_off) + i;
-      const PointPtr lm = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i] : nullptr;
-      {
+    // getCandidate for feature i, appended to `list` when it is visible.  The candidate is made in place (one reference
+    // to the keyframe taken per candidate: the walk visits thousands of features per frame and is on the frame's critical path)
+    auto emit_candidate = [&](size_t i, std::vector<reprojector::Candidate>& list) {
+      if (proj_off >= 0 && i < proj_n) {
+        const size_t at = static_cast<size_t>(proj_off) + i;
+        const Point* lm = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i].get() : nullptr;
         bool fresh;
         if (lm) { const svoh::Vec3 p = lm->pos(); fresh = proj_kind_[at] == 0 && p.x == proj_v_[3 * at] && p.y == proj_v_[3 * at + 1] && p.z == proj_v_[3 * at + 2]; }
         else fresh = proj_kind_[at] == 1 && (4 * i < ref_frame->invmu_sigma2_a_b_vec_.size() ? ref_frame->invmu_sigma2_a_b_vec_[4 * i] : 1.0) == proj_mu_[at];
-        if (!fresh) return reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref);
+        if (fresh) {
+          if (!proj_visible_[at]) return;
+          list.emplace_back();
+          reprojector::Candidate& candidate = list.back();
+          candidate.ref_frame = ref_frame; candidate.ref_index = i;
+          candidate.cur_px[0] = proj_px_[2 * at]; candidate.cur_px[1] = proj_px_[2 * at + 1];
+          candidate.n_reproj = lm ? lm->n_succeeded_reproj_ - lm->n_failed_reproj_ : 0;
+          candidate.score = i < ref_frame->score_vec_.size() ? ref_frame->score_vec_[i] : 0.0;
+          candidate.type = ref_frame->type_vec_[i];
+          candidate.n_obs = lm ? lm->obs_.size() : 0u;
+          return;
+        }
       }
-      if (!proj_visible_[at]) return false;
-      candidate = reprojector::Candidate();
-      candidate.ref_frame = ref_frame; candidate.ref_index = i;
-      candidate.cur_px[0] = proj_px_[2 * at]; candidate.cur_px[1] = proj_px_[2 * at + 1];
-      candidate.n_reproj = lm ? lm->n_succeeded_reproj_ - lm->n_failed_reproj_ : 0;
-      candidate.score = i < ref_frame->score_vec_.size() ? ref_frame->score_vec_[i] : 0.0;
-      candidate.type = ref_frame->type_vec_[i];
-      candidate.n_obs = lm ? lm->obs_.size() : 0u;
-      return true;
+      reprojector::Candidate candidate;
+      if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref)) list.push_back(std::move(candidate));
     };
+    const size_t n_lm = ref_frame->landmark_vec_.size();
     for (size_t i = 0; i < ref_frame->num_features_; ++i) {
       const uint8_t type = ref_frame->type_vec_[i];
-      static const PointPtr no_point;
-      const PointPtr& point = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i] : no_point;
-      reprojector::Candidate candidate;
-      if (point && type != SVOH_FT_OUTLIER && !is_map_point(type) && type != SVOH_FT_FIXED_LANDMARK) {
+      if (i < n_lm && ref_frame->landmark_vec_[i] && type != SVOH_FT_OUTLIER && !is_map_point(type) && type != SVOH_FT_FIXED_LANDMARK) {
+        const PointPtr& point = ref_frame->landmark_vec_[i];
         if (point->n_failed_reproj_ > 10) trash_points.push_back(point);
         else if (point->last_projected_kf_id_.at(camera_index_) != cur_frame->id_) {   // project a point only once
           point->last_projected_kf_id_[camera_index_] = cur_frame->id_;
           if (point->obs_.size() < 2 && options_.remove_unconstrained_points) trash_points.push_back(point);
-          else if (get_candidate(i, candidate)) candidates_.push_back(candidate);
+          else emit_candidate(i, candidates_);
         }
       }
       const bool conv = type == SVOH_FT_CORNER_SEED_CONVERGED || type == SVOH_FT_EDGELET_SEED_CONVERGED;
       const bool unconv = (type == SVOH_FT_CORNER_SEED || type == SVOH_FT_EDGELET_SEED) && options_.reproject_unconverged_seeds;
-      if ((conv || unconv) && get_candidate(i, candidate))
-        (conv ? converged : unconverged).push_back(candidate);
+      if (conv || unconv) emit_candidate(i, conv ? converged : unconverged);
     }
   }
   // the three sortCandidatesByReprojStats calls (:188, 224, 263) happen inside matchCandidatesFused, while the matcher
@@ -1309,17 +1312,26 @@ const std::vector<int32_t>& lastMatchResults() { return g_last_results; }
 // (run()); replay() is the reference's loop over one list (:356-381), reading the finished batches.
 namespace {
 enum Kind { kConvergedSeed = 0, kUnconvergedSeed = 1, kLandmark = 2, kNoCloseView = 3 };
-struct Resolved { Kind kind; FramePtr ref; size_t idx; PointPtr point; int frame_slot; int batch_pos; };
+// ref / point: plain pointers.  The frame is kept alive by SpeculativeMatches::frames (every resolved frame has a slot
+// there), the landmark by its keyframe's landmark_vec_ -- a shared_ptr per candidate here costs two atomic operations
+// per candidate and list, on the frame's critical path.
+struct Resolved { Kind kind; Frame* ref; size_t idx; Point* point; int frame_slot; int batch_pos; };
 struct Batch {
   std::vector<int32_t> ref_idx, level, result, search_level;
   std::vector<double> px, f, grad, depth, state, px_cur, f_cur, A;
   std::vector<uint8_t> type, success;
+  void reserve_more(size_t n)
+  {
+    const size_t m = level.size() + n;
+    ref_idx.reserve(m); level.reserve(m); type.reserve(m); px.reserve(2 * m); f.reserve(3 * m); grad.reserve(2 * m);
+    depth.reserve(m); px_cur.reserve(2 * m); state.reserve(4 * m);
+  }
   void push(const Frame& r, size_t i, int slot)
   {
     ref_idx.push_back(slot); level.push_back(r.level_vec_[i]); type.push_back(r.type_vec_[i]);
-    px.insert(px.end(), r.px_vec_.begin() + 2 * i, r.px_vec_.begin() + 2 * i + 2);
-    f.insert(f.end(), r.f_vec_.begin() + 3 * i, r.f_vec_.begin() + 3 * i + 3);
-    grad.insert(grad.end(), r.grad_vec_.begin() + 2 * i, r.grad_vec_.begin() + 2 * i + 2);
+    const double* p = &r.px_vec_[2 * i]; px.push_back(p[0]); px.push_back(p[1]);
+    const double* q = &r.f_vec_[3 * i]; f.push_back(q[0]); f.push_back(q[1]); f.push_back(q[2]);
+    const double* g = &r.grad_vec_[2 * i]; grad.push_back(g[0]); grad.push_back(g[1]);
   }
   size_t size() const { return level.size(); }
   void clear()
@@ -1331,36 +1343,40 @@ struct Batch {
 struct SpeculativeMatches {
   std::vector<FramePtr> frames;   // distinct reference frames of all lists
   Batch direct, seeds;
-  void clear() { frames.clear(); direct.clear(); seeds.clear(); }
+  int last_slot = -1;
+  void clear() { frames.clear(); direct.clear(); seeds.clear(); last_slot = -1; }
   int slot_of(const FramePtr& f)
   {
-    for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == f) return static_cast<int>(k);
+    if (last_slot >= 0 && frames[static_cast<size_t>(last_slot)].get() == f.get()) return last_slot;   // runs of one keyframe's features
+    for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == f) return last_slot = static_cast<int>(k);
     frames.push_back(f);
-    return static_cast<int>(frames.size() - 1);
+    return last_slot = static_cast<int>(frames.size() - 1);
   }
   // what each candidate of one list matches against
   std::vector<Resolved> plan(const FramePtr& frame, const std::vector<reprojector::Candidate>& candidates)
   {
     const size_t n = candidates.size();
     std::vector<Resolved> rs(n);
+    direct.reserve_more(n); seeds.reserve_more(n);
+    const svoh::Vec3 cur_pos = frame->pos();
     for (size_t i = 0; i < n; ++i) {
       const reprojector::Candidate& c = candidates[i];
       if (!c.ref_frame || c.ref_index >= c.ref_frame->num_features_) throw std::runtime_error("matchCandidates: bad candidate");
       Resolved& r = rs[i];
-      r.batch_pos = -1; r.frame_slot = -1;
-      PointPtr lm = c.ref_index < c.ref_frame->landmark_vec_.size() ? c.ref_frame->landmark_vec_[c.ref_index] : nullptr;
+      r.batch_pos = -1; r.frame_slot = -1; r.point = nullptr; r.ref = nullptr; r.idx = 0;
+      Point* lm = c.ref_index < c.ref_frame->landmark_vec_.size() ? c.ref_frame->landmark_vec_[c.ref_index].get() : nullptr;
       if (!lm) {
-        r.ref = c.ref_frame; r.idx = c.ref_index;
+        r.ref = c.ref_frame.get(); r.idx = c.ref_index;
         if (is_converged_seed(c.type)) r.kind = kConvergedSeed;
         else if (is_unconverged_seed(c.type)) r.kind = kUnconvergedSeed;
         else throw std::runtime_error("matchCandidates: seed type unknown");  // CHECK(false) in the reference
+        r.frame_slot = slot_of(c.ref_frame);
       } else {
         r.point = lm;
         FramePtr rf; size_t ri = 0;
-        if (lm->getCloseViewObs(frame->pos(), rf, ri)) { r.kind = kLandmark; r.ref = rf; r.idx = ri; }
+        if (lm->getCloseViewObs(cur_pos, rf, ri)) { r.kind = kLandmark; r.ref = rf.get(); r.idx = ri; r.frame_slot = slot_of(rf); }
         else r.kind = kNoCloseView;
       }
-      if (r.kind != kNoCloseView) r.frame_slot = slot_of(r.ref);
       if (r.kind == kConvergedSeed || r.kind == kLandmark) {
         r.batch_pos = static_cast<int>(direct.size());
         direct.push(*r.ref, r.idx, r.frame_slot);
@@ -1373,8 +1389,8 @@ struct SpeculativeMatches {
       } else if (r.kind == kUnconvergedSeed) {
         r.batch_pos = static_cast<int>(seeds.size());
         seeds.push(*r.ref, r.idx, r.frame_slot);
-        seeds.state.insert(seeds.state.end(), r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx,
-                           r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx + 4);
+        const double* st = &r.ref->invmu_sigma2_a_b_vec_[4 * r.idx];
+        seeds.state.push_back(st[0]); seeds.state.push_back(st[1]); seeds.state.push_back(st[2]); seeds.state.push_back(st[3]);
       }
     }
     return rs;
@@ -1517,7 +1533,7 @@ struct SpeculativeMatches {
       for (int j = 0; j < 3; ++j) frame->f_vec_[3 * s + j] = b->f_cur[3 * p + j];
       frame->level_vec_[s] = b->search_level[p];
       frame->score_vec_[s] = c.score;
-      if (r.kind == kLandmark) frame->landmark_vec_[s] = r.point;
+      if (r.kind == kLandmark) frame->landmark_vec_[s] = c.ref_frame->landmark_vec_[c.ref_index];   // == r.point, as the shared_ptr
       else { frame->seed_ref_vec_[s].keyframe = c.ref_frame; frame->seed_ref_vec_[s].seed_id = static_cast<int>(c.ref_index); }
       std::copy(c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index,
                 c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index + 4, frame->invmu_sigma2_a_b_vec_.begin() + 4 * s);
