@@ -8,7 +8,13 @@ import test_mini_frontend_gpu as t
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 tmp = pathlib.Path(tempfile.mkdtemp(prefix="chain_", dir="/tmp"))
-cmd, out_dir, poses, stamps, n_frames = t.make_dataset(tmp)
+if os.environ.get("TOOL", "mono") == "stereo":   # tools/svoh_mini_stereo on the stereo sequence of tests/test_mini_stereo_gpu.py
+    import test_mini_stereo_gpu as ts
+    n_frames = 30
+    cmd, out_dir, poses, stamps = ts.make_stereo_dataset(tmp, n_frames)
+    cmd = cmd + [str(n_frames), "8", "0.5"]
+else:
+    cmd, out_dir, poses, stamps, n_frames = t.make_dataset(tmp)
 prof = tmp / "prof"
 env = dict(os.environ, TMPDIR="/tmp")
 # the tool itself directly after `--` (no shell, no env wrapper: the profiler's preload initialises the GPU first)

@@ -108,6 +108,16 @@ def test_mini_stereo_tracks_a_synthetic_stereo_sequence(tmp_path):
     stage = np.median(fc[3:, 9:15], axis=0)
     print("median ms per pair: pyramids %.3f align %.3f reproject %.3f pose %.3f seeds %.3f keyframe %.3f  total %.3f"
           % (tuple(stage) + (stage.sum(),)))
+    print("ms per pair on the caller's clock (image decoding excluded): median %.3f  mean %.3f" % (np.median(fc[3:, 15]), fc[3:, 15].mean()))
+    # the default flow leaves the second camera's seed update in flight across the pair boundary; waiting in place as the
+    # reference does (SVOH_MINI_SYNC=1) is the same arithmetic in the same order: same files
+    traj = open(str(out_dir / "trajectory.txt")).read()
+    rs = subprocess.run(cmd + [str(n_frames), "8", "0.5"], capture_output=True, text=True, env=dict(os.environ, SVOH_MINI_SYNC="1"))
+    assert rs.returncode == 0, rs.stdout + rs.stderr
+    fs = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)
+    assert open(str(out_dir / "trajectory.txt")).read() == traj
+    assert np.array_equal(fs[:, :9], fc[:, :9])
+    print("waiting in place: median %.3f ms per pair" % np.median(fs[3:, 15]))
     assert res["n"] == n_frames
     assert res["rmse"] < 0.03 * path_len + 0.003          # a few per cent of the distance travelled, no scale freedom
     assert 0.9 < res_s["scale"] < 1.1                     # the stereo bootstrap has fixed the scale

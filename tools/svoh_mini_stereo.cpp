@@ -129,7 +129,7 @@ int main(int argc, char** argv)
     io::TrajectoryWriter traj(out_dir + "/trajectory.txt");
     FILE* fc = fopen((out_dir + "/frontend.csv").c_str(), "w");
     if (!fc) throw std::runtime_error("cannot write into " + out_dir);
-    fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_landmarks,alpha,beta,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf\n");
+    fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_landmarks,alpha,beta,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf,ms_pair\n");
 
     std::deque<FramePtr> kfs;
     FrameBundle::Ptr last;
@@ -150,11 +150,14 @@ int main(int argc, char** argv)
         kfs.pop_front();
       }
     };
+    const bool kf_timing = getenv("SVOH_MINI_KF_TIMING") != nullptr;   // where a keyframe's time goes, to stderr
     auto make_keyframe = [&](const FrameBundle::Ptr& b, size_t kf_id) {
       // stereo triangulation of new features where the left frame has no feature yet (frame_handler_stereo.cpp:146-155)
+      const double tk0 = now_ms();
       tri_detector->resetGrid();
       tri_detector->fillGridWithKeypoints(b->at(0)->px_vec_, b->at(0)->num_features_);
       stereo.compute(b->at(0), b->at(1));
+      const double tk1 = now_ms();
       // new seeds in the keyframe's free cells (depth_filter_->addKeyframe, :167-173)
       double d_med = 0, d_min = 0;
       const FramePtr& f = b->at(kf_id);
@@ -165,12 +168,36 @@ int main(int argc, char** argv)
         depth_filter_utils::initializeSeeds(f, seed_detector, (size_t)params.max_n_seeds_per_frame, (float)(0.5 * d_min), (float)(1.5 * d_med), (float)d_med);
         for (size_t i = n_old; i < f->num_features_; ++i) { f->seed_ref_vec_[i].keyframe = f; f->seed_ref_vec_[i].seed_id = (int)i; }
       }
+      const double tk2 = now_ms();
       add_keyframe(b->at(0));
       add_keyframe(b->at(1));
+      if (kf_timing) fprintf(stderr, "[keyframe] stereo triangulation %.3f ms, new seeds %.3f ms, keyframe window %.3f ms\n", tk1 - tk0, tk2 - tk1, now_ms() - tk2);
     };
 
     double sum_ms = 0;
     size_t n_done = 0;
+    // Default flow: the second camera's seed update is sent off without waiting (DepthFilterHip::updateSeedsAsync) and
+    // finished before anything reads the seeds again -- a keyframe of the same pair, or the next pair's alignment.  The
+    // first camera's update cannot overlap it: both update the same seeds, one after the other (frame_handler_stereo.cpp:
+    // 127-129).  SVOH_MINI_SYNC=1 waits in place as the reference does; both flows write the same files.
+    const bool sync_flow = getenv("SVOH_MINI_SYNC") != nullptr;
+    // a pair's CSV row is written once its seed updates have been finished
+    struct Row { bool valid = false, finished = true; size_t n_seed_upd = 0; double ms[7] = { 0, 0, 0, 0, 0, 0, 0 }; size_t n_lm = 0; double alpha = 0, beta = 0; size_t k = 0; int is_kf = 0; size_t n_aligned = 0, n_reproj = 0, n_pose = 0; } row;
+    auto finish_seeds = [&]() {
+      if (row.valid && !row.finished) {
+        const double tf0 = now_ms();
+        row.n_seed_upd += depth_filter.finishUpdateSeeds();
+        row.ms[4] += now_ms() - tf0;
+        row.finished = true;
+      }
+    };
+    auto write_row = [&]() {
+      if (!row.valid) return;
+      finish_seeds();
+      fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.6f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", row.k, row.is_kf, row.n_aligned, row.n_reproj, row.n_pose, row.n_seed_upd,
+              row.n_lm, row.alpha, row.beta, row.ms[0], row.ms[1], row.ms[2], row.ms[3], row.ms[4], row.ms[5], row.ms[6]);
+      row.valid = false;
+    };
     for (size_t k = 0; k < n_frames; ++k) {
       const double t0 = now_ms();
       const io::GrayImage img0 = io::readPngGray(seq.cam0_files[k]), img1 = io::readPngGray(seq.cam1_files[k]);
@@ -187,10 +214,14 @@ int main(int argc, char** argv)
         frame->id_ = (int)(2 * k + (size_t)c);
         bundle->frames_.push_back(frame);
       }
+      // the pair before: its second seed update is needed from here on (alignment points, candidates); the wait is
+      // booked on that pair's ms_seeds
+      const double t0f = now_ms();
+      write_row();
       const double t1 = now_ms();
       size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0;
       double t2 = t1, t3 = t1, t4 = t1, t5 = t1;
-      bool is_kf = false;
+      bool is_kf = false, seeds_in_flight = false;
       if (k == 0) {
         for (const FramePtr& f : bundle->frames_) f->T_f_w_ = svoh::mul(f->T_cam_imu(), T_imu_world0);
         make_keyframe(bundle, 0);
@@ -206,7 +237,9 @@ int main(int argc, char** argv)
         }
         n_aligned = img_align.run(last, bundle);
         t2 = now_ms();
-        // 2. reprojection, per camera (frame_handler_base.cpp:645-744)
+        // 2. reprojection, per camera (frame_handler_base.cpp:645-744).  (Queueing the first camera's candidate projection
+        // behind the bundle alignment, as the mono harness does, was measured here and does not pay: 0.767 against 0.722 ms
+        // per pair -- the hook's walk and three more stream operations cost the alignment stage what the reprojector saves.)
         std::vector<FramePtr> visible(kfs.begin(), kfs.end());
         for (size_t c = 0; c < 2; ++c) {
           std::vector<PointPtr> trash;
@@ -218,20 +251,27 @@ int main(int argc, char** argv)
         if (n_reproj >= 10) n_pose = pose_optimizer.run(bundle, 2.0);
         t4 = now_ms();
         // 4. depth filter, per camera (frame_handler_stereo.cpp:127-129)
-        for (size_t c = 0; c < 2; ++c) n_seed_upd += depth_filter.updateSeeds(visible, bundle->at(c));
+        n_seed_upd += depth_filter.updateSeeds(visible, bundle->at(0));
+        const bool kf_next = k % kf_every == 0 || n_pose < 60;
+        if (sync_flow || kf_next) n_seed_upd += depth_filter.updateSeeds(visible, bundle->at(1));   // a keyframe's new seeds and triangulation come behind it
+        else { depth_filter.updateSeedsAsync(visible, bundle->at(1)); seeds_in_flight = true; }
         t5 = now_ms();
         // 5. keyframe rule
-        if (k % kf_every == 0 || n_pose < 60) { make_keyframe(bundle, (k / kf_every) % 2); is_kf = true; }
+        if (kf_next) { make_keyframe(bundle, (k / kf_every) % 2); is_kf = true; }
       }
       last = bundle;   // the pair before this one is dropped here unless it is a keyframe: its release is part of the pair's time
       const double t6 = now_ms();
       traj.write(seq.cam_ts[k], svoh::inverse(bundle->at(0)->T_imu_world()));
-      fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.6f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", k, (int)is_kf, n_aligned, n_reproj, n_pose, n_seed_upd,
-              num_landmarks(*bundle->at(0)) + num_landmarks(*bundle->at(1)), img_align.lastResult().alpha, img_align.lastResult().beta,
-              t1 - t0b, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5);
+      row.valid = true; row.finished = !seeds_in_flight; row.k = k; row.is_kf = (int)is_kf; row.n_aligned = n_aligned; row.n_reproj = n_reproj; row.n_pose = n_pose;
+      row.n_seed_upd = n_seed_upd; row.n_lm = num_landmarks(*bundle->at(0)) + num_landmarks(*bundle->at(1));
+      row.alpha = img_align.lastResult().alpha; row.beta = img_align.lastResult().beta;
+      row.ms[0] = t0f - t0b; row.ms[1] = t2 - t1; row.ms[2] = t3 - t2; row.ms[3] = t4 - t3; row.ms[4] = t5 - t4; row.ms[5] = t6 - t5;
+      row.ms[6] = t6 - t0b;   // the pair on the caller's clock (image decoding excluded), the wait for the pair before included
+      if (sync_flow) write_row();
       if (k > 0) { sum_ms += t6 - t0b; ++n_done; }
       (void)t0;
     }
+    write_row();
     fclose(fc);
     printf("svoh_mini_stereo: %zu frame pairs, %.3f ms per pair on the GPU path (image decoding excluded), %zu keyframes alive\n", n_done + 1,
            n_done ? sum_ms / n_done : 0.0, kfs.size());
