@@ -217,6 +217,8 @@ __device__ T rank_select(const T* vals, int n, int k, int tid, T* s_out)
   return *s_out;
 }
 
+// NT = 512: a single bundle of more than 256 features (a stereo rig's 2 x 160): one feature per lane instead of two
+// rounds; two waves per SIMD, so the 256-register error types only (the bearing-vector difference needs 334).
 // NT = 256: one bundle spread over four waves (lowest latency of a single bundle).  NT = 64: one wave per bundle,
 // about three features per lane; four bundles share a compute unit (the kernel needs >256 registers, so a SIMD
 // holds one wave), and the one-lane solve of one bundle overlaps the residuals of the other three: the geometry for
@@ -255,19 +257,26 @@ __global__ __launch_bounds__(NT) void pose_optimize_kernel(const PoseArgs a)
   }
   __syncthreads();
 
-  // helper: iterate this thread's features
+  // helper: iterate this thread's features.  The cameras' features form ONE index range (camera after camera) that the
+  // workgroup strides through: a rig of two cameras with 160 features each is 320 lanes' worth of work -- one round of
+  // the 512-thread geometry, not two rounds per camera.  A lane's camera only ever advances; its model is reloaded then.
+  int n_total = 0;
+  for (int c = 0; c < pb.n_cams; ++c) n_total += cams[c].n_features;
   auto for_each_feature = [&](auto&& fn) {
-    for (int c = 0; c < pb.n_cams; ++c) {
-      const DevPoseCam& dc = cams[c];
-      const CamModel cm = load_camera(dc.cam);
-      const Rigid T_cam_imu = load_rigid(dc.T_cam_imu);
-      double Rci[9];
-      to_matrix(T_cam_imu.q, Rci);
-      for (int i = tid; i < dc.n_features; i += NT) {
-        const long long gi = pb.arr_off + dc.feat_off + i;
-        if (!a.usable[gi]) continue;
-        fn(cm, T_cam_imu, Rci, gi);
+    int c = -1, lo = 0, hi = 0;   // camera of the current feature and its index range [lo, hi)
+    CamModel cm = {};
+    Rigid T_cam_imu = {};
+    double Rci[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int j = tid; j < n_total; j += NT) {
+      if (j >= hi) {
+        do { ++c; lo = hi; hi += cams[c].n_features; } while (j >= hi);
+        cm = load_camera(cams[c].cam);
+        T_cam_imu = load_rigid(cams[c].T_cam_imu);
+        to_matrix(T_cam_imu.q, Rci);
       }
+      const long long gi = pb.arr_off + cams[c].feat_off + (j - lo);
+      if (!a.usable[gi]) continue;
+      fn(cm, T_cam_imu, Rci, gi);
     }
   };
 
@@ -677,10 +686,15 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
   // geometry: see pose_optimize_kernel.  SVOH_POSE_THREADS=64/256 forces one (tests run both).
   int nt = n_problems > ctx->num_cus ? 64 : kPoseThreads;
-  { const int v = ctx->knobs.pose_threads; if (v == 64 || v == kPoseThreads) nt = v; }
+  // a few large bundles: one feature per lane (measured, scripts/perf_pose_scaling.py: 2 x 160 features 0.064 ms with 256 threads)
+  if (n_problems * 2 <= ctx->num_cus && (int)max_meas > kPoseThreads && options->error_type != SVOH_POSE_ERR_BEARING_DIFF) nt = 512;
+  { const int v = ctx->knobs.pose_threads; if (v == 64 || v == kPoseThreads || (v == 512 && options->error_type != SVOH_POSE_ERR_BEARING_DIFF)) nt = v; }
   auto launch = [&](auto et) {
     constexpr int ET = decltype(et)::value;
     if (nt == 64) hipLaunchKernelGGL((pose_optimize_kernel<64, ET>), dim3((unsigned)n_problems), dim3(64), err_bytes, ctx->stream, a);
+    else if (nt == 512) {
+      if constexpr (ET != SVOH_POSE_ERR_BEARING_DIFF) hipLaunchKernelGGL((pose_optimize_kernel<512, ET>), dim3((unsigned)n_problems), dim3(512), err_bytes, ctx->stream, a);
+    }
     else hipLaunchKernelGGL((pose_optimize_kernel<kPoseThreads, ET>), dim3((unsigned)n_problems), dim3(kPoseThreads), err_bytes, ctx->stream, a);
   };
   if (options->error_type == SVOH_POSE_ERR_UNIT_PLANE) launch(std::integral_constant<int, SVOH_POSE_ERR_UNIT_PLANE>{});

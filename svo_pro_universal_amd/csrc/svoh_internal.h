@@ -118,7 +118,7 @@ struct SvohKnobs {
   int klt_block = kKnobUnset;                 // SVOH_KLT_BLOCK: 64 / 128 / 256 threads per KLT workgroup
   int matcher_g8 = kKnobUnset;                // SVOH_MATCHER_G8: 0 one lane per unit, 1 eight lanes, 2 packed, 3 one wave per unit (epipolar scans)
   int seed_binning = kKnobUnset;              // SVOH_SEED_BINNING: 0 = no spatial binning of large seed batches
-  int pose_threads = kKnobUnset;              // SVOH_POSE_THREADS: 64 / 256
+  int pose_threads = kKnobUnset;              // SVOH_POSE_THREADS: 64 / 256 / 512
   int align_cluster = kKnobUnset;             // SVOH_ALIGN_CLUSTER: workgroups per problem (0 = never)
 #ifdef SVOH_TEST_HOOKS
   int align_cluster_test_absent = kKnobUnset; // SVOH_ALIGN_CLUSTER_TEST_ABSENT: a partner that never arrives (libsvo_hip_testhooks.so only)

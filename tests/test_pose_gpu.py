@@ -12,13 +12,14 @@ import pose_helpers as ph
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["four_waves_per_bundle", "one_wave_per_bundle"], autouse=True)
+@pytest.fixture(params=["four_waves_per_bundle", "one_wave_per_bundle", "eight_waves_per_bundle"], autouse=True)
 def pose_geometry(request, gpu_ctx):
-    """The pose kernel has two geometries (pose.hip, pose_optimize_kernel<256> for batches up to one bundle per compute
-    unit, <64> beyond): every test of this file runs through both, against the same bars."""
+    """The pose kernel has three geometries (pose.hip, pose_optimize_kernel<256> for batches up to one bundle per compute
+    unit, <64> beyond, <512> for a few bundles of more than 256 features -- not instantiated for the bearing-vector
+    error, which then runs with 256): every test of this file runs through all of them, against the same bars."""
     import os
     old = os.environ.get("SVOH_POSE_THREADS")
-    os.environ["SVOH_POSE_THREADS"] = "256" if request.param == "four_waves_per_bundle" else "64"
+    os.environ["SVOH_POSE_THREADS"] = {"four_waves_per_bundle": "256", "one_wave_per_bundle": "64", "eight_waves_per_bundle": "512"}[request.param]
     gpu_ctx.reload_knobs()
     yield request.param
     if old is None:
