@@ -77,6 +77,7 @@ struct AlignKernelArgs {
   uint8_t* wvis;                        // visibility of the last evaluation
   svoh_align_options opt;
   int32_t lds_img_bytes;                // dynamic LDS available for image staging
+  int32_t rig_build;                    // host side only: a small launch with problems of several cameras -> the instantiation that runs a rig's cameras side by side
   int32_t latency_build;                // host side only: fewer problems than compute units -> the one-wave-per-SIMD build of the 256-thread kernel
   int32_t lds_two_per_cu;               // host side only: the launch counts on two workgroups per compute unit (launch_one sizes the image area for it)
   int32_t ws_lds_bytes;                 // > 0: the feature workspace of a (small) problem lives in LDS behind the image area (512-thread geometry)
@@ -643,7 +644,7 @@ __device__ __forceinline__ void accumulate_camera(
     const AlignKernelArgs& a, const WsView& ws, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
     bool robust, bool dist_jac, float weight_scale, int tid, const double* jc,
-    double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed)
+    double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed, int stride = NT)
 {
   SVOH_PASS_STAMP_BEGIN();
   const CamModel cm = load_camera(cd.cam);
@@ -651,7 +652,9 @@ __device__ __forceinline__ void accumulate_camera(
   const double patch_center_wb = (P + 2 - 1) / 2.0f;
   SVOH_PASS_STAMP(0);
 
-  for (int i = tid; i < cd.n_features; i += NT) {
+  // tid / stride: the lanes that take this camera and how many they are (the whole workgroup, or the camera's waves
+  // when the cameras of a rig run side by side: run_cameras)
+  for (int i = tid; i < cd.n_features; i += stride) {
     const int gi = cd.feat_off + i;
     const double2 vs = *reinterpret_cast<const double2*>(ws_pair(ws, 2, gi));
     if (vs.y == 0.0) continue;
@@ -725,7 +728,7 @@ __device__ __forceinline__ void accumulate_camera_rows(
     const AlignKernelArgs& a, const WsView& ws, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
     bool robust, bool dist_jac, float weight_scale, int tid, const double* jc,
-    double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed)
+    double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed, int stride = NT)
 {
   static_assert(LPP == 2 || LPP == 4 || LPP == 8, "a group is 2, 4 or 8 consecutive lanes");
   SVOH_PASS_STAMP_BEGIN();
@@ -735,7 +738,7 @@ __device__ __forceinline__ void accumulate_camera_rows(
   const int r = tid & (LPP - 1);
   SVOH_PASS_STAMP(0);
 
-  for (int i = tid / LPP; i < cd.n_features; i += NT / LPP) {
+  for (int i = tid / LPP; i < cd.n_features; i += stride / LPP) {   // tid / stride: see accumulate_camera
     const int gi = cd.feat_off + i;
     const double2 vs = *reinterpret_cast<const double2*>(ws_pair(ws, 2, gi));
     if (vs.y == 0.0) continue;
@@ -806,16 +809,16 @@ __device__ __forceinline__ void accumulate_camera_staged(
     const AlignKernelArgs& a, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
     bool robust, bool dist_jac, float weight_scale, int tid, double* stage, const double* jc,
-    double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed)
+    double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed, int stride = NT)
 {
   typedef const __attribute__((address_space(1))) void* gptr;
   typedef __attribute__((address_space(3))) void* lptr;
   const CamModel cm = load_camera(cd.cam);
   const double patch_center = (P - 1) / 2.0f;
   const double patch_center_wb = (P + 2 - 1) / 2.0f;
-  const int lane = tid & 63;
+  const int lane = tid & 63;   // tid / stride: see accumulate_camera (stride is a multiple of 64: a wave's lanes stay together)
   const int n = cd.n_features;
-  const int n_round = (n + NT - 1) / NT * NT;
+  const int n_round = (n + stride - 1) / stride * stride;
   auto request = [&](double* buf, int64_t gi) {
 #pragma unroll
     for (int pr = 0; pr < kWsPairs; ++pr)
@@ -823,7 +826,7 @@ __device__ __forceinline__ void accumulate_camera_staged(
   };
   if (tid < n) request(stage, cd.feat_off + tid);
   int which = 0;
-  for (int i = tid; i < n_round; i += NT, which ^= 1) {
+  for (int i = tid; i < n_round; i += stride, which ^= 1) {
     const int64_t gi = cd.feat_off + i;
     const bool in_range = i < n;
     double* buf = stage + which * (kWsPairs * 128);
@@ -832,7 +835,7 @@ __device__ __forceinline__ void accumulate_camera_staged(
     const double2 zu = *reinterpret_cast<const double2*>(buf + 1 * 128 + lane * 2);
     const double2 vs = *reinterpret_cast<const double2*>(buf + 2 * 128 + lane * 2);
     // the other buffer: its last readers (the previous pass's Jacobian rows) are done -- lgkmcnt(0) at the loop's end
-    if (i + NT < n) request(stage + (which ^ 1) * (kWsPairs * 128), gi + NT);
+    if (i + stride < n) request(stage + (which ^ 1) * (kWsPairs * 128), gi + stride);
     const bool sel = in_range && vs.y != 0.0;
     bool vis = false;
     double mom[AccLayout<D>::NMOM];
@@ -1280,11 +1283,16 @@ __device__ __attribute__((noinline)) void gn_wave_step(const AlignKernelArgs& a,
 // the SIMD anyway).  With the whole register file to itself the kernel spills nothing (274-302 registers instead of
 // 256 + 26-56 spilled), and in a launch that small a spilled register is a round trip to memory nobody hides: the
 // full passes of a single 180-patch problem took twice the cycles of its gradient-only passes.
-template <int P, int NT, bool ILLUM, bool CLUSTER = false, bool ROBUST = false, int LPP = 1, bool LAT = false>
+// RIG: the instantiation for launches of a few problems of SEVERAL cameras (stereo bundles): cameras side by side on the
+// workgroup's waves (run_cameras).  A template parameter, not a run-time branch of every kernel: the bookkeeping costs a
+// single-camera problem 1.5 - 4 % of its kernel (measured: register allocation and a scalar-load dependency per pass),
+// which the mono chain should not pay.
+template <int P, int NT, bool ILLUM, bool CLUSTER = false, bool ROBUST = false, int LPP = 1, bool LAT = false, bool RIG = false>
 __global__ __launch_bounds__(NT, (NT == 256 ? (LAT ? 1 : SVOH_ALIGN_MIN_WAVES_256) : 2))
 void sparse_align_kernel(const AlignKernelArgs a)
 {
   static_assert(!LAT || (NT == 256 && !CLUSTER && LPP == 1), "latency build: the 256-thread lane-per-patch geometry");
+  static_assert(!RIG || (!CLUSTER && LPP == 1 && (LAT || NT == 512)), "rig build: the two lane-per-patch geometries of small launches");
   static_assert(LPP == 1 || (!CLUSTER && NT == 512 && LPP <= P), "rows geometry: 512 threads, no cluster mode");
   static_assert(NT == 256 || NT == 512, "workgroups of 256 or 512 threads");
   constexpr bool ROWS = LPP > 1;
@@ -1509,6 +1517,15 @@ void sparse_align_kernel(const AlignKernelArgs a)
   const bool dist_jac = opt.use_distortion_jacobian != 0;
   const float weight_scale = (float)opt.weight_scale;
 
+  // cameras side by side (run_cameras): when the patches of all cameras fit the workgroup together, wave after wave
+  constexpr int kLanesPerPatch = ROWS ? LPP : 1;
+  bool side_by_side = false;
+  if (RIG && n_cams >= 2) {
+    int lanes_needed = 0;
+    for (int c = 0; c < n_cams; ++c) lanes_needed += (cams[c].n_features * kLanesPerPatch + 63) & ~63;
+    side_by_side = lanes_needed <= NT;
+  }
+
   for (int level = level_hi; level >= level_lo; --level) {
     const double scale = 1.0f / (1 << level);
     // ---- the level's images: resident since the problem's start, staged now, or read from global memory ----
@@ -1547,11 +1564,26 @@ void sparse_align_kernel(const AlignKernelArgs a)
         auto run_cameras = [&](auto gonly_tag, auto& acc_ref) {
           constexpr bool G = decltype(gonly_tag)::value;
           int off = lvl_off;
+          // A rig of several cameras whose patches fit the workgroup together: the cameras run SIDE BY SIDE, camera c on
+          // the waves behind camera c-1's (whole waves: the choice is wave-uniform), instead of one after the other on the
+          // same few waves -- a stereo bundle of 2 x 160 patches is one round of 3 + 3 waves (spread over the four SIMDs
+          // by the hardware's wave placement), not two rounds of 3.  The normal equations are the sum over the cameras
+          // either way (sparse_img_align.cpp:138-154); a lane's partial sum now holds one camera's patches, so sums differ
+          // in order only.  Not when the patches do not fit: the cameras then take turns with the whole workgroup.
+          // (side_by_side: decided once per problem, above the level loop)
+          int cam_base = 0;
           for (int c = 0; c < n_cams; ++c) {
             const DevCamDesc& cd = cams[c];
             const DevImage& rim = cd.ref[level];
             const DevImage& cim = cd.cur[level];
             const Rigid Tcr = uniform_rigid(g_state.Tcr[c]);
+            unsigned cam_stride = NT, cam_t = (unsigned)tid;
+            if (RIG && side_by_side) {   // (uniform)
+              const int cam_width = (cd.n_features * kLanesPerPatch + 63) & ~63;
+              cam_stride = (unsigned)cam_width;
+              cam_t = (unsigned)(tid - cam_base);
+              cam_base += cam_width;
+            }
             if (in_lds) {
               ImgView<true> ref, cur;
               ref.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); ref.pitch = rim.w;
@@ -1559,33 +1591,39 @@ void sparse_align_kernel(const AlignKernelArgs a)
               cur.p = (const __attribute__((address_space(3))) uint8_t*)(lds_img + off); cur.pitch = cim.w;
               off += ((cim.w * cim.h + 15) & ~15);
               if constexpr (ROWS) {
-                accumulate_camera_rows<P, (ROWS ? LPP : 2), D, NT, true, G, ROBUST>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                                                            est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c],
-                                                                            acc_ref, nvis, changed);
-              } else if constexpr (STAGED)
-                accumulate_camera_staged<P, D, NT, true, G, ROBUST>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                                            est_alpha, est_beta, robust, dist_jac, weight_scale, tid,
-                                                            s_stage + wave * kStageDoubles, s_jc[c], acc_ref, nvis, changed);
-              else
+                if (!RIG || cam_t < cam_stride)
+                  accumulate_camera_rows<P, (ROWS ? LPP : 2), D, NT, true, G, ROBUST>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                                            est_alpha, est_beta, robust, dist_jac, weight_scale, (int)cam_t, s_jc[c],
+                                                                            acc_ref, nvis, changed, (int)cam_stride);
+              } else if constexpr (STAGED) {
+                if (!RIG || cam_t < cam_stride)
+                  accumulate_camera_staged<P, D, NT, true, G, ROBUST>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                            est_alpha, est_beta, robust, dist_jac, weight_scale, (int)cam_t,
+                                                            s_stage + wave * kStageDoubles, s_jc[c], acc_ref, nvis, changed, (int)cam_stride);
+              }
+              else if (!RIG || cam_t < cam_stride)   // (unsigned: the lanes of the cameras in front are "negative")
                 accumulate_camera<P, D, NT, true, G, ROBUST>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                                     est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c], acc_ref,
-                                                     nvis, changed);
+                                                     est_alpha, est_beta, robust, dist_jac, weight_scale, (int)cam_t, s_jc[c], acc_ref,
+                                                     nvis, changed, (int)cam_stride);
             } else {
               ImgView<false> ref, cur;
               ref.p = rim.data; ref.pitch = rim.pitch;
               cur.p = cim.data; cur.pitch = cim.pitch;
               if constexpr (ROWS) {
-                accumulate_camera_rows<P, (ROWS ? LPP : 2), D, NT, false, G, ROBUST>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                                                             est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c],
-                                                                             acc_ref, nvis, changed);
-              } else if constexpr (STAGED)
-                accumulate_camera_staged<P, D, NT, false, G, ROBUST>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                                             est_alpha, est_beta, robust, dist_jac, weight_scale, tid,
-                                                             s_stage + wave * kStageDoubles, s_jc[c], acc_ref, nvis, changed);
-              else
+                if (!RIG || cam_t < cam_stride)
+                  accumulate_camera_rows<P, (ROWS ? LPP : 2), D, NT, false, G, ROBUST>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                                             est_alpha, est_beta, robust, dist_jac, weight_scale, (int)cam_t, s_jc[c],
+                                                                             acc_ref, nvis, changed, (int)cam_stride);
+              } else if constexpr (STAGED) {
+                if (!RIG || cam_t < cam_stride)
+                  accumulate_camera_staged<P, D, NT, false, G, ROBUST>(a, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
+                                                             est_alpha, est_beta, robust, dist_jac, weight_scale, (int)cam_t,
+                                                             s_stage + wave * kStageDoubles, s_jc[c], acc_ref, nvis, changed, (int)cam_stride);
+              }
+              else if (!RIG || cam_t < cam_stride)   // (unsigned: the lanes of the cameras in front are "negative")
                 accumulate_camera<P, D, NT, false, G, ROBUST>(a, ws, cd, ref, cur, cim.w, cim.h, Tcr, scale, one_plus_alpha, beta_d,
-                                                      est_alpha, est_beta, robust, dist_jac, weight_scale, tid, s_jc[c], acc_ref,
-                                                      nvis, changed);
+                                                      est_alpha, est_beta, robust, dist_jac, weight_scale, (int)cam_t, s_jc[c], acc_ref,
+                                                      nvis, changed, (int)cam_stride);
             }
           }
         };
@@ -1781,10 +1819,10 @@ void align_gn_update_kernel(const AlignKernelArgs a, const double* sums, svoh_al
 struct LaunchCfg { int nt; size_t lds; };
 
 constexpr size_t kLdsPerCu = 163840;   // gfx950: 160 KB per compute unit
-template <int P, int NT, bool ILLUM, bool CLUSTER, bool ROBUST, int LPP = 1, bool LAT = false>
+template <int P, int NT, bool ILLUM, bool CLUSTER, bool ROBUST, int LPP = 1, bool LAT = false, bool RIG = false>
 static hipError_t launch_one(hipStream_t st, int grid, size_t lds, AlignKernelArgs args)
 {
-  auto kern = sparse_align_kernel<P, NT, ILLUM, CLUSTER, ROBUST, LPP, LAT>;
+  auto kern = sparse_align_kernel<P, NT, ILLUM, CLUSTER, ROBUST, LPP, LAT, RIG>;
   if (NT == 256 && args.lds_two_per_cu) {
     // Two workgroups per compute unit is what the batch geometry is built on, and the budget is tight (28-29.5 KB of
     // static LDS + 51 KB of images = 79-80.5 of the 80 KB a workgroup may have).  The static part is asked of the code
@@ -1818,8 +1856,12 @@ template <int P, bool ILLUM, bool ROBUST>
 static hipError_t launch_nt(hipStream_t st, int nt, int lpp, int grid, size_t lds, const AlignKernelArgs& args)
 {
   if (args.cluster > 1) return launch_one<P, 256, ILLUM, true, ROBUST>(st, grid, lds, args);
-  if (nt == 256) return args.latency_build ? launch_one<P, 256, ILLUM, false, ROBUST, 1, true>(st, grid, lds, args)
-                                           : launch_one<P, 256, ILLUM, false, ROBUST>(st, grid, lds, args);
+  if (nt == 256) {
+    if (args.latency_build) return args.rig_build ? launch_one<P, 256, ILLUM, false, ROBUST, 1, true, true>(st, grid, lds, args)
+                                                  : launch_one<P, 256, ILLUM, false, ROBUST, 1, true>(st, grid, lds, args);
+    return launch_one<P, 256, ILLUM, false, ROBUST>(st, grid, lds, args);
+  }
+  if (lpp <= 1 && args.rig_build) return launch_one<P, 512, ILLUM, false, ROBUST, 1, false, true>(st, grid, lds, args);
   switch (lpp) {
     case 2: return launch_one<P, 512, ILLUM, false, ROBUST, 2>(st, grid, lds, args);
     case 4: return launch_one<P, 512, ILLUM, false, ROBUST, 4>(st, grid, lds, args);
@@ -1901,6 +1943,8 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // pass 1: sizes
   size_t n_cams_total = 0, n_feat_total = 0, host_bytes = 0;
   int max_feat_per_problem = 0;
+  bool have_rig = false;        // some problem has more than one camera
+  bool rig_wants_512 = false;   // a problem of several cameras whose patches fill five to eight waves, camera by camera (geometry choice below)
   for (int p = 0; p < n_problems; ++p) {
     const svoh_align_problem& pb = problems[p];
     SVOH_REQUIRE(ctx, pb.n_cams >= 1 && pb.n_cams <= SVOH_MAX_CAMS, "n_cams out of range");
@@ -1920,6 +1964,12 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
     n_feat_total += nf;
     const int per_share = S > 1 ? nf / S + pb.n_cams : nf;
     if (per_share > max_feat_per_problem) max_feat_per_problem = per_share;
+    if (S == 1 && pb.n_cams >= 2) {
+      have_rig = true;
+      int lanes = 0;
+      for (int c = 0; c < pb.n_cams; ++c) lanes += (pb.cams[c].n_features + 63) & ~63;
+      rig_wants_512 = rig_wants_512 || (lanes > 256 && lanes <= 512);
+    }
   }
   const size_t feat_slots = n_feat_total ? n_feat_total : 1;
 
@@ -2107,6 +2157,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // LDS-DMA workspace path beat one 512-thread workgroup: 384 problems 1.06 -> 0.82 ms)
   int nt = (n_desc >= ctx->num_cus) ? 256 : 512;
   if (max_feat_per_problem <= 256) nt = 256;
+  // a few rigs whose cameras fill five to eight waves between them: 512 threads, so that the cameras run side by side with
+  // one round each (run_cameras in the kernel) instead of taking turns
+  if (!cluster && n_desc < ctx->num_cus && rig_wants_512) nt = 512;
   // Rows geometry (LPP lanes per patch, accumulate_camera_rows): a problem with so few patches that they do not give
   // every SIMD of its compute unit a wave gets 2, 4 or 8 lanes per patch, as many as keep it at one wave per SIMD (256
   // lanes) -- a lane's pass is then a chain of P / LPP rolling rows instead of P.  Measured (one problem, levels 4..2,
@@ -2134,6 +2187,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   size_t lds = (nt == 256) ? 52224 : 78 * 1024;
   // SVOH_ALIGN_LATENCY_BUILD=0 keeps the batch build for small launches too (A/B)
   args.latency_build = (nt == 256 && !cluster && n_desc < ctx->num_cus && SvohKnobs::or_default(ctx->knobs.align_latency_build, 1) != 0) ? 1 : 0;
+  args.rig_build = (!cluster && n_desc < ctx->num_cus && have_rig) ? 1 : 0;
   args.lds_two_per_cu = (nt == 256 && !cluster && ctx->knobs.align_lds == kKnobUnset && ctx->knobs.align_wg_per_cu == kKnobUnset) ? 1 : 0;
   lds = (size_t)SvohKnobs::or_default(ctx->knobs.align_lds, (int)lds);
   // 160 KB per workgroup minus the kernel's static LDS

@@ -115,6 +115,27 @@ def test_stereo_bundle(gpu_ctx, oracle_lib):
     check_run(gpu_ctx, orc, opt, opb, gpb)
 
 
+@pytest.mark.parametrize("sizes", [(70, 130, 20), (125, 125), (160, 150), (129, 3), (40, 0, 90), (300, 200)])
+def test_rig_cameras_side_by_side(gpu_ctx, oracle_lib, sizes):
+    """Round 4: in a launch of a few problems the cameras of a rig run side by side, camera c on the waves behind camera
+    c-1's, when their patches fit the workgroup together (sparse_align_kernel<..., RIG>: the 256-thread latency build and
+    the 512-thread geometry) -- and take turns when they do not (the last case).  Unequal cameras, three cameras, a camera
+    without features, gain + offset with a prior: against the oracle, like every other bundle."""
+    orc = oracle_lib
+    cams = [helpers.small_scene(500 + k, n=max(n, 1), border_features=min(6, n // 4), gain=1.02, offset=1.5) if k != 1 else
+            synth.make_align_scene(500 + k, n_features=max(n, 1), cam=synth.Camera.euroc_like(), border_features=min(6, n // 4), gain=1.02, offset=1.5)
+            for k, n in enumerate(sizes)]
+    for sc, n in zip(cams, sizes):
+        if n == 0: sc.flags[:] = 0      # a camera whose every feature is unusable
+    Tp = synth.SE3(synth.quat_from_axis_angle([0.2, -1, 0.3], 0.003), [0.002, -0.001, 0.001])
+    prior = helpers.make_prior(Tp, 0.5, 0.2)
+    opb, gpb, keep = both(gpu_ctx, orc, cams, prior=prior)
+    for kw in (dict(min_level=2), dict(min_level=1, estimate_illumination_gain=1, estimate_illumination_offset=1)):
+        opt = capi.default_align_options(**kw)
+        check_evaluate(gpu_ctx, orc, opt, opb, gpb, (4, 2))
+        check_run(gpu_ctx, orc, opt, opb, gpb)
+
+
 def test_prior(gpu_ctx, oracle_lib):
     orc = oracle_lib
     sc = helpers.small_scene(35, n=300, gain=1.02, offset=1.0)
