@@ -1917,7 +1917,13 @@ __device__ __forceinline__ void match_direct_body(const MatcherArgs& a, int bloc
   const int i = block * (G8 ? 8 : 64) + unit;
   if (i >= a.n) return;
   if (!feature_indices_ok(a, i)) {
+    if (G8 && (threadIdx.x & 7) != 0) return;
     a.result[i] = SVOH_MATCH_NOT_RUN;
+    // a unit that is not run reads back as zeros in its optional outputs (the launch does not clear the output block)
+    if (a.f_cur) { a.f_cur[3 * i] = 0.0; a.f_cur[3 * i + 1] = 0.0; a.f_cur[3 * i + 2] = 0.0; }
+    if (a.search_level) a.search_level[i] = 0;
+    if (a.h_inv) a.h_inv[i] = 0.0;
+    if (a.A_cur_ref) for (int k = 0; k < 4; ++k) a.A_cur_ref[4 * i + k] = 0.0;
     reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(0u, 0u, 0u, 0u);
     return;
   }
@@ -1964,7 +1970,13 @@ __device__ __forceinline__ void update_seeds_body(const MatcherArgs& a, int bloc
   if (reporter) {
     a.success[i] = 0;
     if (a.result) a.result[i] = SVOH_MATCH_NOT_RUN;
-    reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(0u, 0u, 0u, 0u);   // units that are not run
+    // units that are not run: zeros in the optional outputs (the launch does not clear the output block; a unit that
+    // does run overwrites them below)
+    if (a.px_cur) { a.px_cur[2 * i] = 0.0; a.px_cur[2 * i + 1] = 0.0; }
+    if (a.f_cur) { a.f_cur[3 * i] = 0.0; a.f_cur[3 * i + 1] = 0.0; a.f_cur[3 * i + 2] = 0.0; }
+    if (a.search_level) a.search_level[i] = 0;
+    if (a.A_cur_ref) for (int k = 0; k < 4; ++k) a.A_cur_ref[4 * i + k] = 0.0;
+    reinterpret_cast<uint4*>(a.unit_counts)[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   if (!feature_indices_ok(a, i)) return;
   const int type = a.type[i];
@@ -2851,8 +2863,17 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   uint8_t* d = static_cast<uint8_t*>(dbuf.ptr);
   for (size_t k = 0; k < s.in.size(); ++k) memcpy(h + s.off[k], s.in[k].first, s.in[k].second);
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
-  // optional outputs of units that return before the matcher runs read back as zeros
-  if (!on_device) SVOH_HIP_TRY(ctx, hipMemsetAsync(d + in_total, 0, s.total - in_total, ctx->stream));
+  // geometry: 1 = eight lanes per unit, 0 = one lane per unit, 2 = packed (seed update only; large batches)
+  // 3 = one wave per unit (the epipolar scan 64 steps at a time; seed update only, on request: its scans are short)
+  int g8 = n <= kG8MaxUnits ? 1 : 2;
+  g8 = SvohKnobs::or_default(ctx->knobs.matcher_g8, g8);
+  if (g8 < 0 || g8 > 3) g8 = 0;
+  if (g8 == 3 && (!seeds || defer)) g8 = 1;   // the direct matcher has no scan
+  if (landmark_xyz) g8 = 0;                    // the pixelwise warp exists with one lane per unit only
+  // Optional outputs of units that return before the matcher runs read back as zeros.  The per-unit kernels write those
+  // zeros themselves (match_direct_body, update_seeds_body): a fill of the output block would be one more operation on
+  // the stream of every per-frame call (2.6 us each, tools/svoh_call_overhead).  The packed geometry's kernels do not.
+  if (!on_device && g8 == 2) SVOH_HIP_TRY(ctx, hipMemsetAsync(d + in_total, 0, s.total - in_total, ctx->stream));
 
   MatcherArgs a;
   memset(&a, 0, sizeof a);
@@ -2893,13 +2914,6 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   }
   // small batches: eight lanes per unit (a launch is as slow as its slowest lane, and eight lanes get a unit done
   // ~3x sooner); large batches: one lane per unit (fewer instructions per unit).  The knob SVOH_MATCHER_G8 (read when the context is made) forces one.
-  // geometry: 1 = eight lanes per unit, 0 = one lane per unit, 2 = packed (seed update only; large batches)
-  // 3 = one wave per unit (the epipolar scan 64 steps at a time; seed update only, on request: its scans are short)
-  int g8 = n <= kG8MaxUnits ? 1 : 2;
-  g8 = SvohKnobs::or_default(ctx->knobs.matcher_g8, g8);
-  if (g8 < 0 || g8 > 3) g8 = 0;
-  if (g8 == 3 && (!seeds || defer)) g8 = 1;   // the direct matcher has no scan
-  if (landmark_xyz) g8 = 0;                    // the pixelwise warp exists with one lane per unit only
   if (defer && g8 != 2) {
     // Deferred section: the launch itself waits for svoh_matcher_collect, where a direct batch and a seed batch of
     // the same geometry go out as ONE kernel (match_mixed_kernel).  Remembered: the arguments, the copy of the
