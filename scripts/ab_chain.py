@@ -8,7 +8,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_mini_frontend_gpu as t
 
-other = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "build", "head"))
+# "env:NAME=VALUE" instead of a directory: "other" = the tree's libraries with that environment variable set
+other_env = None
+if len(sys.argv) > 1 and sys.argv[1].startswith("env:"):
+    other_env = sys.argv[1][4:].split("=", 1)
+other = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 and not other_env else os.path.join(ROOT, "build", "head"))
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 tmp = pathlib.Path(tempfile.mkdtemp(prefix="abchain_", dir="/tmp"))
 cmd, out_dir, poses, stamps, n_frames = t.make_dataset(tmp)
@@ -17,7 +21,9 @@ files = {}
 for r in range(rounds):
     for name in ("other", "tree") if r % 2 else ("tree", "other"):
         env = dict(os.environ)
-        if name == "other":
+        if name == "other" and other_env:
+            env[other_env[0]] = other_env[1]
+        elif name == "other":
             env["LD_LIBRARY_PATH"] = other + ":" + env.get("LD_LIBRARY_PATH", "")
         p = subprocess.run(cmd, capture_output=True, text=True, env=env)
         assert p.returncode == 0, p.stdout + p.stderr

@@ -44,11 +44,18 @@ __global__ void work_signal_kernel(const double* in, double* out_host, int n_in,
   if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// raises the flag only: queued behind an ordinary D2H copy, it tells the host that the copy has landed
+__global__ void signal_kernel(unsigned* flag_host, unsigned seq)
+{
+  __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main()
 {
-  const int n_in = 2048, n_out = 512, reps = 300;   // 16 KB in, 4 KB out: one frame's features and results
+  const int n_in = 2048, reps = 300;   // 16 KB in, 4 KB out: one frame's features and results
+  const int n_out = getenv("SVOH_OVERHEAD_N_OUT") ? atoi(getenv("SVOH_OVERHEAD_N_OUT")) : 512;   // doubles copied back (a matcher batch: 16384)
   // SVOH_OVERHEAD_SCHEDULE=spin|yield|block: the runtime's own wait policy (hipSetDeviceFlags) for the *_sync variants
   if (const char* sch = getenv("SVOH_OVERHEAD_SCHEDULE")) {
     const unsigned f = !strcmp(sch, "spin") ? hipDeviceScheduleSpin : !strcmp(sch, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync;
@@ -73,9 +80,9 @@ int main()
   printf("{");
   const char* names[] = { "kernel_sync", "h2d_kernel_sync", "h2d_kernel_d2h_sync", "h2d_memset_events_kernel_d2h_sync",
                           "zero_copy_coherent", "zero_copy_noncoherent", "zero_copy_in_noncoherent_out_device_d2h", "h2d_events_kernel_d2h_sync", "h2d_memset_kernel_d2h_sync", "h2d_fillkernel_kernel_d2h_sync",
-                          "h2d_kernel_copysignal_poll", "h2d_worksignal_poll" };
+                          "h2d_kernel_copysignal_poll", "h2d_worksignal_poll", "h2d_kernel_d2h_signal_poll" };
   for (int work : { 0, 20000 }) {
-    for (int v = 0; v < 12; ++v) {
+    for (int v = 0; v < 13; ++v) {
       std::vector<double> t;
       for (int r = 0; r < reps + 20; ++r) {
         h_in[0] = h_in_nc[0] = (double)r;
@@ -103,6 +110,8 @@ int main()
                    copy_signal_kernel<<<1, 256, 0, s>>>(d_out, h_out, n_out, h_flag, ++seq); break;
           case 11: CK(hipMemcpyAsync(d_in, h_in, n_in * 8, hipMemcpyHostToDevice, s));
                    work_signal_kernel<<<1, 256, 0, s>>>(d_in, h_out, n_in, n_out, work, h_flag, ++seq); break;
+          case 12: CK(hipMemcpyAsync(d_in, h_in, n_in * 8, hipMemcpyHostToDevice, s)); work_kernel<<<1, 256, 0, s>>>(d_in, d_out, n_in, n_out, work);
+                   CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); signal_kernel<<<1, 1, 0, s>>>(h_flag, ++seq); break;
           case 6: work_kernel<<<1, 256, 0, s>>>(h_in_nc, d_out, n_in, n_out, work); CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); break;
         }
         if (v >= 10) {   // the host polls the flag word (bounded: 20 ms, then the ordinary wait)
@@ -113,7 +122,9 @@ int main()
           CK(hipStreamSynchronize(s));
         }
         const double t1 = now_us();
-        if (v >= 10) CK(hipStreamSynchronize(s));     // outside the clock: the stream is drained before the next repetition
+        // SVOH_OVERHEAD_NO_DRAIN=1: the polled variants never call hipStreamSynchronize -- what the runtime's un-reaped
+        // commands then cost the NEXT repetition's calls shows in that repetition's time
+        if (v >= 10 && !getenv("SVOH_OVERHEAD_NO_DRAIN")) CK(hipStreamSynchronize(s));     // outside the clock: the stream is drained before the next repetition
         if (r >= 20) t.push_back(t1 - t0);
       }
       std::sort(t.begin(), t.end());
