@@ -580,7 +580,8 @@ typedef struct svoh_seed_match_outputs {
 /* svoh_update_seeds_batch that also returns the matcher state of every seed (outputs may
  * be NULL = svoh_update_seeds_batch).  Entries of seeds whose update returned before the
  * epipolar search (match_result SVOH_MATCH_NOT_RUN) read back as zeros from a host-resident
- * batch and are left untouched in a device-resident one. */
+ * batch.  In a device-resident batch they are unspecified: the per-unit kernels (batches of up to
+ * 49 152 seeds) write zeros there as well, the packed kernel of larger batches leaves them untouched. */
 int svoh_update_seeds_batch_ex(svoh_ctx* ctx, const svoh_matcher_options* matcher_options,
                                const svoh_depth_filter_options* options,
                                int n_ref_frames, const svoh_frame_view* ref_frames,
