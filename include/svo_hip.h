@@ -160,7 +160,7 @@ typedef struct svoh_context_stats_t {
 int svoh_context_stats(svoh_ctx* ctx, svoh_context_stats_t* out);
 
 /* Tuning and diagnostic knobs (launch geometry overrides: SVOH_ALIGN_THREADS, SVOH_ALIGN_ROWS, SVOH_ALIGN_LDS, SVOH_ALIGN_CLUSTER,
- * SVOH_ALIGN_WG_PER_CU, SVOH_MATCHER_G8, SVOH_SEED_BINNING, SVOH_KLT_BLOCK, SVOH_POSE_THREADS; INTEGRATION.md lists
+ * SVOH_ALIGN_WG_PER_CU, SVOH_MATCHER_G8, SVOH_SEED_BINNING, SVOH_KLT_BLOCK, SVOH_POSE_THREADS, SVOH_COPY_KERNEL; INTEGRATION.md lists
  * them) are read from the environment once, by svoh_create.  No launch path looks at the environment.  A process that
  * changes those variables afterwards (the test-suite does, to run every kernel geometry) asks for them to be read again: */
 int svoh_reload_knobs(svoh_ctx* ctx);

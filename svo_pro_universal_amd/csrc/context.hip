@@ -34,6 +34,29 @@ const Frame* find_frame(const svoh_ctx* ctx, svoh_frame_t id)
   return it == ctx->frames.end() ? nullptr : &it->second;
 }
 
+__global__ __launch_bounds__(256) void svoh_copy_to_host_kernel(uint4* dst, const uint4* src, size_t n16, uint8_t* dst_tail, const uint8_t* src_tail, int n_tail)
+{
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+  __threadfence_system();
+}
+
+hipError_t svoh_copy_to_host(svoh_ctx* ctx, void* dst_pinned, const void* src_device, size_t bytes)
+{
+  if (bytes == 0) return hipSuccess;
+  const bool by_kernel = SvohKnobs::or_default(ctx->knobs.copy_kernel, 1) != 0 && bytes >= ((size_t)16 << 10) && bytes <= ((size_t)1 << 20) &&
+                         !(reinterpret_cast<uintptr_t>(dst_pinned) & 15) && !(reinterpret_cast<uintptr_t>(src_device) & 15);
+  if (!by_kernel) return hipMemcpyAsync(dst_pinned, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  const size_t n16 = bytes / 16;
+  const int n_tail = (int)(bytes - n16 * 16);
+  unsigned blocks = (unsigned)((n16 + 255) / 256);
+  if (blocks > 32) blocks = 32;
+  hipLaunchKernelGGL(svoh_copy_to_host_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<uint4*>(dst_pinned),
+                     static_cast<const uint4*>(src_device), n16, static_cast<uint8_t*>(dst_pinned) + n16 * 16,
+                     static_cast<const uint8_t*>(src_device) + n16 * 16, n_tail);
+  return hipGetLastError();
+}
+
 int reset_counters(svoh_ctx* ctx, unsigned long long** out)
 {
   SVOH_HIP_TRY(ctx, ctx->d_counters.reserve(8 * sizeof(unsigned long long)));
@@ -351,6 +374,7 @@ void load_knobs_from_env(SvohKnobs& k)
   k.align_lds = get("SVOH_ALIGN_LDS");
   k.align_wg_per_cu = get("SVOH_ALIGN_WG_PER_CU");
   k.kernel_timing = get("SVOH_KERNEL_TIMING");
+  k.copy_kernel = get("SVOH_COPY_KERNEL");
 }
 
 extern "C" {

@@ -432,7 +432,7 @@ static int launch_klt(svoh_ctx* ctx, const svoh_klt_options* options, const std:
     if (rc != SVOH_OK) return rc;
   }
   if (on_device) return SVOH_OK;  // stream-ordered; the caller synchronises when it needs the results
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + in_bytes, d + in_bytes, io_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + in_bytes, d + in_bytes, io_bytes));
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(px_cur, h + in_bytes, sizeof(double) * 2 * n);
   memcpy(status, h + in_bytes + sizeof(double) * 2 * n, n);

@@ -3024,7 +3024,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   }
   // everything after the inputs that may have changed comes back in one copy
   const size_t back_from = o_type;
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + back_from, d + back_from, o_nsucc - back_from, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + back_from, d + back_from, o_nsucc - back_from));
   if (defer) {   // the copies to the caller's arrays wait for svoh_matcher_collect
     auto later = [&](void* dst, size_t off, size_t bytes) { if (dst && bytes) ctx->matcher_pending.push_back({ dst, h + off, bytes }); };
     if (seeds) {
@@ -3323,7 +3323,7 @@ static int enqueue_candidates(svoh_ctx* ctx, const svoh_camera* cam, const svoh_
   hipLaunchKernelGGL(project_candidates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "project_candidates launch failed: %s", hipGetErrorString(e));
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_px, d + o_px, total - o_px, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + o_px, d + o_px, total - o_px));
   ctx->cand_pending_n = n;
   ctx->cand_out_off = o_px;
   return SVOH_OK;
@@ -3427,8 +3427,8 @@ static int launch_deferred(svoh_ctx* ctx)
       ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
       rc = reduce_unit_counts(ctx, n0 + n1);
       if (rc != SVOH_OK) return rc;
-      if (v0) SVOH_HIP_TRY(ctx, hipMemcpyAsync(d0.d2h_dst, d0.d2h_src, d0.d2h_bytes, hipMemcpyDeviceToHost, ctx->stream));
-      if (v1) SVOH_HIP_TRY(ctx, hipMemcpyAsync(d1.d2h_dst, d1.d2h_src, d1.d2h_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      if (v0) SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, d0.d2h_dst, d0.d2h_src, d0.d2h_bytes));
+      if (v1) SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, d1.d2h_dst, d1.d2h_src, d1.d2h_bytes));
     }
   }
   return SVOH_OK;

@@ -129,6 +129,7 @@ struct SvohKnobs {
   int align_lds = kKnobUnset;                 // SVOH_ALIGN_LDS: bytes of LDS for image levels
   int align_wg_per_cu = kKnobUnset;           // SVOH_ALIGN_WG_PER_CU
   int kernel_timing = kKnobUnset;             // SVOH_KERNEL_TIMING: 1 = bracket every kernel with an event pair (svoh_set_kernel_timing)
+  int copy_kernel = kKnobUnset;               // SVOH_COPY_KERNEL: 0 = result blocks always come back through hipMemcpyAsync
   static int or_default(int v, int dflt) { return v == kKnobUnset ? dflt : v; }
 };
 void load_knobs_from_env(SvohKnobs& k);
@@ -221,6 +222,12 @@ int reset_counters(svoh_ctx* ctx, unsigned long long** out);
 // sums them into the context's 8 counters AFTER the timed region (atomics on a few shared words
 // inside the kernel would serialise it)
 int reserve_unit_counts(svoh_ctx* ctx, size_t n_units, unsigned int** out);
+// A block of results back to PINNED host memory, queued on the context's stream.  The runtime's copy of 32 KB and more
+// goes through the DMA engine, which costs a round trip 4 - 5 us more than a kernel's own stores over PCIe
+// (tools/svoh_call_overhead, h2d_kernel_copykernel_sync against h2d_kernel_d2h_sync: 32 KB 20.6 / 24.2 us, 128 KB
+// 23.4 / 28.4; 4 KB 18.4 / 16.5 the other way round): blocks of 16 KB .. 1 MB, 16-byte aligned, go through a copy
+// kernel, everything else through hipMemcpyAsync.  SVOH_COPY_KERNEL=0: always hipMemcpyAsync.
+hipError_t svoh_copy_to_host(svoh_ctx* ctx, void* dst_pinned, const void* src_device, size_t bytes);
 int reduce_unit_counts(svoh_ctx* ctx, size_t n_units);
 void set_global_error(const char* msg);
 const Frame* find_frame(const svoh_ctx* ctx, svoh_frame_t id);
