@@ -57,6 +57,22 @@ hipError_t svoh_copy_to_host(svoh_ctx* ctx, void* dst_pinned, const void* src_de
   return hipGetLastError();
 }
 
+hipError_t svoh_copy_to_device(svoh_ctx* ctx, void* dst_device, const void* src_pinned, size_t bytes)
+{
+  if (bytes == 0) return hipSuccess;
+  const bool by_kernel = SvohKnobs::or_default(ctx->knobs.copy_kernel, 1) != 0 && bytes >= ((size_t)32 << 10) && bytes <= ((size_t)1 << 20) &&
+                         !(reinterpret_cast<uintptr_t>(dst_device) & 15) && !(reinterpret_cast<uintptr_t>(src_pinned) & 15);
+  if (!by_kernel) return hipMemcpyAsync(dst_device, src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream);
+  const size_t n16 = bytes / 16;
+  const int n_tail = (int)(bytes - n16 * 16);
+  unsigned blocks = (unsigned)((n16 + 255) / 256);
+  if (blocks > 32) blocks = 32;
+  hipLaunchKernelGGL(svoh_copy_to_host_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<uint4*>(dst_device),
+                     static_cast<const uint4*>(src_pinned), n16, static_cast<uint8_t*>(dst_device) + n16 * 16,
+                     static_cast<const uint8_t*>(src_pinned) + n16 * 16, n_tail);
+  return hipGetLastError();
+}
+
 int reset_counters(svoh_ctx* ctx, unsigned long long** out)
 {
   SVOH_HIP_TRY(ctx, ctx->d_counters.reserve(8 * sizeof(unsigned long long)));

@@ -2862,7 +2862,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   uint8_t* h = static_cast<uint8_t*>(hbuf.ptr);
   uint8_t* d = static_cast<uint8_t*>(dbuf.ptr);
   for (size_t k = 0; k < s.in.size(); ++k) memcpy(h + s.off[k], s.in[k].first, s.in[k].second);
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, in_total));
   // geometry: 1 = eight lanes per unit, 0 = one lane per unit, 2 = packed (seed update only; large batches)
   // 3 = one wave per unit (the epipolar scan 64 steps at a time; seed update only, on request: its scans are short)
   int g8 = n <= kG8MaxUnits ? 1 : 2;
@@ -3143,7 +3143,7 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
   uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch1.ptr);
   uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch1.ptr);
   for (size_t k = 0; k < s.in.size(); ++k) memcpy(h + s.off[k], s.in[k].first, s.in[k].second);
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, in_total));
   if (!on_device && o_end > in_total) SVOH_HIP_TRY(ctx, hipMemsetAsync(d + in_total, 0, o_end - in_total, ctx->stream));
 
   MatcherArgs a;
@@ -3309,7 +3309,7 @@ static int enqueue_candidates(svoh_ctx* ctx, const svoh_camera* cam, const svoh_
   uint8_t* d = static_cast<uint8_t*>(ctx->d_cand.ptr);
   if (n_kf > 0) memcpy(h + o_kf, T_world_kf, sizeof(svoh_se3) * (size_t)n_kf);
   memcpy(h + o_kind, kind, nd); memcpy(h + o_idx, kf, 4 * nd); memcpy(h + o_v, v, 24 * nd); memcpy(h + o_mu, mu, 8 * nd);
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, in_total));
   CandidateArgs a;
   memset(&a, 0, sizeof a);
   a.cam = *cam; a.T_a = *T_a;

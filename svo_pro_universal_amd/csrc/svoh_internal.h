@@ -228,6 +228,10 @@ int reserve_unit_counts(svoh_ctx* ctx, size_t n_units, unsigned int** out);
 // 23.4 / 28.4; 4 KB 18.4 / 16.5 the other way round): blocks of 16 KB .. 1 MB, 16-byte aligned, go through a copy
 // kernel, everything else through hipMemcpyAsync.  SVOH_COPY_KERNEL=0: always hipMemcpyAsync.
 hipError_t svoh_copy_to_host(svoh_ctx* ctx, void* dst_pinned, const void* src_device, size_t bytes);
+// The other direction: a staged input block from PINNED host memory to the device.  Same finding (h2d_kernel_d2h_sync
+// against copyin_kernel_d2h_sync with SVOH_OVERHEAD_N_IN): 32 KB 27.4 / 24.7 us, 64 KB 33.7 / 29.0, 128 KB 48.8 / 37.9; 16 KB
+// 18.1 / 22.6 the other way round -- blocks of 32 KB .. 1 MB are read by a copy kernel, the rest goes through hipMemcpyAsync.
+hipError_t svoh_copy_to_device(svoh_ctx* ctx, void* dst_device, const void* src_pinned, size_t bytes);
 int reduce_unit_counts(svoh_ctx* ctx, size_t n_units);
 void set_global_error(const char* msg);
 const Frame* find_frame(const svoh_ctx* ctx, svoh_frame_t id);

@@ -61,7 +61,8 @@ static double now_us() { return std::chrono::duration<double, std::micro>(std::c
 
 int main()
 {
-  const int n_in = 2048, reps = 300;   // 16 KB in, 4 KB out: one frame's features and results
+  const int n_in = getenv("SVOH_OVERHEAD_N_IN") ? atoi(getenv("SVOH_OVERHEAD_N_IN")) : 2048;   // doubles uploaded (16 KB: one frame's features; a seed batch: 16384)
+  const int reps = 300;
   const int n_out = getenv("SVOH_OVERHEAD_N_OUT") ? atoi(getenv("SVOH_OVERHEAD_N_OUT")) : 512;   // doubles copied back (a matcher batch: 16384)
   // SVOH_OVERHEAD_SCHEDULE=spin|yield|block: the runtime's own wait policy (hipSetDeviceFlags) for the *_sync variants
   if (const char* sch = getenv("SVOH_OVERHEAD_SCHEDULE")) {
@@ -87,9 +88,9 @@ int main()
   printf("{");
   const char* names[] = { "kernel_sync", "h2d_kernel_sync", "h2d_kernel_d2h_sync", "h2d_memset_events_kernel_d2h_sync",
                           "zero_copy_coherent", "zero_copy_noncoherent", "zero_copy_in_noncoherent_out_device_d2h", "h2d_events_kernel_d2h_sync", "h2d_memset_kernel_d2h_sync", "h2d_fillkernel_kernel_d2h_sync",
-                          "h2d_kernel_copysignal_poll", "h2d_worksignal_poll", "h2d_kernel_d2h_signal_poll", "h2d_kernel_copykernel_sync" };
+                          "h2d_kernel_copysignal_poll", "h2d_worksignal_poll", "h2d_kernel_d2h_signal_poll", "h2d_kernel_copykernel_sync", "copyin_kernel_d2h_sync" };
   for (int work : { 0, 20000 }) {
-    for (int v = 0; v < 14; ++v) {
+    for (int v = 0; v < 15; ++v) {
       std::vector<double> t;
       for (int r = 0; r < reps + 20; ++r) {
         h_in[0] = h_in_nc[0] = (double)r;
@@ -121,9 +122,12 @@ int main()
                    CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); signal_kernel<<<1, 1, 0, s>>>(h_flag, ++seq); break;
           case 13: CK(hipMemcpyAsync(d_in, h_in, n_in * 8, hipMemcpyHostToDevice, s)); work_kernel<<<1, 256, 0, s>>>(d_in, d_out, n_in, n_out, work);
                    copy_kernel<<<(n_out + 1023) / 1024 > 32 ? 32 : (n_out + 1023) / 1024, 256, 0, s>>>(d_out, h_out, n_out); break;
+          case 14: copy_kernel<<<(n_in + 1023) / 1024 > 32 ? 32 : (n_in + 1023) / 1024, 256, 0, s>>>(h_in, d_in, n_in);   // the upload by a kernel reading pinned host memory
+                   work_kernel<<<1, 256, 0, s>>>(d_in, d_out, n_in, n_out, work);
+                   CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); break;
           case 6: work_kernel<<<1, 256, 0, s>>>(h_in_nc, d_out, n_in, n_out, work); CK(hipMemcpyAsync(h_out, d_out, n_out * 8, hipMemcpyDeviceToHost, s)); break;
         }
-        if (v >= 10 && v != 13) {   // the host polls the flag word (bounded: 20 ms, then the ordinary wait)
+        if (v >= 10 && v != 13 && v != 14) {   // the host polls the flag word (bounded: 20 ms, then the ordinary wait)
           const double dl = now_us() + 20000.0;
           while (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) != seq && now_us() < dl) __builtin_ia32_pause();
           if (h_out[n_out - 1] == -12345.0) return 2;   // keeps the results' read behind the flag's
@@ -133,7 +137,7 @@ int main()
         const double t1 = now_us();
         // SVOH_OVERHEAD_NO_DRAIN=1: the polled variants never call hipStreamSynchronize -- what the runtime's un-reaped
         // commands then cost the NEXT repetition's calls shows in that repetition's time
-        if (v >= 10 && v != 13 && !getenv("SVOH_OVERHEAD_NO_DRAIN")) CK(hipStreamSynchronize(s));     // outside the clock: the stream is drained before the next repetition
+        if (v >= 10 && v != 13 && v != 14 && !getenv("SVOH_OVERHEAD_NO_DRAIN")) CK(hipStreamSynchronize(s));     // outside the clock: the stream is drained before the next repetition
         if (r >= 20) t.push_back(t1 - t0);
       }
       std::sort(t.begin(), t.end());
