@@ -36,6 +36,9 @@
 #include "svoh_device_utils.h"
 #include "svoh_math.h"
 
+// every wait for the whole stream in this file: the alignment's staging blocks have been read (svoh_internal.h)
+#define SVOH_ALIGN_DRAIN(ctx) do { SVOH_HIP_TRY(ctx, hipStreamSynchronize((ctx)->stream)); (ctx)->align_launches_since_drain = 0; } while (0)
+
 namespace svoh {
 
 struct DevCamDesc {
@@ -1983,13 +1986,17 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // the patch-split entries) must not write a byte of it -- not even the zeroed control block, whose offset moves
   // with the descriptor count and would land inside the earlier call's descriptors -- nor let reserve() replace
   // it, before the earlier call's upload has read it.
-  if (ctx->align_staging_in_flight) {
-    SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_staged));
-    ctx->align_staging_in_flight = false;
+  // (two blocks in turn, an event only between launches queued back to back: svoh_internal.h)
+  ctx->align_desc_slot ^= 1u;
+  PinnedBuffer& h_desc = ctx->align_desc_slot ? ctx->h_desc_odd : ctx->h_desc;
+  if (ctx->align_launches_since_drain >= 2) {
+    // this block was last read by the upload of the launch before the last one, which has not been waited for
+    if (ctx->align_staged_event_valid) SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_staged));
+    else SVOH_ALIGN_DRAIN(ctx);
   }
-  SVOH_HIP_TRY(ctx, ctx->h_desc.reserve(desc_bytes));
+  SVOH_HIP_TRY(ctx, h_desc.reserve(desc_bytes));
   SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
-  memset(static_cast<uint8_t*>(ctx->h_desc.ptr) + ctl_off, 0, 512);
+  memset(static_cast<uint8_t*>(h_desc.ptr) + ctl_off, 0, 512);
   SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
   // results of launches queued since the last fetch are kept one after the other in pinned host memory
   const bool delivers = (S == 1 || cluster) && eval_level < 0;
@@ -2004,7 +2011,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
     const size_t need = sizeof(svoh_align_result) * want_results;
     if (need > ctx->h_results.cap) {
       if (ctx->align_pending_results) {   // earlier launches still deliver into the old block: let them finish, keep theirs
-        SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        SVOH_ALIGN_DRAIN(ctx);
         PinnedBuffer bigger;
         SVOH_HIP_TRY(ctx, bigger.reserve(need * 2));
         memcpy(bigger.ptr, ctx->h_results.ptr, sizeof(svoh_align_result) * ctx->align_pending_results);
@@ -2018,9 +2025,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   SVOH_HIP_TRY(ctx, ctx->d_feat.reserve(feat_slots * (kWsPairs * 16 + 2) + 256));
   SVOH_HIP_TRY(ctx, ctx->d_eval.reserve(74 * sizeof(double) * S));
 
-  DevProblemDesc* hp = static_cast<DevProblemDesc*>(ctx->h_desc.ptr);
+  DevProblemDesc* hp = static_cast<DevProblemDesc*>(h_desc.ptr);
   DevCamDesc* hc = reinterpret_cast<DevCamDesc*>(hp + n_desc);
-  uint8_t* hup = static_cast<uint8_t*>(ctx->h_desc.ptr) + up_base;
+  uint8_t* hup = static_cast<uint8_t*>(h_desc.ptr) + up_base;
   uint8_t* dup = static_cast<uint8_t*>(ctx->d_desc.ptr) + up_base;
   size_t up_off = 0;
   int cam_idx = 0, feat_off = 0;
@@ -2090,9 +2097,13 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
       }
     }
   }
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc.ptr, ctx->h_desc.ptr, up_base + up_off, hipMemcpyHostToDevice, ctx->stream));
-  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_staged, ctx->stream));
-  ctx->align_staging_in_flight = true;
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc.ptr, h_desc.ptr, up_base + up_off, hipMemcpyHostToDevice, ctx->stream));
+  ctx->align_staged_event_valid = false;
+  if (ctx->align_launches_since_drain >= 1) {   // queued behind a launch nobody has waited for: the next one may need this
+    SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_staged, ctx->stream));
+    ctx->align_staged_event_valid = true;
+  }
+  ++ctx->align_launches_since_drain;
 
   AlignKernelArgs args;
   args.problems = static_cast<const DevProblemDesc*>(ctx->d_desc.ptr);
@@ -2248,7 +2259,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   {
     std::vector<long long> h((size_t)n_problems * 20);
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(h.data(), args.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-    SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    SVOH_ALIGN_DRAIN(ctx);
     double sum[20] = {0};
     for (int p = 0; p < n_problems; ++p) for (int k = 0; k < 20; ++k) sum[k] += (double)h[(size_t)p * 20 + k];
     fprintf(stderr, "[stamps] one-lane step: set-up %.0f solve %.0f update %.0f camera poses %.0f\n", sum[8] / n_problems, sum[9] / n_problems,
@@ -2285,7 +2296,7 @@ try {
   SVOH_REQUIRE(ctx, results && n_problems >= 1 && n_problems <= ctx->last_align_n && ctx->h_results.ptr &&
                         ctx->align_pending_results >= (size_t)n_problems, "nothing to fetch");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the copy to h_results was queued behind the kernel
+  SVOH_ALIGN_DRAIN(ctx);   // the copy to h_results was queued behind the kernel
   memcpy(results, static_cast<const svoh_align_result*>(ctx->h_results.ptr) + ctx->align_last_results_off,
          sizeof(svoh_align_result) * n_problems);
   ctx->align_pending_results = 0;
@@ -2298,7 +2309,7 @@ try {
   SVOH_REQUIRE(ctx, results && n_results >= 1 && (size_t)n_results == ctx->align_pending_results,
                "n_results is not the number of results queued since the last fetch");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  SVOH_ALIGN_DRAIN(ctx);
   memcpy(results, ctx->h_results.ptr, sizeof(svoh_align_result) * (size_t)n_results);
   ctx->align_pending_results = 0;
   return SVOH_OK;
@@ -2374,7 +2385,7 @@ try {
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(sel.data(), dsel, (size_t)nf, hipMemcpyDeviceToHost, ctx->stream));
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(vis.data(), dsel + slots, (size_t)nf, hipMemcpyDeviceToHost, ctx->stream));
   }
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  SVOH_ALIGN_DRAIN(ctx);
   memcpy(H64, out, 64 * sizeof(double));
   memcpy(g8, out + 64, 8 * sizeof(double));
   if (chi2) *chi2 = out[72];
@@ -2410,7 +2421,7 @@ try {
   h.alpha = h.alpha_old = problem->alpha_init;
   h.beta = h.beta_old = problem->beta_init;
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(d_state, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // h is a stack object
+  SVOH_ALIGN_DRAIN(ctx);   // h is a stack object
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
@@ -2453,7 +2464,7 @@ try {
   if (rc != SVOH_OK) return rc;
   if (h_state)
     SVOH_HIP_TRY(ctx, hipMemcpyAsync(h_state, d_state, sizeof *h_state, hipMemcpyDeviceToHost, ctx->stream));
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  SVOH_ALIGN_DRAIN(ctx);
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 

@@ -152,7 +152,8 @@ struct svoh_ctx {
   svoh::DevBuffer d_eval;      // evaluate() outputs
   svoh::DevBuffer d_xchg;      // cluster mode of the alignment: exchange slots + arrival counter
   svoh::DevBuffer d_split;     // svoh_sparse_align_split_buffers: a Gauss-Newton state + 74 sums
-  svoh::PinnedBuffer h_desc;
+  svoh::PinnedBuffer h_desc;           // the pinned staging block of even launches ...
+  svoh::PinnedBuffer h_desc_odd;       // ... and of odd ones (see align_launches_since_drain)
   svoh::PinnedBuffer h_results;
   int last_align_n = 0;
   // results of the launches queued since the last fetch, launch after launch in h_results
@@ -163,8 +164,15 @@ struct svoh_ctx {
   static constexpr int kAlignEventRing = 32;
   hipEvent_t ev_align_start[kAlignEventRing] = {}, ev_align_stop[kAlignEventRing] = {};
   unsigned long long align_launches = 0;
-  hipEvent_t ev_align_staged = nullptr;   // the alignment's pinned staging buffers have been consumed
-  bool align_staging_in_flight = false;
+  // The pinned staging blocks are reused.  A launch fetched before the next one is queued (the per-frame use) has
+  // drained the stream: nothing to protect, no event on the stream (an event record costs a launch 4.5 us of stream time,
+  // tools/svoh_call_overhead).  Launches queued back to back alternate between the two blocks; from the second one on
+  // each records ev_align_staged behind its upload, and the third and later wait for the event of the launch before them
+  // -- which lies behind the upload that last read their block.
+  hipEvent_t ev_align_staged = nullptr;
+  bool align_staged_event_valid = false;      // ev_align_staged was recorded by the most recent launch
+  unsigned align_launches_since_drain = 0;    // alignment launches queued since this file last waited for the stream
+  unsigned align_desc_slot = 0;
   bool align_no_cluster = false;   // svoh_sparse_align_batch repeating a launch whose cluster gave up
   hipEvent_t ev_misc_start = nullptr, ev_misc_stop = nullptr;  // KLT / matcher / seeds
   bool misc_timed = false;     // the last KLT / matcher / seed / pose / detector launch was bracketed by the event pair
