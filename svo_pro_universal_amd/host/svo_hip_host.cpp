@@ -1220,15 +1220,34 @@ static void sortCandidatesWithOrder(std::vector<reprojector::Candidate>& candida
   // whatever libstdc++'s introsort leaves, and its moves depend on the comparison results only: sorting 24-byte keys
   // with the same comparator and applying the permutation gives the vector the reference's call gives, for less
   // memory traffic than sorting the 64-byte candidates.
-  struct Key { double score; int n_reproj; uint8_t type; uint32_t at; };
+  // The three-field comparison as ONE comparison of a 128-bit key: type in the top bits, then n_reproj with its sign bit
+  // flipped (signed order = unsigned order), then the score's bits mapped so that unsigned order is the order of the
+  // doubles (negative: all bits flipped; non-negative: sign bit set; -0.0 taken as +0.0, which `>` cannot tell apart).
+  // a.k > b.k is then exactly the reference's lambda (reprojector.cpp:549-555) for every pair -- except when a score
+  // is NaN, which no mapping can order like `>` does: such a list is sorted with the lambda itself.
+  struct Key { unsigned __int128 k; uint32_t at; };
   thread_local std::vector<Key> keys;
   thread_local std::vector<reprojector::Candidate> sorted;
   const size_t n = candidates.size();
   if (order) order->clear();
   if (n < 2) return;
   keys.resize(n);
-  for (size_t i = 0; i < n; ++i) keys[i] = Key{ candidates[i].score, candidates[i].n_reproj, candidates[i].type, static_cast<uint32_t>(i) };
-  std::sort(keys.begin(), keys.end(), [](const Key& lhs, const Key& rhs) {
+  bool any_nan = false;
+  for (size_t i = 0; i < n; ++i) {
+    const reprojector::Candidate& c = candidates[i];
+    double sc = c.score;
+    any_nan = any_nan || sc != sc;
+    if (sc == 0.0) sc = 0.0;   // -0.0 -> +0.0
+    uint64_t bits;
+    memcpy(&bits, &sc, sizeof bits);
+    const uint64_t lo = (bits >> 63) ? ~bits : (bits | (uint64_t(1) << 63));
+    const uint64_t hi = (uint64_t(c.type) << 32) | uint64_t(static_cast<uint32_t>(c.n_reproj) ^ 0x80000000u);
+    keys[i] = Key{ (static_cast<unsigned __int128>(hi) << 64) | lo, static_cast<uint32_t>(i) };
+  }
+  if (!any_nan) std::sort(keys.begin(), keys.end(), [](const Key& lhs, const Key& rhs) { return lhs.k > rhs.k; });
+  else std::sort(keys.begin(), keys.end(), [&candidates](const Key& kl, const Key& kr) {
+    const reprojector::Candidate& lhs = candidates[kl.at];
+    const reprojector::Candidate& rhs = candidates[kr.at];
     return lhs.type > rhs.type || (lhs.type == rhs.type && lhs.n_reproj > rhs.n_reproj) ||
            (lhs.type == rhs.type && lhs.n_reproj == rhs.n_reproj && lhs.score > rhs.score);
   });

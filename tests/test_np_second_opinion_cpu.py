@@ -462,3 +462,15 @@ def test_get_candidate_host_mirror_vs_numpy_second_opinion(tmp_path, cam_kind):
             assert np.abs(host[i, 1:3] - px).max() < 1e-9
             n_vis += 1
     assert 300 < n_vis < n - 300
+
+
+def test_candidate_sort_with_packed_keys_is_the_reference_sort():
+    """reprojector_utils::sortCandidatesByReprojStats compares one 128-bit key per candidate instead of three fields
+    (svo_hip_host.cpp).  The result must be the vector the reference's std::sort call leaves -- for ties too, whose order
+    is introsort's and depends on every comparison's outcome: tests/cpp/host_sort_cpu sorts 400 adversarial lists (runs of
+    equal candidates, -0.0 / +0.0, denormals, infinities, INT_MIN / INT_MAX counts, NaN scores) both ways."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp"), "host_sort_cpu"])
+    r = subprocess.run([os.path.join(root, "tests", "cpp", "host_sort_cpu")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok 400 "), r.stdout + r.stderr
