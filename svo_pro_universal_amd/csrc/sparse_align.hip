@@ -2097,7 +2097,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
       }
     }
   }
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc.ptr, h_desc.ptr, up_base + up_off, hipMemcpyHostToDevice, ctx->stream));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, ctx->d_desc.ptr, h_desc.ptr, up_base + up_off));
   ctx->align_staged_event_valid = false;
   if (ctx->align_launches_since_drain >= 1) {   // queued behind a launch nobody has waited for: the next one may need this
     SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_staged, ctx->stream));
@@ -2249,9 +2249,8 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // the results follow the kernel to pinned host memory right away, so that a caller which queues several
   // launches and fetches once still has every launch's output delivered
   if (delivers) {   // cluster: entry 0 is share 0's copy of the common result
-    SVOH_HIP_TRY(ctx, hipMemcpyAsync(static_cast<svoh_align_result*>(ctx->h_results.ptr) + ctx->align_pending_results,
-                                     ctx->d_results.ptr, sizeof(svoh_align_result) * n_problems,
-                                     hipMemcpyDeviceToHost, ctx->stream));
+    SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, static_cast<svoh_align_result*>(ctx->h_results.ptr) + ctx->align_pending_results,
+                                        ctx->d_results.ptr, sizeof(svoh_align_result) * n_problems));
     ctx->align_last_results_off = ctx->align_pending_results;
     ctx->align_pending_results += (size_t)n_problems;
   }
