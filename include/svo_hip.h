@@ -509,6 +509,11 @@ int svoh_matcher_collect(svoh_ctx* ctx);
  * before collect.  This is how the depth filter's seed update leaves the per-frame critical path
  * (DepthFilterHip::updateSeedsAsync). */
 int svoh_matcher_flush(svoh_ctx* ctx);
+/* In an open deferred section with a queued (not yet flushed) svoh_update_seeds_batch(_ex): replaces the CURRENT frame's
+ * view -- its pose -- by `cur_frame` (same frame handle and camera).  The batch can then be queued, and its inputs
+ * uploaded, BEFORE the pose it is evaluated at is known: everything else the seed update reads (the keyframes' seeds,
+ * their states, the images) does not depend on the pose optimisation that runs meanwhile. */
+int svoh_matcher_deferred_set_cur_frame(svoh_ctx* ctx, const svoh_frame_view* cur_frame);
 
 /* ---- f-4: candidate projection of the reprojector ----------------------------------------------------------
  * Replaces the arithmetic of reprojector_utils::getCandidate / projectPointAndCheckVisibility
@@ -712,6 +717,14 @@ typedef struct svoh_pose_result {
  * removeOutliers.  run()'s return value is n_meas - n_deleted_edges - n_deleted_corners.  Host pointers. */
 int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
                              const svoh_pose_problem* problems, svoh_pose_result* results);
+/* The same call with a hook: after the launch and the copy of its results have been queued, `after_launch(user)` runs on
+ * the calling thread, and only then the call waits -- for an event behind ITS OWN work, not for the stream.  Whatever the
+ * hook queues on the context (the depth filter's staging for the seed update that follows the pose optimisation:
+ * DepthFilterHip::prepareUpdateSeeds) is uploaded while the pose kernel runs and is not waited for here.  The hook must
+ * not call a blocking entry of this context. */
+int svoh_optimize_pose_batch_hook(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
+                                  const svoh_pose_problem* problems, svoh_pose_result* results,
+                                  void (*after_launch)(void* user), void* user);
 
 /* The same for feature arrays that already live on the device (a multi-stream server, or the per-frame chain kept
  * resident): one set of arrays concatenated over all bundles in problem order and, inside a bundle, camera order --

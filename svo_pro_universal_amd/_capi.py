@@ -270,7 +270,7 @@ EXPORTS = [
     "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms", "svoh_sparse_align_kernel_ms_history",
     "svoh_sparse_align_split_buffers", "svoh_sparse_align_split_init", "svoh_sparse_align_partial_sums", "svoh_sparse_align_gn_update",
     "svoh_klt_track_batch", "svoh_klt_track_multi", "svoh_klt_track_indexed", "svoh_last_kernel_ms", "svoh_last_kernel_counters",
-    "svoh_match_direct_batch", "svoh_match_direct_batch_pixelwise", "svoh_matcher_begin_deferred", "svoh_matcher_collect", "svoh_matcher_flush",
+    "svoh_match_direct_batch", "svoh_match_direct_batch_pixelwise", "svoh_matcher_begin_deferred", "svoh_matcher_collect", "svoh_matcher_flush", "svoh_matcher_deferred_set_cur_frame", "svoh_optimize_pose_batch_hook",
     "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex", "svoh_epipolar_match_batch",
     "svoh_project_candidates_enqueue", "svoh_project_candidates_collect", "svoh_project_candidates",
     "svoh_detect_features", "svoh_optimize_pose_batch", "svoh_optimize_pose_batch_packed", "svoh_optimize_points_batch",

@@ -464,6 +464,7 @@ try {
   if (ctx->ev_align_staged) (void)hipEventDestroy(ctx->ev_align_staged);
   if (ctx->ev_misc_start) (void)hipEventDestroy(ctx->ev_misc_start);
   if (ctx->ev_misc_stop) (void)hipEventDestroy(ctx->ev_misc_stop);
+  if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SVOH_OK;

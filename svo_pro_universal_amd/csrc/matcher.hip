@@ -2922,6 +2922,8 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     dl.args.assign(reinterpret_cast<const uint8_t*>(&a), reinterpret_cast<const uint8_t*>(&a) + sizeof a);
     dl.n = n; dl.g8 = g8; dl.valid = true;
     dl.d2h_dst = h + o_type; dl.d2h_src = d + o_type; dl.d2h_bytes = o_nsucc - o_type;
+    dl.views_h = h + o_views; dl.views_d = d + o_views; dl.n_ref = n_ref_frames; dl.n_cur = n_cur;
+    dl.cur_frame_handle = cur_frame[0].frame;
     auto later = [&](void* dst, size_t off, size_t bytes) { if (dst && bytes) ctx->matcher_pending.push_back({ dst, h + off, bytes }); };
     if (seeds) {
       later(fb->type, o_type, (size_t)n); later(state, o_state, sizeof(double) * 4 * n); later(success, o_success, (size_t)n);
@@ -3433,6 +3435,25 @@ static int launch_deferred(svoh_ctx* ctx)
   }
   return SVOH_OK;
 }
+
+int svoh_matcher_deferred_set_cur_frame(svoh_ctx* ctx, const svoh_frame_view* cur_frame)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, cur_frame != nullptr, "NULL argument");
+  SVOH_REQUIRE(ctx, ctx->matcher_deferred, "no deferred section is open");
+  svoh_ctx::DeferredLaunch& dl = ctx->matcher_deferred_launch[1];
+  SVOH_REQUIRE(ctx, dl.valid && dl.views_h && dl.n_cur == 1, "no queued seed batch with one current frame (or it has been sent off already)");
+  SVOH_REQUIRE(ctx, cur_frame->frame == dl.cur_frame_handle, "a different frame: only the view (pose) of the queued batch's current frame can be replaced");
+  DevFrameView v;
+  const int rc = fill_view(ctx, *cur_frame, &v, "current frame");
+  if (rc != SVOH_OK) return rc;
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // the staged copy is replaced as well: it is the upload's source (pinned: it must keep the bytes until the copy has run)
+  DevFrameView* hv = static_cast<DevFrameView*>(dl.views_h) + dl.n_ref;
+  *hv = v;
+  SVOH_HIP_TRY(ctx, hipMemcpyAsync(static_cast<DevFrameView*>(dl.views_d) + dl.n_ref, hv, sizeof(DevFrameView), hipMemcpyHostToDevice, ctx->stream));
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_matcher_flush(svoh_ctx* ctx)
 try {

@@ -564,7 +564,8 @@ using namespace svoh;
 // packed != NULL: the per-feature arrays are the caller's DEVICE arrays (concatenated in problem, then camera order),
 // used in place; only the descriptors travel.
 static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems, const svoh_pose_problem* problems,
-                          const svoh_pose_packed_arrays* packed, svoh_pose_result* results)
+                          const svoh_pose_packed_arrays* packed, svoh_pose_result* results,
+                          void (*after_launch)(void*) = nullptr, void* user = nullptr)
 {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, options && n_problems >= 0, "bad arguments");
@@ -710,7 +711,16 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
     return SVOH_OK;
   }
   SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_outlier, d + o_outlier, total - o_outlier, hipMemcpyDeviceToHost, ctx->stream));
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (after_launch) {
+    // the hook's work goes behind an event and is not waited for: this call's staging (h, d) is not touched by it --
+    // the hook must not enter a blocking call of the context, and the depth filter's staging has blocks of its own
+    if (!ctx->ev_pose_done) SVOH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDisableTiming));
+    SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_pose_done, ctx->stream));
+    after_launch(user);
+    SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_pose_done));
+  } else {
+    SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   memcpy(results, h + o_res, sizeof(svoh_pose_result) * (size_t)n_problems);
   off = 0;
   for (int p = 0; p < n_problems; ++p)
@@ -728,6 +738,13 @@ extern "C" int svoh_optimize_pose_batch(svoh_ctx* ctx, const svoh_pose_options* 
                                         const svoh_pose_problem* problems, svoh_pose_result* results)
 try {
   return run_pose_batch(ctx, options, n_problems, problems, nullptr, results);
+} SVOH_ABI_CATCH(ctx)
+
+extern "C" int svoh_optimize_pose_batch_hook(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,
+                                             const svoh_pose_problem* problems, svoh_pose_result* results,
+                                             void (*after_launch)(void* user), void* user)
+try {
+  return run_pose_batch(ctx, options, n_problems, problems, nullptr, results, after_launch, user);
 } SVOH_ABI_CATCH(ctx)
 
 extern "C" int svoh_optimize_pose_batch_packed(svoh_ctx* ctx, const svoh_pose_options* options, int n_problems,

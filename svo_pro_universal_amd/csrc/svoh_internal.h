@@ -175,6 +175,7 @@ struct svoh_ctx {
   unsigned align_desc_slot = 0;
   bool align_no_cluster = false;   // svoh_sparse_align_batch repeating a launch whose cluster gave up
   hipEvent_t ev_misc_start = nullptr, ev_misc_stop = nullptr;  // KLT / matcher / seeds
+  hipEvent_t ev_pose_done = nullptr;   // svoh_optimize_pose_batch_hook: behind the copy of the results (made at first use)
   bool misc_timed = false;     // the last KLT / matcher / seed / pose / detector launch was bracketed by the event pair
   bool misc_launched = false;  // ... has happened at all (its work counters exist)
   unsigned long long align_timed_launches = 0;   // alignment launches bracketed by events (ring slots in use)
@@ -198,6 +199,9 @@ struct svoh_ctx {
     int n = 0, g8 = 0;
     bool valid = false;
     void* d2h_dst = nullptr; const void* d2h_src = nullptr; size_t d2h_bytes = 0;
+    // the frame views of the batch in its staging blocks (svoh_matcher_deferred_set_cur_frame): n_ref reference frames, then the current one(s)
+    void* views_h = nullptr; void* views_d = nullptr; int n_ref = 0, n_cur = 0;
+    uint64_t cur_frame_handle = 0;
   } matcher_deferred_launch[2];
   // staging of the deferred batches, one pair per kind: nothing else stages through them, so any other call made
   // inside the section (a device-resident batch, an epipolar batch, the detector -- all on d_scratch1 / h_scratch1)

@@ -266,6 +266,38 @@ size_t DepthFilterHip::updateSeeds(const std::vector<FramePtr>& ref_frames_with_
 
 void DepthFilterHip::updateSeedsAsync(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame)
 {
+  if (prepared_) {
+    // prepareUpdateSeeds has queued the batch: the current frame's final pose, and off it goes
+    if (!cur_frame || cur_frame.get() != prepared_cur_ || ref_frames_with_seeds.size() != pending_.frames.size())
+      throw std::runtime_error("DepthFilterHip::updateSeedsAsync: not the update that prepareUpdateSeeds has queued");
+    prepared_ = false; prepared_cur_ = nullptr;
+    if (!async_open_) return;   // (nothing to update: no seeds)
+    const svoh_frame_view cur = view_of(*cur_frame);
+    int rc = svoh_matcher_deferred_set_cur_frame(ctx_, &cur);
+    if (rc == SVOH_OK) rc = svoh_matcher_flush(ctx_);
+    if (rc != SVOH_OK) {
+      const std::string msg = svoh_last_error_string(ctx_);
+      (void)svoh_matcher_collect(ctx_);
+      async_open_ = false;
+      { std::lock_guard<std::mutex> lock(g_async_seed_mu); g_async_seed_owner.erase(ctx_); }
+      pending_.frames.clear();
+      throw std::runtime_error("DepthFilterHip::updateSeedsAsync (prepared): " + msg);
+    }
+    return;
+  }
+  queueUpdateSeeds(ref_frames_with_seeds, cur_frame, true);
+}
+
+void DepthFilterHip::prepareUpdateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame)
+{
+  if (prepared_) throw std::runtime_error("DepthFilterHip::prepareUpdateSeeds: an update is prepared already");
+  queueUpdateSeeds(ref_frames_with_seeds, cur_frame, false);
+  prepared_ = true;
+  prepared_cur_ = cur_frame.get();
+}
+
+void DepthFilterHip::queueUpdateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame, bool send_off)
+{
   if (!cur_frame) throw std::runtime_error("DepthFilterHip::updateSeeds: NULL current frame");
   if (async_open_ || finished_early_) throw std::runtime_error("DepthFilterHip::updateSeedsAsync: the previous update has not been finished");
   px_error_angle_ = updateSeedPxErrorAngle(*cur_frame);
@@ -309,7 +341,7 @@ void DepthFilterHip::updateSeedsAsync(const std::vector<FramePtr>& ref_frames_wi
   { std::lock_guard<std::mutex> lock(g_async_seed_mu); g_async_seed_owner[ctx_] = this; }
   int rc = svoh_update_seeds_batch(ctx_, &matcher_options_, &o, static_cast<int>(q.refs.size()), q.refs.data(), &cur, &fb,
                                    q.state.data(), q.success.data(), last_results_.data(), &q.n_success);
-  if (rc == SVOH_OK) rc = svoh_matcher_flush(ctx_);
+  if (rc == SVOH_OK && send_off) rc = svoh_matcher_flush(ctx_);
   if (rc != SVOH_OK) {
     const std::string msg = svoh_last_error_string(ctx_);
     (void)svoh_matcher_collect(ctx_);
@@ -339,10 +371,15 @@ size_t DepthFilterHip::finishUpdateSeeds()
 size_t DepthFilterHip::finishUpdateSeedsNow()
 {
   Pending& q = pending_;
-  if (!async_open_) { q.frames.clear(); return 0; }
+  if (!async_open_) { q.frames.clear(); prepared_ = false; prepared_cur_ = nullptr; return 0; }
   async_open_ = false;
   { std::lock_guard<std::mutex> lock(g_async_seed_mu); g_async_seed_owner.erase(ctx_); }
-  if (svoh_matcher_collect(ctx_) != SVOH_OK) { q.frames.clear(); throw std::runtime_error(std::string("svoh_matcher_collect: ") + svoh_last_error_string(ctx_)); }
+  if (svoh_matcher_collect(ctx_) != SVOH_OK) { q.frames.clear(); prepared_ = false; throw std::runtime_error(std::string("svoh_matcher_collect: ") + svoh_last_error_string(ctx_)); }
+  if (prepared_) {   // queued by prepareUpdateSeeds and never given its frame's pose: what it computed is not an update of anything
+    prepared_ = false; prepared_cur_ = nullptr;
+    q.frames.clear();
+    return 0;
+  }
   // scatter back in place (ref_frame.invmu_sigma2_a_b_vec_.col(i), type_vec_[i]); a frame's block is the features
   // it had when the update was queued (features are only ever appended)
   size_t off = 0;
@@ -728,7 +765,9 @@ void PoseOptimizerHip::setRotationPrior(const svoh::Quat& R_frame_world, double 
   have_prior_ = true;
 }
 
-size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px)
+size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px) { return run(frame_bundle, reproj_thresh_px, nullptr); }
+
+size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px, const std::function<void()>& after_launch)
 {
   if (!frame_bundle || frame_bundle->empty()) throw std::runtime_error("PoseOptimizer: FrameBundle is empty");   // CHECK
   const size_t nc = frame_bundle->size();
@@ -786,7 +825,18 @@ size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj
     pc.type = fr.type_vec_.data(); pc.xyz_world = xyz[c].data(); pc.usable = usable[c].data(); pc.outlier = outlier[c].data();
   }
   if (n_features == 0) throw std::runtime_error("PoseOptimizer: No features in frames");   // CHECK_GT
-  const int rc = svoh_optimize_pose_batch(ctx_, &o, 1, &pb, &last_);
+  int rc;
+  if (after_launch) {
+    // (an exception cannot cross the C boundary: it is carried over it)
+    struct Hook { const std::function<void()>* fn; std::exception_ptr error; } hook{ &after_launch, nullptr };
+    rc = svoh_optimize_pose_batch_hook(ctx_, &o, 1, &pb, &last_, [](void* user) {
+      Hook* h = static_cast<Hook*>(user);
+      try { (*h->fn)(); } catch (...) { h->error = std::current_exception(); }
+    }, &hook);
+    if (hook.error) std::rethrow_exception(hook.error);
+  } else {
+    rc = svoh_optimize_pose_batch(ctx_, &o, 1, &pb, &last_);
+  }
   if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_optimize_pose_batch: ") + svoh_last_error_string(ctx_));
   measurement_sigma_ = last_.measurement_sigma;
   const Transformation T_imu_world = svoh::load_rigid(last_.T_imu_world);

@@ -249,6 +249,11 @@ class DepthFilterHip {
   // (svoh_detect_features) and frame releases do, so the saving is a non-keyframe saving.
   void updateSeedsAsync(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame);
   size_t finishUpdateSeeds();
+  // The first half of updateSeedsAsync, for a caller that knows the update's inputs before it knows the current frame's
+  // final pose (the per-frame chain: reprojection done, pose optimisation running): the seeds and their states are
+  // staged and uploaded now; updateSeedsAsync(same frames, cur_frame) then only replaces the current frame's view and
+  // sends the kernel off.  Between the two calls nothing but cur_frame's pose may change.
+  void prepareUpdateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame);
   void finishUpdateSeedsEarly();   // what finishPendingSeedUpdate calls
   bool updatePending() const { return async_open_; }
   ~DepthFilterHip();
@@ -275,9 +280,12 @@ class DepthFilterHip {
     int32_t n_success = 0;
   } pending_;
   bool async_open_ = false;
+  bool prepared_ = false;          // prepareUpdateSeeds has queued the batch; updateSeedsAsync has not sent it off yet
+  const Frame* prepared_cur_ = nullptr;
   bool finished_early_ = false;
   size_t early_count_ = 0;
   size_t finishUpdateSeedsNow();
+  void queueUpdateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame, bool send_off);
 };
 
 // Finishes the seed update that a DepthFilterHip has in flight on this context, if there is one (see updateSeedsAsync).
@@ -599,6 +607,9 @@ class PoseOptimizerHip {
   // optimises frame_bundle->at(0)->T_imu_world(), writes T_f_w_ of every frame, marks outliers
   // (type_vec_[i] = kOutlier, landmark / seed reference dropped) and returns the number of remaining measurements
   size_t run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px);
+  // the same, with `after_launch` called between the launch and the wait for its results (svoh_optimize_pose_batch_hook):
+  // host work that does not need the optimised pose -- DepthFilterHip::prepareUpdateSeeds -- runs beside the kernel
+  size_t run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px, const std::function<void()>& after_launch);
   size_t iterCount() const { return static_cast<size_t>(last_.iters); }
   const svoh_pose_result& lastResult() const { return last_; }
   double measurement_sigma_ = 1.0;

@@ -111,6 +111,38 @@ int main(int argc, char** argv)
   printf("seeds: %zu of %d updated, worst relative state difference %.3e\n", n_updated, ns, worst);
   CHECK(worst < 1e-9);
 
+  // ---- round 4: the update queued BEFORE its frame's pose is final (DepthFilterHip::prepareUpdateSeeds, what the per-frame
+  // chain does while the pose optimiser's kernel runs), the pose replaced just before the launch
+  // (svoh_matcher_deferred_set_cur_frame): same states, types and result codes as the one-call update above ----
+  {
+    FramePtr kf2(new Frame);
+    *kf2 = *kf;                               // (shares the pyramid handle; the seeds as they were before the update)
+    kf2->invmu_sigma2_a_b_vec_ = state; kf2->type_vec_ = type;
+    const Transformation T_final = cur->T_f_w_;
+    cur->T_f_w_.t.x += 0.37; cur->T_f_w_.t.z -= 0.2;   // "not optimised yet": a pose the update must NOT be evaluated at
+    DepthFilterHip df2(ctx, dfo);
+    df2.prepareUpdateSeeds({ kf2 }, cur);
+    cur->T_f_w_ = T_final;                    // the pose optimiser has written its result
+    df2.updateSeedsAsync({ kf2 }, cur);
+    const size_t n2 = df2.finishUpdateSeeds();
+    CHECK(n2 == n_updated);
+    CHECK(kf2->type_vec_ == kf->type_vec_);
+    CHECK(kf2->invmu_sigma2_a_b_vec_ == kf->invmu_sigma2_a_b_vec_);   // bit for bit: the same kernel on the same inputs
+    CHECK(df2.lastMatchResults() == depth_filter.lastMatchResults());
+    // a prepared update that is never given its pose updates nothing
+    FramePtr kf3(new Frame);
+    *kf3 = *kf;
+    kf3->invmu_sigma2_a_b_vec_ = state; kf3->type_vec_ = type;
+    {
+      DepthFilterHip df3(ctx, dfo);
+      df3.prepareUpdateSeeds({ kf3 }, cur);
+      CHECK(df3.finishUpdateSeeds() == 0);
+    }
+    CHECK(kf3->invmu_sigma2_a_b_vec_ == state && kf3->type_vec_ == type);
+    kf2->pyramid = 0; kf3->pyramid = 0;       // the handle belongs to kf
+    printf("seeds: the update queued ahead of its pose equals the one-call update\n");
+  }
+
   // ---- alignPyr2DVec ----
   std::vector<Point2f> pr(nt), pc(nt);
   for (int i = 0; i < nt; ++i) { pr[i] = { (float)trk_ref[2 * i], (float)trk_ref[2 * i + 1] }; pc[i] = { (float)trk_cur[2 * i], (float)trk_cur[2 * i + 1] }; }

@@ -97,6 +97,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
     // all streams start their first frame together
     start_gate->fetch_add(1);
     while (start_gate->load() < n_streams) std::this_thread::yield();
+    const bool no_prepare = getenv("SVOH_MINI_NO_PREPARE") != nullptr;   // A/B switch: the seed update staged after the pose optimisation, as before
     const double wall0 = now_ms();
     double sum_ms = 0;
     size_t n_done = 0;
@@ -168,7 +169,12 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
         n_reproj = frame->num_features_;
         t3 = now_ms();
         // 3. pose optimisation (frame_handler_base.cpp:746-790)
-        if (frame->num_features_ >= 10) n_pose = pose_optimizer.run(b_cur, 2.0);
+        // (default flow: while the pose kernel runs, the depth filter's update of this frame is staged and uploaded --
+        // it needs the optimised pose only as the last word before its kernel goes off)
+        if (frame->num_features_ >= 10) {
+          if (sync_flow || no_prepare) n_pose = pose_optimizer.run(b_cur, 2.0);
+          else n_pose = pose_optimizer.run(b_cur, 2.0, [&]() { depth_filter.prepareUpdateSeeds(visible, frame); });
+        }
         t4 = now_ms();
         // 4. depth filter (frame_handler_mono.cpp:125)
         depth_filter.updateSeedsAsync(visible, frame);
