@@ -1508,7 +1508,8 @@ struct SpeculativeMatches {
     const double tr0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
     if (direct.size()) {
       const size_t m = direct.size();
-      direct.result.assign(m, 0); direct.search_level.assign(m, 0); direct.f_cur.assign(3 * m, 0.0); direct.A.assign(4 * m, 0.0);
+      // (outputs: svoh_matcher_collect writes every entry of each -- no fill needed)
+      direct.result.resize(m); direct.search_level.resize(m); direct.f_cur.resize(3 * m); direct.A.resize(4 * m);
       fbd = batch_of(direct);
       const int rc = svoh_match_direct_batch(ctx, &mopt, static_cast<int>(views.size()), views.data(), &cur, &fbd,
                                              direct.depth.data(), direct.px_cur.data(), direct.result.data(),
@@ -1518,8 +1519,8 @@ struct SpeculativeMatches {
     const double tr1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
     if (seeds.size()) {
       const size_t m = seeds.size();
-      seeds.result.assign(m, 0); seeds.search_level.assign(m, 0); seeds.success.assign(m, 0);
-      seeds.px_cur.assign(2 * m, 0.0); seeds.f_cur.assign(3 * m, 0.0); seeds.A.assign(4 * m, 0.0);
+      seeds.result.resize(m); seeds.search_level.resize(m); seeds.success.resize(m);
+      seeds.px_cur.resize(2 * m); seeds.f_cur.resize(3 * m); seeds.A.resize(4 * m);
       fbs = batch_of(seeds);
       svoh_depth_filter_options o{};
       o.seed_convergence_sigma2_thresh = seed_sigma2_thresh;      // updateSeed(..., seed_sigma2_thresh, false, false):
