@@ -350,6 +350,7 @@ def load(path=None):
     lib.svoh_matcher_begin_deferred.argtypes = [C.c_void_p]
     lib.svoh_matcher_collect.argtypes = [C.c_void_p]
     lib.svoh_matcher_flush.argtypes = [C.c_void_p]
+    lib.svoh_matcher_deferred_set_cur_frame.argtypes = [C.c_void_p, P(svoh_frame_view)]
     lib.svoh_sparse_align_batch.argtypes = [C.c_void_p, P(svoh_align_options), C.c_int,
                                             P(svoh_align_problem), P(svoh_align_result)]
     lib.svoh_sparse_align_enqueue.argtypes = [C.c_void_p, P(svoh_align_options), C.c_int,

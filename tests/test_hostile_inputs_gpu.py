@@ -365,3 +365,43 @@ def test_fetch_and_kernel_time_never_hand_out_an_older_launch(gpu_ctx):
     assert list(again.iters) == list(first.iters)
     gpu_ctx.sparse_align(opt, pbs)
     assert lib.svoh_sparse_align_last_kernel_ms(h, C.byref(ms)) == 0
+
+
+def test_deferred_seed_batch_takes_its_frame_pose_late(gpu_ctx):
+    """svoh_matcher_deferred_set_cur_frame (round 4): a seed batch queued in a deferred section at a WRONG pose of the
+    current frame, the view replaced before the flush -- the results are those of the blocking call at the right pose, bit
+    for bit.  Misuse is refused: no section, no queued seed batch, another frame, after the batch has been sent off."""
+    import ctypes as C
+    lib, h = gpu_ctx.lib, gpu_ctx.h
+    lib.svoh_matcher_deferred_set_cur_frame.argtypes = [C.c_void_p, C.POINTER(capi.svoh_frame_view)]
+    sc = synth.make_align_scene(411, n_features=8, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))
+    fr, fc = gpu_ctx.build_pyramid(sc.img_ref, 5), gpu_ctx.build_pyramid(sc.img_cur, 5)
+    sd = synth.make_seed_set(sc, 700)
+    rv = fe.make_frame_view(fr, sc.cam, sc.T_ref_f_w, float(sd["mu_range"]), 1)
+    cv = fe.make_frame_view(fc, sc.cam, sc.T_cur_f_w_gt, 0.0, 2)
+    off = synth.SE3(sc.T_cur_f_w_gt.q, np.array(sc.T_cur_f_w_gt.t) + [0.4, -0.1, 0.3])
+    cv_wrong = fe.make_frame_view(fc, sc.cam, off, 0.0, 2)
+    other = fe.make_frame_view(fr, sc.cam, sc.T_cur_f_w_gt, 0.0, 2)      # another frame handle
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(sc.cam)
+    fbs, ks = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+    want = gpu_ctx.update_seeds_batch(mopt, dopt, [rv], cv, fbs, sd["state"])
+    wrong = gpu_ctx.update_seeds_batch(mopt, dopt, [rv], cv_wrong, fbs, sd["state"])
+    assert not np.array_equal(want[1], wrong[1])                          # the pose matters
+    n = fbs.n
+    rva = (capi.svoh_frame_view * 1)(rv)
+    assert lib.svoh_matcher_deferred_set_cur_frame(h, C.byref(cv)) != 0   # no section
+    assert lib.svoh_matcher_begin_deferred(h) == 0
+    st = np.ascontiguousarray(sd["state"], np.float64).copy()
+    succ, mr, ns = np.zeros(n, np.uint8), np.zeros(n, np.int32), C.c_int32()
+    try:
+        assert lib.svoh_matcher_deferred_set_cur_frame(h, C.byref(cv)) != 0   # no seed batch queued yet
+        assert lib.svoh_update_seeds_batch(h, C.byref(mopt), C.byref(dopt), 1, rva, C.byref(cv_wrong), C.byref(fbs), st.ctypes.data,
+                                           succ.ctypes.data, mr.ctypes.data, C.byref(ns)) == 0
+        assert lib.svoh_matcher_deferred_set_cur_frame(h, None) != 0
+        assert lib.svoh_matcher_deferred_set_cur_frame(h, C.byref(other)) != 0   # not the batch's current frame
+        assert lib.svoh_matcher_deferred_set_cur_frame(h, C.byref(cv)) == 0
+        assert lib.svoh_matcher_flush(h) == 0
+        assert lib.svoh_matcher_deferred_set_cur_frame(h, C.byref(cv_wrong)) != 0   # sent off already
+    finally:
+        assert lib.svoh_matcher_collect(h) == 0
+    assert ns.value == want[0] and np.array_equal(st, want[1]) and np.array_equal(succ, want[2]) and np.array_equal(mr, want[3])
