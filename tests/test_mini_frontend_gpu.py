@@ -119,7 +119,7 @@ def test_pipelined_flow_equals_the_blocking_flow(tmp_path):
     the blocking flow (SVOH_MINI_SYNC=1: the reference's order, host-side candidate projection), byte for byte."""
     cmd, out_dir, poses, stamps, n_frames = make_dataset(tmp_path)
     runs = {}
-    for name, env in (("pipelined", {}), ("blocking", {"SVOH_MINI_SYNC": "1"})):
+    for name, env in (("pipelined", {}), ("blocking", {"SVOH_MINI_SYNC": "1"}), ("pipelined + prepared seed update", {"SVOH_MINI_PREPARE": "1"})):
         e = dict(os.environ); e.update(env)
         r = subprocess.run(cmd, capture_output=True, text=True, env=e)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -128,5 +128,8 @@ def test_pipelined_flow_equals_the_blocking_flow(tmp_path):
         print(name, r.stdout.strip())
     assert runs["pipelined"][0] == runs["blocking"][0]
     assert np.array_equal(runs["pipelined"][1], runs["blocking"][1])
+    # SVOH_MINI_PREPARE=1: the seed update queued while the pose kernel runs, its frame's pose handed over afterwards
+    assert runs["pipelined + prepared seed update"][0] == runs["blocking"][0]
+    assert np.array_equal(runs["pipelined + prepared seed update"][1], runs["blocking"][1])
     print("steady-state ms/frame: pipelined mean %.3f median %.3f, blocking mean %.3f median %.3f" %
           (runs["pipelined"][2].mean(), np.median(runs["pipelined"][2]), runs["blocking"][2].mean(), np.median(runs["blocking"][2])))

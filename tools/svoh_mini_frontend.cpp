@@ -97,7 +97,10 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
     // all streams start their first frame together
     start_gate->fetch_add(1);
     while (start_gate->load() < n_streams) std::this_thread::yield();
-    const bool no_prepare = getenv("SVOH_MINI_NO_PREPARE") != nullptr;   // A/B switch: the seed update staged after the pose optimisation, as before
+    // SVOH_MINI_PREPARE=1: the seed update is staged and uploaded while the pose kernel runs (PoseOptimizerHip::run's hook +
+    // DepthFilterHip::prepareUpdateSeeds).  Off by default: worth 5 - 8 us to ONE stream, but eight streams on one GPU lose a
+    // quarter of their total frame rate with it (measured: ~4 600 against ~6 300 frames/s; the hook's wait is an event wait).
+    const bool no_prepare = getenv("SVOH_MINI_PREPARE") == nullptr;
     const double wall0 = now_ms();
     double sum_ms = 0;
     size_t n_done = 0;
