@@ -48,7 +48,16 @@ typedef enum svoh_status {
   SVOH_ERR_NO_DEVICE = -6
 } svoh_status;
 
-typedef enum svoh_mem_space { SVOH_MEM_HOST = 0, SVOH_MEM_DEVICE = 1 } svoh_mem_space;
+typedef enum svoh_mem_space {
+  SVOH_MEM_HOST = 0,
+  SVOH_MEM_DEVICE = 1,
+  /* svoh_feature_batch only: the arrays are the context's own page-locked staging block, handed out by svoh_matcher_stage
+   * and filled in place by the caller (by several host threads at once, if it likes): nothing is copied on the host,
+   * neither on the way in nor on the way out */
+  SVOH_MEM_STAGED = 2,
+  /* images only (svoh_build_pyramid_multi): page-locked host memory of svoh_host_alloc, read by the device directly */
+  SVOH_MEM_HOST_PINNED = 3
+} svoh_mem_space;
 
 typedef struct svoh_ctx svoh_ctx; /* opaque */
 typedef uint64_t svoh_frame_t;    /* 0 is never a valid handle */
@@ -136,6 +145,18 @@ int svoh_build_pyramid_batch(svoh_ctx* ctx, const uint8_t* img, size_t image_str
                              int n_images, int width, int height, int pitch,
                              int mem_space, int n_levels, int rounding,
                              svoh_frame_t* out_frames);
+
+/* Page-locked host memory (hipHostMalloc): what a camera driver's image buffers should be when many streams feed one
+ * GPU -- svoh_build_pyramid_multi reads such images over PCIe by itself, with no staging copy on the host. */
+int svoh_host_alloc(svoh_ctx* ctx, size_t bytes, void** out);
+int svoh_host_free(svoh_ctx* ctx, void* p);
+
+/* svoh_build_pyramid_batch for images that live at separate addresses (one per camera stream): imgs[i] = level 0 of
+ * image i, all of one size and pitch.  mem_space: SVOH_MEM_HOST (pageable: one copy call per image), SVOH_MEM_HOST_PINNED
+ * (memory of svoh_host_alloc: ONE gather kernel reads all images, at most 256 per call), SVOH_MEM_DEVICE.  The frames
+ * share one device allocation, which lives until the last of them is released. */
+int svoh_build_pyramid_multi(svoh_ctx* ctx, const uint8_t* const* imgs, int n_images, int width, int height, int pitch,
+                             int mem_space, int n_levels, int rounding, svoh_frame_t* out_frames);
 
 /* Copy one level of a device frame back to the host (tightly packed). */
 int svoh_download_level(svoh_ctx* ctx, svoh_frame_t frame, int level,
@@ -270,6 +291,20 @@ int svoh_sparse_align_batch(svoh_ctx* ctx, const svoh_align_options* options,
 int svoh_sparse_align_enqueue(svoh_ctx* ctx, const svoh_align_options* options,
                               int n_problems, const svoh_align_problem* problems);
 int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* results);
+
+/* Launch geometry as a function of the PROBLEM instead of the launch.  svoh_sparse_align_enqueue picks workgroup size,
+ * lanes per patch and workgroups per problem from what the whole launch looks like; the choices differ in the order of
+ * their sums (poses agree to 1e-15, iteration counts are the same), so a problem's result bits depend on what else is in
+ * its launch.  A host that runs many independent camera streams in lock step and wants every stream to reproduce its
+ * single-stream run bit for bit asks, per problem, for the key of the geometry a launch of THAT problem alone gets, and
+ * launches the problems of equal key together: _enqueue_keyed runs every problem in exactly that geometry whatever
+ * n_problems is (it may go out as several launches; results queue up in problem order -- collect them with
+ * svoh_sparse_align_fetch_all, in the order of the enqueue calls).  Keys are only meaningful to the context (and knob
+ * settings) that made them. */
+int svoh_sparse_align_geometry_key(svoh_ctx* ctx, const svoh_align_options* options, const svoh_align_problem* problem,
+                                   int32_t* key);
+int svoh_sparse_align_enqueue_keyed(svoh_ctx* ctx, const svoh_align_options* options, int n_problems,
+                                    const svoh_align_problem* problems, int32_t key);
 /* The results of EVERY launch queued since the last fetch / fetch_all, in launch
  * order; n_results must be their total number.  At most 2^18 results may be
  * queued (enqueue fails beyond that: fetch first). */
@@ -525,7 +560,8 @@ int svoh_matcher_deferred_set_cur_frame(svoh_ctx* ctx, const svoh_frame_view* cu
  * (host/svo_hip_host.cpp: ReprojectorHip).
  *
  * The enqueue form does not synchronise.  With align_result_index >= 0 the current frame's pose is composed ON THE
- * DEVICE from result #align_result_index of the alignment launch queued just before (svoh_sparse_align_enqueue):
+ * DEVICE from result #align_result_index of the alignment results queued since the last fetch (svoh_sparse_align_enqueue
+ * / _enqueue_keyed; the numbering of svoh_sparse_align_fetch_all -- for the usual single launch, the problem's index):
  *   T_f_w = T_cam_imu (first pose argument) * T_icur_iref (alignment result) * T_imu_world_ref
  * (sparse_img_align.cpp:100-107), so that one svoh_sparse_align_fetch delivers the pose AND the candidates of the
  * frame: the candidate projection costs no round trip of its own.  With align_result_index < 0 the first pose argument
@@ -540,6 +576,56 @@ int svoh_project_candidates_collect(svoh_ctx* ctx, int n, double* px, uint8_t* v
 int svoh_project_candidates(svoh_ctx* ctx, const svoh_camera* cam, const svoh_se3* T_f_w, int n_kf,
                             const svoh_se3* T_world_kf, int n, const uint8_t* kind, const int32_t* kf, const double* v,
                             const double* mu, double* px, uint8_t* visible);
+
+/* The candidate projections of MANY current frames (camera streams in lock step) in one launch, staged in place:
+ * _stage sizes the context's page-locked block for n_jobs jobs, n_kf_total keyframe poses and n_points_total points and
+ * hands out its arrays; the caller fills them (job j owns keyframe poses [kf_begin, kf_begin + n_kf) and points
+ * [point_begin, point_begin + n_points); job[i] = the job of point i; kf[i] counts from the job's kf_begin) -- several host
+ * threads may fill disjoint parts at once --, _enqueue_staged uploads and launches without a wait, _wait blocks until the
+ * results stand in out->px / out->visible (valid until the next _stage).  Arithmetic, per point, is that of
+ * svoh_project_candidates_enqueue.  Not to be mixed with a queued svoh_project_candidates_enqueue call. */
+typedef struct svoh_candidate_job {
+  svoh_camera cam;
+  svoh_se3 T_f_w_or_T_cam_imu;      /* as the first pose argument of svoh_project_candidates_enqueue */
+  svoh_se3 T_imu_world_ref;         /* read when align_result_index >= 0 */
+  int32_t align_result_index;       /* < 0: the first pose is T_f_w itself */
+  int32_t kf_begin, n_kf;
+  int32_t point_begin, n_points;
+  int32_t reserved;
+} svoh_candidate_job;
+typedef struct svoh_candidate_stage_t {
+  svoh_candidate_job* jobs;         /* n_jobs */
+  svoh_se3* T_world_kf;             /* n_kf_total */
+  int32_t* job;                     /* n_points_total */
+  uint8_t* kind;                    /* n_points_total */
+  int32_t* kf;                      /* n_points_total */
+  double* v;                        /* 3 x n_points_total */
+  double* mu;                       /* n_points_total */
+  double* px;                       /* out: 2 x n_points_total */
+  uint8_t* visible;                 /* out: n_points_total */
+} svoh_candidate_stage_t;
+int svoh_project_candidates_stage(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_points_total, svoh_candidate_stage_t* out);
+int svoh_project_candidates_enqueue_staged(svoh_ctx* ctx);
+int svoh_project_candidates_wait(svoh_ctx* ctx);
+
+/* A matcher batch staged in place (svoh_feature_batch.mem_space = SVOH_MEM_STAGED).  Inside an open deferred section:
+ * _stage sizes the page-locked block of the section's direct (seeds = 0) or seed (seeds = 1) batch for n units and up to
+ * max_frame_views reference + current frames and hands out every array of the batch; the caller fills the inputs in
+ * place and then makes the usual call -- svoh_match_direct_batch / svoh_update_seeds_batch_ex -- with exactly these
+ * pointers (feature arrays, depth / px_cur resp. state, and the outputs it wants: the others NULL).  The call copies
+ * nothing; after svoh_matcher_collect the outputs stand where they were handed out (until the next _stage of that
+ * kind).  cur_frame_idx is always present (n_cur_frames >= 1 current frames); index checks are the kernels' (a bad index
+ * marks the unit SVOH_MATCH_NOT_RUN).  With want_match_outputs == 0 a seed batch has no px_cur / f_cur / search_level /
+ * A_cur_ref arrays (NULL here) and brings back type, state, result and success only. */
+typedef struct svoh_matcher_stage_t {
+  int32_t* ref_frame_idx;  int32_t* cur_frame_idx;
+  double* px;  double* f;  double* grad;  int32_t* level;  uint8_t* type;
+  double* depth;           /* direct: in */
+  double* px_cur;          /* direct: in / out; seeds: out */
+  double* state;           /* seeds: in / out */
+  int32_t* result;  uint8_t* success;  double* f_cur;  int32_t* search_level;  double* h_inv;  double* A_cur_ref;
+} svoh_matcher_stage_t;
+int svoh_matcher_stage(svoh_ctx* ctx, int seeds, int n, int max_frame_views, int want_match_outputs, svoh_matcher_stage_t* out);
 
 /* DepthFilterOptions used by updateSeed (src/svo_direct/include/svo/direct/depth_filter.h:40-100) */
 typedef struct svoh_depth_filter_options {
@@ -653,6 +739,20 @@ int svoh_detect_features(svoh_ctx* ctx, svoh_frame_t frame, const svoh_detector_
                          const uint8_t* occupancy, const uint8_t* mask, int mask_pitch, int max_n_features,
                          double* px, double* score, int32_t* level, double* grad, uint8_t* type,
                          int32_t* n_features);
+
+/* The detector for MANY frames of one size in one round trip, in two halves.  svoh_detect_cells_batch is the device
+ * half: for every frame and grid cell the best corner (key: score << 32 | ~(level, y, x), as fd_utils::fastDetector's
+ * per-cell best, 0 = none above threshold_primary) and, in the cells that neither `occupancy` nor a corner takes, the
+ * best edgelet (key: float bits of the magnitude << 32 | ~(y, x) on level 1) with its histogram angle.  occupancy: n_frames
+ * x n_cells bytes or NULL; the three outputs n_frames x n_cells each (host).  No mask (a masked-out corner would have to
+ * free its cell between the two phases).  svoh_detect_fill_features is the host half, fd_utils::fillFeatures for corners
+ * then edgelets of ONE frame from its n_cells entries of each array: pure host code without a context, callable from
+ * any thread.  Both halves together give exactly svoh_detect_features' features (mask == NULL). */
+int svoh_detect_cells_batch(svoh_ctx* ctx, int n_frames, const svoh_frame_t* frames, const svoh_detector_options* options,
+                            const uint8_t* occupancy, uint64_t* corner_keys, uint64_t* edge_keys, float* edge_angles);
+int svoh_detect_fill_features(const svoh_detector_options* options, int width, int height, const uint64_t* corner_keys,
+                              const uint64_t* edge_keys, const float* edge_angles, int max_n_features, double* px,
+                              double* score, int32_t* level, double* grad, uint8_t* type, int32_t* n_features);
 
 /* ---- pose optimiser ----------------------------------- */
 

@@ -274,6 +274,11 @@ EXPORTS = [
     "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex", "svoh_epipolar_match_batch",
     "svoh_project_candidates_enqueue", "svoh_project_candidates_collect", "svoh_project_candidates",
     "svoh_detect_features", "svoh_optimize_pose_batch", "svoh_optimize_pose_batch_packed", "svoh_optimize_points_batch",
+    # round 5: what the lock-step front end of many camera streams stages in place and launches once per stage
+    "svoh_host_alloc", "svoh_host_free", "svoh_build_pyramid_multi",
+    "svoh_sparse_align_geometry_key", "svoh_sparse_align_enqueue_keyed",
+    "svoh_project_candidates_stage", "svoh_project_candidates_enqueue_staged", "svoh_project_candidates_wait",
+    "svoh_matcher_stage", "svoh_detect_cells_batch", "svoh_detect_fill_features",
 ]
 
 

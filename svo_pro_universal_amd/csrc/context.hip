@@ -318,6 +318,32 @@ static bool step_rule(int rounding, int in_w, int in_h, bool* writes_all)
   return sse;
 }
 
+// Level 0 of up to 256 images that live at separate page-locked host addresses (one per camera stream) into the frames
+// of one slab: ONE launch reads them all over PCIe, 16 bytes per lane, instead of one copy call per image.
+struct GatherArgs {
+  uint8_t* base;            // level 0 of frame 0
+  size_t frame_stride;
+  int width, height, pitch; // source geometry
+  const uint8_t* src[256];
+};
+__global__ __launch_bounds__(256) void gather_images_kernel(const GatherArgs a)
+{
+  const uint8_t* src = a.src[blockIdx.y];
+  uint8_t* dst = a.base + (size_t)blockIdx.y * a.frame_stride;
+  const size_t n = (size_t)a.width * a.height;
+  if (a.pitch == a.width && !(reinterpret_cast<uintptr_t>(src) & 15) && !(reinterpret_cast<uintptr_t>(dst) & 15)) {
+    const size_t n16 = n / 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+      reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (size_t i = n16 * 16 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+      const size_t y = i / (size_t)a.width, x = i - y * (size_t)a.width;
+      dst[i] = src[y * (size_t)a.pitch + x];
+    }
+  }
+}
+
 // a slab of `bytes` (+ tail padding): from the context's pool of released slabs when one of that size is there
 static hipError_t make_slab(svoh_ctx* ctx, size_t bytes, std::shared_ptr<Slab>* out)
 {
@@ -392,6 +418,9 @@ void load_knobs_from_env(SvohKnobs& k)
   k.kernel_timing = get("SVOH_KERNEL_TIMING");
   k.copy_kernel = get("SVOH_COPY_KERNEL");
 }
+
+static int build_pyramid_levels(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab, uint8_t* base, size_t fbytes, const size_t* offs, const int* ws,
+                                const int* hs, int n_images, int width, int height, int n_levels, int rounding, svoh_frame_t* out_frames);
 
 extern "C" {
 
@@ -558,6 +587,14 @@ try {
       SVOH_HIP_TRY(ctx, hipMemcpy2DAsync(base + fbytes * i, (size_t)width, img + image_stride * i, (size_t)pitch,
                                          (size_t)width, (size_t)height, kind, ctx->stream));
   }
+  const int rc_levels = build_pyramid_levels(ctx, slab, base, fbytes, offs, ws, hs, n_images, width, height, n_levels, rounding, out_frames);
+  return rc_levels;
+} SVOH_ABI_CATCH(ctx)
+
+// levels 1.. of n_images frames whose level 0 is in place (queued on the context's stream), and the frames' handles
+static int build_pyramid_levels(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab, uint8_t* base, size_t fbytes, const size_t* offs, const int* ws,
+                                const int* hs, int n_images, int width, int height, int n_levels, int rounding, svoh_frame_t* out_frames)
+{
   int first_single = 1;   // levels from here on are made one launch each
   {
     // the first 2..4 steps as one launch when every one of them writes its whole level
@@ -585,6 +622,59 @@ try {
   }
   for (int i = 0; i < n_images; ++i)
     out_frames[i] = register_frame(ctx, slab, base + fbytes * i, width, height, n_levels);
+  return SVOH_OK;
+}
+
+int svoh_build_pyramid_multi(svoh_ctx* ctx, const uint8_t* const* imgs, int n_images, int width, int height, int pitch,
+                             int mem_space, int n_levels, int rounding, svoh_frame_t* out_frames)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, imgs && out_frames, "NULL argument");
+  SVOH_REQUIRE(ctx, n_images >= 1 && width > 0 && height > 0 && pitch >= width, "bad image geometry");
+  SVOH_REQUIRE(ctx, n_levels >= 1 && n_levels <= SVOH_MAX_LEVELS, "n_levels out of range");
+  SVOH_REQUIRE(ctx, rounding >= 0 && rounding <= 2, "bad rounding mode");
+  SVOH_REQUIRE(ctx, (width >> (n_levels - 1)) > 0 && (height >> (n_levels - 1)) > 0, "too many levels");
+  SVOH_REQUIRE(ctx, mem_space == SVOH_MEM_HOST || mem_space == SVOH_MEM_DEVICE || mem_space == SVOH_MEM_HOST_PINNED, "bad mem_space");
+  SVOH_REQUIRE(ctx, mem_space != SVOH_MEM_HOST_PINNED || n_images <= 256, "at most 256 page-locked images per call");
+  for (int i = 0; i < n_images; ++i) SVOH_REQUIRE(ctx, imgs[i] != nullptr, "NULL image");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t offs[SVOH_MAX_LEVELS]; int ws[SVOH_MAX_LEVELS], hs[SVOH_MAX_LEVELS];
+  const size_t fbytes = frame_layout(width, height, n_levels, offs, ws, hs);
+  std::shared_ptr<Slab> slab;
+  SVOH_HIP_TRY(ctx, make_slab(ctx, fbytes * (size_t)n_images, &slab));
+  uint8_t* base = static_cast<uint8_t*>(slab->ptr);
+  if (mem_space == SVOH_MEM_HOST_PINNED) {
+    GatherArgs ga;
+    ga.base = base; ga.frame_stride = fbytes; ga.width = width; ga.height = height; ga.pitch = pitch;
+    for (int i = 0; i < n_images; ++i) ga.src[i] = imgs[i];
+    for (int i = n_images; i < 256; ++i) ga.src[i] = nullptr;
+    // enough loads in flight to fill the link: 16 workgroups of 256 x 16 bytes per image
+    hipLaunchKernelGGL(gather_images_kernel, dim3(16, (unsigned)n_images), dim3(256), 0, ctx->stream, ga);
+    SVOH_HIP_TRY(ctx, hipGetLastError());
+  } else {
+    const hipMemcpyKind kind = mem_space == SVOH_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    for (int i = 0; i < n_images; ++i)
+      SVOH_HIP_TRY(ctx, hipMemcpy2DAsync(base + fbytes * i, (size_t)width, imgs[i], (size_t)pitch, (size_t)width, (size_t)height, kind, ctx->stream));
+  }
+  return build_pyramid_levels(ctx, slab, base, fbytes, offs, ws, hs, n_images, width, height, n_levels, rounding, out_frames);
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_host_alloc(svoh_ctx* ctx, size_t bytes, void** out)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, out && bytes > 0, "bad arguments");
+  *out = nullptr;
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SVOH_HIP_TRY(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_host_free(svoh_ctx* ctx, void* p)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!p) return SVOH_OK;
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SVOH_HIP_TRY(ctx, hipHostFree(p));   // (waits for work that may still read the block)
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
@@ -646,7 +736,7 @@ try {
   for (const auto& kv : slabs) fb += kv.second;
   out->frame_bytes = (int64_t)fb;
   const svoh::DevBuffer* bufs[] = { &ctx->d_desc, &ctx->d_results, &ctx->d_feat, &ctx->d_eval, &ctx->d_xchg, &ctx->d_split,
-                                    &ctx->d_counters, &ctx->d_unit_counts, &ctx->d_scratch0, &ctx->d_scratch1, &ctx->d_scratch2, &ctx->d_seed_bin, &ctx->d_match_seeds, &ctx->d_match_direct, &ctx->d_cand };
+                                    &ctx->d_counters, &ctx->d_unit_counts, &ctx->d_scratch0, &ctx->d_scratch1, &ctx->d_scratch2, &ctx->d_seed_bin, &ctx->d_match_seeds, &ctx->d_match_direct, &ctx->d_cand, &ctx->d_cand_multi };
   size_t wb = 0;
   for (const svoh::DevBuffer* b : bufs) wb += b->cap;
   out->workspace_bytes = (int64_t)wb;

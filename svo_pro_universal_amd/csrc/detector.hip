@@ -34,7 +34,7 @@ __device__ __constant__ int kCircleDy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3,
 // ---- FAST-10 score map (fast_10_score.cpp:21-3148 by its fixed point) ----
 // score(x, y) = max over the 16 arcs of 10 contiguous circle pixels of min(p_i - c) resp. min(c - p_i), minus 1;
 // stored as u8 when >= barrier (>= 1), else 0.
-__global__ __launch_bounds__(256) void fast_score_kernel(DevImage im, int barrier, uint8_t* __restrict__ S)
+__device__ __forceinline__ void fast_score_body(const DevImage& im, int barrier, uint8_t* __restrict__ S)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -67,6 +67,12 @@ __global__ __launch_bounds__(256) void fast_score_kernel(DevImage im, int barrie
   }
   S[(size_t)y * im.w + x] = (uint8_t)out;
 }
+__global__ __launch_bounds__(256) void fast_score_kernel(DevImage im, int barrier, uint8_t* __restrict__ S) { fast_score_body(im, barrier, S); }
+// the same for frame blockIdx.z of a batch: ims[z] is the frame's level, its map starts z * map_stride bytes into S
+__global__ __launch_bounds__(256) void fast_score_batch_kernel(const DevImage* __restrict__ ims, int barrier, uint8_t* __restrict__ S, size_t map_stride)
+{
+  fast_score_body(ims[blockIdx.z], barrier, S + (size_t)blockIdx.z * map_stride);
+}
 
 struct GridDesc {
   int cell_size, n_cols, n_rows;
@@ -82,8 +88,8 @@ __device__ __forceinline__ int cell_index(const GridDesc& g, int x, int y, int s
 }
 
 // ---- fast_nonmax_3x3 + border + per-cell best (feature_detection_utils.cpp:176-192) ----
-__global__ __launch_bounds__(256) void fast_select_kernel(const uint8_t* __restrict__ S, int w, int h, int level, int border,
-                                                          float init_score, GridDesc g)
+__device__ __forceinline__ void fast_select_body(const uint8_t* __restrict__ S, int w, int h, int level, int border,
+                                                 float init_score, const GridDesc& g)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -101,6 +107,19 @@ __global__ __launch_bounds__(256) void fast_select_kernel(const uint8_t* __restr
   const unsigned long long key = ((unsigned long long)(unsigned)s << 32) | (unsigned long long)(0xFFFFFFFFu - order);
   atomicMax(g.keys + k, key);
 }
+__global__ __launch_bounds__(256) void fast_select_kernel(const uint8_t* __restrict__ S, int w, int h, int level, int border,
+                                                          float init_score, GridDesc g)
+{
+  fast_select_body(S, w, h, level, border, init_score, g);
+}
+// frame blockIdx.z of a batch (all frames of one size): its map, its occupancy bytes and its keys lie z strides on
+__global__ __launch_bounds__(256) void fast_select_batch_kernel(const uint8_t* __restrict__ S, size_t map_stride, int w, int h, int level, int border,
+                                                                float init_score, GridDesc g, size_t cell_stride)
+{
+  g.occupancy += (size_t)blockIdx.z * cell_stride;
+  g.keys += (size_t)blockIdx.z * cell_stride;
+  fast_select_body(S + (size_t)blockIdx.z * map_stride, w, h, level, border, init_score, g);
+}
 
 // ---- edgelets: GaussianBlur 3x3 + Scharr + magnitude (feature_detection_utils.cpp:326-346) ----
 __device__ __forceinline__ int reflect101(int i, int n)
@@ -110,7 +129,7 @@ __device__ __forceinline__ int reflect101(int i, int n)
   return i;
 }
 
-__global__ __launch_bounds__(256) void edge_score_kernel(DevImage im, int border, int threshold, float* __restrict__ E)
+__device__ __forceinline__ void edge_score_body(const DevImage& im, int border, int threshold, float* __restrict__ E)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -144,16 +163,24 @@ __global__ __launch_bounds__(256) void edge_score_kernel(DevImage im, int border
   }
   E[(size_t)y * im.w + x] = out;
 }
+__global__ __launch_bounds__(256) void edge_score_kernel(DevImage im, int border, int threshold, float* __restrict__ E) { edge_score_body(im, border, threshold, E); }
+__global__ __launch_bounds__(256) void edge_score_batch_kernel(const DevImage* __restrict__ ims, int border, int threshold, float* __restrict__ E, size_t map_stride_floats)
+{
+  edge_score_body(ims[blockIdx.z], border, threshold, E + (size_t)blockIdx.z * map_stride_floats);
+}
 
 // 8-neighbour non-maximum suppression with the reference's asymmetric comparisons + per-cell best (:349-383)
-__global__ __launch_bounds__(256) void edge_select_kernel(const float* __restrict__ E, int w, int h, int border, int threshold,
-                                                          float init_score, GridDesc g)
+// corner_keys != NULL: a cell that holds a corner (a non-zero key) counts as occupied too -- what the occupancy grid says
+// after fd_utils::fillFeatures has marked the corners' cells (svoh_detect_cells_batch: both phases without the host in between)
+__device__ __forceinline__ void edge_select_body(const float* __restrict__ E, int w, int h, int border, int threshold,
+                                                 float init_score, const GridDesc& g, const unsigned long long* __restrict__ corner_keys)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x < border || y < border || x >= w - border || y >= h - border) return;
   const int k = cell_index(g, x, y, 2);
   if ((unsigned)k >= (unsigned)(g.n_cols * g.n_rows) || g.occupancy[k]) return;
+  if (corner_keys && corner_keys[k] != 0ull) return;
   const float* p = E + (size_t)y * w + x;
   const float c = *p;
   if (c < (float)threshold) return;
@@ -163,10 +190,23 @@ __global__ __launch_bounds__(256) void edge_select_kernel(const float* __restric
   const unsigned long long key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned long long)(0xFFFFFFFFu - order);
   atomicMax(g.keys + k, key);   // positive floats order like their bit patterns
 }
+__global__ __launch_bounds__(256) void edge_select_kernel(const float* __restrict__ E, int w, int h, int border, int threshold,
+                                                          float init_score, GridDesc g)
+{
+  edge_select_body(E, w, h, border, threshold, init_score, g, nullptr);
+}
+__global__ __launch_bounds__(256) void edge_select_batch_kernel(const float* __restrict__ E, size_t map_stride_floats, int w, int h, int border, int threshold,
+                                                                float init_score, GridDesc g, const unsigned long long* __restrict__ corner_keys, size_t cell_stride)
+{
+  g.occupancy += (size_t)blockIdx.z * cell_stride;
+  g.keys += (size_t)blockIdx.z * cell_stride;
+  edge_select_body(E + (size_t)blockIdx.z * map_stride_floats, w, h, border, threshold, init_score, g, corner_keys + (size_t)blockIdx.z * cell_stride);
+}
 
 // getAngleAtPixelUsingHistogram(img_pyr[1], (x, y), 4) for the winner of every cell (:831-839, 947-1009)
-__global__ __launch_bounds__(64) void edge_angle_kernel(DevImage im, const unsigned long long* __restrict__ keys, int n_cells,
-                                                        float* __restrict__ angle)
+template <bool BATCH>
+__device__ __forceinline__ void edge_angle_body(const DevImage& im, const unsigned long long* __restrict__ keys, int n_cells,
+                                                float* __restrict__ angle)
 {
   constexpr int n_bins = 36;
   __shared__ double s_hist[64][n_bins + 1];
@@ -205,6 +245,16 @@ __global__ __launch_bounds__(64) void edge_angle_kernel(DevImage im, const unsig
   for (int i = 1; i < n_bins; ++i)
     if (hist[i] > max_v) { max_v = hist[i]; max_bin = i; }
   angle[k] = (float)(max_bin * 2.0 * pi / n_bins);
+}
+__global__ __launch_bounds__(64) void edge_angle_kernel(DevImage im, const unsigned long long* __restrict__ keys, int n_cells,
+                                                        float* __restrict__ angle)
+{
+  edge_angle_body<false>(im, keys, n_cells, angle);
+}
+__global__ __launch_bounds__(64) void edge_angle_batch_kernel(const DevImage* __restrict__ ims, const unsigned long long* __restrict__ keys, int n_cells,
+                                                              float* __restrict__ angle, size_t cell_stride)
+{
+  edge_angle_body<true>(ims[blockIdx.y], keys + (size_t)blockIdx.y * cell_stride, n_cells, angle + (size_t)blockIdx.y * cell_stride);
 }
 
 // ---- host side: fd_utils::fillFeatures (feature_detection_utils.cpp:72-143) ----
@@ -366,5 +416,151 @@ try {
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
   *n_features = n;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+// ---- the detector for many frames in one round trip (svoh_detect_cells_batch) and its host half --------------------
+namespace svoh {
+static void decode_cells(const svoh_detector_options& opt, int n_cells, const uint64_t* keys, const float* angles, bool edges, std::vector<HostCorner>& corners)
+{
+  corners.resize((size_t)n_cells);
+  for (int k = 0; k < n_cells; ++k) {
+    HostCorner c{ 0, 0, 0, (float)(edges ? opt.threshold_secondary : opt.threshold_primary), 0.0f };
+    if (keys[k]) {
+      const unsigned order = 0xFFFFFFFFu - (unsigned)(keys[k] & 0xFFFFFFFFull);
+      if (!edges) {
+        const int lv = (int)(order >> 28), y = (int)((order >> 14) & 0x3FFFu), x = (int)(order & 0x3FFFu);
+        c = HostCorner{ x << lv, y << lv, lv, (float)(unsigned)(keys[k] >> 32), 0.0f };
+      } else {
+        const int y = (int)((order >> 14) & 0x3FFFu), x = (int)(order & 0x3FFFu);
+        const unsigned bits = (unsigned)(keys[k] >> 32);
+        float sc;
+        memcpy(&sc, &bits, sizeof sc);
+        c = HostCorner{ x * 2, y * 2, 0, sc, angles[k] };   // level = 1 - 1, coordinates scaled to level 0
+      }
+    }
+    corners[(size_t)k] = c;
+  }
+}
+}  // namespace svoh
+
+extern "C" int svoh_detect_fill_features(const svoh_detector_options* options, int width, int height, const uint64_t* corner_keys,
+                                         const uint64_t* edge_keys, const float* edge_angles, int max_n_features, double* px,
+                                         double* score, int32_t* level, double* grad, uint8_t* type, int32_t* n_features)
+try {
+  if (!options || !corner_keys || !px || !score || !level || !grad || !type || !n_features || width <= 0 || height <= 0 || options->cell_size < 1)
+    return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "svoh_detect_fill_features: bad arguments");
+  *n_features = 0;
+  if (max_n_features <= 0) return SVOH_OK;
+  const svoh_detector_options& opt = *options;
+  const int n_cols = (int)std::ceil((double)width / opt.cell_size), n_rows = (int)std::ceil((double)height / opt.cell_size);
+  const int n_cells = n_cols * n_rows;
+  std::vector<uint8_t> occ((size_t)n_cells, 0);   // (fillFeatures marks the cells it fills; nobody reads them afterwards here)
+  std::vector<HostCorner> corners;
+  decode_cells(opt, n_cells, corner_keys, nullptr, false, corners);
+  int n = fill_features(corners, SVOH_FT_CORNER, nullptr, 0, opt.threshold_primary, max_n_features, 0, opt, n_cols, occ, px, score, level, grad, type);
+  const int max_features = max_n_features - n;
+  if (opt.detect_edgelets && max_features > 0) {
+    if (!edge_keys || !edge_angles) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "svoh_detect_fill_features: edgelets asked for without their arrays");
+    decode_cells(opt, n_cells, edge_keys, edge_angles, true, corners);
+    n = fill_features(corners, SVOH_FT_EDGELET, nullptr, 0, opt.threshold_secondary, max_features, n, opt, n_cols, occ, px, score, level, grad, type);
+  }
+  *n_features = n;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(nullptr)
+
+extern "C" int svoh_detect_cells_batch(svoh_ctx* ctx, int n_frames, const svoh_frame_t* frames, const svoh_detector_options* options,
+                                       const uint8_t* occupancy, uint64_t* corner_keys, uint64_t* edge_keys, float* edge_angles)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, n_frames >= 1 && n_frames <= 4096 && frames && options && corner_keys, "bad arguments");
+  const svoh_detector_options& opt = *options;
+  SVOH_REQUIRE(ctx, opt.cell_size >= 1 && opt.min_level >= 0 && opt.max_level >= opt.min_level && opt.max_level < SVOH_MAX_LEVELS,
+               "bad detector cell size / level range");
+  SVOH_REQUIRE(ctx, opt.border >= 3, "detector border must be >= 3 (FAST circle radius; the reference's default is 8)");
+  SVOH_REQUIRE(ctx, opt.threshold_primary >= 1.0 && opt.threshold_primary <= 254.0, "threshold_primary out of [1, 254]");
+  SVOH_REQUIRE(ctx, !opt.detect_edgelets || (edge_keys && edge_angles), "edgelets asked for without their output arrays");
+  const Frame* f0 = find_frame(ctx, frames[0]);
+  if (!f0) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frames[0]);
+  const int w = f0->lv[0].w, h = f0->lv[0].h;
+  SVOH_REQUIRE(ctx, w < (1 << 14) && h < (1 << 14), "image larger than 16383 pixels a side");
+  SVOH_REQUIRE(ctx, f0->n_levels > opt.max_level, "pyramid has too few levels for the detector");
+  SVOH_REQUIRE(ctx, !opt.detect_edgelets || f0->n_levels > 1, "the edgelet detector works on level 1");
+  std::vector<const Frame*> fr((size_t)n_frames);
+  for (int i = 0; i < n_frames; ++i) {
+    fr[(size_t)i] = find_frame(ctx, frames[i]);
+    if (!fr[(size_t)i]) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frames[i]);
+    SVOH_REQUIRE(ctx, fr[(size_t)i]->lv[0].w == w && fr[(size_t)i]->lv[0].h == h && fr[(size_t)i]->n_levels == f0->n_levels, "the frames of a batch must be of one size");
+  }
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int n_cols = (int)std::ceil((double)w / opt.cell_size), n_rows = (int)std::ceil((double)h / opt.cell_size);
+  const int n_cells = n_cols * n_rows;
+  const size_t nf = (size_t)n_frames;
+  // one stride for the per-cell arrays (occupancy bytes, corner keys, edge keys, angles): element k of frame z at [z * cell_stride + k]
+  const size_t cell_stride = ((size_t)n_cells + 63) & ~(size_t)63;
+  size_t map_bytes = 0;
+  for (int l = opt.min_level; l <= opt.max_level; ++l) map_bytes = std::max(map_bytes, (size_t)f0->lv[l].w * f0->lv[l].h);
+  if (opt.detect_edgelets) map_bytes = std::max(map_bytes, sizeof(float) * (size_t)f0->lv[1].w * f0->lv[1].h);
+  map_bytes = (map_bytes + 255) & ~(size_t)255;
+  const int n_lv = opt.max_level + 1 > 2 ? opt.max_level + 1 : 2;
+  // device: [image table n_lv x n_frames | occupancy | corner keys | edge keys | angles | maps]; the first two travel up, keys and angles come back
+  const size_t o_occ = (sizeof(DevImage) * (size_t)n_lv * nf + 255) & ~(size_t)255;
+  const size_t o_ck = (o_occ + cell_stride * nf + 255) & ~(size_t)255;
+  const size_t o_ek = o_ck + 8 * cell_stride * nf;
+  const size_t o_ang = o_ek + 8 * cell_stride * nf;
+  const size_t o_map = (o_ang + 4 * cell_stride * nf + 255) & ~(size_t)255;
+  SVOH_HIP_TRY(ctx, ctx->d_scratch2.reserve(o_map + map_bytes * nf));
+  SVOH_HIP_TRY(ctx, ctx->h_scratch1.reserve(o_map));
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch2.ptr);
+  uint8_t* hs = static_cast<uint8_t*>(ctx->h_scratch1.ptr);
+  DevImage* tab = reinterpret_cast<DevImage*>(hs);
+  for (int l = 0; l < n_lv; ++l)
+    for (int i = 0; i < n_frames; ++i) tab[(size_t)l * nf + i] = l < fr[(size_t)i]->n_levels ? fr[(size_t)i]->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
+  for (int i = 0; i < n_frames; ++i) {
+    uint8_t* o = hs + o_occ + cell_stride * (size_t)i;
+    if (occupancy) for (int k = 0; k < n_cells; ++k) o[k] = occupancy[(size_t)i * n_cells + k] ? 1 : 0;
+    else memset(o, 0, (size_t)n_cells);
+  }
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, hs, o_ck));
+  SVOH_HIP_TRY(ctx, hipMemsetAsync(d + o_ck, 0, o_ang - o_ck, ctx->stream));
+  const DevImage* d_tab = reinterpret_cast<const DevImage*>(d);
+  GridDesc g;
+  g.cell_size = opt.cell_size; g.n_cols = n_cols; g.n_rows = n_rows;
+  g.occupancy = d + o_occ;
+  g.keys = reinterpret_cast<unsigned long long*>(d + o_ck);
+  auto grid3d = [&](int iw, int ih) { return dim3((unsigned)((iw + 63) / 64), (unsigned)((ih + 3) / 4), (unsigned)n_frames); };
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
+  for (int l = opt.min_level; l <= opt.max_level; ++l) {
+    const DevImage& im = f0->lv[l];
+    if (im.h < 7 || im.w < 7) continue;
+    uint8_t* S = d + o_map;
+    hipLaunchKernelGGL(fast_score_batch_kernel, grid3d(im.w, im.h), dim3(256), 0, ctx->stream, d_tab + (size_t)l * nf, (int)opt.threshold_primary, S, map_bytes);
+    hipLaunchKernelGGL(fast_select_batch_kernel, grid3d(im.w, im.h), dim3(256), 0, ctx->stream, static_cast<const uint8_t*>(S), map_bytes, im.w, im.h, l, opt.border,
+                       (float)opt.threshold_primary, g, cell_stride);
+  }
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  if (opt.detect_edgelets) {
+    const DevImage& im = f0->lv[1];
+    float* E = reinterpret_cast<float*>(d + o_map);
+    GridDesc ge = g;
+    ge.keys = reinterpret_cast<unsigned long long*>(d + o_ek);
+    hipLaunchKernelGGL(edge_score_batch_kernel, grid3d(im.w, im.h), dim3(256), 0, ctx->stream, d_tab + nf, opt.border, (int)opt.threshold_secondary, E, map_bytes / sizeof(float));
+    hipLaunchKernelGGL(edge_select_batch_kernel, grid3d(im.w, im.h), dim3(256), 0, ctx->stream, static_cast<const float*>(E), map_bytes / sizeof(float), im.w, im.h, opt.border,
+                       (int)opt.threshold_secondary, (float)opt.threshold_secondary, ge, static_cast<const unsigned long long*>(g.keys), cell_stride);
+    hipLaunchKernelGGL(edge_angle_batch_kernel, dim3((unsigned)((n_cells + 63) / 64), (unsigned)n_frames), dim3(64), 0, ctx->stream, d_tab + nf,
+                       static_cast<const unsigned long long*>(ge.keys), n_cells, reinterpret_cast<float*>(d + o_ang), cell_stride);
+    SVOH_HIP_TRY(ctx, hipGetLastError());
+  }
+  if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
+  ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
+  SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, hs + o_ck, d + o_ck, (opt.detect_edgelets ? o_map : o_ek) - o_ck));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n_frames; ++i) {
+    memcpy(corner_keys + (size_t)i * n_cells, hs + o_ck + 8 * cell_stride * (size_t)i, 8 * (size_t)n_cells);
+    if (opt.detect_edgelets) {
+      memcpy(edge_keys + (size_t)i * n_cells, hs + o_ek + 8 * cell_stride * (size_t)i, 8 * (size_t)n_cells);
+      memcpy(edge_angles + (size_t)i * n_cells, hs + o_ang + 4 * cell_stride * (size_t)i, 4 * (size_t)n_cells);
+    }
+  }
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)

@@ -2765,6 +2765,77 @@ __global__ void count_success_kernel(const uint8_t* success, int n, int* out)
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+// The kernels of one batch in geometry g8 (0 one lane per unit, 1 eight lanes, 2 packed, 3 one wave per unit), on the
+// context's stream; max_w x max_h = the largest reference frame (bins of the packed seed update).
+static int launch_matcher_kernels(svoh_ctx* ctx, bool seeds, int g8, MatcherArgs& a, int n, int n_ref_frames, int max_w, int max_h)
+{
+  const int units_per_block = g8 == 1 ? 8 : (g8 == 3 ? 1 : 64);
+  const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
+  if (seeds) {
+    if (g8 == 2) {
+      if (max_w < 1) max_w = 1;
+      if (max_h < 1) max_h = 1;
+      const int tiles_x = (max_w + (1 << kBinShiftX) - 1) >> kBinShiftX, tiles_y = (max_h + (1 << kBinShiftY) - 1) >> kBinShiftY;
+      const size_t n_keys = (size_t)n_ref_frames * tiles_x * tiles_y;
+      const SeedRecIn* rec_in = nullptr;
+      SeedRecOut* rec_out = nullptr;
+      const unsigned* pos_of = nullptr;
+      unsigned* hist_ptr = nullptr;
+      unsigned hist_keys = 0;
+      const dim3 gb((unsigned)((n + 255) / 256));
+      if (n_keys <= kBinMaxKeys && SvohKnobs::or_default(ctx->knobs.seed_binning, 1) != 0) {
+        // [hist | rank | pos_of | records in (128 B each) | records out (64 B each)]
+        const size_t o_rank = (n_keys * sizeof(unsigned) + 255) & ~(size_t)255;
+        const size_t o_pos = o_rank + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255);
+        const size_t o_in = o_pos + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255);
+        const size_t o_out = o_in + (size_t)n * sizeof(SeedRecIn);
+        SVOH_HIP_TRY(ctx, ctx->d_seed_bin.reserve(o_out + (size_t)n * sizeof(SeedRecOut)));
+        uint8_t* base = static_cast<uint8_t*>(ctx->d_seed_bin.ptr);
+        unsigned* hist = reinterpret_cast<unsigned*>(base);
+        unsigned* rank = reinterpret_cast<unsigned*>(base + o_rank);
+        unsigned* pos = reinterpret_cast<unsigned*>(base + o_pos);
+        // the histogram is left zeroed by the previous call's last pass unless the block moved or the key count grew
+        if (ctx->seed_hist_ptr != static_cast<void*>(hist) || n_keys > ctx->seed_hist_clean_keys)
+          SVOH_HIP_TRY(ctx, hipMemsetAsync(hist, 0, n_keys * sizeof(unsigned), ctx->stream));
+        ctx->seed_hist_ptr = hist;
+        ctx->seed_hist_clean_keys = n_keys;
+        hist_keys = (unsigned)n_keys;
+        hist_ptr = hist;
+        hipLaunchKernelGGL(seed_bin_count_kernel, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank);
+        if (n_keys <= kBinScanHereMaxKeys) {
+          hipLaunchKernelGGL(seed_bin_scatter_kernel<true>, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank, pos,
+                             reinterpret_cast<SeedRecIn*>(base + o_in), (unsigned)n_keys);
+        } else {
+          hipLaunchKernelGGL(seed_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, (unsigned)n_keys);
+          hipLaunchKernelGGL(seed_bin_scatter_kernel<false>, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank, pos,
+                             reinterpret_cast<SeedRecIn*>(base + o_in), (unsigned)n_keys);
+        }
+        rec_in = reinterpret_cast<const SeedRecIn*>(base + o_in);
+        rec_out = reinterpret_cast<SeedRecOut*>(base + o_out);
+        pos_of = pos;
+      }
+      hipLaunchKernelGGL(update_seeds_packed_kernel, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0,
+                         ctx->stream, a, rec_in, rec_out);
+      if (rec_out) hipLaunchKernelGGL(seed_unsort_kernel, gb, dim3(256), 0, ctx->stream, a, pos_of, static_cast<const SeedRecOut*>(rec_out),
+                                      hist_ptr, hist_keys);
+    }
+    else if (g8 == 3) hipLaunchKernelGGL(update_seeds_kernel<3>, grid, block, 0, ctx->stream, a);
+    else if (g8) hipLaunchKernelGGL(update_seeds_kernel<1>, grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL(update_seeds_kernel<0>, grid, block, 0, ctx->stream, a);
+  } else {
+    if (g8 == 2) hipLaunchKernelGGL(match_packed_kernel<true>, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0, ctx->stream, a);
+    else if (g8) hipLaunchKernelGGL(match_direct_kernel<true>, grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL(match_direct_kernel<false>, grid, block, 0, ctx->stream, a);
+  }
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  return SVOH_OK;
+}
+
+static int run_matcher_staged(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mopt, const svoh_depth_filter_options* dopt,
+                              int n_ref_frames, const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
+                              const svoh_feature_batch* fb, const double* depth, double* px_cur, int32_t* result, double* f_cur,
+                              int32_t* search_level, double* h_inv, double* A_cur_ref, double* state, uint8_t* success, int32_t* n_success);
+
 static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mopt, const svoh_depth_filter_options* dopt,
                        int n_ref_frames, const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
                        const svoh_feature_batch* fb, const double* depth, double* px_cur, int32_t* result, double* f_cur,
@@ -2777,6 +2848,11 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   const int n = fb->n;
   if (n_success) *n_success = 0;
   if (n <= 0) return SVOH_OK;
+  if (fb->mem_space == SVOH_MEM_STAGED) {
+    SVOH_REQUIRE(ctx, !landmark_xyz, "the pixelwise warp has no staged form");
+    return run_matcher_staged(ctx, seeds, mopt, dopt, n_ref_frames, ref_frames, cur_frame, fb, depth, px_cur, result, f_cur, search_level,
+                              h_inv, A_cur_ref, state, success, n_success);
+  }
   SVOH_REQUIRE(ctx, fb->mem_space == SVOH_MEM_HOST || fb->mem_space == SVOH_MEM_DEVICE, "bad mem_space");
   const bool on_device = fb->mem_space == SVOH_MEM_DEVICE;
   SVOH_REQUIRE(ctx, fb->ref_frame_idx && fb->px && fb->f && fb->grad && fb->level && fb->type, "NULL feature array");
@@ -2873,7 +2949,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   // Optional outputs of units that return before the matcher runs read back as zeros.  The per-unit kernels write those
   // zeros themselves (match_direct_body, update_seeds_body): a fill of the output block would be one more operation on
   // the stream of every per-frame call (2.6 us each, tools/svoh_call_overhead).  The packed geometry's kernels do not.
-  if (!on_device && g8 == 2) SVOH_HIP_TRY(ctx, hipMemsetAsync(d + in_total, 0, s.total - in_total, ctx->stream));
+  if (!on_device && g8 == 2 && !defer) SVOH_HIP_TRY(ctx, hipMemsetAsync(d + in_total, 0, s.total - in_total, ctx->stream));   // (a deferred batch: at its launch)
 
   MatcherArgs a;
   memset(&a, 0, sizeof a);
@@ -2914,13 +2990,16 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   }
   // small batches: eight lanes per unit (a launch is as slow as its slowest lane, and eight lanes get a unit done
   // ~3x sooner); large batches: one lane per unit (fewer instructions per unit).  The knob SVOH_MATCHER_G8 (read when the context is made) forces one.
-  if (defer && g8 != 2) {
-    // Deferred section: the launch itself waits for svoh_matcher_collect, where a direct batch and a seed batch of
-    // the same geometry go out as ONE kernel (match_mixed_kernel).  Remembered: the arguments, the copy of the
+  if (defer) {
+    // Deferred section: the launch itself waits for svoh_matcher_flush / _collect, where a direct batch and a seed batch of
+    // the same per-unit geometry go out as ONE kernel (match_mixed_kernel).  Remembered: the arguments, the copy of the
     // results back to the pinned block, and the copies from there to the caller's arrays.
     svoh_ctx::DeferredLaunch& dl = ctx->matcher_deferred_launch[seeds ? 1 : 0];
     dl.args.assign(reinterpret_cast<const uint8_t*>(&a), reinterpret_cast<const uint8_t*>(&a) + sizeof a);
     dl.n = n; dl.g8 = g8; dl.valid = true;
+    dl.max_w = dl.max_h = 1;
+    for (int k = 0; k < n_ref_frames; ++k) { dl.max_w = views[k].lv[0].w > dl.max_w ? views[k].lv[0].w : dl.max_w; dl.max_h = views[k].lv[0].h > dl.max_h ? views[k].lv[0].h : dl.max_h; }
+    dl.d_block = d; dl.out_off = in_total; dl.out_bytes = s.total - in_total;
     dl.d2h_dst = h + o_type; dl.d2h_src = d + o_type; dl.d2h_bytes = o_nsucc - o_type;
     dl.views_h = h + o_views; dl.views_d = d + o_views; dl.n_ref = n_ref_frames; dl.n_cur = n_cur;
     dl.cur_frame_handle = cur_frame[0].frame;
@@ -2938,8 +3017,6 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     }
     return SVOH_OK;
   }
-  const int units_per_block = g8 == 1 ? 8 : (g8 == 3 ? 1 : 64);
-  const dim3 grid((unsigned)((n + units_per_block - 1) / units_per_block)), block(64);
   {
     unsigned long long* dummy;
     int rc = reset_counters(ctx, &dummy);
@@ -2947,63 +3024,12 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     if (rc != SVOH_OK) return rc;
   }
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
-  if (seeds) {
-    if (g8 == 2) {
-      int max_w = 1, max_h = 1;
-      for (int k = 0; k < n_ref_frames; ++k) { max_w = views[k].lv[0].w > max_w ? views[k].lv[0].w : max_w; max_h = views[k].lv[0].h > max_h ? views[k].lv[0].h : max_h; }
-      const int tiles_x = (max_w + (1 << kBinShiftX) - 1) >> kBinShiftX, tiles_y = (max_h + (1 << kBinShiftY) - 1) >> kBinShiftY;
-      const size_t n_keys = (size_t)n_ref_frames * tiles_x * tiles_y;
-      const SeedRecIn* rec_in = nullptr;
-      SeedRecOut* rec_out = nullptr;
-      const unsigned* pos_of = nullptr;
-      unsigned* hist_ptr = nullptr;
-      unsigned hist_keys = 0;
-      const dim3 gb((unsigned)((n + 255) / 256));
-      if (n_keys <= kBinMaxKeys && SvohKnobs::or_default(ctx->knobs.seed_binning, 1) != 0) {
-        // [hist | rank | pos_of | records in (128 B each) | records out (64 B each)]
-        const size_t o_rank = (n_keys * sizeof(unsigned) + 255) & ~(size_t)255;
-        const size_t o_pos = o_rank + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255);
-        const size_t o_in = o_pos + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255);
-        const size_t o_out = o_in + (size_t)n * sizeof(SeedRecIn);
-        SVOH_HIP_TRY(ctx, ctx->d_seed_bin.reserve(o_out + (size_t)n * sizeof(SeedRecOut)));
-        uint8_t* base = static_cast<uint8_t*>(ctx->d_seed_bin.ptr);
-        unsigned* hist = reinterpret_cast<unsigned*>(base);
-        unsigned* rank = reinterpret_cast<unsigned*>(base + o_rank);
-        unsigned* pos = reinterpret_cast<unsigned*>(base + o_pos);
-        // the histogram is left zeroed by the previous call's last pass unless the block moved or the key count grew
-        if (ctx->seed_hist_ptr != static_cast<void*>(hist) || n_keys > ctx->seed_hist_clean_keys)
-          SVOH_HIP_TRY(ctx, hipMemsetAsync(hist, 0, n_keys * sizeof(unsigned), ctx->stream));
-        ctx->seed_hist_ptr = hist;
-        ctx->seed_hist_clean_keys = n_keys;
-        hist_keys = (unsigned)n_keys;
-        hist_ptr = hist;
-        hipLaunchKernelGGL(seed_bin_count_kernel, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank);
-        if (n_keys <= kBinScanHereMaxKeys) {
-          hipLaunchKernelGGL(seed_bin_scatter_kernel<true>, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank, pos,
-                             reinterpret_cast<SeedRecIn*>(base + o_in), (unsigned)n_keys);
-        } else {
-          hipLaunchKernelGGL(seed_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, (unsigned)n_keys);
-          hipLaunchKernelGGL(seed_bin_scatter_kernel<false>, gb, dim3(256), 0, ctx->stream, a, tiles_x, tiles_y, hist, rank, pos,
-                             reinterpret_cast<SeedRecIn*>(base + o_in), (unsigned)n_keys);
-        }
-        rec_in = reinterpret_cast<const SeedRecIn*>(base + o_in);
-        rec_out = reinterpret_cast<SeedRecOut*>(base + o_out);
-        pos_of = pos;
-      }
-      hipLaunchKernelGGL(update_seeds_packed_kernel, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0,
-                         ctx->stream, a, rec_in, rec_out);
-      if (rec_out) hipLaunchKernelGGL(seed_unsort_kernel, gb, dim3(256), 0, ctx->stream, a, pos_of, static_cast<const SeedRecOut*>(rec_out),
-                                      hist_ptr, hist_keys);
-    }
-    else if (g8 == 3) hipLaunchKernelGGL(update_seeds_kernel<3>, grid, block, 0, ctx->stream, a);
-    else if (g8) hipLaunchKernelGGL(update_seeds_kernel<1>, grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL(update_seeds_kernel<0>, grid, block, 0, ctx->stream, a);
-  } else {
-    if (g8 == 2) hipLaunchKernelGGL(match_packed_kernel<true>, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0, ctx->stream, a);
-    else if (g8) hipLaunchKernelGGL(match_direct_kernel<true>, grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL(match_direct_kernel<false>, grid, block, 0, ctx->stream, a);
+  {
+    int max_w = 1, max_h = 1;
+    for (int k = 0; k < n_ref_frames; ++k) { max_w = views[k].lv[0].w > max_w ? views[k].lv[0].w : max_w; max_h = views[k].lv[0].h > max_h ? views[k].lv[0].h : max_h; }
+    const int rc = launch_matcher_kernels(ctx, seeds, g8, a, n, n_ref_frames, max_w, max_h);
+    if (rc != SVOH_OK) return rc;
   }
-  SVOH_HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
   ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
   {
@@ -3027,21 +3053,6 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   // everything after the inputs that may have changed comes back in one copy
   const size_t back_from = o_type;
   SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + back_from, d + back_from, o_nsucc - back_from));
-  if (defer) {   // the copies to the caller's arrays wait for svoh_matcher_collect
-    auto later = [&](void* dst, size_t off, size_t bytes) { if (dst && bytes) ctx->matcher_pending.push_back({ dst, h + off, bytes }); };
-    if (seeds) {
-      later(fb->type, o_type, (size_t)n); later(state, o_state, sizeof(double) * 4 * n); later(success, o_success, (size_t)n);
-      later(result, o_result, sizeof(int32_t) * n); later(px_cur, o_pxcur, sizeof(double) * 2 * n);
-      later(f_cur, o_fcur, sizeof(double) * 3 * n); later(search_level, o_slevel, sizeof(int32_t) * n);
-      later(A_cur_ref, o_A, sizeof(double) * 4 * n);
-      if (n_success) ctx->matcher_pending_counts.push_back({ n_success, h + o_success, n });
-    } else {
-      later(px_cur, o_pxcur, sizeof(double) * 2 * n); later(result, o_result, sizeof(int32_t) * n);
-      later(f_cur, o_fcur, sizeof(double) * 3 * n); later(search_level, o_slevel, sizeof(int32_t) * n);
-      later(h_inv, o_hinv, sizeof(double) * n); later(A_cur_ref, o_A, sizeof(double) * 4 * n);
-    }
-    return SVOH_OK;
-  }
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (seeds) {
     memcpy(fb->type, h + o_type, (size_t)n);
@@ -3297,7 +3308,8 @@ static int enqueue_candidates(svoh_ctx* ctx, const svoh_camera* cam, const svoh_
   SVOH_REQUIRE(ctx, ctx->cand_pending_n == 0, "a candidate projection is queued already: collect first");
   if (align_result_index >= 0) {
     SVOH_REQUIRE(ctx, T_b != nullptr, "T_post is NULL");
-    SVOH_REQUIRE(ctx, align_result_index < ctx->last_align_n && ctx->d_results.ptr, "no queued alignment result with this index");
+    SVOH_REQUIRE(ctx, (size_t)align_result_index < ctx->align_pending_results && (size_t)align_result_index < ctx->align_result_dev_index.size() && ctx->d_results.ptr,
+                 "no queued alignment result with this index");
   }
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t nd = (size_t)n;
@@ -3316,7 +3328,7 @@ static int enqueue_candidates(svoh_ctx* ctx, const svoh_camera* cam, const svoh_
   memset(&a, 0, sizeof a);
   a.cam = *cam; a.T_a = *T_a;
   if (T_b) a.T_b = *T_b;
-  a.align_result = align_result_index >= 0 ? static_cast<const svoh_align_result*>(ctx->d_results.ptr) + align_result_index : nullptr;
+  a.align_result = align_result_index >= 0 ? static_cast<const svoh_align_result*>(ctx->d_results.ptr) + ctx->align_result_dev_index[(size_t)align_result_index] : nullptr;
   a.T_world_kf = reinterpret_cast<const svoh_se3*>(d + o_kf);
   a.kind = d + o_kind; a.kf = reinterpret_cast<const int32_t*>(d + o_idx);
   a.v = reinterpret_cast<const double*>(d + o_v); a.mu = reinterpret_cast<const double*>(d + o_mu);
@@ -3329,6 +3341,189 @@ static int enqueue_candidates(svoh_ctx* ctx, const svoh_camera* cam, const svoh_
   ctx->cand_pending_n = n;
   ctx->cand_out_off = o_px;
   return SVOH_OK;
+}
+
+
+// ---- a matcher batch staged in place (svoh_matcher_stage, SVOH_MEM_STAGED) -------------------------------------------
+// The caller -- the lock-step front end of many camera streams, with one host thread per few streams -- writes a batch's
+// inputs straight into the section's page-locked block and reads its outputs from there: no concatenation of per-stream
+// arrays, no staging copy inside the call, no copy to caller arrays at collect (at 32 streams those were 3 - 5 MB each way
+// per batch, on ONE thread).  Layout: [views (max) | ref idx | cur idx | px | f | grad | level | (direct: depth) |
+// type | (direct: px_cur in/out; seeds: state in/out) | result | success | (match outputs) | n_success]; everything from
+// `type` on comes back.
+static void layout_matcher_stage(bool seeds, int n, int max_views, bool want_outputs, svoh_ctx::MatcherStage* st)
+{
+  size_t total = 0;
+  auto add = [&](size_t bytes) { const size_t o = total; total = (total + bytes + 63) & ~(size_t)63; return o; };
+  const size_t nn = (size_t)n;
+  st->n = n; st->max_views = max_views; st->want_outputs = want_outputs || !seeds;
+  st->o_views = add(sizeof(DevFrameView) * (size_t)max_views);
+  st->o_idx = add(4 * nn); st->o_cidx = add(4 * nn); st->o_px = add(16 * nn); st->o_f = add(24 * nn); st->o_grad = add(16 * nn); st->o_level = add(4 * nn);
+  st->o_depth = seeds ? 0 : add(8 * nn);
+  st->o_type = add(nn);
+  st->back_from = st->o_type;
+  if (seeds) { st->o_state = add(32 * nn); st->o_pxcur = 0; }
+  else { st->o_pxcur = add(16 * nn); st->o_state = 0; }
+  st->in_total = total;
+  st->o_result = add(4 * nn); st->o_success = add(nn);
+  if (st->want_outputs) {
+    if (seeds) st->o_pxcur = add(16 * nn);
+    st->o_fcur = add(24 * nn); st->o_slevel = add(4 * nn); st->o_hinv = add(8 * nn); st->o_A = add(32 * nn);
+  } else {
+    st->o_fcur = st->o_slevel = st->o_hinv = st->o_A = 0;
+  }
+  st->o_nsucc = add(sizeof(int32_t));
+  st->total = total;
+}
+
+static int run_matcher_staged(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mopt, const svoh_depth_filter_options* dopt,
+                              int n_ref_frames, const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
+                              const svoh_feature_batch* fb, const double* depth, double* px_cur, int32_t* result, double* f_cur,
+                              int32_t* search_level, double* h_inv, double* A_cur_ref, double* state, uint8_t* success, int32_t* n_success)
+{
+  const int kind = seeds ? 1 : 0;
+  svoh_ctx::MatcherStage& st = ctx->matcher_stage[kind];
+  SVOH_REQUIRE(ctx, ctx->matcher_deferred, "a staged batch lives in a deferred section (svoh_matcher_begin_deferred)");
+  SVOH_REQUIRE(ctx, st.valid, "no staged block of this kind: svoh_matcher_stage first");
+  SVOH_REQUIRE(ctx, !ctx->matcher_deferred_used[kind], "one batch of each kind per deferred section: collect first");
+  const int n = fb->n;
+  PinnedBuffer& hbuf = seeds ? ctx->h_match_seeds : ctx->h_match_direct;
+  DevBuffer& dbuf = seeds ? ctx->d_match_seeds : ctx->d_match_direct;
+  uint8_t* h = static_cast<uint8_t*>(hbuf.ptr);
+  uint8_t* d = static_cast<uint8_t*>(dbuf.ptr);
+  SVOH_REQUIRE(ctx, n == st.n && h && d && hbuf.cap >= st.total && dbuf.cap >= st.total, "not the batch that was staged (n differs)");
+  const int n_cur = fb->n_cur_frames > 0 ? fb->n_cur_frames : 1;
+  SVOH_REQUIRE(ctx, n_ref_frames + n_cur <= st.max_views, "more frames than the staged block has room for (max_frame_views)");
+  // the arrays must be the staged ones: anything else would silently be ignored
+  auto at = [&](size_t off) { return static_cast<void*>(h + off); };
+  SVOH_REQUIRE(ctx, fb->ref_frame_idx == at(st.o_idx) && fb->cur_frame_idx == at(st.o_cidx) && fb->px == at(st.o_px) && fb->f == at(st.o_f) &&
+                        fb->grad == at(st.o_grad) && fb->level == at(st.o_level) && fb->type == at(st.o_type),
+               "a staged batch's feature arrays must be the pointers svoh_matcher_stage handed out");
+  if (seeds) {
+    SVOH_REQUIRE(ctx, dopt && state == at(st.o_state) && success == at(st.o_success), "a staged seed batch's state / success must be the staged pointers");
+    SVOH_REQUIRE(ctx, !result || result == at(st.o_result), "result: not the staged pointer");
+    SVOH_REQUIRE(ctx, st.want_outputs || (!px_cur && !f_cur && !search_level && !A_cur_ref), "the block was staged without match outputs");
+    if (st.want_outputs)
+      SVOH_REQUIRE(ctx, (!px_cur || px_cur == at(st.o_pxcur)) && (!f_cur || f_cur == at(st.o_fcur)) && (!search_level || search_level == at(st.o_slevel)) &&
+                            (!A_cur_ref || A_cur_ref == at(st.o_A)), "match outputs: not the staged pointers");
+  } else {
+    SVOH_REQUIRE(ctx, depth == at(st.o_depth) && px_cur == at(st.o_pxcur) && result == at(st.o_result), "a staged direct batch's depth / px_cur / result must be the staged pointers");
+    SVOH_REQUIRE(ctx, (!f_cur || f_cur == at(st.o_fcur)) && (!search_level || search_level == at(st.o_slevel)) && (!h_inv || h_inv == at(st.o_hinv)) &&
+                          (!A_cur_ref || A_cur_ref == at(st.o_A)), "match outputs: not the staged pointers");
+  }
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevFrameView* views = reinterpret_cast<DevFrameView*>(h + st.o_views);
+  int ref_levels = 0, max_w = 1, max_h = 1;
+  for (int k = 0; k < n_ref_frames; ++k) {
+    const int rc = fill_view(ctx, ref_frames[k], &views[k], "reference frame");
+    if (rc != SVOH_OK) return rc;
+    ref_levels = views[k].n_levels > ref_levels ? views[k].n_levels : ref_levels;
+    max_w = views[k].lv[0].w > max_w ? views[k].lv[0].w : max_w; max_h = views[k].lv[0].h > max_h ? views[k].lv[0].h : max_h;
+  }
+  for (int k = 0; k < n_cur; ++k) {
+    const int rc = fill_view(ctx, cur_frame[k], &views[n_ref_frames + k], "current frame");
+    if (rc != SVOH_OK) return rc;
+    SVOH_REQUIRE(ctx, views[n_ref_frames + k].n_levels >= ref_levels, "current frame has fewer pyramid levels than a reference frame");
+  }
+  ctx->matcher_deferred_used[kind] = true;
+  st.valid = false;   // consumed: the outputs stay readable, a second batch needs a new svoh_matcher_stage
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, st.in_total));
+  int g8 = n <= kG8MaxUnits ? 1 : 2;
+  g8 = SvohKnobs::or_default(ctx->knobs.matcher_g8, g8);
+  if (g8 < 0 || g8 > 3) g8 = 0;
+  if (g8 == 3) g8 = 1;
+  MatcherArgs a;
+  memset(&a, 0, sizeof a);
+  a.ref_frames = reinterpret_cast<const DevFrameView*>(d + st.o_views);
+  a.cur_frame = a.ref_frames + n_ref_frames;
+  a.mopt = *mopt;
+  if (dopt) a.dopt = *dopt;
+  a.n = n; a.n_ref_frames = n_ref_frames; a.n_cur_frames = n_cur;
+  a.ref_frame_idx = reinterpret_cast<const int32_t*>(d + st.o_idx);
+  a.cur_frame_idx = reinterpret_cast<const int32_t*>(d + st.o_cidx);
+  a.px = reinterpret_cast<const double*>(d + st.o_px); a.f = reinterpret_cast<const double*>(d + st.o_f);
+  a.grad = reinterpret_cast<const double*>(d + st.o_grad); a.level = reinterpret_cast<const int32_t*>(d + st.o_level);
+  a.type = d + st.o_type;
+  a.result = reinterpret_cast<int32_t*>(d + st.o_result);
+  a.success = d + st.o_success;
+  if (st.want_outputs) {
+    a.f_cur = reinterpret_cast<double*>(d + st.o_fcur); a.search_level = reinterpret_cast<int32_t*>(d + st.o_slevel);
+    a.h_inv = reinterpret_cast<double*>(d + st.o_hinv); a.A_cur_ref = reinterpret_cast<double*>(d + st.o_A);
+  }
+  if (seeds) {
+    a.state = reinterpret_cast<double*>(d + st.o_state);
+    a.px_cur = st.want_outputs ? reinterpret_cast<double*>(d + st.o_pxcur) : nullptr;
+  } else {
+    a.depth = reinterpret_cast<const double*>(d + st.o_depth);
+    a.px_cur = reinterpret_cast<double*>(d + st.o_pxcur);
+  }
+  svoh_ctx::DeferredLaunch& dl = ctx->matcher_deferred_launch[kind];
+  dl.args.assign(reinterpret_cast<const uint8_t*>(&a), reinterpret_cast<const uint8_t*>(&a) + sizeof a);
+  dl.n = n; dl.g8 = g8; dl.valid = true; dl.max_w = max_w; dl.max_h = max_h;
+  dl.d_block = d; dl.out_off = st.in_total; dl.out_bytes = st.o_nsucc - st.in_total;
+  dl.d2h_dst = h + st.back_from; dl.d2h_src = d + st.back_from; dl.d2h_bytes = st.o_nsucc - st.back_from;
+  dl.views_h = h + st.o_views; dl.views_d = d + st.o_views; dl.n_ref = n_ref_frames; dl.n_cur = n_cur;
+  dl.cur_frame_handle = cur_frame[0].frame;
+  if (seeds && n_success) ctx->matcher_pending_counts.push_back({ n_success, h + st.o_success, n });
+  return SVOH_OK;
+}
+
+// ---- the candidate projections of many current frames in one launch (svoh_project_candidates_stage / ...) ----------
+struct MultiCandidateArgs {
+  const svoh_candidate_job* jobs;
+  const svoh_align_result* align_results;   // d_results
+  const uint32_t* result_dev_index;         // per job: where its alignment result lives in align_results (job.align_result_index >= 0)
+  const svoh_se3* T_world_kf;
+  const int32_t* job;
+  const uint8_t* kind;
+  const int32_t* kf;
+  const double* v;
+  const double* mu;
+  double* px;
+  uint8_t* visible;
+  int n, n_jobs;
+};
+
+// per point exactly the arithmetic of project_candidates_kernel
+__global__ __launch_bounds__(256) void project_candidates_multi_kernel(const MultiCandidateArgs a)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const int j = a.job[i];
+  if ((unsigned)j >= (unsigned)a.n_jobs) { a.px[2 * i] = 0.0; a.px[2 * i + 1] = 0.0; a.visible[i] = 0; return; }
+  const svoh_candidate_job& jb = a.jobs[j];
+  Rigid T_f_w = load_rigid(jb.T_f_w_or_T_cam_imu);
+  if (jb.align_result_index >= 0) T_f_w = mul(mul(T_f_w, load_rigid(a.align_results[a.result_dev_index[j]].T_icur_iref)), load_rigid(jb.T_imu_world_ref));
+  const CamModel cm = load_camera(jb.cam);
+  Vec3 xyz = { a.v[3 * i], a.v[3 * i + 1], a.v[3 * i + 2] };
+  bool ok = true;
+  if (a.kind[i]) {
+    const int k = a.kf[i];
+    ok = k >= 0 && k < jb.n_kf;
+    if (ok) {
+      const double depth = 1.0 / a.mu[i];                        // seed::getDepth (seed.h:110-113)
+      const Vec3 in_f = { xyz.x * depth, xyz.y * depth, xyz.z * depth };
+      xyz = transform(load_rigid(a.T_world_kf[jb.kf_begin + k]), in_f);
+    }
+  }
+  double u = 0.0, v = 0.0;
+  if (ok) {
+    const Vec3 xyz_f = transform(T_f_w, xyz);
+    const Vec3 f_tl = back_project3(cm, 0.0, 0.0);
+    const double min_cos = f_tl.z / sqrt(f_tl.x * f_tl.x + f_tl.y * f_tl.y + f_tl.z * f_tl.z);
+    const double cur_cos = xyz_f.z / sqrt(xyz_f.x * xyz_f.x + xyz_f.y * xyz_f.y + xyz_f.z * xyz_f.z);
+    ok = !(cur_cos < min_cos);
+    if (ok) {
+      project3(cm, xyz_f, u, v);
+      ok = u >= 0.0 && v >= 0.0 && u < (double)jb.cam.width && v < (double)jb.cam.height;
+      if (ok) {
+        const int pxi0 = (int)u, pxi1 = (int)v;
+        ok = pxi0 >= 8 && pxi1 >= 8 && pxi0 < jb.cam.width - 8 && pxi1 < jb.cam.height - 8;
+      }
+    }
+  }
+  a.px[2 * i] = u; a.px[2 * i + 1] = v;
+  a.visible[i] = ok ? 1 : 0;
 }
 
 }  // namespace svoh
@@ -3365,6 +3560,119 @@ try {
   return svoh_project_candidates_collect(ctx, n, px, visible);
 } SVOH_ABI_CATCH(ctx)
 
+int svoh_project_candidates_stage(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_points_total, svoh_candidate_stage_t* out)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, out && n_jobs >= 1 && n_jobs <= 4096 && n_kf_total >= 0 && n_kf_total <= (1 << 20) && n_points_total >= 1 && n_points_total <= (1 << 24), "bad arguments");
+  SVOH_REQUIRE(ctx, ctx->cand_stage.state != 2, "a staged candidate projection is in flight: svoh_project_candidates_wait first");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  svoh_ctx::CandStage& st = ctx->cand_stage;
+  size_t total = 0;
+  auto add = [&](size_t bytes) { const size_t o = total; total = (total + bytes + 63) & ~(size_t)63; return o; };
+  const size_t np = (size_t)n_points_total;
+  st.n_jobs = n_jobs; st.n_kf = n_kf_total; st.n_points = n_points_total;
+  st.o_jobs = add(sizeof(svoh_candidate_job) * (size_t)n_jobs + sizeof(uint32_t) * (size_t)n_jobs);   // + the jobs' device result indices
+  st.o_kf = add(sizeof(svoh_se3) * (size_t)(n_kf_total > 0 ? n_kf_total : 1));
+  st.o_job = add(4 * np); st.o_kind = add(np); st.o_idx = add(4 * np); st.o_v = add(24 * np); st.o_mu = add(8 * np);
+  st.in_total = total;
+  st.o_px = add(16 * np); st.o_vis = add(np);
+  st.total = total;
+  SVOH_HIP_TRY(ctx, ctx->h_cand_multi.reserve(total));
+  SVOH_HIP_TRY(ctx, ctx->d_cand_multi.reserve(total));
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_cand_multi.ptr);
+  out->jobs = reinterpret_cast<svoh_candidate_job*>(h + st.o_jobs);
+  out->T_world_kf = reinterpret_cast<svoh_se3*>(h + st.o_kf);
+  out->job = reinterpret_cast<int32_t*>(h + st.o_job); out->kind = h + st.o_kind; out->kf = reinterpret_cast<int32_t*>(h + st.o_idx);
+  out->v = reinterpret_cast<double*>(h + st.o_v); out->mu = reinterpret_cast<double*>(h + st.o_mu);
+  out->px = reinterpret_cast<double*>(h + st.o_px); out->visible = h + st.o_vis;
+  st.state = 1;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_project_candidates_enqueue_staged(svoh_ctx* ctx)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  svoh_ctx::CandStage& st = ctx->cand_stage;
+  SVOH_REQUIRE(ctx, st.state == 1, "nothing staged (svoh_project_candidates_stage)");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_cand_multi.ptr);
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_cand_multi.ptr);
+  svoh_candidate_job* jobs = reinterpret_cast<svoh_candidate_job*>(h + st.o_jobs);
+  uint32_t* dev_idx = reinterpret_cast<uint32_t*>(jobs + st.n_jobs);
+  bool any_result = false;
+  for (int j = 0; j < st.n_jobs; ++j) {
+    const svoh_candidate_job& jb = jobs[j];
+    SVOH_REQUIRE(ctx, jb.cam.distortion == SVOH_DISTORTION_NONE || jb.cam.distortion == SVOH_DISTORTION_RADTAN, "unsupported distortion model");
+    SVOH_REQUIRE(ctx, jb.n_kf >= 0 && jb.kf_begin >= 0 && (int64_t)jb.kf_begin + jb.n_kf <= st.n_kf, "a job's keyframe range leaves the table");
+    SVOH_REQUIRE(ctx, jb.n_points >= 0 && jb.point_begin >= 0 && (int64_t)jb.point_begin + jb.n_points <= st.n_points, "a job's point range leaves the arrays");
+    dev_idx[j] = 0;
+    if (jb.align_result_index >= 0) {
+      SVOH_REQUIRE(ctx, (size_t)jb.align_result_index < ctx->align_pending_results && (size_t)jb.align_result_index < ctx->align_result_dev_index.size() && ctx->d_results.ptr,
+                   "no queued alignment result with this index");
+      dev_idx[j] = ctx->align_result_dev_index[(size_t)jb.align_result_index];
+      any_result = true;
+    }
+  }
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, st.in_total));
+  MultiCandidateArgs a;
+  memset(&a, 0, sizeof a);
+  a.jobs = reinterpret_cast<const svoh_candidate_job*>(d + st.o_jobs);
+  a.result_dev_index = reinterpret_cast<const uint32_t*>(a.jobs + st.n_jobs);
+  a.align_results = any_result ? static_cast<const svoh_align_result*>(ctx->d_results.ptr) : nullptr;
+  a.T_world_kf = reinterpret_cast<const svoh_se3*>(d + st.o_kf);
+  a.job = reinterpret_cast<const int32_t*>(d + st.o_job); a.kind = d + st.o_kind; a.kf = reinterpret_cast<const int32_t*>(d + st.o_idx);
+  a.v = reinterpret_cast<const double*>(d + st.o_v); a.mu = reinterpret_cast<const double*>(d + st.o_mu);
+  a.px = reinterpret_cast<double*>(d + st.o_px); a.visible = d + st.o_vis;
+  a.n = st.n_points; a.n_jobs = st.n_jobs;
+  hipLaunchKernelGGL(project_candidates_multi_kernel, dim3((unsigned)((st.n_points + 255) / 256)), dim3(256), 0, ctx->stream, a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "project_candidates_multi launch failed: %s", hipGetErrorString(e));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + st.o_px, d + st.o_px, st.total - st.o_px));
+  st.state = 2;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_project_candidates_wait(svoh_ctx* ctx)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, ctx->cand_stage.state == 2, "no staged candidate projection in flight");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // returns at once when a fetch of the alignment in front has waited already
+  ctx->cand_stage.state = 0;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_matcher_stage(svoh_ctx* ctx, int seeds, int n, int max_frame_views, int want_match_outputs, svoh_matcher_stage_t* out)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, out && n >= 1 && n <= (1 << 24) && max_frame_views >= 2 && max_frame_views <= (1 << 16), "bad arguments");
+  SVOH_REQUIRE(ctx, ctx->matcher_deferred, "svoh_matcher_stage: inside a deferred section only (svoh_matcher_begin_deferred)");
+  const int kind = seeds ? 1 : 0;
+  SVOH_REQUIRE(ctx, !ctx->matcher_deferred_used[kind], "one batch of each kind per deferred section: collect first");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  svoh_ctx::MatcherStage& st = ctx->matcher_stage[kind];
+  layout_matcher_stage(seeds != 0, n, max_frame_views, want_match_outputs != 0, &st);
+  PinnedBuffer& hbuf = seeds ? ctx->h_match_seeds : ctx->h_match_direct;
+  DevBuffer& dbuf = seeds ? ctx->d_match_seeds : ctx->d_match_direct;
+  SVOH_HIP_TRY(ctx, hbuf.reserve(st.total));
+  SVOH_HIP_TRY(ctx, dbuf.reserve(st.total));
+  uint8_t* h = static_cast<uint8_t*>(hbuf.ptr);
+  memset(out, 0, sizeof *out);
+  out->ref_frame_idx = reinterpret_cast<int32_t*>(h + st.o_idx); out->cur_frame_idx = reinterpret_cast<int32_t*>(h + st.o_cidx);
+  out->px = reinterpret_cast<double*>(h + st.o_px); out->f = reinterpret_cast<double*>(h + st.o_f); out->grad = reinterpret_cast<double*>(h + st.o_grad);
+  out->level = reinterpret_cast<int32_t*>(h + st.o_level); out->type = h + st.o_type;
+  out->result = reinterpret_cast<int32_t*>(h + st.o_result); out->success = h + st.o_success;
+  if (seeds) out->state = reinterpret_cast<double*>(h + st.o_state);
+  else { out->depth = reinterpret_cast<double*>(h + st.o_depth); out->px_cur = reinterpret_cast<double*>(h + st.o_pxcur); }
+  if (st.want_outputs) {
+    if (seeds) out->px_cur = reinterpret_cast<double*>(h + st.o_pxcur);
+    out->f_cur = reinterpret_cast<double*>(h + st.o_fcur); out->search_level = reinterpret_cast<int32_t*>(h + st.o_slevel);
+    out->h_inv = reinterpret_cast<double*>(h + st.o_hinv); out->A_cur_ref = reinterpret_cast<double*>(h + st.o_A);
+  }
+  st.valid = true;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
 int svoh_epipolar_match_batch(svoh_ctx* ctx, const svoh_matcher_options* options, int n_ref_frames,
                               const svoh_frame_view* ref_frames, const svoh_frame_view* cur_frame,
                               const svoh_se3* T_cur_ref, const svoh_feature_batch* features,
@@ -3383,6 +3691,7 @@ try {
   ctx->matcher_pending.clear();
   ctx->matcher_pending_counts.clear();
   ctx->matcher_deferred_launch[0].valid = ctx->matcher_deferred_launch[1].valid = false;
+  ctx->matcher_stage[0].valid = ctx->matcher_stage[1].valid = false;
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
@@ -3408,20 +3717,23 @@ static int launch_deferred(svoh_ctx* ctx)
       if (rc == SVOH_OK) rc = reserve_unit_counts(ctx, n0 + n1, &uc);
       if (rc != SVOH_OK) return rc;
       a0.unit_counts = uc; a1.unit_counts = uc + 4 * n0;
-      auto blocks = [](const svoh_ctx::DeferredLaunch& d) { const int u = d.g8 ? 8 : 64; return (unsigned)((d.n + u - 1) / u); };
+      auto blocks = [](const svoh_ctx::DeferredLaunch& d) { const int u = d.g8 ? 8 : 64; return (unsigned)((d.n + u - 1) / u); };   // per-unit geometries 0 / 1
       if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
-      if (v0 && v1 && d0.g8 == d1.g8) {
+      if (v0 && v1 && d0.g8 == d1.g8 && d0.g8 != 2) {
         const unsigned b0 = blocks(d0), b1 = blocks(d1);
         if (d0.g8) hipLaunchKernelGGL(match_mixed_kernel<true>, dim3(b0 + b1), dim3(64), 0, ctx->stream, a0, a1, (int)b0);
         else hipLaunchKernelGGL(match_mixed_kernel<false>, dim3(b0 + b1), dim3(64), 0, ctx->stream, a0, a1, (int)b0);
       } else {
+        // (the packed geometry's kernels do not write the optional outputs of units that return early: zeroed here)
         if (v0) {
-          if (d0.g8) hipLaunchKernelGGL(match_direct_kernel<true>, dim3(blocks(d0)), dim3(64), 0, ctx->stream, a0);
-          else hipLaunchKernelGGL(match_direct_kernel<false>, dim3(blocks(d0)), dim3(64), 0, ctx->stream, a0);
+          if (d0.g8 == 2 && d0.out_bytes) SVOH_HIP_TRY(ctx, hipMemsetAsync(static_cast<uint8_t*>(d0.d_block) + d0.out_off, 0, d0.out_bytes, ctx->stream));
+          rc = launch_matcher_kernels(ctx, false, d0.g8, a0, d0.n, a0.n_ref_frames, d0.max_w, d0.max_h);
+          if (rc != SVOH_OK) return rc;
         }
         if (v1) {
-          if (d1.g8) hipLaunchKernelGGL(update_seeds_kernel<1>, dim3(blocks(d1)), dim3(64), 0, ctx->stream, a1);
-          else hipLaunchKernelGGL(update_seeds_kernel<0>, dim3(blocks(d1)), dim3(64), 0, ctx->stream, a1);
+          if (d1.g8 == 2 && d1.out_bytes) SVOH_HIP_TRY(ctx, hipMemsetAsync(static_cast<uint8_t*>(d1.d_block) + d1.out_off, 0, d1.out_bytes, ctx->stream));
+          rc = launch_matcher_kernels(ctx, true, d1.g8, a1, d1.n, a1.n_ref_frames, d1.max_w, d1.max_h);
+          if (rc != SVOH_OK) return rc;
         }
       }
       SVOH_HIP_TRY(ctx, hipGetLastError());

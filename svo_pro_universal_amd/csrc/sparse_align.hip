@@ -1905,8 +1905,126 @@ struct SplitArgs {
   int n_shares = 1;                                 // evaluate: workgroups the problem's features are spread over
 };
 
+// The launch geometry of the resident kernel: workgroups per problem (cluster mode), threads per workgroup, lanes per
+// patch, and which build of the 256 / 512-thread kernel.  The geometries differ in the ORDER of their sums only (poses agree
+// to 1e-15), but a caller that wants a problem's result to be the same bits whatever else shares its launch -- the
+// lock-step front end of many camera streams, whose streams must reproduce their single-stream runs byte for byte --
+// asks for the geometry a launch of the problem alone would get (svoh_sparse_align_geometry_key / _enqueue_keyed).
+struct AlignGeometry {
+  int cluster_g = 0;       // 0: one workgroup per problem; >= 2: that many co-resident workgroups per problem
+  int nt = 256;            // 256 / 512 threads
+  int rows = 1;            // lanes per patch (1, 2, 4, 8)
+  bool latency = false;    // the one-wave-per-SIMD build of the 256-thread kernel
+  bool rig = false;        // the build that runs a rig's cameras side by side
+  int32_t key() const { return (1 << 30) | (cluster_g & 0xff) | ((nt == 512 ? 1 : 0) << 8) | ((rows & 0xf) << 9) | ((latency ? 1 : 0) << 13) | ((rig ? 1 : 0) << 14); }
+  static bool from_key(int32_t k, AlignGeometry* g)
+  {
+    if (!(k & (1 << 30)) || (k & ~((1 << 30) | 0x7fff))) return false;
+    g->cluster_g = k & 0xff; g->nt = (k >> 8) & 1 ? 512 : 256; g->rows = (k >> 9) & 0xf; g->latency = (k >> 13) & 1; g->rig = (k >> 14) & 1;
+    return (g->rows == 1 || g->rows == 2 || g->rows == 4 || g->rows == 8) && g->cluster_g != 1 && g->cluster_g <= kClusterMaxWorkgroups;
+  }
+};
+
+// cluster mode: a single problem with many features gets several co-resident workgroups of the resident kernel
+// (one share each) that add their normal equations through a device-side barrier every iteration, instead of
+// one workgroup on one CU.  SVOH_ALIGN_CLUSTER=0 turns it off, =G forces G workgroups.
+// A handful of such problems (a stereo pair of streams, a few cameras) are clustered alike, each with its own
+// exchange slots, as long as every one of them is large and they all fit on the device at once.
+// Returns the workgroups per problem (>= 2) or 0.
+static int decide_cluster(const svoh_ctx* ctx, int n_problems, const svoh_align_problem* problems)
+{
+  if (n_problems > kClusterMaxProblems || ctx->align_no_cluster) return 0;
+  int64_t nf_min = INT64_MAX, nf_max = 0;
+  for (int p = 0; p < n_problems; ++p) {
+    int64_t nf = 0;
+    if (problems[p].n_cams >= 1 && problems[p].n_cams <= SVOH_MAX_CAMS)
+      for (int c = 0; c < problems[p].n_cams; ++c) nf += problems[p].cams[c].n_features > 0 ? problems[p].cams[c].n_features : 0;
+    nf_min = nf < nf_min ? nf : nf_min;
+    nf_max = nf > nf_max ? nf : nf_max;
+  }
+  int g = SvohKnobs::or_default(ctx->knobs.align_cluster, -1);
+  // measured (scripts/perf_small_batch.py): up to 16 problems always gain; 32..64 only when each is large
+  const bool worth = nf_min >= kClusterMinFeatures && (n_problems <= 16 || nf_min >= 3000);
+  if (g < 0) g = worth ? (int)((nf_max + kClusterFeaturesPerWorkgroup - 1) / kClusterFeaturesPerWorkgroup) : 0;
+  if (g > kClusterMaxWorkgroups) g = kClusterMaxWorkgroups;
+  if ((int64_t)g * n_problems > ctx->num_cus) g = ctx->num_cus / n_problems;   // every workgroup on its own CU
+  return g >= 2 ? g : 0;
+}
+
+// what pass 1 of enqueue_align learns about the problems of a launch, as far as the geometry depends on it
+struct LaunchShape { int max_feat_per_problem = 0; bool have_rig = false, rig_wants_512 = false; };
+static void add_to_shape(const svoh_align_problem& pb, int S, LaunchShape* z)
+{
+  int nf = 0;
+  for (int c = 0; c < pb.n_cams; ++c) nf += pb.cams[c].n_features > 0 ? pb.cams[c].n_features : 0;
+  const int per_share = S > 1 ? nf / S + pb.n_cams : nf;
+  if (per_share > z->max_feat_per_problem) z->max_feat_per_problem = per_share;
+  if (S == 1 && pb.n_cams >= 2) {
+    z->have_rig = true;
+    int lanes = 0;
+    for (int c = 0; c < pb.n_cams; ++c) lanes += (pb.cams[c].n_features + 63) & ~63;
+    z->rig_wants_512 = z->rig_wants_512 || (lanes > 256 && lanes <= 512);
+  }
+}
+
+// Geometry.  Many problems: 256-thread workgroups, two per CU (256 VGPRs each), so
+// that one problem's serial solve overlaps the other's patch work; LDS holds levels
+// >= 2 of a 640x480 pyramid.  Few problems (latency mode): 512-thread workgroups.
+// measured on MI355X (2000 patches): one problem takes 0.42 ms with 512 threads, 0.50 ms
+// with 256 and 0.91 ms with 1024 (128-VGPR budget spills), so 512 is the latency geometry
+// (measured, scripts/perf_mid_batch.py: from one problem per CU on, two 256-thread workgroups per CU with the
+// LDS-DMA workspace path beat one 512-thread workgroup: 384 problems 1.06 -> 0.82 ms)
+static AlignGeometry decide_geometry(const svoh_ctx* ctx, const svoh_align_options* opt, int n_desc, int cluster_g, const LaunchShape& z)
+{
+  AlignGeometry g;
+  const bool cluster = cluster_g >= 2;
+  g.cluster_g = cluster ? cluster_g : 0;
+  int nt = (n_desc >= ctx->num_cus) ? 256 : 512;
+  if (z.max_feat_per_problem <= 256) nt = 256;
+  // a few rigs whose cameras fill five to eight waves between them: 512 threads, so that the cameras run side by side with
+  // one round each (run_cameras in the kernel) instead of taking turns
+  if (!cluster && n_desc < ctx->num_cus && z.rig_wants_512) nt = 512;
+  // Rows geometry (LPP lanes per patch, accumulate_camera_rows): a problem with so few patches that they do not give
+  // every SIMD of its compute unit a wave gets 2, 4 or 8 lanes per patch, as many as keep it at one wave per SIMD (256
+  // lanes) -- a lane's pass is then a chain of P / LPP rolling rows instead of P.  Measured (one problem, levels 4..2,
+  // kernel ms, lanes per patch 1 / 2 / 4 / 8): 60 patches of 8x8 0.151 / 0.131 / 0.119 / 0.126; 100 of 4x4 0.092 / 0.087 /
+  // 0.092; 180 of 4x4 0.092 / 0.095 / 0.098; 180 of 8x8 0.137 / 0.143 / 0.137 / 0.169; 2000 of 4x4 0.184 / 0.230 / 0.330:
+  // beyond one wave per SIMD the compute unit is bound by vector issue, and more lanes per patch are more instructions
+  // per patch (every lane repeats the projection, the Jacobian rows and two interpolated rows).
+  // SVOH_ALIGN_ROWS: lanes per patch (2, 4 or 8); anything else = a lane per patch.
+  int rows = 1;
+  if (!cluster && n_desc < ctx->num_cus) {
+    while (rows * 2 <= opt->patch_size && rows * 2 <= 8 && (int64_t)z.max_feat_per_problem * rows * 2 <= 256) rows *= 2;
+    rows = SVOH_ALIGN_ROWS_DEFAULT(rows);
+  }
+  rows = SvohKnobs::or_default(ctx->knobs.align_rows, rows);
+  if (rows != 2 && rows != 4 && rows != 8) rows = 1;
+  if (rows > opt->patch_size || cluster) rows = 1;
+  if (rows > 1) nt = 512;
+  nt = SvohKnobs::or_default(ctx->knobs.align_threads, nt);
+  if (cluster) nt = 256;   // one workgroup per CU at most: all of them are resident together
+  if (nt != 256 && nt != 512) nt = 256;
+  if (nt == 256) rows = 1;
+  g.nt = nt; g.rows = rows;
+  // SVOH_ALIGN_LATENCY_BUILD=0 keeps the batch build for small launches too (A/B)
+  g.latency = nt == 256 && !cluster && n_desc < ctx->num_cus && SvohKnobs::or_default(ctx->knobs.align_latency_build, 1) != 0;
+  g.rig = !cluster && n_desc < ctx->num_cus && z.have_rig;
+  return g;
+}
+
+// the geometry a launch of this problem ALONE gets
+static AlignGeometry geometry_of_single(const svoh_ctx* ctx, const svoh_align_options* opt, const svoh_align_problem& pb)
+{
+  const int g = decide_cluster(ctx, 1, &pb);
+  const int S = g >= 2 ? g : 1;
+  LaunchShape z;
+  add_to_shape(pb, S, &z);
+  return decide_geometry(ctx, opt, S, g, z);
+}
+
 static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_problems,
-                         const svoh_align_problem* problems, int eval_level, const SplitArgs* split = nullptr)
+                         const svoh_align_problem* problems, int eval_level, const SplitArgs* split = nullptr,
+                         const AlignGeometry* forced = nullptr)
 {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   int rc = validate_options(ctx, opt);
@@ -1917,37 +2035,19 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // patch-split evaluation: the one problem becomes S descriptors, share s holding features
   // [n*s/S, n*(s+1)/S) of every camera, one workgroup each
   int S = (split && !split->update && split->n_shares > 1) ? split->n_shares : 1;
-  // cluster mode: a single problem with many features gets several co-resident workgroups of the resident kernel
-  // (one share each) that add their normal equations through a device-side barrier every iteration, instead of
-  // one workgroup on one CU.  SVOH_ALIGN_CLUSTER=0 turns it off, =G forces G workgroups.
-  // A handful of such problems (a stereo pair of streams, a few cameras) are clustered alike, each with its own
-  // exchange slots, as long as every one of them is large and they all fit on the device at once.
   bool cluster = false;
-  if (!split && eval_level < 0 && n_problems <= kClusterMaxProblems && !ctx->align_no_cluster) {
-    int64_t nf_min = INT64_MAX, nf_max = 0;
-    for (int p = 0; p < n_problems; ++p) {
-      int64_t nf = 0;
-      if (problems[p].n_cams >= 1 && problems[p].n_cams <= SVOH_MAX_CAMS)
-        for (int c = 0; c < problems[p].n_cams; ++c) nf += problems[p].cams[c].n_features > 0 ? problems[p].cams[c].n_features : 0;
-      nf_min = nf < nf_min ? nf : nf_min;
-      nf_max = nf > nf_max ? nf : nf_max;
-    }
-    int g = SvohKnobs::or_default(ctx->knobs.align_cluster, -1);
-    // measured (scripts/perf_small_batch.py): up to 16 problems always gain; 32..64 only when each is large
-    const bool worth = nf_min >= kClusterMinFeatures && (n_problems <= 16 || nf_min >= 3000);
-    if (g < 0) g = worth ? (int)((nf_max + kClusterFeaturesPerWorkgroup - 1) / kClusterFeaturesPerWorkgroup) : 0;
-    if (g > kClusterMaxWorkgroups) g = kClusterMaxWorkgroups;
-    if ((int64_t)g * n_problems > ctx->num_cus) g = ctx->num_cus / n_problems;   // every workgroup on its own CU
+  if (!split && eval_level < 0) {
+    const int g = forced ? forced->cluster_g : decide_cluster(ctx, n_problems, problems);
     if (g >= 2) { S = g; cluster = true; }
   }
+  SVOH_REQUIRE(ctx, !forced || (!split && eval_level < 0), "a forced geometry applies to full runs only");
+  SVOH_REQUIRE(ctx, !cluster || (int64_t)S * n_problems <= ctx->num_cus, "cluster mode: more workgroups than compute units");
   SVOH_REQUIRE(ctx, S == 1 || n_problems == 1 || cluster, "shares apply to a single problem");
   const int n_desc = n_problems * S;
 
   // pass 1: sizes
   size_t n_cams_total = 0, n_feat_total = 0, host_bytes = 0;
-  int max_feat_per_problem = 0;
-  bool have_rig = false;        // some problem has more than one camera
-  bool rig_wants_512 = false;   // a problem of several cameras whose patches fill five to eight waves, camera by camera (geometry choice below)
+  LaunchShape shape;   // largest problem (share); some problem has more than one camera; ... whose patches fill five to eight waves, camera by camera
   for (int p = 0; p < n_problems; ++p) {
     const svoh_align_problem& pb = problems[p];
     SVOH_REQUIRE(ctx, pb.n_cams >= 1 && pb.n_cams <= SVOH_MAX_CAMS, "n_cams out of range");
@@ -1965,15 +2065,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
     }
     n_cams_total += (size_t)pb.n_cams * S;
     n_feat_total += nf;
-    const int per_share = S > 1 ? nf / S + pb.n_cams : nf;
-    if (per_share > max_feat_per_problem) max_feat_per_problem = per_share;
-    if (S == 1 && pb.n_cams >= 2) {
-      have_rig = true;
-      int lanes = 0;
-      for (int c = 0; c < pb.n_cams; ++c) lanes += (pb.cams[c].n_features + 63) & ~63;
-      rig_wants_512 = rig_wants_512 || (lanes > 256 && lanes <= 512);
-    }
+    add_to_shape(pb, S, &shape);
   }
+  const int max_feat_per_problem = shape.max_feat_per_problem;
   const size_t feat_slots = n_feat_total ? n_feat_total : 1;
 
   // descriptors, then (256-byte aligned) the zeroed work-queue head and the cluster arrival counters, then the
@@ -1987,8 +2081,11 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // with the descriptor count and would land inside the earlier call's descriptors -- nor let reserve() replace
   // it, before the earlier call's upload has read it.
   // (two blocks in turn, an event only between launches queued back to back: svoh_internal.h)
-  ctx->align_desc_slot ^= 1u;
-  PinnedBuffer& h_desc = ctx->align_desc_slot ? ctx->h_desc_odd : ctx->h_desc;
+  // (the slot is committed only once the upload has been queued: a call that fails in between -- an unknown frame handle,
+  // a failed reserve -- must leave the NEXT call on the block this one was about to use, not on the block the last
+  // successful launch may still be uploading from)
+  const unsigned desc_slot = ctx->align_desc_slot ^ 1u;
+  PinnedBuffer& h_desc = desc_slot ? ctx->h_desc_odd : ctx->h_desc;
   if (ctx->align_launches_since_drain >= 2) {
     // this block was last read by the upload of the launch before the last one, which has not been waited for
     if (ctx->align_staged_event_valid) SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_align_staged));
@@ -1997,9 +2094,26 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   SVOH_HIP_TRY(ctx, h_desc.reserve(desc_bytes));
   SVOH_HIP_TRY(ctx, ctx->d_desc.reserve(desc_bytes));
   memset(static_cast<uint8_t*>(h_desc.ptr) + ctl_off, 0, 512);
-  SVOH_HIP_TRY(ctx, ctx->d_results.reserve(sizeof(svoh_align_result) * ((size_t)n_desc + n_problems)));
-  // results of launches queued since the last fetch are kept one after the other in pinned host memory
+  // results of launches queued since the last fetch are kept one after the other in pinned host memory -- and on the
+  // device as well (a candidate projection queued behind several launches reads the result of any of them):
+  // this launch's device block of n_desc + n_problems results starts behind the blocks of the launches before it
   const bool delivers = (S == 1 || cluster) && eval_level < 0;
+  const size_t dev_results_off = delivers ? ctx->align_pending_dev : 0;
+  {
+    const size_t need = sizeof(svoh_align_result) * (dev_results_off + (size_t)n_desc + n_problems);
+    if (need > ctx->d_results.cap) {
+      if (dev_results_off) {   // earlier launches' results live in the old block: let them finish, take them along
+        SVOH_ALIGN_DRAIN(ctx);
+        DevBuffer bigger;
+        SVOH_HIP_TRY(ctx, bigger.reserve(need * 2));
+        SVOH_HIP_TRY(ctx, hipMemcpy(bigger.ptr, ctx->d_results.ptr, sizeof(svoh_align_result) * dev_results_off, hipMemcpyDeviceToDevice));
+        std::swap(bigger.ptr, ctx->d_results.ptr);
+        std::swap(bigger.cap, ctx->d_results.cap);
+      } else {
+        SVOH_HIP_TRY(ctx, ctx->d_results.reserve(need));
+      }
+    }
+  }
   if (delivers) {
     SVOH_REQUIRE(ctx, ctx->align_pending_results + (size_t)n_problems <= svoh_ctx::kMaxQueuedResults,
                  "too many alignment results queued without a fetch");
@@ -2098,6 +2212,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
     }
   }
   SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, ctx->d_desc.ptr, h_desc.ptr, up_base + up_off));
+  ctx->align_desc_slot = desc_slot;
   ctx->align_staged_event_valid = false;
   if (ctx->align_launches_since_drain >= 1) {   // queued behind a launch nobody has waited for: the next one may need this
     SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_align_staged, ctx->stream));
@@ -2108,7 +2223,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   AlignKernelArgs args;
   args.problems = static_cast<const DevProblemDesc*>(ctx->d_desc.ptr);
   args.cams = reinterpret_cast<const DevCamDesc*>(args.problems + n_desc);
-  args.results = static_cast<svoh_align_result*>(ctx->d_results.ptr);
+  args.results = static_cast<svoh_align_result*>(ctx->d_results.ptr) + dev_results_off;
   double* w = static_cast<double*>(ctx->d_feat.ptr);
   args.wpk = w;
   args.slots = (int64_t)feat_slots;
@@ -2159,48 +2274,17 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   args.stamps = static_cast<long long*>(ctx->d_scratch0.ptr);
 #endif
 
-  // Geometry.  Many problems: 256-thread workgroups, two per CU (256 VGPRs each), so
-  // that one problem's serial solve overlaps the other's patch work; LDS holds levels
-  // >= 2 of a 640x480 pyramid.  Few problems (latency mode): 512-thread workgroups.
-  // measured on MI355X (2000 patches): one problem takes 0.42 ms with 512 threads, 0.50 ms
-  // with 256 and 0.91 ms with 1024 (128-VGPR budget spills), so 512 is the latency geometry
-  // (measured, scripts/perf_mid_batch.py: from one problem per CU on, two 256-thread workgroups per CU with the
-  // LDS-DMA workspace path beat one 512-thread workgroup: 384 problems 1.06 -> 0.82 ms)
-  int nt = (n_desc >= ctx->num_cus) ? 256 : 512;
-  if (max_feat_per_problem <= 256) nt = 256;
-  // a few rigs whose cameras fill five to eight waves between them: 512 threads, so that the cameras run side by side with
-  // one round each (run_cameras in the kernel) instead of taking turns
-  if (!cluster && n_desc < ctx->num_cus && rig_wants_512) nt = 512;
-  // Rows geometry (LPP lanes per patch, accumulate_camera_rows): a problem with so few patches that they do not give
-  // every SIMD of its compute unit a wave gets 2, 4 or 8 lanes per patch, as many as keep it at one wave per SIMD (256
-  // lanes) -- a lane's pass is then a chain of P / LPP rolling rows instead of P.  Measured (one problem, levels 4..2,
-  // kernel ms, lanes per patch 1 / 2 / 4 / 8): 60 patches of 8x8 0.151 / 0.131 / 0.119 / 0.126; 100 of 4x4 0.092 / 0.087 /
-  // 0.092; 180 of 4x4 0.092 / 0.095 / 0.098; 180 of 8x8 0.137 / 0.143 / 0.137 / 0.169; 2000 of 4x4 0.184 / 0.230 / 0.330:
-  // beyond one wave per SIMD the compute unit is bound by vector issue, and more lanes per patch are more instructions
-  // per patch (every lane repeats the projection, the Jacobian rows and two interpolated rows).
-  // SVOH_ALIGN_ROWS: lanes per patch; 0 or 1 = a lane per patch.
-  int rows = 1;
-  if (!cluster && n_desc < ctx->num_cus) {
-    while (rows * 2 <= opt->patch_size && rows * 2 <= 8 && (int64_t)max_feat_per_problem * rows * 2 <= 256) rows *= 2;
-    rows = SVOH_ALIGN_ROWS_DEFAULT(rows);
-  }
-  rows = SvohKnobs::or_default(ctx->knobs.align_rows, rows);
-  if (rows != 2 && rows != 4 && rows != 8) rows = 1;
-  if (rows > opt->patch_size || cluster) rows = 1;
-  if (rows > 1) nt = 512;
-  nt = SvohKnobs::or_default(ctx->knobs.align_threads, nt);
-  if (cluster) nt = 256;   // one workgroup per CU at most: all of them are resident together
-  if (nt != 256 && nt != 512) nt = 256;
-  if (nt == 256) rows = 1;
+  // geometry (decide_geometry): chosen from the launch, or the caller's (a keyed launch: the geometry of a problem alone)
+  const AlignGeometry geo = forced ? *forced : decide_geometry(ctx, opt, n_desc, cluster ? S : 0, shape);
+  const int nt = geo.nt, rows = geo.rows;
   // 256 threads: two workgroups per CU, each with <= 29 KB of static LDS (reduction scratch, the 24 KB LDS-DMA staging
   // area of the workspace rows) -> 51 KB for images: levels 4, 3 and 2 of a 640x480 pyramid side by side (50 400 B);
   // launch_one trims the image area to what the instantiation's static LDS really leaves of half a compute unit
   size_t lds = (nt == 256) ? 52224 : 78 * 1024;
-  // SVOH_ALIGN_LATENCY_BUILD=0 keeps the batch build for small launches too (A/B)
-  args.latency_build = (nt == 256 && !cluster && n_desc < ctx->num_cus && SvohKnobs::or_default(ctx->knobs.align_latency_build, 1) != 0) ? 1 : 0;
-  args.rig_build = (!cluster && n_desc < ctx->num_cus && have_rig) ? 1 : 0;
+  args.latency_build = geo.latency ? 1 : 0;
+  args.rig_build = geo.rig ? 1 : 0;
   args.lds_two_per_cu = (nt == 256 && !cluster && ctx->knobs.align_lds == kKnobUnset && ctx->knobs.align_wg_per_cu == kKnobUnset) ? 1 : 0;
-  lds = (size_t)SvohKnobs::or_default(ctx->knobs.align_lds, (int)lds);
+  lds = (size_t)SvohKnobs::or_default(ctx->knobs.align_lds, (int)lds) & ~(size_t)15;   // the workspace behind the image area is read through 16-byte loads
   // 160 KB per workgroup minus the kernel's static LDS
   const size_t lds_cap = (nt == 256 && SVOH_ALIGN_STAGED) ? 163840 - 32768 : 153856;
   if (lds > lds_cap) lds = lds_cap;
@@ -2250,9 +2334,13 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   // launches and fetches once still has every launch's output delivered
   if (delivers) {   // cluster: entry 0 is share 0's copy of the common result
     SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, static_cast<svoh_align_result*>(ctx->h_results.ptr) + ctx->align_pending_results,
-                                        ctx->d_results.ptr, sizeof(svoh_align_result) * n_problems));
+                                        args.results, sizeof(svoh_align_result) * n_problems));
     ctx->align_last_results_off = ctx->align_pending_results;
+    // where on the device result #k of the queue lives (svoh_project_candidates_enqueue's align_result_index)
+    if (ctx->align_pending_results == 0) ctx->align_result_dev_index.clear();
+    for (int p = 0; p < n_problems; ++p) ctx->align_result_dev_index.push_back((uint32_t)(dev_results_off + (size_t)p));
     ctx->align_pending_results += (size_t)n_problems;
+    ctx->align_pending_dev = dev_results_off + (size_t)n_desc + (size_t)n_problems;
   }
 #ifdef SVOH_PHASE_STAMPS
   {
@@ -2289,6 +2377,36 @@ try {
   return enqueue_align(ctx, options, n_problems, problems, -1);
 } SVOH_ABI_CATCH(ctx)
 
+int svoh_sparse_align_geometry_key(svoh_ctx* ctx, const svoh_align_options* options, const svoh_align_problem* problem, int32_t* key)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  const int rc = validate_options(ctx, options);
+  if (rc != SVOH_OK) return rc;
+  SVOH_REQUIRE(ctx, problem && key, "NULL argument");
+  SVOH_REQUIRE(ctx, problem->n_cams >= 1 && problem->n_cams <= SVOH_MAX_CAMS, "n_cams out of range");
+  *key = geometry_of_single(ctx, options, *problem).key();
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_sparse_align_enqueue_keyed(svoh_ctx* ctx, const svoh_align_options* options, int n_problems,
+                                    const svoh_align_problem* problems, int32_t key)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  AlignGeometry geo;
+  SVOH_REQUIRE(ctx, AlignGeometry::from_key(key, &geo), "not a geometry key of svoh_sparse_align_geometry_key");
+  SVOH_REQUIRE(ctx, n_problems >= 1 && problems, "no problems");
+  // cluster mode wants every workgroup of a launch on a compute unit of its own: more problems than that go out as
+  // several launches, one behind the other (their results queue up in problem order)
+  const int per_launch = geo.cluster_g >= 2 ? (ctx->num_cus / geo.cluster_g > 0 ? ctx->num_cus / geo.cluster_g : 1) : n_problems;
+  for (int p0 = 0; p0 < n_problems; p0 += per_launch) {
+    const int n = n_problems - p0 < per_launch ? n_problems - p0 : per_launch;
+    const int rc = enqueue_align(ctx, options, n, problems + p0, -1, nullptr, &geo);
+    if (rc != SVOH_OK) return rc;
+  }
+  // svoh_sparse_align_fetch hands out the LAST launch's results: a keyed call that was split is fetched with _fetch_all
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
 int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* results)
 try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
@@ -2299,6 +2417,7 @@ try {
   memcpy(results, static_cast<const svoh_align_result*>(ctx->h_results.ptr) + ctx->align_last_results_off,
          sizeof(svoh_align_result) * n_problems);
   ctx->align_pending_results = 0;
+  ctx->align_pending_dev = 0;
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
@@ -2311,6 +2430,7 @@ try {
   SVOH_ALIGN_DRAIN(ctx);
   memcpy(results, ctx->h_results.ptr, sizeof(svoh_align_result) * (size_t)n_results);
   ctx->align_pending_results = 0;
+  ctx->align_pending_dev = 0;
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 

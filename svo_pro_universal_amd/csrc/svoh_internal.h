@@ -123,10 +123,10 @@ struct SvohKnobs {
 #ifdef SVOH_TEST_HOOKS
   int align_cluster_test_absent = kKnobUnset; // SVOH_ALIGN_CLUSTER_TEST_ABSENT: a partner that never arrives (libsvo_hip_testhooks.so only)
 #endif
-  int align_threads = kKnobUnset;             // SVOH_ALIGN_THREADS: 256 / 512 / 1024
-  int align_rows = kKnobUnset;                // SVOH_ALIGN_ROWS: 0 / 1 rows geometry of the alignment (P lanes per patch; 512 / 1024 threads)
+  int align_threads = kKnobUnset;             // SVOH_ALIGN_THREADS: 256 / 512 (anything else = 256)
+  int align_rows = kKnobUnset;                // SVOH_ALIGN_ROWS: lanes per patch of the alignment's 512-thread geometry: 2, 4 or 8 (<= patch size); anything else = a lane per patch
   int align_latency_build = kKnobUnset;       // SVOH_ALIGN_LATENCY_BUILD: 0 = small launches use the batch build of the 256-thread kernel too
-  int align_lds = kKnobUnset;                 // SVOH_ALIGN_LDS: bytes of LDS for image levels
+  int align_lds = kKnobUnset;                 // SVOH_ALIGN_LDS: bytes of LDS for image levels (rounded down to a multiple of 16)
   int align_wg_per_cu = kKnobUnset;           // SVOH_ALIGN_WG_PER_CU
   int kernel_timing = kKnobUnset;             // SVOH_KERNEL_TIMING: 1 = bracket every kernel with an event pair (svoh_set_kernel_timing)
   int copy_kernel = kKnobUnset;               // SVOH_COPY_KERNEL: 0 = result blocks always come back through hipMemcpyAsync
@@ -159,6 +159,11 @@ struct svoh_ctx {
   // results of the launches queued since the last fetch, launch after launch in h_results
   static constexpr size_t kMaxQueuedResults = (size_t)1 << 18;
   size_t align_pending_results = 0, align_last_results_off = 0;
+  // ... and on the device: every launch since the last fetch has its own block of d_results (align_pending_dev results are
+  // taken), so that a candidate projection queued behind SEVERAL launches can read the result of any of them;
+  // align_result_dev_index[k] = where result #k of the queue lives in d_results
+  size_t align_pending_dev = 0;
+  std::vector<uint32_t> align_result_dev_index;
   // a ring of event pairs, one per alignment launch: callers that queue launches back to back (enqueue without
   // fetch) can still read every launch's device time afterwards
   static constexpr int kAlignEventRing = 32;
@@ -197,6 +202,9 @@ struct svoh_ctx {
   struct DeferredLaunch {              // a matcher launch waiting for svoh_matcher_collect (kernel arguments as bytes)
     std::vector<uint8_t> args;
     int n = 0, g8 = 0;
+    int max_w = 0, max_h = 0;          // largest reference frame (the packed geometry's spatial bins)
+    size_t out_off = 0, out_bytes = 0; // packed geometry: the batch's output area in its device block, zeroed ahead of the kernel
+    void* d_block = nullptr;
     bool valid = false;
     void* d2h_dst = nullptr; const void* d2h_src = nullptr; size_t d2h_bytes = 0;
     // the frame views of the batch in its staging blocks (svoh_matcher_deferred_set_cur_frame): n_ref reference frames, then the current one(s)
@@ -208,6 +216,13 @@ struct svoh_ctx {
   // can neither overwrite a queued batch's inputs before its copy has read them nor make reserve() free them
   svoh::DevBuffer d_match_seeds, d_match_direct;
   svoh::PinnedBuffer h_match_seeds, h_match_direct;
+  // svoh_matcher_stage: the layout of the block handed out for the section's direct [0] / seed [1] batch
+  struct MatcherStage {
+    bool valid = false, want_outputs = false;
+    int n = 0, max_views = 0;
+    size_t o_views = 0, o_idx = 0, o_cidx = 0, o_px = 0, o_f = 0, o_grad = 0, o_level = 0, o_type = 0, o_depth = 0, o_pxcur = 0, o_state = 0,
+           o_result = 0, o_success = 0, o_fcur = 0, o_slevel = 0, o_hinv = 0, o_A = 0, o_nsucc = 0, in_total = 0, back_from = 0, total = 0;
+  } matcher_stage[2];
 
   // candidate projection of the reprojector (svoh_project_candidates_enqueue / _collect): its own staging pair -- the
   // call is queued behind an alignment launch whose own staging is still in flight
@@ -215,6 +230,10 @@ struct svoh_ctx {
   svoh::PinnedBuffer h_cand;
   int cand_pending_n = 0;              // points of the queued call whose results wait in h_cand (0: nothing queued)
   size_t cand_out_off = 0;
+  // svoh_project_candidates_stage / _enqueue_staged / _wait: many jobs, staged in place (blocks of their own)
+  svoh::DevBuffer d_cand_multi;
+  svoh::PinnedBuffer h_cand_multi;
+  struct CandStage { int n_jobs = 0, n_kf = 0, n_points = 0; size_t o_jobs = 0, o_kf = 0, o_job = 0, o_kind = 0, o_idx = 0, o_v = 0, o_mu = 0, in_total = 0, o_px = 0, o_vis = 0, total = 0; int state = 0; } cand_stage;   // state: 0 none, 1 staged, 2 in flight
 
   svoh::DevBuffer d_seed_bin;          // packed seed update: histogram, ranks, sorted records (nothing else writes here)
   void* seed_hist_ptr = nullptr;       // the binning histogram at this address ...

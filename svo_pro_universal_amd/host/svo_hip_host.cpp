@@ -1,4 +1,5 @@
 #include "svo_hip_host.h"
+#include "svo_hip_host_internal.h"
 
 #include <algorithm>
 #include <chrono>
@@ -95,21 +96,27 @@ Transformation SparseImgAlignHip::buildProblem(const FrameBundle::Ptr& ref_frame
   return T_iref_world;
 }
 
-size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames)
+size_t SparseImgAlignHip::finishRun(const svoh_align_result& result, const FrameBundle::Ptr& cur_frames, const Transformation& T_iref_world)
 {
-  svoh_align_options opt;
-  svoh_align_problem pb;
-  const Transformation T_iref_world = buildProblem(ref_frames, cur_frames, 0, 1, opt, pb);
-  const int rc = svoh_sparse_align_batch(ctx_, &opt, 1, &pb, &last_);
-  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_sparse_align_batch: ") + svoh_last_error_string(ctx_));
+  last_ = result;
   if (last_.n_fts_to_track == 0) return 0;  // "no features to track" (sparse_img_align.cpp:53-57)
-
   // f->T_f_w_ = f->T_cam_imu() * state.T_icur_iref * T_iref_world_ (sparse_img_align.cpp:103-106)
   const Transformation T_opt = svoh::load_rigid(last_.T_icur_iref);
   for (const FramePtr& f : cur_frames->frames_) f->T_f_w_ = svoh::mul(svoh::mul(f->T_cam_imu(), T_opt), T_iref_world);
   alpha_init_ = 0.0;  // sparse_img_align.cpp:109-110
   beta_init_ = 0.0;
   return static_cast<size_t>(last_.n_fts_to_track);
+}
+
+size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames)
+{
+  svoh_align_options opt;
+  svoh_align_problem pb;
+  const Transformation T_iref_world = buildProblem(ref_frames, cur_frames, 0, 1, opt, pb);
+  svoh_align_result res{};
+  const int rc = svoh_sparse_align_batch(ctx_, &opt, 1, &pb, &res);
+  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_sparse_align_batch: ") + svoh_last_error_string(ctx_));
+  return finishRun(res, cur_frames, T_iref_world);
 }
 
 size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames, const AfterEnqueue& after_enqueue)
@@ -128,12 +135,8 @@ size_t SparseImgAlignHip::run(const FrameBundle::Ptr& ref_frames, const FrameBun
     rc = svoh_sparse_align_batch(ctx_, &opt, 1, &pb, &last_);
     if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_sparse_align_batch: ") + svoh_last_error_string(ctx_));
   }
-  if (last_.n_fts_to_track == 0) return 0;
-  const Transformation T_opt = svoh::load_rigid(last_.T_icur_iref);
-  for (const FramePtr& f : cur_frames->frames_) f->T_f_w_ = svoh::mul(svoh::mul(f->T_cam_imu(), T_opt), T_iref_world);
-  alpha_init_ = 0.0;
-  beta_init_ = 0.0;
-  return static_cast<size_t>(last_.n_fts_to_track);
+  const svoh_align_result res = last_;
+  return finishRun(res, cur_frames, T_iref_world);
 }
 
 size_t SparseImgAlignHip::runSplit(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames, int rank, int world,
@@ -247,7 +250,8 @@ DepthFilterHip::DepthFilterHip(svoh_ctx* ctx, const DepthFilterOptions& options)
   matcher_options_.affine_est_gain = options_.affine_est_gain;
 }
 
-static svoh_frame_view view_of(const Frame& f)
+namespace detail {
+svoh_frame_view viewOf(const Frame& f)
 {
   svoh_frame_view v{};
   v.frame = f.pyramid;
@@ -257,6 +261,8 @@ static svoh_frame_view view_of(const Frame& f)
   v.id = f.id();
   return v;
 }
+}  // namespace detail
+static svoh_frame_view view_of(const Frame& f) { return detail::viewOf(f); }
 
 size_t DepthFilterHip::updateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame)
 {
@@ -556,14 +562,10 @@ void DetectorHip::detect(svoh_frame_t img_pyr, const uint8_t* mask, int mask_pit
                          std::vector<double>& px_vec, std::vector<double>& score_vec, std::vector<int32_t>& level_vec,
                          std::vector<double>& grad_vec, std::vector<uint8_t>& types_vec)
 {
-  svoh_detector_options o{};
-  o.cell_size = static_cast<int32_t>(options_.cell_size);
-  o.max_level = options_.max_level; o.min_level = options_.min_level; o.border = options_.border;
-  o.detect_edgelets = options_.detector_type == DetectorType::kFastGrad;
-  o.threshold_primary = options_.threshold_primary; o.threshold_secondary = options_.threshold_secondary;
+  const svoh_detector_options o = abiOptions();
   const size_t n_cells = grid_.size();
   std::vector<uint8_t> occ(n_cells);
-  for (size_t k = 0; k < n_cells; ++k) occ[k] = grid_.isOccupied(k);
+  occupancyBytes(occ.data());
   std::vector<double> px(2 * n_cells), score(n_cells), grad(2 * n_cells);
   std::vector<int32_t> level(n_cells);
   std::vector<uint8_t> type(n_cells);
@@ -572,6 +574,42 @@ void DetectorHip::detect(svoh_frame_t img_pyr, const uint8_t* mask, int mask_pit
                                       static_cast<int>(std::min<size_t>(max_n_features, n_cells)), px.data(), score.data(),
                                       level.data(), grad.data(), type.data(), &n);
   if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_detect_features: ") + svoh_last_error_string(ctx_));
+  px_vec.insert(px_vec.end(), px.begin(), px.begin() + 2 * n);
+  score_vec.insert(score_vec.end(), score.begin(), score.begin() + n);
+  level_vec.insert(level_vec.end(), level.begin(), level.begin() + n);
+  grad_vec.insert(grad_vec.end(), grad.begin(), grad.begin() + 2 * n);
+  types_vec.insert(types_vec.end(), type.begin(), type.begin() + n);
+  resetGrid();   // FastDetector / FastGradDetector::detect end with resetGrid()
+}
+
+svoh_detector_options DetectorHip::abiOptions() const
+{
+  svoh_detector_options o{};
+  o.cell_size = static_cast<int32_t>(options_.cell_size);
+  o.max_level = options_.max_level; o.min_level = options_.min_level; o.border = options_.border;
+  o.detect_edgelets = options_.detector_type == DetectorType::kFastGrad;
+  o.threshold_primary = options_.threshold_primary; o.threshold_secondary = options_.threshold_secondary;
+  return o;
+}
+
+void DetectorHip::occupancyBytes(uint8_t* out) const
+{
+  for (size_t k = 0; k < grid_.size(); ++k) out[k] = grid_.isOccupied(k);
+}
+
+void DetectorHip::fillFromCells(const uint64_t* corner_keys, const uint64_t* edge_keys, const float* edge_angles, int width, int height,
+                                size_t max_n_features, std::vector<double>& px_vec, std::vector<double>& score_vec, std::vector<int32_t>& level_vec,
+                                std::vector<double>& grad_vec, std::vector<uint8_t>& types_vec)
+{
+  const svoh_detector_options o = abiOptions();
+  const size_t n_cells = grid_.size();
+  std::vector<double> px(2 * n_cells), score(n_cells), grad(2 * n_cells);
+  std::vector<int32_t> level(n_cells);
+  std::vector<uint8_t> type(n_cells);
+  int32_t n = 0;
+  const int rc = svoh_detect_fill_features(&o, width, height, corner_keys, edge_keys, edge_angles, static_cast<int>(std::min<size_t>(max_n_features, n_cells)),
+                                           px.data(), score.data(), level.data(), grad.data(), type.data(), &n);
+  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_detect_fill_features: ") + svoh_last_error_string(nullptr));
   px_vec.insert(px_vec.end(), px.begin(), px.begin() + 2 * n);
   score_vec.insert(score_vec.end(), score.begin(), score.begin() + n);
   level_vec.insert(level_vec.end(), level.begin(), level.begin() + n);
@@ -767,7 +805,7 @@ void PoseOptimizerHip::setRotationPrior(const svoh::Quat& R_frame_world, double 
 
 size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px) { return run(frame_bundle, reproj_thresh_px, nullptr); }
 
-size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px, const std::function<void()>& after_launch)
+void PoseOptimizerHip::prepareRun(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px, svoh_pose_options& o, svoh_pose_problem& pb)
 {
   if (!frame_bundle || frame_bundle->empty()) throw std::runtime_error("PoseOptimizer: FrameBundle is empty");   // CHECK
   const size_t nc = frame_bundle->size();
@@ -778,7 +816,7 @@ size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj
   static const double threshold_uplane = reproj_thresh_px / std::fabs(f0.cam.fx);
   static const double threshold_bearing_diff =
       std::fabs(2 * std::sin(0.5 * (std::atan(reproj_thresh_px / (2.0 * f0.cam.fx)) + std::atan(reproj_thresh_px / (2.0 * f0.cam.fy)))));
-  svoh_pose_options o{};
+  o = svoh_pose_options{};
   o.max_iter = static_cast<int32_t>(solver_options_.max_iter);
   o.eps = solver_options_.eps;
   o.error_type = err_type_ == ErrorType::kUnitPlane ? SVOH_POSE_ERR_UNIT_PLANE
@@ -789,11 +827,12 @@ size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj
   o.prior_lambda = prior_lambda_;
   o.R_prior[0] = R_prior_.w; o.R_prior[1] = R_prior_.x; o.R_prior[2] = R_prior_.y; o.R_prior[3] = R_prior_.z;
 
-  svoh_pose_problem pb{};
+  pb = svoh_pose_problem{};
   pb.n_cams = static_cast<int32_t>(nc);
   svoh::store_rigid(f0.T_imu_world(), pb.T_imu_world);
-  std::vector<std::vector<double>> xyz(nc);
-  std::vector<std::vector<uint8_t>> usable(nc), outlier(nc);
+  std::vector<std::vector<double>>& xyz = run_xyz_;
+  std::vector<std::vector<uint8_t>>&usable = run_usable_, &outlier = run_outlier_;
+  xyz.resize(nc); usable.resize(nc); outlier.resize(nc);
   size_t n_features = 0;
   for (size_t c = 0; c < nc; ++c) {
     Frame& fr = *frame_bundle->at(c);
@@ -825,26 +864,20 @@ size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj
     pc.type = fr.type_vec_.data(); pc.xyz_world = xyz[c].data(); pc.usable = usable[c].data(); pc.outlier = outlier[c].data();
   }
   if (n_features == 0) throw std::runtime_error("PoseOptimizer: No features in frames");   // CHECK_GT
-  int rc;
-  if (after_launch) {
-    // (an exception cannot cross the C boundary: it is carried over it)
-    struct Hook { const std::function<void()>* fn; std::exception_ptr error; } hook{ &after_launch, nullptr };
-    rc = svoh_optimize_pose_batch_hook(ctx_, &o, 1, &pb, &last_, [](void* user) {
-      Hook* h = static_cast<Hook*>(user);
-      try { (*h->fn)(); } catch (...) { h->error = std::current_exception(); }
-    }, &hook);
-    if (hook.error) std::rethrow_exception(hook.error);
-  } else {
-    rc = svoh_optimize_pose_batch(ctx_, &o, 1, &pb, &last_);
-  }
-  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_optimize_pose_batch: ") + svoh_last_error_string(ctx_));
+}
+
+size_t PoseOptimizerHip::finishRun(const FrameBundle::Ptr& frame_bundle, const svoh_pose_result& result)
+{
+  last_ = result;
+  const size_t nc = frame_bundle->size();
+  const Frame& f0 = *frame_bundle->at(0);
   measurement_sigma_ = last_.measurement_sigma;
   const Transformation T_imu_world = svoh::load_rigid(last_.T_imu_world);
   for (size_t c = 0; c < nc; ++c) {
     Frame& fr = *frame_bundle->at(c);
     fr.T_f_w_ = svoh::mul(fr.T_cam_imu(), T_imu_world);
     for (size_t i = 0; i < fr.num_features_; ++i)
-      if (outlier[c][i]) {
+      if (run_outlier_[c][i]) {
         fr.type_vec_[i] = SVOH_FT_OUTLIER;
         fr.seed_ref_vec_[i].keyframe.reset();
         fr.landmark_vec_[i] = nullptr;
@@ -854,6 +887,28 @@ size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj
   stats_.reproj_error_before = last_.reproj_error_before * error_scale;
   stats_.reproj_error_after = last_.reproj_error_after * error_scale;
   return static_cast<size_t>(last_.n_meas - last_.n_deleted_edges - last_.n_deleted_corners);
+}
+
+size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px, const std::function<void()>& after_launch)
+{
+  svoh_pose_options o;
+  svoh_pose_problem pb;
+  prepareRun(frame_bundle, reproj_thresh_px, o, pb);
+  svoh_pose_result res{};
+  int rc;
+  if (after_launch) {
+    // (an exception cannot cross the C boundary: it is carried over it)
+    struct Hook { const std::function<void()>* fn; std::exception_ptr error; } hook{ &after_launch, nullptr };
+    rc = svoh_optimize_pose_batch_hook(ctx_, &o, 1, &pb, &res, [](void* user) {
+      Hook* h = static_cast<Hook*>(user);
+      try { (*h->fn)(); } catch (...) { h->error = std::current_exception(); }
+    }, &hook);
+    if (hook.error) std::rethrow_exception(hook.error);
+  } else {
+    rc = svoh_optimize_pose_batch(ctx_, &o, 1, &pb, &res);
+  }
+  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_optimize_pose_batch: ") + svoh_last_error_string(ctx_));
+  return finishRun(frame_bundle, res);
 }
 
 void resolveAlignmentPoints(Frame& frame)
@@ -884,11 +939,17 @@ void initializeSeeds(const FramePtr& frame, DetectorHip& feature_detector, size_
 {
   const int max_n_features = static_cast<int>(max_n_seeds) - static_cast<int>(frame->num_features_);
   if (max_n_features <= 0) return;   // "Skip seed initialization. Have already enough features."
-  const size_t n_old = frame->num_features_;
   std::vector<double> px, score, grad;
   std::vector<int32_t> level;
   std::vector<uint8_t> type;
   feature_detector.detect(frame->pyramid, nullptr, 0, static_cast<size_t>(max_n_features), px, score, level, grad, type);
+  appendSeeds(frame, px, score, level, grad, type, depth_min, depth_mean);
+}
+
+void appendSeeds(const FramePtr& frame, const std::vector<double>& px, const std::vector<double>& score, const std::vector<int32_t>& level,
+                 const std::vector<double>& grad, const std::vector<uint8_t>& type, float depth_min, float depth_mean)
+{
+  const size_t n_old = frame->num_features_;
   const size_t n_new = level.size();
   const size_t n = n_old + n_new;
   frame->px_vec_.resize(2 * n_old); frame->px_vec_.insert(frame->px_vec_.end(), px.begin(), px.end());
@@ -1059,33 +1120,70 @@ static bool same_pose(const Transformation& a, const Transformation& b)
   return a.q.w == b.q.w && a.q.x == b.q.x && a.q.y == b.q.y && a.q.z == b.q.z && a.t.x == b.t.x && a.t.y == b.t.y && a.t.z == b.t.z;
 }
 
+ReprojectorHip::~ReprojectorHip() = default;
+
+void ReprojectorHip::countCandidateProjection(const std::vector<FramePtr>& kfs, size_t* n_points, size_t* n_kf) const
+{
+  size_t np = 0, nk = 0;
+  for (const FramePtr& kf : kfs) {
+    if (!kf || kf->num_features_ == 0) continue;
+    np += kf->num_features_;
+    ++nk;
+  }
+  if (n_points) *n_points = np;
+  if (n_kf) *n_kf = nk;
+}
+
+void ReprojectorHip::gatherCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const ProjectionArrays& into)
+{
+  proj_kf_off_.clear();
+  size_t at = 0;
+  int32_t k = 0;
+  for (const FramePtr& kf : kfs) {
+    if (!kf || kf->num_features_ == 0) continue;
+    svoh::store_rigid(svoh::inverse(kf->T_f_w_), into.T_world_kf[k]);
+    proj_kf_off_.push_back(ProjKf{ kf.get(), kf->id_, at, kf->num_features_, kf->T_f_w_ });
+    for (size_t i = 0; i < kf->num_features_; ++i, ++at) {
+      const PointPtr& lm = i < kf->landmark_vec_.size() ? kf->landmark_vec_[i] : PointPtr();
+      double* v = into.v + 3 * at;
+      if (lm) {                                       // getCandidate: the landmark's position ...
+        const svoh::Vec3 p = lm->pos();
+        into.kind[at] = 0; v[0] = p.x; v[1] = p.y; v[2] = p.z; into.mu[at] = 1.0;
+      } else {                                        // ... or T_world_cam() * getSeedPosInFrame(i)
+        into.kind[at] = 1;
+        v[0] = kf->f_vec_[3 * i]; v[1] = kf->f_vec_[3 * i + 1]; v[2] = kf->f_vec_[3 * i + 2];
+        into.mu[at] = 4 * i < kf->invmu_sigma2_a_b_vec_.size() ? kf->invmu_sigma2_a_b_vec_[4 * i] : 1.0;
+      }
+      into.kf[at] = k;
+    }
+    ++k;
+  }
+  proj_n_points_ = at; proj_n_kf_ = static_cast<size_t>(k);
+  proj_kind_p_ = into.kind; proj_v_p_ = into.v; proj_mu_p_ = into.mu;
+  proj_px_p_ = nullptr; proj_visible_p_ = nullptr;
+  proj_frame_ = at ? cur_frame.get() : nullptr;
+  proj_frame_id_ = cur_frame->id_;
+  proj_collected_ = false;
+}
+
+void ReprojectorHip::adoptCandidateProjection(const FramePtr& cur_frame, const double* px, const uint8_t* visible)
+{
+  if (proj_frame_ != cur_frame.get() || proj_frame_id_ != cur_frame->id_) throw std::runtime_error("ReprojectorHip::adoptCandidateProjection: not the frame whose projection was gathered");
+  proj_px_p_ = px; proj_visible_p_ = visible;
+  proj_collected_ = true;
+}
+
 void ReprojectorHip::enqueueCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const Transformation* T_iref_world,
                                                 int align_result_index)
 {
   discardCandidateProjection();
-  proj_kf_off_.clear(); proj_kind_.clear(); proj_kf_.clear(); proj_v_.clear(); proj_mu_.clear(); proj_T_world_kf_.clear();
-  for (const FramePtr& kf : kfs) {
-    if (!kf || kf->num_features_ == 0) continue;
-    const int32_t k = static_cast<int32_t>(proj_T_world_kf_.size());
-    svoh_se3 T;
-    svoh::store_rigid(svoh::inverse(kf->T_f_w_), T);
-    proj_T_world_kf_.push_back(T);
-    proj_kf_off_.push_back(ProjKf{ kf.get(), kf->id_, proj_kind_.size(), kf->num_features_, kf->T_f_w_ });
-    for (size_t i = 0; i < kf->num_features_; ++i) {
-      const PointPtr& lm = i < kf->landmark_vec_.size() ? kf->landmark_vec_[i] : PointPtr();
-      if (lm) {                                       // getCandidate: the landmark's position ...
-        const svoh::Vec3 p = lm->pos();
-        proj_kind_.push_back(0); proj_v_.insert(proj_v_.end(), { p.x, p.y, p.z }); proj_mu_.push_back(1.0);
-      } else {                                        // ... or T_world_cam() * getSeedPosInFrame(i)
-        proj_kind_.push_back(1);
-        proj_v_.insert(proj_v_.end(), { kf->f_vec_[3 * i], kf->f_vec_[3 * i + 1], kf->f_vec_[3 * i + 2] });
-        proj_mu_.push_back(4 * i < kf->invmu_sigma2_a_b_vec_.size() ? kf->invmu_sigma2_a_b_vec_[4 * i] : 1.0);
-      }
-      proj_kf_.push_back(k);
-    }
-  }
-  const int n = static_cast<int>(proj_kind_.size());
+  size_t n_points = 0, n_kf = 0;
+  countCandidateProjection(kfs, &n_points, &n_kf);
+  proj_kind_.resize(n_points); proj_kf_.resize(n_points); proj_v_.resize(3 * n_points); proj_mu_.resize(n_points); proj_T_world_kf_.resize(n_kf);
+  gatherCandidateProjection(cur_frame, kfs, ProjectionArrays{ proj_T_world_kf_.data(), proj_kind_.data(), proj_kf_.data(), proj_v_.data(), proj_mu_.data() });
+  const int n = static_cast<int>(n_points);
   if (n == 0) return;
+  proj_frame_ = nullptr;   // (set again below, once the call is queued)
   svoh_se3 Ta, Tb;
   int rc;
   if (align_result_index >= 0 && T_iref_world) {
@@ -1106,31 +1204,20 @@ void ReprojectorHip::enqueueCandidateProjection(const FramePtr& cur_frame, const
 
 void ReprojectorHip::discardCandidateProjection()
 {
-  if (proj_frame_ && !proj_collected_) {   // the queued call's results are dropped, the context is free for the next one
-    proj_px_.resize(2 * proj_kind_.size()); proj_visible_.resize(proj_kind_.size());
-    (void)svoh_project_candidates_collect(ctx_, static_cast<int>(proj_kind_.size()), proj_px_.data(), proj_visible_.data());
+  if (proj_frame_ && !proj_collected_ && proj_kind_p_ == proj_kind_.data()) {   // the queued call's results are dropped, the context is free for the next one
+    proj_px_.resize(2 * proj_n_points_); proj_visible_.resize(proj_n_points_);
+    (void)svoh_project_candidates_collect(ctx_, static_cast<int>(proj_n_points_), proj_px_.data(), proj_visible_.data());
   }
   proj_frame_ = nullptr;
   proj_collected_ = false;
 }
 
-void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs,
-                                     std::vector<PointPtr>& trash_points)
+void ReprojectorHip::walkCandidates(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points)
 {
-  const double ts0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
-  // device projection queued for this frame (enqueueCandidateProjection): take it out of the context now
-  // (pointer AND id: a frame destroyed with its projection still queued may be followed by a new one at the same address)
-  const bool have_proj = proj_frame_ == cur_frame.get() && proj_frame_id_ == cur_frame->id_;
-  if (have_proj && !proj_collected_) {
-    proj_px_.resize(2 * proj_kind_.size()); proj_visible_.resize(proj_kind_.size());
-    if (svoh_project_candidates_collect(ctx_, static_cast<int>(proj_kind_.size()), proj_px_.data(), proj_visible_.data()) != SVOH_OK)
-      throw std::runtime_error(std::string("svoh_project_candidates_collect: ") + svoh_last_error_string(ctx_));
-    proj_collected_ = true;
-  } else if (!have_proj) {
-    discardCandidateProjection();
-  }
-  struct ProjRelease { ReprojectorHip* r; bool on; ~ProjRelease() { if (on) { r->proj_frame_ = nullptr; r->proj_collected_ = false; } } } proj_release{ this, have_proj };
-  const size_t max_total_n_features = options_.max_n_features_per_frame;   // + max_n_fixed_lm, 0 without the global map
+  // device projection queued / adopted for this frame: pointer AND id (a frame destroyed with its projection still
+  // queued may be followed by a new one at the same address)
+  const bool have_proj = proj_frame_ == cur_frame.get() && proj_frame_id_ == cur_frame->id_ && proj_collected_;
+  have_proj_ = have_proj;
   if (options_.max_n_features_per_frame == 0) throw std::runtime_error("Reprojector: max_n_features_per_frame must be > 0");   // CHECK_GT
   if (!grid_)
     grid_.reset(new OccupandyGrid2D(static_cast<int>(options_.cell_size),
@@ -1138,16 +1225,14 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
                                     OccupandyGrid2D::getNCell(cur_frame->cam.height, static_cast<int>(options_.cell_size))));
   grid_->reset();
   stats_ = reprojector::Statistics();
-  auto add = [&](const reprojector::Statistics& st) { stats_.n_matches += st.n_matches; stats_.n_trials += st.n_trials; };
 
   // landmarks of the closest keyframes with overlap (:131-176), converged seeds (:201-241) and unconverged seeds
   // (:243-306): the three candidate lists depend on the visible keyframes and the current pose only, so one walk over
   // the keyframes' features gathers all of them (each list in the order its own loop of the reference gives), and they
   // are matched together
   candidates_.clear();
-  thread_local std::vector<reprojector::Candidate> converged, unconverged;
+  std::vector<reprojector::Candidate>&converged = converged_, &unconverged = unconverged_;
   converged.clear(); unconverged.clear();
-  struct Release { std::vector<reprojector::Candidate>&a, &b, &c; ~Release() { a.clear(); b.clear(); c.clear(); } } release{ candidates_, converged, unconverged };
   for (const FramePtr& ref_frame : visible_kfs) {
     const svoh::Rigid T_world_ref = svoh::inverse(ref_frame->T_f_w_);
     // this keyframe's slice of the device projection, if it was part of it
@@ -1168,14 +1253,14 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
         const size_t at = static_cast<size_t>(proj_off) + i;
         const Point* lm = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i].get() : nullptr;
         bool fresh;
-        if (lm) { const svoh::Vec3 p = lm->pos(); fresh = proj_kind_[at] == 0 && p.x == proj_v_[3 * at] && p.y == proj_v_[3 * at + 1] && p.z == proj_v_[3 * at + 2]; }
-        else fresh = proj_kind_[at] == 1 && (4 * i < ref_frame->invmu_sigma2_a_b_vec_.size() ? ref_frame->invmu_sigma2_a_b_vec_[4 * i] : 1.0) == proj_mu_[at];
+        if (lm) { const svoh::Vec3 p = lm->pos(); fresh = proj_kind_p_[at] == 0 && p.x == proj_v_p_[3 * at] && p.y == proj_v_p_[3 * at + 1] && p.z == proj_v_p_[3 * at + 2]; }
+        else fresh = proj_kind_p_[at] == 1 && (4 * i < ref_frame->invmu_sigma2_a_b_vec_.size() ? ref_frame->invmu_sigma2_a_b_vec_[4 * i] : 1.0) == proj_mu_p_[at];
         if (fresh) {
-          if (!proj_visible_[at]) return;
+          if (!proj_visible_p_[at]) return;
           list.emplace_back();
           reprojector::Candidate& candidate = list.back();
           candidate.ref_frame = ref_frame; candidate.ref_index = i;
-          candidate.cur_px[0] = proj_px_[2 * at]; candidate.cur_px[1] = proj_px_[2 * at + 1];
+          candidate.cur_px[0] = proj_px_p_[2 * at]; candidate.cur_px[1] = proj_px_p_[2 * at + 1];
           candidate.n_reproj = lm ? lm->n_succeeded_reproj_ - lm->n_failed_reproj_ : 0;
           candidate.score = i < ref_frame->score_vec_.size() ? ref_frame->score_vec_[i] : 0.0;
           candidate.type = ref_frame->type_vec_[i];
@@ -1203,13 +1288,44 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
       if (conv || unconv) emit_candidate(i, conv ? converged : unconverged);
     }
   }
-  // the three sortCandidatesByReprojStats calls (:188, 224, 263) happen inside matchCandidatesFused, while the matcher
-  // work of the lists is on the device
-  const double ts1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
-  const double ts3 = ts1;
+  // the projection has been consumed
+  if (have_proj) { proj_frame_ = nullptr; proj_collected_ = false; }
+}
 
+void ReprojectorHip::planMatches(const FramePtr& cur_frame, int n_speculated)
+{
+  if (!sm_) sm_.reset(new detail::SpeculativeMatches);   // keeps its buffers from frame to frame
+  sm_->clear();
+  n_speculated_ = n_speculated < 0 ? 0 : (n_speculated > 3 ? 3 : n_speculated);
+  std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged_, &unconverged_ };
+  plan_rs_.resize(3);
+  for (int k = 0; k < 3; ++k) plan_rs_[k].clear();
+  for (int k = 0; k < n_speculated_; ++k) plan_rs_[k] = sm_->plan(cur_frame, *lists[k]);
+}
+
+void ReprojectorHip::sortCandidateLists()
+{
+  // sortCandidatesByReprojStats of the three lists (reprojector.cpp:188, 224, 263) while the device works: what a
+  // candidate is matched against does not depend on its place in the list, only the replay's visiting order does
+  std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged_, &unconverged_ };
+  std::vector<uint32_t> order;
+  for (int k = 0; k < 3; ++k) {
+    reprojector_utils::sortCandidatesWithOrder(*lists[k], &order);
+    if (k < n_speculated_ && !order.empty()) {
+      std::vector<detail::Resolved> sorted(order.size());
+      for (size_t i = 0; i < order.size(); ++i) sorted[i] = std::move(plan_rs_[k][order[i]]);
+      plan_rs_[k].swap(sorted);
+    }
+  }
+}
+
+void ReprojectorHip::replayMatches(const FramePtr& cur_frame, svoh_ctx* ctx_for_unspeculated)
+{
+  const size_t max_total_n_features = options_.max_n_features_per_frame;   // + max_n_fixed_lm, 0 without the global map
+  std::vector<reprojector::Candidate>&converged = converged_, &unconverged = unconverged_;
   std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged, &unconverged };
   reprojector::Statistics st[3];
+  auto add = [&](const reprojector::Statistics& stt) { stats_.n_matches += stt.n_matches; stats_.n_trials += stt.n_trials; };
   auto before_pass = [&](int pass, size_t& max_n) -> bool {
     max_n = max_total_n_features;
     if (pass == 0) return true;
@@ -1242,21 +1358,90 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
       if (doesFrameHaveEnoughFeatures(cur_frame)) reprojector_utils::setGridCellsOccupied(unconverged, *grid_);    // :300-305
     }
   };
+  reached_unconverged_ = false;
+  for (int k = 0; k < 3; ++k) {
+    size_t max_n = 0;
+    if (stop || !before_pass(k, max_n)) break;
+    if (k < n_speculated_) sm_->replay(cur_frame, max_n, *lists[k], plan_rs_[k], *grid_, st[k]);
+    else {
+      // a pass nobody bet on: its own round trip
+      if (!ctx_for_unspeculated) throw std::runtime_error("ReprojectorHip::replayMatches: a pass that was not planned, and no context to match it on");
+      reprojector_utils::matchCandidates(ctx_for_unspeculated, cur_frame, max_n, options_.affine_est_offset, options_.affine_est_gain, *lists[k], *grid_, st[k],
+                                         options_.seed_sigma2_thresh);
+    }
+    if (k == 2) reached_unconverged_ = true;
+    after_pass(k);
+  }
+  // (the candidate lists are emptied on return: their buffers stay, the frame references go)
+  candidates_.clear(); converged.clear(); unconverged.clear();
+  sm_->clear();
+}
+
+void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs,
+                                     std::vector<PointPtr>& trash_points)
+{
+  const double ts0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  // device projection queued for this frame (enqueueCandidateProjection): take it out of the context now
+  const bool queued = proj_frame_ == cur_frame.get() && proj_frame_id_ == cur_frame->id_;
+  if (queued && !proj_collected_) {
+    proj_px_.resize(2 * proj_n_points_); proj_visible_.resize(proj_n_points_);
+    if (svoh_project_candidates_collect(ctx_, static_cast<int>(proj_n_points_), proj_px_.data(), proj_visible_.data()) != SVOH_OK)
+      throw std::runtime_error(std::string("svoh_project_candidates_collect: ") + svoh_last_error_string(ctx_));
+    proj_px_p_ = proj_px_.data(); proj_visible_p_ = proj_visible_.data();
+    proj_collected_ = true;
+  } else if (!queued) {
+    discardCandidateProjection();
+  }
+  // whatever happens below, no frame reference, no open deferred section and no stale projection stay behind
+  struct Release {
+    ReprojectorHip* r; svoh_ctx* c;
+    ~Release()
+    {
+      r->proj_frame_ = nullptr; r->proj_collected_ = false;
+      r->candidates_.clear(); r->converged_.clear(); r->unconverged_.clear();
+      if (r->sm_) { if (r->sm_->in_flight) { r->sm_->in_flight = false; (void)svoh_matcher_collect(c); } r->sm_->clear(); }
+    }
+  } release{ this, ctx_ };
+  walkCandidates(cur_frame, visible_kfs, trash_points);
+  // the three sortCandidatesByReprojStats calls (:188, 224, 263) happen below, while the matcher work of the lists is on
+  // the device
+  const double ts1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  if (g_reproj_timing.on) (void)svoh_set_kernel_timing(ctx_, 1);
   // The unconverged seeds are many (up to max_n_kfs x max_seeds per frame) and their pass is only reached when the
   // landmarks and converged seeds did not fill the frame: their matcher work joins the common round trip only if the
   // pass was reached on the previous frame (a wrong guess costs one extra round trip or some unused work, nothing else).
-  bool reached_unconverged = false;
-  auto after = [&](int pass) { if (pass == 2) reached_unconverged = true; after_pass(pass); };
-  reprojector_utils::matchCandidatesFused(ctx_, cur_frame, options_.affine_est_offset, options_.affine_est_gain, options_.seed_sigma2_thresh,
-                                          lists, [&](int pass, size_t& max_n) { return !stop && before_pass(pass, max_n); }, after,
-                                          *grid_, st, speculate_unconverged_ ? 3 : 2, true);
-  speculate_unconverged_ = reached_unconverged;
-  // (the candidate lists are emptied on return: their buffers stay, the frame references go)
+  // Reprojector::reprojectFrames' three matchCandidates passes (reprojector.cpp:177-306) with ONE round trip to the
+  // device: none of the three candidate lists depends on a match result (only on the visible keyframes and the current
+  // pose), so all three are planned first, their matcher work runs as one direct batch plus one seed batch queued back
+  // to back, and then the reference's control flow -- pass, enough-features test, grid marking, early return, the
+  // feature budget of the unconverged seeds -- is replayed on finished results.  Work of a pass the control flow never
+  // reaches is wasted, never visible: replay() alone touches the frame, the grid, the points and the seeds.
+  const int n_speculated = speculate_unconverged_ ? 3 : 2;
+  planMatches(cur_frame, n_speculated);
+  const double tp1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  sm_->enqueue(ctx_, cur_frame, options_.affine_est_offset, options_.affine_est_gain, options_.seed_sigma2_thresh);
+  const double tp2 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  sortCandidateLists();
+  const double tp3 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  sm_->finish(ctx_);
+  sm_->direct.useOwnOutputs(); sm_->seeds.useOwnOutputs();
+  double tp4 = tp3;
   if (g_reproj_timing.on) {
-    g_reproj_timing.n_reached3 += reached_unconverged;
+    g_reproj_timing.n_direct += (long)sm_->direct.size(); g_reproj_timing.n_seeds += (long)sm_->seeds.size(); g_reproj_timing.n_spec3 += n_speculated == 3;
+    float kms = 0.f;
+    if (svoh_last_kernel_ms(ctx_, &kms) == SVOH_OK) g_reproj_timing.kernel_ms += kms;
+    tp4 = ReprojTiming::now();
+  }
+  replayMatches(cur_frame, ctx_);
+  speculate_unconverged_ = reached_unconverged_;
+  if (g_reproj_timing.on) {
+    g_reproj_timing.n_reached3 += reached_unconverged_;
     const double ts4 = ReprojTiming::now();
-    g_reproj_timing.t[0] += ts1 - ts0; g_reproj_timing.t[1] += ts3 - ts1;
-    g_reproj_timing.t[5] += ts4 - ts3;   // plan + device + replay together (split below when the fused call reports it)
+    g_reproj_timing.t[0] += ts1 - ts0;                          // walk
+    g_reproj_timing.t[2] += tp1 - ts1;                          // plan
+    g_reproj_timing.t[3] += (tp2 - tp1) + (tp4 - tp3);          // device round trip(s)
+    g_reproj_timing.t[1] += tp3 - tp2;                          // sort
+    g_reproj_timing.t[5] += ts4 - tp4;                          // replay, grid
     ++g_reproj_timing.n;
     g_reproj_timing.end_call();
   }
@@ -1264,7 +1449,7 @@ void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vecto
 
 namespace reprojector_utils {
 // order[k] = where the k-th candidate of the sorted list stood before (empty for lists of fewer than two)
-static void sortCandidatesWithOrder(std::vector<reprojector::Candidate>& candidates, std::vector<uint32_t>* order)
+void sortCandidatesWithOrder(std::vector<reprojector::Candidate>& candidates, std::vector<uint32_t>* order)
 {
   // std::sort(candidates, type > , n_reproj > , score >) of reprojector.cpp:545-556.  The order of EQUAL candidates is
   // whatever libstdc++'s introsort leaves, and its moves depend on the comparison results only: sorting 24-byte keys
@@ -1360,6 +1545,12 @@ void setGridCellsOccupied(const std::vector<reprojector::Candidate>& candidates,
 
 namespace {
 thread_local std::vector<int32_t> g_last_results;
+}
+std::vector<int32_t>& g_last_results_ref() { return g_last_results; }
+const std::vector<int32_t>& lastMatchResults() { return g_last_results; }
+}  // namespace reprojector_utils
+
+namespace {
 bool is_edgelet(uint8_t t) { return t == SVOH_FT_EDGELET || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_EDGELET_SEED_CONVERGED; }
 bool is_converged_seed(uint8_t t)
 {
@@ -1373,249 +1564,213 @@ template <class T>
 void grow(std::vector<T>& v, size_t n, const T& fill = T()) { if (v.size() < n) v.resize(n, fill); }
 }  // namespace
 
-const std::vector<int32_t>& lastMatchResults() { return g_last_results; }
+// ---- detail::SpeculativeMatches (svo_hip_host_internal.h) ----
+namespace detail {
+using reprojector_utils::g_last_results_ref;
 
-// The matcher work of matchCandidate (reprojector.cpp:384-486) for every candidate, speculatively: it depends on no
-// match result, only on the candidate.  plan() resolves what each candidate matches against and appends it to one of
-// two batches (findMatchDirect / updateSeed); the batches of SEVERAL candidate lists can share one pair of launches
-// (run()); replay() is the reference's loop over one list (:356-381), reading the finished batches.
-namespace {
-enum Kind { kConvergedSeed = 0, kUnconvergedSeed = 1, kLandmark = 2, kNoCloseView = 3 };
-// ref / point: plain pointers.  The frame is kept alive by SpeculativeMatches::frames (every resolved frame has a slot
-// there), the landmark by its keyframe's landmark_vec_ -- a shared_ptr per candidate here costs two atomic operations
-// per candidate and list, on the frame's critical path.
-struct Resolved { Kind kind; Frame* ref; size_t idx; Point* point; int frame_slot; int batch_pos; };
-struct Batch {
-  std::vector<int32_t> ref_idx, level, result, search_level;
-  std::vector<double> px, f, grad, depth, state, px_cur, f_cur, A;
-  std::vector<uint8_t> type, success;
-  void reserve_more(size_t n)
-  {
-    const size_t m = level.size() + n;
-    ref_idx.reserve(m); level.reserve(m); type.reserve(m); px.reserve(2 * m); f.reserve(3 * m); grad.reserve(2 * m);
-    depth.reserve(m); px_cur.reserve(2 * m); state.reserve(4 * m);
-  }
-  void push(const Frame& r, size_t i, int slot)
-  {
-    ref_idx.push_back(slot); level.push_back(r.level_vec_[i]); type.push_back(r.type_vec_[i]);
-    const double* p = &r.px_vec_[2 * i]; px.push_back(p[0]); px.push_back(p[1]);
-    const double* q = &r.f_vec_[3 * i]; f.push_back(q[0]); f.push_back(q[1]); f.push_back(q[2]);
-    const double* g = &r.grad_vec_[2 * i]; grad.push_back(g[0]); grad.push_back(g[1]);
-  }
-  size_t size() const { return level.size(); }
-  void clear()
-  {
-    ref_idx.clear(); level.clear(); result.clear(); search_level.clear(); px.clear(); f.clear(); grad.clear(); depth.clear();
-    state.clear(); px_cur.clear(); f_cur.clear(); A.clear(); type.clear(); success.clear();
-  }
-};
-struct SpeculativeMatches {
-  std::vector<FramePtr> frames;   // distinct reference frames of all lists
-  Batch direct, seeds;
-  int last_slot = -1;
-  void clear() { frames.clear(); direct.clear(); seeds.clear(); last_slot = -1; }
-  int slot_of(const FramePtr& f)
-  {
-    if (last_slot >= 0 && frames[static_cast<size_t>(last_slot)].get() == f.get()) return last_slot;   // runs of one keyframe's features
-    for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == f) return last_slot = static_cast<int>(k);
-    frames.push_back(f);
-    return last_slot = static_cast<int>(frames.size() - 1);
-  }
-  // what each candidate of one list matches against
-  std::vector<Resolved> plan(const FramePtr& frame, const std::vector<reprojector::Candidate>& candidates)
-  {
-    const size_t n = candidates.size();
-    std::vector<Resolved> rs(n);
-    direct.reserve_more(n); seeds.reserve_more(n);
-    const svoh::Vec3 cur_pos = frame->pos();
-    for (size_t i = 0; i < n; ++i) {
-      const reprojector::Candidate& c = candidates[i];
-      if (!c.ref_frame || c.ref_index >= c.ref_frame->num_features_) throw std::runtime_error("matchCandidates: bad candidate");
-      Resolved& r = rs[i];
-      r.batch_pos = -1; r.frame_slot = -1; r.point = nullptr; r.ref = nullptr; r.idx = 0;
-      Point* lm = c.ref_index < c.ref_frame->landmark_vec_.size() ? c.ref_frame->landmark_vec_[c.ref_index].get() : nullptr;
-      if (!lm) {
-        r.ref = c.ref_frame.get(); r.idx = c.ref_index;
-        if (is_converged_seed(c.type)) r.kind = kConvergedSeed;
-        else if (is_unconverged_seed(c.type)) r.kind = kUnconvergedSeed;
-        else throw std::runtime_error("matchCandidates: seed type unknown");  // CHECK(false) in the reference
-        r.frame_slot = slot_of(c.ref_frame);
-      } else {
-        r.point = lm;
-        FramePtr rf; size_t ri = 0;
-        if (lm->getCloseViewObs(cur_pos, rf, ri)) { r.kind = kLandmark; r.ref = rf.get(); r.idx = ri; r.frame_slot = slot_of(rf); }
-        else r.kind = kNoCloseView;
+svoh_matcher_options reprojectorMatcherOptions(bool affine_est_offset, bool affine_est_gain)
+{
+  // Matcher matcher; (defaults of matcher.h:39-54) + the two affine flags (reprojector.cpp:352-354)
+  svoh_matcher_options mopt{};
+  mopt.align_max_iter = 10; mopt.max_epi_search_steps = 100; mopt.subpix_refinement = 1;
+  mopt.epi_search_edgelet_filtering = 1; mopt.scan_on_unit_sphere = 1;
+  mopt.epi_search_edgelet_max_angle = 0.7; mopt.max_patch_diff_ratio = 2.0;
+  mopt.affine_est_offset = affine_est_offset; mopt.affine_est_gain = affine_est_gain;
+  return mopt;
+}
+
+svoh_depth_filter_options reprojectorSeedOptions(const Frame& cur_frame, double seed_sigma2_thresh)
+{
+  svoh_depth_filter_options o{};
+  o.seed_convergence_sigma2_thresh = seed_sigma2_thresh;      // updateSeed(..., seed_sigma2_thresh, false, false):
+  o.mappoint_convergence_sigma2_thresh = seed_sigma2_thresh;  // one threshold for every seed type here
+  o.px_error_angle = updateSeedPxErrorAngle(cur_frame);
+  o.check_visibility = 0; o.check_convergence = 0; o.use_vogiatzis_update = 1;
+  return o;
+}
+
+int SpeculativeMatches::slot_of(const FramePtr& f)
+{
+  if (last_slot >= 0 && frames[static_cast<size_t>(last_slot)].get() == f.get()) return last_slot;   // runs of one keyframe's features
+  for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == f) return last_slot = static_cast<int>(k);
+  frames.push_back(f);
+  return last_slot = static_cast<int>(frames.size() - 1);
+}
+
+std::vector<Resolved> SpeculativeMatches::plan(const FramePtr& frame, const std::vector<reprojector::Candidate>& candidates)
+{
+  const size_t n = candidates.size();
+  std::vector<Resolved> rs(n);
+  direct.reserve_more(n); seeds.reserve_more(n);
+  const svoh::Vec3 cur_pos = frame->pos();
+  for (size_t i = 0; i < n; ++i) {
+    const reprojector::Candidate& c = candidates[i];
+    if (!c.ref_frame || c.ref_index >= c.ref_frame->num_features_) throw std::runtime_error("matchCandidates: bad candidate");
+    Resolved& r = rs[i];
+    r.batch_pos = -1; r.frame_slot = -1; r.point = nullptr; r.ref = nullptr; r.idx = 0;
+    Point* lm = c.ref_index < c.ref_frame->landmark_vec_.size() ? c.ref_frame->landmark_vec_[c.ref_index].get() : nullptr;
+    if (!lm) {
+      r.ref = c.ref_frame.get(); r.idx = c.ref_index;
+      if (is_converged_seed(c.type)) r.kind = kConvergedSeed;
+      else if (is_unconverged_seed(c.type)) r.kind = kUnconvergedSeed;
+      else throw std::runtime_error("matchCandidates: seed type unknown");  // CHECK(false) in the reference
+      r.frame_slot = slot_of(c.ref_frame);
+    } else {
+      r.point = lm;
+      FramePtr rf; size_t ri = 0;
+      if (lm->getCloseViewObs(cur_pos, rf, ri)) { r.kind = kLandmark; r.ref = rf.get(); r.idx = ri; r.frame_slot = slot_of(rf); }
+      else r.kind = kNoCloseView;
+    }
+    if (r.kind == kConvergedSeed || r.kind == kLandmark) {
+      r.batch_pos = static_cast<int>(direct.size());
+      direct.push(*r.ref, r.idx, r.frame_slot);
+      if (r.kind == kConvergedSeed) direct.depth.push_back(r.ref->getSeedDepth(r.idx));
+      else {
+        const svoh::Vec3 p = r.ref->pos(), q = r.point->pos();  // (ref_frame->pos() - landmark->pos()).norm()
+        direct.depth.push_back(sqrt((p.x - q.x) * (p.x - q.x) + (p.y - q.y) * (p.y - q.y) + (p.z - q.z) * (p.z - q.z)));
       }
-      if (r.kind == kConvergedSeed || r.kind == kLandmark) {
-        r.batch_pos = static_cast<int>(direct.size());
-        direct.push(*r.ref, r.idx, r.frame_slot);
-        if (r.kind == kConvergedSeed) direct.depth.push_back(r.ref->getSeedDepth(r.idx));
-        else {
-          const svoh::Vec3 p = r.ref->pos(), q = r.point->pos();  // (ref_frame->pos() - landmark->pos()).norm()
-          direct.depth.push_back(sqrt((p.x - q.x) * (p.x - q.x) + (p.y - q.y) * (p.y - q.y) + (p.z - q.z) * (p.z - q.z)));
-        }
-        direct.px_cur.push_back(c.cur_px[0]); direct.px_cur.push_back(c.cur_px[1]);
-      } else if (r.kind == kUnconvergedSeed) {
-        r.batch_pos = static_cast<int>(seeds.size());
-        seeds.push(*r.ref, r.idx, r.frame_slot);
-        const double* st = &r.ref->invmu_sigma2_a_b_vec_[4 * r.idx];
-        seeds.state.push_back(st[0]); seeds.state.push_back(st[1]); seeds.state.push_back(st[2]); seeds.state.push_back(st[3]);
-      }
+      direct.px_cur.push_back(c.cur_px[0]); direct.px_cur.push_back(c.cur_px[1]);
+    } else if (r.kind == kUnconvergedSeed) {
+      r.batch_pos = static_cast<int>(seeds.size());
+      seeds.push(*r.ref, r.idx, r.frame_slot);
+      const double* st = &r.ref->invmu_sigma2_a_b_vec_[4 * r.idx];
+      seeds.state.push_back(st[0]); seeds.state.push_back(st[1]); seeds.state.push_back(st[2]); seeds.state.push_back(st[3]);
     }
-    return rs;
   }
-  // both batches, queued back to back and sent to the device (svoh_matcher_begin_deferred / flush): nothing is waited
-  // for.  finish() is the one wait (svoh_matcher_collect); the caller may work in between -- the reprojector sorts its
-  // candidate lists there, which the matcher work does not depend on.
-  bool in_flight = false;
-  void enqueue(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh)
-  {
-    if (!direct.size() && !seeds.size()) return;
-    // Matcher matcher; (defaults of matcher.h:39-54) + the two affine flags (reprojector.cpp:352-354)
-    svoh_matcher_options mopt{};
-    mopt.align_max_iter = 10; mopt.max_epi_search_steps = 100; mopt.subpix_refinement = 1;
-    mopt.epi_search_edgelet_filtering = 1; mopt.scan_on_unit_sphere = 1;
-    mopt.epi_search_edgelet_max_angle = 0.7; mopt.max_patch_diff_ratio = 2.0;
-    mopt.affine_est_offset = affine_est_offset; mopt.affine_est_gain = affine_est_gain;
-    thread_local std::vector<svoh_frame_view> views;
-    views.clear();
-    for (const FramePtr& f : frames) {
-      svoh_frame_view v{};
-      v.frame = f->pyramid; v.cam = f->cam; svoh::store_rigid(f->T_f_w_, v.T_f_w);
-      v.seed_mu_range = f->seed_mu_range_; v.id = f->id();
-      views.push_back(v);
+  return rs;
+}
+
+void SpeculativeMatches::enqueue(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh)
+{
+  if (!direct.size() && !seeds.size()) return;
+  const svoh_matcher_options mopt = reprojectorMatcherOptions(affine_est_offset, affine_est_gain);
+  thread_local std::vector<svoh_frame_view> views;
+  views.clear();
+  for (const FramePtr& f : frames) views.push_back(viewOf(*f));
+  const svoh_frame_view cur = viewOf(*frame);
+  auto batch_of = [](Batch& b) {
+    svoh_feature_batch fb{};
+    fb.n = static_cast<int32_t>(b.size());
+    fb.ref_frame_idx = b.ref_idx.data(); fb.px = b.px.data(); fb.f = b.f.data(); fb.grad = b.grad.data();
+    fb.level = b.level.data(); fb.type = b.type.data();
+    return fb;
+  };
+  auto fail = [&](const char* what) {
+    const std::string msg = std::string(what) + ": " + svoh_last_error_string(ctx);
+    (void)svoh_matcher_collect(ctx);   // leave no open section behind
+    throw std::runtime_error(msg);
+  };
+  // a seed update still in flight (DepthFilterHip::updateSeedsAsync) holds the context's one deferred section: a batch
+  // issued now would be queued INTO it instead of running -- finish the update first
+  finishPendingSeedUpdate(ctx);
+  if (svoh_matcher_begin_deferred(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_begin_deferred: ") + svoh_last_error_string(ctx));
+  svoh_feature_batch fbd{}, fbs{};
+  const double tr0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  if (direct.size()) {
+    const size_t m = direct.size();
+    // (outputs: svoh_matcher_collect writes every entry of each -- no fill needed)
+    direct.result.resize(m); direct.search_level.resize(m); direct.f_cur.resize(3 * m); direct.A.resize(4 * m);
+    fbd = batch_of(direct);
+    const int rc = svoh_match_direct_batch(ctx, &mopt, static_cast<int>(views.size()), views.data(), &cur, &fbd,
+                                           direct.depth.data(), direct.px_cur.data(), direct.result.data(),
+                                           direct.f_cur.data(), direct.search_level.data(), nullptr, direct.A.data());
+    if (rc != SVOH_OK) fail("svoh_match_direct_batch");
+  }
+  const double tr1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  if (seeds.size()) {
+    const size_t m = seeds.size();
+    seeds.result.resize(m); seeds.search_level.resize(m); seeds.success.resize(m);
+    seeds.px_cur.resize(2 * m); seeds.f_cur.resize(3 * m); seeds.A.resize(4 * m);
+    fbs = batch_of(seeds);
+    const svoh_depth_filter_options o = reprojectorSeedOptions(*frame, seed_sigma2_thresh);
+    const svoh_seed_match_outputs outs{ seeds.px_cur.data(), seeds.f_cur.data(), seeds.search_level.data(), seeds.A.data() };
+    const int rc = svoh_update_seeds_batch_ex(ctx, &mopt, &o, static_cast<int>(views.size()), views.data(), &cur, &fbs,
+                                              seeds.state.data(), seeds.success.data(), seeds.result.data(), nullptr, &outs);
+    if (rc != SVOH_OK) fail("svoh_update_seeds_batch_ex");
+  }
+  if (svoh_matcher_flush(ctx) != SVOH_OK) fail("svoh_matcher_flush");
+  in_flight = true;
+  if (g_reproj_timing.on) { const double tr2 = ReprojTiming::now(); g_reproj_timing.rt[0] += tr1 - tr0; g_reproj_timing.rt[1] += tr2 - tr1; }
+}
+
+void SpeculativeMatches::finish(svoh_ctx* ctx)
+{
+  if (!in_flight) return;
+  in_flight = false;
+  const double tr2 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
+  if (svoh_matcher_collect(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_collect: ") + svoh_last_error_string(ctx));
+  if (g_reproj_timing.on) g_reproj_timing.rt[2] += ReprojTiming::now() - tr2;
+}
+
+void SpeculativeMatches::replay(const FramePtr& frame, size_t max_n_features_per_frame, std::vector<reprojector::Candidate>& candidates,
+                                const std::vector<Resolved>& rs, OccupandyGrid2D& grid, reprojector::Statistics& stats)
+{
+  std::vector<int32_t>& g_last_results = g_last_results_ref();
+  const size_t n = candidates.size();
+  g_last_results.assign(n, -1);
+  size_t i = 0;
+  for (size_t k = 0; k < n; ++k) {
+    reprojector::Candidate& c = candidates[k];
+    const Resolved& r = rs[k];
+    ++i;
+    const size_t grid_index = grid.getCellIndex(static_cast<int>(c.cur_px[0]), static_cast<int>(c.cur_px[1]), 1);
+    if (max_n_features_per_frame > 0 && grid.isOccupied(grid_index)) continue;
+    ++stats.n_trials;
+    bool ok = false;
+    const Batch* b = nullptr;
+    if (r.kind == kConvergedSeed || r.kind == kLandmark) {
+      b = &direct;
+      const int res = direct.out.result[r.batch_pos];
+      g_last_results[k] = res;
+      ok = res == SVOH_MATCH_SUCCESS;
+      c.cur_px[0] = direct.out.px_cur[2 * r.batch_pos]; c.cur_px[1] = direct.out.px_cur[2 * r.batch_pos + 1];  // Keypoint& px_cur
+      if (r.kind == kLandmark) { if (ok) r.point->n_succeeded_reproj_ += 1; else r.point->n_failed_reproj_++; }
+    } else if (r.kind == kUnconvergedSeed) {
+      b = &seeds;
+      g_last_results[k] = seeds.out.result[r.batch_pos];
+      ok = seeds.out.success[r.batch_pos] != 0;
+      // updateSeed changed the seed of the reference frame whether it succeeded or not
+      std::copy(seeds.out.state + 4 * r.batch_pos, seeds.out.state + 4 * r.batch_pos + 4, r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx);
+      r.ref->type_vec_[r.idx] = seeds.out.type[r.batch_pos];
+    } else {
+      g_last_results[k] = 1000;
     }
-    svoh_frame_view cur{};
-    cur.frame = frame->pyramid; cur.cam = frame->cam; svoh::store_rigid(frame->T_f_w_, cur.T_f_w);
-    cur.seed_mu_range = frame->seed_mu_range_; cur.id = frame->id();
-    auto batch_of = [](Batch& b) {
-      svoh_feature_batch fb{};
-      fb.n = static_cast<int32_t>(b.size());
-      fb.ref_frame_idx = b.ref_idx.data(); fb.px = b.px.data(); fb.f = b.f.data(); fb.grad = b.grad.data();
-      fb.level = b.level.data(); fb.type = b.type.data();
-      return fb;
-    };
-    auto fail = [&](const char* what) {
-      const std::string msg = std::string(what) + ": " + svoh_last_error_string(ctx);
-      (void)svoh_matcher_collect(ctx);   // leave no open section behind
-      throw std::runtime_error(msg);
-    };
-    // a seed update still in flight (DepthFilterHip::updateSeedsAsync) holds the context's one deferred section: a batch
-    // issued now would be queued INTO it instead of running -- finish the update first
-    finishPendingSeedUpdate(ctx);
-    if (svoh_matcher_begin_deferred(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_begin_deferred: ") + svoh_last_error_string(ctx));
-    svoh_feature_batch fbd{}, fbs{};
-    const double tr0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
-    if (direct.size()) {
-      const size_t m = direct.size();
-      // (outputs: svoh_matcher_collect writes every entry of each -- no fill needed)
-      direct.result.resize(m); direct.search_level.resize(m); direct.f_cur.resize(3 * m); direct.A.resize(4 * m);
-      fbd = batch_of(direct);
-      const int rc = svoh_match_direct_batch(ctx, &mopt, static_cast<int>(views.size()), views.data(), &cur, &fbd,
-                                             direct.depth.data(), direct.px_cur.data(), direct.result.data(),
-                                             direct.f_cur.data(), direct.search_level.data(), nullptr, direct.A.data());
-      if (rc != SVOH_OK) fail("svoh_match_direct_batch");
+    if (!ok) continue;
+    // matchCandidate's tail (:455-486): fill the first free slot of the frame
+    const size_t s = frame->num_features_;
+    grow(frame->px_vec_, 2 * (s + 1)); grow(frame->f_vec_, 3 * (s + 1)); grow(frame->grad_vec_, 2 * (s + 1));
+    grow(frame->level_vec_, s + 1); grow(frame->type_vec_, s + 1); grow(frame->score_vec_, s + 1);
+    grow(frame->invmu_sigma2_a_b_vec_, 4 * (s + 1)); grow(frame->landmark_vec_, s + 1); grow(frame->seed_ref_vec_, s + 1);
+    const int p = r.batch_pos;
+    if (is_edgelet(c.type)) {
+      const double* A = &b->out.A[4 * p];
+      const double* g = &r.ref->grad_vec_[2 * r.idx];
+      double g0 = A[0] * g[0] + A[2] * g[1], g1 = A[1] * g[0] + A[3] * g[1];
+      const double z = g0 * g0 + g1 * g1;
+      if (z > 0.0) { const double nn = sqrt(z); g0 /= nn; g1 /= nn; }
+      frame->grad_vec_[2 * s] = g0; frame->grad_vec_[2 * s + 1] = g1;
     }
-    const double tr1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
-    if (seeds.size()) {
-      const size_t m = seeds.size();
-      seeds.result.resize(m); seeds.search_level.resize(m); seeds.success.resize(m);
-      seeds.px_cur.resize(2 * m); seeds.f_cur.resize(3 * m); seeds.A.resize(4 * m);
-      fbs = batch_of(seeds);
-      svoh_depth_filter_options o{};
-      o.seed_convergence_sigma2_thresh = seed_sigma2_thresh;      // updateSeed(..., seed_sigma2_thresh, false, false):
-      o.mappoint_convergence_sigma2_thresh = seed_sigma2_thresh;  // one threshold for every seed type here
-      o.px_error_angle = updateSeedPxErrorAngle(*frame);
-      o.check_visibility = 0; o.check_convergence = 0; o.use_vogiatzis_update = 1;
-      const svoh_seed_match_outputs outs{ seeds.px_cur.data(), seeds.f_cur.data(), seeds.search_level.data(), seeds.A.data() };
-      const int rc = svoh_update_seeds_batch_ex(ctx, &mopt, &o, static_cast<int>(views.size()), views.data(), &cur, &fbs,
-                                                seeds.state.data(), seeds.success.data(), seeds.result.data(), nullptr, &outs);
-      if (rc != SVOH_OK) fail("svoh_update_seeds_batch_ex");
-    }
-    if (svoh_matcher_flush(ctx) != SVOH_OK) fail("svoh_matcher_flush");
-    in_flight = true;
-    if (g_reproj_timing.on) { const double tr2 = ReprojTiming::now(); g_reproj_timing.rt[0] += tr1 - tr0; g_reproj_timing.rt[1] += tr2 - tr1; }
+    frame->type_vec_[s] = c.type;
+    frame->px_vec_[2 * s] = b->out.px_cur[2 * p]; frame->px_vec_[2 * s + 1] = b->out.px_cur[2 * p + 1];
+    for (int j = 0; j < 3; ++j) frame->f_vec_[3 * s + j] = b->out.f_cur[3 * p + j];
+    frame->level_vec_[s] = b->out.search_level[p];
+    frame->score_vec_[s] = c.score;
+    if (r.kind == kLandmark) frame->landmark_vec_[s] = c.ref_frame->landmark_vec_[c.ref_index];   // == r.point, as the shared_ptr
+    else { frame->seed_ref_vec_[s].keyframe = c.ref_frame; frame->seed_ref_vec_[s].seed_id = static_cast<int>(c.ref_index); }
+    std::copy(c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index,
+              c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index + 4, frame->invmu_sigma2_a_b_vec_.begin() + 4 * s);
+    ++stats.n_matches;
+    ++frame->num_features_;
+    grid.setOccupied(grid_index);
+    if (max_n_features_per_frame > 0 && frame->num_features_ >= max_n_features_per_frame) break;
   }
-  void finish(svoh_ctx* ctx)
-  {
-    if (!in_flight) return;
-    in_flight = false;
-    const double tr2 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
-    if (svoh_matcher_collect(ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_matcher_collect: ") + svoh_last_error_string(ctx));
-    if (g_reproj_timing.on) g_reproj_timing.rt[2] += ReprojTiming::now() - tr2;
-  }
-  void run(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh)
-  {
-    enqueue(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
-    finish(ctx);
-  }
-  // the reference's loop over one candidate list, in candidate order (reprojector.cpp:356-381)
-  void replay(const FramePtr& frame, size_t max_n_features_per_frame, std::vector<reprojector::Candidate>& candidates,
-              const std::vector<Resolved>& rs, OccupandyGrid2D& grid, reprojector::Statistics& stats)
-  {
-    const size_t n = candidates.size();
-    g_last_results.assign(n, -1);
-    size_t i = 0;
-    for (size_t k = 0; k < n; ++k) {
-      reprojector::Candidate& c = candidates[k];
-      const Resolved& r = rs[k];
-      ++i;
-      const size_t grid_index = grid.getCellIndex(static_cast<int>(c.cur_px[0]), static_cast<int>(c.cur_px[1]), 1);
-      if (max_n_features_per_frame > 0 && grid.isOccupied(grid_index)) continue;
-      ++stats.n_trials;
-      bool ok = false;
-      const Batch* b = nullptr;
-      if (r.kind == kConvergedSeed || r.kind == kLandmark) {
-        b = &direct;
-        const int res = direct.result[r.batch_pos];
-        g_last_results[k] = res;
-        ok = res == SVOH_MATCH_SUCCESS;
-        c.cur_px[0] = direct.px_cur[2 * r.batch_pos]; c.cur_px[1] = direct.px_cur[2 * r.batch_pos + 1];  // Keypoint& px_cur
-        if (r.kind == kLandmark) { if (ok) r.point->n_succeeded_reproj_ += 1; else r.point->n_failed_reproj_++; }
-      } else if (r.kind == kUnconvergedSeed) {
-        b = &seeds;
-        g_last_results[k] = seeds.result[r.batch_pos];
-        ok = seeds.success[r.batch_pos] != 0;
-        // updateSeed changed the seed of the reference frame whether it succeeded or not
-        std::copy(seeds.state.begin() + 4 * r.batch_pos, seeds.state.begin() + 4 * r.batch_pos + 4,
-                  r.ref->invmu_sigma2_a_b_vec_.begin() + 4 * r.idx);
-        r.ref->type_vec_[r.idx] = seeds.type[r.batch_pos];
-      } else {
-        g_last_results[k] = 1000;
-      }
-      if (!ok) continue;
-      // matchCandidate's tail (:455-486): fill the first free slot of the frame
-      const size_t s = frame->num_features_;
-      grow(frame->px_vec_, 2 * (s + 1)); grow(frame->f_vec_, 3 * (s + 1)); grow(frame->grad_vec_, 2 * (s + 1));
-      grow(frame->level_vec_, s + 1); grow(frame->type_vec_, s + 1); grow(frame->score_vec_, s + 1);
-      grow(frame->invmu_sigma2_a_b_vec_, 4 * (s + 1)); grow(frame->landmark_vec_, s + 1); grow(frame->seed_ref_vec_, s + 1);
-      const int p = r.batch_pos;
-      if (is_edgelet(c.type)) {
-        const double* A = &b->A[4 * p];
-        const double* g = &r.ref->grad_vec_[2 * r.idx];
-        double g0 = A[0] * g[0] + A[2] * g[1], g1 = A[1] * g[0] + A[3] * g[1];
-        const double z = g0 * g0 + g1 * g1;
-        if (z > 0.0) { const double nn = sqrt(z); g0 /= nn; g1 /= nn; }
-        frame->grad_vec_[2 * s] = g0; frame->grad_vec_[2 * s + 1] = g1;
-      }
-      frame->type_vec_[s] = c.type;
-      frame->px_vec_[2 * s] = b->px_cur[2 * p]; frame->px_vec_[2 * s + 1] = b->px_cur[2 * p + 1];
-      for (int j = 0; j < 3; ++j) frame->f_vec_[3 * s + j] = b->f_cur[3 * p + j];
-      frame->level_vec_[s] = b->search_level[p];
-      frame->score_vec_[s] = c.score;
-      if (r.kind == kLandmark) frame->landmark_vec_[s] = c.ref_frame->landmark_vec_[c.ref_index];   // == r.point, as the shared_ptr
-      else { frame->seed_ref_vec_[s].keyframe = c.ref_frame; frame->seed_ref_vec_[s].seed_id = static_cast<int>(c.ref_index); }
-      std::copy(c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index,
-                c.ref_frame->invmu_sigma2_a_b_vec_.begin() + 4 * c.ref_index + 4, frame->invmu_sigma2_a_b_vec_.begin() + 4 * s);
-      ++stats.n_matches;
-      ++frame->num_features_;
-      grid.setOccupied(grid_index);
-      if (max_n_features_per_frame > 0 && frame->num_features_ >= max_n_features_per_frame) break;
-    }
-    candidates.erase(candidates.begin(), candidates.begin() + static_cast<std::ptrdiff_t>(i));
-  }
-};
-}  // namespace
+  candidates.erase(candidates.begin(), candidates.begin() + static_cast<std::ptrdiff_t>(i));
+}
+}  // namespace detail
+
+namespace reprojector_utils {
+using detail::SpeculativeMatches;
+using detail::Resolved;
 
 void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features_per_frame, bool affine_est_offset,
                      bool affine_est_gain, std::vector<reprojector::Candidate>& candidates, OccupandyGrid2D& grid,
@@ -1628,35 +1783,26 @@ void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features
   SpeculativeMatches sm;
   const std::vector<Resolved> rs = sm.plan(frame, candidates);
   sm.run(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
+  sm.direct.useOwnOutputs(); sm.seeds.useOwnOutputs();
   sm.replay(frame, max_n_features_per_frame, candidates, rs, grid, stats);
 }
 
 // Reprojector::reprojectFrames' three matchCandidates passes (reprojector.cpp:177-306) with ONE round trip to the
-// device: none of the three candidate lists depends on a match result (only on the visible keyframes and the current
-// pose), so all three are planned first, their matcher work runs as one direct batch plus one seed batch queued back
-// to back, and then the reference's control flow -- pass, enough-features test, grid marking, early return, the
-// feature budget of the unconverged seeds -- is replayed on finished results.  Work of a pass the control flow never
-// reaches is wasted, never visible: replay() alone touches the frame, the grid, the points and the seeds.
+// device (see ReprojectorHip::reprojectFrames, which is made of the same pieces): plan, send off, sort, wait, replay.
 void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh,
                           std::vector<reprojector::Candidate>* lists[3], const std::function<bool(int pass, size_t& max_n)>& before_pass,
                           const std::function<void(int pass)>& after_pass, OccupandyGrid2D& grid, reprojector::Statistics stats[3],
                           int n_speculated, bool sort_in_flight)
 {
   if (!ctx) throw std::runtime_error("matchCandidatesFused: NULL svoh_ctx (no CPU fallback exists)");
-  if (g_reproj_timing.on) (void)svoh_set_kernel_timing(ctx, 1);
   thread_local SpeculativeMatches sm;   // keeps its buffers from frame to frame ...
   sm.clear();
   // ... but no frame reference past the call, and no deferred section left open if something throws in between
   struct Release { SpeculativeMatches& s; svoh_ctx* c; ~Release() { if (s.in_flight) { s.in_flight = false; (void)svoh_matcher_collect(c); } s.clear(); } } release{ sm, ctx };
   std::vector<Resolved> rs[3];
-  const double tp0 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   for (int k = 0; k < 3 && k < n_speculated; ++k) rs[k] = sm.plan(frame, *lists[k]);
-  const double tp1 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   sm.enqueue(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
-  const double tp2 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   if (sort_in_flight) {
-    // sortCandidatesByReprojStats of the three lists (reprojector.cpp:188, 224, 263) while the device works: what a
-    // candidate is matched against does not depend on its place in the list, only the replay's visiting order does
     thread_local std::vector<uint32_t> order;
     for (int k = 0; k < 3; ++k) {
       sortCandidatesWithOrder(*lists[k], &order);
@@ -1667,14 +1813,8 @@ void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_
       }
     }
   }
-  const double tp3 = g_reproj_timing.on ? ReprojTiming::now() : 0.0;
   sm.finish(ctx);
-  if (g_reproj_timing.on) { g_reproj_timing.n_direct += (long)sm.direct.size(); g_reproj_timing.n_seeds += (long)sm.seeds.size(); g_reproj_timing.n_spec3 += n_speculated == 3; }
-  if (g_reproj_timing.on) { float kms = 0.f; if (svoh_last_kernel_ms(ctx, &kms) == SVOH_OK) g_reproj_timing.kernel_ms += kms; }
-  if (g_reproj_timing.on) {
-    const double tp4 = ReprojTiming::now();
-    g_reproj_timing.t[2] += tp1 - tp0; g_reproj_timing.t[3] += (tp2 - tp1) + (tp4 - tp3); g_reproj_timing.t[1] += tp3 - tp2; g_reproj_timing.t[5] -= tp4 - tp0;
-  }
+  sm.direct.useOwnOutputs(); sm.seeds.useOwnOutputs();
   for (int k = 0; k < 3; ++k) {
     size_t max_n = 0;
     if (!before_pass(k, max_n)) break;

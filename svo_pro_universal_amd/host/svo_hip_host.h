@@ -30,6 +30,8 @@
 
 namespace svo_hip {
 
+namespace detail { struct SpeculativeMatches; struct Resolved; }   // svo_hip_host_internal.h
+
 using Transformation = svoh::Rigid;  // minkindr QuatTransformation semantics (svoh_math.h)
 
 // The members of svo::Frame that SparseImgAlign::run reads (frame.h:46-73, 252-306).
@@ -180,6 +182,14 @@ class SparseImgAlignHip {
   using AfterEnqueue = std::function<void(const Transformation& T_iref_world)>;
   size_t run(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames, const AfterEnqueue& after_enqueue);
   bool lastRunRepeated() const { return last_run_repeated_; }
+  // run() in two halves, for a driver that puts the problems of MANY streams into one launch (FrontendLockstep):
+  // prepareRun builds this stream's problem (and returns T_iref_world), the driver launches and fetches, finishRun does
+  // what run() does with the result -- T_f_w_ of every current frame, alpha / beta reset -- and returns run()'s value.
+  Transformation prepareRun(const FrameBundle::Ptr& ref_frames, const FrameBundle::Ptr& cur_frames, svoh_align_options& opt, svoh_align_problem& pb) const
+  {
+    return buildProblem(ref_frames, cur_frames, 0, 1, opt, pb);
+  }
+  size_t finishRun(const svoh_align_result& result, const FrameBundle::Ptr& cur_frames, const Transformation& T_iref_world);
 
   // The same optimisation with the patches split over `world` participants (GPUs): this one takes share `rank`
   // of every camera's features, and between evaluateError and the solve the 74 doubles at d_sums (DEVICE memory)
@@ -230,6 +240,9 @@ namespace depth_filter_utils {
 // mu = 1 / depth_mean, sigma2 = mu_range^2 / 36, a = b = 10, mu_range = 1 / depth_min (seed.h:130-145)
 void initializeSeeds(const FramePtr& frame, DetectorHip& feature_detector, size_t max_n_seeds, float depth_min, float depth_max,
                      float depth_mean);
+// its second half: the detected features (px, score, level, grad, type) appended to the frame as seeds
+void appendSeeds(const FramePtr& frame, const std::vector<double>& px, const std::vector<double>& score, const std::vector<int32_t>& level,
+                 const std::vector<double>& grad, const std::vector<uint8_t>& type, float depth_min, float depth_mean);
 }  // namespace depth_filter_utils
 
 class DepthFilterHip {
@@ -470,6 +483,33 @@ class ReprojectorHip {
   {
     return options_.max_n_features_per_frame > 0 && frame->numTrackedFeatures() >= options_.max_n_features_per_frame;
   }
+  ~ReprojectorHip();
+  ReprojectorHip(const ReprojectorHip&) = delete;
+  ReprojectorHip& operator=(const ReprojectorHip&) = delete;
+
+  // ---- reprojectFrames in the phases it is made of.  reprojectFrames() runs them one after the other with the device
+  // work on its own context; a driver of MANY camera streams (FrontendLockstep) runs each phase for all its streams --
+  // the host phases on a pool of threads, the device phases as ONE launch for everybody.  Same code, same order per
+  // stream: a stream's features, counters and side effects are those of its own reprojectFrames call.
+  // (1) candidate projection: how many points / keyframe poses the projection of `kfs` has, then the inputs written
+  //     where the caller says (its own page-locked block), then the results adopted from where the device left them
+  //     (they are read in place by the next walkCandidates, and must stay valid until it returns)
+  struct ProjectionArrays { svoh_se3* T_world_kf; uint8_t* kind; int32_t* kf; double* v; double* mu; };
+  void countCandidateProjection(const std::vector<FramePtr>& kfs, size_t* n_points, size_t* n_kf) const;
+  void gatherCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const ProjectionArrays& into);
+  void adoptCandidateProjection(const FramePtr& cur_frame, const double* px, const uint8_t* visible);
+  // (2) grid and statistics reset, the walk over the visible keyframes' features: the three candidate lists
+  void walkCandidates(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points);
+  // (3) what every candidate of the first n_speculated lists matches against: the stream's direct and seed batch
+  void planMatches(const FramePtr& cur_frame, int n_speculated);
+  detail::SpeculativeMatches& plannedMatches() { return *sm_; }
+  // (4) sortCandidatesByReprojStats of the three lists (while the device works)
+  void sortCandidateLists();
+  // (5) the reference's three passes over finished batches; ctx_for_unspeculated: where a pass nobody planned is
+  //     matched with a round trip of its own (NULL: there must be none -- n_speculated was 3)
+  void replayMatches(const FramePtr& cur_frame, svoh_ctx* ctx_for_unspeculated);
+  bool reachedUnconvergedPass() const { return reached_unconverged_; }
+
   std::unique_ptr<OccupandyGrid2D> grid_;
   std::vector<reprojector::Candidate> candidates_;
   reprojector::Statistics stats_;
@@ -478,6 +518,7 @@ class ReprojectorHip {
   svoh_ctx* ctx_;
   size_t camera_index_;
   bool speculate_unconverged_ = false;   // was the unconverged-seed pass reached on the previous frame?
+  bool reached_unconverged_ = false;
   // queued / collected device projection: per keyframe the offset of its first feature in the flat arrays
   const Frame* proj_frame_ = nullptr;
   int proj_frame_id_ = 0;
@@ -486,10 +527,20 @@ class ReprojectorHip {
   // how many features the slice covers, the pose it was projected with
   struct ProjKf { const Frame* frame; int id; size_t offset; size_t n_features; Transformation T_f_w; };
   std::vector<ProjKf> proj_kf_off_;
+  // the projection's inputs and results, read through these (the vectors below, or the driver's page-locked block)
+  const uint8_t* proj_kind_p_ = nullptr; const double* proj_v_p_ = nullptr; const double* proj_mu_p_ = nullptr;
+  const double* proj_px_p_ = nullptr; const uint8_t* proj_visible_p_ = nullptr;
+  size_t proj_n_points_ = 0, proj_n_kf_ = 0;
   std::vector<uint8_t> proj_kind_, proj_visible_;
   std::vector<int32_t> proj_kf_;
   std::vector<double> proj_v_, proj_mu_, proj_px_;
   std::vector<svoh_se3> proj_T_world_kf_;
+  // the candidate lists of the converged / unconverged seeds (candidates_ holds the landmarks'), the plan of the frame
+  std::vector<reprojector::Candidate> converged_, unconverged_;
+  std::unique_ptr<detail::SpeculativeMatches> sm_;
+  std::vector<std::vector<detail::Resolved>> plan_rs_;
+  int n_speculated_ = 3;
+  bool have_proj_ = false;
 };
 
 namespace reprojector_utils {
@@ -548,6 +599,13 @@ class DetectorHip {
   void detect(svoh_frame_t img_pyr, const uint8_t* mask, int mask_pitch, size_t max_n_features, std::vector<double>& px_vec,
               std::vector<double>& score_vec, std::vector<int32_t>& level_vec, std::vector<double>& grad_vec,
               std::vector<uint8_t>& types_vec);
+  // detect(img_pyr, ...) in two halves around ONE batched device call for many streams' keyframes
+  // (svoh_detect_cells_batch): the options and this detector's occupancy bytes, then fillFeatures on the cells that came back
+  svoh_detector_options abiOptions() const;
+  void occupancyBytes(uint8_t* out /* grid_.size() */) const;
+  void fillFromCells(const uint64_t* corner_keys, const uint64_t* edge_keys, const float* edge_angles, int width, int height, size_t max_n_features,
+                     std::vector<double>& px_vec, std::vector<double>& score_vec, std::vector<int32_t>& level_vec, std::vector<double>& grad_vec,
+                     std::vector<uint8_t>& types_vec);
   void resetGrid() { grid_.reset(); }
   // OccupandyGrid2D::fillWithKeypoints (occupancy_grid_2d.h:96-107): 2 x n pixel coordinates
   void fillGridWithKeypoints(const std::vector<double>& px_vec, size_t n);
@@ -613,6 +671,11 @@ class PoseOptimizerHip {
   size_t iterCount() const { return static_cast<size_t>(last_.iters); }
   const svoh_pose_result& lastResult() const { return last_; }
   double measurement_sigma_ = 1.0;
+  // run() in two halves (FrontendLockstep: the bundles of many streams in ONE svoh_optimize_pose_batch): prepareRun builds
+  // this stream's options and problem (the arrays it points to live in this object until finishRun), finishRun does what
+  // run() does with the result and returns run()'s value.
+  void prepareRun(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px, svoh_pose_options& o, svoh_pose_problem& pb);
+  size_t finishRun(const FrameBundle::Ptr& frame_bundle, const svoh_pose_result& result);
  private:
   svoh_ctx* ctx_;
   SolverOptions solver_options_;
@@ -621,6 +684,8 @@ class PoseOptimizerHip {
   double prior_lambda_ = 0.0;
   svoh::Quat R_prior_{ 1, 0, 0, 0 };
   svoh_pose_result last_{};
+  std::vector<std::vector<double>> run_xyz_;                 // per camera, between prepareRun and finishRun
+  std::vector<std::vector<uint8_t>> run_usable_, run_outlier_;
 };
 
 // ---------------------------------------------------------------------------
