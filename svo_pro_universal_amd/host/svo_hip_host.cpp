@@ -302,6 +302,18 @@ void DepthFilterHip::prepareUpdateSeeds(const std::vector<FramePtr>& ref_frames_
   prepared_cur_ = cur_frame.get();
 }
 
+svoh_depth_filter_options DepthFilterHip::abiOptions(const Frame& cur_frame)
+{
+  px_error_angle_ = updateSeedPxErrorAngle(cur_frame);
+  have_px_error_angle_ = true;
+  svoh_depth_filter_options o{};
+  o.seed_convergence_sigma2_thresh = options_.seed_convergence_sigma2_thresh;
+  o.mappoint_convergence_sigma2_thresh = options_.mappoint_convergence_sigma2_thresh;
+  o.px_error_angle = px_error_angle_;
+  o.check_visibility = 1; o.check_convergence = 0; o.use_vogiatzis_update = 1;  // depth_filter.cpp:224-225
+  return o;
+}
+
 void DepthFilterHip::queueUpdateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame, bool send_off)
 {
   if (!cur_frame) throw std::runtime_error("DepthFilterHip::updateSeeds: NULL current frame");
@@ -333,11 +345,7 @@ void DepthFilterHip::queueUpdateSeeds(const std::vector<FramePtr>& ref_frames_wi
   fb.n = static_cast<int32_t>(n_total);
   fb.ref_frame_idx = q.ref_idx.data(); fb.px = q.px.data(); fb.f = q.f.data(); fb.grad = q.grad.data();
   fb.level = q.level.data(); fb.type = q.type.data();
-  svoh_depth_filter_options o{};
-  o.seed_convergence_sigma2_thresh = options_.seed_convergence_sigma2_thresh;
-  o.mappoint_convergence_sigma2_thresh = options_.mappoint_convergence_sigma2_thresh;
-  o.px_error_angle = px_error_angle_;
-  o.check_visibility = 1; o.check_convergence = 0; o.use_vogiatzis_update = 1;  // depth_filter.cpp:224-225
+  const svoh_depth_filter_options o = abiOptions(*cur_frame);
   const svoh_frame_view cur = view_of(*cur_frame);
   q.success.assign(n_total, 0);
   // queued in a deferred section and sent to the device at once (svoh_matcher_flush): the kernel runs while the caller

@@ -273,6 +273,9 @@ class DepthFilterHip {
   DepthFilterHip(const DepthFilterHip&) = delete;
   DepthFilterHip& operator=(const DepthFilterHip&) = delete;
   svoh_matcher_options& getMatcherOptions() { return matcher_options_; }
+  // the options updateSeeds passes to the device for an update into cur_frame (depth_filter.cpp:224-225; the
+  // function-local static px_error_angle of updateSeed): for a driver that batches the updates of many streams itself
+  svoh_depth_filter_options abiOptions(const Frame& cur_frame);
   // Matcher::MatchResult of every seed of the last call, in (frame, feature) order
   const std::vector<int32_t>& lastMatchResults() const { return last_results_; }
 

@@ -1,0 +1,621 @@
+// svo_hip_lockstep.cpp -- FrontendLockstep (svo_hip_lockstep.h): many camera streams, one launch per stage.
+#include "svo_hip_lockstep.h"
+
+#include <chrono>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "svo_hip_host_internal.h"
+
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+#define SVOH_CPU_RELAX() _mm_pause()
+#else
+#define SVOH_CPU_RELAX() do { } while (0)
+#endif
+
+namespace svo_hip {
+
+// ---- WorkerPool --------------------------------------------------------------------------------------------------
+WorkerPool::WorkerPool(int n_threads)
+{
+  for (int i = 1; i < n_threads; ++i) {
+    try { threads_.emplace_back(&WorkerPool::worker, this); }
+    catch (...) { break; }   // a thread that cannot be started (pid limit of a container): the pool is smaller, nothing else
+  }
+}
+
+WorkerPool::~WorkerPool()
+{
+  stop_.store(true);
+  generation_.fetch_add(1);
+  { std::lock_guard<std::mutex> lock(mu_); cv_.notify_all(); }
+  for (std::thread& t : threads_) t.join();
+}
+
+void WorkerPool::work_off()
+{
+  for (;;) {
+    const int i = next_.fetch_add(1, std::memory_order_acq_rel);
+    if (i >= n_items_.load(std::memory_order_acquire)) break;
+    try { (*fn_)(i); }
+    catch (...) { std::lock_guard<std::mutex> lock(err_mu_); if (!error_) error_ = std::current_exception(); }
+    pending_.fetch_sub(1, std::memory_order_acq_rel);
+  }
+}
+
+void WorkerPool::worker()
+{
+  unsigned long seen = 0;
+  for (;;) {
+    // the next phase usually follows within microseconds: spin, then yield, then sleep
+    int spins = 0;
+    while (generation_.load(std::memory_order_acquire) == seen) {
+      if (spins < 4000) { SVOH_CPU_RELAX(); ++spins; }
+      else if (spins < 4400) { std::this_thread::yield(); ++spins; }
+      else {
+        sleepers_.fetch_add(1);
+        {
+          std::unique_lock<std::mutex> lock(mu_);
+          cv_.wait(lock, [&] { return generation_.load() != seen || stop_.load(); });
+        }
+        sleepers_.fetch_sub(1);
+      }
+    }
+    if (stop_.load()) return;
+    seen = generation_.load(std::memory_order_acquire);
+    work_off();
+  }
+}
+
+void WorkerPool::run(int n_items, const std::function<void(int)>& fn)
+{
+  if (n_items <= 0) return;
+  if (threads_.empty() || n_items == 1) { for (int i = 0; i < n_items; ++i) fn(i); return; }
+  { std::lock_guard<std::mutex> lock(err_mu_); error_ = nullptr; }
+  fn_ = &fn;
+  n_items_.store(n_items, std::memory_order_release);
+  pending_.store(n_items, std::memory_order_release);   // before next_ is reset: a worker still in its last loop may start on the new items at once
+  next_.store(0, std::memory_order_release);
+  generation_.fetch_add(1);
+  if (sleepers_.load() > 0) { std::lock_guard<std::mutex> lock(mu_); cv_.notify_all(); }
+  work_off();
+  while (pending_.load(std::memory_order_acquire) != 0) SVOH_CPU_RELAX();
+  std::exception_ptr e;
+  { std::lock_guard<std::mutex> lock(err_mu_); e = error_; error_ = nullptr; }
+  if (e) std::rethrow_exception(e);
+}
+
+// ---- FrontendLockstep ----------------------------------------------------------------------------------------------
+namespace {
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+struct FrontendLockstep::Stream {
+  SparseImgAlignHip img_align;
+  ReprojectorHip reprojector;
+  PoseOptimizerHip pose_optimizer;
+  DetectorHip detector;
+  std::deque<FramePtr> kfs;   // the last reprojector.max_n_kfs keyframes
+  FramePtr last, frame;
+  FrameBundle::Ptr b_last, b_cur;
+  std::vector<FramePtr> visible;
+  std::vector<PointPtr> trash;
+  // the round in progress
+  svoh_align_options align_opt{};
+  svoh_align_problem align_pb{};
+  Transformation T_iref_world{ { 1, 0, 0, 0 }, { 0, 0, 0 } };
+  int32_t align_key = 0;
+  int align_result = -1;
+  size_t proj_points = 0, proj_kf = 0, proj_point_off = 0, proj_kf_off = 0;
+  int proj_job = -1;
+  size_t direct_off = 0, seeds_off = 0, ref_off = 0;
+  bool do_pose = false;
+  svoh_pose_options pose_opt{};
+  svoh_pose_problem pose_pb{};
+  int pose_slot = -1;
+  bool want_kf = false;
+  int detect_slot = -1;
+  int detect_max_n = 0;
+  // the depth-filter update in flight
+  std::vector<FramePtr> seed_frames;
+  std::vector<size_t> seed_counts;
+  size_t seed_off = 0, seed_n = 0;
+  // bookkeeping
+  FrameRow row;
+  bool row_open = false;
+  std::vector<FrameRow> done_rows;
+
+  Stream(svoh_ctx* ctx, const LockstepOptions& o, const ReprojectorOptions& ropt)
+      : img_align(ctx, SparseImgAlignHip::getDefaultSolverOptions(), o.params.img_align), reprojector(ctx, ropt, 0), pose_optimizer(ctx),
+        detector(ctx, o.params.detector, o.cam.width, o.cam.height) {}
+};
+
+void FrontendLockstep::check(int rc, const char* what) const
+{
+  if (rc != SVOH_OK) throw std::runtime_error(std::string(what) + ": " + svoh_last_error_string(ctx_));
+}
+
+FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepOptions& options)
+    : ctx_(ctx), opt_(options), pool_(options.n_workers < 1 ? 1 : options.n_workers)
+{
+  if (!ctx_) throw std::runtime_error("FrontendLockstep: NULL svoh_ctx (no CPU fallback exists)");
+  if (n_streams < 1 || n_streams > 256) throw std::runtime_error("FrontendLockstep: n_streams out of range [1, 256]");
+  opt_.params.depth_filter.use_threaded_depthfilter = false;   // the synchronous path
+  ReprojectorOptions ropt;
+  ropt.max_n_features_per_frame = static_cast<size_t>(opt_.params.max_fts);
+  ropt.cell_size = static_cast<size_t>(opt_.params.grid_size);
+  ropt.seed_sigma2_thresh = opt_.params.seed_sigma2_thresh;
+  ropt.affine_est_offset = opt_.params.reprojector_affine_est_offset;
+  ropt.affine_est_gain = opt_.params.reprojector_affine_est_gain;
+  for (int s = 0; s < n_streams; ++s) streams_.emplace_back(new Stream(ctx_, opt_, ropt));
+}
+
+FrontendLockstep::~FrontendLockstep()
+{
+  try { finish(); } catch (...) {}
+  for (auto& st : streams_) {
+    for (const FramePtr& f : st->kfs) for (auto& sr : f->seed_ref_vec_) sr.keyframe.reset();   // break the self references
+    if (st->last) for (auto& sr : st->last->seed_ref_vec_) sr.keyframe.reset();
+  }
+  streams_.clear();
+  drainReleases();
+}
+
+void FrontendLockstep::drainReleases()
+{
+  std::vector<svoh_frame_t> r;
+  { std::lock_guard<std::mutex> lock(release_mu_); r.swap(to_release_); }
+  for (svoh_frame_t h : r) (void)svoh_release_frame(ctx_, h);
+}
+
+const Transformation& FrontendLockstep::pose(int s) const
+{
+  const Stream& st = *streams_.at(static_cast<size_t>(s));
+  if (!st.last) throw std::runtime_error("FrontendLockstep::pose: no frame yet");
+  return st.last->T_f_w_;
+}
+
+size_t FrontendLockstep::keyframesAlive(int s) const { return streams_.at(static_cast<size_t>(s))->kfs.size(); }
+
+std::vector<FrontendLockstep::FrameRow> FrontendLockstep::completedRows(int s)
+{
+  std::vector<FrameRow> out;
+  out.swap(streams_.at(static_cast<size_t>(s))->done_rows);
+  return out;
+}
+
+void FrontendLockstep::finish()
+{
+  finishSeedUpdate();
+  drainReleases();
+}
+
+// The depth-filter update sent off at the end of the last round: wait for it (usually long done), put every seed's state
+// and type where the reference's loop leaves them (ref_frame.invmu_sigma2_a_b_vec_.col(i), type_vec_[i]), close the rows.
+void FrontendLockstep::finishSeedUpdate()
+{
+  if (seeds_in_flight_) {
+    seeds_in_flight_ = false;
+    check(svoh_matcher_collect(ctx_), "svoh_matcher_collect");
+    ++device_calls_;
+    const svoh_matcher_stage_t& ss = seed_stage_;
+    pool_.run(numStreams(), [&](int s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      size_t off = st.seed_off, n_success = 0;
+      for (size_t k = 0; k < st.seed_frames.size(); ++k) {
+        Frame& r = *st.seed_frames[k];
+        const size_t n = st.seed_counts[k];
+        std::copy(ss.state + 4 * off, ss.state + 4 * (off + n), r.invmu_sigma2_a_b_vec_.begin());
+        std::copy(ss.type + off, ss.type + off + n, r.type_vec_.begin());
+        for (size_t i = 0; i < n; ++i) n_success += ss.success[off + i];
+        off += n;
+      }
+      st.seed_frames.clear(); st.seed_counts.clear(); st.seed_n = 0;
+      if (st.row_open) st.row.n_seed_upd = n_success;
+    });
+  }
+  for (auto& stp : streams_) {
+    Stream& st = *stp;
+    if (!st.row_open) continue;
+    size_t n_conv = 0;
+    for (const FramePtr& f : st.kfs)
+      for (size_t i = 0; i < f->num_features_; ++i)
+        n_conv += f->type_vec_[i] == SVOH_FT_CORNER_SEED_CONVERGED || f->type_vec_[i] == SVOH_FT_EDGELET_SEED_CONVERGED;
+    st.row.n_converged = n_conv;
+    st.done_rows.push_back(st.row);
+    st.row_open = false;
+  }
+}
+
+// make_keyframe of the harness for the streams in `which` (their current frame): the detector on every frame in ONE
+// device round trip, then initializeSeeds' second half, the self references of the new seeds, the keyframe window.
+void FrontendLockstep::makeKeyframes(const std::vector<int>& which)
+{
+  if (which.empty()) return;
+  const size_t n_cells = streams_[0]->detector.grid_.size();
+  std::vector<int> detect;   // the streams whose keyframe still has room for seeds ("Skip seed initialization" otherwise)
+  for (int s : which) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    st.detector.resetGrid();
+    st.detector.fillGridWithKeypoints(st.frame->px_vec_, st.frame->num_features_);
+    st.detect_max_n = opt_.params.max_n_seeds_per_frame - static_cast<int>(st.frame->num_features_);
+    st.detect_slot = -1;
+    if (st.detect_max_n > 0) { st.detect_slot = static_cast<int>(detect.size()); detect.push_back(s); }
+  }
+  std::vector<uint64_t> ckeys, ekeys;
+  std::vector<float> angles;
+  if (!detect.empty()) {
+    const size_t n = detect.size();
+    std::vector<svoh_frame_t> frames(n);
+    std::vector<uint8_t> occ(n * n_cells);
+    for (size_t i = 0; i < n; ++i) {
+      Stream& st = *streams_[static_cast<size_t>(detect[i])];
+      frames[i] = st.frame->pyramid;
+      st.detector.occupancyBytes(occ.data() + i * n_cells);
+    }
+    ckeys.resize(n * n_cells); ekeys.resize(n * n_cells); angles.resize(n * n_cells);
+    const svoh_detector_options dopt = streams_[0]->detector.abiOptions();
+    check(svoh_detect_cells_batch(ctx_, static_cast<int>(n), frames.data(), &dopt, occ.data(), ckeys.data(), ekeys.data(), angles.data()), "svoh_detect_cells_batch");
+    ++device_calls_;
+  }
+  pool_.run(static_cast<int>(which.size()), [&](int w) {
+    Stream& st = *streams_[static_cast<size_t>(which[static_cast<size_t>(w)])];
+    const FramePtr& f = st.frame;
+    const size_t n_old = f->num_features_;
+    if (st.detect_slot >= 0) {
+      const size_t i = static_cast<size_t>(st.detect_slot);
+      std::vector<double> px, score, grad;
+      std::vector<int32_t> level;
+      std::vector<uint8_t> type;
+      st.detector.fillFromCells(ckeys.data() + i * n_cells, ekeys.data() + i * n_cells, angles.data() + i * n_cells, opt_.cam.width, opt_.cam.height,
+                                static_cast<size_t>(st.detect_max_n), px, score, level, grad, type);
+      depth_filter_utils::appendSeeds(f, px, score, level, grad, type, opt_.depth_min, opt_.depth_mean);
+    } else {
+      st.detector.resetGrid();
+    }
+    // bootstrap stand-in for the initialiser's landmarks: a keyframe's own new seeds are usable for the
+    // alignment of the next frame at their current depth estimate (self reference)
+    for (size_t i = n_old; i < f->num_features_; ++i) { f->seed_ref_vec_[i].keyframe = f; f->seed_ref_vec_[i].seed_id = static_cast<int>(i); }
+    st.kfs.push_back(f);
+    while (st.kfs.size() > st.reprojector.options_.max_n_kfs) {
+      for (auto& sr : st.kfs.front()->seed_ref_vec_) sr.keyframe.reset();   // break the self references
+      st.kfs.pop_front();
+    }
+  });
+}
+
+void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const Transformation* T_f_w_first)
+{
+  const int S = numStreams();
+  device_calls_ = 0;
+  times_ = RoundTimes();
+  const double t0 = now_ms();
+  drainReleases();
+
+  // ---- pyramids of the round's S images: one call
+  {
+    std::vector<svoh_frame_t> handles(static_cast<size_t>(S));
+    check(svoh_build_pyramid_multi(ctx_, images, S, opt_.cam.width, opt_.cam.height, pitch, opt_.images_mem_space, opt_.params.n_pyr_levels_to_build,
+                                   SVOH_HALFSAMPLE_REFERENCE, handles.data()), "svoh_build_pyramid_multi");
+    ++device_calls_;
+    for (int s = 0; s < S; ++s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      FramePtr frame(new Frame, [this](Frame* f) {
+        if (f->pyramid) { std::lock_guard<std::mutex> lock(release_mu_); to_release_.push_back(f->pyramid); }
+        delete f;
+      });
+      frame->pyramid = handles[static_cast<size_t>(s)];
+      frame->cam = opt_.cam;
+      frame->set_T_cam_imu(svoh::inverse(opt_.T_B_C));
+      frame->id_ = static_cast<int>(round_);
+      st.frame = frame;
+    }
+  }
+  // the previous round's seed update: its results are needed from here on (alignment points, candidates)
+  finishSeedUpdate();
+  const double t1 = now_ms();
+  times_.pyramid = t1 - t0;
+
+  if (round_ == 0) {
+    if (!T_f_w_first) throw std::runtime_error("FrontendLockstep::addImages: the first frames need their poses");
+    std::vector<int> all;
+    for (int s = 0; s < S; ++s) { streams_[static_cast<size_t>(s)]->frame->T_f_w_ = T_f_w_first[s]; all.push_back(s); }
+    makeKeyframes(all);
+    for (auto& stp : streams_) {
+      Stream& st = *stp;
+      st.last = st.frame; st.frame.reset();
+      st.row = FrameRow(); st.row.k = 0; st.row.is_kf = true; st.row_open = true;
+    }
+    times_.keyframe = now_ms() - t1;
+    times_.total = now_ms() - t0;
+    ++round_;
+    return;
+  }
+
+  // ---- 1. sparse image alignment against the last frame (frame_handler_base.cpp:610-643), every stream's problem in the
+  // geometry it would get alone; behind it the candidate projection of every stream, its pose composed on the device
+  pool_.run(S, [&](int s) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    st.frame->T_f_w_ = st.last->T_f_w_;
+    resolveAlignmentPoints(*st.last);
+    st.b_last.reset(new FrameBundle); st.b_cur.reset(new FrameBundle);
+    st.b_last->frames_.push_back(st.last); st.b_cur->frames_.push_back(st.frame);
+    st.img_align.reset();
+    st.visible.assign(st.kfs.begin(), st.kfs.end());
+    st.T_iref_world = st.img_align.prepareRun(st.b_last, st.b_cur, st.align_opt, st.align_pb);
+    st.reprojector.countCandidateProjection(st.visible, &st.proj_points, &st.proj_kf);
+  });
+  std::vector<svoh_align_result> align_results(static_cast<size_t>(S));
+  std::vector<uint8_t> align_repeated(static_cast<size_t>(S), 0);
+  svoh_candidate_stage_t cs{};
+  {
+    // groups of equal launch geometry, in the order their first stream appears
+    std::vector<std::pair<int32_t, std::vector<int>>> groups;
+    for (int s = 0; s < S; ++s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      check(svoh_sparse_align_geometry_key(ctx_, &st.align_opt, &st.align_pb, &st.align_key), "svoh_sparse_align_geometry_key");
+      size_t g = 0;
+      while (g < groups.size() && groups[g].first != st.align_key) ++g;
+      if (g == groups.size()) groups.emplace_back(st.align_key, std::vector<int>());
+      groups[g].second.push_back(s);
+    }
+    int next_result = 0;
+    std::vector<svoh_align_problem> pbs;
+    for (const auto& g : groups) {
+      pbs.clear();
+      for (int s : g.second) { Stream& st = *streams_[static_cast<size_t>(s)]; pbs.push_back(st.align_pb); st.align_result = next_result++; }
+      check(svoh_sparse_align_enqueue_keyed(ctx_, &streams_[static_cast<size_t>(g.second[0])]->align_opt, static_cast<int>(pbs.size()), pbs.data(), g.first),
+            "svoh_sparse_align_enqueue_keyed");
+      ++device_calls_;
+    }
+    // the candidate projections: one staged call for all streams that have a local map
+    size_t n_points = 0, n_kf = 0;
+    int n_jobs = 0;
+    for (auto& stp : streams_) {
+      Stream& st = *stp;
+      st.proj_point_off = n_points; st.proj_kf_off = n_kf; st.proj_job = -1;
+      if (st.proj_points) { st.proj_job = n_jobs++; n_points += st.proj_points; n_kf += st.proj_kf; }
+    }
+    if (n_jobs) {
+      check(svoh_project_candidates_stage(ctx_, n_jobs, static_cast<int>(n_kf), static_cast<int>(n_points), &cs), "svoh_project_candidates_stage");
+      pool_.run(S, [&](int s) {
+        Stream& st = *streams_[static_cast<size_t>(s)];
+        if (st.proj_job < 0) return;
+        svoh_candidate_job& jb = cs.jobs[st.proj_job];
+        jb = svoh_candidate_job{};
+        jb.cam = st.frame->cam;
+        svoh::store_rigid(st.frame->T_cam_imu(), jb.T_f_w_or_T_cam_imu);
+        svoh::store_rigid(st.T_iref_world, jb.T_imu_world_ref);
+        jb.align_result_index = st.align_result;
+        jb.kf_begin = static_cast<int32_t>(st.proj_kf_off); jb.n_kf = static_cast<int32_t>(st.proj_kf);
+        jb.point_begin = static_cast<int32_t>(st.proj_point_off); jb.n_points = static_cast<int32_t>(st.proj_points);
+        const size_t o = st.proj_point_off;
+        st.reprojector.gatherCandidateProjection(st.frame, st.visible,
+                                                 ReprojectorHip::ProjectionArrays{ cs.T_world_kf + st.proj_kf_off, cs.kind + o, cs.kf + o, cs.v + 3 * o, cs.mu + o });
+        for (size_t i = 0; i < st.proj_points; ++i) cs.job[o + i] = st.proj_job;
+      });
+      check(svoh_project_candidates_enqueue_staged(ctx_), "svoh_project_candidates_enqueue_staged");
+      ++device_calls_;
+    }
+    check(svoh_sparse_align_fetch_all(ctx_, S, align_results.data()), "svoh_sparse_align_fetch_all");
+    ++device_calls_;
+    if (n_jobs) check(svoh_project_candidates_wait(ctx_), "svoh_project_candidates_wait");
+    // a cluster of workgroups that never completed (status 3): the blocking entry repeats that problem with one
+    // workgroup, and what was projected behind the first launch used a pose that is not the result's
+    for (int s = 0; s < S; ++s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      if (align_results[static_cast<size_t>(st.align_result)].status != 3) continue;
+      check(svoh_sparse_align_batch(ctx_, &st.align_opt, 1, &st.align_pb, &align_results[static_cast<size_t>(st.align_result)]), "svoh_sparse_align_batch");
+      align_repeated[static_cast<size_t>(s)] = 1;
+      ++device_calls_;
+    }
+  }
+  const double t2 = now_ms();
+  times_.align = t2 - t1;
+
+  // ---- 2. reprojection (frame_handler_base.cpp:645-744): walk and plan per stream, ONE direct batch and ONE seed batch
+  pool_.run(S, [&](int s) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    st.row = FrameRow(); st.row.k = round_;
+    st.row.n_aligned = st.img_align.finishRun(align_results[static_cast<size_t>(st.align_result)], st.b_cur, st.T_iref_world);
+    if (st.proj_job >= 0 && !align_repeated[static_cast<size_t>(s)] && st.row.n_aligned != 0)
+      st.reprojector.adoptCandidateProjection(st.frame, cs.px + 2 * st.proj_point_off, cs.visible + st.proj_point_off);
+    else st.reprojector.discardCandidateProjection();
+    st.trash.clear();
+    st.reprojector.walkCandidates(st.frame, st.visible, st.trash);
+    // (every list is planned: a pass that is not reached wastes its units, never shows -- and a pass nobody planned
+    // would need a round trip of its own)
+    st.reprojector.planMatches(st.frame, 3);
+  });
+  svoh_matcher_stage_t ds{}, ss{};
+  size_t n_direct = 0, n_seeds = 0, n_refs = 0;
+  for (auto& stp : streams_) {
+    Stream& st = *stp;
+    detail::SpeculativeMatches& sm = st.reprojector.plannedMatches();
+    st.direct_off = n_direct; st.seeds_off = n_seeds; st.ref_off = n_refs;
+    n_direct += sm.direct.size(); n_seeds += sm.seeds.size(); n_refs += sm.frames.size();
+  }
+  const bool matcher_work = n_direct + n_seeds > 0;
+  if (matcher_work) {
+    const svoh_matcher_options mopt = detail::reprojectorMatcherOptions(opt_.params.reprojector_affine_est_offset, opt_.params.reprojector_affine_est_gain);
+    const int max_views = static_cast<int>(n_refs) + S + 1;
+    check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
+    struct CloseSection { svoh_ctx* c; bool armed; ~CloseSection() { if (armed) (void)svoh_matcher_collect(c); } } close_section{ ctx_, true };
+    if (n_direct) check(svoh_matcher_stage(ctx_, 0, static_cast<int>(n_direct), max_views, 1, &ds), "svoh_matcher_stage");
+    if (n_seeds) check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_seeds), max_views, 1, &ss), "svoh_matcher_stage");
+    std::vector<svoh_frame_view> refs(n_refs ? n_refs : 1), curs(static_cast<size_t>(S));
+    pool_.run(S, [&](int s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      detail::SpeculativeMatches& sm = st.reprojector.plannedMatches();
+      for (size_t k = 0; k < sm.frames.size(); ++k) refs[st.ref_off + k] = detail::viewOf(*sm.frames[k]);
+      curs[static_cast<size_t>(s)] = detail::viewOf(*st.frame);
+      auto copy_batch = [&](const detail::Batch& b, const svoh_matcher_stage_t& g, size_t o) {
+        const size_t m = b.size();
+        if (!m) return;
+        for (size_t i = 0; i < m; ++i) { g.ref_frame_idx[o + i] = b.ref_idx[i] + static_cast<int32_t>(st.ref_off); g.cur_frame_idx[o + i] = s; }
+        memcpy(g.px + 2 * o, b.px.data(), 16 * m); memcpy(g.f + 3 * o, b.f.data(), 24 * m); memcpy(g.grad + 2 * o, b.grad.data(), 16 * m);
+        memcpy(g.level + o, b.level.data(), 4 * m); memcpy(g.type + o, b.type.data(), m);
+      };
+      copy_batch(sm.direct, ds, st.direct_off);
+      if (const size_t m = sm.direct.size()) { memcpy(ds.depth + st.direct_off, sm.direct.depth.data(), 8 * m); memcpy(ds.px_cur + 2 * st.direct_off, sm.direct.px_cur.data(), 16 * m); }
+      copy_batch(sm.seeds, ss, st.seeds_off);
+      if (const size_t m = sm.seeds.size()) memcpy(ss.state + 4 * st.seeds_off, sm.seeds.state.data(), 32 * m);
+    });
+    auto batch_of = [&](const svoh_matcher_stage_t& g, size_t n) {
+      svoh_feature_batch fb{};
+      fb.n = static_cast<int32_t>(n);
+      fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = S;
+      fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type;
+      fb.mem_space = SVOH_MEM_STAGED;
+      return fb;
+    };
+    if (n_direct) {
+      const svoh_feature_batch fb = batch_of(ds, n_direct);
+      check(svoh_match_direct_batch(ctx_, &mopt, static_cast<int>(n_refs), refs.data(), curs.data(), &fb, ds.depth, ds.px_cur, ds.result, ds.f_cur, ds.search_level,
+                                    nullptr, ds.A_cur_ref), "svoh_match_direct_batch");
+    }
+    if (n_seeds) {
+      const svoh_feature_batch fb = batch_of(ss, n_seeds);
+      const svoh_depth_filter_options o = detail::reprojectorSeedOptions(*streams_[0]->frame, opt_.params.seed_sigma2_thresh);
+      const svoh_seed_match_outputs outs{ ss.px_cur, ss.f_cur, ss.search_level, ss.A_cur_ref };
+      check(svoh_update_seeds_batch_ex(ctx_, &mopt, &o, static_cast<int>(n_refs), refs.data(), curs.data(), &fb, ss.state, ss.success, ss.result, nullptr, &outs),
+            "svoh_update_seeds_batch_ex");
+    }
+    check(svoh_matcher_flush(ctx_), "svoh_matcher_flush");
+    ++device_calls_;
+    // sortCandidatesByReprojStats of every stream's three lists while the device works
+    pool_.run(S, [&](int s) { streams_[static_cast<size_t>(s)]->reprojector.sortCandidateLists(); });
+    close_section.armed = false;
+    check(svoh_matcher_collect(ctx_), "svoh_matcher_collect");
+    ++device_calls_;
+  } else {
+    pool_.run(S, [&](int s) { streams_[static_cast<size_t>(s)]->reprojector.sortCandidateLists(); });
+  }
+  // the reference's three passes per stream on its slices of the finished batches, then the stream's pose problem
+  pool_.run(S, [&](int s) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    detail::SpeculativeMatches& sm = st.reprojector.plannedMatches();
+    if (sm.direct.size()) {
+      const size_t o = st.direct_off;
+      sm.direct.out.result = ds.result + o; sm.direct.out.search_level = ds.search_level + o; sm.direct.out.px_cur = ds.px_cur + 2 * o;
+      sm.direct.out.f_cur = ds.f_cur + 3 * o; sm.direct.out.A = ds.A_cur_ref + 4 * o; sm.direct.out.type = ds.type + o; sm.direct.out.success = ds.success + o;
+    }
+    if (sm.seeds.size()) {
+      const size_t o = st.seeds_off;
+      sm.seeds.out.result = ss.result + o; sm.seeds.out.search_level = ss.search_level + o; sm.seeds.out.px_cur = ss.px_cur + 2 * o;
+      sm.seeds.out.f_cur = ss.f_cur + 3 * o; sm.seeds.out.A = ss.A_cur_ref + 4 * o; sm.seeds.out.state = ss.state + 4 * o; sm.seeds.out.type = ss.type + o;
+      sm.seeds.out.success = ss.success + o;
+    }
+    st.reprojector.replayMatches(st.frame, nullptr);
+    st.row.n_reproj = st.frame->num_features_;
+    // 3. pose optimisation (frame_handler_base.cpp:746-790): this stream's bundle
+    st.do_pose = st.frame->num_features_ >= 10;
+    if (st.do_pose) st.pose_optimizer.prepareRun(st.b_cur, 2.0, st.pose_opt, st.pose_pb);
+  });
+  const double t3 = now_ms();
+  times_.reproject = t3 - t2;
+
+  // ---- 3. the bundles of all streams in one launch
+  {
+    std::vector<svoh_pose_problem> pbs;
+    std::vector<int> who;
+    for (int s = 0; s < S; ++s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      st.pose_slot = -1;
+      if (st.do_pose) { st.pose_slot = static_cast<int>(pbs.size()); pbs.push_back(st.pose_pb); who.push_back(s); }
+    }
+    if (!pbs.empty()) {
+      std::vector<svoh_pose_result> res(pbs.size());
+      check(svoh_optimize_pose_batch(ctx_, &streams_[static_cast<size_t>(who[0])]->pose_opt, static_cast<int>(pbs.size()), pbs.data(), res.data()), "svoh_optimize_pose_batch");
+      ++device_calls_;
+      pool_.run(static_cast<int>(who.size()), [&](int w) {
+        Stream& st = *streams_[static_cast<size_t>(who[static_cast<size_t>(w)])];
+        st.row.n_pose = st.pose_optimizer.finishRun(st.b_cur, res[static_cast<size_t>(w)]);
+      });
+    }
+  }
+  const double t4 = now_ms();
+  times_.pose = t4 - t3;
+
+  // ---- 4. depth filter (frame_handler_mono.cpp:125): the seeds of every stream's keyframes into its new frame, ONE batch,
+  // sent off without a wait and finished at the start of the next round, before anything reads the seeds again
+  {
+    size_t n_total = 0, n_ref_total = 0;
+    for (auto& stp : streams_) {
+      Stream& st = *stp;
+      st.seed_frames = st.visible;
+      st.seed_counts.clear();
+      size_t n = 0;
+      for (const FramePtr& f : st.seed_frames) { st.seed_counts.push_back(f->num_features_); n += f->num_features_; }
+      st.seed_off = n_total; st.seed_n = n; st.ref_off = n_ref_total;
+      n_total += n; n_ref_total += st.seed_frames.size();
+      if (n == 0) { st.seed_frames.clear(); st.seed_counts.clear(); }
+    }
+    if (n_total) {
+      DepthFilterHip df(ctx_, opt_.params.depth_filter);   // (options only: the batch is the driver's)
+      const svoh_depth_filter_options o = df.abiOptions(*streams_[0]->frame);
+      const svoh_matcher_options mopt = df.getMatcherOptions();
+      check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
+      struct CloseSection { svoh_ctx* c; bool armed; ~CloseSection() { if (armed) (void)svoh_matcher_collect(c); } } close_section{ ctx_, true };
+      check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_total), static_cast<int>(n_ref_total) + S + 1, 0, &seed_stage_), "svoh_matcher_stage");
+      const svoh_matcher_stage_t& g = seed_stage_;
+      std::vector<svoh_frame_view> refs(n_ref_total ? n_ref_total : 1), curs(static_cast<size_t>(S));
+      pool_.run(S, [&](int s) {
+        Stream& st = *streams_[static_cast<size_t>(s)];
+        curs[static_cast<size_t>(s)] = detail::viewOf(*st.frame);
+        size_t off = st.seed_off;
+        for (size_t k = 0; k < st.seed_frames.size(); ++k) {
+          const Frame& r = *st.seed_frames[k];
+          refs[st.ref_off + k] = detail::viewOf(r);
+          const size_t n = st.seed_counts[k];
+          for (size_t i = 0; i < n; ++i) { g.ref_frame_idx[off + i] = static_cast<int32_t>(st.ref_off + k); g.cur_frame_idx[off + i] = s; }
+          memcpy(g.px + 2 * off, r.px_vec_.data(), 16 * n); memcpy(g.f + 3 * off, r.f_vec_.data(), 24 * n); memcpy(g.grad + 2 * off, r.grad_vec_.data(), 16 * n);
+          memcpy(g.level + off, r.level_vec_.data(), 4 * n); memcpy(g.type + off, r.type_vec_.data(), n);
+          memcpy(g.state + 4 * off, r.invmu_sigma2_a_b_vec_.data(), 32 * n);
+          off += n;
+        }
+      });
+      svoh_feature_batch fb{};
+      fb.n = static_cast<int32_t>(n_total);
+      fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = S;
+      fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type;
+      fb.mem_space = SVOH_MEM_STAGED;
+      check(svoh_update_seeds_batch(ctx_, &mopt, &o, static_cast<int>(n_ref_total), refs.data(), curs.data(), &fb, g.state, g.success, g.result, nullptr),
+            "svoh_update_seeds_batch");
+      check(svoh_matcher_flush(ctx_), "svoh_matcher_flush");
+      ++device_calls_;
+      close_section.armed = false;
+      seeds_in_flight_ = true;
+    }
+  }
+  const double t5 = now_ms();
+  times_.seeds = t5 - t4;
+
+  // ---- 5. keyframe rule, the new keyframes' detector in one call
+  {
+    std::vector<int> which;
+    for (int s = 0; s < S; ++s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      st.want_kf = round_ % opt_.kf_every == 0 || st.frame->numTrackedFeatures() < opt_.min_tracked;
+      if (st.want_kf) which.push_back(s);
+    }
+    makeKeyframes(which);
+  }
+  for (auto& stp : streams_) {
+    Stream& st = *stp;
+    st.row.is_kf = st.want_kf;
+    st.row_open = true;
+    // the frame before this one is dropped here unless it is a keyframe
+    st.b_last.reset(); st.b_cur.reset(); st.visible.clear(); st.trash.clear();
+    st.last = st.frame; st.frame.reset();
+  }
+  drainReleases();
+  const double t6 = now_ms();
+  times_.keyframe = t6 - t5;
+  times_.total = t6 - t0;
+  ++round_;
+}
+
+}  // namespace svo_hip

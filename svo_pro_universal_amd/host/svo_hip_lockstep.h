@@ -1,0 +1,129 @@
+// svo_hip_lockstep.h -- many camera streams through the per-frame chain in LOCK STEP: one launch per stage for all of them.
+//
+// The reference runs one frame handler per camera stream; its only parallelism across streams is std::async per camera
+// (src/svo/src/frame_handler_base.cpp:681-695).  On an MI355X one EuRoC-sized stream is a chain of latency-bound round
+// trips that keeps < 1 % of the device busy, and a host thread per stream saturates on the launch path near 7 000
+// frames/s.  FrontendLockstep takes ONE frame of EVERY stream at a time and runs the chain of
+// FrameHandlerMono::processFrame (src/svo/src/frame_handler_mono.cpp:120-158, frame_handler_base.cpp:610-825) stage by
+// stage:
+//
+//   pyramids            one gather + one pyramid launch for S images             svoh_build_pyramid_multi
+//   sparse alignment    S problems, grouped by launch geometry                   svoh_sparse_align_enqueue_keyed
+//    + candidate proj.  S jobs queued behind it, poses composed on the device    svoh_project_candidates_stage / _enqueue_staged
+//   reprojection        one direct batch + one seed batch with S current frames  svoh_matcher_stage + svoh_match_direct_batch /
+//                                                                                svoh_update_seeds_batch_ex (cur_frame_idx)
+//   pose optimisation   S bundles                                                svoh_optimize_pose_batch
+//   depth filter        one seed batch over the keyframes of all streams         svoh_matcher_stage + svoh_update_seeds_batch
+//   keyframes           the detector for every new keyframe of the round         svoh_detect_cells_batch
+//
+// Each stream's host work -- the walk over its keyframes, plan, sort, replay, pose staging, seed gathering -- is the
+// SAME code a single stream runs (the phase interfaces of ReprojectorHip / PoseOptimizerHip / SparseImgAlignHip), on a
+// small pool of worker threads that write straight into the context's page-locked staging blocks; only the thread that
+// owns the context talks to the device.  Every alignment problem runs in the launch geometry it would get alone
+// (svoh_sparse_align_geometry_key), every other kernel's result does not depend on what shares its launch: a stream's
+// trajectory and counters are those of its single-stream run, byte for byte (tests/test_mini_frontend_gpu.py).
+//
+// Like tools/svoh_mini_frontend.cpp's single-stream chain this is an integration harness above the mirrors, NOT the
+// reference's frame handler: no map, no initialiser (first pose and depth prior are given), keyframes by a fixed rule.
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "svo_hip_io.h"
+
+namespace svo_hip {
+
+// A fixed set of threads that run `fn(item)` for item = 0 .. n-1 and return when all are done; the calling thread takes
+// part.  Waiting threads spin briefly (a phase follows the last within microseconds), then yield, then sleep.
+class WorkerPool {
+ public:
+  explicit WorkerPool(int n_threads);   // n_threads >= 1 counts the caller: n_threads - 1 threads are started
+  ~WorkerPool();
+  WorkerPool(const WorkerPool&) = delete;
+  WorkerPool& operator=(const WorkerPool&) = delete;
+  int size() const { return static_cast<int>(threads_.size()) + 1; }
+  // exceptions thrown by fn are collected; the first one is rethrown here once every item has been handled or skipped
+  void run(int n_items, const std::function<void(int)>& fn);
+
+ private:
+  void worker();
+  void work_off();
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::atomic<unsigned long> generation_{ 0 };
+  std::atomic<int> next_{ 0 }, pending_{ 0 }, n_items_{ 0 };
+  std::atomic<int> sleepers_{ 0 };
+  std::atomic<bool> stop_{ false };
+  const std::function<void(int)>* fn_ = nullptr;
+  std::mutex err_mu_;
+  std::exception_ptr error_;
+};
+
+struct LockstepOptions {
+  io::FrontendParams params;
+  svoh_camera cam{};
+  Transformation T_B_C{ { 1, 0, 0, 0 }, { 0, 0, 0 } };
+  float depth_min = 1.f, depth_mean = 2.f, depth_max = 4.f;   // the depth prior of a new keyframe's seeds
+  size_t kf_every = 8, min_tracked = 60;                     // the harness' keyframe rule
+  int n_workers = 1;                                          // host threads, the caller included
+  int images_mem_space = SVOH_MEM_HOST;                       // SVOH_MEM_HOST_PINNED: images live in svoh_host_alloc memory
+};
+
+class FrontendLockstep {
+ public:
+  // what a stream's frame left behind (the columns of svoh_mini_frontend's frontend.csv)
+  struct FrameRow { size_t k = 0; bool is_kf = false; size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0, n_converged = 0; };
+  struct RoundTimes { double pyramid = 0, align = 0, reproject = 0, pose = 0, seeds = 0, keyframe = 0, total = 0; };   // ms, the round as a whole
+
+  FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepOptions& options);
+  ~FrontendLockstep();
+  FrontendLockstep(const FrontendLockstep&) = delete;
+  FrontendLockstep& operator=(const FrontendLockstep&) = delete;
+
+  int numStreams() const { return static_cast<int>(streams_.size()); }
+  // One frame of every stream: images[s] = level 0 of stream s' image (all of the camera's size, `pitch` bytes per row).
+  // The first call makes every stream's first keyframe at T_f_w_first[s].
+  void addImages(const uint8_t* const* images, int pitch, const Transformation* T_f_w_first);
+  // the pose of stream s after the last addImages (T_f_w of its newest frame)
+  const Transformation& pose(int s) const;
+  // Rows are complete once the frame's depth-filter update has been finished, i.e. at the start of the next addImages (or
+  // in finish()): completedRows(s) hands out, and forgets, the rows of stream s that became complete since the last call.
+  std::vector<FrameRow> completedRows(int s);
+  const RoundTimes& lastRoundTimes() const { return times_; }
+  size_t keyframesAlive(int s) const;
+  // waits for the depth-filter update in flight and completes the last rows
+  void finish();
+  // device calls per round of the last addImages, for the record (one per stage, whatever the number of streams)
+  int lastRoundDeviceCalls() const { return device_calls_; }
+
+ private:
+  struct Stream;
+  void finishSeedUpdate();
+  void makeKeyframes(const std::vector<int>& which);
+  void drainReleases();
+  void check(int rc, const char* what) const;
+
+  svoh_ctx* ctx_;
+  LockstepOptions opt_;
+  WorkerPool pool_;
+  std::vector<std::unique_ptr<Stream>> streams_;
+  size_t round_ = 0;
+  bool seeds_in_flight_ = false;
+  RoundTimes times_;
+  int device_calls_ = 0;
+  // device pyramids to give up: frames die on whatever thread drops their last reference, the context is single-threaded
+  std::mutex release_mu_;
+  std::vector<svoh_frame_t> to_release_;
+  // the seed update in flight: where each stream's slice of the staged batch lies
+  svoh_matcher_stage_t seed_stage_{};
+};
+
+}  // namespace svo_hip

@@ -133,3 +133,31 @@ def test_pipelined_flow_equals_the_blocking_flow(tmp_path):
     assert np.array_equal(runs["pipelined + prepared seed update"][1], runs["blocking"][1])
     print("steady-state ms/frame: pipelined mean %.3f median %.3f, blocking mean %.3f median %.3f" %
           (runs["pipelined"][2].mean(), np.median(runs["pipelined"][2]), runs["blocking"][2].mean(), np.median(runs["blocking"][2])))
+
+
+def test_lockstep_streams_reproduce_the_single_stream(tmp_path):
+    """Round 5: FrontendLockstep (host/svo_hip_lockstep.h) takes one frame of EVERY stream at a time and runs each stage of
+    the chain as ONE launch for all of them -- alignment problems grouped by the launch geometry each would get alone, one
+    staged candidate projection, one direct + one seed batch with a current frame per stream, one pose batch, one seed
+    update, one detector call for the round's new keyframes -- with the streams' host work on a pool of threads.  Every
+    stream must write the trajectory AND the counters of the single-stream harness, byte for byte, whatever the number of
+    streams, worker threads and groups."""
+    cmd, out_dir, poses, stamps, n_frames = make_dataset(tmp_path)
+    r = subprocess.run(cmd + [str(n_frames), "8", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    single = open(str(out_dir / "trajectory.txt")).read()
+    single_counters = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)[:, :7].copy()
+    assert len(single.splitlines()) == n_frames
+    for n_streams, n_workers, n_groups in ((1, 1, 1), (5, 1, 1), (8, 3, 1), (12, 2, 2)):
+        for d in [out_dir] + [out_dir / ("stream%d" % k) for k in range(1, 64)]:
+            for name in ("trajectory.txt", "frontend.csv"):
+                if (d / name).exists():
+                    (d / name).unlink()
+        r = subprocess.run(cmd + [str(n_frames), "8", str(n_streams), "lockstep", str(n_workers), str(n_groups)], capture_output=True, text=True)
+        print(r.stdout, r.stderr)
+        assert r.returncode == 0, r.stdout + r.stderr
+        for k in range(n_streams):
+            d = out_dir if k == 0 else out_dir / ("stream%d" % k)
+            assert open(str(d / "trajectory.txt")).read() == single, "stream %d of %d (workers %d, groups %d)" % (k, n_streams, n_workers, n_groups)
+            counters = np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :7]
+            assert np.array_equal(counters, single_counters), "counters of stream %d of %d" % (k, n_streams)

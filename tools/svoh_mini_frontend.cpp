@@ -12,7 +12,7 @@
 // fixed rule (every <kf_every> frames or when fewer than <min_tracked> features survive).
 //
 //   svoh_mini_frontend <dataset_root> <calib.yaml> <params.yaml|-> <out_dir> <T_f_w of frame 0: qw qx qy qz tx ty tz>
-//                      <depth_min> <depth_mean> <depth_max> [max_frames] [kf_every] [n_streams]
+//                      <depth_min> <depth_mean> <depth_max> [max_frames] [kf_every] [n_streams] [threads|lockstep] [n_workers] [n_groups] [n_laps]
 // Writes <out>/trajectory.txt (TUM format, T_world_cam) and <out>/frontend.csv (per-frame counters and timings).
 // Environment: SVOH_MINI_SYNC=1 runs every stage as a blocking call, in the reference's order (round 2's flow); by
 // default (a) the candidate projection of the reprojector (f-4) is queued on the device behind the alignment launch
@@ -24,12 +24,20 @@
 // ONE GPU; stream k > 0 writes into <out>/stream<k>/.  At EuRoC sizes a stream keeps the GPU busy for a small part
 // of its frame time (every stage is a latency-bound round trip), so streams share a GPU almost for free until the
 // host cores or the launch path saturate: the tool prints the aggregate frame rate.
+// `lockstep` (round 5; host/svo_hip_lockstep.h): the n_streams streams take one frame each at a time and every STAGE of
+// the chain is ONE launch for all of them (FrontendLockstep), their host work spread over n_workers threads; n_groups > 1
+// runs that many lock-step groups side by side (own context, own threads, n_streams / n_groups streams each), so that one
+// group's host phases overlap the other's device phases.  Every stream writes the trajectory and the counters of its
+// single-stream run, byte for byte (tests/test_mini_frontend_gpu.py).  n_laps > 1 runs the sequence that many times back
+// to back in the lock-step mode (the poses restart, the files hold the last lap): a longer steady state for the rate.
 #include <sys/stat.h>
 
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <deque>
 #include <stdexcept>
 #include <string>
@@ -37,6 +45,7 @@
 #include <vector>
 
 #include "../svo_pro_universal_amd/host/svo_hip_io.h"
+#include "../svo_pro_universal_amd/host/svo_hip_lockstep.h"
 
 using namespace svo_hip;
 
@@ -210,6 +219,90 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
     start_gate->fetch_add(1);   // never leave the other streams waiting at the gate
   }
 }
+
+// one lock-step group: streams [s0, s0 + n) of the run, all fed the same decoded sequence
+struct GroupResult { size_t frames = 0; double wall_ms = 0, steady_ms = 0; size_t steady_rounds = 0; int device_calls = 0; FrontendLockstep::RoundTimes mean{}; std::string error; };
+void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::GrayImage>& images, const std::vector<io::RigCamera>& rig, const io::FrontendParams& params,
+                        const std::string& out_dir, const Transformation& T0, float depth_min, float depth_mean, float depth_max, size_t kf_every, int s0, int n,
+                        int n_workers, int n_laps, std::atomic<int>* start_gate, int n_groups, GroupResult* out)
+{
+  try {
+    svoh_ctx* ctx = nullptr;
+    if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
+    // the decoded sequence in page-locked memory, as a camera driver that feeds a GPU would deliver its images; like the
+    // threads of the other mode, the streams of a group share it read-only (every stream's image still crosses PCIe by itself)
+    const size_t img_bytes = (size_t)images[0].width * images[0].height;
+    uint8_t* pinned = nullptr;
+    if (svoh_host_alloc(ctx, img_bytes * images.size(), (void**)&pinned) != SVOH_OK) throw std::runtime_error(std::string("svoh_host_alloc: ") + svoh_last_error_string(ctx));
+    for (size_t k = 0; k < images.size(); ++k) {
+      if ((size_t)images[k].width * images[k].height != img_bytes) throw std::runtime_error("images of different sizes");
+      memcpy(pinned + k * img_bytes, images[k].data.data(), img_bytes);
+    }
+    for (int lap = 0; lap < n_laps; ++lap) {
+      LockstepOptions lo;
+      lo.params = params; lo.cam = rig.at(0).cam; lo.T_B_C = rig[0].T_B_C;
+      lo.depth_min = depth_min; lo.depth_mean = depth_mean; lo.depth_max = depth_max; lo.kf_every = kf_every; lo.n_workers = n_workers;
+      lo.images_mem_space = SVOH_MEM_HOST_PINNED;
+      FrontendLockstep fe(ctx, n, lo);
+      const bool last_lap = lap + 1 == n_laps;
+      std::vector<std::unique_ptr<io::TrajectoryWriter>> traj;
+      std::vector<FILE*> csv;
+      if (last_lap)
+        for (int i = 0; i < n; ++i) {
+          const int s = s0 + i;
+          const std::string dir = s == 0 ? out_dir : out_dir + "/stream" + std::to_string(s);
+          traj.emplace_back(new io::TrajectoryWriter(dir + "/trajectory.txt"));
+          FILE* fc = fopen((dir + "/frontend.csv").c_str(), "w");
+          if (!fc) throw std::runtime_error("cannot write into " + dir);
+          fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_converged_seeds,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf,ms_frame\n");
+          csv.push_back(fc);
+        }
+      std::vector<FrontendLockstep::RoundTimes> times;
+      auto write_rows = [&]() {
+        for (int i = 0; i < n; ++i)
+          for (const FrontendLockstep::FrameRow& r : fe.completedRows(i)) {
+            if (!last_lap) continue;
+            const FrontendLockstep::RoundTimes& t = times.at(r.k);
+            fprintf(csv[(size_t)i], "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", r.k, (int)r.is_kf, r.n_aligned, r.n_reproj, r.n_pose, r.n_seed_upd,
+                    r.n_converged, t.pyramid, t.align, t.reproject, t.pose, t.seeds, t.keyframe, t.total);
+          }
+      };
+      std::vector<const uint8_t*> ptrs((size_t)n);
+      std::vector<Transformation> T_first((size_t)n, T0);
+      if (lap == 0) {   // all groups start their first frame together
+        start_gate->fetch_add(1);
+        while (start_gate->load() < n_groups) std::this_thread::yield();
+      }
+      const double wall0 = now_ms();
+      for (size_t k = 0; k < images.size(); ++k) {
+        for (int i = 0; i < n; ++i) ptrs[(size_t)i] = pinned + k * img_bytes;
+        const double tr0 = now_ms();
+        fe.addImages(ptrs.data(), images[k].width, T_first.data());
+        const double tr1 = now_ms();
+        FrontendLockstep::RoundTimes t = fe.lastRoundTimes();
+        t.total = tr1 - tr0;
+        times.push_back(t);
+        if (last_lap) for (int i = 0; i < n; ++i) traj[(size_t)i]->write(seq.cam_ts[k], svoh::inverse(fe.pose(i)));
+        write_rows();
+        if (k >= 3) {   // frames 1-2 pay the one-time costs (code objects, the scratch buffers' first allocation)
+          out->steady_ms += tr1 - tr0; ++out->steady_rounds;
+          out->mean.pyramid += t.pyramid; out->mean.align += t.align; out->mean.reproject += t.reproject; out->mean.pose += t.pose; out->mean.seeds += t.seeds; out->mean.keyframe += t.keyframe;
+        }
+        out->device_calls = fe.lastRoundDeviceCalls();
+        out->frames += (size_t)n;
+      }
+      fe.finish();
+      write_rows();
+      out->wall_ms += now_ms() - wall0;
+      for (FILE* f : csv) fclose(f);
+    }
+    (void)svoh_host_free(ctx, pinned);
+    svoh_destroy(ctx);
+  } catch (const std::exception& e) {
+    out->error = e.what();
+    start_gate->fetch_add(1);
+  }
+}
 }  // namespace
 
 int main(int argc, char** argv)
@@ -228,9 +321,46 @@ int main(int argc, char** argv)
     const size_t max_frames = argc > 15 ? (size_t)atol(argv[15]) : seq.size();
     const size_t kf_every = argc > 16 ? (size_t)atol(argv[16]) : 8;
     const int n_streams = argc > 17 ? atoi(argv[17]) : 1;
-    if (n_streams < 1 || n_streams > 64) throw std::runtime_error("n_streams out of range [1, 64]");
+    const bool lockstep = argc > 18 && std::string(argv[18]) == "lockstep";
+    if (argc > 18 && !lockstep && std::string(argv[18]) != "threads") throw std::runtime_error("mode must be threads or lockstep");
+    if (n_streams < 1 || n_streams > (lockstep ? 256 : 64)) throw std::runtime_error("n_streams out of range");
     std::vector<io::GrayImage> images;
     for (size_t k = 0; k < seq.size() && k < max_frames; ++k) images.push_back(io::readPngGray(seq.cam0_files[k]));
+    if (lockstep) {
+      const int n_workers = argc > 19 ? atoi(argv[19]) : 1;
+      const int n_groups = argc > 20 ? atoi(argv[20]) : 1;
+      const int n_laps = argc > 21 ? atoi(argv[21]) : 1;
+      if (n_workers < 1 || n_workers > 256 || n_groups < 1 || n_groups > n_streams || n_laps < 1) throw std::runtime_error("n_workers / n_groups / n_laps out of range");
+      if (images.empty()) throw std::runtime_error("no images");
+      for (int s = 1; s < n_streams; ++s) (void)mkdir((out_dir + "/stream" + std::to_string(s)).c_str(), 0755);
+      std::vector<GroupResult> res((size_t)n_groups);
+      std::atomic<int> gate(0);
+      std::vector<std::thread> threads;
+      auto group_range = [&](int g, int* s0, int* n) { *s0 = (int)((long long)n_streams * g / n_groups); *n = (int)((long long)n_streams * (g + 1) / n_groups) - *s0; };
+      for (int g = 1; g < n_groups; ++g) {
+        int s0, n; group_range(g, &s0, &n);
+        threads.emplace_back(run_lockstep_group, std::cref(seq), std::cref(images), std::cref(rig), std::cref(params), out_dir, std::cref(T0), depth_min, depth_mean, depth_max,
+                             kf_every, s0, n, n_workers, n_laps, &gate, n_groups, &res[(size_t)g]);
+      }
+      { int s0, n; group_range(0, &s0, &n); run_lockstep_group(seq, images, rig, params, out_dir, T0, depth_min, depth_mean, depth_max, kf_every, s0, n, n_workers, n_laps, &gate, n_groups, &res[0]); }
+      for (std::thread& t : threads) t.join();
+      for (const GroupResult& r : res) if (!r.error.empty()) throw std::runtime_error(r.error);
+      double wall = 0, steady_rate = 0;
+      size_t frames = 0;
+      for (int g = 0; g < n_groups; ++g) {
+        const GroupResult& r = res[(size_t)g];
+        int s0, n; group_range(g, &s0, &n);
+        wall = r.wall_ms > wall ? r.wall_ms : wall; frames += r.frames;
+        if (r.steady_rounds) steady_rate += 1e3 * n * (double)r.steady_rounds / r.steady_ms;
+      }
+      const GroupResult& r0 = res[0];
+      const double nr = r0.steady_rounds ? (double)r0.steady_rounds : 1.0;
+      printf("svoh_mini_frontend lockstep: %d streams in %d group(s), %d host thread(s) per group: %zu frames in %.1f ms = %.0f frames/s overall, %.0f frames/s in steady state; "
+             "a round of group 0: %.3f ms (pyramid %.3f align %.3f reproject %.3f pose %.3f seeds %.3f keyframe %.3f), %d device calls per round\n",
+             n_streams, n_groups, n_workers, frames, wall, 1e3 * frames / wall, steady_rate, r0.steady_ms / nr, r0.mean.pyramid / nr, r0.mean.align / nr, r0.mean.reproject / nr,
+             r0.mean.pose / nr, r0.mean.seeds / nr, r0.mean.keyframe / nr, r0.device_calls);
+      return 0;
+    }
     std::vector<StreamResult> results((size_t)n_streams);
     std::atomic<int> gate(0);
     std::vector<std::thread> threads;
