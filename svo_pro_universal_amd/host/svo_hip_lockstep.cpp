@@ -1,7 +1,11 @@
 // svo_hip_lockstep.cpp -- FrontendLockstep (svo_hip_lockstep.h): many camera streams, one launch per stage.
 #include "svo_hip_lockstep.h"
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -18,10 +22,57 @@
 namespace svo_hip {
 
 // ---- WorkerPool --------------------------------------------------------------------------------------------------
-WorkerPool::WorkerPool(int n_threads)
+namespace {
+// the CPUs this process may run on, one hardware thread per core first (so that a pool smaller than the mask does not
+// put two busy threads on the two hardware threads of one core)
+std::vector<int> allowed_cpus()
 {
+  std::vector<int> cpus;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) != 0) return cpus;
+  std::vector<int> first, rest;
+  std::vector<std::pair<int, int>> seen_cores;   // (package, core)
+  for (int c = 0; c < CPU_SETSIZE; ++c) {
+    if (!CPU_ISSET(c, &set)) continue;
+    int core = c, pkg = 0;
+    {
+      char path[128];
+      snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/core_id", c);
+      if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &core) != 1) core = c; fclose(f); }
+      snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/physical_package_id", c);
+      if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &pkg) != 1) pkg = 0; fclose(f); }
+    }
+    const std::pair<int, int> key(pkg, core);
+    bool dup = false;
+    for (const auto& k : seen_cores) dup = dup || k == key;
+    if (dup) rest.push_back(c); else { seen_cores.push_back(key); first.push_back(c); }
+  }
+  cpus = first;
+  cpus.insert(cpus.end(), rest.begin(), rest.end());
+  return cpus;
+}
+std::atomic<unsigned> g_next_cpu_slot{ 0 };
+void bind_to(int cpu)
+{
+  if (cpu < 0) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  CPU_SET(cpu, &set);
+  (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
+}  // namespace
+
+WorkerPool::WorkerPool(int n_threads, bool pin)
+{
+  if (n_threads < 1) n_threads = 1;
+  std::vector<int> cpus;
+  if (pin) cpus = allowed_cpus();
+  const unsigned slot0 = cpus.empty() ? 0u : g_next_cpu_slot.fetch_add(static_cast<unsigned>(n_threads));
+  auto cpu_of = [&](int tid) { return cpus.empty() ? -1 : cpus[(slot0 + static_cast<unsigned>(tid)) % cpus.size()]; };
+  bind_to(cpu_of(0));
   for (int i = 1; i < n_threads; ++i) {
-    try { threads_.emplace_back(&WorkerPool::worker, this); }
+    try { threads_.emplace_back(&WorkerPool::worker, this, i, cpu_of(i)); }
     catch (...) { break; }   // a thread that cannot be started (pid limit of a container): the pool is smaller, nothing else
   }
 }
@@ -34,26 +85,25 @@ WorkerPool::~WorkerPool()
   for (std::thread& t : threads_) t.join();
 }
 
-void WorkerPool::work_off()
+void WorkerPool::work_off(int tid)
 {
-  for (;;) {
-    const int i = next_.fetch_add(1, std::memory_order_acq_rel);
-    if (i >= n_items_.load(std::memory_order_acquire)) break;
+  const int n = n_items_.load(std::memory_order_acquire), step = size();
+  for (int i = tid; i < n; i += step) {
     try { (*fn_)(i); }
     catch (...) { std::lock_guard<std::mutex> lock(err_mu_); if (!error_) error_ = std::current_exception(); }
-    pending_.fetch_sub(1, std::memory_order_acq_rel);
   }
 }
 
-void WorkerPool::worker()
+void WorkerPool::worker(int tid, int cpu)
 {
+  bind_to(cpu);
   unsigned long seen = 0;
   for (;;) {
     // the next phase usually follows within microseconds: spin, then yield, then sleep
     int spins = 0;
     while (generation_.load(std::memory_order_acquire) == seen) {
-      if (spins < 4000) { SVOH_CPU_RELAX(); ++spins; }
-      else if (spins < 4400) { std::this_thread::yield(); ++spins; }
+      if (spins < 20000) { SVOH_CPU_RELAX(); ++spins; }
+      else if (spins < 20400) { std::this_thread::yield(); ++spins; }
       else {
         sleepers_.fetch_add(1);
         {
@@ -65,7 +115,10 @@ void WorkerPool::worker()
     }
     if (stop_.load()) return;
     seen = generation_.load(std::memory_order_acquire);
-    work_off();
+    work_off(tid);
+    // every thread reports back, with or without items of its own: run() does not return -- and the next run() does not
+    // publish its items -- before all of them have, so that no thread can ever be a run behind
+    pending_.fetch_sub(1, std::memory_order_acq_rel);
   }
 }
 
@@ -74,13 +127,13 @@ void WorkerPool::run(int n_items, const std::function<void(int)>& fn)
   if (n_items <= 0) return;
   if (threads_.empty() || n_items == 1) { for (int i = 0; i < n_items; ++i) fn(i); return; }
   { std::lock_guard<std::mutex> lock(err_mu_); error_ = nullptr; }
+  // (every thread of the pool has reported back from the run before)
   fn_ = &fn;
   n_items_.store(n_items, std::memory_order_release);
-  pending_.store(n_items, std::memory_order_release);   // before next_ is reset: a worker still in its last loop may start on the new items at once
-  next_.store(0, std::memory_order_release);
+  pending_.store(static_cast<int>(threads_.size()), std::memory_order_release);
   generation_.fetch_add(1);
   if (sleepers_.load() > 0) { std::lock_guard<std::mutex> lock(mu_); cv_.notify_all(); }
-  work_off();
+  work_off(0);
   while (pending_.load(std::memory_order_acquire) != 0) SVOH_CPU_RELAX();
   std::exception_ptr e;
   { std::lock_guard<std::mutex> lock(err_mu_); e = error_; error_ = nullptr; }
@@ -91,6 +144,23 @@ void WorkerPool::run(int n_items, const std::function<void(int)>& fn)
 namespace {
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
+
+namespace {
+enum Phase { kPhPyramid = 0, kPhFinishSeeds, kPhAlignPrep, kPhAlignLaunch, kPhProjGather, kPhAlignWait, kPhWalkPlan, kPhMatchStage, kPhMatchCopy, kPhMatchSubmit, kPhSort,
+             kPhMatchWait, kPhReplay, kPhPoseCall, kPhPoseApply, kPhSeedStage, kPhSeedGather, kPhSeedSubmit, kPhKeyframe, kPhRest };
+struct PhaseClock {
+  double* acc; double t;
+  explicit PhaseClock(double* a) : acc(a), t(now_ms()) {}
+  void lap(int k) { const double n = now_ms(); acc[k] += n - t; t = n; }
+};
+}  // namespace
+
+const char* FrontendLockstep::phaseName(int k)
+{
+  static const char* names[] = { "pyramid", "finish seeds", "align prep", "align launch", "projection gather", "align wait", "walk + plan", "match stage", "match copy",
+                                 "match submit", "sort", "match wait", "replay + pose prep", "pose call", "pose apply", "seed stage", "seed gather", "seed submit", "keyframe", "rest" };
+  return k >= 0 && k < (int)(sizeof names / sizeof names[0]) ? names[k] : "";
+}
 
 struct FrontendLockstep::Stream {
   SparseImgAlignHip img_align;
@@ -138,7 +208,7 @@ void FrontendLockstep::check(int rc, const char* what) const
 }
 
 FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepOptions& options)
-    : ctx_(ctx), opt_(options), pool_(options.n_workers < 1 ? 1 : options.n_workers)
+    : ctx_(ctx), opt_(options), pool_(options.n_workers < 1 ? 1 : options.n_workers, options.pin_workers)
 {
   if (!ctx_) throw std::runtime_error("FrontendLockstep: NULL svoh_ctx (no CPU fallback exists)");
   if (n_streams < 1 || n_streams > 256) throw std::runtime_error("FrontendLockstep: n_streams out of range [1, 256]");
@@ -216,9 +286,9 @@ void FrontendLockstep::finishSeedUpdate()
       if (st.row_open) st.row.n_seed_upd = n_success;
     });
   }
-  for (auto& stp : streams_) {
-    Stream& st = *stp;
-    if (!st.row_open) continue;
+  pool_.run(numStreams(), [&](int s) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    if (!st.row_open) return;
     size_t n_conv = 0;
     for (const FramePtr& f : st.kfs)
       for (size_t i = 0; i < f->num_features_; ++i)
@@ -226,7 +296,7 @@ void FrontendLockstep::finishSeedUpdate()
     st.row.n_converged = n_conv;
     st.done_rows.push_back(st.row);
     st.row_open = false;
-  }
+  });
 }
 
 // make_keyframe of the harness for the streams in `which` (their current frame): the detector on every frame in ONE
@@ -292,6 +362,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   device_calls_ = 0;
   times_ = RoundTimes();
   const double t0 = now_ms();
+  PhaseClock pc(phase_ms_);
   drainReleases();
 
   // ---- pyramids of the round's S images: one call
@@ -313,8 +384,10 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       st.frame = frame;
     }
   }
+  pc.lap(kPhPyramid);
   // the previous round's seed update: its results are needed from here on (alignment points, candidates)
   finishSeedUpdate();
+  pc.lap(kPhFinishSeeds);
   const double t1 = now_ms();
   times_.pyramid = t1 - t0;
 
@@ -347,6 +420,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     st.T_iref_world = st.img_align.prepareRun(st.b_last, st.b_cur, st.align_opt, st.align_pb);
     st.reprojector.countCandidateProjection(st.visible, &st.proj_points, &st.proj_kf);
   });
+  pc.lap(kPhAlignPrep);
   std::vector<svoh_align_result> align_results(static_cast<size_t>(S));
   std::vector<uint8_t> align_repeated(static_cast<size_t>(S), 0);
   svoh_candidate_stage_t cs{};
@@ -370,6 +444,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
             "svoh_sparse_align_enqueue_keyed");
       ++device_calls_;
     }
+    pc.lap(kPhAlignLaunch);
     // the candidate projections: one staged call for all streams that have a local map
     size_t n_points = 0, n_kf = 0;
     int n_jobs = 0;
@@ -399,6 +474,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       check(svoh_project_candidates_enqueue_staged(ctx_), "svoh_project_candidates_enqueue_staged");
       ++device_calls_;
     }
+    pc.lap(kPhProjGather);
     check(svoh_sparse_align_fetch_all(ctx_, S, align_results.data()), "svoh_sparse_align_fetch_all");
     ++device_calls_;
     if (n_jobs) check(svoh_project_candidates_wait(ctx_), "svoh_project_candidates_wait");
@@ -412,6 +488,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       ++device_calls_;
     }
   }
+  pc.lap(kPhAlignWait);
   const double t2 = now_ms();
   times_.align = t2 - t1;
 
@@ -429,6 +506,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     // would need a round trip of its own)
     st.reprojector.planMatches(st.frame, 3);
   });
+  pc.lap(kPhWalkPlan);
   svoh_matcher_stage_t ds{}, ss{};
   size_t n_direct = 0, n_seeds = 0, n_refs = 0;
   for (auto& stp : streams_) {
@@ -446,6 +524,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     if (n_direct) check(svoh_matcher_stage(ctx_, 0, static_cast<int>(n_direct), max_views, 1, &ds), "svoh_matcher_stage");
     if (n_seeds) check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_seeds), max_views, 1, &ss), "svoh_matcher_stage");
     std::vector<svoh_frame_view> refs(n_refs ? n_refs : 1), curs(static_cast<size_t>(S));
+    pc.lap(kPhMatchStage);
     pool_.run(S, [&](int s) {
       Stream& st = *streams_[static_cast<size_t>(s)];
       detail::SpeculativeMatches& sm = st.reprojector.plannedMatches();
@@ -463,6 +542,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       copy_batch(sm.seeds, ss, st.seeds_off);
       if (const size_t m = sm.seeds.size()) memcpy(ss.state + 4 * st.seeds_off, sm.seeds.state.data(), 32 * m);
     });
+    pc.lap(kPhMatchCopy);
     auto batch_of = [&](const svoh_matcher_stage_t& g, size_t n) {
       svoh_feature_batch fb{};
       fb.n = static_cast<int32_t>(n);
@@ -485,11 +565,14 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     }
     check(svoh_matcher_flush(ctx_), "svoh_matcher_flush");
     ++device_calls_;
+    pc.lap(kPhMatchSubmit);
     // sortCandidatesByReprojStats of every stream's three lists while the device works
     pool_.run(S, [&](int s) { streams_[static_cast<size_t>(s)]->reprojector.sortCandidateLists(); });
+    pc.lap(kPhSort);
     close_section.armed = false;
     check(svoh_matcher_collect(ctx_), "svoh_matcher_collect");
     ++device_calls_;
+    pc.lap(kPhMatchWait);
   } else {
     pool_.run(S, [&](int s) { streams_[static_cast<size_t>(s)]->reprojector.sortCandidateLists(); });
   }
@@ -514,6 +597,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     st.do_pose = st.frame->num_features_ >= 10;
     if (st.do_pose) st.pose_optimizer.prepareRun(st.b_cur, 2.0, st.pose_opt, st.pose_pb);
   });
+  pc.lap(kPhReplay);
   const double t3 = now_ms();
   times_.reproject = t3 - t2;
 
@@ -530,10 +614,12 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       std::vector<svoh_pose_result> res(pbs.size());
       check(svoh_optimize_pose_batch(ctx_, &streams_[static_cast<size_t>(who[0])]->pose_opt, static_cast<int>(pbs.size()), pbs.data(), res.data()), "svoh_optimize_pose_batch");
       ++device_calls_;
+      pc.lap(kPhPoseCall);
       pool_.run(static_cast<int>(who.size()), [&](int w) {
         Stream& st = *streams_[static_cast<size_t>(who[static_cast<size_t>(w)])];
         st.row.n_pose = st.pose_optimizer.finishRun(st.b_cur, res[static_cast<size_t>(w)]);
       });
+      pc.lap(kPhPoseApply);
     }
   }
   const double t4 = now_ms();
@@ -562,6 +648,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_total), static_cast<int>(n_ref_total) + S + 1, 0, &seed_stage_), "svoh_matcher_stage");
       const svoh_matcher_stage_t& g = seed_stage_;
       std::vector<svoh_frame_view> refs(n_ref_total ? n_ref_total : 1), curs(static_cast<size_t>(S));
+      pc.lap(kPhSeedStage);
       pool_.run(S, [&](int s) {
         Stream& st = *streams_[static_cast<size_t>(s)];
         curs[static_cast<size_t>(s)] = detail::viewOf(*st.frame);
@@ -577,6 +664,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
           off += n;
         }
       });
+      pc.lap(kPhSeedGather);
       svoh_feature_batch fb{};
       fb.n = static_cast<int32_t>(n_total);
       fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = S;
@@ -590,6 +678,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       seeds_in_flight_ = true;
     }
   }
+  pc.lap(kPhSeedSubmit);
   const double t5 = now_ms();
   times_.seeds = t5 - t4;
 
@@ -612,6 +701,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     st.last = st.frame; st.frame.reset();
   }
   drainReleases();
+  pc.lap(kPhKeyframe);
   const double t6 = now_ms();
   times_.keyframe = t6 - t5;
   times_.total = t6 - t0;

@@ -44,22 +44,26 @@ namespace svo_hip {
 // part.  Waiting threads spin briefly (a phase follows the last within microseconds), then yield, then sleep.
 class WorkerPool {
  public:
-  explicit WorkerPool(int n_threads);   // n_threads >= 1 counts the caller: n_threads - 1 threads are started
+  // n_threads >= 1 counts the caller: n_threads - 1 threads are started.  pin: every thread of the pool -- the calling
+  // thread included, for good -- is bound to a CPU of its own out of the process' affinity mask, one hardware thread per
+  // core first; pools made one after the other (one per lock-step group) take consecutive CPUs.
+  explicit WorkerPool(int n_threads, bool pin = false);
   ~WorkerPool();
   WorkerPool(const WorkerPool&) = delete;
   WorkerPool& operator=(const WorkerPool&) = delete;
   int size() const { return static_cast<int>(threads_.size()) + 1; }
-  // exceptions thrown by fn are collected; the first one is rethrown here once every item has been handled or skipped
+  // exceptions thrown by fn are collected; the first one is rethrown here once every item has been handled or skipped.
+  // Item i always goes to thread i % size(): a stream's data stays in the caches of the core that touched it last.
   void run(int n_items, const std::function<void(int)>& fn);
 
  private:
-  void worker();
-  void work_off();
+  void worker(int tid, int cpu);
+  void work_off(int tid);
   std::vector<std::thread> threads_;
   std::mutex mu_;
   std::condition_variable cv_;
   std::atomic<unsigned long> generation_{ 0 };
-  std::atomic<int> next_{ 0 }, pending_{ 0 }, n_items_{ 0 };
+  std::atomic<int> pending_{ 0 }, n_items_{ 0 };
   std::atomic<int> sleepers_{ 0 };
   std::atomic<bool> stop_{ false };
   const std::function<void(int)>* fn_ = nullptr;
@@ -74,6 +78,7 @@ struct LockstepOptions {
   float depth_min = 1.f, depth_mean = 2.f, depth_max = 4.f;   // the depth prior of a new keyframe's seeds
   size_t kf_every = 8, min_tracked = 60;                     // the harness' keyframe rule
   int n_workers = 1;                                          // host threads, the caller included
+  bool pin_workers = false;                                   // bind them to CPUs of their own (WorkerPool)
   int images_mem_space = SVOH_MEM_HOST;                       // SVOH_MEM_HOST_PINNED: images live in svoh_host_alloc memory
 };
 
@@ -103,6 +108,10 @@ class FrontendLockstep {
   void finish();
   // device calls per round of the last addImages, for the record (one per stage, whatever the number of streams)
   int lastRoundDeviceCalls() const { return device_calls_; }
+  // where the rounds' time went, phase by phase (sums over all rounds since construction, ms), with the phases' names
+  static constexpr int kNumPhases = 24;
+  const double* phaseTimes() const { return phase_ms_; }
+  static const char* phaseName(int k);
 
  private:
   struct Stream;
@@ -119,6 +128,7 @@ class FrontendLockstep {
   bool seeds_in_flight_ = false;
   RoundTimes times_;
   int device_calls_ = 0;
+  double phase_ms_[kNumPhases] = {};
   // device pyramids to give up: frames die on whatever thread drops their last reference, the context is single-threaded
   std::mutex release_mu_;
   std::vector<svoh_frame_t> to_release_;

@@ -147,7 +147,7 @@ def test_lockstep_streams_reproduce_the_single_stream(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     single = open(str(out_dir / "trajectory.txt")).read()
     single_counters = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)[:, :7].copy()
-    assert len(single.splitlines()) == n_frames
+    assert len(single.splitlines()) == n_frames + 1   # header line
     for n_streams, n_workers, n_groups in ((1, 1, 1), (5, 1, 1), (8, 3, 1), (12, 2, 2)):
         for d in [out_dir] + [out_dir / ("stream%d" % k) for k in range(1, 64)]:
             for name in ("trajectory.txt", "frontend.csv"):

@@ -243,6 +243,7 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
       lo.params = params; lo.cam = rig.at(0).cam; lo.T_B_C = rig[0].T_B_C;
       lo.depth_min = depth_min; lo.depth_mean = depth_mean; lo.depth_max = depth_max; lo.kf_every = kf_every; lo.n_workers = n_workers;
       lo.images_mem_space = SVOH_MEM_HOST_PINNED;
+      lo.pin_workers = getenv("SVOH_LOCKSTEP_PIN") != nullptr && atoi(getenv("SVOH_LOCKSTEP_PIN")) != 0;   // (a shared box: its low CPUs are everybody's)
       FrontendLockstep fe(ctx, n, lo);
       const bool last_lap = lap + 1 == n_laps;
       std::vector<std::unique_ptr<io::TrajectoryWriter>> traj;
@@ -294,6 +295,12 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
       fe.finish();
       write_rows();
       out->wall_ms += now_ms() - wall0;
+      if (last_lap && s0 == 0 && getenv("SVOH_LOCKSTEP_TIMING")) {
+        const double* ph = fe.phaseTimes();
+        fprintf(stderr, "[lockstep] mean ms per round over %zu rounds:", images.size());
+        for (int k = 0; k < FrontendLockstep::kNumPhases; ++k) if (ph[k] > 0) fprintf(stderr, " %s %.3f,", FrontendLockstep::phaseName(k), ph[k] / (double)images.size());
+        fprintf(stderr, "\n");
+      }
       for (FILE* f : csv) fclose(f);
     }
     (void)svoh_host_free(ctx, pinned);
