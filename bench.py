@@ -602,6 +602,165 @@ def bench_frame(args, ctx, dist, rank, world, dev, comm_dev=None):
             "cpu_baseline": cpu}
 
 
+def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
+    """BASELINE config 5's "batched multi-sequence" on ONE GPU per rank: S camera streams through the whole per-frame chain
+    of FrameHandlerMono::processFrame (frame_handler_mono.cpp:120-158) in LOCK STEP -- sparse alignment + candidate
+    projection, reprojection (direct + seed matcher batches), pose optimisation, depth-filter update, detector and seed
+    initialisation at keyframes -- every stage ONE launch for all streams of a group (host/svo_hip_lockstep.h), the
+    streams' host work on W threads per group, G groups side by side (one group's host phases against the other's device
+    phases).  A step = one round = one frame of every stream.  The streams of a rank replay one rendered EuRoC-layout
+    sequence (752x480 radtan, forwards then backwards, so that the run never has to restart); images in page-locked
+    memory, every stream's image crossing PCIe by itself inside the timed region.  Per-stream results are those of the
+    single-stream chain byte for byte (tests/test_mini_frontend_gpu.py::test_lockstep_streams_reproduce_the_single_stream)."""
+    import threading
+    from svo_pro_universal_amd import lockstep as ls
+    cam = synth.Camera.euroc_like(752, 480)
+    n_frames = 40
+    sc = synth.make_align_scene(du.problem_seed(rank, 160), n_features=8, cam=cam, rot_deg=(0.3, 0.5), trans_m=(0.015, 0.025))
+    stepT = sc.T_w_ref.inverse() * sc.T_w_cur
+    poses = [sc.T_w_ref]
+    for _ in range(1, n_frames):
+        poses.append(poses[-1] * stepT)
+    images = [synth.render(cam, T, sc.plane, sc.tex) for T in poses]
+    depth = float(np.mean(sc.depth))
+    params = ("max_fts: 180\ngrid_size: 30\nn_pyr_levels: 3\ndetector_threshold_secondary: 100\nuse_threaded_depthfilter: False\n"
+              "img_align_max_level: 4\nimg_align_min_level: 2\n")
+    n_host = len(os.sched_getaffinity(0))
+    budget = int(os.environ.get("SVOH_BENCH_HOST_THREADS", "0")) or max(1, min(16, n_host // max(1, world)))
+
+    def frame_of(k):   # 0 1 .. n-1 n-2 .. 1 0 1 ..: the camera walks the path forth and back
+        k %= 2 * (n_frames - 1)
+        return k if k < n_frames else 2 * (n_frames - 1) - k
+
+    def run(S, G, W, n_warm, n_steps):
+        G = max(1, min(G, S))
+        ctxs = [ctx] + [fe.Context(dev.index if dev.index is not None else 0, kernel_timing=False) for _ in range(G - 1)]
+        ctx.set_kernel_timing(False)
+        pins = [ls.PinnedImages(c, images) for c in ctxs]
+        ranges = [(S * g // G, S * (g + 1) // G) for g in range(G)]
+        engines = [ls.Lockstep(c, hi - lo, cam, np.array([1.0, 0, 0, 0, 0, 0, 0]), params, 0.5 * depth, depth, 2.0 * depth, 8, W, True)
+                   for c, (lo, hi) in zip(ctxs, ranges)]
+        first = poses[0].inverse().as7()
+        total = n_warm + n_steps
+        gate = threading.Barrier(G + 1)
+        times = [[] for _ in range(G)]
+        errors = []
+
+        def loop(g):
+            try:
+                e, pin, n = engines[g], pins[g], ranges[g][1] - ranges[g][0]
+                for k in range(total):
+                    if k == n_warm:
+                        gate.wait()   # the timed region starts for every group at once
+                    a = pin.address(frame_of(k))
+                    e.add_images([a] * n, cam.width, [first] * n if k == 0 else None)
+                    if k >= n_warm:
+                        times[g].append(e.last_round()[0])
+                e.finish()
+                gate.wait()
+            except Exception as ex:   # noqa: BLE001 -- reported by the caller
+                errors.append(ex)
+                gate.abort()
+        th = [threading.Thread(target=loop, args=(g,)) for g in range(G)]
+        for t in th:
+            t.start()
+        try:
+            gate.wait()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            gate.wait()
+            elapsed = time.perf_counter() - t0
+        except threading.BrokenBarrierError:
+            elapsed = float("nan")
+        for t in th:
+            t.join()
+        if errors:
+            raise errors[0]
+        # where the streams ended up against the poses their last image was rendered at
+        gt = poses[frame_of(total - 1)].inverse()
+        err = [synth.se3_error(synth.SE3.from7(e.pose(0)), gt) for e in engines]
+        rows = engines[0].completed_rows(0)
+        stage = {k: float(np.median([t[k] for t in times[0]])) for k in times[0][0]} if times[0] else {}
+        calls = engines[0].last_round()[1]
+        for e in engines:
+            e.close()
+        for p in pins:
+            p.free()
+        for c in ctxs[1:]:
+            c.close()
+        return {"streams": S, "groups": G, "host_threads_per_group": W, "frames_per_s": S * n_steps / elapsed, "ms_per_round": 1e3 * elapsed / n_steps,
+                "round_stage_ms_median_group0": stage, "device_calls_per_round_per_group": calls,
+                "pose_err_vs_gt": {"rot_rad": float(max(e[0] for e in err)), "trans_m": float(max(e[1] for e in err))},
+                "features_per_frame_median": float(np.median(rows[1:, 3])) if len(rows) > 1 else None}, elapsed
+
+    def shape(S):   # groups and threads per group out of the rank's host-thread budget
+        G = 1 if S < 8 else min(4 if S >= 64 else 3 if S >= 24 else 2, budget)
+        return G, max(1, budget // G)
+
+    S = args.streams
+    G, W = (args.stream_groups, args.stream_workers) if args.stream_groups and args.stream_workers else shape(S)
+    main_run, elapsed = run(S, G, W, max(3, args.warmup), args.steps)
+    elapsed, total_frames = du.combine(dist, world, elapsed, S * args.steps, comm_dev)
+    sweep = []
+    if rank == 0 and world == 1 and not args.no_secondary:
+        for s2 in (1, 8, 32, 64):
+            if s2 == S:
+                sweep.append({k: main_run[k] for k in ("streams", "groups", "host_threads_per_group", "frames_per_s", "ms_per_round")})
+                continue
+            g2, w2 = shape(s2)
+            r2, _ = run(s2, g2, w2, 3, min(args.steps, 80))
+            sweep.append({k: r2[k] for k in ("streams", "groups", "host_threads_per_group", "frames_per_s", "ms_per_round")})
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_frame_stages(cam)
+    if rank != 0:
+        return None
+    return {"metric": "frames/s, S camera streams in lock step through the whole per-frame chain (align + reproject + pose + depth filter + keyframes), one launch per stage",
+            "value": total_frames / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_frame": 1e3 * elapsed / args.steps / S,
+            "dtype": "u8+i32+f32+f64",
+            "config": {"workload": "C5-synth per GPU: %d streams x 752x480 radtan in %d lock-step group(s) with %d host thread(s) each; per stream and frame: 5-level "
+                                   "pyramid, align <=180..720 patches 4x4 levels 4..2, ~100 direct + ~900 seed matcher units, pose over <=180 features, "
+                                   "depth-filter update of <=5 keyframes (~1600 seeds), a keyframe every 8 frames; a step = one frame of every stream; "
+                                   "the streams replay one rendered sequence forth and back" % (S, G, W),
+                       "streams": S, "groups": G, "host_threads_per_group": W, "host_cpus_visible": n_host},
+            "lockstep": main_run, "streams_sweep": sweep,
+            "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                         "note": "a chain of small latency-bound launches by design: the kernels' own rooflines are those of --workload align / seeds / pose / klt"},
+            "cpu_baseline": cpu}
+
+
+def cpu_frame_stages(cam):
+    """The device stages of one stream's frame through the oracle, one thread: 5-level pyramid, SparseImgAlign of 180 features
+    (levels 4..2), 100 direct matches, 900 + 1620 seed updates, the pose optimiser over 180 features.  Host bookkeeping
+    (candidate walk, sort, replay) is the same code on both sides and not part of it."""
+    from oracle import oracle as orc  # test infrastructure: the timed CPU baseline only
+    orc.build(fast=True)
+    sc = synth.make_align_scene(7, n_features=180, patch_size=4, cam=cam, max_level=4, rot_deg=(0.3, 1.0), trans_m=(0.03, 0.10))
+    opt = capi.default_align_options(max_level=4, min_level=2, patch_size=4)
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(cam)
+    NS = 900 + 1620
+    seeds = synth.make_seed_set(sc, NS, seed=2)
+    kf_idx = np.zeros(NS, dtype=np.int32)
+    ref = orc.create_img_pyramid(sc.img_ref, 5, fast=True)
+    c = []
+    t_cpu0 = time.perf_counter()
+    while time.perf_counter() - t_cpu0 < 10.0 and len(c) < 100:
+        t0 = time.perf_counter()
+        cur = orc.create_img_pyramid(sc.img_cur, 5, fast=True)
+        pb = orc.problem_from_scenes([(sc, ref, cur)])
+        orc.sparse_align_run(opt, pb, fast=True)
+        ov_r = [orc.make_frame_view(ref, cam, sc.T_ref_f_w, seeds["mu_range"], 0)]
+        ov_c = orc.make_frame_view(cur, cam, sc.T_cur_f_w_gt, 0.0, 100)
+        fbo, ko = orc.make_feature_batch(kf_idx, seeds["px"], seeds["f"], seeds["grad"], seeds["level"], seeds["type"])
+        orc.update_seeds_batch(mopt, dopt, ov_r, ov_c, fbo, seeds["state"], fast=True)
+        c.append(time.perf_counter() - t0)
+    med = float(np.median(c))
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d repetitions of one stream's frame through the oracle (pyramid + align 180 features + %d seed updates; gcc -O3 -march=native, 1 thread; "
+                      "the direct matches and the pose optimiser, ~5 %% of the frame, are left out)" % (len(c), NS)}
+
+
 def bench_frame_stereo(args, ctx, dist, rank, world, dev, comm_dev=None):
     """C4-synth, one stereo frame pair at a time (latency): BASELINE config 3 / 4 at the sizes of SURVEY.md Appendix A's
     stereo column.  Per pair: two 5-level pyramids (host images in); SparseImgAlign of the BUNDLE -- two cameras x 160
@@ -1074,6 +1233,7 @@ def claim_stdout():
 
 
 def emit(obj):
+    obj.setdefault("host_cpu_slice_rank0", _CPU_SLICE)
     sys.stdout.flush()
     os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(obj) + "\n").encode())
 
@@ -1095,6 +1255,9 @@ def parse_args(argv=None):
     ap.add_argument("--min-level", type=int, default=0)
     ap.add_argument("--max-level", type=int, default=4)
     ap.add_argument("--stereo", action="store_true", help="with --workload frame: the stereo pair chain (BASELINE config 3)")
+    ap.add_argument("--streams", type=int, default=0, help="with --workload frame: S camera streams per GPU through the whole chain in lock step (BASELINE config 5)")
+    ap.add_argument("--stream-groups", type=int, default=0, help="lock-step groups per GPU (default: chosen from S and the host-thread budget)")
+    ap.add_argument("--stream-workers", type=int, default=0, help="host threads per lock-step group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the 8x8-patch leg that the default line carries as `secondary`")
@@ -1123,6 +1286,25 @@ def launch_workers(n, argv):
     env.setdefault("OMP_NUM_THREADS", "4")
     print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env)
+
+
+_CPU_SLICE = None
+
+
+def pin_rank_to_its_cores(local_rank, world):
+    """One rank per GPU on one node: rank r takes the r-th of `world` equal slices of the CPUs this process may run on
+    (os.sched_setaffinity, before any GPU call and before any thread is started), so that the host-bound workloads --
+    the per-frame chains, whose time is host threads waiting on small launches -- do not share cores between ranks.
+    SVOH_BENCH_PIN=0 leaves the affinity alone.  Returns (and remembers for the line) the slice as "first-last (n)"."""
+    global _CPU_SLICE
+    cpus = sorted(os.sched_getaffinity(0))
+    if world > 1 and os.environ.get("SVOH_BENCH_PIN", "1") != "0" and len(cpus) >= world:
+        per = len(cpus) // world
+        mine = cpus[local_rank % world * per:(local_rank % world + 1) * per]
+        os.sched_setaffinity(0, mine)
+        cpus = mine
+    _CPU_SLICE = "%d-%d (%d)" % (cpus[0], cpus[-1], len(cpus))
+    return _CPU_SLICE
 
 
 def bench_launch_check(args, dist, rank, world, comm_dev):
@@ -1157,6 +1339,7 @@ def main(argv=None):
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a different n_gpus than asked for"
                          % (args.gpus, world))
     claim_stdout()
+    cpu_slice = pin_rank_to_its_cores(local_rank, world)
 
     # Rehearsal knobs for a one-GPU box (never set by the driver): all ranks on cuda:0 and gloo for the
     # barrier / MAX / SUM, because RCCL refuses two ranks on one device.
@@ -1186,7 +1369,8 @@ def main(argv=None):
 
     ctx = fe.Context(local_rank)
     if args.workload != "align":
-        out = {"klt": bench_klt, "seeds": bench_seeds, "frame": bench_frame_stereo if args.stereo else bench_frame, "detect": bench_detect,
+        out = {"klt": bench_klt, "seeds": bench_seeds,
+               "frame": bench_frame_streams if args.streams > 0 else (bench_frame_stereo if args.stereo else bench_frame), "detect": bench_detect,
                "pose": bench_pose,
                "align-split": bench_align_split, "align-c4": bench_align_c4, "stereo": bench_stereo,
                "launch-check": lambda a, c, d, r, w, dv, cd: bench_launch_check(a, d, r, w, cd)}[args.workload](

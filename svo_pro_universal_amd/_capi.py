@@ -403,6 +403,14 @@ def load(path=None):
     lib.svoh_epipolar_match_batch.argtypes = [C.c_void_p, P(svoh_matcher_options), C.c_int, P(svoh_frame_view),
                                               P(svoh_frame_view), P(svoh_se3), P(svoh_feature_batch), P(C.c_double),
                                               C.c_void_p, P(svoh_epipolar_match_outputs)]
+    lib.svoh_host_alloc.argtypes = [C.c_void_p, C.c_size_t, P(C.c_void_p)]
+    lib.svoh_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.svoh_build_pyramid_multi.argtypes = [C.c_void_p, P(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(svoh_frame_t)]
+    lib.svoh_sparse_align_geometry_key.argtypes = [C.c_void_p, P(svoh_align_options), P(svoh_align_problem), P(C.c_int32)]
+    lib.svoh_sparse_align_enqueue_keyed.argtypes = [C.c_void_p, P(svoh_align_options), C.c_int, P(svoh_align_problem), C.c_int32]
+    lib.svoh_detect_cells_batch.argtypes = [C.c_void_p, C.c_int, P(svoh_frame_t), P(svoh_detector_options), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svoh_detect_fill_features.argtypes = [P(svoh_detector_options), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int32)]
     if path is None:
         _LIB = lib
     return lib

@@ -709,3 +709,107 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
 }
 
 }  // namespace svo_hip
+
+// ---- C face (svo_hip_lockstep_c.h) ----------------------------------------------------------------------------------
+#include "svo_hip_lockstep_c.h"
+
+struct svohl_engine {
+  std::unique_ptr<svo_hip::FrontendLockstep> fe;
+  std::vector<std::vector<svo_hip::FrontendLockstep::FrameRow>> backlog;   // rows taken from the engine and not handed out yet
+};
+
+namespace {
+thread_local std::string g_svohl_error = "no error";
+template <class F>
+int svohl_guard(F&& f)
+{
+  try { f(); return SVOH_OK; }
+  catch (const std::bad_alloc&) { g_svohl_error = "out of host memory"; return SVOH_ERR_OUT_OF_MEMORY; }
+  catch (const std::exception& e) { g_svohl_error = e.what(); return SVOH_ERR_INVALID_ARGUMENT; }
+  catch (...) { g_svohl_error = "unknown exception"; return SVOH_ERR_INVALID_ARGUMENT; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* svohl_last_error(void) { return g_svohl_error.c_str(); }
+
+int svohl_create(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* params_yaml, double depth_min, double depth_mean,
+                 double depth_max, int kf_every, int n_workers, int images_pinned, svohl_engine** out)
+{
+  return svohl_guard([&] {
+    if (!out || !cam || !T_B_C) throw std::runtime_error("svohl_create: NULL argument");
+    *out = nullptr;
+    svo_hip::LockstepOptions lo;
+    lo.params = svo_hip::io::frontendParamsFromYaml(params_yaml ? svo_hip::io::parseYaml(params_yaml) : svo_hip::io::YamlNode());
+    lo.cam = *cam;
+    lo.T_B_C = svoh::load_rigid(*T_B_C);
+    lo.depth_min = static_cast<float>(depth_min); lo.depth_mean = static_cast<float>(depth_mean); lo.depth_max = static_cast<float>(depth_max);
+    lo.kf_every = kf_every > 0 ? static_cast<size_t>(kf_every) : 8;
+    lo.n_workers = n_workers;
+    lo.images_mem_space = images_pinned ? SVOH_MEM_HOST_PINNED : SVOH_MEM_HOST;
+    std::unique_ptr<svohl_engine> e(new svohl_engine);
+    e->fe.reset(new svo_hip::FrontendLockstep(ctx, n_streams, lo));
+    e->backlog.resize(static_cast<size_t>(n_streams));
+    *out = e.release();
+  });
+}
+
+void svohl_destroy(svohl_engine* e) { try { delete e; } catch (...) {} }
+
+int svohl_add_images(svohl_engine* e, const uint8_t* const* images, int pitch, const svoh_se3* T_f_w_first)
+{
+  return svohl_guard([&] {
+    if (!e || !images) throw std::runtime_error("svohl_add_images: NULL argument");
+    std::vector<svo_hip::Transformation> T;
+    if (T_f_w_first) for (int s = 0; s < e->fe->numStreams(); ++s) T.push_back(svoh::load_rigid(T_f_w_first[s]));
+    e->fe->addImages(images, pitch, T.empty() ? nullptr : T.data());
+  });
+}
+
+int svohl_pose(svohl_engine* e, int stream, svoh_se3* T_f_w)
+{
+  return svohl_guard([&] {
+    if (!e || !T_f_w) throw std::runtime_error("svohl_pose: NULL argument");
+    svoh::store_rigid(e->fe->pose(stream), *T_f_w);
+  });
+}
+
+int svohl_last_round(svohl_engine* e, double times_ms[7], int* device_calls)
+{
+  return svohl_guard([&] {
+    if (!e) throw std::runtime_error("svohl_last_round: NULL argument");
+    const svo_hip::FrontendLockstep::RoundTimes& t = e->fe->lastRoundTimes();
+    if (times_ms) { times_ms[0] = t.pyramid; times_ms[1] = t.align; times_ms[2] = t.reproject; times_ms[3] = t.pose; times_ms[4] = t.seeds; times_ms[5] = t.keyframe; times_ms[6] = t.total; }
+    if (device_calls) *device_calls = e->fe->lastRoundDeviceCalls();
+  });
+}
+
+int svohl_completed_rows(svohl_engine* e, int stream, int max_rows, int64_t* rows, int* n_rows)
+{
+  return svohl_guard([&] {
+    if (!e || !n_rows || (max_rows > 0 && !rows)) throw std::runtime_error("svohl_completed_rows: NULL argument");
+    std::vector<svo_hip::FrontendLockstep::FrameRow>& b = e->backlog.at(static_cast<size_t>(stream));
+    for (const auto& r : e->fe->completedRows(stream)) b.push_back(r);
+    int n = 0;
+    while (n < max_rows && static_cast<size_t>(n) < b.size()) {
+      const auto& r = b[static_cast<size_t>(n)];
+      int64_t* o = rows + 7 * n;
+      o[0] = static_cast<int64_t>(r.k); o[1] = r.is_kf; o[2] = static_cast<int64_t>(r.n_aligned); o[3] = static_cast<int64_t>(r.n_reproj);
+      o[4] = static_cast<int64_t>(r.n_pose); o[5] = static_cast<int64_t>(r.n_seed_upd); o[6] = static_cast<int64_t>(r.n_converged);
+      ++n;
+    }
+    b.erase(b.begin(), b.begin() + n);
+    *n_rows = n;
+  });
+}
+
+int svohl_finish(svohl_engine* e)
+{
+  return svohl_guard([&] {
+    if (!e) throw std::runtime_error("svohl_finish: NULL argument");
+    e->fe->finish();
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+/* svo_hip_lockstep_c.h -- a C face of FrontendLockstep (svo_hip_lockstep.h) in libsvo_hip_host.so, for callers without a
+ * C++ compiler at hand (bench.py drives it through ctypes).  Same conventions as include/svo_hip.h: int status, no
+ * exception crosses the boundary, svohl_last_error() has the text (per calling thread).  One engine = one lock-step group
+ * on one svoh_ctx; an engine's calls come from one thread at a time (several engines may run on several threads). */
+#ifndef SVO_HIP_LOCKSTEP_C_H_
+#define SVO_HIP_LOCKSTEP_C_H_
+
+#include "../../include/svo_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svohl_engine svohl_engine;
+
+/* params_yaml: the reference's parameter file as text (the keys of svo_factory.cpp this library implements; NULL = the
+ * defaults).  images_pinned != 0: the images passed to svohl_add_images live in svoh_host_alloc memory. */
+int svohl_create(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* params_yaml,
+                 double depth_min, double depth_mean, double depth_max, int kf_every, int n_workers, int images_pinned,
+                 svohl_engine** out);
+void svohl_destroy(svohl_engine* e);
+/* one frame of every stream (FrontendLockstep::addImages); T_f_w_first: n_streams poses for the first call, else ignored */
+int svohl_add_images(svohl_engine* e, const uint8_t* const* images, int pitch, const svoh_se3* T_f_w_first);
+int svohl_pose(svohl_engine* e, int stream, svoh_se3* T_f_w);
+/* pyramid, align, reproject, pose, seeds, keyframe, total of the last round (ms) and its device calls */
+int svohl_last_round(svohl_engine* e, double times_ms[7], int* device_calls);
+/* the rows of `stream` completed since the last call: 7 integers each (frame, is_kf, n_aligned, n_reprojected,
+ * n_after_pose_opt, n_seeds_updated, n_converged_seeds); at most max_rows are handed out, *n_rows = how many */
+int svohl_completed_rows(svohl_engine* e, int stream, int max_rows, int64_t* rows, int* n_rows);
+int svohl_finish(svohl_engine* e);
+const char* svohl_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

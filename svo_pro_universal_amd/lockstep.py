@@ -1,0 +1,125 @@
+"""ctypes plumbing over the C face of FrontendLockstep (host/svo_hip_lockstep_c.h in libsvo_hip_host.so): many camera
+streams through the per-frame chain in lock step, one launch per stage.  The engine itself is C++ (host/svo_hip_lockstep.cpp);
+this file only marshals pointers for bench.py and the tests.  No CPU path: the library is loaded or an error is raised."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi as capi
+from . import frontend as fe
+
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "libsvo_hip_host.so")
+_HOST = None
+
+
+def load_host():
+    global _HOST
+    if _HOST is not None:
+        return _HOST
+    capi.load()   # libsvo_hip.so first: the same HIP runtime as the rest of the process (see _capi._share_hip_runtime_with_torch)
+    if not os.path.exists(HOST_LIB_PATH):
+        raise RuntimeError("libsvo_hip_host.so not built (%s): __graft_entry__.build()" % HOST_LIB_PATH)
+    lib = C.CDLL(HOST_LIB_PATH, mode=C.RTLD_GLOBAL)
+    P = C.POINTER
+    lib.svohl_create.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_camera), P(capi.svoh_se3), C.c_char_p, C.c_double, C.c_double, C.c_double,
+                                 C.c_int, C.c_int, C.c_int, P(C.c_void_p)]
+    lib.svohl_destroy.argtypes = [C.c_void_p]
+    lib.svohl_destroy.restype = None
+    lib.svohl_add_images.argtypes = [C.c_void_p, P(C.c_void_p), C.c_int, C.c_void_p]
+    lib.svohl_pose.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_se3)]
+    lib.svohl_last_round.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int)]
+    lib.svohl_completed_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_int64), P(C.c_int)]
+    lib.svohl_finish.argtypes = [C.c_void_p]
+    lib.svohl_last_error.restype = C.c_char_p
+    _HOST = lib
+    return lib
+
+
+class PinnedImages(object):
+    """A sequence of equally sized u8 images in page-locked memory of a context (svoh_host_alloc)."""
+
+    def __init__(self, ctx, images):
+        self.ctx = ctx
+        self.n = len(images)
+        self.bytes = int(images[0].size)
+        p = C.c_void_p()
+        ctx._check(ctx.lib.svoh_host_alloc(ctx.h, C.c_size_t(self.bytes * self.n), C.byref(p)))
+        self.ptr = p.value
+        for k, im in enumerate(images):
+            a = np.ascontiguousarray(im, dtype=np.uint8)
+            assert a.size == self.bytes
+            C.memmove(self.ptr + k * self.bytes, a.ctypes.data, self.bytes)
+
+    def address(self, k):
+        return self.ptr + k * self.bytes
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.svoh_host_free(self.ctx.h, C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+class Lockstep(object):
+    """One lock-step group of n_streams streams on the context `ctx` (frontend.Context)."""
+
+    def __init__(self, ctx, n_streams, cam, T_B_C7, params_yaml, depth_min, depth_mean, depth_max, kf_every=8, n_workers=1, images_pinned=True):
+        self.lib = load_host()
+        self.ctx = ctx
+        self.n = int(n_streams)
+        h = C.c_void_p()
+        c = fe._camera(cam)
+        T = fe._se3(np.asarray(T_B_C7, dtype=np.float64))
+        rc = self.lib.svohl_create(ctx.h, self.n, C.byref(c), C.byref(T), params_yaml.encode() if params_yaml else None, float(depth_min),
+                                   float(depth_mean), float(depth_max), int(kf_every), int(n_workers), 1 if images_pinned else 0, C.byref(h))
+        if rc != 0:
+            raise fe.SvohError(rc, self.lib.svohl_last_error().decode())
+        self.h = h
+        self._ptrs = (C.c_void_p * self.n)()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise fe.SvohError(rc, self.lib.svohl_last_error().decode())
+
+    def add_images(self, addresses, pitch, T_f_w_first=None):
+        """addresses: n_streams host addresses (ints) of the streams' level-0 images."""
+        for i, a in enumerate(addresses):
+            self._ptrs[i] = a
+        first = None
+        if T_f_w_first is not None:
+            arr = (capi.svoh_se3 * self.n)()
+            for i, T in enumerate(T_f_w_first):
+                arr[i] = fe._se3(T)
+            first = C.cast(arr, C.c_void_p)
+        self._check(self.lib.svohl_add_images(self.h, self._ptrs, int(pitch), first))
+
+    def pose(self, s):
+        T = capi.svoh_se3()
+        self._check(self.lib.svohl_pose(self.h, int(s), C.byref(T)))
+        return fe.se3_to_numpy(T)
+
+    def last_round(self):
+        t = (C.c_double * 7)()
+        n = C.c_int()
+        self._check(self.lib.svohl_last_round(self.h, t, C.byref(n)))
+        return dict(zip(("pyramid", "align", "reproject", "pose", "seeds", "keyframe", "total"), list(t))), n.value
+
+    def completed_rows(self, s, max_rows=4096):
+        rows = (C.c_int64 * (7 * max_rows))()
+        n = C.c_int()
+        self._check(self.lib.svohl_completed_rows(self.h, int(s), max_rows, rows, C.byref(n)))
+        return np.array(rows[:7 * n.value], dtype=np.int64).reshape(-1, 7)
+
+    def finish(self):
+        self._check(self.lib.svohl_finish(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.svohl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
