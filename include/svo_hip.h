@@ -158,6 +158,14 @@ int svoh_host_free(svoh_ctx* ctx, void* p);
 int svoh_build_pyramid_multi(svoh_ctx* ctx, const uint8_t* const* imgs, int n_images, int width, int height, int pitch,
                              int mem_space, int n_levels, int rounding, svoh_frame_t* out_frames);
 
+/* The same on a SECOND stream of the context, beside whatever the context's own stream is given afterwards: how the next
+ * frames' images cross PCIe while the current frames' chain is still running.  Call it when the context's stream is idle
+ * -- right behind a call that waited; it waits for the stream otherwise -- and call svoh_prefetch_fence before the first
+ * use of the frames: the fence makes the context's stream wait (on the device, not the host) for the prefetch. */
+int svoh_build_pyramid_multi_prefetch(svoh_ctx* ctx, const uint8_t* const* imgs, int n_images, int width, int height, int pitch,
+                                      int mem_space, int n_levels, int rounding, svoh_frame_t* out_frames);
+int svoh_prefetch_fence(svoh_ctx* ctx);
+
 /* Copy one level of a device frame back to the host (tightly packed). */
 int svoh_download_level(svoh_ctx* ctx, svoh_frame_t frame, int level,
                         uint8_t* out, int* out_width, int* out_height);

@@ -15,6 +15,11 @@ if os.environ.get("TOOL", "mono") == "stereo":   # tools/svoh_mini_stereo on the
     cmd = cmd + [str(n_frames), "8", "0.5"]
 else:
     cmd, out_dir, poses, stamps, n_frames = t.make_dataset(tmp)
+# LOCKSTEP="S:W:G[:laps]": the lock-step mode of the tool (host/svo_hip_lockstep.h) instead of one stream per thread
+if os.environ.get("LOCKSTEP"):
+    ls_ = os.environ["LOCKSTEP"].split(":")
+    cmd = cmd + [str(n_frames), "8", ls_[0], "lockstep", ls_[1], ls_[2]] + ([ls_[3]] if len(ls_) > 3 else [])
+    rnd = rnd + "_lockstep_S%s_W%s_G%s" % tuple(ls_[:3])
 prof = tmp / "prof"
 env = dict(os.environ, TMPDIR="/tmp")
 # the tool itself directly after `--` (no shell, no env wrapper: the profiler's preload initialises the GPU first)

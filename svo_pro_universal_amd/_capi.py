@@ -275,7 +275,7 @@ EXPORTS = [
     "svoh_project_candidates_enqueue", "svoh_project_candidates_collect", "svoh_project_candidates",
     "svoh_detect_features", "svoh_optimize_pose_batch", "svoh_optimize_pose_batch_packed", "svoh_optimize_points_batch",
     # round 5: what the lock-step front end of many camera streams stages in place and launches once per stage
-    "svoh_host_alloc", "svoh_host_free", "svoh_build_pyramid_multi",
+    "svoh_host_alloc", "svoh_host_free", "svoh_build_pyramid_multi", "svoh_build_pyramid_multi_prefetch", "svoh_prefetch_fence",
     "svoh_sparse_align_geometry_key", "svoh_sparse_align_enqueue_keyed",
     "svoh_project_candidates_stage", "svoh_project_candidates_enqueue_staged", "svoh_project_candidates_wait",
     "svoh_matcher_stage", "svoh_detect_cells_batch", "svoh_detect_fill_features",

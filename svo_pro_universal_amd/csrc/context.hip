@@ -419,7 +419,7 @@ void load_knobs_from_env(SvohKnobs& k)
   k.copy_kernel = get("SVOH_COPY_KERNEL");
 }
 
-static int build_pyramid_levels(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab, uint8_t* base, size_t fbytes, const size_t* offs, const int* ws,
+static int build_pyramid_levels(svoh_ctx* ctx, hipStream_t stream, const std::shared_ptr<Slab>& slab, uint8_t* base, size_t fbytes, const size_t* offs, const int* ws,
                                 const int* hs, int n_images, int width, int height, int n_levels, int rounding, svoh_frame_t* out_frames);
 
 extern "C" {
@@ -485,6 +485,7 @@ try {
   if (!ctx) return SVOH_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+  if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); }
   ctx->frames.clear();
   for (int k = 0; k < svoh_ctx::kAlignEventRing; ++k) {
     if (ctx->ev_align_start[k]) (void)hipEventDestroy(ctx->ev_align_start[k]);
@@ -494,6 +495,8 @@ try {
   if (ctx->ev_misc_start) (void)hipEventDestroy(ctx->ev_misc_start);
   if (ctx->ev_misc_stop) (void)hipEventDestroy(ctx->ev_misc_stop);
   if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
+  if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
+  if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SVOH_OK;
@@ -587,12 +590,12 @@ try {
       SVOH_HIP_TRY(ctx, hipMemcpy2DAsync(base + fbytes * i, (size_t)width, img + image_stride * i, (size_t)pitch,
                                          (size_t)width, (size_t)height, kind, ctx->stream));
   }
-  const int rc_levels = build_pyramid_levels(ctx, slab, base, fbytes, offs, ws, hs, n_images, width, height, n_levels, rounding, out_frames);
+  const int rc_levels = build_pyramid_levels(ctx, ctx->stream, slab, base, fbytes, offs, ws, hs, n_images, width, height, n_levels, rounding, out_frames);
   return rc_levels;
 } SVOH_ABI_CATCH(ctx)
 
-// levels 1.. of n_images frames whose level 0 is in place (queued on the context's stream), and the frames' handles
-static int build_pyramid_levels(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab, uint8_t* base, size_t fbytes, const size_t* offs, const int* ws,
+// levels 1.. of n_images frames whose level 0 is in place (queued on `stream`), and the frames' handles
+static int build_pyramid_levels(svoh_ctx* ctx, hipStream_t stream, const std::shared_ptr<Slab>& slab, uint8_t* base, size_t fbytes, const size_t* offs, const int* ws,
                                 const int* hs, int n_images, int width, int height, int n_levels, int rounding, svoh_frame_t* out_frames)
 {
   int first_single = 1;   // levels from here on are made one launch each
@@ -610,14 +613,14 @@ static int build_pyramid_levels(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab
       pa.base = base; pa.frame_stride = fbytes; pa.n_steps = n_steps;
       for (int k = 0; k <= n_steps; ++k) { pa.off[k] = offs[k]; pa.w[k] = ws[k]; pa.h[k] = hs[k]; }
       const dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 63) / 64), (unsigned)n_images);
-      hipLaunchKernelGGL(pyramid_fused_kernel, grid, dim3(256), 0, ctx->stream, pa);
+      hipLaunchKernelGGL(pyramid_fused_kernel, grid, dim3(256), 0, stream, pa);
       SVOH_HIP_TRY(ctx, hipGetLastError());
       first_single = n_steps + 1;
     }
   }
   for (int l = first_single; l < n_levels; ++l) {
     // zero-fill is not needed: every byte of a level the reference would write is written
-    SVOH_HIP_TRY(ctx, launch_half_sample(ctx->stream, base + offs[l - 1], fbytes, ws[l - 1], hs[l - 1], ws[l - 1],
+    SVOH_HIP_TRY(ctx, launch_half_sample(stream, base + offs[l - 1], fbytes, ws[l - 1], hs[l - 1], ws[l - 1],
                                          base + offs[l], fbytes, ws[l], n_images, rounding));
   }
   for (int i = 0; i < n_images; ++i)
@@ -625,9 +628,9 @@ static int build_pyramid_levels(svoh_ctx* ctx, const std::shared_ptr<Slab>& slab
   return SVOH_OK;
 }
 
-int svoh_build_pyramid_multi(svoh_ctx* ctx, const uint8_t* const* imgs, int n_images, int width, int height, int pitch,
-                             int mem_space, int n_levels, int rounding, svoh_frame_t* out_frames)
-try {
+static int build_pyramid_multi_on(svoh_ctx* ctx, hipStream_t stream, const uint8_t* const* imgs, int n_images, int width, int height, int pitch,
+                                  int mem_space, int n_levels, int rounding, svoh_frame_t* out_frames)
+{
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, imgs && out_frames, "NULL argument");
   SVOH_REQUIRE(ctx, n_images >= 1 && width > 0 && height > 0 && pitch >= width, "bad image geometry");
@@ -649,14 +652,51 @@ try {
     for (int i = 0; i < n_images; ++i) ga.src[i] = imgs[i];
     for (int i = n_images; i < 256; ++i) ga.src[i] = nullptr;
     // enough loads in flight to fill the link: 16 workgroups of 256 x 16 bytes per image
-    hipLaunchKernelGGL(gather_images_kernel, dim3(16, (unsigned)n_images), dim3(256), 0, ctx->stream, ga);
+    hipLaunchKernelGGL(gather_images_kernel, dim3(16, (unsigned)n_images), dim3(256), 0, stream, ga);
     SVOH_HIP_TRY(ctx, hipGetLastError());
   } else {
     const hipMemcpyKind kind = mem_space == SVOH_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     for (int i = 0; i < n_images; ++i)
-      SVOH_HIP_TRY(ctx, hipMemcpy2DAsync(base + fbytes * i, (size_t)width, imgs[i], (size_t)pitch, (size_t)width, (size_t)height, kind, ctx->stream));
+      SVOH_HIP_TRY(ctx, hipMemcpy2DAsync(base + fbytes * i, (size_t)width, imgs[i], (size_t)pitch, (size_t)width, (size_t)height, kind, stream));
   }
-  return build_pyramid_levels(ctx, slab, base, fbytes, offs, ws, hs, n_images, width, height, n_levels, rounding, out_frames);
+  return build_pyramid_levels(ctx, stream, slab, base, fbytes, offs, ws, hs, n_images, width, height, n_levels, rounding, out_frames);
+}
+
+int svoh_build_pyramid_multi(svoh_ctx* ctx, const uint8_t* const* imgs, int n_images, int width, int height, int pitch,
+                             int mem_space, int n_levels, int rounding, svoh_frame_t* out_frames)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  return build_pyramid_multi_on(ctx, ctx->stream, imgs, n_images, width, height, pitch, mem_space, n_levels, rounding, out_frames);
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_build_pyramid_multi_prefetch(svoh_ctx* ctx, const uint8_t* const* imgs, int n_images, int width, int height, int pitch,
+                                      int mem_space, int n_levels, int rounding, svoh_frame_t* out_frames)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->upload_stream) {
+    SVOH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    SVOH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
+  }
+  // The slab the frames go into may come from the pool of released frames, whose last readers were queued on the context's
+  // own stream: that stream has to be idle now (returns at once when it is, which is when a caller should prefetch --
+  // right behind a call that waited), and whatever it is given from here on cannot know these slabs.
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const int rc = build_pyramid_multi_on(ctx, ctx->upload_stream, imgs, n_images, width, height, pitch, mem_space, n_levels, rounding, out_frames);
+  if (rc != SVOH_OK) return rc;
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->upload_stream));
+  ctx->upload_pending = true;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_prefetch_fence(svoh_ctx* ctx)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!ctx->upload_pending) return SVOH_OK;
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SVOH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));
+  ctx->upload_pending = false;
+  return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
 int svoh_host_alloc(svoh_ctx* ctx, size_t bytes, void** out)

@@ -181,6 +181,10 @@ struct svoh_ctx {
   bool align_no_cluster = false;   // svoh_sparse_align_batch repeating a launch whose cluster gave up
   hipEvent_t ev_misc_start = nullptr, ev_misc_stop = nullptr;  // KLT / matcher / seeds
   hipEvent_t ev_pose_done = nullptr;   // svoh_optimize_pose_batch_hook: behind the copy of the results (made at first use)
+  // svoh_build_pyramid_multi_prefetch: the next frames' images come up on a stream of their own, beside the chain's work
+  hipStream_t upload_stream = nullptr;
+  hipEvent_t ev_upload = nullptr;
+  bool upload_pending = false;           // ev_upload recorded and not yet waited for by the context's stream (svoh_prefetch_fence)
   bool misc_timed = false;     // the last KLT / matcher / seed / pose / detector launch was bracketed by the event pair
   bool misc_launched = false;  // ... has happened at all (its work counters exist)
   unsigned long long align_timed_launches = 0;   // alignment launches bracketed by events (ring slots in use)

@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -66,6 +67,9 @@ void bind_to(int cpu)
 WorkerPool::WorkerPool(int n_threads, bool pin)
 {
   if (n_threads < 1) n_threads = 1;
+  // how long an idle worker spins (pause instructions), then yields, before it sleeps: SVOH_LOCKSTEP_SPIN / _YIELD
+  if (const char* e = getenv("SVOH_LOCKSTEP_SPIN")) spin_limit_ = atoi(e);
+  if (const char* e = getenv("SVOH_LOCKSTEP_YIELD")) yield_limit_ = atoi(e);
   std::vector<int> cpus;
   if (pin) cpus = allowed_cpus();
   const unsigned slot0 = cpus.empty() ? 0u : g_next_cpu_slot.fetch_add(static_cast<unsigned>(n_threads));
@@ -102,8 +106,8 @@ void WorkerPool::worker(int tid, int cpu)
     // the next phase usually follows within microseconds: spin, then yield, then sleep
     int spins = 0;
     while (generation_.load(std::memory_order_acquire) == seen) {
-      if (spins < 20000) { SVOH_CPU_RELAX(); ++spins; }
-      else if (spins < 20400) { std::this_thread::yield(); ++spins; }
+      if (spins < spin_limit_) { SVOH_CPU_RELAX(); ++spins; }
+      else if (spins < spin_limit_ + yield_limit_) { std::this_thread::yield(); ++spins; }
       else {
         sleepers_.fetch_add(1);
         {
@@ -231,6 +235,7 @@ FrontendLockstep::~FrontendLockstep()
   }
   streams_.clear();
   drainReleases();
+  for (svoh_frame_t h : prefetched_) if (h) (void)svoh_release_frame(ctx_, h);
 }
 
 void FrontendLockstep::drainReleases()
@@ -356,7 +361,19 @@ void FrontendLockstep::makeKeyframes(const std::vector<int>& which)
   });
 }
 
-void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const Transformation* T_f_w_first)
+void FrontendLockstep::prefetch(const uint8_t* const* next_images, int pitch)
+{
+  if (!next_images || !prefetched_.empty()) return;
+  const int S = numStreams();
+  prefetched_.assign(static_cast<size_t>(S), 0);
+  prefetched_from_.assign(next_images, next_images + S);
+  const int rc = svoh_build_pyramid_multi_prefetch(ctx_, next_images, S, opt_.cam.width, opt_.cam.height, pitch, opt_.images_mem_space, opt_.params.n_pyr_levels_to_build,
+                                                   SVOH_HALFSAMPLE_REFERENCE, prefetched_.data());
+  if (rc != SVOH_OK) { prefetched_.clear(); prefetched_from_.clear(); check(rc, "svoh_build_pyramid_multi_prefetch"); }
+  ++device_calls_;
+}
+
+void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const Transformation* T_f_w_first, const uint8_t* const* next_images)
 {
   const int S = numStreams();
   device_calls_ = 0;
@@ -368,9 +385,17 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   // ---- pyramids of the round's S images: one call
   {
     std::vector<svoh_frame_t> handles(static_cast<size_t>(S));
-    check(svoh_build_pyramid_multi(ctx_, images, S, opt_.cam.width, opt_.cam.height, pitch, opt_.images_mem_space, opt_.params.n_pyr_levels_to_build,
-                                   SVOH_HALFSAMPLE_REFERENCE, handles.data()), "svoh_build_pyramid_multi");
-    ++device_calls_;
+    if (!prefetched_.empty()) {   // made during the round before
+      for (int s = 0; s < S; ++s)
+        if (prefetched_from_[static_cast<size_t>(s)] != images[s]) throw std::runtime_error("FrontendLockstep::addImages: not the images that were announced as next_images");
+      handles.swap(prefetched_);
+      prefetched_.clear(); prefetched_from_.clear();
+      check(svoh_prefetch_fence(ctx_), "svoh_prefetch_fence");
+    } else {
+      check(svoh_build_pyramid_multi(ctx_, images, S, opt_.cam.width, opt_.cam.height, pitch, opt_.images_mem_space, opt_.params.n_pyr_levels_to_build,
+                                     SVOH_HALFSAMPLE_REFERENCE, handles.data()), "svoh_build_pyramid_multi");
+      ++device_calls_;
+    }
     for (int s = 0; s < S; ++s) {
       Stream& st = *streams_[static_cast<size_t>(s)];
       FramePtr frame(new Frame, [this](Frame* f) {
@@ -401,6 +426,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       st.last = st.frame; st.frame.reset();
       st.row = FrameRow(); st.row.k = 0; st.row.is_kf = true; st.row_open = true;
     }
+    prefetch(next_images, pitch);
     times_.keyframe = now_ms() - t1;
     times_.total = now_ms() - t0;
     ++round_;
@@ -576,6 +602,8 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   } else {
     pool_.run(S, [&](int s) { streams_[static_cast<size_t>(s)]->reprojector.sortCandidateLists(); });
   }
+  // the context's stream is idle here: the next round's images start their way up now, beside the rest of this round
+  prefetch(next_images, pitch);
   // the reference's three passes per stream on its slices of the finished batches, then the stream's pose problem
   pool_.run(S, [&](int s) {
     Stream& st = *streams_[static_cast<size_t>(s)];
@@ -764,6 +792,37 @@ int svohl_add_images(svohl_engine* e, const uint8_t* const* images, int pitch, c
     std::vector<svo_hip::Transformation> T;
     if (T_f_w_first) for (int s = 0; s < e->fe->numStreams(); ++s) T.push_back(svoh::load_rigid(T_f_w_first[s]));
     e->fe->addImages(images, pitch, T.empty() ? nullptr : T.data());
+  });
+}
+
+int svohl_run_sequence(svohl_engine* e, const uint8_t* base, size_t image_bytes, size_t stream_stride, int n_frames, int pitch, long k_first, int n_rounds,
+                       const svoh_se3* T_f_w_first, double* round_ms)
+{
+  return svohl_guard([&] {
+    if (!e || !base || n_frames < 2 || n_rounds < 0 || k_first < 0) throw std::runtime_error("svohl_run_sequence: bad arguments");
+    const int S = e->fe->numStreams();
+    std::vector<svo_hip::Transformation> T;
+    if (T_f_w_first) for (int s = 0; s < S; ++s) T.push_back(svoh::load_rigid(T_f_w_first[s]));
+    std::vector<const uint8_t*> ptrs(static_cast<size_t>(S)), next(static_cast<size_t>(S));
+    const long period = 2L * (n_frames - 1);
+    const bool prefetch = getenv("SVOH_LOCKSTEP_PREFETCH") == nullptr || atoi(getenv("SVOH_LOCKSTEP_PREFETCH")) != 0;
+    for (long k = k_first; k < k_first + n_rounds; ++k) {
+      const long m = k % period;
+      const long f = m < n_frames ? m : period - m;
+      const long m1 = (k + 1) % period;
+      const long f1 = m1 < n_frames ? m1 : period - m1;
+      for (int s = 0; s < S; ++s) {
+        ptrs[static_cast<size_t>(s)] = base + static_cast<size_t>(s) * stream_stride + static_cast<size_t>(f) * image_bytes;
+        next[static_cast<size_t>(s)] = base + static_cast<size_t>(s) * stream_stride + static_cast<size_t>(f1) * image_bytes;
+      }
+      // (the images of the round after this one are there already -- a replay: they go up during this round)
+      e->fe->addImages(ptrs.data(), pitch, T.empty() ? nullptr : T.data(), prefetch ? next.data() : nullptr);
+      if (round_ms) {
+        const svo_hip::FrontendLockstep::RoundTimes& t = e->fe->lastRoundTimes();
+        double* o = round_ms + 7 * (k - k_first);
+        o[0] = t.pyramid; o[1] = t.align; o[2] = t.reproject; o[3] = t.pose; o[4] = t.seeds; o[5] = t.keyframe; o[6] = t.total;
+      }
+    }
   });
 }
 

@@ -66,6 +66,7 @@ class WorkerPool {
   std::atomic<int> pending_{ 0 }, n_items_{ 0 };
   std::atomic<int> sleepers_{ 0 };
   std::atomic<bool> stop_{ false };
+  int spin_limit_ = 20000, yield_limit_ = 400;
   const std::function<void(int)>* fn_ = nullptr;
   std::mutex err_mu_;
   std::exception_ptr error_;
@@ -96,7 +97,10 @@ class FrontendLockstep {
   int numStreams() const { return static_cast<int>(streams_.size()); }
   // One frame of every stream: images[s] = level 0 of stream s' image (all of the camera's size, `pitch` bytes per row).
   // The first call makes every stream's first keyframe at T_f_w_first[s].
-  void addImages(const uint8_t* const* images, int pitch, const Transformation* T_f_w_first);
+  // next_images (may be NULL): the images of the NEXT call, if the caller has them already -- they are then sent to the
+  // device during this round, on a second stream beside the chain's work (svoh_build_pyramid_multi_prefetch), and the
+  // next call, which must be given exactly these pointers as `images`, finds its pyramids made.
+  void addImages(const uint8_t* const* images, int pitch, const Transformation* T_f_w_first, const uint8_t* const* next_images = nullptr);
   // the pose of stream s after the last addImages (T_f_w of its newest frame)
   const Transformation& pose(int s) const;
   // Rows are complete once the frame's depth-filter update has been finished, i.e. at the start of the next addImages (or
@@ -134,6 +138,10 @@ class FrontendLockstep {
   std::vector<svoh_frame_t> to_release_;
   // the seed update in flight: where each stream's slice of the staged batch lies
   svoh_matcher_stage_t seed_stage_{};
+  // the next round's pyramids, if the caller handed its images in early
+  std::vector<svoh_frame_t> prefetched_;
+  std::vector<const uint8_t*> prefetched_from_;
+  void prefetch(const uint8_t* const* next_images, int pitch);
 };
 
 }  // namespace svo_hip

@@ -21,6 +21,13 @@ int svohl_create(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svo
 void svohl_destroy(svohl_engine* e);
 /* one frame of every stream (FrontendLockstep::addImages); T_f_w_first: n_streams poses for the first call, else ignored */
 int svohl_add_images(svohl_engine* e, const uint8_t* const* images, int pitch, const svoh_se3* T_f_w_first);
+/* n_rounds calls of svohl_add_images in one: every stream gets image frame_of(k) of ONE sequence of n_frames images of
+ * image_bytes each -- stream s reads ITS copy of the sequence at base + s * stream_stride (0: one shared copy, which the
+ * device then serves from its caches after the first stream) -- k = k_first .. k_first + n_rounds - 1; frame_of walks 0 .. n-1, n-2 .. 1, 0, 1 ..: the
+ * camera goes the path forth and back, so a run never has to restart).  round_ms (may be NULL): 7 doubles per round as
+ * svohl_last_round.  For drivers whose own loop is slow (an interpreter holding a global lock between calls). */
+int svohl_run_sequence(svohl_engine* e, const uint8_t* base, size_t image_bytes, size_t stream_stride, int n_frames, int pitch, long k_first, int n_rounds,
+                       const svoh_se3* T_f_w_first, double* round_ms);
 int svohl_pose(svohl_engine* e, int stream, svoh_se3* T_f_w);
 /* pyramid, align, reproject, pose, seeds, keyframe, total of the last round (ms) and its device calls */
 int svohl_last_round(svohl_engine* e, double times_ms[7], int* device_calls);

@@ -28,6 +28,7 @@ def load_host():
     lib.svohl_destroy.restype = None
     lib.svohl_add_images.argtypes = [C.c_void_p, P(C.c_void_p), C.c_int, C.c_void_p]
     lib.svohl_pose.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_se3)]
+    lib.svohl_run_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
     lib.svohl_last_round.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int)]
     lib.svohl_completed_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_int64), P(C.c_int)]
     lib.svohl_finish.argtypes = [C.c_void_p]
@@ -37,22 +38,28 @@ def load_host():
 
 
 class PinnedImages(object):
-    """A sequence of equally sized u8 images in page-locked memory of a context (svoh_host_alloc)."""
+    """n_copies copies (one per camera stream) of a sequence of equally sized u8 images in page-locked memory of a context
+    (svoh_host_alloc).  One copy per stream, because the device reads the images in place: streams that shared a buffer
+    would be served from the device's caches after the first one instead of crossing PCIe, as the images of different
+    cameras must."""
 
-    def __init__(self, ctx, images):
+    def __init__(self, ctx, images, n_copies=1):
         self.ctx = ctx
         self.n = len(images)
         self.bytes = int(images[0].size)
+        self.copies = int(n_copies)
+        self.stride = self.bytes * self.n
         p = C.c_void_p()
-        ctx._check(ctx.lib.svoh_host_alloc(ctx.h, C.c_size_t(self.bytes * self.n), C.byref(p)))
+        ctx._check(ctx.lib.svoh_host_alloc(ctx.h, C.c_size_t(self.stride * self.copies), C.byref(p)))
         self.ptr = p.value
         for k, im in enumerate(images):
             a = np.ascontiguousarray(im, dtype=np.uint8)
             assert a.size == self.bytes
-            C.memmove(self.ptr + k * self.bytes, a.ctypes.data, self.bytes)
+            for c in range(self.copies):
+                C.memmove(self.ptr + c * self.stride + k * self.bytes, a.ctypes.data, self.bytes)
 
-    def address(self, k):
-        return self.ptr + k * self.bytes
+    def address(self, k, copy=0):
+        return self.ptr + copy * self.stride + k * self.bytes
 
     def free(self):
         if self.ptr:
@@ -92,6 +99,21 @@ class Lockstep(object):
                 arr[i] = fe._se3(T)
             first = C.cast(arr, C.c_void_p)
         self._check(self.lib.svohl_add_images(self.h, self._ptrs, int(pitch), first))
+
+    def run_sequence(self, pinned, pitch, k_first, n_rounds, T_f_w_first=None):
+        """n_rounds rounds inside ONE foreign call (the interpreter's lock is released throughout): every stream gets image
+        frame_of(k) of the PinnedImages sequence, k = k_first ..; returns the rounds' stage times, (n_rounds, 7) ms."""
+        first = None
+        if T_f_w_first is not None:
+            arr = (capi.svoh_se3 * self.n)()
+            for i, T in enumerate(T_f_w_first):
+                arr[i] = fe._se3(T)
+            first = C.cast(arr, C.c_void_p)
+        out = np.zeros((max(1, n_rounds), 7))
+        assert pinned.copies >= self.n
+        self._check(self.lib.svohl_run_sequence(self.h, C.c_void_p(pinned.ptr), pinned.bytes, pinned.stride, pinned.n, int(pitch), int(k_first), int(n_rounds), first,
+                                                out.ctypes.data))
+        return out[:n_rounds]
 
     def pose(self, s):
         T = capi.svoh_se3()

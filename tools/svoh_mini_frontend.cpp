@@ -229,14 +229,16 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
   try {
     svoh_ctx* ctx = nullptr;
     if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
-    // the decoded sequence in page-locked memory, as a camera driver that feeds a GPU would deliver its images; like the
-    // threads of the other mode, the streams of a group share it read-only (every stream's image still crosses PCIe by itself)
+    // the decoded sequence in page-locked memory, as a camera driver that feeds a GPU would deliver its images: EVERY STREAM
+    // ITS OWN COPY (the device reads the images in place, and 32 streams reading one buffer would be served from its caches
+    // after the first: every stream's image has to cross PCIe by itself, as the images of 32 different cameras do)
     const size_t img_bytes = (size_t)images[0].width * images[0].height;
+    const size_t seq_bytes = img_bytes * images.size();
     uint8_t* pinned = nullptr;
-    if (svoh_host_alloc(ctx, img_bytes * images.size(), (void**)&pinned) != SVOH_OK) throw std::runtime_error(std::string("svoh_host_alloc: ") + svoh_last_error_string(ctx));
+    if (svoh_host_alloc(ctx, seq_bytes * (size_t)n, (void**)&pinned) != SVOH_OK) throw std::runtime_error(std::string("svoh_host_alloc: ") + svoh_last_error_string(ctx));
     for (size_t k = 0; k < images.size(); ++k) {
       if ((size_t)images[k].width * images[k].height != img_bytes) throw std::runtime_error("images of different sizes");
-      memcpy(pinned + k * img_bytes, images[k].data.data(), img_bytes);
+      for (int i = 0; i < n; ++i) memcpy(pinned + (size_t)i * seq_bytes + k * img_bytes, images[k].data.data(), img_bytes);
     }
     for (int lap = 0; lap < n_laps; ++lap) {
       LockstepOptions lo;
@@ -268,7 +270,8 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
                     r.n_converged, t.pyramid, t.align, t.reproject, t.pose, t.seeds, t.keyframe, t.total);
           }
       };
-      std::vector<const uint8_t*> ptrs((size_t)n);
+      std::vector<const uint8_t*> ptrs((size_t)n), next((size_t)n);
+      const bool prefetch = getenv("SVOH_LOCKSTEP_PREFETCH") == nullptr || atoi(getenv("SVOH_LOCKSTEP_PREFETCH")) != 0;
       std::vector<Transformation> T_first((size_t)n, T0);
       if (lap == 0) {   // all groups start their first frame together
         start_gate->fetch_add(1);
@@ -276,9 +279,12 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
       }
       const double wall0 = now_ms();
       for (size_t k = 0; k < images.size(); ++k) {
-        for (int i = 0; i < n; ++i) ptrs[(size_t)i] = pinned + k * img_bytes;
+        for (int i = 0; i < n; ++i) ptrs[(size_t)i] = pinned + (size_t)i * seq_bytes + k * img_bytes;
+        // the next images of a replay are there already: they go up while this round runs (SVOH_LOCKSTEP_PREFETCH=0: they do not)
+        const bool announce = prefetch && k + 1 < images.size();
+        if (announce) for (int i = 0; i < n; ++i) next[(size_t)i] = pinned + (size_t)i * seq_bytes + (k + 1) * img_bytes;
         const double tr0 = now_ms();
-        fe.addImages(ptrs.data(), images[k].width, T_first.data());
+        fe.addImages(ptrs.data(), images[k].width, T_first.data(), announce ? next.data() : nullptr);
         const double tr1 = now_ms();
         FrontendLockstep::RoundTimes t = fe.lastRoundTimes();
         t.total = tr1 - tr0;
