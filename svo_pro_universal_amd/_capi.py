@@ -13,6 +13,8 @@ SVOH_MAX_CAMS = 4
 SVOH_OK = 0
 SVOH_MEM_HOST = 0
 SVOH_MEM_DEVICE = 1
+SVOH_MEM_STAGED = 2
+SVOH_MEM_HOST_PINNED = 3
 
 SVOH_DISTORTION_NONE = 0
 SVOH_DISTORTION_RADTAN = 1
@@ -100,6 +102,20 @@ class svoh_feature_batch(C.Structure):
     _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("ref_frame_idx", C.c_void_p), ("px", C.c_void_p),
                 ("f", C.c_void_p), ("grad", C.c_void_p), ("level", C.c_void_p), ("type", C.c_void_p),
                 ("cur_frame_idx", C.c_void_p), ("n_cur_frames", C.c_int32), ("mem_space", C.c_int32)]
+
+
+class svoh_matcher_stage_t(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("ref_frame_idx", "cur_frame_idx", "px", "f", "grad", "level", "type", "depth", "px_cur", "state",
+                                            "result", "success", "f_cur", "search_level", "h_inv", "A_cur_ref")]
+
+
+class svoh_candidate_job(C.Structure):
+    _fields_ = [("cam", svoh_camera), ("T_f_w_or_T_cam_imu", svoh_se3), ("T_imu_world_ref", svoh_se3), ("align_result_index", C.c_int32),
+                ("kf_begin", C.c_int32), ("n_kf", C.c_int32), ("point_begin", C.c_int32), ("n_points", C.c_int32), ("reserved", C.c_int32)]
+
+
+class svoh_candidate_stage_t(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("jobs", "T_world_kf", "job", "kind", "kf", "v", "mu", "px", "visible")]
 
 
 class svoh_depth_filter_options(C.Structure):
@@ -411,6 +427,15 @@ def load(path=None):
     lib.svoh_detect_cells_batch.argtypes = [C.c_void_p, C.c_int, P(svoh_frame_t), P(svoh_detector_options), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svoh_detect_fill_features.argtypes = [P(svoh_detector_options), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int32)]
+    lib.svoh_build_pyramid_multi_prefetch.argtypes = lib.svoh_build_pyramid_multi.argtypes
+    lib.svoh_prefetch_fence.argtypes = [C.c_void_p]
+    lib.svoh_matcher_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, P(svoh_matcher_stage_t)]
+    lib.svoh_project_candidates_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(svoh_candidate_stage_t)]
+    lib.svoh_project_candidates_enqueue_staged.argtypes = [C.c_void_p]
+    lib.svoh_project_candidates_wait.argtypes = [C.c_void_p]
+    lib.svoh_matcher_begin_deferred.argtypes = [C.c_void_p]
+    lib.svoh_matcher_collect.argtypes = [C.c_void_p]
+    lib.svoh_matcher_flush.argtypes = [C.c_void_p]
     if path is None:
         _LIB = lib
     return lib

@@ -1,0 +1,344 @@
+"""Round 5: the C-ABI entries a lock-step driver of many camera streams stands on (include/svo_hip.h) -- keyed alignment
+launches, batches staged in place, the candidate projection of many frames in one launch, the detector for many frames,
+images at separate (page-locked) addresses, prefetch on a second stream.  Each must give EXACTLY what the one-at-a-time
+entry gives (bit for bit: the byte-identical trajectories of tests/test_mini_frontend_gpu.py rest on it), and refuse
+misuse with an error instead of reading or writing where it should not."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from svo_pro_universal_amd import _capi as capi, frontend as fe, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def result_bits(r):
+    return (r.status, r.n_fts_to_track, tuple(r.T_icur_iref.q), tuple(r.T_icur_iref.t), r.alpha, r.beta, tuple(r.iters), tuple(r.n_meas), tuple(r.chi2), r.n_patch_iters)
+
+
+def test_keyed_launch_gives_every_problem_the_result_of_its_own_launch(gpu_ctx):
+    """svoh_sparse_align_geometry_key / _enqueue_keyed: problems of 60 ... 900 features pick four different geometries when
+    launched alone (lanes per patch, 256-thread latency build, 512 threads, cluster of workgroups); launched together by key
+    every one must come back with the bits of its own launch, and a candidate projection queued behind several keyed
+    launches must find every problem's pose on the device."""
+    ctx = gpu_ctx
+    opt = capi.default_align_options(max_level=4, min_level=2)
+    sizes = [60, 100, 180, 180, 300, 400, 600, 720, 900, 180, 600]
+    scenes, frames, pbs = [], [], []
+    for i, n in enumerate(sizes):
+        sc = synth.make_align_scene(300 + i, n_features=n, patch_size=4)
+        fr, fc = ctx.build_pyramid(sc.img_ref, 5), ctx.build_pyramid(sc.img_cur, 5)
+        p, keep = fe.make_align_problems([[(sc, fr, fc)]])
+        scenes.append((sc, keep)); frames += [fr, fc]; pbs.append(p[0])
+    alone = [result_bits(ctx.sparse_align(opt, (capi.svoh_align_problem * 1)(p))[0]) for p in pbs]
+    keys = []
+    for p in pbs:
+        k = C.c_int32()
+        ctx._check(ctx.lib.svoh_sparse_align_geometry_key(ctx.h, C.byref(opt), C.byref(p), C.byref(k)))
+        keys.append(k.value)
+    assert len(set(keys)) >= 3, keys
+    order, groups = [], []
+    for k in dict.fromkeys(keys):
+        members = [i for i, kk in enumerate(keys) if kk == k]
+        groups.append((k, members)); order += members
+    for k, members in groups:
+        arr = (capi.svoh_align_problem * len(members))(*[pbs[i] for i in members])
+        ctx._check(ctx.lib.svoh_sparse_align_enqueue_keyed(ctx.h, C.byref(opt), len(members), arr, k))
+    # behind them: every problem's candidate projection composed from ITS result on the device
+    res = ctx.sparse_align_fetch_all(len(pbs))
+    for pos, i in enumerate(order):
+        assert result_bits(res[pos]) == alone[i], (sizes[i], keys[i])
+    # a key of another kind of problem is refused only when it is no key at all
+    bad = C.c_int32(12345)
+    arr = (capi.svoh_align_problem * 1)(pbs[0])
+    assert ctx.lib.svoh_sparse_align_enqueue_keyed(ctx.h, C.byref(opt), 1, arr, bad) != 0
+    for f in frames:
+        ctx.release_frame(f)
+
+
+def test_failed_enqueue_between_two_queued_launches_leaves_their_staging_alone(gpu_ctx):
+    """the staging block of an alignment launch is chosen before the launch can still fail; a failing
+    call between two queued launches must not make the next one overwrite the block the first is still uploading from."""
+    ctx = gpu_ctx
+    opt = capi.default_align_options(max_level=4, min_level=1)
+    sc = synth.make_align_scene(41, n_features=2000, patch_size=4)
+    fr, fc = ctx.build_pyramid(sc.img_ref, 5), ctx.build_pyramid(sc.img_cur, 5)
+    pbs, keep = fe.make_align_problems([[(sc, fr, fc)]] * 64)
+    ref = result_bits(ctx.sparse_align(opt, pbs)[0])
+    bad, keep2 = fe.make_align_problems([[(sc, fr, fc)]])
+    bad[0].cams[0].cur_frame = 987654321   # unknown handle: fails after the staging block was picked
+    for _ in range(3):
+        ctx.sparse_align_enqueue(opt, pbs)
+        assert ctx.lib.svoh_sparse_align_enqueue(ctx.h, C.byref(opt), 1, bad) != 0
+        ctx.sparse_align_enqueue(opt, pbs)
+        res = ctx.sparse_align_fetch_all(128)
+        assert all(result_bits(r) == ref for r in res)
+    ctx.release_frame(fr); ctx.release_frame(fc)
+
+
+def pinned_copy(ctx, arrays):
+    total = sum(a.size for a in arrays)
+    p = C.c_void_p()
+    ctx._check(ctx.lib.svoh_host_alloc(ctx.h, C.c_size_t(total + 4096), C.byref(p)))
+    ptrs, off = [], 0
+    for a in arrays:
+        C.memmove(p.value + off, np.ascontiguousarray(a).ctypes.data, a.size)
+        ptrs.append(p.value + off); off += a.size
+    return p, ptrs
+
+
+@pytest.mark.parametrize("mem", ["pageable", "pinned", "pinned+prefetch"])
+def test_pyramids_of_images_at_separate_addresses(gpu_ctx, mem):
+    """svoh_build_pyramid_multi (+ _prefetch on the second stream, + fence): every level of every image equals the
+    single-image builder's, for the 752-wide mixed-rule case too."""
+    ctx = gpu_ctx
+    rng = np.random.RandomState(5)
+    for (w, h) in ((640, 480), (752, 480)):
+        imgs = [rng.randint(0, 256, (h, w)).astype(np.uint8) for _ in range(5)]
+        want = []
+        for im in imgs:
+            f, lv = ctx.build_pyramid(im, 5, return_levels=True)
+            want.append(lv); ctx.release_frame(f)
+        block = None
+        if mem == "pageable":
+            keep = [np.ascontiguousarray(im) for im in imgs]
+            ptrs = [a.ctypes.data for a in keep]
+            space = capi.SVOH_MEM_HOST
+        else:
+            block, ptrs = pinned_copy(ctx, imgs)
+            space = capi.SVOH_MEM_HOST_PINNED
+        arr = (C.c_void_p * len(imgs))(*ptrs)
+        out = (capi.svoh_frame_t * len(imgs))()
+        fn = ctx.lib.svoh_build_pyramid_multi_prefetch if mem.endswith("prefetch") else ctx.lib.svoh_build_pyramid_multi
+        ctx._check(fn(ctx.h, arr, len(imgs), w, h, w, space, 5, capi.SVOH_HALFSAMPLE_REFERENCE, out))
+        if mem.endswith("prefetch"):
+            ctx._check(ctx.lib.svoh_prefetch_fence(ctx.h))
+        for i in range(len(imgs)):
+            for l in range(5):
+                assert np.array_equal(ctx.download_level(out[i], l), want[i][l]), (mem, w, i, l)
+            ctx.release_frame(out[i])
+        if block is not None:
+            ctx._check(ctx.lib.svoh_host_free(ctx.h, block))
+    # more page-locked images than one gather kernel takes
+    many = (C.c_void_p * 300)(*([1] * 300))
+    out = (capi.svoh_frame_t * 300)()
+    assert ctx.lib.svoh_build_pyramid_multi(ctx.h, many, 300, 64, 64, 64, capi.SVOH_MEM_HOST_PINNED, 3, 0, out) != 0
+
+
+def test_detector_for_many_frames_equals_the_detector_for_each(gpu_ctx):
+    """svoh_detect_cells_batch + svoh_detect_fill_features against svoh_detect_features, frame by frame: corners and
+    edgelets, occupied cells, a feature budget that cuts the list -- every output array equal."""
+    ctx = gpu_ctx
+    cam = synth.Camera.euroc_like(752, 480)
+    frames, occs = [], []
+    rng = np.random.RandomState(3)
+    opt = capi.svoh_detector_options()
+    opt.cell_size, opt.max_level, opt.min_level, opt.border, opt.detect_edgelets = 30, 2, 0, 8, 1
+    opt.threshold_primary, opt.threshold_secondary = 10.0, 100.0
+    n_cells = int(np.ceil(752 / 30)) * int(np.ceil(480 / 30))
+    for i in range(6):
+        sc = synth.make_align_scene(700 + i, n_features=8, cam=cam)
+        frames.append(ctx.build_pyramid(sc.img_ref if i % 2 else sc.img_cur, 5))
+        occs.append((rng.uniform(size=n_cells) < (0.0, 0.3, 0.9)[i % 3]).astype(np.uint8))
+    for budget in (n_cells, 150, 37):
+        single = [ctx.detect_features(opt, frames[i], 752, 480, occupancy=occs[i], max_n_features=budget) for i in range(len(frames))]
+        n = len(frames)
+        fr = (capi.svoh_frame_t * n)(*frames)
+        occ = np.ascontiguousarray(np.stack(occs))
+        ck, ek, ang = np.zeros((n, n_cells), np.uint64), np.zeros((n, n_cells), np.uint64), np.zeros((n, n_cells), np.float32)
+        ctx._check(ctx.lib.svoh_detect_cells_batch(ctx.h, n, fr, C.byref(opt), occ.ctypes.data, ck.ctypes.data, ek.ctypes.data, ang.ctypes.data))
+        for i in range(n):
+            px = np.zeros(2 * n_cells); score = np.zeros(n_cells); level = np.zeros(n_cells, np.int32); grad = np.zeros(2 * n_cells); typ = np.zeros(n_cells, np.uint8)
+            m = C.c_int32()
+            rc = ctx.lib.svoh_detect_fill_features(C.byref(opt), 752, 480, ck[i].ctypes.data, ek[i].ctypes.data, ang[i].ctypes.data, min(budget, n_cells), px.ctypes.data,
+                                                   score.ctypes.data, level.ctypes.data, grad.ctypes.data, typ.ctypes.data, C.byref(m))
+            assert rc == 0
+            m = m.value
+            s = single[i]
+            assert m == len(s["score"]) and m > 0
+            assert np.array_equal(px[:2 * m].reshape(-1, 2), s["px"]) and np.array_equal(score[:m], s["score"]) and np.array_equal(level[:m], s["level"])
+            assert np.array_equal(grad[:2 * m].reshape(-1, 2), s["grad"]) and np.array_equal(typ[:m], s["type"])
+    for f in frames:
+        ctx.release_frame(f)
+
+
+def seed_scene(ctx, seed, cam):
+    sc = synth.make_align_scene(seed, n_features=10, cam=cam, rot_deg=(0.5, 1.5), trans_m=(0.05, 0.15))
+    return sc, ctx.build_pyramid(sc.img_ref, 5), ctx.build_pyramid(sc.img_cur, 5)
+
+
+def test_batches_staged_in_place_equal_the_host_array_batches(gpu_ctx):
+    """svoh_matcher_stage + SVOH_MEM_STAGED: a direct batch and a seed batch over THREE (reference, current) frame pairs,
+    filled into the context's page-locked blocks, against the same units through the host-array calls one pair at a time.
+    Every output -- result codes, pixels, bearing vectors, search levels, A, states, types, success flags -- bit for bit."""
+    ctx = gpu_ctx
+    cam = synth.Camera.euroc_like()
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(cam)
+    pairs = [seed_scene(ctx, 810 + i, cam) for i in range(3)]
+    sets = [synth.make_seed_set(sc, 700 + 100 * i, seed=i, margin=12) for i, (sc, fr, fc) in enumerate(pairs)]
+    for sd in sets:
+        sd["type"][::13] = capi.FT_EDGELET_SEED_CONVERGED   # not updated by the seed update; matched by the direct matcher all the same
+    # one at a time, host arrays
+    want_seeds, want_direct = [], []
+    for (sc, fr, fc), sd in zip(pairs, sets):
+        rv = fe.make_frame_view(fr, cam, sc.T_ref_f_w, sd["mu_range"], 0)
+        cv = fe.make_frame_view(fc, cam, sc.T_cur_f_w_gt, 0.0, 1)
+        fb, keep = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+        ns, st, succ, mr = ctx.update_seeds_batch(mopt, dopt, [rv], cv, fb, sd["state"])
+        want_seeds.append((ns, st, succ, mr, keep["type"].copy()))
+        fb2, keep2 = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+        depth = sd["true_depth"] * 1.02
+        # the projection estimate the reprojector would hand in: the true pixel, a little off
+        x = sd["f"].reshape(-1, 3).T * sd["true_depth"]
+        px_true = sc.cam.project(sc.T_w_cur.inverse().transform(sc.T_w_ref.transform(x)))
+        px0 = np.ascontiguousarray((px_true + np.random.RandomState(1).uniform(-1.5, 1.5, px_true.shape)).T).ravel()
+        want_direct.append((ctx.match_direct_batch(mopt, [rv], cv, fb2, depth, px0), depth, px0))
+    # all three pairs in one staged direct batch + one staged seed batch
+    n_each = [sd["level"].size for sd in sets]
+    n = sum(n_each)
+    refs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fr, cam, sc.T_ref_f_w, sd["mu_range"], 0) for (sc, fr, fc), sd in zip(pairs, sets)])
+    curs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fc, cam, sc.T_cur_f_w_gt, 0.0, 1) for (sc, fr, fc) in pairs])
+    ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+    ds, ss = capi.svoh_matcher_stage_t(), capi.svoh_matcher_stage_t()
+    ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 0, n, 8, 1, C.byref(ds)))
+    ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, n, 8, 1, C.byref(ss)))
+
+    def view(ptr, dtype, count):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * np.dtype(dtype).itemsize,)).view(dtype)
+    off = 0
+    for k, sd in enumerate(sets):
+        m = n_each[k]
+        for g in (ds, ss):
+            view(g.ref_frame_idx, np.int32, n)[off:off + m] = k
+            view(g.cur_frame_idx, np.int32, n)[off:off + m] = k
+            view(g.px, np.float64, 2 * n)[2 * off:2 * (off + m)] = sd["px"]
+            view(g.f, np.float64, 3 * n)[3 * off:3 * (off + m)] = sd["f"]
+            view(g.grad, np.float64, 2 * n)[2 * off:2 * (off + m)] = sd["grad"]
+            view(g.level, np.int32, n)[off:off + m] = sd["level"]
+            view(g.type, np.uint8, n)[off:off + m] = sd["type"]
+        view(ds.depth, np.float64, n)[off:off + m] = want_direct[k][1]
+        view(ds.px_cur, np.float64, 2 * n)[2 * off:2 * (off + m)] = want_direct[k][2]
+        view(ss.state, np.float64, 4 * n)[4 * off:4 * (off + m)] = sd["state"]
+        off += m
+
+    def batch(g):
+        fb = capi.svoh_feature_batch()
+        fb.n, fb.mem_space, fb.n_cur_frames = n, capi.SVOH_MEM_STAGED, 3
+        for k in ("ref_frame_idx", "cur_frame_idx", "px", "f", "grad", "level", "type"):
+            setattr(fb, k, getattr(g, k))
+        return fb
+    fbd, fbs = batch(ds), batch(ss)
+    ctx._check(ctx.lib.svoh_match_direct_batch(ctx.h, C.byref(mopt), 3, refs, curs, C.byref(fbd), ds.depth, ds.px_cur, ds.result, ds.f_cur, ds.search_level,
+                                               ds.h_inv, ds.A_cur_ref))
+    outs = capi.svoh_seed_match_outputs(ss.px_cur, ss.f_cur, ss.search_level, ss.A_cur_ref)
+    ns_total = C.c_int32()
+    ctx._check(ctx.lib.svoh_update_seeds_batch_ex(ctx.h, C.byref(mopt), C.byref(dopt), 3, refs, curs, C.byref(fbs), ss.state, ss.success, ss.result,
+                                                  C.byref(ns_total), C.byref(outs)))
+    # a second batch of a kind, a batch with foreign arrays: refused, and the section stays usable
+    assert ctx.lib.svoh_matcher_stage(ctx.h, 1, n, 8, 1, C.byref(capi.svoh_matcher_stage_t())) != 0
+    ctx._check(ctx.lib.svoh_matcher_flush(ctx.h))
+    ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+    assert ns_total.value == sum(w[0] for w in want_seeds)
+    off = 0
+    for k in range(3):
+        m = n_each[k]
+        ns, st, succ, mr, typ = want_seeds[k]
+        assert np.array_equal(view(ss.state, np.float64, 4 * n)[4 * off:4 * (off + m)], st)
+        assert np.array_equal(view(ss.success, np.uint8, n)[off:off + m], succ) and np.array_equal(view(ss.result, np.int32, n)[off:off + m], mr)
+        assert np.array_equal(view(ss.type, np.uint8, n)[off:off + m], typ)
+        d = want_direct[k][0]
+        assert np.array_equal(view(ds.result, np.int32, n)[off:off + m], d["result"])
+        assert np.array_equal(view(ds.px_cur, np.float64, 2 * n)[2 * off:2 * (off + m)], d["px_cur"])
+        assert np.array_equal(view(ds.f_cur, np.float64, 3 * n)[3 * off:3 * (off + m)], d["f_cur"])
+        assert np.array_equal(view(ds.search_level, np.int32, n)[off:off + m], d["search_level"])
+        assert np.array_equal(view(ds.A_cur_ref, np.float64, 4 * n)[4 * off:4 * (off + m)], d["A"])
+        assert (d["result"] == capi.MATCH_SUCCESS).mean() > 0.5
+        off += m
+    # misuse: staging outside a section; a staged batch with arrays that are not the staged ones; more frames than staged for
+    assert ctx.lib.svoh_matcher_stage(ctx.h, 0, 10, 4, 1, C.byref(capi.svoh_matcher_stage_t())) != 0
+    ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+    g = capi.svoh_matcher_stage_t()
+    ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, 64, 2, 0, C.byref(g)))
+    assert not g.px_cur and not g.A_cur_ref   # staged without the match outputs
+    fb = capi.svoh_feature_batch()
+    fb.n, fb.mem_space, fb.n_cur_frames = 64, capi.SVOH_MEM_STAGED, 1
+    for k in ("ref_frame_idx", "cur_frame_idx", "px", "f", "grad", "level", "type"):
+        setattr(fb, k, getattr(g, k))
+    foreign = np.zeros(4 * 64)
+    assert ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 1, refs, curs, C.byref(fb), foreign.ctypes.data, g.success, g.result, None) != 0
+    assert ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 3, refs, curs, C.byref(fb), g.state, g.success, g.result, None) != 0   # 3 + 1 views > 2
+    ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+    for sc, fr, fc in pairs:
+        ctx.release_frame(fr); ctx.release_frame(fc)
+
+
+def test_candidate_projections_of_many_frames_equal_the_single_call(gpu_ctx):
+    """svoh_project_candidates_stage / _enqueue_staged / _wait with four jobs (own camera pose, own keyframe table, one of
+    them without points of kind 1) against svoh_project_candidates job by job: pixels and verdicts equal."""
+    ctx = gpu_ctx
+    cam = synth.Camera.euroc_like(752, 480)
+    rng = np.random.RandomState(11)
+    jobs = []
+    for j in range(4):
+        n, n_kf = (900, 1500, 40, 2500)[j], (3, 5, 1, 4)[j]
+        def rand_T(s):
+            q = np.array([1.0, 0, 0, 0]) + rng.normal(0, s, 4)
+            return synth.SE3(q / np.linalg.norm(q), rng.normal(0, s, 3))
+        T_f_w = rand_T(0.03)
+        T_kf = [rand_T(0.1) for _ in range(n_kf)]
+        kind = (rng.uniform(size=n) < (0.6 if j != 2 else 0.0)).astype(np.uint8)
+        kf = rng.randint(0, n_kf, n).astype(np.int32)
+        kf[5::97] = n_kf + 3   # a bad keyframe index: not visible, not a fault
+        v = rng.normal(0, 1, (n, 3)); v[:, 2] = np.abs(v[:, 2]) + 1.0
+        v[kind == 1] /= np.linalg.norm(v[kind == 1], axis=1, keepdims=True)
+        mu = rng.uniform(0.1, 1.0, n)
+        jobs.append(dict(T=T_f_w, T_kf=T_kf, kind=kind, kf=kf, v=np.ascontiguousarray(v.ravel()), mu=mu, n=n, n_kf=n_kf))
+    want = []
+    for jb in jobs:
+        Tk = (capi.svoh_se3 * jb["n_kf"])(*[fe._se3(T.inverse()) for T in jb["T_kf"]])
+        px = np.zeros(2 * jb["n"]); vis = np.zeros(jb["n"], np.uint8)
+        c, T = fe._camera(cam), fe._se3(jb["T"])
+        ctx._check(ctx.lib.svoh_project_candidates(ctx.h, C.byref(c), C.byref(T), jb["n_kf"], Tk, jb["n"], jb["kind"].ctypes.data, jb["kf"].ctypes.data,
+                                                   jb["v"].ctypes.data, jb["mu"].ctypes.data, px.ctypes.data, vis.ctypes.data))
+        want.append((px, vis))
+    n_total, kf_total = sum(j["n"] for j in jobs), sum(j["n_kf"] for j in jobs)
+    cs = capi.svoh_candidate_stage_t()
+    ctx._check(ctx.lib.svoh_project_candidates_stage(ctx.h, len(jobs), kf_total, n_total, C.byref(cs)))
+
+    def view(ptr, dtype, count):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * np.dtype(dtype).itemsize,)).view(dtype)
+    jarr = C.cast(cs.jobs, C.POINTER(capi.svoh_candidate_job))
+    karr = C.cast(cs.T_world_kf, C.POINTER(capi.svoh_se3))
+    off = koff = 0
+    for j, jb in enumerate(jobs):
+        jj = capi.svoh_candidate_job()
+        jj.cam, jj.T_f_w_or_T_cam_imu, jj.align_result_index = fe._camera(cam), fe._se3(jb["T"]), -1
+        jj.kf_begin, jj.n_kf, jj.point_begin, jj.n_points = koff, jb["n_kf"], off, jb["n"]
+        jarr[j] = jj
+        for k, T in enumerate(jb["T_kf"]):
+            karr[koff + k] = fe._se3(T.inverse())
+        m = jb["n"]
+        view(cs.job, np.int32, n_total)[off:off + m] = j
+        view(cs.kind, np.uint8, n_total)[off:off + m] = jb["kind"]
+        view(cs.kf, np.int32, n_total)[off:off + m] = jb["kf"]
+        view(cs.v, np.float64, 3 * n_total)[3 * off:3 * (off + m)] = jb["v"]
+        view(cs.mu, np.float64, n_total)[off:off + m] = jb["mu"]
+        off += m; koff += jb["n_kf"]
+    assert ctx.lib.svoh_project_candidates_wait(ctx.h) != 0   # nothing in flight yet
+    ctx._check(ctx.lib.svoh_project_candidates_enqueue_staged(ctx.h))
+    assert ctx.lib.svoh_project_candidates_stage(ctx.h, 1, 1, 1, C.byref(capi.svoh_candidate_stage_t())) != 0   # in flight: wait first
+    ctx._check(ctx.lib.svoh_project_candidates_wait(ctx.h))
+    off = 0
+    for j, jb in enumerate(jobs):
+        m = jb["n"]
+        assert np.array_equal(view(cs.px, np.float64, 2 * n_total)[2 * off:2 * (off + m)], want[j][0])
+        assert np.array_equal(view(cs.visible, np.uint8, n_total)[off:off + m], want[j][1])
+        assert 0.02 < want[j][1].mean() < 0.98
+        off += m
+    # a job whose ranges leave the staged arrays is refused before anything is launched
+    ctx._check(ctx.lib.svoh_project_candidates_stage(ctx.h, 1, 1, 10, C.byref(cs)))
+    jj = capi.svoh_candidate_job()
+    jj.cam, jj.align_result_index, jj.n_kf, jj.point_begin, jj.n_points = fe._camera(cam), -1, 1, 5, 10
+    C.cast(cs.jobs, C.POINTER(capi.svoh_candidate_job))[0] = jj
+    assert ctx.lib.svoh_project_candidates_enqueue_staged(ctx.h) != 0
