@@ -54,6 +54,10 @@ def load(fast=False):
     if key in _LIBS:
         return _LIBS[key]
     path = os.path.join(_HERE, "liboracle_fast.so" if fast else "liboracle.so")
+    # SVO_ORACLE_LIB: another build of the same sources (tests/san/liboracle_asan.so: the oracle under AddressSanitizer,
+    # with the sanitizer runtime preloaded into the interpreter by tests/test_sanitizers_cpu.py)
+    if not fast and os.environ.get("SVO_ORACLE_LIB"):
+        path = os.environ["SVO_ORACLE_LIB"]
     if not os.path.exists(path):
         build(fast)
     lib = C.CDLL(path)

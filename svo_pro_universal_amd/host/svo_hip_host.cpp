@@ -369,6 +369,13 @@ void DepthFilterHip::queueUpdateSeeds(const std::vector<FramePtr>& ref_frames_wi
 void DepthFilterHip::finishUpdateSeedsEarly()
 {
   if (!async_open_) return;
+  if (prepared_) {
+    // queued by prepareUpdateSeeds and not yet given its frame's pose: what it would compute is not an update of anything.
+    // It is dropped, and NOT remembered as finished -- the updateSeedsAsync that follows finds nothing prepared and queues
+    // the update afresh (it used to find "finished early" and throw, the frame's update lost).
+    (void)finishUpdateSeedsNow();
+    return;
+  }
   early_count_ = finishUpdateSeedsNow();
   finished_early_ = true;
 }

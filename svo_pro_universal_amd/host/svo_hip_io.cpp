@@ -376,7 +376,12 @@ GrayImage decodePngGray(const uint8_t* b, size_t n)
   int ch;
   switch (color_type) { case 0: ch = 1; break; case 2: ch = 3; break; case 4: ch = 2; break; case 6: ch = 4; break;
     default: throw std::runtime_error("png: palette images are not supported"); }
+  // The header is not trusted with an allocation: a damaged (or hostile) width / height of 2^31 would ask for exabytes
+  // before a single byte of pixel data has been looked at (found by tests/san/io_fuzz).  deflate expands by at most
+  // ~1032 : 1, so the scanlines the header promises must fit what the IDAT chunks can possibly hold.
+  if (w > (1 << 20) || h > (1 << 20)) throw std::runtime_error("png: image larger than 2^20 pixels a side");
   const size_t stride = (size_t)w * ch;
+  if ((stride + 1) > ((size_t)idat.size() * 1032 + 1024) / (size_t)h + 1) throw std::runtime_error("png: the header promises more pixels than the image data can hold");
   std::vector<uint8_t> raw((stride + 1) * (size_t)h);
   uLongf out_len = (uLongf)raw.size();
   if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size())

@@ -37,40 +37,9 @@
 #include <vector>
 
 #include "svo_hip_io.h"
+#include "svo_hip_pool.h"
 
 namespace svo_hip {
-
-// A fixed set of threads that run `fn(item)` for item = 0 .. n-1 and return when all are done; the calling thread takes
-// part.  Waiting threads spin briefly (a phase follows the last within microseconds), then yield, then sleep.
-class WorkerPool {
- public:
-  // n_threads >= 1 counts the caller: n_threads - 1 threads are started.  pin: every thread of the pool -- the calling
-  // thread included, for good -- is bound to a CPU of its own out of the process' affinity mask, one hardware thread per
-  // core first; pools made one after the other (one per lock-step group) take consecutive CPUs.
-  explicit WorkerPool(int n_threads, bool pin = false);
-  ~WorkerPool();
-  WorkerPool(const WorkerPool&) = delete;
-  WorkerPool& operator=(const WorkerPool&) = delete;
-  int size() const { return static_cast<int>(threads_.size()) + 1; }
-  // exceptions thrown by fn are collected; the first one is rethrown here once every item has been handled or skipped.
-  // Item i always goes to thread i % size(): a stream's data stays in the caches of the core that touched it last.
-  void run(int n_items, const std::function<void(int)>& fn);
-
- private:
-  void worker(int tid, int cpu);
-  void work_off(int tid);
-  std::vector<std::thread> threads_;
-  std::mutex mu_;
-  std::condition_variable cv_;
-  std::atomic<unsigned long> generation_{ 0 };
-  std::atomic<int> pending_{ 0 }, n_items_{ 0 };
-  std::atomic<int> sleepers_{ 0 };
-  std::atomic<bool> stop_{ false };
-  int spin_limit_ = 20000, yield_limit_ = 400;
-  const std::function<void(int)>* fn_ = nullptr;
-  std::mutex err_mu_;
-  std::exception_ptr error_;
-};
 
 struct LockstepOptions {
   io::FrontendParams params;

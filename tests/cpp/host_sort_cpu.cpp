@@ -29,7 +29,7 @@ int main()
     for (size_t i = 0; i < n; ++i) {
       a[i].ref_frame = frame; a[i].ref_index = i;
       a[i].type = (uint8_t)(rnd() % n_types);
-      a[i].n_reproj = (int)(rnd() % n_counts) - 2 + ((rnd() % 97 == 0) ? (rnd() % 2 ? 2147483647 : -2147483647 - 1) : 0);
+      a[i].n_reproj = (rnd() % 97 == 0) ? (rnd() % 2 ? 2147483647 - (int)(rnd() % 2) : -2147483647 - 1 + (int)(rnd() % 2)) : (int)(rnd() % n_counts) - 2;   // (the extremes set, not added: signed overflow is undefined -- found by tests/san)
       const uint64_t pick = rnd() % 10;
       a[i].score = pick < 4 ? specials[rnd() % (sizeof specials / sizeof specials[0])] : pick < 8 ? (double)(rnd() % 40) : (double)(int64_t)rnd() * 1e-12;
       if (with_nan && rnd() % 11 == 0) a[i].score = std::numeric_limits<double>::quiet_NaN();

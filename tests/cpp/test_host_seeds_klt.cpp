@@ -139,7 +139,24 @@ int main(int argc, char** argv)
       CHECK(df3.finishUpdateSeeds() == 0);
     }
     CHECK(kf3->invmu_sigma2_a_b_vec_ == state && kf3->type_vec_ == type);
-    kf2->pyramid = 0; kf3->pyramid = 0;       // the handle belongs to kf
+    // something else needs the context's deferred section between prepare and send-off (a reprojection on the same
+    // context: finishPendingSeedUpdate): the prepared batch is dropped, and updateSeedsAsync then queues the update
+    // afresh -- it used to throw "the previous update has not been finished", the frame's update lost
+    FramePtr kf4(new Frame);
+    *kf4 = *kf;
+    kf4->invmu_sigma2_a_b_vec_ = state; kf4->type_vec_ = type;
+    {
+      DepthFilterHip df4(ctx, dfo);
+      cur->T_f_w_.t.x += 0.37;
+      df4.prepareUpdateSeeds({ kf4 }, cur);
+      finishPendingSeedUpdate(ctx);
+      CHECK(kf4->invmu_sigma2_a_b_vec_ == state && kf4->type_vec_ == type);   // nothing was written back
+      cur->T_f_w_ = T_final;
+      df4.updateSeedsAsync({ kf4 }, cur);
+      CHECK(df4.finishUpdateSeeds() == n_updated);
+      CHECK(kf4->invmu_sigma2_a_b_vec_ == kf->invmu_sigma2_a_b_vec_ && kf4->type_vec_ == kf->type_vec_);
+    }
+    kf2->pyramid = 0; kf3->pyramid = 0; kf4->pyramid = 0;       // the handle belongs to kf
     printf("seeds: the update queued ahead of its pose equals the one-call update\n");
   }
 

@@ -1,0 +1,132 @@
+"""CPU-side code under sanitizers (VERDICT r04 "what's weak" #11; the reference has none: SURVEY.md:288).  tests/san/Makefile
+builds (a) the host mirrors and the dataset / configuration parsers (svo_hip_host.cpp, svo_hip_io.cpp, svo_hip_lockstep.cpp,
+svo_hip_pool.cpp) with AddressSanitizer + UndefinedBehaviorSanitizer, (b) the oracle with the same, (c) the worker pool of
+the lock-step front end with ThreadSanitizer.  Nothing here makes a device call and nothing of it ever runs on a GPU box.
+Findings so far, fixed: the PNG reader allocated what a damaged header asked for (2^31 pixels a side) before looking at the
+data; a signed overflow in the generator of tests/cpp/host_sort_cpu.cpp."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = os.path.join(ROOT, "tests", "san")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:allocator_may_return_null=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+           TSAN_OPTIONS="halt_on_error=1")
+
+
+@pytest.fixture(scope="module")
+def san_build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host"), "libsvo_hip_host.so"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", SAN])
+    return SAN
+
+
+def run(cmd, **kw):
+    r = subprocess.run(cmd, capture_output=True, text=True, env=kw.pop("env", ENV), **kw)
+    assert r.returncode == 0, "%s\n%s\n%s" % (" ".join(cmd), r.stdout[-2000:], r.stderr[-6000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr and "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+    return r.stdout
+
+
+def test_worker_pool_under_thread_sanitizer(san_build):
+    """WorkerPool (host/svo_hip_pool.cpp): back-to-back phases whose items write neighbouring slots, three pools side by
+    side, fewer items than threads, items that throw, workers that have gone to sleep -- no report, and the sums are right."""
+    assert run([os.path.join(san_build, "pool_tsan"), "2500"]).strip() == "ok"
+
+
+def test_host_mirrors_under_address_and_ub_sanitizer(san_build, tmp_path):
+    """What of the host layer runs without a GPU: the candidate sort against std::sort on 400 adversarial lists, getCandidate /
+    Frame::isVisible on 2000 points, the parsers on well-formed files."""
+    assert run([os.path.join(san_build, "host_sort_cpu_asan")]).startswith("ok 400 ")
+    rng = np.random.RandomState(3)
+    n = 2000
+    lines = ["752 480 458.654 457.296 367.215 248.375 1 -0.28340811 0.07395907 0.00019359 1.76187114e-05",
+             "0.99 0.1 0.05 0.02 0.4 -0.1 0.2", "0.98 -0.1 0.15 0.03 0.1 0.05 -0.1", str(n)]
+    for i in range(n):
+        if rng.uniform() < 0.5:
+            f = np.array([rng.uniform(-0.9, 0.9), rng.uniform(-0.7, 0.7), 1.0]); f /= np.linalg.norm(f)
+            lines.append("1 %.17g %.17g %.17g %.17g" % (f[0], f[1], f[2], 1.0 / rng.uniform(0.5, 8.0)))
+        else:
+            lines.append("0 %.17g %.17g %.17g 1" % (rng.uniform(-6, 6), rng.uniform(-4, 4), rng.uniform(-1.0, 8.0)))
+    fin, fout = tmp_path / "in.txt", tmp_path / "out.txt"
+    fin.write_text("\n".join(lines) + "\n")
+    run([os.path.join(san_build, "host_candidates_cpu_asan"), str(fin), str(fout)])
+    vis = np.loadtxt(str(fout))[:, 0]
+    assert 100 < vis.sum() < n - 100
+
+
+def seeds(tmp_path):
+    from test_io_cpu import write_png
+    rng = np.random.RandomState(1)
+    write_png(str(tmp_path / "grey.png"), rng.randint(0, 256, (37, 53)).astype(np.uint8))
+    write_png(str(tmp_path / "rgb.png"), rng.randint(0, 256, (21, 33, 3)).astype(np.uint8), chunk=100)
+    write_png(str(tmp_path / "rgba.png"), rng.randint(0, 256, (16, 16, 4)).astype(np.uint8), filters=(4,))
+    (tmp_path / "calib.yaml").write_text("""label: rig
+cameras:
+- camera:
+    label: cam0
+    image_height: 480
+    image_width: 752
+    type: pinhole
+    intrinsics:
+      cols: 1
+      rows: 4
+      data: [458.654, 457.296, 367.215, 248.375]
+    distortion:
+      type: radial-tangential
+      parameters:
+        cols: 1
+        rows: 4
+        data: [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05]
+  T_B_C:
+    cols: 4
+    rows: 4
+    data: [0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975,
+           0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768,
+           -0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949,
+           0.0, 0.0, 0.0, 1.0]
+""")
+    (tmp_path / "params.yaml").write_text("max_fts: 180\ngrid_size: 30 # comment\nn_pyr_levels: 3\nuse_threaded_depthfilter: False\nimg_align_max_level: 4\n"
+                                          "img_align_min_level: 2\nklt_patch_sizes: [16, 16,\n  16, 8, 8]\nimg_align_robustification: true\n")
+
+
+def test_damaged_png_and_yaml_files_through_the_parsers(san_build, tmp_path):
+    """Truncated, bit-flipped and structurally damaged files (PNG: header fields, filter bytes, scanline data and data amount
+    changed INSIDE a file whose CRCs and deflate stream are then made valid again) through io::decodePngGray, io::parseYaml,
+    io::cameraRigFromYaml, io::frontendParamsFromYaml: refused or parsed, never a sanitizer report."""
+    seeds(tmp_path)
+    for name in ("grey.png", "rgb.png", "rgba.png"):
+        out = run([os.path.join(san_build, "io_fuzz_asan"), "png", str(tmp_path / name), "1500", "11"])
+        parsed, refused = int(out.split()[1]), int(out.split()[3])
+        assert parsed > 100 and refused > 1000, out    # both outcomes occur: the mutations reach the decoder's own arithmetic
+    for name in ("calib.yaml", "params.yaml"):
+        out = run([os.path.join(san_build, "io_fuzz_asan"), "yaml", str(tmp_path / name), "1500", "11"])
+        assert int(out.split()[1]) > 100, out
+    # and the well-formed files through the loaders' dump tool
+    assert "size 53 37" in run([os.path.join(san_build, "test_io_asan"), "png", str(tmp_path / "grey.png")])
+    assert "label cam0" in run([os.path.join(san_build, "test_io_asan"), "rig", str(tmp_path / "calib.yaml")])
+    assert "reprojector 180 30" in run([os.path.join(san_build, "test_io_asan"), "params", str(tmp_path / "params.yaml")])
+    # a header that promises 2^31 x 2^31 pixels over 16 bytes of data is refused before anything is allocated
+    import struct, zlib
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    bomb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 0x7FFFFFFF, 0x7FFFFFFF, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b"")
+    (tmp_path / "bomb.png").write_bytes(bomb)
+    r = subprocess.run([os.path.join(san_build, "test_io_asan"), "png", str(tmp_path / "bomb.png")], capture_output=True, text=True, env=ENV)
+    assert r.returncode != 0 and "AddressSanitizer" not in r.stderr and ("2^20" in r.stderr + r.stdout or "more pixels" in r.stderr + r.stdout), r.stderr[-2000:]
+
+
+def test_oracle_under_address_and_ub_sanitizer(san_build):
+    """The malloc-heavy C oracle: its own CPU tests once more, with tests/san/liboracle_asan.so in place of liboracle.so
+    (SVO_ORACLE_LIB) and the sanitizer runtime preloaded into the interpreter.  Leak checking is off for this one: the
+    interpreter's own allocations would drown it."""
+    asan_rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    env = dict(ENV, LD_PRELOAD=asan_rt, ASAN_OPTIONS="detect_leaks=0", SVO_ORACLE_LIB=os.path.join(san_build, "liboracle_asan.so"))
+    tests = ["tests/test_oracle_cpu.py", "tests/test_oracle_klt_matcher_cpu.py", "tests/test_oracle_pose_cpu.py", "tests/test_oracle_detector_cpu.py", "tests/test_golden_cpu.py"]
+    out = run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + tests, env=env, cwd=ROOT)
+    assert " passed" in out and "failed" not in out, out[-2000:]
