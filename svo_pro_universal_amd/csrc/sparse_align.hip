@@ -626,6 +626,54 @@ __device__ __forceinline__ Rigid uniform_rigid(const Rigid& T)
   return r;
 }
 
+// ---- what a pass over a camera's patches needs of the camera, per level -------------------------------------------------
+// The pass loop used to take it from the camera descriptor in global memory -- the two level images, the camera model,
+// the feature range: ~35 scalars through scalar loads whose addresses depend on the level -- in EVERY pass: 2.2 - 2.7 K
+// cycles per camera and pass by the cycle stamps (round 4), a fifth of a Gauss-Newton iteration of a 180-patch problem.
+// Now the level's start copies them into LDS once (LevelDesc, one thread per camera), and a pass reads them back uniformly
+// (ds_read + v_readfirstlane: values in scalar registers, as before).
+// MEASURED (round 5, A/B on one box, profiles/r05_align_desc_vote_ab.txt) AND NOT KEPT: a 180-patch problem 5.33 -> 5.68 us per
+// iteration with the descriptors in LDS alone, 5.38 - 5.42 with the vote folded as well; the batch of 1024 x 2000 within the
+// box's run-to-run spread (1.19 - 1.23 ms all three builds).  The scalar loads hit the scalar cache and overlap the
+// wave's other work; what the stamps attributed to them was the stamps' own s_waitcnt(0).  Both stay compiled out
+// (SVOH_ALIGN_LDS_DESC=1 / SVOH_ALIGN_FOLD_VOTE=1 build them: same results, all tests green).
+#ifndef SVOH_ALIGN_LDS_DESC
+#define SVOH_ALIGN_LDS_DESC 0
+#endif
+// ... and the visibility vote of a gradient-only pass rides the reduction's barrier instead of having one of its own
+#ifndef SVOH_ALIGN_FOLD_VOTE
+#define SVOH_ALIGN_FOLD_VOTE 0
+#endif
+struct LevelDesc {
+  DevImage ref, cur;
+  svoh_camera cam;
+  int32_t n_features, feat_off;
+};
+struct CamPass {   // the uniform copy a pass works with
+  svoh_camera cam;
+  int32_t n_features, feat_off;
+};
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ DevImage uniform_image(const DevImage& im)
+{
+  DevImage r;
+  const unsigned long long p = reinterpret_cast<unsigned long long>(im.data);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+  r.data = reinterpret_cast<const uint8_t*>(((unsigned long long)hi << 32) | lo);
+  r.w = uniform_i32(im.w); r.h = uniform_i32(im.h); r.pitch = uniform_i32(im.pitch); r.pad = 0;
+  return r;
+}
+__device__ __forceinline__ CamPass uniform_cam_pass(const LevelDesc& d)
+{
+  CamPass r;
+  r.cam.fx = uniform_f64(d.cam.fx); r.cam.fy = uniform_f64(d.cam.fy); r.cam.cx = uniform_f64(d.cam.cx); r.cam.cy = uniform_f64(d.cam.cy);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.cam.d[k] = uniform_f64(d.cam.d[k]);
+  r.cam.distortion = uniform_i32(d.cam.distortion); r.cam.width = uniform_i32(d.cam.width); r.cam.height = uniform_i32(d.cam.height); r.cam.reserved = 0;
+  r.n_features = uniform_i32(d.n_features); r.feat_off = uniform_i32(d.feat_off);
+  return r;
+}
+
 constexpr int kWsPairs = 3;
 __device__ __forceinline__ double* ws_pair(const AlignKernelArgs& a, int pair, int64_t gi) { return a.wpk + ((int64_t)pair * a.slots + gi) * 2; }
 // The workspace as the passes of the 512-thread geometry see it: the launch's global arrays, or -- a problem of a few
@@ -644,7 +692,7 @@ __device__ __forceinline__ double* ws_pair(const WsView& w, int pair, int64_t gi
 // jc: the camera's kJacConsts block (LDS).
 template <int P, int D, int NT, bool LDS, bool GONLY = false, bool ROB = false>
 __device__ __forceinline__ void accumulate_camera(
-    const AlignKernelArgs& a, const WsView& ws, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
+    const AlignKernelArgs& a, const WsView& ws, const CamPass& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
     bool robust, bool dist_jac, float weight_scale, int tid, const double* jc,
     double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed, int stride = NT)
@@ -728,7 +776,7 @@ __device__ __forceinline__ void accumulate_camera(
 // by the group's lane 0.
 template <int P, int LPP, int D, int NT, bool LDS, bool GONLY = false, bool ROB = false>
 __device__ __forceinline__ void accumulate_camera_rows(
-    const AlignKernelArgs& a, const WsView& ws, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
+    const AlignKernelArgs& a, const WsView& ws, const CamPass& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
     bool robust, bool dist_jac, float weight_scale, int tid, const double* jc,
     double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed, int stride = NT)
@@ -809,7 +857,7 @@ __device__ __forceinline__ void accumulate_camera_rows(
 constexpr int kStageDoubles = 2 * kWsPairs * 128;
 template <int P, int D, int NT, bool LDS, bool GONLY = false, bool ROB = false>
 __device__ __forceinline__ void accumulate_camera_staged(
-    const AlignKernelArgs& a, const DevCamDesc& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
+    const AlignKernelArgs& a, const CamPass& cd, const ImgView<LDS>& ref, const ImgView<LDS>& cur, int cw, int ch,
     const Rigid& Tcr, double scale, double one_plus_alpha, double beta_d, bool est_alpha, bool est_beta,
     bool robust, bool dist_jac, float weight_scale, int tid, double* stage, const double* jc,
     double (&acc)[GONLY ? D + 1 : AccLayout<D>::NACC], int& nvis, int& changed, int stride = NT)
@@ -1314,6 +1362,8 @@ void sparse_align_kernel(const AlignKernelArgs a)
   static_assert(NACC <= 45, "g_sum is sized for the 8-parameter case");
   __shared__ double s_x[kXchgStride];   // cluster mode: the block handed to cluster_sum
   __shared__ int s_cluster_ok;
+  __shared__ __align__(16) LevelDesc s_lvd[SVOH_ALIGN_LDS_DESC ? SVOH_MAX_CAMS : 1];   // the cameras at the current level (see LevelDesc)
+  __shared__ int s_changed[SVOH_ALIGN_FOLD_VOTE ? NW : 1];   // a gradient-only pass' visibility vote, wave by wave (SVOH_ALIGN_FOLD_VOTE)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1543,6 +1593,13 @@ void sparse_align_kernel(const AlignKernelArgs a)
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this thread's image requests (issued here or at the problem's start) have landed
     __syncthreads();
+#if SVOH_ALIGN_LDS_DESC
+    if (tid >= 64 && tid < 64 + n_cams) {   // (a lane of the second wave per camera: the first wave's lane 0 is busy below)
+      const DevCamDesc& cdg = cams[tid - 64];
+      LevelDesc& ld = s_lvd[tid - 64];
+      ld.ref = cdg.ref[level]; ld.cur = cdg.cur[level]; ld.cam = cdg.cam; ld.n_features = cdg.n_features; ld.feat_off = cdg.feat_off;
+    }
+#endif
     if (tid == 0) {
       g_state.level_done = 0;
       for (int c = 0; c < n_cams; ++c)
@@ -1576,9 +1633,17 @@ void sparse_align_kernel(const AlignKernelArgs a)
           // (side_by_side: decided once per problem, above the level loop)
           int cam_base = 0;
           for (int c = 0; c < n_cams; ++c) {
-            const DevCamDesc& cd = cams[c];
-            const DevImage& rim = cd.ref[level];
-            const DevImage& cim = cd.cur[level];
+#if SVOH_ALIGN_LDS_DESC
+            const CamPass cd = uniform_cam_pass(s_lvd[c]);
+            const DevImage rim = uniform_image(s_lvd[c].ref);
+            const DevImage cim = uniform_image(s_lvd[c].cur);
+#else
+            const DevCamDesc& cdg = cams[c];
+            CamPass cd;
+            cd.cam = cdg.cam; cd.n_features = cdg.n_features; cd.feat_off = cdg.feat_off;
+            const DevImage& rim = cdg.ref[level];
+            const DevImage& cim = cdg.cur[level];
+#endif
             const Rigid Tcr = uniform_rigid(g_state.Tcr[c]);
             unsigned cam_stride = NT, cam_t = (unsigned)tid;
             if (RIG && side_by_side) {   // (uniform)
@@ -1637,6 +1702,37 @@ void sparse_align_kernel(const AlignKernelArgs a)
           SVOH_OUTER_STAMP_BEGIN();
           run_cameras(std::true_type(), accg);
           SVOH_OUTER_STAMP(5);   // includes the pieces 0..4 counted inside
+#if SVOH_ALIGN_FOLD_VOTE
+          // The vote -- did any patch's visibility differ from the last full pass? -- travels with the reduction: every wave
+          // leaves its own verdict in LDS next to its partial sums, ONE barrier, and everybody reads the NW verdicts.  A pass
+          // that is thrown away has reduced for nothing (that is rare: none on the benchmark scenes); every other pass has one
+          // barrier less (1.1 K cycles of a 180-patch problem's iteration by the stamps).  nvis is only added once the pass counts.
+          {
+            int ridx;
+            bool rvalid;
+            wave_reduce_scatter<D + 1>(accg, lane, ridx, rvalid);
+            if (rvalid) s_red[wave][ridx] = accg[0];
+          }
+          {
+            const int wave_changed = __builtin_amdgcn_ballot_w64(changed != 0) != 0ull;
+            if (lane == 0) s_changed[wave] = wave_changed;
+          }
+          nvis = wave_sum_i32_dpp(nvis);
+          __syncthreads();
+          int changed_here = 0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) changed_here |= s_changed[w];
+          SVOH_OUTER_STAMP(6);
+          if (changed_here && !cluster) {   // visibility moved: this iteration in full
+            SVOH_STAMP_COUNT(5);
+            light = false;
+            __syncthreads();   // (everybody has read the verdicts and nobody reads this pass' partial sums: the full pass may write both)
+            continue;
+          }
+          SVOH_STAMP_COUNT(6);
+          SVOH_STAMP_ADD(2);
+          if (lane == 0) atomicAdd(&g_nvis, nvis);
+#else
           const int changed_here = __syncthreads_or(changed);
           SVOH_OUTER_STAMP(6);
           if (changed_here && !cluster) {   // visibility moved: this iteration in full
@@ -1655,6 +1751,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
           nvis = wave_sum_i32_dpp(nvis);
           if (lane == 0) atomicAdd(&g_nvis, nvis);
           __syncthreads();
+#endif
           if (tid < D + 1) {   // gradient and chi2 only: g_sum[0 .. NH) still holds the level's Hessian
             double v = 0.0;
             for (int w = 0; w < NW; ++w) v += s_red[w][tid];
