@@ -671,7 +671,11 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         ctx.set_kernel_timing(False)
         ranges = [(S * g // G, S * (g + 1) // G) for g in range(G)]
         pins = [ls.PinnedImages(c, images, hi - lo) for c, (lo, hi) in zip(ctxs, ranges)]   # every stream its own copy of the sequence
-        engines = [ls.Lockstep(c, hi - lo, cam, np.array([1.0, 0, 0, 0, 0, 0, 0]), params, 0.5 * depth, depth, 2.0 * depth, 8, W, True)
+        # the groups' host phases on ONE set of worker threads (G group threads + G * (W - 1) shared workers = G * W threads in
+        # all, as with a pool per group: SVOH_LOCKSTEP_SHARED=0), so that a group's phase finds the workers another group's device
+        # wait leaves idle
+        shared = ls.SharedPool(G * (W - 1)) if G > 1 and W > 1 and os.environ.get("SVOH_LOCKSTEP_SHARED", "1") != "0" else None
+        engines = [ls.Lockstep(c, hi - lo, cam, np.array([1.0, 0, 0, 0, 0, 0, 0]), params, 0.5 * depth, depth, 2.0 * depth, 8, W, True, pool=shared, seed=lo)
                    for c, (lo, hi) in zip(ctxs, ranges)]
         first = poses[0].inverse().as7()
         total = n_warm + n_steps
@@ -719,11 +723,14 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         calls = engines[0].last_round()[1]
         for e in engines:
             e.close()
+        if shared is not None:
+            shared.close()
         for p in pins:
             p.free()
         for c in ctxs[1:]:
             c.close()
-        return {"streams": S, "groups": G, "host_threads_per_group": W, "frames_per_s": S * n_steps / elapsed, "ms_per_round": 1e3 * elapsed / n_steps,
+        return {"streams": S, "groups": G, "host_threads_per_group": W, "host_threads": G * W, "workers_shared_between_groups": shared is not None,
+                "frames_per_s": S * n_steps / elapsed, "ms_per_round": 1e3 * elapsed / n_steps,
                 "round_stage_ms_median_group0": stage, "device_calls_per_round_per_group": calls,
                 "all_streams_at_the_same_pose": bool(agree), "rounds_run": total,
                 "pose_vs_rendered_pose_unscaled": {"rot_rad": float(err[0]), "trans_m": float(err[1]), "path_m_per_traverse": float(np.linalg.norm(np.asarray(stepT.t))) * (n_frames - 1)},

@@ -90,8 +90,10 @@ void FrontendLockstep::check(int rc, const char* what) const
 }
 
 FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepOptions& options)
-    : ctx_(ctx), opt_(options), pool_(options.n_workers < 1 ? 1 : options.n_workers, options.pin_workers)
+    : ctx_(ctx), opt_(options)
 {
+  if (opt_.shared_pool) { pool_.shared = opt_.shared_pool; pool_.seed = opt_.shared_pool_seed; }
+  else pool_.own.reset(new WorkerPool(options.n_workers < 1 ? 1 : options.n_workers, options.pin_workers));
   if (!ctx_) throw std::runtime_error("FrontendLockstep: NULL svoh_ctx (no CPU fallback exists)");
   if (n_streams < 1 || n_streams > 256) throw std::runtime_error("FrontendLockstep: n_streams out of range [1, 256]");
   opt_.params.depth_filter.use_threaded_depthfilter = false;   // the synchronous path
@@ -636,17 +638,48 @@ int svohl_guard(F&& f)
 }
 }  // namespace
 
+struct svohl_pool { std::shared_ptr<svo_hip::SharedPool> pool; };
+
 extern "C" {
 
 const char* svohl_last_error(void) { return g_svohl_error.c_str(); }
 
+int svohl_pool_create(int n_workers, svohl_pool** out)
+{
+  return svohl_guard([&] {
+    if (!out || n_workers < 1 || n_workers > 1024) throw std::runtime_error("svohl_pool_create: bad arguments");
+    std::unique_ptr<svohl_pool> p(new svohl_pool);
+    p->pool.reset(new svo_hip::SharedPool(n_workers));
+    *out = p.release();
+  });
+}
+
+void svohl_pool_destroy(svohl_pool* p) { try { delete p; } catch (...) {} }
+
+static int svohl_create_impl(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* params_yaml, double depth_min, double depth_mean,
+                             double depth_max, int kf_every, int n_workers, svohl_pool* pool, int seed, int images_pinned, svohl_engine** out);
+
 int svohl_create(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* params_yaml, double depth_min, double depth_mean,
                  double depth_max, int kf_every, int n_workers, int images_pinned, svohl_engine** out)
+{
+  return svohl_create_impl(ctx, n_streams, cam, T_B_C, params_yaml, depth_min, depth_mean, depth_max, kf_every, n_workers, nullptr, 0, images_pinned, out);
+}
+
+int svohl_create_shared(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* params_yaml, double depth_min, double depth_mean,
+                        double depth_max, int kf_every, svohl_pool* pool, int seed, int images_pinned, svohl_engine** out)
+{
+  if (!pool) { g_svohl_error = "svohl_create_shared: NULL pool"; return SVOH_ERR_INVALID_ARGUMENT; }
+  return svohl_create_impl(ctx, n_streams, cam, T_B_C, params_yaml, depth_min, depth_mean, depth_max, kf_every, 1, pool, seed, images_pinned, out);
+}
+
+static int svohl_create_impl(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* params_yaml, double depth_min, double depth_mean,
+                             double depth_max, int kf_every, int n_workers, svohl_pool* pool, int seed, int images_pinned, svohl_engine** out)
 {
   return svohl_guard([&] {
     if (!out || !cam || !T_B_C) throw std::runtime_error("svohl_create: NULL argument");
     *out = nullptr;
     svo_hip::LockstepOptions lo;
+    if (pool) { lo.shared_pool = pool->pool; lo.shared_pool_seed = seed; }
     lo.params = svo_hip::io::frontendParamsFromYaml(params_yaml ? svo_hip::io::parseYaml(params_yaml) : svo_hip::io::YamlNode());
     lo.cam = *cam;
     lo.T_B_C = svoh::load_rigid(*T_B_C);

@@ -47,7 +47,11 @@ struct LockstepOptions {
   Transformation T_B_C{ { 1, 0, 0, 0 }, { 0, 0, 0 } };
   float depth_min = 1.f, depth_mean = 2.f, depth_max = 4.f;   // the depth prior of a new keyframe's seeds
   size_t kf_every = 8, min_tracked = 60;                     // the harness' keyframe rule
-  int n_workers = 1;                                          // host threads, the caller included
+  int n_workers = 1;                                          // host threads, the caller included (a pool of the engine's own)
+  // ... or, when set, no pool of its own: the engine's phases draw on worker threads shared with other engines (one
+  // engine per lock-step group); item i of this engine prefers worker (i + shared_pool_seed) % workers
+  std::shared_ptr<SharedPool> shared_pool;
+  int shared_pool_seed = 0;
   bool pin_workers = false;                                   // bind them to CPUs of their own (WorkerPool)
   int images_mem_space = SVOH_MEM_HOST;                       // SVOH_MEM_HOST_PINNED: images live in svoh_host_alloc memory
 };
@@ -93,9 +97,16 @@ class FrontendLockstep {
   void drainReleases();
   void check(int rc, const char* what) const;
 
+  // the engine's host phases: on its own pool, or on the pool it shares with other engines
+  struct Runner {
+    std::unique_ptr<WorkerPool> own;
+    std::shared_ptr<SharedPool> shared;
+    int seed = 0;
+    void run(int n_items, const std::function<void(int)>& fn) { if (shared) shared->run(n_items, fn, seed); else own->run(n_items, fn); }
+  };
   svoh_ctx* ctx_;
   LockstepOptions opt_;
-  WorkerPool pool_;
+  Runner pool_;
   std::vector<std::unique_ptr<Stream>> streams_;
   size_t round_ = 0;
   bool seeds_in_flight_ = false;

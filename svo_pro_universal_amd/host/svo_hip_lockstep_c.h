@@ -12,12 +12,21 @@ extern "C" {
 #endif
 
 typedef struct svohl_engine svohl_engine;
+typedef struct svohl_pool svohl_pool;
+
+/* worker threads shared by several engines (SharedPool, svo_hip_pool.h): pass the pool and a seed (the engine's first
+ * stream index) to svohl_create_shared; destroy the pool after its engines */
+int svohl_pool_create(int n_workers, svohl_pool** out);
+void svohl_pool_destroy(svohl_pool* p);
 
 /* params_yaml: the reference's parameter file as text (the keys of svo_factory.cpp this library implements; NULL = the
  * defaults).  images_pinned != 0: the images passed to svohl_add_images live in svoh_host_alloc memory. */
 int svohl_create(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* params_yaml,
                  double depth_min, double depth_mean, double depth_max, int kf_every, int n_workers, int images_pinned,
                  svohl_engine** out);
+int svohl_create_shared(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* params_yaml,
+                        double depth_min, double depth_mean, double depth_max, int kf_every, svohl_pool* pool, int seed, int images_pinned,
+                        svohl_engine** out);
 void svohl_destroy(svohl_engine* e);
 /* one frame of every stream (FrontendLockstep::addImages); T_f_w_first: n_streams poses for the first call, else ignored */
 int svohl_add_images(svohl_engine* e, const uint8_t* const* images, int pitch, const svoh_se3* T_f_w_first);

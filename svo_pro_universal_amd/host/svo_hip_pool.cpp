@@ -138,4 +138,107 @@ void WorkerPool::run(int n_items, const std::function<void(int)>& fn)
   if (e) std::rethrow_exception(e);
 }
 
+// ---- SharedPool ---------------------------------------------------------------------------------------------------
+SharedPool::SharedPool(int n_workers)
+{
+  if (const char* e = getenv("SVOH_LOCKSTEP_SPIN")) spin_limit_ = atoi(e);
+  if (const char* e = getenv("SVOH_LOCKSTEP_YIELD")) yield_limit_ = atoi(e);
+  for (Job& j : jobs_) for (auto& t : j.taken) t.store(0);
+  for (int i = 0; i < n_workers; ++i) {
+    try { threads_.emplace_back(&SharedPool::worker, this, i); }
+    catch (...) { break; }
+  }
+}
+
+SharedPool::~SharedPool()
+{
+  stop_.store(true);
+  epoch_.fetch_add(1);
+  { std::lock_guard<std::mutex> lock(mu_); cv_.notify_all(); }
+  for (std::thread& t : threads_) t.join();
+}
+
+// Take items of `job` until none is left to take: first the ones that prefer this worker, then anybody's.
+bool SharedPool::work_on(Job& job, int worker)
+{
+  const int n = job.n_items, W = static_cast<int>(threads_.size());
+  bool ran = false;
+  auto claim = [&](int i) {
+    const unsigned long long bit = 1ull << (i & 63);
+    return (job.taken[i >> 6].fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+  };
+  auto exec = [&](int i) {
+    try { (*job.fn)(i); }
+    catch (...) { std::lock_guard<std::mutex> lock(job.err_mu); if (!job.error) job.error = std::current_exception(); }
+    job.pending.fetch_sub(1, std::memory_order_acq_rel);
+    ran = true;
+  };
+  if (worker >= 0) {
+    int first = (worker - job.seed) % W;
+    if (first < 0) first += W;
+    for (int i = first; i < n; i += W) if (claim(i)) exec(i);
+  }
+  for (int i = 0; i < n; ++i) {
+    if (job.taken[i >> 6].load(std::memory_order_acquire) & (1ull << (i & 63))) continue;
+    if (claim(i)) exec(i);
+  }
+  return ran;
+}
+
+void SharedPool::worker(int id)
+{
+  int idle = 0;
+  unsigned long seen = epoch_.load();
+  for (;;) {
+    if (stop_.load()) return;
+    bool ran = false;
+    for (Job& j : jobs_) {
+      if (j.state.load(std::memory_order_acquire) != 1) continue;
+      j.readers.fetch_add(1, std::memory_order_acq_rel);
+      if (j.state.load(std::memory_order_acquire) == 1 && j.pending.load(std::memory_order_acquire) > 0) ran = work_on(j, id) || ran;
+      j.readers.fetch_sub(1, std::memory_order_acq_rel);
+    }
+    if (ran) { idle = 0; continue; }
+    if (idle < spin_limit_) { SVOH_CPU_RELAX(); ++idle; }
+    else if (idle < spin_limit_ + yield_limit_) { std::this_thread::yield(); ++idle; }
+    else {
+      sleepers_.fetch_add(1);
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&] { return epoch_.load() != seen || stop_.load(); });
+      }
+      sleepers_.fetch_sub(1);
+      idle = 0;
+    }
+    seen = epoch_.load();
+  }
+}
+
+void SharedPool::run(int n_items, const std::function<void(int)>& fn, int seed)
+{
+  if (n_items <= 0) return;
+  if (threads_.empty() || n_items == 1 || n_items > kMaxItems) { for (int i = 0; i < n_items; ++i) fn(i); return; }
+  // a free slot (there are more slots than groups; a caller that finds none runs its items by itself)
+  Job* job = nullptr;
+  for (Job& j : jobs_) {
+    int expect = 0;
+    if (j.state.load(std::memory_order_relaxed) == 0 && j.readers.load(std::memory_order_acquire) == 0 && j.state.compare_exchange_strong(expect, 2)) { job = &j; break; }
+  }
+  if (!job) { for (int i = 0; i < n_items; ++i) fn(i); return; }
+  // (state 2: claimed by this caller, invisible to the workers, and no worker is still inside from its last life)
+  while (job->readers.load(std::memory_order_acquire) != 0) SVOH_CPU_RELAX();
+  job->fn = &fn; job->n_items = n_items; job->seed = seed; job->error = nullptr;
+  for (auto& t : job->taken) t.store(0, std::memory_order_relaxed);
+  job->pending.store(n_items, std::memory_order_release);
+  job->state.store(1, std::memory_order_release);
+  epoch_.fetch_add(1);
+  if (sleepers_.load() > 0) { std::lock_guard<std::mutex> lock(mu_); cv_.notify_all(); }
+  work_on(*job, -1);
+  while (job->pending.load(std::memory_order_acquire) != 0) SVOH_CPU_RELAX();
+  std::exception_ptr e = job->error;
+  job->error = nullptr;
+  job->state.store(0, std::memory_order_release);   // (workers that still look at it find nothing to take; the next owner waits for them)
+  if (e) std::rethrow_exception(e);
+}
+
 }  // namespace svo_hip

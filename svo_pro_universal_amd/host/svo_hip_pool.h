@@ -45,4 +45,45 @@ class WorkerPool {
   std::exception_ptr error_;
 };
 
+
+// One set of worker threads for SEVERAL lock-step groups.  A group's thread is busy with its context's serial work and
+// waits for the device a third of the time; with a pool of its own its workers idle through all of that.  Here every
+// group's phases draw on the same workers: a phase of 8 items finds up to all of them free and takes a stream's time
+// instead of two or three, and a worker that would idle through one group's device wait serves another group's phase.
+// Item i of a group prefers worker (i + seed) % n_workers -- a stream's data stays in one core's caches as long as that
+// worker is free -- and is taken by whoever is idle otherwise.  run() may be called from several threads at once (one
+// per group); the caller works on its own items too.
+class SharedPool {
+ public:
+  explicit SharedPool(int n_workers);
+  ~SharedPool();
+  SharedPool(const SharedPool&) = delete;
+  SharedPool& operator=(const SharedPool&) = delete;
+  int workers() const { return static_cast<int>(threads_.size()); }
+  void run(int n_items, const std::function<void(int)>& fn, int seed);
+
+ private:
+  static constexpr int kSlots = 16, kMaxItems = 256;
+  struct Job {
+    std::atomic<int> state{ 0 };        // 0 free, 1 live
+    std::atomic<int> readers{ 0 };      // workers looking at the job right now
+    std::atomic<int> pending{ 0 };      // items not finished
+    std::atomic<unsigned long long> taken[kMaxItems / 64];
+    const std::function<void(int)>* fn = nullptr;
+    int n_items = 0, seed = 0;
+    std::mutex err_mu;
+    std::exception_ptr error;
+  };
+  bool work_on(Job& job, int worker);   // true if it ran an item
+  void worker(int id);
+  Job jobs_[kSlots];
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::atomic<unsigned long> epoch_{ 0 };
+  std::atomic<int> sleepers_{ 0 };
+  std::atomic<bool> stop_{ false };
+  int spin_limit_ = 20000, yield_limit_ = 400;
+};
+
 }  // namespace svo_hip

@@ -24,6 +24,11 @@ def load_host():
     P = C.POINTER
     lib.svohl_create.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_camera), P(capi.svoh_se3), C.c_char_p, C.c_double, C.c_double, C.c_double,
                                  C.c_int, C.c_int, C.c_int, P(C.c_void_p)]
+    lib.svohl_pool_create.argtypes = [C.c_int, P(C.c_void_p)]
+    lib.svohl_pool_destroy.argtypes = [C.c_void_p]
+    lib.svohl_pool_destroy.restype = None
+    lib.svohl_create_shared.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_camera), P(capi.svoh_se3), C.c_char_p, C.c_double, C.c_double, C.c_double,
+                                        C.c_int, C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
     lib.svohl_destroy.argtypes = [C.c_void_p]
     lib.svohl_destroy.restype = None
     lib.svohl_add_images.argtypes = [C.c_void_p, P(C.c_void_p), C.c_int, C.c_void_p]
@@ -67,18 +72,40 @@ class PinnedImages(object):
             self.ptr = None
 
 
-class Lockstep(object):
-    """One lock-step group of n_streams streams on the context `ctx` (frontend.Context)."""
+class SharedPool(object):
+    """Worker threads that several Lockstep engines draw on (host/svo_hip_pool.h: SharedPool)."""
 
-    def __init__(self, ctx, n_streams, cam, T_B_C7, params_yaml, depth_min, depth_mean, depth_max, kf_every=8, n_workers=1, images_pinned=True):
+    def __init__(self, n_workers):
+        self.lib = load_host()
+        h = C.c_void_p()
+        if self.lib.svohl_pool_create(int(n_workers), C.byref(h)) != 0:
+            raise RuntimeError(self.lib.svohl_last_error().decode())
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.svohl_pool_destroy(self.h)
+            self.h = None
+
+
+class Lockstep(object):
+    """One lock-step group of n_streams streams on the context `ctx` (frontend.Context).  pool: a SharedPool (the engine
+    then has no threads of its own; seed = its first stream's index among all groups)."""
+
+    def __init__(self, ctx, n_streams, cam, T_B_C7, params_yaml, depth_min, depth_mean, depth_max, kf_every=8, n_workers=1, images_pinned=True,
+                 pool=None, seed=0):
         self.lib = load_host()
         self.ctx = ctx
         self.n = int(n_streams)
         h = C.c_void_p()
         c = fe._camera(cam)
         T = fe._se3(np.asarray(T_B_C7, dtype=np.float64))
-        rc = self.lib.svohl_create(ctx.h, self.n, C.byref(c), C.byref(T), params_yaml.encode() if params_yaml else None, float(depth_min),
-                                   float(depth_mean), float(depth_max), int(kf_every), int(n_workers), 1 if images_pinned else 0, C.byref(h))
+        if pool is not None:
+            rc = self.lib.svohl_create_shared(ctx.h, self.n, C.byref(c), C.byref(T), params_yaml.encode() if params_yaml else None, float(depth_min),
+                                              float(depth_mean), float(depth_max), int(kf_every), pool.h, int(seed), 1 if images_pinned else 0, C.byref(h))
+        else:
+            rc = self.lib.svohl_create(ctx.h, self.n, C.byref(c), C.byref(T), params_yaml.encode() if params_yaml else None, float(depth_min),
+                                       float(depth_mean), float(depth_max), int(kf_every), int(n_workers), 1 if images_pinned else 0, C.byref(h))
         if rc != 0:
             raise fe.SvohError(rc, self.lib.svohl_last_error().decode())
         self.h = h

@@ -38,6 +38,27 @@ static void one_group(int n_threads, int n_rounds, long* checksum)
   *checksum = total;
 }
 
+// the same phases by several callers at once on ONE SharedPool (one caller per lock-step group)
+static void shared_group(svo_hip::SharedPool* pool, int seed, int n_rounds, long* checksum)
+{
+  std::vector<long> slots(67, 0), sums(67, 0);
+  long total = 0;
+  for (int r = 0; r < n_rounds; ++r) {
+    const int n = 1 + (r * 7) % 67;
+    pool->run(n, [&](int i) { slots[(size_t)i] = (long)r * 1000 + i; }, seed);
+    pool->run(n, [&](int i) { sums[(size_t)i] = slots[(size_t)i] + slots[(size_t)((i + 1) % n)]; }, seed);
+    for (int i = 0; i < n; ++i) total += sums[(size_t)i];
+    if (r % 97 == 0) std::this_thread::sleep_for(std::chrono::milliseconds(3));
+    if (r % 53 == 0) {
+      bool caught = false;
+      try { pool->run(n, [&](int i) { if (i == n / 2) throw std::runtime_error("item"); slots[(size_t)i] = -1; }, seed); }
+      catch (const std::runtime_error&) { caught = true; }
+      if (!caught) { fprintf(stderr, "exception lost\n"); abort(); }
+    }
+  }
+  *checksum = total;
+}
+
 int main(int argc, char** argv)
 {
   const int n_rounds = argc > 1 ? atoi(argv[1]) : 3000;
@@ -47,6 +68,13 @@ int main(int argc, char** argv)
   std::thread g1(one_group, 4, n_rounds, &a), g2(one_group, 3, n_rounds, &b);   // two groups side by side, as the tool runs them
   one_group(6, n_rounds, &c);
   g1.join(); g2.join();
+  long e = 0, f = 0, g = 0;
+  {
+    svo_hip::SharedPool shared(5);
+    std::thread s1(shared_group, &shared, 0, n_rounds, &e), s2(shared_group, &shared, 8, n_rounds, &f);
+    shared_group(&shared, 16, n_rounds, &g);
+    s1.join(); s2.join();
+  }
   // the same arithmetic without threads
   auto expect = [](int n_rounds_) {
     long total = 0;
@@ -58,6 +86,7 @@ int main(int argc, char** argv)
   };
   // (after a throwing round the slots of that round hold -1 or the old value, but phase 1 of the next round rewrites every slot it reads)
   if (a != expect(n_rounds) || b != expect(n_rounds) || c != expect(n_rounds) || d != expect(200)) { fprintf(stderr, "checksum mismatch\n"); return 1; }
+  if (e != expect(n_rounds) || f != expect(n_rounds) || g != expect(n_rounds)) { fprintf(stderr, "checksum mismatch (shared pool)\n"); return 1; }
   printf("ok\n");
   return 0;
 }

@@ -222,6 +222,8 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
 
 // one lock-step group: streams [s0, s0 + n) of the run, all fed the same decoded sequence
 struct GroupResult { size_t frames = 0; double wall_ms = 0, steady_ms = 0; size_t steady_rounds = 0; int device_calls = 0; FrontendLockstep::RoundTimes mean{}; std::string error; };
+std::shared_ptr<SharedPool> g_shared_pool;   // SVOH_LOCKSTEP_SHARED=1: the groups' host phases on one set of worker threads
+
 void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::GrayImage>& images, const std::vector<io::RigCamera>& rig, const io::FrontendParams& params,
                         const std::string& out_dir, const Transformation& T0, float depth_min, float depth_mean, float depth_max, size_t kf_every, int s0, int n,
                         int n_workers, int n_laps, std::atomic<int>* start_gate, int n_groups, GroupResult* out)
@@ -245,6 +247,7 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
       lo.params = params; lo.cam = rig.at(0).cam; lo.T_B_C = rig[0].T_B_C;
       lo.depth_min = depth_min; lo.depth_mean = depth_mean; lo.depth_max = depth_max; lo.kf_every = kf_every; lo.n_workers = n_workers;
       lo.images_mem_space = SVOH_MEM_HOST_PINNED;
+      lo.shared_pool = g_shared_pool; lo.shared_pool_seed = s0;
       lo.pin_workers = getenv("SVOH_LOCKSTEP_PIN") != nullptr && atoi(getenv("SVOH_LOCKSTEP_PIN")) != 0;   // (a shared box: its low CPUs are everybody's)
       FrontendLockstep fe(ctx, n, lo);
       const bool last_lap = lap + 1 == n_laps;
@@ -346,6 +349,9 @@ int main(int argc, char** argv)
       if (n_workers < 1 || n_workers > 256 || n_groups < 1 || n_groups > n_streams || n_laps < 1) throw std::runtime_error("n_workers / n_groups / n_laps out of range");
       if (images.empty()) throw std::runtime_error("no images");
       for (int s = 1; s < n_streams; ++s) (void)mkdir((out_dir + "/stream" + std::to_string(s)).c_str(), 0755);
+      // the groups' workers as ONE pool that every group's phases draw on (default; SVOH_LOCKSTEP_SHARED=0: a pool per group)
+      if (n_groups > 1 && (getenv("SVOH_LOCKSTEP_SHARED") == nullptr || atoi(getenv("SVOH_LOCKSTEP_SHARED")) != 0))
+        g_shared_pool.reset(new SharedPool(n_groups * (n_workers - 1)));
       std::vector<GroupResult> res((size_t)n_groups);
       std::atomic<int> gate(0);
       std::vector<std::thread> threads;
