@@ -671,10 +671,10 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         ctx.set_kernel_timing(False)
         ranges = [(S * g // G, S * (g + 1) // G) for g in range(G)]
         pins = [ls.PinnedImages(c, images, hi - lo) for c, (lo, hi) in zip(ctxs, ranges)]   # every stream its own copy of the sequence
-        # the groups' host phases on ONE set of worker threads (G group threads + G * (W - 1) shared workers = G * W threads in
+        # SVOH_LOCKSTEP_SHARED=1: the groups' host phases on ONE set of worker threads (G group threads + G * (W - 1) shared workers = G * W threads in
         # all, as with a pool per group: SVOH_LOCKSTEP_SHARED=0), so that a group's phase finds the workers another group's device
         # wait leaves idle
-        shared = ls.SharedPool(G * (W - 1)) if G > 1 and W > 1 and os.environ.get("SVOH_LOCKSTEP_SHARED", "1") != "0" else None
+        shared = ls.SharedPool(G * (W - 1)) if G > 1 and W > 1 and os.environ.get("SVOH_LOCKSTEP_SHARED", "0") != "0" else None
         engines = [ls.Lockstep(c, hi - lo, cam, np.array([1.0, 0, 0, 0, 0, 0, 0]), params, 0.5 * depth, depth, 2.0 * depth, 8, W, True, pool=shared, seed=lo)
                    for c, (lo, hi) in zip(ctxs, ranges)]
         first = poses[0].inverse().as7()

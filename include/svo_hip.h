@@ -194,6 +194,14 @@ int svoh_context_stats(svoh_ctx* ctx, svoh_context_stats_t* out);
  * changes those variables afterwards (the test-suite does, to run every kernel geometry) asks for them to be read again: */
 int svoh_reload_knobs(svoh_ctx* ctx);
 
+/* How staged blocks travel between page-locked host memory and the device: 0 = the runtime's copies (hipMemcpyAsync), 1 (the
+ * default) = copy kernels for blocks of 16 KB .. 1 MB, where they are the faster call for ONE stream, 2 = copy kernels always.
+ * 2 is for a process that drives SEVERAL contexts on one device (lock-step groups): a runtime copy between two kernels is a
+ * hand-over between the compute queue and the copy engine, and the machine takes only ~160 k such mixed dispatches per second
+ * from all streams together (tools/svoh_dispatch_rate).  Same bytes either way.  SVOH_COPY_KERNEL in the environment sets the
+ * same value when the context is made. */
+int svoh_set_copy_policy(svoh_ctx* ctx, int policy);
+
 /* Kernel timing.  Off by default: bracketing a launch with an event pair costs ~9 us of every call on an MI355X
  * (tools/svoh_call_overhead), a quarter of a small call.  When on (this call, or SVOH_KERNEL_TIMING=1 in the
  * environment of svoh_create), svoh_sparse_align_last_kernel_ms / _kernel_ms_history / svoh_last_kernel_ms report the

@@ -41,16 +41,35 @@ __global__ __launch_bounds__(256) void svoh_copy_to_host_kernel(uint4* dst, cons
   __threadfence_system();
 }
 
+// Policy 2 (svoh_set_copy_policy; what a driver of MANY contexts on one device sets): EVERY staged block travels through a copy
+// kernel, whatever its size.  A hipMemcpyAsync between two kernels of a stream is a hand-over between the compute queue and the
+// copy engine and back; one stream does not notice (policy 1 keeps the runtime's copy where it is the faster call), but the
+// machine takes only ~160 k such mixed dispatches per second from ALL streams together (tools/svoh_dispatch_rate: 2, 4 and 8
+// threads alike, against > 500 k copy-kernel dispatches and > 1 M plain launches) -- which is where four lock-step groups
+// with a handful of copies per round each ran into a wall.
+static bool copy_by_kernel(const svoh_ctx* ctx, const void* a, const void* b, size_t bytes, size_t min_bytes)
+{
+  const int policy = SvohKnobs::or_default(ctx->knobs.copy_kernel, 1);
+  if (policy == 0 || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15)) return false;
+  if (policy >= 2) return bytes >= 16;
+  return bytes >= min_bytes && bytes <= ((size_t)1 << 20);
+}
+static unsigned copy_blocks(size_t n16)
+{
+  // 128 KB in flight per 32 workgroups; a block of several MB gets more of them so that the link stays full
+  size_t blocks = (n16 + 255) / 256;
+  const size_t cap = n16 > ((size_t)1 << 16) ? 128 : 32;
+  return (unsigned)(blocks > cap ? cap : (blocks ? blocks : 1));
+}
+
 hipError_t svoh_copy_to_host(svoh_ctx* ctx, void* dst_pinned, const void* src_device, size_t bytes)
 {
   if (bytes == 0) return hipSuccess;
-  const bool by_kernel = SvohKnobs::or_default(ctx->knobs.copy_kernel, 1) != 0 && bytes >= ((size_t)16 << 10) && bytes <= ((size_t)1 << 20) &&
-                         !(reinterpret_cast<uintptr_t>(dst_pinned) & 15) && !(reinterpret_cast<uintptr_t>(src_device) & 15);
+  const bool by_kernel = copy_by_kernel(ctx, dst_pinned, src_device, bytes, (size_t)16 << 10);
   if (!by_kernel) return hipMemcpyAsync(dst_pinned, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream);
   const size_t n16 = bytes / 16;
   const int n_tail = (int)(bytes - n16 * 16);
-  unsigned blocks = (unsigned)((n16 + 255) / 256);
-  if (blocks > 32) blocks = 32;
+  const unsigned blocks = copy_blocks(n16);
   hipLaunchKernelGGL(svoh_copy_to_host_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<uint4*>(dst_pinned),
                      static_cast<const uint4*>(src_device), n16, static_cast<uint8_t*>(dst_pinned) + n16 * 16,
                      static_cast<const uint8_t*>(src_device) + n16 * 16, n_tail);
@@ -60,13 +79,11 @@ hipError_t svoh_copy_to_host(svoh_ctx* ctx, void* dst_pinned, const void* src_de
 hipError_t svoh_copy_to_device(svoh_ctx* ctx, void* dst_device, const void* src_pinned, size_t bytes)
 {
   if (bytes == 0) return hipSuccess;
-  const bool by_kernel = SvohKnobs::or_default(ctx->knobs.copy_kernel, 1) != 0 && bytes >= ((size_t)32 << 10) && bytes <= ((size_t)1 << 20) &&
-                         !(reinterpret_cast<uintptr_t>(dst_device) & 15) && !(reinterpret_cast<uintptr_t>(src_pinned) & 15);
+  const bool by_kernel = copy_by_kernel(ctx, dst_device, src_pinned, bytes, (size_t)32 << 10);
   if (!by_kernel) return hipMemcpyAsync(dst_device, src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream);
   const size_t n16 = bytes / 16;
   const int n_tail = (int)(bytes - n16 * 16);
-  unsigned blocks = (unsigned)((n16 + 255) / 256);
-  if (blocks > 32) blocks = 32;
+  const unsigned blocks = copy_blocks(n16);
   hipLaunchKernelGGL(svoh_copy_to_host_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<uint4*>(dst_device),
                      static_cast<const uint4*>(src_pinned), n16, static_cast<uint8_t*>(dst_device) + n16 * 16,
                      static_cast<const uint8_t*>(src_pinned) + n16 * 16, n_tail);
@@ -433,12 +450,21 @@ try {
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
+int svoh_set_copy_policy(svoh_ctx* ctx, int policy)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, policy >= 0 && policy <= 2, "copy policy: 0 the runtime's copies, 1 copy kernels for 16 KB .. 1 MB, 2 copy kernels always");
+  ctx->knobs.copy_kernel = policy;
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
 int svoh_reload_knobs(svoh_ctx* ctx)
 try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
-  const int timing = ctx->knobs.kernel_timing;
+  const int timing = ctx->knobs.kernel_timing, copy_policy = ctx->knobs.copy_kernel;
   load_knobs_from_env(ctx->knobs);
   if (ctx->knobs.kernel_timing == kKnobUnset) ctx->knobs.kernel_timing = timing;   // set by svoh_set_kernel_timing, not by the environment
+  if (ctx->knobs.copy_kernel == kKnobUnset) ctx->knobs.copy_kernel = copy_policy;  // ... by svoh_set_copy_policy
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 

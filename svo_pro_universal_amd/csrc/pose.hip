@@ -666,7 +666,7 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
       stage_range((int)((long long)n_problems * t / n_stage_threads), (int)((long long)n_problems * (t + 1) / n_stage_threads));
     for (auto& w : workers) w.join();
   }
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, in_total, hipMemcpyHostToDevice, ctx->stream));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, in_total));
   PoseArgs a;
   a.opt = *options;
   a.problems = reinterpret_cast<const DevPoseProblem*>(d + o_pb);
@@ -705,12 +705,12 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
   ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
   if (packed) {   // per-feature outputs stay on the device; the per-bundle results come back
-    SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_res, d + o_res, total - o_res, hipMemcpyDeviceToHost, ctx->stream));
+    SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + o_res, d + o_res, total - o_res));
     SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(results, h + o_res, sizeof(svoh_pose_result) * (size_t)n_problems);
     return SVOH_OK;
   }
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_outlier, d + o_outlier, total - o_outlier, hipMemcpyDeviceToHost, ctx->stream));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + o_outlier, d + o_outlier, total - o_outlier));
   if (after_launch) {
     // the hook's work goes behind an event and is not waited for: this call's staging (h, d) is not touched by it --
     // the hook must not enter a blocking call of the context, and the depth filter's staging has blocks of its own

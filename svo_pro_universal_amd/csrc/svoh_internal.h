@@ -129,7 +129,7 @@ struct SvohKnobs {
   int align_lds = kKnobUnset;                 // SVOH_ALIGN_LDS: bytes of LDS for image levels (rounded down to a multiple of 16)
   int align_wg_per_cu = kKnobUnset;           // SVOH_ALIGN_WG_PER_CU
   int kernel_timing = kKnobUnset;             // SVOH_KERNEL_TIMING: 1 = bracket every kernel with an event pair (svoh_set_kernel_timing)
-  int copy_kernel = kKnobUnset;               // SVOH_COPY_KERNEL: 0 = result blocks always come back through hipMemcpyAsync
+  int copy_kernel = kKnobUnset;               // SVOH_COPY_KERNEL / svoh_set_copy_policy: 0 = staged blocks through hipMemcpyAsync, 1 (default) = copy kernels for 16 KB .. 1 MB, 2 = copy kernels always
   static int or_default(int v, int dflt) { return v == kKnobUnset ? dflt : v; }
 };
 void load_knobs_from_env(SvohKnobs& k);

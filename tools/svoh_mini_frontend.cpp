@@ -349,8 +349,8 @@ int main(int argc, char** argv)
       if (n_workers < 1 || n_workers > 256 || n_groups < 1 || n_groups > n_streams || n_laps < 1) throw std::runtime_error("n_workers / n_groups / n_laps out of range");
       if (images.empty()) throw std::runtime_error("no images");
       for (int s = 1; s < n_streams; ++s) (void)mkdir((out_dir + "/stream" + std::to_string(s)).c_str(), 0755);
-      // the groups' workers as ONE pool that every group's phases draw on (default; SVOH_LOCKSTEP_SHARED=0: a pool per group)
-      if (n_groups > 1 && (getenv("SVOH_LOCKSTEP_SHARED") == nullptr || atoi(getenv("SVOH_LOCKSTEP_SHARED")) != 0))
+      // SVOH_LOCKSTEP_SHARED=1: the groups' workers as ONE pool that every group's phases draw on (measured: no gain over a pool per group, profiles/r05_shared_pool_ab.txt)
+      if (n_groups > 1 && n_workers > 1 && getenv("SVOH_LOCKSTEP_SHARED") != nullptr && atoi(getenv("SVOH_LOCKSTEP_SHARED")) != 0)
         g_shared_pool.reset(new SharedPool(n_groups * (n_workers - 1)));
       std::vector<GroupResult> res((size_t)n_groups);
       std::atomic<int> gate(0);
