@@ -96,9 +96,10 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
   else pool_.own.reset(new WorkerPool(options.n_workers < 1 ? 1 : options.n_workers, options.pin_workers));
   if (!ctx_) throw std::runtime_error("FrontendLockstep: NULL svoh_ctx (no CPU fallback exists)");
   if (n_streams < 1 || n_streams > 256) throw std::runtime_error("FrontendLockstep: n_streams out of range [1, 256]");
-  // every staged block through a copy kernel: several lock-step groups on one device must not meet at the copy engine
-  // (svoh_set_copy_policy; SVOH_LOCKSTEP_COPY_POLICY overrides for the A/B)
-  check(svoh_set_copy_policy(ctx_, getenv("SVOH_LOCKSTEP_COPY_POLICY") ? atoi(getenv("SVOH_LOCKSTEP_COPY_POLICY")) : 2), "svoh_set_copy_policy");
+  // SVOH_LOCKSTEP_COPY_POLICY=2: every staged block through a copy kernel (svoh_set_copy_policy).  Measured with four groups
+  // on one device and NOT the default: 23.7 / 24.3 k frames/s against 25.6 / 23.3 k with the library's own policy
+  // (profiles/r05_copy_policy_ab.txt) -- the mixed-dispatch ceiling of tools/svoh_dispatch_rate is not what the groups run into.
+  if (getenv("SVOH_LOCKSTEP_COPY_POLICY")) check(svoh_set_copy_policy(ctx_, atoi(getenv("SVOH_LOCKSTEP_COPY_POLICY"))), "svoh_set_copy_policy");
   opt_.params.depth_filter.use_threaded_depthfilter = false;   // the synchronous path
   ReprojectorOptions ropt;
   ropt.max_n_features_per_frame = static_cast<size_t>(opt_.params.max_fts);
