@@ -681,6 +681,7 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         total = n_warm + n_steps
         gate = threading.Barrier(G + 1)
         times = [[] for _ in range(G)]
+        warm_phases = [{} for _ in range(G)]
         errors = []
 
         def loop(g):
@@ -689,6 +690,7 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
                 # (a group's rounds run inside ONE foreign call: with the loop in Python, the groups' threads spend more
                 # time handing the interpreter lock to each other than in their rounds)
                 e.run_sequence(pin, cam.width, 0, n_warm, [first] * n)
+                warm_phases[g] = e.phase_times()
                 gate.wait()   # the timed region starts for every group at once
                 times[g] = e.run_sequence(pin, cam.width, n_warm, n_steps)
                 e.finish()
@@ -721,6 +723,8 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         rows = engines[0].completed_rows(0)
         stage = dict(zip(("pyramid", "align", "reproject", "pose", "seeds", "keyframe", "total"), [float(v) for v in np.median(times[0], axis=0)])) if len(times[0]) else {}
         calls = engines[0].last_round()[1]
+        # where group 0's thread spent the timed rounds: waits for the device against host phases
+        phases = {k: (v - warm_phases[0].get(k, 0.0)) / max(1, n_steps) for k, v in engines[0].phase_times().items()}
         for e in engines:
             e.close()
         if shared is not None:
@@ -731,7 +735,9 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
             c.close()
         return {"streams": S, "groups": G, "host_threads_per_group": W, "host_threads": G * W, "workers_shared_between_groups": shared is not None,
                 "frames_per_s": S * n_steps / elapsed, "ms_per_round": 1e3 * elapsed / n_steps,
-                "round_stage_ms_median_group0": stage, "device_calls_per_round_per_group": calls,
+                "round_stage_ms_median_group0": stage, "round_phase_ms_mean_group0": {k: round(v, 4) for k, v in phases.items()},
+                "device_waits_ms_per_round_group0": round(sum(phases.get(k, 0.0) for k in ("seed wait", "align wait", "match wait", "pose call", "detect wait")), 4),
+                "device_calls_per_round_per_group": calls,
                 "all_streams_at_the_same_pose": bool(agree), "rounds_run": total,
                 "pose_vs_rendered_pose_unscaled": {"rot_rad": float(err[0]), "trans_m": float(err[1]), "path_m_per_traverse": float(np.linalg.norm(np.asarray(stepT.t))) * (n_frames - 1)},
                 "features_per_frame_median": float(np.median(rows[1:, 3])) if len(rows) > 1 else None}, elapsed

@@ -486,6 +486,21 @@ typedef struct svoh_matcher_options {
   double max_patch_diff_ratio;            /* 2.0 */
 } svoh_matcher_options;
 
+/* ---- resident feature columns -----------------------------------------------------------------------------------
+ * The per-feature columns of a keyframe that do not change once the keyframe exists -- px_vec_, f_vec_, grad_vec_,
+ * level_vec_ (src/svo_common/include/svo/common/frame.h:62-73) -- kept in HBM.  A matcher / depth-filter batch then names a
+ * feature by (reference frame, index) instead of carrying its 60 bytes over PCIe every frame: the reprojector and the depth
+ * filter go through the same few keyframes' features frame after frame (reprojector.cpp:131-306, depth_filter.cpp:200-233).
+ * _upload: n_sets sets in one call (one staging block, one copy; the new keyframes of many camera streams); set k has
+ * n[k] >= 0 features, px[k] = 2 x n[k], f[k] = 3 x n[k], grad[k] = 2 x n[k], level[k] = n[k] (host pointers, read before
+ * the call returns).  A set is immutable; a keyframe that gains features gets a new set.  _release: the memory goes back
+ * to the context's pool once every set uploaded with it has been released; batches queued before the release may still
+ * read it (stream order). */
+typedef uint64_t svoh_features_t;
+int svoh_features_upload(svoh_ctx* ctx, int n_sets, const int32_t* n, const double* const* px, const double* const* f,
+                         const double* const* grad, const int32_t* const* level, svoh_features_t* out);
+int svoh_features_release(svoh_ctx* ctx, svoh_features_t features);
+
 /* What the matcher reads of a Frame: pyramid, camera, pose */
 typedef struct svoh_frame_view {
   svoh_frame_t frame;
@@ -493,7 +508,15 @@ typedef struct svoh_frame_view {
   svoh_se3 T_f_w;                         /* Frame::T_f_w_ (camera <- world) */
   double seed_mu_range;                   /* Frame::seed_mu_range_ (depth filter only) */
   int32_t id;                             /* Frame::id() */
-  int32_t reserved;
+  /* 0 everywhere but in ONE place: the current frames of a staged seed batch (SVOH_MEM_STAGED) queued from the hook of
+   * svoh_optimize_pose_batch_hook.  k > 0 there means: T_f_w above holds the frame's T_cam_imu, and the pose the batch is
+   * evaluated at is T_cam_imu * (T_imu_world of result k-1 of the pose batch just launched), composed ON THE DEVICE when
+   * the batch's kernels start -- the depth filter's update can be sent off before the host has seen the optimised pose
+   * (frame_handler_mono.cpp:120-158: optimizePose, then depth_filter_->updateSeeds with the optimised frame). */
+  int32_t pose_result_index_plus1;
+  /* reference frames only, 0 = none: the frame's resident columns, for batches that name their features by index
+   * (svoh_feature_batch::feature_index) */
+  svoh_features_t features;
 } svoh_frame_view;
 
 /* n features referencing one of n_ref_frames reference frames, SoA like Frame's
@@ -518,6 +541,10 @@ typedef struct svoh_feature_batch {
    * of failing the call, and the call returns without synchronising (unless n_success is
    * requested): order later work on svoh_stream() or call svoh_synchronize(). */
   int32_t mem_space;
+  /* SVOH_MEM_STAGED batches only, NULL otherwise: feature i is feature feature_index[i] of the resident columns of its
+   * reference frame (ref_frames[ref_frame_idx[i]].features); px, f, grad and level above are then NULL -- the library
+   * gathers them on the device ahead of the kernels.  An index outside the set marks the unit SVOH_MATCH_NOT_RUN. */
+  const int32_t* feature_index;
 } svoh_feature_batch;
 
 /* Replaces n calls of Matcher::findMatchDirect (src/svo_direct/src/matcher.cpp:31-141),
@@ -640,8 +667,12 @@ typedef struct svoh_matcher_stage_t {
   double* px_cur;          /* direct: in / out; seeds: out */
   double* state;           /* seeds: in / out */
   int32_t* result;  uint8_t* success;  double* f_cur;  int32_t* search_level;  double* h_inv;  double* A_cur_ref;
+  int32_t* feature_index;  /* SVOH_STAGE_RESIDENT_COLUMNS: in (px, f, grad, level above are NULL then) */
 } svoh_matcher_stage_t;
-int svoh_matcher_stage(svoh_ctx* ctx, int seeds, int n, int max_frame_views, int want_match_outputs, svoh_matcher_stage_t* out);
+/* `flags` (the argument was called want_match_outputs: 0 / 1 mean what they meant) */
+#define SVOH_STAGE_MATCH_OUTPUTS 1     /* a seed batch brings px_cur / f_cur / search_level / A_cur_ref back as well */
+#define SVOH_STAGE_RESIDENT_COLUMNS 2  /* features named by (ref_frame_idx, feature_index): see svoh_features_upload */
+int svoh_matcher_stage(svoh_ctx* ctx, int seeds, int n, int max_frame_views, int flags, svoh_matcher_stage_t* out);
 
 /* DepthFilterOptions used by updateSeed (src/svo_direct/include/svo/direct/depth_filter.h:40-100) */
 typedef struct svoh_depth_filter_options {

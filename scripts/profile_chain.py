@@ -33,6 +33,16 @@ if os.environ.get("MODE", "kernel") == "hip":
     shutil.copy(st, os.path.join(dst, "%s_chain_hip_api_stats.csv" % rnd))
     shutil.copy(glob.glob(str(prof / "**" / "*hip_api_trace.csv"), recursive=True)[0], os.path.join(dst, "%s_chain_hip_api_trace.csv" % rnd))
     print("frames:", n_frames)
+elif os.environ.get("MODE") == "trace":
+    # every dispatch and every runtime copy with its start and end on the device: scripts/device_timeline.py reads how much of
+    # the time the device runs something, and how much of it side by side
+    subprocess.check_call(["rocprofv3", "--kernel-trace", "--memory-copy-trace", "--output-format", "csv", "-d", str(prof), "--"] + cmd, env=env, cwd="/tmp")
+    st = glob.glob(str(prof / "**" / "*kernel_trace.csv"), recursive=True)[0]
+    shutil.copy(st, os.path.join(dst, "%s_chain_kernel_trace.csv" % rnd))
+    mc = glob.glob(str(prof / "**" / "*memory_copy_trace.csv"), recursive=True)
+    if mc:
+        shutil.copy(mc[0], os.path.join(dst, "%s_chain_memory_copy_trace.csv" % rnd))
+    sys.exit(0)
 else:
     subprocess.check_call(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(prof), "--"] + cmd, env=env, cwd="/tmp")
     st = glob.glob(str(prof / "**" / "*kernel_stats.csv"), recursive=True)[0]

@@ -14,6 +14,8 @@ SVOH_OK = 0
 SVOH_MEM_HOST = 0
 SVOH_MEM_DEVICE = 1
 SVOH_MEM_STAGED = 2
+SVOH_STAGE_MATCH_OUTPUTS = 1
+SVOH_STAGE_RESIDENT_COLUMNS = 2
 SVOH_MEM_HOST_PINNED = 3
 
 SVOH_DISTORTION_NONE = 0
@@ -95,18 +97,18 @@ class svoh_matcher_options(C.Structure):
 
 class svoh_frame_view(C.Structure):
     _fields_ = [("frame", svoh_frame_t), ("cam", svoh_camera), ("T_f_w", svoh_se3), ("seed_mu_range", C.c_double),
-                ("id", C.c_int32), ("reserved", C.c_int32)]
+                ("id", C.c_int32), ("pose_result_index_plus1", C.c_int32), ("features", C.c_uint64)]
 
 
 class svoh_feature_batch(C.Structure):
     _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("ref_frame_idx", C.c_void_p), ("px", C.c_void_p),
                 ("f", C.c_void_p), ("grad", C.c_void_p), ("level", C.c_void_p), ("type", C.c_void_p),
-                ("cur_frame_idx", C.c_void_p), ("n_cur_frames", C.c_int32), ("mem_space", C.c_int32)]
+                ("cur_frame_idx", C.c_void_p), ("n_cur_frames", C.c_int32), ("mem_space", C.c_int32), ("feature_index", C.c_void_p)]
 
 
 class svoh_matcher_stage_t(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("ref_frame_idx", "cur_frame_idx", "px", "f", "grad", "level", "type", "depth", "px_cur", "state",
-                                            "result", "success", "f_cur", "search_level", "h_inv", "A_cur_ref")]
+                                            "result", "success", "f_cur", "search_level", "h_inv", "A_cur_ref", "feature_index")]
 
 
 class svoh_candidate_job(C.Structure):
@@ -294,7 +296,7 @@ EXPORTS = [
     "svoh_host_alloc", "svoh_host_free", "svoh_build_pyramid_multi", "svoh_build_pyramid_multi_prefetch", "svoh_prefetch_fence",
     "svoh_sparse_align_geometry_key", "svoh_sparse_align_enqueue_keyed",
     "svoh_project_candidates_stage", "svoh_project_candidates_enqueue_staged", "svoh_project_candidates_wait",
-    "svoh_matcher_stage", "svoh_detect_cells_batch", "svoh_detect_fill_features",
+    "svoh_matcher_stage", "svoh_detect_cells_batch", "svoh_detect_fill_features", "svoh_features_upload", "svoh_features_release",
 ]
 
 
@@ -430,6 +432,8 @@ def load(path=None):
     lib.svoh_build_pyramid_multi_prefetch.argtypes = lib.svoh_build_pyramid_multi.argtypes
     lib.svoh_prefetch_fence.argtypes = [C.c_void_p]
     lib.svoh_matcher_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, P(svoh_matcher_stage_t)]
+    lib.svoh_features_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_uint64)]
+    lib.svoh_features_release.argtypes = [C.c_void_p, C.c_uint64]
     lib.svoh_project_candidates_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(svoh_candidate_stage_t)]
     lib.svoh_project_candidates_enqueue_staged.argtypes = [C.c_void_p]
     lib.svoh_project_candidates_wait.argtypes = [C.c_void_p]

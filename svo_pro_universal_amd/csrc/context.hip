@@ -521,6 +521,7 @@ try {
   if (ctx->ev_misc_start) (void)hipEventDestroy(ctx->ev_misc_start);
   if (ctx->ev_misc_stop) (void)hipEventDestroy(ctx->ev_misc_stop);
   if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
+  if (ctx->ev_features) (void)hipEventDestroy(ctx->ev_features);
   if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
   if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -741,6 +742,70 @@ try {
   if (!p) return SVOH_OK;
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   SVOH_HIP_TRY(ctx, hipHostFree(p));   // (waits for work that may still read the block)
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_features_upload(svoh_ctx* ctx, int n_sets, const int32_t* n, const double* const* px, const double* const* f,
+                         const double* const* grad, const int32_t* const* level, svoh_features_t* out)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, n_sets >= 0 && (n_sets == 0 || (n && px && f && grad && level && out)), "bad arguments");
+  if (n_sets == 0) return SVOH_OK;
+  // layout of the call's block: set after set, each [px 16n | f 24n | grad 16n | level 4n], every array 64-byte aligned
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  size_t total = 0;
+  for (int k = 0; k < n_sets; ++k) {
+    SVOH_REQUIRE(ctx, n[k] >= 0 && (n[k] == 0 || (px[k] && f[k] && grad[k] && level[k])), "a set's n is negative or one of its arrays is NULL");
+    const size_t m = (size_t)n[k];
+    total += al(16 * m) + al(24 * m) + al(16 * m) + al(4 * m);
+    out[k] = 0;
+  }
+  if (total == 0) total = 64;
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // the staging block may still be the source of the last upload's copy
+  if (ctx->ev_features) SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_features));
+  else SVOH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_features, hipEventDisableTiming));
+  SVOH_HIP_TRY(ctx, ctx->h_features.reserve(total));
+  auto block = std::make_shared<svoh::FeatureBlock>();
+  block->ptr = ctx->feature_pool->take(total, &block->alloc);
+  if (!block->ptr) {
+    const size_t want = (total + 0xffff) & ~(size_t)0xffff;   // 64 KB steps: blocks of nearly equal size are interchangeable
+    hipError_t e = hipMalloc(&block->ptr, want);
+    if (e != hipSuccess) { block->ptr = nullptr; SVOH_HIP_TRY(ctx, e); }
+    block->alloc = want;
+  }
+  block->pool = ctx->feature_pool;
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_features.ptr);
+  uint8_t* d = static_cast<uint8_t*>(block->ptr);
+  size_t off = 0;
+  std::vector<svoh::FeatureSet> sets((size_t)n_sets);
+  for (int k = 0; k < n_sets; ++k) {
+    const size_t m = (size_t)n[k];
+    svoh::FeatureSet& fs = sets[(size_t)k];
+    fs.block = block; fs.n = n[k];
+    fs.px = reinterpret_cast<const double*>(d + off); if (m) memcpy(h + off, px[k], 16 * m); off += al(16 * m);
+    fs.f = reinterpret_cast<const double*>(d + off); if (m) memcpy(h + off, f[k], 24 * m); off += al(24 * m);
+    fs.grad = reinterpret_cast<const double*>(d + off); if (m) memcpy(h + off, grad[k], 16 * m); off += al(16 * m);
+    fs.level = reinterpret_cast<const int32_t*>(d + off); if (m) memcpy(h + off, level[k], 4 * m); off += al(4 * m);
+  }
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, off ? off : 64));
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_features, ctx->stream));
+  for (int k = 0; k < n_sets; ++k) {
+    const uint64_t id = ctx->next_features_id++;
+    ctx->feature_sets.emplace(id, std::move(sets[(size_t)k]));
+    out[k] = id;
+  }
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_features_release(svoh_ctx* ctx, svoh_features_t features)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  auto it = ctx->feature_sets.find(features);
+  if (it == ctx->feature_sets.end()) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown feature-set handle %llu", (unsigned long long)features);
+  // (no wait: batches queued before this call may still read the block; whoever gets it from the pool writes it on the
+  // context's stream, behind them -- or hipFree waits for the device by itself)
+  ctx->feature_sets.erase(it);
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 

@@ -38,6 +38,9 @@ struct DevFrameView {
   double seed_mu_range;
   int32_t n_levels;
   int32_t id;
+  int32_t pose_result_index_plus1;   // > 0: T_f_w holds T_cam_imu until matcher_prologue_kernel has run (svoh_frame_view)
+  int32_t feat_n;                    // the frame's resident columns (svoh_frame_view::features), or 0 / NULL
+  const double* feat_px; const double* feat_f; const double* feat_grad; const int32_t* feat_level;
 };
 
 struct MatcherArgs {
@@ -2724,8 +2727,10 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
 // host side
 // ---------------------------------------------------------------------------
 
-static int fill_view(svoh_ctx* ctx, const svoh_frame_view& v, DevFrameView* out, const char* what)
+static int fill_view(svoh_ctx* ctx, const svoh_frame_view& v, DevFrameView* out, const char* what, bool pose_from_results_allowed = false)
 {
+  if (v.pose_result_index_plus1 != 0 && !pose_from_results_allowed)
+    return set_error(ctx, SVOH_ERR_INVALID_ARGUMENT, "%s: pose_result_index_plus1 is for the current frames of a staged seed batch queued from the hook of svoh_optimize_pose_batch_hook", what);
   const Frame* f = find_frame(ctx, v.frame);
   if (!f) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "%s: unknown frame handle %llu", what, (unsigned long long)v.frame);
   if (v.cam.distortion != SVOH_DISTORTION_NONE && v.cam.distortion != SVOH_DISTORTION_RADTAN)
@@ -2740,6 +2745,13 @@ static int fill_view(svoh_ctx* ctx, const svoh_frame_view& v, DevFrameView* out,
   out->seed_mu_range = v.seed_mu_range;
   out->n_levels = f->n_levels;
   out->id = v.id;
+  out->pose_result_index_plus1 = v.pose_result_index_plus1;
+  out->feat_n = 0; out->feat_px = out->feat_f = out->feat_grad = nullptr; out->feat_level = nullptr;
+  if (v.features) {
+    auto it = ctx->feature_sets.find(v.features);
+    if (it == ctx->feature_sets.end()) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "%s: unknown feature-set handle %llu", what, (unsigned long long)v.features);
+    out->feat_n = it->second.n; out->feat_px = it->second.px; out->feat_f = it->second.f; out->feat_grad = it->second.grad; out->feat_level = it->second.level;
+  }
   return SVOH_OK;
 }
 
@@ -2854,6 +2866,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
                               h_inv, A_cur_ref, state, success, n_success);
   }
   SVOH_REQUIRE(ctx, fb->mem_space == SVOH_MEM_HOST || fb->mem_space == SVOH_MEM_DEVICE, "bad mem_space");
+  SVOH_REQUIRE(ctx, !fb->feature_index, "feature_index: staged batches only (svoh_matcher_stage with SVOH_STAGE_RESIDENT_COLUMNS)");
   const bool on_device = fb->mem_space == SVOH_MEM_DEVICE;
   SVOH_REQUIRE(ctx, fb->ref_frame_idx && fb->px && fb->f && fb->grad && fb->level && fb->type, "NULL feature array");
   if (seeds) SVOH_REQUIRE(ctx, dopt && state && success, "NULL seed argument");
@@ -3090,6 +3103,7 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
   const int n = fb->n;
   if (n <= 0) return SVOH_OK;
   SVOH_REQUIRE(ctx, fb->mem_space == SVOH_MEM_HOST || fb->mem_space == SVOH_MEM_DEVICE, "bad mem_space");
+  SVOH_REQUIRE(ctx, !fb->feature_index, "feature_index: staged batches only (svoh_matcher_stage with SVOH_STAGE_RESIDENT_COLUMNS)");
   const bool on_device = fb->mem_space == SVOH_MEM_DEVICE;
   SVOH_REQUIRE(ctx, fb->ref_frame_idx && fb->px && fb->f && fb->grad && fb->level && fb->type, "NULL feature array");
   SVOH_REQUIRE(ctx, out->result && out->depth, "result and depth outputs are required");
@@ -3351,14 +3365,17 @@ static int enqueue_candidates(svoh_ctx* ctx, const svoh_camera* cam, const svoh_
 // per batch, on ONE thread).  Layout: [views (max) | ref idx | cur idx | px | f | grad | level | (direct: depth) |
 // type | (direct: px_cur in/out; seeds: state in/out) | result | success | (match outputs) | n_success]; everything from
 // `type` on comes back.
-static void layout_matcher_stage(bool seeds, int n, int max_views, bool want_outputs, svoh_ctx::MatcherStage* st)
+static void layout_matcher_stage(bool seeds, int n, int max_views, bool want_outputs, bool resident, svoh_ctx::MatcherStage* st)
 {
   size_t total = 0;
   auto add = [&](size_t bytes) { const size_t o = total; total = (total + bytes + 63) & ~(size_t)63; return o; };
   const size_t nn = (size_t)n;
-  st->n = n; st->max_views = max_views; st->want_outputs = want_outputs || !seeds;
+  st->n = n; st->max_views = max_views; st->want_outputs = want_outputs || !seeds; st->resident = resident;
   st->o_views = add(sizeof(DevFrameView) * (size_t)max_views);
-  st->o_idx = add(4 * nn); st->o_cidx = add(4 * nn); st->o_px = add(16 * nn); st->o_f = add(24 * nn); st->o_grad = add(16 * nn); st->o_level = add(4 * nn);
+  st->o_idx = add(4 * nn); st->o_cidx = add(4 * nn);
+  // features named by index: the four columns exist on the device only (behind everything that crosses PCIe, see below)
+  st->o_fidx = resident ? add(4 * nn) : 0;
+  if (!resident) { st->o_px = add(16 * nn); st->o_f = add(24 * nn); st->o_grad = add(16 * nn); st->o_level = add(4 * nn); }
   st->o_depth = seeds ? 0 : add(8 * nn);
   st->o_type = add(nn);
   st->back_from = st->o_type;
@@ -3373,6 +3390,7 @@ static void layout_matcher_stage(bool seeds, int n, int max_views, bool want_out
     st->o_fcur = st->o_slevel = st->o_hinv = st->o_A = 0;
   }
   st->o_nsucc = add(sizeof(int32_t));
+  if (resident) { st->o_px = add(16 * nn); st->o_f = add(24 * nn); st->o_grad = add(16 * nn); st->o_level = add(4 * nn); }
   st->total = total;
 }
 
@@ -3396,9 +3414,14 @@ static int run_matcher_staged(svoh_ctx* ctx, bool seeds, const svoh_matcher_opti
   SVOH_REQUIRE(ctx, n_ref_frames + n_cur <= st.max_views, "more frames than the staged block has room for (max_frame_views)");
   // the arrays must be the staged ones: anything else would silently be ignored
   auto at = [&](size_t off) { return static_cast<void*>(h + off); };
-  SVOH_REQUIRE(ctx, fb->ref_frame_idx == at(st.o_idx) && fb->cur_frame_idx == at(st.o_cidx) && fb->px == at(st.o_px) && fb->f == at(st.o_f) &&
-                        fb->grad == at(st.o_grad) && fb->level == at(st.o_level) && fb->type == at(st.o_type),
+  SVOH_REQUIRE(ctx, fb->ref_frame_idx == at(st.o_idx) && fb->cur_frame_idx == at(st.o_cidx) && fb->type == at(st.o_type),
                "a staged batch's feature arrays must be the pointers svoh_matcher_stage handed out");
+  if (st.resident)
+    SVOH_REQUIRE(ctx, fb->feature_index == at(st.o_fidx) && !fb->px && !fb->f && !fb->grad && !fb->level,
+                 "a batch staged with SVOH_STAGE_RESIDENT_COLUMNS names its features by feature_index (the staged pointer); px / f / grad / level are NULL");
+  else
+    SVOH_REQUIRE(ctx, !fb->feature_index && fb->px == at(st.o_px) && fb->f == at(st.o_f) && fb->grad == at(st.o_grad) && fb->level == at(st.o_level),
+                 "a staged batch's feature arrays must be the pointers svoh_matcher_stage handed out");
   if (seeds) {
     SVOH_REQUIRE(ctx, dopt && state == at(st.o_state) && success == at(st.o_success), "a staged seed batch's state / success must be the staged pointers");
     SVOH_REQUIRE(ctx, !result || result == at(st.o_result), "result: not the staged pointer");
@@ -3419,11 +3442,16 @@ static int run_matcher_staged(svoh_ctx* ctx, bool seeds, const svoh_matcher_opti
     if (rc != SVOH_OK) return rc;
     ref_levels = views[k].n_levels > ref_levels ? views[k].n_levels : ref_levels;
     max_w = views[k].lv[0].w > max_w ? views[k].lv[0].w : max_w; max_h = views[k].lv[0].h > max_h ? views[k].lv[0].h : max_h;
+    SVOH_REQUIRE(ctx, !st.resident || ref_frames[k].features != 0, "a reference frame of a batch with feature_index has no resident columns (svoh_frame_view::features)");
   }
+  bool pose_from_results = false;
   for (int k = 0; k < n_cur; ++k) {
-    const int rc = fill_view(ctx, cur_frame[k], &views[n_ref_frames + k], "current frame");
+    const int rc = fill_view(ctx, cur_frame[k], &views[n_ref_frames + k], "current frame", seeds && ctx->in_pose_hook);
     if (rc != SVOH_OK) return rc;
     SVOH_REQUIRE(ctx, views[n_ref_frames + k].n_levels >= ref_levels, "current frame has fewer pyramid levels than a reference frame");
+    const int pr = views[n_ref_frames + k].pose_result_index_plus1;
+    SVOH_REQUIRE(ctx, pr >= 0 && pr <= ctx->n_pose_results, "pose_result_index_plus1: the pose batch in flight has no such result");
+    pose_from_results = pose_from_results || pr > 0;
   }
   ctx->matcher_deferred_used[kind] = true;
   st.valid = false;   // consumed: the outputs stay readable, a second batch needs a new svoh_matcher_stage
@@ -3464,6 +3492,8 @@ static int run_matcher_staged(svoh_ctx* ctx, bool seeds, const svoh_matcher_opti
   dl.d2h_dst = h + st.back_from; dl.d2h_src = d + st.back_from; dl.d2h_bytes = st.o_nsucc - st.back_from;
   dl.views_h = h + st.o_views; dl.views_d = d + st.o_views; dl.n_ref = n_ref_frames; dl.n_cur = n_cur;
   dl.cur_frame_handle = cur_frame[0].frame;
+  dl.pose_from_results = pose_from_results; dl.d_pose_results = pose_from_results ? ctx->d_pose_results : nullptr; dl.n_pose_results = ctx->n_pose_results;
+  dl.d_fidx = st.resident ? d + st.o_fidx : nullptr;
   if (seeds && n_success) ctx->matcher_pending_counts.push_back({ n_success, h + st.o_success, n });
   return SVOH_OK;
 }
@@ -3642,7 +3672,7 @@ try {
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
-int svoh_matcher_stage(svoh_ctx* ctx, int seeds, int n, int max_frame_views, int want_match_outputs, svoh_matcher_stage_t* out)
+int svoh_matcher_stage(svoh_ctx* ctx, int seeds, int n, int max_frame_views, int flags, svoh_matcher_stage_t* out)
 try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, out && n >= 1 && n <= (1 << 24) && max_frame_views >= 2 && max_frame_views <= (1 << 16), "bad arguments");
@@ -3651,7 +3681,8 @@ try {
   SVOH_REQUIRE(ctx, !ctx->matcher_deferred_used[kind], "one batch of each kind per deferred section: collect first");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   svoh_ctx::MatcherStage& st = ctx->matcher_stage[kind];
-  layout_matcher_stage(seeds != 0, n, max_frame_views, want_match_outputs != 0, &st);
+  SVOH_REQUIRE(ctx, (flags & ~(SVOH_STAGE_MATCH_OUTPUTS | SVOH_STAGE_RESIDENT_COLUMNS)) == 0, "unknown flag");
+  layout_matcher_stage(seeds != 0, n, max_frame_views, (flags & SVOH_STAGE_MATCH_OUTPUTS) != 0, (flags & SVOH_STAGE_RESIDENT_COLUMNS) != 0, &st);
   PinnedBuffer& hbuf = seeds ? ctx->h_match_seeds : ctx->h_match_direct;
   DevBuffer& dbuf = seeds ? ctx->d_match_seeds : ctx->d_match_direct;
   SVOH_HIP_TRY(ctx, hbuf.reserve(st.total));
@@ -3659,8 +3690,12 @@ try {
   uint8_t* h = static_cast<uint8_t*>(hbuf.ptr);
   memset(out, 0, sizeof *out);
   out->ref_frame_idx = reinterpret_cast<int32_t*>(h + st.o_idx); out->cur_frame_idx = reinterpret_cast<int32_t*>(h + st.o_cidx);
-  out->px = reinterpret_cast<double*>(h + st.o_px); out->f = reinterpret_cast<double*>(h + st.o_f); out->grad = reinterpret_cast<double*>(h + st.o_grad);
-  out->level = reinterpret_cast<int32_t*>(h + st.o_level); out->type = h + st.o_type;
+  if (st.resident) out->feature_index = reinterpret_cast<int32_t*>(h + st.o_fidx);
+  else {
+    out->px = reinterpret_cast<double*>(h + st.o_px); out->f = reinterpret_cast<double*>(h + st.o_f); out->grad = reinterpret_cast<double*>(h + st.o_grad);
+    out->level = reinterpret_cast<int32_t*>(h + st.o_level);
+  }
+  out->type = h + st.o_type;
   out->result = reinterpret_cast<int32_t*>(h + st.o_result); out->success = h + st.o_success;
   if (seeds) out->state = reinterpret_cast<double*>(h + st.o_state);
   else { out->depth = reinterpret_cast<double*>(h + st.o_depth); out->px_cur = reinterpret_cast<double*>(h + st.o_pxcur); }
@@ -3695,6 +3730,48 @@ try {
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
+// What has to happen on the device between the upload of a queued batch and its kernels, for both kinds in one launch:
+//  * svoh_frame_view::pose_result_index_plus1: current view k's T_f_w holds T_cam_imu; its pose is T_cam_imu * T_imu_world of
+//    result k-1 of the pose batch that ran just before on this stream (PoseOptimizerHip::finishRun's product, the same inline function);
+//  * svoh_feature_batch::feature_index: unit i's px / f / grad / level are those of feature feature_index[i] of its reference
+//    frame's resident columns; an index outside the set (or a reference frame outside the table) poisons ref_frame_idx[i], which
+//    the kernels' own range check turns into SVOH_MATCH_NOT_RUN.
+struct PrologueBatch {
+  DevFrameView* views; int n_ref, n_cur;                     // reference views, then the current ones
+  int n; int32_t* ref_idx; const int32_t* fidx;              // fidx == NULL: nothing to gather
+  double* px; double* f; double* grad; int32_t* level;
+  const svoh_pose_result* pose_results; int n_pose_results;  // pose_results == NULL: no view takes its pose from the device
+};
+__global__ void matcher_prologue_kernel(PrologueBatch b0, PrologueBatch b1, int blocks0)
+{
+  const bool second = (int)blockIdx.x >= blocks0;
+  const PrologueBatch& b = second ? b1 : b0;
+  const int i = ((int)blockIdx.x - (second ? blocks0 : 0)) * (int)blockDim.x + (int)threadIdx.x;
+  if (b.fidx && i < b.n) {
+    const int r = b.ref_idx[i], j = b.fidx[i];
+    bool ok = r >= 0 && r < b.n_ref;
+    const DevFrameView* v = ok ? &b.views[r] : nullptr;
+    ok = ok && j >= 0 && j < v->feat_n;
+    if (ok) {
+      b.px[2 * i] = v->feat_px[2 * j]; b.px[2 * i + 1] = v->feat_px[2 * j + 1];
+      b.f[3 * i] = v->feat_f[3 * j]; b.f[3 * i + 1] = v->feat_f[3 * j + 1]; b.f[3 * i + 2] = v->feat_f[3 * j + 2];
+      b.grad[2 * i] = v->feat_grad[2 * j]; b.grad[2 * i + 1] = v->feat_grad[2 * j + 1];
+      b.level[i] = v->feat_level[j];
+    } else {
+      b.px[2 * i] = b.px[2 * i + 1] = 0.0; b.f[3 * i] = b.f[3 * i + 1] = 0.0; b.f[3 * i + 2] = 1.0; b.grad[2 * i] = 1.0; b.grad[2 * i + 1] = 0.0; b.level[i] = 0;
+      b.ref_idx[i] = -1;
+    }
+  }
+  if (b.pose_results && i < b.n_cur) {
+    DevFrameView& cv = b.views[b.n_ref + i];
+    const int r = cv.pose_result_index_plus1 - 1;
+    if (r >= 0 && r < b.n_pose_results) {
+      cv.T_f_w = mul(cv.T_f_w, load_rigid(b.pose_results[r].T_imu_world));
+      cv.pose_result_index_plus1 = 0;
+    }
+  }
+}
+
 // the kernels of the batches queued in the open deferred section go out now (one kernel when both kinds share a
 // geometry), followed by the copies of their results to the pinned blocks; nothing is waited for
 static int launch_deferred(svoh_ctx* ctx)
@@ -3718,6 +3795,26 @@ static int launch_deferred(svoh_ctx* ctx)
       if (rc != SVOH_OK) return rc;
       a0.unit_counts = uc; a1.unit_counts = uc + 4 * n0;
       auto blocks = [](const svoh_ctx::DeferredLaunch& d) { const int u = d.g8 ? 8 : 64; return (unsigned)((d.n + u - 1) / u); };   // per-unit geometries 0 / 1
+      // poses composed on the device and features named by index: one small launch ahead of the kernels that read them
+      {
+        auto prologue_of = [](const svoh_ctx::DeferredLaunch& d, const MatcherArgs& a, bool valid) {
+          PrologueBatch b;
+          memset(&b, 0, sizeof b);
+          if (!valid || (!d.d_fidx && !d.pose_from_results)) return b;
+          b.views = static_cast<DevFrameView*>(d.views_d); b.n_ref = d.n_ref; b.n_cur = d.n_cur;
+          if (d.d_fidx) {
+            b.n = d.n; b.ref_idx = const_cast<int32_t*>(a.ref_frame_idx); b.fidx = static_cast<const int32_t*>(d.d_fidx);
+            b.px = const_cast<double*>(a.px); b.f = const_cast<double*>(a.f); b.grad = const_cast<double*>(a.grad); b.level = const_cast<int32_t*>(a.level);
+          }
+          if (d.pose_from_results) { b.pose_results = static_cast<const svoh_pose_result*>(d.d_pose_results); b.n_pose_results = d.n_pose_results; }
+          return b;
+        };
+        const PrologueBatch b0 = prologue_of(d0, a0, v0), b1 = prologue_of(d1, a1, v1);
+        auto blocks_of = [](const PrologueBatch& b) { const int m = std::max(b.fidx ? b.n : 0, b.pose_results ? b.n_cur : 0); return (m + 255) / 256; };
+        const int nb0 = blocks_of(b0), nb1 = blocks_of(b1);
+        if (nb0 + nb1 > 0) hipLaunchKernelGGL(matcher_prologue_kernel, dim3((unsigned)(nb0 + nb1)), dim3(256), 0, ctx->stream, b0, b1, nb0);
+        d0.pose_from_results = d1.pose_from_results = false; d0.d_fidx = d1.d_fidx = nullptr;
+      }
       if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, ctx->stream));
       if (v0 && v1 && d0.g8 == d1.g8 && d0.g8 != 2) {
         const unsigned b0 = blocks(d0), b1 = blocks(d1);

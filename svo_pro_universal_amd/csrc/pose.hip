@@ -716,7 +716,10 @@ static int run_pose_batch(svoh_ctx* ctx, const svoh_pose_options* options, int n
     // the hook must not enter a blocking call of the context, and the depth filter's staging has blocks of its own
     if (!ctx->ev_pose_done) SVOH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDisableTiming));
     SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_pose_done, ctx->stream));
+    // (what the hook queues may read this batch's results in place: svoh_frame_view::pose_result_index_plus1)
+    ctx->in_pose_hook = true; ctx->d_pose_results = d + o_res; ctx->n_pose_results = n_problems;
     after_launch(user);
+    ctx->in_pose_hook = false; ctx->d_pose_results = nullptr; ctx->n_pose_results = 0;
     SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_pose_done));
   } else {
     SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -57,6 +57,47 @@ struct SlabPool {
   ~SlabPool() { for (const Entry& e : free_list) (void)hipFree(e.ptr); }
 };
 
+// Released blocks of resident feature columns (svoh_features_upload), for the next upload: any block at least as large as
+// asked and at most twice that.  Same reason as SlabPool: hipFree waits for the whole device.
+struct BlockPool {
+  struct Entry { void* ptr; size_t alloc; };
+  static constexpr size_t kMaxEntries = 256;
+  static constexpr size_t kMaxBytes = (size_t)256 << 20;
+  std::vector<Entry> free_list;
+  size_t held = 0;
+  void* take(size_t want, size_t* got)
+  {
+    size_t best = free_list.size();
+    for (size_t i = 0; i < free_list.size(); ++i)
+      if (free_list[i].alloc >= want && free_list[i].alloc <= 2 * want && (best == free_list.size() || free_list[i].alloc < free_list[best].alloc)) best = i;
+    if (best == free_list.size()) return nullptr;
+    void* p = free_list[best].ptr;
+    *got = free_list[best].alloc;
+    held -= *got;
+    free_list.erase(free_list.begin() + (long)best);
+    return p;
+  }
+  bool give(void* p, size_t alloc)
+  {
+    if (free_list.size() >= kMaxEntries || held + alloc > kMaxBytes) return false;
+    free_list.push_back({ p, alloc });
+    held += alloc;
+    return true;
+  }
+  ~BlockPool() { for (const Entry& e : free_list) (void)hipFree(e.ptr); }
+};
+struct FeatureBlock {   // one upload call's device memory, shared by its sets
+  void* ptr = nullptr;
+  size_t alloc = 0;
+  std::shared_ptr<BlockPool> pool;
+  ~FeatureBlock() { if (ptr && !(pool && pool->give(ptr, alloc))) (void)hipFree(ptr); }
+};
+struct FeatureSet {
+  std::shared_ptr<FeatureBlock> block;
+  int n = 0;
+  const double* px = nullptr; const double* f = nullptr; const double* grad = nullptr; const int32_t* level = nullptr;   // device
+};
+
 // device allocation shared by the frames carved out of it
 struct Slab {
   void* ptr = nullptr;
@@ -144,6 +185,12 @@ struct svoh_ctx {
   std::shared_ptr<svoh::SlabPool> slab_pool = std::make_shared<svoh::SlabPool>();   // declared before `frames`: outlives them
   std::unordered_map<uint64_t, svoh::Frame> frames;
   uint64_t next_frame_id = 1;
+  // resident feature columns (svoh_features_upload)
+  std::shared_ptr<svoh::BlockPool> feature_pool = std::make_shared<svoh::BlockPool>();   // declared before the sets: outlives them
+  std::unordered_map<uint64_t, svoh::FeatureSet> feature_sets;
+  uint64_t next_features_id = 1;
+  svoh::PinnedBuffer h_features;        // the upload's staging block ...
+  hipEvent_t ev_features = nullptr;     // ... and what says its last copy has run (made at first use)
 
   // sparse-align workspaces
   svoh::DevBuffer d_desc;      // problem + camera descriptors
@@ -180,6 +227,8 @@ struct svoh_ctx {
   unsigned align_desc_slot = 0;
   bool align_no_cluster = false;   // svoh_sparse_align_batch repeating a launch whose cluster gave up
   hipEvent_t ev_misc_start = nullptr, ev_misc_stop = nullptr;  // KLT / matcher / seeds
+  // inside the hook of svoh_optimize_pose_batch_hook: where the launched batch's results will be on the device
+  bool in_pose_hook = false; const void* d_pose_results = nullptr; int n_pose_results = 0;
   hipEvent_t ev_pose_done = nullptr;   // svoh_optimize_pose_batch_hook: behind the copy of the results (made at first use)
   // svoh_build_pyramid_multi_prefetch: the next frames' images come up on a stream of their own, beside the chain's work
   hipStream_t upload_stream = nullptr;
@@ -214,6 +263,10 @@ struct svoh_ctx {
     // the frame views of the batch in its staging blocks (svoh_matcher_deferred_set_cur_frame): n_ref reference frames, then the current one(s)
     void* views_h = nullptr; void* views_d = nullptr; int n_ref = 0, n_cur = 0;
     uint64_t cur_frame_handle = 0;
+    // current views whose pose is composed on the device from the pose batch in flight (svoh_frame_view::pose_result_index_plus1)
+    const void* d_pose_results = nullptr; int n_pose_results = 0; bool pose_from_results = false;
+    // features named by index (svoh_feature_batch::feature_index): gathered from the reference frames' resident columns ahead of the kernels
+    const void* d_fidx = nullptr;
   } matcher_deferred_launch[2];
   // staging of the deferred batches, one pair per kind: nothing else stages through them, so any other call made
   // inside the section (a device-resident batch, an epipolar batch, the detector -- all on d_scratch1 / h_scratch1)
@@ -222,8 +275,9 @@ struct svoh_ctx {
   svoh::PinnedBuffer h_match_seeds, h_match_direct;
   // svoh_matcher_stage: the layout of the block handed out for the section's direct [0] / seed [1] batch
   struct MatcherStage {
-    bool valid = false, want_outputs = false;
+    bool valid = false, want_outputs = false, resident = false;
     int n = 0, max_views = 0;
+    size_t o_fidx = 0;
     size_t o_views = 0, o_idx = 0, o_cidx = 0, o_px = 0, o_f = 0, o_grad = 0, o_level = 0, o_type = 0, o_depth = 0, o_pxcur = 0, o_state = 0,
            o_result = 0, o_success = 0, o_fcur = 0, o_slevel = 0, o_hinv = 0, o_A = 0, o_nsucc = 0, in_total = 0, back_from = 0, total = 0;
   } matcher_stage[2];

@@ -259,6 +259,7 @@ svoh_frame_view viewOf(const Frame& f)
   svoh::store_rigid(f.T_f_w_, v.T_f_w);
   v.seed_mu_range = f.seed_mu_range_;
   v.id = f.id();
+  v.features = f.features;
   return v;
 }
 }  // namespace detail
@@ -1307,10 +1308,13 @@ void ReprojectorHip::walkCandidates(const FramePtr& cur_frame, const std::vector
   if (have_proj) { proj_frame_ = nullptr; proj_collected_ = false; }
 }
 
-void ReprojectorHip::planMatches(const FramePtr& cur_frame, int n_speculated)
+void ReprojectorHip::planMatches(const FramePtr& cur_frame, int n_speculated, bool resident_features)
 {
   if (!sm_) sm_.reset(new detail::SpeculativeMatches);   // keeps its buffers from frame to frame
   sm_->clear();
+  // resident_features: every unit names its feature by index into its reference frame's device columns (Frame::features); for
+  // drivers that stage the batches themselves (FrontendLockstep) -- enqueue() below sends explicit columns
+  sm_->setResident(resident_features);
   n_speculated_ = n_speculated < 0 ? 0 : (n_speculated > 3 ? 3 : n_speculated);
   std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged_, &unconverged_ };
   plan_rs_.resize(3);
@@ -1636,6 +1640,7 @@ std::vector<Resolved> SpeculativeMatches::plan(const FramePtr& frame, const std:
       if (lm->getCloseViewObs(cur_pos, rf, ri)) { r.kind = kLandmark; r.ref = rf.get(); r.idx = ri; r.frame_slot = slot_of(rf); }
       else r.kind = kNoCloseView;
     }
+    if (direct.resident && r.ref && !r.ref->features) throw std::runtime_error("matchCandidates: a reference frame without resident feature columns in a batch that names features by index");
     if (r.kind == kConvergedSeed || r.kind == kLandmark) {
       r.batch_pos = static_cast<int>(direct.size());
       direct.push(*r.ref, r.idx, r.frame_slot);
@@ -1658,6 +1663,7 @@ std::vector<Resolved> SpeculativeMatches::plan(const FramePtr& frame, const std:
 void SpeculativeMatches::enqueue(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_offset, bool affine_est_gain, double seed_sigma2_thresh)
 {
   if (!direct.size() && !seeds.size()) return;
+  if (direct.resident) throw std::runtime_error("SpeculativeMatches::enqueue: batches planned with resident_features are staged by their driver");
   const svoh_matcher_options mopt = reprojectorMatcherOptions(affine_est_offset, affine_est_gain);
   thread_local std::vector<svoh_frame_view> views;
   views.clear();

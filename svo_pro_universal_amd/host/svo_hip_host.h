@@ -37,6 +37,7 @@ using Transformation = svoh::Rigid;  // minkindr QuatTransformation semantics (s
 // The members of svo::Frame that SparseImgAlign::run reads (frame.h:46-73, 252-306).
 struct Frame {
   svoh_frame_t pyramid = 0;      // device copy of img_pyr_
+  svoh_features_t features = 0;  // device copy of px_vec_ / f_vec_ / grad_vec_ / level_vec_ of a keyframe whose features are final (svoh_features_upload), or 0
   svoh_camera cam{};             // cam()
   Transformation T_f_w_{ {1, 0, 0, 0}, {0, 0, 0} };
   Transformation T_cam_imu_{ {1, 0, 0, 0}, {0, 0, 0} };
@@ -504,7 +505,7 @@ class ReprojectorHip {
   // (2) grid and statistics reset, the walk over the visible keyframes' features: the three candidate lists
   void walkCandidates(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points);
   // (3) what every candidate of the first n_speculated lists matches against: the stream's direct and seed batch
-  void planMatches(const FramePtr& cur_frame, int n_speculated);
+  void planMatches(const FramePtr& cur_frame, int n_speculated, bool resident_features = false);
   detail::SpeculativeMatches& plannedMatches() { return *sm_; }
   // (4) sortCandidatesByReprojStats of the three lists (while the device works)
   void sortCandidateLists();

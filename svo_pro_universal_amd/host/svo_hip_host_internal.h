@@ -31,6 +31,10 @@ struct Batch {
   std::vector<int32_t> ref_idx, level;
   std::vector<double> px, f, grad, depth, state, px_cur;
   std::vector<uint8_t> type;
+  // resident: a unit names its feature by (ref_idx, fidx) -- the reference frames' columns live on the device
+  // (Frame::features, svoh_features_upload) -- and px / f / grad / level stay empty
+  bool resident = false;
+  std::vector<int32_t> fidx;
   // outputs of a batch that ran on the owner's own context
   std::vector<int32_t> result, search_level;
   std::vector<double> f_cur, A;
@@ -49,21 +53,25 @@ struct Batch {
   }
   void reserve_more(size_t n)
   {
-    const size_t m = level.size() + n;
-    ref_idx.reserve(m); level.reserve(m); type.reserve(m); px.reserve(2 * m); f.reserve(3 * m); grad.reserve(2 * m);
+    const size_t m = size() + n;
+    ref_idx.reserve(m); type.reserve(m);
+    if (resident) fidx.reserve(m);
+    else { level.reserve(m); px.reserve(2 * m); f.reserve(3 * m); grad.reserve(2 * m); }
     depth.reserve(m); px_cur.reserve(2 * m); state.reserve(4 * m);
   }
   void push(const Frame& r, size_t i, int slot)
   {
-    ref_idx.push_back(slot); level.push_back(r.level_vec_[i]); type.push_back(r.type_vec_[i]);
+    ref_idx.push_back(slot); type.push_back(r.type_vec_[i]);
+    if (resident) { fidx.push_back(static_cast<int32_t>(i)); return; }
+    level.push_back(r.level_vec_[i]);
     const double* p = &r.px_vec_[2 * i]; px.push_back(p[0]); px.push_back(p[1]);
     const double* q = &r.f_vec_[3 * i]; f.push_back(q[0]); f.push_back(q[1]); f.push_back(q[2]);
     const double* g = &r.grad_vec_[2 * i]; grad.push_back(g[0]); grad.push_back(g[1]);
   }
-  size_t size() const { return level.size(); }
+  size_t size() const { return type.size(); }
   void clear()
   {
-    ref_idx.clear(); level.clear(); result.clear(); search_level.clear(); px.clear(); f.clear(); grad.clear(); depth.clear();
+    ref_idx.clear(); level.clear(); fidx.clear(); result.clear(); search_level.clear(); px.clear(); f.clear(); grad.clear(); depth.clear();
     state.clear(); px_cur.clear(); f_cur.clear(); A.clear(); type.clear(); success.clear();
     out = Out();
   }
@@ -75,6 +83,7 @@ struct SpeculativeMatches {
   int last_slot = -1;
   bool in_flight = false;
   void clear() { frames.clear(); direct.clear(); seeds.clear(); last_slot = -1; }
+  void setResident(bool on) { direct.resident = seeds.resident = on; }
   int slot_of(const FramePtr& f);
   // what each candidate of one list matches against
   std::vector<Resolved> plan(const FramePtr& frame, const std::vector<reprojector::Candidate>& candidates);

@@ -29,7 +29,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 namespace {
 enum Phase { kPhPyramid = 0, kPhFinishSeeds, kPhAlignPrep, kPhAlignLaunch, kPhProjGather, kPhAlignWait, kPhWalkPlan, kPhMatchStage, kPhMatchCopy, kPhMatchSubmit, kPhSort,
-             kPhMatchWait, kPhReplay, kPhPoseCall, kPhPoseApply, kPhSeedStage, kPhSeedGather, kPhSeedSubmit, kPhKeyframe, kPhRest };
+             kPhMatchWait, kPhReplay, kPhPoseCall, kPhPoseApply, kPhSeedStage, kPhSeedGather, kPhSeedSubmit, kPhKeyframe, kPhSeedWait, kPhDetectWait, kPhPrefetch, kPhRest };
 struct PhaseClock {
   double* acc; double t;
   explicit PhaseClock(double* a) : acc(a), t(now_ms()) {}
@@ -40,7 +40,7 @@ struct PhaseClock {
 const char* FrontendLockstep::phaseName(int k)
 {
   static const char* names[] = { "pyramid", "finish seeds", "align prep", "align launch", "projection gather", "align wait", "walk + plan", "match stage", "match copy",
-                                 "match submit", "sort", "match wait", "replay + pose prep", "pose call", "pose apply", "seed stage", "seed gather", "seed submit", "keyframe", "rest" };
+                                 "match submit", "sort", "match wait", "replay + pose prep", "pose call", "pose apply", "seed stage", "seed gather", "seed submit", "keyframe", "seed wait", "detect wait", "prefetch", "rest" };
   return k >= 0 && k < (int)(sizeof names / sizeof names[0]) ? names[k] : "";
 }
 
@@ -99,6 +99,9 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
   // SVOH_LOCKSTEP_COPY_POLICY=2: every staged block through a copy kernel (svoh_set_copy_policy).  Measured with four groups
   // on one device and NOT the default: 23.7 / 24.3 k frames/s against 25.6 / 23.3 k with the library's own policy
   // (profiles/r05_copy_policy_ab.txt) -- the mixed-dispatch ceiling of tools/svoh_dispatch_rate is not what the groups run into.
+  if (getenv("SVOH_LOCKSTEP_RESIDENT")) opt_.resident_features = atoi(getenv("SVOH_LOCKSTEP_RESIDENT")) != 0;   // (A/B)
+  // SVOH_LOCKSTEP_POSE_CHAIN=0: the depth filter's batch is queued after the host has seen the poses, as in the first version
+  pose_chain_ = getenv("SVOH_LOCKSTEP_POSE_CHAIN") == nullptr || atoi(getenv("SVOH_LOCKSTEP_POSE_CHAIN")) != 0;
   if (getenv("SVOH_LOCKSTEP_COPY_POLICY")) check(svoh_set_copy_policy(ctx_, atoi(getenv("SVOH_LOCKSTEP_COPY_POLICY"))), "svoh_set_copy_policy");
   opt_.params.depth_filter.use_threaded_depthfilter = false;   // the synchronous path
   ReprojectorOptions ropt;
@@ -125,8 +128,10 @@ FrontendLockstep::~FrontendLockstep()
 void FrontendLockstep::drainReleases()
 {
   std::vector<svoh_frame_t> r;
-  { std::lock_guard<std::mutex> lock(release_mu_); r.swap(to_release_); }
+  std::vector<svoh_features_t> fr;
+  { std::lock_guard<std::mutex> lock(release_mu_); r.swap(to_release_); fr.swap(features_to_release_); }
   for (svoh_frame_t h : r) (void)svoh_release_frame(ctx_, h);
+  for (svoh_features_t h : fr) (void)svoh_features_release(ctx_, h);
 }
 
 const Transformation& FrontendLockstep::pose(int s) const
@@ -157,7 +162,9 @@ void FrontendLockstep::finishSeedUpdate()
 {
   if (seeds_in_flight_) {
     seeds_in_flight_ = false;
+    const double tw = now_ms();
     check(svoh_matcher_collect(ctx_), "svoh_matcher_collect");
+    phase_ms_[kPhSeedWait] += now_ms() - tw;   // (part of "finish seeds")
     ++device_calls_;
     const svoh_matcher_stage_t& ss = seed_stage_;
     pool_.run(numStreams(), [&](int s) {
@@ -216,7 +223,9 @@ void FrontendLockstep::makeKeyframes(const std::vector<int>& which)
     }
     ckeys.resize(n * n_cells); ekeys.resize(n * n_cells); angles.resize(n * n_cells);
     const svoh_detector_options dopt = streams_[0]->detector.abiOptions();
+    const double tw = now_ms();
     check(svoh_detect_cells_batch(ctx_, static_cast<int>(n), frames.data(), &dopt, occ.data(), ckeys.data(), ekeys.data(), angles.data()), "svoh_detect_cells_batch");
+    phase_ms_[kPhDetectWait] += now_ms() - tw;   // (part of "keyframe")
     ++device_calls_;
   }
   pool_.run(static_cast<int>(which.size()), [&](int w) {
@@ -243,6 +252,22 @@ void FrontendLockstep::makeKeyframes(const std::vector<int>& which)
       st.kfs.pop_front();
     }
   });
+  // the new keyframes' features are final now: their constant columns go to the device once, in one call
+  if (opt_.resident_features) {
+    const size_t m = which.size();
+    std::vector<int32_t> n(m);
+    std::vector<const double*> px(m), f(m), grad(m);
+    std::vector<const int32_t*> level(m);
+    std::vector<svoh_features_t> handles(m, 0);
+    for (size_t w = 0; w < m; ++w) {
+      const Frame& fr = *streams_[static_cast<size_t>(which[w])]->frame;
+      n[w] = static_cast<int32_t>(fr.num_features_);
+      px[w] = fr.px_vec_.data(); f[w] = fr.f_vec_.data(); grad[w] = fr.grad_vec_.data(); level[w] = fr.level_vec_.data();
+    }
+    check(svoh_features_upload(ctx_, static_cast<int>(m), n.data(), px.data(), f.data(), grad.data(), level.data(), handles.data()), "svoh_features_upload");
+    ++device_calls_;
+    for (size_t w = 0; w < m; ++w) streams_[static_cast<size_t>(which[w])]->frame->features = handles[w];
+  }
 }
 
 void FrontendLockstep::prefetch(const uint8_t* const* next_images, int pitch)
@@ -264,6 +289,21 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   times_ = RoundTimes();
   const double t0 = now_ms();
   PhaseClock pc(phase_ms_);
+  // SVOH_LOCKSTEP_TRACE=<file>: one line per round with what each phase took (appended; several engines share the file)
+  static const char* trace_path = getenv("SVOH_LOCKSTEP_TRACE");
+  double phase_at_start[kNumPhases];
+  if (trace_path) std::copy(phase_ms_, phase_ms_ + kNumPhases, phase_at_start);
+  struct TraceLine {
+    FrontendLockstep* e; const double* start; double t0;
+    ~TraceLine()
+    {
+      if (!trace_path) return;
+      std::string line = "engine " + std::to_string(reinterpret_cast<uintptr_t>(e) & 0xffff) + " round " + std::to_string(e->round_) + " total " + std::to_string(now_ms() - t0);
+      for (int k = 0; k < kNumPhases && phaseName(k)[0]; ++k) { char b[64]; snprintf(b, sizeof b, " | %s %.3f", phaseName(k), e->phase_ms_[k] - start[k]); line += b; }
+      line += "\n";
+      if (FILE* f = fopen(trace_path, "a")) { fputs(line.c_str(), f); fclose(f); }
+    }
+  } trace_line{ this, phase_at_start, t0 };
   drainReleases();
 
   // ---- pyramids of the round's S images: one call
@@ -283,7 +323,11 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     for (int s = 0; s < S; ++s) {
       Stream& st = *streams_[static_cast<size_t>(s)];
       FramePtr frame(new Frame, [this](Frame* f) {
-        if (f->pyramid) { std::lock_guard<std::mutex> lock(release_mu_); to_release_.push_back(f->pyramid); }
+        if (f->pyramid || f->features) {
+          std::lock_guard<std::mutex> lock(release_mu_);
+          if (f->pyramid) to_release_.push_back(f->pyramid);
+          if (f->features) features_to_release_.push_back(f->features);
+        }
         delete f;
       });
       frame->pyramid = handles[static_cast<size_t>(s)];
@@ -414,7 +458,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     st.reprojector.walkCandidates(st.frame, st.visible, st.trash);
     // (every list is planned: a pass that is not reached wastes its units, never shows -- and a pass nobody planned
     // would need a round trip of its own)
-    st.reprojector.planMatches(st.frame, 3);
+    st.reprojector.planMatches(st.frame, 3, opt_.resident_features);
   });
   pc.lap(kPhWalkPlan);
   svoh_matcher_stage_t ds{}, ss{};
@@ -431,8 +475,9 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     const int max_views = static_cast<int>(n_refs) + S + 1;
     check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
     struct CloseSection { svoh_ctx* c; bool armed; ~CloseSection() { if (armed) (void)svoh_matcher_collect(c); } } close_section{ ctx_, true };
-    if (n_direct) check(svoh_matcher_stage(ctx_, 0, static_cast<int>(n_direct), max_views, 1, &ds), "svoh_matcher_stage");
-    if (n_seeds) check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_seeds), max_views, 1, &ss), "svoh_matcher_stage");
+    const int stage_flags = SVOH_STAGE_MATCH_OUTPUTS | (opt_.resident_features ? SVOH_STAGE_RESIDENT_COLUMNS : 0);
+    if (n_direct) check(svoh_matcher_stage(ctx_, 0, static_cast<int>(n_direct), max_views, stage_flags, &ds), "svoh_matcher_stage");
+    if (n_seeds) check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_seeds), max_views, stage_flags, &ss), "svoh_matcher_stage");
     std::vector<svoh_frame_view> refs(n_refs ? n_refs : 1), curs(static_cast<size_t>(S));
     pc.lap(kPhMatchStage);
     pool_.run(S, [&](int s) {
@@ -444,8 +489,12 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
         const size_t m = b.size();
         if (!m) return;
         for (size_t i = 0; i < m; ++i) { g.ref_frame_idx[o + i] = b.ref_idx[i] + static_cast<int32_t>(st.ref_off); g.cur_frame_idx[o + i] = s; }
-        memcpy(g.px + 2 * o, b.px.data(), 16 * m); memcpy(g.f + 3 * o, b.f.data(), 24 * m); memcpy(g.grad + 2 * o, b.grad.data(), 16 * m);
-        memcpy(g.level + o, b.level.data(), 4 * m); memcpy(g.type + o, b.type.data(), m);
+        if (b.resident) memcpy(g.feature_index + o, b.fidx.data(), 4 * m);
+        else {
+          memcpy(g.px + 2 * o, b.px.data(), 16 * m); memcpy(g.f + 3 * o, b.f.data(), 24 * m); memcpy(g.grad + 2 * o, b.grad.data(), 16 * m);
+          memcpy(g.level + o, b.level.data(), 4 * m);
+        }
+        memcpy(g.type + o, b.type.data(), m);
       };
       copy_batch(sm.direct, ds, st.direct_off);
       if (const size_t m = sm.direct.size()) { memcpy(ds.depth + st.direct_off, sm.direct.depth.data(), 8 * m); memcpy(ds.px_cur + 2 * st.direct_off, sm.direct.px_cur.data(), 16 * m); }
@@ -457,7 +506,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       svoh_feature_batch fb{};
       fb.n = static_cast<int32_t>(n);
       fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = S;
-      fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type;
+      fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type; fb.feature_index = g.feature_index;
       fb.mem_space = SVOH_MEM_STAGED;
       return fb;
     };
@@ -487,7 +536,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     pool_.run(S, [&](int s) { streams_[static_cast<size_t>(s)]->reprojector.sortCandidateLists(); });
   }
   // the context's stream is idle here: the next round's images start their way up now, beside the rest of this round
-  prefetch(next_images, pitch);
+  { const double tw = now_ms(); prefetch(next_images, pitch); phase_ms_[kPhPrefetch] += now_ms() - tw; }   // (part of "replay + pose prep")
   // the reference's three passes per stream on its slices of the finished batches, then the stream's pose problem
   pool_.run(S, [&](int s) {
     Stream& st = *streams_[static_cast<size_t>(s)];
@@ -513,7 +562,11 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   const double t3 = now_ms();
   times_.reproject = t3 - t2;
 
-  // ---- 3. the bundles of all streams in one launch
+  // ---- 3 + 4. pose optimisation (frame_handler_base.cpp:746-790) and depth filter (frame_handler_mono.cpp:125): the bundles of all
+  // streams in one launch, and BEHIND it on the device the seeds of every stream's keyframes into its new frame as ONE batch.  The
+  // seed batch is staged before the pose call and sent off from its hook: every current frame takes its pose from the pose
+  // kernel's result on the device (svoh_frame_view::pose_result_index_plus1), so the update runs while the host is still waiting
+  // for -- and then applying -- the poses, and it is finished at the start of the next round, before anything reads the seeds again.
   {
     std::vector<svoh_pose_problem> pbs;
     std::vector<int> who;
@@ -522,24 +575,6 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       st.pose_slot = -1;
       if (st.do_pose) { st.pose_slot = static_cast<int>(pbs.size()); pbs.push_back(st.pose_pb); who.push_back(s); }
     }
-    if (!pbs.empty()) {
-      std::vector<svoh_pose_result> res(pbs.size());
-      check(svoh_optimize_pose_batch(ctx_, &streams_[static_cast<size_t>(who[0])]->pose_opt, static_cast<int>(pbs.size()), pbs.data(), res.data()), "svoh_optimize_pose_batch");
-      ++device_calls_;
-      pc.lap(kPhPoseCall);
-      pool_.run(static_cast<int>(who.size()), [&](int w) {
-        Stream& st = *streams_[static_cast<size_t>(who[static_cast<size_t>(w)])];
-        st.row.n_pose = st.pose_optimizer.finishRun(st.b_cur, res[static_cast<size_t>(w)]);
-      });
-      pc.lap(kPhPoseApply);
-    }
-  }
-  const double t4 = now_ms();
-  times_.pose = t4 - t3;
-
-  // ---- 4. depth filter (frame_handler_mono.cpp:125): the seeds of every stream's keyframes into its new frame, ONE batch,
-  // sent off without a wait and finished at the start of the next round, before anything reads the seeds again
-  {
     size_t n_total = 0, n_ref_total = 0;
     for (auto& stp : streams_) {
       Stream& st = *stp;
@@ -551,48 +586,94 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       n_total += n; n_ref_total += st.seed_frames.size();
       if (n == 0) { st.seed_frames.clear(); st.seed_counts.clear(); }
     }
-    if (n_total) {
-      DepthFilterHip df(ctx_, opt_.params.depth_filter);   // (options only: the batch is the driver's)
-      const svoh_depth_filter_options o = df.abiOptions(*streams_[0]->frame);
-      const svoh_matcher_options mopt = df.getMatcherOptions();
+    // (the order of round 4 -- pose, wait, then the seed batch with the poses the host has applied -- is kept for comparison)
+    const bool chain = pose_chain_ && !pbs.empty() && n_total > 0;
+    DepthFilterHip df(ctx_, opt_.params.depth_filter);   // (options only: the batch is the driver's)
+    const svoh_depth_filter_options dfo = df.abiOptions(*streams_[0]->frame);
+    const svoh_matcher_options df_mopt = df.getMatcherOptions();
+    std::vector<svoh_frame_view> refs(n_ref_total ? n_ref_total : 1), curs(static_cast<size_t>(S));
+    struct CloseSection { svoh_ctx* c; bool armed; ~CloseSection() { if (armed) (void)svoh_matcher_collect(c); } } close_section{ ctx_, false };
+    auto stage_seeds = [&](bool poses_from_device) {
       check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
-      struct CloseSection { svoh_ctx* c; bool armed; ~CloseSection() { if (armed) (void)svoh_matcher_collect(c); } } close_section{ ctx_, true };
-      check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_total), static_cast<int>(n_ref_total) + S + 1, 0, &seed_stage_), "svoh_matcher_stage");
+      close_section.armed = true;
+      check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_total), static_cast<int>(n_ref_total) + S + 1, opt_.resident_features ? SVOH_STAGE_RESIDENT_COLUMNS : 0, &seed_stage_),
+            "svoh_matcher_stage");
       const svoh_matcher_stage_t& g = seed_stage_;
-      std::vector<svoh_frame_view> refs(n_ref_total ? n_ref_total : 1), curs(static_cast<size_t>(S));
       pc.lap(kPhSeedStage);
       pool_.run(S, [&](int s) {
         Stream& st = *streams_[static_cast<size_t>(s)];
-        curs[static_cast<size_t>(s)] = detail::viewOf(*st.frame);
+        svoh_frame_view& cv = curs[static_cast<size_t>(s)];
+        cv = detail::viewOf(*st.frame);
+        if (poses_from_device && st.pose_slot >= 0) {   // T_f_w := T_cam_imu * (result pose_slot of the batch in flight), on the device
+          svoh::store_rigid(st.frame->T_cam_imu(), cv.T_f_w);
+          cv.pose_result_index_plus1 = st.pose_slot + 1;
+        }
         size_t off = st.seed_off;
         for (size_t k = 0; k < st.seed_frames.size(); ++k) {
           const Frame& r = *st.seed_frames[k];
           refs[st.ref_off + k] = detail::viewOf(r);
           const size_t n = st.seed_counts[k];
           for (size_t i = 0; i < n; ++i) { g.ref_frame_idx[off + i] = static_cast<int32_t>(st.ref_off + k); g.cur_frame_idx[off + i] = s; }
-          memcpy(g.px + 2 * off, r.px_vec_.data(), 16 * n); memcpy(g.f + 3 * off, r.f_vec_.data(), 24 * n); memcpy(g.grad + 2 * off, r.grad_vec_.data(), 16 * n);
-          memcpy(g.level + off, r.level_vec_.data(), 4 * n); memcpy(g.type + off, r.type_vec_.data(), n);
+          if (g.feature_index) for (size_t i = 0; i < n; ++i) g.feature_index[off + i] = static_cast<int32_t>(i);
+          else {
+            memcpy(g.px + 2 * off, r.px_vec_.data(), 16 * n); memcpy(g.f + 3 * off, r.f_vec_.data(), 24 * n); memcpy(g.grad + 2 * off, r.grad_vec_.data(), 16 * n);
+            memcpy(g.level + off, r.level_vec_.data(), 4 * n);
+          }
+          memcpy(g.type + off, r.type_vec_.data(), n);
           memcpy(g.state + 4 * off, r.invmu_sigma2_a_b_vec_.data(), 32 * n);
           off += n;
         }
       });
       pc.lap(kPhSeedGather);
+    };
+    auto submit_seeds = [&]() {
+      const svoh_matcher_stage_t& g = seed_stage_;
       svoh_feature_batch fb{};
       fb.n = static_cast<int32_t>(n_total);
       fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = S;
-      fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type;
+      fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type; fb.feature_index = g.feature_index;
       fb.mem_space = SVOH_MEM_STAGED;
-      check(svoh_update_seeds_batch(ctx_, &mopt, &o, static_cast<int>(n_ref_total), refs.data(), curs.data(), &fb, g.state, g.success, g.result, nullptr),
+      check(svoh_update_seeds_batch(ctx_, &df_mopt, &dfo, static_cast<int>(n_ref_total), refs.data(), curs.data(), &fb, g.state, g.success, g.result, nullptr),
             "svoh_update_seeds_batch");
       check(svoh_matcher_flush(ctx_), "svoh_matcher_flush");
       ++device_calls_;
       close_section.armed = false;
       seeds_in_flight_ = true;
+    };
+    if (chain) stage_seeds(true);
+    const double t3b = now_ms();
+    if (!pbs.empty()) {
+      std::vector<svoh_pose_result> res(pbs.size());
+      if (chain) {
+        // (an exception cannot cross the C boundary: it is carried over it)
+        struct Hook { const std::function<void()>* fn; std::exception_ptr error; };
+        const std::function<void()> fn = submit_seeds;
+        Hook hook{ &fn, nullptr };
+        const int rc = svoh_optimize_pose_batch_hook(ctx_, &streams_[static_cast<size_t>(who[0])]->pose_opt, static_cast<int>(pbs.size()), pbs.data(), res.data(),
+                                                     [](void* user) {
+                                                       Hook* h = static_cast<Hook*>(user);
+                                                       try { (*h->fn)(); } catch (...) { h->error = std::current_exception(); }
+                                                     }, &hook);
+        if (hook.error) std::rethrow_exception(hook.error);
+        check(rc, "svoh_optimize_pose_batch_hook");
+      } else {
+        check(svoh_optimize_pose_batch(ctx_, &streams_[static_cast<size_t>(who[0])]->pose_opt, static_cast<int>(pbs.size()), pbs.data(), res.data()), "svoh_optimize_pose_batch");
+      }
+      ++device_calls_;
+      pc.lap(kPhPoseCall);
+      pool_.run(static_cast<int>(who.size()), [&](int w) {
+        Stream& st = *streams_[static_cast<size_t>(who[static_cast<size_t>(w)])];
+        st.row.n_pose = st.pose_optimizer.finishRun(st.b_cur, res[static_cast<size_t>(w)]);
+      });
+      pc.lap(kPhPoseApply);
     }
+    const double t4 = now_ms();
+    times_.pose = t4 - t3b;
+    if (!chain && n_total) { stage_seeds(false); submit_seeds(); }
+    pc.lap(kPhSeedSubmit);
+    times_.seeds = (t3b - t3) + (now_ms() - t4);
   }
-  pc.lap(kPhSeedSubmit);
   const double t5 = now_ms();
-  times_.seeds = t5 - t4;
 
   // ---- 5. keyframe rule, the new keyframes' detector in one call
   {
@@ -777,6 +858,19 @@ int svohl_completed_rows(svohl_engine* e, int stream, int max_rows, int64_t* row
     *n_rows = n;
   });
 }
+
+int svohl_phase_times(svohl_engine* e, int max_phases, double* ms, int* n_phases)
+{
+  return svohl_guard([&] {
+    if (!e || !n_phases || (max_phases > 0 && !ms)) throw std::runtime_error("svohl_phase_times: NULL argument");
+    int n = 0;
+    while (n < svo_hip::FrontendLockstep::kNumPhases && svo_hip::FrontendLockstep::phaseName(n)[0]) ++n;
+    for (int k = 0; k < n && k < max_phases; ++k) ms[k] = e->fe->phaseTimes()[k];
+    *n_phases = n;
+  });
+}
+
+const char* svohl_phase_name(int k) { return svo_hip::FrontendLockstep::phaseName(k); }
 
 int svohl_finish(svohl_engine* e)
 {

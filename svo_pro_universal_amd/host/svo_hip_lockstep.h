@@ -54,6 +54,9 @@ struct LockstepOptions {
   int shared_pool_seed = 0;
   bool pin_workers = false;                                   // bind them to CPUs of their own (WorkerPool)
   int images_mem_space = SVOH_MEM_HOST;                       // SVOH_MEM_HOST_PINNED: images live in svoh_host_alloc memory
+  // a keyframe's constant feature columns are uploaded once (svoh_features_upload); the matcher and depth-filter batches of
+  // the frames after it name features by index instead of carrying 60 bytes per feature over PCIe every frame
+  bool resident_features = true;
 };
 
 class FrontendLockstep {
@@ -110,12 +113,14 @@ class FrontendLockstep {
   std::vector<std::unique_ptr<Stream>> streams_;
   size_t round_ = 0;
   bool seeds_in_flight_ = false;
+  bool pose_chain_ = true;   // the seed update queued behind the pose kernel, its poses taken on the device
   RoundTimes times_;
   int device_calls_ = 0;
   double phase_ms_[kNumPhases] = {};
   // device pyramids to give up: frames die on whatever thread drops their last reference, the context is single-threaded
   std::mutex release_mu_;
   std::vector<svoh_frame_t> to_release_;
+  std::vector<svoh_features_t> features_to_release_;
   // the seed update in flight: where each stream's slice of the staged batch lies
   svoh_matcher_stage_t seed_stage_{};
   // the next round's pyramids, if the caller handed its images in early

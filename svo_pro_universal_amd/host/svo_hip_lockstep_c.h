@@ -44,6 +44,10 @@ int svohl_last_round(svohl_engine* e, double times_ms[7], int* device_calls);
  * n_after_pose_opt, n_seeds_updated, n_converged_seeds); at most max_rows are handed out, *n_rows = how many */
 int svohl_completed_rows(svohl_engine* e, int stream, int max_rows, int64_t* rows, int* n_rows);
 int svohl_finish(svohl_engine* e);
+/* where the rounds' time went since the engine was made: up to max_phases sums (ms) of the group thread's phases, in the
+ * order of svohl_phase_name(0 ..); *n_phases = how many there are */
+int svohl_phase_times(svohl_engine* e, int max_phases, double* ms, int* n_phases);
+const char* svohl_phase_name(int k);
 const char* svohl_last_error(void);
 
 #ifdef __cplusplus

@@ -37,6 +37,9 @@ def load_host():
     lib.svohl_last_round.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int)]
     lib.svohl_completed_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_int64), P(C.c_int)]
     lib.svohl_finish.argtypes = [C.c_void_p]
+    lib.svohl_phase_times.argtypes = [C.c_void_p, C.c_int, P(C.c_double), P(C.c_int)]
+    lib.svohl_phase_name.argtypes = [C.c_int]
+    lib.svohl_phase_name.restype = C.c_char_p
     lib.svohl_last_error.restype = C.c_char_p
     _HOST = lib
     return lib
@@ -138,7 +141,10 @@ class Lockstep(object):
             first = C.cast(arr, C.c_void_p)
         out = np.zeros((max(1, n_rounds), 7))
         assert pinned.copies >= self.n
-        self._check(self.lib.svohl_run_sequence(self.h, C.c_void_p(pinned.ptr), pinned.bytes, pinned.stride, pinned.n, int(pitch), int(k_first), int(n_rounds), first,
+        # (diagnostic: SVOH_LOCKSTEP_SHARED_IMAGES=1 lets every stream read the first copy -- the device then serves the images
+        # from its caches, which says what the images' way over PCIe costs a run; never a number to report)
+        stride = 0 if os.environ.get("SVOH_LOCKSTEP_SHARED_IMAGES") == "1" else pinned.stride
+        self._check(self.lib.svohl_run_sequence(self.h, C.c_void_p(pinned.ptr), pinned.bytes, stride, pinned.n, int(pitch), int(k_first), int(n_rounds), first,
                                                 out.ctypes.data))
         return out[:n_rounds]
 
@@ -161,6 +167,13 @@ class Lockstep(object):
 
     def finish(self):
         self._check(self.lib.svohl_finish(self.h))
+
+    def phase_times(self):
+        """{phase: ms summed over all rounds so far} of the group thread (FrontendLockstep::phaseTimes)."""
+        ms = (C.c_double * 32)()
+        n = C.c_int()
+        self._check(self.lib.svohl_phase_times(self.h, 32, ms, C.byref(n)))
+        return {self.lib.svohl_phase_name(k).decode(): ms[k] for k in range(n.value)}
 
     def close(self):
         if self.h:

@@ -5,15 +5,17 @@ from svo_pro_universal_amd import _capi as capi, synth
 
 
 def make_pose_scene(seed, n=180, cam=None, n_cams=1, noise_px=0.3, outlier_fraction=0.1, edgelet_fraction=0.3,
-                    pose_err=(0.01, 0.03)):
+                    pose_err=(0.01, 0.03), T_cam0_world=None):
     """Random 3-D points in front of the rig, observed with pixel noise (+ gross outliers), an initial pose off
-    by pose_err (rad, m).  Returns dict(cams=[...], T_imu_world_gt, T_imu_world_init, inlier=[...])."""
+    by pose_err (rad, m).  T_cam0_world: camera 0's true pose (the rig's is derived from it).  Returns dict(cams=[...], T_imu_world_gt, T_imu_world_init, inlier=[...])."""
     rng = np.random.RandomState(seed)
     cam = cam or synth.Camera.euroc_like(752, 480)
     T_imu_world_gt = synth.SE3(synth.quat_from_axis_angle(rng.normal(size=3), rng.uniform(0, 0.8)), rng.uniform(-1, 1, 3))
     cams, inliers = [], []
     for c in range(n_cams):
         T_cam_imu = synth.SE3(synth.quat_from_axis_angle(rng.normal(size=3), 0.1), rng.uniform(-0.1, 0.1, 3) + [0.1 * c, 0, 0])
+        if c == 0 and T_cam0_world is not None:   # the rig's true pose is the one that puts camera 0 at the given pose
+            T_imu_world_gt = T_cam_imu.inverse() * T_cam0_world
         T_cam_world = T_cam_imu * T_imu_world_gt
         px_true = np.stack([rng.uniform(20, cam.width - 20, n), rng.uniform(20, cam.height - 20, n)])
         x, y = cam.undistorted_xy(px_true[0], px_true[1])

@@ -273,6 +273,275 @@ def test_batches_staged_in_place_equal_the_host_array_batches(gpu_ctx):
         ctx.release_frame(fr); ctx.release_frame(fc)
 
 
+def _view(ptr, dtype, count):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * np.dtype(dtype).itemsize,)).view(dtype)
+
+
+def _rigid_mul(a7, b7):
+    """svoh::mul(Rigid, Rigid) of csrc/svoh_math.h, operation by operation (IEEE doubles, no contraction): [qw qx qy qz tx ty tz]."""
+    aw, ax, ay, az, atx, aty, atz = [float(v) for v in a7]
+    bw, bx, by, bz, btx, bty, btz = [float(v) for v in b7]
+    w = aw * bw - ax * bx - ay * by - az * bz
+    x = aw * bx + ax * bw + ay * bz - az * by
+    y = aw * by + ay * bw + az * bx - ax * bz
+    z = aw * bz + az * bw + ax * by - ay * bx
+    n2 = w * w + x * x + y * y + z * z
+    if abs(n2 - 1.0) > 1.0e-4:
+        n = float(np.sqrt(n2))
+        w, x, y, z = w / n, x / n, y / n, z / n
+    ux = ay * btz - az * bty; uy = az * btx - ax * btz; uz = ax * bty - ay * btx
+    ux += ux; uy += uy; uz += uz
+    rx = btx + aw * ux + (ay * uz - az * uy)
+    ry = bty + aw * uy + (az * ux - ax * uz)
+    rz = btz + aw * uz + (ax * uy - ay * ux)
+    return np.array([w, x, y, z, atx + rx, aty + ry, atz + rz])
+
+
+def _upload_features(ctx, sets):
+    """svoh_features_upload for a list of seed sets (make_seed_set dictionaries) in ONE call; returns the handles."""
+    m = len(sets)
+    keep = [[np.ascontiguousarray(sd[k], dt) for sd in sets] for k, dt in (("px", np.float64), ("f", np.float64), ("grad", np.float64), ("level", np.int32))]
+    n = (C.c_int32 * m)(*[a.size for a in keep[3]])
+    ptrs = [(C.c_void_p * m)(*[a.ctypes.data for a in col]) for col in keep]
+    out = (C.c_uint64 * m)()
+    ctx._check(ctx.lib.svoh_features_upload(ctx.h, m, n, ptrs[0], ptrs[1], ptrs[2], ptrs[3], out))
+    return [int(h) for h in out]
+
+
+def test_batches_that_name_features_by_index_equal_the_batches_with_their_columns(gpu_ctx):
+    """svoh_features_upload + SVOH_STAGE_RESIDENT_COLUMNS: the constant columns of three reference frames uploaded once; a staged
+    direct batch and a staged seed batch over a shuffled SUBSET of their features, named by (reference frame, index), against the
+    same units staged with their px / f / grad / level.  Every output bit for bit; an index outside a set marks its unit NOT_RUN and
+    leaves the others alone; the misuse cases fail with an error."""
+    ctx = gpu_ctx
+    cam = synth.Camera.euroc_like()
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(cam)
+    pairs = [seed_scene(ctx, 910 + i, cam) for i in range(3)]
+    sets = [synth.make_seed_set(sc, 500 + 150 * i, seed=10 + i, margin=12) for i, (sc, fr, fc) in enumerate(pairs)]
+    for sd in sets:
+        sd["type"][::7] = capi.FT_EDGELET_SEED_CONVERGED
+    handles = _upload_features(ctx, sets)
+    assert len(set(handles)) == 3 and all(handles)
+    rng = np.random.RandomState(5)
+    # units: (frame k, feature j), shuffled across the frames, two thirds of all features
+    units = [(k, j) for k, sd in enumerate(sets) for j in range(sd["level"].size)]
+    rng.shuffle(units)
+    units = units[:2 * len(units) // 3]
+    n = len(units)
+    uk = np.array([u[0] for u in units], np.int32); uj = np.array([u[1] for u in units], np.int32)
+
+    def col(name, width, dtype):
+        return np.concatenate([np.asarray(sets[k][name], dtype).reshape(-1, width)[j] for k, j in units]).astype(dtype)
+    depth = np.array([sets[k]["true_depth"][j] * 1.02 for k, j in units])
+    px0 = np.empty((n, 2))
+    for k, (sc, fr, fc) in enumerate(pairs):
+        sd = sets[k]
+        x = sd["f"].reshape(-1, 3).T * sd["true_depth"]
+        pxt = sc.cam.project(sc.T_w_cur.inverse().transform(sc.T_w_ref.transform(x))).T
+        sel = uk == k
+        px0[sel] = pxt[uj[sel]] + rng.uniform(-1.5, 1.5, (int(sel.sum()), 2))
+    state = col("state", 4, np.float64)
+    typ = col("type", 1, np.uint8)
+
+    def run(resident, bad_unit=None):
+        refs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fr, cam, sc.T_ref_f_w, sd["mu_range"], 0) for (sc, fr, fc), sd in zip(pairs, sets)])
+        if resident:
+            for k in range(3):
+                refs[k].features = handles[k]
+        curs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fc, cam, sc.T_cur_f_w_gt, 0.0, 1) for (sc, fr, fc) in pairs])
+        flags = capi.SVOH_STAGE_MATCH_OUTPUTS | (capi.SVOH_STAGE_RESIDENT_COLUMNS if resident else 0)
+        ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+        ds, ss = capi.svoh_matcher_stage_t(), capi.svoh_matcher_stage_t()
+        ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 0, n, 8, flags, C.byref(ds)))
+        ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, n, 8, flags, C.byref(ss)))
+        for g in (ds, ss):
+            _view(g.ref_frame_idx, np.int32, n)[:] = uk
+            _view(g.cur_frame_idx, np.int32, n)[:] = uk
+            _view(g.type, np.uint8, n)[:] = typ
+            if resident:
+                assert not g.px and not g.f and not g.grad and not g.level
+                fi = _view(g.feature_index, np.int32, n)
+                fi[:] = uj
+                if bad_unit is not None:
+                    fi[bad_unit] = 10 ** 6
+            else:
+                assert not g.feature_index
+                _view(g.px, np.float64, 2 * n)[:] = col("px", 2, np.float64)
+                _view(g.f, np.float64, 3 * n)[:] = col("f", 3, np.float64)
+                _view(g.grad, np.float64, 2 * n)[:] = col("grad", 2, np.float64)
+                _view(g.level, np.int32, n)[:] = col("level", 1, np.int32)
+        _view(ds.depth, np.float64, n)[:] = depth
+        _view(ds.px_cur, np.float64, 2 * n)[:] = px0.ravel()
+        _view(ss.state, np.float64, 4 * n)[:] = state
+
+        def batch(g):
+            fb = capi.svoh_feature_batch()
+            fb.n, fb.mem_space, fb.n_cur_frames = n, capi.SVOH_MEM_STAGED, 3
+            for k in ("ref_frame_idx", "cur_frame_idx", "px", "f", "grad", "level", "type", "feature_index"):
+                setattr(fb, k, getattr(g, k))
+            return fb
+        fbd, fbs = batch(ds), batch(ss)
+        ctx._check(ctx.lib.svoh_match_direct_batch(ctx.h, C.byref(mopt), 3, refs, curs, C.byref(fbd), ds.depth, ds.px_cur, ds.result, ds.f_cur, ds.search_level,
+                                                   ds.h_inv, ds.A_cur_ref))
+        outs = capi.svoh_seed_match_outputs(ss.px_cur, ss.f_cur, ss.search_level, ss.A_cur_ref)
+        ctx._check(ctx.lib.svoh_update_seeds_batch_ex(ctx.h, C.byref(mopt), C.byref(dopt), 3, refs, curs, C.byref(fbs), ss.state, ss.success, ss.result, None, C.byref(outs)))
+        ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+        got = {}
+        for name, g in (("d", ds), ("s", ss)):
+            got[name] = dict(result=_view(g.result, np.int32, n).copy(), px_cur=_view(g.px_cur, np.float64, 2 * n).copy(), f_cur=_view(g.f_cur, np.float64, 3 * n).copy(),
+                             search_level=_view(g.search_level, np.int32, n).copy(), A=_view(g.A_cur_ref, np.float64, 4 * n).copy(), type=_view(g.type, np.uint8, n).copy())
+        got["s"]["state"] = _view(ss.state, np.float64, 4 * n).copy(); got["s"]["success"] = _view(ss.success, np.uint8, n).copy()
+        return got
+
+    want, got = run(False), run(True)
+    assert (want["d"]["result"] == capi.MATCH_SUCCESS).mean() > 0.4 and want["s"]["success"].mean() > 0.3
+    for kind in ("d", "s"):
+        for name, a in want[kind].items():
+            assert np.array_equal(a, got[kind][name]), (kind, name)
+    # an index outside its set: that unit is not run, every other unit is what it was
+    bad = n // 3
+    got_bad = run(True, bad_unit=bad)
+    assert got_bad["d"]["result"][bad] == capi.MATCH_NOT_RUN and got_bad["s"]["result"][bad] == capi.MATCH_NOT_RUN and got_bad["s"]["success"][bad] == 0
+    others = np.arange(n) != bad
+    assert np.array_equal(got_bad["d"]["result"][others], want["d"]["result"][others]) and np.array_equal(got_bad["s"]["state"].reshape(-1, 4)[others], want["s"]["state"].reshape(-1, 4)[others])
+    # misuse: a reference frame without columns; an unknown handle; feature_index in a host-array batch
+    refs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fr, cam, sc.T_ref_f_w, sd["mu_range"], 0) for (sc, fr, fc), sd in zip(pairs, sets)])
+    curs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fc, cam, sc.T_cur_f_w_gt, 0.0, 1) for (sc, fr, fc) in pairs])
+    for which_bad in ("missing", "unknown"):
+        ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+        g = capi.svoh_matcher_stage_t()
+        ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, 16, 8, capi.SVOH_STAGE_RESIDENT_COLUMNS, C.byref(g)))
+        for k in range(3):
+            refs[k].features = handles[k]
+        refs[1].features = 0 if which_bad == "missing" else 987654321
+        fb = capi.svoh_feature_batch()
+        fb.n, fb.mem_space, fb.n_cur_frames = 16, capi.SVOH_MEM_STAGED, 3
+        for k in ("ref_frame_idx", "cur_frame_idx", "type", "feature_index"):
+            setattr(fb, k, getattr(g, k))
+        assert ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 3, refs, curs, C.byref(fb), g.state, g.success, g.result, None) != 0
+        ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+    sd = sets[0]
+    fb, keep = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+    idx = np.zeros(sd["level"].size, np.int32)
+    fb.feature_index = idx.ctypes.data
+    st = sd["state"].copy(); succ = np.zeros(sd["level"].size, np.uint8)
+    assert ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 1, refs, curs, C.byref(fb), st.ctypes.data, succ.ctypes.data, None, None) != 0
+    for h in handles:
+        ctx._check(ctx.lib.svoh_features_release(ctx.h, h))
+    assert ctx.lib.svoh_features_release(ctx.h, handles[0]) != 0   # released already
+    for sc, fr, fc in pairs:
+        ctx.release_frame(fr); ctx.release_frame(fc)
+
+
+def test_seed_batch_behind_the_pose_kernel_takes_its_poses_on_the_device(gpu_ctx):
+    """svoh_frame_view::pose_result_index_plus1: a staged seed batch over three current frames, queued and SENT OFF from the hook of
+    svoh_optimize_pose_batch_hook -- two of the frames take their pose from the pose batch in flight (T_cam_imu x the optimised
+    T_imu_world, composed on the device), one keeps the pose it was given -- against the same batch queued after the host has
+    applied the poses.  States, types, success flags, result codes bit for bit.  Outside the hook the field is refused."""
+    import pose_helpers as ph
+    ctx = gpu_ctx
+    cam = synth.Camera.euroc_like()
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(cam)
+    pairs = [seed_scene(ctx, 940 + i, cam) for i in range(3)]
+    sets = [synth.make_seed_set(sc, 400 + 100 * i, seed=20 + i, margin=12) for i, (sc, fr, fc) in enumerate(pairs)]
+    n_each = [sd["level"].size for sd in sets]
+    n = sum(n_each)
+    # two pose problems whose optimum nobody knows in advance (the batch must really read the device's result): the current
+    # frames 0 and 2 are cameras of rigs 1 and 0
+    pose_of_cur = {0: 1, 2: 0}   # current frame -> pose problem
+    cur_of_pose = {p: k for k, p in pose_of_cur.items()}
+    scenes = [ph.make_pose_scene(300 + i, n=160, cam=cam, T_cam0_world=pairs[cur_of_pose[i]][0].T_cur_f_w_gt) for i in range(2)]
+    popt = capi.default_pose_options(cam)
+    pbs, keeps = zip(*[fe.make_pose_problem(sc["cams"], sc["T_imu_world_init"]) for sc in scenes])
+    res_host = ctx.optimize_pose(popt, list(pbs))
+    T_cam_imu = {k: scenes[p]["cams"][0]["T_cam_imu"] for k, p in pose_of_cur.items()}
+
+    def fill(g):
+        off = 0
+        for k, sd in enumerate(sets):
+            m = n_each[k]
+            _view(g.ref_frame_idx, np.int32, n)[off:off + m] = k
+            _view(g.cur_frame_idx, np.int32, n)[off:off + m] = k
+            _view(g.px, np.float64, 2 * n)[2 * off:2 * (off + m)] = sd["px"]
+            _view(g.f, np.float64, 3 * n)[3 * off:3 * (off + m)] = sd["f"]
+            _view(g.grad, np.float64, 2 * n)[2 * off:2 * (off + m)] = sd["grad"]
+            _view(g.level, np.int32, n)[off:off + m] = sd["level"]
+            _view(g.type, np.uint8, n)[off:off + m] = sd["type"]
+            _view(g.state, np.float64, 4 * n)[4 * off:4 * (off + m)] = sd["state"]
+            off += m
+
+    def batch(g):
+        fb = capi.svoh_feature_batch()
+        fb.n, fb.mem_space, fb.n_cur_frames = n, capi.SVOH_MEM_STAGED, 3
+        for k in ("ref_frame_idx", "cur_frame_idx", "px", "f", "grad", "level", "type"):
+            setattr(fb, k, getattr(g, k))
+        return fb
+    refs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fr, cam, sc.T_ref_f_w, sd["mu_range"], 0) for (sc, fr, fc), sd in zip(pairs, sets)])
+
+    def outputs(g):
+        return dict(state=_view(g.state, np.float64, 4 * n).copy(), type=_view(g.type, np.uint8, n).copy(), success=_view(g.success, np.uint8, n).copy(),
+                    result=_view(g.result, np.int32, n).copy())
+    # (a) the poses applied by the host: T_f_w = T_cam_imu * T_imu_world(result)
+    curs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fc, cam, sc.T_cur_f_w_gt, 0.0, 1) for (sc, fr, fc) in pairs])
+    for k, p in pose_of_cur.items():
+        curs[k].T_f_w = fe._se3(_rigid_mul(T_cam_imu[k].as7(), fe.se3_to_numpy(res_host[p].T_imu_world)))
+    ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+    g = capi.svoh_matcher_stage_t()
+    ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, n, 8, 0, C.byref(g)))
+    fill(g)
+    fb = batch(g)
+    ctx._check(ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 3, refs, curs, C.byref(fb), g.state, g.success, g.result, None))
+    ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+    want = outputs(g)
+    assert want["success"].mean() > 0.2
+    # (b) queued from the pose call's hook, poses taken on the device
+    curs_dev = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fc, cam, sc.T_cur_f_w_gt, 0.0, 1) for (sc, fr, fc) in pairs])
+    for k, p in pose_of_cur.items():
+        curs_dev[k].T_f_w = fe._se3(T_cam_imu[k])
+        curs_dev[k].pose_result_index_plus1 = p + 1
+    ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+    g2 = capi.svoh_matcher_stage_t()
+    ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, n, 8, 0, C.byref(g2)))
+    fill(g2)
+    fb2 = batch(g2)
+    # outside the hook: refused, the staged block stays usable
+    assert ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 3, refs, curs_dev, C.byref(fb2), g2.state, g2.success, g2.result, None) != 0
+    hook_rc = []
+
+    @C.CFUNCTYPE(None, C.c_void_p)
+    def hook(_user):
+        hook_rc.append(ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 3, refs, curs_dev, C.byref(fb2), g2.state, g2.success, g2.result, None))
+        hook_rc.append(ctx.lib.svoh_matcher_flush(ctx.h))
+    arr = (capi.svoh_pose_problem * 2)(*pbs)
+    res = (capi.svoh_pose_result * 2)()
+    ctx.lib.svoh_optimize_pose_batch_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    ctx._check(ctx.lib.svoh_optimize_pose_batch_hook(ctx.h, C.byref(popt), 2, arr, res, hook, None))
+    assert hook_rc == [0, 0], hook_rc
+    ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+    for p in range(2):
+        assert np.array_equal(fe.se3_to_numpy(res[p].T_imu_world), fe.se3_to_numpy(res_host[p].T_imu_world))
+    got = outputs(g2)
+    for name in want:
+        assert np.array_equal(want[name], got[name]), name
+    # an index beyond the batch in flight: refused inside the hook as well
+    curs_dev[0].pose_result_index_plus1 = 3
+    ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+    g3 = capi.svoh_matcher_stage_t()
+    ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, n, 8, 0, C.byref(g3)))
+    fill(g3)
+    fb3 = batch(g3)
+    rc3 = []
+
+    @C.CFUNCTYPE(None, C.c_void_p)
+    def hook3(_user):
+        rc3.append(ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 3, refs, curs_dev, C.byref(fb3), g3.state, g3.success, g3.result, None))
+    ctx._check(ctx.lib.svoh_optimize_pose_batch_hook(ctx.h, C.byref(popt), 2, arr, res, hook3, None))
+    assert rc3 and rc3[0] != 0
+    ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+    for sc, fr, fc in pairs:
+        ctx.release_frame(fr); ctx.release_frame(fc)
+
+
 def test_candidate_projections_of_many_frames_equal_the_single_call(gpu_ctx):
     """svoh_project_candidates_stage / _enqueue_staged / _wait with four jobs (own camera pose, own keyframe table, one of
     them without points of kind 1) against svoh_project_candidates job by job: pixels and verdicts equal."""
