@@ -636,18 +636,30 @@ typedef struct svoh_candidate_job {
   int32_t point_begin, n_points;
   int32_t reserved;
 } svoh_candidate_job;
+/* The form with resident columns (_stage_ranges): entry k of the keyframe table is ALSO a range of points -- the features
+ * 0 .. n_points-1 of the keyframe's resident columns (svoh_features_upload), in order, as points point_begin .. of job
+ * `job`.  Ranges lie back to back (range k+1 begins where range k ends).  Per point only kind and mu cross PCIe: a seed's
+ * bearing vector is the f column of its feature; v is read for landmarks (kind 0) only, and uploaded only when there is one. */
+typedef struct svoh_candidate_range {
+  svoh_features_t features;
+  int32_t point_begin, n_points;
+  int32_t job;
+  int32_t reserved;
+} svoh_candidate_range;
 typedef struct svoh_candidate_stage_t {
   svoh_candidate_job* jobs;         /* n_jobs */
   svoh_se3* T_world_kf;             /* n_kf_total */
-  int32_t* job;                     /* n_points_total */
+  int32_t* job;                     /* n_points_total (NULL in the ranges form) */
   uint8_t* kind;                    /* n_points_total */
-  int32_t* kf;                      /* n_points_total */
+  int32_t* kf;                      /* n_points_total (NULL in the ranges form) */
   double* v;                        /* 3 x n_points_total */
   double* mu;                       /* n_points_total */
   double* px;                       /* out: 2 x n_points_total */
   uint8_t* visible;                 /* out: n_points_total */
+  svoh_candidate_range* ranges;     /* n_kf_total (the ranges form), else NULL */
 } svoh_candidate_stage_t;
 int svoh_project_candidates_stage(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_points_total, svoh_candidate_stage_t* out);
+int svoh_project_candidates_stage_ranges(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_points_total, svoh_candidate_stage_t* out);
 int svoh_project_candidates_enqueue_staged(svoh_ctx* ctx);
 int svoh_project_candidates_wait(svoh_ctx* ctx);
 

@@ -117,7 +117,11 @@ class svoh_candidate_job(C.Structure):
 
 
 class svoh_candidate_stage_t(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("jobs", "T_world_kf", "job", "kind", "kf", "v", "mu", "px", "visible")]
+    _fields_ = [(k, C.c_void_p) for k in ("jobs", "T_world_kf", "job", "kind", "kf", "v", "mu", "px", "visible", "ranges")]
+
+
+class svoh_candidate_range(C.Structure):
+    _fields_ = [("features", C.c_uint64), ("point_begin", C.c_int32), ("n_points", C.c_int32), ("job", C.c_int32), ("reserved", C.c_int32)]
 
 
 class svoh_depth_filter_options(C.Structure):
@@ -295,7 +299,7 @@ EXPORTS = [
     # round 5: what the lock-step front end of many camera streams stages in place and launches once per stage
     "svoh_host_alloc", "svoh_host_free", "svoh_build_pyramid_multi", "svoh_build_pyramid_multi_prefetch", "svoh_prefetch_fence",
     "svoh_sparse_align_geometry_key", "svoh_sparse_align_enqueue_keyed",
-    "svoh_project_candidates_stage", "svoh_project_candidates_enqueue_staged", "svoh_project_candidates_wait",
+    "svoh_project_candidates_stage", "svoh_project_candidates_stage_ranges", "svoh_project_candidates_enqueue_staged", "svoh_project_candidates_wait",
     "svoh_matcher_stage", "svoh_detect_cells_batch", "svoh_detect_fill_features", "svoh_features_upload", "svoh_features_release",
 ]
 
@@ -435,6 +439,7 @@ def load(path=None):
     lib.svoh_features_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_uint64)]
     lib.svoh_features_release.argtypes = [C.c_void_p, C.c_uint64]
     lib.svoh_project_candidates_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(svoh_candidate_stage_t)]
+    lib.svoh_project_candidates_stage_ranges.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(svoh_candidate_stage_t)]
     lib.svoh_project_candidates_enqueue_staged.argtypes = [C.c_void_p]
     lib.svoh_project_candidates_wait.argtypes = [C.c_void_p]
     lib.svoh_matcher_begin_deferred.argtypes = [C.c_void_p]

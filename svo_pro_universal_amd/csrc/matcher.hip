@@ -3556,6 +3556,72 @@ __global__ __launch_bounds__(256) void project_candidates_multi_kernel(const Mul
   a.visible[i] = ok ? 1 : 0;
 }
 
+// The ranges form (svoh_project_candidates_stage_ranges): point i is feature i - point_begin of the keyframe whose range holds it;
+// a seed's bearing vector comes from the keyframe's resident f column.  Same arithmetic per point.
+struct DevCandidateRange { const double* f; int32_t n_feat; int32_t point_begin, n_points; int32_t job; int32_t pad_; };
+struct RangeCandidateArgs {
+  const svoh_candidate_job* jobs;
+  const svoh_align_result* align_results;
+  const uint32_t* result_dev_index;
+  const svoh_se3* T_world_kf;
+  const DevCandidateRange* ranges;
+  const uint8_t* kind;
+  const double* v;      // landmarks only (NULL when the launch has none)
+  const double* mu;
+  double* px;
+  uint8_t* visible;
+  int n, n_jobs, n_ranges;
+};
+
+__global__ __launch_bounds__(256) void project_candidates_ranges_kernel(const RangeCandidateArgs a)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  // the last range that begins at or before i
+  int lo = 0, hi = a.n_ranges;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.ranges[mid].point_begin <= i) lo = mid; else hi = mid; }
+  const DevCandidateRange rg = a.ranges[lo];
+  const int jf = i - rg.point_begin;
+  const int j = rg.job;
+  const bool in_range = jf >= 0 && jf < rg.n_points && (unsigned)j < (unsigned)a.n_jobs;
+  if (!in_range) { a.px[2 * i] = 0.0; a.px[2 * i + 1] = 0.0; a.visible[i] = 0; return; }
+  const svoh_candidate_job& jb = a.jobs[j];
+  Rigid T_f_w = load_rigid(jb.T_f_w_or_T_cam_imu);
+  if (jb.align_result_index >= 0) T_f_w = mul(mul(T_f_w, load_rigid(a.align_results[a.result_dev_index[j]].T_icur_iref)), load_rigid(jb.T_imu_world_ref));
+  const CamModel cm = load_camera(jb.cam);
+  Vec3 xyz = { 0.0, 0.0, 0.0 };
+  bool ok = true;
+  if (a.kind[i]) {
+    ok = lo >= jb.kf_begin && lo < jb.kf_begin + jb.n_kf && jf < rg.n_feat;
+    if (ok) {
+      const double depth = 1.0 / a.mu[i];                        // seed::getDepth (seed.h:110-113)
+      const Vec3 in_f = { rg.f[3 * jf] * depth, rg.f[3 * jf + 1] * depth, rg.f[3 * jf + 2] * depth };
+      xyz = transform(load_rigid(a.T_world_kf[lo]), in_f);
+    }
+  } else {
+    ok = a.v != nullptr;
+    if (ok) { xyz.x = a.v[3 * i]; xyz.y = a.v[3 * i + 1]; xyz.z = a.v[3 * i + 2]; }
+  }
+  double u = 0.0, v = 0.0;
+  if (ok) {
+    const Vec3 xyz_f = transform(T_f_w, xyz);
+    const Vec3 f_tl = back_project3(cm, 0.0, 0.0);
+    const double min_cos = f_tl.z / sqrt(f_tl.x * f_tl.x + f_tl.y * f_tl.y + f_tl.z * f_tl.z);
+    const double cur_cos = xyz_f.z / sqrt(xyz_f.x * xyz_f.x + xyz_f.y * xyz_f.y + xyz_f.z * xyz_f.z);
+    ok = !(cur_cos < min_cos);
+    if (ok) {
+      project3(cm, xyz_f, u, v);
+      ok = u >= 0.0 && v >= 0.0 && u < (double)jb.cam.width && v < (double)jb.cam.height;
+      if (ok) {
+        const int pxi0 = (int)u, pxi1 = (int)v;
+        ok = pxi0 >= 8 && pxi1 >= 8 && pxi0 < jb.cam.width - 8 && pxi1 < jb.cam.height - 8;
+      }
+    }
+  }
+  a.px[2 * i] = u; a.px[2 * i + 1] = v;
+  a.visible[i] = ok ? 1 : 0;
+}
+
 }  // namespace svoh
 
 using namespace svoh;
@@ -3590,8 +3656,8 @@ try {
   return svoh_project_candidates_collect(ctx, n, px, visible);
 } SVOH_ABI_CATCH(ctx)
 
-int svoh_project_candidates_stage(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_points_total, svoh_candidate_stage_t* out)
-try {
+static int stage_candidates(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_points_total, svoh_candidate_stage_t* out, bool ranges)
+{
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, out && n_jobs >= 1 && n_jobs <= 4096 && n_kf_total >= 0 && n_kf_total <= (1 << 20) && n_points_total >= 1 && n_points_total <= (1 << 24), "bad arguments");
   SVOH_REQUIRE(ctx, ctx->cand_stage.state != 2, "a staged candidate projection is in flight: svoh_project_candidates_wait first");
@@ -3603,20 +3669,48 @@ try {
   st.n_jobs = n_jobs; st.n_kf = n_kf_total; st.n_points = n_points_total;
   st.o_jobs = add(sizeof(svoh_candidate_job) * (size_t)n_jobs + sizeof(uint32_t) * (size_t)n_jobs);   // + the jobs' device result indices
   st.o_kf = add(sizeof(svoh_se3) * (size_t)(n_kf_total > 0 ? n_kf_total : 1));
-  st.o_job = add(4 * np); st.o_kind = add(np); st.o_idx = add(4 * np); st.o_v = add(24 * np); st.o_mu = add(8 * np);
-  st.in_total = total;
-  st.o_px = add(16 * np); st.o_vis = add(np);
+  st.ranges = ranges;
+  memset(out, 0, sizeof *out);
+  if (ranges) {
+    SVOH_REQUIRE(ctx, n_kf_total >= 1, "the ranges form needs a keyframe table");
+    // [jobs | T_world_kf | device ranges | kind | mu | v]: v last, uploaded only when a landmark is among the points; the ranges
+    // as the caller writes them (handles) stay on the host
+    st.o_dev_ranges = add(sizeof(DevCandidateRange) * (size_t)n_kf_total);
+    st.o_kind = add(np); st.o_mu = add(8 * np);
+    st.in_total_without_v = total;
+    st.o_v = add(24 * np);
+    st.in_total = total;
+    st.o_px = add(16 * np); st.o_vis = add(np);
+    st.o_ranges = add(sizeof(svoh_candidate_range) * (size_t)n_kf_total);
+    st.o_job = st.o_idx = 0;
+  } else {
+    st.o_job = add(4 * np); st.o_kind = add(np); st.o_idx = add(4 * np); st.o_v = add(24 * np); st.o_mu = add(8 * np);
+    st.in_total = total;
+    st.o_px = add(16 * np); st.o_vis = add(np);
+  }
   st.total = total;
   SVOH_HIP_TRY(ctx, ctx->h_cand_multi.reserve(total));
   SVOH_HIP_TRY(ctx, ctx->d_cand_multi.reserve(total));
   uint8_t* h = static_cast<uint8_t*>(ctx->h_cand_multi.ptr);
   out->jobs = reinterpret_cast<svoh_candidate_job*>(h + st.o_jobs);
   out->T_world_kf = reinterpret_cast<svoh_se3*>(h + st.o_kf);
-  out->job = reinterpret_cast<int32_t*>(h + st.o_job); out->kind = h + st.o_kind; out->kf = reinterpret_cast<int32_t*>(h + st.o_idx);
+  out->kind = h + st.o_kind;
+  if (ranges) out->ranges = reinterpret_cast<svoh_candidate_range*>(h + st.o_ranges);
+  else { out->job = reinterpret_cast<int32_t*>(h + st.o_job); out->kf = reinterpret_cast<int32_t*>(h + st.o_idx); }
   out->v = reinterpret_cast<double*>(h + st.o_v); out->mu = reinterpret_cast<double*>(h + st.o_mu);
   out->px = reinterpret_cast<double*>(h + st.o_px); out->visible = h + st.o_vis;
   st.state = 1;
   return SVOH_OK;
+}
+
+int svoh_project_candidates_stage(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_points_total, svoh_candidate_stage_t* out)
+try {
+  return stage_candidates(ctx, n_jobs, n_kf_total, n_points_total, out, false);
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_project_candidates_stage_ranges(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_points_total, svoh_candidate_stage_t* out)
+try {
+  return stage_candidates(ctx, n_jobs, n_kf_total, n_points_total, out, true);
 } SVOH_ABI_CATCH(ctx)
 
 int svoh_project_candidates_enqueue_staged(svoh_ctx* ctx)
@@ -3642,6 +3736,39 @@ try {
       dev_idx[j] = ctx->align_result_dev_index[(size_t)jb.align_result_index];
       any_result = true;
     }
+  }
+  if (st.ranges) {
+    const svoh_candidate_range* rg = reinterpret_cast<const svoh_candidate_range*>(h + st.o_ranges);
+    DevCandidateRange* dr = reinterpret_cast<DevCandidateRange*>(h + st.o_dev_ranges);
+    int64_t at = 0;
+    for (int k = 0; k < st.n_kf; ++k) {
+      SVOH_REQUIRE(ctx, rg[k].point_begin == at && rg[k].n_points >= 0 && at + rg[k].n_points <= st.n_points, "the ranges must lie back to back inside the point arrays");
+      SVOH_REQUIRE(ctx, rg[k].job >= 0 && rg[k].job < st.n_jobs, "a range's job is out of range");
+      auto it = ctx->feature_sets.find(rg[k].features);
+      if (it == ctx->feature_sets.end()) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "range %d: unknown feature-set handle %llu", k, (unsigned long long)rg[k].features);
+      dr[k].f = it->second.f; dr[k].n_feat = it->second.n; dr[k].point_begin = rg[k].point_begin; dr[k].n_points = rg[k].n_points; dr[k].job = rg[k].job; dr[k].pad_ = 0;
+      at += rg[k].n_points;
+    }
+    SVOH_REQUIRE(ctx, at == st.n_points, "the ranges do not cover the staged points");
+    const bool any_landmark = memchr(h + st.o_kind, 0, (size_t)st.n_points) != nullptr;
+    SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, any_landmark ? st.in_total : st.in_total_without_v));
+    RangeCandidateArgs a;
+    memset(&a, 0, sizeof a);
+    a.jobs = reinterpret_cast<const svoh_candidate_job*>(d + st.o_jobs);
+    a.result_dev_index = reinterpret_cast<const uint32_t*>(a.jobs + st.n_jobs);
+    a.align_results = any_result ? static_cast<const svoh_align_result*>(ctx->d_results.ptr) : nullptr;
+    a.T_world_kf = reinterpret_cast<const svoh_se3*>(d + st.o_kf);
+    a.ranges = reinterpret_cast<const DevCandidateRange*>(d + st.o_dev_ranges);
+    a.kind = d + st.o_kind; a.mu = reinterpret_cast<const double*>(d + st.o_mu);
+    a.v = any_landmark ? reinterpret_cast<const double*>(d + st.o_v) : nullptr;
+    a.px = reinterpret_cast<double*>(d + st.o_px); a.visible = d + st.o_vis;
+    a.n = st.n_points; a.n_jobs = st.n_jobs; a.n_ranges = st.n_kf;
+    hipLaunchKernelGGL(project_candidates_ranges_kernel, dim3((unsigned)((st.n_points + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "project_candidates_ranges launch failed: %s", hipGetErrorString(e));
+    SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + st.o_px, d + st.o_px, st.o_ranges - st.o_px));
+    st.state = 2;
+    return SVOH_OK;
   }
   SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, st.in_total));
   MultiCandidateArgs a;

@@ -1159,6 +1159,10 @@ void ReprojectorHip::gatherCandidateProjection(const FramePtr& cur_frame, const 
     if (!kf || kf->num_features_ == 0) continue;
     svoh::store_rigid(svoh::inverse(kf->T_f_w_), into.T_world_kf[k]);
     proj_kf_off_.push_back(ProjKf{ kf.get(), kf->id_, at, kf->num_features_, kf->T_f_w_ });
+    if (into.ranges) {
+      if (!kf->features) throw std::runtime_error("ReprojectorHip::gatherCandidateProjection: a keyframe without resident feature columns in the ranges form");
+      into.ranges[k] = svoh_candidate_range{ kf->features, into.point_offset + static_cast<int32_t>(at), static_cast<int32_t>(kf->num_features_), into.job, 0 };
+    }
     for (size_t i = 0; i < kf->num_features_; ++i, ++at) {
       const PointPtr& lm = i < kf->landmark_vec_.size() ? kf->landmark_vec_[i] : PointPtr();
       double* v = into.v + 3 * at;
@@ -1167,10 +1171,10 @@ void ReprojectorHip::gatherCandidateProjection(const FramePtr& cur_frame, const 
         into.kind[at] = 0; v[0] = p.x; v[1] = p.y; v[2] = p.z; into.mu[at] = 1.0;
       } else {                                        // ... or T_world_cam() * getSeedPosInFrame(i)
         into.kind[at] = 1;
-        v[0] = kf->f_vec_[3 * i]; v[1] = kf->f_vec_[3 * i + 1]; v[2] = kf->f_vec_[3 * i + 2];
+        if (!into.ranges) { v[0] = kf->f_vec_[3 * i]; v[1] = kf->f_vec_[3 * i + 1]; v[2] = kf->f_vec_[3 * i + 2]; }   // (the ranges form reads the resident f column)
         into.mu[at] = 4 * i < kf->invmu_sigma2_a_b_vec_.size() ? kf->invmu_sigma2_a_b_vec_[4 * i] : 1.0;
       }
-      into.kf[at] = k;
+      if (!into.ranges) into.kf[at] = k;
     }
     ++k;
   }

@@ -498,7 +498,10 @@ class ReprojectorHip {
   // (1) candidate projection: how many points / keyframe poses the projection of `kfs` has, then the inputs written
   //     where the caller says (its own page-locked block), then the results adopted from where the device left them
   //     (they are read in place by the next walkCandidates, and must stay valid until it returns)
-  struct ProjectionArrays { svoh_se3* T_world_kf; uint8_t* kind; int32_t* kf; double* v; double* mu; };
+  //     ranges != NULL (svoh_project_candidates_stage_ranges): every keyframe must have resident columns (Frame::features); its
+  //     entry of the table is written as the range of its points -- they begin at point_offset of the whole launch and belong to
+  //     `job` -- and per point only kind and mu (a landmark's position too) are written: kf stays untouched
+  struct ProjectionArrays { svoh_se3* T_world_kf; uint8_t* kind; int32_t* kf; double* v; double* mu; svoh_candidate_range* ranges = nullptr; int32_t point_offset = 0, job = 0; };
   void countCandidateProjection(const std::vector<FramePtr>& kfs, size_t* n_points, size_t* n_kf) const;
   void gatherCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const ProjectionArrays& into);
   void adoptCandidateProjection(const FramePtr& cur_frame, const double* px, const uint8_t* visible);

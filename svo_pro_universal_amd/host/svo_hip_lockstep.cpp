@@ -408,7 +408,8 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       if (st.proj_points) { st.proj_job = n_jobs++; n_points += st.proj_points; n_kf += st.proj_kf; }
     }
     if (n_jobs) {
-      check(svoh_project_candidates_stage(ctx_, n_jobs, static_cast<int>(n_kf), static_cast<int>(n_points), &cs), "svoh_project_candidates_stage");
+      if (opt_.resident_features) check(svoh_project_candidates_stage_ranges(ctx_, n_jobs, static_cast<int>(n_kf), static_cast<int>(n_points), &cs), "svoh_project_candidates_stage_ranges");
+      else check(svoh_project_candidates_stage(ctx_, n_jobs, static_cast<int>(n_kf), static_cast<int>(n_points), &cs), "svoh_project_candidates_stage");
       pool_.run(S, [&](int s) {
         Stream& st = *streams_[static_cast<size_t>(s)];
         if (st.proj_job < 0) return;
@@ -421,9 +422,10 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
         jb.kf_begin = static_cast<int32_t>(st.proj_kf_off); jb.n_kf = static_cast<int32_t>(st.proj_kf);
         jb.point_begin = static_cast<int32_t>(st.proj_point_off); jb.n_points = static_cast<int32_t>(st.proj_points);
         const size_t o = st.proj_point_off;
-        st.reprojector.gatherCandidateProjection(st.frame, st.visible,
-                                                 ReprojectorHip::ProjectionArrays{ cs.T_world_kf + st.proj_kf_off, cs.kind + o, cs.kf + o, cs.v + 3 * o, cs.mu + o });
-        for (size_t i = 0; i < st.proj_points; ++i) cs.job[o + i] = st.proj_job;
+        ReprojectorHip::ProjectionArrays into{ cs.T_world_kf + st.proj_kf_off, cs.kind + o, cs.kf ? cs.kf + o : nullptr, cs.v + 3 * o, cs.mu + o };
+        if (cs.ranges) { into.ranges = cs.ranges + st.proj_kf_off; into.point_offset = static_cast<int32_t>(o); into.job = st.proj_job; }
+        st.reprojector.gatherCandidateProjection(st.frame, st.visible, into);
+        if (cs.job) for (size_t i = 0; i < st.proj_points; ++i) cs.job[o + i] = st.proj_job;
       });
       check(svoh_project_candidates_enqueue_staged(ctx_), "svoh_project_candidates_enqueue_staged");
       ++device_calls_;

@@ -611,3 +611,101 @@ def test_candidate_projections_of_many_frames_equal_the_single_call(gpu_ctx):
     jj.cam, jj.align_result_index, jj.n_kf, jj.point_begin, jj.n_points = fe._camera(cam), -1, 1, 5, 10
     C.cast(cs.jobs, C.POINTER(capi.svoh_candidate_job))[0] = jj
     assert ctx.lib.svoh_project_candidates_enqueue_staged(ctx.h) != 0
+
+
+@pytest.mark.parametrize("with_landmarks", [False, True])
+def test_candidate_projection_over_resident_columns_equals_the_per_point_form(gpu_ctx, with_landmarks):
+    """svoh_project_candidates_stage_ranges: three jobs, each over the features of a few keyframes whose columns are resident
+    (svoh_features_upload) -- per point only kind and mu are staged, a seed's bearing vector is its keyframe's f column -- against
+    svoh_project_candidates with the same points written out.  With landmarks among the points their positions (v) go up too."""
+    ctx = gpu_ctx
+    cam = synth.Camera.euroc_like(752, 480)
+    rng = np.random.RandomState(23)
+
+    def rand_T(s):
+        q = np.array([1.0, 0, 0, 0]) + rng.normal(0, s, 4)
+        return synth.SE3(q / np.linalg.norm(q), rng.normal(0, s, 3))
+    jobs = []
+    for j in range(3):
+        kfs = []
+        for k in range((2, 4, 1)[j]):
+            n = int(rng.randint(150, 700))
+            f = rng.normal(0, 0.4, (n, 3)); f[:, 2] = 1.0
+            f /= np.linalg.norm(f, axis=1, keepdims=True)
+            kind = np.ones(n, np.uint8)
+            v = f.copy()
+            if with_landmarks:
+                lm = rng.uniform(size=n) < 0.3
+                kind[lm] = 0
+                v[lm] = rng.normal(0, 1, (int(lm.sum()), 3)) + [0, 0, 4.0]
+            kfs.append(dict(T=rand_T(0.1), n=n, f=np.ascontiguousarray(f.ravel()), kind=kind, v=np.ascontiguousarray(v.ravel()), mu=rng.uniform(0.1, 1.0, n),
+                            px=rng.uniform(0, 700, 2 * n), grad=rng.normal(size=2 * n), level=rng.randint(0, 3, n).astype(np.int32)))
+        jobs.append(dict(T=rand_T(0.03), kfs=kfs))
+    all_kfs = [kf for jb in jobs for kf in jb["kfs"]]
+    handles = _upload_features(ctx, all_kfs)
+    # per job through the blocking single-job call, points written out
+    want = []
+    for jb in jobs:
+        n_kf = len(jb["kfs"])
+        Tk = (capi.svoh_se3 * n_kf)(*[fe._se3(kf["T"].inverse()) for kf in jb["kfs"]])
+        kind = np.concatenate([kf["kind"] for kf in jb["kfs"]]); v = np.concatenate([kf["v"] for kf in jb["kfs"]]); mu = np.concatenate([kf["mu"] for kf in jb["kfs"]])
+        kfi = np.concatenate([np.full(kf["n"], k, np.int32) for k, kf in enumerate(jb["kfs"])])
+        n = kind.size
+        px = np.zeros(2 * n); vis = np.zeros(n, np.uint8)
+        c, T = fe._camera(cam), fe._se3(jb["T"])
+        ctx._check(ctx.lib.svoh_project_candidates(ctx.h, C.byref(c), C.byref(T), n_kf, Tk, n, kind.ctypes.data, kfi.ctypes.data, v.ctypes.data, mu.ctypes.data,
+                                                   px.ctypes.data, vis.ctypes.data))
+        want.append((px, vis))
+        assert 0.02 < vis.mean() < 0.98
+    n_total, kf_total = sum(kf["n"] for kf in all_kfs), len(all_kfs)
+    cs = capi.svoh_candidate_stage_t()
+    ctx._check(ctx.lib.svoh_project_candidates_stage_ranges(ctx.h, len(jobs), kf_total, n_total, C.byref(cs)))
+    assert not cs.job and not cs.kf and cs.ranges
+    jarr = C.cast(cs.jobs, C.POINTER(capi.svoh_candidate_job))
+    karr = C.cast(cs.T_world_kf, C.POINTER(capi.svoh_se3))
+    rarr = C.cast(cs.ranges, C.POINTER(capi.svoh_candidate_range))
+    _view(cs.v, np.float64, 3 * n_total)[:] = np.nan   # what is not a landmark's must not be read
+    off = koff = 0
+    for j, jb in enumerate(jobs):
+        jj = capi.svoh_candidate_job()
+        jj.cam, jj.T_f_w_or_T_cam_imu, jj.align_result_index = fe._camera(cam), fe._se3(jb["T"]), -1
+        jj.kf_begin, jj.n_kf, jj.point_begin, jj.n_points = koff, len(jb["kfs"]), off, sum(kf["n"] for kf in jb["kfs"])
+        jarr[j] = jj
+        for k, kf in enumerate(jb["kfs"]):
+            karr[koff + k] = fe._se3(kf["T"].inverse())
+            r = capi.svoh_candidate_range()
+            r.features, r.point_begin, r.n_points, r.job = handles[koff + k], off, kf["n"], j
+            rarr[koff + k] = r
+            m = kf["n"]
+            _view(cs.kind, np.uint8, n_total)[off:off + m] = kf["kind"]
+            _view(cs.mu, np.float64, n_total)[off:off + m] = kf["mu"]
+            lm = kf["kind"] == 0
+            if lm.any():
+                _view(cs.v, np.float64, 3 * n_total).reshape(-1, 3)[off:off + m][lm] = kf["v"].reshape(-1, 3)[lm]
+            off += m
+        koff += len(jb["kfs"])
+    ctx._check(ctx.lib.svoh_project_candidates_enqueue_staged(ctx.h))
+    ctx._check(ctx.lib.svoh_project_candidates_wait(ctx.h))
+    off = 0
+    for j, jb in enumerate(jobs):
+        m = sum(kf["n"] for kf in jb["kfs"])
+        assert np.array_equal(_view(cs.px, np.float64, 2 * n_total)[2 * off:2 * (off + m)], want[j][0])
+        assert np.array_equal(_view(cs.visible, np.uint8, n_total)[off:off + m], want[j][1])
+        off += m
+    # ranges that do not lie back to back, an unknown handle: refused before anything is launched
+    for bad in ("gap", "handle"):
+        ctx._check(ctx.lib.svoh_project_candidates_stage_ranges(ctx.h, 1, 2, 20, C.byref(cs)))
+        jj = capi.svoh_candidate_job()
+        jj.cam, jj.align_result_index, jj.n_kf, jj.point_begin, jj.n_points = fe._camera(cam), -1, 2, 0, 20
+        C.cast(cs.jobs, C.POINTER(capi.svoh_candidate_job))[0] = jj
+        rarr = C.cast(cs.ranges, C.POINTER(capi.svoh_candidate_range))
+        for k in range(2):
+            r = capi.svoh_candidate_range()
+            r.features, r.point_begin, r.n_points, r.job = handles[k], 10 * k + (1 if bad == "gap" and k == 1 else 0), 10, 0
+            if bad == "handle" and k == 1:
+                r.features = 123456789
+            rarr[k] = r
+        _view(cs.kind, np.uint8, 20)[:] = 1
+        assert ctx.lib.svoh_project_candidates_enqueue_staged(ctx.h) != 0
+    for h in handles:
+        ctx._check(ctx.lib.svoh_features_release(ctx.h, h))
