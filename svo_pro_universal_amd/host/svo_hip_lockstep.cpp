@@ -691,8 +691,8 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     Stream& st = *stp;
     st.row.is_kf = st.want_kf;
     st.row_open = true;
-    // the frame before this one is dropped here unless it is a keyframe
-    st.b_last.reset(); st.b_cur.reset(); st.visible.clear(); st.trash.clear();
+    // (the frame before this one lives on in b_last until the next round's alignment set-up replaces the bundles -- on the
+    // pool: taking a dozen frames apart here, on the group's thread, is 0.05 ms of every round)
     st.last = st.frame; st.frame.reset();
   }
   drainReleases();
