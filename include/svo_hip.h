@@ -809,6 +809,13 @@ int svoh_detect_features(svoh_ctx* ctx, svoh_frame_t frame, const svoh_detector_
  * any thread.  Both halves together give exactly svoh_detect_features' features (mask == NULL). */
 int svoh_detect_cells_batch(svoh_ctx* ctx, int n_frames, const svoh_frame_t* frames, const svoh_detector_options* options,
                             const uint8_t* occupancy, uint64_t* corner_keys, uint64_t* edge_keys, float* edge_angles);
+/* The device half in two steps: _enqueue queues uploads, kernels and the copy of the results and returns; _collect waits for
+ * THAT batch (an event behind its copy -- not for work the caller has queued on the context since) and hands the arrays out.
+ * One batch in flight per context; between the two the caller may make any other call.  This is how the detector of a round's
+ * new keyframes runs ahead of the pose optimisation instead of behind the depth filter's update. */
+int svoh_detect_cells_batch_enqueue(svoh_ctx* ctx, int n_frames, const svoh_frame_t* frames, const svoh_detector_options* options,
+                                    const uint8_t* occupancy);
+int svoh_detect_cells_batch_collect(svoh_ctx* ctx, uint64_t* corner_keys, uint64_t* edge_keys, float* edge_angles);
 int svoh_detect_fill_features(const svoh_detector_options* options, int width, int height, const uint64_t* corner_keys,
                               const uint64_t* edge_keys, const float* edge_angles, int max_n_features, double* px,
                               double* score, int32_t* level, double* grad, uint8_t* type, int32_t* n_features);

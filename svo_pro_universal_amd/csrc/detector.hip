@@ -469,17 +469,17 @@ try {
   return SVOH_OK;
 } SVOH_ABI_CATCH(nullptr)
 
-extern "C" int svoh_detect_cells_batch(svoh_ctx* ctx, int n_frames, const svoh_frame_t* frames, const svoh_detector_options* options,
-                                       const uint8_t* occupancy, uint64_t* corner_keys, uint64_t* edge_keys, float* edge_angles)
-try {
+// the device half queued, nothing waited for: what comes back stands in ctx->h_detect behind ctx->ev_detect
+static int enqueue_detect_cells(svoh_ctx* ctx, int n_frames, const svoh_frame_t* frames, const svoh_detector_options* options, const uint8_t* occupancy)
+{
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
-  SVOH_REQUIRE(ctx, n_frames >= 1 && n_frames <= 4096 && frames && options && corner_keys, "bad arguments");
+  SVOH_REQUIRE(ctx, n_frames >= 1 && n_frames <= 4096 && frames && options, "bad arguments");
+  SVOH_REQUIRE(ctx, !ctx->detect_pending.in_flight, "a detector batch is in flight: svoh_detect_cells_batch_collect first");
   const svoh_detector_options& opt = *options;
   SVOH_REQUIRE(ctx, opt.cell_size >= 1 && opt.min_level >= 0 && opt.max_level >= opt.min_level && opt.max_level < SVOH_MAX_LEVELS,
                "bad detector cell size / level range");
   SVOH_REQUIRE(ctx, opt.border >= 3, "detector border must be >= 3 (FAST circle radius; the reference's default is 8)");
   SVOH_REQUIRE(ctx, opt.threshold_primary >= 1.0 && opt.threshold_primary <= 254.0, "threshold_primary out of [1, 254]");
-  SVOH_REQUIRE(ctx, !opt.detect_edgelets || (edge_keys && edge_angles), "edgelets asked for without their output arrays");
   const Frame* f0 = find_frame(ctx, frames[0]);
   if (!f0) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frames[0]);
   const int w = f0->lv[0].w, h = f0->lv[0].h;
@@ -509,10 +509,11 @@ try {
   const size_t o_ek = o_ck + 8 * cell_stride * nf;
   const size_t o_ang = o_ek + 8 * cell_stride * nf;
   const size_t o_map = (o_ang + 4 * cell_stride * nf + 255) & ~(size_t)255;
-  SVOH_HIP_TRY(ctx, ctx->d_scratch2.reserve(o_map + map_bytes * nf));
-  SVOH_HIP_TRY(ctx, ctx->h_scratch1.reserve(o_map));
-  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch2.ptr);
-  uint8_t* hs = static_cast<uint8_t*>(ctx->h_scratch1.ptr);
+  // (blocks of the detector's own: between the two halves the caller may make any other call of the context)
+  SVOH_HIP_TRY(ctx, ctx->d_detect.reserve(o_map + map_bytes * nf));
+  SVOH_HIP_TRY(ctx, ctx->h_detect.reserve(o_map));
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_detect.ptr);
+  uint8_t* hs = static_cast<uint8_t*>(ctx->h_detect.ptr);
   DevImage* tab = reinterpret_cast<DevImage*>(hs);
   for (int l = 0; l < n_lv; ++l)
     for (int i = 0; i < n_frames; ++i) tab[(size_t)l * nf + i] = l < fr[(size_t)i]->n_levels ? fr[(size_t)i]->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
@@ -554,13 +555,52 @@ try {
   if (ctx->timing_on()) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, ctx->stream));
   ctx->misc_timed = ctx->timing_on(); ctx->misc_launched = true;
   SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, hs + o_ck, d + o_ck, (opt.detect_edgelets ? o_map : o_ek) - o_ck));
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < n_frames; ++i) {
-    memcpy(corner_keys + (size_t)i * n_cells, hs + o_ck + 8 * cell_stride * (size_t)i, 8 * (size_t)n_cells);
-    if (opt.detect_edgelets) {
-      memcpy(edge_keys + (size_t)i * n_cells, hs + o_ek + 8 * cell_stride * (size_t)i, 8 * (size_t)n_cells);
-      memcpy(edge_angles + (size_t)i * n_cells, hs + o_ang + 4 * cell_stride * (size_t)i, 4 * (size_t)n_cells);
+  if (!ctx->ev_detect) SVOH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_detect, hipEventDisableTiming));
+  SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_detect, ctx->stream));
+  svoh_ctx::DetectPending& dp = ctx->detect_pending;
+  dp.in_flight = true; dp.n_frames = n_frames; dp.n_cells = n_cells; dp.cell_stride = cell_stride; dp.o_ck = o_ck; dp.o_ek = o_ek; dp.o_ang = o_ang;
+  dp.edgelets = opt.detect_edgelets != 0;
+  return SVOH_OK;
+}
+
+// waits for the batch in flight -- for ITS results, not for what was queued behind it -- and hands them out
+static int collect_detect_cells(svoh_ctx* ctx, uint64_t* corner_keys, uint64_t* edge_keys, float* edge_angles)
+{
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  svoh_ctx::DetectPending& dp = ctx->detect_pending;
+  SVOH_REQUIRE(ctx, dp.in_flight, "no detector batch in flight");
+  SVOH_REQUIRE(ctx, corner_keys && (!dp.edgelets || (edge_keys && edge_angles)), "NULL output array (edgelets were asked for: all three)");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_detect));
+  dp.in_flight = false;
+  const uint8_t* hs = static_cast<const uint8_t*>(ctx->h_detect.ptr);
+  const size_t n_cells = (size_t)dp.n_cells;
+  for (int i = 0; i < dp.n_frames; ++i) {
+    memcpy(corner_keys + (size_t)i * n_cells, hs + dp.o_ck + 8 * dp.cell_stride * (size_t)i, 8 * n_cells);
+    if (dp.edgelets) {
+      memcpy(edge_keys + (size_t)i * n_cells, hs + dp.o_ek + 8 * dp.cell_stride * (size_t)i, 8 * n_cells);
+      memcpy(edge_angles + (size_t)i * n_cells, hs + dp.o_ang + 4 * dp.cell_stride * (size_t)i, 4 * n_cells);
     }
   }
   return SVOH_OK;
+}
+
+extern "C" int svoh_detect_cells_batch_enqueue(svoh_ctx* ctx, int n_frames, const svoh_frame_t* frames, const svoh_detector_options* options, const uint8_t* occupancy)
+try {
+  return enqueue_detect_cells(ctx, n_frames, frames, options, occupancy);
+} SVOH_ABI_CATCH(ctx)
+
+extern "C" int svoh_detect_cells_batch_collect(svoh_ctx* ctx, uint64_t* corner_keys, uint64_t* edge_keys, float* edge_angles)
+try {
+  return collect_detect_cells(ctx, corner_keys, edge_keys, edge_angles);
+} SVOH_ABI_CATCH(ctx)
+
+extern "C" int svoh_detect_cells_batch(svoh_ctx* ctx, int n_frames, const svoh_frame_t* frames, const svoh_detector_options* options,
+                                       const uint8_t* occupancy, uint64_t* corner_keys, uint64_t* edge_keys, float* edge_angles)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, corner_keys && options && (!options->detect_edgelets || (edge_keys && edge_angles)), "NULL output array (edgelets asked for: all three)");
+  const int rc = enqueue_detect_cells(ctx, n_frames, frames, options, occupancy);
+  if (rc != SVOH_OK) return rc;
+  return collect_detect_cells(ctx, corner_keys, edge_keys, edge_angles);
 } SVOH_ABI_CATCH(ctx)

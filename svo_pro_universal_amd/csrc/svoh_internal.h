@@ -297,6 +297,12 @@ struct svoh_ctx {
   void* seed_hist_ptr = nullptr;       // the binning histogram at this address ...
   size_t seed_hist_clean_keys = 0;     // ... is known to be zero for this many keys (its last pass clears it)
 
+  // svoh_detect_cells_batch_enqueue / _collect: the batch in flight, its blocks, the event behind its results
+  struct DetectPending { bool in_flight = false, edgelets = false; int n_frames = 0, n_cells = 0; size_t cell_stride = 0, o_ck = 0, o_ek = 0, o_ang = 0; } detect_pending;
+  svoh::DevBuffer d_detect;
+  svoh::PinnedBuffer h_detect;
+  hipEvent_t ev_detect = nullptr;
+
   // generic scratch for the other paths
   svoh::DevBuffer d_scratch0, d_scratch1, d_scratch2;
   svoh::PinnedBuffer h_scratch0, h_scratch1;

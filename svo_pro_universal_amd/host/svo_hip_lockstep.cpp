@@ -4,6 +4,7 @@
 #include <pthread.h>
 #include <sched.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -100,6 +101,7 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
   // on one device and NOT the default: 23.7 / 24.3 k frames/s against 25.6 / 23.3 k with the library's own policy
   // (profiles/r05_copy_policy_ab.txt) -- the mixed-dispatch ceiling of tools/svoh_dispatch_rate is not what the groups run into.
   if (getenv("SVOH_LOCKSTEP_RESIDENT")) opt_.resident_features = atoi(getenv("SVOH_LOCKSTEP_RESIDENT")) != 0;   // (A/B)
+  detect_ahead_ = getenv("SVOH_LOCKSTEP_DETECT_AHEAD") == nullptr || atoi(getenv("SVOH_LOCKSTEP_DETECT_AHEAD")) != 0;   // (A/B)
   // SVOH_LOCKSTEP_POSE_CHAIN=0: the depth filter's batch is queued after the host has seen the poses, as in the first version
   pose_chain_ = getenv("SVOH_LOCKSTEP_POSE_CHAIN") == nullptr || atoi(getenv("SVOH_LOCKSTEP_POSE_CHAIN")) != 0;
   if (getenv("SVOH_LOCKSTEP_COPY_POLICY")) check(svoh_set_copy_policy(ctx_, atoi(getenv("SVOH_LOCKSTEP_COPY_POLICY"))), "svoh_set_copy_policy");
@@ -195,39 +197,80 @@ void FrontendLockstep::finishSeedUpdate()
   });
 }
 
-// make_keyframe of the harness for the streams in `which` (their current frame): the detector on every frame in ONE
-// device round trip, then initializeSeeds' second half, the self references of the new seeds, the keyframe window.
-void FrontendLockstep::makeKeyframes(const std::vector<int>& which)
+// make_keyframe of the harness in three steps, so that the detector's device work can run ahead of the pose optimisation:
+//   startDetection(which)   the occupancy grids of the streams' current frames (pool), the detector on every frame that still has
+//                           room for seeds ("Skip seed initialization" otherwise) queued in ONE device call, nothing waited for;
+//                           what it reads -- the frames' pyramids and the features the reprojection left -- is final after the
+//                           replay (the pose optimiser flags outliers, it removes nothing);
+//   makeKeyframes(which)    collects the detection (or runs it now, for streams nobody started it for), then initializeSeeds'
+//                           second half, the self references of the new seeds, the keyframe window, the resident columns.
+void FrontendLockstep::startDetection(const std::vector<int>& which)
 {
+  detect_ = DetectBatch();
   if (which.empty()) return;
   const size_t n_cells = streams_[0]->detector.grid_.size();
-  std::vector<int> detect;   // the streams whose keyframe still has room for seeds ("Skip seed initialization" otherwise)
   for (int s : which) {
     Stream& st = *streams_[static_cast<size_t>(s)];
-    st.detector.resetGrid();
-    st.detector.fillGridWithKeypoints(st.frame->px_vec_, st.frame->num_features_);
     st.detect_max_n = opt_.params.max_n_seeds_per_frame - static_cast<int>(st.frame->num_features_);
     st.detect_slot = -1;
-    if (st.detect_max_n > 0) { st.detect_slot = static_cast<int>(detect.size()); detect.push_back(s); }
+    if (st.detect_max_n > 0) { st.detect_slot = static_cast<int>(detect_.streams.size()); detect_.streams.push_back(s); }
   }
-  std::vector<uint64_t> ckeys, ekeys;
-  std::vector<float> angles;
-  if (!detect.empty()) {
-    const size_t n = detect.size();
-    std::vector<svoh_frame_t> frames(n);
-    std::vector<uint8_t> occ(n * n_cells);
-    for (size_t i = 0; i < n; ++i) {
-      Stream& st = *streams_[static_cast<size_t>(detect[i])];
-      frames[i] = st.frame->pyramid;
-      st.detector.occupancyBytes(occ.data() + i * n_cells);
-    }
-    ckeys.resize(n * n_cells); ekeys.resize(n * n_cells); angles.resize(n * n_cells);
-    const svoh_detector_options dopt = streams_[0]->detector.abiOptions();
+  detect_.started_for = which;
+  const size_t n = detect_.streams.size();
+  detect_.occ.resize(n * n_cells);
+  pool_.run(static_cast<int>(which.size()), [&](int w) {
+    Stream& st = *streams_[static_cast<size_t>(which[static_cast<size_t>(w)])];
+    st.detector.resetGrid();
+    st.detector.fillGridWithKeypoints(st.frame->px_vec_, st.frame->num_features_);
+    if (st.detect_slot >= 0) st.detector.occupancyBytes(detect_.occ.data() + static_cast<size_t>(st.detect_slot) * n_cells);
+  });
+  if (n == 0) return;
+  std::vector<svoh_frame_t> frames(n);
+  for (size_t i = 0; i < n; ++i) frames[i] = streams_[static_cast<size_t>(detect_.streams[i])]->frame->pyramid;
+  const svoh_detector_options dopt = streams_[0]->detector.abiOptions();
+  check(svoh_detect_cells_batch_enqueue(ctx_, static_cast<int>(n), frames.data(), &dopt, detect_.occ.data()), "svoh_detect_cells_batch_enqueue");
+  ++device_calls_;
+  detect_.in_flight = true;
+}
+
+void FrontendLockstep::makeKeyframes(const std::vector<int>& which)
+{
+  if (which.empty()) {
+    if (detect_.in_flight) { detect_.in_flight = false; (void)svoh_detect_cells_batch_collect(ctx_, nullptr, nullptr, nullptr); }   // (cannot happen: started for a subset of `which`)
+    return;
+  }
+  const size_t n_cells = streams_[0]->detector.grid_.size();
+  // streams whose detection was not started ahead (the tracked-features rule fired after the pose optimisation): now, blocking
+  std::vector<int> late;
+  for (int s : which) if (std::find(detect_.started_for.begin(), detect_.started_for.end(), s) == detect_.started_for.end()) late.push_back(s);
+  const size_t n_early = detect_.streams.size();
+  detect_.ckeys.resize(n_early * n_cells); detect_.ekeys.resize(n_early * n_cells); detect_.angles.resize(n_early * n_cells);
+  if (detect_.in_flight) {
     const double tw = now_ms();
-    check(svoh_detect_cells_batch(ctx_, static_cast<int>(n), frames.data(), &dopt, occ.data(), ckeys.data(), ekeys.data(), angles.data()), "svoh_detect_cells_batch");
+    detect_.in_flight = false;
+    check(svoh_detect_cells_batch_collect(ctx_, detect_.ckeys.data(), detect_.ekeys.data(), detect_.angles.data()), "svoh_detect_cells_batch_collect");
     phase_ms_[kPhDetectWait] += now_ms() - tw;   // (part of "keyframe")
-    ++device_calls_;
   }
+  if (!late.empty()) {
+    DetectBatch early;
+    std::swap(early, detect_);
+    startDetection(late);
+    // (slots of the late streams follow those of the early ones)
+    const size_t n_late = detect_.streams.size();
+    std::vector<uint64_t> ck(n_late * n_cells), ek(n_late * n_cells);
+    std::vector<float> an(n_late * n_cells);
+    if (detect_.in_flight) {
+      const double tw = now_ms();
+      detect_.in_flight = false;
+      check(svoh_detect_cells_batch_collect(ctx_, ck.data(), ek.data(), an.data()), "svoh_detect_cells_batch_collect");
+      phase_ms_[kPhDetectWait] += now_ms() - tw;
+    }
+    for (int s : detect_.streams) { Stream& st = *streams_[static_cast<size_t>(s)]; st.detect_slot += static_cast<int>(n_early); }
+    early.ckeys.insert(early.ckeys.end(), ck.begin(), ck.end()); early.ekeys.insert(early.ekeys.end(), ek.begin(), ek.end()); early.angles.insert(early.angles.end(), an.begin(), an.end());
+    std::swap(early, detect_);
+  }
+  const std::vector<uint64_t>&ckeys = detect_.ckeys, &ekeys = detect_.ekeys;
+  const std::vector<float>& angles = detect_.angles;
   pool_.run(static_cast<int>(which.size()), [&](int w) {
     Stream& st = *streams_[static_cast<size_t>(which[static_cast<size_t>(w)])];
     const FramePtr& f = st.frame;
@@ -252,6 +295,7 @@ void FrontendLockstep::makeKeyframes(const std::vector<int>& which)
       st.kfs.pop_front();
     }
   });
+  detect_ = DetectBatch();
   // the new keyframes' features are final now: their constant columns go to the device once, in one call
   if (opt_.resident_features) {
     const size_t m = which.size();
@@ -348,6 +392,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     if (!T_f_w_first) throw std::runtime_error("FrontendLockstep::addImages: the first frames need their poses");
     std::vector<int> all;
     for (int s = 0; s < S; ++s) { streams_[static_cast<size_t>(s)]->frame->T_f_w_ = T_f_w_first[s]; all.push_back(s); }
+    startDetection(all);
     makeKeyframes(all);
     for (auto& stp : streams_) {
       Stream& st = *stp;
@@ -563,6 +608,14 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   pc.lap(kPhReplay);
   const double t3 = now_ms();
   times_.reproject = t3 - t2;
+  // a round of periodic keyframes: their detector goes to the device now, ahead of the pose optimisation, and is long done when
+  // the keyframes are made (section 5) -- behind the depth filter's update it would be waited for
+  if (detect_ahead_ && round_ % opt_.kf_every == 0) {
+    std::vector<int> all;
+    for (int s = 0; s < S; ++s) all.push_back(s);
+    startDetection(all);
+    pc.lap(kPhKeyframe);
+  }
 
   // ---- 3 + 4. pose optimisation (frame_handler_base.cpp:746-790) and depth filter (frame_handler_mono.cpp:125): the bundles of all
   // streams in one launch, and BEHIND it on the device the seeds of every stream's keyframes into its new frame as ONE batch.  The

@@ -96,7 +96,17 @@ class FrontendLockstep {
  private:
   struct Stream;
   void finishSeedUpdate();
+  void startDetection(const std::vector<int>& which);
   void makeKeyframes(const std::vector<int>& which);
+  // the detector batch of the round's new keyframes between its two halves
+  struct DetectBatch {
+    std::vector<int> started_for, streams;   // the streams it was started for; those among them whose frame has room for seeds (slot order)
+    std::vector<uint8_t> occ;
+    std::vector<uint64_t> ckeys, ekeys;
+    std::vector<float> angles;
+    bool in_flight = false;
+  } detect_;
+  bool detect_ahead_ = true;
   void drainReleases();
   void check(int rc, const char* what) const;
 
