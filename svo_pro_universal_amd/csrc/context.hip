@@ -807,6 +807,7 @@ try {
   // (no wait: batches queued before this call may still read the block; whoever gets it from the pool writes it on the
   // context's stream, behind them -- or hipFree waits for the device by itself)
   ctx->feature_sets.erase(it);
+  ++ctx->handle_generation;
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 
@@ -907,6 +908,7 @@ try {
   // pool -- the next frame is then written on the context's stream, behind those kernels -- or is freed by hipFree,
   // which waits for the device by itself.
   ctx->frames.erase(it);
+  ++ctx->handle_generation;
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 

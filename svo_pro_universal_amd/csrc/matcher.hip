@@ -3437,21 +3437,45 @@ static int run_matcher_staged(svoh_ctx* ctx, bool seeds, const svoh_matcher_opti
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   DevFrameView* views = reinterpret_cast<DevFrameView*>(h + st.o_views);
   int ref_levels = 0, max_w = 1, max_h = 1;
-  for (int k = 0; k < n_ref_frames; ++k) {
-    const int rc = fill_view(ctx, ref_frames[k], &views[k], "reference frame");
-    if (rc != SVOH_OK) return rc;
-    ref_levels = views[k].n_levels > ref_levels ? views[k].n_levels : ref_levels;
-    max_w = views[k].lv[0].w > max_w ? views[k].lv[0].w : max_w; max_h = views[k].lv[0].h > max_h ? views[k].lv[0].h : max_h;
-    SVOH_REQUIRE(ctx, !st.resident || ref_frames[k].features != 0, "a reference frame of a batch with feature_index has no resident columns (svoh_frame_view::features)");
-  }
   bool pose_from_results = false;
-  for (int k = 0; k < n_cur; ++k) {
-    const int rc = fill_view(ctx, cur_frame[k], &views[n_ref_frames + k], "current frame", seeds && ctx->in_pose_hook);
-    if (rc != SVOH_OK) return rc;
-    SVOH_REQUIRE(ctx, views[n_ref_frames + k].n_levels >= ref_levels, "current frame has fewer pyramid levels than a reference frame");
-    const int pr = views[n_ref_frames + k].pose_result_index_plus1;
-    SVOH_REQUIRE(ctx, pr >= 0 && pr <= ctx->n_pose_results, "pose_result_index_plus1: the pose batch in flight has no such result");
-    pose_from_results = pose_from_results || pr > 0;
+  // the same frames as the last staged batch asked for, none released since: that batch's table (a reprojection's direct and
+  // seed batch name the same keyframes and current frames; a table of 60 views is 10 us of look-ups on the caller's thread)
+  const size_t key_bytes = sizeof(svoh_frame_view) * (size_t)(n_ref_frames + n_cur);
+  bool reuse = ctx->staged_views_generation == ctx->handle_generation && ctx->staged_views_key.size() == key_bytes + sizeof(int) &&
+               memcmp(ctx->staged_views_key.data(), &n_ref_frames, sizeof(int)) == 0 &&
+               memcmp(ctx->staged_views_key.data() + sizeof(int), ref_frames, sizeof(svoh_frame_view) * (size_t)n_ref_frames) == 0 &&
+               memcmp(ctx->staged_views_key.data() + sizeof(int) + sizeof(svoh_frame_view) * (size_t)n_ref_frames, cur_frame, sizeof(svoh_frame_view) * (size_t)n_cur) == 0;
+  for (int k = 0; k < n_cur && reuse; ++k) reuse = cur_frame[k].pose_result_index_plus1 == 0;   // (those go through the checks below)
+  if (reuse) {
+    memcpy(views, ctx->staged_views_resolved.data(), sizeof(DevFrameView) * (size_t)(n_ref_frames + n_cur));
+    ref_levels = ctx->staged_views_ref_levels; max_w = ctx->staged_views_max_w; max_h = ctx->staged_views_max_h;
+    if (st.resident) for (int k = 0; k < n_ref_frames; ++k) SVOH_REQUIRE(ctx, ref_frames[k].features != 0, "a reference frame of a batch with feature_index has no resident columns (svoh_frame_view::features)");
+  } else {
+    for (int k = 0; k < n_ref_frames; ++k) {
+      const int rc = fill_view(ctx, ref_frames[k], &views[k], "reference frame");
+      if (rc != SVOH_OK) return rc;
+      ref_levels = views[k].n_levels > ref_levels ? views[k].n_levels : ref_levels;
+      max_w = views[k].lv[0].w > max_w ? views[k].lv[0].w : max_w; max_h = views[k].lv[0].h > max_h ? views[k].lv[0].h : max_h;
+      SVOH_REQUIRE(ctx, !st.resident || ref_frames[k].features != 0, "a reference frame of a batch with feature_index has no resident columns (svoh_frame_view::features)");
+    }
+    for (int k = 0; k < n_cur; ++k) {
+      const int rc = fill_view(ctx, cur_frame[k], &views[n_ref_frames + k], "current frame", seeds && ctx->in_pose_hook);
+      if (rc != SVOH_OK) return rc;
+      SVOH_REQUIRE(ctx, views[n_ref_frames + k].n_levels >= ref_levels, "current frame has fewer pyramid levels than a reference frame");
+      const int pr = views[n_ref_frames + k].pose_result_index_plus1;
+      SVOH_REQUIRE(ctx, pr >= 0 && pr <= ctx->n_pose_results, "pose_result_index_plus1: the pose batch in flight has no such result");
+      pose_from_results = pose_from_results || pr > 0;
+    }
+    ctx->staged_views_generation = ~0ull;
+    if (!pose_from_results) {
+      ctx->staged_views_key.resize(key_bytes + sizeof(int));
+      memcpy(ctx->staged_views_key.data(), &n_ref_frames, sizeof(int));
+      memcpy(ctx->staged_views_key.data() + sizeof(int), ref_frames, sizeof(svoh_frame_view) * (size_t)n_ref_frames);
+      memcpy(ctx->staged_views_key.data() + sizeof(int) + sizeof(svoh_frame_view) * (size_t)n_ref_frames, cur_frame, sizeof(svoh_frame_view) * (size_t)n_cur);
+      ctx->staged_views_resolved.assign(reinterpret_cast<const uint8_t*>(views), reinterpret_cast<const uint8_t*>(views) + sizeof(DevFrameView) * (size_t)(n_ref_frames + n_cur));
+      ctx->staged_views_ref_levels = ref_levels; ctx->staged_views_max_w = max_w; ctx->staged_views_max_h = max_h;
+      ctx->staged_views_generation = ctx->handle_generation;
+    }
   }
   ctx->matcher_deferred_used[kind] = true;
   st.valid = false;   // consumed: the outputs stay readable, a second batch needs a new svoh_matcher_stage

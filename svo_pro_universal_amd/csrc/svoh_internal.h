@@ -185,6 +185,9 @@ struct svoh_ctx {
   std::shared_ptr<svoh::SlabPool> slab_pool = std::make_shared<svoh::SlabPool>();   // declared before `frames`: outlives them
   std::unordered_map<uint64_t, svoh::Frame> frames;
   uint64_t next_frame_id = 1;
+  // bumped whenever a frame or a feature set is released: what was derived from handles before (the staged batches' view
+  // tables, matcher.hip) must be looked up again
+  uint64_t handle_generation = 0;
   // resident feature columns (svoh_features_upload)
   std::shared_ptr<svoh::BlockPool> feature_pool = std::make_shared<svoh::BlockPool>();   // declared before the sets: outlives them
   std::unordered_map<uint64_t, svoh::FeatureSet> feature_sets;
@@ -297,6 +300,10 @@ struct svoh_ctx {
   void* seed_hist_ptr = nullptr;       // the binning histogram at this address ...
   size_t seed_hist_clean_keys = 0;     // ... is known to be zero for this many keys (its last pass clears it)
 
+  // the frame views of the last staged matcher batch as they were asked for (bytes of the svoh_frame_view arrays) and as they were
+  // resolved: a direct batch and a seed batch of one reprojection name the same frames, the second one copies the table
+  std::vector<uint8_t> staged_views_key; std::vector<uint8_t> staged_views_resolved; uint64_t staged_views_generation = ~0ull;
+  int staged_views_ref_levels = 0, staged_views_max_w = 1, staged_views_max_h = 1;
   // svoh_detect_cells_batch_enqueue / _collect: the batch in flight, its blocks, the event behind its results
   struct DetectPending { bool in_flight = false, edgelets = false; int n_frames = 0, n_cells = 0; size_t cell_stride = 0, o_ck = 0, o_ek = 0, o_ang = 0; } detect_pending;
   svoh::DevBuffer d_detect;
