@@ -744,7 +744,7 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
 
     def shape(S):   # groups and threads per group out of the rank's host-thread budget
         G = 1 if S < 8 else min(4 if S >= 64 else 3 if S >= 24 else 2, budget)
-        return G, max(1, budget // G)
+        return G, max(1, min(budget // G, -(-S // G)))   # (no more threads than a group has streams)
 
     S = args.streams
     G, W = (args.stream_groups, args.stream_workers) if args.stream_groups and args.stream_workers else shape(S)
