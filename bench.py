@@ -757,7 +757,7 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
                 sweep.append({k: main_run[k] for k in ("streams", "groups", "host_threads_per_group", "frames_per_s", "ms_per_round")})
                 continue
             g2, w2 = shape(s2)
-            r2, _ = run(s2, g2, w2, 3, min(args.steps, 80))
+            r2, _ = run(s2, g2, w2, max(3, args.warmup), args.steps)   # (as long as the main run: the map of a short run is still filling)
             sweep.append({k: r2[k] for k in ("streams", "groups", "host_threads_per_group", "frames_per_s", "ms_per_round")})
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
