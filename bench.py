@@ -674,7 +674,13 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         # SVOH_LOCKSTEP_SHARED=1: the groups' host phases on ONE set of worker threads (G group threads + G * (W - 1) shared workers = G * W threads in
         # all, as with a pool per group: SVOH_LOCKSTEP_SHARED=0), so that a group's phase finds the workers another group's device
         # wait leaves idle
-        shared = ls.SharedPool(G * (W - 1)) if G > 1 and W > 1 and os.environ.get("SVOH_LOCKSTEP_SHARED", "0") != "0" else None
+        # SVOH_LOCKSTEP_SHARED=2: ONE pool of G * W - G + 1 threads taken by the groups in turns, a phase at a time (ExclusivePool)
+        mode = os.environ.get("SVOH_LOCKSTEP_SHARED", "0")
+        shared = None
+        if G > 1 and W > 1 and mode == "2":
+            shared = ls.SharedPool(G * W - G + 1, exclusive=True)
+        elif G > 1 and W > 1 and mode != "0":
+            shared = ls.SharedPool(G * (W - 1))
         engines = [ls.Lockstep(c, hi - lo, cam, np.array([1.0, 0, 0, 0, 0, 0, 0]), params, 0.5 * depth, depth, 2.0 * depth, 8, W, True, pool=shared, seed=lo)
                    for c, (lo, hi) in zip(ctxs, ranges)]
         first = poses[0].inverse().as7()

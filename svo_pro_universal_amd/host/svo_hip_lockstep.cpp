@@ -93,7 +93,8 @@ void FrontendLockstep::check(int rc, const char* what) const
 FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepOptions& options)
     : ctx_(ctx), opt_(options)
 {
-  if (opt_.shared_pool) { pool_.shared = opt_.shared_pool; pool_.seed = opt_.shared_pool_seed; }
+  if (opt_.exclusive_pool) pool_.exclusive = opt_.exclusive_pool;
+  else if (opt_.shared_pool) { pool_.shared = opt_.shared_pool; pool_.seed = opt_.shared_pool_seed; }
   else pool_.own.reset(new WorkerPool(options.n_workers < 1 ? 1 : options.n_workers, options.pin_workers));
   if (!ctx_) throw std::runtime_error("FrontendLockstep: NULL svoh_ctx (no CPU fallback exists)");
   if (n_streams < 1 || n_streams > 256) throw std::runtime_error("FrontendLockstep: n_streams out of range [1, 256]");
@@ -778,7 +779,7 @@ int svohl_guard(F&& f)
 }
 }  // namespace
 
-struct svohl_pool { std::shared_ptr<svo_hip::SharedPool> pool; };
+struct svohl_pool { std::shared_ptr<svo_hip::SharedPool> pool; std::shared_ptr<svo_hip::ExclusivePool> exclusive; };
 
 extern "C" {
 
@@ -790,6 +791,16 @@ int svohl_pool_create(int n_workers, svohl_pool** out)
     if (!out || n_workers < 1 || n_workers > 1024) throw std::runtime_error("svohl_pool_create: bad arguments");
     std::unique_ptr<svohl_pool> p(new svohl_pool);
     p->pool.reset(new svo_hip::SharedPool(n_workers));
+    *out = p.release();
+  });
+}
+
+int svohl_pool_create_exclusive(int n_threads, svohl_pool** out)
+{
+  return svohl_guard([&] {
+    if (!out || n_threads < 1 || n_threads > 1024) throw std::runtime_error("svohl_pool_create_exclusive: bad arguments");
+    std::unique_ptr<svohl_pool> p(new svohl_pool);
+    p->exclusive.reset(new svo_hip::ExclusivePool(n_threads));
     *out = p.release();
   });
 }
@@ -819,7 +830,7 @@ static int svohl_create_impl(svoh_ctx* ctx, int n_streams, const svoh_camera* ca
     if (!out || !cam || !T_B_C) throw std::runtime_error("svohl_create: NULL argument");
     *out = nullptr;
     svo_hip::LockstepOptions lo;
-    if (pool) { lo.shared_pool = pool->pool; lo.shared_pool_seed = seed; }
+    if (pool) { lo.shared_pool = pool->pool; lo.shared_pool_seed = seed; lo.exclusive_pool = pool->exclusive; }
     lo.params = svo_hip::io::frontendParamsFromYaml(params_yaml ? svo_hip::io::parseYaml(params_yaml) : svo_hip::io::YamlNode());
     lo.cam = *cam;
     lo.T_B_C = svoh::load_rigid(*T_B_C);

@@ -52,6 +52,8 @@ struct LockstepOptions {
   // engine per lock-step group); item i of this engine prefers worker (i + shared_pool_seed) % workers
   std::shared_ptr<SharedPool> shared_pool;
   int shared_pool_seed = 0;
+  // ... or one pool that the engines take in turns, a phase at a time (ExclusivePool)
+  std::shared_ptr<ExclusivePool> exclusive_pool;
   bool pin_workers = false;                                   // bind them to CPUs of their own (WorkerPool)
   int images_mem_space = SVOH_MEM_HOST;                       // SVOH_MEM_HOST_PINNED: images live in svoh_host_alloc memory
   // a keyframe's constant feature columns are uploaded once (svoh_features_upload); the matcher and depth-filter batches of
@@ -114,8 +116,14 @@ class FrontendLockstep {
   struct Runner {
     std::unique_ptr<WorkerPool> own;
     std::shared_ptr<SharedPool> shared;
+    std::shared_ptr<ExclusivePool> exclusive;
     int seed = 0;
-    void run(int n_items, const std::function<void(int)>& fn) { if (shared) shared->run(n_items, fn, seed); else own->run(n_items, fn); }
+    void run(int n_items, const std::function<void(int)>& fn)
+    {
+      if (exclusive) exclusive->run(n_items, fn);
+      else if (shared) shared->run(n_items, fn, seed);
+      else own->run(n_items, fn);
+    }
   };
   svoh_ctx* ctx_;
   LockstepOptions opt_;

@@ -17,6 +17,9 @@ typedef struct svohl_pool svohl_pool;
 /* worker threads shared by several engines (SharedPool, svo_hip_pool.h): pass the pool and a seed (the engine's first
  * stream index) to svohl_create_shared; destroy the pool after its engines */
 int svohl_pool_create(int n_workers, svohl_pool** out);
+/* ... or ONE pool of n_threads (the calling group's thread counts as one of them) that the engines take in turns, a phase
+ * at a time (ExclusivePool): pass it to svohl_create_shared like the other kind */
+int svohl_pool_create_exclusive(int n_threads, svohl_pool** out);
 void svohl_pool_destroy(svohl_pool* p);
 
 /* params_yaml: the reference's parameter file as text (the keys of svo_factory.cpp this library implements; NULL = the

@@ -46,6 +46,29 @@ class WorkerPool {
 };
 
 
+// ONE WorkerPool for several lock-step groups, one phase at a time: a group's thread takes the whole pool for its phase (every
+// stream of the phase on a thread of its own instead of two or three streams per thread of a pool a third the size) and gives
+// it back before it talks to the device or waits for it.  Unlike SharedPool below nothing runs side by side inside the pool:
+// item i is always on thread i % size(), whoever the caller -- the callers take turns as thread 0.
+class ExclusivePool {
+ public:
+  explicit ExclusivePool(int n_threads) : pool_(n_threads) {}
+  int size() const { return pool_.size(); }
+  void run(int n_items, const std::function<void(int)>& fn)
+  {
+    struct Turn {
+      std::atomic_flag& f;
+      explicit Turn(std::atomic_flag& flag) : f(flag) { while (f.test_and_set(std::memory_order_acquire)) std::this_thread::yield(); }
+      ~Turn() { f.clear(std::memory_order_release); }
+    } turn(busy_);
+    pool_.run(n_items, fn);
+  }
+
+ private:
+  WorkerPool pool_;
+  std::atomic_flag busy_ = ATOMIC_FLAG_INIT;
+};
+
 // One set of worker threads for SEVERAL lock-step groups.  A group's thread is busy with its context's serial work and
 // waits for the device a third of the time; with a pool of its own its workers idle through all of that.  Here every
 // group's phases draw on the same workers: a phase of 8 items finds up to all of them free and takes a stream's time

@@ -25,6 +25,7 @@ def load_host():
     lib.svohl_create.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_camera), P(capi.svoh_se3), C.c_char_p, C.c_double, C.c_double, C.c_double,
                                  C.c_int, C.c_int, C.c_int, P(C.c_void_p)]
     lib.svohl_pool_create.argtypes = [C.c_int, P(C.c_void_p)]
+    lib.svohl_pool_create_exclusive.argtypes = [C.c_int, P(C.c_void_p)]
     lib.svohl_pool_destroy.argtypes = [C.c_void_p]
     lib.svohl_pool_destroy.restype = None
     lib.svohl_create_shared.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_camera), P(capi.svoh_se3), C.c_char_p, C.c_double, C.c_double, C.c_double,
@@ -78,10 +79,12 @@ class PinnedImages(object):
 class SharedPool(object):
     """Worker threads that several Lockstep engines draw on (host/svo_hip_pool.h: SharedPool)."""
 
-    def __init__(self, n_workers):
+    def __init__(self, n_workers, exclusive=False):
+        """exclusive: ONE pool of n_workers threads (a calling group's thread counts as one) taken by the groups in turns, a phase at a
+        time (ExclusivePool) instead of workers that serve several groups' phases side by side."""
         self.lib = load_host()
         h = C.c_void_p()
-        if self.lib.svohl_pool_create(int(n_workers), C.byref(h)) != 0:
+        if (self.lib.svohl_pool_create_exclusive if exclusive else self.lib.svohl_pool_create)(int(n_workers), C.byref(h)) != 0:
             raise RuntimeError(self.lib.svohl_last_error().decode())
         self.h = h
 

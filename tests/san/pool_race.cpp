@@ -1,6 +1,6 @@
 // pool_race.cpp -- WorkerPool (host/svo_hip_pool.h) under ThreadSanitizer: the host phases of the lock-step front end are
 // back-to-back runs of a few microseconds each, with items that write neighbouring slots of shared arrays, pools of
-// several groups side by side, phases with fewer items than threads, exceptions out of items, idle threads that have
+// several groups side by side (pools of their own, a SharedPool, an ExclusivePool taken in turns), phases with fewer items than threads, exceptions out of items, idle threads that have
 // gone to sleep.  No device call.  Prints "ok" and exits 0; ThreadSanitizer makes the exit code non-zero on a report.
 #include <atomic>
 #include <chrono>
@@ -59,6 +59,27 @@ static void shared_group(svo_hip::SharedPool* pool, int seed, int n_rounds, long
   *checksum = total;
 }
 
+// ... and by several callers that take ONE ExclusivePool in turns, a phase at a time
+static void exclusive_group(svo_hip::ExclusivePool* pool, int n_rounds, long* checksum)
+{
+  std::vector<long> slots(67, 0), sums(67, 0);
+  long total = 0;
+  for (int r = 0; r < n_rounds; ++r) {
+    const int n = 1 + (r * 7) % 67;
+    pool->run(n, [&](int i) { slots[(size_t)i] = (long)r * 1000 + i; });
+    pool->run(n, [&](int i) { sums[(size_t)i] = slots[(size_t)i] + slots[(size_t)((i + 1) % n)]; });
+    for (int i = 0; i < n; ++i) total += sums[(size_t)i];
+    if (r % 97 == 0) std::this_thread::sleep_for(std::chrono::milliseconds(3));
+    if (r % 53 == 0) {
+      bool caught = false;
+      try { pool->run(n, [&](int i) { if (i == n / 2) throw std::runtime_error("item"); slots[(size_t)i] = -1; }); }
+      catch (const std::runtime_error&) { caught = true; }
+      if (!caught) { fprintf(stderr, "exception lost\n"); abort(); }
+    }
+  }
+  *checksum = total;
+}
+
 int main(int argc, char** argv)
 {
   const int n_rounds = argc > 1 ? atoi(argv[1]) : 3000;
@@ -75,6 +96,13 @@ int main(int argc, char** argv)
     shared_group(&shared, 16, n_rounds, &g);
     s1.join(); s2.join();
   }
+  long x1 = 0, x2 = 0, x3 = 0;
+  {
+    svo_hip::ExclusivePool excl(5);
+    std::thread t1(exclusive_group, &excl, n_rounds, &x1), t2(exclusive_group, &excl, n_rounds, &x2);
+    exclusive_group(&excl, n_rounds, &x3);
+    t1.join(); t2.join();
+  }
   // the same arithmetic without threads
   auto expect = [](int n_rounds_) {
     long total = 0;
@@ -87,6 +115,7 @@ int main(int argc, char** argv)
   // (after a throwing round the slots of that round hold -1 or the old value, but phase 1 of the next round rewrites every slot it reads)
   if (a != expect(n_rounds) || b != expect(n_rounds) || c != expect(n_rounds) || d != expect(200)) { fprintf(stderr, "checksum mismatch\n"); return 1; }
   if (e != expect(n_rounds) || f != expect(n_rounds) || g != expect(n_rounds)) { fprintf(stderr, "checksum mismatch (shared pool)\n"); return 1; }
+  if (x1 != expect(n_rounds) || x2 != expect(n_rounds) || x3 != expect(n_rounds)) { fprintf(stderr, "checksum mismatch (exclusive pool)\n"); return 1; }
   printf("ok\n");
   return 0;
 }
