@@ -161,3 +161,39 @@ def test_lockstep_streams_reproduce_the_single_stream(tmp_path):
             assert open(str(d / "trajectory.txt")).read() == single, "stream %d of %d (workers %d, groups %d)" % (k, n_streams, n_workers, n_groups)
             counters = np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :7]
             assert np.array_equal(counters, single_counters), "counters of stream %d of %d" % (k, n_streams)
+
+
+def test_lockstep_variants_and_the_tracked_features_rule(tmp_path):
+    """The lock-step engine's switches (explicit feature columns instead of resident ones, the depth filter's batch queued after
+    the host has applied the poses, the detector behind the depth filter's update) are re-orderings of the same arithmetic: same
+    files as the single stream.  And with no periodic keyframes at all (kf_every = 1000) every keyframe comes from the
+    tracked-features rule, which fires AFTER the pose optimisation -- the detector then cannot be started ahead and runs when
+    the keyframes are made."""
+    import os
+    cmd, out_dir, poses, stamps, n_frames = make_dataset(tmp_path)
+
+    def run(args, env=None):
+        for d in [out_dir] + [out_dir / ("stream%d" % k) for k in range(1, 8)]:
+            for name in ("trajectory.txt", "frontend.csv"):
+                if (d / name).exists():
+                    (d / name).unlink()
+        r = subprocess.run(cmd + args, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+        assert r.returncode == 0, r.stdout + r.stderr
+        n_streams = int(args[2])
+        out = []
+        for k in range(n_streams):
+            d = out_dir if k == 0 else out_dir / ("stream%d" % k)
+            out.append((open(str(d / "trajectory.txt")).read(), np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :7].copy()))
+        return out
+    for kf_every in ("8", "1000"):
+        # (without periodic keyframes the rule must fire: the sequence keeps all 180 features of a frame tracked, so the bar is 181 -- a keyframe per frame, each by the rule)
+        rule = {"SVOH_MINI_MIN_TRACKED": "181"} if kf_every == "1000" else {}
+        single = run([str(n_frames), kf_every, "1"], rule)[0]
+        if kf_every == "1000":
+            assert single[1][1:, 1].sum() >= 1, "the tracked-features rule never fired: the case tests nothing"
+        for env in ({}, {"SVOH_LOCKSTEP_RESIDENT": "0"}, {"SVOH_LOCKSTEP_POSE_CHAIN": "0"}, {"SVOH_LOCKSTEP_DETECT_AHEAD": "0"}):
+            if kf_every == "1000" and env:
+                continue
+            for traj, counters in run([str(n_frames), kf_every, "3", "lockstep", "2", "1"], dict(env, **rule)):
+                assert traj == single[0], (kf_every, env)
+                assert np.array_equal(counters, single[1]), (kf_every, env)

@@ -63,7 +63,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
                 float depth_max, size_t kf_every, std::atomic<int>* start_gate, int n_streams, StreamResult* out)
 {
   try {
-    const size_t min_tracked = 60;
+    const size_t min_tracked = getenv("SVOH_MINI_MIN_TRACKED") ? (size_t)atol(getenv("SVOH_MINI_MIN_TRACKED")) : 60;   // (tests raise it to make the rule fire)
     const bool sync_flow = getenv("SVOH_MINI_SYNC") != nullptr && atoi(getenv("SVOH_MINI_SYNC")) != 0;
     svoh_ctx* ctx = nullptr;
     if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
@@ -246,6 +246,7 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
       LockstepOptions lo;
       lo.params = params; lo.cam = rig.at(0).cam; lo.T_B_C = rig[0].T_B_C;
       lo.depth_min = depth_min; lo.depth_mean = depth_mean; lo.depth_max = depth_max; lo.kf_every = kf_every; lo.n_workers = n_workers;
+      if (getenv("SVOH_MINI_MIN_TRACKED")) lo.min_tracked = (size_t)atol(getenv("SVOH_MINI_MIN_TRACKED"));
       lo.images_mem_space = SVOH_MEM_HOST_PINNED;
       lo.shared_pool = g_shared_pool; lo.shared_pool_seed = s0;
       lo.pin_workers = getenv("SVOH_LOCKSTEP_PIN") != nullptr && atoi(getenv("SVOH_LOCKSTEP_PIN")) != 0;   // (a shared box: its low CPUs are everybody's)
