@@ -749,7 +749,7 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
                 "features_per_frame_median": float(np.median(rows[1:, 3])) if len(rows) > 1 else None}, elapsed
 
     def shape(S):   # groups and threads per group out of the rank's host-thread budget
-        G = 1 if S < 8 else min(4 if S >= 64 else 3 if S >= 24 else 2, budget)
+        G = 1 if S < 8 else min(4 if S >= 24 else 2, budget)   # (measured shapes: profiles/r05_lockstep_steps_ab.txt)
         return G, max(1, min(budget // G, -(-S // G)))   # (no more threads than a group has streams)
 
     S = args.streams
