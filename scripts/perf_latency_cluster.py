@@ -6,7 +6,7 @@ from svo_pro_universal_amd import _capi as capi, frontend as fe
 import bench
 ctx = fe.Context(0)
 ms = ctypes.c_float()
-for N in (180, 700, 1000, 2000, 4000, 8000, 20000):
+for N in [int(v) for v in os.environ.get("NS", "180,700,1000,2000,4000,8000,20000").split(",")]:
     problems, scenes, imgs, keep = bench.build_problems(ctx, torch.device("cuda", 0), 0, 1, N, 4, 4)
     for minl in (0, 2):
         opt = capi.default_align_options(min_level=minl)
@@ -16,7 +16,7 @@ for N in (180, 700, 1000, 2000, 4000, 8000, 20000):
             else: os.environ["SVOH_ALIGN_CLUSTER"] = g
             ctx.reload_knobs()
             ts = []; t0 = None
-            for i in range(8):
+            for i in range(int(os.environ.get("REPS", "8"))):
                 a = time.perf_counter(); res = ctx.sparse_align(opt, problems); b = time.perf_counter()
                 ctx.lib.svoh_sparse_align_last_kernel_ms(ctx.h, ctypes.byref(ms))
                 if i >= 2: ts.append((ms.value, (b - a) * 1e3))

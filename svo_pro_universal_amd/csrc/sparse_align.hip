@@ -637,6 +637,15 @@ __device__ __forceinline__ Rigid uniform_rigid(const Rigid& T)
 // box's run-to-run spread (1.19 - 1.23 ms all three builds).  The scalar loads hit the scalar cache and overlap the
 // wave's other work; what the stamps attributed to them was the stamps' own s_waitcnt(0).  Both stay compiled out
 // (SVOH_ALIGN_LDS_DESC=1 / SVOH_ALIGN_FOLD_VOTE=1 build them: same results, all tests green).
+// SVOH_ALIGN_CLUSTER_XCD: the shares of a clustered problem placed on workgroups that share an XCD.  Built, measured
+// (profiles/r05_align_cluster_xcd_ab.txt), compiled out: up to 8 shares per problem nothing changes (2000 patches 0.154 against
+// 0.155 ms), with 16 - 32 shares one XCD is SLOWER than the eight the dispatcher spreads them over (8000 patches, 32 shares:
+// 0.334 against 0.266 ms; 20000: 0.352 against 0.279) -- the shares' image reads and workspace rows then go through one L2 and
+// one fabric port instead of eight, which costs more than the exchange slots meeting in one L2 saves (74 doubles per share and
+// iteration).
+#ifndef SVOH_ALIGN_CLUSTER_XCD
+#define SVOH_ALIGN_CLUSTER_XCD 0
+#endif
 #ifndef SVOH_ALIGN_LDS_DESC
 #define SVOH_ALIGN_LDS_DESC 0
 #endif
@@ -1371,8 +1380,29 @@ void sparse_align_kernel(const AlignKernelArgs a)
   // Persistent workgroups: the grid is sized to what is resident at once and every
   // workgroup pulls the next problem index from a queue head, so problems that need
   // more Gauss-Newton iterations do not leave CUs idle at the end of the launch.
+#if SVOH_ALIGN_CLUSTER_XCD
+  bool first_pull = true;
+#endif
   for (;;) {
   __syncthreads();  // everyone is done with the previous problem's shared state
+#if SVOH_ALIGN_CLUSTER_XCD
+  // Cluster mode: a workgroup takes exactly one share, and WHICH one follows from its block index -- the shares of a problem go
+  // to blocks b, b + 8, b + 16, ..., which the dispatcher is observed to deal to ONE XCD (round robin over the eight: a label
+  // for speed, never for correctness): the shares' exchange slots and the images they all read then meet in one L2.  The
+  // launch's grid is 8 x cluster x ceil(problems / 8) blocks; blocks beyond the last problem leave at once.
+  if constexpr (CLUSTER) {
+    if (tid == 0) {
+      int v = a.n_problems;
+      if (first_pull) {
+        const int x = (int)(blockIdx.x & 7u), srow = (int)(blockIdx.x >> 3);
+        const int c = x + 8 * (srow / a.cluster);
+        if (c < a.n_problems / a.cluster) v = c * a.cluster + srow % a.cluster;
+      }
+      s_pbi = v;
+    }
+    first_pull = false;
+  } else
+#endif
   if (tid == 0) s_pbi = atomicAdd(a.queue, 1);
   __syncthreads();
   const int pbi = s_pbi;
@@ -2398,6 +2428,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   int grid = ctx->num_cus * SvohKnobs::or_default(ctx->knobs.align_wg_per_cu, nt == 256 ? 2 : 1);
   if (grid > n_desc || grid <= 0) grid = n_desc;
   if (cluster) grid = n_desc;
+#if SVOH_ALIGN_CLUSTER_XCD
+  if (cluster) grid = 8 * args.cluster * ((n_desc / args.cluster + 7) / 8);   // (see the kernel's pull)
+#endif
   hipError_t e;
   const bool timed = ctx->timing_on();
   const int ev_slot = (int)(ctx->align_timed_launches % svoh_ctx::kAlignEventRing);
