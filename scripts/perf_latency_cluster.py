@@ -11,7 +11,7 @@ for N in [int(v) for v in os.environ.get("NS", "180,700,1000,2000,4000,8000,2000
     for minl in (0, 2):
         opt = capi.default_align_options(min_level=minl)
         row = []
-        for g in ("0", "2", "4", "8", "16", "32", None):
+        for g in (os.environ.get("GS", "0,2,4,8,16,32").split(",") + [None]):
             if g is None: os.environ.pop("SVOH_ALIGN_CLUSTER", None)
             else: os.environ["SVOH_ALIGN_CLUSTER"] = g
             ctx.reload_knobs()

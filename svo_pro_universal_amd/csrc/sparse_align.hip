@@ -2004,7 +2004,6 @@ static hipError_t launch_nt(hipStream_t st, int nt, int lpp, int grid, size_t ld
 // cost more than the idle CUs; ~200 patches per workgroup is where the per-iteration time stops falling
 constexpr int kWsLdsMaxFeatures = 340;    // features of a problem whose workspace rows are kept in LDS (16 KB)
 constexpr int kClusterMinFeatures = 512;
-constexpr int kClusterFeaturesPerWorkgroup = 192;
 constexpr int kClusterMaxWorkgroups = 32;
 constexpr int kClusterMaxProblems = 64;   // arrival counters: one 32-bit word per problem in a 256-byte block
 
@@ -2072,7 +2071,20 @@ static int decide_cluster(const svoh_ctx* ctx, int n_problems, const svoh_align_
   int g = SvohKnobs::or_default(ctx->knobs.align_cluster, -1);
   // measured (scripts/perf_small_batch.py): up to 16 problems always gain; 32..64 only when each is large
   const bool worth = nf_min >= kClusterMinFeatures && (n_problems <= 16 || nf_min >= 3000);
-  if (g < 0) g = worth ? (int)((nf_max + kClusterFeaturesPerWorkgroup - 1) / kClusterFeaturesPerWorkgroup) : 0;
+  // workgroups per problem against its size, measured (profiles/r05_align_cluster_sweep.txt: one problem of 700 ... 20 000 patches,
+  // 2 ... 32 workgroups): about 250 patches per workgroup up to eight workgroups, eight up to 5 000 patches, then 12 / 16 / 20 --
+  // more workgroups than that pay more per exchange than their shorter passes save (the rule of rounds 2 - 4, one workgroup per 192
+  // patches up to 32, was 4 - 18 % slower between 1 000 and 20 000 patches)
+  auto workgroups_for = [](int64_t nf) {
+    if (nf < 875) return 3;
+    if (nf < 1250) return 4;
+    if (nf < 1750) return 6;
+    if (nf < 5000) return 8;
+    if (nf < 7000) return 12;
+    if (nf < 16000) return 16;
+    return 20;
+  };
+  if (g < 0) g = worth ? workgroups_for(nf_max) : 0;
   if (g > kClusterMaxWorkgroups) g = kClusterMaxWorkgroups;
   if ((int64_t)g * n_problems > ctx->num_cus) g = ctx->num_cus / n_problems;   // every workgroup on its own CU
   return g >= 2 ? g : 0;
