@@ -1371,8 +1371,8 @@ void sparse_align_kernel(const AlignKernelArgs a)
   static_assert(NACC <= 45, "g_sum is sized for the 8-parameter case");
   __shared__ double s_x[kXchgStride];   // cluster mode: the block handed to cluster_sum
   __shared__ int s_cluster_ok;
-  __shared__ __align__(16) LevelDesc s_lvd[SVOH_ALIGN_LDS_DESC ? SVOH_MAX_CAMS : 1];   // the cameras at the current level (see LevelDesc)
-  __shared__ int s_changed[SVOH_ALIGN_FOLD_VOTE ? NW : 1];   // a gradient-only pass' visibility vote, wave by wave (SVOH_ALIGN_FOLD_VOTE)
+  [[maybe_unused]] __shared__ __align__(16) LevelDesc s_lvd[SVOH_ALIGN_LDS_DESC ? SVOH_MAX_CAMS : 1];   // the cameras at the current level (see LevelDesc)
+  [[maybe_unused]] __shared__ int s_changed[SVOH_ALIGN_FOLD_VOTE ? NW : 1];   // a gradient-only pass' visibility vote, wave by wave (SVOH_ALIGN_FOLD_VOTE)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
