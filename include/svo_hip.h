@@ -663,6 +663,20 @@ int svoh_project_candidates_stage_ranges(svoh_ctx* ctx, int n_jobs, int n_kf_tot
 int svoh_project_candidates_enqueue_staged(svoh_ctx* ctx);
 int svoh_project_candidates_wait(svoh_ctx* ctx);
 
+/* The candidate SELECTION of reprojector_utils::matchCandidates (src/svo/src/reprojector.cpp:342-382) for many lists at once, the
+ * matches taken as given: list l (a stream's pass; candidates in visiting order) is candidates [begin[l], begin[l+1]); candidate i
+ * projects into grid cell cell[i] and its match succeeded iff success[i] != 0.  Per list: the first success of every cell that was
+ * free wins the cell (an atomic minimum on the visiting index), candidates are visited up to the winner that fills the frame
+ * (num_features[l] + winners so far >= max_n_features[l]) and only while their cell is free -- exactly the sequential loop, in
+ * parallel.  occupancy: n_lists x n_cells bytes in / out (a list's grid before / after its pass); visited: one byte per candidate
+ * (1 = the loop tried it: n_trials counts these, its side effects apply); n_consumed[l] = how many candidates the loop consumed
+ * (candidates.erase); num_features in / out.  max_n_features[l] must be > 0 (with 0 the reference's loop ignores the grid).
+ * Host pointers, blocking.  The reprojector's mirror keeps the selection on the host by default (it needs the lists sorted, and
+ * the sort runs while the matcher kernel does: HISTORY.md, round 5); SVOH_REPROJ_DEVICE_SELECT=1 routes its replay through here. */
+int svoh_select_matches_batch(svoh_ctx* ctx, int n_lists, const int32_t* begin, const int32_t* cell, const uint8_t* success,
+                              int n_cells, uint8_t* occupancy, const int32_t* max_n_features, int32_t* num_features,
+                              uint8_t* visited, int32_t* n_trials, int32_t* n_matches, int32_t* n_consumed);
+
 /* A matcher batch staged in place (svoh_feature_batch.mem_space = SVOH_MEM_STAGED).  Inside an open deferred section:
  * _stage sizes the page-locked block of the section's direct (seeds = 0) or seed (seeds = 1) batch for n units and up to
  * max_frame_views reference + current frames and hands out every array of the batch; the caller fills the inputs in

@@ -1118,3 +1118,28 @@ void orc_mat4f_inverse(const float m[16], float r[16], int mode)
   mat4f_inverse(m, r);
   g_inv4_mode = old;
 }
+
+
+/* reprojector.cpp:342-382, the matches given (see svo_oracle.h) */
+int orc_select_matches(int n, const int32_t* cell, const uint8_t* success, int n_cells, uint8_t* occupancy, int max_n_features_per_frame,
+                       int* num_features_io, uint8_t* visited, int* n_trials, int* n_matches)
+{
+  int i = 0;
+  *n_trials = 0; *n_matches = 0;
+  for (int k = 0; k < n; ++k) visited[k] = 0;
+  for (int k = 0; k < n; ++k) {
+    ++i;                                                                  /* :358 */
+    const int c = cell[k];
+    if (c < 0 || c >= n_cells) continue;                                  /* (never for a visible candidate) */
+    if (max_n_features_per_frame > 0 && occupancy[c]) continue;           /* :361-364 */
+    ++*n_trials;                                                          /* :366 */
+    visited[k] = 1;
+    if (success[k]) {                                                     /* :368-369 */
+      ++*n_matches;                                                       /* :371 */
+      ++*num_features_io;                                                 /* :372 */
+      occupancy[c] = 1;                                                   /* :373 */
+      if (max_n_features_per_frame > 0 && *num_features_io >= max_n_features_per_frame) break;   /* :374-378 */
+    }
+  }
+  return i;                                                               /* :381 */
+}

@@ -300,7 +300,7 @@ EXPORTS = [
     "svoh_host_alloc", "svoh_host_free", "svoh_build_pyramid_multi", "svoh_build_pyramid_multi_prefetch", "svoh_prefetch_fence",
     "svoh_sparse_align_geometry_key", "svoh_sparse_align_enqueue_keyed",
     "svoh_project_candidates_stage", "svoh_project_candidates_stage_ranges", "svoh_project_candidates_enqueue_staged", "svoh_project_candidates_wait",
-    "svoh_matcher_stage", "svoh_detect_cells_batch", "svoh_detect_cells_batch_enqueue", "svoh_detect_cells_batch_collect", "svoh_detect_fill_features", "svoh_features_upload", "svoh_features_release",
+    "svoh_matcher_stage", "svoh_detect_cells_batch", "svoh_detect_cells_batch_enqueue", "svoh_detect_cells_batch_collect", "svoh_detect_fill_features", "svoh_features_upload", "svoh_features_release", "svoh_select_matches_batch",
 ]
 
 
@@ -440,6 +440,7 @@ def load(path=None):
     lib.svoh_matcher_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, P(svoh_matcher_stage_t)]
     lib.svoh_features_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_uint64)]
     lib.svoh_features_release.argtypes = [C.c_void_p, C.c_uint64]
+    lib.svoh_select_matches_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 7
     lib.svoh_project_candidates_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(svoh_candidate_stage_t)]
     lib.svoh_project_candidates_stage_ranges.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(svoh_candidate_stage_t)]
     lib.svoh_project_candidates_enqueue_staged.argtypes = [C.c_void_p]

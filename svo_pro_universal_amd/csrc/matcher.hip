@@ -3580,6 +3580,85 @@ __global__ __launch_bounds__(256) void project_candidates_multi_kernel(const Mul
   a.visible[i] = ok ? 1 : 0;
 }
 
+// ---- svoh_select_matches_batch: the loop of matchCandidates (reprojector.cpp:342-382) over given matches, one workgroup per list --
+// Sequentially: candidate k is tried iff its cell is free when the loop gets there; a success takes the cell; the loop ends with the
+// success that fills the frame.  In parallel: W(c) = the smallest k among the successes of cell c (cells free at the start only);
+// the winners are the k with k == W(cell[k]); the loop ends at K = the m-th winner in order of k, m = max(1, max_n - n_before)
+// (or runs through the list); k is tried iff k <= K, its cell was free at the start and k <= W(cell[k]).
+struct SelectArgs {
+  const int32_t* begin; const int32_t* cell; const uint8_t* success;
+  int n_cells; uint8_t* occupancy; const int32_t* max_n; int32_t* num_features;
+  uint8_t* visited; int32_t* n_trials; int32_t* n_matches; int32_t* n_consumed;
+  int32_t* first_success;   // scratch: n_lists x n_cells
+};
+__global__ __launch_bounds__(256) void select_matches_kernel(const SelectArgs a)
+{
+  const int l = blockIdx.x, tid = threadIdx.x;
+  const int lo = a.begin[l], n = a.begin[l + 1] - lo;
+  const int32_t* cell = a.cell + lo;
+  const uint8_t* success = a.success + lo;
+  uint8_t* visited = a.visited + lo;
+  uint8_t* occ = a.occupancy + (size_t)l * a.n_cells;
+  int32_t* W = a.first_success + (size_t)l * a.n_cells;
+  __shared__ int s_cnt[256], s_stop, s_trials, s_matches;
+  // W is written by atomics (at the L2) and read back by every wave of the workgroup: agent-scope loads, past the CU's vector L1
+  auto Wat = [&](int c) { return __hip_atomic_load(&W[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  for (int c = tid; c < a.n_cells; c += 256) __hip_atomic_store(&W[c], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) { s_stop = n - 1; s_trials = 0; s_matches = 0; }
+  __syncthreads();
+  // every thread owns a contiguous run of the list, so that counts per thread are counts in visiting order
+  const int per = (n + 255) / 256, k0 = tid * per, k1 = k0 + per < n ? k0 + per : n;
+  for (int k = k0; k < k1; ++k) {
+    const int c = cell[k];
+    if (success[k] && c >= 0 && c < a.n_cells && !occ[c]) atomicMin(&W[c], k);
+  }
+  __threadfence_block();
+  __syncthreads();
+  int winners = 0;
+  for (int k = k0; k < k1; ++k) {
+    const int c = cell[k];
+    winners += (c >= 0 && c < a.n_cells && Wat(c) == k) ? 1 : 0;
+  }
+  s_cnt[tid] = winners;
+  __syncthreads();
+  if (tid == 0) {   // where the m-th winner lies: a scan of 256 counts by one lane (a list has a few thousand candidates)
+    const int n_before = a.num_features[l], max_n = a.max_n[l];
+    int m = max_n - n_before;
+    if (m < 1) m = 1;
+    int acc = 0, owner = -1;
+    for (int t = 0; t < 256; ++t) { if (acc + s_cnt[t] >= m) { owner = t; break; } acc += s_cnt[t]; }
+    if (owner >= 0) {
+      int need = m - acc;
+      const int b0 = owner * per, b1 = b0 + per < n ? b0 + per : n;
+      for (int k = b0; k < b1; ++k) {
+        const int c = cell[k];
+        if (c >= 0 && c < a.n_cells && Wat(c) == k && --need == 0) { s_stop = k; break; }
+      }
+    }
+  }
+  __syncthreads();
+  const int K = s_stop;
+  int trials = 0, matches = 0;
+  for (int k = k0; k < k1; ++k) {
+    const int c = cell[k];
+    const bool in_grid = c >= 0 && c < a.n_cells;
+    const int w = in_grid ? Wat(c) : 0x7fffffff;
+    const bool v = k <= K && in_grid && !occ[c] && k <= w;
+    visited[k] = v ? 1 : 0;
+    trials += v ? 1 : 0;
+    matches += (v && w == k) ? 1 : 0;
+  }
+  if (trials) atomicAdd(&s_trials, trials);
+  if (matches) atomicAdd(&s_matches, matches);
+  __syncthreads();   // (every read of occ[] above precedes the writes below)
+  for (int c = tid; c < a.n_cells; c += 256) if (Wat(c) <= K) occ[c] = 1;
+  if (tid == 0) {
+    a.n_trials[l] = s_trials; a.n_matches[l] = s_matches;
+    a.n_consumed[l] = n > 0 ? K + 1 : 0;
+    a.num_features[l] += s_matches;
+  }
+}
+
 // The ranges form (svoh_project_candidates_stage_ranges): point i is feature i - point_begin of the keyframe whose range holds it;
 // a seed's bearing vector comes from the keyframe's resident f column.  Same arithmetic per point.
 struct DevCandidateRange { const double* f; int32_t n_feat; int32_t point_begin, n_points; int32_t job; int32_t pad_; };
@@ -3651,6 +3730,53 @@ __global__ __launch_bounds__(256) void project_candidates_ranges_kernel(const Ra
 using namespace svoh;
 
 extern "C" {
+
+int svoh_select_matches_batch(svoh_ctx* ctx, int n_lists, const int32_t* begin, const int32_t* cell, const uint8_t* success,
+                              int n_cells, uint8_t* occupancy, const int32_t* max_n_features, int32_t* num_features,
+                              uint8_t* visited, int32_t* n_trials, int32_t* n_matches, int32_t* n_consumed)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, n_lists >= 0 && n_cells >= 1 && n_cells <= (1 << 20), "bad arguments");
+  if (n_lists == 0) return SVOH_OK;
+  SVOH_REQUIRE(ctx, begin && occupancy && max_n_features && num_features && n_trials && n_matches && n_consumed, "NULL argument");
+  SVOH_REQUIRE(ctx, n_lists <= (1 << 16) && begin[0] == 0, "too many lists, or begin[0] != 0");
+  for (int l = 0; l < n_lists; ++l) {
+    SVOH_REQUIRE(ctx, begin[l + 1] >= begin[l], "begin must not decrease");
+    SVOH_REQUIRE(ctx, max_n_features[l] > 0, "max_n_features must be > 0 (with 0 the reference's loop ignores the grid: replay it on the host)");
+  }
+  const size_t n = (size_t)begin[n_lists];
+  SVOH_REQUIRE(ctx, n <= ((size_t)1 << 26) && (n == 0 || (cell && success && visited)), "NULL candidate array, or too many candidates");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  const size_t nl = (size_t)n_lists, nc = (size_t)n_cells;
+  // [begin | max_n | num_features | cell | success | occupancy]  up;  [num_features | occupancy | visited | trials | matches | consumed]  back
+  const size_t o_begin = 0, o_max = al(4 * (nl + 1)), o_cell = o_max + al(4 * nl), o_succ = o_cell + al(4 * n), in_only = o_succ + al(n);
+  const size_t o_nf = in_only, o_occ = o_nf + al(4 * nl), in_total = o_occ + al(nl * nc);
+  const size_t o_vis = in_total, o_tr = o_vis + al(n), o_ma = o_tr + al(4 * nl), o_co = o_ma + al(4 * nl), back_end = o_co + al(4 * nl);
+  const size_t o_w = back_end, total = o_w + al(4 * nl * nc);
+  SVOH_HIP_TRY(ctx, ctx->h_scratch1.reserve(back_end));
+  SVOH_HIP_TRY(ctx, ctx->d_scratch1.reserve(total));
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch1.ptr);
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch1.ptr);
+  memcpy(h + o_begin, begin, 4 * (nl + 1)); memcpy(h + o_max, max_n_features, 4 * nl); memcpy(h + o_nf, num_features, 4 * nl);
+  if (n) { memcpy(h + o_cell, cell, 4 * n); memcpy(h + o_succ, success, n); }
+  memcpy(h + o_occ, occupancy, nl * nc);
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, in_total));
+  SelectArgs a;
+  a.begin = reinterpret_cast<const int32_t*>(d + o_begin); a.cell = reinterpret_cast<const int32_t*>(d + o_cell); a.success = d + o_succ;
+  a.n_cells = n_cells; a.occupancy = d + o_occ; a.max_n = reinterpret_cast<const int32_t*>(d + o_max);
+  a.num_features = reinterpret_cast<int32_t*>(d + o_nf);
+  a.visited = d + o_vis; a.n_trials = reinterpret_cast<int32_t*>(d + o_tr); a.n_matches = reinterpret_cast<int32_t*>(d + o_ma);
+  a.n_consumed = reinterpret_cast<int32_t*>(d + o_co); a.first_success = reinterpret_cast<int32_t*>(d + o_w);
+  hipLaunchKernelGGL(select_matches_kernel, dim3((unsigned)n_lists), dim3(256), 0, ctx->stream, a);
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + o_nf, d + o_nf, back_end - o_nf));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(num_features, h + o_nf, 4 * nl); memcpy(occupancy, h + o_occ, nl * nc);
+  if (n) memcpy(visited, h + o_vis, n);
+  memcpy(n_trials, h + o_tr, 4 * nl); memcpy(n_matches, h + o_ma, 4 * nl); memcpy(n_consumed, h + o_co, 4 * nl);
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
 
 int svoh_project_candidates_enqueue(svoh_ctx* ctx, const svoh_camera* cam, const svoh_se3* T_f_w_or_T_cam_imu, const svoh_se3* T_imu_world_ref,
                                     int align_result_index, int n_kf, const svoh_se3* T_world_kf, int n, const uint8_t* kind,
