@@ -1092,6 +1092,7 @@ ReprojectorHip::ReprojectorHip(svoh_ctx* ctx, const ReprojectorOptions& options,
 {
   if (!ctx_) throw std::runtime_error("ReprojectorHip: NULL svoh_ctx (no CPU fallback exists)");
   if (camera_index_ >= SVOH_MAX_CAMS) throw std::runtime_error("ReprojectorHip: camera index out of range");
+  device_select_ = getenv("SVOH_REPROJ_DEVICE_SELECT") != nullptr && atoi(getenv("SVOH_REPROJ_DEVICE_SELECT")) != 0;
 }
 
 namespace {
@@ -1385,7 +1386,7 @@ void ReprojectorHip::replayMatches(const FramePtr& cur_frame, svoh_ctx* ctx_for_
   for (int k = 0; k < 3; ++k) {
     size_t max_n = 0;
     if (stop || !before_pass(k, max_n)) break;
-    if (k < n_speculated_) sm_->replay(cur_frame, max_n, *lists[k], plan_rs_[k], *grid_, st[k]);
+    if (k < n_speculated_) sm_->replay(cur_frame, max_n, *lists[k], plan_rs_[k], *grid_, st[k], device_select_ ? ctx_for_unspeculated : nullptr);
     else {
       // a pass nobody bet on: its own round trip
       if (!ctx_for_unspeculated) throw std::runtime_error("ReprojectorHip::replayMatches: a pass that was not planned, and no context to match it on");
@@ -1728,18 +1729,41 @@ void SpeculativeMatches::finish(svoh_ctx* ctx)
 }
 
 void SpeculativeMatches::replay(const FramePtr& frame, size_t max_n_features_per_frame, std::vector<reprojector::Candidate>& candidates,
-                                const std::vector<Resolved>& rs, OccupandyGrid2D& grid, reprojector::Statistics& stats)
+                                const std::vector<Resolved>& rs, OccupandyGrid2D& grid, reprojector::Statistics& stats, svoh_ctx* select_on)
 {
   std::vector<int32_t>& g_last_results = g_last_results_ref();
   const size_t n = candidates.size();
   g_last_results.assign(n, -1);
+  // the selection from the device (optional): visited[k] = the loop below tries candidate k; n_stop = where it ends
+  std::vector<uint8_t> visited;
+  size_t n_stop = n;
+  if (select_on && max_n_features_per_frame > 0 && n > 0) {
+    std::vector<int32_t> cell(n);
+    std::vector<uint8_t> success(n), occ(grid.size());
+    for (size_t k = 0; k < n; ++k) {
+      cell[k] = static_cast<int32_t>(grid.getCellIndex(static_cast<int>(candidates[k].cur_px[0]), static_cast<int>(candidates[k].cur_px[1]), 1));
+      const Resolved& r = rs[k];
+      success[k] = (r.kind == kConvergedSeed || r.kind == kLandmark) ? direct.out.result[r.batch_pos] == SVOH_MATCH_SUCCESS
+                   : r.kind == kUnconvergedSeed ? seeds.out.success[r.batch_pos] != 0 : 0;
+    }
+    for (size_t c = 0; c < occ.size(); ++c) occ[c] = grid.isOccupied(c) ? 1 : 0;
+    const int32_t begin[2] = { 0, static_cast<int32_t>(n) };
+    const int32_t max_n = static_cast<int32_t>(max_n_features_per_frame);
+    int32_t n_feat = static_cast<int32_t>(frame->num_features_), n_trials = 0, n_matches = 0, n_consumed = 0;
+    visited.assign(n, 0);
+    if (svoh_select_matches_batch(select_on, 1, begin, cell.data(), success.data(), static_cast<int>(occ.size()), occ.data(), &max_n, &n_feat, visited.data(), &n_trials,
+                                  &n_matches, &n_consumed) != SVOH_OK)
+      throw std::runtime_error(std::string("svoh_select_matches_batch: ") + svoh_last_error_string(select_on));
+    n_stop = static_cast<size_t>(n_consumed);
+  }
   size_t i = 0;
-  for (size_t k = 0; k < n; ++k) {
+  for (size_t k = 0; k < n_stop; ++k) {
     reprojector::Candidate& c = candidates[k];
     const Resolved& r = rs[k];
     ++i;
     const size_t grid_index = grid.getCellIndex(static_cast<int>(c.cur_px[0]), static_cast<int>(c.cur_px[1]), 1);
-    if (max_n_features_per_frame > 0 && grid.isOccupied(grid_index)) continue;
+    if (!visited.empty()) { if (!visited[k]) continue; }
+    else if (max_n_features_per_frame > 0 && grid.isOccupied(grid_index)) continue;
     ++stats.n_trials;
     bool ok = false;
     const Batch* b = nullptr;
@@ -1796,6 +1820,11 @@ void SpeculativeMatches::replay(const FramePtr& frame, size_t max_n_features_per
 namespace reprojector_utils {
 using detail::SpeculativeMatches;
 using detail::Resolved;
+static bool device_select_env()
+{
+  static const bool on = getenv("SVOH_REPROJ_DEVICE_SELECT") != nullptr && atoi(getenv("SVOH_REPROJ_DEVICE_SELECT")) != 0;
+  return on;
+}
 
 void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features_per_frame, bool affine_est_offset,
                      bool affine_est_gain, std::vector<reprojector::Candidate>& candidates, OccupandyGrid2D& grid,
@@ -1809,7 +1838,8 @@ void matchCandidates(svoh_ctx* ctx, const FramePtr& frame, size_t max_n_features
   const std::vector<Resolved> rs = sm.plan(frame, candidates);
   sm.run(ctx, frame, affine_est_offset, affine_est_gain, seed_sigma2_thresh);
   sm.direct.useOwnOutputs(); sm.seeds.useOwnOutputs();
-  sm.replay(frame, max_n_features_per_frame, candidates, rs, grid, stats);
+  // (SVOH_REPROJ_DEVICE_SELECT=1: the loop's selection from svoh_select_matches_batch, as in ReprojectorHip::replayMatches)
+  sm.replay(frame, max_n_features_per_frame, candidates, rs, grid, stats, device_select_env() ? ctx : nullptr);
 }
 
 // Reprojector::reprojectFrames' three matchCandidates passes (reprojector.cpp:177-306) with ONE round trip to the
@@ -1843,7 +1873,7 @@ void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_
   for (int k = 0; k < 3; ++k) {
     size_t max_n = 0;
     if (!before_pass(k, max_n)) break;
-    if (k < n_speculated) sm.replay(frame, max_n, *lists[k], rs[k], grid, stats[k]);
+    if (k < n_speculated) sm.replay(frame, max_n, *lists[k], rs[k], grid, stats[k], device_select_env() ? ctx : nullptr);
     else matchCandidates(ctx, frame, max_n, affine_est_offset, affine_est_gain, *lists[k], grid, stats[k], seed_sigma2_thresh);   // a pass nobody bet on: its own round trip
     after_pass(k);
   }

@@ -515,6 +515,10 @@ class ReprojectorHip {
   // (5) the reference's three passes over finished batches; ctx_for_unspeculated: where a pass nobody planned is
   //     matched with a round trip of its own (NULL: there must be none -- n_speculated was 3)
   void replayMatches(const FramePtr& cur_frame, svoh_ctx* ctx_for_unspeculated);
+  // SVOH_REPROJ_DEVICE_SELECT=1 (read when the reprojector is made): the passes' selection -- which candidates are tried, where a
+  // pass ends -- comes from svoh_select_matches_batch instead of the walk over the grid in replay(); same features, counters, grid
+  // and side effects (tests/cpp/test_host_reprojector.cpp runs both).  Off by default: it is a round trip of its own.
+  bool device_select_ = false;
   bool reachedUnconvergedPass() const { return reached_unconverged_; }
 
   std::unique_ptr<OccupandyGrid2D> grid_;

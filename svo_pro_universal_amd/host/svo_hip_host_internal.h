@@ -98,8 +98,10 @@ struct SpeculativeMatches {
     finish(ctx);
   }
   // the reference's loop over one candidate list, in candidate order (reprojector.cpp:356-381)
+  // select_on: when set (and max_n_features_per_frame > 0), WHICH candidates the loop tries and where it stops is asked of the
+  // device (svoh_select_matches_batch on the finished batches' success flags) instead of being found by walking the grid here
   void replay(const FramePtr& frame, size_t max_n_features_per_frame, std::vector<reprojector::Candidate>& candidates,
-              const std::vector<Resolved>& rs, OccupandyGrid2D& grid, reprojector::Statistics& stats);
+              const std::vector<Resolved>& rs, OccupandyGrid2D& grid, reprojector::Statistics& stats, svoh_ctx* select_on = nullptr);
 };
 
 // Matcher defaults (matcher.h:39-54) + the two affine flags, as reprojector_utils::matchCandidates sets them

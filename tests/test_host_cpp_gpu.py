@@ -73,8 +73,8 @@ def test_cpp_depth_filter_and_klt_mirrors_match_oracle(tmp_path, oracle_lib):
     assert "PASS" in out.stdout
 
 
-@pytest.mark.parametrize("max_n", [60, 0])
-def test_cpp_reprojector_match_candidates_mirror_matches_oracle(tmp_path, oracle_lib, max_n):
+@pytest.mark.parametrize("max_n,device_select", [(60, 0), (0, 0), (60, 1)])
+def test_cpp_reprojector_match_candidates_mirror_matches_oracle(tmp_path, oracle_lib, max_n, device_select):
     """reprojector_utils::matchCandidates (reprojector.cpp:342-486): speculative GPU batches + ordered host
     replay vs the oracle's sequential loop -- converged seeds, seed updates, landmarks with and without a close
     view, pre-occupied grid cells, the early break at max_n_features_per_frame."""
@@ -123,7 +123,10 @@ def test_cpp_reprojector_match_candidates_mirror_matches_oracle(tmp_path, oracle
         cur_px.tofile(f)
         rng.uniform(10, 100, n).tofile(f)
         sc.img_ref.tofile(f); sc.img_cur.tofile(f)
-    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_host_reprojector"), path], capture_output=True, text=True)
+    # device_select: which candidates a pass tries and where it ends comes from svoh_select_matches_batch instead of the host's walk
+    # over the grid (SVOH_REPROJ_DEVICE_SELECT=1) -- same features, counters, grid, trash list
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_host_reprojector"), path], capture_output=True, text=True,
+                         env=dict(os.environ, SVOH_REPROJ_DEVICE_SELECT=str(device_select)))
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASS" in out.stdout

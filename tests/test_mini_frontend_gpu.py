@@ -189,6 +189,10 @@ def test_lockstep_variants_and_the_tracked_features_rule(tmp_path):
         # (without periodic keyframes the rule must fire: the sequence keeps all 180 features of a frame tracked, so the bar is 181 -- a keyframe per frame, each by the rule)
         rule = {"SVOH_MINI_MIN_TRACKED": "181"} if kf_every == "1000" else {}
         single = run([str(n_frames), kf_every, "1"], rule)[0]
+        if kf_every == "8":
+            # the single stream with its passes' selection taken from the device (svoh_select_matches_batch): the same files
+            sel = run([str(n_frames), kf_every, "1"], {"SVOH_REPROJ_DEVICE_SELECT": "1"})[0]
+            assert sel[0] == single[0] and np.array_equal(sel[1], single[1])
         if kf_every == "1000":
             assert single[1][1:, 1].sum() >= 1, "the tracked-features rule never fired: the case tests nothing"
         for env in ({}, {"SVOH_LOCKSTEP_RESIDENT": "0"}, {"SVOH_LOCKSTEP_POSE_CHAIN": "0"}, {"SVOH_LOCKSTEP_DETECT_AHEAD": "0"}):
