@@ -89,6 +89,7 @@ struct AlignKernelArgs {
   long long* stamps;                    // diagnostic builds only (SVOH_PHASE_STAMPS): 8 per problem
   int32_t n_problems;
   int32_t* queue;                       // work queue head: workgroups pull problem indices from it
+  int32_t one_each;                     // the grid has a workgroup per problem: workgroup b solves problem b, nobody asks the queue
   // patch-split mode: evaluate at a caller-owned device state, hand out the undivided sums
   const svoh_align_gn_state* ext_state;
   int32_t raw_sums;
@@ -645,6 +646,12 @@ __device__ __forceinline__ Rigid uniform_rigid(const Rigid& T)
 // iteration).
 #ifndef SVOH_ALIGN_CLUSTER_XCD
 #define SVOH_ALIGN_CLUSTER_XCD 0
+#endif
+// SVOH_ALIGN_ONE_EACH: launches whose grid has a workgroup per problem skip the work queue.  Built, measured
+// (profiles/r05_align_one_each_ab.txt: one 180-patch problem 5.35 us per iteration + 27.1 us either way), compiled out: the
+// returning atomic on the queue head is not what a lone problem's launch pays for.
+#ifndef SVOH_ALIGN_ONE_EACH
+#define SVOH_ALIGN_ONE_EACH 0
 #endif
 #ifndef SVOH_ALIGN_LDS_DESC
 #define SVOH_ALIGN_LDS_DESC 0
@@ -1383,6 +1390,9 @@ void sparse_align_kernel(const AlignKernelArgs a)
 #if SVOH_ALIGN_CLUSTER_XCD
   bool first_pull = true;
 #endif
+#if SVOH_ALIGN_ONE_EACH
+  bool pulled_once = false;
+#endif
   for (;;) {
   __syncthreads();  // everyone is done with the previous problem's shared state
 #if SVOH_ALIGN_CLUSTER_XCD
@@ -1401,6 +1411,14 @@ void sparse_align_kernel(const AlignKernelArgs a)
       s_pbi = v;
     }
     first_pull = false;
+  } else
+#endif
+#if SVOH_ALIGN_ONE_EACH
+  // a launch with a workgroup per problem (one problem alone, a camera stream's frame, the problems of a lock-step round): the
+  // problem index is the block index -- no returning atomic on the queue head ahead of the first descriptor load
+  if (a.one_each) {
+    if (tid == 0) s_pbi = pulled_once ? a.n_problems : (int)blockIdx.x;
+    pulled_once = true;
   } else
 #endif
   if (tid == 0) s_pbi = atomicAdd(a.queue, 1);
@@ -2440,6 +2458,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   int grid = ctx->num_cus * SvohKnobs::or_default(ctx->knobs.align_wg_per_cu, nt == 256 ? 2 : 1);
   if (grid > n_desc || grid <= 0) grid = n_desc;
   if (cluster) grid = n_desc;
+  args.one_each = (!cluster && grid == n_desc) ? 1 : 0;
 #if SVOH_ALIGN_CLUSTER_XCD
   if (cluster) grid = 8 * args.cluster * ((n_desc / args.cluster + 7) / 8);   // (see the kernel's pull)
 #endif
