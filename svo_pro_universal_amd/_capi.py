@@ -57,7 +57,7 @@ class svoh_align_camera(C.Structure):
     _fields_ = [("ref_frame", svoh_frame_t), ("cur_frame", svoh_frame_t), ("cam", svoh_camera),
                 ("ref_T_imu_cam", svoh_se3), ("ref_T_cam_imu", svoh_se3), ("cur_T_cam_imu", svoh_se3),
                 ("ref_pos", C.c_double * 3), ("n_features", C.c_int32), ("mem_space", C.c_int32),
-                ("px", C.c_void_p), ("f", C.c_void_p), ("pos_world", C.c_void_p), ("flags", C.c_void_p)]
+                ("px", C.c_void_p), ("f", C.c_void_p), ("pos_world", C.c_void_p), ("flags", C.c_void_p), ("pos_seed_unit", C.c_void_p)]
 
 
 class svoh_align_problem(C.Structure):

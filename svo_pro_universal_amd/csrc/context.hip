@@ -523,6 +523,7 @@ try {
   if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
   if (ctx->ev_features) (void)hipEventDestroy(ctx->ev_features);
   if (ctx->ev_detect) (void)hipEventDestroy(ctx->ev_detect);
+  if (ctx->ev_matcher_done) (void)hipEventDestroy(ctx->ev_matcher_done);
   if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
   if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

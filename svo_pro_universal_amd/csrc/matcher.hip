@@ -2946,6 +2946,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   }
   PinnedBuffer& hbuf = defer ? (seeds ? ctx->h_match_seeds : ctx->h_match_direct) : ctx->h_scratch1;
   DevBuffer& dbuf = defer ? (seeds ? ctx->d_match_seeds : ctx->d_match_direct) : ctx->d_scratch1;
+  if (defer && seeds) ctx->seed_block.valid = false;   // the seed block is laid out anew (svoh_align_camera::pos_seed_unit)
   SVOH_HIP_TRY(ctx, hbuf.reserve(s.total));
   SVOH_HIP_TRY(ctx, dbuf.reserve(s.total));
   uint8_t* h = static_cast<uint8_t*>(hbuf.ptr);
@@ -3009,7 +3010,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
     // results back to the pinned block, and the copies from there to the caller's arrays.
     svoh_ctx::DeferredLaunch& dl = ctx->matcher_deferred_launch[seeds ? 1 : 0];
     dl.args.assign(reinterpret_cast<const uint8_t*>(&a), reinterpret_cast<const uint8_t*>(&a) + sizeof a);
-    dl.n = n; dl.g8 = g8; dl.valid = true;
+    dl.n = n; dl.g8 = g8; dl.valid = true; dl.seed_block_staged = false; dl.d_fidx = nullptr; dl.pose_from_results = false;
     dl.max_w = dl.max_h = 1;
     for (int k = 0; k < n_ref_frames; ++k) { dl.max_w = views[k].lv[0].w > dl.max_w ? views[k].lv[0].w : dl.max_w; dl.max_h = views[k].lv[0].h > dl.max_h ? views[k].lv[0].h : dl.max_h; }
     dl.d_block = d; dl.out_off = in_total; dl.out_bytes = s.total - in_total;
@@ -3518,6 +3519,7 @@ static int run_matcher_staged(svoh_ctx* ctx, bool seeds, const svoh_matcher_opti
   dl.cur_frame_handle = cur_frame[0].frame;
   dl.pose_from_results = pose_from_results; dl.d_pose_results = pose_from_results ? ctx->d_pose_results : nullptr; dl.n_pose_results = ctx->n_pose_results;
   dl.d_fidx = st.resident ? d + st.o_fidx : nullptr;
+  dl.seed_block_staged = seeds;
   if (seeds && n_success) ctx->matcher_pending_counts.push_back({ n_success, h + st.o_success, n });
   return SVOH_OK;
 }
@@ -3959,6 +3961,7 @@ try {
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   svoh_ctx::MatcherStage& st = ctx->matcher_stage[kind];
   SVOH_REQUIRE(ctx, (flags & ~(SVOH_STAGE_MATCH_OUTPUTS | SVOH_STAGE_RESIDENT_COLUMNS)) == 0, "unknown flag");
+  if (seeds) ctx->seed_block.valid = false;   // (its uploads are stream-ordered behind whatever still reads the old block)
   layout_matcher_stage(seeds != 0, n, max_frame_views, (flags & SVOH_STAGE_MATCH_OUTPUTS) != 0, (flags & SVOH_STAGE_RESIDENT_COLUMNS) != 0, &st);
   PinnedBuffer& hbuf = seeds ? ctx->h_match_seeds : ctx->h_match_direct;
   DevBuffer& dbuf = seeds ? ctx->d_match_seeds : ctx->d_match_direct;
@@ -4117,10 +4120,56 @@ static int launch_deferred(svoh_ctx* ctx)
       if (rc != SVOH_OK) return rc;
       if (v0) SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, d0.d2h_dst, d0.d2h_src, d0.d2h_bytes));
       if (v1) SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, d1.d2h_dst, d1.d2h_src, d1.d2h_bytes));
+      // what collect waits for: these copies, not whatever the caller queues on the stream afterwards
+      if (!ctx->ev_matcher_done) SVOH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_matcher_done, hipEventDisableTiming));
+      SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_matcher_done, ctx->stream));
+      ctx->matcher_done_recorded = true;
+      if (v1 && d1.seed_block_staged) {   // a staged seed batch: its block can serve svoh_align_camera::pos_seed_unit until it is staged again
+        svoh_ctx::SeedBlock& sb = ctx->seed_block;
+        sb.valid = true; sb.views = d1.views_d; sb.n_ref = d1.n_ref; sb.ref_idx = a1.ref_frame_idx; sb.f = a1.f; sb.state = a1.state; sb.n = d1.n;
+      }
     }
   }
   return SVOH_OK;
 }
+
+}  // extern "C"
+
+namespace svoh {
+// svoh_align_camera::pos_seed_unit: feature i of a job with unit u = unit[i] >= 0 gets the position of seed u of the staged seed
+// batch in flight -- T_world_keyframe * (f / mu), Frame::getSeedPosInFrame behind T_world_cam (resolveAlignmentPoints of the host
+// mirror, the same inline functions) -- with the state the update has left in the batch's device block
+struct PosFromSeedsArgs { const PosFromSeedsJob* jobs; const DevFrameView* views; int n_ref; const int32_t* ref_idx; const double* f; const double* state; int n_units; };
+__global__ __launch_bounds__(256) void pos_from_seed_batch_kernel(const PosFromSeedsArgs a)
+{
+  const PosFromSeedsJob jb = a.jobs[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= jb.n) return;
+  const int u = jb.unit[i];
+  if (u < 0 || u >= a.n_units) return;
+  const int r = a.ref_idx[u];
+  if (r < 0 || r >= a.n_ref) return;
+  const double depth = 1.0 / a.state[4 * (size_t)u];   // seed::getDepth (seed.h:110-113)
+  const Vec3 in_kf = { a.f[3 * (size_t)u] * depth, a.f[3 * (size_t)u + 1] * depth, a.f[3 * (size_t)u + 2] * depth };
+  const Vec3 p = transform(inverse(a.views[r].T_f_w), in_kf);
+  jb.pos[3 * (size_t)i] = p.x; jb.pos[3 * (size_t)i + 1] = p.y; jb.pos[3 * (size_t)i + 2] = p.z;
+}
+
+int svoh_launch_pos_from_seed_batch(svoh_ctx* ctx, int n_jobs, int max_n, const PosFromSeedsJob* jobs_device)
+{
+  const svoh_ctx::SeedBlock& sb = ctx->seed_block;
+  SVOH_REQUIRE(ctx, sb.valid, "pos_seed_unit: no staged seed batch has been sent off on this context (or its block has been staged again)");
+  if (n_jobs <= 0 || max_n <= 0) return SVOH_OK;
+  PosFromSeedsArgs a;
+  a.jobs = jobs_device; a.views = static_cast<const DevFrameView*>(sb.views); a.n_ref = sb.n_ref; a.ref_idx = sb.ref_idx; a.f = sb.f; a.state = sb.state; a.n_units = sb.n;
+  hipLaunchKernelGGL(pos_from_seed_batch_kernel, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_jobs), dim3(256), 0, ctx->stream, a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(ctx, SVOH_ERR_HIP, "pos_from_seed_batch launch failed: %s", hipGetErrorString(e));
+  return SVOH_OK;
+}
+}  // namespace svoh
+
+extern "C" {
 
 int svoh_matcher_deferred_set_cur_frame(svoh_ctx* ctx, const svoh_frame_view* cur_frame)
 try {
@@ -4156,7 +4205,9 @@ try {
   ctx->matcher_deferred_used[0] = ctx->matcher_deferred_used[1] = false;
   const int rc_launch = launch_deferred(ctx);   // whatever svoh_matcher_flush has not sent yet
   if (rc_launch != SVOH_OK) return rc_launch;
-  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // the section's results: behind their own copies, not behind what was queued on the stream since the flush
+  if (ctx->matcher_done_recorded) { SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_matcher_done)); ctx->matcher_done_recorded = false; }
+  else SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (const auto& c : ctx->matcher_pending) memcpy(c.dst, c.src, c.bytes);
   for (const auto& c : ctx->matcher_pending_counts) {
     int k = 0;

@@ -2204,6 +2204,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
 
   // pass 1: sizes
   size_t n_cams_total = 0, n_feat_total = 0, host_bytes = 0;
+  int n_pos_jobs = 0;   // cameras whose seed positions come from the seed batch in flight (svoh_align_camera::pos_seed_unit)
   LaunchShape shape;   // largest problem (share); some problem has more than one camera; ... whose patches fill five to eight waves, camera by camera
   for (int p = 0; p < n_problems; ++p) {
     const svoh_align_problem& pb = problems[p];
@@ -2219,11 +2220,18 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
       nf += cam.n_features;
       if (cam.mem_space == SVOH_MEM_HOST && !(split && split->update))
         host_bytes += ((size_t)cam.n_features * (8 * 8 + 1) + 63) & ~(size_t)63;
+      if (cam.pos_seed_unit) {
+        SVOH_REQUIRE(ctx, cam.mem_space == SVOH_MEM_HOST && !split && eval_level < 0, "pos_seed_unit: host-memory cameras of full runs only");
+        host_bytes += (((size_t)cam.n_features * 4 + 63) & ~(size_t)63) + 64;   // the units, and the camera's entry of the job table
+        ++n_pos_jobs;
+      }
     }
     n_cams_total += (size_t)pb.n_cams * S;
     n_feat_total += nf;
     add_to_shape(pb, S, &shape);
   }
+  SVOH_REQUIRE(ctx, n_pos_jobs == 0 || ctx->seed_block.valid,
+               "pos_seed_unit: no staged seed batch has been sent off on this context (or its block has been staged again)");
   const int max_feat_per_problem = shape.max_feat_per_problem;
   const size_t feat_slots = n_feat_total ? n_feat_total : 1;
 
@@ -2304,6 +2312,8 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   int cam_idx = 0, feat_off = 0;
   const int need_levels = opt->max_level + 1;
   const uint8_t* share_base[SVOH_MAX_CAMS] = {};   // uploaded block of camera c (host arrays, S > 1)
+  std::vector<PosFromSeedsJob> pos_jobs;
+  int pos_jobs_max_n = 0;
   for (int pd = 0; pd < n_desc; ++pd) {
     const int p = pd / S, sh = pd % S;
     const svoh_align_problem& pb = problems[p];
@@ -2360,6 +2370,16 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
           share_base[c] = dup + up_off;
           up_off += (n * 65 + 63) & ~(size_t)63;
         }
+        if (sh == 0 && cam.pos_seed_unit) {   // its units go up behind the camera's arrays; the job points at the uploaded positions
+          memcpy(hup + up_off, cam.pos_seed_unit, n * 4);
+          PosFromSeedsJob jb;
+          jb.pos = reinterpret_cast<double*>(const_cast<uint8_t*>(share_base[c]) + n * 40);
+          jb.unit = reinterpret_cast<const int32_t*>(dup + up_off);
+          jb.n = (int32_t)n; jb.pad_ = 0;
+          pos_jobs.push_back(jb);
+          if ((int)n > pos_jobs_max_n) pos_jobs_max_n = (int)n;
+          up_off += (n * 4 + 63) & ~(size_t)63;
+        }
         const uint8_t* dv = share_base[c];
         dc.px = reinterpret_cast<const double*>(dv) + 2 * lo;
         dc.f = reinterpret_cast<const double*>(dv + n * 16) + 3 * lo;
@@ -2368,7 +2388,17 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
       }
     }
   }
+  const PosFromSeedsJob* pos_jobs_device = nullptr;
+  if (!pos_jobs.empty()) {   // the job table rides the same upload
+    memcpy(hup + up_off, pos_jobs.data(), sizeof(PosFromSeedsJob) * pos_jobs.size());
+    pos_jobs_device = reinterpret_cast<const PosFromSeedsJob*>(dup + up_off);
+    up_off += (sizeof(PosFromSeedsJob) * pos_jobs.size() + 63) & ~(size_t)63;
+  }
   SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, ctx->d_desc.ptr, h_desc.ptr, up_base + up_off));
+  if (pos_jobs_device) {
+    const int rcp = svoh_launch_pos_from_seed_batch(ctx, (int)pos_jobs.size(), pos_jobs_max_n, pos_jobs_device);
+    if (rcp != SVOH_OK) return rcp;
+  }
   ctx->align_desc_slot = desc_slot;
   ctx->align_staged_event_valid = false;
   if (ctx->align_launches_since_drain >= 1) {   // queued behind a launch nobody has waited for: the next one may need this

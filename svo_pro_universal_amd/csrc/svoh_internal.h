@@ -270,6 +270,7 @@ struct svoh_ctx {
     const void* d_pose_results = nullptr; int n_pose_results = 0; bool pose_from_results = false;
     // features named by index (svoh_feature_batch::feature_index): gathered from the reference frames' resident columns ahead of the kernels
     const void* d_fidx = nullptr;
+    bool seed_block_staged = false;    // a staged seed batch (its device block can serve svoh_align_camera::pos_seed_unit after the flush)
   } matcher_deferred_launch[2];
   // staging of the deferred batches, one pair per kind: nothing else stages through them, so any other call made
   // inside the section (a device-resident batch, an epipolar batch, the detector -- all on d_scratch1 / h_scratch1)
@@ -304,6 +305,11 @@ struct svoh_ctx {
   // resolved: a direct batch and a seed batch of one reprojection name the same frames, the second one copies the table
   std::vector<uint8_t> staged_views_key; std::vector<uint8_t> staged_views_resolved; uint64_t staged_views_generation = ~0ull;
   int staged_views_ref_levels = 0, staged_views_max_w = 1, staged_views_max_h = 1;
+  // the staged seed batch that was sent off last, as long as its device block stands (svoh_align_camera::pos_seed_unit reads
+  // the seeds' positions from it): where its views, reference indices, bearing vectors and states lie
+  struct SeedBlock { bool valid = false; const void* views = nullptr; int n_ref = 0; const int32_t* ref_idx = nullptr; const double* f = nullptr; const double* state = nullptr; int n = 0; } seed_block;
+  hipEvent_t ev_matcher_done = nullptr;   // behind the copies of a flushed section's results: what svoh_matcher_collect waits for
+  bool matcher_done_recorded = false;
   // svoh_detect_cells_batch_enqueue / _collect: the batch in flight, its blocks, the event behind its results
   struct DetectPending { bool in_flight = false, edgelets = false; int n_frames = 0, n_cells = 0; size_t cell_stride = 0, o_ck = 0, o_ek = 0, o_ang = 0; } detect_pending;
   svoh::DevBuffer d_detect;
@@ -337,6 +343,10 @@ hipError_t svoh_copy_to_device(svoh_ctx* ctx, void* dst_device, const void* src_
 int reduce_unit_counts(svoh_ctx* ctx, size_t n_units);
 void set_global_error(const char* msg);
 const Frame* find_frame(const svoh_ctx* ctx, svoh_frame_t id);
+// svoh_align_camera::pos_seed_unit (matcher.hip): for every job, pos[3 i ..] of the features with unit[i] >= 0 from the seed batch
+// in flight.  `jobs_device`: n_jobs entries in device memory, queued on the context's stream
+struct PosFromSeedsJob { double* pos; const int32_t* unit; int32_t n; int32_t pad_; };
+int svoh_launch_pos_from_seed_batch(svoh_ctx* ctx, int n_jobs, int max_n, const PosFromSeedsJob* jobs_device);
 
 #if defined(__HIPCC__)
 // Wave64 all-lanes integer sum on the VALU's DPP network (quad_perm xor 1, xor 2,

@@ -85,6 +85,7 @@ Transformation SparseImgAlignHip::buildProblem(const FrameBundle::Ptr& ref_frame
     cam.f = r.f_vec_.data() + 3 * lo;
     cam.pos_world = r.pos_world_.data() + 3 * lo;
     cam.flags = r.alignable_.data() + lo;
+    cam.pos_seed_unit = r.pos_seed_unit_.size() == r.num_features_ && r.num_features_ ? r.pos_seed_unit_.data() + lo : nullptr;
   }
   // T_iref_world_ and the optimisation variable (sparse_img_align.cpp:62, 74-75)
   const Transformation T_iref_world = ref_frames->at(0)->T_imu_world();
@@ -927,11 +928,15 @@ size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj
   return finishRun(frame_bundle, res);
 }
 
-void resolveAlignmentPoints(Frame& frame)
+void resolveAlignmentPoints(Frame& frame) { resolveAlignmentPoints(frame, nullptr); }
+
+void resolveAlignmentPoints(Frame& frame, const std::function<int32_t(const Frame& keyframe, size_t seed_id)>& unit_of)
 {
   const size_t n = frame.num_features_;
   frame.pos_world_.assign(3 * n, 0.0);
   frame.alignable_.assign(n, 0);
+  frame.pos_seed_unit_.clear();
+  if (unit_of) frame.pos_seed_unit_.assign(n, -1);
   for (size_t i = 0; i < n; ++i) {
     const uint8_t t = frame.type_vec_[i];
     if (t == SVOH_FT_MAPPOINT || t == SVOH_FT_MAPPOINT_SEED || t == SVOH_FT_MAPPOINT_SEED_CONVERGED) continue;
@@ -943,6 +948,7 @@ void resolveAlignmentPoints(Frame& frame)
       const double depth = kf.getSeedDepth(k);
       p = svoh::transform(svoh::inverse(kf.T_f_w_),
                           svoh::Vec3{ kf.f_vec_[3 * k] * depth, kf.f_vec_[3 * k + 1] * depth, kf.f_vec_[3 * k + 2] * depth });
+      if (unit_of) frame.pos_seed_unit_[i] = unit_of(kf, k);
     } else continue;
     frame.alignable_[i] = 1;
     frame.pos_world_[3 * i] = p.x; frame.pos_world_[3 * i + 1] = p.y; frame.pos_world_[3 * i + 2] = p.z;

@@ -49,6 +49,7 @@ struct Frame {
   std::vector<double> pos_world_;    // 3 x n
   // landmark or seed reference present and not a map point (sparse_img_align.cpp:239-245)
   std::vector<uint8_t> alignable_;   // n
+  std::vector<int32_t> pos_seed_unit_;   // empty, or n: see resolveAlignmentPoints(frame, unit_of)
   // members read / written by the matcher and the depth filter (frame.h:62-73, 160-170)
   std::vector<double> grad_vec_;                 // 2 x n
   std::vector<int32_t> level_vec_;               // n
@@ -152,6 +153,11 @@ struct SolverOptions {
 // Fills Frame::pos_world_ / alignable_ the way sparse_img_align.cpp:239-245 and :281-292 resolve them: the
 // landmark's position, or the seed's position via seed_ref_vec_; neither, or a map point -> not alignable.
 void resolveAlignmentPoints(Frame& frame);
+// The same while a depth-filter update is still in flight on the device: unit_of(keyframe, seed_id) >= 0 names the unit of that
+// staged batch that holds the seed -- the feature's position is then left to the device (Frame::pos_seed_unit_ ->
+// svoh_align_camera::pos_seed_unit: it reads the inverse depth the update leaves), pos_world_ holds the value from the seed's
+// state before the update and is not used for it.  Everything else as above.
+void resolveAlignmentPoints(Frame& frame, const std::function<int32_t(const Frame& keyframe, size_t seed_id)>& unit_of);
 
 class SparseImgAlignHip {
  public:

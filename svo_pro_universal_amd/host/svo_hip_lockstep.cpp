@@ -102,6 +102,7 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
   // on one device and NOT the default: 23.7 / 24.3 k frames/s against 25.6 / 23.3 k with the library's own policy
   // (profiles/r05_copy_policy_ab.txt) -- the mixed-dispatch ceiling of tools/svoh_dispatch_rate is not what the groups run into.
   if (getenv("SVOH_LOCKSTEP_RESIDENT")) opt_.resident_features = atoi(getenv("SVOH_LOCKSTEP_RESIDENT")) != 0;   // (A/B)
+  align_ahead_ = getenv("SVOH_LOCKSTEP_ALIGN_AHEAD") == nullptr || atoi(getenv("SVOH_LOCKSTEP_ALIGN_AHEAD")) != 0;   // (A/B)
   detect_ahead_ = getenv("SVOH_LOCKSTEP_DETECT_AHEAD") == nullptr || atoi(getenv("SVOH_LOCKSTEP_DETECT_AHEAD")) != 0;   // (A/B)
   // SVOH_LOCKSTEP_POSE_CHAIN=0: the depth filter's batch is queued after the host has seen the poses, as in the first version
   pose_chain_ = getenv("SVOH_LOCKSTEP_POSE_CHAIN") == nullptr || atoi(getenv("SVOH_LOCKSTEP_POSE_CHAIN")) != 0;
@@ -383,8 +384,12 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     }
   }
   pc.lap(kPhPyramid);
-  // the previous round's seed update: its results are needed from here on (alignment points, candidates)
-  finishSeedUpdate();
+  // The previous round's seed update: its results are needed from here on (alignment points, candidates) -- unless the alignment
+  // is queued AHEAD of the wait: the only thing it needs of the update is the new inverse depth of the seeds its points hang on,
+  // and the device has that (svoh_align_camera::pos_seed_unit reads the update's batch in place).  The wait for the update and
+  // the host's share of finishing it then run beside the alignment kernel.
+  const bool align_ahead = align_ahead_ && seeds_in_flight_ && round_ > 0 && opt_.images_mem_space >= 0;
+  if (!align_ahead) finishSeedUpdate();
   pc.lap(kPhFinishSeeds);
   const double t1 = now_ms();
   times_.pyramid = t1 - t0;
@@ -412,7 +417,16 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   pool_.run(S, [&](int s) {
     Stream& st = *streams_[static_cast<size_t>(s)];
     st.frame->T_f_w_ = st.last->T_f_w_;
-    resolveAlignmentPoints(*st.last);
+    if (align_ahead)
+      resolveAlignmentPoints(*st.last, [&st](const Frame& kf, size_t seed_id) -> int32_t {   // where the update in flight holds that seed
+        size_t off = st.seed_off;
+        for (size_t k = 0; k < st.seed_frames.size(); ++k) {
+          if (st.seed_frames[k].get() == &kf) return seed_id < st.seed_counts[k] ? static_cast<int32_t>(off + seed_id) : -1;
+          off += st.seed_counts[k];
+        }
+        return -1;   // a keyframe that has left the window: its seeds are not updated any more, the host's value stands
+      });
+    else resolveAlignmentPoints(*st.last);
     st.b_last.reset(new FrameBundle); st.b_cur.reset(new FrameBundle);
     st.b_last->frames_.push_back(st.last); st.b_cur->frames_.push_back(st.frame);
     st.img_align.reset();
@@ -445,6 +459,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       ++device_calls_;
     }
     pc.lap(kPhAlignLaunch);
+    if (align_ahead) { finishSeedUpdate(); pc.lap(kPhFinishSeeds); }
     // the candidate projections: one staged call for all streams that have a local map
     size_t n_points = 0, n_kf = 0;
     int n_jobs = 0;

@@ -109,6 +109,7 @@ class FrontendLockstep {
     bool in_flight = false;
   } detect_;
   bool detect_ahead_ = true;
+  bool align_ahead_ = true;   // the alignment queued ahead of the wait for the previous round's seed update
   void drainReleases();
   void check(int rc, const char* what) const;
 
