@@ -297,6 +297,28 @@ def _rigid_mul(a7, b7):
     return np.array([w, x, y, z, atx + rx, aty + ry, atz + rz])
 
 
+def _rigid_transform(T7, p):
+    """svoh::transform(Rigid, Vec3) of csrc/svoh_math.h, operation by operation."""
+    qw, qx, qy, qz, tx, ty, tz = [float(v) for v in T7]
+    vx, vy, vz = [float(v) for v in p]
+    ux = qy * vz - qz * vy; uy = qz * vx - qx * vz; uz = qx * vy - qy * vx
+    ux += ux; uy += uy; uz += uz
+    rx = vx + qw * ux + (qy * uz - qz * uy)
+    ry = vy + qw * uy + (qz * ux - qx * uz)
+    rz = vz + qw * uz + (qx * uy - qy * ux)
+    return [rx + tx, ry + ty, rz + tz]
+
+
+def _rigid_inverse(T7):
+    """svoh::inverse(Rigid) of csrc/svoh_math.h, operation by operation: conjugate; translation = -(rotation by conj(q) / |q|^2)."""
+    qw, qx, qy, qz, tx, ty, tz = [float(v) for v in T7]
+    n2 = qw * qw + qx * qx + qy * qy + qz * qz
+    iw, ix, iy, iz = qw / n2, -qx / n2, -qy / n2, -qz / n2
+    r = _rigid_transform([iw, ix, iy, iz, 0.0, 0.0, 0.0], [tx, ty, tz])
+    # (transform adds a zero translation: x + 0.0 is x)
+    return [qw, -qx, -qy, -qz, -r[0], -r[1], -r[2]]
+
+
 def _upload_features(ctx, sets):
     """svoh_features_upload for a list of seed sets (make_seed_set dictionaries) in ONE call; returns the handles."""
     m = len(sets)
@@ -709,3 +731,100 @@ def test_candidate_projection_over_resident_columns_equals_the_per_point_form(gp
         assert ctx.lib.svoh_project_candidates_enqueue_staged(ctx.h) != 0
     for h in handles:
         ctx._check(ctx.lib.svoh_features_release(ctx.h, h))
+
+
+def test_alignment_points_taken_from_the_seed_batch_in_flight(gpu_ctx):
+    """svoh_align_camera::pos_seed_unit: two alignment problems whose features are seeds of their reference frames.  A staged
+    depth-filter batch over those seeds is sent off and NOT collected; the alignment queued behind it names its points by unit --
+    the device computes T_world_keyframe x (f / mu) with the inverse depth the update leaves.  Against the same alignment given the
+    positions computed here from the collected states: every field of the result, bit for bit.  A second batch staged in between
+    (the block laid out anew) makes the entry refuse the field."""
+    import copy
+    ctx = gpu_ctx
+    cam = synth.Camera.euroc_like()
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(cam)
+    pairs = [seed_scene(ctx, 960 + i, cam) for i in range(2)]
+    sets = [synth.make_seed_set(sc, 220 + 60 * i, seed=30 + i, margin=14) for i, (sc, fr, fc) in enumerate(pairs)]
+    n_each = [sd["level"].size for sd in sets]
+    n = sum(n_each)
+    refs = (capi.svoh_frame_view * 2)(*[fe.make_frame_view(fr, cam, sc.T_ref_f_w, sd["mu_range"], 0) for (sc, fr, fc), sd in zip(pairs, sets)])
+    curs = (capi.svoh_frame_view * 2)(*[fe.make_frame_view(fc, cam, sc.T_cur_f_w_gt, 0.0, 1) for (sc, fr, fc) in pairs])
+
+    def stage_and_send():
+        ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+        g = capi.svoh_matcher_stage_t()
+        ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, n, 8, 0, C.byref(g)))
+        off = 0
+        for k, sd in enumerate(sets):
+            m = n_each[k]
+            _view(g.ref_frame_idx, np.int32, n)[off:off + m] = k
+            _view(g.cur_frame_idx, np.int32, n)[off:off + m] = k
+            _view(g.px, np.float64, 2 * n)[2 * off:2 * (off + m)] = sd["px"]
+            _view(g.f, np.float64, 3 * n)[3 * off:3 * (off + m)] = sd["f"]
+            _view(g.grad, np.float64, 2 * n)[2 * off:2 * (off + m)] = sd["grad"]
+            _view(g.level, np.int32, n)[off:off + m] = sd["level"]
+            _view(g.type, np.uint8, n)[off:off + m] = sd["type"]
+            _view(g.state, np.float64, 4 * n)[4 * off:4 * (off + m)] = sd["state"]
+            off += m
+        fb = capi.svoh_feature_batch()
+        fb.n, fb.mem_space, fb.n_cur_frames = n, capi.SVOH_MEM_STAGED, 2
+        for k in ("ref_frame_idx", "cur_frame_idx", "px", "f", "grad", "level", "type"):
+            setattr(fb, k, getattr(g, k))
+        ctx._check(ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 2, refs, curs, C.byref(fb), g.state, g.success, g.result, None))
+        ctx._check(ctx.lib.svoh_matcher_flush(ctx.h))
+        return g
+
+    def align_scene(k, pos_world):
+        sc = copy.copy(pairs[k][0])
+        sd = sets[k]
+        sc.n_features = n_each[k]
+        sc.px, sc.f, sc.pos_world = sd["px"], sd["f"], pos_world
+        sc.flags = np.ones(n_each[k], np.uint8)
+        return sc
+    opt = capi.default_align_options(max_level=4, min_level=2)
+    # (a) the update sent off, the alignment queued behind it with its points named by unit, garbage where the positions would be
+    g = stage_and_send()
+    units = [np.arange(sum(n_each[:k]), sum(n_each[:k + 1]), dtype=np.int32) for k in range(2)]
+    units[1][::9] = -1                                   # some points keep the host's position ...
+    pos_dummy = [np.full(3 * m, 1.0e30) for m in n_each]
+    problems, keep = fe.make_align_problems([[(align_scene(k, pos_dummy[k]), pairs[k][1], pairs[k][2])] for k in range(2)])
+    ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))      # (needed here to know the positions of the kept points; the block stands)
+    state_after = _view(g.state, np.float64, 4 * n).copy().reshape(-1, 4)
+    pos_host = []
+    for k, (sc, fr, fc) in enumerate(pairs):
+        lo = sum(n_each[:k])
+        mu = state_after[lo:lo + n_each[k], 0]
+        T_w_kf = _rigid_inverse(fe.se3_to_numpy(refs[k].T_f_w))
+        f = sets[k]["f"].reshape(-1, 3)
+        p = np.empty((n_each[k], 3))
+        for i in range(n_each[k]):
+            depth = 1.0 / float(mu[i])
+            p[i] = _rigid_transform(T_w_kf, [float(f[i, 0]) * depth, float(f[i, 1]) * depth, float(f[i, 2]) * depth])
+        pos_host.append(np.ascontiguousarray(p.ravel()))
+    kept = units[1] < 0
+    pos_dummy[1].reshape(-1, 3)[kept] = pos_host[1].reshape(-1, 3)[kept]   # ... which must then be right on the host side
+    problems, keep = fe.make_align_problems([[(align_scene(k, pos_dummy[k]), pairs[k][1], pairs[k][2])] for k in range(2)])
+    for k in range(2):
+        problems[k].cams[0].pos_seed_unit = units[k].ctypes.data
+    got = ctx.sparse_align(opt, problems)
+    # (b) the positions computed here
+    problems_b, keep_b = fe.make_align_problems([[(align_scene(k, pos_host[k]), pairs[k][1], pairs[k][2])] for k in range(2)])
+    want = ctx.sparse_align(opt, problems_b)
+    for k in range(2):
+        assert result_bits(got[k]) == result_bits(want[k]), k
+        assert want[k].status == 0 and want[k].n_fts_to_track > 50
+    # the update still in flight (not collected): the same again, the alignment queued right behind the flush
+    g = stage_and_send()
+    got2 = ctx.sparse_align(opt, problems)
+    ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+    assert np.array_equal(_view(g.state, np.float64, 4 * n).reshape(-1, 4), state_after)
+    for k in range(2):
+        assert result_bits(got2[k]) == result_bits(want[k]), k
+    # the seed block staged again since: refused before anything is queued
+    ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+    ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, 16, 4, 0, C.byref(capi.svoh_matcher_stage_t())))
+    res = (capi.svoh_align_result * 2)()
+    assert ctx.lib.svoh_sparse_align_batch(ctx.h, C.byref(opt), 2, problems, res) != 0
+    ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+    for sc, fr, fc in pairs:
+        ctx.release_frame(fr); ctx.release_frame(fc)
