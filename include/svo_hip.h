@@ -261,9 +261,9 @@ typedef struct svoh_align_camera {
    * (sparse_img_align.cpp:239-245) */
   const uint8_t* flags;
   /* NULL, or n entries (host memory; SVOH_MEM_HOST cameras only): pos_seed_unit[i] >= 0 says feature i is a seed whose position
-   * is to be taken ON THE DEVICE from unit pos_seed_unit[i] of the depth filter's staged batch that was last sent off on this
-   * context (svoh_update_seeds_batch with SVOH_MEM_STAGED + svoh_matcher_flush, not collected or collected -- its device block
-   * must not have been staged again): T_world_keyframe x (f / mu) with the inverse depth the update leaves, the arithmetic of
+   * is to be taken ON THE DEVICE from unit pos_seed_unit[i] of the seed batch that was last sent off in a deferred section
+   * of this context (svoh_update_seeds_batch(_ex) + svoh_matcher_flush / _collect, host arrays or SVOH_MEM_STAGED; collected or not
+   * -- its device block must not have been laid out for another seed batch since): T_world_keyframe x (f / mu) with the inverse depth the update leaves, the arithmetic of
    * seed_ref.keyframe->T_world_cam() * getSeedPosInFrame(seed_id) (sparse_img_align.cpp:281-292).  pos_world[i] is ignored for
    * such a feature.  The alignment of the next frame can then be queued before the host has seen the update's results. */
   const int32_t* pos_seed_unit;

@@ -4124,9 +4124,9 @@ static int launch_deferred(svoh_ctx* ctx)
       if (!ctx->ev_matcher_done) SVOH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_matcher_done, hipEventDisableTiming));
       SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_matcher_done, ctx->stream));
       ctx->matcher_done_recorded = true;
-      if (v1 && d1.seed_block_staged) {   // a staged seed batch: its block can serve svoh_align_camera::pos_seed_unit until it is staged again
+      if (v1 && a1.state) {   // a seed batch of the section (staged or from host arrays): its device block can serve svoh_align_camera::pos_seed_unit until it is laid out anew
         svoh_ctx::SeedBlock& sb = ctx->seed_block;
-        sb.valid = true; sb.views = d1.views_d; sb.n_ref = d1.n_ref; sb.ref_idx = a1.ref_frame_idx; sb.f = a1.f; sb.state = a1.state; sb.n = d1.n;
+        sb.valid = true; sb.views = a1.ref_frames; sb.n_ref = a1.n_ref_frames; sb.ref_idx = a1.ref_frame_idx; sb.f = a1.f; sb.state = a1.state; sb.n = d1.n;
       }
     }
   }

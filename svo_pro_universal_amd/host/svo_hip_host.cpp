@@ -296,6 +296,17 @@ void DepthFilterHip::updateSeedsAsync(const std::vector<FramePtr>& ref_frames_wi
   queueUpdateSeeds(ref_frames_with_seeds, cur_frame, true);
 }
 
+int32_t DepthFilterHip::unitOfPendingSeed(const Frame& keyframe, size_t seed_id) const
+{
+  if (!async_open_ || prepared_) return -1;
+  size_t off = 0;
+  for (size_t k = 0; k < pending_.frames.size(); ++k) {
+    if (pending_.frames[k].get() == &keyframe) return seed_id < pending_.counts[k] ? static_cast<int32_t>(off + seed_id) : -1;
+    off += pending_.counts[k];
+  }
+  return -1;
+}
+
 void DepthFilterHip::prepareUpdateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame)
 {
   if (prepared_) throw std::runtime_error("DepthFilterHip::prepareUpdateSeeds: an update is prepared already");

@@ -274,6 +274,10 @@ class DepthFilterHip {
   // staged and uploaded now; updateSeedsAsync(same frames, cur_frame) then only replaces the current frame's view and
   // sends the kernel off.  Between the two calls nothing but cur_frame's pose may change.
   void prepareUpdateSeeds(const std::vector<FramePtr>& ref_frames_with_seeds, const FramePtr& cur_frame);
+  // the unit of the update in flight (updateSeedsAsync, not finished yet) that holds seed `seed_id` of `keyframe`, or -1: for
+  // resolveAlignmentPoints(frame, unit_of) -- the next frame's alignment queued before this update's results are back
+  int32_t unitOfPendingSeed(const Frame& keyframe, size_t seed_id) const;
+  bool updateInFlight() const { return async_open_ && !prepared_; }
   void finishUpdateSeedsEarly();   // what finishPendingSeedUpdate calls
   bool updatePending() const { return async_open_; }
   ~DepthFilterHip();

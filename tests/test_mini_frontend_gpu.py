@@ -193,6 +193,9 @@ def test_lockstep_variants_and_the_tracked_features_rule(tmp_path):
             # the single stream with its passes' selection taken from the device (svoh_select_matches_batch): the same files
             sel = run([str(n_frames), kf_every, "1"], {"SVOH_REPROJ_DEVICE_SELECT": "1"})[0]
             assert sel[0] == single[0] and np.array_equal(sel[1], single[1])
+            # ... and with its alignment queued ahead of the wait for the previous frame's seed update (points from the device)
+            ahead = run([str(n_frames), kf_every, "1"], {"SVOH_MINI_ALIGN_AHEAD": "1"})[0]
+            assert ahead[0] == single[0] and np.array_equal(ahead[1], single[1])
         if kf_every == "1000":
             assert single[1][1:, 1].sum() >= 1, "the tracked-features rule never fired: the case tests nothing"
         for env in ({}, {"SVOH_LOCKSTEP_RESIDENT": "0"}, {"SVOH_LOCKSTEP_POSE_CHAIN": "0"}, {"SVOH_LOCKSTEP_DETECT_AHEAD": "0"}, {"SVOH_LOCKSTEP_ALIGN_AHEAD": "0"}):
