@@ -10,6 +10,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/svo_hip.h"
@@ -49,7 +50,15 @@ struct SlabPool {
   }
   bool give(void* p, size_t alloc)
   {
-    if (free_list.size() >= kMaxEntries || held + alloc > kMaxBytes) return false;
+    if (alloc > kMaxBytes) return false;
+    // full: the OLDEST entry goes (not the newcomer).  A context whose frames change size -- another camera, another number of
+    // streams per multi-frame call -- would otherwise keep eight slabs nobody asks for again and pay a hipMalloc + hipFree for
+    // every frame from then on; this way the pool has turned over after eight releases.
+    while (!free_list.empty() && (free_list.size() >= kMaxEntries || held + alloc > kMaxBytes)) {
+      held -= free_list.front().alloc;
+      (void)hipFree(free_list.front().ptr);
+      free_list.erase(free_list.begin());
+    }
     free_list.push_back({ p, alloc });
     held += alloc;
     return true;
@@ -57,29 +66,39 @@ struct SlabPool {
   ~SlabPool() { for (const Entry& e : free_list) (void)hipFree(e.ptr); }
 };
 
-// Released blocks of resident feature columns (svoh_features_upload), for the next upload: any block at least as large as
-// asked and at most twice that.  Same reason as SlabPool: hipFree waits for the whole device.
+// Released blocks of resident feature columns (svoh_features_upload), for the next upload: the smallest block that is large
+// enough.  Same reason as SlabPool: hipFree waits for the whole device -- so blocks are never freed one by one: a call's block
+// is as large as the call's new keyframes (one stream's, or sixty-four streams'), a pool that only took near-equal sizes back
+// filled up with blocks nobody asked for again and then paid a hipFree per release (0.66 ms per round of a group that had
+// served 64 streams before it served 32).  When the pool is full its smaller half is freed in one go.
 struct BlockPool {
   struct Entry { void* ptr; size_t alloc; };
-  static constexpr size_t kMaxEntries = 256;
-  static constexpr size_t kMaxBytes = (size_t)256 << 20;
+  static constexpr size_t kMaxEntries = 1024;
+  static constexpr size_t kMaxBytes = (size_t)2 << 30;
   std::vector<Entry> free_list;
   size_t held = 0;
   void* take(size_t want, size_t* got)
   {
     size_t best = free_list.size();
     for (size_t i = 0; i < free_list.size(); ++i)
-      if (free_list[i].alloc >= want && free_list[i].alloc <= 2 * want && (best == free_list.size() || free_list[i].alloc < free_list[best].alloc)) best = i;
+      if (free_list[i].alloc >= want && (best == free_list.size() || free_list[i].alloc < free_list[best].alloc)) best = i;
     if (best == free_list.size()) return nullptr;
     void* p = free_list[best].ptr;
     *got = free_list[best].alloc;
     held -= *got;
-    free_list.erase(free_list.begin() + (long)best);
+    free_list[best] = free_list.back();
+    free_list.pop_back();
     return p;
   }
   bool give(void* p, size_t alloc)
   {
-    if (free_list.size() >= kMaxEntries || held + alloc > kMaxBytes) return false;
+    if (free_list.size() >= kMaxEntries || held + alloc > kMaxBytes) {
+      std::sort(free_list.begin(), free_list.end(), [](const Entry& a, const Entry& b) { return a.alloc < b.alloc; });
+      const size_t drop = (free_list.size() + 1) / 2;
+      for (size_t i = 0; i < drop; ++i) { held -= free_list[i].alloc; (void)hipFree(free_list[i].ptr); }
+      free_list.erase(free_list.begin(), free_list.begin() + (long)drop);
+      if (held + alloc > kMaxBytes) return false;
+    }
     free_list.push_back({ p, alloc });
     held += alloc;
     return true;
