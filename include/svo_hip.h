@@ -664,10 +664,16 @@ typedef struct svoh_candidate_stage_t {
   double* px;                       /* out: 2 x n_points_total */
   uint8_t* visible;                 /* out: n_points_total */
   svoh_candidate_range* ranges;     /* n_kf_total (the ranges form), else NULL */
+  /* the ranges form: n_points_total entries, preset to -1.  mu_unit[i] >= 0: the seed's inverse depth is read ON THE DEVICE from
+   * unit mu_unit[i] of the seed batch last sent off on this context (as svoh_align_camera::pos_seed_unit; mu[i] is ignored), so
+   * that the projection can be queued before the host has seen that update's results.  Enqueue with
+   * svoh_project_candidates_enqueue_staged_units then. */
+  int32_t* mu_unit;
 } svoh_candidate_stage_t;
 int svoh_project_candidates_stage(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_points_total, svoh_candidate_stage_t* out);
 int svoh_project_candidates_stage_ranges(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_points_total, svoh_candidate_stage_t* out);
 int svoh_project_candidates_enqueue_staged(svoh_ctx* ctx);
+int svoh_project_candidates_enqueue_staged_units(svoh_ctx* ctx);   /* the ranges form with mu_unit entries >= 0 */
 int svoh_project_candidates_wait(svoh_ctx* ctx);
 
 /* The candidate SELECTION of reprojector_utils::matchCandidates (src/svo/src/reprojector.cpp:342-382) for many lists at once, the

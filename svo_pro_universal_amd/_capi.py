@@ -117,7 +117,7 @@ class svoh_candidate_job(C.Structure):
 
 
 class svoh_candidate_stage_t(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("jobs", "T_world_kf", "job", "kind", "kf", "v", "mu", "px", "visible", "ranges")]
+    _fields_ = [(k, C.c_void_p) for k in ("jobs", "T_world_kf", "job", "kind", "kf", "v", "mu", "px", "visible", "ranges", "mu_unit")]
 
 
 class svoh_candidate_range(C.Structure):
@@ -299,7 +299,7 @@ EXPORTS = [
     # round 5: what the lock-step front end of many camera streams stages in place and launches once per stage
     "svoh_host_alloc", "svoh_host_free", "svoh_build_pyramid_multi", "svoh_build_pyramid_multi_prefetch", "svoh_prefetch_fence",
     "svoh_sparse_align_geometry_key", "svoh_sparse_align_enqueue_keyed",
-    "svoh_project_candidates_stage", "svoh_project_candidates_stage_ranges", "svoh_project_candidates_enqueue_staged", "svoh_project_candidates_wait",
+    "svoh_project_candidates_stage", "svoh_project_candidates_stage_ranges", "svoh_project_candidates_enqueue_staged", "svoh_project_candidates_enqueue_staged_units", "svoh_project_candidates_wait",
     "svoh_matcher_stage", "svoh_detect_cells_batch", "svoh_detect_cells_batch_enqueue", "svoh_detect_cells_batch_collect", "svoh_detect_fill_features", "svoh_features_upload", "svoh_features_release", "svoh_select_matches_batch",
 ]
 

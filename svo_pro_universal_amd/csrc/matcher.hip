@@ -3673,6 +3673,8 @@ struct RangeCandidateArgs {
   const uint8_t* kind;
   const double* v;      // landmarks only (NULL when the launch has none)
   const double* mu;
+  const int32_t* mu_unit;       // NULL, or per point: >= 0 = the inverse depth of that unit of the seed batch in flight
+  const double* unit_state; int n_units;
   double* px;
   uint8_t* visible;
   int n, n_jobs, n_ranges;
@@ -3699,7 +3701,9 @@ __global__ __launch_bounds__(256) void project_candidates_ranges_kernel(const Ra
   if (a.kind[i]) {
     ok = lo >= jb.kf_begin && lo < jb.kf_begin + jb.n_kf && jf < rg.n_feat;
     if (ok) {
-      const double depth = 1.0 / a.mu[i];                        // seed::getDepth (seed.h:110-113)
+      double mu_i = a.mu[i];
+      if (a.mu_unit) { const int u = a.mu_unit[i]; if (u >= 0 && u < a.n_units) mu_i = a.unit_state[4 * (size_t)u]; }
+      const double depth = 1.0 / mu_i;                           // seed::getDepth (seed.h:110-113)
       const Vec3 in_f = { rg.f[3 * jf] * depth, rg.f[3 * jf + 1] * depth, rg.f[3 * jf + 2] * depth };
       xyz = transform(load_rigid(a.T_world_kf[lo]), in_f);
     }
@@ -3828,7 +3832,7 @@ static int stage_candidates(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_poi
     // [jobs | T_world_kf | device ranges | kind | mu | v]: v last, uploaded only when a landmark is among the points; the ranges
     // as the caller writes them (handles) stay on the host
     st.o_dev_ranges = add(sizeof(DevCandidateRange) * (size_t)n_kf_total);
-    st.o_kind = add(np); st.o_mu = add(8 * np);
+    st.o_kind = add(np); st.o_mu = add(8 * np); st.o_mu_unit = add(4 * np);
     st.in_total_without_v = total;
     st.o_v = add(24 * np);
     st.in_total = total;
@@ -3847,7 +3851,11 @@ static int stage_candidates(svoh_ctx* ctx, int n_jobs, int n_kf_total, int n_poi
   out->jobs = reinterpret_cast<svoh_candidate_job*>(h + st.o_jobs);
   out->T_world_kf = reinterpret_cast<svoh_se3*>(h + st.o_kf);
   out->kind = h + st.o_kind;
-  if (ranges) out->ranges = reinterpret_cast<svoh_candidate_range*>(h + st.o_ranges);
+  if (ranges) {
+    out->ranges = reinterpret_cast<svoh_candidate_range*>(h + st.o_ranges);
+    out->mu_unit = reinterpret_cast<int32_t*>(h + st.o_mu_unit);
+    memset(out->mu_unit, 0xff, 4 * np);   // -1 everywhere
+  }
   else { out->job = reinterpret_cast<int32_t*>(h + st.o_job); out->kf = reinterpret_cast<int32_t*>(h + st.o_idx); }
   out->v = reinterpret_cast<double*>(h + st.o_v); out->mu = reinterpret_cast<double*>(h + st.o_mu);
   out->px = reinterpret_cast<double*>(h + st.o_px); out->visible = h + st.o_vis;
@@ -3865,10 +3873,12 @@ try {
   return stage_candidates(ctx, n_jobs, n_kf_total, n_points_total, out, true);
 } SVOH_ABI_CATCH(ctx)
 
-int svoh_project_candidates_enqueue_staged(svoh_ctx* ctx)
-try {
+static int enqueue_staged_candidates(svoh_ctx* ctx, bool with_units)
+{
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   svoh_ctx::CandStage& st = ctx->cand_stage;
+  SVOH_REQUIRE(ctx, !with_units || (st.ranges && ctx->seed_block.valid),
+               "mu_unit: the ranges form only, and a seed batch must have been sent off on this context (its block not laid out anew since)");
   SVOH_REQUIRE(ctx, st.state == 1, "nothing staged (svoh_project_candidates_stage)");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   uint8_t* h = static_cast<uint8_t*>(ctx->h_cand_multi.ptr);
@@ -3912,6 +3922,7 @@ try {
     a.T_world_kf = reinterpret_cast<const svoh_se3*>(d + st.o_kf);
     a.ranges = reinterpret_cast<const DevCandidateRange*>(d + st.o_dev_ranges);
     a.kind = d + st.o_kind; a.mu = reinterpret_cast<const double*>(d + st.o_mu);
+    if (with_units) { a.mu_unit = reinterpret_cast<const int32_t*>(d + st.o_mu_unit); a.unit_state = ctx->seed_block.state; a.n_units = ctx->seed_block.n; }
     a.v = any_landmark ? reinterpret_cast<const double*>(d + st.o_v) : nullptr;
     a.px = reinterpret_cast<double*>(d + st.o_px); a.visible = d + st.o_vis;
     a.n = st.n_points; a.n_jobs = st.n_jobs; a.n_ranges = st.n_kf;
@@ -3939,6 +3950,16 @@ try {
   SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + st.o_px, d + st.o_px, st.total - st.o_px));
   st.state = 2;
   return SVOH_OK;
+}
+
+int svoh_project_candidates_enqueue_staged(svoh_ctx* ctx)
+try {
+  return enqueue_staged_candidates(ctx, false);
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_project_candidates_enqueue_staged_units(svoh_ctx* ctx)
+try {
+  return enqueue_staged_candidates(ctx, true);
 } SVOH_ABI_CATCH(ctx)
 
 int svoh_project_candidates_wait(svoh_ctx* ctx)

@@ -314,7 +314,7 @@ struct svoh_ctx {
   // svoh_project_candidates_stage / _enqueue_staged / _wait: many jobs, staged in place (blocks of their own)
   svoh::DevBuffer d_cand_multi;
   svoh::PinnedBuffer h_cand_multi;
-  struct CandStage { int n_jobs = 0, n_kf = 0, n_points = 0; size_t o_jobs = 0, o_kf = 0, o_job = 0, o_kind = 0, o_idx = 0, o_v = 0, o_mu = 0, in_total = 0, o_px = 0, o_vis = 0, total = 0, o_ranges = 0, o_dev_ranges = 0, in_total_without_v = 0; bool ranges = false; int state = 0; } cand_stage;   // state: 0 none, 1 staged, 2 in flight
+  struct CandStage { int n_jobs = 0, n_kf = 0, n_points = 0; size_t o_jobs = 0, o_kf = 0, o_job = 0, o_kind = 0, o_idx = 0, o_v = 0, o_mu = 0, in_total = 0, o_px = 0, o_vis = 0, total = 0, o_ranges = 0, o_dev_ranges = 0, in_total_without_v = 0, o_mu_unit = 0; bool ranges = false; int state = 0; } cand_stage;   // state: 0 none, 1 staged, 2 in flight
 
   svoh::DevBuffer d_seed_bin;          // packed seed update: histogram, ranks, sorted records (nothing else writes here)
   void* seed_hist_ptr = nullptr;       // the binning histogram at this address ...

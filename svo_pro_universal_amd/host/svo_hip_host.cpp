@@ -1168,8 +1168,10 @@ void ReprojectorHip::countCandidateProjection(const std::vector<FramePtr>& kfs, 
   if (n_kf) *n_kf = nk;
 }
 
-void ReprojectorHip::gatherCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const ProjectionArrays& into)
+void ReprojectorHip::gatherCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const ProjectionArrays& into,
+                                               const std::function<int32_t(const Frame& keyframe, size_t seed_id)>& unit_of)
 {
+  if (unit_of && !(into.ranges && into.mu_unit)) throw std::runtime_error("ReprojectorHip::gatherCandidateProjection: seed units need the ranges form with mu_unit");
   proj_kf_off_.clear();
   size_t at = 0;
   int32_t k = 0;
@@ -1191,13 +1193,14 @@ void ReprojectorHip::gatherCandidateProjection(const FramePtr& cur_frame, const 
         into.kind[at] = 1;
         if (!into.ranges) { v[0] = kf->f_vec_[3 * i]; v[1] = kf->f_vec_[3 * i + 1]; v[2] = kf->f_vec_[3 * i + 2]; }   // (the ranges form reads the resident f column)
         into.mu[at] = 4 * i < kf->invmu_sigma2_a_b_vec_.size() ? kf->invmu_sigma2_a_b_vec_[4 * i] : 1.0;
+        if (unit_of) into.mu_unit[at] = unit_of(*kf, i);   // (>= 0: the device reads the update's result; mu above is the state before it)
       }
       if (!into.ranges) into.kf[at] = k;
     }
     ++k;
   }
   proj_n_points_ = at; proj_n_kf_ = static_cast<size_t>(k);
-  proj_kind_p_ = into.kind; proj_v_p_ = into.v; proj_mu_p_ = into.mu;
+  proj_kind_p_ = into.kind; proj_v_p_ = into.v; proj_mu_p_ = into.mu; proj_unit_p_ = unit_of ? into.mu_unit : nullptr;
   proj_px_p_ = nullptr; proj_visible_p_ = nullptr;
   proj_frame_ = at ? cur_frame.get() : nullptr;
   proj_frame_id_ = cur_frame->id_;
@@ -1292,7 +1295,8 @@ void ReprojectorHip::walkCandidates(const FramePtr& cur_frame, const std::vector
         const Point* lm = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i].get() : nullptr;
         bool fresh;
         if (lm) { const svoh::Vec3 p = lm->pos(); fresh = proj_kind_p_[at] == 0 && p.x == proj_v_p_[3 * at] && p.y == proj_v_p_[3 * at + 1] && p.z == proj_v_p_[3 * at + 2]; }
-        else fresh = proj_kind_p_[at] == 1 && (4 * i < ref_frame->invmu_sigma2_a_b_vec_.size() ? ref_frame->invmu_sigma2_a_b_vec_[4 * i] : 1.0) == proj_mu_p_[at];
+        else fresh = proj_kind_p_[at] == 1 && ((proj_unit_p_ && proj_unit_p_[at] >= 0) ||   // (read on the device from the update the driver has finished since)
+                                               (4 * i < ref_frame->invmu_sigma2_a_b_vec_.size() ? ref_frame->invmu_sigma2_a_b_vec_[4 * i] : 1.0) == proj_mu_p_[at]);
         if (fresh) {
           if (!proj_visible_p_[at]) return;
           list.emplace_back();

@@ -511,9 +511,14 @@ class ReprojectorHip {
   //     ranges != NULL (svoh_project_candidates_stage_ranges): every keyframe must have resident columns (Frame::features); its
   //     entry of the table is written as the range of its points -- they begin at point_offset of the whole launch and belong to
   //     `job` -- and per point only kind and mu (a landmark's position too) are written: kf stays untouched
-  struct ProjectionArrays { svoh_se3* T_world_kf; uint8_t* kind; int32_t* kf; double* v; double* mu; svoh_candidate_range* ranges = nullptr; int32_t point_offset = 0, job = 0; };
+  struct ProjectionArrays { svoh_se3* T_world_kf; uint8_t* kind; int32_t* kf; double* v; double* mu; svoh_candidate_range* ranges = nullptr; int32_t point_offset = 0, job = 0;
+                           // mu_unit != NULL (ranges form): a seed point whose keyframe's seeds are in a depth-filter update still in flight
+                           // names the unit of that batch (unit_of, as resolveAlignmentPoints) instead of carrying its inverse depth -- the
+                           // driver must finish that update before it walks the candidates (walkCandidates trusts such points)
+                           int32_t* mu_unit = nullptr; };
   void countCandidateProjection(const std::vector<FramePtr>& kfs, size_t* n_points, size_t* n_kf) const;
-  void gatherCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const ProjectionArrays& into);
+  void gatherCandidateProjection(const FramePtr& cur_frame, const std::vector<FramePtr>& kfs, const ProjectionArrays& into,
+                                 const std::function<int32_t(const Frame& keyframe, size_t seed_id)>& unit_of = nullptr);
   void adoptCandidateProjection(const FramePtr& cur_frame, const double* px, const uint8_t* visible);
   // (2) grid and statistics reset, the walk over the visible keyframes' features: the three candidate lists
   void walkCandidates(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points);
@@ -549,7 +554,7 @@ class ReprojectorHip {
   struct ProjKf { const Frame* frame; int id; size_t offset; size_t n_features; Transformation T_f_w; };
   std::vector<ProjKf> proj_kf_off_;
   // the projection's inputs and results, read through these (the vectors below, or the driver's page-locked block)
-  const uint8_t* proj_kind_p_ = nullptr; const double* proj_v_p_ = nullptr; const double* proj_mu_p_ = nullptr;
+  const uint8_t* proj_kind_p_ = nullptr; const double* proj_v_p_ = nullptr; const double* proj_mu_p_ = nullptr; const int32_t* proj_unit_p_ = nullptr;
   const double* proj_px_p_ = nullptr; const uint8_t* proj_visible_p_ = nullptr;
   size_t proj_n_points_ = 0, proj_n_kf_ = 0;
   std::vector<uint8_t> proj_kind_, proj_visible_;

@@ -459,7 +459,10 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       ++device_calls_;
     }
     pc.lap(kPhAlignLaunch);
-    if (align_ahead) { finishSeedUpdate(); pc.lap(kPhFinishSeeds); }
+    // ... and so is the candidate projection when its points are ranges over resident columns: a seed's inverse depth comes from the
+    // update's batch on the device as well (svoh_candidate_stage_t::mu_unit), the wait moves behind both launches
+    const bool proj_ahead = align_ahead && opt_.resident_features;
+    if (align_ahead && !proj_ahead) { finishSeedUpdate(); pc.lap(kPhFinishSeeds); }
     // the candidate projections: one staged call for all streams that have a local map
     size_t n_points = 0, n_kf = 0;
     int n_jobs = 0;
@@ -484,14 +487,25 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
         jb.point_begin = static_cast<int32_t>(st.proj_point_off); jb.n_points = static_cast<int32_t>(st.proj_points);
         const size_t o = st.proj_point_off;
         ReprojectorHip::ProjectionArrays into{ cs.T_world_kf + st.proj_kf_off, cs.kind + o, cs.kf ? cs.kf + o : nullptr, cs.v + 3 * o, cs.mu + o };
-        if (cs.ranges) { into.ranges = cs.ranges + st.proj_kf_off; into.point_offset = static_cast<int32_t>(o); into.job = st.proj_job; }
-        st.reprojector.gatherCandidateProjection(st.frame, st.visible, into);
+        if (cs.ranges) { into.ranges = cs.ranges + st.proj_kf_off; into.point_offset = static_cast<int32_t>(o); into.job = st.proj_job; into.mu_unit = cs.mu_unit + o; }
+        if (proj_ahead)
+          st.reprojector.gatherCandidateProjection(st.frame, st.visible, into, [&st](const Frame& kf, size_t seed_id) -> int32_t {
+            size_t off = st.seed_off;
+            for (size_t k = 0; k < st.seed_frames.size(); ++k) {
+              if (st.seed_frames[k].get() == &kf) return seed_id < st.seed_counts[k] ? static_cast<int32_t>(off + seed_id) : -1;
+              off += st.seed_counts[k];
+            }
+            return -1;
+          });
+        else st.reprojector.gatherCandidateProjection(st.frame, st.visible, into);
         if (cs.job) for (size_t i = 0; i < st.proj_points; ++i) cs.job[o + i] = st.proj_job;
       });
-      check(svoh_project_candidates_enqueue_staged(ctx_), "svoh_project_candidates_enqueue_staged");
+      if (proj_ahead) check(svoh_project_candidates_enqueue_staged_units(ctx_), "svoh_project_candidates_enqueue_staged_units");
+      else check(svoh_project_candidates_enqueue_staged(ctx_), "svoh_project_candidates_enqueue_staged");
       ++device_calls_;
     }
     pc.lap(kPhProjGather);
+    if (proj_ahead) { finishSeedUpdate(); pc.lap(kPhFinishSeeds); }   // the previous round's seed update: waited for and written back beside the two kernels
     check(svoh_sparse_align_fetch_all(ctx_, S, align_results.data()), "svoh_sparse_align_fetch_all");
     ++device_calls_;
     if (n_jobs) check(svoh_project_candidates_wait(ctx_), "svoh_project_candidates_wait");

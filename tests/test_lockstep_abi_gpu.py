@@ -828,3 +828,95 @@ def test_alignment_points_taken_from_the_seed_batch_in_flight(gpu_ctx):
     ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
     for sc, fr, fc in pairs:
         ctx.release_frame(fr); ctx.release_frame(fc)
+
+
+def test_candidate_projection_reads_inverse_depths_from_the_seed_batch_in_flight(gpu_ctx):
+    """svoh_candidate_stage_t::mu_unit (ranges form): the points of two keyframes are the seeds of a depth-filter batch that has
+    been sent off; the projection queued behind it names each seed's unit instead of carrying its inverse depth.  Against the
+    projection given the inverse depths the update left: pixels and verdicts bit for bit.  Without a seed batch on the context
+    the entry refuses."""
+    ctx = gpu_ctx
+    cam = synth.Camera.euroc_like()
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(cam)
+    pairs = [seed_scene(ctx, 980 + i, cam) for i in range(2)]
+    sets = [synth.make_seed_set(sc, 300 + 80 * i, seed=40 + i, margin=14) for i, (sc, fr, fc) in enumerate(pairs)]
+    n_each = [sd["level"].size for sd in sets]
+    n = sum(n_each)
+    handles = _upload_features(ctx, sets)
+    refs = (capi.svoh_frame_view * 2)(*[fe.make_frame_view(fr, cam, sc.T_ref_f_w, sd["mu_range"], 0) for (sc, fr, fc), sd in zip(pairs, sets)])
+    curs = (capi.svoh_frame_view * 2)(*[fe.make_frame_view(fc, cam, sc.T_cur_f_w_gt, 0.0, 1) for (sc, fr, fc) in pairs])
+
+    def project(mu_per_set, units_per_set, with_units):
+        cs = capi.svoh_candidate_stage_t()
+        ctx._check(ctx.lib.svoh_project_candidates_stage_ranges(ctx.h, 1, 2, n, C.byref(cs)))
+        jj = capi.svoh_candidate_job()
+        jj.cam, jj.T_f_w_or_T_cam_imu, jj.align_result_index = fe._camera(cam), fe._se3(pairs[0][0].T_cur_f_w_gt), -1
+        jj.kf_begin, jj.n_kf, jj.point_begin, jj.n_points = 0, 2, 0, n
+        C.cast(cs.jobs, C.POINTER(capi.svoh_candidate_job))[0] = jj
+        karr = C.cast(cs.T_world_kf, C.POINTER(capi.svoh_se3))
+        rarr = C.cast(cs.ranges, C.POINTER(capi.svoh_candidate_range))
+        assert np.all(_view(cs.mu_unit, np.int32, n) == -1)   # preset
+        off = 0
+        for k, (sc, fr, fc) in enumerate(pairs):
+            karr[k] = fe._se3(_rigid_inverse(fe.se3_to_numpy(refs[k].T_f_w)))
+            r = capi.svoh_candidate_range()
+            r.features, r.point_begin, r.n_points, r.job = handles[k], off, n_each[k], 0
+            rarr[k] = r
+            _view(cs.kind, np.uint8, n)[off:off + n_each[k]] = 1
+            _view(cs.mu, np.float64, n)[off:off + n_each[k]] = mu_per_set[k]
+            if units_per_set is not None:
+                _view(cs.mu_unit, np.int32, n)[off:off + n_each[k]] = units_per_set[k]
+            off += n_each[k]
+        rc = (ctx.lib.svoh_project_candidates_enqueue_staged_units if with_units else ctx.lib.svoh_project_candidates_enqueue_staged)(ctx.h)
+        if rc != 0:
+            return rc, None, None
+        ctx._check(ctx.lib.svoh_project_candidates_wait(ctx.h))
+        return 0, _view(cs.px, np.float64, 2 * n).copy(), _view(cs.visible, np.uint8, n).copy()
+    # no seed batch has been sent off on this context yet (a fresh one): refused
+    fresh = fe.Context(0)
+    try:
+        assert fresh.lib.svoh_project_candidates_stage_ranges(fresh.h, 1, 1, 4, C.byref(capi.svoh_candidate_stage_t())) == 0
+        assert fresh.lib.svoh_project_candidates_enqueue_staged_units(fresh.h) != 0
+    finally:
+        fresh.close()
+    # the update, sent off
+    ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+    g = capi.svoh_matcher_stage_t()
+    ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, n, 8, 0, C.byref(g)))
+    off = 0
+    for k, sd in enumerate(sets):
+        m = n_each[k]
+        _view(g.ref_frame_idx, np.int32, n)[off:off + m] = k
+        _view(g.cur_frame_idx, np.int32, n)[off:off + m] = k
+        for name, width, dt in (("px", 2, np.float64), ("f", 3, np.float64), ("grad", 2, np.float64), ("level", 1, np.int32), ("type", 1, np.uint8), ("state", 4, np.float64)):
+            _view(getattr(g, name), dt, width * n)[width * off:width * (off + m)] = sd[name]
+        off += m
+    fb = capi.svoh_feature_batch()
+    fb.n, fb.mem_space, fb.n_cur_frames = n, capi.SVOH_MEM_STAGED, 2
+    for k in ("ref_frame_idx", "cur_frame_idx", "px", "f", "grad", "level", "type"):
+        setattr(fb, k, getattr(g, k))
+    ctx._check(ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 2, refs, curs, C.byref(fb), g.state, g.success, g.result, None))
+    ctx._check(ctx.lib.svoh_matcher_flush(ctx.h))
+    # the projection behind it, by unit (every ninth point keeps a staged inverse depth: the old one, as a driver would have it)
+    units = [np.arange(sum(n_each[:k]), sum(n_each[:k + 1]), dtype=np.int32) for k in range(2)]
+    old_mu = [sd["state"].reshape(-1, 4)[:, 0].copy() for sd in sets]
+    for k in range(2):
+        units[k][::9] = -1
+    rc, px_u, vis_u = project(old_mu, units, True)
+    assert rc == 0
+    ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+    new_mu = _view(g.state, np.float64, 4 * n).reshape(-1, 4)[:, 0].copy()
+    assert (new_mu != np.concatenate(old_mu)).mean() > 0.3   # the update did move the seeds
+    want_mu = []
+    for k in range(2):
+        lo = sum(n_each[:k])
+        m = new_mu[lo:lo + n_each[k]].copy()
+        m[units[k] < 0] = old_mu[k][units[k] < 0]
+        want_mu.append(m)
+    rc, px_w, vis_w = project(want_mu, None, False)
+    assert rc == 0
+    assert np.array_equal(px_u, px_w) and np.array_equal(vis_u, vis_w) and 0.05 < vis_w.mean() < 1.0
+    for h in handles:
+        ctx._check(ctx.lib.svoh_features_release(ctx.h, h))
+    for sc, fr, fc in pairs:
+        ctx.release_frame(fr); ctx.release_frame(fc)
