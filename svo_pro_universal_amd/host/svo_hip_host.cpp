@@ -1366,6 +1366,37 @@ void ReprojectorHip::sortCandidateLists()
 
 void ReprojectorHip::replayMatches(const FramePtr& cur_frame, svoh_ctx* ctx_for_unspeculated)
 {
+  replay_next_pass_ = 0; replay_paused_ = false;
+  (void)replayPasses(cur_frame, ctx_for_unspeculated, false);
+}
+
+bool ReprojectorHip::replayMatchesUntilUnplanned(const FramePtr& cur_frame)
+{
+  replay_next_pass_ = 0; replay_paused_ = false;
+  return replayPasses(cur_frame, nullptr, true);
+}
+
+void ReprojectorHip::planPausedPass(const FramePtr& cur_frame, bool resident_features)
+{
+  if (!replay_paused_) throw std::runtime_error("ReprojectorHip::planPausedPass: the replay is not waiting for a pass");
+  std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged_, &unconverged_ };
+  // (the batches of the passes that have been replayed are done with; the list is sorted already)
+  sm_->clear();
+  sm_->setResident(resident_features);
+  plan_rs_[replay_next_pass_] = sm_->plan(cur_frame, *lists[replay_next_pass_]);
+  n_speculated_ = replay_next_pass_ + 1;
+}
+
+bool ReprojectorHip::resumeReplay(const FramePtr& cur_frame)
+{
+  if (!replay_paused_) throw std::runtime_error("ReprojectorHip::resumeReplay: the replay is not waiting for a pass");
+  return replayPasses(cur_frame, nullptr, true);
+}
+
+// the passes from replay_next_pass_ on; pause_at_unplanned: a pass that has to run and was not planned stops the replay (true is
+// returned, everything stays as it is) until planPausedPass + the caller's batch + resumeReplay
+bool ReprojectorHip::replayPasses(const FramePtr& cur_frame, svoh_ctx* ctx_for_unspeculated, bool pause_at_unplanned)
+{
   const size_t max_total_n_features = options_.max_n_features_per_frame;   // + max_n_fixed_lm, 0 without the global map
   std::vector<reprojector::Candidate>&converged = converged_, &unconverged = unconverged_;
   std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged, &unconverged };
@@ -1389,7 +1420,7 @@ void ReprojectorHip::replayMatches(const FramePtr& cur_frame, svoh_ctx* ctx_for_
     max_n = max_allowed_total;
     return true;
   };
-  bool stop = false;
+  bool& stop = replay_stop_;
   auto after_pass = [&](int pass) {
     add(st[pass]);
     if (pass == 0) {
@@ -1403,10 +1434,17 @@ void ReprojectorHip::replayMatches(const FramePtr& cur_frame, svoh_ctx* ctx_for_
       if (doesFrameHaveEnoughFeatures(cur_frame)) reprojector_utils::setGridCellsOccupied(unconverged, *grid_);    // :300-305
     }
   };
-  reached_unconverged_ = false;
-  for (int k = 0; k < 3; ++k) {
+  const bool resumed = replay_paused_;
+  if (!resumed) { reached_unconverged_ = false; stop = false; }
+  replay_paused_ = false;
+  for (int k = replay_next_pass_; k < 3; ++k) {
     size_t max_n = 0;
-    if (stop || !before_pass(k, max_n)) break;
+    if (resumed && k == replay_next_pass_) max_n = replay_max_n_;   // (before_pass ran when the replay stopped here)
+    else if (stop || !before_pass(k, max_n)) break;
+    if (k >= n_speculated_ && pause_at_unplanned) {
+      replay_next_pass_ = k; replay_max_n_ = max_n; replay_paused_ = true;
+      return true;
+    }
     if (k < n_speculated_) sm_->replay(cur_frame, max_n, *lists[k], plan_rs_[k], *grid_, st[k], device_select_ ? ctx_for_unspeculated : nullptr);
     else {
       // a pass nobody bet on: its own round trip
@@ -1420,6 +1458,8 @@ void ReprojectorHip::replayMatches(const FramePtr& cur_frame, svoh_ctx* ctx_for_
   // (the candidate lists are emptied on return: their buffers stay, the frame references go)
   candidates_.clear(); converged.clear(); unconverged.clear();
   sm_->clear();
+  replay_next_pass_ = 0;
+  return false;
 }
 
 void ReprojectorHip::reprojectFrames(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs,

@@ -530,6 +530,13 @@ class ReprojectorHip {
   // (5) the reference's three passes over finished batches; ctx_for_unspeculated: where a pass nobody planned is
   //     matched with a round trip of its own (NULL: there must be none -- n_speculated was 3)
   void replayMatches(const FramePtr& cur_frame, svoh_ctx* ctx_for_unspeculated);
+  // The same for drivers that cannot let the replay make a device call of its own (FrontendLockstep's worker threads): a pass
+  // that has to run and was not planned PAUSES the replay -- true is returned, frame, grid, counters and lists stay as they are.
+  // planPausedPass plans that pass' list (plannedMatches() then holds its batch alone), the driver runs the batch, resumeReplay
+  // goes on from there (and may pause again).  Passes in the reference's order either way: same results.
+  bool replayMatchesUntilUnplanned(const FramePtr& cur_frame);
+  void planPausedPass(const FramePtr& cur_frame, bool resident_features = false);
+  bool resumeReplay(const FramePtr& cur_frame);
   // SVOH_REPROJ_DEVICE_SELECT=1 (read when the reprojector is made): the passes' selection -- which candidates are tried, where a
   // pass ends -- comes from svoh_select_matches_batch instead of the walk over the grid in replay(); same features, counters, grid
   // and side effects (tests/cpp/test_host_reprojector.cpp runs both).  Off by default: it is a round trip of its own.
@@ -545,6 +552,8 @@ class ReprojectorHip {
   size_t camera_index_;
   bool speculate_unconverged_ = false;   // was the unconverged-seed pass reached on the previous frame?
   bool reached_unconverged_ = false;
+  bool replayPasses(const FramePtr& cur_frame, svoh_ctx* ctx_for_unspeculated, bool pause_at_unplanned);
+  int replay_next_pass_ = 0; bool replay_paused_ = false, replay_stop_ = false; size_t replay_max_n_ = 0;
   // queued / collected device projection: per keyframe the offset of its first feature in the flat arrays
   const Frame* proj_frame_ = nullptr;
   int proj_frame_id_ = 0;

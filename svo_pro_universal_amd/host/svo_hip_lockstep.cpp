@@ -64,7 +64,7 @@ struct FrontendLockstep::Stream {
   size_t proj_points = 0, proj_kf = 0, proj_point_off = 0, proj_kf_off = 0;
   int proj_job = -1;
   size_t direct_off = 0, seeds_off = 0, ref_off = 0;
-  bool do_pose = false;
+  bool do_pose = false, needs_more = false;
   svoh_pose_options pose_opt{};
   svoh_pose_problem pose_pb{};
   int pose_slot = -1;
@@ -102,6 +102,9 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
   // on one device and NOT the default: 23.7 / 24.3 k frames/s against 25.6 / 23.3 k with the library's own policy
   // (profiles/r05_copy_policy_ab.txt) -- the mixed-dispatch ceiling of tools/svoh_dispatch_rate is not what the groups run into.
   if (getenv("SVOH_LOCKSTEP_RESIDENT")) opt_.resident_features = atoi(getenv("SVOH_LOCKSTEP_RESIDENT")) != 0;   // (A/B)
+  // SVOH_LOCKSTEP_SPECULATE=all: every stream's three lists, always (the first version); =never: the third list is never planned ahead,
+  // every stream that needs it goes through the paused replay (tests); default: as the stream's frame before went
+  if (const char* sp = getenv("SVOH_LOCKSTEP_SPECULATE")) { speculate_all_ = std::string(sp) == "all"; speculate_never_ = std::string(sp) == "never"; }
   align_ahead_ = getenv("SVOH_LOCKSTEP_ALIGN_AHEAD") == nullptr || atoi(getenv("SVOH_LOCKSTEP_ALIGN_AHEAD")) != 0;   // (A/B)
   detect_ahead_ = getenv("SVOH_LOCKSTEP_DETECT_AHEAD") == nullptr || atoi(getenv("SVOH_LOCKSTEP_DETECT_AHEAD")) != 0;   // (A/B)
   // SVOH_LOCKSTEP_POSE_CHAIN=0: the depth filter's batch is queued after the host has seen the poses, as in the first version
@@ -523,7 +526,10 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   const double t2 = now_ms();
   times_.align = t2 - t1;
 
-  // ---- 2. reprojection (frame_handler_base.cpp:645-744): walk and plan per stream, ONE direct batch and ONE seed batch
+  // ---- 2. reprojection (frame_handler_base.cpp:645-744): walk and plan per stream, ONE direct batch and ONE seed batch.
+  // A stream's third list (the unconverged seeds: up to a thousand units) is planned only if its pass was reached on the stream's
+  // frame before -- the policy of ReprojectorHip::reprojectFrames.  A stream that reaches a pass nobody planned pauses its replay;
+  // those streams get one more batch of their own (below), the others lose nothing.
   pool_.run(S, [&](int s) {
     Stream& st = *streams_[static_cast<size_t>(s)];
     st.row = FrameRow(); st.row.k = round_;
@@ -532,22 +538,24 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       st.reprojector.adoptCandidateProjection(st.frame, cs.px + 2 * st.proj_point_off, cs.visible + st.proj_point_off);
     else st.reprojector.discardCandidateProjection();
     st.trash.clear();
+    const bool third = !speculate_never_ && (speculate_all_ || round_ <= 1 || st.reprojector.reachedUnconvergedPass());   // (of the frame before: the walk resets nothing of it)
     st.reprojector.walkCandidates(st.frame, st.visible, st.trash);
-    // (every list is planned: a pass that is not reached wastes its units, never shows -- and a pass nobody planned
-    // would need a round trip of its own)
-    st.reprojector.planMatches(st.frame, 3, opt_.resident_features);
+    st.reprojector.planMatches(st.frame, third ? 3 : 2, opt_.resident_features);
   });
   pc.lap(kPhWalkPlan);
+  // one matcher round for the streams in `who`: their planned batches staged side by side, sent off, `meanwhile` on the host, collected,
+  // every stream's outputs pointed at its slices
   svoh_matcher_stage_t ds{}, ss{};
-  size_t n_direct = 0, n_seeds = 0, n_refs = 0;
-  for (auto& stp : streams_) {
-    Stream& st = *stp;
-    detail::SpeculativeMatches& sm = st.reprojector.plannedMatches();
-    st.direct_off = n_direct; st.seeds_off = n_seeds; st.ref_off = n_refs;
-    n_direct += sm.direct.size(); n_seeds += sm.seeds.size(); n_refs += sm.frames.size();
-  }
-  const bool matcher_work = n_direct + n_seeds > 0;
-  if (matcher_work) {
+  auto matcher_round = [&](const std::vector<int>& who, const std::function<void()>& meanwhile) {
+    size_t n_direct = 0, n_seeds = 0, n_refs = 0;
+    for (int s : who) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      detail::SpeculativeMatches& sm = st.reprojector.plannedMatches();
+      st.direct_off = n_direct; st.seeds_off = n_seeds; st.ref_off = n_refs;
+      n_direct += sm.direct.size(); n_seeds += sm.seeds.size(); n_refs += sm.frames.size();
+    }
+    ds = svoh_matcher_stage_t{}; ss = svoh_matcher_stage_t{};
+    if (n_direct + n_seeds == 0) { if (meanwhile) meanwhile(); return; }
     const svoh_matcher_options mopt = detail::reprojectorMatcherOptions(opt_.params.reprojector_affine_est_offset, opt_.params.reprojector_affine_est_gain);
     const int max_views = static_cast<int>(n_refs) + S + 1;
     check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
@@ -556,12 +564,13 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     if (n_direct) check(svoh_matcher_stage(ctx_, 0, static_cast<int>(n_direct), max_views, stage_flags, &ds), "svoh_matcher_stage");
     if (n_seeds) check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_seeds), max_views, stage_flags, &ss), "svoh_matcher_stage");
     std::vector<svoh_frame_view> refs(n_refs ? n_refs : 1), curs(static_cast<size_t>(S));
+    for (int s = 0; s < S; ++s) curs[static_cast<size_t>(s)] = detail::viewOf(*streams_[static_cast<size_t>(s)]->frame);
     pc.lap(kPhMatchStage);
-    pool_.run(S, [&](int s) {
+    pool_.run(static_cast<int>(who.size()), [&](int w) {
+      const int s = who[static_cast<size_t>(w)];
       Stream& st = *streams_[static_cast<size_t>(s)];
       detail::SpeculativeMatches& sm = st.reprojector.plannedMatches();
       for (size_t k = 0; k < sm.frames.size(); ++k) refs[st.ref_off + k] = detail::viewOf(*sm.frames[k]);
-      curs[static_cast<size_t>(s)] = detail::viewOf(*st.frame);
       auto copy_batch = [&](const detail::Batch& b, const svoh_matcher_stage_t& g, size_t o) {
         const size_t m = b.size();
         if (!m) return;
@@ -602,21 +611,13 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     check(svoh_matcher_flush(ctx_), "svoh_matcher_flush");
     ++device_calls_;
     pc.lap(kPhMatchSubmit);
-    // sortCandidatesByReprojStats of every stream's three lists while the device works
-    pool_.run(S, [&](int s) { streams_[static_cast<size_t>(s)]->reprojector.sortCandidateLists(); });
-    pc.lap(kPhSort);
+    if (meanwhile) meanwhile();
     close_section.armed = false;
     check(svoh_matcher_collect(ctx_), "svoh_matcher_collect");
     ++device_calls_;
     pc.lap(kPhMatchWait);
-  } else {
-    pool_.run(S, [&](int s) { streams_[static_cast<size_t>(s)]->reprojector.sortCandidateLists(); });
-  }
-  // the context's stream is idle here: the next round's images start their way up now, beside the rest of this round
-  { const double tw = now_ms(); prefetch(next_images, pitch); phase_ms_[kPhPrefetch] += now_ms() - tw; }   // (part of "replay + pose prep")
-  // the reference's three passes per stream on its slices of the finished batches, then the stream's pose problem
-  pool_.run(S, [&](int s) {
-    Stream& st = *streams_[static_cast<size_t>(s)];
+  };
+  auto point_outputs = [&](Stream& st) {
     detail::SpeculativeMatches& sm = st.reprojector.plannedMatches();
     if (sm.direct.size()) {
       const size_t o = st.direct_off;
@@ -629,12 +630,48 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       sm.seeds.out.f_cur = ss.f_cur + 3 * o; sm.seeds.out.A = ss.A_cur_ref + 4 * o; sm.seeds.out.state = ss.state + 4 * o; sm.seeds.out.type = ss.type + o;
       sm.seeds.out.success = ss.success + o;
     }
-    st.reprojector.replayMatches(st.frame, nullptr);
+  };
+  auto pose_prep = [&](Stream& st) {
     st.row.n_reproj = st.frame->num_features_;
     // 3. pose optimisation (frame_handler_base.cpp:746-790): this stream's bundle
     st.do_pose = st.frame->num_features_ >= 10;
     if (st.do_pose) st.pose_optimizer.prepareRun(st.b_cur, 2.0, st.pose_opt, st.pose_pb);
+  };
+  {
+    std::vector<int> all(static_cast<size_t>(S));
+    for (int s = 0; s < S; ++s) all[static_cast<size_t>(s)] = s;
+    // sortCandidatesByReprojStats of every stream's three lists while the device works
+    matcher_round(all, [&]() {
+      pool_.run(S, [&](int s) { streams_[static_cast<size_t>(s)]->reprojector.sortCandidateLists(); });
+      pc.lap(kPhSort);
+    });
+  }
+  // the context's stream is idle here: the next round's images start their way up now, beside the rest of this round
+  { const double tw = now_ms(); prefetch(next_images, pitch); phase_ms_[kPhPrefetch] += now_ms() - tw; }   // (part of "replay + pose prep")
+  // the reference's three passes per stream on its slices of the finished batches, then the stream's pose problem
+  pool_.run(S, [&](int s) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    point_outputs(st);
+    st.needs_more = st.reprojector.replayMatchesUntilUnplanned(st.frame);
+    if (!st.needs_more) pose_prep(st);
   });
+  // streams whose replay stands before a pass that was not planned: that pass' list in a batch of their own, and on
+  for (;;) {
+    std::vector<int> more;
+    for (int s = 0; s < S; ++s) if (streams_[static_cast<size_t>(s)]->needs_more) more.push_back(s);
+    if (more.empty()) break;
+    pool_.run(static_cast<int>(more.size()), [&](int w) {
+      Stream& st = *streams_[static_cast<size_t>(more[static_cast<size_t>(w)])];
+      st.reprojector.planPausedPass(st.frame, opt_.resident_features);
+    });
+    matcher_round(more, nullptr);
+    pool_.run(static_cast<int>(more.size()), [&](int w) {
+      Stream& st = *streams_[static_cast<size_t>(more[static_cast<size_t>(w)])];
+      point_outputs(st);
+      st.needs_more = st.reprojector.resumeReplay(st.frame);
+      if (!st.needs_more) pose_prep(st);
+    });
+  }
   pc.lap(kPhReplay);
   const double t3 = now_ms();
   times_.reproject = t3 - t2;

@@ -109,7 +109,9 @@ class FrontendLockstep {
     bool in_flight = false;
   } detect_;
   bool detect_ahead_ = true;
-  bool align_ahead_ = true;   // the alignment queued ahead of the wait for the previous round's seed update
+  bool align_ahead_ = true;
+  bool speculate_never_ = false;
+  bool speculate_all_ = false;   // plan every stream's unconverged-seed list whether or not its pass was reached on the frame before   // the alignment queued ahead of the wait for the previous round's seed update
   void drainReleases();
   void check(int rc, const char* what) const;
 

@@ -198,7 +198,8 @@ def test_lockstep_variants_and_the_tracked_features_rule(tmp_path):
             assert ahead[0] == single[0] and np.array_equal(ahead[1], single[1])
         if kf_every == "1000":
             assert single[1][1:, 1].sum() >= 1, "the tracked-features rule never fired: the case tests nothing"
-        for env in ({}, {"SVOH_LOCKSTEP_RESIDENT": "0"}, {"SVOH_LOCKSTEP_POSE_CHAIN": "0"}, {"SVOH_LOCKSTEP_DETECT_AHEAD": "0"}, {"SVOH_LOCKSTEP_ALIGN_AHEAD": "0"}):
+        for env in ({}, {"SVOH_LOCKSTEP_RESIDENT": "0"}, {"SVOH_LOCKSTEP_POSE_CHAIN": "0"}, {"SVOH_LOCKSTEP_DETECT_AHEAD": "0"}, {"SVOH_LOCKSTEP_ALIGN_AHEAD": "0"},
+                    {"SVOH_LOCKSTEP_SPECULATE": "all"}, {"SVOH_LOCKSTEP_SPECULATE": "never"}):   # (never: every third pass through the paused replay)
             if kf_every == "1000" and env:
                 continue
             for traj, counters in run([str(n_frames), kf_every, "3", "lockstep", "2", "1"], dict(env, **rule)):
