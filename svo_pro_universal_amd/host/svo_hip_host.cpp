@@ -1354,7 +1354,11 @@ void ReprojectorHip::sortCandidateLists()
   // candidate is matched against does not depend on its place in the list, only the replay's visiting order does
   std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged_, &unconverged_ };
   std::vector<uint32_t> order;
-  for (int k = 0; k < 3; ++k) {
+  // (a list that was not planned is sorted when -- if -- its pass is reached: planPausedPass, or matchCandidates' own sort... the
+  // reference sorts it right before its pass as well, reprojector.cpp:263)
+  const int n_sorted = sort_unplanned_lists_ ? 3 : n_speculated_;
+  lists_sorted_ = n_sorted;
+  for (int k = 0; k < n_sorted; ++k) {
     reprojector_utils::sortCandidatesWithOrder(*lists[k], &order);
     if (k < n_speculated_ && !order.empty()) {
       std::vector<detail::Resolved> sorted(order.size());
@@ -1380,7 +1384,8 @@ void ReprojectorHip::planPausedPass(const FramePtr& cur_frame, bool resident_fea
 {
   if (!replay_paused_) throw std::runtime_error("ReprojectorHip::planPausedPass: the replay is not waiting for a pass");
   std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged_, &unconverged_ };
-  // (the batches of the passes that have been replayed are done with; the list is sorted already)
+  // (the batches of the passes that have been replayed are done with; the list is sorted now if it was not planned and so not sorted)
+  if (replay_next_pass_ >= lists_sorted_) { reprojector_utils::sortCandidatesByReprojStats(*lists[replay_next_pass_]); lists_sorted_ = replay_next_pass_ + 1; }
   sm_->clear();
   sm_->setResident(resident_features);
   plan_rs_[replay_next_pass_] = sm_->plan(cur_frame, *lists[replay_next_pass_]);

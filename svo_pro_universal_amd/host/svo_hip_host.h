@@ -534,6 +534,7 @@ class ReprojectorHip {
   // that has to run and was not planned PAUSES the replay -- true is returned, frame, grid, counters and lists stay as they are.
   // planPausedPass plans that pass' list (plannedMatches() then holds its batch alone), the driver runs the batch, resumeReplay
   // goes on from there (and may pause again).  Passes in the reference's order either way: same results.
+  void sortPlannedListsOnly(bool on) { sort_unplanned_lists_ = !on; }
   bool replayMatchesUntilUnplanned(const FramePtr& cur_frame);
   void planPausedPass(const FramePtr& cur_frame, bool resident_features = false);
   bool resumeReplay(const FramePtr& cur_frame);
@@ -553,6 +554,10 @@ class ReprojectorHip {
   bool speculate_unconverged_ = false;   // was the unconverged-seed pass reached on the previous frame?
   bool reached_unconverged_ = false;
   bool replayPasses(const FramePtr& cur_frame, svoh_ctx* ctx_for_unspeculated, bool pause_at_unplanned);
+  // sortCandidateLists sorts every list (reprojectFrames: an unplanned pass goes through matchCandidates, which expects its list
+  // sorted) or, for drivers of the paused replay, the planned ones only (FrontendLockstep sets this to false)
+  bool sort_unplanned_lists_ = true;
+  int lists_sorted_ = 3;
   int replay_next_pass_ = 0; bool replay_paused_ = false, replay_stop_ = false; size_t replay_max_n_ = 0;
   // queued / collected device projection: per keyframe the offset of its first feature in the flat arrays
   const Frame* proj_frame_ = nullptr;

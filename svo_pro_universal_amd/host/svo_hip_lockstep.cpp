@@ -117,7 +117,7 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
   ropt.seed_sigma2_thresh = opt_.params.seed_sigma2_thresh;
   ropt.affine_est_offset = opt_.params.reprojector_affine_est_offset;
   ropt.affine_est_gain = opt_.params.reprojector_affine_est_gain;
-  for (int s = 0; s < n_streams; ++s) streams_.emplace_back(new Stream(ctx_, opt_, ropt));
+  for (int s = 0; s < n_streams; ++s) { streams_.emplace_back(new Stream(ctx_, opt_, ropt)); streams_.back()->reprojector.sortPlannedListsOnly(true); }
 }
 
 FrontendLockstep::~FrontendLockstep()
