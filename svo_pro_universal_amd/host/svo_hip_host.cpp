@@ -1255,10 +1255,49 @@ void ReprojectorHip::discardCandidateProjection()
 
 void ReprojectorHip::walkCandidates(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points)
 {
+  walkLists(cur_frame, visible_kfs, trash_points, 3);
+}
+
+void ReprojectorHip::walkCandidatesWithoutUnconverged(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points)
+{
+  walkLists(cur_frame, visible_kfs, trash_points, 1);
+}
+
+// which: 1 = grid / statistics reset, landmarks (with their trash-list side effects) and converged seeds; 2 = the unconverged seeds
+// only, appended to what a walk with 1 has left (same keyframes, same frame: the list is what one walk with 3 gives -- each list
+// comes out in the order of its own loop of the reference either way, and nothing a landmark or converged-seed pass does changes
+// a seed's inverse depth or type)
+void ReprojectorHip::walkLists(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points, int which)
+{
+  if (which == 2) {
+    if (!unconverged_pending_) throw std::runtime_error("ReprojectorHip: no walk is waiting for its unconverged seeds");
+    unconverged_pending_ = false;
+    const bool have_proj = have_proj_ && proj_frame_ == cur_frame.get() && proj_frame_id_ == cur_frame->id_ && proj_collected_;
+    std::vector<reprojector::Candidate>& unconverged = unconverged_;
+    unconverged.clear();
+    if (options_.reproject_unconverged_seeds)
+      for (const FramePtr& ref_frame : visible_kfs) {
+        const svoh::Rigid T_world_ref = svoh::inverse(ref_frame->T_f_w_);
+        long proj_off = -1;
+        size_t proj_n = 0;
+        if (have_proj)
+          for (const ProjKf& ko : proj_kf_off_)
+            if (ko.frame == ref_frame.get() && ko.id == ref_frame->id_ && same_pose(ko.T_f_w, ref_frame->T_f_w_)) {
+              proj_off = static_cast<long>(ko.offset); proj_n = ko.n_features; break;
+            }
+        for (size_t i = 0; i < ref_frame->num_features_; ++i) {
+          const uint8_t type = ref_frame->type_vec_[i];
+          if (type == SVOH_FT_CORNER_SEED || type == SVOH_FT_EDGELET_SEED) emitCandidate(cur_frame, ref_frame, T_world_ref, proj_off, proj_n, i, unconverged);
+        }
+      }
+    if (have_proj) { proj_frame_ = nullptr; proj_collected_ = false; }
+    return;
+  }
   // device projection queued / adopted for this frame: pointer AND id (a frame destroyed with its projection still
   // queued may be followed by a new one at the same address)
   const bool have_proj = proj_frame_ == cur_frame.get() && proj_frame_id_ == cur_frame->id_ && proj_collected_;
   have_proj_ = have_proj;
+  unconverged_pending_ = which == 1;
   if (options_.max_n_features_per_frame == 0) throw std::runtime_error("Reprojector: max_n_features_per_frame must be > 0");   // CHECK_GT
   if (!grid_)
     grid_.reset(new OccupandyGrid2D(static_cast<int>(options_.cell_size),
@@ -1287,32 +1326,6 @@ void ReprojectorHip::walkCandidates(const FramePtr& cur_frame, const std::vector
         if (ko.frame == ref_frame.get() && ko.id == ref_frame->id_ && same_pose(ko.T_f_w, ref_frame->T_f_w_)) {
           proj_off = static_cast<long>(ko.offset); proj_n = ko.n_features; break;
         }
-    // getCandidate for feature i, appended to `list` when it is visible.  The candidate is made in place (one reference
-    // to the keyframe taken per candidate: the walk visits thousands of features per frame and is on the frame's critical path)
-    auto emit_candidate = [&](size_t i, std::vector<reprojector::Candidate>& list) {
-      if (proj_off >= 0 && i < proj_n) {
-        const size_t at = static_cast<size_t>(proj_off) + i;
-        const Point* lm = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i].get() : nullptr;
-        bool fresh;
-        if (lm) { const svoh::Vec3 p = lm->pos(); fresh = proj_kind_p_[at] == 0 && p.x == proj_v_p_[3 * at] && p.y == proj_v_p_[3 * at + 1] && p.z == proj_v_p_[3 * at + 2]; }
-        else fresh = proj_kind_p_[at] == 1 && ((proj_unit_p_ && proj_unit_p_[at] >= 0) ||   // (read on the device from the update the driver has finished since)
-                                               (4 * i < ref_frame->invmu_sigma2_a_b_vec_.size() ? ref_frame->invmu_sigma2_a_b_vec_[4 * i] : 1.0) == proj_mu_p_[at]);
-        if (fresh) {
-          if (!proj_visible_p_[at]) return;
-          list.emplace_back();
-          reprojector::Candidate& candidate = list.back();
-          candidate.ref_frame = ref_frame; candidate.ref_index = i;
-          candidate.cur_px[0] = proj_px_p_[2 * at]; candidate.cur_px[1] = proj_px_p_[2 * at + 1];
-          candidate.n_reproj = lm ? lm->n_succeeded_reproj_ - lm->n_failed_reproj_ : 0;
-          candidate.score = i < ref_frame->score_vec_.size() ? ref_frame->score_vec_[i] : 0.0;
-          candidate.type = ref_frame->type_vec_[i];
-          candidate.n_obs = lm ? lm->obs_.size() : 0u;
-          return;
-        }
-      }
-      reprojector::Candidate candidate;
-      if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref)) list.push_back(std::move(candidate));
-    };
     const size_t n_lm = ref_frame->landmark_vec_.size();
     for (size_t i = 0; i < ref_frame->num_features_; ++i) {
       const uint8_t type = ref_frame->type_vec_[i];
@@ -1322,16 +1335,45 @@ void ReprojectorHip::walkCandidates(const FramePtr& cur_frame, const std::vector
         else if (point->last_projected_kf_id_.at(camera_index_) != cur_frame->id_) {   // project a point only once
           point->last_projected_kf_id_[camera_index_] = cur_frame->id_;
           if (point->obs_.size() < 2 && options_.remove_unconstrained_points) trash_points.push_back(point);
-          else emit_candidate(i, candidates_);
+          else emitCandidate(cur_frame, ref_frame, T_world_ref, proj_off, proj_n, i, candidates_);
         }
       }
       const bool conv = type == SVOH_FT_CORNER_SEED_CONVERGED || type == SVOH_FT_EDGELET_SEED_CONVERGED;
-      const bool unconv = (type == SVOH_FT_CORNER_SEED || type == SVOH_FT_EDGELET_SEED) && options_.reproject_unconverged_seeds;
-      if (conv || unconv) emit_candidate(i, conv ? converged : unconverged);
+      const bool unconv = (type == SVOH_FT_CORNER_SEED || type == SVOH_FT_EDGELET_SEED) && options_.reproject_unconverged_seeds && (which & 2);
+      if (conv || unconv) emitCandidate(cur_frame, ref_frame, T_world_ref, proj_off, proj_n, i, conv ? converged : unconverged);
     }
   }
-  // the projection has been consumed
-  if (have_proj) { proj_frame_ = nullptr; proj_collected_ = false; }
+  // the projection has been consumed (unless the unconverged seeds may still ask for it)
+  if (have_proj && (which & 2)) { proj_frame_ = nullptr; proj_collected_ = false; }
+}
+
+// getCandidate for feature i of ref_frame, appended to `list` when it is visible.  The candidate is made in place (one reference
+// to the keyframe taken per candidate: the walk visits thousands of features per frame and is on the frame's critical path)
+void ReprojectorHip::emitCandidate(const FramePtr& cur_frame, const FramePtr& ref_frame, const svoh::Rigid& T_world_ref, long proj_off, size_t proj_n, size_t i,
+                                   std::vector<reprojector::Candidate>& list)
+{
+  if (proj_off >= 0 && i < proj_n) {
+    const size_t at = static_cast<size_t>(proj_off) + i;
+    const Point* lm = i < ref_frame->landmark_vec_.size() ? ref_frame->landmark_vec_[i].get() : nullptr;
+    bool fresh;
+    if (lm) { const svoh::Vec3 p = lm->pos(); fresh = proj_kind_p_[at] == 0 && p.x == proj_v_p_[3 * at] && p.y == proj_v_p_[3 * at + 1] && p.z == proj_v_p_[3 * at + 2]; }
+    else fresh = proj_kind_p_[at] == 1 && ((proj_unit_p_ && proj_unit_p_[at] >= 0) ||   // (read on the device from the update the driver has finished since)
+                                           (4 * i < ref_frame->invmu_sigma2_a_b_vec_.size() ? ref_frame->invmu_sigma2_a_b_vec_[4 * i] : 1.0) == proj_mu_p_[at]);
+    if (fresh) {
+      if (!proj_visible_p_[at]) return;
+      list.emplace_back();
+      reprojector::Candidate& candidate = list.back();
+      candidate.ref_frame = ref_frame; candidate.ref_index = i;
+      candidate.cur_px[0] = proj_px_p_[2 * at]; candidate.cur_px[1] = proj_px_p_[2 * at + 1];
+      candidate.n_reproj = lm ? lm->n_succeeded_reproj_ - lm->n_failed_reproj_ : 0;
+      candidate.score = i < ref_frame->score_vec_.size() ? ref_frame->score_vec_[i] : 0.0;
+      candidate.type = ref_frame->type_vec_[i];
+      candidate.n_obs = lm ? lm->obs_.size() : 0u;
+      return;
+    }
+  }
+  reprojector::Candidate candidate;
+  if (reprojector_utils::getCandidate(cur_frame, ref_frame, i, candidate, &T_world_ref)) list.push_back(std::move(candidate));
 }
 
 void ReprojectorHip::planMatches(const FramePtr& cur_frame, int n_speculated, bool resident_features)
@@ -1380,10 +1422,16 @@ bool ReprojectorHip::replayMatchesUntilUnplanned(const FramePtr& cur_frame)
   return replayPasses(cur_frame, nullptr, true);
 }
 
-void ReprojectorHip::planPausedPass(const FramePtr& cur_frame, bool resident_features)
+void ReprojectorHip::planPausedPass(const FramePtr& cur_frame, bool resident_features, const std::vector<FramePtr>* visible_kfs)
 {
   if (!replay_paused_) throw std::runtime_error("ReprojectorHip::planPausedPass: the replay is not waiting for a pass");
   std::vector<reprojector::Candidate>* lists[3] = { &candidates_, &converged_, &unconverged_ };
+  if (replay_next_pass_ == 2 && unconverged_pending_) {   // the walk left the unconverged seeds for now: their turn
+    if (!visible_kfs) throw std::runtime_error("ReprojectorHip::planPausedPass: the unconverged seeds were not walked, and no keyframes to walk them over");
+    std::vector<PointPtr> no_trash;
+    walkLists(cur_frame, *visible_kfs, no_trash, 2);
+    lists_sorted_ = lists_sorted_ < 2 ? lists_sorted_ : 2;
+  }
   // (the batches of the passes that have been replayed are done with; the list is sorted now if it was not planned and so not sorted)
   if (replay_next_pass_ >= lists_sorted_) { reprojector_utils::sortCandidatesByReprojStats(*lists[replay_next_pass_]); lists_sorted_ = replay_next_pass_ + 1; }
   sm_->clear();

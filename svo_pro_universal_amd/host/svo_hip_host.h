@@ -522,6 +522,9 @@ class ReprojectorHip {
   void adoptCandidateProjection(const FramePtr& cur_frame, const double* px, const uint8_t* visible);
   // (2) grid and statistics reset, the walk over the visible keyframes' features: the three candidate lists
   void walkCandidates(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points);
+  //     ... or without the unconverged seeds (the longest list, and in the steady state one whose pass is not reached): for drivers
+  //     of the paused replay -- planPausedPass(…, &visible_kfs) walks them when their pass does come up
+  void walkCandidatesWithoutUnconverged(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points);
   // (3) what every candidate of the first n_speculated lists matches against: the stream's direct and seed batch
   void planMatches(const FramePtr& cur_frame, int n_speculated, bool resident_features = false);
   detail::SpeculativeMatches& plannedMatches() { return *sm_; }
@@ -536,7 +539,7 @@ class ReprojectorHip {
   // goes on from there (and may pause again).  Passes in the reference's order either way: same results.
   void sortPlannedListsOnly(bool on) { sort_unplanned_lists_ = !on; }
   bool replayMatchesUntilUnplanned(const FramePtr& cur_frame);
-  void planPausedPass(const FramePtr& cur_frame, bool resident_features = false);
+  void planPausedPass(const FramePtr& cur_frame, bool resident_features = false, const std::vector<FramePtr>* visible_kfs = nullptr);
   bool resumeReplay(const FramePtr& cur_frame);
   // SVOH_REPROJ_DEVICE_SELECT=1 (read when the reprojector is made): the passes' selection -- which candidates are tried, where a
   // pass ends -- comes from svoh_select_matches_batch instead of the walk over the grid in replay(); same features, counters, grid
@@ -554,6 +557,10 @@ class ReprojectorHip {
   bool speculate_unconverged_ = false;   // was the unconverged-seed pass reached on the previous frame?
   bool reached_unconverged_ = false;
   bool replayPasses(const FramePtr& cur_frame, svoh_ctx* ctx_for_unspeculated, bool pause_at_unplanned);
+  void walkLists(const FramePtr& cur_frame, const std::vector<FramePtr>& visible_kfs, std::vector<PointPtr>& trash_points, int which);
+  void emitCandidate(const FramePtr& cur_frame, const FramePtr& ref_frame, const svoh::Rigid& T_world_ref, long proj_off, size_t proj_n, size_t i,
+                     std::vector<reprojector::Candidate>& list);
+  bool unconverged_pending_ = false;
   // sortCandidateLists sorts every list (reprojectFrames: an unplanned pass goes through matchCandidates, which expects its list
   // sorted) or, for drivers of the paused replay, the planned ones only (FrontendLockstep sets this to false)
   bool sort_unplanned_lists_ = true;

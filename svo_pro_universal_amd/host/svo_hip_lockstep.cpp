@@ -539,7 +539,8 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     else st.reprojector.discardCandidateProjection();
     st.trash.clear();
     const bool third = !speculate_never_ && (speculate_all_ || round_ <= 1 || st.reprojector.reachedUnconvergedPass());   // (of the frame before: the walk resets nothing of it)
-    st.reprojector.walkCandidates(st.frame, st.visible, st.trash);
+    if (third) st.reprojector.walkCandidates(st.frame, st.visible, st.trash);
+    else st.reprojector.walkCandidatesWithoutUnconverged(st.frame, st.visible, st.trash);   // (their turn comes with their pass, if it comes)
     st.reprojector.planMatches(st.frame, third ? 3 : 2, opt_.resident_features);
   });
   pc.lap(kPhWalkPlan);
@@ -662,7 +663,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     if (more.empty()) break;
     pool_.run(static_cast<int>(more.size()), [&](int w) {
       Stream& st = *streams_[static_cast<size_t>(more[static_cast<size_t>(w)])];
-      st.reprojector.planPausedPass(st.frame, opt_.resident_features);
+      st.reprojector.planPausedPass(st.frame, opt_.resident_features, &st.visible);
     });
     matcher_round(more, nullptr);
     pool_.run(static_cast<int>(more.size()), [&](int w) {
