@@ -1871,10 +1871,23 @@ void SpeculativeMatches::replay(const FramePtr& frame, size_t max_n_features_per
     n_stop = static_cast<size_t>(n_consumed);
   }
   size_t i = 0;
+  // The batches' outputs were written by the device a moment ago: every first touch of a line is a miss in all of the host's
+  // caches.  Which candidates will be tried is only known when the loop gets there, so the result code of EVERY candidate a little
+  // ahead is asked for early (one line each), and a successful match's pixel / bearing vector / warp when its code turns up.
+  constexpr size_t kAhead = 24;
+  auto prefetch_result = [&](size_t k2) {
+    if (k2 >= n_stop) return;
+    const Resolved& r2 = rs[k2];
+    if (r2.batch_pos < 0) return;
+    if (r2.kind == kUnconvergedSeed) __builtin_prefetch(&seeds.out.success[r2.batch_pos]);
+    else if (r2.kind == kConvergedSeed || r2.kind == kLandmark) __builtin_prefetch(&direct.out.result[r2.batch_pos]);
+  };
+  for (size_t k2 = 0; k2 < kAhead; ++k2) prefetch_result(k2);
   for (size_t k = 0; k < n_stop; ++k) {
     reprojector::Candidate& c = candidates[k];
     const Resolved& r = rs[k];
     ++i;
+    prefetch_result(k + kAhead);
     const size_t grid_index = grid.getCellIndex(static_cast<int>(c.cur_px[0]), static_cast<int>(c.cur_px[1]), 1);
     if (!visited.empty()) { if (!visited[k]) continue; }
     else if (max_n_features_per_frame > 0 && grid.isOccupied(grid_index)) continue;
