@@ -658,8 +658,11 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
     depth = float(np.mean(sc.depth))
     params = ("max_fts: 180\ngrid_size: 30\nn_pyr_levels: 3\ndetector_threshold_secondary: 100\nuse_threaded_depthfilter: False\n"
               "img_align_max_level: 4\nimg_align_min_level: 2\n")
-    n_host = len(os.sched_getaffinity(0))
-    budget = int(os.environ.get("SVOH_BENCH_HOST_THREADS", "0")) or max(1, min(16, n_host // max(1, world)))
+    # host threads of this rank: its own slice of the CPUs when main() pinned the rank to one (pin_rank_to_its_cores has
+    # divided by the world size already); an equal share of what the process sees when it did not
+    n_slice = len(os.sched_getaffinity(0))
+    n_host = _CPUS_BEFORE_PIN or n_slice
+    budget = int(os.environ.get("SVOH_BENCH_HOST_THREADS", "0")) or max(1, min(16, n_slice if _PINNED else n_slice // max(1, world)))
 
     def frame_of(k):   # 0 1 .. n-1 n-2 .. 1 0 1 ..: the camera walks the path forth and back
         k %= 2 * (n_frames - 1)
@@ -1343,6 +1346,8 @@ def launch_workers(n, argv):
 
 
 _CPU_SLICE = None
+_CPUS_BEFORE_PIN = None   # CPUs the process could run on before pin_rank_to_its_cores narrowed it
+_PINNED = False
 
 
 def pin_rank_to_its_cores(local_rank, world):
@@ -1350,9 +1355,11 @@ def pin_rank_to_its_cores(local_rank, world):
     (os.sched_setaffinity, before any GPU call and before any thread is started), so that the host-bound workloads --
     the per-frame chains, whose time is host threads waiting on small launches -- do not share cores between ranks.
     SVOH_BENCH_PIN=0 leaves the affinity alone.  Returns (and remembers for the line) the slice as "first-last (n)"."""
-    global _CPU_SLICE
+    global _CPU_SLICE, _CPUS_BEFORE_PIN, _PINNED
     cpus = sorted(os.sched_getaffinity(0))
+    _CPUS_BEFORE_PIN = len(cpus)
     if world > 1 and os.environ.get("SVOH_BENCH_PIN", "1") != "0" and len(cpus) >= world:
+        _PINNED = True
         per = len(cpus) // world
         mine = cpus[local_rank % world * per:(local_rank % world + 1) * per]
         os.sched_setaffinity(0, mine)

@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define SVOH_ABI_VERSION 1
+/* 2 (round 5 -> 6): svoh_frame_view.features, svoh_align_camera.pos_seed_unit, svoh_feature_batch.feature_index changed
+ * three struct layouts; _capi.load() and the host layer's constructors refuse a library of another version */
+#define SVOH_ABI_VERSION 2
 #define SVOH_MAX_LEVELS 8
 #define SVOH_MAX_CAMS 4
 

@@ -448,6 +448,65 @@ def fast_corners(img, barrier, fast=False):
     return xy.reshape(-1, 2), sc[:n], nm[:k]
 
 
+# ---- oracle/_ref: the reference's OWN FAST code, compiled from /root/reference (oracle/ref_fast/Makefile) --------
+
+REF_FAST_LIB = os.path.join(_HERE, "_ref", "libfast_ref.so")
+
+
+def ref_fast_available(build_if_possible=True):
+    """True when oracle/_ref/libfast_ref.so exists (it is built where /root/reference exists and travels prebuilt)."""
+    if not os.path.exists(REF_FAST_LIB) and build_if_possible and os.path.isdir("/root/reference/src/fast_neon"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "ref_fast")])
+    return os.path.exists(REF_FAST_LIB)
+
+
+def _padded(img):
+    # the SSE2 detector loads 16 bytes at p + 2 + 2 * stride of the last row it visits: keep the image inside a
+    # larger allocation (16-byte aligned start, like a cv::Mat), same width / height / pitch for the callee; a view with
+    # a pitch larger than its width (a cv::Mat ROI) keeps that pitch
+    assert img.dtype == np.uint8 and img.ndim == 2 and (img.shape[1] <= 1 or img.strides[1] == 1)
+    h, w = img.shape
+    pitch = max(img.strides[0], w) if h > 1 else w
+    buf = np.zeros(h * pitch + 128, np.uint8)
+    off = (-buf.ctypes.data) % 16
+    view = np.lib.stride_tricks.as_strided(buf[off:], shape=(h, w), strides=(pitch, 1))
+    view[...] = img
+    return view, buf
+
+
+def ref_fast_corners(img, barrier):
+    """fast_corner_detect_10_sse2 + fast_corner_score_10 + fast_nonmax_3x3 of the REFERENCE (same tuple as fast_corners)."""
+    if "ref_fast" not in _LIBS:
+        assert ref_fast_available(), "oracle/_ref/libfast_ref.so is missing and /root/reference is not here to build it"
+        lib = C.CDLL(REF_FAST_LIB)
+        lib.fast_ref_detect_score_nonmax.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_int, C.c_void_p]
+        lib.fast_ref_detect_plain.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _LIBS["ref_fast"] = lib
+    lib = _LIBS["ref_fast"]
+    view, keep = _padded(img)
+    cap = max(view.size, 1)
+    xy = np.zeros(2 * cap, np.int32); sc = np.zeros(cap, np.int32); nm = np.zeros(cap, np.int32)
+    k = C.c_int32(0)
+    n = lib.fast_ref_detect_score_nonmax(view.ctypes.data, view.shape[1], view.shape[0], view.strides[0], int(barrier),
+                                         xy.ctypes.data, sc.ctypes.data, nm.ctypes.data, cap, C.byref(k))
+    assert n <= cap
+    del keep
+    return xy[:2 * n].reshape(-1, 2).copy(), sc[:n].copy(), nm[:k.value].copy()
+
+
+def ref_fast_corners_plain(img, barrier):
+    """fast_corner_detect_10 (the plain decision tree) of the REFERENCE: xy [n,2]."""
+    ref_fast_corners(np.zeros((8, 8), np.uint8), 10)
+    lib = _LIBS["ref_fast"]
+    view, keep = _padded(img)
+    cap = max(view.size, 1)
+    xy = np.zeros(2 * cap, np.int32)
+    n = lib.fast_ref_detect_plain(view.ctypes.data, view.shape[1], view.shape[0], view.strides[0], int(barrier), xy.ctypes.data, cap)
+    del keep
+    return xy[:2 * n].reshape(-1, 2).copy()
+
+
 def gaussian_blur_3x3(img, fast=False):
     lib = load(fast); _bind_detector(lib)
     out = np.zeros(img.shape, np.uint8)

@@ -7,6 +7,7 @@ never touches the GPU; `load()` raises if the HIP extension has not been built
 import ctypes as C
 import os
 
+SVOH_ABI_VERSION = 2   # include/svo_hip.h
 SVOH_MAX_LEVELS = 8
 SVOH_MAX_CAMS = 4
 
@@ -348,6 +349,9 @@ def load(path=None):
     lib = C.CDLL(lib_path)
     P = C.POINTER
     lib.svoh_abi_version.restype = C.c_int
+    if lib.svoh_abi_version() != SVOH_ABI_VERSION:   # the ctypes structs below mirror ONE layout of include/svo_hip.h
+        raise RuntimeError("%s has ABI version %d, these bindings mirror version %d: rebuild it (__graft_entry__.build())"
+                           % (lib_path, lib.svoh_abi_version(), SVOH_ABI_VERSION))
     lib.svoh_create.argtypes = [C.c_int, P(C.c_void_p)]
     lib.svoh_destroy.argtypes = [C.c_void_p]
     lib.svoh_last_error_string.argtypes = [C.c_void_p]

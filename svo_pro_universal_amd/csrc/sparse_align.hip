@@ -2199,6 +2199,7 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   }
   SVOH_REQUIRE(ctx, !forced || (!split && eval_level < 0), "a forced geometry applies to full runs only");
   SVOH_REQUIRE(ctx, !cluster || (int64_t)S * n_problems <= ctx->num_cus, "cluster mode: more workgroups than compute units");
+  SVOH_REQUIRE(ctx, !cluster || n_problems <= kClusterMaxProblems, "cluster mode: more problems in one launch than arrival counters");
   SVOH_REQUIRE(ctx, S == 1 || n_problems == 1 || cluster, "shares apply to a single problem");
   const int n_desc = n_problems * S;
 
@@ -2588,7 +2589,13 @@ try {
   SVOH_REQUIRE(ctx, n_problems >= 1 && problems, "no problems");
   // cluster mode wants every workgroup of a launch on a compute unit of its own: more problems than that go out as
   // several launches, one behind the other (their results queue up in problem order)
-  const int per_launch = geo.cluster_g >= 2 ? (ctx->num_cus / geo.cluster_g > 0 ? ctx->num_cus / geo.cluster_g : 1) : n_problems;
+  // -- and never more than the arrival counters of one launch hold (kClusterMaxProblems words at ctl + 256: the uploaded
+  // feature arrays start right behind them)
+  int per_launch = n_problems;
+  if (geo.cluster_g >= 2) {
+    per_launch = ctx->num_cus / geo.cluster_g > 0 ? ctx->num_cus / geo.cluster_g : 1;
+    if (per_launch > kClusterMaxProblems) per_launch = kClusterMaxProblems;
+  }
   for (int p0 = 0; p0 < n_problems; p0 += per_launch) {
     const int n = n_problems - p0 < per_launch ? n_problems - p0 : per_launch;
     const int rc = enqueue_align(ctx, options, n, problems + p0, -1, nullptr, &geo);

@@ -16,6 +16,7 @@ namespace svo_hip {
 SparseImgAlignHip::SparseImgAlignHip(svoh_ctx* ctx, SolverOptions solver_options, SparseImgAlignOptions options)
     : ctx_(ctx), solver_options_(solver_options), options_(options)
 {
+  requireMatchingAbi();
   if (!ctx_) throw std::runtime_error("SparseImgAlignHip: NULL svoh_ctx (no CPU fallback exists)");
   reset();
 }
@@ -236,6 +237,7 @@ DepthFilterHip::~DepthFilterHip()
 
 DepthFilterHip::DepthFilterHip(svoh_ctx* ctx, const DepthFilterOptions& options) : ctx_(ctx), options_(options)
 {
+  requireMatchingAbi();
   if (!ctx_) throw std::runtime_error("DepthFilterHip: NULL svoh_ctx (no CPU fallback exists)");
   if (options_.use_threaded_depthfilter)
     throw std::runtime_error("DepthFilterHip: use_threaded_depthfilter must be false (parity needs the synchronous path)");
@@ -432,6 +434,7 @@ size_t DepthFilterHip::finishUpdateSeedsNow()
 FeatureTrackerHip::FeatureTrackerHip(svoh_ctx* ctx, const FeatureTrackerOptions& options, size_t bundle_size)
     : ctx_(ctx), options_(options), bundle_size_(bundle_size), active_tracks_(bundle_size), terminated_tracks_(bundle_size)
 {
+  requireMatchingAbi();
   if (!ctx_) throw std::runtime_error("FeatureTrackerHip: NULL svoh_ctx (no CPU fallback exists)");
 }
 
@@ -583,6 +586,7 @@ DetectorHip::DetectorHip(svoh_ctx* ctx, const DetectorOptions& options, int imag
             OccupandyGrid2D::getNCell(image_height, static_cast<int>(options.cell_size))),
       ctx_(ctx), options_(options)
 {
+  requireMatchingAbi();
   if (!ctx_) throw std::runtime_error("DetectorHip: NULL svoh_ctx (no CPU fallback exists)");
 }
 
@@ -681,6 +685,7 @@ StereoTriangulationHip::StereoTriangulationHip(svoh_ctx* ctx, const StereoTriang
                                                const std::shared_ptr<DetectorHip>& feature_detector)
   : options_(options), feature_detector_(feature_detector), ctx_(ctx)
 {
+  requireMatchingAbi();
   if (!ctx_) throw std::runtime_error("StereoTriangulationHip: NULL svoh_ctx (no CPU fallback exists)");
   shuffle_ = [](std::vector<size_t>& indices, size_t n_corners) {
     // std::random_shuffle(first, last) as libstdc++ implements it on rand() (stereo_triangulation.cpp:77-78)
@@ -821,6 +826,7 @@ void StereoTriangulationHip::compute(const FramePtr& frame0, const FramePtr& fra
 // ---- pose optimiser -------------------------------------------------------------------
 PoseOptimizerHip::PoseOptimizerHip(svoh_ctx* ctx, SolverOptions solver_options) : ctx_(ctx), solver_options_(solver_options)
 {
+  requireMatchingAbi();
   if (!ctx_) throw std::runtime_error("PoseOptimizerHip: NULL svoh_ctx (no CPU fallback exists)");
 }
 
@@ -1107,6 +1113,7 @@ bool Frame::isVisible(const svoh::Vec3& xyz_w, double* px) const
 ReprojectorHip::ReprojectorHip(svoh_ctx* ctx, const ReprojectorOptions& options, size_t camera_index)
     : options_(options), ctx_(ctx), camera_index_(camera_index)
 {
+  requireMatchingAbi();
   if (!ctx_) throw std::runtime_error("ReprojectorHip: NULL svoh_ctx (no CPU fallback exists)");
   if (camera_index_ >= SVOH_MAX_CAMS) throw std::runtime_error("ReprojectorHip: camera index out of range");
   device_select_ = getenv("SVOH_REPROJ_DEVICE_SELECT") != nullptr && atoi(getenv("SVOH_REPROJ_DEVICE_SELECT")) != 0;

@@ -3,11 +3,24 @@
 #pragma once
 
 #include <cstdint>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "svo_hip_host.h"
 
 namespace svo_hip {
+// The host layer is compiled against include/svo_hip.h's struct layouts: a libsvo_hip.so of another SVOH_ABI_VERSION would
+// read undersized / differently laid out structs.  Every mirror's constructor asks once.
+inline void requireMatchingAbi()
+{
+  static const bool ok = [] {
+    if (svoh_abi_version() != SVOH_ABI_VERSION)
+      throw std::runtime_error("libsvo_hip.so has ABI version " + std::to_string(svoh_abi_version()) + ", the host layer was built for " + std::to_string(SVOH_ABI_VERSION));
+    return true;
+  }();
+  (void)ok;
+}
 namespace reprojector_utils {
 // sortCandidatesByReprojStats; order[k] = where the k-th candidate of the sorted list stood before (empty for lists of fewer than two)
 void sortCandidatesWithOrder(std::vector<reprojector::Candidate>& candidates, std::vector<uint32_t>* order);

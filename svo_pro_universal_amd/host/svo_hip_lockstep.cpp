@@ -93,6 +93,7 @@ void FrontendLockstep::check(int rc, const char* what) const
 FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepOptions& options)
     : ctx_(ctx), opt_(options)
 {
+  requireMatchingAbi();
   if (opt_.exclusive_pool) pool_.exclusive = opt_.exclusive_pool;
   else if (opt_.shared_pool) { pool_.shared = opt_.shared_pool; pool_.seed = opt_.shared_pool_seed; }
   else pool_.own.reset(new WorkerPool(options.n_workers < 1 ? 1 : options.n_workers, options.pin_workers));
@@ -129,6 +130,9 @@ FrontendLockstep::~FrontendLockstep()
   }
   streams_.clear();
   drainReleases();
+  // a prefetch announced for a round that never came may still be writing its slab on the upload stream: the context's
+  // stream waits for it (on the device) before the slab goes back to the pool, where the next build would reuse it unordered
+  (void)svoh_prefetch_fence(ctx_);
   for (svoh_frame_t h : prefetched_) if (h) (void)svoh_release_frame(ctx_, h);
 }
 

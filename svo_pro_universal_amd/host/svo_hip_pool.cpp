@@ -20,7 +20,10 @@ namespace svo_hip {
 namespace {
 // the CPUs this process may run on, one hardware thread per core first (so that a pool smaller than the mask does not
 // put two busy threads on the two hardware threads of one core)
-std::vector<int> allowed_cpus()
+// Read ONCE, at the first pinned pool of the process: a pinned pool binds its calling thread to one CPU for good, so the mask
+// of that thread is a single CPU when it builds its next pool (svoh_mini_frontend: a new engine per lap on the group's
+// thread) -- every later pool would put all its workers on that one CPU.
+std::vector<int> read_allowed_cpus()
 {
   std::vector<int> cpus;
   cpu_set_t set;
@@ -45,6 +48,12 @@ std::vector<int> allowed_cpus()
   }
   cpus = first;
   cpus.insert(cpus.end(), rest.begin(), rest.end());
+  return cpus;
+}
+
+const std::vector<int>& allowed_cpus()
+{
+  static const std::vector<int> cpus = read_allowed_cpus();   // thread-safe (magic static)
   return cpus;
 }
 std::atomic<unsigned> g_next_cpu_slot{ 0 };

@@ -25,7 +25,7 @@ def test_header_functions_are_exported_and_listed():
     assert sorted(capi.EXPORTS) == decl
     for name in decl:
         assert hasattr(lib, name), name
-    assert lib.svoh_abi_version() == 1
+    assert lib.svoh_abi_version() == 2
 
 
 def test_struct_sizes_match_c():

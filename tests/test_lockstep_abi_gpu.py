@@ -57,6 +57,36 @@ def test_keyed_launch_gives_every_problem_the_result_of_its_own_launch(gpu_ctx):
         ctx.release_frame(f)
 
 
+def test_keyed_cluster_launch_of_more_problems_than_arrival_counters(gpu_ctx):
+    """70 - 90 problems of 512 ... 874 patches under ONE cluster key (the round after a keyframe of a large
+    lock-step group) -- with three workgroups per problem a 256-CU device takes 85 per launch, the arrival counters hold 64:
+    the keyed call must cut its launches at 64, every problem must come back with the bits of its own launch, and a plain
+    cluster launch of more than 64 problems is refused."""
+    ctx = gpu_ctx
+    opt = capi.default_align_options(max_level=4, min_level=2)
+    scenes = [synth.make_align_scene(700 + i, n_features=n, patch_size=4) for i, n in enumerate((520, 600, 700, 860))]
+    frames, pbs = [], []
+    for sc in scenes:
+        fr, fc = ctx.build_pyramid(sc.img_ref, 5), ctx.build_pyramid(sc.img_cur, 5)
+        p, keep = fe.make_align_problems([[(sc, fr, fc)]])
+        frames += [fr, fc]; pbs.append((p[0], keep))
+    keys = []
+    for p, _ in pbs:
+        k = C.c_int32()
+        ctx._check(ctx.lib.svoh_sparse_align_geometry_key(ctx.h, C.byref(opt), C.byref(p), C.byref(k)))
+        keys.append(k.value)
+    assert len(set(keys)) == 1 and (keys[0] & 0xff) == 3, [hex(k) for k in keys]    # three workgroups per problem
+    alone = [result_bits(ctx.sparse_align(opt, (capi.svoh_align_problem * 1)(p))[0]) for p, _ in pbs]
+    for n in (65, 86, 130):
+        arr = (capi.svoh_align_problem * n)(*[pbs[i % 4][0] for i in range(n)])
+        ctx._check(ctx.lib.svoh_sparse_align_enqueue_keyed(ctx.h, C.byref(opt), n, arr, keys[0]))
+        res = ctx.sparse_align_fetch_all(n)
+        for i in range(n):
+            assert result_bits(res[i]) == alone[i % 4], (n, i)
+    for f in frames:
+        ctx.release_frame(f)
+
+
 def test_failed_enqueue_between_two_queued_launches_leaves_their_staging_alone(gpu_ctx):
     """the staging block of an alignment launch is chosen before the launch can still fail; a failing
     call between two queued launches must not make the next one overwrite the block the first is still uploading from."""
