@@ -46,6 +46,11 @@ const char* FrontendLockstep::phaseName(int k)
 }
 
 struct FrontendLockstep::Stream {
+  LockstepStreamOptions so;   // this stream's own options
+  size_t k = 0;               // frames taken so far = the number of its next frame
+  // the round in progress: has an image; has an image and a frame before it (goes through the chain); has its first image (makes its first keyframe)
+  bool active = false, tracking = false, starting = false;
+  int slot = -1;              // position among the round's tracking streams (index of its current frame in the batches' frame lists)
   SparseImgAlignHip img_align;
   ReprojectorHip reprojector;
   PoseOptimizerHip pose_optimizer;
@@ -80,9 +85,9 @@ struct FrontendLockstep::Stream {
   bool row_open = false;
   std::vector<FrameRow> done_rows;
 
-  Stream(svoh_ctx* ctx, const LockstepOptions& o, const ReprojectorOptions& ropt)
-      : img_align(ctx, SparseImgAlignHip::getDefaultSolverOptions(), o.params.img_align), reprojector(ctx, ropt, 0), pose_optimizer(ctx),
-        detector(ctx, o.params.detector, o.cam.width, o.cam.height) {}
+  Stream(svoh_ctx* ctx, const LockstepOptions& o, const LockstepStreamOptions& own, const ReprojectorOptions& ropt)
+      : so(own), img_align(ctx, SparseImgAlignHip::getDefaultSolverOptions(), own.params.img_align), reprojector(ctx, ropt, 0), pose_optimizer(ctx),
+        detector(ctx, own.params.detector, o.cam.width, o.cam.height) {}
 };
 
 void FrontendLockstep::check(int rc, const char* what) const
@@ -112,13 +117,36 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
   pose_chain_ = getenv("SVOH_LOCKSTEP_POSE_CHAIN") == nullptr || atoi(getenv("SVOH_LOCKSTEP_POSE_CHAIN")) != 0;
   if (getenv("SVOH_LOCKSTEP_COPY_POLICY")) check(svoh_set_copy_policy(ctx_, atoi(getenv("SVOH_LOCKSTEP_COPY_POLICY"))), "svoh_set_copy_policy");
   opt_.params.depth_filter.use_threaded_depthfilter = false;   // the synchronous path
-  ReprojectorOptions ropt;
-  ropt.max_n_features_per_frame = static_cast<size_t>(opt_.params.max_fts);
-  ropt.cell_size = static_cast<size_t>(opt_.params.grid_size);
-  ropt.seed_sigma2_thresh = opt_.params.seed_sigma2_thresh;
-  ropt.affine_est_offset = opt_.params.reprojector_affine_est_offset;
-  ropt.affine_est_gain = opt_.params.reprojector_affine_est_gain;
-  for (int s = 0; s < n_streams; ++s) { streams_.emplace_back(new Stream(ctx_, opt_, ropt)); streams_.back()->reprojector.sortPlannedListsOnly(true); }
+  if (!opt_.per_stream.empty() && opt_.per_stream.size() != static_cast<size_t>(n_streams)) throw std::runtime_error("FrontendLockstep: per_stream must hold one entry per stream (or none)");
+  if (!opt_.per_stream.empty()) opt_.params = opt_.per_stream[0].params;   // the shared part is read from here
+  opt_.params.depth_filter.use_threaded_depthfilter = false;
+  for (int s = 0; s < n_streams; ++s) {
+    LockstepStreamOptions so;
+    if (opt_.per_stream.empty()) { so.params = opt_.params; so.depth_min = opt_.depth_min; so.depth_mean = opt_.depth_mean; so.depth_max = opt_.depth_max; so.kf_every = opt_.kf_every; so.min_tracked = opt_.min_tracked; }
+    else so = opt_.per_stream[static_cast<size_t>(s)];
+    so.params.depth_filter.use_threaded_depthfilter = false;
+    if (so.kf_every < 1) throw std::runtime_error("FrontendLockstep: kf_every must be >= 1");
+    // what the streams of a round share in ONE device call must be the same for all of them
+    const io::FrontendParams &a = opt_.params, &b = so.params;
+    const bool same = a.n_pyr_levels_to_build == b.n_pyr_levels_to_build && a.grid_size == b.grid_size && a.seed_sigma2_thresh == b.seed_sigma2_thresh &&
+        a.reprojector_affine_est_offset == b.reprojector_affine_est_offset && a.reprojector_affine_est_gain == b.reprojector_affine_est_gain &&
+        a.depth_filter.seed_convergence_sigma2_thresh == b.depth_filter.seed_convergence_sigma2_thresh &&
+        a.depth_filter.mappoint_convergence_sigma2_thresh == b.depth_filter.mappoint_convergence_sigma2_thresh &&
+        a.depth_filter.scan_epi_unit_sphere == b.depth_filter.scan_epi_unit_sphere && a.depth_filter.affine_est_offset == b.depth_filter.affine_est_offset &&
+        a.depth_filter.affine_est_gain == b.depth_filter.affine_est_gain && a.detector.cell_size == b.detector.cell_size && a.detector.max_level == b.detector.max_level &&
+        a.detector.min_level == b.detector.min_level && a.detector.border == b.detector.border && a.detector.detector_type == b.detector.detector_type &&
+        a.detector.threshold_primary == b.detector.threshold_primary && a.detector.threshold_secondary == b.detector.threshold_secondary;
+    if (!same) throw std::runtime_error("FrontendLockstep: stream " + std::to_string(s) + " differs from stream 0 in an option that the streams' shared device calls take once "
+                                        "(pyramid levels, grid, detector, matcher / depth-filter switches): such streams belong in engines of their own");
+    ReprojectorOptions ropt;
+    ropt.max_n_features_per_frame = static_cast<size_t>(so.params.max_fts);
+    ropt.cell_size = static_cast<size_t>(so.params.grid_size);
+    ropt.seed_sigma2_thresh = so.params.seed_sigma2_thresh;
+    ropt.affine_est_offset = so.params.reprojector_affine_est_offset;
+    ropt.affine_est_gain = so.params.reprojector_affine_est_gain;
+    streams_.emplace_back(new Stream(ctx_, opt_, so, ropt));
+    streams_.back()->reprojector.sortPlannedListsOnly(true);
+  }
 }
 
 FrontendLockstep::~FrontendLockstep()
@@ -220,7 +248,7 @@ void FrontendLockstep::startDetection(const std::vector<int>& which)
   const size_t n_cells = streams_[0]->detector.grid_.size();
   for (int s : which) {
     Stream& st = *streams_[static_cast<size_t>(s)];
-    st.detect_max_n = opt_.params.max_n_seeds_per_frame - static_cast<int>(st.frame->num_features_);
+    st.detect_max_n = st.so.params.max_n_seeds_per_frame - static_cast<int>(st.frame->num_features_);
     st.detect_slot = -1;
     if (st.detect_max_n > 0) { st.detect_slot = static_cast<int>(detect_.streams.size()); detect_.streams.push_back(s); }
   }
@@ -291,7 +319,7 @@ void FrontendLockstep::makeKeyframes(const std::vector<int>& which)
       std::vector<uint8_t> type;
       st.detector.fillFromCells(ckeys.data() + i * n_cells, ekeys.data() + i * n_cells, angles.data() + i * n_cells, opt_.cam.width, opt_.cam.height,
                                 static_cast<size_t>(st.detect_max_n), px, score, level, grad, type);
-      depth_filter_utils::appendSeeds(f, px, score, level, grad, type, opt_.depth_min, opt_.depth_mean);
+      depth_filter_utils::appendSeeds(f, px, score, level, grad, type, st.so.depth_min, st.so.depth_mean);
     } else {
       st.detector.resetGrid();
     }
@@ -327,12 +355,16 @@ void FrontendLockstep::prefetch(const uint8_t* const* next_images, int pitch)
 {
   if (!next_images || !prefetched_.empty()) return;
   const int S = numStreams();
+  std::vector<const uint8_t*> imgs;   // the streams that will have a frame
+  for (int s = 0; s < S; ++s) if (next_images[s]) imgs.push_back(next_images[s]);
+  if (imgs.empty()) return;
+  std::vector<svoh_frame_t> handles(imgs.size(), 0);
+  check(svoh_build_pyramid_multi_prefetch(ctx_, imgs.data(), static_cast<int>(imgs.size()), opt_.cam.width, opt_.cam.height, pitch, opt_.images_mem_space,
+                                          opt_.params.n_pyr_levels_to_build, SVOH_HALFSAMPLE_REFERENCE, handles.data()), "svoh_build_pyramid_multi_prefetch");
+  ++device_calls_;
   prefetched_.assign(static_cast<size_t>(S), 0);
   prefetched_from_.assign(next_images, next_images + S);
-  const int rc = svoh_build_pyramid_multi_prefetch(ctx_, next_images, S, opt_.cam.width, opt_.cam.height, pitch, opt_.images_mem_space, opt_.params.n_pyr_levels_to_build,
-                                                   SVOH_HALFSAMPLE_REFERENCE, prefetched_.data());
-  if (rc != SVOH_OK) { prefetched_.clear(); prefetched_from_.clear(); check(rc, "svoh_build_pyramid_multi_prefetch"); }
-  ++device_calls_;
+  for (int s = 0, i = 0; s < S; ++s) if (next_images[s]) prefetched_[static_cast<size_t>(s)] = handles[static_cast<size_t>(i++)];
 }
 
 void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const Transformation* T_f_w_first, const uint8_t* const* next_images)
@@ -358,23 +390,47 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     }
   } trace_line{ this, phase_at_start, t0 };
   drainReleases();
+  if (!images) throw std::runtime_error("FrontendLockstep::addImages: NULL images");
 
-  // ---- pyramids of the round's S images: one call
-  {
-    std::vector<svoh_frame_t> handles(static_cast<size_t>(S));
-    if (!prefetched_.empty()) {   // made during the round before
-      for (int s = 0; s < S; ++s)
-        if (prefetched_from_[static_cast<size_t>(s)] != images[s]) throw std::runtime_error("FrontendLockstep::addImages: not the images that were announced as next_images");
+  // ---- who takes part in this round: the streams that have an image.  A stream with a frame before it goes through the chain
+  // ("tracking", numbered by `slot` among the round's tracking streams); a stream's first image makes its first keyframe ("starting")
+  std::vector<int> trk, starting;
+  int n_active = 0;
+  for (int s = 0; s < S; ++s) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    st.active = images[s] != nullptr;
+    st.tracking = st.active && st.last;
+    st.starting = st.active && !st.last;
+    st.slot = -1;
+    st.do_pose = false; st.needs_more = false; st.want_kf = false; st.proj_job = -1; st.pose_slot = -1; st.align_result = -1;
+    if (st.tracking) { st.slot = static_cast<int>(trk.size()); trk.push_back(s); }
+    if (st.starting) { if (!T_f_w_first) throw std::runtime_error("FrontendLockstep::addImages: a stream's first frame needs its pose (T_f_w_first)"); starting.push_back(s); }
+    n_active += st.active;
+  }
+  const int nT = static_cast<int>(trk.size());
+  if (!prefetched_.empty())   // made during the round before: for exactly the images that were announced
+    for (int s = 0; s < S; ++s)
+      if (prefetched_from_[static_cast<size_t>(s)] != images[s]) throw std::runtime_error("FrontendLockstep::addImages: not the images that were announced as next_images");
+
+  // ---- pyramids of the round's images: one call
+  if (n_active) {
+    std::vector<svoh_frame_t> handles(static_cast<size_t>(S), 0);
+    if (!prefetched_.empty()) {
       handles.swap(prefetched_);
       prefetched_.clear(); prefetched_from_.clear();
       check(svoh_prefetch_fence(ctx_), "svoh_prefetch_fence");
     } else {
-      check(svoh_build_pyramid_multi(ctx_, images, S, opt_.cam.width, opt_.cam.height, pitch, opt_.images_mem_space, opt_.params.n_pyr_levels_to_build,
-                                     SVOH_HALFSAMPLE_REFERENCE, handles.data()), "svoh_build_pyramid_multi");
+      std::vector<const uint8_t*> imgs;
+      for (int s = 0; s < S; ++s) if (images[s]) imgs.push_back(images[s]);
+      std::vector<svoh_frame_t> made(imgs.size(), 0);
+      check(svoh_build_pyramid_multi(ctx_, imgs.data(), static_cast<int>(imgs.size()), opt_.cam.width, opt_.cam.height, pitch, opt_.images_mem_space,
+                                     opt_.params.n_pyr_levels_to_build, SVOH_HALFSAMPLE_REFERENCE, made.data()), "svoh_build_pyramid_multi");
       ++device_calls_;
+      for (int s = 0, i = 0; s < S; ++s) if (images[s]) handles[static_cast<size_t>(s)] = made[static_cast<size_t>(i++)];
     }
     for (int s = 0; s < S; ++s) {
       Stream& st = *streams_[static_cast<size_t>(s)];
+      if (!st.active) continue;
       FramePtr frame(new Frame, [this](Frame* f) {
         if (f->pyramid || f->features) {
           std::lock_guard<std::mutex> lock(release_mu_);
@@ -386,7 +442,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       frame->pyramid = handles[static_cast<size_t>(s)];
       frame->cam = opt_.cam;
       frame->set_T_cam_imu(svoh::inverse(opt_.T_B_C));
-      frame->id_ = static_cast<int>(round_);
+      frame->id_ = static_cast<int>(st.k);
       st.frame = frame;
     }
   }
@@ -395,34 +451,48 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   // is queued AHEAD of the wait: the only thing it needs of the update is the new inverse depth of the seeds its points hang on,
   // and the device has that (svoh_align_camera::pos_seed_unit reads the update's batch in place).  The wait for the update and
   // the host's share of finishing it then run beside the alignment kernel.
-  const bool align_ahead = align_ahead_ && seeds_in_flight_ && round_ > 0 && opt_.images_mem_space >= 0;
+  const bool align_ahead = align_ahead_ && seeds_in_flight_ && nT > 0 && opt_.images_mem_space >= 0;
   if (!align_ahead) finishSeedUpdate();
   pc.lap(kPhFinishSeeds);
   const double t1 = now_ms();
   times_.pyramid = t1 - t0;
 
-  if (round_ == 0) {
-    if (!T_f_w_first) throw std::runtime_error("FrontendLockstep::addImages: the first frames need their poses");
-    std::vector<int> all;
-    for (int s = 0; s < S; ++s) { streams_[static_cast<size_t>(s)]->frame->T_f_w_ = T_f_w_first[s]; all.push_back(s); }
-    startDetection(all);
-    makeKeyframes(all);
+  // the round's end for every stream that had an image: its row opens, its frame becomes its last one
+  auto close_round = [&]() {
     for (auto& stp : streams_) {
       Stream& st = *stp;
+      if (!st.active) continue;
+      st.row.is_kf = st.want_kf;
+      st.row_open = true;
+      // (the frame before this one lives on in b_last until the stream's next alignment set-up replaces the bundles -- on the
+      // pool: taking a dozen frames apart here, on the group's thread, is 0.05 ms of every round)
       st.last = st.frame; st.frame.reset();
-      st.row = FrameRow(); st.row.k = 0; st.row.is_kf = true; st.row_open = true;
+      ++st.k;
     }
+    drainReleases();
+  };
+  for (int s : starting) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    st.frame->T_f_w_ = T_f_w_first[s];
+    st.row = FrameRow(); st.row.k = st.k;
+    st.want_kf = true;
+  }
+  if (nT == 0) {   // nobody to track (the first round of all, or a round nobody has an image for)
+    if (!starting.empty()) { startDetection(starting); makeKeyframes(starting); }
+    close_round();
     prefetch(next_images, pitch);
     times_.keyframe = now_ms() - t1;
     times_.total = now_ms() - t0;
     ++round_;
     return;
   }
+  const Frame& any_frame = *streams_[static_cast<size_t>(trk[0])]->frame;   // (the camera is the engine's: what depends on it is the same for every stream)
 
   // ---- 1. sparse image alignment against the last frame (frame_handler_base.cpp:610-643), every stream's problem in the
   // geometry it would get alone; behind it the candidate projection of every stream, its pose composed on the device
   pool_.run(S, [&](int s) {
     Stream& st = *streams_[static_cast<size_t>(s)];
+    if (!st.tracking) return;
     st.frame->T_f_w_ = st.last->T_f_w_;
     if (align_ahead)
       resolveAlignmentPoints(*st.last, [&st](const Frame& kf, size_t seed_id) -> int32_t {   // where the update in flight holds that seed
@@ -442,17 +512,22 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     st.reprojector.countCandidateProjection(st.visible, &st.proj_points, &st.proj_kf);
   });
   pc.lap(kPhAlignPrep);
-  std::vector<svoh_align_result> align_results(static_cast<size_t>(S));
+  std::vector<svoh_align_result> align_results(static_cast<size_t>(nT));
   std::vector<uint8_t> align_repeated(static_cast<size_t>(S), 0);
   svoh_candidate_stage_t cs{};
   {
-    // groups of equal launch geometry, in the order their first stream appears
+    // groups of equal launch geometry AND equal options, in the order their first stream appears
+    auto same_options = [](const svoh_align_options& a, const svoh_align_options& b) {
+      return a.max_level == b.max_level && a.min_level == b.min_level && a.patch_size == b.patch_size && a.max_iter == b.max_iter && a.eps == b.eps &&
+             a.estimate_illumination_gain == b.estimate_illumination_gain && a.estimate_illumination_offset == b.estimate_illumination_offset &&
+             a.use_distortion_jacobian == b.use_distortion_jacobian && a.robustification == b.robustification && a.weight_scale == b.weight_scale;
+    };
     std::vector<std::pair<int32_t, std::vector<int>>> groups;
-    for (int s = 0; s < S; ++s) {
+    for (int s : trk) {
       Stream& st = *streams_[static_cast<size_t>(s)];
       check(svoh_sparse_align_geometry_key(ctx_, &st.align_opt, &st.align_pb, &st.align_key), "svoh_sparse_align_geometry_key");
       size_t g = 0;
-      while (g < groups.size() && groups[g].first != st.align_key) ++g;
+      while (g < groups.size() && !(groups[g].first == st.align_key && same_options(streams_[static_cast<size_t>(groups[g].second[0])]->align_opt, st.align_opt))) ++g;
       if (g == groups.size()) groups.emplace_back(st.align_key, std::vector<int>());
       groups[g].second.push_back(s);
     }
@@ -473,9 +548,9 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     // the candidate projections: one staged call for all streams that have a local map
     size_t n_points = 0, n_kf = 0;
     int n_jobs = 0;
-    for (auto& stp : streams_) {
-      Stream& st = *stp;
-      st.proj_point_off = n_points; st.proj_kf_off = n_kf; st.proj_job = -1;
+    for (int s : trk) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      st.proj_point_off = n_points; st.proj_kf_off = n_kf;
       if (st.proj_points) { st.proj_job = n_jobs++; n_points += st.proj_points; n_kf += st.proj_kf; }
     }
     if (n_jobs) {
@@ -513,12 +588,12 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     }
     pc.lap(kPhProjGather);
     if (proj_ahead) { finishSeedUpdate(); pc.lap(kPhFinishSeeds); }   // the previous round's seed update: waited for and written back beside the two kernels
-    check(svoh_sparse_align_fetch_all(ctx_, S, align_results.data()), "svoh_sparse_align_fetch_all");
+    check(svoh_sparse_align_fetch_all(ctx_, nT, align_results.data()), "svoh_sparse_align_fetch_all");
     ++device_calls_;
     if (n_jobs) check(svoh_project_candidates_wait(ctx_), "svoh_project_candidates_wait");
     // a cluster of workgroups that never completed (status 3): the blocking entry repeats that problem with one
     // workgroup, and what was projected behind the first launch used a pose that is not the result's
-    for (int s = 0; s < S; ++s) {
+    for (int s : trk) {
       Stream& st = *streams_[static_cast<size_t>(s)];
       if (align_results[static_cast<size_t>(st.align_result)].status != 3) continue;
       check(svoh_sparse_align_batch(ctx_, &st.align_opt, 1, &st.align_pb, &align_results[static_cast<size_t>(st.align_result)]), "svoh_sparse_align_batch");
@@ -536,13 +611,14 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   // those streams get one more batch of their own (below), the others lose nothing.
   pool_.run(S, [&](int s) {
     Stream& st = *streams_[static_cast<size_t>(s)];
-    st.row = FrameRow(); st.row.k = round_;
+    if (!st.tracking) return;
+    st.row = FrameRow(); st.row.k = st.k;
     st.row.n_aligned = st.img_align.finishRun(align_results[static_cast<size_t>(st.align_result)], st.b_cur, st.T_iref_world);
     if (st.proj_job >= 0 && !align_repeated[static_cast<size_t>(s)] && st.row.n_aligned != 0)
       st.reprojector.adoptCandidateProjection(st.frame, cs.px + 2 * st.proj_point_off, cs.visible + st.proj_point_off);
     else st.reprojector.discardCandidateProjection();
     st.trash.clear();
-    const bool third = !speculate_never_ && (speculate_all_ || round_ <= 1 || st.reprojector.reachedUnconvergedPass());   // (of the frame before: the walk resets nothing of it)
+    const bool third = !speculate_never_ && (speculate_all_ || st.k <= 1 || st.reprojector.reachedUnconvergedPass());   // (of the frame before: the walk resets nothing of it)
     if (third) st.reprojector.walkCandidates(st.frame, st.visible, st.trash);
     else st.reprojector.walkCandidatesWithoutUnconverged(st.frame, st.visible, st.trash);   // (their turn comes with their pass, if it comes)
     st.reprojector.planMatches(st.frame, third ? 3 : 2, opt_.resident_features);
@@ -562,14 +638,14 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     ds = svoh_matcher_stage_t{}; ss = svoh_matcher_stage_t{};
     if (n_direct + n_seeds == 0) { if (meanwhile) meanwhile(); return; }
     const svoh_matcher_options mopt = detail::reprojectorMatcherOptions(opt_.params.reprojector_affine_est_offset, opt_.params.reprojector_affine_est_gain);
-    const int max_views = static_cast<int>(n_refs) + S + 1;
+    const int max_views = static_cast<int>(n_refs) + nT + 1;
     check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
     struct CloseSection { svoh_ctx* c; bool armed; ~CloseSection() { if (armed) (void)svoh_matcher_collect(c); } } close_section{ ctx_, true };
     const int stage_flags = SVOH_STAGE_MATCH_OUTPUTS | (opt_.resident_features ? SVOH_STAGE_RESIDENT_COLUMNS : 0);
     if (n_direct) check(svoh_matcher_stage(ctx_, 0, static_cast<int>(n_direct), max_views, stage_flags, &ds), "svoh_matcher_stage");
     if (n_seeds) check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_seeds), max_views, stage_flags, &ss), "svoh_matcher_stage");
-    std::vector<svoh_frame_view> refs(n_refs ? n_refs : 1), curs(static_cast<size_t>(S));
-    for (int s = 0; s < S; ++s) curs[static_cast<size_t>(s)] = detail::viewOf(*streams_[static_cast<size_t>(s)]->frame);
+    std::vector<svoh_frame_view> refs(n_refs ? n_refs : 1), curs(static_cast<size_t>(nT));
+    for (int s : trk) { const Stream& st = *streams_[static_cast<size_t>(s)]; curs[static_cast<size_t>(st.slot)] = detail::viewOf(*st.frame); }
     pc.lap(kPhMatchStage);
     pool_.run(static_cast<int>(who.size()), [&](int w) {
       const int s = who[static_cast<size_t>(w)];
@@ -579,7 +655,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       auto copy_batch = [&](const detail::Batch& b, const svoh_matcher_stage_t& g, size_t o) {
         const size_t m = b.size();
         if (!m) return;
-        for (size_t i = 0; i < m; ++i) { g.ref_frame_idx[o + i] = b.ref_idx[i] + static_cast<int32_t>(st.ref_off); g.cur_frame_idx[o + i] = s; }
+        for (size_t i = 0; i < m; ++i) { g.ref_frame_idx[o + i] = b.ref_idx[i] + static_cast<int32_t>(st.ref_off); g.cur_frame_idx[o + i] = st.slot; }
         if (b.resident) memcpy(g.feature_index + o, b.fidx.data(), 4 * m);
         else {
           memcpy(g.px + 2 * o, b.px.data(), 16 * m); memcpy(g.f + 3 * o, b.f.data(), 24 * m); memcpy(g.grad + 2 * o, b.grad.data(), 16 * m);
@@ -596,7 +672,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     auto batch_of = [&](const svoh_matcher_stage_t& g, size_t n) {
       svoh_feature_batch fb{};
       fb.n = static_cast<int32_t>(n);
-      fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = S;
+      fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = nT;
       fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type; fb.feature_index = g.feature_index;
       fb.mem_space = SVOH_MEM_STAGED;
       return fb;
@@ -608,7 +684,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     }
     if (n_seeds) {
       const svoh_feature_batch fb = batch_of(ss, n_seeds);
-      const svoh_depth_filter_options o = detail::reprojectorSeedOptions(*streams_[0]->frame, opt_.params.seed_sigma2_thresh);
+      const svoh_depth_filter_options o = detail::reprojectorSeedOptions(any_frame, opt_.params.seed_sigma2_thresh);
       const svoh_seed_match_outputs outs{ ss.px_cur, ss.f_cur, ss.search_level, ss.A_cur_ref };
       check(svoh_update_seeds_batch_ex(ctx_, &mopt, &o, static_cast<int>(n_refs), refs.data(), curs.data(), &fb, ss.state, ss.success, ss.result, nullptr, &outs),
             "svoh_update_seeds_batch_ex");
@@ -642,20 +718,17 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     st.do_pose = st.frame->num_features_ >= 10;
     if (st.do_pose) st.pose_optimizer.prepareRun(st.b_cur, 2.0, st.pose_opt, st.pose_pb);
   };
-  {
-    std::vector<int> all(static_cast<size_t>(S));
-    for (int s = 0; s < S; ++s) all[static_cast<size_t>(s)] = s;
-    // sortCandidatesByReprojStats of every stream's three lists while the device works
-    matcher_round(all, [&]() {
-      pool_.run(S, [&](int s) { streams_[static_cast<size_t>(s)]->reprojector.sortCandidateLists(); });
-      pc.lap(kPhSort);
-    });
-  }
+  // sortCandidatesByReprojStats of every stream's three lists while the device works
+  matcher_round(trk, [&]() {
+    pool_.run(S, [&](int s) { Stream& st = *streams_[static_cast<size_t>(s)]; if (st.tracking) st.reprojector.sortCandidateLists(); });
+    pc.lap(kPhSort);
+  });
   // the context's stream is idle here: the next round's images start their way up now, beside the rest of this round
   { const double tw = now_ms(); prefetch(next_images, pitch); phase_ms_[kPhPrefetch] += now_ms() - tw; }   // (part of "replay + pose prep")
   // the reference's three passes per stream on its slices of the finished batches, then the stream's pose problem
   pool_.run(S, [&](int s) {
     Stream& st = *streams_[static_cast<size_t>(s)];
+    if (!st.tracking) return;
     point_outputs(st);
     st.needs_more = st.reprojector.replayMatchesUntilUnplanned(st.frame);
     if (!st.needs_more) pose_prep(st);
@@ -663,7 +736,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   // streams whose replay stands before a pass that was not planned: that pass' list in a batch of their own, and on
   for (;;) {
     std::vector<int> more;
-    for (int s = 0; s < S; ++s) if (streams_[static_cast<size_t>(s)]->needs_more) more.push_back(s);
+    for (int s : trk) if (streams_[static_cast<size_t>(s)]->needs_more) more.push_back(s);
     if (more.empty()) break;
     pool_.run(static_cast<int>(more.size()), [&](int w) {
       Stream& st = *streams_[static_cast<size_t>(more[static_cast<size_t>(w)])];
@@ -680,13 +753,14 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   pc.lap(kPhReplay);
   const double t3 = now_ms();
   times_.reproject = t3 - t2;
-  // a round of periodic keyframes: their detector goes to the device now, ahead of the pose optimisation, and is long done when
-  // the keyframes are made (section 5) -- behind the depth filter's update it would be waited for
-  if (detect_ahead_ && round_ % opt_.kf_every == 0) {
-    std::vector<int> all;
-    for (int s = 0; s < S; ++s) all.push_back(s);
-    startDetection(all);
-    pc.lap(kPhKeyframe);
+  // the streams whose periodic keyframe falls on this frame (every stream counts its own frames), and the streams that start: their
+  // detector goes to the device now, ahead of the pose optimisation, and is long done when the keyframes are made (section 5) --
+  // behind the depth filter's update it would be waited for
+  if (detect_ahead_) {
+    std::vector<int> ahead = starting;
+    for (int s : trk) { const Stream& st = *streams_[static_cast<size_t>(s)]; if (st.k % st.so.kf_every == 0) ahead.push_back(s); }
+    std::sort(ahead.begin(), ahead.end());
+    if (!ahead.empty()) { startDetection(ahead); pc.lap(kPhKeyframe); }
   }
 
   // ---- 3 + 4. pose optimisation (frame_handler_base.cpp:746-790) and depth filter (frame_handler_mono.cpp:125): the bundles of all
@@ -697,14 +771,13 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   {
     std::vector<svoh_pose_problem> pbs;
     std::vector<int> who;
-    for (int s = 0; s < S; ++s) {
+    for (int s : trk) {
       Stream& st = *streams_[static_cast<size_t>(s)];
-      st.pose_slot = -1;
       if (st.do_pose) { st.pose_slot = static_cast<int>(pbs.size()); pbs.push_back(st.pose_pb); who.push_back(s); }
     }
     size_t n_total = 0, n_ref_total = 0;
-    for (auto& stp : streams_) {
-      Stream& st = *stp;
+    for (int s : trk) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
       st.seed_frames = st.visible;
       st.seed_counts.clear();
       size_t n = 0;
@@ -716,20 +789,21 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     // (the order of round 4 -- pose, wait, then the seed batch with the poses the host has applied -- is kept for comparison)
     const bool chain = pose_chain_ && !pbs.empty() && n_total > 0;
     DepthFilterHip df(ctx_, opt_.params.depth_filter);   // (options only: the batch is the driver's)
-    const svoh_depth_filter_options dfo = df.abiOptions(*streams_[0]->frame);
+    const svoh_depth_filter_options dfo = df.abiOptions(any_frame);
     const svoh_matcher_options df_mopt = df.getMatcherOptions();
-    std::vector<svoh_frame_view> refs(n_ref_total ? n_ref_total : 1), curs(static_cast<size_t>(S));
+    std::vector<svoh_frame_view> refs(n_ref_total ? n_ref_total : 1), curs(static_cast<size_t>(nT));
     struct CloseSection { svoh_ctx* c; bool armed; ~CloseSection() { if (armed) (void)svoh_matcher_collect(c); } } close_section{ ctx_, false };
     auto stage_seeds = [&](bool poses_from_device) {
       check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
       close_section.armed = true;
-      check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_total), static_cast<int>(n_ref_total) + S + 1, opt_.resident_features ? SVOH_STAGE_RESIDENT_COLUMNS : 0, &seed_stage_),
+      check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_total), static_cast<int>(n_ref_total) + nT + 1, opt_.resident_features ? SVOH_STAGE_RESIDENT_COLUMNS : 0, &seed_stage_),
             "svoh_matcher_stage");
       const svoh_matcher_stage_t& g = seed_stage_;
       pc.lap(kPhSeedStage);
       pool_.run(S, [&](int s) {
         Stream& st = *streams_[static_cast<size_t>(s)];
-        svoh_frame_view& cv = curs[static_cast<size_t>(s)];
+        if (!st.tracking) return;
+        svoh_frame_view& cv = curs[static_cast<size_t>(st.slot)];
         cv = detail::viewOf(*st.frame);
         if (poses_from_device && st.pose_slot >= 0) {   // T_f_w := T_cam_imu * (result pose_slot of the batch in flight), on the device
           svoh::store_rigid(st.frame->T_cam_imu(), cv.T_f_w);
@@ -740,7 +814,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
           const Frame& r = *st.seed_frames[k];
           refs[st.ref_off + k] = detail::viewOf(r);
           const size_t n = st.seed_counts[k];
-          for (size_t i = 0; i < n; ++i) { g.ref_frame_idx[off + i] = static_cast<int32_t>(st.ref_off + k); g.cur_frame_idx[off + i] = s; }
+          for (size_t i = 0; i < n; ++i) { g.ref_frame_idx[off + i] = static_cast<int32_t>(st.ref_off + k); g.cur_frame_idx[off + i] = st.slot; }
           if (g.feature_index) for (size_t i = 0; i < n; ++i) g.feature_index[off + i] = static_cast<int32_t>(i);
           else {
             memcpy(g.px + 2 * off, r.px_vec_.data(), 16 * n); memcpy(g.f + 3 * off, r.f_vec_.data(), 24 * n); memcpy(g.grad + 2 * off, r.grad_vec_.data(), 16 * n);
@@ -757,7 +831,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       const svoh_matcher_stage_t& g = seed_stage_;
       svoh_feature_batch fb{};
       fb.n = static_cast<int32_t>(n_total);
-      fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = S;
+      fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = nT;
       fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type; fb.feature_index = g.feature_index;
       fb.mem_space = SVOH_MEM_STAGED;
       check(svoh_update_seeds_batch(ctx_, &df_mopt, &dfo, static_cast<int>(n_ref_total), refs.data(), curs.data(), &fb, g.state, g.success, g.result, nullptr),
@@ -802,25 +876,18 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
   }
   const double t5 = now_ms();
 
-  // ---- 5. keyframe rule, the new keyframes' detector in one call
+  // ---- 5. keyframe rule (every stream by its own count and its own thresholds), the new keyframes' detector in one call
   {
-    std::vector<int> which;
-    for (int s = 0; s < S; ++s) {
+    std::vector<int> which = starting;
+    for (int s : trk) {
       Stream& st = *streams_[static_cast<size_t>(s)];
-      st.want_kf = round_ % opt_.kf_every == 0 || st.frame->numTrackedFeatures() < opt_.min_tracked;
+      st.want_kf = st.k % st.so.kf_every == 0 || st.frame->numTrackedFeatures() < st.so.min_tracked;
       if (st.want_kf) which.push_back(s);
     }
+    std::sort(which.begin(), which.end());
     makeKeyframes(which);
   }
-  for (auto& stp : streams_) {
-    Stream& st = *stp;
-    st.row.is_kf = st.want_kf;
-    st.row_open = true;
-    // (the frame before this one lives on in b_last until the next round's alignment set-up replaces the bundles -- on the
-    // pool: taking a dozen frames apart here, on the group's thread, is 0.05 ms of every round)
-    st.last = st.frame; st.frame.reset();
-  }
-  drainReleases();
+  close_round();
   pc.lap(kPhKeyframe);
   const double t6 = now_ms();
   times_.keyframe = t6 - t5;

@@ -41,7 +41,20 @@
 
 namespace svo_hip {
 
+// What may differ between the streams of one engine (round 6).  Everything that decides the options of a device call the streams
+// of a round SHARE -- the camera and its extrinsics, the pyramid's levels, the grid, the detector / matcher / depth-filter switches --
+// must be the same for all of them (the constructor checks and refuses); a stream's own are its feature budgets (max_fts: the
+// reprojector's cap and, with max_seeds_ratio, the seeds per keyframe), its alignment options (streams of different options go
+// into different launches), its keyframe rule and its depth prior.  The reference's counterpart: independent frame handlers, each
+// built from its own parameter file (src/svo/include/svo/frame_handler_base.h:274-374, svo_factory.cpp:107-310).
+struct LockstepStreamOptions {
+  io::FrontendParams params;
+  float depth_min = 1.f, depth_mean = 2.f, depth_max = 4.f;
+  size_t kf_every = 8, min_tracked = 60;
+};
+
 struct LockstepOptions {
+  // every stream's options when per_stream is empty; the options shared by all streams otherwise
   io::FrontendParams params;
   svoh_camera cam{};
   Transformation T_B_C{ { 1, 0, 0, 0 }, { 0, 0, 0 } };
@@ -59,6 +72,8 @@ struct LockstepOptions {
   // a keyframe's constant feature columns are uploaded once (svoh_features_upload); the matcher and depth-filter batches of
   // the frames after it name features by index instead of carrying 60 bytes per feature over PCIe every frame
   bool resident_features = true;
+  // one entry per stream, or empty: every stream runs with params / depth_* / kf_every / min_tracked above
+  std::vector<LockstepStreamOptions> per_stream;
 };
 
 class FrontendLockstep {
@@ -73,8 +88,10 @@ class FrontendLockstep {
   FrontendLockstep& operator=(const FrontendLockstep&) = delete;
 
   int numStreams() const { return static_cast<int>(streams_.size()); }
-  // One frame of every stream: images[s] = level 0 of stream s' image (all of the camera's size, `pitch` bytes per row).
-  // The first call makes every stream's first keyframe at T_f_w_first[s].
+  // One frame of every stream: images[s] = level 0 of stream s' image (all of the camera's size, `pitch` bytes per row), or
+  // NULL: stream s has no frame in this round (cameras of different rates, a dropped frame, a stream that starts later or has
+  // ended) and is left exactly as it is.  A stream's FIRST frame -- in whatever round it comes -- makes its first keyframe at
+  // T_f_w_first[s] (needed in every round in which some stream starts); its k-th frame is numbered k whatever the round.
   // next_images (may be NULL): the images of the NEXT call, if the caller has them already -- they are then sent to the
   // device during this round, on a second stream beside the chain's work (svoh_build_pyramid_multi_prefetch), and the
   // next call, which must be given exactly these pointers as `images`, finds its pyramids made.

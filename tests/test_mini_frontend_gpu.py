@@ -205,3 +205,80 @@ def test_lockstep_variants_and_the_tracked_features_rule(tmp_path):
             for traj, counters in run([str(n_frames), kf_every, "3", "lockstep", "2", "1"], dict(env, **rule)):
                 assert traj == single[0], (kf_every, env)
                 assert np.array_equal(counters, single[1]), (kf_every, env)
+
+
+# ---- round 6: streams that DIFFER ---------------------------------------------------------------------------------------------
+
+HETERO_STREAMS = [   # (start, step, frames, every, phase, kf_every, min_tracked, max_fts)
+    (0, 1, 40, 1, 0, 8, 60, 180),        # the sequence as it is
+    (39, -1, 40, 1, 0, 6, 60, 120),      # backwards, fewer features, keyframes more often
+    (10, 1, 36, 1, 2, 5, 60, 240),       # starts two rounds later, more features
+    (20, -1, 30, 1, 0, 8, 60, 180),      # from the middle, backwards
+    (5, 2, 24, 1, 0, 7, 60, 120),        # every other image: twice the motion per frame
+    (0, 1, 20, 2, 1, 4, 60, 240),        # a camera of half the rate
+    (30, -2, 22, 1, 0, 1000, 20, 180),   # no periodic keyframes and a low bar: its features leave the image, its third pass IS reached
+    (15, 1, 40, 1, 0, 9, 230, 240),      # a bar above what it can track: keyframes by the tracked-features rule
+    (39, -1, 14, 3, 0, 3, 60, 120),      # a third of the rate
+]
+
+
+def write_hetero_spec(tmp_path, poses, streams=HETERO_STREAMS):
+    for m in sorted({s[7] for s in streams}):
+        (tmp_path / ("params%d.yaml" % m)).write_text("max_fts: %d\ngrid_size: 30\nn_pyr_levels: 3\ndetector_threshold_secondary: 100\n"
+                                                       "use_threaded_depthfilter: False\nimg_align_max_level: 4\nimg_align_min_level: 2\n" % m)
+    lines = []
+    for (start, step, frames, every, phase, kf_every, min_tracked, max_fts) in streams:
+        T0 = poses[start].inverse().as7()
+        lines.append("start=%d step=%d frames=%d every=%d phase=%d kf_every=%d min_tracked=%d params=%s T0=%s"
+                     % (start, step, frames, every, phase, kf_every, min_tracked, tmp_path / ("params%d.yaml" % max_fts), ",".join("%.17g" % v for v in T0)))
+    spec = tmp_path / "streams.spec"
+    spec.write_text("# one stream per line (tools/svoh_mini_frontend.cpp: SVOH_MINI_SPEC)\n" + "\n".join(lines) + "\n")
+    return spec
+
+
+def test_lockstep_of_streams_that_differ(tmp_path):
+    """the lock-step engine on streams that have NOTHING in common but the camera -- their own walk over the
+    sequence (start, direction, stride), their own frame rate and first round, their own keyframe period (so keyframe rounds do not
+    coincide), feature budgets of 120 / 180 / 240 (different launch geometries in one round), one stream whose features run out (its
+    third reprojection pass is reached while the others' is not), one that makes its keyframes by the tracked-features rule.  Every
+    stream must write the trajectory and the counters of ITS OWN single-stream run, byte for byte, for (threads, groups) =
+    (1,1), (3,1), (2,2): a gather / scatter that hands stream j's pose, candidates, seeds or keyframe columns to stream k shows here
+    (the test of identical streams cannot see it).  Reference: independent frame handlers, frame_handler_base.h:274-374."""
+    cmd, out_dir, poses, stamps, n_frames = make_dataset(tmp_path)
+    spec = write_hetero_spec(tmp_path, poses)
+    S = len(HETERO_STREAMS)
+    singles = []
+    for i in range(S):
+        r = subprocess.run(cmd + [str(n_frames), "8", "1"], capture_output=True, text=True, env=dict(os.environ, SVOH_MINI_SPEC=str(spec), SVOH_MINI_SPEC_LINE=str(i)))
+        assert r.returncode == 0, r.stdout + r.stderr
+        traj = open(str(out_dir / "trajectory.txt")).read()
+        counters = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)[:, :7].copy()
+        assert len(traj.splitlines()) == HETERO_STREAMS[i][2] + 1 and len(counters) == HETERO_STREAMS[i][2]
+        singles.append((traj, counters))
+    # the streams really differ: no two trajectories alike, keyframes at different frames, different numbers of aligned features
+    assert len({t for t, _ in singles}) == S
+    assert len({tuple(c[:12, 1]) for _, c in singles}) >= 5
+    assert len({int(np.median(c[1:, 2])) for _, c in singles}) >= 3
+    assert singles[7][1][1:, 1].sum() > len(singles[7][1]) // 9 + 1, "stream 7's tracked-features rule never fired: the case tests nothing"
+    for n_workers, n_groups in ((1, 1), (3, 1), (2, 2)):
+        for d in [out_dir] + [out_dir / ("stream%d" % k) for k in range(1, 64)]:
+            for name in ("trajectory.txt", "frontend.csv"):
+                if (d / name).exists():
+                    (d / name).unlink()
+        r = subprocess.run(cmd + [str(n_frames), "8", str(S), "lockstep", str(n_workers), str(n_groups)], capture_output=True, text=True,
+                           env=dict(os.environ, SVOH_MINI_SPEC=str(spec)))
+        print(r.stdout, r.stderr)
+        assert r.returncode == 0, r.stdout + r.stderr
+        for k in range(S):
+            d = out_dir if k == 0 else out_dir / ("stream%d" % k)
+            assert open(str(d / "trajectory.txt")).read() == singles[k][0], "trajectory of stream %d (workers %d, groups %d)" % (k, n_workers, n_groups)
+            counters = np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :7]
+            assert np.array_equal(counters, singles[k][1]), "counters of stream %d (workers %d, groups %d)" % (k, n_workers, n_groups)
+    # the speculation switches on the mix: same files
+    for env in ({"SVOH_LOCKSTEP_SPECULATE": "never"}, {"SVOH_LOCKSTEP_SPECULATE": "all"}, {"SVOH_LOCKSTEP_ALIGN_AHEAD": "0"}):
+        r = subprocess.run(cmd + [str(n_frames), "8", str(S), "lockstep", "2", "1"], capture_output=True, text=True, env=dict(os.environ, SVOH_MINI_SPEC=str(spec), **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        for k in range(S):
+            d = out_dir if k == 0 else out_dir / ("stream%d" % k)
+            assert open(str(d / "trajectory.txt")).read() == singles[k][0], (env, k)
+            assert np.array_equal(np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :7], singles[k][1]), (env, k)

@@ -30,6 +30,15 @@
 // group's host phases overlap the other's device phases.  Every stream writes the trajectory and the counters of its
 // single-stream run, byte for byte (tests/test_mini_frontend_gpu.py).  n_laps > 1 runs the sequence that many times back
 // to back in the lock-step mode (the poses restart, the files hold the last lap): a longer steady state for the rate.
+// SVOH_MINI_SPEC=<file> (round 6): streams that DIFFER.  One line per stream, key=value pairs:
+//   start=<image> step=<+-n> frames=<n>   the stream's j-th frame is image pingpong(start + step * j) of the decoded sequence
+//                                         (the walk turns round at both ends), j = 0 .. frames - 1
+//   every=<n> phase=<n>                   lock-step only: the stream has a frame in round r iff r >= phase and (r - phase) % every == 0
+//   kf_every=<n> min_tracked=<n>          its keyframe rule        params=<yaml>   its own parameter file (max_fts, ...)
+//   T0=qw,qx,qy,qz,tx,ty,tz               T_f_w of its first frame
+// lockstep: n_streams = the number of lines (the command line's n_streams must agree); threads mode with n_streams = 1:
+// SVOH_MINI_SPEC_LINE=<i> runs stream i of the file alone -- the run a lock-step stream must reproduce byte for byte.
+// A frame's timestamp in the trajectory file is its image's.
 #include <sys/stat.h>
 
 #include <atomic>
@@ -57,13 +66,77 @@ static double now_ms()
 namespace {
 struct StreamResult { size_t n_done = 0, n_kfs = 0; double sum_ms = 0, wall_ms = 0; std::string error; };
 
+// one line of SVOH_MINI_SPEC
+struct StreamSpec {
+  long start = 0, step = 1, every = 1, phase = 0, frames = -1, kf_every = -1, min_tracked = -1;
+  std::string params;
+  bool has_T0 = false;
+  Transformation T0{ { 1, 0, 0, 0 }, { 0, 0, 0 } };
+  // image of the stream's j-th frame
+  size_t image(long j, size_t n_images) const
+  {
+    if (n_images < 2) return 0;
+    const long period = 2 * ((long)n_images - 1);
+    long m = (start + step * j) % period;
+    if (m < 0) m += period;
+    return (size_t)(m < (long)n_images ? m : period - m);
+  }
+};
+std::vector<StreamSpec> load_specs(const char* path)
+{
+  std::vector<StreamSpec> out;
+  FILE* f = fopen(path, "r");
+  if (!f) throw std::runtime_error(std::string("cannot read the stream spec ") + path);
+  char line[4096];
+  while (fgets(line, sizeof line, f)) {
+    StreamSpec sp;
+    bool any = false;
+    for (char* tok = strtok(line, " \t\r\n"); tok; tok = strtok(nullptr, " \t\r\n")) {
+      if (tok[0] == '#') break;
+      char* eq = strchr(tok, '=');
+      if (!eq) { fclose(f); throw std::runtime_error(std::string("stream spec: not key=value: ") + tok); }
+      const std::string key(tok, eq), val(eq + 1);
+      any = true;
+      if (key == "start") sp.start = atol(val.c_str());
+      else if (key == "step") sp.step = atol(val.c_str());
+      else if (key == "every") sp.every = atol(val.c_str());
+      else if (key == "phase") sp.phase = atol(val.c_str());
+      else if (key == "frames") sp.frames = atol(val.c_str());
+      else if (key == "kf_every") sp.kf_every = atol(val.c_str());
+      else if (key == "min_tracked") sp.min_tracked = atol(val.c_str());
+      else if (key == "params") sp.params = val;
+      else if (key == "T0") {
+        double v[7];
+        if (sscanf(val.c_str(), "%lf,%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6) != 7) { fclose(f); throw std::runtime_error("stream spec: T0 needs seven numbers"); }
+        sp.T0 = Transformation{ { v[0], v[1], v[2], v[3] }, { v[4], v[5], v[6] } };
+        sp.has_T0 = true;
+      } else { fclose(f); throw std::runtime_error("stream spec: unknown key " + key); }
+    }
+    if (!any) continue;
+    if (sp.every < 1 || sp.phase < 0 || sp.step == 0) { fclose(f); throw std::runtime_error("stream spec: every >= 1, phase >= 0, step != 0"); }
+    out.push_back(sp);
+  }
+  fclose(f);
+  if (out.empty()) throw std::runtime_error("stream spec: no streams");
+  return out;
+}
+
 // one camera stream through the whole chain; images are decoded beforehand and shared read-only
 void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& images, const std::vector<io::RigCamera>& rig,
                 io::FrontendParams params, const std::string& out_dir, const Transformation& T0, float depth_min, float depth_mean,
-                float depth_max, size_t kf_every, std::atomic<int>* start_gate, int n_streams, StreamResult* out)
+                float depth_max, size_t kf_every, std::atomic<int>* start_gate, int n_streams, StreamResult* out, const StreamSpec* spec = nullptr)
 {
   try {
-    const size_t min_tracked = getenv("SVOH_MINI_MIN_TRACKED") ? (size_t)atol(getenv("SVOH_MINI_MIN_TRACKED")) : 60;   // (tests raise it to make the rule fire)
+    size_t min_tracked = getenv("SVOH_MINI_MIN_TRACKED") ? (size_t)atol(getenv("SVOH_MINI_MIN_TRACKED")) : 60;   // (tests raise it to make the rule fire)
+    // the images of the stream's frames, in its order (a spec line: its own walk over the decoded sequence)
+    std::vector<size_t> order;
+    if (spec) {
+      const long n = spec->frames > 0 ? spec->frames : (long)images.size();
+      for (long j = 0; j < n; ++j) order.push_back(spec->image(j, images.size()));
+      if (spec->min_tracked >= 0) min_tracked = (size_t)spec->min_tracked;
+    } else {
+      for (size_t k = 0; k < images.size(); ++k) order.push_back(k);
+    }
     const bool sync_flow = getenv("SVOH_MINI_SYNC") != nullptr && atoi(getenv("SVOH_MINI_SYNC")) != 0;
     // (opt-in: one stream's update is back before its next frame's alignment is set up -- 0.372 / 0.382 ms per frame with it against
     // 0.370 / 0.383 without; several streams in lock step gain 2 - 5 % from the same thing, FrontendLockstep)
@@ -135,8 +208,8 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
               n_seed_upd, n_conv, row.ms[0], row.ms[1], row.ms[2], row.ms[3], row.ms[4], row.ms[5], row.ms[6]);
       row.valid = false;
     };
-    for (size_t k = 0; k < images.size(); ++k) {
-      const io::GrayImage& img = images[k];
+    for (size_t k = 0; k < order.size(); ++k) {
+      const io::GrayImage& img = images[order[k]];
       const double t0 = now_ms();
       FramePtr frame(new Frame, [ctx](Frame* f) { if (f->pyramid) svoh_release_frame(ctx, f->pyramid); delete f; });
       if (svoh_build_pyramid(ctx, img.data.data(), img.width, img.height, img.width, SVOH_MEM_HOST, params.n_pyr_levels_to_build,
@@ -207,7 +280,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
       // the frame's time
       last = frame;
       const double t6 = now_ms();
-      traj.write(seq.cam_ts[k], svoh::inverse(frame->T_f_w_));
+      traj.write(seq.cam_ts[order[k]], svoh::inverse(frame->T_f_w_));
       row.valid = true; row.finished = seeds_finished || k == 0; row.n_seed_upd = n_seed_upd; row.k = k; row.is_kf = (int)is_kf; row.n_aligned = n_aligned; row.n_reproj = n_reproj; row.n_pose = n_pose;
       row.ms[0] = t0f - t0; row.ms[1] = t2 - t1; row.ms[2] = t3 - t2; row.ms[3] = t4 - t3; row.ms[4] = t5 - t4; row.ms[5] = t6 - t5;
       row.ms[6] = t6 - t0;   // the frame as the caller's clock sees it, the previous frame's seed write-back included
@@ -229,12 +302,12 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
 }
 
 // one lock-step group: streams [s0, s0 + n) of the run, all fed the same decoded sequence
-struct GroupResult { size_t frames = 0; double wall_ms = 0, steady_ms = 0; size_t steady_rounds = 0; int device_calls = 0; FrontendLockstep::RoundTimes mean{}; std::string error; };
+struct GroupResult { size_t frames = 0, steady_frames = 0; double wall_ms = 0, steady_ms = 0; size_t steady_rounds = 0; int device_calls = 0; FrontendLockstep::RoundTimes mean{}; std::string error; };
 std::shared_ptr<SharedPool> g_shared_pool;   // SVOH_LOCKSTEP_SHARED=1: the groups' host phases on one set of worker threads
 
 void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::GrayImage>& images, const std::vector<io::RigCamera>& rig, const io::FrontendParams& params,
                         const std::string& out_dir, const Transformation& T0, float depth_min, float depth_mean, float depth_max, size_t kf_every, int s0, int n,
-                        int n_workers, int n_laps, std::atomic<int>* start_gate, int n_groups, GroupResult* out)
+                        int n_workers, int n_laps, std::atomic<int>* start_gate, int n_groups, GroupResult* out, const std::vector<StreamSpec>* specs = nullptr)
 {
   try {
     svoh_ctx* ctx = nullptr;
@@ -255,6 +328,33 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
       lo.params = params; lo.cam = rig.at(0).cam; lo.T_B_C = rig[0].T_B_C;
       lo.depth_min = depth_min; lo.depth_mean = depth_mean; lo.depth_max = depth_max; lo.kf_every = kf_every; lo.n_workers = n_workers;
       if (getenv("SVOH_MINI_MIN_TRACKED")) lo.min_tracked = (size_t)atol(getenv("SVOH_MINI_MIN_TRACKED"));
+      // streams that differ (SVOH_MINI_SPEC): every stream its own parameter file, keyframe rule, first pose and walk over the images
+      std::vector<Transformation> T_first((size_t)n, T0);
+      size_t n_rounds = images.size();
+      if (specs) {
+        n_rounds = 0;
+        for (int i = 0; i < n; ++i) {
+          const StreamSpec& sp = (*specs)[(size_t)(s0 + i)];
+          LockstepStreamOptions so;
+          so.params = sp.params.empty() ? params : io::loadFrontendParams(sp.params);
+          so.depth_min = depth_min; so.depth_mean = depth_mean; so.depth_max = depth_max;
+          so.kf_every = sp.kf_every > 0 ? (size_t)sp.kf_every : kf_every;
+          so.min_tracked = sp.min_tracked >= 0 ? (size_t)sp.min_tracked : lo.min_tracked;
+          lo.per_stream.push_back(so);
+          if (sp.has_T0) T_first[(size_t)i] = sp.T0;
+          const long nf = sp.frames > 0 ? sp.frames : (long)images.size();
+          n_rounds = std::max(n_rounds, (size_t)(sp.phase + sp.every * (nf - 1) + 1));
+        }
+      }
+      // the image (or none) of stream i in round r, and the number of that frame in the stream's own count
+      auto frame_of = [&](int i, size_t r, long* j) -> long {
+        if (!specs) { *j = (long)r; return (long)r; }
+        const StreamSpec& sp = (*specs)[(size_t)(s0 + i)];
+        const long nf = sp.frames > 0 ? sp.frames : (long)images.size();
+        if ((long)r < sp.phase || ((long)r - sp.phase) % sp.every != 0) return -1;
+        *j = ((long)r - sp.phase) / sp.every;
+        return *j < nf ? (long)sp.image(*j, images.size()) : -1;
+      };
       lo.images_mem_space = SVOH_MEM_HOST_PINNED;
       lo.shared_pool = g_shared_pool; lo.shared_pool_seed = s0;
       lo.pin_workers = getenv("SVOH_LOCKSTEP_PIN") != nullptr && atoi(getenv("SVOH_LOCKSTEP_PIN")) != 0;   // (a shared box: its low CPUs are everybody's)
@@ -273,50 +373,64 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
           csv.push_back(fc);
         }
       std::vector<FrontendLockstep::RoundTimes> times;
+      std::vector<std::vector<size_t>> round_of((size_t)n);   // the round in which a stream's j-th frame ran
       auto write_rows = [&]() {
         for (int i = 0; i < n; ++i)
           for (const FrontendLockstep::FrameRow& r : fe.completedRows(i)) {
             if (!last_lap) continue;
-            const FrontendLockstep::RoundTimes& t = times.at(r.k);
+            const FrontendLockstep::RoundTimes& t = times.at(round_of[(size_t)i].at(r.k));
             fprintf(csv[(size_t)i], "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", r.k, (int)r.is_kf, r.n_aligned, r.n_reproj, r.n_pose, r.n_seed_upd,
                     r.n_converged, t.pyramid, t.align, t.reproject, t.pose, t.seeds, t.keyframe, t.total);
           }
       };
       std::vector<const uint8_t*> ptrs((size_t)n), next((size_t)n);
       const bool prefetch = getenv("SVOH_LOCKSTEP_PREFETCH") == nullptr || atoi(getenv("SVOH_LOCKSTEP_PREFETCH")) != 0;
-      std::vector<Transformation> T_first((size_t)n, T0);
       if (lap == 0) {   // all groups start their first frame together
         start_gate->fetch_add(1);
         while (start_gate->load() < n_groups) std::this_thread::yield();
       }
       const double wall0 = now_ms();
-      for (size_t k = 0; k < images.size(); ++k) {
-        for (int i = 0; i < n; ++i) ptrs[(size_t)i] = pinned + (size_t)i * seq_bytes + k * img_bytes;
+      for (size_t k = 0; k < n_rounds; ++k) {
+        std::vector<long> img_now((size_t)n, -1);
+        size_t n_now = 0;
+        for (int i = 0; i < n; ++i) {
+          long j = 0;
+          const long f = frame_of(i, k, &j);
+          img_now[(size_t)i] = f;
+          ptrs[(size_t)i] = f >= 0 ? pinned + (size_t)i * seq_bytes + (size_t)f * img_bytes : nullptr;
+          if (f >= 0) { round_of[(size_t)i].push_back(k); ++n_now; }
+        }
         // the next images of a replay are there already: they go up while this round runs (SVOH_LOCKSTEP_PREFETCH=0: they do not)
-        const bool announce = prefetch && k + 1 < images.size();
-        if (announce) for (int i = 0; i < n; ++i) next[(size_t)i] = pinned + (size_t)i * seq_bytes + (k + 1) * img_bytes;
+        const bool announce = prefetch && k + 1 < n_rounds;
+        if (announce)
+          for (int i = 0; i < n; ++i) {
+            long j = 0;
+            const long f = frame_of(i, k + 1, &j);
+            next[(size_t)i] = f >= 0 ? pinned + (size_t)i * seq_bytes + (size_t)f * img_bytes : nullptr;
+          }
         const double tr0 = now_ms();
-        fe.addImages(ptrs.data(), images[k].width, T_first.data(), announce ? next.data() : nullptr);
+        fe.addImages(ptrs.data(), images[0].width, T_first.data(), announce ? next.data() : nullptr);
         const double tr1 = now_ms();
         FrontendLockstep::RoundTimes t = fe.lastRoundTimes();
         t.total = tr1 - tr0;
         times.push_back(t);
-        if (last_lap) for (int i = 0; i < n; ++i) traj[(size_t)i]->write(seq.cam_ts[k], svoh::inverse(fe.pose(i)));
+        if (last_lap) for (int i = 0; i < n; ++i) if (img_now[(size_t)i] >= 0) traj[(size_t)i]->write(seq.cam_ts[(size_t)img_now[(size_t)i]], svoh::inverse(fe.pose(i)));
         write_rows();
         if (k >= 3) {   // frames 1-2 pay the one-time costs (code objects, the scratch buffers' first allocation)
           out->steady_ms += tr1 - tr0; ++out->steady_rounds;
           out->mean.pyramid += t.pyramid; out->mean.align += t.align; out->mean.reproject += t.reproject; out->mean.pose += t.pose; out->mean.seeds += t.seeds; out->mean.keyframe += t.keyframe;
         }
         out->device_calls = fe.lastRoundDeviceCalls();
-        out->frames += (size_t)n;
+        out->frames += n_now;
+        if (k >= 3) out->steady_frames += n_now;
       }
       fe.finish();
       write_rows();
       out->wall_ms += now_ms() - wall0;
       if (last_lap && s0 == 0 && getenv("SVOH_LOCKSTEP_TIMING")) {
         const double* ph = fe.phaseTimes();
-        fprintf(stderr, "[lockstep] mean ms per round over %zu rounds:", images.size());
-        for (int k = 0; k < FrontendLockstep::kNumPhases; ++k) if (ph[k] > 0) fprintf(stderr, " %s %.3f,", FrontendLockstep::phaseName(k), ph[k] / (double)images.size());
+        fprintf(stderr, "[lockstep] mean ms per round over %zu rounds:", n_rounds);
+        for (int k = 0; k < FrontendLockstep::kNumPhases; ++k) if (ph[k] > 0) fprintf(stderr, " %s %.3f,", FrontendLockstep::phaseName(k), ph[k] / (double)n_rounds);
         fprintf(stderr, "\n");
       }
       for (FILE* f : csv) fclose(f);
@@ -345,13 +459,16 @@ int main(int argc, char** argv)
     const float depth_min = (float)atof(argv[12]), depth_mean = (float)atof(argv[13]), depth_max = (float)atof(argv[14]);
     const size_t max_frames = argc > 15 ? (size_t)atol(argv[15]) : seq.size();
     const size_t kf_every = argc > 16 ? (size_t)atol(argv[16]) : 8;
-    const int n_streams = argc > 17 ? atoi(argv[17]) : 1;
+    int n_streams = argc > 17 ? atoi(argv[17]) : 1;
+    std::vector<StreamSpec> specs;
+    if (getenv("SVOH_MINI_SPEC")) specs = load_specs(getenv("SVOH_MINI_SPEC"));
     const bool lockstep = argc > 18 && std::string(argv[18]) == "lockstep";
     if (argc > 18 && !lockstep && std::string(argv[18]) != "threads") throw std::runtime_error("mode must be threads or lockstep");
     if (n_streams < 1 || n_streams > (lockstep ? 256 : 64)) throw std::runtime_error("n_streams out of range");
     std::vector<io::GrayImage> images;
     for (size_t k = 0; k < seq.size() && k < max_frames; ++k) images.push_back(io::readPngGray(seq.cam0_files[k]));
     if (lockstep) {
+      if (!specs.empty() && (size_t)n_streams != specs.size()) throw std::runtime_error("n_streams must be the number of lines of SVOH_MINI_SPEC");
       const int n_workers = argc > 19 ? atoi(argv[19]) : 1;
       const int n_groups = argc > 20 ? atoi(argv[20]) : 1;
       const int n_laps = argc > 21 ? atoi(argv[21]) : 1;
@@ -368,9 +485,9 @@ int main(int argc, char** argv)
       for (int g = 1; g < n_groups; ++g) {
         int s0, n; group_range(g, &s0, &n);
         threads.emplace_back(run_lockstep_group, std::cref(seq), std::cref(images), std::cref(rig), std::cref(params), out_dir, std::cref(T0), depth_min, depth_mean, depth_max,
-                             kf_every, s0, n, n_workers, n_laps, &gate, n_groups, &res[(size_t)g]);
+                             kf_every, s0, n, n_workers, n_laps, &gate, n_groups, &res[(size_t)g], specs.empty() ? nullptr : &specs);
       }
-      { int s0, n; group_range(0, &s0, &n); run_lockstep_group(seq, images, rig, params, out_dir, T0, depth_min, depth_mean, depth_max, kf_every, s0, n, n_workers, n_laps, &gate, n_groups, &res[0]); }
+      { int s0, n; group_range(0, &s0, &n); run_lockstep_group(seq, images, rig, params, out_dir, T0, depth_min, depth_mean, depth_max, kf_every, s0, n, n_workers, n_laps, &gate, n_groups, &res[0], specs.empty() ? nullptr : &specs); }
       for (std::thread& t : threads) t.join();
       for (const GroupResult& r : res) if (!r.error.empty()) throw std::runtime_error(r.error);
       double wall = 0, steady_rate = 0;
@@ -379,7 +496,7 @@ int main(int argc, char** argv)
         const GroupResult& r = res[(size_t)g];
         int s0, n; group_range(g, &s0, &n);
         wall = r.wall_ms > wall ? r.wall_ms : wall; frames += r.frames;
-        if (r.steady_rounds) steady_rate += 1e3 * n * (double)r.steady_rounds / r.steady_ms;
+        if (r.steady_rounds) steady_rate += 1e3 * (double)r.steady_frames / r.steady_ms;
       }
       const GroupResult& r0 = res[0];
       const double nr = r0.steady_rounds ? (double)r0.steady_rounds : 1.0;
@@ -392,11 +509,21 @@ int main(int argc, char** argv)
     std::vector<StreamResult> results((size_t)n_streams);
     std::atomic<int> gate(0);
     std::vector<std::thread> threads;
+    if (!specs.empty()) {   // ONE stream of the spec file alone, through the single-stream chain
+      if (n_streams != 1 || !getenv("SVOH_MINI_SPEC_LINE")) throw std::runtime_error("threads mode with SVOH_MINI_SPEC: n_streams = 1 and SVOH_MINI_SPEC_LINE=<i>");
+      const StreamSpec& sp = specs.at((size_t)atol(getenv("SVOH_MINI_SPEC_LINE")));
+      const io::FrontendParams own = sp.params.empty() ? params : io::loadFrontendParams(sp.params);
+      run_stream(seq, images, rig, own, out_dir, sp.has_T0 ? sp.T0 : T0, depth_min, depth_mean, depth_max, sp.kf_every > 0 ? (size_t)sp.kf_every : kf_every, &gate, 1, &results[0], &sp);
+      if (!results[0].error.empty()) throw std::runtime_error(results[0].error);
+      printf("svoh_mini_frontend: stream %s of the spec alone: %zu frames, %.3f ms/frame on the GPU path, %zu keyframes alive\n", getenv("SVOH_MINI_SPEC_LINE"), results[0].n_done + 1,
+             results[0].n_done ? results[0].sum_ms / results[0].n_done : 0.0, results[0].n_kfs);
+      return 0;
+    }
     for (int s = 1; s < n_streams; ++s) {
       const std::string dir = out_dir + "/stream" + std::to_string(s);
       (void)mkdir(dir.c_str(), 0755);
       threads.emplace_back(run_stream, std::cref(seq), std::cref(images), std::cref(rig), params, dir, std::cref(T0), depth_min, depth_mean,
-                           depth_max, kf_every, &gate, n_streams, &results[(size_t)s]);
+                           depth_max, kf_every, &gate, n_streams, &results[(size_t)s], (const StreamSpec*)nullptr);
     }
     run_stream(seq, images, rig, params, out_dir, T0, depth_min, depth_mean, depth_max, kf_every, &gate, n_streams, &results[0]);
     for (std::thread& t : threads) t.join();
