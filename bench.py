@@ -668,7 +668,18 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         k %= 2 * (n_frames - 1)
         return k if k < n_frames else 2 * (n_frames - 1) - k
 
-    def run(S, G, W, n_warm, n_steps):
+    def mix_of(s):   # stream s of a rank's --stream-mix: (start, step, every, phase), keyframe period, feature budget
+        step = (1, -1, 1, -1, 2, 1, -1, -2)[s % 8]
+        return ((7 * s) % n_frames, step, 2 if s % 8 == 5 else 1, 0), (8, 6, 5, 7, 9, 4)[s % 6], (180, 120, 240)[s % 3]
+
+    def image_of(sched, k):   # the image of the stream's frame in round k (svohl_run_schedule's rule), or None
+        start, step, every, phase = sched
+        if k < phase or (k - phase) % every:
+            return None
+        m = (start + step * ((k - phase) // every)) % (2 * (n_frames - 1))
+        return m if m < n_frames else 2 * (n_frames - 1) - m
+
+    def run(S, G, W, n_warm, n_steps, mix=False):
         G = max(1, min(G, S))
         ctxs = [ctx] + [fe.Context(dev.index if dev.index is not None else 0, kernel_timing=False) for _ in range(G - 1)]
         ctx.set_kernel_timing(False)
@@ -684,9 +695,13 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
             shared = ls.SharedPool(G * W - G + 1, exclusive=True)
         elif G > 1 and W > 1 and mode != "0":
             shared = ls.SharedPool(G * (W - 1))
-        engines = [ls.Lockstep(c, hi - lo, cam, np.array([1.0, 0, 0, 0, 0, 0, 0]), params, 0.5 * depth, depth, 2.0 * depth, 8, W, True, pool=shared, seed=lo)
-                   for c, (lo, hi) in zip(ctxs, ranges)]
+        per = [None] * G
+        if mix:
+            per = [[dict(params_yaml=params.replace("max_fts: 180", "max_fts: %d" % mix_of(s)[2]), kf_every=mix_of(s)[1]) for s in range(lo, hi)] for lo, hi in ranges]
+        engines = [ls.Lockstep(c, hi - lo, cam, np.array([1.0, 0, 0, 0, 0, 0, 0]), params, 0.5 * depth, depth, 2.0 * depth, 8, W, True, pool=shared, seed=lo, per_stream=ps)
+                   for c, (lo, hi), ps in zip(ctxs, ranges, per)]
         first = poses[0].inverse().as7()
+        frames_taken = [0] * G
         total = n_warm + n_steps
         gate = threading.Barrier(G + 1)
         times = [[] for _ in range(G)]
@@ -698,10 +713,19 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
                 e, pin, n = engines[g], pins[g], ranges[g][1] - ranges[g][0]
                 # (a group's rounds run inside ONE foreign call: with the loop in Python, the groups' threads spend more
                 # time handing the interpreter lock to each other than in their rounds)
-                e.run_sequence(pin, cam.width, 0, n_warm, [first] * n)
+                if mix:
+                    sched = [mix_of(s)[0] for s in range(ranges[g][0], ranges[g][1])]
+                    firsts = [poses[sc[0]].inverse().as7() for sc in sched]
+                    e.run_schedule(pin, cam.width, 0, n_warm, sched, firsts)
+                else:
+                    e.run_sequence(pin, cam.width, 0, n_warm, [first] * n)
                 warm_phases[g] = e.phase_times()
                 gate.wait()   # the timed region starts for every group at once
-                times[g] = e.run_sequence(pin, cam.width, n_warm, n_steps)
+                if mix:
+                    times[g], frames_taken[g] = e.run_schedule(pin, cam.width, n_warm, n_steps, sched, firsts)
+                else:
+                    times[g] = e.run_sequence(pin, cam.width, n_warm, n_steps)
+                    frames_taken[g] = n * n_steps
                 e.finish()
                 gate.wait()
             except Exception as ex:   # noqa: BLE001 -- reported by the caller
@@ -729,6 +753,20 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         agree = all(np.array_equal(e.pose(s), p0) for e in engines for s in range(e.n))
         gt = poses[frame_of(total - 1)].inverse()
         err = synth.se3_error(synth.SE3.from7(p0), gt)
+        mix_info = None
+        if mix:   # every stream against the rendered pose of ITS last image (unscaled, as below)
+            errs, distinct = [], set()
+            for e, (lo, hi) in zip(engines, ranges):
+                for i, s in enumerate(range(lo, hi)):
+                    sched = mix_of(s)[0]
+                    last = max(k for k in range(total) if image_of(sched, k) is not None)
+                    T = e.pose(i)
+                    distinct.add(T.tobytes())
+                    errs.append(synth.se3_error(synth.SE3.from7(T), poses[image_of(sched, last)].inverse()))
+            err = (max(v[0] for v in errs), max(v[1] for v in errs))
+            mix_info = {"distinct_final_poses": len(distinct), "keyframe_periods": sorted({mix_of(s)[1] for s in range(S)}), "max_fts": sorted({mix_of(s)[2] for s in range(S)}),
+                        "steps_over_the_sequence": sorted({mix_of(s)[0][1] for s in range(S)}), "streams_at_half_rate": sum(1 for s in range(S) if mix_of(s)[0][2] == 2),
+                        "pose_error_is": "the maximum over the streams"}
         rows = engines[0].completed_rows(0)
         stage = dict(zip(("pyramid", "align", "reproject", "pose", "seeds", "keyframe", "total"), [float(v) for v in np.median(times[0], axis=0)])) if len(times[0]) else {}
         calls = engines[0].last_round()[1]
@@ -743,7 +781,8 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         for c in ctxs[1:]:
             c.close()
         return {"streams": S, "groups": G, "host_threads_per_group": W, "host_threads": G * W, "workers_shared_between_groups": shared is not None,
-                "frames_per_s": S * n_steps / elapsed, "ms_per_round": 1e3 * elapsed / n_steps,
+                "frames_per_s": sum(frames_taken) / elapsed, "ms_per_round": 1e3 * elapsed / n_steps, "frames_in_the_timed_rounds": int(sum(frames_taken)),
+                "stream_mix": mix_info,
                 "round_stage_ms_median_group0": stage, "round_phase_ms_mean_group0": {k: round(v, 4) for k, v in phases.items()},
                 "device_waits_ms_per_round_group0": round(sum(phases.get(k, 0.0) for k in ("seed wait", "align wait", "match wait", "pose call", "detect wait")), 4),
                 "device_calls_per_round_per_group": calls,
@@ -757,10 +796,14 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
 
     S = args.streams
     G, W = (args.stream_groups, args.stream_workers) if args.stream_groups and args.stream_workers else shape(S)
-    main_run, elapsed = run(S, G, W, max(3, args.warmup), args.steps)
-    elapsed, total_frames = du.combine(dist, world, elapsed, S * args.steps, comm_dev)
+    main_run, elapsed = run(S, G, W, max(3, args.warmup), args.steps, mix=args.stream_mix)
+    elapsed, total_frames = du.combine(dist, world, elapsed, main_run["frames_in_the_timed_rounds"], comm_dev)
+    same_streams = None
+    if args.stream_mix and rank == 0 and world == 1:   # the identical-streams number beside it: the best case of the grouping, speculation and detector batching
+        r0, _ = run(S, G, W, max(3, args.warmup), args.steps)
+        same_streams = {k: r0[k] for k in ("streams", "groups", "host_threads_per_group", "frames_per_s", "ms_per_round", "all_streams_at_the_same_pose", "device_waits_ms_per_round_group0")}
     sweep = []
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if rank == 0 and world == 1 and not args.no_secondary and not args.stream_mix:
         for s2 in (1, 8, 32, 64):
             if s2 == S:
                 sweep.append({k: main_run[k] for k in ("streams", "groups", "host_threads_per_group", "frames_per_s", "ms_per_round")})
@@ -774,14 +817,14 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
     if rank != 0:
         return None
     return {"metric": "frames/s, S camera streams in lock step through the whole per-frame chain (align + reproject + pose + depth filter + keyframes), one launch per stage",
-            "value": total_frames / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_frame": 1e3 * elapsed / args.steps / S,
+            "value": total_frames / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_frame": 1e3 * elapsed * world / max(1, total_frames),
             "dtype": "u8+i32+f32+f64",
             "config": {"workload": "C5-synth per GPU: %d streams x 752x480 radtan in %d lock-step group(s) with %d host thread(s) each; per stream and frame: 5-level "
                                    "pyramid, align <=180..720 patches 4x4 levels 4..2, ~100 direct + ~900 seed matcher units, pose over <=180 features, "
                                    "depth-filter update of <=5 keyframes (~1600 seeds), a keyframe every 8 frames; a step = one frame of every stream; "
-                                   "the streams replay one rendered sequence forth and back" % (S, G, W),
+                                   "the streams replay one rendered sequence forth and back%s" % (S, G, W, " -- EVERY STREAM ITS OWN WALK, keyframe period and feature budget (--stream-mix)" if args.stream_mix else ""),
                        "streams": S, "groups": G, "host_threads_per_group": W, "host_cpus_visible": n_host},
-            "lockstep": main_run, "streams_sweep": sweep,
+            "lockstep": main_run, "identical_streams_beside_it": same_streams, "streams_sweep": sweep,
             "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                          "note": "a chain of small latency-bound launches by design: the kernels' own rooflines are those of --workload align / seeds / pose / klt"},
             "cpu_baseline": cpu}
@@ -1313,6 +1356,8 @@ def parse_args(argv=None):
     ap.add_argument("--max-level", type=int, default=4)
     ap.add_argument("--stereo", action="store_true", help="with --workload frame: the stereo pair chain (BASELINE config 3)")
     ap.add_argument("--streams", type=int, default=0, help="with --workload frame: S camera streams per GPU through the whole chain in lock step (BASELINE config 5)")
+    ap.add_argument("--stream-mix", action="store_true", help="with --streams: streams that DIFFER -- every stream its own walk over the sequence (start, direction, stride), "
+                    "keyframe period 4..9, feature budget 120 / 180 / 240, one stream in eight at half the frame rate (FrontendLockstep's per-stream options)")
     ap.add_argument("--stream-groups", type=int, default=0, help="lock-step groups per GPU (default: chosen from S and the host-thread budget)")
     ap.add_argument("--stream-workers", type=int, default=0, help="host threads per lock-step group")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -983,6 +983,34 @@ static int svohl_create_impl(svoh_ctx* ctx, int n_streams, const svoh_camera* ca
   });
 }
 
+int svohl_create_streams(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* const* params_yaml,
+                         const double* depth_min_mean_max, const int* kf_every, const int* min_tracked, int n_workers, svohl_pool* pool, int seed,
+                         int images_pinned, svohl_engine** out)
+{
+  return svohl_guard([&] {
+    if (!out || !cam || !T_B_C || !params_yaml || !depth_min_mean_max || !kf_every || !min_tracked || n_streams < 1) throw std::runtime_error("svohl_create_streams: NULL argument");
+    *out = nullptr;
+    svo_hip::LockstepOptions lo;
+    if (pool) { lo.shared_pool = pool->pool; lo.shared_pool_seed = seed; lo.exclusive_pool = pool->exclusive; }
+    lo.cam = *cam;
+    lo.T_B_C = svoh::load_rigid(*T_B_C);
+    lo.n_workers = n_workers;
+    lo.images_mem_space = images_pinned ? SVOH_MEM_HOST_PINNED : SVOH_MEM_HOST;
+    for (int s = 0; s < n_streams; ++s) {
+      svo_hip::LockstepStreamOptions so;
+      so.params = svo_hip::io::frontendParamsFromYaml(params_yaml[s] ? svo_hip::io::parseYaml(params_yaml[s]) : svo_hip::io::YamlNode());
+      so.depth_min = static_cast<float>(depth_min_mean_max[3 * s]); so.depth_mean = static_cast<float>(depth_min_mean_max[3 * s + 1]); so.depth_max = static_cast<float>(depth_min_mean_max[3 * s + 2]);
+      so.kf_every = kf_every[s] > 0 ? static_cast<size_t>(kf_every[s]) : 8;
+      so.min_tracked = min_tracked[s] >= 0 ? static_cast<size_t>(min_tracked[s]) : 60;
+      lo.per_stream.push_back(so);
+    }
+    std::unique_ptr<svohl_engine> e(new svohl_engine);
+    e->fe.reset(new svo_hip::FrontendLockstep(ctx, n_streams, lo));
+    e->backlog.resize(static_cast<size_t>(n_streams));
+    *out = e.release();
+  });
+}
+
 void svohl_destroy(svohl_engine* e) { try { delete e; } catch (...) {} }
 
 int svohl_add_images(svohl_engine* e, const uint8_t* const* images, int pitch, const svoh_se3* T_f_w_first)
@@ -1023,6 +1051,40 @@ int svohl_run_sequence(svohl_engine* e, const uint8_t* base, size_t image_bytes,
         o[0] = t.pyramid; o[1] = t.align; o[2] = t.reproject; o[3] = t.pose; o[4] = t.seeds; o[5] = t.keyframe; o[6] = t.total;
       }
     }
+  });
+}
+
+int svohl_run_schedule(svohl_engine* e, const uint8_t* base, size_t image_bytes, size_t stream_stride, int n_frames, int pitch, long k_first, int n_rounds,
+                       const int* start, const int* step, const int* every, const int* phase, const svoh_se3* T_f_w_first, double* round_ms, long* frames_done)
+{
+  return svohl_guard([&] {
+    if (!e || !base || n_frames < 2 || n_rounds < 0 || k_first < 0 || !start || !step || !every || !phase) throw std::runtime_error("svohl_run_schedule: bad arguments");
+    const int S = e->fe->numStreams();
+    for (int s = 0; s < S; ++s) if (every[s] < 1 || phase[s] < 0 || step[s] == 0) throw std::runtime_error("svohl_run_schedule: every >= 1, phase >= 0, step != 0");
+    std::vector<svo_hip::Transformation> T;
+    if (T_f_w_first) for (int s = 0; s < S; ++s) T.push_back(svoh::load_rigid(T_f_w_first[s]));
+    std::vector<const uint8_t*> ptrs(static_cast<size_t>(S)), next(static_cast<size_t>(S));
+    const long period = 2L * (n_frames - 1);
+    const bool prefetch = getenv("SVOH_LOCKSTEP_PREFETCH") == nullptr || atoi(getenv("SVOH_LOCKSTEP_PREFETCH")) != 0;
+    auto image_of = [&](int s, long k) -> const uint8_t* {   // stream s' image in round k, or none
+      if (k < phase[s] || (k - phase[s]) % every[s] != 0) return nullptr;
+      const long j = (k - phase[s]) / every[s];
+      long m = (static_cast<long>(start[s]) + static_cast<long>(step[s]) * j) % period;
+      if (m < 0) m += period;
+      const long f = m < n_frames ? m : period - m;
+      return base + static_cast<size_t>(s) * stream_stride + static_cast<size_t>(f) * image_bytes;
+    };
+    long done = 0;
+    for (long k = k_first; k < k_first + n_rounds; ++k) {
+      for (int s = 0; s < S; ++s) { ptrs[static_cast<size_t>(s)] = image_of(s, k); next[static_cast<size_t>(s)] = image_of(s, k + 1); done += ptrs[static_cast<size_t>(s)] != nullptr; }
+      e->fe->addImages(ptrs.data(), pitch, T.empty() ? nullptr : T.data(), prefetch ? next.data() : nullptr);
+      if (round_ms) {
+        const svo_hip::FrontendLockstep::RoundTimes& t = e->fe->lastRoundTimes();
+        double* o = round_ms + 7 * (k - k_first);
+        o[0] = t.pyramid; o[1] = t.align; o[2] = t.reproject; o[3] = t.pose; o[4] = t.seeds; o[5] = t.keyframe; o[6] = t.total;
+      }
+    }
+    if (frames_done) *frames_done = done;
   });
 }
 

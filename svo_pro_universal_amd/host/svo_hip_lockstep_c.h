@@ -30,8 +30,16 @@ int svohl_create(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svo
 int svohl_create_shared(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* params_yaml,
                         double depth_min, double depth_mean, double depth_max, int kf_every, svohl_pool* pool, int seed, int images_pinned,
                         svohl_engine** out);
+/* Streams that DIFFER (round 6; LockstepStreamOptions): one entry per stream in every array.  params_yaml[s]: stream s' parameter
+ * file as text (NULL entry = defaults) -- what the streams' shared device calls take once (pyramid levels, grid, detector,
+ * matcher / depth-filter switches) must agree, the call fails otherwise; depth_min_mean_max: 3 doubles per stream; kf_every,
+ * min_tracked: the stream's keyframe rule.  pool may be NULL (then n_workers threads of the engine's own). */
+int svohl_create_streams(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* const* params_yaml,
+                         const double* depth_min_mean_max, const int* kf_every, const int* min_tracked, int n_workers, svohl_pool* pool, int seed,
+                         int images_pinned, svohl_engine** out);
 void svohl_destroy(svohl_engine* e);
-/* one frame of every stream (FrontendLockstep::addImages); T_f_w_first: n_streams poses for the first call, else ignored */
+/* one frame of every stream (FrontendLockstep::addImages); images[s] == NULL: stream s has no frame this round; T_f_w_first:
+ * n_streams poses, read for the streams whose first frame this is (may be NULL when no stream starts) */
 int svohl_add_images(svohl_engine* e, const uint8_t* const* images, int pitch, const svoh_se3* T_f_w_first);
 /* n_rounds calls of svohl_add_images in one: every stream gets image frame_of(k) of ONE sequence of n_frames images of
  * image_bytes each -- stream s reads ITS copy of the sequence at base + s * stream_stride (0: one shared copy, which the
@@ -40,6 +48,12 @@ int svohl_add_images(svohl_engine* e, const uint8_t* const* images, int pitch, c
  * svohl_last_round.  For drivers whose own loop is slow (an interpreter holding a global lock between calls). */
 int svohl_run_sequence(svohl_engine* e, const uint8_t* base, size_t image_bytes, size_t stream_stride, int n_frames, int pitch, long k_first, int n_rounds,
                        const svoh_se3* T_f_w_first, double* round_ms);
+/* ... with a schedule per stream: stream s has a frame in round k iff k >= phase[s] and (k - phase[s]) % every[s] == 0; that frame is
+ * its j-th, j = (k - phase[s]) / every[s], and shows image pingpong(start[s] + step[s] * j) of its copy of the sequence (pingpong: the
+ * walk over 0 .. n_frames - 1 that turns round at both ends; step may be negative or larger than one).  T_f_w_first: n_streams poses,
+ * read for a stream in the round of its first frame.  *frames_done (may be NULL): frames taken by all streams in these rounds. */
+int svohl_run_schedule(svohl_engine* e, const uint8_t* base, size_t image_bytes, size_t stream_stride, int n_frames, int pitch, long k_first, int n_rounds,
+                       const int* start, const int* step, const int* every, const int* phase, const svoh_se3* T_f_w_first, double* round_ms, long* frames_done);
 int svohl_pose(svohl_engine* e, int stream, svoh_se3* T_f_w);
 /* pyramid, align, reproject, pose, seeds, keyframe, total of the last round (ms) and its device calls */
 int svohl_last_round(svohl_engine* e, double times_ms[7], int* device_calls);

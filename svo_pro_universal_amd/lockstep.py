@@ -30,6 +30,10 @@ def load_host():
     lib.svohl_pool_destroy.restype = None
     lib.svohl_create_shared.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_camera), P(capi.svoh_se3), C.c_char_p, C.c_double, C.c_double, C.c_double,
                                         C.c_int, C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
+    lib.svohl_create_streams.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_camera), P(capi.svoh_se3), P(C.c_char_p), P(C.c_double), P(C.c_int), P(C.c_int),
+                                         C.c_int, C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
+    lib.svohl_run_schedule.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_long, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int),
+                                       C.c_void_p, C.c_void_p, P(C.c_long)]
     lib.svohl_destroy.argtypes = [C.c_void_p]
     lib.svohl_destroy.restype = None
     lib.svohl_add_images.argtypes = [C.c_void_p, P(C.c_void_p), C.c_int, C.c_void_p]
@@ -99,14 +103,24 @@ class Lockstep(object):
     then has no threads of its own; seed = its first stream's index among all groups)."""
 
     def __init__(self, ctx, n_streams, cam, T_B_C7, params_yaml, depth_min, depth_mean, depth_max, kf_every=8, n_workers=1, images_pinned=True,
-                 pool=None, seed=0):
+                 pool=None, seed=0, per_stream=None):
+        """per_stream (round 6): a list of n_streams dicts(params_yaml, kf_every, min_tracked, depth=(min, mean, max)) -- streams that
+        differ (svohl_create_streams); missing keys take the common arguments."""
         self.lib = load_host()
         self.ctx = ctx
         self.n = int(n_streams)
         h = C.c_void_p()
         c = fe._camera(cam)
         T = fe._se3(np.asarray(T_B_C7, dtype=np.float64))
-        if pool is not None:
+        if per_stream is not None:
+            assert len(per_stream) == self.n
+            yamls = (C.c_char_p * self.n)(*[(d.get("params_yaml", params_yaml) or "").encode() or None for d in per_stream])
+            depth = (C.c_double * (3 * self.n))(*[float(v) for d in per_stream for v in d.get("depth", (depth_min, depth_mean, depth_max))])
+            kfe = (C.c_int * self.n)(*[int(d.get("kf_every", kf_every)) for d in per_stream])
+            mtr = (C.c_int * self.n)(*[int(d.get("min_tracked", 60)) for d in per_stream])
+            rc = self.lib.svohl_create_streams(ctx.h, self.n, C.byref(c), C.byref(T), yamls, depth, kfe, mtr, int(n_workers), pool.h if pool is not None else None,
+                                               int(seed), 1 if images_pinned else 0, C.byref(h))
+        elif pool is not None:
             rc = self.lib.svohl_create_shared(ctx.h, self.n, C.byref(c), C.byref(T), params_yaml.encode() if params_yaml else None, float(depth_min),
                                               float(depth_mean), float(depth_max), int(kf_every), pool.h, int(seed), 1 if images_pinned else 0, C.byref(h))
         else:
@@ -150,6 +164,22 @@ class Lockstep(object):
         self._check(self.lib.svohl_run_sequence(self.h, C.c_void_p(pinned.ptr), pinned.bytes, stride, pinned.n, int(pitch), int(k_first), int(n_rounds), first,
                                                 out.ctypes.data))
         return out[:n_rounds]
+
+    def run_schedule(self, pinned, pitch, k_first, n_rounds, schedule, T_f_w_first=None):
+        """svohl_run_schedule: schedule = list of (start, step, every, phase) per stream; returns (stage times (n_rounds, 7) ms, frames taken)."""
+        first = None
+        if T_f_w_first is not None:
+            arr = (capi.svoh_se3 * self.n)()
+            for i, T in enumerate(T_f_w_first):
+                arr[i] = fe._se3(T)
+            first = C.cast(arr, C.c_void_p)
+        out = np.zeros((max(1, n_rounds), 7))
+        cols = [(C.c_int * self.n)(*[int(sc[j]) for sc in schedule]) for j in range(4)]
+        done = C.c_long(0)
+        assert pinned.copies >= self.n and len(schedule) == self.n
+        self._check(self.lib.svohl_run_schedule(self.h, C.c_void_p(pinned.ptr), pinned.bytes, pinned.stride, pinned.n, int(pitch), int(k_first), int(n_rounds),
+                                                cols[0], cols[1], cols[2], cols[3], first, out.ctypes.data, C.byref(done)))
+        return out[:n_rounds], done.value
 
     def pose(self, s):
         T = capi.svoh_se3()

@@ -217,7 +217,7 @@ HETERO_STREAMS = [   # (start, step, frames, every, phase, kf_every, min_tracked
     (5, 2, 24, 1, 0, 7, 60, 120),        # every other image: twice the motion per frame
     (0, 1, 20, 2, 1, 4, 60, 240),        # a camera of half the rate
     (30, -2, 22, 1, 0, 1000, 20, 180),   # no periodic keyframes and a low bar: its features leave the image, its third pass IS reached
-    (15, 1, 40, 1, 0, 9, 230, 240),      # a bar above what it can track: keyframes by the tracked-features rule
+    (15, 1, 40, 1, 0, 9, 241, 240),      # a bar above what it can track (240): keyframes by the tracked-features rule
     (39, -1, 14, 3, 0, 3, 60, 120),      # a third of the rate
 ]
 
