@@ -62,7 +62,16 @@ def main():
     if os.path.exists(st):
         rows = [r for r in csv.DictReader(open(st)) if rx.search(r["Name"].split("(")[0])]
         out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs")} for r in rows]
-        out["kernel_ms_per_step_rocprof"] = sum(float(r["AverageNs"]) for r in rows) * 1e-6
+        # the kernels of ONE STEP of the workload: those that move at least 1 % of the largest kernel's bytes per dispatch.  bench.py
+        # also times side legs under the same regex (--workload pose: fifty single-bundle dispatches of pose_optimize_kernel<256,0>
+        # for the latency figure); their average duration is not part of a step (it was added until round 5)
+        big = max((d.get("traffic_bytes", 0.0) for d in kernels.values()), default=0.0)
+        in_step = {n for n, d in kernels.items() if d.get("traffic_bytes", 0.0) >= 0.01 * big} if big > 0 else None
+        step_rows = [r for r in rows if in_step is None or r["Name"].split("(")[0] in in_step]
+        out["kernel_ms_per_step_rocprof"] = sum(float(r["AverageNs"]) for r in step_rows) * 1e-6
+        out["kernels_not_part_of_a_step"] = [r["Name"].split("(")[0] for r in rows if r not in step_rows]
+        if in_step is not None:
+            out["traffic_bytes_per_step"] = sum(d["traffic_bytes"] for n, d in kernels.items() if n in in_step)
     # compute side: SQ counters of the dominant kernel (the one with the largest wave-cycle count)
     sq = {}
     for f in sorted(os.listdir(dst)):

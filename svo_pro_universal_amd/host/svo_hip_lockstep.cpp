@@ -104,18 +104,11 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
   else pool_.own.reset(new WorkerPool(options.n_workers < 1 ? 1 : options.n_workers, options.pin_workers));
   if (!ctx_) throw std::runtime_error("FrontendLockstep: NULL svoh_ctx (no CPU fallback exists)");
   if (n_streams < 1 || n_streams > 256) throw std::runtime_error("FrontendLockstep: n_streams out of range [1, 256]");
-  // SVOH_LOCKSTEP_COPY_POLICY=2: every staged block through a copy kernel (svoh_set_copy_policy).  Measured with four groups
-  // on one device and NOT the default: 23.7 / 24.3 k frames/s against 25.6 / 23.3 k with the library's own policy
-  // (profiles/r05_copy_policy_ab.txt) -- the mixed-dispatch ceiling of tools/svoh_dispatch_rate is not what the groups run into.
-  if (getenv("SVOH_LOCKSTEP_RESIDENT")) opt_.resident_features = atoi(getenv("SVOH_LOCKSTEP_RESIDENT")) != 0;   // (A/B)
-  // SVOH_LOCKSTEP_SPECULATE=all: every stream's three lists, always (the first version); =never: the third list is never planned ahead,
-  // every stream that needs it goes through the paused replay (tests); default: as the stream's frame before went
-  if (const char* sp = getenv("SVOH_LOCKSTEP_SPECULATE")) { speculate_all_ = std::string(sp) == "all"; speculate_never_ = std::string(sp) == "never"; }
-  align_ahead_ = getenv("SVOH_LOCKSTEP_ALIGN_AHEAD") == nullptr || atoi(getenv("SVOH_LOCKSTEP_ALIGN_AHEAD")) != 0;   // (A/B)
-  detect_ahead_ = getenv("SVOH_LOCKSTEP_DETECT_AHEAD") == nullptr || atoi(getenv("SVOH_LOCKSTEP_DETECT_AHEAD")) != 0;   // (A/B)
-  // SVOH_LOCKSTEP_POSE_CHAIN=0: the depth filter's batch is queued after the host has seen the poses, as in the first version
-  pose_chain_ = getenv("SVOH_LOCKSTEP_POSE_CHAIN") == nullptr || atoi(getenv("SVOH_LOCKSTEP_POSE_CHAIN")) != 0;
-  if (getenv("SVOH_LOCKSTEP_COPY_POLICY")) check(svoh_set_copy_policy(ctx_, atoi(getenv("SVOH_LOCKSTEP_COPY_POLICY"))), "svoh_set_copy_policy");
+  // (round 6: the A/B switches of round 5 -- alignment / detector ahead, pose chain, copy policy, spin limits -- are gone from the library: their
+  // numbers are in HISTORY round 5 and profiles/r05_*_ab.txt, the orders that won are the code.  What is left are two OPTIONS a caller sets:
+  // resident_features and speculation, which the tests use to drive the explicit-column batches and the paused replay.)
+  speculate_all_ = opt_.speculation == LockstepOptions::kSpeculateAll;
+  speculate_never_ = opt_.speculation == LockstepOptions::kSpeculateNever;
   opt_.params.depth_filter.use_threaded_depthfilter = false;   // the synchronous path
   if (!opt_.per_stream.empty() && opt_.per_stream.size() != static_cast<size_t>(n_streams)) throw std::runtime_error("FrontendLockstep: per_stream must hold one entry per stream (or none)");
   if (!opt_.per_stream.empty()) opt_.params = opt_.per_stream[0].params;   // the shared part is read from here
@@ -1033,7 +1026,7 @@ int svohl_run_sequence(svohl_engine* e, const uint8_t* base, size_t image_bytes,
     if (T_f_w_first) for (int s = 0; s < S; ++s) T.push_back(svoh::load_rigid(T_f_w_first[s]));
     std::vector<const uint8_t*> ptrs(static_cast<size_t>(S)), next(static_cast<size_t>(S));
     const long period = 2L * (n_frames - 1);
-    const bool prefetch = getenv("SVOH_LOCKSTEP_PREFETCH") == nullptr || atoi(getenv("SVOH_LOCKSTEP_PREFETCH")) != 0;
+    const bool prefetch = true;   // (the next images of a replay are known: they go up during the round)
     for (long k = k_first; k < k_first + n_rounds; ++k) {
       const long m = k % period;
       const long f = m < n_frames ? m : period - m;
@@ -1065,7 +1058,7 @@ int svohl_run_schedule(svohl_engine* e, const uint8_t* base, size_t image_bytes,
     if (T_f_w_first) for (int s = 0; s < S; ++s) T.push_back(svoh::load_rigid(T_f_w_first[s]));
     std::vector<const uint8_t*> ptrs(static_cast<size_t>(S)), next(static_cast<size_t>(S));
     const long period = 2L * (n_frames - 1);
-    const bool prefetch = getenv("SVOH_LOCKSTEP_PREFETCH") == nullptr || atoi(getenv("SVOH_LOCKSTEP_PREFETCH")) != 0;
+    const bool prefetch = true;   // (the next images of a replay are known: they go up during the round)
     auto image_of = [&](int s, long k) -> const uint8_t* {   // stream s' image in round k, or none
       if (k < phase[s] || (k - phase[s]) % every[s] != 0) return nullptr;
       const long j = (k - phase[s]) / every[s];

@@ -72,6 +72,11 @@ struct LockstepOptions {
   // a keyframe's constant feature columns are uploaded once (svoh_features_upload); the matcher and depth-filter batches of
   // the frames after it name features by index instead of carrying 60 bytes per feature over PCIe every frame
   bool resident_features = true;
+  // The third candidate list of a stream (its unconverged seeds, up to a thousand matcher units) joins the round's batch ...
+  //   kSpeculateAsBefore  only if the stream's frame before reached that pass (ReprojectorHip::reprojectFrames' own policy); a stream
+  //                       that reaches an unplanned pass pauses its replay and gets a batch of its own
+  //   kSpeculateAll       always          kSpeculateNever   never: every third pass goes through the paused replay (tests)
+  enum Speculation { kSpeculateAsBefore = 0, kSpeculateAll = 1, kSpeculateNever = 2 } speculation = kSpeculateAsBefore;
   // one entry per stream, or empty: every stream runs with params / depth_* / kf_every / min_tracked above
   std::vector<LockstepStreamOptions> per_stream;
 };
@@ -125,10 +130,10 @@ class FrontendLockstep {
     std::vector<float> angles;
     bool in_flight = false;
   } detect_;
-  bool detect_ahead_ = true;
-  bool align_ahead_ = true;
+  const bool detect_ahead_ = true;   // the detector of a round's periodic keyframes ahead of the pose optimisation
+  const bool align_ahead_ = true;    // the alignment queued ahead of the wait for the previous round's seed update
   bool speculate_never_ = false;
-  bool speculate_all_ = false;   // plan every stream's unconverged-seed list whether or not its pass was reached on the frame before   // the alignment queued ahead of the wait for the previous round's seed update
+  bool speculate_all_ = false;   // plan every stream's unconverged-seed list whether or not its pass was reached on the frame before
   void drainReleases();
   void check(int rc, const char* what) const;
 
@@ -151,7 +156,7 @@ class FrontendLockstep {
   std::vector<std::unique_ptr<Stream>> streams_;
   size_t round_ = 0;
   bool seeds_in_flight_ = false;
-  bool pose_chain_ = true;   // the seed update queued behind the pose kernel, its poses taken on the device
+  const bool pose_chain_ = true;   // the seed update queued behind the pose kernel, its poses taken on the device
   RoundTimes times_;
   int device_calls_ = 0;
   double phase_ms_[kNumPhases] = {};

@@ -303,7 +303,6 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
 
 // one lock-step group: streams [s0, s0 + n) of the run, all fed the same decoded sequence
 struct GroupResult { size_t frames = 0, steady_frames = 0; double wall_ms = 0, steady_ms = 0; size_t steady_rounds = 0; int device_calls = 0; FrontendLockstep::RoundTimes mean{}; std::string error; };
-std::shared_ptr<SharedPool> g_shared_pool;   // SVOH_LOCKSTEP_SHARED=1: the groups' host phases on one set of worker threads
 
 void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::GrayImage>& images, const std::vector<io::RigCamera>& rig, const io::FrontendParams& params,
                         const std::string& out_dir, const Transformation& T0, float depth_min, float depth_mean, float depth_max, size_t kf_every, int s0, int n,
@@ -356,8 +355,9 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
         return *j < nf ? (long)sp.image(*j, images.size()) : -1;
       };
       lo.images_mem_space = SVOH_MEM_HOST_PINNED;
-      lo.shared_pool = g_shared_pool; lo.shared_pool_seed = s0;
-      lo.pin_workers = getenv("SVOH_LOCKSTEP_PIN") != nullptr && atoi(getenv("SVOH_LOCKSTEP_PIN")) != 0;   // (a shared box: its low CPUs are everybody's)
+      // the two switches the tests use (the rest of round 5's A/B switches is gone: HISTORY round 5 has their numbers)
+      if (const char* sp = getenv("SVOH_LOCKSTEP_SPECULATE")) lo.speculation = std::string(sp) == "all" ? LockstepOptions::kSpeculateAll : std::string(sp) == "never" ? LockstepOptions::kSpeculateNever : LockstepOptions::kSpeculateAsBefore;
+      if (getenv("SVOH_LOCKSTEP_RESIDENT")) lo.resident_features = atoi(getenv("SVOH_LOCKSTEP_RESIDENT")) != 0;
       FrontendLockstep fe(ctx, n, lo);
       const bool last_lap = lap + 1 == n_laps;
       std::vector<std::unique_ptr<io::TrajectoryWriter>> traj;
@@ -384,7 +384,7 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
           }
       };
       std::vector<const uint8_t*> ptrs((size_t)n), next((size_t)n);
-      const bool prefetch = getenv("SVOH_LOCKSTEP_PREFETCH") == nullptr || atoi(getenv("SVOH_LOCKSTEP_PREFETCH")) != 0;
+      const bool prefetch = true;
       if (lap == 0) {   // all groups start their first frame together
         start_gate->fetch_add(1);
         while (start_gate->load() < n_groups) std::this_thread::yield();
@@ -475,9 +475,6 @@ int main(int argc, char** argv)
       if (n_workers < 1 || n_workers > 256 || n_groups < 1 || n_groups > n_streams || n_laps < 1) throw std::runtime_error("n_workers / n_groups / n_laps out of range");
       if (images.empty()) throw std::runtime_error("no images");
       for (int s = 1; s < n_streams; ++s) (void)mkdir((out_dir + "/stream" + std::to_string(s)).c_str(), 0755);
-      // SVOH_LOCKSTEP_SHARED=1: the groups' workers as ONE pool that every group's phases draw on (measured: no gain over a pool per group, profiles/r05_shared_pool_ab.txt)
-      if (n_groups > 1 && n_workers > 1 && getenv("SVOH_LOCKSTEP_SHARED") != nullptr && atoi(getenv("SVOH_LOCKSTEP_SHARED")) != 0)
-        g_shared_pool.reset(new SharedPool(n_groups * (n_workers - 1)));
       std::vector<GroupResult> res((size_t)n_groups);
       std::atomic<int> gate(0);
       std::vector<std::thread> threads;
