@@ -453,18 +453,42 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
                                        n_cur_frames=B)
     cur_list = [cur_views[i] for i in range(B)]
 
-    def step():
+    def step_units():
         with torch.cuda.stream(ext):
             t["state"].copy_(t["state0"]); t["type"].copy_(t["type0"])
         ctx.update_seeds_device(mopt, dopt, ref_views, cur_list, fbd, t["state"].data_ptr(), t["succ"].data_ptr(),
                                 t["mr"].data_ptr())
         return None, None
 
+    # the keyframes' constant columns resident on the device (svoh_features_upload, once per keyframe's life); the batch = every seed
+    # of every keyframe (SVOH_BATCH_WHOLE_SETS): processed in the tile order computed at upload, no count / scan / scatter / un-sort
+    m = len(seeds)
+    cols = [[np.ascontiguousarray(sd[k], dt) for sd in seeds] for k, dt in (("px", np.float64), ("f", np.float64), ("grad", np.float64), ("level", np.int32))]
+    handles = (ctypes.c_uint64 * m)()
+    ctx._check(ctx.lib.svoh_features_upload(ctx.h, m, (ctypes.c_int32 * m)(*[a.size for a in cols[3]]), *[(ctypes.c_void_p * m)(*[a.ctypes.data for a in c]) for c in cols], handles))
+    ref_views_ws = [fe.make_frame_view(frames[2 * i], cam, sc.T_ref_f_w, seeds[i]["mu_range"], 2 * i) for i, sc in enumerate(scenes)]
+    for i in range(m):
+        ref_views_ws[i].features = handles[i]
+    fbw = fe.make_feature_batch_device(n, None, None, None, None, None, t["type"].data_ptr(), cur_frame_idx=t["idx"].data_ptr(), n_cur_frames=B)
+    fbw.layout = capi.SVOH_BATCH_WHOLE_SETS
+
+    def step_whole_sets():
+        with torch.cuda.stream(ext):
+            t["state"].copy_(t["state0"]); t["type"].copy_(t["type0"])
+        ctx.update_seeds_device(mopt, dopt, ref_views_ws, cur_list, fbw, t["state"].data_ptr(), t["succ"].data_ptr(), t["mr"].data_ptr())
+        return None, None
+    step, other = (step_whole_sets, step_units) if args.whole_sets else (step_units, step_whole_sets)
+
     h_steps = max(2, args.steps // 4)
     h_elapsed, _hk, (st, succ, mres) = timed_steps(ctx, dist, world, dev, step_host, h_steps, 1)
     host_rate = n * h_steps / h_elapsed
+    # the leg that is not the timed one: a few steps, for its kernel time and the equality of the two
+    kms_other = None
+    if not args.no_secondary:   # (profiling runs pass --no-secondary: one leg's kernels only)
+        _e2, kms_other, _ = timed_steps(ctx, dist, world, dev, other, max(3, args.steps // 2), 1)
+        assert np.array_equal(t["state"].cpu().numpy(), st) and np.array_equal(t["mr"].cpu().numpy(), mres) and np.array_equal(t["succ"].cpu().numpy(), succ)
     elapsed, kms, _ = timed_steps(ctx, dist, world, dev, step, args.steps, args.warmup)
-    assert np.array_equal(t["state"].cpu().numpy(), st) and np.array_equal(t["mr"].cpu().numpy(), mres)
+    assert np.array_equal(t["state"].cpu().numpy(), st) and np.array_equal(t["mr"].cpu().numpy(), mres) and np.array_equal(t["succ"].cpu().numpy(), succ)
     cnt = misc_counters(ctx)
     # warp <= 11x11 B, scan 64+64 B per ZMSSD, align 81 B per iteration, state 32 B in + out
     alg = cnt[0] * 121 + cnt[1] * 128 + cnt[2] * 81 + n * 32 + cnt[3] * 32
@@ -497,11 +521,18 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
             "value": total * args.steps / elapsed, "unit": "seed updates/s", "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_frame": 1e3 * elapsed / args.steps / B, "dtype": "i32+f32+f64",
             "config": {"workload": "C4-synth: %d (keyframe, frame) pairs x %d seeds per GPU per step, 640x480, 8x8 patches, "
-                                   "<=100 epipolar steps, seed arrays resident in HBM" % (B, NS), "frame_pairs_per_gpu": B, "seeds_per_keyframe": NS},
+                                   "<=100 epipolar steps, seed arrays resident in HBM%s" % (B, NS, "; the keyframes' columns resident (svoh_features_upload), "
+                                   "the batch = every seed of every keyframe in the upload's tile order (SVOH_BATCH_WHOLE_SETS)" if args.whole_sets else ""),
+                       "frame_pairs_per_gpu": B, "seeds_per_keyframe": NS},
             "kernel_ms": kms, "success_fraction": float(succ.mean()),
+            # both forms give the same bits (asserted above): per-unit columns in the caller's device arrays, binned per step
+            # (count + scatter + packed kernel + un-sort), and whole resident sets (the packed kernel alone)
+            "kernel_ms_units_binned_per_step": kms_other if args.whole_sets else kms,
+            "kernel_ms_whole_resident_sets": kms if args.whole_sets else kms_other,
             "host_staged_seed_updates_per_s": host_rate,  # same work with host arrays staged per call (PCIe-inclusive)
-            "roofline": roofline("update_seeds_packed_kernel (+ seed_bin_count / scan / scatter, seed_unsort: the whole step)", kms,
-                                 alg, "seeds:default" if not args.problems else "seeds:B%d" % B, counters=cnt[:4],
+            "roofline": roofline("update_seeds_packed_kernel alone, over the resident sets' tile-ordered columns" if args.whole_sets else
+                                 "update_seeds_packed_kernel (+ seed_bin_count / scan / scatter, seed_unsort: the whole step)", kms,
+                                 alg, ("seeds-ws:default" if args.whole_sets else "seeds:default") if not args.problems else "seeds:B%d" % B, counters=cnt[:4],
                                  unit_tails={"align_iters_ge5": cnt[4], "align_iters_ge10": cnt[5], "zmssd_ge20": cnt[6],
                                              "zmssd_ge50": cnt[7]}),
             "cpu_baseline": cpu}
@@ -1391,6 +1422,8 @@ def parse_args(argv=None):
                     "keyframe period 4..9, feature budget 120 / 180 / 240, one stream in eight at half the frame rate (FrontendLockstep's per-stream options)")
     ap.add_argument("--stream-groups", type=int, default=0, help="lock-step groups per GPU (default: chosen from S and the host-thread budget)")
     ap.add_argument("--stream-workers", type=int, default=0, help="host threads per lock-step group")
+    ap.add_argument("--whole-sets", action="store_true", help="with --workload seeds: the timed leg is the batch over RESIDENT keyframe columns "
+                    "(svoh_features_upload once; SVOH_BATCH_WHOLE_SETS: tile order from the upload, no per-frame binning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the 8x8-patch leg that the default line carries as `secondary`")

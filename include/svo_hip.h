@@ -530,9 +530,18 @@ typedef struct svoh_frame_view {
 
 /* n features referencing one of n_ref_frames reference frames, SoA like Frame's
  * feature storage (frame.h:62-73) */
+#define SVOH_BATCH_UNITS 0        /* every unit names its reference frame and feature (the arrays below) */
+/* seed batches staged with SVOH_STAGE_RESIDENT_COLUMNS, or seed batches with DEVICE arrays (SVOH_MEM_DEVICE: px / f / grad / level /
+ * ref_frame_idx NULL; always the packed geometry): the units ARE the reference frames' resident features -- unit order:
+ * for r = 0 .. n_ref_frames - 1 in turn, feature 0 .. n_r - 1 of ref_frames[r].features (n = the sum of the sets' sizes, checked).
+ * ref_frame_idx and feature_index need not be filled in (they are not read; the staged pointers are still passed); type,
+ * cur_frame_idx, state and the outputs are per unit in that order.  What it buys: a large batch (the packed geometry) is processed
+ * in the TILE order of the reference pixels that svoh_features_upload computed once per keyframe -- no counting sort, no record
+ * scatter, no un-sort per frame (depth_filter.cpp:200-251 updates every seed of every keyframe: this IS its unit list). */
+#define SVOH_BATCH_WHOLE_SETS 1
 typedef struct svoh_feature_batch {
   int32_t n;
-  int32_t reserved;
+  int32_t layout;                         /* SVOH_BATCH_UNITS (0) / SVOH_BATCH_WHOLE_SETS */
   const int32_t* ref_frame_idx;           /* n: index into the ref_frames array */
   const double* px;                       /* 2 x n  px_vec_ */
   const double* f;                        /* 3 x n  f_vec_ */

@@ -2,7 +2,7 @@
 # Runs on the GPU box.  For every benchmark workload: rocprofv3 kernel-trace/stats of the bench command, then separate
 # counter passes of the SAME command (FETCH_SIZE, WRITE_SIZE, two SQ sets; never mixed with trace flags), raw CSVs of
 # the svoh kernels kept, and one summary json per workload (scripts/pmc_summary.py) -> gpurun_out/profiles/.
-# usage: scripts/profile_round.sh <round> [tags...]     tags: align_p4 align_p8 align_c4 klt seeds pose stereo
+# usage: scripts/profile_round.sh <round> [tags...]     tags: align_p4 align_p8 align_c4 klt seeds seeds_ws pose stereo
 set -e
 ROUND=${1:-r03}; shift || true
 TAGS=${@:-align_p4 align_p8 align_c4 klt seeds pose stereo}
@@ -18,6 +18,7 @@ for tag in $TAGS; do
     align_c4) args="--workload align-c4 $STEPS"; key="align-c4:default"; rx="sparse_align_kernel<4, 256, true, false";;
     klt) args="--workload klt $STEPS"; key="klt:default"; rx="klt_track_kernel";;
     seeds) args="--workload seeds $STEPS"; key="seeds:default"; rx="update_seeds|seed_bin|seed_unsort";;
+    seeds_ws) args="--workload seeds --whole-sets $STEPS"; key="seeds-ws:default"; rx="update_seeds|seed_bin|seed_unsort";;
     pose) args="--workload pose $STEPS"; key="pose:default"; rx="pose_optimize_kernel";;
     stereo) args="--workload stereo $STEPS"; key="stereo:default"; rx="epipolar_match_kernel";;
   esac

@@ -8,6 +8,7 @@ import ctypes as C
 import os
 
 SVOH_ABI_VERSION = 2   # include/svo_hip.h
+SVOH_BATCH_UNITS, SVOH_BATCH_WHOLE_SETS = 0, 1   # svoh_feature_batch.layout
 SVOH_MAX_LEVELS = 8
 SVOH_MAX_CAMS = 4
 
@@ -102,7 +103,7 @@ class svoh_frame_view(C.Structure):
 
 
 class svoh_feature_batch(C.Structure):
-    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("ref_frame_idx", C.c_void_p), ("px", C.c_void_p),
+    _fields_ = [("n", C.c_int32), ("layout", C.c_int32), ("ref_frame_idx", C.c_void_p), ("px", C.c_void_p),
                 ("f", C.c_void_p), ("grad", C.c_void_p), ("level", C.c_void_p), ("type", C.c_void_p),
                 ("cur_frame_idx", C.c_void_p), ("n_cur_frames", C.c_int32), ("mem_space", C.c_int32), ("feature_index", C.c_void_p)]
 

@@ -6,6 +6,7 @@
 // (src/vikit/vikit_common/src/vision.cpp:19-44 SSE2 rule, :73-111 dispatch and
 // scalar rule).  Integer work: results are bit-identical to the reference's.
 #include <cstdarg>
+#include <algorithm>
 #include <cstring>
 
 #include "svoh_internal.h"
@@ -753,13 +754,14 @@ try {
   if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SVOH_REQUIRE(ctx, n_sets >= 0 && (n_sets == 0 || (n && px && f && grad && level && out)), "bad arguments");
   if (n_sets == 0) return SVOH_OK;
-  // layout of the call's block: set after set, each [px 16n | f 24n | grad 16n | level 4n], every array 64-byte aligned
+  // layout of the call's block: set after set, each [px 16n | f 24n | grad 16n | level 4n | the same four in tile order | perm 4n],
+  // every array 64-byte aligned
   auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
   size_t total = 0;
   for (int k = 0; k < n_sets; ++k) {
     SVOH_REQUIRE(ctx, n[k] >= 0 && (n[k] == 0 || (px[k] && f[k] && grad[k] && level[k])), "a set's n is negative or one of its arrays is NULL");
     const size_t m = (size_t)n[k];
-    total += al(16 * m) + al(24 * m) + al(16 * m) + al(4 * m);
+    total += 2 * (al(16 * m) + al(24 * m) + al(16 * m) + al(4 * m)) + al(4 * m);
     out[k] = 0;
   }
   if (total == 0) total = 64;
@@ -789,6 +791,28 @@ try {
     fs.f = reinterpret_cast<const double*>(d + off); if (m) memcpy(h + off, f[k], 24 * m); off += al(24 * m);
     fs.grad = reinterpret_cast<const double*>(d + off); if (m) memcpy(h + off, grad[k], 16 * m); off += al(16 * m);
     fs.level = reinterpret_cast<const int32_t*>(d + off); if (m) memcpy(h + off, level[k], 4 * m); off += al(4 * m);
+    // tile order: a stable sort of the features by (tile row, tile column) of their pixel
+    std::vector<int32_t> perm(m);
+    std::vector<uint32_t> key(m);
+    for (size_t i = 0; i < m; ++i) {
+      perm[i] = (int32_t)i;
+      const double x = px[k][2 * i], y = px[k][2 * i + 1];
+      const uint32_t tx = (x >= 0.0 && x < 1e9) ? (uint32_t)((int)x >> svoh::kBinShiftX) : 0u, ty = (y >= 0.0 && y < 1e9) ? (uint32_t)((int)y >> svoh::kBinShiftY) : 0u;
+      key[i] = (ty << 12) | (tx & 0xfffu);
+    }
+    std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return key[(size_t)a] < key[(size_t)b]; });
+    double* spx = reinterpret_cast<double*>(h + off); fs.spx = reinterpret_cast<const double*>(d + off); off += al(16 * m);
+    double* sf = reinterpret_cast<double*>(h + off); fs.sf = reinterpret_cast<const double*>(d + off); off += al(24 * m);
+    double* sgrad = reinterpret_cast<double*>(h + off); fs.sgrad = reinterpret_cast<const double*>(d + off); off += al(16 * m);
+    int32_t* slevel = reinterpret_cast<int32_t*>(h + off); fs.slevel = reinterpret_cast<const int32_t*>(d + off); off += al(4 * m);
+    int32_t* sperm = reinterpret_cast<int32_t*>(h + off); fs.perm = reinterpret_cast<const int32_t*>(d + off); off += al(4 * m);
+    for (size_t q = 0; q < m; ++q) {
+      const size_t i = (size_t)perm[q];
+      spx[2 * q] = px[k][2 * i]; spx[2 * q + 1] = px[k][2 * i + 1];
+      sf[3 * q] = f[k][3 * i]; sf[3 * q + 1] = f[k][3 * i + 1]; sf[3 * q + 2] = f[k][3 * i + 2];
+      sgrad[2 * q] = grad[k][2 * i]; sgrad[2 * q + 1] = grad[k][2 * i + 1];
+      slevel[q] = level[k][i]; sperm[q] = perm[q];
+    }
   }
   SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, off ? off : 64));
   SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_features, ctx->stream));

@@ -41,7 +41,19 @@ struct DevFrameView {
   int32_t pose_result_index_plus1;   // > 0: T_f_w holds T_cam_imu until matcher_prologue_kernel has run (svoh_frame_view)
   int32_t feat_n;                    // the frame's resident columns (svoh_frame_view::features), or 0 / NULL
   const double* feat_px; const double* feat_f; const double* feat_grad; const int32_t* feat_level;
+  // ... the same columns in tile order, perm[q] = the feature at place q (svoh::FeatureSet)
+  const double* feat_spx; const double* feat_sf; const double* feat_sgrad; const int32_t* feat_slevel; const int32_t* feat_perm;
+  // SVOH_BATCH_WHOLE_SETS: the batch's units [unit_begin, unit_begin + feat_n) are this reference frame's features 0 .. feat_n - 1
+  int32_t unit_begin;
 };
+
+// SVOH_BATCH_WHOLE_SETS: the reference frame whose units hold unit / slot p = the last one that begins at or before p
+__device__ __forceinline__ int whole_sets_frame_of(const DevFrameView* ref_frames, int n_ref, int p)
+{
+  int lo = 0, hi = n_ref;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ref_frames[mid].unit_begin <= p) lo = mid; else hi = mid; }
+  return lo;
+}
 
 struct MatcherArgs {
   const DevFrameView* ref_frames;
@@ -75,6 +87,9 @@ struct MatcherArgs {
   const double* d_inv;        // 3 per feature, or NULL = d_inv_common
   double d_inv_common[3];
   double* depth_out;
+  // SVOH_BATCH_WHOLE_SETS (seed batches over resident columns): ref_frame_idx / px / f / grad / level above are not read by the packed
+  // kernel, which walks the reference frames' tile-ordered columns; the other geometries get them filled in by the prologue
+  int whole_sets;
 };
 
 constexpr int kPwbStride = 100;
@@ -2082,7 +2097,6 @@ __global__ __launch_bounds__(64) void match_mixed_kernel(const MatcherArgs ad, c
 // nothing is shared.  A counting sort by (reference frame, 128x32-pixel tile of the reference pixel) makes the
 // seeds of a workgroup neighbours in both images (the frames of an update are close): their rows share lines.
 // Results do not depend on the processing order; every seed still writes its own entries.
-constexpr int kBinShiftX = 7, kBinShiftY = 5;
 constexpr size_t kBinMaxKeys = (size_t)1 << 20;
 
 __device__ __forceinline__ unsigned seed_bin_key(const MatcherArgs& a, int i, int tiles_x, int tiles_y)
@@ -2315,7 +2329,20 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
   // the seed's inputs: from its sorted record, or straight from the caller's arrays
   int i = slot_i, ri = 0, ci = 0, level = 0, type = 0;
   double pxr = 0.0, pyr = 0.0, gx = 0.0, gy = 0.0;
-  if (live) {
+  int ws_q = 0;                       // whole sets: the slot's place in its reference frame's tile order
+  const double* ws_f = nullptr;
+  if (live && a.whole_sets) {
+    // slot p of the launch = place q of reference frame ri's tile order = feature perm[q] = unit unit_begin + perm[q] of the caller
+    ri = whole_sets_frame_of(a.ref_frames, a.n_ref_frames, slot_i);
+    const DevFrameView& rv = a.ref_frames[ri];
+    ws_q = slot_i - rv.unit_begin;
+    if (ws_q >= 0 && ws_q < rv.feat_n) {
+      i = rv.unit_begin + rv.feat_perm[ws_q];
+      pxr = rv.feat_spx[2 * ws_q]; pyr = rv.feat_spx[2 * ws_q + 1]; gx = rv.feat_sgrad[2 * ws_q]; gy = rv.feat_sgrad[2 * ws_q + 1];
+      level = rv.feat_slevel[ws_q]; ws_f = rv.feat_sf;
+      ci = a.cur_frame_idx ? a.cur_frame_idx[i] : 0; type = a.type[i];
+    } else { ri = -1; }   // (cannot happen: the host checked that the sets' sizes add up to n)
+  } else if (live) {
     if (rec_in) {
       const SeedRecIn& r = rec_in[slot_i];
       pxr = r.px[0]; pyr = r.px[1]; gx = r.grad[0]; gy = r.grad[1];
@@ -2326,6 +2353,7 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
     }
   }
   auto load_f = [&]() -> Vec3 {
+    if (ws_f) return Vec3{ ws_f[3 * ws_q], ws_f[3 * ws_q + 1], ws_f[3 * ws_q + 2] };
     if (rec_in) { const SeedRecIn& r = rec_in[slot_i]; return Vec3{ r.f[0], r.f[1], r.f[2] }; }
     return Vec3{ a.f[3 * i], a.f[3 * i + 1], a.f[3 * i + 2] };
   };
@@ -2747,10 +2775,12 @@ static int fill_view(svoh_ctx* ctx, const svoh_frame_view& v, DevFrameView* out,
   out->id = v.id;
   out->pose_result_index_plus1 = v.pose_result_index_plus1;
   out->feat_n = 0; out->feat_px = out->feat_f = out->feat_grad = nullptr; out->feat_level = nullptr;
+  out->feat_spx = out->feat_sf = out->feat_sgrad = nullptr; out->feat_slevel = out->feat_perm = nullptr; out->unit_begin = 0;
   if (v.features) {
     auto it = ctx->feature_sets.find(v.features);
     if (it == ctx->feature_sets.end()) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "%s: unknown feature-set handle %llu", what, (unsigned long long)v.features);
     out->feat_n = it->second.n; out->feat_px = it->second.px; out->feat_f = it->second.f; out->feat_grad = it->second.grad; out->feat_level = it->second.level;
+    out->feat_spx = it->second.spx; out->feat_sf = it->second.sf; out->feat_sgrad = it->second.sgrad; out->feat_slevel = it->second.slevel; out->feat_perm = it->second.perm;
   }
   return SVOH_OK;
 }
@@ -2795,7 +2825,7 @@ static int launch_matcher_kernels(svoh_ctx* ctx, bool seeds, int g8, MatcherArgs
       unsigned* hist_ptr = nullptr;
       unsigned hist_keys = 0;
       const dim3 gb((unsigned)((n + 255) / 256));
-      if (n_keys <= kBinMaxKeys && SvohKnobs::or_default(ctx->knobs.seed_binning, 1) != 0) {
+      if (!a.whole_sets && n_keys <= kBinMaxKeys && SvohKnobs::or_default(ctx->knobs.seed_binning, 1) != 0) {
         // [hist | rank | pos_of | records in (128 B each) | records out (64 B each)]
         const size_t o_rank = (n_keys * sizeof(unsigned) + 255) & ~(size_t)255;
         const size_t o_pos = o_rank + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255);
@@ -2867,6 +2897,11 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   }
   SVOH_REQUIRE(ctx, fb->mem_space == SVOH_MEM_HOST || fb->mem_space == SVOH_MEM_DEVICE, "bad mem_space");
   SVOH_REQUIRE(ctx, !fb->feature_index, "feature_index: staged batches only (svoh_matcher_stage with SVOH_STAGE_RESIDENT_COLUMNS)");
+  // SVOH_BATCH_WHOLE_SETS on a DEVICE batch: the seeds' state / type / current-frame index live in the caller's device arrays in the
+  // sets' order, the columns are the reference frames' resident ones; always the packed geometry (which walks the tile-ordered copies)
+  const bool whole_sets = fb->layout == SVOH_BATCH_WHOLE_SETS;
+  SVOH_REQUIRE(ctx, fb->layout == SVOH_BATCH_UNITS || (whole_sets && seeds && fb->mem_space == SVOH_MEM_DEVICE && !ctx->matcher_deferred),
+               "svoh_feature_batch::layout: SVOH_BATCH_WHOLE_SETS is for seed batches over resident columns, staged (svoh_matcher_stage) or with device arrays");
   const bool on_device = fb->mem_space == SVOH_MEM_DEVICE;
   SVOH_REQUIRE(ctx, fb->ref_frame_idx && fb->px && fb->f && fb->grad && fb->level && fb->type, "NULL feature array");
   if (seeds) SVOH_REQUIRE(ctx, dopt && state && success, "NULL seed argument");
@@ -2891,6 +2926,14 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   for (int k = 0; k < n_cur; ++k) {
     int rc = fill_view(ctx, cur_frame[k], &views[n_ref_frames + k], "current frame");
     if (rc != SVOH_OK) return rc;
+  }
+  if (whole_sets) {
+    long long begin = 0;
+    for (int k = 0; k < n_ref_frames; ++k) {
+      SVOH_REQUIRE(ctx, ref_frames[k].features != 0, "SVOH_BATCH_WHOLE_SETS: a reference frame has no resident columns (svoh_frame_view::features)");
+      views[k].unit_begin = (int32_t)begin; begin += views[k].feat_n;
+    }
+    SVOH_REQUIRE(ctx, begin == n, "SVOH_BATCH_WHOLE_SETS: the reference frames' resident sets do not add up to the batch's n");
   }
   {
     // the search level is chosen up to the reference pyramid's top (patch_warp.cpp:97-110) and then read
@@ -2960,6 +3003,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   if (g8 < 0 || g8 > 3) g8 = 0;
   if (g8 == 3 && (!seeds || defer)) g8 = 1;   // the direct matcher has no scan
   if (landmark_xyz) g8 = 0;                    // the pixelwise warp exists with one lane per unit only
+  if (whole_sets) g8 = 2;                      // (a device batch over whole sets: the packed geometry reads the resident columns itself)
   // Optional outputs of units that return before the matcher runs read back as zeros.  The per-unit kernels write those
   // zeros themselves (match_direct_body, update_seeds_body): a fill of the output block would be one more operation on
   // the stream of every per-frame call (2.6 us each, tools/svoh_call_overhead).  The packed geometry's kernels do not.
@@ -2974,6 +3018,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   a.n = n;
   a.n_ref_frames = n_ref_frames;
   a.n_cur_frames = n_cur;
+  a.whole_sets = whole_sets ? 1 : 0;
   if (on_device) {
     a.ref_frame_idx = fb->ref_frame_idx; a.cur_frame_idx = fb->cur_frame_idx;
     a.px = fb->px; a.f = fb->f; a.grad = fb->grad; a.level = fb->level; a.type = fb->type;
@@ -3105,6 +3150,7 @@ static int run_epipolar(svoh_ctx* ctx, const svoh_matcher_options* mopt, int n_r
   if (n <= 0) return SVOH_OK;
   SVOH_REQUIRE(ctx, fb->mem_space == SVOH_MEM_HOST || fb->mem_space == SVOH_MEM_DEVICE, "bad mem_space");
   SVOH_REQUIRE(ctx, !fb->feature_index, "feature_index: staged batches only (svoh_matcher_stage with SVOH_STAGE_RESIDENT_COLUMNS)");
+  SVOH_REQUIRE(ctx, fb->layout == SVOH_BATCH_UNITS, "svoh_feature_batch::layout: SVOH_BATCH_WHOLE_SETS is for staged seed batches over resident columns");
   const bool on_device = fb->mem_space == SVOH_MEM_DEVICE;
   SVOH_REQUIRE(ctx, fb->ref_frame_idx && fb->px && fb->f && fb->grad && fb->level && fb->type, "NULL feature array");
   SVOH_REQUIRE(ctx, out->result && out->depth, "result and depth outputs are required");
@@ -3417,6 +3463,9 @@ static int run_matcher_staged(svoh_ctx* ctx, bool seeds, const svoh_matcher_opti
   auto at = [&](size_t off) { return static_cast<void*>(h + off); };
   SVOH_REQUIRE(ctx, fb->ref_frame_idx == at(st.o_idx) && fb->cur_frame_idx == at(st.o_cidx) && fb->type == at(st.o_type),
                "a staged batch's feature arrays must be the pointers svoh_matcher_stage handed out");
+  const bool whole_sets = fb->layout == SVOH_BATCH_WHOLE_SETS;
+  SVOH_REQUIRE(ctx, fb->layout == SVOH_BATCH_UNITS || whole_sets, "svoh_feature_batch::layout: SVOH_BATCH_UNITS or SVOH_BATCH_WHOLE_SETS");
+  SVOH_REQUIRE(ctx, !whole_sets || (seeds && st.resident), "SVOH_BATCH_WHOLE_SETS: seed batches staged with SVOH_STAGE_RESIDENT_COLUMNS");
   if (st.resident)
     SVOH_REQUIRE(ctx, fb->feature_index == at(st.o_fidx) && !fb->px && !fb->f && !fb->grad && !fb->level,
                  "a batch staged with SVOH_STAGE_RESIDENT_COLUMNS names its features by feature_index (the staged pointer); px / f / grad / level are NULL");
@@ -3478,6 +3527,11 @@ static int run_matcher_staged(svoh_ctx* ctx, bool seeds, const svoh_matcher_opti
       ctx->staged_views_generation = ctx->handle_generation;
     }
   }
+  if (whole_sets) {   // the units are the reference frames' features, frame after frame: where each frame's units begin
+    long long begin = 0;
+    for (int k = 0; k < n_ref_frames; ++k) { views[k].unit_begin = (int32_t)begin; begin += views[k].feat_n; }
+    SVOH_REQUIRE(ctx, begin == n, "SVOH_BATCH_WHOLE_SETS: the reference frames' resident sets do not add up to the batch's n");
+  }
   ctx->matcher_deferred_used[kind] = true;
   st.valid = false;   // consumed: the outputs stay readable, a second batch needs a new svoh_matcher_stage
   SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, st.in_total));
@@ -3492,6 +3546,7 @@ static int run_matcher_staged(svoh_ctx* ctx, bool seeds, const svoh_matcher_opti
   a.mopt = *mopt;
   if (dopt) a.dopt = *dopt;
   a.n = n; a.n_ref_frames = n_ref_frames; a.n_cur_frames = n_cur;
+  a.whole_sets = whole_sets ? 1 : 0;
   a.ref_frame_idx = reinterpret_cast<const int32_t*>(d + st.o_idx);
   a.cur_frame_idx = reinterpret_cast<const int32_t*>(d + st.o_cidx);
   a.px = reinterpret_cast<const double*>(d + st.o_px); a.f = reinterpret_cast<const double*>(d + st.o_f);
@@ -4040,6 +4095,7 @@ try {
 struct PrologueBatch {
   DevFrameView* views; int n_ref, n_cur;                     // reference views, then the current ones
   int n; int32_t* ref_idx; const int32_t* fidx;              // fidx == NULL: nothing to gather
+  int whole_sets;                                            // unit i = feature i - unit_begin of the frame whose units hold it: ref_idx is WRITTEN here
   double* px; double* f; double* grad; int32_t* level;
   const svoh_pose_result* pose_results; int n_pose_results;  // pose_results == NULL: no view takes its pose from the device
 };
@@ -4049,7 +4105,9 @@ __global__ void matcher_prologue_kernel(PrologueBatch b0, PrologueBatch b1, int 
   const PrologueBatch& b = second ? b1 : b0;
   const int i = ((int)blockIdx.x - (second ? blocks0 : 0)) * (int)blockDim.x + (int)threadIdx.x;
   if (b.fidx && i < b.n) {
-    const int r = b.ref_idx[i], j = b.fidx[i];
+    int r, j;
+    if (b.whole_sets) { r = whole_sets_frame_of(b.views, b.n_ref, i); j = i - b.views[r].unit_begin; b.ref_idx[i] = r; }
+    else { r = b.ref_idx[i]; j = b.fidx[i]; }
     bool ok = r >= 0 && r < b.n_ref;
     const DevFrameView* v = ok ? &b.views[r] : nullptr;
     ok = ok && j >= 0 && j < v->feat_n;
@@ -4101,10 +4159,12 @@ static int launch_deferred(svoh_ctx* ctx)
         auto prologue_of = [](const svoh_ctx::DeferredLaunch& d, const MatcherArgs& a, bool valid) {
           PrologueBatch b;
           memset(&b, 0, sizeof b);
-          if (!valid || (!d.d_fidx && !d.pose_from_results)) return b;
+          const bool gather = d.d_fidx && !(a.whole_sets && d.g8 == 2);   // (whole sets in the packed geometry: the kernel reads the resident columns itself)
+          if (!valid || (!gather && !d.pose_from_results)) return b;
           b.views = static_cast<DevFrameView*>(d.views_d); b.n_ref = d.n_ref; b.n_cur = d.n_cur;
-          if (d.d_fidx) {
+          if (gather) {
             b.n = d.n; b.ref_idx = const_cast<int32_t*>(a.ref_frame_idx); b.fidx = static_cast<const int32_t*>(d.d_fidx);
+            b.whole_sets = a.whole_sets;
             b.px = const_cast<double*>(a.px); b.f = const_cast<double*>(a.f); b.grad = const_cast<double*>(a.grad); b.level = const_cast<int32_t*>(a.level);
           }
           if (d.pose_from_results) { b.pose_results = static_cast<const svoh_pose_result*>(d.d_pose_results); b.n_pose_results = d.n_pose_results; }

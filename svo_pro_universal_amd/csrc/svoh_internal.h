@@ -115,7 +115,14 @@ struct FeatureSet {
   std::shared_ptr<FeatureBlock> block;
   int n = 0;
   const double* px = nullptr; const double* f = nullptr; const double* grad = nullptr; const int32_t* level = nullptr;   // device
+  // the same columns once more in TILE order (128x32-pixel tiles of px, row-major: the order a large seed batch is processed in,
+  // so that the seeds of a workgroup are neighbours in both images) and perm[q] = the feature that stands at place q of that
+  // order.  A keyframe's pixels never change: the order is computed once, at upload, instead of a counting sort per frame.
+  const double* spx = nullptr; const double* sf = nullptr; const double* sgrad = nullptr; const int32_t* slevel = nullptr;
+  const int32_t* perm = nullptr;
 };
+// the tile of a pixel in that order (also the bins of the per-frame counting sort of batches that carry their own columns)
+constexpr int kBinShiftX = 7, kBinShiftY = 5;
 
 // device allocation shared by the frames carved out of it
 struct Slab {

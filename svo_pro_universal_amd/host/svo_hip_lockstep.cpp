@@ -775,9 +775,9 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       st.seed_counts.clear();
       size_t n = 0;
       for (const FramePtr& f : st.seed_frames) { st.seed_counts.push_back(f->num_features_); n += f->num_features_; }
+      if (n == 0) { st.seed_frames.clear(); st.seed_counts.clear(); }
       st.seed_off = n_total; st.seed_n = n; st.ref_off = n_ref_total;
       n_total += n; n_ref_total += st.seed_frames.size();
-      if (n == 0) { st.seed_frames.clear(); st.seed_counts.clear(); }
     }
     // (the order of round 4 -- pose, wait, then the seed batch with the poses the host has applied -- is kept for comparison)
     const bool chain = pose_chain_ && !pbs.empty() && n_total > 0;
@@ -807,9 +807,10 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
           const Frame& r = *st.seed_frames[k];
           refs[st.ref_off + k] = detail::viewOf(r);
           const size_t n = st.seed_counts[k];
-          for (size_t i = 0; i < n; ++i) { g.ref_frame_idx[off + i] = static_cast<int32_t>(st.ref_off + k); g.cur_frame_idx[off + i] = st.slot; }
-          if (g.feature_index) for (size_t i = 0; i < n; ++i) g.feature_index[off + i] = static_cast<int32_t>(i);
+          // resident columns: the batch is every feature of every keyframe, frame after frame (SVOH_BATCH_WHOLE_SETS) -- nothing names a unit
+          if (g.feature_index) for (size_t i = 0; i < n; ++i) g.cur_frame_idx[off + i] = st.slot;
           else {
+            for (size_t i = 0; i < n; ++i) { g.ref_frame_idx[off + i] = static_cast<int32_t>(st.ref_off + k); g.cur_frame_idx[off + i] = st.slot; }
             memcpy(g.px + 2 * off, r.px_vec_.data(), 16 * n); memcpy(g.f + 3 * off, r.f_vec_.data(), 24 * n); memcpy(g.grad + 2 * off, r.grad_vec_.data(), 16 * n);
             memcpy(g.level + off, r.level_vec_.data(), 4 * n);
           }
@@ -827,6 +828,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = nT;
       fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type; fb.feature_index = g.feature_index;
       fb.mem_space = SVOH_MEM_STAGED;
+      fb.layout = g.feature_index ? SVOH_BATCH_WHOLE_SETS : SVOH_BATCH_UNITS;
       check(svoh_update_seeds_batch(ctx_, &df_mopt, &dfo, static_cast<int>(n_ref_total), refs.data(), curs.data(), &fb, g.state, g.success, g.result, nullptr),
             "svoh_update_seeds_batch");
       check(svoh_matcher_flush(ctx_), "svoh_matcher_flush");

@@ -485,6 +485,88 @@ def test_batches_that_name_features_by_index_equal_the_batches_with_their_column
         ctx.release_frame(fr); ctx.release_frame(fc)
 
 
+@pytest.mark.parametrize("case", ["eight lanes per unit", "packed (forced)", "packed (52 000 units)"])
+def test_whole_sets_seed_batch_equals_the_batch_of_named_units(gpu_ctx, monkeypatch, case):
+    """SVOH_BATCH_WHOLE_SETS (round 6): a staged seed batch whose units ARE the reference frames' resident features, frame after
+    frame -- what DepthFilter::updateSeeds' loop is (depth_filter.cpp:200-251) -- against the same batch with every unit named by
+    (reference frame, feature index).  Small batches: the prologue fills in what the per-unit kernels read.  Large batches (the
+    packed geometry): the kernel walks the tile-ordered copies of the columns that svoh_features_upload made once per keyframe
+    -- no counting sort, no record scatter, no un-sort per frame.  Every output bit for bit; the unit arrays the caller no longer
+    fills in are poisoned here to show they are not read; sets that do not add up to n are refused."""
+    ctx = gpu_ctx
+    cam = synth.Camera.euroc_like()
+    mopt, dopt = capi.default_matcher_options(), capi.default_depth_filter_options(cam)
+    big = case == "packed (52 000 units)"
+    if case == "packed (forced)":
+        monkeypatch.setenv("SVOH_MATCHER_G8", "2")
+        ctx.reload_knobs()
+    pairs = [seed_scene(ctx, 930 + i, cam) for i in range(3)]
+    n_sets, per = (20, 2600) if big else (5, 400)
+    sets = [synth.make_seed_set(pairs[k % 3][0], per + 37 * (k % 4), seed=40 + k, margin=12) for k in range(n_sets)]
+    for sd in sets:
+        sd["type"][::9] = capi.FT_EDGELET_SEED_CONVERGED
+    handles = _upload_features(ctx, sets)
+    n = sum(sd["level"].size for sd in sets)
+    assert (n > 49152) == big
+    uk = np.concatenate([np.full(sd["level"].size, k, np.int32) for k, sd in enumerate(sets)])
+    uj = np.concatenate([np.arange(sd["level"].size, dtype=np.int32) for sd in sets])
+    ck = (uk % 3).astype(np.int32)                      # every set into the current frame of its own scene
+    state = np.concatenate([sd["state"] for sd in sets]); typ = np.concatenate([sd["type"] for sd in sets])
+
+    def run(layout):
+        refs = (capi.svoh_frame_view * n_sets)(*[fe.make_frame_view(pairs[k % 3][1], cam, pairs[k % 3][0].T_ref_f_w, sd["mu_range"], 0) for k, sd in enumerate(sets)])
+        for k in range(n_sets):
+            refs[k].features = handles[k]
+        curs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fc, cam, sc.T_cur_f_w_gt, 0.0, 1) for (sc, fr, fc) in pairs])
+        ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+        g = capi.svoh_matcher_stage_t()
+        ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, n, n_sets + 4, capi.SVOH_STAGE_MATCH_OUTPUTS | capi.SVOH_STAGE_RESIDENT_COLUMNS, C.byref(g)))
+        _view(g.ref_frame_idx, np.int32, n)[:] = uk if layout == capi.SVOH_BATCH_UNITS else -7
+        _view(g.feature_index, np.int32, n)[:] = uj if layout == capi.SVOH_BATCH_UNITS else 10 ** 7
+        _view(g.cur_frame_idx, np.int32, n)[:] = ck
+        _view(g.type, np.uint8, n)[:] = typ
+        _view(g.state, np.float64, 4 * n)[:] = state
+        fb = capi.svoh_feature_batch()
+        fb.n, fb.mem_space, fb.n_cur_frames, fb.layout = n, capi.SVOH_MEM_STAGED, 3, layout
+        for k in ("ref_frame_idx", "cur_frame_idx", "type", "feature_index"):
+            setattr(fb, k, getattr(g, k))
+        outs = capi.svoh_seed_match_outputs(g.px_cur, g.f_cur, g.search_level, g.A_cur_ref)
+        ctx._check(ctx.lib.svoh_update_seeds_batch_ex(ctx.h, C.byref(mopt), C.byref(dopt), n_sets, refs, curs, C.byref(fb), g.state, g.success, g.result, None, C.byref(outs)))
+        ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+        return dict(result=_view(g.result, np.int32, n).copy(), px_cur=_view(g.px_cur, np.float64, 2 * n).copy(), f_cur=_view(g.f_cur, np.float64, 3 * n).copy(),
+                    search_level=_view(g.search_level, np.int32, n).copy(), A=_view(g.A_cur_ref, np.float64, 4 * n).copy(), type=_view(g.type, np.uint8, n).copy(),
+                    state=_view(g.state, np.float64, 4 * n).copy(), success=_view(g.success, np.uint8, n).copy())
+
+    want, got = run(capi.SVOH_BATCH_UNITS), run(capi.SVOH_BATCH_WHOLE_SETS)
+    assert want["success"].mean() > 0.3 and len(set(want["result"])) >= 3
+    for name, a in want.items():
+        assert np.array_equal(a, got[name]), (case, name, int((a != got[name]).sum()))
+    # sets that do not add up to n: refused (the section stays usable)
+    refs = (capi.svoh_frame_view * n_sets)(*[fe.make_frame_view(pairs[k % 3][1], cam, pairs[k % 3][0].T_ref_f_w, sd["mu_range"], 0) for k, sd in enumerate(sets)])
+    for k in range(n_sets):
+        refs[k].features = handles[k]
+    curs = (capi.svoh_frame_view * 3)(*[fe.make_frame_view(fc, cam, sc.T_cur_f_w_gt, 0.0, 1) for (sc, fr, fc) in pairs])
+    ctx._check(ctx.lib.svoh_matcher_begin_deferred(ctx.h))
+    g = capi.svoh_matcher_stage_t()
+    ctx._check(ctx.lib.svoh_matcher_stage(ctx.h, 1, n - 5, n_sets + 4, capi.SVOH_STAGE_RESIDENT_COLUMNS, C.byref(g)))
+    fb = capi.svoh_feature_batch()
+    fb.n, fb.mem_space, fb.n_cur_frames, fb.layout = n - 5, capi.SVOH_MEM_STAGED, 3, capi.SVOH_BATCH_WHOLE_SETS
+    for k in ("ref_frame_idx", "cur_frame_idx", "type", "feature_index"):
+        setattr(fb, k, getattr(g, k))
+    assert ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), n_sets, refs, curs, C.byref(fb), g.state, g.success, g.result, None) != 0
+    ctx._check(ctx.lib.svoh_matcher_collect(ctx.h))
+    # ... and the layout is refused where it has no meaning: a direct batch, a host-array batch
+    sd = sets[0]
+    fbh, keep = fe.make_feature_batch(sd["ref_frame_idx"], sd["px"], sd["f"], sd["grad"], sd["level"], sd["type"])
+    fbh.layout = capi.SVOH_BATCH_WHOLE_SETS
+    st = sd["state"].copy(); succ = np.zeros(sd["level"].size, np.uint8)
+    assert ctx.lib.svoh_update_seeds_batch(ctx.h, C.byref(mopt), C.byref(dopt), 1, refs, curs, C.byref(fbh), st.ctypes.data, succ.ctypes.data, None, None) != 0
+    for h in handles:
+        ctx._check(ctx.lib.svoh_features_release(ctx.h, h))
+    for sc, fr, fc in pairs:
+        ctx.release_frame(fr); ctx.release_frame(fc)
+
+
 def test_seed_batch_behind_the_pose_kernel_takes_its_poses_on_the_device(gpu_ctx):
     """svoh_frame_view::pose_result_index_plus1: a staged seed batch over three current frames, queued and SENT OFF from the hook of
     svoh_optimize_pose_batch_hook -- two of the frames take their pose from the pose batch in flight (T_cam_imu x the optimised
