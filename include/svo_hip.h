@@ -535,7 +535,8 @@ typedef struct svoh_frame_view {
  * ref_frame_idx NULL; always the packed geometry): the units ARE the reference frames' resident features -- unit order:
  * for r = 0 .. n_ref_frames - 1 in turn, feature 0 .. n_r - 1 of ref_frames[r].features (n = the sum of the sets' sizes, checked).
  * ref_frame_idx and feature_index need not be filled in (they are not read; the staged pointers are still passed); type,
- * cur_frame_idx, state and the outputs are per unit in that order.  What it buys: a large batch (the packed geometry) is processed
+ * cur_frame_idx, state and the outputs are per unit in that order; all seeds of a set go into ONE current frame, as updateSeeds'
+ * do (cur_frame_idx must be the same for all units of a set: the packed geometry reads it at the set's first unit).  What it buys: a large batch (the packed geometry) is processed
  * in the TILE order of the reference pixels that svoh_features_upload computed once per keyframe -- no counting sort, no record
  * scatter, no un-sort per frame (depth_filter.cpp:200-251 updates every seed of every keyframe: this IS its unit list). */
 #define SVOH_BATCH_WHOLE_SETS 1

@@ -48,8 +48,14 @@ struct DevFrameView {
 };
 
 // SVOH_BATCH_WHOLE_SETS: the reference frame whose units hold unit / slot p = the last one that begins at or before p
-__device__ __forceinline__ int whole_sets_frame_of(const DevFrameView* ref_frames, int n_ref, int p)
+__device__ __forceinline__ int whole_sets_frame_of(const DevFrameView* ref_frames, int n_ref, int p, int n = 0)
 {
+  // keyframes hold about the same number of seeds: the frame that would hold p if they all held n / n_ref is usually the one
+  // (one load instead of a chain of log2(n_ref) dependent ones at the head of every wave); else the search
+  if (n > 0) {
+    const int g = (int)(((long long)p * n_ref) / n);
+    if (g >= 0 && g < n_ref) { const int b = ref_frames[g].unit_begin; if (p >= b && p < b + ref_frames[g].feat_n) return g; }
+  }
   int lo = 0, hi = n_ref;
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ref_frames[mid].unit_begin <= p) lo = mid; else hi = mid; }
   return lo;
@@ -2333,14 +2339,15 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
   const double* ws_f = nullptr;
   if (live && a.whole_sets) {
     // slot p of the launch = place q of reference frame ri's tile order = feature perm[q] = unit unit_begin + perm[q] of the caller
-    ri = whole_sets_frame_of(a.ref_frames, a.n_ref_frames, slot_i);
+    ri = whole_sets_frame_of(a.ref_frames, a.n_ref_frames, slot_i, a.n);
     const DevFrameView& rv = a.ref_frames[ri];
     ws_q = slot_i - rv.unit_begin;
     if (ws_q >= 0 && ws_q < rv.feat_n) {
       i = rv.unit_begin + rv.feat_perm[ws_q];
       pxr = rv.feat_spx[2 * ws_q]; pyr = rv.feat_spx[2 * ws_q + 1]; gx = rv.feat_sgrad[2 * ws_q]; gy = rv.feat_sgrad[2 * ws_q + 1];
       level = rv.feat_slevel[ws_q]; ws_f = rv.feat_sf;
-      ci = a.cur_frame_idx ? a.cur_frame_idx[i] : 0; type = a.type[i];
+      ci = a.cur_frame_idx ? a.cur_frame_idx[rv.unit_begin] : 0;   // (a set's seeds go into ONE current frame: read at its first unit)
+      type = a.type[i];
     } else { ri = -1; }   // (cannot happen: the host checked that the sets' sizes add up to n)
   } else if (live) {
     if (rec_in) {
@@ -2903,7 +2910,7 @@ static int run_matcher(svoh_ctx* ctx, bool seeds, const svoh_matcher_options* mo
   SVOH_REQUIRE(ctx, fb->layout == SVOH_BATCH_UNITS || (whole_sets && seeds && fb->mem_space == SVOH_MEM_DEVICE && !ctx->matcher_deferred),
                "svoh_feature_batch::layout: SVOH_BATCH_WHOLE_SETS is for seed batches over resident columns, staged (svoh_matcher_stage) or with device arrays");
   const bool on_device = fb->mem_space == SVOH_MEM_DEVICE;
-  SVOH_REQUIRE(ctx, fb->ref_frame_idx && fb->px && fb->f && fb->grad && fb->level && fb->type, "NULL feature array");
+  SVOH_REQUIRE(ctx, fb->type && (whole_sets || (fb->ref_frame_idx && fb->px && fb->f && fb->grad && fb->level)), "NULL feature array");
   if (seeds) SVOH_REQUIRE(ctx, dopt && state && success, "NULL seed argument");
   else SVOH_REQUIRE(ctx, depth && px_cur && result, "NULL match argument");
   const int n_cur = (fb->cur_frame_idx && fb->n_cur_frames > 0) ? fb->n_cur_frames : 1;
@@ -4106,7 +4113,7 @@ __global__ void matcher_prologue_kernel(PrologueBatch b0, PrologueBatch b1, int 
   const int i = ((int)blockIdx.x - (second ? blocks0 : 0)) * (int)blockDim.x + (int)threadIdx.x;
   if (b.fidx && i < b.n) {
     int r, j;
-    if (b.whole_sets) { r = whole_sets_frame_of(b.views, b.n_ref, i); j = i - b.views[r].unit_begin; b.ref_idx[i] = r; }
+    if (b.whole_sets) { r = whole_sets_frame_of(b.views, b.n_ref, i, b.n); j = i - b.views[r].unit_begin; b.ref_idx[i] = r; }
     else { r = b.ref_idx[i]; j = b.fidx[i]; }
     bool ok = r >= 0 && r < b.n_ref;
     const DevFrameView* v = ok ? &b.views[r] : nullptr;
