@@ -859,6 +859,13 @@ int svoh_detect_fill_features(const svoh_detector_options* options, int width, i
                               const uint64_t* edge_keys, const float* edge_angles, int max_n_features, double* px,
                               double* score, int32_t* level, double* grad, uint8_t* type, int32_t* n_features);
 
+/* feature_detection_utils::getAngleAtPixelUsingHistogram(img_pyr[level], px, 4) (feature_detection_utils.cpp:831-839, 947-1009) for n
+ * pixels of possibly different frames and levels in one call: bins[k] = the dominant bin (0 .. 35) of the smoothed 36-bin histogram of the
+ * 9x9 window's gradient directions; the angle is bins[k] * 2 pi / 36.  px: 2 x n integer pixels AT THAT LEVEL.  This is how
+ * FrameHandlerBase::upgradeSeedsToFeatures refreshes the direction of an edgelet it upgrades (frame_handler_base.cpp:893-901).  Blocking. */
+int svoh_histogram_angle_bins(svoh_ctx* ctx, int n_frames, const svoh_frame_t* frames, int n, const int32_t* frame_idx, const int32_t* level,
+                              const int32_t* px, int32_t* bins);
+
 /* ---- pose optimiser ----------------------------------- */
 
 /* PoseOptimizer::ErrorType (src/svo/include/svo/pose_optimizer.h:33) */

@@ -302,7 +302,7 @@ EXPORTS = [
     "svoh_host_alloc", "svoh_host_free", "svoh_build_pyramid_multi", "svoh_build_pyramid_multi_prefetch", "svoh_prefetch_fence",
     "svoh_sparse_align_geometry_key", "svoh_sparse_align_enqueue_keyed",
     "svoh_project_candidates_stage", "svoh_project_candidates_stage_ranges", "svoh_project_candidates_enqueue_staged", "svoh_project_candidates_enqueue_staged_units", "svoh_project_candidates_wait",
-    "svoh_matcher_stage", "svoh_detect_cells_batch", "svoh_detect_cells_batch_enqueue", "svoh_detect_cells_batch_collect", "svoh_detect_fill_features", "svoh_features_upload", "svoh_features_release", "svoh_select_matches_batch",
+    "svoh_matcher_stage", "svoh_detect_cells_batch", "svoh_detect_cells_batch_enqueue", "svoh_detect_cells_batch_collect", "svoh_detect_fill_features", "svoh_histogram_angle_bins", "svoh_features_upload", "svoh_features_release", "svoh_select_matches_batch",
 ]
 
 
@@ -438,6 +438,7 @@ def load(path=None):
     lib.svoh_detect_cells_batch.argtypes = [C.c_void_p, C.c_int, P(svoh_frame_t), P(svoh_detector_options), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svoh_detect_cells_batch_enqueue.argtypes = [C.c_void_p, C.c_int, P(svoh_frame_t), P(svoh_detector_options), C.c_void_p]
     lib.svoh_detect_cells_batch_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svoh_histogram_angle_bins.argtypes = [C.c_void_p, C.c_int, P(svoh_frame_t), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svoh_detect_fill_features.argtypes = [P(svoh_detector_options), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int32)]
     lib.svoh_build_pyramid_multi_prefetch.argtypes = lib.svoh_build_pyramid_multi.argtypes

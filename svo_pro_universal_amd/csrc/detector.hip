@@ -604,3 +604,86 @@ try {
   if (rc != SVOH_OK) return rc;
   return collect_detect_cells(ctx, corner_keys, edge_keys, edge_angles);
 } SVOH_ABI_CATCH(ctx)
+
+// ---- getAngleAtPixelUsingHistogram for given pixels of given frames (the refresh of an upgraded edgelet's direction) ---------------
+namespace svoh {
+struct AngleJob { int32_t frame, level, x, y; };
+// one lane per pixel: the dominant bin of the smoothed 36-bin histogram of the 9x9 window's gradient directions, magnitude-weighted
+// (feature_detection_utils.cpp:831-839, 947-1009; the arithmetic of edge_angle_body above)
+__global__ __launch_bounds__(64) void histogram_angle_bins_kernel(const DevImage* __restrict__ levels /* n_frames x SVOH_MAX_LEVELS */, const AngleJob* __restrict__ jobs,
+                                                                  int n, int32_t* __restrict__ bins)
+{
+  constexpr int n_bins = 36;
+  __shared__ double s_hist[64][n_bins + 1];
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= n) return;
+  const AngleJob j = jobs[k];
+  const DevImage im = levels[(size_t)j.frame * SVOH_MAX_LEVELS + j.level];
+  double* hist = s_hist[threadIdx.x];
+  for (int i = 0; i < n_bins; ++i) hist[i] = 0.0;
+  const double pi = 3.14159265358979323846, pi2 = 2.0 * 3.14159265358979323846;
+  for (int dy = -4; dy <= 4; ++dy)
+    for (int dx = -4; dx <= 4; ++dx) {
+      const int x = j.x + dx, y = j.y + dy;
+      if (y > 0 && y < im.h - 1 && x > 0 && x < im.w - 1) {
+        const uint8_t* q = im.data + (size_t)y * im.pitch + x;
+        const double gx = (double)((int)q[1] - (int)q[-1]);
+        const double gy = (double)((int)q[im.pitch] - (int)q[-(ptrdiff_t)im.pitch]);
+        const double mag = sqrt(gx * gx + gy * gy);
+        const double ang = atan2(gy, gx);
+        size_t bin = (size_t)round(n_bins * (ang + pi) / pi2);
+        bin = (bin < (size_t)n_bins) ? bin : 0u;
+        hist[bin] += mag;
+      }
+    }
+  double prev = hist[n_bins - 1];
+  const double h0 = hist[0];
+  for (int i = 0; i < n_bins; ++i) {
+    const double tmp = hist[i];
+    hist[i] = 0.25 * prev + 0.5 * hist[i] + 0.25 * ((i + 1 == n_bins) ? h0 : hist[i + 1]);
+    prev = tmp;
+  }
+  double max_v = hist[0];
+  int max_bin = 0;
+  for (int i = 1; i < n_bins; ++i)
+    if (hist[i] > max_v) { max_v = hist[i]; max_bin = i; }
+  bins[k] = max_bin;
+}
+}  // namespace svoh
+
+extern "C" int svoh_histogram_angle_bins(svoh_ctx* ctx, int n_frames, const svoh_frame_t* frames, int n, const int32_t* frame_idx, const int32_t* level,
+                                         const int32_t* px, int32_t* bins)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, n >= 0 && n_frames >= 0 && n_frames <= (1 << 16) && n <= (1 << 24), "bad arguments");
+  if (n == 0) return SVOH_OK;
+  SVOH_REQUIRE(ctx, frames && frame_idx && level && px && bins && n_frames >= 1, "NULL argument");
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  const size_t o_lv = 0, o_jobs = al(sizeof(DevImage) * SVOH_MAX_LEVELS * (size_t)n_frames), o_bins = o_jobs + al(sizeof(AngleJob) * (size_t)n), total = o_bins + al(4 * (size_t)n);
+  SVOH_HIP_TRY(ctx, ctx->h_scratch1.reserve(total));
+  SVOH_HIP_TRY(ctx, ctx->d_scratch1.reserve(total));
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_scratch1.ptr);
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_scratch1.ptr);
+  DevImage* lv = reinterpret_cast<DevImage*>(h + o_lv);
+  std::vector<int> n_levels((size_t)n_frames);
+  for (int f = 0; f < n_frames; ++f) {
+    const Frame* fr = find_frame(ctx, frames[f]);
+    if (!fr) return set_error(ctx, SVOH_ERR_BAD_HANDLE, "unknown frame handle %llu", (unsigned long long)frames[f]);
+    n_levels[(size_t)f] = fr->n_levels;
+    for (int l = 0; l < SVOH_MAX_LEVELS; ++l) lv[(size_t)f * SVOH_MAX_LEVELS + l] = l < fr->n_levels ? fr->lv[l] : DevImage{ nullptr, 0, 0, 0, 0 };
+  }
+  AngleJob* jobs = reinterpret_cast<AngleJob*>(h + o_jobs);
+  for (int k = 0; k < n; ++k) {
+    SVOH_REQUIRE(ctx, frame_idx[k] >= 0 && frame_idx[k] < n_frames && level[k] >= 0 && level[k] < n_levels[(size_t)frame_idx[k]], "frame index or level out of range");
+    jobs[k] = AngleJob{ frame_idx[k], level[k], px[2 * k], px[2 * k + 1] };
+  }
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, o_bins));
+  hipLaunchKernelGGL(histogram_angle_bins_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, reinterpret_cast<const DevImage*>(d + o_lv),
+                     reinterpret_cast<const AngleJob*>(d + o_jobs), n, reinterpret_cast<int32_t*>(d + o_bins));
+  SVOH_HIP_TRY(ctx, hipGetLastError());
+  SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + o_bins, d + o_bins, 4 * (size_t)n));
+  SVOH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(bins, h + o_bins, 4 * (size_t)n);
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)

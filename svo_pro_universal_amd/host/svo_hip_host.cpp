@@ -422,8 +422,14 @@ size_t DepthFilterHip::finishUpdateSeedsNow()
   for (size_t k = 0; k < q.frames.size(); ++k) {
     Frame& r = *q.frames[k];
     const size_t n = q.counts[k];
-    std::copy(q.state.begin() + 4 * off, q.state.begin() + 4 * (off + n), r.invmu_sigma2_a_b_vec_.begin());
-    std::copy(q.type.begin() + off, q.type.begin() + off + n, r.type_vec_.begin());
+    // (a seed that became a feature while its update was in flight -- upgradeSeedsToFeatures at a keyframe made between the
+    // update's launch and here -- keeps what the upgrade made of it; units that were no seeds when the update was queued
+    // are not touched by the device either)
+    for (size_t i = 0; i < n; ++i) {
+      if (r.type_vec_[i] >= SVOH_FT_EDGELET) continue;
+      std::copy(q.state.begin() + 4 * (off + i), q.state.begin() + 4 * (off + i + 1), r.invmu_sigma2_a_b_vec_.begin() + 4 * i);
+      r.type_vec_[i] = q.type[off + i];
+    }
     off += n;
   }
   q.frames.clear();
@@ -2015,67 +2021,171 @@ void matchCandidatesFused(svoh_ctx* ctx, const FramePtr& frame, bool affine_est_
 }  // namespace reprojector_utils
 
 // ---- structure optimisation -------------------------------------------------------
+int StructureBatch::gather(const Frame& frame, int max_n_pts)
+{
+  pts.clear(); views.clear(); obs_begin.assign(1, 0); obs_view.clear(); obs_f.clear(); pos.clear();
+  stamp = frame.id_;
+  for (size_t i = 0; i < frame.num_features_; ++i) {
+    if (i >= frame.landmark_vec_.size() || frame.landmark_vec_[i] == nullptr) continue;
+    const uint8_t t = frame.type_vec_[i];   // isEdgelet (types.h:113-118)
+    if (t == SVOH_FT_EDGELET || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_EDGELET_SEED_CONVERGED) continue;
+    pts.push_back(frame.landmark_vec_[i]);
+  }
+  if (max_n_pts > 0) {
+    // the reference partitions the candidates here and then still loops over all of them (:804-819)
+    const size_t n = std::min(static_cast<size_t>(max_n_pts), pts.size());
+    max_n_pts = static_cast<int>(n);
+    std::nth_element(pts.begin(), pts.begin() + n, pts.end(),
+                     [](const PointPtr& lhs, const PointPtr& rhs) { return lhs->last_structure_optim_ < rhs->last_structure_optim_; });
+  }
+  // views = the frames the observations live in
+  std::vector<const Frame*> view_frames;
+  pos.resize(3 * pts.size());
+  for (size_t k = 0; k < pts.size(); ++k) {
+    const Point& pt = *pts[k];
+    pos[3 * k] = pt.pos_.x; pos[3 * k + 1] = pt.pos_.y; pos[3 * k + 2] = pt.pos_.z;
+    for (const Point::Obs& obs : pt.obs_) {
+      const FramePtr f = obs.frame.lock();
+      if (!f) continue;   // "could not unlock weak_ptr<Frame> in Point::optimize": the observation is skipped
+      size_t v = 0;
+      while (v < view_frames.size() && view_frames[v] != f.get()) ++v;
+      if (v == view_frames.size()) {
+        view_frames.push_back(f.get());
+        svoh_se3 T;
+        svoh::store_rigid(f->T_f_w_, T);
+        views.push_back(T);
+      }
+      obs_view.push_back(static_cast<int32_t>(v));
+      for (int c = 0; c < 3; ++c) obs_f.push_back(f->f_vec_[3 * obs.keypoint_index_ + c]);
+    }
+    obs_begin.push_back(static_cast<int32_t>(obs_view.size()));
+  }
+  return max_n_pts;
+}
+
+void StructureBatch::apply(const double* pos_out)
+{
+  for (size_t k = 0; k < pts.size(); ++k) {
+    pts[k]->pos_ = svoh::Vec3{ pos_out[3 * k], pos_out[3 * k + 1], pos_out[3 * k + 2] };
+    pts[k]->last_structure_optim_ = stamp;
+  }
+}
+
 size_t optimizeStructure(svoh_ctx* ctx, const FrameBundle::Ptr& frames, int max_n_pts, int max_iter)
 {
   if (!ctx) throw std::runtime_error("optimizeStructure: NULL svoh_ctx (no CPU fallback exists)");
   if (!frames) throw std::runtime_error("optimizeStructure: NULL frame bundle");
   if (max_n_pts == 0) return 0;   // -1 = optimise all points (frame_handler_base.cpp:785-786)
   size_t n_total = 0;
+  StructureBatch b;
   for (const FramePtr& frame : frames->frames_) {
     const bool optimize_on_sphere = false;   // Camera::Type::kOmni only (:794-796); svoh_camera has no such model
-    std::vector<PointPtr> pts;
-    for (size_t i = 0; i < frame->num_features_; ++i) {
-      if (i >= frame->landmark_vec_.size() || frame->landmark_vec_[i] == nullptr) continue;
-      const uint8_t t = frame->type_vec_[i];   // isEdgelet (types.h:113-118)
-      if (t == SVOH_FT_EDGELET || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_EDGELET_SEED_CONVERGED) continue;
-      pts.push_back(frame->landmark_vec_[i]);
-    }
-    if (max_n_pts > 0) {
-      // the reference partitions the candidates here and then still loops over all of them (:804-819)
-      const size_t n = std::min(static_cast<size_t>(max_n_pts), pts.size());
-      max_n_pts = static_cast<int>(n);
-      std::nth_element(pts.begin(), pts.begin() + n, pts.end(),
-                       [](const PointPtr& lhs, const PointPtr& rhs) { return lhs->last_structure_optim_ < rhs->last_structure_optim_; });
-    }
-    if (pts.empty()) continue;
-    // one device call for the frame's landmarks: views = the frames the observations live in
-    std::vector<const Frame*> view_frames;
-    std::vector<svoh_se3> views;
-    std::vector<int32_t> obs_begin(1, 0), obs_view;
-    std::vector<double> obs_f, pos(3 * pts.size());
-    for (size_t k = 0; k < pts.size(); ++k) {
-      const Point& pt = *pts[k];
-      pos[3 * k] = pt.pos_.x; pos[3 * k + 1] = pt.pos_.y; pos[3 * k + 2] = pt.pos_.z;
-      for (const Point::Obs& obs : pt.obs_) {
-        const FramePtr f = obs.frame.lock();
-        if (!f) continue;   // "could not unlock weak_ptr<Frame> in Point::optimize": the observation is skipped
-        size_t v = 0;
-        while (v < view_frames.size() && view_frames[v] != f.get()) ++v;
-        if (v == view_frames.size()) {
-          view_frames.push_back(f.get());
-          svoh_se3 T;
-          svoh::store_rigid(f->T_f_w_, T);
-          views.push_back(T);
-        }
-        obs_view.push_back(static_cast<int32_t>(v));
-        for (int c = 0; c < 3; ++c) obs_f.push_back(f->f_vec_[3 * obs.keypoint_index_ + c]);
-      }
-      obs_begin.push_back(static_cast<int32_t>(obs_view.size()));
-    }
+    max_n_pts = b.gather(*frame, max_n_pts);
+    if (b.pts.empty()) continue;
     // Point::optimize returns before touching anything when obs_.size() < 2 (point.cpp:255-259); the device applies
     // the same rule to the observations it is given.  (The two differ only for a landmark whose stored observations
     // are >= 2 while fewer than two of their frames are still alive, which the reference reports as an error.)
-    const int rc = svoh_optimize_points_batch(ctx, max_iter, optimize_on_sphere ? 1 : 0, static_cast<int>(views.size()), views.data(),
-                                              static_cast<int>(pts.size()), obs_begin.data(), obs_view.data(), obs_f.data(),
-                                              pos.data(), nullptr);
+    const int rc = svoh_optimize_points_batch(ctx, max_iter, optimize_on_sphere ? 1 : 0, static_cast<int>(b.views.size()), b.views.data(),
+                                              static_cast<int>(b.pts.size()), b.obs_begin.data(), b.obs_view.data(), b.obs_f.data(),
+                                              b.pos.data(), nullptr);
     if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_optimize_points_batch: ") + svoh_last_error_string(ctx));
-    for (size_t k = 0; k < pts.size(); ++k) {
-      pts[k]->pos_ = svoh::Vec3{ pos[3 * k], pos[3 * k + 1], pos[3 * k + 2] };
-      pts[k]->last_structure_optim_ = frame->id_;
-    }
-    n_total += pts.size();
+    b.apply(b.pos.data());
+    n_total += b.pts.size();
   }
   return n_total;
+}
+
+// ---- FrameHandlerBase::upgradeSeedsToFeatures (frame_handler_base.cpp:828-920) -----------------------------------
+size_t upgradeSeedsToFeatures(const FramePtr& frame, int* next_point_id, std::vector<size_t>* edgelets)
+{
+  if (!frame || !next_point_id || !edgelets) throw std::runtime_error("upgradeSeedsToFeatures: NULL argument");
+  Frame& fr = *frame;
+  const size_t n = fr.num_features_;
+  if (fr.landmark_vec_.size() < n) fr.landmark_vec_.resize(n);
+  if (fr.seed_ref_vec_.size() < n) fr.seed_ref_vec_.resize(n);
+  if (fr.track_id_vec_.size() < n) fr.track_id_vec_.resize(n, -1);
+  auto is_corner = [](uint8_t t) { return t == SVOH_FT_CORNER || t == SVOH_FT_CORNER_SEED || t == SVOH_FT_CORNER_SEED_CONVERGED; };       // types.h:106-111
+  auto is_map_pt = [](uint8_t t) { return t == SVOH_FT_MAPPOINT || t == SVOH_FT_MAPPOINT_SEED || t == SVOH_FT_MAPPOINT_SEED_CONVERGED; }; // :120-125
+  auto is_edgelet = [](uint8_t t) { return t == SVOH_FT_EDGELET || t == SVOH_FT_EDGELET_SEED || t == SVOH_FT_EDGELET_SEED_CONVERGED; };  // :113-118
+  size_t update_count = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (fr.landmark_vec_[i]) {
+      // (corner / edgelet / map point, or a fixed landmark: either way) landmark_vec_[i]->addObservation(frame, i)
+      fr.landmark_vec_[i]->obs_.push_back(Point::Obs{ frame, i });
+    } else if (fr.seed_ref_vec_[i].keyframe) {
+      Frame::SeedRef& ref = fr.seed_ref_vec_[i];
+      Frame& kf = *ref.keyframe;
+      const size_t sid = static_cast<size_t>(ref.seed_id);
+      if (kf.landmark_vec_.size() < kf.num_features_) kf.landmark_vec_.resize(kf.num_features_);
+      if (kf.track_id_vec_.size() < kf.num_features_) kf.track_id_vec_.resize(kf.num_features_, -1);
+      // in the multi-camera case another frame of the bundle may have made this seed's point already
+      PointPtr point = kf.landmark_vec_[sid];
+      if (!point) {
+        // xyz_world = T_world_cam * getSeedPosInFrame(seed_id) (seed.h:145-149: f * depth)
+        const double depth = kf.getSeedDepth(sid);
+        point = std::make_shared<Point>();
+        point->pos_ = svoh::transform(svoh::inverse(kf.T_f_w_), svoh::Vec3{ kf.f_vec_[3 * sid] * depth, kf.f_vec_[3 * sid + 1] * depth, kf.f_vec_[3 * sid + 2] * depth });
+        point->id_ = (*next_point_id)++;
+        kf.landmark_vec_[sid] = point;
+        kf.track_id_vec_[sid] = point->id();
+        point->obs_.push_back(Point::Obs{ ref.keyframe, sid });
+      }
+      fr.landmark_vec_[i] = point;
+      fr.track_id_vec_[i] = point->id();
+      point->obs_.push_back(Point::Obs{ frame, i });
+      const uint8_t kt = kf.type_vec_[sid];
+      if (is_corner(kt)) { kf.type_vec_[sid] = SVOH_FT_CORNER; fr.type_vec_[i] = SVOH_FT_CORNER; }
+      else if (is_map_pt(kt)) { kf.type_vec_[sid] = SVOH_FT_MAPPOINT; fr.type_vec_[i] = SVOH_FT_MAPPOINT; }
+      else if (is_edgelet(kt)) { kf.type_vec_[sid] = SVOH_FT_EDGELET; fr.type_vec_[i] = SVOH_FT_EDGELET; edgelets->push_back(i); }
+      else throw std::runtime_error("upgradeSeedsToFeatures: Seed-Type not known");   // CHECK(false)
+      ++update_count;
+      // (a self reference -- the harness' stand-in for the initialiser's landmarks -- is a reference like any other)
+      ref.keyframe.reset();
+      ref.seed_id = -1;
+    }
+  }
+  return update_count;
+}
+
+void refreshEdgeletDirections(svoh_ctx* ctx, const std::vector<FramePtr>& frames, const std::vector<std::vector<size_t>>& edgelets)
+{
+  if (!ctx) throw std::runtime_error("refreshEdgeletDirections: NULL svoh_ctx (no CPU fallback exists)");
+  if (frames.size() != edgelets.size()) throw std::runtime_error("refreshEdgeletDirections: one list per frame");
+  std::vector<svoh_frame_t> handles;
+  std::vector<int32_t> fidx, level, px;
+  for (size_t k = 0; k < frames.size(); ++k) {
+    if (edgelets[k].empty()) continue;
+    const Frame& f = *frames[k];
+    const int32_t slot = static_cast<int32_t>(handles.size());
+    handles.push_back(f.pyramid);
+    for (size_t i : edgelets[k]) {
+      const int lv = f.level_vec_[i];
+      fidx.push_back(slot); level.push_back(lv);
+      // (frame->px_vec_.col(i) / (1 << level)).cast<int>(): truncation
+      px.push_back(static_cast<int32_t>(f.px_vec_[2 * i] / static_cast<double>(1 << lv)));
+      px.push_back(static_cast<int32_t>(f.px_vec_[2 * i + 1] / static_cast<double>(1 << lv)));
+    }
+  }
+  if (fidx.empty()) return;
+  std::vector<int32_t> bins(fidx.size());
+  if (svoh_histogram_angle_bins(ctx, static_cast<int>(handles.size()), handles.data(), static_cast<int>(fidx.size()), fidx.data(), level.data(), px.data(), bins.data()) != SVOH_OK)
+    throw std::runtime_error(std::string("svoh_histogram_angle_bins: ") + svoh_last_error_string(ctx));
+  size_t at = 0;
+  for (size_t k = 0; k < frames.size(); ++k)
+    for (size_t i : edgelets[k]) {
+      const double angle = static_cast<double>(bins[at++]) * 2.0 * 3.14159265358979323846 / 36.0;   // getDominantAngle (:1001-1009)
+      frames[k]->grad_vec_[2 * i] = std::cos(angle);
+      frames[k]->grad_vec_[2 * i + 1] = std::sin(angle);
+    }
+}
+
+void removeObservationsOf(const Frame& frame)
+{
+  for (size_t i = 0; i < frame.num_features_ && i < frame.landmark_vec_.size(); ++i) {
+    if (!frame.landmark_vec_[i]) continue;
+    std::vector<Point::Obs>& obs = frame.landmark_vec_[i]->obs_;
+    obs.erase(std::remove_if(obs.begin(), obs.end(), [&](const Point::Obs& o) { const FramePtr f = o.frame.lock(); return !f || f.get() == &frame; }), obs.end());
+  }
 }
 
 // ---- key points and the keyframe map ----------------------------------------------

@@ -744,6 +744,43 @@ class PoseOptimizerHip {
 // and stamped; max_n_pts == 0 returns at once.  Returns the number of landmarks handed to the optimiser.
 // ---------------------------------------------------------------------------
 size_t optimizeStructure(svoh_ctx* ctx, const FrameBundle::Ptr& frames, int max_n_pts, int max_iter);
+// The same in phases, for callers that put the landmarks of MANY frames (one per camera stream) into one device call
+// (FrontendLockstep): gather() is optimizeStructure's selection and staging for ONE frame; the caller runs
+// svoh_optimize_points_batch over the batch (or over several batches laid side by side: view indices are the batch's own)
+// and hands the optimised positions to apply().
+struct StructureBatch {
+  std::vector<PointPtr> pts;
+  int stamp = 0;                                  // the frame's id: last_structure_optim_ of every point handed in
+  std::vector<svoh_se3> views;
+  std::vector<int32_t> obs_begin, obs_view;       // obs_begin: pts.size() + 1 entries
+  std::vector<double> obs_f, pos;
+  // returns max_n_pts as the reference leaves it for the next frame of a bundle (frame_handler_base.cpp:806)
+  int gather(const Frame& frame, int max_n_pts);
+  void apply(const double* pos_out);
+  size_t size() const { return pts.size(); }
+};
+
+// FrameHandlerBase::upgradeSeedsToFeatures (frame_handler_base.cpp:828-920), what the frame handler does to a frame it has
+// selected as keyframe: every feature with a landmark adds itself to the landmark's observations; every feature that hangs on
+// a seed of an older keyframe -- converged or not -- turns that seed into a landmark (a new Point at the seed's position, observed
+// by the keyframe and by this frame; an existing one when another frame of the bundle made it already) and both features into
+// corner / edgelet / map-point features; an upgraded edgelet's direction is refreshed from this frame's image
+// (getAngleAtPixelUsingHistogram, :893-901).  Two steps, so that a driver of many streams makes ONE device call for the
+// directions of all of them: the host part (returns the number of upgraded features, appends the upgraded edgelets' feature
+// indices to *edgelets), then refreshEdgeletDirections for any number of frames.  next_point_id: the caller's counter of
+// Point ids (Point::id(), point.cpp's global counter).
+size_t upgradeSeedsToFeatures(const FramePtr& frame, int* next_point_id, std::vector<size_t>* edgelets);
+void refreshEdgeletDirections(svoh_ctx* ctx, const std::vector<FramePtr>& frames, const std::vector<std::vector<size_t>>& edgelets);
+inline size_t upgradeSeedsToFeatures(svoh_ctx* ctx, const FramePtr& frame, int* next_point_id)
+{
+  std::vector<std::vector<size_t>> e(1);
+  const size_t n = upgradeSeedsToFeatures(frame, next_point_id, &e[0]);
+  refreshEdgeletDirections(ctx, { frame }, e);
+  return n;
+}
+// A keyframe leaves the map: its observations leave its landmarks (Map::removeKeyframe's loop over Point::removeObservation,
+// map.cpp:64-93, point.cpp:60-66)
+void removeObservationsOf(const Frame& frame);
 
 // ---------------------------------------------------------------------------
 // The part of svo::Map the reprojector's caller uses (second half): keyframe container and

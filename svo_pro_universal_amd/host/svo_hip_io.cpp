@@ -336,6 +336,7 @@ FrontendParams frontendParamsFromYaml(const YamlNode& node)
   p.detector.threshold_primary = node["detector_threshold_primary"].asInt(10);
   p.detector.threshold_secondary = node["detector_threshold_secondary"].asInt(200);
   p.detector.detector_type = node["use_edgelets"].asBool(true) ? DetectorType::kFastGrad : DetectorType::kFast;
+  p.structure_optimization_max_pts = node["structure_optimization_max_pts"].asInt(20);
   p.tracker.klt_max_level = node["klt_max_level"].asInt(4);
   p.tracker.klt_min_level = node["klt_min_level"].asInt(0);
   return p;

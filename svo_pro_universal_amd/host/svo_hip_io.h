@@ -63,6 +63,7 @@ struct FrontendParams {
   DetectorOptions detector;                  // grid_size, n_pyr_levels, detector_threshold_*, use_edgelets
   FeatureTrackerOptions tracker;             // klt_* (svo_factory.cpp:305-306)
   int n_pyr_levels_to_build = 5;             // img_align_max_level + 1 (frame_handler_base.cpp:186)
+  int structure_optimization_max_pts = 20;   // structure_optimization_max_pts (svo_factory.cpp:122)
 };
 FrontendParams frontendParamsFromYaml(const YamlNode& node);
 FrontendParams loadFrontendParams(const std::string& param_yaml_path);

@@ -30,7 +30,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 namespace {
 enum Phase { kPhPyramid = 0, kPhFinishSeeds, kPhAlignPrep, kPhAlignLaunch, kPhProjGather, kPhAlignWait, kPhWalkPlan, kPhMatchStage, kPhMatchCopy, kPhMatchSubmit, kPhSort,
-             kPhMatchWait, kPhReplay, kPhPoseCall, kPhPoseApply, kPhSeedStage, kPhSeedGather, kPhSeedSubmit, kPhKeyframe, kPhSeedWait, kPhDetectWait, kPhPrefetch, kPhRest };
+             kPhMatchWait, kPhReplay, kPhPoseCall, kPhPoseApply, kPhSeedStage, kPhSeedGather, kPhSeedSubmit, kPhKeyframe, kPhSeedWait, kPhDetectWait, kPhPrefetch, kPhStructure, kPhRest };
 struct PhaseClock {
   double* acc; double t;
   explicit PhaseClock(double* a) : acc(a), t(now_ms()) {}
@@ -41,7 +41,7 @@ struct PhaseClock {
 const char* FrontendLockstep::phaseName(int k)
 {
   static const char* names[] = { "pyramid", "finish seeds", "align prep", "align launch", "projection gather", "align wait", "walk + plan", "match stage", "match copy",
-                                 "match submit", "sort", "match wait", "replay + pose prep", "pose call", "pose apply", "seed stage", "seed gather", "seed submit", "keyframe", "seed wait", "detect wait", "prefetch", "rest" };
+                                 "match submit", "sort", "match wait", "replay + pose prep", "pose call", "pose apply", "seed stage", "seed gather", "seed submit", "keyframe", "seed wait", "detect wait", "prefetch", "structure", "rest" };
   return k >= 0 && k < (int)(sizeof names / sizeof names[0]) ? names[k] : "";
 }
 
@@ -80,6 +80,11 @@ struct FrontendLockstep::Stream {
   std::vector<FramePtr> seed_frames;
   std::vector<size_t> seed_counts;
   size_t seed_off = 0, seed_n = 0;
+  // landmarks
+  StructureBatch structure;
+  size_t structure_off = 0, structure_view_off = 0, structure_obs_off = 0;
+  std::vector<size_t> upgraded_edgelets;
+  int next_point_id = 0;
   // bookkeeping
   FrameRow row;
   bool row_open = false;
@@ -205,9 +210,14 @@ void FrontendLockstep::finishSeedUpdate()
       for (size_t k = 0; k < st.seed_frames.size(); ++k) {
         Frame& r = *st.seed_frames[k];
         const size_t n = st.seed_counts[k];
-        std::copy(ss.state + 4 * off, ss.state + 4 * (off + n), r.invmu_sigma2_a_b_vec_.begin());
-        std::copy(ss.type + off, ss.type + off + n, r.type_vec_.begin());
-        for (size_t i = 0; i < n; ++i) n_success += ss.success[off + i];
+        // (a seed that became a feature while its update was in flight -- a keyframe made between the update's launch and here
+        // upgraded it -- keeps what the upgrade made of it: the same rule as DepthFilterHip::finishUpdateSeedsNow)
+        for (size_t i = 0; i < n; ++i) {
+          n_success += ss.success[off + i];
+          if (r.type_vec_[i] >= SVOH_FT_EDGELET) continue;
+          std::copy(ss.state + 4 * (off + i), ss.state + 4 * (off + i + 1), r.invmu_sigma2_a_b_vec_.begin() + 4 * i);
+          r.type_vec_[i] = ss.type[off + i];
+        }
         off += n;
       }
       st.seed_frames.clear(); st.seed_counts.clear(); st.seed_n = 0;
@@ -269,6 +279,20 @@ void FrontendLockstep::makeKeyframes(const std::vector<int>& which)
     if (detect_.in_flight) { detect_.in_flight = false; (void)svoh_detect_cells_batch_collect(ctx_, nullptr, nullptr, nullptr); }   // (cannot happen: started for a subset of `which`)
     return;
   }
+  // the frame handler's step at a new keyframe (frame_handler_mono.cpp:186): the seeds a new keyframe's features hang on become landmarks --
+  // the host part per stream on the pool, the refreshed directions of all streams' upgraded edgelets in ONE device call.  (What the
+  // detector reads -- the features' pixels -- does not change: a detection started ahead stays what it is.)
+  if (opt_.landmarks) {
+    pool_.run(static_cast<int>(which.size()), [&](int w) {
+      Stream& st = *streams_[static_cast<size_t>(which[static_cast<size_t>(w)])];
+      st.upgraded_edgelets.clear();
+      upgradeSeedsToFeatures(st.frame, &st.next_point_id, &st.upgraded_edgelets);
+    });
+    std::vector<FramePtr> fr;
+    std::vector<std::vector<size_t>> ed;
+    for (int s : which) { Stream& st = *streams_[static_cast<size_t>(s)]; if (!st.upgraded_edgelets.empty()) { fr.push_back(st.frame); ed.push_back(st.upgraded_edgelets); } }
+    if (!fr.empty()) { refreshEdgeletDirections(ctx_, fr, ed); ++device_calls_; }
+  }
   const size_t n_cells = streams_[0]->detector.grid_.size();
   // streams whose detection was not started ahead (the tracked-features rule fired after the pose optimisation): now, blocking
   std::vector<int> late;
@@ -322,6 +346,7 @@ void FrontendLockstep::makeKeyframes(const std::vector<int>& which)
     st.kfs.push_back(f);
     while (st.kfs.size() > st.reprojector.options_.max_n_kfs) {
       for (auto& sr : st.kfs.front()->seed_ref_vec_) sr.keyframe.reset();   // break the self references
+      removeObservationsOf(*st.kfs.front());                                 // (Map::removeKeyframe)
       st.kfs.pop_front();
     }
   });
@@ -456,6 +481,8 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
       Stream& st = *stp;
       if (!st.active) continue;
       st.row.is_kf = st.want_kf;
+      st.row.n_landmarks = 0;
+      for (size_t i = 0; i < st.frame->num_features_ && i < st.frame->landmark_vec_.size(); ++i) st.row.n_landmarks += st.frame->landmark_vec_[i] != nullptr;
       st.row_open = true;
       // (the frame before this one lives on in b_last until the stream's next alignment set-up replaces the bundles -- on the
       // pool: taking a dozen frames apart here, on the group's thread, is 0.05 ms of every round)
@@ -862,6 +889,50 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
         st.row.n_pose = st.pose_optimizer.finishRun(st.b_cur, res[static_cast<size_t>(w)]);
       });
       pc.lap(kPhPoseApply);
+    }
+    // ---- 3b. structure optimisation (frame_handler_mono.cpp:157: optimizeStructure(new_frames_, max_pts, 5)): the landmarks of every
+    // stream's frame, gathered per stream on the pool, ONE svoh_optimize_points_batch for all of them (a stream's views and points are a
+    // slice of the call's; Point::optimize of one point does not see another), applied per stream.  It queues behind the depth filter's
+    // update on the context's stream: its wait is that update's wait.
+    if (opt_.landmarks) {
+      pool_.run(S, [&](int s) {
+        Stream& st = *streams_[static_cast<size_t>(s)];
+        if (!st.tracking) return;
+        st.structure.gather(*st.frame, st.so.params.structure_optimization_max_pts);
+      });
+      size_t n_pts = 0, n_views = 0, n_obs = 0;
+      for (int s : trk) {
+        Stream& st = *streams_[static_cast<size_t>(s)];
+        st.structure_off = n_pts; st.structure_view_off = n_views; st.structure_obs_off = n_obs;
+        if (st.so.params.structure_optimization_max_pts == 0) st.structure.pts.clear();   // (optimizeStructure returns at once)
+        n_pts += st.structure.size(); n_views += st.structure.size() ? st.structure.views.size() : 0; n_obs += st.structure.size() ? st.structure.obs_view.size() : 0;
+      }
+      if (n_pts) {
+        std::vector<svoh_se3> views(n_views);
+        std::vector<int32_t> obs_begin(n_pts + 1), obs_view(n_obs);
+        std::vector<double> obs_f(3 * n_obs), pos(3 * n_pts);
+        pool_.run(S, [&](int s) {
+          Stream& st = *streams_[static_cast<size_t>(s)];
+          if (!st.tracking || !st.structure.size()) return;
+          const StructureBatch& b = st.structure;
+          std::copy(b.views.begin(), b.views.end(), views.begin() + st.structure_view_off);
+          for (size_t k = 0; k < b.size(); ++k) obs_begin[st.structure_off + k] = b.obs_begin[k] + static_cast<int32_t>(st.structure_obs_off);
+          for (size_t k = 0; k < b.obs_view.size(); ++k) obs_view[st.structure_obs_off + k] = b.obs_view[k] + static_cast<int32_t>(st.structure_view_off);
+          std::copy(b.obs_f.begin(), b.obs_f.end(), obs_f.begin() + 3 * st.structure_obs_off);
+          std::copy(b.pos.begin(), b.pos.end(), pos.begin() + 3 * st.structure_off);
+        });
+        obs_begin[n_pts] = static_cast<int32_t>(n_obs);
+        check(svoh_optimize_points_batch(ctx_, 5, 0, static_cast<int>(n_views), views.data(), static_cast<int>(n_pts), obs_begin.data(), obs_view.data(), obs_f.data(), pos.data(), nullptr),
+              "svoh_optimize_points_batch");
+        ++device_calls_;
+        pool_.run(S, [&](int s) {
+          Stream& st = *streams_[static_cast<size_t>(s)];
+          if (!st.tracking || !st.structure.size()) return;
+          st.structure.apply(pos.data() + 3 * st.structure_off);
+          st.row.n_struct = st.structure.size();
+        });
+      }
+      pc.lap(kPhStructure);
     }
     const double t4 = now_ms();
     times_.pose = t4 - t3b;

@@ -13,6 +13,7 @@
 //   reprojection        one direct batch + one seed batch with S current frames  svoh_matcher_stage + svoh_match_direct_batch /
 //                                                                                svoh_update_seeds_batch_ex (cur_frame_idx)
 //   pose optimisation   S bundles                                                svoh_optimize_pose_batch
+//   structure optim.    the landmarks of all streams' frames                     svoh_optimize_points_batch
 //   depth filter        one seed batch over the keyframes of all streams         svoh_matcher_stage + svoh_update_seeds_batch
 //   keyframes           the detector for every new keyframe of the round         svoh_detect_cells_batch
 //
@@ -77,6 +78,11 @@ struct LockstepOptions {
   //                       that reaches an unplanned pass pauses its replay and gets a batch of its own
   //   kSpeculateAll       always          kSpeculateNever   never: every third pass goes through the paused replay (tests)
   enum Speculation { kSpeculateAsBefore = 0, kSpeculateAll = 1, kSpeculateNever = 2 } speculation = kSpeculateAsBefore;
+  // landmarks (round 6): a frame selected as keyframe upgrades the seeds its features hang on to points (svo_hip::upgradeSeedsToFeatures,
+  // frame_handler_base.cpp:828-920; the refreshed edgelet directions of all streams in one device call), and every frame's landmarks go
+  // through the structure optimisation (frame_handler_mono.cpp:157) -- all streams' points in ONE svoh_optimize_points_batch per round.
+  // false: the seed-only chain of round 5.
+  bool landmarks = true;
   // one entry per stream, or empty: every stream runs with params / depth_* / kf_every / min_tracked above
   std::vector<LockstepStreamOptions> per_stream;
 };
@@ -84,7 +90,7 @@ struct LockstepOptions {
 class FrontendLockstep {
  public:
   // what a stream's frame left behind (the columns of svoh_mini_frontend's frontend.csv)
-  struct FrameRow { size_t k = 0; bool is_kf = false; size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0, n_converged = 0; };
+  struct FrameRow { size_t k = 0; bool is_kf = false; size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0, n_converged = 0, n_struct = 0, n_landmarks = 0; };
   struct RoundTimes { double pyramid = 0, align = 0, reproject = 0, pose = 0, seeds = 0, keyframe = 0, total = 0; };   // ms, the round as a whole
 
   FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepOptions& options);

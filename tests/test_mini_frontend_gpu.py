@@ -13,6 +13,8 @@ from svo_pro_universal_amd import synth
 from test_io_cpu import write_png
 
 pytestmark = pytest.mark.gpu
+# frontend.csv: frame, is_kf, n_aligned, n_reprojected, n_after_pose_opt, n_seeds_updated, n_converged_seeds, [7 timing columns], n_points_optimized, n_landmarks
+COUNTER_COLS = [0, 1, 2, 3, 4, 5, 6, 14, 15]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
@@ -89,6 +91,10 @@ def test_mini_frontend_tracks_a_synthetic_sequence(tmp_path):
     assert np.median(fc[1:, 3]) > 80                      # the reprojector keeps enough features alive
     assert fc[-1, 6] > 100                                # seeds converge
     assert fc[:, 1].sum() >= 4                            # several keyframes were made
+    # round 6: keyframes upgrade seeds to landmarks, every later frame reprojects and optimises them
+    print("landmarks per frame: median %d (from frame 9 on), points through the structure optimisation per frame: median %d"
+          % (int(np.median(fc[9:, 15])), int(np.median(fc[9:, 14]))))
+    assert np.median(fc[9:, 15]) > 40 and np.median(fc[9:, 14]) > 20
 
 
 def test_streams_share_one_gpu(tmp_path):
@@ -124,7 +130,7 @@ def test_pipelined_flow_equals_the_blocking_flow(tmp_path):
         r = subprocess.run(cmd, capture_output=True, text=True, env=e)
         assert r.returncode == 0, r.stdout + r.stderr
         fc = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)
-        runs[name] = (open(str(out_dir / "trajectory.txt")).read(), fc[:, :7].copy(), fc[3:, 13].copy())
+        runs[name] = (open(str(out_dir / "trajectory.txt")).read(), fc[:, COUNTER_COLS].copy(), fc[3:, 13].copy())
         print(name, r.stdout.strip())
     assert runs["pipelined"][0] == runs["blocking"][0]
     assert np.array_equal(runs["pipelined"][1], runs["blocking"][1])
@@ -146,7 +152,7 @@ def test_lockstep_streams_reproduce_the_single_stream(tmp_path):
     r = subprocess.run(cmd + [str(n_frames), "8", "1"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     single = open(str(out_dir / "trajectory.txt")).read()
-    single_counters = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)[:, :7].copy()
+    single_counters = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)[:, COUNTER_COLS].copy()
     assert len(single.splitlines()) == n_frames + 1   # header line
     for n_streams, n_workers, n_groups in ((1, 1, 1), (5, 1, 1), (8, 3, 1), (12, 2, 2)):
         for d in [out_dir] + [out_dir / ("stream%d" % k) for k in range(1, 64)]:
@@ -159,7 +165,7 @@ def test_lockstep_streams_reproduce_the_single_stream(tmp_path):
         for k in range(n_streams):
             d = out_dir if k == 0 else out_dir / ("stream%d" % k)
             assert open(str(d / "trajectory.txt")).read() == single, "stream %d of %d (workers %d, groups %d)" % (k, n_streams, n_workers, n_groups)
-            counters = np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :7]
+            counters = np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, COUNTER_COLS]
             assert np.array_equal(counters, single_counters), "counters of stream %d of %d" % (k, n_streams)
 
 
@@ -182,7 +188,7 @@ def test_lockstep_variants_and_the_tracked_features_rule(tmp_path):
         out = []
         for k in range(n_streams):
             d = out_dir if k == 0 else out_dir / ("stream%d" % k)
-            out.append((open(str(d / "trajectory.txt")).read(), np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :7].copy()))
+            out.append((open(str(d / "trajectory.txt")).read(), np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, COUNTER_COLS].copy()))
         return out
     for kf_every in ("8", "1000"):
         # (without periodic keyframes the rule must fire: the sequence keeps all 180 features of a frame tracked, so the bar is 181 -- a keyframe per frame, each by the rule)
@@ -252,7 +258,7 @@ def test_lockstep_of_streams_that_differ(tmp_path):
         r = subprocess.run(cmd + [str(n_frames), "8", "1"], capture_output=True, text=True, env=dict(os.environ, SVOH_MINI_SPEC=str(spec), SVOH_MINI_SPEC_LINE=str(i)))
         assert r.returncode == 0, r.stdout + r.stderr
         traj = open(str(out_dir / "trajectory.txt")).read()
-        counters = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)[:, :7].copy()
+        counters = np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)[:, COUNTER_COLS].copy()
         assert len(traj.splitlines()) == HETERO_STREAMS[i][2] + 1 and len(counters) == HETERO_STREAMS[i][2]
         singles.append((traj, counters))
     # the streams really differ: no two trajectories alike, keyframes at different frames, different numbers of aligned features
@@ -272,7 +278,7 @@ def test_lockstep_of_streams_that_differ(tmp_path):
         for k in range(S):
             d = out_dir if k == 0 else out_dir / ("stream%d" % k)
             assert open(str(d / "trajectory.txt")).read() == singles[k][0], "trajectory of stream %d (workers %d, groups %d)" % (k, n_workers, n_groups)
-            counters = np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :7]
+            counters = np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, COUNTER_COLS]
             assert np.array_equal(counters, singles[k][1]), "counters of stream %d (workers %d, groups %d)" % (k, n_workers, n_groups)
     # the speculation switches on the mix: same files
     for env in ({"SVOH_LOCKSTEP_SPECULATE": "never"}, {"SVOH_LOCKSTEP_SPECULATE": "all"}, {"SVOH_LOCKSTEP_RESIDENT": "0"}):
@@ -281,4 +287,4 @@ def test_lockstep_of_streams_that_differ(tmp_path):
         for k in range(S):
             d = out_dir if k == 0 else out_dir / ("stream%d" % k)
             assert open(str(d / "trajectory.txt")).read() == singles[k][0], (env, k)
-            assert np.array_equal(np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :7], singles[k][1]), (env, k)
+            assert np.array_equal(np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, COUNTER_COLS], singles[k][1]), (env, k)

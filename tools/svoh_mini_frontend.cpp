@@ -7,9 +7,15 @@
 //   depth-filter update of the keyframes' seeds                 DepthFilterHip::updateSeeds
 //   at keyframes: feature detection + seed initialisation       DetectorHip + depth_filter_utils::initializeSeeds
 //
+//   structure optimisation of the frame's landmarks              svo_hip::optimizeStructure (frame_handler_mono.cpp:157)
+//   at keyframes: the seeds the frame hangs on become landmarks   svo_hip::upgradeSeedsToFeatures (frame_handler_base.cpp:828-920)
+//
 // It is an integration harness, NOT the reference's frame handler: there is no map, no initialiser (the first
-// pose and a depth prior are given), no structure optimisation, no relocalisation, and keyframes are chosen by a
-// fixed rule (every <kf_every> frames or when fewer than <min_tracked> features survive).
+// pose and a depth prior are given), no relocalisation, and keyframes are chosen by a fixed rule (every <kf_every>
+// frames or when fewer than <min_tracked> features survive).  Round 6: landmarks -- a frame selected as keyframe upgrades
+// the seeds its features hang on to points, as the frame handler does, so that the reprojector's landmark pass, the
+// n_reproj ordering, landmark positions in the alignment and the pose optimiser, and the structure optimisation of every
+// frame are part of the chain (SVOH_MINI_LANDMARKS=0: the seed-only chain of rounds 2 - 5, for comparison).
 //
 //   svoh_mini_frontend <dataset_root> <calib.yaml> <params.yaml|-> <out_dir> <T_f_w of frame 0: qw qx qy qz tx ty tz>
 //                      <depth_min> <depth_mean> <depth_max> [max_frames] [kf_every] [n_streams] [threads|lockstep] [n_workers] [n_groups] [n_laps]
@@ -161,11 +167,16 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
     io::TrajectoryWriter traj(out_dir + "/trajectory.txt");
     FILE* fc = fopen((out_dir + "/frontend.csv").c_str(), "w");
     if (!fc) throw std::runtime_error("cannot write into " + out_dir);
-    fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_converged_seeds,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf,ms_frame\n");
+    fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_converged_seeds,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf,ms_frame,n_points_optimized,n_landmarks\n");
 
     std::deque<FramePtr> kfs;   // the last reprojector.max_n_kfs keyframes
     FramePtr last;
+    const bool landmarks_on = getenv("SVOH_MINI_LANDMARKS") == nullptr || atoi(getenv("SVOH_MINI_LANDMARKS")) != 0;
+    int next_point_id = 0;
     auto make_keyframe = [&](const FramePtr& f) {
+      // the frame handler's step at a new keyframe (frame_handler_mono.cpp:186): the seeds this frame's features hang on become
+      // landmarks (the seed update in flight, if any, leaves such a seed alone when it is written back: DepthFilterHip)
+      if (landmarks_on) upgradeSeedsToFeatures(ctx, f, &next_point_id);
       detector.resetGrid();
       detector.fillGridWithKeypoints(f->px_vec_, f->num_features_);
       const size_t n_old = f->num_features_;
@@ -176,6 +187,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
       kfs.push_back(f);
       while (kfs.size() > ropt.max_n_kfs) {
         for (auto& sr : kfs.front()->seed_ref_vec_) sr.keyframe.reset();   // break the self references
+        removeObservationsOf(*kfs.front());                                 // (Map::removeKeyframe)
         kfs.pop_front();
       }
     };
@@ -191,7 +203,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
     size_t n_done = 0;
     // a frame's CSV row is written once its seed update has been finished (at the start of the next frame in the
     // default flow): the counters of both flows are the same
-    struct Row { bool valid = false, finished = false; size_t k = 0, n_seed_upd = 0; int is_kf = 0; size_t n_aligned = 0, n_reproj = 0, n_pose = 0; double ms[7] = {0, 0, 0, 0, 0, 0, 0}; } row;
+    struct Row { bool valid = false, finished = false; size_t k = 0, n_seed_upd = 0; int is_kf = 0; size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_struct = 0, n_landmarks = 0; double ms[7] = {0, 0, 0, 0, 0, 0, 0}; } row;
     auto finish_row = [&]() {
       if (!row.valid) return;
       if (!row.finished) {
@@ -204,8 +216,8 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
       for (const FramePtr& f : kfs)
         for (size_t i = 0; i < f->num_features_; ++i)
           n_conv += f->type_vec_[i] == SVOH_FT_CORNER_SEED_CONVERGED || f->type_vec_[i] == SVOH_FT_EDGELET_SEED_CONVERGED;
-      fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", row.k, row.is_kf, row.n_aligned, row.n_reproj, row.n_pose,
-              n_seed_upd, n_conv, row.ms[0], row.ms[1], row.ms[2], row.ms[3], row.ms[4], row.ms[5], row.ms[6]);
+      fprintf(fc, "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%zu,%zu\n", row.k, row.is_kf, row.n_aligned, row.n_reproj, row.n_pose,
+              n_seed_upd, n_conv, row.ms[0], row.ms[1], row.ms[2], row.ms[3], row.ms[4], row.ms[5], row.ms[6], row.n_struct, row.n_landmarks);
       row.valid = false;
     };
     for (size_t k = 0; k < order.size(); ++k) {
@@ -226,7 +238,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
       const bool align_ahead = !sync_flow && align_ahead_on && k > 0 && depth_filter.updateInFlight();
       if (!align_ahead) finish_row();
       const double t1 = now_ms();
-      size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0;
+      size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0, n_struct = 0;
       bool seeds_finished = false;
       double t2 = t1, t3 = t1, t4 = t1, t5 = t1;
       bool is_kf = false;
@@ -268,6 +280,8 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
           if (sync_flow || no_prepare) n_pose = pose_optimizer.run(b_cur, 2.0);
           else n_pose = pose_optimizer.run(b_cur, 2.0, [&]() { depth_filter.prepareUpdateSeeds(visible, frame); });
         }
+        // 3b. structure optimisation of the frame's landmarks (frame_handler_mono.cpp:157: optimizeStructure(new_frames_, max_pts, 5))
+        if (landmarks_on) n_struct = optimizeStructure(ctx, b_cur, params.structure_optimization_max_pts, 5);
         t4 = now_ms();
         // 4. depth filter (frame_handler_mono.cpp:125)
         depth_filter.updateSeedsAsync(visible, frame);
@@ -282,6 +296,8 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
       const double t6 = now_ms();
       traj.write(seq.cam_ts[order[k]], svoh::inverse(frame->T_f_w_));
       row.valid = true; row.finished = seeds_finished || k == 0; row.n_seed_upd = n_seed_upd; row.k = k; row.is_kf = (int)is_kf; row.n_aligned = n_aligned; row.n_reproj = n_reproj; row.n_pose = n_pose;
+      row.n_struct = n_struct; row.n_landmarks = 0;
+      for (size_t i = 0; i < frame->num_features_ && i < frame->landmark_vec_.size(); ++i) row.n_landmarks += frame->landmark_vec_[i] != nullptr;
       row.ms[0] = t0f - t0; row.ms[1] = t2 - t1; row.ms[2] = t3 - t2; row.ms[3] = t4 - t3; row.ms[4] = t5 - t4; row.ms[5] = t6 - t5;
       row.ms[6] = t6 - t0;   // the frame as the caller's clock sees it, the previous frame's seed write-back included
       if (sync_flow) finish_row();
@@ -358,6 +374,7 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
       // the two switches the tests use (the rest of round 5's A/B switches is gone: HISTORY round 5 has their numbers)
       if (const char* sp = getenv("SVOH_LOCKSTEP_SPECULATE")) lo.speculation = std::string(sp) == "all" ? LockstepOptions::kSpeculateAll : std::string(sp) == "never" ? LockstepOptions::kSpeculateNever : LockstepOptions::kSpeculateAsBefore;
       if (getenv("SVOH_LOCKSTEP_RESIDENT")) lo.resident_features = atoi(getenv("SVOH_LOCKSTEP_RESIDENT")) != 0;
+      if (getenv("SVOH_MINI_LANDMARKS")) lo.landmarks = atoi(getenv("SVOH_MINI_LANDMARKS")) != 0;
       FrontendLockstep fe(ctx, n, lo);
       const bool last_lap = lap + 1 == n_laps;
       std::vector<std::unique_ptr<io::TrajectoryWriter>> traj;
@@ -369,7 +386,7 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
           traj.emplace_back(new io::TrajectoryWriter(dir + "/trajectory.txt"));
           FILE* fc = fopen((dir + "/frontend.csv").c_str(), "w");
           if (!fc) throw std::runtime_error("cannot write into " + dir);
-          fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_converged_seeds,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf,ms_frame\n");
+          fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_converged_seeds,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf,ms_frame,n_points_optimized,n_landmarks\n");
           csv.push_back(fc);
         }
       std::vector<FrontendLockstep::RoundTimes> times;
@@ -379,8 +396,8 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
           for (const FrontendLockstep::FrameRow& r : fe.completedRows(i)) {
             if (!last_lap) continue;
             const FrontendLockstep::RoundTimes& t = times.at(round_of[(size_t)i].at(r.k));
-            fprintf(csv[(size_t)i], "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", r.k, (int)r.is_kf, r.n_aligned, r.n_reproj, r.n_pose, r.n_seed_upd,
-                    r.n_converged, t.pyramid, t.align, t.reproject, t.pose, t.seeds, t.keyframe, t.total);
+            fprintf(csv[(size_t)i], "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f,%zu,%zu\n", r.k, (int)r.is_kf, r.n_aligned, r.n_reproj, r.n_pose, r.n_seed_upd,
+                    r.n_converged, t.pyramid, t.align, t.reproject, t.pose, t.seeds, t.keyframe, t.total, r.n_struct, r.n_landmarks);
           }
       };
       std::vector<const uint8_t*> ptrs((size_t)n), next((size_t)n);
