@@ -418,7 +418,7 @@ size_t DepthFilterHip::finishUpdateSeedsNow()
   }
   // scatter back in place (ref_frame.invmu_sigma2_a_b_vec_.col(i), type_vec_[i]); a frame's block is the features
   // it had when the update was queued (features are only ever appended)
-  size_t off = 0;
+  size_t off = 0, n_applied = 0;
   for (size_t k = 0; k < q.frames.size(); ++k) {
     Frame& r = *q.frames[k];
     const size_t n = q.counts[k];
@@ -429,11 +429,12 @@ size_t DepthFilterHip::finishUpdateSeedsNow()
       if (r.type_vec_[i] >= SVOH_FT_EDGELET) continue;
       std::copy(q.state.begin() + 4 * (off + i), q.state.begin() + 4 * (off + i + 1), r.invmu_sigma2_a_b_vec_.begin() + 4 * i);
       r.type_vec_[i] = q.type[off + i];
+      n_applied += q.success[off + i];
     }
     off += n;
   }
   q.frames.clear();
-  return static_cast<size_t>(q.n_success);
+  return n_applied;   // the updates that succeeded AND were applied (q.n_success also counts seeds that became features meanwhile)
 }
 
 // ---- FeatureTracker ---------------------------------------------------------------

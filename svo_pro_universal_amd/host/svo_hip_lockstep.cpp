@@ -213,8 +213,8 @@ void FrontendLockstep::finishSeedUpdate()
         // (a seed that became a feature while its update was in flight -- a keyframe made between the update's launch and here
         // upgraded it -- keeps what the upgrade made of it: the same rule as DepthFilterHip::finishUpdateSeedsNow)
         for (size_t i = 0; i < n; ++i) {
-          n_success += ss.success[off + i];
           if (r.type_vec_[i] >= SVOH_FT_EDGELET) continue;
+          n_success += ss.success[off + i];
           std::copy(ss.state + 4 * (off + i), ss.state + 4 * (off + i + 1), r.invmu_sigma2_a_b_vec_.begin() + 4 * i);
           r.type_vec_[i] = ss.type[off + i];
         }

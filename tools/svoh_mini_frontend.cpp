@@ -283,12 +283,15 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
         // 3b. structure optimisation of the frame's landmarks (frame_handler_mono.cpp:157: optimizeStructure(new_frames_, max_pts, 5))
         if (landmarks_on) n_struct = optimizeStructure(ctx, b_cur, params.structure_optimization_max_pts, 5);
         t4 = now_ms();
-        // 4. depth filter (frame_handler_mono.cpp:125)
-        depth_filter.updateSeedsAsync(visible, frame);
-        if (sync_flow) { n_seed_upd = depth_filter.finishUpdateSeeds(); seeds_finished = true; }   // wait here, as the reference does
+        // 4. depth filter (frame_handler_mono.cpp:125: the keyframes that were visible from this frame are updated with it -- in the
+        // reference at the start of the NEXT frame, i.e. after this frame may have become a keyframe and upgraded some of their seeds
+        // to landmarks: a seed that is a feature by then is not updated.  The pipelined flow sends the update off here and drops, when it
+        // writes the results back, those of seeds that were upgraded meanwhile; the blocking flow runs it after the keyframe step.)
+        if (!sync_flow) depth_filter.updateSeedsAsync(visible, frame);
         t5 = now_ms();
         // 5. keyframe rule
         if (k % kf_every == 0 || frame->numTrackedFeatures() < min_tracked) { make_keyframe(frame); is_kf = true; }
+        if (sync_flow) { depth_filter.updateSeedsAsync(visible, frame); n_seed_upd = depth_filter.finishUpdateSeeds(); seeds_finished = true; }   // wait here, as the reference does
       }
       // the frame before this one is dropped here unless it is a keyframe: its release (svoh_release_frame) is part of
       // the frame's time
