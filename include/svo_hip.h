@@ -971,6 +971,12 @@ int svoh_optimize_pose_batch_packed(svoh_ctx* ctx, const svoh_pose_options* opti
 int svoh_optimize_points_batch(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,
                                const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
                                const int32_t* obs_view, const double* obs_f, double* pos, int32_t* iters);
+/* The same on the context's SECOND stream (the one svoh_build_pyramid_multi_prefetch uses), with buffers of its own: the call waits for
+ * ITS kernel only, not for what the first stream is still running.  For a driver that has sent the depth filter's update off and does
+ * not want the frame's structure optimisation to wait behind it (FrontendLockstep): the batch reads nothing the first stream produces. */
+int svoh_optimize_points_batch_side(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,
+                               const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
+                               const int32_t* obs_view, const double* obs_f, double* pos, int32_t* iters);
 
 #ifdef __cplusplus
 }

@@ -345,6 +345,9 @@ struct svoh_ctx {
   // generic scratch for the other paths
   svoh::DevBuffer d_scratch0, d_scratch1, d_scratch2;
   svoh::PinnedBuffer h_scratch0, h_scratch1;
+  // svoh_optimize_points_batch_side: a points batch on the context's SECOND stream, beside what the first one is running
+  svoh::DevBuffer d_points_side;
+  svoh::PinnedBuffer h_points_side;
 };
 
 namespace svoh {

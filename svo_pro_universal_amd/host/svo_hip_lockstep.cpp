@@ -892,8 +892,8 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     }
     // ---- 3b. structure optimisation (frame_handler_mono.cpp:157: optimizeStructure(new_frames_, max_pts, 5)): the landmarks of every
     // stream's frame, gathered per stream on the pool, ONE svoh_optimize_points_batch for all of them (a stream's views and points are a
-    // slice of the call's; Point::optimize of one point does not see another), applied per stream.  It queues behind the depth filter's
-    // update on the context's stream: its wait is that update's wait.
+    // slice of the call's; Point::optimize of one point does not see another), applied per stream.  On the context's SECOND stream: the
+    // depth filter's update is running on the first, and the points need nothing of it.
     if (opt_.landmarks) {
       pool_.run(S, [&](int s) {
         Stream& st = *streams_[static_cast<size_t>(s)];
@@ -922,8 +922,8 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
           std::copy(b.pos.begin(), b.pos.end(), pos.begin() + 3 * st.structure_off);
         });
         obs_begin[n_pts] = static_cast<int32_t>(n_obs);
-        check(svoh_optimize_points_batch(ctx_, 5, 0, static_cast<int>(n_views), views.data(), static_cast<int>(n_pts), obs_begin.data(), obs_view.data(), obs_f.data(), pos.data(), nullptr),
-              "svoh_optimize_points_batch");
+        check(svoh_optimize_points_batch_side(ctx_, 5, 0, static_cast<int>(n_views), views.data(), static_cast<int>(n_pts), obs_begin.data(), obs_view.data(), obs_f.data(), pos.data(), nullptr),
+              "svoh_optimize_points_batch_side");
         ++device_calls_;
         pool_.run(S, [&](int s) {
           Stream& st = *streams_[static_cast<size_t>(s)];

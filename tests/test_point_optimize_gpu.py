@@ -59,6 +59,20 @@ def test_recovers_noise_free_landmarks_at_scale(gpu_ctx):
     assert np.abs(pg - sc["pos_gt"]).max() < 1e-6 and ig.max() <= 15
 
 
+def test_the_batch_on_the_second_stream_gives_the_same_bits(gpu_ctx):
+    """svoh_optimize_points_batch_side (round 6): the same kernel on the context's second stream with buffers of its own, so that a
+    driver's structure optimisation does not wait behind the depth filter's update on the first -- positions and iteration counts
+    bit for bit, also with calls of the two kinds interleaved."""
+    sc = ph.make_structure_scene(11, n_points=3000, n_views=5, noise=0.002, degenerate=True)
+    args = (sc["views"], sc["obs_begin"], sc["obs_view"], sc["obs_f"], sc["pos0"])
+    p0, i0 = gpu_ctx.optimize_points(*args, n_iter=5)
+    for _ in range(3):
+        p1, i1 = gpu_ctx.optimize_points(*args, n_iter=5, side=True)
+        assert np.array_equal(p0, p1) and np.array_equal(i0, i1)
+        p2, i2 = gpu_ctx.optimize_points(*args, n_iter=5)
+        assert np.array_equal(p0, p2) and np.array_equal(i0, i2)
+
+
 def test_empty_and_bad_arguments(gpu_ctx):
     sc = ph.make_structure_scene(10, n_points=4, degenerate=False)
     pg, ig = gpu_ctx.optimize_points(sc["views"], np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros((0, 3)), np.zeros((0, 3)))
