@@ -971,12 +971,15 @@ int svoh_optimize_pose_batch_packed(svoh_ctx* ctx, const svoh_pose_options* opti
 int svoh_optimize_points_batch(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,
                                const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
                                const int32_t* obs_view, const double* obs_f, double* pos, int32_t* iters);
-/* The same on the context's SECOND stream (the one svoh_build_pyramid_multi_prefetch uses), with buffers of its own: the call waits for
- * ITS kernel only, not for what the first stream is still running.  For a driver that has sent the depth filter's update off and does
- * not want the frame's structure optimisation to wait behind it (FrontendLockstep): the batch reads nothing the first stream produces. */
-int svoh_optimize_points_batch_side(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,
-                               const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
-                               const int32_t* obs_view, const double* obs_f, double* pos, int32_t* iters);
+/* The same in two halves: _enqueue stages the batch (buffers of its own), queues upload, kernel and copy back on the context's stream and
+ * returns; _collect waits for THAT batch (an event behind its copy -- not for what the caller has queued since) and hands the positions
+ * out; n_points must be the queued batch's.  One batch in flight per context.  The frame handler optimises a frame's landmarks right
+ * after its pose (frame_handler_mono.cpp:157) and reads them again at the next frame: a driver queues the batch there and collects it
+ * when the next frame's alignment points are resolved (FrontendLockstep). */
+int svoh_optimize_points_batch_enqueue(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,
+                                       const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
+                                       const int32_t* obs_view, const double* obs_f, const double* pos);
+int svoh_optimize_points_batch_collect(svoh_ctx* ctx, int n_points, double* pos, int32_t* iters);
 
 #ifdef __cplusplus
 }

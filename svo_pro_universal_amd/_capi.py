@@ -297,7 +297,7 @@ EXPORTS = [
     "svoh_match_direct_batch", "svoh_match_direct_batch_pixelwise", "svoh_matcher_begin_deferred", "svoh_matcher_collect", "svoh_matcher_flush", "svoh_matcher_deferred_set_cur_frame", "svoh_optimize_pose_batch_hook",
     "svoh_update_seeds_batch", "svoh_update_seeds_batch_ex", "svoh_epipolar_match_batch",
     "svoh_project_candidates_enqueue", "svoh_project_candidates_collect", "svoh_project_candidates",
-    "svoh_detect_features", "svoh_optimize_pose_batch", "svoh_optimize_pose_batch_packed", "svoh_optimize_points_batch", "svoh_optimize_points_batch_side",
+    "svoh_detect_features", "svoh_optimize_pose_batch", "svoh_optimize_pose_batch_packed", "svoh_optimize_points_batch", "svoh_optimize_points_batch_enqueue", "svoh_optimize_points_batch_collect",
     # round 5: what the lock-step front end of many camera streams stages in place and launches once per stage
     "svoh_host_alloc", "svoh_host_free", "svoh_build_pyramid_multi", "svoh_build_pyramid_multi_prefetch", "svoh_prefetch_fence",
     "svoh_sparse_align_geometry_key", "svoh_sparse_align_enqueue_keyed",
@@ -422,7 +422,8 @@ def load(path=None):
                                          P(C.c_int32)]
     lib.svoh_optimize_points_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(svoh_se3), C.c_int, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.svoh_optimize_points_batch_side.argtypes = lib.svoh_optimize_points_batch.argtypes
+    lib.svoh_optimize_points_batch_enqueue.argtypes = lib.svoh_optimize_points_batch.argtypes[:-1]
+    lib.svoh_optimize_points_batch_collect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.svoh_optimize_pose_batch.argtypes = [C.c_void_p, P(svoh_pose_options), C.c_int, P(svoh_pose_problem),
                                              P(svoh_pose_result)]
     lib.svoh_optimize_pose_batch_packed.argtypes = [C.c_void_p, P(svoh_pose_options), C.c_int, P(svoh_pose_problem),

@@ -523,6 +523,7 @@ try {
   if (ctx->ev_misc_stop) (void)hipEventDestroy(ctx->ev_misc_stop);
   if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
   if (ctx->ev_features) (void)hipEventDestroy(ctx->ev_features);
+  if (ctx->ev_points) (void)hipEventDestroy(ctx->ev_points);
   if (ctx->ev_detect) (void)hipEventDestroy(ctx->ev_detect);
   if (ctx->ev_matcher_done) (void)hipEventDestroy(ctx->ev_matcher_done);
   if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }

@@ -759,7 +759,7 @@ try {
   return run_pose_batch(ctx, options, n_problems, problems, arrays, results);
 } SVOH_ABI_CATCH(ctx)
 
-static int run_points_batch(svoh_ctx* ctx, bool side, int n_iter, int using_bearing_vector, int n_views,
+static int run_points_batch(svoh_ctx* ctx, bool queued, int n_iter, int using_bearing_vector, int n_views,
                             const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
                             const int32_t* obs_view, const double* obs_f, double* pos, int32_t* iters)
 {
@@ -778,15 +778,11 @@ static int run_points_batch(svoh_ctx* ctx, bool side, int n_iter, int using_bear
   const size_t o_view = o_begin + al(4 * ((size_t)n_points + 1)), o_f = o_view + al(4 * (n_obs ? n_obs : 1));
   const size_t o_pos = o_f + al(24 * (n_obs ? n_obs : 1)), o_it = o_pos + al(24 * (size_t)n_points);
   const size_t total = o_it + al(4 * (size_t)n_points);
-  // side: the context's second stream (the one the image prefetch uses) and buffers of its own -- the batch reads nothing the first
-  // stream produces (everything comes from the host), so it runs beside whatever is queued there (the depth filter's update)
+  // queued: buffers of its own (the blocking calls' scratch blocks stay free for whoever calls in between) and an event behind the copy back
   hipStream_t stream = ctx->stream;
-  if (side) {
-    if (!ctx->upload_stream) SVOH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
-    stream = ctx->upload_stream;
-  }
-  PinnedBuffer& hb = side ? ctx->h_points_side : ctx->h_scratch0;
-  DevBuffer& db = side ? ctx->d_points_side : ctx->d_scratch0;
+  SVOH_REQUIRE(ctx, !queued || ctx->points_pending == 0, "a points batch is queued: svoh_optimize_points_batch_collect first");
+  PinnedBuffer& hb = queued ? ctx->h_points_q : ctx->h_scratch0;
+  DevBuffer& db = queued ? ctx->d_points_q : ctx->d_scratch0;
   SVOH_HIP_TRY(ctx, hb.reserve(total));
   SVOH_HIP_TRY(ctx, db.reserve(total));
   uint8_t* h = static_cast<uint8_t*>(hb.ptr);
@@ -795,7 +791,7 @@ static int run_points_batch(svoh_ctx* ctx, bool side, int n_iter, int using_bear
   memcpy(h + o_begin, obs_begin, 4 * ((size_t)n_points + 1));
   if (n_obs) { memcpy(h + o_view, obs_view, 4 * n_obs); memcpy(h + o_f, obs_f, 24 * n_obs); }
   memcpy(h + o_pos, pos, 24 * (size_t)n_points);
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(d, h, o_it, hipMemcpyHostToDevice, stream));
+  SVOH_HIP_TRY(ctx, svoh_copy_to_device(ctx, d, h, o_it));
   PointArgs a;
   a.T_f_w = reinterpret_cast<const svoh_se3*>(d + o_T);
   a.obs_begin = reinterpret_cast<const int32_t*>(d + o_begin);
@@ -804,13 +800,19 @@ static int run_points_batch(svoh_ctx* ctx, bool side, int n_iter, int using_bear
   a.pos = reinterpret_cast<double*>(d + o_pos);
   a.iters = reinterpret_cast<int32_t*>(d + o_it);
   a.n_points = n_points; a.n_iter = n_iter; a.on_sphere = using_bearing_vector != 0;
-  const bool timed = !side && ctx->timing_on();
+  const bool timed = !queued && ctx->timing_on();
   if (timed) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_start, stream));
   hipLaunchKernelGGL(point_optimize_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, stream, a);
   SVOH_HIP_TRY(ctx, hipGetLastError());
   if (timed) SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_misc_stop, stream));
-  if (!side) { ctx->misc_timed = timed; ctx->misc_launched = true; }
-  SVOH_HIP_TRY(ctx, hipMemcpyAsync(h + o_pos, d + o_pos, total - o_pos, hipMemcpyDeviceToHost, stream));
+  if (!queued) { ctx->misc_timed = timed; ctx->misc_launched = true; }
+  SVOH_HIP_TRY(ctx, svoh_copy_to_host(ctx, h + o_pos, d + o_pos, total - o_pos));
+  if (queued) {
+    if (!ctx->ev_points) SVOH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_points, hipEventDisableTiming));
+    SVOH_HIP_TRY(ctx, hipEventRecord(ctx->ev_points, stream));
+    ctx->points_pending = n_points; ctx->points_o_pos = o_pos; ctx->points_o_it = o_it;
+    return SVOH_OK;
+  }
   SVOH_HIP_TRY(ctx, hipStreamSynchronize(stream));
   memcpy(pos, h + o_pos, 24 * (size_t)n_points);
   if (iters) memcpy(iters, h + o_it, 4 * (size_t)n_points);
@@ -824,9 +826,23 @@ try {
   return run_points_batch(ctx, false, n_iter, using_bearing_vector, n_views, T_f_w, n_points, obs_begin, obs_view, obs_f, pos, iters);
 } SVOH_ABI_CATCH(ctx)
 
-extern "C" int svoh_optimize_points_batch_side(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,
-                                               const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
-                                               const int32_t* obs_view, const double* obs_f, double* pos, int32_t* iters)
+extern "C" int svoh_optimize_points_batch_enqueue(svoh_ctx* ctx, int n_iter, int using_bearing_vector, int n_views,
+                                                  const svoh_se3* T_f_w, int n_points, const int32_t* obs_begin,
+                                                  const int32_t* obs_view, const double* obs_f, const double* pos)
 try {
-  return run_points_batch(ctx, true, n_iter, using_bearing_vector, n_views, T_f_w, n_points, obs_begin, obs_view, obs_f, pos, iters);
+  return run_points_batch(ctx, true, n_iter, using_bearing_vector, n_views, T_f_w, n_points, obs_begin, obs_view, obs_f, const_cast<double*>(pos), nullptr);
+} SVOH_ABI_CATCH(ctx)
+
+extern "C" int svoh_optimize_points_batch_collect(svoh_ctx* ctx, int n_points, double* pos, int32_t* iters)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, n_points >= 0 && n_points == ctx->points_pending && (n_points == 0 || pos), "n_points is not the size of the queued batch");
+  if (n_points == 0) return SVOH_OK;
+  ctx->points_pending = 0;
+  SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SVOH_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_points));   // THAT batch: not what the caller has queued on the context since
+  const uint8_t* h = static_cast<const uint8_t*>(ctx->h_points_q.ptr);
+  memcpy(pos, h + ctx->points_o_pos, 24 * (size_t)n_points);
+  if (iters) memcpy(iters, h + ctx->points_o_it, 4 * (size_t)n_points);
+  return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)

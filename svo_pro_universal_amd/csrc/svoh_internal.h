@@ -345,9 +345,12 @@ struct svoh_ctx {
   // generic scratch for the other paths
   svoh::DevBuffer d_scratch0, d_scratch1, d_scratch2;
   svoh::PinnedBuffer h_scratch0, h_scratch1;
-  // svoh_optimize_points_batch_side: a points batch on the context's SECOND stream, beside what the first one is running
-  svoh::DevBuffer d_points_side;
-  svoh::PinnedBuffer h_points_side;
+  // svoh_optimize_points_batch_enqueue / _collect: a points batch queued and not waited for (buffers of its own, an event behind its copy back)
+  svoh::DevBuffer d_points_q;
+  svoh::PinnedBuffer h_points_q;
+  hipEvent_t ev_points = nullptr;
+  int points_pending = 0;               // points of the queued batch, or 0
+  size_t points_o_pos = 0, points_o_it = 0;
 };
 
 namespace svoh {

@@ -426,7 +426,7 @@ def _optimize_pose(self, opt, problems):
 def _optimize_points(self, views, obs_begin, obs_view, obs_f, pos, n_iter=5, using_bearing_vector=False, side=False):
     """svoh_optimize_points_batch (Point::optimize for a batch of landmarks).  views: list of 7-vectors
     (q wxyz, t) T_f_w; obs_begin [n+1], obs_view [n_obs], obs_f [n_obs,3], pos [n,3].  Returns (pos, iters).
-    side: svoh_optimize_points_batch_side (the context's second stream)."""
+    side: through svoh_optimize_points_batch_enqueue + _collect (the queued form)."""
     T = (capi.svoh_se3 * max(1, len(views)))(*[_se3(v) for v in views])
     obs_begin = np.ascontiguousarray(obs_begin, dtype=np.int32)
     obs_view = np.ascontiguousarray(obs_view, dtype=np.int32)
@@ -434,9 +434,13 @@ def _optimize_points(self, views, obs_begin, obs_view, obs_f, pos, n_iter=5, usi
     out = np.array(pos, dtype=np.float64, order="C", copy=True)
     n = out.shape[0]
     iters = np.zeros(max(1, n), np.int32)
-    fn = self.lib.svoh_optimize_points_batch_side if side else self.lib.svoh_optimize_points_batch
-    self._check(fn(self.h, int(n_iter), int(bool(using_bearing_vector)), len(views), T, n, obs_begin.ctypes.data, obs_view.ctypes.data,
-                   obs_f.ctypes.data, out.ctypes.data, iters.ctypes.data))
+    if side:
+        self._check(self.lib.svoh_optimize_points_batch_enqueue(self.h, int(n_iter), int(bool(using_bearing_vector)), len(views), T, n, obs_begin.ctypes.data,
+                                                                obs_view.ctypes.data, obs_f.ctypes.data, out.ctypes.data))
+        self._check(self.lib.svoh_optimize_points_batch_collect(self.h, n, out.ctypes.data, iters.ctypes.data))
+    else:
+        self._check(self.lib.svoh_optimize_points_batch(self.h, int(n_iter), int(bool(using_bearing_vector)), len(views), T, n, obs_begin.ctypes.data,
+                                                        obs_view.ctypes.data, obs_f.ctypes.data, out.ctypes.data, iters.ctypes.data))
     return out, iters[:n]
 
 

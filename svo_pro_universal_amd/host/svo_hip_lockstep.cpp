@@ -30,7 +30,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 namespace {
 enum Phase { kPhPyramid = 0, kPhFinishSeeds, kPhAlignPrep, kPhAlignLaunch, kPhProjGather, kPhAlignWait, kPhWalkPlan, kPhMatchStage, kPhMatchCopy, kPhMatchSubmit, kPhSort,
-             kPhMatchWait, kPhReplay, kPhPoseCall, kPhPoseApply, kPhSeedStage, kPhSeedGather, kPhSeedSubmit, kPhKeyframe, kPhSeedWait, kPhDetectWait, kPhPrefetch, kPhStructure, kPhRest };
+             kPhMatchWait, kPhReplay, kPhPoseCall, kPhPoseApply, kPhSeedStage, kPhSeedGather, kPhSeedSubmit, kPhKeyframe, kPhSeedWait, kPhDetectWait, kPhPrefetch, kPhStructure, kPhStructGather, kPhStructCall, kPhStructWait, kPhRest };
 struct PhaseClock {
   double* acc; double t;
   explicit PhaseClock(double* a) : acc(a), t(now_ms()) {}
@@ -41,7 +41,7 @@ struct PhaseClock {
 const char* FrontendLockstep::phaseName(int k)
 {
   static const char* names[] = { "pyramid", "finish seeds", "align prep", "align launch", "projection gather", "align wait", "walk + plan", "match stage", "match copy",
-                                 "match submit", "sort", "match wait", "replay + pose prep", "pose call", "pose apply", "seed stage", "seed gather", "seed submit", "keyframe", "seed wait", "detect wait", "prefetch", "structure", "rest" };
+                                 "match submit", "sort", "match wait", "replay + pose prep", "pose call", "pose apply", "seed stage", "seed gather", "seed submit", "keyframe", "seed wait", "detect wait", "prefetch", "structure", "structure gather", "structure call", "structure wait", "rest" };
   return k >= 0 && k < (int)(sizeof names / sizeof names[0]) ? names[k] : "";
 }
 
@@ -150,6 +150,7 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
 FrontendLockstep::~FrontendLockstep()
 {
   try { finish(); } catch (...) {}
+  if (structure_in_flight_) { std::vector<double> pos(3 * structure_in_flight_); (void)svoh_optimize_points_batch_collect(ctx_, static_cast<int>(structure_in_flight_), pos.data(), nullptr); }
   for (auto& st : streams_) {
     for (const FramePtr& f : st->kfs) for (auto& sr : f->seed_ref_vec_) sr.keyframe.reset();   // break the self references
     if (st->last) for (auto& sr : st->last->seed_ref_vec_) sr.keyframe.reset();
@@ -187,8 +188,25 @@ std::vector<FrontendLockstep::FrameRow> FrontendLockstep::completedRows(int s)
   return out;
 }
 
+void FrontendLockstep::finishStructure()
+{
+  if (!structure_in_flight_) return;
+  const double tw = now_ms();
+  std::vector<double> pos(3 * structure_in_flight_);
+  check(svoh_optimize_points_batch_collect(ctx_, static_cast<int>(structure_in_flight_), pos.data(), nullptr), "svoh_optimize_points_batch_collect");
+  ++device_calls_;
+  structure_in_flight_ = 0;
+  pool_.run(static_cast<int>(structure_streams_.size()), [&](int w) {
+    Stream& st = *streams_[static_cast<size_t>(structure_streams_[static_cast<size_t>(w)])];
+    st.structure.apply(pos.data() + 3 * st.structure_off);
+  });
+  structure_streams_.clear();
+  phase_ms_[kPhStructWait] += now_ms() - tw;
+}
+
 void FrontendLockstep::finish()
 {
+  finishStructure();
   finishSeedUpdate();
   drainReleases();
 }
@@ -465,6 +483,7 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     }
   }
   pc.lap(kPhPyramid);
+  finishStructure();   // the points optimised behind the previous round: their positions are read from here on (alignment points, candidates)
   // The previous round's seed update: its results are needed from here on (alignment points, candidates) -- unless the alignment
   // is queued AHEAD of the wait: the only thing it needs of the update is the new inverse depth of the seeds its points hang on,
   // and the device has that (svoh_align_camera::pos_seed_unit reads the update's batch in place).  The wait for the update and
@@ -892,14 +911,14 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
     }
     // ---- 3b. structure optimisation (frame_handler_mono.cpp:157: optimizeStructure(new_frames_, max_pts, 5)): the landmarks of every
     // stream's frame, gathered per stream on the pool, ONE svoh_optimize_points_batch for all of them (a stream's views and points are a
-    // slice of the call's; Point::optimize of one point does not see another), applied per stream.  On the context's SECOND stream: the
-    // depth filter's update is running on the first, and the points need nothing of it.
+    // slice of the call's; Point::optimize of one point does not see another), applied per stream.
     if (opt_.landmarks) {
       pool_.run(S, [&](int s) {
         Stream& st = *streams_[static_cast<size_t>(s)];
         if (!st.tracking) return;
         st.structure.gather(*st.frame, st.so.params.structure_optimization_max_pts);
       });
+      pc.lap(kPhStructGather);
       size_t n_pts = 0, n_views = 0, n_obs = 0;
       for (int s : trk) {
         Stream& st = *streams_[static_cast<size_t>(s)];
@@ -922,15 +941,18 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
           std::copy(b.pos.begin(), b.pos.end(), pos.begin() + 3 * st.structure_off);
         });
         obs_begin[n_pts] = static_cast<int32_t>(n_obs);
-        check(svoh_optimize_points_batch_side(ctx_, 5, 0, static_cast<int>(n_views), views.data(), static_cast<int>(n_pts), obs_begin.data(), obs_view.data(), obs_f.data(), pos.data(), nullptr),
-              "svoh_optimize_points_batch_side");
+        pc.lap(kPhStructure);
+        // queued (behind the depth filter's update on the context's stream) and NOT waited for: nothing before the next round's alignment
+        // set-up reads a point's position (the keyframe step makes new points and adds observations; it moves none), so the kernel runs
+        // while the host is in the keyframe phase, and its results are taken at the next round's start (finishStructure).  (A stream of
+        // its own was measured and is worse: with four groups' streams on the runtime's four hardware queues a side stream waits behind
+        // another group's chain -- 0.13 - 0.30 ms at the next round's start.)
+        check(svoh_optimize_points_batch_enqueue(ctx_, 5, 0, static_cast<int>(n_views), views.data(), static_cast<int>(n_pts), obs_begin.data(), obs_view.data(), obs_f.data(), pos.data()),
+              "svoh_optimize_points_batch_enqueue");
         ++device_calls_;
-        pool_.run(S, [&](int s) {
-          Stream& st = *streams_[static_cast<size_t>(s)];
-          if (!st.tracking || !st.structure.size()) return;
-          st.structure.apply(pos.data() + 3 * st.structure_off);
-          st.row.n_struct = st.structure.size();
-        });
+        structure_in_flight_ = n_pts;
+        for (int s : trk) { Stream& st = *streams_[static_cast<size_t>(s)]; if (st.structure.size()) { structure_streams_.push_back(s); st.row.n_struct = st.structure.size(); } }
+        pc.lap(kPhStructCall);
       }
       pc.lap(kPhStructure);
     }

@@ -119,13 +119,17 @@ class FrontendLockstep {
   // device calls per round of the last addImages, for the record (one per stage, whatever the number of streams)
   int lastRoundDeviceCalls() const { return device_calls_; }
   // where the rounds' time went, phase by phase (sums over all rounds since construction, ms), with the phases' names
-  static constexpr int kNumPhases = 24;
+  static constexpr int kNumPhases = 32;
   const double* phaseTimes() const { return phase_ms_; }
   static const char* phaseName(int k);
 
  private:
   struct Stream;
   void finishSeedUpdate();
+  // the structure optimisation queued in the round before (side stream): wait for it, every stream's points take their positions
+  void finishStructure();
+  size_t structure_in_flight_ = 0;   // points of the batch in flight
+  std::vector<int> structure_streams_;
   void startDetection(const std::vector<int>& which);
   void makeKeyframes(const std::vector<int>& which);
   // the detector batch of the round's new keyframes between its two halves

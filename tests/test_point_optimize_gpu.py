@@ -59,10 +59,10 @@ def test_recovers_noise_free_landmarks_at_scale(gpu_ctx):
     assert np.abs(pg - sc["pos_gt"]).max() < 1e-6 and ig.max() <= 15
 
 
-def test_the_batch_on_the_second_stream_gives_the_same_bits(gpu_ctx):
-    """svoh_optimize_points_batch_side (round 6): the same kernel on the context's second stream with buffers of its own, so that a
-    driver's structure optimisation does not wait behind the depth filter's update on the first -- positions and iteration counts
-    bit for bit, also with calls of the two kinds interleaved."""
+def test_the_queued_batch_gives_the_same_bits(gpu_ctx):
+    """svoh_optimize_points_batch_enqueue / _collect (round 6): the same kernel queued and collected later, with buffers of its own, so
+    that a driver's structure optimisation is off the frame's critical path -- positions and iteration counts bit for bit, also with
+    calls of the two kinds interleaved; a second batch while one is queued, or a collect of the wrong size, is refused."""
     sc = ph.make_structure_scene(11, n_points=3000, n_views=5, noise=0.002, degenerate=True)
     args = (sc["views"], sc["obs_begin"], sc["obs_view"], sc["obs_f"], sc["pos0"])
     p0, i0 = gpu_ctx.optimize_points(*args, n_iter=5)
@@ -71,6 +71,8 @@ def test_the_batch_on_the_second_stream_gives_the_same_bits(gpu_ctx):
         assert np.array_equal(p0, p1) and np.array_equal(i0, i1)
         p2, i2 = gpu_ctx.optimize_points(*args, n_iter=5)
         assert np.array_equal(p0, p2) and np.array_equal(i0, i2)
+    import ctypes as C
+    assert gpu_ctx.lib.svoh_optimize_points_batch_collect(gpu_ctx.h, 3, C.c_void_p(p0.ctypes.data), None) != 0   # nothing queued
 
 
 def test_empty_and_bad_arguments(gpu_ctx):
