@@ -76,3 +76,37 @@ def test_golden_detect_pose_fixture(gpu_ctx):
     d = gpu_ctx.detect_features(capi.default_detector_options(cell_size=20), fr, 320, 240, z["det_occupancy"])
     pb, keep = fe.make_pose_problem(cams, synth.SE3.from7(z["pose_T_init"]))
     check_golden3(z, d, gpu_ctx.optimize_pose(popt, [pb])[0], keep)
+
+
+def test_histogram_angle_bins_against_the_oracle(gpu_ctx, oracle_lib):
+    """svoh_histogram_angle_bins (round 6): getAngleAtPixelUsingHistogram (feature_detection_utils.cpp:831-839, 947-1009) at given pixels
+    of several frames and levels in one call -- what upgradeSeedsToFeatures refreshes an upgraded edgelet's direction with
+    (frame_handler_base.cpp:893-901) -- against the oracle pixel by pixel.  The dominant bin is an integer: equal, except where the
+    device's atan2 puts a window pixel that lies on a bin boundary into the neighbouring bin and that decides the maximum (<= 2 %)."""
+    import ctypes as C
+    rng = np.random.RandomState(77)
+    cams = [synth.Camera.euroc_like(752, 480), synth.Camera.euroc_like(640, 480)]
+    scenes = [synth.make_align_scene(500 + i, n_features=8, cam=cams[i % 2]) for i in range(3)]
+    pyramids = [oracle_lib.create_img_pyramid(sc.img_ref, 4) for sc in scenes]
+    frames = [gpu_ctx.build_pyramid(sc.img_ref, 4) for sc in scenes]
+    n = 4000
+    fidx = rng.randint(0, 3, n).astype(np.int32)
+    level = rng.randint(0, 4, n).astype(np.int32)
+    px = np.zeros((n, 2), np.int32)
+    for k in range(n):
+        h, w = pyramids[fidx[k]][level[k]].shape
+        px[k] = (rng.randint(-2, w + 2), rng.randint(-2, h + 2))      # the window's own bounds test is part of the function
+    bins = np.zeros(n, np.int32)
+    handles = (capi.svoh_frame_t * 3)(*frames)
+    gpu_ctx._check(gpu_ctx.lib.svoh_histogram_angle_bins(gpu_ctx.h, 3, handles, n, fidx.ctypes.data, level.ctypes.data, px.ctypes.data, bins.ctypes.data))
+    want = np.array([oracle_lib.angle_at_pixel(pyramids[fidx[k]][level[k]], int(px[k, 0]), int(px[k, 1])) for k in range(n)])
+    got = bins.astype(np.float64) * 2.0 * np.pi / 36.0
+    same = got == want
+    assert same.mean() >= 0.98, same.mean()
+    d = np.abs(got - want)[~same]
+    assert d.size == 0 or np.minimum(d, 2 * np.pi - d).max() < np.deg2rad(10.5)
+    # misuse
+    bad_level = level.copy(); bad_level[5] = 9
+    assert gpu_ctx.lib.svoh_histogram_angle_bins(gpu_ctx.h, 3, handles, n, fidx.ctypes.data, bad_level.ctypes.data, px.ctypes.data, bins.ctypes.data) != 0
+    for f in frames:
+        gpu_ctx.release_frame(f)

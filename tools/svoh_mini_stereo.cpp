@@ -147,20 +147,26 @@ int main(int argc, char** argv)
       kfs.push_back(f);
       while (kfs.size() > 2 * ropt.max_n_kfs) {
         for (auto& sr : kfs.front()->seed_ref_vec_) sr.keyframe.reset();
+        removeObservationsOf(*kfs.front());   // (Map::removeKeyframe)
         kfs.pop_front();
       }
     };
     const bool kf_timing = getenv("SVOH_MINI_KF_TIMING") != nullptr;   // where a keyframe's time goes, to stderr
+    const bool landmarks_on = getenv("SVOH_MINI_LANDMARKS") == nullptr || atoi(getenv("SVOH_MINI_LANDMARKS")) != 0;
+    int next_point_id = 1 << 20;   // (the triangulation's points count from 0)
     auto make_keyframe = [&](const FrameBundle::Ptr& b, size_t kf_id) {
-      // stereo triangulation of new features where the left frame has no feature yet (frame_handler_stereo.cpp:146-155)
+      // stereo triangulation of new features where the left frame has no feature yet (frame_handler_stereo.cpp:146-155); the frame that
+      // is not the keyframe upgrades the seeds it hangs on first, as the reference's branch does (:149-154)
       const double tk0 = now_ms();
+      if (landmarks_on) upgradeSeedsToFeatures(ctx, b->at(1 - kf_id), &next_point_id);
       tri_detector->resetGrid();
       tri_detector->fillGridWithKeypoints(b->at(0)->px_vec_, b->at(0)->num_features_);
       stereo.compute(b->at(0), b->at(1));
       const double tk1 = now_ms();
-      // new seeds in the keyframe's free cells (depth_filter_->addKeyframe, :167-173)
+      // the keyframe's seeds become landmarks (upgradeSeedsToFeatures, :162), then new seeds in its free cells (depth_filter_->addKeyframe, :167-173)
       double d_med = 0, d_min = 0;
       const FramePtr& f = b->at(kf_id);
+      if (landmarks_on) upgradeSeedsToFeatures(ctx, f, &next_point_id);
       if (scene_depth(*b->at(0), d_med, d_min)) {
         seed_detector.resetGrid();
         seed_detector.fillGridWithKeypoints(f->px_vec_, f->num_features_);
@@ -249,15 +255,17 @@ int main(int argc, char** argv)
         t3 = now_ms();
         // 3. pose optimisation of the rig
         if (n_reproj >= 10) n_pose = pose_optimizer.run(bundle, 2.0);
+        // 3b. structure optimisation of the pair's landmarks (frame_handler_stereo.cpp:114)
+        if (landmarks_on) (void)optimizeStructure(ctx, bundle, params.structure_optimization_max_pts, 5);
         t4 = now_ms();
-        // 4. depth filter, per camera (frame_handler_stereo.cpp:127-129)
-        n_seed_upd += depth_filter.updateSeeds(visible, bundle->at(0));
+        // 4. depth filter, per camera (frame_handler_stereo.cpp:127-129); at a keyframe BEHIND the keyframe step, as makeKeyframe does
+        // (:162-175: upgradeSeedsToFeatures, addKeyframe, then the two updateSeeds over the keyframes that were visible)
         const bool kf_next = k % kf_every == 0 || n_pose < 60;
-        if (sync_flow || kf_next) n_seed_upd += depth_filter.updateSeeds(visible, bundle->at(1));   // a keyframe's new seeds and triangulation come behind it
+        if (kf_next) { make_keyframe(bundle, (k / kf_every) % 2); is_kf = true; }
+        n_seed_upd += depth_filter.updateSeeds(visible, bundle->at(0));
+        if (sync_flow || kf_next) n_seed_upd += depth_filter.updateSeeds(visible, bundle->at(1));
         else { depth_filter.updateSeedsAsync(visible, bundle->at(1)); seeds_in_flight = true; }
         t5 = now_ms();
-        // 5. keyframe rule
-        if (kf_next) { make_keyframe(bundle, (k / kf_every) % 2); is_kf = true; }
       }
       last = bundle;   // the pair before this one is dropped here unless it is a keyframe: its release is part of the pair's time
       const double t6 = now_ms();
