@@ -474,3 +474,15 @@ def test_candidate_sort_with_packed_keys_is_the_reference_sort():
     subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp"), "host_sort_cpu"])
     r = subprocess.run([os.path.join(root, "tests", "cpp", "host_sort_cpu")], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("ok 400 "), r.stdout + r.stderr
+
+
+def test_upgrade_seeds_to_features_host_half():
+    """svo_hip::upgradeSeedsToFeatures (round 6; FrameHandlerBase::upgradeSeedsToFeatures, frame_handler_base.cpp:828-920) on a
+    hand-made keyframe / frame pair: points at the seeds' positions, types, observations, track ids, cleared seed references, the
+    list of upgraded edgelets, two features on one seed, a feature with a landmark of its own; removeObservationsOf
+    (Map::removeKeyframe).  tests/cpp/host_upgrade_cpu, no GPU call."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp"), "host_upgrade_cpu"])
+    r = subprocess.run([os.path.join(root, "tests", "cpp", "host_upgrade_cpu")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
