@@ -480,8 +480,8 @@ def bench_seeds(args, ctx, dist, rank, world, dev, comm_dev=None):
     step, other = (step_whole_sets, step_units) if args.whole_sets else (step_units, step_whole_sets)
 
     h_steps = max(2, args.steps // 4)
-    h_elapsed, _hk, (st, succ, mres) = timed_steps(ctx, dist, world, dev, step_host, h_steps, 1)
-    host_rate = n * h_steps / h_elapsed
+    h_elapsed, _hk, (st, succ, mres) = timed_steps(ctx, dist, world, dev, step_host, 1 if args.no_secondary else h_steps, 0 if args.no_secondary else 1)
+    host_rate = None if args.no_secondary else n * h_steps / h_elapsed   # (a profiling run keeps ONE call of this leg: it is what the timed leg's results are checked against)
     # the leg that is not the timed one: a few steps, for its kernel time and the equality of the two
     kms_other = None
     if not args.no_secondary:   # (profiling runs pass --no-secondary: one leg's kernels only)

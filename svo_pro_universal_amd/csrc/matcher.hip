@@ -2310,9 +2310,14 @@ __device__ __forceinline__ double packed_refine_enqueue(int tid, bool align_1d, 
   return h_inv;
 }
 
+// WS: the SVOH_BATCH_WHOLE_SETS form (inputs from the reference frames' tile-ordered resident columns, results in place) as an
+// instantiation of its own: as a run-time branch it cost the record form five spilled registers at the three-waves-per-SIMD budget
+template <bool WS>
 __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3))) void update_seeds_packed_kernel(
-    const MatcherArgs a, const SeedRecIn* __restrict__ rec_in, SeedRecOut* __restrict__ rec_out)
+    const MatcherArgs a, const SeedRecIn* __restrict__ rec_in_, SeedRecOut* __restrict__ rec_out_)
 {
+  const SeedRecIn* __restrict__ rec_in = WS ? nullptr : rec_in_;
+  SeedRecOut* __restrict__ rec_out = WS ? nullptr : rec_out_;
   __shared__ __attribute__((aligned(16))) unsigned char s_pwb[kPkThreads * kPwbStride + 16];
   __shared__ int s_res[kPkThreads];              // out of the refinement: (iterations << 8) | converged
   __shared__ double s_dir[2 * kPkThreads];       // 1-D refinements: the direction
@@ -2337,7 +2342,7 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
   double pxr = 0.0, pyr = 0.0, gx = 0.0, gy = 0.0;
   int ws_q = 0;                       // whole sets: the slot's place in its reference frame's tile order
   const double* ws_f = nullptr;
-  if (live && a.whole_sets) {
+  if (WS && live) {
     // slot p of the launch = place q of reference frame ri's tile order = feature perm[q] = unit unit_begin + perm[q] of the caller
     ri = whole_sets_frame_of(a.ref_frames, a.n_ref_frames, slot_i, a.n);
     const DevFrameView& rv = a.ref_frames[ri];
@@ -2349,7 +2354,7 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
       ci = a.cur_frame_idx ? a.cur_frame_idx[rv.unit_begin] : 0;   // (a set's seeds go into ONE current frame: read at its first unit)
       type = a.type[i];
     } else { ri = -1; }   // (cannot happen: the host checked that the sets' sizes add up to n)
-  } else if (live) {
+  } else if (!WS && live) {
     if (rec_in) {
       const SeedRecIn& r = rec_in[slot_i];
       pxr = r.px[0]; pyr = r.px[1]; gx = r.grad[0]; gy = r.grad[1];
@@ -2360,7 +2365,7 @@ __global__ __launch_bounds__(kPkThreads) __attribute__((amdgpu_waves_per_eu(3)))
     }
   }
   auto load_f = [&]() -> Vec3 {
-    if (ws_f) return Vec3{ ws_f[3 * ws_q], ws_f[3 * ws_q + 1], ws_f[3 * ws_q + 2] };
+    if constexpr (WS) return Vec3{ ws_f[3 * ws_q], ws_f[3 * ws_q + 1], ws_f[3 * ws_q + 2] };
     if (rec_in) { const SeedRecIn& r = rec_in[slot_i]; return Vec3{ r.f[0], r.f[1], r.f[2] }; }
     return Vec3{ a.f[3 * i], a.f[3 * i + 1], a.f[3 * i + 2] };
   };
@@ -2863,8 +2868,10 @@ static int launch_matcher_kernels(svoh_ctx* ctx, bool seeds, int g8, MatcherArgs
         rec_out = reinterpret_cast<SeedRecOut*>(base + o_out);
         pos_of = pos;
       }
-      hipLaunchKernelGGL(update_seeds_packed_kernel, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0,
-                         ctx->stream, a, rec_in, rec_out);
+      if (a.whole_sets) hipLaunchKernelGGL(update_seeds_packed_kernel<true>, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0,
+                                           ctx->stream, a, rec_in, rec_out);
+      else hipLaunchKernelGGL(update_seeds_packed_kernel<false>, dim3((unsigned)((n + kPkThreads - 1) / kPkThreads)), dim3(kPkThreads), 0,
+                              ctx->stream, a, rec_in, rec_out);
       if (rec_out) hipLaunchKernelGGL(seed_unsort_kernel, gb, dim3(256), 0, ctx->stream, a, pos_of, static_cast<const SeedRecOut*>(rec_out),
                                       hist_ptr, hist_keys);
     }

@@ -63,8 +63,10 @@ def test_spill_budgets(built):
 def test_klt_seeds_pose_occupancy(built):
     klt = built["klt.o"]["klt_track_kernel"]
     assert klt["vgpr"] <= 96 and klt["vgpr_spill"] == 0          # five waves per SIMD
-    seeds = built["matcher.o"]["update_seeds_packed_kernel"]
+    seeds = built["matcher.o"]["update_seeds_packed_kernel<false>"]
     assert seeds["vgpr"] <= 168 and seeds["vgpr_spill"] <= 4     # three waves per SIMD
+    seeds_ws = built["matcher.o"]["update_seeds_packed_kernel<true>"]   # (round 6: over whole resident sets, results in place)
+    assert seeds_ws["vgpr"] <= 168 and seeds_ws["vgpr_spill"] <= 6
     for name, d in built["pose.o"].items():
         if name.startswith("pose_optimize_kernel<") and not name.endswith(", 1>"):   # unit-plane / image-plane error models
             assert d["vgpr"] <= 256 and d["vgpr_spill"] == 0, name
