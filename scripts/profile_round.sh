@@ -18,7 +18,7 @@ for tag in $TAGS; do
     align_c4) args="--workload align-c4 $STEPS"; key="align-c4:default"; rx="sparse_align_kernel<4, 256, true, false";;
     klt) args="--workload klt $STEPS"; key="klt:default"; rx="klt_track_kernel";;
     seeds) args="--workload seeds $STEPS"; key="seeds:default"; rx="update_seeds|seed_bin|seed_unsort";;
-    seeds_ws) args="--workload seeds --whole-sets $STEPS"; key="seeds-ws:default"; rx="update_seeds_packed";;   # (the one host-array call that checks the results brings its own bin kernels: not part of this step)
+    seeds_ws) args="--workload seeds --whole-sets $STEPS"; key="seeds-ws:default"; rx="update_seeds_packed_kernel<true>";;   # (the one host-array call that checks the results brings its own bin kernels: not part of this step)
     pose) args="--workload pose $STEPS"; key="pose:default"; rx="pose_optimize_kernel";;
     stereo) args="--workload stereo $STEPS"; key="stereo:default"; rx="epipolar_match_kernel";;
   esac
