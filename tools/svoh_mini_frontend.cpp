@@ -220,6 +220,15 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
               n_seed_upd, n_conv, row.ms[0], row.ms[1], row.ms[2], row.ms[3], row.ms[4], row.ms[5], row.ms[6], row.n_struct, row.n_landmarks);
       row.valid = false;
     };
+    StructureBatch structure;
+    bool structure_in_flight = false;
+    auto finish_structure = [&]() {
+      if (!structure_in_flight) return;
+      structure_in_flight = false;
+      if (svoh_optimize_points_batch_collect(ctx, (int)structure.size(), structure.pos.data(), nullptr) != SVOH_OK)
+        throw std::runtime_error(std::string("svoh_optimize_points_batch_collect: ") + svoh_last_error_string(ctx));
+      structure.apply(structure.pos.data());
+    };
     for (size_t k = 0; k < order.size(); ++k) {
       const io::GrayImage& img = images[order[k]];
       const double t0 = now_ms();
@@ -236,6 +245,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
       // position on the device from the update's batch, svoh_align_camera::pos_seed_unit -- and the wait runs in its hook)
       const double t0f = now_ms();
       const bool align_ahead = !sync_flow && align_ahead_on && k > 0 && depth_filter.updateInFlight();
+      finish_structure();   // the points optimised behind the frame before: their positions are read from here on
       if (!align_ahead) finish_row();
       const double t1 = now_ms();
       size_t n_aligned = 0, n_reproj = 0, n_pose = 0, n_seed_upd = 0, n_struct = 0;
@@ -280,8 +290,20 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
           if (sync_flow || no_prepare) n_pose = pose_optimizer.run(b_cur, 2.0);
           else n_pose = pose_optimizer.run(b_cur, 2.0, [&]() { depth_filter.prepareUpdateSeeds(visible, frame); });
         }
-        // 3b. structure optimisation of the frame's landmarks (frame_handler_mono.cpp:157: optimizeStructure(new_frames_, max_pts, 5))
-        if (landmarks_on) n_struct = optimizeStructure(ctx, b_cur, params.structure_optimization_max_pts, 5);
+        // 3b. structure optimisation of the frame's landmarks (frame_handler_mono.cpp:157: optimizeStructure(new_frames_, max_pts, 5)).
+        // Pipelined flow: queued here and collected at the next frame's start, before anything reads a point's position again (the
+        // keyframe step in between makes points and adds observations; it moves none) -- the same bytes as the blocking call.
+        if (landmarks_on && sync_flow) n_struct = optimizeStructure(ctx, b_cur, params.structure_optimization_max_pts, 5);
+        else if (landmarks_on && params.structure_optimization_max_pts != 0) {
+          structure.gather(*frame, params.structure_optimization_max_pts);
+          n_struct = structure.size();
+          if (n_struct) {
+            if (svoh_optimize_points_batch_enqueue(ctx, 5, 0, (int)structure.views.size(), structure.views.data(), (int)structure.size(), structure.obs_begin.data(),
+                                                   structure.obs_view.data(), structure.obs_f.data(), structure.pos.data()) != SVOH_OK)
+              throw std::runtime_error(std::string("svoh_optimize_points_batch_enqueue: ") + svoh_last_error_string(ctx));
+            structure_in_flight = true;
+          }
+        }
         t4 = now_ms();
         // 4. depth filter (frame_handler_mono.cpp:125: the keyframes that were visible from this frame are updated with it -- in the
         // reference at the start of the NEXT frame, i.e. after this frame may have become a keyframe and upgraded some of their seeds
@@ -306,6 +328,7 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
       if (sync_flow) finish_row();
       if (k > 0) { sum_ms += t6 - t0; ++n_done; }
     }
+    finish_structure();
     finish_row();
     out->wall_ms = now_ms() - wall0;
     fclose(fc);
