@@ -1,0 +1,605 @@
+// svo_hip_lockstep_stereo.cpp -- FrontendLockstepStereo (svo_hip_lockstep_stereo.h): many stereo streams, one launch per per-pair stage.
+#include "svo_hip_lockstep_stereo.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "svo_hip_host_internal.h"
+
+namespace svo_hip {
+
+struct FrontendLockstepStereo::Stream {
+  SparseImgAlignHip img_align;
+  ReprojectorHip rp0, rp1;
+  ReprojectorHip* rp[2];
+  PoseOptimizerHip pose_optimizer;
+  DetectorHip seed_detector;
+  std::shared_ptr<DetectorHip> tri_detector;
+  StereoTriangulationHip stereo;
+  unsigned shuffle_state = 12345u;   // (svoh_mini_stereo's reproducible order instead of rand())
+  std::deque<FramePtr> kfs;
+  FrameBundle::Ptr last, bundle;
+  std::vector<FramePtr> visible;
+  std::vector<PointPtr> trash;
+  size_t k = 0;                      // pairs taken so far
+  bool active = false, tracking = false, starting = false;
+  int slot = -1;
+  // the round in progress
+  svoh_align_options align_opt{};
+  svoh_align_problem align_pb{};
+  Transformation T_iref_world{ { 1, 0, 0, 0 }, { 0, 0, 0 } };
+  int32_t align_key = 0;
+  int align_result = -1;
+  size_t direct_off = 0, seeds_off = 0, ref_off = 0;
+  bool needs_more = false;
+  size_t n_reproj = 0;
+  bool do_pose = false;
+  svoh_pose_options pose_opt{};
+  svoh_pose_problem pose_pb{};
+  int pose_slot = -1;
+  size_t n_pose = 0;
+  StructureBatch structure;
+  size_t structure_off = 0, structure_view_off = 0, structure_obs_off = 0;
+  int structure_max_pts = 0;
+  int next_point_id = 1 << 20;       // (the triangulation's points count from 0)
+  // the seed update being built / in flight
+  std::vector<FramePtr> seed_frames;
+  std::vector<size_t> seed_counts;
+  size_t seed_off = 0;
+  PairRow row;
+  bool row_open = false;
+  std::vector<PairRow> done_rows;
+
+  static ReprojectorOptions reprojector_options(const io::FrontendParams& p)
+  {
+    ReprojectorOptions ropt;
+    ropt.max_n_features_per_frame = static_cast<size_t>(p.max_fts);
+    ropt.cell_size = static_cast<size_t>(p.grid_size);
+    ropt.seed_sigma2_thresh = p.seed_sigma2_thresh;
+    ropt.affine_est_offset = p.reprojector_affine_est_offset;
+    ropt.affine_est_gain = true;   // the stereo-imu configuration estimates the gain in the matcher as well
+    return ropt;
+  }
+  static StereoTriangulationOptions triangulation_options()
+  {
+    StereoTriangulationOptions sto;
+    sto.triangulate_n_features = 120;   // svo_factory.cpp:240
+    return sto;
+  }
+  Stream(svoh_ctx* ctx, const StereoLockstepOptions& o)
+      : img_align(ctx, SparseImgAlignHip::getDefaultSolverOptions(), o.params.img_align), rp0(ctx, reprojector_options(o.params), 0), rp1(ctx, reprojector_options(o.params), 1),
+        pose_optimizer(ctx), seed_detector(ctx, o.params.detector, o.rig[0].cam.width, o.rig[0].cam.height),
+        tri_detector(new DetectorHip(ctx, o.params.detector, o.rig[0].cam.width, o.rig[0].cam.height)), stereo(ctx, triangulation_options(), tri_detector)
+  {
+    rp[0] = &rp0; rp[1] = &rp1;
+    rp0.sortPlannedListsOnly(true); rp1.sortPlannedListsOnly(true);
+    stereo.shuffle_ = [this](std::vector<size_t>& idx, size_t n_corners) {
+      auto rnd = [&]() { shuffle_state = shuffle_state * 1664525u + 1013904223u; return shuffle_state >> 8; };
+      auto shuf = [&](size_t a, size_t b) { for (size_t i = b; i > a + 1; --i) std::swap(idx[i - 1], idx[a + rnd() % (i - a)]); };
+      shuf(0, std::min(n_corners, idx.size())); shuf(std::min(n_corners, idx.size()), idx.size());
+    };
+  }
+};
+
+void FrontendLockstepStereo::check(int rc, const char* what) const
+{
+  if (rc != SVOH_OK) throw std::runtime_error(std::string(what) + ": " + svoh_last_error_string(ctx_));
+}
+
+FrontendLockstepStereo::FrontendLockstepStereo(svoh_ctx* ctx, int n_streams, const StereoLockstepOptions& options) : ctx_(ctx), opt_(options)
+{
+  requireMatchingAbi();
+  if (!ctx_) throw std::runtime_error("FrontendLockstepStereo: NULL svoh_ctx (no CPU fallback exists)");
+  if (n_streams < 1 || n_streams > 128) throw std::runtime_error("FrontendLockstepStereo: n_streams out of range [1, 128]");
+  if (opt_.rig.size() != 2) throw std::runtime_error("FrontendLockstepStereo: a rig of two cameras is needed");
+  if (opt_.rig[0].cam.width != opt_.rig[1].cam.width || opt_.rig[0].cam.height != opt_.rig[1].cam.height)
+    throw std::runtime_error("FrontendLockstepStereo: the two cameras must have one image size (their pyramids are built in one call)");
+  if (opt_.kf_every < 1) throw std::runtime_error("FrontendLockstepStereo: kf_every must be >= 1");
+  opt_.params.depth_filter.use_threaded_depthfilter = false;
+  // euroc_stereo_imu.yaml:30-31: img_align_est_illumination_gain / _offset (as svoh_mini_stereo)
+  opt_.params.img_align.estimate_illumination_gain = true;
+  opt_.params.img_align.estimate_illumination_offset = true;
+  pool_.reset(new WorkerPool(opt_.n_workers < 1 ? 1 : opt_.n_workers, false));
+  for (int s = 0; s < n_streams; ++s) streams_.emplace_back(new Stream(ctx_, opt_));
+}
+
+FrontendLockstepStereo::~FrontendLockstepStereo()
+{
+  try { finish(); } catch (...) {}
+  if (seeds_in_flight_) (void)svoh_matcher_collect(ctx_);
+  for (auto& st : streams_) {
+    for (const FramePtr& f : st->kfs) for (auto& sr : f->seed_ref_vec_) sr.keyframe.reset();
+    if (st->last) for (const FramePtr& f : st->last->frames_) for (auto& sr : f->seed_ref_vec_) sr.keyframe.reset();
+  }
+  streams_.clear();
+  drainReleases();
+}
+
+void FrontendLockstepStereo::drainReleases()
+{
+  std::vector<svoh_frame_t> r;
+  { std::lock_guard<std::mutex> lock(release_mu_); r.swap(to_release_); }
+  for (svoh_frame_t h : r) (void)svoh_release_frame(ctx_, h);
+}
+
+Transformation FrontendLockstepStereo::pose(int s) const
+{
+  const Stream& st = *streams_.at(static_cast<size_t>(s));
+  if (!st.last) throw std::runtime_error("FrontendLockstepStereo::pose: no pair yet");
+  return st.last->at(0)->T_imu_world();
+}
+
+size_t FrontendLockstepStereo::keyframesAlive(int s) const { return streams_.at(static_cast<size_t>(s))->kfs.size(); }
+
+std::vector<FrontendLockstepStereo::PairRow> FrontendLockstepStereo::completedRows(int s)
+{
+  std::vector<PairRow> out;
+  out.swap(streams_.at(static_cast<size_t>(s))->done_rows);
+  return out;
+}
+
+void FrontendLockstepStereo::finish()
+{
+  finishSecondSeedUpdate();
+  drainReleases();
+}
+
+namespace {
+size_t num_landmarks(const Frame& f)
+{
+  size_t n = 0;
+  for (size_t i = 0; i < f.num_features_ && i < f.landmark_vec_.size(); ++i) n += f.landmark_vec_[i] != nullptr;
+  return n;
+}
+bool scene_depth(const Frame& f, double& d_med, double& d_min)   // frame_utils::getSceneDepth on the landmarks (as svoh_mini_stereo)
+{
+  std::vector<double> d;
+  for (size_t i = 0; i < f.num_features_ && i < f.landmark_vec_.size(); ++i)
+    if (f.landmark_vec_[i]) { const svoh::Vec3 p = svoh::transform(f.T_f_w_, f.landmark_vec_[i]->pos()); d.push_back(sqrt(p.x * p.x + p.y * p.y + p.z * p.z)); }
+  if (d.empty()) return false;
+  std::sort(d.begin(), d.end());
+  d_med = d[d.size() / 2]; d_min = d.front();
+  return true;
+}
+}  // namespace
+
+// svoh_mini_stereo's make_keyframe for ONE stream, with the mirrors' own blocking calls (the caller is the context's thread)
+void FrontendLockstepStereo::makeKeyframe(Stream& st, size_t kf_id)
+{
+  const FrameBundle::Ptr& b = st.bundle;
+  // stereo triangulation of new features where the left frame has no feature yet (frame_handler_stereo.cpp:146-155); the frame that
+  // is not the keyframe upgrades the seeds it hangs on first, as the reference's branch does (:149-154)
+  if (opt_.landmarks) upgradeSeedsToFeatures(ctx_, b->at(1 - kf_id), &st.next_point_id);
+  st.tri_detector->resetGrid();
+  st.tri_detector->fillGridWithKeypoints(b->at(0)->px_vec_, b->at(0)->num_features_);
+  st.stereo.compute(b->at(0), b->at(1));
+  // the keyframe's seeds become landmarks (upgradeSeedsToFeatures, :162), then new seeds in its free cells (depth_filter_->addKeyframe, :167-173)
+  double d_med = 0, d_min = 0;
+  const FramePtr& f = b->at(kf_id);
+  if (opt_.landmarks) upgradeSeedsToFeatures(ctx_, f, &st.next_point_id);
+  if (scene_depth(*b->at(0), d_med, d_min)) {
+    st.seed_detector.resetGrid();
+    st.seed_detector.fillGridWithKeypoints(f->px_vec_, f->num_features_);
+    const size_t n_old = f->num_features_;
+    depth_filter_utils::initializeSeeds(f, st.seed_detector, static_cast<size_t>(opt_.params.max_n_seeds_per_frame), static_cast<float>(0.5 * d_min), static_cast<float>(1.5 * d_med),
+                                        static_cast<float>(d_med));
+    for (size_t i = n_old; i < f->num_features_; ++i) { f->seed_ref_vec_[i].keyframe = f; f->seed_ref_vec_[i].seed_id = static_cast<int>(i); }
+  }
+  const size_t max_kfs = 2 * st.rp0.options_.max_n_kfs;
+  for (size_t c = 0; c < 2; ++c) {
+    st.kfs.push_back(b->at(c));
+    while (st.kfs.size() > max_kfs) {
+      for (auto& sr : st.kfs.front()->seed_ref_vec_) sr.keyframe.reset();
+      removeObservationsOf(*st.kfs.front());   // (Map::removeKeyframe)
+      st.kfs.pop_front();
+    }
+  }
+}
+
+// depth_filter_->updateSeeds(overlap_kfs, new_frames_->at(c)) (frame_handler_stereo.cpp:127-129) for every tracking stream in ONE batch: the
+// units are DepthFilterHip::queueUpdateSeeds' (every feature of every visible keyframe), a stream's units name its own frames
+void FrontendLockstepStereo::seedUpdate(const std::vector<int>& trk, int c, bool leave_in_flight)
+{
+  sb_ = SeedBatch();
+  sb_.streams = trk;
+  sb_.curs.resize(trk.size());
+  for (int s : trk) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    st.seed_frames = st.visible;
+    st.seed_counts.clear();
+    st.seed_off = sb_.type.size();
+    sb_.curs[static_cast<size_t>(st.slot)] = detail::viewOf(*st.bundle->at(static_cast<size_t>(c)));
+    for (const FramePtr& rf : st.seed_frames) {
+      const Frame& r = *rf;
+      const int32_t ref = static_cast<int32_t>(sb_.refs.size());
+      sb_.refs.push_back(detail::viewOf(r));
+      const size_t n = r.num_features_;
+      st.seed_counts.push_back(n);
+      sb_.ref_idx.insert(sb_.ref_idx.end(), n, ref);
+      sb_.cur_idx.insert(sb_.cur_idx.end(), n, st.slot);
+      sb_.px.insert(sb_.px.end(), r.px_vec_.begin(), r.px_vec_.begin() + 2 * n);
+      sb_.f.insert(sb_.f.end(), r.f_vec_.begin(), r.f_vec_.begin() + 3 * n);
+      sb_.grad.insert(sb_.grad.end(), r.grad_vec_.begin(), r.grad_vec_.begin() + 2 * n);
+      sb_.level.insert(sb_.level.end(), r.level_vec_.begin(), r.level_vec_.begin() + n);
+      sb_.type.insert(sb_.type.end(), r.type_vec_.begin(), r.type_vec_.begin() + n);
+      sb_.state.insert(sb_.state.end(), r.invmu_sigma2_a_b_vec_.begin(), r.invmu_sigma2_a_b_vec_.begin() + 4 * n);
+    }
+  }
+  const size_t n_total = sb_.type.size();
+  if (n_total == 0) { for (int s : trk) { streams_[static_cast<size_t>(s)]->seed_frames.clear(); streams_[static_cast<size_t>(s)]->seed_counts.clear(); } return; }
+  sb_.success.assign(n_total, 0);
+  sb_.result.assign(n_total, SVOH_MATCH_NOT_RUN);
+  svoh_feature_batch fb{};
+  fb.n = static_cast<int32_t>(n_total);
+  fb.ref_frame_idx = sb_.ref_idx.data(); fb.px = sb_.px.data(); fb.f = sb_.f.data(); fb.grad = sb_.grad.data(); fb.level = sb_.level.data(); fb.type = sb_.type.data();
+  fb.cur_frame_idx = sb_.cur_idx.data(); fb.n_cur_frames = static_cast<int32_t>(trk.size());
+  DepthFilterHip df(ctx_, opt_.params.depth_filter);   // (options only: the batch is the driver's)
+  const svoh_depth_filter_options dfo = df.abiOptions(*streams_[static_cast<size_t>(trk[0])]->bundle->at(static_cast<size_t>(c)));
+  const svoh_matcher_options mopt = df.getMatcherOptions();
+  check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
+  int rc = svoh_update_seeds_batch(ctx_, &mopt, &dfo, static_cast<int>(sb_.refs.size()), sb_.refs.data(), sb_.curs.data(), &fb, sb_.state.data(), sb_.success.data(), sb_.result.data(), nullptr);
+  if (rc == SVOH_OK) rc = svoh_matcher_flush(ctx_);
+  if (rc != SVOH_OK) { const std::string msg = svoh_last_error_string(ctx_); (void)svoh_matcher_collect(ctx_); throw std::runtime_error("svoh_update_seeds_batch: " + msg); }
+  ++device_calls_;
+  seeds_in_flight_ = true;
+  if (!leave_in_flight) collectSeedUpdate();
+}
+
+void FrontendLockstepStereo::collectSeedUpdate()
+{
+  if (!seeds_in_flight_) return;
+  seeds_in_flight_ = false;
+  check(svoh_matcher_collect(ctx_), "svoh_matcher_collect");
+  ++device_calls_;
+  pool_->run(static_cast<int>(sb_.streams.size()), [&](int w) {
+    Stream& st = *streams_[static_cast<size_t>(sb_.streams[static_cast<size_t>(w)])];
+    size_t off = st.seed_off, n_applied = 0;
+    for (size_t k = 0; k < st.seed_frames.size(); ++k) {
+      Frame& r = *st.seed_frames[k];
+      const size_t n = st.seed_counts[k];
+      // (a seed that became a feature while its update was in flight keeps what the upgrade made of it: DepthFilterHip::finishUpdateSeedsNow's rule)
+      for (size_t i = 0; i < n; ++i) {
+        if (r.type_vec_[i] >= SVOH_FT_EDGELET) continue;
+        std::copy(sb_.state.begin() + 4 * (off + i), sb_.state.begin() + 4 * (off + i + 1), r.invmu_sigma2_a_b_vec_.begin() + 4 * i);
+        r.type_vec_[i] = sb_.type[off + i];
+        n_applied += sb_.success[off + i];
+      }
+      off += n;
+    }
+    st.seed_frames.clear(); st.seed_counts.clear();
+    st.row.n_seed_upd += n_applied;
+  });
+}
+
+// the second camera's update of the round before: waited for, written back; the rows of that round are complete
+void FrontendLockstepStereo::finishSecondSeedUpdate()
+{
+  collectSeedUpdate();
+  for (auto& stp : streams_) {
+    Stream& st = *stp;
+    if (!st.row_open) continue;
+    st.done_rows.push_back(st.row);
+    st.row_open = false;
+  }
+}
+
+void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t* const* right, int pitch, const Transformation* T_imu_world_first, const svoh::Quat* const* imu_prior)
+{
+  const int S = numStreams();
+  device_calls_ = 0;
+  drainReleases();
+  if (!left || !right) throw std::runtime_error("FrontendLockstepStereo::addPairs: NULL images");
+  std::vector<int> trk, starting;
+  std::vector<const uint8_t*> imgs;
+  for (int s = 0; s < S; ++s) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    if ((left[s] == nullptr) != (right[s] == nullptr)) throw std::runtime_error("FrontendLockstepStereo::addPairs: a pair needs both images");
+    st.active = left[s] != nullptr;
+    st.tracking = st.active && st.last;
+    st.starting = st.active && !st.last;
+    st.slot = -1; st.do_pose = false; st.needs_more = false; st.pose_slot = -1; st.align_result = -1; st.n_reproj = 0; st.n_pose = 0;
+    if (st.tracking) { st.slot = static_cast<int>(trk.size()); trk.push_back(s); }
+    if (st.starting) { if (!T_imu_world_first) throw std::runtime_error("FrontendLockstepStereo::addPairs: a stream's first pair needs its pose"); starting.push_back(s); }
+    if (st.active) { imgs.push_back(left[s]); imgs.push_back(right[s]); }
+  }
+  const int nT = static_cast<int>(trk.size());
+
+  // ---- pyramids of the round's 2 x (active streams) images: one call
+  if (!imgs.empty()) {
+    std::vector<svoh_frame_t> handles(imgs.size(), 0);
+    check(svoh_build_pyramid_multi(ctx_, imgs.data(), static_cast<int>(imgs.size()), opt_.rig[0].cam.width, opt_.rig[0].cam.height, pitch, SVOH_MEM_HOST,
+                                   opt_.params.n_pyr_levels_to_build, SVOH_HALFSAMPLE_REFERENCE, handles.data()), "svoh_build_pyramid_multi");
+    ++device_calls_;
+    size_t at = 0;
+    for (int s = 0; s < S; ++s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      if (!st.active) continue;
+      st.bundle.reset(new FrameBundle);
+      for (int c = 0; c < 2; ++c) {
+        FramePtr frame(new Frame, [this](Frame* f) {
+          if (f->pyramid) { std::lock_guard<std::mutex> lock(release_mu_); to_release_.push_back(f->pyramid); }
+          delete f;
+        });
+        frame->pyramid = handles[at++];
+        frame->cam = opt_.rig[static_cast<size_t>(c)].cam;
+        frame->set_T_cam_imu(svoh::inverse(opt_.rig[static_cast<size_t>(c)].T_B_C));
+        frame->id_ = static_cast<int>(2 * st.k + static_cast<size_t>(c));
+        st.bundle->frames_.push_back(frame);
+      }
+    }
+  }
+  // the pair before: its second seed update is needed from here on (alignment points, candidates)
+  finishSecondSeedUpdate();
+
+  auto close_round = [&]() {
+    for (auto& stp : streams_) {
+      Stream& st = *stp;
+      if (!st.active) continue;
+      st.row.n_landmarks = num_landmarks(*st.bundle->at(0)) + num_landmarks(*st.bundle->at(1));
+      st.row_open = true;
+      st.last = st.bundle; st.bundle.reset();
+      ++st.k;
+    }
+    drainReleases();
+  };
+
+  // ---- first pairs: the rig's pose is given, stereo triangulation + seeds (StereoInit's stand-in, as svoh_mini_stereo's first pair)
+  for (int s : starting) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    for (const FramePtr& f : st.bundle->frames_) f->T_f_w_ = svoh::mul(f->T_cam_imu(), T_imu_world_first[s]);
+    st.row = PairRow(); st.row.k = st.k; st.row.is_kf = true;
+    makeKeyframe(st, 0);
+    st.row.alpha = st.img_align.lastResult().alpha; st.row.beta = st.img_align.lastResult().beta;
+  }
+  if (nT == 0) { close_round(); return; }
+
+  // ---- 1. sparse image alignment of the bundles, each with its stream's IMU rotation prior (frame_handler_base.cpp:610-643)
+  pool_->run(S, [&](int s) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    if (!st.tracking) return;
+    st.row = PairRow(); st.row.k = st.k;
+    for (size_t c = 0; c < 2; ++c) { st.bundle->at(c)->T_f_w_ = st.last->at(c)->T_f_w_; resolveAlignmentPoints(*st.last->at(c)); }
+    st.img_align.reset();
+    if (imu_prior && imu_prior[s] && opt_.lambda_rot > 0) {
+      Transformation T_prior{ *imu_prior[s], { 0, 0, 0 } };   // T_newimu_lastimu_prior: the rotation is what the weights use
+      st.img_align.setWeightedPrior(T_prior, 0.0, 0.0, opt_.lambda_rot, 0.0, 0.0, 0.0);
+    }
+    st.T_iref_world = st.img_align.prepareRun(st.last, st.bundle, st.align_opt, st.align_pb);
+    st.visible.assign(st.kfs.begin(), st.kfs.end());
+  });
+  {
+    auto same_options = [](const svoh_align_options& a, const svoh_align_options& b) {
+      return a.max_level == b.max_level && a.min_level == b.min_level && a.patch_size == b.patch_size && a.max_iter == b.max_iter && a.eps == b.eps &&
+             a.estimate_illumination_gain == b.estimate_illumination_gain && a.estimate_illumination_offset == b.estimate_illumination_offset &&
+             a.use_distortion_jacobian == b.use_distortion_jacobian && a.robustification == b.robustification && a.weight_scale == b.weight_scale;
+    };
+    std::vector<std::pair<int32_t, std::vector<int>>> groups;
+    for (int s : trk) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      check(svoh_sparse_align_geometry_key(ctx_, &st.align_opt, &st.align_pb, &st.align_key), "svoh_sparse_align_geometry_key");
+      size_t g = 0;
+      while (g < groups.size() && !(groups[g].first == st.align_key && same_options(streams_[static_cast<size_t>(groups[g].second[0])]->align_opt, st.align_opt))) ++g;
+      if (g == groups.size()) groups.emplace_back(st.align_key, std::vector<int>());
+      groups[g].second.push_back(s);
+    }
+    int next_result = 0;
+    std::vector<svoh_align_problem> pbs;
+    for (const auto& g : groups) {
+      pbs.clear();
+      for (int s : g.second) { Stream& st = *streams_[static_cast<size_t>(s)]; pbs.push_back(st.align_pb); st.align_result = next_result++; }
+      check(svoh_sparse_align_enqueue_keyed(ctx_, &streams_[static_cast<size_t>(g.second[0])]->align_opt, static_cast<int>(pbs.size()), pbs.data(), g.first), "svoh_sparse_align_enqueue_keyed");
+      ++device_calls_;
+    }
+    std::vector<svoh_align_result> results(static_cast<size_t>(nT));
+    check(svoh_sparse_align_fetch_all(ctx_, nT, results.data()), "svoh_sparse_align_fetch_all");
+    ++device_calls_;
+    for (int s : trk) {   // a cluster of workgroups that never completed (status 3): that problem again, one workgroup
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      if (results[static_cast<size_t>(st.align_result)].status != 3) continue;
+      check(svoh_sparse_align_batch(ctx_, &st.align_opt, 1, &st.align_pb, &results[static_cast<size_t>(st.align_result)]), "svoh_sparse_align_batch");
+      ++device_calls_;
+    }
+    pool_->run(S, [&](int s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      if (!st.tracking) return;
+      st.row.n_aligned = st.img_align.finishRun(results[static_cast<size_t>(st.align_result)], st.bundle, st.T_iref_world);
+    });
+  }
+
+  // ---- 2. reprojection, per camera (frame_handler_base.cpp:645-744): first every stream's camera 0, then every stream's camera 1 -- a
+  // stream's second camera sees what its first did to the landmarks' reprojection statistics and to the seeds it matched
+  svoh_matcher_stage_t ds{}, ss{};
+  for (int c = 0; c < 2; ++c) {
+    const size_t cc = static_cast<size_t>(c);
+    pool_->run(S, [&](int s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      if (!st.tracking) return;
+      ReprojectorHip& rp = *st.rp[c];
+      rp.discardCandidateProjection();
+      st.trash.clear();
+      rp.walkCandidates(st.bundle->at(cc), st.visible, st.trash);
+      rp.planMatches(st.bundle->at(cc), 3, false);
+    });
+    auto matcher_round = [&](const std::vector<int>& who, bool sort_meanwhile) {
+      size_t n_direct = 0, n_seeds = 0, n_refs = 0;
+      for (int s : who) {
+        Stream& st = *streams_[static_cast<size_t>(s)];
+        detail::SpeculativeMatches& sm = st.rp[c]->plannedMatches();
+        st.direct_off = n_direct; st.seeds_off = n_seeds; st.ref_off = n_refs;
+        n_direct += sm.direct.size(); n_seeds += sm.seeds.size(); n_refs += sm.frames.size();
+      }
+      ds = svoh_matcher_stage_t{}; ss = svoh_matcher_stage_t{};
+      auto sort_lists = [&]() { pool_->run(S, [&](int s) { Stream& st = *streams_[static_cast<size_t>(s)]; if (st.tracking) st.rp[c]->sortCandidateLists(); }); };
+      if (n_direct + n_seeds == 0) { if (sort_meanwhile) sort_lists(); return; }
+      const svoh_matcher_options mopt = detail::reprojectorMatcherOptions(opt_.params.reprojector_affine_est_offset, true);
+      const int max_views = static_cast<int>(n_refs) + nT + 1;
+      check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
+      struct CloseSection { svoh_ctx* c; bool armed; ~CloseSection() { if (armed) (void)svoh_matcher_collect(c); } } close_section{ ctx_, true };
+      if (n_direct) check(svoh_matcher_stage(ctx_, 0, static_cast<int>(n_direct), max_views, SVOH_STAGE_MATCH_OUTPUTS, &ds), "svoh_matcher_stage");
+      if (n_seeds) check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_seeds), max_views, SVOH_STAGE_MATCH_OUTPUTS, &ss), "svoh_matcher_stage");
+      std::vector<svoh_frame_view> refs(n_refs ? n_refs : 1), curs(static_cast<size_t>(nT));
+      for (int s : trk) { const Stream& st = *streams_[static_cast<size_t>(s)]; curs[static_cast<size_t>(st.slot)] = detail::viewOf(*st.bundle->at(cc)); }
+      pool_->run(static_cast<int>(who.size()), [&](int w) {
+        Stream& st = *streams_[static_cast<size_t>(who[static_cast<size_t>(w)])];
+        detail::SpeculativeMatches& sm = st.rp[c]->plannedMatches();
+        for (size_t k = 0; k < sm.frames.size(); ++k) refs[st.ref_off + k] = detail::viewOf(*sm.frames[k]);
+        auto copy_batch = [&](const detail::Batch& b, const svoh_matcher_stage_t& g, size_t o) {
+          const size_t m = b.size();
+          if (!m) return;
+          for (size_t i = 0; i < m; ++i) { g.ref_frame_idx[o + i] = b.ref_idx[i] + static_cast<int32_t>(st.ref_off); g.cur_frame_idx[o + i] = st.slot; }
+          memcpy(g.px + 2 * o, b.px.data(), 16 * m); memcpy(g.f + 3 * o, b.f.data(), 24 * m); memcpy(g.grad + 2 * o, b.grad.data(), 16 * m);
+          memcpy(g.level + o, b.level.data(), 4 * m);
+          memcpy(g.type + o, b.type.data(), m);
+        };
+        copy_batch(sm.direct, ds, st.direct_off);
+        if (const size_t m = sm.direct.size()) { memcpy(ds.depth + st.direct_off, sm.direct.depth.data(), 8 * m); memcpy(ds.px_cur + 2 * st.direct_off, sm.direct.px_cur.data(), 16 * m); }
+        copy_batch(sm.seeds, ss, st.seeds_off);
+        if (const size_t m = sm.seeds.size()) memcpy(ss.state + 4 * st.seeds_off, sm.seeds.state.data(), 32 * m);
+      });
+      auto batch_of = [&](const svoh_matcher_stage_t& g, size_t n) {
+        svoh_feature_batch fb{};
+        fb.n = static_cast<int32_t>(n);
+        fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = nT;
+        fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type; fb.feature_index = g.feature_index;
+        fb.mem_space = SVOH_MEM_STAGED;
+        return fb;
+      };
+      if (n_direct) {
+        const svoh_feature_batch fb = batch_of(ds, n_direct);
+        check(svoh_match_direct_batch(ctx_, &mopt, static_cast<int>(n_refs), refs.data(), curs.data(), &fb, ds.depth, ds.px_cur, ds.result, ds.f_cur, ds.search_level, nullptr, ds.A_cur_ref),
+              "svoh_match_direct_batch");
+      }
+      if (n_seeds) {
+        const svoh_feature_batch fb = batch_of(ss, n_seeds);
+        const svoh_depth_filter_options o = detail::reprojectorSeedOptions(*streams_[static_cast<size_t>(trk[0])]->bundle->at(cc), opt_.params.seed_sigma2_thresh);
+        const svoh_seed_match_outputs outs{ ss.px_cur, ss.f_cur, ss.search_level, ss.A_cur_ref };
+        check(svoh_update_seeds_batch_ex(ctx_, &mopt, &o, static_cast<int>(n_refs), refs.data(), curs.data(), &fb, ss.state, ss.success, ss.result, nullptr, &outs), "svoh_update_seeds_batch_ex");
+      }
+      check(svoh_matcher_flush(ctx_), "svoh_matcher_flush");
+      ++device_calls_;
+      if (sort_meanwhile) sort_lists();
+      close_section.armed = false;
+      check(svoh_matcher_collect(ctx_), "svoh_matcher_collect");
+      ++device_calls_;
+    };
+    auto point_outputs = [&](Stream& st) {
+      detail::SpeculativeMatches& sm = st.rp[c]->plannedMatches();
+      if (sm.direct.size()) {
+        const size_t o = st.direct_off;
+        sm.direct.out.result = ds.result + o; sm.direct.out.search_level = ds.search_level + o; sm.direct.out.px_cur = ds.px_cur + 2 * o;
+        sm.direct.out.f_cur = ds.f_cur + 3 * o; sm.direct.out.A = ds.A_cur_ref + 4 * o; sm.direct.out.type = ds.type + o; sm.direct.out.success = ds.success + o;
+      }
+      if (sm.seeds.size()) {
+        const size_t o = st.seeds_off;
+        sm.seeds.out.result = ss.result + o; sm.seeds.out.search_level = ss.search_level + o; sm.seeds.out.px_cur = ss.px_cur + 2 * o;
+        sm.seeds.out.f_cur = ss.f_cur + 3 * o; sm.seeds.out.A = ss.A_cur_ref + 4 * o; sm.seeds.out.state = ss.state + 4 * o; sm.seeds.out.type = ss.type + o;
+        sm.seeds.out.success = ss.success + o;
+      }
+    };
+    matcher_round(trk, true);
+    pool_->run(S, [&](int s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      if (!st.tracking) return;
+      point_outputs(st);
+      st.needs_more = st.rp[c]->replayMatchesUntilUnplanned(st.bundle->at(cc));
+    });
+    for (;;) {   // (all three lists are planned: no replay pauses; kept for a mirror that plans fewer)
+      std::vector<int> more;
+      for (int s : trk) if (streams_[static_cast<size_t>(s)]->needs_more) more.push_back(s);
+      if (more.empty()) break;
+      pool_->run(static_cast<int>(more.size()), [&](int w) { Stream& st = *streams_[static_cast<size_t>(more[static_cast<size_t>(w)])]; st.rp[c]->planPausedPass(st.bundle->at(cc), false, &st.visible); });
+      matcher_round(more, false);
+      pool_->run(static_cast<int>(more.size()), [&](int w) {
+        Stream& st = *streams_[static_cast<size_t>(more[static_cast<size_t>(w)])];
+        point_outputs(st);
+        st.needs_more = st.rp[c]->resumeReplay(st.bundle->at(cc));
+      });
+    }
+    for (int s : trk) { Stream& st = *streams_[static_cast<size_t>(s)]; st.n_reproj += st.bundle->at(cc)->num_features_; }
+  }
+
+  // ---- 3. pose optimisation of the rigs (frame_handler_base.cpp:746-790): one batch
+  {
+    std::vector<svoh_pose_problem> pbs;
+    std::vector<int> who;
+    pool_->run(S, [&](int s) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      if (!st.tracking) return;
+      st.row.n_reproj = st.n_reproj;
+      st.do_pose = st.n_reproj >= 10;
+      if (st.do_pose) st.pose_optimizer.prepareRun(st.bundle, 2.0, st.pose_opt, st.pose_pb);
+    });
+    for (int s : trk) { Stream& st = *streams_[static_cast<size_t>(s)]; if (st.do_pose) { st.pose_slot = static_cast<int>(pbs.size()); pbs.push_back(st.pose_pb); who.push_back(s); } }
+    if (!pbs.empty()) {
+      std::vector<svoh_pose_result> res(pbs.size());
+      check(svoh_optimize_pose_batch(ctx_, &streams_[static_cast<size_t>(who[0])]->pose_opt, static_cast<int>(pbs.size()), pbs.data(), res.data()), "svoh_optimize_pose_batch");
+      ++device_calls_;
+      pool_->run(static_cast<int>(who.size()), [&](int w) {
+        Stream& st = *streams_[static_cast<size_t>(who[static_cast<size_t>(w)])];
+        st.n_pose = st.pose_optimizer.finishRun(st.bundle, res[static_cast<size_t>(w)]);
+        st.row.n_pose = st.n_pose;
+      });
+    }
+  }
+
+  // ---- 3b. structure optimisation (frame_handler_stereo.cpp:114): optimizeStructure works through a bundle's frames one after the other (a
+  // point both cameras see is optimised twice, the second time from the first's result): two batches, each the landmarks of one camera of all streams
+  if (opt_.landmarks && opt_.params.structure_optimization_max_pts != 0) {
+    for (int s : trk) streams_[static_cast<size_t>(s)]->structure_max_pts = opt_.params.structure_optimization_max_pts;
+    for (size_t c = 0; c < 2; ++c) {
+      pool_->run(S, [&](int s) {
+        Stream& st = *streams_[static_cast<size_t>(s)];
+        if (!st.tracking) return;
+        st.structure_max_pts = st.structure.gather(*st.bundle->at(c), st.structure_max_pts);
+      });
+      size_t n_pts = 0, n_views = 0, n_obs = 0;
+      for (int s : trk) {
+        Stream& st = *streams_[static_cast<size_t>(s)];
+        st.structure_off = n_pts; st.structure_view_off = n_views; st.structure_obs_off = n_obs;
+        n_pts += st.structure.size(); n_views += st.structure.size() ? st.structure.views.size() : 0; n_obs += st.structure.size() ? st.structure.obs_view.size() : 0;
+      }
+      if (!n_pts) continue;
+      std::vector<svoh_se3> views(n_views);
+      std::vector<int32_t> obs_begin(n_pts + 1), obs_view(n_obs);
+      std::vector<double> obs_f(3 * n_obs), pos(3 * n_pts);
+      pool_->run(S, [&](int s) {
+        Stream& st = *streams_[static_cast<size_t>(s)];
+        if (!st.tracking || !st.structure.size()) return;
+        const StructureBatch& b = st.structure;
+        std::copy(b.views.begin(), b.views.end(), views.begin() + st.structure_view_off);
+        for (size_t k = 0; k < b.size(); ++k) obs_begin[st.structure_off + k] = b.obs_begin[k] + static_cast<int32_t>(st.structure_obs_off);
+        for (size_t k = 0; k < b.obs_view.size(); ++k) obs_view[st.structure_obs_off + k] = b.obs_view[k] + static_cast<int32_t>(st.structure_view_off);
+        std::copy(b.obs_f.begin(), b.obs_f.end(), obs_f.begin() + 3 * st.structure_obs_off);
+        std::copy(b.pos.begin(), b.pos.end(), pos.begin() + 3 * st.structure_off);
+      });
+      obs_begin[n_pts] = static_cast<int32_t>(n_obs);
+      check(svoh_optimize_points_batch(ctx_, 5, 0, static_cast<int>(n_views), views.data(), static_cast<int>(n_pts), obs_begin.data(), obs_view.data(), obs_f.data(), pos.data(), nullptr),
+            "svoh_optimize_points_batch");
+      ++device_calls_;
+      pool_->run(S, [&](int s) {
+        Stream& st = *streams_[static_cast<size_t>(s)];
+        if (!st.tracking || !st.structure.size()) return;
+        st.structure.apply(pos.data() + 3 * st.structure_off);
+      });
+    }
+  }
+
+  // ---- 4. keyframe rule (svoh_mini_stereo's); a keyframe pair's step comes BEFORE its seed updates, as makeKeyframe does (:162-175)
+  for (int s : trk) {
+    Stream& st = *streams_[static_cast<size_t>(s)];
+    const bool kf_next = st.k % opt_.kf_every == 0 || st.n_pose < 60;
+    if (kf_next) { makeKeyframe(st, (st.k / opt_.kf_every) % 2); st.row.is_kf = true; }
+    st.row.alpha = st.img_align.lastResult().alpha; st.row.beta = st.img_align.lastResult().beta;
+  }
+
+  // ---- 5. depth filter, per camera (frame_handler_stereo.cpp:127-129): the first camera's update of all streams, waited for (the second
+  // starts from its states), then the second camera's, left in flight until the next round
+  seedUpdate(trk, 0, false);
+  seedUpdate(trk, 1, true);
+  close_round();
+}
+
+}  // namespace svo_hip

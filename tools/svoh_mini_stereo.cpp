@@ -10,32 +10,137 @@
 //   depth-filter update of the keyframes' seeds, per camera         DepthFilterHip::updateSeeds
 //   at keyframes: stereo triangulation again + new seeds            StereoTriangulationHip::compute, initializeSeeds
 //
-// A harness over the built mirrors, NOT FrameHandlerStereo: no map (every live keyframe counts as overlapping), no
-// upgrade of converged seeds to landmarks, keyframes by a fixed rule, the first rig pose given.  The IMU prior is read
+// A harness over the built mirrors, NOT FrameHandlerStereo: no map (every live keyframe counts as overlapping), keyframes by a
+// fixed rule, the first rig pose given.  Round 6: a keyframe pair upgrades the seeds its frames hang on to landmarks
+// (upgradeSeedsToFeatures) and every pair's landmarks go through optimizeStructure, as the frame handler does
+// (SVOH_MINI_LANDMARKS=0: without).  The IMU prior is read
 // from <dataset_root>/mav0/imu_prior.csv (one line per frame: qw qx qy qz of R_imu(k)_imu(k-1)), or, without that file,
 // integrated from the raw gyroscope of an EuRoC folder (mav0/imu0/data.csv, io::relativeRotationPrior); with neither no
 // prior is set.
 //
 //   svoh_mini_stereo <dataset_root> <calib.yaml (two cameras)> <params.yaml|-> <out_dir> <T_imu_world of frame 0: qw qx qy qz tx ty tz>
-//                    [max_frames] [kf_every] [prior_lambda_rot]
+//                    [max_frames] [kf_every] [prior_lambda_rot] [n_streams] [n_workers]
 // Writes <out>/trajectory.txt (TUM format, T_world_imu) and <out>/frontend.csv.
+// n_streams given (round 6): that many stereo streams in LOCK STEP on one context (FrontendLockstepStereo, host/svo_hip_lockstep_stereo.h):
+// one pair of every stream at a time, every per-pair stage one launch for all of them; stream k writes into <out>/stream<k>/ (k > 0).
+// SVOH_MINI_STEREO_ROOTS=<root>:<root>:... gives the streams DIFFERENT sequences (stream k replays root k % n; a root's first pose is read
+// from <root>/T0.txt, seven numbers, its priors from its own mav0/imu_prior.csv): every stream must write what the single-stream run of ITS
+// root writes, byte for byte (tests/test_mini_stereo_gpu.py).
+#include <sys/stat.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../svo_pro_universal_amd/host/svo_hip_io.h"
+#include "../svo_pro_universal_amd/host/svo_hip_lockstep_stereo.h"
 
 using namespace svo_hip;
 
 static double now_ms()
 {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// the rotation priors of a dataset root: mav0/imu_prior.csv (one line per frame: qw qx qy qz of R_imu(k)_imu(k-1))
+static void read_priors(const std::string& root, std::vector<svoh::Quat>* imu_prior, std::vector<bool>* have_prior)
+{
+  std::ifstream in(root + "/mav0/imu_prior.csv");
+  std::string line;
+  while (std::getline(in, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    for (char& c : line) if (c == ',') c = ' ';
+    std::istringstream ss(line);
+    svoh::Quat q{ 1, 0, 0, 0 };
+    const bool parsed = static_cast<bool>(ss >> q.w >> q.x >> q.y >> q.z);
+    imu_prior->push_back(parsed ? q : svoh::Quat{ 1, 0, 0, 0 });
+    have_prior->push_back(parsed);
+  }
+}
+
+// n_streams stereo streams in lock step (FrontendLockstepStereo); stream k replays root k % n_roots
+static int run_lockstep(const std::vector<std::string>& roots, const std::vector<io::RigCamera>& rig, const io::FrontendParams& params, const std::string& out_dir,
+                        const Transformation& T0_default, size_t max_frames, size_t kf_every, double lambda_rot, int n_streams, int n_workers)
+{
+  svoh_ctx* ctx = nullptr;
+  if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
+  struct Root { io::EurocSequence seq; std::vector<io::GrayImage> left, right; std::vector<svoh::Quat> prior; std::vector<bool> have; Transformation T0; size_t n = 0; };
+  std::vector<Root> data(roots.size());
+  for (size_t r = 0; r < roots.size(); ++r) {
+    Root& d = data[r];
+    d.seq = io::openEuroc(roots[r]);
+    if (d.seq.cam1_files.size() != d.seq.cam0_files.size()) throw std::runtime_error("two image folders are needed: " + roots[r]);
+    d.n = std::min(d.seq.size(), max_frames);
+    for (size_t k = 0; k < d.n; ++k) { d.left.push_back(io::readPngGray(d.seq.cam0_files[k])); d.right.push_back(io::readPngGray(d.seq.cam1_files[k])); }
+    read_priors(roots[r], &d.prior, &d.have);
+    d.T0 = T0_default;
+    std::ifstream t0(roots[r] + "/T0.txt");
+    double v[7];
+    if (t0 >> v[0] >> v[1] >> v[2] >> v[3] >> v[4] >> v[5] >> v[6]) d.T0 = Transformation{ { v[0], v[1], v[2], v[3] }, { v[4], v[5], v[6] } };
+  }
+  {
+    StereoLockstepOptions lo;
+    lo.params = params; lo.rig = rig; lo.kf_every = kf_every; lo.lambda_rot = lambda_rot; lo.n_workers = n_workers;
+    if (getenv("SVOH_MINI_LANDMARKS")) lo.landmarks = atoi(getenv("SVOH_MINI_LANDMARKS")) != 0;
+    FrontendLockstepStereo fe(ctx, n_streams, lo);
+    std::vector<std::unique_ptr<io::TrajectoryWriter>> traj;
+    std::vector<FILE*> csv;
+    for (int s = 0; s < n_streams; ++s) {
+      const std::string dir = s == 0 ? out_dir : out_dir + "/stream" + std::to_string(s);
+      traj.emplace_back(new io::TrajectoryWriter(dir + "/trajectory.txt"));
+      FILE* fc = fopen((dir + "/frontend.csv").c_str(), "w");
+      if (!fc) throw std::runtime_error("cannot write into " + dir);
+      fprintf(fc, "frame,is_kf,n_aligned,n_reprojected,n_after_pose_opt,n_seeds_updated,n_landmarks,alpha,beta,ms_pyramid,ms_align,ms_reproject,ms_pose,ms_seeds,ms_kf,ms_pair\n");
+      csv.push_back(fc);
+    }
+    auto write_rows = [&]() {
+      for (int s = 0; s < n_streams; ++s)
+        for (const FrontendLockstepStereo::PairRow& r : fe.completedRows(s))
+          fprintf(csv[(size_t)s], "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.6f,%.4f,0,0,0,0,0,0,0\n", r.k, (int)r.is_kf, r.n_aligned, r.n_reproj, r.n_pose, r.n_seed_upd, r.n_landmarks, r.alpha, r.beta);
+    };
+    size_t n_rounds = 0;
+    for (int s = 0; s < n_streams; ++s) n_rounds = std::max(n_rounds, data[(size_t)s % data.size()].n);
+    std::vector<const uint8_t*> left((size_t)n_streams), right((size_t)n_streams);
+    std::vector<Transformation> T_first((size_t)n_streams);
+    std::vector<const svoh::Quat*> prior((size_t)n_streams);
+    double sum_ms = 0;
+    size_t pairs = 0;
+    for (size_t k = 0; k < n_rounds; ++k) {
+      size_t n_now = 0;
+      for (int s = 0; s < n_streams; ++s) {
+        const Root& d = data[(size_t)s % data.size()];
+        const bool has = k < d.n;
+        left[(size_t)s] = has ? d.left[k].data.data() : nullptr;
+        right[(size_t)s] = has ? d.right[k].data.data() : nullptr;
+        T_first[(size_t)s] = d.T0;
+        prior[(size_t)s] = has && k < d.prior.size() && d.have[k] ? &d.prior[k] : nullptr;
+        n_now += has;
+      }
+      const double t0 = now_ms();
+      fe.addPairs(left.data(), right.data(), data[0].left[0].width, T_first.data(), prior.data());
+      const double t1 = now_ms();
+      if (k > 0) { sum_ms += t1 - t0; pairs += n_now; }
+      for (int s = 0; s < n_streams; ++s) {
+        const Root& d = data[(size_t)s % data.size()];
+        if (k < d.n) traj[(size_t)s]->write(d.seq.cam_ts[k], svoh::inverse(fe.pose(s)));
+      }
+      write_rows();
+    }
+    fe.finish();
+    write_rows();
+    for (FILE* f : csv) fclose(f);
+    printf("svoh_mini_stereo lockstep: %d streams, %d host thread(s): %zu pairs in %.1f ms = %.0f pairs/s, %.3f ms per round, %d device calls per round\n", n_streams, n_workers,
+           pairs, sum_ms, pairs ? 1e3 * (double)pairs / sum_ms : 0.0, n_rounds > 1 ? sum_ms / (double)(n_rounds - 1) : 0.0, fe.lastRoundDeviceCalls());
+  }
+  svoh_destroy(ctx);
+  return 0;
 }
 
 int main(int argc, char** argv)
@@ -56,6 +161,16 @@ int main(int argc, char** argv)
     const size_t kf_every = argc > 13 ? (size_t)atol(argv[13]) : 8;
     const double lambda_rot = argc > 14 ? atof(argv[14]) : 0.5;
     const size_t n_frames = std::min(seq.size(), max_frames);
+    if (argc > 15) {   // lock step
+      const int n_streams = atoi(argv[15]), n_workers = argc > 16 ? atoi(argv[16]) : 1;
+      if (n_streams < 1 || n_streams > 128 || n_workers < 1) throw std::runtime_error("n_streams / n_workers out of range");
+      std::vector<std::string> roots;
+      if (const char* e = getenv("SVOH_MINI_STEREO_ROOTS")) { std::stringstream ss(e); std::string r; while (std::getline(ss, r, ':')) if (!r.empty()) roots.push_back(r); }
+      if (roots.empty()) roots.push_back(argv[1]);
+      for (int s = 1; s < n_streams; ++s) (void)mkdir((out_dir + "/stream" + std::to_string(s)).c_str(), 0755);
+      params.depth_filter.use_threaded_depthfilter = false;
+      return run_lockstep(roots, rig, params, out_dir, T_imu_world0, max_frames, kf_every, lambda_rot, n_streams, n_workers);
+    }
 
     // the IMU's relative rotations, if the dataset has them
     // have_prior[k]: a prior was really parsed / integrated for frame k.  The reference applies NO prior to a frame whose
