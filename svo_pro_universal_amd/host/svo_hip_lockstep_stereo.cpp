@@ -2,6 +2,7 @@
 #include "svo_hip_lockstep_stereo.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -206,28 +207,41 @@ void FrontendLockstepStereo::seedUpdate(const std::vector<int>& trk, int c, bool
   sb_ = SeedBatch();
   sb_.streams = trk;
   sb_.curs.resize(trk.size());
-  for (int s : trk) {
-    Stream& st = *streams_[static_cast<size_t>(s)];
+  // where every stream's units and reference frames go, then every stream fills its slices (pool)
+  size_t n_units = 0, n_refs = 0;
+  std::vector<size_t> ref_off(trk.size());
+  for (size_t w = 0; w < trk.size(); ++w) {
+    Stream& st = *streams_[static_cast<size_t>(trk[w])];
     st.seed_frames = st.visible;
     st.seed_counts.clear();
-    st.seed_off = sb_.type.size();
-    sb_.curs[static_cast<size_t>(st.slot)] = detail::viewOf(*st.bundle->at(static_cast<size_t>(c)));
-    for (const FramePtr& rf : st.seed_frames) {
-      const Frame& r = *rf;
-      const int32_t ref = static_cast<int32_t>(sb_.refs.size());
-      sb_.refs.push_back(detail::viewOf(r));
-      const size_t n = r.num_features_;
-      st.seed_counts.push_back(n);
-      sb_.ref_idx.insert(sb_.ref_idx.end(), n, ref);
-      sb_.cur_idx.insert(sb_.cur_idx.end(), n, st.slot);
-      sb_.px.insert(sb_.px.end(), r.px_vec_.begin(), r.px_vec_.begin() + 2 * n);
-      sb_.f.insert(sb_.f.end(), r.f_vec_.begin(), r.f_vec_.begin() + 3 * n);
-      sb_.grad.insert(sb_.grad.end(), r.grad_vec_.begin(), r.grad_vec_.begin() + 2 * n);
-      sb_.level.insert(sb_.level.end(), r.level_vec_.begin(), r.level_vec_.begin() + n);
-      sb_.type.insert(sb_.type.end(), r.type_vec_.begin(), r.type_vec_.begin() + n);
-      sb_.state.insert(sb_.state.end(), r.invmu_sigma2_a_b_vec_.begin(), r.invmu_sigma2_a_b_vec_.begin() + 4 * n);
-    }
+    st.seed_off = n_units;
+    ref_off[w] = n_refs;
+    for (const FramePtr& rf : st.seed_frames) { st.seed_counts.push_back(rf->num_features_); n_units += rf->num_features_; }
+    n_refs += st.seed_frames.size();
   }
+  sb_.refs.resize(n_refs);
+  sb_.ref_idx.resize(n_units); sb_.cur_idx.resize(n_units); sb_.level.resize(n_units); sb_.type.resize(n_units);
+  sb_.px.resize(2 * n_units); sb_.f.resize(3 * n_units); sb_.grad.resize(2 * n_units); sb_.state.resize(4 * n_units);
+  pool_->run(static_cast<int>(trk.size()), [&](int w) {
+    Stream& st = *streams_[static_cast<size_t>(trk[static_cast<size_t>(w)])];
+    sb_.curs[static_cast<size_t>(st.slot)] = detail::viewOf(*st.bundle->at(static_cast<size_t>(c)));
+    size_t off = st.seed_off;
+    for (size_t k = 0; k < st.seed_frames.size(); ++k) {
+      const Frame& r = *st.seed_frames[k];
+      const int32_t ref = static_cast<int32_t>(ref_off[static_cast<size_t>(w)] + k);
+      sb_.refs[static_cast<size_t>(ref)] = detail::viewOf(r);
+      const size_t n = st.seed_counts[k];
+      std::fill(sb_.ref_idx.begin() + off, sb_.ref_idx.begin() + off + n, ref);
+      std::fill(sb_.cur_idx.begin() + off, sb_.cur_idx.begin() + off + n, st.slot);
+      std::copy(r.px_vec_.begin(), r.px_vec_.begin() + 2 * n, sb_.px.begin() + 2 * off);
+      std::copy(r.f_vec_.begin(), r.f_vec_.begin() + 3 * n, sb_.f.begin() + 3 * off);
+      std::copy(r.grad_vec_.begin(), r.grad_vec_.begin() + 2 * n, sb_.grad.begin() + 2 * off);
+      std::copy(r.level_vec_.begin(), r.level_vec_.begin() + n, sb_.level.begin() + off);
+      std::copy(r.type_vec_.begin(), r.type_vec_.begin() + n, sb_.type.begin() + off);
+      std::copy(r.invmu_sigma2_a_b_vec_.begin(), r.invmu_sigma2_a_b_vec_.begin() + 4 * n, sb_.state.begin() + 4 * off);
+      off += n;
+    }
+  });
   const size_t n_total = sb_.type.size();
   if (n_total == 0) { for (int s : trk) { streams_[static_cast<size_t>(s)]->seed_frames.clear(); streams_[static_cast<size_t>(s)]->seed_counts.clear(); } return; }
   sb_.success.assign(n_total, 0);
@@ -290,6 +304,9 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
 {
   const int S = numStreams();
   device_calls_ = 0;
+  // where a round's time goes (sums since construction, ms): pyramids, finish seeds, align, reproject, pose, structure, keyframes, seed updates
+  double tp = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  auto lap = [&](int k) { const double n = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); phase_ms_[k] += n - tp; tp = n; };
   drainReleases();
   if (!left || !right) throw std::runtime_error("FrontendLockstepStereo::addPairs: NULL images");
   std::vector<int> trk, starting;
@@ -331,8 +348,10 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
       }
     }
   }
+  lap(0);
   // the pair before: its second seed update is needed from here on (alignment points, candidates)
   finishSecondSeedUpdate();
+  lap(1);
 
   auto close_round = [&]() {
     for (auto& stp : streams_) {
@@ -409,6 +428,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
     });
   }
 
+  lap(2);
   // ---- 2. reprojection, per camera (frame_handler_base.cpp:645-744): first every stream's camera 0, then every stream's camera 1 -- a
   // stream's second camera sees what its first did to the landmarks' reprojection statistics and to the seeds it matched
   svoh_matcher_stage_t ds{}, ss{};
@@ -521,6 +541,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
     for (int s : trk) { Stream& st = *streams_[static_cast<size_t>(s)]; st.n_reproj += st.bundle->at(cc)->num_features_; }
   }
 
+  lap(3);
   // ---- 3. pose optimisation of the rigs (frame_handler_base.cpp:746-790): one batch
   {
     std::vector<svoh_pose_problem> pbs;
@@ -545,6 +566,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
     }
   }
 
+  lap(4);
   // ---- 3b. structure optimisation (frame_handler_stereo.cpp:114): optimizeStructure works through a bundle's frames one after the other (a
   // point both cameras see is optimised twice, the second time from the first's result): two batches, each the landmarks of one camera of all streams
   if (opt_.landmarks && opt_.params.structure_optimization_max_pts != 0) {
@@ -587,6 +609,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
     }
   }
 
+  lap(5);
   // ---- 4. keyframe rule (svoh_mini_stereo's); a keyframe pair's step comes BEFORE its seed updates, as makeKeyframe does (:162-175)
   for (int s : trk) {
     Stream& st = *streams_[static_cast<size_t>(s)];
@@ -595,11 +618,13 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
     st.row.alpha = st.img_align.lastResult().alpha; st.row.beta = st.img_align.lastResult().beta;
   }
 
+  lap(6);
   // ---- 5. depth filter, per camera (frame_handler_stereo.cpp:127-129): the first camera's update of all streams, waited for (the second
   // starts from its states), then the second camera's, left in flight until the next round
   seedUpdate(trk, 0, false);
   seedUpdate(trk, 1, true);
   close_round();
+  lap(7);
 }
 
 }  // namespace svo_hip

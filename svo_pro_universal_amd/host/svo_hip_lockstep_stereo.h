@@ -60,6 +60,10 @@ class FrontendLockstepStereo {
   size_t keyframesAlive(int s) const;
   void finish();
   int lastRoundDeviceCalls() const { return device_calls_; }
+  // where the rounds' time went (ms summed since construction): pyramids, finish seeds, align, reproject, pose, structure, keyframes, seed updates
+  static constexpr int kNumPhases = 8;
+  const double* phaseTimes() const { return phase_ms_; }
+  static const char* phaseName(int k) { static const char* n[] = { "pyramids", "finish seeds", "align", "reproject", "pose", "structure", "keyframes", "seed updates" }; return k >= 0 && k < kNumPhases ? n[k] : ""; }
 
  private:
   struct Stream;
@@ -75,6 +79,7 @@ class FrontendLockstepStereo {
   std::unique_ptr<WorkerPool> pool_;
   std::vector<std::unique_ptr<Stream>> streams_;
   int device_calls_ = 0;
+  double phase_ms_[kNumPhases] = {};
   bool seeds_in_flight_ = false;
   // the seed batch in flight (host arrays: alive until collected)
   struct SeedBatch {

@@ -152,7 +152,7 @@ def test_stereo_streams_in_lock_step_reproduce_their_single_stream_runs(tmp_path
     STEREO streams, one pair of every stream at a time, every per-pair stage (bundle alignment under each stream's IMU prior, both cameras'
     reprojection, rig pose optimisation, structure optimisation, both depth-filter updates) one launch for all of them.  Five streams over TWO
     different sequences (different scene and motion, 30 and 22 pairs: the shorter streams end earlier): every stream must write the trajectory
-    and the counters of the single-stream run of ITS sequence, byte for byte, for one and for three host threads."""
+    and the counters of the single-stream run of ITS sequence, byte for byte, for (threads, groups) = (1,1), (3,1), (2,2)."""
     cmd_a, out_dir, poses_a, stamps_a = make_stereo_dataset(tmp_path, 30, seed=171, ds="dsA")
     cmd_b, _o, poses_b, stamps_b = make_stereo_dataset(tmp_path, 22, seed=377, ds="dsB")
     singles = []
@@ -163,17 +163,17 @@ def test_stereo_streams_in_lock_step_reproduce_their_single_stream_runs(tmp_path
     assert singles[0][0] != singles[1][0] and len(singles[0][1]) == 30 and len(singles[1][1]) == 22
     roots = "%s:%s" % (tmp_path / "dsA", tmp_path / "dsB")
     S = 5
-    for n_workers in (1, 3):
+    for n_workers, n_groups in ((1, 1), (3, 1), (2, 2)):
         for k in range(S):
             d = out_dir if k == 0 else out_dir / ("stream%d" % k)
             for name in ("trajectory.txt", "frontend.csv"):
                 if (d / name).exists():
                     (d / name).unlink()
-        r = subprocess.run(cmd_a + ["30", "8", "0.5", str(S), str(n_workers)], capture_output=True, text=True, env=dict(os.environ, SVOH_MINI_STEREO_ROOTS=roots))
+        r = subprocess.run(cmd_a + ["30", "8", "0.5", str(S), str(n_workers), str(n_groups)], capture_output=True, text=True, env=dict(os.environ, SVOH_MINI_STEREO_ROOTS=roots))
         print(r.stdout, r.stderr)
         assert r.returncode == 0, r.stdout + r.stderr
         for k in range(S):
             d = out_dir if k == 0 else out_dir / ("stream%d" % k)
             want = singles[k % 2]
-            assert open(str(d / "trajectory.txt")).read() == want[0], "trajectory of stream %d (%d threads)" % (k, n_workers)
-            assert np.array_equal(np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :9], want[1]), "counters of stream %d (%d threads)" % (k, n_workers)
+            assert open(str(d / "trajectory.txt")).read() == want[0], "trajectory of stream %d (%d threads, %d groups)" % (k, n_workers, n_groups)
+            assert np.array_equal(np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :9], want[1]), "counters of stream %d (%d threads, %d groups)" % (k, n_workers, n_groups)

@@ -19,7 +19,7 @@
 // prior is set.
 //
 //   svoh_mini_stereo <dataset_root> <calib.yaml (two cameras)> <params.yaml|-> <out_dir> <T_imu_world of frame 0: qw qx qy qz tx ty tz>
-//                    [max_frames] [kf_every] [prior_lambda_rot] [n_streams] [n_workers]
+//                    [max_frames] [kf_every] [prior_lambda_rot] [n_streams] [n_workers] [n_groups]
 // Writes <out>/trajectory.txt (TUM format, T_world_imu) and <out>/frontend.csv.
 // n_streams given (round 6): that many stereo streams in LOCK STEP on one context (FrontendLockstepStereo, host/svo_hip_lockstep_stereo.h):
 // one pair of every stream at a time, every per-pair stage one launch for all of them; stream k writes into <out>/stream<k>/ (k > 0).
@@ -28,7 +28,9 @@
 // root writes, byte for byte (tests/test_mini_stereo_gpu.py).
 #include <sys/stat.h>
 
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
@@ -66,15 +68,12 @@ static void read_priors(const std::string& root, std::vector<svoh::Quat>* imu_pr
 }
 
 // n_streams stereo streams in lock step (FrontendLockstepStereo); stream k replays root k % n_roots
-static int run_lockstep(const std::vector<std::string>& roots, const std::vector<io::RigCamera>& rig, const io::FrontendParams& params, const std::string& out_dir,
-                        const Transformation& T0_default, size_t max_frames, size_t kf_every, double lambda_rot, int n_streams, int n_workers)
+struct StereoRoot { io::EurocSequence seq; std::vector<io::GrayImage> left, right; std::vector<svoh::Quat> prior; std::vector<bool> have; Transformation T0; size_t n = 0; };
+static std::vector<StereoRoot> load_roots(const std::vector<std::string>& roots, const Transformation& T0_default, size_t max_frames)
 {
-  svoh_ctx* ctx = nullptr;
-  if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
-  struct Root { io::EurocSequence seq; std::vector<io::GrayImage> left, right; std::vector<svoh::Quat> prior; std::vector<bool> have; Transformation T0; size_t n = 0; };
-  std::vector<Root> data(roots.size());
+  std::vector<StereoRoot> data(roots.size());
   for (size_t r = 0; r < roots.size(); ++r) {
-    Root& d = data[r];
+    StereoRoot& d = data[r];
     d.seq = io::openEuroc(roots[r]);
     if (d.seq.cam1_files.size() != d.seq.cam0_files.size()) throw std::runtime_error("two image folders are needed: " + roots[r]);
     d.n = std::min(d.seq.size(), max_frames);
@@ -85,6 +84,17 @@ static int run_lockstep(const std::vector<std::string>& roots, const std::vector
     double v[7];
     if (t0 >> v[0] >> v[1] >> v[2] >> v[3] >> v[4] >> v[5] >> v[6]) d.T0 = Transformation{ { v[0], v[1], v[2], v[3] }, { v[4], v[5], v[6] } };
   }
+  return data;
+}
+
+// one lock-step group: streams [s0, s0 + n_streams) of the run on a context and a thread of their own
+struct StereoGroupResult { size_t pairs = 0; double ms = 0, round_ms = 0; int device_calls = 0; std::string error; };
+static void run_lockstep(const std::vector<StereoRoot>& data, const std::vector<io::RigCamera>& rig, const io::FrontendParams& params, const std::string& out_dir,
+                         size_t kf_every, double lambda_rot, int s0, int n_streams, int n_workers, std::atomic<int>* gate, int n_groups, StereoGroupResult* out)
+try {
+  svoh_ctx* ctx = nullptr;
+  if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
+  auto root_of = [&](int s) -> const StereoRoot& { return data[(size_t)(s0 + s) % data.size()]; };
   {
     StereoLockstepOptions lo;
     lo.params = params; lo.rig = rig; lo.kf_every = kf_every; lo.lambda_rot = lambda_rot; lo.n_workers = n_workers;
@@ -93,7 +103,7 @@ static int run_lockstep(const std::vector<std::string>& roots, const std::vector
     std::vector<std::unique_ptr<io::TrajectoryWriter>> traj;
     std::vector<FILE*> csv;
     for (int s = 0; s < n_streams; ++s) {
-      const std::string dir = s == 0 ? out_dir : out_dir + "/stream" + std::to_string(s);
+      const std::string dir = s0 + s == 0 ? out_dir : out_dir + "/stream" + std::to_string(s0 + s);
       traj.emplace_back(new io::TrajectoryWriter(dir + "/trajectory.txt"));
       FILE* fc = fopen((dir + "/frontend.csv").c_str(), "w");
       if (!fc) throw std::runtime_error("cannot write into " + dir);
@@ -106,16 +116,18 @@ static int run_lockstep(const std::vector<std::string>& roots, const std::vector
           fprintf(csv[(size_t)s], "%zu,%d,%zu,%zu,%zu,%zu,%zu,%.6f,%.4f,0,0,0,0,0,0,0\n", r.k, (int)r.is_kf, r.n_aligned, r.n_reproj, r.n_pose, r.n_seed_upd, r.n_landmarks, r.alpha, r.beta);
     };
     size_t n_rounds = 0;
-    for (int s = 0; s < n_streams; ++s) n_rounds = std::max(n_rounds, data[(size_t)s % data.size()].n);
+    for (int s = 0; s < n_streams; ++s) n_rounds = std::max(n_rounds, root_of(s).n);
     std::vector<const uint8_t*> left((size_t)n_streams), right((size_t)n_streams);
     std::vector<Transformation> T_first((size_t)n_streams);
     std::vector<const svoh::Quat*> prior((size_t)n_streams);
     double sum_ms = 0;
     size_t pairs = 0;
+    gate->fetch_add(1);   // all groups start their first round together
+    while (gate->load() < n_groups) std::this_thread::yield();
     for (size_t k = 0; k < n_rounds; ++k) {
       size_t n_now = 0;
       for (int s = 0; s < n_streams; ++s) {
-        const Root& d = data[(size_t)s % data.size()];
+        const StereoRoot& d = root_of(s);
         const bool has = k < d.n;
         left[(size_t)s] = has ? d.left[k].data.data() : nullptr;
         right[(size_t)s] = has ? d.right[k].data.data() : nullptr;
@@ -126,21 +138,27 @@ static int run_lockstep(const std::vector<std::string>& roots, const std::vector
       const double t0 = now_ms();
       fe.addPairs(left.data(), right.data(), data[0].left[0].width, T_first.data(), prior.data());
       const double t1 = now_ms();
-      if (k > 0) { sum_ms += t1 - t0; pairs += n_now; }
+      if (k > 2) { sum_ms += t1 - t0; pairs += n_now; }   // (the first rounds pay the one-time costs)
       for (int s = 0; s < n_streams; ++s) {
-        const Root& d = data[(size_t)s % data.size()];
+        const StereoRoot& d = root_of(s);
         if (k < d.n) traj[(size_t)s]->write(d.seq.cam_ts[k], svoh::inverse(fe.pose(s)));
       }
       write_rows();
     }
     fe.finish();
     write_rows();
+    if (getenv("SVOH_LOCKSTEP_TIMING") && s0 == 0) {
+      fprintf(stderr, "[lockstep stereo] mean ms per round:");
+      for (int k = 0; k < FrontendLockstepStereo::kNumPhases; ++k) fprintf(stderr, " %s %.3f,", FrontendLockstepStereo::phaseName(k), fe.phaseTimes()[k] / (double)n_rounds);
+      fprintf(stderr, "\n");
+    }
     for (FILE* f : csv) fclose(f);
-    printf("svoh_mini_stereo lockstep: %d streams, %d host thread(s): %zu pairs in %.1f ms = %.0f pairs/s, %.3f ms per round, %d device calls per round\n", n_streams, n_workers,
-           pairs, sum_ms, pairs ? 1e3 * (double)pairs / sum_ms : 0.0, n_rounds > 1 ? sum_ms / (double)(n_rounds - 1) : 0.0, fe.lastRoundDeviceCalls());
+    out->pairs = pairs; out->ms = sum_ms; out->round_ms = n_rounds > 3 ? sum_ms / (double)(n_rounds - 3) : 0.0; out->device_calls = fe.lastRoundDeviceCalls();
   }
   svoh_destroy(ctx);
-  return 0;
+} catch (const std::exception& e) {
+  out->error = e.what();
+  gate->fetch_add(1);
 }
 
 int main(int argc, char** argv)
@@ -162,14 +180,27 @@ int main(int argc, char** argv)
     const double lambda_rot = argc > 14 ? atof(argv[14]) : 0.5;
     const size_t n_frames = std::min(seq.size(), max_frames);
     if (argc > 15) {   // lock step
-      const int n_streams = atoi(argv[15]), n_workers = argc > 16 ? atoi(argv[16]) : 1;
-      if (n_streams < 1 || n_streams > 128 || n_workers < 1) throw std::runtime_error("n_streams / n_workers out of range");
+      const int n_streams = atoi(argv[15]), n_workers = argc > 16 ? atoi(argv[16]) : 1, n_groups = argc > 17 ? atoi(argv[17]) : 1;
+      if (n_streams < 1 || n_streams > 512 || n_workers < 1 || n_groups < 1 || n_groups > n_streams) throw std::runtime_error("n_streams / n_workers / n_groups out of range");
       std::vector<std::string> roots;
       if (const char* e = getenv("SVOH_MINI_STEREO_ROOTS")) { std::stringstream ss(e); std::string r; while (std::getline(ss, r, ':')) if (!r.empty()) roots.push_back(r); }
       if (roots.empty()) roots.push_back(argv[1]);
       for (int s = 1; s < n_streams; ++s) (void)mkdir((out_dir + "/stream" + std::to_string(s)).c_str(), 0755);
       params.depth_filter.use_threaded_depthfilter = false;
-      return run_lockstep(roots, rig, params, out_dir, T_imu_world0, max_frames, kf_every, lambda_rot, n_streams, n_workers);
+      const std::vector<StereoRoot> data = load_roots(roots, T_imu_world0, max_frames);
+      // n_groups lock-step groups side by side (a context and a thread each, n_streams / n_groups streams): one group's host phases meet another's device waits
+      std::vector<StereoGroupResult> res((size_t)n_groups);
+      std::atomic<int> gate(0);
+      std::vector<std::thread> threads;
+      auto range = [&](int g, int* s0, int* n) { *s0 = (int)((long long)n_streams * g / n_groups); *n = (int)((long long)n_streams * (g + 1) / n_groups) - *s0; };
+      for (int g = 1; g < n_groups; ++g) { int s0, n; range(g, &s0, &n); threads.emplace_back(run_lockstep, std::cref(data), std::cref(rig), std::cref(params), out_dir, kf_every, lambda_rot, s0, n, n_workers, &gate, n_groups, &res[(size_t)g]); }
+      { int s0, n; range(0, &s0, &n); run_lockstep(data, rig, params, out_dir, kf_every, lambda_rot, s0, n, n_workers, &gate, n_groups, &res[0]); }
+      for (std::thread& t : threads) t.join();
+      double rate = 0;
+      for (const StereoGroupResult& r : res) { if (!r.error.empty()) throw std::runtime_error(r.error); if (r.ms > 0) rate += 1e3 * (double)r.pairs / r.ms; }
+      printf("svoh_mini_stereo lockstep: %d streams in %d group(s), %d host thread(s) per group: %.0f pairs/s in steady state, a round of group 0 %.3f ms, %d device calls per round\n",
+             n_streams, n_groups, n_workers, rate, res[0].round_ms, res[0].device_calls);
+      return 0;
     }
 
     // the IMU's relative rotations, if the dataset has them
