@@ -923,6 +923,111 @@ def cpu_frame_stages(cam):
                       "the direct matches and the pose optimiser, ~5 %% of the frame, are left out)" % (len(c), NS)}
 
 
+def bench_frame_stereo_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
+    """BASELINE config 3 x config 5 on one GPU: S STEREO streams in lock step (FrontendLockstepStereo, host/svo_hip_lockstep_stereo.h) -- per pair
+    and stream: two 5-level pyramids, the two-camera alignment bundle (pose + illumination gain / offset, IMU rotation prior), both cameras' reprojection,
+    the rig's pose optimisation, structure optimisation, both depth-filter updates, stereo triangulation + new seeds at keyframes.  A step = one round =
+    one pair of every stream.  The streams of a rank replay one rendered stereo sequence (752x480 radtan, baseline 0.11 m, drifting gain and offset) forth
+    and back, every stream reading ITS OWN page-locked copy.  Per-stream results are those of the single-stream stereo chain byte for byte
+    (tests/test_mini_stereo_gpu.py::test_stereo_streams_in_lock_step_reproduce_their_single_stream_runs)."""
+    import threading
+    from svo_pro_universal_amd import lockstep as ls
+    cam = synth.Camera.euroc_like(752, 480)
+    n_pairs, base_m = 30, 0.11
+    sc = synth.make_align_scene(du.problem_seed(rank, 171), n_features=8, cam=cam, rot_deg=(0.3, 0.5), trans_m=(0.015, 0.025))
+    stepT = sc.T_w_ref.inverse() * sc.T_w_cur
+    poses = [sc.T_w_ref]
+    for _ in range(1, n_pairs):
+        poses.append(poses[-1] * stepT)
+    T_B_C = [synth.SE3(), synth.SE3((1.0, 0.0, 0.0, 0.0), (base_m, 0.0, 0.0))]
+    images = []
+    for k, T in enumerate(poses):
+        gain, offset = 1.0 + 0.08 * np.sin(k / 4.0), 6.0 * np.cos(k / 5.0)
+        for c in range(2):
+            images.append(synth.render(cam, T * T_B_C[c], sc.plane, sc.tex, gain=gain, offset=offset))
+    rng = np.random.RandomState(3)
+    prior = np.zeros((n_pairs, 4)); prior[0] = (1, 0, 0, 0)
+    for k in range(1, n_pairs):   # what a gyroscope integration would hand over: R_imu(k)_imu(k-1), slightly off
+        noise = synth.SE3(synth.quat_from_axis_angle(rng.normal(size=3), 2e-4), (0, 0, 0))
+        prior[k] = (noise * (poses[k].inverse() * poses[k - 1])).q
+    params = ("max_fts: 160\ngrid_size: 35\nn_pyr_levels: 3\ndetector_threshold_secondary: 100\nuse_threaded_depthfilter: False\n"
+              "img_align_max_level: 4\nimg_align_min_level: 2\n")
+    n_slice = len(os.sched_getaffinity(0))
+    n_host = _CPUS_BEFORE_PIN or n_slice
+    budget = int(os.environ.get("SVOH_BENCH_HOST_THREADS", "0")) or max(1, min(16, n_slice if _PINNED else n_slice // max(1, world)))
+    S = args.streams
+    G = args.stream_groups or (1 if S < 8 else min(8 if S >= 32 else 4, budget))
+    W = args.stream_workers or max(1, min(budget // G, -(-S // G)))
+    G = max(1, min(G, S))
+    ctxs = [ctx] + [fe.Context(dev.index if dev.index is not None else 0, kernel_timing=False) for _ in range(G - 1)]
+    ctx.set_kernel_timing(False)
+    ranges = [(S * g // G, S * (g + 1) // G) for g in range(G)]
+    pins = [ls.PinnedImages(c, images, hi - lo) for c, (lo, hi) in zip(ctxs, ranges)]
+    T7 = [np.array(list(T.q) + list(T.t)) for T in T_B_C]
+    engines = [ls.LockstepStereo(c, hi - lo, [cam, cam], T7, params, 8, 0.5, W, True) for c, (lo, hi) in zip(ctxs, ranges)]
+    first = poses[0].inverse().as7()
+    n_warm, n_steps = max(3, args.warmup), args.steps
+    gate = threading.Barrier(G + 1)
+    errors, times = [], [None] * G
+
+    def loop(g):
+        try:
+            e, pin, n = engines[g], pins[g], ranges[g][1] - ranges[g][0]
+            e.run_sequence(pin, cam.width, 0, n_warm, [first] * n, prior)
+            gate.wait()
+            times[g] = e.run_sequence(pin, cam.width, n_warm, n_steps, None, prior)
+            e.finish()
+            gate.wait()
+        except Exception as ex:   # noqa: BLE001 -- reported by the caller
+            errors.append(ex)
+            gate.abort()
+    warm_phases = [e.phase_times() for e in engines]
+    th = [threading.Thread(target=loop, args=(g,)) for g in range(G)]
+    for t in th:
+        t.start()
+    try:
+        gate.wait()
+        warm_phases = [e.phase_times() for e in engines]
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        gate.wait()
+        elapsed = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        elapsed = float("nan")
+    for t in th:
+        t.join()
+    if errors:
+        raise errors[0]
+    p0 = engines[0].pose(0)
+    agree = all(np.array_equal(e.pose(s), p0) for e in engines for s in range(e.n))
+    total = n_warm + n_steps
+    m = (total - 1) % (2 * (n_pairs - 1))
+    last_pair = m if m < n_pairs else 2 * (n_pairs - 1) - m
+    err = synth.se3_error(synth.SE3.from7(p0), poses[last_pair].inverse())
+    phases = {k: (v - warm_phases[0].get(k, 0.0)) / max(1, n_steps) for k, v in engines[0].phase_times().items()}
+    for e in engines:
+        e.close()
+    for p in pins:
+        p.free()
+    for c in ctxs[1:]:
+        c.close()
+    elapsed, total_pairs = du.combine(dist, world, elapsed, S * n_steps, comm_dev)
+    if rank != 0:
+        return None
+    return {"metric": "stereo frame pairs/s, S stereo streams in lock step through the whole per-pair chain (bundle align + 2 x reproject + rig pose + structure + 2 x depth filter + keyframes)",
+            "value": total_pairs / elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * elapsed / n_steps, "ms_per_frame": 1e3 * elapsed * world / max(1, total_pairs), "dtype": "u8+i32+f32+f64",
+            "config": {"workload": "C3 x C5-synth per GPU: %d stereo streams x 2 x 752x480 radtan (baseline 0.11 m, IMU rotation prior, illumination gain + offset estimated) in %d "
+                                   "lock-step group(s) with %d host thread(s) each; a step = one pair of every stream; the streams replay one rendered 30-pair sequence forth and back" % (S, G, W),
+                       "streams": S, "groups": G, "host_threads_per_group": W, "host_cpus_visible": n_host},
+            "lockstep_stereo": {"round_ms_median_group0": float(np.median(times[0])) if times[0] is not None and len(times[0]) else None,
+                                "round_phase_ms_mean_group0": {k: round(v, 4) for k, v in phases.items()}, "all_streams_at_the_same_pose": bool(agree),
+                                "pose_vs_rendered_pose_metric_scale": {"rot_rad": float(err[0]), "trans_m": float(err[1])}, "rounds_run": total},
+            "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                         "note": "a chain of small latency-bound launches by design: the kernels' own rooflines are those of --workload align-c4 / seeds / pose / stereo"},
+            "cpu_baseline": None}
+
+
 def bench_frame_stereo(args, ctx, dist, rank, world, dev, comm_dev=None):
     """C4-synth, one stereo frame pair at a time (latency): BASELINE config 3 / 4 at the sizes of SURVEY.md Appendix A's
     stereo column.  Per pair: two 5-level pyramids (host images in); SparseImgAlign of the BUNDLE -- two cameras x 160
@@ -1540,7 +1645,7 @@ def main(argv=None):
     ctx = fe.Context(local_rank)
     if args.workload != "align":
         out = {"klt": bench_klt, "seeds": bench_seeds,
-               "frame": bench_frame_streams if args.streams > 0 else (bench_frame_stereo if args.stereo else bench_frame), "detect": bench_detect,
+               "frame": (bench_frame_stereo_streams if args.stereo else bench_frame_streams) if args.streams > 0 else (bench_frame_stereo if args.stereo else bench_frame), "detect": bench_detect,
                "pose": bench_pose,
                "align-split": bench_align_split, "align-c4": bench_align_c4, "stereo": bench_stereo,
                "launch-check": lambda a, c, d, r, w, dv, cd: bench_launch_check(a, d, r, w, cd)}[args.workload](

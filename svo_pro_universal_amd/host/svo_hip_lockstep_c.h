@@ -67,6 +67,21 @@ int svohl_phase_times(svohl_engine* e, int max_phases, double* ms, int* n_phases
 const char* svohl_phase_name(int k);
 const char* svohl_last_error(void);
 
+/* ---- the stereo engine (FrontendLockstepStereo, svo_hip_lockstep_stereo.h; round 6): same conventions, svohs_last_error() has the text.
+ * cams / T_B_C: the rig's two cameras.  svohs_run_sequence: n_rounds calls of addPairs in one -- stream s reads ITS copy of a sequence of n_pairs
+ * stereo pairs (images left(0) right(0) left(1) right(1) ... of image_bytes each) at base + s * stream_stride, walking it forth and back
+ * (pair_of(k) = 0 .. n-1, n-2 .. 1, 0 ...); prior_forward: 4 doubles (qw qx qy qz of R_imu(f)_imu(f-1)) per pair, or NULL; round_ms: one per round. */
+typedef struct svohs_engine svohs_engine;
+int svohs_create(svoh_ctx* ctx, int n_streams, const svoh_camera* cams, const svoh_se3* T_B_C, const char* params_yaml, int kf_every, double lambda_rot, int n_workers,
+                 int images_pinned, svohs_engine** out);
+void svohs_destroy(svohs_engine* e);
+int svohs_run_sequence(svohs_engine* e, const uint8_t* base, size_t image_bytes, size_t stream_stride, int n_pairs, int pitch, long k_first, int n_rounds,
+                       const svoh_se3* T_imu_world_first, const double* prior_forward, double* round_ms);
+int svohs_pose(svohs_engine* e, int stream, svoh_se3* T_imu_world);
+int svohs_phase_times(svohs_engine* e, double* ms /* 8: pyramids, finish seeds, align, reproject, pose, structure, keyframes, seed updates */);
+int svohs_finish(svohs_engine* e);
+const char* svohs_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -327,7 +327,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
   // ---- pyramids of the round's 2 x (active streams) images: one call
   if (!imgs.empty()) {
     std::vector<svoh_frame_t> handles(imgs.size(), 0);
-    check(svoh_build_pyramid_multi(ctx_, imgs.data(), static_cast<int>(imgs.size()), opt_.rig[0].cam.width, opt_.rig[0].cam.height, pitch, SVOH_MEM_HOST,
+    check(svoh_build_pyramid_multi(ctx_, imgs.data(), static_cast<int>(imgs.size()), opt_.rig[0].cam.width, opt_.rig[0].cam.height, pitch, opt_.images_mem_space,
                                    opt_.params.n_pyr_levels_to_build, SVOH_HALFSAMPLE_REFERENCE, handles.data()), "svoh_build_pyramid_multi");
     ++device_calls_;
     size_t at = 0;
@@ -628,3 +628,105 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
 }
 
 }  // namespace svo_hip
+
+// ---- C face (svo_hip_lockstep_c.h: svohs_*) ---------------------------------------------------------------------------
+#include "svo_hip_lockstep_c.h"
+
+struct svohs_engine { std::unique_ptr<svo_hip::FrontendLockstepStereo> fe; };
+
+namespace {
+thread_local std::string g_svohs_error = "no error";
+template <class F>
+int svohs_guard(F&& f)
+{
+  try { f(); return SVOH_OK; }
+  catch (const std::bad_alloc&) { g_svohs_error = "out of host memory"; return SVOH_ERR_OUT_OF_MEMORY; }
+  catch (const std::exception& e) { g_svohs_error = e.what(); return SVOH_ERR_INVALID_ARGUMENT; }
+  catch (...) { g_svohs_error = "unknown exception"; return SVOH_ERR_INVALID_ARGUMENT; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* svohs_last_error(void) { return g_svohs_error.c_str(); }
+
+int svohs_create(svoh_ctx* ctx, int n_streams, const svoh_camera* cams, const svoh_se3* T_B_C, const char* params_yaml, int kf_every, double lambda_rot, int n_workers,
+                 int images_pinned, svohs_engine** out)
+{
+  return svohs_guard([&] {
+    if (!out || !cams || !T_B_C) throw std::runtime_error("svohs_create: NULL argument");
+    *out = nullptr;
+    svo_hip::StereoLockstepOptions lo;
+    lo.params = svo_hip::io::frontendParamsFromYaml(params_yaml ? svo_hip::io::parseYaml(params_yaml) : svo_hip::io::YamlNode());
+    for (int c = 0; c < 2; ++c) { svo_hip::io::RigCamera rc; rc.label = c ? "cam1" : "cam0"; rc.cam = cams[c]; rc.T_B_C = svoh::load_rigid(T_B_C[c]); lo.rig.push_back(rc); }
+    lo.kf_every = kf_every > 0 ? static_cast<size_t>(kf_every) : 8;
+    lo.lambda_rot = lambda_rot;
+    lo.n_workers = n_workers;
+    lo.images_mem_space = images_pinned ? SVOH_MEM_HOST_PINNED : SVOH_MEM_HOST;
+    std::unique_ptr<svohs_engine> e(new svohs_engine);
+    e->fe.reset(new svo_hip::FrontendLockstepStereo(ctx, n_streams, lo));
+    *out = e.release();
+  });
+}
+
+void svohs_destroy(svohs_engine* e) { try { delete e; } catch (...) {} }
+
+int svohs_run_sequence(svohs_engine* e, const uint8_t* base, size_t image_bytes, size_t stream_stride, int n_pairs, int pitch, long k_first, int n_rounds,
+                       const svoh_se3* T_imu_world_first, const double* prior_forward, double* round_ms)
+{
+  return svohs_guard([&] {
+    if (!e || !base || n_pairs < 2 || n_rounds < 0 || k_first < 0) throw std::runtime_error("svohs_run_sequence: bad arguments");
+    const int S = e->fe->numStreams();
+    std::vector<svo_hip::Transformation> T;
+    if (T_imu_world_first) for (int s = 0; s < S; ++s) T.push_back(svoh::load_rigid(T_imu_world_first[s]));
+    std::vector<const uint8_t*> left(static_cast<size_t>(S)), right(static_cast<size_t>(S));
+    std::vector<const svoh::Quat*> prior(static_cast<size_t>(S), nullptr);
+    const long period = 2L * (n_pairs - 1);
+    auto pair_of = [&](long k) { const long m = k % period; return m < n_pairs ? m : period - m; };
+    for (long k = k_first; k < k_first + n_rounds; ++k) {
+      const long f = pair_of(k);
+      // R_imu(new)_imu(old): walking forwards from pair f - 1 it is prior_forward[f]; walking backwards from pair f + 1 the inverse of prior_forward[f + 1]
+      svoh::Quat q{ 1, 0, 0, 0 };
+      bool have = false;
+      if (prior_forward && k > 0) {
+        const long fp = pair_of(k - 1);
+        if (fp == f - 1) { const double* p = prior_forward + 4 * f; q = svoh::Quat{ p[0], p[1], p[2], p[3] }; have = true; }
+        else if (fp == f + 1) { const double* p = prior_forward + 4 * (f + 1); q = svoh::Quat{ p[0], -p[1], -p[2], -p[3] }; have = true; }
+      }
+      for (int s = 0; s < S; ++s) {
+        left[static_cast<size_t>(s)] = base + static_cast<size_t>(s) * stream_stride + static_cast<size_t>(2 * f) * image_bytes;
+        right[static_cast<size_t>(s)] = base + static_cast<size_t>(s) * stream_stride + static_cast<size_t>(2 * f + 1) * image_bytes;
+        prior[static_cast<size_t>(s)] = have ? &q : nullptr;
+      }
+      const double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+      e->fe->addPairs(left.data(), right.data(), pitch, T.empty() ? nullptr : T.data(), prior.data());
+      if (round_ms) round_ms[k - k_first] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+    }
+  });
+}
+
+int svohs_pose(svohs_engine* e, int stream, svoh_se3* T_imu_world)
+{
+  return svohs_guard([&] {
+    if (!e || !T_imu_world) throw std::runtime_error("svohs_pose: NULL argument");
+    svoh::store_rigid(e->fe->pose(stream), *T_imu_world);
+  });
+}
+
+int svohs_phase_times(svohs_engine* e, double* ms /* 8 */)
+{
+  return svohs_guard([&] {
+    if (!e || !ms) throw std::runtime_error("svohs_phase_times: NULL argument");
+    for (int k = 0; k < svo_hip::FrontendLockstepStereo::kNumPhases; ++k) ms[k] = e->fe->phaseTimes()[k];
+  });
+}
+
+int svohs_finish(svohs_engine* e)
+{
+  return svohs_guard([&] {
+    if (!e) throw std::runtime_error("svohs_finish: NULL argument");
+    e->fe->finish();
+  });
+}
+
+}  // extern "C"

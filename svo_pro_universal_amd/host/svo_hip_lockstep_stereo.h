@@ -39,6 +39,7 @@ struct StereoLockstepOptions {
   double lambda_rot = 0.5;              // img_align_prior_lambda_rot
   int n_workers = 1;                    // host threads, the caller included
   bool landmarks = true;                // upgradeSeedsToFeatures at keyframes, optimizeStructure every pair (as svoh_mini_stereo)
+  int images_mem_space = SVOH_MEM_HOST; // SVOH_MEM_HOST_PINNED: the images live in svoh_host_alloc memory (one gather kernel reads all of them over PCIe)
 };
 
 class FrontendLockstepStereo {

@@ -46,6 +46,14 @@ def load_host():
     lib.svohl_phase_name.argtypes = [C.c_int]
     lib.svohl_phase_name.restype = C.c_char_p
     lib.svohl_last_error.restype = C.c_char_p
+    lib.svohs_create.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_camera), P(capi.svoh_se3), C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, P(C.c_void_p)]
+    lib.svohs_destroy.argtypes = [C.c_void_p]
+    lib.svohs_destroy.restype = None
+    lib.svohs_run_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svohs_pose.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_se3)]
+    lib.svohs_phase_times.argtypes = [C.c_void_p, P(C.c_double)]
+    lib.svohs_finish.argtypes = [C.c_void_p]
+    lib.svohs_last_error.restype = C.c_char_p
     _HOST = lib
     return lib
 
@@ -211,6 +219,67 @@ class Lockstep(object):
     def close(self):
         if self.h:
             self.lib.svohl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LockstepStereo(object):
+    """One lock-step group of n_streams STEREO streams on `ctx` (host/svo_hip_lockstep_stereo.h through its C face, svohs_*)."""
+    PHASES = ("pyramids", "finish seeds", "align", "reproject", "pose", "structure", "keyframes", "seed updates")
+
+    def __init__(self, ctx, n_streams, cams, T_B_C7s, params_yaml, kf_every=8, lambda_rot=0.5, n_workers=1, images_pinned=True):
+        self.lib = load_host()
+        self.ctx = ctx
+        self.n = int(n_streams)
+        cc = (capi.svoh_camera * 2)(fe._camera(cams[0]), fe._camera(cams[1]))
+        TT = (capi.svoh_se3 * 2)(fe._se3(np.asarray(T_B_C7s[0], dtype=np.float64)), fe._se3(np.asarray(T_B_C7s[1], dtype=np.float64)))
+        h = C.c_void_p()
+        rc = self.lib.svohs_create(ctx.h, self.n, cc, TT, params_yaml.encode() if params_yaml else None, int(kf_every), float(lambda_rot), int(n_workers),
+                                   1 if images_pinned else 0, C.byref(h))
+        if rc != 0:
+            raise fe.SvohError(rc, self.lib.svohs_last_error().decode())
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise fe.SvohError(rc, self.lib.svohs_last_error().decode())
+
+    def run_sequence(self, pinned, pitch, k_first, n_rounds, T_imu_world_first=None, prior_forward=None):
+        """pinned: PinnedImages of the interleaved pairs (left 0, right 0, left 1, ...), one copy per stream; returns the rounds' times (ms)."""
+        first = None
+        if T_imu_world_first is not None:
+            arr = (capi.svoh_se3 * self.n)()
+            for i, T in enumerate(T_imu_world_first):
+                arr[i] = fe._se3(T)
+            first = C.cast(arr, C.c_void_p)
+        pr = None if prior_forward is None else np.ascontiguousarray(prior_forward, np.float64)
+        out = np.zeros(max(1, n_rounds))
+        assert pinned.copies >= self.n and pinned.n % 2 == 0
+        self._check(self.lib.svohs_run_sequence(self.h, C.c_void_p(pinned.ptr), pinned.bytes, pinned.stride, pinned.n // 2, int(pitch), int(k_first), int(n_rounds), first,
+                                                None if pr is None else pr.ctypes.data, out.ctypes.data))
+        return out[:n_rounds]
+
+    def pose(self, s):
+        T = capi.svoh_se3()
+        self._check(self.lib.svohs_pose(self.h, int(s), C.byref(T)))
+        return fe.se3_to_numpy(T)
+
+    def phase_times(self):
+        ms = (C.c_double * 8)()
+        self._check(self.lib.svohs_phase_times(self.h, ms))
+        return dict(zip(self.PHASES, list(ms)))
+
+    def finish(self):
+        self._check(self.lib.svohs_finish(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.svohs_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -30,6 +30,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstring>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -95,9 +96,25 @@ try {
   svoh_ctx* ctx = nullptr;
   if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
   auto root_of = [&](int s) -> const StereoRoot& { return data[(size_t)(s0 + s) % data.size()]; };
+  // the decoded pairs in page-locked memory, as a camera driver that feeds a GPU would deliver them: EVERY STREAM ITS OWN COPY (the device
+  // reads the images in place; streams that shared a buffer would be served from its caches after the first)
+  const size_t img_bytes = (size_t)data[0].left[0].width * data[0].left[0].height;
+  std::vector<size_t> stream_off((size_t)n_streams + 1, 0);
+  for (int s = 0; s < n_streams; ++s) stream_off[(size_t)s + 1] = stream_off[(size_t)s] + 2 * img_bytes * root_of(s).n;
+  uint8_t* pinned = nullptr;
+  if (svoh_host_alloc(ctx, stream_off[(size_t)n_streams], (void**)&pinned) != SVOH_OK) throw std::runtime_error(std::string("svoh_host_alloc: ") + svoh_last_error_string(ctx));
+  for (int s = 0; s < n_streams; ++s) {
+    const StereoRoot& d = root_of(s);
+    for (size_t k = 0; k < d.n; ++k) {
+      if (d.left[k].data.size() != img_bytes || d.right[k].data.size() != img_bytes) throw std::runtime_error("images of different sizes");
+      memcpy(pinned + stream_off[(size_t)s] + (2 * k) * img_bytes, d.left[k].data.data(), img_bytes);
+      memcpy(pinned + stream_off[(size_t)s] + (2 * k + 1) * img_bytes, d.right[k].data.data(), img_bytes);
+    }
+  }
   {
     StereoLockstepOptions lo;
     lo.params = params; lo.rig = rig; lo.kf_every = kf_every; lo.lambda_rot = lambda_rot; lo.n_workers = n_workers;
+    lo.images_mem_space = SVOH_MEM_HOST_PINNED;
     if (getenv("SVOH_MINI_LANDMARKS")) lo.landmarks = atoi(getenv("SVOH_MINI_LANDMARKS")) != 0;
     FrontendLockstepStereo fe(ctx, n_streams, lo);
     std::vector<std::unique_ptr<io::TrajectoryWriter>> traj;
@@ -129,8 +146,8 @@ try {
       for (int s = 0; s < n_streams; ++s) {
         const StereoRoot& d = root_of(s);
         const bool has = k < d.n;
-        left[(size_t)s] = has ? d.left[k].data.data() : nullptr;
-        right[(size_t)s] = has ? d.right[k].data.data() : nullptr;
+        left[(size_t)s] = has ? pinned + stream_off[(size_t)s] + (2 * k) * img_bytes : nullptr;
+        right[(size_t)s] = has ? pinned + stream_off[(size_t)s] + (2 * k + 1) * img_bytes : nullptr;
         T_first[(size_t)s] = d.T0;
         prior[(size_t)s] = has && k < d.prior.size() && d.have[k] ? &d.prior[k] : nullptr;
         n_now += has;
@@ -155,6 +172,7 @@ try {
     for (FILE* f : csv) fclose(f);
     out->pairs = pairs; out->ms = sum_ms; out->round_ms = n_rounds > 3 ? sum_ms / (double)(n_rounds - 3) : 0.0; out->device_calls = fe.lastRoundDeviceCalls();
   }
+  (void)svoh_host_free(ctx, pinned);
   svoh_destroy(ctx);
 } catch (const std::exception& e) {
   out->error = e.what();
