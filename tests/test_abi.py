@@ -59,3 +59,20 @@ def test_no_device_is_an_error_not_a_fallback():
         assert rc in (-6, -2)
         assert not h.value
         assert b"CPU" in lib.svoh_last_error_string(None) or rc == -2
+
+
+def test_lockstep_c_face_is_exported_and_refuses_null():
+    """The C faces of the lock-step engines in libsvo_hip_host.so (host/svo_hip_lockstep_c.h: svohl_* mono, svohs_* stereo): every declared
+    function is exported, and a call without an engine fails with an error text instead of crashing.  No GPU, no compute."""
+    from svo_pro_universal_amd import lockstep as ls
+    src = open(os.path.join(ROOT, "svo_pro_universal_amd", "host", "svo_hip_lockstep_c.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decl = sorted(set(re.findall(r"\b(svoh[ls]_[a-z0-9_]+)\s*\(", src)))
+    assert len(decl) >= 20 and "svohl_create_streams" in decl and "svohs_run_sequence" in decl
+    lib = ls.load_host()
+    for name in decl:
+        assert hasattr(lib, name), name
+    assert lib.svohl_finish(None) != 0 and b"NULL" in lib.svohl_last_error()
+    assert lib.svohs_finish(None) != 0 and b"NULL" in lib.svohs_last_error()
+    out = C.c_void_p()
+    assert lib.svohs_create(None, 4, None, None, None, 8, 0.5, 1, 1, C.byref(out)) != 0 and not out.value

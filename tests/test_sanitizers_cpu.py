@@ -43,6 +43,8 @@ def test_host_mirrors_under_address_and_ub_sanitizer(san_build, tmp_path):
     """What of the host layer runs without a GPU: the candidate sort against std::sort on 400 adversarial lists, getCandidate /
     Frame::isVisible on 2000 points, the parsers on well-formed files."""
     assert run([os.path.join(san_build, "host_sort_cpu_asan")]).startswith("ok 400 ")
+    # round 6: upgradeSeedsToFeatures / removeObservationsOf (shared and weak pointers between frames and points)
+    assert run([os.path.join(san_build, "host_upgrade_cpu_asan")]).strip() == "ok"
     rng = np.random.RandomState(3)
     n = 2000
     lines = ["752 480 458.654 457.296 367.215 248.375 1 -0.28340811 0.07395907 0.00019359 1.76187114e-05",
