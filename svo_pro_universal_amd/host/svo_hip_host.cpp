@@ -846,6 +846,25 @@ void PoseOptimizerHip::setRotationPrior(const svoh::Quat& R_frame_world, double 
 
 size_t PoseOptimizerHip::run(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px) { return run(frame_bundle, reproj_thresh_px, nullptr); }
 
+namespace {
+struct PoseOutlierThresholds { double uplane, bearing_diff; };
+// (the reference's two function-local statics: whatever camera and threshold get here first fix them for the process)
+const PoseOutlierThresholds& poseOutlierThresholds(const svoh_camera& cam, double reproj_thresh_px)
+{
+  static const PoseOutlierThresholds t = { reproj_thresh_px / std::fabs(cam.fx),
+                                           std::fabs(2 * std::sin(0.5 * (std::atan(reproj_thresh_px / (2.0 * cam.fx)) + std::atan(reproj_thresh_px / (2.0 * cam.fy))))) };
+  return t;
+}
+}  // namespace
+
+void fixProcessWideThresholds(const svoh_camera& cam, double reproj_thresh_px)
+{
+  (void)poseOutlierThresholds(cam, reproj_thresh_px);
+  Frame f;
+  f.cam = cam;
+  (void)updateSeedPxErrorAngle(f);
+}
+
 void PoseOptimizerHip::prepareRun(const FrameBundle::Ptr& frame_bundle, double reproj_thresh_px, svoh_pose_options& o, svoh_pose_problem& pb)
 {
   if (!frame_bundle || frame_bundle->empty()) throw std::runtime_error("PoseOptimizer: FrameBundle is empty");   // CHECK
@@ -854,9 +873,8 @@ void PoseOptimizerHip::prepareRun(const FrameBundle::Ptr& frame_bundle, double r
   const Frame& f0 = *frame_bundle->at(0);
   // removeOutliers' thresholds are function-local statics: the first bundle ever optimised fixes them
   // (pose_optimizer.cpp:211-212)
-  static const double threshold_uplane = reproj_thresh_px / std::fabs(f0.cam.fx);
-  static const double threshold_bearing_diff =
-      std::fabs(2 * std::sin(0.5 * (std::atan(reproj_thresh_px / (2.0 * f0.cam.fx)) + std::atan(reproj_thresh_px / (2.0 * f0.cam.fy)))));
+  const double threshold_uplane = poseOutlierThresholds(f0.cam, reproj_thresh_px).uplane;
+  const double threshold_bearing_diff = poseOutlierThresholds(f0.cam, reproj_thresh_px).bearing_diff;
   o = svoh_pose_options{};
   o.max_iter = static_cast<int32_t>(solver_options_.max_iter);
   o.eps = solver_options_.eps;

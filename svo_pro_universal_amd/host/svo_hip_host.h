@@ -813,5 +813,11 @@ class Map {
 // (depth_filter.cpp:383-384): the first camera ever passed sets it for the whole process,
 // for the depth filter and the reprojector alike.
 double updateSeedPxErrorAngle(const Frame& cur_frame);
+// The reference keeps three thresholds in function-local statics -- removeOutliers' two (pose_optimizer.cpp:211-212: reproj_thresh / focal
+// length, and its bearing-angle form) and the depth filter's one-pixel angle (depth_filter.cpp:383-384) -- so the FIRST camera that reaches
+// them fixes them for the whole process, whatever cameras come later.  The mirrors do the same.  A driver of several cameras of different
+// focal lengths in one process decides which camera that is by calling this before anything else runs (FrontendLockstep does, with
+// LockstepOptions::cam); calls after the statics are fixed change nothing.
+void fixProcessWideThresholds(const svoh_camera& cam, double reproj_thresh_px);
 
 }  // namespace svo_hip

@@ -112,6 +112,7 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
   // (round 6: the A/B switches of round 5 -- alignment / detector ahead, pose chain, copy policy, spin limits -- are gone from the library: their
   // numbers are in HISTORY round 5 and profiles/r05_*_ab.txt, the orders that won are the code.  What is left are two OPTIONS a caller sets:
   // resident_features and speculation, which the tests use to drive the explicit-column batches and the paused replay.)
+  fixProcessWideThresholds(opt_.cam, 2.0);   // (streams with cameras of their own: the engine's camera is the one the reference's statics see first)
   speculate_all_ = opt_.speculation == LockstepOptions::kSpeculateAll;
   speculate_never_ = opt_.speculation == LockstepOptions::kSpeculateNever;
   opt_.params.depth_filter.use_threaded_depthfilter = false;   // the synchronous path
@@ -124,6 +125,8 @@ FrontendLockstep::FrontendLockstep(svoh_ctx* ctx, int n_streams, const LockstepO
     else so = opt_.per_stream[static_cast<size_t>(s)];
     so.params.depth_filter.use_threaded_depthfilter = false;
     if (so.kf_every < 1) throw std::runtime_error("FrontendLockstep: kf_every must be >= 1");
+    if (so.own_camera && (so.cam.width != opt_.cam.width || so.cam.height != opt_.cam.height))
+      throw std::runtime_error("FrontendLockstep: a stream's own camera must have the image size of the engine's (the streams' pyramids are one call); cameras of another size run as an engine of their own");
     // what the streams of a round share in ONE device call must be the same for all of them
     const io::FrontendParams &a = opt_.params, &b = so.params;
     const bool same = a.n_pyr_levels_to_build == b.n_pyr_levels_to_build && a.grid_size == b.grid_size && a.seed_sigma2_thresh == b.seed_sigma2_thresh &&
@@ -476,8 +479,8 @@ void FrontendLockstep::addImages(const uint8_t* const* images, int pitch, const 
         delete f;
       });
       frame->pyramid = handles[static_cast<size_t>(s)];
-      frame->cam = opt_.cam;
-      frame->set_T_cam_imu(svoh::inverse(opt_.T_B_C));
+      frame->cam = st.so.own_camera ? st.so.cam : opt_.cam;
+      frame->set_T_cam_imu(svoh::inverse(st.so.own_camera ? st.so.T_B_C : opt_.T_B_C));
       frame->id_ = static_cast<int>(st.k);
       st.frame = frame;
     }
@@ -1071,9 +1074,24 @@ static int svohl_create_impl(svoh_ctx* ctx, int n_streams, const svoh_camera* ca
   });
 }
 
+static int svohl_create_streams_impl(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, bool cameras_per_stream, const char* const* params_yaml,
+                                     const double* depth_min_mean_max, const int* kf_every, const int* min_tracked, int n_workers, svohl_pool* pool, int seed,
+                                     int images_pinned, svohl_engine** out);
 int svohl_create_streams(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* const* params_yaml,
                          const double* depth_min_mean_max, const int* kf_every, const int* min_tracked, int n_workers, svohl_pool* pool, int seed,
                          int images_pinned, svohl_engine** out)
+{
+  return svohl_create_streams_impl(ctx, n_streams, cam, T_B_C, false, params_yaml, depth_min_mean_max, kf_every, min_tracked, n_workers, pool, seed, images_pinned, out);
+}
+int svohl_create_streams_cameras(svoh_ctx* ctx, int n_streams, const svoh_camera* cams, const svoh_se3* T_B_Cs, const char* const* params_yaml,
+                                 const double* depth_min_mean_max, const int* kf_every, const int* min_tracked, int n_workers, svohl_pool* pool, int seed,
+                                 int images_pinned, svohl_engine** out)
+{
+  return svohl_create_streams_impl(ctx, n_streams, cams, T_B_Cs, true, params_yaml, depth_min_mean_max, kf_every, min_tracked, n_workers, pool, seed, images_pinned, out);
+}
+static int svohl_create_streams_impl(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, bool cameras_per_stream, const char* const* params_yaml,
+                                     const double* depth_min_mean_max, const int* kf_every, const int* min_tracked, int n_workers, svohl_pool* pool, int seed,
+                                     int images_pinned, svohl_engine** out)
 {
   return svohl_guard([&] {
     if (!out || !cam || !T_B_C || !params_yaml || !depth_min_mean_max || !kf_every || !min_tracked || n_streams < 1) throw std::runtime_error("svohl_create_streams: NULL argument");
@@ -1090,6 +1108,7 @@ int svohl_create_streams(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, c
       so.depth_min = static_cast<float>(depth_min_mean_max[3 * s]); so.depth_mean = static_cast<float>(depth_min_mean_max[3 * s + 1]); so.depth_max = static_cast<float>(depth_min_mean_max[3 * s + 2]);
       so.kf_every = kf_every[s] > 0 ? static_cast<size_t>(kf_every[s]) : 8;
       so.min_tracked = min_tracked[s] >= 0 ? static_cast<size_t>(min_tracked[s]) : 60;
+      if (cameras_per_stream) { so.own_camera = true; so.cam = cam[s]; so.T_B_C = svoh::load_rigid(T_B_C[s]); }
       lo.per_stream.push_back(so);
     }
     std::unique_ptr<svohl_engine> e(new svohl_engine);

@@ -43,8 +43,9 @@
 namespace svo_hip {
 
 // What may differ between the streams of one engine (round 6).  Everything that decides the options of a device call the streams
-// of a round SHARE -- the camera and its extrinsics, the pyramid's levels, the grid, the detector / matcher / depth-filter switches --
-// must be the same for all of them (the constructor checks and refuses); a stream's own are its feature budgets (max_fts: the
+// of a round SHARE -- the image size, the pyramid's levels, the grid, the detector / matcher / depth-filter switches --
+// must be the same for all of them (the constructor checks and refuses); a stream's own are its camera (intrinsics, distortion model and
+// coefficients, extrinsics: every physical camera has its own calibration -- same image size, since the streams' pyramids are one call), its feature budgets (max_fts: the
 // reprojector's cap and, with max_seeds_ratio, the seeds per keyframe), its alignment options (streams of different options go
 // into different launches), its keyframe rule and its depth prior.  The reference's counterpart: independent frame handlers, each
 // built from its own parameter file (src/svo/include/svo/frame_handler_base.h:274-374, svo_factory.cpp:107-310).
@@ -52,6 +53,10 @@ struct LockstepStreamOptions {
   io::FrontendParams params;
   float depth_min = 1.f, depth_mean = 2.f, depth_max = 4.f;
   size_t kf_every = 8, min_tracked = 60;
+  // the stream's own calibration (own_camera = false: LockstepOptions::cam / T_B_C); width and height must be those of LockstepOptions::cam
+  bool own_camera = false;
+  svoh_camera cam{};
+  Transformation T_B_C{ { 1, 0, 0, 0 }, { 0, 0, 0 } };
 };
 
 struct LockstepOptions {

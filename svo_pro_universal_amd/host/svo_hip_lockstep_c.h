@@ -37,6 +37,12 @@ int svohl_create_shared(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, co
 int svohl_create_streams(svoh_ctx* ctx, int n_streams, const svoh_camera* cam, const svoh_se3* T_B_C, const char* const* params_yaml,
                          const double* depth_min_mean_max, const int* kf_every, const int* min_tracked, int n_workers, svohl_pool* pool, int seed,
                          int images_pinned, svohl_engine** out);
+/* ... and a CAMERA per stream: cams / T_B_Cs hold n_streams entries (intrinsics, distortion and extrinsics may differ, width and height may
+ * not: the streams' pyramids are one call).  cams[0] is the engine's camera: the one the reference's process-wide thresholds are taken from
+ * (svo_hip::fixProcessWideThresholds, svo_hip_host.h). */
+int svohl_create_streams_cameras(svoh_ctx* ctx, int n_streams, const svoh_camera* cams, const svoh_se3* T_B_Cs, const char* const* params_yaml,
+                                 const double* depth_min_mean_max, const int* kf_every, const int* min_tracked, int n_workers, svohl_pool* pool, int seed,
+                                 int images_pinned, svohl_engine** out);
 void svohl_destroy(svohl_engine* e);
 /* one frame of every stream (FrontendLockstep::addImages); images[s] == NULL: stream s has no frame this round; T_f_w_first:
  * n_streams poses, read for the streams whose first frame this is (may be NULL when no stream starts) */

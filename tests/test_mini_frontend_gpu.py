@@ -228,22 +228,56 @@ HETERO_STREAMS = [   # (start, step, frames, every, phase, kf_every, min_tracked
 ]
 
 
-def write_hetero_spec(tmp_path, poses, streams=HETERO_STREAMS):
+# streams with a camera of their own ("per-stream cameras"): stream -> (fx, fy factors, cx, cy shifts, distortion factor,
+# T_B_C: rotation about z in degrees and translation).  Every physical camera has its own calibration; the image size is the engine's.
+HETERO_CALIBS = {
+    1: (1.012, 1.008, 1.5, -2.0, 0.9, 0.0, (0.0, 0.0, 0.0)),
+    3: (0.991, 0.994, -2.5, 1.0, 1.1, 1.0, (0.02, -0.01, 0.005)),
+    4: (1.0, 1.0, 0.0, 0.0, 0.0, -0.5, (0.0, 0.03, 0.0)),       # no distortion at all, other extrinsics
+}
+
+
+def write_own_calib(path, cam, spec):
+    fxs, fys, dcx, dcy, ds, rz, t = spec
+    c, s_ = float(np.cos(np.deg2rad(rz))), float(np.sin(np.deg2rad(rz)))
+    T = [c, -s_, 0.0, t[0], s_, c, 0.0, t[1], 0.0, 0.0, 1.0, t[2], 0.0, 0.0, 0.0, 1.0]
+    path.write_text("""cameras:
+- camera:
+    label: cam0
+    image_height: %d
+    image_width: %d
+    type: pinhole
+    intrinsics:
+      data: [%.17g, %.17g, %.17g, %.17g]
+    distortion:
+      type: radial-tangential
+      parameters:
+        data: [%.17g, %.17g, %.17g, %.17g]
+  T_B_C:
+    data: [%s]
+""" % ((cam.height, cam.width, cam.fx * fxs, cam.fy * fys, cam.cx + dcx, cam.cy + dcy) + tuple(d * ds for d in cam.dist) + (", ".join("%.17g" % v for v in T),)))
+
+
+def write_hetero_spec(tmp_path, poses, streams=HETERO_STREAMS, calibs=None):
     for m in sorted({s[7] for s in streams}):
         (tmp_path / ("params%d.yaml" % m)).write_text("max_fts: %d\ngrid_size: 30\nn_pyr_levels: 3\ndetector_threshold_secondary: 100\n"
                                                        "use_threaded_depthfilter: False\nimg_align_max_level: 4\nimg_align_min_level: 2\n" % m)
     lines = []
-    for (start, step, frames, every, phase, kf_every, min_tracked, max_fts) in streams:
+    for i, (start, step, frames, every, phase, kf_every, min_tracked, max_fts) in enumerate(streams):
         T0 = poses[start].inverse().as7()
         lines.append("start=%d step=%d frames=%d every=%d phase=%d kf_every=%d min_tracked=%d params=%s T0=%s"
                      % (start, step, frames, every, phase, kf_every, min_tracked, tmp_path / ("params%d.yaml" % max_fts), ",".join("%.17g" % v for v in T0)))
+        if calibs and i in calibs:
+            write_own_calib(tmp_path / ("calib%d.yaml" % i), synth.Camera.euroc_like(752, 480), calibs[i])
+            lines[-1] += " calib=%s" % (tmp_path / ("calib%d.yaml" % i))
     spec = tmp_path / "streams.spec"
     spec.write_text("# one stream per line (tools/svoh_mini_frontend.cpp: SVOH_MINI_SPEC)\n" + "\n".join(lines) + "\n")
     return spec
 
 
 def test_lockstep_of_streams_that_differ(tmp_path):
-    """the lock-step engine on streams that have NOTHING in common but the camera -- their own walk over the
+    """the lock-step engine on streams that have NOTHING in common but the image size (three of them their own
+    camera calibration: intrinsics, distortion, extrinsics -- next #6) -- their own walk over the
     sequence (start, direction, stride), their own frame rate and first round, their own keyframe period (so keyframe rounds do not
     coincide), feature budgets of 120 / 180 / 240 (different launch geometries in one round), one stream whose features run out (its
     third reprojection pass is reached while the others' is not), one that makes its keyframes by the tracked-features rule.  Every
@@ -251,7 +285,7 @@ def test_lockstep_of_streams_that_differ(tmp_path):
     (1,1), (3,1), (2,2): a gather / scatter that hands stream j's pose, candidates, seeds or keyframe columns to stream k shows here
     (the test of identical streams cannot see it).  Reference: independent frame handlers, frame_handler_base.h:274-374."""
     cmd, out_dir, poses, stamps, n_frames = make_dataset(tmp_path)
-    spec = write_hetero_spec(tmp_path, poses)
+    spec = write_hetero_spec(tmp_path, poses, calibs=HETERO_CALIBS)   # three of the streams with a calibration of their own (next #6)
     S = len(HETERO_STREAMS)
     singles = []
     for i in range(S):

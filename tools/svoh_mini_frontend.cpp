@@ -42,6 +42,7 @@
 //   every=<n> phase=<n>                   lock-step only: the stream has a frame in round r iff r >= phase and (r - phase) % every == 0
 //   kf_every=<n> min_tracked=<n>          its keyframe rule        params=<yaml>   its own parameter file (max_fts, ...)
 //   T0=qw,qx,qy,qz,tx,ty,tz               T_f_w of its first frame
+//   calib=<yaml>                          its own camera calibration (intrinsics, distortion, extrinsics; the image size of the run's)
 // lockstep: n_streams = the number of lines (the command line's n_streams must agree); threads mode with n_streams = 1:
 // SVOH_MINI_SPEC_LINE=<i> runs stream i of the file alone -- the run a lock-step stream must reproduce byte for byte.
 // A frame's timestamp in the trajectory file is its image's.
@@ -75,7 +76,7 @@ struct StreamResult { size_t n_done = 0, n_kfs = 0; double sum_ms = 0, wall_ms =
 // one line of SVOH_MINI_SPEC
 struct StreamSpec {
   long start = 0, step = 1, every = 1, phase = 0, frames = -1, kf_every = -1, min_tracked = -1;
-  std::string params;
+  std::string params, calib;
   bool has_T0 = false;
   Transformation T0{ { 1, 0, 0, 0 }, { 0, 0, 0 } };
   // image of the stream's j-th frame
@@ -111,6 +112,7 @@ std::vector<StreamSpec> load_specs(const char* path)
       else if (key == "kf_every") sp.kf_every = atol(val.c_str());
       else if (key == "min_tracked") sp.min_tracked = atol(val.c_str());
       else if (key == "params") sp.params = val;
+      else if (key == "calib") sp.calib = val;
       else if (key == "T0") {
         double v[7];
         if (sscanf(val.c_str(), "%lf,%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6) != 7) { fclose(f); throw std::runtime_error("stream spec: T0 needs seven numbers"); }
@@ -381,6 +383,10 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
           so.depth_min = depth_min; so.depth_mean = depth_mean; so.depth_max = depth_max;
           so.kf_every = sp.kf_every > 0 ? (size_t)sp.kf_every : kf_every;
           so.min_tracked = sp.min_tracked >= 0 ? (size_t)sp.min_tracked : lo.min_tracked;
+          if (!sp.calib.empty()) {
+            const std::vector<io::RigCamera> own_rig = io::loadCameraRig(sp.calib);
+            so.own_camera = true; so.cam = own_rig.at(0).cam; so.T_B_C = own_rig[0].T_B_C;
+          }
           lo.per_stream.push_back(so);
           if (sp.has_T0) T_first[(size_t)i] = sp.T0;
           const long nf = sp.frames > 0 ? sp.frames : (long)images.size();
@@ -553,7 +559,10 @@ int main(int argc, char** argv)
       if (n_streams != 1 || !getenv("SVOH_MINI_SPEC_LINE")) throw std::runtime_error("threads mode with SVOH_MINI_SPEC: n_streams = 1 and SVOH_MINI_SPEC_LINE=<i>");
       const StreamSpec& sp = specs.at((size_t)atol(getenv("SVOH_MINI_SPEC_LINE")));
       const io::FrontendParams own = sp.params.empty() ? params : io::loadFrontendParams(sp.params);
-      run_stream(seq, images, rig, own, out_dir, sp.has_T0 ? sp.T0 : T0, depth_min, depth_mean, depth_max, sp.kf_every > 0 ? (size_t)sp.kf_every : kf_every, &gate, 1, &results[0], &sp);
+      // the process-wide thresholds are those of the RUN's camera, as in the lock-step engine this stream is compared with (fixProcessWideThresholds)
+      fixProcessWideThresholds(rig.at(0).cam, 2.0);
+      const std::vector<io::RigCamera> own_rig = sp.calib.empty() ? rig : io::loadCameraRig(sp.calib);
+      run_stream(seq, images, own_rig, own, out_dir, sp.has_T0 ? sp.T0 : T0, depth_min, depth_mean, depth_max, sp.kf_every > 0 ? (size_t)sp.kf_every : kf_every, &gate, 1, &results[0], &sp);
       if (!results[0].error.empty()) throw std::runtime_error(results[0].error);
       printf("svoh_mini_frontend: stream %s of the spec alone: %zu frames, %.3f ms/frame on the GPU path, %zu keyframes alive\n", getenv("SVOH_MINI_SPEC_LINE"), results[0].n_done + 1,
              results[0].n_done ? results[0].sum_ms / results[0].n_done : 0.0, results[0].n_kfs);
