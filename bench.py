@@ -743,6 +743,11 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         step = (1, -1, 1, -1, 2, 1, -1, -2)[s % 8]
         return ((7 * s) % n_frames, step, 2 if s % 8 == 5 else 1, 0), (8, 6, 5, 7, 9, 4)[s % 6], (180, 120, 240)[s % 3]
 
+    def camera_of(s):   # ... and every fourth stream of the mix a calibration of its own (same sensor size: LockstepStreamOptions::own_camera)
+        if s % 4 != 3:
+            return cam
+        return synth.Camera(cam.width, cam.height, cam.fx * 1.01, cam.fy * 0.992, cam.cx + 1.5, cam.cy - 2.0, dist=[0.9 * d for d in cam.dist] if cam.dist is not None else None)
+
     def image_of(sched, k):   # the image of the stream's frame in round k (svohl_run_schedule's rule), or None
         start, step, every, phase = sched
         if k < phase or (k - phase) % every:
@@ -759,7 +764,7 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         shared = None   # (a pool shared between the groups was built and raced in round 5: no gain, profiles/r05_shared_pool_ab.txt; every group has its own)
         per = [None] * G
         if mix:
-            per = [[dict(params_yaml=params.replace("max_fts: 180", "max_fts: %d" % mix_of(s)[2]), kf_every=mix_of(s)[1]) for s in range(lo, hi)] for lo, hi in ranges]
+            per = [[dict(params_yaml=params.replace("max_fts: 180", "max_fts: %d" % mix_of(s)[2]), kf_every=mix_of(s)[1], cam=camera_of(s)) for s in range(lo, hi)] for lo, hi in ranges]
         engines = [ls.Lockstep(c, hi - lo, cam, np.array([1.0, 0, 0, 0, 0, 0, 0]), params, 0.5 * depth, depth, 2.0 * depth, 8, W, True, pool=shared, seed=lo, per_stream=ps)
                    for c, (lo, hi), ps in zip(ctxs, ranges, per)]
         first = poses[0].inverse().as7()
@@ -884,7 +889,7 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
             "config": {"workload": "C5-synth per GPU: %d streams x 752x480 radtan in %d lock-step group(s) with %d host thread(s) each; per stream and frame: 5-level "
                                    "pyramid, align <=180..720 patches 4x4 levels 4..2, ~100 direct + ~900 seed matcher units, pose over <=180 features, "
                                    "depth-filter update of <=5 keyframes (~1600 seeds), a keyframe every 8 frames; a step = one frame of every stream; "
-                                   "the streams replay one rendered sequence forth and back%s" % (S, G, W, " -- EVERY STREAM ITS OWN WALK, keyframe period and feature budget (--stream-mix)" if args.stream_mix else ""),
+                                   "the streams replay one rendered sequence forth and back%s" % (S, G, W, " -- EVERY STREAM ITS OWN WALK, keyframe period and feature budget, every fourth its own camera calibration (--stream-mix)" if args.stream_mix else ""),
                        "streams": S, "groups": G, "host_threads_per_group": W, "host_cpus_visible": n_host},
             "lockstep": main_run, "identical_streams_beside_it": same_streams, "streams_sweep": sweep,
             "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,

@@ -111,6 +111,9 @@ FrontendLockstepStereo::~FrontendLockstepStereo()
 {
   try { finish(); } catch (...) {}
   if (seeds_in_flight_) (void)svoh_matcher_collect(ctx_);
+  // a prefetch announced for a round that never came may still be writing its slab on the upload stream
+  (void)svoh_prefetch_fence(ctx_);
+  for (svoh_frame_t h : prefetched_) if (h) (void)svoh_release_frame(ctx_, h);
   for (auto& st : streams_) {
     for (const FramePtr& f : st->kfs) for (auto& sr : f->seed_ref_vec_) sr.keyframe.reset();
     if (st->last) for (const FramePtr& f : st->last->frames_) for (auto& sr : f->seed_ref_vec_) sr.keyframe.reset();
@@ -122,8 +125,10 @@ FrontendLockstepStereo::~FrontendLockstepStereo()
 void FrontendLockstepStereo::drainReleases()
 {
   std::vector<svoh_frame_t> r;
-  { std::lock_guard<std::mutex> lock(release_mu_); r.swap(to_release_); }
+  std::vector<svoh_features_t> fr;
+  { std::lock_guard<std::mutex> lock(release_mu_); r.swap(to_release_); fr.swap(features_to_release_); }
   for (svoh_frame_t h : r) (void)svoh_release_frame(ctx_, h);
+  for (svoh_features_t h : fr) (void)svoh_features_release(ctx_, h);
 }
 
 Transformation FrontendLockstepStereo::pose(int s) const
@@ -189,6 +194,20 @@ void FrontendLockstepStereo::makeKeyframe(Stream& st, size_t kf_id)
                                         static_cast<float>(d_med));
     for (size_t i = n_old; i < f->num_features_; ++i) { f->seed_ref_vec_[i].keyframe = f; f->seed_ref_vec_[i].seed_id = static_cast<int>(i); }
   }
+  // the two frames' features are final now: their constant columns go to the device once (a keyframe's seeds are updated by every later pair)
+  if (opt_.resident_features) {
+    int32_t n[2]; const double *px[2], *fv[2], *grad[2]; const int32_t* level[2];
+    svoh_features_t handles[2] = { 0, 0 };
+    for (size_t c = 0; c < 2; ++c) {
+      const Frame& fr = *b->at(c);
+      n[c] = static_cast<int32_t>(fr.num_features_); px[c] = fr.px_vec_.data(); fv[c] = fr.f_vec_.data(); grad[c] = fr.grad_vec_.data(); level[c] = fr.level_vec_.data();
+    }
+    if (n[0] > 0 && n[1] > 0) {
+      check(svoh_features_upload(ctx_, 2, n, px, fv, grad, level, handles), "svoh_features_upload");
+      ++device_calls_;
+      for (size_t c = 0; c < 2; ++c) b->at(c)->features = handles[c];
+    }
+  }
   const size_t max_kfs = 2 * st.rp0.options_.max_n_kfs;
   for (size_t c = 0; c < 2; ++c) {
     st.kfs.push_back(b->at(c));
@@ -204,59 +223,61 @@ void FrontendLockstepStereo::makeKeyframe(Stream& st, size_t kf_id)
 // units are DepthFilterHip::queueUpdateSeeds' (every feature of every visible keyframe), a stream's units name its own frames
 void FrontendLockstepStereo::seedUpdate(const std::vector<int>& trk, int c, bool leave_in_flight)
 {
-  sb_ = SeedBatch();
-  sb_.streams = trk;
-  sb_.curs.resize(trk.size());
+  sb_streams_ = trk;
   // where every stream's units and reference frames go, then every stream fills its slices (pool)
   size_t n_units = 0, n_refs = 0;
   std::vector<size_t> ref_off(trk.size());
+  bool resident = opt_.resident_features;
   for (size_t w = 0; w < trk.size(); ++w) {
     Stream& st = *streams_[static_cast<size_t>(trk[w])];
     st.seed_frames = st.visible;
     st.seed_counts.clear();
     st.seed_off = n_units;
     ref_off[w] = n_refs;
-    for (const FramePtr& rf : st.seed_frames) { st.seed_counts.push_back(rf->num_features_); n_units += rf->num_features_; }
+    for (const FramePtr& rf : st.seed_frames) { st.seed_counts.push_back(rf->num_features_); n_units += rf->num_features_; resident = resident && rf->features != 0; }
     n_refs += st.seed_frames.size();
   }
-  sb_.refs.resize(n_refs);
-  sb_.ref_idx.resize(n_units); sb_.cur_idx.resize(n_units); sb_.level.resize(n_units); sb_.type.resize(n_units);
-  sb_.px.resize(2 * n_units); sb_.f.resize(3 * n_units); sb_.grad.resize(2 * n_units); sb_.state.resize(4 * n_units);
+  if (n_units == 0) { for (int s : trk) { streams_[static_cast<size_t>(s)]->seed_frames.clear(); streams_[static_cast<size_t>(s)]->seed_counts.clear(); } return; }
+  // the batch is built in the context's page-locked staging area (no copy between the host arrays and the transfer); with resident keyframe
+  // columns (svoh_features_upload at the keyframe step) it is every feature of every visible keyframe, frame after frame (SVOH_BATCH_WHOLE_SETS):
+  // per unit only the seed's state and type cross PCIe, and the kernel works in the tile order computed once per keyframe
+  check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
+  struct CloseSection { svoh_ctx* c; bool armed; ~CloseSection() { if (armed) (void)svoh_matcher_collect(c); } } close_section{ ctx_, true };
+  check(svoh_matcher_stage(ctx_, 1, static_cast<int>(n_units), static_cast<int>(n_refs + trk.size()) + 1, resident ? SVOH_STAGE_RESIDENT_COLUMNS : 0, &seed_stage_), "svoh_matcher_stage");
+  const svoh_matcher_stage_t& g = seed_stage_;
+  std::vector<svoh_frame_view> refs(n_refs), curs(trk.size());
   pool_->run(static_cast<int>(trk.size()), [&](int w) {
     Stream& st = *streams_[static_cast<size_t>(trk[static_cast<size_t>(w)])];
-    sb_.curs[static_cast<size_t>(st.slot)] = detail::viewOf(*st.bundle->at(static_cast<size_t>(c)));
+    curs[static_cast<size_t>(st.slot)] = detail::viewOf(*st.bundle->at(static_cast<size_t>(c)));
     size_t off = st.seed_off;
     for (size_t k = 0; k < st.seed_frames.size(); ++k) {
       const Frame& r = *st.seed_frames[k];
       const int32_t ref = static_cast<int32_t>(ref_off[static_cast<size_t>(w)] + k);
-      sb_.refs[static_cast<size_t>(ref)] = detail::viewOf(r);
+      refs[static_cast<size_t>(ref)] = detail::viewOf(r);
       const size_t n = st.seed_counts[k];
-      std::fill(sb_.ref_idx.begin() + off, sb_.ref_idx.begin() + off + n, ref);
-      std::fill(sb_.cur_idx.begin() + off, sb_.cur_idx.begin() + off + n, st.slot);
-      std::copy(r.px_vec_.begin(), r.px_vec_.begin() + 2 * n, sb_.px.begin() + 2 * off);
-      std::copy(r.f_vec_.begin(), r.f_vec_.begin() + 3 * n, sb_.f.begin() + 3 * off);
-      std::copy(r.grad_vec_.begin(), r.grad_vec_.begin() + 2 * n, sb_.grad.begin() + 2 * off);
-      std::copy(r.level_vec_.begin(), r.level_vec_.begin() + n, sb_.level.begin() + off);
-      std::copy(r.type_vec_.begin(), r.type_vec_.begin() + n, sb_.type.begin() + off);
-      std::copy(r.invmu_sigma2_a_b_vec_.begin(), r.invmu_sigma2_a_b_vec_.begin() + 4 * n, sb_.state.begin() + 4 * off);
+      if (g.feature_index) for (size_t i = 0; i < n; ++i) g.cur_frame_idx[off + i] = st.slot;
+      else {
+        for (size_t i = 0; i < n; ++i) { g.ref_frame_idx[off + i] = ref; g.cur_frame_idx[off + i] = st.slot; }
+        memcpy(g.px + 2 * off, r.px_vec_.data(), 16 * n); memcpy(g.f + 3 * off, r.f_vec_.data(), 24 * n); memcpy(g.grad + 2 * off, r.grad_vec_.data(), 16 * n);
+        memcpy(g.level + off, r.level_vec_.data(), 4 * n);
+      }
+      memcpy(g.type + off, r.type_vec_.data(), n);
+      memcpy(g.state + 4 * off, r.invmu_sigma2_a_b_vec_.data(), 32 * n);
       off += n;
     }
   });
-  const size_t n_total = sb_.type.size();
-  if (n_total == 0) { for (int s : trk) { streams_[static_cast<size_t>(s)]->seed_frames.clear(); streams_[static_cast<size_t>(s)]->seed_counts.clear(); } return; }
-  sb_.success.assign(n_total, 0);
-  sb_.result.assign(n_total, SVOH_MATCH_NOT_RUN);
   svoh_feature_batch fb{};
-  fb.n = static_cast<int32_t>(n_total);
-  fb.ref_frame_idx = sb_.ref_idx.data(); fb.px = sb_.px.data(); fb.f = sb_.f.data(); fb.grad = sb_.grad.data(); fb.level = sb_.level.data(); fb.type = sb_.type.data();
-  fb.cur_frame_idx = sb_.cur_idx.data(); fb.n_cur_frames = static_cast<int32_t>(trk.size());
+  fb.n = static_cast<int32_t>(n_units);
+  fb.ref_frame_idx = g.ref_frame_idx; fb.cur_frame_idx = g.cur_frame_idx; fb.n_cur_frames = static_cast<int32_t>(trk.size());
+  fb.px = g.px; fb.f = g.f; fb.grad = g.grad; fb.level = g.level; fb.type = g.type; fb.feature_index = g.feature_index;
+  fb.mem_space = SVOH_MEM_STAGED;
+  fb.layout = g.feature_index ? SVOH_BATCH_WHOLE_SETS : SVOH_BATCH_UNITS;
   DepthFilterHip df(ctx_, opt_.params.depth_filter);   // (options only: the batch is the driver's)
   const svoh_depth_filter_options dfo = df.abiOptions(*streams_[static_cast<size_t>(trk[0])]->bundle->at(static_cast<size_t>(c)));
   const svoh_matcher_options mopt = df.getMatcherOptions();
-  check(svoh_matcher_begin_deferred(ctx_), "svoh_matcher_begin_deferred");
-  int rc = svoh_update_seeds_batch(ctx_, &mopt, &dfo, static_cast<int>(sb_.refs.size()), sb_.refs.data(), sb_.curs.data(), &fb, sb_.state.data(), sb_.success.data(), sb_.result.data(), nullptr);
-  if (rc == SVOH_OK) rc = svoh_matcher_flush(ctx_);
-  if (rc != SVOH_OK) { const std::string msg = svoh_last_error_string(ctx_); (void)svoh_matcher_collect(ctx_); throw std::runtime_error("svoh_update_seeds_batch: " + msg); }
+  check(svoh_update_seeds_batch(ctx_, &mopt, &dfo, static_cast<int>(refs.size()), refs.data(), curs.data(), &fb, g.state, g.success, g.result, nullptr), "svoh_update_seeds_batch");
+  check(svoh_matcher_flush(ctx_), "svoh_matcher_flush");
+  close_section.armed = false;
   ++device_calls_;
   seeds_in_flight_ = true;
   if (!leave_in_flight) collectSeedUpdate();
@@ -268,8 +289,9 @@ void FrontendLockstepStereo::collectSeedUpdate()
   seeds_in_flight_ = false;
   check(svoh_matcher_collect(ctx_), "svoh_matcher_collect");
   ++device_calls_;
-  pool_->run(static_cast<int>(sb_.streams.size()), [&](int w) {
-    Stream& st = *streams_[static_cast<size_t>(sb_.streams[static_cast<size_t>(w)])];
+  const svoh_matcher_stage_t& g = seed_stage_;
+  pool_->run(static_cast<int>(sb_streams_.size()), [&](int w) {
+    Stream& st = *streams_[static_cast<size_t>(sb_streams_[static_cast<size_t>(w)])];
     size_t off = st.seed_off, n_applied = 0;
     for (size_t k = 0; k < st.seed_frames.size(); ++k) {
       Frame& r = *st.seed_frames[k];
@@ -277,9 +299,9 @@ void FrontendLockstepStereo::collectSeedUpdate()
       // (a seed that became a feature while its update was in flight keeps what the upgrade made of it: DepthFilterHip::finishUpdateSeedsNow's rule)
       for (size_t i = 0; i < n; ++i) {
         if (r.type_vec_[i] >= SVOH_FT_EDGELET) continue;
-        std::copy(sb_.state.begin() + 4 * (off + i), sb_.state.begin() + 4 * (off + i + 1), r.invmu_sigma2_a_b_vec_.begin() + 4 * i);
-        r.type_vec_[i] = sb_.type[off + i];
-        n_applied += sb_.success[off + i];
+        std::copy(g.state + 4 * (off + i), g.state + 4 * (off + i + 1), r.invmu_sigma2_a_b_vec_.begin() + 4 * i);
+        r.type_vec_[i] = g.type[off + i];
+        n_applied += g.success[off + i];
       }
       off += n;
     }
@@ -300,7 +322,25 @@ void FrontendLockstepStereo::finishSecondSeedUpdate()
   }
 }
 
-void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t* const* right, int pitch, const Transformation* T_imu_world_first, const svoh::Quat* const* imu_prior)
+void FrontendLockstepStereo::prefetch(const uint8_t* const* next_left, const uint8_t* const* next_right, int pitch)
+{
+  if (!next_left || !next_right || !prefetched_.empty()) return;
+  const int S = numStreams();
+  std::vector<const uint8_t*> imgs;
+  for (int s = 0; s < S; ++s) {
+    if ((next_left[s] == nullptr) != (next_right[s] == nullptr)) throw std::runtime_error("FrontendLockstepStereo::addPairs: a pair needs both images (next_left / next_right)");
+    if (next_left[s]) { imgs.push_back(next_left[s]); imgs.push_back(next_right[s]); }
+  }
+  if (imgs.empty()) return;
+  prefetched_.assign(imgs.size(), 0);
+  check(svoh_build_pyramid_multi_prefetch(ctx_, imgs.data(), static_cast<int>(imgs.size()), opt_.rig[0].cam.width, opt_.rig[0].cam.height, pitch, opt_.images_mem_space,
+                                          opt_.params.n_pyr_levels_to_build, SVOH_HALFSAMPLE_REFERENCE, prefetched_.data()), "svoh_build_pyramid_multi_prefetch");
+  ++device_calls_;
+  prefetched_from_ = imgs;
+}
+
+void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t* const* right, int pitch, const Transformation* T_imu_world_first, const svoh::Quat* const* imu_prior,
+                                      const uint8_t* const* next_left, const uint8_t* const* next_right)
 {
   const int S = numStreams();
   device_calls_ = 0;
@@ -325,11 +365,18 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
   const int nT = static_cast<int>(trk.size());
 
   // ---- pyramids of the round's 2 x (active streams) images: one call
+  if (!prefetched_.empty() && prefetched_from_ != imgs) throw std::runtime_error("FrontendLockstepStereo::addPairs: not the pairs that were announced as next_left / next_right");
   if (!imgs.empty()) {
     std::vector<svoh_frame_t> handles(imgs.size(), 0);
-    check(svoh_build_pyramid_multi(ctx_, imgs.data(), static_cast<int>(imgs.size()), opt_.rig[0].cam.width, opt_.rig[0].cam.height, pitch, opt_.images_mem_space,
-                                   opt_.params.n_pyr_levels_to_build, SVOH_HALFSAMPLE_REFERENCE, handles.data()), "svoh_build_pyramid_multi");
-    ++device_calls_;
+    if (!prefetched_.empty()) {   // made during the round before: for exactly the images that were announced
+      handles.swap(prefetched_);
+      prefetched_.clear(); prefetched_from_.clear();
+      check(svoh_prefetch_fence(ctx_), "svoh_prefetch_fence");
+    } else {
+      check(svoh_build_pyramid_multi(ctx_, imgs.data(), static_cast<int>(imgs.size()), opt_.rig[0].cam.width, opt_.rig[0].cam.height, pitch, opt_.images_mem_space,
+                                     opt_.params.n_pyr_levels_to_build, SVOH_HALFSAMPLE_REFERENCE, handles.data()), "svoh_build_pyramid_multi");
+      ++device_calls_;
+    }
     size_t at = 0;
     for (int s = 0; s < S; ++s) {
       Stream& st = *streams_[static_cast<size_t>(s)];
@@ -337,7 +384,11 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
       st.bundle.reset(new FrameBundle);
       for (int c = 0; c < 2; ++c) {
         FramePtr frame(new Frame, [this](Frame* f) {
-          if (f->pyramid) { std::lock_guard<std::mutex> lock(release_mu_); to_release_.push_back(f->pyramid); }
+          if (f->pyramid || f->features) {
+            std::lock_guard<std::mutex> lock(release_mu_);
+            if (f->pyramid) to_release_.push_back(f->pyramid);
+            if (f->features) features_to_release_.push_back(f->features);
+          }
           delete f;
         });
         frame->pyramid = handles[at++];
@@ -373,7 +424,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
     makeKeyframe(st, 0);
     st.row.alpha = st.img_align.lastResult().alpha; st.row.beta = st.img_align.lastResult().beta;
   }
-  if (nT == 0) { close_round(); return; }
+  if (nT == 0) { prefetch(next_left, next_right, pitch); close_round(); return; }
 
   // ---- 1. sparse image alignment of the bundles, each with its stream's IMU rotation prior (frame_handler_base.cpp:610-643)
   pool_->run(S, [&](int s) {
@@ -415,6 +466,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
     std::vector<svoh_align_result> results(static_cast<size_t>(nT));
     check(svoh_sparse_align_fetch_all(ctx_, nT, results.data()), "svoh_sparse_align_fetch_all");
     ++device_calls_;
+    prefetch(next_left, next_right, pitch);   // (behind a call that waited: the context's stream is idle, the next pairs cross PCIe beside the rest of the round)
     for (int s : trk) {   // a cluster of workgroups that never completed (status 3): that problem again, one workgroup
       Stream& st = *streams_[static_cast<size_t>(s)];
       if (results[static_cast<size_t>(st.align_result)].status != 3) continue;
@@ -440,8 +492,13 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
       ReprojectorHip& rp = *st.rp[c];
       rp.discardCandidateProjection();
       st.trash.clear();
-      rp.walkCandidates(st.bundle->at(cc), st.visible, st.trash);
-      rp.planMatches(st.bundle->at(cc), 3, false);
+      // the third list (the unconverged seeds: the longest, and in the steady state one whose pass is not reached) joins the batch only if the
+      // camera's pass reached it in the pair before (ReprojectorHip::reprojectFrames' own policy); a replay that does reach an unplanned pass
+      // pauses and gets a batch of its own below.  The passes run in the reference's order either way: same results.
+      const bool third = opt_.speculate_all || st.k <= 1 || rp.reachedUnconvergedPass();
+      if (third) rp.walkCandidates(st.bundle->at(cc), st.visible, st.trash);
+      else rp.walkCandidatesWithoutUnconverged(st.bundle->at(cc), st.visible, st.trash);
+      rp.planMatches(st.bundle->at(cc), third ? 3 : 2, false);
     });
     auto matcher_round = [&](const std::vector<int>& who, bool sort_meanwhile) {
       size_t n_direct = 0, n_seeds = 0, n_refs = 0;
@@ -526,10 +583,11 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
       point_outputs(st);
       st.needs_more = st.rp[c]->replayMatchesUntilUnplanned(st.bundle->at(cc));
     });
-    for (;;) {   // (all three lists are planned: no replay pauses; kept for a mirror that plans fewer)
+    for (;;) {   // the streams whose replay reached a pass that was not planned: that pass' list as a batch of their own, then on from there
       std::vector<int> more;
       for (int s : trk) if (streams_[static_cast<size_t>(s)]->needs_more) more.push_back(s);
       if (more.empty()) break;
+      paused_passes_ += more.size();
       pool_->run(static_cast<int>(more.size()), [&](int w) { Stream& st = *streams_[static_cast<size_t>(more[static_cast<size_t>(w)])]; st.rp[c]->planPausedPass(st.bundle->at(cc), false, &st.visible); });
       matcher_round(more, false);
       pool_->run(static_cast<int>(more.size()), [&](int w) {
@@ -679,7 +737,7 @@ int svohs_run_sequence(svohs_engine* e, const uint8_t* base, size_t image_bytes,
     const int S = e->fe->numStreams();
     std::vector<svo_hip::Transformation> T;
     if (T_imu_world_first) for (int s = 0; s < S; ++s) T.push_back(svoh::load_rigid(T_imu_world_first[s]));
-    std::vector<const uint8_t*> left(static_cast<size_t>(S)), right(static_cast<size_t>(S));
+    std::vector<const uint8_t*> left(static_cast<size_t>(S)), right(static_cast<size_t>(S)), next_left(static_cast<size_t>(S)), next_right(static_cast<size_t>(S));
     std::vector<const svoh::Quat*> prior(static_cast<size_t>(S), nullptr);
     const long period = 2L * (n_pairs - 1);
     auto pair_of = [&](long k) { const long m = k % period; return m < n_pairs ? m : period - m; };
@@ -699,7 +757,15 @@ int svohs_run_sequence(svohs_engine* e, const uint8_t* base, size_t image_bytes,
         prior[static_cast<size_t>(s)] = have ? &q : nullptr;
       }
       const double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-      e->fe->addPairs(left.data(), right.data(), pitch, T.empty() ? nullptr : T.data(), prior.data());
+      const bool has_next = k + 1 < k_first + n_rounds;   // (the next pairs of a replay are known: they go up during the round)
+      if (has_next) {
+        const long fn = pair_of(k + 1);
+        for (int s = 0; s < S; ++s) {
+          next_left[static_cast<size_t>(s)] = base + static_cast<size_t>(s) * stream_stride + static_cast<size_t>(2 * fn) * image_bytes;
+          next_right[static_cast<size_t>(s)] = base + static_cast<size_t>(s) * stream_stride + static_cast<size_t>(2 * fn + 1) * image_bytes;
+        }
+      }
+      e->fe->addPairs(left.data(), right.data(), pitch, T.empty() ? nullptr : T.data(), prior.data(), has_next ? next_left.data() : nullptr, has_next ? next_right.data() : nullptr);
       if (round_ms) round_ms[k - k_first] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
     }
   });

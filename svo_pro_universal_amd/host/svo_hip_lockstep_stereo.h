@@ -40,6 +40,10 @@ struct StereoLockstepOptions {
   int n_workers = 1;                    // host threads, the caller included
   bool landmarks = true;                // upgradeSeedsToFeatures at keyframes, optimizeStructure every pair (as svoh_mini_stereo)
   int images_mem_space = SVOH_MEM_HOST; // SVOH_MEM_HOST_PINNED: the images live in svoh_host_alloc memory (one gather kernel reads all of them over PCIe)
+  // a keyframe pair's constant feature columns are uploaded once (svoh_features_upload); the depth-filter batches of the pairs after it are
+  // whole resident sets (SVOH_BATCH_WHOLE_SETS): per seed only state and type cross PCIe.  false: explicit columns every pair (tests)
+  bool resident_features = true;
+  bool speculate_all = false;           // every camera's third candidate list (its unconverged seeds) joins the round's batch whether or not its pass was reached before (tests)
 };
 
 class FrontendLockstepStereo {
@@ -54,13 +58,18 @@ class FrontendLockstepStereo {
   // One pair of every stream: left[s] / right[s] = level 0 of the two images (the cameras' size, `pitch` bytes per row; both NULL: stream s
   // has no pair this round).  A stream's first pair makes its first keyframes at T_imu_world_first[s].  imu_prior[s] (the array or an
   // entry may be NULL): R_imu(k)_imu(k-1) of the stream's new pair, the rotation the alignment's prior is built from.
-  void addPairs(const uint8_t* const* left, const uint8_t* const* right, int pitch, const Transformation* T_imu_world_first, const svoh::Quat* const* imu_prior);
+  // next_left / next_right (may be NULL): the pairs of the NEXT call, when the caller knows them already -- their pyramids are built during
+  // this round on a second stream, beside the chain's work (svoh_build_pyramid_multi_prefetch: 2 S images cross PCIe per round); the next
+  // call must then bring exactly these images.
+  void addPairs(const uint8_t* const* left, const uint8_t* const* right, int pitch, const Transformation* T_imu_world_first, const svoh::Quat* const* imu_prior,
+                const uint8_t* const* next_left = nullptr, const uint8_t* const* next_right = nullptr);
   Transformation pose(int s) const;     // T_imu_world of stream s' newest pair
   // rows are complete once the pair's second seed update has been finished (at the start of the next addPairs, or in finish())
   std::vector<PairRow> completedRows(int s);
   size_t keyframesAlive(int s) const;
   void finish();
   int lastRoundDeviceCalls() const { return device_calls_; }
+  size_t pausedPasses() const { return paused_passes_; }   // replays that reached a pass nobody had planned (since construction)
   // where the rounds' time went (ms summed since construction): pyramids, finish seeds, align, reproject, pose, structure, keyframes, seed updates
   static constexpr int kNumPhases = 8;
   const double* phaseTimes() const { return phase_ms_; }
@@ -80,18 +89,19 @@ class FrontendLockstepStereo {
   std::unique_ptr<WorkerPool> pool_;
   std::vector<std::unique_ptr<Stream>> streams_;
   int device_calls_ = 0;
+  size_t paused_passes_ = 0;
   double phase_ms_[kNumPhases] = {};
   bool seeds_in_flight_ = false;
-  // the seed batch in flight (host arrays: alive until collected)
-  struct SeedBatch {
-    std::vector<int> streams;
-    std::vector<svoh_frame_view> refs, curs;
-    std::vector<int32_t> ref_idx, cur_idx, level, result;
-    std::vector<double> px, f, grad, state;
-    std::vector<uint8_t> type, success;
-  } sb_;
+  // the seed batch in flight: its streams, and where it was staged (the context's page-locked area: valid until the next stage call)
+  std::vector<int> sb_streams_;
+  svoh_matcher_stage_t seed_stage_{};
   std::mutex release_mu_;
   std::vector<svoh_frame_t> to_release_;
+  std::vector<svoh_features_t> features_to_release_;
+  // the next round's pyramids, announced and under way (in the order left(s), right(s) of the streams that will have a pair)
+  std::vector<svoh_frame_t> prefetched_;
+  std::vector<const uint8_t*> prefetched_from_;
+  void prefetch(const uint8_t* const* next_left, const uint8_t* const* next_right, int pitch);
 };
 
 }  // namespace svo_hip

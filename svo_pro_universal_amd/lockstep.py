@@ -32,6 +32,7 @@ def load_host():
                                         C.c_int, C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
     lib.svohl_create_streams.argtypes = [C.c_void_p, C.c_int, P(capi.svoh_camera), P(capi.svoh_se3), P(C.c_char_p), P(C.c_double), P(C.c_int), P(C.c_int),
                                          C.c_int, C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
+    lib.svohl_create_streams_cameras.argtypes = lib.svohl_create_streams.argtypes
     lib.svohl_run_schedule.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_long, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int),
                                        C.c_void_p, C.c_void_p, P(C.c_long)]
     lib.svohl_destroy.argtypes = [C.c_void_p]
@@ -113,7 +114,8 @@ class Lockstep(object):
     def __init__(self, ctx, n_streams, cam, T_B_C7, params_yaml, depth_min, depth_mean, depth_max, kf_every=8, n_workers=1, images_pinned=True,
                  pool=None, seed=0, per_stream=None):
         """per_stream (round 6): a list of n_streams dicts(params_yaml, kf_every, min_tracked, depth=(min, mean, max)) -- streams that
-        differ (svohl_create_streams); missing keys take the common arguments."""
+        differ (svohl_create_streams); missing keys take the common arguments.  If any dict has "cam" (and optionally "T_B_C7"), every stream
+        gets a camera of its own (svohl_create_streams_cameras: same image size; streams without the key take `cam`; stream 0's is the engine's)."""
         self.lib = load_host()
         self.ctx = ctx
         self.n = int(n_streams)
@@ -126,8 +128,14 @@ class Lockstep(object):
             depth = (C.c_double * (3 * self.n))(*[float(v) for d in per_stream for v in d.get("depth", (depth_min, depth_mean, depth_max))])
             kfe = (C.c_int * self.n)(*[int(d.get("kf_every", kf_every)) for d in per_stream])
             mtr = (C.c_int * self.n)(*[int(d.get("min_tracked", 60)) for d in per_stream])
-            rc = self.lib.svohl_create_streams(ctx.h, self.n, C.byref(c), C.byref(T), yamls, depth, kfe, mtr, int(n_workers), pool.h if pool is not None else None,
-                                               int(seed), 1 if images_pinned else 0, C.byref(h))
+            if any("cam" in d for d in per_stream):
+                cams = (capi.svoh_camera * self.n)(*[fe._camera(d.get("cam", cam)) for d in per_stream])
+                Ts = (capi.svoh_se3 * self.n)(*[fe._se3(np.asarray(d.get("T_B_C7", T_B_C7), dtype=np.float64)) for d in per_stream])
+                rc = self.lib.svohl_create_streams_cameras(ctx.h, self.n, cams, Ts, yamls, depth, kfe, mtr, int(n_workers), pool.h if pool is not None else None,
+                                                           int(seed), 1 if images_pinned else 0, C.byref(h))
+            else:
+                rc = self.lib.svohl_create_streams(ctx.h, self.n, C.byref(c), C.byref(T), yamls, depth, kfe, mtr, int(n_workers), pool.h if pool is not None else None,
+                                                   int(seed), 1 if images_pinned else 0, C.byref(h))
         elif pool is not None:
             rc = self.lib.svohl_create_shared(ctx.h, self.n, C.byref(c), C.byref(T), params_yaml.encode() if params_yaml else None, float(depth_min),
                                               float(depth_mean), float(depth_max), int(kf_every), pool.h, int(seed), 1 if images_pinned else 0, C.byref(h))

@@ -163,17 +163,21 @@ def test_stereo_streams_in_lock_step_reproduce_their_single_stream_runs(tmp_path
     assert singles[0][0] != singles[1][0] and len(singles[0][1]) == 30 and len(singles[1][1]) == 22
     roots = "%s:%s" % (tmp_path / "dsA", tmp_path / "dsB")
     S = 5
-    for n_workers, n_groups in ((1, 1), (3, 1), (2, 2)):
+    # (threads, groups) shapes with the engine as it ships (next pairs' pyramids prefetched, depth-filter batches of whole resident keyframe
+    # sets), then its two other paths: pyramids built at the round's start, explicit feature columns in every seed batch
+    for n_workers, n_groups, env in ((1, 1, {}), (3, 1, {}), (2, 2, {}), (2, 1, {"SVOH_MINI_STEREO_PREFETCH": "0"}), (2, 1, {"SVOH_LOCKSTEP_RESIDENT": "0"}),
+                                      (2, 1, {"SVOH_LOCKSTEP_SPECULATE": "all"})):
         for k in range(S):
             d = out_dir if k == 0 else out_dir / ("stream%d" % k)
             for name in ("trajectory.txt", "frontend.csv"):
                 if (d / name).exists():
                     (d / name).unlink()
-        r = subprocess.run(cmd_a + ["30", "8", "0.5", str(S), str(n_workers), str(n_groups)], capture_output=True, text=True, env=dict(os.environ, SVOH_MINI_STEREO_ROOTS=roots))
+        r = subprocess.run(cmd_a + ["30", "8", "0.5", str(S), str(n_workers), str(n_groups)], capture_output=True, text=True,
+                           env=dict(os.environ, SVOH_MINI_STEREO_ROOTS=roots, **env))
         print(r.stdout, r.stderr)
         assert r.returncode == 0, r.stdout + r.stderr
         for k in range(S):
             d = out_dir if k == 0 else out_dir / ("stream%d" % k)
             want = singles[k % 2]
-            assert open(str(d / "trajectory.txt")).read() == want[0], "trajectory of stream %d (%d threads, %d groups)" % (k, n_workers, n_groups)
-            assert np.array_equal(np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :9], want[1]), "counters of stream %d (%d threads, %d groups)" % (k, n_workers, n_groups)
+            assert open(str(d / "trajectory.txt")).read() == want[0], "trajectory of stream %d (%d threads, %d groups, %s)" % (k, n_workers, n_groups, env)
+            assert np.array_equal(np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, :9], want[1]), "counters of stream %d (%d threads, %d groups, %s)" % (k, n_workers, n_groups, env)

@@ -116,6 +116,8 @@ try {
     lo.params = params; lo.rig = rig; lo.kf_every = kf_every; lo.lambda_rot = lambda_rot; lo.n_workers = n_workers;
     lo.images_mem_space = SVOH_MEM_HOST_PINNED;
     if (getenv("SVOH_MINI_LANDMARKS")) lo.landmarks = atoi(getenv("SVOH_MINI_LANDMARKS")) != 0;
+    if (getenv("SVOH_LOCKSTEP_SPECULATE")) lo.speculate_all = std::string(getenv("SVOH_LOCKSTEP_SPECULATE")) == "all";
+    if (getenv("SVOH_LOCKSTEP_RESIDENT")) lo.resident_features = atoi(getenv("SVOH_LOCKSTEP_RESIDENT")) != 0;   // (the test of the explicit-column batches)
     FrontendLockstepStereo fe(ctx, n_streams, lo);
     std::vector<std::unique_ptr<io::TrajectoryWriter>> traj;
     std::vector<FILE*> csv;
@@ -134,7 +136,8 @@ try {
     };
     size_t n_rounds = 0;
     for (int s = 0; s < n_streams; ++s) n_rounds = std::max(n_rounds, root_of(s).n);
-    std::vector<const uint8_t*> left((size_t)n_streams), right((size_t)n_streams);
+    std::vector<const uint8_t*> left((size_t)n_streams), right((size_t)n_streams), next_left((size_t)n_streams), next_right((size_t)n_streams);
+    const bool announce = !(getenv("SVOH_MINI_STEREO_PREFETCH") && atoi(getenv("SVOH_MINI_STEREO_PREFETCH")) == 0);   // (a replay knows its next pairs; =0: the test of the other path)
     std::vector<Transformation> T_first((size_t)n_streams);
     std::vector<const svoh::Quat*> prior((size_t)n_streams);
     double sum_ms = 0;
@@ -151,9 +154,13 @@ try {
         T_first[(size_t)s] = d.T0;
         prior[(size_t)s] = has && k < d.prior.size() && d.have[k] ? &d.prior[k] : nullptr;
         n_now += has;
+        const bool has_next = k + 1 < d.n;
+        next_left[(size_t)s] = has_next ? pinned + stream_off[(size_t)s] + (2 * (k + 1)) * img_bytes : nullptr;
+        next_right[(size_t)s] = has_next ? pinned + stream_off[(size_t)s] + (2 * (k + 1) + 1) * img_bytes : nullptr;
       }
       const double t0 = now_ms();
-      fe.addPairs(left.data(), right.data(), data[0].left[0].width, T_first.data(), prior.data());
+      const bool more = announce && k + 1 < n_rounds;
+      fe.addPairs(left.data(), right.data(), data[0].left[0].width, T_first.data(), prior.data(), more ? next_left.data() : nullptr, more ? next_right.data() : nullptr);
       const double t1 = now_ms();
       if (k > 2) { sum_ms += t1 - t0; pairs += n_now; }   // (the first rounds pay the one-time costs)
       for (int s = 0; s < n_streams; ++s) {
@@ -167,7 +174,7 @@ try {
     if (getenv("SVOH_LOCKSTEP_TIMING") && s0 == 0) {
       fprintf(stderr, "[lockstep stereo] mean ms per round:");
       for (int k = 0; k < FrontendLockstepStereo::kNumPhases; ++k) fprintf(stderr, " %s %.3f,", FrontendLockstepStereo::phaseName(k), fe.phaseTimes()[k] / (double)n_rounds);
-      fprintf(stderr, "\n");
+      fprintf(stderr, " paused passes %zu\n", fe.pausedPasses());
     }
     for (FILE* f : csv) fclose(f);
     out->pairs = pairs; out->ms = sum_ms; out->round_ms = n_rounds > 3 ? sum_ms / (double)(n_rounds - 3) : 0.0; out->device_calls = fe.lastRoundDeviceCalls();
