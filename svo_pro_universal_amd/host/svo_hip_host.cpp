@@ -708,26 +708,36 @@ StereoTriangulationHip::StereoTriangulationHip(svoh_ctx* ctx, const StereoTriang
   };
 }
 
-void StereoTriangulationHip::compute(const FramePtr& frame0, const FramePtr& frame1)
+namespace {
+size_t numLandmarksOf(const Frame& f)   // Frame::numLandmarks (frame.cpp:144-151)
+{
+  size_t n = 0;
+  for (size_t i = 0; i < f.num_features_ && i < f.landmark_vec_.size(); ++i) n += f.landmark_vec_[i] != nullptr;
+  return n;
+}
+}  // namespace
+
+bool StereoTriangulationHip::wantsFeatures(const Frame& frame0) const { return numLandmarksOf(frame0) < options_.triangulate_n_features; }   // else "sufficient number of features": no effect
+
+svoh_matcher_options StereoTriangulationHip::matcherOptions()
+{
+  svoh_matcher_options mo{};   // Matcher::Options defaults (matcher.h:39-54) + :93-94
+  mo.align_max_iter = 10; mo.max_epi_search_steps = 500; mo.subpix_refinement = 1; mo.epi_search_edgelet_filtering = 1;
+  mo.scan_on_unit_sphere = 1; mo.affine_est_offset = 1; mo.affine_est_gain = 0;
+  mo.epi_search_edgelet_max_angle = 0.7; mo.max_patch_diff_ratio = 2.0;
+  return mo;
+}
+
+bool StereoTriangulationHip::prepare(const FramePtr& frame0, const FramePtr& frame1, const std::vector<double>& new_px, const std::vector<double>& new_scores,
+                                     const std::vector<int32_t>& new_levels, const std::vector<double>& new_grads, const std::vector<uint8_t>& new_types, Job* job)
 {
   last_indices_.clear(); last_results_.clear(); last_n_succeeded_ = last_n_failed_ = 0;
-  if (!frame0 || !frame1) throw std::runtime_error("StereoTriangulationHip::compute: NULL frame");
-  auto num_landmarks = [](const Frame& f) {   // Frame::numLandmarks (frame.cpp:144-151)
-    size_t n = 0;
-    for (size_t i = 0; i < f.num_features_ && i < f.landmark_vec_.size(); ++i) n += f.landmark_vec_[i] != nullptr;
-    return n;
-  };
-  const size_t n_landmarks0 = num_landmarks(*frame0);
-  if (n_landmarks0 >= options_.triangulate_n_features) return;   // "sufficient number of features": no effect
-
-  // detect new features (the detector's grid holds what the caller marked; every cell may deliver one)
-  std::vector<double> new_px, new_scores, new_grads;
-  std::vector<int32_t> new_levels;
-  std::vector<uint8_t> new_types;
-  const size_t max_n_features = feature_detector_->grid_.size();
-  feature_detector_->detect(frame0->pyramid, nullptr, 0, max_n_features, new_px, new_scores, new_levels, new_grads, new_types);
+  *job = Job();
+  if (!frame0 || !frame1) throw std::runtime_error("StereoTriangulationHip: NULL frame");
+  const size_t n_landmarks0 = numLandmarksOf(*frame0);
+  if (n_landmarks0 >= options_.triangulate_n_features) return false;
   const size_t n_new = new_levels.size();
-  if (n_new == 0) return;   // "Stereo Triangulation: No features detected."
+  if (n_new == 0) return false;   // "Stereo Triangulation: No features detected."
 
   // add them to the first frame (:56-69)
   Frame& f0 = *frame0;
@@ -750,52 +760,38 @@ void StereoTriangulationHip::compute(const FramePtr& frame0, const FramePtr& fra
   f0.num_features_ = n0;
 
   // visiting order: corners first, each part shuffled (:71-78)
-  std::vector<size_t> indices(n_new);
-  for (size_t k = 0; k < n_new; ++k) indices[k] = n_old + k;
+  job->indices.resize(n_new);
+  for (size_t k = 0; k < n_new; ++k) job->indices[k] = n_old + k;
   const size_t n_corners = static_cast<size_t>(std::count(new_types.begin(), new_types.end(), static_cast<uint8_t>(SVOH_FT_CORNER)));
-  shuffle_(indices, n_corners);
-  const size_t n_desired = options_.triangulate_n_features - n_landmarks0;
+  shuffle_(job->indices, n_corners);
+  job->n_old = n_old; job->n_new = n_new;
+  job->n_desired = options_.triangulate_n_features - n_landmarks0;
 
   Frame& f1 = *frame1;
   {  // reserve space for features in the second frame (:86-90)
-    const size_t need = f1.num_features_ + n_desired;
+    const size_t need = f1.num_features_ + job->n_desired;
     if (need > f1.landmark_vec_.size() || 2 * need > f1.px_vec_.size()) {
       f1.px_vec_.resize(2 * need); f1.f_vec_.resize(3 * need); f1.grad_vec_.resize(2 * need); f1.score_vec_.resize(need);
       f1.level_vec_.resize(need); f1.type_vec_.resize(need, SVOH_FT_OUTLIER); f1.landmark_vec_.resize(need);
       f1.seed_ref_vec_.resize(need); f1.track_id_vec_.resize(need, -1); f1.invmu_sigma2_a_b_vec_.resize(4 * need);
     }
   }
+  svoh::store_rigid(svoh::mul(f1.T_cam_imu_, f0.T_imu_cam_), job->T_f1_f0);   // frame1->T_cam_body_ * frame0->T_body_cam_
+  job->v0 = view_of(f0); job->v1 = view_of(f1);
+  return true;
+}
 
-  // every candidate through Matcher::findEpipolarMatchDirect in one launch (the loop below only reads the results)
-  svoh_matcher_options mo{};   // Matcher::Options defaults (matcher.h:39-54) + :93-94
-  mo.align_max_iter = 10; mo.max_epi_search_steps = 500; mo.subpix_refinement = 1; mo.epi_search_edgelet_filtering = 1;
-  mo.scan_on_unit_sphere = 1; mo.affine_est_offset = 1; mo.affine_est_gain = 0;
-  mo.epi_search_edgelet_max_angle = 0.7; mo.max_patch_diff_ratio = 2.0;
-  const Transformation T_f1f0 = svoh::mul(f1.T_cam_imu_, f0.T_imu_cam_);   // frame1->T_cam_body_ * frame0->T_body_cam_
-  svoh_se3 T_abi;
-  svoh::store_rigid(T_f1f0, T_abi);
-  std::vector<int32_t> ref_idx(n_new, 0);
-  svoh_feature_batch fb{};
-  fb.n = static_cast<int32_t>(n_new);
-  fb.ref_frame_idx = ref_idx.data();
-  fb.px = f0.px_vec_.data() + 2 * n_old; fb.f = f0.f_vec_.data() + 3 * n_old; fb.grad = f0.grad_vec_.data() + 2 * n_old;
-  fb.level = f0.level_vec_.data() + n_old; fb.type = f0.type_vec_.data() + n_old;
-  const svoh_frame_view v0 = view_of(f0), v1 = view_of(f1);
-  const double d_inv[3] = { options_.mean_depth_inv, options_.min_depth_inv, options_.max_depth_inv };
-  std::vector<int32_t> result(n_new);
-  std::vector<double> depth(n_new), px_cur(2 * n_new), f_cur(3 * n_new), A(4 * n_new);
-  svoh_epipolar_match_outputs out{};
-  out.result = result.data(); out.depth = depth.data(); out.px_cur = px_cur.data(); out.f_cur = f_cur.data();
-  out.A_cur_ref = A.data();
-  const int rc = svoh_epipolar_match_batch(ctx_, &mo, 1, &v0, &v1, &T_abi, &fb, d_inv, nullptr, &out);
-  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_epipolar_match_batch: ") + svoh_last_error_string(ctx_));
-
+void StereoTriangulationHip::finish(const FramePtr& frame0, const FramePtr& frame1, const Job& job, const int32_t* result, const double* depth, const double* px_cur,
+                                    const double* f_cur, const double* A)
+{
   // the reference's loop (:95-137)
-  last_indices_ = indices;
+  Frame &f0 = *frame0, &f1 = *frame1;
+  const size_t n_old = job.n_old, n_new = job.n_new, n_desired = job.n_desired;
+  last_indices_ = job.indices;
   last_results_.assign(n_new, -1);
   const Transformation T_world_cam0 = svoh::inverse(f0.T_f_w_);
   size_t n_succeeded = 0, n_failed = 0;
-  for (const size_t i_ref : indices) {
+  for (const size_t i_ref : job.indices) {
     const size_t k = i_ref - n_old;
     last_results_[k] = result[k];
     if (result[k] == SVOH_MATCH_SUCCESS) {
@@ -828,6 +824,42 @@ void StereoTriangulationHip::compute(const FramePtr& frame0, const FramePtr& fra
     if (n_succeeded >= n_desired) break;
   }
   last_n_succeeded_ = n_succeeded; last_n_failed_ = n_failed;
+}
+
+void StereoTriangulationHip::compute(const FramePtr& frame0, const FramePtr& frame1)
+{
+  last_indices_.clear(); last_results_.clear(); last_n_succeeded_ = last_n_failed_ = 0;
+  if (!frame0 || !frame1) throw std::runtime_error("StereoTriangulationHip::compute: NULL frame");
+  if (!wantsFeatures(*frame0)) return;
+
+  // detect new features (the detector's grid holds what the caller marked; every cell may deliver one)
+  std::vector<double> new_px, new_scores, new_grads;
+  std::vector<int32_t> new_levels;
+  std::vector<uint8_t> new_types;
+  const size_t max_n_features = feature_detector_->grid_.size();
+  feature_detector_->detect(frame0->pyramid, nullptr, 0, max_n_features, new_px, new_scores, new_levels, new_grads, new_types);
+  Job job;
+  if (!prepare(frame0, frame1, new_px, new_scores, new_levels, new_grads, new_types, &job)) return;
+
+  // every candidate through Matcher::findEpipolarMatchDirect in one launch (finish's loop only reads the results)
+  Frame& f0 = *frame0;
+  const size_t n_old = job.n_old, n_new = job.n_new;
+  const svoh_matcher_options mo = matcherOptions();
+  std::vector<int32_t> ref_idx(n_new, 0);
+  svoh_feature_batch fb{};
+  fb.n = static_cast<int32_t>(n_new);
+  fb.ref_frame_idx = ref_idx.data();
+  fb.px = f0.px_vec_.data() + 2 * n_old; fb.f = f0.f_vec_.data() + 3 * n_old; fb.grad = f0.grad_vec_.data() + 2 * n_old;
+  fb.level = f0.level_vec_.data() + n_old; fb.type = f0.type_vec_.data() + n_old;
+  const double d_inv[3] = { options_.mean_depth_inv, options_.min_depth_inv, options_.max_depth_inv };
+  std::vector<int32_t> result(n_new);
+  std::vector<double> depth(n_new), px_cur(2 * n_new), f_cur(3 * n_new), A(4 * n_new);
+  svoh_epipolar_match_outputs out{};
+  out.result = result.data(); out.depth = depth.data(); out.px_cur = px_cur.data(); out.f_cur = f_cur.data();
+  out.A_cur_ref = A.data();
+  const int rc = svoh_epipolar_match_batch(ctx_, &mo, 1, &job.v0, &job.v1, &job.T_f1_f0, &fb, d_inv, nullptr, &out);
+  if (rc != SVOH_OK) throw std::runtime_error(std::string("svoh_epipolar_match_batch: ") + svoh_last_error_string(ctx_));
+  finish(frame0, frame1, job, result.data(), depth.data(), px_cur.data(), f_cur.data(), A.data());
 }
 
 // ---- pose optimiser -------------------------------------------------------------------

@@ -683,6 +683,19 @@ class StereoTriangulationHip {
   std::shared_ptr<DetectorHip> feature_detector_;
   StereoTriangulationHip(svoh_ctx* ctx, const StereoTriangulationOptions& options, const std::shared_ptr<DetectorHip>& feature_detector);
   void compute(const FramePtr& frame0, const FramePtr& frame1);
+  // ---- compute() in the phases it is made of, for a driver of MANY rigs (FrontendLockstepStereo) that runs the detector for all of them
+  // in one call and all their epipolar searches in ONE svoh_epipolar_match_batch (a pair of frames per rig).  Same code, same order per rig.
+  //   wantsFeatures(frame0)   false: "sufficient number of features", compute() returns at once
+  //   prepare(...)            the detector's new features (of frame0, with this object's detector grid) appended to frame0, the visiting
+  //                           order shuffled, room made in frame1; job: the new features are frame0's [n_old, n_old + n_new), the pair's
+  //                           views and T_frame1_frame0 for the batch.  false: nothing to match
+  //   finish(...)             the reference's loop over the batch's results of this pair (result / depth / px_cur / f_cur / A of its n_new units)
+  struct Job { size_t n_old = 0, n_new = 0, n_desired = 0; std::vector<size_t> indices; svoh_frame_view v0{}, v1{}; svoh_se3 T_f1_f0{}; };
+  bool wantsFeatures(const Frame& frame0) const;
+  bool prepare(const FramePtr& frame0, const FramePtr& frame1, const std::vector<double>& new_px, const std::vector<double>& new_scores, const std::vector<int32_t>& new_levels,
+               const std::vector<double>& new_grads, const std::vector<uint8_t>& new_types, Job* job);
+  void finish(const FramePtr& frame0, const FramePtr& frame1, const Job& job, const int32_t* result, const double* depth, const double* px_cur, const double* f_cur, const double* A);
+  static svoh_matcher_options matcherOptions();
   // The reference shuffles the corner and the edgelet part of the new indices with std::random_shuffle (rand()):
   // the default does the same; a caller that needs a reproducible order (tests) sets its own.
   std::function<void(std::vector<size_t>& indices, size_t n_corners)> shuffle_;

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <string>
 
@@ -172,51 +173,201 @@ bool scene_depth(const Frame& f, double& d_med, double& d_min)   // frame_utils:
 }
 }  // namespace
 
-// svoh_mini_stereo's make_keyframe for ONE stream, with the mirrors' own blocking calls (the caller is the context's thread)
-void FrontendLockstepStereo::makeKeyframe(Stream& st, size_t kf_id)
+// svoh_mini_stereo's make_keyframe for the streams `which` (stream, kf_id: which of the pair's frames is the keyframe), every device step
+// ONE call for all of them -- the two detector runs, the epipolar searches of the stereo triangulation, the refreshed edgelet directions,
+// the upload of the resident columns -- and the host steps between them per stream on the pool.  Per stream the steps and their order are
+// those of the single-stream harness (frame_handler_stereo.cpp:146-175): upgradeSeedsToFeatures of the frame that is not the keyframe,
+// StereoTriangulation::compute (detector in the left frame's free cells, epipolar match of every new feature, the loop up to n_desired),
+// upgradeSeedsToFeatures of the keyframe, depth_filter_->addKeyframe (new seeds in its free cells), the keyframe window.
+void FrontendLockstepStereo::makeKeyframes(const std::vector<std::pair<int, size_t>>& which)
 {
-  const FrameBundle::Ptr& b = st.bundle;
-  // stereo triangulation of new features where the left frame has no feature yet (frame_handler_stereo.cpp:146-155); the frame that
-  // is not the keyframe upgrades the seeds it hangs on first, as the reference's branch does (:149-154)
-  if (opt_.landmarks) upgradeSeedsToFeatures(ctx_, b->at(1 - kf_id), &st.next_point_id);
-  st.tri_detector->resetGrid();
-  st.tri_detector->fillGridWithKeypoints(b->at(0)->px_vec_, b->at(0)->num_features_);
-  st.stereo.compute(b->at(0), b->at(1));
-  // the keyframe's seeds become landmarks (upgradeSeedsToFeatures, :162), then new seeds in its free cells (depth_filter_->addKeyframe, :167-173)
-  double d_med = 0, d_min = 0;
-  const FramePtr& f = b->at(kf_id);
-  if (opt_.landmarks) upgradeSeedsToFeatures(ctx_, f, &st.next_point_id);
-  if (scene_depth(*b->at(0), d_med, d_min)) {
+  const size_t K = which.size();
+  if (K == 0) return;
+  auto stream_of = [&](size_t w) -> Stream& { return *streams_[static_cast<size_t>(which[w].first)]; };
+  const int width = opt_.rig[0].cam.width, height = opt_.rig[0].cam.height;
+  const size_t n_cells = stream_of(0).tri_detector->grid_.size();
+  struct Work {
+    std::vector<size_t> edgelets;
+    bool tri = false, tri_match = false, seeds = false;
+    int slot = -1;
+    StereoTriangulationHip::Job job;
+    size_t unit_off = 0;
+    double d_med = 0, d_min = 0;
+    int max_n_seeds = 0;
+  };
+  std::vector<Work> work(K);
+  // one detector call for the frames `frame_of(w)` of the streams with `wanted(w)`: every cell's best corner / edgelet, by the streams' occupancy grids
+  std::vector<uint8_t> occ;
+  std::vector<uint64_t> ckeys, ekeys;
+  std::vector<float> angles;
+  auto detect_cells = [&](const std::function<bool(size_t)>& wanted, const std::function<svoh_frame_t(size_t)>& pyramid_of, DetectorHip& options_of) {
+    std::vector<svoh_frame_t> frames;
+    std::vector<uint8_t> packed;
+    for (size_t w = 0; w < K; ++w) {
+      work[w].slot = -1;
+      if (!wanted(w)) continue;
+      work[w].slot = static_cast<int>(frames.size());
+      frames.push_back(pyramid_of(w));
+      packed.insert(packed.end(), occ.begin() + static_cast<long>(w * n_cells), occ.begin() + static_cast<long>((w + 1) * n_cells));
+    }
+    const size_t n = frames.size();
+    ckeys.assign(n * n_cells, 0); ekeys.assign(n * n_cells, 0); angles.assign(n * n_cells, 0.f);
+    if (!n) return;
+    const svoh_detector_options dopt = options_of.abiOptions();
+    check(svoh_detect_cells_batch_enqueue(ctx_, static_cast<int>(n), frames.data(), &dopt, packed.data()), "svoh_detect_cells_batch_enqueue");
+    check(svoh_detect_cells_batch_collect(ctx_, ckeys.data(), ekeys.data(), angles.data()), "svoh_detect_cells_batch_collect");
+    ++device_calls_;
+  };
+  auto refresh = [&](const std::function<FramePtr(size_t)>& frame_of) {
+    std::vector<FramePtr> fr;
+    std::vector<std::vector<size_t>> ed;
+    for (size_t w = 0; w < K; ++w) if (!work[w].edgelets.empty()) { fr.push_back(frame_of(w)); ed.push_back(work[w].edgelets); }
+    if (!fr.empty()) { refreshEdgeletDirections(ctx_, fr, ed); ++device_calls_; }
+  };
+
+  // ---- the frame that is not the keyframe upgrades the seeds it hangs on first (:149-154); the triangulation detector's grid
+  occ.assign(K * n_cells, 0);
+  pool_->run(static_cast<int>(K), [&](int wi) {
+    const size_t w = static_cast<size_t>(wi);
+    Stream& st = stream_of(w);
+    const FrameBundle::Ptr& b = st.bundle;
+    if (opt_.landmarks) upgradeSeedsToFeatures(b->at(1 - which[w].second), &st.next_point_id, &work[w].edgelets);
+    st.tri_detector->resetGrid();
+    st.tri_detector->fillGridWithKeypoints(b->at(0)->px_vec_, b->at(0)->num_features_);
+    work[w].tri = st.stereo.wantsFeatures(*b->at(0));
+    if (work[w].tri) st.tri_detector->occupancyBytes(occ.data() + w * n_cells);
+    else { st.stereo.last_indices_.clear(); st.stereo.last_results_.clear(); st.stereo.last_n_succeeded_ = st.stereo.last_n_failed_ = 0; }
+  });
+  refresh([&](size_t w) { return stream_of(w).bundle->at(1 - which[w].second); });
+  // ---- stereo triangulation (:146-155): new features where the left frame has none, all streams' epipolar searches in one launch
+  detect_cells([&](size_t w) { return work[w].tri; }, [&](size_t w) { return stream_of(w).bundle->at(0)->pyramid; }, *stream_of(0).tri_detector);
+  pool_->run(static_cast<int>(K), [&](int wi) {
+    const size_t w = static_cast<size_t>(wi);
+    if (!work[w].tri) return;
+    Stream& st = stream_of(w);
+    const size_t i = static_cast<size_t>(work[w].slot);
+    std::vector<double> px, score, grad;
+    std::vector<int32_t> level;
+    std::vector<uint8_t> type;
+    st.tri_detector->fillFromCells(ckeys.data() + i * n_cells, ekeys.data() + i * n_cells, angles.data() + i * n_cells, width, height, n_cells, px, score, level, grad, type);
+    work[w].tri_match = st.stereo.prepare(st.bundle->at(0), st.bundle->at(1), px, score, level, grad, type, &work[w].job);
+  });
+  {
+    size_t n_units = 0, n_pairs = 0;
+    for (size_t w = 0; w < K; ++w) if (work[w].tri_match) { work[w].unit_off = n_units; work[w].slot = static_cast<int>(n_pairs++); n_units += work[w].job.n_new; }
+    if (n_units) {
+      std::vector<svoh_frame_view> v0(n_pairs), v1(n_pairs);
+      std::vector<svoh_se3> T(n_pairs * n_pairs);
+      for (svoh_se3& t : T) svoh::store_rigid(Transformation{ { 1, 0, 0, 0 }, { 0, 0, 0 } }, t);   // (only a pair's own entry is read)
+      std::vector<int32_t> ref_idx(n_units), cur_idx(n_units), level(n_units), result(n_units);
+      std::vector<double> px(2 * n_units), f(3 * n_units), grad(2 * n_units), depth(n_units), px_cur(2 * n_units), f_cur(3 * n_units), A(4 * n_units);
+      std::vector<uint8_t> type(n_units);
+      for (size_t w = 0; w < K; ++w) {
+        if (!work[w].tri_match) continue;
+        const Frame& f0 = *stream_of(w).bundle->at(0);
+        const StereoTriangulationHip::Job& j = work[w].job;
+        const size_t p = static_cast<size_t>(work[w].slot), o = work[w].unit_off;
+        v0[p] = j.v0; v1[p] = j.v1; T[p * n_pairs + p] = j.T_f1_f0;
+        std::fill(ref_idx.begin() + static_cast<long>(o), ref_idx.begin() + static_cast<long>(o + j.n_new), static_cast<int32_t>(p));
+        std::fill(cur_idx.begin() + static_cast<long>(o), cur_idx.begin() + static_cast<long>(o + j.n_new), static_cast<int32_t>(p));
+        std::copy(f0.px_vec_.begin() + static_cast<long>(2 * j.n_old), f0.px_vec_.begin() + static_cast<long>(2 * (j.n_old + j.n_new)), px.begin() + static_cast<long>(2 * o));
+        std::copy(f0.f_vec_.begin() + static_cast<long>(3 * j.n_old), f0.f_vec_.begin() + static_cast<long>(3 * (j.n_old + j.n_new)), f.begin() + static_cast<long>(3 * o));
+        std::copy(f0.grad_vec_.begin() + static_cast<long>(2 * j.n_old), f0.grad_vec_.begin() + static_cast<long>(2 * (j.n_old + j.n_new)), grad.begin() + static_cast<long>(2 * o));
+        std::copy(f0.level_vec_.begin() + static_cast<long>(j.n_old), f0.level_vec_.begin() + static_cast<long>(j.n_old + j.n_new), level.begin() + static_cast<long>(o));
+        std::copy(f0.type_vec_.begin() + static_cast<long>(j.n_old), f0.type_vec_.begin() + static_cast<long>(j.n_old + j.n_new), type.begin() + static_cast<long>(o));
+      }
+      svoh_feature_batch fb{};
+      fb.n = static_cast<int32_t>(n_units);
+      fb.ref_frame_idx = ref_idx.data(); fb.cur_frame_idx = cur_idx.data(); fb.n_cur_frames = static_cast<int32_t>(n_pairs);
+      fb.px = px.data(); fb.f = f.data(); fb.grad = grad.data(); fb.level = level.data(); fb.type = type.data();
+      const StereoTriangulationOptions& so = stream_of(0).stereo.options_;
+      const double d_inv[3] = { so.mean_depth_inv, so.min_depth_inv, so.max_depth_inv };
+      svoh_epipolar_match_outputs out{};
+      out.result = result.data(); out.depth = depth.data(); out.px_cur = px_cur.data(); out.f_cur = f_cur.data(); out.A_cur_ref = A.data();
+      const svoh_matcher_options mo = StereoTriangulationHip::matcherOptions();
+      check(svoh_epipolar_match_batch(ctx_, &mo, static_cast<int>(n_pairs), v0.data(), v1.data(), T.data(), &fb, d_inv, nullptr, &out), "svoh_epipolar_match_batch");
+      ++device_calls_;
+      pool_->run(static_cast<int>(K), [&](int wi) {
+        const size_t w = static_cast<size_t>(wi);
+        if (!work[w].tri_match) return;
+        Stream& st = stream_of(w);
+        const size_t o = work[w].unit_off;
+        st.stereo.finish(st.bundle->at(0), st.bundle->at(1), work[w].job, result.data() + o, depth.data() + o, px_cur.data() + 2 * o, f_cur.data() + 3 * o, A.data() + 4 * o);
+      });
+    }
+  }
+  // ---- the keyframe's seeds become landmarks (upgradeSeedsToFeatures, :162), then new seeds in its free cells (depth_filter_->addKeyframe, :167-173)
+  occ.assign(K * n_cells, 0);
+  pool_->run(static_cast<int>(K), [&](int wi) {
+    const size_t w = static_cast<size_t>(wi);
+    Stream& st = stream_of(w);
+    const FrameBundle::Ptr& b = st.bundle;
+    const FramePtr& f = b->at(which[w].second);
+    work[w].edgelets.clear();
+    if (opt_.landmarks) upgradeSeedsToFeatures(f, &st.next_point_id, &work[w].edgelets);
+    work[w].seeds = false;
+    if (!scene_depth(*b->at(0), work[w].d_med, work[w].d_min)) return;
     st.seed_detector.resetGrid();
     st.seed_detector.fillGridWithKeypoints(f->px_vec_, f->num_features_);
-    const size_t n_old = f->num_features_;
-    depth_filter_utils::initializeSeeds(f, st.seed_detector, static_cast<size_t>(opt_.params.max_n_seeds_per_frame), static_cast<float>(0.5 * d_min), static_cast<float>(1.5 * d_med),
-                                        static_cast<float>(d_med));
-    for (size_t i = n_old; i < f->num_features_; ++i) { f->seed_ref_vec_[i].keyframe = f; f->seed_ref_vec_[i].seed_id = static_cast<int>(i); }
-  }
-  // the two frames' features are final now: their constant columns go to the device once (a keyframe's seeds are updated by every later pair)
+    work[w].max_n_seeds = opt_.params.max_n_seeds_per_frame - static_cast<int>(f->num_features_);
+    if (work[w].max_n_seeds <= 0) return;   // "Skip seed initialization. Have already enough features." (the grid stays as it is, as in initializeSeeds)
+    work[w].seeds = true;
+    st.seed_detector.occupancyBytes(occ.data() + w * n_cells);
+  });
+  refresh([&](size_t w) { return stream_of(w).bundle->at(which[w].second); });
+  detect_cells([&](size_t w) { return work[w].seeds; }, [&](size_t w) { return stream_of(w).bundle->at(which[w].second)->pyramid; }, stream_of(0).seed_detector);
+  pool_->run(static_cast<int>(K), [&](int wi) {
+    const size_t w = static_cast<size_t>(wi);
+    Stream& st = stream_of(w);
+    const FrameBundle::Ptr& b = st.bundle;
+    const FramePtr& f = b->at(which[w].second);
+    if (work[w].seeds) {
+      const size_t i = static_cast<size_t>(work[w].slot), n_old = f->num_features_;
+      std::vector<double> px, score, grad;
+      std::vector<int32_t> level;
+      std::vector<uint8_t> type;
+      st.seed_detector.fillFromCells(ckeys.data() + i * n_cells, ekeys.data() + i * n_cells, angles.data() + i * n_cells, width, height, static_cast<size_t>(work[w].max_n_seeds),
+                                     px, score, level, grad, type);
+      depth_filter_utils::appendSeeds(f, px, score, level, grad, type, static_cast<float>(0.5 * work[w].d_min), static_cast<float>(work[w].d_med));
+      for (size_t k = n_old; k < f->num_features_; ++k) { f->seed_ref_vec_[k].keyframe = f; f->seed_ref_vec_[k].seed_id = static_cast<int>(k); }
+    }
+  });
+  // ---- the frames' features are final now: their constant columns go to the device once (a keyframe's seeds are updated by every later pair)
   if (opt_.resident_features) {
-    int32_t n[2]; const double *px[2], *fv[2], *grad[2]; const int32_t* level[2];
-    svoh_features_t handles[2] = { 0, 0 };
-    for (size_t c = 0; c < 2; ++c) {
-      const Frame& fr = *b->at(c);
-      n[c] = static_cast<int32_t>(fr.num_features_); px[c] = fr.px_vec_.data(); fv[c] = fr.f_vec_.data(); grad[c] = fr.grad_vec_.data(); level[c] = fr.level_vec_.data();
+    std::vector<int32_t> n;
+    std::vector<const double*> px, fv, grad;
+    std::vector<const int32_t*> level;
+    std::vector<FramePtr> frames;
+    for (size_t w = 0; w < K; ++w) {
+      const FrameBundle::Ptr& b = stream_of(w).bundle;
+      if (b->at(0)->num_features_ == 0 || b->at(1)->num_features_ == 0) continue;
+      for (size_t c = 0; c < 2; ++c) {
+        const FramePtr& fr = b->at(c);
+        frames.push_back(fr);
+        n.push_back(static_cast<int32_t>(fr->num_features_)); px.push_back(fr->px_vec_.data()); fv.push_back(fr->f_vec_.data()); grad.push_back(fr->grad_vec_.data()); level.push_back(fr->level_vec_.data());
+      }
     }
-    if (n[0] > 0 && n[1] > 0) {
-      check(svoh_features_upload(ctx_, 2, n, px, fv, grad, level, handles), "svoh_features_upload");
+    if (!frames.empty()) {
+      std::vector<svoh_features_t> handles(frames.size(), 0);
+      check(svoh_features_upload(ctx_, static_cast<int>(frames.size()), n.data(), px.data(), fv.data(), grad.data(), level.data(), handles.data()), "svoh_features_upload");
       ++device_calls_;
-      for (size_t c = 0; c < 2; ++c) b->at(c)->features = handles[c];
+      for (size_t k = 0; k < frames.size(); ++k) frames[k]->features = handles[k];
     }
   }
-  const size_t max_kfs = 2 * st.rp0.options_.max_n_kfs;
-  for (size_t c = 0; c < 2; ++c) {
-    st.kfs.push_back(b->at(c));
-    while (st.kfs.size() > max_kfs) {
-      for (auto& sr : st.kfs.front()->seed_ref_vec_) sr.keyframe.reset();
-      removeObservationsOf(*st.kfs.front());   // (Map::removeKeyframe)
-      st.kfs.pop_front();
+  // ---- the keyframe window
+  pool_->run(static_cast<int>(K), [&](int wi) {
+    Stream& st = stream_of(static_cast<size_t>(wi));
+    const FrameBundle::Ptr& b = st.bundle;
+    const size_t max_kfs = 2 * st.rp0.options_.max_n_kfs;
+    for (size_t c = 0; c < 2; ++c) {
+      st.kfs.push_back(b->at(c));
+      while (st.kfs.size() > max_kfs) {
+        for (auto& sr : st.kfs.front()->seed_ref_vec_) sr.keyframe.reset();
+        removeObservationsOf(*st.kfs.front());   // (Map::removeKeyframe)
+        st.kfs.pop_front();
+      }
     }
-  }
+  });
 }
 
 // depth_filter_->updateSeeds(overlap_kfs, new_frames_->at(c)) (frame_handler_stereo.cpp:127-129) for every tracking stream in ONE batch: the
@@ -417,12 +568,16 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
   };
 
   // ---- first pairs: the rig's pose is given, stereo triangulation + seeds (StereoInit's stand-in, as svoh_mini_stereo's first pair)
-  for (int s : starting) {
-    Stream& st = *streams_[static_cast<size_t>(s)];
-    for (const FramePtr& f : st.bundle->frames_) f->T_f_w_ = svoh::mul(f->T_cam_imu(), T_imu_world_first[s]);
-    st.row = PairRow(); st.row.k = st.k; st.row.is_kf = true;
-    makeKeyframe(st, 0);
-    st.row.alpha = st.img_align.lastResult().alpha; st.row.beta = st.img_align.lastResult().beta;
+  {
+    std::vector<std::pair<int, size_t>> first;
+    for (int s : starting) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      for (const FramePtr& f : st.bundle->frames_) f->T_f_w_ = svoh::mul(f->T_cam_imu(), T_imu_world_first[s]);
+      st.row = PairRow(); st.row.k = st.k; st.row.is_kf = true;
+      first.emplace_back(s, 0);
+    }
+    makeKeyframes(first);
+    for (int s : starting) { Stream& st = *streams_[static_cast<size_t>(s)]; st.row.alpha = st.img_align.lastResult().alpha; st.row.beta = st.img_align.lastResult().beta; }
   }
   if (nT == 0) { prefetch(next_left, next_right, pitch); close_round(); return; }
 
@@ -669,11 +824,15 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
 
   lap(5);
   // ---- 4. keyframe rule (svoh_mini_stereo's); a keyframe pair's step comes BEFORE its seed updates, as makeKeyframe does (:162-175)
-  for (int s : trk) {
-    Stream& st = *streams_[static_cast<size_t>(s)];
-    const bool kf_next = st.k % opt_.kf_every == 0 || st.n_pose < 60;
-    if (kf_next) { makeKeyframe(st, (st.k / opt_.kf_every) % 2); st.row.is_kf = true; }
-    st.row.alpha = st.img_align.lastResult().alpha; st.row.beta = st.img_align.lastResult().beta;
+  {
+    std::vector<std::pair<int, size_t>> kf;
+    for (int s : trk) {
+      Stream& st = *streams_[static_cast<size_t>(s)];
+      const bool kf_next = st.k % opt_.kf_every == 0 || st.n_pose < 60;
+      if (kf_next) { kf.emplace_back(s, (st.k / opt_.kf_every) % 2); st.row.is_kf = true; }
+      st.row.alpha = st.img_align.lastResult().alpha; st.row.beta = st.img_align.lastResult().beta;
+    }
+    makeKeyframes(kf);
   }
 
   lap(6);

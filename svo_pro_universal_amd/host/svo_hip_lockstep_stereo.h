@@ -12,19 +12,20 @@
 //   structure optim.    the left frames' landmarks of all streams, then the right ones    svoh_optimize_points_batch, twice per round
 //   depth filter        the keyframes' seeds into every stream's left frame, then into    svoh_update_seeds_batch, twice per round (the
 //                       its right one (the second update starts from the first's states)  second left in flight until the next round)
-//   keyframes           per stream, with the mirrors' own blocking calls: stereo          StereoTriangulationHip::compute, initializeSeeds,
-//                       triangulation, seed initialisation, upgradeSeedsToFeatures         upgradeSeedsToFeatures
+//   keyframes           the streams that make one: both detector runs, the stereo              svoh_detect_cells_batch, svoh_epipolar_match_batch,
+//                       triangulation's epipolar searches, the refreshed edgelet           svoh_histogram_angle_bins, svoh_features_upload:
+//                       directions, the resident columns -- one call each for all          one call each per round
 //
 // A stream's host work is the SAME code tools/svoh_mini_stereo.cpp runs for one stream (the mirrors' phase interfaces); every
 // kernel's per-unit result does not depend on what shares its launch, every alignment problem runs in the launch geometry it would
 // get alone: a stream's trajectory and counters are those of its single-stream run, byte for byte (tests/test_mini_stereo_gpu.py).
 // Like svoh_mini_stereo this is an integration harness above the mirrors, NOT the reference's frame handler: no map (every live
-// keyframe counts as overlapping), no initialiser (the first rig pose is given), keyframes by a fixed rule.  The keyframe step is not
-// batched (it runs on a stream's every <kf_every>-th pair); what is batched is what runs for every pair.
+// keyframe counts as overlapping), no initialiser (the first rig pose is given), keyframes by a fixed rule.
 #pragma once
 
 #include <deque>
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include "svo_hip_io.h"
@@ -79,7 +80,7 @@ class FrontendLockstepStereo {
   struct Stream;
   void check(int rc, const char* what) const;
   void finishSecondSeedUpdate();
-  void makeKeyframe(Stream& st, size_t kf_id);
+  void makeKeyframes(const std::vector<std::pair<int, size_t>>& which);
   void drainReleases();
   // one depth-filter update of the tracking streams' visible keyframes into their camera c: blocking (collected at once) or left in flight
   void seedUpdate(const std::vector<int>& trk, int c, bool leave_in_flight);
