@@ -100,6 +100,16 @@ FrontendLockstepStereo::FrontendLockstepStereo(svoh_ctx* ctx, int n_streams, con
   if (opt_.rig[0].cam.width != opt_.rig[1].cam.width || opt_.rig[0].cam.height != opt_.rig[1].cam.height)
     throw std::runtime_error("FrontendLockstepStereo: the two cameras must have one image size (their pyramids are built in one call)");
   if (opt_.kf_every < 1) throw std::runtime_error("FrontendLockstepStereo: kf_every must be >= 1");
+  if (!opt_.per_stream_rig.empty()) {
+    if (opt_.per_stream_rig.size() != static_cast<size_t>(n_streams)) throw std::runtime_error("FrontendLockstepStereo: per_stream_rig must hold one rig per stream (or none)");
+    for (const auto& r : opt_.per_stream_rig) {
+      if (r.size() != 2) throw std::runtime_error("FrontendLockstepStereo: a stream's rig needs two cameras");
+      for (const io::RigCamera& c : r)
+        if (c.cam.width != opt_.rig[0].cam.width || c.cam.height != opt_.rig[0].cam.height)
+          throw std::runtime_error("FrontendLockstepStereo: a stream's own cameras must have the image size of the engine's rig (the streams' pyramids are one call)");
+    }
+  }
+  fixProcessWideThresholds(opt_.rig[0].cam, 2.0);   // (rigs of different focal lengths: the engine's first camera is the one the reference's statics see first)
   opt_.params.depth_filter.use_threaded_depthfilter = false;
   // euroc_stereo_imu.yaml:30-31: img_align_est_illumination_gain / _offset (as svoh_mini_stereo)
   opt_.params.img_align.estimate_illumination_gain = true;
@@ -543,8 +553,8 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
           delete f;
         });
         frame->pyramid = handles[at++];
-        frame->cam = opt_.rig[static_cast<size_t>(c)].cam;
-        frame->set_T_cam_imu(svoh::inverse(opt_.rig[static_cast<size_t>(c)].T_B_C));
+        frame->cam = rigOf(s)[static_cast<size_t>(c)].cam;
+        frame->set_T_cam_imu(svoh::inverse(rigOf(s)[static_cast<size_t>(c)].T_B_C));
         frame->id_ = static_cast<int>(2 * st.k + static_cast<size_t>(c));
         st.bundle->frames_.push_back(frame);
       }

@@ -35,7 +35,11 @@ namespace svo_hip {
 
 struct StereoLockstepOptions {
   io::FrontendParams params;            // (illumination gain / offset are estimated, the matcher's gain as well: euroc_stereo_imu.yaml:30-31, as svoh_mini_stereo)
-  std::vector<io::RigCamera> rig;       // the two cameras of EVERY stream's rig
+  std::vector<io::RigCamera> rig;       // the two cameras of every stream's rig ...
+  // ... or a rig per stream (one entry per stream, two cameras each; empty: `rig` for all): intrinsics, distortion, extrinsics / baseline may
+  // differ, the image size may not (the streams' pyramids are one call).  The reference's process-wide static thresholds are taken from
+  // rig[0] (svo_hip::fixProcessWideThresholds)
+  std::vector<std::vector<io::RigCamera>> per_stream_rig;
   size_t kf_every = 8;
   double lambda_rot = 0.5;              // img_align_prior_lambda_rot
   int n_workers = 1;                    // host threads, the caller included
@@ -82,6 +86,7 @@ class FrontendLockstepStereo {
   void finishSecondSeedUpdate();
   void makeKeyframes(const std::vector<std::pair<int, size_t>>& which);
   void drainReleases();
+  const std::vector<io::RigCamera>& rigOf(int s) const { return opt_.per_stream_rig.empty() ? opt_.rig : opt_.per_stream_rig[static_cast<size_t>(s)]; }
   // one depth-filter update of the tracking streams' visible keyframes into their camera c: blocking (collected at once) or left in flight
   void seedUpdate(const std::vector<int>& trk, int c, bool leave_in_flight);
   void collectSeedUpdate();

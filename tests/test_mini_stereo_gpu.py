@@ -21,15 +21,18 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 BASELINE_M = 0.11
 
 
-def make_stereo_dataset(tmp_path, n_frames=30, raw_gyro=False, seed=171, ds="ds"):
+def make_stereo_dataset(tmp_path, n_frames=30, raw_gyro=False, seed=171, ds="ds", baseline=BASELINE_M, focal_factor=1.0, own_calib=False):
+    """own_calib: the rig's calibration is also written to <root>/calib.yaml (svoh_mini_stereo's lock-step mode gives such a root's streams that rig)."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "svo_pro_universal_amd", "host")])
     cam = synth.Camera.euroc_like(752, 480)
+    cam.fx *= focal_factor
+    cam.fy *= focal_factor
     sc = synth.make_align_scene(seed, n_features=8, cam=cam, rot_deg=(0.3, 0.5), trans_m=(0.015, 0.025))
     step = sc.T_w_ref.inverse() * sc.T_w_cur
     poses = [sc.T_w_ref]                       # T_world_imu (= left camera)
     for k in range(1, n_frames):
         poses.append(poses[-1] * step)
-    T_B_C = [synth.SE3(), synth.SE3((1.0, 0.0, 0.0, 0.0), (BASELINE_M, 0.0, 0.0))]
+    T_B_C = [synth.SE3(), synth.SE3((1.0, 0.0, 0.0, 0.0), (baseline, 0.0, 0.0))]
     stamps = [1403636579763555584 + 50000000 * k for k in range(n_frames)]
     for c in range(2):
         data = tmp_path / ds / "mav0" / ("cam%d" % c) / "data"
@@ -76,8 +79,11 @@ def make_stereo_dataset(tmp_path, n_frames=30, raw_gyro=False, seed=171, ds="ds"
   T_B_C:
     data: [1.0, 0.0, 0.0, %.17g, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0]
 """
-    (tmp_path / "calib.yaml").write_text("cameras:\n" + "".join(
-        cam_yaml % ((c, cam.height, cam.width, cam.fx, cam.fy, cam.cx, cam.cy) + tuple(cam.dist) + (BASELINE_M * c,)) for c in range(2)))
+    calib = tmp_path / ("calib_%s.yaml" % ds)
+    calib.write_text("cameras:\n" + "".join(
+        cam_yaml % ((c, cam.height, cam.width, cam.fx, cam.fy, cam.cx, cam.cy) + tuple(cam.dist) + (baseline * c,)) for c in range(2)))
+    if own_calib:
+        (tmp_path / ds / "calib.yaml").write_text(calib.read_text())
     (tmp_path / "params.yaml").write_text("max_fts: 160\ngrid_size: 35\nn_pyr_levels: 3\ndetector_threshold_secondary: 100\n"
                                           "use_threaded_depthfilter: False\nimg_align_max_level: 4\nimg_align_min_level: 2\n")
     out_dir = tmp_path / "out"
@@ -85,7 +91,7 @@ def make_stereo_dataset(tmp_path, n_frames=30, raw_gyro=False, seed=171, ds="ds"
     T0 = poses[0].inverse().as7()
     (tmp_path / ds / "T0.txt").write_text(" ".join("%.17g" % v for v in T0) + "\n")   # (the lock-step mode reads a root's first pose from here)
     tool = os.path.join(ROOT, "svo_pro_universal_amd", "host", "svoh_mini_stereo")
-    cmd = ([tool, str(tmp_path / ds), str(tmp_path / "calib.yaml"), str(tmp_path / "params.yaml"), str(out_dir)] + ["%.17g" % v for v in T0])
+    cmd = ([tool, str(tmp_path / ds), str(calib), str(tmp_path / "params.yaml"), str(out_dir)] + ["%.17g" % v for v in T0])
     return cmd, out_dir, poses, stamps
 
 
@@ -154,10 +160,13 @@ def test_stereo_streams_in_lock_step_reproduce_their_single_stream_runs(tmp_path
     different sequences (different scene and motion, 30 and 22 pairs: the shorter streams end earlier): every stream must write the trajectory
     and the counters of the single-stream run of ITS sequence, byte for byte, for (threads, groups) = (1,1), (3,1), (2,2)."""
     cmd_a, out_dir, poses_a, stamps_a = make_stereo_dataset(tmp_path, 30, seed=171, ds="dsA")
-    cmd_b, _o, poses_b, stamps_b = make_stereo_dataset(tmp_path, 22, seed=377, ds="dsB")
+    # ... and two different RIGS (next #6, "a camera / rig per stream"): dsB's cameras have another focal length and a wider baseline; its root carries
+    # its own calib.yaml.  The reference's process-wide static thresholds are those of the engine's first camera (dsA's) in the lock-step run, so the
+    # single-stream run of dsB takes them from there as well (svo_hip::fixProcessWideThresholds)
+    cmd_b, _o, poses_b, stamps_b = make_stereo_dataset(tmp_path, 22, seed=377, ds="dsB", baseline=0.14, focal_factor=1.03, own_calib=True)
     singles = []
     for cmd, n in ((cmd_a, 30), (cmd_b, 22)):
-        r = subprocess.run(cmd + [str(n), "8", "0.5"], capture_output=True, text=True)
+        r = subprocess.run(cmd + [str(n), "8", "0.5"], capture_output=True, text=True, env=dict(os.environ, SVOH_MINI_STEREO_THRESHOLDS_OF=cmd_a[2]))
         assert r.returncode == 0, r.stdout + r.stderr
         singles.append((open(str(out_dir / "trajectory.txt")).read(), np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)[:, :9].copy()))
     assert singles[0][0] != singles[1][0] and len(singles[0][1]) == 30 and len(singles[1][1]) == 22

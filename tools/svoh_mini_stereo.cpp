@@ -69,7 +69,8 @@ static void read_priors(const std::string& root, std::vector<svoh::Quat>* imu_pr
 }
 
 // n_streams stereo streams in lock step (FrontendLockstepStereo); stream k replays root k % n_roots
-struct StereoRoot { io::EurocSequence seq; std::vector<io::GrayImage> left, right; std::vector<svoh::Quat> prior; std::vector<bool> have; Transformation T0; size_t n = 0; };
+struct StereoRoot { io::EurocSequence seq; std::vector<io::GrayImage> left, right; std::vector<svoh::Quat> prior; std::vector<bool> have; Transformation T0; size_t n = 0;
+                    std::vector<io::RigCamera> rig; /* <root>/calib.yaml when there is one: the root's own rig */ };
 static std::vector<StereoRoot> load_roots(const std::vector<std::string>& roots, const Transformation& T0_default, size_t max_frames)
 {
   std::vector<StereoRoot> data(roots.size());
@@ -84,6 +85,7 @@ static std::vector<StereoRoot> load_roots(const std::vector<std::string>& roots,
     std::ifstream t0(roots[r] + "/T0.txt");
     double v[7];
     if (t0 >> v[0] >> v[1] >> v[2] >> v[3] >> v[4] >> v[5] >> v[6]) d.T0 = Transformation{ { v[0], v[1], v[2], v[3] }, { v[4], v[5], v[6] } };
+    if (std::ifstream(roots[r] + "/calib.yaml").good()) d.rig = io::loadCameraRig(roots[r] + "/calib.yaml");
   }
   return data;
 }
@@ -115,6 +117,11 @@ try {
     StereoLockstepOptions lo;
     lo.params = params; lo.rig = rig; lo.kf_every = kf_every; lo.lambda_rot = lambda_rot; lo.n_workers = n_workers;
     lo.images_mem_space = SVOH_MEM_HOST_PINNED;
+    {   // roots with a calibration of their own: a rig per stream (the command line's for the roots without)
+      bool any = false;
+      for (const StereoRoot& d : data) any = any || !d.rig.empty();
+      if (any) for (int s = 0; s < n_streams; ++s) lo.per_stream_rig.push_back(root_of(s).rig.empty() ? rig : root_of(s).rig);
+    }
     if (getenv("SVOH_MINI_LANDMARKS")) lo.landmarks = atoi(getenv("SVOH_MINI_LANDMARKS")) != 0;
     if (getenv("SVOH_LOCKSTEP_SPECULATE")) lo.speculate_all = std::string(getenv("SVOH_LOCKSTEP_SPECULATE")) == "all";
     if (getenv("SVOH_LOCKSTEP_RESIDENT")) lo.resident_features = atoi(getenv("SVOH_LOCKSTEP_RESIDENT")) != 0;   // (the test of the explicit-column batches)
@@ -197,6 +204,9 @@ int main(int argc, char** argv)
     const io::EurocSequence seq = io::openEuroc(argv[1]);
     const std::vector<io::RigCamera> rig = io::loadCameraRig(argv[2]);
     if (rig.size() != 2 || seq.cam1_files.size() != seq.cam0_files.size()) throw std::runtime_error("a stereo rig and two image folders are needed");
+    // SVOH_MINI_STEREO_THRESHOLDS_OF=<calib.yaml>: the reference's process-wide static thresholds (pose_optimizer.cpp:211-212, depth_filter.cpp:383-384) are
+    // taken from THAT rig's first camera -- the single-stream run of a stream that shares a lock-step engine with rigs of other focal lengths
+    if (const char* e = getenv("SVOH_MINI_STEREO_THRESHOLDS_OF")) fixProcessWideThresholds(io::loadCameraRig(e).at(0).cam, 2.0);
     io::FrontendParams params = std::string(argv[3]) == "-" ? io::frontendParamsFromYaml(io::YamlNode()) : io::loadFrontendParams(argv[3]);
     const std::string out_dir = argv[4];
     const Transformation T_imu_world0{ { atof(argv[5]), atof(argv[6]), atof(argv[7]), atof(argv[8]) }, { atof(argv[9]), atof(argv[10]), atof(argv[11]) } };
