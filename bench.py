@@ -755,10 +755,12 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
         m = (start + step * ((k - phase) // every)) % (2 * (n_frames - 1))
         return m if m < n_frames else 2 * (n_frames - 1) - m
 
-    def run(S, G, W, n_warm, n_steps, mix=False):
+    def run(S, G, W, n_warm, n_steps, mix=False, shared_classes=False):
         G = max(1, min(G, S))
         ctxs = [ctx] + [fe.Context(dev.index if dev.index is not None else 0, kernel_timing=False) for _ in range(G - 1)]
         ctx.set_kernel_timing(False)
+        for c in ctxs:   # svoh_set_align_geometry_classes: one launch geometry for every alignment problem below 512 patches
+            c.set_align_geometry_classes(shared_classes)
         ranges = [(S * g // G, S * (g + 1) // G) for g in range(G)]
         pins = [ls.PinnedImages(c, images, hi - lo) for c, (lo, hi) in zip(ctxs, ranges)]   # every stream its own copy of the sequence
         shared = None   # (a pool shared between the groups was built and raced in round 5: no gain, profiles/r05_shared_pool_ab.txt; every group has its own)
@@ -863,12 +865,20 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
 
     S = args.streams
     G, W = (args.stream_groups, args.stream_workers) if args.stream_groups and args.stream_workers else shape(S)
-    main_run, elapsed = run(S, G, W, max(3, args.warmup), args.steps, mix=args.stream_mix)
+    # streams that differ run with SHARED alignment classes (a round's alignment is then one or two launches instead of a launch per size class;
+    # every stream still reproduces its single-stream run under the same setting: tests/test_mini_frontend_gpu.py); --own-align-classes: the default classes
+    shared_classes = bool(args.stream_mix and not args.own_align_classes)
+    main_run, elapsed = run(S, G, W, max(3, args.warmup), args.steps, mix=args.stream_mix, shared_classes=shared_classes)
+    main_run["shared_alignment_classes"] = shared_classes
     elapsed, total_frames = du.combine(dist, world, elapsed, main_run["frames_in_the_timed_rounds"], comm_dev)
-    same_streams = None
+    same_streams = own_classes = None
     if args.stream_mix and rank == 0 and world == 1:   # the identical-streams number beside it: the best case of the grouping, speculation and detector batching
         r0, _ = run(S, G, W, max(3, args.warmup), args.steps)
         same_streams = {k: r0[k] for k in ("streams", "groups", "host_threads_per_group", "frames_per_s", "ms_per_round", "all_streams_at_the_same_pose", "device_waits_ms_per_round_group0")}
+        if shared_classes:   # ... and the mix with every problem in the geometry that is fastest for it alone (a launch per size class)
+            r1, _ = run(S, G, W, max(3, args.warmup), args.steps, mix=True, shared_classes=False)
+            own_classes = {k: r1[k] for k in ("frames_per_s", "ms_per_round", "device_waits_ms_per_round_group0")}
+            own_classes["align_ms_per_round_group0"] = {k: r1["round_phase_ms_mean_group0"][k] for k in ("align launch", "align wait")}
     sweep = []
     if rank == 0 and world == 1 and not args.no_secondary and not args.stream_mix:
         for s2 in (1, 8, 32, 64):
@@ -891,7 +901,7 @@ def bench_frame_streams(args, ctx, dist, rank, world, dev, comm_dev=None):
                                    "depth-filter update of <=5 keyframes (~1600 seeds), a keyframe every 8 frames; a step = one frame of every stream; "
                                    "the streams replay one rendered sequence forth and back%s" % (S, G, W, " -- EVERY STREAM ITS OWN WALK, keyframe period and feature budget, every fourth its own camera calibration (--stream-mix)" if args.stream_mix else ""),
                        "streams": S, "groups": G, "host_threads_per_group": W, "host_cpus_visible": n_host},
-            "lockstep": main_run, "identical_streams_beside_it": same_streams, "streams_sweep": sweep,
+            "lockstep": main_run, "identical_streams_beside_it": same_streams, "mix_with_own_alignment_classes_beside_it": own_classes, "streams_sweep": sweep,
             "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                          "note": "a chain of small latency-bound launches by design: the kernels' own rooflines are those of --workload align / seeds / pose / klt"},
             "cpu_baseline": cpu}
@@ -1526,6 +1536,7 @@ def parse_args(argv=None):
     ap.add_argument("--patch", type=int, default=4)
     ap.add_argument("--min-level", type=int, default=0)
     ap.add_argument("--max-level", type=int, default=4)
+    ap.add_argument("--own-align-classes", action="store_true", help="with --stream-mix: every alignment problem in the launch geometry that is fastest for it alone (the library's default) instead of shared classes")
     ap.add_argument("--stereo", action="store_true", help="with --workload frame: the stereo pair chain (BASELINE config 3)")
     ap.add_argument("--streams", type=int, default=0, help="with --workload frame: S camera streams per GPU through the whole chain in lock step (BASELINE config 5)")
     ap.add_argument("--stream-mix", action="store_true", help="with --streams: streams that DIFFER -- every stream its own walk over the sequence (start, direction, stride), "

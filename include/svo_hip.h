@@ -328,6 +328,15 @@ int svoh_sparse_align_fetch(svoh_ctx* ctx, int n_problems, svoh_align_result* re
  * settings) that made them. */
 int svoh_sparse_align_geometry_key(svoh_ctx* ctx, const svoh_align_options* options, const svoh_align_problem* problem,
                                    int32_t* key);
+/* Which geometry a problem "alone" gets.  0 (default): the one that is fastest for ONE problem of its size -- five classes below 512
+ * patches (lanes per patch, 256 / 512 threads, the one-wave-per-SIMD build), so a lock-step round of streams of different sizes goes out
+ * as up to four keyed launches one behind the other.  1: SHARED classes -- every problem below 512 patches (all cameras together) runs in
+ * the 512-thread lane-per-patch geometry (one key; a rig's cameras side by side as before), larger ones keep the rule of their size: a
+ * stream alone pays 0 - 5 % of its alignment (measured: sparse_align.hip, decide_geometry), a round of mixed streams is one or two launches.
+ * The setting applies to svoh_sparse_align_geometry_key AND to launches of a single problem (svoh_sparse_align_batch / _enqueue with
+ * n_problems = 1), so that a stream's single-stream run and its lock-step run agree bit for bit under either setting -- as long as both
+ * use the same one. */
+int svoh_set_align_geometry_classes(svoh_ctx* ctx, int shared);
 int svoh_sparse_align_enqueue_keyed(svoh_ctx* ctx, const svoh_align_options* options, int n_problems,
                                     const svoh_align_problem* problems, int32_t key);
 /* The results of EVERY launch queued since the last fetch / fetch_all, in launch

@@ -289,7 +289,7 @@ EXPORTS = [
     "svoh_abi_version", "svoh_create", "svoh_destroy", "svoh_last_error_string",
     "svoh_synchronize", "svoh_stream",
     "svoh_upload_pyramid", "svoh_build_pyramid", "svoh_build_pyramid_batch",
-    "svoh_download_level", "svoh_frame_info", "svoh_release_frame", "svoh_camera_maths", "svoh_context_stats", "svoh_reload_knobs", "svoh_set_kernel_timing", "svoh_set_copy_policy",
+    "svoh_download_level", "svoh_frame_info", "svoh_release_frame", "svoh_camera_maths", "svoh_context_stats", "svoh_reload_knobs", "svoh_set_kernel_timing", "svoh_set_copy_policy", "svoh_set_align_geometry_classes",
     "svoh_sparse_align_batch", "svoh_sparse_align_enqueue", "svoh_sparse_align_fetch", "svoh_sparse_align_fetch_all",
     "svoh_sparse_align_evaluate", "svoh_sparse_align_last_kernel_ms", "svoh_sparse_align_kernel_ms_history",
     "svoh_sparse_align_split_buffers", "svoh_sparse_align_split_init", "svoh_sparse_align_partial_sums", "svoh_sparse_align_gn_update",
@@ -379,6 +379,7 @@ def load(path=None):
     lib.svoh_context_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.svoh_reload_knobs.argtypes = [C.c_void_p]
     lib.svoh_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.svoh_set_align_geometry_classes.argtypes = [C.c_void_p, C.c_int]
     lib.svoh_matcher_begin_deferred.argtypes = [C.c_void_p]
     lib.svoh_matcher_collect.argtypes = [C.c_void_p]
     lib.svoh_matcher_flush.argtypes = [C.c_void_p]

@@ -2173,9 +2173,27 @@ static AlignGeometry decide_geometry(const svoh_ctx* ctx, const svoh_align_optio
   return g;
 }
 
+// svoh_set_align_geometry_classes(ctx, 1): ONE geometry for every problem below the cluster threshold -- 512 threads, a lane per patch, a rig's
+// cameras side by side where they fit -- instead of the five that are each fastest for one problem of their size (rows 2 / 4 below 129 / 65
+// patches, the one-wave-per-SIMD 256-thread build up to 256, 512 threads above).  Measured cost for a problem alone (decide_geometry's table:
+// 100 patches 0.087 -> 0.092 ms, 180 patches 0.092 -> 0.095): what a lock-step round of streams of different sizes saves is a launch per class.
+static bool shared_class_geometry(const svoh_ctx* ctx, const svoh_align_problem& pb, AlignGeometry* g)
+{
+  if (!ctx->align_shared_classes || ctx->align_no_cluster) return false;
+  if (pb.n_cams < 1 || pb.n_cams > SVOH_MAX_CAMS) return false;
+  int64_t nf = 0;
+  for (int c = 0; c < pb.n_cams; ++c) nf += pb.cams[c].n_features > 0 ? pb.cams[c].n_features : 0;
+  if (nf >= kClusterMinFeatures) return false;   // (the large ones keep the rule of their size: decide_cluster)
+  *g = AlignGeometry();
+  g->cluster_g = 0; g->nt = 512; g->rows = 1; g->latency = false; g->rig = pb.n_cams >= 2;
+  return true;
+}
+
 // the geometry a launch of this problem ALONE gets
 static AlignGeometry geometry_of_single(const svoh_ctx* ctx, const svoh_align_options* opt, const svoh_align_problem& pb)
 {
+  AlignGeometry shared;
+  if (shared_class_geometry(ctx, pb, &shared)) return shared;
   const int g = decide_cluster(ctx, 1, &pb);
   const int S = g >= 2 ? g : 1;
   LaunchShape z;
@@ -2192,6 +2210,9 @@ static int enqueue_align(svoh_ctx* ctx, const svoh_align_options* opt, int n_pro
   if (rc != SVOH_OK) return rc;
   SVOH_REQUIRE(ctx, n_problems >= 1 && problems, "no problems");
   SVOH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // a launch of ONE problem under shared classes: the geometry its key names (svoh_set_align_geometry_classes)
+  AlignGeometry shared_single;
+  if (!forced && !split && eval_level < 0 && n_problems == 1 && shared_class_geometry(ctx, problems[0], &shared_single)) forced = &shared_single;
 
   // patch-split evaluation: the one problem becomes S descriptors, share s holding features
   // [n*s/S, n*(s+1)/S) of every camera, one workgroup each
@@ -2581,6 +2602,14 @@ try {
   SVOH_REQUIRE(ctx, problem && key, "NULL argument");
   SVOH_REQUIRE(ctx, problem->n_cams >= 1 && problem->n_cams <= SVOH_MAX_CAMS, "n_cams out of range");
   *key = geometry_of_single(ctx, options, *problem).key();
+  return SVOH_OK;
+} SVOH_ABI_CATCH(ctx)
+
+int svoh_set_align_geometry_classes(svoh_ctx* ctx, int shared)
+try {
+  if (!ctx) return set_error(nullptr, SVOH_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SVOH_REQUIRE(ctx, shared == 0 || shared == 1, "geometry classes: 0 = the fastest geometry for a problem alone, 1 = shared classes");
+  ctx->align_shared_classes = shared != 0;
   return SVOH_OK;
 } SVOH_ABI_CATCH(ctx)
 

@@ -254,6 +254,7 @@ struct svoh_ctx {
   bool align_staged_event_valid = false;      // ev_align_staged was recorded by the most recent launch
   unsigned align_launches_since_drain = 0;    // alignment launches queued since this file last waited for the stream
   unsigned align_desc_slot = 0;
+  bool align_shared_classes = false;   // svoh_set_align_geometry_classes
   bool align_no_cluster = false;   // svoh_sparse_align_batch repeating a launch whose cluster gave up
   hipEvent_t ev_misc_start = nullptr, ev_misc_stop = nullptr;  // KLT / matcher / seeds
   // inside the hook of svoh_optimize_pose_batch_hook: where the launched batch's results will be on the device

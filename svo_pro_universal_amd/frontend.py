@@ -63,6 +63,11 @@ class Context(object):
     def set_kernel_timing(self, on):
         self._check(self.lib.svoh_set_kernel_timing(self.h, 1 if on else 0))
 
+    def set_align_geometry_classes(self, shared):
+        """svoh_set_align_geometry_classes: True = one launch geometry for every alignment problem below 512 patches (a lock-step round of
+        streams of different sizes is then one or two launches instead of up to four)."""
+        self._check(self.lib.svoh_set_align_geometry_classes(self.h, 1 if shared else 0))
+
     def close(self):
         if self.h:
             self.lib.svoh_destroy(self.h)

@@ -314,6 +314,22 @@ def test_lockstep_of_streams_that_differ(tmp_path):
             assert open(str(d / "trajectory.txt")).read() == singles[k][0], "trajectory of stream %d (workers %d, groups %d)" % (k, n_workers, n_groups)
             counters = np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, COUNTER_COLS]
             assert np.array_equal(counters, singles[k][1]), "counters of stream %d (workers %d, groups %d)" % (k, n_workers, n_groups)
+    # shared alignment classes (svoh_set_align_geometry_classes: one launch geometry for every problem below 512 patches, so that a round of streams of
+    # different sizes is one or two launches): the streams alone and in lock step agree under THAT setting as well -- other bits than under the default
+    shared = dict(os.environ, SVOH_MINI_SPEC=str(spec), SVOH_MINI_ALIGN_SHARED_CLASSES="1")
+    singles_shared = []
+    for i in range(S):
+        r = subprocess.run(cmd + [str(n_frames), "8", "1"], capture_output=True, text=True, env=dict(shared, SVOH_MINI_SPEC_LINE=str(i)))
+        assert r.returncode == 0, r.stdout + r.stderr
+        singles_shared.append((open(str(out_dir / "trajectory.txt")).read(), np.loadtxt(str(out_dir / "frontend.csv"), delimiter=",", skiprows=1)[:, COUNTER_COLS].copy()))
+    assert any(a[0] != b[0] for a, b in zip(singles, singles_shared)), "the shared classes changed no stream's bits: the case tests nothing"
+    for n_workers, n_groups in ((3, 1), (2, 2)):
+        r = subprocess.run(cmd + [str(n_frames), "8", str(S), "lockstep", str(n_workers), str(n_groups)], capture_output=True, text=True, env=shared)
+        assert r.returncode == 0, r.stdout + r.stderr
+        for k in range(S):
+            d = out_dir if k == 0 else out_dir / ("stream%d" % k)
+            assert open(str(d / "trajectory.txt")).read() == singles_shared[k][0], "shared classes: trajectory of stream %d (workers %d, groups %d)" % (k, n_workers, n_groups)
+            assert np.array_equal(np.loadtxt(str(d / "frontend.csv"), delimiter=",", skiprows=1)[:, COUNTER_COLS], singles_shared[k][1]), ("shared classes", k)
     # the speculation switches on the mix: same files
     for env in ({"SVOH_LOCKSTEP_SPECULATE": "never"}, {"SVOH_LOCKSTEP_SPECULATE": "all"}, {"SVOH_LOCKSTEP_RESIDENT": "0"}):
         r = subprocess.run(cmd + [str(n_frames), "8", str(S), "lockstep", "2", "1"], capture_output=True, text=True, env=dict(os.environ, SVOH_MINI_SPEC=str(spec), **env))

@@ -151,6 +151,8 @@ void run_stream(const io::EurocSequence& seq, const std::vector<io::GrayImage>& 
     const bool align_ahead_on = getenv("SVOH_MINI_ALIGN_AHEAD") != nullptr && atoi(getenv("SVOH_MINI_ALIGN_AHEAD")) != 0;
     svoh_ctx* ctx = nullptr;
     if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
+    // SVOH_MINI_ALIGN_SHARED_CLASSES=1: svoh_set_align_geometry_classes(ctx, 1) -- in both modes of the tool, so that a stream alone and in lock step agree
+    if (getenv("SVOH_MINI_ALIGN_SHARED_CLASSES") && svoh_set_align_geometry_classes(ctx, atoi(getenv("SVOH_MINI_ALIGN_SHARED_CLASSES")) != 0) != SVOH_OK) throw std::runtime_error(svoh_last_error_string(ctx));
     const svoh_camera& cam = rig.at(0).cam;
 
     params.depth_filter.use_threaded_depthfilter = false;   // the synchronous path
@@ -355,6 +357,7 @@ void run_lockstep_group(const io::EurocSequence& seq, const std::vector<io::Gray
   try {
     svoh_ctx* ctx = nullptr;
     if (svoh_create(0, &ctx) != SVOH_OK) throw std::runtime_error(std::string("svoh_create: ") + svoh_last_error_string(nullptr));
+    if (getenv("SVOH_MINI_ALIGN_SHARED_CLASSES") && svoh_set_align_geometry_classes(ctx, atoi(getenv("SVOH_MINI_ALIGN_SHARED_CLASSES")) != 0) != SVOH_OK) throw std::runtime_error(svoh_last_error_string(ctx));
     // the decoded sequence in page-locked memory, as a camera driver that feeds a GPU would deliver its images: EVERY STREAM
     // ITS OWN COPY (the device reads the images in place, and 32 streams reading one buffer would be served from its caches
     // after the first: every stream's image has to cross PCIe by itself, as the images of 32 different cameras do)
