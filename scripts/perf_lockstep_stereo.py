@@ -12,4 +12,4 @@ print(r.stdout.strip())
 roots = "%s:%s" % (tmp / "dsA", tmp / "dsB")
 for S, W, G in ((1, 1, 1), (8, 4, 1), (16, 8, 1), (32, 16, 1), (32, 4, 4), (32, 2, 8), (64, 4, 4), (64, 2, 8)):
     r = subprocess.run(cmd_a + ["30", "8", "0.5", str(S), str(W), str(G)], capture_output=True, text=True, env=dict(os.environ, SVOH_MINI_STEREO_ROOTS=roots, SVOH_LOCKSTEP_TIMING="1"))
-    print(r.stdout.strip().splitlines()[-1]); print("   ", [l for l in r.stderr.splitlines() if "lockstep stereo" in l][-1:])
+    print(r.stdout.strip().splitlines()[-1]); print("   ", [l for l in r.stderr.splitlines() if "lockstep stereo" in l][-2:])

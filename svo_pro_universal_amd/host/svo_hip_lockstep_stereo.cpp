@@ -508,6 +508,9 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
   // where a round's time goes (sums since construction, ms): pyramids, finish seeds, align, reproject, pose, structure, keyframes, seed updates
   double tp = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   auto lap = [&](int k) { const double n = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); phase_ms_[k] += n - tp; tp = n; };
+  double td = tp;
+  auto detail = [&](int k) { const double n = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); detail_ms_[k] += n - td; td = n; };
+  auto detail_start = [&]() { td = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   drainReleases();
   if (!left || !right) throw std::runtime_error("FrontendLockstepStereo::addPairs: NULL images");
   std::vector<int> trk, starting;
@@ -592,6 +595,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
   if (nT == 0) { prefetch(next_left, next_right, pitch); close_round(); return; }
 
   // ---- 1. sparse image alignment of the bundles, each with its stream's IMU rotation prior (frame_handler_base.cpp:610-643)
+  detail_start();
   pool_->run(S, [&](int s) {
     Stream& st = *streams_[static_cast<size_t>(s)];
     if (!st.tracking) return;
@@ -605,6 +609,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
     st.T_iref_world = st.img_align.prepareRun(st.last, st.bundle, st.align_opt, st.align_pb);
     st.visible.assign(st.kfs.begin(), st.kfs.end());
   });
+  detail(0);
   {
     auto same_options = [](const svoh_align_options& a, const svoh_align_options& b) {
       return a.max_level == b.max_level && a.min_level == b.min_level && a.patch_size == b.patch_size && a.max_iter == b.max_iter && a.eps == b.eps &&
@@ -628,9 +633,11 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
       check(svoh_sparse_align_enqueue_keyed(ctx_, &streams_[static_cast<size_t>(g.second[0])]->align_opt, static_cast<int>(pbs.size()), pbs.data(), g.first), "svoh_sparse_align_enqueue_keyed");
       ++device_calls_;
     }
+    detail(1);
     std::vector<svoh_align_result> results(static_cast<size_t>(nT));
     check(svoh_sparse_align_fetch_all(ctx_, nT, results.data()), "svoh_sparse_align_fetch_all");
     ++device_calls_;
+    detail(2);
     prefetch(next_left, next_right, pitch);   // (behind a call that waited: the context's stream is idle, the next pairs cross PCIe beside the rest of the round)
     for (int s : trk) {   // a cluster of workgroups that never completed (status 3): that problem again, one workgroup
       Stream& st = *streams_[static_cast<size_t>(s)];
@@ -643,6 +650,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
       if (!st.tracking) return;
       st.row.n_aligned = st.img_align.finishRun(results[static_cast<size_t>(st.align_result)], st.bundle, st.T_iref_world);
     });
+    detail(3);
   }
 
   lap(2);
@@ -665,6 +673,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
       else rp.walkCandidatesWithoutUnconverged(st.bundle->at(cc), st.visible, st.trash);
       rp.planMatches(st.bundle->at(cc), third ? 3 : 2, false);
     });
+    detail(4);
     auto matcher_round = [&](const std::vector<int>& who, bool sort_meanwhile) {
       size_t n_direct = 0, n_seeds = 0, n_refs = 0;
       for (int s : who) {
@@ -723,9 +732,11 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
       check(svoh_matcher_flush(ctx_), "svoh_matcher_flush");
       ++device_calls_;
       if (sort_meanwhile) sort_lists();
+      detail(5);
       close_section.armed = false;
       check(svoh_matcher_collect(ctx_), "svoh_matcher_collect");
       ++device_calls_;
+      detail(6);
     };
     auto point_outputs = [&](Stream& st) {
       detail::SpeculativeMatches& sm = st.rp[c]->plannedMatches();
@@ -762,6 +773,7 @@ void FrontendLockstepStereo::addPairs(const uint8_t* const* left, const uint8_t*
       });
     }
     for (int s : trk) { Stream& st = *streams_[static_cast<size_t>(s)]; st.n_reproj += st.bundle->at(cc)->num_features_; }
+    detail(7);
   }
 
   lap(3);

@@ -78,6 +78,10 @@ class FrontendLockstepStereo {
   // where the rounds' time went (ms summed since construction): pyramids, finish seeds, align, reproject, pose, structure, keyframes, seed updates
   static constexpr int kNumPhases = 8;
   const double* phaseTimes() const { return phase_ms_; }
+  // ... and inside "align" and "reproject": align prep / launch / wait / finish, walk + plan, match stage + submit, match wait, replay
+  static constexpr int kNumDetails = 8;
+  const double* detailTimes() const { return detail_ms_; }
+  static const char* detailName(int k) { static const char* n[] = { "align prep", "align launch", "align wait", "align finish", "walk + plan", "match stage + submit", "match wait", "replay" }; return k >= 0 && k < kNumDetails ? n[k] : ""; }
   static const char* phaseName(int k) { static const char* n[] = { "pyramids", "finish seeds", "align", "reproject", "pose", "structure", "keyframes", "seed updates" }; return k >= 0 && k < kNumPhases ? n[k] : ""; }
 
  private:
@@ -97,6 +101,7 @@ class FrontendLockstepStereo {
   int device_calls_ = 0;
   size_t paused_passes_ = 0;
   double phase_ms_[kNumPhases] = {};
+  double detail_ms_[kNumDetails] = {};
   bool seeds_in_flight_ = false;
   // the seed batch in flight: its streams, and where it was staged (the context's page-locked area: valid until the next stage call)
   std::vector<int> sb_streams_;

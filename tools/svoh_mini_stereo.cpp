@@ -149,6 +149,7 @@ try {
     std::vector<const svoh::Quat*> prior((size_t)n_streams);
     double sum_ms = 0;
     size_t pairs = 0;
+    std::vector<double> phase0((size_t)FrontendLockstepStereo::kNumPhases, 0.0), detail0((size_t)FrontendLockstepStereo::kNumDetails, 0.0);
     gate->fetch_add(1);   // all groups start their first round together
     while (gate->load() < n_groups) std::this_thread::yield();
     for (size_t k = 0; k < n_rounds; ++k) {
@@ -170,6 +171,10 @@ try {
       fe.addPairs(left.data(), right.data(), data[0].left[0].width, T_first.data(), prior.data(), more ? next_left.data() : nullptr, more ? next_right.data() : nullptr);
       const double t1 = now_ms();
       if (k > 2) { sum_ms += t1 - t0; pairs += n_now; }   // (the first rounds pay the one-time costs)
+      if (k == 2) {   // ... which the phase sums below leave out as well
+        phase0.assign(fe.phaseTimes(), fe.phaseTimes() + FrontendLockstepStereo::kNumPhases);
+        detail0.assign(fe.detailTimes(), fe.detailTimes() + FrontendLockstepStereo::kNumDetails);
+      }
       for (int s = 0; s < n_streams; ++s) {
         const StereoRoot& d = root_of(s);
         if (k < d.n) traj[(size_t)s]->write(d.seq.cam_ts[k], svoh::inverse(fe.pose(s)));
@@ -179,9 +184,13 @@ try {
     fe.finish();
     write_rows();
     if (getenv("SVOH_LOCKSTEP_TIMING") && s0 == 0) {
+      const double nr = n_rounds > 3 ? (double)(n_rounds - 3) : 1.0;   // (rounds 3 ..: the steady state the rate is quoted on)
       fprintf(stderr, "[lockstep stereo] mean ms per round:");
-      for (int k = 0; k < FrontendLockstepStereo::kNumPhases; ++k) fprintf(stderr, " %s %.3f,", FrontendLockstepStereo::phaseName(k), fe.phaseTimes()[k] / (double)n_rounds);
+      for (int k = 0; k < FrontendLockstepStereo::kNumPhases; ++k) fprintf(stderr, " %s %.3f,", FrontendLockstepStereo::phaseName(k), (fe.phaseTimes()[k] - phase0[(size_t)k]) / nr);
       fprintf(stderr, " paused passes %zu\n", fe.pausedPasses());
+      fprintf(stderr, "[lockstep stereo]   of which:");
+      for (int k = 0; k < FrontendLockstepStereo::kNumDetails; ++k) fprintf(stderr, " %s %.3f,", FrontendLockstepStereo::detailName(k), (fe.detailTimes()[k] - detail0[(size_t)k]) / nr);
+      fprintf(stderr, "\n");
     }
     for (FILE* f : csv) fclose(f);
     out->pairs = pairs; out->ms = sum_ms; out->round_ms = n_rounds > 3 ? sum_ms / (double)(n_rounds - 3) : 0.0; out->device_calls = fe.lastRoundDeviceCalls();
