@@ -80,6 +80,10 @@ const char* svohl_last_error(void);
 typedef struct svohs_engine svohs_engine;
 int svohs_create(svoh_ctx* ctx, int n_streams, const svoh_camera* cams, const svoh_se3* T_B_C, const char* params_yaml, int kf_every, double lambda_rot, int n_workers,
                  int images_pinned, svohs_engine** out);
+/* ... with a RIG per stream: cams / T_B_C hold 2 x n_streams entries (stream s: [2 s], [2 s + 1]); one image size for all (StereoLockstepOptions::per_stream_rig);
+ * stream 0's first camera is the one the reference's process-wide thresholds are taken from */
+int svohs_create_rigs(svoh_ctx* ctx, int n_streams, const svoh_camera* cams, const svoh_se3* T_B_C, const char* params_yaml, int kf_every, double lambda_rot, int n_workers,
+                      int images_pinned, svohs_engine** out);
 void svohs_destroy(svohs_engine* e);
 int svohs_run_sequence(svohs_engine* e, const uint8_t* base, size_t image_bytes, size_t stream_stride, int n_pairs, int pitch, long k_first, int n_rounds,
                        const svoh_se3* T_imu_world_first, const double* prior_forward, double* round_ms);

@@ -493,10 +493,11 @@ void FrontendLockstepStereo::prefetch(const uint8_t* const* next_left, const uin
     if (next_left[s]) { imgs.push_back(next_left[s]); imgs.push_back(next_right[s]); }
   }
   if (imgs.empty()) return;
-  prefetched_.assign(imgs.size(), 0);
+  std::vector<svoh_frame_t> handles(imgs.size(), 0);
   check(svoh_build_pyramid_multi_prefetch(ctx_, imgs.data(), static_cast<int>(imgs.size()), opt_.rig[0].cam.width, opt_.rig[0].cam.height, pitch, opt_.images_mem_space,
-                                          opt_.params.n_pyr_levels_to_build, SVOH_HALFSAMPLE_REFERENCE, prefetched_.data()), "svoh_build_pyramid_multi_prefetch");
+                                          opt_.params.n_pyr_levels_to_build, SVOH_HALFSAMPLE_REFERENCE, handles.data()), "svoh_build_pyramid_multi_prefetch");
   ++device_calls_;
+  prefetched_.swap(handles);   // (only once the call has succeeded: a failed announcement leaves nothing behind)
   prefetched_from_ = imgs;
 }
 
@@ -898,6 +899,30 @@ int svohs_create(svoh_ctx* ctx, int n_streams, const svoh_camera* cams, const sv
     svo_hip::StereoLockstepOptions lo;
     lo.params = svo_hip::io::frontendParamsFromYaml(params_yaml ? svo_hip::io::parseYaml(params_yaml) : svo_hip::io::YamlNode());
     for (int c = 0; c < 2; ++c) { svo_hip::io::RigCamera rc; rc.label = c ? "cam1" : "cam0"; rc.cam = cams[c]; rc.T_B_C = svoh::load_rigid(T_B_C[c]); lo.rig.push_back(rc); }
+    lo.kf_every = kf_every > 0 ? static_cast<size_t>(kf_every) : 8;
+    lo.lambda_rot = lambda_rot;
+    lo.n_workers = n_workers;
+    lo.images_mem_space = images_pinned ? SVOH_MEM_HOST_PINNED : SVOH_MEM_HOST;
+    std::unique_ptr<svohs_engine> e(new svohs_engine);
+    e->fe.reset(new svo_hip::FrontendLockstepStereo(ctx, n_streams, lo));
+    *out = e.release();
+  });
+}
+
+int svohs_create_rigs(svoh_ctx* ctx, int n_streams, const svoh_camera* cams, const svoh_se3* T_B_C, const char* params_yaml, int kf_every, double lambda_rot, int n_workers,
+                      int images_pinned, svohs_engine** out)
+{
+  return svohs_guard([&] {
+    if (!out || !cams || !T_B_C || n_streams < 1) throw std::runtime_error("svohs_create_rigs: NULL argument");
+    *out = nullptr;
+    svo_hip::StereoLockstepOptions lo;
+    lo.params = svo_hip::io::frontendParamsFromYaml(params_yaml ? svo_hip::io::parseYaml(params_yaml) : svo_hip::io::YamlNode());
+    for (int s = 0; s < n_streams; ++s) {
+      std::vector<svo_hip::io::RigCamera> rig;
+      for (int c = 0; c < 2; ++c) { svo_hip::io::RigCamera rc; rc.label = c ? "cam1" : "cam0"; rc.cam = cams[2 * s + c]; rc.T_B_C = svoh::load_rigid(T_B_C[2 * s + c]); rig.push_back(rc); }
+      lo.per_stream_rig.push_back(rig);
+    }
+    lo.rig = lo.per_stream_rig[0];
     lo.kf_every = kf_every > 0 ? static_cast<size_t>(kf_every) : 8;
     lo.lambda_rot = lambda_rot;
     lo.n_workers = n_workers;
