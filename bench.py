@@ -101,7 +101,8 @@ def roofline(kernel, kernel_ms, alg_bytes, workload_key, **extra):
                 r["compute_side"]["fp64_tflops_live"] = tf
                 r["compute_side"]["fp64_fraction_of_measured_peak_63p8_live"] = tf / FP64_PEAK_TFLOPS
                 r["compute_side"]["fp64_fraction_of_vendor_peak_78p6_live"] = tf / FP64_VENDOR_PEAK_TFLOPS
-            # which resource is nearest its ceiling (what `bound` names): the three candidates with their fractions
+            # which resource is nearest its ceiling (`what_binds`; `bound` stays the roofline of SURVEY 8(d) that `peak` / `frac` refer to, "hbm"):
+            # the three candidates with their fractions
             cand = {"hbm": r["frac_live"]}
             if flop:
                 cand["fp64 VALU issue"] = r["compute_side"]["fp64_fraction_of_measured_peak_63p8_live"]
@@ -110,11 +111,10 @@ def roofline(kernel, kernel_ms, alg_bytes, workload_key, **extra):
             top = max(cand, key=lambda k: cand[k])
             if busy is not None and waiting is not None and waiting >= 0.40 and busy < 0.60:
                 # no throughput resource past 60 %: the waves spend their time waiting on their own dependent chains
-                r["bound"] = "latency (waves wait %.0f %% of their cycles; VALU busy %.0f %%, %s %.2f)" % (
+                r["what_binds"] = "latency (waves wait %.0f %% of their cycles; VALU busy %.0f %%, %s %.2f)" % (
                     100 * waiting, 100 * busy, top, cand[top])
             else:
-                r["bound"] = "%s (%.2f of its ceiling%s)" % (top, cand[top], "; VALU busy %.0f %%" % (100 * busy) if busy is not None else "")
-            r["bound_of_the_unit_in_SURVEY_8d"] = "hbm"   # the roofline the metric is priced against; `peak` / `frac` refer to it
+                r["what_binds"] = "%s (%.2f of its ceiling%s)" % (top, cand[top], "; VALU busy %.0f %%" % (100 * busy) if busy is not None else "")
     else:
         r.update({"achieved": alg, "frac": alg / HBM_PEAK_GBS, "traffic": None,
                   "frac_basis": "algorithmic bytes (no PMC summary committed for this workload key)"})
