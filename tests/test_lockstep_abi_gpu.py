@@ -57,6 +57,71 @@ def test_keyed_launch_gives_every_problem_the_result_of_its_own_launch(gpu_ctx):
         ctx.release_frame(f)
 
 
+def test_shared_geometry_classes_one_key_below_the_cluster_threshold(gpu_ctx):
+    """svoh_set_align_geometry_classes(ctx, 1) (round 6): every problem below 512 patches gets ONE key -- mono problems of 40 ... 500 patches,
+    and the two-camera bundles among themselves -- so a lock-step round of streams of different sizes is one launch; the setting also governs a
+    launch of a single problem, so alone == in the shared launch, bit for bit; larger problems keep the cluster rule of their size; against the
+    default classes the results agree to summation order (poses 1e-12, iteration counts exact) and differ in bits somewhere."""
+    ctx = gpu_ctx
+    opt = capi.default_align_options(max_level=4, min_level=2)
+    sizes = [40, 60, 100, 128, 180, 256, 257, 300, 400, 500, 600, 900]
+    keep_all, frames, pbs = [], [], []
+    for i, n in enumerate(sizes):
+        sc = synth.make_align_scene(1300 + i, n_features=n, patch_size=4)
+        fr, fc = ctx.build_pyramid(sc.img_ref, 5), ctx.build_pyramid(sc.img_cur, 5)
+        p, keep = fe.make_align_problems([[(sc, fr, fc)]])
+        keep_all.append((sc, keep)); frames += [fr, fc]; pbs.append(p[0])
+    # two rig bundles of different sizes (8 parameters)
+    opt8 = capi.default_align_options(max_level=4, min_level=2, estimate_illumination_gain=1, estimate_illumination_offset=1)
+    rigs = []
+    for i, n in enumerate((90, 170)):
+        scs = [synth.make_align_scene(1400 + 2 * i + c, n_features=n, patch_size=4, gain=1.03, offset=2.0) for c in range(2)]
+        fr = [(ctx.build_pyramid(sc.img_ref, 5), ctx.build_pyramid(sc.img_cur, 5)) for sc in scs]
+        p, keep = fe.make_align_problems([[(sc, a, b) for sc, (a, b) in zip(scs, fr)]])
+        keep_all.append((scs, keep)); frames += [h for ab in fr for h in ab]; rigs.append(p[0])
+
+    def key_of(o, p):
+        k = C.c_int32()
+        ctx._check(ctx.lib.svoh_sparse_align_geometry_key(ctx.h, C.byref(o), C.byref(p), C.byref(k)))
+        return k.value
+
+    default_keys = [key_of(opt, p) for p in pbs]
+    default_alone = [ctx.sparse_align(opt, (capi.svoh_align_problem * 1)(p))[0] for p in pbs]
+    default_bits = [result_bits(r) for r in default_alone]
+    assert len(set(default_keys[:10])) >= 3
+    try:
+        ctx.set_align_geometry_classes(True)
+        keys = [key_of(opt, p) for p in pbs]
+        assert len(set(keys[:10])) == 1 and keys[10] == default_keys[10] and keys[11] == default_keys[11], [hex(k) for k in keys]
+        rig_keys = [key_of(opt8, p) for p in rigs]
+        assert len(set(rig_keys)) == 1 and rig_keys[0] != keys[0]
+        alone = [ctx.sparse_align(opt, (capi.svoh_align_problem * 1)(p))[0] for p in pbs]
+        arr = (capi.svoh_align_problem * 10)(*pbs[:10])
+        ctx._check(ctx.lib.svoh_sparse_align_enqueue_keyed(ctx.h, C.byref(opt), 10, arr, keys[0]))
+        together = ctx.sparse_align_fetch_all(10)
+        for i in range(10):
+            assert result_bits(together[i]) == result_bits(alone[i]), sizes[i]
+        rig_alone = [ctx.sparse_align(opt8, (capi.svoh_align_problem * 1)(p))[0] for p in rigs]
+        arr = (capi.svoh_align_problem * 2)(*rigs)
+        ctx._check(ctx.lib.svoh_sparse_align_enqueue_keyed(ctx.h, C.byref(opt8), 2, arr, rig_keys[0]))
+        rig_together = ctx.sparse_align_fetch_all(2)
+        for i in range(2):
+            assert result_bits(rig_together[i]) == result_bits(rig_alone[i])
+        # against the default classes: the same alignment up to the order of the sums
+        differs = 0
+        for i, (a, d) in enumerate(zip(alone, default_alone)):
+            assert tuple(a.iters) == tuple(d.iters) and tuple(a.n_meas) == tuple(d.n_meas) and a.n_fts_to_track == d.n_fts_to_track, sizes[i]
+            assert np.allclose(list(a.T_icur_iref.q) + list(a.T_icur_iref.t), list(d.T_icur_iref.q) + list(d.T_icur_iref.t), rtol=0, atol=1e-12), sizes[i]
+            differs += result_bits(a) != default_bits[i]
+        assert differs >= 1, "shared classes changed no problem's bits: the default classes were one class already?"
+        assert ctx.lib.svoh_set_align_geometry_classes(ctx.h, 2) != 0
+    finally:
+        ctx.set_align_geometry_classes(False)
+    assert [key_of(opt, p) for p in pbs] == default_keys
+    for f in frames:
+        ctx.release_frame(f)
+
+
 def test_keyed_cluster_launch_of_more_problems_than_arrival_counters(gpu_ctx):
     """70 - 90 problems of 512 ... 874 patches under ONE cluster key (the round after a keyframe of a large
     lock-step group) -- with three workgroups per problem a 256-CU device takes 85 per launch, the arrival counters hold 64:
