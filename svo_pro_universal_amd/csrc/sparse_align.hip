@@ -614,6 +614,84 @@ __device__ __forceinline__ void stage_image(unsigned char* dst, const DevImage& 
   }
 }
 
+// SVOH_ALIGN_STAGE_REGS: a level's two images (reference and current) through registers instead of LDS-DMA -- every thread requests up to six
+// 16-byte pieces of each image back to back (all in flight together), waits once and writes them to LDS.  Round 6, by the cycle stamps
+// (profiles/r06_align_p4_stamps.txt): the 50 KB of LDS-DMA requests of a problem's start take ~60 K cycles to arrive (a wave's global_load_lds
+// instructions return one behind the other), a fifth of the life of a 180-patch problem and 6 % of a 2000-patch one.
+#ifndef SVOH_ALIGN_STAGE_REGS
+#define SVOH_ALIGN_STAGE_REGS 1
+#endif
+template <int NT, bool REGS>
+__device__ __forceinline__ void stage_image_pair(unsigned char* dst_a, const DevImage& im_a, unsigned char* dst_b, const DevImage& im_b, int tid)
+{
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) v4u* lds16;
+  const bool fast = im_a.pitch == im_a.w && im_b.pitch == im_b.w && ((reinterpret_cast<uintptr_t>(im_a.data) | reinterpret_cast<uintptr_t>(im_b.data)) & 15) == 0;
+  if (!REGS || !fast) { stage_image<NT>(dst_a, im_a, tid); stage_image<NT>(dst_b, im_b, tid); return; }
+  const int total_a = im_a.w * im_a.h, total_b = im_b.w * im_b.h;
+  const int n16a = total_a >> 4, n16b = total_b >> 4;
+  const v4u* src_a = reinterpret_cast<const v4u*>(im_a.data);
+  const v4u* src_b = reinterpret_cast<const v4u*>(im_b.data);
+  lds16 da = (lds16)dst_a;   // (both LDS offsets are multiples of 16: the levels' sizes are rounded up to that)
+  lds16 db = (lds16)dst_b;
+  constexpr int K = 6;
+  const int n16 = n16a > n16b ? n16a : n16b;
+  for (int base = tid; base < n16; base += NT * K) {
+    v4u va[K], vb[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = base + k * NT;
+      if (i < n16a) va[k] = src_a[i];
+      if (i < n16b) vb[k] = src_b[i];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = base + k * NT;
+      if (i < n16a) da[i] = va[k];
+      if (i < n16b) db[i] = vb[k];
+    }
+  }
+  for (int i = (n16a << 4) + tid; i < total_a; i += NT) dst_a[i] = im_a.data[i];
+  for (int i = (n16b << 4) + tid; i < total_b; i += NT) dst_b[i] = im_b.data[i];
+}
+
+// ... and ALL the levels that are resident for a problem's life in one go: a table of the images (workgroup-uniform, in LDS), every thread takes up to
+// sixteen 16-byte pieces of the whole list, requests them back to back, waits ONCE and writes them: one exposed round trip to HBM per problem instead
+// of one per level (the images come cold: 838 MB of pyramids in the benchmark).
+struct StageItem { const unsigned char* src; int dst_off, begin16, bytes, pad_; };
+constexpr int kMaxStageItems = 16;
+template <int NT>
+__device__ __forceinline__ void stage_item_list(unsigned char* lds_base, const StageItem* items, int n_items, int total16, int tid)
+{
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) v4u* lds16;
+  constexpr int K = 16;
+  for (int f0 = tid; f0 < total16; f0 += NT * K) {
+    v4u v[K];
+    int jj[K];
+    int j = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int f = f0 + k * NT;
+      jj[k] = 0;
+      if (f < total16) {
+        while (j + 1 < n_items && f >= items[j + 1].begin16) ++j;
+        jj[k] = j;
+        v[k] = reinterpret_cast<const v4u*>(items[j].src)[f - items[j].begin16];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int f = f0 + k * NT;
+      if (f < total16) ((lds16)(lds_base + items[jj[k]].dst_off))[f - items[jj[k]].begin16] = v[k];
+    }
+  }
+  for (int j = 0; j < n_items; ++j) {   // the images' last bytes (a level of 47 x 30 pixels is 88 pieces and two bytes)
+    const int n16 = j + 1 < n_items ? items[j + 1].begin16 - items[j].begin16 : total16 - items[j].begin16;
+    for (int i = (n16 << 4) + tid; i < items[j].bytes; i += NT) lds_base[items[j].dst_off + i] = items[j].src[i];
+  }
+}
+
 // Values read from LDS are wave-uniform here but the compiler cannot know it;
 // moving them to SGPRs frees a VGPR pair per double in the patch loop.
 __device__ __forceinline__ double uniform_f64(double v)
@@ -1374,6 +1452,10 @@ void sparse_align_kernel(const AlignKernelArgs a)
   // LDS-DMA staging of the workspace rows (accumulate_camera_staged) in the batch geometry; the wide
   // geometries keep their LDS for finer image levels and read the workspace with ordinary loads
   constexpr bool STAGED = SVOH_ALIGN_STAGED && NT == 256 && !ROWS;
+  // the levels' images through registers in the BATCH geometry only (stage_item_list): a workgroup there has a second one beside it on its compute
+  // unit to fill the wait; the small-launch geometries keep the LDS-DMA requests, whose flight overlaps the problem's base phase (measured, one
+  // 180-patch problem: 27.6 us outside the iterations with LDS-DMA, 31.3 with the blocking copy)
+  constexpr bool kStageRegs = SVOH_ALIGN_STAGE_REGS != 0 && NT == 256 && !LAT && !CLUSTER && !ROWS;
   extern __shared__ __align__(16) unsigned char lds_img[];
   __shared__ __align__(16) double s_stage[STAGED ? NW * kStageDoubles : 2];
   __shared__ double s_jc[SVOH_MAX_CAMS][kJacConsts];   // per-camera constants of jac_rows
@@ -1388,6 +1470,7 @@ void sparse_align_kernel(const AlignKernelArgs a)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   __shared__ int s_pbi;
+  __shared__ StageItem s_stage_items[kMaxStageItems];   // the images of the problem's resident levels (stage_item_list)
   // Persistent workgroups: the grid is sized to what is resident at once and every
   // workgroup pulls the next problem index from a queue head, so problems that need
   // more Gauss-Newton iterations do not leave CUs idle at the end of the launch.
@@ -1450,10 +1533,9 @@ void sparse_align_kernel(const AlignKernelArgs a)
   };
   auto stage_level = [&](int l, int off) {
     for (int c = 0; c < n_cams; ++c) {
-      stage_image<NT>(lds_img + off, cams[c].ref[l], tid);
-      off += ((cams[c].ref[l].w * cams[c].ref[l].h + 15) & ~15);
-      stage_image<NT>(lds_img + off, cams[c].cur[l], tid);
-      off += ((cams[c].cur[l].w * cams[c].cur[l].h + 15) & ~15);
+      const int off_cur = off + ((cams[c].ref[l].w * cams[c].ref[l].h + 15) & ~15);
+      stage_image_pair<NT, kStageRegs>(lds_img + off, cams[c].ref[l], lds_img + off_cur, cams[c].cur[l], tid);
+      off = off_cur + ((cams[c].cur[l].w * cams[c].cur[l].h + 15) & ~15);
     }
   };
 
@@ -1464,15 +1546,55 @@ void sparse_align_kernel(const AlignKernelArgs a)
   // phase instead of standing in front of every level's first iteration (three exposed copies per problem before:
   // 6 % of a workgroup's life).  A finer level that fits only by itself is staged when its turn comes, over them.
   {
-    int off = 0;
-    bool room = true;
+    // (uniform) which levels stay resident, and the table of their images; the list form wants images it can take in 16-byte pieces
+    int off = 0, n_items = 0, total16 = 0;
+    bool room = true, list_ok = kStageRegs;
     for (int l = level_hi; l >= level_lo; --l) {
       const int need = level_bytes(l);
       room = room && off + need <= a.lds_img_bytes;
-      if (room) { stage_level(l, off); if (tid == 0) s_lvl_off[l] = off; off += need; }
+      if (!room) continue;
+      for (int c = 0; c < n_cams; ++c)
+        for (int h = 0; h < 2; ++h) {
+          const DevImage& im = h ? cams[c].cur[l] : cams[c].ref[l];
+          list_ok = list_ok && n_items < kMaxStageItems && im.pitch == im.w && (reinterpret_cast<uintptr_t>(im.data) & 15) == 0;
+          ++n_items;
+        }
+      off += need;
+    }
+    off = 0; room = true; n_items = 0;
+    for (int l = level_hi; l >= level_lo; --l) {
+      const int need = level_bytes(l);
+      room = room && off + need <= a.lds_img_bytes;
+      if (room) {
+        if (!list_ok) stage_level(l, off);
+        else if (tid == 0) {
+          int o = off;
+          for (int c = 0; c < n_cams; ++c)
+            for (int h = 0; h < 2; ++h) {
+              const DevImage& im = h ? cams[c].cur[l] : cams[c].ref[l];
+              const int bytes = im.w * im.h;
+              s_stage_items[n_items] = StageItem{ im.data, o, total16, bytes, 0 };
+              ++n_items; total16 += bytes >> 4; o += (bytes + 15) & ~15;
+            }
+        } else {
+          for (int c = 0; c < n_cams; ++c)
+            for (int h = 0; h < 2; ++h) { const DevImage& im = h ? cams[c].cur[l] : cams[c].ref[l]; ++n_items; total16 += (im.w * im.h) >> 4; }
+        }
+        if (tid == 0) s_lvl_off[l] = off;
+        off += need;
+      }
       else if (tid == 0) s_lvl_off[l] = -1;
     }
+    if (list_ok && n_items) {
+      __syncthreads();   // the table is written
+      stage_item_list<NT>(lds_img, s_stage_items, n_items, total16, tid);
+    }
   }
+#ifdef SVOH_STAGE_WAIT_EXPERIMENT
+  // diagnostic build only (with SVOH_PHASE_STAMPS): wait for the levels' LDS-DMA right here and book it as "stage" -- how long the 50 KB take by themselves
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  SVOH_STAMP_ADD(1);
+#endif
   if (tid == 0) {
     g_state.T = load_rigid(pb.T_init);
     g_state.Told = g_state.T;

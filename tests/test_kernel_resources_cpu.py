@@ -46,8 +46,8 @@ def test_alignment_kernels_fit_their_geometry(built):
 def test_spill_budgets(built):
     # the headline instantiations: what spills, spills outside the pixel loops (scripts/isa_loop_census.sh); a count
     # well above today's means the allocation has changed character
-    assert _align(built, 4, 256, False, False, False, 1)["vgpr_spill"] <= 60      # today 33
-    assert _align(built, 8, 256, False, False, False, 1)["vgpr_spill"] <= 90      # today 56
+    assert _align(built, 4, 256, False, False, False, 1)["vgpr_spill"] <= 60      # today 53 (round 6: the levels' images staged through registers at a problem's start; 25 before)
+    assert _align(built, 8, 256, False, False, False, 1)["vgpr_spill"] <= 90      # today 72 (47 before the register staging)
     assert _align(built, 4, 256, True, False, False, 1)["vgpr_spill"] <= 100      # today 61
     # the robust 8x8 instantiations were at 238 - 388 spilled registers (four unrolled rows of
     # Tukey-weighted moments); one row per trip: 36 - 105
