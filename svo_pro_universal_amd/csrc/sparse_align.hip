@@ -1660,7 +1660,10 @@ void sparse_align_kernel(const AlignKernelArgs a)
       // (65 bytes per feature, read once), and the vector-memory counter is in order -- with one feature requested ahead
       // every trip waited for the PREVIOUS trip's stores as well (round 4 stamps: 99 K cycles per 2000-feature problem,
       // 12 K per trip: 9 % of a workgroup's life in the batch)
-      constexpr int kBaseDepth = 4;
+#ifndef SVOH_ALIGN_BASE_DEPTH
+#define SVOH_ALIGN_BASE_DEPTH 4
+#endif
+      constexpr int kBaseDepth = SVOH_ALIGN_BASE_DEPTH;
       for (int i0 = tid; i0 < cd.n_features; i0 += kBaseDepth * NT) {
         FeatIn in[kBaseDepth];
 #pragma unroll
