@@ -1693,11 +1693,13 @@ def main(argv=None):
     # the slowest pair and all workgroups run their memory-bound starts together; eight problems per workgroup show the steady-state rate of a stream of
     # problems (profiles/r06_align_batch_size_sweep.txt).  `value` stays the 1024-pair step.
     if P == 4 and not args.no_secondary and not args.problems and N == 2000 and args.min_level == 0 and args.max_level == 4 and world == 1:
-        big, _ = run_align(args, ctx, dist, rank, world, dev, comm_dev, 4, N, 4096, None, False, steps=max(3, args.steps // 4))
+        big, big_shared = run_align(args, ctx, dist, rank, world, dev, comm_dev, 4, N, 4096, None, False, steps=max(3, args.steps // 4))
         out["steady_state"] = {"frame_pairs_per_step": 4096, "kernel_ms": big["kernel_ms"], "kernel_ms_per_1024_frame_pairs": big["kernel_ms"] / 4.0,
                                "value": big["value"], "unit": big["unit"], "ms_per_step": big["ms_per_step"], "steps": max(3, args.steps // 4),
                                "note": "same kernel, same problems' kind, 8 problems per resident workgroup instead of 2: the tail of the slowest pair and the "
                                        "common start amortise; at the headline's HBM traffic per problem the physical fraction scales with the rate"}
+        big8, _ = run_align(args, ctx, dist, rank, world, dev, comm_dev, 8, N, 4096, big_shared, False, steps=3)   # ... and north_star's 8x8 configuration
+        out["steady_state"]["patch_8"] = {"kernel_ms": big8["kernel_ms"], "kernel_ms_per_1024_frame_pairs": big8["kernel_ms"] / 4.0, "value": big8["value"], "steps": 3}
     ranks_seen = du.ranks_in_collective(dist, world, comm_dev)   # a collective: every rank calls it
     if rank == 0:
         out["ranks_in_collective"] = ranks_seen
