@@ -1678,7 +1678,10 @@ def main(argv=None):
             dist.barrier()
             dist.destroy_process_group()
         return
-    P, N, B = args.patch, args.features, (args.problems or 1024)
+    # 4096 frame pairs per step since the end of round 6 (rounds 2 - 5: 1024).  The kernel's 512 resident workgroups pull problems from a queue; 1024 problems
+    # are exactly two each, so that step ends with the slowest pair and measures a tail, not the kernel's rate (profiles/r06_align_batch_size_sweep.txt: 1.17 ms
+    # per 1024 problems at 1024, 1.04 at 2048, 0.94 at 4096).  The 1024-pair step stays in the line as `step_of_1024`.
+    P, N, B = args.patch, args.features, (args.problems or 4096)
     out, shared = run_align(args, ctx, dist, rank, world, dev, comm_dev, P, N, B, None, not args.no_cpu_baseline and world == 1)
     # the 8x8-patch configuration north_star quotes its roofline target on, carried in the same line (same frame
     # pairs, same launch shape; its own features because the border margin depends on the patch size)
@@ -1689,17 +1692,15 @@ def main(argv=None):
                                                     "patch_iterations_per_s", "solver_failures", "roofline")}
             out["secondary"]["config"] = sec["config"]
             out["secondary"]["steps"] = max(3, args.steps // 2)
-    # ... and the same launch with 4096 frame pairs: the headline step is exactly two problems for each of the 512 resident workgroups, so it ends with
-    # the slowest pair and all workgroups run their memory-bound starts together; eight problems per workgroup show the steady-state rate of a stream of
-    # problems (profiles/r06_align_batch_size_sweep.txt).  `value` stays the 1024-pair step.
+    # ... and the step of rounds 2 - 5 (1024 frame pairs: two problems per resident workgroup), for comparison with their numbers
     if P == 4 and not args.no_secondary and not args.problems and N == 2000 and args.min_level == 0 and args.max_level == 4 and world == 1:
-        big, big_shared = run_align(args, ctx, dist, rank, world, dev, comm_dev, 4, N, 4096, None, False, steps=max(3, args.steps // 4))
-        out["steady_state"] = {"frame_pairs_per_step": 4096, "kernel_ms": big["kernel_ms"], "kernel_ms_per_1024_frame_pairs": big["kernel_ms"] / 4.0,
-                               "value": big["value"], "unit": big["unit"], "ms_per_step": big["ms_per_step"], "steps": max(3, args.steps // 4),
-                               "note": "same kernel, same problems' kind, 8 problems per resident workgroup instead of 2: the tail of the slowest pair and the "
-                                       "common start amortise; at the headline's HBM traffic per problem the physical fraction scales with the rate"}
-        big8, _ = run_align(args, ctx, dist, rank, world, dev, comm_dev, 8, N, 4096, big_shared, False, steps=3)   # ... and north_star's 8x8 configuration
-        out["steady_state"]["patch_8"] = {"kernel_ms": big8["kernel_ms"], "kernel_ms_per_1024_frame_pairs": big8["kernel_ms"] / 4.0, "value": big8["value"], "steps": 3}
+        small, small_shared = run_align(args, ctx, dist, rank, world, dev, comm_dev, 4, N, 1024, None, False, steps=args.steps)
+        out["step_of_1024"] = {"frame_pairs_per_step": 1024, "kernel_ms": small["kernel_ms"], "kernel_ms_min": small["kernel_ms_min"], "kernel_ms_max": small["kernel_ms_max"],
+                               "value": small["value"], "unit": small["unit"], "ms_per_step": small["ms_per_step"], "steps": args.steps,
+                               "roofline": small["roofline"],
+                               "note": "the benchmark's step until round 6: the launch ends with the slowest pair of problems (a tail), all workgroups start together"}
+        small8, _ = run_align(args, ctx, dist, rank, world, dev, comm_dev, 8, N, 1024, small_shared, False, steps=max(3, args.steps // 2))
+        out["step_of_1024"]["patch_8"] = {"kernel_ms": small8["kernel_ms"], "value": small8["value"], "ms_per_step": small8["ms_per_step"], "roofline": small8["roofline"]}
     ranks_seen = du.ranks_in_collective(dist, world, comm_dev)   # a collective: every rank calls it
     if rank == 0:
         out["ranks_in_collective"] = ranks_seen
@@ -1800,7 +1801,8 @@ def run_align(args, ctx, dist, rank, world, dev, comm_dev, P, N, B, shared, with
                 "workload": "SparseImgAlign only: synthetic 640x480, %d patches x %dx%d, levels %d..%d, SE3 6-DoF, "
                             "GN <=10 it/level, eps 5e-4; %d independent frame pairs per GPU per step, inputs "
                             "resident in HBM; every step solves the SAME frame pairs again from the same initial pose "
-                            "(838 MB of pyramids per GPU, far beyond the 256 MB Infinity Cache)" % (N, P, P, args.max_level, args.min_level, B),
+                            "(%d MB of pyramids per GPU, far beyond the 256 MB Infinity Cache; %d problems per resident workgroup of the persistent kernel)"
+                            % (N, P, P, args.max_level, args.min_level, B, B * 2 * 409200 // 1000000, max(1, B // 512)),
                 "frame_pairs_per_gpu": B, "patches_per_frame": N, "patch_size": P,
                 "levels": [args.max_level, args.min_level], "parallelism": "frame-pairs sharded x%d, no collective" % world,
             },

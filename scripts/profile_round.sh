@@ -2,7 +2,7 @@
 # Runs on the GPU box.  For every benchmark workload: rocprofv3 kernel-trace/stats of the bench command, then separate
 # counter passes of the SAME command (FETCH_SIZE, WRITE_SIZE, two SQ sets; never mixed with trace flags), raw CSVs of
 # the svoh kernels kept, and one summary json per workload (scripts/pmc_summary.py) -> gpurun_out/profiles/.
-# usage: scripts/profile_round.sh <round> [tags...]     tags: align_p4 align_p8 align_c4 klt seeds seeds_ws pose stereo
+# usage: scripts/profile_round.sh <round> [tags...]     tags: align_p4 align_p8 align_p4_b1024 align_p8_b1024 align_c4 klt seeds seeds_ws pose stereo
 set -e
 ROUND=${1:-r03}; shift || true
 TAGS=${@:-align_p4 align_p8 align_c4 klt seeds pose stereo}
@@ -13,8 +13,10 @@ mkdir -p $dst
 STEPS="--steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
 for tag in $TAGS; do
   case $tag in
-    align_p4) args="$STEPS"; key="align:B1024:N2000:P4:L4-0"; rx="sparse_align_kernel<4, 256, false, false|sparse_align_kernel.*Li4ELi256ELb0ELb0";;
-    align_p8) args="--patch 8 $STEPS"; key="align:B1024:N2000:P8:L4-0"; rx="sparse_align_kernel<8, 256, false, false";;
+    align_p4) args="$STEPS"; key="align:B4096:N2000:P4:L4-0"; rx="sparse_align_kernel<4, 256, false, false|sparse_align_kernel.*Li4ELi256ELb0ELb0";;
+    align_p8) args="--patch 8 $STEPS"; key="align:B4096:N2000:P8:L4-0"; rx="sparse_align_kernel<8, 256, false, false";;
+    align_p4_b1024) args="--problems 1024 $STEPS"; key="align:B1024:N2000:P4:L4-0"; rx="sparse_align_kernel<4, 256, false, false";;   # the step of rounds 2 - 5 (two problems per resident workgroup)
+    align_p8_b1024) args="--problems 1024 --patch 8 $STEPS"; key="align:B1024:N2000:P8:L4-0"; rx="sparse_align_kernel<8, 256, false, false";;
     align_c4) args="--workload align-c4 $STEPS"; key="align-c4:default"; rx="sparse_align_kernel<4, 256, true, false";;
     klt) args="--workload klt $STEPS"; key="klt:default"; rx="klt_track_kernel";;
     seeds) args="--workload seeds $STEPS"; key="seeds:default"; rx="update_seeds|seed_bin|seed_unsort";;
