@@ -35,7 +35,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     res[ctr] = {"dispatches": len(vals), "mean_per_dispatch_KB_as_reported": sum(vals) / len(vals)}
 st = list(csv.DictReader(open("%s/%s_kernel_stats_svoh.csv" % (dst, rnd))))
 res["kernel_stats"] = st
-res["workload_key"] = "align:B1024:N2000:P4:L4-0"  # the default bench.py workload these passes ran
+res["workload_key"] = "align:B4096:N2000:P4:L4-0"  # the default bench.py workload these passes ran (4096 frame pairs per step since the end of round 6)
 res["units"] = "FETCH_SIZE / WRITE_SIZE in KB (1024 B) per dispatch as rocprofv3 reports them; bench.py applies the gfx950 x2 to FETCH_SIZE"
 json.dump(res, open("%s/%s_summary.json" % (dst, rnd), "w"), indent=1)
 print(json.dumps(res, indent=1))
