@@ -1308,7 +1308,9 @@ def bench_align_c4(args, ctx, dist, rank, world, dev, comm_dev=None):
     """BASELINE config 4's alignment (SURVEY.md Appendix A, C4 column): a stereo bundle per problem -- two cameras
     with different intrinsics (pinhole and EuRoC radtan) behind one rig motion, `--features` patches per camera --
     illumination gain and offset estimated (8-DoF), rotation prior with lambda_rot 0.5, levels 4..2, 4x4 patches."""
-    P, N, B = args.patch, args.features, (args.problems or 512)
+    # (2048 bundles per step since the end of round 6, as the headline's 4096 pairs: 512 were ONE problem per resident workgroup -- the step ended with its
+    # slowest problem: 1.25 ms per 512 bundles against 1.00 at 2048, gpurun_out of the round: profiles/r06_align_batch_size_sweep.txt)
+    P, N, B = args.patch, args.features, (args.problems or 2048)
     opt = capi.default_align_options(max_level=4, min_level=2, patch_size=P, estimate_illumination_gain=1,
                                      estimate_illumination_offset=1)
     cams = [synth.Camera.test_camera(), synth.Camera.euroc_like()]
